@@ -1,0 +1,240 @@
+"""ORACLE (test infrastructure, CPU fp32) -- functional restatement of the reference backbones.
+
+Each function takes the reference's own `state_dict` (same key names) as a plain dict `P` of fp32
+tensors and computes the forward pass with torch.nn.functional primitives; no nn.Module state.
+Reference being restated:
+  unet_simple_forward   <- /root/reference/src/models/unet_simple.py:13-82 (UNetBlock), :164-197 (UNet)
+  time_embedding        <- /root/reference/src/models/modules/misc.py:20-32, :54-67
+  simple_conv_net_forward <- /root/reference/src/models/simple_conv_net.py:12-55, :112-131
+  resnet_unet_forward   <- /root/reference/src/models/unet.py:26-109, :266-315 and
+                           /root/reference/src/models/modules/attention.py:7-73, net_norm.py:18-26
+Parity: pinned against tests/golden/*.npz (outputs of the imported reference) in
+tests/test_oracle_nets.py.  Third-party arithmetic (conv/batch-norm/bilinear/softmax) is PyTorch ATen,
+as in the reference.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this package.
+"""
+import math
+from typing import Dict, List, Optional, Sequence
+
+import torch
+import torch.nn.functional as F
+from torch import Tensor
+
+LEAKY_SLOPE = 0.2  # unet_simple.py:10
+
+
+# ----------------------------------------------------------------------------- dropout sources
+class DropoutOff:
+    """Dropout layers are identity (eval mode)."""
+
+    def apply(self, x: Tensor, p: float) -> Tensor:
+        return x
+
+
+class DropoutSeeded:
+    """Draw Bernoulli(1-p) keep-masks from a torch.Generator in call order; optionally record them.
+
+    The golden generator patches the reference's nn.Dropout modules to draw from the same class, so the
+    reference and the oracle consume identical mask streams when seeded identically.
+    """
+
+    def __init__(self, seed: int, record: bool = False):
+        self.gen = torch.Generator().manual_seed(seed)
+        self.record = record
+        self.masks: List[Tensor] = []
+
+    def apply(self, x: Tensor, p: float) -> Tensor:
+        if p <= 0.0:
+            return x
+        keep = torch.bernoulli(torch.full(x.shape, 1.0 - p), generator=self.gen)
+        if self.record:
+            self.masks.append(keep.to(torch.uint8))
+        return x * keep * (1.0 / (1.0 - p))
+
+
+class DropoutFast:
+    """Same distribution as DropoutSeeded, using the global RNG in place (cpu_baseline timing leg)."""
+
+    def apply(self, x: Tensor, p: float) -> Tensor:
+        if p <= 0.0:
+            return x
+        return F.dropout(x, p=p, training=True)
+
+
+class DropoutFromList:
+    """Replay recorded keep-masks (uint8, NCHW) in call order."""
+
+    def __init__(self, masks: Sequence[Tensor]):
+        self.masks = list(masks)
+        self.pos = 0
+
+    def apply(self, x: Tensor, p: float) -> Tensor:
+        if p <= 0.0:
+            return x
+        keep = self.masks[self.pos].to(x.dtype)
+        self.pos += 1
+        assert keep.shape == x.shape, (keep.shape, x.shape)
+        return x * keep * (1.0 / (1.0 - p))
+
+
+# ----------------------------------------------------------------------------- shared pieces
+def sinusoidal_features(t: Tensor, dim: int) -> Tensor:
+    """misc.py:20-32: [sin(t*f_j), cos(t*f_j)], f_j = exp(-j*ln(1e4)/(dim/2-1))."""
+    half = dim // 2
+    freqs = torch.exp(torch.arange(half, dtype=torch.float32) * (-math.log(10000.0) / (half - 1)))
+    ang = t.to(torch.float32)[:, None] * freqs[None, :]
+    return torch.cat([ang.sin(), ang.cos()], dim=-1)
+
+
+def time_embedding(P: Dict[str, Tensor], prefix: str, t: Tensor, dim: int) -> Tensor:
+    """misc.py:54-67 (non-learned branch): sinusoid(dim) -> Linear -> GELU -> Linear."""
+    e = sinusoidal_features(t, dim)
+    e = F.linear(e, P[f"{prefix}.1.weight"], P[f"{prefix}.1.bias"])
+    e = F.gelu(e)
+    return F.linear(e, P[f"{prefix}.3.weight"], P[f"{prefix}.3.bias"])
+
+
+def film(P: Dict[str, Tensor], prefix: str, temb: Tensor):
+    """SiLU -> Linear(time_dim, 2*C) -> (scale, shift) broadcast over space (unet_simple.py:21-23,72-78)."""
+    ss = F.linear(F.silu(temb), P[f"{prefix}.1.weight"], P[f"{prefix}.1.bias"])
+    scale, shift = ss[:, :, None, None].chunk(2, dim=1)
+    return scale, shift
+
+
+def bilinear_resize_explicit(x: Tensor, out_h: int, out_w: int) -> Tensor:
+    """Bilinear resample with align_corners=False, no antialias, written out as gathers.
+
+    This is the formula the HIP kernels implement; tests check it equals F.interpolate (ATen
+    upsample_bilinear2d) which is what the reference calls (unet_simple.py:103,195).
+      src = (dst + 0.5) * (in / out) - 0.5, clamped below at 0;  i0 = floor(src); i1 = min(i0 + 1, in - 1)
+    """
+    n, c, in_h, in_w = x.shape
+
+    def axis(in_sz, out_sz):
+        scale = in_sz / out_sz
+        dst = torch.arange(out_sz, dtype=torch.float32)
+        src = ((dst + 0.5) * scale - 0.5).clamp_min(0.0)
+        i0 = src.floor().to(torch.int64).clamp_max(in_sz - 1)
+        i1 = (i0 + 1).clamp_max(in_sz - 1)
+        lam = src - i0.to(torch.float32)
+        return i0, i1, lam
+
+    y0, y1, ly = axis(in_h, out_h)
+    x0, x1, lx = axis(in_w, out_w)
+    top = x[:, :, y0, :]
+    bot = x[:, :, y1, :]
+    ly = ly[None, None, :, None]
+    rows = top * (1.0 - ly) + bot * ly
+    left = rows[:, :, :, x0]
+    right = rows[:, :, :, x1]
+    lx = lx[None, None, None, :]
+    return left * (1.0 - lx) + right * lx
+
+
+# ----------------------------------------------------------------------------- unet_simple.UNet (Navier-Stokes)
+def unet_simple_layout(dim: int):
+    """(cin, cout, kernel, stride, pad, norm, act) per block; unet_simple.py:119-139 with UNetBlock's arg mapping."""
+    d = dim
+    enc = [
+        (d, 2 * d, 4, 2, 1, "bn", "leaky"),
+        (2 * d, 2 * d, 4, 2, 1, "bn", "leaky"),
+        (2 * d, 4 * d, 4, 2, 1, "bn", "leaky"),
+        (4 * d, 8 * d, 4, 2, 1, "bn", "leaky"),
+        (8 * d, 8 * d, 2, 2, 0, "bn", "leaky"),
+        (8 * d, 8 * d, 2, 2, 0, "gn", "leaky"),
+    ]
+    # transposed blocks: Upsample(x2, bilinear) then Conv2d(kernel=size-1, stride 1, padding=pad)
+    dec = [
+        (8 * d, 8 * d, 1, 1, 0, "bn", "relu"),
+        (16 * d, 8 * d, 1, 1, 0, "bn", "relu"),
+        (16 * d, 4 * d, 3, 1, 1, "bn", "relu"),
+        (8 * d, 2 * d, 3, 1, 1, "bn", "relu"),
+        (4 * d, 2 * d, 3, 1, 1, "bn", "relu"),
+        (4 * d, d, 3, 1, 1, "bn", "relu"),
+    ]
+    return enc, dec
+
+
+def _norm(P, prefix, x, kind):
+    if kind == "bn":  # eval-mode BatchNorm2d: running statistics (BN always eval at sampling)
+        return F.batch_norm(x, P[f"{prefix}.running_mean"], P[f"{prefix}.running_var"], P[f"{prefix}.weight"],
+                            P[f"{prefix}.bias"], training=False, eps=1e-5)
+    return F.group_norm(x, 8, P[f"{prefix}.weight"], P[f"{prefix}.bias"], eps=1e-5)
+
+
+def unet_simple_forward(P: Dict[str, Tensor], cfg: dict, inputs: Tensor, time: Optional[Tensor] = None,
+                        condition: Optional[Tensor] = None, dropout=None, taps: Optional[dict] = None) -> Tensor:
+    """unet_simple.py:181-197 + :164-179.  cfg keys: dim, upsample_dims (or None), outer_sample_mode,
+    with_time_emb, dropout, input_dropout.  `taps` (optional dict) receives intermediate activations."""
+    dropout = dropout or DropoutOff()
+    dim = cfg["dim"]
+    mode = cfg.get("outer_sample_mode", "bilinear")
+    x = torch.cat([inputs, condition], dim=1) if condition is not None else inputs
+    temb = time_embedding(P, "time_emb_mlp", time, dim) if cfg.get("with_time_emb", False) else None
+    native_hw = x.shape[-2:]
+    if cfg.get("upsample_dims") is not None:
+        x = F.interpolate(x, size=tuple(cfg["upsample_dims"]), mode=mode)
+    x = F.conv2d(x, P["init_conv.weight"], P["init_conv.bias"])
+    x = dropout.apply(x, cfg.get("input_dropout", 0.0))
+    if taps is not None:
+        taps["init"] = x
+    enc, dec = unet_simple_layout(dim)
+    p_drop = cfg.get("dropout", 0.0)
+    skips = []
+    for li, (_, _, k, s, pad, norm, act) in enumerate(enc):
+        pre = f"input_ops.{li}"
+        x = F.conv2d(x, P[f"{pre}.ops.0.weight"], P[f"{pre}.ops.0.bias"], stride=s, padding=pad)
+        x = _norm(P, f"{pre}.ops.1", x, norm)
+        if temb is not None:
+            scale, shift = film(P, f"{pre}.time_mlp", temb)
+            x = x * (scale + 1) + shift
+        x = F.leaky_relu(x, LEAKY_SLOPE)
+        x = dropout.apply(x, p_drop)
+        skips.append(x)
+        if taps is not None:
+            taps[f"enc{li}"] = x
+    x = skips.pop()
+    for li, (_, _, k, s, pad, norm, act) in enumerate(dec):
+        pre = f"output_ops.{li}"
+        x = F.interpolate(x, scale_factor=2, mode="bilinear")
+        x = F.conv2d(x, P[f"{pre}.ops.1.weight"], P[f"{pre}.ops.1.bias"], stride=1, padding=pad)
+        x = _norm(P, f"{pre}.ops.2", x, norm)
+        if temb is not None:
+            scale, shift = film(P, f"{pre}.time_mlp", temb)
+            x = x * (scale + 1) + shift
+        x = F.relu(x)
+        x = dropout.apply(x, p_drop)
+        if taps is not None:
+            taps[f"dec{li}"] = x
+        if skips:
+            x = torch.cat([x, skips.pop()], dim=1)
+    x = F.conv_transpose2d(x, P["readout.0.weight"], P["readout.0.bias"], stride=2, padding=1)
+    if taps is not None:
+        taps["readout"] = x
+    return F.interpolate(x, size=tuple(native_hw), mode=mode)
+
+
+# ----------------------------------------------------------------------------- SimpleConvNet (spring-mesh plumbing)
+def simple_conv_net_forward(P: Dict[str, Tensor], cfg: dict, inputs: Tensor, time: Optional[Tensor] = None,
+                            condition: Optional[Tensor] = None, dropout=None) -> Tensor:
+    """simple_conv_net.py:112-131 with ConvBlock :39-55.  cfg keys: dim, kernel_sizes, with_time_emb, dropout,
+    residual."""
+    dropout = dropout or DropoutOff()
+    x = torch.cat([inputs, condition], dim=1) if condition is not None else inputs
+    temb = time_embedding(P, "time_emb_mlp", time, cfg["dim"]) if cfg.get("with_time_emb", False) else None
+    for li, k in enumerate(cfg["kernel_sizes"]):
+        pre = f"convs.{li}"
+        res = x
+        w = P[f"{pre}.conv.weight"]
+        x = F.conv2d(x, w, P[f"{pre}.conv.bias"], padding=(k - 1) // 2)
+        x = F.batch_norm(x, P[f"{pre}.norm.running_mean"], P[f"{pre}.norm.running_var"], P[f"{pre}.norm.weight"],
+                         P[f"{pre}.norm.bias"], training=False, eps=1e-5)
+        if temb is not None:
+            scale, shift = film(P, f"{pre}.time_mlp", temb)
+            x = x * (scale + 1) + shift
+        x = F.gelu(x)
+        x = dropout.apply(x, cfg.get("dropout", 0.0))
+        if cfg.get("residual", True) and w.shape[0] == w.shape[1]:
+            x = x + res
+    return F.conv2d(x, P["head.weight"], P["head.bias"])

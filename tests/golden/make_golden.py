@@ -1,0 +1,291 @@
+"""Generate the golden fixtures in this directory from the IMPORTED reference (/root/reference).
+
+Run once in the build container:  python tests/golden/make_golden.py
+The reference cannot travel to the GPU box; these small .npz/.json files (inputs + expected outputs of the
+reference's own code) are what pins the oracle (oracle/*.py), which in turn is the checker for the HIP path.
+Fixture kinds: G1 schedules.json, G3 net_*.npz, G4 sample_*.npz, G6 fullsize_checksums.json.
+"""
+import contextlib
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.abspath(os.path.join(HERE, "..", "..")))
+
+from oracle import init as oinit  # noqa: E402
+from oracle import ref_import  # noqa: E402
+from oracle.nets import DropoutSeeded  # noqa: E402
+
+ref_import.activate()
+torch.set_num_threads(max(1, os.cpu_count() or 1))
+
+
+@contextlib.contextmanager
+def patched_dropout(source):
+    """Route every nn.Dropout of the reference through `source` (so masks are seeded / recordable)."""
+    orig = torch.nn.Dropout.forward
+
+    def fwd(self, x):
+        if not self.training or source is None:
+            return x
+        return source.apply(x, self.p)
+
+    torch.nn.Dropout.forward = fwd
+    try:
+        yield
+    finally:
+        torch.nn.Dropout.forward = orig
+
+
+@contextlib.contextmanager
+def patched_randn_like(seed):
+    gen = torch.Generator().manual_seed(seed)
+    orig = torch.randn_like
+    draws = []
+
+    def fake(t, **kw):
+        z = torch.randn(t.shape, generator=gen)
+        draws.append(z)
+        return z
+
+    torch.randn_like = fake
+    try:
+        yield draws
+    finally:
+        torch.randn_like = orig
+
+
+def np_state(sd):
+    return {f"P::{k}": v.detach().cpu().numpy() for k, v in sd.items()}
+
+
+def load_seeded(net, seed):
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    st = oinit.seeded_state(shapes, seed)
+    net.load_state_dict(st, strict=True)
+    return shapes
+
+
+# ------------------------------------------------------------------------------------------------ G1
+def gen_schedules():
+    from src.diffusion.dyffusion import BaseDYffusion
+
+    cases = []
+    grid = [
+        dict(h=4, schedule="before_t1_only", k=0, fac=0, before_t1=True),
+        dict(h=5, schedule="before_t1_only", k=1, fac=0, before_t1=True),
+        dict(h=5, schedule="before_t1_only", k=2, fac=0, before_t1=True),
+        dict(h=7, schedule="before_t1_only", k=25, fac=0, before_t1=True),
+        dict(h=16, schedule="before_t1_only", k=0, fac=0, before_t1=True),
+        dict(h=64, schedule="before_t1_only", k=0, fac=0, before_t1=True),
+        dict(h=5, schedule="linear", k=0, fac=1, before_t1=False),
+        dict(h=5, schedule="linear", k=0, fac=1, before_t1=True),
+        dict(h=5, schedule="linear", k=0, fac=2, before_t1=False),
+        dict(h=6, schedule="linear", k=0, fac=2, before_t1=True),
+    ]
+    names = [None, "only_dynamics", "only_dynamics_plus2", "only_dynamics_plus_discrete2", "every2nd", "every5th",
+             "first3", "first0.5", "every1", "first1"]
+
+    class _Bare(BaseDYffusion):  # the schedule logic lives in BaseDYffusion; no interpolator needed
+        def _interpolate(self, *a, **k):
+            raise NotImplementedError
+
+        def p_losses(self, *a, **k):
+            raise NotImplementedError
+
+    for g in grid:
+        exp, _ = ref_import.build_reference_dyffusion(
+            system="spring-mesh", model="cnn_simple",
+            model_kwargs=dict(dim=4, with_time_emb=True, kernel_sizes=[3], dropout=0.0), horizon=g["h"],
+            diffusion_kwargs=dict(schedule=g["schedule"], additional_interpolation_steps=g["k"],
+                                  additional_interpolation_steps_factor=g["fac"],
+                                  interpolate_before_t1=g["before_t1"]))
+        dy = exp.model
+        case = dict(g)
+        case["num_timesteps"] = dy.num_timesteps
+        case["d_to_i"] = {str(d): float(dy.diffusion_step_to_interpolation_step(d)) for d in range(1, dy.num_timesteps)}
+        case["dynamical_steps"] = {str(d): float(i) for d, i in dy.dynamical_steps.items()}
+        case["artificial_steps"] = {str(d): float(i) for d, i in dy.artificial_interpolation_steps.items()}
+        case["schedules"] = {}
+        for nm in names:
+            try:
+                dy.sampling_schedule = nm if nm is not None else dy.full_sampling_schedule
+                val = [float(s) for s in dy.sampling_schedule]
+                ints = all(isinstance(s, int) for s in dy.sampling_schedule)
+                case["schedules"][str(nm)] = dict(ok=True, steps=val, all_int=ints)
+            except Exception as e:  # invalid for this T: record that the reference refuses it
+                case["schedules"][str(nm)] = dict(ok=False, error=type(e).__name__)
+        cases.append(case)
+    with open(os.path.join(HERE, "schedules.json"), "w") as f:
+        json.dump(cases, f, indent=1)
+    print("schedules.json:", len(cases), "cases")
+
+
+# ------------------------------------------------------------------------------------------------ G3
+def gen_nets():
+    from omegaconf import DictConfig
+    from src.models.simple_conv_net import SimpleConvNet
+    from src.models.unet_simple import UNet
+
+    torch.manual_seed(0)
+    specs = [
+        ("net_unet_simple_a", dict(dim=8, upsample_dims=[64, 64], n_in=6, n_cond=2, n_out=3, hw=(23, 11), nb=2,
+                                   dropout=0.15)),
+        ("net_unet_simple_b", dict(dim=4, upsample_dims=[64, 64], n_in=4, n_cond=1, n_out=4, hw=(10, 10), nb=3,
+                                   dropout=0.3)),
+        ("net_unet_simple_c", dict(dim=8, upsample_dims=[128, 64], n_in=3, n_cond=0, n_out=2, hw=(40, 17), nb=1,
+                                   dropout=0.1)),
+    ]
+    for name, sp in specs:
+        net = UNet(dim=sp["dim"], with_time_emb=True, outer_sample_mode="bilinear", upsample_dims=sp["upsample_dims"],
+                   dropout=sp["dropout"], input_dropout=0.0, num_input_channels=sp["n_in"],
+                   num_output_channels=sp["n_out"], num_conditional_channels=sp["n_cond"], spatial_shape=sp["hw"],
+                   loss_function="mse", verbose=False).eval()
+        shapes = load_seeded(net, seed=11)
+        ref_shapes = oinit.unet_simple_param_shapes(sp["dim"], sp["n_in"] + sp["n_cond"], sp["n_out"])
+        assert {k: tuple(v) for k, v in ref_shapes.items()} == shapes, "oracle shape table != reference state_dict"
+        g = torch.Generator().manual_seed(5)
+        x = torch.randn(sp["nb"], sp["n_in"], *sp["hw"], generator=g)
+        c = torch.rand(sp["nb"], sp["n_cond"], *sp["hw"], generator=g) if sp["n_cond"] else None
+        t = torch.tensor([1.0, 2.5, 0.3333][: sp["nb"]])
+        with torch.no_grad():
+            y_eval = net(x, time=t, condition=c)
+            for m in net.modules():
+                if isinstance(m, torch.nn.Dropout):
+                    m.train()
+            with patched_dropout(DropoutSeeded(seed=77)):
+                y_drop = net(x, time=t, condition=c)
+        arrs = dict(np_state(net.state_dict()), x=x.numpy(), t=t.numpy(), y_eval=y_eval.numpy(),
+                    y_drop=y_drop.numpy(), dropout_seed=np.int64(77),
+                    cfg=json.dumps(dict(dim=sp["dim"], upsample_dims=sp["upsample_dims"], outer_sample_mode="bilinear",
+                                        with_time_emb=True, dropout=sp["dropout"], input_dropout=0.0)))
+        if c is not None:
+            arrs["c"] = c.numpy()
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **arrs)
+        print(name, "y_eval std", float(y_eval.std()), "y_drop std", float(y_drop.std()))
+
+    # SimpleConvNet (spring-mesh plumbing config)
+    net = SimpleConvNet(dim=8, with_time_emb=True, kernel_sizes=[9, 7, 5, 3], dropout=0.1, num_input_channels=8,
+                        num_output_channels=4, num_conditional_channels=1, spatial_shape=(10, 10),
+                        loss_function="mse", verbose=False).eval()
+    shapes = load_seeded(net, seed=12)
+    assert {k: tuple(v) for k, v in oinit.simple_conv_net_param_shapes(8, 9, 4, [9, 7, 5, 3]).items()} == shapes
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(2, 8, 10, 10, generator=g)
+    c = torch.rand(2, 1, 10, 10, generator=g)
+    t = torch.tensor([1.0, 3.0])
+    with torch.no_grad():
+        y_eval = net(x, time=t, condition=c)
+    np.savez_compressed(os.path.join(HERE, "net_simple_conv.npz"), **np_state(net.state_dict()), x=x.numpy(),
+                        c=c.numpy(), t=t.numpy(), y_eval=y_eval.numpy(),
+                        cfg=json.dumps(dict(dim=8, kernel_sizes=[9, 7, 5, 3], with_time_emb=True, dropout=0.1,
+                                            residual=True)))
+    print("net_simple_conv y std", float(y_eval.std()))
+
+
+# ------------------------------------------------------------------------------------------------ G4
+def gen_samples():
+    base_model = dict(dim=4, outer_sample_mode="bilinear", upsample_dims=[64, 64], with_time_emb=True,
+                      input_dropout=0.0, dropout=0.2)
+    variants = [
+        ("sample_cold_refine", dict(h=4), dict()),
+        ("sample_cold_norefine", dict(h=4), dict(refine_intermediate_predictions=False)),
+        ("sample_naive", dict(h=4), dict(sampling_type="naive", refine_intermediate_predictions=False)),
+        ("sample_k2_data", dict(h=5), dict(additional_interpolation_steps=2, forward_conditioning="data",
+                                            refine_intermediate_predictions=False)),
+        ("sample_k2_coldlast", dict(h=5), dict(additional_interpolation_steps=2, use_cold_sampling_for_last_step=True,
+                                                refine_intermediate_predictions=True)),
+        ("sample_k2_onlydyn", dict(h=5), dict(additional_interpolation_steps=2, sampling_schedule="only_dynamics",
+                                               refine_intermediate_predictions=False)),
+        ("sample_k2_plus2", dict(h=5), dict(additional_interpolation_steps=2, sampling_schedule="only_dynamics_plus2",
+                                             refine_intermediate_predictions=False, time_encoding="discrete")),
+        ("sample_ens3", dict(h=4, N=3), dict()),
+        ("sample_dropout", dict(h=4, N=2, dropout_seed=31), dict(enable_interpolator_dropout=True)),
+        ("sample_datanoise", dict(h=4, noise_seed=41), dict(forward_conditioning="data+noise",
+                                                            additional_interpolation_steps=1,
+                                                            refine_intermediate_predictions=False,
+                                                            time_encoding="normalized")),
+        ("sample_linear", dict(h=5), dict(schedule="linear", additional_interpolation_steps_factor=1,
+                                          interpolate_before_t1=False, refine_intermediate_predictions=False)),
+    ]
+    for name, meta, dk in variants:
+        h, N = meta["h"], meta.get("N", 1)
+        dkw = dict(enable_interpolator_dropout=False)
+        dkw.update(dk)
+        exp, ipol = ref_import.build_reference_dyffusion(system="spring-mesh", model="unet_simple",
+                                                         model_kwargs=base_model, horizon=h, diffusion_kwargs=dkw,
+                                                         num_predictions=N)
+        load_seeded(exp.model.model, seed=21)
+        load_seeded(ipol.model, seed=22)
+        g = torch.Generator().manual_seed(9)
+        B = 2
+        x0 = torch.randn(B, 4, 10, 10, generator=g)
+        c = torch.rand(B, 1, 10, 10, generator=g)
+        x0_t = torch.stack([x0] * N, 0).reshape(N * B, 4, 10, 10)  # "N B ... -> (N B) ..." ensemble-major
+        c_t = torch.stack([c] * N, 0).reshape(N * B, 1, 10, 10)
+        src = DropoutSeeded(seed=meta["dropout_seed"]) if "dropout_seed" in meta else None
+        with torch.no_grad(), patched_dropout(src), patched_randn_like(meta.get("noise_seed", 0)):
+            out = exp.predict(x0_t, condition=c_t)
+        arrs = {f"out::{k}": v.numpy() for k, v in out.items()}
+        arrs.update({f"F::{k}": v.numpy() for k, v in exp.model.model.state_dict().items()})
+        arrs.update({f"I::{k}": v.numpy() for k, v in ipol.model.state_dict().items()})
+        dyn = exp.model
+        hp = dict(timesteps=h, num_input_channels=4, num_predictions=N, B=B, model=base_model,
+                  sampling_schedule_resolved=[float(s) for s in dyn.sampling_schedule], **{
+                      k: dkw.get(k, d) for k, d in dict(
+                          schedule="before_t1_only", additional_interpolation_steps=0,
+                          additional_interpolation_steps_factor=0, interpolate_before_t1=True, sampling_type="cold",
+                          sampling_schedule=None, time_encoding="dynamics", refine_intermediate_predictions=True,
+                          use_cold_sampling_for_last_step=False, forward_conditioning="none",
+                          enable_interpolator_dropout=False).items()})
+        hp.update({k: v for k, v in meta.items() if k.endswith("_seed")})
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), x0=x0.numpy(), c=c.numpy(), hp=json.dumps(hp), **arrs)
+        print(name, {k: tuple(v.shape) for k, v in out.items()}, "std t_last", float(out[f"t{h}_preds"].std()))
+
+
+# ------------------------------------------------------------------------------------------------ G6
+def gen_fullsize():
+    """NS 221x42 h=16 dim=64 (BASELINE config 2): checksums + probe points of the reference rollout, dropout OFF
+    (deterministic) and a single interpolator/forecaster forward.  Parameters come from oracle.init.seeded_state."""
+    mk = dict(dim=64, outer_sample_mode="bilinear", upsample_dims=[256, 256], with_time_emb=True, input_dropout=0.0,
+              dropout=0.15)
+    exp, ipol = ref_import.build_reference_dyffusion(system="navier-stokes", model="unet_simple", model_kwargs=mk,
+                                                     horizon=16, diffusion_kwargs=dict(enable_interpolator_dropout=False))
+    load_seeded(exp.model.model, seed=101)
+    load_seeded(ipol.model, seed=102)
+    g = torch.Generator().manual_seed(1)
+    x0 = torch.randn(1, 3, 221, 42, generator=g)
+    c = torch.rand(1, 2, 221, 42, generator=g)
+    probes = [(0, 0, 0, 0), (0, 1, 110, 21), (0, 2, 220, 41), (0, 0, 57, 3), (0, 1, 3, 40), (0, 2, 199, 17),
+              (0, 0, 128, 30), (0, 1, 64, 8)]
+    res = dict(seeds=dict(forecaster=101, interpolator=102, inputs=1), probes=probes, model=mk)
+    with torch.no_grad():
+        yF = exp.model.model(x0, time=torch.tensor([3.0]), condition=c)
+        yI = ipol.model(torch.cat([x0, yF], 1), time=torch.tensor([5.0]), condition=c)
+        res["forecaster_fwd"] = dict(mean=float(yF.mean()), std=float(yF.std()), probes=[float(yF[p]) for p in probes])
+        res["interpolator_fwd"] = dict(mean=float(yI.mean()), std=float(yI.std()), probes=[float(yI[p]) for p in probes])
+        out = exp.predict(x0, condition=c)
+    res["rollout"] = {k: dict(mean=float(v.mean()), std=float(v.std()), probes=[float(v[p]) for p in probes])
+                      for k, v in out.items()}
+    np.savez_compressed(os.path.join(HERE, "fullsize_ns_fields.npz"), yF=yF.numpy().astype(np.float32),
+                        yI=yI.numpy().astype(np.float32), t16=out["t16_preds"].numpy().astype(np.float32),
+                        t1=out["t1_preds"].numpy().astype(np.float32), t8=out["t8_preds"].numpy().astype(np.float32))
+    with open(os.path.join(HERE, "fullsize_checksums.json"), "w") as f:
+        json.dump(res, f, indent=1)
+    print("fullsize:", {k: (round(v["mean"], 5), round(v["std"], 5)) for k, v in res["rollout"].items()})
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["schedules", "nets", "samples", "fullsize"]
+    if "schedules" in which:
+        gen_schedules()
+    if "nets" in which:
+        gen_nets()
+    if "samples" in which:
+        gen_samples()
+    if "fullsize" in which:
+        gen_fullsize()
