@@ -1,0 +1,9 @@
+"""dyffusion_amd: MI355X-native DYffusion sampling engine behind the reference's module API.
+
+Product path = HIP kernels in lib/libdyffusion_hip.so (include/dyffusion_hip.h); importing the modules that run the
+hot path fails loudly when that library is missing.
+"""
+from .dyffusion import DYffusion  # noqa: F401
+from .engine import EngineError, HipEngine, net_config  # noqa: F401
+from .experiment import InterpolatorHandle, MultiHorizonForecastingDYffusion  # noqa: F401
+from .unet_simple import UNet  # noqa: F401

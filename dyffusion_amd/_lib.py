@@ -1,0 +1,87 @@
+"""ctypes binding of libdyffusion_hip.so (C ABI: include/dyffusion_hip.h).
+
+The library is built in-tree by `__graft_entry__.build()` (hipcc --offload-arch=gfx950).  There is deliberately NO
+fallback: if the shared object is missing or a symbol cannot be resolved, importing this module raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libdyffusion_hip.so")
+
+DYF_ABI_VERSION = 1
+DYF_OK, DYF_ERR_INVALID_ARGUMENT, DYF_ERR_UNSUPPORTED, DYF_ERR_HIP, DYF_ERR_STATE = range(5)
+NET_FORECASTER, NET_INTERPOLATOR = 0, 1
+ARCH_UNET_SIMPLE = 0
+FCOND = {"none": 0, "data": 1, "data+noise": 2}
+
+
+class NetConfig(C.Structure):
+    _fields_ = [("arch", C.c_int32), ("in_channels", C.c_int32), ("cond_channels", C.c_int32),
+                ("out_channels", C.c_int32), ("dim", C.c_int32), ("with_time_emb", C.c_int32),
+                ("upsample_h", C.c_int32), ("upsample_w", C.c_int32), ("dropout", C.c_float),
+                ("input_dropout", C.c_float)]
+
+
+class EngineConfig(C.Structure):
+    _fields_ = [("abi_version", C.c_int32), ("device", C.c_int32), ("height", C.c_int32), ("width", C.c_int32),
+                ("max_batch", C.c_int32), ("use_graph", C.c_int32), ("enable_mfma", C.c_int32), ("net", NetConfig * 2)]
+
+
+class PlanStep(C.Structure):
+    _fields_ = [("forecaster_time", C.c_float), ("tau", C.c_float), ("i_next", C.c_float), ("i_cur", C.c_float),
+                ("is_last", C.c_int32), ("out_slot", C.c_int32)]
+
+
+class Plan(C.Structure):
+    _fields_ = [("n_steps", C.c_int32), ("steps", C.POINTER(PlanStep)), ("sampling_cold", C.c_int32),
+                ("cold_for_last_step", C.c_int32), ("forward_conditioning", C.c_int32), ("n_refine", C.c_int32),
+                ("refine_times", C.POINTER(C.c_float)), ("refine_slots", C.POINTER(C.c_int32)),
+                ("n_out_slots", C.c_int32), ("interpolator_dropout", C.c_int32), ("forecaster_dropout", C.c_int32)]
+
+
+# every symbol include/dyffusion_hip.h declares: (name, restype, argtypes)
+_P = C.c_void_p
+SYMBOLS = [
+    ("dyf_engine_create", C.c_int, [C.POINTER(EngineConfig), C.POINTER(_P)]),
+    ("dyf_engine_destroy", None, [_P]),
+    ("dyf_last_error", C.c_char_p, [_P]),
+    ("dyf_abi_version", C.c_int32, []),
+    ("dyf_load_weights", C.c_int, [_P, C.c_int32, C.c_int32, C.POINTER(C.c_char_p), C.POINTER(_P), C.POINTER(_P),
+                                   C.POINTER(C.c_int32)]),
+    ("dyf_net_forward", C.c_int, [_P, C.c_int32, _P, _P, _P, _P, C.c_int32, C.c_int32, C.POINTER(_P), _P]),
+    ("dyf_set_plan", C.c_int, [_P, C.POINTER(Plan)]),
+    ("dyf_sample", C.c_int, [_P, _P, _P, _P, C.c_int32, C.POINTER(_P), _P, _P]),
+    ("dyf_seed", C.c_int, [_P, C.c_uint64]),
+    ("dyf_get_last_x0hat", C.c_int, [_P, _P, C.c_int32, _P]),
+    ("dyf_plan_forward_counts", C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    ("dyf_net_flops", C.c_int, [_P, C.c_int32, C.POINTER(C.c_double)]),
+    ("dyf_time_conv_layer", C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, C.POINTER(C.c_double),
+                                      C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    ("dyf_op_conv2d", C.c_int, [_P, _P, _P] + [C.c_int32] * 9 + [_P, _P, C.c_int32, C.c_int32, _P, _P]),
+]
+
+
+def load_library(path: str = LIB_PATH) -> C.CDLL:
+    if not os.path.exists(path):
+        raise ImportError(
+            f"{path} not found: the DYffusion HIP engine has not been built.  Run `python -c 'import __graft_entry__ as g; "
+            f"g.build()'` from the repository root (needs hipcc).  There is no CPU fallback for the product path.")
+    lib = C.CDLL(path)
+    for name, restype, argtypes in SYMBOLS:
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing: fail loudly
+        fn.restype = restype
+        fn.argtypes = argtypes
+    if lib.dyf_abi_version() != DYF_ABI_VERSION:
+        raise ImportError(f"ABI mismatch: library {lib.dyf_abi_version()} vs binding {DYF_ABI_VERSION}")
+    return lib
+
+
+_LIB = None
+
+
+def lib() -> C.CDLL:
+    global _LIB
+    if _LIB is None:
+        _LIB = load_library()
+    return _LIB

@@ -1,0 +1,101 @@
+// Shared device/host helpers for the gfx950 DYffusion engine.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint16_t bf16_t;  // raw bfloat16 bits; activations are NHWC bf16 in HBM
+
+// ------------------------------------------------------------------------------------------------ bf16
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+
+// round-to-nearest-even, NaN preserved
+__device__ __host__ __forceinline__ bf16_t f32_to_bf16(float f) {
+    uint32_t u;
+#if defined(__HIP_DEVICE_COMPILE__)
+    u = __float_as_uint(f);
+#else
+    __builtin_memcpy(&u, &f, 4);
+#endif
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+}
+
+// ------------------------------------------------------------------------------------------------ activations
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_LEAKY = 2 };
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+    if (act == ACT_RELU) return fmaxf(v, 0.0f);
+    if (act == ACT_LEAKY) return v > 0.0f ? v : 0.2f * v;
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------ counter RNG
+// Stateless keep-mask generator for MC dropout (SURVEY hard-part (c)): one murmur3-finalised 32-bit word per PAIR
+// of elements, 16 bits each, compared against a 16-bit threshold.  `key` identifies (seed, forward index, layer).
+// tests/test_gpu_dropout.py re-implements this in numpy so the RNG path is checked against the oracle bit-for-bit.
+__device__ __host__ __forceinline__ uint32_t fmix32(uint32_t h) {
+    h ^= h >> 16;
+    h *= 0x85EBCA6Bu;
+    h ^= h >> 13;
+    h *= 0xC2B2AE35u;
+    h ^= h >> 16;
+    return h;
+}
+
+__device__ __host__ __forceinline__ uint32_t rng_pair_word(uint32_t pair_index, uint32_t key) {
+    return fmix32(pair_index * 0x9E3779B1u + key);
+}
+
+// key for dropout layer `layer` of the `fwd`-th network forward since dyf_seed(seed)
+__device__ __host__ __forceinline__ uint32_t rng_layer_key(uint32_t seed_lo, uint32_t seed_hi, uint32_t fwd,
+                                                             uint32_t layer) {
+    return fmix32(seed_lo ^ fmix32(seed_hi + 0x9E3779B9u * (fwd * 64u + layer + 1u)));
+}
+
+__device__ __host__ __forceinline__ uint32_t keep_threshold16(float p) {
+    float keep = (1.0f - p) * 65536.0f;
+    return keep >= 65536.0f ? 65536u : (uint32_t)keep;
+}
+
+// element e of the NHWC tensor: keep iff its 16-bit slice of pair word e>>1 is below the threshold
+__device__ __host__ __forceinline__ bool rng_keep(uint32_t e, uint32_t key, uint32_t thresh16) {
+    uint32_t w = rng_pair_word(e >> 1, key);
+    uint32_t v = (e & 1u) ? (w >> 16) : (w & 0xffffu);
+    return v < thresh16;
+}
+
+// Dropout descriptor handed to every kernel that ends in a Dropout layer.
+struct DropSpec {
+    int mode;                 // 0 off, 1 engine RNG, 2 injected mask
+    float scale;              // 1/(1-p)
+    uint32_t thresh16;        // keep threshold (mode 1)
+    uint32_t layer;           // layer slot (mode 1)
+    const uint32_t* state;    // device: {seed_lo, seed_hi, forward_counter} (mode 1)
+    const uint8_t* mask;      // device NHWC uint8 keep mask (mode 2)
+};
+
+__device__ __forceinline__ uint32_t drop_key(const DropSpec& d) {
+    return d.mode == 1 ? rng_layer_key(d.state[0], d.state[1], d.state[2], d.layer) : 0u;
+}
+
+__device__ __forceinline__ float drop_apply(float v, uint32_t e, const DropSpec& d, uint32_t key) {
+    if (d.mode == 0) return v;
+    bool keep = d.mode == 1 ? rng_keep(e, key, d.thresh16) : (d.mask[e] != 0);
+    return keep ? v * d.scale : 0.0f;
+}
+
+// ------------------------------------------------------------------------------------------------ bilinear
+// align_corners=False source coordinate (ATen area_pixel_compute_source_index); oracle: nets.bilinear_resize_explicit
+__device__ __forceinline__ void bilinear_coord(int dst, float scale, int in_size, int& i0, int& i1, float& lam) {
+    float src = ((float)dst + 0.5f) * scale - 0.5f;
+    src = src < 0.0f ? 0.0f : src;
+    i0 = (int)src;
+    if (i0 > in_size - 1) i0 = in_size - 1;
+    i1 = i0 + 1 < in_size ? i0 + 1 : in_size - 1;
+    lam = src - (float)i0;
+}

@@ -1,0 +1,30 @@
+// Conv2d (+ fused epilogue) on NHWC bf16 activations: argument block shared by the direct and the MFMA kernels.
+#pragma once
+#include "common.h"
+
+struct ConvArgs {
+    // input: channel-concatenation of up to two NHWC bf16 tensors (skip connections are never materialised)
+    const bf16_t* src0;
+    const bf16_t* src1;
+    int c0, c1;          // channels taken from src0 / src1 (c1 == 0: single source)
+    int n, h, w;         // input batch / height / width
+    int ho, wo;          // output height / width
+    int kh, kw, stride, pad;
+    int cout;
+    const bf16_t* wpk;   // packed weights [cout][kh*kw][c0+c1] bf16
+    // epilogue: v = acc * A[row*coef_stride + co] + C[row*coef_stride + co]; row = sample index (coef_stride may be 0
+    // to broadcast one row); conv bias, eval-BatchNorm and FiLM (x*(scale+1)+shift) are all folded into A and C.
+    const float* coef_a;
+    const float* coef_c;
+    int coef_stride;
+    int act;
+    DropSpec drop;
+    bf16_t* out_bf16;    // NHWC bf16 output (or null)
+    float* out_f32;      // NHWC fp32 output (GroupNorm input) (or null)
+    const bf16_t* zero_page;  // >= 128 B of zeros in HBM: source of padded taps for the LDS-DMA gather
+};
+
+// path: 0 direct (any shape), 1 implicit-GEMM MFMA (needs c0 % 64 == 0, c1 % 64 == 0, cout % 64 == 0)
+hipError_t conv_init();
+bool conv_mfma_supported(const ConvArgs& a);
+hipError_t launch_conv(const ConvArgs& a, int path, hipStream_t stream);

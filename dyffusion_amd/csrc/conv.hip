@@ -1,0 +1,293 @@
+// Conv2d on NHWC bf16 for gfx950 (MI355X): implicit-GEMM on MFMA + a shape-agnostic direct kernel.
+//
+// Replaces the reference's nn.Conv2d -> BatchNorm2d -> FiLM -> (Leaky)ReLU -> Dropout ATen sequence
+// (src/models/unet_simple.py:29-82) with one kernel per UNetBlock.
+//
+// Implicit GEMM:  Y[M = N*Ho*Wo pixels][Cout] = A[M][K = taps*Cin] * Wpk[Cout][K]^T
+//   * K is walked one (tap, 64-channel chunk) per step: with NHWC activations every A row of a step is one contiguous
+//     128-byte segment of one input pixel, so the A tile is a pure gather of 128-B rows.  Rows are fetched with
+//     LDS-DMA (global_load_lds_dwordx4, 16 B/lane, 1 KiB per wave instruction); taps that fall into the zero padding
+//     read a 128-B zero page instead.  Weights are pre-packed [Cout][tap][Cin] so a B row is the same kind of segment.
+//   * LDS image per stage: A[BM][64] + B[BN][64] bf16, row = 128 B, 16-B chunk index XOR (row & 7): the DMA writes LDS
+//     linearly, so the swizzle is applied to the per-lane SOURCE chunk and again on the ds_read_b128 fragment reads.
+//   * 4 waves, each owns a 64x64 accumulator (2x2 MFMA 32x32x16 bf16 tiles, 64 fp32 regs); two stages, one barrier per
+//     K step, next step's DMA in flight under the current step's 16 MFMAs.
+//   * epilogue through LDS: fp32 tile -> per-(sample, channel) affine (conv bias + BatchNorm + FiLM folded) ->
+//     activation -> dropout -> bf16 -> 16-B coalesced NHWC stores.
+//   * blockIdx -> tile map is XCD-aware (block b runs on XCD b % 8): every XCD walks a contiguous range of tiles so
+//     the 3x3 / 4x4 halo re-reads of neighbouring tiles hit that XCD's own L2.
+#include "conv.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+#define GLB_PTR(p) ((const __attribute__((address_space(1))) void*)(p))
+
+// ------------------------------------------------------------------------------------------------ epilogue math
+struct EpiCtx {
+    const float* coef_a;
+    const float* coef_c;
+    int coef_stride;
+    int act;
+    int cout;
+    int howo;
+};
+
+// ------------------------------------------------------------------------------------------------ direct kernel
+// One thread per (output pixel, output channel).  Correct for every shape; used for layers the MFMA path does not
+// cover (channel counts that are not multiples of 64) and as the on-device cross-check of the MFMA kernel.
+__global__ void conv_direct_kernel(ConvArgs a, long long total) {
+    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int co = (int)(idx % a.cout);
+    const long long m = idx / a.cout;
+    const int howo = a.ho * a.wo;
+    const int n = (int)(m / howo);
+    const int rem = (int)(m % howo);
+    const int oy = rem / a.wo, ox = rem % a.wo;
+    const int cin = a.c0 + a.c1;
+    const bf16_t* wrow = a.wpk + (size_t)co * a.kh * a.kw * cin;
+    float acc = 0.0f;
+    for (int ky = 0; ky < a.kh; ++ky) {
+        const int iy = oy * a.stride - a.pad + ky;
+        if ((unsigned)iy >= (unsigned)a.h) continue;
+        for (int kx = 0; kx < a.kw; ++kx) {
+            const int ix = ox * a.stride - a.pad + kx;
+            if ((unsigned)ix >= (unsigned)a.w) continue;
+            const size_t pix = ((size_t)n * a.h + iy) * a.w + ix;
+            const bf16_t* wt = wrow + (size_t)(ky * a.kw + kx) * cin;
+            const bf16_t* p0 = a.src0 + pix * a.c0;
+            for (int c = 0; c < a.c0; ++c) acc = fmaf(bf16_to_f32(p0[c]), bf16_to_f32(wt[c]), acc);
+            if (a.c1 > 0) {
+                const bf16_t* p1 = a.src1 + pix * a.c1;
+                for (int c = 0; c < a.c1; ++c) acc = fmaf(bf16_to_f32(p1[c]), bf16_to_f32(wt[a.c0 + c]), acc);
+            }
+        }
+    }
+    const size_t ci = (size_t)n * a.coef_stride + co;
+    float v = fmaf(acc, a.coef_a[ci], a.coef_c[ci]);
+    v = apply_act(v, a.act);
+    const uint32_t e = (uint32_t)(m * a.cout + co);
+    v = drop_apply(v, e, a.drop, drop_key(a.drop));
+    if (a.out_bf16) a.out_bf16[(size_t)m * a.cout + co] = f32_to_bf16(v);
+    if (a.out_f32) a.out_f32[(size_t)m * a.cout + co] = v;
+}
+
+// ------------------------------------------------------------------------------------------------ MFMA kernel
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a, int M, int tiles_m, int tiles_n) {
+    static_assert(WM * WN == 4 && BM / WM == 64 && BN / WN == 64, "4 waves, 64x64 accumulator each");
+    constexpr int A_BYTES = BM * 128;
+    constexpr int B_BYTES = BN * 128;
+    constexpr int STAGE = A_BYTES + B_BYTES;
+    constexpr int RA = BM / 32;  // A rows gathered per lane per K step
+    constexpr int RB = BN / 32;
+    static_assert(2 * STAGE >= BM * BN * 4, "epilogue tile must fit in the staging buffers");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+
+    // XCD-aware tile id (bijective for any tile count): XCD x = bid % 8 takes a contiguous run of tiles.
+    const int total = tiles_m * tiles_n;
+    const int bid = blockIdx.x;
+    const int xq = total >> 3, xr = total & 7, xcd = bid & 7;
+    const int tile = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
+    const int tn = tile % tiles_n, tm = tile / tiles_n;
+
+    const int cin = a.c0 + a.c1;
+    const int cpt = cin >> 6;                 // 64-channel chunks per tap
+    const int nk = a.kh * a.kw * cpt;         // K steps
+    const int howo = a.ho * a.wo;
+    const int sub = lane >> 3;                // row inside an 8-row DMA group
+    const int gchunk = (lane & 7) ^ sub;      // swizzled SOURCE chunk for this lane's linear LDS slot
+
+    // ---- per-lane gather descriptors for the A rows this lane fetches
+    int a_iy0[RA], a_ix0[RA], a_pix0[RA];
+#pragma unroll
+    for (int j = 0; j < RA; ++j) {
+        const int row = (j * 4 + wave) * 8 + sub;
+        const int m = tm * BM + row;
+        if (m < M) {
+            const int n_img = m / howo;
+            const int rem = m - n_img * howo;
+            const int oy = rem / a.wo, ox = rem - oy * a.wo;
+            a_iy0[j] = oy * a.stride - a.pad;
+            a_ix0[j] = ox * a.stride - a.pad;
+            a_pix0[j] = n_img * a.h * a.w;
+        } else {
+            a_iy0[j] = -(1 << 28);  // never in range: tile rows past M read the zero page
+            a_ix0[j] = 0;
+            a_pix0[j] = 0;
+        }
+    }
+    // B rows: row r of the tile is output channel tn*BN + r; consecutive K steps are consecutive 128-B segments
+    const char* b_src[RB];
+#pragma unroll
+    for (int j = 0; j < RB; ++j) {
+        const int row = (j * 4 + wave) * 8 + sub;
+        b_src[j] = (const char*)(a.wpk + (size_t)(tn * BN + row) * nk * 64) + gchunk * 16;
+    }
+    const char* zero_src = (const char*)a.zero_page + gchunk * 16;
+
+    // issue-side K-step state (uniform)
+    int is_ky = 0, is_kx = 0, is_chunk = 0;
+
+    auto issue = [&](int stage, int kstep) {
+        char* As = smem + stage * STAGE;
+        char* Bs = As + A_BYTES;
+        const int cb = is_chunk << 6;
+        const bool second = cb >= a.c0;
+        const bf16_t* src = second ? a.src1 : a.src0;
+        const int csrc = second ? a.c1 : a.c0;
+        const int coff = second ? cb - a.c0 : cb;
+#pragma unroll
+        for (int j = 0; j < RA; ++j) {
+            const int iy = a_iy0[j] + is_ky, ix = a_ix0[j] + is_kx;
+            const bool ok = (unsigned)iy < (unsigned)a.h && (unsigned)ix < (unsigned)a.w;
+            const long long pix = (long long)a_pix0[j] + iy * a.w + ix;
+            const char* g = ok ? (const char*)(src + (pix * csrc + coff)) + gchunk * 16 : zero_src;
+            __builtin_amdgcn_global_load_lds(GLB_PTR(g), LDS_PTR(As + (j * 4 + wave) * 1024), 16, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < RB; ++j) {
+            __builtin_amdgcn_global_load_lds(GLB_PTR(b_src[j] + (size_t)kstep * 128), LDS_PTR(Bs + (j * 4 + wave) * 1024),
+                                             16, 0, 0);
+        }
+        // advance (chunk fastest, then kx, then ky): matches the [tap][cin] order of the packed weights
+        if (++is_chunk == cpt) {
+            is_chunk = 0;
+            if (++is_kx == a.kw) {
+                is_kx = 0;
+                ++is_ky;
+            }
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    // fragment read offsets: row*128 + ((k16*2 + (lane>>5)) ^ (row & 7)) * 16 ; row & 7 == lane & 7 for every fragment
+    const int l31 = lane & 31, hi = lane >> 5, l7 = lane & 7;
+    const int a_row_off = (wm * 64 + l31) * 128;
+    const int b_row_off = (wn * 64 + l31) * 128;
+
+    issue(0, 0);
+    for (int k = 0; k < nk; ++k) {
+        const int cur = k & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (k + 1 < nk) issue(cur ^ 1, k + 1);
+        const char* As = smem + cur * STAGE;
+        const char* Bs = As + A_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int coff = (((ks * 2 + hi) ^ l7) << 4);
+            bf16x8 af[2], bfr[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) af[i] = *(const bf16x8*)(As + a_row_off + i * 32 * 128 + coff);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bfr[j] = *(const bf16x8*)(Bs + b_row_off + j * 32 * 128 + coff);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue: accumulators -> LDS fp32 tile [BM][BN] -> affine/act/dropout -> coalesced NHWC stores
+    __syncthreads();
+    float* Ct = (float*)smem;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ml = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                const int nl = wn * 64 + j * 32 + l31;
+                Ct[ml * BN + nl] = acc[i][j][r];
+            }
+    __syncthreads();
+    const uint32_t key = drop_key(a.drop);
+    constexpr int CG = BN / 8;  // 8-channel groups per tile row
+#pragma unroll 2
+    for (int it = 0; it < (BM * CG) / 256; ++it) {
+        const int id = it * 256 + tid;
+        const int row = id / CG, cg = id % CG;
+        const int m = tm * BM + row;
+        if (m >= M) continue;
+        const int co = tn * BN + cg * 8;
+        const float4 v0 = *(const float4*)(Ct + row * BN + cg * 8);
+        const float4 v1 = *(const float4*)(Ct + row * BN + cg * 8 + 4);
+        const size_t ci = (size_t)(m / howo) * a.coef_stride + co;
+        const float4 a0 = *(const float4*)(a.coef_a + ci), a1 = *(const float4*)(a.coef_a + ci + 4);
+        const float4 c0 = *(const float4*)(a.coef_c + ci), c1 = *(const float4*)(a.coef_c + ci + 4);
+        float v[8] = {fmaf(v0.x, a0.x, c0.x), fmaf(v0.y, a0.y, c0.y), fmaf(v0.z, a0.z, c0.z), fmaf(v0.w, a0.w, c0.w),
+                      fmaf(v1.x, a1.x, c1.x), fmaf(v1.y, a1.y, c1.y), fmaf(v1.z, a1.z, c1.z), fmaf(v1.w, a1.w, c1.w)};
+        const uint32_t e0 = (uint32_t)((size_t)m * a.cout + co);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            v[t] = apply_act(v[t], a.act);
+            v[t] = drop_apply(v[t], e0 + t, a.drop, key);
+        }
+        if (a.out_bf16) {
+            uint4 o;
+            o.x = pack_bf16x2(v[0], v[1]);
+            o.y = pack_bf16x2(v[2], v[3]);
+            o.z = pack_bf16x2(v[4], v[5]);
+            o.w = pack_bf16x2(v[6], v[7]);
+            *(uint4*)(a.out_bf16 + (size_t)m * a.cout + co) = o;
+        }
+        if (a.out_f32) {
+            float* o = a.out_f32 + (size_t)m * a.cout + co;
+            *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
+            *(float4*)(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ launchers
+bool conv_mfma_supported(const ConvArgs& a) {
+    return a.c0 > 0 && (a.c0 % 64) == 0 && (a.c1 % 64) == 0 && (a.cout % 64) == 0 && a.zero_page != nullptr;
+}
+
+template <int BM, int BN, int WM, int WN>
+static hipError_t launch_igemm(const ConvArgs& a, hipStream_t stream) {
+    constexpr int lds = 2 * (BM + BN) * 128;
+    const long long M = (long long)a.n * a.ho * a.wo;
+    const int tiles_m = (int)((M + BM - 1) / BM), tiles_n = a.cout / BN;
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN>), dim3(tiles_m * tiles_n), dim3(256), lds, stream, a, (int)M,
+                       tiles_m, tiles_n);
+    return hipGetLastError();
+}
+
+// Raise the dynamic-LDS cap of the MFMA kernels once per process (not legal inside a stream capture).
+hipError_t conv_init() {
+    hipError_t e = hipFuncSetAttribute((const void*)conv_igemm_kernel<128, 128, 2, 2>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 + 128) * 128);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute((const void*)conv_igemm_kernel<256, 64, 4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               2 * (256 + 64) * 128);
+}
+
+hipError_t launch_conv(const ConvArgs& a, int path, hipStream_t stream) {
+    if (path == 1 && conv_mfma_supported(a)) {
+        if (a.cout % 128 == 0) return launch_igemm<128, 128, 2, 2>(a, stream);
+        return launch_igemm<256, 64, 4, 1>(a, stream);
+    }
+    const long long total = (long long)a.n * a.ho * a.wo * a.cout;
+    const int threads = 256;
+    hipLaunchKernelGGL(conv_direct_kernel, dim3((unsigned)((total + threads - 1) / threads)), dim3(threads), 0, stream,
+                       a, total);
+    return hipGetLastError();
+}

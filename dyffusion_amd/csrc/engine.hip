@@ -1,0 +1,959 @@
+// Host side of libdyffusion_hip.so: engine object, weight preparation (K11), per-network forward, sampling-loop
+// executor with hipGraph capture, and the extern "C" entry points declared in include/dyffusion_hip.h.
+//
+// Path being replaced (reference, read-only): src/diffusion/dyffusion.py:335-431 (sample_loop / sample),
+// :140-163 + :480-494 (q_sample / _interpolate), :205-239 (predict_x_last) and src/models/unet_simple.py:164-197.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/dyffusion_hip.h"
+#include "conv.h"
+#include "kernels.h"
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct UBlock {              // one UNetBlock (unet_simple.py:13-82)
+    int cin = 0, cout = 0, k = 0, stride = 1, pad = 0;
+    bool gn = false;         // GroupNorm(8) instead of BatchNorm (last encoder block)
+    bool transposed = false; // decoder block: x2 bilinear upsample in front of the conv
+    int act = ACT_NONE;
+    int film_off = 0;        // offset of this block's channels in the flattened coefficient table
+    int in_h = 0, in_w = 0;  // conv input size (after the x2 upsample for decoder blocks)
+    int out_h = 0, out_w = 0;
+    bf16_t* wpk = nullptr;   // device [cout][k*k][cin]
+    float* gamma = nullptr;  // device (GroupNorm only)
+    float* beta = nullptr;
+    float* static_a = nullptr;  // device [cout]: epilogue of the GroupNorm block's conv (ones / conv bias)
+    float* static_c = nullptr;
+};
+
+struct Net {
+    dyf_net_config cfg{};
+    bool loaded = false;
+    int cin_total = 0, dim = 0, tdim = 0, total_c = 0;
+    int uh = 0, uw = 0;      // resampled grid
+    UBlock blk[12];
+    float *t_w1 = nullptr, *t_b1 = nullptr, *t_w2 = nullptr, *t_b2 = nullptr;
+    float *stem_w = nullptr, *stem_b = nullptr;
+    float *film_w = nullptr, *film_b = nullptr, *norm_a = nullptr, *norm_c = nullptr;
+    int *blk_of = nullptr, *blk_off = nullptr, *blk_cout = nullptr;
+    float *ro_w = nullptr, *ro_b = nullptr;
+    double flops_per_sample = 0.0;
+    // sampler coefficient tables: one (A, C) row pair per distinct time value
+    std::map<float, int> table_of_time;
+    float* tables = nullptr;  // device [ntables][2][total_c]
+    int ntables = 0;
+};
+
+struct Workspace {
+    bf16_t* stem = nullptr;
+    bf16_t* enc[6] = {};
+    float* enc5_raw = nullptr;
+    bf16_t* up = nullptr;
+    bf16_t* dec[6] = {};
+    float* silu = nullptr;
+    float* coef_a = nullptr;
+    float* coef_c = nullptr;
+    bf16_t* zero_page = nullptr;
+};
+
+struct PlanHost {
+    bool set = false;
+    std::vector<dyf_plan_step> steps;
+    std::vector<float> refine_times;
+    std::vector<int> refine_slots;
+    dyf_plan hdr{};
+};
+
+struct GraphEntry {
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+};
+
+}  // namespace
+
+struct dyf_engine {
+    dyf_engine_config cfg{};
+    std::string err;
+    Net net[2];
+    Workspace ws;
+    std::vector<void*> allocs;
+    PlanHost plan;
+    int C = 0, Cs = 0, wC = 0;  // dynamics channels, static-condition channels, window*C
+    // sampler state (fp32 NCHW, engine-owned so a captured graph never sees caller pointers)
+    float *s_init = nullptr, *s_static = nullptr, *s_xs = nullptr, *s_x0hat = nullptr, *s_next = nullptr,
+          *s_cur = nullptr, *s_noisy = nullptr, *s_stack = nullptr;
+    float* s_time = nullptr;   // device scalar scratch for time values
+    uint32_t* rng_state = nullptr;  // device {seed_lo, seed_hi, forward_counter, pad}
+    int stack_slots = 0;
+    std::map<int, GraphEntry> graphs;  // by batch size
+    hipStream_t cap_stream = nullptr;  // capture never runs on the caller's (possibly legacy default) stream
+};
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------ error helpers
+dyf_status fail(dyf_engine* e, dyf_status st, const std::string& msg) {
+    if (e) e->err = msg; else g_create_error = msg;
+    return st;
+}
+
+#define HIP_TRY(e, expr)                                                                                   \
+    do {                                                                                                   \
+        hipError_t _err = (expr);                                                                          \
+        if (_err != hipSuccess)                                                                            \
+            return fail(e, DYF_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_err));              \
+    } while (0)
+
+template <typename T>
+dyf_status dev_alloc(dyf_engine* e, T** out, size_t count) {
+    void* p = nullptr;
+    size_t bytes = std::max<size_t>(count * sizeof(T), 256);
+    HIP_TRY(e, hipMalloc(&p, bytes));
+    HIP_TRY(e, hipMemset(p, 0, bytes));
+    e->allocs.push_back(p);
+    *out = (T*)p;
+    return DYF_OK;
+}
+
+template <typename T>
+dyf_status dev_upload(dyf_engine* e, T** out, const std::vector<T>& host) {
+    dyf_status st = dev_alloc(e, out, host.size());
+    if (st != DYF_OK) return st;
+    if (!host.empty()) HIP_TRY(e, hipMemcpy(*out, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
+    return DYF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ geometry
+void layout_blocks(Net& n) {
+    const int d = n.dim;
+    // (cin, cout, kernel, stride, pad, norm, act): unet_simple.py:119-139 through UNetBlock.__init__ (:14-56)
+    const int enc[6][5] = {{d, 2 * d, 4, 2, 1}, {2 * d, 2 * d, 4, 2, 1}, {2 * d, 4 * d, 4, 2, 1},
+                           {4 * d, 8 * d, 4, 2, 1}, {8 * d, 8 * d, 2, 2, 0}, {8 * d, 8 * d, 2, 2, 0}};
+    const int dec[6][5] = {{8 * d, 8 * d, 1, 1, 0},  {16 * d, 8 * d, 1, 1, 0}, {16 * d, 4 * d, 3, 1, 1},
+                           {8 * d, 2 * d, 3, 1, 1},  {4 * d, 2 * d, 3, 1, 1},  {4 * d, d, 3, 1, 1}};
+    int off = 0;
+    for (int i = 0; i < 12; ++i) {
+        const int* s = i < 6 ? enc[i] : dec[i - 6];
+        UBlock& b = n.blk[i];
+        b.cin = s[0]; b.cout = s[1]; b.k = s[2]; b.stride = s[3]; b.pad = s[4];
+        b.gn = (i == 5);
+        b.transposed = i >= 6;
+        b.act = i < 6 ? ACT_LEAKY : ACT_RELU;
+        b.film_off = off;
+        off += b.cout;
+    }
+    n.total_c = off;
+}
+
+// returns "" or an error message
+std::string layout_geometry(Net& n, int H, int W) {
+    n.uh = n.cfg.upsample_h > 0 ? n.cfg.upsample_h : H;
+    n.uw = n.cfg.upsample_w > 0 ? n.cfg.upsample_w : W;
+    int h = n.uh, w = n.uw;
+    for (int i = 0; i < 6; ++i) {
+        UBlock& b = n.blk[i];
+        b.in_h = h; b.in_w = w;
+        b.out_h = (h + 2 * b.pad - b.k) / b.stride + 1;
+        b.out_w = (w + 2 * b.pad - b.k) / b.stride + 1;
+        if (b.out_h < 1 || b.out_w < 1) return "resampled grid too small for six stride-2 encoder blocks";
+        h = b.out_h; w = b.out_w;
+    }
+    for (int i = 6; i < 12; ++i) {
+        UBlock& b = n.blk[i];
+        b.in_h = 2 * h; b.in_w = 2 * w;
+        b.out_h = b.in_h + 2 * b.pad - b.k + 1;
+        b.out_w = b.in_w + 2 * b.pad - b.k + 1;
+        h = b.out_h; w = b.out_w;
+        if (i < 11) {  // torch.cat([x, skip]) must line up (unet_simple.py:176-177)
+            const UBlock& skip = n.blk[10 - i];
+            if (skip.out_h != h || skip.out_w != w)
+                return "decoder/skip spatial sizes do not match (resampled grid must be divisible by 64)";
+        }
+    }
+    // 2*MAC of conv/linear layers, as torch.utils.flop_counter counts them
+    double f = 2.0 * n.uh * n.uw * (double)n.cin_total * n.dim;
+    for (int i = 0; i < 12; ++i) {
+        const UBlock& b = n.blk[i];
+        f += 2.0 * b.out_h * b.out_w * (double)b.cout * b.cin * b.k * b.k;
+    }
+    f += 2.0 * h * w * (double)n.dim * n.cfg.out_channels * 16;  // ConvTranspose2d k4: per INPUT pixel
+    if (n.cfg.with_time_emb) {
+        f += 2.0 * ((double)n.dim * n.tdim + (double)n.tdim * n.tdim);
+        f += 2.0 * (double)n.tdim * 2 * n.total_c;
+    }
+    n.flops_per_sample = f;
+    return "";
+}
+
+// ------------------------------------------------------------------------------------------------ forward
+struct Source {
+    const float* p;
+    int ch;
+};
+
+struct FwdOpts {
+    const float* coef_a;      // [rows][total_c]
+    const float* coef_c;
+    int coef_stride;          // 0: one row for the whole batch
+    int dropout_mode;         // 0 off, 1 engine RNG, 2 injected
+    const uint8_t* const* masks;  // [12] when dropout_mode == 2
+};
+
+DropSpec make_drop(const dyf_engine* e, const Net& n, const FwdOpts& o, int layer) {
+    DropSpec d{};
+    const float p = n.cfg.dropout;
+    d.mode = (p > 0.0f) ? o.dropout_mode : 0;
+    d.scale = 1.0f / (1.0f - p);
+    d.thresh16 = keep_threshold16(p);
+    d.layer = (uint32_t)layer;
+    d.state = e->rng_state;
+    d.mask = (d.mode == 2 && o.masks) ? o.masks[layer] : nullptr;
+    if (d.mode == 2 && d.mask == nullptr) d.mode = 0;
+    return d;
+}
+
+dyf_status run_conv(dyf_engine* e, const ConvArgs& a, hipStream_t st) {
+    const int path = (e->cfg.enable_mfma && conv_mfma_supported(a)) ? 1 : 0;
+    HIP_TRY(e, launch_conv(a, path, st));
+    return DYF_OK;
+}
+
+ConvArgs block_conv_args(const dyf_engine* e, const Net& n, const UBlock& b, int nb) {
+    ConvArgs a{};
+    a.n = nb; a.h = b.in_h; a.w = b.in_w; a.ho = b.out_h; a.wo = b.out_w;
+    a.kh = b.k; a.kw = b.k; a.stride = b.stride; a.pad = b.pad; a.cout = b.cout;
+    a.wpk = b.wpk;
+    a.act = b.act;
+    a.zero_page = e->ws.zero_page;
+    return a;
+}
+
+dyf_status net_forward(dyf_engine* e, int which, const Source* srcs, int nsrc, int nb, const FwdOpts& o, float* out_dev,
+                       hipStream_t st) {
+    Net& n = e->net[which];
+    Workspace& ws = e->ws;
+    const int H = e->cfg.height, W = e->cfg.width;
+    // ---- stem: outer resample + 1x1 conv
+    StemArgs sa{};
+    int ctot = 0;
+    for (int i = 0; i < nsrc; ++i) {
+        sa.src[i] = srcs[i].p;
+        sa.ch[i] = srcs[i].ch;
+        ctot += srcs[i].ch;
+    }
+    if (ctot != n.cin_total)
+        return fail(e, DYF_ERR_INVALID_ARGUMENT, "channel count of the network inputs does not match its configuration");
+    sa.nsrc = nsrc; sa.cin = ctot; sa.n = nb; sa.h = H; sa.w = W; sa.uh = n.uh; sa.uw = n.uw;
+    sa.resample = (n.uh != H || n.uw != W) ? 1 : 0;
+    sa.wgt = n.stem_w; sa.bias = n.stem_b; sa.dim = n.dim; sa.out = ws.stem;
+    HIP_TRY(e, launch_stem(sa, st));
+    // ---- encoder
+    const bf16_t* x = ws.stem;
+    for (int i = 0; i < 6; ++i) {
+        const UBlock& b = n.blk[i];
+        ConvArgs a = block_conv_args(e, n, b, nb);
+        a.src0 = x; a.c0 = b.cin; a.src1 = nullptr; a.c1 = 0;
+        if (!b.gn) {
+            a.coef_a = o.coef_a + b.film_off; a.coef_c = o.coef_c + b.film_off; a.coef_stride = o.coef_stride;
+            a.drop = make_drop(e, n, o, i);
+            a.out_bf16 = ws.enc[i];
+            dyf_status s = run_conv(e, a, st);
+            if (s != DYF_OK) return s;
+        } else {
+            a.coef_a = b.static_a; a.coef_c = b.static_c; a.coef_stride = 0;
+            a.act = ACT_NONE;
+            a.drop = DropSpec{};
+            a.out_f32 = ws.enc5_raw;
+            dyf_status s = run_conv(e, a, st);
+            if (s != DYF_OK) return s;
+            GroupNormArgs g{};
+            g.x = ws.enc5_raw; g.n = nb; g.hw = b.out_h * b.out_w; g.c = b.cout; g.groups = 8;
+            g.gamma = b.gamma; g.beta = b.beta;
+            g.film_a = o.coef_a + b.film_off; g.film_c = o.coef_c + b.film_off; g.film_stride = o.coef_stride;
+            g.act = b.act; g.drop = make_drop(e, n, o, i); g.out = ws.enc[i];
+            HIP_TRY(e, launch_groupnorm(g, st));
+        }
+        x = ws.enc[i];
+    }
+    // ---- decoder: x2 bilinear upsample of cat[x, skip] (materialised), conv, fused epilogue
+    const bf16_t* skip = nullptr;
+    int skip_c = 0;
+    int lh = n.blk[5].out_h, lw = n.blk[5].out_w;
+    for (int i = 6; i < 12; ++i) {
+        const UBlock& b = n.blk[i];
+        Up2xArgs u{};
+        u.src0 = x; u.c0 = b.cin - skip_c; u.src1 = skip; u.c1 = skip_c; u.n = nb; u.h = lh; u.w = lw; u.out = ws.up;
+        HIP_TRY(e, launch_up2x(u, st));
+        ConvArgs a = block_conv_args(e, n, b, nb);
+        a.src0 = ws.up; a.c0 = b.cin; a.src1 = nullptr; a.c1 = 0;
+        a.coef_a = o.coef_a + b.film_off; a.coef_c = o.coef_c + b.film_off; a.coef_stride = o.coef_stride;
+        a.drop = make_drop(e, n, o, i);
+        a.out_bf16 = ws.dec[i - 6];
+        dyf_status s = run_conv(e, a, st);
+        if (s != DYF_OK) return s;
+        x = ws.dec[i - 6];
+        lh = b.out_h; lw = b.out_w;
+        if (i < 11) {
+            skip = ws.enc[10 - i];
+            skip_c = n.blk[10 - i].cout;
+        }
+    }
+    // ---- readout (sparse transposed conv + final resample)
+    ReadoutArgs r{};
+    r.x = x; r.n = nb; r.ih = lh; r.iw = lw; r.cin = n.dim; r.wgt = n.ro_w; r.bias = n.ro_b; r.cout = n.cfg.out_channels;
+    r.oh = H; r.ow = W; r.out = out_dev;
+    HIP_TRY(e, launch_readout(r, st));
+    if (o.dropout_mode == 1 && n.cfg.dropout > 0.0f) HIP_TRY(e, launch_bump_counter(e->rng_state, st));
+    return DYF_OK;
+}
+
+// coefficient rows for `rows` time values already on the device
+dyf_status compute_coefs(dyf_engine* e, Net& n, const float* time_dev, int rows, float* coef_a, float* coef_c,
+                         hipStream_t st) {
+    FilmArgs f{};
+    if (n.cfg.with_time_emb) {
+        TimeMlpArgs t{};
+        t.time = time_dev; t.rows = rows; t.dim = n.dim; t.w1 = n.t_w1; t.b1 = n.t_b1; t.w2 = n.t_w2; t.b2 = n.t_b2;
+        t.silu_out = e->ws.silu;
+        HIP_TRY(e, launch_time_mlp(t, st));
+        f.silu = e->ws.silu;
+    }
+    f.rows = rows; f.tdim = n.tdim; f.total_c = n.total_c; f.wf = n.film_w; f.bf = n.film_b; f.blk_of = n.blk_of;
+    f.blk_off = n.blk_off; f.blk_cout = n.blk_cout; f.norm_a = n.norm_a; f.norm_c = n.norm_c; f.coef_a = coef_a;
+    f.coef_c = coef_c;
+    HIP_TRY(e, launch_film(f, st));
+    return DYF_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ weights (K11)
+struct TensorView {
+    const float* data;
+    std::vector<int64_t> shape;
+    int64_t numel() const {
+        int64_t n = 1;
+        for (auto s : shape) n *= s;
+        return n;
+    }
+};
+
+}  // namespace
+
+// ================================================================================================ C ABI
+extern "C" {
+
+int32_t dyf_abi_version(void) { return DYF_ABI_VERSION; }
+
+const char* dyf_last_error(const dyf_engine* engine) { return engine ? engine->err.c_str() : g_create_error.c_str(); }
+
+void dyf_engine_destroy(dyf_engine* e) {
+    if (!e) return;
+    (void)hipSetDevice(e->cfg.device);
+    for (auto& kv : e->graphs) {
+        if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
+        if (kv.second.graph) (void)hipGraphDestroy(kv.second.graph);
+    }
+    if (e->cap_stream) (void)hipStreamDestroy(e->cap_stream);
+    for (void* p : e->allocs) (void)hipFree(p);
+    delete e;
+}
+
+dyf_status dyf_engine_create(const dyf_engine_config* cfg, dyf_engine** out_engine) {
+    if (!cfg || !out_engine) return fail(nullptr, DYF_ERR_INVALID_ARGUMENT, "null argument");
+    if (cfg->abi_version != DYF_ABI_VERSION) return fail(nullptr, DYF_ERR_INVALID_ARGUMENT, "ABI version mismatch");
+    if (cfg->height < 1 || cfg->width < 1 || cfg->max_batch < 1)
+        return fail(nullptr, DYF_ERR_INVALID_ARGUMENT, "height, width and max_batch must be positive");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return fail(nullptr, DYF_ERR_HIP, "no HIP device available: the DYffusion engine requires an MI355X (gfx950)");
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(nullptr, DYF_ERR_INVALID_ARGUMENT, "device ordinal out of range");
+    if (hipSetDevice(cfg->device) != hipSuccess) return fail(nullptr, DYF_ERR_HIP, "hipSetDevice failed");
+
+    dyf_engine* e = new dyf_engine();
+    e->cfg = *cfg;
+    if (conv_init() != hipSuccess || hipStreamCreateWithFlags(&e->cap_stream, hipStreamNonBlocking) != hipSuccess) {
+        delete e;
+        return fail(nullptr, DYF_ERR_HIP, "engine initialisation failed (conv_init / stream create)");
+    }
+    auto bail = [&](dyf_status st, const std::string& m) {
+        g_create_error = m;
+        dyf_engine_destroy(e);
+        return st;
+    };
+    for (int w = 0; w < 2; ++w) {
+        Net& n = e->net[w];
+        n.cfg = cfg->net[w];
+        if (n.cfg.arch != DYF_ARCH_UNET_SIMPLE) return bail(DYF_ERR_UNSUPPORTED, "only arch=unet_simple is implemented");
+        if (n.cfg.dim < 4 || (n.cfg.dim & 1)) return bail(DYF_ERR_INVALID_ARGUMENT, "dim must be even and >= 4");
+        if ((8 * n.cfg.dim) % 8 != 0) return bail(DYF_ERR_INVALID_ARGUMENT, "GroupNorm(8) needs 8*dim divisible by 8");
+        if (n.cfg.input_dropout != 0.0f) return bail(DYF_ERR_UNSUPPORTED, "input_dropout > 0 is not implemented");
+        if (n.cfg.dropout < 0.0f || n.cfg.dropout >= 1.0f) return bail(DYF_ERR_INVALID_ARGUMENT, "dropout must be in [0, 1)");
+        n.cin_total = n.cfg.in_channels + n.cfg.cond_channels;
+        if (n.cin_total < 1 || n.cin_total > DYF_MAX_IN_CH || n.cfg.out_channels < 1 || n.cfg.out_channels > DYF_MAX_OUT_CH)
+            return bail(DYF_ERR_UNSUPPORTED, "channel counts outside the supported range (inputs+cond <= 32, outputs <= 8)");
+        n.dim = n.cfg.dim;
+        n.tdim = 2 * n.cfg.dim;
+        layout_blocks(n);
+        std::string m = layout_geometry(n, cfg->height, cfg->width);
+        if (!m.empty()) return bail(DYF_ERR_INVALID_ARGUMENT, m);
+    }
+    // ---- workspace (sized for max_batch, shared by the two networks which run back to back)
+    const size_t nb = (size_t)cfg->max_batch;
+    size_t stem_el = 0, enc_el[6] = {}, dec_el[6] = {}, up_el = 0, raw_el = 0, tc = 0, td = 0;
+    for (int w = 0; w < 2; ++w) {
+        const Net& n = e->net[w];
+        stem_el = std::max(stem_el, nb * n.uh * n.uw * n.dim);
+        for (int i = 0; i < 6; ++i) {
+            const UBlock& b = n.blk[i];
+            enc_el[i] = std::max(enc_el[i], nb * b.out_h * b.out_w * b.cout);
+            const UBlock& d = n.blk[6 + i];
+            dec_el[i] = std::max(dec_el[i], nb * d.out_h * d.out_w * d.cout);
+            up_el = std::max(up_el, nb * d.in_h * d.in_w * d.cin);
+        }
+        raw_el = std::max(raw_el, nb * n.blk[5].out_h * n.blk[5].out_w * n.blk[5].cout);
+        tc = std::max<size_t>(tc, n.total_c);
+        td = std::max<size_t>(td, n.tdim);
+    }
+    Workspace& ws = e->ws;
+#define ALLOC(ptr, count)                                           \
+    do {                                                            \
+        dyf_status _s = dev_alloc(e, &(ptr), (count));              \
+        if (_s != DYF_OK) return bail(_s, e->err);                  \
+    } while (0)
+    ALLOC(ws.stem, stem_el);
+    for (int i = 0; i < 6; ++i) {
+        ALLOC(ws.enc[i], enc_el[i]);
+        ALLOC(ws.dec[i], dec_el[i]);
+    }
+    ALLOC(ws.enc5_raw, raw_el);
+    ALLOC(ws.up, up_el);
+    ALLOC(ws.silu, nb * td);
+    ALLOC(ws.coef_a, nb * tc);
+    ALLOC(ws.coef_c, nb * tc);
+    ALLOC(ws.zero_page, 256);
+    ALLOC(e->s_time, 64);
+    ALLOC(e->rng_state, 4);
+#undef ALLOC
+    *out_engine = e;
+    return DYF_OK;
+}
+
+dyf_status dyf_seed(dyf_engine* e, uint64_t seed) {
+    if (!e) return DYF_ERR_INVALID_ARGUMENT;
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    const uint32_t st[4] = {(uint32_t)(seed & 0xffffffffu), (uint32_t)(seed >> 32), 0u, 0u};
+    HIP_TRY(e, hipMemcpy(e->rng_state, st, sizeof(st), hipMemcpyHostToDevice));
+    return DYF_OK;
+}
+
+dyf_status dyf_load_weights(dyf_engine* e, int32_t which, int32_t n_tensors, const char* const* names,
+                            const float* const* data, const int64_t* const* shapes, const int32_t* ndims) {
+    if (!e) return DYF_ERR_INVALID_ARGUMENT;
+    if (which < 0 || which > 1) return fail(e, DYF_ERR_INVALID_ARGUMENT, "net must be 0 (forecaster) or 1 (interpolator)");
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    Net& n = e->net[which];
+    std::map<std::string, TensorView> sd;
+    for (int i = 0; i < n_tensors; ++i) {
+        TensorView v;
+        v.data = data[i];
+        v.shape.assign(shapes[i], shapes[i] + ndims[i]);
+        sd[names[i]] = v;
+    }
+    std::string missing;
+    auto get = [&](const std::string& key, std::vector<int64_t> want) -> const TensorView* {
+        auto it = sd.find(key);
+        if (it == sd.end()) {
+            if (missing.empty()) missing = "missing tensor '" + key + "' in state_dict";
+            return nullptr;
+        }
+        if (it->second.shape != want) {
+            if (missing.empty()) missing = "tensor '" + key + "' has an unexpected shape";
+            return nullptr;
+        }
+        return &it->second;
+    };
+    auto vec = [](const TensorView* t) { return std::vector<float>(t->data, t->data + t->numel()); };
+    const int64_t d = n.dim, td = n.tdim;
+#define NEED(var, key, ...)                                              \
+    const TensorView* var = get(key, std::vector<int64_t>{__VA_ARGS__}); \
+    if (!var) return fail(e, DYF_ERR_INVALID_ARGUMENT, missing)
+#define UP(dst, hostvec)                                  \
+    do {                                                  \
+        dyf_status _s = dev_upload(e, &(dst), (hostvec)); \
+        if (_s != DYF_OK) return _s;                      \
+    } while (0)
+
+    if (n.cfg.with_time_emb) {
+        NEED(w1, "time_emb_mlp.1.weight", td, d);
+        NEED(b1, "time_emb_mlp.1.bias", td);
+        NEED(w2, "time_emb_mlp.3.weight", td, td);
+        NEED(b2, "time_emb_mlp.3.bias", td);
+        UP(n.t_w1, vec(w1)); UP(n.t_b1, vec(b1)); UP(n.t_w2, vec(w2)); UP(n.t_b2, vec(b2));
+    }
+    {
+        NEED(sw, "init_conv.weight", d, (int64_t)n.cin_total, 1, 1);
+        NEED(sb, "init_conv.bias", d);
+        UP(n.stem_w, vec(sw)); UP(n.stem_b, vec(sb));
+    }
+    std::vector<float> film_w((size_t)2 * n.total_c * n.tdim, 0.0f), film_b((size_t)2 * n.total_c, 0.0f);
+    std::vector<float> norm_a(n.total_c, 1.0f), norm_c(n.total_c, 0.0f);
+    std::vector<int> blk_of(n.total_c), blk_off(12), blk_cout(12);
+    for (int i = 0; i < 12; ++i) {
+        UBlock& b = n.blk[i];
+        const std::string pre = (i < 6 ? "input_ops." + std::to_string(i) : "output_ops." + std::to_string(i - 6));
+        const std::string conv = pre + ".ops." + (b.transposed ? "1" : "0");
+        const std::string norm = pre + ".ops." + (b.transposed ? "2" : "1");
+        NEED(cw, conv + ".weight", (int64_t)b.cout, (int64_t)b.cin, (int64_t)b.k, (int64_t)b.k);
+        NEED(cb, conv + ".bias", (int64_t)b.cout);
+        NEED(nw, norm + ".weight", (int64_t)b.cout);
+        NEED(nbias, norm + ".bias", (int64_t)b.cout);
+        blk_off[i] = b.film_off;
+        blk_cout[i] = b.cout;
+        for (int c = 0; c < b.cout; ++c) blk_of[b.film_off + c] = i;
+        // pack [cout][cin][kh][kw] fp32 -> [cout][tap][cin] bf16 (K-contiguous rows for the implicit GEMM)
+        const int taps = b.k * b.k;
+        std::vector<bf16_t> pk((size_t)b.cout * taps * b.cin);
+        for (int co = 0; co < b.cout; ++co)
+            for (int ci = 0; ci < b.cin; ++ci)
+                for (int t = 0; t < taps; ++t)
+                    pk[((size_t)co * taps + t) * b.cin + ci] = f32_to_bf16(cw->data[((size_t)co * b.cin + ci) * taps + t]);
+        UP(b.wpk, pk);
+        if (!b.gn) {  // eval-mode BatchNorm2d folded with the conv bias: y = conv*a + c
+            NEED(rm, norm + ".running_mean", (int64_t)b.cout);
+            NEED(rv, norm + ".running_var", (int64_t)b.cout);
+            for (int c = 0; c < b.cout; ++c) {
+                const double a = (double)nw->data[c] / std::sqrt((double)rv->data[c] + 1e-5);
+                norm_a[b.film_off + c] = (float)a;
+                norm_c[b.film_off + c] = (float)((double)nbias->data[c] + ((double)cb->data[c] - (double)rm->data[c]) * a);
+            }
+        } else {  // GroupNorm: conv epilogue only adds the bias; the FiLM table carries (1+scale, shift)
+            UP(b.gamma, vec(nw)); UP(b.beta, vec(nbias));
+            UP(b.static_a, std::vector<float>(b.cout, 1.0f));
+            UP(b.static_c, vec(cb));
+        }
+        if (n.cfg.with_time_emb) {
+            NEED(fw, pre + ".time_mlp.1.weight", (int64_t)2 * b.cout, td);
+            NEED(fb, pre + ".time_mlp.1.bias", (int64_t)2 * b.cout);
+            std::copy(fw->data, fw->data + fw->numel(), film_w.begin() + (size_t)2 * b.film_off * n.tdim);
+            std::copy(fb->data, fb->data + fb->numel(), film_b.begin() + (size_t)2 * b.film_off);
+        }
+    }
+    UP(n.film_w, film_w); UP(n.film_b, film_b); UP(n.norm_a, norm_a); UP(n.norm_c, norm_c);
+    UP(n.blk_of, blk_of); UP(n.blk_off, blk_off); UP(n.blk_cout, blk_cout);
+    {
+        const int64_t oc = n.cfg.out_channels;
+        NEED(rw, "readout.0.weight", d, oc, 4, 4);
+        NEED(rb, "readout.0.bias", oc);
+        std::vector<float> pk((size_t)16 * n.dim * oc);
+        for (int ci = 0; ci < n.dim; ++ci)
+            for (int co = 0; co < oc; ++co)
+                for (int t = 0; t < 16; ++t) pk[((size_t)t * n.dim + ci) * oc + co] = rw->data[((size_t)ci * oc + co) * 16 + t];
+        UP(n.ro_w, pk); UP(n.ro_b, vec(rb));
+    }
+#undef NEED
+#undef UP
+    n.loaded = true;
+    n.table_of_time.clear();
+    n.ntables = 0;
+    e->plan.set = false;  // coefficient tables depend on the weights
+    return DYF_OK;
+}
+
+dyf_status dyf_net_flops(const dyf_engine* e, int32_t which, double* flops) {
+    if (!e || !flops || which < 0 || which > 1) return DYF_ERR_INVALID_ARGUMENT;
+    *flops = e->net[which].flops_per_sample;
+    return DYF_OK;
+}
+
+dyf_status dyf_net_forward(dyf_engine* e, int32_t which, const float* inputs_dev, const float* time_dev,
+                           const float* condition_dev, float* out_dev, int32_t nb, int32_t dropout_mode,
+                           const uint8_t* const* masks_dev, void* stream) {
+    if (!e) return DYF_ERR_INVALID_ARGUMENT;
+    if (which < 0 || which > 1) return fail(e, DYF_ERR_INVALID_ARGUMENT, "net must be 0 or 1");
+    Net& n = e->net[which];
+    if (!n.loaded) return fail(e, DYF_ERR_STATE, "dyf_load_weights has not been called for this network");
+    if (nb < 1 || nb > e->cfg.max_batch) return fail(e, DYF_ERR_INVALID_ARGUMENT, "batch size outside [1, max_batch]");
+    if (!inputs_dev || !out_dev) return fail(e, DYF_ERR_INVALID_ARGUMENT, "inputs/out must not be null");
+    if ((n.cfg.cond_channels > 0) != (condition_dev != nullptr))
+        return fail(e, DYF_ERR_INVALID_ARGUMENT, "condition must be given iff num_conditional_channels > 0");
+    if (n.cfg.with_time_emb && !time_dev) return fail(e, DYF_ERR_INVALID_ARGUMENT, "time must be given when with_time_emb");
+    if (dropout_mode < 0 || dropout_mode > 2) return fail(e, DYF_ERR_INVALID_ARGUMENT, "dropout_mode must be 0, 1 or 2");
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    hipStream_t st = (hipStream_t)stream;
+    dyf_status s = compute_coefs(e, n, time_dev, nb, e->ws.coef_a, e->ws.coef_c, st);
+    if (s != DYF_OK) return s;
+    Source srcs[2] = {{inputs_dev, n.cfg.in_channels}, {condition_dev, n.cfg.cond_channels}};
+    FwdOpts o{e->ws.coef_a, e->ws.coef_c, n.total_c, dropout_mode, masks_dev};
+    return net_forward(e, which, srcs, condition_dev ? 2 : 1, nb, o, out_dev, st);
+}
+
+// ------------------------------------------------------------------------------------------------ sampler
+dyf_status dyf_set_plan(dyf_engine* e, const dyf_plan* p) {
+    if (!e || !p) return DYF_ERR_INVALID_ARGUMENT;
+    if (!e->net[0].loaded || !e->net[1].loaded) return fail(e, DYF_ERR_STATE, "load both networks' weights before dyf_set_plan");
+    if (p->n_steps < 1 || !p->steps) return fail(e, DYF_ERR_INVALID_ARGUMENT, "plan needs at least one step");
+    {   // channel bookkeeping of the pair: forecaster (C -> C), interpolator ((window+1)*C -> C), interpolation.py:48-51
+        const int C = e->net[DYF_NET_FORECASTER].cfg.in_channels;
+        if (e->net[DYF_NET_FORECASTER].cfg.out_channels != C || e->net[DYF_NET_INTERPOLATOR].cfg.out_channels != C)
+            return fail(e, DYF_ERR_INVALID_ARGUMENT, "forecaster in/out and interpolator out channels must all equal C");
+        const int wC = e->net[DYF_NET_INTERPOLATOR].cfg.in_channels - C;
+        if (wC < C || wC % C != 0)
+            return fail(e, DYF_ERR_INVALID_ARGUMENT, "interpolator in_channels must be (window+1)*C (interpolation.py:48-51)");
+        e->C = C;
+        e->wC = wC;
+        e->Cs = e->net[DYF_NET_INTERPOLATOR].cfg.cond_channels;  // the interpolator only ever sees the static condition
+    }
+    if (p->n_out_slots < 1) return fail(e, DYF_ERR_INVALID_ARGUMENT, "n_out_slots must be >= 1");
+    const int fc = p->forward_conditioning;
+    const int want_cond = e->Cs + (fc == DYF_FCOND_NONE ? 0 : e->wC);
+    if (e->net[DYF_NET_FORECASTER].cfg.cond_channels != want_cond)
+        return fail(e, DYF_ERR_INVALID_ARGUMENT, "forecaster cond_channels inconsistent with forward_conditioning");
+    for (int i = 0; i < p->n_steps; ++i)
+        if (p->steps[i].out_slot >= p->n_out_slots) return fail(e, DYF_ERR_INVALID_ARGUMENT, "out_slot out of range");
+    for (int i = 0; i < p->n_refine; ++i)
+        if (p->refine_slots[i] < 0 || p->refine_slots[i] >= p->n_out_slots || !(p->refine_times[i] > 0.0f))
+            return fail(e, DYF_ERR_INVALID_ARGUMENT, "refine slot/time out of range");
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    PlanHost& ph = e->plan;
+    ph.steps.assign(p->steps, p->steps + p->n_steps);
+    ph.refine_times.assign(p->refine_times, p->refine_times + p->n_refine);
+    ph.refine_slots.assign(p->refine_slots, p->refine_slots + p->n_refine);
+    ph.hdr = *p;
+    ph.hdr.steps = nullptr; ph.hdr.refine_times = nullptr; ph.hdr.refine_slots = nullptr;
+    if (!e->s_init) {  // sampler state, allocated once (fp32 NCHW)
+        const size_t nbm = (size_t)e->cfg.max_batch, hw = (size_t)e->cfg.height * e->cfg.width;
+        dyf_status s;
+        if ((s = dev_alloc(e, &e->s_init, nbm * e->wC * hw)) != DYF_OK) return s;
+        if ((s = dev_alloc(e, &e->s_static, nbm * std::max(1, e->Cs) * hw)) != DYF_OK) return s;
+        if ((s = dev_alloc(e, &e->s_xs, nbm * e->C * hw)) != DYF_OK) return s;
+        if ((s = dev_alloc(e, &e->s_x0hat, nbm * e->C * hw)) != DYF_OK) return s;
+        if ((s = dev_alloc(e, &e->s_next, nbm * e->C * hw)) != DYF_OK) return s;
+        if ((s = dev_alloc(e, &e->s_cur, nbm * e->C * hw)) != DYF_OK) return s;
+        if ((s = dev_alloc(e, &e->s_noisy, nbm * e->wC * hw)) != DYF_OK) return s;
+    }
+    // forecast stack
+    if (p->n_out_slots > e->stack_slots) {
+        dyf_status s = dev_alloc(e, &e->s_stack, (size_t)p->n_out_slots * e->cfg.max_batch * e->C * e->cfg.height * e->cfg.width);
+        if (s != DYF_OK) return s;
+        e->stack_slots = p->n_out_slots;
+    }
+    // coefficient tables: the time value is the same for the whole batch inside the loop (dyffusion.py:360,372), so
+    // every (network, time) pair of the plan is evaluated once here instead of once per forward
+    for (int w = 0; w < 2; ++w) {
+        Net& n = e->net[w];
+        n.table_of_time.clear();
+        std::vector<float> times;
+        auto add = [&](float t) {
+            if (!n.table_of_time.count(t)) {
+                n.table_of_time[t] = (int)times.size();
+                times.push_back(t);
+            }
+        };
+        if (w == DYF_NET_FORECASTER) {
+            for (auto& s : ph.steps) add(s.forecaster_time);
+        } else {
+            for (auto& s : ph.steps) {
+                if (s.i_next >= 0.0f) add(s.i_next);
+                if (s.i_cur >= 0.0f) add(s.i_cur);
+            }
+            for (float t : ph.refine_times) add(t);
+        }
+        if (times.empty()) times.push_back(0.0f);
+        n.ntables = (int)times.size();
+        dyf_status s = dev_alloc(e, &n.tables, (size_t)n.ntables * 2 * n.total_c);
+        if (s != DYF_OK) return s;
+        float* tdev = nullptr;
+        s = dev_upload(e, &tdev, times);
+        if (s != DYF_OK) return s;
+        for (int i = 0; i < n.ntables; ++i) {
+            float* A = n.tables + (size_t)i * 2 * n.total_c;
+            s = compute_coefs(e, n, tdev + i, 1, A, A + n.total_c, 0);
+            if (s != DYF_OK) return s;
+        }
+    }
+    HIP_TRY(e, hipDeviceSynchronize());
+    for (auto& kv : e->graphs) {
+        if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
+        if (kv.second.graph) (void)hipGraphDestroy(kv.second.graph);
+    }
+    e->graphs.clear();
+    ph.set = true;
+    return DYF_OK;
+}
+
+dyf_status dyf_plan_forward_counts(const dyf_engine* e, int32_t* nf, int32_t* ni) {
+    if (!e || !nf || !ni || !e->plan.set) return DYF_ERR_STATE;
+    const PlanHost& ph = e->plan;
+    int f = 0, i = 0;
+    for (auto& s : ph.steps) {
+        ++f;
+        if (s.i_next >= 0.0f) ++i;
+        const bool plain_last = s.is_last && !ph.hdr.cold_for_last_step;
+        if (ph.hdr.sampling_cold && !plain_last && s.i_cur >= 0.0f) ++i;
+    }
+    i += (int)ph.refine_times.size();
+    *nf = f; *ni = i;
+    return DYF_OK;
+}
+
+}  // extern "C"
+
+namespace {
+
+struct MaskCursor {
+    const uint8_t* const* masks;
+    size_t pos = 0;
+    const uint8_t* const* take(bool on) {
+        if (!masks || !on) return nullptr;
+        const uint8_t* const* p = masks + pos;
+        pos += 12;
+        return p;
+    }
+};
+
+dyf_status run_plan(dyf_engine* e, int nb, const uint8_t* const* masks, const float* noise_dev, hipStream_t st) {
+    const PlanHost& ph = e->plan;
+    Net& F = e->net[DYF_NET_FORECASTER];
+    Net& I = e->net[DYF_NET_INTERPOLATOR];
+    const int H = e->cfg.height, W = e->cfg.width;
+    const size_t field = (size_t)nb * e->C * H * W;
+    const size_t init_el = (size_t)nb * e->wC * H * W;
+    const size_t fbytes = field * sizeof(float);
+    MaskCursor cur{masks};
+    const bool inject = masks != nullptr;
+    const int i_mode = ph.hdr.interpolator_dropout ? (inject ? 2 : 1) : 0;
+    const int f_mode = ph.hdr.forecaster_dropout ? (inject ? 2 : 1) : 0;
+
+    auto interp = [&](float t, const float* x_last, float* out) -> dyf_status {
+        const int ti = I.table_of_time.at(t);
+        const float* A = I.tables + (size_t)ti * 2 * I.total_c;
+        Source srcs[3] = {{e->s_init, e->wC}, {x_last, e->C}, {e->s_static, e->Cs}};
+        FwdOpts o{A, A + I.total_c, 0, i_mode, cur.take(i_mode == 2 && I.cfg.dropout > 0.0f)};
+        return net_forward(e, DYF_NET_INTERPOLATOR, srcs, e->Cs > 0 ? 3 : 2, nb, o, out, st);
+    };
+
+    // x_s = initial_condition[:, -C:]  (dyffusion.py:348); rows are (window*C, H, W) blocks -> strided copy per sample
+    if (e->wC == e->C) {
+        HIP_TRY(e, hipMemcpyAsync(e->s_xs, e->s_init, fbytes, hipMemcpyDeviceToDevice, st));
+    } else {
+        HIP_TRY(e, hipMemcpy2DAsync(e->s_xs, (size_t)e->C * H * W * sizeof(float),
+                                    e->s_init + (size_t)(e->wC - e->C) * H * W, (size_t)e->wC * H * W * sizeof(float),
+                                    (size_t)e->C * H * W * sizeof(float), nb, hipMemcpyDeviceToDevice, st));
+    }
+    int step_idx = 0;
+    for (const dyf_plan_step& s : ph.steps) {
+        // ---- forecaster: x0_hat = F(x_s, enc(s); cond)
+        Source fs[3];
+        int nf = 0;
+        fs[nf++] = {e->s_xs, e->C};
+        if (ph.hdr.forward_conditioning == DYF_FCOND_DATA) {
+            fs[nf++] = {e->s_init, e->wC};
+        } else if (ph.hdr.forward_conditioning == DYF_FCOND_DATA_NOISE) {
+            const float* nz = noise_dev ? noise_dev + (size_t)step_idx * init_el : nullptr;
+            HIP_TRY(e, launch_noisy_condition(e->s_noisy, e->s_init, nz, s.tau, (long long)init_el, e->rng_state,
+                                              (uint32_t)(step_idx & 15), st));
+            fs[nf++] = {e->s_noisy, e->wC};
+        }
+        if (e->Cs > 0) fs[nf++] = {e->s_static, e->Cs};
+        {
+            const int ti = F.table_of_time.at(s.forecaster_time);
+            const float* A = F.tables + (size_t)ti * 2 * F.total_c;
+            FwdOpts o{A, A + F.total_c, 0, f_mode, cur.take(f_mode == 2 && F.cfg.dropout > 0.0f)};
+            dyf_status r = net_forward(e, DYF_NET_FORECASTER, fs, nf, nb, o, e->s_x0hat, st);
+            if (r != DYF_OK) return r;
+        }
+        // ---- x_next = I(x0, x0_hat, i(s_next))   (dyffusion.py:374-379)
+        const float* x_next = e->s_x0hat;
+        if (s.i_next >= 0.0f) {
+            dyf_status r = interp(s.i_next, e->s_x0hat, e->s_next);
+            if (r != DYF_OK) return r;
+            x_next = e->s_next;
+        }
+        // ---- update of x_s  (dyffusion.py:381-393)
+        if (ph.hdr.sampling_cold) {
+            if (s.is_last && !ph.hdr.cold_for_last_step) {
+                HIP_TRY(e, hipMemcpyAsync(e->s_xs, e->s_x0hat, fbytes, hipMemcpyDeviceToDevice, st));
+            } else if (s.i_cur >= 0.0f) {
+                dyf_status r = interp(s.i_cur, e->s_x0hat, e->s_cur);
+                if (r != DYF_OK) return r;
+                HIP_TRY(e, launch_cold_update(e->s_xs, e->s_cur, x_next, (long long)field, st));
+            } else {  // s == 0: x_s - x_s + x_next
+                HIP_TRY(e, hipMemcpyAsync(e->s_xs, x_next, fbytes, hipMemcpyDeviceToDevice, st));
+            }
+        } else {
+            HIP_TRY(e, hipMemcpyAsync(e->s_xs, x_next, fbytes, hipMemcpyDeviceToDevice, st));
+        }
+        if (s.out_slot >= 0)
+            HIP_TRY(e, hipMemcpyAsync(e->s_stack + (size_t)s.out_slot * field, e->s_xs, fbytes, hipMemcpyDeviceToDevice, st));
+        ++step_idx;
+    }
+    // ---- refinement of the intermediate predictions with the final x0_hat (dyffusion.py:408-422)
+    for (size_t r = 0; r < ph.refine_times.size(); ++r) {
+        dyf_status rs = interp(ph.refine_times[r], e->s_x0hat, e->s_stack + (size_t)ph.refine_slots[r] * field);
+        if (rs != DYF_OK) return rs;
+    }
+    return DYF_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+dyf_status dyf_sample(dyf_engine* e, const float* initial_dev, const float* static_dev, float* out_dev, int32_t nb,
+                      const uint8_t* const* masks_dev, const float* noise_dev, void* stream) {
+    if (!e) return DYF_ERR_INVALID_ARGUMENT;
+    if (!e->plan.set) return fail(e, DYF_ERR_STATE, "dyf_set_plan has not been called");
+    if (nb < 1 || nb > e->cfg.max_batch) return fail(e, DYF_ERR_INVALID_ARGUMENT, "batch size outside [1, max_batch]");
+    if (!initial_dev || !out_dev) return fail(e, DYF_ERR_INVALID_ARGUMENT, "initial condition / out must not be null");
+    if ((e->Cs > 0) != (static_dev != nullptr))
+        return fail(e, DYF_ERR_INVALID_ARGUMENT, "static condition must be given iff the networks take one");
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    hipStream_t st = (hipStream_t)stream;
+    const int H = e->cfg.height, W = e->cfg.width;
+    const size_t field = (size_t)nb * e->C * H * W;
+    HIP_TRY(e, hipMemcpyAsync(e->s_init, initial_dev, (size_t)nb * e->wC * H * W * sizeof(float), hipMemcpyDeviceToDevice, st));
+    if (static_dev)
+        HIP_TRY(e, hipMemcpyAsync(e->s_static, static_dev, (size_t)nb * e->Cs * H * W * sizeof(float), hipMemcpyDeviceToDevice, st));
+    const bool graphable = e->cfg.use_graph && masks_dev == nullptr && noise_dev == nullptr;
+    if (!graphable) {
+        dyf_status r = run_plan(e, nb, masks_dev, noise_dev, st);
+        if (r != DYF_OK) return r;
+    } else {
+        GraphEntry& g = e->graphs[nb];
+        if (!g.exec) {
+            HIP_TRY(e, hipStreamBeginCapture(e->cap_stream, hipStreamCaptureModeThreadLocal));
+            dyf_status r = run_plan(e, nb, nullptr, nullptr, e->cap_stream);
+            hipGraph_t graph = nullptr;
+            hipError_t ce = hipStreamEndCapture(e->cap_stream, &graph);
+            if (r != DYF_OK) {
+                if (graph) (void)hipGraphDestroy(graph);
+                e->graphs.erase(nb);
+                return r;
+            }
+            if (ce != hipSuccess) {
+                e->graphs.erase(nb);
+                return fail(e, DYF_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(ce));
+            }
+            g.graph = graph;
+            HIP_TRY(e, hipGraphInstantiate(&g.exec, g.graph, nullptr, nullptr, 0));
+        }
+        HIP_TRY(e, hipGraphLaunch(g.exec, st));
+    }
+    HIP_TRY(e, hipMemcpyAsync(out_dev, e->s_stack, (size_t)e->plan.hdr.n_out_slots * field * sizeof(float),
+                              hipMemcpyDeviceToDevice, st));
+    return DYF_OK;
+}
+
+dyf_status dyf_get_last_x0hat(dyf_engine* e, float* out_dev, int32_t nb, void* stream) {
+    if (!e || !out_dev) return DYF_ERR_INVALID_ARGUMENT;
+    if (!e->plan.set || !e->s_x0hat) return fail(e, DYF_ERR_STATE, "no sampling call has been made yet");
+    if (nb < 1 || nb > e->cfg.max_batch) return fail(e, DYF_ERR_INVALID_ARGUMENT, "batch size outside [1, max_batch]");
+    HIP_TRY(e, hipMemcpyAsync(out_dev, e->s_x0hat, (size_t)nb * e->C * e->cfg.height * e->cfg.width * sizeof(float),
+                              hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return DYF_OK;
+}
+
+dyf_status dyf_time_conv_layer(dyf_engine* e, int32_t which, int32_t layer, int32_t nb, int32_t iters, void* stream,
+                               double* avg_ms, double* flops, double* algo_bytes) {
+    if (!e || which < 0 || which > 1 || layer < 0 || layer > 11 || iters < 1 || !avg_ms)
+        return fail(e, DYF_ERR_INVALID_ARGUMENT, "bad argument to dyf_time_conv_layer");
+    Net& n = e->net[which];
+    if (!n.loaded) return fail(e, DYF_ERR_STATE, "weights not loaded");
+    if (nb < 1 || nb > e->cfg.max_batch) return fail(e, DYF_ERR_INVALID_ARGUMENT, "batch size outside [1, max_batch]");
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    hipStream_t st = (hipStream_t)stream;
+    const UBlock& b = n.blk[layer];
+    ConvArgs a = block_conv_args(e, n, b, nb);
+    // same operands as in net_forward: whatever the last forward left in the workspace (realistic activations)
+    a.src0 = b.transposed ? e->ws.up : (layer == 0 ? e->ws.stem : e->ws.enc[layer - 1]);
+    a.c0 = b.cin;
+    const float* A = n.tables ? n.tables : e->ws.coef_a;                    // row 0 of the plan's tables, or the
+    const float* Cc = n.tables ? n.tables + n.total_c : e->ws.coef_c;       // coefficients of the last forward
+    a.coef_a = b.gn ? b.static_a : A + b.film_off;
+    a.coef_c = b.gn ? b.static_c : Cc + b.film_off;
+    a.coef_stride = 0;
+    a.drop = DropSpec{};
+    if (b.gn) { a.out_f32 = e->ws.enc5_raw; a.act = ACT_NONE; } else { a.out_bf16 = b.transposed ? e->ws.dec[layer - 6] : e->ws.enc[layer]; }
+    hipEvent_t ev0, ev1;
+    HIP_TRY(e, hipEventCreate(&ev0));
+    HIP_TRY(e, hipEventCreate(&ev1));
+    for (int i = 0; i < 2; ++i) {
+        dyf_status s = run_conv(e, a, st);
+        if (s != DYF_OK) return s;
+    }
+    HIP_TRY(e, hipEventRecord(ev0, st));
+    for (int i = 0; i < iters; ++i) {
+        dyf_status s = run_conv(e, a, st);
+        if (s != DYF_OK) return s;
+    }
+    HIP_TRY(e, hipEventRecord(ev1, st));
+    HIP_TRY(e, hipEventSynchronize(ev1));
+    float ms = 0.0f;
+    HIP_TRY(e, hipEventElapsedTime(&ms, ev0, ev1));
+    (void)hipEventDestroy(ev0);
+    (void)hipEventDestroy(ev1);
+    *avg_ms = (double)ms / iters;
+    const double M = (double)nb * b.out_h * b.out_w;
+    if (flops) *flops = 2.0 * M * b.cout * b.cin * b.k * b.k;
+    // algorithmic HBM bytes: read the input once, write the output once, read the weights once (bf16)
+    if (algo_bytes)
+        *algo_bytes = 2.0 * ((double)nb * b.in_h * b.in_w * b.cin + M * b.cout + (double)b.cout * b.cin * b.k * b.k);
+    return DYF_OK;
+}
+
+dyf_status dyf_op_conv2d(dyf_engine* e, const uint16_t* x_dev, const float* w_host, int32_t n, int32_t h, int32_t w,
+                         int32_t cin, int32_t cout, int32_t kh, int32_t kw, int32_t stride, int32_t pad,
+                         const float* scale_dev, const float* shift_dev, int32_t act, int32_t path, uint16_t* y_dev,
+                         void* stream) {
+    if (!e || !x_dev || !w_host || !y_dev) return fail(e, DYF_ERR_INVALID_ARGUMENT, "null argument");
+    if (n < 1 || h < 1 || w < 1 || cin < 1 || cout < 1 || kh < 1 || kw < 1 || stride < 1 || pad < 0)
+        return fail(e, DYF_ERR_INVALID_ARGUMENT, "bad conv geometry");
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    hipStream_t st = (hipStream_t)stream;
+    const int taps = kh * kw;
+    std::vector<bf16_t> pk((size_t)cout * taps * cin);
+    for (int co = 0; co < cout; ++co)
+        for (int ci = 0; ci < cin; ++ci)
+            for (int t = 0; t < taps; ++t)
+                pk[((size_t)co * taps + t) * cin + ci] = f32_to_bf16(w_host[((size_t)co * cin + ci) * taps + t]);
+    bf16_t* wdev = nullptr;
+    float *ones = nullptr, *zeros = nullptr;
+    HIP_TRY(e, hipMalloc((void**)&wdev, pk.size() * sizeof(bf16_t)));
+    HIP_TRY(e, hipMemcpy(wdev, pk.data(), pk.size() * sizeof(bf16_t), hipMemcpyHostToDevice));
+    ConvArgs a{};
+    a.src0 = x_dev; a.c0 = cin; a.n = n; a.h = h; a.w = w;
+    a.ho = (h + 2 * pad - kh) / stride + 1; a.wo = (w + 2 * pad - kw) / stride + 1;
+    a.kh = kh; a.kw = kw; a.stride = stride; a.pad = pad; a.cout = cout; a.wpk = wdev;
+    a.act = act; a.out_bf16 = y_dev; a.zero_page = e->ws.zero_page;
+    if (scale_dev && shift_dev) {
+        a.coef_a = scale_dev; a.coef_c = shift_dev; a.coef_stride = cout;
+    } else {
+        std::vector<float> o1(cout, 1.0f), z0(cout, 0.0f);
+        HIP_TRY(e, hipMalloc((void**)&ones, cout * sizeof(float)));
+        HIP_TRY(e, hipMalloc((void**)&zeros, cout * sizeof(float)));
+        HIP_TRY(e, hipMemcpy(ones, o1.data(), cout * sizeof(float), hipMemcpyHostToDevice));
+        HIP_TRY(e, hipMemcpy(zeros, z0.data(), cout * sizeof(float), hipMemcpyHostToDevice));
+        a.coef_a = ones; a.coef_c = zeros; a.coef_stride = 0;
+    }
+    dyf_status rs = DYF_OK;
+    if (path == 1 && !conv_mfma_supported(a)) {
+        rs = fail(e, DYF_ERR_UNSUPPORTED, "MFMA path needs cin % 64 == 0 and cout % 64 == 0");
+    } else {
+        hipError_t le = launch_conv(a, path, st);
+        if (le == hipSuccess) le = hipStreamSynchronize(st);
+        if (le != hipSuccess) rs = fail(e, DYF_ERR_HIP, std::string("conv launch: ") + hipGetErrorString(le));
+    }
+    (void)hipFree(wdev);
+    if (ones) (void)hipFree(ones);
+    if (zeros) (void)hipFree(zeros);
+    return rs;
+}
+
+}  // extern "C"

@@ -1,0 +1,97 @@
+// HBM-bound kernels around the convolutions: launch prototypes.
+#pragma once
+#include "common.h"
+
+#define DYF_MAX_IN_CH 32   // max channels entering the network stem (inputs + condition)
+#define DYF_MAX_OUT_CH 8   // max output channels of the readout
+
+// K9: sinusoidal features -> Linear -> GELU -> Linear -> SiLU  (misc.py:20-32,54-67; SiLU of every block's time_mlp)
+struct TimeMlpArgs {
+    const float* time;      // [rows]
+    int rows, dim;          // dim = sinusoid width, time_dim = 2*dim
+    const float* w1;        // [2dim][dim]
+    const float* b1;
+    const float* w2;        // [2dim][2dim]
+    const float* b2;
+    float* silu_out;        // [rows][2dim]
+};
+hipError_t launch_time_mlp(const TimeMlpArgs& a, hipStream_t s);
+
+// K9: per-block FiLM heads fused with the folded norm:  A = a_n*(1+scale), C = c_n*(1+scale)+shift  (all blocks of
+// one network in one launch).  With no time embedding scale = shift = 0.
+struct FilmArgs {
+    const float* silu;      // [rows][tdim] or null
+    int rows, tdim, total_c;
+    const float* wf;        // [2*total_c][tdim]: per block, scale rows then shift rows (reference Linear layout)
+    const float* bf;        // [2*total_c]
+    const int* blk_of;      // [total_c] block index of each flattened channel
+    const int* blk_off;     // [nblocks] flattened channel offset of each block
+    const int* blk_cout;    // [nblocks]
+    const float* norm_a;    // [total_c] folded norm scale (1 for the GroupNorm block)
+    const float* norm_c;    // [total_c] folded norm shift (0 for the GroupNorm block)
+    float* coef_a;          // [rows][total_c]
+    float* coef_c;
+};
+hipError_t launch_film(const FilmArgs& a, hipStream_t s);
+
+// K4+K1: outer bilinear resample of the channel-concatenated NCHW fp32 inputs fused with the 1x1 stem conv
+// (unet_simple.py:185-195 upsampler + :166 init_conv) -> NHWC bf16.
+struct StemArgs {
+    const float* src[4];    // up to 4 NCHW fp32 tensors, concatenated on channels
+    int ch[4];
+    int nsrc, cin;          // cin = sum(ch)
+    int n, h, w;            // native grid
+    int uh, uw;             // resampled grid (== h, w when there is no outer resampling)
+    int resample;           // 0: identity, 1: bilinear (align_corners=False)
+    const float* wgt;       // [dim][cin] fp32
+    const float* bias;      // [dim]
+    int dim;
+    bf16_t* out;            // [n][uh][uw][dim]
+};
+hipError_t launch_stem(const StemArgs& a, hipStream_t s);
+
+// K2 (materialised form): bilinear x2 upsample of cat[src0, src1] (NHWC bf16) -> NHWC bf16
+struct Up2xArgs {
+    const bf16_t* src0;
+    const bf16_t* src1;
+    int c0, c1;
+    int n, h, w;            // low-res dims
+    bf16_t* out;            // [n][2h][2w][c0+c1]
+};
+hipError_t launch_up2x(const Up2xArgs& a, hipStream_t s);
+
+// K5: GroupNorm(G) + FiLM + LeakyReLU + Dropout on an fp32 NHWC tensor -> NHWC bf16 (unet_simple.py:56 + :72-80)
+struct GroupNormArgs {
+    const float* x;         // [n][hw][c]
+    int n, hw, c, groups;
+    const float* gamma;
+    const float* beta;
+    const float* film_a;    // [rows][...] (1+scale) at film_off + ch ; stride film_stride (0 = broadcast)
+    const float* film_c;
+    int film_stride;
+    int act;
+    DropSpec drop;
+    bf16_t* out;
+};
+hipError_t launch_groupnorm(const GroupNormArgs& a, hipStream_t s);
+
+// K3+K4: ConvTranspose2d(k4,s2,p1) readout evaluated only where the final bilinear resample needs it
+// (unet_simple.py:141-151 + :195) -> NCHW fp32
+struct ReadoutArgs {
+    const bf16_t* x;        // [n][ih][iw][cin] decoder output
+    int n, ih, iw, cin;
+    const float* wgt;       // [kh][kw][cin][cout] fp32 (repacked ConvTranspose weight)
+    const float* bias;      // [cout]
+    int cout;
+    int oh, ow;             // native grid
+    float* out;             // [n][cout][oh][ow]
+};
+hipError_t launch_readout(const ReadoutArgs& a, hipStream_t s);
+
+// K10: sampler elementwise (dyffusion.py:381-391, :219-227)
+hipError_t launch_cold_update(float* x_s, const float* x_cur, const float* x_next, long long count, hipStream_t s);
+// out = tau*cond + (1-tau)*noise ; noise from `noise` if non-null else Box-Muller on the counter RNG
+hipError_t launch_noisy_condition(float* out, const float* cond, const float* noise, float tau, long long count,
+                                  const uint32_t* rng_state, uint32_t stream_id, hipStream_t s);
+hipError_t launch_bump_counter(uint32_t* rng_state, hipStream_t s);
+hipError_t launch_fill_f32(float* p, float v, long long count, hipStream_t s);

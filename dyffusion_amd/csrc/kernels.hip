@@ -1,0 +1,393 @@
+// HBM-bound kernels of the DYffusion engine (gfx950): stem, x2 bilinear upsample, GroupNorm, readout, time/FiLM heads,
+// sampler elementwise.  Every kernel replaces an unfused ATen sequence of the reference (cited per kernel).
+#include "kernels.h"
+
+// ------------------------------------------------------------------------------------------------ block reduce
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+__device__ __forceinline__ float block_sum(float v, float* scratch /* >= 16 floats */) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if (lane == 0) scratch[wave] = v;
+    __syncthreads();
+    float t = 0.0f;
+    for (int i = 0; i < nw; ++i) t += scratch[i];
+    return t;
+}
+
+// ------------------------------------------------------------------------------------------------ K9 time MLP
+// misc.py:20-32 (SinusoidalPosEmb), :63-66 (Linear -> GELU(erf) -> Linear); the trailing SiLU is the first op of
+// every UNetBlock.time_mlp (unet_simple.py:21-23) and is shared by all blocks.
+__global__ void time_mlp_kernel(TimeMlpArgs a) {
+    extern __shared__ float sh[];  // e[dim] | h[tdim]
+    const int row = blockIdx.x, dim = a.dim, tdim = 2 * a.dim, half = a.dim / 2;
+    float* e = sh;
+    float* h = sh + dim;
+    const float t = a.time[row];
+    const float step = -logf(10000.0f) / (float)(half - 1);
+    for (int i = threadIdx.x; i < dim; i += blockDim.x) {
+        const int j = i < half ? i : i - half;
+        const float ang = t * expf((float)j * step);
+        e[i] = i < half ? sinf(ang) : cosf(ang);
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < tdim; j += blockDim.x) {
+        float acc = a.b1[j];
+        const float* w = a.w1 + (size_t)j * dim;
+        for (int i = 0; i < dim; ++i) acc = fmaf(w[i], e[i], acc);
+        h[j] = 0.5f * acc * (1.0f + erff(acc * 0.70710678118654752f));
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < tdim; j += blockDim.x) {
+        float acc = a.b2[j];
+        const float* w = a.w2 + (size_t)j * tdim;
+        for (int i = 0; i < tdim; ++i) acc = fmaf(w[i], h[i], acc);
+        a.silu_out[(size_t)row * tdim + j] = acc / (1.0f + expf(-acc));
+    }
+}
+
+hipError_t launch_time_mlp(const TimeMlpArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(time_mlp_kernel, dim3(a.rows), dim3(128), (size_t)(3 * a.dim) * sizeof(float), s, a);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ K9 FiLM heads
+// unet_simple.py:72-78: time_mlp Linear -> chunk(scale, shift) -> x*(scale+1)+shift, folded with the block's
+// eval-mode BatchNorm (and conv bias): y = conv*A + C.
+__global__ void film_kernel(FilmArgs a) {
+    const int fc = blockIdx.x * blockDim.x + threadIdx.x;
+    const int row = blockIdx.y;
+    if (fc >= a.total_c) return;
+    float scale = 0.0f, shift = 0.0f;
+    if (a.silu != nullptr) {
+        const int b = a.blk_of[fc];
+        const int cl = fc - a.blk_off[b];
+        const int r_scale = 2 * a.blk_off[b] + cl;
+        const int r_shift = r_scale + a.blk_cout[b];
+        const float* sv = a.silu + (size_t)row * a.tdim;
+        const float* ws = a.wf + (size_t)r_scale * a.tdim;
+        const float* wh = a.wf + (size_t)r_shift * a.tdim;
+        scale = a.bf[r_scale];
+        shift = a.bf[r_shift];
+        for (int i = 0; i < a.tdim; ++i) {
+            scale = fmaf(ws[i], sv[i], scale);
+            shift = fmaf(wh[i], sv[i], shift);
+        }
+    }
+    const float na = a.norm_a[fc], nc = a.norm_c[fc];
+    a.coef_a[(size_t)row * a.total_c + fc] = na * (1.0f + scale);
+    a.coef_c[(size_t)row * a.total_c + fc] = fmaf(nc, 1.0f + scale, shift);
+}
+
+hipError_t launch_film(const FilmArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(film_kernel, dim3((a.total_c + 127) / 128, a.rows), dim3(128), 0, s, a);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ K4+K1 stem
+// unet_simple.py:184-195: cat[inputs, condition] -> Upsample(size, bilinear) -> init_conv 1x1.  One thread per
+// resampled pixel; the sampled channel vector is parked in LDS so the 1x1 can index it dynamically.
+__global__ __launch_bounds__(256) void stem_kernel(StemArgs a) {
+    extern __shared__ float vals[];  // [cin][256]
+    const long long pix = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long total = (long long)a.n * a.uh * a.uw;
+    const bool live = pix < total;
+    const int tid = threadIdx.x;
+    if (live) {
+        const int n = (int)(pix / ((long long)a.uh * a.uw));
+        const int rem = (int)(pix % ((long long)a.uh * a.uw));
+        const int y = rem / a.uw, x = rem % a.uw;
+        int y0 = y, y1 = y, x0 = x, x1 = x;
+        float ly = 0.0f, lx = 0.0f;
+        if (a.resample) {
+            bilinear_coord(y, (float)a.h / (float)a.uh, a.h, y0, y1, ly);
+            bilinear_coord(x, (float)a.w / (float)a.uw, a.w, x0, x1, lx);
+        }
+        int cbase = 0;
+        for (int s = 0; s < a.nsrc; ++s) {
+            const float* src = a.src[s] + (size_t)n * a.ch[s] * a.h * a.w;
+            for (int c = 0; c < a.ch[s]; ++c) {
+                const float* p = src + (size_t)c * a.h * a.w;
+                const float v00 = p[y0 * a.w + x0], v01 = p[y0 * a.w + x1];
+                const float v10 = p[y1 * a.w + x0], v11 = p[y1 * a.w + x1];
+                // same association as ATen's CPU kernel: rows first, then columns
+                const float top = v00 * (1.0f - lx) + v01 * lx;
+                const float bot = v10 * (1.0f - lx) + v11 * lx;
+                vals[(cbase + c) * 256 + tid] = top * (1.0f - ly) + bot * ly;
+            }
+            cbase += a.ch[s];
+        }
+    }
+    __syncthreads();
+    if (!live) return;
+    bf16_t* out = a.out + (size_t)pix * a.dim;
+    for (int d0 = 0; d0 < a.dim; d0 += 8) {
+        float acc[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) acc[t] = (d0 + t < a.dim) ? a.bias[d0 + t] : 0.0f;
+        for (int c = 0; c < a.cin; ++c) {
+            const float v = vals[c * 256 + tid];
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+                if (d0 + t < a.dim) acc[t] = fmaf(a.wgt[(size_t)(d0 + t) * a.cin + c], v, acc[t]);
+        }
+        if ((a.dim & 7) == 0) {
+            uint4 o;
+            o.x = pack_bf16x2(acc[0], acc[1]);
+            o.y = pack_bf16x2(acc[2], acc[3]);
+            o.z = pack_bf16x2(acc[4], acc[5]);
+            o.w = pack_bf16x2(acc[6], acc[7]);
+            *(uint4*)(out + d0) = o;
+        } else {
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+                if (d0 + t < a.dim) out[d0 + t] = f32_to_bf16(acc[t]);
+        }
+    }
+}
+
+hipError_t launch_stem(const StemArgs& a, hipStream_t s) {
+    const long long total = (long long)a.n * a.uh * a.uw;
+    hipLaunchKernelGGL(stem_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), (size_t)a.cin * 256 * sizeof(float),
+                       s, a);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ K2 x2 upsample
+// unet_simple.py:42 nn.Upsample(scale_factor=2, bilinear) applied to cat[x, skip] (:176-177).
+template <int VEC>
+__global__ __launch_bounds__(256) void up2x_kernel(Up2xArgs a, long long total) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int c = a.c0 + a.c1;
+    const int groups = c / VEC;
+    const int g = (int)(idx % groups);
+    const long long pix = idx / groups;
+    const int ow = 2 * a.w, oh = 2 * a.h;
+    const int n = (int)(pix / ((long long)oh * ow));
+    const int rem = (int)(pix % ((long long)oh * ow));
+    const int y = rem / ow, x = rem % ow;
+    int y0, y1, x0, x1;
+    float ly, lx;
+    bilinear_coord(y, 0.5f, a.h, y0, y1, ly);
+    bilinear_coord(x, 0.5f, a.w, x0, x1, lx);
+    int ch = g * VEC;
+    const bf16_t* src = a.src0;
+    int cs = a.c0;
+    if (ch >= a.c0) {
+        src = a.src1;
+        cs = a.c1;
+        ch -= a.c0;
+    }
+    const size_t base = (size_t)n * a.h * a.w;
+    const bf16_t* p00 = src + ((base + (size_t)y0 * a.w + x0) * cs + ch);
+    const bf16_t* p01 = src + ((base + (size_t)y0 * a.w + x1) * cs + ch);
+    const bf16_t* p10 = src + ((base + (size_t)y1 * a.w + x0) * cs + ch);
+    const bf16_t* p11 = src + ((base + (size_t)y1 * a.w + x1) * cs + ch);
+    bf16_t* o = a.out + ((size_t)pix * c + g * VEC);
+    if (VEC == 8) {
+        const uint4 q00 = *(const uint4*)p00, q01 = *(const uint4*)p01, q10 = *(const uint4*)p10, q11 = *(const uint4*)p11;
+        const uint32_t* w00 = (const uint32_t*)&q00;
+        const uint32_t* w01 = (const uint32_t*)&q01;
+        const uint32_t* w10 = (const uint32_t*)&q10;
+        const uint32_t* w11 = (const uint32_t*)&q11;
+        uint32_t r[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            float lo, hi;
+            {
+                const float a00 = __uint_as_float(w00[t] << 16), a01 = __uint_as_float(w01[t] << 16);
+                const float a10 = __uint_as_float(w10[t] << 16), a11 = __uint_as_float(w11[t] << 16);
+                const float top = a00 * (1.0f - lx) + a01 * lx, bot = a10 * (1.0f - lx) + a11 * lx;
+                lo = top * (1.0f - ly) + bot * ly;
+            }
+            {
+                const float a00 = __uint_as_float(w00[t] & 0xffff0000u), a01 = __uint_as_float(w01[t] & 0xffff0000u);
+                const float a10 = __uint_as_float(w10[t] & 0xffff0000u), a11 = __uint_as_float(w11[t] & 0xffff0000u);
+                const float top = a00 * (1.0f - lx) + a01 * lx, bot = a10 * (1.0f - lx) + a11 * lx;
+                hi = top * (1.0f - ly) + bot * ly;
+            }
+            r[t] = pack_bf16x2(lo, hi);
+        }
+        *(uint4*)o = make_uint4(r[0], r[1], r[2], r[3]);
+    } else {
+        const float a00 = bf16_to_f32(*p00), a01 = bf16_to_f32(*p01), a10 = bf16_to_f32(*p10), a11 = bf16_to_f32(*p11);
+        const float top = a00 * (1.0f - lx) + a01 * lx, bot = a10 * (1.0f - lx) + a11 * lx;
+        *o = f32_to_bf16(top * (1.0f - ly) + bot * ly);
+    }
+}
+
+hipError_t launch_up2x(const Up2xArgs& a, hipStream_t s) {
+    const int c = a.c0 + a.c1;
+    const bool vec = (a.c0 % 8 == 0) && (a.c1 % 8 == 0);
+    const long long total = (long long)a.n * 4 * a.h * a.w * (vec ? c / 8 : c);
+    const unsigned blocks = (unsigned)((total + 255) / 256);
+    if (vec)
+        hipLaunchKernelGGL(up2x_kernel<8>, dim3(blocks), dim3(256), 0, s, a, total);
+    else
+        hipLaunchKernelGGL(up2x_kernel<1>, dim3(blocks), dim3(256), 0, s, a, total);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ K5 GroupNorm
+// nn.GroupNorm(8, C) of the last encoder block (unet_simple.py:56) + FiLM + LeakyReLU + Dropout (:72-80).
+__global__ __launch_bounds__(256) void groupnorm_kernel(GroupNormArgs a) {
+    __shared__ float scratch[16];
+    const int n = blockIdx.x / a.groups, g = blockIdx.x % a.groups;
+    const int cpg = a.c / a.groups;
+    const int count = a.hw * cpg;
+    const float* x = a.x + (size_t)n * a.hw * a.c + g * cpg;
+    float s = 0.0f;
+    for (int i = threadIdx.x; i < count; i += blockDim.x) s += x[(size_t)(i / cpg) * a.c + (i % cpg)];
+    const float mean = block_sum(s, scratch) / (float)count;
+    float v = 0.0f;
+    for (int i = threadIdx.x; i < count; i += blockDim.x) {
+        const float d = x[(size_t)(i / cpg) * a.c + (i % cpg)] - mean;
+        v = fmaf(d, d, v);
+    }
+    const float var = block_sum(v, scratch) / (float)count;  // biased, as torch
+    const float rstd = rsqrtf(var + 1e-5f);
+    const uint32_t key = drop_key(a.drop);
+    for (int i = threadIdx.x; i < count; i += blockDim.x) {
+        const int p = i / cpg, ch = g * cpg + (i % cpg);
+        float y = (x[(size_t)p * a.c + (i % cpg)] - mean) * rstd * a.gamma[ch] + a.beta[ch];
+        const size_t fi = (size_t)n * a.film_stride + ch;
+        y = fmaf(y, a.film_a[fi], a.film_c[fi]);
+        y = apply_act(y, a.act);
+        const size_t e = ((size_t)n * a.hw + p) * a.c + ch;
+        y = drop_apply(y, (uint32_t)e, a.drop, key);
+        a.out[e] = f32_to_bf16(y);
+    }
+}
+
+hipError_t launch_groupnorm(const GroupNormArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(groupnorm_kernel, dim3(a.n * a.groups), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ K3+K4 readout
+// ConvTranspose2d(dim -> C, k4, s2, p1) followed by the final bilinear resample to the native grid
+// (unet_simple.py:141-151, :195).  The resample (no antialias) reads only 4 neighbours of each native pixel, so the
+// transposed conv is evaluated at exactly those positions instead of materialising the 2x-resolution tensor.
+// out[u] of a k4/s2/p1 transposed conv gathers input rows i with kh = u + 1 - 2i in [0, 3]: i = (u+1)>>1 and i - 1.
+__global__ __launch_bounds__(256) void readout_kernel(ReadoutArgs a) {
+    extern __shared__ float wsh[];  // [16][cin][cout]
+    const int wcount = 16 * a.cin * a.cout;
+    for (int i = threadIdx.x; i < wcount; i += blockDim.x) wsh[i] = a.wgt[i];
+    __syncthreads();
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long total = (long long)a.n * a.oh * a.ow;
+    if (idx >= total) return;
+    const int n = (int)(idx / ((long long)a.oh * a.ow));
+    const int rem = (int)(idx % ((long long)a.oh * a.ow));
+    const int oy = rem / a.ow, ox = rem % a.ow;
+    const int th = 2 * a.ih, tw = 2 * a.iw;  // transposed-conv output grid
+    int u0, u1, v0, v1;
+    float lu, lv;
+    bilinear_coord(oy, (float)th / (float)a.oh, th, u0, u1, lu);
+    bilinear_coord(ox, (float)tw / (float)a.ow, tw, v0, v1, lv);
+    float acc[DYF_MAX_OUT_CH];
+#pragma unroll
+    for (int c = 0; c < DYF_MAX_OUT_CH; ++c) acc[c] = 0.0f;
+    const int us[2] = {u0, u1}, vs[2] = {v0, v1};
+    const float wu[2] = {1.0f - lu, lu}, wv[2] = {1.0f - lv, lv};
+#pragma unroll
+    for (int a_ = 0; a_ < 2; ++a_) {
+#pragma unroll
+        for (int b_ = 0; b_ < 2; ++b_) {
+            const float bw = wu[a_] * wv[b_];
+            const int u = us[a_], v = vs[b_];
+            const int i_hi = (u + 1) >> 1, j_hi = (v + 1) >> 1;
+#pragma unroll
+            for (int di = 0; di < 2; ++di) {
+                const int i = i_hi - di, kh = u + 1 - 2 * i;
+                if ((unsigned)i >= (unsigned)a.ih) continue;
+#pragma unroll
+                for (int dj = 0; dj < 2; ++dj) {
+                    const int j = j_hi - dj, kw = v + 1 - 2 * j;
+                    if ((unsigned)j >= (unsigned)a.iw) continue;
+                    const bf16_t* px = a.x + (((size_t)n * a.ih + i) * a.iw + j) * a.cin;
+                    const float* wt = wsh + (size_t)(kh * 4 + kw) * a.cin * a.cout;
+                    for (int ci = 0; ci < a.cin; ++ci) {
+                        const float xv = bw * bf16_to_f32(px[ci]);
+#pragma unroll
+                        for (int co = 0; co < DYF_MAX_OUT_CH; ++co)
+                            if (co < a.cout) acc[co] = fmaf(xv, wt[ci * a.cout + co], acc[co]);
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int co = 0; co < DYF_MAX_OUT_CH; ++co)
+        if (co < a.cout) a.out[(((size_t)n * a.cout + co) * a.oh + oy) * a.ow + ox] = acc[co] + a.bias[co];
+}
+
+hipError_t launch_readout(const ReadoutArgs& a, hipStream_t s) {
+    const long long total = (long long)a.n * a.oh * a.ow;
+    hipLaunchKernelGGL(readout_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256),
+                       (size_t)16 * a.cin * a.cout * sizeof(float), s, a);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ K10 sampler
+// dyffusion.py:388  x_s = x_s - I(s) + I(s_next), kept in fp32 (SURVEY hard-part (f))
+__global__ void cold_update_kernel(float* x_s, const float* x_cur, const float* x_next, long long count) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) x_s[i] = x_s[i] - x_cur[i] + x_next[i];
+}
+
+hipError_t launch_cold_update(float* x_s, const float* x_cur, const float* x_next, long long count, hipStream_t s) {
+    hipLaunchKernelGGL(cold_update_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, x_s, x_cur, x_next,
+                       count);
+    return hipGetLastError();
+}
+
+// dyffusion.py:219-227  forward_cond = tfactor*condition + (1-tfactor)*randn_like(condition)
+__global__ void noisy_condition_kernel(float* out, const float* cond, const float* noise, float tau, long long count,
+                                       const uint32_t* rng_state, uint32_t stream_id) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    float z;
+    if (noise != nullptr) {
+        z = noise[i];
+    } else {
+        const uint32_t key = rng_layer_key(rng_state[0], rng_state[1], rng_state[2], 48u + stream_id);
+        const uint32_t w0 = fmix32((uint32_t)i * 0x9E3779B1u + key), w1 = fmix32(w0 ^ 0x68E31DA4u);
+        const float u1 = ((float)(w0 >> 8) + 0.5f) * (1.0f / 16777216.0f);
+        const float u2 = ((float)(w1 >> 8) + 0.5f) * (1.0f / 16777216.0f);
+        z = sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);
+    }
+    out[i] = tau * cond[i] + (1.0f - tau) * z;
+}
+
+hipError_t launch_noisy_condition(float* out, const float* cond, const float* noise, float tau, long long count,
+                                  const uint32_t* rng_state, uint32_t stream_id, hipStream_t s) {
+    hipLaunchKernelGGL(noisy_condition_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, out, cond, noise,
+                       tau, count, rng_state, stream_id);
+    return hipGetLastError();
+}
+
+__global__ void bump_counter_kernel(uint32_t* state) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) state[2] += 1u;
+}
+
+hipError_t launch_bump_counter(uint32_t* rng_state, hipStream_t s) {
+    hipLaunchKernelGGL(bump_counter_kernel, dim3(1), dim3(64), 0, s, rng_state);
+    return hipGetLastError();
+}
+
+__global__ void fill_f32_kernel(float* p, float v, long long count) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) p[i] = v;
+}
+
+hipError_t launch_fill_f32(float* p, float v, long long count, hipStream_t s) {
+    hipLaunchKernelGGL(fill_f32_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, p, v, count);
+    return hipGetLastError();
+}

@@ -1,0 +1,297 @@
+"""Host-side mirror of `src/diffusion/dyffusion.py` (BaseDYffusion :17-431, DYffusion :439-494) on the HIP engine.
+
+`DYffusion.sample()` keeps the reference's signature and return value (dict `t{i}_preds`), but the loop itself
+(forecaster / interpolator forwards, cold-sampling update, refinement pass) runs inside libdyffusion_hip.so as one
+captured hipGraph.  What stays in Python is the scalar bookkeeping that the reference also does in Python: the
+diffusion-step <-> interpolation-time tables and the sampling-schedule parser; it is resolved once into a plan.
+"""
+import math
+from typing import Dict, List, Optional, Sequence, Union
+
+import numpy as np
+import torch
+from torch import Tensor, nn
+
+from . import _lib as L
+from .engine import HipEngine
+from .unet_simple import UNet, _AttrDict
+
+Step = Union[int, float]
+
+
+class DYffusion(nn.Module):
+    def __init__(self, model: UNet, interpolator, timesteps: int, forward_conditioning: str = "data",
+                 schedule: str = "before_t1_only", additional_interpolation_steps: int = 0,
+                 additional_interpolation_steps_factor: int = 0, interpolate_before_t1: bool = False,
+                 sampling_type: str = "cold", sampling_schedule: Union[List[float], str] = None,
+                 time_encoding: str = "dynamics", refine_intermediate_predictions: bool = False,
+                 prediction_timesteps: Optional[Sequence[float]] = None,
+                 enable_interpolator_dropout: Union[bool, str] = True, use_cold_sampling_for_last_step: bool = False,
+                 log_every_t=None, lambda_reconstruction: float = 1.0, lambda_reconstruction2: float = 0.0,
+                 interpolator_horizon: Optional[int] = None, interpolator_window: int = 1,
+                 enable_forecaster_dropout: bool = False, max_batch: int = 64, use_graph: bool = True,
+                 enable_mfma: bool = True, **kwargs):
+        super().__init__()
+        if model is None:
+            raise ValueError("Arg ``model`` is missing... Please provide a backbone model for the diffusion model (e.g. a Unet)")
+        if forward_conditioning not in ("data", "none", "data+noise"):
+            raise ValueError(f"Invalid forward_conditioning: {forward_conditioning}")
+        if enable_interpolator_dropout not in (True, False):
+            raise ValueError(f"Invalid enable_interpolator_dropout: {enable_interpolator_dropout}")
+        sampling_schedule = None if sampling_schedule == "None" else sampling_schedule
+        self.hparams = _AttrDict(
+            timesteps=timesteps, forward_conditioning=forward_conditioning, schedule=schedule,
+            additional_interpolation_steps=additional_interpolation_steps,
+            additional_interpolation_steps_factor=additional_interpolation_steps_factor,
+            interpolate_before_t1=interpolate_before_t1, sampling_type=sampling_type,
+            sampling_schedule=sampling_schedule, time_encoding=time_encoding,
+            refine_intermediate_predictions=refine_intermediate_predictions, prediction_timesteps=prediction_timesteps,
+            enable_interpolator_dropout=enable_interpolator_dropout,
+            use_cold_sampling_for_last_step=use_cold_sampling_for_last_step, log_every_t=log_every_t,
+            lambda_reconstruction=lambda_reconstruction, lambda_reconstruction2=lambda_reconstruction2)
+        self.model = model
+        # the reference stores an InterpolationExperiment here (dyffusion.py:461-468); accept that duck type or a bare net
+        self.interpolator = interpolator
+        self._ipol_net: UNet = getattr(interpolator, "model", interpolator)
+        self.interpolator_window = getattr(interpolator, "window", interpolator_window)
+        self.interpolator_horizon = getattr(interpolator, "true_horizon", interpolator_horizon)
+        self.num_input_channels = model.num_input_channels
+        self.num_output_channels = model.num_output_channels
+        self.num_conditional_channels = model.num_conditional_channels
+        self.spatial_shape = model.spatial_shape
+        self.enable_interpolator_dropout = enable_interpolator_dropout
+        self.enable_forecaster_dropout = enable_forecaster_dropout
+
+        # ---- diffusion-step bookkeeping (dyffusion.py:40-95)
+        horizon = timesteps
+        assert horizon > 1, f"horizon must be > 1, but got {horizon}. Please use datamodule.horizon with > 1"
+        self.di_to_ti_add = 0
+        self.additional_interpolation_steps_fac = 0
+        if schedule == "linear":
+            assert additional_interpolation_steps == 0, "additional_interpolation_steps must be 0 when using linear schedule"
+            self.additional_interpolation_steps_fac = additional_interpolation_steps_factor
+            between = horizon - 1 if interpolate_before_t1 else horizon - 2
+            self.di_to_ti_add = 0 if interpolate_before_t1 else additional_interpolation_steps_factor
+            self.additional_diffusion_steps = additional_interpolation_steps_factor * between
+        elif schedule == "before_t1_only":
+            assert additional_interpolation_steps_factor == 0, \
+                "additional_interpolation_steps_factor must be 0 when using before_t1_only schedule"
+            assert interpolate_before_t1, "interpolate_before_t1 must be True when using before_t1_only schedule"
+            self.additional_diffusion_steps = additional_interpolation_steps
+        else:
+            raise ValueError(f"Invalid schedule: {schedule}")
+        self.num_timesteps = horizon + self.additional_diffusion_steps
+        d2i = {d: self.diffusion_step_to_interpolation_step(d) for d in range(1, self.num_timesteps)}
+        self.dynamical_steps = {d: i for d, i in d2i.items() if float(i).is_integer()}
+        self.artificial_interpolation_steps = {d: i for d, i in d2i.items() if not float(i).is_integer()}
+        self.i_to_diffusion_step = {i: d for d, i in d2i.items()}
+        last_i = self.diffusion_step_to_interpolation_step(self.num_timesteps - 1)
+        if self.interpolator_horizon is None:
+            self.interpolator_horizon = int(last_i + 1)
+        if self.interpolator_horizon != last_i + 1:  # dyffusion.py:472-478
+            raise ValueError(f"interpolator horizon {self.interpolator_horizon} must be equal to the "
+                             f"last interpolation step+1=i_N=i_{self.num_timesteps - 1}={last_i + 1}")
+        self.full_sampling_schedule = list(range(0, self.num_timesteps))
+        self.sampling_schedule = sampling_schedule or self.full_sampling_schedule
+
+        # ---- engine: forecaster + interpolator in one dyf_engine
+        self._engine_opts = dict(max_batch=max_batch, use_graph=use_graph, enable_mfma=enable_mfma)
+        self._engine: Optional[HipEngine] = None
+        self._plan_key = None
+        self.requires_grad_(False)
+        self.eval()
+
+    # ------------------------------------------------------------------ step tables (dyffusion.py:97-138)
+    @property
+    def diffusion_steps(self) -> List[int]:
+        return list(range(0, self.num_timesteps))
+
+    def diffusion_step_to_interpolation_step(self, diffusion_step):
+        T = self.num_timesteps
+        is_t = torch.is_tensor(diffusion_step)
+        ok = bool(((0 <= diffusion_step) & (diffusion_step <= T - 1)).all()) if is_t else 0 <= diffusion_step <= T - 1
+        assert ok, f"diffusion_step must be in [1, num_timesteps-1]=[1, {T - 1}], but got {diffusion_step}"
+        if self.hparams.schedule == "linear":
+            return (diffusion_step + self.di_to_ti_add) / (self.additional_interpolation_steps_fac + 1)
+        k = self.additional_diffusion_steps
+        if is_t:
+            return torch.where(diffusion_step >= k + 1, (diffusion_step - k).float(), diffusion_step / (k + 1))
+        return diffusion_step - k if diffusion_step >= k + 1 else diffusion_step / (k + 1)
+
+    # ------------------------------------------------------------------ sampling schedule (dyffusion.py:241-333)
+    @property
+    def sampling_schedule(self) -> List[Step]:
+        return self._sampling_schedule
+
+    @sampling_schedule.setter
+    def sampling_schedule(self, schedule):
+        T = self.num_timesteps
+        name = schedule
+        if isinstance(schedule, str):
+            dyn = [0] + list(self.dynamical_steps.keys())
+            art = list(self.artificial_interpolation_steps.keys())
+            if "only_dynamics" in name:
+                extra: List[Step] = []
+                if "only_dynamics_plus" in name:
+                    n_plus = int(name.replace("only_dynamics_plus", "").replace("_discrete", ""))
+                    extra = list(np.linspace(0, dyn[1], n_plus + 1, endpoint=False))
+                    if "_discrete" in name:
+                        extra = [int(np.floor(s)) for s in extra]
+                else:
+                    assert name == "only_dynamics", f"Invalid sampling schedule: {name}"
+            elif name.startswith("every"):
+                nth = int(name.replace("every", "").replace("th", "").replace("nd", "").replace("rd", ""))
+                assert 1 <= nth <= T, f"Invalid sampling schedule: {name}"
+                extra = art[::nth]
+            elif name.startswith("first"):
+                first = float(name.replace("first", "").replace("v2", ""))
+                if first < 1:
+                    assert 0 < first < 1, f"Invalid sampling schedule: {name}, must end with number/float > 0"
+                    extra = art[: int(np.ceil(first * len(art)))]
+                else:
+                    assert first.is_integer(), f"If first_n >= 1, it must be an integer, but got {first}"
+                    assert 1 <= first <= T, f"Invalid sampling schedule: {name}"
+                    extra = art[: int(first)]
+            else:
+                raise ValueError(f"Invalid sampling schedule: ``{name}``. ")
+            schedule = sorted(set(list(extra) + dyn))
+        schedule = list(schedule)
+        assert 1 <= schedule[-1] <= T, f"Invalid sampling schedule: {schedule}, must end with number/float <= {T}"
+        if schedule[0] != 0:
+            schedule = [0] + schedule
+        for prev, nxt in zip(schedule[:-1], schedule[1:]):
+            assert nxt > prev, f"Invalid sampling schedule not monotonically increasing: {schedule}"
+        if all(float(s).is_integer() for s in schedule):
+            schedule = [int(s) for s in schedule]
+        self._sampling_schedule = schedule
+        self._plan_key = None
+
+    # ------------------------------------------------------------------ plan (host resolution of dyffusion.py:352-422)
+    def _build_plan(self):
+        T, hp = self.num_timesteps, self.hparams
+        sched = self.sampling_schedule
+        steps, out_step = [], 0
+        for j, s in enumerate(sched):
+            s_next = sched[j + 1] if j + 1 < len(sched) else sched[-1] + 1
+            last = s == T - 1
+            if hp.time_encoding == "discrete":
+                ftime = float(s)
+            elif hp.time_encoding == "normalized":
+                ftime = s / T
+            elif hp.time_encoding == "dynamics":
+                ftime = float(self.diffusion_step_to_interpolation_step(s))
+            else:
+                raise ValueError(f"Invalid time_encoding: {hp.time_encoding}")
+            i_next_raw = math.inf if last else self.diffusion_step_to_interpolation_step(s_next)
+            emits = last or float(i_next_raw).is_integer()
+            out_step = int(i_next_raw) if s < T - 1 else out_step + 1
+            i_next = float(self.diffusion_step_to_interpolation_step(s_next)) if s_next <= T - 1 else None
+            i_cur = float(self.diffusion_step_to_interpolation_step(s)) if s > 0 else None
+            for t in (i_next, i_cur):
+                assert t is None or 0 < t < self.interpolator_horizon, \
+                    f"interpolate time must be in (0, {self.interpolator_horizon}), got {t}"
+            steps.append(dict(forecaster_time=ftime, tau=float(s) / (T - 1), i_next=i_next, i_cur=i_cur,
+                              is_last=last, out_slot=(out_step - 1) if emits else None))
+        refine = []
+        if hp.refine_intermediate_predictions:
+            times = hp.prediction_timesteps or list(self.dynamical_steps.values())
+            emitted = {st["out_slot"] for st in steps if st["out_slot"] is not None}
+            for i_n in [t for t in times if t < T]:
+                if not float(i_n).is_integer():
+                    raise NotImplementedError("non-integer prediction_timesteps are not supported by the HIP engine")
+                assert int(i_n) - 1 in emitted, f"t{int(i_n)}_preds not in intermediates"
+                refine.append((float(i_n), int(i_n) - 1))
+        slots = [st["out_slot"] for st in steps if st["out_slot"] is not None]
+        if any(sl < 0 for sl in slots):
+            raise NotImplementedError("sampling schedules that emit a t0 prediction are not supported")
+        return steps, refine, max(slots) + 1
+
+    def _ensure_engine(self, hw, nb: int) -> HipEngine:
+        if self._engine is None or (self._engine.height, self._engine.width) != tuple(hw) or self._engine.max_batch < nb:
+            opts = dict(self._engine_opts)
+            opts["max_batch"] = max(opts["max_batch"], nb)
+            self._engine = HipEngine(self.model.engine_net_config(), self._ipol_net.engine_net_config(), hw[0], hw[1], **opts)
+            self.model.attach_engine(self._engine, L.NET_FORECASTER)
+            self._ipol_net.attach_engine(self._engine, L.NET_INTERPOLATOR)
+            self._plan_key = None
+        return self._engine
+
+    def _ensure_plan(self, eng: HipEngine):
+        hp = self.hparams
+        key = (tuple(self.sampling_schedule), hp.sampling_type, hp.use_cold_sampling_for_last_step,
+               hp.forward_conditioning, hp.refine_intermediate_predictions, hp.time_encoding,
+               bool(self.enable_interpolator_dropout), bool(self.enable_forecaster_dropout), id(eng))
+        if key == self._plan_key:
+            return
+        if hp.sampling_type not in ("cold", "naive"):
+            raise ValueError(f"unknown sampling type {hp.sampling_type}")
+        steps, refine, n_slots = self._build_plan()
+        eng.set_plan(steps, sampling_cold=hp.sampling_type == "cold",
+                     cold_for_last_step=hp.use_cold_sampling_for_last_step,
+                     forward_conditioning=hp.forward_conditioning, refine=refine, n_out_slots=n_slots,
+                     interpolator_dropout=bool(self.enable_interpolator_dropout or self.training),
+                     forecaster_dropout=bool(self.enable_forecaster_dropout))
+        self._plan_key = key
+        self._emitted_slots = sorted({st["out_slot"] for st in steps if st["out_slot"] is not None})
+
+    # ------------------------------------------------------------------ reference API
+    def sample_loop(self, initial_condition: Tensor, static_condition: Optional[Tensor] = None, log_every_t=None,
+                    num_predictions: int = None, _masks=None, _noise=None):
+        assert len(initial_condition.shape) == 4, f"condition.shape: {initial_condition.shape} (should be 4D)"
+        nb = initial_condition.shape[0]
+        eng = self._ensure_engine(initial_condition.shape[-2:], nb)
+        self._ensure_plan(eng)
+        stack = eng.sample(initial_condition, static_condition, masks=_masks, noise=_noise)
+        intermediates = {f"t{slot + 1}_preds": stack[slot] for slot in self._emitted_slots}
+        x_s = stack[self._emitted_slots[-1]]
+        return eng.last_x0hat(nb), intermediates, x_s
+
+    @torch.no_grad()
+    def sample(self, initial_condition: Tensor, num_samples: int = 1, **kwargs) -> Dict[str, Tensor]:
+        _, intermediates, _ = self.sample_loop(initial_condition, **kwargs)
+        return intermediates
+
+    def predict_forward(self, inputs: Tensor, condition: Tensor = None, metadata=None, **kwargs):
+        """_base_diffusion.py:48-68: `condition` is routed to `static_condition`."""
+        if inputs is not None and condition is not None:
+            kwargs["static_condition"] = condition
+        return self.sample(inputs, **kwargs)
+
+    def q_sample(self, x0: Tensor, x_end: Tensor, t: Optional[Tensor], interpolation_time: Optional[Tensor] = None,
+                 static_condition: Optional[Tensor] = None, **kwargs) -> Tensor:
+        """dyffusion.py:140-163 + :480-494: one interpolator forward I(x_end, x0, i)."""
+        assert t is None or interpolation_time is None, "Either t or interpolation_time must be None."
+        i_time = interpolation_time if t is None else self.diffusion_step_to_interpolation_step(t)
+        assert bool((0 < i_time).all()) and bool((i_time < self.interpolator_horizon).all()), \
+            f"interpolate time must be in (0, {self.interpolator_horizon}), got {i_time}"
+        eng = self._ensure_engine(x0.shape[-2:], x0.shape[0])
+        mode = 1 if (self.training or self.enable_interpolator_dropout) else 0
+        return eng.net_forward(L.NET_INTERPOLATOR, torch.cat([x_end, x0], dim=1), i_time.float(), static_condition,
+                               dropout_mode=mode if self._ipol_net.hparams.dropout > 0 else 0)
+
+    def predict_x_last(self, condition: Tensor, x_t: Tensor, t: Tensor, is_sampling: bool = False,
+                       static_condition: Optional[Tensor] = None) -> Tensor:
+        """dyffusion.py:205-239: one forecaster forward F(x_t, enc(t); cond)."""
+        assert bool((0 <= t).all()) and bool((t <= self.num_timesteps - 1).all()), f"Invalid timestep: {t}"
+        fc = self.hparams.forward_conditioning
+        if fc == "data":
+            cond = condition
+        elif fc == "none":
+            cond = None
+        else:
+            tf = (t / (self.num_timesteps - 1)).view(condition.shape[0], *[1] * (condition.ndim - 1))
+            cond = tf * condition + (1 - tf) * torch.randn_like(condition)
+        if static_condition is not None:
+            cond = static_condition if cond is None else torch.cat([cond, static_condition], dim=1)
+        enc = self.hparams.time_encoding
+        time = t if enc == "discrete" else t / self.num_timesteps if enc == "normalized" else \
+            self.diffusion_step_to_interpolation_step(t)
+        eng = self._ensure_engine(x_t.shape[-2:], x_t.shape[0])
+        return eng.net_forward(L.NET_FORECASTER, x_t, time.float(), cond,
+                               dropout_mode=1 if (self.enable_forecaster_dropout and self.model.hparams.dropout > 0) else 0)
+
+    def p_losses(self, *args, **kwargs):
+        raise NotImplementedError("training (dyffusion.py:496-567) is outside the sampling hot path of this engine")
+
+    def forward(self, *args, **kwargs):
+        return self.p_losses(*args, **kwargs)

@@ -1,0 +1,205 @@
+"""Thin object wrapper over the C ABI (one HipEngine = one dyf_engine).  PyTorch is only used for device memory
+and streams here: every tensor crosses the boundary as a raw device pointer (`tensor.data_ptr()`)."""
+import ctypes as C
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+def _raise(status: int, msg: str):
+    if status == L.DYF_ERR_INVALID_ARGUMENT:
+        raise ValueError(msg)
+    if status == L.DYF_ERR_UNSUPPORTED:
+        raise NotImplementedError(msg)
+    raise EngineError(msg)
+
+
+def net_config(*, in_channels: int, cond_channels: int, out_channels: int, dim: int, with_time_emb: bool = True,
+               upsample_dims: Optional[Sequence[int]] = (256, 256), dropout: float = 0.0,
+               input_dropout: float = 0.0) -> L.NetConfig:
+    uh, uw = (0, 0) if upsample_dims is None else (int(upsample_dims[0]), int(upsample_dims[1]))
+    return L.NetConfig(L.ARCH_UNET_SIMPLE, in_channels, cond_channels, out_channels, dim, int(bool(with_time_emb)), uh,
+                       uw, float(dropout), float(input_dropout))
+
+
+def _f32c(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not t.is_cuda:
+        raise ValueError(f"{name} must live on the GPU (got {t.device}); the HIP engine has no CPU path")
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+class HipEngine:
+    def __init__(self, forecaster: L.NetConfig, interpolator: L.NetConfig, height: int, width: int, max_batch: int,
+                 device: Optional[int] = None, use_graph: bool = True, enable_mfma: bool = True):
+        if not torch.cuda.is_available():
+            raise EngineError("no GPU visible: the DYffusion HIP engine needs an MI355X (gfx950); there is no CPU fallback")
+        self._lib = L.lib()
+        self.device = torch.cuda.current_device() if device is None else int(device)
+        self.height, self.width, self.max_batch = int(height), int(width), int(max_batch)
+        cfg = L.EngineConfig(L.DYF_ABI_VERSION, self.device, self.height, self.width, self.max_batch, int(use_graph),
+                             int(enable_mfma), (L.NetConfig * 2)(forecaster, interpolator))
+        self.cfg = cfg
+        h = C.c_void_p()
+        st = self._lib.dyf_engine_create(C.byref(cfg), C.byref(h))
+        if st != L.DYF_OK:
+            _raise(st, self._lib.dyf_last_error(None).decode())
+        self._h = h
+        self._plan_keepalive = None
+        self.n_out_slots = 0
+
+    # ------------------------------------------------------------------ plumbing
+    def _check(self, st: int):
+        if st != L.DYF_OK:
+            _raise(st, self._lib.dyf_last_error(self._h).decode())
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.dyf_engine_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @staticmethod
+    def _stream() -> C.c_void_p:
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    # ------------------------------------------------------------------ weights
+    def load_weights(self, net: int, state_dict: Dict[str, torch.Tensor]):
+        """state_dict: the reference's `UNet.state_dict()` (same key names)."""
+        items = [(k, v) for k, v in state_dict.items() if not k.endswith("num_batches_tracked")]
+        arrs = [np.ascontiguousarray(v.detach().to("cpu", torch.float32).numpy()) for _, v in items]
+        n = len(items)
+        names = (C.c_char_p * n)(*[k.encode() for k, _ in items])
+        data = (C.c_void_p * n)(*[a.ctypes.data for a in arrs])
+        shp_store = [(C.c_int64 * max(1, a.ndim))(*a.shape) for a in arrs]
+        shapes = (C.c_void_p * n)(*[C.addressof(s) for s in shp_store])
+        ndims = (C.c_int32 * n)(*[a.ndim for a in arrs])
+        self._check(self._lib.dyf_load_weights(self._h, net, n, names, data, shapes, ndims))
+
+    # ------------------------------------------------------------------ per-network seam
+    def net_forward(self, net: int, inputs: torch.Tensor, time: Optional[torch.Tensor] = None,
+                    condition: Optional[torch.Tensor] = None, dropout_mode: int = 0,
+                    masks: Optional[Sequence[torch.Tensor]] = None) -> torch.Tensor:
+        inputs = _f32c(inputs, "inputs")
+        nb = inputs.shape[0]
+        ncfg = self.cfg.net[net]
+        if inputs.dim() != 4 or inputs.shape[1] != ncfg.in_channels or tuple(inputs.shape[2:]) != (self.height, self.width):
+            raise ValueError(f"inputs must be (NB, {ncfg.in_channels}, {self.height}, {self.width}), got {tuple(inputs.shape)}")
+        if condition is not None:
+            condition = _f32c(condition, "condition")
+            if tuple(condition.shape) != (nb, ncfg.cond_channels, self.height, self.width):
+                raise ValueError(f"condition has shape {tuple(condition.shape)}")
+        if time is not None:
+            time = _f32c(time.reshape(-1), "time")
+            if time.numel() != nb:
+                raise ValueError("time must have one entry per batch row")
+        out = torch.empty((nb, ncfg.out_channels, self.height, self.width), dtype=torch.float32, device=inputs.device)
+        mptr = None
+        if masks is not None:
+            keep = [m.contiguous() for m in masks]
+            mptr = (C.c_void_p * len(keep))(*[m.data_ptr() for m in keep])
+        self._check(self._lib.dyf_net_forward(
+            self._h, net, inputs.data_ptr(), None if time is None else time.data_ptr(),
+            None if condition is None else condition.data_ptr(), out.data_ptr(), nb, dropout_mode, mptr, self._stream()))
+        return out
+
+    # ------------------------------------------------------------------ sampler seam
+    def set_plan(self, steps: List[dict], *, sampling_cold: bool, cold_for_last_step: bool, forward_conditioning: str,
+                 refine: Sequence[tuple], n_out_slots: int, interpolator_dropout: bool, forecaster_dropout: bool):
+        n = len(steps)
+        arr = (L.PlanStep * n)()
+        for i, s in enumerate(steps):
+            arr[i] = L.PlanStep(float(s["forecaster_time"]), float(s["tau"]),
+                                -1.0 if s["i_next"] is None else float(s["i_next"]),
+                                -1.0 if s["i_cur"] is None else float(s["i_cur"]), int(s["is_last"]),
+                                -1 if s["out_slot"] is None else int(s["out_slot"]))
+        nr = len(refine)
+        rt = (C.c_float * max(1, nr))(*[float(t) for t, _ in refine])
+        rs = (C.c_int32 * max(1, nr))(*[int(sl) for _, sl in refine])
+        plan = L.Plan(n, arr, int(sampling_cold), int(cold_for_last_step), L.FCOND[forward_conditioning], nr, rt, rs,
+                      int(n_out_slots), int(interpolator_dropout), int(forecaster_dropout))
+        self._plan_keepalive = (arr, rt, rs, plan)
+        self._check(self._lib.dyf_set_plan(self._h, C.byref(plan)))
+        self.n_out_slots = int(n_out_slots)
+
+    def sample(self, initial: torch.Tensor, static: Optional[torch.Tensor] = None,
+               masks: Optional[Sequence[torch.Tensor]] = None, noise: Optional[torch.Tensor] = None,
+               out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Returns the forecast stack (n_out_slots, NB, C, H, W); slot i = t{i+1}_preds."""
+        initial = _f32c(initial, "initial_condition")
+        if initial.dim() != 4:
+            raise AssertionError(f"condition.shape: {tuple(initial.shape)} (should be 4D)")
+        nb = initial.shape[0]
+        if static is not None:
+            static = _f32c(static, "static_condition")
+        c_out = self.cfg.net[L.NET_FORECASTER].out_channels
+        if out is None:
+            out = torch.empty((self.n_out_slots, nb, c_out, self.height, self.width), dtype=torch.float32,
+                              device=initial.device)
+        mptr = None
+        if masks is not None:
+            keep = [m.contiguous() for m in masks]
+            mptr = (C.c_void_p * len(keep))(*[m.data_ptr() for m in keep])
+        if noise is not None:
+            noise = _f32c(noise, "noise")
+        self._check(self._lib.dyf_sample(self._h, initial.data_ptr(), None if static is None else static.data_ptr(),
+                                         out.data_ptr(), nb, mptr, None if noise is None else noise.data_ptr(),
+                                         self._stream()))
+        return out
+
+    def last_x0hat(self, nb: int) -> torch.Tensor:
+        c_out = self.cfg.net[L.NET_FORECASTER].out_channels
+        out = torch.empty((nb, c_out, self.height, self.width), dtype=torch.float32, device=f"cuda:{self.device}")
+        self._check(self._lib.dyf_get_last_x0hat(self._h, out.data_ptr(), nb, self._stream()))
+        return out
+
+    def seed(self, seed: int):
+        self._check(self._lib.dyf_seed(self._h, C.c_uint64(int(seed) & (2 ** 64 - 1))))
+
+    # ------------------------------------------------------------------ introspection
+    def forward_counts(self):
+        a, b = C.c_int32(), C.c_int32()
+        self._check(self._lib.dyf_plan_forward_counts(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
+    def net_flops(self, net: int) -> float:
+        f = C.c_double()
+        self._check(self._lib.dyf_net_flops(self._h, net, C.byref(f)))
+        return f.value
+
+    def time_conv_layer(self, net: int, layer: int, nb: int, iters: int = 20):
+        ms, fl, by = C.c_double(), C.c_double(), C.c_double()
+        self._check(self._lib.dyf_time_conv_layer(self._h, net, layer, nb, iters, self._stream(), C.byref(ms),
+                                                  C.byref(fl), C.byref(by)))
+        return ms.value, fl.value, by.value
+
+    def op_conv2d(self, x_nhwc_bf16: torch.Tensor, weight: torch.Tensor, stride: int, pad: int,
+                  scale: Optional[torch.Tensor] = None, shift: Optional[torch.Tensor] = None, act: int = 0,
+                  path: int = 1) -> torch.Tensor:
+        """Test seam: x (N,H,W,Cin) bf16 on the GPU, weight (Cout,Cin,kh,kw) fp32 (any device) -> (N,Ho,Wo,Cout) bf16."""
+        assert x_nhwc_bf16.dtype == torch.bfloat16 and x_nhwc_bf16.is_cuda and x_nhwc_bf16.is_contiguous()
+        n, h, w, cin = x_nhwc_bf16.shape
+        cout, _, kh, kw = weight.shape
+        wh = np.ascontiguousarray(weight.detach().to("cpu", torch.float32).numpy())
+        ho, wo = (h + 2 * pad - kh) // stride + 1, (w + 2 * pad - kw) // stride + 1
+        y = torch.empty((n, ho, wo, cout), dtype=torch.bfloat16, device=x_nhwc_bf16.device)
+        if scale is not None:
+            scale, shift = _f32c(scale, "scale"), _f32c(shift, "shift")
+        self._check(self._lib.dyf_op_conv2d(self._h, x_nhwc_bf16.data_ptr(), wh.ctypes.data, n, h, w, cin, cout, kh, kw,
+                                            stride, pad, None if scale is None else scale.data_ptr(),
+                                            None if shift is None else shift.data_ptr(), act, path, y.data_ptr(),
+                                            self._stream()))
+        return y

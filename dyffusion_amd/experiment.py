@@ -1,0 +1,64 @@
+"""Caller contract of the hot path: the `predict` / `predict_step` surface of
+`src/experiment_types/_base_experiment.py:315-379,503-567,700-708` and the per-batch entry of
+`forecasting_multi_horizon.py:282-342`, reduced to what drives `DYffusion.sample`."""
+from typing import Any, Dict, Optional
+
+import torch
+from torch import Tensor, nn
+
+from .dyffusion import DYffusion
+from .unet_simple import _AttrDict
+
+
+class InterpolatorHandle:
+    """Duck type of the reference's InterpolationExperiment as DYffusion uses it (dyffusion.py:461-478):
+    `.model`, `.window`, `.true_horizon`."""
+
+    def __init__(self, model, horizon: int, window: int = 1):
+        self.model, self.true_horizon, self.window = model, horizon, window
+
+    def inference_dropout_scope(self, condition: bool, context=None):
+        return self.model.inference_dropout_scope(condition, context)
+
+
+class MultiHorizonForecastingDYffusion(nn.Module):
+    def __init__(self, model: DYffusion, num_predictions: int = 1, window: int = 1, horizon: Optional[int] = None):
+        super().__init__()
+        self.model = model
+        self.hparams = _AttrDict(num_predictions=num_predictions)
+        self.window = window
+        self.horizon = horizon or model.hparams.timesteps
+
+    # _base_experiment.py:503-538 -- "N B ... -> (N B) ...": ensemble-major rows (row = n*B + b)
+    def get_ensemble_inputs(self, inputs_raw: Optional[Tensor], num_predictions: Optional[int] = None) -> Optional[Tensor]:
+        n = num_predictions or self.hparams.num_predictions
+        if inputs_raw is None or n <= 1:
+            return inputs_raw
+        return inputs_raw.unsqueeze(0).expand(n, *inputs_raw.shape).reshape(n * inputs_raw.shape[0], *inputs_raw.shape[1:])
+
+    # _base_experiment.py:315-379,540-567
+    def predict(self, inputs: Tensor, num_predictions: Optional[int] = None, reshape_ensemble_dim: bool = True,
+                **kwargs) -> Dict[str, Tensor]:
+        n = num_predictions or self.hparams.num_predictions
+        results = self.model.predict_forward(inputs, num_predictions=n, **kwargs)
+        if torch.is_tensor(results):
+            results = {"preds": results}
+        if reshape_ensemble_dim:
+            for k, v in list(results.items()):
+                b = v.shape[0]
+                if "preds" in k and b > 1 and n > 1:
+                    assert b % n == 0, f"key={k}: b % #ens_mems = {b} % {n} != 0 ...Did you forget to create the input ensemble?"
+                    results[k] = v.reshape(n, max(1, b // n), *v.shape[1:])
+        return results
+
+    # forecasting_multi_horizon.py:337-342 + :282-332 (first prediction step: tile, sample, cache all horizons)
+    @torch.no_grad()
+    def predict_step(self, batch: Dict[str, Any], batch_idx: int = 0, dataloader_idx: int = None) -> Dict[str, Any]:
+        dynamics = batch["dynamics"]
+        b = dynamics.shape[0]
+        inputs = dynamics[:, : self.window].reshape(b, -1, *dynamics.shape[-2:])  # "b window c h w -> b (window c) h w"
+        cond = batch.get("condition", None)
+        n = self.hparams.num_predictions
+        preds = self.predict(self.get_ensemble_inputs(inputs, n), condition=self.get_ensemble_inputs(cond, n),
+                             num_predictions=n)
+        return {k: v.detach().cpu().numpy() for k, v in preds.items()}

@@ -1,0 +1,148 @@
+"""Host-side mirror of the reference's Navier-Stokes backbone `src/models/unet_simple.py:85-197` (UNet).
+
+Same constructor keywords, same parameter/buffer names (so a Lightning checkpoint's `state_dict` loads unchanged)
+and the same `forward(inputs, time=None, condition=None)` signature -- but `forward` does not run any torch
+operator: it hands device pointers to the HIP engine (dyf_net_forward).  The torch.nn modules below are parameter
+containers only.
+"""
+from contextlib import contextmanager
+from typing import Optional, Sequence
+
+import torch
+from torch import Tensor, nn
+
+from . import _lib as L
+from .engine import HipEngine, net_config
+
+
+class _AttrDict(dict):
+    __getattr__ = dict.get
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+
+def _block_params(cin: int, cout: int, kernel: int, decoder: bool, time_dim: Optional[int], groupnorm: bool,
+                  dropout: float) -> nn.Module:
+    """Parameter container named like UNetBlock (unet_simple.py:13-65): ops.{0|1} conv, ops.{1|2} norm, time_mlp.1."""
+    blk = nn.Module()
+    conv = nn.Conv2d(cin, cout, kernel, bias=True)
+    norm = nn.GroupNorm(8, cout) if groupnorm else nn.BatchNorm2d(cout)
+    blk.ops = nn.Sequential(nn.Identity(), conv, norm) if decoder else nn.Sequential(conv, norm)
+    blk.time_mlp = nn.Sequential(nn.SiLU(), nn.Linear(time_dim, 2 * cout)) if time_dim is not None else None
+    blk.dropout = nn.Dropout(dropout)
+    return blk
+
+
+class UNet(nn.Module):
+    def __init__(self, dim: int, with_time_emb: bool = False, outer_sample_mode: str = "bilinear",
+                 upsample_dims: Optional[Sequence[int]] = (256, 256), dropout: float = 0.0, input_dropout: float = 0.0,
+                 num_input_channels: int = None, num_output_channels: int = None, num_conditional_channels: int = 0,
+                 spatial_shape: Sequence[int] = None, loss_function: str = "mean_squared_error",
+                 datamodule_config=None, name: str = "", verbose: bool = True):
+        super().__init__()
+        if outer_sample_mode != "bilinear":
+            raise NotImplementedError("the HIP engine implements outer_sample_mode='bilinear' (the shipped configs' value)")
+        self.hparams = _AttrDict(dim=dim, with_time_emb=with_time_emb, outer_sample_mode=outer_sample_mode,
+                                 upsample_dims=None if upsample_dims is None else tuple(upsample_dims), dropout=dropout,
+                                 input_dropout=input_dropout, num_input_channels=num_input_channels,
+                                 num_output_channels=num_output_channels,
+                                 num_conditional_channels=num_conditional_channels, spatial_shape=spatial_shape,
+                                 loss_function=loss_function, name=name)
+        self.name, self.verbose = name, verbose
+        self.num_input_channels = num_input_channels
+        self.num_output_channels = num_output_channels
+        self.num_conditional_channels = num_conditional_channels
+        self.spatial_shape = None if spatial_shape is None else tuple(spatial_shape)
+        self.outer_sample_mode = outer_sample_mode
+        cin = num_input_channels + num_conditional_channels
+        self.time_dim = 2 * dim if with_time_emb else None
+        # parameter containers, names as in the reference state_dict
+        self.time_emb_mlp = (nn.Sequential(nn.Identity(), nn.Linear(dim, self.time_dim), nn.GELU(),
+                                           nn.Linear(self.time_dim, self.time_dim)) if with_time_emb else None)
+        self.init_conv = nn.Conv2d(cin, dim, 1)
+        self.dropout_input = nn.Dropout(input_dropout)
+        d = dim
+        enc = [(d, 2 * d, 4), (2 * d, 2 * d, 4), (2 * d, 4 * d, 4), (4 * d, 8 * d, 4), (8 * d, 8 * d, 2), (8 * d, 8 * d, 2)]
+        dec = [(8 * d, 8 * d, 1), (16 * d, 8 * d, 1), (16 * d, 4 * d, 3), (8 * d, 2 * d, 3), (4 * d, 2 * d, 3), (4 * d, d, 3)]
+        self.input_ops = nn.ModuleList([_block_params(a, b, k, False, self.time_dim, i == 5, dropout)
+                                        for i, (a, b, k) in enumerate(enc)])
+        self.output_ops = nn.ModuleList([_block_params(a, b, k, True, self.time_dim, False, dropout) for a, b, k in dec])
+        self.readout = nn.Sequential(nn.ConvTranspose2d(d, num_output_channels, 4, stride=2, padding=1))
+        for m in self.modules():  # unet_simple.py:156-162
+            if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)):
+                m.weight.data.normal_(0.0, 0.02)
+            elif isinstance(m, nn.BatchNorm2d):
+                m.weight.data.normal_(1.0, 0.02)
+                m.bias.data.fill_(0)
+        self.requires_grad_(False)
+        self.eval()
+        self._engine: Optional[HipEngine] = None
+        self._engine_slot = L.NET_FORECASTER
+        self._engine_key = None
+        self._weights_version = 0
+        self._mc_dropout = False
+
+    # ------------------------------------------------------------------ engine plumbing
+    def engine_net_config(self) -> L.NetConfig:
+        hp = self.hparams
+        return net_config(in_channels=self.num_input_channels, cond_channels=self.num_conditional_channels,
+                          out_channels=self.num_output_channels, dim=hp.dim, with_time_emb=hp.with_time_emb,
+                          upsample_dims=hp.upsample_dims, dropout=hp.dropout, input_dropout=hp.input_dropout)
+
+    def attach_engine(self, engine: HipEngine, slot: int):
+        """Used by DYffusion: both networks of a pair live in one engine."""
+        self._engine, self._engine_slot = engine, slot
+        self._engine_key = "attached"
+        engine.load_weights(slot, self.state_dict())
+
+    def load_state_dict(self, state_dict, strict: bool = True, **kw):
+        res = super().load_state_dict(state_dict, strict=strict, **kw)
+        if self._engine is not None:
+            self._engine.load_weights(self._engine_slot, self.state_dict())
+        return res
+
+    def _own_engine(self, nb: int, hw) -> HipEngine:
+        key = (tuple(hw), nb)
+        if self._engine is None or (self._engine_key != "attached" and
+                                    (self._engine_key[0] != key[0] or self._engine_key[1] < nb)):
+            cfg = self.engine_net_config()
+            self._engine = HipEngine(cfg, cfg, hw[0], hw[1], max_batch=nb, use_graph=False)
+            self._engine_slot = L.NET_FORECASTER
+            self._engine_key = key
+            self._engine.load_weights(self._engine_slot, self.state_dict())
+        return self._engine
+
+    # ------------------------------------------------------------------ reference API
+    def forward(self, inputs: Tensor, time: Tensor = None, condition: Tensor = None, return_time_emb: bool = False,
+                **kwargs) -> Tensor:
+        if self.num_conditional_channels > 0:
+            if condition is None:
+                raise ValueError("condition must be given when num_conditional_channels > 0")
+        else:
+            assert condition is None
+        eng = self._own_engine(inputs.shape[0], inputs.shape[-2:])
+        mode = 1 if (self._mc_dropout and self.hparams.dropout > 0) else 0
+        return eng.net_forward(self._engine_slot, inputs, time if self.hparams.with_time_emb else None, condition,
+                               dropout_mode=mode)
+
+    def predict_forward(self, inputs: Tensor, metadata=None, **kwargs):
+        return self(inputs, **kwargs)
+
+    @contextmanager
+    def inference_dropout_scope(self, condition: bool, context=None):
+        """_base_model.py:148-161: only the Dropout layers are switched; BatchNorm stays in eval mode."""
+        assert isinstance(condition, bool), f"Condition must be a boolean, got {condition}"
+        prev = self._mc_dropout
+        if condition:
+            self._mc_dropout = True
+        try:
+            yield None
+        finally:
+            self._mc_dropout = prev
+
+    def enable_inference_dropout(self):
+        self._mc_dropout = True
+
+    def disable_inference_dropout(self):
+        self._mc_dropout = False

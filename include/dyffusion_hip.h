@@ -1,0 +1,158 @@
+/*
+ * dyffusion_hip.h -- C ABI of libdyffusion_hip.so: the MI355X (gfx950) DYffusion sampling engine.
+ *
+ * Drop-in boundary for the reference's hot path (all paths relative to the upstream repo root):
+ *   - per-network seam   BaseModel.forward(inputs, time, condition)        src/models/unet_simple.py:181-197
+ *   - sampler seam       DYffusion.sample(initial_condition, static_condition=..., num_predictions=N)
+ *                                                                          src/diffusion/dyffusion.py:335-431
+ *     reached from BaseDiffusion.predict_forward (src/diffusion/_base_diffusion.py:48-68) and
+ *     BaseExperiment.predict (src/experiment_types/_base_experiment.py:315-356).
+ *
+ * Conventions
+ *   - plain C types only; every pointer named *_dev is DEVICE memory owned by the caller (e.g. a torch tensor's
+ *     data_ptr()), everything else is HOST memory.  Tensors crossing the ABI are fp32, NCHW, contiguous -- the
+ *     reference's layout.  Internally the engine keeps activations NHWC bf16 and accumulates in fp32.
+ *   - the engine owns packed device weights, its workspace arena and captured hipGraphs; no allocation happens
+ *     inside dyf_sample / dyf_net_forward after the first call for a given batch size.
+ *   - one engine per (device, stream); calls on one engine are not re-entrant.
+ *   - every function returns a dyf_status; dyf_last_error(engine) (or NULL for create-time failures) returns a
+ *     message.  The Python shim re-raises ValueError / AssertionError / RuntimeError from these.
+ *   - `stream` arguments are hipStream_t passed as void* (0 = the null stream).
+ */
+#ifndef DYFFUSION_HIP_H
+#define DYFFUSION_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DYF_ABI_VERSION 1
+
+typedef struct dyf_engine dyf_engine;
+
+typedef enum dyf_status {
+    DYF_OK = 0,
+    DYF_ERR_INVALID_ARGUMENT = 1, /* maps to ValueError / AssertionError in the shim */
+    DYF_ERR_UNSUPPORTED = 2,      /* valid in the reference, not implemented by this engine (NotImplementedError) */
+    DYF_ERR_HIP = 3,              /* a HIP runtime call failed (RuntimeError) */
+    DYF_ERR_STATE = 4             /* call order violated, e.g. sampling before weights / plan are set */
+} dyf_status;
+
+/* Which network of the DYffusion pair a call refers to (dyffusion.py:448-468: self.model / self.interpolator). */
+typedef enum dyf_net_id { DYF_NET_FORECASTER = 0, DYF_NET_INTERPOLATOR = 1 } dyf_net_id;
+
+/* Backbone architectures (src/models/). */
+typedef enum dyf_arch {
+    DYF_ARCH_UNET_SIMPLE = 0 /* src/models/unet_simple.py:85-197 (Navier-Stokes / spring-mesh backbone) */
+} dyf_arch;
+
+/* Hyper-parameters of one backbone: the kwargs of unet_simple.UNet.__init__ (unet_simple.py:86-95) plus the
+ * channel bookkeeping of BaseModel (src/models/_base_model.py:43-66). */
+typedef struct dyf_net_config {
+    int32_t arch;             /* dyf_arch */
+    int32_t in_channels;      /* num_input_channels (without the conditional channels) */
+    int32_t cond_channels;    /* num_conditional_channels */
+    int32_t out_channels;     /* num_output_channels */
+    int32_t dim;              /* base width */
+    int32_t with_time_emb;    /* 0/1 */
+    int32_t upsample_h;       /* upsample_dims[0], 0 = no outer resampling */
+    int32_t upsample_w;
+    float dropout;            /* UNetBlock dropout p */
+    float input_dropout;      /* must be 0 (the shipped configs' value) in this version */
+} dyf_net_config;
+
+typedef struct dyf_engine_config {
+    int32_t abi_version;      /* DYF_ABI_VERSION */
+    int32_t device;           /* HIP device ordinal */
+    int32_t height, width;    /* native grid (e.g. 221 x 42) */
+    int32_t max_batch;        /* largest NB = N_ensemble * B the workspace is sized for */
+    int32_t use_graph;        /* capture the rollout in a hipGraph (dyf_sample) */
+    int32_t enable_mfma;      /* 1: implicit-GEMM MFMA conv where shapes allow; 0: direct conv everywhere (debug) */
+    dyf_net_config net[2];    /* indexed by dyf_net_id */
+} dyf_engine_config;
+
+/* One iteration of the sampling loop, resolved on the host (dyffusion.py:352-397). */
+typedef struct dyf_plan_step {
+    float forecaster_time;    /* enc(s): value fed to the forecaster's time embedding */
+    float tau;                /* s/(T-1), used by forward_conditioning="data+noise" */
+    float i_next;             /* interpolation time of s_next, < 0: none (x_next = x0_hat) */
+    float i_cur;              /* interpolation time of s,      < 0: none (x_cur  = x_s)    */
+    int32_t is_last;          /* s == T-1 */
+    int32_t out_slot;         /* index into the forecast stack written after this step, -1: none */
+} dyf_plan_step;
+
+typedef enum dyf_fcond { DYF_FCOND_NONE = 0, DYF_FCOND_DATA = 1, DYF_FCOND_DATA_NOISE = 2 } dyf_fcond;
+
+typedef struct dyf_plan {
+    int32_t n_steps;
+    const dyf_plan_step* steps;
+    int32_t sampling_cold;            /* 1 = "cold", 0 = "naive" (dyffusion.py:381-391) */
+    int32_t cold_for_last_step;       /* use_cold_sampling_for_last_step */
+    int32_t forward_conditioning;     /* dyf_fcond */
+    int32_t n_refine;                 /* refinement pass (dyffusion.py:408-422): number of re-predicted times */
+    const float* refine_times;        /* [n_refine] interpolation times */
+    const int32_t* refine_slots;      /* [n_refine] forecast-stack slots they overwrite */
+    int32_t n_out_slots;              /* h: number of (NB,C,H,W) fields in the forecast stack */
+    int32_t interpolator_dropout;     /* MC dropout active in the interpolator (enable_interpolator_dropout) */
+    int32_t forecaster_dropout;       /* dropout active in the forecaster (module.enable_inference_dropout) */
+} dyf_plan;
+
+/* ---- lifetime ------------------------------------------------------------------------------------------ */
+dyf_status dyf_engine_create(const dyf_engine_config* cfg, dyf_engine** out_engine);
+void dyf_engine_destroy(dyf_engine* engine);
+const char* dyf_last_error(const dyf_engine* engine);
+int32_t dyf_abi_version(void);
+
+/* ---- weights: the reference's state_dict (names as in UNet.state_dict(), host fp32, contiguous) ---------- */
+/* Replaces BaseExperiment.instantiate_model / load_state_dict (_base_experiment.py:173-199).  Folds eval-mode
+ * BatchNorm into per-channel scale/shift, repacks conv weights to the MFMA layout and uploads as bf16. */
+dyf_status dyf_load_weights(dyf_engine* engine, int32_t net, int32_t n_tensors, const char* const* names,
+                            const float* const* data, const int64_t* const* shapes, const int32_t* ndims);
+
+/* ---- per-network seam: BaseModel.forward(inputs, time, condition) (unet_simple.py:181-197) ------------------ */
+/* inputs_dev (NB,in_channels,H,W), time_dev (NB) or NULL when with_time_emb == 0, condition_dev
+ * (NB,cond_channels,H,W) or NULL, out_dev (NB,out_channels,H,W).  dropout_mode: 0 off (eval), 1 on (engine RNG),
+ * 2 on with injected keep-masks: masks_dev[l] is the uint8 NHWC keep-mask of dropout layer l (12 blocks, in
+ * execution order), used by the parity tests. */
+dyf_status dyf_net_forward(dyf_engine* engine, int32_t net, const float* inputs_dev, const float* time_dev,
+                           const float* condition_dev, float* out_dev, int32_t nb, int32_t dropout_mode,
+                           const uint8_t* const* masks_dev, void* stream);
+
+/* ---- sampler seam: DYffusion.sample / sample_loop (dyffusion.py:335-431) ------------------------------------- */
+dyf_status dyf_set_plan(dyf_engine* engine, const dyf_plan* plan);
+/* initial_dev (NB, window*C, H, W); static_dev (NB, Cs, H, W) or NULL; out_dev (n_out_slots, NB, C, H, W): slot i
+ * holds t{i+1}_preds.  masks_dev: NULL, or one pointer per (interpolator/forecaster forward, dropout layer) in
+ * execution order (12 per forward that has dropout on) for the mask-injection parity mode; noise_dev: NULL or
+ * (n_steps, NB, window*C, H, W) standard-normal draws for forward_conditioning="data+noise" parity. */
+dyf_status dyf_sample(dyf_engine* engine, const float* initial_dev, const float* static_dev, float* out_dev,
+                      int32_t nb, const uint8_t* const* masks_dev, const float* noise_dev, void* stream);
+/* Re-seed the engine's counter-based dropout / noise generator (stream position resets to 0). */
+dyf_status dyf_seed(dyf_engine* engine, uint64_t seed);
+/* Copy the last forecaster prediction x0_hat (NB,C,H,W) of the most recent dyf_sample call: the first element of the
+ * tuple DYffusion.sample_loop returns (dyffusion.py:424-426). */
+dyf_status dyf_get_last_x0hat(dyf_engine* engine, float* out_dev, int32_t nb, void* stream);
+
+/* ---- introspection used by bench.py / tests ------------------------------------------------------------------ */
+/* Number of network forwards one dyf_sample call performs under the current plan. */
+dyf_status dyf_plan_forward_counts(const dyf_engine* engine, int32_t* n_forecaster, int32_t* n_interpolator);
+/* 2*MAC of conv/linear layers of one forward of `net` for one sample (elementwise work excluded). */
+dyf_status dyf_net_flops(const dyf_engine* engine, int32_t net, double* flops_per_sample);
+/* Time the dominant conv kernel: average HIP-event duration (ms) of the conv layer `layer` (0..11, encoder then
+ * decoder blocks) of `net` at batch nb over `iters` launches on `stream`; also returns its 2*MAC count. */
+dyf_status dyf_time_conv_layer(dyf_engine* engine, int32_t net, int32_t layer, int32_t nb, int32_t iters,
+                               void* stream, double* avg_ms, double* flops, double* algorithmic_bytes);
+
+/* ---- op-level seam (tests only): one Conv2d + fused epilogue on NHWC bf16 tensors ---------------------------- */
+/* x_dev (N,H,W,Cin) bf16 bits; w (Cout,Cin,kh,kw) host fp32; scale/shift (N,Cout) device fp32 or NULL;
+ * y_dev (N,Ho,Wo,Cout) bf16 bits.  act: 0 none, 1 relu, 2 leaky(0.2).  path: 0 direct, 1 MFMA implicit GEMM. */
+dyf_status dyf_op_conv2d(dyf_engine* engine, const uint16_t* x_dev, const float* w_host, int32_t n, int32_t h,
+                         int32_t w, int32_t cin, int32_t cout, int32_t kh, int32_t kw, int32_t stride, int32_t pad,
+                         const float* scale_dev, const float* shift_dev, int32_t act, int32_t path, uint16_t* y_dev,
+                         void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DYFFUSION_HIP_H */

@@ -1,0 +1,80 @@
+"""-m gpu: the conv kernels (direct and MFMA implicit GEMM) against torch.conv2d on the same bf16-rounded operands.
+
+Through the C ABI test seam dyf_op_conv2d.  Tolerance: output is rounded to bf16 (rel 2^-9) after an fp32
+accumulation whose order differs from ATen's; we require max |err| <= 1.5 * 2^-8 * max|y| + 1e-3 and rel-RMS <= 4e-3.
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.helpers import max_abs, rel_rms
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    # n, h, w, cin, cout, k, stride, pad
+    (2, 16, 16, 64, 128, 3, 1, 1),
+    (1, 32, 32, 64, 128, 4, 2, 1),
+    (3, 8, 8, 128, 64, 2, 2, 0),
+    (2, 8, 8, 192, 64, 1, 1, 0),
+    (1, 20, 12, 128, 256, 3, 1, 1),     # M = 240: not a multiple of the 128-row tile
+    (5, 4, 4, 512, 512, 2, 2, 0),       # tiles span several samples
+    (1, 64, 64, 256, 64, 3, 1, 1),      # 256x64 tile variant
+    (2, 9, 7, 64, 64, 3, 1, 1),
+]
+
+
+@pytest.fixture(scope="module")
+def engine():
+    import dyffusion_amd as D
+    cfg = D.net_config(in_channels=3, cond_channels=0, out_channels=3, dim=64, upsample_dims=[64, 64])
+    return D.HipEngine(cfg, cfg, 16, 16, max_batch=1, use_graph=False)
+
+
+def reference(x_nhwc, w, stride, pad, scale=None, shift=None, act=0):
+    x = x_nhwc.float().permute(0, 3, 1, 2)
+    wq = w.to(torch.bfloat16).float()
+    y = F.conv2d(x, wq, None, stride, pad)
+    if scale is not None:
+        y = y * scale[:, :, None, None] + shift[:, :, None, None]
+    if act == 1:
+        y = F.relu(y)
+    elif act == 2:
+        y = F.leaky_relu(y, 0.2)
+    return y.permute(0, 2, 3, 1)
+
+
+@pytest.mark.parametrize("path", [0, 1], ids=["direct", "mfma"])
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "x".join(map(str, c)))
+def test_conv_matches_torch(engine, case, path):
+    n, h, w, cin, cout, k, stride, pad = case
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    x = torch.randn(n, h, w, cin, generator=g).to(torch.bfloat16)
+    wt = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    scale = 1.0 + 0.3 * torch.randn(n, cout, generator=g)
+    shift = 0.2 * torch.randn(n, cout, generator=g)
+    for act, use_coef in [(0, False), (2, True), (1, True)]:
+        y = engine.op_conv2d(x.cuda(), wt, stride, pad, scale.cuda() if use_coef else None,
+                             shift.cuda() if use_coef else None, act=act, path=path)
+        want = reference(x, wt, stride, pad, scale if use_coef else None, shift if use_coef else None, act)
+        got = y.float().cpu()
+        tol = 1.5 * 2 ** -8 * float(want.abs().max()) + 1e-3
+        assert max_abs(got, want) <= tol, (case, act, max_abs(got, want), tol)
+        assert rel_rms(got, want) <= 4e-3
+
+
+def test_mfma_and_direct_agree_closely(engine):
+    # both accumulate in fp32 from identical bf16 operands: they differ only by summation order (+ final rounding)
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(2, 24, 24, 128, generator=g).to(torch.bfloat16).cuda()
+    wt = torch.randn(128, 128, 3, 3, generator=g) / 34.0
+    a = engine.op_conv2d(x, wt, 1, 1, path=0).float()
+    b = engine.op_conv2d(x, wt, 1, 1, path=1).float()
+    assert rel_rms(a.cpu(), b.cpu()) <= 2.5e-3
+    assert float((a != b).float().mean()) < 0.2  # most outputs round to the same bf16 value
+
+
+def test_mfma_path_rejects_unsupported_channels(engine):
+    x = torch.zeros(1, 8, 8, 32, dtype=torch.bfloat16).cuda()
+    with pytest.raises(NotImplementedError):
+        engine.op_conv2d(x, torch.zeros(64, 32, 3, 3), 1, 1, path=1)

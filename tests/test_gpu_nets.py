@@ -1,0 +1,124 @@
+"""-m gpu: dyf_net_forward (HIP) against the oracle / the reference's golden outputs.
+
+Tolerance (stated): the engine keeps activations in bf16 (8 mantissa bits) and accumulates in fp32; against the
+fp32 oracle we require rel-RMS <= 1.5e-2 per forward (measured values are printed; SURVEY.md 8c quotes 3.5-4.5e-3
+for the reference's own bf16-autocast drift over a rollout).
+"""
+import json
+
+import pytest
+import torch
+
+from oracle import init as oinit
+from oracle import nets
+from tests.gpu_common import DEV, mirror_from_params, nhwc_masks
+from tests.helpers import jload, load_npz, rel_rms, split_state
+
+pytestmark = pytest.mark.gpu
+TOL = 1.5e-2
+
+
+@pytest.mark.parametrize("name", ["net_unet_simple_a", "net_unet_simple_b", "net_unet_simple_c"])
+def test_small_nets_match_reference_goldens(name):
+    """dim 4/8 networks straight from the reference's own outputs (direct-conv path: channels < 64)."""
+    z = load_npz(name + ".npz")
+    P, cfg = split_state(z, "P"), json.loads(str(z["cfg"]))
+    x, t = torch.from_numpy(z["x"]), torch.from_numpy(z["t"])
+    c = torch.from_numpy(z["c"]) if "c" in z else None
+    net = mirror_from_params(P, cfg, x.shape[1], 0 if c is None else c.shape[1], z["y_eval"].shape[1])
+    y = net(x.to(DEV), time=t.to(DEV), condition=None if c is None else c.to(DEV)).cpu()
+    err = rel_rms(y, z["y_eval"])
+    print(name, "eval rel-rms", err)
+    assert err <= TOL
+    # dropout with the reference's own mask stream (seeded), injected as keep-masks
+    src = nets.DropoutSeeded(int(z["dropout_seed"]), record=True)
+    y_or = nets.unet_simple_forward(P, cfg, x, t, c, dropout=src)
+    assert rel_rms(y_or, z["y_drop"]) < 1e-5
+    eng = net._engine
+    y = eng.net_forward(0, x.to(DEV), t.to(DEV), None if c is None else c.to(DEV), dropout_mode=2,
+                        masks=nhwc_masks(src.masks)).cpu()
+    err = rel_rms(y, z["y_drop"])
+    print(name, "dropout rel-rms", err)
+    assert err <= TOL
+
+
+@pytest.mark.parametrize("hw,up,nb,n_in,n_cond", [((23, 11), (64, 64), 3, 6, 2), ((40, 17), (128, 64), 2, 3, 2),
+                                                   ((32, 32), None, 2, 3, 0)])
+def test_dim64_mfma_path_matches_oracle(hw, up, nb, n_in, n_cond):
+    cfg = dict(dim=64, upsample_dims=None if up is None else list(up), outer_sample_mode="bilinear", with_time_emb=True,
+               dropout=0.15, input_dropout=0.0)
+    if up is None:
+        hw = (64, 64)
+    P = oinit.seeded_state(oinit.unet_simple_param_shapes(64, n_in + n_cond, 3), seed=33)
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(nb, n_in, *hw, generator=g)
+    c = torch.rand(nb, n_cond, *hw, generator=g) if n_cond else None
+    t = torch.tensor([1.0, 6.5, 0.25][:nb])
+    net = mirror_from_params(P, cfg, n_in, n_cond, 3)
+    taps = {}
+    with torch.no_grad():
+        want = nets.unet_simple_forward(P, cfg, x, t, c, taps=taps)
+    got = net(x.to(DEV), time=t.to(DEV), condition=None if c is None else c.to(DEV)).cpu()
+    err = rel_rms(got, want)
+    print("dim64", hw, up, "rel-rms", err)
+    assert err <= TOL
+    # MC dropout, injected masks
+    src = nets.DropoutSeeded(5, record=True)
+    with torch.no_grad():
+        want = nets.unet_simple_forward(P, cfg, x, t, c, dropout=src)
+    got = net._engine.net_forward(0, x.to(DEV), t.to(DEV), None if c is None else c.to(DEV), dropout_mode=2,
+                                  masks=nhwc_masks(src.masks)).cpu()
+    err = rel_rms(got, want)
+    print("dim64 dropout", hw, up, "rel-rms", err)
+    assert err <= TOL
+
+
+def test_mfma_and_direct_engines_agree():
+    import dyffusion_amd as D
+    cfg = dict(dim=64, upsample_dims=[64, 64], outer_sample_mode="bilinear", with_time_emb=True, dropout=0.0)
+    P = oinit.seeded_state(oinit.unet_simple_param_shapes(64, 5, 3), seed=34)
+    g = torch.Generator().manual_seed(8)
+    x, c, t = torch.randn(2, 3, 23, 11, generator=g), torch.rand(2, 2, 23, 11, generator=g), torch.tensor([2.0, 3.0])
+    outs = []
+    for mfma in (True, False):
+        net = mirror_from_params(P, cfg, 3, 2, 3)
+        nc = net.engine_net_config()
+        eng = D.HipEngine(nc, nc, 23, 11, max_batch=2, use_graph=False, enable_mfma=mfma)
+        eng.load_weights(0, net.state_dict())
+        outs.append(eng.net_forward(0, x.to(DEV), t.to(DEV), c.to(DEV)).cpu())
+    assert rel_rms(outs[0], outs[1]) <= 6e-3
+
+
+def test_rows_are_independent():
+    cfg = dict(dim=64, upsample_dims=[64, 64], outer_sample_mode="bilinear", with_time_emb=True, dropout=0.0)
+    P = oinit.seeded_state(oinit.unet_simple_param_shapes(64, 5, 3), seed=35)
+    g = torch.Generator().manual_seed(9)
+    x, c = torch.randn(3, 3, 23, 11, generator=g), torch.rand(3, 2, 23, 11, generator=g)
+    t = torch.tensor([1.0, 2.0, 3.0])
+    net = mirror_from_params(P, cfg, 3, 2, 3)
+    full = net(x.to(DEV), time=t.to(DEV), condition=c.to(DEV)).cpu()
+    for r in range(3):
+        one = net(x[r:r + 1].to(DEV), time=t[r:r + 1].to(DEV), condition=c[r:r + 1].to(DEV)).cpu()
+        assert torch.equal(one[0], full[r]), f"row {r} depends on its batch neighbours"
+
+
+def test_fullsize_ns_forwards_match_reference_fields():
+    """BASELINE config 2 shapes (221x42 -> 256^2, dim 64): one forecaster + one interpolator forward vs the
+    reference's own outputs (fixture G6)."""
+    meta, fields = jload("fullsize_checksums.json"), load_npz("fullsize_ns_fields.npz")
+    mk = meta["model"]
+    PF = oinit.seeded_state(oinit.unet_simple_param_shapes(64, 5, 3), meta["seeds"]["forecaster"])
+    PI = oinit.seeded_state(oinit.unet_simple_param_shapes(64, 8, 3), meta["seeds"]["interpolator"])
+    g = torch.Generator().manual_seed(meta["seeds"]["inputs"])
+    x0 = torch.randn(1, 3, 221, 42, generator=g)
+    c = torch.rand(1, 2, 221, 42, generator=g)
+    F_ = mirror_from_params(PF, mk, 3, 2, 3)
+    I_ = mirror_from_params(PI, mk, 6, 2, 3)
+    yF = F_(x0.to(DEV), time=torch.tensor([3.0], device=DEV), condition=c.to(DEV)).cpu()
+    eF = rel_rms(yF, fields["yF"])
+    # feed the interpolator the REFERENCE's forecaster output so the two checks are independent
+    yI = I_(torch.cat([x0, torch.from_numpy(fields["yF"])], 1).to(DEV), time=torch.tensor([5.0], device=DEV),
+            condition=c.to(DEV)).cpu()
+    eI = rel_rms(yI, fields["yI"])
+    print("fullsize forward rel-rms F", eF, "I", eI)
+    assert eF <= TOL and eI <= TOL

@@ -1,0 +1,113 @@
+"""-m gpu: dyf_sample (HIP, hipGraph) against the reference's golden rollouts and the oracle.
+
+Tolerance (stated): rel-RMS <= 3e-2 per forecast field over a rollout (bf16 activations, fp32 state x_s and fp32
+cold-sampling update); measured values are printed.
+"""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import nets, sampler
+from tests.gpu_common import DEV, build_dyffusion, nhwc_masks, oracle_rollout, seeded_pair
+from tests.helpers import jload, load_npz, rel_rms, split_state
+
+pytestmark = pytest.mark.gpu
+TOL = 3e-2
+
+NAMES = ["sample_cold_refine", "sample_cold_norefine", "sample_naive", "sample_k2_data", "sample_k2_coldlast",
+         "sample_k2_onlydyn", "sample_k2_plus2", "sample_ens3", "sample_dropout", "sample_datanoise", "sample_linear"]
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_rollout_matches_reference_golden(name):
+    """Every G4 fixture: predict() outputs of the imported reference (tiny dim-4 nets -> direct-conv path)."""
+    z = load_npz(name + ".npz")
+    hp = json.loads(str(z["hp"]))
+    PF, PI = split_state(z, "F"), split_state(z, "I")
+    N, B = hp["num_predictions"], hp["B"]
+    x0 = torch.from_numpy(z["x0"]).repeat(N, 1, 1, 1)
+    c = torch.from_numpy(z["c"]).repeat(N, 1, 1, 1)
+    m = build_dyffusion(PF, PI, hp["model"], 4, 1, hp, max_batch=N * B)
+    masks = noise = None
+    if hp.get("enable_interpolator_dropout"):
+        src = nets.DropoutSeeded(hp["dropout_seed"], record=True)
+        oracle_rollout(PF, PI, hp["model"], hp, x0, c, drop=src)
+        masks = nhwc_masks(src.masks)
+    if hp["forward_conditioning"] == "data+noise":
+        gen = torch.Generator().manual_seed(hp["noise_seed"])
+        draws = []
+
+        def nf(t):
+            draws.append(torch.randn(t.shape, generator=gen))
+            return draws[-1]
+
+        oracle_rollout(PF, PI, hp["model"], hp, x0, c, noise_fn=nf)
+        noise = torch.stack(draws, 0).to(DEV)
+    _, got, _ = m.sample_loop(x0.to(DEV), static_condition=c.to(DEV), _masks=masks, _noise=noise)
+    want = {k[len("out::"):]: v for k, v in z.items() if k.startswith("out::")}
+    assert sorted(got) == sorted(want)
+    worst = 0.0
+    for k, w in want.items():
+        g = got[k].cpu().reshape(w.shape)  # (N*B, ...) -> (N, B, ...), ensemble-major
+        worst = max(worst, rel_rms(g, w))
+    print(name, "worst rel-rms", worst)
+    assert worst <= TOL
+
+
+def test_graph_replay_equals_eager_and_is_repeatable():
+    hp = dict(timesteps=4, forward_conditioning="none", interpolate_before_t1=True, schedule="before_t1_only",
+              sampling_type="cold", refine_intermediate_predictions=True, enable_interpolator_dropout=False,
+              num_input_channels=3)
+    mk = dict(dim=64, upsample_dims=[64, 64], outer_sample_mode="bilinear", with_time_emb=True, dropout=0.15)
+    PF, PI = seeded_pair(64, 3, 2)
+    g = torch.Generator().manual_seed(2)
+    x0, c = torch.randn(3, 3, 23, 11, generator=g).to(DEV), torch.rand(3, 2, 23, 11, generator=g).to(DEV)
+    a = build_dyffusion(PF, PI, mk, 3, 2, hp, max_batch=3, use_graph=True)
+    b = build_dyffusion(PF, PI, mk, 3, 2, hp, max_batch=3, use_graph=False)
+    ya1, ya2, yb = a.sample(x0, static_condition=c), a.sample(x0, static_condition=c), b.sample(x0, static_condition=c)
+    for k in yb:
+        assert torch.equal(ya1[k], yb[k]) and torch.equal(ya2[k], yb[k]), k
+    want = oracle_rollout(PF, PI, mk, hp, x0.cpu(), c.cpu())
+    worst = max(rel_rms(ya1[k].cpu(), want[k]) for k in want)
+    print("dim64 h=4 rollout worst rel-rms", worst)
+    assert worst <= TOL
+
+
+def test_fullsize_ns_rollout_matches_reference_fields():
+    """BASELINE config 2 (NS 221x42, h=16, cold, refine, dim 64 @256^2), NB=1, dropout off: t1/t8/t16 fields of the
+    imported reference (fixture G6)."""
+    meta, fields = jload("fullsize_checksums.json"), load_npz("fullsize_ns_fields.npz")
+    mk = meta["model"]
+    PF, PI = seeded_pair(64, 3, 2, seeds=(meta["seeds"]["forecaster"], meta["seeds"]["interpolator"]))
+    g = torch.Generator().manual_seed(meta["seeds"]["inputs"])
+    x0 = torch.randn(1, 3, 221, 42, generator=g)
+    c = torch.rand(1, 2, 221, 42, generator=g)
+    hp = dict(timesteps=16, forward_conditioning="none", interpolate_before_t1=True, schedule="before_t1_only",
+              sampling_type="cold", refine_intermediate_predictions=True, enable_interpolator_dropout=False)
+    m = build_dyffusion(PF, PI, mk, 3, 2, hp, max_batch=2)
+    out = m.sample(x0.to(DEV), static_condition=c.to(DEV))
+    assert sorted(out) == sorted(meta["rollout"])
+    errs = {k: rel_rms(out[f"{k}_preds"].cpu(), fields[k]) for k in ("t1", "t8", "t16")}
+    print("fullsize rollout rel-rms", errs)
+    assert max(errs.values()) <= TOL
+    for k, want in meta["rollout"].items():
+        assert abs(float(out[k].mean()) - want["mean"]) <= 0.02 * max(1.0, want["std"]), k
+
+
+def test_ensemble_rows_and_batch_split_invariance():
+    """Ensemble members are independent batch rows: sampling rows [0:2] and [2:4] separately gives the
+    same fields as sampling all four at once (dropout off)."""
+    hp = dict(timesteps=4, forward_conditioning="none", interpolate_before_t1=True, sampling_type="cold",
+              refine_intermediate_predictions=True, enable_interpolator_dropout=False)
+    mk = dict(dim=64, upsample_dims=[64, 64], outer_sample_mode="bilinear", with_time_emb=True, dropout=0.1)
+    PF, PI = seeded_pair(64, 3, 2)
+    g = torch.Generator().manual_seed(3)
+    x0, c = torch.randn(4, 3, 23, 11, generator=g).to(DEV), torch.rand(4, 2, 23, 11, generator=g).to(DEV)
+    m = build_dyffusion(PF, PI, mk, 3, 2, hp, max_batch=4)
+    full = {k: v.clone() for k, v in m.sample(x0, static_condition=c).items()}
+    lo = {k: v.clone() for k, v in m.sample(x0[:2], static_condition=c[:2]).items()}
+    hi = m.sample(x0[2:], static_condition=c[2:])
+    for k in full:
+        assert torch.equal(full[k][:2], lo[k]) and torch.equal(full[k][2:], hi[k]), k

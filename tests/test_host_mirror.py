@@ -1,0 +1,105 @@
+"""CPU checks of the host side: state_dict compatibility, schedule logic vs the reference goldens, the C-ABI
+library's exported symbols, and that the product path refuses to run without the HIP engine / a GPU."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+import dyffusion_amd as D
+from dyffusion_amd import _lib
+from oracle import init as oinit
+from tests.helpers import jload
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+def test_mirror_state_dict_matches_reference_layout():
+    for dim, cin, ccond, cout in [(64, 3, 2, 3), (64, 6, 2, 3), (8, 4, 1, 4)]:
+        net = D.UNet(dim=dim, with_time_emb=True, upsample_dims=[64, 64], dropout=0.1, num_input_channels=cin,
+                     num_output_channels=cout, num_conditional_channels=ccond)
+        want = oinit.unet_simple_param_shapes(dim, cin + ccond, cout)  # verified == reference in make_golden.py
+        got = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+        assert got == {k: tuple(v) for k, v in want.items()}
+
+
+def _pair(h, **kw):
+    F = D.UNet(dim=8, with_time_emb=True, upsample_dims=[64, 64], num_input_channels=4, num_output_channels=4,
+               num_conditional_channels=1)
+    I = D.UNet(dim=8, with_time_emb=True, upsample_dims=[64, 64], num_input_channels=8, num_output_channels=4,
+               num_conditional_channels=1)
+    return D.DYffusion(F, D.InterpolatorHandle(I, h), timesteps=h, forward_conditioning="none", **kw)
+
+
+@pytest.mark.parametrize("case", jload("schedules.json"),
+                         ids=lambda c: f"{c['schedule']}-h{c['h']}-k{c['k']}-f{c['fac']}-b{int(c['before_t1'])}")
+def test_product_schedule_logic_matches_reference(case):
+    m = _pair(case["h"], schedule=case["schedule"], additional_interpolation_steps=case["k"],
+              additional_interpolation_steps_factor=case["fac"], interpolate_before_t1=case["before_t1"])
+    assert m.num_timesteps == case["num_timesteps"]
+    for d, i in case["d_to_i"].items():
+        assert float(m.diffusion_step_to_interpolation_step(int(d))) == pytest.approx(i, abs=1e-12)
+        ti = float(m.diffusion_step_to_interpolation_step(torch.tensor(float(d))))
+        assert ti == pytest.approx(i, abs=4e-6)  # the reference's own float-vs-tensor self check (dyffusion.py:75-80)
+    assert {str(k) for k in m.dynamical_steps} == set(case["dynamical_steps"])
+    for name, want in case["schedules"].items():
+        spec = m.full_sampling_schedule if name == "None" else name
+        if not want["ok"]:
+            with pytest.raises((AssertionError, ValueError, IndexError)):
+                m.sampling_schedule = spec
+            continue
+        m.sampling_schedule = spec
+        assert [float(s) for s in m.sampling_schedule] == pytest.approx(want["steps"], abs=1e-12), name
+
+
+def test_plan_resolution_ns_config():
+    F = D.UNet(dim=64, with_time_emb=True, num_input_channels=3, num_output_channels=3, num_conditional_channels=2)
+    I = D.UNet(dim=64, with_time_emb=True, num_input_channels=6, num_output_channels=3, num_conditional_channels=2)
+    m = D.DYffusion(F, D.InterpolatorHandle(I, 16), timesteps=16, forward_conditioning="none",
+                    interpolate_before_t1=True, refine_intermediate_predictions=True)
+    steps, refine, n_slots = m._build_plan()
+    assert n_slots == 16 and len(steps) == 16 and len(refine) == 15
+    n_i = sum(s["i_next"] is not None for s in steps) + sum(s["i_cur"] is not None and not s["is_last"] for s in steps)
+    assert n_i + len(refine) == 44  # 16 forecaster + 44 interpolator forwards
+    assert [s["out_slot"] for s in steps] == list(range(16))
+
+
+def test_invalid_arguments_raise_like_reference():
+    with pytest.raises(AssertionError):
+        _pair(1, interpolate_before_t1=True)
+    with pytest.raises(AssertionError):
+        _pair(4, interpolate_before_t1=False)
+    with pytest.raises(ValueError):
+        _pair(4, schedule="cosine", interpolate_before_t1=True)
+    with pytest.raises(ValueError):
+        F = D.UNet(dim=8, with_time_emb=True, num_input_channels=4, num_output_channels=4)
+        D.DYffusion(F, D.InterpolatorHandle(F, 7), timesteps=4, interpolate_before_t1=True)  # horizon mismatch
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "dyffusion_hip.h")).read()
+    declared = set(re.findall(r"\b(dyf_[a-z0-9_]+)\s*\(", hdr))
+    assert {"dyf_engine_create", "dyf_sample", "dyf_net_forward", "dyf_load_weights"} <= declared
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in include/dyffusion_hip.h but not exported"
+    assert {n for n, _, _ in _lib.SYMBOLS} == declared, "ctypes binding table out of sync with the header"
+    assert lib.dyf_abi_version() == _lib.DYF_ABI_VERSION
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
+def test_product_path_fails_loudly_without_gpu():
+    m = _pair(4, interpolate_before_t1=True)
+    with pytest.raises(D.EngineError):
+        m.sample(torch.zeros(1, 4, 10, 10), static_condition=torch.zeros(1, 1, 10, 10))
+    with pytest.raises(D.EngineError):
+        m.model(torch.zeros(1, 4, 10, 10), time=torch.zeros(1), condition=torch.zeros(1, 1, 10, 10))
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "dyffusion_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg, fn)).read()
+            assert "oracle" not in src.replace("the oracle", ""), f"{fn} references the oracle package"
