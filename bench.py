@@ -52,6 +52,14 @@ def random_state(net, seed):
     return sd
 
 
+_T0 = time.perf_counter()
+
+
+def log(msg):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(f"[bench +{time.perf_counter() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
 def build_model(nb, use_graph=True):
     import dyffusion_amd as D
 
@@ -68,7 +76,8 @@ def cpu_baseline(F, I):
     reference through tests/golden) runs the SAME workload at NB=1, MC dropout on.  Bounded sample: one rollout."""
     from oracle import nets, sampler
 
-    torch.set_num_threads(os.cpu_count() or 1)
+    # small-tensor ATen ops stop scaling (and bernoulli_/mkldnn oversubscribe) far below 256 threads: cap, and report it
+    torch.set_num_threads(min(os.cpu_count() or 1, int(os.environ.get("DYF_CPU_THREADS", "32"))))
     PF = {k: v.float() for k, v in F.state_dict().items()}
     PI = {k: v.float() for k, v in I.state_dict().items()}
     cfg = dict(DIFFUSION_KW, num_input_channels=C)
@@ -83,7 +92,9 @@ def cpu_baseline(F, I):
         return nets.unet_simple_forward(PI, MODEL_KW, x, t, cond, dropout=drop)
 
     with torch.no_grad():
+        tw = time.perf_counter()
         f_fn(x0, torch.ones(1), c)  # warm-up (thread pool, mkldnn primitives)
+        log(f"cpu baseline warm-up forward {time.perf_counter() - tw:.2f} s on {torch.get_num_threads()} threads")
         reps, t0 = 0, time.perf_counter()
         while reps < 1 or (time.perf_counter() - t0 < 8.0 and reps < 3):
             sampler.sample_loop(f_fn, i_fn, x0, c, cfg)
@@ -119,7 +130,9 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     nb = args.nb
+    log(f"building model, nb={nb}")
     model, F, I = build_model(nb, use_graph=not args.no_graph)
+    log("model built")
     g = torch.Generator().manual_seed(100 + rank)
     x0 = torch.randn(nb, C, H, W, generator=g).to(dev)
     static = torch.rand(nb, CS, H, W, generator=g).to(dev)
@@ -133,8 +146,11 @@ def main():
         return preds
 
     model._ensure_engine((H, W), nb).seed(2 + rank)
+    log("engine created, weights uploaded")
     for _ in range(args.warmup):
         step()
+        torch.cuda.synchronize()
+        log("warm-up step done")
 
     def fence():
         torch.cuda.synchronize()
@@ -148,6 +164,7 @@ def main():
         preds = step()
     fence()
     dt = time.perf_counter() - t0
+    log(f"timed region done: {dt:.3f} s for {args.steps} steps")
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -172,6 +189,7 @@ def main():
         # roofline of the dominant kernel: the last decoder block's 3x3 conv (256 -> 64 ch @256^2, 40 % of a forward),
         # conv_igemm_kernel<256,64,4,1>; HIP events on the launch stream, operands = live workspace activations
         ms, fl, by = eng.time_conv_layer(1, 11, nb, iters=10)
+        log(f"dec5 conv: {ms:.3f} ms per launch")
         result["roofline"] = {"bound": "mfma", "kernel": "conv_igemm_kernel<256,64,4,1> (dec5: 3x3, 256->64 ch @256^2)",
                               "achieved": round(fl / ms / 1e9, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                               "frac": round(fl / ms / 1e9 / PEAK_BF16_TFLOPS, 4), "avg_ms": round(ms, 4),

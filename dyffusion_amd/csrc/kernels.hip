@@ -328,10 +328,80 @@ __global__ __launch_bounds__(256) void readout_kernel(ReadoutArgs a) {
         if (co < a.cout) a.out[(((size_t)n * a.cout + co) * a.oh + oy) * a.ow + ox] = acc[co] + a.bias[co];
 }
 
+// Fast form for cin % 8 == 0 with cin/8 a power of two: LANES = cin/8 lanes share one native pixel, each owns an
+// 8-channel slice, so every tap is ONE 16-B load per lane (a full 128-B line per pixel for dim 64) instead of 64
+// scattered 2-B loads; partial sums are combined with a butterfly over the LANES lanes.
+template <int LANES>
+__global__ __launch_bounds__(256) void readout_sliced_kernel(ReadoutArgs a) {
+    extern __shared__ float wsh[];  // [16][cin][cout]
+    const int wcount = 16 * a.cin * a.cout;
+    for (int i = threadIdx.x; i < wcount; i += blockDim.x) wsh[i] = a.wgt[i];
+    __syncthreads();
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long total = (long long)a.n * a.oh * a.ow;
+    long long idx = gid / LANES;
+    const int slice = (int)(gid % LANES);
+    const bool live = idx < total;
+    if (!live) idx = total - 1;  // keep the whole wave in the shuffles
+    const int n = (int)(idx / ((long long)a.oh * a.ow));
+    const int rem = (int)(idx % ((long long)a.oh * a.ow));
+    const int oy = rem / a.ow, ox = rem % a.ow;
+    const int th = 2 * a.ih, tw = 2 * a.iw;
+    int u0, u1, v0, v1;
+    float lu, lv;
+    bilinear_coord(oy, (float)th / (float)a.oh, th, u0, u1, lu);
+    bilinear_coord(ox, (float)tw / (float)a.ow, tw, v0, v1, lv);
+    float acc[DYF_MAX_OUT_CH];
+#pragma unroll
+    for (int c = 0; c < DYF_MAX_OUT_CH; ++c) acc[c] = 0.0f;
+    const int ci0 = slice * 8;
+#pragma unroll
+    for (int nb4 = 0; nb4 < 4; ++nb4) {
+        const int u = (nb4 & 2) ? u1 : u0, v = (nb4 & 1) ? v1 : v0;
+        const float bw = ((nb4 & 2) ? lu : 1.0f - lu) * ((nb4 & 1) ? lv : 1.0f - lv);
+        const int i_hi = (u + 1) >> 1, j_hi = (v + 1) >> 1;
+#pragma unroll
+        for (int t4 = 0; t4 < 4; ++t4) {
+            const int i = i_hi - (t4 >> 1), j = j_hi - (t4 & 1);
+            const int kh = u + 1 - 2 * i, kw = v + 1 - 2 * j;
+            if ((unsigned)i < (unsigned)a.ih && (unsigned)j < (unsigned)a.iw) {
+                const uint4 q = *(const uint4*)(a.x + (((size_t)n * a.ih + i) * a.iw + j) * a.cin + ci0);
+                const uint32_t qw[4] = {q.x, q.y, q.z, q.w};
+                const float* wt = wsh + ((size_t)(kh * 4 + kw) * a.cin + ci0) * a.cout;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const float xv = bw * ((c & 1) ? __uint_as_float(qw[c >> 1] & 0xffff0000u)
+                                                   : __uint_as_float(qw[c >> 1] << 16));
+#pragma unroll
+                    for (int co = 0; co < DYF_MAX_OUT_CH; ++co)
+                        if (co < a.cout) acc[co] = fmaf(xv, wt[c * a.cout + co], acc[co]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int co = 0; co < DYF_MAX_OUT_CH; ++co) {
+        if (co < a.cout) {
+            float v = acc[co];
+#pragma unroll
+            for (int off = LANES >> 1; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+            if (live && slice == 0) a.out[(((size_t)n * a.cout + co) * a.oh + oy) * a.ow + ox] = v + a.bias[co];
+        }
+    }
+}
+
 hipError_t launch_readout(const ReadoutArgs& a, hipStream_t s) {
     const long long total = (long long)a.n * a.oh * a.ow;
-    hipLaunchKernelGGL(readout_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256),
-                       (size_t)16 * a.cin * a.cout * sizeof(float), s, a);
+    const size_t lds = (size_t)16 * a.cin * a.cout * sizeof(float);
+    const int lanes = (a.cin % 8 == 0) ? a.cin / 8 : 0;
+#define RO_CASE(L)                                                                                                   \
+    if (lanes == L) {                                                                                                \
+        hipLaunchKernelGGL(readout_sliced_kernel<L>, dim3((unsigned)((total * L + 255) / 256)), dim3(256), lds, s, a); \
+        return hipGetLastError();                                                                                    \
+    }
+    RO_CASE(1) RO_CASE(2) RO_CASE(4) RO_CASE(8) RO_CASE(16)
+#undef RO_CASE
+    hipLaunchKernelGGL(readout_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), lds, s, a);
     return hipGetLastError();
 }
 

@@ -40,7 +40,7 @@ def sample_loop(forecaster: NetFn, interpolator: NetFn, x_init: Tensor, static_c
     noise_fn = noise_fn or torch.randn_like
     assert x_init.dim() == 4, f"condition.shape: {x_init.shape} (should be 4D)"
     nb = x_init.shape[0]
-    C = cfg["num_input_channels"]
+    C = cfg.get("num_input_channels") or x_init.shape[1]  # window == 1 unless stated
 
     def full(v):
         return torch.full((nb,), float(v), dtype=torch.float32)
