@@ -18,6 +18,8 @@
 //     the 3x3 / 4x4 halo re-reads of neighbouring tiles hit that XCD's own L2.
 #include "conv.h"
 
+#include <cstdlib>
+
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
@@ -75,9 +77,15 @@ __global__ void conv_direct_kernel(ConvArgs a, long long total) {
 }
 
 // ------------------------------------------------------------------------------------------------ MFMA kernel
-template <int BM, int BN, int WM, int WN>
+// Gather addressing: every A row a lane fetches is described by a 32-bit byte offset of its window origin
+// (n, oy*stride-pad, ox*stride-pad) in each source plus a bit mask of the taps that fall inside the image.  Per K
+// step the lane adds one wave-uniform (tap, chunk) byte offset and selects "out of range" for padded taps: the
+// LDS-DMA is a raw buffer load (buffer_load_dwordx4 ... offen lds), whose bounds check returns zeros for offsets
+// beyond num_records, so the zero padding costs no memory traffic and ~4 VALU instructions per row.
+template <int BM, int BN, int WM, int WN, int SPLIT>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a, int M, int tiles_m, int tiles_n) {
     static_assert(WM * WN == 4 && BM / WM == 64 && BN / WN == 64, "4 waves, 64x64 accumulator each");
+#if defined(__HIP_DEVICE_COMPILE__)  // buffer-resource builtins only exist in the device pass
     constexpr int A_BYTES = BM * 128;
     constexpr int B_BYTES = BN * 128;
     constexpr int STAGE = A_BYTES + B_BYTES;
@@ -100,69 +108,104 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a, int M, i
 
     const int cin = a.c0 + a.c1;
     const int cpt = cin >> 6;                 // 64-channel chunks per tap
-    const int nk = a.kh * a.kw * cpt;         // K steps
+    const int ntaps = a.kh * a.kw;
+    const int nk = ntaps * cpt;               // K steps
     const int howo = a.ho * a.wo;
+    // 2-D tiling when the output plane divides into (BM/16) x 16 tiles; otherwise BM consecutive raster pixels
+    const bool tile2d = (a.wo % 16 == 0) && (a.ho % (BM / 16) == 0);
+    const int tiles_x = a.wo >> 4, tiles_per_img = tile2d ? tiles_x * (a.ho / (BM / 16)) : 1;
     const int sub = lane >> 3;                // row inside an 8-row DMA group
-    const int gchunk = (lane & 7) ^ sub;      // swizzled SOURCE chunk for this lane's linear LDS slot
+    // LDS swizzle key of a tile row r is (r >> 1) & 7: a ds_read_b128 lane group covers 16 rows whose 128-B rows
+    // alternate between the two halves of the 256-B bank row, so the key must change every SECOND row to spread the
+    // group over all 16 16-B slots (conflict-free; key r & 7 is 2-way).  DMA rows are (j*4+wave)*8 + sub.
+    const int gchunk = (lane & 7) ^ ((((wave & 1) << 2) | (sub >> 1)) & 7);  // swizzled SOURCE chunk of this lane's slot
+
+    const size_t npix = (size_t)a.n * a.h * a.w;
+    const auto rsrc_a0 = __builtin_amdgcn_make_buffer_rsrc((void*)a.src0, 0, (int)(unsigned)(npix * a.c0 * 2), 0x00020000);
+    const auto rsrc_a1 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.c1 ? a.src1 : a.src0), 0,
+                                                           (int)(unsigned)(npix * (a.c1 ? a.c1 : a.c0) * 2), 0x00020000);
+    const auto rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void*)a.wpk, 0, (int)(unsigned)((size_t)a.cout * nk * 128), 0x00020000);
 
     // ---- per-lane gather descriptors for the A rows this lane fetches
-    int a_iy0[RA], a_ix0[RA], a_pix0[RA];
+    unsigned a_off0[RA], a_off1[RA], a_mask[RA];
 #pragma unroll
     for (int j = 0; j < RA; ++j) {
         const int row = (j * 4 + wave) * 8 + sub;
         const int m = tm * BM + row;
+        unsigned mask = 0;
+        int pix = 0;
         if (m < M) {
-            const int n_img = m / howo;
-            const int rem = m - n_img * howo;
-            const int oy = rem / a.wo, ox = rem - oy * a.wo;
-            a_iy0[j] = oy * a.stride - a.pad;
-            a_ix0[j] = ox * a.stride - a.pad;
-            a_pix0[j] = n_img * a.h * a.w;
-        } else {
-            a_iy0[j] = -(1 << 28);  // never in range: tile rows past M read the zero page
-            a_ix0[j] = 0;
-            a_pix0[j] = 0;
+            int n_img, oy, ox;
+            if (tile2d) {  // 16-pixel-wide 2-D tile: the taps of one tile re-read a (TH+k-1) x (16+k-1) window from L2
+                n_img = tm / tiles_per_img;
+                const int t = tm - n_img * tiles_per_img;
+                oy = (t / tiles_x) * (BM / 16) + (row >> 4);
+                ox = (t % tiles_x) * 16 + (row & 15);
+            } else {
+                n_img = m / howo;
+                const int rem = m - n_img * howo;
+                oy = rem / a.wo;
+                ox = rem - oy * a.wo;
+            }
+            const int iy0 = oy * a.stride - a.pad, ix0 = ox * a.stride - a.pad;
+            pix = (n_img * a.h + iy0) * a.w + ix0;  // may be "negative": only ever used together with a valid tap
+            // taps inside the image: ky in [ylo, yhi), kx in [xlo, xhi) -> bit (ky*kw + kx)
+            const int ylo = max(0, -iy0), yhi = min(a.kh, a.h - iy0);
+            const int xlo = max(0, -ix0), xhi = min(a.kw, a.w - ix0);
+            const unsigned ym = yhi > ylo ? (1u << yhi) - (1u << ylo) : 0u;
+            const unsigned xm = xhi > xlo ? (1u << xhi) - (1u << xlo) : 0u;
+            for (int ky = 0; ky < a.kh; ++ky) mask |= (((ym >> ky) & 1u) ? xm : 0u) << (ky * a.kw);
         }
+        a_mask[j] = mask;
+        a_off0[j] = (unsigned)pix * (unsigned)(a.c0 * 2) + gchunk * 16;
+        a_off1[j] = (unsigned)pix * (unsigned)(a.c1 * 2) + gchunk * 16;
     }
     // B rows: row r of the tile is output channel tn*BN + r; consecutive K steps are consecutive 128-B segments
-    const char* b_src[RB];
+    unsigned b_off[RB];
 #pragma unroll
     for (int j = 0; j < RB; ++j) {
         const int row = (j * 4 + wave) * 8 + sub;
-        b_src[j] = (const char*)(a.wpk + (size_t)(tn * BN + row) * nk * 64) + gchunk * 16;
+        b_off[j] = (unsigned)(tn * BN + row) * (unsigned)(nk * 128) + gchunk * 16;
     }
-    const char* zero_src = (const char*)a.zero_page + gchunk * 16;
 
-    // issue-side K-step state (uniform)
+    // issue-side K-step state (wave-uniform)
     int is_ky = 0, is_kx = 0, is_chunk = 0;
 
-    auto issue = [&](int stage, int kstep) {
+    // issue the DMA of A slots [j0, j1) and B slots [jb0, jb1) of K step `is_step` into `stage`
+    auto issue_part = [&](int stage, int part) {
         char* As = smem + stage * STAGE;
         char* Bs = As + A_BYTES;
         const int cb = is_chunk << 6;
         const bool second = cb >= a.c0;
-        const bf16_t* src = second ? a.src1 : a.src0;
         const int csrc = second ? a.c1 : a.c0;
         const int coff = second ? cb - a.c0 : cb;
+        const unsigned step_off = (unsigned)(((is_ky * a.w + is_kx) * csrc + coff) * 2);
+        const unsigned tap_bit = 1u << (is_ky * a.kw + is_kx);
 #pragma unroll
         for (int j = 0; j < RA; ++j) {
-            const int iy = a_iy0[j] + is_ky, ix = a_ix0[j] + is_kx;
-            const bool ok = (unsigned)iy < (unsigned)a.h && (unsigned)ix < (unsigned)a.w;
-            const long long pix = (long long)a_pix0[j] + iy * a.w + ix;
-            const char* g = ok ? (const char*)(src + (pix * csrc + coff)) + gchunk * 16 : zero_src;
-            __builtin_amdgcn_global_load_lds(GLB_PTR(g), LDS_PTR(As + (j * 4 + wave) * 1024), 16, 0, 0);
+            if (j % SPLIT != part) continue;
+            const unsigned base = second ? a_off1[j] : a_off0[j];
+            const unsigned vo = (a_mask[j] & tap_bit) ? base + step_off : 0xFFFFFFFFu;
+            if (second)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a1, LDS_PTR(As + (j * 4 + wave) * 1024), 16, vo, 0, 0, 0);
+            else
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a0, LDS_PTR(As + (j * 4 + wave) * 1024), 16, vo, 0, 0, 0);
         }
 #pragma unroll
         for (int j = 0; j < RB; ++j) {
-            __builtin_amdgcn_global_load_lds(GLB_PTR(b_src[j] + (size_t)kstep * 128), LDS_PTR(Bs + (j * 4 + wave) * 1024),
-                                             16, 0, 0);
+            if (j % SPLIT != part) continue;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, LDS_PTR(Bs + (j * 4 + wave) * 1024), 16, b_off[j],
+                                                     ((is_ky * a.kw + is_kx) * cpt + is_chunk) * 128, 0, 0);
         }
-        // advance (chunk fastest, then kx, then ky): matches the [tap][cin] order of the packed weights
-        if (++is_chunk == cpt) {
-            is_chunk = 0;
-            if (++is_kx == a.kw) {
-                is_kx = 0;
-                ++is_ky;
+    };
+    // K order: kx fastest, then ky, then the 64-channel chunk -- all taps of one chunk are consecutive, so a tile's
+    // input window for that chunk (a few tens of KB) is fetched from HBM once and re-read from L2 by the other taps
+    auto issue_advance = [&]() {
+        if (++is_kx == a.kw) {
+            is_kx = 0;
+            if (++is_ky == a.kh) {
+                is_ky = 0;
+                ++is_chunk;
             }
         }
     };
@@ -175,21 +218,30 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a, int M, i
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    // fragment read offsets: row*128 + ((k16*2 + (lane>>5)) ^ (row & 7)) * 16 ; row & 7 == lane & 7 for every fragment
-    const int l31 = lane & 31, hi = lane >> 5, l7 = lane & 7;
+    // fragment read offsets: row*128 + ((k16*2 + (lane>>5)) ^ ((row>>1) & 7)) * 16 ; fragment rows are 32-aligned + (lane&31)
+    const int l31 = lane & 31, hi = lane >> 5, l7 = (lane >> 1) & 7;
     const int a_row_off = (wm * 64 + l31) * 128;
     const int b_row_off = (wn * 64 + l31) * 128;
 
-    issue(0, 0);
+#pragma unroll
+    for (int p = 0; p < SPLIT; ++p) issue_part(0, p);
+    issue_advance();
     for (int k = 0; k < nk; ++k) {
         const int cur = k & 1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (k + 1 < nk) issue(cur ^ 1, k + 1);
+        const bool more = k + 1 < nk;
         const char* As = smem + cur * STAGE;
         const char* Bs = As + A_BYTES;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
+            // next step's DMA is spread over the four k16 sub-steps so its address VALU hides under the MFMAs
+            if (more && (SPLIT == 4 || ks == 0)) {
+                if (SPLIT == 4) issue_part(cur ^ 1, ks);
+                else
+#pragma unroll
+                    for (int p = 0; p < SPLIT; ++p) issue_part(cur ^ 1, p);
+            }
             const int coff = (((ks * 2 + hi) ^ l7) << 4);
             bf16x8 af[2], bfr[2];
 #pragma unroll
@@ -202,6 +254,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a, int M, i
                 for (int j = 0; j < 2; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
         }
+        if (more) issue_advance();
     }
 
     // ---- epilogue: accumulators -> LDS fp32 tile [BM][BN] -> affine/act/dropout -> coalesced NHWC stores
@@ -224,12 +277,20 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a, int M, i
     for (int it = 0; it < (BM * CG) / 256; ++it) {
         const int id = it * 256 + tid;
         const int row = id / CG, cg = id % CG;
-        const int m = tm * BM + row;
-        if (m >= M) continue;
+        if (tm * BM + row >= M) continue;
+        int m, n_img;
+        if (tile2d) {
+            n_img = tm / tiles_per_img;
+            const int t = tm - n_img * tiles_per_img;
+            m = (n_img * a.ho + (t / tiles_x) * (BM / 16) + (row >> 4)) * a.wo + (t % tiles_x) * 16 + (row & 15);
+        } else {
+            m = tm * BM + row;
+            n_img = m / howo;
+        }
         const int co = tn * BN + cg * 8;
         const float4 v0 = *(const float4*)(Ct + row * BN + cg * 8);
         const float4 v1 = *(const float4*)(Ct + row * BN + cg * 8 + 4);
-        const size_t ci = (size_t)(m / howo) * a.coef_stride + co;
+        const size_t ci = (size_t)n_img * a.coef_stride + co;
         const float4 a0 = *(const float4*)(a.coef_a + ci), a1 = *(const float4*)(a.coef_a + ci + 4);
         const float4 c0 = *(const float4*)(a.coef_c + ci), c1 = *(const float4*)(a.coef_c + ci + 4);
         float v[8] = {fmaf(v0.x, a0.x, c0.x), fmaf(v0.y, a0.y, c0.y), fmaf(v0.z, a0.z, c0.z), fmaf(v0.w, a0.w, c0.w),
@@ -254,36 +315,46 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a, int M, i
             *(float4*)(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
         }
     }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------ launchers
 bool conv_mfma_supported(const ConvArgs& a) {
-    return a.c0 > 0 && (a.c0 % 64) == 0 && (a.c1 % 64) == 0 && (a.cout % 64) == 0 && a.zero_page != nullptr;
+    if (!(a.c0 > 0 && (a.c0 % 64) == 0 && (a.c1 % 64) == 0 && (a.cout % 64) == 0)) return false;
+    if (a.kh * a.kw > 32) return false;                       // tap-validity mask is 32 bits
+    const size_t npix = (size_t)a.n * a.h * a.w;              // 32-bit buffer offsets
+    const size_t lim = 0xFFFFFFF0ull;
+    return npix * a.c0 * 2 < lim && npix * (size_t)a.c1 * 2 < lim && (size_t)a.cout * a.kh * a.kw * (a.c0 + a.c1) * 2 < lim;
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int SPLIT>
 static hipError_t launch_igemm(const ConvArgs& a, hipStream_t stream) {
     constexpr int lds = 2 * (BM + BN) * 128;
     const long long M = (long long)a.n * a.ho * a.wo;
     const int tiles_m = (int)((M + BM - 1) / BM), tiles_n = a.cout / BN;
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN>), dim3(tiles_m * tiles_n), dim3(256), lds, stream, a, (int)M,
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, SPLIT>), dim3(tiles_m * tiles_n), dim3(256), lds, stream, a, (int)M,
                        tiles_m, tiles_n);
     return hipGetLastError();
 }
 
 // Raise the dynamic-LDS cap of the MFMA kernels once per process (not legal inside a stream capture).
 hipError_t conv_init() {
-    hipError_t e = hipFuncSetAttribute((const void*)conv_igemm_kernel<128, 128, 2, 2>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 + 128) * 128);
-    if (e != hipSuccess) return e;
-    return hipFuncSetAttribute((const void*)conv_igemm_kernel<256, 64, 4, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                               2 * (256 + 64) * 128);
+    hipError_t e = hipSuccess;
+#define SET_LDS(BM, BN, WM, WN, SP)                                                                     \
+    if (e == hipSuccess)                                                                                \
+        e = hipFuncSetAttribute((const void*)conv_igemm_kernel<BM, BN, WM, WN, SP>,                     \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (BM + BN) * 128);
+    SET_LDS(128, 128, 2, 2, 1) SET_LDS(128, 128, 2, 2, 4) SET_LDS(256, 64, 4, 1, 1) SET_LDS(256, 64, 4, 1, 4)
+#undef SET_LDS
+    return e;
 }
 
 hipError_t launch_conv(const ConvArgs& a, int path, hipStream_t stream) {
     if (path == 1 && conv_mfma_supported(a)) {
-        if (a.cout % 128 == 0) return launch_igemm<128, 128, 2, 2>(a, stream);
-        return launch_igemm<256, 64, 4, 1>(a, stream);
+        static const int split = getenv("DYF_CONV_SPLIT") ? atoi(getenv("DYF_CONV_SPLIT")) : 1;
+        if (a.cout % 128 == 0)
+            return split == 4 ? launch_igemm<128, 128, 2, 2, 4>(a, stream) : launch_igemm<128, 128, 2, 2, 1>(a, stream);
+        return split == 4 ? launch_igemm<256, 64, 4, 1, 4>(a, stream) : launch_igemm<256, 64, 4, 1, 1>(a, stream);
     }
     const long long total = (long long)a.n * a.ho * a.wo * a.cout;
     const int threads = 256;
