@@ -12,6 +12,10 @@ struct ConvArgs {
     int kh, kw, stride, pad;
     int cout;
     const bf16_t* wpk;   // packed weights [cout][kh*kw][c0+c1] bf16
+    // fused x2 bilinear upsample in front of a 3x3/s1/p1 conv: sources are the LOW-res tensors (h, w), output is
+    // (2h, 2w); wpk_up holds the phase-decomposed weights [4][cout][16][c0+c1] (pack_up2x_weights)
+    int up2x;
+    const bf16_t* wpk_up;
     // epilogue: v = acc * A[row*coef_stride + co] + C[row*coef_stride + co]; row = sample index (coef_stride may be 0
     // to broadcast one row); conv bias, eval-BatchNorm and FiLM (x*(scale+1)+shift) are all folded into A and C.
     const float* coef_a;
@@ -28,3 +32,4 @@ struct ConvArgs {
 hipError_t conv_init();
 bool conv_mfma_supported(const ConvArgs& a);
 hipError_t launch_conv(const ConvArgs& a, int path, hipStream_t stream);
+void pack_up2x_weights(const float* w, int cout, int cin, bf16_t* out);

@@ -82,7 +82,24 @@ __global__ void conv_direct_kernel(ConvArgs a, long long total) {
 // step the lane adds one wave-uniform (tap, chunk) byte offset and selects "out of range" for padded taps: the
 // LDS-DMA is a raw buffer load (buffer_load_dwordx4 ... offen lds), whose bounds check returns zeros for offsets
 // beyond num_records, so the zero padding costs no memory traffic and ~4 VALU instructions per row.
-template <int BM, int BN, int WM, int WN, int SPLIT>
+//
+// UP = 1: nn.Upsample(scale_factor=2, bilinear) + Conv2d(3x3, pad 1) of a decoder block (unet_simple.py:40-52) fused
+// by PHASE DECOMPOSITION.  Output pixel (2i+py, 2j+px) is a 3x3 stencil over the LOW-res pixels (i+a, j+b) with
+// weights that are fixed linear combinations of the 3x3 kernel (host: pack_up2x_weights); replicate-clamping the tap
+// coordinates reproduces the edge behaviour of align_corners=False.  What clamping cannot express is the conv's ZERO
+// padding of the upsampled image (up[-1] = 0 while the clamped stencil yields in[0]); it is repaired by extra
+// "correction taps" that only the first/last output row/column see: -w[ky=0,:] on the border row, -w[:,kx=0] on the
+// border column and +w[0,0] on the corner (inclusion/exclusion).  Per phase the packed K axis therefore has 16 taps:
+// 0-8 stencil, 9-11 row correction, 12-14 column correction, 15 corner; tiles that touch no border skip 9-15.
+// The upsampled tensor (4x the bytes of its input) is never materialised and the FLOP count equals the direct conv's.
+struct StepInfo {       // wave-uniform description of the K step being issued
+    int dy, dx;         // tap displacement in input pixels
+    unsigned need;      // UP: border flags a row must have for this tap to contribute
+    unsigned tap_bit;   // !UP: bit of this tap in the row's validity mask
+    int wslot;          // index of the tap on the packed-weight K axis
+};
+
+template <int BM, int BN, int WM, int WN, int UP>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a, int M, int tiles_m, int tiles_n) {
     static_assert(WM * WN == 4 && BM / WM == 64 && BN / WN == 64, "4 waves, 64x64 accumulator each");
 #if defined(__HIP_DEVICE_COMPILE__)  // buffer-resource builtins only exist in the device pass
@@ -91,6 +108,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a, int M, i
     constexpr int STAGE = A_BYTES + B_BYTES;
     constexpr int RA = BM / 32;  // A rows gathered per lane per K step
     constexpr int RB = BN / 32;
+    constexpr int TH = BM / 16;  // 2-D tile: TH rows of 16 pixels
     static_assert(2 * STAGE >= BM * BN * 4, "epilogue tile must fit in the staging buffers");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -104,16 +122,24 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a, int M, i
     const int bid = blockIdx.x;
     const int xq = total >> 3, xr = total & 7, xcd = bid & 7;
     const int tile = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
-    const int tn = tile % tiles_n, tm = tile / tiles_n;
+    const int tn = tile % tiles_n;
+    int tm = tile / tiles_n;
+    int phase = 0;
+    if (UP) {  // the four phases of one low-res tile are consecutive tiles: they share their input window in L2
+        phase = tm & 3;
+        tm >>= 2;
+    }
+    const int py = phase >> 1, px = phase & 1;
 
     const int cin = a.c0 + a.c1;
     const int cpt = cin >> 6;                 // 64-channel chunks per tap
-    const int ntaps = a.kh * a.kw;
-    const int nk = ntaps * cpt;               // K steps
-    const int howo = a.ho * a.wo;
-    // 2-D tiling when the output plane divides into (BM/16) x 16 tiles; otherwise BM consecutive raster pixels
-    const bool tile2d = (a.wo % 16 == 0) && (a.ho % (BM / 16) == 0);
-    const int tiles_x = a.wo >> 4, tiles_per_img = tile2d ? tiles_x * (a.ho / (BM / 16)) : 1;
+    const int wtaps = UP ? 16 : a.kh * a.kw;  // taps on the packed-weight K axis
+    // the plane the tile walks: output pixels, or (UP) low-res input pixels each owning one output pixel per phase
+    const int ph = UP ? a.h : a.ho, pw = UP ? a.w : a.wo;
+    const int plane = ph * pw;
+    // 2-D tiling when the plane divides into TH x 16 tiles; otherwise BM consecutive raster pixels
+    const bool tile2d = UP || ((pw % 16 == 0) && (ph % TH == 0));
+    const int tiles_x = pw >> 4, tiles_per_img = tile2d ? tiles_x * (ph / TH) : 1;
     const int sub = lane >> 3;                // row inside an 8-row DMA group
     // LDS swizzle key of a tile row r is (r >> 1) & 7: a ds_read_b128 lane group covers 16 rows whose 128-B rows
     // alternate between the two halves of the 256-B bank row, so the key must change every SECOND row to spread the
@@ -124,68 +150,127 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a, int M, i
     const auto rsrc_a0 = __builtin_amdgcn_make_buffer_rsrc((void*)a.src0, 0, (int)(unsigned)(npix * a.c0 * 2), 0x00020000);
     const auto rsrc_a1 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.c1 ? a.src1 : a.src0), 0,
                                                            (int)(unsigned)(npix * (a.c1 ? a.c1 : a.c0) * 2), 0x00020000);
-    const auto rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void*)a.wpk, 0, (int)(unsigned)((size_t)a.cout * nk * 128), 0x00020000);
+    const auto rsrc_b = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)a.wpk, 0, (int)(unsigned)((size_t)(UP ? 4 : 1) * a.cout * wtaps * cpt * 128), 0x00020000);
+
+    // tile position on the plane (2-D tiles)
+    int t_img = 0, t_y0 = 0, t_x0 = 0;
+    if (tile2d) {
+        t_img = tm / tiles_per_img;
+        const int t = tm - t_img * tiles_per_img;
+        t_y0 = (t / tiles_x) * TH;
+        t_x0 = (t % tiles_x) * 16;
+    }
+    // UP: which correction-tap groups this tile needs (wave-uniform)
+    const bool has_row = UP && (py == 0 ? t_y0 == 0 : t_y0 + TH == ph);
+    const bool has_col = UP && (px == 0 ? t_x0 == 0 : t_x0 + 16 == pw);
+    const int ntaps = UP ? 9 + (has_row ? 3 : 0) + (has_col ? 3 : 0) + (has_row && has_col ? 1 : 0) : a.kh * a.kw;
+    const int nk = ntaps * cpt;               // K steps of this tile
+    const unsigned need_row = py == 0 ? 1u : 2u, need_col = px == 0 ? 4u : 8u;
 
     // ---- per-lane gather descriptors for the A rows this lane fetches
+    // a_mask: !UP tap validity bits; UP border flags (1 top, 2 bottom, 4 left, 8 right, 16 row exists)
     unsigned a_off0[RA], a_off1[RA], a_mask[RA];
 #pragma unroll
     for (int j = 0; j < RA; ++j) {
         const int row = (j * 4 + wave) * 8 + sub;
-        const int m = tm * BM + row;
         unsigned mask = 0;
         int pix = 0;
-        if (m < M) {
+        if (tm * BM + row < M) {
             int n_img, oy, ox;
-            if (tile2d) {  // 16-pixel-wide 2-D tile: the taps of one tile re-read a (TH+k-1) x (16+k-1) window from L2
-                n_img = tm / tiles_per_img;
-                const int t = tm - n_img * tiles_per_img;
-                oy = (t / tiles_x) * (BM / 16) + (row >> 4);
-                ox = (t % tiles_x) * 16 + (row & 15);
+            if (tile2d) {  // 16-pixel-wide 2-D tile: the taps of one tile re-read a small window from L2
+                n_img = t_img;
+                oy = t_y0 + (row >> 4);
+                ox = t_x0 + (row & 15);
             } else {
-                n_img = m / howo;
-                const int rem = m - n_img * howo;
-                oy = rem / a.wo;
-                ox = rem - oy * a.wo;
+                const int m = tm * BM + row;
+                n_img = m / plane;
+                const int rem = m - n_img * plane;
+                oy = rem / pw;
+                ox = rem - oy * pw;
             }
-            const int iy0 = oy * a.stride - a.pad, ix0 = ox * a.stride - a.pad;
-            pix = (n_img * a.h + iy0) * a.w + ix0;  // may be "negative": only ever used together with a valid tap
-            // taps inside the image: ky in [ylo, yhi), kx in [xlo, xhi) -> bit (ky*kw + kx)
-            const int ylo = max(0, -iy0), yhi = min(a.kh, a.h - iy0);
-            const int xlo = max(0, -ix0), xhi = min(a.kw, a.w - ix0);
-            const unsigned ym = yhi > ylo ? (1u << yhi) - (1u << ylo) : 0u;
-            const unsigned xm = xhi > xlo ? (1u << xhi) - (1u << xlo) : 0u;
-            for (int ky = 0; ky < a.kh; ++ky) mask |= (((ym >> ky) & 1u) ? xm : 0u) << (ky * a.kw);
+            if (UP) {
+                pix = (n_img * a.h + oy) * a.w + ox;
+                mask = 16u | (oy == 0 ? 1u : 0u) | (oy == a.h - 1 ? 2u : 0u) | (ox == 0 ? 4u : 0u) | (ox == a.w - 1 ? 8u : 0u);
+            } else {
+                const int iy0 = oy * a.stride - a.pad, ix0 = ox * a.stride - a.pad;
+                pix = (n_img * a.h + iy0) * a.w + ix0;  // may be "negative": only ever used together with a valid tap
+                // taps inside the image: ky in [ylo, yhi), kx in [xlo, xhi) -> bit (ky*kw + kx)
+                const int ylo = max(0, -iy0), yhi = min(a.kh, a.h - iy0);
+                const int xlo = max(0, -ix0), xhi = min(a.kw, a.w - ix0);
+                const unsigned ym = yhi > ylo ? (1u << yhi) - (1u << ylo) : 0u;
+                const unsigned xm = xhi > xlo ? (1u << xhi) - (1u << xlo) : 0u;
+                for (int ky = 0; ky < a.kh; ++ky) mask |= (((ym >> ky) & 1u) ? xm : 0u) << (ky * a.kw);
+            }
         }
         a_mask[j] = mask;
         a_off0[j] = (unsigned)pix * (unsigned)(a.c0 * 2) + gchunk * 16;
         a_off1[j] = (unsigned)pix * (unsigned)(a.c1 * 2) + gchunk * 16;
     }
-    // B rows: row r of the tile is output channel tn*BN + r; consecutive K steps are consecutive 128-B segments
+    // B rows: row r of the tile is output channel tn*BN + r of this phase's weight set; a K step is one 128-B segment
     unsigned b_off[RB];
 #pragma unroll
     for (int j = 0; j < RB; ++j) {
         const int row = (j * 4 + wave) * 8 + sub;
-        b_off[j] = (unsigned)(tn * BN + row) * (unsigned)(nk * 128) + gchunk * 16;
+        b_off[j] = (unsigned)(phase * a.cout + tn * BN + row) * (unsigned)(wtaps * cpt * 128) + gchunk * 16;
     }
 
-    // issue-side K-step state (wave-uniform)
-    int is_ky = 0, is_kx = 0, is_chunk = 0;
+    // issue-side K-step state (wave-uniform): tap counter (position in this tile's tap list) and chunk
+    int is_tap = 0, is_chunk = 0;
 
-    // issue the DMA of A slots [j0, j1) and B slots [jb0, jb1) of K step `is_step` into `stage`
-    auto issue_part = [&](int stage, int part) {
+    auto step_info = [&](int tpos) {
+        StepInfo si;
+        if (UP) {
+            int t = tpos;  // position -> tap id: 0-8 stencil, then the correction groups this tile has
+            if (t >= 9) {
+                t -= 9;
+                if (has_row && t < 3) t += 9;
+                else {
+                    if (has_row) t -= 3;
+                    if (has_col && t < 3) t += 12;
+                    else t = 15;
+                }
+            }
+            si.wslot = t;
+            si.tap_bit = 0;
+            if (t < 9) { si.dy = t / 3 - 1; si.dx = t % 3 - 1; si.need = 16u; }
+            else if (t < 12) { si.dy = 0; si.dx = t - 10; si.need = 16u | need_row; }
+            else if (t < 15) { si.dy = t - 13; si.dx = 0; si.need = 16u | need_col; }
+            else { si.dy = 0; si.dx = 0; si.need = 16u | need_row | need_col; }
+        } else {
+            si.dy = tpos / a.kw;
+            si.dx = tpos - si.dy * a.kw;
+            si.wslot = tpos;
+            si.tap_bit = 1u << tpos;
+            si.need = 0;
+        }
+        return si;
+    };
+
+    // issue the LDS-DMA of K step (is_tap, is_chunk) into `stage`
+    auto issue = [&](int stage) {
         char* As = smem + stage * STAGE;
         char* Bs = As + A_BYTES;
+        const StepInfo si = step_info(is_tap);
         const int cb = is_chunk << 6;
         const bool second = cb >= a.c0;
         const int csrc = second ? a.c1 : a.c0;
         const int coff = second ? cb - a.c0 : cb;
-        const unsigned step_off = (unsigned)(((is_ky * a.w + is_kx) * csrc + coff) * 2);
-        const unsigned tap_bit = 1u << (is_ky * a.kw + is_kx);
+        const unsigned dyoff = (unsigned)(si.dy * a.w * csrc * 2), dxoff = (unsigned)(si.dx * csrc * 2);
+        const unsigned chunk_off = (unsigned)(coff * 2);
+        // UP: a tap that would step outside the image is clamped back onto the border pixel (replicate)
+        const unsigned kill_y = si.dy < 0 ? 1u : (si.dy > 0 ? 2u : 0u), kill_x = si.dx < 0 ? 4u : (si.dx > 0 ? 8u : 0u);
 #pragma unroll
         for (int j = 0; j < RA; ++j) {
-            if (j % SPLIT != part) continue;
             const unsigned base = second ? a_off1[j] : a_off0[j];
-            const unsigned vo = (a_mask[j] & tap_bit) ? base + step_off : 0xFFFFFFFFu;
+            unsigned vo;
+            if (UP) {
+                const unsigned f = a_mask[j];
+                const unsigned o = base + chunk_off + ((f & kill_y) ? 0u : dyoff) + ((f & kill_x) ? 0u : dxoff);
+                vo = ((f & si.need) == si.need) ? o : 0xFFFFFFFFu;
+            } else {
+                vo = (a_mask[j] & si.tap_bit) ? base + chunk_off + dyoff + dxoff : 0xFFFFFFFFu;
+            }
             if (second)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a1, LDS_PTR(As + (j * 4 + wave) * 1024), 16, vo, 0, 0, 0);
             else
@@ -193,20 +278,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a, int M, i
         }
 #pragma unroll
         for (int j = 0; j < RB; ++j) {
-            if (j % SPLIT != part) continue;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, LDS_PTR(Bs + (j * 4 + wave) * 1024), 16, b_off[j],
-                                                     ((is_ky * a.kw + is_kx) * cpt + is_chunk) * 128, 0, 0);
+                                                     (si.wslot * cpt + is_chunk) * 128, 0, 0);
         }
-    };
-    // K order: kx fastest, then ky, then the 64-channel chunk -- all taps of one chunk are consecutive, so a tile's
-    // input window for that chunk (a few tens of KB) is fetched from HBM once and re-read from L2 by the other taps
-    auto issue_advance = [&]() {
-        if (++is_kx == a.kw) {
-            is_kx = 0;
-            if (++is_ky == a.kh) {
-                is_ky = 0;
-                ++is_chunk;
-            }
+        // K order: taps fastest, then the 64-channel chunk -- all taps of one chunk are consecutive, so a tile's input
+        // window for that chunk (a few tens of KB) is fetched from HBM once and re-read from L2 by the other taps
+        if (++is_tap == ntaps) {
+            is_tap = 0;
+            ++is_chunk;
         }
     };
 
@@ -223,25 +302,16 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a, int M, i
     const int a_row_off = (wm * 64 + l31) * 128;
     const int b_row_off = (wn * 64 + l31) * 128;
 
-#pragma unroll
-    for (int p = 0; p < SPLIT; ++p) issue_part(0, p);
-    issue_advance();
+    issue(0);
     for (int k = 0; k < nk; ++k) {
         const int cur = k & 1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        const bool more = k + 1 < nk;
+        if (k + 1 < nk) issue(cur ^ 1);
         const char* As = smem + cur * STAGE;
         const char* Bs = As + A_BYTES;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            // next step's DMA is spread over the four k16 sub-steps so its address VALU hides under the MFMAs
-            if (more && (SPLIT == 4 || ks == 0)) {
-                if (SPLIT == 4) issue_part(cur ^ 1, ks);
-                else
-#pragma unroll
-                    for (int p = 0; p < SPLIT; ++p) issue_part(cur ^ 1, p);
-            }
             const int coff = (((ks * 2 + hi) ^ l7) << 4);
             bf16x8 af[2], bfr[2];
 #pragma unroll
@@ -254,7 +324,6 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a, int M, i
                 for (int j = 0; j < 2; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
         }
-        if (more) issue_advance();
     }
 
     // ---- epilogue: accumulators -> LDS fp32 tile [BM][BN] -> affine/act/dropout -> coalesced NHWC stores
@@ -278,14 +347,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a, int M, i
         const int id = it * 256 + tid;
         const int row = id / CG, cg = id % CG;
         if (tm * BM + row >= M) continue;
-        int m, n_img;
+        int m, n_img;  // m: output pixel index in the NHWC output tensor
         if (tile2d) {
-            n_img = tm / tiles_per_img;
-            const int t = tm - n_img * tiles_per_img;
-            m = (n_img * a.ho + (t / tiles_x) * (BM / 16) + (row >> 4)) * a.wo + (t % tiles_x) * 16 + (row & 15);
+            n_img = t_img;
+            const int y = t_y0 + (row >> 4), x = t_x0 + (row & 15);
+            m = UP ? (n_img * a.ho + 2 * y + py) * a.wo + 2 * x + px : (n_img * a.ho + y) * a.wo + x;
         } else {
             m = tm * BM + row;
-            n_img = m / howo;
+            n_img = m / plane;
         }
         const int co = tn * BN + cg * 8;
         const float4 v0 = *(const float4*)(Ct + row * BN + cg * 8);
@@ -324,15 +393,29 @@ bool conv_mfma_supported(const ConvArgs& a) {
     if (a.kh * a.kw > 32) return false;                       // tap-validity mask is 32 bits
     const size_t npix = (size_t)a.n * a.h * a.w;              // 32-bit buffer offsets
     const size_t lim = 0xFFFFFFF0ull;
-    return npix * a.c0 * 2 < lim && npix * (size_t)a.c1 * 2 < lim && (size_t)a.cout * a.kh * a.kw * (a.c0 + a.c1) * 2 < lim;
+    const size_t wtaps = a.up2x ? 64 : (size_t)a.kh * a.kw;
+    if (!(npix * a.c0 * 2 < lim && npix * (size_t)a.c1 * 2 < lim && (size_t)a.cout * wtaps * (a.c0 + a.c1) * 2 < lim))
+        return false;
+    if (a.up2x) {  // fused x2 upsample: 3x3/s1/p1 on a low-res plane that tiles into TH x 16
+        const int th = (a.cout % 128 == 0) ? 8 : 16;
+        return a.kh == 3 && a.kw == 3 && a.stride == 1 && a.pad == 1 && a.w % 16 == 0 && a.h % th == 0 &&
+               a.ho == 2 * a.h && a.wo == 2 * a.w && a.wpk_up != nullptr;
+    }
+    return true;
 }
 
-template <int BM, int BN, int WM, int WN, int SPLIT>
-static hipError_t launch_igemm(const ConvArgs& a, hipStream_t stream) {
+template <int BM, int BN, int WM, int WN, int UP>
+static hipError_t launch_igemm(ConvArgs a, hipStream_t stream) {
     constexpr int lds = 2 * (BM + BN) * 128;
-    const long long M = (long long)a.n * a.ho * a.wo;
-    const int tiles_m = (int)((M + BM - 1) / BM), tiles_n = a.cout / BN;
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, SPLIT>), dim3(tiles_m * tiles_n), dim3(256), lds, stream, a, (int)M,
+    long long M = (long long)a.n * a.ho * a.wo;
+    int tiles_m = (int)((M + BM - 1) / BM);
+    if (UP) {  // tiles walk the LOW-res plane once per phase
+        M = (long long)a.n * a.h * a.w;
+        tiles_m = (int)(M / BM) * 4;
+        a.wpk = a.wpk_up;
+    }
+    const int tiles_n = a.cout / BN;
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, UP>), dim3(tiles_m * tiles_n), dim3(256), lds, stream, a, (int)M,
                        tiles_m, tiles_n);
     return hipGetLastError();
 }
@@ -340,25 +423,54 @@ static hipError_t launch_igemm(const ConvArgs& a, hipStream_t stream) {
 // Raise the dynamic-LDS cap of the MFMA kernels once per process (not legal inside a stream capture).
 hipError_t conv_init() {
     hipError_t e = hipSuccess;
-#define SET_LDS(BM, BN, WM, WN, SP)                                                                     \
+#define SET_LDS(BM, BN, WM, WN, UP)                                                                     \
     if (e == hipSuccess)                                                                                \
-        e = hipFuncSetAttribute((const void*)conv_igemm_kernel<BM, BN, WM, WN, SP>,                     \
+        e = hipFuncSetAttribute((const void*)conv_igemm_kernel<BM, BN, WM, WN, UP>,                     \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (BM + BN) * 128);
-    SET_LDS(128, 128, 2, 2, 1) SET_LDS(128, 128, 2, 2, 4) SET_LDS(256, 64, 4, 1, 1) SET_LDS(256, 64, 4, 1, 4)
+    SET_LDS(128, 128, 2, 2, 0) SET_LDS(128, 128, 2, 2, 1) SET_LDS(256, 64, 4, 1, 0) SET_LDS(256, 64, 4, 1, 1)
 #undef SET_LDS
     return e;
 }
 
 hipError_t launch_conv(const ConvArgs& a, int path, hipStream_t stream) {
     if (path == 1 && conv_mfma_supported(a)) {
-        static const int split = getenv("DYF_CONV_SPLIT") ? atoi(getenv("DYF_CONV_SPLIT")) : 1;
         if (a.cout % 128 == 0)
-            return split == 4 ? launch_igemm<128, 128, 2, 2, 4>(a, stream) : launch_igemm<128, 128, 2, 2, 1>(a, stream);
-        return split == 4 ? launch_igemm<256, 64, 4, 1, 4>(a, stream) : launch_igemm<256, 64, 4, 1, 1>(a, stream);
+            return a.up2x ? launch_igemm<128, 128, 2, 2, 1>(a, stream) : launch_igemm<128, 128, 2, 2, 0>(a, stream);
+        return a.up2x ? launch_igemm<256, 64, 4, 1, 1>(a, stream) : launch_igemm<256, 64, 4, 1, 0>(a, stream);
     }
+    if (a.up2x) return hipErrorInvalidValue;  // the direct kernel has no fused-upsample form: caller materialises
     const long long total = (long long)a.n * a.ho * a.wo * a.cout;
     const int threads = 256;
     hipLaunchKernelGGL(conv_direct_kernel, dim3((unsigned)((total + threads - 1) / threads)), dim3(threads), 0, stream,
                        a, total);
     return hipGetLastError();
+}
+
+// Host-side weight transform for the fused x2-upsample conv (see the kernel header): w [cout][cin][3][3] fp32 ->
+// [4 phases][cout][16 taps][cin] bf16.
+void pack_up2x_weights(const float* w, int cout, int cin, bf16_t* out) {
+    // coefficient of w[k] (k = 0,1,2) in the stencil tap a = -1,0,+1 and in the border correction, per phase
+    static const double E[2][3][3] = {{{0.75, 0.25, 0.0}, {0.25, 0.75, 0.75}, {0.0, 0.0, 0.25}},
+                                      {{0.25, 0.0, 0.0}, {0.75, 0.75, 0.25}, {0.0, 0.25, 0.75}}};
+    static const double Cc[2][3] = {{-1.0, 0.0, 0.0}, {0.0, 0.0, -1.0}};
+    for (int py = 0; py < 2; ++py)
+        for (int px = 0; px < 2; ++px) {
+            const int phase = py * 2 + px;
+            for (int co = 0; co < cout; ++co)
+                for (int ci = 0; ci < cin; ++ci) {
+                    const float* k = w + ((size_t)co * cin + ci) * 9;
+                    for (int t = 0; t < 16; ++t) {
+                        const double* fy;
+                        const double* fx;
+                        if (t < 9) { fy = E[py][t / 3]; fx = E[px][t % 3]; }
+                        else if (t < 12) { fy = Cc[py]; fx = E[px][t - 9]; }
+                        else if (t < 15) { fy = E[py][t - 12]; fx = Cc[px]; }
+                        else { fy = Cc[py]; fx = Cc[px]; }
+                        double v = 0.0;
+                        for (int ky = 0; ky < 3; ++ky)
+                            for (int kx = 0; kx < 3; ++kx) v += fy[ky] * fx[kx] * (double)k[ky * 3 + kx];
+                        out[(((size_t)phase * cout + co) * 16 + t) * cin + ci] = f32_to_bf16((float)v);
+                    }
+                }
+        }
 }

@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -28,6 +29,7 @@ struct UBlock {              // one UNetBlock (unet_simple.py:13-82)
     int in_h = 0, in_w = 0;  // conv input size (after the x2 upsample for decoder blocks)
     int out_h = 0, out_w = 0;
     bf16_t* wpk = nullptr;   // device [cout][k*k][cin]
+    bf16_t* wpk_up = nullptr;  // decoder 3x3 blocks: phase-decomposed weights of the fused x2-upsample conv
     float* gamma = nullptr;  // device (GroupNorm only)
     float* beta = nullptr;
     float* static_a = nullptr;  // device [cout]: epilogue of the GroupNorm block's conv (ones / conv bias)
@@ -94,6 +96,8 @@ struct dyf_engine {
     uint32_t* rng_state = nullptr;  // device {seed_lo, seed_hi, forward_counter, pad}
     int stack_slots = 0;
     std::map<int, GraphEntry> graphs;  // by batch size
+    int fuse_min_plane = 32;           // smallest low-res plane side for which the fused form is used
+    bool fuse_up2x = true;             // DYF_FUSE_UP2X=0 falls back to the materialised upsample (A/B testing)
     hipStream_t cap_stream = nullptr;  // capture never runs on the caller's (possibly legacy default) stream
 };
 
@@ -226,6 +230,13 @@ dyf_status run_conv(dyf_engine* e, const ConvArgs& a, hipStream_t st) {
     return DYF_OK;
 }
 
+// Fused x2-upsample conv pays ~7 extra K taps on every tile that touches an image border; on small planes most tiles
+// do, and materialising the (small) upsampled tensor is cheaper (measured: break-even at a 32x32 low-res plane).
+bool use_fused_up(const dyf_engine* e, const UBlock& b, const ConvArgs& f) {
+    return e->cfg.enable_mfma && e->fuse_up2x && b.wpk_up != nullptr && f.h >= e->fuse_min_plane && f.w >= e->fuse_min_plane &&
+           conv_mfma_supported(f);
+}
+
 ConvArgs block_conv_args(const dyf_engine* e, const Net& n, const UBlock& b, int nb) {
     ConvArgs a{};
     a.n = nb; a.h = b.in_h; a.w = b.in_w; a.ho = b.out_h; a.wo = b.out_w;
@@ -289,16 +300,24 @@ dyf_status net_forward(dyf_engine* e, int which, const Source* srcs, int nsrc, i
     int lh = n.blk[5].out_h, lw = n.blk[5].out_w;
     for (int i = 6; i < 12; ++i) {
         const UBlock& b = n.blk[i];
-        Up2xArgs u{};
-        u.src0 = x; u.c0 = b.cin - skip_c; u.src1 = skip; u.c1 = skip_c; u.n = nb; u.h = lh; u.w = lw; u.out = ws.up;
-        HIP_TRY(e, launch_up2x(u, st));
         ConvArgs a = block_conv_args(e, n, b, nb);
-        a.src0 = ws.up; a.c0 = b.cin; a.src1 = nullptr; a.c1 = 0;
         a.coef_a = o.coef_a + b.film_off; a.coef_c = o.coef_c + b.film_off; a.coef_stride = o.coef_stride;
         a.drop = make_drop(e, n, o, i);
         a.out_bf16 = ws.dec[i - 6];
-        dyf_status s = run_conv(e, a, st);
-        if (s != DYF_OK) return s;
+        // fused form: the conv gathers straight from the low-res cat[x, skip] (phase decomposition, conv.hip)
+        ConvArgs f = a;
+        f.src0 = x; f.c0 = b.cin - skip_c; f.src1 = skip; f.c1 = skip_c; f.h = lh; f.w = lw;
+        f.up2x = 1; f.wpk_up = b.wpk_up;
+        if (use_fused_up(e, b, f)) {
+            HIP_TRY(e, launch_conv(f, 1, st));
+        } else {  // materialise the upsampled tensor, then a plain conv
+            Up2xArgs u{};
+            u.src0 = x; u.c0 = b.cin - skip_c; u.src1 = skip; u.c1 = skip_c; u.n = nb; u.h = lh; u.w = lw; u.out = ws.up;
+            HIP_TRY(e, launch_up2x(u, st));
+            a.src0 = ws.up; a.c0 = b.cin; a.src1 = nullptr; a.c1 = 0;
+            dyf_status s = run_conv(e, a, st);
+            if (s != DYF_OK) return s;
+        }
         x = ws.dec[i - 6];
         lh = b.out_h; lw = b.out_w;
         if (i < 11) {
@@ -378,6 +397,8 @@ dyf_status dyf_engine_create(const dyf_engine_config* cfg, dyf_engine** out_engi
 
     dyf_engine* e = new dyf_engine();
     e->cfg = *cfg;
+    if (const char* fu = getenv("DYF_FUSE_UP2X")) e->fuse_up2x = atoi(fu) != 0;
+    if (const char* fm = getenv("DYF_FUSE_MIN_PLANE")) e->fuse_min_plane = atoi(fm);
     if (conv_init() != hipSuccess || hipStreamCreateWithFlags(&e->cap_stream, hipStreamNonBlocking) != hipSuccess) {
         delete e;
         return fail(nullptr, DYF_ERR_HIP, "engine initialisation failed (conv_init / stream create)");
@@ -525,6 +546,11 @@ dyf_status dyf_load_weights(dyf_engine* e, int32_t which, int32_t n_tensors, con
                 for (int t = 0; t < taps; ++t)
                     pk[((size_t)co * taps + t) * b.cin + ci] = f32_to_bf16(cw->data[((size_t)co * b.cin + ci) * taps + t]);
         UP(b.wpk, pk);
+        if (b.transposed && b.k == 3) {
+            std::vector<bf16_t> pu((size_t)4 * b.cout * 16 * b.cin);
+            pack_up2x_weights(cw->data, b.cout, b.cin, pu.data());
+            UP(b.wpk_up, pu);
+        }
         if (!b.gn) {  // eval-mode BatchNorm2d folded with the conv bias: y = conv*a + c
             NEED(rm, norm + ".running_mean", (int64_t)b.cout);
             NEED(rv, norm + ".running_var", (int64_t)b.cout);
@@ -874,6 +900,13 @@ dyf_status dyf_time_conv_layer(dyf_engine* e, int32_t which, int32_t layer, int3
     // same operands as in net_forward: whatever the last forward left in the workspace (realistic activations)
     a.src0 = b.transposed ? e->ws.up : (layer == 0 ? e->ws.stem : e->ws.enc[layer - 1]);
     a.c0 = b.cin;
+    if (b.transposed && layer > 6) {  // fused x2-upsample form when net_forward uses it
+        ConvArgs f = a;
+        const UBlock& skipb = n.blk[11 - layer];
+        f.src0 = e->ws.dec[layer - 7]; f.c0 = b.cin - skipb.cout; f.src1 = e->ws.enc[11 - layer]; f.c1 = skipb.cout;
+        f.h = b.in_h / 2; f.w = b.in_w / 2; f.up2x = 1; f.wpk_up = b.wpk_up;
+        if (use_fused_up(e, b, f)) a = f;
+    }
     const float* A = n.tables ? n.tables : e->ws.coef_a;                    // row 0 of the plan's tables, or the
     const float* Cc = n.tables ? n.tables + n.total_c : e->ws.coef_c;       // coefficients of the last forward
     a.coef_a = b.gn ? b.static_a : A + b.film_off;
@@ -949,6 +982,46 @@ dyf_status dyf_op_conv2d(dyf_engine* e, const uint16_t* x_dev, const float* w_ho
         hipError_t le = launch_conv(a, path, st);
         if (le == hipSuccess) le = hipStreamSynchronize(st);
         if (le != hipSuccess) rs = fail(e, DYF_ERR_HIP, std::string("conv launch: ") + hipGetErrorString(le));
+    }
+    (void)hipFree(wdev);
+    if (ones) (void)hipFree(ones);
+    if (zeros) (void)hipFree(zeros);
+    return rs;
+}
+
+dyf_status dyf_op_upconv2d(dyf_engine* e, const uint16_t* x_dev, const float* w_host, int32_t n, int32_t h, int32_t w,
+                           int32_t cin, int32_t cout, const float* scale_dev, const float* shift_dev, int32_t act,
+                           uint16_t* y_dev, void* stream) {
+    if (!e || !x_dev || !w_host || !y_dev) return fail(e, DYF_ERR_INVALID_ARGUMENT, "null argument");
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    hipStream_t st = (hipStream_t)stream;
+    std::vector<bf16_t> pu((size_t)4 * cout * 16 * cin);
+    pack_up2x_weights(w_host, cout, cin, pu.data());
+    bf16_t* wdev = nullptr;
+    float *ones = nullptr, *zeros = nullptr;
+    HIP_TRY(e, hipMalloc((void**)&wdev, pu.size() * sizeof(bf16_t)));
+    HIP_TRY(e, hipMemcpy(wdev, pu.data(), pu.size() * sizeof(bf16_t), hipMemcpyHostToDevice));
+    ConvArgs a{};
+    a.src0 = x_dev; a.c0 = cin; a.n = n; a.h = h; a.w = w; a.ho = 2 * h; a.wo = 2 * w;
+    a.kh = 3; a.kw = 3; a.stride = 1; a.pad = 1; a.cout = cout; a.wpk = wdev; a.wpk_up = wdev; a.up2x = 1;
+    a.act = act; a.out_bf16 = y_dev;
+    if (scale_dev && shift_dev) {
+        a.coef_a = scale_dev; a.coef_c = shift_dev; a.coef_stride = cout;
+    } else {
+        std::vector<float> o1(cout, 1.0f), z0(cout, 0.0f);
+        HIP_TRY(e, hipMalloc((void**)&ones, cout * sizeof(float)));
+        HIP_TRY(e, hipMalloc((void**)&zeros, cout * sizeof(float)));
+        HIP_TRY(e, hipMemcpy(ones, o1.data(), cout * sizeof(float), hipMemcpyHostToDevice));
+        HIP_TRY(e, hipMemcpy(zeros, z0.data(), cout * sizeof(float), hipMemcpyHostToDevice));
+        a.coef_a = ones; a.coef_c = zeros; a.coef_stride = 0;
+    }
+    dyf_status rs = DYF_OK;
+    if (!conv_mfma_supported(a)) {
+        rs = fail(e, DYF_ERR_UNSUPPORTED, "fused upsample conv needs cin % 64 == 0, cout % 64 == 0, w % 16 == 0, h % 8/16 == 0");
+    } else {
+        hipError_t le = launch_conv(a, 1, st);
+        if (le == hipSuccess) le = hipStreamSynchronize(st);
+        if (le != hipSuccess) rs = fail(e, DYF_ERR_HIP, std::string("upconv launch: ") + hipGetErrorString(le));
     }
     (void)hipFree(wdev);
     if (ones) (void)hipFree(ones);

@@ -203,3 +203,19 @@ class HipEngine:
                                             None if shift is None else shift.data_ptr(), act, path, y.data_ptr(),
                                             self._stream()))
         return y
+
+    def op_upconv2d(self, x_nhwc_bf16: torch.Tensor, weight: torch.Tensor, scale: Optional[torch.Tensor] = None,
+                    shift: Optional[torch.Tensor] = None, act: int = 0) -> torch.Tensor:
+        """Test seam: fused Upsample(x2, bilinear) + Conv2d(3x3, pad 1).  x (N,H,W,Cin) bf16 -> (N,2H,2W,Cout) bf16."""
+        assert x_nhwc_bf16.dtype == torch.bfloat16 and x_nhwc_bf16.is_cuda and x_nhwc_bf16.is_contiguous()
+        n, h, w, cin = x_nhwc_bf16.shape
+        cout = weight.shape[0]
+        wh = np.ascontiguousarray(weight.detach().to("cpu", torch.float32).numpy())
+        y = torch.empty((n, 2 * h, 2 * w, cout), dtype=torch.bfloat16, device=x_nhwc_bf16.device)
+        if scale is not None:
+            scale, shift = _f32c(scale, "scale"), _f32c(shift, "shift")
+        self._check(self._lib.dyf_op_upconv2d(self._h, x_nhwc_bf16.data_ptr(), wh.ctypes.data, n, h, w, cin, cout,
+                                              None if scale is None else scale.data_ptr(),
+                                              None if shift is None else shift.data_ptr(), act, y.data_ptr(),
+                                              self._stream()))
+        return y

@@ -152,6 +152,12 @@ dyf_status dyf_op_conv2d(dyf_engine* engine, const uint16_t* x_dev, const float*
                          const float* scale_dev, const float* shift_dev, int32_t act, int32_t path, uint16_t* y_dev,
                          void* stream);
 
+/* Upsample(x2, bilinear, align_corners=False) + Conv2d(3x3, pad 1) + epilogue in one kernel (phase-decomposed MFMA
+ * implicit GEMM; unet_simple.py:40-52).  x_dev (N,H,W,Cin) bf16 -> y_dev (N,2H,2W,Cout) bf16. */
+dyf_status dyf_op_upconv2d(dyf_engine* engine, const uint16_t* x_dev, const float* w_host, int32_t n, int32_t h,
+                           int32_t w, int32_t cin, int32_t cout, const float* scale_dev, const float* shift_dev,
+                           int32_t act, uint16_t* y_dev, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -78,3 +78,26 @@ def test_mfma_path_rejects_unsupported_channels(engine):
     x = torch.zeros(1, 8, 8, 32, dtype=torch.bfloat16).cuda()
     with pytest.raises(NotImplementedError):
         engine.op_conv2d(x, torch.zeros(64, 32, 3, 3), 1, 1, path=1)
+
+
+UPCASES = [(2, 16, 16, 64, 128), (1, 32, 16, 128, 64), (3, 8, 16, 192, 128), (1, 16, 32, 64, 64), (2, 48, 32, 128, 256)]
+
+
+@pytest.mark.parametrize("case", UPCASES, ids=lambda c: "x".join(map(str, c)))
+def test_fused_upsample_conv_matches_torch(engine, case):
+    """Upsample(x2, bilinear) + Conv2d(3x3, pad 1) by phase decomposition (incl. the border correction taps) vs ATen."""
+    n, h, w, cin, cout = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(n, h, w, cin, generator=g).to(torch.bfloat16)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    scale = 1.0 + 0.3 * torch.randn(n, cout, generator=g)
+    shift = 0.2 * torch.randn(n, cout, generator=g)
+    y = engine.op_upconv2d(x.cuda(), wt, scale.cuda(), shift.cuda(), act=1).float().cpu()
+    up = F.interpolate(x.float().permute(0, 3, 1, 2), scale_factor=2, mode="bilinear")
+    want = F.relu(F.conv2d(up, wt, None, 1, 1) * scale[:, :, None, None] + shift[:, :, None, None]).permute(0, 2, 3, 1)
+    # the engine rounds the COMBINED stencil weights to bf16 (the reference rounds nothing): slightly looser than conv
+    assert rel_rms(y, want) <= 6e-3, rel_rms(y, want)
+    # borders and corners carry the correction taps: check them separately so a wrong correction cannot hide
+    for sl in [(slice(None), 0), (slice(None), -1), (slice(None), slice(None), 0), (slice(None), slice(None), -1)]:
+        assert rel_rms(y[sl], want[sl]) <= 8e-3, (sl, rel_rms(y[sl], want[sl]))
+    assert max_abs(y, want) <= 3 * 2 ** -8 * float(want.abs().max()) + 2e-3
