@@ -7,6 +7,8 @@ struct ConvArgs {
     const bf16_t* src0;
     const bf16_t* src1;
     int c0, c1;          // channels taken from src0 / src1 (c1 == 0: single source)
+    int pix_pitch0;      // elements between consecutive pixels of src0 (0: = c0).  The fused stem feeds enc0 a 16-channel
+                         // tensor and declares c0 = 64: one K chunk then spans 4 horizontally adjacent pixels
     int n, h, w;         // input batch / height / width
     int ho, wo;          // output height / width
     int kh, kw, stride, pad;

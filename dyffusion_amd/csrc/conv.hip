@@ -59,7 +59,7 @@ __global__ void conv_direct_kernel(ConvArgs a, long long total) {
             if ((unsigned)ix >= (unsigned)a.w) continue;
             const size_t pix = ((size_t)n * a.h + iy) * a.w + ix;
             const bf16_t* wt = wrow + (size_t)(ky * a.kw + kx) * cin;
-            const bf16_t* p0 = a.src0 + pix * a.c0;
+            const bf16_t* p0 = a.src0 + pix * (a.pix_pitch0 ? a.pix_pitch0 : a.c0);
             for (int c = 0; c < a.c0; ++c) acc = fmaf(bf16_to_f32(p0[c]), bf16_to_f32(wt[c]), acc);
             if (a.c1 > 0) {
                 const bf16_t* p1 = a.src1 + pix * a.c1;
@@ -147,7 +147,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a, int M, i
     const int gchunk = (lane & 7) ^ ((((wave & 1) << 2) | (sub >> 1)) & 7);  // swizzled SOURCE chunk of this lane's slot
 
     const size_t npix = (size_t)a.n * a.h * a.w;
-    const auto rsrc_a0 = __builtin_amdgcn_make_buffer_rsrc((void*)a.src0, 0, (int)(unsigned)(npix * a.c0 * 2), 0x00020000);
+    const int pitch0 = a.pix_pitch0 ? a.pix_pitch0 : a.c0;
+    const auto rsrc_a0 = __builtin_amdgcn_make_buffer_rsrc((void*)a.src0, 0, (int)(unsigned)(npix * pitch0 * 2), 0x00020000);
     const auto rsrc_a1 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.c1 ? a.src1 : a.src0), 0,
                                                            (int)(unsigned)(npix * (a.c1 ? a.c1 : a.c0) * 2), 0x00020000);
     const auto rsrc_b = __builtin_amdgcn_make_buffer_rsrc(
@@ -204,7 +205,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a, int M, i
             }
         }
         a_mask[j] = mask;
-        a_off0[j] = (unsigned)pix * (unsigned)(a.c0 * 2) + gchunk * 16;
+        a_off0[j] = (unsigned)pix * (unsigned)(pitch0 * 2) + gchunk * 16;
         a_off1[j] = (unsigned)pix * (unsigned)(a.c1 * 2) + gchunk * 16;
     }
     // B rows: row r of the tile is output channel tn*BN + r of this phase's weight set; a K step is one 128-B segment
@@ -254,7 +255,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a, int M, i
         const StepInfo si = step_info(is_tap);
         const int cb = is_chunk << 6;
         const bool second = cb >= a.c0;
-        const int csrc = second ? a.c1 : a.c0;
+        const int csrc = second ? a.c1 : pitch0;
         const int coff = second ? cb - a.c0 : cb;
         const unsigned dyoff = (unsigned)(si.dy * a.w * csrc * 2), dxoff = (unsigned)(si.dx * csrc * 2);
         const unsigned chunk_off = (unsigned)(coff * 2);

@@ -47,6 +47,8 @@ struct Net {
     float *film_w = nullptr, *film_b = nullptr, *norm_a = nullptr, *norm_c = nullptr;
     int *blk_of = nullptr, *blk_off = nullptr, *blk_cout = nullptr;
     float *ro_w = nullptr, *ro_b = nullptr;
+    bf16_t* enc0_fused_w = nullptr;  // [2dim][4][64]: enc0's 4x4 conv composed with init_conv (+ bias channel)
+    bool stem_fused = false;
     double flops_per_sample = 0.0;
     // sampler coefficient tables: one (A, C) row pair per distinct time value
     std::map<float, int> table_of_time;
@@ -56,6 +58,7 @@ struct Net {
 
 struct Workspace {
     bf16_t* stem = nullptr;
+    bf16_t* stem16 = nullptr;  // fused stem: [nb][uh+2][uw+2][16]
     bf16_t* enc[6] = {};
     float* enc5_raw = nullptr;
     bf16_t* up = nullptr;
@@ -97,6 +100,7 @@ struct dyf_engine {
     int stack_slots = 0;
     std::map<int, GraphEntry> graphs;  // by batch size
     int fuse_min_plane = 32;           // smallest low-res plane side for which the fused form is used
+    bool fuse_stem = true;             // DYF_FUSE_STEM=0: separate 1x1 stem kernel + plain enc0
     bool fuse_up2x = true;             // DYF_FUSE_UP2X=0 falls back to the materialised upsample (A/B testing)
     hipStream_t cap_stream = nullptr;  // capture never runs on the caller's (possibly legacy default) stream
 };
@@ -230,6 +234,15 @@ dyf_status run_conv(dyf_engine* e, const ConvArgs& a, hipStream_t st) {
     return DYF_OK;
 }
 
+// enc0 on the fused stem: a 4(kh) x 1 conv over "64-channel" pixels that are really 4 adjacent 16-channel pixels of the
+// zero-bordered stem16 tensor (stride 2, physical padding instead of pad=1).
+void fused_enc0_args(const dyf_engine* e, const Net& n, ConvArgs& a) {
+    a.src0 = e->ws.stem16; a.c0 = 64; a.pix_pitch0 = 16;
+    a.h = n.uh + 2; a.w = n.uw + 2;
+    a.kh = 4; a.kw = 1; a.stride = 2; a.pad = 0;
+    a.wpk = n.enc0_fused_w;
+}
+
 // Fused x2-upsample conv pays ~7 extra K taps on every tile that touches an image border; on small planes most tiles
 // do, and materialising the (small) upsampled tensor is cheaper (measured: break-even at a 32x32 low-res plane).
 bool use_fused_up(const dyf_engine* e, const UBlock& b, const ConvArgs& f) {
@@ -264,14 +277,22 @@ dyf_status net_forward(dyf_engine* e, int which, const Source* srcs, int nsrc, i
         return fail(e, DYF_ERR_INVALID_ARGUMENT, "channel count of the network inputs does not match its configuration");
     sa.nsrc = nsrc; sa.cin = ctot; sa.n = nb; sa.h = H; sa.w = W; sa.uh = n.uh; sa.uw = n.uw;
     sa.resample = (n.uh != H || n.uw != W) ? 1 : 0;
-    sa.wgt = n.stem_w; sa.bias = n.stem_b; sa.dim = n.dim; sa.out = ws.stem;
-    HIP_TRY(e, launch_stem(sa, st));
+    sa.wgt = n.stem_w; sa.bias = n.stem_b; sa.dim = n.dim;
+    const bool fused_stem = n.stem_fused && e->cfg.enable_mfma && e->fuse_stem;
+    if (fused_stem) {
+        sa.out = ws.stem16;
+        HIP_TRY(e, launch_stem16(sa, st));
+    } else {
+        sa.out = ws.stem;
+        HIP_TRY(e, launch_stem(sa, st));
+    }
     // ---- encoder
     const bf16_t* x = ws.stem;
     for (int i = 0; i < 6; ++i) {
         const UBlock& b = n.blk[i];
         ConvArgs a = block_conv_args(e, n, b, nb);
         a.src0 = x; a.c0 = b.cin; a.src1 = nullptr; a.c1 = 0;
+        if (i == 0 && fused_stem) fused_enc0_args(e, n, a);
         if (!b.gn) {
             a.coef_a = o.coef_a + b.film_off; a.coef_c = o.coef_c + b.film_off; a.coef_stride = o.coef_stride;
             a.drop = make_drop(e, n, o, i);
@@ -399,6 +420,7 @@ dyf_status dyf_engine_create(const dyf_engine_config* cfg, dyf_engine** out_engi
     e->cfg = *cfg;
     if (const char* fu = getenv("DYF_FUSE_UP2X")) e->fuse_up2x = atoi(fu) != 0;
     if (const char* fm = getenv("DYF_FUSE_MIN_PLANE")) e->fuse_min_plane = atoi(fm);
+    if (const char* fs = getenv("DYF_FUSE_STEM")) e->fuse_stem = atoi(fs) != 0;
     if (conv_init() != hipSuccess || hipStreamCreateWithFlags(&e->cap_stream, hipStreamNonBlocking) != hipSuccess) {
         delete e;
         return fail(nullptr, DYF_ERR_HIP, "engine initialisation failed (conv_init / stream create)");
@@ -449,6 +471,11 @@ dyf_status dyf_engine_create(const dyf_engine_config* cfg, dyf_engine** out_engi
         if (_s != DYF_OK) return bail(_s, e->err);                  \
     } while (0)
     ALLOC(ws.stem, stem_el);
+    {
+        size_t s16 = 0;
+        for (int w = 0; w < 2; ++w) s16 = std::max(s16, nb * (size_t)(e->net[w].uh + 2) * (e->net[w].uw + 2) * 16);
+        ALLOC(ws.stem16, s16);
+    }
     for (int i = 0; i < 6; ++i) {
         ALLOC(ws.enc[i], enc_el[i]);
         ALLOC(ws.dec[i], dec_el[i]);
@@ -546,6 +573,26 @@ dyf_status dyf_load_weights(dyf_engine* e, int32_t which, int32_t n_tensors, con
                 for (int t = 0; t < taps; ++t)
                     pk[((size_t)co * taps + t) * b.cin + ci] = f32_to_bf16(cw->data[((size_t)co * b.cin + ci) * taps + t]);
         UP(b.wpk, pk);
+        if (i == 0 && b.k == 4 && n.cin_total + 1 <= 16 && b.cout % 64 == 0 && n.uh % 2 == 0 && n.uw % 2 == 0) {
+            // compose_stem_enc0: W'[co][kh][kw][c] = sum_d Wenc0[co][d][kh][kw] * Winit[d][c]; channel cin_total carries
+            // init_conv's bias (its input is the 1-inside-the-image indicator); channels up to 16 are zero
+            const TensorView* sw = &sd["init_conv.weight"];
+            const TensorView* sb = &sd["init_conv.bias"];
+            std::vector<bf16_t> fw((size_t)b.cout * 16 * 16);
+            for (int co = 0; co < b.cout; ++co)
+                for (int t = 0; t < 16; ++t)
+                    for (int c = 0; c < 16; ++c) {
+                        double v = 0.0;
+                        if (c <= n.cin_total)
+                            for (int d2 = 0; d2 < n.dim; ++d2) {
+                                const double we = cw->data[((size_t)co * b.cin + d2) * 16 + t];
+                                v += we * (c < n.cin_total ? (double)sw->data[(size_t)d2 * n.cin_total + c] : (double)sb->data[d2]);
+                            }
+                        fw[((size_t)co * 16 + t) * 16 + c] = f32_to_bf16((float)v);
+                    }
+            UP(n.enc0_fused_w, fw);
+            n.stem_fused = true;
+        }
         if (b.transposed && b.k == 3) {
             std::vector<bf16_t> pu((size_t)4 * b.cout * 16 * b.cin);
             pack_up2x_weights(cw->data, b.cout, b.cin, pu.data());
@@ -900,6 +947,7 @@ dyf_status dyf_time_conv_layer(dyf_engine* e, int32_t which, int32_t layer, int3
     // same operands as in net_forward: whatever the last forward left in the workspace (realistic activations)
     a.src0 = b.transposed ? e->ws.up : (layer == 0 ? e->ws.stem : e->ws.enc[layer - 1]);
     a.c0 = b.cin;
+    if (layer == 0 && n.stem_fused && e->cfg.enable_mfma && e->fuse_stem) fused_enc0_args(e, n, a);
     if (b.transposed && layer > 6) {  // fused x2-upsample form when net_forward uses it
         ConvArgs f = a;
         const UBlock& skipb = n.blk[11 - layer];

@@ -49,6 +49,10 @@ struct StemArgs {
     bf16_t* out;            // [n][uh][uw][dim]
 };
 hipError_t launch_stem(const StemArgs& a, hipStream_t s);
+// Fused-stem form: only the outer resample, written as a zero-bordered [n][uh+2][uw+2][16] bf16 tensor whose channel
+// `cin` is 1 inside the image (carries init_conv's bias through the composed enc0 weights); the 1x1 conv itself is
+// folded into the first encoder block's weights (engine.hip: compose_stem_enc0).
+hipError_t launch_stem16(const StemArgs& a, hipStream_t s);
 
 // K2 (materialised form): bilinear x2 upsample of cat[src0, src1] (NHWC bf16) -> NHWC bf16
 struct Up2xArgs {

@@ -158,6 +158,59 @@ hipError_t launch_stem(const StemArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
+// init_conv is linear and nothing non-linear sits between it and the first encoder conv (dropout_input has p = 0),
+// so conv4x4(init_conv(x)) is ONE 4x4 conv on the resampled raw channels.  This kernel only resamples.
+__global__ __launch_bounds__(256) void stem16_kernel(StemArgs a) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int ph = a.uh + 2, pw = a.uw + 2;
+    const long long total = (long long)a.n * ph * pw;
+    if (idx >= total) return;
+    const int n = (int)(idx / ((long long)ph * pw));
+    const int rem = (int)(idx % ((long long)ph * pw));
+    const int y = rem / pw - 1, x = rem % pw - 1;
+    uint32_t w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if ((unsigned)y < (unsigned)a.uh && (unsigned)x < (unsigned)a.uw) {
+        int y0 = y, y1 = y, x0 = x, x1 = x;
+        float ly = 0.0f, lx = 0.0f;
+        if (a.resample) {
+            bilinear_coord(y, (float)a.h / (float)a.uh, a.h, y0, y1, ly);
+            bilinear_coord(x, (float)a.w / (float)a.uw, a.w, x0, x1, lx);
+        }
+        float v[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) v[c] = 0.0f;
+        int cbase = 0;
+        for (int s = 0; s < a.nsrc; ++s) {
+            const float* src = a.src[s] + (size_t)n * a.ch[s] * a.h * a.w;
+            for (int c = 0; c < a.ch[s]; ++c) {
+                const float* p = src + (size_t)c * a.h * a.w;
+                const float top = p[y0 * a.w + x0] * (1.0f - lx) + p[y0 * a.w + x1] * lx;
+                const float bot = p[y1 * a.w + x0] * (1.0f - lx) + p[y1 * a.w + x1] * lx;
+                const float val = top * (1.0f - ly) + bot * ly;
+                const int cc = cbase + c;
+#pragma unroll
+                for (int k = 0; k < 16; ++k)
+                    if (k == cc) v[k] = val;
+            }
+            cbase += a.ch[s];
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+            if (k == a.cin) v[k] = 1.0f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) w[k] = pack_bf16x2(v[2 * k], v[2 * k + 1]);
+    }
+    uint4* o = (uint4*)(a.out + (size_t)idx * 16);
+    o[0] = make_uint4(w[0], w[1], w[2], w[3]);
+    o[1] = make_uint4(w[4], w[5], w[6], w[7]);
+}
+
+hipError_t launch_stem16(const StemArgs& a, hipStream_t s) {
+    const long long total = (long long)a.n * (a.uh + 2) * (a.uw + 2);
+    hipLaunchKernelGGL(stem16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------------ K2 x2 upsample
 // unet_simple.py:42 nn.Upsample(scale_factor=2, bilinear) applied to cat[x, skip] (:176-177).
 template <int VEC>
