@@ -218,6 +218,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a, int M, i
 
     // issue-side K-step state (wave-uniform): tap counter (position in this tile's tap list) and chunk
     int is_tap = 0, is_chunk = 0;
+    int tap_lo = 0;  // first tap position of the list being walked (9 while a UP tile runs its correction taps)
 
     auto step_info = [&](int tpos) {
         StepInfo si;
@@ -285,7 +286,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a, int M, i
         // K order: taps fastest, then the 64-channel chunk -- all taps of one chunk are consecutive, so a tile's input
         // window for that chunk (a few tens of KB) is fetched from HBM once and re-read from L2 by the other taps
         if (++is_tap == ntaps) {
-            is_tap = 0;
+            is_tap = tap_lo;
             ++is_chunk;
         }
     };
@@ -303,13 +304,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a, int M, i
     const int a_row_off = (wm * 64 + l31) * 128;
     const int b_row_off = (wn * 64 + l31) * 128;
 
-    issue(0);
-    for (int k = 0; k < nk; ++k) {
-        const int cur = k & 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (k + 1 < nk) issue(cur ^ 1);
-        const char* As = smem + cur * STAGE;
+    auto compute = [&](int stage) {
+        const char* As = smem + stage * STAGE;
         const char* Bs = As + A_BYTES;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
@@ -324,6 +320,97 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a, int M, i
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    // UP fast path (both sources have the same channel count): the 9 stencil taps are unrolled and each row's gather
+    // offset is base + yoff[a] + xoff[b] with per-row, per-direction byte offsets precomputed once per tile (clamped to
+    // the border = replicate); one v_add3 per row and K step instead of ~11 VALU.  Rows past M carry an out-of-range
+    // base.  The correction taps of border tiles run afterwards through the general `issue` path.
+    const bool up_fast = UP && (a.c1 == 0 || a.c1 == a.c0) && npix * (size_t)a.c0 * 2 < 0x7F000000ull;
+    if (UP && up_fast) {
+        const unsigned rowb = (unsigned)(a.w * a.c0 * 2), pixb = (unsigned)(a.c0 * 2);
+        unsigned ybase[RA], y_m[RA], y_p[RA], x_m[RA], x_p[RA];
+#pragma unroll
+        for (int j = 0; j < RA; ++j) {
+            const unsigned f = a_mask[j];
+            ybase[j] = (f & 16u) ? a_off0[j] : 0x80000000u;
+            y_m[j] = (f & 1u) ? 0u : 0u - rowb;
+            y_p[j] = (f & 2u) ? 0u : rowb;
+            x_m[j] = (f & 4u) ? 0u : 0u - pixb;
+            x_p[j] = (f & 8u) ? 0u : pixb;
+        }
+        const int ncorr = ntaps - 9;
+        int chunk = 0;
+        unsigned cb_off = 0;  // byte offset of the current chunk inside its source
+        bool second = false;
+
+#define ISSUE_STENCIL(T, STAGE_)                                                                                  \
+    {                                                                                                             \
+        char* As_ = smem + (STAGE_) * STAGE;                                                                      \
+        char* Bs_ = As_ + A_BYTES;                                                                                \
+        _Pragma("unroll") for (int j = 0; j < RA; ++j) {                                                          \
+            const unsigned vo = ybase[j] + cb_off + ((T) / 3 == 0 ? y_m[j] : ((T) / 3 == 2 ? y_p[j] : 0u)) +      \
+                                ((T) % 3 == 0 ? x_m[j] : ((T) % 3 == 2 ? x_p[j] : 0u));                           \
+            if (second)                                                                                           \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a1, LDS_PTR(As_ + (j * 4 + wave) * 1024), 16, vo, 0, 0, 0); \
+            else                                                                                                  \
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a0, LDS_PTR(As_ + (j * 4 + wave) * 1024), 16, vo, 0, 0, 0); \
+        }                                                                                                         \
+        _Pragma("unroll") for (int j = 0; j < RB; ++j)                                                            \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, LDS_PTR(Bs_ + (j * 4 + wave) * 1024), 16, b_off[j],  \
+                                                     ((T) * cpt + chunk) * 128, 0, 0);                            \
+    }
+#define STENCIL_STEP(T)                                                                    \
+    {                                                                                      \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                   \
+        __syncthreads();                                                                   \
+        ISSUE_STENCIL((T) + 1, st ^ 1)                                                     \
+        compute(st);                                                                       \
+        st ^= 1;                                                                           \
+    }
+        int st = 0;
+        ISSUE_STENCIL(0, 0)
+        for (;;) {
+            STENCIL_STEP(0) STENCIL_STEP(1) STENCIL_STEP(2) STENCIL_STEP(3)
+            STENCIL_STEP(4) STENCIL_STEP(5) STENCIL_STEP(6) STENCIL_STEP(7)
+            // tap 8: its successor is tap 0 of the next chunk, the first correction step, or nothing
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            const bool last_chunk = chunk + 1 == cpt;
+            if (!last_chunk) {
+                ++chunk;
+                const int cb = chunk << 6;
+                second = cb >= a.c0;
+                cb_off = (unsigned)((second ? cb - a.c0 : cb) * 2);
+                ISSUE_STENCIL(0, st ^ 1)
+            } else if (ncorr > 0) {
+                tap_lo = 9;
+                is_tap = 9;
+                is_chunk = 0;
+                issue(st ^ 1);
+            }
+            compute(st);
+            st ^= 1;
+            if (last_chunk) break;
+        }
+#undef STENCIL_STEP
+#undef ISSUE_STENCIL
+        for (int k = 0; k < ncorr * cpt; ++k) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (k + 1 < ncorr * cpt) issue(st ^ 1);
+            compute(st);
+            st ^= 1;
+        }
+    } else {
+        issue(0);
+        for (int k = 0; k < nk; ++k) {
+            const int cur = k & 1;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (k + 1 < nk) issue(cur ^ 1);
+            compute(cur);
         }
     }
 
