@@ -52,6 +52,16 @@ def random_state(net, seed):
     return sd
 
 
+def pmc_traffic(nb):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (profiles/r01_pmc_traffic.json:
+    FETCH_SIZE x2 + WRITE_SIZE, separate passes), scaled by rows; None when no PMC run is on record."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            return round(json.load(f)["hbm_bytes_per_row"] * nb)
+    except Exception:
+        return None
+
+
 _T0 = time.perf_counter()
 
 
@@ -187,13 +197,13 @@ def main():
     }
     if rank == 0:
         # roofline of the dominant kernel: the last decoder block's 3x3 conv (256 -> 64 ch @256^2, 40 % of a forward),
-        # conv_igemm_kernel<256,64,4,1>; HIP events on the launch stream, operands = live workspace activations
+        # conv_igemm_kernel<256,64,4,1,1>; HIP events on the launch stream, operands = live workspace activations
         ms, fl, by = eng.time_conv_layer(1, 11, nb, iters=10)
         log(f"dec5 conv: {ms:.3f} ms per launch")
-        result["roofline"] = {"bound": "mfma", "kernel": "conv_igemm_kernel<256,64,4,1> (dec5: 3x3, 256->64 ch @256^2)",
+        result["roofline"] = {"bound": "mfma", "kernel": "conv_igemm_kernel<256,64,4,1,1> (dec5: fused x2-upsample + 3x3 conv, 256->64 ch, 128^2->256^2)",
                               "achieved": round(fl / ms / 1e9, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                               "frac": round(fl / ms / 1e9 / PEAK_BF16_TFLOPS, 4), "avg_ms": round(ms, 4),
-                              "flops_per_launch": fl, "algorithmic_bytes_per_launch": by, "traffic": None}
+                              "flops_per_launch": fl, "algorithmic_bytes_per_launch": by, "traffic": pmc_traffic(nb)}
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(F, I)
         print(json.dumps(result), flush=True)

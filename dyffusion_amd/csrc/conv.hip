@@ -304,22 +304,34 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a, int M, i
     const int a_row_off = (wm * 64 + l31) * 128;
     const int b_row_off = (wn * 64 + l31) * 128;
 
+    // One K step of MFMAs.  Fragment reads are software-pipelined one k16 sub-step ahead (two register sets), so only
+    // the first ds_read latency of a K step is exposed instead of four.
     auto compute = [&](int stage) {
-        const char* As = smem + stage * STAGE;
-        const char* Bs = As + A_BYTES;
+        const char* As = smem + stage * STAGE + a_row_off;
+        const char* Bs = smem + stage * STAGE + A_BYTES + b_row_off;
+        bf16x8 af[2][2], bfr[2][2];
+        {
+            const int coff = ((hi ^ l7) << 4);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) af[0][i] = *(const bf16x8*)(As + i * 32 * 128 + coff);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bfr[0][j] = *(const bf16x8*)(Bs + j * 32 * 128 + coff);
+        }
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            const int coff = (((ks * 2 + hi) ^ l7) << 4);
-            bf16x8 af[2], bfr[2];
+            const int cs = ks & 1, ns = cs ^ 1;
+            if (ks < 3) {
+                const int coff = ((((ks + 1) * 2 + hi) ^ l7) << 4);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) af[i] = *(const bf16x8*)(As + a_row_off + i * 32 * 128 + coff);
+                for (int i = 0; i < 2; ++i) af[ns][i] = *(const bf16x8*)(As + i * 32 * 128 + coff);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) bfr[j] = *(const bf16x8*)(Bs + b_row_off + j * 32 * 128 + coff);
+                for (int j = 0; j < 2; ++j) bfr[ns][j] = *(const bf16x8*)(Bs + j * 32 * 128 + coff);
+            }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cs][i], bfr[cs][j], acc[i][j], 0, 0, 0);
         }
     };
 

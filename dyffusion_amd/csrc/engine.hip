@@ -984,8 +984,10 @@ dyf_status dyf_time_conv_layer(dyf_engine* e, int32_t which, int32_t layer, int3
     const double M = (double)nb * b.out_h * b.out_w;
     if (flops) *flops = 2.0 * M * b.cout * b.cin * b.k * b.k;
     // algorithmic HBM bytes: read the input once, write the output once, read the weights once (bf16)
-    if (algo_bytes)
-        *algo_bytes = 2.0 * ((double)nb * b.in_h * b.in_w * b.cin + M * b.cout + (double)b.cout * b.cin * b.k * b.k);
+    if (algo_bytes) {  // the fused x2-upsample form reads its input at low resolution
+        const double in_px = a.up2x ? (double)a.h * a.w : (double)b.in_h * b.in_w;
+        *algo_bytes = 2.0 * ((double)nb * in_px * b.cin + M * b.cout + (double)b.cout * b.cin * b.k * b.k);
+    }
     return DYF_OK;
 }
 
