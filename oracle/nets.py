@@ -238,3 +238,114 @@ def simple_conv_net_forward(P: Dict[str, Tensor], cfg: dict, inputs: Tensor, tim
         if cfg.get("residual", True) and w.shape[0] == w.shape[1]:
             x = x + res
     return F.conv2d(x, P["head.weight"], P["head.bias"])
+
+
+# ----------------------------------------------------------------------------- unet.Unet (OISST / synthetic backbone)
+def _ws_conv3x3(P, prefix, x):
+    """WeightStandardizedConv2d (unet.py:26-40): per-out-channel (w - mean) * rsqrt(var + 1e-5), biased variance."""
+    w = P[f"{prefix}.weight"]
+    mean = w.mean(dim=(1, 2, 3), keepdim=True)
+    var = w.var(dim=(1, 2, 3), unbiased=False, keepdim=True)
+    return F.conv2d(x, (w - mean) * (var + 1e-5).rsqrt(), P[f"{prefix}.bias"], padding=1)
+
+
+def _resnet_block(P, pre, x, temb, groups, p1, p2, dropout):
+    """ResnetBlock (unet.py:79-109) = Block(FiLM) -> Block -> + residual_conv(x); Block = WS-conv, GroupNorm, FiLM, SiLU,
+    Dropout (unet.py:58-76)."""
+    h = _ws_conv3x3(P, f"{pre}.block1.proj", x)
+    h = F.group_norm(h, groups, P[f"{pre}.block1.norm.weight"], P[f"{pre}.block1.norm.bias"], eps=1e-5)
+    if temb is not None and f"{pre}.mlp.1.weight" in P:
+        scale, shift = film(P, f"{pre}.mlp", temb)
+        h = h * (scale + 1) + shift
+    h = dropout.apply(F.silu(h), p1)
+    h = _ws_conv3x3(P, f"{pre}.block2.proj", h)
+    h = F.group_norm(h, groups, P[f"{pre}.block2.norm.weight"], P[f"{pre}.block2.norm.bias"], eps=1e-5)
+    h = dropout.apply(F.silu(h), p2)
+    if f"{pre}.residual_conv.weight" in P:
+        x = F.conv2d(x, P[f"{pre}.residual_conv.weight"], P[f"{pre}.residual_conv.bias"])
+    return h + x
+
+
+def _channel_layernorm(x, g):
+    """unet.LayerNorm (unet.py:43-52): over the channel dim, biased variance, gain only, eps 1e-5 (fp32)."""
+    var = x.var(dim=1, unbiased=False, keepdim=True)
+    mean = x.mean(dim=1, keepdim=True)
+    return (x - mean) * (var + 1e-5).rsqrt() * g
+
+
+def _linear_attention(P, pre, x, heads, dim_head, p_attn, dropout):
+    """Residual(PreNorm(LayerNorm, LinearAttention(rescale='qkv'))) (attention.py:7-44, net_norm.py:18-26, misc.py:8-14)."""
+    b, c, hh, ww = x.shape
+    n = hh * ww
+    y = _channel_layernorm(x, P[f"{pre}.fn.norm.g"])
+    y = dropout.apply(y, p_attn)
+    qkv = F.conv2d(y, P[f"{pre}.fn.fn.to_qkv.1.weight"]).reshape(b, 3, heads, dim_head, n)
+    q, k, v = qkv[:, 0], qkv[:, 1], qkv[:, 2]
+    q = q.softmax(dim=-2) * dim_head ** -0.5
+    k = k.softmax(dim=-1)
+    v = v / n
+    context = torch.einsum("bhdn,bhen->bhde", k, v)
+    out = torch.einsum("bhde,bhdn->bhen", context, q).reshape(b, heads * dim_head, hh, ww)
+    return F.conv2d(out, P[f"{pre}.fn.fn.to_out.weight"], P[f"{pre}.fn.fn.to_out.bias"]) + x
+
+
+def _full_attention(P, pre, x, heads, dim_head, p_attn, dropout):
+    """Residual(PreNorm(LayerNorm, Attention)) (attention.py:51-73): softmax(q*scale . k) over keys, dropout on the
+    probabilities, times v."""
+    b, c, hh, ww = x.shape
+    n = hh * ww
+    y = _channel_layernorm(x, P[f"{pre}.fn.norm.g"])
+    qkv = F.conv2d(y, P[f"{pre}.fn.fn.to_qkv.weight"]).reshape(b, 3, heads, dim_head, n)
+    q, k, v = qkv[:, 0] * dim_head ** -0.5, qkv[:, 1], qkv[:, 2]
+    attn = torch.einsum("bhdi,bhdj->bhij", q, k).softmax(dim=-1)
+    attn = dropout.apply(attn, p_attn)
+    out = torch.einsum("bhij,bhdj->bhid", attn, v)                        # (b, h, n, d)
+    out = out.permute(0, 1, 3, 2).reshape(b, heads * dim_head, hh, ww)    # "b h (x y) d -> b (h d) x y"
+    return F.conv2d(out, P[f"{pre}.fn.fn.to_out.weight"], P[f"{pre}.fn.fn.to_out.bias"]) + x
+
+
+def resnet_unet_forward(P: Dict[str, Tensor], cfg: dict, x: Tensor, time: Optional[Tensor] = None,
+                        condition: Optional[Tensor] = None, dropout=None) -> Tensor:
+    """unet.Unet.forward (unet.py:266-315).  cfg keys: dim, dim_mults, with_time_emb, block_dropout (second block),
+    block_dropout1 (first block), attn_dropout, resnet_block_groups (8), init_kernel_size (7), init_padding (3);
+    input_dropout must be 0 and there is no outer resampling (the shipped OISST / synthetic settings).
+    NOTE the condition goes FIRST in the channel concat here (unet.py:269), unlike unet_simple."""
+    dropout = dropout or DropoutOff()
+    dim, mults = cfg["dim"], tuple(cfg.get("dim_mults", (1, 2, 4)))
+    groups = cfg.get("resnet_block_groups", 8)
+    p2, p1, pa = cfg.get("block_dropout", 0.0), cfg.get("block_dropout1", 0.0), cfg.get("attn_dropout", 0.0)
+    heads, dh = 4, 32
+    assert cfg.get("input_dropout", 0.0) == 0.0 and cfg.get("upsample_dims") is None
+    if condition is not None:
+        x = torch.cat([condition, x], dim=1)
+    x = F.conv2d(x, P["init_conv.weight"], P["init_conv.bias"], padding=cfg.get("init_padding", 3))
+    r = x
+    temb = time_embedding(P, "time_emb_mlp", time, dim) if cfg.get("with_time_emb", False) else None
+    nlev = len(mults)
+    skips = []
+    for li in range(nlev):
+        pre = f"downs.{li}"
+        x = _resnet_block(P, f"{pre}.0", x, temb, groups, p1, p2, dropout)
+        skips.append(x)
+        x = _resnet_block(P, f"{pre}.1", x, temb, groups, p1, p2, dropout)
+        x = _linear_attention(P, f"{pre}.2", x, heads, dh, pa, dropout)
+        skips.append(x)
+        if li < nlev - 1:
+            x = F.conv2d(x, P[f"{pre}.3.weight"], P[f"{pre}.3.bias"], stride=2, padding=1)   # Downsample: k4 s2 p1
+        else:
+            x = F.conv2d(x, P[f"{pre}.3.weight"], P[f"{pre}.3.bias"], padding=1)
+    x = _resnet_block(P, "mid_block1", x, temb, groups, p1, p2, dropout)
+    x = _full_attention(P, "mid_attn", x, heads, dh, pa, dropout)
+    x = _resnet_block(P, "mid_block2", x, temb, groups, p1, p2, dropout)
+    for li in range(nlev):
+        pre = f"ups.{li}"
+        x = _resnet_block(P, f"{pre}.0", torch.cat([x, skips.pop()], dim=1), temb, groups, p1, p2, dropout)
+        x = _resnet_block(P, f"{pre}.1", torch.cat([x, skips.pop()], dim=1), temb, groups, p1, p2, dropout)
+        x = _linear_attention(P, f"{pre}.2", x, heads, dh, pa, dropout)
+        if li < nlev - 1:
+            x = F.interpolate(x, scale_factor=2, mode="nearest")
+            x = F.conv2d(x, P[f"{pre}.3.1.weight"], P[f"{pre}.3.1.bias"], padding=1)
+        else:
+            x = F.conv2d(x, P[f"{pre}.3.weight"], P[f"{pre}.3.bias"], padding=1)
+    x = _resnet_block(P, "final_res_block", torch.cat([x, r], dim=1), temb, groups, p1, p2, dropout)
+    return F.conv2d(x, P["final_conv.weight"], P["final_conv.bias"])

@@ -187,6 +187,50 @@ def gen_nets():
     print("net_simple_conv y std", float(y_eval.std()))
 
 
+def gen_resnet_unets():
+    """G3 for src.models.unet.Unet (OISST / synthetic backbone): tiny nets, eval + seeded dropout."""
+    from src.models.unet import Unet
+
+    specs = [
+        ("net_unet_resnet_a", dict(dim=8, mults=(1, 2, 4), n_in=2, n_cond=1, n_out=1, hw=(12, 12), nb=2,
+                                   bd=0.3, bd1=0.1, ad=0.2)),
+        ("net_unet_resnet_b", dict(dim=16, mults=(1, 2), n_in=1, n_cond=0, n_out=1, hw=(20, 12), nb=2,
+                                   bd=0.6, bd1=0.2, ad=0.6)),
+    ]
+    for name, sp in specs:
+        net = Unet(dim=sp["dim"], dim_mults=sp["mults"], with_time_emb=True, block_dropout=sp["bd"],
+                   block_dropout1=sp["bd1"], attn_dropout=sp["ad"], num_input_channels=sp["n_in"],
+                   num_output_channels=sp["n_out"], num_conditional_channels=sp["n_cond"], spatial_shape=sp["hw"],
+                   loss_function="mse", verbose=False).eval()
+        shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+        st = oinit.seeded_state(shapes, seed=13)
+        for k in st:  # LayerNorm gains `g` are 4-D (1,C,1,1): treat as gains, not as conv weights
+            if k.endswith(".norm.g"):
+                st[k] = 1.0 + 0.1 * torch.randn(shapes[k], generator=torch.Generator().manual_seed(hash(k) % 997))
+        net.load_state_dict(st, strict=True)
+        g = torch.Generator().manual_seed(7)
+        x = torch.randn(sp["nb"], sp["n_in"], *sp["hw"], generator=g)
+        c = torch.rand(sp["nb"], sp["n_cond"], *sp["hw"], generator=g) if sp["n_cond"] else None
+        t = torch.tensor([1.0, 2.5])
+        with torch.no_grad():
+            y_eval = net(x, time=t, condition=c)
+            for m in net.modules():
+                if isinstance(m, torch.nn.Dropout):
+                    m.train()
+            with patched_dropout(DropoutSeeded(seed=78)):
+                y_drop = net(x, time=t, condition=c)
+        arrs = dict(np_state(net.state_dict()), x=x.numpy(), t=t.numpy(), y_eval=y_eval.numpy(), y_drop=y_drop.numpy(),
+                    dropout_seed=np.int64(78),
+                    cfg=json.dumps(dict(dim=sp["dim"], dim_mults=list(sp["mults"]), with_time_emb=True,
+                                        block_dropout=sp["bd"], block_dropout1=sp["bd1"], attn_dropout=sp["ad"],
+                                        resnet_block_groups=8, input_dropout=0.0, upsample_dims=None)))
+        if c is not None:
+            arrs["c"] = c.numpy()
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), **arrs)
+        print(name, "y_eval std", float(y_eval.std()), "y_drop std", float(y_drop.std()), "params",
+              sum(v.numel() for v in net.state_dict().values()))
+
+
 # ------------------------------------------------------------------------------------------------ G4
 def gen_samples():
     base_model = dict(dim=4, outer_sample_mode="bilinear", upsample_dims=[64, 64], with_time_emb=True,
@@ -280,11 +324,13 @@ def gen_fullsize():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["schedules", "nets", "samples", "fullsize"]
+    which = sys.argv[1:] or ["schedules", "nets", "resnet", "samples", "fullsize"]
     if "schedules" in which:
         gen_schedules()
     if "nets" in which:
         gen_nets()
+    if "resnet" in which:
+        gen_resnet_unets()
     if "samples" in which:
         gen_samples()
     if "fullsize" in which:

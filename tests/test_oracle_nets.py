@@ -75,3 +75,16 @@ def test_fullsize_forwards_match_reference_checksums():
         assert float(y.mean()) == pytest.approx(meta[key]["mean"], abs=1e-5)
         got = [float(y[tuple(p)]) for p in meta["probes"]]
         assert np.allclose(got, meta[key]["probes"], atol=2e-5)
+
+
+@pytest.mark.parametrize("name", ["net_unet_resnet_a", "net_unet_resnet_b"])
+def test_resnet_unet_matches_reference(name):
+    """src.models.unet.Unet (WS-conv, GroupNorm+SiLU, FiLM, LinearAttention, Attention, channel LayerNorm)."""
+    z = load_npz(name + ".npz")
+    P, cfg = split_state(z, "P"), json.loads(str(z["cfg"]))
+    x, t = torch.from_numpy(z["x"]), torch.from_numpy(z["t"])
+    c = torch.from_numpy(z["c"]) if "c" in z else None
+    y = nets.resnet_unet_forward(P, cfg, x, t, c)
+    assert max_abs(y, z["y_eval"]) <= 1e-5 * max(1.0, float(abs(z["y_eval"]).max()))
+    y = nets.resnet_unet_forward(P, cfg, x, t, c, dropout=nets.DropoutSeeded(int(z["dropout_seed"])))
+    assert max_abs(y, z["y_drop"]) <= 1e-5 * max(1.0, float(abs(z["y_drop"]).max()))
