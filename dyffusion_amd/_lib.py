@@ -9,10 +9,10 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libdyffusion_hip.so")
 
-DYF_ABI_VERSION = 1
+DYF_ABI_VERSION = 2
 DYF_OK, DYF_ERR_INVALID_ARGUMENT, DYF_ERR_UNSUPPORTED, DYF_ERR_HIP, DYF_ERR_STATE = range(5)
 NET_FORECASTER, NET_INTERPOLATOR = 0, 1
-ARCH_UNET_SIMPLE = 0
+ARCH_UNET_SIMPLE, ARCH_UNET_RESNET = 0, 1
 FCOND = {"none": 0, "data": 1, "data+noise": 2}
 
 
@@ -20,7 +20,9 @@ class NetConfig(C.Structure):
     _fields_ = [("arch", C.c_int32), ("in_channels", C.c_int32), ("cond_channels", C.c_int32),
                 ("out_channels", C.c_int32), ("dim", C.c_int32), ("with_time_emb", C.c_int32),
                 ("upsample_h", C.c_int32), ("upsample_w", C.c_int32), ("dropout", C.c_float),
-                ("input_dropout", C.c_float)]
+                ("input_dropout", C.c_float), ("n_mults", C.c_int32), ("dim_mults", C.c_int32 * 6),
+                ("block_dropout1", C.c_float), ("attn_dropout", C.c_float), ("groups", C.c_int32),
+                ("init_kernel_size", C.c_int32), ("init_padding", C.c_int32)]
 
 
 class EngineConfig(C.Structure):

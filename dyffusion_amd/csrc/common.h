@@ -26,11 +26,12 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
 }
 
 // ------------------------------------------------------------------------------------------------ activations
-enum { ACT_NONE = 0, ACT_RELU = 1, ACT_LEAKY = 2 };
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_LEAKY = 2, ACT_SILU = 3 };
 
 __device__ __forceinline__ float apply_act(float v, int act) {
     if (act == ACT_RELU) return fmaxf(v, 0.0f);
     if (act == ACT_LEAKY) return v > 0.0f ? v : 0.2f * v;
+    if (act == ACT_SILU) return v / (1.0f + __expf(-v));
     return v;
 }
 

@@ -25,6 +25,7 @@ struct ConvArgs {
     int coef_stride;
     int act;
     DropSpec drop;
+    const bf16_t* residual;  // NHWC bf16 tensor added after activation/dropout (Residual(...) wrappers), or null
     bf16_t* out_bf16;    // NHWC bf16 output (or null)
     float* out_f32;      // NHWC fp32 output (GroupNorm input) (or null)
     const bf16_t* zero_page;  // >= 128 B of zeros in HBM: source of padded taps for the LDS-DMA gather

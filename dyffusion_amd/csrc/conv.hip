@@ -72,6 +72,7 @@ __global__ void conv_direct_kernel(ConvArgs a, long long total) {
     v = apply_act(v, a.act);
     const uint32_t e = (uint32_t)(m * a.cout + co);
     v = drop_apply(v, e, a.drop, drop_key(a.drop));
+    if (a.residual) v += bf16_to_f32(a.residual[(size_t)m * a.cout + co]);
     if (a.out_bf16) a.out_bf16[(size_t)m * a.cout + co] = f32_to_bf16(v);
     if (a.out_f32) a.out_f32[(size_t)m * a.cout + co] = v;
 }
@@ -469,6 +470,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a, int M, i
         for (int t = 0; t < 8; ++t) {
             v[t] = apply_act(v[t], a.act);
             v[t] = drop_apply(v[t], e0 + t, a.drop, key);
+        }
+        if (a.residual) {
+            const uint4 rq = *(const uint4*)(a.residual + (size_t)m * a.cout + co);
+            const uint32_t rw[4] = {rq.x, rq.y, rq.z, rq.w};
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+                v[t] += (t & 1) ? __uint_as_float(rw[t >> 1] & 0xffff0000u) : __uint_as_float(rw[t >> 1] << 16);
         }
         if (a.out_bf16) {
             uint4 o;

@@ -3,141 +3,12 @@
 //
 // Path being replaced (reference, read-only): src/diffusion/dyffusion.py:335-431 (sample_loop / sample),
 // :140-163 + :480-494 (q_sample / _interpolate), :205-239 (predict_x_last) and src/models/unet_simple.py:164-197.
-#include <algorithm>
-#include <cmath>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <map>
-#include <string>
-#include <vector>
+#include "engine_internal.h"
+#include "unet_kernels.h"
 
-#include "../../include/dyffusion_hip.h"
-#include "conv.h"
-#include "kernels.h"
+using namespace dyf;
 
 namespace {
-
-thread_local std::string g_create_error;
-
-struct UBlock {              // one UNetBlock (unet_simple.py:13-82)
-    int cin = 0, cout = 0, k = 0, stride = 1, pad = 0;
-    bool gn = false;         // GroupNorm(8) instead of BatchNorm (last encoder block)
-    bool transposed = false; // decoder block: x2 bilinear upsample in front of the conv
-    int act = ACT_NONE;
-    int film_off = 0;        // offset of this block's channels in the flattened coefficient table
-    int in_h = 0, in_w = 0;  // conv input size (after the x2 upsample for decoder blocks)
-    int out_h = 0, out_w = 0;
-    bf16_t* wpk = nullptr;   // device [cout][k*k][cin]
-    bf16_t* wpk_up = nullptr;  // decoder 3x3 blocks: phase-decomposed weights of the fused x2-upsample conv
-    float* gamma = nullptr;  // device (GroupNorm only)
-    float* beta = nullptr;
-    float* static_a = nullptr;  // device [cout]: epilogue of the GroupNorm block's conv (ones / conv bias)
-    float* static_c = nullptr;
-};
-
-struct Net {
-    dyf_net_config cfg{};
-    bool loaded = false;
-    int cin_total = 0, dim = 0, tdim = 0, total_c = 0;
-    int uh = 0, uw = 0;      // resampled grid
-    UBlock blk[12];
-    float *t_w1 = nullptr, *t_b1 = nullptr, *t_w2 = nullptr, *t_b2 = nullptr;
-    float *stem_w = nullptr, *stem_b = nullptr;
-    float *film_w = nullptr, *film_b = nullptr, *norm_a = nullptr, *norm_c = nullptr;
-    int *blk_of = nullptr, *blk_off = nullptr, *blk_cout = nullptr;
-    float *ro_w = nullptr, *ro_b = nullptr;
-    bf16_t* enc0_fused_w = nullptr;  // [2dim][4][64]: enc0's 4x4 conv composed with init_conv (+ bias channel)
-    bool stem_fused = false;
-    double flops_per_sample = 0.0;
-    // sampler coefficient tables: one (A, C) row pair per distinct time value
-    std::map<float, int> table_of_time;
-    float* tables = nullptr;  // device [ntables][2][total_c]
-    int ntables = 0;
-};
-
-struct Workspace {
-    bf16_t* stem = nullptr;
-    bf16_t* stem16 = nullptr;  // fused stem: [nb][uh+2][uw+2][16]
-    bf16_t* enc[6] = {};
-    float* enc5_raw = nullptr;
-    bf16_t* up = nullptr;
-    bf16_t* dec[6] = {};
-    float* silu = nullptr;
-    float* coef_a = nullptr;
-    float* coef_c = nullptr;
-    bf16_t* zero_page = nullptr;
-};
-
-struct PlanHost {
-    bool set = false;
-    std::vector<dyf_plan_step> steps;
-    std::vector<float> refine_times;
-    std::vector<int> refine_slots;
-    dyf_plan hdr{};
-};
-
-struct GraphEntry {
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t exec = nullptr;
-};
-
-}  // namespace
-
-struct dyf_engine {
-    dyf_engine_config cfg{};
-    std::string err;
-    Net net[2];
-    Workspace ws;
-    std::vector<void*> allocs;
-    PlanHost plan;
-    int C = 0, Cs = 0, wC = 0;  // dynamics channels, static-condition channels, window*C
-    // sampler state (fp32 NCHW, engine-owned so a captured graph never sees caller pointers)
-    float *s_init = nullptr, *s_static = nullptr, *s_xs = nullptr, *s_x0hat = nullptr, *s_next = nullptr,
-          *s_cur = nullptr, *s_noisy = nullptr, *s_stack = nullptr;
-    float* s_time = nullptr;   // device scalar scratch for time values
-    uint32_t* rng_state = nullptr;  // device {seed_lo, seed_hi, forward_counter, pad}
-    int stack_slots = 0;
-    std::map<int, GraphEntry> graphs;  // by batch size
-    int fuse_min_plane = 32;           // smallest low-res plane side for which the fused form is used
-    bool fuse_stem = true;             // DYF_FUSE_STEM=0: separate 1x1 stem kernel + plain enc0
-    bool fuse_up2x = true;             // DYF_FUSE_UP2X=0 falls back to the materialised upsample (A/B testing)
-    hipStream_t cap_stream = nullptr;  // capture never runs on the caller's (possibly legacy default) stream
-};
-
-namespace {
-
-// ------------------------------------------------------------------------------------------------ error helpers
-dyf_status fail(dyf_engine* e, dyf_status st, const std::string& msg) {
-    if (e) e->err = msg; else g_create_error = msg;
-    return st;
-}
-
-#define HIP_TRY(e, expr)                                                                                   \
-    do {                                                                                                   \
-        hipError_t _err = (expr);                                                                          \
-        if (_err != hipSuccess)                                                                            \
-            return fail(e, DYF_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_err));              \
-    } while (0)
-
-template <typename T>
-dyf_status dev_alloc(dyf_engine* e, T** out, size_t count) {
-    void* p = nullptr;
-    size_t bytes = std::max<size_t>(count * sizeof(T), 256);
-    HIP_TRY(e, hipMalloc(&p, bytes));
-    HIP_TRY(e, hipMemset(p, 0, bytes));
-    e->allocs.push_back(p);
-    *out = (T*)p;
-    return DYF_OK;
-}
-
-template <typename T>
-dyf_status dev_upload(dyf_engine* e, T** out, const std::vector<T>& host) {
-    dyf_status st = dev_alloc(e, out, host.size());
-    if (st != DYF_OK) return st;
-    if (!host.empty()) HIP_TRY(e, hipMemcpy(*out, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
-    return DYF_OK;
-}
 
 // ------------------------------------------------------------------------------------------------ geometry
 void layout_blocks(Net& n) {
@@ -202,19 +73,6 @@ std::string layout_geometry(Net& n, int H, int W) {
 }
 
 // ------------------------------------------------------------------------------------------------ forward
-struct Source {
-    const float* p;
-    int ch;
-};
-
-struct FwdOpts {
-    const float* coef_a;      // [rows][total_c]
-    const float* coef_c;
-    int coef_stride;          // 0: one row for the whole batch
-    int dropout_mode;         // 0 off, 1 engine RNG, 2 injected
-    const uint8_t* const* masks;  // [12] when dropout_mode == 2
-};
-
 DropSpec make_drop(const dyf_engine* e, const Net& n, const FwdOpts& o, int layer) {
     DropSpec d{};
     const float p = n.cfg.dropout;
@@ -263,6 +121,7 @@ ConvArgs block_conv_args(const dyf_engine* e, const Net& n, const UBlock& b, int
 dyf_status net_forward(dyf_engine* e, int which, const Source* srcs, int nsrc, int nb, const FwdOpts& o, float* out_dev,
                        hipStream_t st) {
     Net& n = e->net[which];
+    if (n.rn) return rn_forward(e, which, srcs, nsrc, nb, o, out_dev, st);
     Workspace& ws = e->ws;
     const int H = e->cfg.height, W = e->cfg.width;
     // ---- stem: outer resample + 1x1 conv
@@ -373,17 +232,6 @@ dyf_status compute_coefs(dyf_engine* e, Net& n, const float* time_dev, int rows,
     return DYF_OK;
 }
 
-// ------------------------------------------------------------------------------------------------ weights (K11)
-struct TensorView {
-    const float* data;
-    std::vector<int64_t> shape;
-    int64_t numel() const {
-        int64_t n = 1;
-        for (auto s : shape) n *= s;
-        return n;
-    }
-};
-
 }  // namespace
 
 // ================================================================================================ C ABI
@@ -400,6 +248,8 @@ void dyf_engine_destroy(dyf_engine* e) {
         if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
         if (kv.second.graph) (void)hipGraphDestroy(kv.second.graph);
     }
+    rn_destroy(e->net[0]);
+    rn_destroy(e->net[1]);
     if (e->cap_stream) (void)hipStreamDestroy(e->cap_stream);
     for (void* p : e->allocs) (void)hipFree(p);
     delete e;
@@ -433,9 +283,9 @@ dyf_status dyf_engine_create(const dyf_engine_config* cfg, dyf_engine** out_engi
     for (int w = 0; w < 2; ++w) {
         Net& n = e->net[w];
         n.cfg = cfg->net[w];
-        if (n.cfg.arch != DYF_ARCH_UNET_SIMPLE) return bail(DYF_ERR_UNSUPPORTED, "only arch=unet_simple is implemented");
+        if (n.cfg.arch != DYF_ARCH_UNET_SIMPLE && n.cfg.arch != DYF_ARCH_UNET_RESNET)
+            return bail(DYF_ERR_UNSUPPORTED, "arch must be unet_simple (0) or unet / resnet (1)");
         if (n.cfg.dim < 4 || (n.cfg.dim & 1)) return bail(DYF_ERR_INVALID_ARGUMENT, "dim must be even and >= 4");
-        if ((8 * n.cfg.dim) % 8 != 0) return bail(DYF_ERR_INVALID_ARGUMENT, "GroupNorm(8) needs 8*dim divisible by 8");
         if (n.cfg.input_dropout != 0.0f) return bail(DYF_ERR_UNSUPPORTED, "input_dropout > 0 is not implemented");
         if (n.cfg.dropout < 0.0f || n.cfg.dropout >= 1.0f) return bail(DYF_ERR_INVALID_ARGUMENT, "dropout must be in [0, 1)");
         n.cin_total = n.cfg.in_channels + n.cfg.cond_channels;
@@ -443,6 +293,14 @@ dyf_status dyf_engine_create(const dyf_engine_config* cfg, dyf_engine** out_engi
             return bail(DYF_ERR_UNSUPPORTED, "channel counts outside the supported range (inputs+cond <= 32, outputs <= 8)");
         n.dim = n.cfg.dim;
         n.tdim = 2 * n.cfg.dim;
+        if (n.cfg.arch == DYF_ARCH_UNET_RESNET) {
+            if (n.cfg.block_dropout1 < 0.0f || n.cfg.block_dropout1 >= 1.0f || n.cfg.attn_dropout < 0.0f || n.cfg.attn_dropout >= 1.0f)
+                return bail(DYF_ERR_INVALID_ARGUMENT, "dropout rates must be in [0, 1)");
+            std::string m = rn_configure(e, n);
+            if (!m.empty()) return bail(DYF_ERR_INVALID_ARGUMENT, m);
+            continue;
+        }
+        n.n_drop_sites = n.cfg.dropout > 0.0f ? 12 : 0;
         layout_blocks(n);
         std::string m = layout_geometry(n, cfg->height, cfg->width);
         if (!m.empty()) return bail(DYF_ERR_INVALID_ARGUMENT, m);
@@ -489,6 +347,10 @@ dyf_status dyf_engine_create(const dyf_engine_config* cfg, dyf_engine** out_engi
     ALLOC(e->s_time, 64);
     ALLOC(e->rng_state, 4);
 #undef ALLOC
+    {
+        dyf_status rs = rn_alloc_workspace(e);
+        if (rs != DYF_OK) return bail(rs, e->err);
+    }
     *out_engine = e;
     return DYF_OK;
 }
@@ -513,6 +375,15 @@ dyf_status dyf_load_weights(dyf_engine* e, int32_t which, int32_t n_tensors, con
         v.data = data[i];
         v.shape.assign(shapes[i], shapes[i] + ndims[i]);
         sd[names[i]] = v;
+    }
+    if (n.rn) {
+        dyf_status rs = rn_load_weights(e, n, sd);
+        if (rs != DYF_OK) return rs;
+        n.loaded = true;
+        n.table_of_time.clear();
+        n.ntables = 0;
+        e->plan.set = false;
+        return DYF_OK;
     }
     std::string missing;
     auto get = [&](const std::string& key, std::vector<int64_t> want) -> const TensorView* {
@@ -662,7 +533,9 @@ dyf_status dyf_net_forward(dyf_engine* e, int32_t which, const float* inputs_dev
     hipStream_t st = (hipStream_t)stream;
     dyf_status s = compute_coefs(e, n, time_dev, nb, e->ws.coef_a, e->ws.coef_c, st);
     if (s != DYF_OK) return s;
+    // channel order of the stem: unet_simple cat[inputs, condition] (unet_simple.py:184), unet.Unet cat[condition, x] (unet.py:269)
     Source srcs[2] = {{inputs_dev, n.cfg.in_channels}, {condition_dev, n.cfg.cond_channels}};
+    if (n.rn && condition_dev) std::swap(srcs[0], srcs[1]);
     FwdOpts o{e->ws.coef_a, e->ws.coef_c, n.total_c, dropout_mode, masks_dev};
     return net_forward(e, which, srcs, condition_dev ? 2 : 1, nb, o, out_dev, st);
 }
@@ -783,10 +656,10 @@ namespace {
 struct MaskCursor {
     const uint8_t* const* masks;
     size_t pos = 0;
-    const uint8_t* const* take(bool on) {
+    const uint8_t* const* take(bool on, int n_sites) {
         if (!masks || !on) return nullptr;
         const uint8_t* const* p = masks + pos;
-        pos += 12;
+        pos += n_sites;
         return p;
     }
 };
@@ -808,8 +681,12 @@ dyf_status run_plan(dyf_engine* e, int nb, const uint8_t* const* masks, const fl
         const int ti = I.table_of_time.at(t);
         const float* A = I.tables + (size_t)ti * 2 * I.total_c;
         Source srcs[3] = {{e->s_init, e->wC}, {x_last, e->C}, {e->s_static, e->Cs}};
-        FwdOpts o{A, A + I.total_c, 0, i_mode, cur.take(i_mode == 2 && I.cfg.dropout > 0.0f)};
-        return net_forward(e, DYF_NET_INTERPOLATOR, srcs, e->Cs > 0 ? 3 : 2, nb, o, out, st);
+        int ns = e->Cs > 0 ? 3 : 2;
+        if (I.rn && e->Cs > 0) {  // unet.Unet puts the condition first
+            srcs[0] = {e->s_static, e->Cs}; srcs[1] = {e->s_init, e->wC}; srcs[2] = {x_last, e->C};
+        }
+        FwdOpts o{A, A + I.total_c, 0, i_mode, cur.take(i_mode == 2 && I.n_drop_sites > 0, I.n_drop_sites)};
+        return net_forward(e, DYF_NET_INTERPOLATOR, srcs, ns, nb, o, out, st);
     };
 
     // x_s = initial_condition[:, -C:]  (dyffusion.py:348); rows are (window*C, H, W) blocks -> strided copy per sample
@@ -825,7 +702,7 @@ dyf_status run_plan(dyf_engine* e, int nb, const uint8_t* const* masks, const fl
         // ---- forecaster: x0_hat = F(x_s, enc(s); cond)
         Source fs[3];
         int nf = 0;
-        fs[nf++] = {e->s_xs, e->C};
+        if (!F.rn) fs[nf++] = {e->s_xs, e->C};  // unet_simple: inputs first; unet.Unet: condition first
         if (ph.hdr.forward_conditioning == DYF_FCOND_DATA) {
             fs[nf++] = {e->s_init, e->wC};
         } else if (ph.hdr.forward_conditioning == DYF_FCOND_DATA_NOISE) {
@@ -835,10 +712,11 @@ dyf_status run_plan(dyf_engine* e, int nb, const uint8_t* const* masks, const fl
             fs[nf++] = {e->s_noisy, e->wC};
         }
         if (e->Cs > 0) fs[nf++] = {e->s_static, e->Cs};
+        if (F.rn) fs[nf++] = {e->s_xs, e->C};
         {
             const int ti = F.table_of_time.at(s.forecaster_time);
             const float* A = F.tables + (size_t)ti * 2 * F.total_c;
-            FwdOpts o{A, A + F.total_c, 0, f_mode, cur.take(f_mode == 2 && F.cfg.dropout > 0.0f)};
+            FwdOpts o{A, A + F.total_c, 0, f_mode, cur.take(f_mode == 2 && F.n_drop_sites > 0, F.n_drop_sites)};
             dyf_status r = net_forward(e, DYF_NET_FORECASTER, fs, nf, nb, o, e->s_x0hat, st);
             if (r != DYF_OK) return r;
         }
@@ -939,6 +817,7 @@ dyf_status dyf_time_conv_layer(dyf_engine* e, int32_t which, int32_t layer, int3
         return fail(e, DYF_ERR_INVALID_ARGUMENT, "bad argument to dyf_time_conv_layer");
     Net& n = e->net[which];
     if (!n.loaded) return fail(e, DYF_ERR_STATE, "weights not loaded");
+    if (n.rn) return fail(e, DYF_ERR_UNSUPPORTED, "dyf_time_conv_layer addresses the 12 UNetBlocks of arch unet_simple");
     if (nb < 1 || nb > e->cfg.max_batch) return fail(e, DYF_ERR_INVALID_ARGUMENT, "batch size outside [1, max_batch]");
     HIP_TRY(e, hipSetDevice(e->cfg.device));
     hipStream_t st = (hipStream_t)stream;

@@ -1,0 +1,180 @@
+// Internal types of the engine shared by engine.hip (unet_simple backbone, sampler, C ABI) and unet_resnet.hip.
+#pragma once
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/dyffusion_hip.h"
+#include "conv.h"
+#include "kernels.h"
+
+namespace dyf {
+
+struct RNet;  // ResNet-UNet state (unet_resnet.hip)
+
+inline thread_local std::string g_create_error;
+
+struct UBlock {              // one UNetBlock (unet_simple.py:13-82)
+    int cin = 0, cout = 0, k = 0, stride = 1, pad = 0;
+    bool gn = false;         // GroupNorm(8) instead of BatchNorm (last encoder block)
+    bool transposed = false; // decoder block: x2 bilinear upsample in front of the conv
+    int act = ACT_NONE;
+    int film_off = 0;        // offset of this block's channels in the flattened coefficient table
+    int in_h = 0, in_w = 0;  // conv input size (after the x2 upsample for decoder blocks)
+    int out_h = 0, out_w = 0;
+    bf16_t* wpk = nullptr;   // device [cout][k*k][cin]
+    bf16_t* wpk_up = nullptr;  // decoder 3x3 blocks: phase-decomposed weights of the fused x2-upsample conv
+    float* gamma = nullptr;  // device (GroupNorm only)
+    float* beta = nullptr;
+    float* static_a = nullptr;  // device [cout]: epilogue of the GroupNorm block's conv (ones / conv bias)
+    float* static_c = nullptr;
+};
+
+struct Net {
+    dyf_net_config cfg{};
+    bool loaded = false;
+    int cin_total = 0, dim = 0, tdim = 0, total_c = 0;
+    int uh = 0, uw = 0;      // resampled grid
+    UBlock blk[12];
+    float *t_w1 = nullptr, *t_b1 = nullptr, *t_w2 = nullptr, *t_b2 = nullptr;
+    float *stem_w = nullptr, *stem_b = nullptr;
+    float *film_w = nullptr, *film_b = nullptr, *norm_a = nullptr, *norm_c = nullptr;
+    int *blk_of = nullptr, *blk_off = nullptr, *blk_cout = nullptr;
+    float *ro_w = nullptr, *ro_b = nullptr;
+    bf16_t* enc0_fused_w = nullptr;  // [2dim][4][64]: enc0's 4x4 conv composed with init_conv (+ bias channel)
+    bool stem_fused = false;
+    double flops_per_sample = 0.0;
+    int n_drop_sites = 12;   // dropout sites with p > 0 per forward (mask-injection cursor); 12 UNetBlocks for unet_simple
+    struct RNet* rn = nullptr;  // arch == DYF_ARCH_UNET_RESNET: all state lives here (unet_resnet.hip)
+    // sampler coefficient tables: one (A, C) row pair per distinct time value
+    std::map<float, int> table_of_time;
+    float* tables = nullptr;  // device [ntables][2][total_c]
+    int ntables = 0;
+};
+
+struct Workspace {
+    bf16_t* stem = nullptr;
+    bf16_t* stem16 = nullptr;  // fused stem: [nb][uh+2][uw+2][16]
+    bf16_t* enc[6] = {};
+    float* enc5_raw = nullptr;
+    bf16_t* up = nullptr;
+    bf16_t* dec[6] = {};
+    float* silu = nullptr;
+    float* coef_a = nullptr;
+    float* coef_c = nullptr;
+    bf16_t* zero_page = nullptr;
+};
+
+struct PlanHost {
+    bool set = false;
+    std::vector<dyf_plan_step> steps;
+    std::vector<float> refine_times;
+    std::vector<int> refine_slots;
+    dyf_plan hdr{};
+};
+
+struct GraphEntry {
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+};
+
+}  // namespace dyf
+
+struct dyf_engine {
+    dyf_engine_config cfg{};
+    std::string err;
+    dyf::Net net[2];
+    dyf::Workspace ws;
+    std::vector<void*> allocs;
+    dyf::PlanHost plan;
+    int C = 0, Cs = 0, wC = 0;  // dynamics channels, static-condition channels, window*C
+    // sampler state (fp32 NCHW, engine-owned so a captured graph never sees caller pointers)
+    float *s_init = nullptr, *s_static = nullptr, *s_xs = nullptr, *s_x0hat = nullptr, *s_next = nullptr,
+          *s_cur = nullptr, *s_noisy = nullptr, *s_stack = nullptr;
+    float* s_time = nullptr;   // device scalar scratch for time values
+    uint32_t* rng_state = nullptr;  // device {seed_lo, seed_hi, forward_counter, pad}
+    int stack_slots = 0;
+    std::map<int, dyf::GraphEntry> graphs;  // by batch size
+    int fuse_min_plane = 32;           // smallest low-res plane side for which the fused form is used
+    bool fuse_stem = true;             // DYF_FUSE_STEM=0: separate 1x1 stem kernel + plain enc0
+    bool fuse_up2x = true;             // DYF_FUSE_UP2X=0 falls back to the materialised upsample (A/B testing)
+    hipStream_t cap_stream = nullptr;  // capture never runs on the caller's (possibly legacy default) stream
+};
+
+namespace dyf {
+
+// ------------------------------------------------------------------------------------------------ error helpers
+inline dyf_status fail(dyf_engine* e, dyf_status st, const std::string& msg) {
+    if (e) e->err = msg; else g_create_error = msg;
+    return st;
+}
+
+#define HIP_TRY(e, expr)                                                                                   \
+    do {                                                                                                   \
+        hipError_t _err = (expr);                                                                          \
+        if (_err != hipSuccess)                                                                            \
+            return fail(e, DYF_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_err));              \
+    } while (0)
+
+template <typename T>
+dyf_status dev_alloc(dyf_engine* e, T** out, size_t count) {
+    void* p = nullptr;
+    size_t bytes = std::max<size_t>(count * sizeof(T), 256);
+    HIP_TRY(e, hipMalloc(&p, bytes));
+    HIP_TRY(e, hipMemset(p, 0, bytes));
+    e->allocs.push_back(p);
+    *out = (T*)p;
+    return DYF_OK;
+}
+
+template <typename T>
+dyf_status dev_upload(dyf_engine* e, T** out, const std::vector<T>& host) {
+    dyf_status st = dev_alloc(e, out, host.size());
+    if (st != DYF_OK) return st;
+    if (!host.empty()) HIP_TRY(e, hipMemcpy(*out, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
+    return DYF_OK;
+}
+
+
+// host view of one state_dict tensor (dyf_load_weights)
+struct TensorView {
+    const float* data;
+    std::vector<int64_t> shape;
+    int64_t numel() const {
+        int64_t n = 1;
+        for (auto s : shape) n *= s;
+        return n;
+    }
+};
+
+
+struct Source {
+    const float* p;
+    int ch;
+};
+
+struct FwdOpts {
+    const float* coef_a;      // [rows][total_c]
+    const float* coef_c;
+    int coef_stride;          // 0: one row for the whole batch
+    int dropout_mode;         // 0 off, 1 engine RNG, 2 injected
+    const uint8_t* const* masks;  // [12] when dropout_mode == 2
+};
+
+
+}  // namespace dyf
+
+// ---- ResNet-UNet backbone (src/models/unet.py), implemented in unet_resnet.hip
+namespace dyf {
+std::string rn_configure(dyf_engine* e, Net& n);   // "" or an error message; fills geometry + flops
+dyf_status rn_alloc_workspace(dyf_engine* e);
+dyf_status rn_load_weights(dyf_engine* e, Net& n, std::map<std::string, TensorView>& sd);
+dyf_status rn_forward(dyf_engine* e, int which, const Source* srcs, int nsrc, int nb, const FwdOpts& o, float* out_dev,
+                      hipStream_t st);
+void rn_destroy(Net& n);
+}  // namespace dyf

@@ -1,0 +1,74 @@
+// Kernels of the ResNet-UNet backbone (src/models/unet.py, OISST / synthetic configs): launch prototypes.
+#pragma once
+#include "common.h"
+
+// init_conv: k x k (7x7, pad 3) conv of the channel-concatenated NCHW fp32 inputs -> NHWC bf16 (unet.py:149-151, :273)
+struct StemConvArgs {
+    const float* src[4];
+    int ch[4];
+    int nsrc, cin;
+    int n, h, w;
+    int k, pad;
+    const float* wgt;   // [k*k][cin][dim] fp32
+    const float* bias;  // [dim]
+    int dim;
+    bf16_t* out;        // [n][h][w][dim]
+};
+hipError_t launch_stem_conv(const StemConvArgs& a, hipStream_t s);
+
+// K5: GroupNorm(G) + FiLM + SiLU + Dropout (+ residual) of unet.Block (unet.py:58-76) on a bf16 NHWC tensor
+struct GnActArgs {
+    const bf16_t* x;        // raw conv output [n][hw][c]
+    int n, hw, c, groups;
+    const float* gamma;
+    const float* beta;
+    const float* film_a;    // (1+scale) rows, or null (second Block of a ResnetBlock has no FiLM)
+    const float* film_c;
+    int film_stride;
+    int act;
+    DropSpec drop;
+    const bf16_t* residual; // added last (ResnetBlock: h + residual_conv(x)), or null
+    bf16_t* out;
+};
+hipError_t launch_gn_act(const GnActArgs& a, hipStream_t s);
+
+// K6: channel LayerNorm (gain only, biased variance, eps 1e-5) + optional Dropout (unet.py:43-52; attention.py:12)
+struct LayerNormArgs {
+    const bf16_t* x;    // [pixels][c]
+    long long pixels;
+    int c;
+    const float* g;     // [c]
+    DropSpec drop;
+    bf16_t* out;
+};
+hipError_t launch_layernorm_c(const LayerNormArgs& a, hipStream_t s);
+
+// K7: LinearAttention core (attention.py:22-31, rescale "qkv"): qkv [n][hw][3*heads*32] -> out [n][hw][heads*32]
+struct LinAttnArgs {
+    const bf16_t* qkv;
+    int n, hw, heads;   // dim_head = 32
+    bf16_t* out;
+};
+hipError_t launch_linear_attention(const LinAttnArgs& a, hipStream_t s);
+
+// K8 (VALU form for short sequences): softmax(q*scale . k) -> Dropout -> . v  (attention.py:62-72)
+struct AttnArgs {
+    const bf16_t* qkv;      // [n][hw][3*heads*32]
+    int n, hw, heads;
+    DropSpec drop;          // on the probabilities; element index ((n*heads + h)*hw + i)*hw + j
+    bf16_t* out;            // [n][hw][heads*32]
+};
+hipError_t launch_attention(const AttnArgs& a, hipStream_t s);
+
+// final 1x1 conv to the output channels -> NCHW fp32 (unet.py:244-245, :309)
+struct HeadArgs {
+    const bf16_t* x;    // [n][hw][c]
+    int n, hw, c, cout;
+    const float* wgt;   // [cout][c]
+    const float* bias;
+    float* out;         // [n][cout][hw]
+};
+hipError_t launch_head(const HeadArgs& a, hipStream_t s);
+
+// nn.Upsample(scale_factor=2, mode="nearest") (unet.py:16-19) on NHWC bf16
+hipError_t launch_up2x_nearest(const bf16_t* src, int n, int h, int w, int c, bf16_t* out, hipStream_t s);

@@ -1,0 +1,349 @@
+// HBM/LDS-bound kernels of the ResNet-UNet backbone (src/models/unet.py + modules/attention.py) for gfx950.
+#include "unet_kernels.h"
+
+__device__ __forceinline__ float wsum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ float wmax(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+__device__ __forceinline__ float bsum(float v, float* scratch) {
+    v = wsum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if (lane == 0) scratch[wave] = v;
+    __syncthreads();
+    float t = 0.0f;
+    for (int i = 0; i < nw; ++i) t += scratch[i];
+    return t;
+}
+
+// ------------------------------------------------------------------------------------------------ init_conv
+__global__ __launch_bounds__(256) void stem_conv_kernel(StemConvArgs a) {
+    extern __shared__ float wsh[];  // [k*k*cin][dim]
+    const int wcount = a.k * a.k * a.cin * a.dim;
+    for (int i = threadIdx.x; i < wcount; i += blockDim.x) wsh[i] = a.wgt[i];
+    __syncthreads();
+    const long long pix = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long total = (long long)a.n * a.h * a.w;
+    if (pix >= total) return;
+    const int n = (int)(pix / ((long long)a.h * a.w));
+    const int rem = (int)(pix % ((long long)a.h * a.w));
+    const int y = rem / a.w, x = rem % a.w;
+    bf16_t* out = a.out + (size_t)pix * a.dim;
+    for (int d0 = 0; d0 < a.dim; d0 += 16) {
+        float acc[16];
+#pragma unroll
+        for (int t = 0; t < 16; ++t) acc[t] = (d0 + t < a.dim) ? a.bias[d0 + t] : 0.0f;
+        for (int ky = 0; ky < a.k; ++ky) {
+            const int iy = y + ky - a.pad;
+            if ((unsigned)iy >= (unsigned)a.h) continue;
+            for (int kx = 0; kx < a.k; ++kx) {
+                const int ix = x + kx - a.pad;
+                if ((unsigned)ix >= (unsigned)a.w) continue;
+                int cbase = 0;
+                for (int s = 0; s < a.nsrc; ++s) {
+                    const float* src = a.src[s] + ((size_t)n * a.ch[s]) * a.h * a.w + (size_t)iy * a.w + ix;
+                    for (int c = 0; c < a.ch[s]; ++c) {
+                        const float v = src[(size_t)c * a.h * a.w];
+                        const float* wr = wsh + ((size_t)(ky * a.k + kx) * a.cin + cbase + c) * a.dim + d0;
+#pragma unroll
+                        for (int t = 0; t < 16; ++t)
+                            if (d0 + t < a.dim) acc[t] = fmaf(v, wr[t], acc[t]);
+                    }
+                    cbase += a.ch[s];
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 16; ++t)
+            if (d0 + t < a.dim) out[d0 + t] = f32_to_bf16(acc[t]);
+    }
+}
+
+hipError_t launch_stem_conv(const StemConvArgs& a, hipStream_t s) {
+    const long long total = (long long)a.n * a.h * a.w;
+    hipLaunchKernelGGL(stem_conv_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256),
+                       (size_t)a.k * a.k * a.cin * a.dim * sizeof(float), s, a);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ GroupNorm + act
+// One workgroup per (sample, group): wavefront reductions for mean / centred variance, then the fused epilogue.
+__global__ __launch_bounds__(256) void gn_act_kernel(GnActArgs a) {
+    __shared__ float scratch[16];
+    const int n = blockIdx.x / a.groups, g = blockIdx.x % a.groups;
+    const int cpg = a.c / a.groups;
+    const int count = a.hw * cpg;
+    const bf16_t* x = a.x + (size_t)n * a.hw * a.c + g * cpg;
+    float s = 0.0f;
+    for (int i = threadIdx.x; i < count; i += blockDim.x) s += bf16_to_f32(x[(size_t)(i / cpg) * a.c + (i % cpg)]);
+    const float mean = bsum(s, scratch) / (float)count;
+    float v = 0.0f;
+    for (int i = threadIdx.x; i < count; i += blockDim.x) {
+        const float d = bf16_to_f32(x[(size_t)(i / cpg) * a.c + (i % cpg)]) - mean;
+        v = fmaf(d, d, v);
+    }
+    const float rstd = rsqrtf(bsum(v, scratch) / (float)count + 1e-5f);
+    const uint32_t key = drop_key(a.drop);
+    for (int i = threadIdx.x; i < count; i += blockDim.x) {
+        const int p = i / cpg, ch = g * cpg + (i % cpg);
+        const size_t e = ((size_t)n * a.hw + p) * a.c + ch;
+        float y = (bf16_to_f32(a.x[e]) - mean) * rstd * a.gamma[ch] + a.beta[ch];
+        if (a.film_a) {
+            const size_t fi = (size_t)n * a.film_stride + ch;
+            y = fmaf(y, a.film_a[fi], a.film_c[fi]);
+        }
+        y = apply_act(y, a.act);
+        y = drop_apply(y, (uint32_t)e, a.drop, key);
+        if (a.residual) y += bf16_to_f32(a.residual[e]);
+        a.out[e] = f32_to_bf16(y);
+    }
+}
+
+hipError_t launch_gn_act(const GnActArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(gn_act_kernel, dim3(a.n * a.groups), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ channel LayerNorm
+// 8 lanes per pixel (each a strided slice of the channels), butterfly over the 8 lanes.
+__global__ __launch_bounds__(256) void layernorm_c_kernel(LayerNormArgs a) {
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    long long pix = gid >> 3;
+    const int sl = (int)(gid & 7);
+    const bool live = pix < a.pixels;
+    if (!live) pix = a.pixels - 1;
+    const bf16_t* x = a.x + (size_t)pix * a.c;
+    float s = 0.0f;
+    for (int c = sl; c < a.c; c += 8) s += bf16_to_f32(x[c]);
+#pragma unroll
+    for (int off = 4; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    const float mean = s / (float)a.c;
+    float v = 0.0f;
+    for (int c = sl; c < a.c; c += 8) {
+        const float d = bf16_to_f32(x[c]) - mean;
+        v = fmaf(d, d, v);
+    }
+#pragma unroll
+    for (int off = 4; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    const float rstd = rsqrtf(v / (float)a.c + 1e-5f);
+    if (!live) return;
+    const uint32_t key = drop_key(a.drop);
+    for (int c = sl; c < a.c; c += 8) {
+        const size_t e = (size_t)pix * a.c + c;
+        float y = (bf16_to_f32(x[c]) - mean) * rstd * a.g[c];
+        y = drop_apply(y, (uint32_t)e, a.drop, key);
+        a.out[e] = f32_to_bf16(y);
+    }
+}
+
+hipError_t launch_layernorm_c(const LayerNormArgs& a, hipStream_t s) {
+    const long long threads = a.pixels * 8;
+    hipLaunchKernelGGL(layernorm_c_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ LinearAttention
+// One workgroup per (sample, head).  q: softmax over the 32 head channels, times 32^-1/2; k: softmax over the pixels;
+// v / N; context[d][e] = sum_n k[d][n] v[e][n]; out[e][n] = sum_d context[d][e] q[d][n].
+__global__ __launch_bounds__(256) void linear_attention_kernel(LinAttnArgs a) {
+    __shared__ float red[8][32];      // per-wave partials
+    __shared__ float kmax[32], ksum[32];
+    __shared__ float ctx[32][33];
+    __shared__ float tile_k[64][33], tile_v[64][33];
+    const int n = blockIdx.x / a.heads, h = blockIdx.x % a.heads;
+    const int C3 = 3 * a.heads * 32, hd = a.heads * 32;
+    const bf16_t* base = a.qkv + (size_t)n * a.hw * C3;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int d = tid & 31, grp = tid >> 5;  // 8 pixel-groups x 32 channels
+    // ---- pass 1: max over pixels of k[d][.]
+    float m = -3.0e38f;
+    for (int p = grp; p < a.hw; p += 8) m = fmaxf(m, bf16_to_f32(base[(size_t)p * C3 + hd + h * 32 + d]));
+    red[grp][d] = m;
+    __syncthreads();
+    if (tid < 32) {
+        float t = red[0][tid];
+        for (int i = 1; i < 8; ++i) t = fmaxf(t, red[i][tid]);
+        kmax[tid] = t;
+    }
+    __syncthreads();
+    // ---- pass 2: sum over pixels of exp(k - max)
+    float sacc = 0.0f;
+    const float km = kmax[d];
+    for (int p = grp; p < a.hw; p += 8) sacc += __expf(bf16_to_f32(base[(size_t)p * C3 + hd + h * 32 + d]) - km);
+    __syncthreads();
+    red[grp][d] = sacc;
+    __syncthreads();
+    if (tid < 32) {
+        float t = 0.0f;
+        for (int i = 0; i < 8; ++i) t += red[i][tid];
+        ksum[tid] = t;
+    }
+    __syncthreads();
+    // ---- pass 3: context[d][e], thread (dd, e4): 4 entries each; pixels staged 64 at a time
+    const int dd = tid >> 3, e0 = (tid & 7) * 4;
+    float c4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int p0 = 0; p0 < a.hw; p0 += 64) {
+        __syncthreads();
+        for (int i = tid; i < 64 * 32; i += 256) {
+            const int pp = i >> 5, ch = i & 31;
+            const int p = p0 + pp;
+            float kv = 0.0f, vv = 0.0f;
+            if (p < a.hw) {
+                kv = __expf(bf16_to_f32(base[(size_t)p * C3 + hd + h * 32 + ch]) - kmax[ch]) / ksum[ch];
+                vv = bf16_to_f32(base[(size_t)p * C3 + 2 * hd + h * 32 + ch]);
+            }
+            tile_k[pp][ch] = kv;
+            tile_v[pp][ch] = vv;
+        }
+        __syncthreads();
+        for (int pp = 0; pp < 64; ++pp) {
+            const float kv = tile_k[pp][dd];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) c4[t] = fmaf(kv, tile_v[pp][e0 + t], c4[t]);
+        }
+    }
+    const float inv_n = 1.0f / (float)a.hw;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) ctx[dd][e0 + t] = c4[t] * inv_n;
+    __syncthreads();
+    // ---- pass 4: per pixel softmax_d(q) * scale, then out[e] = sum_d ctx[d][e] q[d]
+    const float scale = 0.17677669529663687f;  // 32^-1/2
+    for (int p = tid; p < a.hw; p += 256) {
+        float q[32];
+        float qm = -3.0e38f;
+        const bf16_t* qp = base + (size_t)p * C3 + h * 32;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            q[i] = bf16_to_f32(qp[i]);
+            qm = fmaxf(qm, q[i]);
+        }
+        float qs = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            q[i] = __expf(q[i] - qm);
+            qs += q[i];
+        }
+        const float qn = scale / qs;
+        bf16_t* op = a.out + ((size_t)n * a.hw + p) * hd + h * 32;
+        for (int e = 0; e < 32; ++e) {
+            float o = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 32; ++i) o = fmaf(ctx[i][e], q[i], o);
+            op[e] = f32_to_bf16(o * qn);
+        }
+    }
+    (void)lane; (void)wave;
+}
+
+hipError_t launch_linear_attention(const LinAttnArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(linear_attention_kernel, dim3(a.n * a.heads), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ Attention
+// One thread per query, keys/values of the head streamed through LDS in tiles of 64, online softmax in fp32.
+__global__ __launch_bounds__(64) void attention_kernel(AttnArgs a) {
+    __shared__ float ks[64][33], vs[64][33];
+    const int qtiles = (a.hw + 63) / 64;
+    const int bh = blockIdx.x / qtiles, qt = blockIdx.x % qtiles;
+    const int n = bh / a.heads, h = bh % a.heads;
+    const int C3 = 3 * a.heads * 32, hd = a.heads * 32;
+    const bf16_t* base = a.qkv + (size_t)n * a.hw * C3;
+    const int i = qt * 64 + threadIdx.x;
+    const bool live = i < a.hw;
+    const float scale = 0.17677669529663687f;
+    float q[32], o[32];
+#pragma unroll
+    for (int c = 0; c < 32; ++c) {
+        q[c] = live ? bf16_to_f32(base[(size_t)i * C3 + h * 32 + c]) * scale : 0.0f;
+        o[c] = 0.0f;
+    }
+    float m = -3.0e38f, l = 0.0f;
+    const uint32_t key = drop_key(a.drop);
+    for (int j0 = 0; j0 < a.hw; j0 += 64) {
+        __syncthreads();
+        for (int t = threadIdx.x; t < 64 * 32; t += 64) {
+            const int jj = t >> 5, c = t & 31;
+            const int j = j0 + jj;
+            ks[jj][c] = j < a.hw ? bf16_to_f32(base[(size_t)j * C3 + hd + h * 32 + c]) : 0.0f;
+            vs[jj][c] = j < a.hw ? bf16_to_f32(base[(size_t)j * C3 + 2 * hd + h * 32 + c]) : 0.0f;
+        }
+        __syncthreads();
+        const int jn = min(64, a.hw - j0);
+        for (int jj = 0; jj < jn; ++jj) {
+            float sc = 0.0f;
+#pragma unroll
+            for (int c = 0; c < 32; ++c) sc = fmaf(q[c], ks[jj][c], sc);
+            if (sc > m) {  // rescale the running sums to the new maximum
+                const float f = __expf(m - sc);
+                l *= f;
+#pragma unroll
+                for (int c = 0; c < 32; ++c) o[c] *= f;
+                m = sc;
+            }
+            const float pr = __expf(sc - m);
+            l += pr;  // the softmax normaliser is computed BEFORE dropout (attention.py:69-70)
+            const uint32_t e = (uint32_t)((((size_t)n * a.heads + h) * a.hw + i) * a.hw + (j0 + jj));
+            const float pd = live ? drop_apply(pr, e, a.drop, key) : 0.0f;
+#pragma unroll
+            for (int c = 0; c < 32; ++c) o[c] = fmaf(pd, vs[jj][c], o[c]);
+        }
+    }
+    if (!live) return;
+    bf16_t* op = a.out + ((size_t)n * a.hw + i) * hd + h * 32;  // "b h (x y) d -> b (h d) x y"
+    const float inv = 1.0f / l;
+#pragma unroll
+    for (int c = 0; c < 32; ++c) op[c] = f32_to_bf16(o[c] * inv);
+}
+
+hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
+    const int qtiles = (a.hw + 63) / 64;
+    hipLaunchKernelGGL(attention_kernel, dim3(a.n * a.heads * qtiles), dim3(64), 0, s, a);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------------ head / upsample
+__global__ void head_kernel(HeadArgs a) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = (long long)a.n * a.hw;
+    if (idx >= total) return;
+    const int n = (int)(idx / a.hw), p = (int)(idx % a.hw);
+    const bf16_t* x = a.x + (size_t)idx * a.c;
+    for (int co = 0; co < a.cout; ++co) {
+        float acc = a.bias[co];
+        const float* w = a.wgt + (size_t)co * a.c;
+        for (int c = 0; c < a.c; ++c) acc = fmaf(bf16_to_f32(x[c]), w[c], acc);
+        a.out[((size_t)n * a.cout + co) * a.hw + p] = acc;
+    }
+}
+
+hipError_t launch_head(const HeadArgs& a, hipStream_t s) {
+    const long long total = (long long)a.n * a.hw;
+    hipLaunchKernelGGL(head_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+__global__ void up2x_nearest_kernel(const bf16_t* src, int n, int h, int w, int c, bf16_t* out, long long total) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int ch = (int)(idx % c);
+    const long long pix = idx / c;
+    const int ow = 2 * w, oh = 2 * h;
+    const int ni = (int)(pix / ((long long)oh * ow));
+    const int rem = (int)(pix % ((long long)oh * ow));
+    const int y = rem / ow, x = rem % ow;
+    out[idx] = src[(((size_t)ni * h + (y >> 1)) * w + (x >> 1)) * c + ch];
+}
+
+hipError_t launch_up2x_nearest(const bf16_t* src, int n, int h, int w, int c, bf16_t* out, hipStream_t s) {
+    const long long total = (long long)n * 4 * h * w * c;
+    hipLaunchKernelGGL(up2x_nearest_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, n, h, w, c, out,
+                       total);
+    return hipGetLastError();
+}

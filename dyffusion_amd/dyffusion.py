@@ -14,7 +14,7 @@ from torch import Tensor, nn
 
 from . import _lib as L
 from .engine import HipEngine
-from .unet_simple import UNet, _AttrDict
+from .unet_simple import UNet, _AttrDict  # noqa: F401
 
 Step = Union[int, float]
 
@@ -267,7 +267,7 @@ class DYffusion(nn.Module):
         eng = self._ensure_engine(x0.shape[-2:], x0.shape[0])
         mode = 1 if (self.training or self.enable_interpolator_dropout) else 0
         return eng.net_forward(L.NET_INTERPOLATOR, torch.cat([x_end, x0], dim=1), i_time.float(), static_condition,
-                               dropout_mode=mode if self._ipol_net.hparams.dropout > 0 else 0)
+                               dropout_mode=mode if getattr(self._ipol_net, 'has_dropout', True) else 0)
 
     def predict_x_last(self, condition: Tensor, x_t: Tensor, t: Tensor, is_sampling: bool = False,
                        static_condition: Optional[Tensor] = None) -> Tensor:
@@ -288,7 +288,7 @@ class DYffusion(nn.Module):
             self.diffusion_step_to_interpolation_step(t)
         eng = self._ensure_engine(x_t.shape[-2:], x_t.shape[0])
         return eng.net_forward(L.NET_FORECASTER, x_t, time.float(), cond,
-                               dropout_mode=1 if (self.enable_forecaster_dropout and self.model.hparams.dropout > 0) else 0)
+                               dropout_mode=1 if (self.enable_forecaster_dropout and getattr(self.model, 'has_dropout', True)) else 0)
 
     def p_losses(self, *args, **kwargs):
         raise NotImplementedError("training (dyffusion.py:496-567) is outside the sampling hot path of this engine")

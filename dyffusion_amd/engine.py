@@ -25,8 +25,28 @@ def net_config(*, in_channels: int, cond_channels: int, out_channels: int, dim: 
                upsample_dims: Optional[Sequence[int]] = (256, 256), dropout: float = 0.0,
                input_dropout: float = 0.0) -> L.NetConfig:
     uh, uw = (0, 0) if upsample_dims is None else (int(upsample_dims[0]), int(upsample_dims[1]))
-    return L.NetConfig(L.ARCH_UNET_SIMPLE, in_channels, cond_channels, out_channels, dim, int(bool(with_time_emb)), uh,
-                       uw, float(dropout), float(input_dropout))
+    cfg = L.NetConfig()
+    cfg.arch, cfg.in_channels, cfg.cond_channels, cfg.out_channels = L.ARCH_UNET_SIMPLE, in_channels, cond_channels, out_channels
+    cfg.dim, cfg.with_time_emb, cfg.upsample_h, cfg.upsample_w = dim, int(bool(with_time_emb)), uh, uw
+    cfg.dropout, cfg.input_dropout = float(dropout), float(input_dropout)
+    return cfg
+
+
+def resnet_net_config(*, in_channels: int, cond_channels: int, out_channels: int, dim: int, dim_mults=(1, 2, 4),
+                      with_time_emb: bool = True, block_dropout: float = 0.0, block_dropout1: float = 0.0,
+                      attn_dropout: float = 0.0, input_dropout: float = 0.0, groups: int = 8, init_kernel_size: int = 7,
+                      init_padding: int = 3) -> L.NetConfig:
+    """dyf_net_config for src.models.unet.Unet (no outer resampling)."""
+    cfg = L.NetConfig()
+    cfg.arch, cfg.in_channels, cfg.cond_channels, cfg.out_channels = L.ARCH_UNET_RESNET, in_channels, cond_channels, out_channels
+    cfg.dim, cfg.with_time_emb = dim, int(bool(with_time_emb))
+    cfg.dropout, cfg.input_dropout = float(block_dropout), float(input_dropout)
+    cfg.n_mults = len(dim_mults)
+    for i, m in enumerate(dim_mults):
+        cfg.dim_mults[i] = int(m)
+    cfg.block_dropout1, cfg.attn_dropout, cfg.groups = float(block_dropout1), float(attn_dropout), int(groups)
+    cfg.init_kernel_size, cfg.init_padding = int(init_kernel_size), int(init_padding)
+    return cfg
 
 
 def _f32c(t: torch.Tensor, name: str) -> torch.Tensor:

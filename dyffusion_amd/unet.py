@@ -1,0 +1,176 @@
+"""Host-side mirror of the reference's OISST / synthetic backbone `src/models/unet.py:112-315` (Unet).
+
+Same constructor keywords and the same parameter names as the reference's state_dict; `forward(x, time, condition)`
+hands device pointers to the HIP engine (dyf_net_forward, arch = DYF_ARCH_UNET_RESNET).  The torch.nn modules are
+parameter containers only -- no torch operator runs in forward().
+"""
+from contextlib import contextmanager
+from typing import Optional, Sequence
+
+import torch
+from torch import Tensor, nn
+
+from . import _lib as L
+from .engine import HipEngine, resnet_net_config
+from .unet_simple import _AttrDict
+
+HEADS, DIM_HEAD = 4, 32
+
+
+def _resnet_block(cin: int, cout: int, time_dim: Optional[int], groups: int) -> nn.Module:
+    """Names of ResnetBlock (unet.py:79-98): mlp.1, block{1,2}.{proj,norm}, residual_conv."""
+    blk = nn.Module()
+    blk.mlp = nn.Sequential(nn.SiLU(), nn.Linear(time_dim, cout * 2)) if time_dim is not None else None
+    for i, ci in ((1, cin), (2, cout)):
+        b = nn.Module()
+        b.proj = nn.Conv2d(ci, cout, 3, padding=1)
+        b.norm = nn.GroupNorm(groups, cout)
+        setattr(blk, f"block{i}", b)
+    blk.residual_conv = nn.Conv2d(cin, cout, 1) if cin != cout else nn.Identity()
+    return blk
+
+
+class _Gain(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.g = nn.Parameter(torch.ones(1, dim, 1, 1))
+
+
+def _attention(dim: int, linear: bool) -> nn.Module:
+    """Names of Residual(PreNorm(dim, fn=[Linear]Attention, norm=LayerNorm)): fn.norm.g, fn.fn.to_qkv[.1], fn.fn.to_out."""
+    inner = nn.Module()
+    qkv = nn.Conv2d(dim, HEADS * DIM_HEAD * 3, 1, bias=False)
+    inner.to_qkv = nn.Sequential(nn.Identity(), qkv) if linear else qkv
+    inner.to_out = nn.Conv2d(HEADS * DIM_HEAD, dim, 1)
+    pre = nn.Module()
+    pre.fn = inner
+    pre.norm = _Gain(dim)
+    res = nn.Module()
+    res.fn = pre
+    return res
+
+
+class Unet(nn.Module):
+    def __init__(self, dim, init_dim=None, dim_mults=(1, 2, 4, 8), num_conditions: int = 0, resnet_block_groups=8,
+                 with_time_emb: bool = False, block_dropout: float = 0.0, block_dropout1: float = 0.0,
+                 attn_dropout: float = 0.0, input_dropout: float = 0.0, double_conv_layer: bool = True,
+                 learned_variance=False, learned_sinusoidal_cond=False, learned_sinusoidal_dim=16,
+                 outer_sample_mode: str = None, upsample_dims: tuple = None, keep_spatial_dims: bool = False,
+                 init_kernel_size: int = 7, init_padding: int = 3, init_stride: int = 1,
+                 num_input_channels: int = None, num_output_channels: int = None, num_conditional_channels: int = 0,
+                 spatial_shape: Sequence[int] = None, loss_function: str = "mean_squared_error", datamodule_config=None,
+                 name: str = "", verbose: bool = True):
+        super().__init__()
+        unsupported = dict(init_dim=init_dim not in (None, dim), double_conv_layer=not double_conv_layer,
+                           learned_variance=learned_variance, learned_sinusoidal_cond=learned_sinusoidal_cond,
+                           outer_sample_mode=outer_sample_mode is not None, upsample_dims=upsample_dims is not None,
+                           keep_spatial_dims=keep_spatial_dims, init_stride=init_stride != 1)
+        bad = [k for k, v in unsupported.items() if v]
+        if bad:
+            raise NotImplementedError(f"the HIP engine implements the shipped Unet settings only; unsupported: {bad}")
+        self.hparams = _AttrDict(dim=dim, dim_mults=tuple(dim_mults), resnet_block_groups=resnet_block_groups,
+                                 with_time_emb=with_time_emb, block_dropout=block_dropout, block_dropout1=block_dropout1,
+                                 attn_dropout=attn_dropout, input_dropout=input_dropout, init_kernel_size=init_kernel_size,
+                                 init_padding=init_padding, num_input_channels=num_input_channels,
+                                 num_output_channels=num_output_channels, num_conditional_channels=num_conditional_channels,
+                                 spatial_shape=spatial_shape, outer_sample_mode=None, upsample_dims=None)
+        self.num_input_channels = num_input_channels
+        self.num_conditional_channels = num_conditional_channels
+        cin = num_input_channels + num_conditional_channels
+        self.num_output_channels = num_output_channels or cin
+        self.spatial_shape = None if spatial_shape is None else tuple(spatial_shape)
+        self.time_dim = 2 * dim if with_time_emb else None
+        g, td = resnet_block_groups, self.time_dim
+        self.init_conv = nn.Conv2d(cin, dim, init_kernel_size, padding=init_padding)
+        self.time_emb_mlp = (nn.Sequential(nn.Identity(), nn.Linear(dim, td), nn.GELU(), nn.Linear(td, td))
+                             if with_time_emb else None)
+        dims = [dim] + [dim * m for m in dim_mults]
+        in_out = list(zip(dims[:-1], dims[1:]))
+        self.downs, self.ups = nn.ModuleList(), nn.ModuleList()
+        for i, (a, b) in enumerate(in_out):
+            last = i == len(in_out) - 1
+            down = nn.Conv2d(a, b, 3, padding=1) if last else nn.Conv2d(a, b, 4, 2, 1)
+            self.downs.append(nn.ModuleList([_resnet_block(a, a, td, g), _resnet_block(a, a, td, g), _attention(a, True), down]))
+        mid = dims[-1]
+        self.mid_block1 = _resnet_block(mid, mid, td, g)
+        self.mid_attn = _attention(mid, False)
+        self.mid_block2 = _resnet_block(mid, mid, td, g)
+        for i, (a, b) in enumerate(reversed(in_out)):
+            last = i == len(in_out) - 1
+            up = nn.Conv2d(b, a, 3, padding=1) if last else nn.Sequential(nn.Identity(), nn.Conv2d(b, a, 3, padding=1))
+            self.ups.append(nn.ModuleList([_resnet_block(b + a, b, td, g), _resnet_block(b + a, b, td, g), _attention(b, True), up]))
+        self.final_res_block = _resnet_block(dim * 2, dim, td, g)
+        self.final_conv = nn.Conv2d(dim, self.num_output_channels, 1)
+        self.requires_grad_(False)
+        self.eval()
+        self._engine: Optional[HipEngine] = None
+        self._engine_slot = L.NET_FORECASTER
+        self._engine_key = None
+        self._mc_dropout = False
+
+    # ------------------------------------------------------------------ engine plumbing (same protocol as UNet)
+    def engine_net_config(self) -> L.NetConfig:
+        hp = self.hparams
+        return resnet_net_config(in_channels=self.num_input_channels, cond_channels=self.num_conditional_channels,
+                                 out_channels=self.num_output_channels, dim=hp.dim, dim_mults=hp.dim_mults,
+                                 with_time_emb=hp.with_time_emb, block_dropout=hp.block_dropout,
+                                 block_dropout1=hp.block_dropout1, attn_dropout=hp.attn_dropout,
+                                 input_dropout=hp.input_dropout, groups=hp.resnet_block_groups,
+                                 init_kernel_size=hp.init_kernel_size, init_padding=hp.init_padding)
+
+    @property
+    def has_dropout(self) -> bool:
+        hp = self.hparams
+        return hp.block_dropout > 0 or hp.block_dropout1 > 0 or hp.attn_dropout > 0
+
+    def attach_engine(self, engine: HipEngine, slot: int):
+        self._engine, self._engine_slot, self._engine_key = engine, slot, "attached"
+        engine.load_weights(slot, self.state_dict())
+
+    def load_state_dict(self, state_dict, strict: bool = True, **kw):
+        res = super().load_state_dict(state_dict, strict=strict, **kw)
+        if self._engine is not None:
+            self._engine.load_weights(self._engine_slot, self.state_dict())
+        return res
+
+    def _own_engine(self, nb: int, hw) -> HipEngine:
+        key = (tuple(hw), nb)
+        if self._engine is None or (self._engine_key != "attached" and
+                                    (self._engine_key[0] != key[0] or self._engine_key[1] < nb)):
+            cfg = self.engine_net_config()
+            self._engine = HipEngine(cfg, cfg, hw[0], hw[1], max_batch=nb, use_graph=False)
+            self._engine_slot, self._engine_key = L.NET_FORECASTER, key
+            self._engine.load_weights(self._engine_slot, self.state_dict())
+        return self._engine
+
+    # ------------------------------------------------------------------ reference API
+    def forward(self, x: Tensor, time: Tensor = None, condition: Tensor = None, return_time_emb: bool = False) -> Tensor:
+        if self.num_conditional_channels > 0:
+            if condition is None:
+                raise ValueError("condition must be given when num_conditional_channels > 0")
+        else:
+            assert condition is None, "condition is not None but num_conditional_channels is 0"
+        eng = self._own_engine(x.shape[0], x.shape[-2:])
+        mode = 1 if (self._mc_dropout and self.has_dropout) else 0
+        return eng.net_forward(self._engine_slot, x, time if self.hparams.with_time_emb else None, condition,
+                               dropout_mode=mode)
+
+    def predict_forward(self, inputs: Tensor, metadata=None, **kwargs):
+        return self(inputs, **kwargs)
+
+    @contextmanager
+    def inference_dropout_scope(self, condition: bool, context=None):
+        assert isinstance(condition, bool), f"Condition must be a boolean, got {condition}"
+        prev = self._mc_dropout
+        if condition:
+            self._mc_dropout = True
+        try:
+            yield None
+        finally:
+            self._mc_dropout = prev
+
+    def enable_inference_dropout(self):
+        self._mc_dropout = True
+
+    def disable_inference_dropout(self):
+        self._mc_dropout = False

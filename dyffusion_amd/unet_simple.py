@@ -90,6 +90,10 @@ class UNet(nn.Module):
                           out_channels=self.num_output_channels, dim=hp.dim, with_time_emb=hp.with_time_emb,
                           upsample_dims=hp.upsample_dims, dropout=hp.dropout, input_dropout=hp.input_dropout)
 
+    @property
+    def has_dropout(self) -> bool:
+        return self.hparams.dropout > 0
+
     def attach_engine(self, engine: HipEngine, slot: int):
         """Used by DYffusion: both networks of a pair live in one engine."""
         self._engine, self._engine_slot = engine, slot

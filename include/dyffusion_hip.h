@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DYF_ABI_VERSION 1
+#define DYF_ABI_VERSION 2
 
 typedef struct dyf_engine dyf_engine;
 
@@ -45,7 +45,8 @@ typedef enum dyf_net_id { DYF_NET_FORECASTER = 0, DYF_NET_INTERPOLATOR = 1 } dyf
 
 /* Backbone architectures (src/models/). */
 typedef enum dyf_arch {
-    DYF_ARCH_UNET_SIMPLE = 0 /* src/models/unet_simple.py:85-197 (Navier-Stokes / spring-mesh backbone) */
+    DYF_ARCH_UNET_SIMPLE = 0, /* src/models/unet_simple.py:85-197 (Navier-Stokes / spring-mesh backbone) */
+    DYF_ARCH_UNET_RESNET = 1  /* src/models/unet.py:112-315 (OISST / synthetic backbone: ResnetBlocks + attention) */
 } dyf_arch;
 
 /* Hyper-parameters of one backbone: the kwargs of unet_simple.UNet.__init__ (unet_simple.py:86-95) plus the
@@ -59,8 +60,16 @@ typedef struct dyf_net_config {
     int32_t with_time_emb;    /* 0/1 */
     int32_t upsample_h;       /* upsample_dims[0], 0 = no outer resampling */
     int32_t upsample_w;
-    float dropout;            /* UNetBlock dropout p */
+    float dropout;            /* unet_simple: UNetBlock dropout p; unet: block_dropout (2nd Block of a ResnetBlock) */
     float input_dropout;      /* must be 0 (the shipped configs' value) in this version */
+    /* ---- unet.Unet only (kwargs of Unet.__init__, src/models/unet.py:113-135) ---- */
+    int32_t n_mults;          /* len(dim_mults), <= 6 */
+    int32_t dim_mults[6];
+    float block_dropout1;     /* 1st Block of a ResnetBlock */
+    float attn_dropout;       /* LinearAttention input dropout / Attention probability dropout */
+    int32_t groups;           /* resnet_block_groups */
+    int32_t init_kernel_size; /* 7 */
+    int32_t init_padding;     /* 3 */
 } dyf_net_config;
 
 typedef struct dyf_engine_config {
@@ -114,8 +123,8 @@ dyf_status dyf_load_weights(dyf_engine* engine, int32_t net, int32_t n_tensors, 
 /* ---- per-network seam: BaseModel.forward(inputs, time, condition) (unet_simple.py:181-197) ------------------ */
 /* inputs_dev (NB,in_channels,H,W), time_dev (NB) or NULL when with_time_emb == 0, condition_dev
  * (NB,cond_channels,H,W) or NULL, out_dev (NB,out_channels,H,W).  dropout_mode: 0 off (eval), 1 on (engine RNG),
- * 2 on with injected keep-masks: masks_dev[l] is the uint8 NHWC keep-mask of dropout layer l (12 blocks, in
- * execution order), used by the parity tests. */
+ * 2 on with injected keep-masks: masks_dev[l] is the uint8 keep-mask of the l-th dropout site with p > 0 in
+ * execution order (NHWC for activations, (NB,heads,N,N) for attention probabilities), used by the parity tests. */
 dyf_status dyf_net_forward(dyf_engine* engine, int32_t net, const float* inputs_dev, const float* time_dev,
                            const float* condition_dev, float* out_dev, int32_t nb, int32_t dropout_mode,
                            const uint8_t* const* masks_dev, void* stream);

@@ -1,0 +1,132 @@
+"""-m gpu: the ResNet-UNet backbone (src/models/unet.py: WS-conv, GroupNorm+SiLU+FiLM, LinearAttention, Attention,
+channel LayerNorm) on the HIP engine, against the reference's golden outputs and the oracle.  Tolerance as in
+test_gpu_nets.py (bf16 activations): rel-RMS <= 2e-2 per forward (this net is ~3x deeper than unet_simple)."""
+import json
+
+import pytest
+import torch
+
+import dyffusion_amd as D
+from oracle import init as oinit
+from oracle import nets, sampler
+from tests.gpu_common import DEV
+from tests.helpers import load_npz, rel_rms, split_state
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-2
+
+
+def mirror(P, cfg, n_in, n_cond, n_out):
+    net = D.Unet(dim=cfg["dim"], dim_mults=cfg["dim_mults"], with_time_emb=cfg.get("with_time_emb", True),
+                 block_dropout=cfg.get("block_dropout", 0.0), block_dropout1=cfg.get("block_dropout1", 0.0),
+                 attn_dropout=cfg.get("attn_dropout", 0.0), num_input_channels=n_in, num_output_channels=n_out,
+                 num_conditional_channels=n_cond)
+    net.load_state_dict(P, strict=True)
+    return net
+
+
+def engine_masks(masks, nlev):
+    """oracle keep-masks -> engine layout: activations NCHW -> NHWC; the attention-probability mask (b,h,n,n) of
+    mid_attn is passed unchanged.  Site order (all p > 0): per level [block, block, block, block, linattn], then
+    mid_block1 (2), mid_attn (1), ..."""
+    attn_idx = 5 * nlev + 2
+    return [(m if i == attn_idx else m.permute(0, 2, 3, 1)).contiguous().to(DEV) for i, m in enumerate(masks)]
+
+
+@pytest.mark.parametrize("name", ["net_unet_resnet_a", "net_unet_resnet_b"])
+def test_small_resnet_unets_match_reference_goldens(name):
+    z = load_npz(name + ".npz")
+    P, cfg = split_state(z, "P"), json.loads(str(z["cfg"]))
+    x, t = torch.from_numpy(z["x"]), torch.from_numpy(z["t"])
+    c = torch.from_numpy(z["c"]) if "c" in z else None
+    net = mirror(P, cfg, x.shape[1], 0 if c is None else c.shape[1], z["y_eval"].shape[1])
+    y = net(x.to(DEV), time=t.to(DEV), condition=None if c is None else c.to(DEV)).cpu()
+    err = rel_rms(y, z["y_eval"])
+    print(name, "eval rel-rms", err)
+    assert err <= TOL
+    src = nets.DropoutSeeded(int(z["dropout_seed"]), record=True)
+    y_or = nets.resnet_unet_forward(P, cfg, x, t, c, dropout=src)
+    assert rel_rms(y_or, z["y_drop"]) < 1e-5
+    y = net._engine.net_forward(0, x.to(DEV), t.to(DEV), None if c is None else c.to(DEV), dropout_mode=2,
+                                masks=engine_masks(src.masks, len(cfg["dim_mults"]))).cpu()
+    err = rel_rms(y, z["y_drop"])
+    print(name, "dropout rel-rms", err)
+    assert err <= TOL
+
+
+def rollout_masks(masks, nlev, per_forward):
+    out = []
+    for f0 in range(0, len(masks), per_forward):
+        out += engine_masks(masks[f0:f0 + per_forward], nlev)
+    return out
+
+
+def seeded_unet(dim, mults, cin, cout, seed):
+    net = D.Unet(dim=dim, dim_mults=mults, with_time_emb=True, num_input_channels=cin, num_output_channels=cout)
+    shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    st = oinit.seeded_state(shapes, seed, gain=1.0)
+    for k in st:
+        if k.endswith(".norm.g"):
+            st[k] = 1.0 + 0.1 * torch.randn(shapes[k], generator=torch.Generator().manual_seed(len(k)))
+    return st
+
+
+@pytest.mark.parametrize("hw,nb,n_in,n_cond", [((60, 60), 2, 2, 0), ((32, 48), 2, 1, 1)])
+def test_dim64_oisst_shape_matches_oracle(hw, nb, n_in, n_cond):
+    """OISST configuration of the reference (dim 64, mults (1,2,4), 60x60): MFMA conv path."""
+    cfg = dict(dim=64, dim_mults=[1, 2, 4], with_time_emb=True, block_dropout=0.3, block_dropout1=0.1, attn_dropout=0.2,
+               resnet_block_groups=8, input_dropout=0.0, upsample_dims=None)
+    P = seeded_unet(64, (1, 2, 4), n_in + n_cond, 1, seed=51)
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(nb, n_in, *hw, generator=g)
+    c = torch.rand(nb, n_cond, *hw, generator=g) if n_cond else None
+    t = torch.tensor([1.0, 4.5][:nb])
+    net = mirror(P, cfg, n_in, n_cond, 1)
+    with torch.no_grad():
+        want = nets.resnet_unet_forward(P, cfg, x, t, c)
+    got = net(x.to(DEV), time=t.to(DEV), condition=None if c is None else c.to(DEV)).cpu()
+    err = rel_rms(got, want)
+    print("resnet-unet dim64", hw, "rel-rms", err)
+    assert err <= TOL
+    src = nets.DropoutSeeded(9, record=True)
+    with torch.no_grad():
+        want = nets.resnet_unet_forward(P, cfg, x, t, c, dropout=src)
+    got = net._engine.net_forward(0, x.to(DEV), t.to(DEV), None if c is None else c.to(DEV), dropout_mode=2,
+                                  masks=engine_masks(src.masks, 3)).cpu()
+    err = rel_rms(got, want)
+    print("resnet-unet dim64 dropout", hw, "rel-rms", err)
+    assert err <= TOL
+
+
+def test_oisst_style_rollout_matches_oracle():
+    """DYffusion with the ResNet-UNet pair, OISST settings in miniature: C=1, no static condition, k>0 extra steps,
+    forward_conditioning='data+noise' (injected normal draws), refine off, interpolator MC dropout with injected masks."""
+    mcfg_i = dict(dim=64, dim_mults=[1, 2], with_time_emb=True, block_dropout=0.3, block_dropout1=0.1, attn_dropout=0.2,
+                  resnet_block_groups=8, input_dropout=0.0, upsample_dims=None)
+    mcfg_f = dict(mcfg_i, block_dropout=0.0, block_dropout1=0.0, attn_dropout=0.0)
+    PF, PI = seeded_unet(64, (1, 2), 2, 1, seed=61), seeded_unet(64, (1, 2), 2, 1, seed=62)
+    hp = dict(timesteps=4, schedule="before_t1_only", additional_interpolation_steps=2, interpolate_before_t1=True,
+              sampling_type="cold", refine_intermediate_predictions=False, forward_conditioning="data+noise",
+              time_encoding="dynamics", enable_interpolator_dropout=True)
+    F_ = mirror(PF, mcfg_f, 1, 1, 1)
+    I_ = mirror(PI, mcfg_i, 2, 0, 1)
+    m = D.DYffusion(F_, D.InterpolatorHandle(I_, 4), max_batch=3, **hp)
+    g = torch.Generator().manual_seed(12)
+    x0 = torch.randn(3, 1, 24, 16, generator=g)
+    drop = nets.DropoutSeeded(3, record=True)
+    gen = torch.Generator().manual_seed(4)
+    draws = []
+
+    def nf(t):
+        draws.append(torch.randn(t.shape, generator=gen))
+        return draws[-1]
+
+    with torch.no_grad():
+        want = sampler.sample_loop(lambda x, t, cnd: nets.resnet_unet_forward(PF, mcfg_f, x, t, cnd),
+                                   lambda x, t, cnd: nets.resnet_unet_forward(PI, mcfg_i, x, t, cnd, dropout=drop),
+                                   x0, None, hp, noise_fn=nf)
+    _, got, _ = m.sample_loop(x0.to(DEV), _masks=rollout_masks(drop.masks, 2, 27), _noise=torch.stack(draws, 0).to(DEV))
+    assert sorted(got) == sorted(want)
+    worst = max(rel_rms(got[k].cpu(), want[k]) for k in want)
+    print("OISST-style rollout worst rel-rms", worst)
+    assert worst <= 4e-2

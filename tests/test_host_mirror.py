@@ -103,3 +103,15 @@ def test_product_never_imports_oracle():
         if fn.endswith(".py"):
             src = open(os.path.join(pkg, fn)).read()
             assert "oracle" not in src.replace("the oracle", ""), f"{fn} references the oracle package"
+
+
+def test_resnet_unet_mirror_state_dict_matches_reference_layout():
+    import json
+    from tests.helpers import load_npz, split_state
+    for name in ("net_unet_resnet_a", "net_unet_resnet_b"):
+        z = load_npz(name + ".npz")
+        P, cfg = split_state(z, "P"), json.loads(str(z["cfg"]))
+        n_cond = z["c"].shape[1] if "c" in z else 0
+        net = D.Unet(dim=cfg["dim"], dim_mults=cfg["dim_mults"], with_time_emb=True, num_input_channels=z["x"].shape[1],
+                     num_output_channels=1, num_conditional_channels=n_cond)
+        assert {k: tuple(v.shape) for k, v in net.state_dict().items()} == {k: tuple(v.shape) for k, v in P.items()}
