@@ -29,6 +29,7 @@ struct GnActArgs {
     DropSpec drop;
     const bf16_t* residual; // added last (ResnetBlock: h + residual_conv(x)), or null
     bf16_t* out;
+    double* stats;          // device scratch [n][groups][2] (sum, sum of squares) for the vectorised form, or null
 };
 hipError_t launch_gn_act(const GnActArgs& a, hipStream_t s);
 

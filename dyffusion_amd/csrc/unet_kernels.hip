@@ -1,6 +1,8 @@
 // HBM/LDS-bound kernels of the ResNet-UNet backbone (src/models/unet.py + modules/attention.py) for gfx950.
 #include "unet_kernels.h"
 
+#include <algorithm>
+
 __device__ __forceinline__ float wsum(float v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
@@ -105,7 +107,91 @@ __global__ __launch_bounds__(256) void gn_act_kernel(GnActArgs a) {
     }
 }
 
+// Vectorised two-kernel form (c % 8 == 0, 8-channel chunks never straddle a group): every lane owns one 16-byte chunk
+// of one pixel.  (1) statistics: per-workgroup LDS partials -> one fp64 atomic per (sample, group) and workgroup;
+// (2) apply: normalise + FiLM + SiLU + dropout (+ residual), one 16-B load and one 16-B store per lane.
+// HBM traffic: 2 reads + 1 write of the tensor (+1 read of the residual) instead of 3 strided read passes.
+__global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* x, int hw, int c, int groups, double* stats) {
+    __shared__ float part[64][2];  // groups <= 64
+    const int n = blockIdx.y;
+    const int chunks = c >> 3, cpg = c / groups;
+    for (int i = threadIdx.x; i < groups * 2; i += blockDim.x) (&part[0][0])[i] = 0.0f;
+    __syncthreads();
+    const long long total = (long long)hw * chunks;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int q = (int)(idx % chunks);
+        const long long p = idx / chunks;
+        const uint4 v = *(const uint4*)(x + ((size_t)n * hw + p) * c + q * 8);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        float s = 0.0f, ss = 0.0f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const float lo = __uint_as_float(w[t] << 16), hi = __uint_as_float(w[t] & 0xffff0000u);
+            s += lo + hi;
+            ss = fmaf(lo, lo, fmaf(hi, hi, ss));
+        }
+        const int g = (q * 8) / cpg;
+        atomicAdd(&part[g][0], s);
+        atomicAdd(&part[g][1], ss);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < groups * 2; i += blockDim.x)
+        atomicAdd(&stats[((size_t)n * groups) * 2 + i], (double)(&part[0][0])[i]);
+}
+
+__global__ __launch_bounds__(256) void gn_apply_kernel(GnActArgs a, const double* stats) {
+    const int chunks = a.c >> 3, cpg = a.c / a.groups;
+    const long long total = (long long)a.n * a.hw * chunks;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int q = (int)(idx % chunks);
+    const long long pix = idx / chunks;
+    const int n = (int)(pix / a.hw);
+    const int g = (q * 8) / cpg;
+    const double cnt = (double)a.hw * cpg;
+    const double mean_d = stats[((size_t)n * a.groups + g) * 2] / cnt;
+    const double var_d = stats[((size_t)n * a.groups + g) * 2 + 1] / cnt - mean_d * mean_d;
+    const float mean = (float)mean_d, rstd = rsqrtf(fmaxf((float)var_d, 0.0f) + 1e-5f);
+    const size_t e0 = (size_t)pix * a.c + q * 8;
+    const uint4 v = *(const uint4*)(a.x + e0);
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    uint32_t rw[4] = {0, 0, 0, 0};
+    if (a.residual) {
+        const uint4 r = *(const uint4*)(a.residual + e0);
+        rw[0] = r.x; rw[1] = r.y; rw[2] = r.z; rw[3] = r.w;
+    }
+    const uint32_t key = drop_key(a.drop);
+    float y[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        const int ch = q * 8 + t;
+        const float xv = (t & 1) ? __uint_as_float(w[t >> 1] & 0xffff0000u) : __uint_as_float(w[t >> 1] << 16);
+        float o = (xv - mean) * rstd * a.gamma[ch] + a.beta[ch];
+        if (a.film_a) {
+            const size_t fi = (size_t)n * a.film_stride + ch;
+            o = fmaf(o, a.film_a[fi], a.film_c[fi]);
+        }
+        o = apply_act(o, a.act);
+        o = drop_apply(o, (uint32_t)(e0 + t), a.drop, key);
+        if (a.residual) o += (t & 1) ? __uint_as_float(rw[t >> 1] & 0xffff0000u) : __uint_as_float(rw[t >> 1] << 16);
+        y[t] = o;
+    }
+    *(uint4*)(a.out + e0) = make_uint4(pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]), pack_bf16x2(y[4], y[5]),
+                                       pack_bf16x2(y[6], y[7]));
+}
+
 hipError_t launch_gn_act(const GnActArgs& a, hipStream_t s) {
+    const int cpg = a.c / a.groups;
+    if (a.stats && (a.c % 8 == 0) && (cpg % 8 == 0) && a.groups <= 64) {
+        hipError_t e = hipMemsetAsync(a.stats, 0, (size_t)a.n * a.groups * 2 * sizeof(double), s);
+        if (e != hipSuccess) return e;
+        const long long per_sample = (long long)a.hw * (a.c >> 3);
+        const unsigned bx = (unsigned)std::min<long long>((per_sample + 255) / 256, 64);
+        hipLaunchKernelGGL(gn_stats_kernel, dim3(bx, a.n), dim3(256), 0, s, a.x, a.hw, a.c, a.groups, a.stats);
+        const long long total = (long long)a.n * per_sample;
+        hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a, (const double*)a.stats);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(gn_act_kernel, dim3(a.n * a.groups), dim3(256), 0, s, a);
     return hipGetLastError();
 }

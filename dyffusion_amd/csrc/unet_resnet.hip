@@ -46,6 +46,7 @@ struct RNet {
     std::vector<SampW> downs, ups;
     float *stem_w = nullptr, *stem_b = nullptr, *head_w = nullptr, *head_b = nullptr;
     float *ones = nullptr, *zeros = nullptr;
+    double* gn_stats = nullptr;    // [max_batch][groups][2]
     size_t buf_elems = 0;          // elements of one pool buffer at max_batch
     std::vector<bf16_t*> pool;
 };
@@ -239,6 +240,10 @@ dyf_status rn_alloc_workspace(dyf_engine* e) {
         Net& n = e->net[w];
         if (!n.rn) continue;
         RNet* r = n.rn;
+        {
+            dyf_status s = dev_alloc(e, &r->gn_stats, (size_t)e->cfg.max_batch * n.cfg.groups * 2);
+            if (s != DYF_OK) return s;
+        }
         const int nbuf = 2 * r->nlev + 8;
         // the two networks run back to back: share one pool when both are ResNet-UNets
         if (w == 1 && e->net[0].rn && e->net[0].rn->buf_elems >= r->buf_elems &&
@@ -418,7 +423,7 @@ dyf_status rn_forward(dyf_engine* e, int which, const Source* srcs, int nsrc, in
         GnActArgs g{};
         g.x = t1; g.n = nb; g.hw = hh * ww; g.c = b.cout; g.groups = c.groups; g.gamma = b.g1; g.beta = b.be1;
         if (film) { g.film_a = o.coef_a + b.film_off; g.film_c = o.coef_c + b.film_off; g.film_stride = o.coef_stride; }
-        g.act = ACT_SILU; g.drop = dc.next(c.block_dropout1); g.residual = nullptr; g.out = t1;
+        g.act = ACT_SILU; g.drop = dc.next(c.block_dropout1); g.residual = nullptr; g.out = t1; g.stats = r->gn_stats;
         HIP_TRY(e, launch_gn_act(g, st));
         bf16_t* t2 = pool.get();
         TRY(rconv(e, t1, b.cout, nullptr, 0, nb, hh, ww, 3, 1, 1, b.cout, b.w2, r->ones, b.b2, 0, ACT_NONE, DropSpec{}, nullptr, t2, st));
@@ -432,7 +437,7 @@ dyf_status rn_forward(dyf_engine* e, int which, const Source* srcs, int nsrc, in
         }
         GnActArgs g2{};
         g2.x = t2; g2.n = nb; g2.hw = hh * ww; g2.c = b.cout; g2.groups = c.groups; g2.gamma = b.g2; g2.beta = b.be2;
-        g2.act = ACT_SILU; g2.drop = dc.next(c.dropout); g2.residual = res; g2.out = t2;
+        g2.act = ACT_SILU; g2.drop = dc.next(c.dropout); g2.residual = res; g2.out = t2; g2.stats = r->gn_stats;
         HIP_TRY(e, launch_gn_act(g2, st));
         if (t3) pool.put(t3);
         *out = t2;
