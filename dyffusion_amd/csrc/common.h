@@ -21,8 +21,16 @@ __device__ __host__ __forceinline__ bf16_t f32_to_bf16(float f) {
     return (bf16_t)(u >> 16);
 }
 
+// two fp32 -> packed bf16x2, round-to-nearest-even: one v_cvt_pk_bf16_f32 on gfx950 (no clang builtin; the software
+// form costs ~8 VALU per pair and dominated the conv epilogues)
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+#else
     return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------ activations

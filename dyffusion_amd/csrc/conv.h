@@ -36,3 +36,7 @@ hipError_t conv_init();
 bool conv_mfma_supported(const ConvArgs& a);
 hipError_t launch_conv(const ConvArgs& a, int path, hipStream_t stream);
 void pack_up2x_weights(const float* w, int cout, int cin, bf16_t* out);
+// halo form of the fused x2-upsample conv (conv_up_halo.hip): 16x16 low-res tile x 4 phases x 64 channels per workgroup
+bool conv_up_halo_supported(const ConvArgs& a);
+hipError_t conv_up_halo_init();
+hipError_t launch_conv_up_halo(const ConvArgs& a, hipStream_t stream);

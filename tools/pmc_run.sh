@@ -14,8 +14,8 @@ for grp in \
   "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum" \
   "FETCH_SIZE" \
   "WRITE_SIZE" \
-  "GRBM_GUI_ACTIVE TA_BUSY_avr TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum" ; do
+  "SQ_IFETCH SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SALU SQ_LDS_ADDR_CONFLICT SQ_LDS_UNALIGNED_STALL SQ_INSTS_LDS_LOAD" ; do
   i=$((i+1))
-  timeout 300 rocprofv3 --pmc $grp --kernel-include-regex "conv_igemm|up2x|stem|readout" --output-format csv -d "$R/$OUT/p$i" -o p$i -- python "$R/$@" > "$R/$OUT/p$i.log" 2>&1
+  timeout 300 rocprofv3 --pmc $grp --kernel-include-regex "${DYF_PMC_REGEX:-conv_igemm|conv_up_halo|up2x|stem|readout}" --output-format csv -d "$R/$OUT/p$i" -o p$i -- python "$R/$@" > "$R/$OUT/p$i.log" 2>&1
   echo "pass $i rc=$? : $grp"
 done
