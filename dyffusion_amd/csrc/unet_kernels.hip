@@ -2,6 +2,7 @@
 #include "unet_kernels.h"
 
 #include <algorithm>
+#include <cstdlib>
 
 __device__ __forceinline__ float wsum(float v) {
 #pragma unroll
@@ -333,6 +334,18 @@ hipError_t launch_linear_attention(const LinAttnArgs& a, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------------------ Attention
+__device__ __forceinline__ uint32_t attn_drop_key(const DropSpec& d, uint32_t bh) {
+    return d.mode == 1 ? fmix32(drop_key(d) + bh * 0x9E3779B9u) : 0u;
+}
+// element (query i, key j) of head-sample bh: RNG stream keyed per bh (i*N + j stays below 2^32 for N <= 65535);
+// injected masks are indexed as the (b, h, i, j) tensor the reference's nn.Dropout sees
+__device__ __forceinline__ float attn_drop(float p, const DropSpec& d, uint32_t key, uint32_t bh, uint32_t i, uint32_t j,
+                                           uint32_t n) {
+    if (d.mode == 0) return p;
+    const bool keep = d.mode == 1 ? rng_keep(i * n + j, key, d.thresh16) : (d.mask[((size_t)bh * n + i) * n + j] != 0);
+    return keep ? p * d.scale : 0.0f;
+}
+
 // One thread per query, keys/values of the head streamed through LDS in tiles of 64, online softmax in fp32.
 __global__ __launch_bounds__(64) void attention_kernel(AttnArgs a) {
     __shared__ float ks[64][33], vs[64][33];
@@ -351,7 +364,7 @@ __global__ __launch_bounds__(64) void attention_kernel(AttnArgs a) {
         o[c] = 0.0f;
     }
     float m = -3.0e38f, l = 0.0f;
-    const uint32_t key = drop_key(a.drop);
+    const uint32_t key = attn_drop_key(a.drop, (uint32_t)bh);
     for (int j0 = 0; j0 < a.hw; j0 += 64) {
         __syncthreads();
         for (int t = threadIdx.x; t < 64 * 32; t += 64) {
@@ -375,8 +388,7 @@ __global__ __launch_bounds__(64) void attention_kernel(AttnArgs a) {
             }
             const float pr = __expf(sc - m);
             l += pr;  // the softmax normaliser is computed BEFORE dropout (attention.py:69-70)
-            const uint32_t e = (uint32_t)((((size_t)n * a.heads + h) * a.hw + i) * a.hw + (j0 + jj));
-            const float pd = live ? drop_apply(pr, e, a.drop, key) : 0.0f;
+            const float pd = live ? attn_drop(pr, a.drop, key, (uint32_t)bh, (uint32_t)i, (uint32_t)(j0 + jj), (uint32_t)a.hw) : 0.0f;
 #pragma unroll
             for (int c = 0; c < 32; ++c) o[c] = fmaf(pd, vs[jj][c], o[c]);
         }
@@ -388,7 +400,131 @@ __global__ __launch_bounds__(64) void attention_kernel(AttnArgs a) {
     for (int c = 0; c < 32; ++c) op[c] = f32_to_bf16(o[c] * inv);
 }
 
+// ------------------------------------------------------------------------------------------------ flash attention
+// K8 on MFMA (attention.py:62-72, heads of 32 channels): one wave owns 32 queries, a workgroup 128 queries of one
+// (sample, head); keys/values stream through LDS in tiles of 64.  Both contractions are computed TRANSPOSED so that the
+// softmax row of a query lives in ONE lane pair (lane q and q+32) and never crosses lanes otherwise:
+//   S^T[key][q] = K . Q^T        A = K rows (keys),  B = Q rows (queries)   (2 x v_mfma_f32_32x32x16_bf16, k = channel)
+//   O^T[d][q]  += V^T . P^T      A = V^T rows (d),   B = P^T = the exponentiated S^T registers, packed to bf16
+// The MFMA k-slot <-> key mapping of the second product is chosen to be the C layout of the first (key = 16s + (j&3) +
+// 8(j>>2) + 4*hi), so P feeds the second MFMA straight from registers; V is staged transposed ([d][key], rows padded to
+// 136 B: conflict-free ds_read_b64).  Online softmax in fp32; the normaliser is accumulated BEFORE dropout.
+typedef __attribute__((ext_vector_type(8))) __bf16 fa_bf16x8;
+typedef __attribute__((ext_vector_type(16))) float fa_f32x16;
+
+__global__ __launch_bounds__(256) void flash_attention_kernel(AttnArgs a) {
+    __shared__ __attribute__((aligned(16))) bf16_t Ks[64 * 32];   // [key][32 ch], 16-B chunk ^= (key >> 2) & 3
+    __shared__ __attribute__((aligned(16))) bf16_t Vt[32 * 68];   // [ch][64 keys + 4 pad]
+    const int qblocks = (a.hw + 127) / 128;
+    const int bh = blockIdx.x / qblocks, qb = blockIdx.x % qblocks;
+    const int n = bh / a.heads, h = bh % a.heads;
+    const int C3 = 3 * a.heads * 32, hd = a.heads * 32, N = a.hw;
+    const bf16_t* base = a.qkv + (size_t)n * N * C3;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+    const int q = qb * 128 + wave * 32 + l31;
+    const float scale = 0.17677669529663687f;  // 32^-1/2
+    // Q fragments (B operand of S^T): lane (q, hi) holds channels ks*16 + hi*8 .. +8
+    fa_bf16x8 qf[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (q < N) v = *(const uint4*)(base + (size_t)q * C3 + h * 32 + ks * 16 + hi * 8);
+        qf[ks] = *(fa_bf16x8*)&v;
+    }
+    fa_f32x16 o;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] = 0.0f;
+    float m = -1.0e30f, l = 0.0f;
+    const uint32_t dkey = attn_drop_key(a.drop, (uint32_t)bh);
+
+    for (int j0 = 0; j0 < N; j0 += 64) {
+        __syncthreads();
+        {   // stage K [64][32] and V^T [32][64]: thread -> (key, 16-B chunk of 8 channels)
+            const int key = tid >> 2, ch = tid & 3, j = j0 + key;
+            uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
+            if (j < N) {
+                kv = *(const uint4*)(base + (size_t)j * C3 + hd + h * 32 + ch * 8);
+                vv = *(const uint4*)(base + (size_t)j * C3 + 2 * hd + h * 32 + ch * 8);
+            }
+            *(uint4*)(Ks + key * 32 + ((ch ^ ((key >> 2) & 3)) << 3)) = kv;
+            const bf16_t* ve = (const bf16_t*)&vv;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) Vt[(ch * 8 + i) * 68 + key] = ve[i];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int st = 0; st < 2; ++st) {  // two 32-key sub-tiles
+            const int jb = j0 + st * 32;
+            if (jb >= N) break;
+            fa_f32x16 s;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = 0.0f;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const int key = st * 32 + l31;
+                const fa_bf16x8 kf = *(const fa_bf16x8*)(Ks + key * 32 + (((ks * 2 + hi) ^ ((key >> 2) & 3)) << 3));
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);
+            }
+            // lane (q, hi) now holds keys jb + (r&3) + 8(r>>2) + 4hi of query q
+            float tmax = -1.0e30f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int j = jb + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                s[r] = j < N ? s[r] * scale : -1.0e30f;
+                tmax = fmaxf(tmax, s[r]);
+            }
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            const float mn = fmaxf(m, tmax);
+            const float alpha = __expf(m - mn);
+            m = mn;
+            float psum = 0.0f;
+            float p[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float e = __expf(s[r] - mn);
+                psum += e;
+                const int j = jb + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                p[r] = (j < N && q < N) ? attn_drop(e, a.drop, dkey, (uint32_t)bh, (uint32_t)q, (uint32_t)j, (uint32_t)N) : 0.0f;
+            }
+            psum += __shfl_xor(psum, 32, 64);
+            l = l * alpha + psum;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[r] *= alpha;
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                uint32_t pk[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) pk[t] = pack_bf16x2(p[s2 * 8 + 2 * t], p[s2 * 8 + 2 * t + 1]);
+                const fa_bf16x8 pf = *(fa_bf16x8*)pk;
+                // V^T fragment: lane (d = l31, hi): keys st*32 + 16*s2 + 4*hi + {0..3} and + 8
+                const bf16_t* vr = Vt + l31 * 68 + st * 32 + s2 * 16 + 4 * hi;
+                uint2 v0 = *(const uint2*)vr, v1 = *(const uint2*)(vr + 8);
+                uint32_t vw[4] = {v0.x, v0.y, v1.x, v1.y};
+                const fa_bf16x8 vf = *(fa_bf16x8*)vw;
+                o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o, 0, 0, 0);
+            }
+        }
+    }
+    if (q >= N) return;
+    // O^T[d][q]: lane (q, hi) holds d = (r&3) + 8(r>>2) + 4hi  -> four 8-byte stores of 4 consecutive channels
+    const float inv = 1.0f / l;
+    bf16_t* op = a.out + ((size_t)n * N + q) * hd + h * 32;  // "b h (x y) d -> b (h d) x y"
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        uint2 w;
+        w.x = pack_bf16x2(o[g * 4 + 0] * inv, o[g * 4 + 1] * inv);
+        w.y = pack_bf16x2(o[g * 4 + 2] * inv, o[g * 4 + 3] * inv);
+        *(uint2*)(op + 8 * g + 4 * hi) = w;
+    }
+}
+
 hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
+    static const bool use_flash = !(getenv("DYF_FLASH_ATTN") && atoi(getenv("DYF_FLASH_ATTN")) == 0);
+    if (use_flash && a.hw <= 65535) {
+        const int qblocks = (a.hw + 127) / 128;
+        hipLaunchKernelGGL(flash_attention_kernel, dim3(a.n * a.heads * qblocks), dim3(256), 0, s, a);
+        return hipGetLastError();
+    }
     const int qtiles = (a.hw + 63) / 64;
     hipLaunchKernelGGL(attention_kernel, dim3(a.n * a.heads * qtiles), dim3(64), 0, s, a);
     return hipGetLastError();

@@ -130,3 +130,27 @@ def test_oisst_style_rollout_matches_oracle():
     worst = max(rel_rms(got[k].cpu(), want[k]) for k in want)
     print("OISST-style rollout worst rel-rms", worst)
     assert worst <= 4e-2
+
+
+def test_flash_attention_long_sequence_with_dropout():
+    """Bottleneck Attention on the MFMA flash kernel with a sequence that spans many key tiles and is not a multiple
+    of the tile sizes (N = 30*26 = 780 tokens), attention-probability dropout injected."""
+    cfg = dict(dim=64, dim_mults=[1, 2], with_time_emb=True, block_dropout=0.0, block_dropout1=0.0, attn_dropout=0.3,
+               resnet_block_groups=8, input_dropout=0.0, upsample_dims=None)
+    P = seeded_unet(64, (1, 2), 2, 1, seed=71)
+    g = torch.Generator().manual_seed(8)
+    x, t = torch.randn(2, 2, 60, 52, generator=g), torch.tensor([2.0, 5.0])
+    net = mirror(P, cfg, 2, 0, 1)
+    with torch.no_grad():
+        want = nets.resnet_unet_forward(P, cfg, x, t, None)
+    got = net(x.to(DEV), time=t.to(DEV)).cpu()
+    print("flash attention N=780 eval rel-rms", rel_rms(got, want))
+    assert rel_rms(got, want) <= TOL
+    src = nets.DropoutSeeded(21, record=True)
+    with torch.no_grad():
+        want = nets.resnet_unet_forward(P, cfg, x, t, None, dropout=src)
+    # sites with p > 0: only the attention blocks -> [linattn l0, linattn l1, mid_attn (b,h,n,n), linattn, linattn]
+    masks = [(m if i == 2 else m.permute(0, 2, 3, 1)).contiguous().to(DEV) for i, m in enumerate(src.masks)]
+    got = net._engine.net_forward(0, x.to(DEV), t.to(DEV), None, dropout_mode=2, masks=masks).cpu()
+    print("flash attention N=780 dropout rel-rms", rel_rms(got, want))
+    assert rel_rms(got, want) <= TOL
