@@ -328,7 +328,145 @@ __global__ __launch_bounds__(256) void linear_attention_kernel(LinAttnArgs a) {
     (void)lane; (void)wave;
 }
 
+// Pixel-parallel form (any image size): the three reductions over pixels are split over PIX_BLK-pixel workgroups.
+//   (1) per workgroup online (max, sum exp) of k per head channel            -> partials[bh][blk][32][2]
+//   (2) combine the partials, accumulate the workgroup's part of context    -> atomicAdd ctx[bh][32][32] (fp32)
+//   (3) per pixel: softmax_d(q) * scale, out = ctx^T q
+constexpr int LA_PIX = 1024;  // pixels per workgroup
+
+__global__ __launch_bounds__(256) void linattn_kstats_kernel(LinAttnArgs a, float* partials, int nblk) {
+    __shared__ float rm[8][32], rs[8][32];
+    const int bh = blockIdx.y, n = bh / a.heads, h = bh % a.heads;
+    const int C3 = 3 * a.heads * 32, hd = a.heads * 32;
+    const bf16_t* kb = a.qkv + (size_t)n * a.hw * C3 + hd + h * 32;
+    const int d = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const int p0 = blockIdx.x * LA_PIX, p1 = min(p0 + LA_PIX, a.hw);
+    float m = -3.0e38f, sm = 0.0f;
+    for (int p = p0 + grp; p < p1; p += 8) {
+        const float v = bf16_to_f32(kb[(size_t)p * C3 + d]);
+        if (v > m) { sm *= __expf(m - v); m = v; }
+        sm += __expf(v - m);
+    }
+    rm[grp][d] = m;
+    rs[grp][d] = sm;
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        float M = rm[0][d];
+        for (int i = 1; i < 8; ++i) M = fmaxf(M, rm[i][d]);
+        float S = 0.0f;
+        for (int i = 0; i < 8; ++i) S += rs[i][d] * __expf(rm[i][d] - M);
+        float* o = partials + (((size_t)bh * nblk + blockIdx.x) * 32 + d) * 2;
+        o[0] = M;
+        o[1] = S;
+    }
+}
+
+__global__ __launch_bounds__(256) void linattn_context_kernel(LinAttnArgs a, const float* partials, int nblk, float* ctx) {
+    __shared__ float kmax[32], kinv[32];
+    __shared__ float tile_k[64][33], tile_v[64][33];
+    const int bh = blockIdx.y, n = bh / a.heads, h = bh % a.heads;
+    const int C3 = 3 * a.heads * 32, hd = a.heads * 32;
+    const bf16_t* base = a.qkv + (size_t)n * a.hw * C3;
+    const int tid = threadIdx.x;
+    if (tid < 32) {  // global softmax statistics of k[d][.] from the per-workgroup partials
+        float M = -3.0e38f;
+        for (int b = 0; b < nblk; ++b) M = fmaxf(M, partials[(((size_t)bh * nblk + b) * 32 + tid) * 2]);
+        float S = 0.0f;
+        for (int b = 0; b < nblk; ++b) {
+            const float* pp = partials + (((size_t)bh * nblk + b) * 32 + tid) * 2;
+            S += pp[1] * __expf(pp[0] - M);
+        }
+        kmax[tid] = M;
+        kinv[tid] = 1.0f / S;
+    }
+    __syncthreads();
+    const int dd = tid >> 3, e0 = (tid & 7) * 4;
+    float c4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    const int p0 = blockIdx.x * LA_PIX, p1 = min(p0 + LA_PIX, a.hw);
+    for (int pb = p0; pb < p1; pb += 64) {
+        __syncthreads();
+        for (int i = tid; i < 64 * 32; i += 256) {
+            const int pp = i >> 5, ch = i & 31, p = pb + pp;
+            float kv = 0.0f, vv = 0.0f;
+            if (p < p1) {
+                kv = __expf(bf16_to_f32(base[(size_t)p * C3 + hd + h * 32 + ch]) - kmax[ch]) * kinv[ch];
+                vv = bf16_to_f32(base[(size_t)p * C3 + 2 * hd + h * 32 + ch]);
+            }
+            tile_k[pp][ch] = kv;
+            tile_v[pp][ch] = vv;
+        }
+        __syncthreads();
+        for (int pp = 0; pp < 64; ++pp) {
+            const float kv = tile_k[pp][dd];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) c4[t] = fmaf(kv, tile_v[pp][e0 + t], c4[t]);
+        }
+    }
+    const float inv_n = 1.0f / (float)a.hw;  // v / (h*w)  (attention.py:41)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) atomicAdd(&ctx[((size_t)bh * 32 + dd) * 32 + e0 + t], c4[t] * inv_n);
+}
+
+__global__ __launch_bounds__(256) void linattn_out_kernel(LinAttnArgs a, const float* ctx_all) {
+    __shared__ float ctx[32][33];
+    const int bh = blockIdx.y, n = bh / a.heads, h = bh % a.heads;
+    const int C3 = 3 * a.heads * 32, hd = a.heads * 32;
+    for (int i = threadIdx.x; i < 1024; i += 256) ctx[i >> 5][i & 31] = ctx_all[(size_t)bh * 1024 + i];
+    __syncthreads();
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= a.hw) return;
+    const float scale = 0.17677669529663687f;  // 32^-1/2
+    const bf16_t* qp = a.qkv + ((size_t)n * a.hw + p) * C3 + h * 32;
+    float q[32];
+    float qm = -3.0e38f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint4 v = *(const uint4*)(qp + i * 8);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            q[i * 8 + 2 * t] = __uint_as_float(w[t] << 16);
+            q[i * 8 + 2 * t + 1] = __uint_as_float(w[t] & 0xffff0000u);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 32; ++i) qm = fmaxf(qm, q[i]);
+    float qs = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        q[i] = __expf(q[i] - qm);
+        qs += q[i];
+    }
+    const float qn = scale / qs;
+    bf16_t* op = a.out + ((size_t)n * a.hw + p) * hd + h * 32;
+#pragma unroll
+    for (int e8 = 0; e8 < 4; ++e8) {
+        float o[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 32; ++i) acc = fmaf(ctx[i][e8 * 8 + t], q[i], acc);
+            o[t] = acc * qn;
+        }
+        *(uint4*)(op + e8 * 8) = make_uint4(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]),
+                                            pack_bf16x2(o[6], o[7]));
+    }
+}
+
 hipError_t launch_linear_attention(const LinAttnArgs& a, hipStream_t s) {
+    if (a.scratch) {
+        const int nblk = (a.hw + LA_PIX - 1) / LA_PIX;
+        const int BH = a.n * a.heads;
+        float* partials = a.scratch;                       // [BH][nblk][32][2]
+        float* ctx = a.scratch + (size_t)BH * nblk * 64;   // [BH][32][32]
+        hipError_t e = hipMemsetAsync(ctx, 0, (size_t)BH * 1024 * sizeof(float), s);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(linattn_kstats_kernel, dim3(nblk, BH), dim3(256), 0, s, a, partials, nblk);
+        hipLaunchKernelGGL(linattn_context_kernel, dim3(nblk, BH), dim3(256), 0, s, a, (const float*)partials, nblk, ctx);
+        hipLaunchKernelGGL(linattn_out_kernel, dim3((a.hw + 255) / 256, BH), dim3(256), 0, s, a, (const float*)ctx);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(linear_attention_kernel, dim3(a.n * a.heads), dim3(256), 0, s, a);
     return hipGetLastError();
 }

@@ -47,6 +47,7 @@ struct RNet {
     float *stem_w = nullptr, *stem_b = nullptr, *head_w = nullptr, *head_b = nullptr;
     float *ones = nullptr, *zeros = nullptr;
     double* gn_stats = nullptr;    // [max_batch][groups][2]
+    float* la_scratch = nullptr;   // LinearAttention partials + context
     size_t buf_elems = 0;          // elements of one pool buffer at max_batch
     std::vector<bf16_t*> pool;
 };
@@ -242,6 +243,11 @@ dyf_status rn_alloc_workspace(dyf_engine* e) {
         RNet* r = n.rn;
         {
             dyf_status s = dev_alloc(e, &r->gn_stats, (size_t)e->cfg.max_batch * n.cfg.groups * 2);
+            if (s != DYF_OK) return s;
+        }
+        {
+            const size_t nblk = ((size_t)e->cfg.height * e->cfg.width + 1023) / 1024;
+            dyf_status s = dev_alloc(e, &r->la_scratch, (size_t)e->cfg.max_batch * HEADS * (nblk * 64 + 1024));
             if (s != DYF_OK) return s;
         }
         const int nbuf = 2 * r->nlev + 8;
@@ -458,7 +464,7 @@ dyf_status rn_forward(dyf_engine* e, int which, const Source* srcs, int nsrc, in
         bf16_t* ao = pool.get();
         if (a.linear) {
             LinAttnArgs l{};
-            l.qkv = qkv; l.n = nb; l.hw = hw; l.heads = HEADS; l.out = ao;
+            l.qkv = qkv; l.n = nb; l.hw = hw; l.heads = HEADS; l.out = ao; l.scratch = r->la_scratch;
             HIP_TRY(e, launch_linear_attention(l, st));
         } else {
             AttnArgs t{};
