@@ -119,8 +119,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--nb", type=int, default=int(os.environ.get("DYF_BENCH_NB", "50")),
-                    help="ensemble rows per GPU (reference test ensemble: N=50, mode/test.yaml)")
+    ap.add_argument("--nb", type=int, default=int(os.environ.get("DYF_BENCH_NB", "80")),
+                    help="rows per GPU; default 80 = the reference's NS evaluation batch: eval_batch_size 4 x num_predictions 20 "
+                         "(experiment/navier_stokes.yaml:12-16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     args = ap.parse_args()
@@ -197,10 +198,10 @@ def main():
     }
     if rank == 0:
         # roofline of the dominant kernel: the last decoder block's 3x3 conv (256 -> 64 ch @256^2, 40 % of a forward),
-        # conv_igemm_kernel<256,64,4,1,1>; HIP events on the launch stream, operands = live workspace activations
+        # conv_up_halo_kernel; HIP events on the launch stream, operands = live workspace activations
         ms, fl, by = eng.time_conv_layer(1, 11, nb, iters=10)
         log(f"dec5 conv: {ms:.3f} ms per launch")
-        result["roofline"] = {"bound": "mfma", "kernel": "conv_igemm_kernel<256,64,4,1,1> (dec5: fused x2-upsample + 3x3 conv, 256->64 ch, 128^2->256^2)",
+        result["roofline"] = {"bound": "mfma", "kernel": "conv_up_halo_kernel (dec5: fused x2-upsample + 3x3 conv, 256->64 ch, 128^2->256^2)",
                               "achieved": round(fl / ms / 1e9, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                               "frac": round(fl / ms / 1e9 / PEAK_BF16_TFLOPS, 4), "avg_ms": round(ms, 4),
                               "flops_per_launch": fl, "algorithmic_bytes_per_launch": by, "traffic": pmc_traffic(nb)}

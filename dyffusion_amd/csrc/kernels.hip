@@ -408,6 +408,11 @@ __global__ __launch_bounds__(256) void readout_sliced_kernel(ReadoutArgs a) {
 #pragma unroll
     for (int c = 0; c < DYF_MAX_OUT_CH; ++c) acc[c] = 0.0f;
     const int ci0 = slice * 8;
+    // all 16 (neighbour, tap) input vectors are requested up front (one 16-B load each, independent), so the kernel is
+    // not a chain of 16 dependent L2 round trips; taps outside the image contribute zero
+    uint4 qv[16];
+    int wofs[16];
+    float bwv[16];
 #pragma unroll
     for (int nb4 = 0; nb4 < 4; ++nb4) {
         const int u = (nb4 & 2) ? u1 : u0, v = (nb4 & 1) ? v1 : v0;
@@ -417,19 +422,24 @@ __global__ __launch_bounds__(256) void readout_sliced_kernel(ReadoutArgs a) {
         for (int t4 = 0; t4 < 4; ++t4) {
             const int i = i_hi - (t4 >> 1), j = j_hi - (t4 & 1);
             const int kh = u + 1 - 2 * i, kw = v + 1 - 2 * j;
-            if ((unsigned)i < (unsigned)a.ih && (unsigned)j < (unsigned)a.iw) {
-                const uint4 q = *(const uint4*)(a.x + (((size_t)n * a.ih + i) * a.iw + j) * a.cin + ci0);
-                const uint32_t qw[4] = {q.x, q.y, q.z, q.w};
-                const float* wt = wsh + ((size_t)(kh * 4 + kw) * a.cin + ci0) * a.cout;
+            const bool ok = (unsigned)i < (unsigned)a.ih && (unsigned)j < (unsigned)a.iw;
+            const int ic = ok ? i : 0, jc = ok ? j : 0;
+            qv[nb4 * 4 + t4] = *(const uint4*)(a.x + (((size_t)n * a.ih + ic) * a.iw + jc) * a.cin + ci0);
+            bwv[nb4 * 4 + t4] = ok ? bw : 0.0f;
+            wofs[nb4 * 4 + t4] = ((kh * 4 + kw) * a.cin + ci0) * a.cout;
+        }
+    }
 #pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    const float xv = bw * ((c & 1) ? __uint_as_float(qw[c >> 1] & 0xffff0000u)
-                                                   : __uint_as_float(qw[c >> 1] << 16));
+    for (int s16 = 0; s16 < 16; ++s16) {
+        const uint32_t qw[4] = {qv[s16].x, qv[s16].y, qv[s16].z, qv[s16].w};
+        const float* wt = wsh + wofs[s16];
+        const float bw = bwv[s16];
 #pragma unroll
-                    for (int co = 0; co < DYF_MAX_OUT_CH; ++co)
-                        if (co < a.cout) acc[co] = fmaf(xv, wt[c * a.cout + co], acc[co]);
-                }
-            }
+        for (int c = 0; c < 8; ++c) {
+            const float xv = bw * ((c & 1) ? __uint_as_float(qw[c >> 1] & 0xffff0000u) : __uint_as_float(qw[c >> 1] << 16));
+#pragma unroll
+            for (int co = 0; co < DYF_MAX_OUT_CH; ++co)
+                if (co < a.cout) acc[co] = fmaf(xv, wt[c * a.cout + co], acc[co]);
         }
     }
 #pragma unroll
