@@ -131,14 +131,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank % max(1, ndev)  # one rank per GPU under the driver; ranks wrap only in single-GPU smoke runs
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        backend = os.environ.get("DYF_DIST_BACKEND", "nccl")  # "nccl" IS RCCL on ROCm; gloo only for plumbing checks
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     nb = args.nb
     log(f"building model, nb={nb}")
@@ -147,13 +153,14 @@ def main():
     g = torch.Generator().manual_seed(100 + rank)
     x0 = torch.randn(nb, C, H, W, generator=g).to(dev)
     static = torch.rand(nb, CS, H, W, generator=g).to(dev)
-    gathered = torch.empty((world, HORIZON, nb, C, H, W), dtype=torch.float32, device=dev) if world > 1 else None
+    from dyffusion_amd.distributed import all_gather_rows
 
     def step():
         _, preds, _ = model.sample_loop(x0, static_condition=static)
-        stack = torch.stack([preds[f"t{i}_preds"] for i in range(1, HORIZON + 1)], 0) if world > 1 else None
-        if world > 1:  # the final forecast stack is needed by every rank's metrics: one all-gather over xGMI
-            dist.all_gather_into_tensor(gathered, stack.contiguous())
+        if world > 1:  # every rank's metrics need the full forecast stack: ONE all-gather (RCCL over xGMI) per predict call
+            stack = torch.stack([preds[f"t{i}_preds"] for i in range(1, HORIZON + 1)], 0)  # (h, nb, C, H, W)
+            full = all_gather_rows(stack, world * nb, row_dim=1)
+            assert full.shape[1] == world * nb
         return preds
 
     model._ensure_engine((H, W), nb).seed(2 + rank)
