@@ -62,3 +62,46 @@ class MultiHorizonForecastingDYffusion(nn.Module):
         preds = self.predict(self.get_ensemble_inputs(inputs, n), condition=self.get_ensemble_inputs(cond, n),
                              num_predictions=n)
         return {k: v.detach().cpu().numpy() for k, v in preds.items()}
+
+    # forecasting_multi_horizon.py:114-229 (prediction branch): autoregressive outer loop.  Every outer iteration is
+    # one engine rollout (h fields); the last `window` predicted fields of every ensemble row become the next
+    # iteration's initial condition; rows stay independent, so the (N*B) rows never leave the GPU between iterations.
+    @torch.no_grad()
+    def evaluation_step(self, batch: Dict[str, Any], prediction_horizon: Optional[int] = None, boundary_conditions=None,
+                        t0: float = 0.0, dt: float = 1.0, return_targets: bool = True) -> Dict[str, Tensor]:
+        """Returns {"t{k}_preds": (N, B, C, H, W)} (and "t{k}_targets" when the batch holds them) for
+        k = 1..prediction_horizon.  `boundary_conditions(preds=, targets=, metadata=, time=)` is applied to every
+        predicted field before it is returned / fed back, exactly where the reference applies it."""
+        dynamics = batch["dynamics"]
+        b = dynamics.shape[0]
+        h = self.horizon
+        prediction_horizon = prediction_horizon or h
+        if self.window != 1:
+            raise NotImplementedError("autoregressive evaluation is implemented for window == 1 (the shipped configs)")
+        n = self.hparams.num_predictions
+        n_outer = -(-prediction_horizon // h)
+        cond = self.get_ensemble_inputs(batch.get("condition", None), n)
+        inputs = self.get_ensemble_inputs(dynamics[:, : self.window].reshape(b, -1, *dynamics.shape[-2:]), n)
+        out: Dict[str, Tensor] = {}
+        total_t = t0
+        for ar_step in range(n_outer):
+            preds = self.model.predict_forward(inputs, condition=cond, num_predictions=n)
+            last = None
+            for t_step in range(1, h + 1):
+                total_h = ar_step * h + t_step
+                if total_h > prediction_horizon:
+                    break
+                total_t += dt
+                p = preds[f"t{t_step}_preds"]
+                p = p.reshape(n, b, *p.shape[1:]) if n > 1 else p
+                tgt_idx = self.window + total_h - 1
+                targets = dynamics[:, tgt_idx] if tgt_idx < dynamics.shape[1] else None
+                if boundary_conditions is not None:
+                    p = boundary_conditions(preds=p, targets=targets, metadata=batch.get("metadata", None), time=total_t)
+                out[f"t{total_h}_preds"] = p
+                if return_targets and targets is not None:
+                    out[f"t{total_h}_targets"] = targets
+                last = p
+            if ar_step < n_outer - 1:  # "N B c h w -> (N B) c h w": next initial condition, already ensemble-tiled
+                inputs = last.reshape(-1, *last.shape[-3:]).contiguous()
+        return out

@@ -111,3 +111,48 @@ def test_ensemble_rows_and_batch_split_invariance():
     hi = m.sample(x0[2:], static_condition=c[2:])
     for k in full:
         assert torch.equal(full[k][:2], lo[k]) and torch.equal(full[k][2:], hi[k]), k
+
+
+def test_autoregressive_outer_loop_with_boundary_conditions():
+    """forecasting_multi_horizon.py:114-229: prediction_horizon = 2 * horizon -> two engine rollouts, the last field fed
+    back, a boundary-condition callable applied to every predicted field (as the NS datamodule does)."""
+    import dyffusion_amd as D
+    hp = dict(timesteps=4, forward_conditioning="none", interpolate_before_t1=True, sampling_type="cold",
+              refine_intermediate_predictions=True, enable_interpolator_dropout=False)
+    mk = dict(dim=64, upsample_dims=[64, 64], outer_sample_mode="bilinear", with_time_emb=True, dropout=0.1)
+    PF, PI = seeded_pair(64, 3, 2)
+    g = torch.Generator().manual_seed(5)
+    B, N = 2, 2
+    dyn = torch.randn(B, 9, 3, 23, 11, generator=g)
+    cond = torch.rand(B, 2, 23, 11, generator=g)
+    mask = torch.zeros(3, 23, 11, dtype=torch.bool)
+    mask[:, :2, :] = True
+    mask[0, :, 0] = True
+
+    def bc(preds, targets, metadata, time):
+        preds = preds.clone()
+        preds[..., mask.to(preds.device)] = 0.25 * time
+        return preds
+
+    m = build_dyffusion(PF, PI, mk, 3, 2, hp, max_batch=N * B)
+    exp = D.MultiHorizonForecastingDYffusion(m, num_predictions=N)
+    got = exp.evaluation_step({"dynamics": dyn.to(DEV), "condition": cond.to(DEV)}, prediction_horizon=8,
+                              boundary_conditions=bc)
+    # oracle: same loop on the CPU
+    x = dyn[:, 0].repeat(N, 1, 1, 1)
+    c = cond.repeat(N, 1, 1, 1)
+    t = 0.0
+    worst = 0.0
+    for ar in range(2):
+        o = oracle_rollout(PF, PI, mk, hp, x, c)
+        for k in range(1, 5):
+            t += 1.0
+            p = bc(o[f"t{k}_preds"].reshape(N, B, 3, 23, 11), None, None, t)
+            key = f"t{ar * 4 + k}_preds"
+            assert tuple(got[key].shape) == (N, B, 3, 23, 11)
+            worst = max(worst, rel_rms(got[key].cpu(), p))
+            last = p
+        x = last.reshape(N * B, 3, 23, 11)
+    assert torch.equal(got["t8_targets"].cpu(), dyn[:, 8])
+    print("autoregressive (2 x h=4) worst rel-rms", worst)
+    assert worst <= 4e-2
