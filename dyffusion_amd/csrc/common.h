@@ -98,6 +98,52 @@ __device__ __forceinline__ float drop_apply(float v, uint32_t e, const DropSpec&
     return keep ? v * d.scale : 0.0f;
 }
 
+// Epilogue form: activation + dropout over N (even) consecutive elements starting at the EVEN element index e0.  The
+// (activation, dropout mode) pair is wave-uniform, so it is dispatched ONCE per group with scalar branches and each
+// variant is a straight-line loop (the per-element form above is if-converted by the compiler into ~25 VALU/element
+// with the SiLU exp/rcp always evaluated); the keep word is hashed once per PAIR.
+template <int ACT>
+__device__ __forceinline__ float act_fixed(float v) {
+    if constexpr (ACT == ACT_RELU) return fmaxf(v, 0.0f);
+    else if constexpr (ACT == ACT_LEAKY) return fmaxf(v, 0.2f * v);
+    else if constexpr (ACT == ACT_SILU) return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));  // 1-ulp rcp, no IEEE divide
+    else return v;
+}
+
+template <int N, int ACT, int MODE>
+__device__ __forceinline__ void act_drop_fixed(float* v, uint32_t e0, const DropSpec& d, uint32_t key) {
+#pragma unroll
+    for (int t = 0; t < N; ++t) v[t] = act_fixed<ACT>(v[t]);
+    if constexpr (MODE == 1) {
+        const uint32_t th = d.thresh16;
+        const float sc = d.scale;
+#pragma unroll
+        for (int p = 0; p < N / 2; ++p) {
+            const uint32_t w = rng_pair_word((e0 >> 1) + p, key);
+            v[2 * p] = (w & 0xffffu) < th ? v[2 * p] * sc : 0.0f;
+            v[2 * p + 1] = (w >> 16) < th ? v[2 * p + 1] * sc : 0.0f;
+        }
+    } else if constexpr (MODE == 2) {
+#pragma unroll
+        for (int t = 0; t < N; ++t) v[t] = d.mask[e0 + t] != 0 ? v[t] * d.scale : 0.0f;
+    }
+}
+
+template <int N, int ACT>
+__device__ __forceinline__ void act_drop_mode(float* v, uint32_t e0, const DropSpec& d, uint32_t key) {
+    if (d.mode == 0) act_drop_fixed<N, ACT, 0>(v, e0, d, key);
+    else if (d.mode == 1) act_drop_fixed<N, ACT, 1>(v, e0, d, key);
+    else act_drop_fixed<N, ACT, 2>(v, e0, d, key);
+}
+
+template <int N>
+__device__ __forceinline__ void act_drop(float* v, uint32_t e0, int act, const DropSpec& d, uint32_t key) {
+    if (act == ACT_RELU) act_drop_mode<N, ACT_RELU>(v, e0, d, key);
+    else if (act == ACT_LEAKY) act_drop_mode<N, ACT_LEAKY>(v, e0, d, key);
+    else if (act == ACT_SILU) act_drop_mode<N, ACT_SILU>(v, e0, d, key);
+    else act_drop_mode<N, ACT_NONE>(v, e0, d, key);
+}
+
 // ------------------------------------------------------------------------------------------------ bilinear
 // align_corners=False source coordinate (ATen area_pixel_compute_source_index); oracle: nets.bilinear_resize_explicit
 __device__ __forceinline__ void bilinear_coord(int dst, float scale, int in_size, int& i0, int& i1, float& lam) {

@@ -18,6 +18,7 @@ struct ConvArgs {
     // (2h, 2w); wpk_up holds the phase-decomposed weights [4][cout][16][c0+c1] (pack_up2x_weights)
     int up2x;
     const bf16_t* wpk_up;
+    const bf16_t* wpk_up_frag;  // the same weights in MFMA fragment order (pack_up2x_frag) for the halo kernel, or null
     // epilogue: v = acc * A[row*coef_stride + co] + C[row*coef_stride + co]; row = sample index (coef_stride may be 0
     // to broadcast one row); conv bias, eval-BatchNorm and FiLM (x*(scale+1)+shift) are all folded into A and C.
     const float* coef_a;
@@ -38,5 +39,6 @@ hipError_t launch_conv(const ConvArgs& a, int path, hipStream_t stream);
 void pack_up2x_weights(const float* w, int cout, int cin, bf16_t* out);
 // halo form of the fused x2-upsample conv (conv_up_halo.hip): 16x16 low-res tile x 4 phases x 64 channels per workgroup
 bool conv_up_halo_supported(const ConvArgs& a);
+void pack_up2x_frag(const bf16_t* wpk_up, int cout, int cin, bf16_t* out);
 hipError_t conv_up_halo_init();
 hipError_t launch_conv_up_halo(const ConvArgs& a, hipStream_t stream);

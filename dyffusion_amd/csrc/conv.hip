@@ -466,11 +466,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a, int M, i
         float v[8] = {fmaf(v0.x, a0.x, c0.x), fmaf(v0.y, a0.y, c0.y), fmaf(v0.z, a0.z, c0.z), fmaf(v0.w, a0.w, c0.w),
                       fmaf(v1.x, a1.x, c1.x), fmaf(v1.y, a1.y, c1.y), fmaf(v1.z, a1.z, c1.z), fmaf(v1.w, a1.w, c1.w)};
         const uint32_t e0 = (uint32_t)((size_t)m * a.cout + co);
-#pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            v[t] = apply_act(v[t], a.act);
-            v[t] = drop_apply(v[t], e0 + t, a.drop, key);
-        }
+        act_drop<8>(v, e0, a.act, a.drop, key);
         if (a.residual) {
             const uint4 rq = *(const uint4*)(a.residual + (size_t)m * a.cout + co);
             const uint32_t rw[4] = {rq.x, rq.y, rq.z, rq.w};

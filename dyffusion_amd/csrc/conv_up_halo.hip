@@ -1,23 +1,31 @@
 // Fused x2-bilinear-upsample + 3x3 conv, "halo" form (gfx950): the dominant kernel of the Navier-Stokes backbone
-// (decoder blocks dec3-dec5 of src/models/unet_simple.py:40-52, 69 % of a forward's FLOPs).
+// (decoder blocks dec4-dec5 of src/models/unet_simple.py:40-52, ~55 % of a forward's time).
 //
-// Same mathematics as conv_igemm_kernel<.., UP=1> (phase decomposition + border-correction taps, see conv.hip), but the
-// data movement is re-designed around what bounds that kernel: it re-gathers every input pixel once per tap and phase
-// (36x) through the CU's texture path (TA ~64 B/clk) and synchronises its 4 waves every 16 MFMAs.  Here
-//   * a workgroup owns a 16x16 LOW-res tile and ALL FOUR output phases of 64 output channels: the GEMM tile is
-//     M = 256 pixels x N = 256 (4 phases x 64 channels); each wave owns 64 pixels x 256 columns = 2 x 8 accumulator
-//     tiles of v_mfma_f32_32x32x16_bf16 (256 accumulator registers; one wave per SIMD owns the whole 512-entry file);
-//   * per 64-channel chunk the 18x18 replicate-padded input window ("halo", 41 KB) is DMA'd into LDS ONCE and all 9
-//     stencil taps (and the correction taps) read their A fragments from it at shifted addresses: input traffic per
-//     MFMA drops ~30x, and A fragments are shared by the 4 phases (LDS reads per MFMA: 0.625 KB vs 1 KB);
-//   * a K step is one tap of one chunk: 64 MFMAs per wave between barriers (4x fewer barriers), B tile = 32 KB
-//     (4 phases x 64 channels x 64 k) double-buffered, next step's tile in flight for a whole 2 048-cycle step;
-//   * halo double-buffered across chunks; LDS total 147 KB -> one workgroup per CU, latency hidden by ILP inside the wave
-//     (~2 non-MFMA instructions per MFMA).
+// Same mathematics as conv_igemm_kernel<.., UP=1> (phase decomposition + border-correction taps, see conv.hip); the data
+// movement is designed around what bounded the previous forms of this kernel, the CU's 128 B/clk of LDS bandwidth:
+//   * a workgroup (4 waves, one per SIMD, 512 registers each) owns a 16x16 LOW-res tile and ALL FOUR output phases of 64
+//     output channels: GEMM tile M = 256 pixels x N = 256 (4 phases x 64 channels).  Wave (wm, wn) owns tile rows
+//     8*wm..8*wm+7 (128 pixels) x the two phases with py = wn (128 columns) = 4 x 4 accumulator tiles of
+//     v_mfma_f32_32x32x16_bf16: every fragment that is fetched feeds 4 MFMAs;
+//   * per 64-channel chunk the 18x18 replicate-padded input window ("halo", 41 KB) is DMA'd into LDS ONCE
+//     (buffer_load ... lds) and all 9 stencil taps (and the correction taps) read their pixel fragments from it at
+//     shifted addresses.  This is the ONLY LDS traffic (32 B/clk/CU at MFMA peak);
+//   * the weights never touch LDS: they are pre-packed on the host in MFMA FRAGMENT ORDER (pack_up2x_frag), so that one
+//     wave-wide buffer_load_dwordx4 fetches 1 KB of contiguous memory = one 32-channel x 16-k fragment straight into
+//     registers (L2/L1-resident; 32 B/clk/CU of the vector-memory path).  Four fragment sets are in flight 3 k16
+//     sub-steps (~1 500 cycles) ahead of their use;
+//   * consequently there is NO per-step workgroup barrier: the waves meet only once per 64-channel chunk (halo swap,
+//     every 9-16 steps of 64 MFMAs) and drift apart in between;
+//   * operands are swapped (D^T = W * X^T): an accumulator lane then holds 4 consecutive CHANNELS of one pixel, so the
+//     epilogue (affine / activation / dropout / bf16 pack) runs straight out of the accumulators, pairs lanes l and
+//     l+32 with v_permlane32_swap and stores 16 B per lane: no LDS round trip, no barrier.
 #include "conv.h"
+
+#include <type_traits>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 
@@ -25,17 +33,16 @@ namespace {
 
 constexpr int HALO_W = 18, HALO_PIX = 328;              // 18*18 = 324, padded to a multiple of 8 DMA rows
 constexpr int HALO_BYTES = HALO_PIX * 128;              // 41 984
-constexpr int ZERO_OFF = 2 * HALO_BYTES;                // 128 B of zeros (A rows masked out of a correction tap)
-constexpr int B_OFF = ZERO_OFF + 512;                   // two 32 KB weight stages
-constexpr int B_BYTES = 256 * 128;
-constexpr int LDS_TOTAL = B_OFF + 2 * B_BYTES;          // 150 016 B
+constexpr int ZERO_OFF = 2 * HALO_BYTES;                // 128 B of zeros (pixels masked out of a correction tap)
+constexpr int LDS_TOTAL = ZERO_OFF + 512;               // 84 480 B
 constexpr int HALO_INSTR = HALO_PIX / 8;                // 41 wave-level DMA instructions per halo
-constexpr int NWAVES = 8;                               // 512 threads: two waves per SIMD cover each other's issue gaps
-constexpr int HALO_PER_WAVE = (HALO_INSTR + NWAVES - 1) / NWAVES;  // 6
+constexpr int NWAVES = 4;
+constexpr int HALO_PER_WAVE = (HALO_INSTR + NWAVES - 1) / NWAVES;  // 11
+constexpr int STEP_BYTES = 32768;                       // weights of one (tap, chunk) step: 256 columns x 64 k bf16
 
 }  // namespace
 
-__global__ __launch_bounds__(512, 2) void conv_up_halo_kernel(ConvArgs a, int tiles_x, int tiles_per_img, int tiles_m,
+__global__ __launch_bounds__(256, 1) void conv_up_halo_kernel(ConvArgs a, int tiles_x, int tiles_per_img, int tiles_m,
                                                               int tiles_n) {
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -43,7 +50,6 @@ __global__ __launch_bounds__(512, 2) void conv_up_halo_kernel(ConvArgs a, int ti
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
-    // wave -> (pixel group wm: tile rows 4*wm .. 4*wm+3 = 64 pixels, column half wn: phases py = wn, 128 columns)
     const int wm = wave >> 1, wn = wave & 1;
 
     // XCD-aware tile id; the column blocks of one tile are consecutive (they share the halo in L2)
@@ -66,14 +72,13 @@ __global__ __launch_bounds__(512, 2) void conv_up_halo_kernel(ConvArgs a, int ti
     if (has_row) { tap_list |= 0xBA9ull << (4 * ntaps); ntaps += 3; }
     if (has_col) { tap_list |= 0xEDCull << (4 * ntaps); ntaps += 3; }
     if (has_row && has_col) { tap_list |= 0xFull << (4 * ntaps); ntaps += 1; }
-    const int nsteps = ntaps * cpt;
 
     const size_t npix = (size_t)a.n * a.h * a.w;
     const auto rsrc_a0 = __builtin_amdgcn_make_buffer_rsrc((void*)a.src0, 0, (int)(unsigned)(npix * a.c0 * 2), 0x00020000);
     const auto rsrc_a1 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.c1 ? a.src1 : a.src0), 0,
                                                            (int)(unsigned)(npix * (a.c1 ? a.c1 : a.c0) * 2), 0x00020000);
-    const auto rsrc_b = __builtin_amdgcn_make_buffer_rsrc((void*)a.wpk_up, 0, (int)(unsigned)((size_t)4 * a.cout * 16 * cin * 2),
-                                                          0x00020000);
+    const auto rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.wpk_up_frag, 0,
+                                                          (int)(unsigned)((size_t)4 * a.cout * 16 * cin * 2), 0x00020000);
 
     // ---- halo DMA descriptors: instruction i (i % 4 == wave) fills halo pixels [8i, 8i+8); lane -> (pixel, 16-B chunk)
     const int sub = lane >> 3;
@@ -88,17 +93,8 @@ __global__ __launch_bounds__(512, 2) void conv_up_halo_kernel(ConvArgs a, int ti
         const int gch = (lane & 7) ^ ((hp >> 1) & 7);  // swizzled source chunk of this linear LDS slot
         h_off[j] = (unsigned)((n_img * a.h + y) * a.w + x) * (unsigned)(a.c0 * 2) + gch * 16;  // c0 == c1 (checked on host)
     }
-    // ---- weight DMA descriptors: B row r in [0,256): phase r>>6, channel tn*64 + (r & 63); instruction j*4+wave
-    unsigned b_off[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int r = (j * NWAVES + wave) * 8 + sub;
-        const int gch = (lane & 7) ^ ((r >> 1) & 7);
-        b_off[j] = (unsigned)((r >> 6) * a.cout + tn * 64 + (r & 63)) * (unsigned)(16 * cin * 2) + gch * 16;
-    }
     if (tid < 32) ((uint4*)(smem + ZERO_OFF))[tid] = make_uint4(0, 0, 0, 0);
 
-    int is_step = 0, is_pos = 0, is_chunk = 0;  // issue-side iterator over (chunk, tap-list position)
     auto issue_halo = [&](int chunk) {
         const int cb = chunk << 6;
         const bool second = cb >= a.c0;
@@ -115,259 +111,314 @@ __global__ __launch_bounds__(512, 2) void conv_up_halo_kernel(ConvArgs a, int ti
             }
         }
     };
-    auto issue_b = [&]() {  // weights of step is_step into stage (is_step & 1); advances the iterator
-        if (is_step >= nsteps) return;
-        const int tap = (int)((tap_list >> (4 * is_pos)) & 15ull);
-        char* dst = smem + B_OFF + (is_step & 1) * B_BYTES;
-        const int soff = (tap * cin + (is_chunk << 6)) * 2;
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, LDS_PTR(dst + (j * NWAVES + wave) * 1024), 16, b_off[j], soff, 0, 0);
-        ++is_step;
-        if (++is_pos == ntaps) {
-            is_pos = 0;
-            ++is_chunk;
-        }
-    };
 
-    f32x16 acc[4][2];  // [local column tile; global = wn*4 + nt = phase*2 + half][pixel tile]
+    // ---- weight-fragment stream: step (chunk, tap) of this column block starts at ((tn*cpt + chunk)*16 + tap) * 32 KB;
+    // inside, [wn][ks][column tile][lane] x 16 B.  soff_cur / soff_next: this wave's base of the current / next step.
+    const unsigned w_voff = (unsigned)lane * 16u;
+    int it_pos = 0, it_chunk = 0;
+    auto soff_of = [&](int pos, int chunk) {
+        const int tap = (int)((tap_list >> (4 * pos)) & 15ull);
+        return (unsigned)(((tn * cpt + chunk) * 16 + tap) * STEP_BYTES + wn * (STEP_BYTES / 2));
+    };
+    unsigned soff_cur = soff_of(0, 0), soff_next = soff_cur;
+    auto advance = [&]() {  // the tail re-fetches the last step (harmless, never consumed)
+        soff_cur = soff_next;
+        if (++it_pos == ntaps) { it_pos = 0; ++it_chunk; }
+        if (it_chunk < cpt) soff_next = soff_of(it_pos, it_chunk);
+    };
+    advance();  // -> soff_cur = step 0, soff_next = step 1
+
+    f32x16 acc[4][4];  // [column tile nt = px*2 + half (phase py = wn)][pixel tile mt: tile rows 8*wm + 2*mt + {0,1}]
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[nt][mt][r] = 0.0f;
 
-    // tile pixel of this lane's A rows: pixel tile mt covers tile rows 4*wm + 2*mt + {0,1}
-    int hp0[2];      // halo pixel index of the un-shifted tap
-    bool m_top[2], m_bot[2], m_left, m_right;
-    {
-        const int x = l31 & 15;
-        m_left = has_left && x == 0;
-        m_right = has_right && x == 15;
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            const int y = 4 * wm + 2 * mt + (l31 >> 4);
-            hp0[mt] = (y + 1) * HALO_W + (x + 1);
-            m_top[mt] = has_top && y == 0;
-            m_bot[mt] = has_bot && y == 15;
-        }
-    }
-    const int b_row_off = l31 * 128;
+    const int px_x = l31 & 15, px_r = l31 >> 4;
+    int hp0 = (8 * wm + px_r + 1) * HALO_W + (px_x + 1);  // halo pixel of pixel tile 0 at the un-shifted tap; mt adds 36
+    const bool m_left = has_left && px_x == 0, m_right = has_right && px_x == 15;
+    const bool m_top = has_top && wm == 0 && px_r == 0;   // pixel tile 0
+    const bool m_bot = has_bot && wm == 1 && px_r == 1;   // pixel tile 3
     const unsigned lds_base = (unsigned)(uintptr_t)LDS_PTR(smem);
-    const int bkey = (l31 >> 1) & 7;
 
-    int cs_step = 0, cs_chunk = 0;  // compute-side step counter / chunk
+    u32x4 bq[4][4];   // weight fragments: set = k16 sub-step & 3
+    bf16x8 aq[2][4];  // pixel fragments: two sets
 
-    // One K step: A fragments of (tap displacement d, row masks) for both pixel tiles, then MFMAs into the column tiles
-    // selected by NT_MASK (bit nt).  MASKED: rows whose `keep` flag is false read the zero page.
-#define DSR(dst, addr, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF));
-    // A fragments are read with inline asm as well: every LDS read inside the K loop is hand-counted, so the compiler
-    // inserts no (over-conservative) lgkmcnt waits between the MFMAs.
-#define LOAD_A(DISP, KEEP0, KEEP1, MASKED)                                                                   \
-    bf16x8 af[2][4];                                                                                         \
-    {                                                                                                        \
-        const unsigned Hs = lds_base + (cs_chunk & 1) * HALO_BYTES;                                          \
-        _Pragma("unroll") for (int mt = 0; mt < 2; ++mt) {                                                   \
-            const int hp = hp0[mt] + (DISP);                                                                 \
-            const int key = (hp >> 1) & 7;                                                                   \
-            const bool keep = mt == 0 ? (KEEP0) : (KEEP1);                                                   \
-            _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                               \
-                const unsigned addr = ((MASKED) && !keep) ? lds_base + ZERO_OFF                              \
-                                                           : Hs + hp * 128 + (((ks * 2 + hi) ^ key) << 4);   \
-                DSR(af[mt][ks], addr, 0)                                                                     \
-            }                                                                                                \
-        }                                                                                                    \
-    }
-#define MMA_COLS(NT_MASK)                                                                                    \
-    {                                                                                                        \
-        const unsigned Bb = lds_base + B_OFF + (cs_step & 1) * B_BYTES + b_row_off + wn * 16384;             \
-        _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                                   \
-            const unsigned ad = Bb + (((ks * 2 + hi) ^ bkey) << 4);                                          \
-            _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) {                                               \
-                if (((NT_MASK) >> (wn * 4 + nt)) & 1) {                                                      \
-                    bf16x8 bf;                                                                               \
-                    const unsigned adn = ad + nt * 4096;                                                     \
-                    DSR(bf, adn, 0)                                                                          \
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                       \
-                    __builtin_amdgcn_sched_barrier(0);                                                       \
-                    acc[nt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][ks], bf, acc[nt][0], 0, 0, 0); \
-                    acc[nt][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][ks], bf, acc[nt][1], 0, 0, 0); \
-                }                                                                                            \
-            }                                                                                                \
-        }                                                                                                    \
-    }
-    // All 8 column tiles (the stencil taps, > 90 % of the MFMAs).  hipcc sinks every ds_read next to its first use (one
-    // wave per SIMD then eats the ~100-cycle LDS latency before every pair of MFMAs), so the B-fragment reads are issued
-    // as inline asm with hand-counted waits (cdna_hip_programming.md 5.7): two fragment sets, the reads of k16 sub-step
-    // ks+1 are in flight under the 16 MFMAs of sub-step ks.
-#define DSR4(Q, addr) DSR(Q[0], addr, 0) DSR(Q[1], addr, 4096) DSR(Q[2], addr, 8192) DSR(Q[3], addr, 12288)
+#define ISSUE_B(SET, SOFF, KS)                                                                               \
+    _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                                         \
+        bq[SET][nt] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, w_voff + nt * 1024, (SOFF) + (KS) * 4096, 0);
+#define DSR(dst, addr) asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr));
 #define LGKM_WAIT(N)                                                      \
     asm volatile("s_waitcnt lgkmcnt(" #N ")" ::: "memory");               \
     __builtin_amdgcn_sched_barrier(0);
-#define MFMA8(KS, Q)                                                                                         \
+    // pixel fragments of sub-step KS at halo displacement DISP: 4 pixel tiles, 36 halo pixels (2 rows) apart
+#define RDA(SET, DISP, KS)                                                                                   \
+    _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) {                                                       \
+        const int hpm = hp0 + (DISP) + 36 * mt;                                                              \
+        const unsigned pm = Hs + hpm * 128 + ((((KS) * 2 + hi) ^ ((hpm >> 1) & 7)) << 4);                    \
+        DSR(aq[SET][mt], pm)                                                                                 \
+    }
+#define MFMA16(ASET, BSET)                                                                                   \
     _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) {                                                       \
-        acc[nt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][KS], Q[nt], acc[nt][0], 0, 0, 0);         \
-        acc[nt][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][KS], Q[nt], acc[nt][1], 0, 0, 0);         \
+        const bf16x8 wf = __builtin_bit_cast(bf16x8, bq[BSET][nt]);                                          \
+        _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                                     \
+            acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, aq[ASET][mt], acc[nt][mt], 0, 0, 0);   \
     }
-    // stencil step: A (2 pixel tiles) and B (4 column tiles) fragments of k16 sub-step ks+1 stream in while the 8 MFMAs of
-    // sub-step ks execute; two register sets of 6 fragments
-#define RD6(AQ, Q, KS)                                                                                       \
+    // One stencil step (tap displacement DISP).  On entry pixel set 0 holds sub-step 0 of this step (issued by the
+    // previous step, or by the chunk prologue) and weight sets 0-2 are in flight.  While the 16 MFMAs of sub-step j run,
+    // the pixel fragments of j+1 and the weight fragments of j+3 stream in.  HAS_NEXT: the next step is the stencil tap
+    // at DNEXT of the same chunk, so its first pixel fragments are prefetched too.
+#define STENCIL_STEP(DISP, HAS_NEXT, DNEXT)                                                                  \
     {                                                                                                        \
-        const unsigned ka0 = pa0 + ((((KS) * 2 + hi) ^ key0) << 4), ka1 = pa1 + ((((KS) * 2 + hi) ^ key1) << 4); \
-        const unsigned kb = ba + ((((KS) * 2 + hi) ^ bkey) << 4);                                            \
-        DSR(AQ[0], ka0, 0) DSR(AQ[1], ka1, 0) DSR4(Q, kb)                                                    \
+        ISSUE_B(3, soff_cur, 3)                                                                              \
+        RDA(1, DISP, 1)                                                                                      \
+        LGKM_WAIT(4)                                                                                         \
+        MFMA16(0, 0)                                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+        ISSUE_B(0, soff_next, 0)                                                                             \
+        RDA(0, DISP, 2)                                                                                      \
+        LGKM_WAIT(4)                                                                                         \
+        MFMA16(1, 1)                                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+        ISSUE_B(1, soff_next, 1)                                                                             \
+        RDA(1, DISP, 3)                                                                                      \
+        LGKM_WAIT(4)                                                                                         \
+        MFMA16(0, 2)                                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+        ISSUE_B(2, soff_next, 2)                                                                             \
+        if (HAS_NEXT) {                                                                                      \
+            RDA(0, DNEXT, 0)                                                                                 \
+            LGKM_WAIT(4)                                                                                     \
+        } else {                                                                                             \
+            LGKM_WAIT(0)                                                                                     \
+        }                                                                                                    \
+        MFMA16(1, 3)                                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+        advance();                                                                                           \
     }
-#define MFMA8X(AQ, Q)                                                                                        \
-    _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) {                                                       \
-        acc[nt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AQ[0], Q[nt], acc[nt][0], 0, 0, 0);             \
-        acc[nt][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AQ[1], Q[nt], acc[nt][1], 0, 0, 0);             \
-    }
-#define STENCIL_MMA(DISP)                                                                                    \
+    // One correction step: only the pixel tiles / column tiles that touch the border take part.  BODY(KS, BSET) issues
+    // its (masked) pixel fragments and MFMAs; the weight stream keeps its cadence.
+#define CORR_STEP(BODY)                                                                                      \
     {                                                                                                        \
-        const unsigned Hs = lds_base + (cs_chunk & 1) * HALO_BYTES;                                          \
-        const int hpa = hp0[0] + (DISP), hpb = hp0[1] + (DISP);                                              \
-        const int key0 = (hpa >> 1) & 7, key1 = (hpb >> 1) & 7;                                              \
-        const unsigned pa0 = Hs + hpa * 128, pa1 = Hs + hpb * 128;                                           \
-        const unsigned ba = lds_base + B_OFF + (cs_step & 1) * B_BYTES + b_row_off + wn * 16384;             \
-        bf16x8 aq0[2], aq1[2], q0[4], q1[4];                                                                 \
-        RD6(aq0, q0, 0)                                                                                      \
-        RD6(aq1, q1, 1)                                                                                      \
-        LGKM_WAIT(6)                                                                                         \
-        MFMA8X(aq0, q0)                                                                                      \
-        __builtin_amdgcn_sched_barrier(0);                                                                   \
-        RD6(aq0, q0, 2)                                                                                      \
-        LGKM_WAIT(6)                                                                                         \
-        MFMA8X(aq1, q1)                                                                                      \
-        __builtin_amdgcn_sched_barrier(0);                                                                   \
-        RD6(aq1, q1, 3)                                                                                      \
-        LGKM_WAIT(6)                                                                                         \
-        MFMA8X(aq0, q0)                                                                                      \
-        LGKM_WAIT(0)                                                                                         \
-        MFMA8X(aq1, q1)                                                                                      \
-        __builtin_amdgcn_sched_barrier(0);                                                                   \
+        ISSUE_B(3, soff_cur, 3)                                                                              \
+        BODY(0, 0)                                                                                           \
+        ISSUE_B(0, soff_next, 0)                                                                             \
+        BODY(1, 1)                                                                                           \
+        ISSUE_B(1, soff_next, 1)                                                                             \
+        BODY(2, 2)                                                                                           \
+        ISSUE_B(2, soff_next, 2)                                                                             \
+        BODY(3, 3)                                                                                           \
+        advance();                                                                                           \
     }
-    // every step: wait for this wave's DMAs, workgroup barrier (data visible + previous stage free), prefetch the next
-    // step's weights (and, at the first step of a chunk, the next chunk's halo)
-#define STEP_BEGIN()                                                          \
-    {                                                                         \
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                      \
-        __syncthreads();                                                      \
-        issue_b();                                                            \
+    // masked pixel fragment of tile MT at displacement DISP: lanes with KEEP false read the zero page
+#define RDA_MASKED(DST, MT, DISP, KS, KEEP)                                                                  \
+    {                                                                                                        \
+        const int hpm = hp0 + 36 * (MT) + (DISP);                                                            \
+        const unsigned pm = (KEEP) ? Hs + hpm * 128 + ((((KS) * 2 + hi) ^ ((hpm >> 1) & 7)) << 4) : lds_base + ZERO_OFF; \
+        DSR(DST, pm)                                                                                         \
     }
-#define STEP_END() { ++cs_step; }
+#define MFMA_ONE(NT, MT, BSET, AF)                                                                           \
+    acc[NT][MT] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bq[BSET][NT]), AF, acc[NT][MT], 0, 0, 0);
 
     issue_halo(0);
-    issue_b();
-    for (cs_chunk = 0; cs_chunk < cpt; ++cs_chunk) {
-        // keep the per-tap LDS addresses from being hoisted out of the chunk loop (9 taps x 8 addresses would eat the
-        // registers the B-fragment double buffer needs)
-        asm volatile("" : "+v"(hp0[0]), "+v"(hp0[1]));
+    ISSUE_B(0, soff_cur, 0)
+    ISSUE_B(1, soff_cur, 1)
+    ISSUE_B(2, soff_cur, 2)
+    for (int chunk = 0; chunk < cpt; ++chunk) {
+        // halo of this chunk landed (everything older than the 12 weight loads in flight), every wave is done with the
+        // other buffer -> prefetch the next chunk's halo into it
+        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (chunk + 1 < cpt) issue_halo(chunk + 1);
+        const unsigned Hs = lds_base + (chunk & 1) * HALO_BYTES;
+        asm volatile("" : "+v"(hp0));  // keep the per-tap LDS addresses from being hoisted out of the chunk loop
+        RDA(0, -HALO_W - 1, 0)
         // ---- 9 stencil taps (a, b) in {-1,0,1}^2: displacement a*18 + b in the halo, every phase
-#define STENCIL(T)                                                                           \
-        {                                                                                    \
-            STEP_BEGIN()                                                                     \
-            if ((T) == 0 && cs_chunk + 1 < cpt) issue_halo(cs_chunk + 1);                     \
-            STENCIL_MMA(((T) / 3 - 1) * HALO_W + ((T) % 3 - 1))                               \
-                                                                                             \
-            STEP_END()                                                                       \
+#define D_OF(T) (((T) / 3 - 1) * HALO_W + ((T) % 3 - 1))
+        STENCIL_STEP(D_OF(0), true, D_OF(1))
+        STENCIL_STEP(D_OF(1), true, D_OF(2))
+        STENCIL_STEP(D_OF(2), true, D_OF(3))
+        STENCIL_STEP(D_OF(3), true, D_OF(4))
+        STENCIL_STEP(D_OF(4), true, D_OF(5))
+        STENCIL_STEP(D_OF(5), true, D_OF(6))
+        STENCIL_STEP(D_OF(6), true, D_OF(7))
+        STENCIL_STEP(D_OF(7), true, D_OF(8))
+        STENCIL_STEP(D_OF(8), false, 0)
+#undef D_OF
+        if (has_row) {  // taps 9-11: b = -1,0,+1 on the border row; top -> phase row py = 0 (waves wn = 0), pixel tile 0
+                        // of waves wm = 0; bottom -> py = 1, pixel tile 3 of waves wm = 1
+#define ROW_BODY_B(KS, BSET, B_)                                                             \
+            if (has_top && wn == 0 && wm == 0) {                                             \
+                bf16x8 f;                                                                    \
+                RDA_MASKED(f, 0, (B_), KS, m_top)                                            \
+                LGKM_WAIT(0)                                                                 \
+                MFMA_ONE(0, 0, BSET, f) MFMA_ONE(1, 0, BSET, f) MFMA_ONE(2, 0, BSET, f) MFMA_ONE(3, 0, BSET, f) \
+            }                                                                                \
+            if (has_bot && wn == 1 && wm == 1) {                                             \
+                bf16x8 f;                                                                    \
+                RDA_MASKED(f, 3, (B_), KS, m_bot)                                            \
+                LGKM_WAIT(0)                                                                 \
+                MFMA_ONE(0, 3, BSET, f) MFMA_ONE(1, 3, BSET, f) MFMA_ONE(2, 3, BSET, f) MFMA_ONE(3, 3, BSET, f) \
+            }                                                                                \
+            __builtin_amdgcn_sched_barrier(0);
+#define ROW_M1(KS, BSET) ROW_BODY_B(KS, BSET, -1)
+#define ROW_0(KS, BSET) ROW_BODY_B(KS, BSET, 0)
+#define ROW_P1(KS, BSET) ROW_BODY_B(KS, BSET, 1)
+            CORR_STEP(ROW_M1) CORR_STEP(ROW_0) CORR_STEP(ROW_P1)
+#undef ROW_M1
+#undef ROW_0
+#undef ROW_P1
+#undef ROW_BODY_B
         }
-        STENCIL(0) STENCIL(1) STENCIL(2) STENCIL(3) STENCIL(4) STENCIL(5) STENCIL(6) STENCIL(7) STENCIL(8)
-#undef STENCIL
-        if (has_row) {  // taps 9-11: b = -1,0,+1 on the border row; top -> phases py=0 (cols 0-3), bottom -> py=1 (cols 4-7)
-#define ROWCORR(B_)                                                                          \
-            {                                                                                \
-                STEP_BEGIN()                                                                 \
-                if (has_top) { LOAD_A((B_), m_top[0], m_top[1], true) MMA_COLS(0x0F) }       \
-                if (has_bot) { LOAD_A((B_), m_bot[0], m_bot[1], true) MMA_COLS(0xF0) }       \
-                STEP_END()                                                                   \
-            }
-            ROWCORR(-1) ROWCORR(0) ROWCORR(1)
-#undef ROWCORR
-        }
-        if (has_col) {  // taps 12-14: a = -1,0,+1 on the border column; left -> px=0 (cols 0,1,4,5), right -> px=1 (2,3,6,7)
-#define COLCORR(A_)                                                                          \
-            {                                                                                \
-                STEP_BEGIN()                                                                 \
-                if (has_left) { LOAD_A((A_) * HALO_W, m_left, m_left, true) MMA_COLS(0x33) } \
-                if (has_right) { LOAD_A((A_) * HALO_W, m_right, m_right, true) MMA_COLS(0xCC) } \
-                STEP_END()                                                                   \
-            }
-            COLCORR(-1) COLCORR(0) COLCORR(1)
-#undef COLCORR
+        if (has_col) {  // taps 12-14: a = -1,0,+1 on the border column; left -> px = 0 (column tiles 0,1), right -> px = 1
+#define COL_BODY_A(KS, BSET, A_)                                                             \
+            if (has_left) {                                                                  \
+                bf16x8 f[4];                                                                 \
+                _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) RDA_MASKED(f[mt], mt, (A_) * HALO_W, KS, m_left) \
+                LGKM_WAIT(0)                                                                 \
+                _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) { MFMA_ONE(0, mt, BSET, f[mt]) MFMA_ONE(1, mt, BSET, f[mt]) } \
+            }                                                                                \
+            if (has_right) {                                                                 \
+                bf16x8 f[4];                                                                 \
+                _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) RDA_MASKED(f[mt], mt, (A_) * HALO_W, KS, m_right) \
+                LGKM_WAIT(0)                                                                 \
+                _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) { MFMA_ONE(2, mt, BSET, f[mt]) MFMA_ONE(3, mt, BSET, f[mt]) } \
+            }                                                                                \
+            __builtin_amdgcn_sched_barrier(0);
+#define COL_M1(KS, BSET) COL_BODY_A(KS, BSET, -1)
+#define COL_0(KS, BSET) COL_BODY_A(KS, BSET, 0)
+#define COL_P1(KS, BSET) COL_BODY_A(KS, BSET, 1)
+            CORR_STEP(COL_M1) CORR_STEP(COL_0) CORR_STEP(COL_P1)
+#undef COL_M1
+#undef COL_0
+#undef COL_P1
+#undef COL_BODY_A
         }
         if (has_row && has_col) {  // tap 15: the corner pixel, one phase per corner
-            STEP_BEGIN()
-            if (has_top && has_left) { LOAD_A(0, m_top[0] && m_left, m_top[1] && m_left, true) MMA_COLS(0x03) }
-            if (has_top && has_right) { LOAD_A(0, m_top[0] && m_right, m_top[1] && m_right, true) MMA_COLS(0x0C) }
-            if (has_bot && has_left) { LOAD_A(0, m_bot[0] && m_left, m_bot[1] && m_left, true) MMA_COLS(0x30) }
-            if (has_bot && has_right) { LOAD_A(0, m_bot[0] && m_right, m_bot[1] && m_right, true) MMA_COLS(0xC0) }
-            STEP_END()
+#define CORNER_BODY(KS, BSET)                                                                \
+            if (has_top && wn == 0 && wm == 0) {                                             \
+                if (has_left) {                                                              \
+                    bf16x8 f;                                                                \
+                    RDA_MASKED(f, 0, 0, KS, m_top && m_left)                                 \
+                    LGKM_WAIT(0)                                                             \
+                    MFMA_ONE(0, 0, BSET, f) MFMA_ONE(1, 0, BSET, f)                          \
+                }                                                                            \
+                if (has_right) {                                                             \
+                    bf16x8 f;                                                                \
+                    RDA_MASKED(f, 0, 0, KS, m_top && m_right)                                \
+                    LGKM_WAIT(0)                                                             \
+                    MFMA_ONE(2, 0, BSET, f) MFMA_ONE(3, 0, BSET, f)                          \
+                }                                                                            \
+            }                                                                                \
+            if (has_bot && wn == 1 && wm == 1) {                                             \
+                if (has_left) {                                                              \
+                    bf16x8 f;                                                                \
+                    RDA_MASKED(f, 3, 0, KS, m_bot && m_left)                                 \
+                    LGKM_WAIT(0)                                                             \
+                    MFMA_ONE(0, 3, BSET, f) MFMA_ONE(1, 3, BSET, f)                          \
+                }                                                                            \
+                if (has_right) {                                                             \
+                    bf16x8 f;                                                                \
+                    RDA_MASKED(f, 3, 0, KS, m_bot && m_right)                                \
+                    LGKM_WAIT(0)                                                             \
+                    MFMA_ONE(2, 3, BSET, f) MFMA_ONE(3, 3, BSET, f)                          \
+                }                                                                            \
+            }                                                                                \
+            __builtin_amdgcn_sched_barrier(0);
+            CORR_STEP(CORNER_BODY)
+#undef CORNER_BODY
         }
     }
-#undef LOAD_A
-#undef MMA_COLS
-#undef STENCIL_MMA
-#undef MFMA8X
-#undef RD6
-#undef MFMA8
+#undef MFMA_ONE
+#undef RDA_MASKED
+#undef CORR_STEP
+#undef STENCIL_STEP
+#undef MFMA16
+#undef RDA
 #undef LGKM_WAIT
-#undef DSR4
 #undef DSR
-#undef STEP_BEGIN
-#undef STEP_END
+#undef ISSUE_B
 
-    // ---- epilogue, two rounds: waves wn = 0 / 1 park phase (py = wn, px = round) in LDS tile wn (fp32 [256 px][64 ch],
-    // the whole LDS is free now), then all 512 threads apply affine/act/dropout and store bf16 NHWC
-    float* Ct = (float*)smem;
+    // ---- epilogue straight from the accumulators.  Lane (l31, hi) of tile (nt, mt) holds pixel l31 of pixel tile mt and
+    // channels half*32 + 8*g + 4*hi + {0..3} (g = register group r >> 2).  Groups 2*g2 and 2*g2+1 are packed to bf16 and
+    // exchanged between lanes l and l+32 (v_permlane32_swap), after which every lane owns 8 consecutive channels = 16 B.
     const uint32_t key = drop_key(a.drop);
+    const uint32_t ci_base = (uint32_t)(n_img * a.coef_stride + tn * 64 + 4 * hi);
+    // output pixel (pixel tile 0, px = 0) of this lane, in elements; pixel tile mt adds 4 output rows, px adds one pixel
+    const uint32_t m0 = (uint32_t)((n_img * a.ho + 2 * (ty0 + 8 * wm + px_r) + wn) * a.wo + 2 * (tx0 + px_x));
+    const uint32_t o0 = m0 * (uint32_t)a.cout + (uint32_t)(tn * 64);
+    const uint32_t mt_stride = (uint32_t)(4 * a.wo * a.cout);
+    // (activation, dropout mode) are wave-uniform: the whole epilogue is instantiated per pair and dispatched once
+    auto epilogue = [&](auto act_c, auto mode_c) {
+        constexpr int ACT = decltype(act_c)::value, MODE = decltype(mode_c)::value;
 #pragma unroll
-    for (int px = 0; px < 2; ++px) {
-        __syncthreads();
+        for (int hg = 0; hg < 4; ++hg) {
+            const int cg0 = (hg >> 1) * 32 + 16 * (hg & 1);  // + 4*hi: own channels of group 2*g2; + 8: group 2*g2+1
+            const float4 ca0 = *(const float4*)(a.coef_a + ci_base + cg0), ca1 = *(const float4*)(a.coef_a + ci_base + cg0 + 8);
+            const float4 cc0 = *(const float4*)(a.coef_c + ci_base + cg0), cc1 = *(const float4*)(a.coef_c + ci_base + cg0 + 8);
+            const float ca[8] = {ca0.x, ca0.y, ca0.z, ca0.w, ca1.x, ca1.y, ca1.z, ca1.w};
+            const float cc[8] = {cc0.x, cc0.y, cc0.z, cc0.w, cc1.x, cc1.y, cc1.z, cc1.w};
 #pragma unroll
-        for (int half = 0; half < 2; ++half)
+            for (int px = 0; px < 2; ++px)
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
+                for (int mt = 0; mt < 4; ++mt) {
+                    const uint32_t obase = o0 + mt * mt_stride + px * a.cout + cg0;
+                    const uint32_t e0 = obase + 4 * hi;
+                    float v[8];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int ml = wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    Ct[wn * 16384 + ml * 64 + half * 32 + l31] = acc[px * 2 + half][mt][r];
+                    for (int t = 0; t < 8; ++t) v[t] = fmaf(acc[px * 2 + (hg >> 1)][mt][8 * (hg & 1) + t], ca[t], cc[t]);
+                    act_drop_fixed<4, ACT, MODE>(v, e0, a.drop, key);
+                    act_drop_fixed<4, ACT, MODE>(v + 4, e0 + 8, a.drop, key);
+                    uint32_t p0 = pack_bf16x2(v[0], v[1]), p1 = pack_bf16x2(v[2], v[3]);
+                    uint32_t q0 = pack_bf16x2(v[4], v[5]), q1 = pack_bf16x2(v[6], v[7]);
+                    const auto s0 = __builtin_amdgcn_permlane32_swap(p0, q0, false, false);
+                    const auto s1 = __builtin_amdgcn_permlane32_swap(p1, q1, false, false);
+                    // lanes 0-31: {own group 2*g2, partner's group 2*g2} = channels cg0 + 0..7;
+                    // lanes 32-63: {partner's group 2*g2+1, own group 2*g2+1} = channels cg0 + 8..15
+                    uint4 o;
+                    o.x = s0[0]; o.y = s1[0]; o.z = s0[1]; o.w = s1[1];
+                    *(uint4*)(a.out_bf16 + (size_t)(obase + 8 * hi)) = o;
                 }
-        __syncthreads();
-#pragma unroll 2
-        for (int it = 0; it < 8; ++it) {
-            const int id = it * 512 + tid;
-            const int py = id >> 11, row = (id >> 3) & 255, cg = id & 7;
-            const int y = ty0 + (row >> 4), x = tx0 + (row & 15);
-            const size_t m = ((size_t)n_img * a.ho + 2 * y + py) * a.wo + 2 * x + px;
-            const int co = tn * 64 + cg * 8;
-            const float* cp = Ct + py * 16384 + row * 64 + cg * 8;
-            const float4 v0 = *(const float4*)cp;
-            const float4 v1 = *(const float4*)(cp + 4);
-            const size_t ci = (size_t)n_img * a.coef_stride + co;
-            const float4 a0 = *(const float4*)(a.coef_a + ci), a1 = *(const float4*)(a.coef_a + ci + 4);
-            const float4 c0 = *(const float4*)(a.coef_c + ci), c1 = *(const float4*)(a.coef_c + ci + 4);
-            float v[8] = {fmaf(v0.x, a0.x, c0.x), fmaf(v0.y, a0.y, c0.y), fmaf(v0.z, a0.z, c0.z), fmaf(v0.w, a0.w, c0.w),
-                          fmaf(v1.x, a1.x, c1.x), fmaf(v1.y, a1.y, c1.y), fmaf(v1.z, a1.z, c1.z), fmaf(v1.w, a1.w, c1.w)};
-            const uint32_t e0 = (uint32_t)(m * a.cout + co);
-#pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                v[t] = apply_act(v[t], a.act);
-                v[t] = drop_apply(v[t], e0 + t, a.drop, key);
-            }
-            uint4 o;
-            o.x = pack_bf16x2(v[0], v[1]);
-            o.y = pack_bf16x2(v[2], v[3]);
-            o.z = pack_bf16x2(v[4], v[5]);
-            o.w = pack_bf16x2(v[6], v[7]);
-            *(uint4*)(a.out_bf16 + m * a.cout + co) = o;
         }
-    }
+    };
+    auto by_mode = [&](auto act_c) {
+        if (a.drop.mode == 0) epilogue(act_c, std::integral_constant<int, 0>{});
+        else if (a.drop.mode == 1) epilogue(act_c, std::integral_constant<int, 1>{});
+        else epilogue(act_c, std::integral_constant<int, 2>{});
+    };
+    if (a.act == ACT_RELU) by_mode(std::integral_constant<int, ACT_RELU>{});
+    else if (a.act == ACT_LEAKY) by_mode(std::integral_constant<int, ACT_LEAKY>{});
+    else if (a.act == ACT_SILU) by_mode(std::integral_constant<int, ACT_SILU>{});
+    else by_mode(std::integral_constant<int, ACT_NONE>{});
 #endif
 }
 
+// [4 phases][cout][16 taps][cin] (pack_up2x_weights) -> MFMA fragment order:
+// [column block tn][chunk][tap][wn = py][ks][column tile nt = px*2 + half][lane][8 k]; lane (l31, hi) of fragment
+// (ks, nt) holds channel tn*64 + half*32 + l31, k = chunk*64 + ks*16 + hi*8 + {0..7}
+void pack_up2x_frag(const bf16_t* wpk_up, int cout, int cin, bf16_t* out) {
+    const int cpt = cin / 64;
+    size_t o = 0;
+    for (int tn = 0; tn < cout / 64; ++tn)
+        for (int chunk = 0; chunk < cpt; ++chunk)
+            for (int tap = 0; tap < 16; ++tap)
+                for (int wn = 0; wn < 2; ++wn)
+                    for (int ks = 0; ks < 4; ++ks)
+                        for (int nt = 0; nt < 4; ++nt)
+                            for (int lane = 0; lane < 64; ++lane) {
+                                const int phase = wn * 2 + (nt >> 1);
+                                const int co = tn * 64 + (nt & 1) * 32 + (lane & 31);
+                                const int k0 = chunk * 64 + ks * 16 + (lane >> 5) * 8;
+                                const bf16_t* s = wpk_up + (((size_t)phase * cout + co) * 16 + tap) * cin + k0;
+                                for (int e = 0; e < 8; ++e) out[o++] = s[e];
+                            }
+}
+
 bool conv_up_halo_supported(const ConvArgs& a) {
-    if (!a.up2x || a.wpk_up == nullptr || a.out_bf16 == nullptr || a.residual != nullptr) return false;
+    if (!a.up2x || a.wpk_up_frag == nullptr || a.out_bf16 == nullptr || a.residual != nullptr) return false;
     if (!(a.c0 > 0 && a.c0 % 64 == 0 && (a.c1 == 0 || a.c1 == a.c0) && a.cout % 64 == 0)) return false;
     if (a.h % 16 != 0 || a.w % 16 != 0 || a.ho != 2 * a.h || a.wo != 2 * a.w) return false;
     const size_t npix = (size_t)a.n * a.h * a.w;
@@ -382,7 +433,7 @@ hipError_t conv_up_halo_init() {
 hipError_t launch_conv_up_halo(const ConvArgs& a, hipStream_t stream) {
     const int tiles_x = a.w / 16, tiles_per_img = tiles_x * (a.h / 16);
     const int tiles_m = a.n * tiles_per_img, tiles_n = a.cout / 64;
-    hipLaunchKernelGGL(conv_up_halo_kernel, dim3(tiles_m * tiles_n), dim3(512), LDS_TOTAL, stream, a, tiles_x, tiles_per_img,
+    hipLaunchKernelGGL(conv_up_halo_kernel, dim3(tiles_m * tiles_n), dim3(256), LDS_TOTAL, stream, a, tiles_x, tiles_per_img,
                        tiles_m, tiles_n);
     return hipGetLastError();
 }

@@ -187,7 +187,7 @@ dyf_status net_forward(dyf_engine* e, int which, const Source* srcs, int nsrc, i
         // fused form: the conv gathers straight from the low-res cat[x, skip] (phase decomposition, conv.hip)
         ConvArgs f = a;
         f.src0 = x; f.c0 = b.cin - skip_c; f.src1 = skip; f.c1 = skip_c; f.h = lh; f.w = lw;
-        f.up2x = 1; f.wpk_up = b.wpk_up;
+        f.up2x = 1; f.wpk_up = b.wpk_up; f.wpk_up_frag = b.wpk_up_frag;
         if (use_fused_up(e, b, f)) {
             HIP_TRY(e, launch_conv(f, 1, st));
         } else {  // materialise the upsampled tensor, then a plain conv
@@ -468,6 +468,11 @@ dyf_status dyf_load_weights(dyf_engine* e, int32_t which, int32_t n_tensors, con
             std::vector<bf16_t> pu((size_t)4 * b.cout * 16 * b.cin);
             pack_up2x_weights(cw->data, b.cout, b.cin, pu.data());
             UP(b.wpk_up, pu);
+            if (b.cin % 64 == 0 && b.cout % 64 == 0) {  // MFMA fragment order for the halo kernel
+                std::vector<bf16_t> pf(pu.size());
+                pack_up2x_frag(pu.data(), b.cout, b.cin, pf.data());
+                UP(b.wpk_up_frag, pf);
+            }
         }
         if (!b.gn) {  // eval-mode BatchNorm2d folded with the conv bias: y = conv*a + c
             NEED(rm, norm + ".running_mean", (int64_t)b.cout);
@@ -831,7 +836,7 @@ dyf_status dyf_time_conv_layer(dyf_engine* e, int32_t which, int32_t layer, int3
         ConvArgs f = a;
         const UBlock& skipb = n.blk[11 - layer];
         f.src0 = e->ws.dec[layer - 7]; f.c0 = b.cin - skipb.cout; f.src1 = e->ws.enc[11 - layer]; f.c1 = skipb.cout;
-        f.h = b.in_h / 2; f.w = b.in_w / 2; f.up2x = 1; f.wpk_up = b.wpk_up;
+        f.h = b.in_h / 2; f.w = b.in_w / 2; f.up2x = 1; f.wpk_up = b.wpk_up; f.wpk_up_frag = b.wpk_up_frag;
         if (use_fused_up(e, b, f)) a = f;
     }
     const float* A = n.tables ? n.tables : e->ws.coef_a;                    // row 0 of the plan's tables, or the
@@ -928,11 +933,18 @@ dyf_status dyf_op_upconv2d(dyf_engine* e, const uint16_t* x_dev, const float* w_
     pack_up2x_weights(w_host, cout, cin, pu.data());
     bf16_t* wdev = nullptr;
     float *ones = nullptr, *zeros = nullptr;
-    HIP_TRY(e, hipMalloc((void**)&wdev, pu.size() * sizeof(bf16_t)));
+    const bool frag = cin % 64 == 0 && cout % 64 == 0;
+    HIP_TRY(e, hipMalloc((void**)&wdev, 2 * pu.size() * sizeof(bf16_t)));
     HIP_TRY(e, hipMemcpy(wdev, pu.data(), pu.size() * sizeof(bf16_t), hipMemcpyHostToDevice));
+    if (frag) {
+        std::vector<bf16_t> pf(pu.size());
+        pack_up2x_frag(pu.data(), cout, cin, pf.data());
+        HIP_TRY(e, hipMemcpy(wdev + pu.size(), pf.data(), pf.size() * sizeof(bf16_t), hipMemcpyHostToDevice));
+    }
     ConvArgs a{};
     a.src0 = x_dev; a.c0 = cin; a.n = n; a.h = h; a.w = w; a.ho = 2 * h; a.wo = 2 * w;
     a.kh = 3; a.kw = 3; a.stride = 1; a.pad = 1; a.cout = cout; a.wpk = wdev; a.wpk_up = wdev; a.up2x = 1;
+    a.wpk_up_frag = frag ? wdev + pu.size() : nullptr;
     a.act = act; a.out_bf16 = y_dev;
     if (scale_dev && shift_dev) {
         a.coef_a = scale_dev; a.coef_c = shift_dev; a.coef_stride = cout;

@@ -29,6 +29,7 @@ struct UBlock {              // one UNetBlock (unet_simple.py:13-82)
     int out_h = 0, out_w = 0;
     bf16_t* wpk = nullptr;   // device [cout][k*k][cin]
     bf16_t* wpk_up = nullptr;  // decoder 3x3 blocks: phase-decomposed weights of the fused x2-upsample conv
+    bf16_t* wpk_up_frag = nullptr;  // ... in MFMA fragment order (halo kernel)
     float* gamma = nullptr;  // device (GroupNorm only)
     float* beta = nullptr;
     float* static_a = nullptr;  // device [cout]: epilogue of the GroupNorm block's conv (ones / conv bias)
