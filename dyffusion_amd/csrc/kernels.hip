@@ -2,6 +2,8 @@
 // sampler elementwise.  Every kernel replaces an unfused ATen sequence of the reference (cited per kernel).
 #include "kernels.h"
 
+#include <cstdlib>
+
 // ------------------------------------------------------------------------------------------------ block reduce
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -453,8 +455,131 @@ __global__ __launch_bounds__(256) void readout_sliced_kernel(ReadoutArgs a) {
     }
 }
 
+// Register-weight form for cin == 64 (the NS backbone): the sliced kernel above is bound by its 384 LDS weight reads per
+// thread.  Every native pixel uses each of the 16 (kh, kw) taps of the transposed conv exactly once (u0/u1 and v0/v1 have
+// opposite parities), reading a 3x3 window of decoder pixels.  So 32 lanes share a pixel: lane (kh = 0..3, slice = 0..7)
+// keeps the weights of its kernel row and 8-channel slice in REGISTERS (4 kw x 8 c x CO), loads the 4 input vectors of
+// its row (16 B each; 8 slices = one 128-B line) and the 32 partial sums are combined with a butterfly.  A half-wave
+// walks a contiguous run of native pixels (oy fastest: consecutive pixels share two of the three input rows in L1).
+template <int CO>
+__global__ __launch_bounds__(256) void readout_regw_kernel(ReadoutArgs a, int px_per_half) {
+    const int lane = threadIdx.x & 63;
+    const int half = (int)((blockIdx.x * 256 + threadIdx.x) >> 5);
+    const int kh = (lane >> 3) & 3, slice = lane & 7, ci0 = slice * 8;
+    float w[4][8][CO];
+#pragma unroll
+    for (int kw = 0; kw < 4; ++kw)
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+#pragma unroll
+            for (int co = 0; co < CO; ++co) w[kw][c][co] = a.wgt[((size_t)(kh * 4 + kw) * a.cin + ci0 + c) * CO + co];
+    float bias[CO];
+#pragma unroll
+    for (int co = 0; co < CO; ++co) bias[co] = a.bias[co];
+    const int total = a.n * a.oh * a.ow;
+    const int th = 2 * a.ih, tw = 2 * a.iw;
+    const float sh = (float)th / (float)a.oh, sw = (float)tw / (float)a.ow;
+    const int pu = (kh + 1) & 1;
+    // pixel order: (n, ox, oy), oy fastest; the position is advanced incrementally (no per-pixel divisions)
+    int idx = half * px_per_half;
+    int n, ox, oy;
+    {
+        const int ic = idx < total ? idx : total - 1;
+        n = ic / (a.oh * a.ow);
+        const int rem = ic - n * (a.oh * a.ow);
+        ox = rem / a.oh;
+        oy = rem - ox * a.oh;
+    }
+    // one pixel's inputs: 4 vectors of this lane's kernel row + their bilinear weights
+    struct Px {
+        uint4 q[4];
+        float bw[4];
+        int out_off;  // element offset of channel 0 in `out`, or -1
+    };
+    auto fetch = [&](Px& p) {
+        const bool live = idx < total;
+        int u0, u1, v0, v1;
+        float lu, lv;
+        bilinear_coord(oy, sh, th, u0, u1, lu);
+        bilinear_coord(ox, sw, tw, v0, v1, lv);
+        // kernel row kh pairs with the neighbour u of parity (kh + 1) & 1: kh = u + 1 - 2 i, i = ((u + 1) >> 1) - (kh >> 1)
+        const float wu = ((u0 & 1) == pu ? 1.0f - lu : 0.0f) + ((u1 & 1) == pu ? lu : 0.0f);
+        const int u = (u1 & 1) == pu ? u1 : u0;
+        const int i = ((u + 1) >> 1) - (kh >> 1);
+        const bool row_ok = (unsigned)i < (unsigned)a.ih;
+        const bf16_t* row = a.x + ((size_t)n * a.ih + (row_ok ? i : 0)) * a.iw * a.cin + ci0;
+#pragma unroll
+        for (int kw = 0; kw < 4; ++kw) {
+            const int pv = (kw + 1) & 1;
+            const float wv = ((v0 & 1) == pv ? 1.0f - lv : 0.0f) + ((v1 & 1) == pv ? lv : 0.0f);
+            const int v = (v1 & 1) == pv ? v1 : v0;
+            const int j = ((v + 1) >> 1) - (kw >> 1);
+            const bool ok = row_ok && (unsigned)j < (unsigned)a.iw;
+            p.q[kw] = *(const uint4*)(row + (size_t)(ok ? j : 0) * a.cin);
+            p.bw[kw] = ok ? wu * wv : 0.0f;
+        }
+        p.out_off = live ? ((n * CO) * a.oh + oy) * a.ow + ox : -1;
+        // advance (clamped at the last pixel so that the whole wave stays in the shuffles)
+        ++idx;
+        if (idx < total) {
+            if (++oy == a.oh) {
+                oy = 0;
+                if (++ox == a.ow) { ox = 0; ++n; }
+            }
+        }
+    };
+    auto reduce_store = [&](const Px& p) {
+        float acc[CO];
+#pragma unroll
+        for (int co = 0; co < CO; ++co) acc[co] = 0.0f;
+#pragma unroll
+        for (int kw = 0; kw < 4; ++kw) {
+            const uint32_t qw[4] = {p.q[kw].x, p.q[kw].y, p.q[kw].z, p.q[kw].w};
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const float xv = p.bw[kw] * ((c & 1) ? __uint_as_float(qw[c >> 1] & 0xffff0000u) : __uint_as_float(qw[c >> 1] << 16));
+#pragma unroll
+                for (int co = 0; co < CO; ++co) acc[co] = fmaf(xv, w[kw][c][co], acc[co]);
+            }
+        }
+#pragma unroll
+        for (int co = 0; co < CO; ++co) {
+            float v = acc[co];
+#pragma unroll
+            for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+            if (p.out_off >= 0 && (lane & 31) == 0) a.out[(size_t)p.out_off + (size_t)co * a.oh * a.ow] = v + bias[co];
+        }
+    };
+    // two pixels in flight: the loads of pixel it+1 are issued before the FMAs of pixel it
+    Px p0, p1;
+    fetch(p0);
+    for (int it = 0; it < px_per_half; it += 2) {
+        fetch(p1);
+        reduce_store(p0);
+        fetch(p0);
+        reduce_store(p1);
+    }
+}
+
 hipError_t launch_readout(const ReadoutArgs& a, hipStream_t s) {
     const long long total = (long long)a.n * a.oh * a.ow;
+    static const bool regw = !(getenv("DYF_READOUT_REGW") && atoi(getenv("DYF_READOUT_REGW")) == 0);
+    if (regw && a.cin == 64 && a.cout >= 1 && a.cout <= 4 && total < (1ll << 30)) {
+        // ~16 waves per CU; a half-wave owns a contiguous run of pixels
+        int halves = 256 * 16 * 2;
+        int per = (int)((total + halves - 1) / halves);
+        if (per < 8) per = 8;
+        per += per & 1;  // the kernel walks two pixels per iteration
+        halves = (int)((total + per - 1) / per);
+        const unsigned blocks = (unsigned)((halves + 7) / 8);
+#define RW_CASE(C)                                                                                      \
+        if (a.cout == C) {                                                                              \
+            hipLaunchKernelGGL(readout_regw_kernel<C>, dim3(blocks), dim3(256), 0, s, a, per);          \
+            return hipGetLastError();                                                                   \
+        }
+        RW_CASE(1) RW_CASE(2) RW_CASE(3) RW_CASE(4)
+#undef RW_CASE
+    }
     const size_t lds = (size_t)16 * a.cin * a.cout * sizeof(float);
     const int lanes = (a.cin % 8 == 0) ? a.cin / 8 : 0;
 #define RO_CASE(L)                                                                                                   \
