@@ -542,7 +542,8 @@ hipError_t launch_conv(const ConvArgs& a, int path, hipStream_t stream) {
         static const bool use_halo = !(getenv("DYF_UP_HALO") && atoi(getenv("DYF_UP_HALO")) == 0);
         // halo form wins once most tiles are interior (>= 4x4 tiles per image); below that the gather form's pipelined
         // correction taps are cheaper (measured: dec3 32x32 plane 712 vs 697 TFLOP/s, dec4/dec5 862/905 vs 831/799)
-        if (a.up2x && use_halo && a.h >= 64 && a.w >= 64 && conv_up_halo_supported(a)) return launch_conv_up_halo(a, stream);
+        static const int halo_min = getenv("DYF_HALO_MIN_PLANE") ? atoi(getenv("DYF_HALO_MIN_PLANE")) : 64;
+        if (a.up2x && use_halo && a.h >= halo_min && a.w >= halo_min && conv_up_halo_supported(a)) return launch_conv_up_halo(a, stream);
         if (a.cout % 128 == 0)
             return a.up2x ? launch_igemm<128, 128, 2, 2, 1>(a, stream) : launch_igemm<128, 128, 2, 2, 0>(a, stream);
         return a.up2x ? launch_igemm<256, 64, 4, 1, 1>(a, stream) : launch_igemm<256, 64, 4, 1, 0>(a, stream);

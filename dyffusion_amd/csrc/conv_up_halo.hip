@@ -31,18 +31,21 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
 namespace {
 
-constexpr int HALO_W = 18, HALO_PIX = 328;              // 18*18 = 324, padded to a multiple of 8 DMA rows
-constexpr int HALO_BYTES = HALO_PIX * 128;              // 41 984
+constexpr int TILE_H = 8, TILE_W = 16;                  // low-res tile of a workgroup
+constexpr int HALO_W = 18, HALO_REAL = 180, HALO_PIX = 184;  // 10*18 = 180, padded to a multiple of 8 DMA rows
+constexpr int HALO_BYTES = HALO_PIX * 128;              // 23 552
 constexpr int ZERO_OFF = 2 * HALO_BYTES;                // 128 B of zeros (pixels masked out of a correction tap)
-constexpr int LDS_TOTAL = ZERO_OFF + 512;               // 84 480 B
-constexpr int HALO_INSTR = HALO_PIX / 8;                // 41 wave-level DMA instructions per halo
+constexpr int HOFF_OFF = ZERO_OFF + 512;                // per-thread halo source offsets [HALO_PER_WAVE][256]
+constexpr int HALO_PER_WAVE_C = 6;
+constexpr int LDS_TOTAL = HOFF_OFF + HALO_PER_WAVE_C * 1024;  // 53 760 B
+constexpr int HALO_INSTR = HALO_PIX / 8;                // 23 wave-level DMA instructions per halo
 constexpr int NWAVES = 4;
-constexpr int HALO_PER_WAVE = (HALO_INSTR + NWAVES - 1) / NWAVES;  // 11
+constexpr int HALO_PER_WAVE = (HALO_INSTR + NWAVES - 1) / NWAVES;  // 6
 constexpr int STEP_BYTES = 32768;                       // weights of one (tap, chunk) step: 256 columns x 64 k bf16
 
 }  // namespace
 
-__global__ __launch_bounds__(256, 1) void conv_up_halo_kernel(ConvArgs a, int tiles_x, int tiles_per_img, int tiles_m,
+__global__ __launch_bounds__(256, 2) void conv_up_halo_kernel(ConvArgs a, int tiles_x, int tiles_per_img, int tiles_m,
                                                               int tiles_n) {
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -50,7 +53,7 @@ __global__ __launch_bounds__(256, 1) void conv_up_halo_kernel(ConvArgs a, int ti
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wpy = wave >> 1, wpx = wave & 1;  // output phase of this wave
 
     // XCD-aware tile id; the column blocks of one tile are consecutive (they share the halo in L2)
     const int total = tiles_m * tiles_n;
@@ -60,11 +63,11 @@ __global__ __launch_bounds__(256, 1) void conv_up_halo_kernel(ConvArgs a, int ti
     const int tn = tile % tiles_n, tm = tile / tiles_n;
     const int n_img = tm / tiles_per_img;
     const int t_in = tm - n_img * tiles_per_img;
-    const int ty0 = (t_in / tiles_x) * 16, tx0 = (t_in % tiles_x) * 16;
+    const int ty0 = (t_in / tiles_x) * TILE_H, tx0 = (t_in % tiles_x) * TILE_W;
 
     const int cin = a.c0 + a.c1;
     const int cpt = cin >> 6;
-    const bool has_top = ty0 == 0, has_bot = ty0 + 16 == a.h, has_left = tx0 == 0, has_right = tx0 + 16 == a.w;
+    const bool has_top = ty0 == 0, has_bot = ty0 + TILE_H == a.h, has_left = tx0 == 0, has_right = tx0 + TILE_W == a.w;
     const bool has_row = has_top || has_bot, has_col = has_left || has_right;
     // tap list of this tile, 4 bits per entry: 0-8 stencil, 9-11 row correction, 12-14 column correction, 15 corner
     unsigned long long tap_list = 0x876543210ull;
@@ -81,17 +84,18 @@ __global__ __launch_bounds__(256, 1) void conv_up_halo_kernel(ConvArgs a, int ti
                                                           (int)(unsigned)((size_t)4 * a.cout * 16 * cin * 2), 0x00020000);
 
     // ---- halo DMA descriptors: instruction i (i % 4 == wave) fills halo pixels [8i, 8i+8); lane -> (pixel, 16-B chunk)
+    // (the per-lane source offsets are parked in LDS, not in registers: the K loop needs every VGPR it can get)
     const int sub = lane >> 3;
-    unsigned h_off[HALO_PER_WAVE];
+    unsigned* h_tab = (unsigned*)(smem + HOFF_OFF) + tid;
 #pragma unroll
     for (int j = 0; j < HALO_PER_WAVE; ++j) {
         const int i = j * NWAVES + wave;
         int hp = i * 8 + sub;
-        if (hp > 323) hp = 323;  // padding slots re-read the last halo pixel
+        if (hp > HALO_REAL - 1) hp = HALO_REAL - 1;  // padding slots re-read the last halo pixel
         const int hy = hp / HALO_W, hx = hp - hy * HALO_W;
         const int y = min(max(ty0 - 1 + hy, 0), a.h - 1), x = min(max(tx0 - 1 + hx, 0), a.w - 1);  // replicate clamp
         const int gch = (lane & 7) ^ ((hp >> 1) & 7);  // swizzled source chunk of this linear LDS slot
-        h_off[j] = (unsigned)((n_img * a.h + y) * a.w + x) * (unsigned)(a.c0 * 2) + gch * 16;  // c0 == c1 (checked on host)
+        h_tab[j * 256] = (unsigned)((n_img * a.h + y) * a.w + x) * (unsigned)(a.c0 * 2) + gch * 16;  // c0 == c1 (checked on host)
     }
     if (tid < 32) ((uint4*)(smem + ZERO_OFF))[tid] = make_uint4(0, 0, 0, 0);
 
@@ -105,9 +109,9 @@ __global__ __launch_bounds__(256, 1) void conv_up_halo_kernel(ConvArgs a, int ti
             const int i = j * NWAVES + wave;
             if (i < HALO_INSTR) {
                 if (second)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a1, LDS_PTR(dst + i * 1024), 16, h_off[j] + coff, 0, 0, 0);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a1, LDS_PTR(dst + i * 1024), 16, h_tab[j * 256] + coff, 0, 0, 0);
                 else
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a0, LDS_PTR(dst + i * 1024), 16, h_off[j] + coff, 0, 0, 0);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a0, LDS_PTR(dst + i * 1024), 16, h_tab[j * 256] + coff, 0, 0, 0);
             }
         }
     };
@@ -118,7 +122,7 @@ __global__ __launch_bounds__(256, 1) void conv_up_halo_kernel(ConvArgs a, int ti
     int it_pos = 0, it_chunk = 0;
     auto soff_of = [&](int pos, int chunk) {
         const int tap = (int)((tap_list >> (4 * pos)) & 15ull);
-        return (unsigned)(((tn * cpt + chunk) * 16 + tap) * STEP_BYTES + wn * (STEP_BYTES / 2));
+        return (unsigned)(((tn * cpt + chunk) * 16 + tap) * STEP_BYTES + wpy * (STEP_BYTES / 2) + wpx * 2048);
     };
     unsigned soff_cur = soff_of(0, 0), soff_next = soff_cur;
     auto advance = [&]() {  // the tail re-fetches the last step (harmless, never consumed)
@@ -128,74 +132,76 @@ __global__ __launch_bounds__(256, 1) void conv_up_halo_kernel(ConvArgs a, int ti
     };
     advance();  // -> soff_cur = step 0, soff_next = step 1
 
-    f32x16 acc[4][4];  // [column tile nt = px*2 + half (phase py = wn)][pixel tile mt: tile rows 8*wm + 2*mt + {0,1}]
+    f32x16 acc[2][4];  // [32-channel half][pixel tile mt: tile rows 2*mt + {0,1}]
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt)
+    for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[nt][mt][r] = 0.0f;
 
     const int px_x = l31 & 15, px_r = l31 >> 4;
-    int hp0 = (8 * wm + px_r + 1) * HALO_W + (px_x + 1);  // halo pixel of pixel tile 0 at the un-shifted tap; mt adds 36
+    int hp0 = (px_r + 1) * HALO_W + (px_x + 1);  // halo pixel of pixel tile 0 at the un-shifted tap; mt adds 36
     const bool m_left = has_left && px_x == 0, m_right = has_right && px_x == 15;
-    const bool m_top = has_top && wm == 0 && px_r == 0;   // pixel tile 0
-    const bool m_bot = has_bot && wm == 1 && px_r == 1;   // pixel tile 3
+    const bool m_top = has_top && px_r == 0;   // pixel tile 0
+    const bool m_bot = has_bot && px_r == 1;   // pixel tile 3
     const unsigned lds_base = (unsigned)(uintptr_t)LDS_PTR(smem);
 
-    u32x4 bq[4][4];   // weight fragments: set = k16 sub-step & 3
+    u32x4 bq[4][2];   // weight fragments: set = k16 sub-step & 3
     bf16x8 aq[2][4];  // pixel fragments: two sets
+    unsigned ab[4], ax[4];  // LDS base / swizzle term of the tap whose pixel fragments are being fetched
 
 #define ISSUE_B(SET, SOFF, KS)                                                                               \
-    _Pragma("unroll") for (int nt = 0; nt < 4; ++nt)                                                         \
+    _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                                         \
         bq[SET][nt] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, w_voff + nt * 1024, (SOFF) + (KS) * 4096, 0);
 #define DSR(dst, addr) asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr));
 #define LGKM_WAIT(N)                                                      \
     asm volatile("s_waitcnt lgkmcnt(" #N ")" ::: "memory");               \
     __builtin_amdgcn_sched_barrier(0);
     // pixel fragments of sub-step KS at halo displacement DISP: 4 pixel tiles, 36 halo pixels (2 rows) apart
-#define RDA(SET, DISP, KS)                                                                                   \
-    _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) {                                                       \
-        const int hpm = hp0 + (DISP) + 36 * mt;                                                              \
-        const unsigned pm = Hs + hpm * 128 + ((((KS) * 2 + hi) ^ ((hpm >> 1) & 7)) << 4);                    \
-        DSR(aq[SET][mt], pm)                                                                                 \
+    // LDS address of pixel tile mt at tap displacement d, sub-step ks: ab[mt] + (ax[mt] ^ (ks << 5)) (one v_xad_u32);
+    // ab / ax are recomputed once per tap (the XOR swizzle key depends on the halo pixel, not linearly on d)
+#define TAPADDR(DISP)                                                                                        \
+    {                                                                                                        \
+        int hpb = hp0;                                                                                       \
+        asm volatile("" : "+v"(hpb)); /* opaque: keeps 9 taps x 8 addresses from being hoisted and spilled */ \
+        _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) {                                                   \
+            const int hpm = hpb + (DISP) + 36 * mt;                                                          \
+            ab[mt] = Hs + hpm * 128;                                                                         \
+            ax[mt] = (unsigned)((hi ^ ((hpm >> 1) & 7)) << 4);                                               \
+        }                                                                                                    \
     }
-#define MFMA16(ASET, BSET)                                                                                   \
-    _Pragma("unroll") for (int nt = 0; nt < 4; ++nt) {                                                       \
-        const bf16x8 wf = __builtin_bit_cast(bf16x8, bq[BSET][nt]);                                          \
-        _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                                     \
-            acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, aq[ASET][mt], acc[nt][mt], 0, 0, 0);   \
+#define RDA1(SET, KS, MT)                                                                                    \
+    {                                                                                                        \
+        const unsigned pm = (ax[MT] ^ (unsigned)((KS) << 5)) + ab[MT];                                       \
+        DSR(aq[SET][MT], pm)                                                                                 \
     }
-    // One stencil step (tap displacement DISP).  On entry pixel set 0 holds sub-step 0 of this step (issued by the
-    // previous step, or by the chunk prologue) and weight sets 0-2 are in flight.  While the 16 MFMAs of sub-step j run,
-    // the pixel fragments of j+1 and the weight fragments of j+3 stream in.  HAS_NEXT: the next step is the stencil tap
-    // at DNEXT of the same chunk, so its first pixel fragments are prefetched too.
+#define MF(NT, MT, ASET, BSET)                                                                               \
+    acc[NT][MT] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bq[BSET][NT]), aq[ASET][MT], \
+                                                          acc[NT][MT], 0, 0, 0);
+#define PIN __builtin_amdgcn_sched_barrier(0);
+#define NO_PRE
+#define SLOT(ISET, SOFF, IKS, LOAD, PRE, LSET, LKS, USE_A, USE_B)                                            \
+    {                                                                                                        \
+        LGKM_WAIT(0)                                                                                         \
+        ISSUE_B(ISET, SOFF, IKS)                                                                             \
+        MF(0, 0, USE_A, USE_B) PIN                                                                           \
+        if (LOAD) { PRE RDA1(LSET, LKS, 0) }                                                                 \
+        MF(0, 1, USE_A, USE_B) PIN                                                                           \
+        if (LOAD) RDA1(LSET, LKS, 1)                                                                         \
+        MF(0, 2, USE_A, USE_B) PIN                                                                           \
+        if (LOAD) RDA1(LSET, LKS, 2)                                                                         \
+        MF(0, 3, USE_A, USE_B) PIN                                                                           \
+        if (LOAD) RDA1(LSET, LKS, 3)                                                                         \
+        MF(1, 0, USE_A, USE_B) PIN                                                                           \
+        MF(1, 1, USE_A, USE_B) MF(1, 2, USE_A, USE_B) MF(1, 3, USE_A, USE_B) PIN                             \
+    }
 #define STENCIL_STEP(DISP, HAS_NEXT, DNEXT)                                                                  \
     {                                                                                                        \
-        ISSUE_B(3, soff_cur, 3)                                                                              \
-        RDA(1, DISP, 1)                                                                                      \
-        LGKM_WAIT(4)                                                                                         \
-        MFMA16(0, 0)                                                                                         \
-        __builtin_amdgcn_sched_barrier(0);                                                                   \
-        ISSUE_B(0, soff_next, 0)                                                                             \
-        RDA(0, DISP, 2)                                                                                      \
-        LGKM_WAIT(4)                                                                                         \
-        MFMA16(1, 1)                                                                                         \
-        __builtin_amdgcn_sched_barrier(0);                                                                   \
-        ISSUE_B(1, soff_next, 1)                                                                             \
-        RDA(1, DISP, 3)                                                                                      \
-        LGKM_WAIT(4)                                                                                         \
-        MFMA16(0, 2)                                                                                         \
-        __builtin_amdgcn_sched_barrier(0);                                                                   \
-        ISSUE_B(2, soff_next, 2)                                                                             \
-        if (HAS_NEXT) {                                                                                      \
-            RDA(0, DNEXT, 0)                                                                                 \
-            LGKM_WAIT(4)                                                                                     \
-        } else {                                                                                             \
-            LGKM_WAIT(0)                                                                                     \
-        }                                                                                                    \
-        MFMA16(1, 3)                                                                                         \
-        __builtin_amdgcn_sched_barrier(0);                                                                   \
+        SLOT(3, soff_cur, 3, true, NO_PRE, 1, 1, 0, 0)                                                       \
+        SLOT(0, soff_next, 0, true, NO_PRE, 0, 2, 1, 1)                                                      \
+        SLOT(1, soff_next, 1, true, NO_PRE, 1, 3, 0, 2)                                                      \
+        SLOT(2, soff_next, 2, HAS_NEXT, TAPADDR(DNEXT), 0, 0, 1, 3)                                          \
         advance();                                                                                           \
     }
     // One correction step: only the pixel tiles / column tiles that touch the border take part.  BODY(KS, BSET) issues
@@ -229,13 +235,14 @@ __global__ __launch_bounds__(256, 1) void conv_up_halo_kernel(ConvArgs a, int ti
     for (int chunk = 0; chunk < cpt; ++chunk) {
         // halo of this chunk landed (everything older than the 12 weight loads in flight), every wave is done with the
         // other buffer -> prefetch the next chunk's halo into it
-        asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         if (chunk + 1 < cpt) issue_halo(chunk + 1);
         const unsigned Hs = lds_base + (chunk & 1) * HALO_BYTES;
         asm volatile("" : "+v"(hp0));  // keep the per-tap LDS addresses from being hoisted out of the chunk loop
-        RDA(0, -HALO_W - 1, 0)
+        TAPADDR(-HALO_W - 1)
+        RDA1(0, 0, 0) RDA1(0, 0, 1) RDA1(0, 0, 2) RDA1(0, 0, 3)
         // ---- 9 stencil taps (a, b) in {-1,0,1}^2: displacement a*18 + b in the halo, every phase
 #define D_OF(T) (((T) / 3 - 1) * HALO_W + ((T) % 3 - 1))
         STENCIL_STEP(D_OF(0), true, D_OF(1))
@@ -251,17 +258,17 @@ __global__ __launch_bounds__(256, 1) void conv_up_halo_kernel(ConvArgs a, int ti
         if (has_row) {  // taps 9-11: b = -1,0,+1 on the border row; top -> phase row py = 0 (waves wn = 0), pixel tile 0
                         // of waves wm = 0; bottom -> py = 1, pixel tile 3 of waves wm = 1
 #define ROW_BODY_B(KS, BSET, B_)                                                             \
-            if (has_top && wn == 0 && wm == 0) {                                             \
+            if (has_top && wpy == 0) {                                                       \
                 bf16x8 f;                                                                    \
                 RDA_MASKED(f, 0, (B_), KS, m_top)                                            \
                 LGKM_WAIT(0)                                                                 \
-                MFMA_ONE(0, 0, BSET, f) MFMA_ONE(1, 0, BSET, f) MFMA_ONE(2, 0, BSET, f) MFMA_ONE(3, 0, BSET, f) \
+                MFMA_ONE(0, 0, BSET, f) MFMA_ONE(1, 0, BSET, f)                              \
             }                                                                                \
-            if (has_bot && wn == 1 && wm == 1) {                                             \
+            if (has_bot && wpy == 1) {                                                       \
                 bf16x8 f;                                                                    \
                 RDA_MASKED(f, 3, (B_), KS, m_bot)                                            \
                 LGKM_WAIT(0)                                                                 \
-                MFMA_ONE(0, 3, BSET, f) MFMA_ONE(1, 3, BSET, f) MFMA_ONE(2, 3, BSET, f) MFMA_ONE(3, 3, BSET, f) \
+                MFMA_ONE(0, 3, BSET, f) MFMA_ONE(1, 3, BSET, f)                              \
             }                                                                                \
             __builtin_amdgcn_sched_barrier(0);
 #define ROW_M1(KS, BSET) ROW_BODY_B(KS, BSET, -1)
@@ -275,17 +282,12 @@ __global__ __launch_bounds__(256, 1) void conv_up_halo_kernel(ConvArgs a, int ti
         }
         if (has_col) {  // taps 12-14: a = -1,0,+1 on the border column; left -> px = 0 (column tiles 0,1), right -> px = 1
 #define COL_BODY_A(KS, BSET, A_)                                                             \
-            if (has_left) {                                                                  \
+            if ((has_left && wpx == 0) || (has_right && wpx == 1)) {                         \
+                const bool keep = wpx == 0 ? m_left : m_right;                               \
                 bf16x8 f[4];                                                                 \
-                _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) RDA_MASKED(f[mt], mt, (A_) * HALO_W, KS, m_left) \
+                _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) RDA_MASKED(f[mt], mt, (A_) * HALO_W, KS, keep) \
                 LGKM_WAIT(0)                                                                 \
                 _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) { MFMA_ONE(0, mt, BSET, f[mt]) MFMA_ONE(1, mt, BSET, f[mt]) } \
-            }                                                                                \
-            if (has_right) {                                                                 \
-                bf16x8 f[4];                                                                 \
-                _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) RDA_MASKED(f[mt], mt, (A_) * HALO_W, KS, m_right) \
-                LGKM_WAIT(0)                                                                 \
-                _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) { MFMA_ONE(2, mt, BSET, f[mt]) MFMA_ONE(3, mt, BSET, f[mt]) } \
             }                                                                                \
             __builtin_amdgcn_sched_barrier(0);
 #define COL_M1(KS, BSET) COL_BODY_A(KS, BSET, -1)
@@ -299,32 +301,17 @@ __global__ __launch_bounds__(256, 1) void conv_up_halo_kernel(ConvArgs a, int ti
         }
         if (has_row && has_col) {  // tap 15: the corner pixel, one phase per corner
 #define CORNER_BODY(KS, BSET)                                                                \
-            if (has_top && wn == 0 && wm == 0) {                                             \
-                if (has_left) {                                                              \
-                    bf16x8 f;                                                                \
-                    RDA_MASKED(f, 0, 0, KS, m_top && m_left)                                 \
+            if (((has_top && wpy == 0) || (has_bot && wpy == 1)) && ((has_left && wpx == 0) || (has_right && wpx == 1))) { \
+                const bool keep = (wpy == 0 ? m_top : m_bot) && (wpx == 0 ? m_left : m_right); \
+                bf16x8 f;                                                                    \
+                if (wpy == 0) {                                                              \
+                    RDA_MASKED(f, 0, 0, KS, keep)                                            \
                     LGKM_WAIT(0)                                                             \
                     MFMA_ONE(0, 0, BSET, f) MFMA_ONE(1, 0, BSET, f)                          \
-                }                                                                            \
-                if (has_right) {                                                             \
-                    bf16x8 f;                                                                \
-                    RDA_MASKED(f, 0, 0, KS, m_top && m_right)                                \
-                    LGKM_WAIT(0)                                                             \
-                    MFMA_ONE(2, 0, BSET, f) MFMA_ONE(3, 0, BSET, f)                          \
-                }                                                                            \
-            }                                                                                \
-            if (has_bot && wn == 1 && wm == 1) {                                             \
-                if (has_left) {                                                              \
-                    bf16x8 f;                                                                \
-                    RDA_MASKED(f, 3, 0, KS, m_bot && m_left)                                 \
+                } else {                                                                     \
+                    RDA_MASKED(f, 3, 0, KS, keep)                                            \
                     LGKM_WAIT(0)                                                             \
                     MFMA_ONE(0, 3, BSET, f) MFMA_ONE(1, 3, BSET, f)                          \
-                }                                                                            \
-                if (has_right) {                                                             \
-                    bf16x8 f;                                                                \
-                    RDA_MASKED(f, 3, 0, KS, m_bot && m_right)                                \
-                    LGKM_WAIT(0)                                                             \
-                    MFMA_ONE(2, 3, BSET, f) MFMA_ONE(3, 3, BSET, f)                          \
                 }                                                                            \
             }                                                                                \
             __builtin_amdgcn_sched_barrier(0);
@@ -336,8 +323,12 @@ __global__ __launch_bounds__(256, 1) void conv_up_halo_kernel(ConvArgs a, int ti
 #undef RDA_MASKED
 #undef CORR_STEP
 #undef STENCIL_STEP
-#undef MFMA16
-#undef RDA
+#undef SLOT
+#undef PIN
+#undef MF
+#undef RDA1
+#undef TAPADDR
+#undef NO_PRE
 #undef LGKM_WAIT
 #undef DSR
 #undef ISSUE_B
@@ -348,7 +339,7 @@ __global__ __launch_bounds__(256, 1) void conv_up_halo_kernel(ConvArgs a, int ti
     const uint32_t key = drop_key(a.drop);
     const uint32_t ci_base = (uint32_t)(n_img * a.coef_stride + tn * 64 + 4 * hi);
     // output pixel (pixel tile 0, px = 0) of this lane, in elements; pixel tile mt adds 4 output rows, px adds one pixel
-    const uint32_t m0 = (uint32_t)((n_img * a.ho + 2 * (ty0 + 8 * wm + px_r) + wn) * a.wo + 2 * (tx0 + px_x));
+    const uint32_t m0 = (uint32_t)((n_img * a.ho + 2 * (ty0 + px_r) + wpy) * a.wo + 2 * (tx0 + px_x) + wpx);
     const uint32_t o0 = m0 * (uint32_t)a.cout + (uint32_t)(tn * 64);
     const uint32_t mt_stride = (uint32_t)(4 * a.wo * a.cout);
     // (activation, dropout mode) are wave-uniform: the whole epilogue is instantiated per pair and dispatched once
@@ -362,14 +353,12 @@ __global__ __launch_bounds__(256, 1) void conv_up_halo_kernel(ConvArgs a, int ti
             const float ca[8] = {ca0.x, ca0.y, ca0.z, ca0.w, ca1.x, ca1.y, ca1.z, ca1.w};
             const float cc[8] = {cc0.x, cc0.y, cc0.z, cc0.w, cc1.x, cc1.y, cc1.z, cc1.w};
 #pragma unroll
-            for (int px = 0; px < 2; ++px)
-#pragma unroll
                 for (int mt = 0; mt < 4; ++mt) {
-                    const uint32_t obase = o0 + mt * mt_stride + px * a.cout + cg0;
+                    const uint32_t obase = o0 + mt * mt_stride + cg0;
                     const uint32_t e0 = obase + 4 * hi;
                     float v[8];
 #pragma unroll
-                    for (int t = 0; t < 8; ++t) v[t] = fmaf(acc[px * 2 + (hg >> 1)][mt][8 * (hg & 1) + t], ca[t], cc[t]);
+                    for (int t = 0; t < 8; ++t) v[t] = fmaf(acc[hg >> 1][mt][8 * (hg & 1) + t], ca[t], cc[t]);
                     act_drop_fixed<4, ACT, MODE>(v, e0, a.drop, key);
                     act_drop_fixed<4, ACT, MODE>(v + 4, e0 + 8, a.drop, key);
                     uint32_t p0 = pack_bf16x2(v[0], v[1]), p1 = pack_bf16x2(v[2], v[3]);
@@ -420,7 +409,7 @@ void pack_up2x_frag(const bf16_t* wpk_up, int cout, int cin, bf16_t* out) {
 bool conv_up_halo_supported(const ConvArgs& a) {
     if (!a.up2x || a.wpk_up_frag == nullptr || a.out_bf16 == nullptr || a.residual != nullptr) return false;
     if (!(a.c0 > 0 && a.c0 % 64 == 0 && (a.c1 == 0 || a.c1 == a.c0) && a.cout % 64 == 0)) return false;
-    if (a.h % 16 != 0 || a.w % 16 != 0 || a.ho != 2 * a.h || a.wo != 2 * a.w) return false;
+    if (a.h % TILE_H != 0 || a.w % TILE_W != 0 || a.ho != 2 * a.h || a.wo != 2 * a.w) return false;
     const size_t npix = (size_t)a.n * a.h * a.w;
     return npix * a.c0 * 2 < 0x7F000000ull && (size_t)4 * a.cout * 16 * (a.c0 + a.c1) * 2 < 0x7F000000ull &&
            (size_t)a.n * a.ho * a.wo * a.cout < 0xFFFFFFF0ull;
@@ -431,7 +420,7 @@ hipError_t conv_up_halo_init() {
 }
 
 hipError_t launch_conv_up_halo(const ConvArgs& a, hipStream_t stream) {
-    const int tiles_x = a.w / 16, tiles_per_img = tiles_x * (a.h / 16);
+    const int tiles_x = a.w / TILE_W, tiles_per_img = tiles_x * (a.h / TILE_H);
     const int tiles_m = a.n * tiles_per_img, tiles_n = a.cout / 64;
     hipLaunchKernelGGL(conv_up_halo_kernel, dim3(tiles_m * tiles_n), dim3(256), LDS_TOTAL, stream, a, tiles_x, tiles_per_img,
                        tiles_m, tiles_n);
