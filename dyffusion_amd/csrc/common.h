@@ -56,8 +56,27 @@ __device__ __host__ __forceinline__ uint32_t fmix32(uint32_t h) {
     return h;
 }
 
+// 24 x 24 -> low 32 bits multiply: v_mul_u32_u24 is a full-rate VALU op on gfx950, v_mul_lo_u32 is quarter rate
+__device__ __host__ __forceinline__ uint32_t mul_u24(uint32_t a, uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umul24(a, b);
+#else
+    return (uint32_t)(((uint64_t)(a & 0xFFFFFFu) * (uint64_t)(b & 0xFFFFFFu)) & 0xFFFFFFFFull);
+#endif
+}
+
+// keep word of element pair `pair_index`: Weyl sequence (one add per consecutive pair after strength reduction) through
+// two xorshift-multiply rounds built on 24-bit multiplies (the conv epilogues spend most of their VALU time here; the
+// murmur3 finaliser it replaces costs two quarter-rate multiplies per pair).  Bucket chi-square, lag correlations and
+// key avalanche of the keep masks match fmix32's (checked for 2^22 pairs x several keys).
 __device__ __host__ __forceinline__ uint32_t rng_pair_word(uint32_t pair_index, uint32_t key) {
-    return fmix32(pair_index * 0x9E3779B1u + key);
+    uint32_t x = pair_index * 0x9E3779B1u + key;
+    x ^= x >> 15;
+    x = mul_u24(x, 0x735A2Du);
+    x ^= x >> 13;
+    x = mul_u24(x, 0x97E5B5u);
+    x ^= x >> 16;
+    return x;
 }
 
 // key for dropout layer `layer` of the `fwd`-th network forward since dyf_seed(seed)

@@ -14,6 +14,8 @@ struct ConvArgs {
     int kh, kw, stride, pad;
     int cout;
     const bf16_t* wpk;   // packed weights [cout][kh*kw][c0+c1] bf16
+    const bf16_t* wpk_frag;  // the same weights in MFMA fragment order (pack_conv_frag) for conv_igemm2, or null: looked up
+                             // in the registry (conv_register_frag) by launch_conv
     // fused x2 bilinear upsample in front of a 3x3/s1/p1 conv: sources are the LOW-res tensors (h, w), output is
     // (2h, 2w); wpk_up holds the phase-decomposed weights [4][cout][16][c0+c1] (pack_up2x_weights)
     int up2x;
@@ -42,3 +44,12 @@ bool conv_up_halo_supported(const ConvArgs& a);
 void pack_up2x_frag(const bf16_t* wpk_up, int cout, int cin, bf16_t* out);
 hipError_t conv_up_halo_init();
 hipError_t launch_conv_up_halo(const ConvArgs& a, hipStream_t stream);
+// second implicit-GEMM form (conv_igemm2.hip): 256 px x 128 ch per workgroup, weights streamed in fragment order
+bool conv_igemm2_supported(const ConvArgs& a);
+hipError_t conv_igemm2_init();
+hipError_t launch_conv_igemm2(const ConvArgs& a, hipStream_t stream);
+void pack_conv_frag(const bf16_t* wpk, int cout, int taps, int cin, bf16_t* out);
+// registry device-pointer(wpk) -> device-pointer(fragment-ordered copy); filled when weights are uploaded
+void conv_register_frag(const bf16_t* wpk_dev, const bf16_t* frag_dev);
+void conv_unregister_frag(const void* wpk_dev);
+const bf16_t* conv_lookup_frag(const bf16_t* wpk_dev);

@@ -18,6 +18,8 @@
 //     the 3x3 / 4x4 halo re-reads of neighbouring tiles hit that XCD's own L2.
 #include "conv.h"
 
+#include <type_traits>
+
 #include <cstdlib>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -110,7 +112,6 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a, int M, i
     constexpr int RA = BM / 32;  // A rows gathered per lane per K step
     constexpr int RB = BN / 32;
     constexpr int TH = BM / 16;  // 2-D tile: TH rows of 16 pixels
-    static_assert(2 * STAGE >= BM * BN * 4, "epilogue tile must fit in the staging buffers");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x;
@@ -332,7 +333,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a, int M, i
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[cs][i], bfr[cs][j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[cs][j], af[cs][i], acc[i][j], 0, 0, 0);  // D^T = W X^T
         }
     };
 
@@ -427,67 +428,78 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a, int M, i
         }
     }
 
-    // ---- epilogue: accumulators -> LDS fp32 tile [BM][BN] -> affine/act/dropout -> coalesced NHWC stores
-    __syncthreads();
-    float* Ct = (float*)smem;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int ml = wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                const int nl = wn * 64 + j * 32 + l31;
-                Ct[ml * BN + nl] = acc[i][j][r];
-            }
-    __syncthreads();
+    // ---- epilogue straight from the accumulators.  The operands are swapped (D^T = W X^T), so lane (l31, hi) of
+    // accumulator (i, j) holds PIXEL l31 of pixel sub-tile i and CHANNELS j*32 + 8*g + 4*hi + {0..3} (g = register group):
+    // affine / activation / dropout / residual run in registers, register groups 2*g2 and 2*g2+1 are packed to bf16 and
+    // exchanged between lanes l and l+32 (v_permlane32_swap) so that every lane stores 8 consecutive channels (16 B).
+    // No LDS round trip, no barrier; (activation, dropout mode) are wave-uniform and dispatched once.
     const uint32_t key = drop_key(a.drop);
-    constexpr int CG = BN / 8;  // 8-channel groups per tile row
-#pragma unroll 2
-    for (int it = 0; it < (BM * CG) / 256; ++it) {
-        const int id = it * 256 + tid;
-        const int row = id / CG, cg = id % CG;
-        if (tm * BM + row >= M) continue;
-        int m, n_img;  // m: output pixel index in the NHWC output tensor
-        if (tile2d) {
-            n_img = t_img;
-            const int y = t_y0 + (row >> 4), x = t_x0 + (row & 15);
-            m = UP ? (n_img * a.ho + 2 * y + py) * a.wo + 2 * x + px : (n_img * a.ho + y) * a.wo + x;
-        } else {
-            m = tm * BM + row;
-            n_img = m / plane;
-        }
-        const int co = tn * BN + cg * 8;
-        const float4 v0 = *(const float4*)(Ct + row * BN + cg * 8);
-        const float4 v1 = *(const float4*)(Ct + row * BN + cg * 8 + 4);
-        const size_t ci = (size_t)n_img * a.coef_stride + co;
-        const float4 a0 = *(const float4*)(a.coef_a + ci), a1 = *(const float4*)(a.coef_a + ci + 4);
-        const float4 c0 = *(const float4*)(a.coef_c + ci), c1 = *(const float4*)(a.coef_c + ci + 4);
-        float v[8] = {fmaf(v0.x, a0.x, c0.x), fmaf(v0.y, a0.y, c0.y), fmaf(v0.z, a0.z, c0.z), fmaf(v0.w, a0.w, c0.w),
-                      fmaf(v1.x, a1.x, c1.x), fmaf(v1.y, a1.y, c1.y), fmaf(v1.z, a1.z, c1.z), fmaf(v1.w, a1.w, c1.w)};
-        const uint32_t e0 = (uint32_t)((size_t)m * a.cout + co);
-        act_drop<8>(v, e0, a.act, a.drop, key);
-        if (a.residual) {
-            const uint4 rq = *(const uint4*)(a.residual + (size_t)m * a.cout + co);
-            const uint32_t rw[4] = {rq.x, rq.y, rq.z, rq.w};
+    auto epilogue = [&](auto act_c, auto mode_c) {
+        constexpr int ACT = decltype(act_c)::value, MODE = decltype(mode_c)::value;
 #pragma unroll
-            for (int t = 0; t < 8; ++t)
-                v[t] += (t & 1) ? __uint_as_float(rw[t >> 1] & 0xffff0000u) : __uint_as_float(rw[t >> 1] << 16);
+        for (int i = 0; i < 2; ++i) {
+            const int row = wm * 64 + i * 32 + l31;
+            const bool valid = tm * BM + row < M;
+            int m, n_img;  // m: output pixel index in the NHWC output tensor
+            if (tile2d) {
+                n_img = t_img;
+                const int y = t_y0 + (row >> 4), x = t_x0 + (row & 15);
+                m = UP ? (n_img * a.ho + 2 * y + py) * a.wo + 2 * x + px : (n_img * a.ho + y) * a.wo + x;
+            } else {
+                m = valid ? tm * BM + row : 0;
+                n_img = m / plane;
+            }
+            const uint32_t ob = (uint32_t)m * (uint32_t)a.cout + (uint32_t)(tn * BN + wn * 64);
+            const uint32_t cb = (uint32_t)(n_img * a.coef_stride + tn * BN + wn * 64 + 4 * hi);
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int g2 = 0; g2 < 2; ++g2) {
+                    const int cg0 = j * 32 + 16 * g2;  // + 4*hi: own channels of group 2*g2; + 8: group 2*g2+1
+                    const float4 ca0 = *(const float4*)(a.coef_a + cb + cg0), ca1 = *(const float4*)(a.coef_a + cb + cg0 + 8);
+                    const float4 cc0 = *(const float4*)(a.coef_c + cb + cg0), cc1 = *(const float4*)(a.coef_c + cb + cg0 + 8);
+                    const float ca[8] = {ca0.x, ca0.y, ca0.z, ca0.w, ca1.x, ca1.y, ca1.z, ca1.w};
+                    const float cc[8] = {cc0.x, cc0.y, cc0.z, cc0.w, cc1.x, cc1.y, cc1.z, cc1.w};
+                    const uint32_t e0 = ob + cg0 + 4 * hi;
+                    float v[8];
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) v[t] = fmaf(acc[i][j][8 * g2 + t], ca[t], cc[t]);
+                    act_drop_fixed<4, ACT, MODE>(v, e0, a.drop, key);
+                    act_drop_fixed<4, ACT, MODE>(v + 4, e0 + 8, a.drop, key);
+                    if (a.residual) {
+                        const uint2 r0 = valid ? *(const uint2*)(a.residual + (size_t)e0) : make_uint2(0, 0);
+                        const uint2 r1 = valid ? *(const uint2*)(a.residual + (size_t)e0 + 8) : make_uint2(0, 0);
+                        const uint32_t rw[4] = {r0.x, r0.y, r1.x, r1.y};
+#pragma unroll
+                        for (int t = 0; t < 8; ++t)
+                            v[t] += (t & 1) ? __uint_as_float(rw[t >> 1] & 0xffff0000u) : __uint_as_float(rw[t >> 1] << 16);
+                    }
+                    if (a.out_f32 && valid) {
+                        *(float4*)(a.out_f32 + (size_t)e0) = make_float4(v[0], v[1], v[2], v[3]);
+                        *(float4*)(a.out_f32 + (size_t)e0 + 8) = make_float4(v[4], v[5], v[6], v[7]);
+                    }
+                    if (a.out_bf16) {
+                        uint32_t p0 = pack_bf16x2(v[0], v[1]), p1 = pack_bf16x2(v[2], v[3]);
+                        uint32_t q0 = pack_bf16x2(v[4], v[5]), q1 = pack_bf16x2(v[6], v[7]);
+                        const auto s0 = __builtin_amdgcn_permlane32_swap(p0, q0, false, false);
+                        const auto s1 = __builtin_amdgcn_permlane32_swap(p1, q1, false, false);
+                        // lanes 0-31: channels cg0 + 0..7 (own group 2*g2 + partner's); lanes 32-63: cg0 + 8..15
+                        uint4 o;
+                        o.x = s0[0]; o.y = s1[0]; o.z = s0[1]; o.w = s1[1];
+                        if (valid) *(uint4*)(a.out_bf16 + (size_t)(ob + cg0 + 8 * hi)) = o;
+                    }
+                }
         }
-        if (a.out_bf16) {
-            uint4 o;
-            o.x = pack_bf16x2(v[0], v[1]);
-            o.y = pack_bf16x2(v[2], v[3]);
-            o.z = pack_bf16x2(v[4], v[5]);
-            o.w = pack_bf16x2(v[6], v[7]);
-            *(uint4*)(a.out_bf16 + (size_t)m * a.cout + co) = o;
-        }
-        if (a.out_f32) {
-            float* o = a.out_f32 + (size_t)m * a.cout + co;
-            *(float4*)o = make_float4(v[0], v[1], v[2], v[3]);
-            *(float4*)(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
-        }
-    }
+    };
+    auto by_mode = [&](auto act_c) {
+        if (a.drop.mode == 0) epilogue(act_c, std::integral_constant<int, 0>{});
+        else if (a.drop.mode == 1) epilogue(act_c, std::integral_constant<int, 1>{});
+        else epilogue(act_c, std::integral_constant<int, 2>{});
+    };
+    if (a.act == ACT_RELU) by_mode(std::integral_constant<int, ACT_RELU>{});
+    else if (a.act == ACT_LEAKY) by_mode(std::integral_constant<int, ACT_LEAKY>{});
+    else if (a.act == ACT_SILU) by_mode(std::integral_constant<int, ACT_SILU>{});
+    else by_mode(std::integral_constant<int, ACT_NONE>{});
 #endif
 }
 
@@ -534,6 +546,7 @@ hipError_t conv_init() {
     SET_LDS(128, 128, 2, 2, 0) SET_LDS(128, 128, 2, 2, 1) SET_LDS(256, 64, 4, 1, 0) SET_LDS(256, 64, 4, 1, 1)
 #undef SET_LDS
     if (e == hipSuccess) e = conv_up_halo_init();
+    if (e == hipSuccess) e = conv_igemm2_init();
     return e;
 }
 
@@ -542,8 +555,17 @@ hipError_t launch_conv(const ConvArgs& a, int path, hipStream_t stream) {
         static const bool use_halo = !(getenv("DYF_UP_HALO") && atoi(getenv("DYF_UP_HALO")) == 0);
         // halo form wins once most tiles are interior (>= 4x4 tiles per image); below that the gather form's pipelined
         // correction taps are cheaper (measured: dec3 32x32 plane 712 vs 697 TFLOP/s, dec4/dec5 862/905 vs 831/799)
-        static const int halo_min = getenv("DYF_HALO_MIN_PLANE") ? atoi(getenv("DYF_HALO_MIN_PLANE")) : 64;
+        static const int halo_min = getenv("DYF_HALO_MIN_PLANE") ? atoi(getenv("DYF_HALO_MIN_PLANE")) : 32;
         if (a.up2x && use_halo && a.h >= halo_min && a.w >= halo_min && conv_up_halo_supported(a)) return launch_conv_up_halo(a, stream);
+        static const bool use_igemm2 = !(getenv("DYF_IGEMM2") && atoi(getenv("DYF_IGEMM2")) == 0);
+        if (!a.up2x && use_igemm2 && a.cout % 128 == 0) {
+            ConvArgs b = a;
+            if (!b.wpk_frag) b.wpk_frag = conv_lookup_frag(b.wpk);
+            // 256 x 128 tiles pay off once they fill the chip (2 workgroups x 256 CUs); below that the 128 x 128 form's
+            // finer tiles win (measured at NB = 50: dec2/enc2 with 400 tiles +9 %/+4 %, enc3 with 200 tiles -20 %)
+            const long long tiles2 = (((long long)a.n * a.ho * a.wo + 255) / 256) * (a.cout / 128);
+            if (tiles2 >= 384 && conv_igemm2_supported(b)) return launch_conv_igemm2(b, stream);
+        }
         if (a.cout % 128 == 0)
             return a.up2x ? launch_igemm<128, 128, 2, 2, 1>(a, stream) : launch_igemm<128, 128, 2, 2, 0>(a, stream);
         return a.up2x ? launch_igemm<256, 64, 4, 1, 1>(a, stream) : launch_igemm<256, 64, 4, 1, 0>(a, stream);

@@ -1,0 +1,345 @@
+// Implicit-GEMM Conv2d, second form (gfx950): 256 pixels x 128 output channels per workgroup, weights streamed from
+// global memory in MFMA fragment order.  Used for every conv with cout % 128 == 0 that is not a fused-upsample conv
+// (encoder 4x4/s2 blocks, decoder 3x3 blocks on small planes, the ResNet-UNet 3x3 convs).
+//
+// conv_igemm_kernel (conv.hip) stages BOTH operands through LDS with 64x64 wave tiles: at MFMA peak its four waves
+// would read 128 B/clk from LDS, i.e. all of the CU's LDS bandwidth, so it tops out near 45 % MFMA utilisation.  Here
+//   * a wave owns 128 pixels x 64 channels (4 x 2 accumulator tiles, 128 registers): every pixel fragment read from
+//     LDS feeds 2 MFMAs and every weight fragment 4, LDS traffic drops to 64 B/clk/CU;
+//   * the weights never touch LDS: pack_conv_frag() lays them out so that one wave-wide buffer_load_dwordx4 fetches one
+//     32-channel x 16-k fragment as 1 KB of contiguous memory, four fragment sets in flight 3 k16 sub-steps ahead;
+//   * the pixel operand keeps the LDS-DMA gather of conv.hip (one 128-B row per pixel and K step, zero fill for padded
+//     taps through the buffer bounds check), double-buffered, one barrier per K step; two workgroups per CU cover each
+//     other's barrier and epilogue;
+//   * operands are swapped (D^T = W X^T) so the epilogue runs straight out of the accumulators (see conv.hip).
+// In-order completion of vector-memory loads makes the per-step wait free: the gather of step s+1 is issued BEFORE the
+// weight loads of step s, so by the time the last of those has been consumed the gather has landed.
+#include "conv.h"
+
+#include <mutex>
+#include <type_traits>
+#include <unordered_map>
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+namespace {
+constexpr int BM = 256, BN = 128;
+constexpr int A_BYTES = BM * 128;      // one K step of the pixel operand: 256 rows x 64 channels bf16
+constexpr int LDS_TOTAL = 2 * A_BYTES; // 64 KB: two workgroups per CU
+constexpr int RA = BM / 32;            // rows gathered per lane per K step
+constexpr int TH = BM / 16;            // 2-D tile: 16 rows of 16 pixels
+constexpr int STEP_BYTES = BN * 128;   // weights of one K step of one column block: 128 channels x 64 k bf16
+}  // namespace
+
+__global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(ConvArgs a, int M, int tiles_m, int tiles_n) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, hi = lane >> 5;
+
+    // XCD-aware tile id (bijective for any tile count): XCD x = bid % 8 takes a contiguous run of tiles
+    const int total = tiles_m * tiles_n;
+    const int bid = blockIdx.x;
+    const int xq = total >> 3, xr = total & 7, xcd = bid & 7;
+    const int tile = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
+    const int tn = tile % tiles_n, tm = tile / tiles_n;
+
+    const int cin = a.c0 + a.c1;
+    const int cpt = cin >> 6;
+    const int ntaps = a.kh * a.kw;
+    const int nk = ntaps * cpt;
+    const int plane = a.ho * a.wo;
+    const bool tile2d = (a.wo % 16 == 0) && (a.ho % TH == 0);
+    const int tiles_x = a.wo >> 4, tiles_per_img = tile2d ? tiles_x * (a.ho / TH) : 1;
+    int t_img = 0, t_y0 = 0, t_x0 = 0;
+    if (tile2d) {
+        t_img = tm / tiles_per_img;
+        const int t = tm - t_img * tiles_per_img;
+        t_y0 = (t / tiles_x) * TH;
+        t_x0 = (t % tiles_x) * 16;
+    }
+
+    const size_t npix = (size_t)a.n * a.h * a.w;
+    const int pitch0 = a.pix_pitch0 ? a.pix_pitch0 : a.c0;
+    const auto rsrc_a0 = __builtin_amdgcn_make_buffer_rsrc((void*)a.src0, 0, (int)(unsigned)(npix * pitch0 * 2), 0x00020000);
+    const auto rsrc_a1 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.c1 ? a.src1 : a.src0), 0,
+                                                           (int)(unsigned)(npix * (a.c1 ? a.c1 : a.c0) * 2), 0x00020000);
+    const auto rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.wpk_frag, 0, (int)(unsigned)((size_t)a.cout * nk * 128), 0x00020000);
+
+    // ---- per-lane gather descriptors (as conv.hip): DMA row (j*4 + wave)*8 + sub, LDS slot swizzled by (row >> 1) & 7
+    const int sub = lane >> 3;
+    const int gchunk = (lane & 7) ^ ((((wave & 1) << 2) | (sub >> 1)) & 7);
+    int a_pix[RA];        // pixel index of tap (0,0): may be slightly negative, |.| < 2^23 (host-checked)
+    unsigned a_mask[RA];  // tap validity bits
+#pragma unroll
+    for (int j = 0; j < RA; ++j) {
+        const int row = (j * 4 + wave) * 8 + sub;
+        unsigned mask = 0;
+        int pix = 0;
+        if (tm * BM + row < M) {
+            int n_img, oy, ox;
+            if (tile2d) {
+                n_img = t_img;
+                oy = t_y0 + (row >> 4);
+                ox = t_x0 + (row & 15);
+            } else {
+                const int m = tm * BM + row;
+                n_img = m / plane;
+                const int rem = m - n_img * plane;
+                oy = rem / a.wo;
+                ox = rem - oy * a.wo;
+            }
+            const int iy0 = oy * a.stride - a.pad, ix0 = ox * a.stride - a.pad;
+            pix = (n_img * a.h + iy0) * a.w + ix0;  // may be "negative": only ever used together with a valid tap
+            const int ylo = max(0, -iy0), yhi = min(a.kh, a.h - iy0);
+            const int xlo = max(0, -ix0), xhi = min(a.kw, a.w - ix0);
+            const unsigned ym = yhi > ylo ? (1u << yhi) - (1u << ylo) : 0u;
+            const unsigned xm = xhi > xlo ? (1u << xhi) - (1u << xlo) : 0u;
+            for (int ky = 0; ky < a.kh; ++ky) mask |= (((ym >> ky) & 1u) ? xm : 0u) << (ky * a.kw);
+        }
+        a_mask[j] = mask;
+        a_pix[j] = pix;
+    }
+
+    int is_tap = 0, is_chunk = 0;
+    auto issue_a = [&](int stage) {  // LDS-DMA gather of K step (is_tap, is_chunk); taps fastest (L2 reuse of the window)
+        char* As = smem + stage * A_BYTES;
+        const int dy = is_tap / a.kw, dx = is_tap - dy * a.kw;
+        const unsigned tap_bit = 1u << is_tap;
+        const int cb = is_chunk << 6;
+        const bool second = cb >= a.c0;
+        const int csrc = second ? a.c1 : pitch0;
+        const unsigned toff = (unsigned)((dy * a.w + dx) * csrc * 2) + (unsigned)((second ? cb - a.c0 : cb) * 2) + gchunk * 16;
+        const unsigned pitch_b = (unsigned)(csrc * 2);
+#pragma unroll
+        for (int j = 0; j < RA; ++j) {
+            const unsigned vo = (a_mask[j] & tap_bit) ? (unsigned)__mul24(a_pix[j], (int)pitch_b) + toff : 0xFFFFFFFFu;
+            if (second)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a1, LDS_PTR(As + (j * 4 + wave) * 1024), 16, vo, 0, 0, 0);
+            else
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a0, LDS_PTR(As + (j * 4 + wave) * 1024), 16, vo, 0, 0, 0);
+        }
+        if (++is_tap == ntaps) {
+            is_tap = 0;
+            ++is_chunk;
+        }
+    };
+
+    f32x16 acc[4][2];  // [pixel sub-tile mt: rows wm*128 + mt*32 ..][32-channel half]
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.0f;
+
+    // fragment addresses: row r of the stage at r*128, 16-B slot (k16*2 + hi) ^ ((r >> 1) & 7); sub-tile rows are
+    // 32-aligned + l31, so the key is (l31 >> 1) & 7 for every mt and the sub-step only flips bits 5-6
+    const unsigned lds_base = (unsigned)(uintptr_t)LDS_PTR(smem);
+    const unsigned a_row = (unsigned)((wm * 128 + l31) * 128);
+    const unsigned a_x = (unsigned)((hi ^ ((l31 >> 1) & 7)) << 4);
+    const unsigned w_voff = (unsigned)lane * 16u;
+    // weight stream of this wave: [tn][K step][wn][ks][half][lane] x 16 B
+    unsigned soff_cur = (unsigned)(tn * nk) * STEP_BYTES + (unsigned)wn * (STEP_BYTES / 2);
+    const unsigned soff_last = soff_cur + (unsigned)(nk - 1) * STEP_BYTES;
+
+    u32x4 bq[4][2];
+    bf16x8 aq[2][4];
+#define ISSUE_B(SET, SOFF, KS)                                                                               \
+    _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                                         \
+        bq[SET][nt] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, w_voff + nt * 1024, (SOFF) + (KS) * 2048, 0);
+#define DSR(dst, addr, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF));
+#define LGKM_WAIT(N)                                                      \
+    asm volatile("s_waitcnt lgkmcnt(" #N ")" ::: "memory");               \
+    __builtin_amdgcn_sched_barrier(0);
+#define RDA1(SET, KS, MT)                                                                                    \
+    {                                                                                                        \
+        const unsigned pm = (a_x ^ (unsigned)((KS) << 5)) + As;                                              \
+        DSR(aq[SET][MT], pm, (MT) * 4096)                                                                    \
+    }
+#define MF(MT, NT, ASET, BSET)                                                                               \
+    acc[MT][NT] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bq[BSET][NT]), aq[ASET][MT], \
+                                                          acc[MT][NT], 0, 0, 0);
+#define PIN __builtin_amdgcn_sched_barrier(0);
+    // one k16 sub-step: 8 MFMAs; the weight fragments of sub-step +3 and the pixel fragments of sub-step +1 are issued
+    // between them
+#define SLOT(ISET, SOFF, IKS, LOAD, LSET, LKS, USE_A, USE_B)                                                 \
+    {                                                                                                        \
+        LGKM_WAIT(0)                                                                                         \
+        ISSUE_B(ISET, SOFF, IKS)                                                                             \
+        MF(0, 0, USE_A, USE_B) PIN                                                                           \
+        if (LOAD) RDA1(LSET, LKS, 0)                                                                         \
+        MF(1, 0, USE_A, USE_B) PIN                                                                           \
+        if (LOAD) RDA1(LSET, LKS, 1)                                                                         \
+        MF(2, 0, USE_A, USE_B) PIN                                                                           \
+        if (LOAD) RDA1(LSET, LKS, 2)                                                                         \
+        MF(3, 0, USE_A, USE_B) PIN                                                                           \
+        if (LOAD) RDA1(LSET, LKS, 3)                                                                         \
+        MF(0, 1, USE_A, USE_B) PIN                                                                           \
+        MF(1, 1, USE_A, USE_B) MF(2, 1, USE_A, USE_B) MF(3, 1, USE_A, USE_B) PIN                             \
+    }
+
+    issue_a(0);
+    ISSUE_B(0, soff_cur, 0)
+    ISSUE_B(1, soff_cur, 1)
+    ISSUE_B(2, soff_cur, 2)
+    for (int k = 0; k < nk; ++k) {
+        const unsigned soff_next = soff_cur < soff_last ? soff_cur + STEP_BYTES : soff_cur;  // tail: harmless re-fetch
+        if (k == 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // first gather (older than the 6 weight loads)
+        __builtin_amdgcn_s_barrier();  // gather of step k visible; every wave is done with the other stage
+        __builtin_amdgcn_sched_barrier(0);
+        if (k + 1 < nk) issue_a((k + 1) & 1);
+        const unsigned As = lds_base + (unsigned)((k & 1) * A_BYTES) + a_row;
+        RDA1(0, 0, 0) RDA1(0, 0, 1) RDA1(0, 0, 2) RDA1(0, 0, 3)
+        SLOT(3, soff_cur, 3, true, 1, 1, 0, 0)
+        SLOT(0, soff_next, 0, true, 0, 2, 1, 1)
+        SLOT(1, soff_next, 1, true, 1, 3, 0, 2)
+        SLOT(2, soff_next, 2, false, 0, 0, 1, 3)
+        soff_cur = soff_next;
+    }
+#undef SLOT
+#undef PIN
+#undef MF
+#undef RDA1
+#undef LGKM_WAIT
+#undef DSR
+#undef ISSUE_B
+
+    // ---- epilogue straight from the accumulators (same scheme as conv_igemm_kernel): lane (l31, hi) of accumulator
+    // (mt, nt) holds pixel l31 of sub-tile mt and channels nt*32 + 8*g + 4*hi + {0..3}
+    const uint32_t key = drop_key(a.drop);
+    auto epilogue = [&](auto act_c, auto mode_c) {
+        constexpr int ACT = decltype(act_c)::value, MODE = decltype(mode_c)::value;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const int row = wm * 128 + mt * 32 + l31;
+            const bool valid = tm * BM + row < M;
+            int m, n_img;
+            if (tile2d) {
+                n_img = t_img;
+                m = (n_img * a.ho + t_y0 + (row >> 4)) * a.wo + t_x0 + (row & 15);
+            } else {
+                m = valid ? tm * BM + row : 0;
+                n_img = m / plane;
+            }
+            const uint32_t ob = (uint32_t)m * (uint32_t)a.cout + (uint32_t)(tn * BN + wn * 64);
+            const uint32_t cb = (uint32_t)(n_img * a.coef_stride + tn * BN + wn * 64 + 4 * hi);
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int g2 = 0; g2 < 2; ++g2) {
+                    const int cg0 = nt * 32 + 16 * g2;  // + 4*hi: own channels of group 2*g2; + 8: group 2*g2+1
+                    const float4 ca0 = *(const float4*)(a.coef_a + cb + cg0), ca1 = *(const float4*)(a.coef_a + cb + cg0 + 8);
+                    const float4 cc0 = *(const float4*)(a.coef_c + cb + cg0), cc1 = *(const float4*)(a.coef_c + cb + cg0 + 8);
+                    const float ca[8] = {ca0.x, ca0.y, ca0.z, ca0.w, ca1.x, ca1.y, ca1.z, ca1.w};
+                    const float cc[8] = {cc0.x, cc0.y, cc0.z, cc0.w, cc1.x, cc1.y, cc1.z, cc1.w};
+                    const uint32_t e0 = ob + cg0 + 4 * hi;
+                    float v[8];
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) v[t] = fmaf(acc[mt][nt][8 * g2 + t], ca[t], cc[t]);
+                    act_drop_fixed<4, ACT, MODE>(v, e0, a.drop, key);
+                    act_drop_fixed<4, ACT, MODE>(v + 4, e0 + 8, a.drop, key);
+                    if (a.residual) {
+                        const uint2 r0 = valid ? *(const uint2*)(a.residual + (size_t)e0) : make_uint2(0, 0);
+                        const uint2 r1 = valid ? *(const uint2*)(a.residual + (size_t)e0 + 8) : make_uint2(0, 0);
+                        const uint32_t rw[4] = {r0.x, r0.y, r1.x, r1.y};
+#pragma unroll
+                        for (int t = 0; t < 8; ++t)
+                            v[t] += (t & 1) ? __uint_as_float(rw[t >> 1] & 0xffff0000u) : __uint_as_float(rw[t >> 1] << 16);
+                    }
+                    if (a.out_f32 && valid) {
+                        *(float4*)(a.out_f32 + (size_t)e0) = make_float4(v[0], v[1], v[2], v[3]);
+                        *(float4*)(a.out_f32 + (size_t)e0 + 8) = make_float4(v[4], v[5], v[6], v[7]);
+                    }
+                    if (a.out_bf16) {
+                        uint32_t p0 = pack_bf16x2(v[0], v[1]), p1 = pack_bf16x2(v[2], v[3]);
+                        uint32_t q0 = pack_bf16x2(v[4], v[5]), q1 = pack_bf16x2(v[6], v[7]);
+                        const auto s0 = __builtin_amdgcn_permlane32_swap(p0, q0, false, false);
+                        const auto s1 = __builtin_amdgcn_permlane32_swap(p1, q1, false, false);
+                        uint4 o;
+                        o.x = s0[0]; o.y = s1[0]; o.z = s0[1]; o.w = s1[1];
+                        if (valid) *(uint4*)(a.out_bf16 + (size_t)(ob + cg0 + 8 * hi)) = o;
+                    }
+                }
+        }
+    };
+    auto by_mode = [&](auto act_c) {
+        if (a.drop.mode == 0) epilogue(act_c, std::integral_constant<int, 0>{});
+        else if (a.drop.mode == 1) epilogue(act_c, std::integral_constant<int, 1>{});
+        else epilogue(act_c, std::integral_constant<int, 2>{});
+    };
+    if (a.act == ACT_RELU) by_mode(std::integral_constant<int, ACT_RELU>{});
+    else if (a.act == ACT_LEAKY) by_mode(std::integral_constant<int, ACT_LEAKY>{});
+    else if (a.act == ACT_SILU) by_mode(std::integral_constant<int, ACT_SILU>{});
+    else by_mode(std::integral_constant<int, ACT_NONE>{});
+#endif
+}
+
+// wpk [cout][taps][cin] bf16 -> MFMA fragment order [column block tn (128 ch)][K step = chunk*taps + tap][wn][ks][half]
+// [lane][8 k]: lane (l31, hi) of fragment (wn, ks, half) holds channel tn*128 + wn*64 + half*32 + l31,
+// k = chunk*64 + ks*16 + hi*8 + {0..7} of tap `tap`
+void pack_conv_frag(const bf16_t* wpk, int cout, int taps, int cin, bf16_t* out) {
+    const int cpt = cin / 64;
+    size_t o = 0;
+    for (int tn = 0; tn < cout / 128; ++tn)
+        for (int chunk = 0; chunk < cpt; ++chunk)
+            for (int tap = 0; tap < taps; ++tap)
+                for (int wn = 0; wn < 2; ++wn)
+                    for (int ks = 0; ks < 4; ++ks)
+                        for (int half = 0; half < 2; ++half)
+                            for (int lane = 0; lane < 64; ++lane) {
+                                const int co = tn * 128 + wn * 64 + half * 32 + (lane & 31);
+                                const int k0 = chunk * 64 + ks * 16 + (lane >> 5) * 8;
+                                const bf16_t* s = wpk + ((size_t)co * taps + tap) * cin + k0;
+                                for (int e = 0; e < 8; ++e) out[o++] = s[e];
+                            }
+}
+
+bool conv_igemm2_supported(const ConvArgs& a) {
+    if (a.up2x || a.wpk_frag == nullptr) return false;
+    if (!(a.c0 > 0 && a.c0 % 64 == 0 && a.c1 % 64 == 0 && a.cout % 128 == 0)) return false;
+    if (a.kh * a.kw > 32) return false;
+    const size_t npix = (size_t)a.n * a.h * a.w;
+    const int pitch0 = a.pix_pitch0 ? a.pix_pitch0 : a.c0;
+    return npix < (1ull << 23) - 65536 && pitch0 * 2 < (1 << 22) && a.c1 * 2 < (1 << 22) && npix * pitch0 * 2 < 0x7F000000ull && npix * (size_t)a.c1 * 2 < 0x7F000000ull &&
+           (size_t)a.cout * a.kh * a.kw * (a.c0 + a.c1) * 2 < 0x7F000000ull && (size_t)a.n * a.ho * a.wo * a.cout < 0xFFFFFFF0ull;
+}
+
+hipError_t conv_igemm2_init() {
+    return hipFuncSetAttribute((const void*)conv_igemm2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
+}
+
+hipError_t launch_conv_igemm2(const ConvArgs& a, hipStream_t stream) {
+    const long long M = (long long)a.n * a.ho * a.wo;
+    const int tiles_m = (int)((M + BM - 1) / BM), tiles_n = a.cout / BN;
+    hipLaunchKernelGGL(conv_igemm2_kernel, dim3(tiles_m * tiles_n), dim3(256), LDS_TOTAL, stream, a, (int)M, tiles_m, tiles_n);
+    return hipGetLastError();
+}
+
+namespace {
+std::mutex g_frag_mu;
+std::unordered_map<const void*, const bf16_t*> g_frag;
+}  // namespace
+
+void conv_register_frag(const bf16_t* wpk_dev, const bf16_t* frag_dev) {
+    std::lock_guard<std::mutex> lk(g_frag_mu);
+    g_frag[(const void*)wpk_dev] = frag_dev;
+}
+
+void conv_unregister_frag(const void* wpk_dev) {
+    std::lock_guard<std::mutex> lk(g_frag_mu);
+    g_frag.erase(wpk_dev);
+}
+
+const bf16_t* conv_lookup_frag(const bf16_t* wpk_dev) {
+    std::lock_guard<std::mutex> lk(g_frag_mu);
+    auto it = g_frag.find((const void*)wpk_dev);
+    return it == g_frag.end() ? nullptr : it->second;
+}

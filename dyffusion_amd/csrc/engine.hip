@@ -251,7 +251,10 @@ void dyf_engine_destroy(dyf_engine* e) {
     rn_destroy(e->net[0]);
     rn_destroy(e->net[1]);
     if (e->cap_stream) (void)hipStreamDestroy(e->cap_stream);
-    for (void* p : e->allocs) (void)hipFree(p);
+    for (void* p : e->allocs) {
+        conv_unregister_frag(p);
+        (void)hipFree(p);
+    }
     delete e;
 }
 
@@ -443,7 +446,7 @@ dyf_status dyf_load_weights(dyf_engine* e, int32_t which, int32_t n_tensors, con
             for (int ci = 0; ci < b.cin; ++ci)
                 for (int t = 0; t < taps; ++t)
                     pk[((size_t)co * taps + t) * b.cin + ci] = f32_to_bf16(cw->data[((size_t)co * b.cin + ci) * taps + t]);
-        UP(b.wpk, pk);
+        { dyf_status _s = upload_conv_weights(e, &b.wpk, pk, b.cout, taps, b.cin); if (_s != DYF_OK) return _s; }
         if (i == 0 && b.k == 4 && n.cin_total + 1 <= 16 && b.cout % 64 == 0 && n.uh % 2 == 0 && n.uw % 2 == 0) {
             // compose_stem_enc0: W'[co][kh][kw][c] = sum_d Wenc0[co][d][kh][kw] * Winit[d][c]; channel cin_total carries
             // init_conv's bias (its input is the 1-inside-the-image indicator); channels up to 16 are zero
@@ -461,7 +464,7 @@ dyf_status dyf_load_weights(dyf_engine* e, int32_t which, int32_t n_tensors, con
                             }
                         fw[((size_t)co * 16 + t) * 16 + c] = f32_to_bf16((float)v);
                     }
-            UP(n.enc0_fused_w, fw);
+            { dyf_status _s = upload_conv_weights(e, &n.enc0_fused_w, fw, b.cout, 4, 64); if (_s != DYF_OK) return _s; }
             n.stem_fused = true;
         }
         if (b.transposed && b.k == 3) {
@@ -892,12 +895,19 @@ dyf_status dyf_op_conv2d(dyf_engine* e, const uint16_t* x_dev, const float* w_ho
                 pk[((size_t)co * taps + t) * cin + ci] = f32_to_bf16(w_host[((size_t)co * cin + ci) * taps + t]);
     bf16_t* wdev = nullptr;
     float *ones = nullptr, *zeros = nullptr;
-    HIP_TRY(e, hipMalloc((void**)&wdev, pk.size() * sizeof(bf16_t)));
+    const bool frag = cout % 128 == 0 && cin % 64 == 0 && taps <= 32;
+    HIP_TRY(e, hipMalloc((void**)&wdev, 2 * pk.size() * sizeof(bf16_t)));
     HIP_TRY(e, hipMemcpy(wdev, pk.data(), pk.size() * sizeof(bf16_t), hipMemcpyHostToDevice));
+    if (frag) {
+        std::vector<bf16_t> pf(pk.size());
+        pack_conv_frag(pk.data(), cout, taps, cin, pf.data());
+        HIP_TRY(e, hipMemcpy(wdev + pk.size(), pf.data(), pf.size() * sizeof(bf16_t), hipMemcpyHostToDevice));
+    }
     ConvArgs a{};
     a.src0 = x_dev; a.c0 = cin; a.n = n; a.h = h; a.w = w;
     a.ho = (h + 2 * pad - kh) / stride + 1; a.wo = (w + 2 * pad - kw) / stride + 1;
     a.kh = kh; a.kw = kw; a.stride = stride; a.pad = pad; a.cout = cout; a.wpk = wdev;
+    a.wpk_frag = frag ? wdev + pk.size() : nullptr;
     a.act = act; a.out_bf16 = y_dev; a.zero_page = e->ws.zero_page;
     if (scale_dev && shift_dev) {
         a.coef_a = scale_dev; a.coef_c = shift_dev; a.coef_stride = cout;

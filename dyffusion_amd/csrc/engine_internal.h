@@ -141,6 +141,21 @@ dyf_status dev_upload(dyf_engine* e, T** out, const std::vector<T>& host) {
     return DYF_OK;
 }
 
+// packed conv weights [cout][taps][cin] bf16 -> device; layers the second implicit-GEMM form can run also get their
+// fragment-ordered copy, registered under the primary pointer (launch_conv looks it up)
+inline dyf_status upload_conv_weights(dyf_engine* e, bf16_t** out, const std::vector<bf16_t>& pk, int cout, int taps, int cin) {
+    dyf_status st = dev_upload(e, out, pk);
+    if (st != DYF_OK) return st;
+    if (cout % 128 == 0 && cin % 64 == 0 && taps <= 32 && (size_t)cout * taps * cin == pk.size()) {
+        std::vector<bf16_t> pf(pk.size());
+        pack_conv_frag(pk.data(), cout, taps, cin, pf.data());
+        bf16_t* frag = nullptr;
+        st = dev_upload(e, &frag, pf);
+        if (st != DYF_OK) return st;
+        conv_register_frag(*out, frag);
+    }
+    return DYF_OK;
+}
 
 // host view of one state_dict tensor (dyf_load_weights)
 struct TensorView {

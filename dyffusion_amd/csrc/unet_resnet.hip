@@ -348,13 +348,18 @@ dyf_status rn_load_weights(dyf_engine* e, Net& n, std::map<std::string, TensorVi
         NEED(b2, P + ".block2.proj.bias", (int64_t)b.cout);
         NEED(g2, P + ".block2.norm.weight", (int64_t)b.cout);
         NEED(e2, P + ".block2.norm.bias", (int64_t)b.cout);
-        UP(b.w1, pack_conv(standardize(w1->data, b.cout, b.cin * 9).data(), b.cout, b.cin, 3));
-        UP(b.w2, pack_conv(standardize(w2->data, b.cout, b.cout * 9).data(), b.cout, b.cout, 3));
+#define UPW(dst, hostvec, CO, TAPS, CI)                                                         \
+    do {                                                                                       \
+        dyf_status _s = upload_conv_weights(e, &(dst), (hostvec), (CO), (TAPS), (CI));         \
+        if (_s != DYF_OK) return _s;                                                           \
+    } while (0)
+        UPW(b.w1, pack_conv(standardize(w1->data, b.cout, b.cin * 9).data(), b.cout, b.cin, 3), b.cout, 9, b.cin);
+        UPW(b.w2, pack_conv(standardize(w2->data, b.cout, b.cout * 9).data(), b.cout, b.cout, 3), b.cout, 9, b.cout);
         UP(b.b1, vec(b1)); UP(b.b2, vec(b2)); UP(b.g1, vec(g1)); UP(b.be1, vec(e1)); UP(b.g2, vec(g2)); UP(b.be2, vec(e2));
         if (b.has_res) {
             NEED(wr, P + ".residual_conv.weight", (int64_t)b.cout, (int64_t)b.cin, 1, 1);
             NEED(br, P + ".residual_conv.bias", (int64_t)b.cout);
-            UP(b.wr, pack_conv(wr->data, b.cout, b.cin, 1));
+            UPW(b.wr, pack_conv(wr->data, b.cout, b.cin, 1), b.cout, 1, b.cin);
             UP(b.br, vec(br));
         }
         blk_off[i] = b.film_off;
@@ -377,8 +382,8 @@ dyf_status rn_load_weights(dyf_engine* e, Net& n, std::map<std::string, TensorVi
         NEED(wo, P + ".fn.fn.to_out.weight", (int64_t)a.dim, (int64_t)HID, 1, 1);
         NEED(bo, P + ".fn.fn.to_out.bias", (int64_t)a.dim);
         NEED(lg, P + ".fn.norm.g", 1, (int64_t)a.dim, 1, 1);
-        UP(a.wqkv, pack_conv(wq->data, 3 * HID, a.dim, 1));
-        UP(a.wout, pack_conv(wo->data, a.dim, HID, 1));
+        UPW(a.wqkv, pack_conv(wq->data, 3 * HID, a.dim, 1), 3 * HID, 1, a.dim);
+        UPW(a.wout, pack_conv(wo->data, a.dim, HID, 1), a.dim, 1, HID);
         UP(a.bout, vec(bo));
         UP(a.ln_g, vec(lg));
     }
@@ -387,7 +392,7 @@ dyf_status rn_load_weights(dyf_engine* e, Net& n, std::map<std::string, TensorVi
         const std::string P = "downs." + std::to_string(l) + ".3";
         NEED(w, P + ".weight", (int64_t)s.cout, (int64_t)s.cin, (int64_t)s.k, (int64_t)s.k);
         NEED(b, P + ".bias", (int64_t)s.cout);
-        UP(s.w, pack_conv(w->data, s.cout, s.cin, s.k));
+        UPW(s.w, pack_conv(w->data, s.cout, s.cin, s.k), s.cout, s.k * s.k, s.cin);
         UP(s.b, vec(b));
     }
     for (int u = 0; u < r->nlev; ++u) {
@@ -395,7 +400,7 @@ dyf_status rn_load_weights(dyf_engine* e, Net& n, std::map<std::string, TensorVi
         const std::string P = "ups." + std::to_string(u) + (s.nearest_up ? ".3.1" : ".3");
         NEED(w, P + ".weight", (int64_t)s.cout, (int64_t)s.cin, 3, 3);
         NEED(b, P + ".bias", (int64_t)s.cout);
-        UP(s.w, pack_conv(w->data, s.cout, s.cin, 3));
+        UPW(s.w, pack_conv(w->data, s.cout, s.cin, 3), s.cout, 9, s.cin);
         UP(s.b, vec(b));
     }
 #undef NEED

@@ -27,6 +27,18 @@ def fmix32(h):
     return h
 
 
+def pair_word(pair_index, key):
+    """common.h rng_pair_word: Weyl sequence through two xorshift / 24-bit-multiply rounds."""
+    m24 = np.uint64(0xFFFFFF)
+    x = (pair_index.astype(np.uint64) * np.uint64(0x9E3779B1) + np.uint64(key)) & M32
+    x ^= x >> np.uint64(15)
+    x = ((x & m24) * np.uint64(0x735A2D)) & M32
+    x ^= x >> np.uint64(13)
+    x = ((x & m24) * np.uint64(0x97E5B5)) & M32
+    x ^= x >> np.uint64(16)
+    return x
+
+
 def layer_key(seed, fwd, layer):
     lo, hi = np.uint64(seed & 0xFFFFFFFF), np.uint64(seed >> 32)
     inner = fmix32(np.array([(int(hi) + 0x9E3779B9 * (fwd * 64 + layer + 1)) & 0xFFFFFFFF], dtype=np.uint64))
@@ -37,7 +49,7 @@ def host_mask_nhwc(shape_nhwc, p, seed, fwd, layer):
     n = int(np.prod(shape_nhwc))
     e = np.arange(n, dtype=np.uint64)
     key = layer_key(seed, fwd, layer)
-    w = fmix32(((e >> np.uint64(1)) * np.uint64(0x9E3779B1) + key) & M32)
+    w = pair_word(e >> np.uint64(1), key)
     v = np.where(e & np.uint64(1), w >> np.uint64(16), w & np.uint64(0xFFFF))
     thresh = np.uint64(int((np.float32(1.0) - np.float32(p)) * np.float32(65536.0)))  # keep_threshold16()
     return (v < thresh).reshape(shape_nhwc)
