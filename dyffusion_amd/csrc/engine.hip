@@ -188,16 +188,27 @@ dyf_status net_forward(dyf_engine* e, int which, const Source* srcs, int nsrc, i
         ConvArgs f = a;
         f.src0 = x; f.c0 = b.cin - skip_c; f.src1 = skip; f.c1 = skip_c; f.h = lh; f.w = lw;
         f.up2x = 1; f.wpk_up = b.wpk_up; f.wpk_up_frag = b.wpk_up_frag;
+        const bool prof = e->prof_layer == i && e->prof_ev.size() < 4096;
+        hipEvent_t pe0 = nullptr, pe1 = nullptr;
+        if (prof) {  // dyf_time_layer_in_rollout: HIP events around this block's conv, on the launch stream
+            HIP_TRY(e, hipEventCreate(&pe0));
+            HIP_TRY(e, hipEventCreate(&pe1));
+        }
         if (use_fused_up(e, b, f)) {
+            if (prof) HIP_TRY(e, hipEventRecord(pe0, st));
             HIP_TRY(e, launch_conv(f, 1, st));
+            if (prof) HIP_TRY(e, hipEventRecord(pe1, st));
         } else {  // materialise the upsampled tensor, then a plain conv
             Up2xArgs u{};
             u.src0 = x; u.c0 = b.cin - skip_c; u.src1 = skip; u.c1 = skip_c; u.n = nb; u.h = lh; u.w = lw; u.out = ws.up;
             HIP_TRY(e, launch_up2x(u, st));
             a.src0 = ws.up; a.c0 = b.cin; a.src1 = nullptr; a.c1 = 0;
+            if (prof) HIP_TRY(e, hipEventRecord(pe0, st));
             dyf_status s = run_conv(e, a, st);
             if (s != DYF_OK) return s;
+            if (prof) HIP_TRY(e, hipEventRecord(pe1, st));
         }
+        if (prof) e->prof_ev.emplace_back(pe0, pe1);
         x = ws.dec[i - 6];
         lh = b.out_h; lw = b.out_w;
         if (i < 11) {
@@ -875,6 +886,36 @@ dyf_status dyf_time_conv_layer(dyf_engine* e, int32_t which, int32_t layer, int3
         const double in_px = a.up2x ? (double)a.h * a.w : (double)b.in_h * b.in_w;
         *algo_bytes = 2.0 * ((double)nb * in_px * b.cin + M * b.cout + (double)b.cout * b.cin * b.k * b.k);
     }
+    return DYF_OK;
+}
+
+dyf_status dyf_time_layer_in_rollout(dyf_engine* e, int32_t layer, int32_t nb, void* stream, double* avg_ms,
+                                     int32_t* launches) {
+    if (!e || layer < 6 || layer > 11 || !avg_ms) return fail(e, DYF_ERR_INVALID_ARGUMENT, "decoder layer 6..11 expected");
+    if (!e->plan.set || !e->s_init) return fail(e, DYF_ERR_STATE, "needs a plan and one earlier dyf_sample call (its inputs are re-used)");
+    if (e->net[0].rn || e->net[1].rn) return fail(e, DYF_ERR_UNSUPPORTED, "arch unet_simple only");
+    if (nb < 1 || nb > e->cfg.max_batch) return fail(e, DYF_ERR_INVALID_ARGUMENT, "batch size outside [1, max_batch]");
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    hipStream_t st = (hipStream_t)stream;
+    e->prof_layer = layer;
+    e->prof_ev.clear();
+    dyf_status r = run_plan(e, nb, nullptr, nullptr, st);  // eager launch of the whole rollout, not the captured graph
+    e->prof_layer = -1;
+    hipError_t se = hipStreamSynchronize(st);
+    double tot = 0.0;
+    for (auto& pr : e->prof_ev) {
+        float ms = 0.0f;
+        if (se == hipSuccess && hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) tot += ms;
+        (void)hipEventDestroy(pr.first);
+        (void)hipEventDestroy(pr.second);
+    }
+    const size_t cnt = e->prof_ev.size();
+    e->prof_ev.clear();
+    if (r != DYF_OK) return r;
+    if (se != hipSuccess) return fail(e, DYF_ERR_HIP, std::string("rollout: ") + hipGetErrorString(se));
+    if (cnt == 0) return fail(e, DYF_ERR_STATE, "layer was not launched");
+    *avg_ms = tot / (double)cnt;
+    if (launches) *launches = (int32_t)cnt;
     return DYF_OK;
 }
 

@@ -105,6 +105,9 @@ struct dyf_engine {
     bool fuse_stem = true;             // DYF_FUSE_STEM=0: separate 1x1 stem kernel + plain enc0
     bool fuse_up2x = true;             // DYF_FUSE_UP2X=0 falls back to the materialised upsample (A/B testing)
     hipStream_t cap_stream = nullptr;  // capture never runs on the caller's (possibly legacy default) stream
+    // dyf_time_layer_in_rollout: events recorded around the conv of block prof_layer while a rollout runs eagerly
+    int prof_layer = -1;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_ev;
 };
 
 namespace dyf {

@@ -206,6 +206,12 @@ class HipEngine:
                                                   C.byref(fl), C.byref(by)))
         return ms.value, fl.value, by.value
 
+    def time_layer_in_rollout(self, layer: int, nb: int):
+        """(average ms, launches) of decoder block `layer`'s conv over one eagerly launched rollout of the current plan."""
+        ms, cnt = C.c_double(), C.c_int32()
+        self._check(self._lib.dyf_time_layer_in_rollout(self._h, layer, nb, self._stream(), C.byref(ms), C.byref(cnt)))
+        return ms.value, cnt.value
+
     def op_conv2d(self, x_nhwc_bf16: torch.Tensor, weight: torch.Tensor, stride: int, pad: int,
                   scale: Optional[torch.Tensor] = None, shift: Optional[torch.Tensor] = None, act: int = 0,
                   path: int = 1) -> torch.Tensor:

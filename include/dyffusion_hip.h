@@ -153,6 +153,12 @@ dyf_status dyf_net_flops(const dyf_engine* engine, int32_t net, double* flops_pe
 dyf_status dyf_time_conv_layer(dyf_engine* engine, int32_t net, int32_t layer, int32_t nb, int32_t iters,
                                void* stream, double* avg_ms, double* flops, double* algorithmic_bytes);
 
+/* Benchmark introspection: average duration (HIP events on `stream`) of the conv launch of decoder block `layer` (6..11)
+ * over ONE eagerly launched rollout of the current plan (all forecaster + interpolator forwards, MC dropout as configured),
+ * re-using the inputs of the last dyf_sample call.  `launches` receives the number of launches averaged. */
+dyf_status dyf_time_layer_in_rollout(dyf_engine* engine, int32_t layer, int32_t nb, void* stream, double* avg_ms,
+                                     int32_t* launches);
+
 /* ---- op-level seam (tests only): one Conv2d + fused epilogue on NHWC bf16 tensors ---------------------------- */
 /* x_dev (N,H,W,Cin) bf16 bits; w (Cout,Cin,kh,kw) host fp32; scale/shift (N,Cout) device fp32 or NULL;
  * y_dev (N,Ho,Wo,Cout) bf16 bits.  act: 0 none, 1 relu, 2 leaky(0.2).  path: 0 direct, 1 MFMA implicit GEMM. */
