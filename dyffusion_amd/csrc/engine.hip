@@ -889,6 +889,28 @@ dyf_status dyf_time_conv_layer(dyf_engine* e, int32_t which, int32_t layer, int3
     return DYF_OK;
 }
 
+dyf_status dyf_ensemble_metrics(dyf_engine* e, const float* preds_dev, const float* targets_dev, int32_t n_members,
+                                int64_t n_points, double* out_host, void* stream) {
+    if (!e || !preds_dev || !targets_dev || !out_host) return fail(e, DYF_ERR_INVALID_ARGUMENT, "null argument");
+    if (n_members < 1 || n_members > 64) return fail(e, DYF_ERR_INVALID_ARGUMENT, "n_members outside [1, 64]");
+    if (n_points < 1) return fail(e, DYF_ERR_INVALID_ARGUMENT, "n_points must be positive");
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    hipStream_t st = (hipStream_t)stream;
+    if (!e->metric_sums) {
+        dyf_status s = dev_alloc(e, &e->metric_sums, 4);
+        if (s != DYF_OK) return s;
+    }
+    HIP_TRY(e, launch_ensemble_metrics(preds_dev, targets_dev, n_members, n_points, e->metric_sums, st));
+    double h[3];
+    HIP_TRY(e, hipMemcpyAsync(h, e->metric_sums, sizeof(h), hipMemcpyDeviceToHost, st));
+    HIP_TRY(e, hipStreamSynchronize(st));
+    const double mse = h[0] / (double)n_points;
+    out_host[0] = mse;
+    out_host[1] = std::sqrt(h[1] / (double)n_points) / std::sqrt(mse);
+    out_host[2] = h[2] / (double)n_points;
+    return DYF_OK;
+}
+
 dyf_status dyf_time_layer_in_rollout(dyf_engine* e, int32_t layer, int32_t nb, void* stream, double* avg_ms,
                                      int32_t* launches) {
     if (!e || layer < 6 || layer > 11 || !avg_ms) return fail(e, DYF_ERR_INVALID_ARGUMENT, "decoder layer 6..11 expected");

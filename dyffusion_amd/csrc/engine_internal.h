@@ -106,6 +106,7 @@ struct dyf_engine {
     bool fuse_up2x = true;             // DYF_FUSE_UP2X=0 falls back to the materialised upsample (A/B testing)
     hipStream_t cap_stream = nullptr;  // capture never runs on the caller's (possibly legacy default) stream
     // dyf_time_layer_in_rollout: events recorded around the conv of block prof_layer while a rollout runs eagerly
+    double* metric_sums = nullptr;  // dyf_ensemble_metrics accumulators (device)
     int prof_layer = -1;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_ev;
 };

@@ -649,3 +649,65 @@ hipError_t launch_fill_f32(float* p, float v, long long count, hipStream_t s) {
     hipLaunchKernelGGL(fill_f32_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, p, v, count);
     return hipGetLastError();
 }
+
+// ------------------------------------------------------------------------------------------------ ensemble metrics
+// On-device form of src/utilities/evaluation.py:10-118 (evaluate_ensemble_prediction): for every grid point p of the
+// (B, C, H, W) target the N ensemble members are reduced to
+//   (mean_n x_n - y)^2                     -> "mse" of the ensemble mean            (evaluation.py:43-45)
+//   var_n x_n  (population variance)       -> spread^2 of the spread-skill ratio    (evaluation.py:107-116)
+//   mean_n |x_n - y| - 1/(2 N^2) sum_{n,m} |x_n - x_m|  -> CRPS of the empirical ensemble CDF (xskillscore/properscoring
+//                                            crps_ensemble, evaluation.py:83-95)
+// and summed over points in fp64 (one atomic per wave and quantity).  HBM-bound: every prediction is read exactly once
+// (members staged in LDS, [N][256] floats); the O(N^2) pair term runs out of LDS.
+__global__ __launch_bounds__(256) void ensemble_metrics_kernel(const float* preds, const float* targets, int n_members,
+                                                               long long n_points, double* sums) {
+    extern __shared__ float xs[];  // [n_members][256]
+    const int tid = threadIdx.x;
+    const long long p = (long long)blockIdx.x * 256 + tid;
+    const bool live = p < n_points;
+    float se = 0.0f, var = 0.0f, crps = 0.0f;
+    if (live) {
+        const float y = targets[p];
+        float sum = 0.0f, sabs = 0.0f;
+        for (int n = 0; n < n_members; ++n) {
+            const float x = preds[(size_t)n * n_points + p];
+            xs[n * 256 + tid] = x;
+            sum += x;
+            sabs += fabsf(x - y);
+        }
+        const float inv = 1.0f / (float)n_members;
+        const float mean = sum * inv;
+        float m2 = 0.0f, pair = 0.0f;
+        for (int n = 0; n < n_members; ++n) {
+            const float x = xs[n * 256 + tid];
+            m2 += (x - mean) * (x - mean);
+            for (int m = n + 1; m < n_members; ++m) pair += fabsf(x - xs[m * 256 + tid]);
+        }
+        se = (mean - y) * (mean - y);
+        var = m2 * inv;
+        crps = sabs * inv - pair * inv * inv;  // sum over ordered pairs = 2 * pair; 0.5 * 2 * pair / N^2
+    }
+    // wave reduction in fp64, then one atomic per wave
+    double d0 = se, d1 = var, d2 = crps;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        d0 += __shfl_xor(d0, off, 64);
+        d1 += __shfl_xor(d1, off, 64);
+        d2 += __shfl_xor(d2, off, 64);
+    }
+    if ((tid & 63) == 0) {
+        atomicAdd(sums + 0, d0);
+        atomicAdd(sums + 1, d1);
+        atomicAdd(sums + 2, d2);
+    }
+}
+
+hipError_t launch_ensemble_metrics(const float* preds, const float* targets, int n_members, long long n_points, double* sums,
+                                   hipStream_t s) {
+    const size_t lds = (size_t)n_members * 256 * sizeof(float);
+    hipError_t e = hipMemsetAsync(sums, 0, 3 * sizeof(double), s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(ensemble_metrics_kernel, dim3((unsigned)((n_points + 255) / 256)), dim3(256), lds, s, preds, targets,
+                       n_members, n_points, sums);
+    return hipGetLastError();
+}

@@ -206,6 +206,18 @@ class HipEngine:
                                                   C.byref(fl), C.byref(by)))
         return ms.value, fl.value, by.value
 
+    def ensemble_metrics(self, preds: torch.Tensor, targets: torch.Tensor):
+        """preds (N, B, ...) fp32 on the GPU, targets (B, ...) -> (mse, ssr, crps) floats (dyf_ensemble_metrics)."""
+        n = preds.shape[0]
+        preds = preds.contiguous().float()
+        targets = targets.contiguous().float()
+        if preds.shape[1:] != targets.shape:
+            raise ValueError(f"predictions.shape[1:] ({tuple(preds.shape[1:])}) != targets.shape ({tuple(targets.shape)})")
+        out = (C.c_double * 3)()
+        self._check(self._lib.dyf_ensemble_metrics(self._h, preds.data_ptr(), targets.data_ptr(), n, targets.numel(), out,
+                                                   self._stream()))
+        return out[0], out[1], out[2]
+
     def time_layer_in_rollout(self, layer: int, nb: int):
         """(average ms, launches) of decoder block `layer`'s conv over one eagerly launched rollout of the current plan."""
         ms, cnt = C.c_double(), C.c_int32()

@@ -139,6 +139,14 @@ dyf_status dyf_sample(dyf_engine* engine, const float* initial_dev, const float*
                       int32_t nb, const uint8_t* const* masks_dev, const float* noise_dev, void* stream);
 /* Re-seed the engine's counter-based dropout / noise generator (stream position resets to 0). */
 dyf_status dyf_seed(dyf_engine* engine, uint64_t seed);
+
+/* On-device ensemble metrics, replaces evaluate_ensemble_prediction (src/utilities/evaluation.py:10-118) and the
+ * .cpu().numpy() round trip in front of it (_base_experiment.py:617-640).  preds_dev: (n_members, n_points) fp32 with
+ * n_points = B*C*H*W (the "(N, B, C, H, W)" ensemble stack of one horizon step), targets_dev: (n_points) fp32.
+ * out_host[3] receives {mse of the ensemble mean, spread-skill ratio sqrt(mean var)/sqrt(mse), CRPS}, all averaged over
+ * every point (mean_over_samples=True).  Synchronises `stream`. */
+dyf_status dyf_ensemble_metrics(dyf_engine* engine, const float* preds_dev, const float* targets_dev, int32_t n_members,
+                                int64_t n_points, double* out_host, void* stream);
 /* Copy the last forecaster prediction x0_hat (NB,C,H,W) of the most recent dyf_sample call: the first element of the
  * tuple DYffusion.sample_loop returns (dyffusion.py:424-426). */
 dyf_status dyf_get_last_x0hat(dyf_engine* engine, float* out_dev, int32_t nb, void* stream);

@@ -3,7 +3,8 @@
 Run once in the build container:  python tests/golden/make_golden.py
 The reference cannot travel to the GPU box; these small .npz/.json files (inputs + expected outputs of the
 reference's own code) are what pins the oracle (oracle/*.py), which in turn is the checker for the HIP path.
-Fixture kinds: G1 schedules.json, G3 net_*.npz, G4 sample_*.npz, G6 fullsize_checksums.json.
+Fixture kinds: G1 schedules.json, G3 net_*.npz, G4 sample_*.npz, G6 fullsize_checksums.json; metrics_*.npz
+(ensemble mse / spread-skill of src/utilities/evaluation.py).
 """
 import contextlib
 import json
@@ -323,8 +324,25 @@ def gen_fullsize():
     print("fullsize:", {k: (round(v["mean"], 5), round(v["std"], 5)) for k, v in res["rollout"].items()})
 
 
+def gen_metrics():
+    """Ensemble metrics (SURVEY 8f-3): outputs of the reference's own numpy functions (src/utilities/evaluation.py);
+    its CRPS goes through xskillscore/properscoring, absent here, so only mse / spread-skill are reference-generated."""
+    from src.utilities.evaluation import evaluate_ensemble_mse, evaluate_ensemble_spread_skill_ratio
+
+    rng = np.random.default_rng(17)
+    for name, (n, b, c, hh, ww) in {"a": (5, 3, 2, 7, 6), "b": (20, 2, 3, 13, 9), "c": (1, 4, 1, 5, 5)}.items():
+        truth = rng.normal(size=(b, c, hh, ww)).astype(np.float32)
+        preds = (truth[None] * 0.8 + rng.normal(scale=0.5 + 0.1 * n, size=(n, b, c, hh, ww))).astype(np.float32)
+        mse = float(evaluate_ensemble_mse(preds, truth))
+        ssr = float(evaluate_ensemble_spread_skill_ratio(preds, truth))
+        np.savez(os.path.join(HERE, f"metrics_{name}.npz"), preds=preds, targets=truth, mse=mse, ssr=ssr)
+        print(f"metrics_{name}: mse {mse:.6f} ssr {ssr:.6f}")
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["schedules", "nets", "resnet", "samples", "fullsize"]
+    which = sys.argv[1:] or ["schedules", "nets", "resnet", "samples", "fullsize", "metrics"]
+    if "metrics" in which:
+        gen_metrics()
     if "schedules" in which:
         gen_schedules()
     if "nets" in which:
