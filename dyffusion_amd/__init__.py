@@ -5,7 +5,8 @@ hot path fails loudly when that library is missing.
 """
 from .dyffusion import DYffusion  # noqa: F401
 from .engine import EngineError, HipEngine, net_config, resnet_net_config  # noqa: F401
-from .experiment import InterpolatorHandle, MultiHorizonForecastingDYffusion  # noqa: F401
+from .experiment import InterpolationExperiment, InterpolatorHandle, MultiHorizonForecastingDYffusion  # noqa: F401
+from . import checkpoint  # noqa: F401
 from . import metrics  # noqa: F401
 from .unet import Unet  # noqa: F401
 from .unet_simple import UNet  # noqa: F401

@@ -21,6 +21,79 @@ class InterpolatorHandle:
         return self.model.inference_dropout_scope(condition, context)
 
 
+class InterpolationExperiment(nn.Module):
+    """Stage-1 interpolator experiment, evaluation path (`src/experiment_types/interpolation.py:12-141`): the network is
+    asked for every intermediate step t = 1..h-1 given the first `window` frames and the last frame.  Also serves as the
+    `interpolator` argument of `DYffusion` (`.model`, `.window`, `.true_horizon`, `inference_dropout_scope`)."""
+
+    def __init__(self, model, horizon: int, window: int = 1, num_predictions: int = 1,
+                 stack_window_to_channel_dim: bool = True, enable_inference_dropout: bool = False):
+        super().__init__()
+        assert horizon >= 2, "horizon must be >=2 for interpolation experiments"
+        if not stack_window_to_channel_dim:
+            raise NotImplementedError("stack_window_to_channel_dim=False (no shipped config uses it)")
+        self.model = model
+        self.horizon = self.true_horizon = horizon
+        self.window = window
+        self.hparams = _AttrDict(num_predictions=num_predictions, stack_window_to_channel_dim=True,
+                                 enable_inference_dropout=enable_inference_dropout)
+
+    @property
+    def horizon_range(self):  # interpolation.py:22-27
+        return list(range(1, self.horizon))
+
+    def inference_dropout_scope(self, condition: bool, context=None):
+        return self.model.inference_dropout_scope(condition, context)
+
+    def get_ensemble_inputs(self, inputs_raw: Optional[Tensor], num_predictions: Optional[int] = None) -> Optional[Tensor]:
+        n = num_predictions or self.hparams.num_predictions
+        if inputs_raw is None or n <= 1:
+            return inputs_raw
+        return inputs_raw.unsqueeze(0).expand(n, *inputs_raw.shape).reshape(n * inputs_raw.shape[0], *inputs_raw.shape[1:])
+
+    def get_inputs_from_dynamics(self, dynamics: Tensor) -> Tensor:  # interpolation.py:128-141
+        assert dynamics.shape[1] == self.window + self.horizon, "dynamics must have shape (b, t, c, h, w)"
+        b = dynamics.shape[0]
+        past = dynamics[:, : self.window].reshape(b, -1, *dynamics.shape[-2:])  # "b window c lat lon -> b (window c) lat lon"
+        return torch.cat([past, dynamics[:, -1]], dim=1)
+
+    def get_evaluation_inputs(self, dynamics: Tensor) -> Tensor:
+        return self.get_ensemble_inputs(self.get_inputs_from_dynamics(dynamics))
+
+    # _base_experiment.py:315-379 with the interpolator as the model
+    @torch.no_grad()
+    def predict(self, inputs: Tensor, time: Tensor, num_predictions: Optional[int] = None,
+                reshape_ensemble_dim: bool = True, **kwargs) -> Dict[str, Tensor]:
+        n = num_predictions or self.hparams.num_predictions
+        with self.model.inference_dropout_scope(condition=bool(self.hparams.enable_inference_dropout)):
+            preds = self.model.predict_forward(inputs, time=time, **kwargs)
+        if reshape_ensemble_dim and n > 1 and preds.shape[0] > 1:
+            assert preds.shape[0] % n == 0
+            preds = preds.reshape(n, preds.shape[0] // n, *preds.shape[1:])
+        return {"preds": preds}
+
+    # interpolation.py:69-127: one network call per intermediate step; returns the predictions, the targets and the MSE
+    # of the (ensemble-mean) prediction per step and on average, computed on the GPU
+    @torch.no_grad()
+    def evaluation_step(self, batch: Dict[str, Any], split: str = "val") -> Dict[str, Any]:
+        dynamics = batch["dynamics"]
+        inputs = self.get_evaluation_inputs(dynamics)
+        extra = {k: self.get_ensemble_inputs(v) for k, v in batch.items() if k != "dynamics"}
+        out: Dict[str, Any] = {}
+        mses = []
+        for t_step in self.horizon_range:
+            targets = dynamics[:, self.window + t_step - 1]
+            time = torch.full((inputs.shape[0],), t_step, device=inputs.device, dtype=torch.long)
+            preds = self.predict(inputs, time=time, **extra)["preds"]
+            out[f"t{t_step}_preds"], out[f"t{t_step}_targets"] = preds, targets
+            mean = preds.mean(dim=0) if preds.dim() == targets.dim() + 1 else preds
+            mse = float(((mean - targets) ** 2).mean())
+            out[f"{split}/t{t_step}/ipol/mse"] = mse
+            mses.append(mse)
+        out[f"{split}/{self.horizon}h_avg/ipol/mse"] = float(sum(mses) / len(mses))
+        return out
+
+
 class MultiHorizonForecastingDYffusion(nn.Module):
     def __init__(self, model: DYffusion, num_predictions: int = 1, window: int = 1, horizon: Optional[int] = None):
         super().__init__()

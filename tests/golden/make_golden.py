@@ -339,10 +339,24 @@ def gen_metrics():
         print(f"metrics_{name}: mse {mse:.6f} ssr {ssr:.6f}")
 
 
+def gen_ckpt_keys():
+    """Parameter/buffer names + shapes of the reference's Lightning modules (what a .ckpt's state_dict holds)."""
+    mk = dict(dim=4, upsample_dims=[32, 32], with_time_emb=True, outer_sample_mode="bilinear", dropout=0.1)
+    exp, ipol = ref_import.build_reference_dyffusion(model_kwargs=mk, horizon=4)
+    out = {"model_kwargs": mk, "horizon": 4,
+           "forecasting": {k: list(v.shape) for k, v in exp.state_dict().items()},
+           "interpolation": {k: list(v.shape) for k, v in ipol.state_dict().items()}}
+    with open(os.path.join(HERE, "ckpt_keys.json"), "w") as f:
+        json.dump(out, f, indent=0)
+    print("ckpt_keys:", len(out["forecasting"]), len(out["interpolation"]))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["schedules", "nets", "resnet", "samples", "fullsize", "metrics"]
+    which = sys.argv[1:] or ["schedules", "nets", "resnet", "samples", "fullsize", "metrics", "ckpt"]
     if "metrics" in which:
         gen_metrics()
+    if "ckpt" in which:
+        gen_ckpt_keys()
     if "schedules" in which:
         gen_schedules()
     if "nets" in which:

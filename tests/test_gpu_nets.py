@@ -122,3 +122,33 @@ def test_fullsize_ns_forwards_match_reference_fields():
     eI = rel_rms(yI, fields["yI"])
     print("fullsize forward rel-rms F", eF, "I", eI)
     assert eF <= TOL and eI <= TOL
+
+
+def test_interpolation_experiment_evaluation_step_matches_oracle():
+    """Stage-1 interpolator evaluation (interpolation.py:69-127): t = 1..h-1 from (first frame, last frame), N members."""
+    import dyffusion_amd as D
+
+    h, C, n_cond, nb, N = 4, 2, 1, 2, 3
+    cfg = dict(dim=8, upsample_dims=[64, 64], outer_sample_mode="bilinear", with_time_emb=True, dropout=0.1, input_dropout=0.0)
+    P = oinit.seeded_state(oinit.unet_simple_param_shapes(8, 2 * C + n_cond, C), seed=5)
+    net = mirror_from_params(P, cfg, 2 * C, n_cond, C)
+    exp = D.InterpolationExperiment(net, horizon=h, num_predictions=N, enable_inference_dropout=False)
+    g = torch.Generator().manual_seed(8)
+    dyn = torch.randn(nb, h + 1, C, 19, 13, generator=g)
+    cond = torch.rand(nb, n_cond, 19, 13, generator=g)
+    out = exp.evaluation_step({"dynamics": dyn.to(DEV), "condition": cond.to(DEV)})
+    x = torch.cat([dyn[:, 0], dyn[:, -1]], 1)
+    mses = []
+    for t in range(1, h):
+        with torch.no_grad():
+            want = nets.unet_simple_forward(P, cfg, x, torch.full((nb,), float(t)), cond)
+        got = out[f"t{t}_preds"].cpu()
+        assert got.shape == (N, nb, C, 19, 13)
+        for n in range(N):  # dropout off: every member equals the deterministic forward
+            assert rel_rms(got[n], want) <= TOL
+        assert torch.equal(out[f"t{t}_targets"].cpu(), dyn[:, t])
+        mses.append(float(((want - dyn[:, t]) ** 2).mean()))
+        assert out[f"val/t{t}/ipol/mse"] == pytest.approx(mses[-1], rel=5e-2)
+    assert out[f"val/{h}h_avg/ipol/mse"] == pytest.approx(sum(mses) / len(mses), rel=5e-2)
+    # the same object drives DYffusion as its interpolator
+    assert exp.true_horizon == h and exp.window == 1 and exp.horizon_range == [1, 2, 3]
