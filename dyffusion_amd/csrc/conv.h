@@ -2,6 +2,8 @@
 #pragma once
 #include "common.h"
 
+#include <vector>
+
 struct ConvArgs {
     // input: channel-concatenation of up to two NHWC bf16 tensors (skip connections are never materialised)
     const bf16_t* src0;
@@ -21,6 +23,11 @@ struct ConvArgs {
     int up2x;
     const bf16_t* wpk_up;
     const bf16_t* wpk_up_frag;  // the same weights in MFMA fragment order (pack_up2x_frag) for the halo kernel, or null
+    // sparse output columns of the halo kernel (plan_up_sparse_columns): device lists [2][up_npad] of low-res columns per
+    // horizontal phase, halo origin per list tile; null = every column
+    const int16_t* up_cols;
+    const int16_t* up_cbase;
+    int up_ntiles, up_npad, up_nvalid0, up_nvalid1;
     // epilogue: v = acc * A[row*coef_stride + co] + C[row*coef_stride + co]; row = sample index (coef_stride may be 0
     // to broadcast one row); conv bias, eval-BatchNorm and FiLM (x*(scale+1)+shift) are all folded into A and C.
     const float* coef_a;
@@ -42,6 +49,8 @@ void pack_up2x_weights(const float* w, int cout, int cin, bf16_t* out);
 // halo form of the fused x2-upsample conv (conv_up_halo.hip): 16x16 low-res tile x 4 phases x 64 channels per workgroup
 bool conv_up_halo_supported(const ConvArgs& a);
 void pack_up2x_frag(const bf16_t* wpk_up, int cout, int cin, bf16_t* out);
+bool plan_up_sparse_columns(const std::vector<uint8_t>& needed, int w, std::vector<int16_t>& cols, std::vector<int16_t>& cbase,
+                            int& ntiles, int& nvalid0, int& nvalid1);
 hipError_t conv_up_halo_init();
 hipError_t launch_conv_up_halo(const ConvArgs& a, hipStream_t stream);
 // second implicit-GEMM form (conv_igemm2.hip): 256 px x 128 ch per workgroup, weights streamed in fragment order

@@ -21,7 +21,9 @@
 //     l+32 with v_permlane32_swap and stores 16 B per lane: no LDS round trip, no barrier.
 #include "conv.h"
 
+#include <algorithm>
 #include <type_traits>
+#include <vector>
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -31,23 +33,39 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
 namespace {
 
-constexpr int TILE_H = 8, TILE_W = 16;                  // low-res tile of a workgroup
-constexpr int HALO_W = 18, HALO_REAL = 180, HALO_PIX = 184;  // 10*18 = 180, padded to a multiple of 8 DMA rows
-constexpr int HALO_BYTES = HALO_PIX * 128;              // 23 552
-constexpr int ZERO_OFF = 2 * HALO_BYTES;                // 128 B of zeros (pixels masked out of a correction tap)
-constexpr int HOFF_OFF = ZERO_OFF + 512;                // per-thread halo source offsets [HALO_PER_WAVE][256]
-constexpr int HALO_PER_WAVE_C = 6;
-constexpr int LDS_TOTAL = HOFF_OFF + HALO_PER_WAVE_C * 1024;  // 53 760 B
-constexpr int HALO_INSTR = HALO_PIX / 8;                // 23 wave-level DMA instructions per halo
+constexpr int TILE_H = 8, TILE_W = 16;                  // low-res tile of a workgroup: 8 rows x 16 columns
 constexpr int NWAVES = 4;
-constexpr int HALO_PER_WAVE = (HALO_INSTR + NWAVES - 1) / NWAVES;  // 6
 constexpr int STEP_BYTES = 32768;                       // weights of one (tap, chunk) step: 256 columns x 64 k bf16
+
+// SP = 0: the 16 columns of a tile are contiguous (halo 10 x 18, double-buffered).
+// SP = 1: SPARSE COLUMNS -- the 16 columns of a tile are entries of a per-phase column list (ConvArgs::up_cols): only the
+// output columns a later kernel reads are computed.  The NS backbone resamples its 256-wide grid to 42 native columns
+// (unet_simple.py:195): the readout touches 104 of the 256 columns of the last decoder block, i.e. 52 of 128 low-res columns
+// per horizontal phase.  A list tile spans up to 40 low-res columns (halo 10 x 40 = 51 KB, single-buffered so that two
+// workgroups still fit a CU; the other workgroup covers the exposed halo swap).
+template <int SP>
+struct HaloCfg {
+    static constexpr int W = SP ? 40 : 18;              // halo width in pixels
+    static constexpr int REAL = 10 * W;
+    static constexpr int PIX = (REAL + 7) / 8 * 8;      // padded to a multiple of 8 DMA rows
+    static constexpr int BYTES = PIX * 128;             // 23 552 / 51 200
+    static constexpr int NBUF = SP ? 1 : 2;
+    static constexpr int ZERO_OFF = NBUF * BYTES;       // 128 B of zeros (pixels masked out of a correction tap)
+    static constexpr int HOFF_OFF = ZERO_OFF + 512;     // per-thread halo source offsets [PER_WAVE][256]
+    static constexpr int INSTR = PIX / 8;               // wave-level DMA instructions per halo: 23 / 50
+    static constexpr int PER_WAVE = (INSTR + NWAVES - 1) / NWAVES;
+    static constexpr int LDS_TOTAL = HOFF_OFF + PER_WAVE * 1024;  // 53 760 / 65 024 B
+};
 
 }  // namespace
 
+template <int SP>
 __global__ __launch_bounds__(256, 2) void conv_up_halo_kernel(ConvArgs a, int tiles_x, int tiles_per_img, int tiles_m,
                                                               int tiles_n) {
 #if defined(__HIP_DEVICE_COMPILE__)
+    using H = HaloCfg<SP>;
+    constexpr int HALO_W = H::W, HALO_REAL = H::REAL, HALO_BYTES = H::BYTES, ZERO_OFF = H::ZERO_OFF, HOFF_OFF = H::HOFF_OFF;
+    constexpr int HALO_INSTR = H::INSTR, HALO_PER_WAVE = H::PER_WAVE;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -63,13 +81,31 @@ __global__ __launch_bounds__(256, 2) void conv_up_halo_kernel(ConvArgs a, int ti
     const int tn = tile % tiles_n, tm = tile / tiles_n;
     const int n_img = tm / tiles_per_img;
     const int t_in = tm - n_img * tiles_per_img;
-    const int ty0 = (t_in / tiles_x) * TILE_H, tx0 = (t_in % tiles_x) * TILE_W;
+    const int ty0 = (t_in / tiles_x) * TILE_H;
+    const int lx = t_in % tiles_x;              // column tile: 16 contiguous columns, or 16 entries of the column lists
+    const int px_x = l31 & 15, px_r = l31 >> 4;
+    // low-res column of this lane's pixels and the column the halo starts at
+    int col, cbase;
+    bool lane_valid = true;
+    if (SP) {
+        cbase = a.up_cbase[lx];
+        const int entry = a.up_cols[wpx * a.up_npad + lx * 16 + px_x];  // bit 14: padding entry (computed, not stored)
+        col = entry & 0x3FFF;
+        lane_valid = (entry & 0x4000) == 0;
+    } else {
+        cbase = lx * TILE_W - 1;
+        col = lx * TILE_W + px_x;
+    }
 
     const int cin = a.c0 + a.c1;
     const int cpt = cin >> 6;
-    const bool has_top = ty0 == 0, has_bot = ty0 + TILE_H == a.h, has_left = tx0 == 0, has_right = tx0 + TILE_W == a.w;
-    const bool has_row = has_top || has_bot, has_col = has_left || has_right;
-    // tap list of this tile, 4 bits per entry: 0-8 stencil, 9-11 row correction, 12-14 column correction, 15 corner
+    // border corrections are per WAVE (a wave owns one output phase): the top/bottom row matters to phases py = 0 / 1, the
+    // left/right column to px = 0 / 1.  Waves only meet at the per-chunk barrier, so each runs its own tap list.
+    const bool has_top = ty0 == 0, has_bot = ty0 + TILE_H == a.h;
+    const bool m_left = col == 0, m_right = col == a.w - 1;
+    const bool has_row = wpy == 0 ? has_top : has_bot;
+    const bool has_col = (wpx == 0 ? __builtin_amdgcn_ballot_w64(m_left) : __builtin_amdgcn_ballot_w64(m_right)) != 0ull;
+    // tap list of this wave, 4 bits per entry: 0-8 stencil, 9-11 row correction, 12-14 column correction, 15 corner
     unsigned long long tap_list = 0x876543210ull;
     int ntaps = 9;
     if (has_row) { tap_list |= 0xBA9ull << (4 * ntaps); ntaps += 3; }
@@ -93,7 +129,7 @@ __global__ __launch_bounds__(256, 2) void conv_up_halo_kernel(ConvArgs a, int ti
         int hp = i * 8 + sub;
         if (hp > HALO_REAL - 1) hp = HALO_REAL - 1;  // padding slots re-read the last halo pixel
         const int hy = hp / HALO_W, hx = hp - hy * HALO_W;
-        const int y = min(max(ty0 - 1 + hy, 0), a.h - 1), x = min(max(tx0 - 1 + hx, 0), a.w - 1);  // replicate clamp
+        const int y = min(max(ty0 - 1 + hy, 0), a.h - 1), x = min(max(cbase + hx, 0), a.w - 1);  // replicate clamp
         const int gch = (lane & 7) ^ ((hp >> 1) & 7);  // swizzled source chunk of this linear LDS slot
         h_tab[j * 256] = (unsigned)((n_img * a.h + y) * a.w + x) * (unsigned)(a.c0 * 2) + gch * 16;  // c0 == c1 (checked on host)
     }
@@ -103,7 +139,7 @@ __global__ __launch_bounds__(256, 2) void conv_up_halo_kernel(ConvArgs a, int ti
         const int cb = chunk << 6;
         const bool second = cb >= a.c0;
         const unsigned coff = (unsigned)((second ? cb - a.c0 : cb) * 2);
-        char* dst = smem + (chunk & 1) * HALO_BYTES;
+        char* dst = smem + (H::NBUF == 2 ? (chunk & 1) * HALO_BYTES : 0);
 #pragma unroll
         for (int j = 0; j < HALO_PER_WAVE; ++j) {
             const int i = j * NWAVES + wave;
@@ -140,11 +176,9 @@ __global__ __launch_bounds__(256, 2) void conv_up_halo_kernel(ConvArgs a, int ti
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[nt][mt][r] = 0.0f;
 
-    const int px_x = l31 & 15, px_r = l31 >> 4;
-    int hp0 = (px_r + 1) * HALO_W + (px_x + 1);  // halo pixel of pixel tile 0 at the un-shifted tap; mt adds 36
-    const bool m_left = has_left && px_x == 0, m_right = has_right && px_x == 15;
-    const bool m_top = has_top && px_r == 0;   // pixel tile 0
-    const bool m_bot = has_bot && px_r == 1;   // pixel tile 3
+    int hp0 = (px_r + 1) * HALO_W + (col - cbase);  // halo pixel of pixel tile 0 at the un-shifted tap; mt adds 2 rows
+    const bool m_row = wpy == 0 ? px_r == 0 : px_r == 1;   // border row: pixel tile 0 (top) / 3 (bottom)
+    const bool m_col = wpx == 0 ? m_left : m_right;
     const unsigned lds_base = (unsigned)(uintptr_t)LDS_PTR(smem);
 
     u32x4 bq[4][2];   // weight fragments: set = k16 sub-step & 3
@@ -166,7 +200,7 @@ __global__ __launch_bounds__(256, 2) void conv_up_halo_kernel(ConvArgs a, int ti
         int hpb = hp0;                                                                                       \
         asm volatile("" : "+v"(hpb)); /* opaque: keeps 9 taps x 8 addresses from being hoisted and spilled */ \
         _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) {                                                   \
-            const int hpm = hpb + (DISP) + 36 * mt;                                                          \
+            const int hpm = hpb + (DISP) + 2 * HALO_W * mt;                                                  \
             ab[mt] = Hs + hpm * 128;                                                                         \
             ax[mt] = (unsigned)((hi ^ ((hpm >> 1) & 7)) << 4);                                               \
         }                                                                                                    \
@@ -221,7 +255,7 @@ __global__ __launch_bounds__(256, 2) void conv_up_halo_kernel(ConvArgs a, int ti
     // masked pixel fragment of tile MT at displacement DISP: lanes with KEEP false read the zero page
 #define RDA_MASKED(DST, MT, DISP, KS, KEEP)                                                                  \
     {                                                                                                        \
-        const int hpm = hp0 + 36 * (MT) + (DISP);                                                            \
+        const int hpm = hp0 + 2 * HALO_W * (MT) + (DISP);                                                    \
         const unsigned pm = (KEEP) ? Hs + hpm * 128 + ((((KS) * 2 + hi) ^ ((hpm >> 1) & 7)) << 4) : lds_base + ZERO_OFF; \
         DSR(DST, pm)                                                                                         \
     }
@@ -233,13 +267,21 @@ __global__ __launch_bounds__(256, 2) void conv_up_halo_kernel(ConvArgs a, int ti
     ISSUE_B(1, soff_cur, 1)
     ISSUE_B(2, soff_cur, 2)
     for (int chunk = 0; chunk < cpt; ++chunk) {
-        // halo of this chunk landed (everything older than the 12 weight loads in flight), every wave is done with the
-        // other buffer -> prefetch the next chunk's halo into it
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        if (chunk + 1 < cpt) issue_halo(chunk + 1);
-        const unsigned Hs = lds_base + (chunk & 1) * HALO_BYTES;
+        if (H::NBUF == 2) {
+            // halo of this chunk landed (everything older than the 6 weight loads in flight), every wave is done with the
+            // other buffer -> prefetch the next chunk's halo into it
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            if (chunk + 1 < cpt) issue_halo(chunk + 1);
+        } else {
+            // single buffer: the halo was requested after every wave left the previous chunk (barrier below); it is
+            // younger than the weight loads in flight, so wait for everything, then make it visible
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const unsigned Hs = lds_base + (H::NBUF == 2 ? (chunk & 1) * HALO_BYTES : 0);
         asm volatile("" : "+v"(hp0));  // keep the per-tap LDS addresses from being hoisted out of the chunk loop
         TAPADDR(-HALO_W - 1)
         RDA1(0, 0, 0) RDA1(0, 0, 1) RDA1(0, 0, 2) RDA1(0, 0, 3)
@@ -255,20 +297,19 @@ __global__ __launch_bounds__(256, 2) void conv_up_halo_kernel(ConvArgs a, int ti
         STENCIL_STEP(D_OF(7), true, D_OF(8))
         STENCIL_STEP(D_OF(8), false, 0)
 #undef D_OF
-        if (has_row) {  // taps 9-11: b = -1,0,+1 on the border row; top -> phase row py = 0 (waves wn = 0), pixel tile 0
-                        // of waves wm = 0; bottom -> py = 1, pixel tile 3 of waves wm = 1
+        if (has_row) {  // taps 9-11: b = -1,0,+1 on the border row: pixel tile 0 (top, py = 0) or 3 (bottom, py = 1)
 #define ROW_BODY_B(KS, BSET, B_)                                                             \
-            if (has_top && wpy == 0) {                                                       \
+            {                                                                                \
                 bf16x8 f;                                                                    \
-                RDA_MASKED(f, 0, (B_), KS, m_top)                                            \
-                LGKM_WAIT(0)                                                                 \
-                MFMA_ONE(0, 0, BSET, f) MFMA_ONE(1, 0, BSET, f)                              \
-            }                                                                                \
-            if (has_bot && wpy == 1) {                                                       \
-                bf16x8 f;                                                                    \
-                RDA_MASKED(f, 3, (B_), KS, m_bot)                                            \
-                LGKM_WAIT(0)                                                                 \
-                MFMA_ONE(0, 3, BSET, f) MFMA_ONE(1, 3, BSET, f)                              \
+                if (wpy == 0) {                                                              \
+                    RDA_MASKED(f, 0, (B_), KS, m_row)                                        \
+                    LGKM_WAIT(0)                                                             \
+                    MFMA_ONE(0, 0, BSET, f) MFMA_ONE(1, 0, BSET, f)                          \
+                } else {                                                                     \
+                    RDA_MASKED(f, 3, (B_), KS, m_row)                                        \
+                    LGKM_WAIT(0)                                                             \
+                    MFMA_ONE(0, 3, BSET, f) MFMA_ONE(1, 3, BSET, f)                          \
+                }                                                                            \
             }                                                                                \
             __builtin_amdgcn_sched_barrier(0);
 #define ROW_M1(KS, BSET) ROW_BODY_B(KS, BSET, -1)
@@ -280,12 +321,11 @@ __global__ __launch_bounds__(256, 2) void conv_up_halo_kernel(ConvArgs a, int ti
 #undef ROW_P1
 #undef ROW_BODY_B
         }
-        if (has_col) {  // taps 12-14: a = -1,0,+1 on the border column; left -> px = 0 (column tiles 0,1), right -> px = 1
+        if (has_col) {  // taps 12-14: a = -1,0,+1 on the border column (left for px = 0, right for px = 1)
 #define COL_BODY_A(KS, BSET, A_)                                                             \
-            if ((has_left && wpx == 0) || (has_right && wpx == 1)) {                         \
-                const bool keep = wpx == 0 ? m_left : m_right;                               \
+            {                                                                                \
                 bf16x8 f[4];                                                                 \
-                _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) RDA_MASKED(f[mt], mt, (A_) * HALO_W, KS, keep) \
+                _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) RDA_MASKED(f[mt], mt, (A_) * HALO_W, KS, m_col) \
                 LGKM_WAIT(0)                                                                 \
                 _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) { MFMA_ONE(0, mt, BSET, f[mt]) MFMA_ONE(1, mt, BSET, f[mt]) } \
             }                                                                                \
@@ -301,8 +341,8 @@ __global__ __launch_bounds__(256, 2) void conv_up_halo_kernel(ConvArgs a, int ti
         }
         if (has_row && has_col) {  // tap 15: the corner pixel, one phase per corner
 #define CORNER_BODY(KS, BSET)                                                                \
-            if (((has_top && wpy == 0) || (has_bot && wpy == 1)) && ((has_left && wpx == 0) || (has_right && wpx == 1))) { \
-                const bool keep = (wpy == 0 ? m_top : m_bot) && (wpx == 0 ? m_left : m_right); \
+            {                                                                                \
+                const bool keep = m_row && m_col;                                            \
                 bf16x8 f;                                                                    \
                 if (wpy == 0) {                                                              \
                     RDA_MASKED(f, 0, 0, KS, keep)                                            \
@@ -317,6 +357,11 @@ __global__ __launch_bounds__(256, 2) void conv_up_halo_kernel(ConvArgs a, int ti
             __builtin_amdgcn_sched_barrier(0);
             CORR_STEP(CORNER_BODY)
 #undef CORNER_BODY
+        }
+        if (H::NBUF == 1 && chunk + 1 < cpt) {  // single buffer: every wave is done reading -> request the next chunk's halo
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            issue_halo(chunk + 1);
         }
     }
 #undef MFMA_ONE
@@ -339,7 +384,7 @@ __global__ __launch_bounds__(256, 2) void conv_up_halo_kernel(ConvArgs a, int ti
     const uint32_t key = drop_key(a.drop);
     const uint32_t ci_base = (uint32_t)(n_img * a.coef_stride + tn * 64 + 4 * hi);
     // output pixel (pixel tile 0, px = 0) of this lane, in elements; pixel tile mt adds 4 output rows, px adds one pixel
-    const uint32_t m0 = (uint32_t)((n_img * a.ho + 2 * (ty0 + px_r) + wpy) * a.wo + 2 * (tx0 + px_x) + wpx);
+    const uint32_t m0 = (uint32_t)((n_img * a.ho + 2 * (ty0 + px_r) + wpy) * a.wo + 2 * col + wpx);
     const uint32_t o0 = m0 * (uint32_t)a.cout + (uint32_t)(tn * 64);
     const uint32_t mt_stride = (uint32_t)(4 * a.wo * a.cout);
     // (activation, dropout mode) are wave-uniform: the whole epilogue is instantiated per pair and dispatched once
@@ -369,7 +414,7 @@ __global__ __launch_bounds__(256, 2) void conv_up_halo_kernel(ConvArgs a, int ti
                     // lanes 32-63: {partner's group 2*g2+1, own group 2*g2+1} = channels cg0 + 8..15
                     uint4 o;
                     o.x = s0[0]; o.y = s1[0]; o.z = s0[1]; o.w = s1[1];
-                    *(uint4*)(a.out_bf16 + (size_t)(obase + 8 * hi)) = o;
+                    if (!SP || lane_valid) *(uint4*)(a.out_bf16 + (size_t)(obase + 8 * hi)) = o;
                 }
         }
     };
@@ -410,19 +455,70 @@ bool conv_up_halo_supported(const ConvArgs& a) {
     if (!a.up2x || a.wpk_up_frag == nullptr || a.out_bf16 == nullptr || a.residual != nullptr) return false;
     if (!(a.c0 > 0 && a.c0 % 64 == 0 && (a.c1 == 0 || a.c1 == a.c0) && a.cout % 64 == 0)) return false;
     if (a.h % TILE_H != 0 || a.w % TILE_W != 0 || a.ho != 2 * a.h || a.wo != 2 * a.w) return false;
+    if (a.up_cols && (a.up_cbase == nullptr || a.up_ntiles < 1 || a.up_npad != a.up_ntiles * 16)) return false;
     const size_t npix = (size_t)a.n * a.h * a.w;
     return npix * a.c0 * 2 < 0x7F000000ull && (size_t)4 * a.cout * 16 * (a.c0 + a.c1) * 2 < 0x7F000000ull &&
            (size_t)a.n * a.ho * a.wo * a.cout < 0xFFFFFFF0ull;
 }
 
 hipError_t conv_up_halo_init() {
-    return hipFuncSetAttribute((const void*)conv_up_halo_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
+    hipError_t e = hipFuncSetAttribute((const void*)conv_up_halo_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       HaloCfg<0>::LDS_TOTAL);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)conv_up_halo_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                HaloCfg<1>::LDS_TOTAL);
+    return e;
 }
 
 hipError_t launch_conv_up_halo(const ConvArgs& a, hipStream_t stream) {
-    const int tiles_x = a.w / TILE_W, tiles_per_img = tiles_x * (a.h / TILE_H);
+    const bool sparse = a.up_cols != nullptr;
+    const int tiles_x = sparse ? a.up_ntiles : a.w / TILE_W, tiles_per_img = tiles_x * (a.h / TILE_H);
     const int tiles_m = a.n * tiles_per_img, tiles_n = a.cout / 64;
-    hipLaunchKernelGGL(conv_up_halo_kernel, dim3(tiles_m * tiles_n), dim3(256), LDS_TOTAL, stream, a, tiles_x, tiles_per_img,
-                       tiles_m, tiles_n);
+    if (sparse)
+        hipLaunchKernelGGL(conv_up_halo_kernel<1>, dim3(tiles_m * tiles_n), dim3(256), HaloCfg<1>::LDS_TOTAL, stream, a, tiles_x,
+                           tiles_per_img, tiles_m, tiles_n);
+    else
+        hipLaunchKernelGGL(conv_up_halo_kernel<0>, dim3(tiles_m * tiles_n), dim3(256), HaloCfg<0>::LDS_TOTAL, stream, a, tiles_x,
+                           tiles_per_img, tiles_m, tiles_n);
     return hipGetLastError();
+}
+
+// Column lists of the sparse form: `needed[x]` (x in [0, 2w)) marks the OUTPUT columns somebody reads.  Per horizontal
+// phase px the low-res columns j with needed[2j + px] are listed and dealt evenly to ntiles list tiles of 16 slots (slots
+// past a tile's share repeat its last column with bit 14 set: computed, never stored).  cbase[t] = first halo column of
+// list tile t.  Returns false (dense form must be used) when a list tile does not fit the 40-column halo or the lists would
+// not save at least 20 % of the work.
+bool plan_up_sparse_columns(const std::vector<uint8_t>& needed, int w, std::vector<int16_t>& cols, std::vector<int16_t>& cbase,
+                            int& ntiles, int& nvalid0, int& nvalid1) {
+    std::vector<int> l[2];
+    for (int j = 0; j < w; ++j)
+        for (int px = 0; px < 2; ++px)
+            if (needed[2 * j + px]) l[px].push_back(j);
+    if (l[0].empty() || l[1].empty()) return false;
+    nvalid0 = (int)l[0].size();
+    nvalid1 = (int)l[1].size();
+    const int nmax = std::max(nvalid0, nvalid1);
+    ntiles = (nmax + 15) / 16;
+    if (ntiles * 16 * 5 > w * 4) return false;
+    const int per = (nmax + ntiles - 1) / ntiles;  // entries per tile, balanced
+    cols.assign((size_t)2 * ntiles * 16, 0);
+    cbase.assign(ntiles, 0);
+    for (int t = 0; t < ntiles; ++t) {
+        int lo = w, hi = -1;
+        for (int px = 0; px < 2; ++px) {
+            const int n = (int)l[px].size();
+            for (int i = 0; i < 16; ++i) {
+                const int k = t * per + i;
+                const bool real = i < per && k < n;
+                const int kk = std::min(std::min(k, t * per + per - 1), n - 1);
+                const int c = l[px][std::max(kk, 0)];
+                cols[(size_t)px * ntiles * 16 + t * 16 + i] = (int16_t)(c | (real ? 0 : 0x4000));
+                lo = std::min(lo, c);
+                hi = std::max(hi, c);
+            }
+        }
+        cbase[t] = (int16_t)(lo - 1);
+        if (hi - lo + 3 > HaloCfg<1>::W) return false;
+    }
+    return true;
 }

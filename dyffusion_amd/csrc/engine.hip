@@ -188,6 +188,13 @@ dyf_status net_forward(dyf_engine* e, int which, const Source* srcs, int nsrc, i
         ConvArgs f = a;
         f.src0 = x; f.c0 = b.cin - skip_c; f.src1 = skip; f.c1 = skip_c; f.h = lh; f.w = lw;
         f.up2x = 1; f.wpk_up = b.wpk_up; f.wpk_up_frag = b.wpk_up_frag;
+        f.up_cols = b.up_cols; f.up_cbase = b.up_cbase; f.up_ntiles = b.up_ntiles; f.up_npad = b.up_npad;
+        f.up_nvalid0 = b.up_nvalid0; f.up_nvalid1 = b.up_nvalid1;
+        if (i == 11 && b.up_cols) {  // test hook: poison the output so that a needed-but-unwritten pixel of the sparse form shows
+            const char* pz = getenv("DYF_POISON_DEC5");
+            if (pz && atoi(pz) != 0)
+                HIP_TRY(e, hipMemsetAsync(ws.dec[5], 0xFF, (size_t)nb * b.out_h * b.out_w * b.cout * sizeof(bf16_t), st));
+        }
         const bool prof = e->prof_layer == i && e->prof_ev.size() < 4096;
         hipEvent_t pe0 = nullptr, pe1 = nullptr;
         if (prof) {  // dyf_time_layer_in_rollout: HIP events around this block's conv, on the launch stream
@@ -486,6 +493,35 @@ dyf_status dyf_load_weights(dyf_engine* e, int32_t which, int32_t n_tensors, con
                 std::vector<bf16_t> pf(pu.size());
                 pack_up2x_frag(pu.data(), b.cout, b.cin, pf.data());
                 UP(b.wpk_up_frag, pf);
+            }
+            // The readout (sparse transposed conv + final resample, readout kernels in kernels.hip) reads only the columns
+            // of the last decoder block that the final bilinear interpolation touches: for the NS grid (42 native columns
+            // from a 512-wide transposed-conv output) 104 of 256.  Plan the column lists of the sparse halo form.
+            const bool sparse_ok = !(getenv("DYF_SPARSE_DEC5") && atoi(getenv("DYF_SPARSE_DEC5")) == 0);  // read per upload
+            if (i == 11 && b.wpk_up_frag && sparse_ok) {
+                const int iw = b.out_w, tw = 2 * iw, ow = e->cfg.width;
+                std::vector<uint8_t> needed(iw, 0);
+                for (int ox = 0; ox < ow; ++ox) {
+                    // the readout's bilinear_coord (common.h) in double, both neighbours of a near-integer coordinate
+                    double src = ((double)ox + 0.5) * ((double)tw / (double)ow) - 0.5;
+                    if (src < 0.0) src = 0.0;
+                    for (double eps : {-1e-3, 1e-3}) {
+                        int v0 = (int)std::floor(std::max(0.0, src + eps));
+                        v0 = std::min(v0, tw - 1);
+                        for (int v : {v0, std::min(v0 + 1, tw - 1)}) {
+                            const int jh = (v + 1) >> 1;  // k4/s2/p1 transposed conv: input columns jh and jh - 1
+                            for (int j : {jh, jh - 1})
+                                if (j >= 0 && j < iw) needed[j] = 1;
+                        }
+                    }
+                }
+                std::vector<int16_t> cols, cbase;
+                int nt = 0, nv0 = 0, nv1 = 0;
+                if (plan_up_sparse_columns(needed, iw / 2, cols, cbase, nt, nv0, nv1)) {
+                    UP(b.up_cols, cols);
+                    UP(b.up_cbase, cbase);
+                    b.up_ntiles = nt; b.up_npad = nt * 16; b.up_nvalid0 = nv0; b.up_nvalid1 = nv1;
+                }
             }
         }
         if (!b.gn) {  // eval-mode BatchNorm2d folded with the conv bias: y = conv*a + c
@@ -851,6 +887,8 @@ dyf_status dyf_time_conv_layer(dyf_engine* e, int32_t which, int32_t layer, int3
         const UBlock& skipb = n.blk[11 - layer];
         f.src0 = e->ws.dec[layer - 7]; f.c0 = b.cin - skipb.cout; f.src1 = e->ws.enc[11 - layer]; f.c1 = skipb.cout;
         f.h = b.in_h / 2; f.w = b.in_w / 2; f.up2x = 1; f.wpk_up = b.wpk_up; f.wpk_up_frag = b.wpk_up_frag;
+        f.up_cols = b.up_cols; f.up_cbase = b.up_cbase; f.up_ntiles = b.up_ntiles; f.up_npad = b.up_npad;
+        f.up_nvalid0 = b.up_nvalid0; f.up_nvalid1 = b.up_nvalid1;
         if (use_fused_up(e, b, f)) a = f;
     }
     const float* A = n.tables ? n.tables : e->ws.coef_a;                    // row 0 of the plan's tables, or the
@@ -879,7 +917,9 @@ dyf_status dyf_time_conv_layer(dyf_engine* e, int32_t which, int32_t layer, int3
     (void)hipEventDestroy(ev0);
     (void)hipEventDestroy(ev1);
     *avg_ms = (double)ms / iters;
-    const double M = (double)nb * b.out_h * b.out_w;
+    // output pixels that are computed: all of them, or (sparse-column form of the last block) the columns the readout reads
+    const bool sparse = a.up2x && a.up_cols != nullptr;
+    const double M = (double)nb * b.out_h * (sparse ? (double)(a.up_nvalid0 + a.up_nvalid1) : (double)b.out_w);
     if (flops) *flops = 2.0 * M * b.cout * b.cin * b.k * b.k;
     // algorithmic HBM bytes: read the input once, write the output once, read the weights once (bf16)
     if (algo_bytes) {  // the fused x2-upsample form reads its input at low resolution

@@ -30,6 +30,10 @@ struct UBlock {              // one UNetBlock (unet_simple.py:13-82)
     bf16_t* wpk = nullptr;   // device [cout][k*k][cin]
     bf16_t* wpk_up = nullptr;  // decoder 3x3 blocks: phase-decomposed weights of the fused x2-upsample conv
     bf16_t* wpk_up_frag = nullptr;  // ... in MFMA fragment order (halo kernel)
+    // last decoder block: column lists of the outputs the readout actually reads (plan_up_sparse_columns), or null
+    int16_t* up_cols = nullptr;
+    int16_t* up_cbase = nullptr;
+    int up_ntiles = 0, up_npad = 0, up_nvalid0 = 0, up_nvalid1 = 0;
     float* gamma = nullptr;  // device (GroupNorm only)
     float* beta = nullptr;
     float* static_a = nullptr;  // device [cout]: epilogue of the GroupNorm block's conv (ones / conv bias)

@@ -426,7 +426,8 @@ __global__ __launch_bounds__(256) void readout_sliced_kernel(ReadoutArgs a) {
             const int kh = u + 1 - 2 * i, kw = v + 1 - 2 * j;
             const bool ok = (unsigned)i < (unsigned)a.ih && (unsigned)j < (unsigned)a.iw;
             const int ic = ok ? i : 0, jc = ok ? j : 0;
-            qv[nb4 * 4 + t4] = *(const uint4*)(a.x + (((size_t)n * a.ih + ic) * a.iw + jc) * a.cin + ci0);
+            const uint4 ld = *(const uint4*)(a.x + (((size_t)n * a.ih + ic) * a.iw + jc) * a.cin + ci0);
+            qv[nb4 * 4 + t4] = ok ? ld : make_uint4(0u, 0u, 0u, 0u);
             bwv[nb4 * 4 + t4] = ok ? bw : 0.0f;
             wofs[nb4 * 4 + t4] = ((kh * 4 + kw) * a.cin + ci0) * a.cout;
         }
@@ -515,7 +516,9 @@ __global__ __launch_bounds__(256) void readout_regw_kernel(ReadoutArgs a, int px
             const int v = (v1 & 1) == pv ? v1 : v0;
             const int j = ((v + 1) >> 1) - (kw >> 1);
             const bool ok = row_ok && (unsigned)j < (unsigned)a.iw;
-            p.q[kw] = *(const uint4*)(row + (size_t)(ok ? j : 0) * a.cin);
+            const uint4 qv = *(const uint4*)(row + (size_t)(ok ? j : 0) * a.cin);
+            // taps outside the image contribute exactly zero whatever the (possibly never written) fallback pixel holds
+            p.q[kw] = ok ? qv : make_uint4(0u, 0u, 0u, 0u);
             p.bw[kw] = ok ? wu * wv : 0.0f;
         }
         p.out_off = live ? ((n * CO) * a.oh + oy) * a.ow + ox : -1;

@@ -124,6 +124,29 @@ def test_fullsize_ns_forwards_match_reference_fields():
     assert eF <= TOL and eI <= TOL
 
 
+def test_sparse_last_decoder_block_writes_every_pixel_the_readout_reads(monkeypatch):
+    """The last decoder block computes only the output columns the readout's final bilinear resample touches (104 of 256
+    for the NS grid).  With the block's output buffer poisoned (NaN) before every launch, a needed-but-skipped pixel would
+    surface as NaN in the network output; the dense form (DYF_SPARSE_DEC5=0 at weight upload) must agree bit for bit on the
+    pixels that matter, i.e. on the final output."""
+    meta, fields = jload("fullsize_checksums.json"), load_npz("fullsize_ns_fields.npz")
+    mk = meta["model"]
+    PF = oinit.seeded_state(oinit.unet_simple_param_shapes(64, 5, 3), meta["seeds"]["forecaster"])
+    g = torch.Generator().manual_seed(meta["seeds"]["inputs"] + 1)
+    x0 = torch.randn(3, 3, 221, 42, generator=g)
+    c = torch.rand(3, 2, 221, 42, generator=g)
+    t = torch.tensor([3.0, 0.0, 11.0], device=DEV)
+    monkeypatch.setenv("DYF_POISON_DEC5", "1")
+    sparse = mirror_from_params(PF, mk, 3, 2, 3)
+    y_sparse = sparse(x0.to(DEV), time=t, condition=c.to(DEV)).cpu()
+    assert torch.isfinite(y_sparse).all(), "a pixel the readout reads was not written by the sparse-column conv"
+    assert rel_rms(y_sparse[:1], nets.unet_simple_forward(PF, mk, x0[:1], t[:1].cpu(), c[:1])) <= TOL
+    monkeypatch.setenv("DYF_SPARSE_DEC5", "0")
+    dense = mirror_from_params(PF, mk, 3, 2, 3)
+    y_dense = dense(x0.to(DEV), time=t, condition=c.to(DEV)).cpu()
+    assert torch.equal(y_sparse, y_dense)
+
+
 def test_interpolation_experiment_evaluation_step_matches_oracle():
     """Stage-1 interpolator evaluation (interpolation.py:69-127): t = 1..h-1 from (first frame, last frame), N members."""
     import dyffusion_amd as D
