@@ -215,18 +215,25 @@ def main():
     if rank == 0:
         # roofline of the dominant kernel: the last decoder block's 3x3 conv (256 -> 64 ch @256^2, 40 % of a forward),
         # conv_up_halo_kernel; HIP events on the launch stream, operands = live workspace activations
+        # Dominant kernel: conv_up_halo_kernel<0> (dense form; dec3 + dec4 = 27 % of a forward's time), largest launch dec4.
         # achieved = algorithmic FLOPs of one launch / average duration of that launch INSIDE the rollout: HIP events around
-        # every dec5 conv (60 launches: 16 forecaster + 44 interpolator forwards, MC dropout on) of one eagerly launched
-        # rollout on the launch stream (dyf_time_layer_in_rollout); the isolated back-to-back figure is kept beside it
-        _, fl, by = eng.time_conv_layer(1, 11, nb, iters=1)
-        ms, launches = eng.time_layer_in_rollout(11, nb)
-        ms_iso, _, _ = eng.time_conv_layer(1, 11, nb, iters=10)
-        log(f"dec5 conv: {ms:.3f} ms per launch in the rollout ({launches} launches), {ms_iso:.3f} ms isolated back-to-back")
-        result["roofline"] = {"bound": "mfma", "kernel": "conv_up_halo_kernel (dec5: fused x2-upsample + 3x3 conv, 256->64 ch, 128^2->256^2)",
-                              "achieved": round(fl / ms / 1e9, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                              "frac": round(fl / ms / 1e9 / PEAK_BF16_TFLOPS, 4), "avg_ms": round(ms, 4), "launches": launches,
-                              "avg_ms_isolated": round(ms_iso, 4),
-                              "flops_per_launch": fl, "algorithmic_bytes_per_launch": by, "traffic": pmc_traffic(nb)}
+        # every dec4 conv (60 launches: 16 forecaster + 44 interpolator forwards, MC dropout on) of one eagerly launched
+        # rollout on the launch stream (dyf_time_layer_in_rollout); the isolated back-to-back figure is kept beside it.
+        # The sparse-column instance of the same kernel (dec5, only the output columns the readout reads) is reported too.
+        def layer_roofline(layer, name):
+            _, fl, by = eng.time_conv_layer(1, layer, nb, iters=1)
+            ms, launches = eng.time_layer_in_rollout(layer, nb)
+            ms_iso, _, _ = eng.time_conv_layer(1, layer, nb, iters=10)
+            log(f"{name}: {ms:.3f} ms per launch in the rollout ({launches} launches), {ms_iso:.3f} ms isolated back-to-back")
+            return {"bound": "mfma", "kernel": name, "achieved": round(fl / ms / 1e9, 2), "peak": PEAK_BF16_TFLOPS,
+                    "unit": "TFLOP/s", "frac": round(fl / ms / 1e9 / PEAK_BF16_TFLOPS, 4), "avg_ms": round(ms, 4),
+                    "launches": launches, "avg_ms_isolated": round(ms_iso, 4), "flops_per_launch": fl,
+                    "algorithmic_bytes_per_launch": by}
+
+        result["roofline"] = layer_roofline(10, "conv_up_halo_kernel<0> (dec4: fused x2-upsample + 3x3 conv, 512->128 ch, 64^2->128^2)")
+        result["roofline"]["traffic"] = pmc_traffic(nb)
+        result["roofline_dec5_sparse"] = layer_roofline(
+            11, "conv_up_halo_kernel<1> (dec5: fused x2-upsample + 3x3 conv, 256->64 ch, 128^2->256^2, 104 of 256 output columns)")
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(F, I)
         print(json.dumps(result), flush=True)
