@@ -27,7 +27,9 @@ struct ConvArgs {
     // horizontal phase, halo origin per list tile; null = every column
     const int16_t* up_cols;
     const int16_t* up_cbase;
+    const int16_t* up_cidx;  // [2][up_npad]: column of each list entry's output pixel in the COMPACT output tensor
     int up_ntiles, up_npad, up_nvalid0, up_nvalid1;
+    int up_wo_store;         // columns of the compact output tensor [n][ho][up_wo_store][cout]
     // epilogue: v = acc * A[row*coef_stride + co] + C[row*coef_stride + co]; row = sample index (coef_stride may be 0
     // to broadcast one row); conv bias, eval-BatchNorm and FiLM (x*(scale+1)+shift) are all folded into A and C.
     const float* coef_a;
@@ -50,7 +52,7 @@ void pack_up2x_weights(const float* w, int cout, int cin, bf16_t* out);
 bool conv_up_halo_supported(const ConvArgs& a);
 void pack_up2x_frag(const bf16_t* wpk_up, int cout, int cin, bf16_t* out);
 bool plan_up_sparse_columns(const std::vector<uint8_t>& needed, int w, std::vector<int16_t>& cols, std::vector<int16_t>& cbase,
-                            int& ntiles, int& nvalid0, int& nvalid1);
+                            std::vector<int16_t>& cidx, std::vector<int16_t>& col_map, int& ntiles, int& nvalid0, int& nvalid1);
 hipError_t conv_up_halo_init();
 hipError_t launch_conv_up_halo(const ConvArgs& a, hipStream_t stream);
 // second implicit-GEMM form (conv_igemm2.hip): 256 px x 128 ch per workgroup, weights streamed in fragment order

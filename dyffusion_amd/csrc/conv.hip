@@ -556,6 +556,8 @@ hipError_t launch_conv(const ConvArgs& a, int path, hipStream_t stream) {
         // halo form wins once most tiles are interior (>= 4x4 tiles per image); below that the gather form's pipelined
         // correction taps are cheaper (measured: dec3 32x32 plane 712 vs 697 TFLOP/s, dec4/dec5 862/905 vs 831/799)
         static const int halo_min = getenv("DYF_HALO_MIN_PLANE") ? atoi(getenv("DYF_HALO_MIN_PLANE")) : 32;
+        if (a.up2x && a.up_cols)  // sparse-column form: only the halo kernel writes the compact output tensor
+            return conv_up_halo_supported(a) ? launch_conv_up_halo(a, stream) : hipErrorInvalidValue;
         if (a.up2x && use_halo && a.h >= halo_min && a.w >= halo_min && conv_up_halo_supported(a)) return launch_conv_up_halo(a, stream);
         static const bool use_igemm2 = !(getenv("DYF_IGEMM2") && atoi(getenv("DYF_IGEMM2")) == 0);
         if (!a.up2x && use_igemm2 && a.cout % 128 == 0) {

@@ -85,13 +85,14 @@ __global__ __launch_bounds__(256, 2) void conv_up_halo_kernel(ConvArgs a, int ti
     const int lx = t_in % tiles_x;              // column tile: 16 contiguous columns, or 16 entries of the column lists
     const int px_x = l31 & 15, px_r = l31 >> 4;
     // low-res column of this lane's pixels and the column the halo starts at
-    int col, cbase;
+    int col, cbase, cstore = 0;
     bool lane_valid = true;
     if (SP) {
         cbase = a.up_cbase[lx];
         const int entry = a.up_cols[wpx * a.up_npad + lx * 16 + px_x];  // bit 14: padding entry (computed, not stored)
         col = entry & 0x3FFF;
         lane_valid = (entry & 0x4000) == 0;
+        cstore = a.up_cidx[wpx * a.up_npad + lx * 16 + px_x];  // column of output pixel (.., 2*col + px) in the compact tensor
     } else {
         cbase = lx * TILE_W - 1;
         col = lx * TILE_W + px_x;
@@ -387,6 +388,12 @@ __global__ __launch_bounds__(256, 2) void conv_up_halo_kernel(ConvArgs a, int ti
     const uint32_t m0 = (uint32_t)((n_img * a.ho + 2 * (ty0 + px_r) + wpy) * a.wo + 2 * col + wpx);
     const uint32_t o0 = m0 * (uint32_t)a.cout + (uint32_t)(tn * 64);
     const uint32_t mt_stride = (uint32_t)(4 * a.wo * a.cout);
+    // sparse form: the output tensor keeps only the listed columns, [n][ho][up_wo_store][cout]; the dropout stream stays
+    // indexed by the DENSE position (o0), so masks do not depend on the storage layout
+    const uint32_t store0 = SP ? (uint32_t)((n_img * a.ho + 2 * (ty0 + px_r) + wpy) * a.up_wo_store + cstore) * (uint32_t)a.cout +
+                                 (uint32_t)(tn * 64)
+                           : o0;
+    const uint32_t smt_stride = SP ? (uint32_t)(4 * a.up_wo_store * a.cout) : mt_stride;
     // (activation, dropout mode) are wave-uniform: the whole epilogue is instantiated per pair and dispatched once
     auto epilogue = [&](auto act_c, auto mode_c) {
         constexpr int ACT = decltype(act_c)::value, MODE = decltype(mode_c)::value;
@@ -414,7 +421,8 @@ __global__ __launch_bounds__(256, 2) void conv_up_halo_kernel(ConvArgs a, int ti
                     // lanes 32-63: {partner's group 2*g2+1, own group 2*g2+1} = channels cg0 + 8..15
                     uint4 o;
                     o.x = s0[0]; o.y = s1[0]; o.z = s0[1]; o.w = s1[1];
-                    if (!SP || lane_valid) *(uint4*)(a.out_bf16 + (size_t)(obase + 8 * hi)) = o;
+                    const uint32_t sbase = store0 + mt * smt_stride + cg0;
+                    if (!SP || lane_valid) *(uint4*)(a.out_bf16 + (size_t)(sbase + 8 * hi)) = o;
                 }
         }
     };
@@ -455,7 +463,9 @@ bool conv_up_halo_supported(const ConvArgs& a) {
     if (!a.up2x || a.wpk_up_frag == nullptr || a.out_bf16 == nullptr || a.residual != nullptr) return false;
     if (!(a.c0 > 0 && a.c0 % 64 == 0 && (a.c1 == 0 || a.c1 == a.c0) && a.cout % 64 == 0)) return false;
     if (a.h % TILE_H != 0 || a.w % TILE_W != 0 || a.ho != 2 * a.h || a.wo != 2 * a.w) return false;
-    if (a.up_cols && (a.up_cbase == nullptr || a.up_ntiles < 1 || a.up_npad != a.up_ntiles * 16)) return false;
+    if (a.up_cols && (a.up_cbase == nullptr || a.up_cidx == nullptr || a.up_wo_store < 1 || a.up_ntiles < 1 ||
+                      a.up_npad != a.up_ntiles * 16))
+        return false;
     const size_t npix = (size_t)a.n * a.h * a.w;
     return npix * a.c0 * 2 < 0x7F000000ull && (size_t)4 * a.cout * 16 * (a.c0 + a.c1) * 2 < 0x7F000000ull &&
            (size_t)a.n * a.ho * a.wo * a.cout < 0xFFFFFFF0ull;
@@ -489,7 +499,12 @@ hipError_t launch_conv_up_halo(const ConvArgs& a, hipStream_t stream) {
 // list tile t.  Returns false (dense form must be used) when a list tile does not fit the 40-column halo or the lists would
 // not save at least 20 % of the work.
 bool plan_up_sparse_columns(const std::vector<uint8_t>& needed, int w, std::vector<int16_t>& cols, std::vector<int16_t>& cbase,
-                            int& ntiles, int& nvalid0, int& nvalid1) {
+                            std::vector<int16_t>& cidx, std::vector<int16_t>& col_map, int& ntiles, int& nvalid0, int& nvalid1) {
+    // compact storage order: the needed output columns in increasing order
+    col_map.assign((size_t)2 * w, -1);
+    int nstore = 0;
+    for (int x = 0; x < 2 * w; ++x)
+        if (needed[x]) col_map[x] = (int16_t)nstore++;
     std::vector<int> l[2];
     for (int j = 0; j < w; ++j)
         for (int px = 0; px < 2; ++px)
@@ -502,6 +517,7 @@ bool plan_up_sparse_columns(const std::vector<uint8_t>& needed, int w, std::vect
     if (ntiles * 16 * 5 > w * 4) return false;
     const int per = (nmax + ntiles - 1) / ntiles;  // entries per tile, balanced
     cols.assign((size_t)2 * ntiles * 16, 0);
+    cidx.assign((size_t)2 * ntiles * 16, 0);
     cbase.assign(ntiles, 0);
     for (int t = 0; t < ntiles; ++t) {
         int lo = w, hi = -1;
@@ -513,6 +529,7 @@ bool plan_up_sparse_columns(const std::vector<uint8_t>& needed, int w, std::vect
                 const int kk = std::min(std::min(k, t * per + per - 1), n - 1);
                 const int c = l[px][std::max(kk, 0)];
                 cols[(size_t)px * ntiles * 16 + t * 16 + i] = (int16_t)(c | (real ? 0 : 0x4000));
+                cidx[(size_t)px * ntiles * 16 + t * 16 + i] = col_map[2 * c + px];
                 lo = std::min(lo, c);
                 hi = std::max(hi, c);
             }

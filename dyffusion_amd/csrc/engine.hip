@@ -177,6 +177,7 @@ dyf_status net_forward(dyf_engine* e, int which, const Source* srcs, int nsrc, i
     // ---- decoder: x2 bilinear upsample of cat[x, skip] (materialised), conv, fused epilogue
     const bf16_t* skip = nullptr;
     int skip_c = 0;
+    const UBlock* sparse_out = nullptr;
     int lh = n.blk[5].out_h, lw = n.blk[5].out_w;
     for (int i = 6; i < 12; ++i) {
         const UBlock& b = n.blk[i];
@@ -188,13 +189,16 @@ dyf_status net_forward(dyf_engine* e, int which, const Source* srcs, int nsrc, i
         ConvArgs f = a;
         f.src0 = x; f.c0 = b.cin - skip_c; f.src1 = skip; f.c1 = skip_c; f.h = lh; f.w = lw;
         f.up2x = 1; f.wpk_up = b.wpk_up; f.wpk_up_frag = b.wpk_up_frag;
-        f.up_cols = b.up_cols; f.up_cbase = b.up_cbase; f.up_ntiles = b.up_ntiles; f.up_npad = b.up_npad;
-        f.up_nvalid0 = b.up_nvalid0; f.up_nvalid1 = b.up_nvalid1;
+        f.up_cols = b.up_cols; f.up_cbase = b.up_cbase; f.up_cidx = b.up_cidx; f.up_ntiles = b.up_ntiles; f.up_npad = b.up_npad;
+        f.up_nvalid0 = b.up_nvalid0; f.up_nvalid1 = b.up_nvalid1; f.up_wo_store = b.up_wo_store;
         if (i == 11 && b.up_cols) {  // test hook: poison the output so that a needed-but-unwritten pixel of the sparse form shows
             const char* pz = getenv("DYF_POISON_DEC5");
             if (pz && atoi(pz) != 0)
-                HIP_TRY(e, hipMemsetAsync(ws.dec[5], 0xFF, (size_t)nb * b.out_h * b.out_w * b.cout * sizeof(bf16_t), st));
+                HIP_TRY(e, hipMemsetAsync(ws.dec[5], 0xFF, (size_t)nb * b.out_h * b.out_w * b.cout * sizeof(bf16_t), st));  // whole buffer
         }
+        // sparse-column form (last block only): its output tensor is compact, the readout below must know
+        if (f.up_cols && !(use_fused_up(e, b, f) && conv_up_halo_supported(f))) f.up_cols = nullptr;
+        if (f.up_cols) sparse_out = &b;
         const bool prof = e->prof_layer == i && e->prof_ev.size() < 4096;
         hipEvent_t pe0 = nullptr, pe1 = nullptr;
         if (prof) {  // dyf_time_layer_in_rollout: HIP events around this block's conv, on the launch stream
@@ -225,8 +229,10 @@ dyf_status net_forward(dyf_engine* e, int which, const Source* srcs, int nsrc, i
     }
     // ---- readout (sparse transposed conv + final resample)
     ReadoutArgs r{};
-    r.x = x; r.n = nb; r.ih = lh; r.iw = lw; r.cin = n.dim; r.wgt = n.ro_w; r.bias = n.ro_b; r.cout = n.cfg.out_channels;
+    r.x = x; r.n = nb; r.ih = lh; r.iw = lw; r.cin = n.dim; r.wgt = n.ro_w; r.wfrag = n.ro_wfrag; r.bias = n.ro_b; r.cout = n.cfg.out_channels;
     r.oh = H; r.ow = W; r.out = out_dev;
+    r.iw_store = sparse_out ? sparse_out->up_wo_store : lw;
+    r.col_map = sparse_out ? sparse_out->up_col_map : nullptr;
     HIP_TRY(e, launch_readout(r, st));
     if (o.dropout_mode == 1 && n.cfg.dropout > 0.0f) HIP_TRY(e, launch_bump_counter(e->rng_state, st));
     return DYF_OK;
@@ -515,12 +521,17 @@ dyf_status dyf_load_weights(dyf_engine* e, int32_t which, int32_t n_tensors, con
                         }
                     }
                 }
-                std::vector<int16_t> cols, cbase;
+                std::vector<int16_t> cols, cbase, cidx, cmap;
                 int nt = 0, nv0 = 0, nv1 = 0;
-                if (plan_up_sparse_columns(needed, iw / 2, cols, cbase, nt, nv0, nv1)) {
+                // the compact tensor is read by the MFMA form of the readout only (dim 64, <= 4 output channels)
+                if (n.dim == 64 && n.cfg.out_channels <= 4 &&
+                    plan_up_sparse_columns(needed, iw / 2, cols, cbase, cidx, cmap, nt, nv0, nv1)) {
                     UP(b.up_cols, cols);
                     UP(b.up_cbase, cbase);
+                    UP(b.up_cidx, cidx);
+                    UP(b.up_col_map, cmap);
                     b.up_ntiles = nt; b.up_npad = nt * 16; b.up_nvalid0 = nv0; b.up_nvalid1 = nv1;
+                    b.up_wo_store = nv0 + nv1;
                 }
             }
         }
@@ -555,6 +566,19 @@ dyf_status dyf_load_weights(dyf_engine* e, int32_t which, int32_t n_tensors, con
             for (int co = 0; co < oc; ++co)
                 for (int t = 0; t < 16; ++t) pk[((size_t)t * n.dim + ci) * oc + co] = rw->data[((size_t)ci * oc + co) * 16 + t];
         UP(n.ro_w, pk); UP(n.ro_b, vec(rb));
+        if (n.dim == 64 && oc <= 4) {  // MFMA fragments: lane (m = lane & 15, kg = lane >> 4) of (tap, half): W[tap][half*32 + kg*8 + e][m]
+            std::vector<bf16_t> wf((size_t)16 * 2 * 64 * 8, 0);
+            for (int t = 0; t < 16; ++t)
+                for (int h2 = 0; h2 < 2; ++h2)
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int m = lane & 15, kg = lane >> 4;
+                        for (int el = 0; el < 8; ++el)
+                            if (m < oc)
+                                wf[(((size_t)t * 2 + h2) * 64 + lane) * 8 + el] =
+                                    f32_to_bf16(pk[((size_t)t * n.dim + h2 * 32 + kg * 8 + el) * oc + m]);
+                    }
+            UP(n.ro_wfrag, wf);
+        }
     }
 #undef NEED
 #undef UP
@@ -887,8 +911,8 @@ dyf_status dyf_time_conv_layer(dyf_engine* e, int32_t which, int32_t layer, int3
         const UBlock& skipb = n.blk[11 - layer];
         f.src0 = e->ws.dec[layer - 7]; f.c0 = b.cin - skipb.cout; f.src1 = e->ws.enc[11 - layer]; f.c1 = skipb.cout;
         f.h = b.in_h / 2; f.w = b.in_w / 2; f.up2x = 1; f.wpk_up = b.wpk_up; f.wpk_up_frag = b.wpk_up_frag;
-        f.up_cols = b.up_cols; f.up_cbase = b.up_cbase; f.up_ntiles = b.up_ntiles; f.up_npad = b.up_npad;
-        f.up_nvalid0 = b.up_nvalid0; f.up_nvalid1 = b.up_nvalid1;
+        f.up_cols = b.up_cols; f.up_cbase = b.up_cbase; f.up_cidx = b.up_cidx; f.up_ntiles = b.up_ntiles; f.up_npad = b.up_npad;
+        f.up_nvalid0 = b.up_nvalid0; f.up_nvalid1 = b.up_nvalid1; f.up_wo_store = b.up_wo_store;
         if (use_fused_up(e, b, f)) a = f;
     }
     const float* A = n.tables ? n.tables : e->ws.coef_a;                    // row 0 of the plan's tables, or the

@@ -33,6 +33,9 @@ struct UBlock {              // one UNetBlock (unet_simple.py:13-82)
     // last decoder block: column lists of the outputs the readout actually reads (plan_up_sparse_columns), or null
     int16_t* up_cols = nullptr;
     int16_t* up_cbase = nullptr;
+    int16_t* up_cidx = nullptr;
+    int16_t* up_col_map = nullptr;  // [out_w]: output column -> column of the compact tensor, -1 = not stored
+    int up_wo_store = 0;
     int up_ntiles = 0, up_npad = 0, up_nvalid0 = 0, up_nvalid1 = 0;
     float* gamma = nullptr;  // device (GroupNorm only)
     float* beta = nullptr;
@@ -51,6 +54,7 @@ struct Net {
     float *film_w = nullptr, *film_b = nullptr, *norm_a = nullptr, *norm_c = nullptr;
     int *blk_of = nullptr, *blk_off = nullptr, *blk_cout = nullptr;
     float *ro_w = nullptr, *ro_b = nullptr;
+    bf16_t* ro_wfrag = nullptr;  // readout weights as MFMA fragments (dim 64, <= 4 output channels)
     bf16_t* enc0_fused_w = nullptr;  // [2dim][4][64]: enc0's 4x4 conv composed with init_conv (+ bias channel)
     bool stem_fused = false;
     double flops_per_sample = 0.0;

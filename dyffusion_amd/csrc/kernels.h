@@ -84,7 +84,10 @@ hipError_t launch_groupnorm(const GroupNormArgs& a, hipStream_t s);
 struct ReadoutArgs {
     const bf16_t* x;        // [n][ih][iw][cin] decoder output
     int n, ih, iw, cin;
+    int iw_store;           // columns actually stored per row of x (== iw, or the compact width of the sparse-column decoder block)
+    const int16_t* col_map; // [iw]: column -> stored column, -1 = not stored (compact x), or null
     const float* wgt;       // [kh][kw][cin][cout] fp32 (repacked ConvTranspose weight)
+    const bf16_t* wfrag;    // the same weights as MFMA 16x16x32 A fragments [16 taps][2 k halves][64 lanes][8] bf16 (cin == 64), or null
     const float* bias;      // [cout]
     int cout;
     int oh, ow;             // native grid

@@ -564,9 +564,133 @@ __global__ __launch_bounds__(256) void readout_regw_kernel(ReadoutArgs a, int px
     }
 }
 
+// MFMA form for cin == 64, cout <= 4 (the NS backbone): the register-weight form above is VALU-bound (~230 VALU per lane and
+// pixel).  Here a wave takes 16 native pixels at a time; for each of the 16 (kh, kw) taps the 64-channel contraction of all 16
+// pixels is two v_mfma_f32_16x16x32_bf16 (A = the tap's weights as a [16 (cout, zero-padded)][32 k] fragment held in
+// registers for the whole kernel, B = the pixels' input vectors: lane (pixel p, k-group g) loads 16 B of pixel p's tap
+// vector, exactly its MFMA operand), and the bilinear weight of the tap scales the 3 result rows with 3 FMAs.  Coordinates
+// are computed once per pixel by 4 lanes instead of 32.  Weights are bf16 here (fp32 in the other forms).
+typedef __attribute__((ext_vector_type(8))) __bf16 ro_bf16x8;
+typedef __attribute__((ext_vector_type(4))) float ro_f32x4;
+
+__global__ __launch_bounds__(256, 4) void readout_mfma_kernel(ReadoutArgs a, int groups_per_wave) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    // weight fragments [tap][k half][lane] x 16 B in LDS (32 KB): lane (m = lane & 15, k-group) holds
+    // W[tap][half*32 + kg*8 + e][co = m] (0 for m >= cout); fragment reads are lane-linear, i.e. conflict-free
+    extern __shared__ __attribute__((aligned(16))) char ro_smem[];
+    for (int i = threadIdx.x; i < 16 * 2 * 64; i += 256) ((uint4*)ro_smem)[i] = ((const uint4*)a.wfrag)[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int wave_id = (int)((blockIdx.x * 256 + threadIdx.x) >> 6);
+    const int p = lane & 15, kg = lane >> 4;
+    const ro_bf16x8* wl = (const ro_bf16x8*)ro_smem + lane;
+    const int total = a.n * a.oh * a.ow;
+    const int th = 2 * a.ih, tw = 2 * a.iw;
+    const float sh = (float)th / (float)a.oh, sw = (float)tw / (float)a.ow;
+    const int plane = a.oh * a.ow;
+    for (int g = 0; g < groups_per_wave; ++g) {
+        const int idx0 = (wave_id * groups_per_wave + g) * 16;
+        if (idx0 >= total) break;  // wave-uniform
+        int idx = idx0 + p;
+        const bool live = idx < total;
+        if (!live) idx = total - 1;
+        // pixel order (n, oy, ox), ox fastest: the 16 pixels of a group read the same three input rows
+        const int n = idx / plane;
+        const int rem = idx - n * plane;
+        const int oy = rem / a.ow, ox = rem - oy * a.ow;
+        int u0, u1, v0, v1;
+        float lu, lv;
+        bilinear_coord(oy, sh, th, u0, u1, lu);
+        bilinear_coord(ox, sw, tw, v0, v1, lv);
+        // per kernel row / column: byte offset of the input row / column (or -1) and bilinear weight (see readout_regw_kernel)
+        int ro[4], co_[4];
+        float rw[4], cw[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int par = (k + 1) & 1;
+            rw[k] = ((u0 & 1) == par ? 1.0f - lu : 0.0f) + ((u1 & 1) == par ? lu : 0.0f);
+            const int u = (u1 & 1) == par ? u1 : u0;
+            const int i = ((u + 1) >> 1) - (k >> 1);
+            ro[k] = (unsigned)i < (unsigned)a.ih ? i * a.iw_store * 64 : -1;
+            cw[k] = ((v0 & 1) == par ? 1.0f - lv : 0.0f) + ((v1 & 1) == par ? lv : 0.0f);
+            const int v = (v1 & 1) == par ? v1 : v0;
+            const int j = ((v + 1) >> 1) - (k >> 1);
+            int js = (unsigned)j < (unsigned)a.iw ? j : -1;
+            if (js >= 0 && a.col_map) js = a.col_map[js];  // compact input: stored column of j (always stored when read)
+            co_[k] = js >= 0 ? js * 64 : -1;
+        }
+        // LOADS are issued with a coalesced lane map -- lane s fetches 16-B chunk (s & 3) of pixel (s >> 2), so a quad of
+        // lanes reads 64 contiguous bytes (with the MFMA's own lane map, pixel = lane & 15, every quad touches four cache
+        // lines and the texture path needs 4x the cycles) -- and moved to their MFMA lane with ds_bpermute:
+        // MFMA lane t = (pixel t & 15, k-group t >> 4) takes the registers of load lane (t & 15) * 4 + (t >> 4).
+        const int lp = lane >> 2, lc = lane & 3;  // pixel / chunk this lane LOADS
+        const int src4 = (lp)*4;                  // byte address (lane * 4) of a lane that holds pixel lp's coordinates: lane lp
+        int l_ro[4], l_co[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            l_ro[k] = __builtin_amdgcn_ds_bpermute(src4, ro[k]);
+            l_co[k] = __builtin_amdgcn_ds_bpermute(src4, co_[k]);
+        }
+        const int l_n = __builtin_amdgcn_ds_bpermute(src4, n);
+        const bf16_t* img = a.x + (size_t)l_n * a.ih * a.iw_store * 64 + lc * 8;
+        const int take4 = ((lane & 15) * 4 + (lane >> 4)) * 4;
+        float out[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        // two batches of 8 taps (2 kernel rows): all 16 vector loads of a batch are in flight before its MFMAs
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            uint4 q0[8], q1[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const int kh = b * 2 + (t >> 2), kw = t & 3;
+                const bool ok = l_ro[kh] >= 0 && l_co[kw] >= 0;
+                const bf16_t* px = img + (ok ? l_ro[kh] + l_co[kw] : 0);
+                q0[t] = *(const uint4*)px;
+                q1[t] = *(const uint4*)(px + 32);
+                if (!ok) { q0[t] = make_uint4(0u, 0u, 0u, 0u); q1[t] = q0[t]; }  // taps outside the image: data 0
+            }
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const int kh = b * 2 + (t >> 2), kw = t & 3, tap = kh * 4 + kw;
+                uint4 m0, m1;
+                m0.x = __builtin_amdgcn_ds_bpermute(take4, q0[t].x); m0.y = __builtin_amdgcn_ds_bpermute(take4, q0[t].y);
+                m0.z = __builtin_amdgcn_ds_bpermute(take4, q0[t].z); m0.w = __builtin_amdgcn_ds_bpermute(take4, q0[t].w);
+                m1.x = __builtin_amdgcn_ds_bpermute(take4, q1[t].x); m1.y = __builtin_amdgcn_ds_bpermute(take4, q1[t].y);
+                m1.z = __builtin_amdgcn_ds_bpermute(take4, q1[t].z); m1.w = __builtin_amdgcn_ds_bpermute(take4, q1[t].w);
+                ro_f32x4 d = {0.0f, 0.0f, 0.0f, 0.0f};
+                d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[(tap * 2 + 0) * 64], __builtin_bit_cast(ro_bf16x8, m0), d, 0, 0, 0);
+                d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[(tap * 2 + 1) * 64], __builtin_bit_cast(ro_bf16x8, m1), d, 0, 0, 0);
+                const float bw = (ro[kh] >= 0 && co_[kw] >= 0) ? rw[kh] * cw[kw] : 0.0f;  // this lane's own pixel
+#pragma unroll
+                for (int r = 0; r < 4; ++r) out[r] = fmaf(bw, d[r], out[r]);
+            }
+        }
+        // rows 0..3 of the 16x16 result (= output channels) live in lanes 0-15 (k-group 0), column = pixel
+        if (live && kg == 0) {
+            float* o = a.out + ((size_t)n * a.cout * a.oh + oy) * a.ow + ox;
+            const size_t cs = (size_t)a.oh * a.ow;
+            o[0] = out[0] + a.bias[0];
+            if (a.cout > 1) o[cs] = out[1] + a.bias[1];
+            if (a.cout > 2) o[2 * cs] = out[2] + a.bias[2];
+            if (a.cout > 3) o[3 * cs] = out[3] + a.bias[3];
+        }
+    }
+#endif
+}
+
 hipError_t launch_readout(const ReadoutArgs& a, hipStream_t s) {
     const long long total = (long long)a.n * a.oh * a.ow;
     static const bool regw = !(getenv("DYF_READOUT_REGW") && atoi(getenv("DYF_READOUT_REGW")) == 0);
+    static const bool use_mfma = !(getenv("DYF_READOUT_MFMA") && atoi(getenv("DYF_READOUT_MFMA")) == 0);
+    if (a.col_map && !(a.wfrag && a.cin == 64 && a.cout >= 1 && a.cout <= 4)) return hipErrorInvalidValue;
+    if ((use_mfma || a.col_map) && a.wfrag && a.cin == 64 && a.cout >= 1 && a.cout <= 4 && total < (1ll << 30)) {
+        const long long groups = (total + 15) / 16;
+        long long waves = 256ll * 16;  // 4 waves per SIMD
+        int per = (int)((groups + waves - 1) / waves);
+        if (per < 1) per = 1;
+        waves = (groups + per - 1) / per;
+        hipLaunchKernelGGL(readout_mfma_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 32768, s, a, per);
+        return hipGetLastError();
+    }
     if (regw && a.cin == 64 && a.cout >= 1 && a.cout <= 4 && total < (1ll << 30)) {
         // ~16 waves per CU; a half-wave owns a contiguous run of pixels
         int halves = 256 * 16 * 2;
