@@ -129,22 +129,35 @@ __device__ __forceinline__ float act_fixed(float v) {
     else return v;
 }
 
-template <int N, int ACT, int MODE>
+// The dropout scale 1/(1-p) commutes with the positively homogeneous activations (none, ReLU, LeakyReLU): epilogues fold
+// it into their affine coefficients (drop_prescale) and the dropout itself is a select.  SiLU keeps the multiply.
+template <int ACT, int MODE>
+__device__ __forceinline__ float drop_prescale(const DropSpec& d) {
+    return (MODE != 0 && ACT != ACT_SILU) ? d.scale : 1.0f;
+}
+
+template <int N, int ACT, int MODE, bool PRESCALED = false>
 __device__ __forceinline__ void act_drop_fixed(float* v, uint32_t e0, const DropSpec& d, uint32_t key) {
 #pragma unroll
     for (int t = 0; t < N; ++t) v[t] = act_fixed<ACT>(v[t]);
+    constexpr bool folded = PRESCALED && ACT != ACT_SILU;
     if constexpr (MODE == 1) {
         const uint32_t th = d.thresh16;
-        const float sc = d.scale;
+        const float sc = folded ? 1.0f : d.scale;
 #pragma unroll
         for (int p = 0; p < N / 2; ++p) {
             const uint32_t w = rng_pair_word((e0 >> 1) + p, key);
-            v[2 * p] = (w & 0xffffu) < th ? v[2 * p] * sc : 0.0f;
-            v[2 * p + 1] = (w >> 16) < th ? v[2 * p + 1] * sc : 0.0f;
+            if constexpr (folded) {
+                v[2 * p] = (w & 0xffffu) < th ? v[2 * p] : 0.0f;
+                v[2 * p + 1] = (w >> 16) < th ? v[2 * p + 1] : 0.0f;
+            } else {
+                v[2 * p] = (w & 0xffffu) < th ? v[2 * p] * sc : 0.0f;
+                v[2 * p + 1] = (w >> 16) < th ? v[2 * p + 1] * sc : 0.0f;
+            }
         }
     } else if constexpr (MODE == 2) {
 #pragma unroll
-        for (int t = 0; t < N; ++t) v[t] = d.mask[e0 + t] != 0 ? v[t] * d.scale : 0.0f;
+        for (int t = 0; t < N; ++t) v[t] = d.mask[e0 + t] != 0 ? (folded ? v[t] : v[t] * d.scale) : 0.0f;
     }
 }
 

@@ -238,14 +238,15 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(ConvArgs a, int M, 
                     const int cg0 = nt * 32 + 16 * g2;  // + 4*hi: own channels of group 2*g2; + 8: group 2*g2+1
                     const float4 ca0 = *(const float4*)(a.coef_a + cb + cg0), ca1 = *(const float4*)(a.coef_a + cb + cg0 + 8);
                     const float4 cc0 = *(const float4*)(a.coef_c + cb + cg0), cc1 = *(const float4*)(a.coef_c + cb + cg0 + 8);
-                    const float ca[8] = {ca0.x, ca0.y, ca0.z, ca0.w, ca1.x, ca1.y, ca1.z, ca1.w};
-                    const float cc[8] = {cc0.x, cc0.y, cc0.z, cc0.w, cc1.x, cc1.y, cc1.z, cc1.w};
+                    const float ps = drop_prescale<ACT, MODE>(a.drop);  // dropout scale folded into the affine
+                    const float ca[8] = {ca0.x * ps, ca0.y * ps, ca0.z * ps, ca0.w * ps, ca1.x * ps, ca1.y * ps, ca1.z * ps, ca1.w * ps};
+                    const float cc[8] = {cc0.x * ps, cc0.y * ps, cc0.z * ps, cc0.w * ps, cc1.x * ps, cc1.y * ps, cc1.z * ps, cc1.w * ps};
                     const uint32_t e0 = ob + cg0 + 4 * hi;
                     float v[8];
 #pragma unroll
                     for (int t = 0; t < 8; ++t) v[t] = fmaf(acc[mt][nt][8 * g2 + t], ca[t], cc[t]);
-                    act_drop_fixed<4, ACT, MODE>(v, e0, a.drop, key);
-                    act_drop_fixed<4, ACT, MODE>(v + 4, e0 + 8, a.drop, key);
+                    act_drop_fixed<4, ACT, MODE, true>(v, e0, a.drop, key);
+                    act_drop_fixed<4, ACT, MODE, true>(v + 4, e0 + 8, a.drop, key);
                     if (a.residual) {
                         const uint2 r0 = valid ? *(const uint2*)(a.residual + (size_t)e0) : make_uint2(0, 0);
                         const uint2 r1 = valid ? *(const uint2*)(a.residual + (size_t)e0 + 8) : make_uint2(0, 0);

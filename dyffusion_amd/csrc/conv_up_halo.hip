@@ -402,8 +402,9 @@ __global__ __launch_bounds__(256, 2) void conv_up_halo_kernel(ConvArgs a, int ti
             const int cg0 = (hg >> 1) * 32 + 16 * (hg & 1);  // + 4*hi: own channels of group 2*g2; + 8: group 2*g2+1
             const float4 ca0 = *(const float4*)(a.coef_a + ci_base + cg0), ca1 = *(const float4*)(a.coef_a + ci_base + cg0 + 8);
             const float4 cc0 = *(const float4*)(a.coef_c + ci_base + cg0), cc1 = *(const float4*)(a.coef_c + ci_base + cg0 + 8);
-            const float ca[8] = {ca0.x, ca0.y, ca0.z, ca0.w, ca1.x, ca1.y, ca1.z, ca1.w};
-            const float cc[8] = {cc0.x, cc0.y, cc0.z, cc0.w, cc1.x, cc1.y, cc1.z, cc1.w};
+            const float ps = drop_prescale<ACT, MODE>(a.drop);  // dropout scale folded into the affine
+            const float ca[8] = {ca0.x * ps, ca0.y * ps, ca0.z * ps, ca0.w * ps, ca1.x * ps, ca1.y * ps, ca1.z * ps, ca1.w * ps};
+            const float cc[8] = {cc0.x * ps, cc0.y * ps, cc0.z * ps, cc0.w * ps, cc1.x * ps, cc1.y * ps, cc1.z * ps, cc1.w * ps};
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt) {
                     const uint32_t obase = o0 + mt * mt_stride + cg0;
@@ -411,8 +412,8 @@ __global__ __launch_bounds__(256, 2) void conv_up_halo_kernel(ConvArgs a, int ti
                     float v[8];
 #pragma unroll
                     for (int t = 0; t < 8; ++t) v[t] = fmaf(acc[hg >> 1][mt][8 * (hg & 1) + t], ca[t], cc[t]);
-                    act_drop_fixed<4, ACT, MODE>(v, e0, a.drop, key);
-                    act_drop_fixed<4, ACT, MODE>(v + 4, e0 + 8, a.drop, key);
+                    act_drop_fixed<4, ACT, MODE, true>(v, e0, a.drop, key);
+                    act_drop_fixed<4, ACT, MODE, true>(v + 4, e0 + 8, a.drop, key);
                     uint32_t p0 = pack_bf16x2(v[0], v[1]), p1 = pack_bf16x2(v[2], v[3]);
                     uint32_t q0 = pack_bf16x2(v[4], v[5]), q1 = pack_bf16x2(v[6], v[7]);
                     const auto s0 = __builtin_amdgcn_permlane32_swap(p0, q0, false, false);
