@@ -10,3 +10,4 @@ from . import checkpoint  # noqa: F401
 from . import metrics  # noqa: F401
 from .unet import Unet  # noqa: F401
 from .unet_simple import UNet  # noqa: F401
+from .simple_conv_net import SimpleConvNet  # noqa: F401

@@ -13,6 +13,7 @@ DYF_ABI_VERSION = 2
 DYF_OK, DYF_ERR_INVALID_ARGUMENT, DYF_ERR_UNSUPPORTED, DYF_ERR_HIP, DYF_ERR_STATE = range(5)
 NET_FORECASTER, NET_INTERPOLATOR = 0, 1
 ARCH_UNET_SIMPLE, ARCH_UNET_RESNET = 0, 1
+ARCH_SIMPLE_CONV_NET = 2
 FCOND = {"none": 0, "data": 1, "data+noise": 2}
 
 

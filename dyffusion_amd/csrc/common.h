@@ -34,12 +34,13 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
 }
 
 // ------------------------------------------------------------------------------------------------ activations
-enum { ACT_NONE = 0, ACT_RELU = 1, ACT_LEAKY = 2, ACT_SILU = 3 };
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_LEAKY = 2, ACT_SILU = 3, ACT_GELU = 4 };
 
 __device__ __forceinline__ float apply_act(float v, int act) {
     if (act == ACT_RELU) return fmaxf(v, 0.0f);
     if (act == ACT_LEAKY) return v > 0.0f ? v : 0.2f * v;
     if (act == ACT_SILU) return v / (1.0f + __expf(-v));
+    if (act == ACT_GELU) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));  // exact (erf) GELU, F.gelu default
     return v;
 }
 
@@ -126,6 +127,7 @@ __device__ __forceinline__ float act_fixed(float v) {
     if constexpr (ACT == ACT_RELU) return fmaxf(v, 0.0f);
     else if constexpr (ACT == ACT_LEAKY) return fmaxf(v, 0.2f * v);
     else if constexpr (ACT == ACT_SILU) return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));  // 1-ulp rcp, no IEEE divide
+    else if constexpr (ACT == ACT_GELU) return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
     else return v;
 }
 
@@ -133,14 +135,14 @@ __device__ __forceinline__ float act_fixed(float v) {
 // it into their affine coefficients (drop_prescale) and the dropout itself is a select.  SiLU keeps the multiply.
 template <int ACT, int MODE>
 __device__ __forceinline__ float drop_prescale(const DropSpec& d) {
-    return (MODE != 0 && ACT != ACT_SILU) ? d.scale : 1.0f;
+    return (MODE != 0 && (ACT == ACT_NONE || ACT == ACT_RELU || ACT == ACT_LEAKY)) ? d.scale : 1.0f;
 }
 
 template <int N, int ACT, int MODE, bool PRESCALED = false>
 __device__ __forceinline__ void act_drop_fixed(float* v, uint32_t e0, const DropSpec& d, uint32_t key) {
 #pragma unroll
     for (int t = 0; t < N; ++t) v[t] = act_fixed<ACT>(v[t]);
-    constexpr bool folded = PRESCALED && ACT != ACT_SILU;
+    constexpr bool folded = PRESCALED && (ACT == ACT_NONE || ACT == ACT_RELU || ACT == ACT_LEAKY);
     if constexpr (MODE == 1) {
         const uint32_t th = d.thresh16;
         const float sc = folded ? 1.0f : d.scale;

@@ -506,6 +506,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a, int M, i
 
 // ------------------------------------------------------------------------------------------------ launchers
 bool conv_mfma_supported(const ConvArgs& a) {
+    if (a.act == ACT_GELU) return false;  // the MFMA epilogues are instantiated for none / ReLU / LeakyReLU / SiLU
     if (!(a.c0 > 0 && (a.c0 % 64) == 0 && (a.c1 % 64) == 0 && (a.cout % 64) == 0)) return false;
     if (a.kh * a.kw > 32) return false;                       // tap-validity mask is 32 bits
     const size_t npix = (size_t)a.n * a.h * a.w;              // 32-bit buffer offsets

@@ -122,6 +122,7 @@ dyf_status net_forward(dyf_engine* e, int which, const Source* srcs, int nsrc, i
                        hipStream_t st) {
     Net& n = e->net[which];
     if (n.rn) return rn_forward(e, which, srcs, nsrc, nb, o, out_dev, st);
+    if (n.sc) return sc_forward(e, which, srcs, nsrc, nb, o, out_dev, st);
     Workspace& ws = e->ws;
     const int H = e->cfg.height, W = e->cfg.width;
     // ---- stem: outer resample + 1x1 conv
@@ -274,6 +275,8 @@ void dyf_engine_destroy(dyf_engine* e) {
     }
     rn_destroy(e->net[0]);
     rn_destroy(e->net[1]);
+    sc_destroy(e->net[0]);
+    sc_destroy(e->net[1]);
     if (e->cap_stream) (void)hipStreamDestroy(e->cap_stream);
     for (void* p : e->allocs) {
         conv_unregister_frag(p);
@@ -310,8 +313,8 @@ dyf_status dyf_engine_create(const dyf_engine_config* cfg, dyf_engine** out_engi
     for (int w = 0; w < 2; ++w) {
         Net& n = e->net[w];
         n.cfg = cfg->net[w];
-        if (n.cfg.arch != DYF_ARCH_UNET_SIMPLE && n.cfg.arch != DYF_ARCH_UNET_RESNET)
-            return bail(DYF_ERR_UNSUPPORTED, "arch must be unet_simple (0) or unet / resnet (1)");
+        if (n.cfg.arch != DYF_ARCH_UNET_SIMPLE && n.cfg.arch != DYF_ARCH_UNET_RESNET && n.cfg.arch != DYF_ARCH_SIMPLE_CONV_NET)
+            return bail(DYF_ERR_UNSUPPORTED, "arch must be unet_simple (0), unet / resnet (1) or simple_conv_net (2)");
         if (n.cfg.dim < 4 || (n.cfg.dim & 1)) return bail(DYF_ERR_INVALID_ARGUMENT, "dim must be even and >= 4");
         if (n.cfg.input_dropout != 0.0f) return bail(DYF_ERR_UNSUPPORTED, "input_dropout > 0 is not implemented");
         if (n.cfg.dropout < 0.0f || n.cfg.dropout >= 1.0f) return bail(DYF_ERR_INVALID_ARGUMENT, "dropout must be in [0, 1)");
@@ -324,6 +327,11 @@ dyf_status dyf_engine_create(const dyf_engine_config* cfg, dyf_engine** out_engi
             if (n.cfg.block_dropout1 < 0.0f || n.cfg.block_dropout1 >= 1.0f || n.cfg.attn_dropout < 0.0f || n.cfg.attn_dropout >= 1.0f)
                 return bail(DYF_ERR_INVALID_ARGUMENT, "dropout rates must be in [0, 1)");
             std::string m = rn_configure(e, n);
+            if (!m.empty()) return bail(DYF_ERR_INVALID_ARGUMENT, m);
+            continue;
+        }
+        if (n.cfg.arch == DYF_ARCH_SIMPLE_CONV_NET) {
+            std::string m = sc_configure(e, n);
             if (!m.empty()) return bail(DYF_ERR_INVALID_ARGUMENT, m);
             continue;
         }
@@ -377,6 +385,8 @@ dyf_status dyf_engine_create(const dyf_engine_config* cfg, dyf_engine** out_engi
     {
         dyf_status rs = rn_alloc_workspace(e);
         if (rs != DYF_OK) return bail(rs, e->err);
+        rs = sc_alloc_workspace(e);
+        if (rs != DYF_OK) return bail(rs, e->err);
     }
     *out_engine = e;
     return DYF_OK;
@@ -403,6 +413,7 @@ dyf_status dyf_load_weights(dyf_engine* e, int32_t which, int32_t n_tensors, con
         v.shape.assign(shapes[i], shapes[i] + ndims[i]);
         sd[names[i]] = v;
     }
+    if (n.sc) return sc_load_weights(e, n, sd);
     if (n.rn) {
         dyf_status rs = rn_load_weights(e, n, sd);
         if (rs != DYF_OK) return rs;
@@ -896,7 +907,7 @@ dyf_status dyf_time_conv_layer(dyf_engine* e, int32_t which, int32_t layer, int3
         return fail(e, DYF_ERR_INVALID_ARGUMENT, "bad argument to dyf_time_conv_layer");
     Net& n = e->net[which];
     if (!n.loaded) return fail(e, DYF_ERR_STATE, "weights not loaded");
-    if (n.rn) return fail(e, DYF_ERR_UNSUPPORTED, "dyf_time_conv_layer addresses the 12 UNetBlocks of arch unet_simple");
+    if (n.rn || n.sc) return fail(e, DYF_ERR_UNSUPPORTED, "dyf_time_conv_layer addresses the 12 UNetBlocks of arch unet_simple");
     if (nb < 1 || nb > e->cfg.max_batch) return fail(e, DYF_ERR_INVALID_ARGUMENT, "batch size outside [1, max_batch]");
     HIP_TRY(e, hipSetDevice(e->cfg.device));
     hipStream_t st = (hipStream_t)stream;
@@ -979,7 +990,7 @@ dyf_status dyf_time_layer_in_rollout(dyf_engine* e, int32_t layer, int32_t nb, v
                                      int32_t* launches) {
     if (!e || layer < 6 || layer > 11 || !avg_ms) return fail(e, DYF_ERR_INVALID_ARGUMENT, "decoder layer 6..11 expected");
     if (!e->plan.set || !e->s_init) return fail(e, DYF_ERR_STATE, "needs a plan and one earlier dyf_sample call (its inputs are re-used)");
-    if (e->net[0].rn || e->net[1].rn) return fail(e, DYF_ERR_UNSUPPORTED, "arch unet_simple only");
+    if (e->net[0].rn || e->net[1].rn || e->net[0].sc || e->net[1].sc) return fail(e, DYF_ERR_UNSUPPORTED, "arch unet_simple only");
     if (nb < 1 || nb > e->cfg.max_batch) return fail(e, DYF_ERR_INVALID_ARGUMENT, "batch size outside [1, max_batch]");
     HIP_TRY(e, hipSetDevice(e->cfg.device));
     hipStream_t st = (hipStream_t)stream;

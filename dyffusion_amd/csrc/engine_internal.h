@@ -16,6 +16,7 @@
 namespace dyf {
 
 struct RNet;  // ResNet-UNet state (unet_resnet.hip)
+struct SNet;  // SimpleConvNet state (simple_conv_net.hip)
 
 inline thread_local std::string g_create_error;
 
@@ -60,6 +61,7 @@ struct Net {
     double flops_per_sample = 0.0;
     int n_drop_sites = 12;   // dropout sites with p > 0 per forward (mask-injection cursor); 12 UNetBlocks for unet_simple
     struct RNet* rn = nullptr;  // arch == DYF_ARCH_UNET_RESNET: all state lives here (unet_resnet.hip)
+    struct SNet* sc = nullptr;  // arch == DYF_ARCH_SIMPLE_CONV_NET (simple_conv_net.hip)
     // sampler coefficient tables: one (A, C) row pair per distinct time value
     std::map<float, int> table_of_time;
     float* tables = nullptr;  // device [ntables][2][total_c]
@@ -195,6 +197,16 @@ struct FwdOpts {
 };
 
 
+}  // namespace dyf
+
+// ---- SimpleConvNet backbone (src/models/simple_conv_net.py), implemented in simple_conv_net.hip
+namespace dyf {
+std::string sc_configure(dyf_engine* e, Net& n);
+dyf_status sc_alloc_workspace(dyf_engine* e);
+dyf_status sc_load_weights(dyf_engine* e, Net& n, std::map<std::string, TensorView>& sd);
+dyf_status sc_forward(dyf_engine* e, int which, const Source* srcs, int nsrc, int nb, const FwdOpts& o, float* out_dev,
+                      hipStream_t st);
+void sc_destroy(Net& n);
 }  // namespace dyf
 
 // ---- ResNet-UNet backbone (src/models/unet.py), implemented in unet_resnet.hip

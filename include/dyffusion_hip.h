@@ -46,7 +46,9 @@ typedef enum dyf_net_id { DYF_NET_FORECASTER = 0, DYF_NET_INTERPOLATOR = 1 } dyf
 /* Backbone architectures (src/models/). */
 typedef enum dyf_arch {
     DYF_ARCH_UNET_SIMPLE = 0, /* src/models/unet_simple.py:85-197 (Navier-Stokes / spring-mesh backbone) */
-    DYF_ARCH_UNET_RESNET = 1  /* src/models/unet.py:112-315 (OISST / synthetic backbone: ResnetBlocks + attention) */
+    DYF_ARCH_UNET_RESNET = 1, /* src/models/unet.py:112-315 (OISST / synthetic backbone: ResnetBlocks + attention) */
+    DYF_ARCH_SIMPLE_CONV_NET = 2 /* src/models/simple_conv_net.py:58-131 (spring-mesh backbone); kernel_sizes travel in
+                                  * n_mults / dim_mults, dropout in `dropout` */
 } dyf_arch;
 
 /* Hyper-parameters of one backbone: the kwargs of unet_simple.UNet.__init__ (unet_simple.py:86-95) plus the

@@ -24,6 +24,17 @@ def test_mirror_state_dict_matches_reference_layout():
         assert got == {k: tuple(v) for k, v in want.items()}
 
 
+def test_simple_conv_net_mirror_state_dict_matches_reference_layout():
+    ks = [9, 7, 5, 3]
+    net = D.SimpleConvNet(dim=8, with_time_emb=True, kernel_sizes=ks, dropout=0.1, num_input_channels=8,
+                          num_output_channels=4, num_conditional_channels=1)
+    want = oinit.simple_conv_net_param_shapes(8, 9, 4, ks)  # == reference layout (tests/golden/net_simple_conv.npz)
+    got = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+    assert got == {k: tuple(v) for k, v in want.items()}
+    cfg = net.engine_net_config()
+    assert cfg.arch == 2 and cfg.n_mults == 4 and list(cfg.dim_mults[:4]) == ks
+
+
 def _pair(h, **kw):
     F = D.UNet(dim=8, with_time_emb=True, upsample_dims=[64, 64], num_input_channels=4, num_output_channels=4,
                num_conditional_channels=1)
