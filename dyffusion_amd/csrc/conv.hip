@@ -568,7 +568,9 @@ hipError_t launch_conv(const ConvArgs& a, int path, hipStream_t stream) {
             // 256 x 128 tiles pay off once they fill the chip (2 workgroups x 256 CUs); below that the 128 x 128 form's
             // finer tiles win (measured at NB = 50: dec2/enc2 with 400 tiles +9 %/+4 %, enc3 with 200 tiles -20 %)
             const long long tiles2 = (((long long)a.n * a.ho * a.wo + 255) / 256) * (a.cout / 128);
-            if (tiles2 >= 384 && conv_igemm2_supported(b)) return launch_conv_igemm2(b, stream);
+            const char* mt = getenv("DYF_IGEMM2_MIN_TILES");  // tests force the form on small problems
+            const long long min_tiles = mt ? atoll(mt) : 384;
+            if (tiles2 >= min_tiles && conv_igemm2_supported(b)) return launch_conv_igemm2(b, stream);
         }
         if (a.cout % 128 == 0)
             return a.up2x ? launch_igemm<128, 128, 2, 2, 1>(a, stream) : launch_igemm<128, 128, 2, 2, 0>(a, stream);

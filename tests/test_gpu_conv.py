@@ -63,6 +63,42 @@ def test_conv_matches_torch(engine, case, path):
         assert rel_rms(got, want) <= 4e-3
 
 
+IGEMM2_CASES = [
+    (2, 16, 16, 64, 128, 3, 1, 1),
+    (1, 32, 32, 64, 128, 4, 2, 1),
+    (1, 20, 12, 128, 256, 3, 1, 1),     # M = 240 < one 256-row tile, raster tiling
+    (5, 4, 4, 512, 512, 2, 2, 0),       # a tile spans several samples
+    (3, 33, 17, 64, 128, 3, 1, 1),      # odd plane: raster tiling, 7 tiles with a ragged last one
+    (1, 64, 64, 128, 128, 1, 1, 0),
+    (2, 32, 48, 192, 256, 3, 1, 1),     # 2-D tiles (16 x 16 output tiles), three 64-channel chunks
+]
+
+
+@pytest.mark.parametrize("case", IGEMM2_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_second_igemm_form_matches_torch(engine, case, monkeypatch):
+    """conv_igemm2_kernel (256 x 128 tiles, weights streamed in fragment order) is selected by tile count in production;
+    DYF_IGEMM2_MIN_TILES=1 forces it on these small problems.  Checked against torch and against the 128 x 128 form."""
+    n, h, w, cin, cout, k, stride, pad = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(n, h, w, cin, generator=g).to(torch.bfloat16)
+    wt = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    scale = 1.0 + 0.3 * torch.randn(n, cout, generator=g)
+    shift = 0.2 * torch.randn(n, cout, generator=g)
+    monkeypatch.setenv("DYF_IGEMM2_MIN_TILES", "1000000000")
+    first = engine.op_conv2d(x.cuda(), wt, stride, pad, scale.cuda(), shift.cuda(), act=2, path=1).float().cpu()
+    monkeypatch.setenv("DYF_IGEMM2_MIN_TILES", "1")
+    for act, use_coef in [(0, False), (2, True), (1, True)]:
+        y = engine.op_conv2d(x.cuda(), wt, stride, pad, scale.cuda() if use_coef else None,
+                             shift.cuda() if use_coef else None, act=act, path=1)
+        want = reference(x, wt, stride, pad, scale if use_coef else None, shift if use_coef else None, act)
+        got = y.float().cpu()
+        tol = 1.5 * 2 ** -8 * float(want.abs().max()) + 1e-3
+        assert max_abs(got, want) <= tol, (case, act, max_abs(got, want), tol)
+        assert rel_rms(got, want) <= 4e-3
+        if act == 2:
+            assert rel_rms(got, first) <= 2.5e-3  # the two MFMA forms differ by summation order only
+
+
 def test_mfma_and_direct_agree_closely(engine):
     # both accumulate in fp32 from identical bf16 operands: they differ only by summation order (+ final rounding)
     g = torch.Generator().manual_seed(7)
