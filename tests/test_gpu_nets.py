@@ -102,9 +102,12 @@ def test_rows_are_independent():
         assert torch.equal(one[0], full[r]), f"row {r} depends on its batch neighbours"
 
 
-def test_fullsize_ns_forwards_match_reference_fields():
+@pytest.mark.parametrize("force_igemm2", [False, True], ids=["default-conv-forms", "second-igemm-form"])
+def test_fullsize_ns_forwards_match_reference_fields(force_igemm2, monkeypatch):
     """BASELINE config 2 shapes (221x42 -> 256^2, dim 64): one forecaster + one interpolator forward vs the
-    reference's own outputs (fixture G6)."""
+    reference's own outputs (fixture G6).  force_igemm2: the conv form production picks at bench batch sizes."""
+    if force_igemm2:
+        monkeypatch.setenv("DYF_IGEMM2_MIN_TILES", "1")
     meta, fields = jload("fullsize_checksums.json"), load_npz("fullsize_ns_fields.npz")
     mk = meta["model"]
     PF = oinit.seeded_state(oinit.unet_simple_param_shapes(64, 5, 3), meta["seeds"]["forecaster"])

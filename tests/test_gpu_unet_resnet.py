@@ -71,9 +71,14 @@ def seeded_unet(dim, mults, cin, cout, seed):
     return st
 
 
+@pytest.mark.parametrize("force_igemm2", [False, True], ids=["default-conv-forms", "second-igemm-form"])
 @pytest.mark.parametrize("hw,nb,n_in,n_cond", [((60, 60), 2, 2, 0), ((32, 48), 2, 1, 1)])
-def test_dim64_oisst_shape_matches_oracle(hw, nb, n_in, n_cond):
-    """OISST configuration of the reference (dim 64, mults (1,2,4), 60x60): MFMA conv path."""
+def test_dim64_oisst_shape_matches_oracle(hw, nb, n_in, n_cond, force_igemm2, monkeypatch):
+    """OISST configuration of the reference (dim 64, mults (1,2,4), 60x60): MFMA conv path.  force_igemm2: every conv with
+    cout % 128 == 0 (two-source skip convs, fp32 GroupNorm inputs, residual epilogues) through conv_igemm2_kernel, which
+    production selects only for large batches."""
+    if force_igemm2:
+        monkeypatch.setenv("DYF_IGEMM2_MIN_TILES", "1")
     cfg = dict(dim=64, dim_mults=[1, 2, 4], with_time_emb=True, block_dropout=0.3, block_dropout1=0.1, attn_dropout=0.2,
                resnet_block_groups=8, input_dropout=0.0, upsample_dims=None)
     P = seeded_unet(64, (1, 2, 4), n_in + n_cond, 1, seed=51)
