@@ -35,6 +35,7 @@ struct ConvArgs {
     const float* coef_a;
     const float* coef_c;
     int coef_stride;
+    int coef_div;        // samples per coefficient row (0/1: one row per sample; paired interpolator calls use nb)
     int act;
     DropSpec drop;
     const bf16_t* residual;  // NHWC bf16 tensor added after activation/dropout (Residual(...) wrappers), or null

@@ -69,7 +69,7 @@ __global__ void conv_direct_kernel(ConvArgs a, long long total) {
             }
         }
     }
-    const size_t ci = (size_t)n * a.coef_stride + co;
+    const size_t ci = (size_t)(a.coef_div > 1 ? n / a.coef_div : n) * a.coef_stride + co;
     float v = fmaf(acc, a.coef_a[ci], a.coef_c[ci]);
     v = apply_act(v, a.act);
     const uint32_t e = (uint32_t)(m * a.cout + co);
@@ -450,7 +450,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a, int M, i
                 n_img = m / plane;
             }
             const uint32_t ob = (uint32_t)m * (uint32_t)a.cout + (uint32_t)(tn * BN + wn * 64);
-            const uint32_t cb = (uint32_t)(n_img * a.coef_stride + tn * BN + wn * 64 + 4 * hi);
+            const uint32_t cb = (uint32_t)((a.coef_div > 1 ? n_img / a.coef_div : n_img) * a.coef_stride + tn * BN + wn * 64 + 4 * hi);
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll

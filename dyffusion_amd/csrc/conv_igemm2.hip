@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(ConvArgs a, int M, 
     // ---- per-lane gather descriptors (as conv.hip): DMA row (j*4 + wave)*8 + sub, LDS slot swizzled by (row >> 1) & 7
     const int sub = lane >> 3;
     const int gchunk = (lane & 7) ^ ((((wave & 1) << 2) | (sub >> 1)) & 7);
-    int a_pix[RA];        // pixel index of tap (0,0): may be slightly negative, |.| < 2^23 (host-checked)
+    int a_pix[RA];        // pixel index of tap (0,0): may be slightly negative (offsets are formed modulo 2^32)
     unsigned a_mask[RA];  // tap validity bits
 #pragma unroll
     for (int j = 0; j < RA; ++j) {
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(ConvArgs a, int M, 
         const unsigned pitch_b = (unsigned)(csrc * 2);
 #pragma unroll
         for (int j = 0; j < RA; ++j) {
-            const unsigned vo = (a_mask[j] & tap_bit) ? (unsigned)__mul24(a_pix[j], (int)pitch_b) + toff : 0xFFFFFFFFu;
+            const unsigned vo = (a_mask[j] & tap_bit) ? (unsigned)(a_pix[j] * (int)pitch_b) + toff : 0xFFFFFFFFu;
             if (second)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a1, LDS_PTR(As + (j * 4 + wave) * 1024), 16, vo, 0, 0, 0);
             else
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(ConvArgs a, int M, 
                 n_img = m / plane;
             }
             const uint32_t ob = (uint32_t)m * (uint32_t)a.cout + (uint32_t)(tn * BN + wn * 64);
-            const uint32_t cb = (uint32_t)(n_img * a.coef_stride + tn * BN + wn * 64 + 4 * hi);
+            const uint32_t cb = (uint32_t)((a.coef_div > 1 ? n_img / a.coef_div : n_img) * a.coef_stride + tn * BN + wn * 64 + 4 * hi);
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
@@ -309,7 +309,7 @@ bool conv_igemm2_supported(const ConvArgs& a) {
     if (a.kh * a.kw > 32) return false;
     const size_t npix = (size_t)a.n * a.h * a.w;
     const int pitch0 = a.pix_pitch0 ? a.pix_pitch0 : a.c0;
-    return npix < (1ull << 23) - 65536 && pitch0 * 2 < (1 << 22) && a.c1 * 2 < (1 << 22) && npix * pitch0 * 2 < 0x7F000000ull && npix * (size_t)a.c1 * 2 < 0x7F000000ull &&
+    return npix * pitch0 * 2 < 0x7F000000ull && npix * (size_t)a.c1 * 2 < 0x7F000000ull &&
            (size_t)a.cout * a.kh * a.kw * (a.c0 + a.c1) * 2 < 0x7F000000ull && (size_t)a.n * a.ho * a.wo * a.cout < 0xFFFFFFF0ull;
 }
 

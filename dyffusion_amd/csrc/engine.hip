@@ -135,7 +135,7 @@ dyf_status net_forward(dyf_engine* e, int which, const Source* srcs, int nsrc, i
     }
     if (ctot != n.cin_total)
         return fail(e, DYF_ERR_INVALID_ARGUMENT, "channel count of the network inputs does not match its configuration");
-    sa.nsrc = nsrc; sa.cin = ctot; sa.n = nb; sa.h = H; sa.w = W; sa.uh = n.uh; sa.uw = n.uw;
+    sa.nsrc = nsrc; sa.cin = ctot; sa.n = nb; sa.src_rows = o.src_rows; sa.h = H; sa.w = W; sa.uh = n.uh; sa.uw = n.uw;
     sa.resample = (n.uh != H || n.uw != W) ? 1 : 0;
     sa.wgt = n.stem_w; sa.bias = n.stem_b; sa.dim = n.dim;
     const bool fused_stem = n.stem_fused && e->cfg.enable_mfma && e->fuse_stem;
@@ -155,6 +155,7 @@ dyf_status net_forward(dyf_engine* e, int which, const Source* srcs, int nsrc, i
         if (i == 0 && fused_stem) fused_enc0_args(e, n, a);
         if (!b.gn) {
             a.coef_a = o.coef_a + b.film_off; a.coef_c = o.coef_c + b.film_off; a.coef_stride = o.coef_stride;
+            a.coef_div = o.coef_div;
             a.drop = make_drop(e, n, o, i);
             a.out_bf16 = ws.enc[i];
             dyf_status s = run_conv(e, a, st);
@@ -170,6 +171,7 @@ dyf_status net_forward(dyf_engine* e, int which, const Source* srcs, int nsrc, i
             g.x = ws.enc5_raw; g.n = nb; g.hw = b.out_h * b.out_w; g.c = b.cout; g.groups = 8;
             g.gamma = b.gamma; g.beta = b.beta;
             g.film_a = o.coef_a + b.film_off; g.film_c = o.coef_c + b.film_off; g.film_stride = o.coef_stride;
+            g.film_div = o.coef_div;
             g.act = b.act; g.drop = make_drop(e, n, o, i); g.out = ws.enc[i];
             HIP_TRY(e, launch_groupnorm(g, st));
         }
@@ -184,6 +186,7 @@ dyf_status net_forward(dyf_engine* e, int which, const Source* srcs, int nsrc, i
         const UBlock& b = n.blk[i];
         ConvArgs a = block_conv_args(e, n, b, nb);
         a.coef_a = o.coef_a + b.film_off; a.coef_c = o.coef_c + b.film_off; a.coef_stride = o.coef_stride;
+        a.coef_div = o.coef_div;
         a.drop = make_drop(e, n, o, i);
         a.out_bf16 = ws.dec[i - 6];
         // fused form: the conv gathers straight from the low-res cat[x, skip] (phase decomposition, conv.hip)
@@ -220,7 +223,10 @@ dyf_status net_forward(dyf_engine* e, int which, const Source* srcs, int nsrc, i
             if (s != DYF_OK) return s;
             if (prof) HIP_TRY(e, hipEventRecord(pe1, st));
         }
-        if (prof) e->prof_ev.emplace_back(pe0, pe1);
+        if (prof) {
+            e->prof_ev.emplace_back(pe0, pe1);
+            e->prof_rows.push_back(nb);
+        }
         x = ws.dec[i - 6];
         lh = b.out_h; lw = b.out_w;
         if (i < 11) {
@@ -301,6 +307,7 @@ dyf_status dyf_engine_create(const dyf_engine_config* cfg, dyf_engine** out_engi
     if (const char* fu = getenv("DYF_FUSE_UP2X")) e->fuse_up2x = atoi(fu) != 0;
     if (const char* fm = getenv("DYF_FUSE_MIN_PLANE")) e->fuse_min_plane = atoi(fm);
     if (const char* fs = getenv("DYF_FUSE_STEM")) e->fuse_stem = atoi(fs) != 0;
+    if (const char* pi = getenv("DYF_PAIR_INTERP")) e->pair_interp = atoi(pi) != 0;
     if (conv_init() != hipSuccess || hipStreamCreateWithFlags(&e->cap_stream, hipStreamNonBlocking) != hipSuccess) {
         delete e;
         return fail(nullptr, DYF_ERR_HIP, "engine initialisation failed (conv_init / stream create)");
@@ -341,7 +348,8 @@ dyf_status dyf_engine_create(const dyf_engine_config* cfg, dyf_engine** out_engi
         if (!m.empty()) return bail(DYF_ERR_INVALID_ARGUMENT, m);
     }
     // ---- workspace (sized for max_batch, shared by the two networks which run back to back)
-    const size_t nb = (size_t)cfg->max_batch;
+    // sized for 2 x max_batch rows: the sampler runs the two interpolator calls of a step as ONE forward over 2 nb rows
+    const size_t nb = (size_t)cfg->max_batch * 2;
     size_t stem_el = 0, enc_el[6] = {}, dec_el[6] = {}, up_el = 0, raw_el = 0, tc = 0, td = 0;
     for (int w = 0; w < 2; ++w) {
         const Net& n = e->net[w];
@@ -379,6 +387,8 @@ dyf_status dyf_engine_create(const dyf_engine_config* cfg, dyf_engine** out_engi
     ALLOC(ws.coef_a, nb * tc);
     ALLOC(ws.coef_c, nb * tc);
     ALLOC(ws.zero_page, 256);
+    ALLOC(ws.coef_pair, 4 * tc);
+    ALLOC(e->s_pair, 2 * (size_t)cfg->max_batch * DYF_MAX_OUT_CH * cfg->height * cfg->width);
     ALLOC(e->s_time, 64);
     ALLOC(e->rng_state, 4);
 #undef ALLOC
@@ -779,6 +789,25 @@ dyf_status run_plan(dyf_engine* e, int nb, const uint8_t* const* masks, const fl
         return net_forward(e, DYF_NET_INTERPOLATOR, srcs, ns, nb, o, out, st);
     };
 
+    // Two interpolator calls with the same inputs and different times as ONE forward over 2 nb rows (rows [0, nb): t_a,
+    // rows [nb, 2 nb): t_b): same arithmetic per row, but the small layers and the tile counts of the mid layers see twice
+    // the batch.  The FiLM coefficient rows of the two times are staged next to each other; out: [2][nb][C][H][W].
+    // Not with injected masks (their layout is one tensor per forward and site) and only for arch unet_simple.
+    const bool can_pair = !inject && !I.rn && !I.sc && e->pair_interp;
+    auto interp2 = [&](float ta, float tb, const float* x_last, float* out2) -> dyf_status {
+        const size_t row = (size_t)2 * I.total_c;
+        HIP_TRY(e, hipMemcpyAsync(e->ws.coef_pair, I.tables + (size_t)I.table_of_time.at(ta) * row, row * sizeof(float),
+                                  hipMemcpyDeviceToDevice, st));
+        HIP_TRY(e, hipMemcpyAsync(e->ws.coef_pair + row, I.tables + (size_t)I.table_of_time.at(tb) * row, row * sizeof(float),
+                                  hipMemcpyDeviceToDevice, st));
+        Source srcs[3] = {{e->s_init, e->wC}, {x_last, e->C}, {e->s_static, e->Cs}};
+        const int ns = e->Cs > 0 ? 3 : 2;
+        FwdOpts o{e->ws.coef_pair, e->ws.coef_pair + I.total_c, (int)row, i_mode, nullptr};
+        o.src_rows = nb;
+        o.coef_div = nb;
+        return net_forward(e, DYF_NET_INTERPOLATOR, srcs, ns, 2 * nb, o, out2, st);
+    };
+
     // x_s = initial_condition[:, -C:]  (dyffusion.py:348); rows are (window*C, H, W) blocks -> strided copy per sample
     if (e->wC == e->C) {
         HIP_TRY(e, hipMemcpyAsync(e->s_xs, e->s_init, fbytes, hipMemcpyDeviceToDevice, st));
@@ -812,6 +841,17 @@ dyf_status run_plan(dyf_engine* e, int nb, const uint8_t* const* masks, const fl
         }
         // ---- x_next = I(x0, x0_hat, i(s_next))   (dyffusion.py:374-379)
         const float* x_next = e->s_x0hat;
+        const bool cold_pair = can_pair && ph.hdr.sampling_cold && !(s.is_last && !ph.hdr.cold_for_last_step) &&
+                               s.i_next >= 0.0f && s.i_cur >= 0.0f;
+        if (cold_pair) {  // both interpolations of this step in one forward: s_pair = [I(.., s_next) ; I(.., s)]
+            dyf_status r = interp2(s.i_next, s.i_cur, e->s_x0hat, e->s_pair);
+            if (r != DYF_OK) return r;
+            HIP_TRY(e, launch_cold_update(e->s_xs, e->s_pair + field, e->s_pair, (long long)field, st));
+            if (s.out_slot >= 0)
+                HIP_TRY(e, hipMemcpyAsync(e->s_stack + (size_t)s.out_slot * field, e->s_xs, fbytes, hipMemcpyDeviceToDevice, st));
+            ++step_idx;
+            continue;
+        }
         if (s.i_next >= 0.0f) {
             dyf_status r = interp(s.i_next, e->s_x0hat, e->s_next);
             if (r != DYF_OK) return r;
@@ -837,6 +877,14 @@ dyf_status run_plan(dyf_engine* e, int nb, const uint8_t* const* masks, const fl
     }
     // ---- refinement of the intermediate predictions with the final x0_hat (dyffusion.py:408-422)
     for (size_t r = 0; r < ph.refine_times.size(); ++r) {
+        if (can_pair && r + 1 < ph.refine_times.size() && ph.refine_slots[r + 1] == ph.refine_slots[r] + 1) {
+            // two consecutive output slots are one contiguous [2][nb][C][H][W] block of the forecast stack
+            dyf_status rs = interp2(ph.refine_times[r], ph.refine_times[r + 1], e->s_x0hat,
+                                    e->s_stack + (size_t)ph.refine_slots[r] * field);
+            if (rs != DYF_OK) return rs;
+            ++r;
+            continue;
+        }
         dyf_status rs = interp(ph.refine_times[r], e->s_x0hat, e->s_stack + (size_t)ph.refine_slots[r] * field);
         if (rs != DYF_OK) return rs;
     }
@@ -996,6 +1044,7 @@ dyf_status dyf_time_layer_in_rollout(dyf_engine* e, int32_t layer, int32_t nb, v
     hipStream_t st = (hipStream_t)stream;
     e->prof_layer = layer;
     e->prof_ev.clear();
+    e->prof_rows.clear();
     dyf_status r = run_plan(e, nb, nullptr, nullptr, st);  // eager launch of the whole rollout, not the captured graph
     e->prof_layer = -1;
     hipError_t se = hipStreamSynchronize(st);
@@ -1007,11 +1056,15 @@ dyf_status dyf_time_layer_in_rollout(dyf_engine* e, int32_t layer, int32_t nb, v
         (void)hipEventDestroy(pr.second);
     }
     const size_t cnt = e->prof_ev.size();
+    // a paired interpolator launch covers 2 nb rows: report time per nb-row launch equivalent
+    double units = 0.0;
+    for (int rws : e->prof_rows) units += (double)rws / (double)nb;
     e->prof_ev.clear();
+    e->prof_rows.clear();
     if (r != DYF_OK) return r;
     if (se != hipSuccess) return fail(e, DYF_ERR_HIP, std::string("rollout: ") + hipGetErrorString(se));
     if (cnt == 0) return fail(e, DYF_ERR_STATE, "layer was not launched");
-    *avg_ms = tot / (double)cnt;
+    *avg_ms = tot / units;
     if (launches) *launches = (int32_t)cnt;
     return DYF_OK;
 }

@@ -79,6 +79,7 @@ struct Workspace {
     float* coef_a = nullptr;
     float* coef_c = nullptr;
     bf16_t* zero_page = nullptr;
+    float* coef_pair = nullptr;  // [2][2][total_c]: FiLM coefficient rows of a paired interpolator call
 };
 
 struct PlanHost {
@@ -119,6 +120,9 @@ struct dyf_engine {
     double* metric_sums = nullptr;  // dyf_ensemble_metrics accumulators (device)
     int prof_layer = -1;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_ev;
+    std::vector<int> prof_rows;
+    float* s_pair = nullptr;        // [2][max_batch][C][H][W]: outputs of a paired interpolator call
+    bool pair_interp = true;        // DYF_PAIR_INTERP=0: one forward per interpolator call (A/B testing)
 };
 
 namespace dyf {
@@ -194,6 +198,8 @@ struct FwdOpts {
     int coef_stride;          // 0: one row for the whole batch
     int dropout_mode;         // 0 off, 1 engine RNG, 2 injected
     const uint8_t* const* masks;  // [12] when dropout_mode == 2
+    int src_rows = 0;         // rows of the source tensors (0: = nb); row r of the batch reads source row r % src_rows
+    int coef_div = 0;         // batch rows per coefficient row (0/1: coef_stride semantics unchanged)
 };
 
 

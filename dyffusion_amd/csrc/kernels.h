@@ -41,6 +41,8 @@ struct StemArgs {
     int ch[4];
     int nsrc, cin;          // cin = sum(ch)
     int n, h, w;            // native grid
+    int src_rows;           // rows held by the source tensors (0: = n); output row r reads source row r % src_rows, so
+                            // one launch can run the same inputs under several FiLM rows (paired interpolator calls)
     int uh, uw;             // resampled grid (== h, w when there is no outer resampling)
     int resample;           // 0: identity, 1: bilinear (align_corners=False)
     const float* wgt;       // [dim][cin] fp32
@@ -73,6 +75,7 @@ struct GroupNormArgs {
     const float* film_a;    // [rows][...] (1+scale) at film_off + ch ; stride film_stride (0 = broadcast)
     const float* film_c;
     int film_stride;
+    int film_div;           // samples per coefficient row (0/1: one row per sample)
     int act;
     DropSpec drop;
     bf16_t* out;

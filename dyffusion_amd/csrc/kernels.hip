@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256) void stem_kernel(StemArgs a) {
         }
         int cbase = 0;
         for (int s = 0; s < a.nsrc; ++s) {
-            const float* src = a.src[s] + (size_t)n * a.ch[s] * a.h * a.w;
+            const float* src = a.src[s] + (size_t)(a.src_rows > 0 ? n % a.src_rows : n) * a.ch[s] * a.h * a.w;
             for (int c = 0; c < a.ch[s]; ++c) {
                 const float* p = src + (size_t)c * a.h * a.w;
                 const float v00 = p[y0 * a.w + x0], v01 = p[y0 * a.w + x1];
@@ -183,7 +183,7 @@ __global__ __launch_bounds__(256) void stem16_kernel(StemArgs a) {
         for (int c = 0; c < 16; ++c) v[c] = 0.0f;
         int cbase = 0;
         for (int s = 0; s < a.nsrc; ++s) {
-            const float* src = a.src[s] + (size_t)n * a.ch[s] * a.h * a.w;
+            const float* src = a.src[s] + (size_t)(a.src_rows > 0 ? n % a.src_rows : n) * a.ch[s] * a.h * a.w;
             for (int c = 0; c < a.ch[s]; ++c) {
                 const float* p = src + (size_t)c * a.h * a.w;
                 const float top = p[y0 * a.w + x0] * (1.0f - lx) + p[y0 * a.w + x1] * lx;
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(256) void groupnorm_kernel(GroupNormArgs a) {
     for (int i = threadIdx.x; i < count; i += blockDim.x) {
         const int p = i / cpg, ch = g * cpg + (i % cpg);
         float y = (x[(size_t)p * a.c + (i % cpg)] - mean) * rstd * a.gamma[ch] + a.beta[ch];
-        const size_t fi = (size_t)n * a.film_stride + ch;
+        const size_t fi = (size_t)(a.film_div > 1 ? n / a.film_div : n) * a.film_stride + ch;
         y = fmaf(y, a.film_a[fi], a.film_c[fi]);
         y = apply_act(y, a.act);
         const size_t e = ((size_t)n * a.hw + p) * a.c + ch;
