@@ -206,6 +206,17 @@ __global__ __launch_bounds__(256, 2) void conv_up_halo_kernel(ConvArgs a, int ti
             ax[mt] = (unsigned)((hi ^ ((hpm >> 1) & 7)) << 4);                                               \
         }                                                                                                    \
     }
+    // the same for a correction tap: lanes whose pixel is not on the border (KEEP false) read the zero page
+#define TAPADDR_MASKED(DISP, KEEP)                                                                           \
+    {                                                                                                        \
+        int hpb = hp0;                                                                                       \
+        asm volatile("" : "+v"(hpb));                                                                        \
+        _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) {                                                   \
+            const int hpm = hpb + (DISP) + 2 * HALO_W * mt;                                                  \
+            ab[mt] = (KEEP) ? Hs + hpm * 128 : lds_base + ZERO_OFF;                                          \
+            ax[mt] = (KEEP) ? (unsigned)((hi ^ ((hpm >> 1) & 7)) << 4) : 0u;                                 \
+        }                                                                                                    \
+    }
 #define RDA1(SET, KS, MT)                                                                                    \
     {                                                                                                        \
         const unsigned pm = (ax[MT] ^ (unsigned)((KS) << 5)) + ab[MT];                                       \
@@ -231,14 +242,18 @@ __global__ __launch_bounds__(256, 2) void conv_up_halo_kernel(ConvArgs a, int ti
         MF(1, 0, USE_A, USE_B) PIN                                                                           \
         MF(1, 1, USE_A, USE_B) MF(1, 2, USE_A, USE_B) MF(1, 3, USE_A, USE_B) PIN                             \
     }
-#define STENCIL_STEP(DISP, HAS_NEXT, DNEXT)                                                                  \
+#define STEP_CORE(HAS_NEXT, NEXT_ADDR)                                                                       \
     {                                                                                                        \
         SLOT(3, soff_cur, 3, true, NO_PRE, 1, 1, 0, 0)                                                       \
         SLOT(0, soff_next, 0, true, NO_PRE, 0, 2, 1, 1)                                                      \
         SLOT(1, soff_next, 1, true, NO_PRE, 1, 3, 0, 2)                                                      \
-        SLOT(2, soff_next, 2, HAS_NEXT, TAPADDR(DNEXT), 0, 0, 1, 3)                                          \
+        SLOT(2, soff_next, 2, HAS_NEXT, NEXT_ADDR, 0, 0, 1, 3)                                               \
         advance();                                                                                           \
     }
+#define STENCIL_STEP(DISP, HAS_NEXT, DNEXT) STEP_CORE(HAS_NEXT, TAPADDR(DNEXT))
+    // column-correction tap: the same 8 MFMAs per sub-step as a stencil tap (all pixel tiles, both channel halves), pixel
+    // fragments masked to the border column -> the same software pipeline
+#define COL_STEP(HAS_NEXT, ANEXT) STEP_CORE(HAS_NEXT, TAPADDR_MASKED((ANEXT) * HALO_W, m_col))
     // One correction step: only the pixel tiles / column tiles that touch the border take part.  BODY(KS, BSET) issues
     // its (masked) pixel fragments and MFMAs; the weight stream keeps its cadence.
 #define CORR_STEP(BODY)                                                                                      \
@@ -323,22 +338,11 @@ __global__ __launch_bounds__(256, 2) void conv_up_halo_kernel(ConvArgs a, int ti
 #undef ROW_BODY_B
         }
         if (has_col) {  // taps 12-14: a = -1,0,+1 on the border column (left for px = 0, right for px = 1)
-#define COL_BODY_A(KS, BSET, A_)                                                             \
-            {                                                                                \
-                bf16x8 f[4];                                                                 \
-                _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) RDA_MASKED(f[mt], mt, (A_) * HALO_W, KS, m_col) \
-                LGKM_WAIT(0)                                                                 \
-                _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) { MFMA_ONE(0, mt, BSET, f[mt]) MFMA_ONE(1, mt, BSET, f[mt]) } \
-            }                                                                                \
-            __builtin_amdgcn_sched_barrier(0);
-#define COL_M1(KS, BSET) COL_BODY_A(KS, BSET, -1)
-#define COL_0(KS, BSET) COL_BODY_A(KS, BSET, 0)
-#define COL_P1(KS, BSET) COL_BODY_A(KS, BSET, 1)
-            CORR_STEP(COL_M1) CORR_STEP(COL_0) CORR_STEP(COL_P1)
-#undef COL_M1
-#undef COL_0
-#undef COL_P1
-#undef COL_BODY_A
+            TAPADDR_MASKED(-HALO_W, m_col)
+            RDA1(0, 0, 0) RDA1(0, 0, 1) RDA1(0, 0, 2) RDA1(0, 0, 3)
+            COL_STEP(true, 0)
+            COL_STEP(true, 1)
+            COL_STEP(false, 0)
         }
         if (has_row && has_col) {  // tap 15: the corner pixel, one phase per corner
 #define CORNER_BODY(KS, BSET)                                                                \
@@ -369,6 +373,9 @@ __global__ __launch_bounds__(256, 2) void conv_up_halo_kernel(ConvArgs a, int ti
 #undef RDA_MASKED
 #undef CORR_STEP
 #undef STENCIL_STEP
+#undef COL_STEP
+#undef STEP_CORE
+#undef TAPADDR_MASKED
 #undef SLOT
 #undef PIN
 #undef MF
