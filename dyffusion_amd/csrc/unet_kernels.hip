@@ -166,7 +166,16 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* x, int hw, 
         atomicAdd(&stats[((size_t)n * groups) * 2 + i], (double)(&part[0][0])[i]);
 }
 
-__global__ __launch_bounds__(256) void gn_apply_kernel(GnActArgs a, const double* stats) {
+// (sum, sum of squares) in fp64 -> (mean, 1/std) in fp32, once per (sample, group) instead of once per lane of the apply pass
+__global__ void gn_finalize_kernel(const double* stats, int count, double inv_cnt, float2* mr) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const double mean = stats[2 * i] * inv_cnt;
+    const double var = stats[2 * i + 1] * inv_cnt - mean * mean;
+    mr[i] = make_float2((float)mean, rsqrtf(fmaxf((float)var, 0.0f) + 1e-5f));
+}
+
+__global__ __launch_bounds__(256) void gn_apply_kernel(GnActArgs a, const float2* mr) {
     const int chunks = a.c >> 3, cpg = a.c / a.groups;
     const long long total = (long long)a.n * a.hw * chunks;
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -175,33 +184,46 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnActArgs a, const double
     const long long pix = idx / chunks;
     const int n = (int)(pix / a.hw);
     const int g = (q * 8) / cpg;
-    const double cnt = (double)a.hw * cpg;
-    const double mean_d = stats[((size_t)n * a.groups + g) * 2] / cnt;
-    const double var_d = stats[((size_t)n * a.groups + g) * 2 + 1] / cnt - mean_d * mean_d;
-    const float mean = (float)mean_d, rstd = rsqrtf(fmaxf((float)var_d, 0.0f) + 1e-5f);
+    const float2 ms = mr[(size_t)n * a.groups + g];
+    const float mean = ms.x, rstd = ms.y;
     const size_t e0 = (size_t)pix * a.c + q * 8;
     const uint4 v = *(const uint4*)(a.x + e0);
     const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-    uint32_t rw[4] = {0, 0, 0, 0};
-    if (a.residual) {
-        const uint4 r = *(const uint4*)(a.residual + e0);
-        rw[0] = r.x; rw[1] = r.y; rw[2] = r.z; rw[3] = r.w;
+    // GroupNorm affine and FiLM folded into one FMA per element: y = x * A + C
+    const float4 g0 = *(const float4*)(a.gamma + q * 8), g1 = *(const float4*)(a.gamma + q * 8 + 4);
+    const float4 b0 = *(const float4*)(a.beta + q * 8), b1 = *(const float4*)(a.beta + q * 8 + 4);
+    float A[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+    float C[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        A[t] *= rstd;
+        C[t] = fmaf(-mean, A[t], C[t]);
     }
-    const uint32_t key = drop_key(a.drop);
+    if (a.film_a) {
+        const size_t fi = (size_t)n * a.film_stride + q * 8;
+        const float4 fa0 = *(const float4*)(a.film_a + fi), fa1 = *(const float4*)(a.film_a + fi + 4);
+        const float4 fc0 = *(const float4*)(a.film_c + fi), fc1 = *(const float4*)(a.film_c + fi + 4);
+        const float fa[8] = {fa0.x, fa0.y, fa0.z, fa0.w, fa1.x, fa1.y, fa1.z, fa1.w};
+        const float fc[8] = {fc0.x, fc0.y, fc0.z, fc0.w, fc1.x, fc1.y, fc1.z, fc1.w};
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            A[t] *= fa[t];
+            C[t] = fmaf(C[t], fa[t], fc[t]);
+        }
+    }
     float y[8];
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
-        const int ch = q * 8 + t;
         const float xv = (t & 1) ? __uint_as_float(w[t >> 1] & 0xffff0000u) : __uint_as_float(w[t >> 1] << 16);
-        float o = (xv - mean) * rstd * a.gamma[ch] + a.beta[ch];
-        if (a.film_a) {
-            const size_t fi = (size_t)n * a.film_stride + ch;
-            o = fmaf(o, a.film_a[fi], a.film_c[fi]);
-        }
-        o = apply_act(o, a.act);
-        o = drop_apply(o, (uint32_t)(e0 + t), a.drop, key);
-        if (a.residual) o += (t & 1) ? __uint_as_float(rw[t >> 1] & 0xffff0000u) : __uint_as_float(rw[t >> 1] << 16);
-        y[t] = o;
+        y[t] = fmaf(xv, A[t], C[t]);
+    }
+    act_drop<8>(y, (uint32_t)e0, a.act, a.drop, drop_key(a.drop));  // (activation, dropout mode) dispatched once
+    if (a.residual) {
+        const uint4 r = *(const uint4*)(a.residual + e0);
+        const uint32_t rw[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+            y[t] += (t & 1) ? __uint_as_float(rw[t >> 1] & 0xffff0000u) : __uint_as_float(rw[t >> 1] << 16);
     }
     *(uint4*)(a.out + e0) = make_uint4(pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]), pack_bf16x2(y[4], y[5]),
                                        pack_bf16x2(y[6], y[7]));
@@ -216,7 +238,11 @@ hipError_t launch_gn_act(const GnActArgs& a, hipStream_t s) {
         const unsigned bx = (unsigned)std::min<long long>((per_sample + 255) / 256, 64);
         hipLaunchKernelGGL(gn_stats_kernel, dim3(bx, a.n), dim3(256), 0, s, a.x, a.hw, a.c, a.groups, a.stats);
         const long long total = (long long)a.n * per_sample;
-        hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a, (const double*)a.stats);
+        float2* mr = (float2*)(a.stats + (size_t)a.n * a.groups * 2);  // the scratch holds [n][groups][2] doubles + as many floats
+        const int cnt = a.n * a.groups;
+        hipLaunchKernelGGL(gn_finalize_kernel, dim3((cnt + 255) / 256), dim3(256), 0, s, (const double*)a.stats, cnt,
+                           1.0 / ((double)a.hw * cpg), mr);
+        hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a, (const float2*)mr);
         return hipGetLastError();
     }
     hipLaunchKernelGGL(gn_act_kernel, dim3(a.n * a.groups), dim3(256), 0, s, a);

@@ -242,7 +242,7 @@ dyf_status rn_alloc_workspace(dyf_engine* e) {
         if (!n.rn) continue;
         RNet* r = n.rn;
         {
-            dyf_status s = dev_alloc(e, &r->gn_stats, (size_t)e->cfg.max_batch * n.cfg.groups * 2);
+            dyf_status s = dev_alloc(e, &r->gn_stats, (size_t)e->cfg.max_batch * n.cfg.groups * 3);  // + (mean, rstd) floats
             if (s != DYF_OK) return s;
         }
         {
