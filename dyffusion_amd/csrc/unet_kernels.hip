@@ -145,7 +145,11 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* x, int hw, 
     for (int i = threadIdx.x; i < groups * 2; i += blockDim.x) (&part[0][0])[i] = 0.0f;
     __syncthreads();
     const long long total = (long long)hw * chunks;
+    const int cq = cpg >> 3;  // chunks per group
+    const bool pow2 = (chunks & (chunks - 1)) == 0 && (cq & (cq - 1)) == 0 && chunks <= 64;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        // the whole wave is inside the tensor (its lanes are 64 consecutive chunk indices starting at a multiple of 64)
+        const bool full_wave = (idx - (threadIdx.x & 63)) + 64 <= total;
         const int q = (int)(idx % chunks);
         const long long p = idx / chunks;
         const uint4 v = *(const uint4*)(x + ((size_t)n * hw + p) * c + q * 8);
@@ -158,8 +162,25 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* x, int hw, 
             ss = fmaf(lo, lo, fmaf(hi, hi, ss));
         }
         const int g = (q * 8) / cpg;
-        atomicAdd(&part[g][0], s);
-        atomicAdd(&part[g][1], ss);
+        if (pow2 && full_wave) {
+            // lanes l and l ^ d hold the same group when d < cpg/8 (same group, neighbouring chunks) or d >= chunks (same
+            // chunk of another pixel): butterfly over those strides, then one LDS atomic per group and wave
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                if (d < cq || d >= chunks) {
+                    s += __shfl_xor(s, d, 64);
+                    ss += __shfl_xor(ss, d, 64);
+                }
+            }
+            const int l = threadIdx.x & 63;
+            if (l < chunks && (l & (cq - 1)) == 0) {
+                atomicAdd(&part[g][0], s);
+                atomicAdd(&part[g][1], ss);
+            }
+        } else {
+            atomicAdd(&part[g][0], s);
+            atomicAdd(&part[g][1], ss);
+        }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < groups * 2; i += blockDim.x)
