@@ -56,6 +56,13 @@ bool plan_up_sparse_columns(const std::vector<uint8_t>& needed, int w, std::vect
                             std::vector<int16_t>& cidx, std::vector<int16_t>& col_map, int& ntiles, int& nvalid0, int& nvalid1);
 hipError_t conv_up_halo_init();
 hipError_t launch_conv_up_halo(const ConvArgs& a, hipStream_t stream);
+// plain 3x3 / stride 1 / pad 1 conv on the halo kernel (conv_up_halo.hip, SP = 2): cout % 256 == 0, h % 8 == 0, w % 16 == 0;
+// ConvArgs::wpk_up_frag carries the pack_halo3_frag weights (looked up in the registry by launch_conv)
+bool conv_halo3_supported(const ConvArgs& a);
+hipError_t launch_conv_halo3(const ConvArgs& a, hipStream_t stream);
+void pack_halo3_frag(const bf16_t* wpk, int cout, int cin, bf16_t* out);
+void conv_register_halo3_frag(const bf16_t* wpk_dev, const bf16_t* frag_dev);
+const bf16_t* conv_lookup_halo3_frag(const bf16_t* wpk_dev);
 // second implicit-GEMM form (conv_igemm2.hip): 256 px x 128 ch per workgroup, weights streamed in fragment order
 bool conv_igemm2_supported(const ConvArgs& a);
 hipError_t conv_igemm2_init();

@@ -327,6 +327,7 @@ hipError_t launch_conv_igemm2(const ConvArgs& a, hipStream_t stream) {
 namespace {
 std::mutex g_frag_mu;
 std::unordered_map<const void*, const bf16_t*> g_frag;
+std::unordered_map<const void*, const bf16_t*> g_frag3;  // halo-kernel fragments of plain 3x3 convs
 }  // namespace
 
 void conv_register_frag(const bf16_t* wpk_dev, const bf16_t* frag_dev) {
@@ -337,6 +338,18 @@ void conv_register_frag(const bf16_t* wpk_dev, const bf16_t* frag_dev) {
 void conv_unregister_frag(const void* wpk_dev) {
     std::lock_guard<std::mutex> lk(g_frag_mu);
     g_frag.erase(wpk_dev);
+    g_frag3.erase(wpk_dev);
+}
+
+void conv_register_halo3_frag(const bf16_t* wpk_dev, const bf16_t* frag_dev) {
+    std::lock_guard<std::mutex> lk(g_frag_mu);
+    g_frag3[(const void*)wpk_dev] = frag_dev;
+}
+
+const bf16_t* conv_lookup_halo3_frag(const bf16_t* wpk_dev) {
+    std::lock_guard<std::mutex> lk(g_frag_mu);
+    auto it = g_frag3.find((const void*)wpk_dev);
+    return it == g_frag3.end() ? nullptr : it->second;
 }
 
 const bf16_t* conv_lookup_frag(const bf16_t* wpk_dev) {

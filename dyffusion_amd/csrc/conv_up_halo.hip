@@ -38,6 +38,9 @@ constexpr int NWAVES = 4;
 constexpr int STEP_BYTES = 32768;                       // weights of one (tap, chunk) step: 256 columns x 64 k bf16
 
 // SP = 0: the 16 columns of a tile are contiguous (halo 10 x 18, double-buffered).
+// SP = 2: PLAIN 3x3 / stride 1 / pad 1 convolution on the same machinery: no upsampling, the four waves own four 64-channel
+//         blocks of 256 output channels instead of four phases, out-of-image halo pixels are zero-filled by the DMA's bounds
+//         check (no correction taps at all).  Weights: pack_halo3_frag.
 // SP = 1: SPARSE COLUMNS -- the 16 columns of a tile are entries of a per-phase column list (ConvArgs::up_cols): only the
 // output columns a later kernel reads are computed.  The NS backbone resamples its 256-wide grid to 42 native columns
 // (unet_simple.py:195): the readout touches 104 of the 256 columns of the last decoder block, i.e. 52 of 128 low-res columns
@@ -45,11 +48,11 @@ constexpr int STEP_BYTES = 32768;                       // weights of one (tap, 
 // workgroups still fit a CU; the other workgroup covers the exposed halo swap).
 template <int SP>
 struct HaloCfg {
-    static constexpr int W = SP ? 40 : 18;              // halo width in pixels
+    static constexpr int W = SP == 1 ? 40 : 18;         // halo width in pixels
     static constexpr int REAL = 10 * W;
     static constexpr int PIX = (REAL + 7) / 8 * 8;      // padded to a multiple of 8 DMA rows
     static constexpr int BYTES = PIX * 128;             // 23 552 / 51 200
-    static constexpr int NBUF = SP ? 1 : 2;
+    static constexpr int NBUF = SP == 1 ? 1 : 2;
     static constexpr int ZERO_OFF = NBUF * BYTES;       // 128 B of zeros (pixels masked out of a correction tap)
     static constexpr int HOFF_OFF = ZERO_OFF + 512;     // per-thread halo source offsets [PER_WAVE][256]
     static constexpr int INSTR = PIX / 8;               // wave-level DMA instructions per halo: 23 / 50
@@ -87,7 +90,7 @@ __global__ __launch_bounds__(256, 2) void conv_up_halo_kernel(ConvArgs a, int ti
     // low-res column of this lane's pixels and the column the halo starts at
     int col, cbase, cstore = 0;
     bool lane_valid = true;
-    if (SP) {
+    if (SP == 1) {
         cbase = a.up_cbase[lx];
         const int entry = a.up_cols[wpx * a.up_npad + lx * 16 + px_x];  // bit 14: padding entry (computed, not stored)
         col = entry & 0x3FFF;
@@ -104,8 +107,8 @@ __global__ __launch_bounds__(256, 2) void conv_up_halo_kernel(ConvArgs a, int ti
     // left/right column to px = 0 / 1.  Waves only meet at the per-chunk barrier, so each runs its own tap list.
     const bool has_top = ty0 == 0, has_bot = ty0 + TILE_H == a.h;
     const bool m_left = col == 0, m_right = col == a.w - 1;
-    const bool has_row = wpy == 0 ? has_top : has_bot;
-    const bool has_col = (wpx == 0 ? __builtin_amdgcn_ballot_w64(m_left) : __builtin_amdgcn_ballot_w64(m_right)) != 0ull;
+    const bool has_row = SP != 2 && (wpy == 0 ? has_top : has_bot);
+    const bool has_col = SP != 2 && (wpx == 0 ? __builtin_amdgcn_ballot_w64(m_left) : __builtin_amdgcn_ballot_w64(m_right)) != 0ull;
     // tap list of this wave, 4 bits per entry: 0-8 stencil, 9-11 row correction, 12-14 column correction, 15 corner
     unsigned long long tap_list = 0x876543210ull;
     int ntaps = 9;
@@ -118,7 +121,7 @@ __global__ __launch_bounds__(256, 2) void conv_up_halo_kernel(ConvArgs a, int ti
     const auto rsrc_a1 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.c1 ? a.src1 : a.src0), 0,
                                                            (int)(unsigned)(npix * (a.c1 ? a.c1 : a.c0) * 2), 0x00020000);
     const auto rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.wpk_up_frag, 0,
-                                                          (int)(unsigned)((size_t)4 * a.cout * 16 * cin * 2), 0x00020000);
+                                                          (int)(unsigned)((size_t)(SP == 2 ? 1 : 4) * a.cout * 16 * cin * 2), 0x00020000);
 
     // ---- halo DMA descriptors: instruction i (i % 4 == wave) fills halo pixels [8i, 8i+8); lane -> (pixel, 16-B chunk)
     // (the per-lane source offsets are parked in LDS, not in registers: the K loop needs every VGPR it can get)
@@ -130,9 +133,12 @@ __global__ __launch_bounds__(256, 2) void conv_up_halo_kernel(ConvArgs a, int ti
         int hp = i * 8 + sub;
         if (hp > HALO_REAL - 1) hp = HALO_REAL - 1;  // padding slots re-read the last halo pixel
         const int hy = hp / HALO_W, hx = hp - hy * HALO_W;
-        const int y = min(max(ty0 - 1 + hy, 0), a.h - 1), x = min(max(cbase + hx, 0), a.w - 1);  // replicate clamp
+        const int yy = ty0 - 1 + hy, xx = cbase + hx;
+        const int y = min(max(yy, 0), a.h - 1), x = min(max(xx, 0), a.w - 1);  // replicate clamp (upsample forms)
         const int gch = (lane & 7) ^ ((hp >> 1) & 7);  // swizzled source chunk of this linear LDS slot
-        h_tab[j * 256] = (unsigned)((n_img * a.h + y) * a.w + x) * (unsigned)(a.c0 * 2) + gch * 16;  // c0 == c1 (checked on host)
+        unsigned off = (unsigned)((n_img * a.h + y) * a.w + x) * (unsigned)(a.c0 * 2) + gch * 16;  // c0 == c1 (checked on host)
+        if (SP == 2 && (yy != y || xx != x)) off = 0xFFFFFFFFu;  // plain conv: zero padding = out-of-range DMA offset
+        h_tab[j * 256] = off;
     }
     if (tid < 32) ((uint4*)(smem + ZERO_OFF))[tid] = make_uint4(0, 0, 0, 0);
 
@@ -145,10 +151,12 @@ __global__ __launch_bounds__(256, 2) void conv_up_halo_kernel(ConvArgs a, int ti
         for (int j = 0; j < HALO_PER_WAVE; ++j) {
             const int i = j * NWAVES + wave;
             if (i < HALO_INSTR) {
+                unsigned vo = h_tab[j * 256];
+                if (SP != 2 || vo != 0xFFFFFFFFu) vo += coff;
                 if (second)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a1, LDS_PTR(dst + i * 1024), 16, h_tab[j * 256] + coff, 0, 0, 0);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a1, LDS_PTR(dst + i * 1024), 16, vo, 0, 0, 0);
                 else
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a0, LDS_PTR(dst + i * 1024), 16, h_tab[j * 256] + coff, 0, 0, 0);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a0, LDS_PTR(dst + i * 1024), 16, vo, 0, 0, 0);
             }
         }
     };
@@ -390,17 +398,21 @@ __global__ __launch_bounds__(256, 2) void conv_up_halo_kernel(ConvArgs a, int ti
     // channels half*32 + 8*g + 4*hi + {0..3} (g = register group r >> 2).  Groups 2*g2 and 2*g2+1 are packed to bf16 and
     // exchanged between lanes l and l+32 (v_permlane32_swap), after which every lane owns 8 consecutive channels = 16 B.
     const uint32_t key = drop_key(a.drop);
-    const uint32_t ci_base = (uint32_t)((a.coef_div > 1 ? n_img / a.coef_div : n_img) * a.coef_stride + tn * 64 + 4 * hi);
+    // channel block of this wave: the 64 channels of column block tn (upsample forms: one phase per wave), or (plain form)
+    // the wave's own 64 of the 256 channels of block tn
+    const int ch_blk = SP == 2 ? tn * 256 + wave * 64 : tn * 64;
+    const uint32_t ci_base = (uint32_t)((a.coef_div > 1 ? n_img / a.coef_div : n_img) * a.coef_stride + ch_blk + 4 * hi);
     // output pixel (pixel tile 0, px = 0) of this lane, in elements; pixel tile mt adds 4 output rows, px adds one pixel
-    const uint32_t m0 = (uint32_t)((n_img * a.ho + 2 * (ty0 + px_r) + wpy) * a.wo + 2 * col + wpx);
-    const uint32_t o0 = m0 * (uint32_t)a.cout + (uint32_t)(tn * 64);
-    const uint32_t mt_stride = (uint32_t)(4 * a.wo * a.cout);
+    const uint32_t m0 = SP == 2 ? (uint32_t)((n_img * a.ho + ty0 + px_r) * a.wo + col)
+                                : (uint32_t)((n_img * a.ho + 2 * (ty0 + px_r) + wpy) * a.wo + 2 * col + wpx);
+    const uint32_t o0 = m0 * (uint32_t)a.cout + (uint32_t)ch_blk;
+    const uint32_t mt_stride = (uint32_t)((SP == 2 ? 2 : 4) * a.wo * a.cout);
     // sparse form: the output tensor keeps only the listed columns, [n][ho][up_wo_store][cout]; the dropout stream stays
     // indexed by the DENSE position (o0), so masks do not depend on the storage layout
-    const uint32_t store0 = SP ? (uint32_t)((n_img * a.ho + 2 * (ty0 + px_r) + wpy) * a.up_wo_store + cstore) * (uint32_t)a.cout +
+    const uint32_t store0 = SP == 1 ? (uint32_t)((n_img * a.ho + 2 * (ty0 + px_r) + wpy) * a.up_wo_store + cstore) * (uint32_t)a.cout +
                                  (uint32_t)(tn * 64)
                            : o0;
-    const uint32_t smt_stride = SP ? (uint32_t)(4 * a.up_wo_store * a.cout) : mt_stride;
+    const uint32_t smt_stride = SP == 1 ? (uint32_t)(4 * a.up_wo_store * a.cout) : mt_stride;
     // (activation, dropout mode) are wave-uniform: the whole epilogue is instantiated per pair and dispatched once
     auto epilogue = [&](auto act_c, auto mode_c) {
         constexpr int ACT = decltype(act_c)::value, MODE = decltype(mode_c)::value;
@@ -430,7 +442,7 @@ __global__ __launch_bounds__(256, 2) void conv_up_halo_kernel(ConvArgs a, int ti
                     uint4 o;
                     o.x = s0[0]; o.y = s1[0]; o.z = s0[1]; o.w = s1[1];
                     const uint32_t sbase = store0 + mt * smt_stride + cg0;
-                    if (!SP || lane_valid) *(uint4*)(a.out_bf16 + (size_t)(sbase + 8 * hi)) = o;
+                    if (SP != 1 || lane_valid) *(uint4*)(a.out_bf16 + (size_t)(sbase + 8 * hi)) = o;
                 }
         }
     };
@@ -479,12 +491,49 @@ bool conv_up_halo_supported(const ConvArgs& a) {
            (size_t)a.n * a.ho * a.wo * a.cout < 0xFFFFFFF0ull;
 }
 
+// Plain 3x3 conv through the halo kernel (SP = 2): wpk [cout][9][cin] -> the fragment order of pack_up2x_frag with the four
+// "phases" being the four 64-channel blocks of every 256 output channels (taps 9-15 of the 16-tap axis stay zero).
+void pack_halo3_frag(const bf16_t* wpk, int cout, int cin, bf16_t* out) {
+    const int blocks = cout / 256;
+    std::vector<bf16_t> v((size_t)4 * blocks * 64 * 16 * cin, 0);  // [phase][co' = blk*64 + c][16][cin]
+    for (int p = 0; p < 4; ++p)
+        for (int b = 0; b < blocks; ++b)
+            for (int c = 0; c < 64; ++c)
+                for (int t = 0; t < 9; ++t) {
+                    const bf16_t* src = wpk + ((size_t)(b * 256 + p * 64 + c) * 9 + t) * cin;
+                    bf16_t* dst = v.data() + ((((size_t)p * blocks * 64 + b * 64 + c) * 16) + t) * cin;
+                    std::copy(src, src + cin, dst);
+                }
+    pack_up2x_frag(v.data(), blocks * 64, cin, out);
+}
+
+bool conv_halo3_supported(const ConvArgs& a) {
+    if (a.up2x || a.wpk_up_frag == nullptr || a.out_bf16 == nullptr || a.out_f32 != nullptr || a.residual != nullptr) return false;
+    if (a.kh != 3 || a.kw != 3 || a.stride != 1 || a.pad != 1 || a.pix_pitch0 != 0) return false;
+    if (!(a.c0 > 0 && a.c0 % 64 == 0 && (a.c1 == 0 || a.c1 == a.c0) && a.cout % 256 == 0)) return false;
+    if (a.h % TILE_H != 0 || a.w % TILE_W != 0 || a.ho != a.h || a.wo != a.w) return false;
+    const size_t npix = (size_t)a.n * a.h * a.w;
+    return npix * a.c0 * 2 < 0x7F000000ull && (size_t)a.cout * 16 * (a.c0 + a.c1) * 2 < 0x7F000000ull &&
+           (size_t)a.n * a.ho * a.wo * a.cout < 0xFFFFFFF0ull;
+}
+
+hipError_t launch_conv_halo3(const ConvArgs& a, hipStream_t stream) {
+    const int tiles_x = a.w / TILE_W, tiles_per_img = tiles_x * (a.h / TILE_H);
+    const int tiles_m = a.n * tiles_per_img, tiles_n = a.cout / 256;
+    hipLaunchKernelGGL(conv_up_halo_kernel<2>, dim3(tiles_m * tiles_n), dim3(256), HaloCfg<2>::LDS_TOTAL, stream, a, tiles_x,
+                       tiles_per_img, tiles_m, tiles_n);
+    return hipGetLastError();
+}
+
 hipError_t conv_up_halo_init() {
     hipError_t e = hipFuncSetAttribute((const void*)conv_up_halo_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        HaloCfg<0>::LDS_TOTAL);
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)conv_up_halo_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 HaloCfg<1>::LDS_TOTAL);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)conv_up_halo_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                HaloCfg<2>::LDS_TOTAL);
     return e;
 }
 

@@ -1099,6 +1099,14 @@ dyf_status dyf_op_conv2d(dyf_engine* e, const uint16_t* x_dev, const float* w_ho
     a.ho = (h + 2 * pad - kh) / stride + 1; a.wo = (w + 2 * pad - kw) / stride + 1;
     a.kh = kh; a.kw = kw; a.stride = stride; a.pad = pad; a.cout = cout; a.wpk = wdev;
     a.wpk_frag = frag ? wdev + pk.size() : nullptr;
+    bf16_t* h3dev = nullptr;  // halo form of plain 3x3 convs (looked up through the registry like the engine's own weights)
+    if (taps == 9 && cout % 256 == 0 && cin % 64 == 0) {
+        std::vector<bf16_t> pf((size_t)cout * 16 * cin);
+        pack_halo3_frag(pk.data(), cout, cin, pf.data());
+        HIP_TRY(e, hipMalloc((void**)&h3dev, pf.size() * sizeof(bf16_t)));
+        HIP_TRY(e, hipMemcpy(h3dev, pf.data(), pf.size() * sizeof(bf16_t), hipMemcpyHostToDevice));
+        conv_register_halo3_frag(wdev, h3dev);
+    }
     a.act = act; a.out_bf16 = y_dev; a.zero_page = e->ws.zero_page;
     if (scale_dev && shift_dev) {
         a.coef_a = scale_dev; a.coef_c = shift_dev; a.coef_stride = cout;
@@ -1117,6 +1125,10 @@ dyf_status dyf_op_conv2d(dyf_engine* e, const uint16_t* x_dev, const float* w_ho
         hipError_t le = launch_conv(a, path, st);
         if (le == hipSuccess) le = hipStreamSynchronize(st);
         if (le != hipSuccess) rs = fail(e, DYF_ERR_HIP, std::string("conv launch: ") + hipGetErrorString(le));
+    }
+    if (h3dev) {
+        conv_unregister_frag(wdev);
+        (void)hipFree(h3dev);
     }
     (void)hipFree(wdev);
     if (ones) (void)hipFree(ones);

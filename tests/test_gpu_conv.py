@@ -99,6 +99,34 @@ def test_second_igemm_form_matches_torch(engine, case, monkeypatch):
             assert rel_rms(got, first) <= 2.5e-3  # the two MFMA forms differ by summation order only
 
 
+HALO3_CASES = [(2, 16, 16, 64, 256, 3, 1, 1), (1, 32, 48, 128, 256, 3, 1, 1), (3, 8, 16, 192, 512, 3, 1, 1),
+               (1, 64, 32, 64, 256, 3, 1, 1)]
+
+
+@pytest.mark.parametrize("case", HALO3_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_plain_3x3_on_the_halo_kernel_matches_torch(engine, case, monkeypatch):
+    """conv_up_halo_kernel<2>: plain 3x3 / s1 / p1 conv (cout % 256 == 0) with the window in LDS and zero-filled borders;
+    production uses it from 512 tiles on, DYF_HALO3_MIN_TILES=1 forces it here.  Borders checked separately."""
+    n, h, w, cin, cout, k, stride, pad = case
+    g = torch.Generator().manual_seed(sum(case) + 1)
+    x = torch.randn(n, h, w, cin, generator=g).to(torch.bfloat16)
+    wt = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    scale = 1.0 + 0.3 * torch.randn(n, cout, generator=g)
+    shift = 0.2 * torch.randn(n, cout, generator=g)
+    monkeypatch.setenv("DYF_HALO3", "0")
+    other = engine.op_conv2d(x.cuda(), wt, stride, pad, scale.cuda(), shift.cuda(), act=1, path=1).float().cpu()
+    monkeypatch.setenv("DYF_HALO3", "1")
+    monkeypatch.setenv("DYF_HALO3_MIN_TILES", "1")
+    y = engine.op_conv2d(x.cuda(), wt, stride, pad, scale.cuda(), shift.cuda(), act=1, path=1).float().cpu()
+    want = reference(x, wt, stride, pad, scale, shift, 1)
+    tol = 1.5 * 2 ** -8 * float(want.abs().max()) + 1e-3
+    assert max_abs(y, want) <= tol
+    assert rel_rms(y, want) <= 4e-3
+    for sl in [(slice(None), 0), (slice(None), -1), (slice(None), slice(None), 0), (slice(None), slice(None), -1)]:
+        assert rel_rms(y[sl], want[sl]) <= 5e-3, sl
+    assert rel_rms(y, other) <= 2.5e-3  # vs the implicit-GEMM forms: summation order only
+
+
 def test_mfma_and_direct_agree_closely(engine):
     # both accumulate in fp32 from identical bf16 operands: they differ only by summation order (+ final rounding)
     g = torch.Generator().manual_seed(7)
