@@ -178,27 +178,28 @@ __global__ __launch_bounds__(256) void stem16_kernel(StemArgs a) {
             bilinear_coord(y, (float)a.h / (float)a.uh, a.h, y0, y1, ly);
             bilinear_coord(x, (float)a.w / (float)a.uw, a.w, x0, x1, lx);
         }
+        // channel k of the concatenation lives in source s(k): a static loop over the 16 output slots (the dynamic
+        // (source, channel) walk of the first version cost a 16-way select chain per channel)
+        const int e0 = a.ch[0], e1 = e0 + (a.nsrc > 1 ? a.ch[1] : 0), e2 = e1 + (a.nsrc > 2 ? a.ch[2] : 0);
+        const int nrow = a.src_rows > 0 ? n % a.src_rows : n;
+        const int o00 = y0 * a.w + x0, o01 = y0 * a.w + x1, o10 = y1 * a.w + x0, o11 = y1 * a.w + x1;
+        const size_t plane = (size_t)a.h * a.w;
         float v[16];
 #pragma unroll
-        for (int c = 0; c < 16; ++c) v[c] = 0.0f;
-        int cbase = 0;
-        for (int s = 0; s < a.nsrc; ++s) {
-            const float* src = a.src[s] + (size_t)(a.src_rows > 0 ? n % a.src_rows : n) * a.ch[s] * a.h * a.w;
-            for (int c = 0; c < a.ch[s]; ++c) {
-                const float* p = src + (size_t)c * a.h * a.w;
-                const float top = p[y0 * a.w + x0] * (1.0f - lx) + p[y0 * a.w + x1] * lx;
-                const float bot = p[y1 * a.w + x0] * (1.0f - lx) + p[y1 * a.w + x1] * lx;
-                const float val = top * (1.0f - ly) + bot * ly;
-                const int cc = cbase + c;
-#pragma unroll
-                for (int k = 0; k < 16; ++k)
-                    if (k == cc) v[k] = val;
+        for (int k = 0; k < 16; ++k) {
+            float val = 0.0f;
+            if (k < a.cin) {
+                const int si = k < e0 ? 0 : (k < e1 ? 1 : (k < e2 ? 2 : 3));
+                const int cl = k - (si == 0 ? 0 : (si == 1 ? e0 : (si == 2 ? e1 : e2)));
+                const float* p = a.src[si] + ((size_t)nrow * a.ch[si] + cl) * plane;
+                const float top = p[o00] * (1.0f - lx) + p[o01] * lx;
+                const float bot = p[o10] * (1.0f - lx) + p[o11] * lx;
+                val = top * (1.0f - ly) + bot * ly;
+            } else if (k == a.cin) {
+                val = 1.0f;  // carries init_conv's bias through the composed enc0 weights
             }
-            cbase += a.ch[s];
+            v[k] = val;
         }
-#pragma unroll
-        for (int k = 0; k < 16; ++k)
-            if (k == a.cin) v[k] = 1.0f;
 #pragma unroll
         for (int k = 0; k < 8; ++k) w[k] = pack_bf16x2(v[2 * k], v[2 * k + 1]);
     }
