@@ -61,6 +61,11 @@ hipError_t launch_conv_up_halo(const ConvArgs& a, hipStream_t stream);
 bool conv_halo3_supported(const ConvArgs& a);
 hipError_t launch_conv_halo3(const ConvArgs& a, hipStream_t stream);
 void pack_halo3_frag(const bf16_t* wpk, int cout, int cin, bf16_t* out);
+// 4x4 / stride 2 / pad 1 conv on the halo kernel (SP = 3, space-to-depth view): cout % 256 == 0, single source, output plane
+// tiles by 8x16; fragments (pack_halo_s2_frag) share the halo3 registry
+bool conv_halo_s2_supported(const ConvArgs& a);
+hipError_t launch_conv_halo_s2(const ConvArgs& a, hipStream_t stream);
+void pack_halo_s2_frag(const bf16_t* wpk, int cout, int cin, bf16_t* out);
 void conv_register_halo3_frag(const bf16_t* wpk_dev, const bf16_t* frag_dev);
 const bf16_t* conv_lookup_halo3_frag(const bf16_t* wpk_dev);
 // second implicit-GEMM form (conv_igemm2.hip): 256 px x 128 ch per workgroup, weights streamed in fragment order

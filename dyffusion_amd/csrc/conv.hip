@@ -562,7 +562,8 @@ hipError_t launch_conv(const ConvArgs& a, int path, hipStream_t stream) {
             return conv_up_halo_supported(a) ? launch_conv_up_halo(a, stream) : hipErrorInvalidValue;
         if (a.up2x && use_halo && a.h >= halo_min && a.w >= halo_min && conv_up_halo_supported(a)) return launch_conv_up_halo(a, stream);
         // plain 3x3 / s1 convs with cout % 256 == 0 on 8x16-tileable planes: the halo kernel (one window DMA per chunk
-        // instead of one gather per tap); DYF_HALO3=0 disables, DYF_HALO3_MIN_TILES sets the smallest launch
+        // instead of one gather per tap); DYF_HALO3=0 disables, DYF_HALO3_MIN_TILES sets the smallest launch (default 256
+        // tiles: measured at NB = 80, enc3 with 320 tiles 115 -> 94 us)
         if (!a.up2x && a.kh == 3 && a.kw == 3 && a.cout % 256 == 0 && a.out_f32 == nullptr && a.residual == nullptr) {
             const char* h3 = getenv("DYF_HALO3");
             if (!(h3 && atoi(h3) == 0)) {
@@ -570,7 +571,18 @@ hipError_t launch_conv(const ConvArgs& a, int path, hipStream_t stream) {
                 b.wpk_up_frag = conv_lookup_halo3_frag(b.wpk);
                 const char* mt3 = getenv("DYF_HALO3_MIN_TILES");
                 const long long tiles3 = ((long long)a.n * a.h * a.w / 128) * (a.cout / 256);
-                if (b.wpk_up_frag && tiles3 >= (mt3 ? atoll(mt3) : 512) && conv_halo3_supported(b)) return launch_conv_halo3(b, stream);
+                if (b.wpk_up_frag && tiles3 >= (mt3 ? atoll(mt3) : 256) && conv_halo3_supported(b)) return launch_conv_halo3(b, stream);
+            }
+        }
+        if (!a.up2x && a.kh == 4 && a.kw == 4 && a.stride == 2 && a.cout % 256 == 0 && a.c1 == 0 && a.out_f32 == nullptr &&
+            a.residual == nullptr && a.pix_pitch0 == 0) {  // 4x4 / s2 convs: the same kernel on the space-to-depth view
+            const char* h3 = getenv("DYF_HALO3");
+            if (!(h3 && atoi(h3) == 0)) {
+                ConvArgs b = a;
+                b.wpk_up_frag = conv_lookup_halo3_frag(b.wpk);
+                const char* mt3 = getenv("DYF_HALO3_MIN_TILES");
+                const long long tiles3 = ((long long)a.n * a.ho * a.wo / 128) * (a.cout / 256);
+                if (b.wpk_up_frag && tiles3 >= (mt3 ? atoll(mt3) : 256) && conv_halo_s2_supported(b)) return launch_conv_halo_s2(b, stream);
             }
         }
         static const bool use_igemm2 = !(getenv("DYF_IGEMM2") && atoi(getenv("DYF_IGEMM2")) == 0);

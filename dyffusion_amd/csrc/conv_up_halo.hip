@@ -41,6 +41,11 @@ constexpr int STEP_BYTES = 32768;                       // weights of one (tap, 
 // SP = 2: PLAIN 3x3 / stride 1 / pad 1 convolution on the same machinery: no upsampling, the four waves own four 64-channel
 //         blocks of 256 output channels instead of four phases, out-of-image halo pixels are zero-filled by the DMA's bounds
 //         check (no correction taps at all).  Weights: pack_halo3_frag.
+// SP = 3: 4x4 / stride 2 / pad 1 convolution as SP = 2 on the SPACE-TO-DEPTH view of its input: input pixel (2i+qy, 2j+qx)
+//         belongs to parity plane (qy, qx) at half resolution, kernel row ky = 2a + qy + 1 is displacement a of that plane
+//         (qy = 0: a in {0, +1}; qy = 1: a in {-1, 0}), so every (plane, 64-channel chunk) contributes a 2 x 2 stencil.
+//         The DMA gathers one plane of one chunk per halo (per-lane source offsets: any pixel map is free), the K loop
+//         walks 4 planes x c0/64 chunks x 4 taps.  Weights: pack_halo_s2_frag.
 // SP = 1: SPARSE COLUMNS -- the 16 columns of a tile are entries of a per-phase column list (ConvArgs::up_cols): only the
 // output columns a later kernel reads are computed.  The NS backbone resamples its 256-wide grid to 42 native columns
 // (unet_simple.py:195): the readout touches 104 of the 256 columns of the last decoder block, i.e. 52 of 128 low-res columns
@@ -53,6 +58,7 @@ struct HaloCfg {
     static constexpr int PIX = (REAL + 7) / 8 * 8;      // padded to a multiple of 8 DMA rows
     static constexpr int BYTES = PIX * 128;             // 23 552 / 51 200
     static constexpr int NBUF = SP == 1 ? 1 : 2;
+    static constexpr bool PLAIN = SP >= 2;              // one output-channel block per wave, zero-padded window, no corrections
     static constexpr int ZERO_OFF = NBUF * BYTES;       // 128 B of zeros (pixels masked out of a correction tap)
     static constexpr int HOFF_OFF = ZERO_OFF + 512;     // per-thread halo source offsets [PER_WAVE][256]
     static constexpr int INSTR = PIX / 8;               // wave-level DMA instructions per halo: 23 / 50
@@ -102,16 +108,17 @@ __global__ __launch_bounds__(256, 2) void conv_up_halo_kernel(ConvArgs a, int ti
     }
 
     const int cin = a.c0 + a.c1;
-    const int cpt = cin >> 6;
+    const int cpt = SP == 3 ? 4 * (cin >> 6) : cin >> 6;  // K chunks: (SP = 3) 4 parity planes per 64-channel chunk
     // border corrections are per WAVE (a wave owns one output phase): the top/bottom row matters to phases py = 0 / 1, the
     // left/right column to px = 0 / 1.  Waves only meet at the per-chunk barrier, so each runs its own tap list.
-    const bool has_top = ty0 == 0, has_bot = ty0 + TILE_H == a.h;
-    const bool m_left = col == 0, m_right = col == a.w - 1;
-    const bool has_row = SP != 2 && (wpy == 0 ? has_top : has_bot);
-    const bool has_col = SP != 2 && (wpx == 0 ? __builtin_amdgcn_ballot_w64(m_left) : __builtin_amdgcn_ballot_w64(m_right)) != 0ull;
+    const int gh = SP == 3 ? a.ho : a.h, gw = SP == 3 ? a.wo : a.w;  // the grid the halo / tiles live on
+    const bool has_top = ty0 == 0, has_bot = ty0 + TILE_H == gh;
+    const bool m_left = col == 0, m_right = col == gw - 1;
+    const bool has_row = !H::PLAIN && (wpy == 0 ? has_top : has_bot);
+    const bool has_col = !H::PLAIN && (wpx == 0 ? __builtin_amdgcn_ballot_w64(m_left) : __builtin_amdgcn_ballot_w64(m_right)) != 0ull;
     // tap list of this wave, 4 bits per entry: 0-8 stencil, 9-11 row correction, 12-14 column correction, 15 corner
-    unsigned long long tap_list = 0x876543210ull;
-    int ntaps = 9;
+    unsigned long long tap_list = SP == 3 ? 0x3210ull : 0x876543210ull;
+    int ntaps = SP == 3 ? 4 : 9;
     if (has_row) { tap_list |= 0xBA9ull << (4 * ntaps); ntaps += 3; }
     if (has_col) { tap_list |= 0xEDCull << (4 * ntaps); ntaps += 3; }
     if (has_row && has_col) { tap_list |= 0xFull << (4 * ntaps); ntaps += 1; }
@@ -121,7 +128,7 @@ __global__ __launch_bounds__(256, 2) void conv_up_halo_kernel(ConvArgs a, int ti
     const auto rsrc_a1 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.c1 ? a.src1 : a.src0), 0,
                                                            (int)(unsigned)(npix * (a.c1 ? a.c1 : a.c0) * 2), 0x00020000);
     const auto rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.wpk_up_frag, 0,
-                                                          (int)(unsigned)((size_t)(SP == 2 ? 1 : 4) * a.cout * 16 * cin * 2), 0x00020000);
+                                                          (int)(unsigned)((size_t)(SP == 2 ? 1 : 4) * a.cout * 16 * cin * 2), 0x00020000);  // SP = 3: 4 planes
 
     // ---- halo DMA descriptors: instruction i (i % 4 == wave) fills halo pixels [8i, 8i+8); lane -> (pixel, 16-B chunk)
     // (the per-lane source offsets are parked in LDS, not in registers: the K loop needs every VGPR it can get)
@@ -134,25 +141,28 @@ __global__ __launch_bounds__(256, 2) void conv_up_halo_kernel(ConvArgs a, int ti
         if (hp > HALO_REAL - 1) hp = HALO_REAL - 1;  // padding slots re-read the last halo pixel
         const int hy = hp / HALO_W, hx = hp - hy * HALO_W;
         const int yy = ty0 - 1 + hy, xx = cbase + hx;
-        const int y = min(max(yy, 0), a.h - 1), x = min(max(xx, 0), a.w - 1);  // replicate clamp (upsample forms)
+        const int y = min(max(yy, 0), gh - 1), x = min(max(xx, 0), gw - 1);  // replicate clamp (upsample forms)
         const int gch = (lane & 7) ^ ((hp >> 1) & 7);  // swizzled source chunk of this linear LDS slot
-        unsigned off = (unsigned)((n_img * a.h + y) * a.w + x) * (unsigned)(a.c0 * 2) + gch * 16;  // c0 == c1 (checked on host)
-        if (SP == 2 && (yy != y || xx != x)) off = 0xFFFFFFFFu;  // plain conv: zero padding = out-of-range DMA offset
+        // SP = 3: halo pixel (y, x) of parity plane (0, 0) is input pixel (2y, 2x); the plane offset is added per chunk
+        unsigned off = (SP == 3 ? (unsigned)((n_img * a.h + 2 * y) * a.w + 2 * x) : (unsigned)((n_img * a.h + y) * a.w + x)) *
+                           (unsigned)(a.c0 * 2) + gch * 16;  // c0 == c1 (checked on host)
+        if (H::PLAIN && (yy != y || xx != x)) off = 0xFFFFFFFFu;  // plain convs: zero padding = out-of-range DMA offset
         h_tab[j * 256] = off;
     }
     if (tid < 32) ((uint4*)(smem + ZERO_OFF))[tid] = make_uint4(0, 0, 0, 0);
 
     auto issue_halo = [&](int chunk) {
-        const int cb = chunk << 6;
-        const bool second = cb >= a.c0;
-        const unsigned coff = (unsigned)((second ? cb - a.c0 : cb) * 2);
+        const int cb = SP == 3 ? (chunk >> 2) << 6 : chunk << 6;
+        const bool second = SP != 3 && cb >= a.c0;
+        unsigned coff = (unsigned)((second ? cb - a.c0 : cb) * 2);
+        if (SP == 3) coff += (unsigned)((((chunk >> 1) & 1) * a.w + (chunk & 1)) * a.c0 * 2);  // plane (qy, qx) = chunk & 3
         char* dst = smem + (H::NBUF == 2 ? (chunk & 1) * HALO_BYTES : 0);
 #pragma unroll
         for (int j = 0; j < HALO_PER_WAVE; ++j) {
             const int i = j * NWAVES + wave;
             if (i < HALO_INSTR) {
                 unsigned vo = h_tab[j * 256];
-                if (SP != 2 || vo != 0xFFFFFFFFu) vo += coff;
+                if (!H::PLAIN || vo != 0xFFFFFFFFu) vo += coff;
                 if (second)
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a1, LDS_PTR(dst + i * 1024), 16, vo, 0, 0, 0);
                 else
@@ -307,6 +317,17 @@ __global__ __launch_bounds__(256, 2) void conv_up_halo_kernel(ConvArgs a, int ti
         }
         const unsigned Hs = lds_base + (H::NBUF == 2 ? (chunk & 1) * HALO_BYTES : 0);
         asm volatile("" : "+v"(hp0));  // keep the per-tap LDS addresses from being hoisted out of the chunk loop
+        if (SP == 3) {
+            // 2 x 2 taps of parity plane (qy, qx): displacement a in {0, +1} for parity 0, {-1, 0} for parity 1
+            const int qy = (chunk >> 1) & 1, qx = chunk & 1;
+            const int d00 = -qy * HALO_W - qx, d01 = d00 + 1, d10 = d00 + HALO_W, d11 = d10 + 1;
+            TAPADDR(d00)
+            RDA1(0, 0, 0) RDA1(0, 0, 1) RDA1(0, 0, 2) RDA1(0, 0, 3)
+            STENCIL_STEP(d00, true, d01)
+            STENCIL_STEP(d01, true, d10)
+            STENCIL_STEP(d10, true, d11)
+            STENCIL_STEP(d11, false, 0)
+        } else {
         TAPADDR(-HALO_W - 1)
         RDA1(0, 0, 0) RDA1(0, 0, 1) RDA1(0, 0, 2) RDA1(0, 0, 3)
         // ---- 9 stencil taps (a, b) in {-1,0,1}^2: displacement a*18 + b in the halo, every phase
@@ -321,6 +342,7 @@ __global__ __launch_bounds__(256, 2) void conv_up_halo_kernel(ConvArgs a, int ti
         STENCIL_STEP(D_OF(7), true, D_OF(8))
         STENCIL_STEP(D_OF(8), false, 0)
 #undef D_OF
+        }
         if (has_row) {  // taps 9-11: b = -1,0,+1 on the border row: pixel tile 0 (top, py = 0) or 3 (bottom, py = 1)
 #define ROW_BODY_B(KS, BSET, B_)                                                             \
             {                                                                                \
@@ -400,13 +422,13 @@ __global__ __launch_bounds__(256, 2) void conv_up_halo_kernel(ConvArgs a, int ti
     const uint32_t key = drop_key(a.drop);
     // channel block of this wave: the 64 channels of column block tn (upsample forms: one phase per wave), or (plain form)
     // the wave's own 64 of the 256 channels of block tn
-    const int ch_blk = SP == 2 ? tn * 256 + wave * 64 : tn * 64;
+    const int ch_blk = H::PLAIN ? tn * 256 + wave * 64 : tn * 64;
     const uint32_t ci_base = (uint32_t)((a.coef_div > 1 ? n_img / a.coef_div : n_img) * a.coef_stride + ch_blk + 4 * hi);
     // output pixel (pixel tile 0, px = 0) of this lane, in elements; pixel tile mt adds 4 output rows, px adds one pixel
-    const uint32_t m0 = SP == 2 ? (uint32_t)((n_img * a.ho + ty0 + px_r) * a.wo + col)
+    const uint32_t m0 = H::PLAIN ? (uint32_t)((n_img * a.ho + ty0 + px_r) * a.wo + col)
                                 : (uint32_t)((n_img * a.ho + 2 * (ty0 + px_r) + wpy) * a.wo + 2 * col + wpx);
     const uint32_t o0 = m0 * (uint32_t)a.cout + (uint32_t)ch_blk;
-    const uint32_t mt_stride = (uint32_t)((SP == 2 ? 2 : 4) * a.wo * a.cout);
+    const uint32_t mt_stride = (uint32_t)((H::PLAIN ? 2 : 4) * a.wo * a.cout);
     // sparse form: the output tensor keeps only the listed columns, [n][ho][up_wo_store][cout]; the dropout stream stays
     // indexed by the DENSE position (o0), so masks do not depend on the storage layout
     const uint32_t store0 = SP == 1 ? (uint32_t)((n_img * a.ho + 2 * (ty0 + px_r) + wpy) * a.up_wo_store + cstore) * (uint32_t)a.cout +
@@ -507,6 +529,48 @@ void pack_halo3_frag(const bf16_t* wpk, int cout, int cin, bf16_t* out) {
     pack_up2x_frag(v.data(), blocks * 64, cin, out);
 }
 
+// 4x4 / stride 2 / pad 1 conv through the halo kernel (SP = 3): wpk [cout][16][cin] -> the fragment order of pack_up2x_frag
+// over the virtual K axis [64-channel chunk c][parity plane p = qy*2 + qx][64], "tap" slot t = ty*2 + tx of the 16-tap axis
+// holding kernel tap (ky, kx) = (2*a(qy, ty) + qy + 1, 2*a(qx, tx) + qx + 1), a(q, t) = t - q; slots 4-15 stay zero.
+void pack_halo_s2_frag(const bf16_t* wpk, int cout, int cin, bf16_t* out) {
+    const int blocks = cout / 256, cpt = cin / 64, cin4 = 4 * cin;
+    std::vector<bf16_t> v((size_t)4 * blocks * 64 * 16 * cin4, 0);  // [block-of-64 index][co][16][4*cin]
+    for (int p4 = 0; p4 < 4; ++p4)
+        for (int b = 0; b < blocks; ++b)
+            for (int c = 0; c < 64; ++c) {
+                const int co = b * 256 + p4 * 64 + c;
+                for (int ch = 0; ch < cpt; ++ch)
+                    for (int pl = 0; pl < 4; ++pl) {
+                        const int qy = pl >> 1, qx = pl & 1;
+                        for (int t = 0; t < 4; ++t) {
+                            const int ky = 2 * ((t >> 1) - qy) + qy + 1, kx = 2 * ((t & 1) - qx) + qx + 1;
+                            const bf16_t* src = wpk + ((size_t)co * 16 + ky * 4 + kx) * cin + ch * 64;
+                            bf16_t* dst = v.data() + ((((size_t)p4 * blocks * 64 + b * 64 + c) * 16) + t) * cin4 + (ch * 4 + pl) * 64;
+                            std::copy(src, src + 64, dst);
+                        }
+                    }
+            }
+    pack_up2x_frag(v.data(), blocks * 64, cin4, out);
+}
+
+bool conv_halo_s2_supported(const ConvArgs& a) {
+    if (a.up2x || a.wpk_up_frag == nullptr || a.out_bf16 == nullptr || a.out_f32 != nullptr || a.residual != nullptr) return false;
+    if (a.kh != 4 || a.kw != 4 || a.stride != 2 || a.pad != 1 || a.pix_pitch0 != 0) return false;
+    if (!(a.c0 > 0 && a.c0 % 64 == 0 && a.c1 == 0 && a.cout % 256 == 0)) return false;
+    if (a.h % 2 != 0 || a.w % 2 != 0 || a.ho != a.h / 2 || a.wo != a.w / 2 || a.ho % TILE_H != 0 || a.wo % TILE_W != 0) return false;
+    const size_t npix = (size_t)a.n * a.h * a.w;
+    return npix * a.c0 * 2 < 0x7F000000ull && (size_t)a.cout * 16 * 4 * a.c0 * 2 < 0x7F000000ull &&
+           (size_t)a.n * a.ho * a.wo * a.cout < 0xFFFFFFF0ull;
+}
+
+hipError_t launch_conv_halo_s2(const ConvArgs& a, hipStream_t stream) {
+    const int tiles_x = a.wo / TILE_W, tiles_per_img = tiles_x * (a.ho / TILE_H);
+    const int tiles_m = a.n * tiles_per_img, tiles_n = a.cout / 256;
+    hipLaunchKernelGGL(conv_up_halo_kernel<3>, dim3(tiles_m * tiles_n), dim3(256), HaloCfg<3>::LDS_TOTAL, stream, a, tiles_x,
+                       tiles_per_img, tiles_m, tiles_n);
+    return hipGetLastError();
+}
+
 bool conv_halo3_supported(const ConvArgs& a) {
     if (a.up2x || a.wpk_up_frag == nullptr || a.out_bf16 == nullptr || a.out_f32 != nullptr || a.residual != nullptr) return false;
     if (a.kh != 3 || a.kw != 3 || a.stride != 1 || a.pad != 1 || a.pix_pitch0 != 0) return false;
@@ -534,6 +598,9 @@ hipError_t conv_up_halo_init() {
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)conv_up_halo_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 HaloCfg<2>::LDS_TOTAL);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)conv_up_halo_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                HaloCfg<3>::LDS_TOTAL);
     return e;
 }
 

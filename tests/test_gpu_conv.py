@@ -100,13 +100,16 @@ def test_second_igemm_form_matches_torch(engine, case, monkeypatch):
 
 
 HALO3_CASES = [(2, 16, 16, 64, 256, 3, 1, 1), (1, 32, 48, 128, 256, 3, 1, 1), (3, 8, 16, 192, 512, 3, 1, 1),
-               (1, 64, 32, 64, 256, 3, 1, 1)]
+               (1, 64, 32, 64, 256, 3, 1, 1),
+               # 4 x 4 / stride 2 / pad 1 on the space-to-depth view (conv_up_halo_kernel<3>)
+               (2, 16, 32, 64, 256, 4, 2, 1), (1, 64, 64, 128, 256, 4, 2, 1), (3, 32, 32, 256, 512, 4, 2, 1)]
 
 
 @pytest.mark.parametrize("case", HALO3_CASES, ids=lambda c: "x".join(map(str, c)))
-def test_plain_3x3_on_the_halo_kernel_matches_torch(engine, case, monkeypatch):
-    """conv_up_halo_kernel<2>: plain 3x3 / s1 / p1 conv (cout % 256 == 0) with the window in LDS and zero-filled borders;
-    production uses it from 512 tiles on, DYF_HALO3_MIN_TILES=1 forces it here.  Borders checked separately."""
+def test_plain_convs_on_the_halo_kernel_match_torch(engine, case, monkeypatch):
+    """conv_up_halo_kernel<2> / <3>: plain 3x3 / s1 / p1 and 4x4 / s2 / p1 convs (cout % 256 == 0) with the window in LDS
+    and zero-filled borders; production uses them from 512 tiles on, DYF_HALO3_MIN_TILES=1 forces them here.  Borders
+    checked separately."""
     n, h, w, cin, cout, k, stride, pad = case
     g = torch.Generator().manual_seed(sum(case) + 1)
     x = torch.randn(n, h, w, cin, generator=g).to(torch.bfloat16)
