@@ -1,24 +1,30 @@
-// Fused x2-bilinear-upsample + 3x3 conv, "halo" form (gfx950): the dominant kernel of the Navier-Stokes backbone
-// (decoder blocks dec4-dec5 of src/models/unet_simple.py:40-52, ~55 % of a forward's time).
+// The "halo" convolution kernel (gfx950): fused x2-bilinear-upsample + 3x3 conv of the decoder blocks
+// (src/models/unet_simple.py:40-52; dec3-dec5 = half of a forward's time), and -- same machinery, template SP = 2 / 3 --
+// plain 3x3 / stride 1 and 4x4 / stride 2 convolutions with 256-channel output blocks.
 //
-// Same mathematics as conv_igemm_kernel<.., UP=1> (phase decomposition + border-correction taps, see conv.hip); the data
-// movement is designed around what bounded the previous forms of this kernel, the CU's 128 B/clk of LDS bandwidth:
-//   * a workgroup (4 waves, one per SIMD, 512 registers each) owns a 16x16 LOW-res tile and ALL FOUR output phases of 64
-//     output channels: GEMM tile M = 256 pixels x N = 256 (4 phases x 64 channels).  Wave (wm, wn) owns tile rows
-//     8*wm..8*wm+7 (128 pixels) x the two phases with py = wn (128 columns) = 4 x 4 accumulator tiles of
-//     v_mfma_f32_32x32x16_bf16: every fragment that is fetched feeds 4 MFMAs;
-//   * per 64-channel chunk the 18x18 replicate-padded input window ("halo", 41 KB) is DMA'd into LDS ONCE
-//     (buffer_load ... lds) and all 9 stencil taps (and the correction taps) read their pixel fragments from it at
-//     shifted addresses.  This is the ONLY LDS traffic (32 B/clk/CU at MFMA peak);
+// Upsample forms: same mathematics as conv_igemm_kernel<.., UP=1> (phase decomposition + border-correction taps, see
+// conv.hip).  The data movement is designed around what bounded the previous forms, the CU's 128 B/clk of LDS bandwidth:
+//   * a workgroup (4 waves, 256 registers each, TWO workgroups per CU) owns an 8x16 LOW-res tile and all four output
+//     phases of 64 output channels: GEMM tile M = 128 pixels x N = 256 (4 phases x 64 channels).  A wave owns one phase:
+//     128 pixels x 64 channels = 4 x 2 accumulator tiles of v_mfma_f32_32x32x16_bf16 (128 registers); every pixel
+//     fragment read from LDS feeds 2 MFMAs, every weight fragment 4;
+//   * per 64-channel chunk the 10x18 replicate-padded input window ("halo", 23 KB) is DMA'd into LDS ONCE
+//     (buffer_load ... lds, double-buffered) and all 9 stencil taps (and the correction taps) read their pixel fragments
+//     from it at shifted addresses.  This is the ONLY LDS traffic (64 B/clk/CU at MFMA peak);
 //   * the weights never touch LDS: they are pre-packed on the host in MFMA FRAGMENT ORDER (pack_up2x_frag), so that one
 //     wave-wide buffer_load_dwordx4 fetches 1 KB of contiguous memory = one 32-channel x 16-k fragment straight into
 //     registers (L2/L1-resident; 32 B/clk/CU of the vector-memory path).  Four fragment sets are in flight 3 k16
-//     sub-steps (~1 500 cycles) ahead of their use;
+//     sub-steps ahead of their use;
 //   * consequently there is NO per-step workgroup barrier: the waves meet only once per 64-channel chunk (halo swap,
-//     every 9-16 steps of 64 MFMAs) and drift apart in between;
+//     every 9-16 steps of 32 MFMAs) and drift apart in between; the second workgroup of the CU covers barrier, halo
+//     swap and epilogue of the first;
+//   * inside a k16 sub-step the 4 LDS reads (inline asm, hand-counted lgkmcnt; one v_xad_u32 of address arithmetic each,
+//     per-tap base/swizzle terms precomputed) and the 2 weight loads of later sub-steps are pinned BETWEEN the 8 MFMAs;
 //   * operands are swapped (D^T = W * X^T): an accumulator lane then holds 4 consecutive CHANNELS of one pixel, so the
 //     epilogue (affine / activation / dropout / bf16 pack) runs straight out of the accumulators, pairs lanes l and
 //     l+32 with v_permlane32_swap and stores 16 B per lane: no LDS round trip, no barrier.
+// History (measured): gather form 800 TFLOP/s -> halo + weights through LDS 905 -> weights streamed, 128x128
+// wave tiles, 1 workgroup/CU 1105 -> this form 1200 (dense upsample) / 1310 (plain 3x3, no correction taps).
 #include "conv.h"
 
 #include <algorithm>
