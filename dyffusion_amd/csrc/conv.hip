@@ -12,8 +12,12 @@
 //     linearly, so the swizzle is applied to the per-lane SOURCE chunk and again on the ds_read_b128 fragment reads.
 //   * 4 waves, each owns a 64x64 accumulator (2x2 MFMA 32x32x16 bf16 tiles, 64 fp32 regs); two stages, one barrier per
 //     K step, next step's DMA in flight under the current step's 16 MFMAs.
-//   * epilogue through LDS: fp32 tile -> per-(sample, channel) affine (conv bias + BatchNorm + FiLM folded) ->
-//     activation -> dropout -> bf16 -> 16-B coalesced NHWC stores.
+//   * operands swapped (D^T = W X^T): an accumulator lane holds 4 consecutive channels of one pixel, so the epilogue --
+//     per-(sample, channel) affine (conv bias + BatchNorm + FiLM folded) -> activation -> dropout (+ residual) -> bf16 --
+//     runs straight out of the accumulators (v_permlane32_swap pairs lanes l / l+32 for 16-B stores): no LDS round trip.
+//   * dispatch (launch_conv): fused-upsample convs and plain 3x3-s1 / 4x4-s2 convs with 256-channel blocks -> the halo
+//     kernel (conv_up_halo.hip); other convs with cout % 128 == 0 and >= 384 tiles -> conv_igemm2_kernel (weights
+//     streamed in fragment order); the rest -> this file's conv_igemm_kernel; channels % 64 != 0 -> conv_direct_kernel.
 //   * blockIdx -> tile map is XCD-aware (block b runs on XCD b % 8): every XCD walks a contiguous range of tiles so
 //     the 3x3 / 4x4 halo re-reads of neighbouring tiles hit that XCD's own L2.
 #include "conv.h"
