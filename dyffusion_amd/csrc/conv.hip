@@ -578,14 +578,16 @@ hipError_t launch_conv(const ConvArgs& a, int path, hipStream_t stream) {
                 if (b.wpk_up_frag && tiles3 >= (mt3 ? atoll(mt3) : 256) && conv_halo3_supported(b)) return launch_conv_halo3(b, stream);
             }
         }
-        if (!a.up2x && a.kh == 4 && a.kw == 4 && a.stride == 2 && a.cout % 256 == 0 && a.c1 == 0 && a.out_f32 == nullptr &&
+        if (!a.up2x && a.kh == 4 && a.kw == 4 && a.stride == 2 && a.cout % 128 == 0 && a.c1 == 0 && a.out_f32 == nullptr &&
             a.residual == nullptr && a.pix_pitch0 == 0) {  // 4x4 / s2 convs: the same kernel on the space-to-depth view
             const char* h3 = getenv("DYF_HALO3");
             if (!(h3 && atoi(h3) == 0)) {
                 ConvArgs b = a;
                 b.wpk_up_frag = conv_lookup_halo3_frag(b.wpk);
                 const char* mt3 = getenv("DYF_HALO3_MIN_TILES");
-                const long long tiles3 = ((long long)a.n * a.ho * a.wo / 128) * (a.cout / 256);
+                // cout % 256 == 0: 8 x 16 tiles x 256 channels; else 16 x 16 tiles x 128 channels
+                const long long tiles3 = a.cout % 256 == 0 ? ((long long)a.n * a.ho * a.wo / 128) * (a.cout / 256)
+                                                           : ((long long)a.n * a.ho * a.wo / 256) * (a.cout / 128);
                 if (b.wpk_up_frag && tiles3 >= (mt3 ? atoll(mt3) : 256) && conv_halo_s2_supported(b)) return launch_conv_halo_s2(b, stream);
             }
         }

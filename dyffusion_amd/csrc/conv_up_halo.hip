@@ -52,6 +52,8 @@ constexpr int STEP_BYTES = 32768;                       // weights of one (tap, 
 //         (qy = 0: a in {0, +1}; qy = 1: a in {-1, 0}), so every (plane, 64-channel chunk) contributes a 2 x 2 stencil.
 //         The DMA gathers one plane of one chunk per halo (per-lane source offsets: any pixel map is free), the K loop
 //         walks 4 planes x c0/64 chunks x 4 taps.  Weights: pack_halo_s2_frag.
+// SP = 4: SP = 3 for layers with a multiple of 128 (not 256) output channels: the workgroup's tile is 16 x 16 pixels, waves
+//         (wpy, wpx) = (8-row half, 64-channel block); halo 18 x 18, single-buffered (two workgroups per CU still fit).
 // SP = 1: SPARSE COLUMNS -- the 16 columns of a tile are entries of a per-phase column list (ConvArgs::up_cols): only the
 // output columns a later kernel reads are computed.  The NS backbone resamples its 256-wide grid to 42 native columns
 // (unet_simple.py:195): the readout touches 104 of the 256 columns of the last decoder block, i.e. 52 of 128 low-res columns
@@ -60,11 +62,15 @@ constexpr int STEP_BYTES = 32768;                       // weights of one (tap, 
 template <int SP>
 struct HaloCfg {
     static constexpr int W = SP == 1 ? 40 : 18;         // halo width in pixels
-    static constexpr int REAL = 10 * W;
+    static constexpr int TH = SP == 4 ? 16 : 8;         // tile rows
+    static constexpr int REAL = (TH + 2) * W;
     static constexpr int PIX = (REAL + 7) / 8 * 8;      // padded to a multiple of 8 DMA rows
     static constexpr int BYTES = PIX * 128;             // 23 552 / 51 200
-    static constexpr int NBUF = SP == 1 ? 1 : 2;
+    static constexpr int NBUF = (SP == 1 || SP == 4) ? 1 : 2;
     static constexpr bool PLAIN = SP >= 2;              // one output-channel block per wave, zero-padded window, no corrections
+    static constexpr bool S2 = SP == 3 || SP == 4;      // 4x4 / stride 2 on parity planes
+    static constexpr int BLK = SP == 4 ? 128 : 256;     // plain forms: output channels of a workgroup
+    static constexpr int STEP = BLK * 128;              // weight bytes of one (tap, chunk) step: BLK columns x 64 k bf16
     static constexpr int ZERO_OFF = NBUF * BYTES;       // 128 B of zeros (pixels masked out of a correction tap)
     static constexpr int HOFF_OFF = ZERO_OFF + 512;     // per-thread halo source offsets [PER_WAVE][256]
     static constexpr int INSTR = PIX / 8;               // wave-level DMA instructions per halo: 23 / 50
@@ -96,7 +102,7 @@ __global__ __launch_bounds__(256, 2) void conv_up_halo_kernel(ConvArgs a, int ti
     const int tn = tile % tiles_n, tm = tile / tiles_n;
     const int n_img = tm / tiles_per_img;
     const int t_in = tm - n_img * tiles_per_img;
-    const int ty0 = (t_in / tiles_x) * TILE_H;
+    const int ty0 = (t_in / tiles_x) * H::TH;
     const int lx = t_in % tiles_x;              // column tile: 16 contiguous columns, or 16 entries of the column lists
     const int px_x = l31 & 15, px_r = l31 >> 4;
     // low-res column of this lane's pixels and the column the halo starts at
@@ -114,17 +120,17 @@ __global__ __launch_bounds__(256, 2) void conv_up_halo_kernel(ConvArgs a, int ti
     }
 
     const int cin = a.c0 + a.c1;
-    const int cpt = SP == 3 ? 4 * (cin >> 6) : cin >> 6;  // K chunks: (SP = 3) 4 parity planes per 64-channel chunk
+    const int cpt = H::S2 ? 4 * (cin >> 6) : cin >> 6;  // K chunks: (SP = 3) 4 parity planes per 64-channel chunk
     // border corrections are per WAVE (a wave owns one output phase): the top/bottom row matters to phases py = 0 / 1, the
     // left/right column to px = 0 / 1.  Waves only meet at the per-chunk barrier, so each runs its own tap list.
-    const int gh = SP == 3 ? a.ho : a.h, gw = SP == 3 ? a.wo : a.w;  // the grid the halo / tiles live on
-    const bool has_top = ty0 == 0, has_bot = ty0 + TILE_H == gh;
+    const int gh = H::S2 ? a.ho : a.h, gw = H::S2 ? a.wo : a.w;  // the grid the halo / tiles live on
+    const bool has_top = ty0 == 0, has_bot = ty0 + H::TH == gh;
     const bool m_left = col == 0, m_right = col == gw - 1;
     const bool has_row = !H::PLAIN && (wpy == 0 ? has_top : has_bot);
     const bool has_col = !H::PLAIN && (wpx == 0 ? __builtin_amdgcn_ballot_w64(m_left) : __builtin_amdgcn_ballot_w64(m_right)) != 0ull;
     // tap list of this wave, 4 bits per entry: 0-8 stencil, 9-11 row correction, 12-14 column correction, 15 corner
-    unsigned long long tap_list = SP == 3 ? 0x3210ull : 0x876543210ull;
-    int ntaps = SP == 3 ? 4 : 9;
+    unsigned long long tap_list = H::S2 ? 0x3210ull : 0x876543210ull;
+    int ntaps = H::S2 ? 4 : 9;
     if (has_row) { tap_list |= 0xBA9ull << (4 * ntaps); ntaps += 3; }
     if (has_col) { tap_list |= 0xEDCull << (4 * ntaps); ntaps += 3; }
     if (has_row && has_col) { tap_list |= 0xFull << (4 * ntaps); ntaps += 1; }
@@ -150,7 +156,7 @@ __global__ __launch_bounds__(256, 2) void conv_up_halo_kernel(ConvArgs a, int ti
         const int y = min(max(yy, 0), gh - 1), x = min(max(xx, 0), gw - 1);  // replicate clamp (upsample forms)
         const int gch = (lane & 7) ^ ((hp >> 1) & 7);  // swizzled source chunk of this linear LDS slot
         // SP = 3: halo pixel (y, x) of parity plane (0, 0) is input pixel (2y, 2x); the plane offset is added per chunk
-        unsigned off = (SP == 3 ? (unsigned)((n_img * a.h + 2 * y) * a.w + 2 * x) : (unsigned)((n_img * a.h + y) * a.w + x)) *
+        unsigned off = (H::S2 ? (unsigned)((n_img * a.h + 2 * y) * a.w + 2 * x) : (unsigned)((n_img * a.h + y) * a.w + x)) *
                            (unsigned)(a.c0 * 2) + gch * 16;  // c0 == c1 (checked on host)
         if (H::PLAIN && (yy != y || xx != x)) off = 0xFFFFFFFFu;  // plain convs: zero padding = out-of-range DMA offset
         h_tab[j * 256] = off;
@@ -158,10 +164,10 @@ __global__ __launch_bounds__(256, 2) void conv_up_halo_kernel(ConvArgs a, int ti
     if (tid < 32) ((uint4*)(smem + ZERO_OFF))[tid] = make_uint4(0, 0, 0, 0);
 
     auto issue_halo = [&](int chunk) {
-        const int cb = SP == 3 ? (chunk >> 2) << 6 : chunk << 6;
-        const bool second = SP != 3 && cb >= a.c0;
+        const int cb = H::S2 ? (chunk >> 2) << 6 : chunk << 6;
+        const bool second = !H::S2 && cb >= a.c0;
         unsigned coff = (unsigned)((second ? cb - a.c0 : cb) * 2);
-        if (SP == 3) coff += (unsigned)((((chunk >> 1) & 1) * a.w + (chunk & 1)) * a.c0 * 2);  // plane (qy, qx) = chunk & 3
+        if (H::S2) coff += (unsigned)((((chunk >> 1) & 1) * a.w + (chunk & 1)) * a.c0 * 2);  // plane (qy, qx) = chunk & 3
         char* dst = smem + (H::NBUF == 2 ? (chunk & 1) * HALO_BYTES : 0);
 #pragma unroll
         for (int j = 0; j < HALO_PER_WAVE; ++j) {
@@ -183,7 +189,7 @@ __global__ __launch_bounds__(256, 2) void conv_up_halo_kernel(ConvArgs a, int ti
     int it_pos = 0, it_chunk = 0;
     auto soff_of = [&](int pos, int chunk) {
         const int tap = (int)((tap_list >> (4 * pos)) & 15ull);
-        return (unsigned)(((tn * cpt + chunk) * 16 + tap) * STEP_BYTES + wpy * (STEP_BYTES / 2) + wpx * 2048);
+        return (unsigned)(((tn * cpt + chunk) * 16 + tap) * H::STEP + (SP == 4 ? 0 : wpy * (STEP_BYTES / 2)) + wpx * 2048);
     };
     unsigned soff_cur = soff_of(0, 0), soff_next = soff_cur;
     auto advance = [&]() {  // the tail re-fetches the last step (harmless, never consumed)
@@ -201,7 +207,7 @@ __global__ __launch_bounds__(256, 2) void conv_up_halo_kernel(ConvArgs a, int ti
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[nt][mt][r] = 0.0f;
 
-    int hp0 = (px_r + 1) * HALO_W + (col - cbase);  // halo pixel of pixel tile 0 at the un-shifted tap; mt adds 2 rows
+    int hp0 = (px_r + 1 + (SP == 4 ? 8 * wpy : 0)) * HALO_W + (col - cbase);  // halo pixel of pixel tile 0 at the un-shifted tap; mt adds 2 rows
     const bool m_row = wpy == 0 ? px_r == 0 : px_r == 1;   // border row: pixel tile 0 (top) / 3 (bottom)
     const bool m_col = wpx == 0 ? m_left : m_right;
     const unsigned lds_base = (unsigned)(uintptr_t)LDS_PTR(smem);
@@ -323,7 +329,7 @@ __global__ __launch_bounds__(256, 2) void conv_up_halo_kernel(ConvArgs a, int ti
         }
         const unsigned Hs = lds_base + (H::NBUF == 2 ? (chunk & 1) * HALO_BYTES : 0);
         asm volatile("" : "+v"(hp0));  // keep the per-tap LDS addresses from being hoisted out of the chunk loop
-        if (SP == 3) {
+        if (H::S2) {
             // 2 x 2 taps of parity plane (qy, qx): displacement a in {0, +1} for parity 0, {-1, 0} for parity 1
             const int qy = (chunk >> 1) & 1, qx = chunk & 1;
             const int d00 = -qy * HALO_W - qx, d01 = d00 + 1, d10 = d00 + HALO_W, d11 = d10 + 1;
@@ -428,10 +434,10 @@ __global__ __launch_bounds__(256, 2) void conv_up_halo_kernel(ConvArgs a, int ti
     const uint32_t key = drop_key(a.drop);
     // channel block of this wave: the 64 channels of column block tn (upsample forms: one phase per wave), or (plain form)
     // the wave's own 64 of the 256 channels of block tn
-    const int ch_blk = H::PLAIN ? tn * 256 + wave * 64 : tn * 64;
+    const int ch_blk = H::PLAIN ? tn * H::BLK + (SP == 4 ? wpx : wave) * 64 : tn * 64;
     const uint32_t ci_base = (uint32_t)((a.coef_div > 1 ? n_img / a.coef_div : n_img) * a.coef_stride + ch_blk + 4 * hi);
     // output pixel (pixel tile 0, px = 0) of this lane, in elements; pixel tile mt adds 4 output rows, px adds one pixel
-    const uint32_t m0 = H::PLAIN ? (uint32_t)((n_img * a.ho + ty0 + px_r) * a.wo + col)
+    const uint32_t m0 = H::PLAIN ? (uint32_t)((n_img * a.ho + ty0 + px_r + (SP == 4 ? 8 * wpy : 0)) * a.wo + col)
                                 : (uint32_t)((n_img * a.ho + 2 * (ty0 + px_r) + wpy) * a.wo + 2 * col + wpx);
     const uint32_t o0 = m0 * (uint32_t)a.cout + (uint32_t)ch_blk;
     const uint32_t mt_stride = (uint32_t)((H::PLAIN ? 2 : 4) * a.wo * a.cout);
@@ -539,6 +545,27 @@ void pack_halo3_frag(const bf16_t* wpk, int cout, int cin, bf16_t* out) {
 // over the virtual K axis [64-channel chunk c][parity plane p = qy*2 + qx][64], "tap" slot t = ty*2 + tx of the 16-tap axis
 // holding kernel tap (ky, kx) = (2*a(qy, ty) + qy + 1, 2*a(qx, tx) + qx + 1), a(q, t) = t - q; slots 4-15 stay zero.
 void pack_halo_s2_frag(const bf16_t* wpk, int cout, int cin, bf16_t* out) {
+    if (cout % 256 != 0) {
+        // SP = 4 (128-channel workgroups): [tn][virtual chunk = c*4 + plane][16 slots][ks][wn][nt][lane][8 k]
+        const int cpt = cin / 64;
+        size_t o = 0;
+        for (int tn = 0; tn < cout / 128; ++tn)
+            for (int ch = 0; ch < cpt; ++ch)
+                for (int pl = 0; pl < 4; ++pl)
+                    for (int t = 0; t < 16; ++t)
+                        for (int ks = 0; ks < 4; ++ks)
+                            for (int wn = 0; wn < 2; ++wn)
+                                for (int nt = 0; nt < 2; ++nt)
+                                    for (int lane = 0; lane < 64; ++lane) {
+                                        const int qy = pl >> 1, qx = pl & 1;
+                                        const int ky = 2 * ((t >> 1) - qy) + qy + 1, kx = 2 * ((t & 1) - qx) + qx + 1;
+                                        const int co = tn * 128 + wn * 64 + nt * 32 + (lane & 31);
+                                        const int k0 = ch * 64 + ks * 16 + (lane >> 5) * 8;
+                                        const bf16_t* s = wpk + ((size_t)co * 16 + ky * 4 + kx) * cin + k0;
+                                        for (int e = 0; e < 8; ++e) out[o++] = t < 4 ? s[e] : (bf16_t)0;
+                                    }
+        return;
+    }
     const int blocks = cout / 256, cpt = cin / 64, cin4 = 4 * cin;
     std::vector<bf16_t> v((size_t)4 * blocks * 64 * 16 * cin4, 0);  // [block-of-64 index][co][16][4*cin]
     for (int p4 = 0; p4 < 4; ++p4)
@@ -562,14 +589,22 @@ void pack_halo_s2_frag(const bf16_t* wpk, int cout, int cin, bf16_t* out) {
 bool conv_halo_s2_supported(const ConvArgs& a) {
     if (a.up2x || a.wpk_up_frag == nullptr || a.out_bf16 == nullptr || a.out_f32 != nullptr || a.residual != nullptr) return false;
     if (a.kh != 4 || a.kw != 4 || a.stride != 2 || a.pad != 1 || a.pix_pitch0 != 0) return false;
-    if (!(a.c0 > 0 && a.c0 % 64 == 0 && a.c1 == 0 && a.cout % 256 == 0)) return false;
-    if (a.h % 2 != 0 || a.w % 2 != 0 || a.ho != a.h / 2 || a.wo != a.w / 2 || a.ho % TILE_H != 0 || a.wo % TILE_W != 0) return false;
+    if (!(a.c0 > 0 && a.c0 % 64 == 0 && a.c1 == 0 && a.cout % 128 == 0)) return false;
+    const int th = a.cout % 256 == 0 ? TILE_H : HaloCfg<4>::TH;
+    if (a.h % 2 != 0 || a.w % 2 != 0 || a.ho != a.h / 2 || a.wo != a.w / 2 || a.ho % th != 0 || a.wo % TILE_W != 0) return false;
     const size_t npix = (size_t)a.n * a.h * a.w;
     return npix * a.c0 * 2 < 0x7F000000ull && (size_t)a.cout * 16 * 4 * a.c0 * 2 < 0x7F000000ull &&
            (size_t)a.n * a.ho * a.wo * a.cout < 0xFFFFFFF0ull;
 }
 
 hipError_t launch_conv_halo_s2(const ConvArgs& a, hipStream_t stream) {
+    if (a.cout % 256 != 0) {
+        const int tiles_x = a.wo / TILE_W, tiles_per_img = tiles_x * (a.ho / HaloCfg<4>::TH);
+        const int tiles_m = a.n * tiles_per_img, tiles_n = a.cout / 128;
+        hipLaunchKernelGGL(conv_up_halo_kernel<4>, dim3(tiles_m * tiles_n), dim3(256), HaloCfg<4>::LDS_TOTAL, stream, a, tiles_x,
+                           tiles_per_img, tiles_m, tiles_n);
+        return hipGetLastError();
+    }
     const int tiles_x = a.wo / TILE_W, tiles_per_img = tiles_x * (a.ho / TILE_H);
     const int tiles_m = a.n * tiles_per_img, tiles_n = a.cout / 256;
     hipLaunchKernelGGL(conv_up_halo_kernel<3>, dim3(tiles_m * tiles_n), dim3(256), HaloCfg<3>::LDS_TOTAL, stream, a, tiles_x,
@@ -607,6 +642,9 @@ hipError_t conv_up_halo_init() {
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)conv_up_halo_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 HaloCfg<3>::LDS_TOTAL);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)conv_up_halo_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                HaloCfg<4>::LDS_TOTAL);
     return e;
 }
 

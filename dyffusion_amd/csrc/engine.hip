@@ -1100,7 +1100,7 @@ dyf_status dyf_op_conv2d(dyf_engine* e, const uint16_t* x_dev, const float* w_ho
     a.kh = kh; a.kw = kw; a.stride = stride; a.pad = pad; a.cout = cout; a.wpk = wdev;
     a.wpk_frag = frag ? wdev + pk.size() : nullptr;
     bf16_t* h3dev = nullptr;  // halo form of plain 3x3 convs (looked up through the registry like the engine's own weights)
-    if ((taps == 9 || (kh == 4 && kw == 4)) && cout % 256 == 0 && cin % 64 == 0) {
+    if (((taps == 9 && cout % 256 == 0) || (kh == 4 && kw == 4 && cout % 128 == 0)) && cin % 64 == 0) {
         std::vector<bf16_t> pf((size_t)cout * 16 * cin * (taps == 9 ? 1 : 4));
         if (taps == 9) pack_halo3_frag(pk.data(), cout, cin, pf.data());
         else pack_halo_s2_frag(pk.data(), cout, cin, pf.data());

@@ -172,7 +172,7 @@ inline dyf_status upload_conv_weights(dyf_engine* e, bf16_t** out, const std::ve
         if (st != DYF_OK) return st;
         conv_register_frag(*out, frag);
     }
-    if (taps == 16 && cout % 256 == 0 && cin % 64 == 0 && (size_t)cout * taps * cin == pk.size()) {  // halo form of 4x4 / s2
+    if (taps == 16 && cout % 128 == 0 && cin % 64 == 0 && (size_t)cout * taps * cin == pk.size()) {  // halo form of 4x4 / s2
         std::vector<bf16_t> pf((size_t)cout * 16 * 4 * cin);
         pack_halo_s2_frag(pk.data(), cout, cin, pf.data());
         bf16_t* frag = nullptr;

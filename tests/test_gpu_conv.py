@@ -102,7 +102,9 @@ def test_second_igemm_form_matches_torch(engine, case, monkeypatch):
 HALO3_CASES = [(2, 16, 16, 64, 256, 3, 1, 1), (1, 32, 48, 128, 256, 3, 1, 1), (3, 8, 16, 192, 512, 3, 1, 1),
                (1, 64, 32, 64, 256, 3, 1, 1),
                # 4 x 4 / stride 2 / pad 1 on the space-to-depth view (conv_up_halo_kernel<3>)
-               (2, 16, 32, 64, 256, 4, 2, 1), (1, 64, 64, 128, 256, 4, 2, 1), (3, 32, 32, 256, 512, 4, 2, 1)]
+               (2, 16, 32, 64, 256, 4, 2, 1), (1, 64, 64, 128, 256, 4, 2, 1), (3, 32, 32, 256, 512, 4, 2, 1),
+               # ... with 128-channel workgroups on 16 x 16 tiles (conv_up_halo_kernel<4>)
+               (2, 32, 32, 64, 128, 4, 2, 1), (1, 64, 96, 128, 384, 4, 2, 1), (3, 128, 128, 64, 128, 4, 2, 1)]
 
 
 @pytest.mark.parametrize("case", HALO3_CASES, ids=lambda c: "x".join(map(str, c)))
