@@ -65,6 +65,7 @@ SYMBOLS = [
     ("dyf_time_layer_in_rollout", C.c_int, [_P, C.c_int32, C.c_int32, _P, C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
     ("dyf_op_conv2d", C.c_int, [_P, _P, _P] + [C.c_int32] * 9 + [_P, _P, C.c_int32, C.c_int32, _P, _P]),
     ("dyf_op_upconv2d", C.c_int, [_P, _P, _P] + [C.c_int32] * 5 + [_P, _P, C.c_int32, _P, _P]),
+    ("dyf_op_linear_attention", C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, _P]),
 ]
 
 

@@ -21,13 +21,16 @@ __device__ __host__ __forceinline__ bf16_t f32_to_bf16(float f) {
     return (bf16_t)(u >> 16);
 }
 
-// two fp32 -> packed bf16x2, round-to-nearest-even: one v_cvt_pk_bf16_f32 on gfx950 (no clang builtin; the software
-// form costs ~8 VALU per pair and dominated the conv epilogues)
+// two fp32 -> packed bf16x2, round-to-nearest-even: one v_cvt_pk_bf16_f32 on gfx950 (the software form costs ~8 VALU per
+// pair and dominated the conv epilogues).  Written as a vector conversion, NOT inline asm: the compiler's hazard
+// recogniser does not look inside asm, and a v_exp_f32 / v_rcp_f32 result consumed by the very next VALU instruction needs
+// a wait state (an asm v_cvt right behind a v_exp read the stale register).
+typedef __bf16 bf16x2_native_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_native_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    uint32_t r;
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-    return r;
+    const f32x2_native_t v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_native_t));
 #else
     return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
 #endif

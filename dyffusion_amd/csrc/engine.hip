@@ -1184,4 +1184,21 @@ dyf_status dyf_op_upconv2d(dyf_engine* e, const uint16_t* x_dev, const float* w_
     return rs;
 }
 
+dyf_status dyf_op_linear_attention(dyf_engine* e, const uint16_t* qkv_dev, int32_t n, int32_t hw, uint16_t* out_dev,
+                                   void* stream) {
+    if (!e || !qkv_dev || !out_dev || n < 1 || hw < 1) return fail(e, DYF_ERR_INVALID_ARGUMENT, "dyf_op_linear_attention: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    const int heads = 4;
+    const size_t nblk = ((size_t)hw + 1023) / 1024;
+    float* scratch = nullptr;
+    HIP_TRY(e, hipMalloc((void**)&scratch, (size_t)n * heads * (nblk * 1088 + 1024) * sizeof(float)));
+    LinAttnArgs l{};
+    l.qkv = qkv_dev; l.n = n; l.hw = hw; l.heads = heads; l.out = out_dev; l.scratch = scratch;
+    hipError_t err = launch_linear_attention(l, st);
+    if (err == hipSuccess) err = hipStreamSynchronize(st);
+    (void)hipFree(scratch);
+    if (err != hipSuccess) return fail(e, DYF_ERR_HIP, std::string("dyf_op_linear_attention: ") + hipGetErrorString(err));
+    return DYF_OK;
+}
+
 }  // extern "C"

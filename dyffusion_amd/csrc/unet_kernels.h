@@ -49,7 +49,7 @@ struct LinAttnArgs {
     const bf16_t* qkv;
     int n, hw, heads;   // dim_head = 32
     bf16_t* out;
-    float* scratch;     // device fp32 [n*heads][ceil(hw/1024)*64 + 1024] for the pixel-parallel form, or null
+    float* scratch;     // device fp32 [n*heads][ceil(hw/1024)*1088 + 1024] for the pixel-parallel form, or null
 };
 hipError_t launch_linear_attention(const LinAttnArgs& a, hipStream_t s);
 

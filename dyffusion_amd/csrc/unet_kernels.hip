@@ -144,40 +144,61 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* x, int hw, 
     const int chunks = c >> 3, cpg = c / groups;
     for (int i = threadIdx.x; i < groups * 2; i += blockDim.x) (&part[0][0])[i] = 0.0f;
     __syncthreads();
-    const long long total = (long long)hw * chunks;
     const int cq = cpg >> 3;  // chunks per group
-    const bool pow2 = (chunks & (chunks - 1)) == 0 && (cq & (cq - 1)) == 0 && chunks <= 64;
-    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
-        // the whole wave is inside the tensor (its lanes are 64 consecutive chunk indices starting at a multiple of 64)
-        const bool full_wave = (idx - (threadIdx.x & 63)) + 64 <= total;
-        const int q = (int)(idx % chunks);
-        const long long p = idx / chunks;
-        const uint4 v = *(const uint4*)(x + ((size_t)n * hw + p) * c + q * 8);
-        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    const bool pow2 = (chunks & (chunks - 1)) == 0 && (cq & (cq - 1)) == 0 && chunks <= 256;
+    if (pow2) {
+        // a thread keeps ONE chunk column (q) and walks pixels: no index arithmetic in the loop, the group never changes, so
+        // the partial sums stay in registers until the end
+        const int q = threadIdx.x & (chunks - 1), row = threadIdx.x / chunks, rows = 256 / chunks;
+        const bf16_t* xp = x + (size_t)n * hw * c + q * 8;
         float s = 0.0f, ss = 0.0f;
+        const int step = gridDim.x * rows;
+        int p = blockIdx.x * rows + row;
+        auto add = [&](const uint4& v) {
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const float lo = __uint_as_float(w[t] << 16), hi = __uint_as_float(w[t] & 0xffff0000u);
-            s += lo + hi;
-            ss = fmaf(lo, lo, fmaf(hi, hi, ss));
+            for (int t = 0; t < 4; ++t) {
+                const float lo = __uint_as_float(w[t] << 16), hi = __uint_as_float(w[t] & 0xffff0000u);
+                s += lo + hi;
+                ss = fmaf(lo, lo, fmaf(hi, hi, ss));
+            }
+        };
+        for (; p + 3 * step < hw; p += 4 * step) {  // four independent 16-B loads in flight
+            const uint4 v0 = *(const uint4*)(xp + (size_t)p * c), v1 = *(const uint4*)(xp + (size_t)(p + step) * c);
+            const uint4 v2 = *(const uint4*)(xp + (size_t)(p + 2 * step) * c), v3 = *(const uint4*)(xp + (size_t)(p + 3 * step) * c);
+            add(v0); add(v1); add(v2); add(v3);
         }
-        const int g = (q * 8) / cpg;
-        if (pow2 && full_wave) {
-            // lanes l and l ^ d hold the same group when d < cpg/8 (same group, neighbouring chunks) or d >= chunks (same
-            // chunk of another pixel): butterfly over those strides, then one LDS atomic per group and wave
+        for (; p < hw; p += step) add(*(const uint4*)(xp + (size_t)p * c));
+        // lanes l and l ^ d hold the same group when d < cq (neighbouring chunks of the group) or d >= chunks (same chunk,
+        // another pixel row): butterfly over those strides, then one LDS atomic per group and wave
 #pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                if (d < cq || d >= chunks) {
-                    s += __shfl_xor(s, d, 64);
-                    ss += __shfl_xor(ss, d, 64);
-                }
+        for (int d = 1; d < 64; d <<= 1) {
+            if (d < cq || d >= chunks) {
+                s += __shfl_xor(s, d, 64);
+                ss += __shfl_xor(ss, d, 64);
             }
-            const int l = threadIdx.x & 63;
-            if (l < chunks && (l & (cq - 1)) == 0) {
-                atomicAdd(&part[g][0], s);
-                atomicAdd(&part[g][1], ss);
+        }
+        const int l = threadIdx.x & 63;
+        if ((l & (cq - 1)) == 0 && (chunks >= 64 || l < chunks)) {
+            const int g = (q * 8) / cpg;
+            atomicAdd(&part[g][0], s);
+            atomicAdd(&part[g][1], ss);
+        }
+    } else {
+        const long long total = (long long)hw * chunks;
+        for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+            const int q = (int)(idx % chunks);
+            const long long p = idx / chunks;
+            const uint4 v = *(const uint4*)(x + ((size_t)n * hw + p) * c + q * 8);
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+            float s = 0.0f, ss = 0.0f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float lo = __uint_as_float(w[t] << 16), hi = __uint_as_float(w[t] & 0xffff0000u);
+                s += lo + hi;
+                ss = fmaf(lo, lo, fmaf(hi, hi, ss));
             }
-        } else {
+            const int g = (q * 8) / cpg;
             atomicAdd(&part[g][0], s);
             atomicAdd(&part[g][1], ss);
         }
@@ -256,7 +277,8 @@ hipError_t launch_gn_act(const GnActArgs& a, hipStream_t s) {
         hipError_t e = hipMemsetAsync(a.stats, 0, (size_t)a.n * a.groups * 2 * sizeof(double), s);
         if (e != hipSuccess) return e;
         const long long per_sample = (long long)a.hw * (a.c >> 3);
-        const unsigned bx = (unsigned)std::min<long long>((per_sample + 255) / 256, 64);
+        // >= 4 passes of 256 lanes per workgroup (the partial sums are merged with atomics), at most 64 workgroups per sample
+        const unsigned bx = (unsigned)std::max<long long>(1, std::min<long long>((per_sample + 1023) / 1024, 64));
         hipLaunchKernelGGL(gn_stats_kernel, dim3(bx, a.n), dim3(256), 0, s, a.x, a.hw, a.c, a.groups, a.stats);
         const long long total = (long long)a.n * per_sample;
         float2* mr = (float2*)(a.stats + (size_t)a.n * a.groups * 2);  // the scratch holds [n][groups][2] doubles + as many floats
@@ -401,143 +423,238 @@ __global__ __launch_bounds__(256) void linear_attention_kernel(LinAttnArgs a) {
     (void)lane; (void)wave;
 }
 
-// Pixel-parallel form (any image size): the three reductions over pixels are split over PIX_BLK-pixel workgroups.
-//   (1) per workgroup online (max, sum exp) of k per head channel            -> partials[bh][blk][32][2]
-//   (2) combine the partials, accumulate the workgroup's part of context    -> atomicAdd ctx[bh][32][32] (fp32)
-//   (3) per pixel: softmax_d(q) * scale, out = ctx^T q
-constexpr int LA_PIX = 1024;  // pixels per workgroup
+// Pixel-parallel MFMA form (any image size).  Both contractions of attention.py:28-49 are GEMMs with a 32 x 32 output
+// per (sample, head); they are HBM-bound (16 flop per byte), so the work is arranged around the memory accesses:
+//   (1) context: ctx[d][e] = sum_p softmax_p(k)[p][d] * v[p][e] / (h*w).  The contraction runs over PIXELS while memory is
+//       channel-contiguous; MFMA wants 8 contraction values per lane.  Instead of transposing, lane (c, hi) loads its 8
+//       pixels of channel c as 2-byte loads (32 lanes = 64 contiguous bytes per pixel) -- the k <-> pixel mapping of a
+//       sum is free as long as both operands share it.  One pass over k: a wave keeps its 256 pixels of k in registers,
+//       takes its local per-channel max, exponentiates, and feeds v_mfma_f32_32x32x16_bf16 (k' rounded to bf16: a
+//       2^-9 relative error per term, averaged over the pixel sum); waves and workgroups are merged by the usual (max, sum, acc) rescaling.
+//   (2) out[p][e] = sum_d ctx[d][e] * softmax_d(q)[p][d] * scale: pixels are MFMA columns, so q loads are plain 16-byte
+//       loads, the softmax over d needs one exchange between lanes p and p+32, and the result is stored as 16-byte rows.
+constexpr int LA_HEADS = 4;        // LinearAttention(dim) always has 4 heads of 32 channels (unet.py)
+constexpr int LA_PIX = 1024;       // pixels per workgroup of the context kernel (256 per wave)
+constexpr int LA_PART = 1024 + 64; // floats of one partial: acc[16][64], max[32], sum[32]
+typedef __attribute__((ext_vector_type(8))) __bf16 la_bf16x8;
+typedef __attribute__((ext_vector_type(16))) float la_f32x16;
 
-__global__ __launch_bounds__(256) void linattn_kstats_kernel(LinAttnArgs a, float* partials, int nblk) {
-    __shared__ float rm[8][32], rs[8][32];
-    const int bh = blockIdx.y, n = bh / a.heads, h = bh % a.heads;
-    const int C3 = 3 * a.heads * 32, hd = a.heads * 32;
-    const bf16_t* kb = a.qkv + (size_t)n * a.hw * C3 + hd + h * 32;
-    const int d = threadIdx.x & 31, grp = threadIdx.x >> 5;
-    const int p0 = blockIdx.x * LA_PIX, p1 = min(p0 + LA_PIX, a.hw);
-    float m = -3.0e38f, sm = 0.0f;
-    for (int p = p0 + grp; p < p1; p += 8) {
-        const float v = bf16_to_f32(kb[(size_t)p * C3 + d]);
-        if (v > m) { sm *= __expf(m - v); m = v; }
-        sm += __expf(v - m);
-    }
-    rm[grp][d] = m;
-    rs[grp][d] = sm;
-    __syncthreads();
-    if (threadIdx.x < 32) {
-        float M = rm[0][d];
-        for (int i = 1; i < 8; ++i) M = fmaxf(M, rm[i][d]);
-        float S = 0.0f;
-        for (int i = 0; i < 8; ++i) S += rs[i][d] * __expf(rm[i][d] - M);
-        float* o = partials + (((size_t)bh * nblk + blockIdx.x) * 32 + d) * 2;
-        o[0] = M;
-        o[1] = S;
-    }
+__device__ __forceinline__ la_bf16x8 la_frag(const uint32_t (&w)[4]) {
+    const uint4 v = make_uint4(w[0], w[1], w[2], w[3]);
+    return __builtin_bit_cast(la_bf16x8, v);
+}
+// x -> bf16 hi part (round to nearest) and bf16 lo part of the remainder
+__device__ __forceinline__ void la_split(float x0, float x1, uint32_t& hi, uint32_t& lo) {
+    hi = pack_bf16x2(x0, x1);
+    lo = pack_bf16x2(x0 - __uint_as_float(hi << 16), x1 - __uint_as_float(hi & 0xffff0000u));
 }
 
-__global__ __launch_bounds__(256) void linattn_context_kernel(LinAttnArgs a, const float* partials, int nblk, float* ctx) {
-    __shared__ float kmax[32], kinv[32];
-    __shared__ float tile_k[64][33], tile_v[64][33];
-    const int bh = blockIdx.y, n = bh / a.heads, h = bh % a.heads;
-    const int C3 = 3 * a.heads * 32, hd = a.heads * 32;
-    const bf16_t* base = a.qkv + (size_t)n * a.hw * C3;
-    const int tid = threadIdx.x;
-    if (tid < 32) {  // global softmax statistics of k[d][.] from the per-workgroup partials
-        float M = -3.0e38f;
-        for (int b = 0; b < nblk; ++b) M = fmaxf(M, partials[(((size_t)bh * nblk + b) * 32 + tid) * 2]);
-        float S = 0.0f;
-        for (int b = 0; b < nblk; ++b) {
-            const float* pp = partials + (((size_t)bh * nblk + b) * 32 + tid) * 2;
-            S += pp[1] * __expf(pp[0] - M);
-        }
-        kmax[tid] = M;
-        kinv[tid] = 1.0f / S;
-    }
-    __syncthreads();
-    const int dd = tid >> 3, e0 = (tid & 7) * 4;
-    float c4[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-    const int p0 = blockIdx.x * LA_PIX, p1 = min(p0 + LA_PIX, a.hw);
-    for (int pb = p0; pb < p1; pb += 64) {
-        __syncthreads();
-        for (int i = tid; i < 64 * 32; i += 256) {
-            const int pp = i >> 5, ch = i & 31, p = pb + pp;
-            float kv = 0.0f, vv = 0.0f;
-            if (p < p1) {
-                kv = __expf(bf16_to_f32(base[(size_t)p * C3 + hd + h * 32 + ch]) - kmax[ch]) * kinv[ch];
-                vv = bf16_to_f32(base[(size_t)p * C3 + 2 * hd + h * 32 + ch]);
+__global__ __launch_bounds__(256) void linattn_ctx_mfma_kernel(LinAttnArgs a, float* part, int nblk) {
+    __shared__ float sm_m[4][32], sm_s[4][32];
+    __shared__ float sm_acc[4][16][64];
+    const int bh = blockIdx.y, n = bh / LA_HEADS, h = bh % LA_HEADS;
+    constexpr int C3 = 3 * LA_HEADS * 32, hd = LA_HEADS * 32;  // compile-time pitch: the 256 load offsets are immediates
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), c = lane & 31, hi = lane >> 5;
+    const int pw = blockIdx.x * LA_PIX + wave * 256;  // first pixel of this wave
+    la_f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    float m = -3.0e38f, s = 0.0f;
+    // buffer loads: voffset = this lane's constant (pixel hi*8, channel c), the pixel walk goes through the scalar offset.
+    // The tail wave of a (sample, head) puts the walk into voffset instead, with the buffer ending at the last pixel of the
+    // sample (the range check covers voffset only): pixels past it read 0 and are masked (k: a very negative value).
+    const unsigned lane_off = (unsigned)(hi * 8 * C3 + c) * 2u;
+    const bf16_t* kw = a.qkv + ((size_t)n * a.hw + pw) * C3 + hd + h * 32;  // wave-uniform
+    auto wave_body = [&](auto full_c) {
+        constexpr bool FULL = decltype(full_c)::value;
+        const int left = a.hw - pw;  // valid pixels of this wave (tail: 1..255)
+        const int k_bytes = FULL ? 256 * C3 * 2 : left * C3 * 2 - (hd + h * 32) * 2;
+        const auto rs_k = __builtin_amdgcn_make_buffer_rsrc((void*)kw, 0, k_bytes, 0x00020000);
+        const auto rs_v = __builtin_amdgcn_make_buffer_rsrc((void*)(kw + hd), 0, k_bytes - (FULL ? 0 : hd * 2), 0x00020000);
+        auto ld = [&](const auto& rs, int rel, uint32_t fill) -> uint32_t {  // pixel pw + hi*8 + rel, channel c
+            if (FULL) return (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rs, lane_off, rel * C3 * 2, 0);
+            const uint32_t v = (uint32_t)(uint16_t)__builtin_amdgcn_raw_buffer_load_b16(rs, lane_off + (unsigned)(rel * C3 * 2), 0, 0);
+            return hi * 8 + rel < left ? v : fill;
+        };
+        constexpr uint32_t NEG = 0xC2C8u;  // bf16(-100) for pixels that do not exist; m >= the real maximum keeps exp(.) <= 1
+        // pass 1: this lane's 128 values of k (channel c, pixels with (p >> 3) & 1 == hi), packed two per register
+        uint32_t kp[64];
+#pragma unroll
+        for (int t = 0; t < 16; ++t)
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj)
+                kp[t * 4 + jj] = ld(rs_k, t * 16 + 2 * jj, NEG) | (ld(rs_k, t * 16 + 2 * jj + 1, NEG) << 16);
+        // v is prefetched PF steps ahead; the first steps fly while the max is taken
+        constexpr int PF = 6;
+        uint32_t vq[8][8];
+        auto issue_v = [&](int t) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) vq[t & 7][j] = ld(rs_v, t * 16 + j, 0u);
+            __builtin_amdgcn_sched_barrier(0);  // keep the loads here: sunk to their uses they would serialise the steps
+        };
+#pragma unroll
+        for (int t = 0; t < PF; ++t) issue_v(t);
+#pragma unroll
+        for (int i = 0; i < 64; ++i) m = fmaxf(m, fmaxf(__uint_as_float(kp[i] << 16), __uint_as_float(kp[i] & 0xffff0000u)));
+        m = fmaxf(m, __shfl_xor(m, 32, 64));
+        // pass 2: k' = exp(k - m) against v, 16 pixels per MFMA step
+#pragma unroll
+        for (int t = 0; t < 16; ++t) {
+            if (t + PF < 16) issue_v(t + PF);
+            uint32_t vf[4], kh[4];
+#pragma unroll
+            for (int jj = 0; jj < 4; ++jj) {
+                vf[jj] = vq[t & 7][2 * jj] | (vq[t & 7][2 * jj + 1] << 16);
+                float x0 = __expf(__uint_as_float(kp[t * 4 + jj] << 16) - m);
+                float x1 = __expf(__uint_as_float(kp[t * 4 + jj] & 0xffff0000u) - m);
+                if (!FULL) {  // exp(-100 - m) is not 0 when m is very negative
+                    x0 = hi * 8 + t * 16 + 2 * jj < left ? x0 : 0.0f;
+                    x1 = hi * 8 + t * 16 + 2 * jj + 1 < left ? x1 : 0.0f;
+                }
+                s += x0 + x1;
+                kh[jj] = pack_bf16x2(x0, x1);
             }
-            tile_k[pp][ch] = kv;
-            tile_v[pp][ch] = vv;
+            // D[e][d] += v[p][e] * k'[p][d]: rows e (A = v), columns d = this lane's channel (B = k')
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(la_frag(vf), la_frag(kh), acc, 0, 0, 0);
         }
-        __syncthreads();
-        for (int pp = 0; pp < 64; ++pp) {
-            const float kv = tile_k[pp][dd];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) c4[t] = fmaf(kv, tile_v[pp][e0 + t], c4[t]);
-        }
+        s += __shfl_xor(s, 32, 64);
+    };
+    if (pw + 256 <= a.hw) wave_body(std::true_type{});
+    else if (pw < a.hw) wave_body(std::false_type{});
+    // merge the four waves: column d = c of every accumulator register is rescaled by exp(m_w[d] - M[d])
+    if (hi == 0) {
+        sm_m[wave][c] = m;
+        sm_s[wave][c] = s;
     }
-    const float inv_n = 1.0f / (float)a.hw;  // v / (h*w)  (attention.py:41)
 #pragma unroll
-    for (int t = 0; t < 4; ++t) atomicAdd(&ctx[((size_t)bh * 32 + dd) * 32 + e0 + t], c4[t] * inv_n);
+    for (int r = 0; r < 16; ++r) sm_acc[wave][r][lane] = acc[r];
+    __syncthreads();
+    float M = sm_m[0][c];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) M = fmaxf(M, sm_m[w][c]);
+    float f[4], S = 0.0f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        f[w] = __expf(sm_m[w][c] - M);  // idle waves: m = -3e38 -> 0
+        S = fmaf(f[w], sm_s[w][c], S);
+    }
+    float* o = part + ((size_t)bh * nblk + blockIdx.x) * LA_PART;
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) {
+        const int r = wave * 4 + r4;
+        float v = 0.0f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) v = fmaf(f[w], sm_acc[w][r][lane], v);
+        o[r * 64 + lane] = v;
+    }
+    if (tid < 32) {
+        o[1024 + tid] = M;
+        o[1056 + tid] = S;
+    }
 }
 
-__global__ __launch_bounds__(256) void linattn_out_kernel(LinAttnArgs a, const float* ctx_all) {
-    __shared__ float ctx[32][33];
+// merge the workgroup partials of one (sample, head), normalise, and emit ctx as the A fragments of the output product:
+// frags[bh][hi/lo part][k-step s][lane (e, hi')][8]: slot j of lane (e, hi') = ctx[d = 16 s + 8 hi' + j][e]
+__global__ __launch_bounds__(256) void linattn_merge_kernel(const float* part, int nblk, float inv_n, bf16_t* frags) {
+    const int bh = blockIdx.x, tid = threadIdx.x, lane = tid & 63, rq = tid >> 6, d = lane & 31, hi = lane >> 5;
+    const float* pb = part + (size_t)bh * nblk * LA_PART;
+    float M = -3.0e38f;
+    for (int b = 0; b < nblk; ++b) M = fmaxf(M, pb[(size_t)b * LA_PART + 1024 + d]);
+    float S = 0.0f;
+    for (int b = 0; b < nblk; ++b) S = fmaf(pb[(size_t)b * LA_PART + 1056 + d], __expf(pb[(size_t)b * LA_PART + 1024 + d] - M), S);
+    const float norm = inv_n / S;  // v / (h*w)  (attention.py:41)
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) {
+        const int r = rq * 4 + r4;
+        float v = 0.0f;
+        for (int b = 0; b < nblk; ++b) v = fmaf(pb[(size_t)b * LA_PART + r * 64 + lane], __expf(pb[(size_t)b * LA_PART + 1024 + d] - M), v);
+        v *= norm;
+        const int e = (r >> 2) * 8 + hi * 4 + (r & 3);
+        const size_t idx = (((size_t)bh * 2 * 2 + (d >> 4)) * 64 + ((d >> 3) & 1) * 32 + e) * 8 + (d & 7);
+        const bf16_t vh = f32_to_bf16(v);
+        frags[idx] = vh;
+        frags[idx + 2 * 64 * 8] = f32_to_bf16(v - bf16_to_f32(vh));
+    }
+}
+
+__global__ __launch_bounds__(256) void linattn_out_mfma_kernel(LinAttnArgs a, const bf16_t* frags) {
     const int bh = blockIdx.y, n = bh / a.heads, h = bh % a.heads;
     const int C3 = 3 * a.heads * 32, hd = a.heads * 32;
-    for (int i = threadIdx.x; i < 1024; i += 256) ctx[i >> 5][i & 31] = ctx_all[(size_t)bh * 1024 + i];
-    __syncthreads();
-    const int p = blockIdx.x * 256 + threadIdx.x;
-    if (p >= a.hw) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+    la_bf16x8 ah[2], al[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        ah[s] = *(const la_bf16x8*)(frags + (((size_t)bh * 4 + s) * 64 + lane) * 8);
+        al[s] = *(const la_bf16x8*)(frags + (((size_t)bh * 4 + 2 + s) * 64 + lane) * 8);
+    }
     const float scale = 0.17677669529663687f;  // 32^-1/2
-    const bf16_t* qp = a.qkv + ((size_t)n * a.hw + p) * C3 + h * 32;
-    float q[32];
-    float qm = -3.0e38f;
+#pragma unroll 1
+    for (int g = 0; g < 4; ++g) {
+        const int p = blockIdx.x * 512 + wave * 128 + g * 32 + l31;
+        if (__builtin_amdgcn_readfirstlane(p - l31) >= a.hw) break;
+        const bool valid = p < a.hw;
+        const bf16_t* qp = a.qkv + ((size_t)n * a.hw + (valid ? p : a.hw - 1)) * C3 + h * 32 + hi * 8;
+        const uint4 x[2] = {*(const uint4*)qp, *(const uint4*)(qp + 16)};  // channels 8 hi + {0..7} and 16 + 8 hi + {0..7}
+        float q[16];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const uint4 v = *(const uint4*)(qp + i * 8);
-        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        for (int s = 0; s < 2; ++s) {
+            const uint32_t w[4] = {x[s].x, x[s].y, x[s].z, x[s].w};
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            q[i * 8 + 2 * t] = __uint_as_float(w[t] << 16);
-            q[i * 8 + 2 * t + 1] = __uint_as_float(w[t] & 0xffff0000u);
+            for (int t = 0; t < 4; ++t) {
+                q[s * 8 + 2 * t] = __uint_as_float(w[t] << 16);
+                q[s * 8 + 2 * t + 1] = __uint_as_float(w[t] & 0xffff0000u);
+            }
         }
-    }
+        float qm = q[0];
 #pragma unroll
-    for (int i = 0; i < 32; ++i) qm = fmaxf(qm, q[i]);
-    float qs = 0.0f;
+        for (int i = 1; i < 16; ++i) qm = fmaxf(qm, q[i]);
+        qm = fmaxf(qm, __shfl_xor(qm, 32, 64));
+        float qs = 0.0f;
 #pragma unroll
-    for (int i = 0; i < 32; ++i) {
-        q[i] = __expf(q[i] - qm);
-        qs += q[i];
-    }
-    const float qn = scale / qs;
-    bf16_t* op = a.out + ((size_t)n * a.hw + p) * hd + h * 32;
-#pragma unroll
-    for (int e8 = 0; e8 < 4; ++e8) {
-        float o[8];
-#pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            float acc = 0.0f;
-#pragma unroll
-            for (int i = 0; i < 32; ++i) acc = fmaf(ctx[i][e8 * 8 + t], q[i], acc);
-            o[t] = acc * qn;
+        for (int i = 0; i < 16; ++i) {
+            q[i] = __expf(q[i] - qm);
+            qs += q[i];
         }
-        *(uint4*)(op + e8 * 8) = make_uint4(pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]),
-                                            pack_bf16x2(o[6], o[7]));
+        qs += __shfl_xor(qs, 32, 64);
+        const float qn = scale / qs;
+        la_f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            uint32_t qh[4], ql[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) la_split(q[s * 8 + 2 * t], q[s * 8 + 2 * t + 1], qh[t], ql[t]);
+            // D[e][p] += ctx[d][e] * q'[p][d]; hi*hi + lo*hi + hi*lo keeps the product fp32-accurate
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s], la_frag(qh), acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[s], la_frag(qh), acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s], la_frag(ql), acc, 0, 0, 0);
+        }
+        // lane (p, hi) holds rows e = 8 (r >> 2) + 4 hi + (r & 3); register groups 2 g2 / 2 g2 + 1 are exchanged between lanes
+        // p and p + 32 so that every lane stores 8 consecutive channels
+        bf16_t* op = a.out + ((size_t)n * a.hw + p) * hd + h * 32 + hi * 8;
+#pragma unroll
+        for (int g2 = 0; g2 < 2; ++g2) {
+            const uint32_t p0 = pack_bf16x2(acc[g2 * 8 + 0] * qn, acc[g2 * 8 + 1] * qn), p1 = pack_bf16x2(acc[g2 * 8 + 2] * qn, acc[g2 * 8 + 3] * qn);
+            const uint32_t q0 = pack_bf16x2(acc[g2 * 8 + 4] * qn, acc[g2 * 8 + 5] * qn), q1 = pack_bf16x2(acc[g2 * 8 + 6] * qn, acc[g2 * 8 + 7] * qn);
+            const auto s0 = __builtin_amdgcn_permlane32_swap(p0, q0, false, false);
+            const auto s1 = __builtin_amdgcn_permlane32_swap(p1, q1, false, false);
+            uint4 o;
+            o.x = s0[0]; o.y = s1[0]; o.z = s0[1]; o.w = s1[1];
+            if (valid) *(uint4*)(op + g2 * 16) = o;
+        }
     }
 }
 
 hipError_t launch_linear_attention(const LinAttnArgs& a, hipStream_t s) {
-    if (a.scratch) {
+    if (a.scratch && a.heads == LA_HEADS) {
         const int nblk = (a.hw + LA_PIX - 1) / LA_PIX;
         const int BH = a.n * a.heads;
-        float* partials = a.scratch;                       // [BH][nblk][32][2]
-        float* ctx = a.scratch + (size_t)BH * nblk * 64;   // [BH][32][32]
-        hipError_t e = hipMemsetAsync(ctx, 0, (size_t)BH * 1024 * sizeof(float), s);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(linattn_kstats_kernel, dim3(nblk, BH), dim3(256), 0, s, a, partials, nblk);
-        hipLaunchKernelGGL(linattn_context_kernel, dim3(nblk, BH), dim3(256), 0, s, a, (const float*)partials, nblk, ctx);
-        hipLaunchKernelGGL(linattn_out_kernel, dim3((a.hw + 255) / 256, BH), dim3(256), 0, s, a, (const float*)ctx);
+        float* part = a.scratch;                                          // [BH][nblk][LA_PART]
+        bf16_t* frags = (bf16_t*)(a.scratch + (size_t)BH * nblk * LA_PART);  // [BH][2][2][64][8]
+        hipLaunchKernelGGL(linattn_ctx_mfma_kernel, dim3(nblk, BH), dim3(256), 0, s, a, part, nblk);
+        hipLaunchKernelGGL(linattn_merge_kernel, dim3(BH), dim3(256), 0, s, (const float*)part, nblk, 1.0f / (float)a.hw, frags);
+        hipLaunchKernelGGL(linattn_out_mfma_kernel, dim3((a.hw + 511) / 512, BH), dim3(256), 0, s, a, (const bf16_t*)frags);
         return hipGetLastError();
     }
     hipLaunchKernelGGL(linear_attention_kernel, dim3(a.n * a.heads), dim3(256), 0, s, a);

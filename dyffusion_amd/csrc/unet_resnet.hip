@@ -247,7 +247,7 @@ dyf_status rn_alloc_workspace(dyf_engine* e) {
         }
         {
             const size_t nblk = ((size_t)e->cfg.height * e->cfg.width + 1023) / 1024;
-            dyf_status s = dev_alloc(e, &r->la_scratch, (size_t)e->cfg.max_batch * HEADS * (nblk * 64 + 1024));
+            dyf_status s = dev_alloc(e, &r->la_scratch, (size_t)e->cfg.max_batch * HEADS * (nblk * 1088 + 1024));  // partials + ctx fragments
             if (s != DYF_OK) return s;
         }
         const int nbuf = 2 * r->nlev + 8;

@@ -242,6 +242,15 @@ class HipEngine:
                                             self._stream()))
         return y
 
+    def op_linear_attention(self, qkv_bf16: torch.Tensor) -> torch.Tensor:
+        """Test seam: LinearAttention core.  qkv (N,HW,384) bf16 (to_qkv output, 4 heads x 32) -> (N,HW,128) bf16."""
+        assert qkv_bf16.dtype == torch.bfloat16 and qkv_bf16.is_cuda and qkv_bf16.is_contiguous()
+        n, hw, c3 = qkv_bf16.shape
+        assert c3 == 384
+        y = torch.empty((n, hw, 128), dtype=torch.bfloat16, device=qkv_bf16.device)
+        self._check(self._lib.dyf_op_linear_attention(self._h, qkv_bf16.data_ptr(), n, hw, y.data_ptr(), self._stream()))
+        return y
+
     def op_upconv2d(self, x_nhwc_bf16: torch.Tensor, weight: torch.Tensor, scale: Optional[torch.Tensor] = None,
                     shift: Optional[torch.Tensor] = None, act: int = 0) -> torch.Tensor:
         """Test seam: fused Upsample(x2, bilinear) + Conv2d(3x3, pad 1).  x (N,H,W,Cin) bf16 -> (N,2H,2W,Cout) bf16."""

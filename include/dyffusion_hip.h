@@ -183,6 +183,12 @@ dyf_status dyf_op_upconv2d(dyf_engine* engine, const uint16_t* x_dev, const floa
                            int32_t w, int32_t cin, int32_t cout, const float* scale_dev, const float* shift_dev,
                            int32_t act, uint16_t* y_dev, void* stream);
 
+/* LinearAttention core (attention.py:28-49, 4 heads of 32 channels): qkv_dev (N,HW,384) bf16 = to_qkv output ->
+ * out_dev (N,HW,128) bf16 = softmax_d(q)*scale . (softmax_n(k) . v^T / HW), the input of to_out.  Runs the pixel-parallel
+ * MFMA kernels the ResNet-UNet uses. */
+dyf_status dyf_op_linear_attention(dyf_engine* engine, const uint16_t* qkv_dev, int32_t n, int32_t hw, uint16_t* out_dev,
+                                   void* stream);
+
 #ifdef __cplusplus
 }
 #endif
