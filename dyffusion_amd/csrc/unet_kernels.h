@@ -13,7 +13,11 @@ struct StemConvArgs {
     const float* bias;  // [dim]
     int dim;
     bf16_t* out;        // [n][h][w][dim]
+    const bf16_t* wfrag = nullptr;  // pack_stem_frag(): MFMA form (dim == 64), or null -> VALU form
+    int ksteps = 0;                 // ceil(k*k*cin / 16)
 };
+// [tap][cin][dim] fp32 -> A fragments of the MFMA stem: [k-step][32-channel block][hi/lo part][lane][8] bf16
+void pack_stem_frag(const float* wgt, int kk_total, int dim, bf16_t* out);
 hipError_t launch_stem_conv(const StemConvArgs& a, hipStream_t s);
 
 // K5: GroupNorm(G) + FiLM + SiLU + Dropout (+ residual) of unet.Block (unet.py:58-76) on a bf16 NHWC tensor

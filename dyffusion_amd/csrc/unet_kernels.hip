@@ -94,8 +94,140 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(StemConvArgs a) {
     }
 }
 
+// MFMA form (dim = 64): D[channel][pixel] = W[channel][(tap, cin)] . X[(tap, cin)][pixel], K = k*k*cin padded to 16.
+// One wave owns 32 consecutive pixels (MFMA columns): lane (pixel, hi) gathers its 8 contraction values per step straight
+// from the fp32 NCHW sources (neighbouring lanes = neighbouring pixels: coalesced; the 49-fold reuse of every input lives in
+// L1), bounds-checked per tap (zero padding).  Inputs and weights are split into bf16 hi + lo parts and multiplied as
+// hi*hi + lo*hi + hi*lo, so the result matches the fp32 VALU form to ~2^-16 -- the network input is not rounded to bf16.
+// The (tap, cin) -> (source, offset, dy, dx) table and the weight fragments sit in LDS.
+typedef __attribute__((ext_vector_type(8))) __bf16 st_bf16x8;
+typedef __attribute__((ext_vector_type(16))) float st_f32x16;
+constexpr int STEM_MAX_KSTEPS = 16;
+
+__global__ __launch_bounds__(256) void stem_mfma_kernel(StemConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char st_smem[];
+    int4* tab = (int4*)st_smem;                                         // [ksteps*16]: {offset, dy, dx, source or -1}
+    const uint4* wf = (const uint4*)(st_smem + STEM_MAX_KSTEPS * 16 * sizeof(int4));  // [ksteps][2][2][64] x 16 B
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, hi = lane >> 5;
+    const int K = a.k * a.k * a.cin, plane = a.h * a.w;
+    for (int kk = tid; kk < a.ksteps * 16; kk += 256) {
+        int4 e = make_int4(0, 0, 0, -1);
+        if (kk < K) {
+            const int tap = kk / a.cin, c = kk % a.cin, dy = tap / a.k - a.pad, dx = tap % a.k - a.pad;
+            int s = 0, cl = c;
+            while (cl >= a.ch[s]) { cl -= a.ch[s]; ++s; }
+            e = make_int4(cl * plane + dy * a.w + dx, dy, dx, s);
+        }
+        tab[kk] = e;
+    }
+    {
+        uint4* wdst = (uint4*)(st_smem + STEM_MAX_KSTEPS * 16 * sizeof(int4));
+        const uint4* wsrc = (const uint4*)a.wfrag;
+        for (int i = tid; i < a.ksteps * 4 * 64; i += 256) wdst[i] = wsrc[i];
+    }
+    __syncthreads();
+    const long long total = (long long)a.n * plane;
+    const long long ngroups = (total + 31) / 32;
+    for (long long g = (long long)blockIdx.x * 4 + wave; g < ngroups; g += (long long)gridDim.x * 4) {
+        const long long pix = g * 32 + l31;
+        const bool pvalid = pix < total;
+        const long long pc = pvalid ? pix : total - 1;
+        const int n = (int)(pc / plane), rem = (int)(pc - (long long)n * plane), y = rem / a.w, x = rem - y * a.w;
+        const float* b0 = a.src[0] + (size_t)n * a.ch[0] * plane + rem;
+        const float* b1 = a.nsrc > 1 ? a.src[1] + (size_t)n * a.ch[1] * plane + rem : b0;
+        const float* b2 = a.nsrc > 2 ? a.src[2] + (size_t)n * a.ch[2] * plane + rem : b0;
+        const float* b3 = a.nsrc > 3 ? a.src[3] + (size_t)n * a.ch[3] * plane + rem : b0;
+        st_f32x16 acc[2];
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[rb][r] = 0.0f;
+        for (int s = 0; s < a.ksteps; ++s) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int4 e = tab[s * 16 + hi * 8 + j];
+                const bool ok = e.w >= 0 && (unsigned)(y + e.y) < (unsigned)a.h && (unsigned)(x + e.z) < (unsigned)a.w;
+                const float* bp = e.w <= 0 ? b0 : e.w == 1 ? b1 : e.w == 2 ? b2 : b3;
+                const float t = bp[ok ? e.x : 0];  // always a valid address: no branch around the load
+                v[j] = ok ? t : 0.0f;
+            }
+            uint32_t bh[4], bl[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                bh[t] = pack_bf16x2(v[2 * t], v[2 * t + 1]);
+                bl[t] = pack_bf16x2(v[2 * t] - __uint_as_float(bh[t] << 16), v[2 * t + 1] - __uint_as_float(bh[t] & 0xffff0000u));
+            }
+            const st_bf16x8 xh = __builtin_bit_cast(st_bf16x8, make_uint4(bh[0], bh[1], bh[2], bh[3]));
+            const st_bf16x8 xl = __builtin_bit_cast(st_bf16x8, make_uint4(bl[0], bl[1], bl[2], bl[3]));
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) {
+                const st_bf16x8 wh = __builtin_bit_cast(st_bf16x8, wf[((s * 2 + rb) * 2 + 0) * 64 + lane]);
+                const st_bf16x8 wl = __builtin_bit_cast(st_bf16x8, wf[((s * 2 + rb) * 2 + 1) * 64 + lane]);
+                acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xh, acc[rb], 0, 0, 0);
+                acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, xh, acc[rb], 0, 0, 0);
+                acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xl, acc[rb], 0, 0, 0);
+            }
+        }
+        // lane (pixel, hi) holds channels rb*32 + 8 (r >> 2) + 4 hi + (r & 3); groups 2 g2 / 2 g2 + 1 are exchanged between
+        // lanes p and p + 32 so that every lane stores 8 consecutive channels (as in the conv epilogues)
+        bf16_t* op = a.out + (size_t)pix * a.dim + hi * 8;
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int g2 = 0; g2 < 2; ++g2) {
+                const int cb = rb * 32 + g2 * 16 + 4 * hi;
+                const float4 ba = *(const float4*)(a.bias + cb), bb = *(const float4*)(a.bias + cb + 8);
+                const uint32_t p0 = pack_bf16x2(acc[rb][g2 * 8 + 0] + ba.x, acc[rb][g2 * 8 + 1] + ba.y);
+                const uint32_t p1 = pack_bf16x2(acc[rb][g2 * 8 + 2] + ba.z, acc[rb][g2 * 8 + 3] + ba.w);
+                const uint32_t q0 = pack_bf16x2(acc[rb][g2 * 8 + 4] + bb.x, acc[rb][g2 * 8 + 5] + bb.y);
+                const uint32_t q1 = pack_bf16x2(acc[rb][g2 * 8 + 6] + bb.z, acc[rb][g2 * 8 + 7] + bb.w);
+                const auto s0 = __builtin_amdgcn_permlane32_swap(p0, q0, false, false);
+                const auto s1 = __builtin_amdgcn_permlane32_swap(p1, q1, false, false);
+                uint4 o;
+                o.x = s0[0]; o.y = s1[0]; o.z = s0[1]; o.w = s1[1];
+                if (pvalid) *(uint4*)(op + rb * 32 + g2 * 16) = o;
+            }
+    }
+}
+
+void pack_stem_frag(const float* wgt, int kk_total, int dim, bf16_t* out) {
+    const int ksteps = (kk_total + 15) / 16;
+    size_t o = 0;
+    for (int s = 0; s < ksteps; ++s)
+        for (int rb = 0; rb < dim / 32; ++rb)
+            for (int hl = 0; hl < 2; ++hl)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const int kk = s * 16 + (lane >> 5) * 8 + j, ch = rb * 32 + (lane & 31);
+                        const float w = kk < kk_total ? wgt[(size_t)kk * dim + ch] : 0.0f;
+                        const bf16_t h = f32_to_bf16(w);
+                        float hf;
+                        const uint32_t hb = (uint32_t)h << 16;
+                        __builtin_memcpy(&hf, &hb, 4);
+                        out[o++] = hl == 0 ? h : f32_to_bf16(w - hf);
+                    }
+}
+
 hipError_t launch_stem_conv(const StemConvArgs& a, hipStream_t s) {
     const long long total = (long long)a.n * a.h * a.w;
+    if (a.wfrag && a.dim == 64 && a.ksteps >= 1 && a.ksteps <= STEM_MAX_KSTEPS && a.nsrc <= 4) {
+        static const bool use_mfma = !(getenv("DYF_STEM_MFMA") && atoi(getenv("DYF_STEM_MFMA")) == 0);
+        if (use_mfma) {
+            const size_t lds = STEM_MAX_KSTEPS * 16 * sizeof(int4) + (size_t)a.ksteps * 4 * 64 * 16;
+            static bool attr = false;
+            if (!attr) {
+                hipError_t e = hipFuncSetAttribute((const void*)stem_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                   STEM_MAX_KSTEPS * 16 * sizeof(int4) + STEM_MAX_KSTEPS * 4 * 64 * 16);
+                if (e != hipSuccess) return e;
+                attr = true;
+            }
+            const long long ngroups = (total + 31) / 32;
+            const unsigned grid = (unsigned)std::min<long long>((ngroups + 3) / 4, 2048);
+            hipLaunchKernelGGL(stem_mfma_kernel, dim3(grid), dim3(256), lds, s, a);
+            return hipGetLastError();
+        }
+    }
     hipLaunchKernelGGL(stem_conv_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256),
                        (size_t)a.k * a.k * a.cin * a.dim * sizeof(float), s, a);
     return hipGetLastError();
@@ -891,8 +1023,48 @@ __global__ void head_kernel(HeadArgs a) {
     }
 }
 
+// c % 8 == 0, c/8 a power of two <= 64, cout <= 4: every lane owns ONE 16-byte channel chunk (its weights stay in registers)
+// and walks pixels; the c/8 partial dot products of a pixel are summed across neighbouring lanes.  Loads are fully coalesced
+// (the per-pixel form above strides lanes by a whole pixel: 64 cache lines per load instruction).
+__global__ __launch_bounds__(256) void head_vec_kernel(HeadArgs a) {
+    const int chunks = a.c >> 3, q = threadIdx.x & (chunks - 1), row = threadIdx.x / chunks, rows = 256 / chunks;
+    float w[4][8];
+#pragma unroll
+    for (int co = 0; co < 4; ++co)
+#pragma unroll
+        for (int t = 0; t < 8; ++t) w[co][t] = co < a.cout ? a.wgt[(size_t)co * a.c + q * 8 + t] : 0.0f;
+    const long long total = (long long)a.n * a.hw;
+    for (long long p = (long long)blockIdx.x * rows + row; p < total; p += (long long)gridDim.x * rows) {
+        const uint4 v = *(const uint4*)(a.x + (size_t)p * a.c + q * 8);
+        const uint32_t qw[4] = {v.x, v.y, v.z, v.w};
+        float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const float xv = (t & 1) ? __uint_as_float(qw[t >> 1] & 0xffff0000u) : __uint_as_float(qw[t >> 1] << 16);
+#pragma unroll
+            for (int co = 0; co < 4; ++co) acc[co] = fmaf(xv, w[co][t], acc[co]);
+        }
+        for (int d = 1; d < chunks; d <<= 1)
+#pragma unroll
+            for (int co = 0; co < 4; ++co) acc[co] += __shfl_xor(acc[co], d, 64);
+        if (q == 0) {
+            const int n = (int)(p / a.hw), pp = (int)(p - (long long)n * a.hw);
+#pragma unroll
+            for (int co = 0; co < 4; ++co)
+                if (co < a.cout) a.out[((size_t)n * a.cout + co) * a.hw + pp] = acc[co] + a.bias[co];
+        }
+    }
+}
+
 hipError_t launch_head(const HeadArgs& a, hipStream_t s) {
     const long long total = (long long)a.n * a.hw;
+    const int chunks = a.c >> 3;
+    if ((a.c & 7) == 0 && chunks >= 1 && chunks <= 64 && (chunks & (chunks - 1)) == 0 && a.cout <= 4) {
+        const int rows = 256 / chunks;
+        const unsigned grid = (unsigned)std::max<long long>(1, std::min<long long>((total + rows * 4 - 1) / (rows * 4), 4096));
+        hipLaunchKernelGGL(head_vec_kernel, dim3(grid), dim3(256), 0, s, a);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(head_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
     return hipGetLastError();
 }

@@ -45,6 +45,8 @@ struct RNet {
     std::vector<AttnW> attns;      // downs.l.2 (nlev), mid_attn, ups.l.2 (nlev)
     std::vector<SampW> downs, ups;
     float *stem_w = nullptr, *stem_b = nullptr, *head_w = nullptr, *head_b = nullptr;
+    bf16_t* stem_wfrag = nullptr;  // MFMA stem fragments (dim 64)
+    int stem_ksteps = 0;
     float *ones = nullptr, *zeros = nullptr;
     double* gn_stats = nullptr;    // [max_batch][groups][2]
     float* la_scratch = nullptr;   // LinearAttention partials + context
@@ -316,6 +318,13 @@ dyf_status rn_load_weights(dyf_engine* e, Net& n, std::map<std::string, TensorVi
                 for (int t = 0; t < ks * ks; ++t)
                     pk[((size_t)t * n.cin_total + ci) * d + co] = sw->data[((size_t)co * n.cin_total + ci) * ks * ks + t];
         UP(r->stem_w, pk); UP(r->stem_b, vec(sb));
+        if (d == 64) {  // MFMA stem: weights as bf16 hi/lo A fragments
+            const int kk_total = (int)(ks * ks * n.cin_total);
+            r->stem_ksteps = (kk_total + 15) / 16;
+            std::vector<bf16_t> pf((size_t)r->stem_ksteps * 2 * 2 * 64 * 8);
+            pack_stem_frag(pk.data(), kk_total, (int)d, pf.data());
+            UP(r->stem_wfrag, pf);
+        }
         NEED(hw, "final_conv.weight", (int64_t)c.out_channels, d, 1, 1);
         NEED(hb, "final_conv.bias", (int64_t)c.out_channels);
         UP(r->head_w, vec(hw)); UP(r->head_b, vec(hb));
@@ -493,6 +502,7 @@ dyf_status rn_forward(dyf_engine* e, int which, const Source* srcs, int nsrc, in
     bf16_t* rbuf = pool.get();
     sa.nsrc = nsrc; sa.cin = ctot; sa.n = nb; sa.h = H; sa.w = W; sa.k = c.init_kernel_size; sa.pad = c.init_padding;
     sa.wgt = r->stem_w; sa.bias = r->stem_b; sa.dim = c.dim; sa.out = rbuf;
+    sa.wfrag = r->stem_wfrag; sa.ksteps = r->stem_ksteps;
     HIP_TRY(e, launch_stem_conv(sa, st));
 
     std::vector<bf16_t*> skips;
