@@ -456,7 +456,51 @@ __global__ __launch_bounds__(256) void layernorm_c_kernel(LayerNormArgs a) {
     }
 }
 
+// c % 8 == 0, c/8 a power of two <= 64: c/8 lanes per pixel, each ONE 16-byte chunk kept in registers for both passes
+// (one 16-B load, one 16-B store per lane instead of c/8 two-byte loads three times)
+__global__ __launch_bounds__(256) void layernorm_c_vec_kernel(LayerNormArgs a, int chunks) {
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int q = (int)(gid & (chunks - 1));
+    long long pix = gid / chunks;
+    const bool live = pix < a.pixels;
+    if (!live) pix = a.pixels - 1;
+    const size_t e0 = (size_t)pix * a.c + q * 8;
+    const uint4 v = *(const uint4*)(a.x + e0);
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    float x[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) x[t] = (t & 1) ? __uint_as_float(w[t >> 1] & 0xffff0000u) : __uint_as_float(w[t >> 1] << 16);
+    float s = 0.0f;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) s += x[t];
+    for (int off = 1; off < chunks; off <<= 1) s += __shfl_xor(s, off, 64);
+    const float mean = s / (float)a.c;
+    float var = 0.0f;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        x[t] -= mean;
+        var = fmaf(x[t], x[t], var);
+    }
+    for (int off = 1; off < chunks; off <<= 1) var += __shfl_xor(var, off, 64);
+    const float rstd = rsqrtf(var / (float)a.c + 1e-5f);
+    if (!live) return;
+    const float4 g0 = *(const float4*)(a.g + q * 8), g1 = *(const float4*)(a.g + q * 8 + 4);
+    const float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+    float y[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) y[t] = x[t] * rstd * g[t];
+    act_drop<8>(y, (uint32_t)e0, ACT_NONE, a.drop, drop_key(a.drop));
+    *(uint4*)(a.out + e0) = make_uint4(pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]), pack_bf16x2(y[4], y[5]),
+                                       pack_bf16x2(y[6], y[7]));
+}
+
 hipError_t launch_layernorm_c(const LayerNormArgs& a, hipStream_t s) {
+    const int chunks = a.c >> 3;
+    if ((a.c & 7) == 0 && chunks >= 1 && chunks <= 64 && (chunks & (chunks - 1)) == 0) {
+        const long long threads = a.pixels * chunks;
+        hipLaunchKernelGGL(layernorm_c_vec_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, a, chunks);
+        return hipGetLastError();
+    }
     const long long threads = a.pixels * 8;
     hipLaunchKernelGGL(layernorm_c_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, a);
     return hipGetLastError();
