@@ -82,7 +82,7 @@ struct HaloCfg {
 
 template <int SP>
 __global__ __launch_bounds__(256, 2) void conv_up_halo_kernel(ConvArgs a, int tiles_x, int tiles_per_img, int tiles_m,
-                                                              int tiles_n) {
+                                                              int tiles_n, int xmode) {
 #if defined(__HIP_DEVICE_COMPILE__)
     using H = HaloCfg<SP>;
     constexpr int HALO_W = H::W, HALO_REAL = H::REAL, HALO_BYTES = H::BYTES, ZERO_OFF = H::ZERO_OFF, HOFF_OFF = H::HOFF_OFF;
@@ -99,7 +99,15 @@ __global__ __launch_bounds__(256, 2) void conv_up_halo_kernel(ConvArgs a, int ti
     const int bid = blockIdx.x;
     const int xq = total >> 3, xr = total & 7, xcd = bid & 7;
     const int tile = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
-    const int tn = tile % tiles_n, tm = tile / tiles_n;
+    int tn = tile % tiles_n, tm = tile / tiles_n;
+    if (xmode & 1) {
+        // column block per XCD: XCD x streams only the weights of block x % tiles_n (they stay in its 4 MB L2), the 8 / tiles_n
+        // groups of XCDs split the pixel tiles; the column blocks of one tile no longer share their halo in L2
+        const int groups = 8 / tiles_n, chunk = (tiles_m + groups - 1) / groups, g = xcd / tiles_n;
+        tn = xcd - g * tiles_n;
+        tm = g * chunk + (bid >> 3);
+        if ((bid >> 3) >= chunk || tm >= tiles_m) return;
+    }
     const int n_img = tm / tiles_per_img;
     const int t_in = tm - n_img * tiles_per_img;
     const int ty0 = (t_in / tiles_x) * H::TH;
@@ -142,6 +150,13 @@ __global__ __launch_bounds__(256, 2) void conv_up_halo_kernel(ConvArgs a, int ti
     const auto rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.wpk_up_frag, 0,
                                                           (int)(unsigned)((size_t)(SP == 2 ? 1 : 4) * a.cout * 16 * cin * 2), 0x00020000);  // SP = 3: 4 planes
 
+    // LDS swizzle key of halo pixel hp (XORed into its 16-B chunk index).  A ds_read_b128 is serviced in four NON-contiguous
+    // 16-lane groups ({0-3,12-15,20-27}, {4-11,16-19,28-31}, and the same +32): with lanes = 2 tile rows x 16 columns a group
+    // holds 8 pixels of each row, column sets complementary.  The two rows are HALO_W = 18 pixels apart, so the plain key
+    // (hp >> 1) & 7 repeats one key inside every group (2-way conflict: 7.5 instead of 4 LDS cycles per read, measured as
+    // SQ_LDS_BANK_CONFLICT = 47 % of SQ_LDS_IDX_ACTIVE); subtracting the halo row makes every group hit 16 distinct slots
+    // for every tap displacement (brute-forced over all taps / rows).
+#define HKEY(hp) ((((hp) >> 1) - (int)((unsigned)(hp) / (unsigned)HALO_W)) & 7)
     // ---- halo DMA descriptors: instruction i (i % 4 == wave) fills halo pixels [8i, 8i+8); lane -> (pixel, 16-B chunk)
     // (the per-lane source offsets are parked in LDS, not in registers: the K loop needs every VGPR it can get)
     const int sub = lane >> 3;
@@ -154,7 +169,7 @@ __global__ __launch_bounds__(256, 2) void conv_up_halo_kernel(ConvArgs a, int ti
         const int hy = hp / HALO_W, hx = hp - hy * HALO_W;
         const int yy = ty0 - 1 + hy, xx = cbase + hx;
         const int y = min(max(yy, 0), gh - 1), x = min(max(xx, 0), gw - 1);  // replicate clamp (upsample forms)
-        const int gch = (lane & 7) ^ ((hp >> 1) & 7);  // swizzled source chunk of this linear LDS slot
+        const int gch = (lane & 7) ^ HKEY(hp);  // swizzled source chunk of this linear LDS slot
         // SP = 3: halo pixel (y, x) of parity plane (0, 0) is input pixel (2y, 2x); the plane offset is added per chunk
         unsigned off = (H::S2 ? (unsigned)((n_img * a.h + 2 * y) * a.w + 2 * x) : (unsigned)((n_img * a.h + y) * a.w + x)) *
                            (unsigned)(a.c0 * 2) + gch * 16;  // c0 == c1 (checked on host)
@@ -233,7 +248,7 @@ __global__ __launch_bounds__(256, 2) void conv_up_halo_kernel(ConvArgs a, int ti
         _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) {                                                   \
             const int hpm = hpb + (DISP) + 2 * HALO_W * mt;                                                  \
             ab[mt] = Hs + hpm * 128;                                                                         \
-            ax[mt] = (unsigned)((hi ^ ((hpm >> 1) & 7)) << 4);                                               \
+            ax[mt] = (unsigned)((hi ^ HKEY(hpm)) << 4);                                               \
         }                                                                                                    \
     }
     // the same for a correction tap: lanes whose pixel is not on the border (KEEP false) read the zero page
@@ -244,7 +259,7 @@ __global__ __launch_bounds__(256, 2) void conv_up_halo_kernel(ConvArgs a, int ti
         _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) {                                                   \
             const int hpm = hpb + (DISP) + 2 * HALO_W * mt;                                                  \
             ab[mt] = (KEEP) ? Hs + hpm * 128 : lds_base + ZERO_OFF;                                          \
-            ax[mt] = (KEEP) ? (unsigned)((hi ^ ((hpm >> 1) & 7)) << 4) : 0u;                                 \
+            ax[mt] = (KEEP) ? (unsigned)((hi ^ HKEY(hpm)) << 4) : 0u;                                 \
         }                                                                                                    \
     }
 #define RDA1(SET, KS, MT)                                                                                    \
@@ -302,7 +317,7 @@ __global__ __launch_bounds__(256, 2) void conv_up_halo_kernel(ConvArgs a, int ti
 #define RDA_MASKED(DST, MT, DISP, KS, KEEP)                                                                  \
     {                                                                                                        \
         const int hpm = hp0 + 2 * HALO_W * (MT) + (DISP);                                                    \
-        const unsigned pm = (KEEP) ? Hs + hpm * 128 + ((((KS) * 2 + hi) ^ ((hpm >> 1) & 7)) << 4) : lds_base + ZERO_OFF; \
+        const unsigned pm = (KEEP) ? Hs + hpm * 128 + ((((KS) * 2 + hi) ^ HKEY(hpm)) << 4) : lds_base + ZERO_OFF; \
         DSR(DST, pm)                                                                                         \
     }
 #define MFMA_ONE(NT, MT, BSET, AF)                                                                           \
@@ -602,13 +617,13 @@ hipError_t launch_conv_halo_s2(const ConvArgs& a, hipStream_t stream) {
         const int tiles_x = a.wo / TILE_W, tiles_per_img = tiles_x * (a.ho / HaloCfg<4>::TH);
         const int tiles_m = a.n * tiles_per_img, tiles_n = a.cout / 128;
         hipLaunchKernelGGL(conv_up_halo_kernel<4>, dim3(tiles_m * tiles_n), dim3(256), HaloCfg<4>::LDS_TOTAL, stream, a, tiles_x,
-                           tiles_per_img, tiles_m, tiles_n);
+                           tiles_per_img, tiles_m, tiles_n, 0);
         return hipGetLastError();
     }
     const int tiles_x = a.wo / TILE_W, tiles_per_img = tiles_x * (a.ho / TILE_H);
     const int tiles_m = a.n * tiles_per_img, tiles_n = a.cout / 256;
     hipLaunchKernelGGL(conv_up_halo_kernel<3>, dim3(tiles_m * tiles_n), dim3(256), HaloCfg<3>::LDS_TOTAL, stream, a, tiles_x,
-                       tiles_per_img, tiles_m, tiles_n);
+                       tiles_per_img, tiles_m, tiles_n, 0);
     return hipGetLastError();
 }
 
@@ -626,7 +641,7 @@ hipError_t launch_conv_halo3(const ConvArgs& a, hipStream_t stream) {
     const int tiles_x = a.w / TILE_W, tiles_per_img = tiles_x * (a.h / TILE_H);
     const int tiles_m = a.n * tiles_per_img, tiles_n = a.cout / 256;
     hipLaunchKernelGGL(conv_up_halo_kernel<2>, dim3(tiles_m * tiles_n), dim3(256), HaloCfg<2>::LDS_TOTAL, stream, a, tiles_x,
-                       tiles_per_img, tiles_m, tiles_n);
+                       tiles_per_img, tiles_m, tiles_n, 0);
     return hipGetLastError();
 }
 
@@ -654,10 +669,18 @@ hipError_t launch_conv_up_halo(const ConvArgs& a, hipStream_t stream) {
     const int tiles_m = a.n * tiles_per_img, tiles_n = a.cout / 64;
     if (sparse)
         hipLaunchKernelGGL(conv_up_halo_kernel<1>, dim3(tiles_m * tiles_n), dim3(256), HaloCfg<1>::LDS_TOTAL, stream, a, tiles_x,
-                           tiles_per_img, tiles_m, tiles_n);
-    else
-        hipLaunchKernelGGL(conv_up_halo_kernel<0>, dim3(tiles_m * tiles_n), dim3(256), HaloCfg<0>::LDS_TOTAL, stream, a, tiles_x,
-                           tiles_per_img, tiles_m, tiles_n);
+                           tiles_per_img, tiles_m, tiles_n, 0);
+    else {
+        // DYF_HALO_TN_XCD=1: one column block per XCD (measured on dec4 at NB=80: HBM-side reads 722 -> 513 MB because the
+        // weights stay in L2, but the two column blocks of a tile read their halo on different XCDs; time 649 -> 663 us,
+        // whole rollout unchanged -- the extra reads of the default mapping are served by the Infinity Cache).  Off by default.
+        static const int xenv = getenv("DYF_HALO_TN_XCD") ? atoi(getenv("DYF_HALO_TN_XCD")) : 0;
+        const bool xmode = (xenv & 1) != 0 && (tiles_n == 2 || tiles_n == 4 || tiles_n == 8);
+        const int groups = xmode ? 8 / tiles_n : 1, chunk = (tiles_m + groups - 1) / groups;
+        const unsigned grid = xmode ? (unsigned)(8 * chunk) : (unsigned)(tiles_m * tiles_n);
+        hipLaunchKernelGGL(conv_up_halo_kernel<0>, dim3(grid), dim3(256), HaloCfg<0>::LDS_TOTAL, stream, a, tiles_x, tiles_per_img,
+                           tiles_m, tiles_n, xmode ? 1 : 0);
+    }
     return hipGetLastError();
 }
 
