@@ -1034,6 +1034,25 @@ dyf_status dyf_ensemble_metrics(dyf_engine* e, const float* preds_dev, const flo
     return DYF_OK;
 }
 
+dyf_status dyf_criterion(dyf_engine* e, const float* pred_dev, const float* target_dev, int64_t count, int32_t kind,
+                         double* out_host, void* stream) {
+    if (!e || !pred_dev || !target_dev || !out_host) return fail(e, DYF_ERR_INVALID_ARGUMENT, "null argument");
+    if (count < 1 || kind < 0 || kind > 2) return fail(e, DYF_ERR_INVALID_ARGUMENT, "count must be positive, kind in {0 l1, 1 mse, 2 smooth-l1}");
+    if (((uintptr_t)pred_dev | (uintptr_t)target_dev) & 15) return fail(e, DYF_ERR_INVALID_ARGUMENT, "tensors must be 16-byte aligned");
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    hipStream_t st = (hipStream_t)stream;
+    if (!e->metric_sums) {
+        dyf_status s = dev_alloc(e, &e->metric_sums, 4);
+        if (s != DYF_OK) return s;
+    }
+    HIP_TRY(e, launch_criterion_sum(pred_dev, target_dev, count, kind, e->metric_sums, st));
+    double h = 0.0;
+    HIP_TRY(e, hipMemcpyAsync(&h, e->metric_sums, sizeof(h), hipMemcpyDeviceToHost, st));
+    HIP_TRY(e, hipStreamSynchronize(st));
+    *out_host = h / (double)count;
+    return DYF_OK;
+}
+
 dyf_status dyf_time_layer_in_rollout(dyf_engine* e, int32_t layer, int32_t nb, void* stream, double* avg_ms,
                                      int32_t* launches) {
     if (!e || layer < 6 || layer > 11 || !avg_ms) return fail(e, DYF_ERR_INVALID_ARGUMENT, "decoder layer 6..11 expected");

@@ -106,5 +106,7 @@ hipError_t launch_noisy_condition(float* out, const float* cond, const float* no
 hipError_t launch_bump_counter(uint32_t* rng_state, hipStream_t s);
 hipError_t launch_fill_f32(float* p, float v, long long count, hipStream_t s);
 // on-device ensemble metrics (evaluation.py:10-118): sums[3] (fp64, device) = {sum (mean-y)^2, sum var, sum crps}; n_members <= 64 (one KB of LDS per member)
+// sum of the criterion terms |p-t| (kind 0), (p-t)^2 (1), smooth-L1 (2) over `count` fp32 elements -> *sum (device double)
+hipError_t launch_criterion_sum(const float* p, const float* t, long long count, int kind, double* sum, hipStream_t s);
 hipError_t launch_ensemble_metrics(const float* preds, const float* targets, int n_members, long long n_points, double* sums,
                                    hipStream_t s);

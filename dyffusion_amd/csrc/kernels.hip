@@ -830,6 +830,34 @@ __global__ __launch_bounds__(256) void ensemble_metrics_kernel(const float* pred
     }
 }
 
+// Reduction of the training criterion (src/utilities/utils.py:201-212, reduction = "mean"): sum over all elements of
+// |p - t| (kind 0), (p - t)^2 (kind 1) or smooth-L1 with beta = 1 (kind 2); fp32 per lane, wave butterfly, one fp64 atomic
+// per wave.  HBM-bound: both tensors are read once with 16-byte loads.
+__global__ __launch_bounds__(256) void criterion_sum_kernel(const float* p, const float* t, long long count, int kind, double* sum) {
+    const long long n4 = count >> 2;
+    float acc = 0.0f;
+    auto term = [&](float d) {
+        const float ad = fabsf(d);
+        return kind == 0 ? ad : kind == 1 ? d * d : (ad < 1.0f ? 0.5f * d * d : ad - 0.5f);
+    };
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        const float4 a = ((const float4*)p)[i], b = ((const float4*)t)[i];
+        acc += term(a.x - b.x) + term(a.y - b.y) + term(a.z - b.z) + term(a.w - b.w);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (count & 3)) acc += term(p[n4 * 4 + threadIdx.x] - t[n4 * 4 + threadIdx.x]);
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) acc += __shfl_xor(acc, d, 64);
+    if ((threadIdx.x & 63) == 0) atomicAdd(sum, (double)acc);
+}
+
+hipError_t launch_criterion_sum(const float* p, const float* t, long long count, int kind, double* sum, hipStream_t s) {
+    hipError_t e = hipMemsetAsync(sum, 0, sizeof(double), s);
+    if (e != hipSuccess) return e;
+    const unsigned grid = (unsigned)std::max<long long>(1, std::min<long long>((count / 4 + 1023) / 1024, 2048));
+    hipLaunchKernelGGL(criterion_sum_kernel, dim3(grid), dim3(256), 0, s, p, t, count, kind, sum);
+    return hipGetLastError();
+}
+
 hipError_t launch_ensemble_metrics(const float* preds, const float* targets, int n_members, long long n_points, double* sums,
                                    hipStream_t s) {
     const size_t lds = (size_t)n_members * 256 * sizeof(float);

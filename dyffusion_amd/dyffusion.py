@@ -30,7 +30,7 @@ class DYffusion(nn.Module):
                  log_every_t=None, lambda_reconstruction: float = 1.0, lambda_reconstruction2: float = 0.0,
                  interpolator_horizon: Optional[int] = None, interpolator_window: int = 1,
                  enable_forecaster_dropout: bool = False, max_batch: int = 64, use_graph: bool = True,
-                 enable_mfma: bool = True, **kwargs):
+                 enable_mfma: bool = True, loss_function: str = "mean_squared_error", **kwargs):
         super().__init__()
         if model is None:
             raise ValueError("Arg ``model`` is missing... Please provide a backbone model for the diffusion model (e.g. a Unet)")
@@ -48,7 +48,8 @@ class DYffusion(nn.Module):
             refine_intermediate_predictions=refine_intermediate_predictions, prediction_timesteps=prediction_timesteps,
             enable_interpolator_dropout=enable_interpolator_dropout,
             use_cold_sampling_for_last_step=use_cold_sampling_for_last_step, log_every_t=log_every_t,
-            lambda_reconstruction=lambda_reconstruction, lambda_reconstruction2=lambda_reconstruction2)
+            lambda_reconstruction=lambda_reconstruction, lambda_reconstruction2=lambda_reconstruction2,
+            loss_function=loss_function)  # BaseModel default (_base_model.py:48)
         self.model = model
         # the reference stores an InterpolationExperiment here (dyffusion.py:461-468); accept that duck type or a bare net
         self.interpolator = interpolator
@@ -290,8 +291,37 @@ class DYffusion(nn.Module):
         return eng.net_forward(L.NET_FORECASTER, x_t, time.float(), cond,
                                dropout_mode=1 if (self.enable_forecaster_dropout and getattr(self.model, 'has_dropout', True)) else 0)
 
-    def p_losses(self, *args, **kwargs):
-        raise NotImplementedError("training (dyffusion.py:496-567) is outside the sampling hot path of this engine")
+    def p_losses(self, xt_last: Tensor, condition: Tensor, t: Tensor, static_condition: Optional[Tensor] = None):
+        """dyffusion.py:496-567, forward only: the forecaster objective as the reference evaluates it in validation (eval-mode
+        normalisation; the interpolator keeps MC dropout when `enable_interpolator_dropout`).  Returns the reference's loss
+        dict with the "val/" prefix; values are python floats (reduced on the GPU by `dyf_criterion`).  The training step
+        (autograd through both networks, batch-statistics BatchNorm) is not part of this engine."""
+        if self.training:
+            raise NotImplementedError("p_losses in training mode needs the backward pass; only the eval-mode objective is implemented")
+        lam1, lam2 = self.hparams.lambda_reconstruction, self.hparams.lambda_reconstruction2
+        kind = self.hparams.loss_function
+
+        def sub(x, m):
+            return None if x is None else x[m]
+
+        eng = self._ensure_engine(xt_last.shape[-2:], xt_last.shape[0])
+        x_t = condition.clone()
+        nz = t > 0
+        if bool(nz.any()):
+            x_t[nz] = self.q_sample(x_end=condition[nz], x0=xt_last[nz], t=t[nz], static_condition=sub(static_condition, nz),
+                                    num_predictions=1).to(x_t.dtype)
+        pred = self.predict_x_last(condition=condition, x_t=x_t, t=t, static_condition=static_condition)
+        loss_forward = eng.criterion(pred, xt_last, kind)
+        not_last = t <= self.num_timesteps - 2
+        loss_forward2 = 0.0
+        if lam2 > 0 and bool(not_last.any()):
+            t2 = t[not_last] + 1
+            sc2 = sub(static_condition, not_last)
+            x_i2 = self.q_sample(x_end=condition[not_last], x0=pred[not_last], t=t2, static_condition=sc2, num_predictions=1)
+            pred2 = self.predict_x_last(condition=condition[not_last], x_t=x_i2, t=t2, static_condition=sc2)
+            loss_forward2 = eng.criterion(pred2, xt_last[not_last].contiguous(), kind)
+        return {"loss": lam1 * loss_forward + lam2 * loss_forward2, "val/loss_forward": loss_forward,
+                "val/loss_forward2": loss_forward2}
 
     def forward(self, *args, **kwargs):
         return self.p_losses(*args, **kwargs)

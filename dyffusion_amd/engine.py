@@ -242,6 +242,21 @@ class HipEngine:
                                             self._stream()))
         return y
 
+    def criterion(self, pred: torch.Tensor, target: torch.Tensor, kind: str = "l1") -> float:
+        """Mean L1 / MSE / smooth-L1 between two fp32 device tensors (get_loss, src/utilities/utils.py:201-212)."""
+        name = kind.lower().strip().replace("-", "_")
+        code = 0 if name in ("l1", "mae", "mean_absolute_error") else 1 if name in ("l2", "mse", "mean_squared_error") else \
+            2 if name in ("smoothl1", "smooth") else None
+        if code is None:
+            raise ValueError(f"Unknown loss function {kind}")
+        pred, target = _f32c(pred, "pred"), _f32c(target, "target")
+        if pred.shape != target.shape:
+            raise ValueError(f"shape mismatch: {tuple(pred.shape)} vs {tuple(target.shape)}")
+        out = C.c_double(0.0)
+        self._check(self._lib.dyf_criterion(self._h, pred.data_ptr(), target.data_ptr(), pred.numel(), code, C.byref(out),
+                                            self._stream()))
+        return out.value
+
     def op_linear_attention(self, qkv_bf16: torch.Tensor) -> torch.Tensor:
         """Test seam: LinearAttention core.  qkv (N,HW,384) bf16 (to_qkv output, 4 heads x 32) -> (N,HW,128) bf16."""
         assert qkv_bf16.dtype == torch.bfloat16 and qkv_bf16.is_cuda and qkv_bf16.is_contiguous()

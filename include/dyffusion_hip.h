@@ -183,6 +183,12 @@ dyf_status dyf_op_upconv2d(dyf_engine* engine, const uint16_t* x_dev, const floa
                            int32_t w, int32_t cin, int32_t cout, const float* scale_dev, const float* shift_dev,
                            int32_t act, uint16_t* y_dev, void* stream);
 
+/* Mean of the training criterion over `count` fp32 elements (src/utilities/utils.py:201-212 `get_loss`, reduction "mean"):
+ * kind 0 = L1, 1 = MSE, 2 = smooth-L1 (beta 1).  The reduction the forecaster objective `DYffusion.p_losses`
+ * (dyffusion.py:531,557) applies to (prediction, target); out_host[0] receives the scalar. */
+dyf_status dyf_criterion(dyf_engine* engine, const float* pred_dev, const float* target_dev, int64_t count, int32_t kind,
+                         double* out_host, void* stream);
+
 /* LinearAttention core (attention.py:28-49, 4 heads of 32 channels): qkv_dev (N,HW,384) bf16 = to_qkv output ->
  * out_dev (N,HW,128) bf16 = softmax_d(q)*scale . (softmax_n(k) . v^T / HW), the input of to_out.  Runs the pixel-parallel
  * MFMA kernels the ResNet-UNet uses. */

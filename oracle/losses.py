@@ -1,0 +1,95 @@
+"""ORACLE (test infrastructure, CPU fp32) -- the DYffusion forecaster objective, forward only.
+
+Restates /root/reference/src/diffusion/dyffusion.py:496-567 (`p_losses`) together with the two helpers it calls,
+:140-163 + :480-494 (`q_sample` / `_interpolate`) and :191-239 (`_predict_last_dynamics` / `predict_x_last`), given two
+callables for the networks.  This is the objective as the reference evaluates it in validation (`self.training` false:
+eval-mode normalisation layers); the training step adds autograd on top, which is outside this oracle.
+Parity: pinned against tests/golden/plosses_*.npz (outputs of the imported reference's `DYffusion.p_losses`) in
+tests/test_oracle_losses.py.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this package.
+"""
+from typing import Callable, Dict, Optional
+
+import torch
+from torch import Tensor
+
+from .schedule import build_step_tables
+
+NetFn = Callable[[Tensor, Tensor, Optional[Tensor]], Tensor]  # (inputs, time, condition) -> prediction
+
+
+def criterion_fn(name: str):
+    """src/utilities/utils.py:201-212 (`get_loss`, reduction="mean")."""
+    name = name.lower().strip().replace("-", "_")
+    if name in ("l1", "mae", "mean_absolute_error"):
+        return lambda a, b: (a - b).abs().mean()
+    if name in ("l2", "mse", "mean_squared_error"):
+        return lambda a, b: ((a - b) ** 2).mean()
+    if name in ("smoothl1", "smooth"):
+        return torch.nn.functional.smooth_l1_loss
+    raise ValueError(f"Unknown loss function {name}")
+
+
+def p_losses(forecaster: NetFn, interpolator: NetFn, xt_last: Tensor, condition: Tensor, t: Tensor,
+             static_condition: Optional[Tensor], cfg: dict, noise_fn=None) -> Dict[str, Tensor]:
+    """cfg keys (reference kwarg names): timesteps, schedule, additional_interpolation_steps,
+    additional_interpolation_steps_factor, interpolate_before_t1, time_encoding, forward_conditioning,
+    lambda_reconstruction, lambda_reconstruction2, loss_function."""
+    tab = build_step_tables(cfg["timesteps"], cfg.get("schedule", "before_t1_only"),
+                            cfg.get("additional_interpolation_steps", 0),
+                            cfg.get("additional_interpolation_steps_factor", 0),
+                            cfg.get("interpolate_before_t1", False))
+    T = tab.num_timesteps
+    fcond = cfg.get("forward_conditioning", "data")
+    enc = cfg.get("time_encoding", "dynamics")
+    lam1, lam2 = cfg.get("lambda_reconstruction", 1.0), cfg.get("lambda_reconstruction2", 0.0)
+    crit = criterion_fn(cfg.get("loss_function", "mse"))
+    noise_fn = noise_fn or torch.randn_like
+
+    def i_time(tt: Tensor) -> Tensor:  # dyffusion.py:101-138, per batch row
+        return torch.tensor([float(tab.interpolation_time(float(v))) for v in tt], dtype=torch.float32)
+
+    def q_sample(x_end, x0, tt, sc):  # interpolator in "interpolation mode": I(x_end = t0 data, x0 = last data, i(t))
+        it = i_time(tt)
+        assert bool(((0 < it) & (it < tab.horizon)).all()), f"interpolate time must be in (0, {tab.horizon}), got {it}"
+        return interpolator(torch.cat([x_end, x0], dim=1), it, sc)
+
+    def predict_x_last(cond_data, x_t, tt, sc):
+        assert bool(((0 <= tt) & (tt <= T - 1)).all()), f"Invalid timestep: {tt}"
+        if fcond == "data":
+            cond = cond_data
+        elif fcond == "none":
+            cond = None
+        elif "data+noise" in fcond:
+            tf = (tt / (T - 1)).view(cond_data.shape[0], *[1] * (cond_data.ndim - 1))
+            cond = tf * cond_data + (1 - tf) * noise_fn(cond_data)
+        else:
+            raise ValueError(f"Invalid forward conditioning type: {fcond}")
+        if sc is not None:
+            cond = sc if cond is None else torch.cat([cond, sc], dim=1)
+        time = tt.float() if enc == "discrete" else tt / T if enc == "normalized" else i_time(tt)
+        return forecaster(x_t, time, cond)
+
+    def sub(x, m):
+        return None if x is None else x[m]
+
+    # 1. forecaster inputs: the initial condition for t = 0, an interpolated state for t > 0
+    x_t = condition.clone()
+    nz = t > 0
+    if bool(nz.any()):
+        x_t[nz] = q_sample(condition[nz], xt_last[nz], t[nz], sub(static_condition, nz)).to(x_t.dtype)
+    # 2. predict the last state from x_t
+    pred = predict_x_last(condition, x_t, t, static_condition)
+    loss_forward = crit(pred, xt_last)
+    # 3. one more emulated step: interpolate with the PREDICTED last state, predict again
+    not_last = t <= T - 2
+    loss_forward2 = torch.zeros(())
+    if lam2 > 0 and bool(not_last.any()):
+        t2 = t[not_last] + 1
+        sc2 = sub(static_condition, not_last)
+        x_i2 = q_sample(condition[not_last], pred[not_last], t2, sc2)
+        pred2 = predict_x_last(condition[not_last], x_i2, t2, sc2)
+        loss_forward2 = crit(pred2, xt_last[not_last])
+    return {"loss": lam1 * loss_forward + lam2 * loss_forward2, "loss_forward": loss_forward, "loss_forward2": loss_forward2,
+            "xt_last_pred": pred}

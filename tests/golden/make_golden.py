@@ -292,6 +292,50 @@ def gen_samples():
         print(name, {k: tuple(v.shape) for k, v in out.items()}, "std t_last", float(out[f"t{h}_preds"].std()))
 
 
+# ------------------------------------------------------------------------------------------------ forecaster objective
+def gen_plosses():
+    """`DYffusion.p_losses` of the imported reference in eval mode (the validation objective; dyffusion.py:496-567): per-row
+    diffusion steps incl. t = 0 and t = T-1, both loss terms."""
+    base_model = dict(dim=4, outer_sample_mode="bilinear", upsample_dims=[64, 64], with_time_emb=True,
+                      input_dropout=0.0, dropout=0.2)
+    variants = [
+        ("plosses_a", dict(h=4), dict(lambda_reconstruction=1.0, lambda_reconstruction2=0.5, loss_function="l1")),
+        ("plosses_b", dict(h=5), dict(additional_interpolation_steps=2, forward_conditioning="data", lambda_reconstruction=0.7,
+                                       lambda_reconstruction2=1.0, loss_function="mse", time_encoding="normalized")),
+        ("plosses_c", dict(h=4), dict(lambda_reconstruction2=0.0, loss_function="l1", time_encoding="discrete")),
+    ]
+    for name, meta, dk in variants:
+        h = meta["h"]
+        dkw = dict(enable_interpolator_dropout=False)
+        dkw.update(dk)
+        exp, ipol = ref_import.build_reference_dyffusion(system="spring-mesh", model="unet_simple",
+                                                         model_kwargs=base_model, horizon=h, diffusion_kwargs=dkw)
+        load_seeded(exp.model.model, seed=31)
+        load_seeded(ipol.model, seed=32)
+        dyn = exp.model.eval()
+        T = dyn.num_timesteps
+        g = torch.Generator().manual_seed(19)
+        B = 6
+        xt_last = torch.randn(B, 4, 10, 10, generator=g)
+        cond = torch.randn(B, 4, 10, 10, generator=g)
+        sc = torch.rand(B, 1, 10, 10, generator=g)
+        t = torch.tensor([0, 1, T - 1, 2 % T, T - 2, 0])
+        with torch.no_grad():
+            out = dyn.p_losses(xt_last, cond, t, static_condition=sc)
+        hp = dict(timesteps=h, num_timesteps=T, model=base_model, B=B,
+                  **{k: dkw.get(k, d) for k, d in dict(
+                      schedule="before_t1_only", additional_interpolation_steps=0, additional_interpolation_steps_factor=0,
+                      interpolate_before_t1=True, time_encoding="dynamics", forward_conditioning="none",
+                      lambda_reconstruction=1.0, lambda_reconstruction2=0.0, loss_function="l1",
+                      enable_interpolator_dropout=False).items()})
+        arrs = {f"F::{k}": v.numpy() for k, v in dyn.model.state_dict().items()}
+        arrs.update({f"I::{k}": v.numpy() for k, v in ipol.model.state_dict().items()})
+        vals = {k.split("/")[-1]: float(v) for k, v in out.items()}
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), xt_last=xt_last.numpy(), cond=cond.numpy(), sc=sc.numpy(),
+                            t=t.numpy(), hp=json.dumps(hp), losses=json.dumps(vals), **arrs)
+        print(name, vals)
+
+
 # ------------------------------------------------------------------------------------------------ G6
 def gen_fullsize():
     """NS 221x42 h=16 dim=64 (BASELINE config 2): checksums + probe points of the reference rollout, dropout OFF
@@ -352,7 +396,9 @@ def gen_ckpt_keys():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["schedules", "nets", "resnet", "samples", "fullsize", "metrics", "ckpt"]
+    which = sys.argv[1:] or ["schedules", "nets", "resnet", "samples", "fullsize", "metrics", "ckpt", "plosses"]
+    if "plosses" in which:
+        gen_plosses()
     if "metrics" in which:
         gen_metrics()
     if "ckpt" in which:

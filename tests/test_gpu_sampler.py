@@ -156,3 +156,38 @@ def test_autoregressive_outer_loop_with_boundary_conditions():
     assert torch.equal(got["t8_targets"].cpu(), dyn[:, 8])
     print("autoregressive (2 x h=4) worst rel-rms", worst)
     assert worst <= 4e-2
+
+
+@pytest.mark.parametrize("name", ["plosses_a", "plosses_b", "plosses_c"])
+def test_forecaster_objective_matches_reference_golden(name):
+    """`DYffusion.p_losses` in eval mode (dyffusion.py:496-567): per-row diffusion steps incl. t = 0 and T-1, both loss terms,
+    against the imported reference's values (fixtures plosses_*.npz) and the oracle.  Tolerance: 2 % of the loss value (two
+    to four chained bf16 network forwards; the reduction itself is fp32 / fp64)."""
+    from oracle import losses
+    z = load_npz(name + ".npz")
+    hp = json.loads(str(z["hp"]))
+    PF, PI = split_state(z, "F"), split_state(z, "I")
+    m = build_dyffusion(PF, PI, hp["model"], 4, 1, hp, max_batch=hp["B"])
+    xt_last, cond, sc = (torch.from_numpy(z[k]).to(DEV) for k in ("xt_last", "cond", "sc"))
+    t = torch.from_numpy(z["t"]).to(DEV)
+    got = m.p_losses(xt_last, cond, t, static_condition=sc)
+    want = json.loads(str(z["losses"]))
+    for k_got, k_want in (("loss", "loss"), ("val/loss_forward", "loss_forward"), ("val/loss_forward2", "loss_forward2")):
+        assert abs(got[k_got] - want[k_want]) <= 2e-2 * max(abs(want[k_want]), 1e-3), (k_got, got[k_got], want[k_want])
+    with pytest.raises(NotImplementedError):
+        m.train().p_losses(xt_last, cond, t, static_condition=sc)
+    m.eval()
+
+
+def test_criterion_reduction_matches_torch():
+    import dyffusion_amd as D
+    cfg = D.net_config(in_channels=3, cond_channels=0, out_channels=3, dim=64, upsample_dims=[64, 64])
+    eng = D.HipEngine(cfg, cfg, 16, 16, max_batch=1, use_graph=False)
+    g = torch.Generator().manual_seed(5)
+    for n in (1, 3, 1027, 80 * 3 * 221 * 42):
+        a, b = torch.randn(n, generator=g), 1.5 * torch.randn(n, generator=g)
+        for kind, ref in (("l1", torch.nn.functional.l1_loss), ("mse", torch.nn.functional.mse_loss),
+                          ("smoothl1", torch.nn.functional.smooth_l1_loss)):
+            got = eng.criterion(a.to(DEV), b.to(DEV), kind)
+            want = float(ref(a.double(), b.double()))
+            assert abs(got - want) <= 2e-6 * max(1.0, abs(want)), (n, kind, got, want)
