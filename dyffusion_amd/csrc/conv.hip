@@ -592,12 +592,12 @@ hipError_t launch_conv(const ConvArgs& a, int path, hipStream_t stream) {
             }
         }
         static const bool use_igemm2 = !(getenv("DYF_IGEMM2") && atoi(getenv("DYF_IGEMM2")) == 0);
-        if (!a.up2x && use_igemm2 && a.cout % 128 == 0) {
+        if (!a.up2x && use_igemm2 && a.cout % 64 == 0) {  // cout % 128 == 0: 256 x 128 tiles, else 256 x 64
             ConvArgs b = a;
             if (!b.wpk_frag) b.wpk_frag = conv_lookup_frag(b.wpk);
             // 256 x 128 tiles pay off once they fill the chip (2 workgroups x 256 CUs); below that the 128 x 128 form's
             // finer tiles win (measured at NB = 50: dec2/enc2 with 400 tiles +9 %/+4 %, enc3 with 200 tiles -20 %)
-            const long long tiles2 = (((long long)a.n * a.ho * a.wo + 255) / 256) * (a.cout / 128);
+            const long long tiles2 = (((long long)a.n * a.ho * a.wo + 255) / 256) * (a.cout % 128 == 0 ? a.cout / 128 : a.cout / 64);
             const char* mt = getenv("DYF_IGEMM2_MIN_TILES");  // tests force the form on small problems
             const long long min_tiles = mt ? atoll(mt) : 384;
             if (tiles2 >= min_tiles && conv_igemm2_supported(b)) return launch_conv_igemm2(b, stream);

@@ -27,21 +27,29 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
 
 namespace {
-constexpr int BM = 256, BN = 128;
+constexpr int BM = 256;
 constexpr int A_BYTES = BM * 128;      // one K step of the pixel operand: 256 rows x 64 channels bf16
 constexpr int LDS_TOTAL = 2 * A_BYTES; // 64 KB: two workgroups per CU
 constexpr int RA = BM / 32;            // rows gathered per lane per K step
 constexpr int TH = BM / 16;            // 2-D tile: 16 rows of 16 pixels
-constexpr int STEP_BYTES = BN * 128;   // weights of one K step of one column block: 128 channels x 64 k bf16
 }  // namespace
 
+// WN = 2: 256 pixels x 128 channels per workgroup, waves 2 x 2, each 128 pixels x 64 channels (4 x 2 accumulator tiles).
+// WN = 1: 256 pixels x 64 channels for layers whose output channels are a multiple of 64 only (the 64-channel level of the
+//         ResNet-UNet): waves 4 x 1, each 64 pixels x 64 channels (2 x 2 tiles).  Pixel fragments still feed 2 MFMAs each
+//         (64 B/clk/CU of LDS reads at MFMA peak); every weight fragment feeds 2 instead of 4, i.e. the weight stream costs
+//         64 B/clk/CU of L1 bandwidth at peak -- its limit, fine at the ~50 % this kernel reaches (conv_igemm_kernel<256, 64>
+//         stages both operands through LDS and stops at 19 %).
+template <int WN>
 __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(ConvArgs a, int M, int tiles_m, int tiles_n) {
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    constexpr int BN = 64 * WN, MT = WN == 2 ? 4 : 2;  // channels per workgroup, 32-pixel sub-tiles per wave
+    constexpr int STEP_BYTES = BN * 128;              // weights of one K step of one column block: BN channels x 64 k bf16
+    const int wm = WN == 2 ? wave >> 1 : wave, wn = WN == 2 ? wave & 1 : 0;
     const int l31 = lane & 31, hi = lane >> 5;
 
     // XCD-aware tile id (bijective for any tile count): XCD x = bid % 8 takes a contiguous run of tiles
@@ -132,9 +140,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(ConvArgs a, int M, 
         }
     };
 
-    f32x16 acc[4][2];  // [pixel sub-tile mt: rows wm*128 + mt*32 ..][32-channel half]
+    f32x16 acc[MT][2];  // [pixel sub-tile mt: rows wm*32*MT + mt*32 ..][32-channel half]
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
@@ -143,7 +151,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(ConvArgs a, int M, 
     // fragment addresses: row r of the stage at r*128, 16-B slot (k16*2 + hi) ^ ((r >> 1) & 7); sub-tile rows are
     // 32-aligned + l31, so the key is (l31 >> 1) & 7 for every mt and the sub-step only flips bits 5-6
     const unsigned lds_base = (unsigned)(uintptr_t)LDS_PTR(smem);
-    const unsigned a_row = (unsigned)((wm * 128 + l31) * 128);
+    const unsigned a_row = (unsigned)((wm * (32 * MT) + l31) * 128);
     const unsigned a_x = (unsigned)((hi ^ ((l31 >> 1) & 7)) << 4);
     const unsigned w_voff = (unsigned)lane * 16u;
     // weight stream of this wave: [tn][K step][wn][ks][half][lane] x 16 B
@@ -151,7 +159,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(ConvArgs a, int M, 
     const unsigned soff_last = soff_cur + (unsigned)(nk - 1) * STEP_BYTES;
 
     u32x4 bq[4][2];
-    bf16x8 aq[2][4];
+    bf16x8 aq[2][MT];
 #define ISSUE_B(SET, SOFF, KS)                                                                               \
     _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                                         \
         bq[SET][nt] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, w_voff + nt * 1024, (SOFF) + (KS) * 2048, 0);
@@ -178,12 +186,16 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(ConvArgs a, int M, 
         if (LOAD) RDA1(LSET, LKS, 0)                                                                         \
         MF(1, 0, USE_A, USE_B) PIN                                                                           \
         if (LOAD) RDA1(LSET, LKS, 1)                                                                         \
-        MF(2, 0, USE_A, USE_B) PIN                                                                           \
-        if (LOAD) RDA1(LSET, LKS, 2)                                                                         \
-        MF(3, 0, USE_A, USE_B) PIN                                                                           \
-        if (LOAD) RDA1(LSET, LKS, 3)                                                                         \
-        MF(0, 1, USE_A, USE_B) PIN                                                                           \
-        MF(1, 1, USE_A, USE_B) MF(2, 1, USE_A, USE_B) MF(3, 1, USE_A, USE_B) PIN                             \
+        if constexpr (MT == 4) {                                                                             \
+            MF(2, 0, USE_A, USE_B) PIN                                                                       \
+            if (LOAD) RDA1(LSET, LKS, 2)                                                                     \
+            MF(3, 0, USE_A, USE_B) PIN                                                                       \
+            if (LOAD) RDA1(LSET, LKS, 3)                                                                     \
+            MF(0, 1, USE_A, USE_B) PIN                                                                       \
+            MF(1, 1, USE_A, USE_B) MF(2, 1, USE_A, USE_B) MF(3, 1, USE_A, USE_B) PIN                         \
+        } else {                                                                                             \
+            MF(0, 1, USE_A, USE_B) MF(1, 1, USE_A, USE_B) PIN                                                \
+        }                                                                                                    \
     }
 
     issue_a(0);
@@ -197,7 +209,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(ConvArgs a, int M, 
         __builtin_amdgcn_sched_barrier(0);
         if (k + 1 < nk) issue_a((k + 1) & 1);
         const unsigned As = lds_base + (unsigned)((k & 1) * A_BYTES) + a_row;
-        RDA1(0, 0, 0) RDA1(0, 0, 1) RDA1(0, 0, 2) RDA1(0, 0, 3)
+        RDA1(0, 0, 0) RDA1(0, 0, 1)
+        if constexpr (MT == 4) { RDA1(0, 0, 2) RDA1(0, 0, 3) }
         SLOT(3, soff_cur, 3, true, 1, 1, 0, 0)
         SLOT(0, soff_next, 0, true, 0, 2, 1, 1)
         SLOT(1, soff_next, 1, true, 1, 3, 0, 2)
@@ -218,8 +231,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(ConvArgs a, int M, 
     auto epilogue = [&](auto act_c, auto mode_c) {
         constexpr int ACT = decltype(act_c)::value, MODE = decltype(mode_c)::value;
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-            const int row = wm * 128 + mt * 32 + l31;
+        for (int mt = 0; mt < MT; ++mt) {
+            const int row = wm * (32 * MT) + mt * 32 + l31;
             const bool valid = tm * BM + row < M;
             int m, n_img;
             if (tile2d) {
@@ -288,15 +301,16 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(ConvArgs a, int M, 
 // k = chunk*64 + ks*16 + hi*8 + {0..7} of tap `tap`
 void pack_conv_frag(const bf16_t* wpk, int cout, int taps, int cin, bf16_t* out) {
     const int cpt = cin / 64;
+    const int wns = cout % 128 == 0 ? 2 : 1, bn = 64 * wns;  // column block: 128 channels, or 64 (conv_igemm2_kernel<1>)
     size_t o = 0;
-    for (int tn = 0; tn < cout / 128; ++tn)
+    for (int tn = 0; tn < cout / bn; ++tn)
         for (int chunk = 0; chunk < cpt; ++chunk)
             for (int tap = 0; tap < taps; ++tap)
-                for (int wn = 0; wn < 2; ++wn)
+                for (int wn = 0; wn < wns; ++wn)
                     for (int ks = 0; ks < 4; ++ks)
                         for (int half = 0; half < 2; ++half)
                             for (int lane = 0; lane < 64; ++lane) {
-                                const int co = tn * 128 + wn * 64 + half * 32 + (lane & 31);
+                                const int co = tn * bn + wn * 64 + half * 32 + (lane & 31);
                                 const int k0 = chunk * 64 + ks * 16 + (lane >> 5) * 8;
                                 const bf16_t* s = wpk + ((size_t)co * taps + tap) * cin + k0;
                                 for (int e = 0; e < 8; ++e) out[o++] = s[e];
@@ -305,7 +319,7 @@ void pack_conv_frag(const bf16_t* wpk, int cout, int taps, int cin, bf16_t* out)
 
 bool conv_igemm2_supported(const ConvArgs& a) {
     if (a.up2x || a.wpk_frag == nullptr) return false;
-    if (!(a.c0 > 0 && a.c0 % 64 == 0 && a.c1 % 64 == 0 && a.cout % 128 == 0)) return false;
+    if (!(a.c0 > 0 && a.c0 % 64 == 0 && a.c1 % 64 == 0 && a.cout % 64 == 0)) return false;
     if (a.kh * a.kw > 32) return false;
     const size_t npix = (size_t)a.n * a.h * a.w;
     const int pitch0 = a.pix_pitch0 ? a.pix_pitch0 : a.c0;
@@ -314,13 +328,21 @@ bool conv_igemm2_supported(const ConvArgs& a) {
 }
 
 hipError_t conv_igemm2_init() {
-    return hipFuncSetAttribute((const void*)conv_igemm2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
+    hipError_t e = hipFuncSetAttribute((const void*)conv_igemm2_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv_igemm2_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
+    return e;
 }
 
 hipError_t launch_conv_igemm2(const ConvArgs& a, hipStream_t stream) {
     const long long M = (long long)a.n * a.ho * a.wo;
-    const int tiles_m = (int)((M + BM - 1) / BM), tiles_n = a.cout / BN;
-    hipLaunchKernelGGL(conv_igemm2_kernel, dim3(tiles_m * tiles_n), dim3(256), LDS_TOTAL, stream, a, (int)M, tiles_m, tiles_n);
+    const int tiles_m = (int)((M + BM - 1) / BM);
+    if (a.cout % 128 == 0) {
+        const int tiles_n = a.cout / 128;
+        hipLaunchKernelGGL(conv_igemm2_kernel<2>, dim3(tiles_m * tiles_n), dim3(256), LDS_TOTAL, stream, a, (int)M, tiles_m, tiles_n);
+    } else {
+        const int tiles_n = a.cout / 64;
+        hipLaunchKernelGGL(conv_igemm2_kernel<1>, dim3(tiles_m * tiles_n), dim3(256), LDS_TOTAL, stream, a, (int)M, tiles_m, tiles_n);
+    }
     return hipGetLastError();
 }
 

@@ -1105,7 +1105,7 @@ dyf_status dyf_op_conv2d(dyf_engine* e, const uint16_t* x_dev, const float* w_ho
                 pk[((size_t)co * taps + t) * cin + ci] = f32_to_bf16(w_host[((size_t)co * cin + ci) * taps + t]);
     bf16_t* wdev = nullptr;
     float *ones = nullptr, *zeros = nullptr;
-    const bool frag = cout % 128 == 0 && cin % 64 == 0 && taps <= 32;
+    const bool frag = cout % 64 == 0 && cin % 64 == 0 && taps <= 32;
     HIP_TRY(e, hipMalloc((void**)&wdev, 2 * pk.size() * sizeof(bf16_t)));
     HIP_TRY(e, hipMemcpy(wdev, pk.data(), pk.size() * sizeof(bf16_t), hipMemcpyHostToDevice));
     if (frag) {

@@ -164,7 +164,7 @@ dyf_status dev_upload(dyf_engine* e, T** out, const std::vector<T>& host) {
 inline dyf_status upload_conv_weights(dyf_engine* e, bf16_t** out, const std::vector<bf16_t>& pk, int cout, int taps, int cin) {
     dyf_status st = dev_upload(e, out, pk);
     if (st != DYF_OK) return st;
-    if (cout % 128 == 0 && cin % 64 == 0 && taps <= 32 && (size_t)cout * taps * cin == pk.size()) {
+    if (cout % 64 == 0 && cin % 64 == 0 && taps <= 32 && (size_t)cout * taps * cin == pk.size()) {
         std::vector<bf16_t> pf(pk.size());
         pack_conv_frag(pk.data(), cout, taps, cin, pf.data());
         bf16_t* frag = nullptr;

@@ -71,6 +71,11 @@ IGEMM2_CASES = [
     (3, 33, 17, 64, 128, 3, 1, 1),      # odd plane: raster tiling, 7 tiles with a ragged last one
     (1, 64, 64, 128, 128, 1, 1, 0),
     (2, 32, 48, 192, 256, 3, 1, 1),     # 2-D tiles (16 x 16 output tiles), three 64-channel chunks
+    # cout % 128 != 0 -> conv_igemm2_kernel<1> (256 x 64 tiles, waves 4 x 1)
+    (2, 16, 16, 64, 64, 3, 1, 1),
+    (1, 60, 60, 64, 64, 3, 1, 1),       # the OISST level-0 plane: raster tiling, ragged last tile
+    (3, 15, 15, 128, 192, 3, 1, 1),
+    (1, 32, 32, 64, 320, 1, 1, 0),
 ]
 
 
