@@ -250,6 +250,11 @@ class HipEngine:
         if code is None:
             raise ValueError(f"Unknown loss function {kind}")
         pred, target = _f32c(pred, "pred"), _f32c(target, "target")
+        # the kernel reads 16 bytes per lane: a contiguous view at an odd element offset is copied to an aligned buffer
+        if pred.data_ptr() % 16:
+            pred = pred.clone()
+        if target.data_ptr() % 16:
+            target = target.clone()
         if pred.shape != target.shape:
             raise ValueError(f"shape mismatch: {tuple(pred.shape)} vs {tuple(target.shape)}")
         out = C.c_double(0.0)

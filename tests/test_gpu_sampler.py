@@ -191,3 +191,5 @@ def test_criterion_reduction_matches_torch():
             got = eng.criterion(a.to(DEV), b.to(DEV), kind)
             want = float(ref(a.double(), b.double()))
             assert abs(got - want) <= 2e-6 * max(1.0, abs(want)), (n, kind, got, want)
+    big = torch.randn(4099, generator=g).to(DEV)
+    assert abs(eng.criterion(big[1:], big[:-1], "l1") - float((big[1:] - big[:-1]).abs().double().mean())) <= 1e-5  # misaligned views
