@@ -42,7 +42,12 @@ struct ConvArgs {
     bf16_t* out_bf16;    // NHWC bf16 output (or null)
     float* out_f32;      // NHWC fp32 output (GroupNorm input) (or null)
     const bf16_t* zero_page;  // >= 128 B of zeros in HBM: source of padded taps for the LDS-DMA gather
+    // halo form of the fused-upsample conv: fp32 scratch [n][2*wo + 2*(ho-2)][cout] for the border corrections
+    // (up_border_kernel fills it, conv_up_halo_kernel starts its border accumulators from it); required by that form
+    float* up_border;
 };
+// floats of ConvArgs::up_border for an n x (2h x 2w) x cout output
+inline size_t conv_up_border_floats(int n, int h, int w, int cout) { return (size_t)n * (4 * (size_t)w + 4 * (size_t)h - 4) * cout; }
 
 // path: 0 direct (any shape), 1 implicit-GEMM MFMA (needs c0 % 64 == 0, c1 % 64 == 0, cout % 64 == 0)
 hipError_t conv_init();

@@ -71,8 +71,7 @@ struct HaloCfg {
     static constexpr bool S2 = SP == 3 || SP == 4;      // 4x4 / stride 2 on parity planes
     static constexpr int BLK = SP == 4 ? 128 : 256;     // plain forms: output channels of a workgroup
     static constexpr int STEP = BLK * 128;              // weight bytes of one (tap, chunk) step: BLK columns x 64 k bf16
-    static constexpr int ZERO_OFF = NBUF * BYTES;       // 128 B of zeros (pixels masked out of a correction tap)
-    static constexpr int HOFF_OFF = ZERO_OFF + 512;     // per-thread halo source offsets [PER_WAVE][256]
+    static constexpr int HOFF_OFF = NBUF * BYTES + 512; // per-thread halo source offsets [PER_WAVE][256]
     static constexpr int INSTR = PIX / 8;               // wave-level DMA instructions per halo: 23 / 50
     static constexpr int PER_WAVE = (INSTR + NWAVES - 1) / NWAVES;
     static constexpr int LDS_TOTAL = HOFF_OFF + PER_WAVE * 1024;  // 53 760 / 65 024 B
@@ -85,7 +84,7 @@ __global__ __launch_bounds__(256, 2) void conv_up_halo_kernel(ConvArgs a, int ti
                                                               int tiles_n, int xmode) {
 #if defined(__HIP_DEVICE_COMPILE__)
     using H = HaloCfg<SP>;
-    constexpr int HALO_W = H::W, HALO_REAL = H::REAL, HALO_BYTES = H::BYTES, ZERO_OFF = H::ZERO_OFF, HOFF_OFF = H::HOFF_OFF;
+    constexpr int HALO_W = H::W, HALO_REAL = H::REAL, HALO_BYTES = H::BYTES, HOFF_OFF = H::HOFF_OFF;
     constexpr int HALO_INSTR = H::INSTR, HALO_PER_WAVE = H::PER_WAVE;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -129,19 +128,14 @@ __global__ __launch_bounds__(256, 2) void conv_up_halo_kernel(ConvArgs a, int ti
 
     const int cin = a.c0 + a.c1;
     const int cpt = H::S2 ? 4 * (cin >> 6) : cin >> 6;  // K chunks: (SP = 3) 4 parity planes per 64-channel chunk
-    // border corrections are per WAVE (a wave owns one output phase): the top/bottom row matters to phases py = 0 / 1, the
-    // left/right column to px = 0 / 1.  Waves only meet at the per-chunk barrier, so each runs its own tap list.
     const int gh = H::S2 ? a.ho : a.h, gw = H::S2 ? a.wo : a.w;  // the grid the halo / tiles live on
-    const bool has_top = ty0 == 0, has_bot = ty0 + H::TH == gh;
-    const bool m_left = col == 0, m_right = col == gw - 1;
-    const bool has_row = !H::PLAIN && (wpy == 0 ? has_top : has_bot);
-    const bool has_col = !H::PLAIN && (wpx == 0 ? __builtin_amdgcn_ballot_w64(m_left) : __builtin_amdgcn_ballot_w64(m_right)) != 0ull;
-    // tap list of this wave, 4 bits per entry: 0-8 stencil, 9-11 row correction, 12-14 column correction, 15 corner
-    unsigned long long tap_list = H::S2 ? 0x3210ull : 0x876543210ull;
-    int ntaps = H::S2 ? 4 : 9;
-    if (has_row) { tap_list |= 0xBA9ull << (4 * ntaps); ntaps += 3; }
-    if (has_col) { tap_list |= 0xEDCull << (4 * ntaps); ntaps += 3; }
-    if (has_row && has_col) { tap_list |= 0xFull << (4 * ntaps); ntaps += 1; }
+    // The conv's ZERO padding of the upsampled image (which replicate-clamping the stencil cannot express) is repaired by
+    // correction taps that only the first / last output row / column see.  They are NOT computed here: up_border_kernel
+    // evaluates them for the border ring of the output beforehand and the accumulators of border pixels start from its
+    // result, so every tile runs the same 9-tap stencil (in-kernel corrections cost border tiles up to 7 extra taps, with the
+    // other waves of the workgroup waiting at the chunk barrier: 19 % of dec4, 24 % of dec3).
+    const unsigned long long tap_list = H::S2 ? 0x3210ull : 0x876543210ull;
+    const int ntaps = H::S2 ? 4 : 9;
 
     const size_t npix = (size_t)a.n * a.h * a.w;
     const auto rsrc_a0 = __builtin_amdgcn_make_buffer_rsrc((void*)a.src0, 0, (int)(unsigned)(npix * a.c0 * 2), 0x00020000);
@@ -177,7 +171,6 @@ __global__ __launch_bounds__(256, 2) void conv_up_halo_kernel(ConvArgs a, int ti
         if (H::PLAIN && (yy != y || xx != x)) off = 0xFFFFFFFFu;  // plain convs: zero padding = out-of-range DMA offset
         h_tab[j * 256] = off;
     }
-    if (tid < 32) ((uint4*)(smem + ZERO_OFF))[tid] = make_uint4(0, 0, 0, 0);
 
     auto issue_halo = [&](int chunk) {
         const int cb = H::S2 ? (chunk >> 2) << 6 : chunk << 6;
@@ -222,10 +215,37 @@ __global__ __launch_bounds__(256, 2) void conv_up_halo_kernel(ConvArgs a, int ti
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[nt][mt][r] = 0.0f;
+    if (!H::PLAIN) {
+        // border pixels of the OUTPUT start from the correction sums of up_border_kernel (ring index: top row, bottom row,
+        // left column, right column); lane (l31, hi) holds channels nt*32 + 8*g + 4*hi + {0..3} of its pixel
+        const bool edge_col = col == 0 || col == gw - 1;
+        if (ty0 == 0 || ty0 + H::TH == gh || __builtin_amdgcn_ballot_w64(edge_col) != 0ull) {
+            const int ring_len = 2 * a.wo + 2 * (a.ho - 2);
+            const int X = 2 * col + wpx;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const int Y = 2 * (ty0 + 2 * mt + px_r) + wpy;
+                int ring = -1;
+                if (Y == 0) ring = X;
+                else if (Y == a.ho - 1) ring = a.wo + X;
+                else if (X == 0) ring = 2 * a.wo + Y - 1;
+                else if (X == a.wo - 1) ring = 2 * a.wo + (a.ho - 2) + Y - 1;
+                if (ring >= 0) {
+                    const float* cp = a.up_border + ((size_t)n_img * ring_len + ring) * a.cout + tn * 64 + 4 * hi;
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const float4 v = *(const float4*)(cp + nt * 32 + 8 * g);
+                            acc[nt][mt][4 * g + 0] = v.x; acc[nt][mt][4 * g + 1] = v.y;
+                            acc[nt][mt][4 * g + 2] = v.z; acc[nt][mt][4 * g + 3] = v.w;
+                        }
+                }
+            }
+        }
+    }
 
     int hp0 = (px_r + 1 + (SP == 4 ? 8 * wpy : 0)) * HALO_W + (col - cbase);  // halo pixel of pixel tile 0 at the un-shifted tap; mt adds 2 rows
-    const bool m_row = wpy == 0 ? px_r == 0 : px_r == 1;   // border row: pixel tile 0 (top) / 3 (bottom)
-    const bool m_col = wpx == 0 ? m_left : m_right;
     const unsigned lds_base = (unsigned)(uintptr_t)LDS_PTR(smem);
 
     u32x4 bq[4][2];   // weight fragments: set = k16 sub-step & 3
@@ -250,17 +270,6 @@ __global__ __launch_bounds__(256, 2) void conv_up_halo_kernel(ConvArgs a, int ti
             const int hpm = hpb + (DISP) + 2 * HALO_W * mt;                                                  \
             ab[mt] = Hs + hpm * 128;                                                                         \
             ax[mt] = (unsigned)((hi ^ HKEY(hpm)) << 4);                                               \
-        }                                                                                                    \
-    }
-    // the same for a correction tap: lanes whose pixel is not on the border (KEEP false) read the zero page
-#define TAPADDR_MASKED(DISP, KEEP)                                                                           \
-    {                                                                                                        \
-        int hpb = hp0;                                                                                       \
-        asm volatile("" : "+v"(hpb));                                                                        \
-        _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) {                                                   \
-            const int hpm = hpb + (DISP) + 2 * HALO_W * mt;                                                  \
-            ab[mt] = (KEEP) ? Hs + hpm * 128 : lds_base + ZERO_OFF;                                          \
-            ax[mt] = (KEEP) ? (unsigned)((hi ^ HKEY(hpm)) << 4) : 0u;                                 \
         }                                                                                                    \
     }
 #define RDA1(SET, KS, MT)                                                                                    \
@@ -297,33 +306,6 @@ __global__ __launch_bounds__(256, 2) void conv_up_halo_kernel(ConvArgs a, int ti
         advance();                                                                                           \
     }
 #define STENCIL_STEP(DISP, HAS_NEXT, DNEXT) STEP_CORE(HAS_NEXT, TAPADDR(DNEXT))
-    // column-correction tap: the same 8 MFMAs per sub-step as a stencil tap (all pixel tiles, both channel halves), pixel
-    // fragments masked to the border column -> the same software pipeline
-#define COL_STEP(HAS_NEXT, ANEXT) STEP_CORE(HAS_NEXT, TAPADDR_MASKED((ANEXT) * HALO_W, m_col))
-    // One correction step: only the pixel tiles / column tiles that touch the border take part.  BODY(KS, BSET) issues
-    // its (masked) pixel fragments and MFMAs; the weight stream keeps its cadence.
-#define CORR_STEP(BODY)                                                                                      \
-    {                                                                                                        \
-        ISSUE_B(3, soff_cur, 3)                                                                              \
-        BODY(0, 0)                                                                                           \
-        ISSUE_B(0, soff_next, 0)                                                                             \
-        BODY(1, 1)                                                                                           \
-        ISSUE_B(1, soff_next, 1)                                                                             \
-        BODY(2, 2)                                                                                           \
-        ISSUE_B(2, soff_next, 2)                                                                             \
-        BODY(3, 3)                                                                                           \
-        advance();                                                                                           \
-    }
-    // masked pixel fragment of tile MT at displacement DISP: lanes with KEEP false read the zero page
-#define RDA_MASKED(DST, MT, DISP, KS, KEEP)                                                                  \
-    {                                                                                                        \
-        const int hpm = hp0 + 2 * HALO_W * (MT) + (DISP);                                                    \
-        const unsigned pm = (KEEP) ? Hs + hpm * 128 + ((((KS) * 2 + hi) ^ HKEY(hpm)) << 4) : lds_base + ZERO_OFF; \
-        DSR(DST, pm)                                                                                         \
-    }
-#define MFMA_ONE(NT, MT, BSET, AF)                                                                           \
-    acc[NT][MT] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bq[BSET][NT]), AF, acc[NT][MT], 0, 0, 0);
-
     issue_halo(0);
     ISSUE_B(0, soff_cur, 0)
     ISSUE_B(1, soff_cur, 1)
@@ -371,69 +353,14 @@ __global__ __launch_bounds__(256, 2) void conv_up_halo_kernel(ConvArgs a, int ti
         STENCIL_STEP(D_OF(8), false, 0)
 #undef D_OF
         }
-        if (has_row) {  // taps 9-11: b = -1,0,+1 on the border row: pixel tile 0 (top, py = 0) or 3 (bottom, py = 1)
-#define ROW_BODY_B(KS, BSET, B_)                                                             \
-            {                                                                                \
-                bf16x8 f;                                                                    \
-                if (wpy == 0) {                                                              \
-                    RDA_MASKED(f, 0, (B_), KS, m_row)                                        \
-                    LGKM_WAIT(0)                                                             \
-                    MFMA_ONE(0, 0, BSET, f) MFMA_ONE(1, 0, BSET, f)                          \
-                } else {                                                                     \
-                    RDA_MASKED(f, 3, (B_), KS, m_row)                                        \
-                    LGKM_WAIT(0)                                                             \
-                    MFMA_ONE(0, 3, BSET, f) MFMA_ONE(1, 3, BSET, f)                          \
-                }                                                                            \
-            }                                                                                \
-            __builtin_amdgcn_sched_barrier(0);
-#define ROW_M1(KS, BSET) ROW_BODY_B(KS, BSET, -1)
-#define ROW_0(KS, BSET) ROW_BODY_B(KS, BSET, 0)
-#define ROW_P1(KS, BSET) ROW_BODY_B(KS, BSET, 1)
-            CORR_STEP(ROW_M1) CORR_STEP(ROW_0) CORR_STEP(ROW_P1)
-#undef ROW_M1
-#undef ROW_0
-#undef ROW_P1
-#undef ROW_BODY_B
-        }
-        if (has_col) {  // taps 12-14: a = -1,0,+1 on the border column (left for px = 0, right for px = 1)
-            TAPADDR_MASKED(-HALO_W, m_col)
-            RDA1(0, 0, 0) RDA1(0, 0, 1) RDA1(0, 0, 2) RDA1(0, 0, 3)
-            COL_STEP(true, 0)
-            COL_STEP(true, 1)
-            COL_STEP(false, 0)
-        }
-        if (has_row && has_col) {  // tap 15: the corner pixel, one phase per corner
-#define CORNER_BODY(KS, BSET)                                                                \
-            {                                                                                \
-                const bool keep = m_row && m_col;                                            \
-                bf16x8 f;                                                                    \
-                if (wpy == 0) {                                                              \
-                    RDA_MASKED(f, 0, 0, KS, keep)                                            \
-                    LGKM_WAIT(0)                                                             \
-                    MFMA_ONE(0, 0, BSET, f) MFMA_ONE(1, 0, BSET, f)                          \
-                } else {                                                                     \
-                    RDA_MASKED(f, 3, 0, KS, keep)                                            \
-                    LGKM_WAIT(0)                                                             \
-                    MFMA_ONE(0, 3, BSET, f) MFMA_ONE(1, 3, BSET, f)                          \
-                }                                                                            \
-            }                                                                                \
-            __builtin_amdgcn_sched_barrier(0);
-            CORR_STEP(CORNER_BODY)
-#undef CORNER_BODY
-        }
         if (H::NBUF == 1 && chunk + 1 < cpt) {  // single buffer: every wave is done reading -> request the next chunk's halo
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
             issue_halo(chunk + 1);
         }
     }
-#undef MFMA_ONE
-#undef RDA_MASKED
-#undef CORR_STEP
 #undef STENCIL_STEP
-#undef COL_STEP
 #undef STEP_CORE
-#undef TAPADDR_MASKED
 #undef SLOT
 #undef PIN
 #undef MF
@@ -646,6 +573,9 @@ hipError_t launch_conv_halo3(const ConvArgs& a, hipStream_t stream) {
     return hipGetLastError();
 }
 
+constexpr int UB_LDS = 4 * 2 * 8192;  // up_border_kernel: per wave two stages of [2 samples][32 pixels][64 channels] bf16
+__global__ void up_border_kernel(ConvArgs a, int tr, int tc);
+
 hipError_t conv_up_halo_init() {
     hipError_t e = hipFuncSetAttribute((const void*)conv_up_halo_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        HaloCfg<0>::LDS_TOTAL);
@@ -661,10 +591,193 @@ hipError_t conv_up_halo_init() {
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)conv_up_halo_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 HaloCfg<4>::LDS_TOTAL);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)up_border_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, UB_LDS);
     return e;
 }
 
+// Border corrections of the fused x2-upsample conv (see conv.hip / pack_up2x_weights: taps 9-11 on the first / last output
+// row, 12-14 on the first / last output column, 15 on the corners), evaluated for the ring of border OUTPUT pixels only and
+// left in ConvArgs::up_border (fp32) as the starting value of those pixels' accumulators.  A small GEMM (3 taps x cin per
+// pixel, 7 on the corners) whose time is memory latency, so it is organised around that:
+//   * both MFMA operands come straight from global memory: weight fragments from the halo kernel's own stream (its tap slots
+//     9-15: one coalesced 1 KB load per fragment), lane (pixel, hi) 16 B of its NHWC input pixel;
+//   * the ring is walked in 8 segments (top / bottom row x px, left / right column x py) so that the 32 pixels of a wave share
+//     their phase; a workgroup = one 32-pixel tile x 8 samples (4 waves x 2 samples: the waves stream the same weights at the
+//     same time and meet in L1); the loads of iteration i+1 (64 channels of one tap) are issued before the MFMAs of i;
+//   * the four corner pixels need 7 taps: they get workgroups of their own with the SAMPLES as MFMA columns (64 per
+//     workgroup), the taps dealt to the four waves and summed through LDS -- no workgroup runs a longer chain than the rest.
+struct UbStage {
+    uint4 wa[4], wb[4];
+};
+__global__ __launch_bounds__(256) void up_border_kernel(ConvArgs a, int tr, int tc) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    extern __shared__ __attribute__((aligned(16))) char ub_smem[];
+    const int lane = threadIdx.x & 63, l31 = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int cb_blk = blockIdx.z;
+    const int nseg = 4 * tr + 4 * tc;
+    const bool cornerwg = (int)blockIdx.x >= nseg;
+    if (cornerwg && (blockIdx.y & 7) != 0) return;  // a corner workgroup covers 64 samples
+    const int nbase = blockIdx.y * 8;
+    int py, px, i0 = 0, j0 = 0, tt = 0;
+    bool rowseg = true;
+    if (cornerwg) {
+        const int c = blockIdx.x - nseg;
+        py = c >> 1; px = c & 1;
+        i0 = py ? a.h - 1 : 0;
+        j0 = px ? a.w - 1 : 0;
+    } else {
+        int t = blockIdx.x, seg;
+        if (t < 4 * tr) { seg = t / tr; tt = t - seg * tr; }
+        else { t -= 4 * tr; seg = 4 + t / tc; tt = t - (seg - 4) * tc; }
+        rowseg = seg < 4;
+        if (rowseg) { py = seg >> 1; px = seg & 1; i0 = py ? a.h - 1 : 0; }           // output row 0 / ho-1, columns 2j + px
+        else { px = (seg - 4) >> 1; py = seg & 1; j0 = px ? a.w - 1 : 0; }            // output column 0 / wo-1, rows 2i + py
+    }
+    // tile pixel p (0..31) -> low-res pixel (i, j) and whether it is a real ring pixel of this segment
+    auto tile_pixel = [&](int p, int& ii, int& jj) -> bool {
+        if (cornerwg) { ii = i0; jj = j0; return true; }
+        if (rowseg) {
+            ii = i0; jj = tt * 32 + p;
+            const bool ok = jj < a.w;
+            jj = min(jj, a.w - 1);
+            return ok && !(px ? jj == a.w - 1 : jj == 0);  // corners belong to the corner workgroups
+        }
+        const int idx = tt * 32 + p;
+        jj = j0; ii = min(py ? idx : idx + 1, a.h - 1);
+        return idx < a.h - 1;
+    };
+    const int cin = a.c0 + a.c1, kchunks = cin >> 6;
+    // samples: MFMA columns are pixels and a wave owns 2 samples; corner workgroups: columns are 2 x 32 samples
+    if (!cornerwg && nbase + wave * 2 >= a.n) return;  // wave-uniform
+    auto sample_of = [&](int r, int p) { return min(cornerwg ? nbase + r * 32 + p : nbase + wave * 2 + r, a.n - 1); };
+    // slots of this wave: segments run 3 taps; corner workgroups deal their 7 taps to the waves (0,4 / 1,5 / 2,6 / 3)
+    const int u0 = cornerwg ? wave : 0, ustride = cornerwg ? 4 : 1, nslots = cornerwg ? (wave < 3 ? 2 : 1) : 3;
+    const int niter = nslots * kchunks;
+    typedef __attribute__((ext_vector_type(8))) __bf16 bx8;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[r][nt][q] = 0.0f;
+    const size_t npix = (size_t)a.n * a.h * a.w;
+    const auto rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)a.src0, 0, (int)(unsigned)(npix * a.c0 * 2), 0x00020000);
+    const auto rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.c1 ? a.src1 : a.src0), 0,
+                                                       (int)(unsigned)(npix * (a.c1 ? a.c1 : a.c0) * 2), 0x00020000);
+    char* xs = ub_smem + wave * 16384;
+    // The input pixels go through LDS: read directly as MFMA fragments every lane would touch its own cache line per load
+    // (L1 line throughput, not bytes, was the limit: 51 us per launch); the DMA fetches 8 full 128-B pixel rows per
+    // instruction, lane -> (pixel, 16-B piece), pieces swizzled by (pixel >> 1) & 7 for the conflict-free fragment reads.
+    const int dsub = lane >> 3, dslot = lane & 7;
+    auto load = [&](UbStage& st, int stage, int it) {
+        const int u = u0 + (it % nslots) * ustride, kc = it / nslots;  // taps innermost (their pixel rows overlap: L1 / L2 reuse)
+        int tap, dy = 0, dx = 0;
+        if ((cornerwg || rowseg) && u < 3) { tap = 9 + u; dx = u - 1; }
+        else if (cornerwg && u < 6) { tap = 12 + (u - 3); dy = u - 4; }
+        else if (cornerwg) { tap = 15; }
+        else { tap = 12 + u; dy = u - 1; }
+        const bool first = kc * 64 < a.c0;
+        const int cs = first ? a.c0 : a.c1;
+        const unsigned coff = (unsigned)((first ? kc * 64 : kc * 64 - a.c0) * 2);
+        char* dst = xs + stage * 8192;
+#pragma unroll
+        for (int d = 0; d < 8; ++d) {
+            const int r = d >> 2, p = (d & 3) * 8 + dsub;
+            int ii, jj;
+            (void)tile_pixel(p, ii, jj);
+            const int sy = min(max(ii + dy, 0), a.h - 1), sx = min(max(jj + dx, 0), a.w - 1);
+            const unsigned off = (unsigned)(((sample_of(r, p) * a.h + sy) * a.w + sx) * cs * 2) + coff +
+                                 (unsigned)((dslot ^ ((p >> 1) & 7)) << 4);
+            if (first) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, LDS_PTR(dst + d * 1024), 16, off, 0, 0, 0);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, LDS_PTR(dst + d * 1024), 16, off, 0, 0, 0);
+        }
+        const char* wf = (const char*)a.wpk_up_frag + ((size_t)(cb_blk * kchunks + kc) * 16 + tap) * STEP_BYTES + py * (STEP_BYTES / 2) +
+                         px * 2048 + lane * 16;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            st.wa[q] = *(const uint4*)(wf + q * 4096);
+            st.wb[q] = *(const uint4*)(wf + q * 4096 + 1024);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto compute = [&](const UbStage& st, int stage, bool more) {
+        // 16 vector-memory operations of the NEXT stage may still be in flight; everything older (this stage's DMA) has landed
+        if (more) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        const char* src = xs + stage * 8192 + l31 * 128;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int piece = ((q * 2 + hi) ^ ((l31 >> 1) & 7)) << 4;
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const uint4 xv = *(const uint4*)(src + r * 4096 + piece);
+                acc[r][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bx8, st.wa[q]), __builtin_bit_cast(bx8, xv), acc[r][0], 0, 0, 0);
+                acc[r][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bx8, st.wb[q]), __builtin_bit_cast(bx8, xv), acc[r][1], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    UbStage sa, sb;
+    load(sa, 0, 0);
+    for (int it = 0; it < niter; it += 2) {
+        if (it + 1 < niter) load(sb, 1, it + 1);
+        compute(sa, 0, it + 1 < niter);
+        if (it + 1 < niter) {
+            if (it + 2 < niter) load(sa, 0, it + 2);
+            compute(sb, 1, it + 2 < niter);
+        }
+    }
+    int ii, jj;
+    const bool valid = tile_pixel(l31, ii, jj);
+    const int Y = 2 * ii + py, X = 2 * jj + px;
+    const int ring = Y == 0 ? X : Y == a.ho - 1 ? a.wo + X : X == 0 ? 2 * a.wo + Y - 1 : 2 * a.wo + (a.ho - 2) + Y - 1;
+    const int ring_len = 2 * a.wo + 2 * (a.ho - 2);
+    if (cornerwg) {  // sum the four waves' taps (the staging buffers are dead once every wave is past its loop)
+        __syncthreads();
+        float* red = (float*)ub_smem;  // [3][2][2][16][64]
+        if (wave > 0) {
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) red[((((wave - 1) * 2 + r) * 2 + nt) * 16 + q) * 64 + lane] = acc[r][nt][q];
+        }
+        __syncthreads();
+        if (wave > 0) return;
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int q = 0; q < 16; ++q)
+#pragma unroll
+                    for (int w = 0; w < 3; ++w) acc[r][nt][q] += red[(((w * 2 + r) * 2 + nt) * 16 + q) * 64 + lane];
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int smp = cornerwg ? nbase + r * 32 + l31 : nbase + wave * 2 + r;
+        if (smp >= a.n || !valid) continue;
+        float* op = a.up_border + ((size_t)smp * ring_len + ring) * a.cout + cb_blk * 64 + 4 * hi;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *(float4*)(op + nt * 32 + 8 * g) =
+                    make_float4(acc[r][nt][4 * g], acc[r][nt][4 * g + 1], acc[r][nt][4 * g + 2], acc[r][nt][4 * g + 3]);
+    }
+#endif
+}
+
 hipError_t launch_conv_up_halo(const ConvArgs& a, hipStream_t stream) {
+    if (a.up_border == nullptr || a.wpk_up_frag == nullptr) return hipErrorInvalidValue;
+    {
+        const int tr = (a.w + 31) / 32, tc = (a.h - 1 + 31) / 32;
+        hipLaunchKernelGGL(up_border_kernel, dim3(4 * tr + 4 * tc + 4, (a.n + 7) / 8, a.cout / 64), dim3(256), UB_LDS, stream, a, tr, tc);
+    }
     const bool sparse = a.up_cols != nullptr;
     const int tiles_x = sparse ? a.up_ntiles : a.w / TILE_W, tiles_per_img = tiles_x * (a.h / TILE_H);
     const int tiles_m = a.n * tiles_per_img, tiles_n = a.cout / 64;

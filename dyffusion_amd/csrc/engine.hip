@@ -192,7 +192,7 @@ dyf_status net_forward(dyf_engine* e, int which, const Source* srcs, int nsrc, i
         // fused form: the conv gathers straight from the low-res cat[x, skip] (phase decomposition, conv.hip)
         ConvArgs f = a;
         f.src0 = x; f.c0 = b.cin - skip_c; f.src1 = skip; f.c1 = skip_c; f.h = lh; f.w = lw;
-        f.up2x = 1; f.wpk_up = b.wpk_up; f.wpk_up_frag = b.wpk_up_frag;
+        f.up2x = 1; f.wpk_up = b.wpk_up; f.wpk_up_frag = b.wpk_up_frag; f.up_border = ws.up_border;
         f.up_cols = b.up_cols; f.up_cbase = b.up_cbase; f.up_cidx = b.up_cidx; f.up_ntiles = b.up_ntiles; f.up_npad = b.up_npad;
         f.up_nvalid0 = b.up_nvalid0; f.up_nvalid1 = b.up_nvalid1; f.up_wo_store = b.up_wo_store;
         if (i == 11 && b.up_cols) {  // test hook: poison the output so that a needed-but-unwritten pixel of the sparse form shows
@@ -350,7 +350,7 @@ dyf_status dyf_engine_create(const dyf_engine_config* cfg, dyf_engine** out_engi
     // ---- workspace (sized for max_batch, shared by the two networks which run back to back)
     // sized for 2 x max_batch rows: the sampler runs the two interpolator calls of a step as ONE forward over 2 nb rows
     const size_t nb = (size_t)cfg->max_batch * 2;
-    size_t stem_el = 0, enc_el[6] = {}, dec_el[6] = {}, up_el = 0, raw_el = 0, tc = 0, td = 0;
+    size_t stem_el = 0, enc_el[6] = {}, dec_el[6] = {}, up_el = 0, raw_el = 0, tc = 0, td = 0, ub_el = 0;
     for (int w = 0; w < 2; ++w) {
         const Net& n = e->net[w];
         stem_el = std::max(stem_el, nb * n.uh * n.uw * n.dim);
@@ -360,6 +360,7 @@ dyf_status dyf_engine_create(const dyf_engine_config* cfg, dyf_engine** out_engi
             const UBlock& d = n.blk[6 + i];
             dec_el[i] = std::max(dec_el[i], nb * d.out_h * d.out_w * d.cout);
             up_el = std::max(up_el, nb * d.in_h * d.in_w * d.cin);
+            ub_el = std::max(ub_el, conv_up_border_floats((int)nb, d.out_h / 2, d.out_w / 2, d.cout));
         }
         raw_el = std::max(raw_el, nb * n.blk[5].out_h * n.blk[5].out_w * n.blk[5].cout);
         tc = std::max<size_t>(tc, n.total_c);
@@ -387,6 +388,7 @@ dyf_status dyf_engine_create(const dyf_engine_config* cfg, dyf_engine** out_engi
     ALLOC(ws.coef_a, nb * tc);
     ALLOC(ws.coef_c, nb * tc);
     ALLOC(ws.zero_page, 256);
+    ALLOC(ws.up_border, ub_el);
     ALLOC(ws.coef_pair, 4 * tc);
     ALLOC(e->s_pair, 2 * (size_t)cfg->max_batch * DYF_MAX_OUT_CH * cfg->height * cfg->width);
     ALLOC(e->s_time, 64);
@@ -969,7 +971,7 @@ dyf_status dyf_time_conv_layer(dyf_engine* e, int32_t which, int32_t layer, int3
         ConvArgs f = a;
         const UBlock& skipb = n.blk[11 - layer];
         f.src0 = e->ws.dec[layer - 7]; f.c0 = b.cin - skipb.cout; f.src1 = e->ws.enc[11 - layer]; f.c1 = skipb.cout;
-        f.h = b.in_h / 2; f.w = b.in_w / 2; f.up2x = 1; f.wpk_up = b.wpk_up; f.wpk_up_frag = b.wpk_up_frag;
+        f.h = b.in_h / 2; f.w = b.in_w / 2; f.up2x = 1; f.wpk_up = b.wpk_up; f.wpk_up_frag = b.wpk_up_frag; f.up_border = e->ws.up_border;
         f.up_cols = b.up_cols; f.up_cbase = b.up_cbase; f.up_cidx = b.up_cidx; f.up_ntiles = b.up_ntiles; f.up_npad = b.up_npad;
         f.up_nvalid0 = b.up_nvalid0; f.up_nvalid1 = b.up_nvalid1; f.up_wo_store = b.up_wo_store;
         if (use_fused_up(e, b, f)) a = f;
@@ -1179,6 +1181,9 @@ dyf_status dyf_op_upconv2d(dyf_engine* e, const uint16_t* x_dev, const float* w_
     a.kh = 3; a.kw = 3; a.stride = 1; a.pad = 1; a.cout = cout; a.wpk = wdev; a.wpk_up = wdev; a.up2x = 1;
     a.wpk_up_frag = frag ? wdev + pu.size() : nullptr;
     a.act = act; a.out_bf16 = y_dev;
+    float* border = nullptr;
+    HIP_TRY(e, hipMalloc((void**)&border, conv_up_border_floats(n, h, w, cout) * sizeof(float)));
+    a.up_border = border;
     if (scale_dev && shift_dev) {
         a.coef_a = scale_dev; a.coef_c = shift_dev; a.coef_stride = cout;
     } else {
@@ -1198,6 +1203,7 @@ dyf_status dyf_op_upconv2d(dyf_engine* e, const uint16_t* x_dev, const float* w_
         if (le != hipSuccess) rs = fail(e, DYF_ERR_HIP, std::string("upconv launch: ") + hipGetErrorString(le));
     }
     (void)hipFree(wdev);
+    (void)hipFree(border);
     if (ones) (void)hipFree(ones);
     if (zeros) (void)hipFree(zeros);
     return rs;

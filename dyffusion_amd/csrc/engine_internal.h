@@ -79,6 +79,7 @@ struct Workspace {
     float* coef_a = nullptr;
     float* coef_c = nullptr;
     bf16_t* zero_page = nullptr;
+    float* up_border = nullptr;  // border-correction scratch of the fused-upsample halo convs (ConvArgs::up_border)
     float* coef_pair = nullptr;  // [2][2][total_c]: FiLM coefficient rows of a paired interpolator call
 };
 
