@@ -3,20 +3,21 @@
 // plain 3x3 / stride 1 and 4x4 / stride 2 convolutions with 256-channel output blocks.
 //
 // Upsample forms: same mathematics as conv_igemm_kernel<.., UP=1> (phase decomposition + border-correction taps, see
-// conv.hip).  The data movement is designed around what bounded the previous forms, the CU's 128 B/clk of LDS bandwidth:
+// conv.hip), with the correction taps evaluated beforehand by up_border_kernel (below) for the border ring of the output:
+// border accumulators start from its result and every tile runs the same 9-tap stencil.  The data movement is designed around what bounded the previous forms, the CU's 128 B/clk of LDS bandwidth:
 //   * a workgroup (4 waves, 256 registers each, TWO workgroups per CU) owns an 8x16 LOW-res tile and all four output
 //     phases of 64 output channels: GEMM tile M = 128 pixels x N = 256 (4 phases x 64 channels).  A wave owns one phase:
 //     128 pixels x 64 channels = 4 x 2 accumulator tiles of v_mfma_f32_32x32x16_bf16 (128 registers); every pixel
 //     fragment read from LDS feeds 2 MFMAs, every weight fragment 4;
 //   * per 64-channel chunk the 10x18 replicate-padded input window ("halo", 23 KB) is DMA'd into LDS ONCE
-//     (buffer_load ... lds, double-buffered) and all 9 stencil taps (and the correction taps) read their pixel fragments
+//     (buffer_load ... lds, double-buffered) and all 9 stencil taps read their pixel fragments
 //     from it at shifted addresses.  This is the ONLY LDS traffic (64 B/clk/CU at MFMA peak);
 //   * the weights never touch LDS: they are pre-packed on the host in MFMA FRAGMENT ORDER (pack_up2x_frag), so that one
 //     wave-wide buffer_load_dwordx4 fetches 1 KB of contiguous memory = one 32-channel x 16-k fragment straight into
 //     registers (L2/L1-resident; 32 B/clk/CU of the vector-memory path).  Four fragment sets are in flight 3 k16
 //     sub-steps ahead of their use;
 //   * consequently there is NO per-step workgroup barrier: the waves meet only once per 64-channel chunk (halo swap,
-//     every 9-16 steps of 32 MFMAs) and drift apart in between; the second workgroup of the CU covers barrier, halo
+//     every 9 steps of 32 MFMAs) and drift apart in between; the second workgroup of the CU covers barrier, halo
 //     swap and epilogue of the first;
 //   * inside a k16 sub-step the 4 LDS reads (inline asm, hand-counted lgkmcnt; one v_xad_u32 of address arithmetic each,
 //     per-tap base/swizzle terms precomputed) and the 2 weight loads of later sub-steps are pinned BETWEEN the 8 MFMAs;
@@ -24,7 +25,8 @@
 //     epilogue (affine / activation / dropout / bf16 pack) runs straight out of the accumulators, pairs lanes l and
 //     l+32 with v_permlane32_swap and stores 16 B per lane: no LDS round trip, no barrier.
 // History (measured): gather form 800 TFLOP/s -> halo + weights through LDS 905 -> weights streamed, 128x128
-// wave tiles, 1 workgroup/CU 1105 -> this form 1200 (dense upsample) / 1310 (plain 3x3, no correction taps).
+// wave tiles, 1 workgroup/CU 1105 -> this form 1200 (dense upsample, corrections in-kernel) / 1310 (plain 3x3) -> corrections
+// moved to the ring kernel.
 #include "conv.h"
 
 #include <algorithm>
