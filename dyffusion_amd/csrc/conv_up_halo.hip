@@ -250,7 +250,7 @@ __global__ __launch_bounds__(256, 2) void conv_up_halo_kernel(ConvArgs a, int ti
     int hp0 = (px_r + 1 + (SP == 4 ? 8 * wpy : 0)) * HALO_W + (col - cbase);  // halo pixel of pixel tile 0 at the un-shifted tap; mt adds 2 rows
     const unsigned lds_base = (unsigned)(uintptr_t)LDS_PTR(smem);
 
-    u32x4 bq[4][2];   // weight fragments: set = k16 sub-step & 3
+    u32x4 bq[6][2];   // weight fragments: ring of 6 sets (9-tap modes: 5 sub-steps ahead), 4 sets in the 4-tap modes
     bf16x8 aq[2][4];  // pixel fragments: two sets
     unsigned ab[4], ax[4];  // LDS base / swizzle term of the tap whose pixel fragments are being fetched
 
@@ -309,14 +309,28 @@ __global__ __launch_bounds__(256, 2) void conv_up_halo_kernel(ConvArgs a, int ti
     }
 #define STENCIL_STEP(DISP, HAS_NEXT, DNEXT) STEP_CORE(HAS_NEXT, TAPADDR(DNEXT))
     issue_halo(0);
-    ISSUE_B(0, soff_cur, 0)
-    ISSUE_B(1, soff_cur, 1)
-    ISSUE_B(2, soff_cur, 2)
+    // 9-tap modes: the (chunk, tap) order is fixed, so the weight stream is addressed directly: sub-step g = 4*tap + ks of a
+    // chunk uses ring set g % 6 and requests the fragments of sub-step g + 5 (36 sub-steps per chunk = 6 turns of the ring);
+    // the L2 round trip of a fragment is longer than the 3 sub-steps the 4-set ring gave it
+    const unsigned soff_w = (unsigned)(wpy * (STEP_BYTES / 2) + wpx * 2048);
+    unsigned soff_c = (unsigned)((tn * cpt) * 16) * (unsigned)STEP_BYTES + soff_w, soff_n = soff_c;
+    if (H::S2) {
+        ISSUE_B(0, soff_cur, 0)
+        ISSUE_B(1, soff_cur, 1)
+        ISSUE_B(2, soff_cur, 2)
+    } else {
+        ISSUE_B(0, soff_c, 0)
+        ISSUE_B(1, soff_c, 1)
+        ISSUE_B(2, soff_c, 2)
+        ISSUE_B(3, soff_c, 3)
+        ISSUE_B(4, soff_c + STEP_BYTES, 0)
+    }
     for (int chunk = 0; chunk < cpt; ++chunk) {
         if (H::NBUF == 2) {
-            // halo of this chunk landed (everything older than the 6 weight loads in flight), every wave is done with the
+            // halo of this chunk landed (everything older than the 6 / 10 weight loads in flight), every wave is done with the
             // other buffer -> prefetch the next chunk's halo into it
-            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            if (H::S2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
             if (chunk + 1 < cpt) issue_halo(chunk + 1);
@@ -340,19 +354,48 @@ __global__ __launch_bounds__(256, 2) void conv_up_halo_kernel(ConvArgs a, int ti
             STENCIL_STEP(d10, true, d11)
             STENCIL_STEP(d11, false, 0)
         } else {
+        soff_n = chunk + 1 < cpt ? soff_c + 16u * (unsigned)STEP_BYTES : soff_c;  // tail: harmless re-fetch
         TAPADDR(-HALO_W - 1)
         RDA1(0, 0, 0) RDA1(0, 0, 1) RDA1(0, 0, 2) RDA1(0, 0, 3)
-        // ---- 9 stencil taps (a, b) in {-1,0,1}^2: displacement a*18 + b in the halo, every phase
+        // ---- 9 stencil taps (a, b) in {-1,0,1}^2: displacement a*18 + b in the halo; 36 sub-steps, weights 5 ahead
 #define D_OF(T) (((T) / 3 - 1) * HALO_W + ((T) % 3 - 1))
-        STENCIL_STEP(D_OF(0), true, D_OF(1))
-        STENCIL_STEP(D_OF(1), true, D_OF(2))
-        STENCIL_STEP(D_OF(2), true, D_OF(3))
-        STENCIL_STEP(D_OF(3), true, D_OF(4))
-        STENCIL_STEP(D_OF(4), true, D_OF(5))
-        STENCIL_STEP(D_OF(5), true, D_OF(6))
-        STENCIL_STEP(D_OF(6), true, D_OF(7))
-        STENCIL_STEP(D_OF(7), true, D_OF(8))
-        STENCIL_STEP(D_OF(8), false, 0)
+        SLOT(5, soff_c + 1 * STEP_BYTES, 1, true, NO_PRE, 1, 1, 0, 0)
+        SLOT(0, soff_c + 1 * STEP_BYTES, 2, true, NO_PRE, 0, 2, 1, 1)
+        SLOT(1, soff_c + 1 * STEP_BYTES, 3, true, NO_PRE, 1, 3, 0, 2)
+        SLOT(2, soff_c + 2 * STEP_BYTES, 0, true, TAPADDR(D_OF(1)), 0, 0, 1, 3)
+        SLOT(3, soff_c + 2 * STEP_BYTES, 1, true, NO_PRE, 1, 1, 0, 4)
+        SLOT(4, soff_c + 2 * STEP_BYTES, 2, true, NO_PRE, 0, 2, 1, 5)
+        SLOT(5, soff_c + 2 * STEP_BYTES, 3, true, NO_PRE, 1, 3, 0, 0)
+        SLOT(0, soff_c + 3 * STEP_BYTES, 0, true, TAPADDR(D_OF(2)), 0, 0, 1, 1)
+        SLOT(1, soff_c + 3 * STEP_BYTES, 1, true, NO_PRE, 1, 1, 0, 2)
+        SLOT(2, soff_c + 3 * STEP_BYTES, 2, true, NO_PRE, 0, 2, 1, 3)
+        SLOT(3, soff_c + 3 * STEP_BYTES, 3, true, NO_PRE, 1, 3, 0, 4)
+        SLOT(4, soff_c + 4 * STEP_BYTES, 0, true, TAPADDR(D_OF(3)), 0, 0, 1, 5)
+        SLOT(5, soff_c + 4 * STEP_BYTES, 1, true, NO_PRE, 1, 1, 0, 0)
+        SLOT(0, soff_c + 4 * STEP_BYTES, 2, true, NO_PRE, 0, 2, 1, 1)
+        SLOT(1, soff_c + 4 * STEP_BYTES, 3, true, NO_PRE, 1, 3, 0, 2)
+        SLOT(2, soff_c + 5 * STEP_BYTES, 0, true, TAPADDR(D_OF(4)), 0, 0, 1, 3)
+        SLOT(3, soff_c + 5 * STEP_BYTES, 1, true, NO_PRE, 1, 1, 0, 4)
+        SLOT(4, soff_c + 5 * STEP_BYTES, 2, true, NO_PRE, 0, 2, 1, 5)
+        SLOT(5, soff_c + 5 * STEP_BYTES, 3, true, NO_PRE, 1, 3, 0, 0)
+        SLOT(0, soff_c + 6 * STEP_BYTES, 0, true, TAPADDR(D_OF(5)), 0, 0, 1, 1)
+        SLOT(1, soff_c + 6 * STEP_BYTES, 1, true, NO_PRE, 1, 1, 0, 2)
+        SLOT(2, soff_c + 6 * STEP_BYTES, 2, true, NO_PRE, 0, 2, 1, 3)
+        SLOT(3, soff_c + 6 * STEP_BYTES, 3, true, NO_PRE, 1, 3, 0, 4)
+        SLOT(4, soff_c + 7 * STEP_BYTES, 0, true, TAPADDR(D_OF(6)), 0, 0, 1, 5)
+        SLOT(5, soff_c + 7 * STEP_BYTES, 1, true, NO_PRE, 1, 1, 0, 0)
+        SLOT(0, soff_c + 7 * STEP_BYTES, 2, true, NO_PRE, 0, 2, 1, 1)
+        SLOT(1, soff_c + 7 * STEP_BYTES, 3, true, NO_PRE, 1, 3, 0, 2)
+        SLOT(2, soff_c + 8 * STEP_BYTES, 0, true, TAPADDR(D_OF(7)), 0, 0, 1, 3)
+        SLOT(3, soff_c + 8 * STEP_BYTES, 1, true, NO_PRE, 1, 1, 0, 4)
+        SLOT(4, soff_c + 8 * STEP_BYTES, 2, true, NO_PRE, 0, 2, 1, 5)
+        SLOT(5, soff_c + 8 * STEP_BYTES, 3, true, NO_PRE, 1, 3, 0, 0)
+        SLOT(0, soff_n + 0 * STEP_BYTES, 0, true, TAPADDR(D_OF(8)), 0, 0, 1, 1)
+        SLOT(1, soff_n + 0 * STEP_BYTES, 1, true, NO_PRE, 1, 1, 0, 2)
+        SLOT(2, soff_n + 0 * STEP_BYTES, 2, true, NO_PRE, 0, 2, 1, 3)
+        SLOT(3, soff_n + 0 * STEP_BYTES, 3, true, NO_PRE, 1, 3, 0, 4)
+        SLOT(4, soff_n + 1 * STEP_BYTES, 0, false, NO_PRE, 0, 0, 1, 5)
+        soff_c = soff_n;
 #undef D_OF
         }
         if (H::NBUF == 1 && chunk + 1 < cpt) {  // single buffer: every wave is done reading -> request the next chunk's halo
