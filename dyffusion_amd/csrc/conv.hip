@@ -559,8 +559,9 @@ hipError_t conv_init() {
 hipError_t launch_conv(const ConvArgs& a, int path, hipStream_t stream) {
     if (path == 1 && conv_mfma_supported(a)) {
         static const bool use_halo = !(getenv("DYF_UP_HALO") && atoi(getenv("DYF_UP_HALO")) == 0);
-        // halo form wins once most tiles are interior (>= 4x4 tiles per image); below that the gather form's pipelined
-        // correction taps are cheaper (measured: dec3 32x32 plane 712 vs 697 TFLOP/s, dec4/dec5 862/905 vs 831/799)
+        // halo form from 32 x 32 low-res planes on; below that (dec2: 16 x 16, 2 tiles per image) the materialised upsample +
+        // plain 3x3 halo conv is still slightly ahead (7 715 vs 7 690 fields/s with DYF_HALO_MIN_PLANE=16: 640 workgroups of
+        // the fused form fill 1.25 rounds of the 512 resident ones)
         static const int halo_min = getenv("DYF_HALO_MIN_PLANE") ? atoi(getenv("DYF_HALO_MIN_PLANE")) : 32;
         if (a.up2x && a.up_cols)  // sparse-column form: only the halo kernel writes the compact output tensor
             return conv_up_halo_supported(a) ? launch_conv_up_halo(a, stream) : hipErrorInvalidValue;
