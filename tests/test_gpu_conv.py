@@ -154,7 +154,10 @@ def test_mfma_path_rejects_unsupported_channels(engine):
         engine.op_conv2d(x, torch.zeros(64, 32, 3, 3), 1, 1, path=1)
 
 
-UPCASES = [(2, 16, 16, 64, 128), (1, 32, 16, 128, 64), (3, 8, 16, 192, 128), (1, 16, 32, 64, 64), (2, 48, 32, 128, 256)]
+UPCASES = [(2, 16, 16, 64, 128), (1, 32, 16, 128, 64), (3, 8, 16, 192, 128), (1, 16, 32, 64, 64), (2, 48, 32, 128, 256),
+           # halo form + border-ring kernel: ragged ring tiles (47 and 48 pixels), 9 samples = one full group of 8 + 1,
+           # corner workgroups with fewer than 64 samples; two input chunks from two sources are covered by the network tests
+           (9, 32, 48, 64, 64), (1, 64, 32, 128, 128)]
 
 
 @pytest.mark.parametrize("case", UPCASES, ids=lambda c: "x".join(map(str, c)))
