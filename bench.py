@@ -1,14 +1,19 @@
 """Headline benchmark: sampled fields/sec of the DYffusion h-step rollout (BASELINE.json metric).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--nb NB]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--nb NB] [--ensemble-total M]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 One "step" = one `DYffusion.sample` call = one full h=16 rollout (16 forecaster + 44 interpolator forwards,
 cold sampling, refine pass, MC dropout ON in the interpolator) over NB ensemble rows resident in HBM, executed by
 libdyffusion_hip.so as a captured hipGraph.  Workload = BASELINE.json configs[1]: Navier-Stokes 221x42, C=3 (+2
-static channels), unet_simple dim 64 @256^2, bf16 MFMA / fp32 accumulate.  With N>1 every rank owns NB rows (weak
-scaling, rows are independent ensemble members) and the forecast stack is all-gathered over RCCL at the end of every
-step.  value = N * NB * h * K / max-over-ranks wall time.
+static channels), unet_simple dim 64 @256^2, bf16 MFMA / fp32 accumulate.
+
+N > 1 (one process per GPU, RCCL): rows are independent ensemble members, so the rollout itself has no exchange step;
+every rank keeps the SAME seed and samples its block of global rows (the dropout streams are keyed by the global row, so
+the fields do not depend on N), and at the end of EVERY step the forecast stack is all-gathered over RCCL
+(`dyffusion_amd.distributed`: one all_gather_into_tensor per field, straight into the (h, N*NB, C, H, W) result) -- inside
+the timed region.  Default = weak scaling: NB rows per rank.  `--ensemble-total M` = strong scaling: a FIXED M-row ensemble
+(e.g. the reference's 50 members) split 7,7,6,... over the ranks.  value = total rows * h * K / max-over-ranks wall time.
 """
 import argparse
 import json
@@ -53,13 +58,17 @@ def random_state(net, seed):
 
 
 def pmc_traffic(nb):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (profiles/r01_pmc_traffic.json:
-    FETCH_SIZE x2 + WRITE_SIZE, separate passes), scaled by rows; None when no PMC run is on record."""
+    """HBM bytes per launch of the dominant kernel.  PMC counters cannot be read from inside this process: the number is
+    REPLAYED from the committed rocprofv3 --pmc passes of this same command (profiles/*_pmc_traffic.json: FETCH_SIZE and
+    WRITE_SIZE in separate passes, corrected as MI355X_MICROARCH.md prescribes), scaled by rows; None when none is on record."""
+    import glob
+
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-            return round(json.load(f)["hbm_bytes_per_row"] * nb)
+        newest = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[-1]
+        with open(newest) as f:
+            return round(json.load(f)["hbm_bytes_per_row"] * nb), os.path.basename(newest)
     except Exception:
-        return None
+        return None, None
 
 
 _T0 = time.perf_counter()
@@ -81,19 +90,32 @@ def build_model(nb, use_graph=True):
     return m, F, I
 
 
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(F, I):
     """Reference CPU path timed on this host: the pure-PyTorch fp32 restatement (oracle/, parity-locked to the imported
-    reference through tests/golden) runs the SAME workload at NB=1, MC dropout on.  Bounded sample: one rollout."""
+    reference through tests/golden) runs the SAME workload, MC dropout on (RNG is a third of the reference's CPU time and is
+    not skipped), at NB = 1 and NB = 4.  Bounded sample (~30 s): full rollouts, repeated while time allows.
+    Threads: ATen's small-tensor ops and bernoulli_ stop scaling far below the core count of a 2-socket host, so one
+    interpolator forward is timed at 32 / 64 / all cores and the fastest setting is used -- and reported."""
     from oracle import nets, sampler
 
-    # small-tensor ATen ops stop scaling (and bernoulli_/mkldnn oversubscribe) far below 256 threads: cap, and report it
-    torch.set_num_threads(min(os.cpu_count() or 1, int(os.environ.get("DYF_CPU_THREADS", "32"))))
+    ncpu = os.cpu_count() or 1
     PF = {k: v.float() for k, v in F.state_dict().items()}
     PI = {k: v.float() for k, v in I.state_dict().items()}
     cfg = dict(DIFFUSION_KW, num_input_channels=C)
     drop = nets.DropoutFast()
     g = torch.Generator().manual_seed(1)
-    x0, c = torch.randn(1, C, H, W, generator=g), torch.rand(1, CS, H, W, generator=g)
+    x4, c4 = torch.randn(4, C, H, W, generator=g), torch.rand(4, CS, H, W, generator=g)
 
     def f_fn(x, t, cond):
         return nets.unet_simple_forward(PF, MODEL_KW, x, t, cond)
@@ -102,16 +124,34 @@ def cpu_baseline(F, I):
         return nets.unet_simple_forward(PI, MODEL_KW, x, t, cond, dropout=drop)
 
     with torch.no_grad():
-        tw = time.perf_counter()
-        f_fn(x0, torch.ones(1), c)  # warm-up (thread pool, mkldnn primitives)
-        log(f"cpu baseline warm-up forward {time.perf_counter() - tw:.2f} s on {torch.get_num_threads()} threads")
-        reps, t0 = 0, time.perf_counter()
-        while reps < 1 or (time.perf_counter() - t0 < 8.0 and reps < 3):
-            sampler.sample_loop(f_fn, i_fn, x0, c, cfg)
-            reps += 1
-        dt = time.perf_counter() - t0
-    return {"value": round(reps * HORIZON / dt, 4), "unit": "fields/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{reps} full h={HORIZON} rollout(s) at NB=1 (60 network forwards each), fp32, MC dropout on, {dt:.1f} s"}
+        best = None
+        forced = os.environ.get("DYF_CPU_THREADS")
+        for nt in ([int(forced)] if forced else sorted({min(32, ncpu), min(64, ncpu), ncpu})):
+            torch.set_num_threads(nt)
+            xi = torch.cat([x4[:1], x4[:1]], 1)
+            i_fn(xi, torch.ones(1), c4[:1])  # warm-up (thread pool, mkldnn primitives)
+            t0 = time.perf_counter()
+            i_fn(xi, torch.ones(1), c4[:1])
+            dt = time.perf_counter() - t0
+            log(f"cpu baseline: one interpolator forward on {nt} threads {dt:.3f} s")
+            if best is None or dt < best[1]:
+                best = (nt, dt)
+        torch.set_num_threads(best[0])
+        res = {}
+        for nb, budget, max_reps in ((1, 14.0, 3), (4, 10.0, 3)):
+            reps, t0 = 0, time.perf_counter()
+            while reps < 1 or (time.perf_counter() - t0 < budget and reps < max_reps):
+                sampler.sample_loop(f_fn, i_fn, x4[:nb], c4[:nb], cfg)
+                reps += 1
+            dt = time.perf_counter() - t0
+            res[nb] = (reps, dt, reps * nb * HORIZON / dt)
+            log(f"cpu baseline NB={nb}: {reps} rollout(s) in {dt:.1f} s = {res[nb][2]:.3f} fields/s")
+    top = max(res, key=lambda k: res[k][2])
+    return {"value": round(res[top][2], 4), "unit": "fields/s", "cores": best[0], "kind": "port",
+            "host_cores": ncpu, "cpu_model": cpu_model(),
+            "fields_per_s_nb1": round(res[1][2], 4), "fields_per_s_nb4": round(res[4][2], 4),
+            "sample": f"full h={HORIZON} rollouts (60 network forwards each), fp32, MC dropout on: NB=1 x{res[1][0]} in {res[1][1]:.1f} s, "
+                      f"NB=4 x{res[4][0]} in {res[4][1]:.1f} s; {best[0]} of {ncpu} host threads (fastest of 32/64/all on one forward)"}
 
 
 def main():
@@ -122,6 +162,8 @@ def main():
     ap.add_argument("--nb", type=int, default=int(os.environ.get("DYF_BENCH_NB", "80")),
                     help="rows per GPU; default 80 = the reference's NS evaluation batch: eval_batch_size 4 x num_predictions 20 "
                          "(experiment/navier_stokes.yaml:12-16)")
+    ap.add_argument("--ensemble-total", type=int, default=int(os.environ.get("DYF_BENCH_ENSEMBLE", "0")),
+                    help="strong scaling: a fixed ensemble of this many rows split over the ranks (0 = weak scaling, --nb rows per rank)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     args = ap.parse_args()
@@ -146,33 +188,33 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    nb = args.nb
-    log(f"building model, nb={nb}")
+    from dyffusion_amd.distributed import rows_per_rank, sample_sharded, shard_rows
+
+    strong = args.ensemble_total > 0
+    total_rows = args.ensemble_total if strong else world * args.nb
+    nb = rows_per_rank(total_rows, world)  # rows every rank launches (uneven shards repeat a row, distributed.py)
+    log(f"building model, {total_rows} rows over {world} rank(s), {nb} per rank")
     model, F, I = build_model(nb, use_graph=not args.no_graph)
     log("model built")
-    g = torch.Generator().manual_seed(100 + rank)
-    x0 = torch.randn(nb, C, H, W, generator=g).to(dev)
-    static = torch.rand(nb, CS, H, W, generator=g).to(dev)
-    from dyffusion_amd.distributed import all_gather_rows
-
-    gather = os.environ.get("DYF_BENCH_GATHER", "0") == "1"
+    # every rank holds the full (total_rows, ...) inputs (111 KB per row) and the same seed; sample_sharded makes it
+    # sample its own block of global rows and all-gathers the forecast stack
+    g = torch.Generator().manual_seed(100)
+    x0 = torch.randn(total_rows, C, H, W, generator=g).to(dev)
+    static = torch.rand(total_rows, CS, H, W, generator=g).to(dev)
+    gather = os.environ.get("DYF_BENCH_GATHER", "1") == "1"  # =0: time the rollouts without the exchange (A/B)
+    lo, hi = shard_rows(total_rows, world, rank)
 
     def step():
-        _, preds, _ = model.sample_loop(x0, static_condition=static)
-        if world > 1:
-            # Rows (ensemble members x batch) are independent: the rollout itself has NO exchange step, so the data path
-            # runs without a collective.  What the reference's DDP evaluation does exchange is per-rank metric scalars
-            # (torchmetrics sync, _base_experiment.py:560-650): one small all-reduce per predict call stands in for it.
-            # DYF_BENCH_GATHER=1 additionally all-gathers the full forecast stack onto every rank (sample_sharded).
-            partial = torch.stack([preds[f"t{i}_preds"].float().abs().mean() for i in range(1, HORIZON + 1)])
-            dist.all_reduce(partial, op=dist.ReduceOp.SUM)
-            if gather:
-                stack = torch.stack([preds[f"t{i}_preds"] for i in range(1, HORIZON + 1)], 0)  # (h, nb, C, H, W)
-                full = all_gather_rows(stack, world * nb, row_dim=1)
-                assert full.shape[1] == world * nb
+        if world > 1 and gather:
+            preds = sample_sharded(model, x0, static)
+            assert preds[f"t{HORIZON}_preds"].shape[0] == total_rows
+        else:
+            model.set_row_offset(lo)
+            preds = model.sample(x0[lo:hi], static_condition=static[lo:hi])
         return preds
 
-    model._ensure_engine((H, W), nb).seed(2 + rank)
+    model.seed(2)
+    model._ensure_engine((H, W), nb)
     log("engine created, weights uploaded")
     for _ in range(args.warmup):
         step()
@@ -198,19 +240,21 @@ def main():
         dt = float(t.item())
     assert all(torch.isfinite(v).all() for v in preds.values()), "non-finite forecast"
 
-    fields = world * nb * HORIZON * args.steps
+    fields = total_rows * HORIZON * args.steps
     eng = model._engine
     n_f, n_i = eng.forward_counts()
     flops_rollout_row = n_f * eng.net_flops(0) + n_i * eng.net_flops(1)
     result = {
         "metric": "sampled fields/sec (h-step rollout)", "value": round(fields / dt, 3), "unit": "fields/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "bf16",
+        "data": "synthetic",
         "config": {"workload": "BASELINE configs[1]: Navier-Stokes 221x42, C=3+2 static ch, unet_simple dim 64 @256^2, "
                                "DYffusion h=16 cold sampling + refine, interpolator MC dropout p=0.15, hipGraph rollout",
-                   "rows_per_gpu": nb, "net_forwards_per_rollout": n_f + n_i, "parallelism": f"ensemble-sharded dp{world}" + (" + all-gather of the forecast stack" if gather and world > 1 else ""),
+                   "rows_per_gpu": nb, "total_rows": total_rows, "net_forwards_per_rollout": n_f + n_i,
+                   "parallelism": f"ensemble-sharded dp{world}" + (" + RCCL all-gather of the forecast stack every step" if gather and world > 1 else ""),
                    "gflop_per_field": round(flops_rollout_row / HORIZON / 1e9, 2),
-                   "whole_rollout_tflops": round(world * nb * flops_rollout_row * args.steps / dt / 1e12, 2)},
+                   "whole_rollout_tflops": round(total_rows * flops_rollout_row * args.steps / dt / 1e12, 2)},
     }
     if rank == 0:
         # roofline of the dominant kernel: the last decoder block's 3x3 conv (256 -> 64 ch @256^2, 40 % of a forward),
@@ -230,8 +274,10 @@ def main():
                     "launches": launches, "avg_ms_isolated": round(ms_iso, 4), "flops_per_launch": fl,
                     "algorithmic_bytes_per_launch": by}
 
-        result["roofline"] = layer_roofline(10, "conv_up_halo_kernel<0> (dec4: fused x2-upsample + 3x3 conv, 512->128 ch, 64^2->128^2)")
-        result["roofline"]["traffic"] = pmc_traffic(nb)
+        result["roofline"] = layer_roofline(10, "conv_up_halo_kernel<0> (dec4: fused x2-upsample + 3x3 conv, 256->128 ch, 64^2->128^2)")
+        result["roofline"]["traffic"], result["roofline"]["traffic_source"] = pmc_traffic(nb)
+        if result["roofline"]["traffic_source"]:
+            result["roofline"]["traffic_source"] = "replayed from profiles/" + result["roofline"]["traffic_source"] + " (rocprofv3 --pmc passes of this command)"
         result["roofline_dec5_sparse"] = layer_roofline(
             11, "conv_up_halo_kernel<1> (dec5: fused x2-upsample + 3x3 conv, 256->64 ch, 128^2->256^2, 104 of 256 output columns)")
         if world == 1 and not args.no_cpu_baseline:

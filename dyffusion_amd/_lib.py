@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DYF_LIB") or os.path.join(_HERE, "lib", "libdyffusion_hip.so")  # DYF_LIB: experiment builds
 
-DYF_ABI_VERSION = 2
+DYF_ABI_VERSION = 3
 DYF_OK, DYF_ERR_INVALID_ARGUMENT, DYF_ERR_UNSUPPORTED, DYF_ERR_HIP, DYF_ERR_STATE = range(5)
 NET_FORECASTER, NET_INTERPOLATOR = 0, 1
 ARCH_UNET_SIMPLE, ARCH_UNET_RESNET = 0, 1
@@ -43,7 +43,7 @@ class Plan(C.Structure):
                 ("n_out_slots", C.c_int32), ("interpolator_dropout", C.c_int32), ("forecaster_dropout", C.c_int32)]
 
 
-# every symbol include/dyffusion_hip.h declares: (name, restype, argtypes)
+# every symbol include/dyffusion_hip.h and include/dyffusion_hip_testing.h declare: (name, restype, argtypes)
 _P = C.c_void_p
 SYMBOLS = [
     ("dyf_engine_create", C.c_int, [C.POINTER(EngineConfig), C.POINTER(_P)]),
@@ -56,7 +56,8 @@ SYMBOLS = [
     ("dyf_set_plan", C.c_int, [_P, C.POINTER(Plan)]),
     ("dyf_sample", C.c_int, [_P, _P, _P, _P, C.c_int32, C.POINTER(_P), _P, _P]),
     ("dyf_seed", C.c_int, [_P, C.c_uint64]),
-    ("dyf_get_last_x0hat", C.c_int, [_P, _P, C.c_int32, _P]),
+    ("dyf_set_row_offset", C.c_int, [_P, C.c_uint32]),
+    ("dyf_get_sampler_state", C.c_int, [_P, C.c_int32, _P, C.c_int32, _P]),
     ("dyf_plan_forward_counts", C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     ("dyf_net_flops", C.c_int, [_P, C.c_int32, C.POINTER(C.c_double)]),
     ("dyf_time_conv_layer", C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, C.POINTER(C.c_double),
@@ -67,6 +68,7 @@ SYMBOLS = [
     ("dyf_op_upconv2d", C.c_int, [_P, _P, _P] + [C.c_int32] * 5 + [_P, _P, C.c_int32, _P, _P]),
     ("dyf_op_linear_attention", C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, _P]),
     ("dyf_criterion", C.c_int, [_P, _P, _P, C.c_int64, C.c_int32, _P, _P]),
+    ("dyf_debug_read_block_output", C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
 ]
 
 

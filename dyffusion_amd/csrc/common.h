@@ -48,9 +48,13 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 }
 
 // ------------------------------------------------------------------------------------------------ counter RNG
-// Stateless keep-mask generator for MC dropout (SURVEY hard-part (c)): one murmur3-finalised 32-bit word per PAIR
-// of elements, 16 bits each, compared against a 16-bit threshold.  `key` identifies (seed, forward index, layer).
-// tests/test_gpu_dropout.py re-implements this in numpy so the RNG path is checked against the oracle bit-for-bit.
+// Stateless keep-mask generator for MC dropout (SURVEY hard-part (c)).  The keep bit of an element is a pure function of
+//   (seed, forward index, GLOBAL batch row, dropout layer, element index inside the row's NHWC tensor),
+// so a rollout does not depend on how its rows are batched: sampling rows [a, b) on one GPU, the paired 2 nb-row
+// interpolator launches and the one-process-per-GPU sharding of an ensemble all draw the same masks (SURVEY 8e
+// "independent sub-streams per row", results invariant to the number of GPUs).  One 32-bit word per PAIR of elements,
+// 16 bits each, compared against a 16-bit threshold.  tests/rng_host.py re-implements this in numpy so that RNG-mode
+// rollouts are checked against the oracle fed with exactly these masks.
 __device__ __host__ __forceinline__ uint32_t fmix32(uint32_t h) {
     h ^= h >> 16;
     h *= 0x85EBCA6Bu;
@@ -69,24 +73,41 @@ __device__ __host__ __forceinline__ uint32_t mul_u24(uint32_t a, uint32_t b) {
 #endif
 }
 
-// keep word of element pair `pair_index`: Weyl sequence (one add per consecutive pair after strength reduction) through
-// two xorshift-multiply rounds built on 24-bit multiplies (the conv epilogues spend most of their VALU time here; the
-// murmur3 finaliser it replaces costs two quarter-rate multiplies per pair).  Bucket chi-square, lag correlations and
-// key avalanche of the keep masks match fmix32's (checked for 2^22 pairs x several keys).
-__device__ __host__ __forceinline__ uint32_t rng_pair_word(uint32_t pair_index, uint32_t key) {
-    uint32_t x = pair_index * 0x9E3779B1u + key;
+// 64-bit stream key of one (forward, row, layer): k0 offsets the Weyl sequence, k1 enters between the two multiply rounds
+// (folded into a v_mad_u32_u24, i.e. free), so two streams are not windows of one 2^32-periodic sequence.
+struct RngKey {
+    uint32_t k0, k1;
+};
+
+// keep word of element pair `pair_index` of a row: Weyl sequence (one add per consecutive pair after strength reduction)
+// through two xorshift-multiply rounds built on 24-bit multiplies (the conv epilogues spend most of their VALU time here;
+// the murmur3 finaliser costs two quarter-rate multiplies per pair).
+__device__ __host__ __forceinline__ uint32_t rng_pair_word(uint32_t pair_index, RngKey key) {
+    uint32_t x = pair_index * 0x9E3779B1u + key.k0;
     x ^= x >> 15;
-    x = mul_u24(x, 0x735A2Du);
+    x = mul_u24(x, 0x735A2Du) + key.k1;
     x ^= x >> 13;
     x = mul_u24(x, 0x97E5B5u);
     x ^= x >> 16;
     return x;
 }
 
-// key for dropout layer `layer` of the `fwd`-th network forward since dyf_seed(seed)
-__device__ __host__ __forceinline__ uint32_t rng_layer_key(uint32_t seed_lo, uint32_t seed_hi, uint32_t fwd,
-                                                             uint32_t layer) {
-    return fmix32(seed_lo ^ fmix32(seed_hi + 0x9E3779B9u * (fwd * 64u + layer + 1u)));
+// per-(forward, global row) key pair; written to the engine's row-key table by rng_begin_forward_kernel (kernels.hip)
+// before every forward that draws masks
+__device__ __host__ __forceinline__ RngKey rng_row_key(uint32_t seed_lo, uint32_t seed_hi, uint32_t fwd, uint32_t grow) {
+    const uint32_t a = fmix32(seed_lo ^ fmix32(seed_hi + 0x9E3779B9u * (fwd + 1u)));
+    const uint32_t b = fmix32(a + 0x85EBCA77u * (grow + 1u));
+    return RngKey{b, fmix32(b ^ seed_hi ^ 0x27D4EB2Fu)};
+}
+
+// per-layer salt pair (host: make_drop), xor-ed / added into the row key
+__device__ __host__ __forceinline__ RngKey rng_layer_salt(uint32_t layer) {
+    const uint32_t s = fmix32(0x9E3779B9u * (layer + 1u));
+    return RngKey{s, fmix32(s + 0x165667B1u)};
+}
+
+__device__ __host__ __forceinline__ RngKey rng_stream_key(RngKey row, RngKey salt) {
+    return RngKey{row.k0 ^ salt.k0, row.k1 + salt.k1};
 }
 
 __device__ __host__ __forceinline__ uint32_t keep_threshold16(float p) {
@@ -94,8 +115,8 @@ __device__ __host__ __forceinline__ uint32_t keep_threshold16(float p) {
     return keep >= 65536.0f ? 65536u : (uint32_t)keep;
 }
 
-// element e of the NHWC tensor: keep iff its 16-bit slice of pair word e>>1 is below the threshold
-__device__ __host__ __forceinline__ bool rng_keep(uint32_t e, uint32_t key, uint32_t thresh16) {
+// element e of the row's NHWC tensor: keep iff its 16-bit slice of pair word e>>1 is below the threshold
+__device__ __host__ __forceinline__ bool rng_keep(uint32_t e, RngKey key, uint32_t thresh16) {
     uint32_t w = rng_pair_word(e >> 1, key);
     uint32_t v = (e & 1u) ? (w >> 16) : (w & 0xffffu);
     return v < thresh16;
@@ -106,18 +127,23 @@ struct DropSpec {
     int mode;                 // 0 off, 1 engine RNG, 2 injected mask
     float scale;              // 1/(1-p)
     uint32_t thresh16;        // keep threshold (mode 1)
-    uint32_t layer;           // layer slot (mode 1)
-    const uint32_t* state;    // device: {seed_lo, seed_hi, forward_counter} (mode 1)
-    const uint8_t* mask;      // device NHWC uint8 keep mask (mode 2)
+    RngKey salt;              // rng_layer_salt(layer slot) (mode 1)
+    const uint32_t* row_keys; // device [launch rows][2]: rng_row_key of every row of this launch (mode 1)
+    const uint8_t* mask;      // device NHWC uint8 keep mask of the whole launch (mode 2)
 };
 
-__device__ __forceinline__ uint32_t drop_key(const DropSpec& d) {
-    return d.mode == 1 ? rng_layer_key(d.state[0], d.state[1], d.state[2], d.layer) : 0u;
+// stream key of launch row `n` (batch row inside this launch)
+__device__ __forceinline__ RngKey drop_row_key(const DropSpec& d, int n) {
+    if (d.mode != 1) return RngKey{0u, 0u};
+    const uint2 rk = *(const uint2*)(d.row_keys + 2 * (size_t)n);
+    return rng_stream_key(RngKey{rk.x, rk.y}, d.salt);
 }
 
-__device__ __forceinline__ float drop_apply(float v, uint32_t e, const DropSpec& d, uint32_t key) {
+// e: element index in the whole launch tensor (mask injection); row0: index of the row's first element (engine RNG keys on
+// e - row0)
+__device__ __forceinline__ float drop_apply(float v, uint32_t e, uint32_t row0, const DropSpec& d, RngKey key) {
     if (d.mode == 0) return v;
-    bool keep = d.mode == 1 ? rng_keep(e, key, d.thresh16) : (d.mask[e] != 0);
+    bool keep = d.mode == 1 ? rng_keep(e - row0, key, d.thresh16) : (d.mask[e] != 0);
     return keep ? v * d.scale : 0.0f;
 }
 
@@ -142,7 +168,7 @@ __device__ __forceinline__ float drop_prescale(const DropSpec& d) {
 }
 
 template <int N, int ACT, int MODE, bool PRESCALED = false>
-__device__ __forceinline__ void act_drop_fixed(float* v, uint32_t e0, const DropSpec& d, uint32_t key) {
+__device__ __forceinline__ void act_drop_fixed(float* v, uint32_t e0, uint32_t row0, const DropSpec& d, RngKey key) {
 #pragma unroll
     for (int t = 0; t < N; ++t) v[t] = act_fixed<ACT>(v[t]);
     constexpr bool folded = PRESCALED && (ACT == ACT_NONE || ACT == ACT_RELU || ACT == ACT_LEAKY);
@@ -151,7 +177,7 @@ __device__ __forceinline__ void act_drop_fixed(float* v, uint32_t e0, const Drop
         const float sc = folded ? 1.0f : d.scale;
 #pragma unroll
         for (int p = 0; p < N / 2; ++p) {
-            const uint32_t w = rng_pair_word((e0 >> 1) + p, key);
+            const uint32_t w = rng_pair_word(((e0 - row0) >> 1) + p, key);
             if constexpr (folded) {
                 v[2 * p] = (w & 0xffffu) < th ? v[2 * p] : 0.0f;
                 v[2 * p + 1] = (w >> 16) < th ? v[2 * p + 1] : 0.0f;
@@ -167,18 +193,18 @@ __device__ __forceinline__ void act_drop_fixed(float* v, uint32_t e0, const Drop
 }
 
 template <int N, int ACT>
-__device__ __forceinline__ void act_drop_mode(float* v, uint32_t e0, const DropSpec& d, uint32_t key) {
-    if (d.mode == 0) act_drop_fixed<N, ACT, 0>(v, e0, d, key);
-    else if (d.mode == 1) act_drop_fixed<N, ACT, 1>(v, e0, d, key);
-    else act_drop_fixed<N, ACT, 2>(v, e0, d, key);
+__device__ __forceinline__ void act_drop_mode(float* v, uint32_t e0, uint32_t row0, const DropSpec& d, RngKey key) {
+    if (d.mode == 0) act_drop_fixed<N, ACT, 0>(v, e0, row0, d, key);
+    else if (d.mode == 1) act_drop_fixed<N, ACT, 1>(v, e0, row0, d, key);
+    else act_drop_fixed<N, ACT, 2>(v, e0, row0, d, key);
 }
 
 template <int N>
-__device__ __forceinline__ void act_drop(float* v, uint32_t e0, int act, const DropSpec& d, uint32_t key) {
-    if (act == ACT_RELU) act_drop_mode<N, ACT_RELU>(v, e0, d, key);
-    else if (act == ACT_LEAKY) act_drop_mode<N, ACT_LEAKY>(v, e0, d, key);
-    else if (act == ACT_SILU) act_drop_mode<N, ACT_SILU>(v, e0, d, key);
-    else act_drop_mode<N, ACT_NONE>(v, e0, d, key);
+__device__ __forceinline__ void act_drop(float* v, uint32_t e0, uint32_t row0, int act, const DropSpec& d, RngKey key) {
+    if (act == ACT_RELU) act_drop_mode<N, ACT_RELU>(v, e0, row0, d, key);
+    else if (act == ACT_LEAKY) act_drop_mode<N, ACT_LEAKY>(v, e0, row0, d, key);
+    else if (act == ACT_SILU) act_drop_mode<N, ACT_SILU>(v, e0, row0, d, key);
+    else act_drop_mode<N, ACT_NONE>(v, e0, row0, d, key);
 }
 
 // ------------------------------------------------------------------------------------------------ bilinear

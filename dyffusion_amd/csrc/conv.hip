@@ -77,7 +77,7 @@ __global__ void conv_direct_kernel(ConvArgs a, long long total) {
     float v = fmaf(acc, a.coef_a[ci], a.coef_c[ci]);
     v = apply_act(v, a.act);
     const uint32_t e = (uint32_t)(m * a.cout + co);
-    v = drop_apply(v, e, a.drop, drop_key(a.drop));
+    v = drop_apply(v, e, (uint32_t)n * (uint32_t)(a.ho * a.wo * a.cout), a.drop, drop_row_key(a.drop, n));
     if (a.residual) v += bf16_to_f32(a.residual[(size_t)m * a.cout + co]);
     if (a.out_bf16) a.out_bf16[(size_t)m * a.cout + co] = f32_to_bf16(v);
     if (a.out_f32) a.out_f32[(size_t)m * a.cout + co] = v;
@@ -437,7 +437,6 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a, int M, i
     // affine / activation / dropout / residual run in registers, register groups 2*g2 and 2*g2+1 are packed to bf16 and
     // exchanged between lanes l and l+32 (v_permlane32_swap) so that every lane stores 8 consecutive channels (16 B).
     // No LDS round trip, no barrier; (activation, dropout mode) are wave-uniform and dispatched once.
-    const uint32_t key = drop_key(a.drop);
     auto epilogue = [&](auto act_c, auto mode_c) {
         constexpr int ACT = decltype(act_c)::value, MODE = decltype(mode_c)::value;
 #pragma unroll
@@ -454,6 +453,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a, int M, i
                 n_img = m / plane;
             }
             const uint32_t ob = (uint32_t)m * (uint32_t)a.cout + (uint32_t)(tn * BN + wn * 64);
+            const RngKey key = drop_row_key(a.drop, n_img);  // dropout streams are per batch row
+            const uint32_t row0 = (uint32_t)n_img * (uint32_t)(a.ho * a.wo * a.cout);
             const uint32_t cb = (uint32_t)((a.coef_div > 1 ? n_img / a.coef_div : n_img) * a.coef_stride + tn * BN + wn * 64 + 4 * hi);
 #pragma unroll
             for (int j = 0; j < 2; ++j)
@@ -469,8 +470,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a, int M, i
                     float v[8];
 #pragma unroll
                     for (int t = 0; t < 8; ++t) v[t] = fmaf(acc[i][j][8 * g2 + t], ca[t], cc[t]);
-                    act_drop_fixed<4, ACT, MODE, true>(v, e0, a.drop, key);
-                    act_drop_fixed<4, ACT, MODE, true>(v + 4, e0 + 8, a.drop, key);
+                    act_drop_fixed<4, ACT, MODE, true>(v, e0, row0, a.drop, key);
+                    act_drop_fixed<4, ACT, MODE, true>(v + 4, e0 + 8, row0, a.drop, key);
                     if (a.residual) {
                         const uint2 r0 = valid ? *(const uint2*)(a.residual + (size_t)e0) : make_uint2(0, 0);
                         const uint2 r1 = valid ? *(const uint2*)(a.residual + (size_t)e0 + 8) : make_uint2(0, 0);

@@ -227,7 +227,6 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(ConvArgs a, int M, 
 
     // ---- epilogue straight from the accumulators (same scheme as conv_igemm_kernel): lane (l31, hi) of accumulator
     // (mt, nt) holds pixel l31 of sub-tile mt and channels nt*32 + 8*g + 4*hi + {0..3}
-    const uint32_t key = drop_key(a.drop);
     auto epilogue = [&](auto act_c, auto mode_c) {
         constexpr int ACT = decltype(act_c)::value, MODE = decltype(mode_c)::value;
 #pragma unroll
@@ -243,6 +242,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(ConvArgs a, int M, 
                 n_img = m / plane;
             }
             const uint32_t ob = (uint32_t)m * (uint32_t)a.cout + (uint32_t)(tn * BN + wn * 64);
+            const RngKey key = drop_row_key(a.drop, n_img);  // dropout streams are per batch row
+            const uint32_t row0 = (uint32_t)n_img * (uint32_t)(a.ho * a.wo * a.cout);
             const uint32_t cb = (uint32_t)((a.coef_div > 1 ? n_img / a.coef_div : n_img) * a.coef_stride + tn * BN + wn * 64 + 4 * hi);
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
@@ -258,8 +259,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(ConvArgs a, int M, 
                     float v[8];
 #pragma unroll
                     for (int t = 0; t < 8; ++t) v[t] = fmaf(acc[mt][nt][8 * g2 + t], ca[t], cc[t]);
-                    act_drop_fixed<4, ACT, MODE, true>(v, e0, a.drop, key);
-                    act_drop_fixed<4, ACT, MODE, true>(v + 4, e0 + 8, a.drop, key);
+                    act_drop_fixed<4, ACT, MODE, true>(v, e0, row0, a.drop, key);
+                    act_drop_fixed<4, ACT, MODE, true>(v + 4, e0 + 8, row0, a.drop, key);
                     if (a.residual) {
                         const uint2 r0 = valid ? *(const uint2*)(a.residual + (size_t)e0) : make_uint2(0, 0);
                         const uint2 r1 = valid ? *(const uint2*)(a.residual + (size_t)e0 + 8) : make_uint2(0, 0);

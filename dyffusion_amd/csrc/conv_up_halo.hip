@@ -419,7 +419,8 @@ __global__ __launch_bounds__(256, 2) void conv_up_halo_kernel(ConvArgs a, int ti
     // ---- epilogue straight from the accumulators.  Lane (l31, hi) of tile (nt, mt) holds pixel l31 of pixel tile mt and
     // channels half*32 + 8*g + 4*hi + {0..3} (g = register group r >> 2).  Groups 2*g2 and 2*g2+1 are packed to bf16 and
     // exchanged between lanes l and l+32 (v_permlane32_swap), after which every lane owns 8 consecutive channels = 16 B.
-    const uint32_t key = drop_key(a.drop);
+    const RngKey key = drop_row_key(a.drop, n_img);
+    const uint32_t row0 = (uint32_t)n_img * (uint32_t)(a.ho * a.wo * a.cout);  // dropout streams are per batch row
     // channel block of this wave: the 64 channels of column block tn (upsample forms: one phase per wave), or (plain form)
     // the wave's own 64 of the 256 channels of block tn
     const int ch_blk = H::PLAIN ? tn * H::BLK + (SP == 4 ? wpx : wave) * 64 : tn * 64;
@@ -453,8 +454,8 @@ __global__ __launch_bounds__(256, 2) void conv_up_halo_kernel(ConvArgs a, int ti
                     float v[8];
 #pragma unroll
                     for (int t = 0; t < 8; ++t) v[t] = fmaf(acc[hg >> 1][mt][8 * (hg & 1) + t], ca[t], cc[t]);
-                    act_drop_fixed<4, ACT, MODE, true>(v, e0, a.drop, key);
-                    act_drop_fixed<4, ACT, MODE, true>(v + 4, e0 + 8, a.drop, key);
+                    act_drop_fixed<4, ACT, MODE, true>(v, e0, row0, a.drop, key);
+                    act_drop_fixed<4, ACT, MODE, true>(v + 4, e0 + 8, row0, a.drop, key);
                     uint32_t p0 = pack_bf16x2(v[0], v[1]), p1 = pack_bf16x2(v[2], v[3]);
                     uint32_t q0 = pack_bf16x2(v[4], v[5]), q1 = pack_bf16x2(v[6], v[7]);
                     const auto s0 = __builtin_amdgcn_permlane32_swap(p0, q0, false, false);

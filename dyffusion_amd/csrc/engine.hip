@@ -5,6 +5,7 @@
 // :140-163 + :480-494 (q_sample / _interpolate), :205-239 (predict_x_last) and src/models/unet_simple.py:164-197.
 #include "engine_internal.h"
 #include "unet_kernels.h"
+#include "../../include/dyffusion_hip_testing.h"
 
 using namespace dyf;
 
@@ -79,8 +80,8 @@ DropSpec make_drop(const dyf_engine* e, const Net& n, const FwdOpts& o, int laye
     d.mode = (p > 0.0f) ? o.dropout_mode : 0;
     d.scale = 1.0f / (1.0f - p);
     d.thresh16 = keep_threshold16(p);
-    d.layer = (uint32_t)layer;
-    d.state = e->rng_state;
+    d.salt = rng_layer_salt((uint32_t)layer);
+    d.row_keys = e->row_keys;
     d.mask = (d.mode == 2 && o.masks) ? o.masks[layer] : nullptr;
     if (d.mode == 2 && d.mask == nullptr) d.mode = 0;
     return d;
@@ -125,6 +126,8 @@ dyf_status net_forward(dyf_engine* e, int which, const Source* srcs, int nsrc, i
     if (n.sc) return sc_forward(e, which, srcs, nsrc, nb, o, out_dev, st);
     Workspace& ws = e->ws;
     const int H = e->cfg.height, W = e->cfg.width;
+    if (o.dropout_mode == 1 && n.cfg.dropout > 0.0f)
+        HIP_TRY(e, launch_rng_begin_forward(e->rng_state, e->row_keys, nb, o.src_rows > 0 ? o.src_rows : nb, st));
     // ---- stem: outer resample + 1x1 conv
     StemArgs sa{};
     int ctot = 0;
@@ -195,11 +198,8 @@ dyf_status net_forward(dyf_engine* e, int which, const Source* srcs, int nsrc, i
         f.up2x = 1; f.wpk_up = b.wpk_up; f.wpk_up_frag = b.wpk_up_frag; f.up_border = ws.up_border;
         f.up_cols = b.up_cols; f.up_cbase = b.up_cbase; f.up_cidx = b.up_cidx; f.up_ntiles = b.up_ntiles; f.up_npad = b.up_npad;
         f.up_nvalid0 = b.up_nvalid0; f.up_nvalid1 = b.up_nvalid1; f.up_wo_store = b.up_wo_store;
-        if (i == 11 && b.up_cols) {  // test hook: poison the output so that a needed-but-unwritten pixel of the sparse form shows
-            const char* pz = getenv("DYF_POISON_DEC5");
-            if (pz && atoi(pz) != 0)
-                HIP_TRY(e, hipMemsetAsync(ws.dec[5], 0xFF, (size_t)nb * b.out_h * b.out_w * b.cout * sizeof(bf16_t), st));  // whole buffer
-        }
+        if (i == 11 && b.up_cols && e->poison_dec5)  // test hook: a needed-but-unwritten pixel of the sparse form shows as NaN
+            HIP_TRY(e, hipMemsetAsync(ws.dec[5], 0xFF, (size_t)nb * b.out_h * b.out_w * b.cout * sizeof(bf16_t), st));  // whole buffer
         // sparse-column form (last block only): its output tensor is compact, the readout below must know
         if (f.up_cols && !(use_fused_up(e, b, f) && conv_up_halo_supported(f))) f.up_cols = nullptr;
         if (f.up_cols) sparse_out = &b;
@@ -238,10 +238,10 @@ dyf_status net_forward(dyf_engine* e, int which, const Source* srcs, int nsrc, i
     ReadoutArgs r{};
     r.x = x; r.n = nb; r.ih = lh; r.iw = lw; r.cin = n.dim; r.wgt = n.ro_w; r.wfrag = n.ro_wfrag; r.bias = n.ro_b; r.cout = n.cfg.out_channels;
     r.oh = H; r.ow = W; r.out = out_dev;
+    e->last_dec5_sparse = sparse_out != nullptr;
     r.iw_store = sparse_out ? sparse_out->up_wo_store : lw;
     r.col_map = sparse_out ? sparse_out->up_col_map : nullptr;
     HIP_TRY(e, launch_readout(r, st));
-    if (o.dropout_mode == 1 && n.cfg.dropout > 0.0f) HIP_TRY(e, launch_bump_counter(e->rng_state, st));
     return DYF_OK;
 }
 
@@ -284,10 +284,10 @@ void dyf_engine_destroy(dyf_engine* e) {
     sc_destroy(e->net[0]);
     sc_destroy(e->net[1]);
     if (e->cap_stream) (void)hipStreamDestroy(e->cap_stream);
-    for (void* p : e->allocs) {
-        conv_unregister_frag(p);
-        (void)hipFree(p);
-    }
+    release_allocs(e->allocs);
+    release_allocs(e->net_allocs[0]);
+    release_allocs(e->net_allocs[1]);
+    release_allocs(e->plan_allocs);
     delete e;
 }
 
@@ -308,6 +308,7 @@ dyf_status dyf_engine_create(const dyf_engine_config* cfg, dyf_engine** out_engi
     if (const char* fm = getenv("DYF_FUSE_MIN_PLANE")) e->fuse_min_plane = atoi(fm);
     if (const char* fs = getenv("DYF_FUSE_STEM")) e->fuse_stem = atoi(fs) != 0;
     if (const char* pi = getenv("DYF_PAIR_INTERP")) e->pair_interp = atoi(pi) != 0;
+    if (const char* pz = getenv("DYF_POISON_DEC5")) e->poison_dec5 = atoi(pz) != 0;
     if (conv_init() != hipSuccess || hipStreamCreateWithFlags(&e->cap_stream, hipStreamNonBlocking) != hipSuccess) {
         delete e;
         return fail(nullptr, DYF_ERR_HIP, "engine initialisation failed (conv_init / stream create)");
@@ -392,7 +393,8 @@ dyf_status dyf_engine_create(const dyf_engine_config* cfg, dyf_engine** out_engi
     ALLOC(ws.coef_pair, 4 * tc);
     ALLOC(e->s_pair, 2 * (size_t)cfg->max_batch * DYF_MAX_OUT_CH * cfg->height * cfg->width);
     ALLOC(e->s_time, 64);
-    ALLOC(e->rng_state, 4);
+    ALLOC(e->rng_state, DYF_RNG_STATE_WORDS);
+    ALLOC(e->row_keys, 4 * nb);  // [2 x max_batch rows][2]
 #undef ALLOC
     {
         dyf_status rs = rn_alloc_workspace(e);
@@ -407,8 +409,18 @@ dyf_status dyf_engine_create(const dyf_engine_config* cfg, dyf_engine** out_engi
 dyf_status dyf_seed(dyf_engine* e, uint64_t seed) {
     if (!e) return DYF_ERR_INVALID_ARGUMENT;
     HIP_TRY(e, hipSetDevice(e->cfg.device));
-    const uint32_t st[4] = {(uint32_t)(seed & 0xffffffffu), (uint32_t)(seed >> 32), 0u, 0u};
+    // seed words and both counters; the row offset (word 3) belongs to dyf_set_row_offset
+    const uint32_t st[3] = {(uint32_t)(seed & 0xffffffffu), (uint32_t)(seed >> 32), 0u};
+    const uint32_t zero = 0u;
     HIP_TRY(e, hipMemcpy(e->rng_state, st, sizeof(st), hipMemcpyHostToDevice));
+    HIP_TRY(e, hipMemcpy(e->rng_state + 4, &zero, sizeof(zero), hipMemcpyHostToDevice));
+    return DYF_OK;
+}
+
+dyf_status dyf_set_row_offset(dyf_engine* e, uint32_t first_row) {
+    if (!e) return DYF_ERR_INVALID_ARGUMENT;
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    HIP_TRY(e, hipMemcpy(e->rng_state + 3, &first_row, sizeof(first_row), hipMemcpyHostToDevice));
     return DYF_OK;
 }
 
@@ -418,6 +430,14 @@ dyf_status dyf_load_weights(dyf_engine* e, int32_t which, int32_t n_tensors, con
     if (which < 0 || which > 1) return fail(e, DYF_ERR_INVALID_ARGUMENT, "net must be 0 (forecaster) or 1 (interpolator)");
     HIP_TRY(e, hipSetDevice(e->cfg.device));
     Net& n = e->net[which];
+    // a reload replaces the previous packed weights (and invalidates the plan's coefficient tables and captured graphs)
+    e->plan.set = false;
+    n.loaded = false;
+    if (!e->net_allocs[which].empty()) {
+        HIP_TRY(e, hipDeviceSynchronize());
+        release_allocs(e->net_allocs[which]);
+    }
+    AllocScope scope(e, &e->net_allocs[which]);
     std::map<std::string, TensorView> sd;
     for (int i = 0; i < n_tensors; ++i) {
         TensorView v;
@@ -688,12 +708,27 @@ dyf_status dyf_set_plan(dyf_engine* e, const dyf_plan* p) {
     }
     // forecast stack
     if (p->n_out_slots > e->stack_slots) {
+        if (e->s_stack) {
+            HIP_TRY(e, hipDeviceSynchronize());
+            e->allocs.erase(std::remove(e->allocs.begin(), e->allocs.end(), (void*)e->s_stack), e->allocs.end());
+            (void)hipFree(e->s_stack);
+            e->s_stack = nullptr;
+        }
         dyf_status s = dev_alloc(e, &e->s_stack, (size_t)p->n_out_slots * e->cfg.max_batch * e->C * e->cfg.height * e->cfg.width);
         if (s != DYF_OK) return s;
         e->stack_slots = p->n_out_slots;
     }
     // coefficient tables: the time value is the same for the whole batch inside the loop (dyffusion.py:360,372), so
     // every (network, time) pair of the plan is evaluated once here instead of once per forward
+    ph.set = false;
+    HIP_TRY(e, hipDeviceSynchronize());  // graphs of the previous plan may still be running on their tables
+    for (auto& kv : e->graphs) {
+        if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
+        if (kv.second.graph) (void)hipGraphDestroy(kv.second.graph);
+    }
+    e->graphs.clear();
+    release_allocs(e->plan_allocs);
+    AllocScope scope(e, &e->plan_allocs);
     for (int w = 0; w < 2; ++w) {
         Net& n = e->net[w];
         n.table_of_time.clear();
@@ -727,11 +762,6 @@ dyf_status dyf_set_plan(dyf_engine* e, const dyf_plan* p) {
         }
     }
     HIP_TRY(e, hipDeviceSynchronize());
-    for (auto& kv : e->graphs) {
-        if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
-        if (kv.second.graph) (void)hipGraphDestroy(kv.second.graph);
-    }
-    e->graphs.clear();
     ph.set = true;
     return DYF_OK;
 }
@@ -828,8 +858,8 @@ dyf_status run_plan(dyf_engine* e, int nb, const uint8_t* const* masks, const fl
             fs[nf++] = {e->s_init, e->wC};
         } else if (ph.hdr.forward_conditioning == DYF_FCOND_DATA_NOISE) {
             const float* nz = noise_dev ? noise_dev + (size_t)step_idx * init_el : nullptr;
-            HIP_TRY(e, launch_noisy_condition(e->s_noisy, e->s_init, nz, s.tau, (long long)init_el, e->rng_state,
-                                              (uint32_t)(step_idx & 15), st));
+            HIP_TRY(e, launch_noisy_condition(e->s_noisy, e->s_init, nz, s.tau, (long long)init_el, e->wC * H * W,
+                                              e->rng_state, st));
             fs[nf++] = {e->s_noisy, e->wC};
         }
         if (e->Cs > 0) fs[nf++] = {e->s_static, e->Cs};
@@ -849,6 +879,8 @@ dyf_status run_plan(dyf_engine* e, int nb, const uint8_t* const* masks, const fl
             dyf_status r = interp2(s.i_next, s.i_cur, e->s_x0hat, e->s_pair);
             if (r != DYF_OK) return r;
             HIP_TRY(e, launch_cold_update(e->s_xs, e->s_pair + field, e->s_pair, (long long)field, st));
+            if (&s == &ph.steps.back())  // sample_loop's third return value for a truncated schedule (dyffusion.py:424-425)
+                HIP_TRY(e, hipMemcpyAsync(e->s_next, e->s_pair, fbytes, hipMemcpyDeviceToDevice, st));
             if (s.out_slot >= 0)
                 HIP_TRY(e, hipMemcpyAsync(e->s_stack + (size_t)s.out_slot * field, e->s_xs, fbytes, hipMemcpyDeviceToDevice, st));
             ++step_idx;
@@ -942,11 +974,16 @@ dyf_status dyf_sample(dyf_engine* e, const float* initial_dev, const float* stat
     return DYF_OK;
 }
 
-dyf_status dyf_get_last_x0hat(dyf_engine* e, float* out_dev, int32_t nb, void* stream) {
+dyf_status dyf_get_sampler_state(dyf_engine* e, int32_t what, float* out_dev, int32_t nb, void* stream) {
     if (!e || !out_dev) return DYF_ERR_INVALID_ARGUMENT;
     if (!e->plan.set || !e->s_x0hat) return fail(e, DYF_ERR_STATE, "no sampling call has been made yet");
     if (nb < 1 || nb > e->cfg.max_batch) return fail(e, DYF_ERR_INVALID_ARGUMENT, "batch size outside [1, max_batch]");
-    HIP_TRY(e, hipMemcpyAsync(out_dev, e->s_x0hat, (size_t)nb * e->C * e->cfg.height * e->cfg.width * sizeof(float),
+    const float* src = nullptr;
+    if (what == DYF_STATE_X0_HAT) src = e->s_x0hat;
+    else if (what == DYF_STATE_X_S) src = e->s_xs;
+    else if (what == DYF_STATE_X_NEXT) src = e->plan.steps.back().i_next >= 0.0f ? e->s_next : e->s_x0hat;  // = x0_hat past T-1
+    else return fail(e, DYF_ERR_INVALID_ARGUMENT, "what must be a dyf_sampler_state");
+    HIP_TRY(e, hipMemcpyAsync(out_dev, src, (size_t)nb * e->C * e->cfg.height * e->cfg.width * sizeof(float),
                               hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return DYF_OK;
 }
@@ -1087,6 +1124,21 @@ dyf_status dyf_time_layer_in_rollout(dyf_engine* e, int32_t layer, int32_t nb, v
     if (cnt == 0) return fail(e, DYF_ERR_STATE, "layer was not launched");
     *avg_ms = tot / units;
     if (launches) *launches = (int32_t)cnt;
+    return DYF_OK;
+}
+
+dyf_status dyf_debug_read_block_output(dyf_engine* e, int32_t which, int32_t layer, int32_t nb, float* out_dev, void* stream) {
+    if (!e || !out_dev || which < 0 || which > 1 || layer < 0 || layer > 11)
+        return fail(e, DYF_ERR_INVALID_ARGUMENT, "bad argument to dyf_debug_read_block_output");
+    const Net& n = e->net[which];
+    if (n.rn || n.sc) return fail(e, DYF_ERR_UNSUPPORTED, "dyf_debug_read_block_output addresses the 12 UNetBlocks of arch unet_simple");
+    if (nb < 1 || nb > 2 * e->cfg.max_batch) return fail(e, DYF_ERR_INVALID_ARGUMENT, "batch size outside [1, 2 max_batch]");
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    const UBlock& b = n.blk[layer];
+    const bf16_t* src = layer < 6 ? e->ws.enc[layer] : e->ws.dec[layer - 6];
+    const bool sparse = layer == 11 && e->last_dec5_sparse;
+    HIP_TRY(e, launch_nhwc_to_nchw_f32(src, nb, b.out_h, b.out_w, sparse ? b.up_wo_store : b.out_w, b.cout,
+                                       sparse ? b.up_col_map : nullptr, out_dev, (hipStream_t)stream));
     return DYF_OK;
 }
 

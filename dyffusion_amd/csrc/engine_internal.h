@@ -103,14 +103,18 @@ struct dyf_engine {
     std::string err;
     dyf::Net net[2];
     dyf::Workspace ws;
-    std::vector<void*> allocs;
+    std::vector<void*> allocs;          // lifetime of the engine (workspace, sampler state)
+    std::vector<void*> net_allocs[2];   // packed weights of one network: released when dyf_load_weights is called again
+    std::vector<void*> plan_allocs;     // coefficient tables of the current plan: released by the next dyf_set_plan
+    std::vector<void*>* alloc_sink = nullptr;  // where dev_alloc records (AllocScope), null = allocs
     dyf::PlanHost plan;
     int C = 0, Cs = 0, wC = 0;  // dynamics channels, static-condition channels, window*C
     // sampler state (fp32 NCHW, engine-owned so a captured graph never sees caller pointers)
     float *s_init = nullptr, *s_static = nullptr, *s_xs = nullptr, *s_x0hat = nullptr, *s_next = nullptr,
           *s_cur = nullptr, *s_noisy = nullptr, *s_stack = nullptr;
     float* s_time = nullptr;   // device scalar scratch for time values
-    uint32_t* rng_state = nullptr;  // device {seed_lo, seed_hi, forward_counter, pad}
+    uint32_t* rng_state = nullptr;  // device {seed_lo, seed_hi, forward counter, row offset, noise counter, ...} (kernels.h)
+    uint32_t* row_keys = nullptr;   // device [2 max_batch][2]: per-row stream keys of the forward being launched (common.h)
     int stack_slots = 0;
     std::map<int, dyf::GraphEntry> graphs;  // by batch size
     int fuse_min_plane = 32;           // smallest low-res plane side for which the fused form is used
@@ -124,6 +128,8 @@ struct dyf_engine {
     std::vector<int> prof_rows;
     float* s_pair = nullptr;        // [2][max_batch][C][H][W]: outputs of a paired interpolator call
     bool pair_interp = true;        // DYF_PAIR_INTERP=0: one forward per interpolator call (A/B testing)
+    bool last_dec5_sparse = false;  // the most recent unet_simple forward stored dec5 in the compact sparse-column layout
+    bool poison_dec5 = false;       // DYF_POISON_DEC5=1 (test hook, read once at create): NaN-fill dec5's output before its conv
 };
 
 namespace dyf {
@@ -147,9 +153,26 @@ dyf_status dev_alloc(dyf_engine* e, T** out, size_t count) {
     size_t bytes = std::max<size_t>(count * sizeof(T), 256);
     HIP_TRY(e, hipMalloc(&p, bytes));
     HIP_TRY(e, hipMemset(p, 0, bytes));
-    e->allocs.push_back(p);
+    (e->alloc_sink ? *e->alloc_sink : e->allocs).push_back(p);
     *out = (T*)p;
     return DYF_OK;
+}
+
+// device allocations made while the scope is alive are recorded in `list`
+struct AllocScope {
+    dyf_engine* e;
+    std::vector<void*>* prev;
+    AllocScope(dyf_engine* eng, std::vector<void*>* list) : e(eng), prev(eng->alloc_sink) { e->alloc_sink = list; }
+    ~AllocScope() { e->alloc_sink = prev; }
+};
+
+// free every allocation of `list` (and their registered fragment copies); the device must be idle
+inline void release_allocs(std::vector<void*>& list) {
+    for (void* p : list) {
+        conv_unregister_frag(p);
+        (void)hipFree(p);
+    }
+    list.clear();
 }
 
 template <typename T>

@@ -102,8 +102,12 @@ hipError_t launch_readout(const ReadoutArgs& a, hipStream_t s);
 hipError_t launch_cold_update(float* x_s, const float* x_cur, const float* x_next, long long count, hipStream_t s);
 // out = tau*cond + (1-tau)*noise ; noise from `noise` if non-null else Box-Muller on the counter RNG
 hipError_t launch_noisy_condition(float* out, const float* cond, const float* noise, float tau, long long count,
-                                  const uint32_t* rng_state, uint32_t stream_id, hipStream_t s);
-hipError_t launch_bump_counter(uint32_t* rng_state, hipStream_t s);
+                                  int row_elems, uint32_t* rng_state, hipStream_t s);
+// rng_state (device): {seed_lo, seed_hi, forward counter, global index of the engine's batch row 0, noise-call counter, ...}
+#define DYF_RNG_STATE_WORDS 8
+hipError_t launch_nhwc_to_nchw_f32(const bf16_t* src, int n, int h, int w, int w_store, int c, const int16_t* col_map,
+                                   float* out, hipStream_t s);
+hipError_t launch_rng_begin_forward(uint32_t* rng_state, uint32_t* row_keys, int rows, int rows_per_fwd, hipStream_t s);
 hipError_t launch_fill_f32(float* p, float v, long long count, hipStream_t s);
 // on-device ensemble metrics (evaluation.py:10-118): sums[3] (fp64, device) = {sum (mean-y)^2, sum var, sum crps}; n_members <= 64 (one KB of LDS per member)
 // sum of the criterion terms |p-t| (kind 0), (p-t)^2 (1), smooth-L1 (2) over `count` fp32 elements -> *sum (device double)

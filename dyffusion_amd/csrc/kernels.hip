@@ -308,7 +308,7 @@ __global__ __launch_bounds__(256) void groupnorm_kernel(GroupNormArgs a) {
     }
     const float var = block_sum(v, scratch) / (float)count;  // biased, as torch
     const float rstd = rsqrtf(var + 1e-5f);
-    const uint32_t key = drop_key(a.drop);
+    const RngKey key = drop_row_key(a.drop, n);
     for (int i = threadIdx.x; i < count; i += blockDim.x) {
         const int p = i / cpg, ch = g * cpg + (i % cpg);
         float y = (x[(size_t)p * a.c + (i % cpg)] - mean) * rstd * a.gamma[ch] + a.beta[ch];
@@ -316,7 +316,7 @@ __global__ __launch_bounds__(256) void groupnorm_kernel(GroupNormArgs a) {
         y = fmaf(y, a.film_a[fi], a.film_c[fi]);
         y = apply_act(y, a.act);
         const size_t e = ((size_t)n * a.hw + p) * a.c + ch;
-        y = drop_apply(y, (uint32_t)e, a.drop, key);
+        y = drop_apply(y, (uint32_t)e, (uint32_t)((size_t)n * a.hw * a.c), a.drop, key);
         a.out[e] = f32_to_bf16(y);
     }
 }
@@ -735,16 +735,19 @@ hipError_t launch_cold_update(float* x_s, const float* x_cur, const float* x_nex
 }
 
 // dyffusion.py:219-227  forward_cond = tfactor*condition + (1-tfactor)*randn_like(condition)
+// Engine draws (noise == nullptr): Box-Muller on two hashed words per element; the stream is keyed by (seed, noise-call
+// counter rng_state[4], GLOBAL batch row rng_state[3] + n) and the element index inside the row, like the dropout masks.
 __global__ void noisy_condition_kernel(float* out, const float* cond, const float* noise, float tau, long long count,
-                                       const uint32_t* rng_state, uint32_t stream_id) {
+                                       int row_elems, const uint32_t* rng_state) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
     float z;
     if (noise != nullptr) {
         z = noise[i];
     } else {
-        const uint32_t key = rng_layer_key(rng_state[0], rng_state[1], rng_state[2], 48u + stream_id);
-        const uint32_t w0 = fmix32((uint32_t)i * 0x9E3779B1u + key), w1 = fmix32(w0 ^ 0x68E31DA4u);
+        const uint32_t n = (uint32_t)(i / row_elems), e = (uint32_t)(i - (long long)n * row_elems);
+        const RngKey rk = rng_row_key(rng_state[0], rng_state[1] ^ 0x4E6F6973u, rng_state[4], rng_state[3] + n);
+        const uint32_t w0 = fmix32(e * 0x9E3779B1u + rk.k0), w1 = fmix32(w0 ^ rk.k1);
         const float u1 = ((float)(w0 >> 8) + 0.5f) * (1.0f / 16777216.0f);
         const float u2 = ((float)(w1 >> 8) + 0.5f) * (1.0f / 16777216.0f);
         z = sqrtf(-2.0f * logf(u1)) * cosf(6.283185307179586f * u2);
@@ -752,19 +755,55 @@ __global__ void noisy_condition_kernel(float* out, const float* cond, const floa
     out[i] = tau * cond[i] + (1.0f - tau) * z;
 }
 
+__global__ void rng_bump_kernel(uint32_t* state, int slot, uint32_t by) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) state[slot] += by;
+}
+
 hipError_t launch_noisy_condition(float* out, const float* cond, const float* noise, float tau, long long count,
-                                  const uint32_t* rng_state, uint32_t stream_id, hipStream_t s) {
+                                  int row_elems, uint32_t* rng_state, hipStream_t s) {
     hipLaunchKernelGGL(noisy_condition_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, out, cond, noise,
-                       tau, count, rng_state, stream_id);
+                       tau, count, row_elems, rng_state);
+    if (noise == nullptr)  // every call draws a fresh field (dyffusion.py:227 randn_like), also on graph replay
+        hipLaunchKernelGGL(rng_bump_kernel, dim3(1), dim3(64), 0, s, rng_state, 4, 1u);
     return hipGetLastError();
 }
 
-__global__ void bump_counter_kernel(uint32_t* state) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) state[2] += 1u;
+// Start of a forward that draws dropout masks: fill the row-key table of the launch and advance the forward counter.
+// Launch row r belongs to forward (counter + r / rows_per_fwd) and global batch row (row offset + r % rows_per_fwd): a
+// paired interpolator launch (2 nb rows = two forwards of nb rows) draws exactly the masks of two separate forwards.
+__global__ __launch_bounds__(256) void rng_begin_forward_kernel(uint32_t* state, uint32_t* row_keys, int rows, int rows_per_fwd) {
+    const uint32_t lo = state[0], hi = state[1], fwd0 = state[2], row0 = state[3];
+    for (int r = threadIdx.x; r < rows; r += blockDim.x) {
+        const RngKey k = rng_row_key(lo, hi, fwd0 + (uint32_t)(r / rows_per_fwd), row0 + (uint32_t)(r % rows_per_fwd));
+        row_keys[2 * r] = k.k0;
+        row_keys[2 * r + 1] = k.k1;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) state[2] = fwd0 + (uint32_t)((rows + rows_per_fwd - 1) / rows_per_fwd);
 }
 
-hipError_t launch_bump_counter(uint32_t* rng_state, hipStream_t s) {
-    hipLaunchKernelGGL(bump_counter_kernel, dim3(1), dim3(64), 0, s, rng_state);
+hipError_t launch_rng_begin_forward(uint32_t* rng_state, uint32_t* row_keys, int rows, int rows_per_fwd, hipStream_t s) {
+    hipLaunchKernelGGL(rng_begin_forward_kernel, dim3(1), dim3(256), 0, s, rng_state, row_keys, rows, rows_per_fwd);
+    return hipGetLastError();
+}
+
+// test seam (dyf_debug_read_block_output): NHWC bf16 activation -> NCHW fp32; col_map (or null) maps a dense column to its
+// column in a compact tensor of width w_store, -1 = not stored (NaN)
+__global__ void nhwc_to_nchw_f32_kernel(const bf16_t* src, int n, int h, int w, int w_store, int c, const int16_t* col_map,
+                                        float* out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = (long long)n * c * h * w;
+    if (i >= total) return;
+    const int x = (int)(i % w), y = (int)((i / w) % h), ch = (int)((i / ((long long)w * h)) % c), b = (int)(i / ((long long)w * h * c));
+    const int xs = col_map ? col_map[x] : x;
+    out[i] = xs < 0 ? __uint_as_float(0x7fc00000u) : bf16_to_f32(src[(((size_t)b * h + y) * w_store + xs) * c + ch]);
+}
+
+hipError_t launch_nhwc_to_nchw_f32(const bf16_t* src, int n, int h, int w, int w_store, int c, const int16_t* col_map,
+                                   float* out, hipStream_t s) {
+    const long long total = (long long)n * c * h * w;
+    hipLaunchKernelGGL(nhwc_to_nchw_f32_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, n, h, w, w_store, c,
+                       col_map, out);
     return hipGetLastError();
 }
 

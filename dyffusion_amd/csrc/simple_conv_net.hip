@@ -186,6 +186,8 @@ dyf_status sc_forward(dyf_engine* e, int which, const Source* srcs, int nsrc, in
     }
     if (ctot != n.cin_total)
         return fail(e, DYF_ERR_INVALID_ARGUMENT, "channel count of the network inputs does not match its configuration");
+    if (o.dropout_mode == 1 && n.cfg.dropout > 0.0f)
+        HIP_TRY(e, launch_rng_begin_forward(e->rng_state, e->row_keys, nb, o.src_rows > 0 ? o.src_rows : nb, st));
     const long long tot = (long long)nb * hw * ctot;
     hipLaunchKernelGGL(pack_inputs_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, sp[0], sp[1], sp[2], sp[3], sc[0],
                        sc[1], sc[2], sc[3], nb, hw, s->packed);
@@ -204,8 +206,8 @@ dyf_status sc_forward(dyf_engine* e, int which, const Source* srcs, int nsrc, in
         d.mode = p > 0.0f ? o.dropout_mode : 0;
         d.scale = 1.0f / (1.0f - p);
         d.thresh16 = keep_threshold16(p);
-        d.layer = (uint32_t)i;
-        d.state = e->rng_state;
+        d.salt = rng_layer_salt((uint32_t)i);
+        d.row_keys = e->row_keys;
         d.mask = (d.mode == 2 && o.masks) ? o.masks[i] : nullptr;
         if (d.mode == 2 && d.mask == nullptr) d.mode = 0;
         a.drop = d;
@@ -219,7 +221,6 @@ dyf_status sc_forward(dyf_engine* e, int which, const Source* srcs, int nsrc, in
     HeadArgs h{};
     h.x = x; h.n = nb; h.hw = hw; h.c = n.dim; h.cout = n.cfg.out_channels; h.wgt = s->head_w; h.bias = s->head_b; h.out = out_dev;
     HIP_TRY(e, launch_head(h, st));
-    if (o.dropout_mode == 1 && n.cfg.dropout > 0.0f) HIP_TRY(e, launch_bump_counter(e->rng_state, st));
     return DYF_OK;
 }
 

@@ -40,7 +40,8 @@ hipError_t launch_gn_act(const GnActArgs& a, hipStream_t s);
 // K6: channel LayerNorm (gain only, biased variance, eps 1e-5) + optional Dropout (unet.py:43-52; attention.py:12)
 struct LayerNormArgs {
     const bf16_t* x;    // [pixels][c]
-    long long pixels;
+    long long pixels;   // n * hw
+    int hw;             // pixels per batch row (the dropout streams are per row)
     int c;
     const float* g;     // [c]
     DropSpec drop;

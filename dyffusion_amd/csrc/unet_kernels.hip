@@ -250,7 +250,8 @@ __global__ __launch_bounds__(256) void gn_act_kernel(GnActArgs a) {
         v = fmaf(d, d, v);
     }
     const float rstd = rsqrtf(bsum(v, scratch) / (float)count + 1e-5f);
-    const uint32_t key = drop_key(a.drop);
+    const RngKey key = drop_row_key(a.drop, n);
+    const uint32_t row0 = (uint32_t)((size_t)n * a.hw * a.c);
     for (int i = threadIdx.x; i < count; i += blockDim.x) {
         const int p = i / cpg, ch = g * cpg + (i % cpg);
         const size_t e = ((size_t)n * a.hw + p) * a.c + ch;
@@ -260,7 +261,7 @@ __global__ __launch_bounds__(256) void gn_act_kernel(GnActArgs a) {
             y = fmaf(y, a.film_a[fi], a.film_c[fi]);
         }
         y = apply_act(y, a.act);
-        y = drop_apply(y, (uint32_t)e, a.drop, key);
+        y = drop_apply(y, (uint32_t)e, row0, a.drop, key);
         if (a.residual) y += bf16_to_f32(a.residual[e]);
         a.out[e] = f32_to_bf16(y);
     }
@@ -391,7 +392,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnActArgs a, const float2
         const float xv = (t & 1) ? __uint_as_float(w[t >> 1] & 0xffff0000u) : __uint_as_float(w[t >> 1] << 16);
         y[t] = fmaf(xv, A[t], C[t]);
     }
-    act_drop<8>(y, (uint32_t)e0, a.act, a.drop, drop_key(a.drop));  // (activation, dropout mode) dispatched once
+    act_drop<8>(y, (uint32_t)e0, (uint32_t)((size_t)n * a.hw * a.c), a.act, a.drop, drop_row_key(a.drop, n));  // (activation, dropout mode) dispatched once
     if (a.residual) {
         const uint4 r = *(const uint4*)(a.residual + e0);
         const uint32_t rw[4] = {r.x, r.y, r.z, r.w};
@@ -447,11 +448,13 @@ __global__ __launch_bounds__(256) void layernorm_c_kernel(LayerNormArgs a) {
     for (int off = 4; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
     const float rstd = rsqrtf(v / (float)a.c + 1e-5f);
     if (!live) return;
-    const uint32_t key = drop_key(a.drop);
+    const int n = (int)(pix / a.hw);
+    const RngKey key = drop_row_key(a.drop, n);
+    const uint32_t row0 = (uint32_t)((size_t)n * a.hw * a.c);
     for (int c = sl; c < a.c; c += 8) {
         const size_t e = (size_t)pix * a.c + c;
         float y = (bf16_to_f32(x[c]) - mean) * rstd * a.g[c];
-        y = drop_apply(y, (uint32_t)e, a.drop, key);
+        y = drop_apply(y, (uint32_t)e, row0, a.drop, key);
         a.out[e] = f32_to_bf16(y);
     }
 }
@@ -489,7 +492,8 @@ __global__ __launch_bounds__(256) void layernorm_c_vec_kernel(LayerNormArgs a, i
     float y[8];
 #pragma unroll
     for (int t = 0; t < 8; ++t) y[t] = x[t] * rstd * g[t];
-    act_drop<8>(y, (uint32_t)e0, ACT_NONE, a.drop, drop_key(a.drop));
+    const int n = (int)(pix / a.hw);
+    act_drop<8>(y, (uint32_t)e0, (uint32_t)((size_t)n * a.hw * a.c), ACT_NONE, a.drop, drop_row_key(a.drop, n));
     *(uint4*)(a.out + e0) = make_uint4(pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]), pack_bf16x2(y[4], y[5]),
                                        pack_bf16x2(y[6], y[7]));
 }
@@ -838,12 +842,15 @@ hipError_t launch_linear_attention(const LinAttnArgs& a, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------------------ Attention
-__device__ __forceinline__ uint32_t attn_drop_key(const DropSpec& d, uint32_t bh) {
-    return d.mode == 1 ? fmix32(drop_key(d) + bh * 0x9E3779B9u) : 0u;
+// stream of (batch row n, head h): the row's stream key with the head folded in
+__device__ __forceinline__ RngKey attn_drop_key(const DropSpec& d, int n, uint32_t h) {
+    RngKey k = drop_row_key(d, n);
+    if (d.mode == 1) k.k0 = fmix32(k.k0 + (h + 1u) * 0x9E3779B9u);
+    return k;
 }
 // element (query i, key j) of head-sample bh: RNG stream keyed per bh (i*N + j stays below 2^32 for N <= 65535);
 // injected masks are indexed as the (b, h, i, j) tensor the reference's nn.Dropout sees
-__device__ __forceinline__ float attn_drop(float p, const DropSpec& d, uint32_t key, uint32_t bh, uint32_t i, uint32_t j,
+__device__ __forceinline__ float attn_drop(float p, const DropSpec& d, RngKey key, uint32_t bh, uint32_t i, uint32_t j,
                                            uint32_t n) {
     if (d.mode == 0) return p;
     const bool keep = d.mode == 1 ? rng_keep(i * n + j, key, d.thresh16) : (d.mask[((size_t)bh * n + i) * n + j] != 0);
@@ -868,7 +875,7 @@ __global__ __launch_bounds__(64) void attention_kernel(AttnArgs a) {
         o[c] = 0.0f;
     }
     float m = -3.0e38f, l = 0.0f;
-    const uint32_t key = attn_drop_key(a.drop, (uint32_t)bh);
+    const RngKey key = attn_drop_key(a.drop, n, (uint32_t)h);
     for (int j0 = 0; j0 < a.hw; j0 += 64) {
         __syncthreads();
         for (int t = threadIdx.x; t < 64 * 32; t += 64) {
@@ -939,7 +946,7 @@ __global__ __launch_bounds__(256) void flash_attention_kernel(AttnArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[r] = 0.0f;
     float m = -1.0e30f, l = 0.0f;
-    const uint32_t dkey = attn_drop_key(a.drop, (uint32_t)bh);
+    const RngKey dkey = attn_drop_key(a.drop, n, (uint32_t)h);
 
     for (int j0 = 0; j0 < N; j0 += 64) {
         __syncthreads();

@@ -78,8 +78,8 @@ struct DropCtx {  // walks the dropout sites in execution order (same order as t
         d.mode = o->dropout_mode;
         d.scale = 1.0f / (1.0f - p);
         d.thresh16 = keep_threshold16(p);
-        d.layer = (uint32_t)site++;
-        d.state = e->rng_state;
+        d.salt = rng_layer_salt((uint32_t)site++);
+        d.row_keys = e->row_keys;
         if (d.mode == 2) {
             d.mask = o->masks ? o->masks[mask_idx++] : nullptr;
             if (!d.mask) d.mode = 0;
@@ -428,6 +428,8 @@ dyf_status rn_forward(dyf_engine* e, int which, const Source* srcs, int nsrc, in
     pool.free_list = r->pool;
     DropCtx dc{e, &o};
     const bool film = c.with_time_emb != 0;
+    if (o.dropout_mode == 1 && (c.dropout > 0.0f || c.block_dropout1 > 0.0f || c.attn_dropout > 0.0f))
+        HIP_TRY(e, launch_rng_begin_forward(e->rng_state, e->row_keys, nb, o.src_rows > 0 ? o.src_rows : nb, st));
 
 #define TRY(expr)                         \
     do {                                  \
@@ -469,7 +471,7 @@ dyf_status rn_forward(dyf_engine* e, int which, const Source* srcs, int nsrc, in
         const int hw = hh * ww;
         bf16_t* ln = pool.get();
         LayerNormArgs la{};
-        la.x = x; la.pixels = (long long)nb * hw; la.c = a.dim; la.g = a.ln_g; la.out = ln;
+        la.x = x; la.pixels = (long long)nb * hw; la.hw = hw; la.c = a.dim; la.g = a.ln_g; la.out = ln;
         la.drop = a.linear ? dc.next(c.attn_dropout) : DropSpec{};  // LinearAttention drops its (normalised) input
         HIP_TRY(e, launch_layernorm_c(la, st));
         bf16_t* qkv = pool.get();
@@ -566,7 +568,6 @@ dyf_status rn_forward(dyf_engine* e, int which, const Source* srcs, int nsrc, in
     ha.x = yf; ha.n = nb; ha.hw = H * W; ha.c = c.dim; ha.cout = c.out_channels; ha.wgt = r->head_w; ha.bias = r->head_b; ha.out = out_dev;
     HIP_TRY(e, launch_head(ha, st));
     pool.put(yf);
-    if (o.dropout_mode == 1 && dc.site > 0) HIP_TRY(e, launch_bump_counter(e->rng_state, st));
 #undef TRY
     return DYF_OK;
 }

@@ -1,13 +1,22 @@
 """Ensemble-sharded sampling across the GPUs of one node.
 
 Ensemble members / batch items are independent rows of the NB batch dimension for the whole rollout
-(`_base_experiment.py:503-538` tiles them; no op in the path mixes rows), so the path shards with NO collective
-inside the rollout.  Each rank (one process per GPU) samples its contiguous block of rows with its own engine and
-dropout sub-stream; ONE all-gather of the forecast stack (RCCL over xGMI with backend "nccl", gloo on CPU for the
-tests) makes the full `(h, NB, C, H, W)` stack available on every rank.  The reference has no inference collective
-(it only replicates the whole module under Lightning DDP, `src/configs/trainer/ddp.yaml`).
+(`_base_experiment.py:503-538` tiles them, row = n*B + b; no op in the path mixes rows), so the path shards with NO
+collective inside the rollout.  One process per GPU; rank r samples the contiguous block of rows `shard_rows` gives it
+with its own engine, and ONE exchange -- an all-gather of the forecast stack (RCCL over xGMI with backend "nccl", gloo on
+CPU for the tests) -- makes every `t{i}_preds` (NB, C, H, W) available on every rank.  The reference has no inference
+collective (it only replicates the whole module under Lightning DDP, `src/configs/trainer/ddp.yaml`).
+
+Results do not depend on the number of GPUs: every rank keeps the SAME seed and tells its engine the global index of its
+first row (`set_row_offset`), and the engine's dropout / noise streams are keyed by the global row (csrc/common.h).
+
+Layout of the exchange: every rank samples the same number of rows (`rows_per_rank` = ceil(NB / world); ranks that own
+fewer rows -- 50 members on 8 GPUs are 7,7,6,6,6,6,6,6 -- repeat their last row, whose result is dropped), so the
+collective is one `all_gather_into_tensor` per forecast field straight from the engine's output slot into the
+pre-allocated `(h, world * rows_per_rank, C, H, W)` result: no staging copies when NB divides evenly; otherwise one
+index-select per field drops the padding rows.
 """
-from typing import Callable, Dict, List, Optional, Tuple
+from typing import Dict, List, Optional, Protocol, Tuple
 
 import torch
 import torch.distributed as dist
@@ -16,45 +25,89 @@ from torch import Tensor
 
 def shard_rows(total_rows: int, world_size: int, rank: int) -> Tuple[int, int]:
     """Contiguous, balanced split: the first `total_rows % world_size` ranks own one extra row (50 rows on 8 GPUs ->
-    7,7,6,6,6,6,6,6)."""
+    7,7,6,6,6,6,6,6).  A rank may own no row at all when total_rows < world_size."""
     base, extra = divmod(total_rows, world_size)
     start = rank * base + min(rank, extra)
     return start, start + base + (1 if rank < extra else 0)
 
 
-def all_gather_rows(local: Tensor, total_rows: int, group=None, row_dim: int = 1) -> Tensor:
-    """All-gather tensors that are sharded along `row_dim` by `shard_rows` (uneven shards are padded to the largest
-    one for the collective and trimmed afterwards)."""
-    world = dist.get_world_size(group)
-    counts = [shard_rows(total_rows, world, r)[1] - shard_rows(total_rows, world, r)[0] for r in range(world)]
-    cmax = max(counts)
-    x = local.movedim(row_dim, 0).contiguous()
-    assert x.shape[0] == counts[dist.get_rank(group)], (x.shape, counts)
-    if x.shape[0] < cmax:
-        pad = torch.zeros((cmax - x.shape[0], *x.shape[1:]), dtype=x.dtype, device=x.device)
-        x = torch.cat([x, pad], 0)
-    out = torch.empty((world * cmax, *x.shape[1:]), dtype=x.dtype, device=x.device)
-    if dist.get_backend(group) == "gloo":
-        parts = [torch.empty_like(x) for _ in range(world)]
-        dist.all_gather(parts, x, group=group)
-        out = torch.cat(parts, 0)
+def rows_per_rank(total_rows: int, world_size: int) -> int:
+    return -(-total_rows // world_size)
+
+
+def _gather_into(out_field: Tensor, local_field: Tensor, group) -> None:
+    """out_field (world * r, ...) <- all-gather of local_field (r, ...), both contiguous."""
+    if dist.get_backend(group) == "gloo":  # CPU tests: gloo has no all_gather_into_tensor
+        world = dist.get_world_size(group)
+        r = local_field.shape[0]
+        dist.all_gather([out_field[k * r:(k + 1) * r] for k in range(world)], local_field, group=group)
     else:
-        dist.all_gather_into_tensor(out, x, group=group)
-    pieces = [out[r * cmax: r * cmax + counts[r]] for r in range(world)]
-    return torch.cat(pieces, 0).movedim(0, row_dim)
+        dist.all_gather_into_tensor(out_field, local_field, group=group)
 
 
-def sample_sharded(sample_fn: Callable[[Tensor, Optional[Tensor]], Dict[str, Tensor]], initial_condition: Tensor,
-                   static_condition: Optional[Tensor] = None, group=None) -> Dict[str, Tensor]:
-    """Every rank passes the FULL (NB, ...) inputs; it samples only its own rows with `sample_fn` (e.g.
-    `lambda x, c: model.sample(x, static_condition=c)`) and receives the full `t{i}_preds` dict."""
+def _valid_rows(total_rows: int, world: int, device) -> Optional[Tensor]:
+    """Indices of the real rows inside the padded (world * rows_per_rank) gather layout, or None when nothing is padded."""
+    rpr = rows_per_rank(total_rows, world)
+    if total_rows == world * rpr:
+        return None
+    spans = [shard_rows(total_rows, world, r) for r in range(world)]
+    return torch.cat([torch.arange(r * rpr, r * rpr + (b - a)) for r, (a, b) in enumerate(spans)]).to(device)
+
+
+def all_gather_rows(local: Tensor, total_rows: int, group=None, row_dim: int = 1) -> Tensor:
+    """All-gather a tensor sharded along `row_dim` (0 or 1) by `shard_rows`.  `local` holds this rank's rows, optionally
+    already padded to `rows_per_rank` rows; the result has exactly `total_rows` rows in global order."""
+    assert row_dim in (0, 1)
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    rpr = rows_per_rank(total_rows, world)
+    lo, hi = shard_rows(total_rows, world, rank)
+    x = local.unsqueeze(0) if row_dim == 0 else local  # (fields, rows, ...)
+    assert x.shape[1] in (hi - lo, rpr), (tuple(x.shape), hi - lo, rpr)
+    if x.shape[1] < rpr:  # pad to the common row count (only uneven shards pay this copy)
+        pad = torch.zeros((x.shape[0], rpr - x.shape[1], *x.shape[2:]), dtype=x.dtype, device=x.device)
+        x = torch.cat([x, pad], 1)
+    x = x.contiguous()
+    out = torch.empty((x.shape[0], world * rpr, *x.shape[2:]), dtype=x.dtype, device=x.device)
+    for i in range(x.shape[0]):
+        _gather_into(out[i], x[i], group)
+    keep = _valid_rows(total_rows, world, out.device)
+    if keep is not None:
+        out = out.index_select(1, keep)
+    return out.squeeze(0) if row_dim == 0 else out
+
+
+class _Sampler(Protocol):  # what sample_sharded needs of `DYffusion`
+    def sample(self, initial_condition: Tensor, **kwargs) -> Dict[str, Tensor]: ...
+
+    def set_row_offset(self, first_row: int) -> None: ...
+
+
+def sample_sharded(model: _Sampler, initial_condition: Tensor, static_condition: Optional[Tensor] = None,
+                   group=None) -> Dict[str, Tensor]:
+    """Every rank passes the FULL (NB, ...) inputs and the same-seeded `model` (a `DYffusion`); it samples only its own
+    rows and receives the full `t{i}_preds` dict.  Identical to `model.sample` on one GPU, bit for bit."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
-        return sample_fn(initial_condition, static_condition)
+        model.set_row_offset(0)
+        kw = {} if static_condition is None else {"static_condition": static_condition}
+        return model.sample(initial_condition, **kw)
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     nb = initial_condition.shape[0]
+    rpr = rows_per_rank(nb, world)
     lo, hi = shard_rows(nb, world, rank)
-    local = sample_fn(initial_condition[lo:hi], None if static_condition is None else static_condition[lo:hi])
+    # every rank runs `rpr` rows (same batch size = same captured graph, uniform collective): ranks that own fewer rows
+    # re-run their last row (or row 0 of the batch when they own none); those results are dropped after the gather
+    idx = torch.arange(lo, lo + rpr).clamp_max(max(hi - 1, 0)).clamp_max(nb - 1).to(initial_condition.device)
+    x = initial_condition.index_select(0, idx) if (hi - lo) < rpr else initial_condition[lo:hi]
+    c = None if static_condition is None else \
+        (static_condition.index_select(0, idx) if (hi - lo) < rpr else static_condition[lo:hi])
+    model.set_row_offset(lo)
+    local = model.sample(x, **({} if c is None else {"static_condition": c}))
     keys: List[str] = sorted(local, key=lambda k: int(k[1:].split("_")[0]))
-    stack = torch.stack([local[k] for k in keys], 0)  # (h, rows_local, C, H, W)
-    full = all_gather_rows(stack, nb, group=group, row_dim=1)
-    return {k: full[i] for i, k in enumerate(keys)}
+    out = {}
+    keep = _valid_rows(nb, world, initial_condition.device)
+    for k in keys:
+        field = local[k].contiguous()  # a slot of the engine's forecast stack: already contiguous
+        full = torch.empty((world * rpr, *field.shape[1:]), dtype=field.dtype, device=field.device)
+        _gather_into(full, field, group)
+        out[k] = full if keep is None else full.index_select(0, keep)
+    return out

@@ -99,6 +99,8 @@ class DYffusion(nn.Module):
         self._engine_opts = dict(max_batch=max_batch, use_graph=use_graph, enable_mfma=enable_mfma)
         self._engine: Optional[HipEngine] = None
         self._plan_key = None
+        self._seed: Optional[int] = None
+        self._row_offset = 0
         self.requires_grad_(False)
         self.eval()
 
@@ -215,14 +217,33 @@ class DYffusion(nn.Module):
             self.model.attach_engine(self._engine, L.NET_FORECASTER)
             self._ipol_net.attach_engine(self._engine, L.NET_INTERPOLATOR)
             self._plan_key = None
+            if self._seed is not None:  # a re-created engine (batch growth, new grid) keeps the caller's stream
+                self._engine.seed(self._seed)
+            self._engine.set_row_offset(self._row_offset)
         return self._engine
+
+    # ------------------------------------------------------------------ stochastic stream (no reference counterpart: the
+    # reference draws MC-dropout masks / noise from torch's global generator, i.e. `pl.seed_everything`)
+    def seed(self, seed: int):
+        """Seed the engine's dropout / noise generator (restarts its stream); survives engine re-creation."""
+        self._seed = int(seed)
+        if self._engine is not None:
+            self._engine.seed(self._seed)
+
+    def set_row_offset(self, first_row: int):
+        """Global index of batch row 0 of the tensors this object is given (ensemble sharding, distributed.py)."""
+        if int(first_row) == self._row_offset:
+            return  # (a blocking 4-byte upload otherwise: keep it out of steady-state sampling loops)
+        self._row_offset = int(first_row)
+        if self._engine is not None:
+            self._engine.set_row_offset(self._row_offset)
 
     def _ensure_plan(self, eng: HipEngine):
         hp = self.hparams
         key = (tuple(self.sampling_schedule), hp.sampling_type, hp.use_cold_sampling_for_last_step,
                hp.forward_conditioning, hp.refine_intermediate_predictions, hp.time_encoding,
                bool(self.enable_interpolator_dropout), bool(self.enable_forecaster_dropout), id(eng))
-        if key == self._plan_key:
+        if key == self._plan_key and eng.plan_valid:  # reloading weights invalidates the engine's plan (FiLM tables)
             return
         if hp.sampling_type not in ("cold", "naive"):
             raise ValueError(f"unknown sampling type {hp.sampling_type}")
@@ -244,8 +265,11 @@ class DYffusion(nn.Module):
         self._ensure_plan(eng)
         stack = eng.sample(initial_condition, static_condition, masks=_masks, noise=_noise)
         intermediates = {f"t{slot + 1}_preds": stack[slot] for slot in self._emitted_slots}
-        x_s = stack[self._emitted_slots[-1]]
-        return eng.last_x0hat(nb), intermediates, x_s
+        x_s = eng.sampler_state(1, nb)
+        if self.sampling_schedule[-1] < self.num_timesteps - 1:
+            # dyffusion.py:424-425: a schedule that stops before T-1 returns (x_s, intermediates, x_interpolated_s_next)
+            return x_s, intermediates, eng.sampler_state(2, nb)
+        return eng.sampler_state(0, nb), intermediates, x_s
 
     @torch.no_grad()
     def sample(self, initial_condition: Tensor, num_samples: int = 1, **kwargs) -> Dict[str, Tensor]:

@@ -75,6 +75,8 @@ class HipEngine:
         self._h = h
         self._plan_keepalive = None
         self.n_out_slots = 0
+        self.plan_valid = False   # cleared by load_weights: the plan's FiLM tables are functions of the weights
+        self.weights_version = 0
 
     # ------------------------------------------------------------------ plumbing
     def _check(self, st: int):
@@ -107,6 +109,8 @@ class HipEngine:
         shp_store = [(C.c_int64 * max(1, a.ndim))(*a.shape) for a in arrs]
         shapes = (C.c_void_p * n)(*[C.addressof(s) for s in shp_store])
         ndims = (C.c_int32 * n)(*[a.ndim for a in arrs])
+        self.plan_valid = False
+        self.weights_version += 1
         self._check(self._lib.dyf_load_weights(self._h, net, n, names, data, shapes, ndims))
 
     # ------------------------------------------------------------------ per-network seam
@@ -154,6 +158,7 @@ class HipEngine:
         self._plan_keepalive = (arr, rt, rs, plan)
         self._check(self._lib.dyf_set_plan(self._h, C.byref(plan)))
         self.n_out_slots = int(n_out_slots)
+        self.plan_valid = True
 
     def sample(self, initial: torch.Tensor, static: Optional[torch.Tensor] = None,
                masks: Optional[Sequence[torch.Tensor]] = None, noise: Optional[torch.Tensor] = None,
@@ -163,9 +168,19 @@ class HipEngine:
         if initial.dim() != 4:
             raise AssertionError(f"condition.shape: {tuple(initial.shape)} (should be 4D)")
         nb = initial.shape[0]
+        # the C ABI copies nb * channels * H * W floats from raw pointers: validate the shapes here
+        icfg = self.cfg.net[L.NET_INTERPOLATOR]
+        c_out = self.cfg.net[L.NET_FORECASTER].out_channels
+        if tuple(initial.shape[2:]) != (self.height, self.width) or initial.shape[1] != icfg.in_channels - c_out:
+            raise ValueError(f"initial_condition must be (NB, {icfg.in_channels - c_out}, {self.height}, {self.width}), "
+                             f"got {tuple(initial.shape)}")
+        if (static is None) != (icfg.cond_channels == 0):
+            raise ValueError("static_condition must be given iff the networks take conditional channels")
         if static is not None:
             static = _f32c(static, "static_condition")
-        c_out = self.cfg.net[L.NET_FORECASTER].out_channels
+            if tuple(static.shape) != (nb, icfg.cond_channels, self.height, self.width):
+                raise ValueError(f"static_condition must be ({nb}, {icfg.cond_channels}, {self.height}, {self.width}), "
+                                 f"got {tuple(static.shape)}")
         if out is None:
             out = torch.empty((self.n_out_slots, nb, c_out, self.height, self.width), dtype=torch.float32,
                               device=initial.device)
@@ -175,19 +190,43 @@ class HipEngine:
             mptr = (C.c_void_p * len(keep))(*[m.data_ptr() for m in keep])
         if noise is not None:
             noise = _f32c(noise, "noise")
+        if tuple(out.shape) != (self.n_out_slots, nb, c_out, self.height, self.width) or not out.is_contiguous() \
+                or out.dtype != torch.float32:
+            raise ValueError("out must be a contiguous fp32 (n_out_slots, NB, C, H, W) tensor")
         self._check(self._lib.dyf_sample(self._h, initial.data_ptr(), None if static is None else static.data_ptr(),
                                          out.data_ptr(), nb, mptr, None if noise is None else noise.data_ptr(),
                                          self._stream()))
         return out
 
-    def last_x0hat(self, nb: int) -> torch.Tensor:
+    def sampler_state(self, what: int, nb: int) -> torch.Tensor:
+        """what: 0 = last x0_hat, 1 = x_s, 2 = x_interpolated_s_next of the final step (dyf_sampler_state)."""
         c_out = self.cfg.net[L.NET_FORECASTER].out_channels
         out = torch.empty((nb, c_out, self.height, self.width), dtype=torch.float32, device=f"cuda:{self.device}")
-        self._check(self._lib.dyf_get_last_x0hat(self._h, out.data_ptr(), nb, self._stream()))
+        self._check(self._lib.dyf_get_sampler_state(self._h, what, out.data_ptr(), nb, self._stream()))
         return out
 
+    def last_x0hat(self, nb: int) -> torch.Tensor:
+        return self.sampler_state(0, nb)
+
     def seed(self, seed: int):
+        """Re-seed the dropout / noise generator; forward and noise counters restart at 0."""
         self._check(self._lib.dyf_seed(self._h, C.c_uint64(int(seed) & (2 ** 64 - 1))))
+
+    def set_row_offset(self, first_row: int):
+        """Global index of this engine's batch row 0 (ensemble sharding): rows draw the masks of the un-sharded batch."""
+        self._check(self._lib.dyf_set_row_offset(self._h, C.c_uint32(int(first_row))))
+
+    def read_block_output(self, net: int, layer: int, nb: int) -> torch.Tensor:
+        """Test seam: output of UNetBlock `layer` (0..11) of the most recent unet_simple forward, fp32 NCHW."""
+        d = self.cfg.net[net].dim
+        ch = [2 * d, 2 * d, 4 * d, 8 * d, 8 * d, 8 * d, 8 * d, 8 * d, 4 * d, 2 * d, 2 * d, d][layer]
+        uh = self.cfg.net[net].upsample_h or self.height
+        uw = self.cfg.net[net].upsample_w or self.width
+        sh = layer + 1 if layer < 6 else 11 - layer   # log2 of the block output's down-sampling factor
+        shape = (nb, ch, uh >> sh, uw >> sh)
+        out = torch.empty(shape, dtype=torch.float32, device=f"cuda:{self.device}")
+        self._check(self._lib.dyf_debug_read_block_output(self._h, net, layer, nb, out.data_ptr(), self._stream()))
+        return out
 
     # ------------------------------------------------------------------ introspection
     def forward_counts(self):

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define DYF_ABI_VERSION 2
+#define DYF_ABI_VERSION 3
 
 typedef struct dyf_engine dyf_engine;
 
@@ -139,8 +139,14 @@ dyf_status dyf_set_plan(dyf_engine* engine, const dyf_plan* plan);
  * (n_steps, NB, window*C, H, W) standard-normal draws for forward_conditioning="data+noise" parity. */
 dyf_status dyf_sample(dyf_engine* engine, const float* initial_dev, const float* static_dev, float* out_dev,
                       int32_t nb, const uint8_t* const* masks_dev, const float* noise_dev, void* stream);
-/* Re-seed the engine's counter-based dropout / noise generator (stream position resets to 0). */
+/* Re-seed the engine's counter-based dropout / noise generator (forward and noise counters reset to 0).  The keep bit of
+ * an element is a function of (seed, forward index, GLOBAL batch row, dropout layer, element index inside the row), see
+ * csrc/common.h: a rollout does not depend on how its rows are batched or sharded over GPUs. */
 dyf_status dyf_seed(dyf_engine* engine, uint64_t seed);
+/* Global index of this engine's batch row 0 (default 0).  A rank that samples rows [lo, hi) of an N*B-row ensemble
+ * (_base_experiment.py:503-538 tiles them, row = n*B + b) sets lo: its rows then draw exactly the masks / noise they
+ * would draw inside the un-sharded batch. */
+dyf_status dyf_set_row_offset(dyf_engine* engine, uint32_t first_row);
 
 /* On-device ensemble metrics, replaces evaluate_ensemble_prediction (src/utilities/evaluation.py:10-118) and the
  * .cpu().numpy() round trip in front of it (_base_experiment.py:617-640).  preds_dev: (n_members, n_points) fp32 with
@@ -148,52 +154,23 @@ dyf_status dyf_seed(dyf_engine* engine, uint64_t seed);
  * out_host[3] receives {mse of the ensemble mean, spread-skill ratio sqrt(mean var)/sqrt(mse), CRPS}, all averaged over
  * every point (mean_over_samples=True).  Synchronises `stream`. */
 dyf_status dyf_ensemble_metrics(dyf_engine* engine, const float* preds_dev, const float* targets_dev, int32_t n_members,
-                                int64_t n_points, double* out_host, void* stream);
-/* Copy the last forecaster prediction x0_hat (NB,C,H,W) of the most recent dyf_sample call: the first element of the
- * tuple DYffusion.sample_loop returns (dyffusion.py:424-426). */
-dyf_status dyf_get_last_x0hat(dyf_engine* engine, float* out_dev, int32_t nb, void* stream);
+                                int64_t n_points, double* out_host, void* stream);   /* n_members <= 64 (members are staged in LDS) */
+/* Copy one (NB,C,H,W) field of the sampler's state after the most recent dyf_sample call: what sample_loop returns
+ * beside the intermediates (dyffusion.py:424-426): (x0_hat, ., x_s), or (x_s, ., x_interpolated_s_next) when the sampling
+ * schedule stops before T-1. */
+typedef enum dyf_sampler_state { DYF_STATE_X0_HAT = 0, DYF_STATE_X_S = 1, DYF_STATE_X_NEXT = 2 } dyf_sampler_state;
+dyf_status dyf_get_sampler_state(dyf_engine* engine, int32_t what, float* out_dev, int32_t nb, void* stream);
 
-/* ---- introspection used by bench.py / tests ------------------------------------------------------------------ */
+/* ---- introspection (bench.py FLOP accounting); timing / op-level test seams live in dyffusion_hip_testing.h ---------- */
 /* Number of network forwards one dyf_sample call performs under the current plan. */
 dyf_status dyf_plan_forward_counts(const dyf_engine* engine, int32_t* n_forecaster, int32_t* n_interpolator);
 /* 2*MAC of conv/linear layers of one forward of `net` for one sample (elementwise work excluded). */
 dyf_status dyf_net_flops(const dyf_engine* engine, int32_t net, double* flops_per_sample);
-/* Time the dominant conv kernel: average HIP-event duration (ms) of the conv layer `layer` (0..11, encoder then
- * decoder blocks) of `net` at batch nb over `iters` launches on `stream`; also returns its 2*MAC count. */
-dyf_status dyf_time_conv_layer(dyf_engine* engine, int32_t net, int32_t layer, int32_t nb, int32_t iters,
-                               void* stream, double* avg_ms, double* flops, double* algorithmic_bytes);
-
-/* Benchmark introspection: average duration (HIP events on `stream`) of the conv launch of decoder block `layer` (6..11)
- * over ONE eagerly launched rollout of the current plan (all forecaster + interpolator forwards, MC dropout as configured),
- * re-using the inputs of the last dyf_sample call.  `launches` receives the number of launches averaged. */
-dyf_status dyf_time_layer_in_rollout(dyf_engine* engine, int32_t layer, int32_t nb, void* stream, double* avg_ms,
-                                     int32_t* launches);
-
-/* ---- op-level seam (tests only): one Conv2d + fused epilogue on NHWC bf16 tensors ---------------------------- */
-/* x_dev (N,H,W,Cin) bf16 bits; w (Cout,Cin,kh,kw) host fp32; scale/shift (N,Cout) device fp32 or NULL;
- * y_dev (N,Ho,Wo,Cout) bf16 bits.  act: 0 none, 1 relu, 2 leaky(0.2).  path: 0 direct, 1 MFMA implicit GEMM. */
-dyf_status dyf_op_conv2d(dyf_engine* engine, const uint16_t* x_dev, const float* w_host, int32_t n, int32_t h,
-                         int32_t w, int32_t cin, int32_t cout, int32_t kh, int32_t kw, int32_t stride, int32_t pad,
-                         const float* scale_dev, const float* shift_dev, int32_t act, int32_t path, uint16_t* y_dev,
-                         void* stream);
-
-/* Upsample(x2, bilinear, align_corners=False) + Conv2d(3x3, pad 1) + epilogue in one kernel (phase-decomposed MFMA
- * implicit GEMM; unet_simple.py:40-52).  x_dev (N,H,W,Cin) bf16 -> y_dev (N,2H,2W,Cout) bf16. */
-dyf_status dyf_op_upconv2d(dyf_engine* engine, const uint16_t* x_dev, const float* w_host, int32_t n, int32_t h,
-                           int32_t w, int32_t cin, int32_t cout, const float* scale_dev, const float* shift_dev,
-                           int32_t act, uint16_t* y_dev, void* stream);
-
 /* Mean of the training criterion over `count` fp32 elements (src/utilities/utils.py:201-212 `get_loss`, reduction "mean"):
  * kind 0 = L1, 1 = MSE, 2 = smooth-L1 (beta 1).  The reduction the forecaster objective `DYffusion.p_losses`
  * (dyffusion.py:531,557) applies to (prediction, target); out_host[0] receives the scalar. */
 dyf_status dyf_criterion(dyf_engine* engine, const float* pred_dev, const float* target_dev, int64_t count, int32_t kind,
                          double* out_host, void* stream);
-
-/* LinearAttention core (attention.py:28-49, 4 heads of 32 channels): qkv_dev (N,HW,384) bf16 = to_qkv output ->
- * out_dev (N,HW,128) bf16 = softmax_d(q)*scale . (softmax_n(k) . v^T / HW), the input of to_out.  Runs the pixel-parallel
- * MFMA kernels the ResNet-UNet uses. */
-dyf_status dyf_op_linear_attention(dyf_engine* engine, const uint16_t* qkv_dev, int32_t n, int32_t hw, uint16_t* out_dev,
-                                   void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,55 @@
+/*
+ * dyffusion_hip_testing.h -- test / benchmark seams of libdyffusion_hip.so.  NOT part of the drop-in boundary
+ * (include/dyffusion_hip.h): op-level entry points for the kernel parity tests, per-layer timers for bench.py's roofline
+ * object, and activation read-back for per-layer parity analysis.  Same conventions as the public header.
+ */
+#ifndef DYFFUSION_HIP_TESTING_H
+#define DYFFUSION_HIP_TESTING_H
+
+#include "dyffusion_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Time the dominant conv kernel: average HIP-event duration (ms) of the conv layer `layer` (0..11, encoder then
+ * decoder blocks) of `net` at batch nb over `iters` launches on `stream`; also returns its 2*MAC count. */
+dyf_status dyf_time_conv_layer(dyf_engine* engine, int32_t net, int32_t layer, int32_t nb, int32_t iters,
+                               void* stream, double* avg_ms, double* flops, double* algorithmic_bytes);
+
+/* Benchmark introspection: average duration (HIP events on `stream`) of the conv launch of decoder block `layer` (6..11)
+ * over ONE eagerly launched rollout of the current plan (all forecaster + interpolator forwards, MC dropout as configured),
+ * re-using the inputs of the last dyf_sample call.  `launches` receives the number of launches averaged. */
+dyf_status dyf_time_layer_in_rollout(dyf_engine* engine, int32_t layer, int32_t nb, void* stream, double* avg_ms,
+                                     int32_t* launches);
+
+/* ---- op-level seam (tests only): one Conv2d + fused epilogue on NHWC bf16 tensors ---------------------------- */
+/* x_dev (N,H,W,Cin) bf16 bits; w (Cout,Cin,kh,kw) host fp32; scale/shift (N,Cout) device fp32 or NULL;
+ * y_dev (N,Ho,Wo,Cout) bf16 bits.  act: 0 none, 1 relu, 2 leaky(0.2).  path: 0 direct, 1 MFMA implicit GEMM. */
+dyf_status dyf_op_conv2d(dyf_engine* engine, const uint16_t* x_dev, const float* w_host, int32_t n, int32_t h,
+                         int32_t w, int32_t cin, int32_t cout, int32_t kh, int32_t kw, int32_t stride, int32_t pad,
+                         const float* scale_dev, const float* shift_dev, int32_t act, int32_t path, uint16_t* y_dev,
+                         void* stream);
+
+/* Upsample(x2, bilinear, align_corners=False) + Conv2d(3x3, pad 1) + epilogue in one kernel (phase-decomposed MFMA
+ * implicit GEMM; unet_simple.py:40-52).  x_dev (N,H,W,Cin) bf16 -> y_dev (N,2H,2W,Cout) bf16. */
+dyf_status dyf_op_upconv2d(dyf_engine* engine, const uint16_t* x_dev, const float* w_host, int32_t n, int32_t h,
+                           int32_t w, int32_t cin, int32_t cout, const float* scale_dev, const float* shift_dev,
+                           int32_t act, uint16_t* y_dev, void* stream);
+
+/* LinearAttention core (attention.py:28-49, 4 heads of 32 channels): qkv_dev (N,HW,384) bf16 = to_qkv output ->
+ * out_dev (N,HW,128) bf16 = softmax_d(q)*scale . (softmax_n(k) . v^T / HW), the input of to_out.  Runs the pixel-parallel
+ * MFMA kernels the ResNet-UNet uses. */
+dyf_status dyf_op_linear_attention(dyf_engine* engine, const uint16_t* qkv_dev, int32_t n, int32_t hw, uint16_t* out_dev,
+                                   void* stream);
+
+/* Read back the output of UNetBlock `layer` (0..11: encoder then decoder blocks) of the most recent unet_simple forward
+ * as fp32 NCHW (NB, cout, h, w) -- per-layer parity analysis against the oracle's taps (oracle/nets.py `taps=`).  The last
+ * decoder block is returned dense; positions its sparse-column form did not compute are NaN. */
+dyf_status dyf_debug_read_block_output(dyf_engine* engine, int32_t net, int32_t layer, int32_t nb, float* out_dev,
+                                       void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DYFFUSION_HIP_TESTING_H */

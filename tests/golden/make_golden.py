@@ -395,8 +395,64 @@ def gen_ckpt_keys():
     print("ckpt_keys:", len(out["forecasting"]), len(out["interpolation"]))
 
 
+# ------------------------------------------------------------------------------------------------ stochastic statistics
+def gen_ensemble_stats():
+    """SURVEY 8c "stochastic mode: ensemble mean/variance within sampling error of the oracle over >= 256 members".
+    The imported reference samples a 256-member ensemble (torch's own Bernoulli stream for the interpolator's MC dropout)
+    of a dim-64 unet_simple pair on a 23x11 grid (resampled to 64^2), h=4, cold + refine; per-pixel ensemble mean and
+    variance of every forecast field are stored.  (a) stats_ens256.npz.
+    (b) the same statistics for BASELINE config 2 at full size (NS 221x42, h=16), 8 members: per-horizon scalars in
+    fullsize_dropout_stats.json (mean / std over members and pixels, ensemble spread = sqrt(mean per-pixel variance))."""
+    mk = dict(dim=64, outer_sample_mode="bilinear", upsample_dims=[64, 64], with_time_emb=True, input_dropout=0.0,
+              dropout=0.15)
+    exp, ipol = ref_import.build_reference_dyffusion(system="navier-stokes", model="unet_simple", model_kwargs=mk,
+                                                     horizon=4, diffusion_kwargs=dict(enable_interpolator_dropout=True))
+    load_seeded(exp.model.model, seed=101)
+    load_seeded(ipol.model, seed=102)
+    g = torch.Generator().manual_seed(4)
+    x0 = torch.randn(1, 3, 23, 11, generator=g)
+    c = torch.rand(1, 2, 23, 11, generator=g)
+    N = 256
+    torch.manual_seed(1234)
+    outs = []
+    with torch.no_grad():
+        for _ in range(N // 64):
+            outs.append(exp.predict(x0.repeat(64, 1, 1, 1), condition=c.repeat(64, 1, 1, 1)))
+    arrs = dict(x0=x0.numpy(), c=c.numpy(), n_members=np.int64(N),
+                hp=json.dumps(dict(timesteps=4, model=mk, seeds=dict(forecaster=101, interpolator=102, inputs=4))))
+    for k in outs[0]:
+        v = torch.cat([o[k] for o in outs], 0).double()
+        arrs[f"mean::{k}"] = v.mean(0).float().numpy()
+        arrs[f"var::{k}"] = v.var(0, unbiased=True).float().numpy()
+        print(k, "ensemble mean std", float(v.mean(0).std()), "spread", float(v.var(0).mean().sqrt()))
+    np.savez_compressed(os.path.join(HERE, "stats_ens256.npz"), **arrs)
+
+    mk = dict(mk, upsample_dims=[256, 256])
+    exp, ipol = ref_import.build_reference_dyffusion(system="navier-stokes", model="unet_simple", model_kwargs=mk,
+                                                     horizon=16, diffusion_kwargs=dict(enable_interpolator_dropout=True))
+    load_seeded(exp.model.model, seed=101)
+    load_seeded(ipol.model, seed=102)
+    g = torch.Generator().manual_seed(1)
+    x0 = torch.randn(1, 3, 221, 42, generator=g)
+    c = torch.rand(1, 2, 221, 42, generator=g)
+    torch.manual_seed(4321)
+    M = 8
+    with torch.no_grad():
+        out = exp.predict(x0.repeat(M, 1, 1, 1), condition=c.repeat(M, 1, 1, 1))
+    res = dict(seeds=dict(forecaster=101, interpolator=102, inputs=1, torch=4321), n_members=M, model=mk, rollout={})
+    for k, v in out.items():
+        v = v.double()
+        res["rollout"][k] = dict(mean=float(v.mean()), std=float(v.std()), spread=float(v.var(0, unbiased=True).mean().sqrt()),
+                                 ens_mean_std=float(v.mean(0).std()))
+    with open(os.path.join(HERE, "fullsize_dropout_stats.json"), "w") as f:
+        json.dump(res, f, indent=1)
+    print("fullsize dropout stats:", {k: (round(v["std"], 4), round(v["spread"], 4)) for k, v in res["rollout"].items()})
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["schedules", "nets", "resnet", "samples", "fullsize", "metrics", "ckpt", "plosses"]
+    if "stats" in which:
+        gen_ensemble_stats()
     if "plosses" in which:
         gen_plosses()
     if "metrics" in which:

@@ -21,9 +21,24 @@ def test_shard_rows_balanced_and_complete():
     assert [b - a for a, b in (shard_rows(50, 8, r) for r in range(8))] == [7, 7, 6, 6, 6, 6, 6, 6]
 
 
-def _fake_rollout(x, c):
-    """Stands in for model.sample on CPU: every output row is a deterministic function of its own input row only."""
-    return {f"t{i}_preds": x * i + (0 if c is None else c.sum(1, keepdim=True)) for i in range(1, 4)}
+def _fake_rollout(x, c, row0=0):
+    """Stands in for model.sample on CPU: every output row is a deterministic function of its own input row and of its
+    GLOBAL row index (as the engine's row-keyed dropout streams are)."""
+    rows = torch.arange(row0, row0 + x.shape[0], dtype=x.dtype).view(-1, 1, 1, 1)
+    return {f"t{i}_preds": x * i + (0 if c is None else c.sum(1, keepdim=True)) + 0.125 * rows for i in range(1, 4)}
+
+
+class _FakeModel:
+    """Duck type of DYffusion for sample_sharded: `sample` + `set_row_offset`."""
+
+    def __init__(self):
+        self.row0 = 0
+
+    def set_row_offset(self, first_row):
+        self.row0 = int(first_row)
+
+    def sample(self, x, static_condition=None):
+        return _fake_rollout(x, static_condition, self.row0)
 
 
 def _worker(rank, world, port, nb, q):
@@ -33,7 +48,7 @@ def _worker(rank, world, port, nb, q):
     g = torch.Generator().manual_seed(0)
     x = torch.randn(nb, 3, 5, 4, generator=g)
     c = torch.rand(nb, 2, 5, 4, generator=g)
-    out = sample_sharded(_fake_rollout, x, c)
+    out = sample_sharded(_FakeModel(), x, c)
     want = _fake_rollout(x, c)
     ok = all(torch.equal(out[k], want[k]) for k in want) and sorted(out) == sorted(want)
     lo, hi = shard_rows(nb, world, rank)
@@ -44,7 +59,7 @@ def _worker(rank, world, port, nb, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("nb", [6, 7])  # even and uneven shards
+@pytest.mark.parametrize("nb", [6, 7, 1])  # even shards, uneven shards, a rank that owns no row
 def test_sharded_sampling_world2_gloo(nb):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))

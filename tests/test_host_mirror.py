@@ -89,7 +89,8 @@ def test_invalid_arguments_raise_like_reference():
 
 
 def test_library_exports_every_declared_symbol():
-    hdr = open(os.path.join(ROOT, "include", "dyffusion_hip.h")).read()
+    hdr = open(os.path.join(ROOT, "include", "dyffusion_hip.h")).read() + \
+        open(os.path.join(ROOT, "include", "dyffusion_hip_testing.h")).read()
     declared = set(re.findall(r"\b(dyf_[a-z0-9_]+)\s*\(", hdr))
     assert {"dyf_engine_create", "dyf_sample", "dyf_net_forward", "dyf_load_weights"} <= declared
     lib = ctypes.CDLL(_lib.LIB_PATH)
