@@ -11,3 +11,4 @@ from . import metrics  # noqa: F401
 from .unet import Unet  # noqa: F401
 from .unet_simple import UNet  # noqa: F401
 from .simple_conv_net import SimpleConvNet  # noqa: F401
+from .boundary import PhysicalSystemsBoundaryConditions  # noqa: F401

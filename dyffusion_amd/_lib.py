@@ -43,6 +43,15 @@ class Plan(C.Structure):
                 ("n_out_slots", C.c_int32), ("interpolator_dropout", C.c_int32), ("forecaster_dropout", C.c_int32)]
 
 
+class BcArgs(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("n_fields", C.c_int32), ("rows", C.c_int32), ("channels", C.c_int32),
+                ("height", C.c_int32), ("width", C.c_int32), ("n_meta", C.c_int32), ("row_meta_dev", C.c_void_p),
+                ("time_factor_dev", C.c_void_p), ("times_per_meta", C.c_int32), ("fixed_mask_dev", C.c_void_p),
+                ("in_velocity_dev", C.c_void_p), ("vertex_y_dev", C.c_void_p), ("boundary_dev", C.c_void_p)]
+
+
+BC_NAVIER_STOKES, BC_SPRING_MESH = 0, 1
+
 # every symbol include/dyffusion_hip.h and include/dyffusion_hip_testing.h declare: (name, restype, argtypes)
 _P = C.c_void_p
 SYMBOLS = [
@@ -68,6 +77,7 @@ SYMBOLS = [
     ("dyf_op_upconv2d", C.c_int, [_P, _P, _P] + [C.c_int32] * 5 + [_P, _P, C.c_int32, _P, _P]),
     ("dyf_op_linear_attention", C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, _P]),
     ("dyf_criterion", C.c_int, [_P, _P, _P, C.c_int64, C.c_int32, _P, _P]),
+    ("dyf_apply_boundary_conditions", C.c_int, [_P, C.POINTER(BcArgs), _P, _P]),
     ("dyf_debug_read_block_output", C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
 ]
 

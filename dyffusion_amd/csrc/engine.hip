@@ -1073,6 +1073,26 @@ dyf_status dyf_ensemble_metrics(dyf_engine* e, const float* preds_dev, const flo
     return DYF_OK;
 }
 
+dyf_status dyf_apply_boundary_conditions(dyf_engine* e, const dyf_bc_args* bc, float* preds_dev, void* stream) {
+    if (!e || !bc || !preds_dev) return fail(e, DYF_ERR_INVALID_ARGUMENT, "null argument");
+    if (bc->kind != DYF_BC_NAVIER_STOKES && bc->kind != DYF_BC_SPRING_MESH)
+        return fail(e, DYF_ERR_UNSUPPORTED, "Boundary conditions are implemented for navier-stokes and spring-mesh");  // as the reference
+    if (bc->n_fields < 1 || bc->rows < 1 || bc->channels < 1 || bc->height < 1 || bc->width < 1 || bc->n_meta < 1)
+        return fail(e, DYF_ERR_INVALID_ARGUMENT, "boundary conditions: bad geometry");
+    if (!bc->row_meta_dev || !bc->fixed_mask_dev) return fail(e, DYF_ERR_INVALID_ARGUMENT, "row_meta / fixed_mask must be given");
+    if (bc->kind == DYF_BC_NAVIER_STOKES && (!bc->in_velocity_dev || !bc->vertex_y_dev || !bc->time_factor_dev))
+        return fail(e, DYF_ERR_INVALID_ARGUMENT, "navier-stokes boundary conditions need in_velocity, vertex_y and time_factor");
+    if (bc->kind == DYF_BC_SPRING_MESH && !bc->boundary_dev)
+        return fail(e, DYF_ERR_INVALID_ARGUMENT, "spring-mesh boundary conditions need the boundary values");
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    BcArgs a{};
+    a.preds = preds_dev; a.kind = bc->kind; a.n_fields = bc->n_fields; a.rows = bc->rows; a.c = bc->channels; a.h = bc->height;
+    a.w = bc->width; a.n_meta = bc->n_meta; a.row_meta = bc->row_meta_dev; a.time_factor = bc->time_factor_dev; a.times_per_meta = bc->times_per_meta;
+    a.fixed_mask = bc->fixed_mask_dev; a.in_velocity = bc->in_velocity_dev; a.vertex_y = bc->vertex_y_dev; a.boundary = bc->boundary_dev;
+    HIP_TRY(e, launch_boundary_conditions(a, (hipStream_t)stream));
+    return DYF_OK;
+}
+
 dyf_status dyf_criterion(dyf_engine* e, const float* pred_dev, const float* target_dev, int64_t count, int32_t kind,
                          double* out_host, void* stream) {
     if (!e || !pred_dev || !target_dev || !out_host) return fail(e, DYF_ERR_INVALID_ARGUMENT, "null argument");

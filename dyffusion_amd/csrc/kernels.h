@@ -105,6 +105,21 @@ hipError_t launch_noisy_condition(float* out, const float* cond, const float* no
                                   int row_elems, uint32_t* rng_state, hipStream_t s);
 // rng_state (device): {seed_lo, seed_hi, forward counter, global index of the engine's batch row 0, noise-call counter, ...}
 #define DYF_RNG_STATE_WORDS 8
+
+// boundary conditions of the physical-systems benchmark on a (fields, rows, C, H, W) fp32 stack, in place (kernels.hip)
+struct BcArgs {
+    float* preds;
+    int kind;                    // 0 navier-stokes, 1 spring-mesh
+    int n_fields, rows, c, h, w, n_meta;
+    const int* row_meta;         // [rows]
+    const float* time_factor;    // [n_fields] or [n_fields][n_meta]: 1 - exp(-5 t)
+    int times_per_meta;
+    const uint8_t* fixed_mask;   // [n_meta][c][h][w]
+    const float* in_velocity;    // [n_meta]
+    const float* vertex_y;       // [n_meta][w]
+    const float* boundary;       // [n_meta][c][h][w]
+};
+hipError_t launch_boundary_conditions(const BcArgs& a, hipStream_t s);
 hipError_t launch_nhwc_to_nchw_f32(const bf16_t* src, int n, int h, int w, int w_store, int c, const int16_t* col_map,
                                    float* out, hipStream_t s);
 hipError_t launch_rng_begin_forward(uint32_t* rng_state, uint32_t* row_keys, int rows, int rows_per_fwd, hipStream_t s);

@@ -95,12 +95,55 @@ class InterpolationExperiment(nn.Module):
 
 
 class MultiHorizonForecastingDYffusion(nn.Module):
-    def __init__(self, model: DYffusion, num_predictions: int = 1, window: int = 1, horizon: Optional[int] = None):
+    """Caller contract of the hot path: `src/experiment_types/forecasting_multi_horizon.py` (AbstractMultiHorizonForecasting-
+    Experiment :20-229, MultiHorizonForecastingDYffusion :398-424) over `_base_experiment.py` (`predict` :315-379, ensemble
+    tiling / reshape :503-567, `evaluation_step` :484-492, `predict_step` :700-708), reduced to what drives `DYffusion.sample`.
+    `datamodule` is any object with the two methods `evaluation_step` touches: `boundary_conditions(preds, targets, metadata,
+    time)` and `get_boundary_condition_kwargs(batch, batch_idx, split)` (e.g. built on `PhysicalSystemsBoundaryConditions`)."""
+
+    def __init__(self, model: DYffusion, num_predictions: int = 1, window: int = 1, horizon: Optional[int] = None,
+                 autoregressive_steps: int = 0, prediction_horizon: Optional[int] = None, datamodule=None):
         super().__init__()
+        assert autoregressive_steps >= 0, f"Autoregressive steps must be >= 0, but is {autoregressive_steps}"
+        if autoregressive_steps > 0:
+            assert prediction_horizon is None, "Cannot use ``prediction_horizon`` with autoregressive_steps > 0"
         self.model = model
-        self.hparams = _AttrDict(num_predictions=num_predictions)
+        self.hparams = _AttrDict(num_predictions=num_predictions, autoregressive_steps=autoregressive_steps)
         self.window = window
         self.horizon = horizon or model.hparams.timesteps
+        self._prediction_horizon = prediction_horizon
+        self._datamodule = datamodule
+        self._predict_step_outputs = []
+
+    # ---- forecasting_multi_horizon.py:45-100
+    @property
+    def true_horizon(self) -> int:
+        return self.horizon
+
+    @property
+    def horizon_range(self):
+        return list(range(1, self.horizon + 1))
+
+    @property
+    def prediction_timesteps(self):
+        return self.horizon_range
+
+    @property
+    def prediction_horizon(self) -> int:
+        if self._prediction_horizon:
+            return self._prediction_horizon
+        return self.horizon * (self.hparams.autoregressive_steps + 1)
+
+    @property
+    def num_autoregressive_steps(self) -> int:
+        n = self.hparams.autoregressive_steps
+        if n == 0 and self._prediction_horizon is not None:
+            n = max(1, -(-self._prediction_horizon // self.true_horizon)) - 1
+        return n
+
+    @property
+    def datamodule(self):
+        return self._datamodule
 
     # _base_experiment.py:503-538 -- "N B ... -> (N B) ...": ensemble-major rows (row = n*B + b)
     def get_ensemble_inputs(self, inputs_raw: Optional[Tensor], num_predictions: Optional[int] = None) -> Optional[Tensor]:
@@ -112,69 +155,90 @@ class MultiHorizonForecastingDYffusion(nn.Module):
     # _base_experiment.py:315-379,540-567
     def predict(self, inputs: Tensor, num_predictions: Optional[int] = None, reshape_ensemble_dim: bool = True,
                 **kwargs) -> Dict[str, Tensor]:
-        n = num_predictions or self.hparams.num_predictions
-        results = self.model.predict_forward(inputs, num_predictions=n, **kwargs)
+        """`inputs` are already ensemble-tiled ((N*B, ...)); returns `t{i}_preds` reshaped to (N, B, ...).  As in the
+        reference, `num_predictions` only travels to the sampler; the reshape uses the module's own ensemble size."""
+        n = self.hparams.num_predictions
+        results = self.model.predict_forward(inputs, num_predictions=num_predictions or n, **kwargs)
         if torch.is_tensor(results):
             results = {"preds": results}
         if reshape_ensemble_dim:
-            for k, v in list(results.items()):
-                b = v.shape[0]
-                if "preds" in k and b > 1 and n > 1:
-                    assert b % n == 0, f"key={k}: b % #ens_mems = {b} % {n} != 0 ...Did you forget to create the input ensemble?"
-                    results[k] = v.reshape(n, max(1, b // n), *v.shape[1:])
+            first = next(v for k, v in results.items() if "preds" in k)
+            if first.shape[0] > 1 and n > 1 and first.shape[0] % n == 0:
+                for k, v in list(results.items()):
+                    if "targets" not in k and "true" not in k:
+                        b = v.shape[0]
+                        assert b % n == 0, f"key={k}: b % #ens_mems = {b} % {n} != 0 ...Did you forget to create the input ensemble?"
+                        results[k] = v.reshape(n, max(1, b // n), *v.shape[1:])
         return results
 
-    # forecasting_multi_horizon.py:337-342 + :282-332 (first prediction step: tile, sample, cache all horizons)
+    # _base_experiment.py:484-492
     @torch.no_grad()
-    def predict_step(self, batch: Dict[str, Any], batch_idx: int = 0, dataloader_idx: int = None) -> Dict[str, Any]:
-        dynamics = batch["dynamics"]
-        b = dynamics.shape[0]
-        inputs = dynamics[:, : self.window].reshape(b, -1, *dynamics.shape[-2:])  # "b window c h w -> b (window c) h w"
-        cond = batch.get("condition", None)
-        n = self.hparams.num_predictions
-        preds = self.predict(self.get_ensemble_inputs(inputs, n), condition=self.get_ensemble_inputs(cond, n),
-                             num_predictions=n)
-        return {k: v.detach().cpu().numpy() for k, v in preds.items()}
+    def evaluation_step(self, batch: Dict[str, Any], batch_idx: int = 0, split: str = "predict", **kwargs) -> Dict[str, Any]:
+        if self.datamodule is not None and "boundary_conditions" not in kwargs:
+            kwargs["boundary_conditions"] = self.datamodule.boundary_conditions
+            kwargs.update(self.datamodule.get_boundary_condition_kwargs(batch, batch_idx, split))
+        return self._evaluation_step(batch, batch_idx, split, **kwargs)
 
-    # forecasting_multi_horizon.py:114-229 (prediction branch): autoregressive outer loop.  Every outer iteration is
-    # one engine rollout (h fields); the last `window` predicted fields of every ensemble row become the next
-    # iteration's initial condition; rows stay independent, so the (N*B) rows never leave the GPU between iterations.
+    # forecasting_multi_horizon.py:114-229 (prediction branch; metrics belong to the training harness): autoregressive
+    # outer loop.  Every outer iteration is ONE engine rollout (all h fields at once -- the reference's per-horizon
+    # `get_preds_at_t_for_batch` pops them from a cache, :319-329); the last `window` predicted fields of every ensemble row
+    # become the next iteration's initial condition, so the (N*B) rows never leave the GPU between iterations.
     @torch.no_grad()
-    def evaluation_step(self, batch: Dict[str, Any], prediction_horizon: Optional[int] = None, boundary_conditions=None,
-                        t0: float = 0.0, dt: float = 1.0, return_targets: bool = True) -> Dict[str, Tensor]:
-        """Returns {"t{k}_preds": (N, B, C, H, W)} (and "t{k}_targets" when the batch holds them) for
-        k = 1..prediction_horizon.  `boundary_conditions(preds=, targets=, metadata=, time=)` is applied to every
-        predicted field before it is returned / fed back, exactly where the reference applies it."""
-        dynamics = batch["dynamics"]
-        b = dynamics.shape[0]
-        h = self.horizon
-        prediction_horizon = prediction_horizon or h
+    def _evaluation_step(self, batch: Dict[str, Any], batch_idx: int = 0, split: str = "predict", dataloader_idx: int = None,
+                         return_outputs: bool = True, boundary_conditions=None, t0=0.0, dt=1.0,
+                         prediction_horizon: Optional[int] = None, as_numpy: bool = False) -> Dict[str, Any]:
+        """Returns {"t{k}_targets": (B, C, H, W), "t{k}_preds": (N, B, C, H, W)} for k = 1..prediction_horizon (torch tensors on
+        the GPU, or numpy arrays like the reference with `as_numpy`).  `boundary_conditions(preds=, targets=, metadata=, time=)`
+        is applied to every predicted field before it is returned / fed back, exactly where the reference applies it."""
         if self.window != 1:
             raise NotImplementedError("autoregressive evaluation is implemented for window == 1 (the shipped configs)")
+        dynamics = batch["dynamics"].clone()
+        b = dynamics.shape[0]
+        h = self.true_horizon
+        prediction_horizon = prediction_horizon or self.prediction_horizon
+        n_outer = max(1, -(-prediction_horizon // h))  # = num_autoregressive_steps + 1 (forecasting_multi_horizon.py:71-76,141)
+        if dynamics.shape[1] < prediction_horizon:
+            raise ValueError(f"Prediction horizon {prediction_horizon} is larger than {dynamics.shape}[1]")
         n = self.hparams.num_predictions
-        n_outer = -(-prediction_horizon // h)
         cond = self.get_ensemble_inputs(batch.get("condition", None), n)
-        inputs = self.get_ensemble_inputs(dynamics[:, : self.window].reshape(b, -1, *dynamics.shape[-2:]), n)
-        out: Dict[str, Tensor] = {}
+        out: Dict[str, Any] = {}
+        conv = (lambda v: None if v is None else v.detach().cpu().numpy()) if as_numpy else (lambda v: v)
+        inputs = None
         total_t = t0
         for ar_step in range(n_outer):
-            preds = self.model.predict_forward(inputs, condition=cond, num_predictions=n)
+            if inputs is None:  # transform_inputs: "b window c lat lon -> b (window c) lat lon", then the ensemble tiling
+                inputs = self.get_ensemble_inputs(batch["dynamics"][:, : self.window].reshape(b, -1, *dynamics.shape[-2:]), n)
+            preds = self.predict(inputs, condition=cond, num_predictions=None if ar_step == 0 else 1)
             last = None
-            for t_step in range(1, h + 1):
+            for t_step in self.prediction_timesteps:
                 total_h = ar_step * h + t_step
                 if total_h > prediction_horizon:
                     break
-                total_t += dt
+                total_t = total_t + dt
                 p = preds[f"t{t_step}_preds"]
-                p = p.reshape(n, b, *p.shape[1:]) if n > 1 else p
-                tgt_idx = self.window + total_h - 1
-                targets = dynamics[:, tgt_idx] if tgt_idx < dynamics.shape[1] else None
+                targets = dynamics[:, self.window + total_h - 1]
                 if boundary_conditions is not None:
                     p = boundary_conditions(preds=p, targets=targets, metadata=batch.get("metadata", None), time=total_t)
-                out[f"t{total_h}_preds"] = p
-                if return_targets and targets is not None:
-                    out[f"t{total_h}_targets"] = targets
+                if return_outputs:
+                    out[f"t{total_h}_targets"] = conv(targets)
+                    out[f"t{total_h}_preds"] = conv(p)
                 last = p
             if ar_step < n_outer - 1:  # "N B c h w -> (N B) c h w": next initial condition, already ensemble-tiled
                 inputs = last.reshape(-1, *last.shape[-3:]).contiguous()
+                batch["dynamics"] *= 1e6  # as the reference: "become completely dummy after first multistep prediction"
         return out
+
+    # _base_experiment.py:700-708
+    def predict_step(self, batch: Dict[str, Any], batch_idx: int = 0, dataloader_idx: int = None, **kwargs) -> None:
+        results = self.evaluation_step(batch, batch_idx, split="predict", as_numpy=True, **kwargs)
+        self._predict_step_outputs.append(results)
+
+    def on_predict_epoch_end(self) -> Dict[str, Any]:
+        """Concatenate the per-batch outputs along the batch dimension (predictions: dim 1 of (N, B, ...))."""
+        import numpy as np
+
+        outs, self._predict_step_outputs = self._predict_step_outputs, []
+        if not outs:
+            return {}
+        return {k: np.concatenate([o[k] for o in outs], axis=1 if ("preds" in k and outs[0][k].ndim == 5) else 0)
+                for k in outs[0]}

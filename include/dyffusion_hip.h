@@ -161,6 +161,29 @@ dyf_status dyf_ensemble_metrics(dyf_engine* engine, const float* preds_dev, cons
 typedef enum dyf_sampler_state { DYF_STATE_X0_HAT = 0, DYF_STATE_X_S = 1, DYF_STATE_X_NEXT = 2 } dyf_sampler_state;
 dyf_status dyf_get_sampler_state(dyf_engine* engine, int32_t what, float* out_dev, int32_t nb, void* stream);
 
+/* ---- boundary conditions of the physical-systems benchmark -------------------------------------------------------------- */
+/* Replaces PhysicalSystemsBenchmarkDataModule.boundary_conditions (src/datamodules/physical_systems_benchmark.py:245-297:
+ * a Python loop over batch elements with boolean-mask writes), which _evaluation_step applies to every predicted field
+ * before it is returned / fed back (src/experiment_types/forecasting_multi_horizon.py:175-182), by ONE masked write over a
+ * (n_fields, rows, C, H, W) fp32 stack, in place.  row_meta_dev[row] = batch element whose metadata applies to the row, -1 =
+ * untouched (the host resolves the reference's indexing of ensemble stacks).  navier-stokes: preds[fixed_mask] = 0, then
+ * channel 0 of grid row 0 = in_velocity*4*y*(0.41-y)/0.41^2*(1-exp(-5t)); spring-mesh: preds = where(fixed_mask, boundary). */
+typedef enum dyf_bc_kind { DYF_BC_NAVIER_STOKES = 0, DYF_BC_SPRING_MESH = 1 } dyf_bc_kind;
+typedef struct dyf_bc_args {
+    int32_t kind;                  /* dyf_bc_kind */
+    int32_t n_fields, rows, channels, height, width;
+    int32_t n_meta;                /* batch elements the metadata tensors hold */
+    const int32_t* row_meta_dev;   /* [rows] */
+    const float* time_factor_dev;  /* navier-stokes: 1 - exp(-5 t) of every field (t = its physical time; evaluated by the host
+                                    * in double like the reference's math.exp), [n_fields] or [n_fields][n_meta] */
+    int32_t times_per_meta;        /* 0 / 1 */
+    const uint8_t* fixed_mask_dev; /* [n_meta][C][H][W], non-zero = fixed */
+    const float* in_velocity_dev;  /* navier-stokes [n_meta] */
+    const float* vertex_y_dev;     /* navier-stokes [n_meta][W]: metadata["vertices"][:, 1, 0, :] */
+    const float* boundary_dev;     /* spring-mesh [n_meta][C][H][W]: cat[zeros (p), features[:, 0, 2:] (q)] */
+} dyf_bc_args;
+dyf_status dyf_apply_boundary_conditions(dyf_engine* engine, const dyf_bc_args* args, float* preds_dev, void* stream);
+
 /* ---- introspection (bench.py FLOP accounting); timing / op-level test seams live in dyffusion_hip_testing.h ---------- */
 /* Number of network forwards one dyf_sample call performs under the current plan. */
 dyf_status dyf_plan_forward_counts(const dyf_engine* engine, int32_t* n_forecaster, int32_t* n_interpolator);

@@ -395,6 +395,104 @@ def gen_ckpt_keys():
     print("ckpt_keys:", len(out["forecasting"]), len(out["interpolation"]))
 
 
+# ------------------------------------------------------------------------------------------------ boundary conditions
+def gen_boundary():
+    """`PhysicalSystemsBenchmarkDataModule.boundary_conditions` of the imported reference
+    (src/datamodules/physical_systems_benchmark.py:245-297) on seeded inputs.  Stored: the metadata, the seed of the
+    prediction tensor, and the (flat index, value) pairs of every element the reference changed -- all other elements must
+    come back untouched.  Cases: NS (B,3,221,42) with a float time; NS ensemble stack (N,B,...) with per-batch times (the
+    reference's first-dimension indexing); spring-mesh (B,4,10,10) and (N,B,4,10,10)."""
+    from types import SimpleNamespace
+    from src.datamodules.physical_systems_benchmark import PhysicalSystemsBenchmarkDataModule as DM
+
+    def run(system, shape, B, time, seed):
+        g = torch.Generator().manual_seed(seed)
+        preds = torch.randn(*shape, generator=g)
+        C, Hh, Ww = shape[-3:]
+        meta = {"fixed_mask": torch.rand(B, C, Hh, Ww, generator=g) < 0.04}
+        if system == "navier-stokes":
+            meta["in_velocity"] = 0.5 + torch.rand(B, generator=g)
+            vert = torch.zeros(B, 2, Hh, Ww)
+            vert[:, 1] = (torch.linspace(0.0, 0.41, Ww)[None, None, :] + 0.001 * torch.rand(B, 1, Ww, generator=g)).expand(B, Hh, Ww)
+            vert[:, 0] = torch.linspace(0.0, 2.2, Hh)[None, :, None]
+            meta["vertices"] = vert
+        else:
+            meta["features"] = torch.randn(B, 5, 4, Hh, Ww, generator=g)
+        targets = torch.zeros(B, C, Hh, Ww)
+        fake = SimpleNamespace(hparams=SimpleNamespace(physical_system=system))
+        before = preds.clone()
+        out = DM.boundary_conditions(fake, preds, targets, meta, time=time)
+        changed = (out != before).reshape(-1).nonzero().reshape(-1)
+        arrs = dict(system=system, shape=np.array(shape), B=np.int64(B), seed=np.int64(seed),
+                    fixed_mask=np.packbits(meta["fixed_mask"].numpy()), changed_idx=changed.numpy().astype(np.int64),
+                    changed_val=out.reshape(-1)[changed].numpy(),
+                    time=np.array(time if not torch.is_tensor(time) else time.numpy(), dtype=np.float64))
+        if system == "navier-stokes":
+            arrs.update(in_velocity=meta["in_velocity"].numpy(), vertex_y=meta["vertices"][:, 1, 0, :].numpy())
+        else:
+            arrs.update(base_q=meta["features"][:, 0, 2:].numpy())
+        print(system, shape, "changed", int(changed.numel()), "of", out.numel())
+        return arrs
+
+    np.savez_compressed(os.path.join(HERE, "boundary_ns_b2.npz"), **run("navier-stokes", (2, 3, 221, 42), 2, 0.37, 51))
+    np.savez_compressed(os.path.join(HERE, "boundary_ns_n3b2.npz"),
+                        **run("navier-stokes", (3, 2, 3, 221, 42), 2, torch.tensor([0.2, 1.5]), 52))
+    np.savez_compressed(os.path.join(HERE, "boundary_spring_b3.npz"), **run("spring-mesh", (3, 4, 10, 10), 3, 1.0, 53))
+    np.savez_compressed(os.path.join(HERE, "boundary_spring_n2b3.npz"), **run("spring-mesh", (2, 3, 4, 10, 10), 3, 1.0, 54))
+
+
+# ------------------------------------------------------------------------------------------------ caller contract (C1, 8f-1)
+def gen_predict_step():
+    """`predict_step` of the imported reference (`_base_experiment.py:700-703` -> `evaluation_step` :484-492 ->
+    `_evaluation_step`, forecasting_multi_horizon.py:114-229): spring-mesh batch, N=3 ensemble members, horizon 4 with one
+    autoregressive step (prediction horizon 8), the datamodule's boundary conditions applied to every field.
+    Stored: the batch, both networks' weights and every array predict_step appends to `_predict_step_outputs`."""
+    from types import SimpleNamespace
+    from src.datamodules.physical_systems_benchmark import PhysicalSystemsBenchmarkDataModule as DM
+
+    base_model = dict(dim=4, outer_sample_mode="bilinear", upsample_dims=[64, 64], with_time_emb=True,
+                      input_dropout=0.0, dropout=0.2)
+    N, B, h = 3, 2, 4
+    exp, ipol = ref_import.build_reference_dyffusion(system="spring-mesh", model="unet_simple", model_kwargs=base_model,
+                                                     horizon=h, diffusion_kwargs=dict(enable_interpolator_dropout=False),
+                                                     num_predictions=N)
+    load_seeded(exp.model.model, seed=21)
+    load_seeded(ipol.model, seed=22)
+    exp.hparams.autoregressive_steps = 1
+    assert exp.prediction_horizon == 2 * h and exp.num_autoregressive_steps == 1
+    fake = SimpleNamespace(hparams=SimpleNamespace(physical_system="spring-mesh"))
+
+    class FakeDM:  # the two datamodule methods evaluation_step touches (_base_experiment.py:486-488)
+        def boundary_conditions(self, preds, targets, metadata, time=None):
+            return DM.boundary_conditions(fake, preds, targets, metadata, time=time)
+
+        def get_boundary_condition_kwargs(self, batch, batch_idx, split):
+            return dict(t0=0.0, dt=1.0)
+
+    exp._datamodule = FakeDM()
+    g = torch.Generator().manual_seed(3)
+    dyn = torch.randn(B, 1 + 2 * h, 4, 10, 10, generator=g)
+    cond = torch.rand(B, 1, 10, 10, generator=g)
+    fixed = torch.rand(B, 4, 10, 10, generator=g) < 0.1
+    feats = torch.randn(B, 5, 4, 10, 10, generator=g)
+    batch = {"dynamics": dyn.clone(), "condition": cond, "metadata": {"fixed_mask": fixed, "features": feats}}
+    exp._predict_step_outputs = []
+    with torch.no_grad():
+        ret = exp.predict_step(batch, 0)
+    assert ret is None and len(exp._predict_step_outputs) == 1
+    res = exp._predict_step_outputs[0]
+    arrs = {f"out::{k}": np.asarray(v) for k, v in res.items()}
+    arrs.update({f"F::{k}": v.numpy() for k, v in exp.model.model.state_dict().items()})
+    arrs.update({f"I::{k}": v.numpy() for k, v in ipol.model.state_dict().items()})
+    hp = dict(timesteps=h, num_input_channels=4, num_predictions=N, B=B, model=base_model, prediction_horizon=2 * h,
+              schedule="before_t1_only", interpolate_before_t1=True, sampling_type="cold", time_encoding="dynamics",
+              refine_intermediate_predictions=True, forward_conditioning="none", enable_interpolator_dropout=False)
+    np.savez_compressed(os.path.join(HERE, "predict_step_spring_ar2.npz"), dynamics=dyn.numpy(), condition=cond.numpy(),
+                        fixed_mask=fixed.numpy(), base_q=feats[:, 0, 2:].numpy(), hp=json.dumps(hp), **arrs)
+    print("predict_step_spring_ar2:", {k: v.shape for k, v in res.items() if k in ("t1_preds", "t8_preds", "t8_targets")},
+          "dynamics scaled by", float(batch["dynamics"].abs().mean() / dyn.abs().mean()))
+
+
 # ------------------------------------------------------------------------------------------------ stochastic statistics
 def gen_ensemble_stats():
     """SURVEY 8c "stochastic mode: ensemble mean/variance within sampling error of the oracle over >= 256 members".
@@ -450,9 +548,13 @@ def gen_ensemble_stats():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["schedules", "nets", "resnet", "samples", "fullsize", "metrics", "ckpt", "plosses"]
+    which = sys.argv[1:] or ["schedules", "nets", "resnet", "samples", "fullsize", "metrics", "ckpt", "plosses", "stats", "boundary", "predict_step"]
     if "stats" in which:
         gen_ensemble_stats()
+    if "boundary" in which:
+        gen_boundary()
+    if "predict_step" in which:
+        gen_predict_step()
     if "plosses" in which:
         gen_plosses()
     if "metrics" in which:

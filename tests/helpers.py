@@ -32,3 +32,28 @@ def max_abs(a, b):
 def jload(name):
     with open(os.path.join(GOLDEN, name)) as f:
         return json.load(f)
+
+
+def boundary_case(name):
+    """Rebuild the inputs of a boundary_*.npz fixture (tests/golden/make_golden.py::gen_boundary): returns
+    (system, preds, targets, metadata, time, expected) with `expected` = the imported reference's output."""
+    z = load_npz(name + ".npz")
+    system, shape, B = str(z["system"]), tuple(int(v) for v in z["shape"]), int(z["B"])
+    C, Hh, Ww = shape[-3:]
+    g = torch.Generator().manual_seed(int(z["seed"]))
+    preds = torch.randn(*shape, generator=g)
+    fixed = torch.from_numpy(np.unpackbits(z["fixed_mask"])[: B * C * Hh * Ww].reshape(B, C, Hh, Ww).astype(bool))
+    meta = {"fixed_mask": fixed}
+    if system == "navier-stokes":
+        vert = torch.zeros(B, 2, Hh, Ww)
+        vert[:, 1] = torch.from_numpy(z["vertex_y"])[:, None, :].expand(B, Hh, Ww)
+        meta.update(in_velocity=torch.from_numpy(z["in_velocity"]), vertices=vert)
+    else:
+        feat = torch.zeros(B, 5, 4, Hh, Ww)
+        feat[:, 0, 2:] = torch.from_numpy(z["base_q"])
+        meta["features"] = feat
+    t = z["time"]
+    time = float(t) if t.ndim == 0 else torch.from_numpy(t.astype(np.float32))
+    expected = preds.clone().reshape(-1)
+    expected[torch.from_numpy(z["changed_idx"])] = torch.from_numpy(z["changed_val"])
+    return system, preds, torch.zeros(B, C, Hh, Ww), meta, time, expected.reshape(shape)

@@ -1,0 +1,68 @@
+"""-m gpu: the N>1 path end to end on ONE GPU: two ranks (gloo rendezvous on 127.0.0.1, both engines on cuda:0) run
+`sample_sharded` with MC dropout on -- row sharding, global-row dropout streams, padded uneven shards, the all-gather of the
+forecast stack -- and must reproduce, BIT FOR BIT, what a single process samples for the whole batch (results
+are invariant to the number of GPUs).  RCCL itself needs one device per rank; the driver's multi-GPU bench covers it."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+HP = dict(timesteps=4, forward_conditioning="none", interpolate_before_t1=True, schedule="before_t1_only",
+          sampling_type="cold", refine_intermediate_predictions=True, enable_interpolator_dropout=True)
+MK = dict(dim=64, upsample_dims=[64, 64], outer_sample_mode="bilinear", with_time_emb=True, dropout=0.15)
+
+
+def _inputs(nb):
+    g = torch.Generator().manual_seed(77)
+    return torch.randn(nb, 3, 23, 11, generator=g), torch.rand(nb, 2, 23, 11, generator=g)
+
+
+def _model(max_batch):
+    from tests.gpu_common import build_dyffusion, seeded_pair
+    PF, PI = seeded_pair(64, 3, 2)
+    m = build_dyffusion(PF, PI, MK, 3, 2, HP, max_batch=max_batch)
+    m.seed(31337)
+    return m
+
+
+def _worker(rank, world, port, nb, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from dyffusion_amd.distributed import sample_sharded
+    torch.cuda.set_device(0)
+    x0, c = _inputs(nb)
+    out = sample_sharded(_model(nb), x0.cuda(), c.cuda())
+    if rank == 0:
+        q.put({k: v.cpu() for k, v in out.items()})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("nb", [6, 5])  # even shards (3 + 3), uneven shards (3 + 2: rank 1 repeats a row, dropped after the gather)
+def test_two_ranks_reproduce_the_single_process_fields_bitwise(nb):
+    x0, c = _inputs(nb)
+    want = {k: v.cpu() for k, v in _model(nb).sample(x0.cuda(), static_condition=c.cuda()).items()}
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, nb, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert sorted(got) == sorted(want)
+    for k in want:
+        assert got[k].shape == want[k].shape == (nb, 3, 23, 11)
+        assert torch.equal(got[k], want[k]), (k, float((got[k] - want[k]).abs().max()))
+    # MC dropout is on: the rows really are different members
+    assert not torch.equal(want["t4_preds"][0], want["t4_preds"][1])

@@ -1,0 +1,88 @@
+"""-m gpu: the caller contract of the hot path on the engine, against outputs of the imported reference.
+
+  * `MultiHorizonForecastingDYffusion.predict()` (`_base_experiment.py:315-379`): ensemble-tiled inputs -> `t{i}_preds`
+    reshaped to (N, B, ...), ensemble-major -- golden `sample_ens3` (N=3, B=2).
+  * `predict_step()` (`_base_experiment.py:700-703` -> `evaluation_step` -> `_evaluation_step`,
+    forecasting_multi_horizon.py:114-229): numpy outputs appended to `_predict_step_outputs`, targets next to predictions,
+    TWO autoregressive outer iterations re-feeding t4, the datamodule's spring-mesh boundary conditions applied to every
+    field on the device, the batch's dynamics scaled by 1e6 afterwards -- golden `predict_step_spring_ar2`.
+"""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+import dyffusion_amd as D
+from tests.gpu_common import DEV, build_dyffusion
+from tests.helpers import load_npz, rel_rms, split_state
+
+pytestmark = pytest.mark.gpu
+TOL = 3e-2
+
+
+def test_predict_matches_reference_golden_ensemble_layout():
+    z = load_npz("sample_ens3.npz")
+    hp = json.loads(str(z["hp"]))
+    N, B = hp["num_predictions"], hp["B"]
+    m = build_dyffusion(split_state(z, "F"), split_state(z, "I"), hp["model"], 4, 1, hp, max_batch=N * B)
+    exp = D.MultiHorizonForecastingDYffusion(m, num_predictions=N)
+    x0, c = torch.from_numpy(z["x0"]).to(DEV), torch.from_numpy(z["c"]).to(DEV)
+    out = exp.predict(exp.get_ensemble_inputs(x0), condition=exp.get_ensemble_inputs(c))
+    want = {k[len("out::"):]: v for k, v in z.items() if k.startswith("out::")}
+    assert sorted(out) == sorted(want)
+    for k, w in want.items():
+        assert tuple(out[k].shape) == w.shape == (N, B, 4, 10, 10), k
+        assert rel_rms(out[k].cpu(), w) <= TOL, k
+    # dropout is off in this fixture: the N members of one batch item are identical, batch items differ (ensemble-major rows)
+    assert torch.equal(out["t4_preds"][0], out["t4_preds"][2]) and not torch.equal(out["t4_preds"][0, 0], out["t4_preds"][0, 1])
+    flat = exp.predict(exp.get_ensemble_inputs(x0), condition=exp.get_ensemble_inputs(c), reshape_ensemble_dim=False)
+    assert tuple(flat["t4_preds"].shape) == (N * B, 4, 10, 10)
+    assert torch.equal(flat["t4_preds"].reshape(N, B, 4, 10, 10), out["t4_preds"])
+
+
+class _SpringDataModule:
+    """The two datamodule methods `evaluation_step` touches (_base_experiment.py:486-488), on the device op."""
+
+    def __init__(self, engine):
+        self.bc = D.PhysicalSystemsBoundaryConditions("spring-mesh", engine)
+
+    def boundary_conditions(self, preds, targets, metadata, time=None):
+        return self.bc(preds=preds, targets=targets, metadata=metadata, time=time)
+
+    def get_boundary_condition_kwargs(self, batch, batch_idx, split):
+        return dict(t0=0.0, dt=1.0)
+
+
+def test_predict_step_autoregressive_with_boundary_conditions_matches_reference_golden():
+    z = load_npz("predict_step_spring_ar2.npz")
+    hp = json.loads(str(z["hp"]))
+    N, B, h = hp["num_predictions"], hp["B"], hp["timesteps"]
+    m = build_dyffusion(split_state(z, "F"), split_state(z, "I"), hp["model"], 4, 1, hp, max_batch=N * B)
+    eng = m._ensure_engine((10, 10), N * B)
+    exp = D.MultiHorizonForecastingDYffusion(m, num_predictions=N, autoregressive_steps=1, datamodule=_SpringDataModule(eng))
+    assert exp.prediction_horizon == 2 * h == hp["prediction_horizon"] and exp.num_autoregressive_steps == 1
+    feats = torch.zeros(B, 5, 4, 10, 10)
+    feats[:, 0, 2:] = torch.from_numpy(z["base_q"])
+    dyn = torch.from_numpy(z["dynamics"]).to(DEV)
+    batch = {"dynamics": dyn.clone(), "condition": torch.from_numpy(z["condition"]).to(DEV),
+             "metadata": {"fixed_mask": torch.from_numpy(z["fixed_mask"]), "features": feats}}
+    assert exp.predict_step(batch, 0) is None  # like the reference: results are collected, not returned
+    got = exp._predict_step_outputs[0]
+    want = {k[len("out::"):]: v for k, v in z.items() if k.startswith("out::")}
+    assert list(got) == list(want)  # same keys in the same order: t1_targets, t1_preds, ..., t8_targets, t8_preds
+    worst = 0.0
+    fixed = z["fixed_mask"]
+    for k, w in want.items():
+        assert isinstance(got[k], np.ndarray) and got[k].shape == w.shape, k
+        if k.endswith("targets"):
+            assert np.array_equal(got[k], w), k
+            continue
+        worst = max(worst, rel_rms(got[k], w))
+        # boundary values are written, not computed: exact on every fixed node of every member (rows n*B + b -> metadata b)
+        assert np.array_equal(got[k][:, fixed], w[:, fixed]), k
+    print("predict_step (2 x h=4, spring BC) worst rel-rms", worst)
+    assert worst <= 4e-2
+    assert torch.allclose(batch["dynamics"], dyn * 1e6)  # forecasting_multi_horizon.py:221
+    merged = exp.on_predict_epoch_end()
+    assert merged["t8_preds"].shape == (N, B, 4, 10, 10) and exp._predict_step_outputs == []
