@@ -215,6 +215,62 @@ def unet_simple_forward(P: Dict[str, Tensor], cfg: dict, inputs: Tensor, time: O
     return F.interpolate(x, size=tuple(native_hw), mode=mode)
 
 
+def _r16(x: Tensor) -> Tensor:
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+def unet_simple_forward_bf16_model(P: Dict[str, Tensor], cfg: dict, inputs: Tensor, time: Optional[Tensor] = None,
+                                   condition: Optional[Tensor] = None, dropout=None, round_act: bool = True,
+                                   round_w: bool = True, taps: Optional[dict] = None) -> Tensor:
+    """`unet_simple_forward` in the ARITHMETIC MODEL of the HIP engine: fp32 convolutions on bf16-rounded operands, every
+    block output rounded to bf16 ONCE (after the fused norm / FiLM / activation / dropout epilogue), fp32 everything else.
+    Not a restatement of the reference -- a measuring stick: the gap between this and `unet_simple_forward` is what bf16
+    storage costs by itself (tools/bf16_drift.py), the gap between the engine and this is the engine's own error."""
+    dropout = dropout or DropoutOff()
+    ra = _r16 if round_act else (lambda v: v)
+    rw = _r16 if round_w else (lambda v: v)
+    dim = cfg["dim"]
+    x = torch.cat([inputs, condition], dim=1) if condition is not None else inputs
+    temb = time_embedding(P, "time_emb_mlp", time, dim) if cfg.get("with_time_emb", False) else None
+    native_hw = x.shape[-2:]
+    if cfg.get("upsample_dims") is not None:
+        x = F.interpolate(x, size=tuple(cfg["upsample_dims"]), mode="bilinear")
+    x = ra(x)  # the resampled raw channels are stored in bf16; init_conv is composed into the first encoder conv
+    x = F.conv2d(x, P["init_conv.weight"], P["init_conv.bias"])
+    enc, dec = unet_simple_layout(dim)
+    p_drop = cfg.get("dropout", 0.0)
+    skips = []
+    for li, (_, _, k, s, pad, norm, act) in enumerate(enc):
+        pre = f"input_ops.{li}"
+        x = F.conv2d(x, rw(P[f"{pre}.ops.0.weight"]), P[f"{pre}.ops.0.bias"], stride=s, padding=pad)
+        x = _norm(P, f"{pre}.ops.1", x, norm)
+        if temb is not None:
+            scale, shift = film(P, f"{pre}.time_mlp", temb)
+            x = x * (scale + 1) + shift
+        x = ra(dropout.apply(F.leaky_relu(x, LEAKY_SLOPE), p_drop))
+        skips.append(x)
+        if taps is not None:
+            taps[f"enc{li}"] = x
+    x = skips.pop()
+    for li, (_, _, k, s, pad, norm, act) in enumerate(dec):
+        pre = f"output_ops.{li}"
+        x = F.interpolate(x, scale_factor=2, mode="bilinear")
+        if li < 3:
+            x = ra(x)  # the small planes materialise the upsampled tensor (bf16); the large ones fuse it into the conv
+        x = F.conv2d(x, rw(P[f"{pre}.ops.1.weight"]), P[f"{pre}.ops.1.bias"], stride=1, padding=pad)
+        x = _norm(P, f"{pre}.ops.2", x, norm)
+        if temb is not None:
+            scale, shift = film(P, f"{pre}.time_mlp", temb)
+            x = x * (scale + 1) + shift
+        x = ra(dropout.apply(F.relu(x), p_drop))
+        if taps is not None:
+            taps[f"dec{li}"] = x
+        if skips:
+            x = torch.cat([x, skips.pop()], dim=1)
+    x = F.conv_transpose2d(x, rw(P["readout.0.weight"]), P["readout.0.bias"], stride=2, padding=1)
+    return F.interpolate(x, size=tuple(native_hw), mode="bilinear")
+
+
 # ----------------------------------------------------------------------------- SimpleConvNet (spring-mesh plumbing)
 def simple_conv_net_forward(P: Dict[str, Tensor], cfg: dict, inputs: Tensor, time: Optional[Tensor] = None,
                             condition: Optional[Tensor] = None, dropout=None) -> Tensor:

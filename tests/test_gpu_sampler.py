@@ -1,7 +1,13 @@
 """-m gpu: dyf_sample (HIP, hipGraph) against the reference's golden rollouts and the oracle.
 
-Tolerance (stated): rel-RMS <= 3e-2 per forecast field over a rollout (bf16 activations, fp32 state x_s and fp32
-cold-sampling update); measured values are printed.
+Tolerance (stated): rel-RMS <= 2.5e-2 per forecast field over a rollout for the bf16 engine (bf16 operands and block
+outputs, fp32 accumulation, fp32 sampler state and cold-sampling update); measured values are printed (7.5e-3 - 2.1e-2).
+Why not SURVEY 8c's 1e-2: that figure rested on "the reference's own bf16-autocast drift is 3.5e-3 - 4.5e-3"; measured on
+the full-size fixture G6 (tools/bf16_drift.py, profiles/r02_bf16_drift.json) the reference under torch.autocast(bf16)
+drifts 3.1e-2 - 4.1e-2 from its fp32 self over the h=16 rollout, bf16-rounded weights ALONE give 1.1e-2 - 1.4e-2, and the
+oracle evaluated with the engine's rounding points (`nets.unet_simple_forward_bf16_model`) 1.7e-2 - 2.1e-2 -- which is what
+the engine measures, layer by layer (`test_fullsize_engine_error_is_the_bf16_storage_error`).  The fp16 build of the same
+kernels (11-bit mantissa) is held to 1e-2 (tests/test_gpu_fp16.py).
 """
 import json
 
@@ -14,7 +20,7 @@ from tests.gpu_common import DEV, build_dyffusion, nhwc_masks, oracle_rollout, s
 from tests.helpers import jload, load_npz, rel_rms, split_state
 
 pytestmark = pytest.mark.gpu
-TOL = 3e-2
+TOL = 2.5e-2
 
 NAMES = ["sample_cold_refine", "sample_cold_norefine", "sample_naive", "sample_k2_data", "sample_k2_coldlast",
          "sample_k2_onlydyn", "sample_k2_plus2", "sample_ens3", "sample_dropout", "sample_datanoise", "sample_linear"]
@@ -94,6 +100,45 @@ def test_fullsize_ns_rollout_matches_reference_fields():
     assert max(errs.values()) <= TOL
     for k, want in meta["rollout"].items():
         assert abs(float(out[k].mean()) - want["mean"]) <= 0.02 * max(1.0, want["std"]), k
+
+
+def test_fullsize_engine_error_is_the_bf16_storage_error():
+    """Per block of one full-size interpolator forward and over the h=16 rollout: the engine's distance from the fp32 oracle
+    is the distance of the oracle's own bf16 arithmetic model (same rounding points, fp32 everywhere else) -- no layer of
+    the engine adds error beyond bf16 storage.  Allowed: 1.25 x the model's error (rounding ties fall differently)."""
+    meta = jload("fullsize_checksums.json")
+    mk = meta["model"]
+    PF, PI = seeded_pair(64, 3, 2, seeds=(meta["seeds"]["forecaster"], meta["seeds"]["interpolator"]))
+    g = torch.Generator().manual_seed(meta["seeds"]["inputs"])
+    x0, c = torch.randn(1, 3, 221, 42, generator=g), torch.rand(1, 2, 221, 42, generator=g)
+    from tests.gpu_common import mirror_from_params
+    net = mirror_from_params(PI, mk, 6, 2, 3)
+    xin, t = torch.cat([x0, 0.5 * x0.flip(-1) + 0.1], 1), torch.tensor([5.0])
+    y = net(xin.to(DEV), time=t.to(DEV), condition=c.to(DEV)).cpu()
+    taps32, taps16 = {}, {}
+    with torch.no_grad():
+        y32 = nets.unet_simple_forward(PI, mk, xin, t, c, taps=taps32)
+        y16 = nets.unet_simple_forward_bf16_model(PI, mk, xin, t, c, taps=taps16)
+    for li, nm in enumerate([f"enc{i}" for i in range(6)] + [f"dec{i}" for i in range(6)]):
+        a = net._engine.read_block_output(0, li, 1).cpu()
+        ok = torch.isfinite(a)  # the last decoder block computes only the columns the readout reads
+        e_eng, e_model = rel_rms(a[ok], taps32[nm][ok]), rel_rms(taps16[nm][ok], taps32[nm][ok])
+        print(f"{nm}: engine {e_eng:.2e}  bf16 model {e_model:.2e}  ({float(ok.float().mean()):.2f} of the block computed)")
+        assert e_eng <= 1.25 * e_model + 2e-4, nm
+    assert rel_rms(y, y32) <= 1.25 * rel_rms(y16, y32)
+    hp = dict(timesteps=16, forward_conditioning="none", interpolate_before_t1=True, schedule="before_t1_only",
+              sampling_type="cold", refine_intermediate_predictions=True, enable_interpolator_dropout=False)
+    m = build_dyffusion(PF, PI, mk, 3, 2, hp, max_batch=2)
+    out = m.sample(x0.to(DEV), static_condition=c.to(DEV))
+    with torch.no_grad():
+        o32 = oracle_rollout(PF, PI, mk, hp, x0, c)
+        o16 = sampler.sample_loop(lambda x, tt, cond: nets.unet_simple_forward_bf16_model(PF, mk, x, tt, cond),
+                                  lambda x, tt, cond: nets.unet_simple_forward_bf16_model(PI, mk, x, tt, cond), x0, c, hp)
+    drift = jload("../../profiles/r02_bf16_drift.json")["results"]["autocast"]
+    for k in ("t1", "t8", "t16"):
+        e_eng, e_model = rel_rms(out[f"{k}_preds"].cpu(), o32[f"{k}_preds"]), rel_rms(o16[f"{k}_preds"], o32[f"{k}_preds"])
+        print(f"rollout {k}: engine {e_eng:.2e}  bf16 model {e_model:.2e}  reference under bf16 autocast {drift[k]:.2e}")
+        assert e_eng <= 1.25 * e_model and e_eng <= drift[k]
 
 
 def test_ensemble_rows_and_batch_split_invariance():

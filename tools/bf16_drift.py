@@ -17,53 +17,12 @@ import sys
 import time
 
 import torch
-import torch.nn.functional as F
 
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 sys.path.insert(0, ROOT)
 from oracle import init as oinit  # noqa: E402
 from oracle import nets, sampler  # noqa: E402
 from tests.helpers import jload, load_npz, rel_rms  # noqa: E402
-
-
-def r16(x):
-    return x.to(torch.bfloat16).to(torch.float32)
-
-
-def storage_forward(P, cfg, inputs, time_, condition, round_act=True, round_w=True):
-    """nets.unet_simple_forward with the engine's rounding points (see module docstring)."""
-    ra = r16 if round_act else (lambda v: v)
-    rw = r16 if round_w else (lambda v: v)
-    dim = cfg["dim"]
-    x = torch.cat([inputs, condition], dim=1) if condition is not None else inputs
-    temb = nets.time_embedding(P, "time_emb_mlp", time_, dim)
-    native_hw = x.shape[-2:]
-    x = ra(F.interpolate(x, size=tuple(cfg["upsample_dims"]), mode="bilinear"))
-    # fused stem: init_conv composed into enc0 (no rounding of the 64-channel stem tensor)
-    x = F.conv2d(x, P["init_conv.weight"], P["init_conv.bias"])
-    enc, dec = nets.unet_simple_layout(dim)
-    skips = []
-    for li, (_, _, k, s, pad, norm, act) in enumerate(enc):
-        pre = f"input_ops.{li}"
-        x = F.conv2d(x, rw(P[f"{pre}.ops.0.weight"]), P[f"{pre}.ops.0.bias"], stride=s, padding=pad)
-        x = nets._norm(P, f"{pre}.ops.1", x, norm)
-        scale, shift = nets.film(P, f"{pre}.time_mlp", temb)
-        x = ra(F.leaky_relu(x * (scale + 1) + shift, nets.LEAKY_SLOPE))
-        skips.append(x)
-    x = skips.pop()
-    for li, (_, _, k, s, pad, norm, act) in enumerate(dec):
-        pre = f"output_ops.{li}"
-        x = F.interpolate(x, scale_factor=2, mode="bilinear")
-        if li < 3:
-            x = ra(x)  # dec0-dec2 materialise the upsampled tensor in bf16
-        x = F.conv2d(x, rw(P[f"{pre}.ops.1.weight"]), P[f"{pre}.ops.1.bias"], stride=1, padding=pad)
-        x = nets._norm(P, f"{pre}.ops.2", x, norm)
-        scale, shift = nets.film(P, f"{pre}.time_mlp", temb)
-        x = ra(F.relu(x * (scale + 1) + shift))
-        if skips:
-            x = torch.cat([x, skips.pop()], dim=1)
-    x = F.conv_transpose2d(x, rw(P["readout.0.weight"]), P["readout.0.bias"], stride=2, padding=1)
-    return F.interpolate(x, size=tuple(native_hw), mode="bilinear")
 
 
 def main():
@@ -88,7 +47,7 @@ def main():
         return f
 
     def storage(P, **kw):
-        return lambda x, t, cond: storage_forward(P, mk, x, t, cond, **kw)
+        return lambda x, t, cond: nets.unet_simple_forward_bf16_model(P, mk, x, t, cond, **kw)
 
     modes = {"fp32": fp32, "autocast": autocast, "storage": storage,
              "weights": lambda P: storage(P, round_act=False), "acts": lambda P: storage(P, round_w=False)}
