@@ -8,6 +8,9 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("DYF_LIB") or os.path.join(_HERE, "lib", "libdyffusion_hip.so")  # DYF_LIB: experiment builds
+# the fp16 build of the same sources (-DDYF_F16=1): same ABI, fp16 storage + v_mfma_*_f16 (BASELINE configs[4])
+LIB_PATH_F16 = os.environ.get("DYF_LIB_F16") or os.path.join(_HERE, "lib", "libdyffusion_hip_f16.so")
+DTYPES = {"bf16": 0, "bfloat16": 0, "fp16": 1, "float16": 1, "half": 1}
 
 DYF_ABI_VERSION = 3
 DYF_OK, DYF_ERR_INVALID_ARGUMENT, DYF_ERR_UNSUPPORTED, DYF_ERR_HIP, DYF_ERR_STATE = range(5)
@@ -28,7 +31,8 @@ class NetConfig(C.Structure):
 
 class EngineConfig(C.Structure):
     _fields_ = [("abi_version", C.c_int32), ("device", C.c_int32), ("height", C.c_int32), ("width", C.c_int32),
-                ("max_batch", C.c_int32), ("use_graph", C.c_int32), ("enable_mfma", C.c_int32), ("net", NetConfig * 2)]
+                ("max_batch", C.c_int32), ("use_graph", C.c_int32), ("enable_mfma", C.c_int32), ("dtype", C.c_int32),
+                ("net", NetConfig * 2)]
 
 
 class PlanStep(C.Structure):
@@ -59,6 +63,7 @@ SYMBOLS = [
     ("dyf_engine_destroy", None, [_P]),
     ("dyf_last_error", C.c_char_p, [_P]),
     ("dyf_abi_version", C.c_int32, []),
+    ("dyf_dtype", C.c_int32, []),
     ("dyf_load_weights", C.c_int, [_P, C.c_int32, C.c_int32, C.POINTER(C.c_char_p), C.POINTER(_P), C.POINTER(_P),
                                    C.POINTER(C.c_int32)]),
     ("dyf_net_forward", C.c_int, [_P, C.c_int32, _P, _P, _P, _P, C.c_int32, C.c_int32, C.POINTER(_P), _P]),
@@ -76,6 +81,7 @@ SYMBOLS = [
     ("dyf_op_conv2d", C.c_int, [_P, _P, _P] + [C.c_int32] * 9 + [_P, _P, C.c_int32, C.c_int32, _P, _P]),
     ("dyf_op_upconv2d", C.c_int, [_P, _P, _P] + [C.c_int32] * 5 + [_P, _P, C.c_int32, _P, _P]),
     ("dyf_op_linear_attention", C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, _P]),
+    ("dyf_op_attention", C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, _P]),
     ("dyf_criterion", C.c_int, [_P, _P, _P, C.c_int64, C.c_int32, _P, _P]),
     ("dyf_apply_boundary_conditions", C.c_int, [_P, C.POINTER(BcArgs), _P, _P]),
     ("dyf_debug_read_block_output", C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
@@ -97,11 +103,15 @@ def load_library(path: str = LIB_PATH) -> C.CDLL:
     return lib
 
 
-_LIB = None
+_LIBS = {}
 
 
-def lib() -> C.CDLL:
-    global _LIB
-    if _LIB is None:
-        _LIB = load_library()
-    return _LIB
+def lib(dtype: str = "bf16") -> C.CDLL:
+    """The C-ABI library for `dtype`: "bf16" -> libdyffusion_hip.so, "fp16" -> libdyffusion_hip_f16.so."""
+    code = DTYPES[dtype]
+    if code not in _LIBS:
+        l = load_library(LIB_PATH_F16 if code else LIB_PATH)
+        if l.dyf_dtype() != code:
+            raise ImportError(f"library for dtype {dtype} reports dyf_dtype() = {l.dyf_dtype()}")
+        _LIBS[code] = l
+    return _LIBS[code]

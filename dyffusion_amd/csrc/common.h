@@ -3,36 +3,65 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-typedef uint16_t bf16_t;  // raw bfloat16 bits; activations are NHWC bf16 in HBM
-
-// ------------------------------------------------------------------------------------------------ bf16
-__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
-
-// round-to-nearest-even, NaN preserved
-__device__ __host__ __forceinline__ bf16_t f32_to_bf16(float f) {
-    uint32_t u;
-#if defined(__HIP_DEVICE_COMPILE__)
-    u = __float_as_uint(f);
-#else
-    __builtin_memcpy(&u, &f, 4);
+// 16-bit storage element of activations and weights in HBM (NHWC), raw bits.  One source, two builds of the library:
+//   default        bfloat16  (libdyffusion_hip.so,     v_mfma_f32_32x32x16_bf16) -- BASELINE configs[1]: "bf16"
+//   -DDYF_F16=1    IEEE fp16 (libdyffusion_hip_f16.so, v_mfma_f32_32x32x16_f16)  -- BASELINE configs[4]: "fp16 MFMA conv/attn"
+// Same MFMA rate, same bytes; fp16 carries 11 mantissa bits instead of 8 (rollout error 4-8x lower) and overflows at 65504.
+// Accumulation, normalisation statistics, FiLM coefficients and the sampler state are fp32 in both builds.
+#ifndef DYF_F16
+#define DYF_F16 0
 #endif
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
-}
+typedef uint16_t el16_t;
 
-// two fp32 -> packed bf16x2, round-to-nearest-even: one v_cvt_pk_bf16_f32 on gfx950 (the software form costs ~8 VALU per
-// pair and dominated the conv epilogues).  Written as a vector conversion, NOT inline asm: the compiler's hazard
-// recogniser does not look inside asm, and a v_exp_f32 / v_rcp_f32 result consumed by the very next VALU instruction needs
-// a wait state (an asm v_cvt right behind a v_exp read the stale register).
-typedef __bf16 bf16x2_native_t __attribute__((ext_vector_type(2)));
+#if DYF_F16
+typedef _Float16 el16_native_t;
+#define DYF_MFMA_32x32x16(a, b, c, x, y, z) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, x, y, z)
+#define DYF_MFMA_16x16x32(a, b, c, x, y, z) __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, x, y, z)
+#define DYF_DTYPE_NAME "fp16"
+#else
+typedef __bf16 el16_native_t;
+#define DYF_MFMA_32x32x16(a, b, c, x, y, z) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z)
+#define DYF_MFMA_16x16x32(a, b, c, x, y, z) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, x, y, z)
+#define DYF_DTYPE_NAME "bf16"
+#endif
+typedef el16_native_t el16x8_t __attribute__((ext_vector_type(8)));  // one MFMA operand fragment (8 k-values per lane)
+typedef el16_native_t el16x2_native_t __attribute__((ext_vector_type(2)));
 typedef float f32x2_native_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+
+// ------------------------------------------------------------------------------------------------ element conversions
+#if DYF_F16
+__device__ __host__ __forceinline__ float el16_to_f32(el16_t v) { return (float)__builtin_bit_cast(_Float16, v); }
+// round-to-nearest-even (v_cvt_f16_f32 / compiler-rt on the host); overflow -> inf as IEEE prescribes
+__device__ __host__ __forceinline__ el16_t f32_to_el16(float f) { return __builtin_bit_cast(el16_t, (_Float16)f); }
+// low / high element of a packed pair
+__device__ __forceinline__ float el16_lo(uint32_t w) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(w & 0xffffu)); }
+__device__ __forceinline__ float el16_hi(uint32_t w) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(w >> 16)); }
+#else
+__device__ __host__ __forceinline__ float el16_to_f32(el16_t v) {
+    const uint32_t u = ((uint32_t)v) << 16;
+    return __builtin_bit_cast(float, u);
+}
+// round-to-nearest-even, NaN preserved
+__device__ __host__ __forceinline__ el16_t f32_to_el16(float f) {
+    uint32_t u = __builtin_bit_cast(uint32_t, f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (el16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (el16_t)(u >> 16);
+}
+__device__ __forceinline__ float el16_lo(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float el16_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+#endif
+
+// two fp32 -> packed pair, round-to-nearest-even: one v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32 on gfx950 (the software form
+// costs ~8 VALU per pair and dominated the conv epilogues).  Written as a vector conversion, NOT inline asm: the compiler's
+// hazard recogniser does not look inside asm, and a v_exp_f32 / v_rcp_f32 result consumed by the very next VALU
+// instruction needs a wait state (an asm v_cvt right behind a v_exp read the stale register).
+__device__ __forceinline__ uint32_t pack_el16x2(float lo, float hi) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const f32x2_native_t v = {lo, hi};
-    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_native_t));
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, el16x2_native_t));
 #else
-    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+    return (uint32_t)f32_to_el16(lo) | ((uint32_t)f32_to_el16(hi) << 16);
 #endif
 }
 

@@ -6,8 +6,8 @@
 
 struct ConvArgs {
     // input: channel-concatenation of up to two NHWC bf16 tensors (skip connections are never materialised)
-    const bf16_t* src0;
-    const bf16_t* src1;
+    const el16_t* src0;
+    const el16_t* src1;
     int c0, c1;          // channels taken from src0 / src1 (c1 == 0: single source)
     int pix_pitch0;      // elements between consecutive pixels of src0 (0: = c0).  The fused stem feeds enc0 a 16-channel
                          // tensor and declares c0 = 64: one K chunk then spans 4 horizontally adjacent pixels
@@ -15,14 +15,14 @@ struct ConvArgs {
     int ho, wo;          // output height / width
     int kh, kw, stride, pad;
     int cout;
-    const bf16_t* wpk;   // packed weights [cout][kh*kw][c0+c1] bf16
-    const bf16_t* wpk_frag;  // the same weights in MFMA fragment order (pack_conv_frag) for conv_igemm2, or null: looked up
+    const el16_t* wpk;   // packed weights [cout][kh*kw][c0+c1] bf16
+    const el16_t* wpk_frag;  // the same weights in MFMA fragment order (pack_conv_frag) for conv_igemm2, or null: looked up
                              // in the registry (conv_register_frag) by launch_conv
     // fused x2 bilinear upsample in front of a 3x3/s1/p1 conv: sources are the LOW-res tensors (h, w), output is
     // (2h, 2w); wpk_up holds the phase-decomposed weights [4][cout][16][c0+c1] (pack_up2x_weights)
     int up2x;
-    const bf16_t* wpk_up;
-    const bf16_t* wpk_up_frag;  // the same weights in MFMA fragment order (pack_up2x_frag) for the halo kernel, or null
+    const el16_t* wpk_up;
+    const el16_t* wpk_up_frag;  // the same weights in MFMA fragment order (pack_up2x_frag) for the halo kernel, or null
     // sparse output columns of the halo kernel (plan_up_sparse_columns): device lists [2][up_npad] of low-res columns per
     // horizontal phase, halo origin per list tile; null = every column
     const int16_t* up_cols;
@@ -38,10 +38,10 @@ struct ConvArgs {
     int coef_div;        // samples per coefficient row (0/1: one row per sample; paired interpolator calls use nb)
     int act;
     DropSpec drop;
-    const bf16_t* residual;  // NHWC bf16 tensor added after activation/dropout (Residual(...) wrappers), or null
-    bf16_t* out_bf16;    // NHWC bf16 output (or null)
+    const el16_t* residual;  // NHWC bf16 tensor added after activation/dropout (Residual(...) wrappers), or null
+    el16_t* out_el16;    // NHWC bf16 output (or null)
     float* out_f32;      // NHWC fp32 output (GroupNorm input) (or null)
-    const bf16_t* zero_page;  // >= 128 B of zeros in HBM: source of padded taps for the LDS-DMA gather
+    const el16_t* zero_page;  // >= 128 B of zeros in HBM: source of padded taps for the LDS-DMA gather
     // halo form of the fused-upsample conv: fp32 scratch [n][2*wo + 2*(ho-2)][cout] for the border corrections
     // (up_border_kernel fills it, conv_up_halo_kernel starts its border accumulators from it); required by that form
     float* up_border;
@@ -53,10 +53,10 @@ inline size_t conv_up_border_floats(int n, int h, int w, int cout) { return (siz
 hipError_t conv_init();
 bool conv_mfma_supported(const ConvArgs& a);
 hipError_t launch_conv(const ConvArgs& a, int path, hipStream_t stream);
-void pack_up2x_weights(const float* w, int cout, int cin, bf16_t* out);
+void pack_up2x_weights(const float* w, int cout, int cin, el16_t* out);
 // halo form of the fused x2-upsample conv (conv_up_halo.hip): 16x16 low-res tile x 4 phases x 64 channels per workgroup
 bool conv_up_halo_supported(const ConvArgs& a);
-void pack_up2x_frag(const bf16_t* wpk_up, int cout, int cin, bf16_t* out);
+void pack_up2x_frag(const el16_t* wpk_up, int cout, int cin, el16_t* out);
 bool plan_up_sparse_columns(const std::vector<uint8_t>& needed, int w, std::vector<int16_t>& cols, std::vector<int16_t>& cbase,
                             std::vector<int16_t>& cidx, std::vector<int16_t>& col_map, int& ntiles, int& nvalid0, int& nvalid1);
 hipError_t conv_up_halo_init();
@@ -65,20 +65,20 @@ hipError_t launch_conv_up_halo(const ConvArgs& a, hipStream_t stream);
 // ConvArgs::wpk_up_frag carries the pack_halo3_frag weights (looked up in the registry by launch_conv)
 bool conv_halo3_supported(const ConvArgs& a);
 hipError_t launch_conv_halo3(const ConvArgs& a, hipStream_t stream);
-void pack_halo3_frag(const bf16_t* wpk, int cout, int cin, bf16_t* out);
+void pack_halo3_frag(const el16_t* wpk, int cout, int cin, el16_t* out);
 // 4x4 / stride 2 / pad 1 conv on the halo kernel (SP = 3, space-to-depth view): cout % 256 == 0, single source, output plane
 // tiles by 8x16; fragments (pack_halo_s2_frag) share the halo3 registry
 bool conv_halo_s2_supported(const ConvArgs& a);
 hipError_t launch_conv_halo_s2(const ConvArgs& a, hipStream_t stream);
-void pack_halo_s2_frag(const bf16_t* wpk, int cout, int cin, bf16_t* out);
-void conv_register_halo3_frag(const bf16_t* wpk_dev, const bf16_t* frag_dev);
-const bf16_t* conv_lookup_halo3_frag(const bf16_t* wpk_dev);
+void pack_halo_s2_frag(const el16_t* wpk, int cout, int cin, el16_t* out);
+void conv_register_halo3_frag(const el16_t* wpk_dev, const el16_t* frag_dev);
+const el16_t* conv_lookup_halo3_frag(const el16_t* wpk_dev);
 // second implicit-GEMM form (conv_igemm2.hip): 256 px x 128 ch per workgroup, weights streamed in fragment order
 bool conv_igemm2_supported(const ConvArgs& a);
 hipError_t conv_igemm2_init();
 hipError_t launch_conv_igemm2(const ConvArgs& a, hipStream_t stream);
-void pack_conv_frag(const bf16_t* wpk, int cout, int taps, int cin, bf16_t* out);
+void pack_conv_frag(const el16_t* wpk, int cout, int taps, int cin, el16_t* out);
 // registry device-pointer(wpk) -> device-pointer(fragment-ordered copy); filled when weights are uploaded
-void conv_register_frag(const bf16_t* wpk_dev, const bf16_t* frag_dev);
+void conv_register_frag(const el16_t* wpk_dev, const el16_t* frag_dev);
 void conv_unregister_frag(const void* wpk_dev);
-const bf16_t* conv_lookup_frag(const bf16_t* wpk_dev);
+const el16_t* conv_lookup_frag(const el16_t* wpk_dev);

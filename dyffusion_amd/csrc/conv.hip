@@ -25,8 +25,6 @@
 #include <type_traits>
 
 #include <cstdlib>
-
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
@@ -55,7 +53,7 @@ __global__ void conv_direct_kernel(ConvArgs a, long long total) {
     const int rem = (int)(m % howo);
     const int oy = rem / a.wo, ox = rem % a.wo;
     const int cin = a.c0 + a.c1;
-    const bf16_t* wrow = a.wpk + (size_t)co * a.kh * a.kw * cin;
+    const el16_t* wrow = a.wpk + (size_t)co * a.kh * a.kw * cin;
     float acc = 0.0f;
     for (int ky = 0; ky < a.kh; ++ky) {
         const int iy = oy * a.stride - a.pad + ky;
@@ -64,12 +62,12 @@ __global__ void conv_direct_kernel(ConvArgs a, long long total) {
             const int ix = ox * a.stride - a.pad + kx;
             if ((unsigned)ix >= (unsigned)a.w) continue;
             const size_t pix = ((size_t)n * a.h + iy) * a.w + ix;
-            const bf16_t* wt = wrow + (size_t)(ky * a.kw + kx) * cin;
-            const bf16_t* p0 = a.src0 + pix * (a.pix_pitch0 ? a.pix_pitch0 : a.c0);
-            for (int c = 0; c < a.c0; ++c) acc = fmaf(bf16_to_f32(p0[c]), bf16_to_f32(wt[c]), acc);
+            const el16_t* wt = wrow + (size_t)(ky * a.kw + kx) * cin;
+            const el16_t* p0 = a.src0 + pix * (a.pix_pitch0 ? a.pix_pitch0 : a.c0);
+            for (int c = 0; c < a.c0; ++c) acc = fmaf(el16_to_f32(p0[c]), el16_to_f32(wt[c]), acc);
             if (a.c1 > 0) {
-                const bf16_t* p1 = a.src1 + pix * a.c1;
-                for (int c = 0; c < a.c1; ++c) acc = fmaf(bf16_to_f32(p1[c]), bf16_to_f32(wt[a.c0 + c]), acc);
+                const el16_t* p1 = a.src1 + pix * a.c1;
+                for (int c = 0; c < a.c1; ++c) acc = fmaf(el16_to_f32(p1[c]), el16_to_f32(wt[a.c0 + c]), acc);
             }
         }
     }
@@ -78,8 +76,8 @@ __global__ void conv_direct_kernel(ConvArgs a, long long total) {
     v = apply_act(v, a.act);
     const uint32_t e = (uint32_t)(m * a.cout + co);
     v = drop_apply(v, e, (uint32_t)n * (uint32_t)(a.ho * a.wo * a.cout), a.drop, drop_row_key(a.drop, n));
-    if (a.residual) v += bf16_to_f32(a.residual[(size_t)m * a.cout + co]);
-    if (a.out_bf16) a.out_bf16[(size_t)m * a.cout + co] = f32_to_bf16(v);
+    if (a.residual) v += el16_to_f32(a.residual[(size_t)m * a.cout + co]);
+    if (a.out_el16) a.out_el16[(size_t)m * a.cout + co] = f32_to_el16(v);
     if (a.out_f32) a.out_f32[(size_t)m * a.cout + co] = v;
 }
 
@@ -315,13 +313,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a, int M, i
     auto compute = [&](int stage) {
         const char* As = smem + stage * STAGE + a_row_off;
         const char* Bs = smem + stage * STAGE + A_BYTES + b_row_off;
-        bf16x8 af[2][2], bfr[2][2];
+        el16x8_t af[2][2], bfr[2][2];
         {
             const int coff = ((hi ^ l7) << 4);
 #pragma unroll
-            for (int i = 0; i < 2; ++i) af[0][i] = *(const bf16x8*)(As + i * 32 * 128 + coff);
+            for (int i = 0; i < 2; ++i) af[0][i] = *(const el16x8_t*)(As + i * 32 * 128 + coff);
 #pragma unroll
-            for (int j = 0; j < 2; ++j) bfr[0][j] = *(const bf16x8*)(Bs + j * 32 * 128 + coff);
+            for (int j = 0; j < 2; ++j) bfr[0][j] = *(const el16x8_t*)(Bs + j * 32 * 128 + coff);
         }
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
@@ -329,15 +327,15 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a, int M, i
             if (ks < 3) {
                 const int coff = ((((ks + 1) * 2 + hi) ^ l7) << 4);
 #pragma unroll
-                for (int i = 0; i < 2; ++i) af[ns][i] = *(const bf16x8*)(As + i * 32 * 128 + coff);
+                for (int i = 0; i < 2; ++i) af[ns][i] = *(const el16x8_t*)(As + i * 32 * 128 + coff);
 #pragma unroll
-                for (int j = 0; j < 2; ++j) bfr[ns][j] = *(const bf16x8*)(Bs + j * 32 * 128 + coff);
+                for (int j = 0; j < 2; ++j) bfr[ns][j] = *(const el16x8_t*)(Bs + j * 32 * 128 + coff);
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[cs][j], af[cs][i], acc[i][j], 0, 0, 0);  // D^T = W X^T
+                    acc[i][j] = DYF_MFMA_32x32x16(bfr[cs][j], af[cs][i], acc[i][j], 0, 0, 0);  // D^T = W X^T
         }
     };
 
@@ -478,21 +476,21 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a, int M, i
                         const uint32_t rw[4] = {r0.x, r0.y, r1.x, r1.y};
 #pragma unroll
                         for (int t = 0; t < 8; ++t)
-                            v[t] += (t & 1) ? __uint_as_float(rw[t >> 1] & 0xffff0000u) : __uint_as_float(rw[t >> 1] << 16);
+                            v[t] += (t & 1) ? el16_hi(rw[t >> 1]) : el16_lo(rw[t >> 1]);
                     }
                     if (a.out_f32 && valid) {
                         *(float4*)(a.out_f32 + (size_t)e0) = make_float4(v[0], v[1], v[2], v[3]);
                         *(float4*)(a.out_f32 + (size_t)e0 + 8) = make_float4(v[4], v[5], v[6], v[7]);
                     }
-                    if (a.out_bf16) {
-                        uint32_t p0 = pack_bf16x2(v[0], v[1]), p1 = pack_bf16x2(v[2], v[3]);
-                        uint32_t q0 = pack_bf16x2(v[4], v[5]), q1 = pack_bf16x2(v[6], v[7]);
+                    if (a.out_el16) {
+                        uint32_t p0 = pack_el16x2(v[0], v[1]), p1 = pack_el16x2(v[2], v[3]);
+                        uint32_t q0 = pack_el16x2(v[4], v[5]), q1 = pack_el16x2(v[6], v[7]);
                         const auto s0 = __builtin_amdgcn_permlane32_swap(p0, q0, false, false);
                         const auto s1 = __builtin_amdgcn_permlane32_swap(p1, q1, false, false);
                         // lanes 0-31: channels cg0 + 0..7 (own group 2*g2 + partner's); lanes 32-63: cg0 + 8..15
                         uint4 o;
                         o.x = s0[0]; o.y = s1[0]; o.z = s0[1]; o.w = s1[1];
-                        if (valid) *(uint4*)(a.out_bf16 + (size_t)(ob + cg0 + 8 * hi)) = o;
+                        if (valid) *(uint4*)(a.out_el16 + (size_t)(ob + cg0 + 8 * hi)) = o;
                     }
                 }
         }
@@ -618,7 +616,7 @@ hipError_t launch_conv(const ConvArgs& a, int path, hipStream_t stream) {
 
 // Host-side weight transform for the fused x2-upsample conv (see the kernel header): w [cout][cin][3][3] fp32 ->
 // [4 phases][cout][16 taps][cin] bf16.
-void pack_up2x_weights(const float* w, int cout, int cin, bf16_t* out) {
+void pack_up2x_weights(const float* w, int cout, int cin, el16_t* out) {
     // coefficient of w[k] (k = 0,1,2) in the stencil tap a = -1,0,+1 and in the border correction, per phase
     static const double E[2][3][3] = {{{0.75, 0.25, 0.0}, {0.25, 0.75, 0.75}, {0.0, 0.0, 0.25}},
                                       {{0.25, 0.0, 0.0}, {0.75, 0.75, 0.25}, {0.0, 0.25, 0.75}}};
@@ -639,7 +637,7 @@ void pack_up2x_weights(const float* w, int cout, int cin, bf16_t* out) {
                         double v = 0.0;
                         for (int ky = 0; ky < 3; ++ky)
                             for (int kx = 0; kx < 3; ++kx) v += fy[ky] * fx[kx] * (double)k[ky * 3 + kx];
-                        out[(((size_t)phase * cout + co) * 16 + t) * cin + ci] = f32_to_bf16((float)v);
+                        out[(((size_t)phase * cout + co) * 16 + t) * cin + ci] = f32_to_el16((float)v);
                     }
                 }
         }

@@ -19,8 +19,6 @@
 #include <mutex>
 #include <type_traits>
 #include <unordered_map>
-
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
@@ -159,7 +157,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(ConvArgs a, int M, 
     const unsigned soff_last = soff_cur + (unsigned)(nk - 1) * STEP_BYTES;
 
     u32x4 bq[4][2];
-    bf16x8 aq[2][MT];
+    el16x8_t aq[2][MT];
 #define ISSUE_B(SET, SOFF, KS)                                                                               \
     _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                                         \
         bq[SET][nt] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, w_voff + nt * 1024, (SOFF) + (KS) * 2048, 0);
@@ -173,7 +171,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(ConvArgs a, int M, 
         DSR(aq[SET][MT], pm, (MT) * 4096)                                                                    \
     }
 #define MF(MT, NT, ASET, BSET)                                                                               \
-    acc[MT][NT] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bq[BSET][NT]), aq[ASET][MT], \
+    acc[MT][NT] = DYF_MFMA_32x32x16(__builtin_bit_cast(el16x8_t, bq[BSET][NT]), aq[ASET][MT], \
                                                           acc[MT][NT], 0, 0, 0);
 #define PIN __builtin_amdgcn_sched_barrier(0);
     // one k16 sub-step: 8 MFMAs; the weight fragments of sub-step +3 and the pixel fragments of sub-step +1 are issued
@@ -267,20 +265,20 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(ConvArgs a, int M, 
                         const uint32_t rw[4] = {r0.x, r0.y, r1.x, r1.y};
 #pragma unroll
                         for (int t = 0; t < 8; ++t)
-                            v[t] += (t & 1) ? __uint_as_float(rw[t >> 1] & 0xffff0000u) : __uint_as_float(rw[t >> 1] << 16);
+                            v[t] += (t & 1) ? el16_hi(rw[t >> 1]) : el16_lo(rw[t >> 1]);
                     }
                     if (a.out_f32 && valid) {
                         *(float4*)(a.out_f32 + (size_t)e0) = make_float4(v[0], v[1], v[2], v[3]);
                         *(float4*)(a.out_f32 + (size_t)e0 + 8) = make_float4(v[4], v[5], v[6], v[7]);
                     }
-                    if (a.out_bf16) {
-                        uint32_t p0 = pack_bf16x2(v[0], v[1]), p1 = pack_bf16x2(v[2], v[3]);
-                        uint32_t q0 = pack_bf16x2(v[4], v[5]), q1 = pack_bf16x2(v[6], v[7]);
+                    if (a.out_el16) {
+                        uint32_t p0 = pack_el16x2(v[0], v[1]), p1 = pack_el16x2(v[2], v[3]);
+                        uint32_t q0 = pack_el16x2(v[4], v[5]), q1 = pack_el16x2(v[6], v[7]);
                         const auto s0 = __builtin_amdgcn_permlane32_swap(p0, q0, false, false);
                         const auto s1 = __builtin_amdgcn_permlane32_swap(p1, q1, false, false);
                         uint4 o;
                         o.x = s0[0]; o.y = s1[0]; o.z = s0[1]; o.w = s1[1];
-                        if (valid) *(uint4*)(a.out_bf16 + (size_t)(ob + cg0 + 8 * hi)) = o;
+                        if (valid) *(uint4*)(a.out_el16 + (size_t)(ob + cg0 + 8 * hi)) = o;
                     }
                 }
         }
@@ -300,7 +298,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(ConvArgs a, int M, 
 // wpk [cout][taps][cin] bf16 -> MFMA fragment order [column block tn (128 ch)][K step = chunk*taps + tap][wn][ks][half]
 // [lane][8 k]: lane (l31, hi) of fragment (wn, ks, half) holds channel tn*128 + wn*64 + half*32 + l31,
 // k = chunk*64 + ks*16 + hi*8 + {0..7} of tap `tap`
-void pack_conv_frag(const bf16_t* wpk, int cout, int taps, int cin, bf16_t* out) {
+void pack_conv_frag(const el16_t* wpk, int cout, int taps, int cin, el16_t* out) {
     const int cpt = cin / 64;
     const int wns = cout % 128 == 0 ? 2 : 1, bn = 64 * wns;  // column block: 128 channels, or 64 (conv_igemm2_kernel<1>)
     size_t o = 0;
@@ -313,7 +311,7 @@ void pack_conv_frag(const bf16_t* wpk, int cout, int taps, int cin, bf16_t* out)
                             for (int lane = 0; lane < 64; ++lane) {
                                 const int co = tn * bn + wn * 64 + half * 32 + (lane & 31);
                                 const int k0 = chunk * 64 + ks * 16 + (lane >> 5) * 8;
-                                const bf16_t* s = wpk + ((size_t)co * taps + tap) * cin + k0;
+                                const el16_t* s = wpk + ((size_t)co * taps + tap) * cin + k0;
                                 for (int e = 0; e < 8; ++e) out[o++] = s[e];
                             }
 }
@@ -349,11 +347,11 @@ hipError_t launch_conv_igemm2(const ConvArgs& a, hipStream_t stream) {
 
 namespace {
 std::mutex g_frag_mu;
-std::unordered_map<const void*, const bf16_t*> g_frag;
-std::unordered_map<const void*, const bf16_t*> g_frag3;  // halo-kernel fragments of plain 3x3 convs
+std::unordered_map<const void*, const el16_t*> g_frag;
+std::unordered_map<const void*, const el16_t*> g_frag3;  // halo-kernel fragments of plain 3x3 convs
 }  // namespace
 
-void conv_register_frag(const bf16_t* wpk_dev, const bf16_t* frag_dev) {
+void conv_register_frag(const el16_t* wpk_dev, const el16_t* frag_dev) {
     std::lock_guard<std::mutex> lk(g_frag_mu);
     g_frag[(const void*)wpk_dev] = frag_dev;
 }
@@ -364,18 +362,18 @@ void conv_unregister_frag(const void* wpk_dev) {
     g_frag3.erase(wpk_dev);
 }
 
-void conv_register_halo3_frag(const bf16_t* wpk_dev, const bf16_t* frag_dev) {
+void conv_register_halo3_frag(const el16_t* wpk_dev, const el16_t* frag_dev) {
     std::lock_guard<std::mutex> lk(g_frag_mu);
     g_frag3[(const void*)wpk_dev] = frag_dev;
 }
 
-const bf16_t* conv_lookup_halo3_frag(const bf16_t* wpk_dev) {
+const el16_t* conv_lookup_halo3_frag(const el16_t* wpk_dev) {
     std::lock_guard<std::mutex> lk(g_frag_mu);
     auto it = g_frag3.find((const void*)wpk_dev);
     return it == g_frag3.end() ? nullptr : it->second;
 }
 
-const bf16_t* conv_lookup_frag(const bf16_t* wpk_dev) {
+const el16_t* conv_lookup_frag(const el16_t* wpk_dev) {
     std::lock_guard<std::mutex> lk(g_frag_mu);
     auto it = g_frag.find((const void*)wpk_dev);
     return it == g_frag.end() ? nullptr : it->second;

@@ -32,8 +32,6 @@
 #include <algorithm>
 #include <type_traits>
 #include <vector>
-
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
@@ -251,7 +249,7 @@ __global__ __launch_bounds__(256, 2) void conv_up_halo_kernel(ConvArgs a, int ti
     const unsigned lds_base = (unsigned)(uintptr_t)LDS_PTR(smem);
 
     u32x4 bq[6][2];   // weight fragments: ring of 6 sets (9-tap modes: 5 sub-steps ahead), 4 sets in the 4-tap modes
-    bf16x8 aq[2][4];  // pixel fragments: two sets
+    el16x8_t aq[2][4];  // pixel fragments: two sets
     unsigned ab[4], ax[4];  // LDS base / swizzle term of the tap whose pixel fragments are being fetched
 
 #define ISSUE_B(SET, SOFF, KS)                                                                               \
@@ -280,7 +278,7 @@ __global__ __launch_bounds__(256, 2) void conv_up_halo_kernel(ConvArgs a, int ti
         DSR(aq[SET][MT], pm)                                                                                 \
     }
 #define MF(NT, MT, ASET, BSET)                                                                               \
-    acc[NT][MT] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, bq[BSET][NT]), aq[ASET][MT], \
+    acc[NT][MT] = DYF_MFMA_32x32x16(__builtin_bit_cast(el16x8_t, bq[BSET][NT]), aq[ASET][MT], \
                                                           acc[NT][MT], 0, 0, 0);
 #define PIN __builtin_amdgcn_sched_barrier(0);
 #define NO_PRE
@@ -456,8 +454,8 @@ __global__ __launch_bounds__(256, 2) void conv_up_halo_kernel(ConvArgs a, int ti
                     for (int t = 0; t < 8; ++t) v[t] = fmaf(acc[hg >> 1][mt][8 * (hg & 1) + t], ca[t], cc[t]);
                     act_drop_fixed<4, ACT, MODE, true>(v, e0, row0, a.drop, key);
                     act_drop_fixed<4, ACT, MODE, true>(v + 4, e0 + 8, row0, a.drop, key);
-                    uint32_t p0 = pack_bf16x2(v[0], v[1]), p1 = pack_bf16x2(v[2], v[3]);
-                    uint32_t q0 = pack_bf16x2(v[4], v[5]), q1 = pack_bf16x2(v[6], v[7]);
+                    uint32_t p0 = pack_el16x2(v[0], v[1]), p1 = pack_el16x2(v[2], v[3]);
+                    uint32_t q0 = pack_el16x2(v[4], v[5]), q1 = pack_el16x2(v[6], v[7]);
                     const auto s0 = __builtin_amdgcn_permlane32_swap(p0, q0, false, false);
                     const auto s1 = __builtin_amdgcn_permlane32_swap(p1, q1, false, false);
                     // lanes 0-31: {own group 2*g2, partner's group 2*g2} = channels cg0 + 0..7;
@@ -465,7 +463,7 @@ __global__ __launch_bounds__(256, 2) void conv_up_halo_kernel(ConvArgs a, int ti
                     uint4 o;
                     o.x = s0[0]; o.y = s1[0]; o.z = s0[1]; o.w = s1[1];
                     const uint32_t sbase = store0 + mt * smt_stride + cg0;
-                    if (SP != 1 || lane_valid) *(uint4*)(a.out_bf16 + (size_t)(sbase + 8 * hi)) = o;
+                    if (SP != 1 || lane_valid) *(uint4*)(a.out_el16 + (size_t)(sbase + 8 * hi)) = o;
                 }
         }
     };
@@ -484,7 +482,7 @@ __global__ __launch_bounds__(256, 2) void conv_up_halo_kernel(ConvArgs a, int ti
 // [4 phases][cout][16 taps][cin] (pack_up2x_weights) -> MFMA fragment order:
 // [column block tn][chunk][tap][wn = py][ks][column tile nt = px*2 + half][lane][8 k]; lane (l31, hi) of fragment
 // (ks, nt) holds channel tn*64 + half*32 + l31, k = chunk*64 + ks*16 + hi*8 + {0..7}
-void pack_up2x_frag(const bf16_t* wpk_up, int cout, int cin, bf16_t* out) {
+void pack_up2x_frag(const el16_t* wpk_up, int cout, int cin, el16_t* out) {
     const int cpt = cin / 64;
     size_t o = 0;
     for (int tn = 0; tn < cout / 64; ++tn)
@@ -497,13 +495,13 @@ void pack_up2x_frag(const bf16_t* wpk_up, int cout, int cin, bf16_t* out) {
                                 const int phase = wn * 2 + (nt >> 1);
                                 const int co = tn * 64 + (nt & 1) * 32 + (lane & 31);
                                 const int k0 = chunk * 64 + ks * 16 + (lane >> 5) * 8;
-                                const bf16_t* s = wpk_up + (((size_t)phase * cout + co) * 16 + tap) * cin + k0;
+                                const el16_t* s = wpk_up + (((size_t)phase * cout + co) * 16 + tap) * cin + k0;
                                 for (int e = 0; e < 8; ++e) out[o++] = s[e];
                             }
 }
 
 bool conv_up_halo_supported(const ConvArgs& a) {
-    if (!a.up2x || a.wpk_up_frag == nullptr || a.out_bf16 == nullptr || a.residual != nullptr) return false;
+    if (!a.up2x || a.wpk_up_frag == nullptr || a.out_el16 == nullptr || a.residual != nullptr) return false;
     if (!(a.c0 > 0 && a.c0 % 64 == 0 && (a.c1 == 0 || a.c1 == a.c0) && a.cout % 64 == 0)) return false;
     if (a.h % TILE_H != 0 || a.w % TILE_W != 0 || a.ho != 2 * a.h || a.wo != 2 * a.w) return false;
     if (a.up_cols && (a.up_cbase == nullptr || a.up_cidx == nullptr || a.up_wo_store < 1 || a.up_ntiles < 1 ||
@@ -516,15 +514,15 @@ bool conv_up_halo_supported(const ConvArgs& a) {
 
 // Plain 3x3 conv through the halo kernel (SP = 2): wpk [cout][9][cin] -> the fragment order of pack_up2x_frag with the four
 // "phases" being the four 64-channel blocks of every 256 output channels (taps 9-15 of the 16-tap axis stay zero).
-void pack_halo3_frag(const bf16_t* wpk, int cout, int cin, bf16_t* out) {
+void pack_halo3_frag(const el16_t* wpk, int cout, int cin, el16_t* out) {
     const int blocks = cout / 256;
-    std::vector<bf16_t> v((size_t)4 * blocks * 64 * 16 * cin, 0);  // [phase][co' = blk*64 + c][16][cin]
+    std::vector<el16_t> v((size_t)4 * blocks * 64 * 16 * cin, 0);  // [phase][co' = blk*64 + c][16][cin]
     for (int p = 0; p < 4; ++p)
         for (int b = 0; b < blocks; ++b)
             for (int c = 0; c < 64; ++c)
                 for (int t = 0; t < 9; ++t) {
-                    const bf16_t* src = wpk + ((size_t)(b * 256 + p * 64 + c) * 9 + t) * cin;
-                    bf16_t* dst = v.data() + ((((size_t)p * blocks * 64 + b * 64 + c) * 16) + t) * cin;
+                    const el16_t* src = wpk + ((size_t)(b * 256 + p * 64 + c) * 9 + t) * cin;
+                    el16_t* dst = v.data() + ((((size_t)p * blocks * 64 + b * 64 + c) * 16) + t) * cin;
                     std::copy(src, src + cin, dst);
                 }
     pack_up2x_frag(v.data(), blocks * 64, cin, out);
@@ -533,7 +531,7 @@ void pack_halo3_frag(const bf16_t* wpk, int cout, int cin, bf16_t* out) {
 // 4x4 / stride 2 / pad 1 conv through the halo kernel (SP = 3): wpk [cout][16][cin] -> the fragment order of pack_up2x_frag
 // over the virtual K axis [64-channel chunk c][parity plane p = qy*2 + qx][64], "tap" slot t = ty*2 + tx of the 16-tap axis
 // holding kernel tap (ky, kx) = (2*a(qy, ty) + qy + 1, 2*a(qx, tx) + qx + 1), a(q, t) = t - q; slots 4-15 stay zero.
-void pack_halo_s2_frag(const bf16_t* wpk, int cout, int cin, bf16_t* out) {
+void pack_halo_s2_frag(const el16_t* wpk, int cout, int cin, el16_t* out) {
     if (cout % 256 != 0) {
         // SP = 4 (128-channel workgroups): [tn][virtual chunk = c*4 + plane][16 slots][ks][wn][nt][lane][8 k]
         const int cpt = cin / 64;
@@ -550,13 +548,13 @@ void pack_halo_s2_frag(const bf16_t* wpk, int cout, int cin, bf16_t* out) {
                                         const int ky = 2 * ((t >> 1) - qy) + qy + 1, kx = 2 * ((t & 1) - qx) + qx + 1;
                                         const int co = tn * 128 + wn * 64 + nt * 32 + (lane & 31);
                                         const int k0 = ch * 64 + ks * 16 + (lane >> 5) * 8;
-                                        const bf16_t* s = wpk + ((size_t)co * 16 + ky * 4 + kx) * cin + k0;
-                                        for (int e = 0; e < 8; ++e) out[o++] = t < 4 ? s[e] : (bf16_t)0;
+                                        const el16_t* s = wpk + ((size_t)co * 16 + ky * 4 + kx) * cin + k0;
+                                        for (int e = 0; e < 8; ++e) out[o++] = t < 4 ? s[e] : (el16_t)0;
                                     }
         return;
     }
     const int blocks = cout / 256, cpt = cin / 64, cin4 = 4 * cin;
-    std::vector<bf16_t> v((size_t)4 * blocks * 64 * 16 * cin4, 0);  // [block-of-64 index][co][16][4*cin]
+    std::vector<el16_t> v((size_t)4 * blocks * 64 * 16 * cin4, 0);  // [block-of-64 index][co][16][4*cin]
     for (int p4 = 0; p4 < 4; ++p4)
         for (int b = 0; b < blocks; ++b)
             for (int c = 0; c < 64; ++c) {
@@ -566,8 +564,8 @@ void pack_halo_s2_frag(const bf16_t* wpk, int cout, int cin, bf16_t* out) {
                         const int qy = pl >> 1, qx = pl & 1;
                         for (int t = 0; t < 4; ++t) {
                             const int ky = 2 * ((t >> 1) - qy) + qy + 1, kx = 2 * ((t & 1) - qx) + qx + 1;
-                            const bf16_t* src = wpk + ((size_t)co * 16 + ky * 4 + kx) * cin + ch * 64;
-                            bf16_t* dst = v.data() + ((((size_t)p4 * blocks * 64 + b * 64 + c) * 16) + t) * cin4 + (ch * 4 + pl) * 64;
+                            const el16_t* src = wpk + ((size_t)co * 16 + ky * 4 + kx) * cin + ch * 64;
+                            el16_t* dst = v.data() + ((((size_t)p4 * blocks * 64 + b * 64 + c) * 16) + t) * cin4 + (ch * 4 + pl) * 64;
                             std::copy(src, src + 64, dst);
                         }
                     }
@@ -576,7 +574,7 @@ void pack_halo_s2_frag(const bf16_t* wpk, int cout, int cin, bf16_t* out) {
 }
 
 bool conv_halo_s2_supported(const ConvArgs& a) {
-    if (a.up2x || a.wpk_up_frag == nullptr || a.out_bf16 == nullptr || a.out_f32 != nullptr || a.residual != nullptr) return false;
+    if (a.up2x || a.wpk_up_frag == nullptr || a.out_el16 == nullptr || a.out_f32 != nullptr || a.residual != nullptr) return false;
     if (a.kh != 4 || a.kw != 4 || a.stride != 2 || a.pad != 1 || a.pix_pitch0 != 0) return false;
     if (!(a.c0 > 0 && a.c0 % 64 == 0 && a.c1 == 0 && a.cout % 128 == 0)) return false;
     const int th = a.cout % 256 == 0 ? TILE_H : HaloCfg<4>::TH;
@@ -602,7 +600,7 @@ hipError_t launch_conv_halo_s2(const ConvArgs& a, hipStream_t stream) {
 }
 
 bool conv_halo3_supported(const ConvArgs& a) {
-    if (a.up2x || a.wpk_up_frag == nullptr || a.out_bf16 == nullptr || a.out_f32 != nullptr || a.residual != nullptr) return false;
+    if (a.up2x || a.wpk_up_frag == nullptr || a.out_el16 == nullptr || a.out_f32 != nullptr || a.residual != nullptr) return false;
     if (a.kh != 3 || a.kw != 3 || a.stride != 1 || a.pad != 1 || a.pix_pitch0 != 0) return false;
     if (!(a.c0 > 0 && a.c0 % 64 == 0 && (a.c1 == 0 || a.c1 == a.c0) && a.cout % 256 == 0)) return false;
     if (a.h % TILE_H != 0 || a.w % TILE_W != 0 || a.ho != a.h || a.wo != a.w) return false;
@@ -700,7 +698,6 @@ __global__ __launch_bounds__(256) void up_border_kernel(ConvArgs a, int tr, int 
     // slots of this wave: segments run 3 taps; corner workgroups deal their 7 taps to the waves (0,4 / 1,5 / 2,6 / 3)
     const int u0 = cornerwg ? wave : 0, ustride = cornerwg ? 4 : 1, nslots = cornerwg ? (wave < 3 ? 2 : 1) : 3;
     const int niter = nslots * kchunks;
-    typedef __attribute__((ext_vector_type(8))) __bf16 bx8;
     f32x16 acc[2][2];
 #pragma unroll
     for (int r = 0; r < 2; ++r)
@@ -760,8 +757,8 @@ __global__ __launch_bounds__(256) void up_border_kernel(ConvArgs a, int tr, int 
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
                 const uint4 xv = *(const uint4*)(src + r * 4096 + piece);
-                acc[r][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bx8, st.wa[q]), __builtin_bit_cast(bx8, xv), acc[r][0], 0, 0, 0);
-                acc[r][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bx8, st.wb[q]), __builtin_bit_cast(bx8, xv), acc[r][1], 0, 0, 0);
+                acc[r][0] = DYF_MFMA_32x32x16(__builtin_bit_cast(el16x8_t, st.wa[q]), __builtin_bit_cast(el16x8_t, xv), acc[r][0], 0, 0, 0);
+                acc[r][1] = DYF_MFMA_32x32x16(__builtin_bit_cast(el16x8_t, st.wb[q]), __builtin_bit_cast(el16x8_t, xv), acc[r][1], 0, 0, 0);
             }
         }
         __builtin_amdgcn_sched_barrier(0);

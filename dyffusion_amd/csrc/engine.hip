@@ -150,7 +150,7 @@ dyf_status net_forward(dyf_engine* e, int which, const Source* srcs, int nsrc, i
         HIP_TRY(e, launch_stem(sa, st));
     }
     // ---- encoder
-    const bf16_t* x = ws.stem;
+    const el16_t* x = ws.stem;
     for (int i = 0; i < 6; ++i) {
         const UBlock& b = n.blk[i];
         ConvArgs a = block_conv_args(e, n, b, nb);
@@ -160,7 +160,7 @@ dyf_status net_forward(dyf_engine* e, int which, const Source* srcs, int nsrc, i
             a.coef_a = o.coef_a + b.film_off; a.coef_c = o.coef_c + b.film_off; a.coef_stride = o.coef_stride;
             a.coef_div = o.coef_div;
             a.drop = make_drop(e, n, o, i);
-            a.out_bf16 = ws.enc[i];
+            a.out_el16 = ws.enc[i];
             dyf_status s = run_conv(e, a, st);
             if (s != DYF_OK) return s;
         } else {
@@ -181,7 +181,7 @@ dyf_status net_forward(dyf_engine* e, int which, const Source* srcs, int nsrc, i
         x = ws.enc[i];
     }
     // ---- decoder: x2 bilinear upsample of cat[x, skip] (materialised), conv, fused epilogue
-    const bf16_t* skip = nullptr;
+    const el16_t* skip = nullptr;
     int skip_c = 0;
     const UBlock* sparse_out = nullptr;
     int lh = n.blk[5].out_h, lw = n.blk[5].out_w;
@@ -191,7 +191,7 @@ dyf_status net_forward(dyf_engine* e, int which, const Source* srcs, int nsrc, i
         a.coef_a = o.coef_a + b.film_off; a.coef_c = o.coef_c + b.film_off; a.coef_stride = o.coef_stride;
         a.coef_div = o.coef_div;
         a.drop = make_drop(e, n, o, i);
-        a.out_bf16 = ws.dec[i - 6];
+        a.out_el16 = ws.dec[i - 6];
         // fused form: the conv gathers straight from the low-res cat[x, skip] (phase decomposition, conv.hip)
         ConvArgs f = a;
         f.src0 = x; f.c0 = b.cin - skip_c; f.src1 = skip; f.c1 = skip_c; f.h = lh; f.w = lw;
@@ -199,7 +199,7 @@ dyf_status net_forward(dyf_engine* e, int which, const Source* srcs, int nsrc, i
         f.up_cols = b.up_cols; f.up_cbase = b.up_cbase; f.up_cidx = b.up_cidx; f.up_ntiles = b.up_ntiles; f.up_npad = b.up_npad;
         f.up_nvalid0 = b.up_nvalid0; f.up_nvalid1 = b.up_nvalid1; f.up_wo_store = b.up_wo_store;
         if (i == 11 && b.up_cols && e->poison_dec5)  // test hook: a needed-but-unwritten pixel of the sparse form shows as NaN
-            HIP_TRY(e, hipMemsetAsync(ws.dec[5], 0xFF, (size_t)nb * b.out_h * b.out_w * b.cout * sizeof(bf16_t), st));  // whole buffer
+            HIP_TRY(e, hipMemsetAsync(ws.dec[5], 0xFF, (size_t)nb * b.out_h * b.out_w * b.cout * sizeof(el16_t), st));  // whole buffer
         // sparse-column form (last block only): its output tensor is compact, the readout below must know
         if (f.up_cols && !(use_fused_up(e, b, f) && conv_up_halo_supported(f))) f.up_cols = nullptr;
         if (f.up_cols) sparse_out = &b;
@@ -270,6 +270,8 @@ extern "C" {
 
 int32_t dyf_abi_version(void) { return DYF_ABI_VERSION; }
 
+int32_t dyf_dtype(void) { return DYF_F16 ? DYF_DTYPE_F16 : DYF_DTYPE_BF16; }
+
 const char* dyf_last_error(const dyf_engine* engine) { return engine ? engine->err.c_str() : g_create_error.c_str(); }
 
 void dyf_engine_destroy(dyf_engine* e) {
@@ -294,6 +296,9 @@ void dyf_engine_destroy(dyf_engine* e) {
 dyf_status dyf_engine_create(const dyf_engine_config* cfg, dyf_engine** out_engine) {
     if (!cfg || !out_engine) return fail(nullptr, DYF_ERR_INVALID_ARGUMENT, "null argument");
     if (cfg->abi_version != DYF_ABI_VERSION) return fail(nullptr, DYF_ERR_INVALID_ARGUMENT, "ABI version mismatch");
+    if (cfg->dtype != dyf_dtype())
+        return fail(nullptr, DYF_ERR_INVALID_ARGUMENT, std::string("this library is the ") + DYF_DTYPE_NAME +
+                    " build: engine dtype must match (libdyffusion_hip.so = bf16, libdyffusion_hip_f16.so = fp16)");
     if (cfg->height < 1 || cfg->width < 1 || cfg->max_batch < 1)
         return fail(nullptr, DYF_ERR_INVALID_ARGUMENT, "height, width and max_batch must be positive");
     int ndev = 0;
@@ -508,18 +513,18 @@ dyf_status dyf_load_weights(dyf_engine* e, int32_t which, int32_t n_tensors, con
         for (int c = 0; c < b.cout; ++c) blk_of[b.film_off + c] = i;
         // pack [cout][cin][kh][kw] fp32 -> [cout][tap][cin] bf16 (K-contiguous rows for the implicit GEMM)
         const int taps = b.k * b.k;
-        std::vector<bf16_t> pk((size_t)b.cout * taps * b.cin);
+        std::vector<el16_t> pk((size_t)b.cout * taps * b.cin);
         for (int co = 0; co < b.cout; ++co)
             for (int ci = 0; ci < b.cin; ++ci)
                 for (int t = 0; t < taps; ++t)
-                    pk[((size_t)co * taps + t) * b.cin + ci] = f32_to_bf16(cw->data[((size_t)co * b.cin + ci) * taps + t]);
+                    pk[((size_t)co * taps + t) * b.cin + ci] = f32_to_el16(cw->data[((size_t)co * b.cin + ci) * taps + t]);
         { dyf_status _s = upload_conv_weights(e, &b.wpk, pk, b.cout, taps, b.cin); if (_s != DYF_OK) return _s; }
         if (i == 0 && b.k == 4 && n.cin_total + 1 <= 16 && b.cout % 64 == 0 && n.uh % 2 == 0 && n.uw % 2 == 0) {
             // compose_stem_enc0: W'[co][kh][kw][c] = sum_d Wenc0[co][d][kh][kw] * Winit[d][c]; channel cin_total carries
             // init_conv's bias (its input is the 1-inside-the-image indicator); channels up to 16 are zero
             const TensorView* sw = &sd["init_conv.weight"];
             const TensorView* sb = &sd["init_conv.bias"];
-            std::vector<bf16_t> fw((size_t)b.cout * 16 * 16);
+            std::vector<el16_t> fw((size_t)b.cout * 16 * 16);
             for (int co = 0; co < b.cout; ++co)
                 for (int t = 0; t < 16; ++t)
                     for (int c = 0; c < 16; ++c) {
@@ -529,17 +534,17 @@ dyf_status dyf_load_weights(dyf_engine* e, int32_t which, int32_t n_tensors, con
                                 const double we = cw->data[((size_t)co * b.cin + d2) * 16 + t];
                                 v += we * (c < n.cin_total ? (double)sw->data[(size_t)d2 * n.cin_total + c] : (double)sb->data[d2]);
                             }
-                        fw[((size_t)co * 16 + t) * 16 + c] = f32_to_bf16((float)v);
+                        fw[((size_t)co * 16 + t) * 16 + c] = f32_to_el16((float)v);
                     }
             { dyf_status _s = upload_conv_weights(e, &n.enc0_fused_w, fw, b.cout, 4, 64); if (_s != DYF_OK) return _s; }
             n.stem_fused = true;
         }
         if (b.transposed && b.k == 3) {
-            std::vector<bf16_t> pu((size_t)4 * b.cout * 16 * b.cin);
+            std::vector<el16_t> pu((size_t)4 * b.cout * 16 * b.cin);
             pack_up2x_weights(cw->data, b.cout, b.cin, pu.data());
             UP(b.wpk_up, pu);
             if (b.cin % 64 == 0 && b.cout % 64 == 0) {  // MFMA fragment order for the halo kernel
-                std::vector<bf16_t> pf(pu.size());
+                std::vector<el16_t> pf(pu.size());
                 pack_up2x_frag(pu.data(), b.cout, b.cin, pf.data());
                 UP(b.wpk_up_frag, pf);
             }
@@ -610,7 +615,7 @@ dyf_status dyf_load_weights(dyf_engine* e, int32_t which, int32_t n_tensors, con
                 for (int t = 0; t < 16; ++t) pk[((size_t)t * n.dim + ci) * oc + co] = rw->data[((size_t)ci * oc + co) * 16 + t];
         UP(n.ro_w, pk); UP(n.ro_b, vec(rb));
         if (n.dim == 64 && oc <= 4) {  // MFMA fragments: lane (m = lane & 15, kg = lane >> 4) of (tap, half): W[tap][half*32 + kg*8 + e][m]
-            std::vector<bf16_t> wf((size_t)16 * 2 * 64 * 8, 0);
+            std::vector<el16_t> wf((size_t)16 * 2 * 64 * 8, 0);
             for (int t = 0; t < 16; ++t)
                 for (int h2 = 0; h2 < 2; ++h2)
                     for (int lane = 0; lane < 64; ++lane) {
@@ -618,7 +623,7 @@ dyf_status dyf_load_weights(dyf_engine* e, int32_t which, int32_t n_tensors, con
                         for (int el = 0; el < 8; ++el)
                             if (m < oc)
                                 wf[(((size_t)t * 2 + h2) * 64 + lane) * 8 + el] =
-                                    f32_to_bf16(pk[((size_t)t * n.dim + h2 * 32 + kg * 8 + el) * oc + m]);
+                                    f32_to_el16(pk[((size_t)t * n.dim + h2 * 32 + kg * 8 + el) * oc + m]);
                     }
             UP(n.ro_wfrag, wf);
         }
@@ -1019,7 +1024,7 @@ dyf_status dyf_time_conv_layer(dyf_engine* e, int32_t which, int32_t layer, int3
     a.coef_c = b.gn ? b.static_c : Cc + b.film_off;
     a.coef_stride = 0;
     a.drop = DropSpec{};
-    if (b.gn) { a.out_f32 = e->ws.enc5_raw; a.act = ACT_NONE; } else { a.out_bf16 = b.transposed ? e->ws.dec[layer - 6] : e->ws.enc[layer]; }
+    if (b.gn) { a.out_f32 = e->ws.enc5_raw; a.act = ACT_NONE; } else { a.out_el16 = b.transposed ? e->ws.dec[layer - 6] : e->ws.enc[layer]; }
     hipEvent_t ev0, ev1;
     HIP_TRY(e, hipEventCreate(&ev0));
     HIP_TRY(e, hipEventCreate(&ev1));
@@ -1155,7 +1160,7 @@ dyf_status dyf_debug_read_block_output(dyf_engine* e, int32_t which, int32_t lay
     if (nb < 1 || nb > 2 * e->cfg.max_batch) return fail(e, DYF_ERR_INVALID_ARGUMENT, "batch size outside [1, 2 max_batch]");
     HIP_TRY(e, hipSetDevice(e->cfg.device));
     const UBlock& b = n.blk[layer];
-    const bf16_t* src = layer < 6 ? e->ws.enc[layer] : e->ws.dec[layer - 6];
+    const el16_t* src = layer < 6 ? e->ws.enc[layer] : e->ws.dec[layer - 6];
     const bool sparse = layer == 11 && e->last_dec5_sparse;
     HIP_TRY(e, launch_nhwc_to_nchw_f32(src, nb, b.out_h, b.out_w, sparse ? b.up_wo_store : b.out_w, b.cout,
                                        sparse ? b.up_col_map : nullptr, out_dev, (hipStream_t)stream));
@@ -1172,36 +1177,36 @@ dyf_status dyf_op_conv2d(dyf_engine* e, const uint16_t* x_dev, const float* w_ho
     HIP_TRY(e, hipSetDevice(e->cfg.device));
     hipStream_t st = (hipStream_t)stream;
     const int taps = kh * kw;
-    std::vector<bf16_t> pk((size_t)cout * taps * cin);
+    std::vector<el16_t> pk((size_t)cout * taps * cin);
     for (int co = 0; co < cout; ++co)
         for (int ci = 0; ci < cin; ++ci)
             for (int t = 0; t < taps; ++t)
-                pk[((size_t)co * taps + t) * cin + ci] = f32_to_bf16(w_host[((size_t)co * cin + ci) * taps + t]);
-    bf16_t* wdev = nullptr;
+                pk[((size_t)co * taps + t) * cin + ci] = f32_to_el16(w_host[((size_t)co * cin + ci) * taps + t]);
+    el16_t* wdev = nullptr;
     float *ones = nullptr, *zeros = nullptr;
     const bool frag = cout % 64 == 0 && cin % 64 == 0 && taps <= 32;
-    HIP_TRY(e, hipMalloc((void**)&wdev, 2 * pk.size() * sizeof(bf16_t)));
-    HIP_TRY(e, hipMemcpy(wdev, pk.data(), pk.size() * sizeof(bf16_t), hipMemcpyHostToDevice));
+    HIP_TRY(e, hipMalloc((void**)&wdev, 2 * pk.size() * sizeof(el16_t)));
+    HIP_TRY(e, hipMemcpy(wdev, pk.data(), pk.size() * sizeof(el16_t), hipMemcpyHostToDevice));
     if (frag) {
-        std::vector<bf16_t> pf(pk.size());
+        std::vector<el16_t> pf(pk.size());
         pack_conv_frag(pk.data(), cout, taps, cin, pf.data());
-        HIP_TRY(e, hipMemcpy(wdev + pk.size(), pf.data(), pf.size() * sizeof(bf16_t), hipMemcpyHostToDevice));
+        HIP_TRY(e, hipMemcpy(wdev + pk.size(), pf.data(), pf.size() * sizeof(el16_t), hipMemcpyHostToDevice));
     }
     ConvArgs a{};
     a.src0 = x_dev; a.c0 = cin; a.n = n; a.h = h; a.w = w;
     a.ho = (h + 2 * pad - kh) / stride + 1; a.wo = (w + 2 * pad - kw) / stride + 1;
     a.kh = kh; a.kw = kw; a.stride = stride; a.pad = pad; a.cout = cout; a.wpk = wdev;
     a.wpk_frag = frag ? wdev + pk.size() : nullptr;
-    bf16_t* h3dev = nullptr;  // halo form of plain 3x3 convs (looked up through the registry like the engine's own weights)
+    el16_t* h3dev = nullptr;  // halo form of plain 3x3 convs (looked up through the registry like the engine's own weights)
     if (((taps == 9 && cout % 256 == 0) || (kh == 4 && kw == 4 && cout % 128 == 0)) && cin % 64 == 0) {
-        std::vector<bf16_t> pf((size_t)cout * 16 * cin * (taps == 9 ? 1 : 4));
+        std::vector<el16_t> pf((size_t)cout * 16 * cin * (taps == 9 ? 1 : 4));
         if (taps == 9) pack_halo3_frag(pk.data(), cout, cin, pf.data());
         else pack_halo_s2_frag(pk.data(), cout, cin, pf.data());
-        HIP_TRY(e, hipMalloc((void**)&h3dev, pf.size() * sizeof(bf16_t)));
-        HIP_TRY(e, hipMemcpy(h3dev, pf.data(), pf.size() * sizeof(bf16_t), hipMemcpyHostToDevice));
+        HIP_TRY(e, hipMalloc((void**)&h3dev, pf.size() * sizeof(el16_t)));
+        HIP_TRY(e, hipMemcpy(h3dev, pf.data(), pf.size() * sizeof(el16_t), hipMemcpyHostToDevice));
         conv_register_halo3_frag(wdev, h3dev);
     }
-    a.act = act; a.out_bf16 = y_dev; a.zero_page = e->ws.zero_page;
+    a.act = act; a.out_el16 = y_dev; a.zero_page = e->ws.zero_page;
     if (scale_dev && shift_dev) {
         a.coef_a = scale_dev; a.coef_c = shift_dev; a.coef_stride = cout;
     } else {
@@ -1236,23 +1241,23 @@ dyf_status dyf_op_upconv2d(dyf_engine* e, const uint16_t* x_dev, const float* w_
     if (!e || !x_dev || !w_host || !y_dev) return fail(e, DYF_ERR_INVALID_ARGUMENT, "null argument");
     HIP_TRY(e, hipSetDevice(e->cfg.device));
     hipStream_t st = (hipStream_t)stream;
-    std::vector<bf16_t> pu((size_t)4 * cout * 16 * cin);
+    std::vector<el16_t> pu((size_t)4 * cout * 16 * cin);
     pack_up2x_weights(w_host, cout, cin, pu.data());
-    bf16_t* wdev = nullptr;
+    el16_t* wdev = nullptr;
     float *ones = nullptr, *zeros = nullptr;
     const bool frag = cin % 64 == 0 && cout % 64 == 0;
-    HIP_TRY(e, hipMalloc((void**)&wdev, 2 * pu.size() * sizeof(bf16_t)));
-    HIP_TRY(e, hipMemcpy(wdev, pu.data(), pu.size() * sizeof(bf16_t), hipMemcpyHostToDevice));
+    HIP_TRY(e, hipMalloc((void**)&wdev, 2 * pu.size() * sizeof(el16_t)));
+    HIP_TRY(e, hipMemcpy(wdev, pu.data(), pu.size() * sizeof(el16_t), hipMemcpyHostToDevice));
     if (frag) {
-        std::vector<bf16_t> pf(pu.size());
+        std::vector<el16_t> pf(pu.size());
         pack_up2x_frag(pu.data(), cout, cin, pf.data());
-        HIP_TRY(e, hipMemcpy(wdev + pu.size(), pf.data(), pf.size() * sizeof(bf16_t), hipMemcpyHostToDevice));
+        HIP_TRY(e, hipMemcpy(wdev + pu.size(), pf.data(), pf.size() * sizeof(el16_t), hipMemcpyHostToDevice));
     }
     ConvArgs a{};
     a.src0 = x_dev; a.c0 = cin; a.n = n; a.h = h; a.w = w; a.ho = 2 * h; a.wo = 2 * w;
     a.kh = 3; a.kw = 3; a.stride = 1; a.pad = 1; a.cout = cout; a.wpk = wdev; a.wpk_up = wdev; a.up2x = 1;
     a.wpk_up_frag = frag ? wdev + pu.size() : nullptr;
-    a.act = act; a.out_bf16 = y_dev;
+    a.act = act; a.out_el16 = y_dev;
     float* border = nullptr;
     HIP_TRY(e, hipMalloc((void**)&border, conv_up_border_floats(n, h, w, cout) * sizeof(float)));
     a.up_border = border;
@@ -1295,6 +1300,18 @@ dyf_status dyf_op_linear_attention(dyf_engine* e, const uint16_t* qkv_dev, int32
     if (err == hipSuccess) err = hipStreamSynchronize(st);
     (void)hipFree(scratch);
     if (err != hipSuccess) return fail(e, DYF_ERR_HIP, std::string("dyf_op_linear_attention: ") + hipGetErrorString(err));
+    return DYF_OK;
+}
+
+dyf_status dyf_op_attention(dyf_engine* e, const uint16_t* qkv_dev, int32_t n, int32_t hw, uint16_t* out_dev, void* stream) {
+    if (!e || !qkv_dev || !out_dev || n < 1 || hw < 1) return fail(e, DYF_ERR_INVALID_ARGUMENT, "dyf_op_attention: bad arguments");
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    hipStream_t st = (hipStream_t)stream;
+    AttnArgs a{};
+    a.qkv = qkv_dev; a.n = n; a.hw = hw; a.heads = 4; a.out = out_dev; a.drop = DropSpec{};
+    hipError_t err = launch_attention(a, st);
+    if (err == hipSuccess) err = hipStreamSynchronize(st);
+    if (err != hipSuccess) return fail(e, DYF_ERR_HIP, std::string("dyf_op_attention: ") + hipGetErrorString(err));
     return DYF_OK;
 }
 

@@ -28,9 +28,9 @@ struct UBlock {              // one UNetBlock (unet_simple.py:13-82)
     int film_off = 0;        // offset of this block's channels in the flattened coefficient table
     int in_h = 0, in_w = 0;  // conv input size (after the x2 upsample for decoder blocks)
     int out_h = 0, out_w = 0;
-    bf16_t* wpk = nullptr;   // device [cout][k*k][cin]
-    bf16_t* wpk_up = nullptr;  // decoder 3x3 blocks: phase-decomposed weights of the fused x2-upsample conv
-    bf16_t* wpk_up_frag = nullptr;  // ... in MFMA fragment order (halo kernel)
+    el16_t* wpk = nullptr;   // device [cout][k*k][cin]
+    el16_t* wpk_up = nullptr;  // decoder 3x3 blocks: phase-decomposed weights of the fused x2-upsample conv
+    el16_t* wpk_up_frag = nullptr;  // ... in MFMA fragment order (halo kernel)
     // last decoder block: column lists of the outputs the readout actually reads (plan_up_sparse_columns), or null
     int16_t* up_cols = nullptr;
     int16_t* up_cbase = nullptr;
@@ -55,8 +55,8 @@ struct Net {
     float *film_w = nullptr, *film_b = nullptr, *norm_a = nullptr, *norm_c = nullptr;
     int *blk_of = nullptr, *blk_off = nullptr, *blk_cout = nullptr;
     float *ro_w = nullptr, *ro_b = nullptr;
-    bf16_t* ro_wfrag = nullptr;  // readout weights as MFMA fragments (dim 64, <= 4 output channels)
-    bf16_t* enc0_fused_w = nullptr;  // [2dim][4][64]: enc0's 4x4 conv composed with init_conv (+ bias channel)
+    el16_t* ro_wfrag = nullptr;  // readout weights as MFMA fragments (dim 64, <= 4 output channels)
+    el16_t* enc0_fused_w = nullptr;  // [2dim][4][64]: enc0's 4x4 conv composed with init_conv (+ bias channel)
     bool stem_fused = false;
     double flops_per_sample = 0.0;
     int n_drop_sites = 12;   // dropout sites with p > 0 per forward (mask-injection cursor); 12 UNetBlocks for unet_simple
@@ -69,16 +69,16 @@ struct Net {
 };
 
 struct Workspace {
-    bf16_t* stem = nullptr;
-    bf16_t* stem16 = nullptr;  // fused stem: [nb][uh+2][uw+2][16]
-    bf16_t* enc[6] = {};
+    el16_t* stem = nullptr;
+    el16_t* stem16 = nullptr;  // fused stem: [nb][uh+2][uw+2][16]
+    el16_t* enc[6] = {};
     float* enc5_raw = nullptr;
-    bf16_t* up = nullptr;
-    bf16_t* dec[6] = {};
+    el16_t* up = nullptr;
+    el16_t* dec[6] = {};
     float* silu = nullptr;
     float* coef_a = nullptr;
     float* coef_c = nullptr;
-    bf16_t* zero_page = nullptr;
+    el16_t* zero_page = nullptr;
     float* up_border = nullptr;  // border-correction scratch of the fused-upsample halo convs (ConvArgs::up_border)
     float* coef_pair = nullptr;  // [2][2][total_c]: FiLM coefficient rows of a paired interpolator call
 };
@@ -185,29 +185,29 @@ dyf_status dev_upload(dyf_engine* e, T** out, const std::vector<T>& host) {
 
 // packed conv weights [cout][taps][cin] bf16 -> device; layers the second implicit-GEMM form can run also get their
 // fragment-ordered copy, registered under the primary pointer (launch_conv looks it up)
-inline dyf_status upload_conv_weights(dyf_engine* e, bf16_t** out, const std::vector<bf16_t>& pk, int cout, int taps, int cin) {
+inline dyf_status upload_conv_weights(dyf_engine* e, el16_t** out, const std::vector<el16_t>& pk, int cout, int taps, int cin) {
     dyf_status st = dev_upload(e, out, pk);
     if (st != DYF_OK) return st;
     if (cout % 64 == 0 && cin % 64 == 0 && taps <= 32 && (size_t)cout * taps * cin == pk.size()) {
-        std::vector<bf16_t> pf(pk.size());
+        std::vector<el16_t> pf(pk.size());
         pack_conv_frag(pk.data(), cout, taps, cin, pf.data());
-        bf16_t* frag = nullptr;
+        el16_t* frag = nullptr;
         st = dev_upload(e, &frag, pf);
         if (st != DYF_OK) return st;
         conv_register_frag(*out, frag);
     }
     if (taps == 16 && cout % 128 == 0 && cin % 64 == 0 && (size_t)cout * taps * cin == pk.size()) {  // halo form of 4x4 / s2
-        std::vector<bf16_t> pf((size_t)cout * 16 * 4 * cin);
+        std::vector<el16_t> pf((size_t)cout * 16 * 4 * cin);
         pack_halo_s2_frag(pk.data(), cout, cin, pf.data());
-        bf16_t* frag = nullptr;
+        el16_t* frag = nullptr;
         st = dev_upload(e, &frag, pf);
         if (st != DYF_OK) return st;
         conv_register_halo3_frag(*out, frag);
     }
     if (taps == 9 && cout % 256 == 0 && cin % 64 == 0 && (size_t)cout * taps * cin == pk.size()) {  // halo form of plain 3x3
-        std::vector<bf16_t> pf((size_t)cout * 16 * cin);
+        std::vector<el16_t> pf((size_t)cout * 16 * cin);
         pack_halo3_frag(pk.data(), cout, cin, pf.data());
-        bf16_t* frag = nullptr;
+        el16_t* frag = nullptr;
         st = dev_upload(e, &frag, pf);
         if (st != DYF_OK) return st;
         conv_register_halo3_frag(*out, frag);

@@ -48,7 +48,7 @@ struct StemArgs {
     const float* wgt;       // [dim][cin] fp32
     const float* bias;      // [dim]
     int dim;
-    bf16_t* out;            // [n][uh][uw][dim]
+    el16_t* out;            // [n][uh][uw][dim]
 };
 hipError_t launch_stem(const StemArgs& a, hipStream_t s);
 // Fused-stem form: only the outer resample, written as a zero-bordered [n][uh+2][uw+2][16] bf16 tensor whose channel
@@ -58,11 +58,11 @@ hipError_t launch_stem16(const StemArgs& a, hipStream_t s);
 
 // K2 (materialised form): bilinear x2 upsample of cat[src0, src1] (NHWC bf16) -> NHWC bf16
 struct Up2xArgs {
-    const bf16_t* src0;
-    const bf16_t* src1;
+    const el16_t* src0;
+    const el16_t* src1;
     int c0, c1;
     int n, h, w;            // low-res dims
-    bf16_t* out;            // [n][2h][2w][c0+c1]
+    el16_t* out;            // [n][2h][2w][c0+c1]
 };
 hipError_t launch_up2x(const Up2xArgs& a, hipStream_t s);
 
@@ -78,19 +78,19 @@ struct GroupNormArgs {
     int film_div;           // samples per coefficient row (0/1: one row per sample)
     int act;
     DropSpec drop;
-    bf16_t* out;
+    el16_t* out;
 };
 hipError_t launch_groupnorm(const GroupNormArgs& a, hipStream_t s);
 
 // K3+K4: ConvTranspose2d(k4,s2,p1) readout evaluated only where the final bilinear resample needs it
 // (unet_simple.py:141-151 + :195) -> NCHW fp32
 struct ReadoutArgs {
-    const bf16_t* x;        // [n][ih][iw][cin] decoder output
+    const el16_t* x;        // [n][ih][iw][cin] decoder output
     int n, ih, iw, cin;
     int iw_store;           // columns actually stored per row of x (== iw, or the compact width of the sparse-column decoder block)
     const int16_t* col_map; // [iw]: column -> stored column, -1 = not stored (compact x), or null
     const float* wgt;       // [kh][kw][cin][cout] fp32 (repacked ConvTranspose weight)
-    const bf16_t* wfrag;    // the same weights as MFMA 16x16x32 A fragments [16 taps][2 k halves][64 lanes][8] bf16 (cin == 64), or null
+    const el16_t* wfrag;    // the same weights as MFMA 16x16x32 A fragments [16 taps][2 k halves][64 lanes][8] bf16 (cin == 64), or null
     const float* bias;      // [cout]
     int cout;
     int oh, ow;             // native grid
@@ -120,7 +120,7 @@ struct BcArgs {
     const float* boundary;       // [n_meta][c][h][w]
 };
 hipError_t launch_boundary_conditions(const BcArgs& a, hipStream_t s);
-hipError_t launch_nhwc_to_nchw_f32(const bf16_t* src, int n, int h, int w, int w_store, int c, const int16_t* col_map,
+hipError_t launch_nhwc_to_nchw_f32(const el16_t* src, int n, int h, int w, int w_store, int c, const int16_t* col_map,
                                    float* out, hipStream_t s);
 hipError_t launch_rng_begin_forward(uint32_t* rng_state, uint32_t* row_keys, int rows, int rows_per_fwd, hipStream_t s);
 hipError_t launch_fill_f32(float* p, float v, long long count, hipStream_t s);

@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256) void stem_kernel(StemArgs a) {
     }
     __syncthreads();
     if (!live) return;
-    bf16_t* out = a.out + (size_t)pix * a.dim;
+    el16_t* out = a.out + (size_t)pix * a.dim;
     for (int d0 = 0; d0 < a.dim; d0 += 8) {
         float acc[8];
 #pragma unroll
@@ -140,15 +140,15 @@ __global__ __launch_bounds__(256) void stem_kernel(StemArgs a) {
         }
         if ((a.dim & 7) == 0) {
             uint4 o;
-            o.x = pack_bf16x2(acc[0], acc[1]);
-            o.y = pack_bf16x2(acc[2], acc[3]);
-            o.z = pack_bf16x2(acc[4], acc[5]);
-            o.w = pack_bf16x2(acc[6], acc[7]);
+            o.x = pack_el16x2(acc[0], acc[1]);
+            o.y = pack_el16x2(acc[2], acc[3]);
+            o.z = pack_el16x2(acc[4], acc[5]);
+            o.w = pack_el16x2(acc[6], acc[7]);
             *(uint4*)(out + d0) = o;
         } else {
 #pragma unroll
             for (int t = 0; t < 8; ++t)
-                if (d0 + t < a.dim) out[d0 + t] = f32_to_bf16(acc[t]);
+                if (d0 + t < a.dim) out[d0 + t] = f32_to_el16(acc[t]);
         }
     }
 }
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(256) void stem16_kernel(StemArgs a) {
             v[k] = val;
         }
 #pragma unroll
-        for (int k = 0; k < 8; ++k) w[k] = pack_bf16x2(v[2 * k], v[2 * k + 1]);
+        for (int k = 0; k < 8; ++k) w[k] = pack_el16x2(v[2 * k], v[2 * k + 1]);
     }
     uint4* o = (uint4*)(a.out + (size_t)idx * 16);
     o[0] = make_uint4(w[0], w[1], w[2], w[3]);
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256) void up2x_kernel(Up2xArgs a, long long total) 
     bilinear_coord(y, 0.5f, a.h, y0, y1, ly);
     bilinear_coord(x, 0.5f, a.w, x0, x1, lx);
     int ch = g * VEC;
-    const bf16_t* src = a.src0;
+    const el16_t* src = a.src0;
     int cs = a.c0;
     if (ch >= a.c0) {
         src = a.src1;
@@ -241,11 +241,11 @@ __global__ __launch_bounds__(256) void up2x_kernel(Up2xArgs a, long long total) 
         ch -= a.c0;
     }
     const size_t base = (size_t)n * a.h * a.w;
-    const bf16_t* p00 = src + ((base + (size_t)y0 * a.w + x0) * cs + ch);
-    const bf16_t* p01 = src + ((base + (size_t)y0 * a.w + x1) * cs + ch);
-    const bf16_t* p10 = src + ((base + (size_t)y1 * a.w + x0) * cs + ch);
-    const bf16_t* p11 = src + ((base + (size_t)y1 * a.w + x1) * cs + ch);
-    bf16_t* o = a.out + ((size_t)pix * c + g * VEC);
+    const el16_t* p00 = src + ((base + (size_t)y0 * a.w + x0) * cs + ch);
+    const el16_t* p01 = src + ((base + (size_t)y0 * a.w + x1) * cs + ch);
+    const el16_t* p10 = src + ((base + (size_t)y1 * a.w + x0) * cs + ch);
+    const el16_t* p11 = src + ((base + (size_t)y1 * a.w + x1) * cs + ch);
+    el16_t* o = a.out + ((size_t)pix * c + g * VEC);
     if (VEC == 8) {
         const uint4 q00 = *(const uint4*)p00, q01 = *(const uint4*)p01, q10 = *(const uint4*)p10, q11 = *(const uint4*)p11;
         const uint32_t* w00 = (const uint32_t*)&q00;
@@ -257,24 +257,24 @@ __global__ __launch_bounds__(256) void up2x_kernel(Up2xArgs a, long long total) 
         for (int t = 0; t < 4; ++t) {
             float lo, hi;
             {
-                const float a00 = __uint_as_float(w00[t] << 16), a01 = __uint_as_float(w01[t] << 16);
-                const float a10 = __uint_as_float(w10[t] << 16), a11 = __uint_as_float(w11[t] << 16);
+                const float a00 = el16_lo(w00[t]), a01 = el16_lo(w01[t]);
+                const float a10 = el16_lo(w10[t]), a11 = el16_lo(w11[t]);
                 const float top = a00 * (1.0f - lx) + a01 * lx, bot = a10 * (1.0f - lx) + a11 * lx;
                 lo = top * (1.0f - ly) + bot * ly;
             }
             {
-                const float a00 = __uint_as_float(w00[t] & 0xffff0000u), a01 = __uint_as_float(w01[t] & 0xffff0000u);
-                const float a10 = __uint_as_float(w10[t] & 0xffff0000u), a11 = __uint_as_float(w11[t] & 0xffff0000u);
+                const float a00 = el16_hi(w00[t]), a01 = el16_hi(w01[t]);
+                const float a10 = el16_hi(w10[t]), a11 = el16_hi(w11[t]);
                 const float top = a00 * (1.0f - lx) + a01 * lx, bot = a10 * (1.0f - lx) + a11 * lx;
                 hi = top * (1.0f - ly) + bot * ly;
             }
-            r[t] = pack_bf16x2(lo, hi);
+            r[t] = pack_el16x2(lo, hi);
         }
         *(uint4*)o = make_uint4(r[0], r[1], r[2], r[3]);
     } else {
-        const float a00 = bf16_to_f32(*p00), a01 = bf16_to_f32(*p01), a10 = bf16_to_f32(*p10), a11 = bf16_to_f32(*p11);
+        const float a00 = el16_to_f32(*p00), a01 = el16_to_f32(*p01), a10 = el16_to_f32(*p10), a11 = el16_to_f32(*p11);
         const float top = a00 * (1.0f - lx) + a01 * lx, bot = a10 * (1.0f - lx) + a11 * lx;
-        *o = f32_to_bf16(top * (1.0f - ly) + bot * ly);
+        *o = f32_to_el16(top * (1.0f - ly) + bot * ly);
     }
 }
 
@@ -317,7 +317,7 @@ __global__ __launch_bounds__(256) void groupnorm_kernel(GroupNormArgs a) {
         y = apply_act(y, a.act);
         const size_t e = ((size_t)n * a.hw + p) * a.c + ch;
         y = drop_apply(y, (uint32_t)e, (uint32_t)((size_t)n * a.hw * a.c), a.drop, key);
-        a.out[e] = f32_to_bf16(y);
+        a.out[e] = f32_to_el16(y);
     }
 }
 
@@ -367,10 +367,10 @@ __global__ __launch_bounds__(256) void readout_kernel(ReadoutArgs a) {
                 for (int dj = 0; dj < 2; ++dj) {
                     const int j = j_hi - dj, kw = v + 1 - 2 * j;
                     if ((unsigned)j >= (unsigned)a.iw) continue;
-                    const bf16_t* px = a.x + (((size_t)n * a.ih + i) * a.iw + j) * a.cin;
+                    const el16_t* px = a.x + (((size_t)n * a.ih + i) * a.iw + j) * a.cin;
                     const float* wt = wsh + (size_t)(kh * 4 + kw) * a.cin * a.cout;
                     for (int ci = 0; ci < a.cin; ++ci) {
-                        const float xv = bw * bf16_to_f32(px[ci]);
+                        const float xv = bw * el16_to_f32(px[ci]);
 #pragma unroll
                         for (int co = 0; co < DYF_MAX_OUT_CH; ++co)
                             if (co < a.cout) acc[co] = fmaf(xv, wt[ci * a.cout + co], acc[co]);
@@ -440,7 +440,7 @@ __global__ __launch_bounds__(256) void readout_sliced_kernel(ReadoutArgs a) {
         const float bw = bwv[s16];
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
-            const float xv = bw * ((c & 1) ? __uint_as_float(qw[c >> 1] & 0xffff0000u) : __uint_as_float(qw[c >> 1] << 16));
+            const float xv = bw * ((c & 1) ? el16_hi(qw[c >> 1]) : el16_lo(qw[c >> 1]));
 #pragma unroll
             for (int co = 0; co < DYF_MAX_OUT_CH; ++co)
                 if (co < a.cout) acc[co] = fmaf(xv, wt[c * a.cout + co], acc[co]);
@@ -509,7 +509,7 @@ __global__ __launch_bounds__(256) void readout_regw_kernel(ReadoutArgs a, int px
         const int u = (u1 & 1) == pu ? u1 : u0;
         const int i = ((u + 1) >> 1) - (kh >> 1);
         const bool row_ok = (unsigned)i < (unsigned)a.ih;
-        const bf16_t* row = a.x + ((size_t)n * a.ih + (row_ok ? i : 0)) * a.iw * a.cin + ci0;
+        const el16_t* row = a.x + ((size_t)n * a.ih + (row_ok ? i : 0)) * a.iw * a.cin + ci0;
 #pragma unroll
         for (int kw = 0; kw < 4; ++kw) {
             const int pv = (kw + 1) & 1;
@@ -541,7 +541,7 @@ __global__ __launch_bounds__(256) void readout_regw_kernel(ReadoutArgs a, int px
             const uint32_t qw[4] = {p.q[kw].x, p.q[kw].y, p.q[kw].z, p.q[kw].w};
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
-                const float xv = p.bw[kw] * ((c & 1) ? __uint_as_float(qw[c >> 1] & 0xffff0000u) : __uint_as_float(qw[c >> 1] << 16));
+                const float xv = p.bw[kw] * ((c & 1) ? el16_hi(qw[c >> 1]) : el16_lo(qw[c >> 1]));
 #pragma unroll
                 for (int co = 0; co < CO; ++co) acc[co] = fmaf(xv, w[kw][c][co], acc[co]);
             }
@@ -571,7 +571,6 @@ __global__ __launch_bounds__(256) void readout_regw_kernel(ReadoutArgs a, int px
 // registers for the whole kernel, B = the pixels' input vectors: lane (pixel p, k-group g) loads 16 B of pixel p's tap
 // vector, exactly its MFMA operand), and the bilinear weight of the tap scales the 3 result rows with 3 FMAs.  Coordinates
 // are computed once per pixel by 4 lanes instead of 32.  Weights are bf16 here (fp32 in the other forms).
-typedef __attribute__((ext_vector_type(8))) __bf16 ro_bf16x8;
 typedef __attribute__((ext_vector_type(4))) float ro_f32x4;
 
 __global__ __launch_bounds__(256, 4) void readout_mfma_kernel(ReadoutArgs a, int groups_per_wave) {
@@ -584,7 +583,7 @@ __global__ __launch_bounds__(256, 4) void readout_mfma_kernel(ReadoutArgs a, int
     const int lane = threadIdx.x & 63;
     const int wave_id = (int)((blockIdx.x * 256 + threadIdx.x) >> 6);
     const int p = lane & 15, kg = lane >> 4;
-    const ro_bf16x8* wl = (const ro_bf16x8*)ro_smem + lane;
+    const el16x8_t* wl = (const el16x8_t*)ro_smem + lane;
     const int total = a.n * a.oh * a.ow;
     const int th = 2 * a.ih, tw = 2 * a.iw;
     const float sh = (float)th / (float)a.oh, sw = (float)tw / (float)a.ow;
@@ -633,7 +632,7 @@ __global__ __launch_bounds__(256, 4) void readout_mfma_kernel(ReadoutArgs a, int
             l_co[k] = __builtin_amdgcn_ds_bpermute(src4, co_[k]);
         }
         const int l_n = __builtin_amdgcn_ds_bpermute(src4, n);
-        const bf16_t* img = a.x + (size_t)l_n * a.ih * a.iw_store * 64 + lc * 8;
+        const el16_t* img = a.x + (size_t)l_n * a.ih * a.iw_store * 64 + lc * 8;
         const int take4 = ((lane & 15) * 4 + (lane >> 4)) * 4;
         float out[4] = {0.0f, 0.0f, 0.0f, 0.0f};
         // two batches of 8 taps (2 kernel rows): all 16 vector loads of a batch are in flight before its MFMAs
@@ -644,7 +643,7 @@ __global__ __launch_bounds__(256, 4) void readout_mfma_kernel(ReadoutArgs a, int
             for (int t = 0; t < 8; ++t) {
                 const int kh = b * 2 + (t >> 2), kw = t & 3;
                 const bool ok = l_ro[kh] >= 0 && l_co[kw] >= 0;
-                const bf16_t* px = img + (ok ? l_ro[kh] + l_co[kw] : 0);
+                const el16_t* px = img + (ok ? l_ro[kh] + l_co[kw] : 0);
                 q0[t] = *(const uint4*)px;
                 q1[t] = *(const uint4*)(px + 32);
                 if (!ok) { q0[t] = make_uint4(0u, 0u, 0u, 0u); q1[t] = q0[t]; }  // taps outside the image: data 0
@@ -658,8 +657,8 @@ __global__ __launch_bounds__(256, 4) void readout_mfma_kernel(ReadoutArgs a, int
                 m1.x = __builtin_amdgcn_ds_bpermute(take4, q1[t].x); m1.y = __builtin_amdgcn_ds_bpermute(take4, q1[t].y);
                 m1.z = __builtin_amdgcn_ds_bpermute(take4, q1[t].z); m1.w = __builtin_amdgcn_ds_bpermute(take4, q1[t].w);
                 ro_f32x4 d = {0.0f, 0.0f, 0.0f, 0.0f};
-                d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[(tap * 2 + 0) * 64], __builtin_bit_cast(ro_bf16x8, m0), d, 0, 0, 0);
-                d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[(tap * 2 + 1) * 64], __builtin_bit_cast(ro_bf16x8, m1), d, 0, 0, 0);
+                d = DYF_MFMA_16x16x32(wl[(tap * 2 + 0) * 64], __builtin_bit_cast(el16x8_t, m0), d, 0, 0, 0);
+                d = DYF_MFMA_16x16x32(wl[(tap * 2 + 1) * 64], __builtin_bit_cast(el16x8_t, m1), d, 0, 0, 0);
                 const float bw = (ro[kh] >= 0 && co_[kw] >= 0) ? rw[kh] * cw[kw] : 0.0f;  // this lane's own pixel
 #pragma unroll
                 for (int r = 0; r < 4; ++r) out[r] = fmaf(bw, d[r], out[r]);
@@ -831,17 +830,17 @@ hipError_t launch_boundary_conditions(const BcArgs& a, hipStream_t s) {
 
 // test seam (dyf_debug_read_block_output): NHWC bf16 activation -> NCHW fp32; col_map (or null) maps a dense column to its
 // column in a compact tensor of width w_store, -1 = not stored (NaN)
-__global__ void nhwc_to_nchw_f32_kernel(const bf16_t* src, int n, int h, int w, int w_store, int c, const int16_t* col_map,
+__global__ void nhwc_to_nchw_f32_kernel(const el16_t* src, int n, int h, int w, int w_store, int c, const int16_t* col_map,
                                         float* out) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long total = (long long)n * c * h * w;
     if (i >= total) return;
     const int x = (int)(i % w), y = (int)((i / w) % h), ch = (int)((i / ((long long)w * h)) % c), b = (int)(i / ((long long)w * h * c));
     const int xs = col_map ? col_map[x] : x;
-    out[i] = xs < 0 ? __uint_as_float(0x7fc00000u) : bf16_to_f32(src[(((size_t)b * h + y) * w_store + xs) * c + ch]);
+    out[i] = xs < 0 ? __uint_as_float(0x7fc00000u) : el16_to_f32(src[(((size_t)b * h + y) * w_store + xs) * c + ch]);
 }
 
-hipError_t launch_nhwc_to_nchw_f32(const bf16_t* src, int n, int h, int w, int w_store, int c, const int16_t* col_map,
+hipError_t launch_nhwc_to_nchw_f32(const el16_t* src, int n, int h, int w, int w_store, int c, const int16_t* col_map,
                                    float* out, hipStream_t s) {
     const long long total = (long long)n * c * h * w;
     hipLaunchKernelGGL(nhwc_to_nchw_f32_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, n, h, w, w_store, c,

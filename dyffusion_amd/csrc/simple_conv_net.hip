@@ -16,17 +16,17 @@ namespace dyf {
 struct SNet {
     int nk = 0;
     int ks[6] = {};
-    bf16_t* w[6] = {};          // [dim][k*k][cin] bf16
+    el16_t* w[6] = {};          // [dim][k*k][cin] bf16
     float *head_w = nullptr, *head_b = nullptr;
-    bf16_t* packed = nullptr;   // [max_batch][H][W][cin_total]
-    bf16_t* buf[2] = {};        // ping-pong activations [max_batch][H][W][dim]
+    el16_t* packed = nullptr;   // [max_batch][H][W][cin_total]
+    el16_t* buf[2] = {};        // ping-pong activations [max_batch][H][W][dim]
 };
 
 namespace {
 
 // cat of up to 4 NCHW fp32 tensors -> NHWC bf16
 __global__ void pack_inputs_kernel(const float* s0, const float* s1, const float* s2, const float* s3, int c0, int c1, int c2, int c3,
-                                   int n, int hw, bf16_t* out) {
+                                   int n, int hw, el16_t* out) {
     const int ctot = c0 + c1 + c2 + c3;
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long long)n * hw * ctot) return;
@@ -38,7 +38,7 @@ __global__ void pack_inputs_kernel(const float* s0, const float* s1, const float
     else if (c < c0 + c1) v = s1[((size_t)b * c1 + (c - c0)) * hw + p];
     else if (c < c0 + c1 + c2) v = s2[((size_t)b * c2 + (c - c0 - c1)) * hw + p];
     else v = s3[((size_t)b * c3 + (c - c0 - c1 - c2)) * hw + p];
-    out[idx] = f32_to_bf16(v);
+    out[idx] = f32_to_el16(v);
 }
 
 }  // namespace
@@ -133,11 +133,11 @@ dyf_status sc_load_weights(dyf_engine* e, Net& n, std::map<std::string, TensorVi
         NEED(rm, P + ".norm.running_mean", d);
         NEED(rv, P + ".norm.running_var", d);
         const int taps = (int)(k * k);
-        std::vector<bf16_t> pk((size_t)d * taps * cin);
+        std::vector<el16_t> pk((size_t)d * taps * cin);
         for (int co = 0; co < d; ++co)
             for (int ci = 0; ci < cin; ++ci)
                 for (int t = 0; t < taps; ++t)
-                    pk[((size_t)co * taps + t) * cin + ci] = f32_to_bf16(cw->data[((size_t)co * cin + ci) * taps + t]);
+                    pk[((size_t)co * taps + t) * cin + ci] = f32_to_el16(cw->data[((size_t)co * cin + ci) * taps + t]);
         UP(s->w[i], pk);
         const int off = i * (int)d;
         for (int ch = 0; ch < d; ++ch) {  // eval-mode BatchNorm2d folded with the conv bias: y = conv*a + c
@@ -192,7 +192,7 @@ dyf_status sc_forward(dyf_engine* e, int which, const Source* srcs, int nsrc, in
     hipLaunchKernelGGL(pack_inputs_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, sp[0], sp[1], sp[2], sp[3], sc[0],
                        sc[1], sc[2], sc[3], nb, hw, s->packed);
     HIP_TRY(e, hipGetLastError());
-    const bf16_t* x = s->packed;
+    const el16_t* x = s->packed;
     int cin = ctot;
     for (int i = 0; i < s->nk; ++i) {
         ConvArgs a{};
@@ -212,7 +212,7 @@ dyf_status sc_forward(dyf_engine* e, int which, const Source* srcs, int nsrc, in
         if (d.mode == 2 && d.mask == nullptr) d.mode = 0;
         a.drop = d;
         a.residual = (cin == n.dim) ? x : nullptr;  // simple_conv_net.py:52-54 (residual=True)
-        a.out_bf16 = s->buf[i & 1];
+        a.out_el16 = s->buf[i & 1];
         a.zero_page = e->ws.zero_page;
         HIP_TRY(e, launch_conv(a, 0, st));
         x = s->buf[i & 1];

@@ -12,17 +12,17 @@ struct StemConvArgs {
     const float* wgt;   // [k*k][cin][dim] fp32
     const float* bias;  // [dim]
     int dim;
-    bf16_t* out;        // [n][h][w][dim]
-    const bf16_t* wfrag = nullptr;  // pack_stem_frag(): MFMA form (dim == 64), or null -> VALU form
+    el16_t* out;        // [n][h][w][dim]
+    const el16_t* wfrag = nullptr;  // pack_stem_frag(): MFMA form (dim == 64), or null -> VALU form
     int ksteps = 0;                 // ceil(k*k*cin / 16)
 };
 // [tap][cin][dim] fp32 -> A fragments of the MFMA stem: [k-step][32-channel block][hi/lo part][lane][8] bf16
-void pack_stem_frag(const float* wgt, int kk_total, int dim, bf16_t* out);
+void pack_stem_frag(const float* wgt, int kk_total, int dim, el16_t* out);
 hipError_t launch_stem_conv(const StemConvArgs& a, hipStream_t s);
 
 // K5: GroupNorm(G) + FiLM + SiLU + Dropout (+ residual) of unet.Block (unet.py:58-76) on a bf16 NHWC tensor
 struct GnActArgs {
-    const bf16_t* x;        // raw conv output [n][hw][c]
+    const el16_t* x;        // raw conv output [n][hw][c]
     int n, hw, c, groups;
     const float* gamma;
     const float* beta;
@@ -31,45 +31,47 @@ struct GnActArgs {
     int film_stride;
     int act;
     DropSpec drop;
-    const bf16_t* residual; // added last (ResnetBlock: h + residual_conv(x)), or null
-    bf16_t* out;
-    double* stats;          // device scratch [n][groups][2] (sum, sum of squares) for the vectorised form, or null
+    const el16_t* residual; // added last (ResnetBlock: h + residual_conv(x)), or null
+    el16_t* out;
+    double* stats;          // device scratch of gn_stats_doubles(n, groups) doubles for the vectorised form, or null
 };
+#define GN_MAX_BLOCKS 64    // workgroups per sample of the statistics pass
+inline size_t gn_stats_doubles(size_t n, size_t groups) { return n * groups * (2 * GN_MAX_BLOCKS + 1); }
 hipError_t launch_gn_act(const GnActArgs& a, hipStream_t s);
 
 // K6: channel LayerNorm (gain only, biased variance, eps 1e-5) + optional Dropout (unet.py:43-52; attention.py:12)
 struct LayerNormArgs {
-    const bf16_t* x;    // [pixels][c]
+    const el16_t* x;    // [pixels][c]
     long long pixels;   // n * hw
     int hw;             // pixels per batch row (the dropout streams are per row)
     int c;
     const float* g;     // [c]
     DropSpec drop;
-    bf16_t* out;
+    el16_t* out;
 };
 hipError_t launch_layernorm_c(const LayerNormArgs& a, hipStream_t s);
 
 // K7: LinearAttention core (attention.py:22-31, rescale "qkv"): qkv [n][hw][3*heads*32] -> out [n][hw][heads*32]
 struct LinAttnArgs {
-    const bf16_t* qkv;
+    const el16_t* qkv;
     int n, hw, heads;   // dim_head = 32
-    bf16_t* out;
+    el16_t* out;
     float* scratch;     // device fp32 [n*heads][ceil(hw/1024)*1088 + 1024] for the pixel-parallel form, or null
 };
 hipError_t launch_linear_attention(const LinAttnArgs& a, hipStream_t s);
 
 // K8 (VALU form for short sequences): softmax(q*scale . k) -> Dropout -> . v  (attention.py:62-72)
 struct AttnArgs {
-    const bf16_t* qkv;      // [n][hw][3*heads*32]
+    const el16_t* qkv;      // [n][hw][3*heads*32]
     int n, hw, heads;
     DropSpec drop;          // on the probabilities; element index ((n*heads + h)*hw + i)*hw + j
-    bf16_t* out;            // [n][hw][heads*32]
+    el16_t* out;            // [n][hw][heads*32]
 };
 hipError_t launch_attention(const AttnArgs& a, hipStream_t s);
 
 // final 1x1 conv to the output channels -> NCHW fp32 (unet.py:244-245, :309)
 struct HeadArgs {
-    const bf16_t* x;    // [n][hw][c]
+    const el16_t* x;    // [n][hw][c]
     int n, hw, c, cout;
     const float* wgt;   // [cout][c]
     const float* bias;
@@ -78,4 +80,4 @@ struct HeadArgs {
 hipError_t launch_head(const HeadArgs& a, hipStream_t s);
 
 // nn.Upsample(scale_factor=2, mode="nearest") (unet.py:16-19) on NHWC bf16
-hipError_t launch_up2x_nearest(const bf16_t* src, int n, int h, int w, int c, bf16_t* out, hipStream_t s);
+hipError_t launch_up2x_nearest(const el16_t* src, int n, int h, int w, int c, el16_t* out, hipStream_t s);

@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(StemConvArgs a) {
     const int n = (int)(pix / ((long long)a.h * a.w));
     const int rem = (int)(pix % ((long long)a.h * a.w));
     const int y = rem / a.w, x = rem % a.w;
-    bf16_t* out = a.out + (size_t)pix * a.dim;
+    el16_t* out = a.out + (size_t)pix * a.dim;
     const bool vec = (a.dim & 15) == 0;
     for (int d0 = 0; d0 < a.dim; d0 += 16) {
         float acc[16];
@@ -80,16 +80,16 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(StemConvArgs a) {
         }
         if (vec) {
             uint4 o0, o1;
-            o0.x = pack_bf16x2(acc[0], acc[1]); o0.y = pack_bf16x2(acc[2], acc[3]);
-            o0.z = pack_bf16x2(acc[4], acc[5]); o0.w = pack_bf16x2(acc[6], acc[7]);
-            o1.x = pack_bf16x2(acc[8], acc[9]); o1.y = pack_bf16x2(acc[10], acc[11]);
-            o1.z = pack_bf16x2(acc[12], acc[13]); o1.w = pack_bf16x2(acc[14], acc[15]);
+            o0.x = pack_el16x2(acc[0], acc[1]); o0.y = pack_el16x2(acc[2], acc[3]);
+            o0.z = pack_el16x2(acc[4], acc[5]); o0.w = pack_el16x2(acc[6], acc[7]);
+            o1.x = pack_el16x2(acc[8], acc[9]); o1.y = pack_el16x2(acc[10], acc[11]);
+            o1.z = pack_el16x2(acc[12], acc[13]); o1.w = pack_el16x2(acc[14], acc[15]);
             *(uint4*)(out + d0) = o0;
             *(uint4*)(out + d0 + 8) = o1;
         } else {
 #pragma unroll
             for (int t = 0; t < 16; ++t)
-                if (d0 + t < a.dim) out[d0 + t] = f32_to_bf16(acc[t]);
+                if (d0 + t < a.dim) out[d0 + t] = f32_to_el16(acc[t]);
         }
     }
 }
@@ -100,7 +100,6 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(StemConvArgs a) {
 // L1), bounds-checked per tap (zero padding).  Inputs and weights are split into bf16 hi + lo parts and multiplied as
 // hi*hi + lo*hi + hi*lo, so the result matches the fp32 VALU form to ~2^-16 -- the network input is not rounded to bf16.
 // The (tap, cin) -> (source, offset, dy, dx) table and the weight fragments sit in LDS.
-typedef __attribute__((ext_vector_type(8))) __bf16 st_bf16x8;
 typedef __attribute__((ext_vector_type(16))) float st_f32x16;
 constexpr int STEM_MAX_KSTEPS = 16;
 
@@ -155,33 +154,33 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(StemConvArgs a) {
             uint32_t bh[4], bl[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                bh[t] = pack_bf16x2(v[2 * t], v[2 * t + 1]);
-                bl[t] = pack_bf16x2(v[2 * t] - __uint_as_float(bh[t] << 16), v[2 * t + 1] - __uint_as_float(bh[t] & 0xffff0000u));
+                bh[t] = pack_el16x2(v[2 * t], v[2 * t + 1]);
+                bl[t] = pack_el16x2(v[2 * t] - el16_lo(bh[t]), v[2 * t + 1] - el16_hi(bh[t]));
             }
-            const st_bf16x8 xh = __builtin_bit_cast(st_bf16x8, make_uint4(bh[0], bh[1], bh[2], bh[3]));
-            const st_bf16x8 xl = __builtin_bit_cast(st_bf16x8, make_uint4(bl[0], bl[1], bl[2], bl[3]));
+            const el16x8_t xh = __builtin_bit_cast(el16x8_t, make_uint4(bh[0], bh[1], bh[2], bh[3]));
+            const el16x8_t xl = __builtin_bit_cast(el16x8_t, make_uint4(bl[0], bl[1], bl[2], bl[3]));
 #pragma unroll
             for (int rb = 0; rb < 2; ++rb) {
-                const st_bf16x8 wh = __builtin_bit_cast(st_bf16x8, wf[((s * 2 + rb) * 2 + 0) * 64 + lane]);
-                const st_bf16x8 wl = __builtin_bit_cast(st_bf16x8, wf[((s * 2 + rb) * 2 + 1) * 64 + lane]);
-                acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xh, acc[rb], 0, 0, 0);
-                acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, xh, acc[rb], 0, 0, 0);
-                acc[rb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, xl, acc[rb], 0, 0, 0);
+                const el16x8_t wh = __builtin_bit_cast(el16x8_t, wf[((s * 2 + rb) * 2 + 0) * 64 + lane]);
+                const el16x8_t wl = __builtin_bit_cast(el16x8_t, wf[((s * 2 + rb) * 2 + 1) * 64 + lane]);
+                acc[rb] = DYF_MFMA_32x32x16(wh, xh, acc[rb], 0, 0, 0);
+                acc[rb] = DYF_MFMA_32x32x16(wl, xh, acc[rb], 0, 0, 0);
+                acc[rb] = DYF_MFMA_32x32x16(wh, xl, acc[rb], 0, 0, 0);
             }
         }
         // lane (pixel, hi) holds channels rb*32 + 8 (r >> 2) + 4 hi + (r & 3); groups 2 g2 / 2 g2 + 1 are exchanged between
         // lanes p and p + 32 so that every lane stores 8 consecutive channels (as in the conv epilogues)
-        bf16_t* op = a.out + (size_t)pix * a.dim + hi * 8;
+        el16_t* op = a.out + (size_t)pix * a.dim + hi * 8;
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
             for (int g2 = 0; g2 < 2; ++g2) {
                 const int cb = rb * 32 + g2 * 16 + 4 * hi;
                 const float4 ba = *(const float4*)(a.bias + cb), bb = *(const float4*)(a.bias + cb + 8);
-                const uint32_t p0 = pack_bf16x2(acc[rb][g2 * 8 + 0] + ba.x, acc[rb][g2 * 8 + 1] + ba.y);
-                const uint32_t p1 = pack_bf16x2(acc[rb][g2 * 8 + 2] + ba.z, acc[rb][g2 * 8 + 3] + ba.w);
-                const uint32_t q0 = pack_bf16x2(acc[rb][g2 * 8 + 4] + bb.x, acc[rb][g2 * 8 + 5] + bb.y);
-                const uint32_t q1 = pack_bf16x2(acc[rb][g2 * 8 + 6] + bb.z, acc[rb][g2 * 8 + 7] + bb.w);
+                const uint32_t p0 = pack_el16x2(acc[rb][g2 * 8 + 0] + ba.x, acc[rb][g2 * 8 + 1] + ba.y);
+                const uint32_t p1 = pack_el16x2(acc[rb][g2 * 8 + 2] + ba.z, acc[rb][g2 * 8 + 3] + ba.w);
+                const uint32_t q0 = pack_el16x2(acc[rb][g2 * 8 + 4] + bb.x, acc[rb][g2 * 8 + 5] + bb.y);
+                const uint32_t q1 = pack_el16x2(acc[rb][g2 * 8 + 6] + bb.z, acc[rb][g2 * 8 + 7] + bb.w);
                 const auto s0 = __builtin_amdgcn_permlane32_swap(p0, q0, false, false);
                 const auto s1 = __builtin_amdgcn_permlane32_swap(p1, q1, false, false);
                 uint4 o;
@@ -191,7 +190,7 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(StemConvArgs a) {
     }
 }
 
-void pack_stem_frag(const float* wgt, int kk_total, int dim, bf16_t* out) {
+void pack_stem_frag(const float* wgt, int kk_total, int dim, el16_t* out) {
     const int ksteps = (kk_total + 15) / 16;
     size_t o = 0;
     for (int s = 0; s < ksteps; ++s)
@@ -201,11 +200,8 @@ void pack_stem_frag(const float* wgt, int kk_total, int dim, bf16_t* out) {
                     for (int j = 0; j < 8; ++j) {
                         const int kk = s * 16 + (lane >> 5) * 8 + j, ch = rb * 32 + (lane & 31);
                         const float w = kk < kk_total ? wgt[(size_t)kk * dim + ch] : 0.0f;
-                        const bf16_t h = f32_to_bf16(w);
-                        float hf;
-                        const uint32_t hb = (uint32_t)h << 16;
-                        __builtin_memcpy(&hf, &hb, 4);
-                        out[o++] = hl == 0 ? h : f32_to_bf16(w - hf);
+                        const el16_t h = f32_to_el16(w);
+                        out[o++] = hl == 0 ? h : f32_to_el16(w - el16_to_f32(h));
                     }
 }
 
@@ -240,13 +236,13 @@ __global__ __launch_bounds__(256) void gn_act_kernel(GnActArgs a) {
     const int n = blockIdx.x / a.groups, g = blockIdx.x % a.groups;
     const int cpg = a.c / a.groups;
     const int count = a.hw * cpg;
-    const bf16_t* x = a.x + (size_t)n * a.hw * a.c + g * cpg;
+    const el16_t* x = a.x + (size_t)n * a.hw * a.c + g * cpg;
     float s = 0.0f;
-    for (int i = threadIdx.x; i < count; i += blockDim.x) s += bf16_to_f32(x[(size_t)(i / cpg) * a.c + (i % cpg)]);
+    for (int i = threadIdx.x; i < count; i += blockDim.x) s += el16_to_f32(x[(size_t)(i / cpg) * a.c + (i % cpg)]);
     const float mean = bsum(s, scratch) / (float)count;
     float v = 0.0f;
     for (int i = threadIdx.x; i < count; i += blockDim.x) {
-        const float d = bf16_to_f32(x[(size_t)(i / cpg) * a.c + (i % cpg)]) - mean;
+        const float d = el16_to_f32(x[(size_t)(i / cpg) * a.c + (i % cpg)]) - mean;
         v = fmaf(d, d, v);
     }
     const float rstd = rsqrtf(bsum(v, scratch) / (float)count + 1e-5f);
@@ -255,15 +251,15 @@ __global__ __launch_bounds__(256) void gn_act_kernel(GnActArgs a) {
     for (int i = threadIdx.x; i < count; i += blockDim.x) {
         const int p = i / cpg, ch = g * cpg + (i % cpg);
         const size_t e = ((size_t)n * a.hw + p) * a.c + ch;
-        float y = (bf16_to_f32(a.x[e]) - mean) * rstd * a.gamma[ch] + a.beta[ch];
+        float y = (el16_to_f32(a.x[e]) - mean) * rstd * a.gamma[ch] + a.beta[ch];
         if (a.film_a) {
             const size_t fi = (size_t)n * a.film_stride + ch;
             y = fmaf(y, a.film_a[fi], a.film_c[fi]);
         }
         y = apply_act(y, a.act);
         y = drop_apply(y, (uint32_t)e, row0, a.drop, key);
-        if (a.residual) y += bf16_to_f32(a.residual[e]);
-        a.out[e] = f32_to_bf16(y);
+        if (a.residual) y += el16_to_f32(a.residual[e]);
+        a.out[e] = f32_to_el16(y);
     }
 }
 
@@ -271,11 +267,15 @@ __global__ __launch_bounds__(256) void gn_act_kernel(GnActArgs a) {
 // of one pixel.  (1) statistics: per-workgroup LDS partials -> one fp64 atomic per (sample, group) and workgroup;
 // (2) apply: normalise + FiLM + SiLU + dropout (+ residual), one 16-B load and one 16-B store per lane.
 // HBM traffic: 2 reads + 1 write of the tensor (+1 read of the residual) instead of 3 strided read passes.
-__global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* x, int hw, int c, int groups, double* stats) {
-    __shared__ float part[64][2];  // groups <= 64
+// Deterministic: every wave owns a slot per group in LDS (one lane per group and wave writes it), the four slots are added in
+// wave order, and each workgroup stores its partial to stats[n][group][sum | sum of squares][workgroup]; gn_finalize_kernel
+// adds the workgroups' partials in index order.  (Atomic merges made GroupNorm -- and with it every rollout of the ResNet-UNet
+// -- differ from run to run by a rounding flip that the sampling recursion amplifies.)
+__global__ __launch_bounds__(256) void gn_stats_kernel(const el16_t* x, int hw, int c, int groups, double* stats) {
+    __shared__ float part[4][64][2];  // [wave][group]; groups <= 64
     const int n = blockIdx.y;
     const int chunks = c >> 3, cpg = c / groups;
-    for (int i = threadIdx.x; i < groups * 2; i += blockDim.x) (&part[0][0])[i] = 0.0f;
+    for (int i = threadIdx.x; i < 4 * 64 * 2; i += blockDim.x) (&part[0][0][0])[i] = 0.0f;
     __syncthreads();
     const int cq = cpg >> 3;  // chunks per group
     const bool pow2 = (chunks & (chunks - 1)) == 0 && (cq & (cq - 1)) == 0 && chunks <= 256;
@@ -283,7 +283,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* x, int hw, 
         // a thread keeps ONE chunk column (q) and walks pixels: no index arithmetic in the loop, the group never changes, so
         // the partial sums stay in registers until the end
         const int q = threadIdx.x & (chunks - 1), row = threadIdx.x / chunks, rows = 256 / chunks;
-        const bf16_t* xp = x + (size_t)n * hw * c + q * 8;
+        const el16_t* xp = x + (size_t)n * hw * c + q * 8;
         float s = 0.0f, ss = 0.0f;
         const int step = gridDim.x * rows;
         int p = blockIdx.x * rows + row;
@@ -291,7 +291,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* x, int hw, 
             const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                const float lo = __uint_as_float(w[t] << 16), hi = __uint_as_float(w[t] & 0xffff0000u);
+                const float lo = el16_lo(w[t]), hi = el16_hi(w[t]);
                 s += lo + hi;
                 ss = fmaf(lo, lo, fmaf(hi, hi, ss));
             }
@@ -303,7 +303,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* x, int hw, 
         }
         for (; p < hw; p += step) add(*(const uint4*)(xp + (size_t)p * c));
         // lanes l and l ^ d hold the same group when d < cq (neighbouring chunks of the group) or d >= chunks (same chunk,
-        // another pixel row): butterfly over those strides, then one LDS atomic per group and wave
+        // another pixel row): butterfly over those strides, then one LDS slot per group and wave
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
             if (d < cq || d >= chunks) {
@@ -314,8 +314,8 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* x, int hw, 
         const int l = threadIdx.x & 63;
         if ((l & (cq - 1)) == 0 && (chunks >= 64 || l < chunks)) {
             const int g = (q * 8) / cpg;
-            atomicAdd(&part[g][0], s);
-            atomicAdd(&part[g][1], ss);
+            part[threadIdx.x >> 6][g][0] = s;   // exactly one lane of the wave holds group g
+            part[threadIdx.x >> 6][g][1] = ss;
         }
     } else {
         const long long total = (long long)hw * chunks;
@@ -327,26 +327,34 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const bf16_t* x, int hw, 
             float s = 0.0f, ss = 0.0f;
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                const float lo = __uint_as_float(w[t] << 16), hi = __uint_as_float(w[t] & 0xffff0000u);
+                const float lo = el16_lo(w[t]), hi = el16_hi(w[t]);
                 s += lo + hi;
                 ss = fmaf(lo, lo, fmaf(hi, hi, ss));
             }
             const int g = (q * 8) / cpg;
-            atomicAdd(&part[g][0], s);
-            atomicAdd(&part[g][1], ss);
+            atomicAdd(&part[0][g][0], s);   // channel counts whose 16-byte chunks are not a power of two: order not fixed
+            atomicAdd(&part[0][g][1], ss);
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < groups * 2; i += blockDim.x)
-        atomicAdd(&stats[((size_t)n * groups) * 2 + i], (double)(&part[0][0])[i]);
+    for (int i = threadIdx.x; i < groups * 2; i += blockDim.x) {
+        const int g = i >> 1, k = i & 1;
+        const double v = (double)part[0][g][k] + (double)part[1][g][k] + (double)part[2][g][k] + (double)part[3][g][k];
+        stats[(((size_t)n * groups + g) * 2 + k) * GN_MAX_BLOCKS + blockIdx.x] = v;
+    }
 }
 
 // (sum, sum of squares) in fp64 -> (mean, 1/std) in fp32, once per (sample, group) instead of once per lane of the apply pass
-__global__ void gn_finalize_kernel(const double* stats, int count, double inv_cnt, float2* mr) {
+__global__ void gn_finalize_kernel(const double* stats, int count, int nblocks, double inv_cnt, float2* mr) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
-    const double mean = stats[2 * i] * inv_cnt;
-    const double var = stats[2 * i + 1] * inv_cnt - mean * mean;
+    double s = 0.0, ss = 0.0;
+    for (int b = 0; b < nblocks; ++b) {  // fixed order
+        s += stats[((size_t)i * 2 + 0) * GN_MAX_BLOCKS + b];
+        ss += stats[((size_t)i * 2 + 1) * GN_MAX_BLOCKS + b];
+    }
+    const double mean = s * inv_cnt;
+    const double var = ss * inv_cnt - mean * mean;
     mr[i] = make_float2((float)mean, rsqrtf(fmaxf((float)var, 0.0f) + 1e-5f));
 }
 
@@ -389,7 +397,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnActArgs a, const float2
     float y[8];
 #pragma unroll
     for (int t = 0; t < 8; ++t) {
-        const float xv = (t & 1) ? __uint_as_float(w[t >> 1] & 0xffff0000u) : __uint_as_float(w[t >> 1] << 16);
+        const float xv = (t & 1) ? el16_hi(w[t >> 1]) : el16_lo(w[t >> 1]);
         y[t] = fmaf(xv, A[t], C[t]);
     }
     act_drop<8>(y, (uint32_t)e0, (uint32_t)((size_t)n * a.hw * a.c), a.act, a.drop, drop_row_key(a.drop, n));  // (activation, dropout mode) dispatched once
@@ -398,25 +406,24 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnActArgs a, const float2
         const uint32_t rw[4] = {r.x, r.y, r.z, r.w};
 #pragma unroll
         for (int t = 0; t < 8; ++t)
-            y[t] += (t & 1) ? __uint_as_float(rw[t >> 1] & 0xffff0000u) : __uint_as_float(rw[t >> 1] << 16);
+            y[t] += (t & 1) ? el16_hi(rw[t >> 1]) : el16_lo(rw[t >> 1]);
     }
-    *(uint4*)(a.out + e0) = make_uint4(pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]), pack_bf16x2(y[4], y[5]),
-                                       pack_bf16x2(y[6], y[7]));
+    *(uint4*)(a.out + e0) = make_uint4(pack_el16x2(y[0], y[1]), pack_el16x2(y[2], y[3]), pack_el16x2(y[4], y[5]),
+                                       pack_el16x2(y[6], y[7]));
 }
 
 hipError_t launch_gn_act(const GnActArgs& a, hipStream_t s) {
     const int cpg = a.c / a.groups;
     if (a.stats && (a.c % 8 == 0) && (cpg % 8 == 0) && a.groups <= 64) {
-        hipError_t e = hipMemsetAsync(a.stats, 0, (size_t)a.n * a.groups * 2 * sizeof(double), s);
-        if (e != hipSuccess) return e;
         const long long per_sample = (long long)a.hw * (a.c >> 3);
-        // >= 4 passes of 256 lanes per workgroup (the partial sums are merged with atomics), at most 64 workgroups per sample
-        const unsigned bx = (unsigned)std::max<long long>(1, std::min<long long>((per_sample + 1023) / 1024, 64));
+        // >= 4 passes of 256 lanes per workgroup, at most GN_MAX_BLOCKS workgroups per sample (their partials are added in order)
+        const unsigned bx = (unsigned)std::max<long long>(1, std::min<long long>((per_sample + 1023) / 1024, GN_MAX_BLOCKS));
         hipLaunchKernelGGL(gn_stats_kernel, dim3(bx, a.n), dim3(256), 0, s, a.x, a.hw, a.c, a.groups, a.stats);
         const long long total = (long long)a.n * per_sample;
-        float2* mr = (float2*)(a.stats + (size_t)a.n * a.groups * 2);  // the scratch holds [n][groups][2] doubles + as many floats
+        // the scratch holds [n][groups][2][GN_MAX_BLOCKS] doubles + [n][groups] float2 (gn_stats_doubles())
+        float2* mr = (float2*)(a.stats + (size_t)a.n * a.groups * 2 * GN_MAX_BLOCKS);
         const int cnt = a.n * a.groups;
-        hipLaunchKernelGGL(gn_finalize_kernel, dim3((cnt + 255) / 256), dim3(256), 0, s, (const double*)a.stats, cnt,
+        hipLaunchKernelGGL(gn_finalize_kernel, dim3((cnt + 255) / 256), dim3(256), 0, s, (const double*)a.stats, cnt, (int)bx,
                            1.0 / ((double)a.hw * cpg), mr);
         hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a, (const float2*)mr);
         return hipGetLastError();
@@ -433,15 +440,15 @@ __global__ __launch_bounds__(256) void layernorm_c_kernel(LayerNormArgs a) {
     const int sl = (int)(gid & 7);
     const bool live = pix < a.pixels;
     if (!live) pix = a.pixels - 1;
-    const bf16_t* x = a.x + (size_t)pix * a.c;
+    const el16_t* x = a.x + (size_t)pix * a.c;
     float s = 0.0f;
-    for (int c = sl; c < a.c; c += 8) s += bf16_to_f32(x[c]);
+    for (int c = sl; c < a.c; c += 8) s += el16_to_f32(x[c]);
 #pragma unroll
     for (int off = 4; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
     const float mean = s / (float)a.c;
     float v = 0.0f;
     for (int c = sl; c < a.c; c += 8) {
-        const float d = bf16_to_f32(x[c]) - mean;
+        const float d = el16_to_f32(x[c]) - mean;
         v = fmaf(d, d, v);
     }
 #pragma unroll
@@ -453,9 +460,9 @@ __global__ __launch_bounds__(256) void layernorm_c_kernel(LayerNormArgs a) {
     const uint32_t row0 = (uint32_t)((size_t)n * a.hw * a.c);
     for (int c = sl; c < a.c; c += 8) {
         const size_t e = (size_t)pix * a.c + c;
-        float y = (bf16_to_f32(x[c]) - mean) * rstd * a.g[c];
+        float y = (el16_to_f32(x[c]) - mean) * rstd * a.g[c];
         y = drop_apply(y, (uint32_t)e, row0, a.drop, key);
-        a.out[e] = f32_to_bf16(y);
+        a.out[e] = f32_to_el16(y);
     }
 }
 
@@ -472,7 +479,7 @@ __global__ __launch_bounds__(256) void layernorm_c_vec_kernel(LayerNormArgs a, i
     const uint32_t w[4] = {v.x, v.y, v.z, v.w};
     float x[8];
 #pragma unroll
-    for (int t = 0; t < 8; ++t) x[t] = (t & 1) ? __uint_as_float(w[t >> 1] & 0xffff0000u) : __uint_as_float(w[t >> 1] << 16);
+    for (int t = 0; t < 8; ++t) x[t] = (t & 1) ? el16_hi(w[t >> 1]) : el16_lo(w[t >> 1]);
     float s = 0.0f;
 #pragma unroll
     for (int t = 0; t < 8; ++t) s += x[t];
@@ -494,8 +501,8 @@ __global__ __launch_bounds__(256) void layernorm_c_vec_kernel(LayerNormArgs a, i
     for (int t = 0; t < 8; ++t) y[t] = x[t] * rstd * g[t];
     const int n = (int)(pix / a.hw);
     act_drop<8>(y, (uint32_t)e0, (uint32_t)((size_t)n * a.hw * a.c), ACT_NONE, a.drop, drop_row_key(a.drop, n));
-    *(uint4*)(a.out + e0) = make_uint4(pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]), pack_bf16x2(y[4], y[5]),
-                                       pack_bf16x2(y[6], y[7]));
+    *(uint4*)(a.out + e0) = make_uint4(pack_el16x2(y[0], y[1]), pack_el16x2(y[2], y[3]), pack_el16x2(y[4], y[5]),
+                                       pack_el16x2(y[6], y[7]));
 }
 
 hipError_t launch_layernorm_c(const LayerNormArgs& a, hipStream_t s) {
@@ -520,12 +527,12 @@ __global__ __launch_bounds__(256) void linear_attention_kernel(LinAttnArgs a) {
     __shared__ float tile_k[64][33], tile_v[64][33];
     const int n = blockIdx.x / a.heads, h = blockIdx.x % a.heads;
     const int C3 = 3 * a.heads * 32, hd = a.heads * 32;
-    const bf16_t* base = a.qkv + (size_t)n * a.hw * C3;
+    const el16_t* base = a.qkv + (size_t)n * a.hw * C3;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int d = tid & 31, grp = tid >> 5;  // 8 pixel-groups x 32 channels
     // ---- pass 1: max over pixels of k[d][.]
     float m = -3.0e38f;
-    for (int p = grp; p < a.hw; p += 8) m = fmaxf(m, bf16_to_f32(base[(size_t)p * C3 + hd + h * 32 + d]));
+    for (int p = grp; p < a.hw; p += 8) m = fmaxf(m, el16_to_f32(base[(size_t)p * C3 + hd + h * 32 + d]));
     red[grp][d] = m;
     __syncthreads();
     if (tid < 32) {
@@ -537,7 +544,7 @@ __global__ __launch_bounds__(256) void linear_attention_kernel(LinAttnArgs a) {
     // ---- pass 2: sum over pixels of exp(k - max)
     float sacc = 0.0f;
     const float km = kmax[d];
-    for (int p = grp; p < a.hw; p += 8) sacc += __expf(bf16_to_f32(base[(size_t)p * C3 + hd + h * 32 + d]) - km);
+    for (int p = grp; p < a.hw; p += 8) sacc += __expf(el16_to_f32(base[(size_t)p * C3 + hd + h * 32 + d]) - km);
     __syncthreads();
     red[grp][d] = sacc;
     __syncthreads();
@@ -557,8 +564,8 @@ __global__ __launch_bounds__(256) void linear_attention_kernel(LinAttnArgs a) {
             const int p = p0 + pp;
             float kv = 0.0f, vv = 0.0f;
             if (p < a.hw) {
-                kv = __expf(bf16_to_f32(base[(size_t)p * C3 + hd + h * 32 + ch]) - kmax[ch]) / ksum[ch];
-                vv = bf16_to_f32(base[(size_t)p * C3 + 2 * hd + h * 32 + ch]);
+                kv = __expf(el16_to_f32(base[(size_t)p * C3 + hd + h * 32 + ch]) - kmax[ch]) / ksum[ch];
+                vv = el16_to_f32(base[(size_t)p * C3 + 2 * hd + h * 32 + ch]);
             }
             tile_k[pp][ch] = kv;
             tile_v[pp][ch] = vv;
@@ -579,10 +586,10 @@ __global__ __launch_bounds__(256) void linear_attention_kernel(LinAttnArgs a) {
     for (int p = tid; p < a.hw; p += 256) {
         float q[32];
         float qm = -3.0e38f;
-        const bf16_t* qp = base + (size_t)p * C3 + h * 32;
+        const el16_t* qp = base + (size_t)p * C3 + h * 32;
 #pragma unroll
         for (int i = 0; i < 32; ++i) {
-            q[i] = bf16_to_f32(qp[i]);
+            q[i] = el16_to_f32(qp[i]);
             qm = fmaxf(qm, q[i]);
         }
         float qs = 0.0f;
@@ -592,12 +599,12 @@ __global__ __launch_bounds__(256) void linear_attention_kernel(LinAttnArgs a) {
             qs += q[i];
         }
         const float qn = scale / qs;
-        bf16_t* op = a.out + ((size_t)n * a.hw + p) * hd + h * 32;
+        el16_t* op = a.out + ((size_t)n * a.hw + p) * hd + h * 32;
         for (int e = 0; e < 32; ++e) {
             float o = 0.0f;
 #pragma unroll
             for (int i = 0; i < 32; ++i) o = fmaf(ctx[i][e], q[i], o);
-            op[e] = f32_to_bf16(o * qn);
+            op[e] = f32_to_el16(o * qn);
         }
     }
     (void)lane; (void)wave;
@@ -616,17 +623,16 @@ __global__ __launch_bounds__(256) void linear_attention_kernel(LinAttnArgs a) {
 constexpr int LA_HEADS = 4;        // LinearAttention(dim) always has 4 heads of 32 channels (unet.py)
 constexpr int LA_PIX = 1024;       // pixels per workgroup of the context kernel (256 per wave)
 constexpr int LA_PART = 1024 + 64; // floats of one partial: acc[16][64], max[32], sum[32]
-typedef __attribute__((ext_vector_type(8))) __bf16 la_bf16x8;
 typedef __attribute__((ext_vector_type(16))) float la_f32x16;
 
-__device__ __forceinline__ la_bf16x8 la_frag(const uint32_t (&w)[4]) {
+__device__ __forceinline__ el16x8_t la_frag(const uint32_t (&w)[4]) {
     const uint4 v = make_uint4(w[0], w[1], w[2], w[3]);
-    return __builtin_bit_cast(la_bf16x8, v);
+    return __builtin_bit_cast(el16x8_t, v);
 }
 // x -> bf16 hi part (round to nearest) and bf16 lo part of the remainder
 __device__ __forceinline__ void la_split(float x0, float x1, uint32_t& hi, uint32_t& lo) {
-    hi = pack_bf16x2(x0, x1);
-    lo = pack_bf16x2(x0 - __uint_as_float(hi << 16), x1 - __uint_as_float(hi & 0xffff0000u));
+    hi = pack_el16x2(x0, x1);
+    lo = pack_el16x2(x0 - el16_lo(hi), x1 - el16_hi(hi));
 }
 
 __global__ __launch_bounds__(256) void linattn_ctx_mfma_kernel(LinAttnArgs a, float* part, int nblk) {
@@ -644,7 +650,7 @@ __global__ __launch_bounds__(256) void linattn_ctx_mfma_kernel(LinAttnArgs a, fl
     // The tail wave of a (sample, head) puts the walk into voffset instead, with the buffer ending at the last pixel of the
     // sample (the range check covers voffset only): pixels past it read 0 and are masked (k: a very negative value).
     const unsigned lane_off = (unsigned)(hi * 8 * C3 + c) * 2u;
-    const bf16_t* kw = a.qkv + ((size_t)n * a.hw + pw) * C3 + hd + h * 32;  // wave-uniform
+    const el16_t* kw = a.qkv + ((size_t)n * a.hw + pw) * C3 + hd + h * 32;  // wave-uniform
     auto wave_body = [&](auto full_c) {
         constexpr bool FULL = decltype(full_c)::value;
         const int left = a.hw - pw;  // valid pixels of this wave (tail: 1..255)
@@ -675,7 +681,7 @@ __global__ __launch_bounds__(256) void linattn_ctx_mfma_kernel(LinAttnArgs a, fl
 #pragma unroll
         for (int t = 0; t < PF; ++t) issue_v(t);
 #pragma unroll
-        for (int i = 0; i < 64; ++i) m = fmaxf(m, fmaxf(__uint_as_float(kp[i] << 16), __uint_as_float(kp[i] & 0xffff0000u)));
+        for (int i = 0; i < 64; ++i) m = fmaxf(m, fmaxf(el16_lo(kp[i]), el16_hi(kp[i])));
         m = fmaxf(m, __shfl_xor(m, 32, 64));
         // pass 2: k' = exp(k - m) against v, 16 pixels per MFMA step
 #pragma unroll
@@ -685,17 +691,17 @@ __global__ __launch_bounds__(256) void linattn_ctx_mfma_kernel(LinAttnArgs a, fl
 #pragma unroll
             for (int jj = 0; jj < 4; ++jj) {
                 vf[jj] = vq[t & 7][2 * jj] | (vq[t & 7][2 * jj + 1] << 16);
-                float x0 = __expf(__uint_as_float(kp[t * 4 + jj] << 16) - m);
-                float x1 = __expf(__uint_as_float(kp[t * 4 + jj] & 0xffff0000u) - m);
+                float x0 = __expf(el16_lo(kp[t * 4 + jj]) - m);
+                float x1 = __expf(el16_hi(kp[t * 4 + jj]) - m);
                 if (!FULL) {  // exp(-100 - m) is not 0 when m is very negative
                     x0 = hi * 8 + t * 16 + 2 * jj < left ? x0 : 0.0f;
                     x1 = hi * 8 + t * 16 + 2 * jj + 1 < left ? x1 : 0.0f;
                 }
                 s += x0 + x1;
-                kh[jj] = pack_bf16x2(x0, x1);
+                kh[jj] = pack_el16x2(x0, x1);
             }
             // D[e][d] += v[p][e] * k'[p][d]: rows e (A = v), columns d = this lane's channel (B = k')
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(la_frag(vf), la_frag(kh), acc, 0, 0, 0);
+            acc = DYF_MFMA_32x32x16(la_frag(vf), la_frag(kh), acc, 0, 0, 0);
         }
         s += __shfl_xor(s, 32, 64);
     };
@@ -735,7 +741,7 @@ __global__ __launch_bounds__(256) void linattn_ctx_mfma_kernel(LinAttnArgs a, fl
 
 // merge the workgroup partials of one (sample, head), normalise, and emit ctx as the A fragments of the output product:
 // frags[bh][hi/lo part][k-step s][lane (e, hi')][8]: slot j of lane (e, hi') = ctx[d = 16 s + 8 hi' + j][e]
-__global__ __launch_bounds__(256) void linattn_merge_kernel(const float* part, int nblk, float inv_n, bf16_t* frags) {
+__global__ __launch_bounds__(256) void linattn_merge_kernel(const float* part, int nblk, float inv_n, el16_t* frags) {
     const int bh = blockIdx.x, tid = threadIdx.x, lane = tid & 63, rq = tid >> 6, d = lane & 31, hi = lane >> 5;
     const float* pb = part + (size_t)bh * nblk * LA_PART;
     float M = -3.0e38f;
@@ -751,21 +757,21 @@ __global__ __launch_bounds__(256) void linattn_merge_kernel(const float* part, i
         v *= norm;
         const int e = (r >> 2) * 8 + hi * 4 + (r & 3);
         const size_t idx = (((size_t)bh * 2 * 2 + (d >> 4)) * 64 + ((d >> 3) & 1) * 32 + e) * 8 + (d & 7);
-        const bf16_t vh = f32_to_bf16(v);
+        const el16_t vh = f32_to_el16(v);
         frags[idx] = vh;
-        frags[idx + 2 * 64 * 8] = f32_to_bf16(v - bf16_to_f32(vh));
+        frags[idx + 2 * 64 * 8] = f32_to_el16(v - el16_to_f32(vh));
     }
 }
 
-__global__ __launch_bounds__(256) void linattn_out_mfma_kernel(LinAttnArgs a, const bf16_t* frags) {
+__global__ __launch_bounds__(256) void linattn_out_mfma_kernel(LinAttnArgs a, const el16_t* frags) {
     const int bh = blockIdx.y, n = bh / a.heads, h = bh % a.heads;
     const int C3 = 3 * a.heads * 32, hd = a.heads * 32;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
-    la_bf16x8 ah[2], al[2];
+    el16x8_t ah[2], al[2];
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
-        ah[s] = *(const la_bf16x8*)(frags + (((size_t)bh * 4 + s) * 64 + lane) * 8);
-        al[s] = *(const la_bf16x8*)(frags + (((size_t)bh * 4 + 2 + s) * 64 + lane) * 8);
+        ah[s] = *(const el16x8_t*)(frags + (((size_t)bh * 4 + s) * 64 + lane) * 8);
+        al[s] = *(const el16x8_t*)(frags + (((size_t)bh * 4 + 2 + s) * 64 + lane) * 8);
     }
     const float scale = 0.17677669529663687f;  // 32^-1/2
 #pragma unroll 1
@@ -773,7 +779,7 @@ __global__ __launch_bounds__(256) void linattn_out_mfma_kernel(LinAttnArgs a, co
         const int p = blockIdx.x * 512 + wave * 128 + g * 32 + l31;
         if (__builtin_amdgcn_readfirstlane(p - l31) >= a.hw) break;
         const bool valid = p < a.hw;
-        const bf16_t* qp = a.qkv + ((size_t)n * a.hw + (valid ? p : a.hw - 1)) * C3 + h * 32 + hi * 8;
+        const el16_t* qp = a.qkv + ((size_t)n * a.hw + (valid ? p : a.hw - 1)) * C3 + h * 32 + hi * 8;
         const uint4 x[2] = {*(const uint4*)qp, *(const uint4*)(qp + 16)};  // channels 8 hi + {0..7} and 16 + 8 hi + {0..7}
         float q[16];
 #pragma unroll
@@ -781,8 +787,8 @@ __global__ __launch_bounds__(256) void linattn_out_mfma_kernel(LinAttnArgs a, co
             const uint32_t w[4] = {x[s].x, x[s].y, x[s].z, x[s].w};
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                q[s * 8 + 2 * t] = __uint_as_float(w[t] << 16);
-                q[s * 8 + 2 * t + 1] = __uint_as_float(w[t] & 0xffff0000u);
+                q[s * 8 + 2 * t] = el16_lo(w[t]);
+                q[s * 8 + 2 * t + 1] = el16_hi(w[t]);
             }
         }
         float qm = q[0];
@@ -806,17 +812,17 @@ __global__ __launch_bounds__(256) void linattn_out_mfma_kernel(LinAttnArgs a, co
 #pragma unroll
             for (int t = 0; t < 4; ++t) la_split(q[s * 8 + 2 * t], q[s * 8 + 2 * t + 1], qh[t], ql[t]);
             // D[e][p] += ctx[d][e] * q'[p][d]; hi*hi + lo*hi + hi*lo keeps the product fp32-accurate
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s], la_frag(qh), acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[s], la_frag(qh), acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s], la_frag(ql), acc, 0, 0, 0);
+            acc = DYF_MFMA_32x32x16(ah[s], la_frag(qh), acc, 0, 0, 0);
+            acc = DYF_MFMA_32x32x16(al[s], la_frag(qh), acc, 0, 0, 0);
+            acc = DYF_MFMA_32x32x16(ah[s], la_frag(ql), acc, 0, 0, 0);
         }
         // lane (p, hi) holds rows e = 8 (r >> 2) + 4 hi + (r & 3); register groups 2 g2 / 2 g2 + 1 are exchanged between lanes
         // p and p + 32 so that every lane stores 8 consecutive channels
-        bf16_t* op = a.out + ((size_t)n * a.hw + p) * hd + h * 32 + hi * 8;
+        el16_t* op = a.out + ((size_t)n * a.hw + p) * hd + h * 32 + hi * 8;
 #pragma unroll
         for (int g2 = 0; g2 < 2; ++g2) {
-            const uint32_t p0 = pack_bf16x2(acc[g2 * 8 + 0] * qn, acc[g2 * 8 + 1] * qn), p1 = pack_bf16x2(acc[g2 * 8 + 2] * qn, acc[g2 * 8 + 3] * qn);
-            const uint32_t q0 = pack_bf16x2(acc[g2 * 8 + 4] * qn, acc[g2 * 8 + 5] * qn), q1 = pack_bf16x2(acc[g2 * 8 + 6] * qn, acc[g2 * 8 + 7] * qn);
+            const uint32_t p0 = pack_el16x2(acc[g2 * 8 + 0] * qn, acc[g2 * 8 + 1] * qn), p1 = pack_el16x2(acc[g2 * 8 + 2] * qn, acc[g2 * 8 + 3] * qn);
+            const uint32_t q0 = pack_el16x2(acc[g2 * 8 + 4] * qn, acc[g2 * 8 + 5] * qn), q1 = pack_el16x2(acc[g2 * 8 + 6] * qn, acc[g2 * 8 + 7] * qn);
             const auto s0 = __builtin_amdgcn_permlane32_swap(p0, q0, false, false);
             const auto s1 = __builtin_amdgcn_permlane32_swap(p1, q1, false, false);
             uint4 o;
@@ -831,10 +837,10 @@ hipError_t launch_linear_attention(const LinAttnArgs& a, hipStream_t s) {
         const int nblk = (a.hw + LA_PIX - 1) / LA_PIX;
         const int BH = a.n * a.heads;
         float* part = a.scratch;                                          // [BH][nblk][LA_PART]
-        bf16_t* frags = (bf16_t*)(a.scratch + (size_t)BH * nblk * LA_PART);  // [BH][2][2][64][8]
+        el16_t* frags = (el16_t*)(a.scratch + (size_t)BH * nblk * LA_PART);  // [BH][2][2][64][8]
         hipLaunchKernelGGL(linattn_ctx_mfma_kernel, dim3(nblk, BH), dim3(256), 0, s, a, part, nblk);
         hipLaunchKernelGGL(linattn_merge_kernel, dim3(BH), dim3(256), 0, s, (const float*)part, nblk, 1.0f / (float)a.hw, frags);
-        hipLaunchKernelGGL(linattn_out_mfma_kernel, dim3((a.hw + 511) / 512, BH), dim3(256), 0, s, a, (const bf16_t*)frags);
+        hipLaunchKernelGGL(linattn_out_mfma_kernel, dim3((a.hw + 511) / 512, BH), dim3(256), 0, s, a, (const el16_t*)frags);
         return hipGetLastError();
     }
     hipLaunchKernelGGL(linear_attention_kernel, dim3(a.n * a.heads), dim3(256), 0, s, a);
@@ -864,14 +870,14 @@ __global__ __launch_bounds__(64) void attention_kernel(AttnArgs a) {
     const int bh = blockIdx.x / qtiles, qt = blockIdx.x % qtiles;
     const int n = bh / a.heads, h = bh % a.heads;
     const int C3 = 3 * a.heads * 32, hd = a.heads * 32;
-    const bf16_t* base = a.qkv + (size_t)n * a.hw * C3;
+    const el16_t* base = a.qkv + (size_t)n * a.hw * C3;
     const int i = qt * 64 + threadIdx.x;
     const bool live = i < a.hw;
     const float scale = 0.17677669529663687f;
     float q[32], o[32];
 #pragma unroll
     for (int c = 0; c < 32; ++c) {
-        q[c] = live ? bf16_to_f32(base[(size_t)i * C3 + h * 32 + c]) * scale : 0.0f;
+        q[c] = live ? el16_to_f32(base[(size_t)i * C3 + h * 32 + c]) * scale : 0.0f;
         o[c] = 0.0f;
     }
     float m = -3.0e38f, l = 0.0f;
@@ -881,8 +887,8 @@ __global__ __launch_bounds__(64) void attention_kernel(AttnArgs a) {
         for (int t = threadIdx.x; t < 64 * 32; t += 64) {
             const int jj = t >> 5, c = t & 31;
             const int j = j0 + jj;
-            ks[jj][c] = j < a.hw ? bf16_to_f32(base[(size_t)j * C3 + hd + h * 32 + c]) : 0.0f;
-            vs[jj][c] = j < a.hw ? bf16_to_f32(base[(size_t)j * C3 + 2 * hd + h * 32 + c]) : 0.0f;
+            ks[jj][c] = j < a.hw ? el16_to_f32(base[(size_t)j * C3 + hd + h * 32 + c]) : 0.0f;
+            vs[jj][c] = j < a.hw ? el16_to_f32(base[(size_t)j * C3 + 2 * hd + h * 32 + c]) : 0.0f;
         }
         __syncthreads();
         const int jn = min(64, a.hw - j0);
@@ -905,10 +911,10 @@ __global__ __launch_bounds__(64) void attention_kernel(AttnArgs a) {
         }
     }
     if (!live) return;
-    bf16_t* op = a.out + ((size_t)n * a.hw + i) * hd + h * 32;  // "b h (x y) d -> b (h d) x y"
+    el16_t* op = a.out + ((size_t)n * a.hw + i) * hd + h * 32;  // "b h (x y) d -> b (h d) x y"
     const float inv = 1.0f / l;
 #pragma unroll
-    for (int c = 0; c < 32; ++c) op[c] = f32_to_bf16(o[c] * inv);
+    for (int c = 0; c < 32; ++c) op[c] = f32_to_el16(o[c] * inv);
 }
 
 // ------------------------------------------------------------------------------------------------ flash attention
@@ -920,27 +926,26 @@ __global__ __launch_bounds__(64) void attention_kernel(AttnArgs a) {
 // The MFMA k-slot <-> key mapping of the second product is chosen to be the C layout of the first (key = 16s + (j&3) +
 // 8(j>>2) + 4*hi), so P feeds the second MFMA straight from registers; V is staged transposed ([d][key], rows padded to
 // 136 B: conflict-free ds_read_b64).  Online softmax in fp32; the normaliser is accumulated BEFORE dropout.
-typedef __attribute__((ext_vector_type(8))) __bf16 fa_bf16x8;
 typedef __attribute__((ext_vector_type(16))) float fa_f32x16;
 
 __global__ __launch_bounds__(256) void flash_attention_kernel(AttnArgs a) {
-    __shared__ __attribute__((aligned(16))) bf16_t Ks[64 * 32];   // [key][32 ch], 16-B chunk ^= (key >> 2) & 3
-    __shared__ __attribute__((aligned(16))) bf16_t Vt[32 * 68];   // [ch][64 keys + 4 pad]
+    __shared__ __attribute__((aligned(16))) el16_t Ks[64 * 32];   // [key][32 ch], 16-B chunk ^= (key >> 2) & 3
+    __shared__ __attribute__((aligned(16))) el16_t Vt[32 * 68];   // [ch][64 keys + 4 pad]
     const int qblocks = (a.hw + 127) / 128;
     const int bh = blockIdx.x / qblocks, qb = blockIdx.x % qblocks;
     const int n = bh / a.heads, h = bh % a.heads;
     const int C3 = 3 * a.heads * 32, hd = a.heads * 32, N = a.hw;
-    const bf16_t* base = a.qkv + (size_t)n * N * C3;
+    const el16_t* base = a.qkv + (size_t)n * N * C3;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
     const int q = qb * 128 + wave * 32 + l31;
     const float scale = 0.17677669529663687f;  // 32^-1/2
     // Q fragments (B operand of S^T): lane (q, hi) holds channels ks*16 + hi*8 .. +8
-    fa_bf16x8 qf[2];
+    el16x8_t qf[2];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
         uint4 v = make_uint4(0, 0, 0, 0);
         if (q < N) v = *(const uint4*)(base + (size_t)q * C3 + h * 32 + ks * 16 + hi * 8);
-        qf[ks] = *(fa_bf16x8*)&v;
+        qf[ks] = *(el16x8_t*)&v;
     }
     fa_f32x16 o;
 #pragma unroll
@@ -958,7 +963,7 @@ __global__ __launch_bounds__(256) void flash_attention_kernel(AttnArgs a) {
                 vv = *(const uint4*)(base + (size_t)j * C3 + 2 * hd + h * 32 + ch * 8);
             }
             *(uint4*)(Ks + key * 32 + ((ch ^ ((key >> 2) & 3)) << 3)) = kv;
-            const bf16_t* ve = (const bf16_t*)&vv;
+            const el16_t* ve = (const el16_t*)&vv;
 #pragma unroll
             for (int i = 0; i < 8; ++i) Vt[(ch * 8 + i) * 68 + key] = ve[i];
         }
@@ -973,8 +978,8 @@ __global__ __launch_bounds__(256) void flash_attention_kernel(AttnArgs a) {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 const int key = st * 32 + l31;
-                const fa_bf16x8 kf = *(const fa_bf16x8*)(Ks + key * 32 + (((ks * 2 + hi) ^ ((key >> 2) & 3)) << 3));
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], s, 0, 0, 0);
+                const el16x8_t kf = *(const el16x8_t*)(Ks + key * 32 + (((ks * 2 + hi) ^ ((key >> 2) & 3)) << 3));
+                s = DYF_MFMA_32x32x16(kf, qf[ks], s, 0, 0, 0);
             }
             // lane (q, hi) now holds keys jb + (r&3) + 8(r>>2) + 4hi of query q
             float tmax = -1.0e30f;
@@ -1005,26 +1010,26 @@ __global__ __launch_bounds__(256) void flash_attention_kernel(AttnArgs a) {
             for (int s2 = 0; s2 < 2; ++s2) {
                 uint32_t pk[4];
 #pragma unroll
-                for (int t = 0; t < 4; ++t) pk[t] = pack_bf16x2(p[s2 * 8 + 2 * t], p[s2 * 8 + 2 * t + 1]);
-                const fa_bf16x8 pf = *(fa_bf16x8*)pk;
+                for (int t = 0; t < 4; ++t) pk[t] = pack_el16x2(p[s2 * 8 + 2 * t], p[s2 * 8 + 2 * t + 1]);
+                const el16x8_t pf = *(el16x8_t*)pk;
                 // V^T fragment: lane (d = l31, hi): keys st*32 + 16*s2 + 4*hi + {0..3} and + 8
-                const bf16_t* vr = Vt + l31 * 68 + st * 32 + s2 * 16 + 4 * hi;
+                const el16_t* vr = Vt + l31 * 68 + st * 32 + s2 * 16 + 4 * hi;
                 uint2 v0 = *(const uint2*)vr, v1 = *(const uint2*)(vr + 8);
                 uint32_t vw[4] = {v0.x, v0.y, v1.x, v1.y};
-                const fa_bf16x8 vf = *(fa_bf16x8*)vw;
-                o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o, 0, 0, 0);
+                const el16x8_t vf = *(el16x8_t*)vw;
+                o = DYF_MFMA_32x32x16(vf, pf, o, 0, 0, 0);
             }
         }
     }
     if (q >= N) return;
     // O^T[d][q]: lane (q, hi) holds d = (r&3) + 8(r>>2) + 4hi  -> four 8-byte stores of 4 consecutive channels
     const float inv = 1.0f / l;
-    bf16_t* op = a.out + ((size_t)n * N + q) * hd + h * 32;  // "b h (x y) d -> b (h d) x y"
+    el16_t* op = a.out + ((size_t)n * N + q) * hd + h * 32;  // "b h (x y) d -> b (h d) x y"
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         uint2 w;
-        w.x = pack_bf16x2(o[g * 4 + 0] * inv, o[g * 4 + 1] * inv);
-        w.y = pack_bf16x2(o[g * 4 + 2] * inv, o[g * 4 + 3] * inv);
+        w.x = pack_el16x2(o[g * 4 + 0] * inv, o[g * 4 + 1] * inv);
+        w.y = pack_el16x2(o[g * 4 + 2] * inv, o[g * 4 + 3] * inv);
         *(uint2*)(op + 8 * g + 4 * hi) = w;
     }
 }
@@ -1047,7 +1052,7 @@ __global__ void head_kernel(HeadArgs a) {
     const long long total = (long long)a.n * a.hw;
     if (idx >= total) return;
     const int n = (int)(idx / a.hw), p = (int)(idx % a.hw);
-    const bf16_t* x = a.x + (size_t)idx * a.c;
+    const el16_t* x = a.x + (size_t)idx * a.c;
     if ((a.c & 7) == 0 && a.cout <= 4) {  // 16-byte loads of the pixel's channels, all outputs accumulated in one pass
         float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
         for (int c0 = 0; c0 < a.c; c0 += 8) {
@@ -1055,7 +1060,7 @@ __global__ void head_kernel(HeadArgs a) {
             const uint32_t qw[4] = {q.x, q.y, q.z, q.w};
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
-                const float v = (t & 1) ? __uint_as_float(qw[t >> 1] & 0xffff0000u) : __uint_as_float(qw[t >> 1] << 16);
+                const float v = (t & 1) ? el16_hi(qw[t >> 1]) : el16_lo(qw[t >> 1]);
 #pragma unroll
                 for (int co = 0; co < 4; ++co)
                     if (co < a.cout) acc[co] = fmaf(v, a.wgt[(size_t)co * a.c + c0 + t], acc[co]);
@@ -1069,7 +1074,7 @@ __global__ void head_kernel(HeadArgs a) {
     for (int co = 0; co < a.cout; ++co) {
         float acc = a.bias[co];
         const float* w = a.wgt + (size_t)co * a.c;
-        for (int c = 0; c < a.c; ++c) acc = fmaf(bf16_to_f32(x[c]), w[c], acc);
+        for (int c = 0; c < a.c; ++c) acc = fmaf(el16_to_f32(x[c]), w[c], acc);
         a.out[((size_t)n * a.cout + co) * a.hw + p] = acc;
     }
 }
@@ -1091,7 +1096,7 @@ __global__ __launch_bounds__(256) void head_vec_kernel(HeadArgs a) {
         float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
-            const float xv = (t & 1) ? __uint_as_float(qw[t >> 1] & 0xffff0000u) : __uint_as_float(qw[t >> 1] << 16);
+            const float xv = (t & 1) ? el16_hi(qw[t >> 1]) : el16_lo(qw[t >> 1]);
 #pragma unroll
             for (int co = 0; co < 4; ++co) acc[co] = fmaf(xv, w[co][t], acc[co]);
         }
@@ -1120,7 +1125,7 @@ hipError_t launch_head(const HeadArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
-__global__ void up2x_nearest_kernel(const bf16_t* src, int n, int h, int w, int c, bf16_t* out, long long total) {
+__global__ void up2x_nearest_kernel(const el16_t* src, int n, int h, int w, int c, el16_t* out, long long total) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
     const int ch = (int)(idx % c);
@@ -1147,7 +1152,7 @@ __global__ __launch_bounds__(256) void up2x_nearest_vec_kernel(const uint4* src,
     out[o + rs + c8] = v;
 }
 
-hipError_t launch_up2x_nearest(const bf16_t* src, int n, int h, int w, int c, bf16_t* out, hipStream_t s) {
+hipError_t launch_up2x_nearest(const el16_t* src, int n, int h, int w, int c, el16_t* out, hipStream_t s) {
     const long long total = (long long)n * 4 * h * w * c;
     if (c % 8 == 0 && total / 32 < 0xFFFFFFFFll) {
         const unsigned tv = (unsigned)((long long)n * h * w * (c / 8));

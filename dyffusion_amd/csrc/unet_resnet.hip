@@ -17,7 +17,7 @@ struct RBlockW {  // ResnetBlock
     int cin = 0, cout = 0;
     bool has_res = false;
     int film_off = 0;
-    bf16_t *w1 = nullptr, *w2 = nullptr, *wr = nullptr;
+    el16_t *w1 = nullptr, *w2 = nullptr, *wr = nullptr;
     float *b1 = nullptr, *b2 = nullptr, *br = nullptr;
     float *g1 = nullptr, *be1 = nullptr, *g2 = nullptr, *be2 = nullptr;
 };
@@ -26,14 +26,14 @@ struct AttnW {
     int dim = 0;
     bool linear = true;
     float* ln_g = nullptr;
-    bf16_t *wqkv = nullptr, *wout = nullptr;
+    el16_t *wqkv = nullptr, *wout = nullptr;
     float* bout = nullptr;
 };
 
 struct SampW {  // down / up sampling conv
     int cin = 0, cout = 0, k = 3, stride = 1, pad = 1;
     bool nearest_up = false;
-    bf16_t* w = nullptr;
+    el16_t* w = nullptr;
     float* b = nullptr;
 };
 
@@ -45,13 +45,13 @@ struct RNet {
     std::vector<AttnW> attns;      // downs.l.2 (nlev), mid_attn, ups.l.2 (nlev)
     std::vector<SampW> downs, ups;
     float *stem_w = nullptr, *stem_b = nullptr, *head_w = nullptr, *head_b = nullptr;
-    bf16_t* stem_wfrag = nullptr;  // MFMA stem fragments (dim 64)
+    el16_t* stem_wfrag = nullptr;  // MFMA stem fragments (dim 64)
     int stem_ksteps = 0;
     float *ones = nullptr, *zeros = nullptr;
     double* gn_stats = nullptr;    // [max_batch][groups][2]
     float* la_scratch = nullptr;   // LinearAttention partials + context
     size_t buf_elems = 0;          // elements of one pool buffer at max_batch
-    std::vector<bf16_t*> pool;
+    std::vector<el16_t*> pool;
 };
 
 namespace {
@@ -59,13 +59,13 @@ namespace {
 constexpr int HEADS = 4, DIM_HEAD = 32, HID = HEADS * DIM_HEAD;
 
 struct Pool {
-    std::vector<bf16_t*> free_list;
-    bf16_t* get() {
-        bf16_t* p = free_list.back();
+    std::vector<el16_t*> free_list;
+    el16_t* get() {
+        el16_t* p = free_list.back();
         free_list.pop_back();
         return p;
     }
-    void put(bf16_t* p) { free_list.push_back(p); }
+    void put(el16_t* p) { free_list.push_back(p); }
 };
 
 struct DropCtx {  // walks the dropout sites in execution order (same order as the reference / oracle)
@@ -88,26 +88,26 @@ struct DropCtx {  // walks the dropout sites in execution order (same order as t
     }
 };
 
-dyf_status rconv(dyf_engine* e, const bf16_t* s0, int c0, const bf16_t* s1, int c1, int n, int h, int w, int k, int stride,
-                 int pad, int cout, const bf16_t* wpk, const float* coef_a, const float* coef_c, int coef_stride, int act,
-                 const DropSpec& drop, const bf16_t* residual, bf16_t* out, hipStream_t st) {
+dyf_status rconv(dyf_engine* e, const el16_t* s0, int c0, const el16_t* s1, int c1, int n, int h, int w, int k, int stride,
+                 int pad, int cout, const el16_t* wpk, const float* coef_a, const float* coef_c, int coef_stride, int act,
+                 const DropSpec& drop, const el16_t* residual, el16_t* out, hipStream_t st) {
     ConvArgs a{};
     a.src0 = s0; a.c0 = c0; a.src1 = s1; a.c1 = c1; a.n = n; a.h = h; a.w = w;
     a.ho = (h + 2 * pad - k) / stride + 1; a.wo = (w + 2 * pad - k) / stride + 1;
     a.kh = k; a.kw = k; a.stride = stride; a.pad = pad; a.cout = cout; a.wpk = wpk;
     a.coef_a = coef_a; a.coef_c = coef_c; a.coef_stride = coef_stride; a.act = act; a.drop = drop;
-    a.residual = residual; a.out_bf16 = out;
+    a.residual = residual; a.out_el16 = out;
     const int path = (e->cfg.enable_mfma && conv_mfma_supported(a)) ? 1 : 0;
     HIP_TRY(e, launch_conv(a, path, st));
     return DYF_OK;
 }
 
-std::vector<bf16_t> pack_conv(const float* w, int cout, int cin, int k) {
+std::vector<el16_t> pack_conv(const float* w, int cout, int cin, int k) {
     const int taps = k * k;
-    std::vector<bf16_t> pk((size_t)cout * taps * cin);
+    std::vector<el16_t> pk((size_t)cout * taps * cin);
     for (int co = 0; co < cout; ++co)
         for (int ci = 0; ci < cin; ++ci)
-            for (int t = 0; t < taps; ++t) pk[((size_t)co * taps + t) * cin + ci] = f32_to_bf16(w[((size_t)co * cin + ci) * taps + t]);
+            for (int t = 0; t < taps; ++t) pk[((size_t)co * taps + t) * cin + ci] = f32_to_el16(w[((size_t)co * cin + ci) * taps + t]);
     return pk;
 }
 
@@ -244,7 +244,7 @@ dyf_status rn_alloc_workspace(dyf_engine* e) {
         if (!n.rn) continue;
         RNet* r = n.rn;
         {
-            dyf_status s = dev_alloc(e, &r->gn_stats, (size_t)e->cfg.max_batch * n.cfg.groups * 3);  // + (mean, rstd) floats
+            dyf_status s = dev_alloc(e, &r->gn_stats, gn_stats_doubles((size_t)e->cfg.max_batch, (size_t)n.cfg.groups));
             if (s != DYF_OK) return s;
         }
         {
@@ -260,7 +260,7 @@ dyf_status rn_alloc_workspace(dyf_engine* e) {
             continue;
         }
         for (int i = 0; i < nbuf; ++i) {
-            bf16_t* p = nullptr;
+            el16_t* p = nullptr;
             dyf_status s = dev_alloc(e, &p, r->buf_elems);
             if (s != DYF_OK) return s;
             r->pool.push_back(p);
@@ -321,7 +321,7 @@ dyf_status rn_load_weights(dyf_engine* e, Net& n, std::map<std::string, TensorVi
         if (d == 64) {  // MFMA stem: weights as bf16 hi/lo A fragments
             const int kk_total = (int)(ks * ks * n.cin_total);
             r->stem_ksteps = (kk_total + 15) / 16;
-            std::vector<bf16_t> pf((size_t)r->stem_ksteps * 2 * 2 * 64 * 8);
+            std::vector<el16_t> pf((size_t)r->stem_ksteps * 2 * 2 * 64 * 8);
             pack_stem_frag(pk.data(), kk_total, (int)d, pf.data());
             UP(r->stem_wfrag, pf);
         }
@@ -438,20 +438,20 @@ dyf_status rn_forward(dyf_engine* e, int which, const Source* srcs, int nsrc, in
     } while (0)
 
     // ResnetBlock on cat[a0 (c_a0 ch), a1 (c_a1 ch)] at hh x ww; returns the output buffer (cout channels)
-    auto resblock = [&](const RBlockW& b, const bf16_t* a0, int c_a0, const bf16_t* a1, int c_a1, int hh, int ww,
-                        bf16_t** out) -> dyf_status {
-        bf16_t* t1 = pool.get();
+    auto resblock = [&](const RBlockW& b, const el16_t* a0, int c_a0, const el16_t* a1, int c_a1, int hh, int ww,
+                        el16_t** out) -> dyf_status {
+        el16_t* t1 = pool.get();
         TRY(rconv(e, a0, c_a0, a1, c_a1, nb, hh, ww, 3, 1, 1, b.cout, b.w1, r->ones, b.b1, 0, ACT_NONE, DropSpec{}, nullptr, t1, st));
         GnActArgs g{};
         g.x = t1; g.n = nb; g.hw = hh * ww; g.c = b.cout; g.groups = c.groups; g.gamma = b.g1; g.beta = b.be1;
         if (film) { g.film_a = o.coef_a + b.film_off; g.film_c = o.coef_c + b.film_off; g.film_stride = o.coef_stride; }
         g.act = ACT_SILU; g.drop = dc.next(c.block_dropout1); g.residual = nullptr; g.out = t1; g.stats = r->gn_stats;
         HIP_TRY(e, launch_gn_act(g, st));
-        bf16_t* t2 = pool.get();
+        el16_t* t2 = pool.get();
         TRY(rconv(e, t1, b.cout, nullptr, 0, nb, hh, ww, 3, 1, 1, b.cout, b.w2, r->ones, b.b2, 0, ACT_NONE, DropSpec{}, nullptr, t2, st));
         pool.put(t1);
-        const bf16_t* res = a0;  // identity shortcut (single source, cin == cout)
-        bf16_t* t3 = nullptr;
+        const el16_t* res = a0;  // identity shortcut (single source, cin == cout)
+        el16_t* t3 = nullptr;
         if (b.has_res) {
             t3 = pool.get();
             TRY(rconv(e, a0, c_a0, a1, c_a1, nb, hh, ww, 1, 1, 0, b.cout, b.wr, r->ones, b.br, 0, ACT_NONE, DropSpec{}, nullptr, t3, st));
@@ -467,17 +467,17 @@ dyf_status rn_forward(dyf_engine* e, int which, const Source* srcs, int nsrc, in
     };
 
     // Residual(PreNorm(LayerNorm, [Linear]Attention)) on x (dim channels) at hh x ww
-    auto attention = [&](const AttnW& a, const bf16_t* x, int hh, int ww, bf16_t** out) -> dyf_status {
+    auto attention = [&](const AttnW& a, const el16_t* x, int hh, int ww, el16_t** out) -> dyf_status {
         const int hw = hh * ww;
-        bf16_t* ln = pool.get();
+        el16_t* ln = pool.get();
         LayerNormArgs la{};
         la.x = x; la.pixels = (long long)nb * hw; la.hw = hw; la.c = a.dim; la.g = a.ln_g; la.out = ln;
         la.drop = a.linear ? dc.next(c.attn_dropout) : DropSpec{};  // LinearAttention drops its (normalised) input
         HIP_TRY(e, launch_layernorm_c(la, st));
-        bf16_t* qkv = pool.get();
+        el16_t* qkv = pool.get();
         TRY(rconv(e, ln, a.dim, nullptr, 0, nb, hh, ww, 1, 1, 0, 3 * HID, a.wqkv, r->ones, r->zeros, 0, ACT_NONE, DropSpec{}, nullptr, qkv, st));
         pool.put(ln);
-        bf16_t* ao = pool.get();
+        el16_t* ao = pool.get();
         if (a.linear) {
             LinAttnArgs l{};
             l.qkv = qkv; l.n = nb; l.hw = hw; l.heads = HEADS; l.out = ao; l.scratch = r->la_scratch;
@@ -489,7 +489,7 @@ dyf_status rn_forward(dyf_engine* e, int which, const Source* srcs, int nsrc, in
             HIP_TRY(e, launch_attention(t, st));
         }
         pool.put(qkv);
-        bf16_t* y = pool.get();
+        el16_t* y = pool.get();
         TRY(rconv(e, ao, HID, nullptr, 0, nb, hh, ww, 1, 1, 0, a.dim, a.wout, r->ones, a.bout, 0, ACT_NONE, DropSpec{}, x, y, st));
         pool.put(ao);
         *out = y;
@@ -501,18 +501,18 @@ dyf_status rn_forward(dyf_engine* e, int which, const Source* srcs, int nsrc, in
     int ctot = 0;
     for (int i = 0; i < nsrc; ++i) { sa.src[i] = srcs[i].p; sa.ch[i] = srcs[i].ch; ctot += srcs[i].ch; }
     if (ctot != n.cin_total) return fail(e, DYF_ERR_INVALID_ARGUMENT, "channel count of the network inputs does not match its configuration");
-    bf16_t* rbuf = pool.get();
+    el16_t* rbuf = pool.get();
     sa.nsrc = nsrc; sa.cin = ctot; sa.n = nb; sa.h = H; sa.w = W; sa.k = c.init_kernel_size; sa.pad = c.init_padding;
     sa.wgt = r->stem_w; sa.bias = r->stem_b; sa.dim = c.dim; sa.out = rbuf;
     sa.wfrag = r->stem_wfrag; sa.ksteps = r->stem_ksteps;
     HIP_TRY(e, launch_stem_conv(sa, st));
 
-    std::vector<bf16_t*> skips;
-    bf16_t* x = rbuf;
+    std::vector<el16_t*> skips;
+    el16_t* x = rbuf;
     int bi = 0, ai = 0;
     for (int l = 0; l < r->nlev; ++l) {
         const int hh = r->lev_h[l], ww = r->lev_w[l], dl = r->dims[l];
-        bf16_t *x1, *x2, *x3;
+        el16_t *x1, *x2, *x3;
         TRY(resblock(r->blocks[bi++], x, dl, nullptr, 0, hh, ww, &x1));
         if (x != rbuf) pool.put(x);
         skips.push_back(x1);
@@ -521,13 +521,13 @@ dyf_status rn_forward(dyf_engine* e, int which, const Source* srcs, int nsrc, in
         pool.put(x2);
         skips.push_back(x3);
         const SampW& s = r->downs[l];
-        bf16_t* xd = pool.get();
+        el16_t* xd = pool.get();
         TRY(rconv(e, x3, dl, nullptr, 0, nb, hh, ww, s.k, s.stride, s.pad, s.cout, s.w, r->ones, s.b, 0, ACT_NONE, DropSpec{}, nullptr, xd, st));
         x = xd;
     }
     {
         const int hh = r->lev_h[r->nlev - 1], ww = r->lev_w[r->nlev - 1], dm = r->dims[r->nlev];
-        bf16_t *m1, *m2, *m3;
+        el16_t *m1, *m2, *m3;
         TRY(resblock(r->blocks[bi++], x, dm, nullptr, 0, hh, ww, &m1));
         pool.put(x);
         TRY(attention(r->attns[ai++], m1, hh, ww, &m2));
@@ -538,19 +538,19 @@ dyf_status rn_forward(dyf_engine* e, int which, const Source* srcs, int nsrc, in
     }
     for (int l = r->nlev - 1, u = 0; l >= 0; --l, ++u) {
         const int hh = r->lev_h[l], ww = r->lev_w[l], dout = r->dims[l + 1], din = r->dims[l];
-        bf16_t *y1, *y2, *y3;
-        bf16_t* s1 = skips.back(); skips.pop_back();
+        el16_t *y1, *y2, *y3;
+        el16_t* s1 = skips.back(); skips.pop_back();
         TRY(resblock(r->blocks[bi++], x, dout, s1, din, hh, ww, &y1));
         pool.put(x); pool.put(s1);
-        bf16_t* s2 = skips.back(); skips.pop_back();
+        el16_t* s2 = skips.back(); skips.pop_back();
         TRY(resblock(r->blocks[bi++], y1, dout, s2, din, hh, ww, &y2));
         pool.put(y1); pool.put(s2);
         TRY(attention(r->attns[ai++], y2, hh, ww, &y3));
         pool.put(y2);
         const SampW& s = r->ups[u];
-        bf16_t* xu = pool.get();
+        el16_t* xu = pool.get();
         if (s.nearest_up) {
-            bf16_t* up = pool.get();
+            el16_t* up = pool.get();
             HIP_TRY(e, launch_up2x_nearest(y3, nb, hh, ww, dout, up, st));
             TRY(rconv(e, up, dout, nullptr, 0, nb, 2 * hh, 2 * ww, 3, 1, 1, s.cout, s.w, r->ones, s.b, 0, ACT_NONE, DropSpec{}, nullptr, xu, st));
             pool.put(up);
@@ -560,7 +560,7 @@ dyf_status rn_forward(dyf_engine* e, int which, const Source* srcs, int nsrc, in
         pool.put(y3);
         x = xu;
     }
-    bf16_t* yf;
+    el16_t* yf;
     TRY(resblock(r->blocks[bi++], x, c.dim, rbuf, c.dim, H, W, &yf));
     pool.put(x);
     pool.put(rbuf);

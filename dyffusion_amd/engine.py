@@ -59,14 +59,15 @@ def _f32c(t: torch.Tensor, name: str) -> torch.Tensor:
 
 class HipEngine:
     def __init__(self, forecaster: L.NetConfig, interpolator: L.NetConfig, height: int, width: int, max_batch: int,
-                 device: Optional[int] = None, use_graph: bool = True, enable_mfma: bool = True):
+                 device: Optional[int] = None, use_graph: bool = True, enable_mfma: bool = True, dtype: str = "bf16"):
         if not torch.cuda.is_available():
             raise EngineError("no GPU visible: the DYffusion HIP engine needs an MI355X (gfx950); there is no CPU fallback")
-        self._lib = L.lib()
+        self.dtype = dtype
+        self._lib = L.lib(dtype)
         self.device = torch.cuda.current_device() if device is None else int(device)
         self.height, self.width, self.max_batch = int(height), int(width), int(max_batch)
         cfg = L.EngineConfig(L.DYF_ABI_VERSION, self.device, self.height, self.width, self.max_batch, int(use_graph),
-                             int(enable_mfma), (L.NetConfig * 2)(forecaster, interpolator))
+                             int(enable_mfma), L.DTYPES[dtype], (L.NetConfig * 2)(forecaster, interpolator))
         self.cfg = cfg
         h = C.c_void_p()
         st = self._lib.dyf_engine_create(C.byref(cfg), C.byref(h))
@@ -303,11 +304,23 @@ class HipEngine:
 
     def op_linear_attention(self, qkv_bf16: torch.Tensor) -> torch.Tensor:
         """Test seam: LinearAttention core.  qkv (N,HW,384) bf16 (to_qkv output, 4 heads x 32) -> (N,HW,128) bf16."""
-        assert qkv_bf16.dtype == torch.bfloat16 and qkv_bf16.is_cuda and qkv_bf16.is_contiguous()
+        assert qkv_bf16.dtype == self.torch_dtype and qkv_bf16.is_cuda and qkv_bf16.is_contiguous()
         n, hw, c3 = qkv_bf16.shape
         assert c3 == 384
-        y = torch.empty((n, hw, 128), dtype=torch.bfloat16, device=qkv_bf16.device)
+        y = torch.empty((n, hw, 128), dtype=qkv_bf16.dtype, device=qkv_bf16.device)
         self._check(self._lib.dyf_op_linear_attention(self._h, qkv_bf16.data_ptr(), n, hw, y.data_ptr(), self._stream()))
+        return y
+
+    @property
+    def torch_dtype(self) -> torch.dtype:
+        return torch.float16 if L.DTYPES[self.dtype] else torch.bfloat16
+
+    def op_attention(self, qkv: torch.Tensor) -> torch.Tensor:
+        """Test seam: Attention core.  qkv (N,HW,384) in the engine's 16-bit dtype (to_qkv output) -> (N,HW,128)."""
+        assert qkv.dtype == self.torch_dtype and qkv.is_cuda and qkv.is_contiguous() and qkv.shape[2] == 384
+        n, hw, _ = qkv.shape
+        y = torch.empty((n, hw, 128), dtype=qkv.dtype, device=qkv.device)
+        self._check(self._lib.dyf_op_attention(self._h, qkv.data_ptr(), n, hw, y.data_ptr(), self._stream()))
         return y
 
     def op_upconv2d(self, x_nhwc_bf16: torch.Tensor, weight: torch.Tensor, scale: Optional[torch.Tensor] = None,

@@ -138,7 +138,7 @@ class Unet(nn.Module):
         if self._engine is None or (self._engine_key != "attached" and
                                     (self._engine_key[0] != key[0] or self._engine_key[1] < nb)):
             cfg = self.engine_net_config()
-            self._engine = HipEngine(cfg, cfg, hw[0], hw[1], max_batch=nb, use_graph=False)
+            self._engine = HipEngine(cfg, cfg, hw[0], hw[1], max_batch=nb, use_graph=False, dtype=getattr(self, "engine_dtype", "bf16"))
             self._engine_slot, self._engine_key = L.NET_FORECASTER, key
             self._engine.load_weights(self._engine_slot, self.state_dict())
         return self._engine

@@ -11,7 +11,8 @@
  * Conventions
  *   - plain C types only; every pointer named *_dev is DEVICE memory owned by the caller (e.g. a torch tensor's
  *     data_ptr()), everything else is HOST memory.  Tensors crossing the ABI are fp32, NCHW, contiguous -- the
- *     reference's layout.  Internally the engine keeps activations NHWC bf16 and accumulates in fp32.
+ *     reference's layout.  Internally the engine keeps activations NHWC in a 16-bit format (bf16, or fp16 in the
+ *     libdyffusion_hip_f16.so build) and accumulates in fp32.
  *   - the engine owns packed device weights, its workspace arena and captured hipGraphs; no allocation happens
  *     inside dyf_sample / dyf_net_forward after the first call for a given batch size.
  *   - one engine per (device, stream); calls on one engine are not re-entrant.
@@ -74,6 +75,8 @@ typedef struct dyf_net_config {
     int32_t init_padding;     /* 3 */
 } dyf_net_config;
 
+typedef enum dyf_dtype_id { DYF_DTYPE_BF16 = 0, DYF_DTYPE_F16 = 1 } dyf_dtype_id;
+
 typedef struct dyf_engine_config {
     int32_t abi_version;      /* DYF_ABI_VERSION */
     int32_t device;           /* HIP device ordinal */
@@ -81,6 +84,9 @@ typedef struct dyf_engine_config {
     int32_t max_batch;        /* largest NB = N_ensemble * B the workspace is sized for */
     int32_t use_graph;        /* capture the rollout in a hipGraph (dyf_sample) */
     int32_t enable_mfma;      /* 1: implicit-GEMM MFMA conv where shapes allow; 0: direct conv everywhere (debug) */
+    int32_t dtype;            /* dyf_dtype of activations / weights in HBM and of the MFMA operands; must equal dyf_dtype() of
+                               * the library: libdyffusion_hip.so is the bf16 build, libdyffusion_hip_f16.so the fp16 build of the
+                               * same sources (-DDYF_F16=1), same ABI */
     dyf_net_config net[2];    /* indexed by dyf_net_id */
 } dyf_engine_config;
 
@@ -115,6 +121,7 @@ dyf_status dyf_engine_create(const dyf_engine_config* cfg, dyf_engine** out_engi
 void dyf_engine_destroy(dyf_engine* engine);
 const char* dyf_last_error(const dyf_engine* engine);
 int32_t dyf_abi_version(void);
+int32_t dyf_dtype(void);   /* dyf_dtype_id this library was built for */
 
 /* ---- weights: the reference's state_dict (names as in UNet.state_dict(), host fp32, contiguous) ---------- */
 /* Replaces BaseExperiment.instantiate_model / load_state_dict (_base_experiment.py:173-199).  Folds eval-mode

@@ -43,6 +43,12 @@ dyf_status dyf_op_upconv2d(dyf_engine* engine, const uint16_t* x_dev, const floa
 dyf_status dyf_op_linear_attention(dyf_engine* engine, const uint16_t* qkv_dev, int32_t n, int32_t hw, uint16_t* out_dev,
                                    void* stream);
 
+/* Attention core (attention.py:62-72, 4 heads of 32 channels, no dropout): qkv_dev (N,HW,384) 16-bit = to_qkv output ->
+ * out_dev (N,HW,128) = softmax_j(q_i . k_j / sqrt(32)) . v_j, the input of to_out.  Runs the MFMA flash kernel the bottleneck
+ * of the ResNet-UNet uses (HW up to 65 535: 16 384 tokens for the 512^2 synthetic configuration). */
+dyf_status dyf_op_attention(dyf_engine* engine, const uint16_t* qkv_dev, int32_t n, int32_t hw, uint16_t* out_dev,
+                            void* stream);
+
 /* Read back the output of UNetBlock `layer` (0..11: encoder then decoder blocks) of the most recent unet_simple forward
  * as fp32 NCHW (NB, cout, h, w) -- per-layer parity analysis against the oracle's taps (oracle/nets.py `taps=`).  The last
  * decoder block is returned dense; positions its sparse-column form did not compute are NaN. */

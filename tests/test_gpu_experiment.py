@@ -18,7 +18,7 @@ from tests.gpu_common import DEV, build_dyffusion
 from tests.helpers import load_npz, rel_rms, split_state
 
 pytestmark = pytest.mark.gpu
-TOL = 3e-2
+TOL = 2.5e-2
 
 
 def test_predict_matches_reference_golden_ensemble_layout():
@@ -82,7 +82,7 @@ def test_predict_step_autoregressive_with_boundary_conditions_matches_reference_
         # boundary values are written, not computed: exact on every fixed node of every member (rows n*B + b -> metadata b)
         assert np.array_equal(got[k][:, fixed], w[:, fixed]), k
     print("predict_step (2 x h=4, spring BC) worst rel-rms", worst)
-    assert worst <= 4e-2
+    assert worst <= 2.5e-2
     assert torch.allclose(batch["dynamics"], dyn * 1e6)  # forecasting_multi_horizon.py:221
     merged = exp.on_predict_epoch_end()
     assert merged["t8_preds"].shape == (N, B, 4, 10, 10) and exp._predict_step_outputs == []

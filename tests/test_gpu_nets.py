@@ -1,8 +1,8 @@
 """-m gpu: dyf_net_forward (HIP) against the oracle / the reference's golden outputs.
 
 Tolerance (stated): the engine keeps activations in bf16 (8 mantissa bits) and accumulates in fp32; against the
-fp32 oracle we require rel-RMS <= 1.5e-2 per forward (measured values are printed; SURVEY.md 8c quotes 3.5-4.5e-3
-for the reference's own bf16-autocast drift over a rollout).
+fp32 oracle we require rel-RMS <= 1e-2 per unet_simple forward (measured 4.3e-3 - 6.3e-3, printed; the reference itself
+under torch.autocast(bf16) is at 1.2e-2 per forward on the full-size fixture, profiles/r02_bf16_drift.json).
 """
 import json
 
@@ -15,7 +15,7 @@ from tests.gpu_common import DEV, mirror_from_params, nhwc_masks
 from tests.helpers import jload, load_npz, rel_rms, split_state
 
 pytestmark = pytest.mark.gpu
-TOL = 1.5e-2
+TOL = 1e-2
 
 
 @pytest.mark.parametrize("name", ["net_unet_simple_a", "net_unet_simple_b", "net_unet_simple_c"])

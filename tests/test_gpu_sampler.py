@@ -200,7 +200,7 @@ def test_autoregressive_outer_loop_with_boundary_conditions():
         x = last.reshape(N * B, 3, 23, 11)
     assert torch.equal(got["t8_targets"].cpu(), dyn[:, 8])
     print("autoregressive (2 x h=4) worst rel-rms", worst)
-    assert worst <= 4e-2
+    assert worst <= 2.5e-2
 
 
 @pytest.mark.parametrize("name", ["plosses_a", "plosses_b", "plosses_c"])
