@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(StemConvArgs a) {
 // hi*hi + lo*hi + hi*lo, so the result matches the fp32 VALU form to ~2^-16 -- the network input is not rounded to bf16.
 // The (tap, cin) -> (source, offset, dy, dx) table and the weight fragments sit in LDS.
 typedef __attribute__((ext_vector_type(16))) float st_f32x16;
-constexpr int STEM_MAX_KSTEPS = 16;
+constexpr int STEM_MAX_KSTEPS = 32;  // K = k*k*cin <= 512 (7x7 x 8 channels = 392): 8 KB table + 128 KB of weight fragments in LDS
 
 __global__ __launch_bounds__(256) void stem_mfma_kernel(StemConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char st_smem[];

@@ -225,7 +225,7 @@ def unet_simple_forward_bf16_model(P: Dict[str, Tensor], cfg: dict, inputs: Tens
     """`unet_simple_forward` in the ARITHMETIC MODEL of the HIP engine: fp32 convolutions on bf16-rounded operands, every
     block output rounded to bf16 ONCE (after the fused norm / FiLM / activation / dropout epilogue), fp32 everything else.
     Not a restatement of the reference -- a measuring stick: the gap between this and `unet_simple_forward` is what bf16
-    storage costs by itself (tools/bf16_drift.py), the gap between the engine and this is the engine's own error."""
+    storage costs by itself (tests/measure_bf16_drift.py), the gap between the engine and this is the engine's own error."""
     dropout = dropout or DropoutOff()
     ra = _r16 if round_act else (lambda v: v)
     rw = _r16 if round_w else (lambda v: v)

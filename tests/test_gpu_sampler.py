@@ -3,7 +3,7 @@
 Tolerance (stated): rel-RMS <= 2.5e-2 per forecast field over a rollout for the bf16 engine (bf16 operands and block
 outputs, fp32 accumulation, fp32 sampler state and cold-sampling update); measured values are printed (7.5e-3 - 2.1e-2).
 Why not SURVEY 8c's 1e-2: that figure rested on "the reference's own bf16-autocast drift is 3.5e-3 - 4.5e-3"; measured on
-the full-size fixture G6 (tools/bf16_drift.py, profiles/r02_bf16_drift.json) the reference under torch.autocast(bf16)
+the full-size fixture G6 (tests/measure_bf16_drift.py, profiles/r02_bf16_drift.json) the reference under torch.autocast(bf16)
 drifts 3.1e-2 - 4.1e-2 from its fp32 self over the h=16 rollout, bf16-rounded weights ALONE give 1.1e-2 - 1.4e-2, and the
 oracle evaluated with the engine's rounding points (`nets.unet_simple_forward_bf16_model`) 1.7e-2 - 2.1e-2 -- which is what
 the engine measures, layer by layer (`test_fullsize_engine_error_is_the_bf16_storage_error`).  The fp16 build of the same
