@@ -55,6 +55,7 @@ class BcArgs(C.Structure):
 
 
 BC_NAVIER_STOKES, BC_SPRING_MESH = 0, 1
+TRAIN_BATCH_STATS, TRAIN_DROPOUT = 1, 2
 
 # every symbol include/dyffusion_hip.h and include/dyffusion_hip_testing.h declare: (name, restype, argtypes)
 _P = C.c_void_p
@@ -83,6 +84,11 @@ SYMBOLS = [
     ("dyf_op_linear_attention", C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, _P]),
     ("dyf_op_attention", C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, _P]),
     ("dyf_criterion", C.c_int, [_P, _P, _P, C.c_int64, C.c_int32, _P, _P]),
+    ("dyf_train_forward", C.c_int, [_P, C.c_int32, C.c_int32, _P, _P, _P, _P, C.c_int32, C.c_int32, _P]),
+    ("dyf_train_backward", C.c_int, [_P, C.c_int32, _P, _P, C.c_int32, _P]),
+    ("dyf_train_zero_grads", C.c_int, [_P, C.c_int32]),
+    ("dyf_train_export", C.c_int, [_P, C.c_int32, C.c_int32, C.POINTER(C.c_char_p), C.POINTER(_P)]),
+    ("dyf_criterion_grad", C.c_int, [_P, _P, _P, C.c_int64, C.c_int32, C.c_float, _P, _P]),
     ("dyf_apply_boundary_conditions", C.c_int, [_P, C.POINTER(BcArgs), _P, _P]),
     ("dyf_debug_read_block_output", C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
 ]

@@ -286,6 +286,7 @@ void dyf_engine_destroy(dyf_engine* e) {
     sc_destroy(e->net[0]);
     sc_destroy(e->net[1]);
     if (e->cap_stream) (void)hipStreamDestroy(e->cap_stream);
+    train_destroy(e);
     release_allocs(e->allocs);
     release_allocs(e->net_allocs[0]);
     release_allocs(e->net_allocs[1]);
@@ -634,7 +635,7 @@ dyf_status dyf_load_weights(dyf_engine* e, int32_t which, int32_t n_tensors, con
     n.table_of_time.clear();
     n.ntables = 0;
     e->plan.set = false;  // coefficient tables depend on the weights
-    return DYF_OK;
+    return train_store_weights(e, which, sd);  // fp32 copy in the training layout (train.hip)
 }
 
 dyf_status dyf_net_flops(const dyf_engine* e, int32_t which, double* flops) {

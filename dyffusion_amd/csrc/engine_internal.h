@@ -15,6 +15,7 @@
 
 namespace dyf {
 
+struct TrainState;  // fp32 training copies of the parameters, gradients and forward tapes (train.hip)
 struct RNet;  // ResNet-UNet state (unet_resnet.hip)
 struct SNet;  // SimpleConvNet state (simple_conv_net.hip)
 
@@ -128,6 +129,7 @@ struct dyf_engine {
     std::vector<int> prof_rows;
     float* s_pair = nullptr;        // [2][max_batch][C][H][W]: outputs of a paired interpolator call
     bool pair_interp = true;        // DYF_PAIR_INTERP=0: one forward per interpolator call (A/B testing)
+    dyf::TrainState* train = nullptr;  // training path (arch unet_simple), created by the first dyf_load_weights
     bool last_dec5_sparse = false;  // the most recent unet_simple forward stored dec5 in the compact sparse-column layout
     bool poison_dec5 = false;       // DYF_POISON_DEC5=1 (test hook, read once at create): NaN-fill dec5's output before its conv
 };
@@ -243,6 +245,12 @@ struct FwdOpts {
 };
 
 
+}  // namespace dyf
+
+// ---- training step (train.hip)
+namespace dyf {
+dyf_status train_store_weights(dyf_engine* e, int which, std::map<std::string, TensorView>& sd);
+void train_destroy(dyf_engine* e);
 }  // namespace dyf
 
 // ---- SimpleConvNet backbone (src/models/simple_conv_net.py), implemented in simple_conv_net.hip

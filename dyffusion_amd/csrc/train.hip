@@ -1,0 +1,964 @@
+// Training step of the forecaster objective on the GPU: forward WITH batch-statistics BatchNorm / dropout and the backward
+// pass of arch unet_simple.
+//
+// Replaces, for `DYffusion.p_losses` in training mode (src/diffusion/dyffusion.py:496-567, entered from
+// BaseDiffusion.forward, src/diffusion/_base_diffusion.py:81-106), what the reference gets from torch.autograd over
+// src/models/unet_simple.py:13-82,164-197: conv / transposed-conv dgrad + wgrad, BatchNorm2d in training mode (batch mean /
+// biased variance, running-statistics update), GroupNorm, FiLM `x*(scale+1)+shift` with its time-MLP, (Leaky)ReLU, Dropout,
+// bilinear resampling (align_corners=False) and its adjoint, skip concatenation.  The frozen interpolator takes part with
+// running-statistics BatchNorm and input gradients only (the second loss term differentiates THROUGH it, :534-557).
+//
+// First correct form: everything here is fp32 (NHWC activations, fp32 weights in [cout][tap][cin] order) on plain VALU
+// kernels -- gradient parity with autograd is ~1e-5, not bf16-limited.  The MFMA implicit-GEMM machinery of the sampling
+// path (conv.hip, conv_igemm2.hip, conv_up_halo.hip) is the next step for dgrad (a conv with transposed / flipped weights)
+// and wgrad (pixels as the contraction axis, like linattn_ctx_mfma_kernel); see DESIGN.md.
+#include "engine_internal.h"
+
+#include "../../include/dyffusion_hip.h"
+
+using namespace dyf;
+
+namespace dyf {
+
+struct TBlockW {            // fp32 parameters (and gradients) of one UNetBlock
+    float *w = nullptr, *wt = nullptr;   // conv weight [cout][tap][cin] and its [tap][cin][cout] transpose (forward)
+    float *b = nullptr, *gamma = nullptr, *beta = nullptr, *rmean = nullptr, *rvar = nullptr;
+    float *fw = nullptr, *fb = nullptr;  // FiLM head Linear(tdim -> 2 cout)
+    float *g_w = nullptr, *g_b = nullptr, *g_gamma = nullptr, *g_beta = nullptr, *g_fw = nullptr, *g_fb = nullptr;
+};
+
+struct TNet {
+    TBlockW blk[12];
+    float *t_w1 = nullptr, *t_b1 = nullptr, *t_w2 = nullptr, *t_b2 = nullptr, *g_t_w1 = nullptr, *g_t_b1 = nullptr,
+          *g_t_w2 = nullptr, *g_t_b2 = nullptr;
+    float *stem_w = nullptr, *stem_wt = nullptr, *stem_b = nullptr, *g_stem_w = nullptr, *g_stem_b = nullptr;  // [dim][cin]
+    float *ro_w = nullptr, *ro_wt = nullptr, *ro_b = nullptr, *g_ro_w = nullptr, *g_ro_b = nullptr;  // conv C: [dim][16][C]
+    std::vector<std::pair<float*, size_t>> grads;  // every gradient buffer (zeroing)
+    std::vector<void*> owned;
+    bool ready = false;
+};
+
+struct TTape {              // what one recorded forward leaves for its backward
+    int net = -1, nb = 0, flags = 0;
+    std::vector<void*> owned;
+    float *x_in = nullptr, *x_up = nullptr, *s0 = nullptr;
+    float *cin_ptr[12] = {}, *z[12] = {}, *y[12] = {}, *ss[12] = {}, *mean[12] = {}, *rstd[12] = {};
+    float *xlast = nullptr;      // input of the readout
+    float *e0 = nullptr, *l1 = nullptr, *gl = nullptr, *temb = nullptr, *silu = nullptr;  // time-MLP chain
+    uint32_t* row_keys = nullptr;
+};
+
+struct TrainState {
+    TNet net[2];
+    TTape tape[4];
+};
+
+}  // namespace dyf
+
+namespace {
+
+#define TK(expr)                                                        \
+    do {                                                                \
+        hipError_t _e = (expr);                                         \
+        if (_e != hipSuccess) return fail(e, DYF_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e)); \
+    } while (0)
+
+inline unsigned nblk(long long total, int bs = 256) { return (unsigned)((total + bs - 1) / bs); }
+
+// ------------------------------------------------------------------------------------------------ layout / resampling
+__global__ void t_nchw_cat_to_nhwc(const float* s0, int c0, const float* s1, int c1, const float* s2, int c2, int n, int hw, float* out) {
+    const int C = c0 + c1 + c2;
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)n * hw * C) return;
+    const int c = (int)(i % C);
+    const long long p = i / C;
+    const int b = (int)(p / hw), px = (int)(p % hw);
+    float v;
+    if (c < c0) v = s0[((size_t)b * c0 + c) * hw + px];
+    else if (c < c0 + c1) v = s1[((size_t)b * c1 + (c - c0)) * hw + px];
+    else v = s2[((size_t)b * c2 + (c - c0 - c1)) * hw + px];
+    out[i] = v;
+}
+
+// NHWC channel range [c_lo, c_lo + cn) -> NCHW (cn channels)
+__global__ void t_nhwc_to_nchw(const float* in, int n, int hw, int C, int c_lo, int cn, float* out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)n * cn * hw) return;
+    const int px = (int)(i % hw), c = (int)((i / hw) % cn), b = (int)(i / ((long long)hw * cn));
+    out[i] = in[((size_t)b * hw + px) * C + c_lo + c];
+}
+
+__global__ void t_nchw_to_nhwc(const float* in, int n, int hw, int C, float* out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)n * C * hw) return;
+    const int c = (int)(i % C);
+    const long long p = i / C;
+    const int b = (int)(p / hw), px = (int)(p % hw);
+    out[i] = in[((size_t)b * C + c) * hw + px];
+}
+
+// F.interpolate(mode="bilinear", align_corners=False), NHWC fp32
+__global__ void t_resize_fwd(const float* in, int n, int ih, int iw, int C, int oh, int ow, float* out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)n * oh * ow * C) return;
+    const int c = (int)(i % C);
+    const long long p = i / C;
+    const int ox = (int)(p % ow), oy = (int)((p / ow) % oh), b = (int)(p / ((long long)ow * oh));
+    int y0, y1, x0, x1;
+    float ly, lx;
+    bilinear_coord(oy, (float)ih / (float)oh, ih, y0, y1, ly);
+    bilinear_coord(ox, (float)iw / (float)ow, iw, x0, x1, lx);
+    const float* base = in + (size_t)b * ih * iw * C + c;
+    const float v00 = base[((size_t)y0 * iw + x0) * C], v01 = base[((size_t)y0 * iw + x1) * C];
+    const float v10 = base[((size_t)y1 * iw + x0) * C], v11 = base[((size_t)y1 * iw + x1) * C];
+    const float top = v00 * (1.0f - lx) + v01 * lx, bot = v10 * (1.0f - lx) + v11 * lx;
+    out[i] = top * (1.0f - ly) + bot * ly;
+}
+
+// adjoint of t_resize_fwd: din (zero-initialised) += scatter of dout
+__global__ void t_resize_bwd(const float* dout, int n, int ih, int iw, int C, int oh, int ow, float* din) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)n * oh * ow * C) return;
+    const int c = (int)(i % C);
+    const long long p = i / C;
+    const int ox = (int)(p % ow), oy = (int)((p / ow) % oh), b = (int)(p / ((long long)ow * oh));
+    int y0, y1, x0, x1;
+    float ly, lx;
+    bilinear_coord(oy, (float)ih / (float)oh, ih, y0, y1, ly);
+    bilinear_coord(ox, (float)iw / (float)ow, iw, x0, x1, lx);
+    const float g = dout[i];
+    float* base = din + (size_t)b * ih * iw * C + c;
+    atomicAdd(base + ((size_t)y0 * iw + x0) * C, g * (1.0f - ly) * (1.0f - lx));
+    atomicAdd(base + ((size_t)y0 * iw + x1) * C, g * (1.0f - ly) * lx);
+    atomicAdd(base + ((size_t)y1 * iw + x0) * C, g * ly * (1.0f - lx));
+    atomicAdd(base + ((size_t)y1 * iw + x1) * C, g * ly * lx);
+}
+
+// ------------------------------------------------------------------------------------------------ convolution (fp32, NHWC)
+struct TConv {
+    int n, h, w, cin, ho, wo, cout, k, s, p;
+};
+
+// y[n,oy,ox,co] = b[co] + sum_{tap,ci} x[n, oy*s-p+ky, ox*s-p+kx, ci] * wt[tap][ci][co]
+__global__ void t_conv_fwd(TConv g, const float* x, const float* wt, const float* bias, float* y) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)g.n * g.ho * g.wo * g.cout) return;
+    const int co = (int)(i % g.cout);
+    const long long pix = i / g.cout;
+    const int ox = (int)(pix % g.wo), oy = (int)((pix / g.wo) % g.ho), b = (int)(pix / ((long long)g.wo * g.ho));
+    float acc = bias ? bias[co] : 0.0f;
+    for (int ky = 0; ky < g.k; ++ky) {
+        const int iy = oy * g.s - g.p + ky;
+        if ((unsigned)iy >= (unsigned)g.h) continue;
+        for (int kx = 0; kx < g.k; ++kx) {
+            const int ix = ox * g.s - g.p + kx;
+            if ((unsigned)ix >= (unsigned)g.w) continue;
+            const float* xp = x + (((size_t)b * g.h + iy) * g.w + ix) * g.cin;
+            const float* wp = wt + (size_t)(ky * g.k + kx) * g.cin * g.cout + co;
+            for (int ci = 0; ci < g.cin; ++ci) acc = fmaf(xp[ci], wp[(size_t)ci * g.cout], acc);
+        }
+    }
+    y[i] = acc;
+}
+
+// dx[n,iy,ix,ci] = sum over (ky,kx) with (iy+p-ky) % s == 0 and co of dz[n,(iy+p-ky)/s,(ix+p-kx)/s,co] * w[co][tap][ci]
+// (+ bias[ci] when used as the FORWARD of a transposed convolution)
+__global__ void t_conv_dgrad(TConv g, const float* dz, const float* w, const float* bias, float* dx) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)g.n * g.h * g.w * g.cin) return;
+    const int ci = (int)(i % g.cin);
+    const long long pix = i / g.cin;
+    const int ix = (int)(pix % g.w), iy = (int)((pix / g.w) % g.h), b = (int)(pix / ((long long)g.w * g.h));
+    float acc = bias ? bias[ci] : 0.0f;
+    const int taps = g.k * g.k;
+    for (int ky = 0; ky < g.k; ++ky) {
+        const int ty = iy + g.p - ky;
+        if (ty < 0 || ty % g.s) continue;
+        const int oy = ty / g.s;
+        if (oy >= g.ho) continue;
+        for (int kx = 0; kx < g.k; ++kx) {
+            const int tx = ix + g.p - kx;
+            if (tx < 0 || tx % g.s) continue;
+            const int ox = tx / g.s;
+            if (ox >= g.wo) continue;
+            const float* zp = dz + (((size_t)b * g.ho + oy) * g.wo + ox) * g.cout;
+            const float* wp = w + (size_t)(ky * g.k + kx) * g.cin + ci;
+            for (int co = 0; co < g.cout; ++co) acc = fmaf(zp[co], wp[(size_t)co * taps * g.cin], acc);
+        }
+    }
+    dx[i] = acc;
+}
+
+// dw[co][tap][ci] += sum_{n,oy,ox} dz[n,oy,ox,co] * x[n,oy*s-p+ky,ox*s-p+kx,ci].  One workgroup = a 16 x 16 (co, ci) tile of
+// one tap over a slice of the output pixels; slices are merged with atomics.  db[co] += sum dz (tap 0 / ci-tile 0 only).
+__global__ __launch_bounds__(256) void t_conv_wgrad(TConv g, const float* dz, const float* x, float* dw, float* db, int pix_per_block) {
+    const int taps = g.k * g.k;
+    const int co_tiles = (g.cout + 15) / 16, ci_tiles = (g.cin + 15) / 16;
+    int bid = blockIdx.x;
+    const int cit = bid % ci_tiles; bid /= ci_tiles;
+    const int cot = bid % co_tiles; bid /= co_tiles;
+    const int tap = bid % taps;
+    const int slice = bid / taps;
+    const int ky = tap / g.k, kx = tap % g.k;
+    const int tco = threadIdx.x >> 4, tci = threadIdx.x & 15;
+    const int co = cot * 16 + tco, ci = cit * 16 + tci;
+    const long long M = (long long)g.n * g.ho * g.wo;
+    const long long m0 = (long long)slice * pix_per_block, m1 = m0 + pix_per_block < M ? m0 + pix_per_block : M;
+    __shared__ float sz[16][17], sx[16][17];
+    float acc = 0.0f, accb = 0.0f;
+    for (long long mb = m0; mb < m1; mb += 16) {
+        {   // stage 16 pixels x 16 channels of dz and of the shifted x
+            const int pp = threadIdx.x >> 4, cc = threadIdx.x & 15;
+            const long long m = mb + pp;
+            float vz = 0.0f, vx = 0.0f;
+            if (m < m1) {
+                const int ox = (int)(m % g.wo), oy = (int)((m / g.wo) % g.ho), b = (int)(m / ((long long)g.wo * g.ho));
+                if (cot * 16 + cc < g.cout) vz = dz[(size_t)m * g.cout + cot * 16 + cc];
+                const int iy = oy * g.s - g.p + ky, ix = ox * g.s - g.p + kx;
+                if ((unsigned)iy < (unsigned)g.h && (unsigned)ix < (unsigned)g.w && cit * 16 + cc < g.cin)
+                    vx = x[(((size_t)b * g.h + iy) * g.w + ix) * g.cin + cit * 16 + cc];
+            }
+            sz[pp][cc] = vz;
+            sx[pp][cc] = vx;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int pp = 0; pp < 16; ++pp) {
+            acc = fmaf(sz[pp][tco], sx[pp][tci], acc);
+            accb += sz[pp][tco];
+        }
+        __syncthreads();
+    }
+    if (co < g.cout && ci < g.cin) atomicAdd(dw + ((size_t)co * taps + tap) * g.cin + ci, acc);
+    if (db && tap == 0 && cit == 0 && tci == 0 && co < g.cout) atomicAdd(db + co, accb);
+}
+
+// ------------------------------------------------------------------------------------------------ normalisation + FiLM + act + dropout
+// per-(sample, channel) sums over the plane: S[n][c] = sum z, Q[n][c] = sum z^2   (fp64 accumulators, zero-initialised)
+__global__ __launch_bounds__(256) void t_nc_sums(const float* z, int hw, int C, int px_per_block, double* S, double* Q) {
+    const int b = blockIdx.y;
+    const int p0 = blockIdx.x * px_per_block, p1 = min(p0 + px_per_block, hw);
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        double s = 0.0, q = 0.0;
+        const float* zp = z + ((size_t)b * hw) * C + c;
+        for (int p = p0; p < p1; ++p) {
+            const double v = zp[(size_t)p * C];
+            s += v;
+            q += v * v;
+        }
+        atomicAdd(S + (size_t)b * C + c, s);
+        atomicAdd(Q + (size_t)b * C + c, q);
+    }
+}
+
+// kind 0: BatchNorm, batch statistics (index = channel; also updates the running statistics, momentum 0.1, unbiased var)
+// kind 1: BatchNorm, running statistics (eval);  kind 2: GroupNorm (index = sample * groups + group)
+__global__ void t_stats_finalize(int kind, const double* S, const double* Q, int n, int hw, int C, int groups, float* rmean, float* rvar,
+                                 float* mean, float* rstd) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (kind == 2) {
+        if (i >= n * groups) return;
+        const int b = i / groups, gq = i % groups, cpg = C / groups;
+        double s = 0.0, q = 0.0;
+        for (int c = gq * cpg; c < (gq + 1) * cpg; ++c) {
+            s += S[(size_t)b * C + c];
+            q += Q[(size_t)b * C + c];
+        }
+        const double cnt = (double)hw * cpg, m = s / cnt, var = q / cnt - m * m;
+        mean[i] = (float)m;
+        rstd[i] = (float)(1.0 / sqrt((var > 0.0 ? var : 0.0) + 1e-5));
+        return;
+    }
+    if (i >= C) return;
+    if (kind == 1) {
+        mean[i] = rmean[i];
+        rstd[i] = 1.0f / sqrtf(rvar[i] + 1e-5f);
+        return;
+    }
+    double s = 0.0, q = 0.0;
+    for (int b = 0; b < n; ++b) {
+        s += S[(size_t)b * C + i];
+        q += Q[(size_t)b * C + i];
+    }
+    const double cnt = (double)n * hw, m = s / cnt, var = fmax(q / cnt - m * m, 0.0);
+    mean[i] = (float)m;
+    rstd[i] = (float)(1.0 / sqrt(var + 1e-5));
+    rmean[i] = 0.9f * rmean[i] + 0.1f * (float)m;                                      // nn.BatchNorm2d, momentum 0.1
+    rvar[i] = 0.9f * rvar[i] + 0.1f * (float)(cnt > 1.0 ? var * cnt / (cnt - 1.0) : var);
+}
+
+struct TNorm {
+    int n, hw, C, groups, gn, act;      // gn: statistics index = (sample, group) instead of channel
+    const float *mean, *rstd, *gamma, *beta, *ss;  // ss [n][2C]: FiLM (scale | shift) or null
+    int drop;                           // dropout on
+    float drop_scale;
+    uint32_t thresh16;
+    RngKey salt;
+    const uint32_t* row_keys;
+};
+
+__device__ __forceinline__ float t_act(float u, int act) { return act == ACT_RELU ? fmaxf(u, 0.0f) : act == ACT_LEAKY ? (u > 0.0f ? u : 0.2f * u) : u; }
+__device__ __forceinline__ float t_dact(float u, int act) { return act == ACT_RELU ? (u > 0.0f ? 1.0f : 0.0f) : act == ACT_LEAKY ? (u > 0.0f ? 1.0f : 0.2f) : 1.0f; }
+
+__device__ __forceinline__ float t_keep(const TNorm& a, int b, uint32_t e_in_row) {
+    if (!a.drop) return 1.0f;
+    const RngKey rk = rng_stream_key(RngKey{a.row_keys[2 * b], a.row_keys[2 * b + 1]}, a.salt);
+    return rng_keep(e_in_row, rk, a.thresh16) ? a.drop_scale : 0.0f;
+}
+
+__global__ void t_norm_fwd(TNorm a, const float* z, float* y) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long per = (long long)a.hw * a.C;
+    if (i >= per * a.n) return;
+    const int c = (int)(i % a.C), b = (int)(i / per);
+    const int idx = a.gn ? b * a.groups + c / (a.C / a.groups) : c;
+    float v = (z[i] - a.mean[idx]) * a.rstd[idx] * a.gamma[c] + a.beta[c];
+    if (a.ss) v = v * (1.0f + a.ss[(size_t)b * 2 * a.C + c]) + a.ss[(size_t)b * 2 * a.C + a.C + c];
+    y[i] = t_act(v, a.act) * t_keep(a, b, (uint32_t)(i - (long long)b * per));
+}
+
+// backward reductions, per (sample, channel) over the plane:
+//   A = sum dpre * v (dscale), B = sum dpre (dshift), Cc = sum dbn * xhat, Dd = sum dbn,  dbn = dpre * (1 + scale)
+__global__ __launch_bounds__(256) void t_norm_bwd_sums(TNorm a, const float* z, const float* dy, int px_per_block, double* A, double* B,
+                                                       double* Cc, double* Dd) {
+    const int b = blockIdx.y;
+    const int p0 = blockIdx.x * px_per_block, p1 = min(p0 + px_per_block, a.hw);
+    const long long per = (long long)a.hw * a.C;
+    for (int c = threadIdx.x; c < a.C; c += blockDim.x) {
+        const int idx = a.gn ? b * a.groups + c / (a.C / a.groups) : c;
+        const float mu = a.mean[idx], rs = a.rstd[idx], ga = a.gamma[c], be = a.beta[c];
+        const float sc = a.ss ? a.ss[(size_t)b * 2 * a.C + c] : 0.0f, sh = a.ss ? a.ss[(size_t)b * 2 * a.C + a.C + c] : 0.0f;
+        double sa = 0.0, sb = 0.0, scx = 0.0, sd = 0.0;
+        for (int p = p0; p < p1; ++p) {
+            const long long e = (long long)p * a.C + c;
+            const float xh = (z[(size_t)b * per + e] - mu) * rs, v = xh * ga + be, u = v * (1.0f + sc) + sh;
+            const float dpre = dy[(size_t)b * per + e] * t_keep(a, b, (uint32_t)e) * t_dact(u, a.act);
+            const float dbn = dpre * (1.0f + sc);
+            sa += (double)dpre * v;
+            sb += dpre;
+            scx += (double)dbn * xh;
+            sd += dbn;
+        }
+        atomicAdd(A + (size_t)b * a.C + c, sa);
+        atomicAdd(B + (size_t)b * a.C + c, sb);
+        atomicAdd(Cc + (size_t)b * a.C + c, scx);
+        atomicAdd(Dd + (size_t)b * a.C + c, sd);
+    }
+}
+
+// combine: dgamma / dbeta (accumulated), dss[n][2C] = (A | B), and the two sums of the normalisation backward per statistics
+// index: S1 = sum gamma*dbn, S2 = sum gamma*dbn*xhat
+__global__ void t_norm_bwd_combine(TNorm a, const double* A, const double* B, const double* Cc, const double* Dd, float* g_gamma,
+                                   float* g_beta, float* dss, float* S1, float* S2, int batch_stats) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < a.C) {
+        double dg = 0.0, db = 0.0;
+        for (int b = 0; b < a.n; ++b) {
+            dg += Cc[(size_t)b * a.C + i];
+            db += Dd[(size_t)b * a.C + i];
+        }
+        if (g_gamma) {
+            g_gamma[i] += (float)dg;
+            g_beta[i] += (float)db;
+        }
+        if (!a.gn) {
+            S1[i] = batch_stats ? (float)(a.gamma[i] * db) : 0.0f;   // running statistics: the norm is a fixed affine map
+            S2[i] = batch_stats ? (float)(a.gamma[i] * dg) : 0.0f;
+        }
+    }
+    if (dss && i < a.n * a.C) {
+        const int b = i / a.C, c = i % a.C;
+        dss[(size_t)b * 2 * a.C + c] = (float)A[i];
+        dss[(size_t)b * 2 * a.C + a.C + c] = (float)B[i];
+    }
+    if (a.gn && i < a.n * a.groups) {
+        const int b = i / a.groups, gq = i % a.groups, cpg = a.C / a.groups;
+        double s1 = 0.0, s2 = 0.0;
+        for (int c = gq * cpg; c < (gq + 1) * cpg; ++c) {
+            s1 += (double)a.gamma[c] * Dd[(size_t)b * a.C + c];
+            s2 += (double)a.gamma[c] * Cc[(size_t)b * a.C + c];
+        }
+        S1[i] = (float)s1;
+        S2[i] = (float)s2;
+    }
+}
+
+// dz = rstd * (gamma*dbn - (S1 + xhat*S2) / count)
+__global__ void t_norm_bwd_apply(TNorm a, const float* z, const float* dy, const float* S1, const float* S2, float inv_count, float* dz) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long per = (long long)a.hw * a.C;
+    if (i >= per * a.n) return;
+    const int c = (int)(i % a.C), b = (int)(i / per);
+    const int idx = a.gn ? b * a.groups + c / (a.C / a.groups) : c;
+    const float xh = (z[i] - a.mean[idx]) * a.rstd[idx], v = xh * a.gamma[c] + a.beta[c];
+    const float sc = a.ss ? a.ss[(size_t)b * 2 * a.C + c] : 0.0f, sh = a.ss ? a.ss[(size_t)b * 2 * a.C + a.C + c] : 0.0f;
+    const float u = v * (1.0f + sc) + sh;
+    const float dbn = dy[i] * t_keep(a, b, (uint32_t)(i - (long long)b * per)) * t_dact(u, a.act) * (1.0f + sc);
+    dz[i] = a.rstd[idx] * (a.gamma[c] * dbn - (S1[idx] + xh * S2[idx]) * inv_count);
+}
+
+// ------------------------------------------------------------------------------------------------ small dense layers (time MLP, FiLM heads)
+// y[r][o] = b[o] + sum_k f(x[r][k]) * W[o][k];  f = identity (pre = 0) or SiLU (pre = 1)
+__global__ void t_linear_fwd(const float* x, const float* W, const float* bias, int rows, int K, int O, int pre, float* y) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * O) return;
+    const int r = i / O, o = i % O;
+    float acc = bias[o];
+    for (int k = 0; k < K; ++k) {
+        float v = x[(size_t)r * K + k];
+        if (pre) v = v / (1.0f + expf(-v));
+        acc = fmaf(v, W[(size_t)o * K + k], acc);
+    }
+    y[i] = acc;
+}
+// dW[o][k] += sum_r dy[r][o] * f(x[r][k]);  db[o] += sum_r dy[r][o]
+__global__ void t_linear_bwd_w(const float* x, const float* dy, int rows, int K, int O, int pre, float* dW, float* db) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= O * K) return;
+    const int o = i / K, k = i % K;
+    float acc = 0.0f, accb = 0.0f;
+    for (int r = 0; r < rows; ++r) {
+        float v = x[(size_t)r * K + k];
+        if (pre) v = v / (1.0f + expf(-v));
+        acc = fmaf(dy[(size_t)r * O + o], v, acc);
+        accb += dy[(size_t)r * O + o];
+    }
+    dW[i] += acc;
+    if (k == 0) db[o] += accb;
+}
+// dx[r][k] (+)= f'(x[r][k]) * sum_o dy[r][o] * W[o][k]
+__global__ void t_linear_bwd_x(const float* x, const float* W, const float* dy, int rows, int K, int O, int pre, int accumulate, float* dx) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * K) return;
+    const int r = i / K, k = i % K;
+    float acc = 0.0f;
+    for (int o = 0; o < O; ++o) acc = fmaf(dy[(size_t)r * O + o], W[(size_t)o * K + k], acc);
+    if (pre) {
+        const float v = x[i], sg = 1.0f / (1.0f + expf(-v));
+        acc *= sg * (1.0f + v * (1.0f - sg));
+    }
+    dx[i] = accumulate ? dx[i] + acc : acc;
+}
+__global__ void t_silu_bwd(const float* x, const float* dsilu, long long n, float* dx) {  // dx = dsilu * silu'(x)
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float v = x[i], sg = 1.0f / (1.0f + expf(-v));
+    dx[i] = dsilu[i] * sg * (1.0f + v * (1.0f - sg));
+}
+__global__ void t_sinusoid(const float* t, int rows, int dim, float* out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * dim) return;
+    const int r = i / dim, k = i % dim, half = dim / 2, j = k < half ? k : k - half;
+    const float ang = t[r] * expf((float)j * (-logf(10000.0f) / (float)(half - 1)));
+    out[i] = k < half ? sinf(ang) : cosf(ang);
+}
+__global__ void t_gelu_fwd(const float* x, long long n, float* y) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = 0.5f * x[i] * (1.0f + erff(x[i] * 0.70710678118654752f));
+}
+__global__ void t_gelu_bwd(const float* x, long long n, float* d) {  // d *= gelu'(x)
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) d[i] *= 0.5f * (1.0f + erff(x[i] * 0.70710678118654752f)) + x[i] * 0.3989422804014327f * expf(-0.5f * x[i] * x[i]);
+}
+
+// ------------------------------------------------------------------------------------------------ element-wise helpers
+__global__ void t_concat2(const float* a, int ca, const float* b, int cb, long long pixels, float* out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int C = ca + cb;
+    if (i >= pixels * C) return;
+    const int c = (int)(i % C);
+    const long long p = i / C;
+    out[i] = c < ca ? a[p * ca + c] : b[p * cb + (c - ca)];
+}
+// split the gradient of cat[a, b]: da = d[..., :ca] (assign), db += d[..., ca:]
+__global__ void t_split2(const float* d, int ca, int cb, long long pixels, float* da, float* db) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int C = ca + cb;
+    if (i >= pixels * C) return;
+    const int c = (int)(i % C);
+    const long long p = i / C;
+    if (c < ca) da[p * ca + c] = d[i];
+    else db[p * cb + (c - ca)] += d[i];
+}
+__global__ void t_add(float* a, const float* b, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) a[i] += b[i];
+}
+__global__ void t_bias_grad(const float* d, long long pixels, int C, float* db) {  // db[c] += sum_p d[p][c]
+    const int c = blockIdx.x;
+    __shared__ float red[256];
+    float s = 0.0f;
+    for (long long p = threadIdx.x; p < pixels; p += 256) s += d[p * C + c];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) db[c] += red[0];
+}
+// d(mean criterion)/d pred * scale: kind 0 L1 (sign), 1 MSE, 2 smooth-L1 (beta 1)
+__global__ void t_criterion_grad(const float* pred, const float* target, long long n, int kind, float scale, float* d) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float r = pred[i] - target[i];
+    float gsign = r > 0.0f ? 1.0f : (r < 0.0f ? -1.0f : 0.0f);
+    float g = kind == 0 ? gsign : kind == 1 ? 2.0f * r : (fabsf(r) < 1.0f ? r : gsign);
+    d[i] = g * scale / (float)n;
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+template <typename T>
+dyf_status talloc(dyf_engine* e, std::vector<void*>& owner, T** out, size_t count, bool zero = true) {
+    void* p = nullptr;
+    const size_t bytes = std::max<size_t>(count * sizeof(T), 256);
+    TK(hipMalloc(&p, bytes));
+    if (zero) TK(hipMemset(p, 0, bytes));
+    owner.push_back(p);
+    *out = (T*)p;
+    return DYF_OK;
+}
+
+dyf_status tupload(dyf_engine* e, std::vector<void*>& owner, float** out, const std::vector<float>& h) {
+    dyf_status s = talloc(e, owner, out, h.size(), false);
+    if (s != DYF_OK) return s;
+    TK(hipMemcpy(*out, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice));
+    return DYF_OK;
+}
+
+void tfree(std::vector<void*>& owner) {
+    for (void* p : owner) (void)hipFree(p);
+    owner.clear();
+}
+
+dyf_status conv_fwd(dyf_engine* e, const TConv& g, const float* x, const float* wt, const float* b, float* y, hipStream_t st) {
+    hipLaunchKernelGGL(t_conv_fwd, dim3(nblk((long long)g.n * g.ho * g.wo * g.cout)), dim3(256), 0, st, g, x, wt, b, y);
+    TK(hipGetLastError());
+    return DYF_OK;
+}
+dyf_status conv_dgrad(dyf_engine* e, const TConv& g, const float* dz, const float* w, const float* bias, float* dx, hipStream_t st) {
+    hipLaunchKernelGGL(t_conv_dgrad, dim3(nblk((long long)g.n * g.h * g.w * g.cin)), dim3(256), 0, st, g, dz, w, bias, dx);
+    TK(hipGetLastError());
+    return DYF_OK;
+}
+dyf_status conv_wgrad(dyf_engine* e, const TConv& g, const float* dz, const float* x, float* dw, float* db, hipStream_t st) {
+    const long long M = (long long)g.n * g.ho * g.wo;
+    const int tiles = g.k * g.k * ((g.cout + 15) / 16) * ((g.cin + 15) / 16);
+    long long slices = std::max<long long>(1, std::min<long long>((M + 255) / 256, (4096 + tiles - 1) / tiles));
+    const int ppb = (int)(((M + slices - 1) / slices + 15) / 16 * 16);
+    slices = (M + ppb - 1) / ppb;
+    hipLaunchKernelGGL(t_conv_wgrad, dim3((unsigned)(tiles * slices)), dim3(256), 0, st, g, dz, x, dw, db, ppb);
+    TK(hipGetLastError());
+    return DYF_OK;
+}
+
+TConv block_geom(const UBlock& b, int nb) {
+    return TConv{nb, b.in_h, b.in_w, b.cin, b.out_h, b.out_w, b.cout, b.k, b.stride, b.pad};
+}
+
+}  // namespace
+
+namespace dyf {
+
+void train_destroy(dyf_engine* e) {
+    if (!e->train) return;
+    for (auto& n : e->train->net) tfree(n.owned);
+    for (auto& t : e->train->tape) tfree(t.owned);
+    delete e->train;
+    e->train = nullptr;
+}
+
+// called by dyf_load_weights (arch unet_simple): keep an fp32 copy of the parameters in the training layout
+dyf_status train_store_weights(dyf_engine* e, int which, std::map<std::string, TensorView>& sd) {
+    if (!e->train) e->train = new TrainState();
+    TNet& t = e->train->net[which];
+    const Net& n = e->net[which];
+    TK(hipDeviceSynchronize());
+    tfree(t.owned);
+    t = TNet{};
+    auto V = [&](const std::string& k) { const TensorView& v = sd.at(k); return std::vector<float>(v.data, v.data + v.numel()); };
+    auto grad = [&](float** g, size_t cnt) -> dyf_status {
+        dyf_status s = talloc(e, t.owned, g, cnt);
+        if (s == DYF_OK) t.grads.emplace_back(*g, cnt);
+        return s;
+    };
+#define TS(expr) do { dyf_status _s = (expr); if (_s != DYF_OK) return _s; } while (0)
+    for (int i = 0; i < 12; ++i) {
+        const UBlock& b = n.blk[i];
+        TBlockW& w = t.blk[i];
+        const std::string pre = (i < 6 ? "input_ops." + std::to_string(i) : "output_ops." + std::to_string(i - 6));
+        const std::string conv = pre + ".ops." + (b.transposed ? "1" : "0"), norm = pre + ".ops." + (b.transposed ? "2" : "1");
+        const std::vector<float> cw = V(conv + ".weight");
+        const int taps = b.k * b.k;
+        std::vector<float> a((size_t)b.cout * taps * b.cin), at(a.size());
+        for (int co = 0; co < b.cout; ++co)
+            for (int ci = 0; ci < b.cin; ++ci)
+                for (int tp = 0; tp < taps; ++tp) {
+                    const float v = cw[((size_t)co * b.cin + ci) * taps + tp];
+                    a[((size_t)co * taps + tp) * b.cin + ci] = v;
+                    at[((size_t)tp * b.cin + ci) * b.cout + co] = v;
+                }
+        TS(tupload(e, t.owned, &w.w, a)); TS(tupload(e, t.owned, &w.wt, at));
+        TS(tupload(e, t.owned, &w.b, V(conv + ".bias")));
+        TS(tupload(e, t.owned, &w.gamma, V(norm + ".weight"))); TS(tupload(e, t.owned, &w.beta, V(norm + ".bias")));
+        if (!b.gn) { TS(tupload(e, t.owned, &w.rmean, V(norm + ".running_mean"))); TS(tupload(e, t.owned, &w.rvar, V(norm + ".running_var"))); }
+        TS(grad(&w.g_w, a.size())); TS(grad(&w.g_b, b.cout)); TS(grad(&w.g_gamma, b.cout)); TS(grad(&w.g_beta, b.cout));
+        if (n.cfg.with_time_emb) {
+            TS(tupload(e, t.owned, &w.fw, V(pre + ".time_mlp.1.weight"))); TS(tupload(e, t.owned, &w.fb, V(pre + ".time_mlp.1.bias")));
+            TS(grad(&w.g_fw, (size_t)2 * b.cout * n.tdim)); TS(grad(&w.g_fb, (size_t)2 * b.cout));
+        }
+    }
+    if (n.cfg.with_time_emb) {
+        TS(tupload(e, t.owned, &t.t_w1, V("time_emb_mlp.1.weight"))); TS(tupload(e, t.owned, &t.t_b1, V("time_emb_mlp.1.bias")));
+        TS(tupload(e, t.owned, &t.t_w2, V("time_emb_mlp.3.weight"))); TS(tupload(e, t.owned, &t.t_b2, V("time_emb_mlp.3.bias")));
+        TS(grad(&t.g_t_w1, (size_t)n.tdim * n.dim)); TS(grad(&t.g_t_b1, n.tdim)); TS(grad(&t.g_t_w2, (size_t)n.tdim * n.tdim)); TS(grad(&t.g_t_b2, n.tdim));
+    }
+    {
+        const std::vector<float> sw = V("init_conv.weight");  // [dim][cin] (1x1)
+        std::vector<float> swt(sw.size());
+        for (int d = 0; d < n.dim; ++d)
+            for (int c = 0; c < n.cin_total; ++c) swt[(size_t)c * n.dim + d] = sw[(size_t)d * n.cin_total + c];
+        TS(tupload(e, t.owned, &t.stem_w, sw)); TS(tupload(e, t.owned, &t.stem_wt, swt)); TS(tupload(e, t.owned, &t.stem_b, V("init_conv.bias")));
+        TS(grad(&t.g_stem_w, sw.size())); TS(grad(&t.g_stem_b, n.dim));
+    }
+    {   // readout ConvTranspose2d(dim -> C, k4, s2, p1) as the dgrad form of a conv C: (C ch, 2h x 2w) -> (dim ch, h x w):
+        // Wc[co = dim][tap][ci = C] = W_T[co][ci][ky][kx]
+        const std::vector<float> rw = V("readout.0.weight");
+        const int oc = n.cfg.out_channels;
+        std::vector<float> a((size_t)n.dim * 16 * oc), at(a.size());
+        for (int co = 0; co < n.dim; ++co)
+            for (int ci = 0; ci < oc; ++ci)
+                for (int tp = 0; tp < 16; ++tp) {
+                    const float v = rw[((size_t)co * oc + ci) * 16 + tp];
+                    a[((size_t)co * 16 + tp) * oc + ci] = v;
+                    at[((size_t)tp * oc + ci) * n.dim + co] = v;
+                }
+        TS(tupload(e, t.owned, &t.ro_w, a)); TS(tupload(e, t.owned, &t.ro_wt, at)); TS(tupload(e, t.owned, &t.ro_b, V("readout.0.bias")));
+        TS(grad(&t.g_ro_w, a.size())); TS(grad(&t.g_ro_b, oc));
+    }
+#undef TS
+    t.ready = true;
+    return DYF_OK;
+}
+
+}  // namespace dyf
+
+extern "C" {
+
+dyf_status dyf_train_zero_grads(dyf_engine* e, int32_t which) {
+    if (!e || which < 0 || which > 1) return DYF_ERR_INVALID_ARGUMENT;
+    if (!e->train || !e->train->net[which].ready) return fail(e, DYF_ERR_STATE, "training needs arch unet_simple with loaded weights");
+    TK(hipSetDevice(e->cfg.device));
+    for (auto& g : e->train->net[which].grads) TK(hipMemsetAsync(g.first, 0, g.second * sizeof(float), 0));
+    TK(hipDeviceSynchronize());
+    return DYF_OK;
+}
+
+dyf_status dyf_train_forward(dyf_engine* e, int32_t which, int32_t slot, const float* inputs_dev, const float* time_dev,
+                             const float* cond_dev, float* out_dev, int32_t nb, int32_t flags, void* stream) {
+    if (!e || which < 0 || which > 1 || slot < 0 || slot > 3 || !inputs_dev || !out_dev || nb < 1)
+        return fail(e, DYF_ERR_INVALID_ARGUMENT, "dyf_train_forward: bad arguments");
+    if (!e->train || !e->train->net[which].ready) return fail(e, DYF_ERR_STATE, "training needs arch unet_simple with loaded weights");
+    Net& n = e->net[which];
+    TNet& w = e->train->net[which];
+    if ((n.cfg.cond_channels > 0) != (cond_dev != nullptr)) return fail(e, DYF_ERR_INVALID_ARGUMENT, "condition must be given iff num_conditional_channels > 0");
+    if (n.cfg.with_time_emb && !time_dev) return fail(e, DYF_ERR_INVALID_ARGUMENT, "time must be given when with_time_emb");
+    TK(hipSetDevice(e->cfg.device));
+    hipStream_t st = (hipStream_t)stream;
+    TTape& t = e->train->tape[slot];
+    TK(hipStreamSynchronize(st));
+    tfree(t.owned);
+    t = TTape{};
+    t.net = which; t.nb = nb; t.flags = flags;
+    const bool bn_batch = flags & DYF_TRAIN_BATCH_STATS, drop_on = (flags & DYF_TRAIN_DROPOUT) && n.cfg.dropout > 0.0f;
+    const int H = e->cfg.height, W = e->cfg.width, hw = H * W, cin = n.cin_total, C = n.cfg.out_channels;
+#define TS(expr) do { dyf_status _s = (expr); if (_s != DYF_OK) return _s; } while (0)
+#define TA(ptr, count) TS(talloc(e, t.owned, &(ptr), (size_t)(count), false))
+    if (drop_on) {  // this forward's dropout streams (engine generator, keyed per global row); kept for the backward
+        if (nb > 2 * e->cfg.max_batch) return fail(e, DYF_ERR_INVALID_ARGUMENT, "batch larger than the engine's row-key table");
+        TK(launch_rng_begin_forward(e->rng_state, e->row_keys, nb, nb, st));
+        TS(talloc(e, t.owned, &t.row_keys, (size_t)2 * nb, false));
+        TK(hipMemcpyAsync(t.row_keys, e->row_keys, (size_t)2 * nb * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+    }
+    // ---- time embedding chain: sinusoid -> Linear -> GELU -> Linear ; every block: SiLU -> Linear -> (scale | shift)
+    if (n.cfg.with_time_emb) {
+        TA(t.e0, nb * n.dim); TA(t.l1, nb * n.tdim); TA(t.gl, nb * n.tdim); TA(t.temb, nb * n.tdim);
+        hipLaunchKernelGGL(t_sinusoid, dim3(nblk(nb * n.dim)), dim3(256), 0, st, time_dev, nb, n.dim, t.e0);
+        hipLaunchKernelGGL(t_linear_fwd, dim3(nblk(nb * n.tdim)), dim3(256), 0, st, t.e0, w.t_w1, w.t_b1, nb, n.dim, n.tdim, 0, t.l1);
+        hipLaunchKernelGGL(t_gelu_fwd, dim3(nblk((long long)nb * n.tdim)), dim3(256), 0, st, t.l1, (long long)nb * n.tdim, t.gl);
+        hipLaunchKernelGGL(t_linear_fwd, dim3(nblk(nb * n.tdim)), dim3(256), 0, st, t.gl, w.t_w2, w.t_b2, nb, n.tdim, n.tdim, 0, t.temb);
+    }
+    // ---- stem: cat -> outer resample -> 1x1 conv
+    TA(t.x_in, (size_t)nb * hw * cin);
+    hipLaunchKernelGGL(t_nchw_cat_to_nhwc, dim3(nblk((long long)nb * hw * cin)), dim3(256), 0, st, inputs_dev, n.cfg.in_channels, cond_dev,
+                       n.cfg.cond_channels, (const float*)nullptr, 0, nb, hw, t.x_in);
+    if (n.uh != H || n.uw != W) {
+        TA(t.x_up, (size_t)nb * n.uh * n.uw * cin);
+        hipLaunchKernelGGL(t_resize_fwd, dim3(nblk((long long)nb * n.uh * n.uw * cin)), dim3(256), 0, st, t.x_in, nb, H, W, cin, n.uh, n.uw, t.x_up);
+    } else {
+        t.x_up = t.x_in;
+    }
+    TA(t.s0, (size_t)nb * n.uh * n.uw * n.dim);
+    TS(conv_fwd(e, TConv{nb, n.uh, n.uw, cin, n.uh, n.uw, n.dim, 1, 1, 0}, t.x_up, w.stem_wt, w.stem_b, t.s0, st));
+    double *S = nullptr, *Q = nullptr;
+    TS(talloc(e, t.owned, &S, (size_t)nb * 1024 * 2));
+    Q = S + (size_t)nb * 1024;
+    // ---- the 12 blocks
+    const float* x = t.s0;
+    int lh = n.uh, lw = n.uw;
+    for (int i = 0; i < 12; ++i) {
+        const UBlock& b = n.blk[i];
+        if (b.cout > 1024) return fail(e, DYF_ERR_UNSUPPORTED, "training path: more than 1024 channels per block");
+        const float* cx = x;
+        if (b.transposed) {  // x2 bilinear upsample in front of the conv
+            float* u = nullptr;
+            TA(u, (size_t)nb * b.in_h * b.in_w * b.cin);
+            hipLaunchKernelGGL(t_resize_fwd, dim3(nblk((long long)nb * b.in_h * b.in_w * b.cin)), dim3(256), 0, st, x, nb, lh, lw, b.cin, b.in_h, b.in_w, u);
+            cx = u;
+        }
+        t.cin_ptr[i] = (float*)cx;
+        const long long out_el = (long long)nb * b.out_h * b.out_w * b.cout;
+        TA(t.z[i], out_el); TA(t.y[i], out_el);
+        TS(conv_fwd(e, block_geom(b, nb), cx, w.blk[i].wt, w.blk[i].b, t.z[i], st));
+        const int ohw = b.out_h * b.out_w, nidx = b.gn ? nb * 8 : b.cout;
+        TA(t.mean[i], nidx); TA(t.rstd[i], nidx);
+        const int kind = b.gn ? 2 : (bn_batch ? 0 : 1);
+        if (kind != 1) {
+            TK(hipMemsetAsync(S, 0, (size_t)nb * 1024 * 2 * sizeof(double), st));
+            const int ppb = std::max(1, (ohw + 63) / 64);
+            hipLaunchKernelGGL(t_nc_sums, dim3((ohw + ppb - 1) / ppb, nb), dim3(256), 0, st, t.z[i], ohw, b.cout, ppb, S, Q);
+        }
+        hipLaunchKernelGGL(t_stats_finalize, dim3(nblk(std::max(nidx, b.cout))), dim3(256), 0, st, kind, S, Q, nb, ohw, b.cout, 8, w.blk[i].rmean,
+                           w.blk[i].rvar, t.mean[i], t.rstd[i]);
+        if (n.cfg.with_time_emb) {
+            TA(t.ss[i], (size_t)nb * 2 * b.cout);
+            hipLaunchKernelGGL(t_linear_fwd, dim3(nblk(nb * 2 * b.cout)), dim3(256), 0, st, t.temb, w.blk[i].fw, w.blk[i].fb, nb, n.tdim, 2 * b.cout, 1, t.ss[i]);
+        }
+        TNorm a{nb, ohw, b.cout, 8, b.gn ? 1 : 0, b.act, t.mean[i], t.rstd[i], w.blk[i].gamma, w.blk[i].beta, t.ss[i], drop_on ? 1 : 0,
+                1.0f / (1.0f - n.cfg.dropout), keep_threshold16(n.cfg.dropout), rng_layer_salt((uint32_t)i), t.row_keys};
+        hipLaunchKernelGGL(t_norm_fwd, dim3(nblk(out_el)), dim3(256), 0, st, a, t.z[i], t.y[i]);
+        TK(hipGetLastError());
+        x = t.y[i];
+        lh = b.out_h; lw = b.out_w;
+        if (i >= 6 && i < 11) {  // torch.cat([x, skip]) (unet_simple.py:176-177)
+            const UBlock& sk = n.blk[10 - i];
+            float* cat = nullptr;
+            TA(cat, (size_t)nb * lh * lw * (b.cout + sk.cout));
+            hipLaunchKernelGGL(t_concat2, dim3(nblk((long long)nb * lh * lw * (b.cout + sk.cout))), dim3(256), 0, st, t.y[i], b.cout, t.y[10 - i], sk.cout,
+                               (long long)nb * lh * lw, cat);
+            x = cat;
+        }
+    }
+    t.xlast = (float*)x;
+    // ---- readout: ConvTranspose2d (dgrad form of conv C) + final resample
+    float *r = nullptr, *o = nullptr;
+    TA(r, (size_t)nb * 4 * lh * lw * C);
+    TS(conv_dgrad(e, TConv{nb, 2 * lh, 2 * lw, C, lh, lw, n.dim, 4, 2, 1}, x, w.ro_w, w.ro_b, r, st));
+    TA(o, (size_t)nb * hw * C);
+    hipLaunchKernelGGL(t_resize_fwd, dim3(nblk((long long)nb * hw * C)), dim3(256), 0, st, r, nb, 2 * lh, 2 * lw, C, H, W, o);
+    hipLaunchKernelGGL(t_nhwc_to_nchw, dim3(nblk((long long)nb * hw * C)), dim3(256), 0, st, o, nb, hw, C, 0, C, out_dev);
+    TK(hipGetLastError());
+#undef TA
+#undef TS
+    return DYF_OK;
+}
+
+dyf_status dyf_train_backward(dyf_engine* e, int32_t slot, const float* dout_dev, float* dinputs_dev, int32_t param_grads, void* stream) {
+    if (!e || slot < 0 || slot > 3 || !dout_dev) return fail(e, DYF_ERR_INVALID_ARGUMENT, "dyf_train_backward: bad arguments");
+    if (!e->train || e->train->tape[slot].net < 0) return fail(e, DYF_ERR_STATE, "no forward recorded in this tape slot");
+    TK(hipSetDevice(e->cfg.device));
+    hipStream_t st = (hipStream_t)stream;
+    TTape& t = e->train->tape[slot];
+    Net& n = e->net[t.net];
+    TNet& w = e->train->net[t.net];
+    const int nb = t.nb, H = e->cfg.height, W = e->cfg.width, hw = H * W, cin = n.cin_total, C = n.cfg.out_channels;
+    const bool bn_batch = t.flags & DYF_TRAIN_BATCH_STATS, drop_on = (t.flags & DYF_TRAIN_DROPOUT) && n.cfg.dropout > 0.0f;
+    std::vector<void*> tmp;
+#define TS(expr) do { dyf_status _s = (expr); if (_s != DYF_OK) { tfree(tmp); return _s; } } while (0)
+#define TA(ptr, count) TS(talloc(e, tmp, &(ptr), (size_t)(count), false))
+#define TZ(ptr, count) TS(talloc(e, tmp, &(ptr), (size_t)(count), true))
+    const int lh = n.blk[11].out_h, lw = n.blk[11].out_w;
+    // ---- final resample adjoint, readout
+    float *d_o = nullptr, *d_r = nullptr, *dx = nullptr;
+    TA(d_o, (size_t)nb * hw * C);
+    hipLaunchKernelGGL(t_nchw_to_nhwc, dim3(nblk((long long)nb * hw * C)), dim3(256), 0, st, dout_dev, nb, hw, C, d_o);
+    TZ(d_r, (size_t)nb * 4 * lh * lw * C);
+    hipLaunchKernelGGL(t_resize_bwd, dim3(nblk((long long)nb * hw * C)), dim3(256), 0, st, d_o, nb, 2 * lh, 2 * lw, C, H, W, d_r);
+    const TConv gc{nb, 2 * lh, 2 * lw, C, lh, lw, n.dim, 4, 2, 1};
+    if (param_grads) {
+        TS(conv_wgrad(e, gc, t.xlast, d_r, w.g_ro_w, nullptr, st));
+        hipLaunchKernelGGL(t_bias_grad, dim3(C), dim3(256), 0, st, d_r, (long long)nb * 4 * lh * lw, C, w.g_ro_b);
+    }
+    TA(dx, (size_t)nb * lh * lw * n.dim);
+    TS(conv_fwd(e, gc, d_r, w.ro_wt, nullptr, dx, st));
+    // ---- blocks, last to first
+    float* dskip[5] = {};
+    for (int j = 0; j < 5; ++j) TZ(dskip[j], (size_t)nb * n.blk[j].out_h * n.blk[j].out_w * n.blk[j].cout);
+    float* dsilu = nullptr;
+    if (n.cfg.with_time_emb) TZ(dsilu, (size_t)nb * n.tdim);
+    double* R = nullptr;
+    TS(talloc(e, tmp, &R, (size_t)nb * 1024 * 4));
+    float *S1 = nullptr, *S2 = nullptr, *dss = nullptr;
+    TA(S1, std::max(1024, nb * 8)); TA(S2, std::max(1024, nb * 8)); TA(dss, (size_t)nb * 2 * 1024);
+    float* dy = dx;  // gradient w.r.t. the output of block i (for i < 11: the y part of the concat)
+    for (int i = 11; i >= 0; --i) {
+        const UBlock& b = n.blk[i];
+        const int ohw = b.out_h * b.out_w;
+        const long long out_el = (long long)nb * ohw * b.cout;
+        if (i >= 6 && i < 11) {  // dy currently holds d cat[y_i, skip]: split
+            const UBlock& sk = n.blk[10 - i];
+            float* dyi = nullptr;
+            TA(dyi, out_el);
+            hipLaunchKernelGGL(t_split2, dim3(nblk((long long)nb * ohw * (b.cout + sk.cout))), dim3(256), 0, st, dy, b.cout, sk.cout, (long long)nb * ohw, dyi,
+                               dskip[10 - i]);
+            dy = dyi;
+        } else if (i < 5) {  // encoder outputs also feed the decoder through the skips
+            hipLaunchKernelGGL(t_add, dim3(nblk(out_el)), dim3(256), 0, st, dy, dskip[i], out_el);
+        }
+        TNorm a{nb, ohw, b.cout, 8, b.gn ? 1 : 0, b.act, t.mean[i], t.rstd[i], w.blk[i].gamma, w.blk[i].beta, t.ss[i], drop_on ? 1 : 0,
+                1.0f / (1.0f - n.cfg.dropout), keep_threshold16(n.cfg.dropout), rng_layer_salt((uint32_t)i), t.row_keys};
+        TK(hipMemsetAsync(R, 0, (size_t)nb * 1024 * 4 * sizeof(double), st));
+        double *A = R, *B = R + (size_t)nb * 1024, *Cc = R + (size_t)2 * nb * 1024, *Dd = R + (size_t)3 * nb * 1024;
+        const int ppb = std::max(1, (ohw + 63) / 64);
+        hipLaunchKernelGGL(t_norm_bwd_sums, dim3((ohw + ppb - 1) / ppb, nb), dim3(256), 0, st, a, t.z[i], dy, ppb, A, B, Cc, Dd);
+        const bool batch_stats = b.gn || bn_batch;
+        hipLaunchKernelGGL(t_norm_bwd_combine, dim3(nblk(std::max(nb * b.cout, nb * 8))), dim3(256), 0, st, a, A, B, Cc, Dd,
+                           param_grads ? w.blk[i].g_gamma : (float*)nullptr, param_grads ? w.blk[i].g_beta : (float*)nullptr,
+                           n.cfg.with_time_emb ? dss : (float*)nullptr, S1, S2, batch_stats ? 1 : 0);
+        float* dz = nullptr;
+        TA(dz, out_el);
+        const float inv_count = b.gn ? 1.0f / ((float)ohw * (b.cout / 8)) : 1.0f / ((float)nb * ohw);
+        hipLaunchKernelGGL(t_norm_bwd_apply, dim3(nblk(out_el)), dim3(256), 0, st, a, t.z[i], dy, S1, S2, inv_count, dz);
+        if (n.cfg.with_time_emb) {  // FiLM head: ss = W silu(temb) + b
+            if (param_grads)
+                hipLaunchKernelGGL(t_linear_bwd_w, dim3(nblk(2 * b.cout * n.tdim)), dim3(256), 0, st, t.temb, dss, nb, n.tdim, 2 * b.cout, 1, w.blk[i].g_fw,
+                                   w.blk[i].g_fb);
+            // d silu(temb) accumulated over the blocks (the SiLU derivative is applied once below)
+            hipLaunchKernelGGL(t_linear_bwd_x, dim3(nblk(nb * n.tdim)), dim3(256), 0, st, t.temb, w.blk[i].fw, dss, nb, n.tdim, 2 * b.cout, 0, 1, dsilu);
+        }
+        const TConv g = block_geom(b, nb);
+        if (param_grads) TS(conv_wgrad(e, g, dz, t.cin_ptr[i], w.blk[i].g_w, w.blk[i].g_b, st));
+        float* dcx = nullptr;  // gradient w.r.t. the conv input (block 0's feeds the stem's 1x1 conv)
+        TA(dcx, (size_t)nb * b.in_h * b.in_w * b.cin);
+        TS(conv_dgrad(e, g, dz, w.blk[i].w, nullptr, dcx, st));
+        if (b.transposed) {  // adjoint of the x2 upsample
+            const int ph = b.in_h / 2, pw = b.in_w / 2;
+            float* dlow = nullptr;
+            TZ(dlow, (size_t)nb * ph * pw * b.cin);
+            hipLaunchKernelGGL(t_resize_bwd, dim3(nblk((long long)nb * b.in_h * b.in_w * b.cin)), dim3(256), 0, st, dcx, nb, ph, pw, b.cin, b.in_h, b.in_w, dlow);
+            dcx = dlow;
+        }
+        dy = dcx;  // gradient w.r.t. the previous tensor (block i-1's output, a concat for i in 7..11, the stem for i == 0)
+        TK(hipGetLastError());
+    }
+    // ---- stem
+    const TConv gs{nb, n.uh, n.uw, cin, n.uh, n.uw, n.dim, 1, 1, 0};
+    if (param_grads) TS(conv_wgrad(e, gs, dy, t.x_up, w.g_stem_w, w.g_stem_b, st));
+    if (dinputs_dev) {
+        float* dxu = nullptr;
+        TA(dxu, (size_t)nb * n.uh * n.uw * cin);
+        TS(conv_dgrad(e, gs, dy, w.stem_w, nullptr, dxu, st));
+        float* dxi = dxu;
+        if (t.x_up != t.x_in) {
+            TZ(dxi, (size_t)nb * hw * cin);
+            hipLaunchKernelGGL(t_resize_bwd, dim3(nblk((long long)nb * n.uh * n.uw * cin)), dim3(256), 0, st, dxu, nb, H, W, cin, n.uh, n.uw, dxi);
+        }
+        hipLaunchKernelGGL(t_nhwc_to_nchw, dim3(nblk((long long)nb * hw * n.cfg.in_channels)), dim3(256), 0, st, dxi, nb, hw, cin, 0, n.cfg.in_channels, dinputs_dev);
+    }
+    // ---- time MLP: dsilu = sum over blocks of dss . W_film ; temb -> SiLU is shared by all blocks
+    if (n.cfg.with_time_emb && param_grads) {
+        float *dtemb = nullptr, *dgl = nullptr;
+        TA(dtemb, (size_t)nb * n.tdim); TA(dgl, (size_t)nb * n.tdim);
+        hipLaunchKernelGGL(t_silu_bwd, dim3(nblk((long long)nb * n.tdim)), dim3(256), 0, st, t.temb, dsilu, (long long)nb * n.tdim, dtemb);
+        hipLaunchKernelGGL(t_linear_bwd_w, dim3(nblk(n.tdim * n.tdim)), dim3(256), 0, st, t.gl, dtemb, nb, n.tdim, n.tdim, 0, w.g_t_w2, w.g_t_b2);
+        hipLaunchKernelGGL(t_linear_bwd_x, dim3(nblk(nb * n.tdim)), dim3(256), 0, st, t.gl, w.t_w2, dtemb, nb, n.tdim, n.tdim, 0, 0, dgl);
+        hipLaunchKernelGGL(t_gelu_bwd, dim3(nblk((long long)nb * n.tdim)), dim3(256), 0, st, t.l1, (long long)nb * n.tdim, dgl);
+        hipLaunchKernelGGL(t_linear_bwd_w, dim3(nblk(n.tdim * n.dim)), dim3(256), 0, st, t.e0, dgl, nb, n.dim, n.tdim, 0, w.g_t_w1, w.g_t_b1);
+        TK(hipGetLastError());
+    }
+    TK(hipStreamSynchronize(st));
+    tfree(tmp);
+#undef TA
+#undef TZ
+#undef TS
+    return DYF_OK;
+}
+
+// Copy gradients (and the updated BatchNorm running statistics) out, addressed by the reference's state_dict names, in
+// PyTorch's layouts: conv weights (cout, cin, kh, kw), ConvTranspose2d (cin, cout, kh, kw), Linear (out, in).
+dyf_status dyf_train_export(dyf_engine* e, int32_t which, int32_t n_tensors, const char* const* names, float* const* out_host) {
+    if (!e || which < 0 || which > 1 || !names || !out_host) return fail(e, DYF_ERR_INVALID_ARGUMENT, "dyf_train_export: bad arguments");
+    if (!e->train || !e->train->net[which].ready) return fail(e, DYF_ERR_STATE, "training needs arch unet_simple with loaded weights");
+    TK(hipSetDevice(e->cfg.device));
+    TK(hipDeviceSynchronize());
+    const Net& n = e->net[which];
+    const TNet& w = e->train->net[which];
+    auto pull = [&](const float* dev, size_t cnt) {
+        std::vector<float> h(cnt);
+        (void)hipMemcpy(h.data(), dev, cnt * sizeof(float), hipMemcpyDeviceToHost);
+        return h;
+    };
+    for (int q = 0; q < n_tensors; ++q) {
+        const std::string name = names[q];
+        float* out = out_host[q];
+        bool done = false;
+        auto flat = [&](const std::string& key, const float* dev, size_t cnt) {
+            if (!done && name == key && dev) {
+                const std::vector<float> h = pull(dev, cnt);
+                std::copy(h.begin(), h.end(), out);
+                done = true;
+            }
+        };
+        for (int i = 0; i < 12 && !done; ++i) {
+            const UBlock& b = n.blk[i];
+            const TBlockW& bw = w.blk[i];
+            const std::string pre = (i < 6 ? "input_ops." + std::to_string(i) : "output_ops." + std::to_string(i - 6));
+            const std::string conv = pre + ".ops." + (b.transposed ? "1" : "0"), norm = pre + ".ops." + (b.transposed ? "2" : "1");
+            if (name == conv + ".weight") {  // [co][tap][ci] -> (co, ci, kh, kw)
+                const int taps = b.k * b.k;
+                const std::vector<float> h = pull(bw.g_w, (size_t)b.cout * taps * b.cin);
+                for (int co = 0; co < b.cout; ++co)
+                    for (int ci = 0; ci < b.cin; ++ci)
+                        for (int tp = 0; tp < taps; ++tp) out[((size_t)co * b.cin + ci) * taps + tp] = h[((size_t)co * taps + tp) * b.cin + ci];
+                done = true;
+            }
+            flat(conv + ".bias", bw.g_b, b.cout);
+            flat(norm + ".weight", bw.g_gamma, b.cout);
+            flat(norm + ".bias", bw.g_beta, b.cout);
+            flat(norm + ".running_mean", bw.rmean, b.cout);
+            flat(norm + ".running_var", bw.rvar, b.cout);
+            flat(pre + ".time_mlp.1.weight", bw.g_fw, (size_t)2 * b.cout * n.tdim);
+            flat(pre + ".time_mlp.1.bias", bw.g_fb, (size_t)2 * b.cout);
+        }
+        flat("time_emb_mlp.1.weight", w.g_t_w1, (size_t)n.tdim * n.dim);
+        flat("time_emb_mlp.1.bias", w.g_t_b1, n.tdim);
+        flat("time_emb_mlp.3.weight", w.g_t_w2, (size_t)n.tdim * n.tdim);
+        flat("time_emb_mlp.3.bias", w.g_t_b2, n.tdim);
+        flat("init_conv.weight", w.g_stem_w, (size_t)n.dim * n.cin_total);
+        flat("init_conv.bias", w.g_stem_b, n.dim);
+        flat("readout.0.bias", w.g_ro_b, n.cfg.out_channels);
+        if (!done && name == "readout.0.weight") {  // [co = dim][tap][ci = C] -> ConvTranspose2d (dim, C, 4, 4)
+            const int oc = n.cfg.out_channels;
+            const std::vector<float> h = pull(w.g_ro_w, (size_t)n.dim * 16 * oc);
+            for (int co = 0; co < n.dim; ++co)
+                for (int ci = 0; ci < oc; ++ci)
+                    for (int tp = 0; tp < 16; ++tp) out[((size_t)co * oc + ci) * 16 + tp] = h[((size_t)co * 16 + tp) * oc + ci];
+            done = true;
+        }
+        if (!done) return fail(e, DYF_ERR_INVALID_ARGUMENT, "dyf_train_export: unknown tensor '" + name + "'");
+    }
+    return DYF_OK;
+}
+
+// d(scale * mean-criterion(pred, target)) / d pred  (get_loss, src/utilities/utils.py:201-212; kinds as dyf_criterion)
+dyf_status dyf_criterion_grad(dyf_engine* e, const float* pred_dev, const float* target_dev, int64_t count, int32_t kind, float scale,
+                              float* dpred_dev, void* stream) {
+    if (!e || !pred_dev || !target_dev || !dpred_dev || count < 1 || kind < 0 || kind > 2)
+        return fail(e, DYF_ERR_INVALID_ARGUMENT, "dyf_criterion_grad: bad arguments");
+    TK(hipSetDevice(e->cfg.device));
+    hipLaunchKernelGGL(t_criterion_grad, dim3(nblk(count)), dim3(256), 0, (hipStream_t)stream, pred_dev, target_dev, (long long)count, kind, scale, dpred_dev);
+    TK(hipGetLastError());
+    return DYF_OK;
+}
+
+}  // extern "C"

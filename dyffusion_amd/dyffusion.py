@@ -317,12 +317,13 @@ class DYffusion(nn.Module):
                                dropout_mode=1 if (self.enable_forecaster_dropout and getattr(self.model, 'has_dropout', True)) else 0)
 
     def p_losses(self, xt_last: Tensor, condition: Tensor, t: Tensor, static_condition: Optional[Tensor] = None):
-        """dyffusion.py:496-567, forward only: the forecaster objective as the reference evaluates it in validation (eval-mode
-        normalisation; the interpolator keeps MC dropout when `enable_interpolator_dropout`).  Returns the reference's loss
-        dict with the "val/" prefix; values are python floats (reduced on the GPU by `dyf_criterion`).  The training step
-        (autograd through both networks, batch-statistics BatchNorm) is not part of this engine."""
+        """dyffusion.py:496-567.  Eval mode (`self.training` false): the forecaster objective as the reference evaluates it in
+        validation (eval-mode normalisation; the interpolator keeps MC dropout when `enable_interpolator_dropout`), on the
+        sampling kernels; returns the reference's loss dict with the "val/" prefix, values are python floats (reduced on the
+        GPU by `dyf_criterion`).  Training mode: see `_p_losses_train` (forward with batch-statistics BatchNorm and the backward
+        pass on the engine; `out["loss"].backward()` fills the forecaster's `.grad`s)."""
         if self.training:
-            raise NotImplementedError("p_losses in training mode needs the backward pass; only the eval-mode objective is implemented")
+            return self._p_losses_train(xt_last, condition, t, static_condition)
         lam1, lam2 = self.hparams.lambda_reconstruction, self.hparams.lambda_reconstruction2
         kind = self.hparams.loss_function
 
@@ -348,5 +349,125 @@ class DYffusion(nn.Module):
         return {"loss": lam1 * loss_forward + lam2 * loss_forward2, "val/loss_forward": loss_forward,
                 "val/loss_forward2": loss_forward2}
 
+    # ------------------------------------------------------------------ training step
+    def train(self, mode: bool = True):
+        super().train(mode)
+        self.model.eval()  # the parameter containers never run torch ops; the engine is told the mode per call
+        return self
+
+    def _sync_engine_weights(self, eng: HipEngine):
+        """Re-upload a network whose parameters were modified in place since the last upload (optimizer.step())."""
+        for net, slot in ((self.model, L.NET_FORECASTER), (self._ipol_net, L.NET_INTERPOLATOR)):
+            ver = sum(int(p._version) for p in net.state_dict().values())
+            if getattr(net, "_uploaded_version", None) != (id(eng), ver):
+                if getattr(net, "_uploaded_version", None) is not None or net._engine is not eng:
+                    eng.load_weights(slot, net.state_dict())
+                net._uploaded_version = (id(eng), sum(int(p._version) for p in net.state_dict().values()))
+
+    def _p_losses_train(self, xt_last: Tensor, condition: Tensor, t: Tensor, static_condition: Optional[Tensor] = None):
+        """`p_losses` with `self.training` (dyffusion.py:496-567 under torch.autograd in the reference).  The forecaster runs in
+        train mode (batch-statistics BatchNorm with running-statistics update, Dropout active), the frozen interpolator in
+        eval mode with its Dropout active (:154-160: `self.training or enable_interpolator_dropout`); both loss terms; the
+        second term is differentiated THROUGH the interpolator.  Returns the reference's dict ("train/" prefix); `out["loss"]`
+        is a scalar tensor whose `.backward()` runs the engine's backward pass and ACCUMULATES into `param.grad` of the
+        forecaster's parameters (so `torch.optim` / Lightning's `training_step` work unchanged).  arch unet_simple, fp32."""
+        lam1, lam2 = self.hparams.lambda_reconstruction, self.hparams.lambda_reconstruction2
+        kind = self.hparams.loss_function
+        eng = self._ensure_engine(xt_last.shape[-2:], xt_last.shape[0])
+        self._sync_engine_weights(eng)
+        ipol_drop = bool(getattr(self._ipol_net, "has_dropout", True))
+        f_drop = bool(getattr(self.model, "has_dropout", True))
+        T = self.num_timesteps
+
+        def sub(x, m):
+            return None if x is None else x[m].contiguous()
+
+        def f_inputs(cond_data, tt, sc):  # predict_x_last (dyffusion.py:205-239): conditioning + time encoding
+            fc = self.hparams.forward_conditioning
+            if fc == "data":
+                cond = cond_data
+            elif fc == "none":
+                cond = None
+            else:
+                tf = (tt / (T - 1)).view(cond_data.shape[0], *[1] * (cond_data.ndim - 1))
+                cond = tf * cond_data + (1 - tf) * torch.randn_like(cond_data)
+            if sc is not None:
+                cond = sc if cond is None else torch.cat([cond, sc], dim=1)
+            enc = self.hparams.time_encoding
+            time = tt.float() if enc == "discrete" else tt / T if enc == "normalized" else self.diffusion_step_to_interpolation_step(tt)
+            return time.float(), cond
+
+        x_t = condition.clone()
+        nz = t > 0
+        if bool(nz.any()):
+            it = self.diffusion_step_to_interpolation_step(t[nz]).float()
+            x_t[nz] = eng.train_forward(L.NET_INTERPOLATOR, 0, torch.cat([condition[nz], xt_last[nz]], 1), it, sub(static_condition, nz),
+                                        batch_stats=False, dropout=ipol_drop)
+        time1, cond1 = f_inputs(condition, t, static_condition)
+        pred = eng.train_forward(L.NET_FORECASTER, 1, x_t, time1, cond1, batch_stats=True, dropout=f_drop)
+        loss_forward = eng.criterion(pred, xt_last, kind)
+        not_last = t <= T - 2
+        state = dict(eng=eng, pred=pred, target=xt_last, kind=kind, lam1=lam1, lam2=lam2, not_last=None, n_fwd=1)
+        loss_forward2 = 0.0
+        if lam2 > 0 and bool(not_last.any()):
+            t2 = t[not_last] + 1
+            sc2 = sub(static_condition, not_last)
+            cond_nl = condition[not_last].contiguous()
+            it2 = self.diffusion_step_to_interpolation_step(t2).float()
+            x_i2 = eng.train_forward(L.NET_INTERPOLATOR, 2, torch.cat([cond_nl, pred[not_last]], 1), it2, sc2, batch_stats=False,
+                                     dropout=ipol_drop)
+            time2, cond2 = f_inputs(cond_nl, t2, sc2)
+            pred2 = eng.train_forward(L.NET_FORECASTER, 3, x_i2, time2, cond2, batch_stats=True, dropout=f_drop)
+            target2 = xt_last[not_last].contiguous()
+            loss_forward2 = eng.criterion(pred2, target2, kind)
+            state.update(not_last=not_last, pred2=pred2, target2=target2, n_fwd=2)
+        total = lam1 * loss_forward + lam2 * loss_forward2
+        self._train_state = state
+        if not hasattr(self, "_grad_anchor"):
+            self._grad_anchor = torch.zeros((), requires_grad=True)
+        loss = _EngineLoss.apply(self._grad_anchor, self, float(total))
+        return {"loss": loss, "train/loss_forward": loss_forward, "train/loss_forward2": loss_forward2}
+
+    def _train_backward(self, upstream: float):
+        st = self._train_state
+        eng, C = st["eng"], self.num_input_channels
+        d_pred = eng.criterion_grad(st["pred"], st["target"], st["kind"], st["lam1"] * upstream)
+        if st["not_last"] is not None:
+            d_pred2 = eng.criterion_grad(st["pred2"], st["target2"], st["kind"], st["lam2"] * upstream)
+            d_xi2 = eng.train_backward(3, d_pred2, want_dinputs=True, param_grads=True)    # second forecaster pass
+            d_ipol = eng.train_backward(2, d_xi2, want_dinputs=True, param_grads=False)    # through the frozen interpolator
+            d_pred[st["not_last"]] += d_ipol[:, -C:]                                        # inputs = cat[x_0 window, x_last = pred]
+        eng.train_backward(1, d_pred, want_dinputs=False, param_grads=True)
+        sd = self.model.state_dict(keep_vars=True)
+        shapes = {k: tuple(v.shape) for k, v in sd.items() if isinstance(v, nn.Parameter)}
+        grads = eng.train_export(L.NET_FORECASTER, shapes)
+        for k, g in grads.items():
+            p = sd[k]
+            p.grad = g.to(p.device) if p.grad is None else p.grad + g.to(p.device)
+        eng.train_zero_grads(L.NET_FORECASTER)
+        # BatchNorm buffers as module.train() leaves them (running statistics, num_batches_tracked)
+        bufs = {k: tuple(v.shape) for k, v in sd.items() if k.endswith("running_mean") or k.endswith("running_var")}
+        with torch.no_grad():
+            for k, v in eng.train_export(L.NET_FORECASTER, bufs).items():
+                sd[k].copy_(v)
+            for k, v in sd.items():
+                if k.endswith("num_batches_tracked"):
+                    v += st["n_fwd"]
+        self.model._uploaded_version = (id(eng), sum(int(p._version) for p in self.model.state_dict().values()))
+
     def forward(self, *args, **kwargs):
         return self.p_losses(*args, **kwargs)
+
+
+class _EngineLoss(torch.autograd.Function):
+    """Scalar loss whose backward is the engine's backward pass (dyf_train_backward)."""
+
+    @staticmethod
+    def forward(ctx, anchor, owner, value):
+        ctx.owner = owner
+        return anchor.new_tensor(value)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        ctx.owner._train_backward(float(grad_out))
+        return None, None, None

@@ -76,6 +76,7 @@ class HipEngine:
         self._h = h
         self._plan_keepalive = None
         self.n_out_slots = 0
+        self._tape_net = {}       # tape slot -> network of the recorded training forward
         self.plan_valid = False   # cleared by load_weights: the plan's FiLM tables are functions of the weights
         self.weights_version = 0
 
@@ -301,6 +302,61 @@ class HipEngine:
         self._check(self._lib.dyf_criterion(self._h, pred.data_ptr(), target.data_ptr(), pred.numel(), code, C.byref(out),
                                             self._stream()))
         return out.value
+
+    # ------------------------------------------------------------------ training step (arch unet_simple, fp32)
+    def train_forward(self, net: int, slot: int, inputs: torch.Tensor, time: Optional[torch.Tensor],
+                      condition: Optional[torch.Tensor], batch_stats: bool, dropout: bool) -> torch.Tensor:
+        """One RECORDED forward (tape `slot`, 0..3): batch-statistics BatchNorm iff `batch_stats`, Dropout iff `dropout`."""
+        inputs = _f32c(inputs, "inputs")
+        nb = inputs.shape[0]
+        ncfg = self.cfg.net[net]
+        if inputs.dim() != 4 or inputs.shape[1] != ncfg.in_channels or tuple(inputs.shape[2:]) != (self.height, self.width):
+            raise ValueError(f"inputs must be (NB, {ncfg.in_channels}, {self.height}, {self.width}), got {tuple(inputs.shape)}")
+        if condition is not None:
+            condition = _f32c(condition, "condition")
+            if tuple(condition.shape) != (nb, ncfg.cond_channels, self.height, self.width):
+                raise ValueError(f"condition has shape {tuple(condition.shape)}")
+        if time is not None:
+            time = _f32c(time.reshape(-1), "time")
+        out = torch.empty((nb, ncfg.out_channels, self.height, self.width), dtype=torch.float32, device=inputs.device)
+        flags = (L.TRAIN_BATCH_STATS if batch_stats else 0) | (L.TRAIN_DROPOUT if dropout else 0)
+        self._tape_net[slot] = net
+        self._check(self._lib.dyf_train_forward(self._h, net, slot, inputs.data_ptr(), None if time is None else time.data_ptr(),
+                                                None if condition is None else condition.data_ptr(), out.data_ptr(), nb, flags,
+                                                self._stream()))
+        return out
+
+    def train_backward(self, slot: int, dout: torch.Tensor, want_dinputs: bool, param_grads: bool) -> Optional[torch.Tensor]:
+        dout = _f32c(dout, "dout")
+        din = None
+        if want_dinputs:
+            net = self._tape_net[slot]
+            din = torch.empty((dout.shape[0], self.cfg.net[net].in_channels, self.height, self.width), dtype=torch.float32,
+                              device=dout.device)
+        self._check(self._lib.dyf_train_backward(self._h, slot, dout.data_ptr(), None if din is None else din.data_ptr(),
+                                                 int(param_grads), self._stream()))
+        return din
+
+    def train_zero_grads(self, net: int):
+        self._check(self._lib.dyf_train_zero_grads(self._h, net))
+
+    def train_export(self, net: int, names_shapes: Dict[str, tuple]) -> Dict[str, torch.Tensor]:
+        """Gradients (or updated BatchNorm running statistics) by state_dict name -> CPU fp32 tensors."""
+        names = list(names_shapes)
+        bufs = [np.empty(names_shapes[k], dtype=np.float32) for k in names]
+        cn = (C.c_char_p * len(names))(*[k.encode() for k in names])
+        cp = (C.c_void_p * len(names))(*[b.ctypes.data for b in bufs])
+        self._check(self._lib.dyf_train_export(self._h, net, len(names), cn, cp))
+        return {k: torch.from_numpy(b) for k, b in zip(names, bufs)}
+
+    def criterion_grad(self, pred: torch.Tensor, target: torch.Tensor, kind: str, scale: float) -> torch.Tensor:
+        name = kind.lower().strip().replace("-", "_")
+        code = 0 if name in ("l1", "mae", "mean_absolute_error") else 1 if name in ("l2", "mse", "mean_squared_error") else 2
+        pred, target = _f32c(pred, "pred"), _f32c(target, "target")
+        d = torch.empty_like(pred)
+        self._check(self._lib.dyf_criterion_grad(self._h, pred.data_ptr(), target.data_ptr(), pred.numel(), code, float(scale),
+                                                 d.data_ptr(), self._stream()))
+        return d
 
     def op_linear_attention(self, qkv_bf16: torch.Tensor) -> torch.Tensor:
         """Test seam: LinearAttention core.  qkv (N,HW,384) bf16 (to_qkv output, 4 heads x 32) -> (N,HW,128) bf16."""

@@ -168,6 +168,28 @@ dyf_status dyf_ensemble_metrics(dyf_engine* engine, const float* preds_dev, cons
 typedef enum dyf_sampler_state { DYF_STATE_X0_HAT = 0, DYF_STATE_X_S = 1, DYF_STATE_X_NEXT = 2 } dyf_sampler_state;
 dyf_status dyf_get_sampler_state(dyf_engine* engine, int32_t what, float* out_dev, int32_t nb, void* stream);
 
+/* ---- training step: DYffusion.p_losses in training mode (dyffusion.py:496-567; arch unet_simple) ---------------------------- */
+/* What the reference gets from torch.autograd over unet_simple.py.  A forward is RECORDED in one of four tape slots (the
+ * objective runs up to two interpolator and two forecaster forwards); dyf_train_backward consumes a slot: gradient of a
+ * scalar loss w.r.t. the network's parameters (accumulated into the engine's gradient buffers when param_grads != 0) and,
+ * when dinputs_dev != NULL, w.r.t. its `inputs` (NB,in_channels,H,W) -- the frozen interpolator is differentiated through.
+ * flags: DYF_TRAIN_BATCH_STATS = BatchNorm with batch statistics (+ running-statistics update, momentum 0.1; module.train()),
+ * otherwise running statistics (frozen / eval network); DYF_TRAIN_DROPOUT = Dropout layers active (engine generator, same
+ * streams as sampling; the backward re-derives the masks).  All arithmetic fp32. */
+#define DYF_TRAIN_BATCH_STATS 1
+#define DYF_TRAIN_DROPOUT 2
+dyf_status dyf_train_forward(dyf_engine* engine, int32_t net, int32_t slot, const float* inputs_dev, const float* time_dev,
+                             const float* condition_dev, float* out_dev, int32_t nb, int32_t flags, void* stream);
+dyf_status dyf_train_backward(dyf_engine* engine, int32_t slot, const float* dout_dev, float* dinputs_dev, int32_t param_grads,
+                              void* stream);
+dyf_status dyf_train_zero_grads(dyf_engine* engine, int32_t net);
+/* Copy gradients out by the reference's state_dict names (PyTorch layouts), HOST fp32 buffers; "*.running_mean/var" return the
+ * updated BatchNorm statistics. */
+dyf_status dyf_train_export(dyf_engine* engine, int32_t net, int32_t n_tensors, const char* const* names, float* const* out_host);
+/* d(scale * mean criterion)/d pred, kinds as dyf_criterion (the loss terms of p_losses, dyffusion.py:531,557). */
+dyf_status dyf_criterion_grad(dyf_engine* engine, const float* pred_dev, const float* target_dev, int64_t count, int32_t kind,
+                              float scale, float* dpred_dev, void* stream);
+
 /* ---- boundary conditions of the physical-systems benchmark -------------------------------------------------------------- */
 /* Replaces PhysicalSystemsBenchmarkDataModule.boundary_conditions (src/datamodules/physical_systems_benchmark.py:245-297:
  * a Python loop over batch elements with boolean-mask writes), which _evaluation_step applies to every predicted field

@@ -1,11 +1,13 @@
-"""ORACLE (test infrastructure, CPU fp32) -- the DYffusion forecaster objective, forward only.
+"""ORACLE (test infrastructure, CPU fp32) -- the DYffusion forecaster objective.
 
 Restates /root/reference/src/diffusion/dyffusion.py:496-567 (`p_losses`) together with the two helpers it calls,
 :140-163 + :480-494 (`q_sample` / `_interpolate`) and :191-239 (`_predict_last_dynamics` / `predict_x_last`), given two
-callables for the networks.  This is the objective as the reference evaluates it in validation (`self.training` false:
-eval-mode normalisation layers); the training step adds autograd on top, which is outside this oracle.
-Parity: pinned against tests/golden/plosses_*.npz (outputs of the imported reference's `DYffusion.p_losses`) in
-tests/test_oracle_losses.py.
+callables for the networks.  With eval-mode callables this is the objective as the reference evaluates it in validation;
+with a training-mode forecaster callable (`nets.unet_simple_forward(..., bn_training=True, dropout=...)`) and parameters that
+require grad, torch.autograd over it is the reference's training step (the callables decide the mode, as module.train() /
+the interpolator's frozen eval mode do in the reference).
+Parity: pinned against tests/golden/plosses_*.npz (outputs of the imported reference's `DYffusion.p_losses`) and
+plosses_train_*.npz (its losses AND gradients in training mode) in tests/test_oracle_losses.py.
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this package.
 """

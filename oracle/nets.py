@@ -156,7 +156,9 @@ def unet_simple_layout(dim: int):
     return enc, dec
 
 
-def _norm(P, prefix, x, kind):
+def _norm(P, prefix, x, kind, bn_training: bool = False):
+    if kind == "bn" and bn_training:  # module.train(): batch statistics (the running-statistics update is not modelled)
+        return F.batch_norm(x, None, None, P[f"{prefix}.weight"], P[f"{prefix}.bias"], training=True, eps=1e-5)
     if kind == "bn":  # eval-mode BatchNorm2d: running statistics (BN always eval at sampling)
         return F.batch_norm(x, P[f"{prefix}.running_mean"], P[f"{prefix}.running_var"], P[f"{prefix}.weight"],
                             P[f"{prefix}.bias"], training=False, eps=1e-5)
@@ -164,9 +166,11 @@ def _norm(P, prefix, x, kind):
 
 
 def unet_simple_forward(P: Dict[str, Tensor], cfg: dict, inputs: Tensor, time: Optional[Tensor] = None,
-                        condition: Optional[Tensor] = None, dropout=None, taps: Optional[dict] = None) -> Tensor:
+                        condition: Optional[Tensor] = None, dropout=None, taps: Optional[dict] = None,
+                        bn_training: bool = False) -> Tensor:
     """unet_simple.py:181-197 + :164-179.  cfg keys: dim, upsample_dims (or None), outer_sample_mode,
-    with_time_emb, dropout, input_dropout.  `taps` (optional dict) receives intermediate activations."""
+    with_time_emb, dropout, input_dropout.  `taps` (optional dict) receives intermediate activations.  `bn_training`:
+    BatchNorm2d as under module.train() (batch statistics) -- the training step of the forecaster."""
     dropout = dropout or DropoutOff()
     dim = cfg["dim"]
     mode = cfg.get("outer_sample_mode", "bilinear")
@@ -185,7 +189,7 @@ def unet_simple_forward(P: Dict[str, Tensor], cfg: dict, inputs: Tensor, time: O
     for li, (_, _, k, s, pad, norm, act) in enumerate(enc):
         pre = f"input_ops.{li}"
         x = F.conv2d(x, P[f"{pre}.ops.0.weight"], P[f"{pre}.ops.0.bias"], stride=s, padding=pad)
-        x = _norm(P, f"{pre}.ops.1", x, norm)
+        x = _norm(P, f"{pre}.ops.1", x, norm, bn_training)
         if temb is not None:
             scale, shift = film(P, f"{pre}.time_mlp", temb)
             x = x * (scale + 1) + shift
@@ -199,7 +203,7 @@ def unet_simple_forward(P: Dict[str, Tensor], cfg: dict, inputs: Tensor, time: O
         pre = f"output_ops.{li}"
         x = F.interpolate(x, scale_factor=2, mode="bilinear")
         x = F.conv2d(x, P[f"{pre}.ops.1.weight"], P[f"{pre}.ops.1.bias"], stride=1, padding=pad)
-        x = _norm(P, f"{pre}.ops.2", x, norm)
+        x = _norm(P, f"{pre}.ops.2", x, norm, bn_training)
         if temb is not None:
             scale, shift = film(P, f"{pre}.time_mlp", temb)
             x = x * (scale + 1) + shift

@@ -336,6 +336,64 @@ def gen_plosses():
         print(name, vals)
 
 
+def gen_plosses_train():
+    """The TRAINING step of the imported reference: `DYffusion.p_losses` with the module in train mode (forecaster:
+    batch-statistics BatchNorm, Dropout active; frozen interpolator in eval mode with its Dropout active), loss.backward().
+    All nn.Dropout layers draw from DropoutSeeded(seed) in call order.  Stored: inputs, weights, the loss dict, the gradient
+    of `loss` w.r.t. every forecaster parameter and the BatchNorm running statistics after the step."""
+    base_model = dict(dim=4, outer_sample_mode="bilinear", upsample_dims=[64, 64], with_time_emb=True,
+                      input_dropout=0.0, dropout=0.2)
+    variants = [
+        ("plosses_train_a", dict(h=4, seed=71), dict(lambda_reconstruction=1.0, lambda_reconstruction2=0.5, loss_function="l1")),
+        ("plosses_train_b", dict(h=5, seed=72), dict(additional_interpolation_steps=2, forward_conditioning="data",
+                                                      lambda_reconstruction=0.7, lambda_reconstruction2=1.0, loss_function="mse",
+                                                      time_encoding="normalized")),
+    ]
+    for name, meta, dk in variants:
+        h = meta["h"]
+        dkw = dict(enable_interpolator_dropout=True)
+        dkw.update(dk)
+        exp, ipol = ref_import.build_reference_dyffusion(system="spring-mesh", model="unet_simple",
+                                                         model_kwargs=base_model, horizon=h, diffusion_kwargs=dkw)
+        load_seeded(exp.model.model, seed=31)
+        load_seeded(ipol.model, seed=32)
+        dyn = exp.model
+        dyn.train()
+        # nn.Module.train() recurses into the frozen interpolator as well; `freeze_model` (dyffusion.py:468, utils.py:553-557)
+        # put it in eval mode and Lightning (>= 2.2) restores every submodule's own mode when fitting: keep it frozen in eval
+        dyn.interpolator.eval()
+        for p in dyn.model.parameters():
+            p.requires_grad_(True)
+        assert not ipol.model.training and all(not p.requires_grad for p in ipol.model.parameters())
+        T = dyn.num_timesteps
+        g = torch.Generator().manual_seed(19)
+        B = 6
+        xt_last = torch.randn(B, 4, 10, 10, generator=g)
+        cond = torch.randn(B, 4, 10, 10, generator=g)
+        sc = torch.rand(B, 1, 10, 10, generator=g)
+        t = torch.tensor([0, 1, T - 1, 2 % T, T - 2, 0])
+        sd0 = {k: v.detach().clone() for k, v in dyn.model.state_dict().items()}
+        with patched_dropout(DropoutSeeded(seed=meta["seed"])):
+            out = dyn.p_losses(xt_last, cond, t, static_condition=sc)
+            out["loss"].backward()
+        hp = dict(timesteps=h, num_timesteps=T, model=base_model, B=B, dropout_seed=meta["seed"],
+                  **{k: dkw.get(k, d) for k, d in dict(
+                      schedule="before_t1_only", additional_interpolation_steps=0, additional_interpolation_steps_factor=0,
+                      interpolate_before_t1=True, time_encoding="dynamics", forward_conditioning="none",
+                      lambda_reconstruction=1.0, lambda_reconstruction2=0.0, loss_function="l1",
+                      enable_interpolator_dropout=True).items()})
+        arrs = {f"F::{k}": v.numpy() for k, v in sd0.items()}
+        arrs.update({f"I::{k}": v.numpy() for k, v in ipol.model.state_dict().items()})
+        arrs.update({f"G::{k}": p.grad.numpy() for k, p in dyn.model.named_parameters()})
+        arrs.update({f"B::{k}": v.detach().numpy() for k, v in dyn.model.state_dict().items()
+                     if k.endswith("running_mean") or k.endswith("running_var") or k.endswith("num_batches_tracked")})
+        vals = {k.split("/")[-1]: float(v) for k, v in out.items()}
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), xt_last=xt_last.numpy(), cond=cond.numpy(), sc=sc.numpy(),
+                            t=t.numpy(), hp=json.dumps(hp), losses=json.dumps(vals), **arrs)
+        gn = float(torch.cat([p.grad.reshape(-1) for p in dyn.model.parameters()]).norm())
+        print(name, vals, "grad norm", gn)
+
+
 # ------------------------------------------------------------------------------------------------ G6
 def gen_fullsize():
     """NS 221x42 h=16 dim=64 (BASELINE config 2): checksums + probe points of the reference rollout, dropout OFF
@@ -548,7 +606,7 @@ def gen_ensemble_stats():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["schedules", "nets", "resnet", "samples", "fullsize", "metrics", "ckpt", "plosses", "stats", "boundary", "predict_step"]
+    which = sys.argv[1:] or ["schedules", "nets", "resnet", "samples", "fullsize", "metrics", "ckpt", "plosses", "stats", "boundary", "predict_step", "plosses_train"]
     if "stats" in which:
         gen_ensemble_stats()
     if "boundary" in which:
@@ -557,6 +615,8 @@ if __name__ == "__main__":
         gen_predict_step()
     if "plosses" in which:
         gen_plosses()
+    if "plosses_train" in which:
+        gen_plosses_train()
     if "metrics" in which:
         gen_metrics()
     if "ckpt" in which:

@@ -1,0 +1,113 @@
+"""-m gpu: the training step of the forecaster objective on the engine: `DYffusion.p_losses` in training
+mode + `loss.backward()` -- forward with batch-statistics BatchNorm and Dropout, backward through the forecaster (twice) and
+THROUGH the frozen interpolator (second loss term) -- against torch.autograd over the oracle, which
+tests/test_oracle_losses.py pins to the imported reference's own losses and gradients (plosses_train_*.npz).
+
+The engine draws its dropout masks from its own generator; the oracle replays exactly those masks (tests/rng_host.py):
+forward counter 0 = first interpolator call, 1 = first forecaster pass, 2 / 3 = the second pair.
+Tolerance (stated): the training path is fp32 end to end -- losses within 1e-4 relative, every parameter's gradient within
+1e-3 of the global gradient norm (measured ~1e-5; the reductions run in a different order than ATen's).
+"""
+import json
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import losses, nets
+from tests import rng_host as R
+from tests.gpu_common import DEV, build_dyffusion
+from tests.helpers import load_npz, split_state
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_step(PF, PI, mk, hp, xt_last, cond, t, sc, seed):
+    uh, uw = mk["upsample_dims"]
+    drop = R.EngineDropout(seed, mk["dim"], uh, uw)
+    PFg = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and not k.endswith(("running_mean", "running_var")) else v)
+           for k, v in PF.items()}
+    bn_batches = []
+    orig = F.batch_norm
+
+    def spy(x, rm, rv, weight=None, bias=None, training=False, momentum=0.1, eps=1e-5):
+        if training:
+            bn_batches.append((x.detach().mean((0, 2, 3)), x.detach().var((0, 2, 3), unbiased=True)))
+        return orig(x, rm, rv, weight, bias, training, momentum, eps)
+
+    def f_fn(x, tt, c):
+        drop.begin_forward()
+        return nets.unet_simple_forward(PFg, mk, x, tt, c, dropout=drop, bn_training=True)
+
+    def i_fn(x, tt, c):
+        drop.begin_forward()
+        return nets.unet_simple_forward(PI, mk, x, tt, c, dropout=drop)
+
+    F.batch_norm = spy
+    try:
+        out = losses.p_losses(f_fn, i_fn, xt_last, cond, t, sc, hp)
+    finally:
+        F.batch_norm = orig
+    out["loss"].backward()
+    return out, {k: v.grad for k, v in PFg.items() if torch.is_tensor(v) and v.requires_grad}, bn_batches
+
+
+@pytest.mark.parametrize("name", ["plosses_train_a", "plosses_train_b"])
+def test_training_step_matches_autograd_of_the_oracle(name):
+    z = load_npz(name + ".npz")
+    hp = json.loads(str(z["hp"]))
+    mk = hp["model"]
+    PF, PI = split_state(z, "F"), split_state(z, "I")
+    xt_last, cond, sc, t = (torch.from_numpy(z[k]) for k in ("xt_last", "cond", "sc", "t"))
+    m = build_dyffusion(PF, PI, mk, 4, 1, hp, max_batch=hp["B"])
+    seed = 20240928
+    m.seed(seed)
+    m.train()
+    out = m.p_losses(xt_last.to(DEV), cond.to(DEV), t.to(DEV), static_condition=sc.to(DEV))
+    assert set(out) == {"loss", "train/loss_forward", "train/loss_forward2"}
+    out["loss"].backward()
+    want, grads, bn_batches = _oracle_step(PF, PI, mk, hp, xt_last, cond, t, sc, seed)
+    for k_got, k_want in (("loss", "loss"), ("train/loss_forward", "loss_forward"), ("train/loss_forward2", "loss_forward2")):
+        assert float(out[k_got]) == pytest.approx(float(want[k_want]), rel=1e-4), k_got
+    got = {k: p.grad for k, p in m.model.named_parameters()}
+    assert sorted(got) == sorted(grads)
+    gn = float(torch.cat([g.reshape(-1) for g in grads.values()]).norm())
+    worst = max(float((got[k].cpu() - grads[k]).norm()) for k in grads) / gn
+    print(f"{name}: loss {float(out['loss']):.6f}, grad norm {gn:.4f}, worst per-tensor gradient error / grad norm = {worst:.2e}")
+    assert worst <= 1e-3
+    # the reference's own gradients (different dropout masks) have the same scale: a sanity anchor, not a parity check
+    G = split_state(z, "G")
+    assert 0.5 <= gn / float(torch.cat([g.reshape(-1) for g in G.values()]).norm()) <= 2.0
+    # BatchNorm buffers as module.train() leaves them: two forecaster passes -> two momentum-0.1 updates
+    sd = m.model.state_dict()
+    n_pass = 2 if hp["lambda_reconstruction2"] > 0 else 1
+    assert int(sd["input_ops.0.ops.1.num_batches_tracked"]) == n_pass
+    rm, rv = PF["input_ops.0.ops.1.running_mean"].clone(), PF["input_ops.0.ops.1.running_var"].clone()
+    per_pass = len(bn_batches) // n_pass
+    for p in range(n_pass):
+        bm, bv = bn_batches[p * per_pass]
+        rm, rv = 0.9 * rm + 0.1 * bm, 0.9 * rv + 0.1 * bv
+    assert torch.allclose(sd["input_ops.0.ops.1.running_mean"].cpu(), rm, rtol=1e-4, atol=1e-6)
+    assert torch.allclose(sd["input_ops.0.ops.1.running_var"].cpu(), rv, rtol=1e-4, atol=1e-6)
+    m.eval()
+
+
+def test_sgd_steps_reduce_the_loss_and_resync_the_engine():
+    """torch.optim over the mirror's parameters: the engine re-uploads weights that an optimizer modified in place."""
+    z = load_npz("plosses_train_a.npz")
+    hp = json.loads(str(z["hp"]))
+    hp["model"] = dict(hp["model"], dropout=0.0)  # deterministic objective
+    PF, PI = split_state(z, "F"), split_state(z, "I")
+    xt_last, cond, sc, t = (torch.from_numpy(z[k]).to(DEV) for k in ("xt_last", "cond", "sc", "t"))
+    m = build_dyffusion(PF, PI, hp["model"], 4, 1, hp, max_batch=hp["B"])
+    m.train()
+    opt = torch.optim.SGD(m.model.parameters(), lr=0.05)
+    hist = []
+    for _ in range(4):
+        opt.zero_grad()
+        out = m.p_losses(xt_last, cond, t, static_condition=sc)
+        out["loss"].backward()
+        opt.step()
+        hist.append(float(out["loss"]))
+    print("loss over 4 SGD steps:", [round(v, 5) for v in hist])
+    assert hist[-1] < hist[0]
