@@ -426,6 +426,44 @@ def gen_fullsize():
     print("fullsize:", {k: (round(v["mean"], 5), round(v["std"], 5)) for k, v in res["rollout"].items()})
 
 
+def gen_fullsize_oisst():
+    """G6 for BASELINE configs[2]: OISST 60x60, C=1, no static condition, `unet.Unet` dim 64 mults (1,2,4) for both networks,
+    h=7 with k=25 extra interpolation steps (T=32: 32 forecaster + 61 interpolator forwards), forward_conditioning
+    "data+noise" (torch.randn_like patched to a seeded generator), cold sampling, no refinement, dropout off, NB=1.
+    Stored: all seven forecast fields; parameters come from oracle.init.seeded_state (seeds in the fixture)."""
+    mk = dict(dim=64, dim_mults=(1, 2, 4), with_time_emb=True, block_dropout=0.0, block_dropout1=0.0, attn_dropout=0.0)
+    exp, ipol = ref_import.build_reference_dyffusion(
+        system="oisst", model="unet_resnet", model_kwargs=mk, horizon=7,
+        diffusion_kwargs=dict(additional_interpolation_steps=25, forward_conditioning="data+noise",
+                              refine_intermediate_predictions=False, enable_interpolator_dropout=False))
+
+    def seed_net(net, seed):
+        shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+        st = oinit.seeded_state(shapes, seed, gain=1.0)
+        for k in st:
+            if k.endswith(".norm.g"):
+                st[k] = 1.0 + 0.1 * torch.randn(shapes[k], generator=torch.Generator().manual_seed(len(k)))
+        net.load_state_dict(st, strict=True)
+
+    seed_net(exp.model.model, 201)
+    seed_net(ipol.model, 202)
+    g = torch.Generator().manual_seed(11)
+    x0 = torch.randn(1, 1, 60, 60, generator=g)
+    with torch.no_grad(), patched_randn_like(301) as draws:
+        out = exp.predict(x0)
+    assert exp.model.num_timesteps == 32 and len(draws) == 32 and sorted(out) == [f"t{i}_preds" for i in range(1, 8)]
+    np.savez_compressed(os.path.join(HERE, "fullsize_oisst_fields.npz"), x0=x0.numpy(),
+                        meta=json.dumps(dict(seeds=dict(forecaster=201, interpolator=202, inputs=11, noise=301),
+                                             model=dict(mk, dim_mults=list(mk["dim_mults"])), timesteps=7,
+                                             additional_interpolation_steps=25, num_timesteps=32,
+                                             forecaster_channels=dict(inputs=exp.model.model.num_input_channels,
+                                                                      cond=exp.model.model.num_conditional_channels),
+                                             interpolator_channels=dict(inputs=ipol.model.num_input_channels,
+                                                                        cond=ipol.model.num_conditional_channels))),
+                        **{k: v.numpy().astype(np.float32) for k, v in out.items()})
+    print("fullsize OISST:", {k: (round(float(v.mean()), 4), round(float(v.std()), 4)) for k, v in out.items()})
+
+
 def gen_metrics():
     """Ensemble metrics (SURVEY 8f-3): outputs of the reference's own numpy functions (src/utilities/evaluation.py);
     its CRPS goes through xskillscore/properscoring, absent here, so only mse / spread-skill are reference-generated."""
@@ -606,7 +644,7 @@ def gen_ensemble_stats():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["schedules", "nets", "resnet", "samples", "fullsize", "metrics", "ckpt", "plosses", "stats", "boundary", "predict_step", "plosses_train"]
+    which = sys.argv[1:] or ["schedules", "nets", "resnet", "samples", "fullsize", "metrics", "ckpt", "plosses", "stats", "boundary", "predict_step", "plosses_train", "fullsize_oisst"]
     if "stats" in which:
         gen_ensemble_stats()
     if "boundary" in which:
@@ -631,3 +669,5 @@ if __name__ == "__main__":
         gen_samples()
     if "fullsize" in which:
         gen_fullsize()
+    if "fullsize_oisst" in which:
+        gen_fullsize_oisst()

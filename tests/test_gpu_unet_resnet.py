@@ -159,3 +159,33 @@ def test_flash_attention_long_sequence_with_dropout():
     got = net._engine.net_forward(0, x.to(DEV), t.to(DEV), None, dropout_mode=2, masks=masks).cpu()
     print("flash attention N=780 dropout rel-rms", rel_rms(got, want))
     assert rel_rms(got, want) <= TOL
+
+
+@pytest.mark.parametrize("dtype,tol", [("bf16", 7e-2), ("fp16", 1e-2)])
+def test_fullsize_oisst_rollout_matches_reference_fields(dtype, tol):
+    """BASELINE configs[2] at full size (fixture G6-OISST, outputs of the imported reference): 60x60, C=1, ResNet-UNet dim 64
+    mults (1,2,4) for both networks, h=7 with k=25 extra interpolation steps -- the T=32 plan of 32 forecaster + 61
+    interpolator forwards -- forward_conditioning "data+noise" with the reference's normal draws injected, cold sampling,
+    dropout off, NB=1.  All seven fields.  Tolerance: the recursion chains 93 forwards of a network with ~60 16-bit
+    roundings per forward (every conv output is stored before its GroupNorm): measured 4.6e-2 - 5.2e-2 in bf16 (1e-2 per
+    forward), 6e-3 in fp16; the fp16 build is the one held to SURVEY 8c's 1e-2."""
+    z = load_npz("fullsize_oisst_fields.npz")
+    meta = json.loads(str(z["meta"]))
+    fc, ic = meta["forecaster_channels"], meta["interpolator_channels"]
+    cfg = dict(meta["model"], resnet_block_groups=8, input_dropout=0.0, upsample_dims=None)
+    PF = seeded_unet(64, (1, 2, 4), fc["inputs"] + fc["cond"], 1, seed=meta["seeds"]["forecaster"])
+    PI = seeded_unet(64, (1, 2, 4), ic["inputs"] + ic["cond"], 1, seed=meta["seeds"]["interpolator"])
+    F_, I_ = mirror(PF, cfg, fc["inputs"], fc["cond"], 1), mirror(PI, cfg, ic["inputs"], ic["cond"], 1)
+    hp = dict(timesteps=7, schedule="before_t1_only", additional_interpolation_steps=25, interpolate_before_t1=True,
+              sampling_type="cold", refine_intermediate_predictions=False, forward_conditioning="data+noise",
+              time_encoding="dynamics", enable_interpolator_dropout=False)
+    m = D.DYffusion(F_, D.InterpolatorHandle(I_, 7), max_batch=1, dtype=dtype, **hp)
+    assert m.num_timesteps == meta["num_timesteps"] == 32
+    x0 = torch.from_numpy(z["x0"])
+    gen = torch.Generator().manual_seed(meta["seeds"]["noise"])  # the draws the reference's patched randn_like made, in order
+    noise = torch.stack([torch.randn(x0.shape, generator=gen) for _ in range(32)], 0)
+    _, got, _ = m.sample_loop(x0.to(DEV), _noise=noise.to(DEV))
+    assert m._engine.forward_counts() == (32, 61)
+    errs = {k: rel_rms(got[k].cpu(), z[k]) for k in sorted(got)}
+    print(f"full-size OISST rollout ({dtype}) rel-rms", {k: round(v, 5) for k, v in errs.items()})
+    assert sorted(got) == [f"t{i}_preds" for i in range(1, 8)] and max(errs.values()) <= tol
