@@ -219,9 +219,7 @@ def test_forecaster_objective_matches_reference_golden(name):
     want = json.loads(str(z["losses"]))
     for k_got, k_want in (("loss", "loss"), ("val/loss_forward", "loss_forward"), ("val/loss_forward2", "loss_forward2")):
         assert abs(got[k_got] - want[k_want]) <= 2e-2 * max(abs(want[k_want]), 1e-3), (k_got, got[k_got], want[k_want])
-    with pytest.raises(NotImplementedError):
-        m.train().p_losses(xt_last, cond, t, static_condition=sc)
-    m.eval()
+    assert all(isinstance(v, float) for v in got.values())  # eval mode: plain floats ("val/" keys); training: tests/test_gpu_training.py
 
 
 def test_criterion_reduction_matches_torch():
