@@ -742,19 +742,61 @@ __global__ __launch_bounds__(256) void linattn_ctx_mfma_kernel(LinAttnArgs a, fl
 // merge the workgroup partials of one (sample, head), normalise, and emit ctx as the A fragments of the output product:
 // frags[bh][hi/lo part][k-step s][lane (e, hi')][8]: slot j of lane (e, hi') = ctx[d = 16 s + 8 hi' + j][e]
 __global__ __launch_bounds__(256) void linattn_merge_kernel(const float* part, int nblk, float inv_n, el16_t* frags) {
+    // One workgroup per (sample, head).  At 512^2 there are 256 partials per head: the serial three-pass form (max, sum,
+    // weighted accumulation, each a chain of dependent loads) took 225 us; here the max / sum passes run 8 partial-groups wide,
+    // the rescaling factors exp(M_b - M) are computed once into LDS, and the accumulation keeps 4 loads in flight.
+    __shared__ float wexp[256][32];   // [partial][column d]; nblk <= 256 per pass (looped otherwise)
+    __shared__ float red[8][32];
     const int bh = blockIdx.x, tid = threadIdx.x, lane = tid & 63, rq = tid >> 6, d = lane & 31, hi = lane >> 5;
+    const int d8 = tid & 31, bq = tid >> 5;
     const float* pb = part + (size_t)bh * nblk * LA_PART;
-    float M = -3.0e38f;
-    for (int b = 0; b < nblk; ++b) M = fmaxf(M, pb[(size_t)b * LA_PART + 1024 + d]);
+    float m = -3.0e38f;
+    for (int b = bq; b < nblk; b += 8) m = fmaxf(m, pb[(size_t)b * LA_PART + 1024 + d8]);
+    red[bq][d8] = m;
+    __syncthreads();
+    float M = red[0][d];
+#pragma unroll
+    for (int q = 1; q < 8; ++q) M = fmaxf(M, red[q][d]);
+    const float M8 = fmaxf(fmaxf(fmaxf(red[0][d8], red[1][d8]), fmaxf(red[2][d8], red[3][d8])),
+                           fmaxf(fmaxf(red[4][d8], red[5][d8]), fmaxf(red[6][d8], red[7][d8])));
+    __syncthreads();
+    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    float ssum = 0.0f;
+    for (int b0 = 0; b0 < nblk; b0 += 256) {
+        const int nb = min(256, nblk - b0);
+        for (int b = bq; b < nb; b += 8) {
+            const float w = __expf(pb[(size_t)(b0 + b) * LA_PART + 1024 + d8] - M8);
+            wexp[b][d8] = w;
+            ssum = fmaf(pb[(size_t)(b0 + b) * LA_PART + 1056 + d8], w, ssum);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+            const int r = rq * 4 + r4;
+            const float* pr = pb + (size_t)b0 * LA_PART + r * 64 + lane;
+            float v0 = 0.0f, v1 = 0.0f, v2 = 0.0f, v3 = 0.0f;
+            int b = 0;
+            for (; b + 3 < nb; b += 4) {
+                v0 = fmaf(pr[(size_t)b * LA_PART], wexp[b][d], v0);
+                v1 = fmaf(pr[(size_t)(b + 1) * LA_PART], wexp[b + 1][d], v1);
+                v2 = fmaf(pr[(size_t)(b + 2) * LA_PART], wexp[b + 2][d], v2);
+                v3 = fmaf(pr[(size_t)(b + 3) * LA_PART], wexp[b + 3][d], v3);
+            }
+            for (; b < nb; ++b) v0 = fmaf(pr[(size_t)b * LA_PART], wexp[b][d], v0);
+            acc[r4] += (v0 + v1) + (v2 + v3);
+        }
+        __syncthreads();
+    }
+    red[bq][d8] = ssum;
+    __syncthreads();
     float S = 0.0f;
-    for (int b = 0; b < nblk; ++b) S = fmaf(pb[(size_t)b * LA_PART + 1056 + d], __expf(pb[(size_t)b * LA_PART + 1024 + d] - M), S);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) S += red[q][d];
     const float norm = inv_n / S;  // v / (h*w)  (attention.py:41)
 #pragma unroll
     for (int r4 = 0; r4 < 4; ++r4) {
         const int r = rq * 4 + r4;
-        float v = 0.0f;
-        for (int b = 0; b < nblk; ++b) v = fmaf(pb[(size_t)b * LA_PART + r * 64 + lane], __expf(pb[(size_t)b * LA_PART + 1024 + d] - M), v);
-        v *= norm;
+        const float v = acc[r4] * norm;
         const int e = (r >> 2) * 8 + hi * 4 + (r & 3);
         const size_t idx = (((size_t)bh * 2 * 2 + (d >> 4)) * 64 + ((d >> 3) & 1) * 32 + e) * 8 + (d & 7);
         const el16_t vh = f32_to_el16(v);
