@@ -45,6 +45,11 @@ struct ConvArgs {
     // halo form of the fused-upsample conv: fp32 scratch [n][2*wo + 2*(ho-2)][cout] for the border corrections
     // (up_border_kernel fills it, conv_up_halo_kernel starts its border accumulators from it); required by that form
     float* up_border;
+    // split-K of conv_igemm_kernel<128,128> at small batches: fp32 scratch [splitk][n*ho*wo][cout] (engine workspace; null =
+    // never split), its capacity in floats, and the split factor (set by the launcher)
+    float* splitk_ws;
+    long long splitk_cap;
+    int splitk;
 };
 // floats of ConvArgs::up_border for an n x (2h x 2w) x cout output
 inline size_t conv_up_border_floats(int n, int h, int w, int cout) { return (size_t)n * (4 * (size_t)w + 4 * (size_t)h - 4) * cout; }

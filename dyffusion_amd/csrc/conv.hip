@@ -420,14 +420,41 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a, int M, i
             st ^= 1;
         }
     } else {
+        // split-K (small batches): blockIdx.y walks its share [k0, k1) of the K steps; K order is taps fastest, then chunks
+        const int nsplit = a.splitk > 1 ? a.splitk : 1;
+        const int k0 = (int)((long long)nk * blockIdx.y / nsplit), k1 = (int)((long long)nk * (blockIdx.y + 1) / nsplit);
+        is_chunk = k0 / ntaps;
+        is_tap = k0 - is_chunk * ntaps;
         issue(0);
-        for (int k = 0; k < nk; ++k) {
-            const int cur = k & 1;
+        for (int k = k0; k < k1; ++k) {
+            const int cur = (k - k0) & 1;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
-            if (k + 1 < nk) issue(cur ^ 1);
+            if (k + 1 < k1) issue(cur ^ 1);
             compute(cur);
         }
+    }
+
+    if (!UP && a.splitk > 1) {
+        // split-K partial: raw fp32 accumulators to splitk_ws[split][m][cout]; conv_splitk_finish_kernel adds the splits in
+        // index order (deterministic) and runs the epilogue.  Lane (l31, hi) of accumulator (i, j): pixel l31 of sub-tile i,
+        // channels j*32 + 8*g + 4*hi + {0..3}.
+        const int l31s = lane & 31, his = lane >> 5;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = wm * 64 + i * 32 + l31s;
+            if (tm * BM + row >= M) continue;
+            int m;
+            if (tile2d) m = (t_img * a.ho + t_y0 + (row >> 4)) * a.wo + t_x0 + (row & 15);
+            else m = tm * BM + row;
+            float* dst = a.splitk_ws + ((size_t)blockIdx.y * M + m) * a.cout + tn * BN + wn * 64 + 4 * his;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *(float4*)(dst + j * 32 + 8 * g) = make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+        }
+        return;
     }
 
     // ---- epilogue straight from the accumulators.  The operands are swapped (D^T = W X^T), so lane (l31, hi) of
@@ -507,6 +534,27 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs a, int M, i
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------ split-K finish
+// Small batches leave the small-plane / deep-K layers (enc1-enc5, dec1, dec2 of unet_simple) with a handful of workgroups that
+// each walk up to 144 K steps: a forward at NB = 1 spent 300 of its 316 us there.  conv_igemm_kernel<128,128> then splits the
+// K steps over blockIdx.y; this kernel adds the partials in split order and applies the epilogue of conv_direct_kernel.
+__global__ void conv_splitk_finish_kernel(ConvArgs a, long long M) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M * a.cout) return;
+    const int co = (int)(i % a.cout);
+    const long long m = i / a.cout;
+    const int n = (int)(m / ((long long)a.ho * a.wo));
+    float acc = 0.0f;
+    for (int s = 0; s < a.splitk; ++s) acc += a.splitk_ws[((size_t)s * M + m) * a.cout + co];
+    const size_t ci = (size_t)(a.coef_div > 1 ? n / a.coef_div : n) * a.coef_stride + co;
+    float v = fmaf(acc, a.coef_a[ci], a.coef_c[ci]);
+    v = apply_act(v, a.act);
+    v = drop_apply(v, (uint32_t)i, (uint32_t)n * (uint32_t)(a.ho * a.wo * a.cout), a.drop, drop_row_key(a.drop, n));
+    if (a.residual) v += el16_to_f32(a.residual[i]);
+    if (a.out_el16) a.out_el16[i] = f32_to_el16(v);
+    if (a.out_f32) a.out_f32[i] = v;
+}
+
 // ------------------------------------------------------------------------------------------------ launchers
 bool conv_mfma_supported(const ConvArgs& a) {
     if (a.act == ACT_GELU) return false;  // the MFMA epilogues are instantiated for none / ReLU / LeakyReLU / SiLU
@@ -536,8 +584,20 @@ static hipError_t launch_igemm(ConvArgs a, hipStream_t stream) {
         a.wpk = a.wpk_up;
     }
     const int tiles_n = a.cout / BN;
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, UP>), dim3(tiles_m * tiles_n), dim3(256), lds, stream, a, (int)M,
+    a.splitk = 1;
+    if (!UP && BM == 128 && a.splitk_ws) {
+        // The split factor is a function of the layer's K depth ONLY (never of the batch), so every batch size of the
+        // small-batch regime sums in the same order: rows stay bit-identical under batch splits / ensemble sharding.
+        static const bool enabled = !(getenv("DYF_SPLITK") && atoi(getenv("DYF_SPLITK")) == 0);
+        const int nk = a.kh * a.kw * ((a.c0 + a.c1) >> 6);
+        const int s = std::min(16, nk / 8);
+        const long long need = (long long)s * M * a.cout;
+        if (enabled && s > 1 && (long long)tiles_m * tiles_n < 256 && need <= a.splitk_cap) a.splitk = s;
+    }
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, UP>), dim3(tiles_m * tiles_n, a.splitk), dim3(256), lds, stream, a, (int)M,
                        tiles_m, tiles_n);
+    if (a.splitk > 1)
+        hipLaunchKernelGGL(conv_splitk_finish_kernel, dim3((unsigned)((M * a.cout + 255) / 256)), dim3(256), 0, stream, a, M);
     return hipGetLastError();
 }
 

@@ -116,6 +116,7 @@ ConvArgs block_conv_args(const dyf_engine* e, const Net& n, const UBlock& b, int
     a.wpk = b.wpk;
     a.act = b.act;
     a.zero_page = e->ws.zero_page;
+    a.splitk_ws = e->ws.splitk; a.splitk_cap = DYF_SPLITK_FLOATS;
     return a;
 }
 
@@ -397,6 +398,7 @@ dyf_status dyf_engine_create(const dyf_engine_config* cfg, dyf_engine** out_engi
     ALLOC(ws.zero_page, 256);
     ALLOC(ws.up_border, ub_el);
     ALLOC(ws.coef_pair, 4 * tc);
+    ALLOC(ws.splitk, DYF_SPLITK_FLOATS);
     ALLOC(e->s_pair, 2 * (size_t)cfg->max_batch * DYF_MAX_OUT_CH * cfg->height * cfg->width);
     ALLOC(e->s_time, 64);
     ALLOC(e->rng_state, DYF_RNG_STATE_WORDS);

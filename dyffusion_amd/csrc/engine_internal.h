@@ -13,6 +13,8 @@
 #include "conv.h"
 #include "kernels.h"
 
+#define DYF_SPLITK_FLOATS (32ll << 20)  // 128 MB: 16 splits x 2 M outputs (a layer that fills < 256 tiles of 128 x 128)
+
 namespace dyf {
 
 struct TrainState;  // fp32 training copies of the parameters, gradients and forward tapes (train.hip)
@@ -82,6 +84,7 @@ struct Workspace {
     el16_t* zero_page = nullptr;
     float* up_border = nullptr;  // border-correction scratch of the fused-upsample halo convs (ConvArgs::up_border)
     float* coef_pair = nullptr;  // [2][2][total_c]: FiLM coefficient rows of a paired interpolator call
+    float* splitk = nullptr;     // split-K partials of the small-batch convs (ConvArgs::splitk_ws), DYF_SPLITK_FLOATS floats
 };
 
 struct PlanHost {

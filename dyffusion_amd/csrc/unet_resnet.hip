@@ -97,6 +97,7 @@ dyf_status rconv(dyf_engine* e, const el16_t* s0, int c0, const el16_t* s1, int 
     a.kh = k; a.kw = k; a.stride = stride; a.pad = pad; a.cout = cout; a.wpk = wpk;
     a.coef_a = coef_a; a.coef_c = coef_c; a.coef_stride = coef_stride; a.act = act; a.drop = drop;
     a.residual = residual; a.out_el16 = out;
+    a.splitk_ws = e->ws.splitk; a.splitk_cap = DYF_SPLITK_FLOATS;
     const int path = (e->cfg.enable_mfma && conv_mfma_supported(a)) ? 1 : 0;
     HIP_TRY(e, launch_conv(a, path, st));
     return DYF_OK;
