@@ -586,13 +586,18 @@ static hipError_t launch_igemm(ConvArgs a, hipStream_t stream) {
     const int tiles_n = a.cout / BN;
     a.splitk = 1;
     if (!UP && BM == 128 && a.splitk_ws) {
-        // The split factor is a function of the layer's K depth ONLY (never of the batch), so every batch size of the
-        // small-batch regime sums in the same order: rows stay bit-identical under batch splits / ensemble sharding.
+        // Split factor: the layer's K depth allows nk / 8 (<= 16); the launch takes as much of it as is needed to fill the 512
+        // resident workgroups (power of two), and only when its own tiles fill less than a quarter of them -- a layer with many
+        // output pixels pays more for writing / re-reading the partials than it gains (enc1 at NB = 7: 224 tiles, 58 MB of
+        // partials).  Tiny problems (<= 32 tiles) always get the layer's full factor, so small batches, their row splits and
+        // the paired launches sum in the same order and stay bit-identical.
         static const bool enabled = !(getenv("DYF_SPLITK") && atoi(getenv("DYF_SPLITK")) == 0);
         const int nk = a.kh * a.kw * ((a.c0 + a.c1) >> 6);
-        const int s = std::min(16, nk / 8);
+        const long long tiles = (long long)tiles_m * tiles_n;
+        int s = std::min(16, nk / 8);
+        while (s > 1 && s * tiles > 512) s >>= 1;
         const long long need = (long long)s * M * a.cout;
-        if (enabled && s > 1 && (long long)tiles_m * tiles_n < 256 && need <= a.splitk_cap) a.splitk = s;
+        if (enabled && s > 1 && tiles <= 128 && need <= a.splitk_cap) a.splitk = s;
     }
     hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, UP>), dim3(tiles_m * tiles_n, a.splitk), dim3(256), lds, stream, a, (int)M,
                        tiles_m, tiles_n);

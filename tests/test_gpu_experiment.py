@@ -86,3 +86,52 @@ def test_predict_step_autoregressive_with_boundary_conditions_matches_reference_
     assert torch.allclose(batch["dynamics"], dyn * 1e6)  # forecasting_multi_horizon.py:221
     merged = exp.on_predict_epoch_end()
     assert merged["t8_preds"].shape == (N, B, 4, 10, 10) and exp._predict_step_outputs == []
+
+
+def test_navier_stokes_long_rollout_with_device_boundary_conditions():
+    """BASELINE configs[3] in structure, at full size: Navier-Stokes 221x42, dim 64 @256^2, prediction horizon 32 with horizon
+    16 -> two autoregressive outer iterations re-feeding t16, N=2 members x B=2, the reference's NS boundary conditions
+    (fixed mask zeroed, parabolic inflow growing as 1 - exp(-5 t), per-batch-element times t0 + k dt) applied to every field
+    on the device.  Checks: every field finite and carrying the boundary values EXACTLY where the reference writes them
+    (ensemble members 0..B-1 of the (N, B, ...) stack -- its first-dimension indexing), untouched elsewhere relative to a run
+    without boundary conditions for the first outer iteration, and the second iteration starting from the BC-applied t16."""
+    from oracle import boundary as obc
+    from tests.gpu_common import seeded_pair
+    PF, PI = seeded_pair(64, 3, 2)
+    mk = dict(dim=64, upsample_dims=[256, 256], outer_sample_mode="bilinear", with_time_emb=True, dropout=0.15)
+    hp = dict(timesteps=16, forward_conditioning="none", interpolate_before_t1=True, sampling_type="cold",
+              refine_intermediate_predictions=True, enable_interpolator_dropout=False)
+    N, B = 2, 2
+    g = torch.Generator().manual_seed(8)
+    dyn = torch.randn(B, 33, 3, 221, 42, generator=g)
+    cond = torch.rand(B, 2, 221, 42, generator=g)
+    meta = {"fixed_mask": torch.rand(B, 3, 221, 42, generator=g) < 0.05, "in_velocity": 1.0 + torch.rand(B, generator=g),
+            "vertices": torch.rand(B, 2, 221, 42, generator=g) * 0.41}
+    m = build_dyffusion(PF, PI, mk, 3, 2, hp, max_batch=N * B)
+    bc = D.PhysicalSystemsBoundaryConditions("navier-stokes", m._ensure_engine((221, 42), N * B))
+
+    class DM:
+        def boundary_conditions(self, preds, targets, metadata, time=None):
+            return bc(preds=preds, targets=targets, metadata=metadata, time=time)
+
+        def get_boundary_condition_kwargs(self, batch, batch_idx, split):
+            return dict(t0=torch.tensor([0.0, 0.5]), dt=torch.tensor([0.01, 0.02]))
+
+    exp = D.MultiHorizonForecastingDYffusion(m, num_predictions=N, prediction_horizon=32, datamodule=DM())
+    batch = {"dynamics": dyn.clone().to(DEV), "condition": cond.to(DEV), "metadata": meta}
+    out = exp.evaluation_step(batch)
+    free = D.MultiHorizonForecastingDYffusion(m, num_predictions=N, prediction_horizon=16).evaluation_step(
+        {"dynamics": dyn.clone().to(DEV), "condition": cond.to(DEV)})
+    assert [k for k in out if k.endswith("preds")] == [f"t{k}_preds" for k in range(1, 33)]
+    for k in (1, 16, 17, 32):
+        p = out[f"t{k}_preds"].cpu()
+        assert tuple(p.shape) == (N, B, 3, 221, 42) and bool(torch.isfinite(p).all())
+        time = torch.tensor([0.0, 0.5])
+        for _ in range(k):  # total_t += dt per step, in fp32, as _evaluation_step accumulates it
+            time = time + torch.tensor([0.01, 0.02])
+        want = obc.boundary_conditions("navier-stokes", p.clone(), dyn[:, k], meta, time=time)
+        assert torch.equal(p, want), k  # idempotent: the field already satisfies the reference's boundary conditions
+        if k <= 16:  # first outer iteration: identical to the unconstrained rollout away from the written elements
+            q = obc.boundary_conditions("navier-stokes", free[f"t{k}_preds"].cpu().clone(), dyn[:, k], meta, time=time)
+            assert torch.equal(p, q), k
+    assert not torch.equal(out["t17_preds"].cpu(), out["t1_preds"].cpu())
