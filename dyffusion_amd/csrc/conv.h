@@ -76,6 +76,10 @@ void pack_halo3_frag(const el16_t* wpk, int cout, int cin, el16_t* out);
 bool conv_halo_s2_supported(const ConvArgs& a);
 hipError_t launch_conv_halo_s2(const ConvArgs& a, hipStream_t stream);
 void pack_halo_s2_frag(const el16_t* wpk, int cout, int cin, el16_t* out);
+// plain 3x3 / s1 / p1 conv with cout % 64 == 0 on ANY plane size (SP = 5: four pixel sub-tiles per workgroup, ragged edges)
+bool conv_halo5_supported(const ConvArgs& a);
+hipError_t launch_conv_halo5(const ConvArgs& a, hipStream_t stream);
+void pack_halo3_frag64(const el16_t* wpk, int cout, int cin, el16_t* out);
 void conv_register_halo3_frag(const el16_t* wpk_dev, const el16_t* frag_dev);
 const el16_t* conv_lookup_halo3_frag(const el16_t* wpk_dev);
 // second implicit-GEMM form (conv_igemm2.hip): 256 px x 128 ch per workgroup, weights streamed in fragment order

@@ -643,6 +643,22 @@ hipError_t launch_conv(const ConvArgs& a, int path, hipStream_t stream) {
                 if (b.wpk_up_frag && tiles3 >= (mt3 ? atoll(mt3) : 256) && conv_halo3_supported(b)) return launch_conv_halo3(b, stream);
             }
         }
+        // 3x3 / s1 convs with 64 or 128 (any multiple of 64 that is not one of 256) output channels -- the ResNet-UNet levels --
+        // on planes of any size: SP = 5 of the halo kernel, when the 16 x 32 tiles cover the plane reasonably (>= 60 %: not
+        // 15 x 15) and fill the chip.  DYF_HALO5=0 disables, DYF_HALO5_MIN_TILES sets the smallest launch.
+        if (!a.up2x && a.kh == 3 && a.kw == 3 && a.stride == 1 && a.cout % 64 == 0 && a.cout % 256 != 0 && a.out_f32 == nullptr &&
+            a.residual == nullptr) {
+            static const bool h5 = !(getenv("DYF_HALO5") && atoi(getenv("DYF_HALO5")) == 0);
+            static const long long h5_min = getenv("DYF_HALO5_MIN_TILES") ? atoll(getenv("DYF_HALO5_MIN_TILES")) : 256;
+            if (h5) {
+                ConvArgs b = a;
+                b.wpk_up_frag = conv_lookup_halo3_frag(b.wpk);
+                const long long ty = (a.h + 15) / 16, tx = (a.w + 31) / 32;
+                const long long tiles5 = (long long)a.n * ty * tx * (a.cout / 64);
+                const bool covers = 10ll * a.h * a.w >= 6ll * ty * 16 * tx * 32;
+                if (b.wpk_up_frag && covers && tiles5 >= h5_min && conv_halo5_supported(b)) return launch_conv_halo5(b, stream);
+            }
+        }
         if (!a.up2x && a.kh == 4 && a.kw == 4 && a.stride == 2 && a.cout % 128 == 0 && a.c1 == 0 && a.out_f32 == nullptr &&
             a.residual == nullptr && a.pix_pitch0 == 0) {  // 4x4 / s2 convs: the same kernel on the space-to-depth view
             const char* h3 = getenv("DYF_HALO3");

@@ -54,6 +54,13 @@ constexpr int STEP_BYTES = 32768;                       // weights of one (tap, 
 //         walks 4 planes x c0/64 chunks x 4 taps.  Weights: pack_halo_s2_frag.
 // SP = 4: SP = 3 for layers with a multiple of 128 (not 256) output channels: the workgroup's tile is 16 x 16 pixels, waves
 //         (wpy, wpx) = (8-row half, 64-channel block); halo 18 x 18, single-buffered (two workgroups per CU still fit).
+// SP = 5: plain 3x3 / stride 1 / pad 1 convolution for layers with a multiple of 64 (not 256) output channels -- the 64- and
+//         128-channel levels of the ResNet-UNet, whose planes (60x60, 30x30, 512x512 ...) need not tile evenly.  The four waves
+//         own four 8 x 16 PIXEL sub-tiles of a 16 x 32 tile and the SAME 64 output channels: one 18 x 34 halo (77 KB, single
+//         buffer, two workgroups per CU), every weight fragment is requested by four waves at about the same time (three of
+//         the four requests are L1 hits), pixels beyond the right / bottom edge of a ragged plane are zero-filled by the DMA's
+//         bounds check and masked at the store.  The halo source offsets are recomputed per chunk instead of being parked in
+//         LDS (no room).  Weights: pack_halo3_frag64.
 // SP = 1: SPARSE COLUMNS -- the 16 columns of a tile are entries of a per-phase column list (ConvArgs::up_cols): only the
 // output columns a later kernel reads are computed.  The NS backbone resamples its 256-wide grid to 42 native columns
 // (unet_simple.py:195): the readout touches 104 of the 256 columns of the last decoder block, i.e. 52 of 128 low-res columns
@@ -61,20 +68,22 @@ constexpr int STEP_BYTES = 32768;                       // weights of one (tap, 
 // workgroups still fit a CU; the other workgroup covers the exposed halo swap).
 template <int SP>
 struct HaloCfg {
-    static constexpr int W = SP == 1 ? 40 : 18;         // halo width in pixels
-    static constexpr int TH = SP == 4 ? 16 : 8;         // tile rows
+    static constexpr int W = SP == 1 ? 40 : SP == 5 ? 34 : 18;  // halo width in pixels
+    static constexpr int TH = (SP == 4 || SP == 5) ? 16 : 8;    // tile rows
+    static constexpr int TW = SP == 5 ? 32 : 16;        // tile columns
     static constexpr int REAL = (TH + 2) * W;
     static constexpr int PIX = (REAL + 7) / 8 * 8;      // padded to a multiple of 8 DMA rows
     static constexpr int BYTES = PIX * 128;             // 23 552 / 51 200
-    static constexpr int NBUF = (SP == 1 || SP == 4) ? 1 : 2;
+    static constexpr int NBUF = (SP == 1 || SP == 4 || SP == 5) ? 1 : 2;
     static constexpr bool PLAIN = SP >= 2;              // one output-channel block per wave, zero-padded window, no corrections
     static constexpr bool S2 = SP == 3 || SP == 4;      // 4x4 / stride 2 on parity planes
-    static constexpr int BLK = SP == 4 ? 128 : 256;     // plain forms: output channels of a workgroup
+    static constexpr int BLK = SP == 4 ? 128 : SP == 5 ? 64 : 256;  // plain forms: output channels of a workgroup
     static constexpr int STEP = BLK * 128;              // weight bytes of one (tap, chunk) step: BLK columns x 64 k bf16
     static constexpr int HOFF_OFF = NBUF * BYTES + 512; // per-thread halo source offsets [PER_WAVE][256]
     static constexpr int INSTR = PIX / 8;               // wave-level DMA instructions per halo: 23 / 50
     static constexpr int PER_WAVE = (INSTR + NWAVES - 1) / NWAVES;
-    static constexpr int LDS_TOTAL = HOFF_OFF + PER_WAVE * 1024;  // 53 760 / 65 024 B
+    static constexpr bool HAS_TAB = SP != 5;            // per-thread halo source offsets parked in LDS
+    static constexpr int LDS_TOTAL = HOFF_OFF + (HAS_TAB ? PER_WAVE * 1024 : 0);  // 53 760 / 65 024 / (SP 5) 79 360 B
 };
 
 }  // namespace
@@ -122,8 +131,9 @@ __global__ __launch_bounds__(256, 2) void conv_up_halo_kernel(ConvArgs a, int ti
         lane_valid = (entry & 0x4000) == 0;
         cstore = a.up_cidx[wpx * a.up_npad + lx * 16 + px_x];  // column of output pixel (.., 2*col + px) in the compact tensor
     } else {
-        cbase = lx * TILE_W - 1;
-        col = lx * TILE_W + px_x;
+        cbase = lx * H::TW - 1;
+        col = lx * H::TW + (SP == 5 ? 16 * wpx : 0) + px_x;
+        if (SP == 5) lane_valid = col < a.w;  // ragged planes: columns beyond the image are computed on zeros and not stored
     }
 
     const int cin = a.c0 + a.c1;
@@ -142,7 +152,7 @@ __global__ __launch_bounds__(256, 2) void conv_up_halo_kernel(ConvArgs a, int ti
     const auto rsrc_a1 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.c1 ? a.src1 : a.src0), 0,
                                                            (int)(unsigned)(npix * (a.c1 ? a.c1 : a.c0) * 2), 0x00020000);
     const auto rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.wpk_up_frag, 0,
-                                                          (int)(unsigned)((size_t)(SP == 2 ? 1 : 4) * a.cout * 16 * cin * 2), 0x00020000);  // SP = 3: 4 planes
+                                                          (int)(unsigned)((size_t)((SP == 2 || SP == 5) ? 1 : 4) * a.cout * 16 * cin * 2), 0x00020000);  // SP = 3: 4 planes
 
     // LDS swizzle key of halo pixel hp (XORed into its 16-B chunk index).  A ds_read_b128 is serviced in four NON-contiguous
     // 16-lane groups ({0-3,12-15,20-27}, {4-11,16-19,28-31}, and the same +32): with lanes = 2 tile rows x 16 columns a group
@@ -156,8 +166,7 @@ __global__ __launch_bounds__(256, 2) void conv_up_halo_kernel(ConvArgs a, int ti
     // (the per-lane source offsets are parked in LDS, not in registers: the K loop needs every VGPR it can get)
     const int sub = lane >> 3;
     unsigned* h_tab = (unsigned*)(smem + HOFF_OFF) + tid;
-#pragma unroll
-    for (int j = 0; j < HALO_PER_WAVE; ++j) {
+    auto halo_off = [&](int j) -> unsigned {
         const int i = j * NWAVES + wave;
         int hp = i * 8 + sub;
         if (hp > HALO_REAL - 1) hp = HALO_REAL - 1;  // padding slots re-read the last halo pixel
@@ -169,7 +178,11 @@ __global__ __launch_bounds__(256, 2) void conv_up_halo_kernel(ConvArgs a, int ti
         unsigned off = (H::S2 ? (unsigned)((n_img * a.h + 2 * y) * a.w + 2 * x) : (unsigned)((n_img * a.h + y) * a.w + x)) *
                            (unsigned)(a.c0 * 2) + gch * 16;  // c0 == c1 (checked on host)
         if (H::PLAIN && (yy != y || xx != x)) off = 0xFFFFFFFFu;  // plain convs: zero padding = out-of-range DMA offset
-        h_tab[j * 256] = off;
+        return off;
+    };
+    if (H::HAS_TAB) {
+#pragma unroll
+        for (int j = 0; j < HALO_PER_WAVE; ++j) h_tab[j * 256] = halo_off(j);
     }
 
     auto issue_halo = [&](int chunk) {
@@ -182,7 +195,7 @@ __global__ __launch_bounds__(256, 2) void conv_up_halo_kernel(ConvArgs a, int ti
         for (int j = 0; j < HALO_PER_WAVE; ++j) {
             const int i = j * NWAVES + wave;
             if (i < HALO_INSTR) {
-                unsigned vo = h_tab[j * 256];
+                unsigned vo = H::HAS_TAB ? h_tab[j * 256] : halo_off(j);
                 if (!H::PLAIN || vo != 0xFFFFFFFFu) vo += coff;
                 if (second)
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a1, LDS_PTR(dst + i * 1024), 16, vo, 0, 0, 0);
@@ -245,16 +258,18 @@ __global__ __launch_bounds__(256, 2) void conv_up_halo_kernel(ConvArgs a, int ti
         }
     }
 
-    int hp0 = (px_r + 1 + (SP == 4 ? 8 * wpy : 0)) * HALO_W + (col - cbase);  // halo pixel of pixel tile 0 at the un-shifted tap; mt adds 2 rows
+    int hp0 = (px_r + 1 + ((SP == 4 || SP == 5) ? 8 * wpy : 0)) * HALO_W + (col - cbase);  // halo pixel of pixel tile 0 at the un-shifted tap; mt adds 2 rows
     const unsigned lds_base = (unsigned)(uintptr_t)LDS_PTR(smem);
 
     u32x4 bq[6][2];   // weight fragments: ring of 6 sets (9-tap modes: 5 sub-steps ahead), 4 sets in the 4-tap modes
     el16x8_t aq[2][4];  // pixel fragments: two sets
     unsigned ab[4], ax[4];  // LDS base / swizzle term of the tap whose pixel fragments are being fetched
 
+    // weights of one (tap, chunk) step: WSTEP bytes, inside [ks][column tile][lane] x 16 B with KSS bytes per k16 sub-step
+    constexpr unsigned WSTEP = SP == 5 ? 8192u : (unsigned)STEP_BYTES, KSS = SP == 5 ? 2048u : 4096u;
 #define ISSUE_B(SET, SOFF, KS)                                                                               \
     _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                                         \
-        bq[SET][nt] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, w_voff + nt * 1024, (SOFF) + (KS) * 4096, 0);
+        bq[SET][nt] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, w_voff + nt * 1024, (SOFF) + (KS) * KSS, 0);
 #define DSR(dst, addr) asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr));
 #define LGKM_WAIT(N)                                                      \
     asm volatile("s_waitcnt lgkmcnt(" #N ")" ::: "memory");               \
@@ -310,8 +325,8 @@ __global__ __launch_bounds__(256, 2) void conv_up_halo_kernel(ConvArgs a, int ti
     // 9-tap modes: the (chunk, tap) order is fixed, so the weight stream is addressed directly: sub-step g = 4*tap + ks of a
     // chunk uses ring set g % 6 and requests the fragments of sub-step g + 5 (36 sub-steps per chunk = 6 turns of the ring);
     // the L2 round trip of a fragment is longer than the 3 sub-steps the 4-set ring gave it
-    const unsigned soff_w = (unsigned)(wpy * (STEP_BYTES / 2) + wpx * 2048);
-    unsigned soff_c = (unsigned)((tn * cpt) * 16) * (unsigned)STEP_BYTES + soff_w, soff_n = soff_c;
+    const unsigned soff_w = SP == 5 ? 0u : (unsigned)(wpy * (STEP_BYTES / 2) + wpx * 2048);  // SP 5: all waves, same weights
+    unsigned soff_c = (unsigned)((tn * cpt) * 16) * WSTEP + soff_w, soff_n = soff_c;
     if (H::S2) {
         ISSUE_B(0, soff_cur, 0)
         ISSUE_B(1, soff_cur, 1)
@@ -321,7 +336,7 @@ __global__ __launch_bounds__(256, 2) void conv_up_halo_kernel(ConvArgs a, int ti
         ISSUE_B(1, soff_c, 1)
         ISSUE_B(2, soff_c, 2)
         ISSUE_B(3, soff_c, 3)
-        ISSUE_B(4, soff_c + STEP_BYTES, 0)
+        ISSUE_B(4, soff_c + WSTEP, 0)
     }
     for (int chunk = 0; chunk < cpt; ++chunk) {
         if (H::NBUF == 2) {
@@ -352,47 +367,47 @@ __global__ __launch_bounds__(256, 2) void conv_up_halo_kernel(ConvArgs a, int ti
             STENCIL_STEP(d10, true, d11)
             STENCIL_STEP(d11, false, 0)
         } else {
-        soff_n = chunk + 1 < cpt ? soff_c + 16u * (unsigned)STEP_BYTES : soff_c;  // tail: harmless re-fetch
+        soff_n = chunk + 1 < cpt ? soff_c + 16u * WSTEP : soff_c;  // tail: harmless re-fetch
         TAPADDR(-HALO_W - 1)
         RDA1(0, 0, 0) RDA1(0, 0, 1) RDA1(0, 0, 2) RDA1(0, 0, 3)
         // ---- 9 stencil taps (a, b) in {-1,0,1}^2: displacement a*18 + b in the halo; 36 sub-steps, weights 5 ahead
 #define D_OF(T) (((T) / 3 - 1) * HALO_W + ((T) % 3 - 1))
-        SLOT(5, soff_c + 1 * STEP_BYTES, 1, true, NO_PRE, 1, 1, 0, 0)
-        SLOT(0, soff_c + 1 * STEP_BYTES, 2, true, NO_PRE, 0, 2, 1, 1)
-        SLOT(1, soff_c + 1 * STEP_BYTES, 3, true, NO_PRE, 1, 3, 0, 2)
-        SLOT(2, soff_c + 2 * STEP_BYTES, 0, true, TAPADDR(D_OF(1)), 0, 0, 1, 3)
-        SLOT(3, soff_c + 2 * STEP_BYTES, 1, true, NO_PRE, 1, 1, 0, 4)
-        SLOT(4, soff_c + 2 * STEP_BYTES, 2, true, NO_PRE, 0, 2, 1, 5)
-        SLOT(5, soff_c + 2 * STEP_BYTES, 3, true, NO_PRE, 1, 3, 0, 0)
-        SLOT(0, soff_c + 3 * STEP_BYTES, 0, true, TAPADDR(D_OF(2)), 0, 0, 1, 1)
-        SLOT(1, soff_c + 3 * STEP_BYTES, 1, true, NO_PRE, 1, 1, 0, 2)
-        SLOT(2, soff_c + 3 * STEP_BYTES, 2, true, NO_PRE, 0, 2, 1, 3)
-        SLOT(3, soff_c + 3 * STEP_BYTES, 3, true, NO_PRE, 1, 3, 0, 4)
-        SLOT(4, soff_c + 4 * STEP_BYTES, 0, true, TAPADDR(D_OF(3)), 0, 0, 1, 5)
-        SLOT(5, soff_c + 4 * STEP_BYTES, 1, true, NO_PRE, 1, 1, 0, 0)
-        SLOT(0, soff_c + 4 * STEP_BYTES, 2, true, NO_PRE, 0, 2, 1, 1)
-        SLOT(1, soff_c + 4 * STEP_BYTES, 3, true, NO_PRE, 1, 3, 0, 2)
-        SLOT(2, soff_c + 5 * STEP_BYTES, 0, true, TAPADDR(D_OF(4)), 0, 0, 1, 3)
-        SLOT(3, soff_c + 5 * STEP_BYTES, 1, true, NO_PRE, 1, 1, 0, 4)
-        SLOT(4, soff_c + 5 * STEP_BYTES, 2, true, NO_PRE, 0, 2, 1, 5)
-        SLOT(5, soff_c + 5 * STEP_BYTES, 3, true, NO_PRE, 1, 3, 0, 0)
-        SLOT(0, soff_c + 6 * STEP_BYTES, 0, true, TAPADDR(D_OF(5)), 0, 0, 1, 1)
-        SLOT(1, soff_c + 6 * STEP_BYTES, 1, true, NO_PRE, 1, 1, 0, 2)
-        SLOT(2, soff_c + 6 * STEP_BYTES, 2, true, NO_PRE, 0, 2, 1, 3)
-        SLOT(3, soff_c + 6 * STEP_BYTES, 3, true, NO_PRE, 1, 3, 0, 4)
-        SLOT(4, soff_c + 7 * STEP_BYTES, 0, true, TAPADDR(D_OF(6)), 0, 0, 1, 5)
-        SLOT(5, soff_c + 7 * STEP_BYTES, 1, true, NO_PRE, 1, 1, 0, 0)
-        SLOT(0, soff_c + 7 * STEP_BYTES, 2, true, NO_PRE, 0, 2, 1, 1)
-        SLOT(1, soff_c + 7 * STEP_BYTES, 3, true, NO_PRE, 1, 3, 0, 2)
-        SLOT(2, soff_c + 8 * STEP_BYTES, 0, true, TAPADDR(D_OF(7)), 0, 0, 1, 3)
-        SLOT(3, soff_c + 8 * STEP_BYTES, 1, true, NO_PRE, 1, 1, 0, 4)
-        SLOT(4, soff_c + 8 * STEP_BYTES, 2, true, NO_PRE, 0, 2, 1, 5)
-        SLOT(5, soff_c + 8 * STEP_BYTES, 3, true, NO_PRE, 1, 3, 0, 0)
-        SLOT(0, soff_n + 0 * STEP_BYTES, 0, true, TAPADDR(D_OF(8)), 0, 0, 1, 1)
-        SLOT(1, soff_n + 0 * STEP_BYTES, 1, true, NO_PRE, 1, 1, 0, 2)
-        SLOT(2, soff_n + 0 * STEP_BYTES, 2, true, NO_PRE, 0, 2, 1, 3)
-        SLOT(3, soff_n + 0 * STEP_BYTES, 3, true, NO_PRE, 1, 3, 0, 4)
-        SLOT(4, soff_n + 1 * STEP_BYTES, 0, false, NO_PRE, 0, 0, 1, 5)
+        SLOT(5, soff_c + 1 * WSTEP, 1, true, NO_PRE, 1, 1, 0, 0)
+        SLOT(0, soff_c + 1 * WSTEP, 2, true, NO_PRE, 0, 2, 1, 1)
+        SLOT(1, soff_c + 1 * WSTEP, 3, true, NO_PRE, 1, 3, 0, 2)
+        SLOT(2, soff_c + 2 * WSTEP, 0, true, TAPADDR(D_OF(1)), 0, 0, 1, 3)
+        SLOT(3, soff_c + 2 * WSTEP, 1, true, NO_PRE, 1, 1, 0, 4)
+        SLOT(4, soff_c + 2 * WSTEP, 2, true, NO_PRE, 0, 2, 1, 5)
+        SLOT(5, soff_c + 2 * WSTEP, 3, true, NO_PRE, 1, 3, 0, 0)
+        SLOT(0, soff_c + 3 * WSTEP, 0, true, TAPADDR(D_OF(2)), 0, 0, 1, 1)
+        SLOT(1, soff_c + 3 * WSTEP, 1, true, NO_PRE, 1, 1, 0, 2)
+        SLOT(2, soff_c + 3 * WSTEP, 2, true, NO_PRE, 0, 2, 1, 3)
+        SLOT(3, soff_c + 3 * WSTEP, 3, true, NO_PRE, 1, 3, 0, 4)
+        SLOT(4, soff_c + 4 * WSTEP, 0, true, TAPADDR(D_OF(3)), 0, 0, 1, 5)
+        SLOT(5, soff_c + 4 * WSTEP, 1, true, NO_PRE, 1, 1, 0, 0)
+        SLOT(0, soff_c + 4 * WSTEP, 2, true, NO_PRE, 0, 2, 1, 1)
+        SLOT(1, soff_c + 4 * WSTEP, 3, true, NO_PRE, 1, 3, 0, 2)
+        SLOT(2, soff_c + 5 * WSTEP, 0, true, TAPADDR(D_OF(4)), 0, 0, 1, 3)
+        SLOT(3, soff_c + 5 * WSTEP, 1, true, NO_PRE, 1, 1, 0, 4)
+        SLOT(4, soff_c + 5 * WSTEP, 2, true, NO_PRE, 0, 2, 1, 5)
+        SLOT(5, soff_c + 5 * WSTEP, 3, true, NO_PRE, 1, 3, 0, 0)
+        SLOT(0, soff_c + 6 * WSTEP, 0, true, TAPADDR(D_OF(5)), 0, 0, 1, 1)
+        SLOT(1, soff_c + 6 * WSTEP, 1, true, NO_PRE, 1, 1, 0, 2)
+        SLOT(2, soff_c + 6 * WSTEP, 2, true, NO_PRE, 0, 2, 1, 3)
+        SLOT(3, soff_c + 6 * WSTEP, 3, true, NO_PRE, 1, 3, 0, 4)
+        SLOT(4, soff_c + 7 * WSTEP, 0, true, TAPADDR(D_OF(6)), 0, 0, 1, 5)
+        SLOT(5, soff_c + 7 * WSTEP, 1, true, NO_PRE, 1, 1, 0, 0)
+        SLOT(0, soff_c + 7 * WSTEP, 2, true, NO_PRE, 0, 2, 1, 1)
+        SLOT(1, soff_c + 7 * WSTEP, 3, true, NO_PRE, 1, 3, 0, 2)
+        SLOT(2, soff_c + 8 * WSTEP, 0, true, TAPADDR(D_OF(7)), 0, 0, 1, 3)
+        SLOT(3, soff_c + 8 * WSTEP, 1, true, NO_PRE, 1, 1, 0, 4)
+        SLOT(4, soff_c + 8 * WSTEP, 2, true, NO_PRE, 0, 2, 1, 5)
+        SLOT(5, soff_c + 8 * WSTEP, 3, true, NO_PRE, 1, 3, 0, 0)
+        SLOT(0, soff_n + 0 * WSTEP, 0, true, TAPADDR(D_OF(8)), 0, 0, 1, 1)
+        SLOT(1, soff_n + 0 * WSTEP, 1, true, NO_PRE, 1, 1, 0, 2)
+        SLOT(2, soff_n + 0 * WSTEP, 2, true, NO_PRE, 0, 2, 1, 3)
+        SLOT(3, soff_n + 0 * WSTEP, 3, true, NO_PRE, 1, 3, 0, 4)
+        SLOT(4, soff_n + 1 * WSTEP, 0, false, NO_PRE, 0, 0, 1, 5)
         soff_c = soff_n;
 #undef D_OF
         }
@@ -421,10 +436,11 @@ __global__ __launch_bounds__(256, 2) void conv_up_halo_kernel(ConvArgs a, int ti
     const uint32_t row0 = (uint32_t)n_img * (uint32_t)(a.ho * a.wo * a.cout);  // dropout streams are per batch row
     // channel block of this wave: the 64 channels of column block tn (upsample forms: one phase per wave), or (plain form)
     // the wave's own 64 of the 256 channels of block tn
-    const int ch_blk = H::PLAIN ? tn * H::BLK + (SP == 4 ? wpx : wave) * 64 : tn * 64;
+    const int ch_blk = H::PLAIN ? tn * H::BLK + (SP == 5 ? 0 : (SP == 4 ? wpx : wave) * 64) : tn * 64;
     const uint32_t ci_base = (uint32_t)((a.coef_div > 1 ? n_img / a.coef_div : n_img) * a.coef_stride + ch_blk + 4 * hi);
     // output pixel (pixel tile 0, px = 0) of this lane, in elements; pixel tile mt adds 4 output rows, px adds one pixel
-    const uint32_t m0 = H::PLAIN ? (uint32_t)((n_img * a.ho + ty0 + px_r + (SP == 4 ? 8 * wpy : 0)) * a.wo + col)
+    const int orow0 = ty0 + px_r + ((SP == 4 || SP == 5) ? 8 * wpy : 0);  // plain forms: output row of pixel tile 0 (mt adds 2)
+    const uint32_t m0 = H::PLAIN ? (uint32_t)((n_img * a.ho + orow0) * a.wo + col)
                                 : (uint32_t)((n_img * a.ho + 2 * (ty0 + px_r) + wpy) * a.wo + 2 * col + wpx);
     const uint32_t o0 = m0 * (uint32_t)a.cout + (uint32_t)ch_blk;
     const uint32_t mt_stride = (uint32_t)((H::PLAIN ? 2 : 4) * a.wo * a.cout);
@@ -463,7 +479,8 @@ __global__ __launch_bounds__(256, 2) void conv_up_halo_kernel(ConvArgs a, int ti
                     uint4 o;
                     o.x = s0[0]; o.y = s1[0]; o.z = s0[1]; o.w = s1[1];
                     const uint32_t sbase = store0 + mt * smt_stride + cg0;
-                    if (SP != 1 || lane_valid) *(uint4*)(a.out_el16 + (size_t)(sbase + 8 * hi)) = o;
+                    if ((SP != 1 && SP != 5) || (lane_valid && (SP != 5 || orow0 + 2 * mt < a.ho)))
+                        *(uint4*)(a.out_el16 + (size_t)(sbase + 8 * hi)) = o;
                 }
         }
     };
@@ -573,6 +590,44 @@ void pack_halo_s2_frag(const el16_t* wpk, int cout, int cin, el16_t* out) {
     pack_up2x_frag(v.data(), blocks * 64, cin4, out);
 }
 
+// Plain 3x3 conv with a multiple of 64 output channels (SP = 5): wpk [cout][9][cin] ->
+// [column block tn][chunk][16 tap slots][ks][column tile nt][lane][8 k]; lane (l31, hi) of fragment (ks, nt) holds channel
+// tn*64 + nt*32 + l31, k = chunk*64 + ks*16 + hi*8 + {0..7}; slots 9-15 stay zero.
+void pack_halo3_frag64(const el16_t* wpk, int cout, int cin, el16_t* out) {
+    const int cpt = cin / 64;
+    size_t o = 0;
+    for (int tn = 0; tn < cout / 64; ++tn)
+        for (int chunk = 0; chunk < cpt; ++chunk)
+            for (int tap = 0; tap < 16; ++tap)
+                for (int ks = 0; ks < 4; ++ks)
+                    for (int nt = 0; nt < 2; ++nt)
+                        for (int lane = 0; lane < 64; ++lane) {
+                            const int co = tn * 64 + nt * 32 + (lane & 31);
+                            const int k0 = chunk * 64 + ks * 16 + (lane >> 5) * 8;
+                            const el16_t* sp = wpk + ((size_t)co * 9 + tap) * cin + k0;
+                            for (int e2 = 0; e2 < 8; ++e2) out[o++] = tap < 9 ? sp[e2] : (el16_t)0;
+                        }
+}
+
+bool conv_halo5_supported(const ConvArgs& a) {
+    if (a.up2x || a.wpk_up_frag == nullptr || a.out_el16 == nullptr || a.out_f32 != nullptr || a.residual != nullptr) return false;
+    if (a.kh != 3 || a.kw != 3 || a.stride != 1 || a.pad != 1 || a.pix_pitch0 != 0) return false;
+    if (!(a.c0 > 0 && a.c0 % 64 == 0 && (a.c1 == 0 || a.c1 == a.c0) && a.cout % 64 == 0)) return false;
+    if (a.ho != a.h || a.wo != a.w) return false;
+    const size_t npix = (size_t)a.n * a.h * a.w;
+    return npix * a.c0 * 2 < 0x7F000000ull && (size_t)a.cout * 16 * (a.c0 + a.c1) * 2 < 0x7F000000ull &&
+           (size_t)a.n * a.ho * a.wo * a.cout < 0xFFFFFFF0ull;
+}
+
+hipError_t launch_conv_halo5(const ConvArgs& a, hipStream_t stream) {
+    using H5 = HaloCfg<5>;
+    const int tiles_x = (a.w + H5::TW - 1) / H5::TW, tiles_per_img = tiles_x * ((a.h + H5::TH - 1) / H5::TH);
+    const int tiles_m = a.n * tiles_per_img, tiles_n = a.cout / 64;
+    hipLaunchKernelGGL(conv_up_halo_kernel<5>, dim3(tiles_m * tiles_n), dim3(256), H5::LDS_TOTAL, stream, a, tiles_x,
+                       tiles_per_img, tiles_m, tiles_n, 0);
+    return hipGetLastError();
+}
+
 bool conv_halo_s2_supported(const ConvArgs& a) {
     if (a.up2x || a.wpk_up_frag == nullptr || a.out_el16 == nullptr || a.out_f32 != nullptr || a.residual != nullptr) return false;
     if (a.kh != 4 || a.kw != 4 || a.stride != 2 || a.pad != 1 || a.pix_pitch0 != 0) return false;
@@ -635,6 +690,9 @@ hipError_t conv_up_halo_init() {
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)conv_up_halo_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 HaloCfg<4>::LDS_TOTAL);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)conv_up_halo_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                HaloCfg<5>::LDS_TOTAL);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)up_border_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, UB_LDS);
     return e;
 }

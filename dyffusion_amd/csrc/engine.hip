@@ -1201,9 +1201,10 @@ dyf_status dyf_op_conv2d(dyf_engine* e, const uint16_t* x_dev, const float* w_ho
     a.kh = kh; a.kw = kw; a.stride = stride; a.pad = pad; a.cout = cout; a.wpk = wdev;
     a.wpk_frag = frag ? wdev + pk.size() : nullptr;
     el16_t* h3dev = nullptr;  // halo form of plain 3x3 convs (looked up through the registry like the engine's own weights)
-    if (((taps == 9 && cout % 256 == 0) || (kh == 4 && kw == 4 && cout % 128 == 0)) && cin % 64 == 0) {
+    if (((taps == 9 && cout % 64 == 0) || (kh == 4 && kw == 4 && cout % 128 == 0)) && cin % 64 == 0) {
         std::vector<el16_t> pf((size_t)cout * 16 * cin * (taps == 9 ? 1 : 4));
-        if (taps == 9) pack_halo3_frag(pk.data(), cout, cin, pf.data());
+        if (taps == 9 && cout % 256 == 0) pack_halo3_frag(pk.data(), cout, cin, pf.data());
+        else if (taps == 9) pack_halo3_frag64(pk.data(), cout, cin, pf.data());
         else pack_halo_s2_frag(pk.data(), cout, cin, pf.data());
         HIP_TRY(e, hipMalloc((void**)&h3dev, pf.size() * sizeof(el16_t)));
         HIP_TRY(e, hipMemcpy(h3dev, pf.data(), pf.size() * sizeof(el16_t), hipMemcpyHostToDevice));

@@ -21,6 +21,12 @@ CASES = [
     (5, 4, 4, 512, 512, 2, 2, 0),       # tiles span several samples
     (1, 64, 64, 256, 64, 3, 1, 1),      # 256x64 tile variant
     (2, 9, 7, 64, 64, 3, 1, 1),
+    # plain 3x3 convs with 64 / 128 output channels on the halo kernel's SP = 5 form (>= 256 tiles of 16 x 32 pixels): the
+    # ResNet-UNet levels at the OISST plane sizes (ragged: 60 = 3*16 + 12 = 32 + 28), a plane narrower than a tile, two chunks
+    (32, 60, 60, 64, 64, 3, 1, 1),
+    (70, 30, 30, 128, 128, 3, 1, 1),
+    (140, 20, 37, 64, 128, 3, 1, 1),
+    (300, 17, 9, 128, 64, 3, 1, 1),
 ]
 
 
