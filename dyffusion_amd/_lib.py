@@ -32,7 +32,7 @@ class NetConfig(C.Structure):
 class EngineConfig(C.Structure):
     _fields_ = [("abi_version", C.c_int32), ("device", C.c_int32), ("height", C.c_int32), ("width", C.c_int32),
                 ("max_batch", C.c_int32), ("use_graph", C.c_int32), ("enable_mfma", C.c_int32), ("dtype", C.c_int32),
-                ("net", NetConfig * 2)]
+                ("batch_invariant", C.c_int32), ("net", NetConfig * 2)]
 
 
 class PlanStep(C.Structure):

@@ -50,6 +50,7 @@ struct ConvArgs {
     float* splitk_ws;
     long long splitk_cap;
     int splitk;
+    int n_sel;          // batch the kernel FORM is selected for (tile-count thresholds, split-K); 0 = this launch's n
 };
 // floats of ConvArgs::up_border for an n x (2h x 2w) x cout output
 inline size_t conv_up_border_floats(int n, int h, int w, int cout) { return (size_t)n * (4 * (size_t)w + 4 * (size_t)h - 4) * cout; }

@@ -593,7 +593,7 @@ static hipError_t launch_igemm(ConvArgs a, hipStream_t stream) {
         // the paired launches sum in the same order and stay bit-identical.
         static const bool enabled = !(getenv("DYF_SPLITK") && atoi(getenv("DYF_SPLITK")) == 0);
         const int nk = a.kh * a.kw * ((a.c0 + a.c1) >> 6);
-        const long long tiles = (long long)tiles_m * tiles_n;
+        const long long tiles = (((long long)(a.n_sel > 0 ? a.n_sel : a.n) * a.ho * a.wo + BM - 1) / BM) * tiles_n;
         int s = std::min(16, nk / 8);
         while (s > 1 && s * tiles > 512) s >>= 1;
         const long long need = (long long)s * M * a.cout;
@@ -621,6 +621,7 @@ hipError_t conv_init() {
 }
 
 hipError_t launch_conv(const ConvArgs& a, int path, hipStream_t stream) {
+    const long long nsel = a.n_sel > 0 ? a.n_sel : a.n;  // rows the kernel form is chosen for (ConvArgs::n_sel)
     if (path == 1 && conv_mfma_supported(a)) {
         static const bool use_halo = !(getenv("DYF_UP_HALO") && atoi(getenv("DYF_UP_HALO")) == 0);
         // halo form from 32 x 32 low-res planes on; below that (dec2: 16 x 16, 2 tiles per image) the materialised upsample +
@@ -639,7 +640,7 @@ hipError_t launch_conv(const ConvArgs& a, int path, hipStream_t stream) {
                 ConvArgs b = a;
                 b.wpk_up_frag = conv_lookup_halo3_frag(b.wpk);
                 const char* mt3 = getenv("DYF_HALO3_MIN_TILES");
-                const long long tiles3 = ((long long)a.n * a.h * a.w / 128) * (a.cout / 256);
+                const long long tiles3 = (nsel * a.h * a.w / 128) * (a.cout / 256);
                 if (b.wpk_up_frag && tiles3 >= (mt3 ? atoll(mt3) : 256) && conv_halo3_supported(b)) return launch_conv_halo3(b, stream);
             }
         }
@@ -654,7 +655,7 @@ hipError_t launch_conv(const ConvArgs& a, int path, hipStream_t stream) {
                 ConvArgs b = a;
                 b.wpk_up_frag = conv_lookup_halo3_frag(b.wpk);
                 const long long ty = (a.h + 15) / 16, tx = (a.w + 31) / 32;
-                const long long tiles5 = (long long)a.n * ty * tx * (a.cout / 64);
+                const long long tiles5 = nsel * ty * tx * (a.cout / 64);
                 const bool covers = 10ll * a.h * a.w >= 6ll * ty * 16 * tx * 32;
                 if (b.wpk_up_frag && covers && tiles5 >= h5_min && conv_halo5_supported(b)) return launch_conv_halo5(b, stream);
             }
@@ -667,8 +668,8 @@ hipError_t launch_conv(const ConvArgs& a, int path, hipStream_t stream) {
                 b.wpk_up_frag = conv_lookup_halo3_frag(b.wpk);
                 const char* mt3 = getenv("DYF_HALO3_MIN_TILES");
                 // cout % 256 == 0: 8 x 16 tiles x 256 channels; else 16 x 16 tiles x 128 channels
-                const long long tiles3 = a.cout % 256 == 0 ? ((long long)a.n * a.ho * a.wo / 128) * (a.cout / 256)
-                                                           : ((long long)a.n * a.ho * a.wo / 256) * (a.cout / 128);
+                const long long tiles3 = a.cout % 256 == 0 ? (nsel * a.ho * a.wo / 128) * (a.cout / 256)
+                                                           : (nsel * a.ho * a.wo / 256) * (a.cout / 128);
                 if (b.wpk_up_frag && tiles3 >= (mt3 ? atoll(mt3) : 256) && conv_halo_s2_supported(b)) return launch_conv_halo_s2(b, stream);
             }
         }
@@ -678,7 +679,7 @@ hipError_t launch_conv(const ConvArgs& a, int path, hipStream_t stream) {
             if (!b.wpk_frag) b.wpk_frag = conv_lookup_frag(b.wpk);
             // 256 x 128 tiles pay off once they fill the chip (2 workgroups x 256 CUs); below that the 128 x 128 form's
             // finer tiles win (measured at NB = 50: dec2/enc2 with 400 tiles +9 %/+4 %, enc3 with 200 tiles -20 %)
-            const long long tiles2 = (((long long)a.n * a.ho * a.wo + 255) / 256) * (a.cout % 128 == 0 ? a.cout / 128 : a.cout / 64);
+            const long long tiles2 = ((nsel * a.ho * a.wo + 255) / 256) * (a.cout % 128 == 0 ? a.cout / 128 : a.cout / 64);
             const char* mt = getenv("DYF_IGEMM2_MIN_TILES");  // tests force the form on small problems
             const long long min_tiles = mt ? atoll(mt) : 384;
             if (tiles2 >= min_tiles && conv_igemm2_supported(b)) return launch_conv_igemm2(b, stream);

@@ -117,6 +117,7 @@ ConvArgs block_conv_args(const dyf_engine* e, const Net& n, const UBlock& b, int
     a.act = b.act;
     a.zero_page = e->ws.zero_page;
     a.splitk_ws = e->ws.splitk; a.splitk_cap = DYF_SPLITK_FLOATS;
+    a.n_sel = e->cfg.batch_invariant ? 2 * e->cfg.max_batch : 0;
     return a;
 }
 

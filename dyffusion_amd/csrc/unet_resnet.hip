@@ -98,6 +98,7 @@ dyf_status rconv(dyf_engine* e, const el16_t* s0, int c0, const el16_t* s1, int 
     a.coef_a = coef_a; a.coef_c = coef_c; a.coef_stride = coef_stride; a.act = act; a.drop = drop;
     a.residual = residual; a.out_el16 = out;
     a.splitk_ws = e->ws.splitk; a.splitk_cap = DYF_SPLITK_FLOATS;
+    a.n_sel = e->cfg.batch_invariant ? 2 * e->cfg.max_batch : 0;
     const int path = (e->cfg.enable_mfma && conv_mfma_supported(a)) ? 1 : 0;
     HIP_TRY(e, launch_conv(a, path, st));
     return DYF_OK;

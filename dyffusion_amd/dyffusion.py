@@ -30,7 +30,8 @@ class DYffusion(nn.Module):
                  log_every_t=None, lambda_reconstruction: float = 1.0, lambda_reconstruction2: float = 0.0,
                  interpolator_horizon: Optional[int] = None, interpolator_window: int = 1,
                  enable_forecaster_dropout: bool = False, max_batch: int = 64, use_graph: bool = True,
-                 enable_mfma: bool = True, loss_function: str = "mean_squared_error", dtype: str = "bf16", **kwargs):
+                 enable_mfma: bool = True, loss_function: str = "mean_squared_error", dtype: str = "bf16",
+                 batch_invariant: bool = False, **kwargs):
         super().__init__()
         if model is None:
             raise ValueError("Arg ``model`` is missing... Please provide a backbone model for the diffusion model (e.g. a Unet)")
@@ -97,7 +98,8 @@ class DYffusion(nn.Module):
 
         # ---- engine: forecaster + interpolator in one dyf_engine
         # dtype: "bf16" (default, BASELINE configs[1]) or "fp16" (configs[4]): 16-bit storage / MFMA operand format of the engine
-        self._engine_opts = dict(max_batch=max_batch, use_graph=use_graph, enable_mfma=enable_mfma, dtype=dtype)
+        self._engine_opts = dict(max_batch=max_batch, use_graph=use_graph, enable_mfma=enable_mfma, dtype=dtype,
+                                 batch_invariant=batch_invariant)  # batch_invariant: bit-identical rows under any batching / sharding
         self._engine: Optional[HipEngine] = None
         self._plan_key = None
         self._seed: Optional[int] = None

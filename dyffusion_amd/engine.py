@@ -59,7 +59,8 @@ def _f32c(t: torch.Tensor, name: str) -> torch.Tensor:
 
 class HipEngine:
     def __init__(self, forecaster: L.NetConfig, interpolator: L.NetConfig, height: int, width: int, max_batch: int,
-                 device: Optional[int] = None, use_graph: bool = True, enable_mfma: bool = True, dtype: str = "bf16"):
+                 device: Optional[int] = None, use_graph: bool = True, enable_mfma: bool = True, dtype: str = "bf16",
+                 batch_invariant: bool = False):
         if not torch.cuda.is_available():
             raise EngineError("no GPU visible: the DYffusion HIP engine needs an MI355X (gfx950); there is no CPU fallback")
         self.dtype = dtype
@@ -67,7 +68,8 @@ class HipEngine:
         self.device = torch.cuda.current_device() if device is None else int(device)
         self.height, self.width, self.max_batch = int(height), int(width), int(max_batch)
         cfg = L.EngineConfig(L.DYF_ABI_VERSION, self.device, self.height, self.width, self.max_batch, int(use_graph),
-                             int(enable_mfma), L.DTYPES[dtype], (L.NetConfig * 2)(forecaster, interpolator))
+                             int(enable_mfma), L.DTYPES[dtype], int(batch_invariant),
+                             (L.NetConfig * 2)(forecaster, interpolator))
         self.cfg = cfg
         h = C.c_void_p()
         st = self._lib.dyf_engine_create(C.byref(cfg), C.byref(h))

@@ -87,6 +87,9 @@ typedef struct dyf_engine_config {
     int32_t dtype;            /* dyf_dtype of activations / weights in HBM and of the MFMA operands; must equal dyf_dtype() of
                                * the library: libdyffusion_hip.so is the bf16 build, libdyffusion_hip_f16.so the fp16 build of the
                                * same sources (-DDYF_F16=1), same ABI */
+    int32_t batch_invariant;  /* 1: the kernel form of every layer (implicit-GEMM variant, split-K factor, halo forms) is chosen for
+                               * 2 * max_batch rows whatever the batch of a call, so a row's result is bit-identical under any
+                               * batching / sharding served by engines of equal max_batch; 0: chosen per call (fastest) */
     dyf_net_config net[2];    /* indexed by dyf_net_id */
 } dyf_engine_config;
 

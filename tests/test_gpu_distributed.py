@@ -25,7 +25,7 @@ def _inputs(nb):
 def _model(max_batch):
     from tests.gpu_common import build_dyffusion, seeded_pair
     PF, PI = seeded_pair(64, 3, 2)
-    m = build_dyffusion(PF, PI, MK, 3, 2, HP, max_batch=max_batch)
+    m = build_dyffusion(PF, PI, MK, 3, 2, HP, max_batch=max_batch, batch_invariant=True)
     m.seed(31337)
     return m
 

@@ -117,7 +117,7 @@ def test_attention_core_16384_tokens(dtype):
 
 def test_config5_h32_rollout_properties():
     """h=32 rollout at 512^2 x 4 channels (fp16, dropout on in the interpolator): every field finite, rows independent
-    (2-row batch == two 1-row batches with row offsets), hipGraph replay == eager launches, bit for bit."""
+    (2-row batch == two 1-row batches with row offsets; engines created with batch_invariant=True: kernel forms chosen for max_batch), hipGraph replay == eager launches, bit for bit."""
     F_, _ = _seeded_unet(64, (1, 2, 4), 4, 4, seed=91)
     I_, _ = _seeded_unet(64, (1, 2, 4), 8, 4, seed=92, block_dropout=0.1, attn_dropout=0.1)
     hp = dict(timesteps=32, forward_conditioning="none", interpolate_before_t1=True, schedule="before_t1_only",
@@ -126,7 +126,7 @@ def test_config5_h32_rollout_properties():
     x0 = torch.randn(2, 4, 512, 512, generator=g).to(DEV)
 
     def run(rows, offset, use_graph):
-        m = D.DYffusion(F_, D.InterpolatorHandle(I_, 32), max_batch=2, dtype="fp16", use_graph=use_graph, **hp)
+        m = D.DYffusion(F_, D.InterpolatorHandle(I_, 32), max_batch=2, dtype="fp16", use_graph=use_graph, batch_invariant=True, **hp)
         m.seed(5)
         m.set_row_offset(offset)
         return {k: v.clone() for k, v in m.sample(x0[rows]).items()}
