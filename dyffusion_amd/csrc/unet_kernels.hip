@@ -992,75 +992,98 @@ __global__ __launch_bounds__(256) void flash_attention_kernel(AttnArgs a) {
     fa_f32x16 o;
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[r] = 0.0f;
-    float m = -1.0e30f, l = 0.0f;
+    float m = -1.0e30f, l = 0.0f;   // running maximum in the log2 domain (scores are pre-multiplied by scale * log2 e)
     const RngKey dkey = attn_drop_key(a.drop, n, (uint32_t)h);
+    const float c2 = scale * 1.4426950408889634f;
 
-    for (int j0 = 0; j0 < N; j0 += 64) {
-        __syncthreads();
-        {   // stage K [64][32] and V^T [32][64]: thread -> (key, 16-B chunk of 8 channels)
-            const int key = tid >> 2, ch = tid & 3, j = j0 + key;
-            uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
-            if (j < N) {
-                kv = *(const uint4*)(base + (size_t)j * C3 + hd + h * 32 + ch * 8);
-                vv = *(const uint4*)(base + (size_t)j * C3 + 2 * hd + h * 32 + ch * 8);
-            }
-            *(uint4*)(Ks + key * 32 + ((ch ^ ((key >> 2) & 3)) << 3)) = kv;
-            const el16_t* ve = (const el16_t*)&vv;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) Vt[(ch * 8 + i) * 68 + key] = ve[i];
+    // K / V of the NEXT 64-key tile travel through registers: their global loads are issued right after the current tile has
+    // been written to LDS and land while it is being consumed (the un-prefetched form exposed one HBM/L2 round trip per tile:
+    // 4.2 ms for 4 x 4 heads x 16 384 tokens)
+    const int skey = tid >> 2, sch = tid & 3;   // staging role: thread -> (key, 16-B chunk of 8 channels)
+    uint4 kv_n = make_uint4(0, 0, 0, 0), vv_n = make_uint4(0, 0, 0, 0);
+    auto fetch = [&](int j0) {
+        const int j = j0 + skey;
+        kv_n = make_uint4(0, 0, 0, 0);
+        vv_n = kv_n;
+        if (j < N) {
+            kv_n = *(const uint4*)(base + (size_t)j * C3 + hd + h * 32 + sch * 8);
+            vv_n = *(const uint4*)(base + (size_t)j * C3 + 2 * hd + h * 32 + sch * 8);
         }
-        __syncthreads();
+    };
+    fetch(0);
+
+    // one 32-key sub-tile; FAST: all 32 keys exist and no dropout on the probabilities (no per-element masks)
+    auto subtile = [&](int jb, int st, auto fast_c) {
+        constexpr bool FAST = decltype(fast_c)::value;
+        fa_f32x16 sc;
 #pragma unroll
-        for (int st = 0; st < 2; ++st) {  // two 32-key sub-tiles
-            const int jb = j0 + st * 32;
-            if (jb >= N) break;
-            fa_f32x16 s;
+        for (int r = 0; r < 16; ++r) sc[r] = 0.0f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s[r] = 0.0f;
+        for (int ks = 0; ks < 2; ++ks) {
+            const int key = st * 32 + l31;
+            const el16x8_t kf = *(const el16x8_t*)(Ks + key * 32 + (((ks * 2 + hi) ^ ((key >> 2) & 3)) << 3));
+            sc = DYF_MFMA_32x32x16(kf, qf[ks], sc, 0, 0, 0);
+        }
+        // lane (q, hi) now holds keys jb + (r&3) + 8(r>>2) + 4hi of query q
+        float tmax = -1.0e30f;
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) {
-                const int key = st * 32 + l31;
-                const el16x8_t kf = *(const el16x8_t*)(Ks + key * 32 + (((ks * 2 + hi) ^ ((key >> 2) & 3)) << 3));
-                s = DYF_MFMA_32x32x16(kf, qf[ks], s, 0, 0, 0);
-            }
-            // lane (q, hi) now holds keys jb + (r&3) + 8(r>>2) + 4hi of query q
-            float tmax = -1.0e30f;
+        for (int r = 0; r < 16; ++r) {
+            if (FAST) sc[r] *= c2;
+            else sc[r] = (jb + (r & 3) + 8 * (r >> 2) + 4 * hi) < N ? sc[r] * c2 : -1.0e30f;
+            tmax = fmaxf(tmax, sc[r]);
+        }
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float mn = fmaxf(m, tmax);
+        const float alpha = __builtin_amdgcn_exp2f(m - mn);
+        m = mn;
+        float psum = 0.0f;
+        float p[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int j = jb + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                s[r] = j < N ? s[r] * scale : -1.0e30f;
-                tmax = fmaxf(tmax, s[r]);
-            }
-            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-            const float mn = fmaxf(m, tmax);
-            const float alpha = __expf(m - mn);
-            m = mn;
-            float psum = 0.0f;
-            float p[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float e = __expf(s[r] - mn);
-                psum += e;
+        for (int r = 0; r < 16; ++r) {
+            const float e = __builtin_amdgcn_exp2f(sc[r] - mn);
+            psum += e;
+            if (FAST) p[r] = e;
+            else {
                 const int j = jb + (r & 3) + 8 * (r >> 2) + 4 * hi;
                 p[r] = (j < N && q < N) ? attn_drop(e, a.drop, dkey, (uint32_t)bh, (uint32_t)q, (uint32_t)j, (uint32_t)N) : 0.0f;
             }
-            psum += __shfl_xor(psum, 32, 64);
-            l = l * alpha + psum;
+        }
+        psum += __shfl_xor(psum, 32, 64);
+        l = l * alpha + psum;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o[r] *= alpha;
+        for (int r = 0; r < 16; ++r) o[r] *= alpha;
 #pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                uint32_t pk[4];
+        for (int s2 = 0; s2 < 2; ++s2) {
+            uint32_t pk[4];
 #pragma unroll
-                for (int t = 0; t < 4; ++t) pk[t] = pack_el16x2(p[s2 * 8 + 2 * t], p[s2 * 8 + 2 * t + 1]);
-                const el16x8_t pf = *(el16x8_t*)pk;
-                // V^T fragment: lane (d = l31, hi): keys st*32 + 16*s2 + 4*hi + {0..3} and + 8
-                const el16_t* vr = Vt + l31 * 68 + st * 32 + s2 * 16 + 4 * hi;
-                uint2 v0 = *(const uint2*)vr, v1 = *(const uint2*)(vr + 8);
-                uint32_t vw[4] = {v0.x, v0.y, v1.x, v1.y};
-                const el16x8_t vf = *(el16x8_t*)vw;
-                o = DYF_MFMA_32x32x16(vf, pf, o, 0, 0, 0);
-            }
+            for (int t = 0; t < 4; ++t) pk[t] = pack_el16x2(p[s2 * 8 + 2 * t], p[s2 * 8 + 2 * t + 1]);
+            const el16x8_t pf = *(el16x8_t*)pk;
+            // V^T fragment: lane (d = l31, hi): keys st*32 + 16*s2 + 4*hi + {0..3} and + 8
+            const el16_t* vr = Vt + l31 * 68 + st * 32 + s2 * 16 + 4 * hi;
+            uint2 v0 = *(const uint2*)vr, v1 = *(const uint2*)(vr + 8);
+            uint32_t vw[4] = {v0.x, v0.y, v1.x, v1.y};
+            const el16x8_t vf = *(el16x8_t*)vw;
+            o = DYF_MFMA_32x32x16(vf, pf, o, 0, 0, 0);
+        }
+    };
+
+    for (int j0 = 0; j0 < N; j0 += 64) {
+        __syncthreads();  // every wave is done reading the previous tile
+        {   // stage K [64][32] and V^T [32][64] from the prefetched registers
+            *(uint4*)(Ks + skey * 32 + ((sch ^ ((skey >> 2) & 3)) << 3)) = kv_n;
+            const el16_t* ve = (const el16_t*)&vv_n;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) Vt[(sch * 8 + i) * 68 + skey] = ve[i];
+        }
+        if (j0 + 64 < N) fetch(j0 + 64);
+        __syncthreads();
+        const bool fast = a.drop.mode == 0 && j0 + 64 <= N;  // block-uniform
+        if (fast) {
+            subtile(j0, 0, std::true_type{});
+            subtile(j0 + 32, 1, std::true_type{});
+        } else {
+            subtile(j0, 0, std::false_type{});
+            if (j0 + 32 < N) subtile(j0 + 32, 1, std::false_type{});
         }
     }
     if (q >= N) return;
