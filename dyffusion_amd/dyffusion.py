@@ -198,19 +198,24 @@ class DYffusion(nn.Module):
                     f"interpolate time must be in (0, {self.interpolator_horizon}), got {t}"
             steps.append(dict(forecaster_time=ftime, tau=float(s) / (T - 1), i_next=i_next, i_cur=i_cur,
                               is_last=last, out_slot=(out_step - 1) if emits else None))
-        refine = []
-        if hp.refine_intermediate_predictions:
-            times = hp.prediction_timesteps or list(self.dynamical_steps.values())
-            emitted = {st["out_slot"] for st in steps if st["out_slot"] is not None}
-            for i_n in [t for t in times if t < T]:
-                if not float(i_n).is_integer():
-                    raise NotImplementedError("non-integer prediction_timesteps are not supported by the HIP engine")
-                assert int(i_n) - 1 in emitted, f"t{int(i_n)}_preds not in intermediates"
-                refine.append((float(i_n), int(i_n) - 1))
         slots = [st["out_slot"] for st in steps if st["out_slot"] is not None]
         if any(sl < 0 for sl in slots):
             raise NotImplementedError("sampling schedules that emit a t0 prediction are not supported")
-        return steps, refine, max(slots) + 1
+        n_slots = max(slots) + 1
+        refine, extra_keys = [], {}
+        if hp.refine_intermediate_predictions:
+            times = hp.prediction_timesteps or list(self.dynamical_steps.values())
+            emitted = set(slots)
+            for i_n in [t for t in times if t < T]:
+                if float(i_n).is_integer():
+                    assert int(i_n) - 1 in emitted, f"t{int(i_n)}_preds not in intermediates"
+                    refine.append((float(i_n), int(i_n) - 1))
+                else:  # fractional prediction time (dyffusion.py:414-421): a NEW key "t{i_n}_preds", in a slot of its own
+                    extra_keys[n_slots] = f"t{i_n}_preds"
+                    refine.append((float(i_n), n_slots))
+                    n_slots += 1
+        self._extra_keys = extra_keys
+        return steps, refine, n_slots
 
     def _ensure_engine(self, hw, nb: int) -> HipEngine:
         if self._engine is None or (self._engine.height, self._engine.width) != tuple(hw) or self._engine.max_batch < nb:
@@ -245,6 +250,7 @@ class DYffusion(nn.Module):
         hp = self.hparams
         key = (tuple(self.sampling_schedule), hp.sampling_type, hp.use_cold_sampling_for_last_step,
                hp.forward_conditioning, hp.refine_intermediate_predictions, hp.time_encoding,
+               None if hp.prediction_timesteps is None else tuple(hp.prediction_timesteps),
                bool(self.enable_interpolator_dropout), bool(self.enable_forecaster_dropout), id(eng))
         if key == self._plan_key and eng.plan_valid:  # reloading weights invalidates the engine's plan (FiLM tables)
             return
@@ -258,6 +264,8 @@ class DYffusion(nn.Module):
                      forecaster_dropout=bool(self.enable_forecaster_dropout))
         self._plan_key = key
         self._emitted_slots = sorted({st["out_slot"] for st in steps if st["out_slot"] is not None})
+        self._slot_keys = {sl: f"t{sl + 1}_preds" for sl in self._emitted_slots}
+        self._slot_keys.update(self._extra_keys)
 
     # ------------------------------------------------------------------ reference API
     def sample_loop(self, initial_condition: Tensor, static_condition: Optional[Tensor] = None, log_every_t=None,
@@ -267,7 +275,7 @@ class DYffusion(nn.Module):
         eng = self._ensure_engine(initial_condition.shape[-2:], nb)
         self._ensure_plan(eng)
         stack = eng.sample(initial_condition, static_condition, masks=_masks, noise=_noise)
-        intermediates = {f"t{slot + 1}_preds": stack[slot] for slot in self._emitted_slots}
+        intermediates = {key: stack[slot] for slot, key in self._slot_keys.items()}
         x_s = eng.sampler_state(1, nb)
         if self.sampling_schedule[-1] < self.num_timesteps - 1:
             # dyffusion.py:424-425: a schedule that stops before T-1 returns (x_s, intermediates, x_interpolated_s_next)

@@ -190,8 +190,6 @@ class MultiHorizonForecastingDYffusion(nn.Module):
         """Returns {"t{k}_targets": (B, C, H, W), "t{k}_preds": (N, B, C, H, W)} for k = 1..prediction_horizon (torch tensors on
         the GPU, or numpy arrays like the reference with `as_numpy`).  `boundary_conditions(preds=, targets=, metadata=, time=)`
         is applied to every predicted field before it is returned / fed back, exactly where the reference applies it."""
-        if self.window != 1:
-            raise NotImplementedError("autoregressive evaluation is implemented for window == 1 (the shipped configs)")
         dynamics = batch["dynamics"].clone()
         b = dynamics.shape[0]
         h = self.true_horizon
@@ -209,7 +207,7 @@ class MultiHorizonForecastingDYffusion(nn.Module):
             if inputs is None:  # transform_inputs: "b window c lat lon -> b (window c) lat lon", then the ensemble tiling
                 inputs = self.get_ensemble_inputs(batch["dynamics"][:, : self.window].reshape(b, -1, *dynamics.shape[-2:]), n)
             preds = self.predict(inputs, condition=cond, num_predictions=None if ar_step == 0 else 1)
-            last = None
+            ar_window = []  # predictions at the last `window` horizon steps: the next outer iteration's initial condition
             for t_step in self.prediction_timesteps:
                 total_h = ar_step * h + t_step
                 if total_h > prediction_horizon:
@@ -222,9 +220,10 @@ class MultiHorizonForecastingDYffusion(nn.Module):
                 if return_outputs:
                     out[f"t{total_h}_targets"] = conv(targets)
                     out[f"t{total_h}_preds"] = conv(p)
-                last = p
-            if ar_step < n_outer - 1:  # "N B c h w -> (N B) c h w": next initial condition, already ensemble-tiled
-                inputs = last.reshape(-1, *last.shape[-3:]).contiguous()
+                if t_step in self.horizon_range[-self.window:]:  # forecasting_multi_horizon.py:194-197
+                    ar_window.append(p.reshape(-1, *p.shape[-3:]))
+            if ar_step < n_outer - 1:  # "(N B) window c h w -> (N B) (window c) h w": already ensemble-tiled (:218-220)
+                inputs = torch.cat(ar_window, dim=1).contiguous()
                 batch["dynamics"] *= 1e6  # as the reference: "become completely dummy after first multistep prediction"
         return out
 

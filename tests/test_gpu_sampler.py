@@ -23,7 +23,7 @@ pytestmark = pytest.mark.gpu
 TOL = 2.5e-2
 
 NAMES = ["sample_cold_refine", "sample_cold_norefine", "sample_naive", "sample_k2_data", "sample_k2_coldlast",
-         "sample_k2_onlydyn", "sample_k2_plus2", "sample_ens3", "sample_dropout", "sample_datanoise", "sample_linear"]
+         "sample_k2_onlydyn", "sample_k2_plus2", "sample_ens3", "sample_dropout", "sample_datanoise", "sample_linear", "sample_fractional_refine"]
 
 
 @pytest.mark.parametrize("name", NAMES)
@@ -200,6 +200,34 @@ def test_autoregressive_outer_loop_with_boundary_conditions():
         x = last.reshape(N * B, 3, 23, 11)
     assert torch.equal(got["t8_targets"].cpu(), dyn[:, 8])
     print("autoregressive (2 x h=4) worst rel-rms", worst)
+    assert worst <= 2.5e-2
+
+
+def test_autoregressive_outer_loop_with_window_2():
+    """forecasting_multi_horizon.py:194-221 with window = 2: the last TWO predicted fields of an outer iteration, stacked on
+    the channel axis, are the next iteration's initial condition; the interpolator sees (window + 1) * C channels."""
+    import dyffusion_amd as D
+    hp = dict(timesteps=4, forward_conditioning="none", interpolate_before_t1=True, sampling_type="cold",
+              refine_intermediate_predictions=True, enable_interpolator_dropout=False, num_input_channels=3)
+    mk = dict(dim=64, upsample_dims=[64, 64], outer_sample_mode="bilinear", with_time_emb=True, dropout=0.1)
+    PF, PI = seeded_pair(64, 3, 2, window=2)
+    g = torch.Generator().manual_seed(15)
+    B, N, W = 2, 2, 2
+    dyn = torch.randn(B, W + 8, 3, 23, 11, generator=g)
+    cond = torch.rand(B, 2, 23, 11, generator=g)
+    m = build_dyffusion(PF, PI, mk, 3, 2, hp, window=W, max_batch=N * B)
+    exp = D.MultiHorizonForecastingDYffusion(m, num_predictions=N, window=W, prediction_horizon=8)
+    got = exp.evaluation_step({"dynamics": dyn.to(DEV), "condition": cond.to(DEV)})
+    x = dyn[:, :W].reshape(B, W * 3, 23, 11).repeat(N, 1, 1, 1)
+    c = cond.repeat(N, 1, 1, 1)
+    worst = 0.0
+    for ar in range(2):
+        o = oracle_rollout(PF, PI, mk, hp, x, c)
+        for k in range(1, 5):
+            worst = max(worst, rel_rms(got[f"t{ar * 4 + k}_preds"].cpu().reshape(N * B, 3, 23, 11), o[f"t{k}_preds"]))
+        x = torch.cat([o["t3_preds"], o["t4_preds"]], dim=1)
+    assert torch.equal(got["t8_targets"].cpu(), dyn[:, W + 7])
+    print("autoregressive window=2 (2 x h=4) worst rel-rms", worst)
     assert worst <= 2.5e-2
 
 
