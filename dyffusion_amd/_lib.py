@@ -26,7 +26,7 @@ class NetConfig(C.Structure):
                 ("upsample_h", C.c_int32), ("upsample_w", C.c_int32), ("dropout", C.c_float),
                 ("input_dropout", C.c_float), ("n_mults", C.c_int32), ("dim_mults", C.c_int32 * 6),
                 ("block_dropout1", C.c_float), ("attn_dropout", C.c_float), ("groups", C.c_int32),
-                ("init_kernel_size", C.c_int32), ("init_padding", C.c_int32)]
+                ("init_kernel_size", C.c_int32), ("init_padding", C.c_int32), ("outer_nearest", C.c_int32)]
 
 
 class EngineConfig(C.Structure):

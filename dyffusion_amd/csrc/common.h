@@ -238,7 +238,15 @@ __device__ __forceinline__ void act_drop(float* v, uint32_t e0, uint32_t row0, i
 
 // ------------------------------------------------------------------------------------------------ bilinear
 // align_corners=False source coordinate (ATen area_pixel_compute_source_index); oracle: nets.bilinear_resize_explicit
-__device__ __forceinline__ void bilinear_coord(int dst, float scale, int in_size, int& i0, int& i1, float& lam) {
+// nearest = true: F.interpolate(mode="nearest") (ATen nearest_neighbor_compute_source_index: floor(dst * scale), clamped) as
+// the degenerate stencil i0 = i1, lam = 0 -- every consumer of the two-tap form then also evaluates outer_sample_mode="nearest"
+__device__ __forceinline__ void bilinear_coord(int dst, float scale, int in_size, int& i0, int& i1, float& lam, bool nearest = false) {
+    if (nearest) {
+        i0 = min((int)floorf((float)dst * scale), in_size - 1);
+        i1 = i0;
+        lam = 0.0f;
+        return;
+    }
     float src = ((float)dst + 0.5f) * scale - 0.5f;
     src = src < 0.0f ? 0.0f : src;
     i0 = (int)src;

@@ -142,6 +142,7 @@ dyf_status net_forward(dyf_engine* e, int which, const Source* srcs, int nsrc, i
         return fail(e, DYF_ERR_INVALID_ARGUMENT, "channel count of the network inputs does not match its configuration");
     sa.nsrc = nsrc; sa.cin = ctot; sa.n = nb; sa.src_rows = o.src_rows; sa.h = H; sa.w = W; sa.uh = n.uh; sa.uw = n.uw;
     sa.resample = (n.uh != H || n.uw != W) ? 1 : 0;
+    sa.nearest = n.cfg.outer_nearest;
     sa.wgt = n.stem_w; sa.bias = n.stem_b; sa.dim = n.dim;
     const bool fused_stem = n.stem_fused && e->cfg.enable_mfma && e->fuse_stem;
     if (fused_stem) {
@@ -239,7 +240,7 @@ dyf_status net_forward(dyf_engine* e, int which, const Source* srcs, int nsrc, i
     // ---- readout (sparse transposed conv + final resample)
     ReadoutArgs r{};
     r.x = x; r.n = nb; r.ih = lh; r.iw = lw; r.cin = n.dim; r.wgt = n.ro_w; r.wfrag = n.ro_wfrag; r.bias = n.ro_b; r.cout = n.cfg.out_channels;
-    r.oh = H; r.ow = W; r.out = out_dev;
+    r.oh = H; r.ow = W; r.out = out_dev; r.nearest = n.cfg.outer_nearest;
     e->last_dec5_sparse = sparse_out != nullptr;
     r.iw_store = sparse_out ? sparse_out->up_wo_store : lw;
     r.col_map = sparse_out ? sparse_out->up_col_map : nullptr;
@@ -563,6 +564,7 @@ dyf_status dyf_load_weights(dyf_engine* e, int32_t which, int32_t n_tensors, con
                     // the readout's bilinear_coord (common.h) in double, both neighbours of a near-integer coordinate
                     double src = ((double)ox + 0.5) * ((double)tw / (double)ow) - 0.5;
                     if (src < 0.0) src = 0.0;
+                    if (n.cfg.outer_nearest) src = (double)ox * ((double)tw / (double)ow);  // floor(dst * scale): the one column read
                     for (double eps : {-1e-3, 1e-3}) {
                         int v0 = (int)std::floor(std::max(0.0, src + eps));
                         v0 = std::min(v0, tw - 1);

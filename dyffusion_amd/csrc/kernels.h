@@ -44,7 +44,8 @@ struct StemArgs {
     int src_rows;           // rows held by the source tensors (0: = n); output row r reads source row r % src_rows, so
                             // one launch can run the same inputs under several FiLM rows (paired interpolator calls)
     int uh, uw;             // resampled grid (== h, w when there is no outer resampling)
-    int resample;           // 0: identity, 1: bilinear (align_corners=False)
+    int resample;           // 0: identity, 1: resample to (uh, uw)
+    int nearest;            // outer_sample_mode: 0 bilinear (align_corners=False), 1 nearest
     const float* wgt;       // [dim][cin] fp32
     const float* bias;      // [dim]
     int dim;
@@ -94,6 +95,7 @@ struct ReadoutArgs {
     const float* bias;      // [cout]
     int cout;
     int oh, ow;             // native grid
+    int nearest;            // final resample: 0 bilinear, 1 nearest (outer_sample_mode)
     float* out;             // [n][cout][oh][ow]
 };
 hipError_t launch_readout(const ReadoutArgs& a, hipStream_t s);

@@ -107,8 +107,8 @@ __global__ __launch_bounds__(256) void stem_kernel(StemArgs a) {
         int y0 = y, y1 = y, x0 = x, x1 = x;
         float ly = 0.0f, lx = 0.0f;
         if (a.resample) {
-            bilinear_coord(y, (float)a.h / (float)a.uh, a.h, y0, y1, ly);
-            bilinear_coord(x, (float)a.w / (float)a.uw, a.w, x0, x1, lx);
+            bilinear_coord(y, (float)a.h / (float)a.uh, a.h, y0, y1, ly, a.nearest != 0);
+            bilinear_coord(x, (float)a.w / (float)a.uw, a.w, x0, x1, lx, a.nearest != 0);
         }
         int cbase = 0;
         for (int s = 0; s < a.nsrc; ++s) {
@@ -175,8 +175,8 @@ __global__ __launch_bounds__(256) void stem16_kernel(StemArgs a) {
         int y0 = y, y1 = y, x0 = x, x1 = x;
         float ly = 0.0f, lx = 0.0f;
         if (a.resample) {
-            bilinear_coord(y, (float)a.h / (float)a.uh, a.h, y0, y1, ly);
-            bilinear_coord(x, (float)a.w / (float)a.uw, a.w, x0, x1, lx);
+            bilinear_coord(y, (float)a.h / (float)a.uh, a.h, y0, y1, ly, a.nearest != 0);
+            bilinear_coord(x, (float)a.w / (float)a.uw, a.w, x0, x1, lx, a.nearest != 0);
         }
         // channel k of the concatenation lives in source s(k): a static loop over the 16 output slots (the dynamic
         // (source, channel) walk of the first version cost a 16-way select chain per channel)
@@ -345,8 +345,8 @@ __global__ __launch_bounds__(256) void readout_kernel(ReadoutArgs a) {
     const int th = 2 * a.ih, tw = 2 * a.iw;  // transposed-conv output grid
     int u0, u1, v0, v1;
     float lu, lv;
-    bilinear_coord(oy, (float)th / (float)a.oh, th, u0, u1, lu);
-    bilinear_coord(ox, (float)tw / (float)a.ow, tw, v0, v1, lv);
+    bilinear_coord(oy, (float)th / (float)a.oh, th, u0, u1, lu, a.nearest != 0);
+    bilinear_coord(ox, (float)tw / (float)a.ow, tw, v0, v1, lv, a.nearest != 0);
     float acc[DYF_MAX_OUT_CH];
 #pragma unroll
     for (int c = 0; c < DYF_MAX_OUT_CH; ++c) acc[c] = 0.0f;
@@ -405,8 +405,8 @@ __global__ __launch_bounds__(256) void readout_sliced_kernel(ReadoutArgs a) {
     const int th = 2 * a.ih, tw = 2 * a.iw;
     int u0, u1, v0, v1;
     float lu, lv;
-    bilinear_coord(oy, (float)th / (float)a.oh, th, u0, u1, lu);
-    bilinear_coord(ox, (float)tw / (float)a.ow, tw, v0, v1, lv);
+    bilinear_coord(oy, (float)th / (float)a.oh, th, u0, u1, lu, a.nearest != 0);
+    bilinear_coord(ox, (float)tw / (float)a.ow, tw, v0, v1, lv, a.nearest != 0);
     float acc[DYF_MAX_OUT_CH];
 #pragma unroll
     for (int c = 0; c < DYF_MAX_OUT_CH; ++c) acc[c] = 0.0f;
@@ -502,8 +502,8 @@ __global__ __launch_bounds__(256) void readout_regw_kernel(ReadoutArgs a, int px
         const bool live = idx < total;
         int u0, u1, v0, v1;
         float lu, lv;
-        bilinear_coord(oy, sh, th, u0, u1, lu);
-        bilinear_coord(ox, sw, tw, v0, v1, lv);
+        bilinear_coord(oy, sh, th, u0, u1, lu, a.nearest != 0);
+        bilinear_coord(ox, sw, tw, v0, v1, lv, a.nearest != 0);
         // kernel row kh pairs with the neighbour u of parity (kh + 1) & 1: kh = u + 1 - 2 i, i = ((u + 1) >> 1) - (kh >> 1)
         const float wu = ((u0 & 1) == pu ? 1.0f - lu : 0.0f) + ((u1 & 1) == pu ? lu : 0.0f);
         const int u = (u1 & 1) == pu ? u1 : u0;
@@ -600,8 +600,8 @@ __global__ __launch_bounds__(256, 4) void readout_mfma_kernel(ReadoutArgs a, int
         const int oy = rem / a.ow, ox = rem - oy * a.ow;
         int u0, u1, v0, v1;
         float lu, lv;
-        bilinear_coord(oy, sh, th, u0, u1, lu);
-        bilinear_coord(ox, sw, tw, v0, v1, lv);
+        bilinear_coord(oy, sh, th, u0, u1, lu, a.nearest != 0);
+        bilinear_coord(ox, sw, tw, v0, v1, lv, a.nearest != 0);
         // per kernel row / column: byte offset of the input row / column (or -1) and bilinear weight (see readout_regw_kernel)
         int ro[4], co_[4];
         float rw[4], cw[4];

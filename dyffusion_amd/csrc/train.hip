@@ -98,7 +98,7 @@ __global__ void t_nchw_to_nhwc(const float* in, int n, int hw, int C, float* out
 }
 
 // F.interpolate(mode="bilinear", align_corners=False), NHWC fp32
-__global__ void t_resize_fwd(const float* in, int n, int ih, int iw, int C, int oh, int ow, float* out) {
+__global__ void t_resize_fwd(const float* in, int n, int ih, int iw, int C, int oh, int ow, int nearest, float* out) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long long)n * oh * ow * C) return;
     const int c = (int)(i % C);
@@ -106,8 +106,8 @@ __global__ void t_resize_fwd(const float* in, int n, int ih, int iw, int C, int 
     const int ox = (int)(p % ow), oy = (int)((p / ow) % oh), b = (int)(p / ((long long)ow * oh));
     int y0, y1, x0, x1;
     float ly, lx;
-    bilinear_coord(oy, (float)ih / (float)oh, ih, y0, y1, ly);
-    bilinear_coord(ox, (float)iw / (float)ow, iw, x0, x1, lx);
+    bilinear_coord(oy, (float)ih / (float)oh, ih, y0, y1, ly, nearest != 0);
+    bilinear_coord(ox, (float)iw / (float)ow, iw, x0, x1, lx, nearest != 0);
     const float* base = in + (size_t)b * ih * iw * C + c;
     const float v00 = base[((size_t)y0 * iw + x0) * C], v01 = base[((size_t)y0 * iw + x1) * C];
     const float v10 = base[((size_t)y1 * iw + x0) * C], v11 = base[((size_t)y1 * iw + x1) * C];
@@ -116,7 +116,7 @@ __global__ void t_resize_fwd(const float* in, int n, int ih, int iw, int C, int 
 }
 
 // adjoint of t_resize_fwd: din (zero-initialised) += scatter of dout
-__global__ void t_resize_bwd(const float* dout, int n, int ih, int iw, int C, int oh, int ow, float* din) {
+__global__ void t_resize_bwd(const float* dout, int n, int ih, int iw, int C, int oh, int ow, int nearest, float* din) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long long)n * oh * ow * C) return;
     const int c = (int)(i % C);
@@ -124,8 +124,8 @@ __global__ void t_resize_bwd(const float* dout, int n, int ih, int iw, int C, in
     const int ox = (int)(p % ow), oy = (int)((p / ow) % oh), b = (int)(p / ((long long)ow * oh));
     int y0, y1, x0, x1;
     float ly, lx;
-    bilinear_coord(oy, (float)ih / (float)oh, ih, y0, y1, ly);
-    bilinear_coord(ox, (float)iw / (float)ow, iw, x0, x1, lx);
+    bilinear_coord(oy, (float)ih / (float)oh, ih, y0, y1, ly, nearest != 0);
+    bilinear_coord(ox, (float)iw / (float)ow, iw, x0, x1, lx, nearest != 0);
     const float g = dout[i];
     float* base = din + (size_t)b * ih * iw * C + c;
     atomicAdd(base + ((size_t)y0 * iw + x0) * C, g * (1.0f - ly) * (1.0f - lx));
@@ -694,7 +694,7 @@ dyf_status dyf_train_forward(dyf_engine* e, int32_t which, int32_t slot, const f
                        n.cfg.cond_channels, (const float*)nullptr, 0, nb, hw, t.x_in);
     if (n.uh != H || n.uw != W) {
         TA(t.x_up, (size_t)nb * n.uh * n.uw * cin);
-        hipLaunchKernelGGL(t_resize_fwd, dim3(nblk((long long)nb * n.uh * n.uw * cin)), dim3(256), 0, st, t.x_in, nb, H, W, cin, n.uh, n.uw, t.x_up);
+        hipLaunchKernelGGL(t_resize_fwd, dim3(nblk((long long)nb * n.uh * n.uw * cin)), dim3(256), 0, st, t.x_in, nb, H, W, cin, n.uh, n.uw, n.cfg.outer_nearest, t.x_up);
     } else {
         t.x_up = t.x_in;
     }
@@ -713,7 +713,7 @@ dyf_status dyf_train_forward(dyf_engine* e, int32_t which, int32_t slot, const f
         if (b.transposed) {  // x2 bilinear upsample in front of the conv
             float* u = nullptr;
             TA(u, (size_t)nb * b.in_h * b.in_w * b.cin);
-            hipLaunchKernelGGL(t_resize_fwd, dim3(nblk((long long)nb * b.in_h * b.in_w * b.cin)), dim3(256), 0, st, x, nb, lh, lw, b.cin, b.in_h, b.in_w, u);
+            hipLaunchKernelGGL(t_resize_fwd, dim3(nblk((long long)nb * b.in_h * b.in_w * b.cin)), dim3(256), 0, st, x, nb, lh, lw, b.cin, b.in_h, b.in_w, 0, u);
             cx = u;
         }
         t.cin_ptr[i] = (float*)cx;
@@ -755,7 +755,7 @@ dyf_status dyf_train_forward(dyf_engine* e, int32_t which, int32_t slot, const f
     TA(r, (size_t)nb * 4 * lh * lw * C);
     TS(conv_dgrad(e, TConv{nb, 2 * lh, 2 * lw, C, lh, lw, n.dim, 4, 2, 1}, x, w.ro_w, w.ro_b, r, st));
     TA(o, (size_t)nb * hw * C);
-    hipLaunchKernelGGL(t_resize_fwd, dim3(nblk((long long)nb * hw * C)), dim3(256), 0, st, r, nb, 2 * lh, 2 * lw, C, H, W, o);
+    hipLaunchKernelGGL(t_resize_fwd, dim3(nblk((long long)nb * hw * C)), dim3(256), 0, st, r, nb, 2 * lh, 2 * lw, C, H, W, n.cfg.outer_nearest, o);
     hipLaunchKernelGGL(t_nhwc_to_nchw, dim3(nblk((long long)nb * hw * C)), dim3(256), 0, st, o, nb, hw, C, 0, C, out_dev);
     TK(hipGetLastError());
 #undef TA
@@ -783,7 +783,7 @@ dyf_status dyf_train_backward(dyf_engine* e, int32_t slot, const float* dout_dev
     TA(d_o, (size_t)nb * hw * C);
     hipLaunchKernelGGL(t_nchw_to_nhwc, dim3(nblk((long long)nb * hw * C)), dim3(256), 0, st, dout_dev, nb, hw, C, d_o);
     TZ(d_r, (size_t)nb * 4 * lh * lw * C);
-    hipLaunchKernelGGL(t_resize_bwd, dim3(nblk((long long)nb * hw * C)), dim3(256), 0, st, d_o, nb, 2 * lh, 2 * lw, C, H, W, d_r);
+    hipLaunchKernelGGL(t_resize_bwd, dim3(nblk((long long)nb * hw * C)), dim3(256), 0, st, d_o, nb, 2 * lh, 2 * lw, C, H, W, n.cfg.outer_nearest, d_r);
     const TConv gc{nb, 2 * lh, 2 * lw, C, lh, lw, n.dim, 4, 2, 1};
     if (param_grads) {
         TS(conv_wgrad(e, gc, t.xlast, d_r, w.g_ro_w, nullptr, st));
@@ -845,7 +845,7 @@ dyf_status dyf_train_backward(dyf_engine* e, int32_t slot, const float* dout_dev
             const int ph = b.in_h / 2, pw = b.in_w / 2;
             float* dlow = nullptr;
             TZ(dlow, (size_t)nb * ph * pw * b.cin);
-            hipLaunchKernelGGL(t_resize_bwd, dim3(nblk((long long)nb * b.in_h * b.in_w * b.cin)), dim3(256), 0, st, dcx, nb, ph, pw, b.cin, b.in_h, b.in_w, dlow);
+            hipLaunchKernelGGL(t_resize_bwd, dim3(nblk((long long)nb * b.in_h * b.in_w * b.cin)), dim3(256), 0, st, dcx, nb, ph, pw, b.cin, b.in_h, b.in_w, 0, dlow);
             dcx = dlow;
         }
         dy = dcx;  // gradient w.r.t. the previous tensor (block i-1's output, a concat for i in 7..11, the stem for i == 0)
@@ -861,7 +861,7 @@ dyf_status dyf_train_backward(dyf_engine* e, int32_t slot, const float* dout_dev
         float* dxi = dxu;
         if (t.x_up != t.x_in) {
             TZ(dxi, (size_t)nb * hw * cin);
-            hipLaunchKernelGGL(t_resize_bwd, dim3(nblk((long long)nb * n.uh * n.uw * cin)), dim3(256), 0, st, dxu, nb, H, W, cin, n.uh, n.uw, dxi);
+            hipLaunchKernelGGL(t_resize_bwd, dim3(nblk((long long)nb * n.uh * n.uw * cin)), dim3(256), 0, st, dxu, nb, H, W, cin, n.uh, n.uw, n.cfg.outer_nearest, dxi);
         }
         hipLaunchKernelGGL(t_nhwc_to_nchw, dim3(nblk((long long)nb * hw * n.cfg.in_channels)), dim3(256), 0, st, dxi, nb, hw, cin, 0, n.cfg.in_channels, dinputs_dev);
     }

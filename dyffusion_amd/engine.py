@@ -23,12 +23,15 @@ def _raise(status: int, msg: str):
 
 def net_config(*, in_channels: int, cond_channels: int, out_channels: int, dim: int, with_time_emb: bool = True,
                upsample_dims: Optional[Sequence[int]] = (256, 256), dropout: float = 0.0,
-               input_dropout: float = 0.0) -> L.NetConfig:
+               input_dropout: float = 0.0, outer_sample_mode: str = "bilinear") -> L.NetConfig:
     uh, uw = (0, 0) if upsample_dims is None else (int(upsample_dims[0]), int(upsample_dims[1]))
     cfg = L.NetConfig()
     cfg.arch, cfg.in_channels, cfg.cond_channels, cfg.out_channels = L.ARCH_UNET_SIMPLE, in_channels, cond_channels, out_channels
     cfg.dim, cfg.with_time_emb, cfg.upsample_h, cfg.upsample_w = dim, int(bool(with_time_emb)), uh, uw
     cfg.dropout, cfg.input_dropout = float(dropout), float(input_dropout)
+    if outer_sample_mode not in ("bilinear", "nearest"):
+        raise NotImplementedError(f"outer_sample_mode={outer_sample_mode!r}: the HIP engine implements 'bilinear' and 'nearest'")
+    cfg.outer_nearest = int(outer_sample_mode == "nearest")
     return cfg
 
 

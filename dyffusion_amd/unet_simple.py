@@ -41,8 +41,8 @@ class UNet(nn.Module):
                  spatial_shape: Sequence[int] = None, loss_function: str = "mean_squared_error",
                  datamodule_config=None, name: str = "", verbose: bool = True):
         super().__init__()
-        if outer_sample_mode != "bilinear":
-            raise NotImplementedError("the HIP engine implements outer_sample_mode='bilinear' (the shipped configs' value)")
+        if outer_sample_mode not in ("bilinear", "nearest"):
+            raise NotImplementedError("the HIP engine implements outer_sample_mode 'bilinear' and 'nearest'")
         self.hparams = _AttrDict(dim=dim, with_time_emb=with_time_emb, outer_sample_mode=outer_sample_mode,
                                  upsample_dims=None if upsample_dims is None else tuple(upsample_dims), dropout=dropout,
                                  input_dropout=input_dropout, num_input_channels=num_input_channels,
@@ -88,7 +88,8 @@ class UNet(nn.Module):
         hp = self.hparams
         return net_config(in_channels=self.num_input_channels, cond_channels=self.num_conditional_channels,
                           out_channels=self.num_output_channels, dim=hp.dim, with_time_emb=hp.with_time_emb,
-                          upsample_dims=hp.upsample_dims, dropout=hp.dropout, input_dropout=hp.input_dropout)
+                          upsample_dims=hp.upsample_dims, dropout=hp.dropout, input_dropout=hp.input_dropout,
+                          outer_sample_mode=hp.outer_sample_mode)
 
     @property
     def has_dropout(self) -> bool:

@@ -73,6 +73,8 @@ typedef struct dyf_net_config {
     int32_t groups;           /* resnet_block_groups */
     int32_t init_kernel_size; /* 7 */
     int32_t init_padding;     /* 3 */
+    int32_t outer_nearest;    /* unet_simple outer_sample_mode: 0 "bilinear", 1 "nearest" (upsampler + final F.interpolate,
+                               * unet_simple.py:103,195) */
 } dyf_net_config;
 
 typedef enum dyf_dtype_id { DYF_DTYPE_BF16 = 0, DYF_DTYPE_F16 = 1 } dyf_dtype_id;

@@ -140,9 +140,16 @@ def gen_nets():
                                    dropout=0.3)),
         ("net_unet_simple_c", dict(dim=8, upsample_dims=[128, 64], n_in=3, n_cond=0, n_out=2, hw=(40, 17), nb=1,
                                    dropout=0.1)),
+        # outer_sample_mode="nearest" (unet_simple.py:172-179): both outer resamples pick the floor(dst * in/out) source
+        ("net_unet_simple_d", dict(dim=8, upsample_dims=[64, 64], n_in=5, n_cond=1, n_out=3, hw=(23, 11), nb=2,
+                                   dropout=0.2, mode="nearest")),
     ]
+    only = os.environ.get("DYF_GOLDEN_ONLY")
     for name, sp in specs:
-        net = UNet(dim=sp["dim"], with_time_emb=True, outer_sample_mode="bilinear", upsample_dims=sp["upsample_dims"],
+        if only and name != only:
+            continue
+        mode = sp.get("mode", "bilinear")
+        net = UNet(dim=sp["dim"], with_time_emb=True, outer_sample_mode=mode, upsample_dims=sp["upsample_dims"],
                    dropout=sp["dropout"], input_dropout=0.0, num_input_channels=sp["n_in"],
                    num_output_channels=sp["n_out"], num_conditional_channels=sp["n_cond"], spatial_shape=sp["hw"],
                    loss_function="mse", verbose=False).eval()
@@ -162,13 +169,15 @@ def gen_nets():
                 y_drop = net(x, time=t, condition=c)
         arrs = dict(np_state(net.state_dict()), x=x.numpy(), t=t.numpy(), y_eval=y_eval.numpy(),
                     y_drop=y_drop.numpy(), dropout_seed=np.int64(77),
-                    cfg=json.dumps(dict(dim=sp["dim"], upsample_dims=sp["upsample_dims"], outer_sample_mode="bilinear",
+                    cfg=json.dumps(dict(dim=sp["dim"], upsample_dims=sp["upsample_dims"], outer_sample_mode=mode,
                                         with_time_emb=True, dropout=sp["dropout"], input_dropout=0.0)))
         if c is not None:
             arrs["c"] = c.numpy()
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **arrs)
         print(name, "y_eval std", float(y_eval.std()), "y_drop std", float(y_drop.std()))
 
+    if only:
+        return
     # SimpleConvNet (spring-mesh plumbing config)
     net = SimpleConvNet(dim=8, with_time_emb=True, kernel_sizes=[9, 7, 5, 3], dropout=0.1, num_input_channels=8,
                         num_output_channels=4, num_conditional_channels=1, spatial_shape=(10, 10),

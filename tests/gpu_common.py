@@ -14,7 +14,7 @@ DEV = "cuda:0"
 
 def mirror_from_params(P, cfg, n_in, n_cond, n_out):
     net = D.UNet(dim=cfg["dim"], with_time_emb=cfg.get("with_time_emb", True), upsample_dims=cfg.get("upsample_dims"),
-                 dropout=cfg.get("dropout", 0.0), input_dropout=cfg.get("input_dropout", 0.0), num_input_channels=n_in,
+                 outer_sample_mode=cfg.get("outer_sample_mode", "bilinear"), dropout=cfg.get("dropout", 0.0), input_dropout=cfg.get("input_dropout", 0.0), num_input_channels=n_in,
                  num_output_channels=n_out, num_conditional_channels=n_cond)
     net.load_state_dict(P, strict=True)
     return net

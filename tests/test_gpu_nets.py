@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-2
 
 
-@pytest.mark.parametrize("name", ["net_unet_simple_a", "net_unet_simple_b", "net_unet_simple_c"])
+@pytest.mark.parametrize("name", ["net_unet_simple_a", "net_unet_simple_b", "net_unet_simple_c", "net_unet_simple_d"])
 def test_small_nets_match_reference_goldens(name):
     """dim 4/8 networks straight from the reference's own outputs (direct-conv path: channels < 64)."""
     z = load_npz(name + ".npz")
@@ -42,10 +42,13 @@ def test_small_nets_match_reference_goldens(name):
     assert err <= TOL
 
 
-@pytest.mark.parametrize("hw,up,nb,n_in,n_cond", [((23, 11), (64, 64), 3, 6, 2), ((40, 17), (128, 64), 2, 3, 2),
-                                                   ((32, 32), None, 2, 3, 0)])
-def test_dim64_mfma_path_matches_oracle(hw, up, nb, n_in, n_cond):
-    cfg = dict(dim=64, upsample_dims=None if up is None else list(up), outer_sample_mode="bilinear", with_time_emb=True,
+@pytest.mark.parametrize("hw,up,nb,n_in,n_cond,mode", [((23, 11), (64, 64), 3, 6, 2, "bilinear"),
+                                                        ((40, 17), (128, 64), 2, 3, 2, "bilinear"),
+                                                        ((32, 32), None, 2, 3, 0, "bilinear"),
+                                                        ((23, 11), (64, 64), 3, 6, 2, "nearest"),
+                                                        ((221, 42), (256, 256), 1, 3, 2, "nearest")])
+def test_dim64_mfma_path_matches_oracle(hw, up, nb, n_in, n_cond, mode):
+    cfg = dict(dim=64, upsample_dims=None if up is None else list(up), outer_sample_mode=mode, with_time_emb=True,
                dropout=0.15, input_dropout=0.0)
     if up is None:
         hw = (64, 64)

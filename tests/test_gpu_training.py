@@ -52,11 +52,14 @@ def _oracle_step(PF, PI, mk, hp, xt_last, cond, t, sc, seed):
     return out, {k: v.grad for k, v in PFg.items() if torch.is_tensor(v) and v.requires_grad}, bn_batches
 
 
-@pytest.mark.parametrize("name", ["plosses_train_a", "plosses_train_b"])
-def test_training_step_matches_autograd_of_the_oracle(name):
+@pytest.mark.parametrize("name,mode", [("plosses_train_a", "bilinear"), ("plosses_train_b", "bilinear"),
+                                       ("plosses_train_a", "nearest")])
+def test_training_step_matches_autograd_of_the_oracle(name, mode):
+    """`mode`: the outer_sample_mode of both networks (the nearest case reuses the fixture's weights and inputs; the oracle's
+    nearest forward is pinned by net_unet_simple_d.npz, its gradients by torch.autograd)."""
     z = load_npz(name + ".npz")
     hp = json.loads(str(z["hp"]))
-    mk = hp["model"]
+    mk = dict(hp["model"], outer_sample_mode=mode)
     PF, PI = split_state(z, "F"), split_state(z, "I")
     xt_last, cond, sc, t = (torch.from_numpy(z[k]) for k in ("xt_last", "cond", "sc", "t"))
     m = build_dyffusion(PF, PI, mk, 4, 1, hp, max_batch=hp["B"])
@@ -77,7 +80,7 @@ def test_training_step_matches_autograd_of_the_oracle(name):
     assert worst <= 1e-3
     # the reference's own gradients (different dropout masks) have the same scale: a sanity anchor, not a parity check
     G = split_state(z, "G")
-    assert 0.5 <= gn / float(torch.cat([g.reshape(-1) for g in G.values()]).norm()) <= 2.0
+    assert mode != "bilinear" or 0.5 <= gn / float(torch.cat([g.reshape(-1) for g in G.values()]).norm()) <= 2.0
     # BatchNorm buffers as module.train() leaves them: two forecaster passes -> two momentum-0.1 updates
     sd = m.model.state_dict()
     n_pass = 2 if hp["lambda_reconstruction2"] > 0 else 1

@@ -11,7 +11,7 @@ from tests.helpers import load_npz, max_abs, split_state
 TOL = 2e-6  # fp32, same ATen primitives as the reference -> agreement to rounding
 
 
-@pytest.mark.parametrize("name", ["net_unet_simple_a", "net_unet_simple_b", "net_unet_simple_c"])
+@pytest.mark.parametrize("name", ["net_unet_simple_a", "net_unet_simple_b", "net_unet_simple_c", "net_unet_simple_d"])
 def test_unet_simple_matches_reference(name):
     z = load_npz(name + ".npz")
     P = split_state(z, "P")
