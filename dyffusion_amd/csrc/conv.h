@@ -64,7 +64,16 @@ void pack_up2x_weights(const float* w, int cout, int cin, el16_t* out);
 bool conv_up_halo_supported(const ConvArgs& a);
 void pack_up2x_frag(const el16_t* wpk_up, int cout, int cin, el16_t* out);
 bool plan_up_sparse_columns(const std::vector<uint8_t>& needed, int w, std::vector<int16_t>& cols, std::vector<int16_t>& cbase,
-                            std::vector<int16_t>& cidx, std::vector<int16_t>& col_map, int& ntiles, int& nvalid0, int& nvalid1);
+                            std::vector<int16_t>& cidx, std::vector<int16_t>& col_map, int& ntiles, int& nvalid0, int& nvalid1,
+                            int slots = 16);
+// rows form of the halo kernels (conv_halo_rows.hip): 4 x 32 low-res tiles, one-row MFMA pixel tiles
+int conv_halo_rows_slots();
+int conv_halo_rows_sparse_halo_w();
+bool conv_halo_rows_up_supported(const ConvArgs& a);   // in addition to conv_up_halo_supported
+bool conv_halo_rows3_supported(const ConvArgs& a);     // in addition to conv_halo3_supported (h % 8 / w % 16 not needed)
+hipError_t conv_halo_rows_init();
+hipError_t launch_conv_halo_rows_up(const ConvArgs& a, hipStream_t stream);  // main kernel only (after up_border_kernel)
+hipError_t launch_conv_halo_rows3(const ConvArgs& a, hipStream_t stream);
 hipError_t conv_up_halo_init();
 hipError_t launch_conv_up_halo(const ConvArgs& a, hipStream_t stream);
 // plain 3x3 / stride 1 / pad 1 conv on the halo kernel (conv_up_halo.hip, SP = 2): cout % 256 == 0, h % 8 == 0, w % 16 == 0;

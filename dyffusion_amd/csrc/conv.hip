@@ -616,6 +616,7 @@ hipError_t conv_init() {
     SET_LDS(128, 128, 2, 2, 0) SET_LDS(128, 128, 2, 2, 1) SET_LDS(256, 64, 4, 1, 0) SET_LDS(256, 64, 4, 1, 1)
 #undef SET_LDS
     if (e == hipSuccess) e = conv_up_halo_init();
+    if (e == hipSuccess) e = conv_halo_rows_init();
     if (e == hipSuccess) e = conv_igemm2_init();
     return e;
 }
@@ -634,20 +635,23 @@ hipError_t launch_conv(const ConvArgs& a, int path, hipStream_t stream) {
         // plain 3x3 / s1 convs with cout % 256 == 0 on 8x16-tileable planes: the halo kernel (one window DMA per chunk
         // instead of one gather per tap); DYF_HALO3=0 disables, DYF_HALO3_MIN_TILES sets the smallest launch (default 256
         // tiles: measured at NB = 80, enc3 with 320 tiles 115 -> 94 us)
-        if (!a.up2x && a.kh == 3 && a.kw == 3 && a.cout % 256 == 0 && a.out_f32 == nullptr && a.residual == nullptr) {
+        static const bool h5_all = getenv("DYF_HALO5_ALL") && atoi(getenv("DYF_HALO5_ALL")) != 0;
+        if (!a.up2x && a.kh == 3 && a.kw == 3 && a.cout % 256 == 0 && !h5_all && a.out_f32 == nullptr && a.residual == nullptr) {
             const char* h3 = getenv("DYF_HALO3");
             if (!(h3 && atoi(h3) == 0)) {
                 ConvArgs b = a;
                 b.wpk_up_frag = conv_lookup_halo3_frag(b.wpk);
                 const char* mt3 = getenv("DYF_HALO3_MIN_TILES");
                 const long long tiles3 = (nsel * a.h * a.w / 128) * (a.cout / 256);
-                if (b.wpk_up_frag && tiles3 >= (mt3 ? atoll(mt3) : 256) && conv_halo3_supported(b)) return launch_conv_halo3(b, stream);
+                static const bool rows = !(getenv("DYF_HALO_ROWS") && atoi(getenv("DYF_HALO_ROWS")) == 0);
+                if (b.wpk_up_frag && tiles3 >= (mt3 ? atoll(mt3) : 256) && conv_halo3_supported(b))
+                    return rows && conv_halo_rows3_supported(b) ? launch_conv_halo_rows3(b, stream) : launch_conv_halo3(b, stream);
             }
         }
         // 3x3 / s1 convs with 64 or 128 (any multiple of 64 that is not one of 256) output channels -- the ResNet-UNet levels --
         // on planes of any size: SP = 5 of the halo kernel, when the 16 x 32 tiles cover the plane reasonably (>= 60 %: not
         // 15 x 15) and fill the chip.  DYF_HALO5=0 disables, DYF_HALO5_MIN_TILES sets the smallest launch.
-        if (!a.up2x && a.kh == 3 && a.kw == 3 && a.stride == 1 && a.cout % 64 == 0 && a.cout % 256 != 0 && a.out_f32 == nullptr &&
+        if (!a.up2x && a.kh == 3 && a.kw == 3 && a.stride == 1 && a.cout % 64 == 0 && (a.cout % 256 != 0 || h5_all) && a.out_f32 == nullptr &&
             a.residual == nullptr) {
             static const bool h5 = !(getenv("DYF_HALO5") && atoi(getenv("DYF_HALO5")) == 0);
             static const long long h5_min = getenv("DYF_HALO5_MIN_TILES") ? atoll(getenv("DYF_HALO5_MIN_TILES")) : 256;

@@ -1,0 +1,381 @@
+// "Rows" form of the halo convolution (gfx950): the same fused x2-bilinear-upsample + 3x3 conv (SP = 0 dense, SP = 1 sparse
+// output columns) and plain 3x3 / stride 1 / pad 1 conv with 256-channel blocks (SP = 2) as conv_up_halo.hip, same weight
+// fragment streams (pack_up2x_frag / pack_halo3_frag), same border ring (up_border_kernel), same epilogue -- with the pixel
+// tile of an MFMA turned from 2 rows x 16 columns into ONE ROW of 32 columns, a wave owning 4 rows x 32 columns.
+//
+// Why: conv_up_halo_kernel runs the same instruction stream at 1 290 TFLOP/s on real activations and at 1 750 on all-zero
+// operands (tools/scratch experiments): the package is power-limited, and what the kernel can still save is
+// operand traffic.  Dropping half of the pixel-fragment LDS reads (timing experiment, wrong results) was worth 18-20 % on
+// dec2 / dec3 and 11 % on dec4.  With 2 x 16 pixel tiles every (tile, tap) pair reads its own fragment: 36 reads per k16
+// sub-step of a chunk.  With one-row tiles the fragment of halo row r at horizontal shift dx IS the operand of tile row r - dy
+// for all three dy: 6 halo rows x 3 shifts = 18 reads feed the same 36 (tile, tap) products -- half the LDS traffic, and one
+// v_xad_u32 of address arithmetic per 6 reads (the rows are an immediate offset apart; the swizzle key depends on the halo
+// COLUMN only, which is also conflict-free for the four 16-lane groups a ds_read_b128 is serviced in).
+//
+// K loop per 64-channel chunk: 12 super-slots (dx, ks), each 3 mini-slots (dy) of 8 MFMAs = 2 weight fragments x 4 tile
+// rows; the weight ring (6 sets, 5 mini-slots ahead) is the one of conv_up_halo_kernel, addressed (tap, ks) directly; the 6
+// row fragments of super-slot s + 1 are read, two per mini-slot, during super-slot s.
+#include "conv.h"
+
+#include <algorithm>
+#include <type_traits>
+#include <vector>
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+
+namespace {
+
+constexpr int R_TH = 4, R_TW = 32, R_NWAVES = 4;
+constexpr int R_STEP_BYTES = 32768;  // weights of one (tap, chunk) step: 256 columns x 64 k
+
+template <int SP>
+struct RowsCfg {
+    static constexpr int W = SP == 1 ? 72 : 34;       // halo width in pixels (SP 1: span of a 32-entry column list)
+    static constexpr int REAL = (R_TH + 2) * W;       // 204 / 432
+    static constexpr int PIX = (REAL + 7) / 8 * 8;    // padded to whole DMA instructions (8 pixels each)
+    static constexpr int BYTES = PIX * 128;           // 26 624 / 55 296
+    static constexpr int NBUF = SP == 1 ? 1 : 2;
+    static constexpr bool PLAIN = SP == 2;
+    static constexpr int INSTR = PIX / 8;             // 26 / 54
+    static constexpr int PER_WAVE = (INSTR + R_NWAVES - 1) / R_NWAVES;
+    static constexpr int HOFF_OFF = NBUF * BYTES;     // per-thread halo source offsets [PER_WAVE][256]
+    static constexpr int LDS_TOTAL = HOFF_OFF + PER_WAVE * 1024;  // 60 416 / 69 632 B: two workgroups per CU
+    static constexpr int ROW_BYTES = W * 128;
+};
+
+// weight offset of mini-slot g = (dx * 4 + ks) * 3 + dy inside a chunk's 16-tap block: tap (dy, dx) step, k16 sub-step ks
+constexpr unsigned rows_woff(int g) { return (unsigned)(((g % 3) * 3 + g / 12) * R_STEP_BYTES + ((g / 3) % 4) * 4096); }
+
+}  // namespace
+
+template <int SP>
+__global__ __launch_bounds__(256, 2) void conv_halo_rows_kernel(ConvArgs a, int tiles_x, int tiles_per_img, int tiles_m, int tiles_n) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    using H = RowsCfg<SP>;
+    constexpr int HALO_W = H::W, HALO_REAL = H::REAL, HALO_BYTES = H::BYTES;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int wpy = wave >> 1, wpx = wave & 1;  // output phase of this wave (upsample forms)
+
+    // XCD-aware tile id; the column blocks of one tile are consecutive (they share the halo in L2)
+    const int total = tiles_m * tiles_n;
+    const int bid = blockIdx.x;
+    const int xq = total >> 3, xr = total & 7, xcd = bid & 7;
+    const int tile = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
+    const int tn = tile % tiles_n, tm = tile / tiles_n;
+    const int n_img = tm / tiles_per_img;
+    const int t_in = tm - n_img * tiles_per_img;
+    const int ty0 = (t_in / tiles_x) * R_TH;
+    const int lx = t_in % tiles_x;  // column tile: 32 contiguous columns, or 32 entries of the column lists
+    int col, cbase, cstore = 0;
+    bool lane_valid = true;
+    if (SP == 1) {
+        cbase = a.up_cbase[lx];
+        const int entry = a.up_cols[wpx * a.up_npad + lx * 32 + l31];  // bit 14: padding entry (computed, not stored)
+        col = entry & 0x3FFF;
+        lane_valid = (entry & 0x4000) == 0;
+        cstore = a.up_cidx[wpx * a.up_npad + lx * 32 + l31];
+    } else {
+        cbase = lx * R_TW - 1;
+        col = lx * R_TW + l31;
+    }
+
+    const int cin = a.c0 + a.c1;
+    const int cpt = cin >> 6;
+    const int gh = a.h, gw = a.w;
+    const size_t npix = (size_t)a.n * a.h * a.w;
+    const auto rsrc_a0 = __builtin_amdgcn_make_buffer_rsrc((void*)a.src0, 0, (int)(unsigned)(npix * a.c0 * 2), 0x00020000);
+    const auto rsrc_a1 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.c1 ? a.src1 : a.src0), 0,
+                                                           (int)(unsigned)(npix * (a.c1 ? a.c1 : a.c0) * 2), 0x00020000);
+    const auto rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.wpk_up_frag, 0,
+                                                          (int)(unsigned)((size_t)(H::PLAIN ? 1 : 4) * a.cout * 16 * cin * 2), 0x00020000);
+
+    // LDS swizzle key of halo column hx (XORed into the 16-B chunk index of the pixel's 128-B row).  A ds_read_b128 of 32
+    // consecutive pixels of one halo row is serviced in four 16-lane groups ({0-3,12-15,20-27}, ...): with this key every group
+    // touches each of the 64 banks once, for every horizontal shift.
+#define HKEY(hx) (((hx) >> 1) & 7)
+    // ---- halo DMA: instruction i (i % 4 == wave) fills halo pixels [8i, 8i+8); lane -> (pixel, 16-B chunk); the per-lane
+    // source offsets are parked in LDS (the K loop needs every VGPR)
+    const int sub = lane >> 3;
+    unsigned* h_tab = (unsigned*)(smem + H::HOFF_OFF) + tid;
+#pragma unroll
+    for (int j = 0; j < H::PER_WAVE; ++j) {
+        const int i = j * R_NWAVES + wave;
+        int hp = i * 8 + sub;
+        if (hp > HALO_REAL - 1) hp = HALO_REAL - 1;  // padding slots re-read the last halo pixel
+        const int hy = hp / HALO_W, hx = hp - hy * HALO_W;
+        const int yy = ty0 - 1 + hy, xx = cbase + hx;
+        const int y = min(max(yy, 0), gh - 1), x = min(max(xx, 0), gw - 1);  // replicate clamp (upsample forms)
+        const int gch = (lane & 7) ^ HKEY(hx);
+        unsigned off = (unsigned)((n_img * a.h + y) * a.w + x) * (unsigned)(a.c0 * 2) + gch * 16;  // c0 == c1 (checked on host)
+        if (H::PLAIN && (yy != y || xx != x)) off = 0xFFFFFFFFu;  // plain convs: zero padding = out-of-range DMA offset
+        h_tab[j * 256] = off;
+    }
+    auto issue_halo = [&](int chunk) {
+        const int cb = chunk << 6;
+        const bool second = cb >= a.c0;
+        const unsigned coff = (unsigned)((second ? cb - a.c0 : cb) * 2);
+        char* dst = smem + (H::NBUF == 2 ? (chunk & 1) * HALO_BYTES : 0);
+#pragma unroll
+        for (int j = 0; j < H::PER_WAVE; ++j) {
+            const int i = j * R_NWAVES + wave;
+            if (i < H::INSTR) {
+                unsigned vo = h_tab[j * 256];
+                if (!H::PLAIN || vo != 0xFFFFFFFFu) vo += coff;
+                if (second)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a1, LDS_PTR(dst + i * 1024), 16, vo, 0, 0, 0);
+                else
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a0, LDS_PTR(dst + i * 1024), 16, vo, 0, 0, 0);
+            }
+        }
+    };
+
+    f32x16 acc[2][4];  // [32-channel half][tile row]
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nt][t][r] = 0.0f;
+    if (!H::PLAIN) {
+        // border pixels of the OUTPUT start from the correction sums of up_border_kernel (ring index: top row, bottom row,
+        // left column, right column); lane (l31, hi) holds channels nt*32 + 8*g + 4*hi + {0..3} of its pixel
+        const bool edge_col = col == 0 || col == gw - 1;
+        if (ty0 == 0 || ty0 + R_TH == gh || __builtin_amdgcn_ballot_w64(edge_col) != 0ull) {
+            const int ring_len = 2 * a.wo + 2 * (a.ho - 2);
+            const int X = 2 * col + wpx;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int Y = 2 * (ty0 + t) + wpy;
+                int ring = -1;
+                if (Y == 0) ring = X;
+                else if (Y == a.ho - 1) ring = a.wo + X;
+                else if (X == 0) ring = 2 * a.wo + Y - 1;
+                else if (X == a.wo - 1) ring = 2 * a.wo + (a.ho - 2) + Y - 1;
+                if (ring >= 0) {
+                    const float* cp = a.up_border + ((size_t)n_img * ring_len + ring) * a.cout + tn * 64 + 4 * hi;
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const float4 v = *(const float4*)(cp + nt * 32 + 8 * g);
+                            acc[nt][t][4 * g + 0] = v.x; acc[nt][t][4 * g + 1] = v.y;
+                            acc[nt][t][4 * g + 2] = v.z; acc[nt][t][4 * g + 3] = v.w;
+                        }
+                }
+            }
+        }
+    }
+
+    int cl = col - cbase;  // halo column of this lane's pixel at dx = 0 (>= 1); halo row of tile row t at dy = 0 is t + 1
+    const unsigned lds_base = (unsigned)(uintptr_t)LDS_PTR(smem);
+    const unsigned w_voff = (unsigned)lane * 16u;
+
+    u32x4 bq[6][2];     // weight fragments: ring of 6 sets, 5 mini-slots ahead
+    el16x8_t pq[2][6];  // pixel fragments: halo rows 0..5 of the current / next super-slot
+    unsigned ab = 0, ax = 0, pa = 0;
+
+#define ISSUE_B(SET, SOFF)                                                                                   \
+    _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                                         \
+        bq[SET][nt] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, w_voff + nt * 1024, (SOFF), 0);
+#define DSRO(dst, addr, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
+#define LGKM_WAIT0                                                        \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                    \
+    __builtin_amdgcn_sched_barrier(0);
+#define PIN __builtin_amdgcn_sched_barrier(0);
+    // LDS address of the row-0 fragment of super-slot SN = dx * 4 + ks: pixel column cl + dx - 1, k16 sub-step ks
+#define PADDR(SN)                                                                                            \
+    {                                                                                                        \
+        if (((SN) & 3) == 0) {                                                                               \
+            int c = cl + ((SN) >> 2) - 1;                                                                    \
+            asm volatile("" : "+v"(c)); /* opaque: keeps the addresses of all shifts from being hoisted */   \
+            ab = Hs + (unsigned)c * 128u;                                                                    \
+            ax = (unsigned)((hi ^ HKEY(c)) << 4);                                                            \
+        }                                                                                                    \
+        pa = (ax ^ (unsigned)(((SN) & 3) << 5)) + ab;                                                        \
+    }
+#define RD(SET, R) DSRO(pq[SET][R], pa, (R) * H::ROW_BYTES)
+#define MF(NT, T, ASET, BSET, DY)                                                                            \
+    acc[NT][T] = DYF_MFMA_32x32x16(__builtin_bit_cast(el16x8_t, bq[BSET][NT]), pq[ASET][(T) + (DY)], acc[NT][T], 0, 0, 0);
+    // mini-slot G of the chunk (dy = G % 3): 8 MFMAs on ring set G % 6; requests the fragments of mini-slot G + 5
+#define WSRC(G) ((G) < 36 ? soff_c + rows_woff((G) % 36) : soff_n + rows_woff((G) % 36))
+#define MS(G, ASET, LSET, R0, R1, LOAD, WAITL)                                                               \
+    {                                                                                                        \
+        if (WAITL) { LGKM_WAIT0 }                                                                            \
+        ISSUE_B(((G) + 5) % 6, WSRC((G) + 5))                                                                \
+        MF(0, 0, ASET, (G) % 6, (G) % 3) PIN                                                                 \
+        if (LOAD) { RD(LSET, R0) }                                                                           \
+        MF(0, 1, ASET, (G) % 6, (G) % 3) PIN                                                                 \
+        if (LOAD) { RD(LSET, R1) }                                                                           \
+        MF(0, 2, ASET, (G) % 6, (G) % 3) PIN                                                                 \
+        MF(0, 3, ASET, (G) % 6, (G) % 3) PIN                                                                 \
+        MF(1, 0, ASET, (G) % 6, (G) % 3) MF(1, 1, ASET, (G) % 6, (G) % 3)                                    \
+        MF(1, 2, ASET, (G) % 6, (G) % 3) MF(1, 3, ASET, (G) % 6, (G) % 3) PIN                                \
+    }
+    // super-slot S: uses pq[S & 1], fetches the row fragments of super-slot S + 1 into pq[(S + 1) & 1]
+#define SS(S, LOAD)                                                                                          \
+    {                                                                                                        \
+        LGKM_WAIT0                                                                                           \
+        if (LOAD) PADDR((S) + 1)                                                                             \
+        MS(3 * (S) + 0, (S) & 1, ((S) + 1) & 1, 0, 1, LOAD, false)                                           \
+        MS(3 * (S) + 1, (S) & 1, ((S) + 1) & 1, 2, 3, LOAD, false)                                           \
+        MS(3 * (S) + 2, (S) & 1, ((S) + 1) & 1, 4, 5, LOAD, false)                                           \
+    }
+
+    issue_halo(0);
+    const unsigned soff_w = (unsigned)(wpy * (R_STEP_BYTES / 2) + wpx * 2048);
+    unsigned soff_c = (unsigned)((tn * cpt) * 16) * (unsigned)R_STEP_BYTES + soff_w, soff_n = soff_c;
+    // (pinned in program order: the compiler's own vmcnt at the loop head is merged over the entry and the back edge)
+    PIN
+    ISSUE_B(0, soff_c + rows_woff(0)) PIN
+    ISSUE_B(1, soff_c + rows_woff(1)) PIN
+    ISSUE_B(2, soff_c + rows_woff(2)) PIN
+    ISSUE_B(3, soff_c + rows_woff(3)) PIN
+    ISSUE_B(4, soff_c + rows_woff(4)) PIN
+    for (int chunk = 0; chunk < cpt; ++chunk) {
+        if (H::NBUF == 2) {
+            // halo of this chunk landed (everything older than the 10 weight loads in flight), every wave is done with the
+            // other buffer -> prefetch the next chunk's halo into it
+            asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            if (chunk + 1 < cpt) issue_halo(chunk + 1);
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const unsigned Hs = lds_base + (H::NBUF == 2 ? (chunk & 1) * HALO_BYTES : 0);
+        asm volatile("" : "+v"(cl));  // keep the LDS addresses from being hoisted out of the chunk loop
+        soff_n = chunk + 1 < cpt ? soff_c + 16u * (unsigned)R_STEP_BYTES : soff_c;  // tail: harmless re-fetch
+        PADDR(0)
+        RD(0, 0) RD(0, 1) RD(0, 2) RD(0, 3) RD(0, 4) RD(0, 5)
+        SS(0, true) SS(1, true) SS(2, true) SS(3, true)
+        SS(4, true) SS(5, true) SS(6, true) SS(7, true)
+        SS(8, true) SS(9, true) SS(10, true) SS(11, false)
+        soff_c = soff_n;
+        if (H::NBUF == 1 && chunk + 1 < cpt) {  // single buffer: every wave is done reading -> request the next chunk's halo
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            issue_halo(chunk + 1);
+        }
+    }
+#undef SS
+#undef MS
+#undef WSRC
+#undef MF
+#undef RD
+#undef PADDR
+#undef PIN
+#undef LGKM_WAIT0
+#undef DSRO
+#undef ISSUE_B
+
+    // ---- epilogue straight from the accumulators (conv_up_halo_kernel's, with tile rows instead of row pairs).  Lane (l31, hi)
+    // of tile (nt, t) holds pixel (row t, column l31) and channels nt*32 + 8*g + 4*hi + {0..3}.
+    const RngKey key = drop_row_key(a.drop, n_img);
+    const uint32_t row0 = (uint32_t)n_img * (uint32_t)(a.ho * a.wo * a.cout);
+    const int ch_blk = H::PLAIN ? tn * 256 + wave * 64 : tn * 64;
+    const uint32_t ci_base = (uint32_t)((a.coef_div > 1 ? n_img / a.coef_div : n_img) * a.coef_stride + ch_blk + 4 * hi);
+    const uint32_t m0 = H::PLAIN ? (uint32_t)((n_img * a.ho + ty0) * a.wo + col)
+                                : (uint32_t)((n_img * a.ho + 2 * ty0 + wpy) * a.wo + 2 * col + wpx);
+    const uint32_t o0 = m0 * (uint32_t)a.cout + (uint32_t)ch_blk;
+    const uint32_t t_stride = (uint32_t)((H::PLAIN ? 1 : 2) * a.wo * a.cout);
+    const uint32_t store0 = SP == 1 ? (uint32_t)((n_img * a.ho + 2 * ty0 + wpy) * a.up_wo_store + cstore) * (uint32_t)a.cout +
+                                          (uint32_t)(tn * 64)
+                                    : o0;
+    const uint32_t st_stride = SP == 1 ? (uint32_t)(2 * a.up_wo_store * a.cout) : t_stride;
+    auto epilogue = [&](auto act_c, auto mode_c) {
+        constexpr int ACT = decltype(act_c)::value, MODE = decltype(mode_c)::value;
+#pragma unroll
+        for (int hg = 0; hg < 4; ++hg) {
+            const int cg0 = (hg >> 1) * 32 + 16 * (hg & 1);
+            const float4 ca0 = *(const float4*)(a.coef_a + ci_base + cg0), ca1 = *(const float4*)(a.coef_a + ci_base + cg0 + 8);
+            const float4 cc0 = *(const float4*)(a.coef_c + ci_base + cg0), cc1 = *(const float4*)(a.coef_c + ci_base + cg0 + 8);
+            const float ps = drop_prescale<ACT, MODE>(a.drop);
+            const float ca[8] = {ca0.x * ps, ca0.y * ps, ca0.z * ps, ca0.w * ps, ca1.x * ps, ca1.y * ps, ca1.z * ps, ca1.w * ps};
+            const float cc[8] = {cc0.x * ps, cc0.y * ps, cc0.z * ps, cc0.w * ps, cc1.x * ps, cc1.y * ps, cc1.z * ps, cc1.w * ps};
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const uint32_t obase = o0 + t * t_stride + cg0;
+                const uint32_t e0 = obase + 4 * hi;
+                float v[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = fmaf(acc[hg >> 1][t][8 * (hg & 1) + q], ca[q], cc[q]);
+                act_drop_fixed<4, ACT, MODE, true>(v, e0, row0, a.drop, key);
+                act_drop_fixed<4, ACT, MODE, true>(v + 4, e0 + 8, row0, a.drop, key);
+                uint32_t p0 = pack_el16x2(v[0], v[1]), p1 = pack_el16x2(v[2], v[3]);
+                uint32_t q0 = pack_el16x2(v[4], v[5]), q1 = pack_el16x2(v[6], v[7]);
+                const auto s0 = __builtin_amdgcn_permlane32_swap(p0, q0, false, false);
+                const auto s1 = __builtin_amdgcn_permlane32_swap(p1, q1, false, false);
+                uint4 o;
+                o.x = s0[0]; o.y = s1[0]; o.z = s0[1]; o.w = s1[1];
+                const uint32_t sbase = store0 + t * st_stride + cg0;
+                if (SP != 1 || lane_valid) *(uint4*)(a.out_el16 + (size_t)(sbase + 8 * hi)) = o;
+            }
+        }
+    };
+    auto by_mode = [&](auto act_c) {
+        if (a.drop.mode == 0) epilogue(act_c, std::integral_constant<int, 0>{});
+        else if (a.drop.mode == 1) epilogue(act_c, std::integral_constant<int, 1>{});
+        else epilogue(act_c, std::integral_constant<int, 2>{});
+    };
+    if (a.act == ACT_RELU) by_mode(std::integral_constant<int, ACT_RELU>{});
+    else if (a.act == ACT_LEAKY) by_mode(std::integral_constant<int, ACT_LEAKY>{});
+    else if (a.act == ACT_SILU) by_mode(std::integral_constant<int, ACT_SILU>{});
+    else by_mode(std::integral_constant<int, ACT_NONE>{});
+#undef HKEY
+#endif
+}
+
+int conv_halo_rows_slots() { return R_TW; }
+int conv_halo_rows_sparse_halo_w() { return RowsCfg<1>::W; }
+
+// dense / sparse upsample forms: the geometry the rows kernels tile (4 x 32 low-res pixels); everything else as
+// conv_up_halo_supported (checked by the caller)
+bool conv_halo_rows_up_supported(const ConvArgs& a) {
+    if (a.h % R_TH != 0) return false;
+    if (a.up_cols) return a.up_ntiles >= 1 && a.up_npad == a.up_ntiles * R_TW;
+    return a.w % R_TW == 0;
+}
+
+bool conv_halo_rows3_supported(const ConvArgs& a) { return a.h % R_TH == 0 && a.w % R_TW == 0; }
+
+hipError_t conv_halo_rows_init() {
+    hipError_t e = hipFuncSetAttribute((const void*)conv_halo_rows_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       RowsCfg<0>::LDS_TOTAL);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)conv_halo_rows_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                RowsCfg<1>::LDS_TOTAL);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)conv_halo_rows_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                RowsCfg<2>::LDS_TOTAL);
+    return e;
+}
+
+// the conv_up_halo_kernel<0 / 1> part of launch_conv_up_halo (the border ring has been launched by the caller)
+hipError_t launch_conv_halo_rows_up(const ConvArgs& a, hipStream_t stream) {
+    const bool sparse = a.up_cols != nullptr;
+    const int tiles_x = sparse ? a.up_ntiles : a.w / R_TW, tiles_per_img = tiles_x * (a.h / R_TH);
+    const int tiles_m = a.n * tiles_per_img, tiles_n = a.cout / 64;
+    if (sparse)
+        hipLaunchKernelGGL(conv_halo_rows_kernel<1>, dim3(tiles_m * tiles_n), dim3(256), RowsCfg<1>::LDS_TOTAL, stream, a, tiles_x,
+                           tiles_per_img, tiles_m, tiles_n);
+    else
+        hipLaunchKernelGGL(conv_halo_rows_kernel<0>, dim3(tiles_m * tiles_n), dim3(256), RowsCfg<0>::LDS_TOTAL, stream, a, tiles_x,
+                           tiles_per_img, tiles_m, tiles_n);
+    return hipGetLastError();
+}
+
+hipError_t launch_conv_halo_rows3(const ConvArgs& a, hipStream_t stream) {
+    const int tiles_x = a.w / R_TW, tiles_per_img = tiles_x * (a.h / R_TH);
+    const int tiles_m = a.n * tiles_per_img, tiles_n = a.cout / 256;
+    hipLaunchKernelGGL(conv_halo_rows_kernel<2>, dim3(tiles_m * tiles_n), dim3(256), RowsCfg<2>::LDS_TOTAL, stream, a, tiles_x,
+                       tiles_per_img, tiles_m, tiles_n);
+    return hipGetLastError();
+}

@@ -267,9 +267,21 @@ __global__ __launch_bounds__(256, 2) void conv_up_halo_kernel(ConvArgs a, int ti
 
     // weights of one (tap, chunk) step: WSTEP bytes, inside [ks][column tile][lane] x 16 B with KSS bytes per k16 sub-step
     constexpr unsigned WSTEP = SP == 5 ? 8192u : (unsigned)STEP_BYTES, KSS = SP == 5 ? 2048u : 4096u;
+// timing experiments (wrong results): -DHALO_EXP_W_ALIAS serves the weight stream from 16 KB (L1 hits), -DHALO_EXP_LDS_SKIP
+// drops the pixel-fragment reads of odd k16 sub-steps (half the LDS read traffic)
+#ifdef HALO_EXP_W_ALIAS
+#define W_ALIAS(x) ((x) & 0x3FFFu)
+#else
+#define W_ALIAS(x) (x)
+#endif
+#ifdef HALO_EXP_LDS_SKIP
+#define LDS_KEEP(KS) (((KS) & 1) == 0)
+#else
+#define LDS_KEEP(KS) true
+#endif
 #define ISSUE_B(SET, SOFF, KS)                                                                               \
     _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                                         \
-        bq[SET][nt] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, w_voff + nt * 1024, (SOFF) + (KS) * KSS, 0);
+        bq[SET][nt] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, w_voff + nt * 1024, W_ALIAS((SOFF) + (KS) * KSS), 0);
 #define DSR(dst, addr) asm volatile("ds_read_b128 %0, %1" : "=v"(dst) : "v"(addr));
 #define LGKM_WAIT(N)                                                      \
     asm volatile("s_waitcnt lgkmcnt(" #N ")" ::: "memory");               \
@@ -290,7 +302,7 @@ __global__ __launch_bounds__(256, 2) void conv_up_halo_kernel(ConvArgs a, int ti
 #define RDA1(SET, KS, MT)                                                                                    \
     {                                                                                                        \
         const unsigned pm = (ax[MT] ^ (unsigned)((KS) << 5)) + ab[MT];                                       \
-        DSR(aq[SET][MT], pm)                                                                                 \
+        if (LDS_KEEP(KS)) DSR(aq[SET][MT], pm)                                                               \
     }
 #define MF(NT, MT, ASET, BSET)                                                                               \
     acc[NT][MT] = DYF_MFMA_32x32x16(__builtin_bit_cast(el16x8_t, bq[BSET][NT]), aq[ASET][MT], \
@@ -327,16 +339,25 @@ __global__ __launch_bounds__(256, 2) void conv_up_halo_kernel(ConvArgs a, int ti
     // the L2 round trip of a fragment is longer than the 3 sub-steps the 4-set ring gave it
     const unsigned soff_w = SP == 5 ? 0u : (unsigned)(wpy * (STEP_BYTES / 2) + wpx * 2048);  // SP 5: all waves, same weights
     unsigned soff_c = (unsigned)((tn * cpt) * 16) * WSTEP + soff_w, soff_n = soff_c;
+    // (pinned in program order: the compiler otherwise issues the oldest set LAST, and its own s_waitcnt at the loop head --
+    // merged over the entry edge and the back edge -- becomes vmcnt(2) in the first sub-step of EVERY chunk: a full drain of
+    // the weight ring and of the halo DMA just requested for the next chunk, i.e. no double buffering at all)
+#ifndef HALO_NO_PREPIN
+#define PPIN PIN
+#else
+#define PPIN
+#endif
+    PPIN
     if (H::S2) {
-        ISSUE_B(0, soff_cur, 0)
-        ISSUE_B(1, soff_cur, 1)
-        ISSUE_B(2, soff_cur, 2)
+        ISSUE_B(0, soff_cur, 0) PPIN
+        ISSUE_B(1, soff_cur, 1) PPIN
+        ISSUE_B(2, soff_cur, 2) PPIN
     } else {
-        ISSUE_B(0, soff_c, 0)
-        ISSUE_B(1, soff_c, 1)
-        ISSUE_B(2, soff_c, 2)
-        ISSUE_B(3, soff_c, 3)
-        ISSUE_B(4, soff_c + WSTEP, 0)
+        ISSUE_B(0, soff_c, 0) PPIN
+        ISSUE_B(1, soff_c, 1) PPIN
+        ISSUE_B(2, soff_c, 2) PPIN
+        ISSUE_B(3, soff_c, 3) PPIN
+        ISSUE_B(4, soff_c + WSTEP, 0) PPIN
     }
     for (int chunk = 0; chunk < cpt; ++chunk) {
         if (H::NBUF == 2) {
@@ -522,8 +543,9 @@ bool conv_up_halo_supported(const ConvArgs& a) {
     if (!(a.c0 > 0 && a.c0 % 64 == 0 && (a.c1 == 0 || a.c1 == a.c0) && a.cout % 64 == 0)) return false;
     if (a.h % TILE_H != 0 || a.w % TILE_W != 0 || a.ho != 2 * a.h || a.wo != 2 * a.w) return false;
     if (a.up_cols && (a.up_cbase == nullptr || a.up_cidx == nullptr || a.up_wo_store < 1 || a.up_ntiles < 1 ||
-                      a.up_npad != a.up_ntiles * 16))
+                      (a.up_npad != a.up_ntiles * 16 && a.up_npad != a.up_ntiles * conv_halo_rows_slots())))
         return false;
+    if (a.up_cols && a.up_npad != a.up_ntiles * 16 && !conv_halo_rows_up_supported(a)) return false;
     const size_t npix = (size_t)a.n * a.h * a.w;
     return npix * a.c0 * 2 < 0x7F000000ull && (size_t)4 * a.cout * 16 * (a.c0 + a.c1) * 2 < 0x7F000000ull &&
            (size_t)a.n * a.ho * a.wo * a.cout < 0xFFFFFFF0ull;
@@ -880,6 +902,10 @@ hipError_t launch_conv_up_halo(const ConvArgs& a, hipStream_t stream) {
         hipLaunchKernelGGL(up_border_kernel, dim3(4 * tr + 4 * tc + 4, (a.n + 7) / 8, a.cout / 64), dim3(256), UB_LDS, stream, a, tr, tc);
     }
     const bool sparse = a.up_cols != nullptr;
+    // rows form (conv_halo_rows.hip: one-row pixel tiles, half the LDS fragment reads) where the plane tiles by 4 x 32;
+    // DYF_HALO_ROWS=0 keeps this file's kernels.  The sparse lists are planned for one form or the other (32 / 16 slots).
+    static const bool rows = !(getenv("DYF_HALO_ROWS") && atoi(getenv("DYF_HALO_ROWS")) == 0);
+    if (sparse ? a.up_npad != a.up_ntiles * 16 : (rows && conv_halo_rows_up_supported(a))) return launch_conv_halo_rows_up(a, stream);
     const int tiles_x = sparse ? a.up_ntiles : a.w / TILE_W, tiles_per_img = tiles_x * (a.h / TILE_H);
     const int tiles_m = a.n * tiles_per_img, tiles_n = a.cout / 64;
     if (sparse)
@@ -905,7 +931,10 @@ hipError_t launch_conv_up_halo(const ConvArgs& a, hipStream_t stream) {
 // list tile t.  Returns false (dense form must be used) when a list tile does not fit the 40-column halo or the lists would
 // not save at least 20 % of the work.
 bool plan_up_sparse_columns(const std::vector<uint8_t>& needed, int w, std::vector<int16_t>& cols, std::vector<int16_t>& cbase,
-                            std::vector<int16_t>& cidx, std::vector<int16_t>& col_map, int& ntiles, int& nvalid0, int& nvalid1) {
+                            std::vector<int16_t>& cidx, std::vector<int16_t>& col_map, int& ntiles, int& nvalid0, int& nvalid1,
+                            int slots) {
+    // slots per list tile: 16 (conv_up_halo_kernel<1>, 40-column halo) or 32 (conv_halo_rows_kernel<1>)
+    const int halo_w = slots == 16 ? HaloCfg<1>::W : conv_halo_rows_sparse_halo_w();
     // compact storage order: the needed output columns in increasing order
     col_map.assign((size_t)2 * w, -1);
     int nstore = 0;
@@ -919,29 +948,29 @@ bool plan_up_sparse_columns(const std::vector<uint8_t>& needed, int w, std::vect
     nvalid0 = (int)l[0].size();
     nvalid1 = (int)l[1].size();
     const int nmax = std::max(nvalid0, nvalid1);
-    ntiles = (nmax + 15) / 16;
-    if (ntiles * 16 * 5 > w * 4) return false;
+    ntiles = (nmax + slots - 1) / slots;
+    if (ntiles * slots * 5 > w * 4) return false;
     const int per = (nmax + ntiles - 1) / ntiles;  // entries per tile, balanced
-    cols.assign((size_t)2 * ntiles * 16, 0);
-    cidx.assign((size_t)2 * ntiles * 16, 0);
+    cols.assign((size_t)2 * ntiles * slots, 0);
+    cidx.assign((size_t)2 * ntiles * slots, 0);
     cbase.assign(ntiles, 0);
     for (int t = 0; t < ntiles; ++t) {
         int lo = w, hi = -1;
         for (int px = 0; px < 2; ++px) {
             const int n = (int)l[px].size();
-            for (int i = 0; i < 16; ++i) {
+            for (int i = 0; i < slots; ++i) {
                 const int k = t * per + i;
                 const bool real = i < per && k < n;
                 const int kk = std::min(std::min(k, t * per + per - 1), n - 1);
                 const int c = l[px][std::max(kk, 0)];
-                cols[(size_t)px * ntiles * 16 + t * 16 + i] = (int16_t)(c | (real ? 0 : 0x4000));
-                cidx[(size_t)px * ntiles * 16 + t * 16 + i] = col_map[2 * c + px];
+                cols[(size_t)px * ntiles * slots + t * slots + i] = (int16_t)(c | (real ? 0 : 0x4000));
+                cidx[(size_t)px * ntiles * slots + t * slots + i] = col_map[2 * c + px];
                 lo = std::min(lo, c);
                 hi = std::max(hi, c);
             }
         }
         cbase[t] = (int16_t)(lo - 1);
-        if (hi - lo + 3 > HaloCfg<1>::W) return false;
+        if (hi - lo + 3 > halo_w) return false;
     }
     return true;
 }

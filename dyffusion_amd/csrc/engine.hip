@@ -578,13 +578,23 @@ dyf_status dyf_load_weights(dyf_engine* e, int32_t which, int32_t n_tensors, con
                 std::vector<int16_t> cols, cbase, cidx, cmap;
                 int nt = 0, nv0 = 0, nv1 = 0;
                 // the compact tensor is read by the MFMA form of the readout only (dim 64, <= 4 output channels)
-                if (n.dim == 64 && n.cfg.out_channels <= 4 &&
-                    plan_up_sparse_columns(needed, iw / 2, cols, cbase, cidx, cmap, nt, nv0, nv1)) {
+                // list tiles of 32 slots for the rows form of the halo kernel (conv_halo_rows.hip), 16 for conv_up_halo_kernel<1>
+                static const bool rows_env = !(getenv("DYF_HALO_ROWS") && atoi(getenv("DYF_HALO_ROWS")) == 0);
+                int slots = rows_env && (b.out_h / 2) % 4 == 0 ? conv_halo_rows_slots() : 16;
+                bool planned = false;
+                if (n.dim == 64 && n.cfg.out_channels <= 4) {
+                    planned = plan_up_sparse_columns(needed, iw / 2, cols, cbase, cidx, cmap, nt, nv0, nv1, slots);
+                    if (!planned && slots != 16) {
+                        slots = 16;
+                        planned = plan_up_sparse_columns(needed, iw / 2, cols, cbase, cidx, cmap, nt, nv0, nv1, slots);
+                    }
+                }
+                if (planned) {
                     UP(b.up_cols, cols);
                     UP(b.up_cbase, cbase);
                     UP(b.up_cidx, cidx);
                     UP(b.up_col_map, cmap);
-                    b.up_ntiles = nt; b.up_npad = nt * 16; b.up_nvalid0 = nv0; b.up_nvalid1 = nv1;
+                    b.up_ntiles = nt; b.up_npad = nt * slots; b.up_nvalid0 = nv0; b.up_nvalid1 = nv1;
                     b.up_wo_store = nv0 + nv1;
                 }
             }

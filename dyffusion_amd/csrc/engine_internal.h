@@ -209,7 +209,8 @@ inline dyf_status upload_conv_weights(dyf_engine* e, el16_t** out, const std::ve
         if (st != DYF_OK) return st;
         conv_register_halo3_frag(*out, frag);
     }
-    if (taps == 9 && cout % 64 == 0 && cout % 256 != 0 && cin % 64 == 0 && (size_t)cout * taps * cin == pk.size()) {
+    const bool h5_all = getenv("DYF_HALO5_ALL") && atoi(getenv("DYF_HALO5_ALL")) != 0;  // experiment: SP = 5 for every 3x3
+    if (taps == 9 && cout % 64 == 0 && (cout % 256 != 0 || h5_all) && cin % 64 == 0 && (size_t)cout * taps * cin == pk.size()) {
         std::vector<el16_t> pf((size_t)cout * 16 * cin);  // halo form of plain 3x3 convs with 64 / 128 output channels (SP = 5)
         pack_halo3_frag64(pk.data(), cout, cin, pf.data());
         el16_t* frag = nullptr;
@@ -217,7 +218,7 @@ inline dyf_status upload_conv_weights(dyf_engine* e, el16_t** out, const std::ve
         if (st != DYF_OK) return st;
         conv_register_halo3_frag(*out, frag);
     }
-    if (taps == 9 && cout % 256 == 0 && cin % 64 == 0 && (size_t)cout * taps * cin == pk.size()) {  // halo form of plain 3x3
+    if (taps == 9 && cout % 256 == 0 && !h5_all && cin % 64 == 0 && (size_t)cout * taps * cin == pk.size()) {  // halo form of plain 3x3
         std::vector<el16_t> pf((size_t)cout * 16 * cin);
         pack_halo3_frag(pk.data(), cout, cin, pf.data());
         el16_t* frag = nullptr;

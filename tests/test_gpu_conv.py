@@ -112,6 +112,8 @@ def test_second_igemm_form_matches_torch(engine, case, monkeypatch):
 
 HALO3_CASES = [(2, 16, 16, 64, 256, 3, 1, 1), (1, 32, 48, 128, 256, 3, 1, 1), (3, 8, 16, 192, 512, 3, 1, 1),
                (1, 64, 32, 64, 256, 3, 1, 1),
+               # planes that tile by 4 x 32 run the rows form (conv_halo_rows_kernel<2>): 3 chunks, 2 column tiles, 2 blocks
+               (2, 32, 64, 192, 512, 3, 1, 1), (1, 8, 32, 64, 256, 3, 1, 1),
                # 4 x 4 / stride 2 / pad 1 on the space-to-depth view (conv_up_halo_kernel<3>)
                (2, 16, 32, 64, 256, 4, 2, 1), (1, 64, 64, 128, 256, 4, 2, 1), (3, 32, 32, 256, 512, 4, 2, 1),
                # ... with 128-channel workgroups on 16 x 16 tiles (conv_up_halo_kernel<4>)
@@ -163,7 +165,9 @@ def test_mfma_path_rejects_unsupported_channels(engine):
 UPCASES = [(2, 16, 16, 64, 128), (1, 32, 16, 128, 64), (3, 8, 16, 192, 128), (1, 16, 32, 64, 64), (2, 48, 32, 128, 256),
            # halo form + border-ring kernel: ragged ring tiles (47 and 48 pixels), 9 samples = one full group of 8 + 1,
            # corner workgroups with fewer than 64 samples; two input chunks from two sources are covered by the network tests
-           (9, 32, 48, 64, 64), (1, 64, 32, 128, 128)]
+           (9, 32, 48, 64, 64), (1, 64, 32, 128, 128),
+           # planes that tile by 4 x 32 run the rows form (conv_halo_rows_kernel<0>); w = 48 above stays on conv_up_halo_kernel<0>
+           (2, 40, 64, 192, 128), (9, 32, 32, 64, 64)]
 
 
 @pytest.mark.parametrize("case", UPCASES, ids=lambda c: "x".join(map(str, c)))
