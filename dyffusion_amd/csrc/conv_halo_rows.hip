@@ -180,9 +180,14 @@ __global__ __launch_bounds__(256, 2) void conv_halo_rows_kernel(ConvArgs a, int 
     el16x8_t pq[2][6];  // pixel fragments: halo rows 0..5 of the current / next super-slot
     unsigned ab = 0, ax = 0, pa = 0;
 
+#ifdef HALO_EXP_W_ALIAS
+#define W_ALIAS(x) ((x) & 0x3FFFu)
+#else
+#define W_ALIAS(x) (x)
+#endif
 #define ISSUE_B(SET, SOFF)                                                                                   \
     _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                                         \
-        bq[SET][nt] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, w_voff + nt * 1024, (SOFF), 0);
+        bq[SET][nt] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, w_voff + nt * 1024, W_ALIAS(SOFF), 0);
 #define DSRO(dst, addr, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(OFF));
 #define LGKM_WAIT0                                                        \
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                    \
@@ -228,7 +233,13 @@ __global__ __launch_bounds__(256, 2) void conv_halo_rows_kernel(ConvArgs a, int 
     }
 
     issue_halo(0);
+    // timing experiments (wrong results): -DHALO_EXP_W_SHARE makes the four waves stream the SAME fragments (do simultaneous
+    // requests meet in L1?), -DHALO_EXP_W_ALIAS serves the stream from 16 KB
+#ifdef HALO_EXP_W_SHARE
+    const unsigned soff_w = 0u;
+#else
     const unsigned soff_w = (unsigned)(wpy * (R_STEP_BYTES / 2) + wpx * 2048);
+#endif
     unsigned soff_c = (unsigned)((tn * cpt) * 16) * (unsigned)R_STEP_BYTES + soff_w, soff_n = soff_c;
     // (pinned in program order: the compiler's own vmcnt at the loop head is merged over the entry and the back edge)
     PIN
