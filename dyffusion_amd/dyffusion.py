@@ -13,7 +13,7 @@ import torch
 from torch import Tensor, nn
 
 from . import _lib as L
-from .engine import HipEngine
+from .engine import EngineLoss, HipEngine, collect_train_results, sync_weights
 from .unet_simple import UNet, _AttrDict  # noqa: F401
 
 Step = Union[int, float]
@@ -367,12 +367,8 @@ class DYffusion(nn.Module):
 
     def _sync_engine_weights(self, eng: HipEngine):
         """Re-upload a network whose parameters were modified in place since the last upload (optimizer.step())."""
-        for net, slot in ((self.model, L.NET_FORECASTER), (self._ipol_net, L.NET_INTERPOLATOR)):
-            ver = sum(int(p._version) for p in net.state_dict().values())
-            if getattr(net, "_uploaded_version", None) != (id(eng), ver):
-                if getattr(net, "_uploaded_version", None) is not None or net._engine is not eng:
-                    eng.load_weights(slot, net.state_dict())
-                net._uploaded_version = (id(eng), sum(int(p._version) for p in net.state_dict().values()))
+        sync_weights(self.model, eng, L.NET_FORECASTER)
+        sync_weights(self._ipol_net, eng, L.NET_INTERPOLATOR)
 
     def _p_losses_train(self, xt_last: Tensor, condition: Tensor, t: Tensor, static_condition: Optional[Tensor] = None):
         """`p_losses` with `self.training` (dyffusion.py:496-567 under torch.autograd in the reference).  The forecaster runs in
@@ -435,7 +431,7 @@ class DYffusion(nn.Module):
         self._train_state = state
         if not hasattr(self, "_grad_anchor"):
             self._grad_anchor = torch.zeros((), requires_grad=True)
-        loss = _EngineLoss.apply(self._grad_anchor, self, float(total))
+        loss = EngineLoss.apply(self._grad_anchor, self, float(total))
         return {"loss": loss, "train/loss_forward": loss_forward, "train/loss_forward2": loss_forward2}
 
     def _train_backward(self, upstream: float):
@@ -448,36 +444,7 @@ class DYffusion(nn.Module):
             d_ipol = eng.train_backward(2, d_xi2, want_dinputs=True, param_grads=False)    # through the frozen interpolator
             d_pred[st["not_last"]] += d_ipol[:, -C:]                                        # inputs = cat[x_0 window, x_last = pred]
         eng.train_backward(1, d_pred, want_dinputs=False, param_grads=True)
-        sd = self.model.state_dict(keep_vars=True)
-        shapes = {k: tuple(v.shape) for k, v in sd.items() if isinstance(v, nn.Parameter)}
-        grads = eng.train_export(L.NET_FORECASTER, shapes)
-        for k, g in grads.items():
-            p = sd[k]
-            p.grad = g.to(p.device) if p.grad is None else p.grad + g.to(p.device)
-        eng.train_zero_grads(L.NET_FORECASTER)
-        # BatchNorm buffers as module.train() leaves them (running statistics, num_batches_tracked)
-        bufs = {k: tuple(v.shape) for k, v in sd.items() if k.endswith("running_mean") or k.endswith("running_var")}
-        with torch.no_grad():
-            for k, v in eng.train_export(L.NET_FORECASTER, bufs).items():
-                sd[k].copy_(v)
-            for k, v in sd.items():
-                if k.endswith("num_batches_tracked"):
-                    v += st["n_fwd"]
-        self.model._uploaded_version = (id(eng), sum(int(p._version) for p in self.model.state_dict().values()))
+        collect_train_results(self.model, eng, L.NET_FORECASTER, st["n_fwd"])
 
     def forward(self, *args, **kwargs):
         return self.p_losses(*args, **kwargs)
-
-
-class _EngineLoss(torch.autograd.Function):
-    """Scalar loss whose backward is the engine's backward pass (dyf_train_backward)."""
-
-    @staticmethod
-    def forward(ctx, anchor, owner, value):
-        ctx.owner = owner
-        return anchor.new_tensor(value)
-
-    @staticmethod
-    def backward(ctx, grad_out):
-        ctx.owner._train_backward(float(grad_out))
-        return None, None, None

@@ -399,3 +399,53 @@ class HipEngine:
                                               None if shift is None else shift.data_ptr(), act, y.data_ptr(),
                                               self._stream()))
         return y
+
+
+class EngineLoss(torch.autograd.Function):
+    """Scalar loss whose backward is the engine's backward pass: `owner._train_backward(upstream)` runs dyf_train_backward and
+    accumulates into `param.grad` (so `loss.backward()` / torch.optim / Lightning's training_step work unchanged)."""
+
+    @staticmethod
+    def forward(ctx, anchor, owner, value):
+        ctx.owner = owner
+        return anchor.new_tensor(value)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        ctx.owner._train_backward(float(grad_out))
+        return None, None, None
+
+
+def state_version(net) -> int:
+    return sum(int(p._version) for p in net.state_dict().values())
+
+
+def sync_weights(net, eng: "HipEngine", slot: int) -> None:
+    """Re-upload a network whose parameters were modified in place since the last upload (optimizer.step())."""
+    mark = getattr(net, "_uploaded_version", None)
+    ver = state_version(net)
+    if mark != (id(eng), ver):
+        if mark is not None or getattr(net, "_engine", None) is not eng:
+            eng.load_weights(slot, net.state_dict())
+        net._uploaded_version = (id(eng), state_version(net))
+
+
+def collect_train_results(net, eng: "HipEngine", slot: int, n_forwards: int) -> None:
+    """After dyf_train_backward: add the engine's parameter gradients of network `slot` to `param.grad`, clear them in the
+    engine, and bring the BatchNorm buffers to what module.train() leaves (running statistics after `n_forwards` momentum
+    updates, num_batches_tracked)."""
+    sd = net.state_dict(keep_vars=True)
+    shapes = {k: tuple(v.shape) for k, v in sd.items() if isinstance(v, torch.nn.Parameter)}
+    for k, g in eng.train_export(slot, shapes).items():
+        p = sd[k]
+        p.grad = g.to(p.device) if p.grad is None else p.grad + g.to(p.device)
+    eng.train_zero_grads(slot)
+    bufs = {k: tuple(v.shape) for k, v in sd.items() if k.endswith("running_mean") or k.endswith("running_var")}
+    with torch.no_grad():
+        for k, v in eng.train_export(slot, bufs).items():
+            sd[k].copy_(v)
+        for k, v in sd.items():
+            if k.endswith("num_batches_tracked"):
+                v += n_forwards
+    net._uploaded_version = (id(eng), state_version(net))
+

@@ -22,7 +22,7 @@ class InterpolatorHandle:
 
 
 class InterpolationExperiment(nn.Module):
-    """Stage-1 interpolator experiment, evaluation path (`src/experiment_types/interpolation.py:12-141`): the network is
+    """Stage-1 interpolator experiment (`src/experiment_types/interpolation.py:12-167`): evaluation -- the network is
     asked for every intermediate step t = 1..h-1 given the first `window` frames and the last frame.  Also serves as the
     `interpolator` argument of `DYffusion` (`.model`, `.window`, `.true_horizon`, `inference_dropout_scope`)."""
 
@@ -92,6 +92,24 @@ class InterpolationExperiment(nn.Module):
             mses.append(mse)
         out[f"{split}/{self.horizon}h_avg/ipol/mse"] = float(sum(mses) / len(mses))
         return out
+
+
+    # --------------------------------- training (stage 1)
+    def get_loss(self, batch: Dict[str, Any]) -> Tensor:
+        """interpolation.py:149-167: one uniformly drawn interpolation time per batch item, the frame at that time as the
+        target, `model.get_loss(inputs, targets, time=t, **rest of the batch)`.  With the module in train mode the returned
+        scalar's `.backward()` runs the engine's backward pass (UNet.get_loss)."""
+        dynamics = batch["dynamics"]
+        inputs = self.get_inputs_from_dynamics(dynamics)
+        b = dynamics.shape[0]
+        possible_times = torch.tensor(self.horizon_range, device=dynamics.device, dtype=torch.long)
+        t = possible_times[torch.randint(len(possible_times), (b,), device=dynamics.device, dtype=torch.long)]
+        targets = dynamics[torch.arange(b, device=dynamics.device), self.window + t - 1]
+        return self.model.get_loss(inputs=inputs, targets=targets, time=t, **{k: v for k, v in batch.items() if k != "dynamics"})
+
+    def training_step(self, batch: Dict[str, Any], batch_idx: int = 0):  # _base_experiment.py:440-470 without the logging
+        loss = self.get_loss(batch)
+        return {"loss": loss}
 
 
 class MultiHorizonForecastingDYffusion(nn.Module):

@@ -95,3 +95,18 @@ def p_losses(forecaster: NetFn, interpolator: NetFn, xt_last: Tensor, condition:
         loss_forward2 = crit(pred2, xt_last[not_last])
     return {"loss": lam1 * loss_forward + lam2 * loss_forward2, "loss_forward": loss_forward, "loss_forward2": loss_forward2,
             "xt_last_pred": pred}
+
+
+def interpolation_loss(interpolator: NetFn, dynamics: Tensor, t: Tensor, condition: Optional[Tensor], window: int,
+                       loss_function: str) -> Tensor:
+    """Stage-1 objective of the interpolator: /root/reference/src/experiment_types/interpolation.py:149-167 (`get_loss`,
+    given the drawn interpolation times t in horizon_range = 1..h-1) with :128-141 (`get_inputs_from_dynamics`, window frames
+    stacked on channels + the last frame) and src/models/_base_model.py:108-138 (`BaseModel.get_loss`: predict, criterion).
+    dynamics (b, window + h, c, H, W).  Pinned by tests/golden/interp_train_*.npz (loss and gradients of the imported
+    reference in train mode) in tests/test_oracle_losses.py."""
+    b = dynamics.shape[0]
+    past = dynamics[:, :window].reshape(b, -1, *dynamics.shape[-2:])  # "b window c lat lon -> b (window c) lat lon"
+    inputs = torch.cat([past, dynamics[:, -1]], dim=1)
+    targets = dynamics[torch.arange(b), window + t.long() - 1]
+    pred = interpolator(inputs, t, condition)
+    return criterion_fn(loss_function)(pred, targets)

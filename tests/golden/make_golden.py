@@ -408,6 +408,51 @@ def gen_plosses_train():
         print(name, vals, "grad norm", gn)
 
 
+def gen_interp_train():
+    """Stage 1 of the reference's training: `InterpolationExperiment.get_loss(batch)` (interpolation.py:149-167 ->
+    `BaseModel.get_loss`, _base_model.py:108-138) with the interpolator network in train mode (batch-statistics BatchNorm,
+    Dropout active) and loss.backward().  The random interpolation times come from a patched torch.randint (fixed indices,
+    stored); all nn.Dropout layers draw from DropoutSeeded(seed) in call order.  Stored: batch, weights, chosen times, loss,
+    the gradient w.r.t. every parameter and the BatchNorm running statistics after the step."""
+    base_model = dict(dim=4, outer_sample_mode="bilinear", upsample_dims=[64, 64], with_time_emb=True,
+                      input_dropout=0.0, dropout=0.2)
+    for name, h, loss_fn, seed, idx in (("interp_train_a", 4, "mse", 81, [0, 2, 1, 2, 0]),
+                                        ("interp_train_b", 6, "l1", 82, [4, 0, 3, 1, 2])):
+        _, ipol = ref_import.build_reference_dyffusion(system="spring-mesh", model="unet_simple", model_kwargs=base_model,
+                                                       horizon=h)
+        load_seeded(ipol.model, seed=41)
+        from src.utilities.utils import get_loss
+        ipol.model.criterion = get_loss(loss_fn)
+        ipol.train()
+        for p_ in ipol.model.parameters():
+            p_.requires_grad_(True)
+        g = torch.Generator().manual_seed(23)
+        B = len(idx)
+        dynamics = torch.randn(B, 1 + h, 4, 10, 10, generator=g)
+        cond = torch.rand(B, 1, 10, 10, generator=g)
+        sd0 = {k: v.detach().clone() for k, v in ipol.model.state_dict().items()}
+        orig_randint = torch.randint
+        torch.randint = lambda *a, **k: torch.tensor(idx, dtype=torch.long)
+        try:
+            with patched_dropout(DropoutSeeded(seed=seed)):
+                loss = ipol.get_loss(dict(dynamics=dynamics, condition=cond))
+                loss.backward()
+        finally:
+            torch.randint = orig_randint
+        times = torch.tensor(list(ipol.horizon_range))[torch.tensor(idx)]
+        arrs = {f"P::{k}": v.numpy() for k, v in sd0.items()}
+        arrs.update({f"G::{k}": p_.grad.numpy() for k, p_ in ipol.model.named_parameters()})
+        arrs.update({f"B::{k}": v.detach().numpy() for k, v in ipol.model.state_dict().items()
+                     if k.endswith("running_mean") or k.endswith("running_var") or k.endswith("num_batches_tracked")})
+        hp = dict(horizon=h, window=1, model=base_model, loss_function=loss_fn, dropout_seed=seed, randint=idx,
+                  horizon_range=[int(v) for v in ipol.horizon_range])
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), dynamics=dynamics.numpy(), cond=cond.numpy(), t=times.numpy(),
+                            loss=np.float64(float(loss)), hp=json.dumps(hp), **arrs)
+        print(name, "times", times.tolist(), "loss", float(loss), "grad norm",
+              float(torch.cat([p_.grad.reshape(-1) for p_ in ipol.model.parameters()]).norm()))
+
+
+
 # ------------------------------------------------------------------------------------------------ G6
 def gen_fullsize():
     """NS 221x42 h=16 dim=64 (BASELINE config 2): checksums + probe points of the reference rollout, dropout OFF
@@ -658,7 +703,7 @@ def gen_ensemble_stats():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["schedules", "nets", "resnet", "samples", "fullsize", "metrics", "ckpt", "plosses", "stats", "boundary", "predict_step", "plosses_train", "fullsize_oisst"]
+    which = sys.argv[1:] or ["schedules", "nets", "resnet", "samples", "fullsize", "metrics", "ckpt", "plosses", "stats", "boundary", "predict_step", "plosses_train", "fullsize_oisst", "interp_train"]
     if "stats" in which:
         gen_ensemble_stats()
     if "boundary" in which:
@@ -669,6 +714,8 @@ if __name__ == "__main__":
         gen_plosses()
     if "plosses_train" in which:
         gen_plosses_train()
+    if "interp_train" in which:
+        gen_interp_train()
     if "metrics" in which:
         gen_metrics()
     if "ckpt" in which:

@@ -114,3 +114,61 @@ def test_sgd_steps_reduce_the_loss_and_resync_the_engine():
         hist.append(float(out["loss"]))
     print("loss over 4 SGD steps:", [round(v, 5) for v in hist])
     assert hist[-1] < hist[0]
+
+
+@pytest.mark.parametrize("name", ["interp_train_a", "interp_train_b"])
+def test_interpolator_training_step_matches_autograd_of_the_oracle(name, monkeypatch):
+    """Stage 1 (`InterpolationExperiment.get_loss` in train mode + backward, interpolation.py:149-167) on the engine against
+    torch.autograd over `oracle.losses.interpolation_loss`, which tests/test_oracle_losses.py pins to the imported reference's
+    loss and gradients (interp_train_*.npz).  The oracle replays the engine's dropout masks (forward counter 0)."""
+    import dyffusion_amd as D
+    from tests.gpu_common import mirror_from_params
+    z = load_npz(name + ".npz")
+    hp = json.loads(str(z["hp"]))
+    mk, P = hp["model"], split_state(z, "P")
+    dyn, cond, t = torch.from_numpy(z["dynamics"]), torch.from_numpy(z["cond"]), torch.from_numpy(z["t"])
+    B, C = dyn.shape[0], dyn.shape[2]
+    net = mirror_from_params(P, mk, (hp["window"] + 1) * C, cond.shape[1], C)
+    net.hparams.loss_function = hp["loss_function"]
+    exp = D.InterpolationExperiment(net, horizon=hp["horizon"], window=hp["window"])
+    exp.train()
+    seed = 777
+    net._own_engine(B, dyn.shape[-2:]).seed(seed)
+    idx = torch.tensor(hp["randint"])
+    monkeypatch.setattr(torch, "randint", lambda *a, **k: idx.to(k.get("device", "cpu")))
+    loss = exp.get_loss(dict(dynamics=dyn.to(DEV), condition=cond.to(DEV)))
+    monkeypatch.undo()
+    loss.backward()
+    # oracle with the engine's masks
+    uh, uw = mk["upsample_dims"]
+    drop = R.EngineDropout(seed, mk["dim"], uh, uw)
+    drop.begin_forward()
+    Pg = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and not k.endswith(("running_mean", "running_var")) else v)
+          for k, v in P.items()}
+    want = losses.interpolation_loss(lambda x, tt, c: nets.unet_simple_forward(Pg, mk, x, tt, c, dropout=drop, bn_training=True),
+                                     dyn, t, cond, hp["window"], hp["loss_function"])
+    want.backward()
+    assert float(loss) == pytest.approx(float(want), rel=1e-4)
+    grads = {k: v.grad for k, v in Pg.items() if torch.is_tensor(v) and v.requires_grad}
+    got = {k: p.grad for k, p in net.named_parameters()}
+    assert sorted(got) == sorted(grads)
+    gn = float(torch.cat([g.reshape(-1) for g in grads.values()]).norm())
+    worst = max(float((got[k].cpu() - grads[k]).norm()) for k in grads) / gn
+    print(f"{name}: loss {float(loss):.6f}, grad norm {gn:.4f}, worst per-tensor gradient error / grad norm = {worst:.2e}")
+    assert worst <= 1e-3
+    G = split_state(z, "G")  # the reference's own gradients (other masks): same scale
+    assert 0.5 <= gn / float(torch.cat([g.reshape(-1) for g in G.values()]).norm()) <= 2.0
+    assert int(net.state_dict()["input_ops.0.ops.1.num_batches_tracked"]) == int(P["input_ops.0.ops.1.num_batches_tracked"]) + 1
+    # an optimizer step on the module's parameters reaches the engine: the loss of the same batch changes
+    opt = torch.optim.SGD(net.parameters(), lr=0.05)
+    opt.step()
+    net._own_engine(B, dyn.shape[-2:]).seed(seed)
+    monkeypatch.setattr(torch, "randint", lambda *a, **k: idx.to(k.get("device", "cpu")))
+    loss2 = exp.get_loss(dict(dynamics=dyn.to(DEV), condition=cond.to(DEV)))
+    monkeypatch.undo()
+    assert float(loss2) < float(loss)
+    # eval mode: plain forward + criterion (no tape)
+    exp.eval()
+    le = net.get_loss(exp.get_inputs_from_dynamics(dyn.to(DEV)), dyn[torch.arange(B), hp["window"] + t - 1].to(DEV), time=t.to(DEV),
+                      condition=cond.to(DEV))
+    assert le.requires_grad is False and float(le) > 0
