@@ -258,8 +258,8 @@ def main():
     }
     if rank == 0:
         # roofline of the dominant kernel: the last decoder block's 3x3 conv (256 -> 64 ch @256^2, 40 % of a forward),
-        # conv_up_halo_kernel; HIP events on the launch stream, operands = live workspace activations
-        # Dominant kernel: conv_up_halo_kernel<0> (dense form; dec3 + dec4 = 27 % of a forward's time), largest launch dec4.
+        # HIP events on the launch stream, operands = live workspace activations
+        # Dominant kernel: conv_halo_rows_kernel<0> (dense form; dec3 + dec4 = 27 % of a forward's time), largest launch dec4.
         # achieved = algorithmic FLOPs of one launch / average duration of that launch INSIDE the rollout: HIP events around
         # every dec4 conv (60 launches: 16 forecaster + 44 interpolator forwards, MC dropout on) of one eagerly launched
         # rollout on the launch stream (dyf_time_layer_in_rollout); the isolated back-to-back figure is kept beside it.
@@ -274,12 +274,12 @@ def main():
                     "launches": launches, "avg_ms_isolated": round(ms_iso, 4), "flops_per_launch": fl,
                     "algorithmic_bytes_per_launch": by}
 
-        result["roofline"] = layer_roofline(10, "conv_up_halo_kernel<0> (dec4: fused x2-upsample + 3x3 conv, 256->128 ch, 64^2->128^2)")
+        result["roofline"] = layer_roofline(10, "conv_halo_rows_kernel<0> (dec4: fused x2-upsample + 3x3 conv, 256->128 ch, 64^2->128^2)")
         result["roofline"]["traffic"], result["roofline"]["traffic_source"] = pmc_traffic(nb)
         if result["roofline"]["traffic_source"]:
             result["roofline"]["traffic_source"] = "replayed from profiles/" + result["roofline"]["traffic_source"] + " (rocprofv3 --pmc passes of this command)"
         result["roofline_dec5_sparse"] = layer_roofline(
-            11, "conv_up_halo_kernel<1> (dec5: fused x2-upsample + 3x3 conv, 256->64 ch, 128^2->256^2, 104 of 256 output columns)")
+            11, "conv_halo_rows_kernel<1> (dec5: fused x2-upsample + 3x3 conv, 256->64 ch, 128^2->256^2, 104 of 256 output columns)")
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(F, I)
         print(json.dumps(result), flush=True)

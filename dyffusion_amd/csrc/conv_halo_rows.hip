@@ -303,31 +303,44 @@ __global__ __launch_bounds__(256, 2) void conv_halo_rows_kernel(ConvArgs a, int 
     const uint32_t st_stride = SP == 1 ? (uint32_t)(2 * a.up_wo_store * a.cout) : t_stride;
     auto epilogue = [&](auto act_c, auto mode_c) {
         constexpr int ACT = decltype(act_c)::value, MODE = decltype(mode_c)::value;
+        // 32-channel half outermost, tile rows, then the two 16-channel groups of the half: the two 32-byte pieces of a pixel's
+        // 64-byte half block are stored back to back and leave the L2 as whole 64-byte writes (with the channel groups
+        // outermost PMC counted 1.65x the algorithmic write bytes)
+        const float ps = drop_prescale<ACT, MODE>(a.drop);  // dropout scale folded into the affine
 #pragma unroll
-        for (int hg = 0; hg < 4; ++hg) {
-            const int cg0 = (hg >> 1) * 32 + 16 * (hg & 1);
-            const float4 ca0 = *(const float4*)(a.coef_a + ci_base + cg0), ca1 = *(const float4*)(a.coef_a + ci_base + cg0 + 8);
-            const float4 cc0 = *(const float4*)(a.coef_c + ci_base + cg0), cc1 = *(const float4*)(a.coef_c + ci_base + cg0 + 8);
-            const float ps = drop_prescale<ACT, MODE>(a.drop);
-            const float ca[8] = {ca0.x * ps, ca0.y * ps, ca0.z * ps, ca0.w * ps, ca1.x * ps, ca1.y * ps, ca1.z * ps, ca1.w * ps};
-            const float cc[8] = {cc0.x * ps, cc0.y * ps, cc0.z * ps, cc0.w * ps, cc1.x * ps, cc1.y * ps, cc1.z * ps, cc1.w * ps};
+        for (int nt = 0; nt < 2; ++nt) {
+            float ca[2][8], cc[2][8];
+#pragma unroll
+            for (int g2 = 0; g2 < 2; ++g2) {
+                const int cg0 = nt * 32 + 16 * g2;
+                const float4 ca0 = *(const float4*)(a.coef_a + ci_base + cg0), ca1 = *(const float4*)(a.coef_a + ci_base + cg0 + 8);
+                const float4 cc0 = *(const float4*)(a.coef_c + ci_base + cg0), cc1 = *(const float4*)(a.coef_c + ci_base + cg0 + 8);
+                ca[g2][0] = ca0.x * ps; ca[g2][1] = ca0.y * ps; ca[g2][2] = ca0.z * ps; ca[g2][3] = ca0.w * ps;
+                ca[g2][4] = ca1.x * ps; ca[g2][5] = ca1.y * ps; ca[g2][6] = ca1.z * ps; ca[g2][7] = ca1.w * ps;
+                cc[g2][0] = cc0.x * ps; cc[g2][1] = cc0.y * ps; cc[g2][2] = cc0.z * ps; cc[g2][3] = cc0.w * ps;
+                cc[g2][4] = cc1.x * ps; cc[g2][5] = cc1.y * ps; cc[g2][6] = cc1.z * ps; cc[g2][7] = cc1.w * ps;
+            }
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                const uint32_t obase = o0 + t * t_stride + cg0;
-                const uint32_t e0 = obase + 4 * hi;
-                float v[8];
 #pragma unroll
-                for (int q = 0; q < 8; ++q) v[q] = fmaf(acc[hg >> 1][t][8 * (hg & 1) + q], ca[q], cc[q]);
-                act_drop_fixed<4, ACT, MODE, true>(v, e0, row0, a.drop, key);
-                act_drop_fixed<4, ACT, MODE, true>(v + 4, e0 + 8, row0, a.drop, key);
-                uint32_t p0 = pack_el16x2(v[0], v[1]), p1 = pack_el16x2(v[2], v[3]);
-                uint32_t q0 = pack_el16x2(v[4], v[5]), q1 = pack_el16x2(v[6], v[7]);
-                const auto s0 = __builtin_amdgcn_permlane32_swap(p0, q0, false, false);
-                const auto s1 = __builtin_amdgcn_permlane32_swap(p1, q1, false, false);
-                uint4 o;
-                o.x = s0[0]; o.y = s1[0]; o.z = s0[1]; o.w = s1[1];
-                const uint32_t sbase = store0 + t * st_stride + cg0;
-                if (SP != 1 || lane_valid) *(uint4*)(a.out_el16 + (size_t)(sbase + 8 * hi)) = o;
+                for (int g2 = 0; g2 < 2; ++g2) {
+                    const int cg0 = nt * 32 + 16 * g2;
+                    const uint32_t obase = o0 + t * t_stride + cg0;
+                    const uint32_t e0 = obase + 4 * hi;
+                    float v[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) v[q] = fmaf(acc[nt][t][8 * g2 + q], ca[g2][q], cc[g2][q]);
+                    act_drop_fixed<4, ACT, MODE, true>(v, e0, row0, a.drop, key);
+                    act_drop_fixed<4, ACT, MODE, true>(v + 4, e0 + 8, row0, a.drop, key);
+                    uint32_t p0 = pack_el16x2(v[0], v[1]), p1 = pack_el16x2(v[2], v[3]);
+                    uint32_t q0 = pack_el16x2(v[4], v[5]), q1 = pack_el16x2(v[6], v[7]);
+                    const auto s0 = __builtin_amdgcn_permlane32_swap(p0, q0, false, false);
+                    const auto s1 = __builtin_amdgcn_permlane32_swap(p1, q1, false, false);
+                    uint4 o;
+                    o.x = s0[0]; o.y = s1[0]; o.z = s0[1]; o.w = s1[1];
+                    const uint32_t sbase = store0 + t * st_stride + cg0;
+                    if (SP != 1 || lane_valid) *(uint4*)(a.out_el16 + (size_t)(sbase + 8 * hi)) = o;
+                }
             }
         }
     };

@@ -474,21 +474,33 @@ __global__ __launch_bounds__(256, 2) void conv_up_halo_kernel(ConvArgs a, int ti
     // (activation, dropout mode) are wave-uniform: the whole epilogue is instantiated per pair and dispatched once
     auto epilogue = [&](auto act_c, auto mode_c) {
         constexpr int ACT = decltype(act_c)::value, MODE = decltype(mode_c)::value;
+        // 32-channel half outermost, pixel tiles, then the two 16-channel groups of the half: the two 32-byte pieces of a
+        // pixel's 64-byte half block are stored back to back and leave the L2 as whole 64-byte writes (with the channel groups
+        // outermost PMC counted 1.2-1.65x the algorithmic write bytes)
+        const float ps = drop_prescale<ACT, MODE>(a.drop);  // dropout scale folded into the affine
 #pragma unroll
-        for (int hg = 0; hg < 4; ++hg) {
-            const int cg0 = (hg >> 1) * 32 + 16 * (hg & 1);  // + 4*hi: own channels of group 2*g2; + 8: group 2*g2+1
-            const float4 ca0 = *(const float4*)(a.coef_a + ci_base + cg0), ca1 = *(const float4*)(a.coef_a + ci_base + cg0 + 8);
-            const float4 cc0 = *(const float4*)(a.coef_c + ci_base + cg0), cc1 = *(const float4*)(a.coef_c + ci_base + cg0 + 8);
-            const float ps = drop_prescale<ACT, MODE>(a.drop);  // dropout scale folded into the affine
-            const float ca[8] = {ca0.x * ps, ca0.y * ps, ca0.z * ps, ca0.w * ps, ca1.x * ps, ca1.y * ps, ca1.z * ps, ca1.w * ps};
-            const float cc[8] = {cc0.x * ps, cc0.y * ps, cc0.z * ps, cc0.w * ps, cc1.x * ps, cc1.y * ps, cc1.z * ps, cc1.w * ps};
+        for (int nt = 0; nt < 2; ++nt) {
+            float ca[2][8], cc[2][8];
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt) {
+            for (int g2 = 0; g2 < 2; ++g2) {
+                const int cg0 = nt * 32 + 16 * g2;  // + 4*hi: own channels of group 2*g2; + 8: group 2*g2+1
+                const float4 ca0 = *(const float4*)(a.coef_a + ci_base + cg0), ca1 = *(const float4*)(a.coef_a + ci_base + cg0 + 8);
+                const float4 cc0 = *(const float4*)(a.coef_c + ci_base + cg0), cc1 = *(const float4*)(a.coef_c + ci_base + cg0 + 8);
+                ca[g2][0] = ca0.x * ps; ca[g2][1] = ca0.y * ps; ca[g2][2] = ca0.z * ps; ca[g2][3] = ca0.w * ps;
+                ca[g2][4] = ca1.x * ps; ca[g2][5] = ca1.y * ps; ca[g2][6] = ca1.z * ps; ca[g2][7] = ca1.w * ps;
+                cc[g2][0] = cc0.x * ps; cc[g2][1] = cc0.y * ps; cc[g2][2] = cc0.z * ps; cc[g2][3] = cc0.w * ps;
+                cc[g2][4] = cc1.x * ps; cc[g2][5] = cc1.y * ps; cc[g2][6] = cc1.z * ps; cc[g2][7] = cc1.w * ps;
+            }
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+                for (int g2 = 0; g2 < 2; ++g2) {
+                    const int cg0 = nt * 32 + 16 * g2;
                     const uint32_t obase = o0 + mt * mt_stride + cg0;
                     const uint32_t e0 = obase + 4 * hi;
                     float v[8];
 #pragma unroll
-                    for (int t = 0; t < 8; ++t) v[t] = fmaf(acc[hg >> 1][mt][8 * (hg & 1) + t], ca[t], cc[t]);
+                    for (int t = 0; t < 8; ++t) v[t] = fmaf(acc[nt][mt][8 * g2 + t], ca[g2][t], cc[g2][t]);
                     act_drop_fixed<4, ACT, MODE, true>(v, e0, row0, a.drop, key);
                     act_drop_fixed<4, ACT, MODE, true>(v + 4, e0 + 8, row0, a.drop, key);
                     uint32_t p0 = pack_el16x2(v[0], v[1]), p1 = pack_el16x2(v[2], v[3]);
@@ -503,6 +515,7 @@ __global__ __launch_bounds__(256, 2) void conv_up_halo_kernel(ConvArgs a, int ti
                     if ((SP != 1 && SP != 5) || (lane_valid && (SP != 5 || orow0 + 2 * mt < a.ho)))
                         *(uint4*)(a.out_el16 + (size_t)(sbase + 8 * hi)) = o;
                 }
+            }
         }
     };
     auto by_mode = [&](auto act_c) {
