@@ -13,6 +13,7 @@
 // path (conv.hip, conv_igemm2.hip, conv_up_halo.hip) is the next step for dgrad (a conv with transposed / flipped weights)
 // and wgrad (pixels as the contraction axis, like linattn_ctx_mfma_kernel); see DESIGN.md.
 #include "engine_internal.h"
+#include "train_internal.h"
 
 #include "../../include/dyffusion_hip.h"
 
@@ -51,6 +52,11 @@ struct TTape {              // what one recorded forward leaves for its backward
 struct TrainState {
     TNet net[2];
     TTape tape[4];
+    // caching allocator of the tapes / temporaries: blocks go back to the pool instead of hipFree (which synchronises the
+    // device) and are handed out again by exact size -- after the first step a training step allocates nothing.  Everything
+    // runs on one stream, so reuse is ordered behind the previous use.
+    std::multimap<size_t, void*> pool;
+    hipStream_t stream = nullptr;  // stream of the running train_forward / train_backward (zero-fills are queued on it)
 };
 
 }  // namespace dyf
@@ -135,9 +141,6 @@ __global__ void t_resize_bwd(const float* dout, int n, int ih, int iw, int C, in
 }
 
 // ------------------------------------------------------------------------------------------------ convolution (fp32, NHWC)
-struct TConv {
-    int n, h, w, cin, ho, wo, cout, k, s, p;
-};
 
 // y[n,oy,ox,co] = b[co] + sum_{tap,ci} x[n, oy*s-p+ky, ox*s-p+kx, ci] * wt[tap][ci][co]
 __global__ void t_conv_fwd(TConv g, const float* x, const float* wt, const float* bias, float* y) {
@@ -238,10 +241,11 @@ __global__ __launch_bounds__(256) void t_conv_wgrad(TConv g, const float* dz, co
 __global__ __launch_bounds__(256) void t_nc_sums(const float* z, int hw, int C, int px_per_block, double* S, double* Q) {
     const int b = blockIdx.y;
     const int p0 = blockIdx.x * px_per_block, p1 = min(p0 + px_per_block, hw);
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    const int nsub = (C < 256 && 256 % C == 0) ? 256 / C : 1, sub = nsub > 1 ? (int)threadIdx.x / C : 0;
+    for (int c = nsub > 1 ? (int)threadIdx.x % C : (int)threadIdx.x; c < C; c += (nsub > 1 ? C : (int)blockDim.x)) {
         double s = 0.0, q = 0.0;
         const float* zp = z + ((size_t)b * hw) * C + c;
-        for (int p = p0; p < p1; ++p) {
+        for (int p = p0 + sub; p < p1; p += nsub) {
             const double v = zp[(size_t)p * C];
             s += v;
             q += v * v;
@@ -324,12 +328,14 @@ __global__ __launch_bounds__(256) void t_norm_bwd_sums(TNorm a, const float* z, 
     const int b = blockIdx.y;
     const int p0 = blockIdx.x * px_per_block, p1 = min(p0 + px_per_block, a.hw);
     const long long per = (long long)a.hw * a.C;
-    for (int c = threadIdx.x; c < a.C; c += blockDim.x) {
+    // fewer channels than threads: 256 / C groups of threads share the block's pixels (coalesced rows, every lane busy)
+    const int nsub = (a.C < 256 && 256 % a.C == 0) ? 256 / a.C : 1, sub = nsub > 1 ? (int)threadIdx.x / a.C : 0;
+    for (int c = nsub > 1 ? (int)threadIdx.x % a.C : (int)threadIdx.x; c < a.C; c += (nsub > 1 ? a.C : (int)blockDim.x)) {
         const int idx = a.gn ? b * a.groups + c / (a.C / a.groups) : c;
         const float mu = a.mean[idx], rs = a.rstd[idx], ga = a.gamma[c], be = a.beta[c];
         const float sc = a.ss ? a.ss[(size_t)b * 2 * a.C + c] : 0.0f, sh = a.ss ? a.ss[(size_t)b * 2 * a.C + a.C + c] : 0.0f;
         double sa = 0.0, sb = 0.0, scx = 0.0, sd = 0.0;
-        for (int p = p0; p < p1; ++p) {
+        for (int p = p0 + sub; p < p1; p += nsub) {
             const long long e = (long long)p * a.C + c;
             const float xh = (z[(size_t)b * per + e] - mu) * rs, v = xh * ga + be, u = v * (1.0f + sc) + sh;
             const float dpre = dy[(size_t)b * per + e] * t_keep(a, b, (uint32_t)e) * t_dact(u, a.act);
@@ -399,19 +405,31 @@ __global__ void t_norm_bwd_apply(TNorm a, const float* z, const float* dy, const
 
 // ------------------------------------------------------------------------------------------------ small dense layers (time MLP, FiLM heads)
 // y[r][o] = b[o] + sum_k f(x[r][k]) * W[o][k];  f = identity (pre = 0) or SiLU (pre = 1)
-__global__ void t_linear_fwd(const float* x, const float* W, const float* bias, int rows, int K, int O, int pre, float* y) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= rows * O) return;
-    const int r = i / O, o = i % O;
-    float acc = bias[o];
-    for (int k = 0; k < K; ++k) {
-        float v = x[(size_t)r * K + k];
-        if (pre) v = v / (1.0f + expf(-v));
-        acc = fmaf(v, W[(size_t)o * K + k], acc);
+// y[r][o] = bias[o] + sum_k f(x[r][k]) W[o][k] (f = SiLU when pre): one wave per output column o, lanes over k (coalesced rows
+// of W), every row r of the (small) batch from the same W row
+__global__ __launch_bounds__(256) void t_linear_fwd(const float* x, const float* W, const float* bias, int rows, int K, int O, int pre, float* y) {
+    const int o = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (o >= O) return;
+    for (int r0 = 0; r0 < rows; r0 += 4) {
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int k = lane; k < K; k += 64) {
+            const float wv = W[(size_t)o * K + k];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (r0 + q < rows) {
+                    float v = x[(size_t)(r0 + q) * K + k];
+                    if (pre) v = v / (1.0f + expf(-v));
+                    acc[q] = fmaf(v, wv, acc[q]);
+                }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float a = acc[q];
+            for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off);
+            if (lane == 0 && r0 + q < rows) y[(size_t)(r0 + q) * O + o] = a + bias[o];
+        }
     }
-    y[i] = acc;
 }
-// dW[o][k] += sum_r dy[r][o] * f(x[r][k]);  db[o] += sum_r dy[r][o]
 __global__ void t_linear_bwd_w(const float* x, const float* dy, int rows, int K, int O, int pre, float* dW, float* db) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= O * K) return;
@@ -427,17 +445,26 @@ __global__ void t_linear_bwd_w(const float* x, const float* dy, int rows, int K,
     if (k == 0) db[o] += accb;
 }
 // dx[r][k] (+)= f'(x[r][k]) * sum_o dy[r][o] * W[o][k]
-__global__ void t_linear_bwd_x(const float* x, const float* W, const float* dy, int rows, int K, int O, int pre, int accumulate, float* dx) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= rows * K) return;
-    const int r = i / K, k = i % K;
+// dx[r][k] = (sum_o dy[r][o] W[o][k]) * f'(x[r][k]): a block = one row r x 16 columns k, 16 groups of threads split the O axis
+// (one workgroup looping over all of O took 214 us per FiLM head -- pure latency)
+__global__ __launch_bounds__(256) void t_linear_bwd_x(const float* x, const float* W, const float* dy, int rows, int K, int O, int pre, int accumulate, float* dx) {
+    __shared__ float red[16][17];
+    const int kb = (K + 15) / 16;
+    const int r = blockIdx.x / kb, k = (blockIdx.x % kb) * 16 + (threadIdx.x & 15), og = threadIdx.x >> 4;
     float acc = 0.0f;
-    for (int o = 0; o < O; ++o) acc = fmaf(dy[(size_t)r * O + o], W[(size_t)o * K + k], acc);
-    if (pre) {
-        const float v = x[i], sg = 1.0f / (1.0f + expf(-v));
-        acc *= sg * (1.0f + v * (1.0f - sg));
+    if (k < K)
+        for (int o = og; o < O; o += 16) acc = fmaf(dy[(size_t)r * O + o], W[(size_t)o * K + k], acc);
+    red[og][threadIdx.x & 15] = acc;
+    __syncthreads();
+    if (og == 0 && k < K) {
+        for (int q = 1; q < 16; ++q) acc += red[q][threadIdx.x & 15];
+        const size_t i = (size_t)r * K + k;
+        if (pre) {
+            const float v = x[i], sg = 1.0f / (1.0f + expf(-v));
+            acc *= sg * (1.0f + v * (1.0f - sg));
+        }
+        dx[i] = accumulate ? dx[i] + acc : acc;
     }
-    dx[i] = accumulate ? dx[i] + acc : acc;
 }
 __global__ void t_silu_bwd(const float* x, const float* dsilu, long long n, float* dx) {  // dx = dsilu * silu'(x)
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -497,6 +524,28 @@ __global__ void t_bias_grad(const float* d, long long pixels, int C, float* db) 
     }
     if (threadIdx.x == 0) db[c] += red[0];
 }
+// the same sums for channel counts that divide 256 or are multiples of 256: coalesced rows, one slice of the pixels per block
+__global__ __launch_bounds__(256) void t_bias_grad_rows(const float* d, long long pixels, int C, int rows_per_block, float* db) {
+    __shared__ float red[256];
+    const long long p0 = (long long)blockIdx.x * rows_per_block, p1 = p0 + rows_per_block < pixels ? p0 + rows_per_block : pixels;
+    if (C <= 256) {
+        const int c = threadIdx.x % C, sub = threadIdx.x / C, step = 256 / C;
+        float s = 0.0f;
+        for (long long p = p0 + sub; p < p1; p += step) s += d[p * C + c];
+        red[threadIdx.x] = s;
+        __syncthreads();
+        if (sub == 0) {
+            for (int k = 1; k < step; ++k) s += red[k * C + c];
+            atomicAdd(db + c, s);
+        }
+    } else {
+        for (int c = threadIdx.x; c < C; c += 256) {
+            float s = 0.0f;
+            for (long long p = p0; p < p1; ++p) s += d[p * C + c];
+            atomicAdd(db + c, s);
+        }
+    }
+}
 // d(mean criterion)/d pred * scale: kind 0 L1 (sign), 1 MSE, 2 smooth-L1 (beta 1)
 __global__ void t_criterion_grad(const float* pred, const float* target, long long n, int kind, float scale, float* d) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -508,13 +557,25 @@ __global__ void t_criterion_grad(const float* pred, const float* target, long lo
 }
 
 // ------------------------------------------------------------------------------------------------ host side
+std::map<void*, size_t>& g_block_bytes() {  // size of every live training block (for the pool)
+    static std::map<void*, size_t> m;
+    return m;
+}
 template <typename T>
 dyf_status talloc(dyf_engine* e, std::vector<void*>& owner, T** out, size_t count, bool zero = true) {
     void* p = nullptr;
-    const size_t bytes = std::max<size_t>(count * sizeof(T), 256);
-    TK(hipMalloc(&p, bytes));
-    if (zero) TK(hipMemset(p, 0, bytes));
+    const size_t bytes = (std::max<size_t>(count * sizeof(T), 256) + 255) / 256 * 256;
+    TrainState* ts = e->train;
+    auto it = ts ? ts->pool.find(bytes) : std::multimap<size_t, void*>::iterator();
+    if (ts && it != ts->pool.end()) {
+        p = it->second;
+        ts->pool.erase(it);
+    } else {
+        TK(hipMalloc(&p, bytes));
+    }
+    if (zero) TK(hipMemsetAsync(p, 0, bytes, ts ? ts->stream : nullptr));
     owner.push_back(p);
+    g_block_bytes()[p] = bytes;
     *out = (T*)p;
     return DYF_OK;
 }
@@ -526,23 +587,53 @@ dyf_status tupload(dyf_engine* e, std::vector<void*>& owner, float** out, const 
     return DYF_OK;
 }
 
-void tfree(std::vector<void*>& owner) {
-    for (void* p : owner) (void)hipFree(p);
+void tfree(dyf_engine* e, std::vector<void*>& owner) {  // back to the pool (train_destroy releases the pool)
+    for (void* p : owner) {
+        auto it = g_block_bytes().find(p);
+        if (e->train && it != g_block_bytes().end()) e->train->pool.emplace(it->second, p);
+        else (void)hipFree(p);
+    }
     owner.clear();
 }
 
+// DYF_TRAIN_MFMA=0 keeps the plain VALU kernels (A/B and a second implementation for the tests)
+bool train_mfma() {
+    static const bool on = !(getenv("DYF_TRAIN_MFMA") && atoi(getenv("DYF_TRAIN_MFMA")) == 0);
+    return on;
+}
+
 dyf_status conv_fwd(dyf_engine* e, const TConv& g, const float* x, const float* wt, const float* b, float* y, hipStream_t st) {
+    if (train_mfma() && tgemm_conv_fwd(g, x, wt, b, y, st)) {
+        TK(hipGetLastError());
+        return DYF_OK;
+    }
     hipLaunchKernelGGL(t_conv_fwd, dim3(nblk((long long)g.n * g.ho * g.wo * g.cout)), dim3(256), 0, st, g, x, wt, b, y);
     TK(hipGetLastError());
     return DYF_OK;
 }
 dyf_status conv_dgrad(dyf_engine* e, const TConv& g, const float* dz, const float* w, const float* bias, float* dx, hipStream_t st) {
+    if (train_mfma() && tgemm_conv_dgrad(g, dz, w, bias, dx, st)) {
+        TK(hipGetLastError());
+        return DYF_OK;
+    }
     hipLaunchKernelGGL(t_conv_dgrad, dim3(nblk((long long)g.n * g.h * g.w * g.cin)), dim3(256), 0, st, g, dz, w, bias, dx);
     TK(hipGetLastError());
     return DYF_OK;
 }
 dyf_status conv_wgrad(dyf_engine* e, const TConv& g, const float* dz, const float* x, float* dw, float* db, hipStream_t st) {
     const long long M = (long long)g.n * g.ho * g.wo;
+    if (train_mfma() && tgemm_conv_wgrad(g, dz, x, dw, st)) {
+        if (db) {
+            if (256 % g.cout == 0 || g.cout % 256 == 0) {
+                const int rpb = (int)std::max<long long>(64, (M + 1023) / 1024);
+                hipLaunchKernelGGL(t_bias_grad_rows, dim3((unsigned)((M + rpb - 1) / rpb)), dim3(256), 0, st, dz, M, g.cout, rpb, db);
+            } else {
+                hipLaunchKernelGGL(t_bias_grad, dim3(g.cout), dim3(256), 0, st, dz, M, g.cout, db);
+            }
+        }
+        TK(hipGetLastError());
+        return DYF_OK;
+    }
     const int tiles = g.k * g.k * ((g.cout + 15) / 16) * ((g.cin + 15) / 16);
     long long slices = std::max<long long>(1, std::min<long long>((M + 255) / 256, (4096 + tiles - 1) / tiles));
     const int ppb = (int)(((M + slices - 1) / slices + 15) / 16 * 16);
@@ -562,8 +653,12 @@ namespace dyf {
 
 void train_destroy(dyf_engine* e) {
     if (!e->train) return;
-    for (auto& n : e->train->net) tfree(n.owned);
-    for (auto& t : e->train->tape) tfree(t.owned);
+    for (auto& n : e->train->net) tfree(e, n.owned);
+    for (auto& t : e->train->tape) tfree(e, t.owned);
+    for (auto& kv : e->train->pool) {
+        g_block_bytes().erase(kv.second);
+        (void)hipFree(kv.second);
+    }
     delete e->train;
     e->train = nullptr;
 }
@@ -574,7 +669,7 @@ dyf_status train_store_weights(dyf_engine* e, int which, std::map<std::string, T
     TNet& t = e->train->net[which];
     const Net& n = e->net[which];
     TK(hipDeviceSynchronize());
-    tfree(t.owned);
+    tfree(e, t.owned);
     t = TNet{};
     auto V = [&](const std::string& k) { const TensorView& v = sd.at(k); return std::vector<float>(v.data, v.data + v.numel()); };
     auto grad = [&](float** g, size_t cnt) -> dyf_status {
@@ -665,9 +760,10 @@ dyf_status dyf_train_forward(dyf_engine* e, int32_t which, int32_t slot, const f
     if (n.cfg.with_time_emb && !time_dev) return fail(e, DYF_ERR_INVALID_ARGUMENT, "time must be given when with_time_emb");
     TK(hipSetDevice(e->cfg.device));
     hipStream_t st = (hipStream_t)stream;
+    e->train->stream = st;
     TTape& t = e->train->tape[slot];
     TK(hipStreamSynchronize(st));
-    tfree(t.owned);
+    tfree(e, t.owned);
     t = TTape{};
     t.net = which; t.nb = nb; t.flags = flags;
     const bool bn_batch = flags & DYF_TRAIN_BATCH_STATS, drop_on = (flags & DYF_TRAIN_DROPOUT) && n.cfg.dropout > 0.0f;
@@ -684,9 +780,9 @@ dyf_status dyf_train_forward(dyf_engine* e, int32_t which, int32_t slot, const f
     if (n.cfg.with_time_emb) {
         TA(t.e0, nb * n.dim); TA(t.l1, nb * n.tdim); TA(t.gl, nb * n.tdim); TA(t.temb, nb * n.tdim);
         hipLaunchKernelGGL(t_sinusoid, dim3(nblk(nb * n.dim)), dim3(256), 0, st, time_dev, nb, n.dim, t.e0);
-        hipLaunchKernelGGL(t_linear_fwd, dim3(nblk(nb * n.tdim)), dim3(256), 0, st, t.e0, w.t_w1, w.t_b1, nb, n.dim, n.tdim, 0, t.l1);
+        hipLaunchKernelGGL(t_linear_fwd, dim3((unsigned)((n.tdim + 3) / 4)), dim3(256), 0, st, t.e0, w.t_w1, w.t_b1, nb, n.dim, n.tdim, 0, t.l1);
         hipLaunchKernelGGL(t_gelu_fwd, dim3(nblk((long long)nb * n.tdim)), dim3(256), 0, st, t.l1, (long long)nb * n.tdim, t.gl);
-        hipLaunchKernelGGL(t_linear_fwd, dim3(nblk(nb * n.tdim)), dim3(256), 0, st, t.gl, w.t_w2, w.t_b2, nb, n.tdim, n.tdim, 0, t.temb);
+        hipLaunchKernelGGL(t_linear_fwd, dim3((unsigned)((n.tdim + 3) / 4)), dim3(256), 0, st, t.gl, w.t_w2, w.t_b2, nb, n.tdim, n.tdim, 0, t.temb);
     }
     // ---- stem: cat -> outer resample -> 1x1 conv
     TA(t.x_in, (size_t)nb * hw * cin);
@@ -725,14 +821,14 @@ dyf_status dyf_train_forward(dyf_engine* e, int32_t which, int32_t slot, const f
         const int kind = b.gn ? 2 : (bn_batch ? 0 : 1);
         if (kind != 1) {
             TK(hipMemsetAsync(S, 0, (size_t)nb * 1024 * 2 * sizeof(double), st));
-            const int ppb = std::max(1, (ohw + 63) / 64);
+            const int ppb = std::max(16, (ohw + 255) / 256);
             hipLaunchKernelGGL(t_nc_sums, dim3((ohw + ppb - 1) / ppb, nb), dim3(256), 0, st, t.z[i], ohw, b.cout, ppb, S, Q);
         }
         hipLaunchKernelGGL(t_stats_finalize, dim3(nblk(std::max(nidx, b.cout))), dim3(256), 0, st, kind, S, Q, nb, ohw, b.cout, 8, w.blk[i].rmean,
                            w.blk[i].rvar, t.mean[i], t.rstd[i]);
         if (n.cfg.with_time_emb) {
             TA(t.ss[i], (size_t)nb * 2 * b.cout);
-            hipLaunchKernelGGL(t_linear_fwd, dim3(nblk(nb * 2 * b.cout)), dim3(256), 0, st, t.temb, w.blk[i].fw, w.blk[i].fb, nb, n.tdim, 2 * b.cout, 1, t.ss[i]);
+            hipLaunchKernelGGL(t_linear_fwd, dim3((unsigned)((2 * b.cout + 3) / 4)), dim3(256), 0, st, t.temb, w.blk[i].fw, w.blk[i].fb, nb, n.tdim, 2 * b.cout, 1, t.ss[i]);
         }
         TNorm a{nb, ohw, b.cout, 8, b.gn ? 1 : 0, b.act, t.mean[i], t.rstd[i], w.blk[i].gamma, w.blk[i].beta, t.ss[i], drop_on ? 1 : 0,
                 1.0f / (1.0f - n.cfg.dropout), keep_threshold16(n.cfg.dropout), rng_layer_salt((uint32_t)i), t.row_keys};
@@ -768,13 +864,14 @@ dyf_status dyf_train_backward(dyf_engine* e, int32_t slot, const float* dout_dev
     if (!e->train || e->train->tape[slot].net < 0) return fail(e, DYF_ERR_STATE, "no forward recorded in this tape slot");
     TK(hipSetDevice(e->cfg.device));
     hipStream_t st = (hipStream_t)stream;
+    e->train->stream = st;
     TTape& t = e->train->tape[slot];
     Net& n = e->net[t.net];
     TNet& w = e->train->net[t.net];
     const int nb = t.nb, H = e->cfg.height, W = e->cfg.width, hw = H * W, cin = n.cin_total, C = n.cfg.out_channels;
     const bool bn_batch = t.flags & DYF_TRAIN_BATCH_STATS, drop_on = (t.flags & DYF_TRAIN_DROPOUT) && n.cfg.dropout > 0.0f;
     std::vector<void*> tmp;
-#define TS(expr) do { dyf_status _s = (expr); if (_s != DYF_OK) { tfree(tmp); return _s; } } while (0)
+#define TS(expr) do { dyf_status _s = (expr); if (_s != DYF_OK) { tfree(e, tmp); return _s; } } while (0)
 #define TA(ptr, count) TS(talloc(e, tmp, &(ptr), (size_t)(count), false))
 #define TZ(ptr, count) TS(talloc(e, tmp, &(ptr), (size_t)(count), true))
     const int lh = n.blk[11].out_h, lw = n.blk[11].out_w;
@@ -819,7 +916,7 @@ dyf_status dyf_train_backward(dyf_engine* e, int32_t slot, const float* dout_dev
                 1.0f / (1.0f - n.cfg.dropout), keep_threshold16(n.cfg.dropout), rng_layer_salt((uint32_t)i), t.row_keys};
         TK(hipMemsetAsync(R, 0, (size_t)nb * 1024 * 4 * sizeof(double), st));
         double *A = R, *B = R + (size_t)nb * 1024, *Cc = R + (size_t)2 * nb * 1024, *Dd = R + (size_t)3 * nb * 1024;
-        const int ppb = std::max(1, (ohw + 63) / 64);
+        const int ppb = std::max(16, (ohw + 255) / 256);
         hipLaunchKernelGGL(t_norm_bwd_sums, dim3((ohw + ppb - 1) / ppb, nb), dim3(256), 0, st, a, t.z[i], dy, ppb, A, B, Cc, Dd);
         const bool batch_stats = b.gn || bn_batch;
         hipLaunchKernelGGL(t_norm_bwd_combine, dim3(nblk(std::max(nb * b.cout, nb * 8))), dim3(256), 0, st, a, A, B, Cc, Dd,
@@ -834,7 +931,7 @@ dyf_status dyf_train_backward(dyf_engine* e, int32_t slot, const float* dout_dev
                 hipLaunchKernelGGL(t_linear_bwd_w, dim3(nblk(2 * b.cout * n.tdim)), dim3(256), 0, st, t.temb, dss, nb, n.tdim, 2 * b.cout, 1, w.blk[i].g_fw,
                                    w.blk[i].g_fb);
             // d silu(temb) accumulated over the blocks (the SiLU derivative is applied once below)
-            hipLaunchKernelGGL(t_linear_bwd_x, dim3(nblk(nb * n.tdim)), dim3(256), 0, st, t.temb, w.blk[i].fw, dss, nb, n.tdim, 2 * b.cout, 0, 1, dsilu);
+            hipLaunchKernelGGL(t_linear_bwd_x, dim3((unsigned)(nb * ((n.tdim + 15) / 16))), dim3(256), 0, st, t.temb, w.blk[i].fw, dss, nb, n.tdim, 2 * b.cout, 0, 1, dsilu);
         }
         const TConv g = block_geom(b, nb);
         if (param_grads) TS(conv_wgrad(e, g, dz, t.cin_ptr[i], w.blk[i].g_w, w.blk[i].g_b, st));
@@ -871,13 +968,13 @@ dyf_status dyf_train_backward(dyf_engine* e, int32_t slot, const float* dout_dev
         TA(dtemb, (size_t)nb * n.tdim); TA(dgl, (size_t)nb * n.tdim);
         hipLaunchKernelGGL(t_silu_bwd, dim3(nblk((long long)nb * n.tdim)), dim3(256), 0, st, t.temb, dsilu, (long long)nb * n.tdim, dtemb);
         hipLaunchKernelGGL(t_linear_bwd_w, dim3(nblk(n.tdim * n.tdim)), dim3(256), 0, st, t.gl, dtemb, nb, n.tdim, n.tdim, 0, w.g_t_w2, w.g_t_b2);
-        hipLaunchKernelGGL(t_linear_bwd_x, dim3(nblk(nb * n.tdim)), dim3(256), 0, st, t.gl, w.t_w2, dtemb, nb, n.tdim, n.tdim, 0, 0, dgl);
+        hipLaunchKernelGGL(t_linear_bwd_x, dim3((unsigned)(nb * ((n.tdim + 15) / 16))), dim3(256), 0, st, t.gl, w.t_w2, dtemb, nb, n.tdim, n.tdim, 0, 0, dgl);
         hipLaunchKernelGGL(t_gelu_bwd, dim3(nblk((long long)nb * n.tdim)), dim3(256), 0, st, t.l1, (long long)nb * n.tdim, dgl);
         hipLaunchKernelGGL(t_linear_bwd_w, dim3(nblk(n.tdim * n.dim)), dim3(256), 0, st, t.e0, dgl, nb, n.dim, n.tdim, 0, w.g_t_w1, w.g_t_b1);
         TK(hipGetLastError());
     }
     TK(hipStreamSynchronize(st));
-    tfree(tmp);
+    tfree(e, tmp);
 #undef TA
 #undef TZ
 #undef TS

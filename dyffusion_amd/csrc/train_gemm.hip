@@ -1,0 +1,249 @@
+// fp32 implicit-GEMM convolutions of the training step on the matrix cores (gfx950 `v_mfma_f32_32x32x2_f32`): forward,
+// data gradient and weight gradient of `nn.Conv2d` on fp32 NHWC tensors (csrc/train.hip: conv_fwd / conv_dgrad / conv_wgrad;
+// the reference gets them from torch.autograd over src/models/unet_simple.py:29-56).  Operands stay fp32 end to end, so the
+// gradient parity with autograd over the oracle stays at the 1e-6 level of the plain VALU kernels these replace (only the
+// summation order differs); fp32 MFMA peaks at 157 TFLOP/s on MI355X, the VALU kernels ran at 4-6.
+//
+// One kernel, three gathers.  C[M][N] = sum_k A(m, k) * B(k, n), workgroup tile 128 x 64, K stage 16, 4 waves of 64 x 32
+// (two 32 x 32 accumulators, one B fragment feeds both):
+//   forward   M = output pixels, N = cout, K = (tap, ci):  A = x at the tap's shifted pixel (zero outside), B = wt[tap][ci][co]
+//   dgrad     M = input pixels,  N = cin,  K = (tap, co):  A = dz at ((iy + p - ky) / s, ..) where divisible, B = w[co][tap][ci]
+//   wgrad     M = cout, N = cin, K = output pixels (one tap per workgroup, pixel range split over workgroups, merged with
+//             atomics like the kernel it replaces):  A = dz[pixel][co], B = x at the tap's shifted pixel
+// Both operand tiles sit in LDS as [row][16 k] with k permuted to [k even | k odd] (a lane of the 32x32x2 MFMA needs
+// k = 2j + (lane >> 5) for j = 0..7: two ds_read_b128), rows 20 floats apart (conflict-free for the b128 lane groups).
+// Global loads are 16-byte vectors along the contiguous axis of each operand (channels), issued for stage s + 1 before the
+// MFMAs of stage s.
+#include "train_internal.h"
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+namespace {
+
+constexpr int GM = 128, GN = 64, GK = 16, LDR = 20;
+enum { TG_FWD = 0, TG_DGRAD = 1, TG_WGRAD = 2 };
+
+template <int MODE>
+__global__ __launch_bounds__(256) void t_gemm_mfma(dyf::TConv g, const float* __restrict__ Ap, const float* __restrict__ Bp,
+                                                   const float* __restrict__ bias, float* __restrict__ Cp, int split_len) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __shared__ __attribute__((aligned(16))) float As[2][GM * LDR];
+    __shared__ __attribute__((aligned(16))) float Bs[2][GN * LDR];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tm = blockIdx.x, tn = blockIdx.y;
+    const int taps = g.k * g.k;
+    const long long opix = (long long)g.n * g.ho * g.wo, ipix = (long long)g.n * g.h * g.w;
+    const long long M = MODE == TG_FWD ? opix : MODE == TG_DGRAD ? ipix : g.cout;
+    const int CK = MODE == TG_FWD ? g.cin : g.cout;  // channels per tap on the K axis (forward / dgrad)
+    int tap = 0;
+    long long kbeg = 0, kend = 0;  // wgrad: pixel range of this workgroup
+    int nstage, st0 = 0;  // stages [st0, st0 + nstage) of the K axis
+    if (MODE == TG_WGRAD) {
+        tap = blockIdx.z % taps;
+        kbeg = (long long)(blockIdx.z / taps) * split_len;
+        kend = kbeg + split_len < opix ? kbeg + split_len : opix;
+        nstage = (int)((kend - kbeg + GK - 1) / GK);
+    } else {
+        // split_len > 0: split-K over gridDim.z workgroups of split_len stages each (layers with few output tiles and a deep K:
+        // the 4 x 4 ... 16 x 16 planes at small batches), merged with atomics into the zero-initialised output
+        const int total = taps * CK / GK;
+        st0 = split_len > 0 ? (int)blockIdx.z * split_len : 0;
+        nstage = split_len > 0 ? min(split_len, total - st0) : total;
+    }
+
+    // ---- per-thread load slots
+    // A, forward / dgrad: 2 slots (row = s >> 2, k quad = s & 3), float4 along k; wgrad: 2 slots (k = s >> 5, m quad = s & 31)
+    int a_b[2], a_y[2], a_x[2];
+    bool a_ok[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int s = tid + 256 * i;
+        a_b[i] = a_y[i] = a_x[i] = 0;
+        a_ok[i] = false;
+        if (MODE != TG_WGRAD) {
+            const long long m = (long long)tm * GM + (s >> 2);
+            a_ok[i] = m < M;
+            const int pw = MODE == TG_FWD ? g.wo : g.w, ph = MODE == TG_FWD ? g.ho : g.h;
+            const long long mm = a_ok[i] ? m : 0;
+            a_x[i] = (int)(mm % pw);
+            a_y[i] = (int)((mm / pw) % ph);
+            a_b[i] = (int)(mm / ((long long)pw * ph));
+        }
+    }
+    const int b_k = tid >> 4, b_nq = tid & 15;  // B: k row, n quad
+
+    float4 ra[2], rb;
+    auto load = [&](int stage) {
+        if (MODE != TG_WGRAD) {
+            const int k0 = stage * GK;
+            const int tp = k0 / CK, c0 = k0 - tp * CK;
+            const int ky = tp / g.k, kx = tp - ky * g.k;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int kq = (tid + 256 * i) & 3;
+                ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (MODE == TG_FWD) {
+                    const int iy = a_y[i] * g.s - g.p + ky, ix = a_x[i] * g.s - g.p + kx;
+                    if (a_ok[i] && (unsigned)iy < (unsigned)g.h && (unsigned)ix < (unsigned)g.w)
+                        ra[i] = *(const float4*)(Ap + (((size_t)a_b[i] * g.h + iy) * g.w + ix) * g.cin + c0 + kq * 4);
+                } else {
+                    const int ty = a_y[i] + g.p - ky, tx = a_x[i] + g.p - kx;
+                    const int oy = ty / g.s, ox = tx / g.s;
+                    if (a_ok[i] && ty >= 0 && tx >= 0 && oy * g.s == ty && ox * g.s == tx && oy < g.ho && ox < g.wo)
+                        ra[i] = *(const float4*)(Ap + (((size_t)a_b[i] * g.ho + oy) * g.wo + ox) * g.cout + c0 + kq * 4);
+                }
+            }
+            if (MODE == TG_FWD)
+                rb = *(const float4*)(Bp + ((size_t)tp * g.cin + c0 + b_k) * g.cout + tn * GN + b_nq * 4);
+            else
+                rb = *(const float4*)(Bp + ((size_t)(c0 + b_k) * taps + tp) * g.cin + tn * GN + b_nq * 4);
+        } else {
+            const long long p0 = kbeg + (long long)stage * GK;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int s = tid + 256 * i;
+                const long long pix = p0 + (s >> 5);
+                const int m = tm * GM + (s & 31) * 4;
+                ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (pix < kend && m < g.cout) ra[i] = *(const float4*)(Ap + (size_t)pix * g.cout + m);
+            }
+            const long long pix = p0 + b_k;
+            rb = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (pix < kend) {
+                const int ox = (int)(pix % g.wo), oy = (int)((pix / g.wo) % g.ho), b = (int)(pix / ((long long)g.wo * g.ho));
+                const int ky = tap / g.k, kx = tap - ky * g.k;
+                const int iy = oy * g.s - g.p + ky, ix = ox * g.s - g.p + kx;
+                if ((unsigned)iy < (unsigned)g.h && (unsigned)ix < (unsigned)g.w)
+                    rb = *(const float4*)(Bp + (((size_t)b * g.h + iy) * g.w + ix) * g.cin + tn * GN + b_nq * 4);
+            }
+        }
+    };
+    // element k of a row lives at (k & 1) * 8 + (k >> 1)
+    auto store = [&](int buf) {
+        if (MODE != TG_WGRAD) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int s = tid + 256 * i;
+                float* d = &As[buf][(s >> 2) * LDR + 2 * (s & 3)];  // k = 4 kq + e: e = 0, 2 -> even half; e = 1, 3 -> odd half
+                *(float2*)d = make_float2(ra[i].x, ra[i].z);
+                *(float2*)(d + 8) = make_float2(ra[i].y, ra[i].w);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int s = tid + 256 * i;
+                const int k = s >> 5, kp = (k & 1) * 8 + (k >> 1);
+                float* d = &As[buf][((s & 31) * 4) * LDR + kp];
+                d[0] = ra[i].x; d[LDR] = ra[i].y; d[2 * LDR] = ra[i].z; d[3 * LDR] = ra[i].w;
+            }
+        }
+        const int kp = (b_k & 1) * 8 + (b_k >> 1);
+        float* d = &Bs[buf][(b_nq * 4) * LDR + kp];
+        d[0] = rb.x; d[LDR] = rb.y; d[2 * LDR] = rb.z; d[3 * LDR] = rb.w;
+    };
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+
+    if (nstage > 0) {
+        load(st0);
+        store(0);
+    }
+    __syncthreads();
+    for (int st = 0; st < nstage; ++st) {
+        const int buf = st & 1;
+        if (st + 1 < nstage) load(st0 + st + 1);
+        const float* ar0 = &As[buf][(wm * 64 + l31) * LDR + hi * 8];
+        const float* ar1 = ar0 + 32 * LDR;
+        const float* br = &Bs[buf][(wn * 32 + l31) * LDR + hi * 8];
+        const float4 a00 = *(const float4*)ar0, a01 = *(const float4*)(ar0 + 4);
+        const float4 a10 = *(const float4*)ar1, a11 = *(const float4*)(ar1 + 4);
+        const float4 b0 = *(const float4*)br, b1 = *(const float4*)(br + 4);
+        const float af0[8] = {a00.x, a00.y, a00.z, a00.w, a01.x, a01.y, a01.z, a01.w};
+        const float af1[8] = {a10.x, a10.y, a10.z, a10.w, a11.x, a11.y, a11.z, a11.w};
+        const float bf[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af0[j], bf[j], acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af1[j], bf[j], acc[1], 0, 0, 0);
+        }
+        if (st + 1 < nstage) store(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane (l31, hi), register r of accumulator i: row wm*64 + i*32 + 8*(r/4) + 4*hi + r%4, column wn*32 + l31
+    const int n = tn * GN + wn * 32 + l31;
+    const float bv = (MODE != TG_WGRAD && bias) ? bias[n] : 0.0f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const long long m = (long long)tm * GM + wm * 64 + i * 32 + 8 * (r >> 2) + 4 * hi + (r & 3);
+            if (m >= M) continue;
+            if (MODE == TG_WGRAD) {
+                atomicAdd(Cp + ((size_t)m * taps + tap) * g.cin + n, acc[i][r]);
+            } else {
+                const int NC = MODE == TG_FWD ? g.cout : g.cin;
+                if (split_len > 0) atomicAdd(Cp + (size_t)m * NC + n, acc[i][r] + (blockIdx.z == 0 ? bv : 0.0f));
+                else Cp[(size_t)m * NC + n] = acc[i][r] + bv;
+            }
+        }
+#endif
+}
+
+}  // namespace
+
+namespace dyf {
+
+// split-K plan of a forward / dgrad launch: (splits, stages per split); splits == 1 -> no split
+static void plan_splitk(long long tiles, int stages, int& splits, int& len) {
+    splits = 1;
+    len = 0;
+    if (tiles >= 128 || stages < 16) return;
+    long long want = std::min<long long>((512 + tiles - 1) / tiles, stages / 4);  // >= 4 stages per split
+    if (want < 2) return;
+    len = (int)((stages + want - 1) / want);
+    splits = (stages + len - 1) / len;
+    if (splits < 2) { splits = 1; len = 0; }
+}
+
+bool tgemm_conv_fwd(const TConv& g, const float* x, const float* wt, const float* bias, float* y, hipStream_t st) {
+    if (g.cin % GK != 0 || g.cout % GN != 0) return false;
+    const long long M = (long long)g.n * g.ho * g.wo, mt = (M + GM - 1) / GM;
+    int splits, len;
+    plan_splitk(mt * (g.cout / GN), g.k * g.k * g.cin / GK, splits, len);
+    if (splits > 1 && hipMemsetAsync(y, 0, (size_t)M * g.cout * sizeof(float), st) != hipSuccess) return false;
+    hipLaunchKernelGGL(t_gemm_mfma<TG_FWD>, dim3((unsigned)mt, g.cout / GN, splits), dim3(256), 0, st, g, x, wt, bias, y, len);
+    return true;
+}
+
+bool tgemm_conv_dgrad(const TConv& g, const float* dz, const float* w, const float* bias, float* dx, hipStream_t st) {
+    if (g.cout % GK != 0 || g.cin % GN != 0) return false;
+    const long long M = (long long)g.n * g.h * g.w, mt = (M + GM - 1) / GM;
+    int splits, len;
+    plan_splitk(mt * (g.cin / GN), g.k * g.k * g.cout / GK, splits, len);
+    if (splits > 1 && hipMemsetAsync(dx, 0, (size_t)M * g.cin * sizeof(float), st) != hipSuccess) return false;
+    hipLaunchKernelGGL(t_gemm_mfma<TG_DGRAD>, dim3((unsigned)mt, g.cin / GN, splits), dim3(256), 0, st, g, dz, w, bias, dx, len);
+    return true;
+}
+
+// dw += ... (the caller accumulates the bias gradient separately)
+bool tgemm_conv_wgrad(const TConv& g, const float* dz, const float* x, float* dw, hipStream_t st) {
+    if (g.cin % GN != 0 || g.cout % 4 != 0) return false;
+    const long long pix = (long long)g.n * g.ho * g.wo;
+    const int taps = g.k * g.k, mt = (g.cout + GM - 1) / GM, nt = g.cin / GN;
+    // enough workgroups to fill the chip, at least 256 pixels per split
+    long long splits = std::max<long long>(1, std::min<long long>((pix + 255) / 256, (2048 + (long long)mt * nt * taps - 1) / ((long long)mt * nt * taps)));
+    int len = (int)(((pix + splits - 1) / splits + GK - 1) / GK * GK);
+    splits = (pix + len - 1) / len;
+    if ((long long)taps * splits > 65535) return false;
+    hipLaunchKernelGGL(t_gemm_mfma<TG_WGRAD>, dim3(mt, nt, (unsigned)(taps * splits)), dim3(256), 0, st, g, dz, x, nullptr, dw, len);
+    return true;
+}
+
+}  // namespace dyf

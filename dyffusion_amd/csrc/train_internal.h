@@ -1,0 +1,19 @@
+// Shared between train.hip (the recorded forward / backward of arch unet_simple) and train_gemm.hip (its convolutions on the
+// fp32 matrix cores).
+#pragma once
+#include "common.h"
+
+#include <algorithm>
+
+namespace dyf {
+
+struct TConv {  // geometry of one nn.Conv2d on NHWC fp32 tensors: x (n, h, w, cin) -> y (n, ho, wo, cout), k x k / stride s / pad p
+    int n, h, w, cin, ho, wo, cout, k, s, p;
+};
+
+// fp32 MFMA implicit-GEMM forms (train_gemm.hip); return false when the shape is not covered (caller falls back to the VALU kernel)
+bool tgemm_conv_fwd(const TConv& g, const float* x, const float* wt, const float* bias, float* y, hipStream_t st);
+bool tgemm_conv_dgrad(const TConv& g, const float* dz, const float* w, const float* bias, float* dx, hipStream_t st);
+bool tgemm_conv_wgrad(const TConv& g, const float* dz, const float* x, float* dw, hipStream_t st);
+
+}  // namespace dyf

@@ -172,3 +172,37 @@ def test_interpolator_training_step_matches_autograd_of_the_oracle(name, monkeyp
     le = net.get_loss(exp.get_inputs_from_dynamics(dyn.to(DEV)), dyn[torch.arange(B), hp["window"] + t - 1].to(DEV), time=t.to(DEV),
                       condition=cond.to(DEV))
     assert le.requires_grad is False and float(le) > 0
+
+
+def test_training_step_at_dim64_on_the_matrix_cores_matches_autograd_of_the_oracle():
+    """The fp32 MFMA implicit-GEMM convolutions (csrc/train_gemm.hip: forward, dgrad, wgrad, split-K on the small planes) only
+    take layers with >= 64 channels: a dim-64 pair on 23 x 11 fields / 128 x 128 backbone grid, both loss terms, against
+    torch.autograd over the oracle with the engine's own masks -- same tolerances as the dim-4 fixtures.  (At a 64 x 64
+    grid the batch statistics of the 2 x 2 plane come from 12 values and amplify fp32 rounding: 1.2e-3 with the VALU kernels,
+    4.9e-4 with these.)"""
+    from tests.gpu_common import seeded_pair
+    mk = dict(dim=64, outer_sample_mode="bilinear", upsample_dims=[128, 128], with_time_emb=True, input_dropout=0.0, dropout=0.15)
+    hp = dict(timesteps=4, schedule="before_t1_only", additional_interpolation_steps=0, additional_interpolation_steps_factor=0,
+              interpolate_before_t1=True, time_encoding="dynamics", forward_conditioning="none", lambda_reconstruction=1.0,
+              lambda_reconstruction2=0.5, loss_function="l1", enable_interpolator_dropout=True, model=mk)
+    C, Cs, B = 3, 2, 3
+    PF, PI = seeded_pair(64, C, Cs)
+    g = torch.Generator().manual_seed(3)
+    xt_last, cond = torch.randn(B, C, 23, 11, generator=g), torch.randn(B, C, 23, 11, generator=g)
+    sc, t = torch.rand(B, Cs, 23, 11, generator=g), torch.tensor([0, 2, 3])
+    m = build_dyffusion(PF, PI, mk, C, Cs, hp, max_batch=B)
+    seed = 4242
+    m.seed(seed)
+    m.train()
+    out = m.p_losses(xt_last.to(DEV), cond.to(DEV), t.to(DEV), static_condition=sc.to(DEV))
+    out["loss"].backward()
+    want, grads, _ = _oracle_step(PF, PI, mk, hp, xt_last, cond, t, sc, seed)
+    for k_got, k_want in (("loss", "loss"), ("train/loss_forward", "loss_forward"), ("train/loss_forward2", "loss_forward2")):
+        assert float(out[k_got]) == pytest.approx(float(want[k_want]), rel=1e-4), k_got
+    got = {k: p.grad for k, p in m.model.named_parameters()}
+    gn = float(torch.cat([g_.reshape(-1) for g_ in grads.values()]).norm())
+    errs = {k: float((got[k].cpu() - grads[k]).norm()) / gn for k in grads}
+    worst = max(errs, key=errs.get)
+    print(f"dim 64: loss {float(out['loss']):.6f}, grad norm {gn:.4f}, worst per-tensor gradient error / grad norm = {errs[worst]:.2e} ({worst})")
+    assert errs[worst] <= 1e-3
+    m.eval()

@@ -22,7 +22,8 @@ xt_last = torch.randn(B, bench.C, bench.H, bench.W, generator=g).cuda()
 cond = torch.randn(B, bench.C, bench.H, bench.W, generator=g).cuda()
 static = torch.rand(B, bench.CS, bench.H, bench.W, generator=g).cuda()
 t = torch.randint(0, bench.HORIZON, (B,), generator=g).cuda()
-for it in range(2):
+best = None
+for it in range(5):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     out = model.p_losses(xt_last, cond, t, static_condition=static)
@@ -31,6 +32,13 @@ for it in range(2):
     out["loss"].backward()
     torch.cuda.synchronize()
     t2 = time.perf_counter()
+    if it > 0 and (best is None or t2 - t0 < best[2] - best[0]):
+        best = (t0, t1, t2)
+    for p_ in model.model.parameters():
+        p_.grad = None
+t0, t1, t2 = best
+out = model.p_losses(xt_last, cond, t, static_condition=static)
+out["loss"].backward()
 gn = float(torch.cat([p.grad.reshape(-1) for p in model.model.parameters()]).norm())
 fl = model._engine.net_flops(0)
 print(f"training step B={B}: forward {1e3 * (t1 - t0):.0f} ms, backward {1e3 * (t2 - t1):.0f} ms, loss {float(out['loss']):.4f}, "
