@@ -511,18 +511,16 @@ __global__ void t_add(float* a, const float* b, long long n) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) a[i] += b[i];
 }
-__global__ void t_bias_grad(const float* d, long long pixels, int C, float* db) {  // db[c] += sum_p d[p][c]
-    const int c = blockIdx.x;
-    __shared__ float red[256];
-    float s = 0.0f;
-    for (long long p = threadIdx.x; p < pixels; p += 256) s += d[p * C + c];
-    red[threadIdx.x] = s;
+// db[c] += sum_p d[p][c] for any (small) channel count: coalesced sweep of a slice of the tensor, per-block sums in LDS
+__global__ __launch_bounds__(256) void t_bias_grad(const float* d, long long pixels, int C, long long elems_per_block, float* db) {
+    extern __shared__ float bg_sh[];
+    for (int c = threadIdx.x; c < C; c += 256) bg_sh[c] = 0.0f;
     __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) db[c] += red[0];
+    const long long total = pixels * C;
+    const long long e0 = (long long)blockIdx.x * elems_per_block, e1 = e0 + elems_per_block < total ? e0 + elems_per_block : total;
+    for (long long i = e0 + threadIdx.x; i < e1; i += 256) atomicAdd(&bg_sh[(int)(i % C)], d[i]);
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) atomicAdd(db + c, bg_sh[c]);
 }
 // the same sums for channel counts that divide 256 or are multiples of 256: coalesced rows, one slice of the pixels per block
 __global__ __launch_bounds__(256) void t_bias_grad_rows(const float* d, long long pixels, int C, int rows_per_block, float* db) {
@@ -596,6 +594,11 @@ void tfree(dyf_engine* e, std::vector<void*>& owner) {  // back to the pool (tra
     owner.clear();
 }
 
+void launch_bias_grad(const float* d, long long pixels, int C, float* db, hipStream_t st) {
+    const long long total = pixels * C, per = std::max<long long>(4096, (total + 1023) / 1024);
+    hipLaunchKernelGGL(t_bias_grad, dim3((unsigned)((total + per - 1) / per)), dim3(256), (size_t)C * sizeof(float), st, d, pixels, C, per, db);
+}
+
 // DYF_TRAIN_MFMA=0 keeps the plain VALU kernels (A/B and a second implementation for the tests)
 bool train_mfma() {
     static const bool on = !(getenv("DYF_TRAIN_MFMA") && atoi(getenv("DYF_TRAIN_MFMA")) == 0);
@@ -628,7 +631,7 @@ dyf_status conv_wgrad(dyf_engine* e, const TConv& g, const float* dz, const floa
                 const int rpb = (int)std::max<long long>(64, (M + 1023) / 1024);
                 hipLaunchKernelGGL(t_bias_grad_rows, dim3((unsigned)((M + rpb - 1) / rpb)), dim3(256), 0, st, dz, M, g.cout, rpb, db);
             } else {
-                hipLaunchKernelGGL(t_bias_grad, dim3(g.cout), dim3(256), 0, st, dz, M, g.cout, db);
+                launch_bias_grad(dz, M, g.cout, db, st);
             }
         }
         TK(hipGetLastError());
@@ -884,7 +887,7 @@ dyf_status dyf_train_backward(dyf_engine* e, int32_t slot, const float* dout_dev
     const TConv gc{nb, 2 * lh, 2 * lw, C, lh, lw, n.dim, 4, 2, 1};
     if (param_grads) {
         TS(conv_wgrad(e, gc, t.xlast, d_r, w.g_ro_w, nullptr, st));
-        hipLaunchKernelGGL(t_bias_grad, dim3(C), dim3(256), 0, st, d_r, (long long)nb * 4 * lh * lw, C, w.g_ro_b);
+        launch_bias_grad(d_r, (long long)nb * 4 * lh * lw, C, w.g_ro_b, st);
     }
     TA(dx, (size_t)nb * lh * lw * n.dim);
     TS(conv_fwd(e, gc, d_r, w.ro_wt, nullptr, dx, st));
