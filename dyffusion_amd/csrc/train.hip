@@ -8,10 +8,10 @@
 // bilinear resampling (align_corners=False) and its adjoint, skip concatenation.  The frozen interpolator takes part with
 // running-statistics BatchNorm and input gradients only (the second loss term differentiates THROUGH it, :534-557).
 //
-// First correct form: everything here is fp32 (NHWC activations, fp32 weights in [cout][tap][cin] order) on plain VALU
-// kernels -- gradient parity with autograd is ~1e-5, not bf16-limited.  The MFMA implicit-GEMM machinery of the sampling
-// path (conv.hip, conv_igemm2.hip, conv_up_halo.hip) is the next step for dgrad (a conv with transposed / flipped weights)
-// and wgrad (pixels as the contraction axis, like linattn_ctx_mfma_kernel); see DESIGN.md.
+// Everything here is fp32 (NHWC activations, fp32 weights in [cout][tap][cin] and [tap][cin][cout] order, fp64 statistics):
+// gradient parity with autograd is ~1e-6, not bf16-limited.  The convolutions with >= 64 channels run on the fp32 matrix cores
+// (train_gemm.hip: one implicit-GEMM kernel with forward / dgrad / wgrad gathers); the plain VALU kernels below serve the 3- /
+// 5- / 8-channel ends of the network and DYF_TRAIN_MFMA=0.  Tapes and temporaries come from a caching allocator (TrainState).
 #include "engine_internal.h"
 #include "train_internal.h"
 

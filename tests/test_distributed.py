@@ -73,3 +73,48 @@ def test_sharded_sampling_world2_gloo(nb):
     for p in procs:
         p.join(timeout=60)
     assert sorted(results) == [(0, True), (1, True)]
+
+
+def _grad_worker(rank, world, port, q):
+    from dyffusion_amd.distributed import all_reduce_gradients
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    params = [torch.nn.Parameter(torch.zeros(s)) for s in [(4, 3, 3, 3), (7,), (5, 2), (1,)]]
+    frozen = torch.nn.Parameter(torch.zeros(3))  # no gradient: skipped
+    per_rank = []
+    for r in range(world):
+        g = torch.Generator().manual_seed(100 + r)
+        per_rank.append([torch.randn(p.shape, generator=g) for p in params])
+    for p, gr in zip(params, per_rank[rank]):
+        p.grad = gr.clone()
+    calls_small = all_reduce_gradients(params + [frozen], bucket_bytes=64)  # several buckets
+    ok = calls_small > 1 and frozen.grad is None
+    for k, p in enumerate(params):
+        want = sum(per_rank[r][k] for r in range(world)) / world
+        ok = ok and torch.allclose(p.grad, want, atol=1e-6)
+    for p, gr in zip(params, per_rank[rank]):
+        p.grad = gr.clone()
+    ok = ok and all_reduce_gradients(params) == 1  # one bucket
+    for k, p in enumerate(params):
+        ok = ok and torch.allclose(p.grad, sum(per_rank[r][k] for r in range(world)) / world, atol=1e-6)
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_all_reduce_world2_gloo():
+    """Data-parallel training: `all_reduce_gradients` averages the `param.grad` the engine's backward wrote (bucketed)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_grad_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(results) == [(0, True), (1, True)]
