@@ -122,6 +122,60 @@ __global__ void t_resize_fwd(const float* in, int n, int ih, int iw, int C, int 
 }
 
 // adjoint of t_resize_fwd: din (zero-initialised) += scatter of dout
+// The x2 bilinear upsample (align_corners = False) of the decoder blocks and its adjoint as GATHERS over 4 channels per thread
+// (C % 4 == 0).  Output row 2i + p reads input rows (i - 1 + p, i + p) with weights (0.25, 0.75) / (0.75, 0.25), clamped at the
+// borders; so input row i collects 0.25 dout[2i-1] + 0.75 dout[2i] + 0.75 dout[2i+1] + 0.25 dout[2i+2], rows outside dropped, the
+// clamped taps of the first / last output row added (their whole weight lands on row 0 / h-1).  No atomics, every store 16 B.
+__device__ __forceinline__ void up2x_adj_taps(int i, int h, int o[4], float w[4]) {
+    o[0] = 2 * i - 1; o[1] = 2 * i; o[2] = 2 * i + 1; o[3] = 2 * i + 2;
+    w[0] = i >= 1 ? 0.25f : 0.0f;
+    w[1] = i >= 1 ? 0.75f : 1.0f;
+    w[2] = i <= h - 2 ? 0.75f : 1.0f;
+    w[3] = i <= h - 2 ? 0.25f : 0.0f;
+    o[0] = max(o[0], 0);
+    o[3] = min(o[3], 2 * h - 1);
+}
+__global__ __launch_bounds__(256) void t_up2x_bwd(const float* dout, int n, int h, int w, int C4, float* din) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)n * h * w * C4) return;
+    const int c4 = (int)(idx % C4);
+    const long long p = idx / C4;
+    const int j = (int)(p % w), i = (int)((p / w) % h), b = (int)(p / ((long long)w * h));
+    int oy[4], ox[4];
+    float wy[4], wx[4];
+    up2x_adj_taps(i, h, oy, wy);
+    up2x_adj_taps(j, w, ox, wx);
+    const float4* src = (const float4*)dout + (size_t)b * (4 * (size_t)h * w) * C4 + c4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float f = wy[a] * wx[q];
+            const float4 v = src[((size_t)oy[a] * (2 * w) + ox[q]) * C4];
+            acc.x = fmaf(f, v.x, acc.x); acc.y = fmaf(f, v.y, acc.y); acc.z = fmaf(f, v.z, acc.z); acc.w = fmaf(f, v.w, acc.w);
+        }
+    ((float4*)din)[idx] = acc;
+}
+__global__ __launch_bounds__(256) void t_up2x_fwd(const float* in, int n, int h, int w, int C4, float* out) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)n * 4 * h * w * C4) return;
+    const int c4 = (int)(idx % C4);
+    const long long p = idx / C4;
+    const int ox = (int)(p % (2 * w)), oy = (int)((p / (2 * w)) % (2 * h)), b = (int)(p / (4LL * w * h));
+    int y0, y1, x0, x1;
+    float ly, lx;
+    bilinear_coord(oy, 0.5f, h, y0, y1, ly);
+    bilinear_coord(ox, 0.5f, w, x0, x1, lx);
+    const float4* base = (const float4*)in + (size_t)b * h * w * C4 + c4;
+    const float4 v00 = base[((size_t)y0 * w + x0) * C4], v01 = base[((size_t)y0 * w + x1) * C4];
+    const float4 v10 = base[((size_t)y1 * w + x0) * C4], v11 = base[((size_t)y1 * w + x1) * C4];
+    float4 r;
+#define UP2X_MIX(m) { const float top = v00.m * (1.0f - lx) + v01.m * lx, bot = v10.m * (1.0f - lx) + v11.m * lx; r.m = top * (1.0f - ly) + bot * ly; }
+    UP2X_MIX(x) UP2X_MIX(y) UP2X_MIX(z) UP2X_MIX(w)
+#undef UP2X_MIX
+    ((float4*)out)[idx] = r;
+}
 __global__ void t_resize_bwd(const float* dout, int n, int ih, int iw, int C, int oh, int ow, int nearest, float* din) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long long)n * oh * ow * C) return;
@@ -190,6 +244,55 @@ __global__ void t_conv_dgrad(TConv g, const float* dz, const float* w, const flo
         }
     }
     dx[i] = acc;
+}
+
+// t_conv_dgrad for a handful of result channels (cin <= 4: the readout's transposed conv 64 -> C, run as the dgrad form): 16
+// lanes per pixel, lane q owns channels co = 4q + {0..3} (+ 64, ...) of dz -- a pixel's 256-byte row is one coalesced read per
+// tap --, the weights sit in LDS as [tap][co][4], the cin partial sums are reduced over the 16 lanes with shuffles.
+__global__ __launch_bounds__(256) void t_conv_dgrad_smalln(TConv g, const float* dz, const float* w, const float* bias, float* dx) {
+    extern __shared__ float4 sn_w[];  // [taps][cout]
+    const int taps = g.k * g.k;
+    for (int i = threadIdx.x; i < taps * g.cout; i += 256) {
+        const int tap = i / g.cout, co = i - tap * g.cout;
+        const float* wp = w + ((size_t)co * taps + tap) * g.cin;
+        sn_w[i] = make_float4(wp[0], g.cin > 1 ? wp[1] : 0.0f, g.cin > 2 ? wp[2] : 0.0f, g.cin > 3 ? wp[3] : 0.0f);
+    }
+    __syncthreads();
+    const long long pix = ((long long)blockIdx.x * 256 + threadIdx.x) >> 4;
+    const int q = threadIdx.x & 15;
+    const long long total = (long long)g.n * g.h * g.w;
+    const bool live = pix < total;
+    const long long pp = live ? pix : total - 1;
+    const int ix = (int)(pp % g.w), iy = (int)((pp / g.w) % g.h), b = (int)(pp / ((long long)g.w * g.h));
+    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+    for (int ky = 0; ky < g.k; ++ky) {
+        const int ty = iy + g.p - ky, oy = ty / g.s;
+        if (ty < 0 || oy * g.s != ty || oy >= g.ho) continue;
+        for (int kx = 0; kx < g.k; ++kx) {
+            const int tx = ix + g.p - kx, ox = tx / g.s;
+            if (tx < 0 || ox * g.s != tx || ox >= g.wo) continue;
+            const float* zp = dz + (((size_t)b * g.ho + oy) * g.wo + ox) * g.cout;
+            const float4* wt = sn_w + (size_t)(ky * g.k + kx) * g.cout;
+            for (int c0 = 4 * q; c0 < g.cout; c0 += 64) {
+                const float4 z = *(const float4*)(zp + c0);
+                const float4 w0 = wt[c0], w1 = wt[c0 + 1], w2 = wt[c0 + 2], w3 = wt[c0 + 3];
+                a0 = fmaf(z.x, w0.x, fmaf(z.y, w1.x, fmaf(z.z, w2.x, fmaf(z.w, w3.x, a0))));
+                a1 = fmaf(z.x, w0.y, fmaf(z.y, w1.y, fmaf(z.z, w2.y, fmaf(z.w, w3.y, a1))));
+                a2 = fmaf(z.x, w0.z, fmaf(z.y, w1.z, fmaf(z.z, w2.z, fmaf(z.w, w3.z, a2))));
+                a3 = fmaf(z.x, w0.w, fmaf(z.y, w1.w, fmaf(z.z, w2.w, fmaf(z.w, w3.w, a3))));
+            }
+        }
+    }
+    for (int off = 8; off > 0; off >>= 1) {
+        a0 += __shfl_xor(a0, off); a1 += __shfl_xor(a1, off); a2 += __shfl_xor(a2, off); a3 += __shfl_xor(a3, off);
+    }
+    if (live && q == 0) {
+        float* o = dx + (size_t)pix * g.cin;
+        o[0] = a0 + (bias ? bias[0] : 0.0f);
+        if (g.cin > 1) o[1] = a1 + (bias ? bias[1] : 0.0f);
+        if (g.cin > 2) o[2] = a2 + (bias ? bias[2] : 0.0f);
+        if (g.cin > 3) o[3] = a3 + (bias ? bias[3] : 0.0f);
+    }
 }
 
 // dw[co][tap][ci] += sum_{n,oy,ox} dz[n,oy,ox,co] * x[n,oy*s-p+ky,ox*s-p+kx,ci].  One workgroup = a 16 x 16 (co, ci) tile of
@@ -619,6 +722,12 @@ dyf_status conv_dgrad(dyf_engine* e, const TConv& g, const float* dz, const floa
         TK(hipGetLastError());
         return DYF_OK;
     }
+    if (g.cin <= 4 && g.cout % 64 == 0 && (size_t)g.k * g.k * g.cout * 16 <= 65536) {
+        hipLaunchKernelGGL(t_conv_dgrad_smalln, dim3(nblk((long long)g.n * g.h * g.w * 16)), dim3(256), (size_t)g.k * g.k * g.cout * 16, st, g, dz, w,
+                           bias, dx);
+        TK(hipGetLastError());
+        return DYF_OK;
+    }
     hipLaunchKernelGGL(t_conv_dgrad, dim3(nblk((long long)g.n * g.h * g.w * g.cin)), dim3(256), 0, st, g, dz, w, bias, dx);
     TK(hipGetLastError());
     return DYF_OK;
@@ -812,7 +921,10 @@ dyf_status dyf_train_forward(dyf_engine* e, int32_t which, int32_t slot, const f
         if (b.transposed) {  // x2 bilinear upsample in front of the conv
             float* u = nullptr;
             TA(u, (size_t)nb * b.in_h * b.in_w * b.cin);
-            hipLaunchKernelGGL(t_resize_fwd, dim3(nblk((long long)nb * b.in_h * b.in_w * b.cin)), dim3(256), 0, st, x, nb, lh, lw, b.cin, b.in_h, b.in_w, 0, u);
+            if (b.cin % 4 == 0 && b.in_h == 2 * lh && b.in_w == 2 * lw)
+                hipLaunchKernelGGL(t_up2x_fwd, dim3(nblk((long long)nb * b.in_h * b.in_w * (b.cin / 4))), dim3(256), 0, st, x, nb, lh, lw, b.cin / 4, u);
+            else
+                hipLaunchKernelGGL(t_resize_fwd, dim3(nblk((long long)nb * b.in_h * b.in_w * b.cin)), dim3(256), 0, st, x, nb, lh, lw, b.cin, b.in_h, b.in_w, 0, u);
             cx = u;
         }
         t.cin_ptr[i] = (float*)cx;
@@ -944,8 +1056,13 @@ dyf_status dyf_train_backward(dyf_engine* e, int32_t slot, const float* dout_dev
         if (b.transposed) {  // adjoint of the x2 upsample
             const int ph = b.in_h / 2, pw = b.in_w / 2;
             float* dlow = nullptr;
-            TZ(dlow, (size_t)nb * ph * pw * b.cin);
-            hipLaunchKernelGGL(t_resize_bwd, dim3(nblk((long long)nb * b.in_h * b.in_w * b.cin)), dim3(256), 0, st, dcx, nb, ph, pw, b.cin, b.in_h, b.in_w, 0, dlow);
+            if (b.cin % 4 == 0 && b.in_h == 2 * ph && b.in_w == 2 * pw) {
+                TA(dlow, (size_t)nb * ph * pw * b.cin);
+                hipLaunchKernelGGL(t_up2x_bwd, dim3(nblk((long long)nb * ph * pw * (b.cin / 4))), dim3(256), 0, st, dcx, nb, ph, pw, b.cin / 4, dlow);
+            } else {
+                TZ(dlow, (size_t)nb * ph * pw * b.cin);
+                hipLaunchKernelGGL(t_resize_bwd, dim3(nblk((long long)nb * b.in_h * b.in_w * b.cin)), dim3(256), 0, st, dcx, nb, ph, pw, b.cin, b.in_h, b.in_w, 0, dlow);
+            }
             dcx = dlow;
         }
         dy = dcx;  // gradient w.r.t. the previous tensor (block i-1's output, a concat for i in 7..11, the stem for i == 0)
