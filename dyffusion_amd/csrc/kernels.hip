@@ -594,7 +594,9 @@ __global__ __launch_bounds__(256, 4) void readout_mfma_kernel(ReadoutArgs a, int
         int idx = idx0 + p;
         const bool live = idx < total;
         if (!live) idx = total - 1;
-        // pixel order (n, oy, ox), ox fastest: the 16 pixels of a group read the same three input rows
+        // pixel order (n, oy, ox), ox fastest: the 16 pixels of a group read the same three input rows.  (Tried: vertical strips,
+        // oy fastest, whose 4-row windows overlap -- 90 instead of 256 distinct input pixels per group, but every load then
+        // touches 16 different rows: 312 vs 253 us per paired launch.)
         const int n = idx / plane;
         const int rem = idx - n * plane;
         const int oy = rem / a.ow, ox = rem - oy * a.ow;
