@@ -66,3 +66,40 @@ def test_two_ranks_reproduce_the_single_process_fields_bitwise(nb):
         assert torch.equal(got[k], want[k]), (k, float((got[k] - want[k]).abs().max()))
     # MC dropout is on: the rows really are different members
     assert not torch.equal(want["t4_preds"][0], want["t4_preds"][1])
+
+
+def _rccl_worker(port, q):
+    """World size 1 over backend "nccl" (= RCCL): the collective entry points the N > 1 path uses, on the one GPU of this box."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    from dyffusion_amd.distributed import _gather_into, all_gather_rows, all_reduce_gradients
+    g = torch.Generator().manual_seed(5)
+    field = torch.randn(6, 3, 23, 11, generator=g).cuda()
+    full = torch.empty_like(field)
+    _gather_into(full, field, None)              # dist.all_gather_into_tensor on RCCL
+    stack = torch.randn(4, 6, 3, 5, 4, generator=g).cuda()
+    back = all_gather_rows(stack, 6, row_dim=1)
+    p = torch.nn.Parameter(torch.zeros(5, device="cuda"))
+    p.grad = torch.arange(5.0, device="cuda")
+    calls = all_reduce_gradients([p])            # world 1: no collective
+    t = torch.ones(4, device="cuda")
+    dist.all_reduce(t)                           # the bench's barrier / max-over-ranks timing reduction
+    dist.barrier()
+    torch.cuda.synchronize()
+    q.put(bool(torch.equal(full, field) and torch.equal(back, stack) and calls == 0 and float(t.sum()) == 4.0))
+    dist.destroy_process_group()
+
+
+def test_rccl_collectives_single_rank():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(port, q))
+    p.start()
+    assert q.get(timeout=300) is True
+    p.join(timeout=120)
+    assert p.exitcode == 0
