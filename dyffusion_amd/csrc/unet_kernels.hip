@@ -1012,9 +1012,14 @@ __global__ __launch_bounds__(256) void flash_attention_kernel(AttnArgs a) {
     };
     fetch(0);
 
-    // one 32-key sub-tile; FAST: all 32 keys exist and no dropout on the probabilities (no per-element masks)
-    auto subtile = [&](int jb, int st, auto fast_c) {
-        constexpr bool FAST = decltype(fast_c)::value;
+    // one 32-key sub-tile; variant 1 (FAST): all 32 keys exist and no dropout on the probabilities; variant 2: all 32 keys and
+    // the query exist, dropout from the engine's generator with an even token count -- keys j, j + 1 of a register pair share
+    // one keep word (rng_keep hashes element pair (q*N + j) >> 1), so 8 hashes serve the lane's 16 probabilities and there are
+    // no per-element bounds or mode tests (the general form, variant 0, ran the 16 384-token attention of the 512^2
+    // configuration at 4.3 ms per NB = 4 call against 1.6 ms without dropout)
+    auto subtile = [&](int jb, int st, auto variant_c) {
+        constexpr int VARIANT = decltype(variant_c)::value;
+        constexpr bool FAST = VARIANT != 0;
         fa_f32x16 sc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) sc[r] = 0.0f;
@@ -1042,10 +1047,22 @@ __global__ __launch_bounds__(256) void flash_attention_kernel(AttnArgs a) {
         for (int r = 0; r < 16; ++r) {
             const float e = __builtin_amdgcn_exp2f(sc[r] - mn);
             psum += e;
-            if (FAST) p[r] = e;
+            if (VARIANT == 1) p[r] = e;
+            else if (VARIANT == 2) p[r] = e;  // masked below, pair by pair
             else {
                 const int j = jb + (r & 3) + 8 * (r >> 2) + 4 * hi;
                 p[r] = (j < N && q < N) ? attn_drop(e, a.drop, dkey, (uint32_t)bh, (uint32_t)q, (uint32_t)j, (uint32_t)N) : 0.0f;
+            }
+        }
+        if (VARIANT == 2) {
+            const uint32_t th = a.drop.thresh16;
+            const float dsc = a.drop.scale;
+            const uint32_t e0 = (uint32_t)q * (uint32_t)N + (uint32_t)(jb + 4 * hi);  // even: N even, jb and 4*hi multiples of 4
+#pragma unroll
+            for (int pr = 0; pr < 8; ++pr) {  // registers 2*pr, 2*pr + 1: keys e0 + 8*(pr >> 1) + 2*(pr & 1) + {0, 1}
+                const uint32_t w = rng_pair_word((e0 + 8u * (uint32_t)(pr >> 1) + 2u * (uint32_t)(pr & 1)) >> 1, dkey);
+                p[2 * pr] = (w & 0xffffu) < th ? p[2 * pr] * dsc : 0.0f;
+                p[2 * pr + 1] = (w >> 16) < th ? p[2 * pr + 1] * dsc : 0.0f;
             }
         }
         psum += __shfl_xor(psum, 32, 64);
@@ -1077,13 +1094,16 @@ __global__ __launch_bounds__(256) void flash_attention_kernel(AttnArgs a) {
         }
         if (j0 + 64 < N) fetch(j0 + 64);
         __syncthreads();
-        const bool fast = a.drop.mode == 0 && j0 + 64 <= N;  // block-uniform
-        if (fast) {
-            subtile(j0, 0, std::true_type{});
-            subtile(j0 + 32, 1, std::true_type{});
+        const bool whole = j0 + 64 <= N;  // block-uniform
+        if (whole && a.drop.mode == 0) {
+            subtile(j0, 0, std::integral_constant<int, 1>{});
+            subtile(j0 + 32, 1, std::integral_constant<int, 1>{});
+        } else if (whole && a.drop.mode == 1 && (N & 1) == 0 && (qb + 1) * 128 <= N) {
+            subtile(j0, 0, std::integral_constant<int, 2>{});
+            subtile(j0 + 32, 1, std::integral_constant<int, 2>{});
         } else {
-            subtile(j0, 0, std::false_type{});
-            if (j0 + 32 < N) subtile(j0 + 32, 1, std::false_type{});
+            subtile(j0, 0, std::integral_constant<int, 0>{});
+            if (j0 + 32 < N) subtile(j0 + 32, 1, std::integral_constant<int, 0>{});
         }
     }
     if (q >= N) return;

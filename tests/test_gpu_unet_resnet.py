@@ -2,6 +2,7 @@
 channel LayerNorm) on the HIP engine, against the reference's golden outputs and the oracle.  Tolerance as in
 test_gpu_nets.py (bf16 activations): rel-RMS <= 2e-2 per forward (this net is ~3x deeper than unet_simple)."""
 import json
+import os
 
 import pytest
 import torch
@@ -189,3 +190,40 @@ def test_fullsize_oisst_rollout_matches_reference_fields(dtype, tol):
     errs = {k: rel_rms(got[k].cpu(), z[k]) for k in sorted(got)}
     print(f"full-size OISST rollout ({dtype}) rel-rms", {k: round(v, 5) for k, v in errs.items()})
     assert sorted(got) == [f"t{i}_preds" for i in range(1, 8)] and max(errs.values()) <= tol
+
+
+_ATTN_DROP_SCRIPT = r"""
+import sys, torch
+sys.path.insert(0, {root!r})
+from tests.test_gpu_unet_resnet import mirror, seeded_unet
+cfg = dict(dim=64, dim_mults=[1, 2], with_time_emb=True, block_dropout=0.0, block_dropout1=0.0, attn_dropout=0.3,
+           resnet_block_groups=8, input_dropout=0.0, upsample_dims=None)
+P = seeded_unet(64, (1, 2), 2, 1, seed=71)
+g = torch.Generator().manual_seed(8)
+x, t = torch.randn(3, 2, 32, 32, generator=g), torch.tensor([2.0, 5.0, 1.0])
+net = mirror(P, cfg, 2, 0, 1)
+net(x.cuda(), time=t.cuda())  # creates the engine
+net._engine.seed(2024)
+y = net._engine.net_forward(0, x.cuda(), t.cuda(), None, dropout_mode=1).cpu()
+torch.save(y, {out!r})
+"""
+
+
+def test_flash_attention_engine_dropout_draws_the_masks_of_the_plain_kernel(tmp_path):
+    """Attention-probability dropout from the engine's generator: the flash kernel hashes one keep word per PAIR of keys
+    (16 x 16 = 256 tokens: both query blocks are whole, the paired form runs), the plain kernel (DYF_FLASH_ATTN=0) evaluates
+    `rng_keep(q * N + j)` per element.  Same seed -> the same masks, so the outputs agree to rounding (different masks at
+    p = 0.3 would differ by tens of percent).  The kernel form is chosen once per process: two subprocesses."""
+    import subprocess
+    import sys as _sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    outs = []
+    for flash in ("1", "0"):
+        out = str(tmp_path / f"y{flash}.pt")
+        env = dict(os.environ, DYF_FLASH_ATTN=flash)
+        subprocess.run([_sys.executable, "-c", _ATTN_DROP_SCRIPT.format(root=root, out=out)], check=True, env=env, timeout=600)
+        outs.append(torch.load(out))
+    err = rel_rms(outs[0], outs[1])
+    print("flash (paired keep words) vs plain attention kernel, engine dropout: rel-rms", err)
+    assert err <= 1e-2
+    assert float(outs[0].std()) > 0
