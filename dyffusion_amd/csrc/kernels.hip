@@ -679,6 +679,117 @@ __global__ __launch_bounds__(256, 4) void readout_mfma_kernel(ReadoutArgs a, int
 #endif
 }
 
+// The same arithmetic with the gather staged through LDS by DMA.  readout_mfma_kernel loads with a coalesced lane map (a quad of
+// lanes = 64 contiguous bytes of one pixel) and moves every 16-byte piece to its MFMA lane with four ds_bpermute: 128 shuffles
+// per 16 pixels, and the LDS pipe -- not the gather -- sets its time.  Here `buffer_load ... lds` writes the quads straight into
+// a per-wave staging area (lane i fetches piece (i & 3) ^ (pixel & 3) of pixel i >> 2 into slot i: the swizzle keeps the
+// fragment reads conflict-free) and the MFMA lane (pixel p, k-group g) reads its operand back with ONE ds_read_b128 from slot
+// 4p + (g ^ (p & 3)).  Taps outside the image get the out-of-range offset (DMA writes zeros).  Only the 4 non-zero rows of the
+// weight fragments are kept in LDS (8 KB + 4 x 8 KB staging per workgroup: four workgroups per CU as before).
+__global__ __launch_bounds__(256, 4) void readout_dma_kernel(ReadoutArgs a, int groups_per_wave) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    extern __shared__ __attribute__((aligned(16))) char rd_smem[];
+    // weights: [tap][half][k-group][row m < 4] x 16 B  (row m of the 16-row A fragment; rows >= cout are zero in wfrag)
+    for (int i = threadIdx.x; i < 16 * 2 * 4 * 4; i += 256) {
+        const int m = i & 3, kg = (i >> 2) & 3, th = i >> 4;
+        ((uint4*)rd_smem)[i] = ((const uint4*)a.wfrag)[th * 64 + kg * 16 + m];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wave_id = (int)((blockIdx.x * 256 + threadIdx.x) >> 6);
+    const int p = lane & 15, kg = lane >> 4;
+    char* stage = rd_smem + 8192 + wave * 8192;  // [4 taps][2 halves][64 slots] x 16 B
+    const uint4* wl = (const uint4*)rd_smem + kg * 4 + (p & 3);
+    const bool wrow = p < 4;
+    const int total = a.n * a.oh * a.ow;
+    const int th = 2 * a.ih, tw = 2 * a.iw;
+    const float sh = (float)th / (float)a.oh, sw = (float)tw / (float)a.ow;
+    const int plane = a.oh * a.ow;
+    const size_t xbytes = (size_t)a.n * a.ih * a.iw_store * 64 * sizeof(el16_t);
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.x, 0, (int)(unsigned)xbytes, 0x00020000);
+    const int lp = lane >> 2, lc = lane & 3;             // pixel / slot piece this lane FETCHES
+    const unsigned piece_off = (unsigned)((lc ^ (lp & 3)) * 16);
+    const int src4 = lp * 4;                             // ds_bpermute byte address of lane lp (holds pixel lp's coordinates)
+    const unsigned rd_off = (unsigned)((p * 4 + (kg ^ (p & 3))) * 16);
+    for (int g = 0; g < groups_per_wave; ++g) {
+        const int idx0 = (wave_id * groups_per_wave + g) * 16;
+        if (idx0 >= total) break;  // wave-uniform
+        int idx = idx0 + p;
+        const bool live = idx < total;
+        if (!live) idx = total - 1;
+        const int n = idx / plane;
+        const int rem = idx - n * plane;
+        const int oy = rem / a.ow, ox = rem - oy * a.ow;
+        int u0, u1, v0, v1;
+        float lu, lv;
+        bilinear_coord(oy, sh, th, u0, u1, lu, a.nearest != 0);
+        bilinear_coord(ox, sw, tw, v0, v1, lv, a.nearest != 0);
+        int ro[4], co_[4];
+        float rw[4], cw[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int par = (k + 1) & 1;
+            rw[k] = ((u0 & 1) == par ? 1.0f - lu : 0.0f) + ((u1 & 1) == par ? lu : 0.0f);
+            const int u = (u1 & 1) == par ? u1 : u0;
+            const int i = ((u + 1) >> 1) - (k >> 1);
+            ro[k] = (unsigned)i < (unsigned)a.ih ? (n * a.ih + i) * a.iw_store * 128 : -1;  // byte offset of the input row
+            cw[k] = ((v0 & 1) == par ? 1.0f - lv : 0.0f) + ((v1 & 1) == par ? lv : 0.0f);
+            const int v = (v1 & 1) == par ? v1 : v0;
+            const int j = ((v + 1) >> 1) - (k >> 1);
+            int js = (unsigned)j < (unsigned)a.iw ? j : -1;
+            if (js >= 0 && a.col_map) js = a.col_map[js];
+            co_[k] = js >= 0 ? js * 128 : -1;
+        }
+        int l_ro[4], l_co[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            l_ro[k] = __builtin_amdgcn_ds_bpermute(src4, ro[k]);
+            l_co[k] = __builtin_amdgcn_ds_bpermute(src4, co_[k]);
+        }
+        float out[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int kh = 0; kh < 4; ++kh) {
+            // the previous batch's fragment reads are complete (their results were consumed by MFMAs): refill the staging area
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int kw = 0; kw < 4; ++kw) {
+                const bool ok = l_ro[kh] >= 0 && l_co[kw] >= 0;
+                const unsigned vo = ok ? (unsigned)(l_ro[kh] + l_co[kw]) + piece_off : 0xFFFFFFFFu;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(stage + (kw * 2 + 0) * 1024), 16, vo, 0, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(stage + (kw * 2 + 1) * 1024), 16,
+                                                         ok ? vo + 64u : 0xFFFFFFFFu, 0, 0, 0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int kw = 0; kw < 4; ++kw) {
+                const int tap = kh * 4 + kw;
+                const uint4 b0 = *(const uint4*)(stage + (kw * 2 + 0) * 1024 + rd_off);
+                const uint4 b1 = *(const uint4*)(stage + (kw * 2 + 1) * 1024 + rd_off);
+                uint4 w0 = make_uint4(0u, 0u, 0u, 0u), w1 = w0;
+                if (wrow) {
+                    w0 = wl[(tap * 2 + 0) * 16];
+                    w1 = wl[(tap * 2 + 1) * 16];
+                }
+                ro_f32x4 d = {0.0f, 0.0f, 0.0f, 0.0f};
+                d = DYF_MFMA_16x16x32(__builtin_bit_cast(el16x8_t, w0), __builtin_bit_cast(el16x8_t, b0), d, 0, 0, 0);
+                d = DYF_MFMA_16x16x32(__builtin_bit_cast(el16x8_t, w1), __builtin_bit_cast(el16x8_t, b1), d, 0, 0, 0);
+                const float bw = (ro[kh] >= 0 && co_[kw] >= 0) ? rw[kh] * cw[kw] : 0.0f;  // this lane's own pixel
+#pragma unroll
+                for (int r = 0; r < 4; ++r) out[r] = fmaf(bw, d[r], out[r]);
+            }
+        }
+        if (live && kg == 0) {
+            float* o = a.out + ((size_t)n * a.cout * a.oh + oy) * a.ow + ox;
+            const size_t cs = (size_t)a.oh * a.ow;
+            o[0] = out[0] + a.bias[0];
+            if (a.cout > 1) o[cs] = out[1] + a.bias[1];
+            if (a.cout > 2) o[2 * cs] = out[2] + a.bias[2];
+            if (a.cout > 3) o[3 * cs] = out[3] + a.bias[3];
+        }
+    }
+#endif
+}
+
 hipError_t launch_readout(const ReadoutArgs& a, hipStream_t s) {
     const long long total = (long long)a.n * a.oh * a.ow;
     static const bool regw = !(getenv("DYF_READOUT_REGW") && atoi(getenv("DYF_READOUT_REGW")) == 0);
@@ -690,7 +801,12 @@ hipError_t launch_readout(const ReadoutArgs& a, hipStream_t s) {
         int per = (int)((groups + waves - 1) / waves);
         if (per < 1) per = 1;
         waves = (groups + per - 1) / per;
-        hipLaunchKernelGGL(readout_mfma_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 32768, s, a, per);
+        // DMA-staged gather (DYF_READOUT_DMA=0: the register-shuffle form); the DMA's buffer descriptor addresses < 4 GB
+        static const bool use_dma = !(getenv("DYF_READOUT_DMA") && atoi(getenv("DYF_READOUT_DMA")) == 0);
+        if (use_dma && (size_t)a.n * a.ih * a.iw_store * 128 < 0x7F000000ull)
+            hipLaunchKernelGGL(readout_dma_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 8192 + 4 * 8192, s, a, per);
+        else
+            hipLaunchKernelGGL(readout_mfma_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 32768, s, a, per);
         return hipGetLastError();
     }
     if (regw && a.cin == 64 && a.cout >= 1 && a.cout <= 4 && total < (1ll << 30)) {
