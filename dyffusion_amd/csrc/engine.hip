@@ -244,6 +244,10 @@ dyf_status net_forward(dyf_engine* e, int which, const Source* srcs, int nsrc, i
     e->last_dec5_sparse = sparse_out != nullptr;
     r.iw_store = sparse_out ? sparse_out->up_wo_store : lw;
     r.col_map = sparse_out ? sparse_out->up_col_map : nullptr;
+    if (n.ro_row_tab && (sparse_out != nullptr) == n.ro_tab_sparse) {  // the tables were built for this storage layout
+        r.row_tab = n.ro_row_tab;
+        r.col_tab = n.ro_col_tab;
+    }
     HIP_TRY(e, launch_readout(r, st));
     return DYF_OK;
 }
@@ -642,6 +646,20 @@ dyf_status dyf_load_weights(dyf_engine* e, int32_t which, int32_t n_tensors, con
                                     f32_to_el16(pk[((size_t)t * n.dim + h2 * 32 + kg * 8 + el) * oc + m]);
                     }
             UP(n.ro_wfrag, wf);
+            // tap tables of the readout for this engine's geometry and the storage layout of the last decoder block's output
+            // (compact when its sparse column lists were planned above)
+            const UBlock& lb = n.blk[11];
+            dyf_status _s = dev_alloc(e, &n.ro_row_tab, (size_t)2 * e->cfg.height);
+            if (_s == DYF_OK) _s = dev_alloc(e, &n.ro_col_tab, (size_t)2 * e->cfg.width);
+            if (_s != DYF_OK) return _s;
+            ReadoutArgs ta{};
+            ta.ih = lb.out_h; ta.iw = lb.out_w; ta.oh = e->cfg.height; ta.ow = e->cfg.width; ta.nearest = n.cfg.outer_nearest;
+            n.ro_tab_sparse = lb.up_cols != nullptr;
+            ta.iw_store = n.ro_tab_sparse ? lb.up_wo_store : lb.out_w;
+            ta.col_map = n.ro_tab_sparse ? lb.up_col_map : nullptr;
+            ta.row_tab = n.ro_row_tab; ta.col_tab = n.ro_col_tab;
+            HIP_TRY(e, launch_readout_tables(ta, nullptr));
+            HIP_TRY(e, hipDeviceSynchronize());
         }
     }
 #undef NEED

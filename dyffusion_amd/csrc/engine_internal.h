@@ -59,6 +59,8 @@ struct Net {
     int *blk_of = nullptr, *blk_off = nullptr, *blk_cout = nullptr;
     float *ro_w = nullptr, *ro_b = nullptr;
     el16_t* ro_wfrag = nullptr;  // readout weights as MFMA fragments (dim 64, <= 4 output channels)
+    uint4 *ro_row_tab = nullptr, *ro_col_tab = nullptr;  // tap tables of the readout (launch_readout_tables), with ro_wfrag
+    bool ro_tab_sparse = false;  // ... built for the compact (sparse-column) layout of the last decoder block's output
     el16_t* enc0_fused_w = nullptr;  // [2dim][4][64]: enc0's 4x4 conv composed with init_conv (+ bias channel)
     bool stem_fused = false;
     double flops_per_sample = 0.0;

@@ -97,8 +97,15 @@ struct ReadoutArgs {
     int oh, ow;             // native grid
     int nearest;            // final resample: 0 bilinear, 1 nearest (outer_sample_mode)
     float* out;             // [n][cout][oh][ow]
+    // per-geometry tap tables (launch_readout_tables, built once at weight upload), or null: entry = {int off[4]; float w[4]}.
+    // row_tab[oy]: byte offset of input row i(oy, kh) inside a sample (i * iw_store * 128, -1 outside) and its bilinear row weight;
+    // col_tab[ox]: byte offset of the stored input column j(ox, kw) (col_map applied, -1 outside) and its column weight
+    const uint4* row_tab;
+    const uint4* col_tab;
 };
 hipError_t launch_readout(const ReadoutArgs& a, hipStream_t s);
+// fills a.row_tab (oh entries of 32 B) / a.col_tab (ow entries) for the geometry and col_map of `a` (device pointers, writable)
+hipError_t launch_readout_tables(const ReadoutArgs& a, hipStream_t s);
 
 // K10: sampler elementwise (dyffusion.py:381-391, :219-227)
 hipError_t launch_cold_update(float* x_s, const float* x_cur, const float* x_next, long long count, hipStream_t s);

@@ -679,7 +679,58 @@ __global__ __launch_bounds__(256, 4) void readout_mfma_kernel(ReadoutArgs a, int
 #endif
 }
 
-// The same arithmetic with the gather staged through LDS by DMA.  readout_mfma_kernel loads with a coalesced lane map (a quad of
+// Tap tables of the readout for one geometry: the coordinate arithmetic of readout_mfma_kernel, evaluated once per output row /
+// column instead of once per pixel and forward (the MFMA forms spend most of their issue slots on it: 16 pixels per wave).
+__global__ void readout_tables_kernel(ReadoutArgs a, uint4* row_tab, uint4* col_tab) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int th = 2 * a.ih, tw = 2 * a.iw;
+    if (t < a.oh) {
+        int u0, u1;
+        float lu;
+        bilinear_coord(t, (float)th / (float)a.oh, th, u0, u1, lu, a.nearest != 0);
+        int off[4];
+        float w[4];
+        for (int k = 0; k < 4; ++k) {
+            const int par = (k + 1) & 1;
+            w[k] = ((u0 & 1) == par ? 1.0f - lu : 0.0f) + ((u1 & 1) == par ? lu : 0.0f);
+            const int u = (u1 & 1) == par ? u1 : u0;
+            const int i = ((u + 1) >> 1) - (k >> 1);
+            off[k] = (unsigned)i < (unsigned)a.ih ? i * a.iw_store * 128 : -1;
+        }
+        row_tab[2 * t] = make_uint4((unsigned)off[0], (unsigned)off[1], (unsigned)off[2], (unsigned)off[3]);
+        row_tab[2 * t + 1] = make_uint4(__float_as_uint(w[0]), __float_as_uint(w[1]), __float_as_uint(w[2]), __float_as_uint(w[3]));
+    }
+    if (t < a.ow) {
+        int v0, v1;
+        float lv;
+        bilinear_coord(t, (float)tw / (float)a.ow, tw, v0, v1, lv, a.nearest != 0);
+        int off[4];
+        float w[4];
+        for (int k = 0; k < 4; ++k) {
+            const int par = (k + 1) & 1;
+            w[k] = ((v0 & 1) == par ? 1.0f - lv : 0.0f) + ((v1 & 1) == par ? lv : 0.0f);
+            const int v = (v1 & 1) == par ? v1 : v0;
+            const int j = ((v + 1) >> 1) - (k >> 1);
+            int js = (unsigned)j < (unsigned)a.iw ? j : -1;
+            if (js >= 0 && a.col_map) js = a.col_map[js];
+            off[k] = js >= 0 ? js * 128 : -1;
+        }
+        col_tab[2 * t] = make_uint4((unsigned)off[0], (unsigned)off[1], (unsigned)off[2], (unsigned)off[3]);
+        col_tab[2 * t + 1] = make_uint4(__float_as_uint(w[0]), __float_as_uint(w[1]), __float_as_uint(w[2]), __float_as_uint(w[3]));
+    }
+}
+
+hipError_t launch_readout_tables(const ReadoutArgs& a, hipStream_t s) {
+    const int n = a.oh > a.ow ? a.oh : a.ow;
+    hipLaunchKernelGGL(readout_tables_kernel, dim3((n + 255) / 256), dim3(256), 0, s, a, (uint4*)a.row_tab, (uint4*)a.col_tab);
+    return hipGetLastError();
+}
+
+// The same arithmetic with the gather staged through LDS by DMA and the tap coordinates from tables.  Measured per paired launch
+// (160 rows): 256 us (register shuffles) -> 247 (DMA staging, two-deep batch pipeline) -> 239 (tap tables).  Tried and slower: a
+// vertical-strip form that stages every input row segment once (2.9x less gather traffic: 284 us) -- the kernel is bound by none
+// of gather bytes, shuffles or latency alone but by the LDS pipe serving 64 fragment reads per 16 pixels for an MFMA whose 16
+// result rows hold 3 output channels.  readout_mfma_kernel loads with a coalesced lane map (a quad of
 // lanes = 64 contiguous bytes of one pixel) and moves every 16-byte piece to its MFMA lane with four ds_bpermute: 128 shuffles
 // per 16 pixels, and the LDS pipe -- not the gather -- sets its time.  Here `buffer_load ... lds` writes the quads straight into
 // a per-wave staging area (lane i fetches piece (i & 3) ^ (pixel & 3) of pixel i >> 2 into slot i: the swizzle keeps the
@@ -720,26 +771,15 @@ __global__ __launch_bounds__(256, 4) void readout_dma_kernel(ReadoutArgs a, int 
         const int n = idx / plane;
         const int rem = idx - n * plane;
         const int oy = rem / a.ow, ox = rem - oy * a.ow;
-        int u0, u1, v0, v1;
-        float lu, lv;
-        bilinear_coord(oy, sh, th, u0, u1, lu, a.nearest != 0);
-        bilinear_coord(ox, sw, tw, v0, v1, lv, a.nearest != 0);
-        int ro[4], co_[4];
-        float rw[4], cw[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int par = (k + 1) & 1;
-            rw[k] = ((u0 & 1) == par ? 1.0f - lu : 0.0f) + ((u1 & 1) == par ? lu : 0.0f);
-            const int u = (u1 & 1) == par ? u1 : u0;
-            const int i = ((u + 1) >> 1) - (k >> 1);
-            ro[k] = (unsigned)i < (unsigned)a.ih ? (n * a.ih + i) * a.iw_store * 128 : -1;  // byte offset of the input row
-            cw[k] = ((v0 & 1) == par ? 1.0f - lv : 0.0f) + ((v1 & 1) == par ? lv : 0.0f);
-            const int v = (v1 & 1) == par ? v1 : v0;
-            const int j = ((v + 1) >> 1) - (k >> 1);
-            int js = (unsigned)j < (unsigned)a.iw ? j : -1;
-            if (js >= 0 && a.col_map) js = a.col_map[js];
-            co_[k] = js >= 0 ? js * 128 : -1;
-        }
+        // tap tables (readout_tables_kernel): row offsets / weights of this output row, column offsets / weights of this column
+        const uint4 rto = a.row_tab[2 * oy], rtw = a.row_tab[2 * oy + 1], cto = a.col_tab[2 * ox], ctw = a.col_tab[2 * ox + 1];
+        const int nbase = n * a.ih * a.iw_store * 128;
+        const int rto_[4] = {(int)rto.x, (int)rto.y, (int)rto.z, (int)rto.w};
+        const int ro[4] = {rto_[0] >= 0 ? nbase + rto_[0] : -1, rto_[1] >= 0 ? nbase + rto_[1] : -1, rto_[2] >= 0 ? nbase + rto_[2] : -1,
+                           rto_[3] >= 0 ? nbase + rto_[3] : -1};
+        const int co_[4] = {(int)cto.x, (int)cto.y, (int)cto.z, (int)cto.w};
+        const float rw[4] = {__uint_as_float(rtw.x), __uint_as_float(rtw.y), __uint_as_float(rtw.z), __uint_as_float(rtw.w)};
+        const float cw[4] = {__uint_as_float(ctw.x), __uint_as_float(ctw.y), __uint_as_float(ctw.z), __uint_as_float(ctw.w)};
         int l_ro[4], l_co[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -747,24 +787,39 @@ __global__ __launch_bounds__(256, 4) void readout_dma_kernel(ReadoutArgs a, int 
             l_co[k] = __builtin_amdgcn_ds_bpermute(src4, co_[k]);
         }
         float out[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        // 8 batches of 2 taps, two staging halves: the DMA of batch b + 1 is in flight while batch b is consumed (with one batch
+        // of 4 taps at a time every group paid four exposed memory round trips -- the kernel's time was that latency chain)
+        auto issue = [&](int bt) {
+            const int kh = bt >> 1;
+            char* st = stage + (bt & 1) * 4096;
 #pragma unroll
-        for (int kh = 0; kh < 4; ++kh) {
-            // the previous batch's fragment reads are complete (their results were consumed by MFMAs): refill the staging area
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-            for (int kw = 0; kw < 4; ++kw) {
+            for (int t = 0; t < 2; ++t) {
+                const int kw = (bt & 1) * 2 + t;
                 const bool ok = l_ro[kh] >= 0 && l_co[kw] >= 0;
                 const unsigned vo = ok ? (unsigned)(l_ro[kh] + l_co[kw]) + piece_off : 0xFFFFFFFFu;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(stage + (kw * 2 + 0) * 1024), 16, vo, 0, 0, 0);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(stage + (kw * 2 + 1) * 1024), 16,
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(st + (t * 2 + 0) * 1024), 16, vo, 0, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(st + (t * 2 + 1) * 1024), 16,
                                                          ok ? vo + 64u : 0xFFFFFFFFu, 0, 0, 0);
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        };
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the previous group's fragment reads are complete
+        issue(0);
 #pragma unroll
-            for (int kw = 0; kw < 4; ++kw) {
-                const int tap = kh * 4 + kw;
-                const uint4 b0 = *(const uint4*)(stage + (kw * 2 + 0) * 1024 + rd_off);
-                const uint4 b1 = *(const uint4*)(stage + (kw * 2 + 1) * 1024 + rd_off);
+        for (int bt = 0; bt < 8; ++bt) {
+            if (bt + 1 < 8) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // batch bt - 1 has been read out of the half that is refilled
+                issue(bt + 1);
+                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");    // batch bt has landed
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            const int kh = bt >> 1;
+            const char* st = stage + (bt & 1) * 4096;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const int kw = (bt & 1) * 2 + t, tap = kh * 4 + kw;
+                const uint4 b0 = *(const uint4*)(st + (t * 2 + 0) * 1024 + rd_off);
+                const uint4 b1 = *(const uint4*)(st + (t * 2 + 1) * 1024 + rd_off);
                 uint4 w0 = make_uint4(0u, 0u, 0u, 0u), w1 = w0;
                 if (wrow) {
                     w0 = wl[(tap * 2 + 0) * 16];
@@ -803,7 +858,7 @@ hipError_t launch_readout(const ReadoutArgs& a, hipStream_t s) {
         waves = (groups + per - 1) / per;
         // DMA-staged gather (DYF_READOUT_DMA=0: the register-shuffle form); the DMA's buffer descriptor addresses < 4 GB
         static const bool use_dma = !(getenv("DYF_READOUT_DMA") && atoi(getenv("DYF_READOUT_DMA")) == 0);
-        if (use_dma && (size_t)a.n * a.ih * a.iw_store * 128 < 0x7F000000ull)
+        if (use_dma && a.row_tab && a.col_tab && (size_t)a.n * a.ih * a.iw_store * 128 < 0x7F000000ull)
             hipLaunchKernelGGL(readout_dma_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 8192 + 4 * 8192, s, a, per);
         else
             hipLaunchKernelGGL(readout_mfma_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 32768, s, a, per);
