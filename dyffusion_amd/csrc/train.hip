@@ -56,6 +56,7 @@ struct TrainState {
     // device) and are handed out again by exact size -- after the first step a training step allocates nothing.  Everything
     // runs on one stream, so reuse is ordered behind the previous use.
     std::multimap<size_t, void*> pool;
+    size_t pool_bytes = 0;  // bytes idle in the pool
     hipStream_t stream = nullptr;  // stream of the running train_forward / train_backward (zero-fills are queued on it)
 };
 
@@ -671,6 +672,7 @@ dyf_status talloc(dyf_engine* e, std::vector<void*>& owner, T** out, size_t coun
     if (ts && it != ts->pool.end()) {
         p = it->second;
         ts->pool.erase(it);
+        ts->pool_bytes -= bytes;
     } else {
         TK(hipMalloc(&p, bytes));
     }
@@ -691,10 +693,24 @@ dyf_status tupload(dyf_engine* e, std::vector<void*>& owner, float** out, const 
 void tfree(dyf_engine* e, std::vector<void*>& owner) {  // back to the pool (train_destroy releases the pool)
     for (void* p : owner) {
         auto it = g_block_bytes().find(p);
-        if (e->train && it != g_block_bytes().end()) e->train->pool.emplace(it->second, p);
-        else (void)hipFree(p);
+        if (e->train && it != g_block_bytes().end()) {
+            e->train->pool.emplace(it->second, p);
+            e->train->pool_bytes += it->second;
+        } else {
+            (void)hipFree(p);
+        }
     }
     owner.clear();
+    // safety valve: batch sizes that keep changing leave blocks of every size behind -- past 32 GB of idle blocks, start over
+    if (e->train && e->train->pool_bytes > ((size_t)32 << 30)) {
+        (void)hipDeviceSynchronize();
+        for (auto& kv : e->train->pool) {
+            g_block_bytes().erase(kv.second);
+            (void)hipFree(kv.second);
+        }
+        e->train->pool.clear();
+        e->train->pool_bytes = 0;
+    }
 }
 
 void launch_bias_grad(const float* d, long long pixels, int C, float* db, hipStream_t st) {
