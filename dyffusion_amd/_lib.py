@@ -89,6 +89,7 @@ SYMBOLS = [
     ("dyf_train_zero_grads", C.c_int, [_P, C.c_int32]),
     ("dyf_train_export", C.c_int, [_P, C.c_int32, C.c_int32, C.POINTER(C.c_char_p), C.POINTER(_P)]),
     ("dyf_criterion_grad", C.c_int, [_P, _P, _P, C.c_int64, C.c_int32, C.c_float, _P, _P]),
+    ("dyf_train_conv_check", C.c_int, [_P] + [C.c_int32] * 9 + [C.c_uint32, C.POINTER(C.c_float)]),
     ("dyf_apply_boundary_conditions", C.c_int, [_P, C.POINTER(BcArgs), _P, _P]),
     ("dyf_debug_read_block_output", C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
 ]

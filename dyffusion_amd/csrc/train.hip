@@ -57,6 +57,8 @@ struct TrainState {
     // runs on one stream, so reuse is ordered behind the previous use.
     std::multimap<size_t, void*> pool;
     size_t pool_bytes = 0;  // bytes idle in the pool
+    float* splitk_ws = nullptr;  // partial sums of the split-K convolutions (train_gemm.hip), TRAIN_SPLITK_FLOATS floats
+    std::vector<void*> ws_owned;
     hipStream_t stream = nullptr;  // stream of the running train_forward / train_backward (zero-fills are queued on it)
 };
 
@@ -677,6 +679,12 @@ dyf_status talloc(dyf_engine* e, std::vector<void*>& owner, T** out, size_t coun
         TK(hipMalloc(&p, bytes));
     }
     if (zero) TK(hipMemsetAsync(p, 0, bytes, ts ? ts->stream : nullptr));
+    else {
+        // test hook (DYF_TRAIN_POISON=1): blocks handed out without zero-fill start as NaN patterns, so a kernel that consumes a
+        // buffer it did not fully write shows up in the gradients instead of hiding behind whatever the block held before
+        static const bool poison = getenv("DYF_TRAIN_POISON") && atoi(getenv("DYF_TRAIN_POISON")) != 0;
+        if (poison) TK(hipMemsetAsync(p, 0xFF, bytes, ts ? ts->stream : nullptr));
+    }
     owner.push_back(p);
     g_block_bytes()[p] = bytes;
     *out = (T*)p;
@@ -718,6 +726,13 @@ void launch_bias_grad(const float* d, long long pixels, int C, float* db, hipStr
     hipLaunchKernelGGL(t_bias_grad, dim3((unsigned)((total + per - 1) / per)), dim3(256), (size_t)C * sizeof(float), st, d, pixels, C, per, db);
 }
 
+constexpr size_t TRAIN_SPLITK_FLOATS = (size_t)16 << 20;  // 64 MB: 512 tiles x 128 x 64 partial sums and change
+float* splitk_ws(dyf_engine* e) {
+    TrainState* ts = e->train;
+    if (ts && !ts->splitk_ws && talloc(e, ts->ws_owned, &ts->splitk_ws, TRAIN_SPLITK_FLOATS, false) != DYF_OK) ts->splitk_ws = nullptr;
+    return ts ? ts->splitk_ws : nullptr;
+}
+
 // DYF_TRAIN_MFMA=0 keeps the plain VALU kernels (A/B and a second implementation for the tests)
 bool train_mfma() {
     static const bool on = !(getenv("DYF_TRAIN_MFMA") && atoi(getenv("DYF_TRAIN_MFMA")) == 0);
@@ -725,7 +740,7 @@ bool train_mfma() {
 }
 
 dyf_status conv_fwd(dyf_engine* e, const TConv& g, const float* x, const float* wt, const float* b, float* y, hipStream_t st) {
-    if (train_mfma() && tgemm_conv_fwd(g, x, wt, b, y, st)) {
+    if (train_mfma() && tgemm_conv_fwd(g, x, wt, b, y, splitk_ws(e), TRAIN_SPLITK_FLOATS, st)) {
         TK(hipGetLastError());
         return DYF_OK;
     }
@@ -734,7 +749,7 @@ dyf_status conv_fwd(dyf_engine* e, const TConv& g, const float* x, const float* 
     return DYF_OK;
 }
 dyf_status conv_dgrad(dyf_engine* e, const TConv& g, const float* dz, const float* w, const float* bias, float* dx, hipStream_t st) {
-    if (train_mfma() && tgemm_conv_dgrad(g, dz, w, bias, dx, st)) {
+    if (train_mfma() && tgemm_conv_dgrad(g, dz, w, bias, dx, splitk_ws(e), TRAIN_SPLITK_FLOATS, st)) {
         TK(hipGetLastError());
         return DYF_OK;
     }
@@ -783,6 +798,7 @@ void train_destroy(dyf_engine* e) {
     if (!e->train) return;
     for (auto& n : e->train->net) tfree(e, n.owned);
     for (auto& t : e->train->tape) tfree(e, t.owned);
+    tfree(e, e->train->ws_owned);
     for (auto& kv : e->train->pool) {
         g_block_bytes().erase(kv.second);
         (void)hipFree(kv.second);
@@ -1191,6 +1207,89 @@ dyf_status dyf_criterion_grad(dyf_engine* e, const float* pred_dev, const float*
     TK(hipSetDevice(e->cfg.device));
     hipLaunchKernelGGL(t_criterion_grad, dim3(nblk(count)), dim3(256), 0, (hipStream_t)stream, pred_dev, target_dev, (long long)count, kind, scale, dpred_dev);
     TK(hipGetLastError());
+    return DYF_OK;
+}
+
+// Test seam (include/dyffusion_hip_testing.h): one training convolution on hash-random fp32 data through the fp32 matrix-core
+// form (train_gemm.hip; with the split-K workspace, and -- forward / dgrad -- once more without it) against the plain VALU kernel.
+// kind 0 forward, 1 dgrad, 2 wgrad.  out_host[0] = max |mfma - valu| / max |valu|, out_host[1] = the same for the unsplit launch,
+// out_host[2] = 1 if the matrix-core form took the shape (0: it declined and nothing was compared).
+__global__ void t_fill_hash(float* p, long long n, uint32_t seed) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t h = fmix32((uint32_t)i * 0x9E3779B1u + seed);
+    p[i] = ((float)(h >> 8) * (1.0f / 8388608.0f) - 1.0f);  // uniform in [-1, 1)
+}
+__global__ void t_maxabs2(const float* a, const float* b, long long n, unsigned* out) {  // out[0] = max |a - b|, out[1] = max |b| (bit patterns)
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    atomicMax(out, __float_as_uint(fabsf(a[i] - b[i])));
+    atomicMax(out + 1, __float_as_uint(fabsf(b[i])));
+    atomicMax(out + 2, __float_as_uint(fabsf(a[i])));
+}
+
+dyf_status dyf_train_conv_check(dyf_engine* e, int32_t kind, int32_t n, int32_t h, int32_t w, int32_t cin, int32_t cout, int32_t k,
+                                int32_t s, int32_t p, uint32_t seed, float* out_host) {
+    if (!e || !out_host || kind < 0 || kind > 2 || n < 1 || h < 1 || w < 1 || cin < 1 || cout < 1 || k < 1 || s < 1)
+        return fail(e, DYF_ERR_INVALID_ARGUMENT, "dyf_train_conv_check: bad arguments");
+    TK(hipSetDevice(e->cfg.device));
+    if (!e->train) e->train = new TrainState();
+    const int ho = (h + 2 * p - k) / s + 1, wo = (w + 2 * p - k) / s + 1;
+    const TConv g{n, h, w, cin, ho, wo, cout, k, s, p};
+    const long long nx = (long long)n * h * w * cin, nz = (long long)n * ho * wo * cout, nw = (long long)cout * k * k * cin;
+    std::vector<void*> tmp;
+    float *x = nullptr, *z = nullptr, *wgt = nullptr, *bias = nullptr, *ref = nullptr, *got = nullptr;
+    unsigned* mx = nullptr;
+    const long long nout = kind == 0 ? nz : kind == 1 ? nx : nw;
+#define CK(expr) do { dyf_status _s = (expr); if (_s != DYF_OK) { tfree(e, tmp); return _s; } } while (0)
+    CK(talloc(e, tmp, &x, (size_t)nx, false)); CK(talloc(e, tmp, &z, (size_t)nz, false)); CK(talloc(e, tmp, &wgt, (size_t)nw, false));
+    CK(talloc(e, tmp, &bias, (size_t)std::max(cin, cout), false));
+    CK(talloc(e, tmp, &ref, (size_t)nout, true)); CK(talloc(e, tmp, &got, (size_t)nout, true)); CK(talloc(e, tmp, &mx, (size_t)4, true));
+    hipStream_t st = nullptr;
+    hipLaunchKernelGGL(t_fill_hash, dim3(nblk(nx)), dim3(256), 0, st, x, nx, seed);
+    hipLaunchKernelGGL(t_fill_hash, dim3(nblk(nz)), dim3(256), 0, st, z, nz, seed + 1u);
+    hipLaunchKernelGGL(t_fill_hash, dim3(nblk(nw)), dim3(256), 0, st, wgt, nw, seed + 2u);   // used in BOTH weight layouts' index spaces
+    hipLaunchKernelGGL(t_fill_hash, dim3(nblk(std::max(cin, cout))), dim3(256), 0, st, bias, (long long)std::max(cin, cout), seed + 3u);
+    float res[3] = {0.0f, 0.0f, 0.0f};
+    for (int pass = 0; pass < 2; ++pass) {  // pass 0: with the split-K workspace, pass 1: without
+        float* ws = pass == 0 ? splitk_ws(e) : nullptr;
+        bool took = false;
+        TK(hipMemsetAsync(got, 0, (size_t)nout * sizeof(float), st));
+        TK(hipMemsetAsync(ref, 0, (size_t)nout * sizeof(float), st));
+        if (kind == 0) {
+            took = tgemm_conv_fwd(g, x, wgt, bias, got, ws, TRAIN_SPLITK_FLOATS, st);
+            hipLaunchKernelGGL(t_conv_fwd, dim3(nblk(nz)), dim3(256), 0, st, g, x, wgt, bias, ref);
+        } else if (kind == 1) {
+            took = tgemm_conv_dgrad(g, z, wgt, bias, got, ws, TRAIN_SPLITK_FLOATS, st);
+            hipLaunchKernelGGL(t_conv_dgrad, dim3(nblk(nx)), dim3(256), 0, st, g, z, wgt, bias, ref);
+        } else {
+            took = tgemm_conv_wgrad(g, z, x, got, st);
+            const long long M = (long long)n * ho * wo;
+            const int tiles = k * k * ((cout + 15) / 16) * ((cin + 15) / 16);
+            long long slices = std::max<long long>(1, std::min<long long>((M + 255) / 256, (4096 + tiles - 1) / tiles));
+            const int ppb = (int)(((M + slices - 1) / slices + 15) / 16 * 16);
+            slices = (M + ppb - 1) / ppb;
+            hipLaunchKernelGGL(t_conv_wgrad, dim3((unsigned)(tiles * slices)), dim3(256), 0, st, g, z, x, ref, (float*)nullptr, ppb);
+        }
+        TK(hipGetLastError());
+        res[2] = took ? 1.0f : 0.0f;
+        if (took) {
+            TK(hipMemsetAsync(mx, 0, 16, st));
+            hipLaunchKernelGGL(t_maxabs2, dim3(nblk(nout)), dim3(256), 0, st, got, ref, nout, mx);
+            unsigned hm[3];
+            TK(hipMemcpy(hm, mx, sizeof(hm), hipMemcpyDeviceToHost));
+            float d, m, ga;
+            memcpy(&d, &hm[0], 4); memcpy(&m, &hm[1], 4); memcpy(&ga, &hm[2], 4);
+            res[pass] = m > 0.0f ? d / m : 1.0f;  // an all-zero reference is a failed check, not a perfect one
+            if (!(ga > 0.0f)) res[pass] = 1.0f;
+            if (getenv("DYF_TRAIN_CHECK_VERBOSE")) fprintf(stderr, "conv_check kind %d pass %d: max|diff| %g max|ref| %g max|got| %g\n", kind, pass, d, m, ga);
+        }
+        if (kind == 2) { res[1] = res[0]; break; }
+    }
+#undef CK
+    TK(hipDeviceSynchronize());
+    tfree(e, tmp);
+    out_host[0] = res[0]; out_host[1] = res[1]; out_host[2] = res[2];
     return DYF_OK;
 }
 

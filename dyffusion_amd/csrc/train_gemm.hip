@@ -47,7 +47,9 @@ __global__ __launch_bounds__(256) void t_gemm_mfma(dyf::TConv g, const float* __
         nstage = (int)((kend - kbeg + GK - 1) / GK);
     } else {
         // split_len > 0: split-K over gridDim.z workgroups of split_len stages each (layers with few output tiles and a deep K:
-        // the 4 x 4 ... 16 x 16 planes at small batches), merged with atomics into the zero-initialised output
+        // the 4 x 4 ... 16 x 16 planes at small batches); the partial sums go to a workspace and are merged in a fixed order
+        // (merging with atomics made the ACTIVATIONS differ in the last bit from run to run, which a (Leaky)ReLU near zero
+        // turns into a different derivative now and then: gradients moved by up to 5e-4 of their norm between identical runs)
         const int total = taps * CK / GK;
         st0 = split_len > 0 ? (int)blockIdx.z * split_len : 0;
         nstage = split_len > 0 ? min(split_len, total - st0) : total;
@@ -189,11 +191,21 @@ __global__ __launch_bounds__(256) void t_gemm_mfma(dyf::TConv g, const float* __
                 atomicAdd(Cp + ((size_t)m * taps + tap) * g.cin + n, acc[i][r]);
             } else {
                 const int NC = MODE == TG_FWD ? g.cout : g.cin;
-                if (split_len > 0) atomicAdd(Cp + (size_t)m * NC + n, acc[i][r] + (blockIdx.z == 0 ? bv : 0.0f));
+                // split-K: raw partial sums to Cp[split][m][n] (the workspace); t_splitk_finish adds them in split order
+                if (split_len > 0) Cp[((size_t)blockIdx.z * M + m) * NC + n] = acc[i][r];
                 else Cp[(size_t)m * NC + n] = acc[i][r] + bv;
             }
         }
 #endif
+}
+
+// y[i] = bias[i % N] + sum over the splits, in split order
+__global__ void t_splitk_finish(const float* ws, int splits, long long MN, int N, const float* bias, float* y) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= MN) return;
+    float s = bias ? bias[i % N] : 0.0f;
+    for (int z = 0; z < splits; ++z) s += ws[(size_t)z * MN + i];
+    y[i] = s;
 }
 
 }  // namespace
@@ -204,7 +216,8 @@ namespace dyf {
 static void plan_splitk(long long tiles, int stages, int& splits, int& len) {
     splits = 1;
     len = 0;
-    if (tiles >= 128 || stages < 16) return;
+    static const bool enabled = !(getenv("DYF_TRAIN_SPLITK") && atoi(getenv("DYF_TRAIN_SPLITK")) == 0);
+    if (!enabled || tiles >= 128 || stages < 16) return;
     long long want = std::min<long long>((512 + tiles - 1) / tiles, stages / 4);  // >= 4 stages per split
     if (want < 2) return;
     len = (int)((stages + want - 1) / want);
@@ -212,23 +225,29 @@ static void plan_splitk(long long tiles, int stages, int& splits, int& len) {
     if (splits < 2) { splits = 1; len = 0; }
 }
 
-bool tgemm_conv_fwd(const TConv& g, const float* x, const float* wt, const float* bias, float* y, hipStream_t st) {
+bool tgemm_conv_fwd(const TConv& g, const float* x, const float* wt, const float* bias, float* y, float* ws, size_t ws_floats,
+                    hipStream_t st) {
     if (g.cin % GK != 0 || g.cout % GN != 0) return false;
     const long long M = (long long)g.n * g.ho * g.wo, mt = (M + GM - 1) / GM;
     int splits, len;
     plan_splitk(mt * (g.cout / GN), g.k * g.k * g.cin / GK, splits, len);
-    if (splits > 1 && hipMemsetAsync(y, 0, (size_t)M * g.cout * sizeof(float), st) != hipSuccess) return false;
-    hipLaunchKernelGGL(t_gemm_mfma<TG_FWD>, dim3((unsigned)mt, g.cout / GN, splits), dim3(256), 0, st, g, x, wt, bias, y, len);
+    if (splits > 1 && (ws == nullptr || (size_t)splits * M * g.cout > ws_floats)) { splits = 1; len = 0; }
+    hipLaunchKernelGGL(t_gemm_mfma<TG_FWD>, dim3((unsigned)mt, g.cout / GN, splits), dim3(256), 0, st, g, x, wt, bias, splits > 1 ? ws : y, len);
+    if (splits > 1)
+        hipLaunchKernelGGL(t_splitk_finish, dim3((unsigned)((M * g.cout + 255) / 256)), dim3(256), 0, st, ws, splits, M * g.cout, g.cout, bias, y);
     return true;
 }
 
-bool tgemm_conv_dgrad(const TConv& g, const float* dz, const float* w, const float* bias, float* dx, hipStream_t st) {
+bool tgemm_conv_dgrad(const TConv& g, const float* dz, const float* w, const float* bias, float* dx, float* ws, size_t ws_floats,
+                      hipStream_t st) {
     if (g.cout % GK != 0 || g.cin % GN != 0) return false;
     const long long M = (long long)g.n * g.h * g.w, mt = (M + GM - 1) / GM;
     int splits, len;
     plan_splitk(mt * (g.cin / GN), g.k * g.k * g.cout / GK, splits, len);
-    if (splits > 1 && hipMemsetAsync(dx, 0, (size_t)M * g.cin * sizeof(float), st) != hipSuccess) return false;
-    hipLaunchKernelGGL(t_gemm_mfma<TG_DGRAD>, dim3((unsigned)mt, g.cin / GN, splits), dim3(256), 0, st, g, dz, w, bias, dx, len);
+    if (splits > 1 && (ws == nullptr || (size_t)splits * M * g.cin > ws_floats)) { splits = 1; len = 0; }
+    hipLaunchKernelGGL(t_gemm_mfma<TG_DGRAD>, dim3((unsigned)mt, g.cin / GN, splits), dim3(256), 0, st, g, dz, w, bias, splits > 1 ? ws : dx, len);
+    if (splits > 1)
+        hipLaunchKernelGGL(t_splitk_finish, dim3((unsigned)((M * g.cin + 255) / 256)), dim3(256), 0, st, ws, splits, M * g.cin, g.cin, bias, dx);
     return true;
 }
 

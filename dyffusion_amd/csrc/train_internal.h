@@ -12,8 +12,11 @@ struct TConv {  // geometry of one nn.Conv2d on NHWC fp32 tensors: x (n, h, w, c
 };
 
 // fp32 MFMA implicit-GEMM forms (train_gemm.hip); return false when the shape is not covered (caller falls back to the VALU kernel)
-bool tgemm_conv_fwd(const TConv& g, const float* x, const float* wt, const float* bias, float* y, hipStream_t st);
-bool tgemm_conv_dgrad(const TConv& g, const float* dz, const float* w, const float* bias, float* dx, hipStream_t st);
+// ws / ws_floats: workspace for the split-K partial sums of launches with few output tiles (null: never split)
+bool tgemm_conv_fwd(const TConv& g, const float* x, const float* wt, const float* bias, float* y, float* ws, size_t ws_floats,
+                    hipStream_t st);
+bool tgemm_conv_dgrad(const TConv& g, const float* dz, const float* w, const float* bias, float* dx, float* ws, size_t ws_floats,
+                      hipStream_t st);
 bool tgemm_conv_wgrad(const TConv& g, const float* dz, const float* x, float* dw, hipStream_t st);
 
 }  // namespace dyf

@@ -228,6 +228,8 @@ class DYffusion(nn.Module):
             if self._seed is not None:  # a re-created engine (batch growth, new grid) keeps the caller's stream
                 self._engine.seed(self._seed)
             self._engine.set_row_offset(self._row_offset)
+        # an optimizer / EMA swap may have modified a network in place since its last upload (version counters: ~0.1 ms)
+        self._sync_engine_weights(self._engine)
         return self._engine
 
     # ------------------------------------------------------------------ stochastic stream (no reference counterpart: the

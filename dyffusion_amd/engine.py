@@ -363,6 +363,13 @@ class HipEngine:
                                                  d.data_ptr(), self._stream()))
         return d
 
+    def train_conv_check(self, kind: int, n: int, h: int, w: int, cin: int, cout: int, k: int, s: int, p: int, seed: int = 1):
+        """Test seam: one training convolution (0 forward, 1 dgrad, 2 wgrad) on the fp32 matrix cores vs the plain VALU kernel.
+        Returns (relative max error with split-K workspace, without, whether the matrix-core form took the shape)."""
+        out = (C.c_float * 3)()
+        self._check(self._lib.dyf_train_conv_check(self._h, kind, n, h, w, cin, cout, k, s, p, C.c_uint32(seed), out))
+        return float(out[0]), float(out[1]), bool(out[2])
+
     def op_linear_attention(self, qkv_bf16: torch.Tensor) -> torch.Tensor:
         """Test seam: LinearAttention core.  qkv (N,HW,384) bf16 (to_qkv output, 4 heads x 32) -> (N,HW,128) bf16."""
         assert qkv_bf16.dtype == self.torch_dtype and qkv_bf16.is_cuda and qkv_bf16.is_contiguous()
@@ -420,14 +427,17 @@ def state_version(net) -> int:
     return sum(int(p._version) for p in net.state_dict().values())
 
 
+def upload_weights(net, eng: "HipEngine", slot: int) -> None:
+    """dyf_load_weights of `net`'s state_dict, remembering which version of the parameters the engine now holds."""
+    eng.load_weights(slot, net.state_dict())
+    net._uploaded_version = (id(eng), state_version(net))
+
+
 def sync_weights(net, eng: "HipEngine", slot: int) -> None:
-    """Re-upload a network whose parameters were modified in place since the last upload (optimizer.step())."""
-    mark = getattr(net, "_uploaded_version", None)
-    ver = state_version(net)
-    if mark != (id(eng), ver):
-        if mark is not None or getattr(net, "_engine", None) is not eng:
-            eng.load_weights(slot, net.state_dict())
-        net._uploaded_version = (id(eng), state_version(net))
+    """Re-upload a network whose parameters or buffers were modified in place since the last upload (optimizer.step(), an EMA
+    swap, `p.data.copy_`): every tensor carries a version counter, their sum identifies the uploaded state."""
+    if getattr(net, "_uploaded_version", None) != (id(eng), state_version(net)):
+        upload_weights(net, eng, slot)
 
 
 def collect_train_results(net, eng: "HipEngine", slot: int, n_forwards: int) -> None:

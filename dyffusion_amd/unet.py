@@ -11,7 +11,7 @@ import torch
 from torch import Tensor, nn
 
 from . import _lib as L
-from .engine import HipEngine, resnet_net_config
+from .engine import HipEngine, resnet_net_config, sync_weights, upload_weights
 from .unet_simple import _AttrDict
 
 HEADS, DIM_HEAD = 4, 32
@@ -125,12 +125,12 @@ class Unet(nn.Module):
 
     def attach_engine(self, engine: HipEngine, slot: int):
         self._engine, self._engine_slot, self._engine_key = engine, slot, "attached"
-        engine.load_weights(slot, self.state_dict())
+        upload_weights(self, engine, slot)
 
     def load_state_dict(self, state_dict, strict: bool = True, **kw):
         res = super().load_state_dict(state_dict, strict=strict, **kw)
         if self._engine is not None:
-            self._engine.load_weights(self._engine_slot, self.state_dict())
+            upload_weights(self, self._engine, self._engine_slot)
         return res
 
     def _own_engine(self, nb: int, hw) -> HipEngine:
@@ -140,7 +140,7 @@ class Unet(nn.Module):
             cfg = self.engine_net_config()
             self._engine = HipEngine(cfg, cfg, hw[0], hw[1], max_batch=nb, use_graph=False, dtype=getattr(self, "engine_dtype", "bf16"))
             self._engine_slot, self._engine_key = L.NET_FORECASTER, key
-            self._engine.load_weights(self._engine_slot, self.state_dict())
+            upload_weights(self, self._engine, self._engine_slot)
         return self._engine
 
     # ------------------------------------------------------------------ reference API
@@ -151,6 +151,7 @@ class Unet(nn.Module):
         else:
             assert condition is None, "condition is not None but num_conditional_channels is 0"
         eng = self._own_engine(x.shape[0], x.shape[-2:])
+        sync_weights(self, eng, self._engine_slot)  # parameters modified in place since the last upload
         mode = 1 if (self._mc_dropout and self.has_dropout) else 0
         return eng.net_forward(self._engine_slot, x, time if self.hparams.with_time_emb else None, condition,
                                dropout_mode=mode)

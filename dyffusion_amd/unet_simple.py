@@ -12,7 +12,7 @@ import torch
 from torch import Tensor, nn
 
 from . import _lib as L
-from .engine import EngineLoss, HipEngine, collect_train_results, net_config, sync_weights
+from .engine import EngineLoss, HipEngine, collect_train_results, net_config, sync_weights, upload_weights
 
 
 class _AttrDict(dict):
@@ -99,12 +99,12 @@ class UNet(nn.Module):
         """Used by DYffusion: both networks of a pair live in one engine."""
         self._engine, self._engine_slot = engine, slot
         self._engine_key = "attached"
-        engine.load_weights(slot, self.state_dict())
+        upload_weights(self, engine, slot)
 
     def load_state_dict(self, state_dict, strict: bool = True, **kw):
         res = super().load_state_dict(state_dict, strict=strict, **kw)
         if self._engine is not None:
-            self._engine.load_weights(self._engine_slot, self.state_dict())
+            upload_weights(self, self._engine, self._engine_slot)
         return res
 
     def _own_engine(self, nb: int, hw) -> HipEngine:
@@ -115,7 +115,7 @@ class UNet(nn.Module):
             self._engine = HipEngine(cfg, cfg, hw[0], hw[1], max_batch=nb, use_graph=False, dtype=getattr(self, "engine_dtype", "bf16"))
             self._engine_slot = L.NET_FORECASTER
             self._engine_key = key
-            self._engine.load_weights(self._engine_slot, self.state_dict())
+            upload_weights(self, self._engine, self._engine_slot)
         return self._engine
 
     # ------------------------------------------------------------------ reference API
@@ -127,6 +127,7 @@ class UNet(nn.Module):
         else:
             assert condition is None
         eng = self._own_engine(inputs.shape[0], inputs.shape[-2:])
+        sync_weights(self, eng, self._engine_slot)  # parameters modified in place since the last upload (optimizer, EMA swap)
         mode = 1 if (self._mc_dropout and self.hparams.dropout > 0) else 0
         return eng.net_forward(self._engine_slot, inputs, time if self.hparams.with_time_emb else None, condition,
                                dropout_mode=mode)

@@ -49,6 +49,13 @@ dyf_status dyf_op_linear_attention(dyf_engine* engine, const uint16_t* qkv_dev, 
 dyf_status dyf_op_attention(dyf_engine* engine, const uint16_t* qkv_dev, int32_t n, int32_t hw, uint16_t* out_dev,
                             void* stream);
 
+/* One training convolution (csrc/train_gemm.hip: fp32 matrix-core forward / dgrad / wgrad of nn.Conv2d on NHWC fp32 tensors) on
+ * hash-random data against the plain VALU kernel of csrc/train.hip.  kind 0 forward, 1 data gradient, 2 weight gradient; geometry
+ * as nn.Conv2d(cin, cout, k, stride s, padding p) on (n, h, w).  out_host[0] = max |mfma - valu| / max |valu| with the split-K
+ * workspace, [1] = the same for the unsplit launch, [2] = 1 if the matrix-core form took the shape. */
+dyf_status dyf_train_conv_check(dyf_engine* engine, int32_t kind, int32_t n, int32_t h, int32_t w, int32_t cin, int32_t cout,
+                                int32_t k, int32_t s, int32_t p, uint32_t seed, float* out_host);
+
 /* Read back the output of UNetBlock `layer` (0..11: encoder then decoder blocks) of the most recent unet_simple forward
  * as fp32 NCHW (NB, cout, h, w) -- per-layer parity analysis against the oracle's taps (oracle/nets.py `taps=`).  The last
  * decoder block is returned dense; positions its sparse-column form did not compute are NaN. */

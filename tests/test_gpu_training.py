@@ -206,3 +206,69 @@ def test_training_step_at_dim64_on_the_matrix_cores_matches_autograd_of_the_orac
     print(f"dim 64: loss {float(out['loss']):.6f}, grad norm {gn:.4f}, worst per-tensor gradient error / grad norm = {errs[worst]:.2e} ({worst})")
     assert errs[worst] <= 1e-3
     m.eval()
+
+
+def test_sampling_after_training_uses_the_updated_weights():
+    """Train -> sample -> train -> sample on ONE engine (captured rollout graph, weights re-uploaded after optimizer.step()):
+    every sample must equal, bit for bit, what a fresh engine built from the current state_dict samples with the same seed --
+    i.e. weight reload invalidates everything derived from the old weights (packed fragments, FiLM tables, graph)."""
+    from tests.gpu_common import seeded_pair
+    mk = dict(dim=64, outer_sample_mode="bilinear", upsample_dims=[64, 64], with_time_emb=True, input_dropout=0.0, dropout=0.1)
+    hp = dict(timesteps=4, schedule="before_t1_only", additional_interpolation_steps=0, additional_interpolation_steps_factor=0,
+              interpolate_before_t1=True, time_encoding="dynamics", forward_conditioning="none", lambda_reconstruction=1.0,
+              lambda_reconstruction2=0.5, loss_function="l1", enable_interpolator_dropout=True, sampling_type="cold",
+              refine_intermediate_predictions=True, model=mk)
+    C, Cs, B = 3, 2, 3
+    PF, PI = seeded_pair(64, C, Cs)
+    g = torch.Generator().manual_seed(5)
+    xt_last, cond = torch.randn(B, C, 23, 11, generator=g).to(DEV), torch.randn(B, C, 23, 11, generator=g).to(DEV)
+    sc = torch.rand(B, Cs, 23, 11, generator=g).to(DEV)
+    m = build_dyffusion(PF, PI, mk, C, Cs, hp, max_batch=B, use_graph=True)
+    opt = torch.optim.SGD(m.model.parameters(), lr=0.05)
+    prev = None
+    for round_ in range(2):
+        m.train()
+        for _ in range(2):
+            opt.zero_grad()
+            out = m.p_losses(xt_last, cond, torch.tensor([0, 1, 3], device=DEV), static_condition=sc)
+            out["loss"].backward()
+            opt.step()
+        m.eval()
+        m.seed(99)
+        got = {k: v.clone() for k, v in m.sample(cond, static_condition=sc).items()}
+        sdF = {k: v.detach().cpu().clone() for k, v in m.model.state_dict().items()}
+        fresh = build_dyffusion(sdF, PI, mk, C, Cs, hp, max_batch=B, use_graph=True)
+        fresh.seed(99)
+        want = fresh.sample(cond, static_condition=sc)
+        for k in want:
+            assert torch.equal(got[k], want[k]), (round_, k)
+        if prev is not None:
+            assert not torch.equal(prev["t4_preds"], got["t4_preds"])  # the second round of training changed the forecast
+        prev = got
+
+
+CONV_CASES = [
+    # (n, h, w, cin, cout, k, s, p)
+    (2, 32, 32, 64, 128, 4, 2, 1),    # encoder conv, 512 output pixels: split-K
+    (3, 8, 8, 512, 512, 2, 2, 0),     # 2x2 / s2 on a tiny plane: 48 output pixels, K = 2048
+    (2, 16, 16, 256, 128, 3, 1, 1),   # decoder 3x3
+    (1, 40, 24, 64, 64, 3, 1, 1),     # 960 pixels: not a multiple of the 128-row tile
+    (2, 8, 8, 1024, 512, 1, 1, 0),    # 1x1 on the concat
+    (2, 64, 64, 128, 64, 3, 1, 1),    # many tiles: no split
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "x".join(map(str, c)))
+@pytest.mark.parametrize("kind", [0, 1, 2], ids=["forward", "dgrad", "wgrad"])
+def test_matrix_core_training_convs_match_the_plain_kernels(case, kind):
+    """csrc/train_gemm.hip (fp32 MFMA implicit GEMM: forward, data gradient, weight gradient; split-K with the ordered merge) against
+    the one-thread-per-output VALU kernels of csrc/train.hip on hash-random data: fp32 operands on both sides, so only the
+    summation order differs."""
+    import dyffusion_amd as D
+    from dyffusion_amd.engine import net_config
+    cfg = net_config(in_channels=3, cond_channels=2, out_channels=3, dim=64, with_time_emb=True, upsample_dims=(64, 64), dropout=0.0)
+    eng = D.HipEngine(cfg, cfg, 23, 11, max_batch=1, use_graph=False)
+    split, unsplit, took = eng.train_conv_check(kind, *case, seed=7 + kind)
+    assert took, "the matrix-core form declined a shape it is meant for"
+    print(f"kind {kind} {case}: rel max err split {split:.2e}, unsplit {unsplit:.2e}")
+    assert split <= 2e-5 and unsplit <= 2e-5
