@@ -181,3 +181,22 @@ def test_interpolation_experiment_evaluation_step_matches_oracle():
     assert out[f"val/{h}h_avg/ipol/mse"] == pytest.approx(sum(mses) / len(mses), rel=5e-2)
     # the same object drives DYffusion as its interpolator
     assert exp.true_horizon == h and exp.window == 1 and exp.horizon_range == [1, 2, 3]
+
+
+def test_module_on_the_gpu_and_in_place_weight_edits_reach_the_engine():
+    """`net.cuda()` (state_dict tensors on the device) uploads like CPU parameters; an in-place edit of a parameter afterwards
+    (EMA swap, manual surgery) is picked up by the next forward through the version counters, without `load_state_dict`."""
+    cfg = dict(dim=64, upsample_dims=[64, 64], outer_sample_mode="bilinear", with_time_emb=True, dropout=0.0)
+    P = oinit.seeded_state(oinit.unet_simple_param_shapes(64, 5, 3), seed=33)
+    g = torch.Generator().manual_seed(4)
+    x, c, t = torch.randn(2, 3, 23, 11, generator=g), torch.rand(2, 2, 23, 11, generator=g), torch.tensor([1.0, 2.0])
+    net = mirror_from_params(P, cfg, 3, 2, 3).cuda()
+    y = net(x.to(DEV), time=t.to(DEV), condition=c.to(DEV)).cpu()
+    assert rel_rms(y, nets.unet_simple_forward(P, cfg, x, t, c)) <= TOL
+    with torch.no_grad():
+        net.readout[0].bias.add_(0.5)          # in place: no load_state_dict
+        net.output_ops[5].ops[2].weight.mul_(1.25)
+    P2 = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+    y2 = net(x.to(DEV), time=t.to(DEV), condition=c.to(DEV)).cpu()
+    assert rel_rms(y2, nets.unet_simple_forward(P2, cfg, x, t, c)) <= TOL
+    assert rel_rms(y2, y) > 0.05
