@@ -1210,6 +1210,91 @@ dyf_status dyf_criterion_grad(dyf_engine* e, const float* pred_dev, const float*
     return DYF_OK;
 }
 
+// [co][ci][taps] (PyTorch conv weight) -> w [co][tap][ci] and wt [tap][ci][co], on the device
+__global__ void t_repack_conv(const float* raw, int cout, int cin, int taps, float* w, float* wt) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)cout * cin * taps) return;
+    const int tp = (int)(i % taps), ci = (int)((i / taps) % cin), co = (int)(i / ((long long)taps * cin));
+    const float v = raw[i];
+    w[((size_t)co * taps + tp) * cin + ci] = v;
+    wt[((size_t)tp * cin + ci) * cout + co] = v;
+}
+
+// In-place refresh of an existing training copy (same shapes): one H2D copy per tensor, the two conv layouts written by a kernel.
+// Gradient buffers, tapes and every allocation stay as they are.
+static dyf_status train_refresh_weights(dyf_engine* e, int which, std::map<std::string, TensorView>& sd) {
+    TNet& t = e->train->net[which];
+    const Net& n = e->net[which];
+    size_t stage_el = 0;
+    for (int i = 0; i < 12; ++i) stage_el = std::max(stage_el, (size_t)n.blk[i].cout * n.blk[i].cin * n.blk[i].k * n.blk[i].k);
+    stage_el = std::max(stage_el, (size_t)n.dim * 16 * n.cfg.out_channels);
+    stage_el = std::max(stage_el, (size_t)n.dim * n.cin_total);
+    std::vector<void*> tmp;
+    float* stage = nullptr;
+    dyf_status st0 = talloc(e, tmp, &stage, stage_el, false);
+    if (st0 != DYF_OK) return st0;
+    TK(hipDeviceSynchronize());
+    auto put = [&](float* dst, const std::string& key, size_t want) -> bool {
+        const TensorView& v = sd.at(key);
+        if ((size_t)v.numel() != want) throw std::out_of_range("size of " + key);
+        return hipMemcpy(dst, v.data, want * sizeof(float), hipMemcpyHostToDevice) == hipSuccess;
+    };
+    auto put_conv = [&](const std::string& key, int cout, int cin, int taps, float* w, float* wt) -> bool {
+        const size_t el = (size_t)cout * cin * taps;
+        if (!put(stage, key, el)) return false;
+        hipLaunchKernelGGL(t_repack_conv, dim3(nblk((long long)el)), dim3(256), 0, nullptr, stage, cout, cin, taps, w, wt);
+        return hipDeviceSynchronize() == hipSuccess;  // the staging buffer is overwritten by the next tensor
+    };
+    bool ok = true;
+    for (int i = 0; i < 12 && ok; ++i) {
+        const UBlock& b = n.blk[i];
+        TBlockW& w = t.blk[i];
+        const std::string pre = (i < 6 ? "input_ops." + std::to_string(i) : "output_ops." + std::to_string(i - 6));
+        const std::string conv = pre + ".ops." + (b.transposed ? "1" : "0"), norm = pre + ".ops." + (b.transposed ? "2" : "1");
+        ok = put_conv(conv + ".weight", b.cout, b.cin, b.k * b.k, w.w, w.wt) && put(w.b, conv + ".bias", b.cout) &&
+             put(w.gamma, norm + ".weight", b.cout) && put(w.beta, norm + ".bias", b.cout);
+        if (ok && !b.gn) ok = put(w.rmean, norm + ".running_mean", b.cout) && put(w.rvar, norm + ".running_var", b.cout);
+        if (ok && n.cfg.with_time_emb)
+            ok = put(w.fw, pre + ".time_mlp.1.weight", (size_t)2 * b.cout * n.tdim) && put(w.fb, pre + ".time_mlp.1.bias", (size_t)2 * b.cout);
+    }
+    if (ok && n.cfg.with_time_emb)
+        ok = put(t.t_w1, "time_emb_mlp.1.weight", (size_t)n.tdim * n.dim) && put(t.t_b1, "time_emb_mlp.1.bias", n.tdim) &&
+             put(t.t_w2, "time_emb_mlp.3.weight", (size_t)n.tdim * n.tdim) && put(t.t_b2, "time_emb_mlp.3.bias", n.tdim);
+    if (ok) ok = put_conv("init_conv.weight", n.dim, n.cin_total, 1, t.stem_w, t.stem_wt) && put(t.stem_b, "init_conv.bias", n.dim);
+    if (ok) ok = put_conv("readout.0.weight", n.dim, n.cfg.out_channels, 16, t.ro_w, t.ro_wt) && put(t.ro_b, "readout.0.bias", n.cfg.out_channels);
+    tfree(e, tmp);
+    if (!ok) return fail(e, DYF_ERR_HIP, "dyf_train_load_weights: upload failed");
+    return DYF_OK;
+}
+
+// Refresh ONLY the training copy of a network's parameters (fp32, both conv layouts) -- what a training loop needs after every
+// optimizer.step().  dyf_load_weights also rebuilds everything the sampling path derives from the weights (BatchNorm folding,
+// phase-decomposed / fragment-ordered bf16 packs, FiLM tables: ~170 ms of host work for a unet_simple of dim 64); the sampling copy
+// is left as it is and must be reloaded with dyf_load_weights before the network is sampled again (the Python module tracks both).
+dyf_status dyf_train_load_weights(dyf_engine* e, int32_t which, int32_t n_tensors, const char* const* names, const float* const* data,
+                                  const int64_t* const* shapes, const int32_t* ndims) {
+    if (!e || which < 0 || which > 1 || n_tensors < 1 || !names || !data || !shapes || !ndims)
+        return fail(e, DYF_ERR_INVALID_ARGUMENT, "dyf_train_load_weights: bad arguments");
+    TK(hipSetDevice(e->cfg.device));
+    const Net& n = e->net[which];
+    if (n.rn || n.sc || !n.loaded || !e->train || !e->train->net[which].ready)
+        return fail(e, DYF_ERR_STATE, "dyf_train_load_weights: arch unet_simple with weights loaded once by dyf_load_weights");
+    std::map<std::string, TensorView> sd;
+    for (int i = 0; i < n_tensors; ++i) {
+        TensorView v;
+        v.data = data[i];
+        v.shape.assign(shapes[i], shapes[i] + ndims[i]);
+        sd[names[i]] = v;
+    }
+    // same tensors and shapes as the copy in place (dyf_load_weights validated those)
+    try {
+        return train_refresh_weights(e, which, sd);
+    } catch (const std::exception& ex) {
+        e->train->net[which].ready = false;
+        return fail(e, DYF_ERR_INVALID_ARGUMENT, std::string("dyf_train_load_weights: state_dict does not match the loaded network: ") + ex.what());
+    }
+}
+
 // Test seam (include/dyffusion_hip_testing.h): one training convolution on hash-random fp32 data through the fp32 matrix-core
 // form (train_gemm.hip; with the split-K workspace, and -- forward / dgrad -- once more without it) against the plain VALU kernel.
 // kind 0 forward, 1 dgrad, 2 wgrad.  out_host[0] = max |mfma - valu| / max |valu|, out_host[1] = the same for the unsplit launch,

@@ -13,7 +13,7 @@ import torch
 from torch import Tensor, nn
 
 from . import _lib as L
-from .engine import EngineLoss, HipEngine, collect_train_results, sync_weights
+from .engine import EngineLoss, HipEngine, collect_train_results, sync_train_weights, sync_weights
 from .unet_simple import UNet, _AttrDict  # noqa: F401
 
 Step = Union[int, float]
@@ -217,7 +217,7 @@ class DYffusion(nn.Module):
         self._extra_keys = extra_keys
         return steps, refine, n_slots
 
-    def _ensure_engine(self, hw, nb: int) -> HipEngine:
+    def _ensure_engine(self, hw, nb: int, sync: bool = True) -> HipEngine:
         if self._engine is None or (self._engine.height, self._engine.width) != tuple(hw) or self._engine.max_batch < nb:
             opts = dict(self._engine_opts)
             opts["max_batch"] = max(opts["max_batch"], nb)
@@ -228,8 +228,10 @@ class DYffusion(nn.Module):
             if self._seed is not None:  # a re-created engine (batch growth, new grid) keeps the caller's stream
                 self._engine.seed(self._seed)
             self._engine.set_row_offset(self._row_offset)
-        # an optimizer / EMA swap may have modified a network in place since its last upload (version counters: ~0.1 ms)
-        self._sync_engine_weights(self._engine)
+        # an optimizer / EMA swap may have modified a network in place since its last upload (version counters: ~0.1 ms);
+        # the training step refreshes only the engine's training copy instead (sync=False, _p_losses_train)
+        if sync:
+            self._sync_engine_weights(self._engine)
         return self._engine
 
     # ------------------------------------------------------------------ stochastic stream (no reference counterpart: the
@@ -381,8 +383,9 @@ class DYffusion(nn.Module):
         forecaster's parameters (so `torch.optim` / Lightning's `training_step` work unchanged).  arch unet_simple, fp32."""
         lam1, lam2 = self.hparams.lambda_reconstruction, self.hparams.lambda_reconstruction2
         kind = self.hparams.loss_function
-        eng = self._ensure_engine(xt_last.shape[-2:], xt_last.shape[0])
-        self._sync_engine_weights(eng)
+        eng = self._ensure_engine(xt_last.shape[-2:], xt_last.shape[0], sync=False)
+        sync_train_weights(self.model, eng, L.NET_FORECASTER)        # fp32 training copy only: no re-packing of the sampling path
+        sync_train_weights(self._ipol_net, eng, L.NET_INTERPOLATOR)  # frozen: a no-op after the first step
         ipol_drop = bool(getattr(self._ipol_net, "has_dropout", True))
         f_drop = bool(getattr(self.model, "has_dropout", True))
         T = self.num_timesteps

@@ -106,8 +106,8 @@ class HipEngine:
         return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
     # ------------------------------------------------------------------ weights
-    def load_weights(self, net: int, state_dict: Dict[str, torch.Tensor]):
-        """state_dict: the reference's `UNet.state_dict()` (same key names)."""
+    @staticmethod
+    def _marshal_state_dict(state_dict: Dict[str, torch.Tensor]):
         items = [(k, v) for k, v in state_dict.items() if not k.endswith("num_batches_tracked")]
         arrs = [np.ascontiguousarray(v.detach().to("cpu", torch.float32).numpy()) for _, v in items]
         n = len(items)
@@ -116,9 +116,20 @@ class HipEngine:
         shp_store = [(C.c_int64 * max(1, a.ndim))(*a.shape) for a in arrs]
         shapes = (C.c_void_p * n)(*[C.addressof(s) for s in shp_store])
         ndims = (C.c_int32 * n)(*[a.ndim for a in arrs])
+        return n, names, data, shapes, ndims, (arrs, shp_store)  # the last element keeps the buffers alive
+
+    def load_weights(self, net: int, state_dict: Dict[str, torch.Tensor]):
+        """state_dict: the reference's `UNet.state_dict()` (same key names)."""
+        n, names, data, shapes, ndims, _keep = self._marshal_state_dict(state_dict)
         self.plan_valid = False
         self.weights_version += 1
         self._check(self._lib.dyf_load_weights(self._h, net, n, names, data, shapes, ndims))
+
+    def train_load_weights(self, net: int, state_dict: Dict[str, torch.Tensor]):
+        """Refresh only the training copy of `net`'s parameters (after optimizer.step()); the sampling copy keeps the weights of
+        the last `load_weights` until that is called again."""
+        n, names, data, shapes, ndims, _keep = self._marshal_state_dict(state_dict)
+        self._check(self._lib.dyf_train_load_weights(self._h, net, n, names, data, shapes, ndims))
 
     # ------------------------------------------------------------------ per-network seam
     def net_forward(self, net: int, inputs: torch.Tensor, time: Optional[torch.Tensor] = None,
@@ -428,16 +439,32 @@ def state_version(net) -> int:
 
 
 def upload_weights(net, eng: "HipEngine", slot: int) -> None:
-    """dyf_load_weights of `net`'s state_dict, remembering which version of the parameters the engine now holds."""
+    """dyf_load_weights of `net`'s state_dict (sampling copy AND training copy), remembering which version of the parameters
+    the engine now holds."""
     eng.load_weights(slot, net.state_dict())
-    net._uploaded_version = (id(eng), state_version(net))
+    net._uploaded_version = net._train_version = (id(eng), state_version(net))
 
 
 def sync_weights(net, eng: "HipEngine", slot: int) -> None:
-    """Re-upload a network whose parameters or buffers were modified in place since the last upload (optimizer.step(), an EMA
-    swap, `p.data.copy_`): every tensor carries a version counter, their sum identifies the uploaded state."""
+    """Before SAMPLING / inference: re-upload a network whose parameters or buffers were modified in place since the last full
+    upload (optimizer.step(), an EMA swap, `p.data.copy_`): every tensor carries a version counter, their sum identifies the
+    uploaded state."""
     if getattr(net, "_uploaded_version", None) != (id(eng), state_version(net)):
         upload_weights(net, eng, slot)
+
+
+def sync_train_weights(net, eng: "HipEngine", slot: int) -> None:
+    """Before a TRAINING step: refresh only the engine's fp32 training copy (dyf_train_load_weights, ~10x cheaper than the full
+    upload, which re-derives every packed 16-bit layout of the sampling path); the sampling copy is brought up to date by
+    `sync_weights` when the network is next sampled."""
+    ver = (id(eng), state_version(net))
+    if getattr(net, "_train_version", None) == ver:
+        return
+    if getattr(net, "_uploaded_version", None) is None or net._uploaded_version[0] != id(eng):
+        upload_weights(net, eng, slot)  # this engine has never seen the network: full load first
+    else:
+        eng.train_load_weights(slot, net.state_dict())
+        net._train_version = ver
 
 
 def collect_train_results(net, eng: "HipEngine", slot: int, n_forwards: int) -> None:
@@ -457,5 +484,6 @@ def collect_train_results(net, eng: "HipEngine", slot: int, n_forwards: int) -> 
         for k, v in sd.items():
             if k.endswith("num_batches_tracked"):
                 v += n_forwards
-    net._uploaded_version = (id(eng), state_version(net))
+    # the engine's TRAINING copy holds exactly these buffers; its sampling copy still has the old running statistics folded in
+    net._train_version = (id(eng), state_version(net))
 

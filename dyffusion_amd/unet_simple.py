@@ -12,7 +12,8 @@ import torch
 from torch import Tensor, nn
 
 from . import _lib as L
-from .engine import EngineLoss, HipEngine, collect_train_results, net_config, sync_weights, upload_weights
+from .engine import (EngineLoss, HipEngine, collect_train_results, net_config, sync_train_weights, sync_weights,
+                     upload_weights)
 
 
 class _AttrDict(dict):
@@ -153,7 +154,7 @@ class UNet(nn.Module):
         if self.num_conditional_channels > 0 and condition is None:
             raise ValueError("condition must be given when num_conditional_channels > 0")
         eng = self._own_engine(inputs.shape[0], inputs.shape[-2:])
-        sync_weights(self, eng, self._engine_slot)
+        sync_train_weights(self, eng, self._engine_slot)  # the fp32 training copy only
         time = kwargs.get("time") if self.hparams.with_time_emb else None
         pred = eng.train_forward(self._engine_slot, 0, inputs, None if time is None else time.float(), condition,
                                  batch_stats=True, dropout=self.has_dropout)

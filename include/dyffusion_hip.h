@@ -190,6 +190,11 @@ dyf_status dyf_train_backward(dyf_engine* engine, int32_t slot, const float* dou
 dyf_status dyf_train_zero_grads(dyf_engine* engine, int32_t net);
 /* Copy gradients out by the reference's state_dict names (PyTorch layouts), HOST fp32 buffers; "*.running_mean/var" return the
  * updated BatchNorm statistics. */
+/* Refresh only the TRAINING copy of a network's parameters (after optimizer.step()): same arguments as dyf_load_weights, which
+ * must have loaded the network once.  The sampling copy (folded / packed 16-bit weights, FiLM tables) is NOT updated: call
+ * dyf_load_weights again before sampling the network. */
+dyf_status dyf_train_load_weights(dyf_engine* engine, int32_t net, int32_t n_tensors, const char* const* names,
+                                  const float* const* data, const int64_t* const* shapes, const int32_t* ndims);
 dyf_status dyf_train_export(dyf_engine* engine, int32_t net, int32_t n_tensors, const char* const* names, float* const* out_host);
 /* d(scale * mean criterion)/d pred, kinds as dyf_criterion (the loss terms of p_losses, dyffusion.py:531,557). */
 dyf_status dyf_criterion_grad(dyf_engine* engine, const float* pred_dev, const float* target_dev, int64_t count, int32_t kind,
