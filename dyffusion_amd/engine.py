@@ -435,7 +435,25 @@ class EngineLoss(torch.autograd.Function):
 
 
 def state_version(net) -> int:
-    return sum(int(p._version) for p in net.state_dict().values())
+    """Identifies the state of a module's parameters and buffers: the sum of their in-place modification counters
+    (`Tensor._version`: optimizer steps, `p.mul_()`, `load_state_dict`, ...) and of their storage addresses (`p.data = other`
+    swaps).  NOT visible to it: in-place writes through an alias, e.g. `p.data.copy_(...)` -- call `mark_weights_modified()`
+    on the module (or `load_state_dict`) after such an edit.  The tensor list is cached on the module (the mirrors drop it in
+    `_apply`, i.e. on .cuda() / .to() / .float(), which replace buffer objects): ~20 us per call."""
+    vt = net.__dict__.get("_version_tensors")
+    if vt is None:
+        vt = list(net.parameters()) + list(net.buffers())
+        net.__dict__["_version_tensors"] = vt
+    v = net.__dict__.get("_manual_version", 0)
+    for t in vt:
+        v += t._version + t.data_ptr()
+    return v
+
+
+def mark_weights_modified(net) -> None:
+    """Force the next engine use of `net` to re-upload its weights (after edits the version counters cannot see)."""
+    net.__dict__["_manual_version"] = net.__dict__.get("_manual_version", 0) + 1
+    net.__dict__.pop("_version_tensors", None)
 
 
 def upload_weights(net, eng: "HipEngine", slot: int) -> None:
@@ -446,9 +464,8 @@ def upload_weights(net, eng: "HipEngine", slot: int) -> None:
 
 
 def sync_weights(net, eng: "HipEngine", slot: int) -> None:
-    """Before SAMPLING / inference: re-upload a network whose parameters or buffers were modified in place since the last full
-    upload (optimizer.step(), an EMA swap, `p.data.copy_`): every tensor carries a version counter, their sum identifies the
-    uploaded state."""
+    """Before SAMPLING / inference: re-upload a network whose parameters or buffers were modified since the last full upload
+    (optimizer.step(), `p.data = ...` swaps; see `state_version` for what is detected)."""
     if getattr(net, "_uploaded_version", None) != (id(eng), state_version(net)):
         upload_weights(net, eng, slot)
 

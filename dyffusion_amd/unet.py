@@ -11,7 +11,7 @@ import torch
 from torch import Tensor, nn
 
 from . import _lib as L
-from .engine import HipEngine, resnet_net_config, sync_weights, upload_weights
+from .engine import HipEngine, mark_weights_modified, resnet_net_config, sync_weights, upload_weights
 from .unet_simple import _AttrDict
 
 HEADS, DIM_HEAD = 4, 32
@@ -126,6 +126,15 @@ class Unet(nn.Module):
     def attach_engine(self, engine: HipEngine, slot: int):
         self._engine, self._engine_slot, self._engine_key = engine, slot, "attached"
         upload_weights(self, engine, slot)
+
+    def _apply(self, fn, *args, **kwargs):  # .cuda() / .to() / .float() replace buffer objects: drop state_version's cache
+        self.__dict__.pop("_version_tensors", None)
+        return super()._apply(fn, *args, **kwargs)
+
+    def mark_weights_modified(self):
+        """Call after editing weights in a way `Tensor._version` does not record (e.g. `p.data.copy_(ema)`): the next forward /
+        sample / training step re-uploads them."""
+        mark_weights_modified(self)
 
     def load_state_dict(self, state_dict, strict: bool = True, **kw):
         res = super().load_state_dict(state_dict, strict=strict, **kw)

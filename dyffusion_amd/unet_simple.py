@@ -12,7 +12,7 @@ import torch
 from torch import Tensor, nn
 
 from . import _lib as L
-from .engine import (EngineLoss, HipEngine, collect_train_results, net_config, sync_train_weights, sync_weights,
+from .engine import (EngineLoss, mark_weights_modified, HipEngine, collect_train_results, net_config, sync_train_weights, sync_weights,
                      upload_weights)
 
 
@@ -101,6 +101,15 @@ class UNet(nn.Module):
         self._engine, self._engine_slot = engine, slot
         self._engine_key = "attached"
         upload_weights(self, engine, slot)
+
+    def _apply(self, fn, *args, **kwargs):  # .cuda() / .to() / .float() replace buffer objects: drop state_version's cache
+        self.__dict__.pop("_version_tensors", None)
+        return super()._apply(fn, *args, **kwargs)
+
+    def mark_weights_modified(self):
+        """Call after editing weights in a way `Tensor._version` does not record (e.g. `p.data.copy_(ema)`): the next forward /
+        sample / training step re-uploads them."""
+        mark_weights_modified(self)
 
     def load_state_dict(self, state_dict, strict: bool = True, **kw):
         res = super().load_state_dict(state_dict, strict=strict, **kw)

@@ -200,3 +200,9 @@ def test_module_on_the_gpu_and_in_place_weight_edits_reach_the_engine():
     y2 = net(x.to(DEV), time=t.to(DEV), condition=c.to(DEV)).cpu()
     assert rel_rms(y2, nets.unet_simple_forward(P2, cfg, x, t, c)) <= TOL
     assert rel_rms(y2, y) > 0.05
+    # a write through the `.data` alias is invisible to the version counters: the module must be told
+    net.readout[0].bias.data.sub_(0.5)
+    net.mark_weights_modified()
+    P3 = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
+    y3 = net(x.to(DEV), time=t.to(DEV), condition=c.to(DEV)).cpu()
+    assert rel_rms(y3, nets.unet_simple_forward(P3, cfg, x, t, c)) <= TOL and rel_rms(y3, y2) > 0.01
