@@ -451,5 +451,13 @@ class DYffusion(nn.Module):
         eng.train_backward(1, d_pred, want_dinputs=False, param_grads=True)
         collect_train_results(self.model, eng, L.NET_FORECASTER, st["n_fwd"])
 
-    def forward(self, *args, **kwargs):
-        return self.p_losses(*args, **kwargs)
+    def forward(self, inputs: Tensor, targets: Tensor = None, condition: Tensor = None, time: Tensor = None):
+        """`BaseDiffusion.forward` (_base_diffusion.py:81-106): draws one diffusion step per batch item unless `time` is given
+        and evaluates `p_losses(targets, condition=inputs, t, static_condition=condition)`."""
+        b = (targets if targets is not None else inputs).shape[0]
+        t = time if time is not None else torch.randint(0, self.num_timesteps, (b,), device=inputs.device, dtype=torch.long)
+        return self.p_losses(targets, condition=inputs, t=t, static_condition=condition)
+
+    def get_loss(self, inputs: Tensor, targets: Tensor, metadata=None, **kwargs):
+        """`BaseDiffusion.get_loss` (_base_diffusion.py:108-117)."""
+        return self(inputs, targets, **kwargs)

@@ -170,6 +170,22 @@ class MultiHorizonForecastingDYffusion(nn.Module):
             return inputs_raw
         return inputs_raw.unsqueeze(0).expand(n, *inputs_raw.shape).reshape(n * inputs_raw.shape[0], *inputs_raw.shape[1:])
 
+    # --------------------------------- training (stage 2)
+    def get_loss(self, batch: Dict[str, Any]):
+        """forecasting_multi_horizon.py:412-420: the first `window` frames (stacked on channels) are the inputs, the last frame the
+        target, every other batch entry (the static condition) goes through; `DYffusion.get_loss` draws the diffusion steps and
+        evaluates `p_losses`.  Returns the loss dict (`"loss"` is the scalar to call `.backward()` on in training mode).
+        (In the training split the reference does not tile inputs into an ensemble; nor does this.)"""
+        dynamics = batch["dynamics"]
+        b = dynamics.shape[0]
+        inputs = dynamics[:, : self.window].reshape(b, -1, *dynamics.shape[-2:])  # "b window c lat lon -> b (window c) lat lon"
+        extra = {k: v for k, v in batch.items() if k not in ("dynamics", "metadata")}
+        return self.model.get_loss(inputs=inputs, targets=dynamics[:, -1], **extra)
+
+    def training_step(self, batch: Dict[str, Any], batch_idx: int = 0):  # _base_experiment.py:440-470 without the logging
+        out = self.get_loss(batch)
+        return out if isinstance(out, dict) else {"loss": out}
+
     # _base_experiment.py:315-379,540-567
     def predict(self, inputs: Tensor, num_predictions: Optional[int] = None, reshape_ensemble_dim: bool = True,
                 **kwargs) -> Dict[str, Tensor]:

@@ -135,3 +135,30 @@ def test_navier_stokes_long_rollout_with_device_boundary_conditions():
             q = obc.boundary_conditions("navier-stokes", free[f"t{k}_preds"].cpu().clone(), dyn[:, k], meta, time=time)
             assert torch.equal(p, q), k
     assert not torch.equal(out["t17_preds"].cpu(), out["t1_preds"].cpu())
+
+
+def test_forecaster_experiment_get_loss_routes_the_batch_like_the_reference(monkeypatch):
+    """`MultiHorizonForecastingDYffusion.get_loss(batch)` (forecasting_multi_horizon.py:412-420 -> BaseDiffusion.get_loss / forward,
+    _base_diffusion.py:81-117): first frame(s) = inputs = `condition`, last frame = `xt_last`, batch["condition"] = static
+    condition, one diffusion step per item from torch.randint -- equal to calling `p_losses` with those arguments directly."""
+    import json
+    from tests.gpu_common import DEV, build_dyffusion
+    from tests.helpers import load_npz, split_state
+    z = load_npz("plosses_a.npz")
+    hp = json.loads(str(z["hp"]))
+    PF, PI = split_state(z, "F"), split_state(z, "I")
+    xt_last, cond, sc, t = (torch.from_numpy(z[k]).to(DEV) for k in ("xt_last", "cond", "sc", "t"))
+    m = build_dyffusion(PF, PI, hp["model"], 4, 1, hp, max_batch=xt_last.shape[0])
+    exp = D.MultiHorizonForecastingDYffusion(m, window=1)
+    h = hp["timesteps"]
+    dyn = torch.randn(xt_last.shape[0], 1 + h, *xt_last.shape[1:], device=DEV)
+    dyn[:, 0], dyn[:, -1] = cond, xt_last
+    monkeypatch.setattr(torch, "randint", lambda *a, **k: t.clone())
+    got = exp.get_loss({"dynamics": dyn, "condition": sc})
+    monkeypatch.undo()
+    want = m.p_losses(xt_last, cond, t, static_condition=sc)
+    assert set(got) == set(want)
+    for k in want:
+        assert float(got[k]) == float(want[k]), k
+    ref = json.loads(str(z["losses"]))  # the imported reference's own p_losses on these tensors
+    assert float(got["loss"]) == pytest.approx(ref["loss"], rel=2e-2)
