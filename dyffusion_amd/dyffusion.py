@@ -304,10 +304,41 @@ class DYffusion(nn.Module):
         i_time = interpolation_time if t is None else self.diffusion_step_to_interpolation_step(t)
         assert bool((0 < i_time).all()) and bool((i_time < self.interpolator_horizon).all()), \
             f"interpolate time must be in (0, {self.interpolator_horizon}), got {i_time}"
-        eng = self._ensure_engine(x0.shape[-2:], x0.shape[0])
+        return self._interpolate(initial_condition=x_end, x_last=x0, t=i_time, static_condition=static_condition)
+
+    def _interpolate(self, initial_condition: Tensor, x_last: Tensor, t: Tensor, static_condition: Optional[Tensor] = None,
+                     **kwargs) -> Tensor:
+        """dyffusion.py:480-494: interpolator inputs = cat[initial_condition, x_last] on channels, time in (0, horizon)."""
+        assert bool((0 < t).all()) and bool((t < self.interpolator_horizon).all()), \
+            f"interpolate time must be in (0, {self.interpolator_horizon}), got {t}"
+        eng = self._ensure_engine(x_last.shape[-2:], x_last.shape[0])
         mode = 1 if (self.training or self.enable_interpolator_dropout) else 0
-        return eng.net_forward(L.NET_INTERPOLATOR, torch.cat([x_end, x0], dim=1), i_time.float(), static_condition,
+        return eng.net_forward(L.NET_INTERPOLATOR, torch.cat([initial_condition, x_last], dim=1), t.float(), static_condition,
                                dropout_mode=mode if getattr(self._ipol_net, 'has_dropout', True) else 0)
+
+    def get_condition(self, condition: Optional[Tensor], x_last: Optional[Tensor] = None, prediction_type: str = "forward",
+                      static_condition: Optional[Tensor] = None, shape=None) -> Optional[Tensor]:
+        """dyffusion.py:177-190: the static condition is concatenated behind the dynamical one on the channel axis."""
+        if static_condition is None:
+            return condition
+        if condition is None:
+            return static_condition
+        return torch.cat([condition, static_condition], dim=1)
+
+    def _predict_last_dynamics(self, forward_condition: Optional[Tensor], x_t: Tensor, t: Tensor) -> Tensor:
+        """dyffusion.py:192-203: time encoding + one forecaster forward."""
+        enc = self.hparams.time_encoding
+        if enc == "discrete":
+            time = t
+        elif enc == "normalized":
+            time = t / self.num_timesteps
+        elif enc == "dynamics":
+            time = self.diffusion_step_to_interpolation_step(t)
+        else:
+            raise ValueError(f"Invalid time_encoding: {enc}")
+        eng = self._ensure_engine(x_t.shape[-2:], x_t.shape[0])
+        return eng.net_forward(L.NET_FORECASTER, x_t, time.float(), forward_condition,
+                               dropout_mode=1 if (self.enable_forecaster_dropout and getattr(self.model, 'has_dropout', True)) else 0)
 
     def predict_x_last(self, condition: Tensor, x_t: Tensor, t: Tensor, is_sampling: bool = False,
                        static_condition: Optional[Tensor] = None) -> Tensor:
@@ -318,17 +349,14 @@ class DYffusion(nn.Module):
             cond = condition
         elif fc == "none":
             cond = None
-        else:
+        elif "data+noise" in fc:
             tf = (t / (self.num_timesteps - 1)).view(condition.shape[0], *[1] * (condition.ndim - 1))
             cond = tf * condition + (1 - tf) * torch.randn_like(condition)
-        if static_condition is not None:
-            cond = static_condition if cond is None else torch.cat([cond, static_condition], dim=1)
-        enc = self.hparams.time_encoding
-        time = t if enc == "discrete" else t / self.num_timesteps if enc == "normalized" else \
-            self.diffusion_step_to_interpolation_step(t)
-        eng = self._ensure_engine(x_t.shape[-2:], x_t.shape[0])
-        return eng.net_forward(L.NET_FORECASTER, x_t, time.float(), cond,
-                               dropout_mode=1 if (self.enable_forecaster_dropout and getattr(self.model, 'has_dropout', True)) else 0)
+        else:
+            raise ValueError(f"Invalid forward conditioning type: {fc}")
+        cond = self.get_condition(condition=cond, x_last=None, prediction_type="forward", static_condition=static_condition,
+                                  shape=condition.shape)
+        return self._predict_last_dynamics(x_t=x_t, forward_condition=cond, t=t)
 
     def p_losses(self, xt_last: Tensor, condition: Tensor, t: Tensor, static_condition: Optional[Tensor] = None):
         """dyffusion.py:496-567.  Eval mode (`self.training` false): the forecaster objective as the reference evaluates it in
