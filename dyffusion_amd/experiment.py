@@ -262,6 +262,46 @@ class MultiHorizonForecastingDYffusion(nn.Module):
         return out
 
     # _base_experiment.py:700-708
+    # --------------------------------- validation / test epochs: ensemble metrics on the device
+    def ensemble_logging_infix(self, split: str) -> str:  # _base_experiment.py:609-615 (no logging_infix, no input noise)
+        return f"{self.hparams.num_predictions}ens_mems/"
+
+    def validation_step(self, batch: Dict[str, Any], batch_idx: int = 0, dataloader_idx: int = None, **kwargs):
+        """_base_experiment.py:603-607: the evaluation step's fields stay on the GPU (no `torch_to_numpy`)."""
+        results = self.evaluation_step(batch, batch_idx, split="val", **kwargs)
+        self.__dict__.setdefault("_validation_step_outputs", []).append(results)
+        return results
+
+    def test_step(self, batch: Dict[str, Any], batch_idx: int = 0, dataloader_idx: int = None, **kwargs):
+        results = self.evaluation_step(batch, batch_idx, split="test", **kwargs)
+        self.__dict__.setdefault("_test_step_outputs", []).append(results)
+        return results
+
+    def _eval_ensemble_predictions(self, outputs, split: str) -> Dict[str, float]:
+        """_base_experiment.py:569-640: concatenate the steps' outputs (predictions (N, B, ...) along B, targets along their batch
+        axis) and evaluate CRPS / spread-skill ratio / ensemble-mean MSE per horizon and on average -- with
+        `dyffusion_amd.metrics` (ensemble_metrics_kernel), not after a `.cpu().numpy()` round trip.  Returns what the reference
+        logs: `{split}/{N}ens_mems/t{k}/{crps|ssr|mse}` and `.../avg/...`."""
+        from .metrics import eval_ensemble_predictions
+        n = self.hparams.num_predictions
+        if n <= 1 or not outputs:  # use_ensemble_predictions(split), :497-498
+            return {}
+        results = {}
+        for key, first in outputs[0].items():
+            if not torch.is_tensor(first):
+                continue
+            axis = 1 if (first.shape[0] == n and first.dim() >= 2 and "targets" not in key and "true" not in key) else 0
+            results[key] = torch.cat([o[key] for o in outputs], dim=axis)
+        return eval_ensemble_predictions(results, self.model._engine, split=split, infix=self.ensemble_logging_infix(split))
+
+    def on_validation_epoch_end(self) -> Dict[str, float]:
+        outs, self.__dict__["_validation_step_outputs"] = self.__dict__.get("_validation_step_outputs", []), []
+        return self._eval_ensemble_predictions(outs, split="val")
+
+    def on_test_epoch_end(self, calc_ensemble_metrics: bool = True) -> Dict[str, float]:
+        outs, self.__dict__["_test_step_outputs"] = self.__dict__.get("_test_step_outputs", []), []
+        return self._eval_ensemble_predictions(outs, split="test") if calc_ensemble_metrics else {}
+
     def predict_step(self, batch: Dict[str, Any], batch_idx: int = 0, dataloader_idx: int = None, **kwargs) -> None:
         results = self.evaluation_step(batch, batch_idx, split="predict", as_numpy=True, **kwargs)
         self._predict_step_outputs.append(results)

@@ -162,3 +162,34 @@ def test_forecaster_experiment_get_loss_routes_the_batch_like_the_reference(monk
         assert float(got[k]) == float(want[k]), k
     ref = json.loads(str(z["losses"]))  # the imported reference's own p_losses on these tensors
     assert float(got["loss"]) == pytest.approx(ref["loss"], rel=2e-2)
+
+
+def test_validation_epoch_ensemble_metrics_on_the_device():
+    """validation_step x 2 + on_validation_epoch_end (_base_experiment.py:603-660): the per-horizon CRPS / SSR / MSE of the
+    concatenated ensemble forecasts, computed on the GPU, against oracle/metrics.py (pinned to the reference's
+    evaluate_ensemble_prediction by tests/test_oracle_metrics.py) on the same fields."""
+    from oracle import metrics as om
+    from tests.gpu_common import seeded_pair
+    mk = dict(dim=8, outer_sample_mode="bilinear", upsample_dims=[64, 64], with_time_emb=True, input_dropout=0.0, dropout=0.2)
+    hp = dict(timesteps=3, forward_conditioning="none", interpolate_before_t1=True, schedule="before_t1_only",
+              sampling_type="cold", refine_intermediate_predictions=True, enable_interpolator_dropout=True)
+    C, Cs, N = 2, 1, 4
+    PF, PI = seeded_pair(8, C, Cs)
+    m = build_dyffusion(PF, PI, mk, C, Cs, hp, max_batch=N * 3)
+    m.seed(7)
+    exp = D.MultiHorizonForecastingDYffusion(m, num_predictions=N, window=1)
+    g = torch.Generator().manual_seed(2)
+    outs = []
+    for b in (3, 2):
+        batch = {"dynamics": torch.randn(b, 1 + 3, C, 19, 13, generator=g).to(DEV), "condition": torch.rand(b, Cs, 19, 13, generator=g).to(DEV)}
+        outs.append(exp.validation_step(batch, 0))
+    got = exp.on_validation_epoch_end()
+    assert exp.on_validation_epoch_end() == {}  # the outputs were consumed
+    for k in (1, 2, 3):
+        preds = torch.cat([o[f"t{k}_preds"] for o in outs], dim=1).cpu().numpy()     # (N, 5, C, H, W)
+        targets = torch.cat([o[f"t{k}_targets"] for o in outs], dim=0).cpu().numpy()
+        assert preds.shape[:2] == (N, 5)
+        ref = om.evaluate_ensemble_prediction(preds, targets)
+        for name in ("mse", "ssr", "crps"):
+            assert got[f"val/{N}ens_mems/t{k}/{name}"] == pytest.approx(ref[name], rel=5e-5), (k, name)
+    assert got[f"val/{N}ens_mems/avg/crps"] == pytest.approx(np.mean([got[f"val/{N}ens_mems/t{k}/crps"] for k in (1, 2, 3)]))
