@@ -69,6 +69,9 @@ SYMBOLS = [
                                    C.POINTER(C.c_int32)]),
     ("dyf_train_load_weights", C.c_int, [_P, C.c_int32, C.c_int32, C.POINTER(C.c_char_p), C.POINTER(_P), C.POINTER(_P),
                                          C.POINTER(C.c_int32)]),
+    ("dyf_train_load_weights_dev", C.c_int, [_P, C.c_int32, C.c_int32, C.POINTER(C.c_char_p), C.POINTER(_P), C.POINTER(_P),
+                                             C.POINTER(C.c_int32)]),
+    ("dyf_train_export_dev", C.c_int, [_P, C.c_int32, C.c_int32, C.POINTER(C.c_char_p), C.POINTER(_P)]),
     ("dyf_net_forward", C.c_int, [_P, C.c_int32, _P, _P, _P, _P, C.c_int32, C.c_int32, C.POINTER(_P), _P]),
     ("dyf_set_plan", C.c_int, [_P, C.POINTER(Plan)]),
     ("dyf_sample", C.c_int, [_P, _P, _P, _P, C.c_int32, C.POINTER(_P), _P, _P]),

@@ -1135,7 +1135,22 @@ dyf_status dyf_train_backward(dyf_engine* e, int32_t slot, const float* dout_dev
 
 // Copy gradients (and the updated BatchNorm running statistics) out, addressed by the reference's state_dict names, in
 // PyTorch's layouts: conv weights (cout, cin, kh, kw), ConvTranspose2d (cin, cout, kh, kw), Linear (out, in).
+// [co][tap][ci] -> (co, ci, tap), on the device
+__global__ void t_unpack_conv(const float* g, int cout, int cin, int taps, float* out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)cout * cin * taps) return;
+    const int tp = (int)(i % taps), ci = (int)((i / taps) % cin), co = (int)(i / ((long long)taps * cin));
+    out[i] = g[((size_t)co * taps + tp) * cin + ci];
+}
+static dyf_status train_export_impl(dyf_engine* e, int32_t which, int32_t n_tensors, const char* const* names, float* const* out_host, bool dev);
 dyf_status dyf_train_export(dyf_engine* e, int32_t which, int32_t n_tensors, const char* const* names, float* const* out_host) {
+    return train_export_impl(e, which, n_tensors, names, out_host, false);
+}
+// the same into DEVICE buffers (contiguous fp32, on the engine's GPU): no host round trip
+dyf_status dyf_train_export_dev(dyf_engine* e, int32_t which, int32_t n_tensors, const char* const* names, float* const* out_dev) {
+    return train_export_impl(e, which, n_tensors, names, out_dev, true);
+}
+static dyf_status train_export_impl(dyf_engine* e, int32_t which, int32_t n_tensors, const char* const* names, float* const* out_host, bool dev) {
     if (!e || which < 0 || which > 1 || !names || !out_host) return fail(e, DYF_ERR_INVALID_ARGUMENT, "dyf_train_export: bad arguments");
     if (!e->train || !e->train->net[which].ready) return fail(e, DYF_ERR_STATE, "training needs arch unet_simple with loaded weights");
     TK(hipSetDevice(e->cfg.device));
@@ -1151,10 +1166,14 @@ dyf_status dyf_train_export(dyf_engine* e, int32_t which, int32_t n_tensors, con
         const std::string name = names[q];
         float* out = out_host[q];
         bool done = false;
-        auto flat = [&](const std::string& key, const float* dev, size_t cnt) {
-            if (!done && name == key && dev) {
-                const std::vector<float> h = pull(dev, cnt);
-                std::copy(h.begin(), h.end(), out);
+        auto flat = [&](const std::string& key, const float* dptr, size_t cnt) {
+            if (!done && name == key && dptr) {
+                if (dev) {
+                    (void)hipMemcpy(out, dptr, cnt * sizeof(float), hipMemcpyDeviceToDevice);
+                } else {
+                    const std::vector<float> h = pull(dptr, cnt);
+                    std::copy(h.begin(), h.end(), out);
+                }
                 done = true;
             }
         };
@@ -1165,6 +1184,11 @@ dyf_status dyf_train_export(dyf_engine* e, int32_t which, int32_t n_tensors, con
             const std::string conv = pre + ".ops." + (b.transposed ? "1" : "0"), norm = pre + ".ops." + (b.transposed ? "2" : "1");
             if (name == conv + ".weight") {  // [co][tap][ci] -> (co, ci, kh, kw)
                 const int taps = b.k * b.k;
+                if (dev) {
+                    hipLaunchKernelGGL(t_unpack_conv, dim3(nblk((long long)b.cout * taps * b.cin)), dim3(256), 0, nullptr, bw.g_w, b.cout, b.cin, taps, out);
+                    done = true;
+                    continue;
+                }
                 const std::vector<float> h = pull(bw.g_w, (size_t)b.cout * taps * b.cin);
                 for (int co = 0; co < b.cout; ++co)
                     for (int ci = 0; ci < b.cin; ++ci)
@@ -1188,6 +1212,10 @@ dyf_status dyf_train_export(dyf_engine* e, int32_t which, int32_t n_tensors, con
         flat("readout.0.bias", w.g_ro_b, n.cfg.out_channels);
         if (!done && name == "readout.0.weight") {  // [co = dim][tap][ci = C] -> ConvTranspose2d (dim, C, 4, 4)
             const int oc = n.cfg.out_channels;
+            if (dev) {
+                hipLaunchKernelGGL(t_unpack_conv, dim3(nblk((long long)n.dim * 16 * oc)), dim3(256), 0, nullptr, w.g_ro_w, n.dim, oc, 16, out);
+                continue;
+            }
             const std::vector<float> h = pull(w.g_ro_w, (size_t)n.dim * 16 * oc);
             for (int co = 0; co < n.dim; ++co)
                 for (int ci = 0; ci < oc; ++ci)
@@ -1196,6 +1224,7 @@ dyf_status dyf_train_export(dyf_engine* e, int32_t which, int32_t n_tensors, con
         }
         if (!done) return fail(e, DYF_ERR_INVALID_ARGUMENT, "dyf_train_export: unknown tensor '" + name + "'");
     }
+    if (dev) TK(hipDeviceSynchronize());
     return DYF_OK;
 }
 
@@ -1222,7 +1251,7 @@ __global__ void t_repack_conv(const float* raw, int cout, int cin, int taps, flo
 
 // In-place refresh of an existing training copy (same shapes): one H2D copy per tensor, the two conv layouts written by a kernel.
 // Gradient buffers, tapes and every allocation stay as they are.
-static dyf_status train_refresh_weights(dyf_engine* e, int which, std::map<std::string, TensorView>& sd) {
+static dyf_status train_refresh_weights(dyf_engine* e, int which, std::map<std::string, TensorView>& sd, bool dev) {
     TNet& t = e->train->net[which];
     const Net& n = e->net[which];
     size_t stage_el = 0;
@@ -1237,10 +1266,16 @@ static dyf_status train_refresh_weights(dyf_engine* e, int which, std::map<std::
     auto put = [&](float* dst, const std::string& key, size_t want) -> bool {
         const TensorView& v = sd.at(key);
         if ((size_t)v.numel() != want) throw std::out_of_range("size of " + key);
-        return hipMemcpy(dst, v.data, want * sizeof(float), hipMemcpyHostToDevice) == hipSuccess;
+        return hipMemcpy(dst, v.data, want * sizeof(float), dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice) == hipSuccess;
     };
     auto put_conv = [&](const std::string& key, int cout, int cin, int taps, float* w, float* wt) -> bool {
         const size_t el = (size_t)cout * cin * taps;
+        if (dev) {  // the source is device memory: repack straight from it
+            const TensorView& v = sd.at(key);
+            if ((size_t)v.numel() != el) throw std::out_of_range("size of " + key);
+            hipLaunchKernelGGL(t_repack_conv, dim3(nblk((long long)el)), dim3(256), 0, nullptr, v.data, cout, cin, taps, w, wt);
+            return hipGetLastError() == hipSuccess;
+        }
         if (!put(stage, key, el)) return false;
         hipLaunchKernelGGL(t_repack_conv, dim3(nblk((long long)el)), dim3(256), 0, nullptr, stage, cout, cin, taps, w, wt);
         return hipDeviceSynchronize() == hipSuccess;  // the staging buffer is overwritten by the next tensor
@@ -1262,6 +1297,7 @@ static dyf_status train_refresh_weights(dyf_engine* e, int which, std::map<std::
              put(t.t_w2, "time_emb_mlp.3.weight", (size_t)n.tdim * n.tdim) && put(t.t_b2, "time_emb_mlp.3.bias", n.tdim);
     if (ok) ok = put_conv("init_conv.weight", n.dim, n.cin_total, 1, t.stem_w, t.stem_wt) && put(t.stem_b, "init_conv.bias", n.dim);
     if (ok) ok = put_conv("readout.0.weight", n.dim, n.cfg.out_channels, 16, t.ro_w, t.ro_wt) && put(t.ro_b, "readout.0.bias", n.cfg.out_channels);
+    if (dev) (void)hipDeviceSynchronize();
     tfree(e, tmp);
     if (!ok) return fail(e, DYF_ERR_HIP, "dyf_train_load_weights: upload failed");
     return DYF_OK;
@@ -1271,8 +1307,19 @@ static dyf_status train_refresh_weights(dyf_engine* e, int which, std::map<std::
 // optimizer.step().  dyf_load_weights also rebuilds everything the sampling path derives from the weights (BatchNorm folding,
 // phase-decomposed / fragment-ordered bf16 packs, FiLM tables: ~170 ms of host work for a unet_simple of dim 64); the sampling copy
 // is left as it is and must be reloaded with dyf_load_weights before the network is sampled again (the Python module tracks both).
+static dyf_status train_load_weights_impl(dyf_engine* e, int32_t which, int32_t n_tensors, const char* const* names,
+                                          const float* const* data, const int64_t* const* shapes, const int32_t* ndims, bool dev);
 dyf_status dyf_train_load_weights(dyf_engine* e, int32_t which, int32_t n_tensors, const char* const* names, const float* const* data,
                                   const int64_t* const* shapes, const int32_t* ndims) {
+    return train_load_weights_impl(e, which, n_tensors, names, data, shapes, ndims, false);
+}
+// the same with DEVICE pointers (contiguous fp32 tensors on the engine's GPU, e.g. the parameters of a module moved to the GPU)
+dyf_status dyf_train_load_weights_dev(dyf_engine* e, int32_t which, int32_t n_tensors, const char* const* names,
+                                      const float* const* data_dev, const int64_t* const* shapes, const int32_t* ndims) {
+    return train_load_weights_impl(e, which, n_tensors, names, data_dev, shapes, ndims, true);
+}
+static dyf_status train_load_weights_impl(dyf_engine* e, int32_t which, int32_t n_tensors, const char* const* names,
+                                          const float* const* data, const int64_t* const* shapes, const int32_t* ndims, bool dev) {
     if (!e || which < 0 || which > 1 || n_tensors < 1 || !names || !data || !shapes || !ndims)
         return fail(e, DYF_ERR_INVALID_ARGUMENT, "dyf_train_load_weights: bad arguments");
     TK(hipSetDevice(e->cfg.device));
@@ -1288,7 +1335,7 @@ dyf_status dyf_train_load_weights(dyf_engine* e, int32_t which, int32_t n_tensor
     }
     // same tensors and shapes as the copy in place (dyf_load_weights validated those)
     try {
-        return train_refresh_weights(e, which, sd);
+        return train_refresh_weights(e, which, sd, dev);
     } catch (const std::exception& ex) {
         e->train->net[which].ready = false;
         return fail(e, DYF_ERR_INVALID_ARGUMENT, std::string("dyf_train_load_weights: state_dict does not match the loaded network: ") + ex.what());

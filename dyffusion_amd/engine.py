@@ -127,7 +127,20 @@ class HipEngine:
 
     def train_load_weights(self, net: int, state_dict: Dict[str, torch.Tensor]):
         """Refresh only the training copy of `net`'s parameters (after optimizer.step()); the sampling copy keeps the weights of
-        the last `load_weights` until that is called again."""
+        the last `load_weights` until that is called again.  Tensors that all live on this engine's GPU are read in place
+        (dyf_train_load_weights_dev)."""
+        items = [(k, v) for k, v in state_dict.items() if not k.endswith("num_batches_tracked")]
+        if items and all(v.is_cuda and v.device.index == self.device for _, v in items):
+            ts = [v.detach().to(torch.float32).contiguous() for _, v in items]
+            n = len(items)
+            names = (C.c_char_p * n)(*[k.encode() for k, _ in items])
+            data = (C.c_void_p * n)(*[t.data_ptr() for t in ts])
+            shp_store = [(C.c_int64 * max(1, t.dim()))(*t.shape) for t in ts]
+            shapes = (C.c_void_p * n)(*[C.addressof(s_) for s_ in shp_store])
+            ndims = (C.c_int32 * n)(*[t.dim() for t in ts])
+            torch.cuda.current_stream().synchronize()  # the optimizer's kernels have written these tensors
+            self._check(self._lib.dyf_train_load_weights_dev(self._h, net, n, names, data, shapes, ndims))
+            return
         n, names, data, shapes, ndims, _keep = self._marshal_state_dict(state_dict)
         self._check(self._lib.dyf_train_load_weights(self._h, net, n, names, data, shapes, ndims))
 
@@ -356,9 +369,17 @@ class HipEngine:
     def train_zero_grads(self, net: int):
         self._check(self._lib.dyf_train_zero_grads(self._h, net))
 
-    def train_export(self, net: int, names_shapes: Dict[str, tuple]) -> Dict[str, torch.Tensor]:
-        """Gradients (or updated BatchNorm running statistics) by state_dict name -> CPU fp32 tensors."""
+    def train_export(self, net: int, names_shapes: Dict[str, tuple], device: Optional[torch.device] = None) -> Dict[str, torch.Tensor]:
+        """Gradients (or updated BatchNorm running statistics) by state_dict name -> fp32 tensors: on the CPU, or -- `device` =
+        this engine's GPU -- written there directly (device-to-device, dyf_train_export_dev)."""
         names = list(names_shapes)
+        if device is not None and device.type == "cuda":
+            outs = [torch.empty(names_shapes[k], dtype=torch.float32, device=device) for k in names]
+            cn = (C.c_char_p * len(names))(*[k.encode() for k in names])
+            cp = (C.c_void_p * len(names))(*[o.data_ptr() for o in outs])
+            torch.cuda.current_stream().synchronize()
+            self._check(self._lib.dyf_train_export_dev(self._h, net, len(names), cn, cp))
+            return dict(zip(names, outs))
         bufs = [np.empty(names_shapes[k], dtype=np.float32) for k in names]
         cn = (C.c_char_p * len(names))(*[k.encode() for k in names])
         cp = (C.c_void_p * len(names))(*[b.ctypes.data for b in bufs])
@@ -490,13 +511,16 @@ def collect_train_results(net, eng: "HipEngine", slot: int, n_forwards: int) -> 
     updates, num_batches_tracked)."""
     sd = net.state_dict(keep_vars=True)
     shapes = {k: tuple(v.shape) for k, v in sd.items() if isinstance(v, torch.nn.Parameter)}
-    for k, g in eng.train_export(slot, shapes).items():
+    on_gpu = all(v.is_cuda and v.device.index == eng.device for v in sd.values() if torch.is_tensor(v) and v.is_floating_point())
+    dev = next(iter(sd.values())).device if on_gpu else None
+    for k, g in eng.train_export(slot, shapes, device=dev).items():
         p = sd[k]
-        p.grad = g.to(p.device) if p.grad is None else p.grad + g.to(p.device)
+        g = g.to(device=p.device, dtype=p.dtype)
+        p.grad = g if p.grad is None else p.grad + g
     eng.train_zero_grads(slot)
     bufs = {k: tuple(v.shape) for k, v in sd.items() if k.endswith("running_mean") or k.endswith("running_var")}
     with torch.no_grad():
-        for k, v in eng.train_export(slot, bufs).items():
+        for k, v in eng.train_export(slot, bufs, device=dev).items():
             sd[k].copy_(v)
         for k, v in sd.items():
             if k.endswith("num_batches_tracked"):

@@ -195,6 +195,11 @@ dyf_status dyf_train_zero_grads(dyf_engine* engine, int32_t net);
  * dyf_load_weights again before sampling the network. */
 dyf_status dyf_train_load_weights(dyf_engine* engine, int32_t net, int32_t n_tensors, const char* const* names,
                                   const float* const* data, const int64_t* const* shapes, const int32_t* ndims);
+/* dyf_train_load_weights / dyf_train_export with DEVICE pointers (contiguous fp32 tensors on the engine's GPU -- the parameters /
+ * gradients of a module that lives on the GPU): device-to-device copies and repack kernels, no host round trip. */
+dyf_status dyf_train_load_weights_dev(dyf_engine* engine, int32_t net, int32_t n_tensors, const char* const* names,
+                                      const float* const* data_dev, const int64_t* const* shapes, const int32_t* ndims);
+dyf_status dyf_train_export_dev(dyf_engine* engine, int32_t net, int32_t n_tensors, const char* const* names, float* const* out_dev);
 dyf_status dyf_train_export(dyf_engine* engine, int32_t net, int32_t n_tensors, const char* const* names, float* const* out_host);
 /* d(scale * mean criterion)/d pred, kinds as dyf_criterion (the loss terms of p_losses, dyffusion.py:531,557). */
 dyf_status dyf_criterion_grad(dyf_engine* engine, const float* pred_dev, const float* target_dev, int64_t count, int32_t kind,

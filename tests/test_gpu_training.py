@@ -274,3 +274,36 @@ def test_matrix_core_training_convs_match_the_plain_kernels(case, kind):
     assert took, "the matrix-core form declined a shape it is meant for"
     print(f"kind {kind} {case}: rel max err split {split:.2e}, unsplit {unsplit:.2e}")
     assert split <= 2e-5 and unsplit <= 2e-5
+
+
+def test_gpu_resident_parameters_train_like_cpu_resident_ones():
+    """A forecaster moved to the GPU: gradients are exported device-to-device (dyf_train_export_dev) and the refreshed weights read
+    in place (dyf_train_load_weights_dev).  Two SGD steps must produce the parameters of the CPU-resident run (host round
+    trips through dyf_train_export / dyf_train_load_weights), up to the atomics of the weight-gradient kernels.  (SGD, not
+    Adam: the conv biases in front of a training-mode BatchNorm have an exactly-zero true gradient, i.e. pure rounding noise,
+    which Adam's normalisation turns into steps of size lr in a random direction.)"""
+    z = load_npz("plosses_train_a.npz")
+    hp = json.loads(str(z["hp"]))
+    hp["model"] = dict(hp["model"], dropout=0.0)
+    PF, PI = split_state(z, "F"), split_state(z, "I")
+    xt_last, cond, sc, t = (torch.from_numpy(z[k]).to(DEV) for k in ("xt_last", "cond", "sc", "t"))
+    finals = []
+    for on_gpu in (False, True):
+        m = build_dyffusion(PF, PI, hp["model"], 4, 1, hp, max_batch=hp["B"])
+        if on_gpu:
+            m.model.cuda()
+        m.train()
+        opt = torch.optim.SGD(m.model.parameters(), lr=0.05)
+        for _ in range(2):
+            opt.zero_grad()
+            out = m.p_losses(xt_last, cond, t, static_condition=sc)
+            out["loss"].backward()
+            assert all(p.grad is not None and p.grad.device == p.device for p in m.model.parameters())
+            opt.step()
+        finals.append({k: v.detach().cpu().clone() for k, v in m.model.state_dict().items()})
+    for k, a in finals[0].items():
+        b = finals[1][k]
+        if a.is_floating_point():
+            assert torch.allclose(a, b, rtol=1e-4, atol=2e-6), k
+        else:
+            assert torch.equal(a, b), k
