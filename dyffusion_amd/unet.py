@@ -73,7 +73,8 @@ class Unet(nn.Module):
                                  attn_dropout=attn_dropout, input_dropout=input_dropout, init_kernel_size=init_kernel_size,
                                  init_padding=init_padding, num_input_channels=num_input_channels,
                                  num_output_channels=num_output_channels, num_conditional_channels=num_conditional_channels,
-                                 spatial_shape=spatial_shape, outer_sample_mode=None, upsample_dims=None)
+                                 spatial_shape=spatial_shape, outer_sample_mode=None, upsample_dims=None,
+                                 loss_function=loss_function)
         self.num_input_channels = num_input_channels
         self.num_conditional_channels = num_conditional_channels
         cin = num_input_channels + num_conditional_channels
@@ -164,6 +165,18 @@ class Unet(nn.Module):
         mode = 1 if (self._mc_dropout and self.has_dropout) else 0
         return eng.net_forward(self._engine_slot, x, time if self.hparams.with_time_emb else None, condition,
                                dropout_mode=mode)
+
+    def get_loss(self, inputs: Tensor, targets: Tensor, condition: Tensor = None, metadata=None, predictions_mask=None,
+                 return_predictions: bool = False, **kwargs):
+        """`BaseModel.get_loss` (_base_model.py:108-138) in eval mode: predict, then the network's criterion.  The engine's training
+        step (recorded forward + backward) exists for arch `unet_simple` only (csrc/train.hip)."""
+        if self.training:
+            raise NotImplementedError("training step of the ResNet-UNet on the HIP engine (csrc/train.hip covers arch unet_simple)")
+        predictions = self(inputs, condition=condition, **kwargs)
+        p = predictions if predictions_mask is None else predictions[predictions_mask]
+        kind = getattr(self.hparams, "loss_function", "mean_squared_error")
+        loss = predictions.new_tensor(self._engine.criterion(p.contiguous(), targets, kind))
+        return (loss, predictions) if return_predictions else loss
 
     def predict_forward(self, inputs: Tensor, metadata=None, **kwargs):
         return self(inputs, **kwargs)
