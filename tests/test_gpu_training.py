@@ -307,3 +307,38 @@ def test_gpu_resident_parameters_train_like_cpu_resident_ones():
             assert torch.allclose(a, b, rtol=1e-4, atol=2e-6), k
         else:
             assert torch.equal(a, b), k
+
+
+def test_engine_lifecycle_does_not_leak_device_memory():
+    """Create -> sample (graph) -> training step -> sample -> destroy, repeatedly: everything the engine allocated (workspace, packed
+    weights, captured graphs, training copy, tapes, allocator pool) is returned when it is destroyed."""
+    import gc
+    from tests.gpu_common import seeded_pair
+    mk = dict(dim=64, outer_sample_mode="bilinear", upsample_dims=[64, 64], with_time_emb=True, input_dropout=0.0, dropout=0.1)
+    hp = dict(timesteps=3, schedule="before_t1_only", additional_interpolation_steps=0, additional_interpolation_steps_factor=0,
+              interpolate_before_t1=True, time_encoding="dynamics", forward_conditioning="none", lambda_reconstruction=1.0,
+              lambda_reconstruction2=0.5, loss_function="l1", enable_interpolator_dropout=True, sampling_type="cold",
+              refine_intermediate_predictions=True, model=mk)
+    PF, PI = seeded_pair(64, 3, 2)
+    g = torch.Generator().manual_seed(5)
+    x, c = torch.randn(2, 3, 23, 11, generator=g).to(DEV), torch.rand(2, 2, 23, 11, generator=g).to(DEV)
+
+    def used():
+        free, total = torch.cuda.mem_get_info()
+        return (total - free) / 2 ** 20
+
+    marks = []
+    for _ in range(5):
+        m = build_dyffusion(PF, PI, mk, 3, 2, hp, max_batch=2, use_graph=True)
+        m.sample(x, static_condition=c)
+        m.train()
+        out = m.p_losses(x, x, torch.tensor([0, 2], device=DEV), static_condition=c)
+        out["loss"].backward()
+        m.eval()
+        m.sample(x, static_condition=c)
+        del m, out
+        gc.collect()
+        torch.cuda.synchronize()
+        marks.append(used())
+    print("MiB in use after each destroy:", [round(v) for v in marks])
+    assert marks[-1] - marks[1] <= 32.0
