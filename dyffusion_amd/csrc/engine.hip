@@ -322,7 +322,7 @@ dyf_status dyf_engine_create(const dyf_engine_config* cfg, dyf_engine** out_engi
     if (const char* fs = getenv("DYF_FUSE_STEM")) e->fuse_stem = atoi(fs) != 0;
     if (const char* pi = getenv("DYF_PAIR_INTERP")) e->pair_interp = atoi(pi) != 0;
     if (const char* pz = getenv("DYF_POISON_DEC5")) e->poison_dec5 = atoi(pz) != 0;
-    if (conv_init() != hipSuccess || hipStreamCreateWithFlags(&e->cap_stream, hipStreamNonBlocking) != hipSuccess) {
+    if (conv_init() != hipSuccess || linattn_fused_init() != hipSuccess || hipStreamCreateWithFlags(&e->cap_stream, hipStreamNonBlocking) != hipSuccess) {
         delete e;
         return fail(nullptr, DYF_ERR_HIP, "engine initialisation failed (conv_init / stream create)");
     }

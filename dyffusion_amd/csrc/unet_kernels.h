@@ -60,6 +60,22 @@ struct LinAttnArgs {
 };
 hipError_t launch_linear_attention(const LinAttnArgs& a, hipStream_t s);
 
+// K7 fused: LayerNorm output -> to_qkv -> LinearAttention core -> to_out + bias + residual, qkv never written (dim 64 / 128)
+struct LinAttnFusedArgs {
+    const el16_t* xn;         // [n][hw][c] normalised (and dropped) input
+    const el16_t* xres;       // [n][hw][c] residual (the block input)
+    int n, hw, c;
+    const el16_t* wqkv_frag;  // linattn_fused_pack() orders
+    const el16_t* wout_frag;
+    const float* bout;        // [c]
+    el16_t* y;                // [n][hw][c]
+    float* scratch;           // as LinAttnArgs.scratch
+};
+bool linattn_fused_supported(int c);
+hipError_t linattn_fused_init();
+void linattn_fused_pack(const float* w_qkv, const float* w_out, int c, el16_t* qkv_frag, el16_t* out_frag);
+hipError_t launch_linear_attention_fused(const LinAttnFusedArgs& a, hipStream_t s);
+
 // K8 (VALU form for short sequences): softmax(q*scale . k) -> Dropout -> . v  (attention.py:62-72)
 struct AttnArgs {
     const el16_t* qkv;      // [n][hw][3*heads*32]

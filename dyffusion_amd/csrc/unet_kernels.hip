@@ -741,7 +741,9 @@ __global__ __launch_bounds__(256) void linattn_ctx_mfma_kernel(LinAttnArgs a, fl
 
 // merge the workgroup partials of one (sample, head), normalise, and emit ctx as the A fragments of the output product:
 // frags[bh][hi/lo part][k-step s][lane (e, hi')][8]: slot j of lane (e, hi') = ctx[d = 16 s + 8 hi' + j][e]
-__global__ __launch_bounds__(256) void linattn_merge_kernel(const float* part, int nblk, float inv_n, el16_t* frags) {
+// dmap 0: slot j of lane (e, hi') = ctx[d = 16 s + 8 hi' + j][e] (linattn_out_mfma_kernel: q' fragments loaded from memory);
+// dmap 1: d = 16 s + 8 (j >> 2) + 4 hi' + (j & 3) (linattn_fused_out_kernel: q' fragments are MFMA accumulator registers)
+__global__ __launch_bounds__(256) void linattn_merge_kernel(const float* part, int nblk, float inv_n, el16_t* frags, int dmap) {
     // One workgroup per (sample, head).  At 512^2 there are 256 partials per head: the serial three-pass form (max, sum,
     // weighted accumulation, each a chain of dependent loads) took 225 us; here the max / sum passes run 8 partial-groups wide,
     // the rescaling factors exp(M_b - M) are computed once into LDS, and the accumulation keeps 4 loads in flight.
@@ -798,7 +800,8 @@ __global__ __launch_bounds__(256) void linattn_merge_kernel(const float* part, i
         const int r = rq * 4 + r4;
         const float v = acc[r4] * norm;
         const int e = (r >> 2) * 8 + hi * 4 + (r & 3);
-        const size_t idx = (((size_t)bh * 2 * 2 + (d >> 4)) * 64 + ((d >> 3) & 1) * 32 + e) * 8 + (d & 7);
+        const int fh = dmap ? (d >> 2) & 1 : (d >> 3) & 1, fj = dmap ? ((d >> 3) & 1) * 4 + (d & 3) : d & 7;
+        const size_t idx = (((size_t)bh * 2 * 2 + (d >> 4)) * 64 + fh * 32 + e) * 8 + fj;
         const el16_t vh = f32_to_el16(v);
         frags[idx] = vh;
         frags[idx + 2 * 64 * 8] = f32_to_el16(v - el16_to_f32(vh));
@@ -881,11 +884,332 @@ hipError_t launch_linear_attention(const LinAttnArgs& a, hipStream_t s) {
         float* part = a.scratch;                                          // [BH][nblk][LA_PART]
         el16_t* frags = (el16_t*)(a.scratch + (size_t)BH * nblk * LA_PART);  // [BH][2][2][64][8]
         hipLaunchKernelGGL(linattn_ctx_mfma_kernel, dim3(nblk, BH), dim3(256), 0, s, a, part, nblk);
-        hipLaunchKernelGGL(linattn_merge_kernel, dim3(BH), dim3(256), 0, s, (const float*)part, nblk, 1.0f / (float)a.hw, frags);
+        hipLaunchKernelGGL(linattn_merge_kernel, dim3(BH), dim3(256), 0, s, (const float*)part, nblk, 1.0f / (float)a.hw, frags, 0);
         hipLaunchKernelGGL(linattn_out_mfma_kernel, dim3((a.hw + 511) / 512, BH), dim3(256), 0, s, a, (const el16_t*)frags);
         return hipGetLastError();
     }
     hipLaunchKernelGGL(linear_attention_kernel, dim3(a.n * a.heads), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+
+// ---- fused form: to_qkv, both contractions and to_out (+ bias + residual) in two passes over the normalised input ----
+// The qkv tensor (3 * 128 channels per pixel: 829 MB at 300 x 60 x 60) and the attention output (128 channels) never exist:
+//   pass 1 (context):  per 32-pixel group, k_h and v_h = W x on the matrix cores (x fragment = one 16-byte load per lane and
+//       k-step: rows are pixels); the accumulators come out as lane (channel, hi) x 16 pixels, which IS the operand layout of
+//       the pixel contraction ctx_h[e][d] += v[p][e] k'[p][d] (any pixel <-> k-slot mapping works as long as both operands
+//       share it); the softmax over pixels is online (running max per column d, accumulators rescaled only when a group
+//       raises it); the workgroup's (max, sum, acc) partial goes to the same merge kernel as the unfused form;
+//   pass 2 (output):  q_h = W_q x with pixels as MFMA columns, so a lane (pixel, hi) holds 16 of the head's 32 channels:
+//       softmax over d with one lane exchange; out_h = ctx_h^T q' (hi/lo split operands, fp32-accurate); the bf16 result
+//       registers are the B operand of to_out (k = head channel), whose accumulators get bias + residual and are stored as
+//       16-byte channel rows.
+// HBM: xn read twice, residual read once, y written once (4 x 138 MB at OISST level 0, against 2.5 GB for the unfused chain).
+constexpr int LF_GROUPS = 32;  // 32-pixel groups per workgroup (= LA_PIX pixels: the partial layout is shared with the unfused form)
+
+template <int C>
+struct LfCfg {
+    static constexpr int KS = C / 16;
+    static constexpr int CTX_W = 8 * KS * 1024;                   // k0..3, v0..3 fragments
+    static constexpr int CTX_LDS = CTX_W + 4 * 16 * 64 * 4 + 2 * 4 * 32 * 4;
+    static constexpr int OUT_WQ = 4 * KS * 1024, OUT_WO = (C / 32) * 8 * 1024, OUT_CF = 4 * 4 * 1024;
+    static constexpr int OUT_LDS = OUT_WQ + OUT_WO + OUT_CF + C * 4;
+};
+
+template <int C>
+__global__ __launch_bounds__(256) void linattn_fused_ctx_kernel(const el16_t* __restrict__ xn, int hw, const el16_t* __restrict__ wfrag,
+                                                                float* __restrict__ part, int nblk) {
+    constexpr int KS = LfCfg<C>::KS;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lf_smem[];
+    uint4* wl = (uint4*)lf_smem;                                  // [8][KS][64]
+    float* sm_acc = (float*)(lf_smem + LfCfg<C>::CTX_W);           // [4 waves][16][64]
+    float* sm_m = sm_acc + 4 * 16 * 64;                           // [4][32]
+    float* sm_s = sm_m + 4 * 32;
+    const int n = blockIdx.y, blk = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, hi = lane >> 5;
+    {
+        const uint4* src = (const uint4*)wfrag + 4 * KS * 64;     // groups 4..11 of [q0..3, k0..3, v0..3]
+        for (int i = tid; i < 8 * KS * 64; i += 256) wl[i] = src[i];
+    }
+    __syncthreads();
+    const int ngroups = (hw + 31) >> 5;
+    const el16_t* xs = xn + (size_t)n * hw * C + 8 * hi;
+    la_f32x16 acc[4];
+    float m[4], sum[4];
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+        m[h] = -3.0e38f;
+        sum[h] = 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[h][r] = 0.0f;
+    }
+    auto load = [&](int g, uint4 (&xf)[KS]) {
+        const int p = min(g * 32 + l31, hw - 1);  // pixels past the end repeat the last one (their k' is masked below)
+        const uint4* src = (const uint4*)(xs + (size_t)p * C);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) xf[s] = src[2 * s];
+    };
+    int g = blk * LF_GROUPS + wave;
+    const int gend = min((blk + 1) * LF_GROUPS, ngroups);
+    uint4 xc[KS], xnx[KS];
+    if (g < gend) load(g, xc);
+    for (; g < gend; g += 4) {
+        if (g + 4 < gend) load(g + 4, xnx);
+        const bool full = (g + 1) * 32 <= hw;  // wave-uniform
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            int wlane = lane;
+            asm volatile("" : "+v"(wlane));  // the weight fragments are loop-invariant LDS reads: hoisted, they cost 128+ registers
+            la_f32x16 dk, dv;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dk[r] = dv[r] = 0.0f;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const el16x8_t xa = __builtin_bit_cast(el16x8_t, xc[s]);
+                dk = DYF_MFMA_32x32x16(xa, __builtin_bit_cast(el16x8_t, wl[(h * KS + s) * 64 + wlane]), dk, 0, 0, 0);
+                dv = DYF_MFMA_32x32x16(xa, __builtin_bit_cast(el16x8_t, wl[((4 + h) * KS + s) * 64 + wlane]), dv, 0, 0, 0);
+            }
+            // lane (channel l31, hi): register r = pixel g*32 + 8 (r >> 2) + 4 hi + (r & 3)
+            float gm = dk[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) gm = fmaxf(gm, dk[r]);
+            gm = fmaxf(gm, __shfl_xor(gm, 32, 64));
+            if (__builtin_amdgcn_ballot_w64(gm > m[h]) != 0) {
+                const float mn = fmaxf(m[h], gm), f = __expf(m[h] - mn);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[h][r] *= f;
+                sum[h] *= f;
+                m[h] = mn;
+            }
+            uint32_t kh[8], vh[8];
+#pragma unroll
+            for (int r2 = 0; r2 < 8; ++r2) {
+                float x0 = __expf(dk[2 * r2] - m[h]), x1 = __expf(dk[2 * r2 + 1] - m[h]);
+                if (!full) {
+                    const int p0 = g * 32 + 8 * (r2 >> 1) + 4 * hi + 2 * (r2 & 1);
+                    x0 = p0 < hw ? x0 : 0.0f;
+                    x1 = p0 + 1 < hw ? x1 : 0.0f;
+                }
+                sum[h] += x0 + x1;
+                kh[r2] = pack_el16x2(x0, x1);
+                vh[r2] = pack_el16x2(dv[2 * r2], dv[2 * r2 + 1]);
+            }
+            const uint32_t v0[4] = {vh[0], vh[1], vh[2], vh[3]}, v1[4] = {vh[4], vh[5], vh[6], vh[7]};
+            const uint32_t k0[4] = {kh[0], kh[1], kh[2], kh[3]}, k1[4] = {kh[4], kh[5], kh[6], kh[7]};
+            acc[h] = DYF_MFMA_32x32x16(la_frag(v0), la_frag(k0), acc[h], 0, 0, 0);
+            acc[h] = DYF_MFMA_32x32x16(la_frag(v1), la_frag(k1), acc[h], 0, 0, 0);
+        }
+#pragma unroll
+        for (int s = 0; s < KS; ++s) xc[s] = xnx[s];
+    }
+    // merge the four waves per head (as linattn_ctx_mfma_kernel) and emit the partial
+#pragma unroll
+    for (int h = 0; h < 4; ++h) {
+        const float sh = sum[h] + __shfl_xor(sum[h], 32, 64);
+        if (hi == 0) {
+            sm_m[wave * 32 + l31] = m[h];
+            sm_s[wave * 32 + l31] = sh;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sm_acc[(wave * 16 + r) * 64 + lane] = acc[h][r];
+        __syncthreads();
+        float M = sm_m[l31];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) M = fmaxf(M, sm_m[w * 32 + l31]);
+        float f[4], S = 0.0f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            f[w] = __expf(sm_m[w * 32 + l31] - M);
+            S = fmaf(f[w], sm_s[w * 32 + l31], S);
+        }
+        float* o = part + ((size_t)(n * LA_HEADS + h) * nblk + blk) * LA_PART;
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+            const int r = wave * 4 + r4;
+            float v = 0.0f;
+#pragma unroll
+            for (int w = 0; w < 4; ++w) v = fmaf(f[w], sm_acc[(w * 16 + r) * 64 + lane], v);
+            o[r * 64 + lane] = v;
+        }
+        if (tid < 32) {
+            o[1024 + tid] = M;
+            o[1056 + tid] = S;
+        }
+        __syncthreads();
+    }
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void linattn_fused_out_kernel(const el16_t* __restrict__ xn, const el16_t* __restrict__ xres, int hw,
+                                                                const el16_t* __restrict__ wfrag, const el16_t* __restrict__ wofrag,
+                                                                const float* __restrict__ bias, const el16_t* __restrict__ frags,
+                                                                el16_t* __restrict__ y) {
+    constexpr int KS = LfCfg<C>::KS, OG = C / 32;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lf_smem[];
+    uint4* wq = (uint4*)lf_smem;                                            // [4][KS][64]
+    uint4* wo = (uint4*)(lf_smem + LfCfg<C>::OUT_WQ);                        // [OG][8][64]
+    uint4* cf = (uint4*)(lf_smem + LfCfg<C>::OUT_WQ + LfCfg<C>::OUT_WO);      // [4 heads][hi s0, hi s1, lo s0, lo s1][64]
+    float* bl = (float*)(lf_smem + LfCfg<C>::OUT_WQ + LfCfg<C>::OUT_WO + LfCfg<C>::OUT_CF);
+    const int n = blockIdx.y, blk = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, hi = lane >> 5;
+    for (int i = tid; i < 4 * KS * 64; i += 256) wq[i] = ((const uint4*)wfrag)[i];
+    for (int i = tid; i < OG * 8 * 64; i += 256) wo[i] = ((const uint4*)wofrag)[i];
+    for (int i = tid; i < 4 * 4 * 64; i += 256) cf[i] = ((const uint4*)frags)[(size_t)n * 4 * 4 * 64 + i];
+    for (int i = tid; i < C; i += 256) bl[i] = bias[i];
+    __syncthreads();
+    const int ngroups = (hw + 31) >> 5;
+    const el16_t* xs = xn + (size_t)n * hw * C + 8 * hi;
+    const el16_t* rs = xres + (size_t)n * hw * C + 8 * hi;
+    el16_t* ys = y + (size_t)n * hw * C + 8 * hi;
+    const float scale = 0.17677669529663687f;  // 32^-1/2
+    auto load = [&](int g, uint4 (&xf)[KS]) {
+        const int p = min(g * 32 + l31, hw - 1);
+        const uint4* src = (const uint4*)(xs + (size_t)p * C);
+#pragma unroll
+        for (int s = 0; s < KS; ++s) xf[s] = src[2 * s];
+    };
+    int g = blk * LF_GROUPS + wave;
+    const int gend = min((blk + 1) * LF_GROUPS, ngroups);
+    uint4 xc[KS], xnx[KS];
+    if (g < gend) load(g, xc);
+    for (; g < gend; g += 4) {
+        if (g + 4 < gend) load(g + 4, xnx);
+        const int p = g * 32 + l31;
+        const bool valid = p < hw;
+        const size_t poff = (size_t)(valid ? p : hw - 1) * C;
+        uint4 res[OG][2];
+#pragma unroll
+        for (int og = 0; og < OG; ++og)
+#pragma unroll
+            for (int g2 = 0; g2 < 2; ++g2) res[og][g2] = *(const uint4*)(rs + poff + og * 32 + g2 * 16);
+        la_f32x16 d3[OG];
+#pragma unroll
+        for (int og = 0; og < OG; ++og)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) d3[og][r] = 0.0f;
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+            int wlane = lane;
+            asm volatile("" : "+v"(wlane));  // as above: keep the LDS fragment reads inside the loop
+            la_f32x16 d1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) d1[r] = 0.0f;
+#pragma unroll
+            for (int s = 0; s < KS; ++s)
+                d1 = DYF_MFMA_32x32x16(__builtin_bit_cast(el16x8_t, wq[(h * KS + s) * 64 + wlane]), __builtin_bit_cast(el16x8_t, xc[s]), d1, 0, 0, 0);
+            // lane (pixel, hi): register r = q[d = 8 (r >> 2) + 4 hi + (r & 3)]
+            float qm = d1[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) qm = fmaxf(qm, d1[r]);
+            qm = fmaxf(qm, __shfl_xor(qm, 32, 64));
+            float qs = 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                d1[r] = __expf(d1[r] - qm);
+                qs += d1[r];
+            }
+            qs += __shfl_xor(qs, 32, 64);
+            const float qn = scale / qs;
+            la_f32x16 d2;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) d2[r] = 0.0f;
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                uint32_t qh[4], ql[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) la_split(d1[s2 * 8 + 2 * t], d1[s2 * 8 + 2 * t + 1], qh[t], ql[t]);
+                const el16x8_t ch = __builtin_bit_cast(el16x8_t, cf[(h * 4 + s2) * 64 + wlane]);
+                const el16x8_t cl = __builtin_bit_cast(el16x8_t, cf[(h * 4 + 2 + s2) * 64 + wlane]);
+                d2 = DYF_MFMA_32x32x16(ch, la_frag(qh), d2, 0, 0, 0);
+                d2 = DYF_MFMA_32x32x16(cl, la_frag(qh), d2, 0, 0, 0);
+                d2 = DYF_MFMA_32x32x16(ch, la_frag(ql), d2, 0, 0, 0);
+            }
+            // out_h[e = 8 (r >> 2) + 4 hi + (r & 3)][pixel]: registers 8 t .. 8 t + 7 are k-step 2 h + t of to_out
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                uint32_t ob[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) ob[i] = pack_el16x2(d2[t * 8 + 2 * i] * qn, d2[t * 8 + 2 * i + 1] * qn);
+#pragma unroll
+                for (int og = 0; og < OG; ++og)
+                    d3[og] = DYF_MFMA_32x32x16(__builtin_bit_cast(el16x8_t, wo[(og * 8 + 2 * h + t) * 64 + wlane]), la_frag(ob), d3[og], 0, 0, 0);
+            }
+        }
+        // lane (pixel, hi) holds channels 32 og + 8 (r >> 2) + 4 hi + (r & 3); after the exchange with lane pixel + 32 it
+        // holds the 8 consecutive channels 32 og + 16 g2 + 8 hi + {0..7}: + bias + residual, one 16-byte store
+#pragma unroll
+        for (int og = 0; og < OG; ++og)
+#pragma unroll
+            for (int g2 = 0; g2 < 2; ++g2) {
+                float v[8];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(d3[og][g2 * 8 + i]), __float_as_uint(d3[og][g2 * 8 + 4 + i]), false, false);
+                    v[i] = __uint_as_float(sw[0]);
+                    v[4 + i] = __uint_as_float(sw[1]);
+                }
+                const int cb = og * 32 + g2 * 16 + hi * 8;
+                const float4 b0 = *(const float4*)(bl + cb), b1 = *(const float4*)(bl + cb + 4);
+                const uint4 rr = res[og][g2];
+                uint4 o;
+                o.x = pack_el16x2(v[0] + b0.x + el16_lo(rr.x), v[1] + b0.y + el16_hi(rr.x));
+                o.y = pack_el16x2(v[2] + b0.z + el16_lo(rr.y), v[3] + b0.w + el16_hi(rr.y));
+                o.z = pack_el16x2(v[4] + b1.x + el16_lo(rr.z), v[5] + b1.y + el16_hi(rr.z));
+                o.w = pack_el16x2(v[6] + b1.z + el16_lo(rr.w), v[7] + b1.w + el16_hi(rr.w));
+                if (valid) *(uint4*)(ys + (size_t)p * C + og * 32 + g2 * 16) = o;
+            }
+#pragma unroll
+        for (int s = 0; s < KS; ++s) xc[s] = xnx[s];
+    }
+}
+
+bool linattn_fused_supported(int c) {
+    static const bool on = !(getenv("DYF_LINATTN_FUSED") && atoi(getenv("DYF_LINATTN_FUSED")) == 0);
+    return on && (c == 64 || c == 128);
+}
+
+hipError_t linattn_fused_init() {
+    hipError_t e = hipFuncSetAttribute((const void*)linattn_fused_ctx_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, LfCfg<64>::CTX_LDS);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)linattn_fused_ctx_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, LfCfg<128>::CTX_LDS);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)linattn_fused_out_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, LfCfg<64>::OUT_LDS);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)linattn_fused_out_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, LfCfg<128>::OUT_LDS);
+    return e;
+}
+
+// host side of the fragment orders above (w_qkv [384][c], w_out [c][128], both row-major fp32)
+void linattn_fused_pack(const float* w_qkv, const float* w_out, int c, el16_t* qkv_frag, el16_t* out_frag) {
+    const int ks = c / 16;
+    for (int grp = 0; grp < 12; ++grp)      // q0..3, k0..3, v0..3: rows 32 grp .. 32 grp + 31 of to_qkv
+        for (int s = 0; s < ks; ++s)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 8; ++j)
+                    qkv_frag[(((size_t)grp * ks + s) * 64 + lane) * 8 + j] =
+                        f32_to_el16(w_qkv[(size_t)(32 * grp + (lane & 31)) * c + 16 * s + 8 * (lane >> 5) + j]);
+    for (int og = 0; og < c / 32; ++og)
+        for (int s3 = 0; s3 < 8; ++s3)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int j = 0; j < 8; ++j) {
+                    const int he = 16 * s3 + 8 * (j >> 2) + 4 * (lane >> 5) + (j & 3);
+                    out_frag[(((size_t)og * 8 + s3) * 64 + lane) * 8 + j] = f32_to_el16(w_out[(size_t)(32 * og + (lane & 31)) * 128 + he]);
+                }
+}
+
+hipError_t launch_linear_attention_fused(const LinAttnFusedArgs& a, hipStream_t s) {
+    const int nblk = (a.hw + LA_PIX - 1) / LA_PIX, BH = a.n * LA_HEADS;
+    float* part = a.scratch;
+    el16_t* frags = (el16_t*)(a.scratch + (size_t)BH * nblk * LA_PART);
+    const dim3 grid(nblk, a.n);
+    if (a.c == 64) {
+        hipLaunchKernelGGL(linattn_fused_ctx_kernel<64>, grid, dim3(256), LfCfg<64>::CTX_LDS, s, a.xn, a.hw, a.wqkv_frag, part, nblk);
+    } else {
+        hipLaunchKernelGGL(linattn_fused_ctx_kernel<128>, grid, dim3(256), LfCfg<128>::CTX_LDS, s, a.xn, a.hw, a.wqkv_frag, part, nblk);
+    }
+    hipLaunchKernelGGL(linattn_merge_kernel, dim3(BH), dim3(256), 0, s, (const float*)part, nblk, 1.0f / (float)a.hw, frags, 1);
+    if (a.c == 64) {
+        hipLaunchKernelGGL(linattn_fused_out_kernel<64>, grid, dim3(256), LfCfg<64>::OUT_LDS, s, a.xn, a.xres, a.hw, a.wqkv_frag, a.wout_frag, a.bout, (const el16_t*)frags, a.y);
+    } else {
+        hipLaunchKernelGGL(linattn_fused_out_kernel<128>, grid, dim3(256), LfCfg<128>::OUT_LDS, s, a.xn, a.xres, a.hw, a.wqkv_frag, a.wout_frag, a.bout, (const el16_t*)frags, a.y);
+    }
     return hipGetLastError();
 }
 

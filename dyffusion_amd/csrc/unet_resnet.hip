@@ -27,6 +27,7 @@ struct AttnW {
     bool linear = true;
     float* ln_g = nullptr;
     el16_t *wqkv = nullptr, *wout = nullptr;
+    el16_t *wqkv_frag = nullptr, *wout_frag = nullptr;  // fused LinearAttention (dim 64 / 128)
     float* bout = nullptr;
 };
 
@@ -397,6 +398,12 @@ dyf_status rn_load_weights(dyf_engine* e, Net& n, std::map<std::string, TensorVi
         UPW(a.wout, pack_conv(wo->data, a.dim, HID, 1), a.dim, 1, HID);
         UP(a.bout, vec(bo));
         UP(a.ln_g, vec(lg));
+        if (a.linear && linattn_fused_supported(a.dim)) {
+            std::vector<el16_t> fq((size_t)3 * HID * a.dim), fo((size_t)a.dim * HID);
+            linattn_fused_pack(wq->data, wo->data, a.dim, fq.data(), fo.data());
+            UP(a.wqkv_frag, fq);
+            UP(a.wout_frag, fo);
+        }
     }
     for (int l = 0; l < r->nlev; ++l) {
         SampW& s = r->downs[l];
@@ -476,6 +483,16 @@ dyf_status rn_forward(dyf_engine* e, int which, const Source* srcs, int nsrc, in
         la.x = x; la.pixels = (long long)nb * hw; la.hw = hw; la.c = a.dim; la.g = a.ln_g; la.out = ln;
         la.drop = a.linear ? dc.next(c.attn_dropout) : DropSpec{};  // LinearAttention drops its (normalised) input
         HIP_TRY(e, launch_layernorm_c(la, st));
+        if (a.linear && a.wqkv_frag) {  // to_qkv, both contractions, to_out + residual: two passes over ln
+            el16_t* yf = pool.get();
+            LinAttnFusedArgs f{};
+            f.xn = ln; f.xres = x; f.n = nb; f.hw = hw; f.c = a.dim; f.wqkv_frag = a.wqkv_frag; f.wout_frag = a.wout_frag;
+            f.bout = a.bout; f.y = yf; f.scratch = r->la_scratch;
+            HIP_TRY(e, launch_linear_attention_fused(f, st));
+            pool.put(ln);
+            *out = yf;
+            return DYF_OK;
+        }
         el16_t* qkv = pool.get();
         TRY(rconv(e, ln, a.dim, nullptr, 0, nb, hh, ww, 1, 1, 0, 3 * HID, a.wqkv, r->ones, r->zeros, 0, ACT_NONE, DropSpec{}, nullptr, qkv, st));
         pool.put(ln);
