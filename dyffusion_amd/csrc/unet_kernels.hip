@@ -767,7 +767,8 @@ __global__ __launch_bounds__(256) void linattn_merge_kernel(const float* part, i
     for (int b0 = 0; b0 < nblk; b0 += 256) {
         const int nb = min(256, nblk - b0);
         for (int b = bq; b < nb; b += 8) {
-            const float w = __expf(pb[(size_t)(b0 + b) * LA_PART + 1024 + d8] - M8);
+            const float dm = pb[(size_t)(b0 + b) * LA_PART + 1024 + d8] - M8;
+            const float w = dmap ? __builtin_amdgcn_exp2f(dm) : __expf(dm);  // the fused form keeps its maxima in log2 units
             wexp[b][d8] = w;
             ssum = fmaf(pb[(size_t)(b0 + b) * LA_PART + 1056 + d8], w, ssum);
         }
@@ -905,6 +906,14 @@ hipError_t launch_linear_attention(const LinAttnArgs& a, hipStream_t s) {
 //       registers are the B operand of to_out (k = head channel), whose accumulators get bias + residual and are stored as
 //       16-byte channel rows.
 // HBM: xn read twice, residual read once, y written once (4 x 138 MB at OISST level 0, against 2.5 GB for the unfused chain).
+__device__ __forceinline__ float lf_max32(float x) {  // max over lanes l and l ^ 32 (one VALU op instead of an LDS round trip)
+    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+}
+__device__ __forceinline__ float lf_sum32(float x) {
+    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+}
 constexpr int LF_GROUPS = 32;  // 32-pixel groups per workgroup (= LA_PIX pixels: the partial layout is shared with the unfused form)
 
 template <int C>
@@ -917,7 +926,7 @@ struct LfCfg {
 };
 
 template <int C>
-__global__ __launch_bounds__(256) void linattn_fused_ctx_kernel(const el16_t* __restrict__ xn, int hw, const el16_t* __restrict__ wfrag,
+__global__ __launch_bounds__(256, 2) void linattn_fused_ctx_kernel(const el16_t* __restrict__ xn, int hw, const el16_t* __restrict__ wfrag,
                                                                 float* __restrict__ part, int nblk) {
     constexpr int KS = LfCfg<C>::KS;
     extern __shared__ __attribute__((aligned(16))) unsigned char lf_smem[];
@@ -953,9 +962,9 @@ __global__ __launch_bounds__(256) void linattn_fused_ctx_kernel(const el16_t* __
     const int gend = min((blk + 1) * LF_GROUPS, ngroups);
     uint4 xc[KS], xnx[KS];
     if (g < gend) load(g, xc);
-    for (; g < gend; g += 4) {
-        if (g + 4 < gend) load(g + 4, xnx);
-        const bool full = (g + 1) * 32 <= hw;  // wave-uniform
+    // W_k is pre-scaled by log2(e) (linattn_fused_pack): exp(k - max) = exp2(k2 - max2), and m[] is in log2 units
+    auto group = [&](int g, auto full_c) {
+        constexpr bool FULL = decltype(full_c)::value;  // a straight-line body: the masks of the tail group would split it into 60 blocks
 #pragma unroll
         for (int h = 0; h < 4; ++h) {
             int wlane = lane;
@@ -973,9 +982,9 @@ __global__ __launch_bounds__(256) void linattn_fused_ctx_kernel(const el16_t* __
             float gm = dk[0];
 #pragma unroll
             for (int r = 1; r < 16; ++r) gm = fmaxf(gm, dk[r]);
-            gm = fmaxf(gm, __shfl_xor(gm, 32, 64));
+            gm = lf_max32(gm);
             if (__builtin_amdgcn_ballot_w64(gm > m[h]) != 0) {
-                const float mn = fmaxf(m[h], gm), f = __expf(m[h] - mn);
+                const float mn = fmaxf(m[h], gm), f = __builtin_amdgcn_exp2f(m[h] - mn);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[h][r] *= f;
                 sum[h] *= f;
@@ -984,8 +993,8 @@ __global__ __launch_bounds__(256) void linattn_fused_ctx_kernel(const el16_t* __
             uint32_t kh[8], vh[8];
 #pragma unroll
             for (int r2 = 0; r2 < 8; ++r2) {
-                float x0 = __expf(dk[2 * r2] - m[h]), x1 = __expf(dk[2 * r2 + 1] - m[h]);
-                if (!full) {
+                float x0 = __builtin_amdgcn_exp2f(dk[2 * r2] - m[h]), x1 = __builtin_amdgcn_exp2f(dk[2 * r2 + 1] - m[h]);
+                if (!FULL) {
                     const int p0 = g * 32 + 8 * (r2 >> 1) + 4 * hi + 2 * (r2 & 1);
                     x0 = p0 < hw ? x0 : 0.0f;
                     x1 = p0 + 1 < hw ? x1 : 0.0f;
@@ -999,13 +1008,23 @@ __global__ __launch_bounds__(256) void linattn_fused_ctx_kernel(const el16_t* __
             acc[h] = DYF_MFMA_32x32x16(la_frag(v0), la_frag(k0), acc[h], 0, 0, 0);
             acc[h] = DYF_MFMA_32x32x16(la_frag(v1), la_frag(k1), acc[h], 0, 0, 0);
         }
+    };
+    constexpr bool PREFETCH = KS <= 4;  // dim 128: a second fragment set spills; the second wave of the SIMD covers the loads
+    for (; g < gend; g += 4) {
+        if (PREFETCH && g + 4 < gend) load(g + 4, xnx);
+        if ((g + 1) * 32 <= hw) group(g, std::true_type{});  // wave-uniform
+        else group(g, std::false_type{});
+        if (PREFETCH) {
 #pragma unroll
-        for (int s = 0; s < KS; ++s) xc[s] = xnx[s];
+            for (int s = 0; s < KS; ++s) xc[s] = xnx[s];
+        } else if (g + 4 < gend) {
+            load(g + 4, xc);
+        }
     }
     // merge the four waves per head (as linattn_ctx_mfma_kernel) and emit the partial
 #pragma unroll
     for (int h = 0; h < 4; ++h) {
-        const float sh = sum[h] + __shfl_xor(sum[h], 32, 64);
+        const float sh = lf_sum32(sum[h]);
         if (hi == 0) {
             sm_m[wave * 32 + l31] = m[h];
             sm_s[wave * 32 + l31] = sh;
@@ -1019,7 +1038,7 @@ __global__ __launch_bounds__(256) void linattn_fused_ctx_kernel(const el16_t* __
         float f[4], S = 0.0f;
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
-            f[w] = __expf(sm_m[w * 32 + l31] - M);
+            f[w] = __builtin_amdgcn_exp2f(sm_m[w * 32 + l31] - M);
             S = fmaf(f[w], sm_s[w * 32 + l31], S);
         }
         float* o = part + ((size_t)(n * LA_HEADS + h) * nblk + blk) * LA_PART;
@@ -1040,7 +1059,7 @@ __global__ __launch_bounds__(256) void linattn_fused_ctx_kernel(const el16_t* __
 }
 
 template <int C>
-__global__ __launch_bounds__(256) void linattn_fused_out_kernel(const el16_t* __restrict__ xn, const el16_t* __restrict__ xres, int hw,
+__global__ __launch_bounds__(256, 2) void linattn_fused_out_kernel(const el16_t* __restrict__ xn, const el16_t* __restrict__ xres, int hw,
                                                                 const el16_t* __restrict__ wfrag, const el16_t* __restrict__ wofrag,
                                                                 const float* __restrict__ bias, const el16_t* __restrict__ frags,
                                                                 el16_t* __restrict__ y) {
@@ -1101,28 +1120,29 @@ __global__ __launch_bounds__(256) void linattn_fused_out_kernel(const el16_t* __
             float qm = d1[0];
 #pragma unroll
             for (int r = 1; r < 16; ++r) qm = fmaxf(qm, d1[r]);
-            qm = fmaxf(qm, __shfl_xor(qm, 32, 64));
+            qm = lf_max32(qm);
             float qs = 0.0f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                d1[r] = __expf(d1[r] - qm);
+                d1[r] = __builtin_amdgcn_exp2f(d1[r] - qm);  // W_q is pre-scaled by log2(e)
                 qs += d1[r];
             }
-            qs += __shfl_xor(qs, 32, 64);
+            qs = lf_sum32(qs);
             const float qn = scale / qs;
             la_f32x16 d2;
 #pragma unroll
             for (int r = 0; r < 16; ++r) d2[r] = 0.0f;
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
-                uint32_t qh[4], ql[4];
+                // q' in [0, 1] rounded to 16 bits (q itself is fp32 here; the unfused form rounds q before the exponential);
+                // the context keeps its hi + lo parts: a second MFMA, no VALU work
+                uint32_t qh[4];
 #pragma unroll
-                for (int t = 0; t < 4; ++t) la_split(d1[s2 * 8 + 2 * t], d1[s2 * 8 + 2 * t + 1], qh[t], ql[t]);
+                for (int t = 0; t < 4; ++t) qh[t] = pack_el16x2(d1[s2 * 8 + 2 * t], d1[s2 * 8 + 2 * t + 1]);
                 const el16x8_t ch = __builtin_bit_cast(el16x8_t, cf[(h * 4 + s2) * 64 + wlane]);
                 const el16x8_t cl = __builtin_bit_cast(el16x8_t, cf[(h * 4 + 2 + s2) * 64 + wlane]);
                 d2 = DYF_MFMA_32x32x16(ch, la_frag(qh), d2, 0, 0, 0);
                 d2 = DYF_MFMA_32x32x16(cl, la_frag(qh), d2, 0, 0, 0);
-                d2 = DYF_MFMA_32x32x16(ch, la_frag(ql), d2, 0, 0, 0);
             }
             // out_h[e = 8 (r >> 2) + 4 hi + (r & 3)][pixel]: registers 8 t .. 8 t + 7 are k-step 2 h + t of to_out
 #pragma unroll
@@ -1183,8 +1203,8 @@ void linattn_fused_pack(const float* w_qkv, const float* w_out, int c, el16_t* q
         for (int s = 0; s < ks; ++s)
             for (int lane = 0; lane < 64; ++lane)
                 for (int j = 0; j < 8; ++j)
-                    qkv_frag[(((size_t)grp * ks + s) * 64 + lane) * 8 + j] =
-                        f32_to_el16(w_qkv[(size_t)(32 * grp + (lane & 31)) * c + 16 * s + 8 * (lane >> 5) + j]);
+                    qkv_frag[(((size_t)grp * ks + s) * 64 + lane) * 8 + j] =  // q and k feed exponentials: base 2 on the device
+                        f32_to_el16((grp < 8 ? 1.4426950408889634f : 1.0f) * w_qkv[(size_t)(32 * grp + (lane & 31)) * c + 16 * s + 8 * (lane >> 5) + j]);
     for (int og = 0; og < c / 32; ++og)
         for (int s3 = 0; s3 < 8; ++s3)
             for (int lane = 0; lane < 64; ++lane)
