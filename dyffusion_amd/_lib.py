@@ -87,6 +87,7 @@ SYMBOLS = [
     ("dyf_op_conv2d", C.c_int, [_P, _P, _P] + [C.c_int32] * 9 + [_P, _P, C.c_int32, C.c_int32, _P, _P]),
     ("dyf_op_upconv2d", C.c_int, [_P, _P, _P] + [C.c_int32] * 5 + [_P, _P, C.c_int32, _P, _P]),
     ("dyf_op_linear_attention", C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, _P]),
+    ("dyf_op_linear_attention_fused", C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P]),
     ("dyf_op_attention", C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, _P]),
     ("dyf_criterion", C.c_int, [_P, _P, _P, C.c_int64, C.c_int32, _P, _P]),
     ("dyf_train_forward", C.c_int, [_P, C.c_int32, C.c_int32, _P, _P, _P, _P, C.c_int32, C.c_int32, _P]),

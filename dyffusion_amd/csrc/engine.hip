@@ -1338,6 +1338,38 @@ dyf_status dyf_op_linear_attention(dyf_engine* e, const uint16_t* qkv_dev, int32
     return DYF_OK;
 }
 
+dyf_status dyf_op_linear_attention_fused(dyf_engine* e, const uint16_t* xn_dev, const uint16_t* xres_dev, int32_t n, int32_t hw,
+                                         int32_t c, const float* wqkv_host, const float* wout_host, const float* bout_host,
+                                         uint16_t* y_dev, void* stream) {
+    if (!e || !xn_dev || !xres_dev || !wqkv_host || !wout_host || !bout_host || !y_dev || n < 1 || hw < 1)
+        return fail(e, DYF_ERR_INVALID_ARGUMENT, "dyf_op_linear_attention_fused: bad arguments");
+    if (c != 64 && c != 128) return fail(e, DYF_ERR_UNSUPPORTED, "dyf_op_linear_attention_fused: dim 64 or 128");
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    hipStream_t st = (hipStream_t)stream;
+    std::vector<el16_t> fq((size_t)384 * c), fo((size_t)c * 128);
+    linattn_fused_pack(wqkv_host, wout_host, c, fq.data(), fo.data());
+    const size_t nblk = ((size_t)hw + 1023) / 1024;
+    float *scratch = nullptr, *bo = nullptr;
+    el16_t *dq = nullptr, *dout = nullptr;
+    hipError_t err = hipMalloc((void**)&scratch, (size_t)n * 4 * (nblk * 1088 + 1024) * sizeof(float));
+    if (err == hipSuccess) err = hipMalloc((void**)&bo, (size_t)c * sizeof(float));
+    if (err == hipSuccess) err = hipMalloc((void**)&dq, fq.size() * sizeof(el16_t));
+    if (err == hipSuccess) err = hipMalloc((void**)&dout, fo.size() * sizeof(el16_t));
+    if (err == hipSuccess) err = hipMemcpy(bo, bout_host, (size_t)c * sizeof(float), hipMemcpyHostToDevice);
+    if (err == hipSuccess) err = hipMemcpy(dq, fq.data(), fq.size() * sizeof(el16_t), hipMemcpyHostToDevice);
+    if (err == hipSuccess) err = hipMemcpy(dout, fo.data(), fo.size() * sizeof(el16_t), hipMemcpyHostToDevice);
+    if (err == hipSuccess) {
+        LinAttnFusedArgs f{};
+        f.xn = xn_dev; f.xres = xres_dev; f.n = n; f.hw = hw; f.c = c; f.wqkv_frag = dq; f.wout_frag = dout; f.bout = bo;
+        f.y = y_dev; f.scratch = scratch;
+        err = launch_linear_attention_fused(f, st);
+    }
+    if (err == hipSuccess) err = hipStreamSynchronize(st);
+    (void)hipFree(scratch); (void)hipFree(bo); (void)hipFree(dq); (void)hipFree(dout);
+    if (err != hipSuccess) return fail(e, DYF_ERR_HIP, std::string("dyf_op_linear_attention_fused: ") + hipGetErrorString(err));
+    return DYF_OK;
+}
+
 dyf_status dyf_op_attention(dyf_engine* e, const uint16_t* qkv_dev, int32_t n, int32_t hw, uint16_t* out_dev, void* stream) {
     if (!e || !qkv_dev || !out_dev || n < 1 || hw < 1) return fail(e, DYF_ERR_INVALID_ARGUMENT, "dyf_op_attention: bad arguments");
     HIP_TRY(e, hipSetDevice(e->cfg.device));

@@ -411,6 +411,19 @@ class HipEngine:
         self._check(self._lib.dyf_op_linear_attention(self._h, qkv_bf16.data_ptr(), n, hw, y.data_ptr(), self._stream()))
         return y
 
+    def op_linear_attention_fused(self, xn: torch.Tensor, xres: torch.Tensor, wqkv: torch.Tensor, wout: torch.Tensor,
+                                  bout: torch.Tensor) -> torch.Tensor:
+        """Test seam: the fused LinearAttention block (to_qkv + core + to_out + bias + residual).  xn, xres (N,HW,C) in the engine's
+        16-bit dtype on the device, C in {64, 128}; wqkv (384,C), wout (C,128), bout (C) fp32 on the host -> (N,HW,C)."""
+        assert xn.dtype == self.torch_dtype and xn.is_cuda and xn.is_contiguous() and xres.shape == xn.shape and xres.is_contiguous()
+        n, hw, c = xn.shape
+        wq, wo, bo = (t.detach().to(torch.float32).cpu().contiguous() for t in (wqkv, wout, bout))
+        assert wq.shape == (384, c) and wo.shape == (c, 128) and bo.shape == (c,)
+        y = torch.empty_like(xn)
+        self._check(self._lib.dyf_op_linear_attention_fused(self._h, xn.data_ptr(), xres.data_ptr(), n, hw, c, wq.data_ptr(),
+                                                            wo.data_ptr(), bo.data_ptr(), y.data_ptr(), self._stream()))
+        return y
+
     @property
     def torch_dtype(self) -> torch.dtype:
         return torch.float16 if L.DTYPES[self.dtype] else torch.bfloat16

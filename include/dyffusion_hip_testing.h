@@ -43,6 +43,14 @@ dyf_status dyf_op_upconv2d(dyf_engine* engine, const uint16_t* x_dev, const floa
 dyf_status dyf_op_linear_attention(dyf_engine* engine, const uint16_t* qkv_dev, int32_t n, int32_t hw, uint16_t* out_dev,
                                    void* stream);
 
+/* The fused LinearAttention block the ResNet-UNet runs for dim 64 / 128 (csrc/unet_kernels.hip linattn_fused_*): xn_dev
+ * (N,HW,C) 16-bit = the PreNorm LayerNorm output, xres_dev (N,HW,C) = the block input (residual); wqkv_host (384,C),
+ * wout_host (C,128), bout_host (C) fp32 = to_qkv / to_out parameters -> y_dev (N,HW,C) = to_out(core(to_qkv(xn))) + xres.
+ * The to_qkv and core outputs are never written to memory. */
+dyf_status dyf_op_linear_attention_fused(dyf_engine* engine, const uint16_t* xn_dev, const uint16_t* xres_dev, int32_t n,
+                                         int32_t hw, int32_t c, const float* wqkv_host, const float* wout_host,
+                                         const float* bout_host, uint16_t* y_dev, void* stream);
+
 /* Attention core (attention.py:62-72, 4 heads of 32 channels, no dropout): qkv_dev (N,HW,384) 16-bit = to_qkv output ->
  * out_dev (N,HW,128) = softmax_j(q_i . k_j / sqrt(32)) . v_j, the input of to_out.  Runs the MFMA flash kernel the bottleneck
  * of the ResNet-UNet uses (HW up to 65 535: 16 384 tokens for the 512^2 synthetic configuration). */

@@ -35,3 +35,36 @@ def test_linear_attention_matches_fp32_reference(engine, n, hw):
     assert torch.isfinite(got).all()
     err = (got - want).abs().max().item()
     assert err <= 2.0 ** -8 * want.abs().max().item() + 1e-6, err  # output is bf16: half an ulp of the largest value
+
+
+def _ref_block(xn, xres, wqkv, wout, bout):
+    """to_qkv (1x1, no bias) -> the core above -> to_out (1x1 + bias) + residual, all fp32 (attention.py:22-49, unet.py Residual)."""
+    qkv = xn.float() @ wqkv.t()
+    return _ref(qkv) @ wout.t() + bout + xres.float()
+
+
+# hw: a single pixel, one short / one exact / one-and-a-bit 32-pixel group, the OISST levels (15^2, 30^2, 60^2 = several
+# workgroups with a 16-pixel tail group), exactly one workgroup, one pixel more, a workgroup whose later waves are idle
+@pytest.mark.parametrize("c", [64, 128])
+@pytest.mark.parametrize("n,hw", [(2, 1), (2, 31), (1, 32), (3, 33), (3, 225), (2, 900), (1, 1024), (1, 1025), (2, 3600), (1, 5000)])
+def test_fused_linear_attention_block_matches_fp32_reference(engine, n, hw, c):
+    g = torch.Generator().manual_seed(n * 7919 + hw + c)
+    xn = torch.randn(n, hw, c, generator=g).to(torch.bfloat16)       # LayerNorm output: unit variance per pixel
+    xres = (2.0 * torch.randn(n, hw, c, generator=g)).to(torch.bfloat16)
+    wqkv = torch.randn(384, c, generator=g) * (1.5 / c ** 0.5)
+    wqkv[128:160] *= 3.0                                               # a head whose k logits spread widely over the pixels
+    wout = torch.randn(c, 128, generator=g) * (8.0 / 128 ** 0.5)       # the core output is O(1 / hw ... 1): keep to_out visible
+    bout = torch.randn(c, generator=g)
+    want = _ref_block(xn, xres, wqkv, wout, bout)
+    att = want - xres.float() - bout                                   # the attention branch alone
+    # (1) the branch by itself (zero residual and bias): its own 16-bit operands (weights, v, k', q', core output) and the 16-bit store
+    alone = engine.op_linear_attention_fused(xn.cuda(), torch.zeros_like(xres).cuda(), wqkv, wout, torch.zeros_like(bout)).float().cpu()
+    assert torch.isfinite(alone).all()
+    branch_err = (alone - att).abs().max().item()
+    print(f"fused linattn c={c} n={n} hw={hw}: branch max {att.abs().max().item():.3e}, err {branch_err:.3e}")
+    assert branch_err <= 1.5e-2 * att.abs().max().item(), branch_err
+    # (2) with bias and residual: additionally half an ulp of the largest stored value
+    got = engine.op_linear_attention_fused(xn.cuda(), xres.cuda(), wqkv, wout, bout).float().cpu()
+    assert torch.isfinite(got).all()
+    err = (got - want).abs().max().item()
+    assert err <= 2.0 ** -8 * want.abs().max().item() + 1.5e-2 * att.abs().max().item() + 1e-6, err
