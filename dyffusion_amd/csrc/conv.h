@@ -92,6 +92,12 @@ hipError_t launch_conv_halo5(const ConvArgs& a, hipStream_t stream);
 void pack_halo3_frag64(const el16_t* wpk, int cout, int cin, el16_t* out);
 void conv_register_halo3_frag(const el16_t* wpk_dev, const el16_t* frag_dev);
 const el16_t* conv_lookup_halo3_frag(const el16_t* wpk_dev);
+// enc0 on the fused stem (conv_enc0_stem.hip): persistent, weights resident in LDS, pixel fragments straight from global memory;
+// the fragments (pack_enc0_stem_frag) are registered in the halo3 registry under the composed weights' pointer
+bool conv_enc0_stem_supported(const ConvArgs& a);
+hipError_t conv_enc0_stem_init();
+hipError_t launch_conv_enc0_stem(const ConvArgs& a, const el16_t* wfrag, hipStream_t stream);
+void pack_enc0_stem_frag(const el16_t* wpk, int cout, el16_t* out);
 // second implicit-GEMM form (conv_igemm2.hip): 256 px x 128 ch per workgroup, weights streamed in fragment order
 bool conv_igemm2_supported(const ConvArgs& a);
 hipError_t conv_igemm2_init();

@@ -618,6 +618,7 @@ hipError_t conv_init() {
     if (e == hipSuccess) e = conv_up_halo_init();
     if (e == hipSuccess) e = conv_halo_rows_init();
     if (e == hipSuccess) e = conv_igemm2_init();
+    if (e == hipSuccess) e = conv_enc0_stem_init();
     return e;
 }
 
@@ -663,6 +664,10 @@ hipError_t launch_conv(const ConvArgs& a, int path, hipStream_t stream) {
                 const bool covers = 10ll * a.h * a.w >= 6ll * ty * 16 * tx * 32;
                 if (b.wpk_up_frag && covers && tiles5 >= h5_min && conv_halo5_supported(b)) return launch_conv_halo5(b, stream);
             }
+        }
+        if (a.pix_pitch0 == 16 && conv_enc0_stem_supported(a)) {  // enc0 on the fused stem: HBM-bound, its own persistent kernel
+            const el16_t* f = conv_lookup_halo3_frag(a.wpk);
+            if (f) return launch_conv_enc0_stem(a, f, stream);
         }
         if (!a.up2x && a.kh == 4 && a.kw == 4 && a.stride == 2 && a.cout % 128 == 0 && a.c1 == 0 && a.out_f32 == nullptr &&
             a.residual == nullptr && a.pix_pitch0 == 0) {  // 4x4 / s2 convs: the same kernel on the space-to-depth view

@@ -546,6 +546,13 @@ dyf_status dyf_load_weights(dyf_engine* e, int32_t which, int32_t n_tensors, con
                         fw[((size_t)co * 16 + t) * 16 + c] = f32_to_el16((float)v);
                     }
             { dyf_status _s = upload_conv_weights(e, &n.enc0_fused_w, fw, b.cout, 4, 64); if (_s != DYF_OK) return _s; }
+            if (b.cout == 64 || b.cout == 128) {  // fragments of the persistent enc0 kernel (conv_enc0_stem.hip)
+                std::vector<el16_t> pf(fw.size());
+                pack_enc0_stem_frag(fw.data(), b.cout, pf.data());
+                el16_t* frag = nullptr;
+                UP(frag, pf);
+                conv_register_halo3_frag(n.enc0_fused_w, frag);
+            }
             n.stem_fused = true;
         }
         if (b.transposed && b.k == 3) {

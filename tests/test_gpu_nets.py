@@ -206,3 +206,47 @@ def test_module_on_the_gpu_and_in_place_weight_edits_reach_the_engine():
     P3 = {k: v.detach().cpu().clone() for k, v in net.state_dict().items()}
     y3 = net(x.to(DEV), time=t.to(DEV), condition=c.to(DEV)).cpu()
     assert rel_rms(y3, nets.unet_simple_forward(P3, cfg, x, t, c)) <= TOL and rel_rms(y3, y2) > 0.01
+
+
+_ENC0_SCRIPT = """
+import sys, torch
+sys.path.insert(0, {root!r})
+from tests.gpu_common import mirror_from_params, seeded_pair
+PF, PI = seeded_pair(64, 3, 2, seeds=(31, 32))
+mk = dict(dim=64, with_time_emb=True, upsample_dims=[256, 256], dropout=0.25)
+g = torch.Generator().manual_seed(5)
+x, c, t = torch.randn(8, 6, 221, 42, generator=g), torch.rand(8, 2, 221, 42, generator=g), torch.arange(8.0)
+net = mirror_from_params(PI, mk, 6, 2, 3)
+net(x.cuda(), time=t.cuda(), condition=c.cuda())  # creates the engine
+eng = net._engine
+outs = {{}}
+for mode in (0, 1):
+    eng.seed(77)
+    y = eng.net_forward(net._engine_slot, x.cuda(), t.cuda(), c.cuda(), dropout_mode=mode)
+    outs[f"enc0_{{mode}}"] = eng.read_block_output(net._engine_slot, 0, 8).cpu()
+    outs[f"y_{{mode}}"] = y.cpu()
+torch.save(outs, {out!r})
+"""
+
+
+def test_persistent_enc0_kernel_matches_the_implicit_gemm_form(tmp_path):
+    """enc0 on the fused stem at NB = 8 (4 096 row segments: the persistent kernel of conv_enc0_stem.hip takes the layer) against
+    the same forward with DYF_ENC0_STEM=0 (conv_igemm2_kernel): same K order, same epilogue and dropout stream -> the block output
+    agrees to a 16-bit rounding tie, with and without engine dropout.  The form is chosen once per process: two subprocesses."""
+    import os
+    import subprocess
+    import sys as _sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    outs = []
+    for on in ("1", "0"):
+        out = str(tmp_path / f"enc0_{on}.pt")
+        subprocess.run([_sys.executable, "-c", _ENC0_SCRIPT.format(root=root, out=out)], check=True, env=dict(os.environ, DYF_ENC0_STEM=on),
+                       timeout=900)
+        outs.append(torch.load(out))
+    for k in outs[0]:
+        a, b = outs[0][k], outs[1][k]
+        assert torch.isfinite(a).all() and float(a.std()) > 0, k
+        err, frac = rel_rms(a, b), float((a != b).float().mean())
+        print(f"{k}: persistent vs implicit-GEMM enc0 rel-rms {err:.2e}, {frac:.2e} of the elements differ")
+        assert err <= (2e-3 if k.startswith("enc0") else 1e-2), k
+    assert float((outs[0]["enc0_1"] == 0).float().mean()) > 0.2  # dropout was on (p = 0.25 after ReLU)
