@@ -208,7 +208,123 @@ __global__ __launch_bounds__(256) void stem16_kernel(StemArgs a) {
     o[1] = make_uint4(w[4], w[5], w[6], w[7]);
 }
 
+// Row-block form of stem16_kernel: one workgroup per (sample, block of ST_ROWS padded output rows).  The source rows the
+// block touches (<= ST_ROWS + 2 when the grid is upsampled: all channels, native width) are staged in LDS as [row][x][channel]
+// once, with loads that are contiguous along x; every lane then reads its four taps as 16-byte LDS rows and two lanes share a
+// pixel (8 channels = 16 bytes each), so a wave's store instruction writes 1 KB of consecutive bytes.  stem16_kernel issues 4
+// scattered 4-byte global loads per channel and pixel (32 per thread for the NS inputs).  The expressions are the same (x
+// first, then y); the compiler contracts them into FMAs differently, so the two forms agree to a 16-bit rounding tie, not bit
+// for bit.  (One ROW per workgroup was slower than stem16_kernel: 41 280 workgroups each waiting for its own staging round trip.)
+constexpr int ST_ROWS = 8;
+template <int CP>  // channels padded to a multiple of 4 (LDS row of a source pixel)
+__global__ __launch_bounds__(512) void stem16_rows_kernel(StemArgs a, int nblk) {
+    extern __shared__ __attribute__((aligned(16))) float st_rows[];  // [ST_ROWS + 2][w][CP]
+    const int ph = a.uh + 2, pw = a.uw + 2;
+    const int n = blockIdx.x / nblk, rb = blockIdx.x - n * nblk;
+    const int py0 = rb * ST_ROWS, py1 = min(py0 + ST_ROWS, ph);           // padded rows of this block
+    const int ya = max(py0 - 1, 0), yb = min(py1 - 2, a.uh - 1);          // image rows among them (ya > yb: border only)
+    const float ys = (float)a.h / (float)a.uh, xs = (float)a.w / (float)a.uw;
+    int sbase = 0;
+    if (ya <= yb) {
+        int s0 = ya, s1 = yb, t0, t1;
+        float l;
+        if (a.resample) {
+            bilinear_coord(ya, ys, a.h, s0, t0, l, a.nearest != 0);
+            bilinear_coord(yb, ys, a.h, t1, s1, l, a.nearest != 0);
+        }
+        sbase = s0;
+        const int nsrc_rows = s1 - s0 + 1;  // <= ST_ROWS + 2 (host: h <= uh)
+        const int nrow = a.src_rows > 0 ? n % a.src_rows : n;
+        const size_t plane = (size_t)a.h * a.w;
+        const int per_row = a.cin * a.w;
+        for (int j = threadIdx.x; j < per_row; j += 512) {  // a thread keeps its (channel, x) and walks the rows: no divisions inside
+            const int k = j / a.w, x = j - k * a.w;
+            int si = 0, cl = k;
+            while (cl >= a.ch[si]) cl -= a.ch[si++];
+            const float* sp = a.src[si] + ((size_t)nrow * a.ch[si] + cl) * plane + (size_t)s0 * a.w + x;
+            float* dp = st_rows + (size_t)x * CP + k;
+            for (int r = 0; r < nsrc_rows; ++r) dp[(size_t)r * a.w * CP] = sp[(size_t)r * a.w];
+        }
+    }
+    // per-column (x0, x1, lx) and per-row (y0, y1, ly) stencils, once per workgroup: the item loop below is instruction-bound
+    // (the two source-coordinate evaluations and an integer division per 16 bytes were half of it)
+    int4* xtab = (int4*)(st_rows + (size_t)(ST_ROWS + 2) * a.w * CP);   // [pw]: x0 * CP, x1 * CP, lx; .w = valid
+    int4* ytab = xtab + pw;                                             // [ST_ROWS]: row offsets into st_rows, ly; .w = valid
+    for (int px = threadIdx.x; px < pw + ST_ROWS; px += 512) {
+        if (px < pw) {
+            const int x = px - 1;
+            int x0 = x, x1 = x;
+            float lx = 0.0f;
+            const bool ok = (unsigned)x < (unsigned)a.uw;
+            if (ok && a.resample) bilinear_coord(x, xs, a.w, x0, x1, lx, a.nearest != 0);
+            xtab[px] = make_int4(ok ? x0 * CP : 0, ok ? x1 * CP : 0, __float_as_int(lx), ok);
+        } else {
+            const int r = px - pw, y = py0 + r - 1;
+            int y0 = y, y1 = y;
+            float ly = 0.0f;
+            const bool ok = (unsigned)y < (unsigned)a.uh && py0 + r < py1;
+            if (ok && a.resample) bilinear_coord(y, ys, a.h, y0, y1, ly, a.nearest != 0);
+            ytab[r] = make_int4(ok ? (y0 - sbase) * a.w * CP : 0, ok ? (y1 - sbase) * a.w * CP : 0, __float_as_int(ly), ok);
+        }
+    }
+    __syncthreads();
+    uint4* oblk = (uint4*)(a.out + (((size_t)n * ph + py0) * pw) * 16);
+    const int total = (py1 - py0) * 2 * pw;
+    int r = 0, j = threadIdx.x;  // item i = r * 2 pw + j, advanced without a division (512 <= 2 pw is checked by the launcher)
+    for (int i = threadIdx.x; i < total; i += 512) {
+        const int px = j >> 1, half = j & 1;
+        const int4 xt = xtab[px], yt = ytab[r];
+        uint32_t w[4] = {0, 0, 0, 0};
+        if (xt.w && yt.w) {
+            const int x0 = xt.x, x1 = xt.y;
+            const float lx = __int_as_float(xt.z), ly = __int_as_float(yt.z);
+            const float* r0 = st_rows + yt.x;
+            const float* r1 = st_rows + yt.y;
+            float v[8];
+#pragma unroll
+            for (int q2 = 0; q2 < 2; ++q2) {
+                const int q = 2 * half + q2;  // 4-channel group of the concatenation
+                float t00[4] = {0, 0, 0, 0}, t01[4] = {0, 0, 0, 0}, t10[4] = {0, 0, 0, 0}, t11[4] = {0, 0, 0, 0};
+                if (4 * q < CP) {
+                    const float4 p00 = *(const float4*)(r0 + x0 + 4 * q), p01 = *(const float4*)(r0 + x1 + 4 * q);
+                    const float4 p10 = *(const float4*)(r1 + x0 + 4 * q), p11 = *(const float4*)(r1 + x1 + 4 * q);
+                    t00[0] = p00.x; t00[1] = p00.y; t00[2] = p00.z; t00[3] = p00.w;
+                    t01[0] = p01.x; t01[1] = p01.y; t01[2] = p01.z; t01[3] = p01.w;
+                    t10[0] = p10.x; t10[1] = p10.y; t10[2] = p10.z; t10[3] = p10.w;
+                    t11[0] = p11.x; t11[1] = p11.y; t11[2] = p11.z; t11[3] = p11.w;
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int k = 4 * q + e;
+                    const float top = t00[e] * (1.0f - lx) + t01[e] * lx;
+                    const float bot = t10[e] * (1.0f - lx) + t11[e] * lx;
+                    float val = top * (1.0f - ly) + bot * ly;
+                    if (k >= a.cin) val = k == a.cin ? 1.0f : 0.0f;  // slot cin carries init_conv's bias through the composed enc0 weights
+                    v[4 * q2 + e] = val;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) w[k] = pack_el16x2(v[2 * k], v[2 * k + 1]);
+        }
+        oblk[i] = make_uint4(w[0], w[1], w[2], w[3]);
+        j += 512;
+        if (j >= 2 * pw) { j -= 2 * pw; ++r; }
+    }
+}
+
 hipError_t launch_stem16(const StemArgs& a, hipStream_t s) {
+    const int cp = (a.cin + 3) / 4 * 4;  // cin <= 15 (the fused stem's bias channel is slot cin)
+    const size_t lds = (size_t)(ST_ROWS + 2) * a.w * cp * sizeof(float) + (size_t)(a.uw + 2 + ST_ROWS) * 16;  // rows + stencil tables
+    const char* env = getenv("DYF_STEM16_ROWS");  // read per launch: the parity test flips it
+    if (!(env && atoi(env) == 0) && lds <= 48 * 1024 && cp <= 16 && a.h <= a.uh && 2 * (a.uw + 2) >= 512) {
+        const int nblk = (a.uh + 2 + ST_ROWS - 1) / ST_ROWS;
+        const dim3 grid((unsigned)(a.n * nblk)), block(512);
+        if (cp == 4) hipLaunchKernelGGL(stem16_rows_kernel<4>, grid, block, lds, s, a, nblk);
+        else if (cp == 8) hipLaunchKernelGGL(stem16_rows_kernel<8>, grid, block, lds, s, a, nblk);
+        else if (cp == 12) hipLaunchKernelGGL(stem16_rows_kernel<12>, grid, block, lds, s, a, nblk);
+        else hipLaunchKernelGGL(stem16_rows_kernel<16>, grid, block, lds, s, a, nblk);
+        return hipGetLastError();
+    }
     const long long total = (long long)a.n * (a.uh + 2) * (a.uw + 2);
     hipLaunchKernelGGL(stem16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
     return hipGetLastError();

@@ -11,7 +11,7 @@ import torch
 
 from oracle import init as oinit
 from oracle import nets
-from tests.gpu_common import DEV, mirror_from_params, nhwc_masks
+from tests.gpu_common import DEV, mirror_from_params, nhwc_masks, seeded_pair
 from tests.helpers import jload, load_npz, rel_rms, split_state
 
 pytestmark = pytest.mark.gpu
@@ -250,3 +250,29 @@ def test_persistent_enc0_kernel_matches_the_implicit_gemm_form(tmp_path):
         print(f"{k}: persistent vs implicit-GEMM enc0 rel-rms {err:.2e}, {frac:.2e} of the elements differ")
         assert err <= (2e-3 if k.startswith("enc0") else 1e-2), k
     assert float((outs[0]["enc0_1"] == 0).float().mean()) > 0.2  # dropout was on (p = 0.25 after ReLU)
+
+
+@pytest.mark.parametrize("mode", ["bilinear", "nearest"])
+def test_row_block_stem_matches_the_per_pixel_form(mode, monkeypatch):
+    """The fused stem's resample kernel (221 x 42 -> 256 x 256, zero-bordered 16-channel tensor): the row-block form
+    (stem16_rows_kernel: the block's source rows in LDS, 16-byte tap reads, two lanes per pixel) evaluates the same expressions in
+    the same order as the per-pixel form (DYF_STEM16_ROWS=0); FMA contraction differs, so the first block's output agrees to a
+    16-bit rounding tie on a few elements (nearest: no arithmetic, bit for bit)."""
+    PF, PI = seeded_pair(64, 3, 2, seeds=(41, 42))
+    mk = dict(dim=64, with_time_emb=True, upsample_dims=[256, 256], outer_sample_mode=mode)
+    g = torch.Generator().manual_seed(9)
+    x, c, t = torch.randn(3, 6, 221, 42, generator=g), torch.rand(3, 2, 221, 42, generator=g), torch.tensor([1.0, 4.0, 7.0])
+    net = mirror_from_params(PI, mk, 6, 2, 3)
+    outs = []
+    for rows in ("1", "0"):
+        monkeypatch.setenv("DYF_STEM16_ROWS", rows)
+        y = net(x.to(DEV), time=t.to(DEV), condition=c.to(DEV)).cpu()
+        outs.append((net._engine.read_block_output(net._engine_slot, 0, 3).cpu(), y))
+    (e_new, y_new), (e_old, y_old) = outs
+    assert torch.isfinite(y_new).all() and float(e_new.std()) > 0
+    frac = float((e_new != e_old).float().mean())
+    print(f"stem forms ({mode}): {frac:.2e} of the first block's outputs differ, rel-rms {rel_rms(e_new, e_old):.2e}; network output rel-rms {rel_rms(y_new, y_old):.2e}")
+    if mode == "nearest":
+        assert torch.equal(e_new, e_old) and torch.equal(y_new, y_old)
+    else:
+        assert frac <= 1e-3 and rel_rms(e_new, e_old) <= 1e-3 and rel_rms(y_new, y_old) <= 1e-2  # a flipped 16-bit value is a 4e-3 perturbation
