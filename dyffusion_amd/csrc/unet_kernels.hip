@@ -957,6 +957,7 @@ __global__ __launch_bounds__(256, 2) void linattn_fused_ctx_kernel(const el16_t*
         const uint4* src = (const uint4*)(xs + (size_t)p * C);
 #pragma unroll
         for (int s = 0; s < KS; ++s) xf[s] = src[2 * s];
+        __builtin_amdgcn_sched_barrier(0);  // issue here, a group ahead (the scheduler would sink the loads to their uses)
     };
     int g = blk * LF_GROUPS + wave;
     const int gend = min((blk + 1) * LF_GROUPS, ngroups);
@@ -1011,7 +1012,9 @@ __global__ __launch_bounds__(256, 2) void linattn_fused_ctx_kernel(const el16_t*
     };
     constexpr bool PREFETCH = KS <= 4;  // dim 128: a second fragment set spills; the second wave of the SIMD covers the loads
     for (; g < gend; g += 4) {
-        if (PREFETCH && g + 4 < gend) load(g + 4, xnx);
+        // unconditional (past the end: re-read this group): a conditional prefetch is a branch join at which the compiler's
+        // s_waitcnt model takes the NEWEST loads for the ones needed, and every MFMA of the group waits for the prefetch
+        if (PREFETCH) load(g + 4 < gend ? g + 4 : g, xnx);
         if ((g + 1) * 32 <= hw) group(g, std::true_type{});  // wave-uniform
         else group(g, std::false_type{});
         if (PREFETCH) {
@@ -1086,13 +1089,14 @@ __global__ __launch_bounds__(256, 2) void linattn_fused_out_kernel(const el16_t*
         const uint4* src = (const uint4*)(xs + (size_t)p * C);
 #pragma unroll
         for (int s = 0; s < KS; ++s) xf[s] = src[2 * s];
+        __builtin_amdgcn_sched_barrier(0);
     };
     int g = blk * LF_GROUPS + wave;
     const int gend = min((blk + 1) * LF_GROUPS, ngroups);
     uint4 xc[KS], xnx[KS];
     if (g < gend) load(g, xc);
     for (; g < gend; g += 4) {
-        if (g + 4 < gend) load(g + 4, xnx);
+        load(g + 4 < gend ? g + 4 : g, xnx);  // unconditional: see linattn_fused_ctx_kernel
         const int p = g * 32 + l31;
         const bool valid = p < hw;
         const size_t poff = (size_t)(valid ? p : hw - 1) * C;
@@ -1176,7 +1180,10 @@ __global__ __launch_bounds__(256, 2) void linattn_fused_out_kernel(const el16_t*
                 o.y = pack_el16x2(v[2] + b0.z + el16_lo(rr.y), v[3] + b0.w + el16_hi(rr.y));
                 o.z = pack_el16x2(v[4] + b1.x + el16_lo(rr.z), v[5] + b1.y + el16_hi(rr.z));
                 o.w = pack_el16x2(v[6] + b1.z + el16_lo(rr.w), v[7] + b1.w + el16_hi(rr.w));
-                if (valid) *(uint4*)(ys + (size_t)p * C + og * 32 + g2 * 16) = o;
+                // lanes past the end computed the sample's LAST pixel (clamped loads) and store it again, value for value: no
+                // exec-masked branch around the store, so the s_waitcnt counts stay exact across the loop (a join would make the
+                // next group's fragments wait for vmcnt(0), i.e. for these stores to be acknowledged)
+                *(uint4*)(ys + poff + og * 32 + g2 * 16) = o;
             }
 #pragma unroll
         for (int s = 0; s < KS; ++s) xc[s] = xnx[s];
