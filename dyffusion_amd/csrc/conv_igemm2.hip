@@ -225,32 +225,56 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(ConvArgs a, int M, 
 
     // ---- epilogue straight from the accumulators (same scheme as conv_igemm_kernel): lane (l31, hi) of accumulator
     // (mt, nt) holds pixel l31 of sub-tile mt and channels nt*32 + 8*g + 4*hi + {0..3}
-    auto epilogue = [&](auto act_c, auto mode_c) {
+    // Order of memory operations: the coefficient loads of step s + 1 are issued BEFORE the store of step s, and full tiles run a
+    // branch-free copy (no exec-masked `if (valid)` around the stores).  A global load issued after a store has to wait for
+    // vmcnt(0), i.e. for the store's acknowledgement (gfx9 counts stores in vmcnt; the compiler cannot hoist a load over a store that
+    // may alias), and a branch join makes the compiler's s_waitcnt model fall back to vmcnt(0) as well: the 16 steps of a wave's
+    // epilogue used to expose 16 store round trips.
+    // FAST: 16-bit output only, no residual (every hot launch): those pointer tests are wave-uniform branches, and joins too.
+    auto epilogue = [&](auto act_c, auto mode_c, auto full_c, auto fast_c) {
         constexpr int ACT = decltype(act_c)::value, MODE = decltype(mode_c)::value;
+        constexpr bool FULL = decltype(full_c)::value, FAST = decltype(fast_c)::value;
+        uint32_t ob_[MT], row0_[MT], cb_[MT];
+        RngKey key_[MT];
+        bool valid_[MT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const int row = wm * (32 * MT) + mt * 32 + l31;
-            const bool valid = tm * BM + row < M;
+            valid_[mt] = FULL || tm * BM + row < M;
             int m, n_img;
             if (tile2d) {
                 n_img = t_img;
                 m = (n_img * a.ho + t_y0 + (row >> 4)) * a.wo + t_x0 + (row & 15);
             } else {
-                m = valid ? tm * BM + row : 0;
+                m = valid_[mt] ? tm * BM + row : 0;
                 n_img = m / plane;
             }
-            const uint32_t ob = (uint32_t)m * (uint32_t)a.cout + (uint32_t)(tn * BN + wn * 64);
-            const RngKey key = drop_row_key(a.drop, n_img);  // dropout streams are per batch row
-            const uint32_t row0 = (uint32_t)n_img * (uint32_t)(a.ho * a.wo * a.cout);
-            const uint32_t cb = (uint32_t)((a.coef_div > 1 ? n_img / a.coef_div : n_img) * a.coef_stride + tn * BN + wn * 64 + 4 * hi);
+            ob_[mt] = (uint32_t)m * (uint32_t)a.cout + (uint32_t)(tn * BN + wn * 64);
+            key_[mt] = drop_row_key(a.drop, n_img);  // dropout streams are per batch row
+            row0_[mt] = (uint32_t)n_img * (uint32_t)(a.ho * a.wo * a.cout);
+            cb_[mt] = (uint32_t)((a.coef_div > 1 ? n_img / a.coef_div : n_img) * a.coef_stride + tn * BN + wn * 64 + 4 * hi);
+        }
+        const float ps = drop_prescale<ACT, MODE>(a.drop);  // dropout scale folded into the affine
+        auto load_coef = [&](int step, float4 (&c)[4]) {
+            const int mt = step >> 2, cg0 = ((step >> 1) & 1) * 32 + 16 * (step & 1);
+            c[0] = *(const float4*)(a.coef_a + cb_[mt] + cg0);
+            c[1] = *(const float4*)(a.coef_a + cb_[mt] + cg0 + 8);
+            c[2] = *(const float4*)(a.coef_c + cb_[mt] + cg0);
+            c[3] = *(const float4*)(a.coef_c + cb_[mt] + cg0 + 8);
+        };
+        float4 cf[2][4];
+        load_coef(0, cf[0]);
 #pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-                for (int g2 = 0; g2 < 2; ++g2) {
+        for (int step = 0; step < 4 * MT; ++step) {
+            const int mt = step >> 2, nt = (step >> 1) & 1, g2 = step & 1;
+            if (step + 1 < 4 * MT) load_coef(step + 1, cf[(step + 1) & 1]);
+            const float4 ca0 = cf[step & 1][0], ca1 = cf[step & 1][1], cc0 = cf[step & 1][2], cc1 = cf[step & 1][3];
+            const bool valid = valid_[mt];
+            const uint32_t ob = ob_[mt], row0 = row0_[mt];
+            const RngKey key = key_[mt];
+            {
+                {
                     const int cg0 = nt * 32 + 16 * g2;  // + 4*hi: own channels of group 2*g2; + 8: group 2*g2+1
-                    const float4 ca0 = *(const float4*)(a.coef_a + cb + cg0), ca1 = *(const float4*)(a.coef_a + cb + cg0 + 8);
-                    const float4 cc0 = *(const float4*)(a.coef_c + cb + cg0), cc1 = *(const float4*)(a.coef_c + cb + cg0 + 8);
-                    const float ps = drop_prescale<ACT, MODE>(a.drop);  // dropout scale folded into the affine
                     const float ca[8] = {ca0.x * ps, ca0.y * ps, ca0.z * ps, ca0.w * ps, ca1.x * ps, ca1.y * ps, ca1.z * ps, ca1.w * ps};
                     const float cc[8] = {cc0.x * ps, cc0.y * ps, cc0.z * ps, cc0.w * ps, cc1.x * ps, cc1.y * ps, cc1.z * ps, cc1.w * ps};
                     const uint32_t e0 = ob + cg0 + 4 * hi;
@@ -259,7 +283,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(ConvArgs a, int M, 
                     for (int t = 0; t < 8; ++t) v[t] = fmaf(acc[mt][nt][8 * g2 + t], ca[t], cc[t]);
                     act_drop_fixed<4, ACT, MODE, true>(v, e0, row0, a.drop, key);
                     act_drop_fixed<4, ACT, MODE, true>(v + 4, e0 + 8, row0, a.drop, key);
-                    if (a.residual) {
+                    if (!FAST && a.residual) {
                         const uint2 r0 = valid ? *(const uint2*)(a.residual + (size_t)e0) : make_uint2(0, 0);
                         const uint2 r1 = valid ? *(const uint2*)(a.residual + (size_t)e0 + 8) : make_uint2(0, 0);
                         const uint32_t rw[4] = {r0.x, r0.y, r1.x, r1.y};
@@ -267,26 +291,34 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(ConvArgs a, int M, 
                         for (int t = 0; t < 8; ++t)
                             v[t] += (t & 1) ? el16_hi(rw[t >> 1]) : el16_lo(rw[t >> 1]);
                     }
-                    if (a.out_f32 && valid) {
+                    if (!FAST && a.out_f32 && valid) {
                         *(float4*)(a.out_f32 + (size_t)e0) = make_float4(v[0], v[1], v[2], v[3]);
                         *(float4*)(a.out_f32 + (size_t)e0 + 8) = make_float4(v[4], v[5], v[6], v[7]);
                     }
-                    if (a.out_el16) {
+                    if (FAST || a.out_el16) {
                         uint32_t p0 = pack_el16x2(v[0], v[1]), p1 = pack_el16x2(v[2], v[3]);
                         uint32_t q0 = pack_el16x2(v[4], v[5]), q1 = pack_el16x2(v[6], v[7]);
                         const auto s0 = __builtin_amdgcn_permlane32_swap(p0, q0, false, false);
                         const auto s1 = __builtin_amdgcn_permlane32_swap(p1, q1, false, false);
                         uint4 o;
                         o.x = s0[0]; o.y = s1[0]; o.z = s0[1]; o.w = s1[1];
-                        if (valid) *(uint4*)(a.out_el16 + (size_t)(ob + cg0 + 8 * hi)) = o;
+                        if (FULL || valid) *(uint4*)(a.out_el16 + (size_t)(ob + cg0 + 8 * hi)) = o;
                     }
                 }
+            }
         }
     };
+    const bool tile_full = tile2d || (tm + 1) * BM <= M;  // wave-uniform: every row of the tile is an output pixel
+    const bool fast = a.out_el16 != nullptr && a.out_f32 == nullptr && a.residual == nullptr;
+    auto by_full = [&](auto act_c, auto mode_c) {
+        if (tile_full && fast) epilogue(act_c, mode_c, std::true_type{}, std::true_type{});
+        else if (tile_full) epilogue(act_c, mode_c, std::true_type{}, std::false_type{});
+        else epilogue(act_c, mode_c, std::false_type{}, std::false_type{});
+    };
     auto by_mode = [&](auto act_c) {
-        if (a.drop.mode == 0) epilogue(act_c, std::integral_constant<int, 0>{});
-        else if (a.drop.mode == 1) epilogue(act_c, std::integral_constant<int, 1>{});
-        else epilogue(act_c, std::integral_constant<int, 2>{});
+        if (a.drop.mode == 0) by_full(act_c, std::integral_constant<int, 0>{});
+        else if (a.drop.mode == 1) by_full(act_c, std::integral_constant<int, 1>{});
+        else by_full(act_c, std::integral_constant<int, 2>{});
     };
     if (a.act == ACT_RELU) by_mode(std::integral_constant<int, ACT_RELU>{});
     else if (a.act == ACT_LEAKY) by_mode(std::integral_constant<int, ACT_LEAKY>{});
