@@ -180,9 +180,16 @@ __global__ __launch_bounds__(256, 2) void conv_up_halo_kernel(ConvArgs a, int ti
         if (H::PLAIN && (yy != y || xx != x)) off = 0xFFFFFFFFu;  // plain convs: zero padding = out-of-range DMA offset
         return off;
     };
+    // SP = 5 has no LDS room for the table; its two workgroups per CU are set by LDS, not by registers (124 of 256 used), so the
+    // offsets of a second chunk (two-source convs, K = 1 152) come from registers instead of being recomputed (~30 VALU each,
+    // 20 per wave and chunk: PMC counted 2 560 vector instructions per wave against 384 MFMAs)
+    unsigned h_reg[H::HAS_TAB ? 1 : HALO_PER_WAVE];
     if (H::HAS_TAB) {
 #pragma unroll
         for (int j = 0; j < HALO_PER_WAVE; ++j) h_tab[j * 256] = halo_off(j);
+    } else {
+#pragma unroll
+        for (int j = 0; j < HALO_PER_WAVE; ++j) h_reg[j] = halo_off(j);
     }
 
     auto issue_halo = [&](int chunk) {
@@ -195,7 +202,7 @@ __global__ __launch_bounds__(256, 2) void conv_up_halo_kernel(ConvArgs a, int ti
         for (int j = 0; j < HALO_PER_WAVE; ++j) {
             const int i = j * NWAVES + wave;
             if (i < HALO_INSTR) {
-                unsigned vo = H::HAS_TAB ? h_tab[j * 256] : halo_off(j);
+                unsigned vo = H::HAS_TAB ? h_tab[j * 256] : h_reg[H::HAS_TAB ? 0 : j];
                 if (!H::PLAIN || vo != 0xFFFFFFFFu) vo += coff;
                 if (second)
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a1, LDS_PTR(dst + i * 1024), 16, vo, 0, 0, 0);
