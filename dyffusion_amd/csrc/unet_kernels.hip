@@ -412,6 +412,74 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnActArgs a, const float2
                                        pack_el16x2(y[6], y[7]));
 }
 
+// Walk form of gn_apply_kernel (channel chunks per pixel a power of two <= 256): a thread keeps ONE 16-byte channel chunk and
+// applies it to GP pixels of its sample: the per-chunk coefficient setup (GroupNorm affine x FiLM: 6 vector loads, ~50 VALU) is
+// paid once instead of per pixel, and the GP tensor loads (and residual loads) are in flight together.
+#ifndef GN_GP
+#define GN_GP 4
+#endif
+constexpr int GP = GN_GP;
+__global__ __launch_bounds__(256) void gn_apply_walk_kernel(GnActArgs a, const float2* mr) {
+    const int chunks = a.c >> 3, cpg = a.c / a.groups;
+    const int n = blockIdx.y;
+    const int q = threadIdx.x & (chunks - 1), row = threadIdx.x / chunks, rows = 256 / chunks;
+    const int g = (q * 8) / cpg;
+    const float2 ms = mr[(size_t)n * a.groups + g];
+    const float mean = ms.x, rstd = ms.y;
+    const float4 g0 = *(const float4*)(a.gamma + q * 8), g1 = *(const float4*)(a.gamma + q * 8 + 4);
+    const float4 b0 = *(const float4*)(a.beta + q * 8), b1 = *(const float4*)(a.beta + q * 8 + 4);
+    float A[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+    float C[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        A[t] *= rstd;
+        C[t] = fmaf(-mean, A[t], C[t]);
+    }
+    if (a.film_a) {
+        const size_t fi = (size_t)n * a.film_stride + q * 8;
+        const float4 fa0 = *(const float4*)(a.film_a + fi), fa1 = *(const float4*)(a.film_a + fi + 4);
+        const float4 fc0 = *(const float4*)(a.film_c + fi), fc1 = *(const float4*)(a.film_c + fi + 4);
+        const float fa[8] = {fa0.x, fa0.y, fa0.z, fa0.w, fa1.x, fa1.y, fa1.z, fa1.w};
+        const float fc[8] = {fc0.x, fc0.y, fc0.z, fc0.w, fc1.x, fc1.y, fc1.z, fc1.w};
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            A[t] *= fa[t];
+            C[t] = fmaf(C[t], fa[t], fc[t]);
+        }
+    }
+    const RngKey key = drop_row_key(a.drop, n);
+    const uint32_t row0 = (uint32_t)((size_t)n * a.hw * a.c);
+    const int p0 = blockIdx.x * rows * GP + row;
+    uint4 v[GP], r[GP];
+#pragma unroll
+    for (int i = 0; i < GP; ++i) {
+        const int p = min(p0 + i * rows, a.hw - 1);  // past the end: re-read the last pixel (not stored)
+        const size_t e0 = ((size_t)n * a.hw + p) * a.c + q * 8;
+        v[i] = *(const uint4*)(a.x + e0);
+        if (a.residual) r[i] = *(const uint4*)(a.residual + e0);
+    }
+#pragma unroll
+    for (int i = 0; i < GP; ++i) {
+        const int p = p0 + i * rows;
+        const size_t e0 = ((size_t)n * a.hw + min(p, a.hw - 1)) * a.c + q * 8;
+        const uint32_t w[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+        float y[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const float xv = (t & 1) ? el16_hi(w[t >> 1]) : el16_lo(w[t >> 1]);
+            y[t] = fmaf(xv, A[t], C[t]);
+        }
+        act_drop<8>(y, (uint32_t)e0, row0, a.act, a.drop, key);
+        if (a.residual) {
+            const uint32_t rw[4] = {r[i].x, r[i].y, r[i].z, r[i].w};
+#pragma unroll
+            for (int t = 0; t < 8; ++t) y[t] += (t & 1) ? el16_hi(rw[t >> 1]) : el16_lo(rw[t >> 1]);
+        }
+        if (p < a.hw)
+            *(uint4*)(a.out + e0) = make_uint4(pack_el16x2(y[0], y[1]), pack_el16x2(y[2], y[3]), pack_el16x2(y[4], y[5]), pack_el16x2(y[6], y[7]));
+    }
+}
+
 hipError_t launch_gn_act(const GnActArgs& a, hipStream_t s) {
     const int cpg = a.c / a.groups;
     if (a.stats && (a.c % 8 == 0) && (cpg % 8 == 0) && a.groups <= 64) {
@@ -425,7 +493,14 @@ hipError_t launch_gn_act(const GnActArgs& a, hipStream_t s) {
         const int cnt = a.n * a.groups;
         hipLaunchKernelGGL(gn_finalize_kernel, dim3((cnt + 255) / 256), dim3(256), 0, s, (const double*)a.stats, cnt, (int)bx,
                            1.0 / ((double)a.hw * cpg), mr);
-        hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a, (const float2*)mr);
+        const int chunks = a.c >> 3;
+        static const bool walk = !(getenv("DYF_GN_WALK") && atoi(getenv("DYF_GN_WALK")) == 0);
+        if (walk && (chunks & (chunks - 1)) == 0 && chunks <= 256 && a.n <= 65535) {
+            const int rows = 256 / chunks;
+            hipLaunchKernelGGL(gn_apply_walk_kernel, dim3((unsigned)((a.hw + rows * GP - 1) / (rows * GP)), a.n), dim3(256), 0, s, a, (const float2*)mr);
+        } else {
+            hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a, (const float2*)mr);
+        }
         return hipGetLastError();
     }
     hipLaunchKernelGGL(gn_act_kernel, dim3(a.n * a.groups), dim3(256), 0, s, a);
