@@ -394,12 +394,84 @@ __global__ __launch_bounds__(256) void up2x_kernel(Up2xArgs a, long long total) 
     }
 }
 
+// Quad form: a thread produces the 2 x 2 output pixels of one input pixel (one 16-byte channel chunk) from its 3 x 3 input
+// neighbourhood: 9 loads and one index decomposition per FOUR outputs (up2x_kernel<8>: 16 loads and three 64-bit divisions per
+// four), same stencils (bilinear_coord) and the same expressions per output.
+__global__ __launch_bounds__(256) void up2x_quad_kernel(Up2xArgs a, long long total) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int c = a.c0 + a.c1, groups = c >> 3;
+    const int g = (int)(idx % groups);
+    const int pix = (int)(idx / groups);           // input pixel (n, i, j)
+    const int plane = a.h * a.w;
+    const int n = pix / plane, rem = pix - n * plane;
+    const int i = rem / a.w, j = rem - i * a.w;
+    int ch = g * 8;
+    const el16_t* src = a.src0;
+    int cs = a.c0;
+    if (ch >= a.c0) {
+        src = a.src1;
+        cs = a.c1;
+        ch -= a.c0;
+    }
+    // rows / columns the four outputs read: output 2i reads (i-1, i), output 2i+1 reads (i, i+1), clamped by bilinear_coord
+    int ya[2], yb[2], xa[2], xb[2];
+    float ly[2], lx[2];
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+        bilinear_coord(2 * i + d, 0.5f, a.h, ya[d], yb[d], ly[d]);
+        bilinear_coord(2 * j + d, 0.5f, a.w, xa[d], xb[d], lx[d]);
+    }
+    const int ys[3] = {ya[0], i, yb[1]}, xs[3] = {xa[0], j, xb[1]};  // (ya[1] == yb[0] == i except at a clamped border, where the weight of the other tap is 0 or the indices coincide)
+    uint4 t[3][3];
+    const el16_t* base = src + (size_t)n * plane * cs + ch;
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) t[r][q] = *(const uint4*)(base + ((size_t)ys[r] * a.w + xs[q]) * cs);
+    const int ow = 2 * a.w;
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+            // taps of output (2i+dy, 2j+dx): rows ys[dy], ys[dy+1], columns xs[dx], xs[dx+1].  At a clamped border (output 0 of
+            // input 0) bilinear_coord's second tap is index 1 with weight exactly 0; slot 1 holds index 0 there: finite * 0 either way
+            const uint4 q00 = t[dy][dx], q01 = t[dy][dx + 1], q10 = t[dy + 1][dx], q11 = t[dy + 1][dx + 1];
+            const uint32_t* w00 = (const uint32_t*)&q00;
+            const uint32_t* w01 = (const uint32_t*)&q01;
+            const uint32_t* w10 = (const uint32_t*)&q10;
+            const uint32_t* w11 = (const uint32_t*)&q11;
+            const float fx = lx[dx], fy = ly[dy];
+            uint32_t o[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float lo, hi;
+                {
+                    const float a00 = el16_lo(w00[k]), a01 = el16_lo(w01[k]), a10 = el16_lo(w10[k]), a11 = el16_lo(w11[k]);
+                    const float top = a00 * (1.0f - fx) + a01 * fx, bot = a10 * (1.0f - fx) + a11 * fx;
+                    lo = top * (1.0f - fy) + bot * fy;
+                }
+                {
+                    const float a00 = el16_hi(w00[k]), a01 = el16_hi(w01[k]), a10 = el16_hi(w10[k]), a11 = el16_hi(w11[k]);
+                    const float top = a00 * (1.0f - fx) + a01 * fx, bot = a10 * (1.0f - fx) + a11 * fx;
+                    hi = top * (1.0f - fy) + bot * fy;
+                }
+                o[k] = pack_el16x2(lo, hi);
+            }
+            *(uint4*)(a.out + (((size_t)n * 2 * a.h + 2 * i + dy) * ow + 2 * j + dx) * c + g * 8) = make_uint4(o[0], o[1], o[2], o[3]);
+        }
+}
+
 hipError_t launch_up2x(const Up2xArgs& a, hipStream_t s) {
     const int c = a.c0 + a.c1;
     const bool vec = (a.c0 % 8 == 0) && (a.c1 % 8 == 0);
     const long long total = (long long)a.n * 4 * a.h * a.w * (vec ? c / 8 : c);
     const unsigned blocks = (unsigned)((total + 255) / 256);
-    if (vec)
+    const char* env = getenv("DYF_UP2X_QUAD");  // read per launch (parity test)
+    if (vec && !(env && atoi(env) == 0) && a.h >= 2 && a.w >= 2) {
+        const long long quads = total / 4;
+        hipLaunchKernelGGL(up2x_quad_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, s, a, quads);
+    } else if (vec)
         hipLaunchKernelGGL(up2x_kernel<8>, dim3(blocks), dim3(256), 0, s, a, total);
     else
         hipLaunchKernelGGL(up2x_kernel<1>, dim3(blocks), dim3(256), 0, s, a, total);

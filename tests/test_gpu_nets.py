@@ -276,3 +276,24 @@ def test_row_block_stem_matches_the_per_pixel_form(mode, monkeypatch):
         assert torch.equal(e_new, e_old) and torch.equal(y_new, y_old)
     else:
         assert frac <= 1e-3 and rel_rms(e_new, e_old) <= 1e-3 and rel_rms(y_new, y_old) <= 1e-2  # a flipped 16-bit value is a 4e-3 perturbation
+
+
+def test_quad_form_of_the_x2_upsample_matches_the_per_pixel_form(monkeypatch):
+    """The materialised x2 bilinear upsample of the small decoder planes (dec0-dec2): up2x_quad_kernel (a thread makes the 2 x 2
+    outputs of one input pixel from its 3 x 3 neighbourhood) against up2x_kernel<8> (DYF_UP2X_QUAD=0): same stencils and
+    expressions; FMA contraction may differ by a 16-bit rounding tie on a few elements."""
+    PF, PI = seeded_pair(64, 3, 2, seeds=(43, 44))
+    mk = dict(dim=64, with_time_emb=True, upsample_dims=[256, 256])
+    g = torch.Generator().manual_seed(10)
+    x, c, t = torch.randn(2, 6, 221, 42, generator=g), torch.rand(2, 2, 221, 42, generator=g), torch.tensor([2.0, 6.0])
+    net = mirror_from_params(PI, mk, 6, 2, 3)
+    outs = []
+    for quad in ("1", "0"):
+        monkeypatch.setenv("DYF_UP2X_QUAD", quad)
+        y = net(x.to(DEV), time=t.to(DEV), condition=c.to(DEV)).cpu()
+        outs.append([net._engine.read_block_output(net._engine_slot, li, 2).cpu() for li in (6, 7, 8)] + [y])
+    for name, a, b in zip(("dec0", "dec1", "dec2", "y"), outs[0], outs[1]):
+        assert torch.isfinite(a).all() and float(a.std()) > 0
+        frac, err = float((a != b).float().mean()), rel_rms(a, b)
+        print(f"{name}: quad vs per-pixel upsample: {frac:.2e} of the elements differ, rel-rms {err:.2e}")
+        assert err <= (1e-3 if name == "dec0" else 1e-2), name
