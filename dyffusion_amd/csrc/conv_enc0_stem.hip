@@ -9,10 +9,15 @@
 //     is ONE 16-byte global load per lane (lane = output pixel, hi = channel half); the 16 loads of a tile are issued a whole tile
 //     ahead of their use, neighbouring taps / rows hit the L1 / L2;
 //   * the weights (cout x 256 x 2 B <= 64 KB) stay in LDS as MFMA A fragments for the lifetime of the workgroup, which is
-//     persistent: 2 workgroups per CU walk contiguous ranges of 32-pixel row segments (a wave keeps its column segment and moves
+//     persistent: one 8-wave workgroup per CU walks a contiguous range of 32-pixel row segments (a wave keeps its column segment and moves
 //     down the rows, so half of its input rows were fetched by its previous tile);
 //   * operands are swapped (D^T = W X^T) so the epilogue runs from the accumulators exactly as in conv_igemm2.hip: lane (pixel, hi)
-//     holds channels 32 nt + 8 g + 4 hi + {0..3}, exchanged pairwise (v_permlane32_swap) into 16-byte channel rows.
+//     holds channels 32 nt + 8 g + 4 hi + {0..3}, exchanged pairwise (v_permlane32_swap) into 16-byte channel rows;
+//   * a tile's output (32 pixels x cout channels) is one contiguous run of memory: the 16-byte rows go through a per-wave LDS
+//     staging tile and leave as whole 1 KB wave stores: 327 -> 260 us at 160 rows against storing the 32-byte pieces of the
+//     128-byte lines straight from the registers, ~100 instructions apart (8 times the store instructions' address work in the
+//     texture path; the WRITE_SIZE counter reads 1.42-1.44x the algorithmic bytes for BOTH forms and 1.00x for conv_igemm2, so
+//     it is not what separated them).
 #include "conv.h"
 
 #include <type_traits>
@@ -20,21 +25,26 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 namespace {
 constexpr int E0_KSTEPS = 16;
+constexpr int E0_WAVES = 8, E0_THREADS = E0_WAVES * 64;  // one workgroup per CU: the weights are fetched once per CU
+constexpr int e0_lds_bytes(int nt) { return E0_KSTEPS * nt * 1024 + E0_WAVES * 2 * nt * 32 * 4 + E0_WAVES * 32 * (nt * 64 + 16); }
 }
 
 template <int NT>  // cout / 32
-__global__ __launch_bounds__(256, 2) void conv_enc0_stem_kernel(ConvArgs a, const el16_t* __restrict__ wfrag, int tiles, int tiles_per_wg) {
+__global__ __launch_bounds__(512) void conv_enc0_stem_kernel(ConvArgs a, const el16_t* __restrict__ wfrag, int tiles, int tiles_per_wg) {
 #if defined(__gfx950__)
     extern __shared__ __attribute__((aligned(16))) unsigned char e0_smem[];
     uint4* wl = (uint4*)e0_smem;  // [16 k-steps][NT][64 lanes]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, hi = lane >> 5;
-    for (int i = tid; i < E0_KSTEPS * NT * 64; i += 256) wl[i] = ((const uint4*)wfrag)[i];
+    for (int i = tid; i < E0_KSTEPS * NT * 64; i += E0_THREADS) wl[i] = ((const uint4*)wfrag)[i];
     __syncthreads();
     // Epilogue coefficients live in a per-wave LDS row, refreshed when the wave's tile moves to another coefficient row (sample):
     // loaded from global memory inside the epilogue they would make every (nt, g2) step wait for vmcnt(0), i.e. for the
     // acknowledgement of the stores of the step before (gfx9 counts stores in vmcnt) -- 8 exposed store round trips per tile.
     float* coefl = (float*)(e0_smem + E0_KSTEPS * NT * 1024) + wave * (2 * NT * 32);  // [a | c][cout]
     int coef_row = -1;
+    // output staging tile of this wave: [32 pixels][cout * 2 B + 16 B pad] (the pad spreads the pixels' rows over the banks)
+    constexpr int OROW = NT * 64 + 16;
+    unsigned char* ostage = e0_smem + E0_KSTEPS * NT * 1024 + E0_WAVES * 2 * NT * 32 * 4 + wave * (32 * OROW);
     const int segs = a.wo >> 5;               // 32-pixel segments per output row
     const int plane = a.ho * a.wo;
     const int t0 = blockIdx.x * tiles_per_wg, t1 = min(t0 + tiles_per_wg, tiles);
@@ -89,8 +99,7 @@ __global__ __launch_bounds__(256, 2) void conv_enc0_stem_kernel(ConvArgs a, cons
         }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            uint4 o2[2];  // the two 32-byte pieces of a pixel's 64-byte block leave back to back: they merge into one 64-B L2 write
-                          // (stored ~100 instructions apart, PMC counted 1.48x the algorithmic write bytes)
+            uint4 o2[2];
 #pragma unroll
             for (int g2 = 0; g2 < 2; ++g2) {
                 const int cg0 = nt * 32 + 16 * g2;
@@ -110,13 +119,21 @@ __global__ __launch_bounds__(256, 2) void conv_enc0_stem_kernel(ConvArgs a, cons
                 const auto s1 = __builtin_amdgcn_permlane32_swap(p1, q1, false, false);
                 o2[g2].x = s0[0]; o2[g2].y = s1[0]; o2[g2].z = s0[1]; o2[g2].w = s1[1];
             }
-            *(uint4*)(a.out_el16 + (size_t)(ob + nt * 32 + 8 * hi)) = o2[0];
-            *(uint4*)(a.out_el16 + (size_t)(ob + nt * 32 + 16 + 8 * hi)) = o2[1];
+            *(uint4*)(ostage + l31 * OROW + (nt * 32 + 8 * hi) * 2) = o2[0];
+            *(uint4*)(ostage + l31 * OROW + (nt * 32 + 16 + 8 * hi) * 2) = o2[1];
+        }
+        // the tile is cout * 64 contiguous bytes of the output: store instruction k writes bytes [1024 k, 1024 k + 1024)
+        el16_t* tbase = a.out_el16 + (size_t)t * 32 * cout;
+#pragma unroll
+        for (int k = 0; k < NT * 2; ++k) {
+            const int off = k * 1024 + lane * 16;                 // byte offset inside the tile
+            const int px = off / (NT * 64), within = off - px * (NT * 64);
+            *(uint4*)((unsigned char*)tbase + off) = *(const uint4*)(ostage + px * OROW + within);
         }
     };
 
     auto run = [&](auto act_c, auto mode_c) {
-        // Every wave owns an even number of tiles (launcher: tiles per workgroup and the tile count are multiples of 8), and both
+        // Every wave owns an even number of tiles (launcher: tiles per workgroup and the tile count are multiples of 16), and both
         // prefetches are unconditional (the one past the wave's last tile re-reads a valid tile): no branch joins between a
         // load and its use, so the compiler's s_waitcnt vmcnt counts stay exact and the loads really fly a tile ahead.  (With
         // `if (more) load(...)` the join made every k-step wait for the NEWEST 16 loads.)
@@ -124,11 +141,11 @@ __global__ __launch_bounds__(256, 2) void conv_enc0_stem_kernel(ConvArgs a, cons
         int t = t0 + wave;
         if (t >= t1) return;
         load(t, xa);
-        for (; t < t1; t += 8) {  // two tiles per turn: the fragment sets swap roles without register moves
-            load(t + 4, xb);
+        for (; t < t1; t += 2 * E0_WAVES) {  // two tiles per turn: the fragment sets swap roles without register moves
+            load(t + E0_WAVES, xb);
             tile(t, xa, act_c, mode_c);
-            load(t + 8 < t1 ? t + 8 : t, xa);
-            tile(t + 4, xb, act_c, mode_c);
+            load(t + 2 * E0_WAVES < t1 ? t + 2 * E0_WAVES : t, xa);
+            tile(t + E0_WAVES, xb, act_c, mode_c);
         }
     };
     auto by_mode = [&](auto act_c) {
@@ -159,27 +176,27 @@ bool conv_enc0_stem_supported(const ConvArgs& a) {
     static const bool on = !(getenv("DYF_ENC0_STEM") && atoi(getenv("DYF_ENC0_STEM")) == 0);
     if (!on || a.pix_pitch0 != 16 || a.c0 != 64 || a.c1 != 0 || a.kh != 4 || a.kw != 1 || a.stride != 2 || a.pad != 0) return false;
     if (a.up2x || a.residual || a.out_f32 || !a.out_el16 || (a.cout != 64 && a.cout != 128)) return false;
-    if (a.wo % 32 != 0 || (a.ho * (a.wo / 32)) % 8 != 0 || a.h != 2 * a.ho + 2 || a.w != 2 * a.wo + 2) return false;
+    if (a.wo % 32 != 0 || (a.ho * (a.wo / 32)) % 16 != 0 || a.h != 2 * a.ho + 2 || a.w != 2 * a.wo + 2) return false;
     const long long nsel = a.n_sel > 0 ? a.n_sel : a.n;
-    if (nsel * a.ho * (a.wo / 32) < 4096) return false;  // persistent form: needs >= 8 tiles for each of 512 workgroups
+    if (nsel * a.ho * (a.wo / 32) < 4096) return false;  // persistent form: needs >= 16 tiles for each of 256 workgroups
     return (size_t)a.n * a.ho * a.wo * a.cout < 0xFFFFFFF0ull;
 }
 
 hipError_t conv_enc0_stem_init() {
-    hipError_t e = hipFuncSetAttribute((const void*)conv_enc0_stem_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, E0_KSTEPS * 4 * 1024 + 4 * 2 * 128 * 4);
-    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv_enc0_stem_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, E0_KSTEPS * 2 * 1024 + 4 * 2 * 64 * 4);
+    hipError_t e = hipFuncSetAttribute((const void*)conv_enc0_stem_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, e0_lds_bytes(4));
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv_enc0_stem_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, e0_lds_bytes(2));
     return e;
 }
 
 hipError_t launch_conv_enc0_stem(const ConvArgs& a, const el16_t* wfrag, hipStream_t stream) {
     const int tiles = a.n * a.ho * (a.wo / 32);
-    int nwg = std::min(512, (tiles + 7) / 8);
+    int nwg = std::min(256, (tiles + 15) / 16);
     int per = (tiles + nwg - 1) / nwg;
-    per = (per + 7) / 8 * 8;  // a wave keeps its column segment (wo = 128: 4 segments) and its fragment-set parity
+    per = (per + 15) / 16 * 16;  // a wave keeps its column segment (wo = 128: 4 segments) and its fragment-set parity
     nwg = (tiles + per - 1) / per;
     if (a.cout == 128)
-        hipLaunchKernelGGL(conv_enc0_stem_kernel<4>, dim3(nwg), dim3(256), E0_KSTEPS * 4 * 1024 + 4 * 2 * 128 * 4, stream, a, wfrag, tiles, per);
+        hipLaunchKernelGGL(conv_enc0_stem_kernel<4>, dim3(nwg), dim3(E0_THREADS), e0_lds_bytes(4), stream, a, wfrag, tiles, per);
     else
-        hipLaunchKernelGGL(conv_enc0_stem_kernel<2>, dim3(nwg), dim3(256), E0_KSTEPS * 2 * 1024 + 4 * 2 * 64 * 4, stream, a, wfrag, tiles, per);
+        hipLaunchKernelGGL(conv_enc0_stem_kernel<2>, dim3(nwg), dim3(E0_THREADS), e0_lds_bytes(2), stream, a, wfrag, tiles, per);
     return hipGetLastError();
 }
