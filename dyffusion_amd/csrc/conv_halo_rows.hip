@@ -41,7 +41,16 @@ struct RowsCfg {
     static constexpr int INSTR = PIX / 8;             // 26 / 54
     static constexpr int PER_WAVE = (INSTR + R_NWAVES - 1) / R_NWAVES;
     static constexpr int HOFF_OFF = NBUF * BYTES;     // per-thread halo source offsets [PER_WAVE][256]
-    static constexpr int LDS_TOTAL = HOFF_OFF + PER_WAVE * 1024;  // 60 416 / 69 632 B: two workgroups per CU
+    static constexpr int TAB_END = HOFF_OFF + PER_WAVE * 1024;    // 60 416 / 69 632 B
+    // output staging (dense forms, -DHALO_NO_STAGE disables): per wave one tile row of [32 pixels][64 channels] 16-bit + 16 B pad
+    // per pixel; the sparse form has no room for it next to its 55 KB halo (two workgroups per CU)
+#ifndef HALO_NO_STAGE
+    static constexpr bool STAGE = SP != 1;
+#else
+    static constexpr bool STAGE = false;
+#endif
+    static constexpr int OROW = 144;
+    static constexpr int LDS_TOTAL = TAB_END + (STAGE ? R_NWAVES * 32 * OROW : 0);  // 78 848 / 69 632 B: two workgroups per CU
     static constexpr int ROW_BYTES = W * 128;
 };
 
@@ -303,10 +312,62 @@ __global__ __launch_bounds__(256, 2) void conv_halo_rows_kernel(ConvArgs a, int 
     const uint32_t st_stride = SP == 1 ? (uint32_t)(2 * a.up_wo_store * a.cout) : t_stride;
     auto epilogue = [&](auto act_c, auto mode_c) {
         constexpr int ACT = decltype(act_c)::value, MODE = decltype(mode_c)::value;
+        const float ps = drop_prescale<ACT, MODE>(a.drop);  // dropout scale folded into the affine
+        if constexpr (H::STAGE) {
+            // Dense forms: a tile row of this wave is 32 pixels x 128 bytes (its 64 channels), one whole 128-byte line per pixel.
+            // Stored from the registers, an instruction writes a 32-byte piece of 32 different lines; through a per-wave LDS
+            // staging row it writes 8 whole lines (lane = (pixel, 16-byte chunk)): a quarter of the line requests, no partial
+            // lines.  (conv_enc0_stem.hip: the same change was worth 20 % of a store-bound kernel.)
+            unsigned char* ost = (unsigned char*)smem + H::TAB_END + wave * (32 * H::OROW);
+            float ca[2][2][8], cc[2][2][8];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int g2 = 0; g2 < 2; ++g2) {
+                    const int cg0 = nt * 32 + 16 * g2;
+                    const float4 ca0 = *(const float4*)(a.coef_a + ci_base + cg0), ca1 = *(const float4*)(a.coef_a + ci_base + cg0 + 8);
+                    const float4 cc0 = *(const float4*)(a.coef_c + ci_base + cg0), cc1 = *(const float4*)(a.coef_c + ci_base + cg0 + 8);
+                    ca[nt][g2][0] = ca0.x * ps; ca[nt][g2][1] = ca0.y * ps; ca[nt][g2][2] = ca0.z * ps; ca[nt][g2][3] = ca0.w * ps;
+                    ca[nt][g2][4] = ca1.x * ps; ca[nt][g2][5] = ca1.y * ps; ca[nt][g2][6] = ca1.z * ps; ca[nt][g2][7] = ca1.w * ps;
+                    cc[nt][g2][0] = cc0.x * ps; cc[nt][g2][1] = cc0.y * ps; cc[nt][g2][2] = cc0.z * ps; cc[nt][g2][3] = cc0.w * ps;
+                    cc[nt][g2][4] = cc1.x * ps; cc[nt][g2][5] = cc1.y * ps; cc[nt][g2][6] = cc1.z * ps; cc[nt][g2][7] = cc1.w * ps;
+                }
+            const uint32_t pstride = (uint32_t)((H::PLAIN ? 1 : 2) * a.cout);     // elements between the row's consecutive pixels
+            const uint32_t row_base = store0 - (uint32_t)l31 * pstride;             // pixel 0 of this wave's tile row 0
+            const int rpx = lane >> 3, rch = lane & 7;                              // read-back role: (pixel 8 k + rpx, 16-byte chunk)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int g2 = 0; g2 < 2; ++g2) {
+                        const int cg0 = nt * 32 + 16 * g2;
+                        const uint32_t e0 = o0 + t * t_stride + cg0 + 4 * hi;
+                        float v[8];
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) v[q] = fmaf(acc[nt][t][8 * g2 + q], ca[nt][g2][q], cc[nt][g2][q]);
+                        act_drop_fixed<4, ACT, MODE, true>(v, e0, row0, a.drop, key);
+                        act_drop_fixed<4, ACT, MODE, true>(v + 4, e0 + 8, row0, a.drop, key);
+                        uint32_t p0 = pack_el16x2(v[0], v[1]), p1 = pack_el16x2(v[2], v[3]);
+                        uint32_t q0 = pack_el16x2(v[4], v[5]), q1 = pack_el16x2(v[6], v[7]);
+                        const auto s0 = __builtin_amdgcn_permlane32_swap(p0, q0, false, false);
+                        const auto s1 = __builtin_amdgcn_permlane32_swap(p1, q1, false, false);
+                        uint4 o;
+                        o.x = s0[0]; o.y = s1[0]; o.z = s0[1]; o.w = s1[1];
+                        *(uint4*)(ost + l31 * H::OROW + (cg0 + 8 * hi) * 2) = o;
+                    }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int px = 8 * k + rpx;
+                    const uint4 o = *(const uint4*)(ost + px * H::OROW + rch * 16);
+                    *(uint4*)(a.out_el16 + (size_t)(row_base + t * st_stride + (uint32_t)px * pstride + rch * 8)) = o;
+                }
+            }
+            return;
+        }
         // 32-channel half outermost, tile rows, then the two 16-channel groups of the half: the two 32-byte pieces of a pixel's
         // 64-byte half block are stored back to back and leave the L2 as whole 64-byte writes (with the channel groups
         // outermost PMC counted 1.65x the algorithmic write bytes)
-        const float ps = drop_prescale<ACT, MODE>(a.drop);  // dropout scale folded into the affine
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
             float ca[2][8], cc[2][8];
