@@ -83,7 +83,17 @@ struct HaloCfg {
     static constexpr int INSTR = PIX / 8;               // wave-level DMA instructions per halo: 23 / 50
     static constexpr int PER_WAVE = (INSTR + NWAVES - 1) / NWAVES;
     static constexpr bool HAS_TAB = SP != 5;            // per-thread halo source offsets parked in LDS
-    static constexpr int LDS_TOTAL = HOFF_OFF + (HAS_TAB ? PER_WAVE * 1024 : 0);  // 53 760 / 65 024 / (SP 5) 79 360 B
+    static constexpr int TAB_END = HOFF_OFF + (HAS_TAB ? PER_WAVE * 1024 : 0);    // 53 760 / 65 024 / (SP 5) 79 360 B
+    // output staging of the stride-2 forms (-DHALO_NO_STAGE disables): per wave one pixel tile of [32 pixels][64 channels] 16-bit +
+    // 16 B pad per pixel -> whole 128-byte lines per store instruction (see conv_halo_rows.hip); the other forms run on the rows
+    // kernels (SP 0-2) or have no LDS left (SP 5)
+#ifndef HALO_NO_STAGE
+    static constexpr bool STAGE = SP == 3 || SP == 4;
+#else
+    static constexpr bool STAGE = false;
+#endif
+    static constexpr int OROW = 144;
+    static constexpr int LDS_TOTAL = TAB_END + (STAGE ? NWAVES * 32 * OROW : 0);  // SP 3 / 4: 72 192 B, two workgroups per CU
 };
 
 }  // namespace
@@ -481,10 +491,60 @@ __global__ __launch_bounds__(256, 2) void conv_up_halo_kernel(ConvArgs a, int ti
     // (activation, dropout mode) are wave-uniform: the whole epilogue is instantiated per pair and dispatched once
     auto epilogue = [&](auto act_c, auto mode_c) {
         constexpr int ACT = decltype(act_c)::value, MODE = decltype(mode_c)::value;
+        const float ps = drop_prescale<ACT, MODE>(a.drop);  // dropout scale folded into the affine
+        if constexpr (H::STAGE) {
+            // stride-2 forms: a pixel tile (2 rows x 16 pixels) of this wave is 32 whole 128-byte lines (its 64 channels of each
+            // pixel); through the per-wave LDS staging tile a store instruction writes 8 of them (lane = (pixel, 16-byte chunk))
+            // instead of a 32-byte piece of 32 lines
+            unsigned char* ost = (unsigned char*)smem + H::TAB_END + wave * (32 * H::OROW);
+            float ca[2][2][8], cc[2][2][8];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int g2 = 0; g2 < 2; ++g2) {
+                    const int cg0 = nt * 32 + 16 * g2;
+                    const float4 ca0 = *(const float4*)(a.coef_a + ci_base + cg0), ca1 = *(const float4*)(a.coef_a + ci_base + cg0 + 8);
+                    const float4 cc0 = *(const float4*)(a.coef_c + ci_base + cg0), cc1 = *(const float4*)(a.coef_c + ci_base + cg0 + 8);
+                    ca[nt][g2][0] = ca0.x * ps; ca[nt][g2][1] = ca0.y * ps; ca[nt][g2][2] = ca0.z * ps; ca[nt][g2][3] = ca0.w * ps;
+                    ca[nt][g2][4] = ca1.x * ps; ca[nt][g2][5] = ca1.y * ps; ca[nt][g2][6] = ca1.z * ps; ca[nt][g2][7] = ca1.w * ps;
+                    cc[nt][g2][0] = cc0.x * ps; cc[nt][g2][1] = cc0.y * ps; cc[nt][g2][2] = cc0.z * ps; cc[nt][g2][3] = cc0.w * ps;
+                    cc[nt][g2][4] = cc1.x * ps; cc[nt][g2][5] = cc1.y * ps; cc[nt][g2][6] = cc1.z * ps; cc[nt][g2][7] = cc1.w * ps;
+                }
+            const uint32_t tile_base = o0 - (uint32_t)(px_r * a.wo + px_x) * (uint32_t)a.cout;  // pixel (row 0, column 0) of pixel tile 0
+            const int rpx = lane >> 3, rch = lane & 7;  // read-back role: (pixel 8 k + rpx, 16-byte chunk)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int g2 = 0; g2 < 2; ++g2) {
+                        const int cg0 = nt * 32 + 16 * g2;
+                        const uint32_t e0 = o0 + mt * mt_stride + cg0 + 4 * hi;
+                        float v[8];
+#pragma unroll
+                        for (int t = 0; t < 8; ++t) v[t] = fmaf(acc[nt][mt][8 * g2 + t], ca[nt][g2][t], cc[nt][g2][t]);
+                        act_drop_fixed<4, ACT, MODE, true>(v, e0, row0, a.drop, key);
+                        act_drop_fixed<4, ACT, MODE, true>(v + 4, e0 + 8, row0, a.drop, key);
+                        uint32_t p0 = pack_el16x2(v[0], v[1]), p1 = pack_el16x2(v[2], v[3]);
+                        uint32_t q0 = pack_el16x2(v[4], v[5]), q1 = pack_el16x2(v[6], v[7]);
+                        const auto s0 = __builtin_amdgcn_permlane32_swap(p0, q0, false, false);
+                        const auto s1 = __builtin_amdgcn_permlane32_swap(p1, q1, false, false);
+                        uint4 o;
+                        o.x = s0[0]; o.y = s1[0]; o.z = s0[1]; o.w = s1[1];
+                        *(uint4*)(ost + l31 * H::OROW + (cg0 + 8 * hi) * 2) = o;
+                    }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int px = 8 * k + rpx;
+                    const uint4 o = *(const uint4*)(ost + px * H::OROW + rch * 16);
+                    *(uint4*)(a.out_el16 + (size_t)(tile_base + mt * mt_stride + (uint32_t)((px >> 4) * a.wo + (px & 15)) * (uint32_t)a.cout + rch * 8)) = o;
+                }
+            }
+            return;
+        }
         // 32-channel half outermost, pixel tiles, then the two 16-channel groups of the half: the two 32-byte pieces of a
         // pixel's 64-byte half block are stored back to back and leave the L2 as whole 64-byte writes (with the channel groups
         // outermost PMC counted 1.2-1.65x the algorithmic write bytes)
-        const float ps = drop_prescale<ACT, MODE>(a.drop);  // dropout scale folded into the affine
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
             float ca[2][8], cc[2][8];
