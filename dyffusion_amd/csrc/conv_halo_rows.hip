@@ -49,8 +49,15 @@ struct RowsCfg {
 #else
     static constexpr bool STAGE = false;
 #endif
+    // sparse form: room for HALF a tile row per wave (16 pixels, two passes per row) + the row's compact column indices
+#ifndef HALO_NO_STAGE
+    static constexpr bool STAGE_HALF = SP == 1;
+#else
+    static constexpr bool STAGE_HALF = false;
+#endif
     static constexpr int OROW = 144;
-    static constexpr int LDS_TOTAL = TAB_END + (STAGE ? R_NWAVES * 32 * OROW : 0);  // 78 848 / 69 632 B: two workgroups per CU
+    static constexpr int LDS_TOTAL = TAB_END + (STAGE ? R_NWAVES * 32 * OROW : 0) +
+                                     (STAGE_HALF ? R_NWAVES * (16 * OROW + 128) : 0);  // 78 848 / 79 360 B: two workgroups per CU
     static constexpr int ROW_BYTES = W * 128;
 };
 
@@ -361,6 +368,68 @@ __global__ __launch_bounds__(256, 2) void conv_halo_rows_kernel(ConvArgs a, int 
                     const int px = 8 * k + rpx;
                     const uint4 o = *(const uint4*)(ost + px * H::OROW + rch * 16);
                     *(uint4*)(a.out_el16 + (size_t)(row_base + t * st_stride + (uint32_t)px * pstride + rch * 8)) = o;
+                }
+            }
+            return;
+        }
+        if constexpr (H::STAGE_HALF) {
+            // Sparse form: the same whole-line stores with half a tile row (16 list entries) staged at a time; the compact column
+            // of every entry (or -1 for a padding entry: computed, not stored) travels through LDS to the lane that stores it.
+            unsigned char* ost = (unsigned char*)smem + H::TAB_END + wave * (16 * H::OROW + 128);
+            int* cst = (int*)(ost + 16 * H::OROW);
+            if (hi == 0) cst[l31] = lane_valid ? cstore : -1;
+            float ca[2][2][8], cc[2][2][8];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int g2 = 0; g2 < 2; ++g2) {
+                    const int cg0 = nt * 32 + 16 * g2;
+                    const float4 ca0 = *(const float4*)(a.coef_a + ci_base + cg0), ca1 = *(const float4*)(a.coef_a + ci_base + cg0 + 8);
+                    const float4 cc0 = *(const float4*)(a.coef_c + ci_base + cg0), cc1 = *(const float4*)(a.coef_c + ci_base + cg0 + 8);
+                    ca[nt][g2][0] = ca0.x * ps; ca[nt][g2][1] = ca0.y * ps; ca[nt][g2][2] = ca0.z * ps; ca[nt][g2][3] = ca0.w * ps;
+                    ca[nt][g2][4] = ca1.x * ps; ca[nt][g2][5] = ca1.y * ps; ca[nt][g2][6] = ca1.z * ps; ca[nt][g2][7] = ca1.w * ps;
+                    cc[nt][g2][0] = cc0.x * ps; cc[nt][g2][1] = cc0.y * ps; cc[nt][g2][2] = cc0.z * ps; cc[nt][g2][3] = cc0.w * ps;
+                    cc[nt][g2][4] = cc1.x * ps; cc[nt][g2][5] = cc1.y * ps; cc[nt][g2][6] = cc1.z * ps; cc[nt][g2][7] = cc1.w * ps;
+                }
+            // compact output row of this wave's tile row 0, column 0, channel block tn
+            const uint32_t row_base = (uint32_t)((n_img * a.ho + 2 * ty0 + wpy) * a.up_wo_store) * (uint32_t)a.cout + (uint32_t)(tn * 64);
+            const int rpx = lane >> 3, rch = lane & 7;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                uint4 o[2][2];
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int g2 = 0; g2 < 2; ++g2) {
+                        const int cg0 = nt * 32 + 16 * g2;
+                        const uint32_t e0 = o0 + t * t_stride + cg0 + 4 * hi;  // dropout stream: dense position
+                        float v[8];
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) v[q] = fmaf(acc[nt][t][8 * g2 + q], ca[nt][g2][q], cc[nt][g2][q]);
+                        act_drop_fixed<4, ACT, MODE, true>(v, e0, row0, a.drop, key);
+                        act_drop_fixed<4, ACT, MODE, true>(v + 4, e0 + 8, row0, a.drop, key);
+                        uint32_t p0 = pack_el16x2(v[0], v[1]), p1 = pack_el16x2(v[2], v[3]);
+                        uint32_t q0 = pack_el16x2(v[4], v[5]), q1 = pack_el16x2(v[6], v[7]);
+                        const auto s0 = __builtin_amdgcn_permlane32_swap(p0, q0, false, false);
+                        const auto s1 = __builtin_amdgcn_permlane32_swap(p1, q1, false, false);
+                        o[nt][g2].x = s0[0]; o[nt][g2].y = s1[0]; o[nt][g2].z = s0[1]; o[nt][g2].w = s1[1];
+                    }
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    if ((l31 >> 4) == h) {
+#pragma unroll
+                        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                            for (int g2 = 0; g2 < 2; ++g2)
+                                *(uint4*)(ost + (l31 & 15) * H::OROW + (nt * 32 + 16 * g2 + 8 * hi) * 2) = o[nt][g2];
+                    }
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        const int px16 = 8 * k + rpx;
+                        const int c = cst[16 * h + px16];
+                        const uint4 val = *(const uint4*)(ost + px16 * H::OROW + rch * 16);
+                        if (c >= 0) *(uint4*)(a.out_el16 + (size_t)(row_base + t * st_stride + (uint32_t)c * (uint32_t)a.cout + rch * 8)) = val;
+                    }
                 }
             }
             return;
