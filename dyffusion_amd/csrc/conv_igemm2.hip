@@ -27,7 +27,8 @@ typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 namespace {
 constexpr int BM = 256;
 constexpr int A_BYTES = BM * 128;      // one K step of the pixel operand: 256 rows x 64 channels bf16
-constexpr int LDS_TOTAL = 2 * A_BYTES; // 64 KB: two workgroups per CU
+constexpr int OROW = 144;              // output staging: [16 pixels][64 channels] 16-bit + 16 B pad per pixel and wave
+constexpr int LDS_TOTAL = 2 * A_BYTES + 4 * 16 * OROW; // 64 KB + 9 KB staging: two workgroups per CU
 constexpr int RA = BM / 32;            // rows gathered per lane per K step
 constexpr int TH = BM / 16;            // 2-D tile: 16 rows of 16 pixels
 }  // namespace
@@ -264,6 +265,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(ConvArgs a, int M, 
         };
         float4 cf[2][4];
         load_coef(0, cf[0]);
+        // FAST + FULL (every hot launch): a wave's 32 x 64 sub-tile is 32 whole 128-byte lines; its 16-byte rows go through a per-wave
+        // LDS staging tile, half at a time, and leave as stores of 8 whole lines (stored from the registers a store instruction
+        // writes a 32-byte piece of 32 lines -- worth 20 % of the store-bound conv_enc0_stem_kernel, 1-5 % of the halo kernels)
+        constexpr bool STAGED = FAST && FULL;
+        unsigned char* ost = (unsigned char*)smem + 2 * A_BYTES + wave * (16 * OROW);
+        const int rpx = lane >> 3, rch = lane & 7;  // read-back role: (pixel 8 k + rpx of the half, 16-byte chunk)
+        uint4 ostage[4];
 #pragma unroll
         for (int step = 0; step < 4 * MT; ++step) {
             const int mt = step >> 2, nt = (step >> 1) & 1, g2 = step & 1;
@@ -302,7 +310,26 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(ConvArgs a, int M, 
                         const auto s1 = __builtin_amdgcn_permlane32_swap(p1, q1, false, false);
                         uint4 o;
                         o.x = s0[0]; o.y = s1[0]; o.z = s0[1]; o.w = s1[1];
-                        if (FULL || valid) *(uint4*)(a.out_el16 + (size_t)(ob + cg0 + 8 * hi)) = o;
+                        if (STAGED) ostage[step & 3] = o;
+                        else if (FULL || valid) *(uint4*)(a.out_el16 + (size_t)(ob + cg0 + 8 * hi)) = o;
+                    }
+                }
+            }
+            if (STAGED && (step & 3) == 3) {
+                const int row0w = wm * (32 * MT) + mt * 32;  // first tile row of this sub-tile
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    if ((l31 >> 4) == h) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)  // q = nt * 2 + g2: channels 16 q + 8 hi ..
+                            *(uint4*)(ost + (l31 & 15) * OROW + (16 * q + 8 * hi) * 2) = ostage[q];
+                    }
+#pragma unroll
+                    for (int k = 0; k < 2; ++k) {
+                        const int rowp = row0w + 16 * h + 8 * k + rpx;
+                        const int mp = tile2d ? (t_img * a.ho + t_y0 + (rowp >> 4)) * a.wo + t_x0 + (rowp & 15) : tm * BM + rowp;
+                        const uint4 val = *(const uint4*)(ost + (8 * k + rpx) * OROW + rch * 16);
+                        *(uint4*)(a.out_el16 + (size_t)((uint32_t)mp * (uint32_t)a.cout + (uint32_t)(tn * BN + wn * 64) + rch * 8)) = val;
                     }
                 }
             }
