@@ -243,7 +243,14 @@ __global__ __launch_bounds__(512) void stem16_rows_kernel(StemArgs a, int nblk) 
             while (cl >= a.ch[si]) cl -= a.ch[si++];
             const float* sp = a.src[si] + ((size_t)nrow * a.ch[si] + cl) * plane + (size_t)s0 * a.w + x;
             float* dp = st_rows + (size_t)x * CP + k;
-            for (int r = 0; r < nsrc_rows; ++r) dp[(size_t)r * a.w * CP] = sp[(size_t)r * a.w];
+            // all row loads in flight together (a rolled loop waited for each load before its LDS store: ~10 serial round trips
+            // were the lifetime of a workgroup)
+            float tmp[ST_ROWS + 2];
+#pragma unroll
+            for (int r = 0; r < ST_ROWS + 2; ++r) tmp[r] = r < nsrc_rows ? sp[(size_t)r * a.w] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < ST_ROWS + 2; ++r)
+                if (r < nsrc_rows) dp[(size_t)r * a.w * CP] = tmp[r];
         }
     }
     // per-column (x0, x1, lx) and per-row (y0, y1, ly) stencils, once per workgroup: the item loop below is instruction-bound
@@ -269,6 +276,63 @@ __global__ __launch_bounds__(512) void stem16_rows_kernel(StemArgs a, int nblk) 
     }
     __syncthreads();
     uint4* oblk = (uint4*)(a.out + (((size_t)n * ph + py0) * pw) * 16);
+    if (a.cin <= 8 && (a.uw & 63) == 0) {
+        // At most 8 input channels (the NS nets: 8): channels 8-15 of a pixel are constants (the bias slot, zeros), so only ONE lane per
+        // pixel does arithmetic -- the loop is instruction-bound -- and the pixel's two 16-byte halves pass through a per-wave
+        // LDS tile so that a wave still stores 2 x 1 KB of consecutive bytes for its 64 consecutive pixels.
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        unsigned char* stg = (unsigned char*)(ytab + ST_ROWS) + wave * 2048;  // [64 pixels][32 B]
+        const uint4 zero4 = make_uint4(0, 0, 0, 0);
+        const uint4 half1 = a.cin == 8 ? make_uint4(pack_el16x2(1.0f, 0.0f), 0, 0, 0) : zero4;  // slot cin = 1 (init_conv's bias)
+        for (int i = threadIdx.x; i < (py1 - py0) * 4; i += 512) {  // the two zero border pixels of every row
+            const int rr = i >> 2, q = i & 3;
+            oblk[(size_t)rr * 2 * pw + (q < 2 ? q : 2 * pw - 4 + q)] = zero4;
+        }
+        const int total_in = (py1 - py0) * a.uw;
+        int r = 0, j = threadIdx.x;  // interior pixel (row r of the block, column j)
+        while (j >= a.uw) { j -= a.uw; ++r; }
+        for (int i = threadIdx.x; i < total_in; i += 512) {
+            const int4 xt = xtab[j + 1], yt = ytab[r];
+            uint4 w = zero4;
+            if (yt.w) {
+                const int x0 = xt.x, x1 = xt.y;
+                const float lx = __int_as_float(xt.z), ly = __int_as_float(yt.z);
+                const float* r0 = st_rows + yt.x;
+                const float* r1 = st_rows + yt.y;
+                float v[8];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    float t00[4] = {0, 0, 0, 0}, t01[4] = {0, 0, 0, 0}, t10[4] = {0, 0, 0, 0}, t11[4] = {0, 0, 0, 0};
+                    if (4 * q < CP) {
+                        const float4 p00 = *(const float4*)(r0 + x0 + 4 * q), p01 = *(const float4*)(r0 + x1 + 4 * q);
+                        const float4 p10 = *(const float4*)(r1 + x0 + 4 * q), p11 = *(const float4*)(r1 + x1 + 4 * q);
+                        t00[0] = p00.x; t00[1] = p00.y; t00[2] = p00.z; t00[3] = p00.w;
+                        t01[0] = p01.x; t01[1] = p01.y; t01[2] = p01.z; t01[3] = p01.w;
+                        t10[0] = p10.x; t10[1] = p10.y; t10[2] = p10.z; t10[3] = p10.w;
+                        t11[0] = p11.x; t11[1] = p11.y; t11[2] = p11.z; t11[3] = p11.w;
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int k = 4 * q + e;
+                        const float top = t00[e] * (1.0f - lx) + t01[e] * lx;
+                        const float bot = t10[e] * (1.0f - lx) + t11[e] * lx;
+                        float val = top * (1.0f - ly) + bot * ly;
+                        if (k >= a.cin) val = k == a.cin ? 1.0f : 0.0f;
+                        v[k] = val;
+                    }
+                }
+                w = make_uint4(pack_el16x2(v[0], v[1]), pack_el16x2(v[2], v[3]), pack_el16x2(v[4], v[5]), pack_el16x2(v[6], v[7]));
+            }
+            *(uint4*)(stg + lane * 32) = w;
+            *(uint4*)(stg + lane * 32 + 16) = yt.w ? half1 : zero4;
+            uint4* dst = oblk + (size_t)r * 2 * pw + 2 * (1 + j - lane) + lane;  // the wave's 64 pixels: 128 consecutive 16-byte chunks
+            dst[0] = *(const uint4*)(stg + lane * 16);
+            dst[64] = *(const uint4*)(stg + 1024 + lane * 16);
+            j += 512;
+            while (j >= a.uw) { j -= a.uw; ++r; }
+        }
+        return;
+    }
     const int total = (py1 - py0) * 2 * pw;
     int r = 0, j = threadIdx.x;  // item i = r * 2 pw + j, advanced without a division (512 <= 2 pw is checked by the launcher)
     for (int i = threadIdx.x; i < total; i += 512) {
@@ -314,7 +378,7 @@ __global__ __launch_bounds__(512) void stem16_rows_kernel(StemArgs a, int nblk) 
 
 hipError_t launch_stem16(const StemArgs& a, hipStream_t s) {
     const int cp = (a.cin + 3) / 4 * 4;  // cin <= 15 (the fused stem's bias channel is slot cin)
-    const size_t lds = (size_t)(ST_ROWS + 2) * a.w * cp * sizeof(float) + (size_t)(a.uw + 2 + ST_ROWS) * 16;  // rows + stencil tables
+    const size_t lds = (size_t)(ST_ROWS + 2) * a.w * cp * sizeof(float) + (size_t)(a.uw + 2 + ST_ROWS) * 16 + 8 * 2048;  // rows + stencil tables + per-wave output tiles
     const char* env = getenv("DYF_STEM16_ROWS");  // read per launch: the parity test flips it
     if (!(env && atoi(env) == 0) && lds <= 48 * 1024 && cp <= 16 && a.h <= a.uh && 2 * (a.uw + 2) >= 512) {
         const int nblk = (a.uh + 2 + ST_ROWS - 1) / ST_ROWS;
