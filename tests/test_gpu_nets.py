@@ -217,6 +217,7 @@ mk = dict(dim=64, with_time_emb=True, upsample_dims=[256, 256], dropout=0.25)
 g = torch.Generator().manual_seed(5)
 x, c, t = torch.randn(8, 6, 221, 42, generator=g), torch.rand(8, 2, 221, 42, generator=g), torch.arange(8.0)
 net = mirror_from_params(PI, mk, 6, 2, 3)
+net.engine_dtype = {dtype!r}
 net(x.cuda(), time=t.cuda(), condition=c.cuda())  # creates the engine
 eng = net._engine
 outs = {{}}
@@ -229,7 +230,8 @@ torch.save(outs, {out!r})
 """
 
 
-def test_persistent_enc0_kernel_matches_the_implicit_gemm_form(tmp_path):
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+def test_persistent_enc0_kernel_matches_the_implicit_gemm_form(tmp_path, dtype):
     """enc0 on the fused stem at NB = 8 (4 096 row segments: the persistent kernel of conv_enc0_stem.hip takes the layer) against
     the same forward with DYF_ENC0_STEM=0 (conv_igemm2_kernel): same K order, same epilogue and dropout stream -> the block output
     agrees to a 16-bit rounding tie, with and without engine dropout.  The form is chosen once per process: two subprocesses."""
@@ -240,7 +242,7 @@ def test_persistent_enc0_kernel_matches_the_implicit_gemm_form(tmp_path):
     outs = []
     for on in ("1", "0"):
         out = str(tmp_path / f"enc0_{on}.pt")
-        subprocess.run([_sys.executable, "-c", _ENC0_SCRIPT.format(root=root, out=out)], check=True, env=dict(os.environ, DYF_ENC0_STEM=on),
+        subprocess.run([_sys.executable, "-c", _ENC0_SCRIPT.format(root=root, out=out, dtype=dtype)], check=True, env=dict(os.environ, DYF_ENC0_STEM=on),
                        timeout=900)
         outs.append(torch.load(out))
     for k in outs[0]:
