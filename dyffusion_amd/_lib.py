@@ -98,6 +98,8 @@ SYMBOLS = [
     ("dyf_train_conv_check", C.c_int, [_P] + [C.c_int32] * 9 + [C.c_uint32, C.POINTER(C.c_float)]),
     ("dyf_apply_boundary_conditions", C.c_int, [_P, C.POINTER(BcArgs), _P, _P]),
     ("dyf_debug_read_block_output", C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
+    ("dyf_debug_form_log", None, [C.c_int32]),
+    ("dyf_debug_form_log_read", C.c_int32, [C.c_char_p, C.c_int32]),
 ]
 
 

@@ -25,13 +25,22 @@ class PhysicalSystemsBoundaryConditions:
             raise NotImplementedError(f"Boundary conditions for {physical_system} not implemented")  # as the reference
         self.physical_system = physical_system
         self.engine = engine
+        self._meta_ref = None     # the metadata object itself: an id() alone is reused by CPython once the dict is freed
         self._meta_key = None
         self._meta_dev: Dict[str, Tensor] = {}
 
     # ------------------------------------------------------------------ metadata -> device tensors (cached per batch)
+    def _source_key(self, metadata):
+        """Identity of the tensors the device copies were made from: storage address and in-place modification counter."""
+        names = ("fixed_mask", "in_velocity", "vertices") if self.physical_system == "navier-stokes" else ("fixed_mask", "features")
+        return tuple((metadata[k].data_ptr(), metadata[k]._version, tuple(metadata[k].shape)) for k in names)
+
     def _prepare(self, metadata, device) -> Dict[str, Tensor]:
-        key = id(metadata)
-        if key == self._meta_key:
+        """The cache holds a REFERENCE to the metadata dict it was built from and is hit only by that very object with
+        unchanged source tensors -- the evaluation loop applies the conditions to every horizon step of one batch (h calls per
+        outer iteration); the next batch's dict is a different object even when CPython gives it the freed one's address."""
+        key = (str(device), self._source_key(metadata))
+        if metadata is self._meta_ref and key == self._meta_key:
             return self._meta_dev
         d: Dict[str, Tensor] = {"fixed_mask": metadata["fixed_mask"].to(device=device, dtype=torch.uint8).contiguous()}
         if self.physical_system == "navier-stokes":
@@ -40,7 +49,7 @@ class PhysicalSystemsBoundaryConditions:
         else:
             base_q = metadata["features"][:, 0, 2:].to(device=device, dtype=torch.float32)
             d["boundary"] = torch.cat([torch.zeros_like(base_q), base_q], dim=1).contiguous()
-        self._meta_key, self._meta_dev = key, d
+        self._meta_ref, self._meta_key, self._meta_dev = metadata, key, d
         return d
 
     def _row_meta(self, preds: Tensor, batch_size: int) -> Tensor:
@@ -72,6 +81,8 @@ class PhysicalSystemsBoundaryConditions:
         c, h, w = preds.shape[-3:]
         if tuple(d["fixed_mask"].shape[1:]) != (c, h, w):
             raise AssertionError(f"fixed_mask={tuple(d['fixed_mask'].shape[1:])}, predictions={tuple(preds.shape)}")
+        if batch_size > d["fixed_mask"].shape[0]:  # the kernel indexes fixed_mask[b] / in_velocity[b] with the row's element
+            raise IndexError(f"batch of {batch_size} elements but the metadata holds {d['fixed_mask'].shape[0]}")
         row_meta = self._row_meta(preds, batch_size).to(preds.device)
         a = L.BcArgs()
         a.kind = L.BC_NAVIER_STOKES if self.physical_system == "navier-stokes" else L.BC_SPRING_MESH

@@ -13,6 +13,14 @@
 #endif
 typedef uint16_t el16_t;
 
+// Kernel-form log (test seam, include/dyffusion_hip_testing.h dyf_debug_form_log*): every launcher that chooses between kernel
+// forms notes the form it took and the batch rows of the launch; off unless a test enables it (one predictable branch).
+extern bool g_dyf_form_log_on;
+void dyf_form_note_slow(const char* form, long long rows);
+static inline void dyf_form_note(const char* form, long long rows) {
+    if (g_dyf_form_log_on) dyf_form_note_slow(form, rows);
+}
+
 #if DYF_F16
 typedef _Float16 el16_native_t;
 #define DYF_MFMA_32x32x16(a, b, c, x, y, z) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, x, y, z)

@@ -2,7 +2,12 @@
 #pragma once
 #include "common.h"
 
+#include <string>
 #include <vector>
+
+// kernel-form log (common.h dyf_form_note; test seam dyf_debug_form_log*)
+void dyf_form_log_enable(bool on);
+std::string dyf_form_log_text();
 
 struct ConvArgs {
     // input: channel-concatenation of up to two NHWC bf16 tensors (skip connections are never materialised)

@@ -25,6 +25,29 @@
 #include <type_traits>
 
 #include <cstdlib>
+#include <map>
+#include <mutex>
+#include <string>
+
+// ---- kernel-form log (common.h): form name + "@rows" -> launches noted since it was enabled
+bool g_dyf_form_log_on = false;
+static std::mutex g_form_mu;
+static std::map<std::string, long long> g_form_log;
+void dyf_form_note_slow(const char* form, long long rows) {
+    std::lock_guard<std::mutex> lk(g_form_mu);
+    ++g_form_log[std::string(form) + "@" + std::to_string(rows)];
+}
+void dyf_form_log_enable(bool on) {
+    std::lock_guard<std::mutex> lk(g_form_mu);
+    g_form_log.clear();
+    g_dyf_form_log_on = on;
+}
+std::string dyf_form_log_text() {
+    std::lock_guard<std::mutex> lk(g_form_mu);
+    std::string t;
+    for (auto& kv : g_form_log) t += kv.first + "=" + std::to_string(kv.second) + ";";
+    return t;
+}
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 #define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
@@ -599,6 +622,9 @@ static hipError_t launch_igemm(ConvArgs a, hipStream_t stream) {
         const long long need = (long long)s * M * a.cout;
         if (enabled && s > 1 && tiles <= 128 && need <= a.splitk_cap) a.splitk = s;
     }
+    dyf_form_note(a.splitk > 1 ? (BM == 128 ? "conv_igemm_kernel<128,128>+splitk" : "conv_igemm_kernel<256,64>+splitk")
+                               : (BM == 128 ? (UP ? "conv_igemm_kernel<128,128,UP>" : "conv_igemm_kernel<128,128>")
+                                            : (UP ? "conv_igemm_kernel<256,64,UP>" : "conv_igemm_kernel<256,64>")), a.n);
     hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, WM, WN, UP>), dim3(tiles_m * tiles_n, a.splitk), dim3(256), lds, stream, a, (int)M,
                        tiles_m, tiles_n);
     if (a.splitk > 1)
@@ -700,6 +726,7 @@ hipError_t launch_conv(const ConvArgs& a, int path, hipStream_t stream) {
     if (a.up2x) return hipErrorInvalidValue;  // the direct kernel has no fused-upsample form: caller materialises
     const long long total = (long long)a.n * a.ho * a.wo * a.cout;
     const int threads = 256;
+    dyf_form_note("conv_direct_kernel", a.n);
     hipLaunchKernelGGL(conv_direct_kernel, dim3((unsigned)((total + threads - 1) / threads)), dim3(threads), 0, stream,
                        a, total);
     return hipGetLastError();

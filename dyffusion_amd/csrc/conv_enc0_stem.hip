@@ -194,6 +194,7 @@ hipError_t launch_conv_enc0_stem(const ConvArgs& a, const el16_t* wfrag, hipStre
     int per = (tiles + nwg - 1) / nwg;
     per = (per + 15) / 16 * 16;  // a wave keeps its column segment (wo = 128: 4 segments) and its fragment-set parity
     nwg = (tiles + per - 1) / per;
+    dyf_form_note("conv_enc0_stem_kernel", a.n);
     if (a.cout == 128)
         hipLaunchKernelGGL(conv_enc0_stem_kernel<4>, dim3(nwg), dim3(E0_THREADS), e0_lds_bytes(4), stream, a, wfrag, tiles, per);
     else

@@ -517,6 +517,7 @@ hipError_t launch_conv_halo_rows_up(const ConvArgs& a, hipStream_t stream) {
     const bool sparse = a.up_cols != nullptr;
     const int tiles_x = sparse ? a.up_ntiles : a.w / R_TW, tiles_per_img = tiles_x * (a.h / R_TH);
     const int tiles_m = a.n * tiles_per_img, tiles_n = a.cout / 64;
+    dyf_form_note(sparse ? "conv_halo_rows_kernel<1>" : "conv_halo_rows_kernel<0>", a.n);
     if (sparse)
         hipLaunchKernelGGL(conv_halo_rows_kernel<1>, dim3(tiles_m * tiles_n), dim3(256), RowsCfg<1>::LDS_TOTAL, stream, a, tiles_x,
                            tiles_per_img, tiles_m, tiles_n);
@@ -529,6 +530,7 @@ hipError_t launch_conv_halo_rows_up(const ConvArgs& a, hipStream_t stream) {
 hipError_t launch_conv_halo_rows3(const ConvArgs& a, hipStream_t stream) {
     const int tiles_x = a.w / R_TW, tiles_per_img = tiles_x * (a.h / R_TH);
     const int tiles_m = a.n * tiles_per_img, tiles_n = a.cout / 256;
+    dyf_form_note("conv_halo_rows_kernel<2>", a.n);
     hipLaunchKernelGGL(conv_halo_rows_kernel<2>, dim3(tiles_m * tiles_n), dim3(256), RowsCfg<2>::LDS_TOTAL, stream, a, tiles_x,
                        tiles_per_img, tiles_m, tiles_n);
     return hipGetLastError();

@@ -394,6 +394,7 @@ hipError_t conv_igemm2_init() {
 hipError_t launch_conv_igemm2(const ConvArgs& a, hipStream_t stream) {
     const long long M = (long long)a.n * a.ho * a.wo;
     const int tiles_m = (int)((M + BM - 1) / BM);
+    dyf_form_note(a.cout % 128 == 0 ? "conv_igemm2_kernel<2>" : "conv_igemm2_kernel<1>", a.n);
     if (a.cout % 128 == 0) {
         const int tiles_n = a.cout / 128;
         hipLaunchKernelGGL(conv_igemm2_kernel<2>, dim3(tiles_m * tiles_n), dim3(256), LDS_TOTAL, stream, a, (int)M, tiles_m, tiles_n);

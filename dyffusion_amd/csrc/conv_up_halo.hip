@@ -725,6 +725,7 @@ hipError_t launch_conv_halo5(const ConvArgs& a, hipStream_t stream) {
     using H5 = HaloCfg<5>;
     const int tiles_x = (a.w + H5::TW - 1) / H5::TW, tiles_per_img = tiles_x * ((a.h + H5::TH - 1) / H5::TH);
     const int tiles_m = a.n * tiles_per_img, tiles_n = a.cout / 64;
+    dyf_form_note("conv_up_halo_kernel<5>", a.n);
     hipLaunchKernelGGL(conv_up_halo_kernel<5>, dim3(tiles_m * tiles_n), dim3(256), H5::LDS_TOTAL, stream, a, tiles_x,
                        tiles_per_img, tiles_m, tiles_n, 0);
     return hipGetLastError();
@@ -745,12 +746,14 @@ hipError_t launch_conv_halo_s2(const ConvArgs& a, hipStream_t stream) {
     if (a.cout % 256 != 0) {
         const int tiles_x = a.wo / TILE_W, tiles_per_img = tiles_x * (a.ho / HaloCfg<4>::TH);
         const int tiles_m = a.n * tiles_per_img, tiles_n = a.cout / 128;
+        dyf_form_note("conv_up_halo_kernel<4>", a.n);
         hipLaunchKernelGGL(conv_up_halo_kernel<4>, dim3(tiles_m * tiles_n), dim3(256), HaloCfg<4>::LDS_TOTAL, stream, a, tiles_x,
                            tiles_per_img, tiles_m, tiles_n, 0);
         return hipGetLastError();
     }
     const int tiles_x = a.wo / TILE_W, tiles_per_img = tiles_x * (a.ho / TILE_H);
     const int tiles_m = a.n * tiles_per_img, tiles_n = a.cout / 256;
+    dyf_form_note("conv_up_halo_kernel<3>", a.n);
     hipLaunchKernelGGL(conv_up_halo_kernel<3>, dim3(tiles_m * tiles_n), dim3(256), HaloCfg<3>::LDS_TOTAL, stream, a, tiles_x,
                        tiles_per_img, tiles_m, tiles_n, 0);
     return hipGetLastError();
@@ -769,6 +772,7 @@ bool conv_halo3_supported(const ConvArgs& a) {
 hipError_t launch_conv_halo3(const ConvArgs& a, hipStream_t stream) {
     const int tiles_x = a.w / TILE_W, tiles_per_img = tiles_x * (a.h / TILE_H);
     const int tiles_m = a.n * tiles_per_img, tiles_n = a.cout / 256;
+    dyf_form_note("conv_up_halo_kernel<2>", a.n);
     hipLaunchKernelGGL(conv_up_halo_kernel<2>, dim3(tiles_m * tiles_n), dim3(256), HaloCfg<2>::LDS_TOTAL, stream, a, tiles_x,
                        tiles_per_img, tiles_m, tiles_n, 0);
     return hipGetLastError();
@@ -988,6 +992,7 @@ hipError_t launch_conv_up_halo(const ConvArgs& a, hipStream_t stream) {
     if (sparse ? a.up_npad != a.up_ntiles * 16 : (rows && conv_halo_rows_up_supported(a))) return launch_conv_halo_rows_up(a, stream);
     const int tiles_x = sparse ? a.up_ntiles : a.w / TILE_W, tiles_per_img = tiles_x * (a.h / TILE_H);
     const int tiles_m = a.n * tiles_per_img, tiles_n = a.cout / 64;
+    dyf_form_note(sparse ? "conv_up_halo_kernel<1>" : "conv_up_halo_kernel<0>", a.n);
     if (sparse)
         hipLaunchKernelGGL(conv_up_halo_kernel<1>, dim3(tiles_m * tiles_n), dim3(256), HaloCfg<1>::LDS_TOTAL, stream, a, tiles_x,
                            tiles_per_img, tiles_m, tiles_n, 0);

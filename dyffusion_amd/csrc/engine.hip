@@ -426,6 +426,9 @@ dyf_status dyf_seed(dyf_engine* e, uint64_t seed) {
     // seed words and both counters; the row offset (word 3) belongs to dyf_set_row_offset
     const uint32_t st[3] = {(uint32_t)(seed & 0xffffffffu), (uint32_t)(seed >> 32), 0u};
     const uint32_t zero = 0u;
+    // rollouts read and bump rng_state on the caller's / the engine's capture stream, which may be non-blocking streams the
+    // null-stream copy below is not ordered against: let everything in flight finish first (re-seeding is rare)
+    HIP_TRY(e, hipDeviceSynchronize());
     HIP_TRY(e, hipMemcpy(e->rng_state, st, sizeof(st), hipMemcpyHostToDevice));
     HIP_TRY(e, hipMemcpy(e->rng_state + 4, &zero, sizeof(zero), hipMemcpyHostToDevice));
     return DYF_OK;
@@ -434,7 +437,11 @@ dyf_status dyf_seed(dyf_engine* e, uint64_t seed) {
 dyf_status dyf_set_row_offset(dyf_engine* e, uint32_t first_row) {
     if (!e) return DYF_ERR_INVALID_ARGUMENT;
     HIP_TRY(e, hipSetDevice(e->cfg.device));
+    if (e->row_offset_known && e->row_offset == first_row) return DYF_OK;  // a rank sets the same offset before every predict call
+    HIP_TRY(e, hipDeviceSynchronize());  // as dyf_seed: in-flight rollouts on other streams read this word
     HIP_TRY(e, hipMemcpy(e->rng_state + 3, &first_row, sizeof(first_row), hipMemcpyHostToDevice));
+    e->row_offset = first_row;
+    e->row_offset_known = true;
     return DYF_OK;
 }
 
@@ -1191,6 +1198,17 @@ dyf_status dyf_time_layer_in_rollout(dyf_engine* e, int32_t layer, int32_t nb, v
     *avg_ms = tot / units;
     if (launches) *launches = (int32_t)cnt;
     return DYF_OK;
+}
+
+void dyf_debug_form_log(int32_t enable) { dyf_form_log_enable(enable != 0); }
+int32_t dyf_debug_form_log_read(char* buf, int32_t cap) {
+    const std::string t = dyf_form_log_text();
+    if (buf && cap > 0) {
+        const size_t n = std::min<size_t>(t.size(), (size_t)cap - 1);
+        memcpy(buf, t.data(), n);
+        buf[n] = 0;
+    }
+    return (int32_t)t.size();
 }
 
 dyf_status dyf_debug_read_block_output(dyf_engine* e, int32_t which, int32_t layer, int32_t nb, float* out_dev, void* stream) {

@@ -120,6 +120,8 @@ struct dyf_engine {
           *s_cur = nullptr, *s_noisy = nullptr, *s_stack = nullptr;
     float* s_time = nullptr;   // device scalar scratch for time values
     uint32_t* rng_state = nullptr;  // device {seed_lo, seed_hi, forward counter, row offset, noise counter, ...} (kernels.h)
+    uint32_t row_offset = 0;        // host copy of rng_state[3] (dyf_set_row_offset skips the device write when unchanged)
+    bool row_offset_known = false;
     uint32_t* row_keys = nullptr;   // device [2 max_batch][2]: per-row stream keys of the forward being launched (common.h)
     int stack_slots = 0;
     std::map<int, dyf::GraphEntry> graphs;  // by batch size

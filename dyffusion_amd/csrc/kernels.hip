@@ -383,6 +383,7 @@ hipError_t launch_stem16(const StemArgs& a, hipStream_t s) {
     if (!(env && atoi(env) == 0) && lds <= 48 * 1024 && cp <= 16 && a.h <= a.uh && 2 * (a.uw + 2) >= 512) {
         const int nblk = (a.uh + 2 + ST_ROWS - 1) / ST_ROWS;
         const dim3 grid((unsigned)(a.n * nblk)), block(512);
+        dyf_form_note("stem16_rows_kernel", a.n);
         if (cp == 4) hipLaunchKernelGGL(stem16_rows_kernel<4>, grid, block, lds, s, a, nblk);
         else if (cp == 8) hipLaunchKernelGGL(stem16_rows_kernel<8>, grid, block, lds, s, a, nblk);
         else if (cp == 12) hipLaunchKernelGGL(stem16_rows_kernel<12>, grid, block, lds, s, a, nblk);
@@ -390,6 +391,7 @@ hipError_t launch_stem16(const StemArgs& a, hipStream_t s) {
         return hipGetLastError();
     }
     const long long total = (long long)a.n * (a.uh + 2) * (a.uw + 2);
+    dyf_form_note("stem16_kernel", a.n);
     hipLaunchKernelGGL(stem16_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
     return hipGetLastError();
 }
@@ -534,6 +536,7 @@ hipError_t launch_up2x(const Up2xArgs& a, hipStream_t s) {
     const char* env = getenv("DYF_UP2X_QUAD");  // read per launch (parity test)
     if (vec && !(env && atoi(env) == 0) && a.h >= 2 && a.w >= 2) {
         const long long quads = total / 4;
+        dyf_form_note("up2x_quad_kernel", a.n);
         hipLaunchKernelGGL(up2x_quad_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, s, a, quads);
     } else if (vec)
         hipLaunchKernelGGL(up2x_kernel<8>, dim3(blocks), dim3(256), 0, s, a, total);
@@ -1110,7 +1113,9 @@ hipError_t launch_readout(const ReadoutArgs& a, hipStream_t s) {
         waves = (groups + per - 1) / per;
         // DMA-staged gather (DYF_READOUT_DMA=0: the register-shuffle form); the DMA's buffer descriptor addresses < 4 GB
         static const bool use_dma = !(getenv("DYF_READOUT_DMA") && atoi(getenv("DYF_READOUT_DMA")) == 0);
-        if (use_dma && a.row_tab && a.col_tab && (size_t)a.n * a.ih * a.iw_store * 128 < 0x7F000000ull)
+        const bool dma = use_dma && a.row_tab && a.col_tab && (size_t)a.n * a.ih * a.iw_store * 128 < 0x7F000000ull;
+        dyf_form_note(dma ? "readout_dma_kernel" : "readout_mfma_kernel", a.n);
+        if (dma)
             hipLaunchKernelGGL(readout_dma_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 8192 + 4 * 8192, s, a, per);
         else
             hipLaunchKernelGGL(readout_mfma_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 32768, s, a, per);

@@ -446,7 +446,9 @@ class DYffusion(nn.Module):
         pred = eng.train_forward(L.NET_FORECASTER, 1, x_t, time1, cond1, batch_stats=True, dropout=f_drop)
         loss_forward = eng.criterion(pred, xt_last, kind)
         not_last = t <= T - 2
-        state = dict(eng=eng, pred=pred, target=xt_last, kind=kind, lam1=lam1, lam2=lam2, not_last=None, n_fwd=1)
+        eng.train_step_id += 1
+        state = dict(eng=eng, pred=pred, target=xt_last, kind=kind, lam1=lam1, lam2=lam2, not_last=None, n_fwd=1,
+                     step_id=eng.train_step_id)
         loss_forward2 = 0.0
         if lam2 > 0 and bool(not_last.any()):
             t2 = t[not_last] + 1
@@ -469,7 +471,7 @@ class DYffusion(nn.Module):
 
     def _train_backward(self, upstream: float):
         st = self._train_state
-        eng, C = st["eng"], self.num_input_channels
+        eng, C = st["eng"], self.num_output_channels  # the x_last part of the interpolator's inputs cat[x_0 window, x_last]
         d_pred = eng.criterion_grad(st["pred"], st["target"], st["kind"], st["lam1"] * upstream)
         if st["not_last"] is not None:
             d_pred2 = eng.criterion_grad(st["pred2"], st["target2"], st["kind"], st["lam2"] * upstream)

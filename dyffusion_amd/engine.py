@@ -82,6 +82,8 @@ class HipEngine:
         self._plan_keepalive = None
         self.n_out_slots = 0
         self._tape_net = {}       # tape slot -> network of the recorded training forward
+        self._tape_nb = {}        # tape slot -> batch rows of the recorded forward (train_backward validates dout against it)
+        self.train_step_id = 0    # bumped by every p_losses / get_loss training forward: a loss of an older step cannot run backward
         self.plan_valid = False   # cleared by load_weights: the plan's FiLM tables are functions of the weights
         self.weights_version = 0
 
@@ -259,6 +261,23 @@ class HipEngine:
         self._check(self._lib.dyf_debug_read_block_output(self._h, net, layer, nb, out.data_ptr(), self._stream()))
         return out
 
+    def form_log(self, enable: bool) -> None:
+        """Test seam: clear and enable (or disable) the process-wide kernel-form log (dyf_debug_form_log)."""
+        self._lib.dyf_debug_form_log(int(bool(enable)))
+
+    def form_log_read(self) -> Dict[str, Dict[int, int]]:
+        """{kernel form: {batch rows of the launch: launches noted}} since the log was enabled."""
+        n = self._lib.dyf_debug_form_log_read(None, 0)
+        buf = C.create_string_buffer(n + 1)
+        self._lib.dyf_debug_form_log_read(buf, n + 1)
+        out: Dict[str, Dict[int, int]] = {}
+        for item in buf.value.decode().split(";"):
+            if item:
+                key, cnt = item.rsplit("=", 1)
+                form, rows = key.rsplit("@", 1)
+                out.setdefault(form, {})[int(rows)] = int(cnt)
+        return out
+
     # ------------------------------------------------------------------ introspection
     def forward_counts(self):
         a, b = C.c_int32(), C.c_int32()
@@ -350,6 +369,7 @@ class HipEngine:
         out = torch.empty((nb, ncfg.out_channels, self.height, self.width), dtype=torch.float32, device=inputs.device)
         flags = (L.TRAIN_BATCH_STATS if batch_stats else 0) | (L.TRAIN_DROPOUT if dropout else 0)
         self._tape_net[slot] = net
+        self._tape_nb[slot] = nb
         self._check(self._lib.dyf_train_forward(self._h, net, slot, inputs.data_ptr(), None if time is None else time.data_ptr(),
                                                 None if condition is None else condition.data_ptr(), out.data_ptr(), nb, flags,
                                                 self._stream()))
@@ -357,9 +377,14 @@ class HipEngine:
 
     def train_backward(self, slot: int, dout: torch.Tensor, want_dinputs: bool, param_grads: bool) -> Optional[torch.Tensor]:
         dout = _f32c(dout, "dout")
+        if slot not in self._tape_net:
+            raise EngineError(f"tape slot {slot} holds no recorded forward")
+        net = self._tape_net[slot]
+        want = (self._tape_nb[slot], self.cfg.net[net].out_channels, self.height, self.width)
+        if tuple(dout.shape) != want:  # the C ABI reads / writes nb rows from raw pointers
+            raise ValueError(f"dout must have the recorded forward's output shape {want}, got {tuple(dout.shape)}")
         din = None
         if want_dinputs:
-            net = self._tape_net[slot]
             din = torch.empty((dout.shape[0], self.cfg.net[net].in_channels, self.height, self.width), dtype=torch.float32,
                               device=dout.device)
         self._check(self._lib.dyf_train_backward(self._h, slot, dout.data_ptr(), None if din is None else din.data_ptr(),
@@ -460,10 +485,17 @@ class EngineLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, anchor, owner, value):
         ctx.owner = owner
+        ctx.step_id = owner._train_state["step_id"]  # the engine's tapes are single-slot: they belong to the LATEST forward
         return anchor.new_tensor(value)
 
     @staticmethod
     def backward(ctx, grad_out):
+        st = getattr(ctx.owner, "_train_state", None)
+        if st is None or st.get("step_id") != ctx.step_id or st.get("consumed"):
+            raise RuntimeError("this loss belongs to an earlier training forward (or has already been back-propagated): the "
+                               "engine records one step at a time -- call .backward() on a loss before the next p_losses() / "
+                               "get_loss() of the same engine, and only once")
+        st["consumed"] = True
         ctx.owner._train_backward(float(grad_out))
         return None, None, None
 

@@ -228,9 +228,13 @@ class MultiHorizonForecastingDYffusion(nn.Module):
         b = dynamics.shape[0]
         h = self.true_horizon
         prediction_horizon = prediction_horizon or self.prediction_horizon
-        n_outer = max(1, -(-prediction_horizon // h))  # = num_autoregressive_steps + 1 (forecasting_multi_horizon.py:71-76,141)
-        if dynamics.shape[1] < prediction_horizon:
-            raise ValueError(f"Prediction horizon {prediction_horizon} is larger than {dynamics.shape}[1]")
+        if split == "val" and dataloader_idx in (0, None):
+            n_outer = 1  # forecasting_multi_horizon.py:134-136: "Simple evaluation without autoregressive steps", no length check
+        else:
+            assert split in ("val", "test", "predict")
+            n_outer = max(1, -(-prediction_horizon // h))  # = num_autoregressive_steps + 1 (forecasting_multi_horizon.py:71-76,141)
+            if dynamics.shape[1] < prediction_horizon:
+                raise ValueError(f"Prediction horizon {prediction_horizon} is larger than {dynamics.shape}[1]")
         n = self.hparams.num_predictions
         cond = self.get_ensemble_inputs(batch.get("condition", None), n)
         out: Dict[str, Any] = {}
@@ -268,7 +272,7 @@ class MultiHorizonForecastingDYffusion(nn.Module):
 
     def validation_step(self, batch: Dict[str, Any], batch_idx: int = 0, dataloader_idx: int = None, **kwargs):
         """_base_experiment.py:603-607: the evaluation step's fields stay on the GPU (no `torch_to_numpy`)."""
-        results = self.evaluation_step(batch, batch_idx, split="val", **kwargs)
+        results = self.evaluation_step(batch, batch_idx, split="val", dataloader_idx=dataloader_idx, **kwargs)
         self.__dict__.setdefault("_validation_step_outputs", []).append(results)
         return results
 

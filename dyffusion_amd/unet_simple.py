@@ -168,7 +168,8 @@ class UNet(nn.Module):
         pred = eng.train_forward(self._engine_slot, 0, inputs, None if time is None else time.float(), condition,
                                  batch_stats=True, dropout=self.has_dropout)
         value = eng.criterion(pred, targets, kind)
-        self._train_state = dict(eng=eng, pred=pred, targets=targets.float().contiguous(), kind=kind)
+        eng.train_step_id += 1
+        self._train_state = dict(eng=eng, pred=pred, targets=targets.float().contiguous(), kind=kind, step_id=eng.train_step_id)
         if not hasattr(self, "_grad_anchor"):
             self._grad_anchor = torch.zeros((), requires_grad=True)
         loss = EngineLoss.apply(self._grad_anchor, self, float(value))

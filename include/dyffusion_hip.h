@@ -153,7 +153,9 @@ dyf_status dyf_sample(dyf_engine* engine, const float* initial_dev, const float*
                       int32_t nb, const uint8_t* const* masks_dev, const float* noise_dev, void* stream);
 /* Re-seed the engine's counter-based dropout / noise generator (forward and noise counters reset to 0).  The keep bit of
  * an element is a function of (seed, forward index, GLOBAL batch row, dropout layer, element index inside the row), see
- * csrc/common.h: a rollout does not depend on how its rows are batched or sharded over GPUs. */
+ * csrc/common.h: a rollout does not depend on how its rows are batched or sharded over GPUs.  dyf_seed and dyf_set_row_offset
+ * wait for the device to go idle before they write the generator state (hipDeviceSynchronize), so they are ordered against
+ * rollouts in flight on ANY stream. */
 dyf_status dyf_seed(dyf_engine* engine, uint64_t seed);
 /* Global index of this engine's batch row 0 (default 0).  A rank that samples rows [lo, hi) of an N*B-row ensemble
  * (_base_experiment.py:503-538 tiles them, row = n*B + b) sets lo: its rows then draw exactly the masks / noise they

@@ -70,6 +70,16 @@ dyf_status dyf_train_conv_check(dyf_engine* engine, int32_t kind, int32_t n, int
 dyf_status dyf_debug_read_block_output(dyf_engine* engine, int32_t net, int32_t layer, int32_t nb, float* out_dev,
                                        void* stream);
 
+/* Kernel-form log: which kernel FORM every launcher took (conv_halo_rows_kernel<0/1/2>, conv_up_halo_kernel<3/4/5>,
+ * conv_igemm2_kernel<1/2>, conv_igemm_kernel<..>(+splitk), conv_enc0_stem_kernel, stem16_rows_kernel, up2x_quad_kernel,
+ * readout_dma_kernel, ...) and for how many batch rows.  Forms are chosen per launch from tile counts (csrc/conv.hip
+ * launch_conv), so a parity test at NB = 1 does not exercise the kernels a NB = 80 benchmark runs: tests enable the log, run the
+ * engine (a hipGraph capture notes its launches once; replays launch nothing on the host) and assert the forms.  Process-wide.
+ * dyf_debug_form_log(1) clears and enables, (0) disables; dyf_debug_form_log_read writes "form@rows=count;..." (sorted by name),
+ * NUL-terminated and truncated to cap bytes, and returns the untruncated length. */
+void dyf_debug_form_log(int32_t enable);
+int32_t dyf_debug_form_log_read(char* buf, int32_t cap);
+
 #ifdef __cplusplus
 }
 #endif

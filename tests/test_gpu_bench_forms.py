@@ -1,0 +1,152 @@
+"""-m gpu: the kernel FORMS bench.py runs, held to the oracle.
+
+Kernel forms are chosen per launch from tile counts (csrc/conv.hip launch_conv): a full-size parity test at NB = 1..3 runs
+the implicit-GEMM / split-K forms for enc1-enc3 and dec2, while bench.py at NB = 80 (paired interpolator launches: 160 rows)
+runs conv_up_halo_kernel<3/4> (stride-2 halo), conv_halo_rows_kernel<0/1/2>, the persistent conv_enc0_stem_kernel and no
+split-K.  These tests run BASELINE configs[1] exactly as bench.py builds it -- NB = 80 rows, hipGraph, paired launches -- on 80
+DISTINCT inputs, assert from the engine's form log that those kernels were the ones launched, and compare rows of the result
+with CPU oracle rollouts of the same rows (reference: src/diffusion/dyffusion.py:335-426, src/models/unet_simple.py:181-197):
+
+  (a) MC dropout off: rows {0, 41, 63, 64, 79} of t1 / t8 / t16, first call and graph replay, rel-RMS <= 2.5e-2 (the bf16
+      bound of tests/test_gpu_sampler.py);
+  (b) MC dropout on (engine generator): rows {0, 79} against the oracle drawing the engine's masks rebuilt on the host
+      (tests/rng_host.EngineDropout with the row's global index);
+  (c) one interpolator forward over 160 rows (the paired launch size): block outputs of rows {0, 79, 80, 159} against the
+      oracle's taps, <= 1.25 x the oracle's own bf16 storage model per block.
+"""
+import pytest
+import torch
+
+from oracle import nets, sampler
+from tests import rng_host as R
+from tests.gpu_common import DEV, build_dyffusion, mirror_from_params, oracle_rollout, seeded_pair
+from tests.helpers import jload, rel_rms
+
+pytestmark = pytest.mark.gpu
+TOL = 2.5e-2
+NB = 80
+HP = dict(timesteps=16, forward_conditioning="none", interpolate_before_t1=True, schedule="before_t1_only",
+          sampling_type="cold", refine_intermediate_predictions=True, enable_interpolator_dropout=False)
+# forms bench.py's engine must take at NB = 80: {form: batch rows of its launches}; 160 = paired interpolator launches
+BENCH_FORMS = {
+    "conv_enc0_stem_kernel": {80, 160},       # enc0 on the fused stem
+    "conv_up_halo_kernel<4>": {80, 160},      # enc1 (4x4 s2, 128 channels)
+    "conv_up_halo_kernel<3>": {80, 160},      # enc2, enc3 (4x4 s2, 256 / 512 channels)
+    "conv_halo_rows_kernel<2>": {80, 160},    # dec2 (plain 3x3, 256-channel blocks)
+    "conv_halo_rows_kernel<0>": {80, 160},    # dec3, dec4 (fused x2 upsample + 3x3)
+    "conv_halo_rows_kernel<1>": {80, 160},    # dec5 (sparse output columns)
+    "stem16_rows_kernel": {80, 160},
+    "readout_dma_kernel": {80, 160},
+    "up2x_quad_kernel": {80, 160},
+}
+
+
+def _setup():
+    meta = jload("fullsize_checksums.json")
+    mk = meta["model"]
+    PF, PI = seeded_pair(64, 3, 2, seeds=(meta["seeds"]["forecaster"], meta["seeds"]["interpolator"]))
+    g = torch.Generator().manual_seed(4242)
+    x0, c = torch.randn(NB, 3, 221, 42, generator=g), torch.rand(NB, 2, 221, 42, generator=g)
+    return mk, PF, PI, x0, c
+
+
+def _assert_bench_forms(forms):
+    print("kernel forms launched:", {k: sorted(v) for k, v in forms.items()})
+    for form, rows in BENCH_FORMS.items():
+        assert form in forms, f"{form} was not launched: {sorted(forms)}"
+        assert rows <= set(forms[form]), (form, forms[form])
+    assert not any("splitk" in f for f in forms), "split-K forms are small-batch forms"
+    # every MFMA conv of the 256^2 .. 32^2 planes went to one of the forms above: the implicit-GEMM kernels may only have
+    # served the small planes (enc4, enc5, dec0, dec1: 16^2 .. 4^2)
+    assert "conv_direct_kernel" not in forms
+
+
+def test_nb80_graph_paired_rollout_rows_match_the_oracle():
+    """(a)"""
+    mk, PF, PI, x0, c = _setup()
+    m = build_dyffusion(PF, PI, mk, 3, 2, HP, max_batch=NB, use_graph=True)
+    m._ensure_engine((221, 42), NB)
+    eng = m._engine
+    eng.form_log(True)
+    first = {k: v.clone() for k, v in m.sample(x0.to(DEV), static_condition=c.to(DEV)).items()}  # captures the graph
+    forms = eng.form_log_read()
+    eng.form_log(False)
+    _assert_bench_forms(forms)
+    replay = m.sample(x0.to(DEV), static_condition=c.to(DEV))
+    for k in first:
+        assert torch.equal(first[k], replay[k]), k
+    rows = [0, 41, 63, 64, 79]
+    want = oracle_rollout(PF, PI, mk, HP, x0[rows], c[rows])
+    worst = 0.0
+    for k in ("t1_preds", "t8_preds", "t16_preds"):
+        for j, r in enumerate(rows):
+            e = rel_rms(replay[k][r].cpu(), want[k][j])
+            print(f"NB=80 graph+paired, dropout off: {k} row {r}: rel-RMS {e:.3e}")
+            worst = max(worst, e)
+    assert worst <= TOL
+
+
+def test_nb80_graph_paired_rollout_with_mc_dropout_rows_match_the_oracle_on_the_engines_masks():
+    """(b) the benchmarked mode itself: MC dropout drawn by the engine's generator inside the captured, paired rollout."""
+    mk, PF, PI, x0, c = _setup()
+    hp = dict(HP, enable_interpolator_dropout=True)
+    m = build_dyffusion(PF, PI, mk, 3, 2, hp, max_batch=NB, use_graph=True)
+    seed = 20260929
+    m.seed(seed)
+    m._ensure_engine((221, 42), NB)
+    eng = m._engine
+    eng.form_log(True)
+    got = m.sample(x0.to(DEV), static_condition=c.to(DEV))
+    forms = eng.form_log_read()
+    eng.form_log(False)
+    _assert_bench_forms(forms)
+    uh, uw = mk["upsample_dims"]
+    for r in (0, 79):
+        drop = R.EngineDropout(seed, mk["dim"], uh, uw, row_offset=r)
+
+        def i_fn(x, t, cond):
+            drop.begin_forward()
+            return nets.unet_simple_forward(PI, mk, x, t, cond, dropout=drop)
+
+        with torch.no_grad():
+            want = sampler.sample_loop(lambda x, t, cond: nets.unet_simple_forward(PF, mk, x, t, cond), i_fn,
+                                       x0[r:r + 1], c[r:r + 1], hp)
+        for k in ("t1_preds", "t8_preds", "t16_preds"):
+            e = rel_rms(got[k][r].cpu(), want[k][0])
+            print(f"NB=80 graph+paired, MC dropout on: {k} row {r}: rel-RMS {e:.3e}")
+            assert e <= TOL, (k, r, e)
+
+
+def test_nb160_forward_block_outputs_match_the_oracle_taps():
+    """(c) per block, at the row count of a paired interpolator launch."""
+    mk, PF, PI, x0, c = _setup()
+    g = torch.Generator().manual_seed(77)
+    n = 2 * NB
+    xin = torch.randn(n, 6, 221, 42, generator=g)
+    cc = torch.rand(n, 2, 221, 42, generator=g)
+    t = torch.arange(n, dtype=torch.float32) % 15 + 1
+    net = mirror_from_params(PI, mk, 6, 2, 3)
+    net._own_engine(n, (221, 42))
+    eng = net._engine
+    eng.form_log(True)
+    y = net(xin.to(DEV), time=t.to(DEV), condition=cc.to(DEV)).cpu()
+    forms = eng.form_log_read()
+    eng.form_log(False)
+    for form in BENCH_FORMS:
+        assert form in forms and n in forms[form], (form, forms.get(form))
+    rows = [0, 79, 80, 159]
+    taps32, taps16 = {}, {}
+    with torch.no_grad():
+        y32 = nets.unet_simple_forward(PI, mk, xin[rows], t[rows], cc[rows], taps=taps32)
+        y16 = nets.unet_simple_forward_bf16_model(PI, mk, xin[rows], t[rows], cc[rows], taps=taps16)
+    for li, nm in enumerate([f"enc{i}" for i in range(6)] + [f"dec{i}" for i in range(6)]):
+        a = eng.read_block_output(0, li, n)[rows].cpu()
+        ok = torch.isfinite(a)  # the last decoder block computes only the columns the readout reads
+        assert bool(ok.any())
+        for j, r in enumerate(rows):
+            e_eng = rel_rms(a[j][ok[j]], taps32[nm][j][ok[j]])
+            e_model = rel_rms(taps16[nm][j][ok[j]], taps32[nm][j][ok[j]])
+            print(f"{nm} row {r}: engine {e_eng:.2e}  bf16 model {e_model:.2e}")
+            assert e_eng <= 1.25 * e_model + 2e-4, (nm, r)
+    for j, r in enumerate(rows):
+        assert rel_rms(y[r], y32[j]) <= 1.25 * rel_rms(y16[j], y32[j]) + 2e-4, r

@@ -127,3 +127,54 @@ def test_resnet_unet_mirror_state_dict_matches_reference_layout():
         net = D.Unet(dim=cfg["dim"], dim_mults=cfg["dim_mults"], with_time_emb=True, num_input_channels=z["x"].shape[1],
                      num_output_channels=1, num_conditional_channels=n_cond)
         assert {k: tuple(v.shape) for k, v in net.state_dict().items()} == {k: tuple(v.shape) for k, v in P.items()}
+
+
+def test_boundary_metadata_cache_is_keyed_by_the_object_not_its_address():
+    """A freed metadata dict's address is reused by CPython (`id()` collides for consecutive per-step batch dicts): the device
+    copies must be rebuilt for a new dict even at the same address, and reused for the same dict (h calls per batch)."""
+    from dyffusion_amd.boundary import PhysicalSystemsBoundaryConditions
+
+    bc = PhysicalSystemsBoundaryConditions("navier-stokes", engine=None)
+
+    def mk(i):
+        return {"fixed_mask": torch.full((2, 3, 4, 5), bool(i % 2)), "in_velocity": torch.full((2,), float(i)),
+                "vertices": torch.full((2, 2, 4, 5), float(i))}
+
+    seen_ids = set()
+    for i in range(6):  # each dict dies before the next is made: addresses repeat
+        meta = mk(i)
+        seen_ids.add(id(meta))
+        d = bc._prepare(meta, "cpu")
+        assert float(d["in_velocity"][0]) == float(i) and bool(d["fixed_mask"].any()) == bool(i % 2), i
+        assert bc._prepare(meta, "cpu") is d  # same object, unchanged tensors: cache hit
+        meta["in_velocity"].add_(100.0)       # in-place edit of a source tensor: cache miss
+        assert float(bc._prepare(meta, "cpu")["in_velocity"][0]) == float(i) + 100.0
+        del meta, d
+    assert len(seen_ids) < 6, "this interpreter did not reuse an address; the test did not exercise the collision"
+
+
+def test_validation_split_runs_one_outer_iteration_like_the_reference():
+    """forecasting_multi_horizon.py:134-141: split == 'val' with dataloader_idx in (0, None) -> ONE rollout and no length check;
+    every other split runs num_autoregressive_steps + 1 rollouts and refuses batches shorter than the prediction horizon."""
+    calls = []
+
+    class FakeDiffusion(torch.nn.Module):
+        hparams = D.dyffusion._AttrDict(timesteps=4)
+        _engine = None
+
+        def predict_forward(self, inputs, num_predictions=None, **kw):
+            calls.append(inputs.clone())
+            return {f"t{k}_preds": inputs[:, :3] + k for k in range(1, 5)}
+
+    exp = D.MultiHorizonForecastingDYffusion(FakeDiffusion(), num_predictions=2, autoregressive_steps=2)
+    assert exp.prediction_horizon == 12
+    dyn = torch.randn(3, 1 + 4, 3, 6, 5)  # window + ONE horizon: a normal validation batch
+    out = exp.validation_step({"dynamics": dyn.clone()})
+    assert len(calls) == 1 and sorted(out) == sorted([f"t{k}_{s}" for k in range(1, 5) for s in ("preds", "targets")])
+    assert torch.equal(out["t4_targets"], dyn[:, 4])  # batch["dynamics"] not multiplied by 1e6
+    with pytest.raises(ValueError):
+        exp.evaluation_step({"dynamics": dyn.clone()}, split="test")
+    calls.clear()
+    long = torch.randn(3, 1 + 12, 3, 6, 5)
+    out = exp.validation_step({"dynamics": long.clone()}, dataloader_idx=1)  # second val loader: the full autoregressive rollout
+    assert len(calls) == 3 and "t12_preds" in out
