@@ -55,9 +55,11 @@ def _assert_bench_forms(forms):
     for form, rows in BENCH_FORMS.items():
         assert form in forms, f"{form} was not launched: {sorted(forms)}"
         assert rows <= set(forms[form]), (form, forms[form])
-    assert not any("splitk" in f for f in forms), "split-K forms are small-batch forms"
-    # every MFMA conv of the 256^2 .. 32^2 planes went to one of the forms above: the implicit-GEMM kernels may only have
-    # served the small planes (enc4, enc5, dec0, dec1: 16^2 .. 4^2)
+    # the implicit-GEMM kernels (with split-K where a launch has <= 128 tiles) serve only the small planes: enc4, enc5, dec0,
+    # dec1 (16^2 .. 4^2) -- 4 launches per forward; every conv of the 256^2 .. 32^2 planes went to one of the forms above
+    n_fwd = sum(forms["readout_dma_kernel"].values())
+    small = sum(sum(v.values()) for f, v in forms.items() if f.startswith("conv_igemm"))
+    assert small == 4 * n_fwd, (small, n_fwd, forms)
     assert "conv_direct_kernel" not in forms
 
 
