@@ -59,14 +59,18 @@ def random_state(net, seed):
 
 def pmc_traffic(nb):
     """HBM bytes per launch of the dominant kernel.  PMC counters cannot be read from inside this process: the number is
-    REPLAYED from the committed rocprofv3 --pmc passes of this same command (profiles/*_pmc_traffic.json: FETCH_SIZE and
-    WRITE_SIZE in separate passes, corrected as MI355X_MICROARCH.md prescribes), scaled by rows; None when none is on record."""
+    REPLAYED from the newest committed profiles/*_pmc_traffic.json (rocprofv3 --pmc passes, FETCH_SIZE and WRITE_SIZE in separate
+    passes, corrected as MI355X_MICROARCH.md prescribes; the file records the command that produced it), scaled by rows; None
+    when none is on record.  Returns (bytes, description of the source)."""
     import glob
 
     try:
         newest = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[-1]
         with open(newest) as f:
-            return round(json.load(f)["hbm_bytes_per_row"] * nb), os.path.basename(newest)
+            rec = json.load(f)
+        cmd = rec.get("command", "command not recorded")
+        return round(rec["hbm_bytes_per_row"] * nb), (f"replayed, not measured in this run: profiles/{os.path.basename(newest)} "
+                                                      f"(separate rocprofv3 --pmc passes of `{cmd}`), scaled to {nb} rows")
     except Exception:
         return None, None
 
@@ -88,6 +92,102 @@ def build_model(nb, use_graph=True):
     I.load_state_dict(random_state(I, 1))
     m = D.DYffusion(F, D.InterpolatorHandle(I, HORIZON), max_batch=nb, use_graph=use_graph, **DIFFUSION_KW)
     return m, F, I
+
+
+def _resnet_state(net, seed, conv_gain=1.0):
+    sd = random_state(net, seed)
+    for k in sd:
+        if k.endswith(".norm.g"):
+            sd[k] = torch.ones_like(sd[k])
+        elif sd[k].dim() == 4 and conv_gain != 1.0:
+            sd[k] = sd[k] * conv_gain
+    return sd
+
+
+def _resnet_roofline(eng, kind, nb, name, peak_tflops):
+    ms, launches, fl, by = eng.time_kernel_in_rollout(kind, nb)
+    r = {"kernel": name, "avg_ms": round(ms, 4), "launches": launches, "algorithmic_bytes_per_launch": by,
+         "hbm_gbps": round(by / ms / 1e6, 1), "hbm_frac": round(by / ms / 1e6 / 8000.0, 4)}
+    if fl > 0:
+        r.update({"bound": "mfma", "achieved": round(fl / ms / 1e9, 2), "peak": peak_tflops, "unit": "TFLOP/s",
+                  "frac": round(fl / ms / 1e9 / peak_tflops, 4), "flops_per_launch": fl})
+    else:
+        r.update({"bound": "hbm", "achieved": r["hbm_gbps"], "peak": 8000.0, "unit": "GB/s", "frac": r["hbm_frac"]})
+    return r
+
+
+def _time_rollouts(model, x0, reps):
+    model.sample(x0)  # captures the graph
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        out = model.sample(x0)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    assert all(bool(torch.isfinite(v).all()) for v in out.values()), "non-finite forecast"
+    return dt
+
+
+def bench_oisst(dev, nb=300, reps=3):
+    """BASELINE configs[2] shapes on ONE GPU: OISST 60x60x1, ResNet-UNet pair dim 64 mults (1,2,4), DYffusion h=7, k=25 (T=32: 32
+    forecaster + 61 interpolator forwards), data+noise, MC dropout on, hipGraph; NB rows (50 members x 6 tiles)."""
+    import dyffusion_amd as D
+
+    kw = dict(dim=64, dim_mults=(1, 2, 4), with_time_emb=True)
+    F = D.Unet(num_input_channels=1, num_output_channels=1, num_conditional_channels=1, block_dropout=0.3, attn_dropout=0.1, **kw)
+    I = D.Unet(num_input_channels=2, num_output_channels=1, num_conditional_channels=0, block_dropout=0.6, block_dropout1=0.2,
+               attn_dropout=0.6, **kw)
+    F.load_state_dict(_resnet_state(F, 0))
+    I.load_state_dict(_resnet_state(I, 1))
+    dtype = os.environ.get("DYF_BENCH_OISST_DTYPE", D.default_dtype_for(I))
+    m = D.DYffusion(F, D.InterpolatorHandle(I, 7), timesteps=7, forward_conditioning="data+noise", interpolate_before_t1=True,
+                    additional_interpolation_steps=25, refine_intermediate_predictions=False, max_batch=nb, dtype=dtype)
+    m.seed(2)
+    x0 = torch.randn(nb, 1, 60, 60, generator=torch.Generator().manual_seed(3)).to(dev)
+    dt = _time_rollouts(m, x0, reps)
+    eng = m._engine
+    nf, ni = eng.forward_counts()
+    fl = nf * eng.net_flops(0) + ni * eng.net_flops(1)
+    res = {"workload": "BASELINE configs[2] shapes, 1 GPU: OISST 60x60x1, unet.Unet dim 64 mults (1,2,4), DYffusion h=7 k=25 "
+                       "(T=32), data+noise, MC dropout on, hipGraph rollout", "dtype": dtype, "rows": nb,
+           "net_forwards_per_rollout": nf + ni, "fields_per_s": round(nb * 7 / dt, 1), "ms_per_rollout": round(1e3 * dt, 2),
+           "gflop_per_field": round(fl / 7 / 1e9, 2), "whole_rollout_tflops": round(nb * fl / dt / 1e12, 1),
+           "roofline": _resnet_roofline(eng, 0, nb, "level-0 3x3 weight-standardised convs 64->64 @60x60", PEAK_BF16_TFLOPS),
+           "roofline_groupnorm": _resnet_roofline(eng, 2, nb, "GroupNorm(8)+FiLM+SiLU+dropout(+residual) chain, 64 ch @60x60", PEAK_BF16_TFLOPS)}
+    log(f"OISST NB={nb} ({dtype}): {res['ms_per_rollout']} ms per rollout -> {res['fields_per_s']} fields/s")
+    del m
+    return res
+
+
+def bench_synth512(dev, nb=4, reps=1):
+    """BASELINE configs[4] shapes on ONE GPU: synthetic 512x512x4ch, ResNet-UNet pair dim 64 mults (1,2,4) (bottleneck attention
+    over 128^2 = 16 384 tokens), DYffusion h=32 (32 + 61 forwards), fp16, MC dropout on, hipGraph; NB rows."""
+    import dyffusion_amd as D
+
+    I = D.Unet(dim=64, dim_mults=(1, 2, 4), with_time_emb=True, num_input_channels=8, num_output_channels=4,
+               block_dropout=0.1, attn_dropout=0.1)
+    F = D.Unet(dim=64, dim_mults=(1, 2, 4), with_time_emb=True, num_input_channels=4, num_output_channels=4)
+    # conv gains halved: the h=32 recursion of a random-init pair must stay inside fp16's range
+    I.load_state_dict(_resnet_state(I, 1, 0.5))
+    F.load_state_dict(_resnet_state(F, 0, 0.5))
+    m = D.DYffusion(F, D.InterpolatorHandle(I, 32), timesteps=32, forward_conditioning="none", interpolate_before_t1=True,
+                    refine_intermediate_predictions=False, enable_interpolator_dropout=True, max_batch=nb, dtype="fp16")
+    m.seed(2)
+    x0 = torch.randn(nb, 4, 512, 512, generator=torch.Generator().manual_seed(4)).to(dev)
+    dt = _time_rollouts(m, x0, reps)
+    eng = m._engine
+    nf, ni = eng.forward_counts()
+    fl = nf * eng.net_flops(0) + ni * eng.net_flops(1)
+    res = {"workload": "BASELINE configs[4] shapes, 1 GPU: synthetic 512x512x4, unet.Unet dim 64 mults (1,2,4), DYffusion h=32, "
+                       "fp16 MFMA conv/attention, MC dropout on, hipGraph rollout", "dtype": "fp16", "rows": nb,
+           "net_forwards_per_rollout": nf + ni, "fields_per_s": round(nb * 32 / dt, 1), "ms_per_rollout": round(1e3 * dt, 2),
+           "gflop_per_field": round(fl / 32 / 1e9, 2), "whole_rollout_tflops": round(nb * fl / dt / 1e12, 1),
+           "roofline": _resnet_roofline(eng, 1, nb, "flash_attention_kernel (16 384 tokens, 4 heads x 32; dropout on the "
+                                                    "probabilities in the interpolator's launches)", PEAK_BF16_TFLOPS),
+           "roofline_conv": _resnet_roofline(eng, 0, nb, "level-0 3x3 weight-standardised convs 64->64 @512x512", PEAK_BF16_TFLOPS)}
+    log(f"512^2 NB={nb} (fp16): {res['ms_per_rollout']} ms per rollout -> {res['fields_per_s']} fields/s")
+    del m
+    return res
 
 
 def cpu_model():
@@ -165,6 +265,7 @@ def main():
     ap.add_argument("--ensemble-total", type=int, default=int(os.environ.get("DYF_BENCH_ENSEMBLE", "0")),
                     help="strong scaling: a fixed ensemble of this many rows split over the ranks (0 = weak scaling, --nb rows per rank)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-configs", action="store_true", help="skip the OISST (configs[2]) and 512^2 (configs[4]) lines")
     ap.add_argument("--no-graph", action="store_true")
     args = ap.parse_args()
 
@@ -244,6 +345,7 @@ def main():
     eng = model._engine
     n_f, n_i = eng.forward_counts()
     flops_rollout_row = n_f * eng.net_flops(0) + n_i * eng.net_flops(1)
+    exec_rollout_row = n_f * eng.net_flops_executed(0) + n_i * eng.net_flops_executed(1)
     result = {
         "metric": "sampled fields/sec (h-step rollout)", "value": round(fields / dt, 3), "unit": "fields/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
@@ -253,8 +355,13 @@ def main():
                                "DYffusion h=16 cold sampling + refine, interpolator MC dropout p=0.15, hipGraph rollout",
                    "rows_per_gpu": nb, "total_rows": total_rows, "net_forwards_per_rollout": n_f + n_i,
                    "parallelism": f"ensemble-sharded dp{world}" + (" + RCCL all-gather of the forecast stack every step" if gather and world > 1 else ""),
+                   # gflop_per_field / whole_rollout_tflops: the REFERENCE's dense 2*MAC count (what the CPU path executes);
+                   # executed_*: the contractions this engine runs (sparse last decoder block, stem composed into enc0,
+                   # readout at the 4 neighbours the final resample reads)
                    "gflop_per_field": round(flops_rollout_row / HORIZON / 1e9, 2),
-                   "whole_rollout_tflops": round(total_rows * flops_rollout_row * args.steps / dt / 1e12, 2)},
+                   "whole_rollout_tflops": round(total_rows * flops_rollout_row * args.steps / dt / 1e12, 2),
+                   "executed_gflop_per_field": round(exec_rollout_row / HORIZON / 1e9, 2),
+                   "executed_whole_rollout_tflops": round(total_rows * exec_rollout_row * args.steps / dt / 1e12, 2)},
     }
     if rank == 0:
         # roofline of the dominant kernel: the last decoder block's 3x3 conv (256 -> 64 ch @256^2, 40 % of a forward),
@@ -276,10 +383,18 @@ def main():
 
         result["roofline"] = layer_roofline(10, "conv_halo_rows_kernel<0> (dec4: fused x2-upsample + 3x3 conv, 256->128 ch, 64^2->128^2)")
         result["roofline"]["traffic"], result["roofline"]["traffic_source"] = pmc_traffic(nb)
-        if result["roofline"]["traffic_source"]:
-            result["roofline"]["traffic_source"] = "replayed from profiles/" + result["roofline"]["traffic_source"] + " (rocprofv3 --pmc passes of this command)"
         result["roofline_dec5_sparse"] = layer_roofline(
             11, "conv_halo_rows_kernel<1> (dec5: fused x2-upsample + 3x3 conv, 256->64 ch, 128^2->256^2, 104 of 256 output columns)")
+        if world == 1 and not args.no_extra_configs:
+            # BASELINE configs[2] and configs[4] at their named shapes on this GPU (not the headline metric: extra keys)
+            del model, preds
+            torch.cuda.empty_cache()
+            for key, fn in (("config2_oisst", bench_oisst), ("config4_synth512", bench_synth512)):
+                try:
+                    result[key] = fn(dev)
+                except Exception as ex:  # the headline line must survive a failure here
+                    result[key] = {"error": f"{type(ex).__name__}: {ex}"}
+                torch.cuda.empty_cache()
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(F, I)
         print(json.dumps(result), flush=True)

@@ -4,7 +4,7 @@ Product path = HIP kernels in lib/libdyffusion_hip.so (include/dyffusion_hip.h);
 hot path fails loudly when that library is missing.
 """
 from .dyffusion import DYffusion  # noqa: F401
-from .engine import EngineError, HipEngine, net_config, resnet_net_config  # noqa: F401
+from .engine import EngineError, HipEngine, default_dtype_for, net_config, resnet_net_config  # noqa: F401
 from .experiment import InterpolationExperiment, InterpolatorHandle, MultiHorizonForecastingDYffusion  # noqa: F401
 from . import checkpoint  # noqa: F401
 from . import metrics  # noqa: F401

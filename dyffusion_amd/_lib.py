@@ -80,10 +80,13 @@ SYMBOLS = [
     ("dyf_get_sampler_state", C.c_int, [_P, C.c_int32, _P, C.c_int32, _P]),
     ("dyf_plan_forward_counts", C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     ("dyf_net_flops", C.c_int, [_P, C.c_int32, C.POINTER(C.c_double)]),
+    ("dyf_net_flops_executed", C.c_int, [_P, C.c_int32, C.POINTER(C.c_double)]),
     ("dyf_time_conv_layer", C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, C.POINTER(C.c_double),
                                       C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     ("dyf_ensemble_metrics", C.c_int, [_P, _P, _P, C.c_int32, C.c_int64, C.POINTER(C.c_double), _P]),
     ("dyf_time_layer_in_rollout", C.c_int, [_P, C.c_int32, C.c_int32, _P, C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
+    ("dyf_time_kernel_in_rollout", C.c_int, [_P, C.c_int32, C.c_int32, _P, C.POINTER(C.c_double), C.POINTER(C.c_int32),
+                                             C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     ("dyf_op_conv2d", C.c_int, [_P, _P, _P] + [C.c_int32] * 9 + [_P, _P, C.c_int32, C.c_int32, _P, _P]),
     ("dyf_op_upconv2d", C.c_int, [_P, _P, _P] + [C.c_int32] * 5 + [_P, _P, C.c_int32, _P, _P]),
     ("dyf_op_linear_attention", C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, _P]),

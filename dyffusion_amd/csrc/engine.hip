@@ -691,6 +691,26 @@ dyf_status dyf_net_flops(const dyf_engine* e, int32_t which, double* flops) {
     return DYF_OK;
 }
 
+dyf_status dyf_net_flops_executed(const dyf_engine* e, int32_t which, double* flops) {
+    if (!e || !flops || which < 0 || which > 1) return DYF_ERR_INVALID_ARGUMENT;
+    const Net& n = e->net[which];
+    double f = n.flops_per_sample;
+    if (!n.rn && !n.sc && n.loaded) {
+        const UBlock& l = n.blk[11];
+        if (l.up_cols)  // sparse last decoder block: only the output columns the readout reads
+            f -= 2.0 * l.out_h * (double)(l.out_w - (l.up_nvalid0 + l.up_nvalid1)) * l.cout * l.cin * l.k * l.k;
+        if (n.stem_fused) {  // init_conv composed into enc0: a 4 (kh) x 64 (4 pixels x 16 channels) contraction per output
+            const UBlock& b0 = n.blk[0];
+            f -= 2.0 * n.uh * n.uw * (double)n.cin_total * n.dim;
+            f -= 2.0 * b0.out_h * b0.out_w * (double)b0.cout * (b0.cin * b0.k * b0.k - 256.0);
+        }
+        if (n.ro_wfrag)  // readout evaluated at the 4 transposed-conv outputs the final bilinear resample reads
+            f -= 2.0 * 16.0 * n.dim * n.cfg.out_channels * ((double)l.out_h * l.out_w - (double)e->cfg.height * e->cfg.width);
+    }
+    *flops = f;
+    return DYF_OK;
+}
+
 dyf_status dyf_net_forward(dyf_engine* e, int32_t which, const float* inputs_dev, const float* time_dev,
                            const float* condition_dev, float* out_dev, int32_t nb, int32_t dropout_mode,
                            const uint8_t* const* masks_dev, void* stream) {
@@ -1165,15 +1185,9 @@ dyf_status dyf_criterion(dyf_engine* e, const float* pred_dev, const float* targ
     return DYF_OK;
 }
 
-dyf_status dyf_time_layer_in_rollout(dyf_engine* e, int32_t layer, int32_t nb, void* stream, double* avg_ms,
-                                     int32_t* launches) {
-    if (!e || layer < 6 || layer > 11 || !avg_ms) return fail(e, DYF_ERR_INVALID_ARGUMENT, "decoder layer 6..11 expected");
-    if (!e->plan.set || !e->s_init) return fail(e, DYF_ERR_STATE, "needs a plan and one earlier dyf_sample call (its inputs are re-used)");
-    if (e->net[0].rn || e->net[1].rn || e->net[0].sc || e->net[1].sc) return fail(e, DYF_ERR_UNSUPPORTED, "arch unet_simple only");
-    if (nb < 1 || nb > e->cfg.max_batch) return fail(e, DYF_ERR_INVALID_ARGUMENT, "batch size outside [1, max_batch]");
-    HIP_TRY(e, hipSetDevice(e->cfg.device));
-    hipStream_t st = (hipStream_t)stream;
-    e->prof_layer = layer;
+// eager rollout with events around the launches of the kernel class e->prof_layer names; average per nb-row launch equivalent
+static dyf_status time_class_in_rollout(dyf_engine* e, int cls, int nb, hipStream_t st, double* avg_ms, int32_t* launches) {
+    e->prof_layer = cls;
     e->prof_ev.clear();
     e->prof_rows.clear();
     dyf_status r = run_plan(e, nb, nullptr, nullptr, st);  // eager launch of the whole rollout, not the captured graph
@@ -1194,10 +1208,38 @@ dyf_status dyf_time_layer_in_rollout(dyf_engine* e, int32_t layer, int32_t nb, v
     e->prof_rows.clear();
     if (r != DYF_OK) return r;
     if (se != hipSuccess) return fail(e, DYF_ERR_HIP, std::string("rollout: ") + hipGetErrorString(se));
-    if (cnt == 0) return fail(e, DYF_ERR_STATE, "layer was not launched");
+    if (cnt == 0) return fail(e, DYF_ERR_STATE, "kernel class was not launched");
     *avg_ms = tot / units;
     if (launches) *launches = (int32_t)cnt;
     return DYF_OK;
+}
+
+dyf_status dyf_time_layer_in_rollout(dyf_engine* e, int32_t layer, int32_t nb, void* stream, double* avg_ms,
+                                     int32_t* launches) {
+    if (!e || layer < 6 || layer > 11 || !avg_ms) return fail(e, DYF_ERR_INVALID_ARGUMENT, "decoder layer 6..11 expected");
+    if (!e->plan.set || !e->s_init) return fail(e, DYF_ERR_STATE, "needs a plan and one earlier dyf_sample call (its inputs are re-used)");
+    if (e->net[0].rn || e->net[1].rn || e->net[0].sc || e->net[1].sc) return fail(e, DYF_ERR_UNSUPPORTED, "arch unet_simple only");
+    if (nb < 1 || nb > e->cfg.max_batch) return fail(e, DYF_ERR_INVALID_ARGUMENT, "batch size outside [1, max_batch]");
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    return time_class_in_rollout(e, layer, nb, (hipStream_t)stream, avg_ms, launches);
+}
+
+dyf_status dyf_time_kernel_in_rollout(dyf_engine* e, int32_t kind, int32_t nb, void* stream, double* avg_ms, int32_t* launches,
+                                      double* flops, double* algorithmic_bytes) {
+    if (!e || kind < 0 || kind > 2 || !avg_ms) return fail(e, DYF_ERR_INVALID_ARGUMENT, "kind 0 (level-0 3x3 convs), 1 (attention core) or 2 (level-0 GroupNorm chain) expected");
+    if (!e->plan.set || !e->s_init) return fail(e, DYF_ERR_STATE, "needs a plan and one earlier dyf_sample call (its inputs are re-used)");
+    if (!e->net[0].rn || !e->net[1].rn) return fail(e, DYF_ERR_UNSUPPORTED, "arch unet (ResNet-UNet) pair only");
+    if (nb < 1 || nb > e->cfg.max_batch) return fail(e, DYF_ERR_INVALID_ARGUMENT, "batch size outside [1, max_batch]");
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    const double H = e->cfg.height, W = e->cfg.width, d = e->net[1].cfg.dim;
+    int lv = e->net[1].cfg.n_mults - 1;
+    const double tok = (H / (1 << lv)) * (W / (1 << lv));  // tokens of the bottleneck attention
+    if (flops) *flops = kind == 0 ? 2.0 * nb * H * W * 9.0 * d * d : kind == 1 ? (double)nb * 4 * 2.0 * 2.0 * tok * tok * 32 : 0.0;
+    if (algorithmic_bytes)  // 16-bit tensors, every operand once
+        *algorithmic_bytes = kind == 0 ? 2.0 * (2.0 * nb * H * W * d + 9.0 * d * d)
+                           : kind == 1 ? 2.0 * nb * tok * (384.0 + 128.0)
+                                       : 2.0 * nb * H * W * d * 2.0;  // GroupNorm chain, fused ideal: read once, write once
+    return time_class_in_rollout(e, DYF_PROF_RESNET_BASE + kind, nb, (hipStream_t)stream, avg_ms, launches);
 }
 
 void dyf_debug_form_log(int32_t enable) { dyf_form_log_enable(enable != 0); }

@@ -143,6 +143,32 @@ struct dyf_engine {
 
 namespace dyf {
 
+// dyf_time_layer_in_rollout / dyf_time_kernel_in_rollout: HIP events on the launch stream around the launches of one kernel
+// class while a rollout runs eagerly.  `match` = this launch belongs to the class e->prof_layer names.
+struct ProfScope {
+    dyf_engine* e;
+    hipStream_t st;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    ProfScope(dyf_engine* eng, bool match, int rows, hipStream_t s) : e(eng), st(s) {
+        if (!match || e->prof_ev.size() >= 4096) return;
+        if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess || hipEventRecord(e0, st) != hipSuccess) {
+            e0 = e1 = nullptr;
+            return;
+        }
+        e->prof_rows.push_back(rows);
+    }
+    ~ProfScope() {
+        if (!e0) return;
+        (void)hipEventRecord(e1, st);
+        e->prof_ev.emplace_back(e0, e1);
+    }
+};
+// kernel classes of the ResNet-UNet path (dyf_time_kernel_in_rollout `kind`); e->prof_layer = DYF_PROF_RESNET_BASE + kind
+#define DYF_PROF_RESNET_BASE 100
+#define DYF_PROF_RN_CONV3_L0 0   // 3x3 WS-convs of the full-resolution level with cin == cout == dim
+#define DYF_PROF_RN_ATTENTION 1  // bottleneck Attention core (flash kernel)
+#define DYF_PROF_RN_GN_L0 2      // GroupNorm(+FiLM+SiLU+dropout(+residual)) chain of the full-resolution level, dim channels
+
 // ------------------------------------------------------------------------------------------------ error helpers
 inline dyf_status fail(dyf_engine* e, dyf_status st, const std::string& msg) {
     if (e) e->err = msg; else g_create_error = msg;

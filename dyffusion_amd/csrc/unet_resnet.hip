@@ -101,6 +101,8 @@ dyf_status rconv(dyf_engine* e, const el16_t* s0, int c0, const el16_t* s1, int 
     a.splitk_ws = e->ws.splitk; a.splitk_cap = DYF_SPLITK_FLOATS;
     a.n_sel = e->cfg.batch_invariant ? 2 * e->cfg.max_batch : 0;
     const int path = (e->cfg.enable_mfma && conv_mfma_supported(a)) ? 1 : 0;
+    ProfScope prof(e, e->prof_layer == DYF_PROF_RESNET_BASE + DYF_PROF_RN_CONV3_L0 && k == 3 && stride == 1 && h == e->cfg.height &&
+                          w == e->cfg.width && c0 + c1 == cout && residual == nullptr, n, st);
     HIP_TRY(e, launch_conv(a, path, st));
     return DYF_OK;
 }
@@ -455,7 +457,10 @@ dyf_status rn_forward(dyf_engine* e, int which, const Source* srcs, int nsrc, in
         g.x = t1; g.n = nb; g.hw = hh * ww; g.c = b.cout; g.groups = c.groups; g.gamma = b.g1; g.beta = b.be1;
         if (film) { g.film_a = o.coef_a + b.film_off; g.film_c = o.coef_c + b.film_off; g.film_stride = o.coef_stride; }
         g.act = ACT_SILU; g.drop = dc.next(c.block_dropout1); g.residual = nullptr; g.out = t1; g.stats = r->gn_stats;
-        HIP_TRY(e, launch_gn_act(g, st));
+        {
+            ProfScope prof(e, e->prof_layer == DYF_PROF_RESNET_BASE + DYF_PROF_RN_GN_L0 && hh == H && b.cout == c.dim, nb, st);
+            HIP_TRY(e, launch_gn_act(g, st));
+        }
         el16_t* t2 = pool.get();
         TRY(rconv(e, t1, b.cout, nullptr, 0, nb, hh, ww, 3, 1, 1, b.cout, b.w2, r->ones, b.b2, 0, ACT_NONE, DropSpec{}, nullptr, t2, st));
         pool.put(t1);
@@ -469,7 +474,10 @@ dyf_status rn_forward(dyf_engine* e, int which, const Source* srcs, int nsrc, in
         GnActArgs g2{};
         g2.x = t2; g2.n = nb; g2.hw = hh * ww; g2.c = b.cout; g2.groups = c.groups; g2.gamma = b.g2; g2.beta = b.be2;
         g2.act = ACT_SILU; g2.drop = dc.next(c.dropout); g2.residual = res; g2.out = t2; g2.stats = r->gn_stats;
-        HIP_TRY(e, launch_gn_act(g2, st));
+        {
+            ProfScope prof(e, e->prof_layer == DYF_PROF_RESNET_BASE + DYF_PROF_RN_GN_L0 && hh == H && b.cout == c.dim, nb, st);
+            HIP_TRY(e, launch_gn_act(g2, st));
+        }
         if (t3) pool.put(t3);
         *out = t2;
         return DYF_OK;
@@ -505,6 +513,7 @@ dyf_status rn_forward(dyf_engine* e, int which, const Source* srcs, int nsrc, in
             AttnArgs t{};
             t.qkv = qkv; t.n = nb; t.hw = hw; t.heads = HEADS; t.out = ao;
             t.drop = dc.next(c.attn_dropout);  // Attention drops the softmax probabilities
+            ProfScope prof(e, e->prof_layer == DYF_PROF_RESNET_BASE + DYF_PROF_RN_ATTENTION, nb, st);
             HIP_TRY(e, launch_attention(t, st));
         }
         pool.put(qkv);

@@ -13,7 +13,7 @@ import torch
 from torch import Tensor, nn
 
 from . import _lib as L
-from .engine import EngineLoss, HipEngine, collect_train_results, sync_train_weights, sync_weights
+from .engine import EngineLoss, HipEngine, collect_train_results, default_dtype_for, sync_train_weights, sync_weights
 from .unet_simple import UNet, _AttrDict  # noqa: F401
 
 Step = Union[int, float]
@@ -30,7 +30,7 @@ class DYffusion(nn.Module):
                  log_every_t=None, lambda_reconstruction: float = 1.0, lambda_reconstruction2: float = 0.0,
                  interpolator_horizon: Optional[int] = None, interpolator_window: int = 1,
                  enable_forecaster_dropout: bool = False, max_batch: int = 64, use_graph: bool = True,
-                 enable_mfma: bool = True, loss_function: str = "mean_squared_error", dtype: str = "bf16",
+                 enable_mfma: bool = True, loss_function: str = "mean_squared_error", dtype: Optional[str] = None,
                  batch_invariant: bool = False, **kwargs):
         super().__init__()
         if model is None:
@@ -97,7 +97,9 @@ class DYffusion(nn.Module):
         self.sampling_schedule = sampling_schedule or self.full_sampling_schedule
 
         # ---- engine: forecaster + interpolator in one dyf_engine
-        # dtype: "bf16" (default, BASELINE configs[1]) or "fp16" (configs[4]): 16-bit storage / MFMA operand format of the engine
+        # dtype: 16-bit storage / MFMA operand format of the engine: "bf16" or "fp16"; None = the forecaster class's default
+        # (engine.default_dtype_for: bf16 for unet_simple -- BASELINE configs[1] --, fp16 for the ResNet-UNet -- configs[2], [4])
+        dtype = dtype or default_dtype_for(model)
         self._engine_opts = dict(max_batch=max_batch, use_graph=use_graph, enable_mfma=enable_mfma, dtype=dtype,
                                  batch_invariant=batch_invariant)  # batch_invariant: bit-identical rows under any batching / sharding
         self._engine: Optional[HipEngine] = None

@@ -52,6 +52,15 @@ def resnet_net_config(*, in_channels: int, cond_channels: int, out_channels: int
     return cfg
 
 
+def default_dtype_for(net) -> str:
+    """16-bit storage / MFMA operand format an engine is built with when the caller names none: "bf16" for the unet_simple /
+    SimpleConvNet backbones (BASELINE configs[1]: "bf16"), "fp16" for the ResNet-UNet `unet.Unet` (OISST, 512^2: ~60 16-bit
+    roundings per forward and 93 chained forwards per rollout -- bf16's 8 mantissa bits give 4e-2 .. 5e-2 per field over the
+    OISST rollout, fp16's 11 bits 6e-3 at the same MFMA rate and the same bytes).  A network class states
+    its default as `default_engine_dtype`; `net.engine_dtype = "bf16" | "fp16"` or `DYffusion(dtype=...)` override it."""
+    return getattr(net, "engine_dtype", None) or getattr(net, "default_engine_dtype", "bf16")
+
+
 def _f32c(t: torch.Tensor, name: str) -> torch.Tensor:
     if not t.is_cuda:
         raise ValueError(f"{name} must live on the GPU (got {t.device}); the HIP engine has no CPU path")
@@ -289,6 +298,11 @@ class HipEngine:
         self._check(self._lib.dyf_net_flops(self._h, net, C.byref(f)))
         return f.value
 
+    def net_flops_executed(self, net: int) -> float:
+        f = C.c_double()
+        self._check(self._lib.dyf_net_flops_executed(self._h, net, C.byref(f)))
+        return f.value
+
     def time_conv_layer(self, net: int, layer: int, nb: int, iters: int = 20):
         ms, fl, by = C.c_double(), C.c_double(), C.c_double()
         self._check(self._lib.dyf_time_conv_layer(self._h, net, layer, nb, iters, self._stream(), C.byref(ms),
@@ -312,6 +326,14 @@ class HipEngine:
         ms, cnt = C.c_double(), C.c_int32()
         self._check(self._lib.dyf_time_layer_in_rollout(self._h, layer, nb, self._stream(), C.byref(ms), C.byref(cnt)))
         return ms.value, cnt.value
+
+    def time_kernel_in_rollout(self, kind: int, nb: int):
+        """ResNet-UNet pair: (average ms, launches, flops per launch, algorithmic bytes per launch) of kernel class `kind` (0 level-0
+        3x3 convs, 1 bottleneck attention core, 2 level-0 GroupNorm chain) over one eagerly launched rollout of the current plan."""
+        ms, cnt, fl, by = C.c_double(), C.c_int32(), C.c_double(), C.c_double()
+        self._check(self._lib.dyf_time_kernel_in_rollout(self._h, kind, nb, self._stream(), C.byref(ms), C.byref(cnt), C.byref(fl),
+                                                         C.byref(by)))
+        return ms.value, cnt.value, fl.value, by.value
 
     def op_conv2d(self, x_nhwc_bf16: torch.Tensor, weight: torch.Tensor, stride: int, pad: int,
                   scale: Optional[torch.Tensor] = None, shift: Optional[torch.Tensor] = None, act: int = 0,

@@ -11,7 +11,7 @@ import torch
 from torch import Tensor, nn
 
 from . import _lib as L
-from .engine import HipEngine, mark_weights_modified, resnet_net_config, sync_weights, upload_weights
+from .engine import HipEngine, default_dtype_for, mark_weights_modified, resnet_net_config, sync_weights, upload_weights
 from .unet_simple import _AttrDict
 
 HEADS, DIM_HEAD = 4, 32
@@ -51,6 +51,8 @@ def _attention(dim: int, linear: bool) -> nn.Module:
 
 
 class Unet(nn.Module):
+    default_engine_dtype = "fp16"  # engine.default_dtype_for: the ResNet-UNet is held to 1e-2 per field in fp16 (bf16: 4e-2 .. 5e-2)
+
     def __init__(self, dim, init_dim=None, dim_mults=(1, 2, 4, 8), num_conditions: int = 0, resnet_block_groups=8,
                  with_time_emb: bool = False, block_dropout: float = 0.0, block_dropout1: float = 0.0,
                  attn_dropout: float = 0.0, input_dropout: float = 0.0, double_conv_layer: bool = True,
@@ -148,7 +150,7 @@ class Unet(nn.Module):
         if self._engine is None or (self._engine_key != "attached" and
                                     (self._engine_key[0] != key[0] or self._engine_key[1] < nb)):
             cfg = self.engine_net_config()
-            self._engine = HipEngine(cfg, cfg, hw[0], hw[1], max_batch=nb, use_graph=False, dtype=getattr(self, "engine_dtype", "bf16"))
+            self._engine = HipEngine(cfg, cfg, hw[0], hw[1], max_batch=nb, use_graph=False, dtype=default_dtype_for(self))
             self._engine_slot, self._engine_key = L.NET_FORECASTER, key
             upload_weights(self, self._engine, self._engine_slot)
         return self._engine

@@ -12,7 +12,7 @@ import torch
 from torch import Tensor, nn
 
 from . import _lib as L
-from .engine import (EngineLoss, mark_weights_modified, HipEngine, collect_train_results, net_config, sync_train_weights, sync_weights,
+from .engine import (EngineLoss, default_dtype_for, mark_weights_modified, HipEngine, collect_train_results, net_config, sync_train_weights, sync_weights,
                      upload_weights)
 
 
@@ -122,7 +122,7 @@ class UNet(nn.Module):
         if self._engine is None or (self._engine_key != "attached" and
                                     (self._engine_key[0] != key[0] or self._engine_key[1] < nb)):
             cfg = self.engine_net_config()
-            self._engine = HipEngine(cfg, cfg, hw[0], hw[1], max_batch=nb, use_graph=False, dtype=getattr(self, "engine_dtype", "bf16"))
+            self._engine = HipEngine(cfg, cfg, hw[0], hw[1], max_batch=nb, use_graph=False, dtype=default_dtype_for(self))
             self._engine_slot = L.NET_FORECASTER
             self._engine_key = key
             upload_weights(self, self._engine, self._engine_slot)

@@ -235,6 +235,10 @@ dyf_status dyf_apply_boundary_conditions(dyf_engine* engine, const dyf_bc_args* 
 dyf_status dyf_plan_forward_counts(const dyf_engine* engine, int32_t* n_forecaster, int32_t* n_interpolator);
 /* 2*MAC of conv/linear layers of one forward of `net` for one sample (elementwise work excluded). */
 dyf_status dyf_net_flops(const dyf_engine* engine, int32_t net, double* flops_per_sample);
+/* The same count for the contractions the engine actually EXECUTES after dyf_load_weights: arch unet_simple skips the output
+ * columns of the last decoder block that the final resample never reads, contracts init_conv into the first encoder conv, and
+ * evaluates the readout only at the 4 neighbours the final bilinear resample reads (<= dyf_net_flops; equal for other archs). */
+dyf_status dyf_net_flops_executed(const dyf_engine* engine, int32_t net, double* flops_per_sample);
 /* Mean of the training criterion over `count` fp32 elements (src/utilities/utils.py:201-212 `get_loss`, reduction "mean"):
  * kind 0 = L1, 1 = MSE, 2 = smooth-L1 (beta 1).  The reduction the forecaster objective `DYffusion.p_losses`
  * (dyffusion.py:531,557) applies to (prediction, target); out_host[0] receives the scalar. */

@@ -23,6 +23,14 @@ dyf_status dyf_time_conv_layer(dyf_engine* engine, int32_t net, int32_t layer, i
 dyf_status dyf_time_layer_in_rollout(dyf_engine* engine, int32_t layer, int32_t nb, void* stream, double* avg_ms,
                                      int32_t* launches);
 
+/* The same for a ResNet-UNet pair (arch unet.Unet: BASELINE configs[2] OISST, configs[4] 512^2): kind 0 = the 3x3 weight-
+ * standardised convs of the full-resolution level with cin == cout == dim (the largest share of an OISST forward), 1 = the
+ * bottleneck Attention core (flash kernel), 2 = the GroupNorm(+FiLM+SiLU+dropout(+residual)) chain of the full-resolution level
+ * (dim channels; all kernels of one Block's normalisation count as ONE launch).  avg_ms is per launch over nb rows; flops = 2*MAC
+ * of one launch (0 for kind 2), algorithmic_bytes = 16-bit operands once each (kind 2: one read + one write of the tensor). */
+dyf_status dyf_time_kernel_in_rollout(dyf_engine* engine, int32_t kind, int32_t nb, void* stream, double* avg_ms,
+                                      int32_t* launches, double* flops, double* algorithmic_bytes);
+
 /* ---- op-level seam (tests only): one Conv2d + fused epilogue on NHWC bf16 tensors ---------------------------- */
 /* x_dev (N,H,W,Cin) bf16 bits; w (Cout,Cin,kh,kw) host fp32; scale/shift (N,Cout) device fp32 or NULL;
  * y_dev (N,Ho,Wo,Cout) bf16 bits.  act: 0 none, 1 relu, 2 leaky(0.2).  path: 0 direct, 1 MFMA implicit GEMM. */

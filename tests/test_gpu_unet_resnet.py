@@ -1,6 +1,10 @@
 """-m gpu: the ResNet-UNet backbone (src/models/unet.py: WS-conv, GroupNorm+SiLU+FiLM, LinearAttention, Attention,
-channel LayerNorm) on the HIP engine, against the reference's golden outputs and the oracle.  Tolerance as in
-test_gpu_nets.py (bf16 activations): rel-RMS <= 2e-2 per forward (this net is ~3x deeper than unet_simple)."""
+channel LayerNorm) on the HIP engine, against the reference's golden outputs and the oracle.
+
+Both 16-bit builds are tested.  fp16 is this backbone's DEFAULT (dyffusion_amd.engine.default_dtype_for):
+rel-RMS <= 4e-3 per forward, <= 1e-2 per field over a rollout (SURVEY 8c's bound for a 16-bit engine).  bf16 (explicit
+`engine_dtype = "bf16"` / `DYffusion(dtype="bf16")`): <= 2e-2 per forward (the net is ~3x deeper than unet_simple), rollouts as
+stated in the tests."""
 import json
 import os
 
@@ -14,14 +18,30 @@ from tests.gpu_common import DEV
 from tests.helpers import load_npz, rel_rms, split_state
 
 pytestmark = pytest.mark.gpu
-TOL = 2e-2
+TOL = {"bf16": 2e-2, "fp16": 4e-3}
+DTYPES = ["fp16", "bf16"]
 
 
-def mirror(P, cfg, n_in, n_cond, n_out):
+def test_fp16_is_the_default_dtype_of_the_resnet_unet():
+    net = D.Unet(dim=8, dim_mults=(1, 2), with_time_emb=True, num_input_channels=2, num_output_channels=1)
+    assert D.default_dtype_for(net) == "fp16"
+    y = net(torch.randn(1, 2, 8, 8).to(DEV), time=torch.ones(1).to(DEV))
+    assert net._engine.dtype == "fp16" and bool(torch.isfinite(y).all())
+    m = D.DYffusion(net, D.InterpolatorHandle(D.Unet(dim=8, dim_mults=(1, 2), with_time_emb=True, num_input_channels=2,
+                                                     num_output_channels=1), 4), timesteps=4, forward_conditioning="data",
+                    interpolate_before_t1=True)
+    assert m._engine_opts["dtype"] == "fp16"
+    ns = D.UNet(dim=8, with_time_emb=True, upsample_dims=[64, 64], num_input_channels=2, num_output_channels=1)
+    assert D.default_dtype_for(ns) == "bf16"
+
+
+def mirror(P, cfg, n_in, n_cond, n_out, dtype=None):
     net = D.Unet(dim=cfg["dim"], dim_mults=cfg["dim_mults"], with_time_emb=cfg.get("with_time_emb", True),
                  block_dropout=cfg.get("block_dropout", 0.0), block_dropout1=cfg.get("block_dropout1", 0.0),
                  attn_dropout=cfg.get("attn_dropout", 0.0), num_input_channels=n_in, num_output_channels=n_out,
                  num_conditional_channels=n_cond)
+    if dtype is not None:
+        net.engine_dtype = dtype
     net.load_state_dict(P, strict=True)
     return net
 
@@ -34,25 +54,27 @@ def engine_masks(masks, nlev):
     return [(m if i == attn_idx else m.permute(0, 2, 3, 1)).contiguous().to(DEV) for i, m in enumerate(masks)]
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("name", ["net_unet_resnet_a", "net_unet_resnet_b"])
-def test_small_resnet_unets_match_reference_goldens(name):
+def test_small_resnet_unets_match_reference_goldens(name, dtype):
     z = load_npz(name + ".npz")
     P, cfg = split_state(z, "P"), json.loads(str(z["cfg"]))
     x, t = torch.from_numpy(z["x"]), torch.from_numpy(z["t"])
     c = torch.from_numpy(z["c"]) if "c" in z else None
-    net = mirror(P, cfg, x.shape[1], 0 if c is None else c.shape[1], z["y_eval"].shape[1])
+    net = mirror(P, cfg, x.shape[1], 0 if c is None else c.shape[1], z["y_eval"].shape[1], dtype)
     y = net(x.to(DEV), time=t.to(DEV), condition=None if c is None else c.to(DEV)).cpu()
+    assert net._engine.dtype == dtype
     err = rel_rms(y, z["y_eval"])
-    print(name, "eval rel-rms", err)
-    assert err <= TOL
+    print(name, dtype, "eval rel-rms", err)
+    assert err <= TOL[dtype]
     src = nets.DropoutSeeded(int(z["dropout_seed"]), record=True)
     y_or = nets.resnet_unet_forward(P, cfg, x, t, c, dropout=src)
     assert rel_rms(y_or, z["y_drop"]) < 1e-5
     y = net._engine.net_forward(0, x.to(DEV), t.to(DEV), None if c is None else c.to(DEV), dropout_mode=2,
                                 masks=engine_masks(src.masks, len(cfg["dim_mults"]))).cpu()
     err = rel_rms(y, z["y_drop"])
-    print(name, "dropout rel-rms", err)
-    assert err <= TOL
+    print(name, dtype, "dropout rel-rms", err)
+    assert err <= TOL[dtype]
 
 
 def rollout_masks(masks, nlev, per_forward):
@@ -72,9 +94,10 @@ def seeded_unet(dim, mults, cin, cout, seed):
     return st
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("force_igemm2", [False, True], ids=["default-conv-forms", "second-igemm-form"])
 @pytest.mark.parametrize("hw,nb,n_in,n_cond", [((60, 60), 2, 2, 0), ((32, 48), 2, 1, 1)])
-def test_dim64_oisst_shape_matches_oracle(hw, nb, n_in, n_cond, force_igemm2, monkeypatch):
+def test_dim64_oisst_shape_matches_oracle(hw, nb, n_in, n_cond, force_igemm2, dtype, monkeypatch):
     """OISST configuration of the reference (dim 64, mults (1,2,4), 60x60): MFMA conv path.  force_igemm2: every conv with
     cout % 128 == 0 (two-source skip convs, fp32 GroupNorm inputs, residual epilogues) through conv_igemm2_kernel, which
     production selects only for large batches."""
@@ -87,24 +110,25 @@ def test_dim64_oisst_shape_matches_oracle(hw, nb, n_in, n_cond, force_igemm2, mo
     x = torch.randn(nb, n_in, *hw, generator=g)
     c = torch.rand(nb, n_cond, *hw, generator=g) if n_cond else None
     t = torch.tensor([1.0, 4.5][:nb])
-    net = mirror(P, cfg, n_in, n_cond, 1)
+    net = mirror(P, cfg, n_in, n_cond, 1, dtype)
     with torch.no_grad():
         want = nets.resnet_unet_forward(P, cfg, x, t, c)
     got = net(x.to(DEV), time=t.to(DEV), condition=None if c is None else c.to(DEV)).cpu()
     err = rel_rms(got, want)
-    print("resnet-unet dim64", hw, "rel-rms", err)
-    assert err <= TOL
+    print("resnet-unet dim64", dtype, hw, "rel-rms", err)
+    assert err <= TOL[dtype]
     src = nets.DropoutSeeded(9, record=True)
     with torch.no_grad():
         want = nets.resnet_unet_forward(P, cfg, x, t, c, dropout=src)
     got = net._engine.net_forward(0, x.to(DEV), t.to(DEV), None if c is None else c.to(DEV), dropout_mode=2,
                                   masks=engine_masks(src.masks, 3)).cpu()
     err = rel_rms(got, want)
-    print("resnet-unet dim64 dropout", hw, "rel-rms", err)
-    assert err <= TOL
+    print("resnet-unet dim64 dropout", dtype, hw, "rel-rms", err)
+    assert err <= TOL[dtype]
 
 
-def test_oisst_style_rollout_matches_oracle():
+@pytest.mark.parametrize("dtype,tol", [("fp16", 1e-2), ("bf16", 3e-2)])
+def test_oisst_style_rollout_matches_oracle(dtype, tol):
     """DYffusion with the ResNet-UNet pair, OISST settings in miniature: C=1, no static condition, k>0 extra steps,
     forward_conditioning='data+noise' (injected normal draws), refine off, interpolator MC dropout with injected masks."""
     mcfg_i = dict(dim=64, dim_mults=[1, 2], with_time_emb=True, block_dropout=0.3, block_dropout1=0.1, attn_dropout=0.2,
@@ -116,7 +140,7 @@ def test_oisst_style_rollout_matches_oracle():
               time_encoding="dynamics", enable_interpolator_dropout=True)
     F_ = mirror(PF, mcfg_f, 1, 1, 1)
     I_ = mirror(PI, mcfg_i, 2, 0, 1)
-    m = D.DYffusion(F_, D.InterpolatorHandle(I_, 4), max_batch=3, **hp)
+    m = D.DYffusion(F_, D.InterpolatorHandle(I_, 4), max_batch=3, dtype=dtype, **hp)
     g = torch.Generator().manual_seed(12)
     x0 = torch.randn(3, 1, 24, 16, generator=g)
     drop = nets.DropoutSeeded(3, record=True)
@@ -134,11 +158,12 @@ def test_oisst_style_rollout_matches_oracle():
     _, got, _ = m.sample_loop(x0.to(DEV), _masks=rollout_masks(drop.masks, 2, 27), _noise=torch.stack(draws, 0).to(DEV))
     assert sorted(got) == sorted(want)
     worst = max(rel_rms(got[k].cpu(), want[k]) for k in want)
-    print("OISST-style rollout worst rel-rms", worst)
-    assert worst <= 3e-2
+    print("OISST-style rollout", dtype, "worst rel-rms", worst)
+    assert worst <= tol
 
 
-def test_flash_attention_long_sequence_with_dropout():
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_flash_attention_long_sequence_with_dropout(dtype):
     """Bottleneck Attention on the MFMA flash kernel with a sequence that spans many key tiles and is not a multiple
     of the tile sizes (N = 30*26 = 780 tokens), attention-probability dropout injected."""
     cfg = dict(dim=64, dim_mults=[1, 2], with_time_emb=True, block_dropout=0.0, block_dropout1=0.0, attn_dropout=0.3,
@@ -146,20 +171,20 @@ def test_flash_attention_long_sequence_with_dropout():
     P = seeded_unet(64, (1, 2), 2, 1, seed=71)
     g = torch.Generator().manual_seed(8)
     x, t = torch.randn(2, 2, 60, 52, generator=g), torch.tensor([2.0, 5.0])
-    net = mirror(P, cfg, 2, 0, 1)
+    net = mirror(P, cfg, 2, 0, 1, dtype)
     with torch.no_grad():
         want = nets.resnet_unet_forward(P, cfg, x, t, None)
     got = net(x.to(DEV), time=t.to(DEV)).cpu()
-    print("flash attention N=780 eval rel-rms", rel_rms(got, want))
-    assert rel_rms(got, want) <= TOL
+    print("flash attention N=780", dtype, "eval rel-rms", rel_rms(got, want))
+    assert rel_rms(got, want) <= TOL[dtype]
     src = nets.DropoutSeeded(21, record=True)
     with torch.no_grad():
         want = nets.resnet_unet_forward(P, cfg, x, t, None, dropout=src)
     # sites with p > 0: only the attention blocks -> [linattn l0, linattn l1, mid_attn (b,h,n,n), linattn, linattn]
     masks = [(m if i == 2 else m.permute(0, 2, 3, 1)).contiguous().to(DEV) for i, m in enumerate(src.masks)]
     got = net._engine.net_forward(0, x.to(DEV), t.to(DEV), None, dropout_mode=2, masks=masks).cpu()
-    print("flash attention N=780 dropout rel-rms", rel_rms(got, want))
-    assert rel_rms(got, want) <= TOL
+    print("flash attention N=780", dtype, "dropout rel-rms", rel_rms(got, want))
+    assert rel_rms(got, want) <= TOL[dtype]
 
 
 @pytest.mark.parametrize("dtype,tol", [("bf16", 7e-2), ("fp16", 1e-2)])
