@@ -56,6 +56,13 @@ struct ConvArgs {
     long long splitk_cap;
     int splitk;
     int n_sel;          // batch the kernel FORM is selected for (tile-count thresholds, split-K); 0 = this launch's n
+    // GroupNorm statistics of the OUTPUT from the fp32 accumulators (the conv feeds a GroupNorm: unet.py:58-76): when non-null,
+    // a kernel form that supports it (conv_up_halo_kernel<5>; launch_conv_stats reports whether the launch did) writes, per
+    // sample, `gn_slots` partial (sum, sum of squares) pairs of every 8-channel octet of y = acc * A + C over the pixels of one
+    // (tile, wave): gn_part[((n * gn_slots + slot) * (cout / 8) + octet) * 2 + {0, 1}] fp32.  Fixed slots, no atomics: the
+    // consumer (gn_apply_part_kernel) adds them in slot order, so results are reproducible run to run.
+    float* gn_part;
+    int gn_slots;       // set by the launcher
 };
 // floats of ConvArgs::up_border for an n x (2h x 2w) x cout output
 inline size_t conv_up_border_floats(int n, int h, int w, int cout) { return (size_t)n * (4 * (size_t)w + 4 * (size_t)h - 4) * cout; }
@@ -64,6 +71,10 @@ inline size_t conv_up_border_floats(int n, int h, int w, int cout) { return (siz
 hipError_t conv_init();
 bool conv_mfma_supported(const ConvArgs& a);
 hipError_t launch_conv(const ConvArgs& a, int path, hipStream_t stream);
+// launch_conv for a conv whose output feeds a GroupNorm (a.gn_part != null): *gn_slots receives the partial-sum slots per sample
+// the launch wrote (0: this kernel form does not produce statistics -- the caller runs the statistics pass)
+hipError_t launch_conv_stats(const ConvArgs& a, int path, hipStream_t stream, int* gn_slots);
+int conv_halo5_gn_slots(int h, int w);  // slots per sample of conv_up_halo_kernel<5> on an h x w plane (sizing of gn_part)
 void pack_up2x_weights(const float* w, int cout, int cin, el16_t* out);
 // halo form of the fused x2-upsample conv (conv_up_halo.hip): 16x16 low-res tile x 4 phases x 64 channels per workgroup
 bool conv_up_halo_supported(const ConvArgs& a);

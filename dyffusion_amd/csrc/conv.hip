@@ -649,6 +649,18 @@ hipError_t conv_init() {
 }
 
 hipError_t launch_conv(const ConvArgs& a, int path, hipStream_t stream) {
+    if (a.gn_part == nullptr) return launch_conv_stats(a, path, stream, nullptr);
+    ConvArgs b = a;  // statistics are only produced through launch_conv_stats (the caller must learn whether they were)
+    b.gn_part = nullptr;
+    return launch_conv_stats(b, path, stream, nullptr);
+}
+
+hipError_t launch_conv_stats(const ConvArgs& a_in, int path, hipStream_t stream, int* gn_slots) {
+    if (gn_slots) *gn_slots = 0;
+    ConvArgs a = a_in;
+    float* const gn_part = gn_slots ? a_in.gn_part : nullptr;
+    a.gn_part = nullptr;  // only the form below that produces statistics sees the buffer
+    a.gn_slots = 0;
     const long long nsel = a.n_sel > 0 ? a.n_sel : a.n;  // rows the kernel form is chosen for (ConvArgs::n_sel)
     if (path == 1 && conv_mfma_supported(a)) {
         static const bool use_halo = !(getenv("DYF_UP_HALO") && atoi(getenv("DYF_UP_HALO")) == 0);
@@ -688,7 +700,14 @@ hipError_t launch_conv(const ConvArgs& a, int path, hipStream_t stream) {
                 const long long ty = (a.h + 15) / 16, tx = (a.w + 31) / 32;
                 const long long tiles5 = nsel * ty * tx * (a.cout / 64);
                 const bool covers = 10ll * a.h * a.w >= 6ll * ty * 16 * tx * 32;
-                if (b.wpk_up_frag && covers && tiles5 >= h5_min && conv_halo5_supported(b)) return launch_conv_halo5(b, stream);
+                if (b.wpk_up_frag && covers && tiles5 >= h5_min && conv_halo5_supported(b)) {
+                    if (gn_part && a.act == ACT_NONE && a.drop.mode == 0) {  // statistics of the raw conv output
+                        b.gn_part = gn_part;
+                        b.gn_slots = conv_halo5_gn_slots(a.h, a.w);
+                        *gn_slots = b.gn_slots;
+                    }
+                    return launch_conv_halo5(b, stream);
+                }
             }
         }
         if (a.pix_pitch0 == 16 && conv_enc0_stem_supported(a)) {  // enc0 on the fused stem: HBM-bound, its own persistent kernel

@@ -16,6 +16,7 @@
 // weight loads of step s, so by the time the last of those has been consumed the gather has landed.
 #include "conv.h"
 
+#include <cstdlib>
 #include <mutex>
 #include <type_traits>
 #include <unordered_map>
@@ -394,8 +395,19 @@ hipError_t conv_igemm2_init() {
 hipError_t launch_conv_igemm2(const ConvArgs& a, hipStream_t stream) {
     const long long M = (long long)a.n * a.ho * a.wo;
     const int tiles_m = (int)((M + BM - 1) / BM);
-    dyf_form_note(a.cout % 128 == 0 ? "conv_igemm2_kernel<2>" : "conv_igemm2_kernel<1>", a.n);
-    if (a.cout % 128 == 0) {
+    // 256 x 128 tiles whenever cout allows.  Tried (round 3): 256 x 64 tiles when the large ones quantise badly on the 512 resident
+    // workgroups -- the 15 x 15 level of the ResNet-UNet at 300 rows is 528 tiles = two rounds for 1.03 rounds of work, 1 056 small
+    // tiles are three rounds of half the size -- but a small tile takes ~0.75 of a large one's time (every pixel fragment feeds half
+    // as many MFMAs): OISST rollout 675 -> 698 ms.  DYF_IGEMM2_BALANCE=1 re-enables the experiment.
+    static const bool balance = getenv("DYF_IGEMM2_BALANCE") && atoi(getenv("DYF_IGEMM2_BALANCE")) != 0;
+    bool small = a.cout % 128 != 0;
+    if (!small && balance) {
+        const long long sel = a.n_sel > 0 ? ((long long)a.n_sel * a.ho * a.wo + BM - 1) / BM : tiles_m;
+        const long long tb = sel * (a.cout / 128), ts = sel * (a.cout / 64);
+        small = 0.56 * (double)((ts + 511) / 512) < 0.92 * (double)((tb + 511) / 512);
+    }
+    dyf_form_note(small ? "conv_igemm2_kernel<1>" : "conv_igemm2_kernel<2>", a.n);
+    if (!small) {
         const int tiles_n = a.cout / 128;
         hipLaunchKernelGGL(conv_igemm2_kernel<2>, dim3(tiles_m * tiles_n), dim3(256), LDS_TOTAL, stream, a, (int)M, tiles_m, tiles_n);
     } else {

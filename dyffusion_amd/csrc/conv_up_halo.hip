@@ -203,6 +203,9 @@ __global__ __launch_bounds__(256, 2) void conv_up_halo_kernel(ConvArgs a, int ti
     }
 
     auto issue_halo = [&](int chunk) {
+#ifdef HALO_EXP_NO_HALO
+        if (a.n > 0) return;  // timing experiment (wrong results): no halo DMA
+#endif
         const int cb = H::S2 ? (chunk >> 2) << 6 : chunk << 6;
         const bool second = !H::S2 && cb >= a.c0;
         unsigned coff = (unsigned)((second ? cb - a.c0 : cb) * 2);
@@ -467,6 +470,19 @@ __global__ __launch_bounds__(256, 2) void conv_up_halo_kernel(ConvArgs a, int ti
 #undef DSR
 #undef ISSUE_B
 
+#ifdef HALO_EXP_NO_EPI
+    if (a.n > 0) {  // timing experiment (wrong results): no epilogue; the accumulators stay live through an impossible store
+        float sacc = 0.0f;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sacc += acc[nt][mt][r];
+        if (sacc == 12345.678f) a.out_el16[0] = 1;
+        return;
+    }
+#endif
     // ---- epilogue straight from the accumulators.  Lane (l31, hi) of tile (nt, mt) holds pixel l31 of pixel tile mt and
     // channels half*32 + 8*g + 4*hi + {0..3} (g = register group r >> 2).  Groups 2*g2 and 2*g2+1 are packed to bf16 and
     // exchanged between lanes l and l+32 (v_permlane32_swap), after which every lane owns 8 consecutive channels = 16 B.
@@ -545,14 +561,85 @@ __global__ __launch_bounds__(256, 2) void conv_up_halo_kernel(ConvArgs a, int ti
         // 32-channel half outermost, pixel tiles, then the two 16-channel groups of the half: the two 32-byte pieces of a
         // pixel's 64-byte half block are stored back to back and leave the L2 as whole 64-byte writes (with the channel groups
         // outermost PMC counted 1.2-1.65x the algorithmic write bytes)
+        // SP = 5 feeding a GroupNorm (a.gn_part; the launcher asks only with act = none and no dropout: one instantiation carries
+        // the code): a pass of its own over the accumulators, BEFORE the store loop -- per lane (sum, sum of squares) of
+        // y = acc * A + C for the 8 channel octets of the wave's 64 channels (a lane holds channels 8*o + 4*hi + {0..3} of octet
+        // o = 4*nt + g), pixels outside the image masked by a 0 / 1 factor (no branches).  The coefficients pass through an opaque
+        // copy so that the compiler does not merge this pass with the store loop below and keep 128 products alive (it spilled).
+        constexpr bool STATS = SP == 5 && ACT == ACT_NONE && MODE == 0;
+        // SP = 5: the 16 coefficient loads of the wave's 64 channels go out once, together, for the statistics pass AND the store loop
+        float4 k4a[SP == 5 ? 8 : 1], k4c[SP == 5 ? 8 : 1];
+        if constexpr (SP == 5) {
+#pragma unroll
+            for (int o = 0; o < 8; ++o) {
+                k4a[o] = *(const float4*)(a.coef_a + ci_base + (o >> 2) * 32 + 8 * (o & 3));
+                k4c[o] = *(const float4*)(a.coef_c + ci_base + (o >> 2) * 32 + 8 * (o & 3));
+            }
+        }
+        if constexpr (STATS) if (a.gn_part != nullptr) {
+            float mval[4];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) mval[mt] = (lane_valid && orow0 + 2 * mt < a.ho) ? 1.0f : 0.0f;
+            float w[16];
+            // y is formed with an opaque factor 1.0 so that the compiler does not merge this pass with the store loop below and keep
+            // 128 products alive across it (it spilled)
+            float one = 1.0f;
+            asm volatile("" : "+v"(one));
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 ka = k4a[4 * nt + g], kc = k4c[4 * nt + g];
+                    const float kx = ka.x * one, ky = ka.y * one, kz = ka.z * one, kw = ka.w * one;
+                    float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt) {
+                        const float y0 = fmaf(acc[nt][mt][4 * g + 0], kx, kc.x), y1 = fmaf(acc[nt][mt][4 * g + 1], ky, kc.y);
+                        const float y2 = fmaf(acc[nt][mt][4 * g + 2], kz, kc.z), y3 = fmaf(acc[nt][mt][4 * g + 3], kw, kc.w);
+                        s1 = fmaf(mval[mt], (y0 + y1) + (y2 + y3), s1);
+                        s2 = fmaf(mval[mt], fmaf(y0, y0, fmaf(y1, y1, fmaf(y2, y2, y3 * y3))), s2);
+                    }
+                    w[2 * (4 * nt + g)] = s1;
+                    w[2 * (4 * nt + g) + 1] = s2;
+                }
+            // wave reduction of the 16 values as a reduce-scatter butterfly: at stride d the lane keeps the half of its values its
+            // bit selects and adds the partner's copy of that half (8 + 4 + 2 + 1 exchanges), then two plain exchanges over the
+            // remaining lane bits: 17 cross-lane moves instead of 96.  Lane L < 16 ends with value index
+            // 8*(L&1) + 4*((L>>1)&1) + 2*((L>>2)&1) + ((L>>3)&1), index = 2*octet + {0: sum, 1: sum of squares}.
+#pragma unroll
+            for (int half = 8, d = 1; half >= 1; half >>= 1, d <<= 1) {
+                const bool up = (lane & d) != 0;
+#pragma unroll
+                for (int j = 0; j < half; ++j) {
+                    const float send = up ? w[j] : w[j + half];
+                    const float keep = up ? w[j + half] : w[j];
+                    w[j] = keep + __shfl_xor(send, d, 64);
+                }
+            }
+            float tot = w[0];
+            tot += __shfl_xor(tot, 16, 64);
+            tot += __shfl_xor(tot, 32, 64);
+            if (lane < 16) {
+                const int idx = 8 * (lane & 1) + 4 * ((lane >> 1) & 1) + 2 * ((lane >> 2) & 1) + ((lane >> 3) & 1);
+                const int slot = t_in * NWAVES + wave;
+                a.gn_part[((size_t)(n_img * a.gn_slots + slot) * (a.cout >> 3) + tn * 8) * 2 + idx] = tot;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
             float ca[2][8], cc[2][8];
 #pragma unroll
             for (int g2 = 0; g2 < 2; ++g2) {
                 const int cg0 = nt * 32 + 16 * g2;  // + 4*hi: own channels of group 2*g2; + 8: group 2*g2+1
-                const float4 ca0 = *(const float4*)(a.coef_a + ci_base + cg0), ca1 = *(const float4*)(a.coef_a + ci_base + cg0 + 8);
-                const float4 cc0 = *(const float4*)(a.coef_c + ci_base + cg0), cc1 = *(const float4*)(a.coef_c + ci_base + cg0 + 8);
+                float4 ca0, ca1, cc0, cc1;
+                if constexpr (SP == 5) {
+                    ca0 = k4a[4 * nt + 2 * g2]; ca1 = k4a[4 * nt + 2 * g2 + 1];
+                    cc0 = k4c[4 * nt + 2 * g2]; cc1 = k4c[4 * nt + 2 * g2 + 1];
+                } else {
+                    ca0 = *(const float4*)(a.coef_a + ci_base + cg0); ca1 = *(const float4*)(a.coef_a + ci_base + cg0 + 8);
+                    cc0 = *(const float4*)(a.coef_c + ci_base + cg0); cc1 = *(const float4*)(a.coef_c + ci_base + cg0 + 8);
+                }
                 ca[g2][0] = ca0.x * ps; ca[g2][1] = ca0.y * ps; ca[g2][2] = ca0.z * ps; ca[g2][3] = ca0.w * ps;
                 ca[g2][4] = ca1.x * ps; ca[g2][5] = ca1.y * ps; ca[g2][6] = ca1.z * ps; ca[g2][7] = ca1.w * ps;
                 cc[g2][0] = cc0.x * ps; cc[g2][1] = cc0.y * ps; cc[g2][2] = cc0.z * ps; cc[g2][3] = cc0.w * ps;
@@ -579,6 +666,9 @@ __global__ __launch_bounds__(256, 2) void conv_up_halo_kernel(ConvArgs a, int ti
                     uint4 o;
                     o.x = s0[0]; o.y = s1[0]; o.z = s0[1]; o.w = s1[1];
                     const uint32_t sbase = store0 + mt * smt_stride + cg0;
+#ifdef HALO_EXP_NO_STORE
+                    if (a.n < 0)  // timing experiment (wrong results): the epilogue computes, nothing is stored
+#endif
                     if ((SP != 1 && SP != 5) || (lane_valid && (SP != 5 || orow0 + 2 * mt < a.ho)))
                         *(uint4*)(a.out_el16 + (size_t)(sbase + 8 * hi)) = o;
                 }
@@ -719,6 +809,11 @@ bool conv_halo5_supported(const ConvArgs& a) {
     const size_t npix = (size_t)a.n * a.h * a.w;
     return npix * a.c0 * 2 < 0x7F000000ull && (size_t)a.cout * 16 * (a.c0 + a.c1) * 2 < 0x7F000000ull &&
            (size_t)a.n * a.ho * a.wo * a.cout < 0xFFFFFFF0ull;
+}
+
+int conv_halo5_gn_slots(int h, int w) {
+    using H5 = HaloCfg<5>;
+    return ((w + H5::TW - 1) / H5::TW) * ((h + H5::TH - 1) / H5::TH) * NWAVES;
 }
 
 hipError_t launch_conv_halo5(const ConvArgs& a, hipStream_t stream) {

@@ -34,10 +34,16 @@ struct GnActArgs {
     const el16_t* residual; // added last (ResnetBlock: h + residual_conv(x)), or null
     el16_t* out;
     double* stats;          // device scratch of gn_stats_doubles(n, groups) doubles for the vectorised form, or null
+    // statistics already taken by the producing conv's epilogue (ConvArgs::gn_part, from the fp32 accumulators): per sample
+    // `part_slots` partial (sum, sum of squares) pairs per 8-channel octet, [n][part_slots][c / 8][2] fp32, or null.  The apply
+    // kernel then finalises (mean, 1/std) itself, adding the slots in index order: ONE launch and no statistics pass over the tensor.
+    const float* part = nullptr;
+    int part_slots = 0;
 };
 #define GN_MAX_BLOCKS 64    // workgroups per sample of the statistics pass
 inline size_t gn_stats_doubles(size_t n, size_t groups) { return n * groups * (2 * GN_MAX_BLOCKS + 1); }
 hipError_t launch_gn_act(const GnActArgs& a, hipStream_t s);
+bool gn_part_supported(int c, int groups);
 
 // K6: channel LayerNorm (gain only, biased variance, eps 1e-5) + optional Dropout (unet.py:43-52; attention.py:12)
 struct LayerNormArgs {

@@ -480,9 +480,153 @@ __global__ __launch_bounds__(256) void gn_apply_walk_kernel(GnActArgs a, const f
     }
 }
 
+// gn_apply_walk_kernel with the statistics coming from the producing conv's epilogue (GnActArgs::part): the workgroup first
+// finalises (mean, 1/std) of its sample's groups in LDS -- thread (value v = group / {sum, sum of squares}, slice) adds its share
+// of the slots in index order in fp64, the slices are added in order -- so neither a statistics pass nor a finalize launch runs.
+__global__ __launch_bounds__(256) void gn_apply_part_kernel(GnActArgs a) {
+    __shared__ double red[256];
+    __shared__ float2 mr_s[64];
+    const int chunks = a.c >> 3, cpg = a.c / a.groups;
+    const int n = blockIdx.y;
+    const int q = threadIdx.x & (chunks - 1), row = threadIdx.x / chunks, rows = 256 / chunks;
+    // the tensor loads go out first: the finalisation below (two dependent L2 round trips and three barriers) runs under them
+    const int p0 = blockIdx.x * rows * GP + row;
+    uint4 v[GP], r[GP];
+#pragma unroll
+    for (int i = 0; i < GP; ++i) {
+        const int p = min(p0 + i * rows, a.hw - 1);  // past the end: re-read the last pixel (not stored)
+        const size_t e0 = ((size_t)n * a.hw + p) * a.c + q * 8;
+        v[i] = *(const uint4*)(a.x + e0);
+        if (a.residual) r[i] = *(const uint4*)(a.residual + e0);
+    }
+    {
+        const int nval = 2 * a.groups, opg = cpg >> 3;      // octets per group
+        const int nsl = 256 / nval;                          // slices (groups <= 64 -> nsl >= 2)
+        const int vi = threadIdx.x % nval, sl = threadIdx.x / nval;
+        double acc = 0.0;
+        if (sl < nsl) {
+            const int g = vi >> 1, k = vi & 1;
+            const float* p = a.part + (size_t)n * a.part_slots * chunks * 2;
+            for (int s = sl; s < a.part_slots; s += nsl)
+                for (int o = 0; o < opg; ++o) acc += (double)p[((size_t)s * chunks + g * opg + o) * 2 + k];
+        }
+        red[threadIdx.x] = acc;
+        __syncthreads();
+        if (threadIdx.x < nval) {
+            double t = 0.0;
+            for (int i = 0; i < nsl; ++i) t += red[i * nval + threadIdx.x];
+            red[threadIdx.x] = t;
+        }
+        __syncthreads();
+        if (threadIdx.x < a.groups) {
+            const double inv = 1.0 / ((double)a.hw * cpg);
+            const double mean = red[2 * threadIdx.x] * inv;
+            const double var = red[2 * threadIdx.x + 1] * inv - mean * mean;
+            mr_s[threadIdx.x] = make_float2((float)mean, rsqrtf(fmaxf((float)var, 0.0f) + 1e-5f));
+        }
+        __syncthreads();
+    }
+    const int g = (q * 8) / cpg;
+    const float2 ms = mr_s[g];
+    const float mean = ms.x, rstd = ms.y;
+    const float4 g0 = *(const float4*)(a.gamma + q * 8), g1 = *(const float4*)(a.gamma + q * 8 + 4);
+    const float4 b0 = *(const float4*)(a.beta + q * 8), b1 = *(const float4*)(a.beta + q * 8 + 4);
+    float A[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+    float C[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        A[t] *= rstd;
+        C[t] = fmaf(-mean, A[t], C[t]);
+    }
+    if (a.film_a) {
+        const size_t fi = (size_t)n * a.film_stride + q * 8;
+        const float4 fa0 = *(const float4*)(a.film_a + fi), fa1 = *(const float4*)(a.film_a + fi + 4);
+        const float4 fc0 = *(const float4*)(a.film_c + fi), fc1 = *(const float4*)(a.film_c + fi + 4);
+        const float fa[8] = {fa0.x, fa0.y, fa0.z, fa0.w, fa1.x, fa1.y, fa1.z, fa1.w};
+        const float fc[8] = {fc0.x, fc0.y, fc0.z, fc0.w, fc1.x, fc1.y, fc1.z, fc1.w};
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            A[t] *= fa[t];
+            C[t] = fmaf(C[t], fa[t], fc[t]);
+        }
+    }
+    const RngKey key = drop_row_key(a.drop, n);
+    const uint32_t row0 = (uint32_t)((size_t)n * a.hw * a.c);
+#pragma unroll
+    for (int i = 0; i < GP; ++i) {
+        const int p = p0 + i * rows;
+        const size_t e0 = ((size_t)n * a.hw + min(p, a.hw - 1)) * a.c + q * 8;
+        const uint32_t w[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+        float y[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const float xv = (t & 1) ? el16_hi(w[t >> 1]) : el16_lo(w[t >> 1]);
+            y[t] = fmaf(xv, A[t], C[t]);
+        }
+        act_drop<8>(y, (uint32_t)e0, row0, a.act, a.drop, key);
+        if (a.residual) {
+            const uint32_t rw[4] = {r[i].x, r[i].y, r[i].z, r[i].w};
+#pragma unroll
+            for (int t = 0; t < 8; ++t) y[t] += (t & 1) ? el16_hi(rw[t >> 1]) : el16_lo(rw[t >> 1]);
+        }
+        if (p < a.hw)
+            *(uint4*)(a.out + e0) = make_uint4(pack_el16x2(y[0], y[1]), pack_el16x2(y[2], y[3]), pack_el16x2(y[4], y[5]), pack_el16x2(y[6], y[7]));
+    }
+}
+
+// Large planes (512^2: 2 048 slots per sample): the finalisation is too much to repeat in every workgroup of the apply pass --
+// one workgroup per sample does it once (same order of additions as gn_apply_part_kernel's prologue) and gn_apply_walk_kernel runs.
+__global__ __launch_bounds__(256) void gn_finalize_part_kernel(const float* part, int part_slots, int c, int groups, int hw, float2* mr) {
+    __shared__ double red[256];
+    const int chunks = c >> 3, cpg = c / groups, n = blockIdx.x;
+    const int nval = 2 * groups, opg = cpg >> 3, nsl = 256 / nval;
+    const int vi = threadIdx.x % nval, sl = threadIdx.x / nval;
+    double acc = 0.0;
+    if (sl < nsl) {
+        const int g = vi >> 1, k = vi & 1;
+        const float* p = part + (size_t)n * part_slots * chunks * 2;
+        for (int s = sl; s < part_slots; s += nsl)
+            for (int o = 0; o < opg; ++o) acc += (double)p[((size_t)s * chunks + g * opg + o) * 2 + k];
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    if (threadIdx.x < nval) {
+        double t = 0.0;
+        for (int i = 0; i < nsl; ++i) t += red[i * nval + threadIdx.x];
+        red[threadIdx.x] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x < groups) {
+        const double inv = 1.0 / ((double)hw * cpg);
+        const double mean = red[2 * threadIdx.x] * inv;
+        const double var = red[2 * threadIdx.x + 1] * inv - mean * mean;
+        mr[(size_t)n * groups + threadIdx.x] = make_float2((float)mean, rsqrtf(fmaxf((float)var, 0.0f) + 1e-5f));
+    }
+}
+
+bool gn_part_supported(int c, int groups) {  // shapes gn_apply_part_kernel takes (the caller asks before requesting conv statistics)
+    const int chunks = c >> 3;
+    return c % 8 == 0 && groups >= 1 && c % groups == 0 && (c / groups) % 8 == 0 && groups <= 64 && (chunks & (chunks - 1)) == 0 && chunks <= 256;
+}
+
 hipError_t launch_gn_act(const GnActArgs& a, hipStream_t s) {
     const int cpg = a.c / a.groups;
+    if (a.part && a.part_slots > 0 && gn_part_supported(a.c, a.groups) && a.n <= 65535) {
+        const int chunks = a.c >> 3, rows = 256 / chunks;
+        const unsigned bx = (unsigned)((a.hw + rows * GP - 1) / (rows * GP));
+        if ((long long)a.part_slots * chunks * 2 > 1024 && a.stats) {  // > 4 KB of partials per sample: finalise once per sample
+            float2* mr = (float2*)(a.stats + (size_t)a.n * a.groups * 2 * GN_MAX_BLOCKS);
+            dyf_form_note("gn_finalize_part_kernel+gn_apply", a.n);
+            hipLaunchKernelGGL(gn_finalize_part_kernel, dim3(a.n), dim3(256), 0, s, a.part, a.part_slots, a.c, a.groups, a.hw, mr);
+            hipLaunchKernelGGL(gn_apply_walk_kernel, dim3(bx, a.n), dim3(256), 0, s, a, (const float2*)mr);
+            return hipGetLastError();
+        }
+        dyf_form_note("gn_apply_part_kernel", a.n);
+        hipLaunchKernelGGL(gn_apply_part_kernel, dim3(bx, a.n), dim3(256), 0, s, a);
+        return hipGetLastError();
+    }
     if (a.stats && (a.c % 8 == 0) && (cpg % 8 == 0) && a.groups <= 64) {
+        dyf_form_note("gn_stats_kernel+gn_apply", a.n);
         const long long per_sample = (long long)a.hw * (a.c >> 3);
         // >= 4 passes of 256 lanes per workgroup, at most GN_MAX_BLOCKS workgroups per sample (their partials are added in order)
         const unsigned bx = (unsigned)std::max<long long>(1, std::min<long long>((per_sample + 1023) / 1024, GN_MAX_BLOCKS));

@@ -50,6 +50,8 @@ struct RNet {
     int stem_ksteps = 0;
     float *ones = nullptr, *zeros = nullptr;
     double* gn_stats = nullptr;    // [max_batch][groups][2]
+    float* gn_part = nullptr;      // GroupNorm partial sums written by conv epilogues (ConvArgs::gn_part), gn_part_floats
+    size_t gn_part_floats = 0;
     float* la_scratch = nullptr;   // LinearAttention partials + context
     size_t buf_elems = 0;          // elements of one pool buffer at max_batch
     std::vector<el16_t*> pool;
@@ -91,7 +93,8 @@ struct DropCtx {  // walks the dropout sites in execution order (same order as t
 
 dyf_status rconv(dyf_engine* e, const el16_t* s0, int c0, const el16_t* s1, int c1, int n, int h, int w, int k, int stride,
                  int pad, int cout, const el16_t* wpk, const float* coef_a, const float* coef_c, int coef_stride, int act,
-                 const DropSpec& drop, const el16_t* residual, el16_t* out, hipStream_t st) {
+                 const DropSpec& drop, const el16_t* residual, el16_t* out, hipStream_t st, float* gn_part = nullptr,
+                 int* gn_slots = nullptr) {
     ConvArgs a{};
     a.src0 = s0; a.c0 = c0; a.src1 = s1; a.c1 = c1; a.n = n; a.h = h; a.w = w;
     a.ho = (h + 2 * pad - k) / stride + 1; a.wo = (w + 2 * pad - k) / stride + 1;
@@ -103,7 +106,12 @@ dyf_status rconv(dyf_engine* e, const el16_t* s0, int c0, const el16_t* s1, int 
     const int path = (e->cfg.enable_mfma && conv_mfma_supported(a)) ? 1 : 0;
     ProfScope prof(e, e->prof_layer == DYF_PROF_RESNET_BASE + DYF_PROF_RN_CONV3_L0 && k == 3 && stride == 1 && h == e->cfg.height &&
                           w == e->cfg.width && c0 + c1 == cout && residual == nullptr, n, st);
-    HIP_TRY(e, launch_conv(a, path, st));
+    if (gn_part && gn_slots) {
+        a.gn_part = gn_part;
+        HIP_TRY(e, launch_conv_stats(a, path, st, gn_slots));
+    } else {
+        HIP_TRY(e, launch_conv(a, path, st));
+    }
     return DYF_OK;
 }
 
@@ -250,6 +258,13 @@ dyf_status rn_alloc_workspace(dyf_engine* e) {
         RNet* r = n.rn;
         {
             dyf_status s = dev_alloc(e, &r->gn_stats, gn_stats_doubles((size_t)e->cfg.max_batch, (size_t)n.cfg.groups));
+            if (s != DYF_OK) return s;
+        }
+        {
+            int maxc = 0;
+            for (auto& b : r->blocks) maxc = std::max(maxc, b.cout);
+            r->gn_part_floats = (size_t)e->cfg.max_batch * conv_halo5_gn_slots(e->cfg.height, e->cfg.width) * (maxc / 8 + 1) * 2;
+            dyf_status s = dev_alloc(e, &r->gn_part, r->gn_part_floats);
             if (s != DYF_OK) return s;
         }
         {
@@ -452,17 +467,25 @@ dyf_status rn_forward(dyf_engine* e, int which, const Source* srcs, int nsrc, in
     auto resblock = [&](const RBlockW& b, const el16_t* a0, int c_a0, const el16_t* a1, int c_a1, int hh, int ww,
                         el16_t** out) -> dyf_status {
         el16_t* t1 = pool.get();
-        TRY(rconv(e, a0, c_a0, a1, c_a1, nb, hh, ww, 3, 1, 1, b.cout, b.w1, r->ones, b.b1, 0, ACT_NONE, DropSpec{}, nullptr, t1, st));
+        // GroupNorm statistics from the conv's fp32 accumulators where the kernel form produces them (conv_up_halo_kernel<5>)
+        static const bool fuse_stats = !(getenv("DYF_GN_CONV_STATS") && atoi(getenv("DYF_GN_CONV_STATS")) == 0);
+        const bool ask = fuse_stats && gn_part_supported(b.cout, c.groups) &&
+                         (size_t)nb * conv_halo5_gn_slots(hh, ww) * (b.cout / 8) * 2 <= r->gn_part_floats;
+        int slots1 = 0, slots2 = 0;
+        TRY(rconv(e, a0, c_a0, a1, c_a1, nb, hh, ww, 3, 1, 1, b.cout, b.w1, r->ones, b.b1, 0, ACT_NONE, DropSpec{}, nullptr, t1, st,
+                  ask ? r->gn_part : nullptr, &slots1));
         GnActArgs g{};
         g.x = t1; g.n = nb; g.hw = hh * ww; g.c = b.cout; g.groups = c.groups; g.gamma = b.g1; g.beta = b.be1;
         if (film) { g.film_a = o.coef_a + b.film_off; g.film_c = o.coef_c + b.film_off; g.film_stride = o.coef_stride; }
         g.act = ACT_SILU; g.drop = dc.next(c.block_dropout1); g.residual = nullptr; g.out = t1; g.stats = r->gn_stats;
+        if (slots1 > 0) { g.part = r->gn_part; g.part_slots = slots1; }
         {
             ProfScope prof(e, e->prof_layer == DYF_PROF_RESNET_BASE + DYF_PROF_RN_GN_L0 && hh == H && b.cout == c.dim, nb, st);
             HIP_TRY(e, launch_gn_act(g, st));
         }
         el16_t* t2 = pool.get();
-        TRY(rconv(e, t1, b.cout, nullptr, 0, nb, hh, ww, 3, 1, 1, b.cout, b.w2, r->ones, b.b2, 0, ACT_NONE, DropSpec{}, nullptr, t2, st));
+        TRY(rconv(e, t1, b.cout, nullptr, 0, nb, hh, ww, 3, 1, 1, b.cout, b.w2, r->ones, b.b2, 0, ACT_NONE, DropSpec{}, nullptr, t2, st,
+                  ask ? r->gn_part : nullptr, &slots2));
         pool.put(t1);
         const el16_t* res = a0;  // identity shortcut (single source, cin == cout)
         el16_t* t3 = nullptr;
@@ -474,6 +497,7 @@ dyf_status rn_forward(dyf_engine* e, int which, const Source* srcs, int nsrc, in
         GnActArgs g2{};
         g2.x = t2; g2.n = nb; g2.hw = hh * ww; g2.c = b.cout; g2.groups = c.groups; g2.gamma = b.g2; g2.beta = b.be2;
         g2.act = ACT_SILU; g2.drop = dc.next(c.dropout); g2.residual = res; g2.out = t2; g2.stats = r->gn_stats;
+        if (slots2 > 0) { g2.part = r->gn_part; g2.part_slots = slots2; }
         {
             ProfScope prof(e, e->prof_layer == DYF_PROF_RESNET_BASE + DYF_PROF_RN_GN_L0 && hh == H && b.cout == c.dim, nb, st);
             HIP_TRY(e, launch_gn_act(g2, st));

@@ -152,3 +152,100 @@ def test_nb160_forward_block_outputs_match_the_oracle_taps():
             assert e_eng <= 1.25 * e_model + 2e-4, (nm, r)
     for j, r in enumerate(rows):
         assert rel_rms(y[r], y32[j]) <= 1.25 * rel_rms(y16[j], y32[j]) + 2e-4, r
+
+
+# ------------------------------------------------------------------------------------------------ BASELINE configs[2] (OISST)
+# The same question for the ResNet-UNet path: at NB = 300 (bench.py's config2_oisst line) the level-0 / level-1 3x3 convs run on
+# conv_up_halo_kernel<5> with GroupNorm statistics taken in its epilogue and applied by gn_apply_part_kernel, the 15 x 15 level on
+# conv_igemm2_kernel<2> -- none of which a 2-row parity test launches.  Reference: src/models/unet.py:58-109, 266-315.
+OISST_FORMS = ["conv_up_halo_kernel<5>", "conv_igemm2_kernel<2>", "gn_apply_part_kernel", "gn_stats_kernel+gn_apply"]
+OISST_TOL = {"fp16": (4e-3, 1e-2), "bf16": (2e-2, 7e-2)}  # (per forward, per field over the T=32 rollout)
+
+
+def _oisst_setup(block_dropout=0.0, block_dropout1=0.0, attn_dropout=0.0):
+    import json as _json
+
+    from tests.helpers import load_npz
+    from tests.test_gpu_unet_resnet import seeded_unet
+    z = load_npz("fullsize_oisst_fields.npz")
+    meta = _json.loads(str(z["meta"]))
+    cfg = dict(meta["model"], resnet_block_groups=8, input_dropout=0.0, upsample_dims=None, block_dropout=block_dropout,
+               block_dropout1=block_dropout1, attn_dropout=attn_dropout)
+    PF = seeded_unet(64, (1, 2, 4), 2, 1, seed=meta["seeds"]["forecaster"])
+    PI = seeded_unet(64, (1, 2, 4), 2, 1, seed=meta["seeds"]["interpolator"])
+    return cfg, PF, PI
+
+
+@pytest.mark.parametrize("dtype", ["fp16", "bf16"])
+def test_oisst_nb300_forward_with_injected_dropout_matches_the_oracle(dtype):
+    """One interpolator forward over 300 DISTINCT rows, eval and with every dropout site active (masks recorded from the oracle's
+    seeded draws and injected): all 300 rows against the oracle."""
+    from tests.test_gpu_unet_resnet import engine_masks, mirror
+    cfg, _, PI = _oisst_setup(block_dropout=0.3, block_dropout1=0.1, attn_dropout=0.2)
+    nb = 300
+    g = torch.Generator().manual_seed(31)
+    x, t = torch.randn(nb, 2, 60, 60, generator=g), (torch.arange(nb) % 7 + 1).float() * 0.5
+    net = mirror(PI, cfg, 2, 0, 1, dtype)
+    net._own_engine(nb, (60, 60))
+    eng = net._engine
+    eng.form_log(True)
+    got = net(x.to(DEV), time=t.to(DEV)).cpu()
+    forms = eng.form_log_read()
+    eng.form_log(False)
+    print("kernel forms launched:", {k: sorted(v) for k, v in forms.items()})
+    for f in OISST_FORMS:
+        assert f in forms and nb in forms[f], (f, forms.get(f))
+    with torch.no_grad():
+        want = nets.resnet_unet_forward(PI, cfg, x, t, None)
+    errs = torch.tensor([rel_rms(got[r], want[r]) for r in range(nb)])
+    print(f"OISST NB=300 forward ({dtype}), eval: rel-RMS per row max {float(errs.max()):.3e} mean {float(errs.mean()):.3e}")
+    assert float(errs.max()) <= OISST_TOL[dtype][0]
+    src = nets.DropoutSeeded(17, record=True)
+    with torch.no_grad():
+        want = nets.resnet_unet_forward(PI, cfg, x, t, None, dropout=src)
+    got = eng.net_forward(0, x.to(DEV), t.to(DEV), None, dropout_mode=2, masks=engine_masks(src.masks, 3)).cpu()
+    errs = torch.tensor([rel_rms(got[r], want[r]) for r in range(nb)])
+    print(f"OISST NB=300 forward ({dtype}), dropout injected: rel-RMS per row max {float(errs.max()):.3e} mean {float(errs.mean()):.3e}")
+    assert float(errs.max()) <= OISST_TOL[dtype][0]
+
+
+@pytest.mark.parametrize("dtype", ["fp16", "bf16"])
+def test_oisst_nb300_rollout_rows_match_the_oracle(dtype):
+    """The T = 32 rollout (32 forecaster + 61 interpolator forwards, data+noise with injected normal draws, dropout off) over 300
+    distinct rows: rows {0, 150, 299} of all seven fields against oracle rollouts of those rows."""
+    import dyffusion_amd as D
+    from tests.test_gpu_unet_resnet import mirror
+    cfg, PF, PI = _oisst_setup()
+    nb = 300
+    F_, I_ = mirror(PF, cfg, 1, 1, 1), mirror(PI, cfg, 2, 0, 1)
+    hp = dict(timesteps=7, schedule="before_t1_only", additional_interpolation_steps=25, interpolate_before_t1=True,
+              sampling_type="cold", refine_intermediate_predictions=False, forward_conditioning="data+noise",
+              time_encoding="dynamics", enable_interpolator_dropout=False)
+    m = D.DYffusion(F_, D.InterpolatorHandle(I_, 7), max_batch=nb, dtype=dtype, **hp)
+    g = torch.Generator().manual_seed(33)
+    x0 = torch.randn(nb, 1, 60, 60, generator=g)
+    noise = torch.randn(32, nb, 1, 60, 60, generator=g)
+    m._ensure_engine((60, 60), nb)
+    eng = m._engine
+    eng.form_log(True)
+    _, got, _ = m.sample_loop(x0.to(DEV), _noise=noise.to(DEV))
+    forms = eng.form_log_read()
+    eng.form_log(False)
+    for f in OISST_FORMS[:3]:
+        assert f in forms and nb in forms[f], (f, forms.get(f))
+    rows = [0, 150, 299]
+    it = iter(range(32))
+
+    def nf(tensor):
+        return noise[next(it)][rows]
+
+    with torch.no_grad():
+        want = sampler.sample_loop(lambda x, t, cnd: nets.resnet_unet_forward(PF, cfg, x, t, cnd),
+                                   lambda x, t, cnd: nets.resnet_unet_forward(PI, cfg, x, t, cnd), x0[rows], None, hp, noise_fn=nf)
+    assert sorted(got) == sorted(want)
+    worst = 0.0
+    for k in sorted(want):
+        for j, r in enumerate(rows):
+            worst = max(worst, rel_rms(got[k][r].cpu(), want[k][j]))
+    print(f"OISST NB=300 rollout ({dtype}): worst rel-RMS over rows {rows} and 7 fields {worst:.3e}")
+    assert worst <= OISST_TOL[dtype][1]

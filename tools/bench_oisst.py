@@ -21,10 +21,12 @@ for net, seed in ((F, 0), (I, 1)):
     for k in sd:
         if k.endswith(".norm.g"):
             sd[k] = torch.ones_like(sd[k])
+        elif sd[k].dim() == 4:
+            sd[k] = sd[k] * 0.5  # the T=32 recursion of a random-init pair must stay inside fp16's range (as bench.py)
     net.load_state_dict(sd)
 m = D.DYffusion(F, D.InterpolatorHandle(I, 7), timesteps=7, forward_conditioning="data+noise", interpolate_before_t1=True,
                 additional_interpolation_steps=25, refine_intermediate_predictions=False, max_batch=nb,
-                use_graph=os.environ.get("DYF_NO_GRAPH", "0") != "1")
+                use_graph=os.environ.get("DYF_NO_GRAPH", "0") != "1", dtype=os.environ.get("DYF_OISST_DTYPE") or None)
 x0 = torch.randn(nb, 1, 60, 60).cuda()
 m.sample(x0)
 torch.cuda.synchronize()
