@@ -1127,7 +1127,7 @@ dyf_status dyf_time_conv_layer(dyf_engine* e, int32_t which, int32_t layer, int3
 dyf_status dyf_ensemble_metrics(dyf_engine* e, const float* preds_dev, const float* targets_dev, int32_t n_members,
                                 int64_t n_points, double* out_host, void* stream) {
     if (!e || !preds_dev || !targets_dev || !out_host) return fail(e, DYF_ERR_INVALID_ARGUMENT, "null argument");
-    if (n_members < 1 || n_members > 64) return fail(e, DYF_ERR_INVALID_ARGUMENT, "n_members outside [1, 64]");
+    if (n_members < 1 || n_members > 15360) return fail(e, DYF_ERR_INVALID_ARGUMENT, "n_members outside [1, 15360]");
     if (n_points < 1) return fail(e, DYF_ERR_INVALID_ARGUMENT, "n_points must be positive");
     HIP_TRY(e, hipSetDevice(e->cfg.device));
     hipStream_t st = (hipStream_t)stream;

@@ -1340,6 +1340,78 @@ __global__ __launch_bounds__(256) void ensemble_metrics_kernel(const float* pred
     }
 }
 
+// More than 64 members (the reference has no cap, evaluation.py:10-80): the [N][256] staging tile no longer fits the 64 KB of LDS,
+// so a workgroup takes P < 256 points (N * P floats staged) and T = 256 / P threads share a point: thread (point pi = tid % P,
+// share sh = tid / P) owns the members n = sh, sh + T, ...; the shares' partial sums meet in LDS and are added in share order.
+// The O(N^2) pair term is then spread over all 256 threads.  Same definitions as ensemble_metrics_kernel.
+__global__ __launch_bounds__(256) void ensemble_metrics_tiled_kernel(const float* preds, const float* targets, int n_members,
+                                                                     long long n_points, double* sums, int P) {
+    extern __shared__ float xs[];        // [n_members][P] members, then [3][256] partials
+    float* red = xs + (size_t)n_members * P;
+    const int tid = threadIdx.x, T = 256 / P;
+    const int pi = tid % P, sh = tid / P;
+    const long long p0 = (long long)blockIdx.x * P, p = p0 + pi;
+    const bool live = p < n_points;
+    for (int i = tid; i < n_members * P; i += 256) {  // staging: consecutive threads -> consecutive points of one member
+        const int n = i / P, q = i - n * P;
+        xs[i] = p0 + q < n_points ? preds[(size_t)n * n_points + p0 + q] : 0.0f;
+    }
+    __syncthreads();
+    const float y = live ? targets[p] : 0.0f;
+    float sum = 0.0f, sabs = 0.0f;
+    for (int n = sh; n < n_members; n += T) {
+        const float x = xs[n * P + pi];
+        sum += x;
+        sabs += fabsf(x - y);
+    }
+    red[tid] = sum;
+    red[256 + tid] = sabs;
+    __syncthreads();
+    float tsum = 0.0f, tabs = 0.0f;
+    for (int k = 0; k < T; ++k) {  // every share adds the T partials in the same order: all hold the same mean
+        tsum += red[k * P + pi];
+        tabs += red[256 + k * P + pi];
+    }
+    const float inv = 1.0f / (float)n_members;
+    const float mean = tsum * inv;
+    __syncthreads();
+    float m2 = 0.0f;
+    double pair = 0.0;  // up to N^2 / 2 terms per point: rows in fp32, the sum of rows in fp64
+    for (int n = sh; n < n_members; n += T) {
+        const float x = xs[n * P + pi];
+        m2 += (x - mean) * (x - mean);
+        float row = 0.0f;
+        for (int m = n + 1; m < n_members; ++m) row += fabsf(x - xs[m * P + pi]);
+        pair += (double)row;
+    }
+    red[tid] = m2;
+    red[256 + tid] = (float)pair;
+    __syncthreads();
+    float se = 0.0f, var = 0.0f, crps = 0.0f;
+    if (live && sh == 0) {
+        float tm2 = 0.0f, tpair = 0.0f;
+        for (int k = 0; k < T; ++k) {
+            tm2 += red[k * P + pi];
+            tpair += red[256 + k * P + pi];
+        }
+        se = (mean - y) * (mean - y);
+        var = tm2 * inv;
+        crps = tabs * inv - tpair * inv * inv;
+    }
+    double d0 = se, d1 = var, d2 = crps;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        d0 += __shfl_xor(d0, off, 64);
+        d1 += __shfl_xor(d1, off, 64);
+        d2 += __shfl_xor(d2, off, 64);
+    }
+    if ((tid & 63) == 0) {
+        atomicAdd(sums + 0, d0);
+        atomicAdd(sums + 1, d1);
+        atomicAdd(sums + 2, d2);
+    }
+}
+
 // Reduction of the training criterion (src/utilities/utils.py:201-212, reduction = "mean"): sum over all elements of
 // |p - t| (kind 0), (p - t)^2 (kind 1) or smooth-L1 with beta = 1 (kind 2); fp32 per lane, wave butterfly, one fp64 atomic
 // per wave.  HBM-bound: both tensors are read once with 16-byte loads.
@@ -1373,6 +1445,15 @@ hipError_t launch_ensemble_metrics(const float* preds, const float* targets, int
     const size_t lds = (size_t)n_members * 256 * sizeof(float);
     hipError_t e = hipMemsetAsync(sums, 0, 3 * sizeof(double), s);
     if (e != hipSuccess) return e;
+    if (n_members > 64) {  // points per workgroup: the largest power of two with n_members * P floats <= 60 KB
+        int P = 128;
+        while (P > 1 && (size_t)n_members * P * sizeof(float) > 60 * 1024) P >>= 1;
+        if ((size_t)n_members * P * sizeof(float) > 60 * 1024) return hipErrorInvalidValue;  // > 15 360 members
+        const size_t lds2 = ((size_t)n_members * P + 2 * 256) * sizeof(float);
+        hipLaunchKernelGGL(ensemble_metrics_tiled_kernel, dim3((unsigned)((n_points + P - 1) / P)), dim3(256), lds2, s, preds, targets,
+                           n_members, n_points, sums, P);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(ensemble_metrics_kernel, dim3((unsigned)((n_points + 255) / 256)), dim3(256), lds, s, preds, targets,
                        n_members, n_points, sums);
     return hipGetLastError();

@@ -168,7 +168,8 @@ dyf_status dyf_set_row_offset(dyf_engine* engine, uint32_t first_row);
  * out_host[3] receives {mse of the ensemble mean, spread-skill ratio sqrt(mean var)/sqrt(mse), CRPS}, all averaged over
  * every point (mean_over_samples=True).  Synchronises `stream`. */
 dyf_status dyf_ensemble_metrics(dyf_engine* engine, const float* preds_dev, const float* targets_dev, int32_t n_members,
-                                int64_t n_points, double* out_host, void* stream);   /* n_members <= 64 (members are staged in LDS) */
+                                int64_t n_points, double* out_host, void* stream);   /* n_members <= 15 360: up to 64 members a workgroup stages
+                                * [N][256 points] in LDS; beyond that fewer points per workgroup, several threads per point */
 /* Copy one (NB,C,H,W) field of the sampler's state after the most recent dyf_sample call: what sample_loop returns
  * beside the intermediates (dyffusion.py:424-426): (x0_hat, ., x_s), or (x_s, ., x_interpolated_s_next) when the sampling
  * schedule stops before T-1. */

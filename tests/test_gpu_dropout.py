@@ -157,6 +157,17 @@ def test_ensemble_statistics_match_the_reference():
         print(f"{k}: z-score RMS of the ensemble means {z_rms:.3f} (1 = sampling error only), variance ratio {ratio:.4f}")
         assert 0.75 <= z_rms <= 1.6, (k, z_rms)
         assert 0.90 <= ratio <= 1.10, (k, ratio)
+    # the 256-member stack scored on the device (dyf_ensemble_metrics beyond 64 members) against the numpy oracle, with the
+    # reference ensemble's mean standing in for the truth
+    from dyffusion_amd.metrics import evaluate_ensemble_prediction
+    from oracle import metrics as om
+    k = sorted(out)[-1]
+    truth = torch.from_numpy(z[f"mean::{k}"]).float()
+    stack = out[k].reshape(N, 1, *truth.shape)  # (members, samples, C, H, W)
+    got = evaluate_ensemble_prediction(stack, truth[None].to(DEV), m._engine)
+    ref = om.evaluate_ensemble_prediction(stack.cpu().numpy(), truth[None].numpy())
+    for name in ("mse", "ssr", "crps"):
+        assert got[name] == pytest.approx(ref[name], rel=5e-5), (name, got[name], ref[name])
 
 
 def test_fullsize_rollout_with_dropout_matches_reference_statistics():

@@ -88,9 +88,11 @@ def test_predict_step_autoregressive_with_boundary_conditions_matches_reference_
     assert merged["t8_preds"].shape == (N, B, 4, 10, 10) and exp._predict_step_outputs == []
 
 
-def test_navier_stokes_long_rollout_with_device_boundary_conditions():
-    """BASELINE configs[3] in structure, at full size: Navier-Stokes 221x42, dim 64 @256^2, prediction horizon 32 with horizon
-    16 -> two autoregressive outer iterations re-feeding t16, N=2 members x B=2, the reference's NS boundary conditions
+@pytest.mark.parametrize("ph", [32, 64], ids=["2-outer-iterations", "configs3-h64-4-outer-iterations"])
+def test_navier_stokes_long_rollout_with_device_boundary_conditions(ph):
+    """BASELINE configs[3] at full size: Navier-Stokes 221x42, dim 64 @256^2, prediction horizon 64 (and 32) with horizon
+    16 -> four (two) autoregressive outer iterations re-feeding t16 / t32 / t48 (forecasting_multi_horizon.py:149-221), N=2
+    members x B=2, the reference's NS boundary conditions
     (fixed mask zeroed, parabolic inflow growing as 1 - exp(-5 t), per-batch-element times t0 + k dt) applied to every field
     on the device.  Checks: every field finite and carrying the boundary values EXACTLY where the reference writes them
     (ensemble members 0..B-1 of the (N, B, ...) stack -- its first-dimension indexing), untouched elsewhere relative to a run
@@ -103,7 +105,7 @@ def test_navier_stokes_long_rollout_with_device_boundary_conditions():
               refine_intermediate_predictions=True, enable_interpolator_dropout=False)
     N, B = 2, 2
     g = torch.Generator().manual_seed(8)
-    dyn = torch.randn(B, 33, 3, 221, 42, generator=g)
+    dyn = torch.randn(B, ph + 1, 3, 221, 42, generator=g)
     cond = torch.rand(B, 2, 221, 42, generator=g)
     meta = {"fixed_mask": torch.rand(B, 3, 221, 42, generator=g) < 0.05, "in_velocity": 1.0 + torch.rand(B, generator=g),
             "vertices": torch.rand(B, 2, 221, 42, generator=g) * 0.41}
@@ -117,13 +119,14 @@ def test_navier_stokes_long_rollout_with_device_boundary_conditions():
         def get_boundary_condition_kwargs(self, batch, batch_idx, split):
             return dict(t0=torch.tensor([0.0, 0.5]), dt=torch.tensor([0.01, 0.02]))
 
-    exp = D.MultiHorizonForecastingDYffusion(m, num_predictions=N, prediction_horizon=32, datamodule=DM())
+    exp = D.MultiHorizonForecastingDYffusion(m, num_predictions=N, prediction_horizon=ph, datamodule=DM())
+    assert exp.num_autoregressive_steps == ph // 16 - 1
     batch = {"dynamics": dyn.clone().to(DEV), "condition": cond.to(DEV), "metadata": meta}
     out = exp.evaluation_step(batch)
     free = D.MultiHorizonForecastingDYffusion(m, num_predictions=N, prediction_horizon=16).evaluation_step(
         {"dynamics": dyn.clone().to(DEV), "condition": cond.to(DEV)})
-    assert [k for k in out if k.endswith("preds")] == [f"t{k}_preds" for k in range(1, 33)]
-    for k in (1, 16, 17, 32):
+    assert [k for k in out if k.endswith("preds")] == [f"t{k}_preds" for k in range(1, ph + 1)]
+    for k in sorted({1, 16, 17, 32, ph - 31, ph - 16, ph - 15, ph}):
         p = out[f"t{k}_preds"].cpu()
         assert tuple(p.shape) == (N, B, 3, 221, 42) and bool(torch.isfinite(p).all())
         time = torch.tensor([0.0, 0.5])
@@ -135,6 +138,16 @@ def test_navier_stokes_long_rollout_with_device_boundary_conditions():
             q = obc.boundary_conditions("navier-stokes", free[f"t{k}_preds"].cpu().clone(), dyn[:, k], meta, time=time)
             assert torch.equal(p, q), k
     assert not torch.equal(out["t17_preds"].cpu(), out["t1_preds"].cpu())
+    # every outer iteration starts from the BC-applied last field of the one before: re-running iteration j alone from that field
+    # (one rollout, no boundary conditions) reproduces the raw forecasts the boundary conditions were then applied to
+    for j in range(1, ph // 16):
+        start = out[f"t{16 * j}_preds"].reshape(N * B, 3, 221, 42)
+        again = m.sample(start, static_condition=cond.to(DEV).repeat(N, 1, 1, 1))
+        time = torch.tensor([0.0, 0.5])
+        for _ in range(16 * j + 16):
+            time = time + torch.tensor([0.01, 0.02])
+        q = obc.boundary_conditions("navier-stokes", again["t16_preds"].reshape(N, B, 3, 221, 42).cpu().clone(), dyn[:, 16 * j + 16], meta, time=time)
+        assert torch.equal(out[f"t{16 * j + 16}_preds"].cpu(), q), j
 
 
 def test_forecaster_experiment_get_loss_routes_the_batch_like_the_reference(monkeypatch):

@@ -17,7 +17,9 @@ def _engine():
     return HipEngine(net.engine_net_config(), net.engine_net_config(), height=16, width=16, max_batch=1, use_graph=False)
 
 
-@pytest.mark.parametrize("shape", [(20, 4, 3, 221, 42), (1, 2, 1, 9, 7), (64, 1, 2, 33, 5), (5, 3, 2, 60, 60)])
+@pytest.mark.parametrize("shape", [(20, 4, 3, 221, 42), (1, 2, 1, 9, 7), (64, 1, 2, 33, 5), (5, 3, 2, 60, 60),
+                                   # > 64 members: the tiled kernel (fewer points per workgroup, several threads per point)
+                                   (65, 1, 2, 33, 5), (256, 2, 3, 23, 11), (1000, 1, 1, 17, 9), (4097, 1, 1, 5, 3)])
 def test_ensemble_metrics_match_oracle(shape):
     from dyffusion_amd.metrics import evaluate_ensemble_prediction
 
@@ -58,4 +60,4 @@ def test_argument_checks():
     with pytest.raises(ValueError):
         eng.ensemble_metrics(torch.zeros(3, 2, 5).cuda(), torch.zeros(2, 4).cuda())
     with pytest.raises(ValueError):
-        eng.ensemble_metrics(torch.zeros(65, 2, 5).cuda(), torch.zeros(2, 5).cuda())
+        eng.ensemble_metrics(torch.zeros(15361, 2, 5).cuda(), torch.zeros(2, 5).cuda())  # beyond the 60 KB staging tile
