@@ -10,9 +10,9 @@ static channels), unet_simple dim 64 @256^2, bf16 MFMA / fp32 accumulate.
 
 N > 1 (one process per GPU, RCCL): rows are independent ensemble members, so the rollout itself has no exchange step;
 every rank keeps the SAME seed and samples its block of global rows (the dropout streams are keyed by the global row, so
-the fields do not depend on N), and at the end of EVERY step the forecast stack is all-gathered over RCCL
-(`dyffusion_amd.distributed`: one all_gather_into_tensor per field, straight into the (h, N*NB, C, H, W) result) -- inside
-the timed region.  Default = weak scaling: NB rows per rank.  `--ensemble-total M` = strong scaling: a FIXED M-row ensemble
+the fields do not depend on N), and at the end of EVERY step the forecast stack is all-gathered over RCCL in ONE collective
+issued by the engine itself on the rollout's stream (`dyf_sample_gather`; `DYF_BENCH_EXCHANGE=torch`: one
+all_gather_into_tensor through torch.distributed) -- inside the timed region.  Default = weak scaling: NB rows per rank.  `--ensemble-total M` = strong scaling: a FIXED M-row ensemble
 (e.g. the reference's 50 members) split 7,7,6,... over the ranks.  value = total rows * h * K / max-over-ranks wall time.
 """
 import argparse
@@ -291,7 +291,7 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
-    from dyffusion_amd.distributed import rows_per_rank, sample_sharded, shard_rows
+    from dyffusion_amd.distributed import init_engine_comm, rows_per_rank, sample_sharded, shard_rows
 
     strong = args.ensemble_total > 0
     total_rows = args.ensemble_total if strong else world * args.nb
@@ -309,7 +309,7 @@ def main():
 
     def step():
         if world > 1 and gather:
-            preds = sample_sharded(model, x0, static)
+            preds = sample_sharded(model, x0, static, exchange=exchange)
             assert preds[f"t{HORIZON}_preds"].shape[0] == total_rows
         else:
             model.set_row_offset(lo)
@@ -319,6 +319,12 @@ def main():
     model.seed(2)
     model._ensure_engine((H, W), nb)
     log("engine created, weights uploaded")
+    # N > 1 over RCCL: the ENGINE owns the communicator (dyf_comm_init) and issues the one all-gather of the forecast stack
+    # itself, on the rollout's stream (dyf_sample_gather); DYF_BENCH_EXCHANGE=torch selects the torch.distributed route
+    exchange = os.environ.get("DYF_BENCH_EXCHANGE", "engine" if world > 1 and dist.get_backend() == "nccl" else "torch")
+    if world > 1 and gather and exchange == "engine":
+        init_engine_comm(model, (H, W), total_rows)
+        log("engine-owned RCCL communicator initialised")
     for _ in range(args.warmup):
         step()
         torch.cuda.synchronize()
@@ -356,7 +362,7 @@ def main():
         "config": {"workload": "BASELINE configs[1]: Navier-Stokes 221x42, C=3+2 static ch, unet_simple dim 64 @256^2, "
                                "DYffusion h=16 cold sampling + refine, interpolator MC dropout p=0.15, hipGraph rollout",
                    "rows_per_gpu": nb, "total_rows": total_rows, "net_forwards_per_rollout": n_f + n_i,
-                   "parallelism": f"ensemble-sharded dp{world}" + (" + RCCL all-gather of the forecast stack every step" if gather and world > 1 else ""),
+                   "parallelism": f"ensemble-sharded dp{world}" + (f" + ONE all-gather of the forecast stack per step ({exchange}-owned exchange)" if gather and world > 1 else ""),
                    # gflop_per_field / whole_rollout_tflops: the REFERENCE's dense 2*MAC count (what the CPU path executes);
                    # executed_*: the contractions this engine runs (sparse last decoder block, stem composed into enc0,
                    # readout at the 4 neighbours the final resample reads)

@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("DYF_LIB") or os.path.join(_HERE, "lib", "libdyffusion
 LIB_PATH_F16 = os.environ.get("DYF_LIB_F16") or os.path.join(_HERE, "lib", "libdyffusion_hip_f16.so")
 DTYPES = {"bf16": 0, "bfloat16": 0, "fp16": 1, "float16": 1, "half": 1}
 
-DYF_ABI_VERSION = 3
+DYF_ABI_VERSION = 4
 DYF_OK, DYF_ERR_INVALID_ARGUMENT, DYF_ERR_UNSUPPORTED, DYF_ERR_HIP, DYF_ERR_STATE = range(5)
 NET_FORECASTER, NET_INTERPOLATOR = 0, 1
 ARCH_UNET_SIMPLE, ARCH_UNET_RESNET = 0, 1
@@ -55,6 +55,7 @@ class BcArgs(C.Structure):
 
 
 BC_NAVIER_STOKES, BC_SPRING_MESH = 0, 1
+COMM_ID_BYTES = 128  # DYF_COMM_ID_BYTES (ncclUniqueId)
 TRAIN_BATCH_STATS, TRAIN_DROPOUT = 1, 2
 
 # every symbol include/dyffusion_hip.h and include/dyffusion_hip_testing.h declare: (name, restype, argtypes)
@@ -77,6 +78,10 @@ SYMBOLS = [
     ("dyf_sample", C.c_int, [_P, _P, _P, _P, C.c_int32, C.POINTER(_P), _P, _P]),
     ("dyf_seed", C.c_int, [_P, C.c_uint64]),
     ("dyf_set_row_offset", C.c_int, [_P, C.c_uint32]),
+    ("dyf_comm_unique_id", C.c_int, [_P]),
+    ("dyf_comm_init", C.c_int, [_P, _P, C.c_int32, C.c_int32]),
+    ("dyf_comm_destroy", C.c_int, [_P]),
+    ("dyf_sample_gather", C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, _P]),
     ("dyf_get_sampler_state", C.c_int, [_P, C.c_int32, _P, C.c_int32, _P]),
     ("dyf_plan_forward_counts", C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     ("dyf_net_flops", C.c_int, [_P, C.c_int32, C.POINTER(C.c_double)]),

@@ -4,6 +4,10 @@
 // Path being replaced (reference, read-only): src/diffusion/dyffusion.py:335-431 (sample_loop / sample),
 // :140-163 + :480-494 (q_sample / _interpolate), :205-239 (predict_x_last) and src/models/unet_simple.py:164-197.
 #include "engine_internal.h"
+
+#include <dlfcn.h>
+#include <mutex>
+#include <rccl/rccl.h>  // types only: the functions are resolved with dlsym (rccl_api below)
 #include "unet_kernels.h"
 #include "../../include/dyffusion_hip_testing.h"
 
@@ -292,6 +296,7 @@ void dyf_engine_destroy(dyf_engine* e) {
     rn_destroy(e->net[1]);
     sc_destroy(e->net[0]);
     sc_destroy(e->net[1]);
+    (void)dyf_comm_destroy(e);
     if (e->cap_stream) (void)hipStreamDestroy(e->cap_stream);
     train_destroy(e);
     release_allocs(e->allocs);
@@ -1002,12 +1007,13 @@ dyf_status run_plan(dyf_engine* e, int nb, const uint8_t* const* masks, const fl
 
 extern "C" {
 
-dyf_status dyf_sample(dyf_engine* e, const float* initial_dev, const float* static_dev, float* out_dev, int32_t nb,
-                      const uint8_t* const* masks_dev, const float* noise_dev, void* stream) {
+// dyf_sample without the final copy: the forecast stack of the call stays in e->s_stack, [n_out_slots][nb][C][H][W]
+static dyf_status sample_into_stack(dyf_engine* e, const float* initial_dev, const float* static_dev, int32_t nb,
+                                    const uint8_t* const* masks_dev, const float* noise_dev, void* stream) {
     if (!e) return DYF_ERR_INVALID_ARGUMENT;
     if (!e->plan.set) return fail(e, DYF_ERR_STATE, "dyf_set_plan has not been called");
     if (nb < 1 || nb > e->cfg.max_batch) return fail(e, DYF_ERR_INVALID_ARGUMENT, "batch size outside [1, max_batch]");
-    if (!initial_dev || !out_dev) return fail(e, DYF_ERR_INVALID_ARGUMENT, "initial condition / out must not be null");
+    if (!initial_dev) return fail(e, DYF_ERR_INVALID_ARGUMENT, "initial condition must not be null");
     if ((e->Cs > 0) != (static_dev != nullptr))
         return fail(e, DYF_ERR_INVALID_ARGUMENT, "static condition must be given iff the networks take one");
     HIP_TRY(e, hipSetDevice(e->cfg.device));
@@ -1042,8 +1048,122 @@ dyf_status dyf_sample(dyf_engine* e, const float* initial_dev, const float* stat
         }
         HIP_TRY(e, hipGraphLaunch(g.exec, st));
     }
+    (void)field;
+    return DYF_OK;
+}
+
+dyf_status dyf_sample(dyf_engine* e, const float* initial_dev, const float* static_dev, float* out_dev, int32_t nb,
+                      const uint8_t* const* masks_dev, const float* noise_dev, void* stream) {
+    if (e && !out_dev) return fail(e, DYF_ERR_INVALID_ARGUMENT, "out must not be null");
+    dyf_status r = sample_into_stack(e, initial_dev, static_dev, nb, masks_dev, noise_dev, stream);
+    if (r != DYF_OK) return r;
+    const size_t field = (size_t)nb * e->C * e->cfg.height * e->cfg.width;
     HIP_TRY(e, hipMemcpyAsync(out_dev, e->s_stack, (size_t)e->plan.hdr.n_out_slots * field * sizeof(float),
-                              hipMemcpyDeviceToDevice, st));
+                              hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return DYF_OK;
+}
+
+// ---- engine-owned exchange (SURVEY 8b "Ownership", 8e): RCCL communicator + ONE all-gather of the forecast stack -----------
+// librccl is opened lazily (dlopen) the first time a communicator is asked for: the library has no link-time dependency on it
+// and loads on hosts without RCCL; a copy already mapped into the process (PyTorch's) is reused.
+namespace {
+struct RcclApi {
+    void* lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    std::string err;
+};
+RcclApi& rccl_api() {
+    static RcclApi api;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char* names[] = {getenv("DYF_RCCL_LIB"), "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"};
+        for (const char* nm : names) {
+            if (!nm || !*nm) continue;
+            api.lib = dlopen(nm, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);  // already mapped (torch's copy)?
+            if (!api.lib) api.lib = dlopen(nm, RTLD_NOW | RTLD_LOCAL);
+            if (api.lib) break;
+        }
+        if (!api.lib) { api.err = std::string("librccl not found: ") + (dlerror() ? dlerror() : ""); return; }
+#define SYM(field, name) api.field = (decltype(api.field))dlsym(api.lib, name); if (!api.field) api.err = std::string("librccl lacks ") + name;
+        SYM(GetUniqueId, "ncclGetUniqueId") SYM(CommInitRank, "ncclCommInitRank") SYM(CommDestroy, "ncclCommDestroy")
+        SYM(AllGather, "ncclAllGather") SYM(GetErrorString, "ncclGetErrorString")
+#undef SYM
+    });
+    return api;
+}
+}  // namespace
+
+dyf_status dyf_comm_unique_id(uint8_t* id_out) {
+    if (!id_out) return DYF_ERR_INVALID_ARGUMENT;
+    RcclApi& api = rccl_api();
+    if (!api.err.empty()) return fail(nullptr, DYF_ERR_UNSUPPORTED, api.err);
+    ncclUniqueId id;
+    ncclResult_t r = api.GetUniqueId(&id);
+    if (r != ncclSuccess) return fail(nullptr, DYF_ERR_HIP, std::string("ncclGetUniqueId: ") + api.GetErrorString(r));
+    static_assert(sizeof(id) == DYF_COMM_ID_BYTES, "ncclUniqueId is 128 bytes");
+    memcpy(id_out, &id, sizeof(id));
+    return DYF_OK;
+}
+
+dyf_status dyf_comm_init(dyf_engine* e, const uint8_t* unique_id, int32_t rank, int32_t world) {
+    if (!e || !unique_id) return fail(e, DYF_ERR_INVALID_ARGUMENT, "null argument");
+    if (world < 1 || rank < 0 || rank >= world) return fail(e, DYF_ERR_INVALID_ARGUMENT, "rank outside [0, world)");
+    RcclApi& api = rccl_api();
+    if (!api.err.empty()) return fail(e, DYF_ERR_UNSUPPORTED, api.err);
+    if (e->comm) return fail(e, DYF_ERR_STATE, "the engine already owns a communicator (dyf_comm_destroy first)");
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    ncclUniqueId id;
+    memcpy(&id, unique_id, sizeof(id));
+    ncclComm_t comm = nullptr;
+    ncclResult_t r = api.CommInitRank(&comm, world, id, rank);
+    if (r != ncclSuccess) return fail(e, DYF_ERR_HIP, std::string("ncclCommInitRank: ") + api.GetErrorString(r));
+    e->comm = comm;
+    e->comm_rank = rank;
+    e->comm_world = world;
+    return DYF_OK;
+}
+
+dyf_status dyf_comm_destroy(dyf_engine* e) {
+    if (!e) return DYF_ERR_INVALID_ARGUMENT;
+    if (e->comm) {
+        (void)hipDeviceSynchronize();
+        (void)rccl_api().CommDestroy((ncclComm_t)e->comm);
+        e->comm = nullptr;
+    }
+    if (e->gather_recv) {
+        (void)hipFree(e->gather_recv);
+        e->gather_recv = nullptr;
+        e->gather_recv_floats = 0;
+    }
+    return DYF_OK;
+}
+
+dyf_status dyf_sample_gather(dyf_engine* e, const float* initial_dev, const float* static_dev, float* out_full_dev, int32_t nb,
+                             int32_t total_rows, void* stream) {
+    if (!e || !out_full_dev) return fail(e, DYF_ERR_INVALID_ARGUMENT, "null argument");
+    if (!e->comm) return fail(e, DYF_ERR_STATE, "dyf_comm_init has not been called");
+    const int world = e->comm_world;
+    if (total_rows < 1 || (long long)nb * world < total_rows || nb != (total_rows + world - 1) / world)
+        return fail(e, DYF_ERR_INVALID_ARGUMENT, "every rank samples nb = ceil(total_rows / world) rows");
+    dyf_status r = sample_into_stack(e, initial_dev, static_dev, nb, nullptr, nullptr, stream);
+    if (r != DYF_OK) return r;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t row = (size_t)e->C * e->cfg.height * e->cfg.width, slots = (size_t)e->plan.hdr.n_out_slots;
+    const size_t send = slots * nb * row;  // floats: the contiguous local stack
+    if (e->gather_recv_floats < send * world) {
+        if (e->gather_recv) { HIP_TRY(e, hipDeviceSynchronize()); (void)hipFree(e->gather_recv); e->gather_recv = nullptr; }
+        HIP_TRY(e, hipMalloc((void**)&e->gather_recv, send * world * sizeof(float)));
+        e->gather_recv_floats = send * world;
+    }
+    RcclApi& api = rccl_api();
+    ncclResult_t nr = api.AllGather(e->s_stack, e->gather_recv, send, ncclFloat, (ncclComm_t)e->comm, st);  // ONE collective
+    if (nr != ncclSuccess) return fail(e, DYF_ERR_HIP, std::string("ncclAllGather: ") + api.GetErrorString(nr));
+    // [world][slots][nb][row] -> [slots][total_rows][row] in global row order (rank r owns rows shard(r); its padding rows drop)
+    HIP_TRY(e, launch_gather_unpack(e->gather_recv, out_full_dev, world, (int)slots, nb, total_rows, (long long)row, st));
     return DYF_OK;
 }
 

@@ -136,6 +136,11 @@ struct dyf_engine {
     std::vector<int> prof_rows;
     float* s_pair = nullptr;        // [2][max_batch][C][H][W]: outputs of a paired interpolator call
     bool pair_interp = true;        // DYF_PAIR_INTERP=0: one forward per interpolator call (A/B testing)
+    // engine-owned exchange (dyf_comm_init / dyf_sample_gather): RCCL communicator (ncclComm_t) and the all-gather receive buffer
+    void* comm = nullptr;
+    int comm_rank = 0, comm_world = 1;
+    float* gather_recv = nullptr;
+    size_t gather_recv_floats = 0;
     dyf::TrainState* train = nullptr;  // training path (arch unet_simple), created by the first dyf_load_weights
     bool last_dec5_sparse = false;  // the most recent unet_simple forward stored dec5 in the compact sparse-column layout
     bool poison_dec5 = false;       // DYF_POISON_DEC5=1 (test hook, read once at create): NaN-fill dec5's output before its conv

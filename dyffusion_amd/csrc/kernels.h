@@ -138,3 +138,7 @@ hipError_t launch_fill_f32(float* p, float v, long long count, hipStream_t s);
 hipError_t launch_criterion_sum(const float* p, const float* t, long long count, int kind, double* sum, hipStream_t s);
 hipError_t launch_ensemble_metrics(const float* preds, const float* targets, int n_members, long long n_points, double* sums,
                                    hipStream_t s);
+
+// dyf_sample_gather: all-gather receive layout [world][slots][nb][row floats] -> [slots][total_rows][row] in global row order;
+// rank r owns the contiguous block of rows shard(r) (the first total_rows % world ranks one extra), its padding rows are dropped
+hipError_t launch_gather_unpack(const float* recv, float* out, int world, int slots, int nb, int total_rows, long long row, hipStream_t s);

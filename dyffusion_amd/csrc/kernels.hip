@@ -1458,3 +1458,40 @@ hipError_t launch_ensemble_metrics(const float* preds, const float* targets, int
                        n_members, n_points, sums);
     return hipGetLastError();
 }
+
+// ------------------------------------------------------------------------------------------------ exchange unpack
+__global__ __launch_bounds__(256) void gather_unpack_kernel(const float4* recv, float4* out, int world, int slots, int nb, int total_rows,
+                                                            long long row4) {
+    const int g = blockIdx.y;                 // global row
+    const int slot = blockIdx.z;
+    const int base = total_rows / world, extra = total_rows % world;
+    // owner of global row g under the balanced contiguous split: ranks < extra own base + 1 rows
+    const int cut = extra * (base + 1);
+    const int r = g < cut ? g / (base + 1) : extra + (g - cut) / max(base, 1);
+    const int j = g < cut ? g - r * (base + 1) : (g - cut) - (r - extra) * base;
+    const float4* src = recv + (((size_t)r * slots + slot) * nb + j) * row4;
+    float4* dst = out + ((size_t)slot * total_rows + g) * row4;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < row4; i += (long long)gridDim.x * 256) dst[i] = src[i];
+}
+
+__global__ __launch_bounds__(256) void gather_unpack_scalar_kernel(const float* recv, float* out, int world, int slots, int nb,
+                                                                   int total_rows, long long row) {
+    const int g = blockIdx.y, slot = blockIdx.z;
+    const int base = total_rows / world, extra = total_rows % world, cut = extra * (base + 1);
+    const int r = g < cut ? g / (base + 1) : extra + (g - cut) / max(base, 1);
+    const int j = g < cut ? g - r * (base + 1) : (g - cut) - (r - extra) * base;
+    const float* src = recv + (((size_t)r * slots + slot) * nb + j) * row;
+    float* dst = out + ((size_t)slot * total_rows + g) * row;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < row; i += (long long)gridDim.x * 256) dst[i] = src[i];
+}
+
+hipError_t launch_gather_unpack(const float* recv, float* out, int world, int slots, int nb, int total_rows, long long row, hipStream_t s) {
+    const bool vec = row % 4 == 0 && ((uintptr_t)recv & 15) == 0 && ((uintptr_t)out & 15) == 0;
+    const long long units = vec ? row / 4 : row;
+    const dim3 grid((unsigned)std::max<long long>(1, std::min<long long>((units + 1023) / 1024, 64)), (unsigned)total_rows, (unsigned)slots);
+    if (vec)
+        hipLaunchKernelGGL(gather_unpack_kernel, grid, dim3(256), 0, s, (const float4*)recv, (float4*)out, world, slots, nb, total_rows, units);
+    else
+        hipLaunchKernelGGL(gather_unpack_scalar_kernel, grid, dim3(256), 0, s, recv, out, world, slots, nb, total_rows, row);
+    return hipGetLastError();
+}

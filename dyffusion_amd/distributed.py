@@ -11,10 +11,17 @@ Results do not depend on the number of GPUs: every rank keeps the SAME seed and 
 first row (`set_row_offset`), and the engine's dropout / noise streams are keyed by the global row (csrc/common.h).
 
 Layout of the exchange: every rank samples the same number of rows (`rows_per_rank` = ceil(NB / world); ranks that own
-fewer rows -- 50 members on 8 GPUs are 7,7,6,6,6,6,6,6 -- repeat their last row, whose result is dropped), so the
-collective is one `all_gather_into_tensor` per forecast field straight from the engine's output slot into the
-pre-allocated `(h, world * rows_per_rank, C, H, W)` result: no staging copies when NB divides evenly; otherwise one
-index-select per field drops the padding rows.
+fewer rows -- 50 members on 8 GPUs are 7,7,6,6,6,6,6,6 -- repeat their last row, whose result is dropped), and the whole
+local forecast stack `(h, rows_per_rank, C, H, W)` -- one contiguous tensor -- travels in ONE collective per predict call
+(NS h=16, 80 rows per rank: one 143 MB message per rank instead of sixteen of 8.9 MB; a ring all-gather over xGMI is
+per-link bound, so one large message).  Two routes:
+
+* `exchange="engine"` (default on GPUs once `init_engine_comm` has run): `dyf_sample_gather` -- the ENGINE owns the RCCL
+  communicator (SURVEY 8b "Ownership"), enqueues `ncclAllGather` on the rollout's stream right behind the captured graph and
+  unpacks `[world][h][rows][...]` to `[h][NB][...]` in one kernel; no torch.distributed call in the predict path, and a host
+  without torch can shard through the C ABI alone.
+* `exchange="torch"`: one `all_gather_into_tensor` (`all_gather` under gloo, for the CPU tests) of the stack, then one
+  transposing copy.
 """
 from typing import Dict, List, Optional, Protocol, Tuple
 
@@ -82,10 +89,30 @@ class _Sampler(Protocol):  # what sample_sharded needs of `DYffusion`
     def set_row_offset(self, first_row: int) -> None: ...
 
 
+def init_engine_comm(model, hw, total_rows: int, group=None) -> None:
+    """Create the engines' own RCCL communicator over the ranks of `group`: rank 0 draws the unique id (dyf_comm_unique_id),
+    torch.distributed only carries those 128 bytes to the other ranks (any side channel would do), every rank calls dyf_comm_init."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    from .engine import HipEngine
+    box = [HipEngine.comm_unique_id(model._engine_opts["dtype"]) if rank == 0 else None]
+    dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    model.comm_init(box[0], rank, world, hw, rows_per_rank(total_rows, world))
+    model._engine_comm_world = world
+
+
+def _unpack_stack(full: Tensor, total_rows: int, world: int) -> Tensor:
+    """(world, h, rpr, ...) all-gather layout -> (h, total_rows, ...) in global row order (padding rows dropped)."""
+    h, rpr = full.shape[1], full.shape[2]
+    stack = full.transpose(0, 1).reshape(h, world * rpr, *full.shape[3:])  # one transposing copy
+    keep = _valid_rows(total_rows, world, full.device)
+    return stack if keep is None else stack.index_select(1, keep)
+
+
 def sample_sharded(model: _Sampler, initial_condition: Tensor, static_condition: Optional[Tensor] = None,
-                   group=None) -> Dict[str, Tensor]:
+                   group=None, exchange: Optional[str] = None) -> Dict[str, Tensor]:
     """Every rank passes the FULL (NB, ...) inputs and the same-seeded `model` (a `DYffusion`); it samples only its own
-    rows and receives the full `t{i}_preds` dict.  Identical to `model.sample` on one GPU, bit for bit."""
+    rows and receives the full `t{i}_preds` dict.  Identical to `model.sample` on one GPU, bit for bit.  ONE collective per
+    call; `exchange`: "engine" (dyf_sample_gather: needs `init_engine_comm`), "torch", or None = engine when available."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         model.set_row_offset(0)
         kw = {} if static_condition is None else {"static_condition": static_condition}
@@ -101,16 +128,24 @@ def sample_sharded(model: _Sampler, initial_condition: Tensor, static_condition:
     c = None if static_condition is None else \
         (static_condition.index_select(0, idx) if (hi - lo) < rpr else static_condition[lo:hi])
     model.set_row_offset(lo)
-    local = model.sample(x, **({} if c is None else {"static_condition": c}))
-    keys: List[str] = sorted(local, key=lambda k: int(k[1:].split("_")[0]))
-    out = {}
-    keep = _valid_rows(nb, world, initial_condition.device)
-    for k in keys:
-        field = local[k].contiguous()  # a slot of the engine's forecast stack: already contiguous
-        full = torch.empty((world * rpr, *field.shape[1:]), dtype=field.dtype, device=field.device)
-        _gather_into(full, field, group)
-        out[k] = full if keep is None else full.index_select(0, keep)
-    return out
+    if exchange is None:
+        exchange = "engine" if getattr(model, "_engine_comm_world", 1) == world and initial_condition.is_cuda else "torch"
+    if exchange == "engine":
+        return model.sample_gathered(x, c, nb)
+    if not hasattr(model, "sample_stack"):  # duck-typed samplers (tests): per-field route over the dict
+        local = model.sample(x, **({} if c is None else {"static_condition": c}))
+        keys: List[str] = sorted(local, key=lambda k: float(k[1:].split("_")[0]))
+        stack, slot_keys = torch.stack([local[k] for k in keys], 0), dict(enumerate(keys))
+    else:
+        stack, slot_keys = model.sample_stack(x, c)
+    stack = stack.contiguous()  # (h, rpr, C, H, W): the engine's forecast stack, already contiguous
+    full = torch.empty((world, *stack.shape), dtype=stack.dtype, device=stack.device)
+    if dist.get_backend(group) == "gloo":  # CPU tests: gloo has no all_gather_into_tensor
+        dist.all_gather([full[k] for k in range(world)], stack, group=group)
+    else:
+        dist.all_gather_into_tensor(full, stack, group=group)  # ONE collective
+    out = _unpack_stack(full, nb, world)
+    return {key: out[slot] for slot, key in slot_keys.items()}
 
 
 def all_reduce_gradients(parameters, group=None, bucket_bytes: int = 64 << 20) -> int:

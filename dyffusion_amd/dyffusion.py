@@ -288,6 +288,32 @@ class DYffusion(nn.Module):
             return x_s, intermediates, eng.sampler_state(2, nb)
         return eng.sampler_state(0, nb), intermediates, x_s
 
+    # ------------------------------------------------------------------ ensemble sharding over GPUs (distributed.py)
+    def sample_stack(self, initial_condition: Tensor, static_condition: Optional[Tensor] = None):
+        """The forecast stack of one rollout as ONE contiguous tensor (n_out_slots, NB, C, H, W) plus the {slot: key} map -- what
+        `sample` slices its dict from; `distributed.sample_sharded` exchanges it with a single collective."""
+        nb = initial_condition.shape[0]
+        eng = self._ensure_engine(initial_condition.shape[-2:], nb)
+        self._ensure_plan(eng)
+        return eng.sample(initial_condition, static_condition), dict(self._slot_keys)
+
+    def comm_init(self, unique_id: bytes, rank: int, world: int, hw, rows_per_rank: int):
+        """Give this model's engine its own RCCL communicator (dyf_comm_init) for `sample_gathered`."""
+        eng = self._ensure_engine(hw, rows_per_rank)
+        if eng.comm_world != 1:
+            eng.comm_destroy()
+        eng.comm_init(unique_id, rank, world)
+
+    @torch.no_grad()
+    def sample_gathered(self, initial_condition: Tensor, static_condition: Optional[Tensor], total_rows: int) -> Dict[str, Tensor]:
+        """Engine-owned exchange (dyf_sample_gather): sample this rank's rows, all-gather the stack over RCCL inside the engine,
+        return the FULL `t{i}_preds` dict ((total_rows, C, H, W) each, global row order)."""
+        nb = initial_condition.shape[0]
+        eng = self._ensure_engine(initial_condition.shape[-2:], nb)
+        self._ensure_plan(eng)
+        full = eng.sample_gather(initial_condition, static_condition, total_rows)
+        return {key: full[slot] for slot, key in self._slot_keys.items()}
+
     @torch.no_grad()
     def sample(self, initial_condition: Tensor, num_samples: int = 1, **kwargs) -> Dict[str, Tensor]:
         _, intermediates, _ = self.sample_loop(initial_condition, **kwargs)

@@ -92,6 +92,7 @@ class HipEngine:
         self.n_out_slots = 0
         self._tape_net = {}       # tape slot -> network of the recorded training forward
         self._tape_nb = {}        # tape slot -> batch rows of the recorded forward (train_backward validates dout against it)
+        self.comm_rank, self.comm_world = 0, 1
         self.train_step_id = 0    # bumped by every p_losses / get_loss training forward: a loss of an older step cannot run backward
         self.plan_valid = False   # cleared by load_weights: the plan's FiLM tables are functions of the weights
         self.weights_version = 0
@@ -238,6 +239,49 @@ class HipEngine:
         self._check(self._lib.dyf_sample(self._h, initial.data_ptr(), None if static is None else static.data_ptr(),
                                          out.data_ptr(), nb, mptr, None if noise is None else noise.data_ptr(),
                                          self._stream()))
+        return out
+
+    # ------------------------------------------------------------------ engine-owned exchange (ensemble sharding over GPUs)
+    @staticmethod
+    def comm_unique_id(dtype: str = "bf16") -> bytes:
+        """128-byte RCCL unique id (dyf_comm_unique_id): created on ONE rank, handed to every rank's `comm_init`."""
+        lib = L.lib(dtype)
+        buf = (C.c_uint8 * L.COMM_ID_BYTES)()
+        st = lib.dyf_comm_unique_id(buf)
+        if st != L.DYF_OK:
+            _raise(st, lib.dyf_last_error(None).decode())
+        return bytes(buf)
+
+    def comm_init(self, unique_id: bytes, rank: int, world: int):
+        """This engine's RCCL communicator over `world` ranks (dyf_comm_init); needed by `sample_gather`."""
+        if len(unique_id) != L.COMM_ID_BYTES:
+            raise ValueError(f"unique_id must be {L.COMM_ID_BYTES} bytes")
+        buf = (C.c_uint8 * L.COMM_ID_BYTES).from_buffer_copy(unique_id)
+        self._check(self._lib.dyf_comm_init(self._h, buf, int(rank), int(world)))
+        self.comm_rank, self.comm_world = int(rank), int(world)
+
+    def comm_destroy(self):
+        self._check(self._lib.dyf_comm_destroy(self._h))
+        self.comm_world = 1
+
+    def sample_gather(self, initial: torch.Tensor, static: Optional[torch.Tensor], total_rows: int) -> torch.Tensor:
+        """dyf_sample_gather: rollout of this rank's rows, ONE all-gather of the forecast stack, unpack -> (n_out_slots, total_rows,
+        C, H, W) with every rank's rows in global order."""
+        initial = _f32c(initial, "initial_condition")
+        nb = initial.shape[0]
+        icfg = self.cfg.net[L.NET_INTERPOLATOR]
+        c_out = self.cfg.net[L.NET_FORECASTER].out_channels
+        if initial.dim() != 4 or tuple(initial.shape[2:]) != (self.height, self.width) or initial.shape[1] != icfg.in_channels - c_out:
+            raise ValueError(f"initial_condition must be (NB, {icfg.in_channels - c_out}, {self.height}, {self.width}), got {tuple(initial.shape)}")
+        if (static is None) != (icfg.cond_channels == 0):
+            raise ValueError("static_condition must be given iff the networks take conditional channels")
+        if static is not None:
+            static = _f32c(static, "static_condition")
+            if tuple(static.shape) != (nb, icfg.cond_channels, self.height, self.width):
+                raise ValueError(f"static_condition has shape {tuple(static.shape)}")
+        out = torch.empty((self.n_out_slots, int(total_rows), c_out, self.height, self.width), dtype=torch.float32, device=initial.device)
+        self._check(self._lib.dyf_sample_gather(self._h, initial.data_ptr(), None if static is None else static.data_ptr(),
+                                                out.data_ptr(), nb, int(total_rows), self._stream()))
         return out
 
     def sampler_state(self, what: int, nb: int) -> torch.Tensor:

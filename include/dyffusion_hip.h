@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define DYF_ABI_VERSION 3
+#define DYF_ABI_VERSION 4
 
 typedef struct dyf_engine dyf_engine;
 
@@ -161,6 +161,24 @@ dyf_status dyf_seed(dyf_engine* engine, uint64_t seed);
  * (_base_experiment.py:503-538 tiles them, row = n*B + b) sets lo: its rows then draw exactly the masks / noise they
  * would draw inside the un-sharded batch. */
 dyf_status dyf_set_row_offset(dyf_engine* engine, uint32_t first_row);
+
+/* ---- engine-owned exchange of the ensemble-sharded path (one process per GPU; the reference has no inference collective) ------- */
+/* Ensemble members / batch items are independent rows for the whole rollout (_base_experiment.py:503-538 tiles them, row = n*B + b),
+ * so rank r of `world` samples the contiguous block of global rows [lo_r, hi_r) of a total_rows-row ensemble -- balanced split, the
+ * first total_rows % world ranks own one row more -- with NO collective inside the rollout, and ONE RCCL all-gather (xGMI) of the
+ * local forecast stack at the end.  The engine owns the communicator: a host binding this ABI needs no torch.distributed.
+ *   dyf_comm_unique_id   rank 0 creates the 128-byte RCCL unique id; the caller distributes it (MPI, a file, torch.distributed ...)
+ *   dyf_comm_init        every rank, same id: ncclCommInitRank on the engine's device (librccl is dlopen'ed here, on first use)
+ *   dyf_sample_gather    dyf_sample of this rank's nb = ceil(total_rows / world) rows (ranks owning fewer repeat a row; call
+ *                        dyf_set_row_offset(lo_r) first so the rows draw the masks of the un-sharded batch), then ncclAllGather of the
+ *                        contiguous [n_out_slots][nb][C][H][W] stack and one unpack pass, all enqueued on `stream`:
+ *                        out_full_dev (n_out_slots, total_rows, C, H, W) holds t{i+1}_preds of ALL rows, global order, on every rank. */
+#define DYF_COMM_ID_BYTES 128
+dyf_status dyf_comm_unique_id(uint8_t* id_out /* [DYF_COMM_ID_BYTES], host */);
+dyf_status dyf_comm_init(dyf_engine* engine, const uint8_t* unique_id, int32_t rank, int32_t world);
+dyf_status dyf_comm_destroy(dyf_engine* engine);
+dyf_status dyf_sample_gather(dyf_engine* engine, const float* initial_dev, const float* static_dev, float* out_full_dev, int32_t nb,
+                             int32_t total_rows, void* stream);
 
 /* On-device ensemble metrics, replaces evaluate_ensemble_prediction (src/utilities/evaluation.py:10-118) and the
  * .cpu().numpy() round trip in front of it (_base_experiment.py:617-640).  preds_dev: (n_members, n_points) fp32 with

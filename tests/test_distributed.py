@@ -41,6 +41,15 @@ class _FakeModel:
         return _fake_rollout(x, static_condition, self.row0)
 
 
+class _FakeStackModel(_FakeModel):
+    """... with DYffusion.sample_stack: the forecast stack as one (h, rows, C, H, W) tensor + {slot: key}."""
+
+    def sample_stack(self, x, static_condition=None):
+        d = _fake_rollout(x, static_condition, self.row0)
+        keys = sorted(d)
+        return torch.stack([d[k] for k in keys], 0), dict(enumerate(keys))
+
+
 def _worker(rank, world, port, nb, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -48,9 +57,16 @@ def _worker(rank, world, port, nb, q):
     g = torch.Generator().manual_seed(0)
     x = torch.randn(nb, 3, 5, 4, generator=g)
     c = torch.rand(nb, 2, 5, 4, generator=g)
-    out = sample_sharded(_FakeModel(), x, c)
     want = _fake_rollout(x, c)
-    ok = all(torch.equal(out[k], want[k]) for k in want) and sorted(out) == sorted(want)
+    ok = True
+    calls, orig = [], dist.all_gather
+    dist.all_gather = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    for model in (_FakeModel(), _FakeStackModel()):  # dict route and stack route
+        del calls[:]
+        out = sample_sharded(model, x, c)
+        ok = ok and len(calls) == 1  # ONE collective per predict call, whatever the horizon
+        ok = ok and all(torch.equal(out[k], want[k]) for k in want) and sorted(out) == sorted(want)
+    dist.all_gather = orig
     lo, hi = shard_rows(nb, world, rank)
     back = all_gather_rows(x[lo:hi], nb, row_dim=0)
     ok = ok and torch.equal(back, x)

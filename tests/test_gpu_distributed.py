@@ -103,3 +103,54 @@ def test_rccl_collectives_single_rank():
     assert q.get(timeout=300) is True
     p.join(timeout=120)
     assert p.exitcode == 0
+
+
+def _engine_comm_worker(q):
+    """The ENGINE-owned exchange through the C ABI alone (no torch.distributed): dyf_comm_unique_id -> dyf_comm_init (rank 0 of 1)
+    -> dyf_sample_gather = rollout + ncclAllGather on the rollout's stream + unpack.  World size 1 (RCCL needs one device per
+    rank): the gathered stack must equal dyf_sample's, bit for bit, first call (graph capture) and replay."""
+    torch.cuda.set_device(0)
+    from dyffusion_amd.engine import HipEngine
+    nb = 5
+    x0, c = _inputs(nb)
+    m = _model(nb)
+    want = [{k: v.clone() for k, v in m.sample(x0.cuda(), static_condition=c.cuda()).items()} for _ in range(2)]
+    m.seed(31337)  # restart the dropout stream: the gathered calls must draw the same masks
+    uid = HipEngine.comm_unique_id()
+    m.comm_init(uid, 0, 1, (23, 11), nb)
+    got = [{k: v.clone() for k, v in m.sample_gathered(x0.cuda(), c.cuda(), nb).items()} for _ in range(2)]
+    torch.cuda.synchronize()
+    ok = all(sorted(g) == sorted(w) and all(torch.equal(g[k], w[k]) for k in w) for g, w in zip(got, want))
+    ok = ok and not torch.equal(got[0]["t4_preds"], got[1]["t4_preds"])  # MC dropout: the replay drew fresh masks
+    try:
+        m._engine.comm_init(uid, 0, 1)  # a second communicator on the same engine is refused
+        ok = False
+    except RuntimeError:
+        pass
+    m._engine.comm_destroy()
+    q.put(bool(ok))
+
+
+def test_engine_owned_rccl_exchange_single_rank():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_engine_comm_worker, args=(q,))
+    p.start()
+    assert q.get(timeout=300) is True
+    p.join(timeout=120)
+    assert p.exitcode == 0
+
+
+def test_gather_unpack_matches_the_row_split():
+    """The unpack kernel behind dyf_sample_gather against the host's shard arithmetic: world 1 exercises the identity; the index
+    map for world > 1 (uneven shards, padding rows dropped) is the torch route's `_unpack_stack`, checked here on the GPU."""
+    from dyffusion_amd.distributed import _unpack_stack, rows_per_rank, shard_rows
+    g = torch.Generator().manual_seed(3)
+    for world, total in [(2, 5), (8, 50), (4, 3), (3, 9)]:
+        rpr = rows_per_rank(total, world)
+        full = torch.randn(world, 4, rpr, 3, 6, 5, generator=g).cuda()
+        out = _unpack_stack(full, total, world)
+        assert out.shape == (4, total, 3, 6, 5)
+        for r in range(world):
+            lo, hi = shard_rows(total, world, r)
+            assert torch.equal(out[:, lo:hi], full[r, :, : hi - lo])
