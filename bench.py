@@ -323,8 +323,19 @@ def main():
     # itself, on the rollout's stream (dyf_sample_gather); DYF_BENCH_EXCHANGE=torch selects the torch.distributed route
     exchange = os.environ.get("DYF_BENCH_EXCHANGE", "engine" if world > 1 and dist.get_backend() == "nccl" else "torch")
     if world > 1 and gather and exchange == "engine":
-        init_engine_comm(model, (H, W), total_rows)
-        log("engine-owned RCCL communicator initialised")
+        try:
+            init_engine_comm(model, (H, W), total_rows)
+            ok = 1
+        except Exception as ex:  # e.g. no librccl for dlopen: every rank falls back to the torch.distributed route together
+            log(f"engine-owned communicator unavailable ({type(ex).__name__}: {ex})")
+            ok = 0
+        flag = torch.tensor([ok], device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 1:
+            log("engine-owned RCCL communicator initialised")
+        else:
+            exchange = "torch"
+            model._engine_comm_world = 1
     for _ in range(args.warmup):
         step()
         torch.cuda.synchronize()
