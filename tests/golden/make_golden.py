@@ -408,6 +408,74 @@ def gen_plosses_train():
         print(name, vals, "grad norm", gn)
 
 
+def gen_plosses_train_resnet():
+    """The TRAINING step of the imported reference with the ResNet-UNet `src.models.unet.Unet` as the forecaster (OISST channel
+    plumbing: C=1, forecaster conditioned on the initial condition, interpolator 2 -> 1): `DYffusion.p_losses` in train mode
+    (GroupNorm has no batch statistics; every nn.Dropout -- block dropouts, LinearAttention input dropout, Attention
+    probability dropout -- draws from DropoutSeeded(seed) in call order; the frozen interpolator in eval mode with its dropout
+    active), loss.backward().  Stored: inputs, weights, losses, the gradient w.r.t. every forecaster parameter, and for variant
+    b the normal draws of forward_conditioning="data+noise"."""
+    variants = [
+        ("plosses_train_resnet_a", dict(h=4, seed=81, dim=8, mults=(1, 2), hw=(12, 8)),
+         dict(forward_conditioning="data", lambda_reconstruction=1.0, lambda_reconstruction2=0.5, loss_function="l1")),
+        ("plosses_train_resnet_b", dict(h=5, seed=82, dim=8, mults=(1, 2, 4), hw=(12, 12)),
+         dict(additional_interpolation_steps=2, forward_conditioning="data+noise", lambda_reconstruction=0.7,
+              lambda_reconstruction2=1.0, loss_function="mse")),
+    ]
+    for name, meta, dk in variants:
+        h = meta["h"]
+        mk = dict(dim=meta["dim"], dim_mults=meta["mults"], with_time_emb=True, block_dropout=0.2, block_dropout1=0.1, attn_dropout=0.15)
+        dkw = dict(enable_interpolator_dropout=True)
+        dkw.update(dk)
+        exp, ipol = ref_import.build_reference_dyffusion(system="oisst", model="unet_resnet", model_kwargs=mk, horizon=h,
+                                                         diffusion_kwargs=dkw, box_size=meta["hw"][0])
+
+        def seed_net(net, seed):
+            shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
+            st = oinit.seeded_state(shapes, seed, gain=1.0)
+            for k in st:
+                if k.endswith(".norm.g"):
+                    st[k] = 1.0 + 0.1 * torch.randn(shapes[k], generator=torch.Generator().manual_seed(len(k)))
+            net.load_state_dict(st, strict=True)
+
+        seed_net(exp.model.model, 41)
+        seed_net(ipol.model, 42)
+        dyn = exp.model
+        dyn.train()
+        dyn.interpolator.eval()  # frozen (see gen_plosses_train)
+        for p in dyn.model.parameters():
+            p.requires_grad_(True)
+        assert not ipol.model.training and all(not p.requires_grad for p in ipol.model.parameters())
+        T = dyn.num_timesteps
+        fch, ich = dyn.model, ipol.model
+        g = torch.Generator().manual_seed(23)
+        B, (Hh, Ww) = 5, meta["hw"]
+        xt_last = torch.randn(B, 1, Hh, Ww, generator=g)
+        cond = torch.randn(B, 1, Hh, Ww, generator=g)
+        t = torch.tensor([0, 1, T - 1, 2 % T, T - 2])
+        sd0 = {k: v.detach().clone() for k, v in dyn.model.state_dict().items()}
+        with patched_dropout(DropoutSeeded(seed=meta["seed"])), patched_randn_like(500 + meta["seed"]) as draws:
+            out = dyn.p_losses(xt_last, cond, t, static_condition=None)
+            out["loss"].backward()
+        hp = dict(timesteps=h, num_timesteps=T, model=dict(mk, dim_mults=list(mk["dim_mults"])), B=B, dropout_seed=meta["seed"],
+                  noise_seed=500 + meta["seed"], n_noise_draws=len(draws),
+                  forecaster_channels=dict(inputs=fch.num_input_channels, cond=fch.num_conditional_channels),
+                  interpolator_channels=dict(inputs=ich.num_input_channels, cond=ich.num_conditional_channels),
+                  **{k: dkw.get(k, d) for k, d in dict(
+                      schedule="before_t1_only", additional_interpolation_steps=0, additional_interpolation_steps_factor=0,
+                      interpolate_before_t1=True, time_encoding="dynamics", forward_conditioning="none",
+                      lambda_reconstruction=1.0, lambda_reconstruction2=0.0, loss_function="l1",
+                      enable_interpolator_dropout=True).items()})
+        arrs = {f"F::{k}": v.numpy() for k, v in sd0.items()}
+        arrs.update({f"I::{k}": v.numpy() for k, v in ipol.model.state_dict().items()})
+        arrs.update({f"G::{k}": p.grad.numpy() for k, p in dyn.model.named_parameters()})
+        vals = {k.split("/")[-1]: float(v) for k, v in out.items()}
+        np.savez_compressed(os.path.join(HERE, name + ".npz"), xt_last=xt_last.numpy(), cond=cond.numpy(), t=t.numpy(),
+                            hp=json.dumps(hp), losses=json.dumps(vals), **arrs)
+        gn = float(torch.cat([p.grad.reshape(-1) for p in dyn.model.parameters()]).norm())
+        print(name, vals, "grad norm", gn, "noise draws", len(draws), "channels", hp["forecaster_channels"], hp["interpolator_channels"])
+
+
 def gen_interp_train():
     """Stage 1 of the reference's training: `InterpolationExperiment.get_loss(batch)` (interpolation.py:149-167 ->
     `BaseModel.get_loss`, _base_model.py:108-138) with the interpolator network in train mode (batch-statistics BatchNorm,
@@ -703,7 +771,7 @@ def gen_ensemble_stats():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["schedules", "nets", "resnet", "samples", "fullsize", "metrics", "ckpt", "plosses", "stats", "boundary", "predict_step", "plosses_train", "fullsize_oisst", "interp_train"]
+    which = sys.argv[1:] or ["schedules", "nets", "resnet", "samples", "fullsize", "metrics", "ckpt", "plosses", "stats", "boundary", "predict_step", "plosses_train", "fullsize_oisst", "interp_train", "plosses_train_resnet"]
     if "stats" in which:
         gen_ensemble_stats()
     if "boundary" in which:
@@ -714,6 +782,8 @@ if __name__ == "__main__":
         gen_plosses()
     if "plosses_train" in which:
         gen_plosses_train()
+    if "plosses_train_resnet" in which:
+        gen_plosses_train_resnet()
     if "interp_train" in which:
         gen_interp_train()
     if "metrics" in which:
