@@ -479,7 +479,7 @@ dyf_status dyf_load_weights(dyf_engine* e, int32_t which, int32_t n_tensors, con
         n.table_of_time.clear();
         n.ntables = 0;
         e->plan.set = false;
-        return DYF_OK;
+        return rn_train_store_weights(e, which, sd);  // fp32 copy in the training layout (train_resnet.inc)
     }
     std::string missing;
     auto get = [&](const std::string& key, std::vector<int64_t> want) -> const TensorView* {

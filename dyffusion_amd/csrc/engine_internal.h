@@ -297,6 +297,7 @@ struct FwdOpts {
 // ---- training step (train.hip)
 namespace dyf {
 dyf_status train_store_weights(dyf_engine* e, int which, std::map<std::string, TensorView>& sd);
+dyf_status rn_train_store_weights(dyf_engine* e, int which, std::map<std::string, TensorView>& sd);  // arch unet.Unet
 void train_destroy(dyf_engine* e);
 }  // namespace dyf
 

@@ -49,9 +49,14 @@ struct TTape {              // what one recorded forward leaves for its backward
     uint32_t* row_keys = nullptr;
 };
 
+struct RTNet;   // ResNet-UNet training copy / tapes (train_resnet.inc)
+struct RTape;
+
 struct TrainState {
     TNet net[2];
     TTape tape[4];
+    RTNet* rnet[2] = {nullptr, nullptr};
+    RTape* rtape[4] = {nullptr, nullptr, nullptr, nullptr};
     // caching allocator of the tapes / temporaries: blocks go back to the pool instead of hipFree (which synchronises the
     // device) and are handed out again by exact size -- after the first step a training step allocates nothing.  Everything
     // runs on one stream, so reuse is ordered behind the previous use.
@@ -407,8 +412,17 @@ struct TNorm {
     const uint32_t* row_keys;
 };
 
-__device__ __forceinline__ float t_act(float u, int act) { return act == ACT_RELU ? fmaxf(u, 0.0f) : act == ACT_LEAKY ? (u > 0.0f ? u : 0.2f * u) : u; }
-__device__ __forceinline__ float t_dact(float u, int act) { return act == ACT_RELU ? (u > 0.0f ? 1.0f : 0.0f) : act == ACT_LEAKY ? (u > 0.0f ? 1.0f : 0.2f) : 1.0f; }
+__device__ __forceinline__ float t_act(float u, int act) {
+    if (act == ACT_SILU) return u / (1.0f + expf(-u));
+    return act == ACT_RELU ? fmaxf(u, 0.0f) : act == ACT_LEAKY ? (u > 0.0f ? u : 0.2f * u) : u;
+}
+__device__ __forceinline__ float t_dact(float u, int act) {
+    if (act == ACT_SILU) {
+        const float sg = 1.0f / (1.0f + expf(-u));
+        return sg * (1.0f + u * (1.0f - sg));
+    }
+    return act == ACT_RELU ? (u > 0.0f ? 1.0f : 0.0f) : act == ACT_LEAKY ? (u > 0.0f ? 1.0f : 0.2f) : 1.0f;
+}
 
 __device__ __forceinline__ float t_keep(const TNorm& a, int b, uint32_t e_in_row) {
     if (!a.drop) return 1.0f;
@@ -792,10 +806,13 @@ TConv block_geom(const UBlock& b, int nb) {
 
 }  // namespace
 
+#include "train_resnet.inc"  // recorded forward / backward of the ResNet-UNet (arch unet.Unet)
+
 namespace dyf {
 
 void train_destroy(dyf_engine* e) {
     if (!e->train) return;
+    rn_train_destroy(e);
     for (auto& n : e->train->net) tfree(e, n.owned);
     for (auto& t : e->train->tape) tfree(e, t.owned);
     tfree(e, e->train->ws_owned);
@@ -886,7 +903,8 @@ extern "C" {
 
 dyf_status dyf_train_zero_grads(dyf_engine* e, int32_t which) {
     if (!e || which < 0 || which > 1) return DYF_ERR_INVALID_ARGUMENT;
-    if (!e->train || !e->train->net[which].ready) return fail(e, DYF_ERR_STATE, "training needs arch unet_simple with loaded weights");
+    if (e->net[which].rn) { TK(hipSetDevice(e->cfg.device)); return rn_train_zero_grads(e, which); }
+    if (!e->train || !e->train->net[which].ready) return fail(e, DYF_ERR_STATE, "training needs arch unet_simple / unet with loaded weights");
     TK(hipSetDevice(e->cfg.device));
     for (auto& g : e->train->net[which].grads) TK(hipMemsetAsync(g.first, 0, g.second * sizeof(float), 0));
     TK(hipDeviceSynchronize());
@@ -897,6 +915,15 @@ dyf_status dyf_train_forward(dyf_engine* e, int32_t which, int32_t slot, const f
                              const float* cond_dev, float* out_dev, int32_t nb, int32_t flags, void* stream) {
     if (!e || which < 0 || which > 1 || slot < 0 || slot > 3 || !inputs_dev || !out_dev || nb < 1)
         return fail(e, DYF_ERR_INVALID_ARGUMENT, "dyf_train_forward: bad arguments");
+    if (e->net[which].rn) {
+        TK(hipSetDevice(e->cfg.device));
+        if (e->train) {  // the slot now belongs to this forward: drop a unet_simple tape that may sit in it
+            tfree(e, e->train->tape[slot].owned);
+            e->train->tape[slot] = TTape{};
+        }
+        return rn_train_forward(e, which, slot, inputs_dev, time_dev, cond_dev, out_dev, nb, flags, (hipStream_t)stream);
+    }
+    if (e->net[which].sc) return fail(e, DYF_ERR_UNSUPPORTED, "training step: arch unet_simple and unet (SimpleConvNet is the CPU plumbing config)");
     if (!e->train || !e->train->net[which].ready) return fail(e, DYF_ERR_STATE, "training needs arch unet_simple with loaded weights");
     Net& n = e->net[which];
     TNet& w = e->train->net[which];
@@ -1008,6 +1035,10 @@ dyf_status dyf_train_forward(dyf_engine* e, int32_t which, int32_t slot, const f
 
 dyf_status dyf_train_backward(dyf_engine* e, int32_t slot, const float* dout_dev, float* dinputs_dev, int32_t param_grads, void* stream) {
     if (!e || slot < 0 || slot > 3 || !dout_dev) return fail(e, DYF_ERR_INVALID_ARGUMENT, "dyf_train_backward: bad arguments");
+    if (e->train && e->train->rtape[slot] && e->train->tape[slot].net < 0) {  // the slot holds a ResNet-UNet forward
+        TK(hipSetDevice(e->cfg.device));
+        return rn_train_backward(e, slot, dout_dev, dinputs_dev, param_grads, (hipStream_t)stream);
+    }
     if (!e->train || e->train->tape[slot].net < 0) return fail(e, DYF_ERR_STATE, "no forward recorded in this tape slot");
     TK(hipSetDevice(e->cfg.device));
     hipStream_t st = (hipStream_t)stream;
@@ -1152,6 +1183,7 @@ dyf_status dyf_train_export_dev(dyf_engine* e, int32_t which, int32_t n_tensors,
 }
 static dyf_status train_export_impl(dyf_engine* e, int32_t which, int32_t n_tensors, const char* const* names, float* const* out_host, bool dev) {
     if (!e || which < 0 || which > 1 || !names || !out_host) return fail(e, DYF_ERR_INVALID_ARGUMENT, "dyf_train_export: bad arguments");
+    if (e->net[which].rn) { TK(hipSetDevice(e->cfg.device)); return rn_train_export(e, which, n_tensors, names, out_host, dev); }
     if (!e->train || !e->train->net[which].ready) return fail(e, DYF_ERR_STATE, "training needs arch unet_simple with loaded weights");
     TK(hipSetDevice(e->cfg.device));
     TK(hipDeviceSynchronize());
@@ -1324,8 +1356,28 @@ static dyf_status train_load_weights_impl(dyf_engine* e, int32_t which, int32_t 
         return fail(e, DYF_ERR_INVALID_ARGUMENT, "dyf_train_load_weights: bad arguments");
     TK(hipSetDevice(e->cfg.device));
     const Net& n = e->net[which];
+    if (n.rn && n.loaded) {  // ResNet-UNet: the training copy is rebuilt (device tensors are staged through the host)
+        std::map<std::string, TensorView> sd;
+        std::vector<std::vector<float>> stage;
+        if (dev) TK(hipDeviceSynchronize());
+        for (int i = 0; i < n_tensors; ++i) {
+            TensorView v;
+            v.shape.assign(shapes[i], shapes[i] + ndims[i]);
+            v.data = data[i];
+            if (dev) {
+                stage.emplace_back((size_t)v.numel());
+                TK(hipMemcpy(stage.back().data(), data[i], stage.back().size() * sizeof(float), hipMemcpyDeviceToHost));
+            }
+            sd[names[i]] = v;
+        }
+        if (dev) {
+            size_t k = 0;
+            for (int i = 0; i < n_tensors; ++i) sd[names[i]].data = stage[k++].data();
+        }
+        return rn_train_store_weights(e, which, sd);
+    }
     if (n.rn || n.sc || !n.loaded || !e->train || !e->train->net[which].ready)
-        return fail(e, DYF_ERR_STATE, "dyf_train_load_weights: arch unet_simple with weights loaded once by dyf_load_weights");
+        return fail(e, DYF_ERR_STATE, "dyf_train_load_weights: arch unet_simple / unet with weights loaded once by dyf_load_weights");
     std::map<std::string, TensorView> sd;
     for (int i = 0; i < n_tensors; ++i) {
         TensorView v;

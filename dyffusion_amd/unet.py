@@ -11,7 +11,8 @@ import torch
 from torch import Tensor, nn
 
 from . import _lib as L
-from .engine import HipEngine, default_dtype_for, mark_weights_modified, resnet_net_config, sync_weights, upload_weights
+from .engine import (EngineLoss, HipEngine, collect_train_results, default_dtype_for, mark_weights_modified, resnet_net_config,
+                     sync_train_weights, sync_weights, upload_weights)
 from .unet_simple import _AttrDict
 
 HEADS, DIM_HEAD = 4, 32
@@ -170,15 +171,38 @@ class Unet(nn.Module):
 
     def get_loss(self, inputs: Tensor, targets: Tensor, condition: Tensor = None, metadata=None, predictions_mask=None,
                  return_predictions: bool = False, **kwargs):
-        """`BaseModel.get_loss` (_base_model.py:108-138) in eval mode: predict, then the network's criterion.  The engine's training
-        step (recorded forward + backward) exists for arch `unet_simple` only (csrc/train.hip)."""
-        if self.training:
-            raise NotImplementedError("training step of the ResNet-UNet on the HIP engine (csrc/train.hip covers arch unet_simple)")
-        predictions = self(inputs, condition=condition, **kwargs)
-        p = predictions if predictions_mask is None else predictions[predictions_mask]
+        """`BaseModel.get_loss` (_base_model.py:108-138): predict, then the network's criterion.  In eval mode a plain forward; with
+        the module in TRAIN mode the engine's recorded fp32 forward (Dropout active; csrc/train_resnet.inc) -- the returned
+        scalar's `.backward()` runs dyf_train_backward and accumulates into `param.grad`."""
         kind = getattr(self.hparams, "loss_function", "mean_squared_error")
-        loss = predictions.new_tensor(self._engine.criterion(p.contiguous(), targets, kind))
-        return (loss, predictions) if return_predictions else loss
+        if not self.training:
+            predictions = self(inputs, condition=condition, **kwargs)
+            p = predictions if predictions_mask is None else predictions[predictions_mask]
+            loss = predictions.new_tensor(self._engine.criterion(p.contiguous(), targets, kind))
+            return (loss, predictions) if return_predictions else loss
+        if predictions_mask is not None:
+            raise NotImplementedError("predictions_mask in the engine's training step")
+        if self.num_conditional_channels > 0 and condition is None:
+            raise ValueError("condition must be given when num_conditional_channels > 0")
+        eng = self._own_engine(inputs.shape[0], inputs.shape[-2:])
+        sync_train_weights(self, eng, self._engine_slot)
+        time = kwargs.get("time") if self.hparams.with_time_emb else None
+        pred = eng.train_forward(self._engine_slot, 0, inputs, None if time is None else time.float(), condition,
+                                 batch_stats=True, dropout=self.has_dropout)
+        value = eng.criterion(pred, targets, kind)
+        eng.train_step_id += 1
+        self._train_state = dict(eng=eng, pred=pred, targets=targets.float().contiguous(), kind=kind, step_id=eng.train_step_id)
+        if not hasattr(self, "_grad_anchor"):
+            self._grad_anchor = torch.zeros((), requires_grad=True)
+        loss = EngineLoss.apply(self._grad_anchor, self, float(value))
+        return (loss, pred) if return_predictions else loss
+
+    def _train_backward(self, upstream: float):
+        st = self._train_state
+        eng = st["eng"]
+        d = eng.criterion_grad(st["pred"], st["targets"], st["kind"], upstream)
+        eng.train_backward(0, d, want_dinputs=False, param_grads=True)
+        collect_train_results(self, eng, self._engine_slot, 1)
 
     def predict_forward(self, inputs: Tensor, metadata=None, **kwargs):
         return self(inputs, **kwargs)

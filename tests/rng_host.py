@@ -109,3 +109,36 @@ class EngineDropout:
         keep = mask_nchw(x.shape[0], (h, w, c), p, self.seed, self.fwd, self.site, self.row_offset).to(x.dtype)
         self.site += 1
         return x * keep * (1.0 / (1.0 - p))
+
+
+class ResnetEngineDropout:
+    """Dropout source for `oracle.nets.resnet_unet_forward(..., dropout=)` that replays the ENGINE's masks in the training step of
+    the ResNet-UNet (csrc/train_resnet.inc): sites are numbered in execution order over the layers with p > 0; a feature map
+    (b, C, H, W) is indexed NHWC inside its row, the bottleneck Attention's probabilities (b, heads, N, N) as (h * N + i) * N + j.
+    Call `begin_forward()` before every network forward that draws masks."""
+
+    def __init__(self, seed, attn_tokens, row_offset=0, first_forward=0):
+        self.seed, self.row_offset, self.attn_tokens = seed, row_offset, attn_tokens
+        self.fwd = first_forward - 1
+        self.site = 0
+
+    def begin_forward(self):
+        self.fwd += 1
+        self.site = 0
+
+    def apply(self, x, p):
+        if p <= 0.0:
+            return x
+        b = x.shape[0]
+        probs = x.dim() == 4 and x.shape[1] == 4 and x.shape[2] == x.shape[3] == self.attn_tokens
+        rows = []
+        for r in range(b):
+            if probs:
+                m = row_mask_nhwc((4, self.attn_tokens, self.attn_tokens), p, self.seed, self.fwd, self.site, self.row_offset + r)
+            else:
+                c, h, w = x.shape[1:]
+                m = row_mask_nhwc((h, w, c), p, self.seed, self.fwd, self.site, self.row_offset + r).transpose(2, 0, 1)
+            rows.append(m)
+        keep = torch.from_numpy(np.stack(rows, 0).astype(np.float32))
+        self.site += 1
+        return x * keep * (1.0 / (1.0 - p))
