@@ -97,6 +97,7 @@ SYMBOLS = [
     ("dyf_op_linear_attention", C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, _P]),
     ("dyf_op_linear_attention_fused", C.c_int, [_P, _P, _P, C.c_int32, C.c_int32, C.c_int32, _P, _P, _P, _P, _P]),
     ("dyf_op_attention", C.c_int, [_P, _P, C.c_int32, C.c_int32, _P, _P]),
+    ("dyf_op_attention_dropout", C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_float, _P, _P]),
     ("dyf_criterion", C.c_int, [_P, _P, _P, C.c_int64, C.c_int32, _P, _P]),
     ("dyf_train_forward", C.c_int, [_P, C.c_int32, C.c_int32, _P, _P, _P, _P, C.c_int32, C.c_int32, _P]),
     ("dyf_train_backward", C.c_int, [_P, C.c_int32, _P, _P, C.c_int32, _P]),

@@ -1558,11 +1558,24 @@ dyf_status dyf_op_linear_attention_fused(dyf_engine* e, const uint16_t* xn_dev, 
 }
 
 dyf_status dyf_op_attention(dyf_engine* e, const uint16_t* qkv_dev, int32_t n, int32_t hw, uint16_t* out_dev, void* stream) {
-    if (!e || !qkv_dev || !out_dev || n < 1 || hw < 1) return fail(e, DYF_ERR_INVALID_ARGUMENT, "dyf_op_attention: bad arguments");
+    return dyf_op_attention_dropout(e, qkv_dev, n, hw, 0.0f, out_dev, stream);
+}
+
+dyf_status dyf_op_attention_dropout(dyf_engine* e, const uint16_t* qkv_dev, int32_t n, int32_t hw, float p, uint16_t* out_dev, void* stream) {
+    if (!e || !qkv_dev || !out_dev || n < 1 || hw < 1 || p < 0.0f || p >= 1.0f) return fail(e, DYF_ERR_INVALID_ARGUMENT, "dyf_op_attention: bad arguments");
     HIP_TRY(e, hipSetDevice(e->cfg.device));
     hipStream_t st = (hipStream_t)stream;
     AttnArgs a{};
     a.qkv = qkv_dev; a.n = n; a.hw = hw; a.heads = 4; a.out = out_dev; a.drop = DropSpec{};
+    if (p > 0.0f) {  // dropout on the probabilities from the engine's generator (forward counter advances, as in a network forward)
+        if (n > 2 * e->cfg.max_batch) return fail(e, DYF_ERR_INVALID_ARGUMENT, "more rows than the engine's row-key table (2 max_batch)");
+        HIP_TRY(e, launch_rng_begin_forward(e->rng_state, e->row_keys, n, n, st));
+        a.drop.mode = 1;
+        a.drop.scale = 1.0f / (1.0f - p);
+        a.drop.thresh16 = keep_threshold16(p);
+        a.drop.salt = rng_layer_salt(0u);
+        a.drop.row_keys = e->row_keys;
+    }
     hipError_t err = launch_attention(a, st);
     if (err == hipSuccess) err = hipStreamSynchronize(st);
     if (err != hipSuccess) return fail(e, DYF_ERR_HIP, std::string("dyf_op_attention: ") + hipGetErrorString(err));

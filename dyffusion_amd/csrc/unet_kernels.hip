@@ -1689,11 +1689,206 @@ __global__ __launch_bounds__(256) void flash_attention_kernel(AttnArgs a) {
     }
 }
 
+// ---- second form (round 3): the same data flow with the softmax's VALU work cut to what the exponentials need.
+// The first form is VALU-bound: per 32-key sub-tile a lane spends 16 scale multiplies, 16 max, 16 subtractions, 16 exp2, 16 adds,
+// 16 rescales of O, 8 packs and two cross-lane exchanges (~370 issue cycles) next to 4 MFMAs (128 cycles).  Here:
+//   * Q is multiplied by scale * log2(e) ONCE, when its fragments are loaded;
+//   * the running maximum m enters through the MFMA's C operand: the score accumulators START at -m, so the MFMA delivers s - m
+//     (16 register moves instead of 16 subtractions behind the MFMA's latency);
+//   * m is LAZY: it moves only when some score of the sub-tile exceeds it by more than 2^6 (then, and on the first sub-tile, a
+//     wave-uniform slow path rescales O and l) -- exp2 of a value <= 6 is at most 64, harmless in fp32 sums and in the 16-bit P
+//     operand -- so the common path has no rescale of O, no alpha, and no cross-lane exchange at all;
+//   * the normaliser is summed per LANE (both lanes of a query share m) and the two halves meet once, at the end;
+//   * the dropout scale 1/(1-p) is applied once to the output instead of to every kept probability.
+// Common path per sub-tile and lane: 8 v_max3, one compare, 16 v_exp_f32, 16 adds, 8 packs (+ 8 keep words and 16 selects with
+// dropout on the probabilities).
+// VARIANT 1: whole tile, no dropout; 2: whole tile, engine dropout with paired keep words; 0: general (partial tiles; dropout per
+// element when DROP).  DROP is the kernel's compile-time dropout switch: the no-dropout kernel carries no generator code at all
+// (register budget: 128 per lane for 4 waves per SIMD).
+template <int VARIANT, bool DROP>
+__device__ __forceinline__ void fa2_subtile(const AttnArgs& a, const el16_t* Ks, const el16_t* Vt, const el16x8_t (&qf)[2], fa_f32x16& o,
+                                            float& m, float& l_lane, bool& first, int jb, int st, int q, int N, int l31,
+                                            int hi, RngKey dkey, uint32_t bh) {
+    fa_f32x16 sc;
+    const float nm = -m;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sc[r] = nm;   // 16 moves instead of a second 16-register tuple kept alive across the loop
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        const int key = st * 32 + l31;
+        const el16x8_t kf = *(const el16x8_t*)(Ks + key * 32 + (((ks * 2 + hi) ^ ((key >> 2) & 3)) << 3));
+        sc = DYF_MFMA_32x32x16(kf, qf[ks], sc, 0, 0, 0);
+    }
+    // lane (q, hi) holds (score - m) of keys jb + (r&3) + 8(r>>2) + 4hi of query q, in the log2 domain
+    if (VARIANT == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            if (jb + (r & 3) + 8 * (r >> 2) + 4 * hi >= N) sc[r] = -1.0e30f;
+    }
+    float tmax = fmaxf(fmaxf(sc[0], sc[1]), sc[2]);
+#pragma unroll
+    for (int r = 3; r < 15; r += 2) tmax = fmaxf(fmaxf(tmax, sc[r]), sc[r + 1]);
+    tmax = fmaxf(tmax, sc[15]);
+    if (first || __builtin_amdgcn_ballot_w64(tmax > 6.0f) != 0ull) {  // wave-uniform; rare after the first sub-tiles
+        const float tm = fmaxf(tmax, __shfl_xor(tmax, 32, 64));         // both lanes of a query agree on the new maximum
+        const float delta = first ? tm : fmaxf(tm, 0.0f);               // first sub-tile: m = the exact maximum (m was 0)
+        const float alpha = __builtin_amdgcn_exp2f(-delta);             // (first: O and l are still zero)
+        m += delta;
+        l_lane *= alpha;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            o[r] *= alpha;
+            sc[r] -= delta;
+        }
+        first = false;
+    }
+    float p[16], psum = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+#ifdef FA_EXP_NO_EXP
+        p[r] = sc[r] + 1.0f;  // timing experiment (wrong results): no exponentials
+#else
+        p[r] = __builtin_amdgcn_exp2f(sc[r]);
+#endif
+        psum += p[r];   // the normaliser is accumulated BEFORE dropout (attention.py:69-70)
+    }
+    l_lane += psum;
+    if (VARIANT == 2) {
+        const uint32_t th = a.drop.thresh16;
+        const uint32_t e0 = (uint32_t)q * (uint32_t)N + (uint32_t)(jb + 4 * hi);  // even: N even, jb and 4*hi multiples of 4
+#pragma unroll
+        for (int pr = 0; pr < 8; ++pr) {  // registers 2*pr, 2*pr + 1: keys e0 + 8*(pr >> 1) + 2*(pr & 1) + {0, 1}
+            const uint32_t w = rng_pair_word((e0 + 8u * (uint32_t)(pr >> 1) + 2u * (uint32_t)(pr & 1)) >> 1, dkey);
+            p[2 * pr] = (w & 0xffffu) < th ? p[2 * pr] : 0.0f;
+            p[2 * pr + 1] = (w >> 16) < th ? p[2 * pr + 1] : 0.0f;
+        }
+    } else if (VARIANT == 0 && DROP) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int j = jb + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            const bool keep = j < N && q < N &&
+                              (a.drop.mode == 1 ? rng_keep((uint32_t)q * (uint32_t)N + (uint32_t)j, dkey, a.drop.thresh16)
+                                                : (a.drop.mask[((size_t)bh * N + q) * N + j] != 0));
+            p[r] = keep ? p[r] : 0.0f;
+        }
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+        uint32_t pk[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) pk[t] = pack_el16x2(p[s2 * 8 + 2 * t], p[s2 * 8 + 2 * t + 1]);
+        const el16x8_t pf = *(el16x8_t*)pk;
+        const el16_t* vr = Vt + l31 * 68 + st * 32 + s2 * 16 + 4 * hi;  // V^T fragment: lane (d = l31, hi): keys st*32 + 16*s2 + 4*hi + {0..3} and + 8
+        uint2 v0 = *(const uint2*)vr, v1 = *(const uint2*)(vr + 8);
+        uint32_t vw[4] = {v0.x, v0.y, v1.x, v1.y};
+        const el16x8_t vf = *(el16x8_t*)vw;
+        o = DYF_MFMA_32x32x16(vf, pf, o, 0, 0, 0);
+    }
+}
+
+// Occupancy decides this kernel (measured, 16 384 tokens x 4 heads x NB = 4, no dropout): the chain K-fragment read -> 2 MFMA ->
+// max -> 16 exp -> pack -> V-fragment read -> 2 MFMA of a sub-tile is latency, not issue, bound -- removing the exponentials AND the
+// V^T staging altogether moved 1.72 ms to 1.49 ms, while 3 instead of 2 resident waves per SIMD moved it to 1.24 ms.  Hence the
+// register diet (no second accumulator tuple) and 4 waves per SIMD.
+#ifndef FA2_MINW
+#define FA2_MINW 4
+#endif
+template <bool DROP>
+__global__ __launch_bounds__(256, FA2_MINW) void flash_attention2_kernel(AttnArgs a) {
+    __shared__ __attribute__((aligned(16))) el16_t Ks[64 * 32];   // [key][32 ch], 16-B chunk ^= (key >> 2) & 3
+    __shared__ __attribute__((aligned(16))) el16_t Vt[32 * 68];   // [ch][64 keys + 4 pad]
+    const int qblocks = (a.hw + 127) / 128;
+    const int bh = blockIdx.x / qblocks, qb = blockIdx.x % qblocks;
+    const int n = bh / a.heads, h = bh % a.heads;
+    const int C3 = 3 * a.heads * 32, hd = a.heads * 32, N = a.hw;
+    const el16_t* base = a.qkv + (size_t)n * N * C3;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
+    const int q = qb * 128 + wave * 32 + l31;
+    const float c2 = 0.17677669529663687f * 1.4426950408889634f;  // 32^-1/2 * log2(e): scores live in the log2 domain
+    el16x8_t qf[2];  // Q fragments (B operand of S^T), pre-multiplied by c2: lane (q, hi) holds channels ks*16 + hi*8 .. +8
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (q < N) v = *(const uint4*)(base + (size_t)q * C3 + h * 32 + ks * 16 + hi * 8);
+        uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) w[t] = pack_el16x2(el16_lo(w[t]) * c2, el16_hi(w[t]) * c2);
+        qf[ks] = *(el16x8_t*)w;
+    }
+    fa_f32x16 o;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] = 0.0f;
+    float m = 0.0f, l_lane = 0.0f;
+    bool first = true;
+    const RngKey dkey = DROP ? attn_drop_key(a.drop, n, (uint32_t)h) : RngKey{0u, 0u};
+
+    const int skey = tid >> 2, sch = tid & 3;   // staging role: thread -> (key, 16-B chunk of 8 channels)
+    uint4 kv_n = make_uint4(0, 0, 0, 0), vv_n = make_uint4(0, 0, 0, 0);
+    auto fetch = [&](int j0) {  // K / V of the NEXT 64-key tile travel through registers while the current one is consumed
+        const int j = j0 + skey;
+        kv_n = make_uint4(0, 0, 0, 0);
+        vv_n = kv_n;
+        if (j < N) {
+            kv_n = *(const uint4*)(base + (size_t)j * C3 + hd + h * 32 + sch * 8);
+            vv_n = *(const uint4*)(base + (size_t)j * C3 + 2 * hd + h * 32 + sch * 8);
+        }
+    };
+    fetch(0);
+    for (int j0 = 0; j0 < N; j0 += 64) {
+#ifndef FA_EXP_NOSYNC
+        __syncthreads();  // every wave is done reading the previous tile
+#endif
+        {
+            *(uint4*)(Ks + skey * 32 + ((sch ^ ((skey >> 2) & 3)) << 3)) = kv_n;
+            const el16_t* ve = (const el16_t*)&vv_n;
+#ifdef FA_EXP_NO_VT
+            if (j0 == 0)  // timing experiment (wrong results): V^T staged once
+#endif
+#pragma unroll
+            for (int i = 0; i < 8; ++i) Vt[(sch * 8 + i) * 68 + skey] = ve[i];
+        }
+        if (j0 + 64 < N) fetch(j0 + 64);
+#ifndef FA_EXP_NOSYNC
+        __syncthreads();
+#endif
+        const bool whole = j0 + 64 <= N;  // block-uniform
+        // (the two sub-tiles of a tile run as a rolled loop: unrolled, the compiler interleaves them and needs > 128 registers)
+        if (whole && !DROP) {
+#pragma nounroll
+            for (int st = 0; st < 2; ++st)
+                fa2_subtile<1, false>(a, Ks, Vt, qf, o, m, l_lane, first, j0 + 32 * st, st, q, N, l31, hi, dkey, (uint32_t)bh);
+        } else if (DROP && whole && a.drop.mode == 1 && (N & 1) == 0 && (qb + 1) * 128 <= N) {
+#pragma nounroll
+            for (int st = 0; st < 2; ++st)
+                fa2_subtile<2, DROP>(a, Ks, Vt, qf, o, m, l_lane, first, j0 + 32 * st, st, q, N, l31, hi, dkey, (uint32_t)bh);
+        } else {
+            fa2_subtile<0, DROP>(a, Ks, Vt, qf, o, m, l_lane, first, j0, 0, q, N, l31, hi, dkey, (uint32_t)bh);
+            if (j0 + 32 < N) fa2_subtile<0, DROP>(a, Ks, Vt, qf, o, m, l_lane, first, j0 + 32, 1, q, N, l31, hi, dkey, (uint32_t)bh);
+        }
+    }
+    const float l = l_lane + __shfl_xor(l_lane, 32, 64);
+    if (q >= N) return;
+    // O^T[d][q]: lane (q, hi) holds d = (r&3) + 8(r>>2) + 4hi  -> four 8-byte stores of 4 consecutive channels
+    const float inv = (DROP ? a.drop.scale : 1.0f) / l;
+    el16_t* op = a.out + ((size_t)n * N + q) * hd + h * 32;  // "b h (x y) d -> b (h d) x y"
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        uint2 w;
+        w.x = pack_el16x2(o[g * 4 + 0] * inv, o[g * 4 + 1] * inv);
+        w.y = pack_el16x2(o[g * 4 + 2] * inv, o[g * 4 + 3] * inv);
+        *(uint2*)(op + 8 * g + 4 * hi) = w;
+    }
+}
+
 hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
-    static const bool use_flash = !(getenv("DYF_FLASH_ATTN") && atoi(getenv("DYF_FLASH_ATTN")) == 0);
-    if (use_flash && a.hw <= 65535) {
+    // DYF_FLASH_ATTN: unset / 2 = flash_attention2_kernel, 1 = the first flash form, 0 = the plain per-query kernel
+    static const int flash = getenv("DYF_FLASH_ATTN") ? atoi(getenv("DYF_FLASH_ATTN")) : 2;
+    if (flash != 0 && a.hw <= 65535) {
         const int qblocks = (a.hw + 127) / 128;
-        hipLaunchKernelGGL(flash_attention_kernel, dim3(a.n * a.heads * qblocks), dim3(256), 0, s, a);
+        dyf_form_note(flash == 1 ? "flash_attention_kernel" : "flash_attention2_kernel", a.n);
+        if (flash == 1) hipLaunchKernelGGL(flash_attention_kernel, dim3(a.n * a.heads * qblocks), dim3(256), 0, s, a);
+        else if (a.drop.mode != 0) hipLaunchKernelGGL(flash_attention2_kernel<true>, dim3(a.n * a.heads * qblocks), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(flash_attention2_kernel<false>, dim3(a.n * a.heads * qblocks), dim3(256), 0, s, a);
         return hipGetLastError();
     }
     const int qtiles = (a.hw + 63) / 64;

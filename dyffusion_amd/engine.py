@@ -519,12 +519,13 @@ class HipEngine:
     def torch_dtype(self) -> torch.dtype:
         return torch.float16 if L.DTYPES[self.dtype] else torch.bfloat16
 
-    def op_attention(self, qkv: torch.Tensor) -> torch.Tensor:
-        """Test seam: Attention core.  qkv (N,HW,384) in the engine's 16-bit dtype (to_qkv output) -> (N,HW,128)."""
+    def op_attention(self, qkv: torch.Tensor, p_drop: float = 0.0) -> torch.Tensor:
+        """Test seam: Attention core.  qkv (N,HW,384) in the engine's 16-bit dtype (to_qkv output) -> (N,HW,128); p_drop > 0:
+        dropout on the probabilities from the engine's generator."""
         assert qkv.dtype == self.torch_dtype and qkv.is_cuda and qkv.is_contiguous() and qkv.shape[2] == 384
         n, hw, _ = qkv.shape
         y = torch.empty((n, hw, 128), dtype=qkv.dtype, device=qkv.device)
-        self._check(self._lib.dyf_op_attention(self._h, qkv.data_ptr(), n, hw, y.data_ptr(), self._stream()))
+        self._check(self._lib.dyf_op_attention_dropout(self._h, qkv.data_ptr(), n, hw, float(p_drop), y.data_ptr(), self._stream()))
         return y
 
     def op_upconv2d(self, x_nhwc_bf16: torch.Tensor, weight: torch.Tensor, scale: Optional[torch.Tensor] = None,

@@ -64,6 +64,10 @@ dyf_status dyf_op_linear_attention_fused(dyf_engine* engine, const uint16_t* xn_
  * of the ResNet-UNet uses (HW up to 65 535: 16 384 tokens for the 512^2 synthetic configuration). */
 dyf_status dyf_op_attention(dyf_engine* engine, const uint16_t* qkv_dev, int32_t n, int32_t hw, uint16_t* out_dev,
                             void* stream);
+/* ... with nn.Dropout(p) on the softmax probabilities (attention.py:70), masks from the engine's generator: the form the
+ * interpolator's bottleneck runs under MC dropout (n <= 2 max_batch rows). */
+dyf_status dyf_op_attention_dropout(dyf_engine* engine, const uint16_t* qkv_dev, int32_t n, int32_t hw, float p, uint16_t* out_dev,
+                                    void* stream);
 
 /* One training convolution (csrc/train_gemm.hip: fp32 matrix-core forward / dgrad / wgrad of nn.Conv2d on NHWC fp32 tensors) on
  * hash-random data against the plain VALU kernel of csrc/train.hip.  kind 0 forward, 1 data gradient, 2 weight gradient; geometry

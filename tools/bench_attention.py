@@ -1,5 +1,5 @@
 """Time the flash-attention core (dyf_op_attention: 4 heads x 32 dims) at the bottleneck of BASELINE configs[4]: 16 384 tokens
-(128 x 128), NB rows.  usage: python tools/bench_attention.py [NB] [tokens]"""
+(128 x 128), NB rows, without and with dropout on the probabilities.  usage: python tools/bench_attention.py [NB] [tokens] [p]"""
 import os
 import sys
 
@@ -13,18 +13,21 @@ from dyffusion_amd.engine import net_config  # noqa: E402
 nb = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 16384
 cfg = net_config(in_channels=3, cond_channels=2, out_channels=3, dim=64, with_time_emb=True, upsample_dims=(64, 64), dropout=0.0)
-eng = D.HipEngine(cfg, cfg, 23, 11, max_batch=1, use_graph=False)
+p = float(sys.argv[3]) if len(sys.argv) > 3 else 0.1
+eng = D.HipEngine(cfg, cfg, 23, 11, max_batch=max(1, nb), use_graph=False)
 g = torch.Generator().manual_seed(0)
 qkv = torch.randn(nb, n, 384, generator=g).to(eng.torch_dtype).cuda()
-y = eng.op_attention(qkv)
-torch.cuda.synchronize()
-ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-reps = 10
-ev0.record()
-for _ in range(reps):
-    y = eng.op_attention(qkv)
-ev1.record()
-torch.cuda.synchronize()
-ms = ev0.elapsed_time(ev1) / reps
 fl = nb * 4 * 2 * 2 * n * n * 32
-print(f"flash attention NB={nb}, {n} tokens, 4 heads x 32: {ms:.3f} ms, {fl / ms / 1e9:.1f} TFLOP/s, finite={bool(torch.isfinite(y.float()).all())}")
+for pd in (0.0, p):
+    y = eng.op_attention(qkv, pd)
+    torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 10
+    ev0.record()
+    for _ in range(reps):
+        y = eng.op_attention(qkv, pd)
+    ev1.record()
+    torch.cuda.synchronize()
+    ms = ev0.elapsed_time(ev1) / reps
+    print(f"attention core NB={nb}, {n} tokens, 4 heads x 32, dropout p={pd}: {ms:.3f} ms, {fl / ms / 1e9:.1f} TFLOP/s = "
+          f"{fl / ms / 1e9 / 2500:.3f} of the dense MFMA peak, finite={bool(torch.isfinite(y.float()).all())}")
