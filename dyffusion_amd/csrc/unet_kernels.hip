@@ -1705,120 +1705,179 @@ __global__ __launch_bounds__(256) void flash_attention_kernel(AttnArgs a) {
 // VARIANT 1: whole tile, no dropout; 2: whole tile, engine dropout with paired keep words; 0: general (partial tiles; dropout per
 // element when DROP).  DROP is the kernel's compile-time dropout switch: the no-dropout kernel carries no generator code at all
 // (register budget: 128 per lane for 4 waves per SIMD).
-template <int VARIANT, bool DROP>
-__device__ __forceinline__ void fa2_subtile(const AttnArgs& a, const el16_t* Ks, const el16_t* Vt, const el16x8_t (&qf)[2], fa_f32x16& o,
-                                            float& m, float& l_lane, bool& first, int jb, int st, int q, int N, int l31,
-                                            int hi, RngKey dkey, uint32_t bh) {
-    fa_f32x16 sc;
-    const float nm = -m;
+// QB: 32-query blocks per wave.  QB = 2 (sequences of >= 512 tokens): a wave owns 64 queries -- two independent softmax chains
+// for the scheduler to interleave, and every K / V fragment read from LDS feeds two MFMAs.
+typedef float fa_f32x2 __attribute__((ext_vector_type(2)));
+// kf0 / kf1 / vf0: this lane's LDS addresses of the K fragments (ks = 0, 1) and of the V^T fragment of sub-tile 0 (sub-tile st adds
+// a wave-uniform offset: the swizzle key (key >> 2) & 3 does not depend on st).  NEGM: the tuple -m lives in registers across the
+// loop and is the MFMA's C operand (kernels with the registers to spare); otherwise 16 moves per sub-tile rebuild it.
+template <int VARIANT, bool DROP, int QB, bool NEGM>
+__device__ __forceinline__ void fa2_subtile(const AttnArgs& a, const el16_t* kf0, const el16_t* kf1, const el16_t* vf0, const el16x8_t (&qf)[QB][2],
+                                            fa_f32x16 (&o)[QB], fa_f32x16 (&negm)[QB], float (&m)[QB], fa_f32x2 (&l2)[QB], bool& first, int jb,
+                                            int st, int q0, int N, int hi, RngKey dkey, uint32_t bh) {
+    fa_f32x16 sc[QB];
+    {
+        const el16x8_t k0 = *(const el16x8_t*)(kf0 + st * 1024), k1 = *(const el16x8_t*)(kf1 + st * 1024);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) sc[r] = nm;   // 16 moves instead of a second 16-register tuple kept alive across the loop
+        for (int b = 0; b < QB; ++b) {
+            if (NEGM) {
+                sc[b] = DYF_MFMA_32x32x16(k0, qf[b][0], negm[b], 0, 0, 0);
+            } else {
+                const float nm = -m[b];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-        const int key = st * 32 + l31;
-        const el16x8_t kf = *(const el16x8_t*)(Ks + key * 32 + (((ks * 2 + hi) ^ ((key >> 2) & 3)) << 3));
-        sc = DYF_MFMA_32x32x16(kf, qf[ks], sc, 0, 0, 0);
+                for (int r = 0; r < 16; ++r) sc[b][r] = nm;
+                sc[b] = DYF_MFMA_32x32x16(k0, qf[b][0], sc[b], 0, 0, 0);
+            }
+            sc[b] = DYF_MFMA_32x32x16(k1, qf[b][1], sc[b], 0, 0, 0);
+        }
     }
     // lane (q, hi) holds (score - m) of keys jb + (r&3) + 8(r>>2) + 4hi of query q, in the log2 domain
-    if (VARIANT == 0) {
+    float tmax[QB];
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-            if (jb + (r & 3) + 8 * (r >> 2) + 4 * hi >= N) sc[r] = -1.0e30f;
+    for (int b = 0; b < QB; ++b) {
+        if (VARIANT == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (jb + (r & 3) + 8 * (r >> 2) + 4 * hi >= N) sc[b][r] = -1.0e30f;
+        }
+        float t = fmaxf(fmaxf(sc[b][0], sc[b][1]), sc[b][2]);
+#pragma unroll
+        for (int r = 3; r < 15; r += 2) t = fmaxf(fmaxf(t, sc[b][r]), sc[b][r + 1]);
+        tmax[b] = fmaxf(t, sc[b][15]);
     }
-    float tmax = fmaxf(fmaxf(sc[0], sc[1]), sc[2]);
+    const float tany = QB == 2 ? fmaxf(tmax[0], tmax[QB - 1]) : tmax[0];
+    if (first || __builtin_amdgcn_ballot_w64(tany > 6.0f) != 0ull) {  // wave-uniform; rare after the first sub-tiles
 #pragma unroll
-    for (int r = 3; r < 15; r += 2) tmax = fmaxf(fmaxf(tmax, sc[r]), sc[r + 1]);
-    tmax = fmaxf(tmax, sc[15]);
-    if (first || __builtin_amdgcn_ballot_w64(tmax > 6.0f) != 0ull) {  // wave-uniform; rare after the first sub-tiles
-        const float tm = fmaxf(tmax, __shfl_xor(tmax, 32, 64));         // both lanes of a query agree on the new maximum
-        const float delta = first ? tm : fmaxf(tm, 0.0f);               // first sub-tile: m = the exact maximum (m was 0)
-        const float alpha = __builtin_amdgcn_exp2f(-delta);             // (first: O and l are still zero)
-        m += delta;
-        l_lane *= alpha;
+        for (int b = 0; b < QB; ++b) {
+            const float tm = fmaxf(tmax[b], __shfl_xor(tmax[b], 32, 64));  // both lanes of a query agree on the new maximum
+            const float delta = first ? tm : fmaxf(tm, 0.0f);               // first sub-tile: m = the exact maximum (m was 0)
+            const float alpha = __builtin_amdgcn_exp2f(-delta);             // (first: O and l are still zero)
+            m[b] += delta;
+            l2[b] *= alpha;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            o[r] *= alpha;
-            sc[r] -= delta;
+            for (int r = 0; r < 16; ++r) {
+                o[b][r] *= alpha;
+                sc[b][r] -= delta;
+                if (NEGM) negm[b][r] = -m[b];
+            }
         }
         first = false;
     }
-    float p[16], psum = 0.0f;
+    uint32_t pk[QB][8];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-#ifdef FA_EXP_NO_EXP
-        p[r] = sc[r] + 1.0f;  // timing experiment (wrong results): no exponentials
-#else
-        p[r] = __builtin_amdgcn_exp2f(sc[r]);
-#endif
-        psum += p[r];   // the normaliser is accumulated BEFORE dropout (attention.py:69-70)
-    }
-    l_lane += psum;
-    if (VARIANT == 2) {
-        const uint32_t th = a.drop.thresh16;
-        const uint32_t e0 = (uint32_t)q * (uint32_t)N + (uint32_t)(jb + 4 * hi);  // even: N even, jb and 4*hi multiples of 4
-#pragma unroll
-        for (int pr = 0; pr < 8; ++pr) {  // registers 2*pr, 2*pr + 1: keys e0 + 8*(pr >> 1) + 2*(pr & 1) + {0, 1}
-            const uint32_t w = rng_pair_word((e0 + 8u * (uint32_t)(pr >> 1) + 2u * (uint32_t)(pr & 1)) >> 1, dkey);
-            p[2 * pr] = (w & 0xffffu) < th ? p[2 * pr] : 0.0f;
-            p[2 * pr + 1] = (w >> 16) < th ? p[2 * pr + 1] : 0.0f;
-        }
-    } else if (VARIANT == 0 && DROP) {
+    for (int b = 0; b < QB; ++b) {
+        float p[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int j = jb + (r & 3) + 8 * (r >> 2) + 4 * hi;
-            const bool keep = j < N && q < N &&
-                              (a.drop.mode == 1 ? rng_keep((uint32_t)q * (uint32_t)N + (uint32_t)j, dkey, a.drop.thresh16)
-                                                : (a.drop.mask[((size_t)bh * N + q) * N + j] != 0));
-            p[r] = keep ? p[r] : 0.0f;
+#ifdef FA_EXP_NO_EXP
+            p[r] = sc[b][r] + 1.0f;  // timing experiment (wrong results): no exponentials
+#else
+            p[r] = __builtin_amdgcn_exp2f(sc[b][r]);
+#endif
         }
+        // the normaliser is accumulated BEFORE dropout (attention.py:69-70), two elements per instruction (v_pk_add_f32: a plain
+        // wave64 VALU instruction occupies the SIMD for 4 cycles -- PMC: 4.6 cycles per VALU instruction, VALU busy 82 % of the
+        // kernel against 23 % for the MFMA pipe)
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) l2[b] += fa_f32x2{p[r], p[r + 1]};
+        const int q = q0 + 32 * b;
+        if (VARIANT == 2) {
+            const uint32_t th = a.drop.thresh16;
+            const uint32_t e0 = (uint32_t)q * (uint32_t)N + (uint32_t)(jb + 4 * hi);  // even: N even, jb and 4*hi multiples of 4
+#pragma unroll
+            for (int pr = 0; pr < 8; ++pr) {  // registers 2*pr, 2*pr + 1: keys e0 + 8*(pr >> 1) + 2*(pr & 1) + {0, 1}
+                const uint32_t w = rng_pair_word((e0 + 8u * (uint32_t)(pr >> 1) + 2u * (uint32_t)(pr & 1)) >> 1, dkey);
+                p[2 * pr] = (w & 0xffffu) < th ? p[2 * pr] : 0.0f;
+                p[2 * pr + 1] = (w >> 16) < th ? p[2 * pr + 1] : 0.0f;
+            }
+        } else if (VARIANT == 0 && DROP) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int j = jb + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                const bool keep = j < N && q < N &&
+                                  (a.drop.mode == 1 ? rng_keep((uint32_t)q * (uint32_t)N + (uint32_t)j, dkey, a.drop.thresh16)
+                                                    : (a.drop.mask[((size_t)bh * N + q) * N + j] != 0));
+                p[r] = keep ? p[r] : 0.0f;
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 8; ++t) pk[b][t] = pack_el16x2(p[2 * t], p[2 * t + 1]);
     }
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {
-        uint32_t pk[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) pk[t] = pack_el16x2(p[s2 * 8 + 2 * t], p[s2 * 8 + 2 * t + 1]);
-        const el16x8_t pf = *(el16x8_t*)pk;
-        const el16_t* vr = Vt + l31 * 68 + st * 32 + s2 * 16 + 4 * hi;  // V^T fragment: lane (d = l31, hi): keys st*32 + 16*s2 + 4*hi + {0..3} and + 8
+        const el16_t* vr = vf0 + st * 32 + s2 * 16;  // V^T fragment: lane (d = l31, hi): keys st*32 + 16*s2 + 4*hi + {0..3} and + 8
         uint2 v0 = *(const uint2*)vr, v1 = *(const uint2*)(vr + 8);
         uint32_t vw[4] = {v0.x, v0.y, v1.x, v1.y};
         const el16x8_t vf = *(el16x8_t*)vw;
-        o = DYF_MFMA_32x32x16(vf, pf, o, 0, 0, 0);
+#pragma unroll
+        for (int b = 0; b < QB; ++b) {
+            uint32_t pw[4] = {pk[b][4 * s2], pk[b][4 * s2 + 1], pk[b][4 * s2 + 2], pk[b][4 * s2 + 3]};
+            o[b] = DYF_MFMA_32x32x16(vf, *(el16x8_t*)pw, o[b], 0, 0, 0);
+        }
     }
 }
 
 // Occupancy decides this kernel (measured, 16 384 tokens x 4 heads x NB = 4, no dropout): the chain K-fragment read -> 2 MFMA ->
 // max -> 16 exp -> pack -> V-fragment read -> 2 MFMA of a sub-tile is latency, not issue, bound -- removing the exponentials AND the
 // V^T staging altogether moved 1.72 ms to 1.49 ms, while 3 instead of 2 resident waves per SIMD moved it to 1.24 ms.  Hence the
-// register diet (no second accumulator tuple) and 4 waves per SIMD.
+// register diet (no second accumulator tuple, rolled sub-tile loop) and 4 waves per SIMD for the 32-query form.
 #ifndef FA2_MINW
 #define FA2_MINW 4
 #endif
-template <bool DROP>
-__global__ __launch_bounds__(256, FA2_MINW) void flash_attention2_kernel(AttnArgs a) {
+#ifndef FA2_MINW2
+#define FA2_MINW2 3
+#endif
+template <bool DROP, int QB>
+__global__ __launch_bounds__(256, QB == 2 ? FA2_MINW2 : FA2_MINW) void flash_attention2_kernel(AttnArgs a) {
+    // NEGM (the -m tuple resident in registers) measured SLOWER for the 32-query no-dropout kernel (1.24 vs 1.17 ms: 128 registers
+    // leave the scheduler no slack at 4 waves per SIMD): off everywhere; -DFA2_NEGM=1 re-enables the experiment
+#ifndef FA2_NEGM
+#define FA2_NEGM 0
+#endif
+    constexpr bool NEGM = FA2_NEGM && !DROP && QB == 1;
     __shared__ __attribute__((aligned(16))) el16_t Ks[64 * 32];   // [key][32 ch], 16-B chunk ^= (key >> 2) & 3
     __shared__ __attribute__((aligned(16))) el16_t Vt[32 * 68];   // [ch][64 keys + 4 pad]
-    const int qblocks = (a.hw + 127) / 128;
-    const int bh = blockIdx.x / qblocks, qb = blockIdx.x % qblocks;
+    constexpr int QW = 32 * QB, QG = 4 * QW;   // queries per wave / per workgroup
+    const int qblocks = (a.hw + QG - 1) / QG;
+    // XCD-aware block map: workgroup b runs on XCD b % 8 and every XCD has its own 4 MB L2.  All query blocks of one (sample,
+    // head) stream the same K / V (2 MB at 16 384 tokens): dealt round-robin over the XCDs every L2 sees every (sample, head)
+    // -- 33 MB at NB = 4 -- and the kernel runs at the fabric's rate; with (sample, head) pinned to XCD (bh % 8) each L2
+    // holds the one or two K / V sets its workgroups are walking.
+    int bh = blockIdx.x / qblocks, qb = blockIdx.x % qblocks;
+    if ((a.n * a.heads) % 8 == 0) {
+        const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
+        bh = (k / qblocks) * 8 + xcd;
+        qb = k % qblocks;
+    }
     const int n = bh / a.heads, h = bh % a.heads;
     const int C3 = 3 * a.heads * 32, hd = a.heads * 32, N = a.hw;
     const el16_t* base = a.qkv + (size_t)n * N * C3;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
-    const int q = qb * 128 + wave * 32 + l31;
+    const int q0 = qb * QG + wave * QW + l31;   // query of block 0; block b: + 32 b
     const float c2 = 0.17677669529663687f * 1.4426950408889634f;  // 32^-1/2 * log2(e): scores live in the log2 domain
-    el16x8_t qf[2];  // Q fragments (B operand of S^T), pre-multiplied by c2: lane (q, hi) holds channels ks*16 + hi*8 .. +8
+    el16x8_t qf[QB][2];  // Q fragments (B operand of S^T), pre-multiplied by c2: lane (q, hi) holds channels ks*16 + hi*8 .. +8
+    fa_f32x16 o[QB], negm[QB];
+    float m[QB];
+    fa_f32x2 l2[QB];
+    const el16_t* kf0 = Ks + l31 * 32 + (((0 + hi) ^ ((l31 >> 2) & 3)) << 3);
+    const el16_t* kf1 = Ks + l31 * 32 + (((2 + hi) ^ ((l31 >> 2) & 3)) << 3);
+    const el16_t* vf0 = Vt + l31 * 68 + 4 * hi;
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (q < N) v = *(const uint4*)(base + (size_t)q * C3 + h * 32 + ks * 16 + hi * 8);
-        uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    for (int b = 0; b < QB; ++b) {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) w[t] = pack_el16x2(el16_lo(w[t]) * c2, el16_hi(w[t]) * c2);
-        qf[ks] = *(el16x8_t*)w;
+        for (int ks = 0; ks < 2; ++ks) {
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (q0 + 32 * b < N) v = *(const uint4*)(base + (size_t)(q0 + 32 * b) * C3 + h * 32 + ks * 16 + hi * 8);
+            uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int t = 0; t < 4; ++t) w[t] = pack_el16x2(el16_lo(w[t]) * c2, el16_hi(w[t]) * c2);
+            qf[b][ks] = *(el16x8_t*)w;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[b][r] = negm[b][r] = 0.0f;
+        m[b] = 0.0f;
+        l2[b] = fa_f32x2{0.0f, 0.0f};
     }
-    fa_f32x16 o;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) o[r] = 0.0f;
-    float m = 0.0f, l_lane = 0.0f;
     bool first = true;
     const RngKey dkey = DROP ? attn_drop_key(a.drop, n, (uint32_t)h) : RngKey{0u, 0u};
 
@@ -1856,27 +1915,32 @@ __global__ __launch_bounds__(256, FA2_MINW) void flash_attention2_kernel(AttnArg
         if (whole && !DROP) {
 #pragma nounroll
             for (int st = 0; st < 2; ++st)
-                fa2_subtile<1, false>(a, Ks, Vt, qf, o, m, l_lane, first, j0 + 32 * st, st, q, N, l31, hi, dkey, (uint32_t)bh);
-        } else if (DROP && whole && a.drop.mode == 1 && (N & 1) == 0 && (qb + 1) * 128 <= N) {
+                fa2_subtile<1, false, QB, NEGM>(a, kf0, kf1, vf0, qf, o, negm, m, l2, first, j0 + 32 * st, st, q0, N, hi, dkey, (uint32_t)bh);
+        } else if (DROP && whole && a.drop.mode == 1 && (N & 1) == 0 && (qb + 1) * QG <= N) {
 #pragma nounroll
             for (int st = 0; st < 2; ++st)
-                fa2_subtile<2, DROP>(a, Ks, Vt, qf, o, m, l_lane, first, j0 + 32 * st, st, q, N, l31, hi, dkey, (uint32_t)bh);
+                fa2_subtile<2, DROP, QB, NEGM>(a, kf0, kf1, vf0, qf, o, negm, m, l2, first, j0 + 32 * st, st, q0, N, hi, dkey, (uint32_t)bh);
         } else {
-            fa2_subtile<0, DROP>(a, Ks, Vt, qf, o, m, l_lane, first, j0, 0, q, N, l31, hi, dkey, (uint32_t)bh);
-            if (j0 + 32 < N) fa2_subtile<0, DROP>(a, Ks, Vt, qf, o, m, l_lane, first, j0 + 32, 1, q, N, l31, hi, dkey, (uint32_t)bh);
+            fa2_subtile<0, DROP, QB, NEGM>(a, kf0, kf1, vf0, qf, o, negm, m, l2, first, j0, 0, q0, N, hi, dkey, (uint32_t)bh);
+            if (j0 + 32 < N) fa2_subtile<0, DROP, QB, NEGM>(a, kf0, kf1, vf0, qf, o, negm, m, l2, first, j0 + 32, 1, q0, N, hi, dkey, (uint32_t)bh);
         }
     }
-    const float l = l_lane + __shfl_xor(l_lane, 32, 64);
-    if (q >= N) return;
-    // O^T[d][q]: lane (q, hi) holds d = (r&3) + 8(r>>2) + 4hi  -> four 8-byte stores of 4 consecutive channels
-    const float inv = (DROP ? a.drop.scale : 1.0f) / l;
-    el16_t* op = a.out + ((size_t)n * N + q) * hd + h * 32;  // "b h (x y) d -> b (h d) x y"
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        uint2 w;
-        w.x = pack_el16x2(o[g * 4 + 0] * inv, o[g * 4 + 1] * inv);
-        w.y = pack_el16x2(o[g * 4 + 2] * inv, o[g * 4 + 3] * inv);
-        *(uint2*)(op + 8 * g + 4 * hi) = w;
+    for (int b = 0; b < QB; ++b) {
+        const float ll = l2[b].x + l2[b].y;
+        const float l = ll + __shfl_xor(ll, 32, 64);
+        const int q = q0 + 32 * b;
+        if (q >= N) continue;
+        // O^T[d][q]: lane (q, hi) holds d = (r&3) + 8(r>>2) + 4hi  -> four 8-byte stores of 4 consecutive channels
+        const float inv = (DROP ? a.drop.scale : 1.0f) / l;
+        el16_t* op = a.out + ((size_t)n * N + q) * hd + h * 32;  // "b h (x y) d -> b (h d) x y"
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            uint2 w;
+            w.x = pack_el16x2(o[b][g * 4 + 0] * inv, o[b][g * 4 + 1] * inv);
+            w.y = pack_el16x2(o[b][g * 4 + 2] * inv, o[b][g * 4 + 3] * inv);
+            *(uint2*)(op + 8 * g + 4 * hi) = w;
+        }
     }
 }
 
@@ -1885,10 +1949,17 @@ hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
     static const int flash = getenv("DYF_FLASH_ATTN") ? atoi(getenv("DYF_FLASH_ATTN")) : 2;
     if (flash != 0 && a.hw <= 65535) {
         const int qblocks = (a.hw + 127) / 128;
-        dyf_form_note(flash == 1 ? "flash_attention_kernel" : "flash_attention2_kernel", a.n);
+        // 64 queries per wave from 512 tokens on (DYF_FLASH_QB=1 keeps 32): shorter sequences would leave CUs without a workgroup
+        static const int qb_env = getenv("DYF_FLASH_QB") ? atoi(getenv("DYF_FLASH_QB")) : 2;
+        // (with dropout on the probabilities the 64-query form spills at 3 waves per SIMD: 1.98 vs 1.86 ms -- 32 queries there)
+        const bool qb2 = flash != 1 && qb_env == 2 && a.hw >= 512 && a.drop.mode == 0;
+        dyf_form_note(flash == 1 ? "flash_attention_kernel" : qb2 ? "flash_attention2_kernel<QB=2>" : "flash_attention2_kernel<QB=1>", a.n);
+        const int qblocks2 = (a.hw + 255) / 256;
         if (flash == 1) hipLaunchKernelGGL(flash_attention_kernel, dim3(a.n * a.heads * qblocks), dim3(256), 0, s, a);
-        else if (a.drop.mode != 0) hipLaunchKernelGGL(flash_attention2_kernel<true>, dim3(a.n * a.heads * qblocks), dim3(256), 0, s, a);
-        else hipLaunchKernelGGL(flash_attention2_kernel<false>, dim3(a.n * a.heads * qblocks), dim3(256), 0, s, a);
+        else if (qb2 && a.drop.mode != 0) hipLaunchKernelGGL((flash_attention2_kernel<true, 2>), dim3(a.n * a.heads * qblocks2), dim3(256), 0, s, a);
+        else if (qb2) hipLaunchKernelGGL((flash_attention2_kernel<false, 2>), dim3(a.n * a.heads * qblocks2), dim3(256), 0, s, a);
+        else if (a.drop.mode != 0) hipLaunchKernelGGL((flash_attention2_kernel<true, 1>), dim3(a.n * a.heads * qblocks), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((flash_attention2_kernel<false, 1>), dim3(a.n * a.heads * qblocks), dim3(256), 0, s, a);
         return hipGetLastError();
     }
     const int qtiles = (a.hw + 63) / 64;
