@@ -273,7 +273,11 @@ __global__ __launch_bounds__(256, 2) void conv_halo_rows_kernel(ConvArgs a, int 
             __builtin_amdgcn_sched_barrier(0);
             if (chunk + 1 < cpt) issue_halo(chunk + 1);
         } else {
+#ifdef HALO_EXP_NO_DMA_WAIT  // timing experiment (wrong results): the single-buffered halo is not waited for
+            asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+#else
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
         }
