@@ -105,8 +105,13 @@ def _resnet_state(net, seed, conv_gain=1.0):
 
 
 def _resnet_roofline(eng, kind, nb, name, peak_tflops):
-    ms, launches, fl, by = eng.time_kernel_in_rollout(kind, nb)
-    r = {"kernel": name, "avg_ms": round(ms, 4), "launches": launches, "algorithmic_bytes_per_launch": by,
+    # with row groups the rollout's launches cover one group's share of the rows: time those (an eager rollout of that many rows
+    # on the engine itself; inside the concurrent run the same launch shares the chip with the other groups' kernels)
+    groups = eng.row_groups
+    rows = -(-nb // groups)
+    ms, launches, fl, by = eng.time_kernel_in_rollout(kind, rows)
+    r = {"kernel": name, "rows_per_launch": rows, "row_groups": groups, "avg_ms": round(ms, 4), "launches": launches,
+         "algorithmic_bytes_per_launch": by,
          "hbm_gbps": round(by / ms / 1e6, 1), "hbm_frac": round(by / ms / 1e6 / 8000.0, 4)}
     if fl > 0:
         r.update({"bound": "mfma", "achieved": round(fl / ms / 1e9, 2), "peak": peak_tflops, "unit": "TFLOP/s",
@@ -150,7 +155,7 @@ def bench_oisst(dev, nb=300, reps=3):
     nf, ni = eng.forward_counts()
     fl = nf * eng.net_flops(0) + ni * eng.net_flops(1)
     res = {"workload": "BASELINE configs[2] shapes, 1 GPU: OISST 60x60x1, unet.Unet dim 64 mults (1,2,4), DYffusion h=7 k=25 "
-                       "(T=32), data+noise, MC dropout on, hipGraph rollout", "dtype": dtype, "rows": nb,
+                       "(T=32), data+noise, MC dropout on, hipGraph rollout", "dtype": dtype, "rows": nb, "row_groups": eng.row_groups,
            "net_forwards_per_rollout": nf + ni, "fields_per_s": round(nb * 7 / dt, 1), "ms_per_rollout": round(1e3 * dt, 2),
            "gflop_per_field": round(fl / 7 / 1e9, 2), "whole_rollout_tflops": round(nb * fl / dt / 1e12, 1),
            "roofline": _resnet_roofline(eng, 0, nb, "level-0 3x3 weight-standardised convs 64->64 @60x60", PEAK_BF16_TFLOPS),
@@ -183,7 +188,7 @@ def bench_synth512(dev, nb=4, reps=1):
                        "fp16 MFMA conv/attention, MC dropout on, hipGraph rollout", "dtype": "fp16", "rows": nb,
            "net_forwards_per_rollout": nf + ni, "fields_per_s": round(nb * 32 / dt, 1), "ms_per_rollout": round(1e3 * dt, 2),
            "gflop_per_field": round(fl / 32 / 1e9, 2), "whole_rollout_tflops": round(nb * fl / dt / 1e12, 1),
-           "roofline": _resnet_roofline(eng, 1, nb, "flash_attention_kernel (16 384 tokens, 4 heads x 32; dropout on the "
+           "roofline": _resnet_roofline(eng, 1, nb, "flash_attention2_kernel (16 384 tokens, 4 heads x 32; dropout on the "
                                                     "probabilities in the interpolator's launches)", PEAK_BF16_TFLOPS),
            "roofline_conv": _resnet_roofline(eng, 0, nb, "level-0 3x3 weight-standardised convs 64->64 @512x512", PEAK_BF16_TFLOPS)}
     log(f"512^2 NB={nb} (fp16): {res['ms_per_rollout']} ms per rollout -> {res['fields_per_s']} fields/s")

@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("DYF_LIB") or os.path.join(_HERE, "lib", "libdyffusion
 LIB_PATH_F16 = os.environ.get("DYF_LIB_F16") or os.path.join(_HERE, "lib", "libdyffusion_hip_f16.so")
 DTYPES = {"bf16": 0, "bfloat16": 0, "fp16": 1, "float16": 1, "half": 1}
 
-DYF_ABI_VERSION = 4
+DYF_ABI_VERSION = 5
 DYF_OK, DYF_ERR_INVALID_ARGUMENT, DYF_ERR_UNSUPPORTED, DYF_ERR_HIP, DYF_ERR_STATE = range(5)
 NET_FORECASTER, NET_INTERPOLATOR = 0, 1
 ARCH_UNET_SIMPLE, ARCH_UNET_RESNET = 0, 1
@@ -78,6 +78,8 @@ SYMBOLS = [
     ("dyf_sample", C.c_int, [_P, _P, _P, _P, C.c_int32, C.POINTER(_P), _P, _P]),
     ("dyf_seed", C.c_int, [_P, C.c_uint64]),
     ("dyf_set_row_offset", C.c_int, [_P, C.c_uint32]),
+    ("dyf_set_row_groups", C.c_int, [_P, C.c_int32]),
+    ("dyf_row_groups", C.c_int32, [_P]),
     ("dyf_comm_unique_id", C.c_int, [_P]),
     ("dyf_comm_init", C.c_int, [_P, _P, C.c_int32, C.c_int32]),
     ("dyf_comm_destroy", C.c_int, [_P]),

@@ -15,6 +15,26 @@ using namespace dyf;
 
 namespace {
 
+thread_local bool g_creating_group_child = false;  // dyf_engine_create called for a row group: no groups of its own
+
+// Row groups by default (dyf_set_row_groups / DYF_ROW_GROUPS override): the ResNet-UNet on small planes launches ~150 kernels per
+// forward, most of them under-filling 256 CUs or leaving a ragged last round (528 workgroups on 512 slots at the 15 x 15 level
+// of the OISST shapes at 300 rows); three concurrent rollouts of a third of the rows each cover one another's tails and launch
+// gaps (+16 % at 300 rows).  unet_simple at 80 rows gains 1.5 % with two groups -- not worth a second copy
+// of the workspace -- and large planes (512 x 512) fill the chip with a few rows: no groups.
+int default_row_groups(const dyf_engine* e) {
+    if (e->cfg.net[0].arch != DYF_ARCH_UNET_RESNET || e->cfg.net[1].arch != DYF_ARCH_UNET_RESNET) return 1;
+    if (e->cfg.batch_invariant) return 1;  // forms are pinned to 2 max_batch rows: a group's smaller max_batch would change them
+    const long long plane = (long long)e->cfg.height * e->cfg.width;
+    if (plane > 128 * 128) return 1;
+    const long long pix = plane * e->cfg.max_batch;
+    // OISST shapes (60 x 60), fields/s with 1 / 2 / 3 / 4 groups: 300 rows 3 198 / 3 568 / 3 722 / 2 966; 150 rows 2 758 / 3 005 /
+    // 3 126 / 2 209; 80 rows 2 182 / 2 231 / 2 055 / 1 347; 512 rows 3 620 / 3 805 / 3 835 / 3 541
+    if (pix >= 120ll * 60 * 60) return 3;
+    if (pix >= 64ll * 60 * 60) return 2;
+    return 1;
+}
+
 // ------------------------------------------------------------------------------------------------ geometry
 void layout_blocks(Net& n) {
     const int d = n.dim;
@@ -285,9 +305,21 @@ int32_t dyf_dtype(void) { return DYF_F16 ? DYF_DTYPE_F16 : DYF_DTYPE_BF16; }
 
 const char* dyf_last_error(const dyf_engine* engine) { return engine ? engine->err.c_str() : g_create_error.c_str(); }
 
+static void destroy_groups(dyf_engine* e) {
+    for (dyf_engine* c : e->groups) {
+        if (c->group_stream) { (void)hipStreamSynchronize(c->group_stream); (void)hipStreamDestroy(c->group_stream); }
+        if (c->group_done) (void)hipEventDestroy(c->group_done);
+        dyf_engine_destroy(c);
+    }
+    e->groups.clear();
+    e->last_groups = 0;
+}
+
 void dyf_engine_destroy(dyf_engine* e) {
     if (!e) return;
     (void)hipSetDevice(e->cfg.device);
+    destroy_groups(e);
+    if (e->group_fork) (void)hipEventDestroy(e->group_fork);
     for (auto& kv : e->graphs) {
         if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
         if (kv.second.graph) (void)hipGraphDestroy(kv.second.graph);
@@ -422,8 +454,59 @@ dyf_status dyf_engine_create(const dyf_engine_config* cfg, dyf_engine** out_engi
         if (rs != DYF_OK) return bail(rs, e->err);
     }
     *out_engine = e;
+    if (!g_creating_group_child) {
+        // default: DYF_ROW_GROUPS, else by architecture (measured on the ResNet-UNet shapes)
+        int g = 1;
+        if (const char* rg = getenv("DYF_ROW_GROUPS")) g = atoi(rg);
+        else g = default_row_groups(e);
+        if (g > 1) {
+            dyf_status gs = dyf_set_row_groups(e, g);
+            if (gs != DYF_OK) {
+                g_create_error = e->err;
+                dyf_engine_destroy(e);
+                *out_engine = nullptr;
+                return gs;
+            }
+        }
+    }
     return DYF_OK;
 }
+
+dyf_status dyf_set_row_groups(dyf_engine* e, int32_t n_groups) {
+    if (!e) return DYF_ERR_INVALID_ARGUMENT;
+    if (e->is_group_child) return fail(e, DYF_ERR_STATE, "row groups do not nest");
+    if (n_groups < 1 || n_groups > 8) return fail(e, DYF_ERR_INVALID_ARGUMENT, "n_groups must be in [1, 8]");
+    if (e->net[0].loaded || e->net[1].loaded)
+        return fail(e, DYF_ERR_STATE, "dyf_set_row_groups must be called before dyf_load_weights (the groups hold their own packed weights)");
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    HIP_TRY(e, hipDeviceSynchronize());
+    destroy_groups(e);
+    if (n_groups == 1 || e->cfg.max_batch < 2 * e->group_min_rows) return DYF_OK;
+    n_groups = std::min<int>(n_groups, e->cfg.max_batch / e->group_min_rows);
+    if (!e->group_fork) HIP_TRY(e, hipEventCreateWithFlags(&e->group_fork, hipEventDisableTiming));
+    dyf_engine_config cc = e->cfg;
+    cc.max_batch = (e->cfg.max_batch + n_groups - 1) / n_groups;
+    for (int g = 0; g < n_groups; ++g) {
+        dyf_engine* c = nullptr;
+        g_creating_group_child = true;
+        dyf_status cs = dyf_engine_create(&cc, &c);
+        g_creating_group_child = false;
+        if (cs != DYF_OK) {
+            destroy_groups(e);
+            return fail(e, cs, "row group engine: " + g_create_error);
+        }
+        c->is_group_child = true;
+        e->groups.push_back(c);
+        if (hipStreamCreateWithFlags(&c->group_stream, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&c->group_done, hipEventDisableTiming) != hipSuccess) {
+            destroy_groups(e);
+            return fail(e, DYF_ERR_HIP, "row group stream / event creation failed");
+        }
+    }
+    return DYF_OK;
+}
+
+int32_t dyf_row_groups(const dyf_engine* e) { return e ? std::max<int>(1, (int)e->groups.size()) : 0; }
 
 dyf_status dyf_seed(dyf_engine* e, uint64_t seed) {
     if (!e) return DYF_ERR_INVALID_ARGUMENT;
@@ -450,8 +533,22 @@ dyf_status dyf_set_row_offset(dyf_engine* e, uint32_t first_row) {
     return DYF_OK;
 }
 
+static dyf_status load_weights_one(dyf_engine* e, int32_t which, int32_t n_tensors, const char* const* names,
+                                   const float* const* data, const int64_t* const* shapes, const int32_t* ndims);
+
 dyf_status dyf_load_weights(dyf_engine* e, int32_t which, int32_t n_tensors, const char* const* names,
                             const float* const* data, const int64_t* const* shapes, const int32_t* ndims) {
+    dyf_status ts = load_weights_one(e, which, n_tensors, names, data, shapes, ndims);
+    if (ts != DYF_OK || !e) return ts;
+    for (dyf_engine* c : e->groups) {  // every row group packs its own copy
+        ts = load_weights_one(c, which, n_tensors, names, data, shapes, ndims);
+        if (ts != DYF_OK) return fail(e, ts, "row group: " + c->err);
+    }
+    return DYF_OK;
+}
+
+static dyf_status load_weights_one(dyf_engine* e, int32_t which, int32_t n_tensors, const char* const* names,
+                                   const float* const* data, const int64_t* const* shapes, const int32_t* ndims) {
     if (!e) return DYF_ERR_INVALID_ARGUMENT;
     if (which < 0 || which > 1) return fail(e, DYF_ERR_INVALID_ARGUMENT, "net must be 0 (forecaster) or 1 (interpolator)");
     HIP_TRY(e, hipSetDevice(e->cfg.device));
@@ -841,6 +938,14 @@ dyf_status dyf_set_plan(dyf_engine* e, const dyf_plan* p) {
     }
     HIP_TRY(e, hipDeviceSynchronize());
     ph.set = true;
+    e->last_groups = 0;
+    for (dyf_engine* c : e->groups) {
+        dyf_status cs = dyf_set_plan(c, p);
+        if (cs != DYF_OK) {
+            ph.set = false;
+            return fail(e, cs, "row group: " + c->err);
+        }
+    }
     return DYF_OK;
 }
 
@@ -1019,7 +1124,38 @@ static dyf_status sample_into_stack(dyf_engine* e, const float* initial_dev, con
     HIP_TRY(e, hipSetDevice(e->cfg.device));
     hipStream_t st = (hipStream_t)stream;
     const int H = e->cfg.height, W = e->cfg.width;
-    const size_t field = (size_t)nb * e->C * H * W;
+    e->last_groups = 0;
+    const int G = (int)e->groups.size();
+    if (G > 1 && masks_dev == nullptr && noise_dev == nullptr && nb >= 2 * e->group_min_rows) {
+        // rows split over the groups: per = ceil(nb / g) rows each (the last one takes the remainder), every share on its own stream
+        int g_use = std::min(G, nb / e->group_min_rows);
+        if ((nb + g_use - 1) / g_use > e->groups[0]->cfg.max_batch) g_use = G;  // ceil(nb / G) always fits a group's max_batch
+        const int per = (nb + g_use - 1) / g_use, used = (nb + per - 1) / per;
+        const size_t row = (size_t)e->C * H * W, slots = (size_t)e->plan.hdr.n_out_slots;
+        for (int g = 0; g < used; ++g)  // same seed and stream position as this engine, batch row 0 = global row offset + g * per
+            HIP_TRY(e, launch_rng_clone(e->groups[g]->rng_state, e->rng_state, (uint32_t)(g * per), false, st));
+        HIP_TRY(e, hipEventRecord(e->group_fork, st));
+        for (int g = 0; g < used; ++g) {
+            dyf_engine* c = e->groups[g];
+            const int rows = std::min(per, nb - g * per);
+            HIP_TRY(e, hipStreamWaitEvent(c->group_stream, e->group_fork, 0));
+            dyf_status r = sample_into_stack(c, initial_dev + (size_t)g * per * e->wC * H * W,
+                                             static_dev ? static_dev + (size_t)g * per * e->Cs * H * W : nullptr, rows, nullptr,
+                                             nullptr, c->group_stream);
+            if (r != DYF_OK) return fail(e, r, "row group: " + c->err);
+            // the share's stack [slots][rows][C][H][W] into rows [g per, g per + rows) of this engine's [slots][nb][C][H][W]
+            HIP_TRY(e, hipMemcpy2DAsync(e->s_stack + (size_t)g * per * row, (size_t)nb * row * sizeof(float), c->s_stack,
+                                        (size_t)rows * row * sizeof(float), (size_t)rows * row * sizeof(float), slots,
+                                        hipMemcpyDeviceToDevice, c->group_stream));
+            HIP_TRY(e, hipEventRecord(c->group_done, c->group_stream));
+        }
+        for (int g = 0; g < used; ++g) HIP_TRY(e, hipStreamWaitEvent(st, e->groups[g]->group_done, 0));
+        HIP_TRY(e, launch_rng_clone(e->rng_state, e->groups[0]->rng_state, 0u, true, st));  // the counters the rollout advanced
+        e->last_groups = used;
+        e->last_per = per;
+        e->last_nb = nb;
+        return DYF_OK;
+    }
     HIP_TRY(e, hipMemcpyAsync(e->s_init, initial_dev, (size_t)nb * e->wC * H * W * sizeof(float), hipMemcpyDeviceToDevice, st));
     if (static_dev)
         HIP_TRY(e, hipMemcpyAsync(e->s_static, static_dev, (size_t)nb * e->Cs * H * W * sizeof(float), hipMemcpyDeviceToDevice, st));
@@ -1048,7 +1184,6 @@ static dyf_status sample_into_stack(dyf_engine* e, const float* initial_dev, con
         }
         HIP_TRY(e, hipGraphLaunch(g.exec, st));
     }
-    (void)field;
     return DYF_OK;
 }
 
@@ -1171,6 +1306,17 @@ dyf_status dyf_get_sampler_state(dyf_engine* e, int32_t what, float* out_dev, in
     if (!e || !out_dev) return DYF_ERR_INVALID_ARGUMENT;
     if (!e->plan.set || !e->s_x0hat) return fail(e, DYF_ERR_STATE, "no sampling call has been made yet");
     if (nb < 1 || nb > e->cfg.max_batch) return fail(e, DYF_ERR_INVALID_ARGUMENT, "batch size outside [1, max_batch]");
+    if (e->last_groups > 0) {  // the most recent call ran on the row groups: its state lives there, share by share
+        if (nb != e->last_nb) return fail(e, DYF_ERR_INVALID_ARGUMENT, "batch size differs from the sampling call's");
+        const size_t row = (size_t)e->C * e->cfg.height * e->cfg.width;
+        for (int g = 0; g < e->last_groups; ++g) {
+            dyf_engine* c = e->groups[g];
+            dyf_status r = dyf_get_sampler_state(c, what, out_dev + (size_t)g * e->last_per * row,
+                                                 std::min(e->last_per, nb - g * e->last_per), stream);
+            if (r != DYF_OK) return fail(e, r, "row group: " + c->err);
+        }
+        return DYF_OK;
+    }
     const float* src = nullptr;
     if (what == DYF_STATE_X0_HAT) src = e->s_x0hat;
     else if (what == DYF_STATE_X_S) src = e->s_xs;

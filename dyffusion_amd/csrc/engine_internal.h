@@ -141,6 +141,16 @@ struct dyf_engine {
     int comm_rank = 0, comm_world = 1;
     float* gather_recv = nullptr;
     size_t gather_recv_floats = 0;
+    // row groups (dyf_set_row_groups): child engines with max_batch / G rows each; a dyf_sample call of enough rows is split over
+    // them, every share a rollout of its own (own workspace, own captured graph) on its own stream, so kernels of different groups
+    // overlap: tails of under-filled launches and launch gaps of one group are covered by the others
+    std::vector<dyf_engine*> groups;
+    bool is_group_child = false;
+    hipStream_t group_stream = nullptr;  // child: the stream its share runs on
+    hipEvent_t group_done = nullptr;     // child: recorded behind its share
+    hipEvent_t group_fork = nullptr;     // parent: recorded on the caller's stream in front of the shares
+    int group_min_rows = 16;             // a call with fewer rows per group than this runs ungrouped
+    int last_groups = 0, last_per = 0, last_nb = 0;  // split of the most recent sampling call (dyf_get_sampler_state)
     dyf::TrainState* train = nullptr;  // training path (arch unet_simple), created by the first dyf_load_weights
     bool last_dec5_sparse = false;  // the most recent unet_simple forward stored dec5 in the compact sparse-column layout
     bool poison_dec5 = false;       // DYF_POISON_DEC5=1 (test hook, read once at create): NaN-fill dec5's output before its conv

@@ -131,6 +131,7 @@ struct BcArgs {
 hipError_t launch_boundary_conditions(const BcArgs& a, hipStream_t s);
 hipError_t launch_nhwc_to_nchw_f32(const el16_t* src, int n, int h, int w, int w_store, int c, const int16_t* col_map,
                                    float* out, hipStream_t s);
+hipError_t launch_rng_clone(uint32_t* dst, const uint32_t* src, uint32_t row_add, bool counters_only, hipStream_t s);
 hipError_t launch_rng_begin_forward(uint32_t* rng_state, uint32_t* row_keys, int rows, int rows_per_fwd, hipStream_t s);
 hipError_t launch_fill_f32(float* p, float v, long long count, hipStream_t s);
 // on-device ensemble metrics (evaluation.py:10-118): sums[3] (fp64, device) = {sum (mean-y)^2, sum var, sum crps}; n_members <= 64 (one KB of LDS per member)

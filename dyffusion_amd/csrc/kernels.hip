@@ -1188,6 +1188,24 @@ __global__ void rng_bump_kernel(uint32_t* state, int slot, uint32_t by) {
     if (threadIdx.x == 0 && blockIdx.x == 0) state[slot] += by;
 }
 
+// row groups (engine.hip): a child engine's stream position = the parent's, its batch row 0 = the parent's row 0 + row_add;
+// counters_only: the parent adopts the counters a child advanced (words 2 and 4)
+__global__ void rng_clone_kernel(uint32_t* dst, const uint32_t* src, uint32_t row_add, int counters_only) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (counters_only) {
+        dst[2] = src[2];
+        dst[4] = src[4];
+        return;
+    }
+    for (int i = 0; i < DYF_RNG_STATE_WORDS; ++i) dst[i] = src[i];
+    dst[3] = src[3] + row_add;
+}
+
+hipError_t launch_rng_clone(uint32_t* dst, const uint32_t* src, uint32_t row_add, bool counters_only, hipStream_t s) {
+    hipLaunchKernelGGL(rng_clone_kernel, dim3(1), dim3(64), 0, s, dst, src, row_add, counters_only ? 1 : 0);
+    return hipGetLastError();
+}
+
 hipError_t launch_noisy_condition(float* out, const float* cond, const float* noise, float tau, long long count,
                                   int row_elems, uint32_t* rng_state, hipStream_t s) {
     hipLaunchKernelGGL(noisy_condition_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, out, cond, noise,

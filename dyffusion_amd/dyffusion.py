@@ -31,7 +31,7 @@ class DYffusion(nn.Module):
                  interpolator_horizon: Optional[int] = None, interpolator_window: int = 1,
                  enable_forecaster_dropout: bool = False, max_batch: int = 64, use_graph: bool = True,
                  enable_mfma: bool = True, loss_function: str = "mean_squared_error", dtype: Optional[str] = None,
-                 batch_invariant: bool = False, **kwargs):
+                 batch_invariant: bool = False, row_groups: Optional[int] = None, **kwargs):
         super().__init__()
         if model is None:
             raise ValueError("Arg ``model`` is missing... Please provide a backbone model for the diffusion model (e.g. a Unet)")
@@ -101,7 +101,8 @@ class DYffusion(nn.Module):
         # (engine.default_dtype_for: bf16 for unet_simple -- BASELINE configs[1] --, fp16 for the ResNet-UNet -- configs[2], [4])
         dtype = dtype or default_dtype_for(model)
         self._engine_opts = dict(max_batch=max_batch, use_graph=use_graph, enable_mfma=enable_mfma, dtype=dtype,
-                                 batch_invariant=batch_invariant)  # batch_invariant: bit-identical rows under any batching / sharding
+                                 batch_invariant=batch_invariant,  # batch_invariant: bit-identical rows under any batching / sharding
+                                 row_groups=row_groups)  # concurrent row groups of a sampling call (None = engine default)
         self._engine: Optional[HipEngine] = None
         self._plan_key = None
         self._seed: Optional[int] = None

@@ -72,7 +72,7 @@ def _f32c(t: torch.Tensor, name: str) -> torch.Tensor:
 class HipEngine:
     def __init__(self, forecaster: L.NetConfig, interpolator: L.NetConfig, height: int, width: int, max_batch: int,
                  device: Optional[int] = None, use_graph: bool = True, enable_mfma: bool = True, dtype: str = "bf16",
-                 batch_invariant: bool = False):
+                 batch_invariant: bool = False, row_groups: Optional[int] = None):
         if not torch.cuda.is_available():
             raise EngineError("no GPU visible: the DYffusion HIP engine needs an MI355X (gfx950); there is no CPU fallback")
         self.dtype = dtype
@@ -88,6 +88,8 @@ class HipEngine:
         if st != L.DYF_OK:
             _raise(st, self._lib.dyf_last_error(None).decode())
         self._h = h
+        if row_groups is not None:  # None: the engine's own default (dyf_engine_create, DYF_ROW_GROUPS)
+            self._check(self._lib.dyf_set_row_groups(self._h, int(row_groups)))
         self._plan_keepalive = None
         self.n_out_slots = 0
         self._tape_net = {}       # tape slot -> network of the recorded training forward
@@ -297,6 +299,11 @@ class HipEngine:
     def seed(self, seed: int):
         """Re-seed the dropout / noise generator; forward and noise counters restart at 0."""
         self._check(self._lib.dyf_seed(self._h, C.c_uint64(int(seed) & (2 ** 64 - 1))))
+
+    @property
+    def row_groups(self) -> int:
+        """Number of concurrent row groups a large enough sampling call is split over (dyf_set_row_groups; 1 = none)."""
+        return int(self._lib.dyf_row_groups(self._h))
 
     def set_row_offset(self, first_row: int):
         """Global index of this engine's batch row 0 (ensemble sharding): rows draw the masks of the un-sharded batch."""

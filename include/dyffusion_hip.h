@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define DYF_ABI_VERSION 4
+#define DYF_ABI_VERSION 5
 
 typedef struct dyf_engine dyf_engine;
 
@@ -161,6 +161,17 @@ dyf_status dyf_seed(dyf_engine* engine, uint64_t seed);
  * (_base_experiment.py:503-538 tiles them, row = n*B + b) sets lo: its rows then draw exactly the masks / noise they
  * would draw inside the un-sharded batch. */
 dyf_status dyf_set_row_offset(dyf_engine* engine, uint32_t first_row);
+/* Row groups (ABI 5).  The rows of a sampling call are independent for the whole rollout, so the engine may run them as n_groups
+ * concurrent rollouts of ceil(NB / n_groups) rows each -- own workspace, own packed weights, own captured hipGraph, own HIP stream,
+ * forked from and joined into the caller's stream -- so that under-filled launches, ragged last rounds of workgroups and launch
+ * gaps of one group are covered by the kernels of the others.  Row g*per + i of the call is row i of group g and draws the
+ * masks / noise of global row (row offset + g*per + i): the generator streams are those of the ungrouped call.  Default: chosen
+ * at dyf_engine_create from the architecture and max_batch (ResNet-UNet on planes <= 128 x 128, not batch_invariant: 3 groups from
+ * 432 000 pixels x rows = 120 rows of 60 x 60, 2 from 230 400 = 64 rows; otherwise 1; environment DYF_ROW_GROUPS overrides).  Must be called before dyf_load_weights.
+ * Calls with fewer than 32 rows, with injected masks / noise, and every other entry point run on the engine itself.
+ * dyf_row_groups returns the number of groups in effect (1 = none). */
+dyf_status dyf_set_row_groups(dyf_engine* engine, int32_t n_groups);
+int32_t dyf_row_groups(const dyf_engine* engine);
 
 /* ---- engine-owned exchange of the ensemble-sharded path (one process per GPU; the reference has no inference collective) ------- */
 /* Ensemble members / batch items are independent rows for the whole rollout (_base_experiment.py:503-538 tiles them, row = n*B + b),
