@@ -14,10 +14,12 @@ struct StemConvArgs {
     int dim;
     el16_t* out;        // [n][h][w][dim]
     const el16_t* wfrag = nullptr;  // pack_stem_frag(): MFMA form (dim == 64), or null -> VALU form
-    int ksteps = 0;                 // ceil(k*k*cin / 16)
+    int ksteps = 0;                 // stem_frag_steps(k, cin) = cin * ceil(k*k / 16)
 };
-// [tap][cin][dim] fp32 -> A fragments of the MFMA stem: [k-step][32-channel block][hi/lo part][lane][8] bf16
-void pack_stem_frag(const float* wgt, int kk_total, int dim, el16_t* out);
+// k16 steps of the MFMA stem (channel-major K, the taps of a channel padded to whole steps), 0 = shape not taken by it
+int stem_frag_steps(int k, int cin);
+// [tap][cin][dim] fp32 -> A fragments of the MFMA stem: [channel][step of the channel][32-channel block][hi/lo part][lane][8] 16-bit
+void pack_stem_frag(const float* wgt, int k, int cin, int dim, el16_t* out);
 hipError_t launch_stem_conv(const StemConvArgs& a, hipStream_t s);
 
 // K5: GroupNorm(G) + FiLM + SiLU + Dropout (+ residual) of unet.Block (unet.py:58-76) on a bf16 NHWC tensor

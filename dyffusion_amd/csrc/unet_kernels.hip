@@ -94,83 +94,104 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(StemConvArgs a) {
     }
 }
 
-// MFMA form (dim = 64): D[channel][pixel] = W[channel][(tap, cin)] . X[(tap, cin)][pixel], K = k*k*cin padded to 16.
-// One wave owns 32 consecutive pixels (MFMA columns): lane (pixel, hi) gathers its 8 contraction values per step straight
-// from the fp32 NCHW sources (neighbouring lanes = neighbouring pixels: coalesced; the 49-fold reuse of every input lives in
-// L1), bounds-checked per tap (zero padding).  Inputs and weights are split into bf16 hi + lo parts and multiplied as
-// hi*hi + lo*hi + hi*lo, so the result matches the fp32 VALU form to ~2^-16 -- the network input is not rounded to bf16.
-// The (tap, cin) -> (source, offset, dy, dx) table and the weight fragments sit in LDS.
+// MFMA form (dim = 64): D[channel][pixel] = W[channel][(cin, tap)] . X[(cin, tap)][pixel].  The contraction index is CHANNEL-major
+// with the k*k taps of a channel padded to TS = ceil(k*k / 16) k16 steps (7 x 7: 49 -> 64): a step then gathers 8 taps per lane of
+// ONE input channel plane, so
+//   * the plane is a wave-uniform buffer resource (base = source + (sample, channel) plane, 4 * h * w bytes) and the per-lane part
+//     of an address -- 4 (rem + dy w + dx), or 0xFFFFFFFF for a tap that falls into the zero padding: the buffer bounds check
+//     returns 0 for it -- is the SAME for every channel: TS * 8 offsets computed once per pixel group, kept in registers;
+//   * a step is 8 buffer loads with no address arithmetic, the hi / lo split and 6 MFMAs; the loads of channel c + 1 are issued
+//     before the MFMAs of channel c.
+// One wave owns 32 consecutive pixels of one sample (MFMA columns; neighbouring lanes = neighbouring pixels: coalesced; the
+// k*k-fold reuse of an input lives in L1).  Inputs and weights are split into 16-bit hi + lo parts and multiplied as
+// hi*hi + lo*hi + hi*lo, so the result matches the fp32 VALU form to ~2^-16 -- the network input is not rounded to 16 bits.
+// The weight fragments ([cin * TS steps][2][hi/lo][64 lanes] x 16 B, <= 128 KB) sit in LDS.
+// (First form, rounds 1-2: tap-major K with a per-element {offset, dy, dx, source} table in LDS: bounds checks, a source-pointer
+// select and 64-bit address arithmetic per gathered value compiled into ~1 000 instructions per k16 step -- 1.31 ms per launch at
+// 4 rows of 512^2 x 8 channels, VALU/branch-bound at one wave per SIMD.)
 typedef __attribute__((ext_vector_type(16))) float st_f32x16;
-constexpr int STEM_MAX_KSTEPS = 32;  // K = k*k*cin <= 512 (7x7 x 8 channels = 392): 8 KB table + 128 KB of weight fragments in LDS
+constexpr int STEM_MAX_KSTEPS = 32;  // cin * TS <= 32 (7 x 7 x 8 channels): 128 KB of weight fragments in LDS
 
-__global__ __launch_bounds__(256) void stem_mfma_kernel(StemConvArgs a) {
+template <int TS>
+__global__ __launch_bounds__(256) void stem_mfma_kernel(StemConvArgs a, int gps) {
     extern __shared__ __attribute__((aligned(16))) char st_smem[];
-    int4* tab = (int4*)st_smem;                                         // [ksteps*16]: {offset, dy, dx, source or -1}
-    const uint4* wf = (const uint4*)(st_smem + STEM_MAX_KSTEPS * 16 * sizeof(int4));  // [ksteps][2][2][64] x 16 B
+    const uint4* wf = (const uint4*)st_smem;  // [cin * TS][2][2][64] x 16 B
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31, hi = lane >> 5;
-    const int K = a.k * a.k * a.cin, plane = a.h * a.w;
-    for (int kk = tid; kk < a.ksteps * 16; kk += 256) {
-        int4 e = make_int4(0, 0, 0, -1);
-        if (kk < K) {
-            const int tap = kk / a.cin, c = kk % a.cin, dy = tap / a.k - a.pad, dx = tap % a.k - a.pad;
-            int s = 0, cl = c;
-            while (cl >= a.ch[s]) { cl -= a.ch[s]; ++s; }
-            e = make_int4(cl * plane + dy * a.w + dx, dy, dx, s);
-        }
-        tab[kk] = e;
-    }
+    const int plane = a.h * a.w, kk = a.k * a.k;
     {
-        uint4* wdst = (uint4*)(st_smem + STEM_MAX_KSTEPS * 16 * sizeof(int4));
+        uint4* wdst = (uint4*)st_smem;
         const uint4* wsrc = (const uint4*)a.wfrag;
-        for (int i = tid; i < a.ksteps * 4 * 64; i += 256) wdst[i] = wsrc[i];
+        for (int i = tid; i < a.cin * TS * 4 * 64; i += 256) wdst[i] = wsrc[i];
     }
+    int dydx[TS * 8];  // tap displacement of this lane's j-th value of step t: dy | dx << 16; dy = 0x7fff: no such tap
+#pragma unroll
+    for (int i = 0; i < TS * 8; ++i) {
+        const int tap = (i >> 3) * 16 + hi * 8 + (i & 7);
+        const int dy = tap / a.k - a.pad, dx = tap % a.k - a.pad;
+        dydx[i] = tap < kk ? ((dy & 0xffff) | (dx << 16)) : 0x7fff;
+    }
+    const float *sp0 = a.src[0], *sp1 = a.src[1], *sp2 = a.src[2], *sp3 = a.src[3];
+    const int ch0 = a.ch[0], ch1 = a.ch[1], ch2 = a.ch[2], ch3 = a.ch[3];
     __syncthreads();
-    const long long total = (long long)a.n * plane;
-    const long long ngroups = (total + 31) / 32;
-    for (long long g = (long long)blockIdx.x * 4 + wave; g < ngroups; g += (long long)gridDim.x * 4) {
-        const long long pix = g * 32 + l31;
-        const bool pvalid = pix < total;
-        const long long pc = pvalid ? pix : total - 1;
-        const int n = (int)(pc / plane), rem = (int)(pc - (long long)n * plane), y = rem / a.w, x = rem - y * a.w;
-        const float* b0 = a.src[0] + (size_t)n * a.ch[0] * plane + rem;
-        const float* b1 = a.nsrc > 1 ? a.src[1] + (size_t)n * a.ch[1] * plane + rem : b0;
-        const float* b2 = a.nsrc > 2 ? a.src[2] + (size_t)n * a.ch[2] * plane + rem : b0;
-        const float* b3 = a.nsrc > 3 ? a.src[3] + (size_t)n * a.ch[3] * plane + rem : b0;
+    const int ngroups = a.n * gps;
+    for (int g = blockIdx.x * 4 + wave; g < ngroups; g += gridDim.x * 4) {
+        const int n = g / gps, rem = (g - n * gps) * 32 + l31;
+        const bool pvalid = rem < plane;
+        const int y = rem / a.w, x = rem - y * a.w;
+        unsigned voff[TS * 8];
+#pragma unroll
+        for (int i = 0; i < TS * 8; ++i) {
+            const int dy = (int)(short)(dydx[i] & 0xffff), dx = dydx[i] >> 16;
+            const bool ok = pvalid && (unsigned)(y + dy) < (unsigned)a.h && (unsigned)(x + dx) < (unsigned)a.w;
+            voff[i] = ok ? (unsigned)(rem + dy * a.w + dx) * 4u : 0xFFFFFFFFu;
+        }
         st_f32x16 acc[2];
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[rb][r] = 0.0f;
-        for (int s = 0; s < a.ksteps; ++s) {
-            float v[8];
+        float v[TS * 8], nv[TS * 8];
+        int src = 0, cl = 0;  // (source, channel inside the source) of the channel being fetched: wave-uniform
+        auto fetch = [&](float (&dst)[TS * 8]) {
+            const float* sp = src == 0 ? sp0 : src == 1 ? sp1 : src == 2 ? sp2 : sp3;
+            const int chs = src == 0 ? ch0 : src == 1 ? ch1 : src == 2 ? ch2 : ch3;
+            const float* base = sp + ((size_t)n * chs + cl) * plane;
+            const auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, plane * 4, 0x00020000);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int4 e = tab[s * 16 + hi * 8 + j];
-                const bool ok = e.w >= 0 && (unsigned)(y + e.y) < (unsigned)a.h && (unsigned)(x + e.z) < (unsigned)a.w;
-                const float* bp = e.w <= 0 ? b0 : e.w == 1 ? b1 : e.w == 2 ? b2 : b3;
-                const float t = bp[ok ? e.x : 0];  // always a valid address: no branch around the load
-                v[j] = ok ? t : 0.0f;
+            for (int i = 0; i < TS * 8; ++i) dst[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff[i], 0, 0));
+            if (++cl == chs) { cl = 0; ++src; }
+        };
+        fetch(v);
+        for (int c = 0; c < a.cin; ++c) {
+            if (c + 1 < a.cin) fetch(nv);
+#pragma unroll
+            for (int t = 0; t < TS; ++t) {
+                uint32_t bh[4], bl[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    bh[q] = pack_el16x2(v[t * 8 + 2 * q], v[t * 8 + 2 * q + 1]);
+                    bl[q] = pack_el16x2(v[t * 8 + 2 * q] - el16_lo(bh[q]), v[t * 8 + 2 * q + 1] - el16_hi(bh[q]));
+                }
+                const el16x8_t xh = __builtin_bit_cast(el16x8_t, make_uint4(bh[0], bh[1], bh[2], bh[3]));
+                const el16x8_t xl = __builtin_bit_cast(el16x8_t, make_uint4(bl[0], bl[1], bl[2], bl[3]));
+                const int step = c * TS + t;
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb) {
+                    const el16x8_t wh = __builtin_bit_cast(el16x8_t, wf[((step * 2 + rb) * 2 + 0) * 64 + lane]);
+                    const el16x8_t wl = __builtin_bit_cast(el16x8_t, wf[((step * 2 + rb) * 2 + 1) * 64 + lane]);
+                    acc[rb] = DYF_MFMA_32x32x16(wh, xh, acc[rb], 0, 0, 0);
+                    acc[rb] = DYF_MFMA_32x32x16(wl, xh, acc[rb], 0, 0, 0);
+                    acc[rb] = DYF_MFMA_32x32x16(wh, xl, acc[rb], 0, 0, 0);
+                }
             }
-            uint32_t bh[4], bl[4];
+            if (c + 1 < a.cin) {
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                bh[t] = pack_el16x2(v[2 * t], v[2 * t + 1]);
-                bl[t] = pack_el16x2(v[2 * t] - el16_lo(bh[t]), v[2 * t + 1] - el16_hi(bh[t]));
-            }
-            const el16x8_t xh = __builtin_bit_cast(el16x8_t, make_uint4(bh[0], bh[1], bh[2], bh[3]));
-            const el16x8_t xl = __builtin_bit_cast(el16x8_t, make_uint4(bl[0], bl[1], bl[2], bl[3]));
-#pragma unroll
-            for (int rb = 0; rb < 2; ++rb) {
-                const el16x8_t wh = __builtin_bit_cast(el16x8_t, wf[((s * 2 + rb) * 2 + 0) * 64 + lane]);
-                const el16x8_t wl = __builtin_bit_cast(el16x8_t, wf[((s * 2 + rb) * 2 + 1) * 64 + lane]);
-                acc[rb] = DYF_MFMA_32x32x16(wh, xh, acc[rb], 0, 0, 0);
-                acc[rb] = DYF_MFMA_32x32x16(wl, xh, acc[rb], 0, 0, 0);
-                acc[rb] = DYF_MFMA_32x32x16(wh, xl, acc[rb], 0, 0, 0);
+                for (int i = 0; i < TS * 8; ++i) v[i] = nv[i];
             }
         }
         // lane (pixel, hi) holds channels rb*32 + 8 (r >> 2) + 4 hi + (r & 3); groups 2 g2 / 2 g2 + 1 are exchanged between
         // lanes p and p + 32 so that every lane stores 8 consecutive channels (as in the conv epilogues)
-        el16_t* op = a.out + (size_t)pix * a.dim + hi * 8;
+        el16_t* op = a.out + ((size_t)n * plane + rem) * a.dim + hi * 8;
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
@@ -190,38 +211,57 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(StemConvArgs a) {
     }
 }
 
-void pack_stem_frag(const float* wgt, int kk_total, int dim, el16_t* out) {
-    const int ksteps = (kk_total + 15) / 16;
+int stem_frag_steps(int k, int cin) {  // k16 steps of the MFMA stem, or 0 if this shape runs on the VALU form
+    const int ts = (k * k + 15) / 16;
+    if ((ts != 1 && ts != 2 && ts != 4) || cin * ts > STEM_MAX_KSTEPS) return 0;
+    return cin * ts;
+}
+
+void pack_stem_frag(const float* wgt, int k, int cin, int dim, el16_t* out) {
+    const int kk = k * k, ts = (kk + 15) / 16;
     size_t o = 0;
-    for (int s = 0; s < ksteps; ++s)
-        for (int rb = 0; rb < dim / 32; ++rb)
-            for (int hl = 0; hl < 2; ++hl)
-                for (int lane = 0; lane < 64; ++lane)
-                    for (int j = 0; j < 8; ++j) {
-                        const int kk = s * 16 + (lane >> 5) * 8 + j, ch = rb * 32 + (lane & 31);
-                        const float w = kk < kk_total ? wgt[(size_t)kk * dim + ch] : 0.0f;
-                        const el16_t h = f32_to_el16(w);
-                        out[o++] = hl == 0 ? h : f32_to_el16(w - el16_to_f32(h));
-                    }
+    for (int c = 0; c < cin; ++c)
+        for (int t = 0; t < ts; ++t)
+            for (int rb = 0; rb < dim / 32; ++rb)
+                for (int hl = 0; hl < 2; ++hl)
+                    for (int lane = 0; lane < 64; ++lane)
+                        for (int j = 0; j < 8; ++j) {
+                            const int tap = t * 16 + (lane >> 5) * 8 + j, ch = rb * 32 + (lane & 31);
+                            const float w = tap < kk ? wgt[((size_t)tap * cin + c) * dim + ch] : 0.0f;
+                            const el16_t h = f32_to_el16(w);
+                            out[o++] = hl == 0 ? h : f32_to_el16(w - el16_to_f32(h));
+                        }
 }
 
 hipError_t launch_stem_conv(const StemConvArgs& a, hipStream_t s) {
     const long long total = (long long)a.n * a.h * a.w;
-    if (a.wfrag && a.dim == 64 && a.ksteps >= 1 && a.ksteps <= STEM_MAX_KSTEPS && a.nsrc <= 4) {
+    if (a.wfrag && a.dim == 64 && a.ksteps >= 1 && a.ksteps == stem_frag_steps(a.k, a.cin) && a.nsrc <= 4 &&
+        (long long)a.h * a.w * 4 < (1ll << 31)) {
         static const bool use_mfma = !(getenv("DYF_STEM_MFMA") && atoi(getenv("DYF_STEM_MFMA")) == 0);
         if (use_mfma) {
-            const size_t lds = STEM_MAX_KSTEPS * 16 * sizeof(int4) + (size_t)a.ksteps * 4 * 64 * 16;
+            const int ts = (a.k * a.k + 15) / 16;
+            const size_t lds = (size_t)a.ksteps * 4 * 64 * 16;
             static bool attr = false;
             if (!attr) {
-                hipError_t e = hipFuncSetAttribute((const void*)stem_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                   STEM_MAX_KSTEPS * 16 * sizeof(int4) + STEM_MAX_KSTEPS * 4 * 64 * 16);
+                const int cap = STEM_MAX_KSTEPS * 4 * 64 * 16;
+                hipError_t e = hipFuncSetAttribute((const void*)stem_mfma_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+                if (e == hipSuccess) e = hipFuncSetAttribute((const void*)stem_mfma_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
+                if (e == hipSuccess) e = hipFuncSetAttribute((const void*)stem_mfma_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, cap);
                 if (e != hipSuccess) return e;
                 attr = true;
             }
-            const long long ngroups = (total + 31) / 32;
-            const unsigned grid = (unsigned)std::min<long long>((ngroups + 3) / 4, 2048);
-            hipLaunchKernelGGL(stem_mfma_kernel, dim3(grid), dim3(256), lds, s, a);
-            return hipGetLastError();
+            const int gps = (a.h * a.w + 31) / 32;  // pixel groups per sample (the last one of a sample may be partial)
+            const long long ngroups = (long long)a.n * gps;
+            if (ngroups < (1ll << 31)) {
+                // persistent: as many workgroups as fit the chip at once (each copies the fragments, up to 128 KB, into LDS first)
+                const long long resident = 256ll * std::max<long long>(1, std::min<long long>(4, (160 * 1024) / (long long)lds));
+                const unsigned grid = (unsigned)std::min<long long>((ngroups + 3) / 4, resident);
+                dyf_form_note("stem_mfma_kernel", a.n);
+                if (ts == 1) hipLaunchKernelGGL(stem_mfma_kernel<1>, dim3(grid), dim3(256), lds, s, a, gps);
+                else if (ts == 2) hipLaunchKernelGGL(stem_mfma_kernel<2>, dim3(grid), dim3(256), lds, s, a, gps);
+                else hipLaunchKernelGGL(stem_mfma_kernel<4>, dim3(grid), dim3(256), lds, s, a, gps);
+                return hipGetLastError();
+            }
         }
     }
     hipLaunchKernelGGL(stem_conv_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256),
@@ -575,32 +615,28 @@ __global__ __launch_bounds__(256) void gn_apply_part_kernel(GnActArgs a) {
 }
 
 // Large planes (512^2: 2 048 slots per sample): the finalisation is too much to repeat in every workgroup of the apply pass --
-// one workgroup per sample does it once (same order of additions as gn_apply_part_kernel's prologue) and gn_apply_walk_kernel runs.
+// one workgroup per (sample, group) does it once (fixed order: 128 slot lanes x 2 sums, then a tree over the lanes) and
+// gn_apply_walk_kernel runs.  (First form: one workgroup per sample, 16 slot lanes per sum: 27 us at 512^2, 6 % of that rollout.)
 __global__ __launch_bounds__(256) void gn_finalize_part_kernel(const float* part, int part_slots, int c, int groups, int hw, float2* mr) {
     __shared__ double red[256];
-    const int chunks = c >> 3, cpg = c / groups, n = blockIdx.x;
-    const int nval = 2 * groups, opg = cpg >> 3, nsl = 256 / nval;
-    const int vi = threadIdx.x % nval, sl = threadIdx.x / nval;
+    const int chunks = c >> 3, cpg = c / groups, opg = cpg >> 3;
+    const int g = blockIdx.x, n = blockIdx.y;
+    const int k = threadIdx.x & 1, sl = threadIdx.x >> 1;
+    const float* p = part + (size_t)n * part_slots * chunks * 2 + (size_t)g * opg * 2 + k;
     double acc = 0.0;
-    if (sl < nsl) {
-        const int g = vi >> 1, k = vi & 1;
-        const float* p = part + (size_t)n * part_slots * chunks * 2;
-        for (int s = sl; s < part_slots; s += nsl)
-            for (int o = 0; o < opg; ++o) acc += (double)p[((size_t)s * chunks + g * opg + o) * 2 + k];
-    }
+    for (int s = sl; s < part_slots; s += 128)
+        for (int o = 0; o < opg; ++o) acc += (double)p[((size_t)s * chunks + o) * 2];
     red[threadIdx.x] = acc;
     __syncthreads();
-    if (threadIdx.x < nval) {
-        double t = 0.0;
-        for (int i = 0; i < nsl; ++i) t += red[i * nval + threadIdx.x];
-        red[threadIdx.x] = t;
+    for (int stride = 64; stride >= 1; stride >>= 1) {
+        if (sl < stride) red[threadIdx.x] += red[threadIdx.x + 2 * stride];
+        __syncthreads();
     }
-    __syncthreads();
-    if (threadIdx.x < groups) {
+    if (threadIdx.x == 0) {
         const double inv = 1.0 / ((double)hw * cpg);
-        const double mean = red[2 * threadIdx.x] * inv;
-        const double var = red[2 * threadIdx.x + 1] * inv - mean * mean;
-        mr[(size_t)n * groups + threadIdx.x] = make_float2((float)mean, rsqrtf(fmaxf((float)var, 0.0f) + 1e-5f));
+        const double mean = red[0] * inv;
+        const double var = red[1] * inv - mean * mean;
+        mr[(size_t)n * groups + g] = make_float2((float)mean, rsqrtf(fmaxf((float)var, 0.0f) + 1e-5f));
     }
 }
 
@@ -617,7 +653,7 @@ hipError_t launch_gn_act(const GnActArgs& a, hipStream_t s) {
         if ((long long)a.part_slots * chunks * 2 > 1024 && a.stats) {  // > 4 KB of partials per sample: finalise once per sample
             float2* mr = (float2*)(a.stats + (size_t)a.n * a.groups * 2 * GN_MAX_BLOCKS);
             dyf_form_note("gn_finalize_part_kernel+gn_apply", a.n);
-            hipLaunchKernelGGL(gn_finalize_part_kernel, dim3(a.n), dim3(256), 0, s, a.part, a.part_slots, a.c, a.groups, a.hw, mr);
+            hipLaunchKernelGGL(gn_finalize_part_kernel, dim3(a.groups, a.n), dim3(256), 0, s, a.part, a.part_slots, a.c, a.groups, a.hw, mr);
             hipLaunchKernelGGL(gn_apply_walk_kernel, dim3(bx, a.n), dim3(256), 0, s, a, (const float2*)mr);
             return hipGetLastError();
         }

@@ -338,11 +338,10 @@ dyf_status rn_load_weights(dyf_engine* e, Net& n, std::map<std::string, TensorVi
                 for (int t = 0; t < ks * ks; ++t)
                     pk[((size_t)t * n.cin_total + ci) * d + co] = sw->data[((size_t)co * n.cin_total + ci) * ks * ks + t];
         UP(r->stem_w, pk); UP(r->stem_b, vec(sb));
-        if (d == 64) {  // MFMA stem: weights as bf16 hi/lo A fragments
-            const int kk_total = (int)(ks * ks * n.cin_total);
-            r->stem_ksteps = (kk_total + 15) / 16;
+        r->stem_ksteps = d == 64 ? stem_frag_steps((int)ks, n.cin_total) : 0;
+        if (r->stem_ksteps > 0) {  // MFMA stem: weights as 16-bit hi/lo A fragments, channel-major K
             std::vector<el16_t> pf((size_t)r->stem_ksteps * 2 * 2 * 64 * 8);
-            pack_stem_frag(pk.data(), kk_total, (int)d, pf.data());
+            pack_stem_frag(pk.data(), (int)ks, n.cin_total, (int)d, pf.data());
             UP(r->stem_wfrag, pf);
         }
         NEED(hw, "final_conv.weight", (int64_t)c.out_channels, d, 1, 1);
