@@ -1747,6 +1747,9 @@ typedef float fa_f32x2 __attribute__((ext_vector_type(2)));
 // kf0 / kf1 / vf0: this lane's LDS addresses of the K fragments (ks = 0, 1) and of the V^T fragment of sub-tile 0 (sub-tile st adds
 // a wave-uniform offset: the swizzle key (key >> 2) & 3 does not depend on st).  NEGM: the tuple -m lives in registers across the
 // loop and is the MFMA's C operand (kernels with the registers to spare); otherwise 16 moves per sub-tile rebuild it.
+#ifndef FA2_PKMOV
+#define FA2_PKMOV 0  // measured: 1.184 ms with v_pk_mov_b32 vs 1.159 ms with the compiler's 16 v_mov_b32 (same box): not kept
+#endif
 template <int VARIANT, bool DROP, int QB, bool NEGM>
 __device__ __forceinline__ void fa2_subtile(const AttnArgs& a, const el16_t* kf0, const el16_t* kf1, const el16_t* vf0, const el16x8_t (&qf)[QB][2],
                                             fa_f32x16 (&o)[QB], fa_f32x16 (&negm)[QB], float (&m)[QB], fa_f32x2 (&l2)[QB], bool& first, int jb,
@@ -1759,9 +1762,21 @@ __device__ __forceinline__ void fa2_subtile(const AttnArgs& a, const el16_t* kf0
             if (NEGM) {
                 sc[b] = DYF_MFMA_32x32x16(k0, qf[b][0], negm[b], 0, 0, 0);
             } else {
+                // accumulator initialised with -m; -DFA2_PKMOV=1: two registers per instruction (v_pk_mov_b32) -- an experiment
+#if FA2_PKMOV
+                const fa_f32x2 nm2 = {-m[b], -m[b]};
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    fa_f32x2 t;
+                    asm volatile("v_pk_mov_b32 %0, %1, %1" : "=v"(t) : "v"(nm2));
+                    sc[b][r] = t[0];
+                    sc[b][r + 1] = t[1];
+                }
+#else
                 const float nm = -m[b];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) sc[b][r] = nm;
+#endif
                 sc[b] = DYF_MFMA_32x32x16(k0, qf[b][0], sc[b], 0, 0, 0);
             }
             sc[b] = DYF_MFMA_32x32x16(k1, qf[b][1], sc[b], 0, 0, 0);
