@@ -78,6 +78,8 @@ SYMBOLS = [
     ("dyf_sample", C.c_int, [_P, _P, _P, _P, C.c_int32, C.POINTER(_P), _P, _P]),
     ("dyf_seed", C.c_int, [_P, C.c_uint64]),
     ("dyf_set_row_offset", C.c_int, [_P, C.c_uint32]),
+    ("dyf_set_log_intermediates", C.c_int, [_P, C.c_int32]),
+    ("dyf_get_log", C.c_int, [_P, C.c_int32, C.c_int32, _P, C.c_int32, _P]),
     ("dyf_set_row_groups", C.c_int, [_P, C.c_int32]),
     ("dyf_row_groups", C.c_int32, [_P]),
     ("dyf_comm_unique_id", C.c_int, [_P]),

@@ -329,6 +329,7 @@ void dyf_engine_destroy(dyf_engine* e) {
     sc_destroy(e->net[0]);
     sc_destroy(e->net[1]);
     (void)dyf_comm_destroy(e);
+    if (e->s_log) (void)hipFree(e->s_log);
     if (e->cap_stream) (void)hipStreamDestroy(e->cap_stream);
     train_destroy(e);
     release_allocs(e->allocs);
@@ -1032,6 +1033,11 @@ dyf_status run_plan(dyf_engine* e, int nb, const uint8_t* const* masks, const fl
                                     (size_t)e->C * H * W * sizeof(float), nb, hipMemcpyDeviceToDevice, st));
     }
     int step_idx = 0;
+    // log_every_t: slot (step, what) of e->s_log; what 0 = x0_hat, 1 = x_interpolated_s_next, 2 = x_interpolated_s (dyffusion.py:398-406)
+    const bool logging = e->log_on && e->s_log != nullptr;
+    auto log_to = [&](int what) { return e->s_log + ((size_t)step_idx * 3 + what) * field; };
+#define LOG_COPY(what, src) do { if (logging) HIP_TRY(e, hipMemcpyAsync(log_to(what), (src), fbytes, hipMemcpyDeviceToDevice, st)); } while (0)
+    if (logging) { e->log_has_cur.assign(ph.steps.size(), 0); e->log_nb = nb; }
     for (const dyf_plan_step& s : ph.steps) {
         // ---- forecaster: x0_hat = F(x_s, enc(s); cond)
         Source fs[3];
@@ -1053,6 +1059,7 @@ dyf_status run_plan(dyf_engine* e, int nb, const uint8_t* const* masks, const fl
             FwdOpts o{A, A + F.total_c, 0, f_mode, cur.take(f_mode == 2 && F.n_drop_sites > 0, F.n_drop_sites)};
             dyf_status r = net_forward(e, DYF_NET_FORECASTER, fs, nf, nb, o, e->s_x0hat, st);
             if (r != DYF_OK) return r;
+            LOG_COPY(0, e->s_x0hat);
         }
         // ---- x_next = I(x0, x0_hat, i(s_next))   (dyffusion.py:374-379)
         const float* x_next = e->s_x0hat;
@@ -1061,6 +1068,9 @@ dyf_status run_plan(dyf_engine* e, int nb, const uint8_t* const* masks, const fl
         if (cold_pair) {  // both interpolations of this step in one forward: s_pair = [I(.., s_next) ; I(.., s)]
             dyf_status r = interp2(s.i_next, s.i_cur, e->s_x0hat, e->s_pair);
             if (r != DYF_OK) return r;
+            LOG_COPY(1, e->s_pair);
+            LOG_COPY(2, e->s_pair + field);
+            if (logging) e->log_has_cur[step_idx] = 1;
             HIP_TRY(e, launch_cold_update(e->s_xs, e->s_pair + field, e->s_pair, (long long)field, st));
             if (&s == &ph.steps.back())  // sample_loop's third return value for a truncated schedule (dyffusion.py:424-425)
                 HIP_TRY(e, hipMemcpyAsync(e->s_next, e->s_pair, fbytes, hipMemcpyDeviceToDevice, st));
@@ -1074,15 +1084,25 @@ dyf_status run_plan(dyf_engine* e, int nb, const uint8_t* const* masks, const fl
             if (r != DYF_OK) return r;
             x_next = e->s_next;
         }
+        LOG_COPY(1, x_next);
         // ---- update of x_s  (dyffusion.py:381-393)
         if (ph.hdr.sampling_cold) {
             if (s.is_last && !ph.hdr.cold_for_last_step) {
+                // the reference logs its variable x_interpolated_s as it stands: the previous iteration's value
+                if (logging && step_idx > 0 && e->log_has_cur[step_idx - 1]) {
+                    HIP_TRY(e, hipMemcpyAsync(log_to(2), log_to(2) - 3 * field, fbytes, hipMemcpyDeviceToDevice, st));
+                    e->log_has_cur[step_idx] = 1;
+                }
                 HIP_TRY(e, hipMemcpyAsync(e->s_xs, e->s_x0hat, fbytes, hipMemcpyDeviceToDevice, st));
             } else if (s.i_cur >= 0.0f) {
                 dyf_status r = interp(s.i_cur, e->s_x0hat, e->s_cur);
                 if (r != DYF_OK) return r;
+                LOG_COPY(2, e->s_cur);
+                if (logging) e->log_has_cur[step_idx] = 1;
                 HIP_TRY(e, launch_cold_update(e->s_xs, e->s_cur, x_next, (long long)field, st));
             } else {  // s == 0: x_s - x_s + x_next
+                LOG_COPY(2, e->s_xs);  // x_interpolated_s = x_s (dyffusion.py:385)
+                if (logging) e->log_has_cur[step_idx] = 1;
                 HIP_TRY(e, hipMemcpyAsync(e->s_xs, x_next, fbytes, hipMemcpyDeviceToDevice, st));
             }
         } else {
@@ -1105,6 +1125,7 @@ dyf_status run_plan(dyf_engine* e, int nb, const uint8_t* const* masks, const fl
         dyf_status rs = interp(ph.refine_times[r], e->s_x0hat, e->s_stack + (size_t)ph.refine_slots[r] * field);
         if (rs != DYF_OK) return rs;
     }
+#undef LOG_COPY
     return DYF_OK;
 }
 
@@ -1126,7 +1147,7 @@ static dyf_status sample_into_stack(dyf_engine* e, const float* initial_dev, con
     const int H = e->cfg.height, W = e->cfg.width;
     e->last_groups = 0;
     const int G = (int)e->groups.size();
-    if (G > 1 && masks_dev == nullptr && noise_dev == nullptr && nb >= 2 * e->group_min_rows) {
+    if (G > 1 && !e->log_on && masks_dev == nullptr && noise_dev == nullptr && nb >= 2 * e->group_min_rows) {
         // rows split over the groups: per = ceil(nb / g) rows each (the last one takes the remainder), every share on its own stream
         int g_use = std::min(G, nb / e->group_min_rows);
         if ((nb + g_use - 1) / g_use > e->groups[0]->cfg.max_batch) g_use = G;  // ceil(nb / G) always fits a group's max_batch
@@ -1159,7 +1180,18 @@ static dyf_status sample_into_stack(dyf_engine* e, const float* initial_dev, con
     HIP_TRY(e, hipMemcpyAsync(e->s_init, initial_dev, (size_t)nb * e->wC * H * W * sizeof(float), hipMemcpyDeviceToDevice, st));
     if (static_dev)
         HIP_TRY(e, hipMemcpyAsync(e->s_static, static_dev, (size_t)nb * e->Cs * H * W * sizeof(float), hipMemcpyDeviceToDevice, st));
-    const bool graphable = e->cfg.use_graph && masks_dev == nullptr && noise_dev == nullptr;
+    if (e->log_on) {  // (re)size the log for the current plan
+        const size_t need = e->plan.steps.size() * 3 * (size_t)e->cfg.max_batch * e->C * H * W;
+        if (need > e->s_log_floats) {
+            HIP_TRY(e, hipDeviceSynchronize());
+            if (e->s_log) (void)hipFree(e->s_log);
+            e->s_log = nullptr;
+            e->s_log_floats = 0;
+            HIP_TRY(e, hipMalloc((void**)&e->s_log, need * sizeof(float)));
+            e->s_log_floats = need;
+        }
+    }
+    const bool graphable = e->cfg.use_graph && !e->log_on && masks_dev == nullptr && noise_dev == nullptr;
     if (!graphable) {
         dyf_status r = run_plan(e, nb, masks_dev, noise_dev, st);
         if (r != DYF_OK) return r;
@@ -1324,6 +1356,26 @@ dyf_status dyf_get_sampler_state(dyf_engine* e, int32_t what, float* out_dev, in
     else return fail(e, DYF_ERR_INVALID_ARGUMENT, "what must be a dyf_sampler_state");
     HIP_TRY(e, hipMemcpyAsync(out_dev, src, (size_t)nb * e->C * e->cfg.height * e->cfg.width * sizeof(float),
                               hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return DYF_OK;
+}
+
+dyf_status dyf_set_log_intermediates(dyf_engine* e, int32_t enable) {
+    if (!e) return DYF_ERR_INVALID_ARGUMENT;
+    e->log_on = enable != 0;  // the log of the last logged call stays readable after logging is switched off
+    return DYF_OK;
+}
+
+dyf_status dyf_get_log(dyf_engine* e, int32_t step, int32_t what, float* out_dev, int32_t nb, void* stream) {
+    if (!e || !out_dev) return DYF_ERR_INVALID_ARGUMENT;
+    if (!e->s_log || e->log_has_cur.size() != e->plan.steps.size())
+        return fail(e, DYF_ERR_STATE, "no sampling call has been logged (dyf_set_log_intermediates, then dyf_sample)");
+    if (step < 0 || step >= (int)e->plan.steps.size() || what < 0 || what > 2 || nb != e->log_nb)
+        return fail(e, DYF_ERR_INVALID_ARGUMENT, "step / what / batch size outside the logged call");
+    if (what == 2 && !e->log_has_cur[step])
+        return fail(e, DYF_ERR_STATE, "x_interpolated_s is not defined at this step (naive sampling, or a first step that is the last)");
+    const size_t field = (size_t)nb * e->C * e->cfg.height * e->cfg.width;
+    HIP_TRY(e, hipMemcpyAsync(out_dev, e->s_log + ((size_t)step * 3 + what) * field, field * sizeof(float), hipMemcpyDeviceToDevice,
+                              (hipStream_t)stream));
     return DYF_OK;
 }
 

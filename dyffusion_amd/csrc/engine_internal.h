@@ -151,6 +151,13 @@ struct dyf_engine {
     hipEvent_t group_fork = nullptr;     // parent: recorded on the caller's stream in front of the shares
     int group_min_rows = 16;             // a call with fewer rows per group than this runs ungrouped
     int last_groups = 0, last_per = 0, last_nb = 0;  // split of the most recent sampling call (dyf_get_sampler_state)
+    // log_every_t (dyf_set_log_intermediates): per sampling step {x0_hat, x_interpolated_s_next, x_interpolated_s} copied out of
+    // the rollout, [n_steps][3][max_batch][C][H][W] fp32; such calls run eagerly on the engine itself (no graph, no row groups)
+    bool log_on = false;
+    float* s_log = nullptr;
+    size_t s_log_floats = 0;
+    int log_nb = 0;                  // batch rows of the logged call
+    std::vector<uint8_t> log_has_cur;  // per step: slot 2 (x_interpolated_s) was defined at that step
     dyf::TrainState* train = nullptr;  // training path (arch unet_simple), created by the first dyf_load_weights
     bool last_dec5_sparse = false;  // the most recent unet_simple forward stored dec5 in the compact sparse-column layout
     bool poison_dec5 = false;       // DYF_POISON_DEC5=1 (test hook, read once at create): NaN-fill dec5's output before its conv

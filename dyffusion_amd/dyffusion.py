@@ -270,6 +270,7 @@ class DYffusion(nn.Module):
                      interpolator_dropout=bool(self.enable_interpolator_dropout or self.training),
                      forecaster_dropout=bool(self.enable_forecaster_dropout))
         self._plan_key = key
+        self._plan_steps = steps
         self._emitted_slots = sorted({st["out_slot"] for st in steps if st["out_slot"] is not None})
         self._slot_keys = {sl: f"t{sl + 1}_preds" for sl in self._emitted_slots}
         self._slot_keys.update(self._extra_keys)
@@ -281,8 +282,25 @@ class DYffusion(nn.Module):
         nb = initial_condition.shape[0]
         eng = self._ensure_engine(initial_condition.shape[-2:], nb)
         self._ensure_plan(eng)
-        stack = eng.sample(initial_condition, static_condition, masks=_masks, noise=_noise)
+        log_every_t = log_every_t or self.hparams.log_every_t  # dyffusion.py:343-344 ("auto" = 1: any value logs every step)
+        if log_every_t is not None:
+            eng.set_log_intermediates(True)
+        try:
+            stack = eng.sample(initial_condition, static_condition, masks=_masks, noise=_noise)
+        finally:
+            if log_every_t is not None:
+                eng.set_log_intermediates(False)
         intermediates = {key: stack[slot] for slot, key in self._slot_keys.items()}
+        if log_every_t is not None:  # dyffusion.py:396-406
+            cold = self.hparams.sampling_type == "cold"
+            for j, (s, st) in enumerate(zip(self.sampling_schedule, self._plan_steps)):
+                x_next = eng.get_log(j, 1, nb)
+                if st["out_slot"] is not None:
+                    intermediates[f"t{st['out_slot'] + 1}_preds2"] = x_next
+                intermediates[f"intermediate_{s}_x0hat"] = eng.get_log(j, 0, nb)
+                intermediates[f"xipol_{s}_dmodel"] = x_next
+                if cold:
+                    intermediates[f"xipol_{s}_dmodel2"] = eng.get_log(j, 2, nb)
         x_s = eng.sampler_state(1, nb)
         if self.sampling_schedule[-1] < self.num_timesteps - 1:
             # dyffusion.py:424-425: a schedule that stops before T-1 returns (x_s, intermediates, x_interpolated_s_next)

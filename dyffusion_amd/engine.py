@@ -300,6 +300,16 @@ class HipEngine:
         """Re-seed the dropout / noise generator; forward and noise counters restart at 0."""
         self._check(self._lib.dyf_seed(self._h, C.c_uint64(int(seed) & (2 ** 64 - 1))))
 
+    def set_log_intermediates(self, enable: bool):
+        """log_every_t: keep x0_hat / x_interpolated_s_next / x_interpolated_s of every sampling step of the next `sample` calls."""
+        self._check(self._lib.dyf_set_log_intermediates(self._h, int(bool(enable))))
+
+    def get_log(self, step: int, what: int, nb: int) -> torch.Tensor:
+        c_out = self.cfg.net[L.NET_FORECASTER].out_channels
+        out = torch.empty((nb, c_out, self.height, self.width), dtype=torch.float32, device=f"cuda:{self.device}")
+        self._check(self._lib.dyf_get_log(self._h, int(step), int(what), out.data_ptr(), nb, self._stream()))
+        return out
+
     @property
     def row_groups(self) -> int:
         """Number of concurrent row groups a large enough sampling call is split over (dyf_set_row_groups; 1 = none)."""

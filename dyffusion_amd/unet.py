@@ -180,8 +180,6 @@ class Unet(nn.Module):
             p = predictions if predictions_mask is None else predictions[predictions_mask]
             loss = predictions.new_tensor(self._engine.criterion(p.contiguous(), targets, kind))
             return (loss, predictions) if return_predictions else loss
-        if predictions_mask is not None:
-            raise NotImplementedError("predictions_mask in the engine's training step")
         if self.num_conditional_channels > 0 and condition is None:
             raise ValueError("condition must be given when num_conditional_channels > 0")
         eng = self._own_engine(inputs.shape[0], inputs.shape[-2:])
@@ -189,9 +187,16 @@ class Unet(nn.Module):
         time = kwargs.get("time") if self.hparams.with_time_emb else None
         pred = eng.train_forward(self._engine_slot, 0, inputs, None if time is None else time.float(), condition,
                                  batch_stats=True, dropout=self.has_dropout)
-        value = eng.criterion(pred, targets, kind)
+        # _base_model.py:132-135: criterion(predictions[predictions_mask], targets) -- the mean runs over the selected elements
+        mask = None
+        if predictions_mask is not None:  # boolean index over the leading dimensions, as torch's predictions[predictions_mask]
+            mask = predictions_mask.to(device=pred.device, dtype=torch.bool)
+            mask = mask.reshape(tuple(mask.shape) + (1,) * (pred.dim() - mask.dim())).expand_as(pred)
+        value = eng.criterion(pred, targets, kind) if mask is None else \
+            eng.criterion(pred[mask].contiguous(), targets.reshape(-1), kind)  # predictions[mask] and targets hold the same elements
         eng.train_step_id += 1
-        self._train_state = dict(eng=eng, pred=pred, targets=targets.float().contiguous(), kind=kind, step_id=eng.train_step_id)
+        self._train_state = dict(eng=eng, pred=pred, targets=targets.float().contiguous(), kind=kind, step_id=eng.train_step_id,
+                                 mask=mask)
         if not hasattr(self, "_grad_anchor"):
             self._grad_anchor = torch.zeros((), requires_grad=True)
         loss = EngineLoss.apply(self._grad_anchor, self, float(value))
@@ -200,7 +205,11 @@ class Unet(nn.Module):
     def _train_backward(self, upstream: float):
         st = self._train_state
         eng = st["eng"]
-        d = eng.criterion_grad(st["pred"], st["targets"], st["kind"], upstream)
+        if st.get("mask") is None:
+            d = eng.criterion_grad(st["pred"], st["targets"], st["kind"], upstream)
+        else:  # gradient of the masked mean: zero outside the mask
+            d = torch.zeros_like(st["pred"])
+            d[st["mask"]] = eng.criterion_grad(st["pred"][st["mask"]].contiguous(), st["targets"].reshape(-1), st["kind"], upstream)
         eng.train_backward(0, d, want_dinputs=False, param_grads=True)
         collect_train_results(self, eng, self._engine_slot, 1)
 

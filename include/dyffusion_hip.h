@@ -151,6 +151,14 @@ dyf_status dyf_set_plan(dyf_engine* engine, const dyf_plan* plan);
  * (n_steps, NB, window*C, H, W) standard-normal draws for forward_conditioning="data+noise" parity. */
 dyf_status dyf_sample(dyf_engine* engine, const float* initial_dev, const float* static_dev, float* out_dev,
                       int32_t nb, const uint8_t* const* masks_dev, const float* noise_dev, void* stream);
+/* log_every_t of sample_loop (dyffusion.py:339-344, 398-406): with logging enabled a dyf_sample call also keeps, per sampling step,
+ * x0_hat (what = 0, the reference's `intermediate_{s}_x0hat`), x_interpolated_s_next (1: `xipol_{s}_dmodel`, and `t{k}_preds2` on
+ * the steps that emit a forecast) and, for cold sampling, x_interpolated_s (2: `xipol_{s}_dmodel2`; as in the reference the last
+ * step without cold sampling reports the previous step's value).  Logged calls run eagerly on the engine's own workspace (no
+ * captured graph, no row groups).  dyf_get_log copies one (NB, C, H, W) tensor of the most recent logged call; `step` indexes the
+ * plan's steps. */
+dyf_status dyf_set_log_intermediates(dyf_engine* engine, int32_t enable);
+dyf_status dyf_get_log(dyf_engine* engine, int32_t step, int32_t what, float* out_dev, int32_t nb, void* stream);
 /* Re-seed the engine's counter-based dropout / noise generator (forward and noise counters reset to 0).  The keep bit of
  * an element is a function of (seed, forward index, GLOBAL batch row, dropout layer, element index inside the row), see
  * csrc/common.h: a rollout does not depend on how its rows are batched or sharded over GPUs.  dyf_seed and dyf_set_row_offset

@@ -23,7 +23,7 @@ def sample_loop(forecaster: NetFn, interpolator: NetFn, x_init: Tensor, static_c
     """cfg keys (reference kwarg names): timesteps, schedule, additional_interpolation_steps,
     additional_interpolation_steps_factor, interpolate_before_t1, sampling_type, sampling_schedule, time_encoding,
     refine_intermediate_predictions, prediction_timesteps, use_cold_sampling_for_last_step, forward_conditioning,
-    num_input_channels (C of the dynamics).
+    log_every_t, num_input_channels (C of the dynamics).
 
     `forecaster(x_s, time, cond)` and `interpolator(cat[x_init, x_last], time, static)` are net forwards; the
     interpolator callable owns its dropout source (MC dropout on/off is the caller's choice).
@@ -65,6 +65,8 @@ def sample_loop(forecaster: NetFn, interpolator: NetFn, x_init: Tensor, static_c
     x_s = x_init[:, -C:]
     out: Dict[str, Tensor] = {}
     x_last_hat = None
+    log = cfg.get("log_every_t") is not None  # dyffusion.py:343-344, 398-406: per-step intermediates next to the forecasts
+    x_cur = None
     for st in plan:
         x_last_hat = forecast(x_s, st)
         x_next = interp(x_last_hat, st.i_next) if st.i_next is not None else x_last_hat
@@ -80,6 +82,13 @@ def sample_loop(forecaster: NetFn, interpolator: NetFn, x_init: Tensor, static_c
             raise ValueError(f"unknown sampling type {kind}")
         if st.out_step is not None:
             out[f"t{st.out_step}_preds"] = x_s
+            if log:
+                out[f"t{st.out_step}_preds2"] = x_next
+        if log:
+            out[f"intermediate_{st.s}_x0hat"] = x_last_hat
+            out[f"xipol_{st.s}_dmodel"] = x_next
+            if kind == "cold":  # the reference logs the variable as it stands: on a last step without cold sampling, the previous step's
+                out[f"xipol_{st.s}_dmodel2"] = x_cur
     if cfg.get("refine_intermediate_predictions", False):
         for i_n in refine_times(tab, cfg.get("prediction_timesteps")):
             key = int(i_n) if float(i_n).is_integer() else i_n

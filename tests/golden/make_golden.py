@@ -267,6 +267,10 @@ def gen_samples():
                                           interpolate_before_t1=False, refine_intermediate_predictions=False)),
         # refinement pass at fractional prediction times (dyffusion.py:412-421): extra keys "t0.5_preds", "t1.5_preds", ...
         ("sample_fractional_refine", dict(h=4), dict(prediction_timesteps=[0.5, 1, 1.5, 2, 3, 3.5])),
+        # log_every_t: the per-step intermediates of sample_loop (dyffusion.py:396-406): t{k}_preds2, intermediate_{s}_x0hat,
+        # xipol_{s}_dmodel, xipol_{s}_dmodel2
+        ("sample_log_cold", dict(h=4), dict(log_every_t=1, additional_interpolation_steps=1)),
+        ("sample_log_naive", dict(h=4), dict(log_every_t=1, sampling_type="naive", refine_intermediate_predictions=False)),
     ]
     only = os.environ.get("DYF_GOLDEN_ONLY")
     for name, meta, dk in variants:
@@ -300,7 +304,7 @@ def gen_samples():
                           additional_interpolation_steps_factor=0, interpolate_before_t1=True, sampling_type="cold",
                           sampling_schedule=None, time_encoding="dynamics", refine_intermediate_predictions=True,
                           use_cold_sampling_for_last_step=False, forward_conditioning="none",
-                          enable_interpolator_dropout=False, prediction_timesteps=None).items()})
+                          enable_interpolator_dropout=False, prediction_timesteps=None, log_every_t=None).items()})
         hp.update({k: v for k, v in meta.items() if k.endswith("_seed")})
         np.savez_compressed(os.path.join(HERE, name + ".npz"), x0=x0.numpy(), c=c.numpy(), hp=json.dumps(hp), **arrs)
         print(name, {k: tuple(v.shape) for k, v in out.items()}, "std t_last", float(out[f"t{h}_preds"].std()))

@@ -39,7 +39,7 @@ def build_dyffusion(PF, PI, mcfg, C, Cs, hp, window=1, **engine_kw):
     keys = ["forward_conditioning", "schedule", "additional_interpolation_steps", "additional_interpolation_steps_factor",
             "interpolate_before_t1", "sampling_type", "sampling_schedule", "time_encoding",
             "refine_intermediate_predictions", "prediction_timesteps", "use_cold_sampling_for_last_step", "enable_interpolator_dropout",
-            "lambda_reconstruction", "lambda_reconstruction2", "loss_function"]
+            "lambda_reconstruction", "lambda_reconstruction2", "loss_function", "log_every_t"]
     kw = {k: hp[k] for k in keys if k in hp}
     return D.DYffusion(F, D.InterpolatorHandle(I, hp["timesteps"], window), timesteps=hp["timesteps"], **kw, **engine_kw)
 

@@ -23,7 +23,8 @@ pytestmark = pytest.mark.gpu
 TOL = 2.5e-2
 
 NAMES = ["sample_cold_refine", "sample_cold_norefine", "sample_naive", "sample_k2_data", "sample_k2_coldlast",
-         "sample_k2_onlydyn", "sample_k2_plus2", "sample_ens3", "sample_dropout", "sample_datanoise", "sample_linear", "sample_fractional_refine"]
+         "sample_k2_onlydyn", "sample_k2_plus2", "sample_ens3", "sample_dropout", "sample_datanoise", "sample_linear", "sample_fractional_refine",
+         "sample_log_cold", "sample_log_naive"]
 
 
 @pytest.mark.parametrize("name", NAMES)

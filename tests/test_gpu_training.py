@@ -342,3 +342,48 @@ def test_engine_lifecycle_does_not_leak_device_memory():
         marks.append(used())
     print("MiB in use after each destroy:", [round(v) for v in marks])
     assert marks[-1] - marks[1] <= 32.0
+
+
+@pytest.mark.parametrize("mask_kind", ["rows", "elements"])
+def test_get_loss_with_predictions_mask_matches_autograd_of_the_oracle(mask_kind):
+    """`BaseModel.get_loss(..., predictions_mask=m)` (_base_model.py:132-135): `criterion(predictions[m], targets)` -- the mean and
+    its gradient run over the selected elements only.  Engine training step vs torch.autograd over the oracle's forward with the
+    engine's dropout masks; a mask over the batch rows (1-D) and a full-shape element mask."""
+    from tests.gpu_common import mirror_from_params
+    z = load_npz("interp_train_a.npz")
+    hp = json.loads(str(z["hp"]))
+    mk, P = hp["model"], split_state(z, "P")
+    dyn, cond, t = torch.from_numpy(z["dynamics"]), torch.from_numpy(z["cond"]), torch.from_numpy(z["t"])
+    B, C = dyn.shape[0], dyn.shape[2]
+    w = hp["window"]
+    net = mirror_from_params(P, mk, (w + 1) * C, cond.shape[1], C)
+    net.hparams.loss_function = hp["loss_function"]
+    net.train()
+    x = torch.cat([dyn[:, :w].reshape(B, w * C, *dyn.shape[-2:]), dyn[:, -1]], dim=1)  # window frames + the last frame
+    full_targets = dyn[torch.arange(B), w + t - 1]
+    g = torch.Generator().manual_seed(3)
+    if mask_kind == "rows":
+        m = torch.zeros(B, dtype=torch.bool)
+        m[::2] = True
+    else:
+        m = torch.rand(full_targets.shape, generator=g) < 0.4
+    targets = full_targets[m]
+    seed = 515
+    net._own_engine(B, dyn.shape[-2:]).seed(seed)
+    loss = net.get_loss(x.to(DEV), targets.to(DEV), condition=cond.to(DEV), time=t.to(DEV), predictions_mask=m.to(DEV))
+    loss.backward()
+    uh, uw = mk["upsample_dims"]
+    drop = R.EngineDropout(seed, mk["dim"], uh, uw)
+    drop.begin_forward()
+    Pg = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and not k.endswith(("running_mean", "running_var")) else v)
+          for k, v in P.items()}
+    pred = nets.unet_simple_forward(Pg, mk, x, t.float(), cond, dropout=drop, bn_training=True)
+    want = losses.criterion_fn(hp["loss_function"])(pred[m], targets)
+    want.backward()
+    assert float(loss) == pytest.approx(float(want), rel=1e-4)
+    grads = {k: v.grad for k, v in Pg.items() if torch.is_tensor(v) and v.requires_grad}
+    got = {k: p.grad for k, p in net.named_parameters()}
+    gn = float(torch.cat([gg.reshape(-1) for gg in grads.values()]).norm())
+    worst = max(float((got[k].cpu() - grads[k]).norm()) for k in grads) / gn
+    print(f"predictions_mask ({mask_kind}): loss {float(loss):.6f}, worst per-tensor gradient error / grad norm = {worst:.2e}")
+    assert worst <= 1e-3

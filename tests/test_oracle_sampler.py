@@ -8,7 +8,8 @@ from oracle import nets, sampler
 from tests.helpers import load_npz, max_abs, split_state
 
 NAMES = ["sample_cold_refine", "sample_cold_norefine", "sample_naive", "sample_k2_data", "sample_k2_coldlast",
-         "sample_k2_onlydyn", "sample_k2_plus2", "sample_ens3", "sample_dropout", "sample_datanoise", "sample_linear", "sample_fractional_refine"]
+         "sample_k2_onlydyn", "sample_k2_plus2", "sample_ens3", "sample_dropout", "sample_datanoise", "sample_linear", "sample_fractional_refine",
+         "sample_log_cold", "sample_log_naive"]
 
 
 def run_oracle(z):
