@@ -159,6 +159,9 @@ __device__ __host__ __forceinline__ bool rng_keep(uint32_t e, RngKey key, uint32
     return v < thresh16;
 }
 
+// Dropout site id (rng_layer_salt argument) of unet_simple's dropout_input; the 12 UNetBlocks are sites 0..11
+#define DYF_INPUT_DROP_SITE 12u
+
 // Dropout descriptor handed to every kernel that ends in a Dropout layer.
 struct DropSpec {
     int mode;                 // 0 off, 1 engine RNG, 2 injected mask

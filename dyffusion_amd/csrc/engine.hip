@@ -106,7 +106,22 @@ DropSpec make_drop(const dyf_engine* e, const Net& n, const FwdOpts& o, int laye
     d.thresh16 = keep_threshold16(p);
     d.salt = rng_layer_salt((uint32_t)layer);
     d.row_keys = e->row_keys;
-    d.mask = (d.mode == 2 && o.masks) ? o.masks[layer] : nullptr;
+    // injected masks arrive in execution order: dropout_input (when its p > 0) first, then the 12 blocks
+    d.mask = (d.mode == 2 && o.masks) ? o.masks[layer + (n.cfg.input_dropout > 0.0f ? 1 : 0)] : nullptr;
+    if (d.mode == 2 && d.mask == nullptr) d.mode = 0;
+    return d;
+}
+
+// dropout_input of unet_simple (unet_simple.py:116,168): a Dropout on init_conv's output -- the first site of a forward
+DropSpec make_input_drop(const dyf_engine* e, const Net& n, const FwdOpts& o) {
+    DropSpec d{};
+    const float p = n.cfg.input_dropout;
+    d.mode = (p > 0.0f) ? o.dropout_mode : 0;
+    d.scale = 1.0f / (1.0f - p);
+    d.thresh16 = keep_threshold16(p);
+    d.salt = rng_layer_salt(DYF_INPUT_DROP_SITE);
+    d.row_keys = e->row_keys;
+    d.mask = (d.mode == 2 && o.masks) ? o.masks[0] : nullptr;
     if (d.mode == 2 && d.mask == nullptr) d.mode = 0;
     return d;
 }
@@ -152,7 +167,7 @@ dyf_status net_forward(dyf_engine* e, int which, const Source* srcs, int nsrc, i
     if (n.sc) return sc_forward(e, which, srcs, nsrc, nb, o, out_dev, st);
     Workspace& ws = e->ws;
     const int H = e->cfg.height, W = e->cfg.width;
-    if (o.dropout_mode == 1 && n.cfg.dropout > 0.0f)
+    if (o.dropout_mode == 1 && (n.cfg.dropout > 0.0f || n.cfg.input_dropout > 0.0f))
         HIP_TRY(e, launch_rng_begin_forward(e->rng_state, e->row_keys, nb, o.src_rows > 0 ? o.src_rows : nb, st));
     // ---- stem: outer resample + 1x1 conv
     StemArgs sa{};
@@ -168,7 +183,9 @@ dyf_status net_forward(dyf_engine* e, int which, const Source* srcs, int nsrc, i
     sa.resample = (n.uh != H || n.uw != W) ? 1 : 0;
     sa.nearest = n.cfg.outer_nearest;
     sa.wgt = n.stem_w; sa.bias = n.stem_b; sa.dim = n.dim;
-    const bool fused_stem = n.stem_fused && e->cfg.enable_mfma && e->fuse_stem;
+    // a Dropout between init_conv and the first encoder conv (input_dropout > 0) breaks their composition: separate stem kernel
+    const bool fused_stem = n.stem_fused && e->cfg.enable_mfma && e->fuse_stem && n.cfg.input_dropout == 0.0f;
+    sa.drop = make_input_drop(e, n, o);
     if (fused_stem) {
         sa.out = ws.stem16;
         HIP_TRY(e, launch_stem16(sa, st));
@@ -375,7 +392,9 @@ dyf_status dyf_engine_create(const dyf_engine_config* cfg, dyf_engine** out_engi
         if (n.cfg.arch != DYF_ARCH_UNET_SIMPLE && n.cfg.arch != DYF_ARCH_UNET_RESNET && n.cfg.arch != DYF_ARCH_SIMPLE_CONV_NET)
             return bail(DYF_ERR_UNSUPPORTED, "arch must be unet_simple (0), unet / resnet (1) or simple_conv_net (2)");
         if (n.cfg.dim < 4 || (n.cfg.dim & 1)) return bail(DYF_ERR_INVALID_ARGUMENT, "dim must be even and >= 4");
-        if (n.cfg.input_dropout != 0.0f) return bail(DYF_ERR_UNSUPPORTED, "input_dropout > 0 is not implemented");
+        if (n.cfg.input_dropout < 0.0f || n.cfg.input_dropout >= 1.0f) return bail(DYF_ERR_INVALID_ARGUMENT, "input_dropout must be in [0, 1)");
+        if (n.cfg.input_dropout != 0.0f && n.cfg.arch == DYF_ARCH_SIMPLE_CONV_NET)
+            return bail(DYF_ERR_UNSUPPORTED, "input_dropout > 0: arch simple_conv_net has no such layer");
         if (n.cfg.dropout < 0.0f || n.cfg.dropout >= 1.0f) return bail(DYF_ERR_INVALID_ARGUMENT, "dropout must be in [0, 1)");
         n.cin_total = n.cfg.in_channels + n.cfg.cond_channels;
         if (n.cin_total < 1 || n.cin_total > DYF_MAX_IN_CH || n.cfg.out_channels < 1 || n.cfg.out_channels > DYF_MAX_OUT_CH)
@@ -394,7 +413,7 @@ dyf_status dyf_engine_create(const dyf_engine_config* cfg, dyf_engine** out_engi
             if (!m.empty()) return bail(DYF_ERR_INVALID_ARGUMENT, m);
             continue;
         }
-        n.n_drop_sites = n.cfg.dropout > 0.0f ? 12 : 0;
+        n.n_drop_sites = (n.cfg.dropout > 0.0f ? 12 : 0) + (n.cfg.input_dropout > 0.0f ? 1 : 0);
         layout_blocks(n);
         std::string m = layout_geometry(n, cfg->height, cfg->width);
         if (!m.empty()) return bail(DYF_ERR_INVALID_ARGUMENT, m);
@@ -1394,7 +1413,7 @@ dyf_status dyf_time_conv_layer(dyf_engine* e, int32_t which, int32_t layer, int3
     // same operands as in net_forward: whatever the last forward left in the workspace (realistic activations)
     a.src0 = b.transposed ? e->ws.up : (layer == 0 ? e->ws.stem : e->ws.enc[layer - 1]);
     a.c0 = b.cin;
-    if (layer == 0 && n.stem_fused && e->cfg.enable_mfma && e->fuse_stem) fused_enc0_args(e, n, a);
+    if (layer == 0 && n.stem_fused && e->cfg.enable_mfma && e->fuse_stem && n.cfg.input_dropout == 0.0f) fused_enc0_args(e, n, a);
     if (b.transposed && layer > 6) {  // fused x2-upsample form when net_forward uses it
         ConvArgs f = a;
         const UBlock& skipb = n.blk[11 - layer];

@@ -50,6 +50,7 @@ struct StemArgs {
     const float* bias;      // [dim]
     int dim;
     el16_t* out;            // [n][uh][uw][dim]
+    DropSpec drop;          // dropout_input on the 1x1 conv's output (stem_kernel only; mode 0 = off)
 };
 hipError_t launch_stem(const StemArgs& a, hipStream_t s);
 // Fused-stem form: only the outer resample, written as a zero-bordered [n][uh+2][uw+2][16] bf16 tensor whose channel

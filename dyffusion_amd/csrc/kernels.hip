@@ -128,6 +128,9 @@ __global__ __launch_bounds__(256) void stem_kernel(StemArgs a) {
     __syncthreads();
     if (!live) return;
     el16_t* out = a.out + (size_t)pix * a.dim;
+    const int n_row = (int)(pix / ((long long)a.uh * a.uw));
+    const RngKey dkey = drop_row_key(a.drop, n_row);
+    const uint32_t row0 = (uint32_t)n_row * (uint32_t)(a.uh * a.uw * a.dim);
     for (int d0 = 0; d0 < a.dim; d0 += 8) {
         float acc[8];
 #pragma unroll
@@ -137,6 +140,11 @@ __global__ __launch_bounds__(256) void stem_kernel(StemArgs a) {
 #pragma unroll
             for (int t = 0; t < 8; ++t)
                 if (d0 + t < a.dim) acc[t] = fmaf(a.wgt[(size_t)(d0 + t) * a.cin + c], v, acc[t]);
+        }
+        if (a.drop.mode != 0) {  // dropout_input (unet_simple.py:168)
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+                if (d0 + t < a.dim) acc[t] = drop_apply(acc[t], (uint32_t)(pix * a.dim + d0 + t), row0, a.drop, dkey);
         }
         if ((a.dim & 7) == 0) {
             uint4 o;

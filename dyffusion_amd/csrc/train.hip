@@ -430,6 +430,16 @@ __device__ __forceinline__ float t_keep(const TNorm& a, int b, uint32_t e_in_row
     return rng_keep(e_in_row, rk, a.thresh16) ? a.drop_scale : 0.0f;
 }
 
+// Dropout on a whole NHWC tensor (input_dropout on init_conv's output, unet_simple.py:116,168): y = keep ? x / (1 - p) : 0 with the
+// engine's per-(forward, global row, site) streams; its adjoint is the same map, so one kernel serves both passes (in place).
+__global__ void t_dropout_map(const float* x, float* y, int n, long long per, float scale, uint32_t thresh16, RngKey salt, const uint32_t* row_keys) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= per * n) return;
+    const int b = (int)(i / per);
+    const RngKey rk = rng_stream_key(RngKey{row_keys[2 * b], row_keys[2 * b + 1]}, salt);
+    y[i] = rng_keep((uint32_t)(i - (long long)b * per), rk, thresh16) ? x[i] * scale : 0.0f;
+}
+
 __global__ void t_norm_fwd(TNorm a, const float* z, float* y) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long per = (long long)a.hw * a.C;
@@ -938,10 +948,11 @@ dyf_status dyf_train_forward(dyf_engine* e, int32_t which, int32_t slot, const f
     t = TTape{};
     t.net = which; t.nb = nb; t.flags = flags;
     const bool bn_batch = flags & DYF_TRAIN_BATCH_STATS, drop_on = (flags & DYF_TRAIN_DROPOUT) && n.cfg.dropout > 0.0f;
+    const bool in_drop_on = (flags & DYF_TRAIN_DROPOUT) && n.cfg.input_dropout > 0.0f;
     const int H = e->cfg.height, W = e->cfg.width, hw = H * W, cin = n.cin_total, C = n.cfg.out_channels;
 #define TS(expr) do { dyf_status _s = (expr); if (_s != DYF_OK) return _s; } while (0)
 #define TA(ptr, count) TS(talloc(e, t.owned, &(ptr), (size_t)(count), false))
-    if (drop_on) {  // this forward's dropout streams (engine generator, keyed per global row); kept for the backward
+    if (drop_on || in_drop_on) {  // this forward's dropout streams (engine generator, keyed per global row); kept for the backward
         if (nb > 2 * e->cfg.max_batch) return fail(e, DYF_ERR_INVALID_ARGUMENT, "batch larger than the engine's row-key table");
         TK(launch_rng_begin_forward(e->rng_state, e->row_keys, nb, nb, st));
         TS(talloc(e, t.owned, &t.row_keys, (size_t)2 * nb, false));
@@ -967,6 +978,11 @@ dyf_status dyf_train_forward(dyf_engine* e, int32_t which, int32_t slot, const f
     }
     TA(t.s0, (size_t)nb * n.uh * n.uw * n.dim);
     TS(conv_fwd(e, TConv{nb, n.uh, n.uw, cin, n.uh, n.uw, n.dim, 1, 1, 0}, t.x_up, w.stem_wt, w.stem_b, t.s0, st));
+    if (in_drop_on) {  // dropout_input (site DYF_INPUT_DROP_SITE), in place: the stem's conv needs its input only for the weight gradient
+        const long long per = (long long)n.uh * n.uw * n.dim;
+        hipLaunchKernelGGL(t_dropout_map, dim3(nblk(per * nb)), dim3(256), 0, st, t.s0, t.s0, nb, per, 1.0f / (1.0f - n.cfg.input_dropout),
+                           keep_threshold16(n.cfg.input_dropout), rng_layer_salt(DYF_INPUT_DROP_SITE), t.row_keys);
+    }
     double *S = nullptr, *Q = nullptr;
     TS(talloc(e, t.owned, &S, (size_t)nb * 1024 * 2));
     Q = S + (size_t)nb * 1024;
@@ -1132,6 +1148,11 @@ dyf_status dyf_train_backward(dyf_engine* e, int32_t slot, const float* dout_dev
         TK(hipGetLastError());
     }
     // ---- stem
+    if ((t.flags & DYF_TRAIN_DROPOUT) && n.cfg.input_dropout > 0.0f) {  // adjoint of dropout_input: the same keep map on the gradient
+        const long long per = (long long)n.uh * n.uw * n.dim;
+        hipLaunchKernelGGL(t_dropout_map, dim3(nblk(per * nb)), dim3(256), 0, st, dy, (float*)dy, nb, per, 1.0f / (1.0f - n.cfg.input_dropout),
+                           keep_threshold16(n.cfg.input_dropout), rng_layer_salt(DYF_INPUT_DROP_SITE), t.row_keys);
+    }
     const TConv gs{nb, n.uh, n.uw, cin, n.uh, n.uw, n.dim, 1, 1, 0};
     if (param_grads) TS(conv_wgrad(e, gs, dy, t.x_up, w.g_stem_w, w.g_stem_b, st));
     if (dinputs_dev) {

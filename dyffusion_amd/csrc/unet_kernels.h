@@ -105,3 +105,5 @@ hipError_t launch_head(const HeadArgs& a, hipStream_t s);
 
 // nn.Upsample(scale_factor=2, mode="nearest") (unet.py:16-19) on NHWC bf16
 hipError_t launch_up2x_nearest(const el16_t* src, int n, int h, int w, int c, el16_t* out, hipStream_t s);
+// Dropout over a whole NHWC tensor (input_dropout of unet.Unet); per_row = elements of one sample (even)
+hipError_t launch_drop16(const el16_t* x, el16_t* y, int n, long long per_row, const DropSpec& d, hipStream_t s);

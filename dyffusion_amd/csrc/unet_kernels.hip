@@ -2124,6 +2124,27 @@ __global__ __launch_bounds__(256) void up2x_nearest_vec_kernel(const uint4* src,
     out[o + rs + c8] = v;
 }
 
+// Dropout on a whole NHWC 16-bit tensor (unet.Unet's dropout_input / dropout_input_for_residual on init_conv's output, unet.py:276-277;
+// only with input_dropout > 0, which no shipped config sets): two elements per thread, one keep word per pair.
+__global__ __launch_bounds__(256) void drop16_kernel(const el16_t* x, el16_t* y, long long pairs_total, uint32_t pairs_per_row, DropSpec d) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= pairs_total) return;
+    const int n = (int)(i / pairs_per_row);
+    const uint32_t e0 = (uint32_t)(i - (long long)n * pairs_per_row) * 2u;
+    const RngKey key = drop_row_key(d, n);
+    const uint32_t row0 = (uint32_t)n * pairs_per_row * 2u;
+    float v[2] = {el16_to_f32(x[2 * i]), el16_to_f32(x[2 * i + 1])};
+    act_drop_mode<2, ACT_NONE>(v, row0 + e0, row0, d, key);
+    *(uint32_t*)(y + 2 * i) = pack_el16x2(v[0], v[1]);
+}
+
+hipError_t launch_drop16(const el16_t* x, el16_t* y, int n, long long per_row, const DropSpec& d, hipStream_t s) {
+    if (per_row % 2 != 0 || per_row / 2 > 0xFFFFFFFFll) return hipErrorInvalidValue;
+    const long long pairs = (long long)n * per_row / 2;
+    hipLaunchKernelGGL(drop16_kernel, dim3((unsigned)((pairs + 255) / 256)), dim3(256), 0, s, x, y, pairs, (uint32_t)(per_row / 2), d);
+    return hipGetLastError();
+}
+
 hipError_t launch_up2x_nearest(const el16_t* src, int n, int h, int w, int c, el16_t* out, hipStream_t s) {
     const long long total = (long long)n * 4 * h * w * c;
     if (c % 8 == 0 && total / 32 < 0xFFFFFFFFll) {

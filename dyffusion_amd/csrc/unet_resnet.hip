@@ -248,6 +248,7 @@ std::string rn_configure(dyf_engine* e, Net& n) {
     n.n_drop_sites = 0;
     for (size_t i = 0; i < r->blocks.size(); ++i) n.n_drop_sites += (c.block_dropout1 > 0) + (c.dropout > 0);
     if (c.attn_dropout > 0) n.n_drop_sites += (int)r->attns.size();
+    if (c.input_dropout > 0) n.n_drop_sites += 2;  // dropout_input_for_residual, dropout_input (unet.py:276-277)
     return "";
 }
 
@@ -453,7 +454,7 @@ dyf_status rn_forward(dyf_engine* e, int which, const Source* srcs, int nsrc, in
     pool.free_list = r->pool;
     DropCtx dc{e, &o};
     const bool film = c.with_time_emb != 0;
-    if (o.dropout_mode == 1 && (c.dropout > 0.0f || c.block_dropout1 > 0.0f || c.attn_dropout > 0.0f))
+    if (o.dropout_mode == 1 && (c.dropout > 0.0f || c.block_dropout1 > 0.0f || c.attn_dropout > 0.0f || c.input_dropout > 0.0f))
         HIP_TRY(e, launch_rng_begin_forward(e->rng_state, e->row_keys, nb, o.src_rows > 0 ? o.src_rows : nb, st));
 
 #define TRY(expr)                         \
@@ -557,15 +558,25 @@ dyf_status rn_forward(dyf_engine* e, int which, const Source* srcs, int nsrc, in
     sa.wgt = r->stem_w; sa.bias = r->stem_b; sa.dim = c.dim; sa.out = rbuf;
     sa.wfrag = r->stem_wfrag; sa.ksteps = r->stem_ksteps;
     HIP_TRY(e, launch_stem_conv(sa, st));
+    el16_t* x0 = rbuf;  // what the first block reads; rbuf stays the copy for the final residual
+    if (c.input_dropout > 0.0f) {
+        // unet.py:276-277: r = dropout_input_for_residual(x); x = dropout_input(x) -- two sites, the residual's first
+        const DropSpec dr = dc.next(c.input_dropout), dx = dc.next(c.input_dropout);
+        if (dr.mode != 0 || dx.mode != 0) {
+            x0 = pool.get();
+            HIP_TRY(e, launch_drop16(rbuf, x0, nb, (long long)H * W * c.dim, dx, st));    // x from the raw stem output ...
+            HIP_TRY(e, launch_drop16(rbuf, rbuf, nb, (long long)H * W * c.dim, dr, st));  // ... then the residual copy in place
+        }
+    }
 
     std::vector<el16_t*> skips;
-    el16_t* x = rbuf;
+    el16_t* x = x0;
     int bi = 0, ai = 0;
     for (int l = 0; l < r->nlev; ++l) {
         const int hh = r->lev_h[l], ww = r->lev_w[l], dl = r->dims[l];
         el16_t *x1, *x2, *x3;
         TRY(resblock(r->blocks[bi++], x, dl, nullptr, 0, hh, ww, &x1));
-        if (x != rbuf) pool.put(x);
+        if (x != rbuf) pool.put(x);  // (the dropped-out input copy x0 goes back to the pool here, too)
         skips.push_back(x1);
         TRY(resblock(r->blocks[bi++], x1, dl, nullptr, 0, hh, ww, &x2));
         TRY(attention(r->attns[ai++], x2, hh, ww, &x3));

@@ -125,7 +125,7 @@ class Unet(nn.Module):
     @property
     def has_dropout(self) -> bool:
         hp = self.hparams
-        return hp.block_dropout > 0 or hp.block_dropout1 > 0 or hp.attn_dropout > 0
+        return hp.block_dropout > 0 or hp.block_dropout1 > 0 or hp.attn_dropout > 0 or hp.input_dropout > 0
 
     def attach_engine(self, engine: HipEngine, slot: int):
         self._engine, self._engine_slot, self._engine_key = engine, slot, "attached"

@@ -94,7 +94,7 @@ class UNet(nn.Module):
 
     @property
     def has_dropout(self) -> bool:
-        return self.hparams.dropout > 0
+        return self.hparams.dropout > 0 or self.hparams.input_dropout > 0
 
     def attach_engine(self, engine: HipEngine, slot: int):
         """Used by DYffusion: both networks of a pair live in one engine."""
@@ -138,7 +138,7 @@ class UNet(nn.Module):
             assert condition is None
         eng = self._own_engine(inputs.shape[0], inputs.shape[-2:])
         sync_weights(self, eng, self._engine_slot)  # parameters modified in place since the last upload (optimizer, EMA swap)
-        mode = 1 if (self._mc_dropout and self.hparams.dropout > 0) else 0
+        mode = 1 if (self._mc_dropout and self.has_dropout) else 0
         return eng.net_forward(self._engine_slot, inputs, time if self.hparams.with_time_emb else None, condition,
                                dropout_mode=mode)
 

@@ -64,7 +64,8 @@ typedef struct dyf_net_config {
     int32_t upsample_h;       /* upsample_dims[0], 0 = no outer resampling */
     int32_t upsample_w;
     float dropout;            /* unet_simple: UNetBlock dropout p; unet: block_dropout (2nd Block of a ResnetBlock) */
-    float input_dropout;      /* must be 0 (the shipped configs' value) in this version */
+    float input_dropout;      /* Dropout on init_conv's output: unet_simple.py:116,168 (one site, the first of a forward; the engine then
+                               * runs the un-fused stem), unet.py:162-163,276-277 (two sites: residual copy, input); 0 in every shipped config */
     /* ---- unet.Unet only (kwargs of Unet.__init__, src/models/unet.py:113-135) ---- */
     int32_t n_mults;          /* len(dim_mults), <= 6 */
     int32_t dim_mults[6];

@@ -368,18 +368,21 @@ def resnet_unet_forward(P: Dict[str, Tensor], cfg: dict, x: Tensor, time: Option
                         condition: Optional[Tensor] = None, dropout=None) -> Tensor:
     """unet.Unet.forward (unet.py:266-315).  cfg keys: dim, dim_mults, with_time_emb, block_dropout (second block),
     block_dropout1 (first block), attn_dropout, resnet_block_groups (8), init_kernel_size (7), init_padding (3);
-    input_dropout must be 0 and there is no outer resampling (the shipped OISST / synthetic settings).
+    input_dropout (two sites: residual copy, then x), no outer resampling (the shipped OISST / synthetic settings).
     NOTE the condition goes FIRST in the channel concat here (unet.py:269), unlike unet_simple."""
     dropout = dropout or DropoutOff()
     dim, mults = cfg["dim"], tuple(cfg.get("dim_mults", (1, 2, 4)))
     groups = cfg.get("resnet_block_groups", 8)
     p2, p1, pa = cfg.get("block_dropout", 0.0), cfg.get("block_dropout1", 0.0), cfg.get("attn_dropout", 0.0)
     heads, dh = 4, 32
-    assert cfg.get("input_dropout", 0.0) == 0.0 and cfg.get("upsample_dims") is None
+    assert cfg.get("upsample_dims") is None
     if condition is not None:
         x = torch.cat([condition, x], dim=1)
     x = F.conv2d(x, P["init_conv.weight"], P["init_conv.bias"], padding=cfg.get("init_padding", 3))
-    r = x
+    # unet.py:276-277: two independent Dropouts on init_conv's output, the copy kept for the final residual first
+    p_in = cfg.get("input_dropout", 0.0)
+    r = dropout.apply(x, p_in) if p_in > 0 else x
+    x = dropout.apply(x, p_in)
     temb = time_embedding(P, "time_emb_mlp", time, dim) if cfg.get("with_time_emb", False) else None
     nlev = len(mults)
     skips = []

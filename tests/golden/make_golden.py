@@ -143,6 +143,9 @@ def gen_nets():
         # outer_sample_mode="nearest" (unet_simple.py:172-179): both outer resamples pick the floor(dst * in/out) source
         ("net_unet_simple_d", dict(dim=8, upsample_dims=[64, 64], n_in=5, n_cond=1, n_out=3, hw=(23, 11), nb=2,
                                    dropout=0.2, mode="nearest")),
+        # input_dropout > 0 (unet_simple.py:116, 168): a Dropout on init_conv's output, the FIRST dropout site of a forward
+        ("net_unet_simple_e", dict(dim=8, upsample_dims=[64, 64], n_in=4, n_cond=1, n_out=3, hw=(23, 11), nb=2,
+                                   dropout=0.15, input_dropout=0.1)),
     ]
     only = os.environ.get("DYF_GOLDEN_ONLY")
     for name, sp in specs:
@@ -150,7 +153,7 @@ def gen_nets():
             continue
         mode = sp.get("mode", "bilinear")
         net = UNet(dim=sp["dim"], with_time_emb=True, outer_sample_mode=mode, upsample_dims=sp["upsample_dims"],
-                   dropout=sp["dropout"], input_dropout=0.0, num_input_channels=sp["n_in"],
+                   dropout=sp["dropout"], input_dropout=sp.get("input_dropout", 0.0), num_input_channels=sp["n_in"],
                    num_output_channels=sp["n_out"], num_conditional_channels=sp["n_cond"], spatial_shape=sp["hw"],
                    loss_function="mse", verbose=False).eval()
         shapes = load_seeded(net, seed=11)
@@ -170,7 +173,7 @@ def gen_nets():
         arrs = dict(np_state(net.state_dict()), x=x.numpy(), t=t.numpy(), y_eval=y_eval.numpy(),
                     y_drop=y_drop.numpy(), dropout_seed=np.int64(77),
                     cfg=json.dumps(dict(dim=sp["dim"], upsample_dims=sp["upsample_dims"], outer_sample_mode=mode,
-                                        with_time_emb=True, dropout=sp["dropout"], input_dropout=0.0)))
+                                        with_time_emb=True, dropout=sp["dropout"], input_dropout=sp.get("input_dropout", 0.0))))
         if c is not None:
             arrs["c"] = c.numpy()
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **arrs)
@@ -206,10 +209,16 @@ def gen_resnet_unets():
                                    bd=0.3, bd1=0.1, ad=0.2)),
         ("net_unet_resnet_b", dict(dim=16, mults=(1, 2), n_in=1, n_cond=0, n_out=1, hw=(20, 12), nb=2,
                                    bd=0.6, bd1=0.2, ad=0.6)),
+        # input_dropout > 0 (unet.py:162-163, 276-277): dropout_input_for_residual and dropout_input on init_conv's output
+        ("net_unet_resnet_c", dict(dim=8, mults=(1, 2), n_in=2, n_cond=1, n_out=1, hw=(12, 16), nb=2,
+                                   bd=0.3, bd1=0.1, ad=0.2, ind=0.15)),
     ]
+    only = os.environ.get("DYF_GOLDEN_ONLY")
     for name, sp in specs:
+        if only and name != only:
+            continue
         net = Unet(dim=sp["dim"], dim_mults=sp["mults"], with_time_emb=True, block_dropout=sp["bd"],
-                   block_dropout1=sp["bd1"], attn_dropout=sp["ad"], num_input_channels=sp["n_in"],
+                   block_dropout1=sp["bd1"], attn_dropout=sp["ad"], input_dropout=sp.get("ind", 0.0), num_input_channels=sp["n_in"],
                    num_output_channels=sp["n_out"], num_conditional_channels=sp["n_cond"], spatial_shape=sp["hw"],
                    loss_function="mse", verbose=False).eval()
         shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
@@ -233,7 +242,7 @@ def gen_resnet_unets():
                     dropout_seed=np.int64(78),
                     cfg=json.dumps(dict(dim=sp["dim"], dim_mults=list(sp["mults"]), with_time_emb=True,
                                         block_dropout=sp["bd"], block_dropout1=sp["bd1"], attn_dropout=sp["ad"],
-                                        resnet_block_groups=8, input_dropout=0.0, upsample_dims=None)))
+                                        resnet_block_groups=8, input_dropout=sp.get("ind", 0.0), upsample_dims=None)))
         if c is not None:
             arrs["c"] = c.numpy()
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **arrs)

@@ -91,9 +91,14 @@ class EngineDropout:
     """Dropout source for `oracle.nets.unet_simple_forward(..., dropout=)` that replays the ENGINE's masks: call
     `begin_forward()` before every network forward that draws masks (same order as the engine's forward counter)."""
 
-    def __init__(self, seed, dim, uh, uw, row_offset=0, first_forward=0):
+    INPUT_SITE = 12  # csrc/common.h DYF_INPUT_DROP_SITE: dropout_input on init_conv's output (only drawn when input_dropout > 0)
+
+    def __init__(self, seed, dim, uh, uw, row_offset=0, first_forward=0, input_dropout=False):
         self.seed, self.row_offset = seed, row_offset
-        self.shapes = unet_simple_site_shapes(dim, uh, uw)
+        blocks = unet_simple_site_shapes(dim, uh, uw)
+        # (shape, layer id) in execution order: the oracle calls apply() for dropout_input first, then once per UNetBlock
+        self.sites = ([((uh, uw, dim), self.INPUT_SITE)] if input_dropout else []) + [(sh, i) for i, sh in enumerate(blocks)]
+        self.shapes = blocks
         self.fwd = first_forward - 1
         self.site = 0
 
@@ -104,9 +109,9 @@ class EngineDropout:
     def apply(self, x, p):
         if p <= 0.0:
             return x
-        h, w, c = self.shapes[self.site]
-        assert tuple(x.shape[1:]) == (c, h, w), (x.shape, self.shapes[self.site])
-        keep = mask_nchw(x.shape[0], (h, w, c), p, self.seed, self.fwd, self.site, self.row_offset).to(x.dtype)
+        (h, w, c), layer = self.sites[self.site]
+        assert tuple(x.shape[1:]) == (c, h, w), (x.shape, self.sites[self.site])
+        keep = mask_nchw(x.shape[0], (h, w, c), p, self.seed, self.fwd, layer, self.row_offset).to(x.dtype)
         self.site += 1
         return x * keep * (1.0 / (1.0 - p))
 

@@ -61,6 +61,51 @@ def test_rng_mode_forward_equals_oracle_with_host_reproduced_masks():
         assert err <= 1.5e-2
 
 
+def test_input_dropout_forward_and_rollout_equal_the_oracle_on_the_engines_masks():
+    """input_dropout > 0 (unet_simple.py:116,168: a Dropout on init_conv's output, the first site of a forward): the engine runs the
+    separate stem kernel with the dropout in its epilogue (the stem -> enc0 composition needs nothing non-linear in between).  One
+    forward with a row offset, and a whole rollout (paired interpolator launches, graph) against the oracle on host-rebuilt masks."""
+    mk = dict(MK64, input_dropout=0.1)
+    P = oinit.seeded_state(oinit.unet_simple_param_shapes(64, 5, 3), seed=36)
+    g = torch.Generator().manual_seed(10)
+    x, c, t = torch.randn(2, 3, 23, 11, generator=g), torch.rand(2, 2, 23, 11, generator=g), torch.tensor([2.0, 3.0])
+    net = mirror_from_params(P, mk, 3, 2, 3)
+    seed = 424242
+    y_eval = net(x.to(DEV), time=t.to(DEV), condition=c.to(DEV)).cpu()
+    with torch.no_grad():
+        assert rel_rms(y_eval, nets.unet_simple_forward(P, mk, x, t, c)) <= 1e-2  # dropout off: the un-fused stem path itself
+    with net.inference_dropout_scope(True):
+        net._engine.seed(seed)
+        net._engine.set_row_offset(3)
+        y = net(x.to(DEV), time=t.to(DEV), condition=c.to(DEV)).cpu()
+        net._engine.set_row_offset(0)
+    drop = R.EngineDropout(seed, 64, 64, 64, row_offset=3, input_dropout=True)
+    drop.begin_forward()
+    with torch.no_grad():
+        want = nets.unet_simple_forward(P, mk, x, t, c, dropout=drop)
+    err = rel_rms(y, want)
+    print("input_dropout forward vs oracle(host masks): rel-rms", err)
+    assert err <= 1.5e-2 and rel_rms(y, y_eval) > 0.1
+    # rollout
+    PF, PI = seeded_pair(64, 3, 2)
+    m = build_dyffusion(PF, PI, mk, 3, 2, HP4, max_batch=3)
+    m.seed(99)
+    x0, cc = torch.randn(3, 3, 23, 11, generator=g), torch.rand(3, 2, 23, 11, generator=g)
+    got = m.sample(x0.to(DEV), static_condition=cc.to(DEV))
+    uh, uw = mk["upsample_dims"]
+    dr = R.EngineDropout(99, 64, uh, uw, input_dropout=True)
+
+    def i_fn(xx, tt, cond):
+        dr.begin_forward()
+        return nets.unet_simple_forward(PI, mk, xx, tt, cond, dropout=dr)
+
+    with torch.no_grad():
+        want = sampler.sample_loop(lambda xx, tt, cond: nets.unet_simple_forward(PF, mk, xx, tt, cond), i_fn, x0, cc, HP4)
+    worst = max(rel_rms(got[k].cpu(), want[k]) for k in want)
+    print("input_dropout rollout vs oracle(host masks): worst rel-rms", worst)
+    assert worst <= 2.5e-2
+
+
 def _oracle_rollout_with_engine_masks(PF, PI, mk, hp, x0, c, seed, row_offset=0, first_forward=0):
     """oracle.sampler.sample_loop with the interpolator drawing the ENGINE's masks: the forward counter advances by one
     per interpolator forward, in the order sample_loop makes them (next-step, then current-step, then the refinement

@@ -18,7 +18,7 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-2
 
 
-@pytest.mark.parametrize("name", ["net_unet_simple_a", "net_unet_simple_b", "net_unet_simple_c", "net_unet_simple_d"])
+@pytest.mark.parametrize("name", ["net_unet_simple_a", "net_unet_simple_b", "net_unet_simple_c", "net_unet_simple_d", "net_unet_simple_e"])
 def test_small_nets_match_reference_goldens(name):
     """dim 4/8 networks straight from the reference's own outputs (direct-conv path: channels < 64)."""
     z = load_npz(name + ".npz")

@@ -387,3 +387,37 @@ def test_get_loss_with_predictions_mask_matches_autograd_of_the_oracle(mask_kind
     worst = max(float((got[k].cpu() - grads[k]).norm()) for k in grads) / gn
     print(f"predictions_mask ({mask_kind}): loss {float(loss):.6f}, worst per-tensor gradient error / grad norm = {worst:.2e}")
     assert worst <= 1e-3
+
+
+def test_training_step_with_input_dropout_matches_autograd_of_the_oracle():
+    """input_dropout > 0 in TRAIN mode (reference golden net_unet_simple_e's network: dim 8, input_dropout 0.1, dropout 0.15): the
+    stage-1 `get_loss` step -- dropout_input and its adjoint (the same keep map on the gradient) -- against torch.autograd over the
+    oracle with the engine's masks."""
+    from tests.gpu_common import mirror_from_params
+    z = load_npz("net_unet_simple_e.npz")
+    P, cfg = split_state(z, "P"), json.loads(str(z["cfg"]))
+    assert cfg["input_dropout"] > 0
+    x, t, c = torch.from_numpy(z["x"]), torch.from_numpy(z["t"]), torch.from_numpy(z["c"])
+    n_out = z["y_eval"].shape[1]
+    net = mirror_from_params(P, cfg, x.shape[1], c.shape[1], n_out)
+    net.train()
+    targets = torch.randn(x.shape[0], n_out, *x.shape[-2:], generator=torch.Generator().manual_seed(8))
+    seed = 2024
+    net._own_engine(x.shape[0], x.shape[-2:]).seed(seed)
+    loss = net.get_loss(x.to(DEV), targets.to(DEV), condition=c.to(DEV), time=t.to(DEV))
+    loss.backward()
+    uh, uw = cfg["upsample_dims"]
+    drop = R.EngineDropout(seed, cfg["dim"], uh, uw, input_dropout=True)
+    drop.begin_forward()
+    Pg = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and not k.endswith(("running_mean", "running_var")) else v)
+          for k, v in P.items()}
+    pred = nets.unet_simple_forward(Pg, cfg, x, t, c, dropout=drop, bn_training=True)
+    want = F.mse_loss(pred, targets)
+    want.backward()
+    assert float(loss) == pytest.approx(float(want), rel=1e-4)
+    grads = {k: v.grad for k, v in Pg.items() if torch.is_tensor(v) and v.requires_grad}
+    got = {k: p.grad for k, p in net.named_parameters()}
+    gn = float(torch.cat([gg.reshape(-1) for gg in grads.values()]).norm())
+    worst = max(float((got[k].cpu() - grads[k]).norm()) for k in grads) / gn
+    print(f"input_dropout training step: loss {float(loss):.6f}, worst per-tensor gradient error / grad norm = {worst:.2e}")
+    assert worst <= 1e-3

@@ -19,7 +19,7 @@ import dyffusion_amd as D
 from oracle import losses, nets
 from tests import rng_host as R
 from tests.gpu_common import DEV
-from tests.helpers import load_npz, split_state
+from tests.helpers import load_npz, rel_rms, split_state
 
 pytestmark = pytest.mark.gpu
 
@@ -188,3 +188,59 @@ def test_dim64_resnet_training_step_on_the_matrix_core_convs():
     print(f"dim-64 ResNet-UNet: loss {float(out['loss']):.6f}, grad norm {gn:.4f}, worst gradient error / grad norm {errs[worst]:.2e} ({worst})")
     assert errs[worst] <= 1e-3
     m.eval()
+
+
+def test_resnet_training_step_with_input_dropout_matches_autograd_of_the_oracle():
+    """input_dropout > 0 (unet.py:162-163, 276-277: dropout_input_for_residual and dropout_input on init_conv's output, the first two
+    sites of a forward) in TRAIN mode, on the network of the reference golden net_unet_resnet_c: stage-1 `get_loss` + backward on the
+    engine against torch.autograd over the oracle with the engine's masks."""
+    from tests.test_gpu_unet_resnet import mirror
+    z = load_npz("net_unet_resnet_c.npz")
+    P, cfg = split_state(z, "P"), json.loads(str(z["cfg"]))
+    assert cfg["input_dropout"] > 0
+    x, t, c = torch.from_numpy(z["x"]), torch.from_numpy(z["t"]), torch.from_numpy(z["c"])
+    net = mirror(P, cfg, x.shape[1], c.shape[1], 1)
+    net.train()
+    y = torch.randn(x.shape[0], 1, *x.shape[-2:], generator=torch.Generator().manual_seed(12))
+    seed = 777001
+    net._own_engine(x.shape[0], x.shape[-2:]).seed(seed)
+    loss = net.get_loss(x.to(DEV), y.to(DEV), condition=c.to(DEV), time=t.to(DEV))
+    loss.backward()
+    nlev = len(cfg["dim_mults"])
+    hw_mid = (x.shape[-2] >> (nlev - 1)) * (x.shape[-1] >> (nlev - 1))
+    drop = R.ResnetEngineDropout(seed, hw_mid)
+    drop.begin_forward()
+    Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    want = ((nets.resnet_unet_forward(Pg, cfg, x, t, c, dropout=drop) - y) ** 2).mean()
+    want.backward()
+    assert float(loss) == pytest.approx(float(want), rel=1e-4)
+    gn = float(torch.cat([v.grad.reshape(-1) for v in Pg.values()]).norm())
+    worst = max(float((p.grad.cpu() - Pg[k].grad).norm()) for k, p in net.named_parameters()) / gn
+    print(f"ResNet-UNet input_dropout training step: loss {float(loss):.6f}, worst gradient error / grad norm {worst:.2e}")
+    assert worst <= 1e-3
+
+
+def test_resnet_sampling_forward_with_input_dropout_draws_the_same_streams():
+    """The SAMPLING path (16-bit activations, `drop16_kernel`) with the engine's generator: sites 0 / 1 of a forward are the residual
+    copy's and the input's dropout, as in the training step -- forward with MC dropout on vs the oracle on host-rebuilt masks
+    (attention dropout off: its probability mask is covered by the injected-mask golden test)."""
+    from tests.test_gpu_unet_resnet import mirror
+    z = load_npz("net_unet_resnet_c.npz")
+    P, cfg = split_state(z, "P"), json.loads(str(z["cfg"]))
+    cfg = dict(cfg, attn_dropout=0.0)
+    x, t, c = torch.from_numpy(z["x"]), torch.from_numpy(z["t"]), torch.from_numpy(z["c"])
+    net = mirror(P, cfg, x.shape[1], c.shape[1], 1)
+    seed = 31415
+    with net.inference_dropout_scope(True):
+        net(x.to(DEV), time=t.to(DEV), condition=c.to(DEV))
+        net._engine.seed(seed)
+        y = net(x.to(DEV), time=t.to(DEV), condition=c.to(DEV)).cpu()
+    nlev = len(cfg["dim_mults"])
+    drop = R.ResnetEngineDropout(seed, (x.shape[-2] >> (nlev - 1)) * (x.shape[-1] >> (nlev - 1)))
+    drop.begin_forward()
+    with torch.no_grad():
+        want = nets.resnet_unet_forward(P, cfg, x, t, c, dropout=drop)
+        off = nets.resnet_unet_forward(P, cfg, x, t, c)
+    err = rel_rms(y, want)
+    print(f"ResNet-UNet sampling forward, input_dropout on, engine streams vs host masks: rel-rms {err:.3e} (dropout effect {rel_rms(off, want):.2f})")
+    assert err <= 4e-3 and rel_rms(off, want) > 0.05

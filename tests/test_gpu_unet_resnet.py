@@ -38,7 +38,8 @@ def test_fp16_is_the_default_dtype_of_the_resnet_unet():
 def mirror(P, cfg, n_in, n_cond, n_out, dtype=None):
     net = D.Unet(dim=cfg["dim"], dim_mults=cfg["dim_mults"], with_time_emb=cfg.get("with_time_emb", True),
                  block_dropout=cfg.get("block_dropout", 0.0), block_dropout1=cfg.get("block_dropout1", 0.0),
-                 attn_dropout=cfg.get("attn_dropout", 0.0), num_input_channels=n_in, num_output_channels=n_out,
+                 attn_dropout=cfg.get("attn_dropout", 0.0), input_dropout=cfg.get("input_dropout", 0.0), num_input_channels=n_in,
+                 num_output_channels=n_out,
                  num_conditional_channels=n_cond)
     if dtype is not None:
         net.engine_dtype = dtype
@@ -46,16 +47,16 @@ def mirror(P, cfg, n_in, n_cond, n_out, dtype=None):
     return net
 
 
-def engine_masks(masks, nlev):
+def engine_masks(masks, nlev, n_input=0):
     """oracle keep-masks -> engine layout: activations NCHW -> NHWC; the attention-probability mask (b,h,n,n) of
     mid_attn is passed unchanged.  Site order (all p > 0): per level [block, block, block, block, linattn], then
     mid_block1 (2), mid_attn (1), ..."""
-    attn_idx = 5 * nlev + 2
+    attn_idx = n_input + 5 * nlev + 2  # n_input = 2 with input_dropout > 0: dropout_input_for_residual, dropout_input come first
     return [(m if i == attn_idx else m.permute(0, 2, 3, 1)).contiguous().to(DEV) for i, m in enumerate(masks)]
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("name", ["net_unet_resnet_a", "net_unet_resnet_b"])
+@pytest.mark.parametrize("name", ["net_unet_resnet_a", "net_unet_resnet_b", "net_unet_resnet_c"])
 def test_small_resnet_unets_match_reference_goldens(name, dtype):
     z = load_npz(name + ".npz")
     P, cfg = split_state(z, "P"), json.loads(str(z["cfg"]))
@@ -71,7 +72,7 @@ def test_small_resnet_unets_match_reference_goldens(name, dtype):
     y_or = nets.resnet_unet_forward(P, cfg, x, t, c, dropout=src)
     assert rel_rms(y_or, z["y_drop"]) < 1e-5
     y = net._engine.net_forward(0, x.to(DEV), t.to(DEV), None if c is None else c.to(DEV), dropout_mode=2,
-                                masks=engine_masks(src.masks, len(cfg["dim_mults"]))).cpu()
+                                masks=engine_masks(src.masks, len(cfg["dim_mults"]), 2 if cfg.get("input_dropout", 0) > 0 else 0)).cpu()
     err = rel_rms(y, z["y_drop"])
     print(name, dtype, "dropout rel-rms", err)
     assert err <= TOL[dtype]

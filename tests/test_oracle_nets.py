@@ -11,7 +11,7 @@ from tests.helpers import load_npz, max_abs, split_state
 TOL = 2e-6  # fp32, same ATen primitives as the reference -> agreement to rounding
 
 
-@pytest.mark.parametrize("name", ["net_unet_simple_a", "net_unet_simple_b", "net_unet_simple_c", "net_unet_simple_d"])
+@pytest.mark.parametrize("name", ["net_unet_simple_a", "net_unet_simple_b", "net_unet_simple_c", "net_unet_simple_d", "net_unet_simple_e"])
 def test_unet_simple_matches_reference(name):
     z = load_npz(name + ".npz")
     P = split_state(z, "P")
@@ -77,7 +77,7 @@ def test_fullsize_forwards_match_reference_checksums():
         assert np.allclose(got, meta[key]["probes"], atol=2e-5)
 
 
-@pytest.mark.parametrize("name", ["net_unet_resnet_a", "net_unet_resnet_b"])
+@pytest.mark.parametrize("name", ["net_unet_resnet_a", "net_unet_resnet_b", "net_unet_resnet_c"])
 def test_resnet_unet_matches_reference(name):
     """src.models.unet.Unet (WS-conv, GroupNorm+SiLU, FiLM, LinearAttention, Attention, channel LayerNorm)."""
     z = load_npz(name + ".npz")
