@@ -103,6 +103,8 @@ dyf_status rconv(dyf_engine* e, const el16_t* s0, int c0, const el16_t* s1, int 
     a.residual = residual; a.out_el16 = out;
     a.splitk_ws = e->ws.splitk; a.splitk_cap = DYF_SPLITK_FLOATS;
     a.n_sel = e->cfg.batch_invariant ? 2 * e->cfg.max_batch : 0;
+    // a row group shares the chip with the launches of its sibling groups: choose the kernel form by the tile count of all of them
+    if (e->form_rows_scale > 1 && !e->cfg.batch_invariant) a.n_sel = n * e->form_rows_scale;
     const int path = (e->cfg.enable_mfma && conv_mfma_supported(a)) ? 1 : 0;
     ProfScope prof(e, e->prof_layer == DYF_PROF_RESNET_BASE + DYF_PROF_RN_CONV3_L0 && k == 3 && stride == 1 && h == e->cfg.height &&
                           w == e->cfg.width && c0 + c1 == cout && residual == nullptr, n, st);
