@@ -18,6 +18,7 @@
 #include "conv.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <type_traits>
 #include <vector>
 typedef __attribute__((ext_vector_type(16))) float f32x16;
@@ -520,7 +521,11 @@ hipError_t conv_halo_rows_init() {
 hipError_t launch_conv_halo_rows_up(const ConvArgs& a, hipStream_t stream) {
     const bool sparse = a.up_cols != nullptr;
     const int tiles_x = sparse ? a.up_ntiles : a.w / R_TW, tiles_per_img = tiles_x * (a.h / R_TH);
-    const int tiles_m = a.n * tiles_per_img, tiles_n = a.cout / 64;
+    int tiles_m = a.n * tiles_per_img;
+    const int tiles_n = a.cout / 64;
+    // timing experiment (WRONG results): 13 of 16 sparse tiles -- what packing the 52-column lists without padded slots would save
+    static const bool exp1316 = getenv("DYF_EXP_DEC5_1316") && atoi(getenv("DYF_EXP_DEC5_1316")) != 0;
+    if (sparse && exp1316) tiles_m = tiles_m * 13 / 16;
     dyf_form_note(sparse ? "conv_halo_rows_kernel<1>" : "conv_halo_rows_kernel<0>", a.n);
     if (sparse)
         hipLaunchKernelGGL(conv_halo_rows_kernel<1>, dim3(tiles_m * tiles_n), dim3(256), RowsCfg<1>::LDS_TOTAL, stream, a, tiles_x,
