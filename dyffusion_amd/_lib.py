@@ -26,7 +26,8 @@ class NetConfig(C.Structure):
                 ("upsample_h", C.c_int32), ("upsample_w", C.c_int32), ("dropout", C.c_float),
                 ("input_dropout", C.c_float), ("n_mults", C.c_int32), ("dim_mults", C.c_int32 * 6),
                 ("block_dropout1", C.c_float), ("attn_dropout", C.c_float), ("groups", C.c_int32),
-                ("init_kernel_size", C.c_int32), ("init_padding", C.c_int32), ("outer_nearest", C.c_int32)]
+                ("init_kernel_size", C.c_int32), ("init_padding", C.c_int32), ("outer_nearest", C.c_int32),
+                ("keep_spatial_dims", C.c_int32), ("single_conv_layer", C.c_int32), ("learned_sinusoidal_dim", C.c_int32)]
 
 
 class EngineConfig(C.Structure):

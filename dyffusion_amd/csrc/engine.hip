@@ -301,6 +301,7 @@ dyf_status compute_coefs(dyf_engine* e, Net& n, const float* time_dev, int rows,
         TimeMlpArgs t{};
         t.time = time_dev; t.rows = rows; t.dim = n.dim; t.w1 = n.t_w1; t.b1 = n.t_b1; t.w2 = n.t_w2; t.b2 = n.t_b2;
         t.silu_out = e->ws.silu;
+        if (n.t_learned) { t.learned_w = n.t_learned; t.learned_half = n.cfg.learned_sinusoidal_dim / 2; }
         HIP_TRY(e, launch_time_mlp(t, st));
         f.silu = e->ws.silu;
     }

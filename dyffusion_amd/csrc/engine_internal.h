@@ -54,6 +54,7 @@ struct Net {
     int uh = 0, uw = 0;      // resampled grid
     UBlock blk[12];
     float *t_w1 = nullptr, *t_b1 = nullptr, *t_w2 = nullptr, *t_b2 = nullptr;
+    float* t_learned = nullptr;  // learned_sinusoidal_cond: time_emb_mlp.0.weights (cfg.learned_sinusoidal_dim / 2 frequencies)
     float *stem_w = nullptr, *stem_b = nullptr;
     float *film_w = nullptr, *film_b = nullptr, *norm_a = nullptr, *norm_c = nullptr;
     int *blk_of = nullptr, *blk_off = nullptr, *blk_cout = nullptr;

@@ -14,6 +14,8 @@ struct TimeMlpArgs {
     const float* w2;        // [2dim][2dim]
     const float* b2;
     float* silu_out;        // [rows][2dim]
+    const float* learned_w = nullptr;  // LearnedSinusoidalPosEmb (misc.py:35-51): `learned_half` frequencies; features
+    int learned_half = 0;              // [t, sin(2 pi t w), cos(2 pi t w)], w1 is [2dim][2 learned_half + 1]
 };
 hipError_t launch_time_mlp(const TimeMlpArgs& a, hipStream_t s);
 

@@ -27,15 +27,25 @@ __device__ __forceinline__ float block_sum(float v, float* scratch /* >= 16 floa
 // every UNetBlock.time_mlp (unet_simple.py:21-23) and is shared by all blocks.
 __global__ void time_mlp_kernel(TimeMlpArgs a) {
     extern __shared__ float sh[];  // e[dim] | h[tdim]
-    const int row = blockIdx.x, dim = a.dim, tdim = 2 * a.dim, half = a.dim / 2;
+    const int row = blockIdx.x, tdim = 2 * a.dim, half = a.dim / 2;
+    const int dim = a.learned_w ? 2 * a.learned_half + 1 : a.dim;  // number of time features
     float* e = sh;
     float* h = sh + dim;
     const float t = a.time[row];
-    const float step = -logf(10000.0f) / (float)(half - 1);
-    for (int i = threadIdx.x; i < dim; i += blockDim.x) {
-        const int j = i < half ? i : i - half;
-        const float ang = t * expf((float)j * step);
-        e[i] = i < half ? sinf(ang) : cosf(ang);
+    if (a.learned_w) {
+        for (int i = threadIdx.x; i < dim; i += blockDim.x) {
+            if (i == 0) { e[0] = t; continue; }
+            const int j = (i - 1) % a.learned_half;
+            const float ang = t * a.learned_w[j] * 6.283185307179586f;
+            e[i] = i <= a.learned_half ? sinf(ang) : cosf(ang);
+        }
+    } else {
+        const float step = -logf(10000.0f) / (float)(half - 1);
+        for (int i = threadIdx.x; i < dim; i += blockDim.x) {
+            const int j = i < half ? i : i - half;
+            const float ang = t * expf((float)j * step);
+            e[i] = i < half ? sinf(ang) : cosf(ang);
+        }
     }
     __syncthreads();
     for (int j = threadIdx.x; j < tdim; j += blockDim.x) {
@@ -54,7 +64,7 @@ __global__ void time_mlp_kernel(TimeMlpArgs a) {
 }
 
 hipError_t launch_time_mlp(const TimeMlpArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(time_mlp_kernel, dim3(a.rows), dim3(128), (size_t)(3 * a.dim) * sizeof(float), s, a);
+    hipLaunchKernelGGL(time_mlp_kernel, dim3(a.rows), dim3(128), (size_t)(3 * a.dim + 2 * a.learned_half + 1) * sizeof(float), s, a);
     return hipGetLastError();
 }
 

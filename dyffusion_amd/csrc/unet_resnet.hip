@@ -16,6 +16,7 @@ namespace dyf {
 struct RBlockW {  // ResnetBlock
     int cin = 0, cout = 0;
     bool has_res = false;
+    bool single = false;  // double_conv_layer=False: no second Block (unet.py:94)
     int film_off = 0;
     el16_t *w1 = nullptr, *w2 = nullptr, *wr = nullptr;
     float *b1 = nullptr, *b2 = nullptr, *br = nullptr;
@@ -151,6 +152,9 @@ std::string rn_configure(dyf_engine* e, Net& n) {
     if (c.n_mults < 1 || c.n_mults > 6) return "dim_mults must have 1..6 entries";
     if (c.upsample_h != 0 || c.upsample_w != 0) return "unet.Unet with an outer resampler is not implemented";
     if (c.groups < 1) return "resnet_block_groups must be positive";
+    if (c.learned_sinusoidal_dim < 0 || c.learned_sinusoidal_dim % 2 != 0 || c.learned_sinusoidal_dim > 256)
+        return "learned_sinusoidal_dim must be even and <= 256";
+    const bool keep = c.keep_spatial_dims != 0;
     if (c.init_kernel_size < 1 || c.init_kernel_size > 9 || c.init_padding * 2 + 1 != c.init_kernel_size)
         return "init_conv must be a 'same' convolution with an odd kernel <= 9";
     RNet* r = new RNet();
@@ -166,7 +170,7 @@ std::string rn_configure(dyf_engine* e, Net& n) {
     for (int l = 0; l < r->nlev; ++l) {
         r->lev_h[l] = h;
         r->lev_w[l] = w;
-        if (l < r->nlev - 1) {
+        if (l < r->nlev - 1 && !keep) {
             if (h % 2 || w % 2) return "grid must be divisible by 2^(levels-1) (unet.py down/up sampling)";
             h /= 2;
             w /= 2;
@@ -176,7 +180,7 @@ std::string rn_configure(dyf_engine* e, Net& n) {
     int off = 0;
     auto add_block = [&](int cin, int cout) {
         RBlockW b;
-        b.cin = cin; b.cout = cout; b.has_res = cin != cout; b.film_off = off;
+        b.cin = cin; b.cout = cout; b.has_res = cin != cout; b.film_off = off; b.single = c.single_conv_layer != 0;
         off += cout;
         r->blocks.push_back(b);
     };
@@ -196,12 +200,12 @@ std::string rn_configure(dyf_engine* e, Net& n) {
     for (int l = 0; l < r->nlev; ++l) {
         SampW s;
         s.cin = r->dims[l]; s.cout = r->dims[l + 1];
-        if (l < r->nlev - 1) { s.k = 4; s.stride = 2; s.pad = 1; } else { s.k = 3; s.stride = 1; s.pad = 1; }
+        if (l < r->nlev - 1 && !keep) { s.k = 4; s.stride = 2; s.pad = 1; } else { s.k = 3; s.stride = 1; s.pad = 1; }
         r->downs.push_back(s);
     }
     for (int l = r->nlev - 1; l >= 0; --l) {
         SampW s;
-        s.cin = r->dims[l + 1]; s.cout = r->dims[l]; s.k = 3; s.stride = 1; s.pad = 1; s.nearest_up = l > 0;
+        s.cin = r->dims[l + 1]; s.cout = r->dims[l]; s.k = 3; s.stride = 1; s.pad = 1; s.nearest_up = l > 0 && !keep;
         r->ups.push_back(s);
     }
     // ---- 2*MAC of conv / matmul layers per sample (torch flop counter convention)
@@ -210,7 +214,7 @@ std::string rn_configure(dyf_engine* e, Net& n) {
     f += 2.0 * e->cfg.height * e->cfg.width * (double)n.cin_total * c.dim * ks * ks;
     auto blk_f = [&](const RBlockW& b, int hh, int ww) {
         double px = (double)hh * ww;
-        return 2.0 * px * b.cout * (9.0 * b.cin + 9.0 * b.cout + (b.has_res ? b.cin : 0));
+        return 2.0 * px * b.cout * (9.0 * b.cin + (b.single ? 0.0 : 9.0 * b.cout) + (b.has_res ? b.cin : 0));
     };
     auto attn_f = [&](const AttnW& a, int hh, int ww) {
         double px = (double)hh * ww;
@@ -223,7 +227,7 @@ std::string rn_configure(dyf_engine* e, Net& n) {
         f += blk_f(r->blocks[bi++], r->lev_h[l], r->lev_w[l]) + blk_f(r->blocks[bi++], r->lev_h[l], r->lev_w[l]);
         f += attn_f(r->attns[ai++], r->lev_h[l], r->lev_w[l]);
         const SampW& s = r->downs[l];
-        const int oh = l < r->nlev - 1 ? r->lev_h[l] / 2 : r->lev_h[l], ow = l < r->nlev - 1 ? r->lev_w[l] / 2 : r->lev_w[l];
+        const int oh = s.stride == 2 ? r->lev_h[l] / 2 : r->lev_h[l], ow = s.stride == 2 ? r->lev_w[l] / 2 : r->lev_w[l];
         f += 2.0 * oh * ow * (double)s.cout * s.cin * s.k * s.k;
     }
     const int mh = r->lev_h[r->nlev - 1], mw = r->lev_w[r->nlev - 1];
@@ -248,7 +252,7 @@ std::string rn_configure(dyf_engine* e, Net& n) {
     }
     r->buf_elems = per_sample * (size_t)e->cfg.max_batch;
     n.n_drop_sites = 0;
-    for (size_t i = 0; i < r->blocks.size(); ++i) n.n_drop_sites += (c.block_dropout1 > 0) + (c.dropout > 0);
+    for (size_t i = 0; i < r->blocks.size(); ++i) n.n_drop_sites += (c.block_dropout1 > 0) + (c.dropout > 0 && !c.single_conv_layer);
     if (c.attn_dropout > 0) n.n_drop_sites += (int)r->attns.size();
     if (c.input_dropout > 0) n.n_drop_sites += 2;  // dropout_input_for_residual, dropout_input (unet.py:276-277)
     return "";
@@ -325,8 +329,13 @@ dyf_status rn_load_weights(dyf_engine* e, Net& n, std::map<std::string, TensorVi
     } while (0)
     const int64_t d = c.dim, td = n.tdim;
     if (c.with_time_emb) {
-        NEED(w1, "time_emb_mlp.1.weight", td, d);
+        const int64_t tfeat = c.learned_sinusoidal_dim > 0 ? c.learned_sinusoidal_dim + 1 : d;
+        NEED(w1, "time_emb_mlp.1.weight", td, tfeat);
         NEED(b1, "time_emb_mlp.1.bias", td);
+        if (c.learned_sinusoidal_dim > 0) {
+            NEED(lw, "time_emb_mlp.0.weights", (int64_t)c.learned_sinusoidal_dim / 2);
+            UP(n.t_learned, vec(lw));
+        }
         NEED(w2, "time_emb_mlp.3.weight", td, td);
         NEED(b2, "time_emb_mlp.3.bias", td);
         UP(n.t_w1, vec(w1)); UP(n.t_b1, vec(b1)); UP(n.t_w2, vec(w2)); UP(n.t_b2, vec(b2));
@@ -375,18 +384,25 @@ dyf_status rn_load_weights(dyf_engine* e, Net& n, std::map<std::string, TensorVi
         NEED(b1, P + ".block1.proj.bias", (int64_t)b.cout);
         NEED(g1, P + ".block1.norm.weight", (int64_t)b.cout);
         NEED(e1, P + ".block1.norm.bias", (int64_t)b.cout);
-        NEED(w2, P + ".block2.proj.weight", (int64_t)b.cout, (int64_t)b.cout, 3, 3);
-        NEED(b2, P + ".block2.proj.bias", (int64_t)b.cout);
-        NEED(g2, P + ".block2.norm.weight", (int64_t)b.cout);
-        NEED(e2, P + ".block2.norm.bias", (int64_t)b.cout);
+        const TensorView *w2 = nullptr, *b2 = nullptr, *g2 = nullptr, *e2 = nullptr;
+        if (!b.single) {
+            w2 = get(P + ".block2.proj.weight", std::vector<int64_t>{(int64_t)b.cout, (int64_t)b.cout, 3, 3});
+            b2 = get(P + ".block2.proj.bias", std::vector<int64_t>{(int64_t)b.cout});
+            g2 = get(P + ".block2.norm.weight", std::vector<int64_t>{(int64_t)b.cout});
+            e2 = get(P + ".block2.norm.bias", std::vector<int64_t>{(int64_t)b.cout});
+            if (!w2 || !b2 || !g2 || !e2) return fail(e, DYF_ERR_INVALID_ARGUMENT, missing);
+        }
 #define UPW(dst, hostvec, CO, TAPS, CI)                                                         \
     do {                                                                                       \
         dyf_status _s = upload_conv_weights(e, &(dst), (hostvec), (CO), (TAPS), (CI));         \
         if (_s != DYF_OK) return _s;                                                           \
     } while (0)
         UPW(b.w1, pack_conv(standardize(w1->data, b.cout, b.cin * 9).data(), b.cout, b.cin, 3), b.cout, 9, b.cin);
-        UPW(b.w2, pack_conv(standardize(w2->data, b.cout, b.cout * 9).data(), b.cout, b.cout, 3), b.cout, 9, b.cout);
-        UP(b.b1, vec(b1)); UP(b.b2, vec(b2)); UP(b.g1, vec(g1)); UP(b.be1, vec(e1)); UP(b.g2, vec(g2)); UP(b.be2, vec(e2));
+        UP(b.b1, vec(b1)); UP(b.g1, vec(g1)); UP(b.be1, vec(e1));
+        if (!b.single) {
+            UPW(b.w2, pack_conv(standardize(w2->data, b.cout, b.cout * 9).data(), b.cout, b.cout, 3), b.cout, 9, b.cout);
+            UP(b.b2, vec(b2)); UP(b.g2, vec(g2)); UP(b.be2, vec(e2));
+        }
         if (b.has_res) {
             NEED(wr, P + ".residual_conv.weight", (int64_t)b.cout, (int64_t)b.cin, 1, 1);
             NEED(br, P + ".residual_conv.bias", (int64_t)b.cout);
@@ -481,6 +497,19 @@ dyf_status rn_forward(dyf_engine* e, int which, const Source* srcs, int nsrc, in
         if (film) { g.film_a = o.coef_a + b.film_off; g.film_c = o.coef_c + b.film_off; g.film_stride = o.coef_stride; }
         g.act = ACT_SILU; g.drop = dc.next(c.block_dropout1); g.residual = nullptr; g.out = t1; g.stats = r->gn_stats;
         if (slots1 > 0) { g.part = r->gn_part; g.part_slots = slots1; }
+        if (b.single) {  // double_conv_layer=False: h = block1(x); return h + residual_conv(x)
+            el16_t* tr = nullptr;
+            g.residual = a0;
+            if (b.has_res) {
+                tr = pool.get();
+                TRY(rconv(e, a0, c_a0, a1, c_a1, nb, hh, ww, 1, 1, 0, b.cout, b.wr, r->ones, b.br, 0, ACT_NONE, DropSpec{}, nullptr, tr, st));
+                g.residual = tr;
+            }
+            HIP_TRY(e, launch_gn_act(g, st));
+            if (tr) pool.put(tr);
+            *out = t1;
+            return DYF_OK;
+        }
         {
             ProfScope prof(e, e->prof_layer == DYF_PROF_RESNET_BASE + DYF_PROF_RN_GN_L0 && hh == H && b.cout == c.dim, nb, st);
             HIP_TRY(e, launch_gn_act(g, st));

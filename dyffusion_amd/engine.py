@@ -38,7 +38,8 @@ def net_config(*, in_channels: int, cond_channels: int, out_channels: int, dim: 
 def resnet_net_config(*, in_channels: int, cond_channels: int, out_channels: int, dim: int, dim_mults=(1, 2, 4),
                       with_time_emb: bool = True, block_dropout: float = 0.0, block_dropout1: float = 0.0,
                       attn_dropout: float = 0.0, input_dropout: float = 0.0, groups: int = 8, init_kernel_size: int = 7,
-                      init_padding: int = 3) -> L.NetConfig:
+                      init_padding: int = 3, keep_spatial_dims: bool = False, double_conv_layer: bool = True,
+                      learned_sinusoidal_dim: int = 0) -> L.NetConfig:
     """dyf_net_config for src.models.unet.Unet (no outer resampling)."""
     cfg = L.NetConfig()
     cfg.arch, cfg.in_channels, cfg.cond_channels, cfg.out_channels = L.ARCH_UNET_RESNET, in_channels, cond_channels, out_channels
@@ -49,6 +50,8 @@ def resnet_net_config(*, in_channels: int, cond_channels: int, out_channels: int
         cfg.dim_mults[i] = int(m)
     cfg.block_dropout1, cfg.attn_dropout, cfg.groups = float(block_dropout1), float(attn_dropout), int(groups)
     cfg.init_kernel_size, cfg.init_padding = int(init_kernel_size), int(init_padding)
+    cfg.keep_spatial_dims, cfg.single_conv_layer = int(bool(keep_spatial_dims)), int(not double_conv_layer)
+    cfg.learned_sinusoidal_dim = int(learned_sinusoidal_dim)
     return cfg
 
 

@@ -18,11 +18,11 @@ from .unet_simple import _AttrDict
 HEADS, DIM_HEAD = 4, 32
 
 
-def _resnet_block(cin: int, cout: int, time_dim: Optional[int], groups: int) -> nn.Module:
-    """Names of ResnetBlock (unet.py:79-98): mlp.1, block{1,2}.{proj,norm}, residual_conv."""
+def _resnet_block(cin: int, cout: int, time_dim: Optional[int], groups: int, double: bool = True) -> nn.Module:
+    """Names of ResnetBlock (unet.py:79-98): mlp.1, block{1,2}.{proj,norm}, residual_conv (block2 = Identity without double_conv_layer)."""
     blk = nn.Module()
     blk.mlp = nn.Sequential(nn.SiLU(), nn.Linear(time_dim, cout * 2)) if time_dim is not None else None
-    for i, ci in ((1, cin), (2, cout)):
+    for i, ci in ((1, cin), (2, cout)) if double else ((1, cin),):
         b = nn.Module()
         b.proj = nn.Conv2d(ci, cout, 3, padding=1)
         b.norm = nn.GroupNorm(groups, cout)
@@ -64,10 +64,11 @@ class Unet(nn.Module):
                  spatial_shape: Sequence[int] = None, loss_function: str = "mean_squared_error", datamodule_config=None,
                  name: str = "", verbose: bool = True):
         super().__init__()
-        unsupported = dict(init_dim=init_dim not in (None, dim), double_conv_layer=not double_conv_layer,
-                           learned_variance=learned_variance, learned_sinusoidal_cond=learned_sinusoidal_cond,
+        # (outer_sample_mode / upsample_dims: the reference's own constructor raises AttributeError for them -- unet.py:155 reads
+        # self.outer_sample_mode, which is never set -- so there is no behaviour to reproduce)
+        unsupported = dict(init_dim=init_dim not in (None, dim), learned_variance=learned_variance,
                            outer_sample_mode=outer_sample_mode is not None, upsample_dims=upsample_dims is not None,
-                           keep_spatial_dims=keep_spatial_dims, init_stride=init_stride != 1)
+                           init_stride=init_stride != 1)
         bad = [k for k, v in unsupported.items() if v]
         if bad:
             raise NotImplementedError(f"the HIP engine implements the shipped Unet settings only; unsupported: {bad}")
@@ -77,7 +78,9 @@ class Unet(nn.Module):
                                  init_padding=init_padding, num_input_channels=num_input_channels,
                                  num_output_channels=num_output_channels, num_conditional_channels=num_conditional_channels,
                                  spatial_shape=spatial_shape, outer_sample_mode=None, upsample_dims=None,
-                                 loss_function=loss_function)
+                                 loss_function=loss_function, keep_spatial_dims=bool(keep_spatial_dims),
+                                 double_conv_layer=bool(double_conv_layer), learned_sinusoidal_cond=bool(learned_sinusoidal_cond),
+                                 learned_sinusoidal_dim=int(learned_sinusoidal_dim))
         self.num_input_channels = num_input_channels
         self.num_conditional_channels = num_conditional_channels
         cin = num_input_channels + num_conditional_channels
@@ -86,24 +89,31 @@ class Unet(nn.Module):
         self.time_dim = 2 * dim if with_time_emb else None
         g, td = resnet_block_groups, self.time_dim
         self.init_conv = nn.Conv2d(cin, dim, init_kernel_size, padding=init_padding)
-        self.time_emb_mlp = (nn.Sequential(nn.Identity(), nn.Linear(dim, td), nn.GELU(), nn.Linear(td, td))
-                             if with_time_emb else None)
+        if with_time_emb and learned_sinusoidal_cond:  # misc.py:35-59: a `weights` parameter (dim / 2 frequencies), dim + 1 features
+            assert learned_sinusoidal_dim % 2 == 0
+            emb = nn.Module()
+            emb.weights = nn.Parameter(torch.randn(learned_sinusoidal_dim // 2))
+            self.time_emb_mlp = nn.Sequential(emb, nn.Linear(learned_sinusoidal_dim + 1, td), nn.GELU(), nn.Linear(td, td))
+        else:
+            self.time_emb_mlp = (nn.Sequential(nn.Identity(), nn.Linear(dim, td), nn.GELU(), nn.Linear(td, td))
+                                 if with_time_emb else None)
         dims = [dim] + [dim * m for m in dim_mults]
         in_out = list(zip(dims[:-1], dims[1:]))
         self.downs, self.ups = nn.ModuleList(), nn.ModuleList()
+        dbl = bool(double_conv_layer)
         for i, (a, b) in enumerate(in_out):
-            last = i == len(in_out) - 1
+            last = i == len(in_out) - 1 or keep_spatial_dims
             down = nn.Conv2d(a, b, 3, padding=1) if last else nn.Conv2d(a, b, 4, 2, 1)
-            self.downs.append(nn.ModuleList([_resnet_block(a, a, td, g), _resnet_block(a, a, td, g), _attention(a, True), down]))
+            self.downs.append(nn.ModuleList([_resnet_block(a, a, td, g, dbl), _resnet_block(a, a, td, g, dbl), _attention(a, True), down]))
         mid = dims[-1]
-        self.mid_block1 = _resnet_block(mid, mid, td, g)
+        self.mid_block1 = _resnet_block(mid, mid, td, g, dbl)
         self.mid_attn = _attention(mid, False)
-        self.mid_block2 = _resnet_block(mid, mid, td, g)
+        self.mid_block2 = _resnet_block(mid, mid, td, g, dbl)
         for i, (a, b) in enumerate(reversed(in_out)):
-            last = i == len(in_out) - 1
+            last = i == len(in_out) - 1 or keep_spatial_dims
             up = nn.Conv2d(b, a, 3, padding=1) if last else nn.Sequential(nn.Identity(), nn.Conv2d(b, a, 3, padding=1))
-            self.ups.append(nn.ModuleList([_resnet_block(b + a, b, td, g), _resnet_block(b + a, b, td, g), _attention(b, True), up]))
-        self.final_res_block = _resnet_block(dim * 2, dim, td, g)
+            self.ups.append(nn.ModuleList([_resnet_block(b + a, b, td, g, dbl), _resnet_block(b + a, b, td, g, dbl), _attention(b, True), up]))
+        self.final_res_block = _resnet_block(dim * 2, dim, td, g, dbl)
         self.final_conv = nn.Conv2d(dim, self.num_output_channels, 1)
         self.requires_grad_(False)
         self.eval()
@@ -120,7 +130,9 @@ class Unet(nn.Module):
                                  with_time_emb=hp.with_time_emb, block_dropout=hp.block_dropout,
                                  block_dropout1=hp.block_dropout1, attn_dropout=hp.attn_dropout,
                                  input_dropout=hp.input_dropout, groups=hp.resnet_block_groups,
-                                 init_kernel_size=hp.init_kernel_size, init_padding=hp.init_padding)
+                                 init_kernel_size=hp.init_kernel_size, init_padding=hp.init_padding,
+                                 keep_spatial_dims=hp.keep_spatial_dims, double_conv_layer=hp.double_conv_layer,
+                                 learned_sinusoidal_dim=hp.learned_sinusoidal_dim if hp.learned_sinusoidal_cond else 0)
 
     @property
     def has_dropout(self) -> bool:

@@ -76,6 +76,11 @@ typedef struct dyf_net_config {
     int32_t init_padding;     /* 3 */
     int32_t outer_nearest;    /* unet_simple outer_sample_mode: 0 "bilinear", 1 "nearest" (upsampler + final F.interpolate,
                                * unet_simple.py:103,195) */
+    /* ---- unet.Unet options no shipped config sets (unet.py:127-135); 0 = the shipped default ---- */
+    int32_t keep_spatial_dims;      /* 1: no down / up sampling, plain 3x3 convs between the levels (unet.py:190,214) */
+    int32_t single_conv_layer;      /* 1: double_conv_layer=False, a ResnetBlock's second Block is nn.Identity (unet.py:94) */
+    int32_t learned_sinusoidal_dim; /* > 0: learned_sinusoidal_cond=True with this (even) dim: time features
+                                     * [t, sin(2 pi t w), cos(2 pi t w)] with the parameter time_emb_mlp.0.weights (misc.py:35-59) */
 } dyf_net_config;
 
 typedef enum dyf_dtype_id { DYF_DTYPE_BF16 = 0, DYF_DTYPE_F16 = 1 } dyf_dtype_id;

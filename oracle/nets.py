@@ -88,8 +88,14 @@ def sinusoidal_features(t: Tensor, dim: int) -> Tensor:
 
 
 def time_embedding(P: Dict[str, Tensor], prefix: str, t: Tensor, dim: int) -> Tensor:
-    """misc.py:54-67 (non-learned branch): sinusoid(dim) -> Linear -> GELU -> Linear."""
-    e = sinusoidal_features(t, dim)
+    """misc.py:54-67: sinusoid(dim) -> Linear -> GELU -> Linear; with learned_sinusoidal_cond (a `{prefix}.0.weights` parameter,
+    misc.py:35-51) the features are [t, sin(2 pi t w), cos(2 pi t w)]."""
+    if f"{prefix}.0.weights" in P:
+        tt = t.float()[:, None]
+        fr = tt * P[f"{prefix}.0.weights"][None, :] * 2 * math.pi
+        e = torch.cat([tt, fr.sin(), fr.cos()], dim=-1)
+    else:
+        e = sinusoidal_features(t, dim)
     e = F.linear(e, P[f"{prefix}.1.weight"], P[f"{prefix}.1.bias"])
     e = F.gelu(e)
     return F.linear(e, P[f"{prefix}.3.weight"], P[f"{prefix}.3.bias"])
@@ -318,9 +324,10 @@ def _resnet_block(P, pre, x, temb, groups, p1, p2, dropout):
         scale, shift = film(P, f"{pre}.mlp", temb)
         h = h * (scale + 1) + shift
     h = dropout.apply(F.silu(h), p1)
-    h = _ws_conv3x3(P, f"{pre}.block2.proj", h)
-    h = F.group_norm(h, groups, P[f"{pre}.block2.norm.weight"], P[f"{pre}.block2.norm.bias"], eps=1e-5)
-    h = dropout.apply(F.silu(h), p2)
+    if f"{pre}.block2.proj.weight" in P:  # double_conv_layer=False: block2 = nn.Identity() (unet.py:94)
+        h = _ws_conv3x3(P, f"{pre}.block2.proj", h)
+        h = F.group_norm(h, groups, P[f"{pre}.block2.norm.weight"], P[f"{pre}.block2.norm.bias"], eps=1e-5)
+        h = dropout.apply(F.silu(h), p2)
     if f"{pre}.residual_conv.weight" in P:
         x = F.conv2d(x, P[f"{pre}.residual_conv.weight"], P[f"{pre}.residual_conv.bias"])
     return h + x
@@ -375,9 +382,11 @@ def resnet_unet_forward(P: Dict[str, Tensor], cfg: dict, x: Tensor, time: Option
     groups = cfg.get("resnet_block_groups", 8)
     p2, p1, pa = cfg.get("block_dropout", 0.0), cfg.get("block_dropout1", 0.0), cfg.get("attn_dropout", 0.0)
     heads, dh = 4, 32
-    assert cfg.get("upsample_dims") is None
+    keep = bool(cfg.get("keep_spatial_dims", False))  # unet.py:190,214: no down / up sampling, plain 3x3 convs instead
     if condition is not None:
         x = torch.cat([condition, x], dim=1)
+    # (no outer resampler: the reference's Unet cannot be constructed with upsample_dims -- unet.py:155 reads an attribute that is never set)
+    assert cfg.get("upsample_dims") is None
     x = F.conv2d(x, P["init_conv.weight"], P["init_conv.bias"], padding=cfg.get("init_padding", 3))
     # unet.py:276-277: two independent Dropouts on init_conv's output, the copy kept for the final residual first
     p_in = cfg.get("input_dropout", 0.0)
@@ -393,7 +402,7 @@ def resnet_unet_forward(P: Dict[str, Tensor], cfg: dict, x: Tensor, time: Option
         x = _resnet_block(P, f"{pre}.1", x, temb, groups, p1, p2, dropout)
         x = _linear_attention(P, f"{pre}.2", x, heads, dh, pa, dropout)
         skips.append(x)
-        if li < nlev - 1:
+        if li < nlev - 1 and not keep:
             x = F.conv2d(x, P[f"{pre}.3.weight"], P[f"{pre}.3.bias"], stride=2, padding=1)   # Downsample: k4 s2 p1
         else:
             x = F.conv2d(x, P[f"{pre}.3.weight"], P[f"{pre}.3.bias"], padding=1)
@@ -405,7 +414,7 @@ def resnet_unet_forward(P: Dict[str, Tensor], cfg: dict, x: Tensor, time: Option
         x = _resnet_block(P, f"{pre}.0", torch.cat([x, skips.pop()], dim=1), temb, groups, p1, p2, dropout)
         x = _resnet_block(P, f"{pre}.1", torch.cat([x, skips.pop()], dim=1), temb, groups, p1, p2, dropout)
         x = _linear_attention(P, f"{pre}.2", x, heads, dh, pa, dropout)
-        if li < nlev - 1:
+        if li < nlev - 1 and not keep:
             x = F.interpolate(x, scale_factor=2, mode="nearest")
             x = F.conv2d(x, P[f"{pre}.3.1.weight"], P[f"{pre}.3.1.bias"], padding=1)
         else:

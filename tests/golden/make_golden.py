@@ -212,6 +212,15 @@ def gen_resnet_unets():
         # input_dropout > 0 (unet.py:162-163, 276-277): dropout_input_for_residual and dropout_input on init_conv's output
         ("net_unet_resnet_c", dict(dim=8, mults=(1, 2), n_in=2, n_cond=1, n_out=1, hw=(12, 16), nb=2,
                                    bd=0.3, bd1=0.1, ad=0.2, ind=0.15)),
+        # options no shipped config sets (unet.py:127-135): keep_spatial_dims, double_conv_layer=False, learned_sinusoidal_cond
+        ("net_unet_resnet_d", dict(dim=8, mults=(1, 2, 2), n_in=2, n_cond=1, n_out=1, hw=(10, 14), nb=2, bd=0.3, bd1=0.1, ad=0.2,
+                                   extra=dict(keep_spatial_dims=True))),
+        ("net_unet_resnet_e", dict(dim=8, mults=(1, 2), n_in=2, n_cond=0, n_out=2, hw=(12, 12), nb=2, bd=0.3, bd1=0.2, ad=0.1,
+                                   extra=dict(double_conv_layer=False))),
+        # (the outer resampler of unet.Unet cannot be pinned: the reference constructor raises AttributeError -- unet.py:155 reads
+        # self.outer_sample_mode, which is never set -- so upsample_dims / outer_sample_mode stay unsupported here as well)
+        ("net_unet_resnet_g", dict(dim=8, mults=(1, 2), n_in=2, n_cond=1, n_out=1, hw=(12, 16), nb=2, bd=0.2, bd1=0.0, ad=0.0,
+                                   extra=dict(learned_sinusoidal_cond=True, learned_sinusoidal_dim=16))),
     ]
     only = os.environ.get("DYF_GOLDEN_ONLY")
     for name, sp in specs:
@@ -220,10 +229,12 @@ def gen_resnet_unets():
         net = Unet(dim=sp["dim"], dim_mults=sp["mults"], with_time_emb=True, block_dropout=sp["bd"],
                    block_dropout1=sp["bd1"], attn_dropout=sp["ad"], input_dropout=sp.get("ind", 0.0), num_input_channels=sp["n_in"],
                    num_output_channels=sp["n_out"], num_conditional_channels=sp["n_cond"], spatial_shape=sp["hw"],
-                   loss_function="mse", verbose=False).eval()
+                   loss_function="mse", verbose=False, **sp.get("extra", {})).eval()
         shapes = {k: tuple(v.shape) for k, v in net.state_dict().items()}
         st = oinit.seeded_state(shapes, seed=13)
         for k in st:  # LayerNorm gains `g` are 4-D (1,C,1,1): treat as gains, not as conv weights
+            if k.endswith(".weights"):  # LearnedSinusoidalPosEmb frequencies: randn like the reference's init
+                st[k] = torch.randn(shapes[k], generator=torch.Generator().manual_seed(5))
             if k.endswith(".norm.g"):
                 st[k] = 1.0 + 0.1 * torch.randn(shapes[k], generator=torch.Generator().manual_seed(hash(k) % 997))
         net.load_state_dict(st, strict=True)
@@ -242,7 +253,8 @@ def gen_resnet_unets():
                     dropout_seed=np.int64(78),
                     cfg=json.dumps(dict(dim=sp["dim"], dim_mults=list(sp["mults"]), with_time_emb=True,
                                         block_dropout=sp["bd"], block_dropout1=sp["bd1"], attn_dropout=sp["ad"],
-                                        resnet_block_groups=8, input_dropout=sp.get("ind", 0.0), upsample_dims=None)))
+                                        resnet_block_groups=8, input_dropout=sp.get("ind", 0.0),
+                                        **{"upsample_dims": None, **sp.get("extra", {})})))
         if c is not None:
             arrs["c"] = c.numpy()
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **arrs)

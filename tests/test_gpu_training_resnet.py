@@ -244,3 +244,42 @@ def test_resnet_sampling_forward_with_input_dropout_draws_the_same_streams():
     err = rel_rms(y, want)
     print(f"ResNet-UNet sampling forward, input_dropout on, engine streams vs host masks: rel-rms {err:.3e} (dropout effect {rel_rms(off, want):.2f})")
     assert err <= 4e-3 and rel_rms(off, want) > 0.05
+
+
+@pytest.mark.parametrize("name", ["net_unet_resnet_d", "net_unet_resnet_e", "net_unet_resnet_g"],
+                         ids=["keep_spatial_dims", "single_conv_layer", "learned_sinusoidal_cond"])
+def test_resnet_training_step_with_unet_options_matches_autograd_of_the_oracle(name):
+    """The unet.Unet options no shipped config sets (unet.py:127-135), in TRAIN mode on the networks of the reference goldens:
+    keep_spatial_dims (plain 3x3 convs between the levels), double_conv_layer=False (block2 = Identity), learned_sinusoidal_cond
+    (the frequencies `time_emb_mlp.0.weights` are a parameter and get a gradient).  Stage-1 `get_loss` + backward vs torch.autograd
+    over the oracle with the engine's masks."""
+    from tests.test_gpu_unet_resnet import mirror
+    z = load_npz(name + ".npz")
+    P, cfg = split_state(z, "P"), json.loads(str(z["cfg"]))
+    x, t = torch.from_numpy(z["x"]), torch.from_numpy(z["t"])
+    c = torch.from_numpy(z["c"]) if "c" in z else None
+    n_out = z["y_eval"].shape[1]
+    net = mirror(P, cfg, x.shape[1], 0 if c is None else c.shape[1], n_out)
+    net.train()
+    y = torch.randn(x.shape[0], n_out, *x.shape[-2:], generator=torch.Generator().manual_seed(21))
+    seed = 90210
+    net._own_engine(x.shape[0], x.shape[-2:]).seed(seed)
+    loss = net.get_loss(x.to(DEV), y.to(DEV), condition=None if c is None else c.to(DEV), time=t.to(DEV))
+    loss.backward()
+    nlev = len(cfg["dim_mults"])
+    shrink = 0 if cfg.get("keep_spatial_dims") else nlev - 1
+    drop = R.ResnetEngineDropout(seed, (x.shape[-2] >> shrink) * (x.shape[-1] >> shrink))
+    drop.begin_forward()
+    Pg = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    want = ((nets.resnet_unet_forward(Pg, cfg, x, t, c, dropout=drop) - y) ** 2).mean()
+    want.backward()
+    assert float(loss) == pytest.approx(float(want), rel=1e-4)
+    gn = float(torch.cat([v.grad.reshape(-1) for v in Pg.values()]).norm())
+    got = dict(net.named_parameters())
+    assert sorted(got) == sorted(Pg)
+    worst = max(float((p.grad.cpu() - Pg[k].grad).norm()) for k, p in got.items()) / gn
+    print(f"{name}: loss {float(loss):.6f}, worst gradient error / grad norm {worst:.2e}")
+    assert worst <= 1e-3
+    if "time_emb_mlp.0.weights" in Pg:
+        gw, ww = got["time_emb_mlp.0.weights"].grad.cpu(), Pg["time_emb_mlp.0.weights"].grad
+        assert float((gw - ww).norm()) <= 1e-3 * float(ww.norm()) + 1e-9 and float(ww.norm()) > 0

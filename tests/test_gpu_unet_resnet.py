@@ -39,6 +39,8 @@ def mirror(P, cfg, n_in, n_cond, n_out, dtype=None):
     net = D.Unet(dim=cfg["dim"], dim_mults=cfg["dim_mults"], with_time_emb=cfg.get("with_time_emb", True),
                  block_dropout=cfg.get("block_dropout", 0.0), block_dropout1=cfg.get("block_dropout1", 0.0),
                  attn_dropout=cfg.get("attn_dropout", 0.0), input_dropout=cfg.get("input_dropout", 0.0), num_input_channels=n_in,
+                 keep_spatial_dims=cfg.get("keep_spatial_dims", False), double_conv_layer=cfg.get("double_conv_layer", True),
+                 learned_sinusoidal_cond=cfg.get("learned_sinusoidal_cond", False), learned_sinusoidal_dim=cfg.get("learned_sinusoidal_dim", 16),
                  num_output_channels=n_out,
                  num_conditional_channels=n_cond)
     if dtype is not None:
@@ -47,16 +49,16 @@ def mirror(P, cfg, n_in, n_cond, n_out, dtype=None):
     return net
 
 
-def engine_masks(masks, nlev, n_input=0):
-    """oracle keep-masks -> engine layout: activations NCHW -> NHWC; the attention-probability mask (b,h,n,n) of
-    mid_attn is passed unchanged.  Site order (all p > 0): per level [block, block, block, block, linattn], then
-    mid_block1 (2), mid_attn (1), ..."""
-    attn_idx = n_input + 5 * nlev + 2  # n_input = 2 with input_dropout > 0: dropout_input_for_residual, dropout_input come first
-    return [(m if i == attn_idx else m.permute(0, 2, 3, 1)).contiguous().to(DEV) for i, m in enumerate(masks)]
+def engine_masks(masks, nlev=None, n_input=0):
+    """oracle keep-masks -> engine layout: activations NCHW -> NHWC; the attention-probability mask (b, heads = 4, n, n) of
+    mid_attn is passed unchanged (every activation has >= 8 channels, so the head count identifies it).  Site order = execution
+    order over the layers with p > 0."""
+    return [(m if (m.shape[1] == 4 and m.shape[2] == m.shape[3]) else m.permute(0, 2, 3, 1)).contiguous().to(DEV) for m in masks]
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("name", ["net_unet_resnet_a", "net_unet_resnet_b", "net_unet_resnet_c"])
+@pytest.mark.parametrize("name", ["net_unet_resnet_a", "net_unet_resnet_b", "net_unet_resnet_c", "net_unet_resnet_d", "net_unet_resnet_e",
+                                  "net_unet_resnet_g"])
 def test_small_resnet_unets_match_reference_goldens(name, dtype):
     z = load_npz(name + ".npz")
     P, cfg = split_state(z, "P"), json.loads(str(z["cfg"]))

@@ -77,7 +77,8 @@ def test_fullsize_forwards_match_reference_checksums():
         assert np.allclose(got, meta[key]["probes"], atol=2e-5)
 
 
-@pytest.mark.parametrize("name", ["net_unet_resnet_a", "net_unet_resnet_b", "net_unet_resnet_c"])
+@pytest.mark.parametrize("name", ["net_unet_resnet_a", "net_unet_resnet_b", "net_unet_resnet_c", "net_unet_resnet_d", "net_unet_resnet_e",
+                                  "net_unet_resnet_g"])
 def test_resnet_unet_matches_reference(name):
     """src.models.unet.Unet (WS-conv, GroupNorm+SiLU, FiLM, LinearAttention, Attention, channel LayerNorm)."""
     z = load_npz(name + ".npz")
