@@ -77,3 +77,43 @@ def test_generator_statistics():
     # neighbouring elements of one stream (the two halves of a pair word, consecutive pair words)
     for lag in (1, 2, 3, 128):
         assert abs(np.corrcoef(a[lag:].astype(np.float64), a[:-lag].astype(np.float64))[0, 1]) < 0.01
+
+
+def test_joint_structure_the_epilogues_consume():
+    """What a forward actually draws: the SAME pair index (element e of a row) under the 13 site keys of one forward (12 UNetBlocks +
+    dropout_input), under the two consecutive forward indices of a paired interpolator launch, and under neighbouring global rows.
+    All 13 x 2 x 2 streams of one element must be jointly independent: pairwise correlations at sampling-error level, every pair's
+    joint keep rate = (1 - p)^2, and the number of sites that keep an element binomial(13, 1 - p) (mean, variance, and the tails an
+    MFMA tile sees: 32 consecutive elements of 13 sites never all dropped / all kept more often than chance)."""
+    p, n = 0.15, 1 << 16
+    keep = 1.0 - p
+    streams = {}
+    for fwd in (5, 6):
+        for row in (40, 41):
+            for layer in range(13):
+                streams[(fwd, row, layer)] = R.row_mask_nhwc((n,), p, 20260929, fwd, layer, row).astype(np.float64)
+    keys = sorted(streams)
+    M = np.stack([streams[k] for k in keys], 0)
+    assert np.all(np.abs(M.mean(1) - keep) < 5 * np.sqrt(p * keep / n))
+    C = np.corrcoef(M)
+    off = C[~np.eye(len(keys), dtype=bool)]
+    assert np.abs(off).max() < 0.02, np.abs(off).max()  # 52 x 51 pairs, sampling error 1/sqrt(n) = 0.004
+    # joint keep rate of every pair of streams
+    J = (M @ M.T) / n
+    offj = J[~np.eye(len(keys), dtype=bool)]
+    assert np.abs(offj - keep * keep).max() < 6 * np.sqrt(keep * keep * (1 - keep * keep) / n)
+    # the 13 sites of one (forward, row): kept-site count per element is binomial(13, keep)
+    S = np.stack([streams[(5, 40, l)] for l in range(13)], 0).sum(0)
+    assert abs(S.mean() - 13 * keep) < 5 * np.sqrt(13 * p * keep / n)
+    assert abs(S.var() - 13 * p * keep) < 0.05 * 13 * p * keep
+    from math import comb
+    for k in (13, 12, 8):
+        want = comb(13, k) * keep ** k * p ** (13 - k)
+        got = float((S == k).mean())
+        assert abs(got - want) < 5 * np.sqrt(want * (1 - want) / n) + 1e-4, (k, got, want)
+    # lagged cross-correlations between sites (an epilogue walks consecutive pair indices of all sites together)
+    a = streams[(5, 40, 0)]
+    for l in (1, 5, 12):
+        b = streams[(5, 40, l)]
+        for lag in (1, 2, 31, 32):
+            assert abs(np.corrcoef(a[lag:], b[:-lag])[0, 1]) < 0.02
