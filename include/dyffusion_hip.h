@@ -183,6 +183,8 @@ dyf_status dyf_set_row_offset(dyf_engine* engine, uint32_t first_row);
  * at dyf_engine_create from the architecture and max_batch (ResNet-UNet on planes <= 128 x 128, not batch_invariant: 3 groups from
  * 432 000 pixels x rows = 120 rows of 60 x 60, 2 from 230 400 = 64 rows; otherwise 1; environment DYF_ROW_GROUPS overrides).  Must be called before dyf_load_weights.
  * Calls with fewer than 32 rows, with injected masks / noise, and every other entry point run on the engine itself.
+ * Three groups plus the caller's stream fill the 4 hardware queues of a HIP process: with other busy streams or other live engines
+ * in the process two groups are the robust choice.
  * dyf_row_groups returns the number of groups in effect (1 = none). */
 dyf_status dyf_set_row_groups(dyf_engine* engine, int32_t n_groups);
 int32_t dyf_row_groups(const dyf_engine* engine);
