@@ -34,6 +34,11 @@ struct ConvArgs {
     const int16_t* up_cbase;
     const int16_t* up_cidx;  // [2][up_npad]: column of each list entry's output pixel in the COMPACT output tensor
     int up_ntiles, up_npad, up_nvalid0, up_nvalid1;
+    // mixed list tiling of conv_halo_rows_kernel<1, SH> (plan_up_sparse_columns_mixed): up_mix[s] list tiles of shape s per row
+    // block of that shape (32 entries x 4 rows | 16 x 8 | 4 x 32), laid out [32-entry tiles | 16-entry tiles | 4-entry tiles] in
+    // up_cols / up_cidx (up_npad = 32 a + 16 b + 4 c) and up_cbase (a + b + c entries); all zero = uniform 32- (or 16-) slot tiles
+    int up_mix[3];
+    int up_sh_off, up_sh_cb;  // set per launch by launch_conv_halo_rows_up: first list entry / first cbase entry of the launch's shape
     int up_wo_store;         // columns of the compact output tensor [n][ho][up_wo_store][cout]
     // epilogue: v = acc * A[row*coef_stride + co] + C[row*coef_stride + co]; row = sample index (coef_stride may be 0
     // to broadcast one row); conv bias, eval-BatchNorm and FiLM (x*(scale+1)+shift) are all folded into A and C.
@@ -85,6 +90,12 @@ bool plan_up_sparse_columns(const std::vector<uint8_t>& needed, int w, std::vect
 // rows form of the halo kernels (conv_halo_rows.hip): 4 x 32 low-res tiles, one-row MFMA pixel tiles
 int conv_halo_rows_slots();
 int conv_halo_rows_sparse_halo_w();
+int conv_halo_rows_sparse_halo_w_shape(int shape);  // halo width of list-tile shape 0 / 1 / 2 (32 x 4 rows | 16 x 8 | 4 x 32)
+// Mixed list tiling for conv_halo_rows_kernel<1, SH>: the per-phase lists are cut into a 32-entry, b 16-entry and c 4-entry tiles
+// (mix = {a, b, c}) so that no MFMA lane is padding when the lists allow it (52 entries = 3 x 16 + 4); h = low-res rows (the 16- /
+// 4-entry shapes own 8 / 32 rows).  False when a tile does not fit its shape's halo or the rows do not divide.
+bool plan_up_sparse_columns_mixed(const std::vector<uint8_t>& needed, int w, int h, std::vector<int16_t>& cols, std::vector<int16_t>& cbase,
+                                  std::vector<int16_t>& cidx, std::vector<int16_t>& col_map, int mix[3], int& nvalid0, int& nvalid1);
 bool conv_halo_rows_up_supported(const ConvArgs& a);   // in addition to conv_up_halo_supported
 bool conv_halo_rows3_supported(const ConvArgs& a);     // in addition to conv_halo3_supported (h % 8 / w % 16 not needed)
 hipError_t conv_halo_rows_init();

@@ -31,13 +31,22 @@ namespace {
 constexpr int R_TH = 4, R_TW = 32, R_NWAVES = 4;
 constexpr int R_STEP_BYTES = 32768;  // weights of one (tap, chunk) step: 256 columns x 64 k
 
-template <int SP>
+// SH (sparse form only): shape of the 32 list slots of a tile row set.  0: 32 entries x 4 rows (72-pixel halo: up to 26 entries of
+// the NS lists fit).  1: 16 entries x 8 rows (lanes 16..31 own the rows 4..7 of the tile; 48-pixel halo).  2: 4 entries x 32 rows
+// (12-pixel halo).  Shapes 1 and 2 let a 52-entry list be tiled as 3 x 16 + 4 with every lane used (13 instead of 16 MFMA tile
+// units per 32 rows); they keep the column-only swizzle key -- lanes of different row sets that read the same column collide in
+// LDS (2- / 4-way), which the LDS pipe (17 % busy in these kernels) absorbs -- and store straight from the registers.
+template <int SP, int SH = 0>
 struct RowsCfg {
-    static constexpr int W = SP == 1 ? 72 : 34;       // halo width in pixels (SP 1: span of a 32-entry column list)
-    static constexpr int REAL = (R_TH + 2) * W;       // 204 / 432
+    static constexpr int COLS = SP == 1 ? (SH == 1 ? 16 : SH == 2 ? 4 : 32) : 32;  // list entries (columns) per tile row set
+    static constexpr int RSETS = 32 / COLS;                                          // row sets of 4 rows each
+    static constexpr int ROWS = R_TH * RSETS;                                        // tile rows of a workgroup
+    static constexpr int W = SP == 1 ? (SH == 1 ? 48 : SH == 2 ? 12 : 72) : 34;  // halo width in pixels
+    static constexpr int REAL = (ROWS + 2) * W;       // 204 / 432 / 480 / 408
     static constexpr int PIX = (REAL + 7) / 8 * 8;    // padded to whole DMA instructions (8 pixels each)
     static constexpr int BYTES = PIX * 128;           // 26 624 / 55 296
     static constexpr int NBUF = SP == 1 ? 1 : 2;
+    static_assert(SP == 1 || SH == 0, "shapes are a property of the sparse form");
     static constexpr bool PLAIN = SP == 2;
     static constexpr int INSTR = PIX / 8;             // 26 / 54
     static constexpr int PER_WAVE = (INSTR + R_NWAVES - 1) / R_NWAVES;
@@ -52,7 +61,7 @@ struct RowsCfg {
 #endif
     // sparse form: room for HALF a tile row per wave (16 pixels, two passes per row) + the row's compact column indices
 #ifndef HALO_NO_STAGE
-    static constexpr bool STAGE_HALF = SP == 1;
+    static constexpr bool STAGE_HALF = SP == 1 && SH == 0;
 #else
     static constexpr bool STAGE_HALF = false;
 #endif
@@ -67,10 +76,10 @@ constexpr unsigned rows_woff(int g) { return (unsigned)(((g % 3) * 3 + g / 12) *
 
 }  // namespace
 
-template <int SP>
+template <int SP, int SH = 0>
 __global__ __launch_bounds__(256, 2) void conv_halo_rows_kernel(ConvArgs a, int tiles_x, int tiles_per_img, int tiles_m, int tiles_n) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    using H = RowsCfg<SP>;
+    using H = RowsCfg<SP, SH>;
     constexpr int HALO_W = H::W, HALO_REAL = H::REAL, HALO_BYTES = H::BYTES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -87,16 +96,19 @@ __global__ __launch_bounds__(256, 2) void conv_halo_rows_kernel(ConvArgs a, int 
     const int tn = tile % tiles_n, tm = tile / tiles_n;
     const int n_img = tm / tiles_per_img;
     const int t_in = tm - n_img * tiles_per_img;
-    const int ty0 = (t_in / tiles_x) * R_TH;
-    const int lx = t_in % tiles_x;  // column tile: 32 contiguous columns, or 32 entries of the column lists
+    const int ty0 = (t_in / tiles_x) * H::ROWS;
+    const int lx = t_in % tiles_x;  // column tile: 32 contiguous columns, or COLS entries of the column lists
+    // sparse shapes: lane -> (list entry ci of the tile, row set rs); the lane's four tile rows are ty0 + 4 rs + {0..3}
+    const int ci = l31 & (H::COLS - 1), rs = l31 / H::COLS;
     int col, cbase, cstore = 0;
     bool lane_valid = true;
     if (SP == 1) {
-        cbase = a.up_cbase[lx];
-        const int entry = a.up_cols[wpx * a.up_npad + lx * 32 + l31];  // bit 14: padding entry (computed, not stored)
+        cbase = a.up_cbase[a.up_sh_cb + lx];
+        const int li = wpx * a.up_npad + a.up_sh_off + lx * H::COLS + ci;
+        const int entry = a.up_cols[li];  // bit 14: padding entry (computed, not stored)
         col = entry & 0x3FFF;
         lane_valid = (entry & 0x4000) == 0;
-        cstore = a.up_cidx[wpx * a.up_npad + lx * 32 + l31];
+        cstore = a.up_cidx[li];
     } else {
         cbase = lx * R_TW - 1;
         col = lx * R_TW + l31;
@@ -163,12 +175,12 @@ __global__ __launch_bounds__(256, 2) void conv_halo_rows_kernel(ConvArgs a, int 
         // border pixels of the OUTPUT start from the correction sums of up_border_kernel (ring index: top row, bottom row,
         // left column, right column); lane (l31, hi) holds channels nt*32 + 8*g + 4*hi + {0..3} of its pixel
         const bool edge_col = col == 0 || col == gw - 1;
-        if (ty0 == 0 || ty0 + R_TH == gh || __builtin_amdgcn_ballot_w64(edge_col) != 0ull) {
+        if (ty0 == 0 || ty0 + H::ROWS == gh || __builtin_amdgcn_ballot_w64(edge_col) != 0ull) {
             const int ring_len = 2 * a.wo + 2 * (a.ho - 2);
             const int X = 2 * col + wpx;
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                const int Y = 2 * (ty0 + t) + wpy;
+                const int Y = 2 * (ty0 + R_TH * rs + t) + wpy;
                 int ring = -1;
                 if (Y == 0) ring = X;
                 else if (Y == a.ho - 1) ring = a.wo + X;
@@ -189,7 +201,8 @@ __global__ __launch_bounds__(256, 2) void conv_halo_rows_kernel(ConvArgs a, int 
         }
     }
 
-    int cl = col - cbase;  // halo column of this lane's pixel at dx = 0 (>= 1); halo row of tile row t at dy = 0 is t + 1
+    int cl = col - cbase;  // halo column of this lane's pixel at dx = 0 (>= 1); halo row of tile row t at dy = 0 is 4 rs + t + 1
+    const unsigned rs_off = (unsigned)(rs * R_TH * H::ROW_BYTES);  // the lane's row set inside the halo (0 unless a sparse shape)
     const unsigned lds_base = (unsigned)(uintptr_t)LDS_PTR(smem);
     const unsigned w_voff = (unsigned)lane * 16u;
 
@@ -216,7 +229,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_rows_kernel(ConvArgs a, int 
         if (((SN) & 3) == 0) {                                                                               \
             int c = cl + ((SN) >> 2) - 1;                                                                    \
             asm volatile("" : "+v"(c)); /* opaque: keeps the addresses of all shifts from being hoisted */   \
-            ab = Hs + (unsigned)c * 128u;                                                                    \
+            ab = Hs + rs_off + (unsigned)c * 128u;                                                           \
             ax = (unsigned)((hi ^ HKEY(c)) << 4);                                                            \
         }                                                                                                    \
         pa = (ax ^ (unsigned)(((SN) & 3) << 5)) + ab;                                                        \
@@ -314,11 +327,12 @@ __global__ __launch_bounds__(256, 2) void conv_halo_rows_kernel(ConvArgs a, int 
     const uint32_t row0 = (uint32_t)n_img * (uint32_t)(a.ho * a.wo * a.cout);
     const int ch_blk = H::PLAIN ? tn * 256 + wave * 64 : tn * 64;
     const uint32_t ci_base = (uint32_t)((a.coef_div > 1 ? n_img / a.coef_div : n_img) * a.coef_stride + ch_blk + 4 * hi);
+    const int ry0 = ty0 + R_TH * rs;  // first of the lane's four tile rows
     const uint32_t m0 = H::PLAIN ? (uint32_t)((n_img * a.ho + ty0) * a.wo + col)
-                                : (uint32_t)((n_img * a.ho + 2 * ty0 + wpy) * a.wo + 2 * col + wpx);
+                                : (uint32_t)((n_img * a.ho + 2 * ry0 + wpy) * a.wo + 2 * col + wpx);
     const uint32_t o0 = m0 * (uint32_t)a.cout + (uint32_t)ch_blk;
     const uint32_t t_stride = (uint32_t)((H::PLAIN ? 1 : 2) * a.wo * a.cout);
-    const uint32_t store0 = SP == 1 ? (uint32_t)((n_img * a.ho + 2 * ty0 + wpy) * a.up_wo_store + cstore) * (uint32_t)a.cout +
+    const uint32_t store0 = SP == 1 ? (uint32_t)((n_img * a.ho + 2 * ry0 + wpy) * a.up_wo_store + cstore) * (uint32_t)a.cout +
                                           (uint32_t)(tn * 64)
                                     : o0;
     const uint32_t st_stride = SP == 1 ? (uint32_t)(2 * a.up_wo_store * a.cout) : t_stride;
@@ -499,9 +513,17 @@ int conv_halo_rows_sparse_halo_w() { return RowsCfg<1>::W; }
 // conv_up_halo_supported (checked by the caller)
 bool conv_halo_rows_up_supported(const ConvArgs& a) {
     if (a.h % R_TH != 0) return false;
+    if (a.up_cols && (a.up_mix[0] | a.up_mix[1] | a.up_mix[2]) != 0) {  // mixed shapes
+        if (a.up_mix[0] < 0 || a.up_mix[1] < 0 || a.up_mix[2] < 0) return false;
+        if (a.up_mix[1] > 0 && a.h % (R_TH * 2) != 0) return false;
+        if (a.up_mix[2] > 0 && a.h % (R_TH * 8) != 0) return false;
+        return a.up_ntiles == a.up_mix[0] + a.up_mix[1] + a.up_mix[2] && a.up_npad == 32 * a.up_mix[0] + 16 * a.up_mix[1] + 4 * a.up_mix[2];
+    }
     if (a.up_cols) return a.up_ntiles >= 1 && a.up_npad == a.up_ntiles * R_TW;
     return a.w % R_TW == 0;
 }
+
+int conv_halo_rows_sparse_halo_w_shape(int shape) { return shape == 1 ? RowsCfg<1, 1>::W : shape == 2 ? RowsCfg<1, 2>::W : RowsCfg<1, 0>::W; }
 
 bool conv_halo_rows3_supported(const ConvArgs& a) { return a.h % R_TH == 0 && a.w % R_TW == 0; }
 
@@ -514,21 +536,52 @@ hipError_t conv_halo_rows_init() {
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)conv_halo_rows_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 RowsCfg<2>::LDS_TOTAL);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)conv_halo_rows_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (RowsCfg<1, 1>::LDS_TOTAL));
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)conv_halo_rows_kernel<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (RowsCfg<1, 2>::LDS_TOTAL));
     return e;
 }
 
 // the conv_up_halo_kernel<0 / 1> part of launch_conv_up_halo (the border ring has been launched by the caller)
 hipError_t launch_conv_halo_rows_up(const ConvArgs& a, hipStream_t stream) {
     const bool sparse = a.up_cols != nullptr;
+    const int tiles_n = a.cout / 64;
+    if (sparse && (a.up_mix[0] | a.up_mix[1] | a.up_mix[2]) != 0) {
+        // mixed shapes: one launch per shape over its own row blocks; the smallest launch (the 4-entry tiles) goes first
+        dyf_form_note("conv_halo_rows_kernel<1>", a.n);
+        constexpr int LDS_S0 = RowsCfg<1, 0>::LDS_TOTAL, LDS_S1 = RowsCfg<1, 1>::LDS_TOTAL, LDS_S2 = RowsCfg<1, 2>::LDS_TOTAL;
+        const int cnt[3] = {a.up_mix[0], a.up_mix[1], a.up_mix[2]};
+        const int off[3] = {0, 32 * cnt[0], 32 * cnt[0] + 16 * cnt[1]}, cb[3] = {0, cnt[0], cnt[0] + cnt[1]};
+        for (int sh = 2; sh >= 0; --sh) {
+            if (cnt[sh] == 0) continue;
+            ConvArgs b = a;
+            b.up_sh_off = off[sh];
+            b.up_sh_cb = cb[sh];
+            const int rows = sh == 0 ? R_TH : sh == 1 ? 2 * R_TH : 8 * R_TH;
+            const int tiles_x = cnt[sh], tiles_per_img = tiles_x * (a.h / rows), tiles_m = a.n * tiles_per_img;
+            if (sh == 0)
+                hipLaunchKernelGGL((conv_halo_rows_kernel<1, 0>), dim3(tiles_m * tiles_n), dim3(256), LDS_S0, stream, b, tiles_x,
+                                   tiles_per_img, tiles_m, tiles_n);
+            else if (sh == 1)
+                hipLaunchKernelGGL((conv_halo_rows_kernel<1, 1>), dim3(tiles_m * tiles_n), dim3(256), LDS_S1, stream, b, tiles_x,
+                                   tiles_per_img, tiles_m, tiles_n);
+            else
+                hipLaunchKernelGGL((conv_halo_rows_kernel<1, 2>), dim3(tiles_m * tiles_n), dim3(256), LDS_S2, stream, b, tiles_x,
+                                   tiles_per_img, tiles_m, tiles_n);
+        }
+        return hipGetLastError();
+    }
     const int tiles_x = sparse ? a.up_ntiles : a.w / R_TW, tiles_per_img = tiles_x * (a.h / R_TH);
     int tiles_m = a.n * tiles_per_img;
-    const int tiles_n = a.cout / 64;
     // timing experiment (WRONG results): 13 of 16 sparse tiles -- what packing the 52-column lists without padded slots would save
     static const bool exp1316 = getenv("DYF_EXP_DEC5_1316") && atoi(getenv("DYF_EXP_DEC5_1316")) != 0;
     if (sparse && exp1316) tiles_m = tiles_m * 13 / 16;
     dyf_form_note(sparse ? "conv_halo_rows_kernel<1>" : "conv_halo_rows_kernel<0>", a.n);
     if (sparse)
-        hipLaunchKernelGGL(conv_halo_rows_kernel<1>, dim3(tiles_m * tiles_n), dim3(256), RowsCfg<1>::LDS_TOTAL, stream, a, tiles_x,
+        hipLaunchKernelGGL((conv_halo_rows_kernel<1, 0>), dim3(tiles_m * tiles_n), dim3(256), RowsCfg<1>::LDS_TOTAL, stream, a, tiles_x,
                            tiles_per_img, tiles_m, tiles_n);
     else
         hipLaunchKernelGGL(conv_halo_rows_kernel<0>, dim3(tiles_m * tiles_n), dim3(256), RowsCfg<0>::LDS_TOTAL, stream, a, tiles_x,

@@ -712,10 +712,11 @@ bool conv_up_halo_supported(const ConvArgs& a) {
     if (!a.up2x || a.wpk_up_frag == nullptr || a.out_el16 == nullptr || a.residual != nullptr) return false;
     if (!(a.c0 > 0 && a.c0 % 64 == 0 && (a.c1 == 0 || a.c1 == a.c0) && a.cout % 64 == 0)) return false;
     if (a.h % TILE_H != 0 || a.w % TILE_W != 0 || a.ho != 2 * a.h || a.wo != 2 * a.w) return false;
+    const bool mixed = (a.up_mix[0] | a.up_mix[1] | a.up_mix[2]) != 0;
     if (a.up_cols && (a.up_cbase == nullptr || a.up_cidx == nullptr || a.up_wo_store < 1 || a.up_ntiles < 1 ||
-                      (a.up_npad != a.up_ntiles * 16 && a.up_npad != a.up_ntiles * conv_halo_rows_slots())))
+                      (!mixed && a.up_npad != a.up_ntiles * 16 && a.up_npad != a.up_ntiles * conv_halo_rows_slots())))
         return false;
-    if (a.up_cols && a.up_npad != a.up_ntiles * 16 && !conv_halo_rows_up_supported(a)) return false;
+    if (a.up_cols && (mixed || a.up_npad != a.up_ntiles * 16) && !conv_halo_rows_up_supported(a)) return false;
     const size_t npix = (size_t)a.n * a.h * a.w;
     return npix * a.c0 * 2 < 0x7F000000ull && (size_t)4 * a.cout * 16 * (a.c0 + a.c1) * 2 < 0x7F000000ull &&
            (size_t)a.n * a.ho * a.wo * a.cout < 0xFFFFFFF0ull;
@@ -1084,7 +1085,8 @@ hipError_t launch_conv_up_halo(const ConvArgs& a, hipStream_t stream) {
     // rows form (conv_halo_rows.hip: one-row pixel tiles, half the LDS fragment reads) where the plane tiles by 4 x 32;
     // DYF_HALO_ROWS=0 keeps this file's kernels.  The sparse lists are planned for one form or the other (32 / 16 slots).
     static const bool rows = !(getenv("DYF_HALO_ROWS") && atoi(getenv("DYF_HALO_ROWS")) == 0);
-    if (sparse ? a.up_npad != a.up_ntiles * 16 : (rows && conv_halo_rows_up_supported(a))) return launch_conv_halo_rows_up(a, stream);
+    if (sparse ? ((a.up_mix[0] | a.up_mix[1] | a.up_mix[2]) != 0 || a.up_npad != a.up_ntiles * 16) : (rows && conv_halo_rows_up_supported(a)))
+        return launch_conv_halo_rows_up(a, stream);
     const int tiles_x = sparse ? a.up_ntiles : a.w / TILE_W, tiles_per_img = tiles_x * (a.h / TILE_H);
     const int tiles_m = a.n * tiles_per_img, tiles_n = a.cout / 64;
     dyf_form_note(sparse ? "conv_up_halo_kernel<1>" : "conv_up_halo_kernel<0>", a.n);
@@ -1152,5 +1154,85 @@ bool plan_up_sparse_columns(const std::vector<uint8_t>& needed, int w, std::vect
         cbase[t] = (int16_t)(lo - 1);
         if (hi - lo + 3 > halo_w) return false;
     }
+    return true;
+}
+
+bool plan_up_sparse_columns_mixed(const std::vector<uint8_t>& needed, int w, int h, std::vector<int16_t>& cols, std::vector<int16_t>& cbase,
+                                  std::vector<int16_t>& cidx, std::vector<int16_t>& col_map, int mix[3], int& nvalid0, int& nvalid1) {
+    col_map.assign((size_t)2 * w, -1);
+    int nstore = 0;
+    for (int x = 0; x < 2 * w; ++x)
+        if (needed[x]) col_map[x] = (int16_t)nstore++;
+    std::vector<int> l[2];
+    for (int j = 0; j < w; ++j)
+        for (int px = 0; px < 2; ++px)
+            if (needed[2 * j + px]) l[px].push_back(j);
+    if (l[0].empty() || l[1].empty()) return false;
+    nvalid0 = (int)l[0].size();
+    nvalid1 = (int)l[1].size();
+    const int nmax = std::max(nvalid0, nvalid1);
+    // greedy from the front: 16-entry tiles while at least 16 entries remain, then 4-entry tiles (32-entry tiles only where their
+    // 72-pixel halo fits, which the interleaved phase lists of the NS geometry do not allow: a = 0 there)
+    struct T { int first, slots, shape; };
+    std::vector<T> tiles;
+    const int slots_of[3] = {32, 16, 4};
+    auto span_ok = [&](int first, int cnt, int shape) {
+        int lo = w, hi = -1;
+        for (int px = 0; px < 2; ++px) {
+            const int n = (int)l[px].size();
+            for (int i = 0; i < cnt; ++i) {
+                const int c = l[px][std::min(first + i, n - 1)];
+                lo = std::min(lo, c);
+                hi = std::max(hi, c);
+            }
+        }
+        return hi - lo + 3 <= conv_halo_rows_sparse_halo_w_shape(shape);
+    };
+    int pos = 0;
+    mix[0] = mix[1] = mix[2] = 0;
+    std::vector<T> ta, tb, tc;
+    while (nmax - pos >= 32 && span_ok(pos, 32, 0)) { ta.push_back({pos, 32, 0}); pos += 32; }
+    while (nmax - pos >= 16) {
+        if (!span_ok(pos, 16, 1)) return false;
+        tb.push_back({pos, 16, 1});
+        pos += 16;
+    }
+    while (pos < nmax) {
+        const int cnt = std::min(4, nmax - pos);
+        if (!span_ok(pos, cnt, 2)) return false;
+        tc.push_back({pos, 4, 2});
+        pos += 4;
+    }
+    // (a 32-entry tile in front of 16-entry tiles keeps list order: a, then b, then c -- the layout the launches index)
+    mix[0] = (int)ta.size(); mix[1] = (int)tb.size(); mix[2] = (int)tc.size();
+    if (mix[1] > 0 && h % 8 != 0) return false;
+    if (mix[2] > 0 && h % 32 != 0) return false;
+    if (mix[0] + mix[1] + mix[2] == 0) return false;
+    const int npad = 32 * mix[0] + 16 * mix[1] + 4 * mix[2];
+    // not worth it unless it beats uniform 32-slot tiles: tile units per 32 rows
+    const int units_mixed = 8 * mix[0] + 4 * mix[1] + mix[2], units_uniform = 8 * ((nmax + 31) / 32);
+    if (units_mixed >= units_uniform) return false;
+    cols.assign((size_t)2 * npad, 0);
+    cidx.assign((size_t)2 * npad, 0);
+    cbase.clear();
+    int off = 0;
+    for (const std::vector<T>* grp : {&ta, &tb, &tc})
+        for (const T& t : *grp) {
+            int lo = w;
+            for (int px = 0; px < 2; ++px) {
+                const int n = (int)l[px].size();
+                for (int i = 0; i < t.slots; ++i) {
+                    const int k = t.first + i;
+                    const bool real = k < n;
+                    const int c = l[px][std::min(k, n - 1)];
+                    cols[(size_t)px * npad + off + i] = (int16_t)(c | (real ? 0 : 0x4000));
+                    cidx[(size_t)px * npad + off + i] = col_map[2 * c + px];
+                    lo = std::min(lo, c);
+                }
+            }
+            cbase.push_back((int16_t)(lo - 1));
+            off += t.slots;
+            (void)slots_of;
+        }
     return true;
 }

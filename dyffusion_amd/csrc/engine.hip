@@ -242,6 +242,7 @@ dyf_status net_forward(dyf_engine* e, int which, const Source* srcs, int nsrc, i
         f.up2x = 1; f.wpk_up = b.wpk_up; f.wpk_up_frag = b.wpk_up_frag; f.up_border = ws.up_border;
         f.up_cols = b.up_cols; f.up_cbase = b.up_cbase; f.up_cidx = b.up_cidx; f.up_ntiles = b.up_ntiles; f.up_npad = b.up_npad;
         f.up_nvalid0 = b.up_nvalid0; f.up_nvalid1 = b.up_nvalid1; f.up_wo_store = b.up_wo_store;
+        f.up_mix[0] = b.up_mix[0]; f.up_mix[1] = b.up_mix[1]; f.up_mix[2] = b.up_mix[2];
         if (i == 11 && b.up_cols && e->poison_dec5)  // test hook: a needed-but-unwritten pixel of the sparse form shows as NaN
             HIP_TRY(e, hipMemsetAsync(ws.dec[5], 0xFF, (size_t)nb * b.out_h * b.out_w * b.cout * sizeof(el16_t), st));  // whole buffer
         // sparse-column form (last block only): its output tensor is compact, the readout below must know
@@ -727,7 +728,16 @@ static dyf_status load_weights_one(dyf_engine* e, int32_t which, int32_t n_tenso
                 static const bool rows_env = !(getenv("DYF_HALO_ROWS") && atoi(getenv("DYF_HALO_ROWS")) == 0);
                 int slots = rows_env && (b.out_h / 2) % 4 == 0 ? conv_halo_rows_slots() : 16;
                 bool planned = false;
-                if (n.dim == 64 && n.cfg.out_channels <= 4) {
+                int mix[3] = {0, 0, 0};
+                // mixed list tiling (no padded MFMA lanes: 52 entries = 3 x 16 + 4) first; DYF_SPARSE_MIXED=0: uniform tiles only
+                static const bool mixed_env = !(getenv("DYF_SPARSE_MIXED") && atoi(getenv("DYF_SPARSE_MIXED")) == 0);
+                if (n.dim == 64 && n.cfg.out_channels <= 4 && mixed_env && slots == conv_halo_rows_slots() &&
+                    plan_up_sparse_columns_mixed(needed, iw / 2, b.out_h / 2, cols, cbase, cidx, cmap, mix, nv0, nv1)) {
+                    planned = true;
+                    nt = mix[0] + mix[1] + mix[2];
+                }
+                if (!planned && n.dim == 64 && n.cfg.out_channels <= 4) {
+                    mix[0] = mix[1] = mix[2] = 0;
                     planned = plan_up_sparse_columns(needed, iw / 2, cols, cbase, cidx, cmap, nt, nv0, nv1, slots);
                     if (!planned && slots != 16) {
                         slots = 16;
@@ -740,6 +750,8 @@ static dyf_status load_weights_one(dyf_engine* e, int32_t which, int32_t n_tenso
                     UP(b.up_cidx, cidx);
                     UP(b.up_col_map, cmap);
                     b.up_ntiles = nt; b.up_npad = nt * slots; b.up_nvalid0 = nv0; b.up_nvalid1 = nv1;
+                    b.up_mix[0] = mix[0]; b.up_mix[1] = mix[1]; b.up_mix[2] = mix[2];
+                    if (mix[0] | mix[1] | mix[2]) b.up_npad = 32 * mix[0] + 16 * mix[1] + 4 * mix[2];
                     b.up_wo_store = nv0 + nv1;
                 }
             }
@@ -1426,6 +1438,7 @@ dyf_status dyf_time_conv_layer(dyf_engine* e, int32_t which, int32_t layer, int3
         f.h = b.in_h / 2; f.w = b.in_w / 2; f.up2x = 1; f.wpk_up = b.wpk_up; f.wpk_up_frag = b.wpk_up_frag; f.up_border = e->ws.up_border;
         f.up_cols = b.up_cols; f.up_cbase = b.up_cbase; f.up_cidx = b.up_cidx; f.up_ntiles = b.up_ntiles; f.up_npad = b.up_npad;
         f.up_nvalid0 = b.up_nvalid0; f.up_nvalid1 = b.up_nvalid1; f.up_wo_store = b.up_wo_store;
+        f.up_mix[0] = b.up_mix[0]; f.up_mix[1] = b.up_mix[1]; f.up_mix[2] = b.up_mix[2];
         if (use_fused_up(e, b, f)) a = f;
     }
     const float* A = n.tables ? n.tables : e->ws.coef_a;                    // row 0 of the plan's tables, or the

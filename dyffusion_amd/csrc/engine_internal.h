@@ -41,6 +41,7 @@ struct UBlock {              // one UNetBlock (unet_simple.py:13-82)
     int16_t* up_col_map = nullptr;  // [out_w]: output column -> column of the compact tensor, -1 = not stored
     int up_wo_store = 0;
     int up_ntiles = 0, up_npad = 0, up_nvalid0 = 0, up_nvalid1 = 0;
+    int up_mix[3] = {0, 0, 0};  // mixed list tiling (ConvArgs::up_mix), all zero = uniform tiles
     float* gamma = nullptr;  // device (GroupNorm only)
     float* beta = nullptr;
     float* static_a = nullptr;  // device [cout]: epilogue of the GroupNorm block's conv (ones / conv bias)
