@@ -76,8 +76,8 @@ constexpr unsigned rows_woff(int g) { return (unsigned)(((g % 3) * 3 + g / 12) *
 
 }  // namespace
 
-template <int SP, int SH = 0>
-__global__ __launch_bounds__(256, 2) void conv_halo_rows_kernel(ConvArgs a, int tiles_x, int tiles_per_img, int tiles_m, int tiles_n) {
+template <int SP, int SH>
+__device__ __forceinline__ void conv_halo_rows_body(const ConvArgs& a, int tiles_x, int tiles_per_img, int tiles_m, int tiles_n, int bid) {
 #if defined(__HIP_DEVICE_COMPILE__)
     using H = RowsCfg<SP, SH>;
     constexpr int HALO_W = H::W, HALO_REAL = H::REAL, HALO_BYTES = H::BYTES;
@@ -90,7 +90,6 @@ __global__ __launch_bounds__(256, 2) void conv_halo_rows_kernel(ConvArgs a, int 
 
     // XCD-aware tile id; the column blocks of one tile are consecutive (they share the halo in L2)
     const int total = tiles_m * tiles_n;
-    const int bid = blockIdx.x;
     const int xq = total >> 3, xr = total & 7, xcd = bid & 7;
     const int tile = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (bid >> 3);
     const int tn = tile % tiles_n, tm = tile / tiles_n;
@@ -506,6 +505,30 @@ __global__ __launch_bounds__(256, 2) void conv_halo_rows_kernel(ConvArgs a, int 
 #endif
 }
 
+template <int SP, int SH = 0>
+__global__ __launch_bounds__(256, 2) void conv_halo_rows_kernel(ConvArgs a, int tiles_x, int tiles_per_img, int tiles_m, int tiles_n) {
+    conv_halo_rows_body<SP, SH>(a, tiles_x, tiles_per_img, tiles_m, tiles_n, (int)blockIdx.x);
+}
+
+// The 16-entry and the 4-entry list tiles of the mixed sparse tiling in ONE grid (blocks [0, n2): 4-entry tiles, the rest: 16-entry
+// tiles): launched separately, the 4-entry tiles -- 1/13 of the work, 320 workgroups at 80 rows -- cost a whole round of the chip.
+struct RowsMixGeom {
+    int off, cb, tiles_x, tiles_per_img, tiles_m;
+};
+__global__ __launch_bounds__(256, 2) void conv_halo_rows_mixed_kernel(ConvArgs a, RowsMixGeom g1, RowsMixGeom g2, int tiles_n) {
+    const int n2 = g2.tiles_m * tiles_n;
+    ConvArgs b = a;
+    if ((int)blockIdx.x < n2) {
+        b.up_sh_off = g2.off;
+        b.up_sh_cb = g2.cb;
+        conv_halo_rows_body<1, 2>(b, g2.tiles_x, g2.tiles_per_img, g2.tiles_m, tiles_n, (int)blockIdx.x);
+    } else {
+        b.up_sh_off = g1.off;
+        b.up_sh_cb = g1.cb;
+        conv_halo_rows_body<1, 1>(b, g1.tiles_x, g1.tiles_per_img, g1.tiles_m, tiles_n, (int)blockIdx.x - n2);
+    }
+}
+
 int conv_halo_rows_slots() { return R_TW; }
 int conv_halo_rows_sparse_halo_w() { return RowsCfg<1>::W; }
 
@@ -542,6 +565,9 @@ hipError_t conv_halo_rows_init() {
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)conv_halo_rows_kernel<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (RowsCfg<1, 2>::LDS_TOTAL));
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)conv_halo_rows_mixed_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                std::max((int)RowsCfg<1, 1>::LDS_TOTAL, (int)RowsCfg<1, 2>::LDS_TOTAL));
     return e;
 }
 
@@ -555,8 +581,15 @@ hipError_t launch_conv_halo_rows_up(const ConvArgs& a, hipStream_t stream) {
         constexpr int LDS_S0 = RowsCfg<1, 0>::LDS_TOTAL, LDS_S1 = RowsCfg<1, 1>::LDS_TOTAL, LDS_S2 = RowsCfg<1, 2>::LDS_TOTAL;
         const int cnt[3] = {a.up_mix[0], a.up_mix[1], a.up_mix[2]};
         const int off[3] = {0, 32 * cnt[0], 32 * cnt[0] + 16 * cnt[1]}, cb[3] = {0, cnt[0], cnt[0] + cnt[1]};
+        static const bool one_grid = !(getenv("DYF_SPARSE_MIXED_ONE_GRID") && atoi(getenv("DYF_SPARSE_MIXED_ONE_GRID")) == 0);
+        if (one_grid && cnt[1] > 0 && cnt[2] > 0) {  // the 16- and 4-entry tiles in one grid; 32-entry tiles (if any) on their own below
+            RowsMixGeom g1{off[1], cb[1], cnt[1], cnt[1] * (a.h / (2 * R_TH)), a.n * cnt[1] * (a.h / (2 * R_TH))};
+            RowsMixGeom g2{off[2], cb[2], cnt[2], cnt[2] * (a.h / (8 * R_TH)), a.n * cnt[2] * (a.h / (8 * R_TH))};
+            hipLaunchKernelGGL(conv_halo_rows_mixed_kernel, dim3((g1.tiles_m + g2.tiles_m) * tiles_n), dim3(256), std::max(LDS_S1, LDS_S2), stream, a,
+                               g1, g2, tiles_n);
+        }
         for (int sh = 2; sh >= 0; --sh) {
-            if (cnt[sh] == 0) continue;
+            if (cnt[sh] == 0 || (one_grid && sh != 0 && cnt[1] > 0 && cnt[2] > 0)) continue;
             ConvArgs b = a;
             b.up_sh_off = off[sh];
             b.up_sh_cb = cb[sh];
