@@ -408,7 +408,8 @@ def main():
         result["roofline"] = layer_roofline(10, "conv_halo_rows_kernel<0> (dec4: fused x2-upsample + 3x3 conv, 256->128 ch, 64^2->128^2)")
         result["roofline"]["traffic"], result["roofline"]["traffic_source"] = pmc_traffic(nb)
         result["roofline_dec5_sparse"] = layer_roofline(
-            11, "conv_halo_rows_kernel<1> (dec5: fused x2-upsample + 3x3 conv, 256->64 ch, 128^2->256^2, 104 of 256 output columns)")
+            11, "conv_halo_rows_mixed_kernel = conv_halo_rows_kernel<1, SH> (dec5: fused x2-upsample + 3x3 conv, 256->64 ch, 128^2->256^2, "
+                "104 of 256 output columns as 3 x 16 + 4 list entries per phase)")
         if world == 1 and not args.no_extra_configs:
             # BASELINE configs[2] and configs[4] at their named shapes on this GPU (not the headline metric: extra keys)
             # the NS engine is CLOSED first (dyf_engine_destroy; `del` alone would not: the network modules hold it too): a live engine's
