@@ -452,6 +452,64 @@ __device__ __forceinline__ void conv_halo_rows_body(const ConvArgs& a, int tiles
             }
             return;
         }
+        if constexpr (SP == 1 && SH != 0) {
+            // Sparse lane shapes (16 entries x 2 row sets, 4 entries x 8 row sets): whole-line stores through a per-wave staging row of
+            // all 32 list slots, laid OVER the halo buffer -- the K loop is over, a barrier makes sure every wave is done reading it
+            // (their halo leaves no LDS for a staging area of its own; stored as 32-byte pieces straight from the registers these
+            // tiles wrote 1.24x the output and the stores cost 9 % of the launch: 537 vs 489 us with the stores removed).
+#ifndef HALO_NO_STAGE_SHAPES
+            __syncthreads();
+            unsigned char* ost = (unsigned char*)smem + wave * (32 * H::OROW + 128);
+            int* cst = (int*)(ost + 32 * H::OROW);
+            if (hi == 0) cst[l31] = lane_valid ? cstore : -1;
+            float ca[2][2][8], cc[2][2][8];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int g2 = 0; g2 < 2; ++g2) {
+                    const int cg0 = nt * 32 + 16 * g2;
+                    const float4 ca0 = *(const float4*)(a.coef_a + ci_base + cg0), ca1 = *(const float4*)(a.coef_a + ci_base + cg0 + 8);
+                    const float4 cc0 = *(const float4*)(a.coef_c + ci_base + cg0), cc1 = *(const float4*)(a.coef_c + ci_base + cg0 + 8);
+                    ca[nt][g2][0] = ca0.x * ps; ca[nt][g2][1] = ca0.y * ps; ca[nt][g2][2] = ca0.z * ps; ca[nt][g2][3] = ca0.w * ps;
+                    ca[nt][g2][4] = ca1.x * ps; ca[nt][g2][5] = ca1.y * ps; ca[nt][g2][6] = ca1.z * ps; ca[nt][g2][7] = ca1.w * ps;
+                    cc[nt][g2][0] = cc0.x * ps; cc[nt][g2][1] = cc0.y * ps; cc[nt][g2][2] = cc0.z * ps; cc[nt][g2][3] = cc0.w * ps;
+                    cc[nt][g2][4] = cc1.x * ps; cc[nt][g2][5] = cc1.y * ps; cc[nt][g2][6] = cc1.z * ps; cc[nt][g2][7] = cc1.w * ps;
+                }
+            const int rpx = lane >> 3, rch = lane & 7;  // read-back role: (slot 8 k + rpx, 16-byte chunk)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int g2 = 0; g2 < 2; ++g2) {
+                        const int cg0 = nt * 32 + 16 * g2;
+                        const uint32_t e0 = o0 + t * t_stride + cg0 + 4 * hi;  // dropout stream: dense position
+                        float v[8];
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) v[q] = fmaf(acc[nt][t][8 * g2 + q], ca[nt][g2][q], cc[nt][g2][q]);
+                        act_drop_fixed<4, ACT, MODE, true>(v, e0, row0, a.drop, key);
+                        act_drop_fixed<4, ACT, MODE, true>(v + 4, e0 + 8, row0, a.drop, key);
+                        uint32_t p0 = pack_el16x2(v[0], v[1]), p1 = pack_el16x2(v[2], v[3]);
+                        uint32_t q0 = pack_el16x2(v[4], v[5]), q1 = pack_el16x2(v[6], v[7]);
+                        const auto s0 = __builtin_amdgcn_permlane32_swap(p0, q0, false, false);
+                        const auto s1 = __builtin_amdgcn_permlane32_swap(p1, q1, false, false);
+                        uint4 o;
+                        o.x = s0[0]; o.y = s1[0]; o.z = s0[1]; o.w = s1[1];
+                        *(uint4*)(ost + l31 * H::OROW + (cg0 + 8 * hi) * 2) = o;
+                    }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int px = 8 * k + rpx;
+                    const int c = cst[px];
+                    const int orow = 2 * (ty0 + R_TH * (px / H::COLS) + t) + wpy;  // output row of the slot's row set
+                    const uint4 val = *(const uint4*)(ost + px * H::OROW + rch * 16);
+                    if (c >= 0)
+                        *(uint4*)(a.out_el16 + ((size_t)((n_img * a.ho + orow) * a.up_wo_store + c) * a.cout + tn * 64 + rch * 8)) = val;
+                }
+            }
+            return;
+#endif
+        }
         // 32-channel half outermost, tile rows, then the two 16-channel groups of the half: the two 32-byte pieces of a pixel's
         // 64-byte half block are stored back to back and leave the L2 as whole 64-byte writes (with the channel groups
         // outermost PMC counted 1.65x the algorithmic write bytes)
@@ -487,7 +545,11 @@ __device__ __forceinline__ void conv_halo_rows_body(const ConvArgs& a, int tiles
                     uint4 o;
                     o.x = s0[0]; o.y = s1[0]; o.z = s0[1]; o.w = s1[1];
                     const uint32_t sbase = store0 + t * st_stride + cg0;
+#ifdef HALO_EXP_NO_STORE  // timing experiment (wrong results): the register-store epilogue without its stores
+                    if (o.x == 0x12345678u && o.y == 0x9abcdef0u) *(uint4*)(a.out_el16 + (size_t)(sbase + 8 * hi)) = o;
+#else
                     if (SP != 1 || lane_valid) *(uint4*)(a.out_el16 + (size_t)(sbase + 8 * hi)) = o;
+#endif
                 }
             }
         }
