@@ -1747,13 +1747,18 @@ typedef float fa_f32x2 __attribute__((ext_vector_type(2)));
 // kf0 / kf1 / vf0: this lane's LDS addresses of the K fragments (ks = 0, 1) and of the V^T fragment of sub-tile 0 (sub-tile st adds
 // a wave-uniform offset: the swizzle key (key >> 2) & 3 does not depend on st).  NEGM: the tuple -m lives in registers across the
 // loop and is the MFMA's C operand (kernels with the registers to spare); otherwise 16 moves per sub-tile rebuild it.
+#ifndef FA2_BIAS
+#define FA2_BIAS 0  // -DFA2_BIAS=1: -m from a third (bf16, k-slot 0) matrix instruction instead of 16 v_mov per sub-tile: measured
+                   // 1.162-1.186 vs 1.143 ms without dropout, 1.870 vs 1.903 ms with -- the kernel is not issue-bound; not kept
+#endif
+typedef __attribute__((ext_vector_type(4))) short fa_bf16x4;
 #ifndef FA2_PKMOV
 #define FA2_PKMOV 0  // measured: 1.184 ms with v_pk_mov_b32 vs 1.159 ms with the compiler's 16 v_mov_b32 (same box): not kept
 #endif
 template <int VARIANT, bool DROP, int QB, bool NEGM>
 __device__ __forceinline__ void fa2_subtile(const AttnArgs& a, const el16_t* kf0, const el16_t* kf1, const el16_t* vf0, const el16x8_t (&qf)[QB][2],
                                             fa_f32x16 (&o)[QB], fa_f32x16 (&negm)[QB], float (&m)[QB], fa_f32x2 (&l2)[QB], bool& first, int jb,
-                                            int st, int q0, int N, int hi, RngKey dkey, uint32_t bh) {
+                                            int st, int q0, int N, int hi, RngKey dkey, uint32_t bh, fa_bf16x4 aone, fa_bf16x4 (&bm)[QB]) {
     fa_f32x16 sc[QB];
     {
         const el16x8_t k0 = *(const el16x8_t*)(kf0 + st * 1024), k1 = *(const el16x8_t*)(kf1 + st * 1024);
@@ -1761,6 +1766,14 @@ __device__ __forceinline__ void fa2_subtile(const AttnArgs& a, const el16_t* kf0
         for (int b = 0; b < QB; ++b) {
             if (NEGM) {
                 sc[b] = DYF_MFMA_32x32x16(k0, qf[b][0], negm[b], 0, 0, 0);
+#if FA2_BIAS
+            } else if (true) {
+                // the -m of every score comes from a THIRD matrix instruction (k-slot 0: 1 on the key side, -m on the query side, bf16)
+                // on the idle matrix pipe instead of 16 v_mov per sub-tile on the saturated vector pipe; m is kept bf16-exact
+                const fa_f32x16 zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+                sc[b] = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(aone, bm[b], zero, 0, 0, 0);
+                sc[b] = DYF_MFMA_32x32x16(k0, qf[b][0], sc[b], 0, 0, 0);
+#endif
             } else {
                 // accumulator initialised with -m; -DFA2_PKMOV=1: two registers per instruction (v_pk_mov_b32) -- an experiment
 #if FA2_PKMOV
@@ -1801,7 +1814,16 @@ __device__ __forceinline__ void fa2_subtile(const AttnArgs& a, const el16_t* kf0
 #pragma unroll
         for (int b = 0; b < QB; ++b) {
             const float tm = fmaxf(tmax[b], __shfl_xor(tmax[b], 32, 64));  // both lanes of a query agree on the new maximum
-            const float delta = first ? tm : fmaxf(tm, 0.0f);               // first sub-tile: m = the exact maximum (m was 0)
+            float delta = first ? tm : fmaxf(tm, 0.0f);                     // first sub-tile: m = the exact maximum (m was 0)
+#if FA2_BIAS
+            {   // m stays exactly representable in bf16 (round to nearest even): it travels as a bf16 MFMA operand
+                uint32_t u = __builtin_bit_cast(uint32_t, m[b] + delta);
+                u = (u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u;
+                const float mn = __builtin_bit_cast(float, u);
+                delta = mn - m[b];
+                bm[b][0] = (short)(hi == 0 ? ((__builtin_bit_cast(uint32_t, -mn)) >> 16) : 0u);
+            }
+#endif
             const float alpha = __builtin_amdgcn_exp2f(-delta);             // (first: O and l are still zero)
             m[b] += delta;
             l2[b] *= alpha;
@@ -1931,6 +1953,12 @@ __global__ __launch_bounds__(256, QB == 2 ? FA2_MINW2 : FA2_MINW) void flash_att
     }
     bool first = true;
     const RngKey dkey = DROP ? attn_drop_key(a.drop, n, (uint32_t)h) : RngKey{0u, 0u};
+    // bias operands of the third matrix instruction (32x32x8, lane (row / column, hi) holds k = 4 hi .. 4 hi + 3): k-slot 0 carries
+    // 1 on the key side and -m on the query side
+    const fa_bf16x4 aone = {(short)(hi == 0 ? 0x3F80 : 0), 0, 0, 0};
+    fa_bf16x4 bm[QB];
+#pragma unroll
+    for (int b = 0; b < QB; ++b) bm[b] = fa_bf16x4{0, 0, 0, 0};
 
     const int skey = tid >> 2, sch = tid & 3;   // staging role: thread -> (key, 16-B chunk of 8 channels)
     uint4 kv_n = make_uint4(0, 0, 0, 0), vv_n = make_uint4(0, 0, 0, 0);
@@ -1966,14 +1994,14 @@ __global__ __launch_bounds__(256, QB == 2 ? FA2_MINW2 : FA2_MINW) void flash_att
         if (whole && !DROP) {
 #pragma nounroll
             for (int st = 0; st < 2; ++st)
-                fa2_subtile<1, false, QB, NEGM>(a, kf0, kf1, vf0, qf, o, negm, m, l2, first, j0 + 32 * st, st, q0, N, hi, dkey, (uint32_t)bh);
+                fa2_subtile<1, false, QB, NEGM>(a, kf0, kf1, vf0, qf, o, negm, m, l2, first, j0 + 32 * st, st, q0, N, hi, dkey, (uint32_t)bh, aone, bm);
         } else if (DROP && whole && a.drop.mode == 1 && (N & 1) == 0 && (qb + 1) * QG <= N) {
 #pragma nounroll
             for (int st = 0; st < 2; ++st)
-                fa2_subtile<2, DROP, QB, NEGM>(a, kf0, kf1, vf0, qf, o, negm, m, l2, first, j0 + 32 * st, st, q0, N, hi, dkey, (uint32_t)bh);
+                fa2_subtile<2, DROP, QB, NEGM>(a, kf0, kf1, vf0, qf, o, negm, m, l2, first, j0 + 32 * st, st, q0, N, hi, dkey, (uint32_t)bh, aone, bm);
         } else {
-            fa2_subtile<0, DROP, QB, NEGM>(a, kf0, kf1, vf0, qf, o, negm, m, l2, first, j0, 0, q0, N, hi, dkey, (uint32_t)bh);
-            if (j0 + 32 < N) fa2_subtile<0, DROP, QB, NEGM>(a, kf0, kf1, vf0, qf, o, negm, m, l2, first, j0 + 32, 1, q0, N, hi, dkey, (uint32_t)bh);
+            fa2_subtile<0, DROP, QB, NEGM>(a, kf0, kf1, vf0, qf, o, negm, m, l2, first, j0, 0, q0, N, hi, dkey, (uint32_t)bh, aone, bm);
+            if (j0 + 32 < N) fa2_subtile<0, DROP, QB, NEGM>(a, kf0, kf1, vf0, qf, o, negm, m, l2, first, j0 + 32, 1, q0, N, hi, dkey, (uint32_t)bh, aone, bm);
         }
     }
 #pragma unroll
