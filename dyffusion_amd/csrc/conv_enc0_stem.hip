@@ -128,7 +128,13 @@ __global__ __launch_bounds__(512) void conv_enc0_stem_kernel(ConvArgs a, const e
         for (int k = 0; k < NT * 2; ++k) {
             const int off = k * 1024 + lane * 16;                 // byte offset inside the tile
             const int px = off / (NT * 64), within = off - px * (NT * 64);
-            *(uint4*)((unsigned char*)tbase + off) = *(const uint4*)(ostage + px * OROW + within);
+            const uint4 ov = *(const uint4*)(ostage + px * OROW + within);
+#ifdef DYF_NT_STORES  // experiment: non-temporal stores
+            typedef __attribute__((ext_vector_type(4))) unsigned nt_u32x4;
+            __builtin_nontemporal_store(__builtin_bit_cast(nt_u32x4, ov), (nt_u32x4*)((unsigned char*)tbase + off));
+#else
+            *(uint4*)((unsigned char*)tbase + off) = ov;
+#endif
         }
     };
 

@@ -385,7 +385,15 @@ __device__ __forceinline__ void conv_halo_rows_body(const ConvArgs& a, int tiles
                 for (int k = 0; k < 4; ++k) {
                     const int px = 8 * k + rpx;
                     const uint4 o = *(const uint4*)(ost + px * H::OROW + rch * 16);
+#ifdef HALO_EXP_NO_STORE  // timing experiment (wrong results): the staged epilogue without its global stores
+                    if (o.x == 0x12345678u && o.y == 0x9abcdef0u)
+#endif
+#ifndef HALO_NO_NT_STORE  // non-temporal stores (the output is not read again by this kernel, and the weights / halos keep their
+                         // place in L2): dec4 558 -> 545 us; -DHALO_NO_NT_STORE restores plain stores
+                    __builtin_nontemporal_store(__builtin_bit_cast(u32x4, o), (u32x4*)(a.out_el16 + (size_t)(row_base + t * st_stride + (uint32_t)px * pstride + rch * 8)));
+#else
                     *(uint4*)(a.out_el16 + (size_t)(row_base + t * st_stride + (uint32_t)px * pstride + rch * 8)) = o;
+#endif
                 }
             }
             return;
@@ -503,8 +511,14 @@ __device__ __forceinline__ void conv_halo_rows_body(const ConvArgs& a, int tiles
                     const int c = cst[px];
                     const int orow = 2 * (ty0 + R_TH * (px / H::COLS) + t) + wpy;  // output row of the slot's row set
                     const uint4 val = *(const uint4*)(ost + px * H::OROW + rch * 16);
-                    if (c >= 0)
+                    if (c >= 0) {
+#ifndef HALO_NO_NT_STORE
+                        __builtin_nontemporal_store(__builtin_bit_cast(u32x4, val),
+                                                    (u32x4*)(a.out_el16 + ((size_t)((n_img * a.ho + orow) * a.up_wo_store + c) * a.cout + tn * 64 + rch * 8)));
+#else
                         *(uint4*)(a.out_el16 + ((size_t)((n_img * a.ho + orow) * a.up_wo_store + c) * a.cout + tn * 64 + rch * 8)) = val;
+#endif
+                    }
                 }
             }
             return;

@@ -553,7 +553,11 @@ __global__ __launch_bounds__(256, 2) void conv_up_halo_kernel(ConvArgs a, int ti
                 for (int k = 0; k < 4; ++k) {
                     const int px = 8 * k + rpx;
                     const uint4 o = *(const uint4*)(ost + px * H::OROW + rch * 16);
+#ifdef DYF_NT_STORES  // experiment: non-temporal stores
+                    __builtin_nontemporal_store(__builtin_bit_cast(u32x4, o), (u32x4*)(a.out_el16 + (size_t)(tile_base + mt * mt_stride + (uint32_t)((px >> 4) * a.wo + (px & 15)) * (uint32_t)a.cout + rch * 8)));
+#else
                     *(uint4*)(a.out_el16 + (size_t)(tile_base + mt * mt_stride + (uint32_t)((px >> 4) * a.wo + (px & 15)) * (uint32_t)a.cout + rch * 8)) = o;
+#endif
                 }
             }
             return;
