@@ -586,6 +586,26 @@ __global__ __launch_bounds__(256, 2) void conv_halo_rows_kernel(ConvArgs a, int 
     conv_halo_rows_body<SP, SH>(a, tiles_x, tiles_per_img, tiles_m, tiles_n, (int)blockIdx.x);
 }
 
+// EXPERIMENT (DYF_ROWS_PERSISTENT=512; off by default: measured SLOWER, dec4 541 -> 555 us, dec3 283 -> 287 us -- the hardware already
+// starts a new one-tile workgroup the moment one retires, so nothing is gained, and the tile boundary adds a barrier).
+// Persistent form: 512 resident workgroups walk the tiles (stride = grid, a multiple of 8: a workgroup stays on its XCD).  A wave
+// that ends waits for its stores to be acknowledged (s_endpgm implies s_waitcnt 0) and holds its registers and LDS meanwhile: in
+// the one-tile form that store phase is 12-17 % of dec3 / dec4 (565 vs 470 us with the stores removed).  Here the next tile's halo
+// DMA and weight stream are issued right behind the stores; the boundary between tiles is a bare s_barrier behind an LDS wait (not
+// __syncthreads, whose fence would wait for the stores).
+template <int SP, int SH = 0>
+__global__ __launch_bounds__(256, 2) void conv_halo_rows_persistent_kernel(ConvArgs a, int tiles_x, int tiles_per_img, int tiles_m, int tiles_n) {
+    const int total = tiles_m * tiles_n;
+    for (int bid = (int)blockIdx.x; bid < total; bid += (int)gridDim.x) {
+        conv_halo_rows_body<SP, SH>(a, tiles_x, tiles_per_img, tiles_m, tiles_n, bid);
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+    }
+}
+
 // The 16-entry and the 4-entry list tiles of the mixed sparse tiling in ONE grid (blocks [0, n2): 4-entry tiles, the rest: 16-entry
 // tiles): launched separately, the 4-entry tiles -- 1/13 of the work, 320 workgroups at 80 rows -- cost a whole round of the chip.
 struct RowsMixGeom {
@@ -642,6 +662,9 @@ hipError_t conv_halo_rows_init() {
         e = hipFuncSetAttribute((const void*)conv_halo_rows_kernel<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (RowsCfg<1, 2>::LDS_TOTAL));
     if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)conv_halo_rows_persistent_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                RowsCfg<0>::LDS_TOTAL);
+    if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)conv_halo_rows_mixed_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 std::max((int)RowsCfg<1, 1>::LDS_TOTAL, (int)RowsCfg<1, 2>::LDS_TOTAL));
     return e;
@@ -689,8 +712,12 @@ hipError_t launch_conv_halo_rows_up(const ConvArgs& a, hipStream_t stream) {
     static const bool exp1316 = getenv("DYF_EXP_DEC5_1316") && atoi(getenv("DYF_EXP_DEC5_1316")) != 0;
     if (sparse && exp1316) tiles_m = tiles_m * 13 / 16;
     dyf_form_note(sparse ? "conv_halo_rows_kernel<1>" : "conv_halo_rows_kernel<0>", a.n);
+    static const int persist = getenv("DYF_ROWS_PERSISTENT") ? atoi(getenv("DYF_ROWS_PERSISTENT")) : 0;
     if (sparse)
         hipLaunchKernelGGL((conv_halo_rows_kernel<1, 0>), dim3(tiles_m * tiles_n), dim3(256), RowsCfg<1>::LDS_TOTAL, stream, a, tiles_x,
+                           tiles_per_img, tiles_m, tiles_n);
+    else if (persist > 0 && tiles_m * tiles_n > persist)
+        hipLaunchKernelGGL(conv_halo_rows_persistent_kernel<0>, dim3(persist), dim3(256), RowsCfg<0>::LDS_TOTAL, stream, a, tiles_x,
                            tiles_per_img, tiles_m, tiles_n);
     else
         hipLaunchKernelGGL(conv_halo_rows_kernel<0>, dim3(tiles_m * tiles_n), dim3(256), RowsCfg<0>::LDS_TOTAL, stream, a, tiles_x,
