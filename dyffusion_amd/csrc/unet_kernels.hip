@@ -614,6 +614,165 @@ __global__ __launch_bounds__(256) void gn_apply_part_kernel(GnActArgs a) {
     }
 }
 
+// Small planes (a sample's tensor fits the registers of one 512- or 1024-lane workgroup: hw * c / 8 <= THREADS * MAXI chunks -- the 30x30x128
+// and 15x15x256 levels of the OISST ResNet-UNet, whose convs do not produce statistics): ONE kernel, one read of the tensor from HBM.
+// A lane keeps one 16-byte channel chunk column and, KEEP, MAXI pixels of it in registers (512 lanes x 16 chunks = 128 KB: the
+// 15x15x256 level); larger samples (30x30x128 = 225 KB: 1024 lanes would have to hold it in 64 of their 128 registers, which
+// spills) are walked twice, the second time out of L2.  The statistics are reduced like gn_stats_kernel's
+// (lane sums in fp32, butterfly over the lanes of a group, one LDS slot per (wave, group), the waves added in order in fp64:
+// deterministic), then normalise + FiLM + activation + dropout (+ residual) run from the registers.  Would replace gn_stats_kernel +
+// gn_finalize_kernel + gn_apply_walk_kernel (5.2 + 4.9 + 11.9 us per GroupNorm at 100 rows of the OISST shapes).
+// EXPERIMENT (DYF_GN_FUSED_SAMPLE=1), measured and not adopted: correct (tests/test_gpu_bench_forms.py and test_gpu_unet_resnet.py
+// pass with it on) but no faster where the chip is full -- OISST rollout at 300 rows 3 740 / 3 791 fields/s with it, 3 797 without,
+// 3 824 with DYF_GN_FUSED_REREAD=1 (both levels walked twice), same box: the three short launches it removes already overlap
+// with the other row groups' kernels -- and slower where it is not: one workgroup per sample is 16 workgroups at 16 rows
+// (595 against 730 fields/s).
+template <int MAXI, int THREADS, bool KEEP>
+__global__ __launch_bounds__(THREADS) void gn_fused_sample_kernel(GnActArgs a) {
+    __shared__ float part[THREADS / 64][64][2];  // [wave][group]
+    __shared__ float2 mr_s[64];
+    const int chunks = a.c >> 3, cpg = a.c / a.groups, cq = cpg >> 3;
+    const int n = blockIdx.x;
+    const int q = threadIdx.x & (chunks - 1), row = threadIdx.x / chunks, rows = THREADS / chunks;
+    const el16_t* xp = a.x + (size_t)n * a.hw * a.c + q * 8;
+    float s = 0.0f, ss = 0.0f;
+    auto add = [&](const uint4& u) {
+        const uint32_t w[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const float lo = el16_lo(w[t]), hi = el16_hi(w[t]);
+            s += lo + hi;
+            ss = fmaf(lo, lo, fmaf(hi, hi, ss));
+        }
+    };
+    uint4 v[KEEP ? MAXI : 1];
+    if constexpr (KEEP) {
+#pragma unroll
+        for (int i = 0; i < MAXI; ++i) {
+            const int p = row + i * rows;
+            v[i] = p < a.hw ? *(const uint4*)(xp + (size_t)p * a.c) : make_uint4(0, 0, 0, 0);  // zeros add nothing to the sums
+        }
+#pragma unroll
+        for (int i = 0; i < MAXI; ++i) add(v[i]);
+    } else {
+        int p = row;
+        for (; p + 3 * rows < a.hw; p += 4 * rows) {  // four independent 16-B loads in flight
+            const uint4 v0 = *(const uint4*)(xp + (size_t)p * a.c), v1 = *(const uint4*)(xp + (size_t)(p + rows) * a.c);
+            const uint4 v2 = *(const uint4*)(xp + (size_t)(p + 2 * rows) * a.c), v3 = *(const uint4*)(xp + (size_t)(p + 3 * rows) * a.c);
+            add(v0); add(v1); add(v2); add(v3);
+        }
+        for (; p < a.hw; p += rows) add(*(const uint4*)(xp + (size_t)p * a.c));
+    }
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {  // lanes l and l ^ d hold the same group when d < cq or d >= chunks
+        if (d < cq || d >= chunks) {
+            s += __shfl_xor(s, d, 64);
+            ss += __shfl_xor(ss, d, 64);
+        }
+    }
+    const int l = threadIdx.x & 63;
+    const int g = (q * 8) / cpg;
+    if ((l & (cq - 1)) == 0 && (chunks >= 64 || l < chunks)) {  // exactly one lane of the wave holds group g
+        part[threadIdx.x >> 6][g][0] = s;
+        part[threadIdx.x >> 6][g][1] = ss;
+    }
+    __syncthreads();
+    if (threadIdx.x < a.groups) {
+        double ds = 0.0, dss = 0.0;
+        // chunks > 64: a wave covers 64 of the chunk columns only and holds a slot for the groups that overlap them
+        for (int w = 0; w < THREADS / 64; ++w) {
+            const int q0 = (w * 64) & (chunks - 1), q1 = chunks >= 64 ? q0 + 64 : chunks;
+            const int gq = threadIdx.x * cq;  // first chunk column of the group
+            if (gq < q1 && gq + cq > q0) {
+                ds += (double)part[w][threadIdx.x][0];
+                dss += (double)part[w][threadIdx.x][1];
+            }
+        }
+        const double inv = 1.0 / ((double)a.hw * cpg);
+        const double mean = ds * inv;
+        const double var = dss * inv - mean * mean;
+        mr_s[threadIdx.x] = make_float2((float)mean, rsqrtf(fmaxf((float)var, 0.0f) + 1e-5f));
+    }
+    __syncthreads();
+    const float2 ms = mr_s[g];
+    const float mean = ms.x, rstd = ms.y;
+    const float4 g0 = *(const float4*)(a.gamma + q * 8), g1 = *(const float4*)(a.gamma + q * 8 + 4);
+    const float4 b0 = *(const float4*)(a.beta + q * 8), b1 = *(const float4*)(a.beta + q * 8 + 4);
+    float A[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+    float C[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        A[t] *= rstd;
+        C[t] = fmaf(-mean, A[t], C[t]);
+    }
+    if (a.film_a) {
+        const size_t fi = (size_t)n * a.film_stride + q * 8;
+        const float4 fa0 = *(const float4*)(a.film_a + fi), fa1 = *(const float4*)(a.film_a + fi + 4);
+        const float4 fc0 = *(const float4*)(a.film_c + fi), fc1 = *(const float4*)(a.film_c + fi + 4);
+        const float fa[8] = {fa0.x, fa0.y, fa0.z, fa0.w, fa1.x, fa1.y, fa1.z, fa1.w};
+        const float fc[8] = {fc0.x, fc0.y, fc0.z, fc0.w, fc1.x, fc1.y, fc1.z, fc1.w};
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            A[t] *= fa[t];
+            C[t] = fmaf(C[t], fa[t], fc[t]);
+        }
+    }
+    const RngKey key = drop_row_key(a.drop, n);
+    const uint32_t row0 = (uint32_t)((size_t)n * a.hw * a.c);
+    auto finish = [&](const uint4& xv4, const uint4& rv, int p) {  // p < hw
+        const size_t e0 = ((size_t)n * a.hw + p) * a.c + q * 8;
+        const uint32_t w[4] = {xv4.x, xv4.y, xv4.z, xv4.w};
+        float y[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const float xv = (t & 1) ? el16_hi(w[t >> 1]) : el16_lo(w[t >> 1]);
+            y[t] = fmaf(xv, A[t], C[t]);
+        }
+        act_drop<8>(y, (uint32_t)e0, row0, a.act, a.drop, key);
+        if (a.residual) {
+            const uint32_t rw[4] = {rv.x, rv.y, rv.z, rv.w};
+#pragma unroll
+            for (int t = 0; t < 8; ++t) y[t] += (t & 1) ? el16_hi(rw[t >> 1]) : el16_lo(rw[t >> 1]);
+        }
+        *(uint4*)(a.out + e0) = make_uint4(pack_el16x2(y[0], y[1]), pack_el16x2(y[2], y[3]), pack_el16x2(y[4], y[5]), pack_el16x2(y[6], y[7]));
+    };
+    constexpr int RB = 4;  // loads in flight
+    if constexpr (KEEP) {
+#pragma unroll
+        for (int i0 = 0; i0 < MAXI; i0 += RB) {
+            uint4 r[RB];
+            if (a.residual) {
+#pragma unroll
+                for (int j = 0; j < RB; ++j) {
+                    const int p = min(row + (i0 + j) * rows, a.hw - 1);
+                    r[j] = *(const uint4*)(a.residual + ((size_t)n * a.hw + p) * a.c + q * 8);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < RB; ++j) {
+                const int p = row + (i0 + j) * rows;
+                if (p < a.hw) finish(v[i0 + j], r[j], p);
+            }
+        }
+    } else {
+        // second walk over the sample: these 16-byte chunks were read by this workgroup a few microseconds ago (L2 hits)
+        for (int pb = row; pb < a.hw; pb += RB * rows) {
+            uint4 x4[RB], r[RB];
+#pragma unroll
+            for (int j = 0; j < RB; ++j) {
+                const int p = min(pb + j * rows, a.hw - 1);
+                x4[j] = *(const uint4*)(xp + (size_t)p * a.c);
+                if (a.residual) r[j] = *(const uint4*)(a.residual + ((size_t)n * a.hw + p) * a.c + q * 8);
+            }
+#pragma unroll
+            for (int j = 0; j < RB; ++j) {
+                const int p = pb + j * rows;
+                if (p < a.hw) finish(x4[j], r[j], p);
+            }
+        }
+    }
+}
+
 // Large planes (512^2: 2 048 slots per sample): the finalisation is too much to repeat in every workgroup of the apply pass --
 // one workgroup per (sample, group) does it once (fixed order: 128 slot lanes x 2 sums, then a tree over the lanes) and
 // gn_apply_walk_kernel runs.  (First form: one workgroup per sample, 16 slot lanes per sum: 27 us at 512^2, 6 % of that rollout.)
@@ -662,6 +821,19 @@ hipError_t launch_gn_act(const GnActArgs& a, hipStream_t s) {
         return hipGetLastError();
     }
     if (a.stats && (a.c % 8 == 0) && (cpg % 8 == 0) && a.groups <= 64) {
+        {
+            const int chunks = a.c >> 3, cq = cpg >> 3;
+            static const bool fused = getenv("DYF_GN_FUSED_SAMPLE") && atoi(getenv("DYF_GN_FUSED_SAMPLE")) != 0;  // experiment, off
+            const long long per = (long long)a.hw * chunks;
+            static const int reread = getenv("DYF_GN_FUSED_REREAD") ? atoi(getenv("DYF_GN_FUSED_REREAD")) : 0;  // experiment: 1 = never keep
+            if (fused && (chunks & (chunks - 1)) == 0 && (cq & (cq - 1)) == 0 && chunks <= 256 && per <= 1024 * 32) {
+                dyf_form_note("gn_fused_sample_kernel", a.n);
+                if (per <= 512 * 8 && !reread) hipLaunchKernelGGL((gn_fused_sample_kernel<8, 512, true>), dim3(a.n), dim3(512), 0, s, a);
+                else if (per <= 512 * 16 && !reread) hipLaunchKernelGGL((gn_fused_sample_kernel<16, 512, true>), dim3(a.n), dim3(512), 0, s, a);
+                else hipLaunchKernelGGL((gn_fused_sample_kernel<1, 1024, false>), dim3(a.n), dim3(1024), 0, s, a);
+                return hipGetLastError();
+            }
+        }
         dyf_form_note("gn_stats_kernel+gn_apply", a.n);
         const long long per_sample = (long long)a.hw * (a.c >> 3);
         // >= 4 passes of 256 lanes per workgroup, at most GN_MAX_BLOCKS workgroups per sample (their partials are added in order)
