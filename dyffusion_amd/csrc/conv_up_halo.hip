@@ -580,6 +580,96 @@ __global__ __launch_bounds__(256, 2) void conv_up_halo_kernel(ConvArgs a, int ti
                 k4c[o] = *(const float4*)(a.coef_c + ci_base + (o >> 2) * 32 + 8 * (o & 3));
             }
         }
+#ifdef H5_LEAN  // EXPERIMENT, measured slower and off (see the end of this comment)
+        // SP = 5 without activation / dropout (every conv of the ResNet-UNet that feeds a GroupNorm, and its plain 3x3 convs):
+        // y = acc * A + C is formed ONCE, in place, with packed fp32 math (a lane's channel pairs are register pairs), octet by octet
+        // with the octet's coefficients loaded there (all 16 loads up front spilled); pixels outside a ragged plane are zeroed (they
+        // are not stored and then add nothing to the sums); the sums of the octet follow at once, the store loop reads y.
+        // PMC had counted 2 461 vector instructions per wave against 384 MFMAs, ~1 100 of them in this epilogue (y formed twice --
+        // once per pass, behind an opaque copy that kept the two passes apart --, masked scalar sums, register copies).
+        // Measured (level-0 64 -> 64 convs of the OISST rollout, 300 rows): 116.5 us without it, 152 us with it (228 us in its first
+        // form with the 16 coefficient loads up front): the kernel already sits at 256 registers with 5 spill slots; in the full
+        // kernel (all activation x dropout epilogues instantiated) this path comes out with 52-199 spill slots -- ~230 MB of scratch
+        // traffic per launch -- although it allocates 250 registers and no spill when it is the only epilogue (-DH5_COUNT).  The
+        // instruction count does drop (epilogue ~930 -> ~620 VALU per wave); what it needs is register headroom first.
+        if constexpr (STATS) {
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            f32x2 m2[4];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const float m = (lane_valid && orow0 + 2 * mt < a.ho) ? 1.0f : 0.0f;
+                m2[mt] = f32x2{m, m};
+            }
+            const bool stats = a.gn_part != nullptr;
+            float w[16];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 ka = *(const float4*)(a.coef_a + ci_base + nt * 32 + 8 * g), kc = *(const float4*)(a.coef_c + ci_base + nt * 32 + 8 * g);
+                    const f32x2 k01 = {ka.x, ka.y}, k23 = {ka.z, ka.w}, c01 = {kc.x, kc.y}, c23 = {kc.z, kc.w};
+                    f32x2 s1a = {0.0f, 0.0f}, s1b = {0.0f, 0.0f}, s2a = {0.0f, 0.0f}, s2b = {0.0f, 0.0f};  // two chains each: packed ops have latency
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt) {
+                        f32x2 y01 = {acc[nt][mt][4 * g + 0], acc[nt][mt][4 * g + 1]}, y23 = {acc[nt][mt][4 * g + 2], acc[nt][mt][4 * g + 3]};
+                        y01 = (y01 * k01 + c01) * m2[mt];
+                        y23 = (y23 * k23 + c23) * m2[mt];
+                        acc[nt][mt][4 * g + 0] = y01.x; acc[nt][mt][4 * g + 1] = y01.y;
+                        acc[nt][mt][4 * g + 2] = y23.x; acc[nt][mt][4 * g + 3] = y23.y;
+                        s1a += y01;
+                        s1b += y23;
+                        s2a = y01 * y01 + s2a;
+                        s2b = y23 * y23 + s2b;
+                    }
+                    s1a += s1b;
+                    s2a += s2b;
+                    w[2 * (4 * nt + g)] = s1a.x + s1a.y;
+                    w[2 * (4 * nt + g) + 1] = s2a.x + s2a.y;
+                    __builtin_amdgcn_sched_barrier(0);  // octet by octet: hoisted together the 64 packed products got fresh registers and spilled
+                }
+            if (stats) {
+                // wave reduction: the reduce-scatter butterfly of the general path below
+#pragma unroll
+                for (int half = 8, d = 1; half >= 1; half >>= 1, d <<= 1) {
+                    const bool up = (lane & d) != 0;
+#pragma unroll
+                    for (int j = 0; j < half; ++j) {
+                        const float send = up ? w[j] : w[j + half];
+                        const float keep = up ? w[j + half] : w[j];
+                        w[j] = keep + __shfl_xor(send, d, 64);
+                    }
+                }
+                float tot = w[0];
+                tot += __shfl_xor(tot, 16, 64);
+                tot += __shfl_xor(tot, 32, 64);
+                if (lane < 16) {
+                    const int idx = 8 * (lane & 1) + 4 * ((lane >> 1) & 1) + 2 * ((lane >> 2) & 1) + ((lane >> 3) & 1);
+                    const int slot = t_in * NWAVES + wave;
+                    a.gn_part[((size_t)(n_img * a.gn_slots + slot) * (a.cout >> 3) + tn * 8) * 2 + idx] = tot;
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int g2 = 0; g2 < 2; ++g2) {
+                        const uint32_t p0 = pack_el16x2(acc[nt][mt][8 * g2 + 0], acc[nt][mt][8 * g2 + 1]), p1 = pack_el16x2(acc[nt][mt][8 * g2 + 2], acc[nt][mt][8 * g2 + 3]);
+                        const uint32_t q0 = pack_el16x2(acc[nt][mt][8 * g2 + 4], acc[nt][mt][8 * g2 + 5]), q1 = pack_el16x2(acc[nt][mt][8 * g2 + 6], acc[nt][mt][8 * g2 + 7]);
+                        const auto s0 = __builtin_amdgcn_permlane32_swap(p0, q0, false, false);
+                        const auto s1 = __builtin_amdgcn_permlane32_swap(p1, q1, false, false);
+                        uint4 o;
+                        o.x = s0[0]; o.y = s1[0]; o.z = s0[1]; o.w = s1[1];
+                        const uint32_t sbase = store0 + mt * smt_stride + nt * 32 + 16 * g2;
+#ifdef HALO_EXP_NO_STORE
+                        if (a.n < 0)
+#endif
+                        if (lane_valid && orow0 + 2 * mt < a.ho) *(uint4*)(a.out_el16 + (size_t)(sbase + 8 * hi)) = o;
+                    }
+            return;
+        }
+#endif
         if constexpr (STATS) if (a.gn_part != nullptr) {
             float mval[4];
 #pragma unroll
@@ -684,6 +774,10 @@ __global__ __launch_bounds__(256, 2) void conv_up_halo_kernel(ConvArgs a, int ti
         else if (a.drop.mode == 1) epilogue(act_c, std::integral_constant<int, 1>{});
         else epilogue(act_c, std::integral_constant<int, 2>{});
     };
+#ifdef H5_COUNT  // ISA counting aid: only the (no activation, no dropout) epilogue is instantiated
+    epilogue(std::integral_constant<int, ACT_NONE>{}, std::integral_constant<int, 0>{});
+    return;
+#endif
     if (a.act == ACT_RELU) by_mode(std::integral_constant<int, ACT_RELU>{});
     else if (a.act == ACT_LEAKY) by_mode(std::integral_constant<int, ACT_LEAKY>{});
     else if (a.act == ACT_SILU) by_mode(std::integral_constant<int, ACT_SILU>{});
