@@ -98,7 +98,11 @@ struct HaloCfg {
 
 }  // namespace
 
-template <int SP>
+// PLAIN_EPI: only the (no activation, no dropout) epilogue is instantiated -- the launcher picks it for such launches (every 3x3
+// conv of the ResNet-UNet: its activation follows the GroupNorm).  With all twelve (activation x dropout mode) epilogues in one
+// kernel the SP = 5 form sits at 256 registers with spill slots; alone this one allocates without spilling: level-0 convs of the
+// OISST rollout 121.3 -> 114.7 us (300 rows), 51.7 -> 48.7 us (100 rows).
+template <int SP, bool PLAIN_EPI = false>
 __global__ __launch_bounds__(256, 2) void conv_up_halo_kernel(ConvArgs a, int tiles_x, int tiles_per_img, int tiles_m,
                                                               int tiles_n, int xmode) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -590,7 +594,7 @@ __global__ __launch_bounds__(256, 2) void conv_up_halo_kernel(ConvArgs a, int ti
         // Measured (level-0 64 -> 64 convs of the OISST rollout, 300 rows): 116.5 us without it, 152 us with it (228 us in its first
         // form with the 16 coefficient loads up front): the kernel already sits at 256 registers with 5 spill slots; in the full
         // kernel (all activation x dropout epilogues instantiated) this path comes out with 52-199 spill slots -- ~230 MB of scratch
-        // traffic per launch -- although it allocates 250 registers and no spill when it is the only epilogue (-DH5_COUNT).  The
+        // traffic per launch -- although it allocates 250 registers and no spill when it is the only epilogue (PLAIN_EPI; there: 119.8 us against 114.7 us).  The
         // instruction count does drop (epilogue ~930 -> ~620 VALU per wave); what it needs is register headroom first.
         if constexpr (STATS) {
             typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -774,10 +778,10 @@ __global__ __launch_bounds__(256, 2) void conv_up_halo_kernel(ConvArgs a, int ti
         else if (a.drop.mode == 1) epilogue(act_c, std::integral_constant<int, 1>{});
         else epilogue(act_c, std::integral_constant<int, 2>{});
     };
-#ifdef H5_COUNT  // ISA counting aid: only the (no activation, no dropout) epilogue is instantiated
-    epilogue(std::integral_constant<int, ACT_NONE>{}, std::integral_constant<int, 0>{});
-    return;
-#endif
+    if constexpr (PLAIN_EPI) {
+        epilogue(std::integral_constant<int, ACT_NONE>{}, std::integral_constant<int, 0>{});
+        return;
+    }
     if (a.act == ACT_RELU) by_mode(std::integral_constant<int, ACT_RELU>{});
     else if (a.act == ACT_LEAKY) by_mode(std::integral_constant<int, ACT_LEAKY>{});
     else if (a.act == ACT_SILU) by_mode(std::integral_constant<int, ACT_SILU>{});
@@ -920,8 +924,13 @@ hipError_t launch_conv_halo5(const ConvArgs& a, hipStream_t stream) {
     const int tiles_x = (a.w + H5::TW - 1) / H5::TW, tiles_per_img = tiles_x * ((a.h + H5::TH - 1) / H5::TH);
     const int tiles_m = a.n * tiles_per_img, tiles_n = a.cout / 64;
     dyf_form_note("conv_up_halo_kernel<5>", a.n);
-    hipLaunchKernelGGL(conv_up_halo_kernel<5>, dim3(tiles_m * tiles_n), dim3(256), H5::LDS_TOTAL, stream, a, tiles_x,
-                       tiles_per_img, tiles_m, tiles_n, 0);
+    static const bool plain_epi = !(getenv("DYF_HALO5_PLAIN_EPI") && atoi(getenv("DYF_HALO5_PLAIN_EPI")) == 0);
+    if (plain_epi && a.act == ACT_NONE && a.drop.mode == 0)
+        hipLaunchKernelGGL((conv_up_halo_kernel<5, true>), dim3(tiles_m * tiles_n), dim3(256), H5::LDS_TOTAL, stream, a, tiles_x,
+                           tiles_per_img, tiles_m, tiles_n, 0);
+    else
+        hipLaunchKernelGGL(conv_up_halo_kernel<5>, dim3(tiles_m * tiles_n), dim3(256), H5::LDS_TOTAL, stream, a, tiles_x,
+                           tiles_per_img, tiles_m, tiles_n, 0);
     return hipGetLastError();
 }
 
@@ -992,6 +1001,9 @@ hipError_t conv_up_halo_init() {
                                 HaloCfg<4>::LDS_TOTAL);
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)conv_up_halo_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                HaloCfg<5>::LDS_TOTAL);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)(conv_up_halo_kernel<5, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 HaloCfg<5>::LDS_TOTAL);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)up_border_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, UB_LDS);
     return e;
