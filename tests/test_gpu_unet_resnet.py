@@ -256,3 +256,41 @@ def test_flash_attention_engine_dropout_draws_the_masks_of_the_plain_kernel(tmp_
         print(f"flash form {flash} (paired keep words) vs plain attention kernel, engine dropout: rel-rms", err)
         assert err <= 1e-2
     assert float(outs["2"].std()) > 0
+
+
+_HALO5_EPI_SCRIPT = r"""
+import sys, torch
+sys.path.insert(0, {root!r})
+from tests.test_gpu_unet_resnet import mirror, seeded_unet
+cfg = dict(dim=64, dim_mults=[1, 2, 4], with_time_emb=True, block_dropout=0.0, block_dropout1=0.0, attn_dropout=0.0,
+           resnet_block_groups=8, input_dropout=0.0, upsample_dims=None)
+P = seeded_unet(64, (1, 2, 4), 2, 1, seed=5)
+g = torch.Generator().manual_seed(6)
+nb = 40  # 60 x 60 planes at 40 rows: the 3x3 convs run on conv_up_halo_kernel<5> (ragged 16 x 32 tiles)
+x, t = torch.randn(nb, 2, 60, 60, generator=g), (torch.arange(nb) % 7 + 1).float()
+net = mirror(P, cfg, 2, 0, 1)
+net._own_engine(nb, (60, 60))
+net._engine.form_log(True)
+y = net(x.cuda(), time=t.cuda()).cpu()
+forms = net._engine.form_log_read()
+assert "conv_up_halo_kernel<5>" in forms, forms
+torch.save(y, {out!r})
+"""
+
+
+def test_halo5_plain_epilogue_instantiation_equals_the_general_one(tmp_path):
+    """conv_up_halo_kernel<5, true> (only the no-activation / no-dropout epilogue instantiated: what every 3x3 conv of the
+    ResNet-UNet launches by default) against the general instantiation (DYF_HALO5_PLAIN_EPI=0, all twelve epilogues): the same
+    source path compiled twice, so the forward must agree BITWISE; the default one is pinned to the oracle by every other test of
+    this file.  The switch is read once per process: two subprocesses."""
+    import subprocess
+    import sys as _sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    outs = {}
+    for v in ("1", "0"):
+        out = str(tmp_path / f"y{v}.pt")
+        env = dict(os.environ, DYF_HALO5_PLAIN_EPI=v)
+        subprocess.run([_sys.executable, "-c", _HALO5_EPI_SCRIPT.format(root=root, out=out)], check=True, env=env, timeout=600)
+        outs[v] = torch.load(out)
+    assert torch.isfinite(outs["1"]).all() and float(outs["1"].std()) > 0
+    assert torch.equal(outs["1"], outs["0"])
