@@ -31,9 +31,13 @@ class PhysicalSystemsBoundaryConditions:
 
     # ------------------------------------------------------------------ metadata -> device tensors (cached per batch)
     def _source_key(self, metadata):
-        """Identity of the tensors the device copies were made from: storage address and in-place modification counter."""
+        """Identity of the tensors the device copies were made from: storage address and in-place modification counter.
+        Tensors created under `torch.inference_mode()` (Lightning's evaluation loops move the batch to the device inside it)
+        have no version counter -- reading `_version` raises -- and cannot be modified in place outside that mode, so the
+        address and shape identify them."""
         names = ("fixed_mask", "in_velocity", "vertices") if self.physical_system == "navier-stokes" else ("fixed_mask", "features")
-        return tuple((metadata[k].data_ptr(), metadata[k]._version, tuple(metadata[k].shape)) for k in names)
+        return tuple((metadata[k].data_ptr(), None if metadata[k].is_inference() else metadata[k]._version,
+                      tuple(metadata[k].shape)) for k in names)
 
     def _prepare(self, metadata, device) -> Dict[str, Tensor]:
         """The cache holds a REFERENCE to the metadata dict it was built from and is hit only by that very object with

@@ -602,6 +602,7 @@ static dyf_status load_weights_one(dyf_engine* e, int32_t which, int32_t n_tenso
         n.table_of_time.clear();
         n.ntables = 0;
         e->plan.set = false;
+        if (e->is_group_child) return DYF_OK;  // row groups only sample: no fp32 training copy, no gradient buffers
         return rn_train_store_weights(e, which, sd);  // fp32 copy in the training layout (train_resnet.inc)
     }
     std::string missing;
@@ -821,6 +822,7 @@ static dyf_status load_weights_one(dyf_engine* e, int32_t which, int32_t n_tenso
     n.table_of_time.clear();
     n.ntables = 0;
     e->plan.set = false;  // coefficient tables depend on the weights
+    if (e->is_group_child) return DYF_OK;
     return train_store_weights(e, which, sd);  // fp32 copy in the training layout (train.hip)
 }
 
@@ -1192,6 +1194,11 @@ static dyf_status sample_into_stack(dyf_engine* e, const float* initial_dev, con
         for (int g = 0; g < used; ++g)  // same seed and stream position as this engine, batch row 0 = global row offset + g * per
             HIP_TRY(e, launch_rng_clone(e->groups[g]->rng_state, e->rng_state, (uint32_t)(g * per), false, st));
         HIP_TRY(e, hipEventRecord(e->group_fork, st));
+        // the parent keeps the call's inputs too (dyf_time_kernel_in_rollout / dyf_time_layer_in_rollout re-run the plan on
+        // e->s_init / e->s_static: without this copy they would read whatever hipMalloc left there); 29 KB per OISST row
+        HIP_TRY(e, hipMemcpyAsync(e->s_init, initial_dev, (size_t)nb * e->wC * H * W * sizeof(float), hipMemcpyDeviceToDevice, st));
+        if (static_dev)
+            HIP_TRY(e, hipMemcpyAsync(e->s_static, static_dev, (size_t)nb * e->Cs * H * W * sizeof(float), hipMemcpyDeviceToDevice, st));
         for (int g = 0; g < used; ++g) {
             dyf_engine* c = e->groups[g];
             const int rows = std::min(per, nb - g * per);

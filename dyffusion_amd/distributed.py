@@ -89,15 +89,46 @@ class _Sampler(Protocol):  # what sample_sharded needs of `DYffusion`
     def set_row_offset(self, first_row: int) -> None: ...
 
 
-def init_engine_comm(model, hw, total_rows: int, group=None) -> None:
+def _all_ok(ok: bool, group, device) -> bool:
+    """Every rank learns whether ALL ranks succeeded (all-reduce MIN of a flag: 4 bytes; under RCCL the flag lives on the GPU)."""
+    on_gpu = dist.get_backend(group) == "nccl"
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device if on_gpu else "cpu")
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    return bool(int(flag.item()))
+
+
+def init_engine_comm(model, hw, total_rows: int, group=None) -> bool:
     """Create the engines' own RCCL communicator over the ranks of `group`: rank 0 draws the unique id (dyf_comm_unique_id),
-    torch.distributed only carries those 128 bytes to the other ranks (any side channel would do), every rank calls dyf_comm_init."""
+    torch.distributed only carries those 128 bytes to the other ranks (any side channel would do), every rank calls dyf_comm_init.
+
+    Failure-safe: every collective below is entered by EVERY rank whatever went wrong locally.  Rank 0 broadcasts
+    `(ok, id | error text)` -- if it could not draw the id (e.g. no librccl to dlopen) the others see that instead of blocking
+    in the broadcast -- and the per-rank `dyf_comm_init` status is agreed with one all-reduce(MIN): either all ranks return
+    True and own a communicator, or all return False, none keeps one, and `sample_sharded` takes the torch.distributed route."""
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     from .engine import HipEngine
-    box = [HipEngine.comm_unique_id(model._engine_opts["dtype"]) if rank == 0 else None]
+    box = [None]
+    if rank == 0:
+        try:
+            box = [(True, HipEngine.comm_unique_id(model._engine_opts["dtype"]))]
+        except Exception as ex:
+            box = [(False, f"{type(ex).__name__}: {ex}")]
     dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-    model.comm_init(box[0], rank, world, hw, rows_per_rank(total_rows, world))
-    model._engine_comm_world = world
+    ok, payload = box[0]
+    if not ok:  # the same verdict on every rank: nobody calls dyf_comm_init, no further collective
+        model._comm_error = payload
+        return False
+    err = None
+    try:
+        model.comm_init(payload, rank, world, hw, rows_per_rank(total_rows, world))
+    except Exception as ex:
+        err = f"{type(ex).__name__}: {ex}"
+    dev = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+    if _all_ok(err is None, group, dev):
+        return True
+    model._comm_error = err or "dyf_comm_init failed on another rank"
+    model.comm_destroy()
+    return False
 
 
 def _unpack_stack(full: Tensor, total_rows: int, world: int) -> Tensor:
@@ -129,7 +160,10 @@ def sample_sharded(model: _Sampler, initial_condition: Tensor, static_condition:
         (static_condition.index_select(0, idx) if (hi - lo) < rpr else static_condition[lo:hi])
     model.set_row_offset(lo)
     if exchange is None:
-        exchange = "engine" if getattr(model, "_engine_comm_world", 1) == world and initial_condition.is_cuda else "torch"
+        # decided from the LIVE engine: a communicator belongs to the engine it was created on, and `_ensure_engine` replaces
+        # the engine when the grid or the batch grows (every rank launches the same rows on the same grid, so all ranks agree)
+        live = getattr(model, "engine_comm_world", None)
+        exchange = "engine" if live is not None and live() == world and initial_condition.is_cuda else "torch"
     if exchange == "engine":
         return model.sample_gathered(x, c, nb)
     if not hasattr(model, "sample_stack"):  # duck-typed samplers (tests): per-field route over the dict

@@ -323,6 +323,18 @@ class DYffusion(nn.Module):
             eng.comm_destroy()
         eng.comm_init(unique_id, rank, world)
 
+    def comm_destroy(self):
+        """Drop the live engine's communicator, if it has one (no-op otherwise)."""
+        if self._engine is not None and self._engine.comm_world != 1:
+            self._engine.comm_destroy()
+
+    def engine_comm_world(self) -> int:
+        """World size of the LIVE engine's RCCL communicator (1 = none).  A communicator is owned by the engine it was created on:
+        when `_ensure_engine` replaces the engine (new grid, larger batch) it is gone, `sample_sharded` then falls back to the
+        torch.distributed exchange until `distributed.init_engine_comm` runs again (an RCCL unique id is single-use, so the new
+        engine cannot re-join by itself)."""
+        return 1 if self._engine is None else self._engine.comm_world
+
     @torch.no_grad()
     def sample_gathered(self, initial_condition: Tensor, static_condition: Optional[Tensor], total_rows: int) -> Dict[str, Tensor]:
         """Engine-owned exchange (dyf_sample_gather): sample this rank's rows, all-gather the stack over RCCL inside the engine,

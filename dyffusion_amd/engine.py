@@ -578,7 +578,11 @@ class EngineLoss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out):
         st = getattr(ctx.owner, "_train_state", None)
-        if st is None or st.get("step_id") != ctx.step_id or st.get("consumed"):
+        # the owner's own record AND the engine-wide counter: two owners can share one engine (a DYffusion and its attached
+        # forecaster's get_loss both record into the same tape slots), and a training forward by EITHER overwrites the tapes
+        eng = None if st is None else st.get("eng")
+        if st is None or st.get("step_id") != ctx.step_id or st.get("consumed") or \
+                (eng is not None and eng.train_step_id != ctx.step_id):
             raise RuntimeError("this loss belongs to an earlier training forward (or has already been back-propagated): the "
                                "engine records one step at a time -- call .backward() on a loss before the next p_losses() / "
                                "get_loss() of the same engine, and only once")

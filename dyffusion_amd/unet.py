@@ -163,7 +163,10 @@ class Unet(nn.Module):
         if self._engine is None or (self._engine_key != "attached" and
                                     (self._engine_key[0] != key[0] or self._engine_key[1] < nb)):
             cfg = self.engine_net_config()
-            self._engine = HipEngine(cfg, cfg, hw[0], hw[1], max_batch=nb, use_graph=False, dtype=default_dtype_for(self))
+            # row_groups=1: this engine serves net_forward / the training step, never dyf_sample -- the default row groups would
+            # cost a workspace and a packed weight copy each for nothing
+            self._engine = HipEngine(cfg, cfg, hw[0], hw[1], max_batch=nb, use_graph=False, dtype=default_dtype_for(self),
+                                     row_groups=1)
             self._engine_slot, self._engine_key = L.NET_FORECASTER, key
             upload_weights(self, self._engine, self._engine_slot)
         return self._engine

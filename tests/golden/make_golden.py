@@ -10,12 +10,16 @@ import contextlib
 import json
 import os
 import sys
+import zlib
 
 import numpy as np
 import torch
 
-HERE = os.path.dirname(os.path.abspath(__file__))
-sys.path.insert(0, os.path.abspath(os.path.join(HERE, "..", "..")))
+_DIR = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.abspath(os.path.join(_DIR, "..", "..")))
+# DYF_GOLDEN_OUT=<dir>: write the fixtures somewhere else (tests/test_golden_regen.py regenerates into a scratch directory and
+# compares with the committed files bit for bit)
+HERE = os.environ.get("DYF_GOLDEN_OUT") or _DIR
 
 from oracle import init as oinit  # noqa: E402
 from oracle import ref_import  # noqa: E402
@@ -236,7 +240,7 @@ def gen_resnet_unets():
             if k.endswith(".weights"):  # LearnedSinusoidalPosEmb frequencies: randn like the reference's init
                 st[k] = torch.randn(shapes[k], generator=torch.Generator().manual_seed(5))
             if k.endswith(".norm.g"):
-                st[k] = 1.0 + 0.1 * torch.randn(shapes[k], generator=torch.Generator().manual_seed(hash(k) % 997))
+                st[k] = 1.0 + 0.1 * torch.randn(shapes[k], generator=torch.Generator().manual_seed(zlib.crc32(k.encode()) % 997))  # (not hash(k): str hashes are salted per process)
         net.load_state_dict(st, strict=True)
         g = torch.Generator().manual_seed(7)
         x = torch.randn(sp["nb"], sp["n_in"], *sp["hw"], generator=g)

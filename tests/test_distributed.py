@@ -134,3 +134,76 @@ def test_gradient_all_reduce_world2_gloo():
     for p in procs:
         p.join(timeout=60)
     assert sorted(results) == [(0, True), (1, True)]
+
+
+class _CommModel(_FakeStackModel):
+    """Duck type of the communicator surface of DYffusion (comm_init / comm_destroy / engine_comm_world)."""
+
+    _engine_opts = {"dtype": "bf16"}
+
+    def __init__(self, fail_init_on_rank=None):
+        super().__init__()
+        self.fail_init_on_rank, self.world, self.destroyed = fail_init_on_rank, 1, 0
+
+    def comm_init(self, unique_id, rank, world, hw, rows):
+        assert unique_id == b"\x07" * 128
+        if rank == self.fail_init_on_rank:
+            raise RuntimeError("ncclCommInitRank: unhandled system error (test)")
+        self.world = world
+
+    def comm_destroy(self):
+        self.destroyed += 1
+        self.world = 1
+
+    def engine_comm_world(self):
+        return self.world
+
+
+def _comm_worker(rank, world, port, q):
+    import dyffusion_amd.engine as E
+    from dyffusion_amd.distributed import init_engine_comm
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ok = True
+    # (1) rank 0 cannot draw the unique id: every rank returns False, nobody blocks in the broadcast, nobody calls comm_init
+    def no_rccl(dtype="bf16"):
+        raise NotImplementedError("librccl not found (test)")
+    orig = E.HipEngine.comm_unique_id
+    E.HipEngine.comm_unique_id = staticmethod(no_rccl)
+    m = _CommModel()
+    ok = ok and init_engine_comm(m, (5, 4), 6) is False and m.world == 1 and "librccl" in m._comm_error
+    # (2) the id exists but ONE rank's dyf_comm_init fails: all ranks agree on False and drop their communicator
+    E.HipEngine.comm_unique_id = staticmethod(lambda dtype="bf16": b"\x07" * 128)
+    m = _CommModel(fail_init_on_rank=1)
+    ok = ok and init_engine_comm(m, (5, 4), 6) is False and m.world == 1 and m.destroyed == 1
+    # ... and sample_sharded then takes the torch route by itself (engine_comm_world() == 1), still one collective
+    g = torch.Generator().manual_seed(0)
+    x, c = torch.randn(6, 3, 5, 4, generator=g), torch.rand(6, 2, 5, 4, generator=g)
+    out = sample_sharded(m, x, c)
+    want = _fake_rollout(x, c)
+    ok = ok and all(torch.equal(out[k], want[k]) for k in want)
+    # (3) success on every rank
+    m = _CommModel()
+    ok = ok and init_engine_comm(m, (5, 4), 6) is True and m.world == world and m.destroyed == 0
+    E.HipEngine.comm_unique_id = orig
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_init_engine_comm_is_failure_safe_world2_gloo():
+    """a rank that cannot create / join the engine-owned communicator must not leave the others in a collective."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_comm_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(results) == [(0, True), (1, True)]

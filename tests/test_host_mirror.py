@@ -178,3 +178,56 @@ def test_validation_split_runs_one_outer_iteration_like_the_reference():
     long = torch.randn(3, 1 + 12, 3, 6, 5)
     out = exp.validation_step({"dynamics": long.clone()}, dataloader_idx=1)  # second val loader: the full autoregressive rollout
     assert len(calls) == 3 and "t12_preds" in out
+
+
+def test_boundary_metadata_key_accepts_inference_tensors():
+    """Lightning's evaluation loops move the batch to the device under torch.inference_mode(); such tensors have no
+    version counter (`_version` raises), and the per-batch metadata cache key must not read it."""
+    import torch
+    from dyffusion_amd.boundary import PhysicalSystemsBoundaryConditions
+
+    bc = PhysicalSystemsBoundaryConditions("navier-stokes", engine=None)
+    with torch.inference_mode():
+        meta = {"fixed_mask": torch.zeros(2, 3, 5, 4, dtype=torch.bool), "in_velocity": torch.ones(2, 1),
+                "vertices": torch.zeros(2, 2, 5, 4)}
+    assert meta["fixed_mask"].is_inference()
+    key = bc._source_key(meta)
+    assert key == bc._source_key(meta) and key[0][1] is None
+    plain = {k: v.clone() for k, v in meta.items()}  # ordinary tensors keep their modification counter in the key
+    k0 = bc._source_key(plain)
+    plain["in_velocity"].mul_(2)
+    assert bc._source_key(plain) != k0
+
+
+def test_engine_loss_rejects_a_tape_overwritten_by_another_owner():
+    """two owners can share one engine (a DYffusion and its attached forecaster's get_loss); a training forward by the
+    OTHER owner overwrites the tape slots, so a loss of the first owner must refuse to run backward."""
+    import pytest
+    import torch
+    from dyffusion_amd.engine import EngineLoss
+
+    class Eng:
+        train_step_id = 0
+
+    class Owner:
+        def __init__(self, eng):
+            self.eng, self.ran = eng, 0
+
+        def forward(self):
+            self.eng.train_step_id += 1
+            self._train_state = dict(eng=self.eng, step_id=self.eng.train_step_id)
+            return EngineLoss.apply(torch.zeros((), requires_grad=True), self, 1.0)
+
+        def _train_backward(self, upstream):
+            self.ran += 1
+
+    eng = Eng()
+    a, b = Owner(eng), Owner(eng)
+    la = a.forward()
+    la.backward()
+    assert a.ran == 1
+    la = a.forward()
+    b.forward()  # overwrites the shared tapes
+    with pytest.raises(RuntimeError, match="earlier training forward"):
+        la.backward()
+    assert a.ran == 1
