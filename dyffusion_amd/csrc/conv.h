@@ -1,6 +1,7 @@
 // Conv2d (+ fused epilogue) on NHWC bf16 activations: argument block shared by the direct and the MFMA kernels.
 #pragma once
 #include "common.h"
+#include "gn_fused.h"
 
 #include <string>
 #include <vector>
@@ -68,6 +69,10 @@ struct ConvArgs {
     // consumer (gn_apply_part_kernel) adds them in slot order, so results are reproducible run to run.
     float* gn_part;
     int gn_slots;       // set by the launcher
+    // GroupNorm FUSED into this conv's epilogue (gn_fused.h; gnf.gran != null): y = conv + bias is normalised per (sample, group),
+    // FiLM / `act` (SiLU) / `drop` / `residual` applied, and the finished activation stored -- only through launch_conv_gn_fused,
+    // which reports whether a kernel form that can do it took the launch (coef_a / coef_c are then unused)
+    GnFuse gnf;
 };
 // floats of ConvArgs::up_border for an n x (2h x 2w) x cout output
 inline size_t conv_up_border_floats(int n, int h, int w, int cout) { return (size_t)n * (4 * (size_t)w + 4 * (size_t)h - 4) * cout; }
@@ -79,6 +84,12 @@ hipError_t launch_conv(const ConvArgs& a, int path, hipStream_t stream);
 // launch_conv for a conv whose output feeds a GroupNorm (a.gn_part != null): *gn_slots receives the partial-sum slots per sample
 // the launch wrote (0: this kernel form does not produce statistics -- the caller runs the statistics pass)
 hipError_t launch_conv_stats(const ConvArgs& a, int path, hipStream_t stream, int* gn_slots);
+// launch_conv for a conv followed by GroupNorm + FiLM + SiLU + Dropout (+ residual), a.gnf filled in except `slots`: *fused = the
+// launch did all of it (conv_up_halo_kernel<5, 2>, conv_igemm2_kernel<2, true>); false = NOTHING was launched (the shape / batch is
+// not served by a fused form: the caller runs the conv and the GroupNorm kernels)
+hipError_t launch_conv_gn_fused(const ConvArgs& a, int path, hipStream_t stream, bool* fused);
+int conv_gn_fused_max_slots(int h, int w);
+int conv_igemm2_gn_slots(int ho, int wo);  // slots per sample of the fused conv_igemm2_kernel<2> on an ho x wo output plane (0: not served)  // upper bound of GnFuse::slots on an h x w plane (sizing of GnFuse::gran), 0 = never fused
 int conv_halo5_gn_slots(int h, int w);  // slots per sample of conv_up_halo_kernel<5> on an h x w plane (sizing of gn_part)
 void pack_up2x_weights(const float* w, int cout, int cin, el16_t* out);
 // halo form of the fused x2-upsample conv (conv_up_halo.hip): 16x16 low-res tile x 4 phases x 64 channels per workgroup

@@ -751,6 +751,67 @@ hipError_t launch_conv_stats(const ConvArgs& a_in, int path, hipStream_t stream,
     return hipGetLastError();
 }
 
+// ---- GroupNorm fused into the conv (gn_fused.h).  The form is used exactly where the un-fused launch would have taken
+// conv_up_halo_kernel<5> / conv_igemm2_kernel<2> (same tile thresholds), when a sample's slots are few enough to sweep.
+static const int GN_FUSE_MAX_SLOTS = 64;  // gn_fuse_sweep<16>: 4 slot classes x 16
+
+int conv_gn_fused_max_slots(int h, int w) {
+    int best = 0;
+    const int s5 = conv_halo5_gn_slots(h, w);
+    if (s5 <= GN_FUSE_MAX_SLOTS) best = s5;
+    const int si = conv_igemm2_gn_slots(h, w);
+    if (si > 0 && si <= GN_FUSE_MAX_SLOTS) best = std::max(best, si);
+    return best;
+}
+
+hipError_t launch_conv_gn_fused(const ConvArgs& a_in, int path, hipStream_t stream, bool* fused) {
+    *fused = false;
+    ConvArgs a = a_in;  // (DYF_GN_FUSED=0 is read per engine, dyf_engine_create: the caller then never asks)
+    a.gn_part = nullptr;
+    a.gn_slots = 0;
+    const GnFuse& G = a.gnf;
+    if (path != 1 || G.gran == nullptr || G.epoch == nullptr || a.act != ACT_SILU || a.drop.mode == 2 || a.out_el16 == nullptr ||
+        a.out_f32 != nullptr || a.up2x || !conv_mfma_supported(a))
+        return hipSuccess;
+    const int cpg = G.groups > 0 ? a.cout / G.groups : 0;
+    if (cpg < 8 || cpg % 8 != 0 || 64 % cpg != 0 || cpg * G.groups != a.cout) return hipSuccess;  // a group lies inside one 64-channel block
+    const long long nsel = a.n_sel > 0 ? a.n_sel : a.n;
+    if (a.kh == 3 && a.kw == 3 && a.stride == 1 && a.pad == 1 && a.cout % 64 == 0 && a.cout % 256 != 0) {
+        static const bool h5 = !(getenv("DYF_HALO5") && atoi(getenv("DYF_HALO5")) == 0);
+        static const long long h5_min = getenv("DYF_HALO5_MIN_TILES") ? atoll(getenv("DYF_HALO5_MIN_TILES")) : 256;
+        ConvArgs b = a;
+        b.wpk_up_frag = conv_lookup_halo3_frag(b.wpk);
+        const long long ty = (a.h + 15) / 16, tx = (a.w + 31) / 32;
+        const long long tiles5 = nsel * ty * tx * (a.cout / 64);
+        const bool covers = 10ll * a.h * a.w >= 6ll * ty * 16 * tx * 32;
+        const int slots = conv_halo5_gn_slots(a.h, a.w);
+        if (h5 && b.wpk_up_frag && covers && tiles5 >= h5_min && slots <= GN_FUSE_MAX_SLOTS && slots <= G.max_slots && conv_halo5_supported(b)) {
+            b.gnf.slots = slots;
+            *fused = true;
+            return launch_conv_halo5(b, stream);
+        }
+    }
+    static const bool use_igemm2 = !(getenv("DYF_IGEMM2") && atoi(getenv("DYF_IGEMM2")) == 0);
+    if (use_igemm2 && a.cout % 128 == 0) {
+        ConvArgs b = a;
+        if (!b.wpk_frag) b.wpk_frag = conv_lookup_frag(b.wpk);
+        const long long tiles2 = ((nsel * a.ho * a.wo + 255) / 256) * (a.cout / 128);
+        // un-fused, the 256 x 128 tiles pay off from 384 tiles on (below that conv_igemm_kernel<128, 128> is ahead); fused, the form
+        // also saves the three GroupNorm launches behind it: taken from 256 tiles on (the 128 -> 128 convs of the 15 x 15 level at
+        // 300 rows: 264 tiles) -- DYF_GN_FUSE_MIN_TILES overrides, DYF_IGEMM2_MIN_TILES (tests) wins
+        const char* mt = getenv("DYF_IGEMM2_MIN_TILES");
+        const char* mf = getenv("DYF_GN_FUSE_MIN_TILES");
+        const long long min_tiles = mt ? atoll(mt) : mf ? atoll(mf) : 256;
+        const int slots = conv_igemm2_gn_slots(a.ho, a.wo);
+        if (tiles2 >= min_tiles && slots > 0 && slots <= GN_FUSE_MAX_SLOTS && slots <= G.max_slots && conv_igemm2_supported(b)) {
+            b.gnf.slots = slots;
+            *fused = true;
+            return launch_conv_igemm2(b, stream);
+        }
+    }
+    return hipSuccess;
+}
+
 // Host-side weight transform for the fused x2-upsample conv (see the kernel header): w [cout][cin][3][3] fp32 ->
 // [4 phases][cout][16 taps][cin] bf16.
 void pack_up2x_weights(const float* w, int cout, int cin, el16_t* out) {

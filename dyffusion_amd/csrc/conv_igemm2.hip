@@ -15,6 +15,7 @@
 // In-order completion of vector-memory loads makes the per-step wait free: the gather of step s+1 is issued BEFORE the
 // weight loads of step s, so by the time the last of those has been consumed the gather has landed.
 #include "conv.h"
+#include "gn_fused.h"
 
 #include <cstdlib>
 #include <mutex>
@@ -40,7 +41,11 @@ constexpr int TH = BM / 16;            // 2-D tile: 16 rows of 16 pixels
 //         (64 B/clk/CU of LDS reads at MFMA peak); every weight fragment feeds 2 instead of 4, i.e. the weight stream costs
 //         64 B/clk/CU of L1 bandwidth at peak -- its limit, fine at the ~50 % this kernel reaches (conv_igemm_kernel<256, 64>
 //         stages both operands through LDS and stops at 19 %).
-template <int WN>
+// GNF (WN = 2): GroupNorm fused into the epilogue (gn_fused.h; ConvArgs::gnf).  A wave's slab of 128 output rows lies in at most
+// two samples (the launcher requires planes of >= 128 pixels): it publishes the octet sums of each, sweeps the granules of each
+// (slot = slab index inside the sample, in row order) and keeps both (A, C) tables in its OWN 1 KB of LDS -- no workgroup barrier;
+// every lane then picks the table of its row's sample.
+template <int WN, bool GNF = false>
 __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(ConvArgs a, int M, int tiles_m, int tiles_n) {
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -49,6 +54,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(ConvArgs a, int M, 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr int BN = 64 * WN, MT = WN == 2 ? 4 : 2;  // channels per workgroup, 32-pixel sub-tiles per wave
     constexpr int STEP_BYTES = BN * 128;              // weights of one K step of one column block: BN channels x 64 k bf16
+    static_assert(!GNF || WN == 2, "the fused GroupNorm epilogue exists for WN = 2");
     const int wm = WN == 2 ? wave >> 1 : wave, wn = WN == 2 ? wave & 1 : 0;
     const int l31 = lane & 31, hi = lane >> 5;
 
@@ -233,6 +239,93 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(ConvArgs a, int M, 
     // may alias), and a branch join makes the compiler's s_waitcnt model fall back to vmcnt(0) as well: the 16 steps of a wave's
     // epilogue used to expose 16 store round trips.
     // FAST: 16-bit output only, no residual (every hot launch): those pointer tests are wave-uniform branches, and joins too.
+    // ---- GNF phases A and B (gn_fused.h): statistics of y = acc + bias per (sample, octet), exchanged through granules
+    float* const gcf = (float*)(smem + LDS_TOTAL) + wave * 256;  // this wave's (A, C) tables: [2 samples][A[64] | C[64]]
+    int g_bnd = 0x7fffffff;  // first output row (index into M) of the slab's SECOND sample
+    if constexpr (GNF) {
+        const GnFuse& G = a.gnf;
+        const uint32_t tag = (*G.epoch << 8) | G.conv_tag;
+        const int slab0 = tm * BM + wm * 128;  // first row of this wave's slab
+        const int ch0 = tn * BN + wn * 64;     // first channel of this wave's block
+        const int oct = a.cout >> 3, cpg = a.cout / G.groups;
+        int nA, slotA, nslotsA, nslotsB = 0, slotB = 0;
+        bool cross = false;
+        if (tile2d) {
+            nA = t_img;
+            nslotsA = tiles_per_img * 2;
+            slotA = (tm - t_img * tiles_per_img) * 2 + wm;
+        } else {
+            nA = slab0 / plane;
+            g_bnd = (nA + 1) * plane;
+            cross = slab0 + 128 > g_bnd && g_bnd < M;
+            const int fA = (nA * plane) >> 7;
+            slotA = (slab0 >> 7) - fA;
+            nslotsA = ((g_bnd - 1) >> 7) - fA + 1;
+            if (cross) {
+                const int fB = g_bnd >> 7;
+                slotB = (slab0 >> 7) - fB;  // = 0: the slab that crosses into a sample is that sample's first
+                nslotsB = ((g_bnd + plane - 1) >> 7) - fB + 1;
+            }
+        }
+        auto publish = [&](int n_img, int slot, bool second) {
+            float mval[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int row = slab0 + mt * 32 + l31;
+                const bool in = tile2d ? true : (second ? (row >= g_bnd && row < M) : (row < g_bnd && row < M));
+                mval[mt] = in ? 1.0f : 0.0f;
+            }
+            float w[16];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 b4 = *(const float4*)(G.bias + ch0 + nt * 32 + 8 * g + 4 * hi);
+                    float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        const float y0 = acc[mt][nt][4 * g + 0] + b4.x, y1 = acc[mt][nt][4 * g + 1] + b4.y;
+                        const float y2 = acc[mt][nt][4 * g + 2] + b4.z, y3 = acc[mt][nt][4 * g + 3] + b4.w;
+                        s1 = fmaf(mval[mt], (y0 + y1) + (y2 + y3), s1);
+                        s2 = fmaf(mval[mt], fmaf(y0, y0, fmaf(y1, y1, fmaf(y2, y2, y3 * y3))), s2);
+                    }
+                    w[2 * (4 * nt + g)] = s1;
+                    w[2 * (4 * nt + g) + 1] = s2;
+                }
+#pragma unroll
+            for (int half = 8, d = 1; half >= 1; half >>= 1, d <<= 1) {  // reduce-scatter butterfly (conv_up_halo_kernel<5>)
+                const bool up = (lane & d) != 0;
+#pragma unroll
+                for (int j = 0; j < half; ++j) {
+                    const float send = up ? w[j] : w[j + half];
+                    const float keep = up ? w[j + half] : w[j];
+                    w[j] = keep + __shfl_xor(send, d, 64);
+                }
+            }
+            float tot = w[0];
+            tot += __shfl_xor(tot, 16, 64);
+            tot += __shfl_xor(tot, 32, 64);
+            if (lane < 16) {
+                const int idx = 8 * (lane & 1) + 4 * ((lane >> 1) & 1) + 2 * ((lane >> 2) & 1) + ((lane >> 3) & 1);
+                gn_store_granule(G.gran + (((size_t)n_img * G.max_slots + slot) * oct + (ch0 >> 3)) * 2 + idx, tag, tot);
+            }
+        };
+        const bool liveA = slab0 < M;  // slabs beyond the last row publish nothing and need no coefficients
+        if (liveA) publish(nA, slotA, false);
+        if (cross) publish(nA + 1, slotB, true);
+        const double inv_count = 1.0 / ((double)plane * cpg);
+        auto coefs = [&](int n_img, int nslots, float* dst) {
+            const float2 mr = gn_fuse_sweep<16>(G.gran + ((size_t)n_img * G.max_slots * oct + (ch0 >> 3)) * 2, oct * 2, nslots, tag, cpg,
+                                                inv_count, G.err, lane);
+            const float2 ac = gn_fuse_coef(G, ch0 + lane, a.coef_div > 1 ? n_img / a.coef_div : n_img, mr);
+            dst[lane] = ac.x;
+            dst[64 + lane] = ac.y;
+        };
+        if (G.slots < 0) nslotsA = nslotsB = 0;  // timing experiment
+        if (liveA) coefs(nA, nslotsA, gcf);
+        if (cross) coefs(nA + 1, nslotsB, gcf + 128);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // this wave's own table writes, read back below by its other lanes
+    }
     auto epilogue = [&](auto act_c, auto mode_c, auto full_c, auto fast_c) {
         constexpr int ACT = decltype(act_c)::value, MODE = decltype(mode_c)::value;
         constexpr bool FULL = decltype(full_c)::value, FAST = decltype(fast_c)::value;
@@ -259,6 +352,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(ConvArgs a, int M, 
         const float ps = drop_prescale<ACT, MODE>(a.drop);  // dropout scale folded into the affine
         auto load_coef = [&](int step, float4 (&c)[4]) {
             const int mt = step >> 2, cg0 = ((step >> 1) & 1) * 32 + 16 * (step & 1);
+            if constexpr (GNF) {  // the table of the row's sample (first / second sample of the slab), channels + 4 * hi
+                const float* t = gcf + ((!tile2d && tm * BM + wm * (32 * MT) + mt * 32 + l31 >= g_bnd) ? 128 : 0) + 4 * hi + cg0;
+                c[0] = *(const float4*)(t);
+                c[1] = *(const float4*)(t + 8);
+                c[2] = *(const float4*)(t + 64);
+                c[3] = *(const float4*)(t + 72);
+                return;
+            }
             c[0] = *(const float4*)(a.coef_a + cb_[mt] + cg0);
             c[1] = *(const float4*)(a.coef_a + cb_[mt] + cg0 + 8);
             c[2] = *(const float4*)(a.coef_c + cb_[mt] + cg0);
@@ -266,6 +367,16 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(ConvArgs a, int M, 
         };
         float4 cf[2][4];
         load_coef(0, cf[0]);
+        // GNF: the ResnetBlock's shortcut, fetched one step ahead of its use, BEFORE the previous step's stores (as the coefficients)
+        const bool gnf_res = GNF && a.residual != nullptr;
+        uint2 rs[2][2];
+        auto load_res = [&](int step, uint2 (&r)[2]) {
+            const int mt = step >> 2, cg0 = ((step >> 1) & 1) * 32 + 16 * (step & 1);
+            const size_t e0 = (size_t)(ob_[mt] + cg0 + 4 * hi);
+            r[0] = valid_[mt] ? *(const uint2*)(a.residual + e0) : make_uint2(0, 0);
+            r[1] = valid_[mt] ? *(const uint2*)(a.residual + e0 + 8) : make_uint2(0, 0);
+        };
+        if (gnf_res) load_res(0, rs[0]);
         // FAST + FULL (every hot launch): a wave's 32 x 64 sub-tile is 32 whole 128-byte lines; its 16-byte rows go through a per-wave
         // LDS staging tile, half at a time, and leave as stores of 8 whole lines (stored from the registers a store instruction
         // writes a 32-byte piece of 32 lines -- worth 20 % of the store-bound conv_enc0_stem_kernel, 1-5 % of the halo kernels)
@@ -277,6 +388,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(ConvArgs a, int M, 
         for (int step = 0; step < 4 * MT; ++step) {
             const int mt = step >> 2, nt = (step >> 1) & 1, g2 = step & 1;
             if (step + 1 < 4 * MT) load_coef(step + 1, cf[(step + 1) & 1]);
+            if (gnf_res && step + 1 < 4 * MT) load_res(step + 1, rs[(step + 1) & 1]);
             const float4 ca0 = cf[step & 1][0], ca1 = cf[step & 1][1], cc0 = cf[step & 1][2], cc1 = cf[step & 1][3];
             const bool valid = valid_[mt];
             const uint32_t ob = ob_[mt], row0 = row0_[mt];
@@ -292,7 +404,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(ConvArgs a, int M, 
                     for (int t = 0; t < 8; ++t) v[t] = fmaf(acc[mt][nt][8 * g2 + t], ca[t], cc[t]);
                     act_drop_fixed<4, ACT, MODE, true>(v, e0, row0, a.drop, key);
                     act_drop_fixed<4, ACT, MODE, true>(v + 4, e0 + 8, row0, a.drop, key);
-                    if (!FAST && a.residual) {
+                    if (gnf_res) {
+                        const uint32_t rw[4] = {rs[step & 1][0].x, rs[step & 1][0].y, rs[step & 1][1].x, rs[step & 1][1].y};
+#pragma unroll
+                        for (int t = 0; t < 8; ++t)
+                            v[t] += (t & 1) ? el16_hi(rw[t >> 1]) : el16_lo(rw[t >> 1]);
+                    } else if (!FAST && a.residual) {
                         const uint2 r0 = valid ? *(const uint2*)(a.residual + (size_t)e0) : make_uint2(0, 0);
                         const uint2 r1 = valid ? *(const uint2*)(a.residual + (size_t)e0 + 8) : make_uint2(0, 0);
                         const uint32_t rw[4] = {r0.x, r0.y, r1.x, r1.y};
@@ -337,7 +454,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(ConvArgs a, int M, 
         }
     };
     const bool tile_full = tile2d || (tm + 1) * BM <= M;  // wave-uniform: every row of the tile is an output pixel
-    const bool fast = a.out_el16 != nullptr && a.out_f32 == nullptr && a.residual == nullptr;
+    const bool fast = a.out_el16 != nullptr && a.out_f32 == nullptr && (GNF || a.residual == nullptr);  // GNF adds its residual itself
     auto by_full = [&](auto act_c, auto mode_c) {
         if (tile_full && fast) epilogue(act_c, mode_c, std::true_type{}, std::true_type{});
         else if (tile_full) epilogue(act_c, mode_c, std::true_type{}, std::false_type{});
@@ -348,11 +465,23 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(ConvArgs a, int M, 
         else if (a.drop.mode == 1) by_full(act_c, std::integral_constant<int, 1>{});
         else by_full(act_c, std::integral_constant<int, 2>{});
     };
+    if constexpr (GNF) {  // SiLU, dropout off or from the engine's generator (the launcher checks)
+        if (a.drop.mode == 1) by_full(std::integral_constant<int, ACT_SILU>{}, std::integral_constant<int, 1>{});
+        else by_full(std::integral_constant<int, ACT_SILU>{}, std::integral_constant<int, 0>{});
+        return;
+    }
     if (a.act == ACT_RELU) by_mode(std::integral_constant<int, ACT_RELU>{});
     else if (a.act == ACT_LEAKY) by_mode(std::integral_constant<int, ACT_LEAKY>{});
     else if (a.act == ACT_SILU) by_mode(std::integral_constant<int, ACT_SILU>{});
     else by_mode(std::integral_constant<int, ACT_NONE>{});
 #endif
+}
+
+int conv_igemm2_gn_slots(int ho, int wo) {
+    const int plane = ho * wo;
+    if (wo % 16 == 0 && ho % TH == 0) return (wo / 16) * (ho / TH) * 2;  // 2-D tiles: two 128-row slabs per tile, all inside the sample
+    if (plane < 128) return 0;  // a slab would touch more than two samples
+    return (plane + 127) / 128 + 1;
 }
 
 // wpk [cout][taps][cin] bf16 -> MFMA fragment order [column block tn (128 ch)][K step = chunk*taps + tap][wn][ks][half]
@@ -388,6 +517,7 @@ bool conv_igemm2_supported(const ConvArgs& a) {
 
 hipError_t conv_igemm2_init() {
     hipError_t e = hipFuncSetAttribute((const void*)conv_igemm2_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)(conv_igemm2_kernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL + 4096);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv_igemm2_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
     return e;
 }
@@ -405,6 +535,14 @@ hipError_t launch_conv_igemm2(const ConvArgs& a, hipStream_t stream) {
         const long long sel = a.n_sel > 0 ? ((long long)a.n_sel * a.ho * a.wo + BM - 1) / BM : tiles_m;
         const long long tb = sel * (a.cout / 128), ts = sel * (a.cout / 64);
         small = 0.56 * (double)((ts + 511) / 512) < 0.92 * (double)((tb + 511) / 512);
+    }
+    if (a.gnf.gran != nullptr) {  // GroupNorm fused (launch_conv_gn_fused checked the shape): + 4 KB of LDS for the waves' (A, C) tables
+        dyf_form_note("conv_igemm2_kernel<2>+gn_fused", a.n);
+        const int tiles_n = a.cout / 128;
+        ConvArgs b = a;
+        if (getenv("DYF_GN_FUSE_NOWAIT")) b.gnf.slots = -1;  // timing experiment (WRONG results): no granule sweep
+        hipLaunchKernelGGL((conv_igemm2_kernel<2, true>), dim3(tiles_m * tiles_n), dim3(256), LDS_TOTAL + 4096, stream, b, (int)M, tiles_m, tiles_n);
+        return hipGetLastError();
     }
     dyf_form_note(small ? "conv_igemm2_kernel<1>" : "conv_igemm2_kernel<2>", a.n);
     if (!small) {

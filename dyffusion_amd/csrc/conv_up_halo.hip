@@ -28,6 +28,7 @@
 // wave tiles, 1 workgroup/CU 1105 -> this form 1200 (dense upsample, corrections in-kernel) / 1310 (plain 3x3) -> corrections
 // moved to the ring kernel.
 #include "conv.h"
+#include "gn_fused.h"
 
 #include <algorithm>
 #include <type_traits>
@@ -102,11 +103,15 @@ struct HaloCfg {
 // conv of the ResNet-UNet: its activation follows the GroupNorm).  With all twelve (activation x dropout mode) epilogues in one
 // kernel the SP = 5 form sits at 256 registers with spill slots; alone this one allocates without spilling: level-0 convs of the
 // OISST rollout 121.3 -> 114.7 us (300 rows), 51.7 -> 48.7 us (100 rows).
-template <int SP, bool PLAIN_EPI = false>
+// EPI = 2 (SP = 5 only): GroupNorm fused into this conv -- in-launch statistics exchange between the workgroups of a sample, then
+// normalise + FiLM + SiLU + dropout (+ residual) in the epilogue (gn_fused.h; ConvArgs::gnf).
+template <int SP, int EPI = 0>
 __global__ __launch_bounds__(256, 2) void conv_up_halo_kernel(ConvArgs a, int tiles_x, int tiles_per_img, int tiles_m,
                                                               int tiles_n, int xmode) {
 #if defined(__HIP_DEVICE_COMPILE__)
     using H = HaloCfg<SP>;
+    constexpr bool PLAIN_EPI = EPI == 1;
+    static_assert(EPI != 2 || SP == 5, "the fused GroupNorm epilogue exists for SP = 5");
     constexpr int HALO_W = H::W, HALO_REAL = H::REAL, HALO_BYTES = H::BYTES, HOFF_OFF = H::HOFF_OFF;
     constexpr int HALO_INSTR = H::INSTR, HALO_PER_WAVE = H::PER_WAVE;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -508,6 +513,130 @@ __global__ __launch_bounds__(256, 2) void conv_up_halo_kernel(ConvArgs a, int ti
                                  (uint32_t)(tn * 64)
                            : o0;
     const uint32_t smt_stride = SP == 1 ? (uint32_t)(4 * a.up_wo_store * a.cout) : mt_stride;
+    if constexpr (EPI == 2) {
+        // ---- GroupNorm fused (gn_fused.h).  Phase A: (sum, sum of squares) of y = acc + bias per 8-channel octet over this wave's
+        // 128 pixels (pixels beyond a ragged plane masked by a 0 / 1 factor), reduce-scatter butterfly, 16 granules per wave.
+        const GnFuse& G = a.gnf;
+        const uint32_t tag = (*G.epoch << 8) | G.conv_tag;
+        {
+            float mval[4];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) mval[mt] = (lane_valid && orow0 + 2 * mt < a.ho) ? 1.0f : 0.0f;
+            float w[16];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 b4 = *(const float4*)(G.bias + ch_blk + nt * 32 + 8 * g + 4 * hi);
+                    float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt) {
+                        const float y0 = acc[nt][mt][4 * g + 0] + b4.x, y1 = acc[nt][mt][4 * g + 1] + b4.y;
+                        const float y2 = acc[nt][mt][4 * g + 2] + b4.z, y3 = acc[nt][mt][4 * g + 3] + b4.w;
+                        s1 = fmaf(mval[mt], (y0 + y1) + (y2 + y3), s1);
+                        s2 = fmaf(mval[mt], fmaf(y0, y0, fmaf(y1, y1, fmaf(y2, y2, y3 * y3))), s2);
+                    }
+                    w[2 * (4 * nt + g)] = s1;
+                    w[2 * (4 * nt + g) + 1] = s2;
+                }
+#pragma unroll
+            for (int half = 8, d = 1; half >= 1; half >>= 1, d <<= 1) {
+                const bool up = (lane & d) != 0;
+#pragma unroll
+                for (int j = 0; j < half; ++j) {
+                    const float send = up ? w[j] : w[j + half];
+                    const float keep = up ? w[j + half] : w[j];
+                    w[j] = keep + __shfl_xor(send, d, 64);
+                }
+            }
+            float tot = w[0];
+            tot += __shfl_xor(tot, 16, 64);
+            tot += __shfl_xor(tot, 32, 64);
+            if (lane < 16) {
+                const int idx = 8 * (lane & 1) + 4 * ((lane >> 1) & 1) + 2 * ((lane >> 2) & 1) + ((lane >> 3) & 1);
+                const int slot = t_in * NWAVES + wave;
+                gn_store_granule(G.gran + (((size_t)n_img * G.max_slots + slot) * (a.cout >> 3) + tn * 8) * 2 + idx, tag, tot);
+            }
+        }
+        // residual (the ResnetBlock's shortcut, added last): two 8-byte pieces per (nt, mt, g2) step, fetched one (nt, mt) group AHEAD
+        // of its use -- a load issued behind a store waits for that store's acknowledgement (gfx9 counts stores in vmcnt), so the
+        // loads of group s + 1 go out before the stores of group s; the first group goes out here, under the sweep
+        const bool has_res = a.residual != nullptr;
+        uint2 rq[2][4];
+        auto load_res = [&](int nt, int mt, uint2 (&r)[4]) {
+            const bool st_ok = lane_valid && orow0 + 2 * mt < a.ho;
+#pragma unroll
+            for (int g2 = 0; g2 < 2; ++g2) {
+                const size_t e0 = (size_t)(o0 + mt * mt_stride + nt * 32 + 16 * g2 + 4 * hi);
+                r[2 * g2] = st_ok ? *(const uint2*)(a.residual + e0) : make_uint2(0, 0);
+                r[2 * g2 + 1] = st_ok ? *(const uint2*)(a.residual + e0 + 8) : make_uint2(0, 0);
+            }
+        };
+        if (has_res) load_res(0, 0, rq[0]);
+        // Phase B: wave 0 sweeps the sample's granules and parks (A, C) of the block's 64 channels in LDS (its own 512 bytes behind
+        // the halo: the other waves may still be in their K loop)
+        float* cfA = (float*)(smem + H::LDS_TOTAL);
+        float* cfC = cfA + 64;
+        if (wave == 0) {
+            const int cpg = a.cout / G.groups;
+            const float2 mr = gn_fuse_sweep<16>(G.gran + ((size_t)n_img * G.max_slots * (a.cout >> 3) + tn * 8) * 2, (a.cout >> 3) * 2,
+                                                G.slots, tag, cpg, 1.0 / ((double)a.ho * a.wo * cpg), G.err, lane);
+            const float2 ac = gn_fuse_coef(G, ch_blk + lane, a.coef_div > 1 ? n_img / a.coef_div : n_img, mr);
+            cfA[lane] = ac.x;
+            cfC[lane] = ac.y;
+        }
+        __syncthreads();
+        // Phase C: y * A + C -> SiLU -> dropout -> (+ residual) -> 16-bit, stored as the plain epilogue stores
+        auto fused = [&](auto mode_c) {
+            constexpr int MODE = decltype(mode_c)::value;
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+                float ca[2][8], cc[2][8];
+#pragma unroll
+                for (int g2 = 0; g2 < 2; ++g2) {
+                    const int cg0 = nt * 32 + 16 * g2 + 4 * hi;
+                    const float4 a0 = *(const float4*)(cfA + cg0), a1 = *(const float4*)(cfA + cg0 + 8);
+                    const float4 c0 = *(const float4*)(cfC + cg0), c1 = *(const float4*)(cfC + cg0 + 8);
+                    ca[g2][0] = a0.x; ca[g2][1] = a0.y; ca[g2][2] = a0.z; ca[g2][3] = a0.w;
+                    ca[g2][4] = a1.x; ca[g2][5] = a1.y; ca[g2][6] = a1.z; ca[g2][7] = a1.w;
+                    cc[g2][0] = c0.x; cc[g2][1] = c0.y; cc[g2][2] = c0.z; cc[g2][3] = c0.w;
+                    cc[g2][4] = c1.x; cc[g2][5] = c1.y; cc[g2][6] = c1.z; cc[g2][7] = c1.w;
+                }
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+                    const int s = nt * 4 + mt;
+                    if (has_res && s + 1 < 8) load_res((s + 1) >> 2, (s + 1) & 3, rq[(s + 1) & 1]);
+                    const bool st_ok = lane_valid && orow0 + 2 * mt < a.ho;
+#pragma unroll
+                    for (int g2 = 0; g2 < 2; ++g2) {
+                        const int cg0 = nt * 32 + 16 * g2;
+                        const uint32_t e0 = o0 + mt * mt_stride + cg0 + 4 * hi;
+                        float v[8];
+#pragma unroll
+                        for (int t = 0; t < 8; ++t) v[t] = fmaf(acc[nt][mt][8 * g2 + t], ca[g2][t], cc[g2][t]);
+                        act_drop_fixed<4, ACT_SILU, MODE, true>(v, e0, row0, a.drop, key);
+                        act_drop_fixed<4, ACT_SILU, MODE, true>(v + 4, e0 + 8, row0, a.drop, key);
+                        if (has_res) {
+                            const uint2 r0 = rq[s & 1][2 * g2], r1 = rq[s & 1][2 * g2 + 1];
+                            const uint32_t rw[4] = {r0.x, r0.y, r1.x, r1.y};
+#pragma unroll
+                            for (int t = 0; t < 8; ++t) v[t] += (t & 1) ? el16_hi(rw[t >> 1]) : el16_lo(rw[t >> 1]);
+                        }
+                        uint32_t p0 = pack_el16x2(v[0], v[1]), p1 = pack_el16x2(v[2], v[3]);
+                        uint32_t q0 = pack_el16x2(v[4], v[5]), q1 = pack_el16x2(v[6], v[7]);
+                        const auto s0 = __builtin_amdgcn_permlane32_swap(p0, q0, false, false);
+                        const auto s1 = __builtin_amdgcn_permlane32_swap(p1, q1, false, false);
+                        uint4 o;
+                        o.x = s0[0]; o.y = s1[0]; o.z = s0[1]; o.w = s1[1];
+                        if (st_ok) *(uint4*)(a.out_el16 + (size_t)(o0 + mt * mt_stride + cg0 + 8 * hi)) = o;
+                    }
+                }
+            }
+        };
+        if (a.drop.mode == 1) fused(std::integral_constant<int, 1>{});
+        else fused(std::integral_constant<int, 0>{});
+        return;
+    }
     // (activation, dropout mode) are wave-uniform: the whole epilogue is instantiated per pair and dispatched once
     auto epilogue = [&](auto act_c, auto mode_c) {
         constexpr int ACT = decltype(act_c)::value, MODE = decltype(mode_c)::value;
@@ -905,7 +1034,8 @@ void pack_halo3_frag64(const el16_t* wpk, int cout, int cin, el16_t* out) {
 }
 
 bool conv_halo5_supported(const ConvArgs& a) {
-    if (a.up2x || a.wpk_up_frag == nullptr || a.out_el16 == nullptr || a.out_f32 != nullptr || a.residual != nullptr) return false;
+    // (a residual is only added by the fused-GroupNorm epilogue, EPI = 2)
+    if (a.up2x || a.wpk_up_frag == nullptr || a.out_el16 == nullptr || a.out_f32 != nullptr || (a.residual != nullptr && a.gnf.gran == nullptr)) return false;
     if (a.kh != 3 || a.kw != 3 || a.stride != 1 || a.pad != 1 || a.pix_pitch0 != 0) return false;
     if (!(a.c0 > 0 && a.c0 % 64 == 0 && (a.c1 == 0 || a.c1 == a.c0) && a.cout % 64 == 0)) return false;
     if (a.ho != a.h || a.wo != a.w) return false;
@@ -923,10 +1053,16 @@ hipError_t launch_conv_halo5(const ConvArgs& a, hipStream_t stream) {
     using H5 = HaloCfg<5>;
     const int tiles_x = (a.w + H5::TW - 1) / H5::TW, tiles_per_img = tiles_x * ((a.h + H5::TH - 1) / H5::TH);
     const int tiles_m = a.n * tiles_per_img, tiles_n = a.cout / 64;
-    dyf_form_note("conv_up_halo_kernel<5>", a.n);
+    dyf_form_note(a.gnf.gran ? "conv_up_halo_kernel<5>+gn_fused" : "conv_up_halo_kernel<5>", a.n);
     static const bool plain_epi = !(getenv("DYF_HALO5_PLAIN_EPI") && atoi(getenv("DYF_HALO5_PLAIN_EPI")) == 0);
-    if (plain_epi && a.act == ACT_NONE && a.drop.mode == 0)
-        hipLaunchKernelGGL((conv_up_halo_kernel<5, true>), dim3(tiles_m * tiles_n), dim3(256), H5::LDS_TOTAL, stream, a, tiles_x,
+    if (a.gnf.gran != nullptr) {  // GroupNorm fused: + 1 KB of LDS for the per-channel (A, C) table
+        ConvArgs b = a;
+        if (getenv("DYF_GN_FUSE_NOWAIT")) b.gnf.slots = 0;  // timing experiment (WRONG results): no granule sweep
+        hipLaunchKernelGGL((conv_up_halo_kernel<5, 2>), dim3(tiles_m * tiles_n), dim3(256), H5::LDS_TOTAL + 1024, stream, b, tiles_x,
+                           tiles_per_img, tiles_m, tiles_n, 0);
+    }
+    else if (plain_epi && a.act == ACT_NONE && a.drop.mode == 0)
+        hipLaunchKernelGGL((conv_up_halo_kernel<5, 1>), dim3(tiles_m * tiles_n), dim3(256), H5::LDS_TOTAL, stream, a, tiles_x,
                            tiles_per_img, tiles_m, tiles_n, 0);
     else
         hipLaunchKernelGGL(conv_up_halo_kernel<5>, dim3(tiles_m * tiles_n), dim3(256), H5::LDS_TOTAL, stream, a, tiles_x,
@@ -1003,8 +1139,11 @@ hipError_t conv_up_halo_init() {
         e = hipFuncSetAttribute((const void*)conv_up_halo_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 HaloCfg<5>::LDS_TOTAL);
     if (e == hipSuccess)
-        e = hipFuncSetAttribute((const void*)(conv_up_halo_kernel<5, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        e = hipFuncSetAttribute((const void*)(conv_up_halo_kernel<5, 1>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 HaloCfg<5>::LDS_TOTAL);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)(conv_up_halo_kernel<5, 2>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                HaloCfg<5>::LDS_TOTAL + 1024);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)up_border_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, UB_LDS);
     return e;
 }

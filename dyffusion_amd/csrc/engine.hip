@@ -350,6 +350,7 @@ void dyf_engine_destroy(dyf_engine* e) {
     (void)dyf_comm_destroy(e);
     if (e->s_log) (void)hipFree(e->s_log);
     if (e->cap_stream) (void)hipStreamDestroy(e->cap_stream);
+    if (e->gn_err_host) (void)hipHostFree(e->gn_err_host);
     train_destroy(e);
     release_allocs(e->allocs);
     release_allocs(e->net_allocs[0]);
@@ -469,6 +470,13 @@ dyf_status dyf_engine_create(const dyf_engine_config* cfg, dyf_engine** out_engi
     ALLOC(e->rng_state, DYF_RNG_STATE_WORDS);
     ALLOC(e->row_keys, 4 * nb);  // [2 x max_batch rows][2]
 #undef ALLOC
+    // host-visible error word of the fused GroupNorm convs (gn_fused.h): pinned + mapped, read by the host without a sync
+    if (hipHostMalloc((void**)&e->gn_err_host, 64, hipHostMallocMapped) == hipSuccess) {
+        memset(e->gn_err_host, 0, 64);
+        if (hipHostGetDevicePointer((void**)&e->gn_err_dev, e->gn_err_host, 0) != hipSuccess) e->gn_err_dev = nullptr;
+    }
+    if (!e->gn_err_dev) e->gn_fuse_disabled = true;  // no way to report a timed-out sweep: keep to the three-kernel path
+    if (const char* gf = getenv("DYF_GN_FUSED")) if (atoi(gf) == 0) e->gn_fuse_disabled = true;
     {
         dyf_status rs = rn_alloc_workspace(e);
         if (rs != DYF_OK) return bail(rs, e->err);
@@ -852,6 +860,35 @@ dyf_status dyf_net_flops_executed(const dyf_engine* e, int32_t which, double* fl
     return DYF_OK;
 }
 
+// A fused GroupNorm conv (gn_fused.h) whose granule sweep timed out raised the engine's host-visible error word and NaN-poisoned
+// its output.  Checked at the head of every forward / sampling entry point (a plain host read, no synchronisation): the engine
+// then drops its captured graphs, keeps to the three-kernel GroupNorm path from now on and fails THIS call, naming the earlier one.
+static dyf_status gn_fuse_check(dyf_engine* e) {
+    bool hit = false;
+    auto one = [&](dyf_engine* x) {
+        if (x->gn_err_host && *(volatile uint32_t*)x->gn_err_host != 0u) hit = true;
+    };
+    one(e);
+    for (dyf_engine* c : e->groups) one(c);
+    if (!hit) return DYF_OK;
+    (void)hipSetDevice(e->cfg.device);
+    (void)hipDeviceSynchronize();
+    auto disable = [](dyf_engine* x) {
+        if (x->gn_err_host) *(volatile uint32_t*)x->gn_err_host = 0u;
+        x->gn_fuse_disabled = true;
+        for (auto& kv : x->graphs) {
+            if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
+            if (kv.second.graph) (void)hipGraphDestroy(kv.second.graph);
+        }
+        x->graphs.clear();
+    };
+    disable(e);
+    for (dyf_engine* c : e->groups) disable(c);
+    return fail(e, DYF_ERR_STATE,
+                "a fused GroupNorm convolution of an EARLIER call timed out waiting for its sample's statistics (that call's output was "
+                "NaN-poisoned); the engine now runs the un-fused GroupNorm kernels -- repeat the call");
+}
+
 dyf_status dyf_net_forward(dyf_engine* e, int32_t which, const float* inputs_dev, const float* time_dev,
                            const float* condition_dev, float* out_dev, int32_t nb, int32_t dropout_mode,
                            const uint8_t* const* masks_dev, void* stream) {
@@ -866,6 +903,10 @@ dyf_status dyf_net_forward(dyf_engine* e, int32_t which, const float* inputs_dev
     if (n.cfg.with_time_emb && !time_dev) return fail(e, DYF_ERR_INVALID_ARGUMENT, "time must be given when with_time_emb");
     if (dropout_mode < 0 || dropout_mode > 2) return fail(e, DYF_ERR_INVALID_ARGUMENT, "dropout_mode must be 0, 1 or 2");
     HIP_TRY(e, hipSetDevice(e->cfg.device));
+    {
+        dyf_status gs = gn_fuse_check(e);
+        if (gs != DYF_OK) return gs;
+    }
     hipStream_t st = (hipStream_t)stream;
     dyf_status s = compute_coefs(e, n, time_dev, nb, e->ws.coef_a, e->ws.coef_c, st);
     if (s != DYF_OK) return s;
@@ -1178,6 +1219,10 @@ static dyf_status sample_into_stack(dyf_engine* e, const float* initial_dev, con
     if (!e->plan.set) return fail(e, DYF_ERR_STATE, "dyf_set_plan has not been called");
     if (nb < 1 || nb > e->cfg.max_batch) return fail(e, DYF_ERR_INVALID_ARGUMENT, "batch size outside [1, max_batch]");
     if (!initial_dev) return fail(e, DYF_ERR_INVALID_ARGUMENT, "initial condition must not be null");
+    if (!e->is_group_child) {
+        dyf_status gs = gn_fuse_check(e);
+        if (gs != DYF_OK) return gs;
+    }
     if ((e->Cs > 0) != (static_dev != nullptr))
         return fail(e, DYF_ERR_INVALID_ARGUMENT, "static condition must be given iff the networks take one");
     HIP_TRY(e, hipSetDevice(e->cfg.device));

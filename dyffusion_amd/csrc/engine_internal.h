@@ -164,6 +164,11 @@ struct dyf_engine {
     dyf::TrainState* train = nullptr;  // training path (arch unet_simple), created by the first dyf_load_weights
     bool last_dec5_sparse = false;  // the most recent unet_simple forward stored dec5 in the compact sparse-column layout
     bool poison_dec5 = false;       // DYF_POISON_DEC5=1 (test hook, read once at create): NaN-fill dec5's output before its conv
+    // GroupNorm fused into the producing conv (gn_fused.h): host-visible error word (pinned, mapped) a timed-out granule sweep raises,
+    // its device alias, and the switch that sends later forwards down the three-kernel path once that has happened
+    uint32_t* gn_err_host = nullptr;
+    uint32_t* gn_err_dev = nullptr;
+    bool gn_fuse_disabled = false;
 };
 
 namespace dyf {

@@ -47,6 +47,9 @@ inline size_t gn_stats_doubles(size_t n, size_t groups) { return n * groups * (2
 hipError_t launch_gn_act(const GnActArgs& a, hipStream_t s);
 bool gn_part_supported(int c, int groups);
 
+// forward-epoch word of the fused GroupNorm convs (gn_fused.h): ++*epoch, once per forward, on the forward's stream
+hipError_t launch_gn_epoch_bump(uint32_t* epoch, hipStream_t s);
+
 // K6: channel LayerNorm (gain only, biased variance, eps 1e-5) + optional Dropout (unet.py:43-52; attention.py:12)
 struct LayerNormArgs {
     const el16_t* x;    // [pixels][c]

@@ -804,6 +804,20 @@ bool gn_part_supported(int c, int groups) {  // shapes gn_apply_part_kernel take
     return c % 8 == 0 && groups >= 1 && c % groups == 0 && (c / groups) % 8 == 0 && groups <= 64 && (chunks & (chunks - 1)) == 0 && chunks <= 256;
 }
 
+// forward-epoch word of the fused GroupNorm convs (gn_fused.h): the granule tags of a forward are built from it, so it must change
+// on every forward -- also on hipGraph replays, where kernel arguments are frozen but memory is not
+__global__ void gn_epoch_bump_kernel(uint32_t* epoch) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        uint32_t v = (*epoch + 1u) & 0x00ffffffu;
+        *epoch = v ? v : 1u;  // never 0: a zeroed granule buffer must not match
+    }
+}
+
+hipError_t launch_gn_epoch_bump(uint32_t* epoch, hipStream_t s) {
+    hipLaunchKernelGGL(gn_epoch_bump_kernel, dim3(1), dim3(64), 0, s, epoch);
+    return hipGetLastError();
+}
+
 hipError_t launch_gn_act(const GnActArgs& a, hipStream_t s) {
     const int cpg = a.c / a.groups;
     if (a.part && a.part_slots > 0 && gn_part_supported(a.c, a.groups) && a.n <= 65535) {

@@ -53,6 +53,11 @@ struct RNet {
     double* gn_stats = nullptr;    // [max_batch][groups][2]
     float* gn_part = nullptr;      // GroupNorm partial sums written by conv epilogues (ConvArgs::gn_part), gn_part_floats
     size_t gn_part_floats = 0;
+    // GroupNorm fused into the producing conv (gn_fused.h): granule buffer [max_batch][gn_max_slots][maxc / 8][2] x 8 B (zeroed
+    // once: tags never repeat), the forward-epoch word the tags are built from, 0 slots = no level of this grid is served
+    unsigned long long* gn_gran = nullptr;
+    uint32_t* gn_epoch = nullptr;
+    int gn_max_slots = 0;
     float* la_scratch = nullptr;   // LinearAttention partials + context
     size_t buf_elems = 0;          // elements of one pool buffer at max_batch
     std::vector<el16_t*> pool;
@@ -275,6 +280,17 @@ dyf_status rn_alloc_workspace(dyf_engine* e) {
             if (s != DYF_OK) return s;
         }
         {
+            int maxc = 0;
+            for (auto& b : r->blocks) maxc = std::max(maxc, b.cout);
+            for (int l = 0; l < r->nlev; ++l) r->gn_max_slots = std::max(r->gn_max_slots, conv_gn_fused_max_slots(r->lev_h[l], r->lev_w[l]));
+            if (r->gn_max_slots > 0) {
+                dyf_status s = dev_alloc(e, &r->gn_gran, (size_t)e->cfg.max_batch * r->gn_max_slots * (maxc / 8) * 2);
+                if (s != DYF_OK) return s;
+                s = dev_alloc(e, &r->gn_epoch, 64);
+                if (s != DYF_OK) return s;
+            }
+        }
+        {
             const size_t nblk = ((size_t)e->cfg.height * e->cfg.width + 1023) / 1024;
             dyf_status s = dev_alloc(e, &r->la_scratch, (size_t)e->cfg.max_batch * HEADS * (nblk * 1088 + 1024));  // partials + ctx fragments
             if (s != DYF_OK) return s;
@@ -481,6 +497,36 @@ dyf_status rn_forward(dyf_engine* e, int which, const Source* srcs, int nsrc, in
         if (_s != DYF_OK) return _s;      \
     } while (0)
 
+    // GroupNorm fused into the producing conv (gn_fused.h): one epoch per forward, one tag per conv of the forward
+    const bool gn_fuse_on = r->gn_gran != nullptr && !e->gn_fuse_disabled && o.dropout_mode != 2;
+    int gn_conv_idx = 0;
+    if (gn_fuse_on) HIP_TRY(e, launch_gn_epoch_bump(r->gn_epoch, st));
+    // conv + GroupNorm(+FiLM) + SiLU + Dropout (+ residual) in ONE launch where a fused form serves the shape; *fused = false:
+    // nothing was launched
+    auto conv_gn = [&](const el16_t* s0, int c0, const el16_t* s1, int c1, int hh, int ww, int cout, const el16_t* wpk,
+                       const float* bias, const float* gamma, const float* beta, bool with_film, int film_off, const DropSpec& drop,
+                       const el16_t* residual, el16_t* out, bool* fused) -> dyf_status {
+        *fused = false;
+        if (!gn_fuse_on || gn_conv_idx >= 255) return DYF_OK;
+        ConvArgs a{};
+        a.src0 = s0; a.c0 = c0; a.src1 = s1; a.c1 = c1; a.n = nb; a.h = hh; a.w = ww; a.ho = hh; a.wo = ww;
+        a.kh = 3; a.kw = 3; a.stride = 1; a.pad = 1; a.cout = cout; a.wpk = wpk;
+        a.coef_a = r->ones; a.coef_c = bias; a.coef_stride = 0; a.coef_div = o.coef_div;
+        a.act = ACT_SILU; a.drop = drop; a.residual = residual; a.out_el16 = out;
+        a.n_sel = e->cfg.batch_invariant ? 2 * e->cfg.max_batch : 0;
+        if (e->form_rows_scale > 1 && !e->cfg.batch_invariant) a.n_sel = nb * e->form_rows_scale;
+        a.gnf.gran = r->gn_gran; a.gnf.epoch = r->gn_epoch; a.gnf.conv_tag = (uint32_t)(gn_conv_idx + 1);
+        a.gnf.max_slots = r->gn_max_slots; a.gnf.groups = c.groups; a.gnf.bias = bias; a.gnf.gamma = gamma; a.gnf.beta = beta;
+        if (with_film) { a.gnf.film_a = o.coef_a + film_off; a.gnf.film_c = o.coef_c + film_off; a.gnf.film_stride = o.coef_stride; }
+        a.gnf.err = e->gn_err_dev;
+        const int path = (e->cfg.enable_mfma && conv_mfma_supported(a)) ? 1 : 0;
+        ProfScope prof(e, e->prof_layer == DYF_PROF_RESNET_BASE + DYF_PROF_RN_CONV3_L0 && hh == e->cfg.height && ww == e->cfg.width &&
+                              c0 + c1 == cout, nb, st);
+        HIP_TRY(e, launch_conv_gn_fused(a, path, st, fused));
+        if (*fused) ++gn_conv_idx;
+        return DYF_OK;
+    };
+
     // ResnetBlock on cat[a0 (c_a0 ch), a1 (c_a1 ch)] at hh x ww; returns the output buffer (cout channels)
     auto resblock = [&](const RBlockW& b, const el16_t* a0, int c_a0, const el16_t* a1, int c_a1, int hh, int ww,
                         el16_t** out) -> dyf_status {
@@ -490,34 +536,8 @@ dyf_status rn_forward(dyf_engine* e, int which, const Source* srcs, int nsrc, in
         const bool ask = fuse_stats && gn_part_supported(b.cout, c.groups) &&
                          (size_t)nb * conv_halo5_gn_slots(hh, ww) * (b.cout / 8) * 2 <= r->gn_part_floats;
         int slots1 = 0, slots2 = 0;
-        TRY(rconv(e, a0, c_a0, a1, c_a1, nb, hh, ww, 3, 1, 1, b.cout, b.w1, r->ones, b.b1, 0, ACT_NONE, DropSpec{}, nullptr, t1, st,
-                  ask ? r->gn_part : nullptr, &slots1));
-        GnActArgs g{};
-        g.x = t1; g.n = nb; g.hw = hh * ww; g.c = b.cout; g.groups = c.groups; g.gamma = b.g1; g.beta = b.be1;
-        if (film) { g.film_a = o.coef_a + b.film_off; g.film_c = o.coef_c + b.film_off; g.film_stride = o.coef_stride; }
-        g.act = ACT_SILU; g.drop = dc.next(c.block_dropout1); g.residual = nullptr; g.out = t1; g.stats = r->gn_stats;
-        if (slots1 > 0) { g.part = r->gn_part; g.part_slots = slots1; }
-        if (b.single) {  // double_conv_layer=False: h = block1(x); return h + residual_conv(x)
-            el16_t* tr = nullptr;
-            g.residual = a0;
-            if (b.has_res) {
-                tr = pool.get();
-                TRY(rconv(e, a0, c_a0, a1, c_a1, nb, hh, ww, 1, 1, 0, b.cout, b.wr, r->ones, b.br, 0, ACT_NONE, DropSpec{}, nullptr, tr, st));
-                g.residual = tr;
-            }
-            HIP_TRY(e, launch_gn_act(g, st));
-            if (tr) pool.put(tr);
-            *out = t1;
-            return DYF_OK;
-        }
-        {
-            ProfScope prof(e, e->prof_layer == DYF_PROF_RESNET_BASE + DYF_PROF_RN_GN_L0 && hh == H && b.cout == c.dim, nb, st);
-            HIP_TRY(e, launch_gn_act(g, st));
-        }
-        el16_t* t2 = pool.get();
-        TRY(rconv(e, t1, b.cout, nullptr, 0, nb, hh, ww, 3, 1, 1, b.cout, b.w2, r->ones, b.b2, 0, ACT_NONE, DropSpec{}, nullptr, t2, st,
-                  ask ? r->gn_part : nullptr, &slots2));
-        pool.put(t1);
+        const DropSpec drop1 = dc.next(c.block_dropout1);
+        // the shortcut first: the fused second conv adds it in its epilogue
         const el16_t* res = a0;  // identity shortcut (single source, cin == cout)
         el16_t* t3 = nullptr;
         if (b.has_res) {
@@ -525,14 +545,40 @@ dyf_status rn_forward(dyf_engine* e, int which, const Source* srcs, int nsrc, in
             TRY(rconv(e, a0, c_a0, a1, c_a1, nb, hh, ww, 1, 1, 0, b.cout, b.wr, r->ones, b.br, 0, ACT_NONE, DropSpec{}, nullptr, t3, st));
             res = t3;
         }
-        GnActArgs g2{};
-        g2.x = t2; g2.n = nb; g2.hw = hh * ww; g2.c = b.cout; g2.groups = c.groups; g2.gamma = b.g2; g2.beta = b.be2;
-        g2.act = ACT_SILU; g2.drop = dc.next(c.dropout); g2.residual = res; g2.out = t2; g2.stats = r->gn_stats;
-        if (slots2 > 0) { g2.part = r->gn_part; g2.part_slots = slots2; }
-        {
+        bool fused1 = false;
+        TRY(conv_gn(a0, c_a0, a1, c_a1, hh, ww, b.cout, b.w1, b.b1, b.g1, b.be1, film, b.film_off, drop1, b.single ? res : nullptr, t1,
+                    &fused1));
+        if (!fused1) {
+            TRY(rconv(e, a0, c_a0, a1, c_a1, nb, hh, ww, 3, 1, 1, b.cout, b.w1, r->ones, b.b1, 0, ACT_NONE, DropSpec{}, nullptr, t1, st,
+                      ask ? r->gn_part : nullptr, &slots1));
+            GnActArgs g{};
+            g.x = t1; g.n = nb; g.hw = hh * ww; g.c = b.cout; g.groups = c.groups; g.gamma = b.g1; g.beta = b.be1;
+            if (film) { g.film_a = o.coef_a + b.film_off; g.film_c = o.coef_c + b.film_off; g.film_stride = o.coef_stride; }
+            g.act = ACT_SILU; g.drop = drop1; g.residual = b.single ? res : nullptr; g.out = t1; g.stats = r->gn_stats;
+            if (slots1 > 0) { g.part = r->gn_part; g.part_slots = slots1; }
+            ProfScope prof(e, e->prof_layer == DYF_PROF_RESNET_BASE + DYF_PROF_RN_GN_L0 && hh == H && b.cout == c.dim, nb, st);
+            HIP_TRY(e, launch_gn_act(g, st));
+        }
+        if (b.single) {  // double_conv_layer=False: h = block1(x); return h + residual_conv(x)
+            if (t3) pool.put(t3);
+            *out = t1;
+            return DYF_OK;
+        }
+        el16_t* t2 = pool.get();
+        const DropSpec drop2 = dc.next(c.dropout);
+        bool fused2 = false;
+        TRY(conv_gn(t1, b.cout, nullptr, 0, hh, ww, b.cout, b.w2, b.b2, b.g2, b.be2, false, 0, drop2, res, t2, &fused2));
+        if (!fused2) {
+            TRY(rconv(e, t1, b.cout, nullptr, 0, nb, hh, ww, 3, 1, 1, b.cout, b.w2, r->ones, b.b2, 0, ACT_NONE, DropSpec{}, nullptr, t2, st,
+                      ask ? r->gn_part : nullptr, &slots2));
+            GnActArgs g2{};
+            g2.x = t2; g2.n = nb; g2.hw = hh * ww; g2.c = b.cout; g2.groups = c.groups; g2.gamma = b.g2; g2.beta = b.be2;
+            g2.act = ACT_SILU; g2.drop = drop2; g2.residual = res; g2.out = t2; g2.stats = r->gn_stats;
+            if (slots2 > 0) { g2.part = r->gn_part; g2.part_slots = slots2; }
             ProfScope prof(e, e->prof_layer == DYF_PROF_RESNET_BASE + DYF_PROF_RN_GN_L0 && hh == H && b.cout == c.dim, nb, st);
             HIP_TRY(e, launch_gn_act(g2, st));
         }
+        pool.put(t1);
         if (t3) pool.put(t3);
         *out = t2;
         return DYF_OK;

@@ -50,3 +50,14 @@ def oracle_rollout(PF, PI, mcfg, hp, x0, c, drop=None, noise_fn=None):
         return sampler.sample_loop(lambda x, t, cond: nets.unet_simple_forward(PF, mcfg, x, t, cond),
                                    lambda x, t, cond: nets.unet_simple_forward(PI, mcfg, x, t, cond, dropout=drop),
                                    x0, c, hp, noise_fn=noise_fn)
+
+
+_ORACLE_CACHE = {}
+
+
+def cached(key, fn):
+    """Memo for CPU-oracle results shared by the parametrisations of one test (bf16 / fp16 builds compare with the SAME fp32 oracle
+    output): the full-size oracle runs are what the GPU suite spends its time on."""
+    if key not in _ORACLE_CACHE:
+        _ORACLE_CACHE[key] = fn()
+    return _ORACLE_CACHE[key]

@@ -19,7 +19,7 @@ import torch
 
 from oracle import nets, sampler
 from tests import rng_host as R
-from tests.gpu_common import DEV, build_dyffusion, mirror_from_params, oracle_rollout, seeded_pair
+from tests.gpu_common import DEV, build_dyffusion, cached, mirror_from_params, oracle_rollout, seeded_pair
 from tests.helpers import jload, rel_rms
 
 pytestmark = pytest.mark.gpu
@@ -156,9 +156,13 @@ def test_nb160_forward_block_outputs_match_the_oracle_taps():
 
 # ------------------------------------------------------------------------------------------------ BASELINE configs[2] (OISST)
 # The same question for the ResNet-UNet path: at NB = 300 (bench.py's config2_oisst line) the level-0 / level-1 3x3 convs run on
-# conv_up_halo_kernel<5> with GroupNorm statistics taken in its epilogue and applied by gn_apply_part_kernel, the 15 x 15 level on
-# conv_igemm2_kernel<2> -- none of which a 2-row parity test launches.  Reference: src/models/unet.py:58-109, 266-315.
-OISST_FORMS = ["conv_up_halo_kernel<5>", "conv_igemm2_kernel<2>", "gn_apply_part_kernel", "gn_stats_kernel+gn_apply"]
+# conv_up_halo_kernel<5, 2> and the 15 x 15 level on conv_igemm2_kernel<2, true>, both with the GroupNorm FUSED into their epilogue
+# (round 4, csrc/gn_fused.h: in-launch statistics exchange between the workgroups of a sample, no GroupNorm kernel at all) -- none
+# of which a 2-row parity test launches.  With INJECTED dropout masks the engine keeps to the un-fused chain (statistics from the
+# conv epilogue + gn_apply_part_kernel, gn_stats + gn_apply on the 15 x 15 level).  Reference: src/models/unet.py:58-109, 266-315.
+OISST_FORMS = ["conv_up_halo_kernel<5>+gn_fused", "conv_igemm2_kernel<2>+gn_fused"]
+OISST_FORMS_UNFUSED = ["conv_up_halo_kernel<5>", "conv_igemm2_kernel<2>", "gn_apply_part_kernel", "gn_stats_kernel+gn_apply"]
+GN_KERNELS = ["gn_apply_part_kernel", "gn_stats_kernel+gn_apply", "gn_finalize_part_kernel+gn_apply"]
 OISST_TOL = {"fp16": (4e-3, 1e-2), "bf16": (2e-2, 7e-2)}  # (per forward, per field over the T=32 rollout)
 
 
@@ -195,15 +199,24 @@ def test_oisst_nb300_forward_with_injected_dropout_matches_the_oracle(dtype):
     print("kernel forms launched:", {k: sorted(v) for k, v in forms.items()})
     for f in OISST_FORMS:
         assert f in forms and nb in forms[f], (f, forms.get(f))
+    assert not any(f in forms for f in GN_KERNELS), sorted(forms)  # every GroupNorm of the forward ran inside its conv
     with torch.no_grad():
-        want = nets.resnet_unet_forward(PI, cfg, x, t, None)
+        want = cached("oisst300_fwd_eval", lambda: nets.resnet_unet_forward(PI, cfg, x, t, None))
     errs = torch.tensor([rel_rms(got[r], want[r]) for r in range(nb)])
     print(f"OISST NB=300 forward ({dtype}), eval: rel-RMS per row max {float(errs.max()):.3e} mean {float(errs.mean()):.3e}")
     assert float(errs.max()) <= OISST_TOL[dtype][0]
-    src = nets.DropoutSeeded(17, record=True)
-    with torch.no_grad():
-        want = nets.resnet_unet_forward(PI, cfg, x, t, None, dropout=src)
-    got = eng.net_forward(0, x.to(DEV), t.to(DEV), None, dropout_mode=2, masks=engine_masks(src.masks, 3)).cpu()
+    def with_masks():
+        src = nets.DropoutSeeded(17, record=True)
+        with torch.no_grad():
+            return nets.resnet_unet_forward(PI, cfg, x, t, None, dropout=src), src.masks
+
+    want, masks = cached("oisst300_fwd_drop", with_masks)
+    eng.form_log(True)
+    got = eng.net_forward(0, x.to(DEV), t.to(DEV), None, dropout_mode=2, masks=engine_masks(masks, 3)).cpu()
+    forms = eng.form_log_read()
+    eng.form_log(False)
+    for f in OISST_FORMS_UNFUSED:
+        assert f in forms and nb in forms[f], (f, forms.get(f))
     errs = torch.tensor([rel_rms(got[r], want[r]) for r in range(nb)])
     print(f"OISST NB=300 forward ({dtype}), dropout injected: rel-RMS per row max {float(errs.max()):.3e} mean {float(errs.mean()):.3e}")
     assert float(errs.max()) <= OISST_TOL[dtype][0]
@@ -231,17 +244,19 @@ def test_oisst_nb300_rollout_rows_match_the_oracle(dtype):
     _, got, _ = m.sample_loop(x0.to(DEV), _noise=noise.to(DEV))
     forms = eng.form_log_read()
     eng.form_log(False)
-    for f in OISST_FORMS[:3]:
+    for f in OISST_FORMS:
         assert f in forms and nb in forms[f], (f, forms.get(f))
+    assert not any(f in forms for f in GN_KERNELS), sorted(forms)
     rows = [0, 150, 299]
-    it = iter(range(32))
 
-    def nf(tensor):
-        return noise[next(it)][rows]
+    def oracle():
+        it = iter(range(32))
+        with torch.no_grad():
+            return sampler.sample_loop(lambda x, t, cnd: nets.resnet_unet_forward(PF, cfg, x, t, cnd),
+                                       lambda x, t, cnd: nets.resnet_unet_forward(PI, cfg, x, t, cnd), x0[rows], None, hp,
+                                       noise_fn=lambda tensor: noise[next(it)][rows])
 
-    with torch.no_grad():
-        want = sampler.sample_loop(lambda x, t, cnd: nets.resnet_unet_forward(PF, cfg, x, t, cnd),
-                                   lambda x, t, cnd: nets.resnet_unet_forward(PI, cfg, x, t, cnd), x0[rows], None, hp, noise_fn=nf)
+    want = cached("oisst300_rollout_rows", oracle)
     assert sorted(got) == sorted(want)
     worst = 0.0
     for k in sorted(want):

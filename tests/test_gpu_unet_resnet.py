@@ -274,6 +274,7 @@ net._engine.form_log(True)
 y = net(x.cuda(), time=t.cuda()).cpu()
 forms = net._engine.form_log_read()
 assert "conv_up_halo_kernel<5>" in forms, forms
+assert "gn_apply_part_kernel" in forms, forms
 torch.save(y, {out!r})
 """
 
@@ -289,8 +290,68 @@ def test_halo5_plain_epilogue_instantiation_equals_the_general_one(tmp_path):
     outs = {}
     for v in ("1", "0"):
         out = str(tmp_path / f"y{v}.pt")
-        env = dict(os.environ, DYF_HALO5_PLAIN_EPI=v)
+        env = dict(os.environ, DYF_HALO5_PLAIN_EPI=v, DYF_GN_FUSED="0")  # the un-fused chain: conv<5> + statistics epilogue + gn_apply_part
         subprocess.run([_sys.executable, "-c", _HALO5_EPI_SCRIPT.format(root=root, out=out)], check=True, env=env, timeout=600)
         outs[v] = torch.load(out)
     assert torch.isfinite(outs["1"]).all() and float(outs["1"].std()) > 0
     assert torch.equal(outs["1"], outs["0"])
+
+
+def test_fused_groupnorm_convs_match_the_unfused_chain_and_are_reproducible():
+    """Round 4 (csrc/gn_fused.h): GroupNorm + FiLM + SiLU + dropout (+ residual) inside the producing conv, with the statistics
+    exchanged between the workgroups of a sample INSIDE the launch, against the three-kernel chain (DYF_GN_FUSED=0, read per engine)
+    on the OISST shapes at 40 rows -- conv_up_halo_kernel<5, 2> on the 60 x 60 and 30 x 30 levels, conv_igemm2_kernel<2, true> (rows of
+    the 15 x 15 planes straddle the 256-pixel tiles) -- eval and with the engine's MC dropout (same masks: the streams are keyed by
+    element, not by kernel).  The fused form normalises the fp32 accumulators, the chain the 16-bit rounded conv output: they agree
+    to 16-bit rounding.  Two runs of the fused form must agree BITWISE (slot-ordered sums, whatever order the workgroups arrive in)."""
+    cfg = dict(dim=64, dim_mults=[1, 2, 4], with_time_emb=True, block_dropout=0.3, block_dropout1=0.1, attn_dropout=0.0,
+               resnet_block_groups=8, input_dropout=0.0, upsample_dims=None)
+    P = seeded_unet(64, (1, 2, 4), 2, 1, seed=5)
+    g = torch.Generator().manual_seed(6)
+    nb = 40
+    x, t = torch.randn(nb, 2, 60, 60, generator=g), (torch.arange(nb) % 7 + 1).float()
+    outs = {}
+    prev = os.environ.get("DYF_GN_FUSED")
+    try:
+        for fused in ("1", "0"):
+            os.environ["DYF_GN_FUSED"] = fused
+            os.environ["DYF_IGEMM2_MIN_TILES"] = "1"  # the large-batch implicit-GEMM form at 40 rows (as at 300 rows by default)
+            net = mirror(P, cfg, 2, 0, 1, "fp16")
+            net._own_engine(nb, (60, 60))
+            eng = net._engine
+            eng.form_log(True)
+            y_eval = net(x.to(DEV), time=t.to(DEV)).cpu()
+            forms = eng.form_log_read()
+            eng.form_log(False)
+            print(fused, sorted(forms))
+            if fused == "1":
+                assert "conv_up_halo_kernel<5>+gn_fused" in forms and "conv_igemm2_kernel<2>+gn_fused" in forms, sorted(forms)
+                # 26 of the 30 GroupNorms run inside their conv; the four 64 -> 64 convs of the 30 x 30 level are, at 40 rows, below
+                # the tile threshold of conv_up_halo_kernel<5> (80 of 256 tiles; at the benchmark's 300 rows they are above it)
+                assert "gn_apply_part_kernel" not in forms and sum(forms.get("gn_stats_kernel+gn_apply", {}).values()) <= 4, forms
+            else:
+                assert not any(k.endswith("+gn_fused") for k in forms) and "gn_apply_part_kernel" in forms, sorted(forms)
+            eng.seed(11)
+            y_d1 = eng.net_forward(0, x.to(DEV), t.to(DEV), None, dropout_mode=1).cpu()
+            eng.seed(11)
+            y_d2 = eng.net_forward(0, x.to(DEV), t.to(DEV), None, dropout_mode=1).cpu()
+            y_eval2 = net(x.to(DEV), time=t.to(DEV)).cpu()
+            assert torch.equal(y_eval, y_eval2) and torch.equal(y_d1, y_d2), "not reproducible run to run"
+            outs[fused] = (y_eval, y_d1)
+            eng.close()
+    finally:
+        os.environ.pop("DYF_IGEMM2_MIN_TILES", None)
+        if prev is None:
+            os.environ.pop("DYF_GN_FUSED", None)
+        else:
+            os.environ["DYF_GN_FUSED"] = prev
+    with torch.no_grad():
+        want = nets.resnet_unet_forward(P, cfg, x, t, None)
+    for i, nm in enumerate(("eval", "engine dropout")):
+        e = max(rel_rms(outs["1"][i][r], outs["0"][i][r]) for r in range(nb))
+        print(f"fused vs un-fused GroupNorm, {nm}: worst row rel-RMS {e:.3e}")
+        assert e <= 4e-3
+    e1 = max(rel_rms(outs["1"][0][r], want[r]) for r in range(nb))
+    e0 = max(rel_rms(outs["0"][0][r], want[r]) for r in range(nb))
+    print(f"vs the fp32 oracle: fused {e1:.3e}, un-fused {e0:.3e}")
+    assert e1 <= 4e-3
