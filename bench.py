@@ -8,6 +8,12 @@ cold sampling, refine pass, MC dropout ON in the interpolator) over NB ensemble 
 libdyffusion_hip.so as a captured hipGraph.  Workload = BASELINE.json configs[1]: Navier-Stokes 221x42, C=3 (+2
 static channels), unet_simple dim 64 @256^2, bf16 MFMA / fp32 accumulate.
 
+Beside the headline line (N = 1) the JSON carries: `batch_curve` + `strong_scaling_projection` (what sharding a FIXED ensemble over 8
+GPUs would give, from this GPU's own small-batch rates), `config1_ns_c2` (the 2-channel NS variant), `config3_ns_ar64` (BASELINE
+configs[3]), `config2_oisst` (+ its batch curve), `config4_synth512`, `train_step` (both backbones) and `cpu_baseline`.
+For N > 1: the NS line (weak by default) + a `strong` object (50- and 80-row ensembles split over the ranks) + `config2_oisst` /
+`config4_synth512` on 300 / 8 rows sharded N ways, every one through the engine-owned all-gather, with `nranks_seen` = ncclCommCount.
+
 N > 1 (one process per GPU, RCCL): rows are independent ensemble members, so the rollout itself has no exchange step;
 every rank keeps the SAME seed and samples its block of global rows (the dropout streams are keyed by the global row, so
 the fields do not depend on N), and at the end of EVERY step the forecast stack is all-gathered over RCCL in ONE collective
@@ -57,22 +63,29 @@ def random_state(net, seed):
     return sd
 
 
-def pmc_traffic(nb):
+def pmc_traffic(nb, forms):
     """HBM bytes per launch of the dominant kernel.  PMC counters cannot be read from inside this process: the number is
     REPLAYED from the newest committed profiles/*_pmc_traffic.json (rocprofv3 --pmc passes, FETCH_SIZE and WRITE_SIZE in separate
-    passes, corrected as MI355X_MICROARCH.md prescribes; the file records the command that produced it), scaled by rows; None
-    when none is on record.  Returns (bytes, description of the source)."""
+    passes, corrected as MI355X_MICROARCH.md prescribes; the file records the command that produced it), scaled by rows -- and
+    only while the kernel it was measured on is still the one this run launched for that layer: `forms` is the engine's form log
+    of a rollout of THIS process ({kernel form: {rows: launches}}); a record whose `kernel` is not in it at `nb` rows is stale and
+    NOT replayed.  Returns (bytes | None, description of the source)."""
     import glob
 
     try:
         newest = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[-1]
         with open(newest) as f:
             rec = json.load(f)
+        name = os.path.basename(newest)
+        kern = rec.get("kernel")
+        if not kern or kern not in forms or nb not in forms[kern]:
+            return None, (f"profiles/{name} was measured on {kern!r}; this run's rollout launched {sorted(forms)} -- the record is "
+                          f"stale and was NOT replayed (re-run tools/pmc_traffic.sh)")
         cmd = rec.get("command", "command not recorded")
-        return round(rec["hbm_bytes_per_row"] * nb), (f"replayed, not measured in this run: profiles/{os.path.basename(newest)} "
-                                                      f"(separate rocprofv3 --pmc passes of `{cmd}`), scaled to {nb} rows")
-    except Exception:
-        return None, None
+        return round(rec["hbm_bytes_per_row"] * nb), (f"replayed, not measured in this run: profiles/{name} (separate rocprofv3 --pmc "
+                                                      f"passes of `{cmd}`; kernel {kern} still launched at {nb} rows), scaled to {nb} rows")
+    except Exception as ex:
+        return None, f"no usable profiles/*_pmc_traffic.json ({type(ex).__name__})"
 
 
 _T0 = time.perf_counter()
@@ -83,14 +96,15 @@ def log(msg):
         print(f"[bench +{time.perf_counter() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
 
 
-def build_model(nb, use_graph=True):
+def build_model(nb, use_graph=True, channels=C, **extra):
     import dyffusion_amd as D
 
-    F = D.UNet(num_input_channels=C, num_output_channels=C, num_conditional_channels=CS, spatial_shape=(H, W), **MODEL_KW)
-    I = D.UNet(num_input_channels=2 * C, num_output_channels=C, num_conditional_channels=CS, spatial_shape=(H, W), **MODEL_KW)
+    c = channels
+    F = D.UNet(num_input_channels=c, num_output_channels=c, num_conditional_channels=CS, spatial_shape=(H, W), **MODEL_KW)
+    I = D.UNet(num_input_channels=2 * c, num_output_channels=c, num_conditional_channels=CS, spatial_shape=(H, W), **MODEL_KW)
     F.load_state_dict(random_state(F, 0))
     I.load_state_dict(random_state(I, 1))
-    m = D.DYffusion(F, D.InterpolatorHandle(I, HORIZON), max_batch=nb, use_graph=use_graph, **DIFFUSION_KW)
+    m = D.DYffusion(F, D.InterpolatorHandle(I, HORIZON), max_batch=nb, use_graph=use_graph, **dict(DIFFUSION_KW, **extra))
     return m, F, I
 
 
@@ -109,7 +123,15 @@ def _resnet_roofline(eng, kind, nb, name, peak_tflops):
     # on the engine itself; inside the concurrent run the same launch shares the chip with the other groups' kernels)
     groups = eng.row_groups
     rows = -(-nb // groups)
-    ms, launches, fl, by = eng.time_kernel_in_rollout(kind, rows)
+    try:
+        ms, launches, fl, by = eng.time_kernel_in_rollout(kind, rows)
+    except Exception as ex:
+        if "not launched" not in str(ex):
+            raise
+        ms, launches, fl, by = 0.0, 0, 0.0, 0.0
+    if launches == 0 or ms <= 0:  # e.g. the GroupNorm chain: fused into the convs (csrc/gn_fused.h), no launch of its own is left
+        return {"kernel": name, "rows_per_launch": rows, "row_groups": groups, "launches": 0,
+                "note": "no launch of this kernel class in the rollout"}
     r = {"kernel": name, "rows_per_launch": rows, "row_groups": groups, "avg_ms": round(ms, 4), "launches": launches,
          "algorithmic_bytes_per_launch": by,
          "hbm_gbps": round(by / ms / 1e6, 1), "hbm_frac": round(by / ms / 1e6 / 8000.0, 4)}
@@ -121,21 +143,98 @@ def _resnet_roofline(eng, kind, nb, name, peak_tflops):
     return r
 
 
-def _time_rollouts(model, x0, reps):
-    model.sample(x0)  # captures the graph
+def _time_rollouts(model, x0, reps, static=None):
+    kw = {} if static is None else {"static_condition": static}
+    model.sample(x0, **kw)  # captures the graph
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(reps):
-        out = model.sample(x0)
+        out = model.sample(x0, **kw)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
     assert all(bool(torch.isfinite(v).all()) for v in out.values()), "non-finite forecast"
     return dt
 
 
-def bench_oisst(dev, nb=300, reps=3):
-    """BASELINE configs[2] shapes on ONE GPU: OISST 60x60x1, ResNet-UNet pair dim 64 mults (1,2,4), DYffusion h=7, k=25 (T=32: 32
-    forecaster + 61 interpolator forwards), data+noise, MC dropout on, hipGraph; NB rows (50 members x 6 tiles)."""
+def projection(curve, total, parts=8):
+    """What sharding a FIXED ensemble of `total` rows over `parts` GPUs would give against one GPU running all of it, from this GPU's
+    own rates: parts * f(ceil(total / parts)) / f(total), f = fields/s at that many rows per GPU (the all-gather of the forecast stack,
+    ~0.1 ms per MB over xGMI, is not in it).  The ceiling is total / ceil(total / parts) (50 rows on 8 GPUs: 7.14)."""
+    per = -(-total // parts)
+    if per not in curve or total not in curve:
+        return None
+    # the sharded job finishes when the slowest GPU -- one that runs `per` rows -- does: time = per * h / f(per); one GPU: total * h / f(total)
+    return {"rows_total": total, "gpus": parts, "rows_per_gpu": per, "speedup": round((total / curve[total]) / (per / curve[per]), 3),
+            "ceiling": round(total / per, 3)}
+
+
+def ns_batch_curve(model, dev, nbs=(1, 4, 7, 10, 25, 38, 50, 80)):
+    """fields/s of the headline NS workload at smaller row counts on the SAME engine (graph per batch size; kernel forms are chosen
+    per call from tile counts: split-K / implicit-GEMM forms at small batches) -- the rows one GPU gets when an ensemble is sharded."""
+    g = torch.Generator().manual_seed(101)
+    curve = {}
+    for nb in nbs:
+        x0 = torch.randn(nb, C, H, W, generator=g).to(dev)
+        st = torch.rand(nb, CS, H, W, generator=g).to(dev)
+        dt = _time_rollouts(model, x0, 3 if nb >= 25 else 5, st)
+        curve[nb] = round(nb * HORIZON / dt, 1)
+    log(f"NS batch curve (fields/s): {curve}")
+    return curve
+
+
+def bench_ns_c2(dev, nb):
+    """The 2-channel Navier-Stokes variant (BASELINE.json writes '221x42x2ch'; the reference's data has 3 channels)."""
+    m, _, _ = build_model(nb, channels=2)
+    m.seed(2)
+    g = torch.Generator().manual_seed(100)
+    x0, st = torch.randn(nb, 2, H, W, generator=g).to(dev), torch.rand(nb, CS, H, W, generator=g).to(dev)
+    dt = _time_rollouts(m, x0, 3, st)
+    res = {"workload": "Navier-Stokes 221x42 with C=2 dynamics channels (+2 static), otherwise BASELINE configs[1]", "dtype": "bf16",
+           "rows": nb, "fields_per_s": round(nb * HORIZON / dt, 1), "ms_per_rollout": round(1e3 * dt, 2)}
+    log(f"NS C=2 NB={nb}: {res['ms_per_rollout']} ms per rollout -> {res['fields_per_s']} fields/s")
+    m._engine.close()
+    return res
+
+
+def bench_ns_ar64(model, dev, b=4, n=20):
+    """BASELINE configs[3] on ONE GPU: Navier-Stokes long rollout, prediction_horizon 64 with horizon 16 = FOUR autoregressive outer
+    iterations of the headline rollout re-feeding t16 (forecasting_multi_horizon.py:114-229), the datamodule's boundary conditions
+    (obstacle mask + parabolic inflow, physical_systems_benchmark.py:245-297) applied to every field by the device op."""
+    import dyffusion_amd as D
+
+    nb = b * n
+    exp = D.MultiHorizonForecastingDYffusion(model, num_predictions=n)
+    g = torch.Generator().manual_seed(3)
+    dyn = torch.randn(b, 65, C, H, W, generator=g).to(dev)
+    static = torch.rand(b, CS, H, W, generator=g).to(dev)
+    meta = {"fixed_mask": (torch.rand(b, C, H, W, generator=g) < 0.06), "in_velocity": 1.0 + torch.rand(b, generator=g),
+            "vertices": torch.rand(b, 2, H, W, generator=g) * 0.41}
+    bc = D.PhysicalSystemsBoundaryConditions("navier-stokes", model._ensure_engine((H, W), nb))
+    batch = {"dynamics": dyn, "condition": static, "metadata": meta}
+
+    def run():
+        batch["dynamics"] = dyn.clone()  # evaluation_step rescales the batch's dynamics after the first outer iteration
+        return exp.evaluation_step(batch, prediction_horizon=64, boundary_conditions=bc, t0=torch.zeros(b), dt=torch.full((b,), 0.01))
+
+    run()
+    torch.cuda.synchronize()
+    reps = 2
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        out = run()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    keys = [k for k in out if k.endswith("preds")]
+    assert len(keys) == 64 and all(bool(torch.isfinite(out[k]).all()) for k in keys)
+    res = {"workload": "BASELINE configs[3] shapes, 1 GPU: Navier-Stokes prediction_horizon 64 = 4 autoregressive outer iterations of the "
+                       "h=16 rollout (240 network forwards), refine on, device boundary conditions on every field, ensemble of "
+                       f"{n} x batch {b}", "dtype": "bf16", "rows": nb, "fields_per_s": round(nb * 64 / dt, 1),
+           "ms_per_forecast": round(1e3 * dt, 2), "ms_per_outer_iteration": round(1e3 * dt / 4, 2)}
+    log(f"NS AR-64 rows={nb}: {res['ms_per_forecast']} ms per 64-step forecast -> {res['fields_per_s']} fields/s")
+    return res
+
+
+def oisst_model(nb, dtype=None, row_groups=None):
     import dyffusion_amd as D
 
     kw = dict(dim=64, dim_mults=(1, 2, 4), with_time_emb=True)
@@ -145,29 +244,55 @@ def bench_oisst(dev, nb=300, reps=3):
     # conv gains halved (as for the 512^2 pair): the T=32 recursion of a random-init pair must stay inside fp16's range
     F.load_state_dict(_resnet_state(F, 0, 0.5))
     I.load_state_dict(_resnet_state(I, 1, 0.5))
-    dtype = os.environ.get("DYF_BENCH_OISST_DTYPE", D.default_dtype_for(I))
+    dtype = dtype or os.environ.get("DYF_BENCH_OISST_DTYPE", D.default_dtype_for(I))
     m = D.DYffusion(F, D.InterpolatorHandle(I, 7), timesteps=7, forward_conditioning="data+noise", interpolate_before_t1=True,
-                    additional_interpolation_steps=25, refine_intermediate_predictions=False, max_batch=nb, dtype=dtype)
+                    additional_interpolation_steps=25, refine_intermediate_predictions=False, max_batch=nb, dtype=dtype,
+                    row_groups=row_groups)
     m.seed(2)
+    return m, F, I, dtype
+
+
+OISST_WORKLOAD = ("BASELINE configs[2] shapes: OISST 60x60x1, unet.Unet dim 64 mults (1,2,4), DYffusion h=7 k=25 (T=32), data+noise, "
+                  "MC dropout on, hipGraph rollout")
+
+
+def bench_oisst(dev, nb=300, reps=3):
+    """BASELINE configs[2] shapes on ONE GPU: OISST 60x60x1, ResNet-UNet pair dim 64 mults (1,2,4), DYffusion h=7, k=25 (T=32: 32
+    forecaster + 61 interpolator forwards), data+noise, MC dropout on, hipGraph; NB rows (50 members x 6 tiles)."""
+    m, F, I, dtype = oisst_model(nb)
     x0 = torch.randn(nb, 1, 60, 60, generator=torch.Generator().manual_seed(3)).to(dev)
     dt = _time_rollouts(m, x0, reps)
     eng = m._engine
     nf, ni = eng.forward_counts()
     fl = nf * eng.net_flops(0) + ni * eng.net_flops(1)
-    res = {"workload": "BASELINE configs[2] shapes, 1 GPU: OISST 60x60x1, unet.Unet dim 64 mults (1,2,4), DYffusion h=7 k=25 "
-                       "(T=32), data+noise, MC dropout on, hipGraph rollout", "dtype": dtype, "rows": nb, "row_groups": eng.row_groups,
+    res = {"workload": OISST_WORKLOAD + ", 1 GPU", "dtype": dtype, "rows": nb, "row_groups": eng.row_groups,
            "net_forwards_per_rollout": nf + ni, "fields_per_s": round(nb * 7 / dt, 1), "ms_per_rollout": round(1e3 * dt, 2),
            "gflop_per_field": round(fl / 7 / 1e9, 2), "whole_rollout_tflops": round(nb * fl / dt / 1e12, 1),
-           "roofline": _resnet_roofline(eng, 0, nb, "level-0 3x3 weight-standardised convs 64->64 @60x60", PEAK_BF16_TFLOPS),
-           "roofline_groupnorm": _resnet_roofline(eng, 2, nb, "GroupNorm(8)+FiLM+SiLU+dropout(+residual) chain, 64 ch @60x60", PEAK_BF16_TFLOPS)}
+           "roofline": _resnet_roofline(eng, 0, nb, "level-0 3x3 weight-standardised convs 64->64 @60x60 WITH the GroupNorm + FiLM + SiLU + "
+                                                    "dropout (+ residual) of their Block fused into the epilogue (conv_up_halo_kernel<5, 2>)",
+                                        PEAK_BF16_TFLOPS),
+           "roofline_groupnorm": _resnet_roofline(eng, 2, nb, "separate GroupNorm(8)+FiLM+SiLU+dropout(+residual) launches, 64 ch @60x60",
+                                                  PEAK_BF16_TFLOPS)}
     log(f"OISST NB={nb} ({dtype}): {res['ms_per_rollout']} ms per rollout -> {res['fields_per_s']} fields/s")
-    del m
+    eng.close()
     return res
 
 
-def bench_synth512(dev, nb=4, reps=1):
-    """BASELINE configs[4] shapes on ONE GPU: synthetic 512x512x4ch, ResNet-UNet pair dim 64 mults (1,2,4) (bottleneck attention
-    over 128^2 = 16 384 tokens), DYffusion h=32 (32 + 61 forwards), fp16, MC dropout on, hipGraph; NB rows."""
+def oisst_batch_curve(dev, first, nbs=(38, 75, 150)):
+    """fields/s of the OISST workload at the row counts one GPU gets when 300 rows are sharded 8 / 4 / 2 ways: an engine of its own
+    per point (the default row groups follow max_batch: 3 from 120 rows, 2 from 64, none below)."""
+    curve = dict(first)
+    for nb in nbs:
+        m, _, _, _ = oisst_model(nb)
+        x0 = torch.randn(nb, 1, 60, 60, generator=torch.Generator().manual_seed(3)).to(dev)
+        dt = _time_rollouts(m, x0, 3)
+        curve[nb] = round(nb * 7 / dt, 1)
+        m._engine.close()
+    log(f"OISST batch curve (fields/s): {curve}")
+    return dict(sorted(curve.items()))
+
+
+def synth512_model(nb):
     import dyffusion_amd as D
 
     I = D.Unet(dim=64, dim_mults=(1, 2, 4), with_time_emb=True, num_input_channels=8, num_output_channels=4,
@@ -179,21 +304,110 @@ def bench_synth512(dev, nb=4, reps=1):
     m = D.DYffusion(F, D.InterpolatorHandle(I, 32), timesteps=32, forward_conditioning="none", interpolate_before_t1=True,
                     refine_intermediate_predictions=False, enable_interpolator_dropout=True, max_batch=nb, dtype="fp16")
     m.seed(2)
+    return m
+
+
+SYNTH512_WORKLOAD = ("BASELINE configs[4] shapes: synthetic 512x512x4, unet.Unet dim 64 mults (1,2,4), DYffusion h=32, fp16 MFMA "
+                     "conv/attention, MC dropout on, hipGraph rollout")
+
+
+def bench_synth512(dev, nb=4, reps=1):
+    """BASELINE configs[4] shapes on ONE GPU: synthetic 512x512x4ch, ResNet-UNet pair dim 64 mults (1,2,4) (bottleneck attention
+    over 128^2 = 16 384 tokens), DYffusion h=32 (32 + 61 forwards), fp16, MC dropout on, hipGraph; NB rows."""
+    m = synth512_model(nb)
     x0 = torch.randn(nb, 4, 512, 512, generator=torch.Generator().manual_seed(4)).to(dev)
     dt = _time_rollouts(m, x0, reps)
     eng = m._engine
     nf, ni = eng.forward_counts()
     fl = nf * eng.net_flops(0) + ni * eng.net_flops(1)
-    res = {"workload": "BASELINE configs[4] shapes, 1 GPU: synthetic 512x512x4, unet.Unet dim 64 mults (1,2,4), DYffusion h=32, "
-                       "fp16 MFMA conv/attention, MC dropout on, hipGraph rollout", "dtype": "fp16", "rows": nb,
+    res = {"workload": SYNTH512_WORKLOAD + ", 1 GPU", "dtype": "fp16", "rows": nb,
            "net_forwards_per_rollout": nf + ni, "fields_per_s": round(nb * 32 / dt, 1), "ms_per_rollout": round(1e3 * dt, 2),
            "gflop_per_field": round(fl / 32 / 1e9, 2), "whole_rollout_tflops": round(nb * fl / dt / 1e12, 1),
            "roofline": _resnet_roofline(eng, 1, nb, "flash_attention2_kernel (16 384 tokens, 4 heads x 32; dropout on the "
                                                     "probabilities in the interpolator's launches)", PEAK_BF16_TFLOPS),
            "roofline_conv": _resnet_roofline(eng, 0, nb, "level-0 3x3 weight-standardised convs 64->64 @512x512", PEAK_BF16_TFLOPS)}
     log(f"512^2 NB={nb} (fp16): {res['ms_per_rollout']} ms per rollout -> {res['fields_per_s']} fields/s")
-    del m
+    eng.close()
     return res
+
+
+PEAK_FP32_MFMA_TFLOPS = 157.3  # v_mfma_f32_32x32x2_f32 dense peak, MI355X_MICROARCH.md
+
+
+def bench_train_steps(dev):
+    """The TRAINING step of the forecaster objective (`DYffusion.p_losses` in train mode + `loss.backward()`: 2 interpolator + 2
+    forecaster recorded forwards, backward through both forecaster passes and once through the frozen interpolator; dyffusion.py:496-567)
+    for both backbones, fp32 activations on the fp32 matrix cores (csrc/train*.hip).  FLOP model: conv / matmul 2*MAC of a forward,
+    x (4 forwards + 2 x 2 forecaster backward passes at 2 forward-equivalents each + 1 interpolator input-gradient pass at 1)."""
+    import dyffusion_amd as D
+
+    out = {}
+    # ---- unet_simple at the NS shapes, B = 32
+    B = 32
+    m, F, I = build_model(B, use_graph=False, lambda_reconstruction=1.0, lambda_reconstruction2=0.5, loss_function="l1")
+    m.train()
+    g = torch.Generator().manual_seed(0)
+    xt_last, cond = torch.randn(B, C, H, W, generator=g).to(dev), torch.randn(B, C, H, W, generator=g).to(dev)
+    static = torch.rand(B, CS, H, W, generator=g).to(dev)
+    t = torch.randint(0, HORIZON, (B,), generator=g).to(dev)
+
+    def timed(step, reps):
+        step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            loss = step()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps, loss
+
+    def step_ns():
+        o = m.p_losses(xt_last, cond, t, static_condition=static)
+        o["loss"].backward()
+        for p_ in m.model.parameters():
+            p_.grad = None
+        return float(o["loss"])
+
+    dt, loss = timed(step_ns, 2)
+    fwd = m._engine.net_flops(0)  # both nets: ~48.2 GF per row
+    fl = B * fwd * (4 + 2 * 2 * 2 + 1)
+    out["unet_simple_ns"] = {"workload": f"p_losses + backward, NS 221x42 shapes (unet_simple dim 64 @256^2), B={B}, both loss terms, fp32",
+                             "batch": B, "ms_per_step": round(1e3 * dt, 1), "loss": round(loss, 4), "achieved": round(fl / dt / 1e12, 1),
+                             "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(fl / dt / 1e12 / PEAK_FP32_MFMA_TFLOPS, 3),
+                             "samples_per_s": round(B / dt, 1)}
+    log(f"train step unet_simple B={B}: {1e3 * dt:.1f} ms")
+    m._engine.close()
+    del m
+    # ---- unet.Unet at the OISST shapes, B = 8
+    B = 8
+    kw = dict(dim=64, dim_mults=(1, 2, 4), with_time_emb=True)
+    F = D.Unet(num_input_channels=1, num_output_channels=1, num_conditional_channels=1, block_dropout=0.3, attn_dropout=0.1, **kw)
+    I = D.Unet(num_input_channels=2, num_output_channels=1, num_conditional_channels=0, block_dropout=0.6, block_dropout1=0.2,
+               attn_dropout=0.6, **kw)
+    F.load_state_dict(_resnet_state(F, 0, 0.5))
+    I.load_state_dict(_resnet_state(I, 1, 0.5))
+    m2 = D.DYffusion(F, D.InterpolatorHandle(I, 7), timesteps=7, forward_conditioning="data+noise", interpolate_before_t1=True,
+                     additional_interpolation_steps=25, lambda_reconstruction=0.5, lambda_reconstruction2=0.5, loss_function="l1",
+                     max_batch=B)
+    m2.train()
+    x2, c2 = torch.randn(B, 1, 60, 60, generator=g).to(dev), torch.randn(B, 1, 60, 60, generator=g).to(dev)
+    t2 = torch.randint(0, m2.num_timesteps, (B,), generator=g).to(dev)
+
+    def step_rn():
+        o = m2.p_losses(x2, c2, t2, static_condition=None)
+        o["loss"].backward()
+        for p_ in m2.model.parameters():
+            p_.grad = None
+        return float(o["loss"])
+
+    dt, loss = timed(step_rn, 3)
+    fl = B * (m2._engine.net_flops(0) * (2 + 2 * 2 * 2) + m2._engine.net_flops(1) * (2 + 1))
+    out["unet_resnet_oisst"] = {"workload": f"p_losses + backward, OISST 60x60 shapes (unet.Unet dim 64 mults (1,2,4)), B={B}, both loss "
+                                            "terms, fp32", "batch": B, "ms_per_step": round(1e3 * dt, 1), "loss": round(loss, 4),
+                                "achieved": round(fl / dt / 1e12, 1), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                "frac": round(fl / dt / 1e12 / PEAK_FP32_MFMA_TFLOPS, 3), "samples_per_s": round(B / dt, 1)}
+    log(f"train step unet.Unet B={B}: {1e3 * dt:.1f} ms")
+    m2._engine.close()
+    return out
 
 
 def cpu_model():
@@ -272,7 +486,8 @@ def main():
     ap.add_argument("--ensemble-total", type=int, default=int(os.environ.get("DYF_BENCH_ENSEMBLE", "0")),
                     help="strong scaling: a fixed ensemble of this many rows split over the ranks (0 = weak scaling, --nb rows per rank)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra-configs", action="store_true", help="skip the OISST (configs[2]) and 512^2 (configs[4]) lines")
+    ap.add_argument("--no-extra-configs", action="store_true",
+                    help="only the headline NS line (+ rooflines): no batch curve, no other configs, no training steps")
     ap.add_argument("--no-graph", action="store_true")
     args = ap.parse_args()
 
@@ -302,49 +517,10 @@ def main():
     total_rows = args.ensemble_total if strong else world * args.nb
     nb = rows_per_rank(total_rows, world)  # rows every rank launches (uneven shards repeat a row, distributed.py)
     log(f"building model, {total_rows} rows over {world} rank(s), {nb} per rank")
-    model, F, I = build_model(nb, use_graph=not args.no_graph)
+    model, F, I = build_model(max(nb, args.nb if world > 1 else nb), use_graph=not args.no_graph)
     log("model built")
-    # every rank holds the full (total_rows, ...) inputs (111 KB per row) and the same seed; sample_sharded makes it
-    # sample its own block of global rows and all-gathers the forecast stack
-    g = torch.Generator().manual_seed(100)
-    x0 = torch.randn(total_rows, C, H, W, generator=g).to(dev)
-    static = torch.rand(total_rows, CS, H, W, generator=g).to(dev)
     gather = os.environ.get("DYF_BENCH_GATHER", "1") == "1"  # =0: time the rollouts without the exchange (A/B)
-    lo, hi = shard_rows(total_rows, world, rank)
-
-    def step():
-        if world > 1 and gather:
-            preds = sample_sharded(model, x0, static, exchange=exchange)
-            assert preds[f"t{HORIZON}_preds"].shape[0] == total_rows
-        else:
-            model.set_row_offset(lo)
-            preds = model.sample(x0[lo:hi], static_condition=static[lo:hi])
-        return preds
-
-    model.seed(2)
-    model._ensure_engine((H, W), nb)
-    log("engine created, weights uploaded")
-    # N > 1 over RCCL: the ENGINE owns the communicator (dyf_comm_init) and issues the one all-gather of the forecast stack
-    # itself, on the rollout's stream (dyf_sample_gather); DYF_BENCH_EXCHANGE=torch selects the torch.distributed route
-    exchange = os.environ.get("DYF_BENCH_EXCHANGE", "engine" if world > 1 and dist.get_backend() == "nccl" else "torch")
-    if world > 1 and gather and exchange == "engine":
-        try:
-            init_engine_comm(model, (H, W), total_rows)
-            ok = 1
-        except Exception as ex:  # e.g. no librccl for dlopen: every rank falls back to the torch.distributed route together
-            log(f"engine-owned communicator unavailable ({type(ex).__name__}: {ex})")
-            ok = 0
-        flag = torch.tensor([ok], device=dev)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) == 1:
-            log("engine-owned RCCL communicator initialised")
-        else:
-            exchange = "torch"
-            model._engine_comm_world = 1
-    for _ in range(args.warmup):
-        step()
-        torch.cuda.synchronize()
-        log("warm-up step done")
+    want_engine_comm = world > 1 and gather and os.environ.get("DYF_BENCH_EXCHANGE", "engine" if dist.get_backend() == "nccl" else "torch") == "engine"
 
     def fence():
         torch.cuda.synchronize()
@@ -352,18 +528,54 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        preds = step()
-    fence()
-    dt = time.perf_counter() - t0
+    def sharded_run(mdl, x_full, s_full, hw, horizon, steps, warmup):
+        """K timed steps of `mdl` on the rows of x_full sharded over the ranks: every rank samples its block of global rows (same seed,
+        global-row dropout streams) and, N > 1, the forecast stack is all-gathered inside EVERY step (one collective, issued by the
+        engine on the rollout's stream when it owns a communicator).  Returns (seconds MAX over ranks, exchange used, ncclCommCount)."""
+        rows = x_full.shape[0]
+        lo, hi = shard_rows(rows, world, rank)
+        exch, seen = "none", 0
+        if world > 1 and gather:
+            exch = "torch"
+            if want_engine_comm:
+                if mdl.engine_comm_world() == world or init_engine_comm(mdl, hw, rows):
+                    exch, seen = "engine", mdl._engine.comm_count()
+                else:
+                    log(f"engine-owned communicator unavailable ({getattr(mdl, '_comm_error', '?')}): torch.distributed exchange")
+
+        def step():
+            if world > 1 and gather:
+                preds = sample_sharded(mdl, x_full, s_full, exchange=exch)
+                assert next(iter(preds.values())).shape[0] == rows
+                return preds
+            mdl.set_row_offset(lo)
+            return mdl.sample(x_full[lo:hi], **({} if s_full is None else {"static_condition": s_full[lo:hi]}))
+
+        for _ in range(warmup):
+            step()
+            torch.cuda.synchronize()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            preds = step()
+        fence()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        assert all(bool(torch.isfinite(v).all()) for v in preds.values()), "non-finite forecast"
+        return dt, exch, seen
+
+    # every rank holds the full (total_rows, ...) inputs (111 KB per row) and the same seed
+    g = torch.Generator().manual_seed(100)
+    x0 = torch.randn(total_rows, C, H, W, generator=g).to(dev)
+    static = torch.rand(total_rows, CS, H, W, generator=g).to(dev)
+    model.seed(2)
+    model._ensure_engine((H, W), max(nb, args.nb if world > 1 else nb))
+    log("engine created, weights uploaded")
+    dt, exchange, nranks_seen = sharded_run(model, x0, static, (H, W), HORIZON, args.steps, args.warmup)
     log(f"timed region done: {dt:.3f} s for {args.steps} steps")
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    assert all(torch.isfinite(v).all() for v in preds.values()), "non-finite forecast"
 
     fields = total_rows * HORIZON * args.steps
     eng = model._engine
@@ -387,14 +599,53 @@ def main():
                    "executed_gflop_per_field": round(exec_rollout_row / HORIZON / 1e9, 2),
                    "executed_whole_rollout_tflops": round(total_rows * exec_rollout_row * args.steps / dt / 1e12, 2)},
     }
-    if rank == 0:
-        # roofline of the dominant kernel: the last decoder block's 3x3 conv (256 -> 64 ch @256^2, 40 % of a forward),
-        # HIP events on the launch stream, operands = live workspace activations
-        # Dominant kernel: conv_halo_rows_kernel<0> (dense form; dec3 + dec4 = 27 % of a forward's time), largest launch dec4.
-        # achieved = algorithmic FLOPs of one launch / average duration of that launch INSIDE the rollout: HIP events around
-        # every dec4 conv (60 launches: 16 forecaster + 44 interpolator forwards, MC dropout on) of one eagerly launched
-        # rollout on the launch stream (dyf_time_layer_in_rollout); the isolated back-to-back figure is kept beside it.
-        # The sparse-column instance of the same kernel (dec5, only the output columns the readout reads) is reported too.
+    if world > 1:
+        result["nranks_seen"] = nranks_seen  # ncclCommCount of the engine's communicator (0: the torch.distributed route ran)
+
+    extras = not args.no_extra_configs
+    if world > 1 and extras:
+        # ---- N > 1: the other multi-GPU workloads of BASELINE.json, each sharded over the ranks through the same exchange.
+        # STRONG scaling of the headline workload: a fixed ensemble (the reference's 50 members; its 80-row evaluation batch) split over
+        # the ranks -- what north_star's ">= 6x at 8 GPUs" is about; the weak line above keeps 80 rows per GPU.
+        result["strong"] = {}
+        for m_rows in (50, 80):
+            gs = torch.Generator().manual_seed(100)
+            xs, ss = torch.randn(m_rows, C, H, W, generator=gs).to(dev), torch.rand(m_rows, CS, H, W, generator=gs).to(dev)
+            d2, ex2, seen2 = sharded_run(model, xs, ss, (H, W), HORIZON, max(3, args.steps), 1)
+            k = max(3, args.steps)
+            result["strong"][f"ensemble_{m_rows}"] = {"total_rows": m_rows, "rows_per_gpu": rows_per_rank(m_rows, world), "scaling": "strong",
+                                                      "fields_per_s": round(m_rows * HORIZON * k / d2, 1), "ms_per_step": round(1e3 * d2 / k, 3),
+                                                      "exchange": ex2, "nranks_seen": seen2}
+            log(f"strong scaling, {m_rows} rows over {world} ranks: {result['strong'][f'ensemble_{m_rows}']}")
+        eng.close()
+        del model
+        torch.cuda.empty_cache()
+        for key, make, shape, rows, horizon, wl in (
+                ("config2_oisst", lambda r: oisst_model(r)[0], (1, 60, 60), 300, 7, OISST_WORKLOAD),
+                ("config4_synth512", synth512_model, (4, 512, 512), 8, 32, SYNTH512_WORKLOAD)):
+            try:
+                rpr = rows_per_rank(rows, world)
+                mdl = make(rpr)
+                xf = torch.randn(rows, *shape, generator=torch.Generator().manual_seed(3)).to(dev)
+                mdl._ensure_engine(shape[1:], rpr)
+                reps = 3 if key == "config2_oisst" else 1
+                d3, ex3, seen3 = sharded_run(mdl, xf, None, shape[1:], horizon, reps, 1)
+                result[key] = {"workload": wl + f", {rows} rows sharded over {world} GPUs", "total_rows": rows, "rows_per_gpu": rpr,
+                               "row_groups": mdl._engine.row_groups, "scaling": "strong", "fields_per_s": round(rows * horizon * reps / d3, 1),
+                               "ms_per_rollout": round(1e3 * d3 / reps, 2), "exchange": ex3, "nranks_seen": seen3}
+                log(f"{key} on {world} ranks: {result[key]}")
+                mdl._engine.close()
+                del mdl
+            except Exception as ex:  # identical on every rank (same shapes): the headline line must survive
+                result[key] = {"error": f"{type(ex).__name__}: {ex}"}
+            torch.cuda.empty_cache()
+
+    if rank == 0 and world == 1:
+        # roofline of the dominant kernel: conv_halo_rows_kernel<0> (dense form; dec3 + dec4 = 27 % of a forward's time), largest launch
+        # dec4.  achieved = algorithmic FLOPs of one launch / average duration of that launch INSIDE the rollout: HIP events around every
+        # dec4 conv (60 launches: 16 forecaster + 44 interpolator forwards, MC dropout on) of one eagerly launched rollout on the launch
+        # stream (dyf_time_layer_in_rollout); the isolated back-to-back figure is kept beside it.  The sparse-column instance of the
+        # same kernel (dec5, only the output columns the readout reads) is reported too.
         def layer_roofline(layer, name):
             _, fl, by = eng.time_conv_layer(1, layer, nb, iters=1)
             ms, launches = eng.time_layer_in_rollout(layer, nb)
@@ -405,27 +656,51 @@ def main():
                     "launches": launches, "avg_ms_isolated": round(ms_iso, 4), "flops_per_launch": fl,
                     "algorithmic_bytes_per_launch": by}
 
+        eng.form_log(True)
         result["roofline"] = layer_roofline(10, "conv_halo_rows_kernel<0> (dec4: fused x2-upsample + 3x3 conv, 256->128 ch, 64^2->128^2)")
-        result["roofline"]["traffic"], result["roofline"]["traffic_source"] = pmc_traffic(nb)
+        forms = eng.form_log_read()  # the kernel forms of an eager rollout of THIS run (dyf_time_layer_in_rollout): guards the PMC replay
+        eng.form_log(False)
+        result["roofline"]["traffic"], result["roofline"]["traffic_source"] = pmc_traffic(nb, forms)
         result["roofline_dec5_sparse"] = layer_roofline(
             11, "conv_halo_rows_mixed_kernel = conv_halo_rows_kernel<1, SH> (dec5: fused x2-upsample + 3x3 conv, 256->64 ch, 128^2->256^2, "
                 "104 of 256 output columns as 3 x 16 + 4 list entries per phase)")
-        if world == 1 and not args.no_extra_configs:
-            # BASELINE configs[2] and configs[4] at their named shapes on this GPU (not the headline metric: extra keys)
-            # the NS engine is CLOSED first (dyf_engine_destroy; `del` alone would not: the network modules hold it too): a live engine's
-            # captured graph keeps a hardware queue, and the three concurrent row groups of the OISST rollout then share the 4
-            # queues of the process with it (3 660 vs 2 870 fields/s measured)
-            eng.close()
-            del model, preds
-            torch.cuda.empty_cache()
-            for key, fn in (("config2_oisst", bench_oisst), ("config4_synth512", bench_synth512)):
+        if extras:
+            def guarded(key, fn):
                 try:
-                    result[key] = fn(dev)
+                    result[key] = fn()
                 except Exception as ex:  # the headline line must survive a failure here
                     result[key] = {"error": f"{type(ex).__name__}: {ex}"}
                 torch.cuda.empty_cache()
-        if world == 1 and not args.no_cpu_baseline:
+
+            # the NS engine is CLOSED before the OISST line (dyf_engine_destroy; `del` alone would not: the network modules hold it
+            # too): a live engine's captured graph keeps a hardware queue, and the three concurrent row groups of the OISST rollout
+            # then share the 4 queues of the process with it (3 660 vs 2 870 fields/s measured).  So: NS extras that
+            # need this engine first, then close it, then OISST FIRST among the other engines.
+            guarded("batch_curve", lambda: {"unit": "fields/s", "navier_stokes": ns_batch_curve(model, dev)})
+            guarded("config3_ns_ar64", lambda: bench_ns_ar64(model, dev))
+            eng.close()
+            del model
+            torch.cuda.empty_cache()
+            guarded("config2_oisst", lambda: bench_oisst(dev))
+            curve = result["batch_curve"]
+            if "error" not in curve and "fields_per_s" in result["config2_oisst"]:
+                try:
+                    curve["oisst"] = oisst_batch_curve(dev, {300: result["config2_oisst"]["fields_per_s"]})
+                except Exception as ex:
+                    curve["oisst"] = {"error": f"{type(ex).__name__}: {ex}"}
+                torch.cuda.empty_cache()
+                oi = {k: v for k, v in curve["oisst"].items() if isinstance(k, int)}
+                result["strong_scaling_projection"] = {
+                    "what": "time of ONE GPU on the whole ensemble / time of the slowest of 8 GPUs on its ceil(rows / 8) share, from this "
+                            "GPU's batch curve (the 1-collective all-gather of the forecast stack is not in it)",
+                    "navier_stokes_80": projection(curve["navier_stokes"], 80), "navier_stokes_50": projection(curve["navier_stokes"], 50),
+                    "oisst_300": projection(oi, 300)}
+            guarded("config1_ns_c2", lambda: bench_ns_c2(dev, nb))
+            guarded("config4_synth512", lambda: bench_synth512(dev))
+            guarded("train_step", lambda: bench_train_steps(dev))
+        if not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(F, I)
+    if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()

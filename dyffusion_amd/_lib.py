@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("DYF_LIB") or os.path.join(_HERE, "lib", "libdyffusion
 LIB_PATH_F16 = os.environ.get("DYF_LIB_F16") or os.path.join(_HERE, "lib", "libdyffusion_hip_f16.so")
 DTYPES = {"bf16": 0, "bfloat16": 0, "fp16": 1, "float16": 1, "half": 1}
 
-DYF_ABI_VERSION = 5
+DYF_ABI_VERSION = 6
 DYF_OK, DYF_ERR_INVALID_ARGUMENT, DYF_ERR_UNSUPPORTED, DYF_ERR_HIP, DYF_ERR_STATE = range(5)
 NET_FORECASTER, NET_INTERPOLATOR = 0, 1
 ARCH_UNET_SIMPLE, ARCH_UNET_RESNET = 0, 1
@@ -86,6 +86,7 @@ SYMBOLS = [
     ("dyf_comm_unique_id", C.c_int, [_P]),
     ("dyf_comm_init", C.c_int, [_P, _P, C.c_int32, C.c_int32]),
     ("dyf_comm_destroy", C.c_int, [_P]),
+    ("dyf_comm_count", C.c_int, [_P, _P]),
     ("dyf_sample_gather", C.c_int, [_P, _P, _P, _P, C.c_int32, C.c_int32, _P]),
     ("dyf_get_sampler_state", C.c_int, [_P, C.c_int32, _P, C.c_int32, _P]),
     ("dyf_plan_forward_counts", C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),

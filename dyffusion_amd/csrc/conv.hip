@@ -617,10 +617,12 @@ static hipError_t launch_igemm(ConvArgs a, hipStream_t stream) {
         static const bool enabled = !(getenv("DYF_SPLITK") && atoi(getenv("DYF_SPLITK")) == 0);
         const int nk = a.kh * a.kw * ((a.c0 + a.c1) >> 6);
         const long long tiles = (((long long)(a.n_sel > 0 ? a.n_sel : a.n) * a.ho * a.wo + BM - 1) / BM) * tiles_n;
+        static const long long max_tiles = getenv("DYF_SPLITK_MAX_TILES") ? atoll(getenv("DYF_SPLITK_MAX_TILES")) : 128;
+        static const long long fill = getenv("DYF_SPLITK_FILL") ? atoll(getenv("DYF_SPLITK_FILL")) : 512;
         int s = std::min(16, nk / 8);
-        while (s > 1 && s * tiles > 512) s >>= 1;
+        while (s > 1 && s * tiles > fill) s >>= 1;
         const long long need = (long long)s * M * a.cout;
-        if (enabled && s > 1 && tiles <= 128 && need <= a.splitk_cap) a.splitk = s;
+        if (enabled && s > 1 && tiles <= max_tiles && need <= a.splitk_cap) a.splitk = s;
     }
     dyf_form_note(a.splitk > 1 ? (BM == 128 ? "conv_igemm_kernel<128,128>+splitk" : "conv_igemm_kernel<256,64>+splitk")
                                : (BM == 128 ? (UP ? "conv_igemm_kernel<128,128,UP>" : "conv_igemm_kernel<128,128>")

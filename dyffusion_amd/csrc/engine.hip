@@ -515,7 +515,9 @@ dyf_status dyf_set_row_groups(dyf_engine* e, int32_t n_groups) {
     n_groups = std::min<int>(n_groups, e->cfg.max_batch / e->group_min_rows);
     if (!e->group_fork) HIP_TRY(e, hipEventCreateWithFlags(&e->group_fork, hipEventDisableTiming));
     dyf_engine_config cc = e->cfg;
-    cc.max_batch = (e->cfg.max_batch + n_groups - 1) / n_groups;
+    // a child holds a HALF of max_batch even when there are three or more groups: a call may then run on two groups only (what
+    // sample_into_stack does while the engine owns a communicator, below) without re-creating anything
+    cc.max_batch = (e->cfg.max_batch + std::min(n_groups, 2) - 1) / std::min(n_groups, 2);
     for (int g = 0; g < n_groups; ++g) {
         dyf_engine* c = nullptr;
         g_creating_group_child = true;
@@ -864,17 +866,20 @@ dyf_status dyf_net_flops_executed(const dyf_engine* e, int32_t which, double* fl
 // its output.  Checked at the head of every forward / sampling entry point (a plain host read, no synchronisation): the engine
 // then drops its captured graphs, keeps to the three-kernel GroupNorm path from now on and fails THIS call, naming the earlier one.
 static dyf_status gn_fuse_check(dyf_engine* e) {
-    bool hit = false;
+    bool hit = false, slow = false;
     auto one = [&](dyf_engine* x) {
-        if (x->gn_err_host && *(volatile uint32_t*)x->gn_err_host != 0u) hit = true;
+        if (x->gn_err_host && ((volatile uint32_t*)x->gn_err_host)[0] != 0u) hit = true;
+        if (x->gn_err_host && ((volatile uint32_t*)x->gn_err_host)[1] != 0u) slow = true;
     };
     one(e);
     for (dyf_engine* c : e->groups) one(c);
-    if (!hit) return DYF_OK;
+    if (!hit && !slow) return DYF_OK;
     (void)hipSetDevice(e->cfg.device);
     (void)hipDeviceSynchronize();
+    one(e);  // (a time-out may have been raised while the device drained)
+    for (dyf_engine* c : e->groups) one(c);
     auto disable = [](dyf_engine* x) {
-        if (x->gn_err_host) *(volatile uint32_t*)x->gn_err_host = 0u;
+        if (x->gn_err_host) ((volatile uint32_t*)x->gn_err_host)[0] = ((volatile uint32_t*)x->gn_err_host)[1] = 0u;
         x->gn_fuse_disabled = true;
         for (auto& kv : x->graphs) {
             if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
@@ -884,6 +889,9 @@ static dyf_status gn_fuse_check(dyf_engine* e) {
     };
     disable(e);
     for (dyf_engine* c : e->groups) disable(c);
+    // slow only: every sweep did match (results are correct) but took > 1 ms -- the sample's workgroups were not co-scheduled (a
+    // GPU shared with another process): later calls take the three-kernel path, nothing to report
+    if (!hit) return DYF_OK;
     return fail(e, DYF_ERR_STATE,
                 "a fused GroupNorm convolution of an EARLIER call timed out waiting for its sample's statistics (that call's output was "
                 "NaN-poisoned); the engine now runs the un-fused GroupNorm kernels -- repeat the call");
@@ -1014,6 +1022,19 @@ dyf_status dyf_set_plan(dyf_engine* e, const dyf_plan* p) {
             float* A = n.tables + (size_t)i * 2 * n.total_c;
             s = compute_coefs(e, n, tdev + i, 1, A, A + n.total_c, 0);
             if (s != DYF_OK) return s;
+        }
+    }
+    {   // FiLM coefficient rows of the refinement pass in REFINE ORDER, contiguous: a batched refinement launch (run_plan) covers
+        // k consecutive prediction times with one forward over k * nb rows and reads row (batch row / nb) of this table
+        Net& I = e->net[DYF_NET_INTERPOLATOR];
+        const size_t row = (size_t)2 * I.total_c;
+        e->refine_coef = nullptr;
+        if (!ph.refine_times.empty()) {
+            dyf_status s = dev_alloc(e, &e->refine_coef, ph.refine_times.size() * row);
+            if (s != DYF_OK) return s;
+            for (size_t r = 0; r < ph.refine_times.size(); ++r)
+                HIP_TRY(e, hipMemcpy(e->refine_coef + r * row, I.tables + (size_t)I.table_of_time.at(ph.refine_times[r]) * row,
+                                     row * sizeof(float), hipMemcpyDeviceToDevice));
         }
     }
     HIP_TRY(e, hipDeviceSynchronize());
@@ -1191,18 +1212,31 @@ dyf_status run_plan(dyf_engine* e, int nb, const uint8_t* const* masks, const fl
             HIP_TRY(e, hipMemcpyAsync(e->s_stack + (size_t)s.out_slot * field, e->s_xs, fbytes, hipMemcpyDeviceToDevice, st));
         ++step_idx;
     }
-    // ---- refinement of the intermediate predictions with the final x0_hat (dyffusion.py:408-422)
-    for (size_t r = 0; r < ph.refine_times.size(); ++r) {
-        if (can_pair && r + 1 < ph.refine_times.size() && ph.refine_slots[r + 1] == ph.refine_slots[r] + 1) {
-            // two consecutive output slots are one contiguous [2][nb][C][H][W] block of the forecast stack
-            dyf_status rs = interp2(ph.refine_times[r], ph.refine_times[r + 1], e->s_x0hat,
-                                    e->s_stack + (size_t)ph.refine_slots[r] * field);
+    // ---- refinement of the intermediate predictions with the final x0_hat (dyffusion.py:408-422).  The h - 1 interpolator calls
+    // share their inputs and do not depend on one another: runs of consecutive output slots go out as ONE forward over k * nb rows
+    // (row r: prediction time r / nb, the masks of forward counter + r / nb -- exactly those of k separate forwards), written
+    // straight into the contiguous [k][nb][C][H][W] block of the forecast stack.  k is bounded by the workspace (2 max_batch rows):
+    // an engine created for 80 rows refines a 10-row call in one 150-row launch instead of eight 20-row ones (the small-batch /
+    // ensemble-sharded regime); at nb = max_batch it is the pair it always was.  DYF_REFINE_BATCH caps k.
+    const int refine_cap = getenv("DYF_REFINE_BATCH") ? std::max(1, atoi(getenv("DYF_REFINE_BATCH"))) : 1 << 20;  // read per capture
+    const int kmax = can_pair ? std::max(1, std::min(refine_cap, 2 * e->cfg.max_batch / nb)) : 1;
+    for (size_t r = 0; r < ph.refine_times.size();) {
+        size_t k = 1;
+        while ((int)k < kmax && r + k < ph.refine_times.size() && ph.refine_slots[r + k] == ph.refine_slots[r] + (int)k) ++k;
+        if (k >= 2) {
+            const size_t row = (size_t)2 * I.total_c;
+            Source srcs[3] = {{e->s_init, e->wC}, {e->s_x0hat, e->C}, {e->s_static, e->Cs}};
+            const int ns = e->Cs > 0 ? 3 : 2;
+            FwdOpts o{e->refine_coef + r * row, e->refine_coef + r * row + I.total_c, (int)row, i_mode, nullptr};
+            o.src_rows = nb;
+            o.coef_div = nb;
+            dyf_status rs = net_forward(e, DYF_NET_INTERPOLATOR, srcs, ns, (int)k * nb, o, e->s_stack + (size_t)ph.refine_slots[r] * field, st);
             if (rs != DYF_OK) return rs;
-            ++r;
-            continue;
+        } else {
+            dyf_status rs = interp(ph.refine_times[r], e->s_x0hat, e->s_stack + (size_t)ph.refine_slots[r] * field);
+            if (rs != DYF_OK) return rs;
         }
-        dyf_status rs = interp(ph.refine_times[r], e->s_x0hat, e->s_stack + (size_t)ph.refine_slots[r] * field);
-        if (rs != DYF_OK) return rs;
+        r += k;
     }
 #undef LOG_COPY
     return DYF_OK;
@@ -1232,8 +1266,13 @@ static dyf_status sample_into_stack(dyf_engine* e, const float* initial_dev, con
     const int G = (int)e->groups.size();
     if (G > 1 && !e->log_on && masks_dev == nullptr && noise_dev == nullptr && nb >= 2 * e->group_min_rows) {
         // rows split over the groups: per = ceil(nb / g) rows each (the last one takes the remainder), every share on its own stream
-        int g_use = std::min(G, nb / e->group_min_rows);
-        if ((nb + g_use - 1) / g_use > e->groups[0]->cfg.max_batch) g_use = G;  // ceil(nb / G) always fits a group's max_batch
+        // Three concurrent groups + the caller's stream use all four hardware queues a HIP process gets: ONE more stream with work
+        // (or a live graph) makes two groups share a queue and the 300-row OISST rollout drops from ~3 850 to ~3 100 fields/s, below
+        // what two groups deliver with or without company (~3 700).  An engine that owns a communicator lives in a
+        // multi-GPU process -- RCCL and torch.distributed bring streams of their own -- so it keeps to two groups.
+        const int g_cap = e->comm ? std::min(G, 2) : G;
+        int g_use = std::min(g_cap, nb / e->group_min_rows);
+        if ((nb + g_use - 1) / g_use > e->groups[0]->cfg.max_batch) g_use = g_cap;  // ceil(nb / min(G, 2)) always fits a group's max_batch
         const int per = (nb + g_use - 1) / g_use, used = (nb + per - 1) / per;
         const size_t row = (size_t)e->C * H * W, slots = (size_t)e->plan.hdr.n_out_slots;
         for (int g = 0; g < used; ++g)  // same seed and stream position as this engine, batch row 0 = global row offset + g * per
@@ -1327,6 +1366,7 @@ struct RcclApi {
     ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     std::string err;
@@ -1345,7 +1385,7 @@ RcclApi& rccl_api() {
         if (!api.lib) { api.err = std::string("librccl not found: ") + (dlerror() ? dlerror() : ""); return; }
 #define SYM(field, name) api.field = (decltype(api.field))dlsym(api.lib, name); if (!api.field) api.err = std::string("librccl lacks ") + name;
         SYM(GetUniqueId, "ncclGetUniqueId") SYM(CommInitRank, "ncclCommInitRank") SYM(CommDestroy, "ncclCommDestroy")
-        SYM(AllGather, "ncclAllGather") SYM(GetErrorString, "ncclGetErrorString")
+        SYM(AllGather, "ncclAllGather") SYM(GetErrorString, "ncclGetErrorString") SYM(CommCount, "ncclCommCount")
 #undef SYM
     });
     return api;
@@ -1379,6 +1419,17 @@ dyf_status dyf_comm_init(dyf_engine* e, const uint8_t* unique_id, int32_t rank, 
     e->comm = comm;
     e->comm_rank = rank;
     e->comm_world = world;
+    return DYF_OK;
+}
+
+dyf_status dyf_comm_count(const dyf_engine* e, int32_t* ranks_out) {
+    if (!e || !ranks_out) return DYF_ERR_INVALID_ARGUMENT;
+    *ranks_out = 0;
+    if (!e->comm) return DYF_OK;  // no communicator: 0 ranks
+    RcclApi& api = rccl_api();
+    int n = 0;
+    if (!api.CommCount || api.CommCount((ncclComm_t)e->comm, &n) != ncclSuccess) return DYF_ERR_HIP;
+    *ranks_out = n;
     return DYF_OK;
 }
 

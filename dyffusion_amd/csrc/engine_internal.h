@@ -137,6 +137,7 @@ struct dyf_engine {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_ev;
     std::vector<int> prof_rows;
     float* s_pair = nullptr;        // [2][max_batch][C][H][W]: outputs of a paired interpolator call
+    float* refine_coef = nullptr;   // [n_refine][2][total_c]: FiLM rows of the refinement pass in refine order (plan allocation)
     bool pair_interp = true;        // DYF_PAIR_INTERP=0: one forward per interpolator call (A/B testing)
     // engine-owned exchange (dyf_comm_init / dyf_sample_gather): RCCL communicator (ncclComm_t) and the all-gather receive buffer
     void* comm = nullptr;

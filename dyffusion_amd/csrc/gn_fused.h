@@ -18,7 +18,7 @@
 // that share the granule buffer.  Tags never repeat, so the buffer is zeroed once at allocation and never again.
 //
 // Residency: a workgroup waits only for workgroups of its own sample, which have neighbouring block ids (observed: blocks are
-// dispatched in id order, XCD = id % 8); HIP does not promise that, so the sweep is BOUNDED: on time-out the wave raises the
+// dispatched in id order, XCD = id % 8); HIP does not promise that, so the sweep is BOUNDED (2 s): on time-out the wave raises the
 // engine's host-visible error word, poisons its coefficients with NaN and goes on -- the launch always terminates, the failure is
 // loud (NaN output + dyf_sample error) and the engine falls back to the three-kernel path.  The launchers use this form only
 // when a sample's workgroups are few (<= 32) against the 512 resident ones.
@@ -38,7 +38,8 @@ struct GnFuse {
     const float* film_a;       // (1 + scale) rows [row][film_stride] or null (second Block of a ResnetBlock: no FiLM)
     const float* film_c;
     int film_stride;
-    uint32_t* err;             // host-visible (pinned, mapped) error word: nonzero after a sweep timed out
+    uint32_t* err;             // host-visible (pinned, mapped) words: [0] nonzero after a sweep timed out (output NaN-poisoned),
+                               // [1] nonzero after a sweep took > 1 024 passes (correct, but the workgroups are not co-scheduled)
 };
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -60,8 +61,11 @@ __device__ __forceinline__ double gn_shfl_xor_f64(double v, int d) {
 // L of the block.  cpg = channels per group (8, 16, 32 or 64), count = elements per (sample, group).
 // Lane (v = L & 15, sg = L >> 4) adds the slots sg, sg + 4, ... of value v = 2 * octet + {0: sum, 1: sum of squares} in fp64; the
 // four slot classes are combined by two exchanges (a + b is commutative: every lane gets the same bits).
-#ifndef GN_FUSE_SPIN_LIMIT
-#define GN_FUSE_SPIN_LIMIT 400000  // passes of >= ~1 us each: a sweep that has not matched after ~0.5 s never will
+// Bounded by TIME (s_memrealtime: a constant 100 MHz counter), not by passes: under time-slicing (two processes on one GPU) a sweep
+// can legitimately take milliseconds; 2 s without a match is a dead launch.  The clock and the error word (another sweep of this
+// engine already gave up: do not queue 2 s behind every later conv of the rollout) are looked at every 1 024 passes.
+#ifndef GN_FUSE_TIMEOUT_TICKS
+#define GN_FUSE_TIMEOUT_TICKS 200000000ull
 #endif
 template <int MAXJ>
 __device__ __forceinline__ float2 gn_fuse_sweep(const unsigned long long* base, int slot_stride, int nslots, uint32_t tag, int cpg,
@@ -70,6 +74,7 @@ __device__ __forceinline__ float2 gn_fuse_sweep(const unsigned long long* base, 
     const gn_gu64* p = (const gn_gu64*)base + v;
     double part = 0.0;
     bool failed = false;
+    unsigned long long t_start = 0;
     for (unsigned spins = 0;; ++spins) {
         bool ok = true;
         part = 0.0;
@@ -83,9 +88,20 @@ __device__ __forceinline__ float2 gn_fuse_sweep(const unsigned long long* base, 
             }
         }
         if (__all(ok)) break;
-        if (spins > GN_FUSE_SPIN_LIMIT) {  // wave-uniform
-            failed = true;
-            break;
+        if ((spins & 1023u) == 1023u) {  // wave-uniform
+            const unsigned long long now = __builtin_amdgcn_s_memrealtime();
+            if (t_start == 0) {
+                t_start = now;
+                // a sweep that needed 1 024 passes (> 1 ms; they take two or three when the chip is ours) means the sample's
+                // workgroups are not co-scheduled -- a GPU shared with another process.  err[1]: the host then switches the
+                // engine to the three-kernel GroupNorm path (no error: this launch still completes correctly)
+                if (lane == 0 && err) __hip_atomic_store(err + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            const bool gave_up = err && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u;
+            if (gave_up || now - t_start > GN_FUSE_TIMEOUT_TICKS) {
+                failed = true;
+                break;
+            }
         }
         __builtin_amdgcn_s_sleep(8);
     }

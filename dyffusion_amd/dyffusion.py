@@ -6,6 +6,7 @@ captured hipGraph.  What stays in Python is the scalar bookkeeping that the refe
 diffusion-step <-> interpolation-time tables and the sampling-schedule parser; it is resolved once into a plan.
 """
 import math
+import os
 from typing import Dict, List, Optional, Sequence, Union
 
 import numpy as np
@@ -17,6 +18,7 @@ from .engine import EngineLoss, HipEngine, collect_train_results, default_dtype_
 from .unet_simple import UNet, _AttrDict  # noqa: F401
 
 Step = Union[int, float]
+BF16_RESNET_MAX_FORWARDS = 32  # longest sampling plan (network forwards) a ResNet-UNet pair is served in bf16 storage (_ensure_plan)
 
 
 class DYffusion(nn.Module):
@@ -31,7 +33,8 @@ class DYffusion(nn.Module):
                  interpolator_horizon: Optional[int] = None, interpolator_window: int = 1,
                  enable_forecaster_dropout: bool = False, max_batch: int = 64, use_graph: bool = True,
                  enable_mfma: bool = True, loss_function: str = "mean_squared_error", dtype: Optional[str] = None,
-                 batch_invariant: bool = False, row_groups: Optional[int] = None, **kwargs):
+                 batch_invariant: bool = False, row_groups: Optional[int] = None, allow_bf16_long_rollout: bool = False,
+                 **kwargs):
         super().__init__()
         if model is None:
             raise ValueError("Arg ``model`` is missing... Please provide a backbone model for the diffusion model (e.g. a Unet)")
@@ -103,6 +106,7 @@ class DYffusion(nn.Module):
         self._engine_opts = dict(max_batch=max_batch, use_graph=use_graph, enable_mfma=enable_mfma, dtype=dtype,
                                  batch_invariant=batch_invariant,  # batch_invariant: bit-identical rows under any batching / sharding
                                  row_groups=row_groups)  # concurrent row groups of a sampling call (None = engine default)
+        self.allow_bf16_long_rollout = bool(allow_bf16_long_rollout)
         self._engine: Optional[HipEngine] = None
         self._plan_key = None
         self._seed: Optional[int] = None
@@ -269,6 +273,18 @@ class DYffusion(nn.Module):
                      forward_conditioning=hp.forward_conditioning, refine=refine, n_out_slots=n_slots,
                      interpolator_dropout=bool(self.enable_interpolator_dropout or self.training),
                      forecaster_dropout=bool(self.enable_forecaster_dropout))
+        # bf16 storage and the ResNet-UNet: ~1e-2 per forward, 4.6e-2 - 5.2e-2 per field over the T = 32 OISST plan (93 chained
+        # forwards; tests/test_gpu_unet_resnet.py) -- twice the 2.5e-2 this engine holds its 16-bit rollouts to.  Such a plan is
+        # REFUSED in bf16 rather than served at a tolerance nobody asked for: fp16 (the backbone's default) carries 6e-3 over the
+        # same rollout at the same speed.  DYF_ALLOW_BF16_LONG_ROLLOUT=1 / allow_bf16_long_rollout overrides (timing experiments).
+        nf, ni = eng.forward_counts()
+        if eng.dtype == "bf16" and eng.cfg.net[L.NET_FORECASTER].arch == L.ARCH_UNET_RESNET and nf + ni > BF16_RESNET_MAX_FORWARDS \
+                and not (self.allow_bf16_long_rollout or os.environ.get("DYF_ALLOW_BF16_LONG_ROLLOUT") == "1"):
+            eng.plan_valid = False
+            raise NotImplementedError(
+                f"a rollout of {nf + ni} network forwards of unet.Unet in bf16 storage drifts ~5e-2 from the fp32 reference "
+                f"(limit here: {BF16_RESNET_MAX_FORWARDS} forwards, <= 2.5e-2); use dtype='fp16' (the default for this backbone, "
+                f"6e-3 over the same rollout) or pass allow_bf16_long_rollout=True to accept the drift")
         self._plan_key = key
         self._plan_steps = steps
         self._emitted_slots = sorted({st["out_slot"] for st in steps if st["out_slot"] is not None})

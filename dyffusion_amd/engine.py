@@ -269,6 +269,12 @@ class HipEngine:
         self._check(self._lib.dyf_comm_destroy(self._h))
         self.comm_world = 1
 
+    def comm_count(self) -> int:
+        """Ranks of this engine's communicator as RCCL reports them (ncclCommCount); 0 when it owns none."""
+        n = C.c_int32(0)
+        self._check(self._lib.dyf_comm_count(self._h, C.byref(n)))
+        return n.value
+
     def sample_gather(self, initial: torch.Tensor, static: Optional[torch.Tensor], total_rows: int) -> torch.Tensor:
         """dyf_sample_gather: rollout of this rank's rows, ONE all-gather of the forecast stack, unpack -> (n_out_slots, total_rows,
         C, H, W) with every rank's rows in global order."""

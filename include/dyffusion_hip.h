@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define DYF_ABI_VERSION 5
+#define DYF_ABI_VERSION 6
 
 typedef struct dyf_engine dyf_engine;
 
@@ -204,6 +204,8 @@ int32_t dyf_row_groups(const dyf_engine* engine);
 dyf_status dyf_comm_unique_id(uint8_t* id_out /* [DYF_COMM_ID_BYTES], host */);
 dyf_status dyf_comm_init(dyf_engine* engine, const uint8_t* unique_id, int32_t rank, int32_t world);
 dyf_status dyf_comm_destroy(dyf_engine* engine);
+/* ranks of the engine's communicator as RCCL itself reports them (ncclCommCount); 0 = the engine owns none (ABI 6) */
+dyf_status dyf_comm_count(const dyf_engine* engine, int32_t* ranks_out);
 dyf_status dyf_sample_gather(dyf_engine* engine, const float* initial_dev, const float* static_dev, float* out_full_dev, int32_t nb,
                              int32_t total_rows, void* stream);
 

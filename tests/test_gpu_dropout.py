@@ -122,17 +122,21 @@ def _oracle_rollout_with_engine_masks(PF, PI, mk, hp, x0, c, seed, row_offset=0,
     return out, drop.fwd + 1
 
 
+@pytest.mark.parametrize("max_batch", [3, 24], ids=["paired-refine", "batched-refine"])
 @pytest.mark.parametrize("hp_extra", [dict(), dict(additional_interpolation_steps=2, timesteps=5, use_cold_sampling_for_last_step=True)],
                          ids=["h4", "h5k2_coldlast"])
-def test_rng_mode_rollout_equals_oracle_with_host_reproduced_masks(hp_extra):
+def test_rng_mode_rollout_equals_oracle_with_host_reproduced_masks(hp_extra, max_batch):
     """(a) The benchmarked mode: engine RNG + paired interpolator launches + hipGraph.  Two consecutive sample() calls:
-    the second continues the forward counter where the first stopped (fresh masks on graph replay)."""
+    the second continues the forward counter where the first stopped (fresh masks on graph replay).
+    max_batch = 24 (round 4): the workspace holds 48 rows, so the refinement pass of the 3-row call -- h - 1 interpolator forwards
+    that share their inputs -- goes out as ONE forward over (h - 1) * 3 rows (engine.hip run_plan) instead of pairs; row r must
+    draw the masks of forward counter + r / 3, exactly what the oracle's sequential calls draw."""
     hp = dict(HP4, **hp_extra)
     PF, PI = seeded_pair(64, 3, 2)
     g = torch.Generator().manual_seed(21)
     nb = 3
     x0, c = torch.randn(nb, 3, 23, 11, generator=g), torch.rand(nb, 2, 23, 11, generator=g)
-    m = build_dyffusion(PF, PI, MK64, 3, 2, hp, max_batch=nb, use_graph=True)
+    m = build_dyffusion(PF, PI, MK64, 3, 2, hp, max_batch=max_batch, use_graph=True)
     seed = 987654321
     m.seed(seed)
     got1 = {k: v.cpu() for k, v in m.sample(x0.to(DEV), static_condition=c.to(DEV)).items()}

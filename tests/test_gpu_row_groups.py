@@ -8,6 +8,7 @@ import pytest
 import torch
 
 import dyffusion_amd as D
+from dyffusion_amd.engine import HipEngine
 from oracle import nets, sampler
 from tests.gpu_common import cached, DEV, build_dyffusion, oracle_rollout, seeded_pair
 from tests.helpers import rel_rms
@@ -42,7 +43,7 @@ def test_default_groups_follow_architecture_and_size():
     assert ns._engine.row_groups == 1  # unet_simple: no groups unless asked for
 
 
-@pytest.mark.parametrize("dtype", ["fp16", "bf16"])
+@pytest.mark.parametrize("dtype", ["fp16"])  # (a 93-forward ResNet-UNet plan is refused in bf16: test_gpu_unet_resnet.py)
 def test_oisst_nb300_grouped_rollout_rows_match_the_oracle(dtype):
     """300 rows on 3 groups of 100 (the benchmarked split): rows of every group, all 7 fields, against oracle rollouts of those rows."""
     from tests.test_gpu_bench_forms import OISST_TOL
@@ -63,7 +64,7 @@ def test_oisst_nb300_grouped_rollout_rows_match_the_oracle(dtype):
     for f in ("conv_up_halo_kernel<5>+gn_fused", "conv_igemm2_kernel<2>+gn_fused"):
         assert f in forms and 100 in forms[f], (f, forms.get(f))
     assert all(nb not in v for v in forms.values()), forms
-    rows = [0, 99, 100, 199, 200, 299]
+    rows = [0, 100, 299]  # a row of each of the three groups
 
     def oracle():
         with torch.no_grad():
@@ -156,3 +157,57 @@ def test_row_groups_must_be_set_before_the_weights_and_small_calls_run_ungrouped
     assert all(set(v) == {8} or set(v) <= {8, 16} for v in forms.values()), forms  # paired interpolator launches are 16 rows
     for k in big:
         assert rel_rms(small[k], big[k][:8]) <= 2.5e-2
+
+
+def test_live_communicator_and_a_second_engine_keep_the_grouped_rollout_fast():
+    """VERDICT r3 item 3 / DESIGN 4.5: three concurrent row groups + the caller's stream use all four hardware queues of the process;
+    one more stream with work (RCCL's, torch.distributed's, a second engine's graph) makes two groups share a queue and the 300-row
+    OISST rollout falls well below what TWO groups deliver.  An engine that owns a communicator therefore runs its calls on two
+    groups (engine.hip sample_into_stack).  Here: the clean 3-group rate; then, with a live 1-rank RCCL communicator on the engine
+    AND a second engine with a captured graph alive in the process, the same call must (a) launch 150-row shares and (b) stay
+    within 15 % of the clean rate (measured: 3 700 vs 3 850 fields/s; the perturbed 3-group rate is ~3 100)."""
+    import time
+
+    from tests.gpu_common import build_dyffusion, seeded_pair
+    cfg, PF, PI, mirror = _oisst_pair(block_dropout=0.3, attn_dropout=0.1)
+    nb = 300
+    F_, I_ = mirror(PF, cfg, 1, 1, 1), mirror(PI, cfg, 2, 0, 1)
+    m = D.DYffusion(F_, D.InterpolatorHandle(I_, 7), max_batch=nb, forward_conditioning="data+noise", **OISST_HP)
+    x0 = torch.randn(nb, 1, 60, 60, generator=torch.Generator().manual_seed(5)).to(DEV)
+
+    def rate(fn, reps=3):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return nb * 7 * reps / (time.perf_counter() - t0)
+
+    clean = rate(lambda: m.sample(x0))
+    eng = m._engine
+    assert eng.row_groups == 3
+    # company: a second engine with a captured graph, kept alive, and a live communicator on the sampling engine
+    PF2, PI2 = seeded_pair(64, 3, 2)
+    mk = dict(dim=64, upsample_dims=[64, 64], outer_sample_mode="bilinear", with_time_emb=True, dropout=0.15)
+    hp = dict(timesteps=4, forward_conditioning="none", interpolate_before_t1=True, schedule="before_t1_only", sampling_type="cold",
+              refine_intermediate_predictions=True, enable_interpolator_dropout=True)
+    other = build_dyffusion(PF2, PI2, mk, 3, 2, hp, max_batch=8)
+    xo, co = torch.randn(8, 3, 23, 11).to(DEV), torch.rand(8, 2, 23, 11).to(DEV)
+    other.sample(xo, static_condition=co)
+    other.sample(xo, static_condition=co)  # graph replay
+    m.comm_init(HipEngine.comm_unique_id(eng.dtype), 0, 1, (60, 60), nb)
+    assert eng.comm_count() == 1
+    eng.form_log(True)
+    m.sample(x0)
+    forms = eng.form_log_read()
+    eng.form_log(False)
+    rows = set(forms["conv_up_halo_kernel<5>+gn_fused"])
+    assert rows == {150}, rows  # two groups of 150 rows, not three of 100
+    busy = rate(lambda: (m.sample(x0), other.sample(xo, static_condition=co))[0])
+    gathered = rate(lambda: m.sample_gathered(x0, None, nb))
+    print(f"OISST 300 rows: clean 3 groups {clean:.0f} fields/s; live communicator + second engine: {busy:.0f} (sample), "
+          f"{gathered:.0f} (sample_gathered through the 1-rank all-gather)")
+    assert busy >= 0.85 * clean and gathered >= 0.85 * clean
+    other._engine.close()
+    eng.close()

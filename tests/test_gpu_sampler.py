@@ -265,3 +265,42 @@ def test_criterion_reduction_matches_torch():
             assert abs(got - want) <= 2e-6 * max(1.0, abs(want)), (n, kind, got, want)
     big = torch.randn(4099, generator=g).to(DEV)
     assert abs(eng.criterion(big[1:], big[:-1], "l1") - float((big[1:] - big[:-1]).abs().double().mean())) <= 1e-5  # misaligned views
+
+
+def test_lightning_checkpoint_through_to_dyf_sample_matches_the_reference(tmp_path):
+    """SURVEY 8f-4 end to end: a checkpoint in the layout Lightning writes for `MultiHorizonForecastingDYffusion`
+    (`state_dict["model.model.*"]` = forecaster, `["model.interpolator.model.*"]` = the frozen interpolator copy; src/interface.py:115-172)
+    on disk -> `load_networks_from_checkpoints` -> fresh engine networks -> `dyf_sample`, against the fields the REFERENCE produced
+    with those weights (fixture sample_cold_refine, make_golden.py)."""
+    from dyffusion_amd.checkpoint import load_networks_from_checkpoints
+    from tests.gpu_common import mirror_from_params
+    import dyffusion_amd as D
+
+    z = load_npz("sample_cold_refine.npz")
+    hp = json.loads(str(z["hp"]))
+    PF, PI = split_state(z, "F"), split_state(z, "I")
+    sd = {"model.model." + k: v.clone() for k, v in PF.items()}
+    sd.update({"model.interpolator.model." + k: v.clone() for k, v in PI.items()})
+    sd["model.interpolator.some_metric_buffer"] = torch.zeros(3)  # non-network state of the wrapped experiment: ignored
+    path = tmp_path / "epoch=3-step=77.ckpt"
+    torch.save({"state_dict": sd, "epoch": 3, "global_step": 77, "pytorch-lightning_version": "2.0.0"}, path)
+    mk = hp["model"]
+    kw = dict(dim=mk["dim"], with_time_emb=True, upsample_dims=mk["upsample_dims"], outer_sample_mode=mk["outer_sample_mode"],
+              dropout=mk["dropout"], num_output_channels=4)
+    F = D.UNet(num_input_channels=4, num_conditional_channels=1, **kw)   # forward_conditioning = "none": static condition only
+    I = D.UNet(num_input_channels=8, num_conditional_channels=1, **kw)
+    for net in (F, I):  # start from weights that are NOT the checkpoint's
+        for p_ in net.parameters():
+            torch.nn.init.normal_(p_, std=0.5)
+    meta = load_networks_from_checkpoints(F, I, forecaster_ckpt=str(path))
+    assert meta == {"epoch": 3, "global_step": 77}
+    keys = ["forward_conditioning", "schedule", "additional_interpolation_steps", "interpolate_before_t1", "sampling_type",
+            "time_encoding", "refine_intermediate_predictions", "enable_interpolator_dropout"]
+    m = D.DYffusion(F, D.InterpolatorHandle(I, hp["timesteps"]), timesteps=hp["timesteps"], max_batch=hp["B"],
+                    **{k: hp[k] for k in keys})
+    got = m.sample(torch.from_numpy(z["x0"]).to(DEV), static_condition=torch.from_numpy(z["c"]).to(DEV))
+    want = {k[len("out::"):]: v for k, v in z.items() if k.startswith("out::")}
+    assert sorted(got) == sorted(want)
+    worst = max(rel_rms(got[k].cpu().reshape(w.shape), w) for k, w in want.items())
+    print("checkpoint -> dyf_sample vs the reference's fields: worst rel-rms", worst)
+    assert worst <= TOL

@@ -190,14 +190,36 @@ def test_flash_attention_long_sequence_with_dropout(dtype):
     assert rel_rms(got, want) <= TOL[dtype]
 
 
-@pytest.mark.parametrize("dtype,tol", [("bf16", 7e-2), ("fp16", 1e-2)])
+def test_bf16_is_refused_for_long_resnet_unet_rollouts():
+    """the T = 32 OISST plan in bf16 storage drifts 4.6e-2 - 5.2e-2 per field (measured through round 3 under a 7e-2
+    'tolerance').  The engine now refuses a ResNet-UNet plan of more than 32 forwards in bf16 instead of serving it; fp16 (the
+    backbone's default) is held to 1e-2 below; allow_bf16_long_rollout=True is the explicit override."""
+    cfg = dict(dim=64, dim_mults=[1, 2, 4], with_time_emb=True, block_dropout=0.0, block_dropout1=0.0, attn_dropout=0.0,
+               resnet_block_groups=8, input_dropout=0.0, upsample_dims=None)
+    PF, PI = seeded_unet(64, (1, 2, 4), 2, 1, seed=1), seeded_unet(64, (1, 2, 4), 2, 1, seed=2)
+    hp = dict(timesteps=7, schedule="before_t1_only", additional_interpolation_steps=25, interpolate_before_t1=True,
+              sampling_type="cold", refine_intermediate_predictions=False, forward_conditioning="data", enable_interpolator_dropout=False)
+    x0 = torch.randn(2, 1, 60, 60, generator=torch.Generator().manual_seed(0)).to(DEV)
+    m = D.DYffusion(mirror(PF, cfg, 1, 1, 1), D.InterpolatorHandle(mirror(PI, cfg, 2, 0, 1), 7), max_batch=2, dtype="bf16", **hp)
+    with pytest.raises(NotImplementedError, match="bf16"):
+        m.sample(x0)
+    m2 = D.DYffusion(mirror(PF, cfg, 1, 1, 1), D.InterpolatorHandle(mirror(PI, cfg, 2, 0, 1), 7), max_batch=2, dtype="bf16",
+                     allow_bf16_long_rollout=True, **hp)
+    out = m2.sample(x0)
+    assert sorted(out) == [f"t{i}_preds" for i in range(1, 8)] and all(bool(torch.isfinite(v).all()) for v in out.values())
+    short = dict(hp, additional_interpolation_steps=2)  # T = 9: 9 + 15 forwards, served in bf16
+    m3 = D.DYffusion(mirror(PF, cfg, 1, 1, 1), D.InterpolatorHandle(mirror(PI, cfg, 2, 0, 1), 7), max_batch=2, dtype="bf16", **short)
+    assert sum(m3.sample(x0)["t7_preds"].shape) > 0 and sum(m3._engine.forward_counts()) <= 32
+
+
+@pytest.mark.parametrize("dtype,tol", [("fp16", 1e-2)])
 def test_fullsize_oisst_rollout_matches_reference_fields(dtype, tol):
     """BASELINE configs[2] at full size (fixture G6-OISST, outputs of the imported reference): 60x60, C=1, ResNet-UNet dim 64
     mults (1,2,4) for both networks, h=7 with k=25 extra interpolation steps -- the T=32 plan of 32 forecaster + 61
     interpolator forwards -- forward_conditioning "data+noise" with the reference's normal draws injected, cold sampling,
     dropout off, NB=1.  All seven fields.  Tolerance: the recursion chains 93 forwards of a network with ~60 16-bit
-    roundings per forward (every conv output is stored before its GroupNorm): measured 4.6e-2 - 5.2e-2 in bf16 (1e-2 per
-    forward), 6e-3 in fp16; the fp16 build is the one held to SURVEY 8c's 1e-2."""
+    roundings per forward: measured 4.6e-2 - 5.2e-2 in bf16 (1e-2 per forward) -- such plans are refused in bf16 since round 4, see the
+    test above -- and 6e-3 in fp16, the build held to SURVEY 8c's 1e-2."""
     z = load_npz("fullsize_oisst_fields.npz")
     meta = json.loads(str(z["meta"]))
     fc, ic = meta["forecaster_channels"], meta["interpolator_channels"]
