@@ -483,6 +483,7 @@ dyf_status dyf_engine_create(const dyf_engine_config* cfg, dyf_engine** out_engi
         rs = sc_alloc_workspace(e);
         if (rs != DYF_OK) return bail(rs, e->err);
     }
+    if (const char* gm = getenv("DYF_GROUP_MIN_ROWS")) e->group_min_rows = std::max(1, atoi(gm));
     *out_engine = e;
     if (!g_creating_group_child) {
         // default: DYF_ROW_GROUPS, else by architecture (measured on the ResNet-UNet shapes)

@@ -1185,9 +1185,12 @@ __global__ __launch_bounds__(256) void linattn_ctx_mfma_kernel(LinAttnArgs a, fl
 // dmap 0: slot j of lane (e, hi') = ctx[d = 16 s + 8 hi' + j][e] (linattn_out_mfma_kernel: q' fragments loaded from memory);
 // dmap 1: d = 16 s + 8 (j >> 2) + 4 hi' + (j & 3) (linattn_fused_out_kernel: q' fragments are MFMA accumulator registers)
 __global__ __launch_bounds__(256) void linattn_merge_kernel(const float* part, int nblk, float inv_n, el16_t* frags, int dmap) {
-    // One workgroup per (sample, head).  At 512^2 there are 256 partials per head: the serial three-pass form (max, sum,
-    // weighted accumulation, each a chain of dependent loads) took 225 us; here the max / sum passes run 8 partial-groups wide,
-    // the rescaling factors exp(M_b - M) are computed once into LDS, and the accumulation keeps 4 loads in flight.
+    // gridDim.y workgroups per (sample, head), each owning 16 / gridDim.y of the 16 row blocks r (64 ctx entries each) -- round 4: at
+    // 512^2 with 4 rows the launch was 16 workgroups on a 256-CU chip reading 1.1 MB each (46 us, 12 launches per forward).  At
+    // 512^2 there are 256 partials per head: the serial three-pass form (max, sum, weighted accumulation, each a chain of dependent
+    // loads) took 225 us; here the max / sum passes run 8 partial-groups wide, the rescaling factors exp(M_b - M) are computed once
+    // into LDS (by every workgroup of the head: 8 K exponentials), and the accumulation keeps 4 loads in flight.  The result does
+    // not depend on gridDim.y (same per-entry summation order).
     __shared__ float wexp[256][32];   // [partial][column d]; nblk <= 256 per pass (looped otherwise)
     __shared__ float red[8][32];
     const int bh = blockIdx.x, tid = threadIdx.x, lane = tid & 63, rq = tid >> 6, d = lane & 31, hi = lane >> 5;
@@ -1217,6 +1220,7 @@ __global__ __launch_bounds__(256) void linattn_merge_kernel(const float* part, i
 #pragma unroll
         for (int r4 = 0; r4 < 4; ++r4) {
             const int r = rq * 4 + r4;
+            if ((r4 % (int)gridDim.y) != (int)blockIdx.y) continue;  // this workgroup's share of the wave's four row blocks
             const float* pr = pb + (size_t)b0 * LA_PART + r * 64 + lane;
             float v0 = 0.0f, v1 = 0.0f, v2 = 0.0f, v3 = 0.0f;
             int b = 0;
@@ -1240,6 +1244,7 @@ __global__ __launch_bounds__(256) void linattn_merge_kernel(const float* part, i
 #pragma unroll
     for (int r4 = 0; r4 < 4; ++r4) {
         const int r = rq * 4 + r4;
+        if ((r4 % (int)gridDim.y) != (int)blockIdx.y) continue;
         const float v = acc[r4] * norm;
         const int e = (r >> 2) * 8 + hi * 4 + (r & 3);
         const int fh = dmap ? (d >> 2) & 1 : (d >> 3) & 1, fj = dmap ? ((d >> 3) & 1) * 4 + (d & 3) : d & 7;
@@ -1326,7 +1331,7 @@ hipError_t launch_linear_attention(const LinAttnArgs& a, hipStream_t s) {
         float* part = a.scratch;                                          // [BH][nblk][LA_PART]
         el16_t* frags = (el16_t*)(a.scratch + (size_t)BH * nblk * LA_PART);  // [BH][2][2][64][8]
         hipLaunchKernelGGL(linattn_ctx_mfma_kernel, dim3(nblk, BH), dim3(256), 0, s, a, part, nblk);
-        hipLaunchKernelGGL(linattn_merge_kernel, dim3(BH), dim3(256), 0, s, (const float*)part, nblk, 1.0f / (float)a.hw, frags, 0);
+        hipLaunchKernelGGL(linattn_merge_kernel, dim3(BH, (nblk >= 32 && BH < 128) ? 4 : 1), dim3(256), 0, s, (const float*)part, nblk, 1.0f / (float)a.hw, frags, 0);
         hipLaunchKernelGGL(linattn_out_mfma_kernel, dim3((a.hw + 511) / 512, BH), dim3(256), 0, s, a, (const el16_t*)frags);
         return hipGetLastError();
     }
@@ -1672,7 +1677,7 @@ hipError_t launch_linear_attention_fused(const LinAttnFusedArgs& a, hipStream_t 
     } else {
         hipLaunchKernelGGL(linattn_fused_ctx_kernel<128>, grid, dim3(256), LfCfg<128>::CTX_LDS, s, a.xn, a.hw, a.wqkv_frag, part, nblk);
     }
-    hipLaunchKernelGGL(linattn_merge_kernel, dim3(BH), dim3(256), 0, s, (const float*)part, nblk, 1.0f / (float)a.hw, frags, 1);
+    hipLaunchKernelGGL(linattn_merge_kernel, dim3(BH, (nblk >= 32 && BH < 128) ? 4 : 1), dim3(256), 0, s, (const float*)part, nblk, 1.0f / (float)a.hw, frags, 1);
     if (a.c == 64) {
         hipLaunchKernelGGL(linattn_fused_out_kernel<64>, grid, dim3(256), LfCfg<64>::OUT_LDS, s, a.xn, a.xres, a.hw, a.wqkv_frag, a.wout_frag, a.bout, (const el16_t*)frags, a.y);
     } else {

@@ -66,7 +66,12 @@ class Unet(nn.Module):
         super().__init__()
         # (outer_sample_mode / upsample_dims: the reference's own constructor raises AttributeError for them -- unet.py:155 reads
         # self.outer_sample_mode, which is never set -- so there is no behaviour to reproduce)
-        unsupported = dict(init_dim=init_dim not in (None, dim), learned_variance=learned_variance,
+        # learned_variance: accepted -- in the reference it only feeds `default_out_dim` (unet.py:233), which `out_dim =
+        # default(output_channels, ...)` never uses because output_channels = num_output_channels or input_channels is always set:
+        # a no-op there, a no-op here.  init_dim != dim: the reference's own forward fails (final_res_block is built for 2 * dim
+        # channels, unet.py:236, but receives 2 * init_dim): nothing to reproduce.  init_stride != 1 (a half-resolution output) is
+        # the one real option left out.
+        unsupported = dict(init_dim=init_dim not in (None, dim),
                            outer_sample_mode=outer_sample_mode is not None, upsample_dims=upsample_dims is not None,
                            init_stride=init_stride != 1)
         bad = [k for k, v in unsupported.items() if v]
@@ -80,7 +85,7 @@ class Unet(nn.Module):
                                  spatial_shape=spatial_shape, outer_sample_mode=None, upsample_dims=None,
                                  loss_function=loss_function, keep_spatial_dims=bool(keep_spatial_dims),
                                  double_conv_layer=bool(double_conv_layer), learned_sinusoidal_cond=bool(learned_sinusoidal_cond),
-                                 learned_sinusoidal_dim=int(learned_sinusoidal_dim))
+                                 learned_sinusoidal_dim=int(learned_sinusoidal_dim), learned_variance=bool(learned_variance))
         self.num_input_channels = num_input_channels
         self.num_conditional_channels = num_conditional_channels
         cin = num_input_channels + num_conditional_channels

@@ -231,3 +231,28 @@ def test_engine_loss_rejects_a_tape_overwritten_by_another_owner():
     with pytest.raises(RuntimeError, match="earlier training forward"):
         la.backward()
     assert a.ran == 1
+
+
+def test_unet_learned_variance_is_the_reference_noop_and_init_dim_is_refused():
+    """unet.py:233-236: `learned_variance` only feeds default_out_dim, which out_dim = default(output_channels, ...) never uses
+    (output_channels is always set) -- accepted as the no-op it is; init_dim != dim cannot run in the reference either
+    (final_res_block expects 2 * dim channels) and stays refused, as does init_stride != 1."""
+    import os
+    import pytest
+    import dyffusion_amd as D
+
+    kw = dict(dim=8, dim_mults=(1, 2), with_time_emb=True, num_input_channels=2, num_output_channels=3, num_conditional_channels=1)
+    a, b = D.Unet(**kw), D.Unet(learned_variance=True, **kw)
+    assert {k: tuple(v.shape) for k, v in a.state_dict().items()} == {k: tuple(v.shape) for k, v in b.state_dict().items()}
+    assert b.final_conv.out_channels == 3 and b.hparams.learned_variance is True
+    for bad in (dict(init_dim=16), dict(init_stride=2)):
+        with pytest.raises(NotImplementedError):
+            D.Unet(**bad, **kw)
+    if os.path.isdir("/root/reference/src"):  # the reference agrees (build container only)
+        from oracle import ref_import
+        ref_import.activate()
+        from src.models.unet import Unet as RefUnet
+        r = RefUnet(dim=8, dim_mults=(1, 2), with_time_emb=True, learned_variance=True, num_input_channels=2, num_output_channels=3,
+                    num_conditional_channels=1, spatial_shape=(8, 8), verbose=False)
+        assert r.final_conv.out_channels == 3
+        assert {k: tuple(v.shape) for k, v in r.state_dict().items()} == {k: tuple(v.shape) for k, v in b.state_dict().items()}
