@@ -674,8 +674,9 @@ hipError_t launch_conv_stats(const ConvArgs& a_in, int path, hipStream_t stream,
             return conv_up_halo_supported(a) ? launch_conv_up_halo(a, stream) : hipErrorInvalidValue;
         if (a.up2x && use_halo && a.h >= halo_min && a.w >= halo_min && conv_up_halo_supported(a)) return launch_conv_up_halo(a, stream);
         // plain 3x3 / s1 convs with cout % 256 == 0 on 8x16-tileable planes: the halo kernel (one window DMA per chunk
-        // instead of one gather per tap); DYF_HALO3=0 disables, DYF_HALO3_MIN_TILES sets the smallest launch (default 256
-        // tiles: measured at NB = 80, enc3 with 320 tiles 115 -> 94 us)
+        // instead of one gather per tap); DYF_HALO3=0 disables, DYF_HALO3_MIN_TILES sets the smallest launch (measured at NB = 80,
+        // enc3 with 320 tiles 115 -> 94 us; round 4, with the rows forms: from 80 tiles on -- NS at 7 / 10 / 25 rows +3.4 / +5.7 /
+        // +2.5 % against the 256 of rounds 1-3, nothing lost at 4 or 80 rows; 64 costs 2.4 % at 4 rows)
         static const bool h5_all = getenv("DYF_HALO5_ALL") && atoi(getenv("DYF_HALO5_ALL")) != 0;
         if (!a.up2x && a.kh == 3 && a.kw == 3 && a.cout % 256 == 0 && !h5_all && a.out_f32 == nullptr && a.residual == nullptr) {
             const char* h3 = getenv("DYF_HALO3");
@@ -685,7 +686,7 @@ hipError_t launch_conv_stats(const ConvArgs& a_in, int path, hipStream_t stream,
                 const char* mt3 = getenv("DYF_HALO3_MIN_TILES");
                 const long long tiles3 = (nsel * a.h * a.w / 128) * (a.cout / 256);
                 static const bool rows = !(getenv("DYF_HALO_ROWS") && atoi(getenv("DYF_HALO_ROWS")) == 0);
-                if (b.wpk_up_frag && tiles3 >= (mt3 ? atoll(mt3) : 256) && conv_halo3_supported(b))
+                if (b.wpk_up_frag && tiles3 >= (mt3 ? atoll(mt3) : 80) && conv_halo3_supported(b))
                     return rows && conv_halo_rows3_supported(b) ? launch_conv_halo_rows3(b, stream) : launch_conv_halo3(b, stream);
             }
         }
@@ -726,7 +727,7 @@ hipError_t launch_conv_stats(const ConvArgs& a_in, int path, hipStream_t stream,
                 // cout % 256 == 0: 8 x 16 tiles x 256 channels; else 16 x 16 tiles x 128 channels
                 const long long tiles3 = a.cout % 256 == 0 ? (nsel * a.ho * a.wo / 128) * (a.cout / 256)
                                                            : (nsel * a.ho * a.wo / 256) * (a.cout / 128);
-                if (b.wpk_up_frag && tiles3 >= (mt3 ? atoll(mt3) : 256) && conv_halo_s2_supported(b)) return launch_conv_halo_s2(b, stream);
+                if (b.wpk_up_frag && tiles3 >= (mt3 ? atoll(mt3) : 80) && conv_halo_s2_supported(b)) return launch_conv_halo_s2(b, stream);
             }
         }
         static const bool use_igemm2 = !(getenv("DYF_IGEMM2") && atoi(getenv("DYF_IGEMM2")) == 0);
