@@ -141,6 +141,10 @@ bool conv_igemm2_supported(const ConvArgs& a);
 hipError_t conv_igemm2_init();
 hipError_t launch_conv_igemm2(const ConvArgs& a, hipStream_t stream);
 void pack_conv_frag(const el16_t* wpk, int cout, int taps, int cin, el16_t* out);
+// small-M 1x1 / 2x2-s2 convs (conv_skinny.hip): 32 x 32 tiles, K split over the workgroup's four waves, one launch (replaces
+// conv_igemm_kernel<128,128> + split-K + conv_splitk_finish_kernel in the few-rows regime); fragments: pack_conv_frag
+bool conv_skinny_supported(const ConvArgs& a);
+hipError_t launch_conv_skinny(const ConvArgs& a, hipStream_t stream);
 // registry device-pointer(wpk) -> device-pointer(fragment-ordered copy); filled when weights are uploaded
 void conv_register_frag(const el16_t* wpk_dev, const el16_t* frag_dev);
 void conv_unregister_frag(const void* wpk_dev);

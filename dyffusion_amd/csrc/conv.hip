@@ -741,6 +741,18 @@ hipError_t launch_conv_stats(const ConvArgs& a_in, int path, hipStream_t stream,
             const long long min_tiles = mt ? atoll(mt) : 384;
             if (tiles2 >= min_tiles && conv_igemm2_supported(b)) return launch_conv_igemm2(b, stream);
         }
+        // few rows: 1x1 / 2x2-s2 convs whose 128 x 128 tiles would not even fill a quarter of the chip (the split-K regime of
+        // launch_igemm) run on conv_skinny_kernel -- K split over the four waves of a 32 x 32 tile, one launch (DYF_SKINNY=0 disables)
+        if (!a.up2x && a.cout % 128 == 0) {
+            static const bool skinny = !(getenv("DYF_SKINNY") && atoi(getenv("DYF_SKINNY")) == 0);
+            const long long tiles128 = ((nsel * a.ho * a.wo + 127) / 128) * (a.cout / 128);
+            ConvArgs b = a;
+            if (!b.wpk_frag) b.wpk_frag = conv_lookup_frag(b.wpk);
+            // (64 tiles of 128 x 128: NS at 1 / 4 / 7 / 10 rows +10.6 / +4 / +2 / +1 %, nothing lost at 25 / 38; at 128 the 25- and
+            // 38-row rollouts lose 2.5 %)
+            static const long long sk_max = getenv("DYF_SKINNY_MAX_TILES") ? atoll(getenv("DYF_SKINNY_MAX_TILES")) : 64;
+            if (skinny && tiles128 <= sk_max && conv_skinny_supported(b)) return launch_conv_skinny(b, stream);
+        }
         if (a.cout % 128 == 0)
             return a.up2x ? launch_igemm<128, 128, 2, 2, 1>(a, stream) : launch_igemm<128, 128, 2, 2, 0>(a, stream);
         return a.up2x ? launch_igemm<256, 64, 4, 1, 1>(a, stream) : launch_igemm<256, 64, 4, 1, 0>(a, stream);
