@@ -692,11 +692,13 @@ hipError_t launch_conv_stats(const ConvArgs& a_in, int path, hipStream_t stream,
         }
         // 3x3 / s1 convs with 64 or 128 (any multiple of 64 that is not one of 256) output channels -- the ResNet-UNet levels --
         // on planes of any size: SP = 5 of the halo kernel, when the 16 x 32 tiles cover the plane reasonably (>= 60 %: not
-        // 15 x 15) and fill the chip.  DYF_HALO5=0 disables, DYF_HALO5_MIN_TILES sets the smallest launch.
+        // 15 x 15).  DYF_HALO5=0 disables, DYF_HALO5_MIN_TILES sets the smallest launch (64 tiles since round 4: with the GroupNorm
+        // fused into this form a small launch also saves the three GroupNorm kernels behind the implicit-GEMM fallback -- OISST
+        // shapes at 38 / 75 rows +5.8 / +3 % against the 256 of round 3).
         if (!a.up2x && a.kh == 3 && a.kw == 3 && a.stride == 1 && a.cout % 64 == 0 && (a.cout % 256 != 0 || h5_all) && a.out_f32 == nullptr &&
             a.residual == nullptr) {
             static const bool h5 = !(getenv("DYF_HALO5") && atoi(getenv("DYF_HALO5")) == 0);
-            static const long long h5_min = getenv("DYF_HALO5_MIN_TILES") ? atoll(getenv("DYF_HALO5_MIN_TILES")) : 256;
+            static const long long h5_min = getenv("DYF_HALO5_MIN_TILES") ? atoll(getenv("DYF_HALO5_MIN_TILES")) : 64;
             if (h5) {
                 ConvArgs b = a;
                 b.wpk_up_frag = conv_lookup_halo3_frag(b.wpk);
@@ -793,7 +795,7 @@ hipError_t launch_conv_gn_fused(const ConvArgs& a_in, int path, hipStream_t stre
     const long long nsel = a.n_sel > 0 ? a.n_sel : a.n;
     if (a.kh == 3 && a.kw == 3 && a.stride == 1 && a.pad == 1 && a.cout % 64 == 0 && a.cout % 256 != 0) {
         static const bool h5 = !(getenv("DYF_HALO5") && atoi(getenv("DYF_HALO5")) == 0);
-        static const long long h5_min = getenv("DYF_HALO5_MIN_TILES") ? atoll(getenv("DYF_HALO5_MIN_TILES")) : 256;
+        static const long long h5_min = getenv("DYF_HALO5_MIN_TILES") ? atoll(getenv("DYF_HALO5_MIN_TILES")) : 64;
         ConvArgs b = a;
         b.wpk_up_frag = conv_lookup_halo3_frag(b.wpk);
         const long long ty = (a.h + 15) / 16, tx = (a.w + 31) / 32;

@@ -58,9 +58,37 @@ def _assert_bench_forms(forms):
     # the implicit-GEMM kernels (with split-K where a launch has <= 128 tiles) serve only the small planes: enc4, enc5, dec0,
     # dec1 (16^2 .. 4^2) -- 4 launches per forward; every conv of the 256^2 .. 32^2 planes went to one of the forms above
     n_fwd = sum(forms["readout_dma_kernel"].values())
-    small = sum(sum(v.values()) for f, v in forms.items() if f.startswith("conv_igemm"))
+    # (conv_skinny_kernel, round 4: the launches of <= 64 tiles -- enc5 and dec0 of an unpaired 80-row forward -- instead of split-K)
+    small = sum(sum(v.values()) for f, v in forms.items() if f.startswith("conv_igemm") or f == "conv_skinny_kernel")
     assert small == 4 * n_fwd, (small, n_fwd, forms)
     assert "conv_direct_kernel" not in forms
+
+
+def oracle_nb80_rows(mk, PF, PI, x0, c, rows):
+    """fp32 oracle rollouts of rows of the 80-row benchmark batch, MC dropout off (t1 / t8 / t16 are what the test compares)."""
+    def run():
+        out = oracle_rollout(PF, PI, mk, HP, x0[rows], c[rows])
+        return {k: out[k] for k in ("t1_preds", "t8_preds", "t16_preds")}
+    return cached("ns80_rows_" + "_".join(map(str, rows)), run, depends_on=[x0[rows], c[rows], PF["init_conv.weight"], PI["readout.0.weight"]])
+
+
+def oracle_nb80_row_with_engine_masks(mk, PF, PI, x0, c, hp, seed, r):
+    """fp32 oracle rollout of ONE row of the 80-row batch with the interpolator drawing the ENGINE's MC-dropout masks of global row r,
+    rebuilt on the host (tests/rng_host.py)."""
+    uh, uw = mk["upsample_dims"]
+
+    def run():
+        drop = R.EngineDropout(seed, mk["dim"], uh, uw, row_offset=r)
+
+        def i_fn(x, t, cond):
+            drop.begin_forward()
+            return nets.unet_simple_forward(PI, mk, x, t, cond, dropout=drop)
+
+        with torch.no_grad():
+            out = sampler.sample_loop(lambda x, t, cond: nets.unet_simple_forward(PF, mk, x, t, cond), i_fn, x0[r:r + 1], c[r:r + 1], hp)
+        return {k: out[k] for k in ("t1_preds", "t8_preds", "t16_preds")}
+    return cached(f"ns80_dropout_seed{seed}_row{r}", run,
+                  depends_on=[x0[r:r + 1], c[r:r + 1], PF["init_conv.weight"], PI["readout.0.weight"], torch.tensor([float(seed % 100003), float(r)])])
 
 
 def test_nb80_graph_paired_rollout_rows_match_the_oracle():
@@ -77,8 +105,8 @@ def test_nb80_graph_paired_rollout_rows_match_the_oracle():
     replay = m.sample(x0.to(DEV), static_condition=c.to(DEV))
     for k in first:
         assert torch.equal(first[k], replay[k]), k
-    rows = [0, 79]  # (an oracle rollout of 60 forwards at 256^2 is 20-30 s of CPU time per row: the suite's budget)
-    want = oracle_rollout(PF, PI, mk, HP, x0[rows], c[rows])
+    rows = [0, 79]  # (an oracle rollout of 60 forwards at 256^2 is 20-30 s of CPU time per row: disk-cached, tests/gpu_common.cached)
+    want = oracle_nb80_rows(mk, PF, PI, x0, c, rows)
     worst = 0.0
     for k in ("t1_preds", "t8_preds", "t16_preds"):
         for j, r in enumerate(rows):
@@ -102,17 +130,8 @@ def test_nb80_graph_paired_rollout_with_mc_dropout_rows_match_the_oracle_on_the_
     forms = eng.form_log_read()
     eng.form_log(False)
     _assert_bench_forms(forms)
-    uh, uw = mk["upsample_dims"]
     for r in (79,):
-        drop = R.EngineDropout(seed, mk["dim"], uh, uw, row_offset=r)
-
-        def i_fn(x, t, cond):
-            drop.begin_forward()
-            return nets.unet_simple_forward(PI, mk, x, t, cond, dropout=drop)
-
-        with torch.no_grad():
-            want = sampler.sample_loop(lambda x, t, cond: nets.unet_simple_forward(PF, mk, x, t, cond), i_fn,
-                                       x0[r:r + 1], c[r:r + 1], hp)
+        want = oracle_nb80_row_with_engine_masks(mk, PF, PI, x0, c, hp, seed, r)
         for k in ("t1_preds", "t8_preds", "t16_preds"):
             e = rel_rms(got[k][r].cpu(), want[k][0])
             print(f"NB=80 graph+paired, MC dropout on: {k} row {r}: rel-RMS {e:.3e}")
@@ -180,15 +199,54 @@ def _oisst_setup(block_dropout=0.0, block_dropout1=0.0, attn_dropout=0.0):
     return cfg, PF, PI
 
 
+def oisst_fwd_case():
+    """Inputs of the 300-row forward test; the oracle evaluates every 5th row and the last one (rows are independent; 300 rows of fp32
+    CPU forward are a minute)."""
+    cfg, _, PI = _oisst_setup(block_dropout=0.3, block_dropout1=0.1, attn_dropout=0.2)
+    nb = 300
+    g = torch.Generator().manual_seed(31)
+    x, t = torch.randn(nb, 2, 60, 60, generator=g), (torch.arange(nb) % 7 + 1).float() * 0.5
+    return cfg, PI, x, t, sorted(set(range(0, nb, 5)) | {nb - 1})
+
+
+def oracle_oisst_fwd_eval(cfg, PI, x, t, rows):
+    def run():
+        with torch.no_grad():
+            return nets.resnet_unet_forward(PI, cfg, x[rows], t[rows], None)
+    return cached("oisst300_fwd_eval", run, depends_on=[x[rows], t[rows], PI["init_conv.weight"], PI["final_conv.weight"]])
+
+
+OISST_ROLLOUT_HP = dict(timesteps=7, schedule="before_t1_only", additional_interpolation_steps=25, interpolate_before_t1=True,
+                        sampling_type="cold", refine_intermediate_predictions=False, forward_conditioning="data+noise",
+                        time_encoding="dynamics", enable_interpolator_dropout=False)
+
+
+def oisst_rollout_case():
+    cfg, PF, PI = _oisst_setup()
+    nb = 300
+    g = torch.Generator().manual_seed(33)
+    x0 = torch.randn(nb, 1, 60, 60, generator=g)
+    noise = torch.randn(32, nb, 1, 60, 60, generator=g)
+    return cfg, PF, PI, x0, noise, [150, 299]
+
+
+def oracle_oisst_rollout_rows(cfg, PF, PI, x0, noise, rows):
+    def run():
+        it = iter(range(32))
+        with torch.no_grad():
+            return sampler.sample_loop(lambda x, t, cnd: nets.resnet_unet_forward(PF, cfg, x, t, cnd),
+                                       lambda x, t, cnd: nets.resnet_unet_forward(PI, cfg, x, t, cnd), x0[rows], None, OISST_ROLLOUT_HP,
+                                       noise_fn=lambda tensor: noise[next(it)][rows])
+    return cached("oisst300_rollout_rows", run, depends_on=[x0[rows], noise[:, rows], PF["init_conv.weight"], PI["final_conv.weight"]])
+
+
 @pytest.mark.parametrize("dtype", ["fp16", "bf16"])
 def test_oisst_nb300_forward_with_injected_dropout_matches_the_oracle(dtype):
     """One interpolator forward over 300 DISTINCT rows, eval and with every dropout site active (masks recorded from the oracle's
     seeded draws and injected): every 5th row against the oracle."""
     from tests.test_gpu_unet_resnet import engine_masks, mirror
-    cfg, _, PI = _oisst_setup(block_dropout=0.3, block_dropout1=0.1, attn_dropout=0.2)
-    nb = 300
-    g = torch.Generator().manual_seed(31)
-    x, t = torch.randn(nb, 2, 60, 60, generator=g), (torch.arange(nb) % 7 + 1).float() * 0.5
+    cfg, PI, x, t, rows = oisst_fwd_case()
+    nb = x.shape[0]
     net = mirror(PI, cfg, 2, 0, 1, dtype)
     net._own_engine(nb, (60, 60))
     eng = net._engine
@@ -200,10 +258,7 @@ def test_oisst_nb300_forward_with_injected_dropout_matches_the_oracle(dtype):
     for f in OISST_FORMS:
         assert f in forms and nb in forms[f], (f, forms.get(f))
     assert not any(f in forms for f in GN_KERNELS), sorted(forms)  # every GroupNorm of the forward ran inside its conv
-    # the oracle evaluates every 5th row and the last one (rows are independent; 300 rows of fp32 CPU forward are a minute)
-    rows = sorted(set(range(0, nb, 5)) | {nb - 1})
-    with torch.no_grad():
-        want = cached("oisst300_fwd_eval", lambda: nets.resnet_unet_forward(PI, cfg, x[rows], t[rows], None))
+    want = oracle_oisst_fwd_eval(cfg, PI, x, t, rows)
     errs = torch.tensor([rel_rms(got[r], want[j]) for j, r in enumerate(rows)])
     print(f"OISST NB=300 forward ({dtype}), eval: rel-RMS per row max {float(errs.max()):.3e} mean {float(errs.mean()):.3e}")
     assert float(errs.max()) <= OISST_TOL[dtype][0]
@@ -238,16 +293,10 @@ def test_oisst_nb300_rollout_rows_match_the_oracle(dtype):
     distinct rows: rows {150, 299} of all seven fields against oracle rollouts of those rows."""
     import dyffusion_amd as D
     from tests.test_gpu_unet_resnet import mirror
-    cfg, PF, PI = _oisst_setup()
-    nb = 300
+    cfg, PF, PI, x0, noise, rows = oisst_rollout_case()
+    nb = x0.shape[0]
     F_, I_ = mirror(PF, cfg, 1, 1, 1), mirror(PI, cfg, 2, 0, 1)
-    hp = dict(timesteps=7, schedule="before_t1_only", additional_interpolation_steps=25, interpolate_before_t1=True,
-              sampling_type="cold", refine_intermediate_predictions=False, forward_conditioning="data+noise",
-              time_encoding="dynamics", enable_interpolator_dropout=False)
-    m = D.DYffusion(F_, D.InterpolatorHandle(I_, 7), max_batch=nb, dtype=dtype, **hp)
-    g = torch.Generator().manual_seed(33)
-    x0 = torch.randn(nb, 1, 60, 60, generator=g)
-    noise = torch.randn(32, nb, 1, 60, 60, generator=g)
+    m = D.DYffusion(F_, D.InterpolatorHandle(I_, 7), max_batch=nb, dtype=dtype, **OISST_ROLLOUT_HP)
     m._ensure_engine((60, 60), nb)
     eng = m._engine
     eng.form_log(True)
@@ -257,16 +306,7 @@ def test_oisst_nb300_rollout_rows_match_the_oracle(dtype):
     for f in OISST_FORMS:
         assert f in forms and nb in forms[f], (f, forms.get(f))
     assert not any(f in forms for f in GN_KERNELS), sorted(forms)
-    rows = [150, 299]
-
-    def oracle():
-        it = iter(range(32))
-        with torch.no_grad():
-            return sampler.sample_loop(lambda x, t, cnd: nets.resnet_unet_forward(PF, cfg, x, t, cnd),
-                                       lambda x, t, cnd: nets.resnet_unet_forward(PI, cfg, x, t, cnd), x0[rows], None, hp,
-                                       noise_fn=lambda tensor: noise[next(it)][rows])
-
-    want = cached("oisst300_rollout_rows", oracle)
+    want = oracle_oisst_rollout_rows(cfg, PF, PI, x0, noise, rows)
     assert sorted(got) == sorted(want)
     worst = 0.0
     for k in sorted(want):

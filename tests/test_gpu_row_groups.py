@@ -43,16 +43,29 @@ def test_default_groups_follow_architecture_and_size():
     assert ns._engine.row_groups == 1  # unet_simple: no groups unless asked for
 
 
+def grouped_case():
+    cfg, PF, PI, mirror = _oisst_pair()
+    hp = dict(OISST_HP, forward_conditioning="data", enable_interpolator_dropout=False)
+    x0 = torch.randn(300, 1, 60, 60, generator=torch.Generator().manual_seed(33))
+    return cfg, PF, PI, mirror, hp, x0, [0, 100, 299]  # a row of each of the three groups
+
+
+def oracle_grouped_rows(cfg, PF, PI, hp, x0, rows):
+    def run():
+        with torch.no_grad():
+            return sampler.sample_loop(lambda x, t, cnd: nets.resnet_unet_forward(PF, cfg, x, t, cnd),
+                                       lambda x, t, cnd: nets.resnet_unet_forward(PI, cfg, x, t, cnd), x0[rows], None, hp)
+    return cached("oisst300_grouped_rows", run, depends_on=[x0[rows], PF["init_conv.weight"], PI["final_conv.weight"]])
+
+
 @pytest.mark.parametrize("dtype", ["fp16"])  # (a 93-forward ResNet-UNet plan is refused in bf16: test_gpu_unet_resnet.py)
 def test_oisst_nb300_grouped_rollout_rows_match_the_oracle(dtype):
     """300 rows on 3 groups of 100 (the benchmarked split): rows of every group, all 7 fields, against oracle rollouts of those rows."""
     from tests.test_gpu_bench_forms import OISST_TOL
-    cfg, PF, PI, mirror = _oisst_pair()
-    nb = 300
+    cfg, PF, PI, mirror, hp, x0, rows = grouped_case()
+    nb = x0.shape[0]
     F_, I_ = mirror(PF, cfg, 1, 1, 1), mirror(PI, cfg, 2, 0, 1)
-    hp = dict(OISST_HP, forward_conditioning="data", enable_interpolator_dropout=False)
     m = D.DYffusion(F_, D.InterpolatorHandle(I_, 7), max_batch=nb, dtype=dtype, **hp)
-    x0 = torch.randn(nb, 1, 60, 60, generator=torch.Generator().manual_seed(33))
     m._ensure_engine((60, 60), nb)
     eng = m._engine
     assert eng.row_groups == 3
@@ -64,14 +77,7 @@ def test_oisst_nb300_grouped_rollout_rows_match_the_oracle(dtype):
     for f in ("conv_up_halo_kernel<5>+gn_fused", "conv_igemm2_kernel<2>+gn_fused"):
         assert f in forms and 100 in forms[f], (f, forms.get(f))
     assert all(nb not in v for v in forms.values()), forms
-    rows = [0, 100, 299]  # a row of each of the three groups
-
-    def oracle():
-        with torch.no_grad():
-            return sampler.sample_loop(lambda x, t, cnd: nets.resnet_unet_forward(PF, cfg, x, t, cnd),
-                                       lambda x, t, cnd: nets.resnet_unet_forward(PI, cfg, x, t, cnd), x0[rows], None, hp)
-
-    want = cached("oisst300_grouped_rows", oracle)  # shared by the two dtype parametrisations
+    want = oracle_grouped_rows(cfg, PF, PI, hp, x0, rows)
     assert sorted(got) == sorted(want)
     worst = max(rel_rms(got[k][r].cpu(), want[k][j]) for k in want for j, r in enumerate(rows))
     print(f"OISST NB=300 on 3 row groups ({dtype}): worst rel-RMS over rows {rows} and 7 fields {worst:.3e}")
