@@ -375,6 +375,19 @@ def bench_train_steps(dev):
                              "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(fl / dt / 1e12 / PEAK_FP32_MFMA_TFLOPS, 3),
                              "samples_per_s": round(B / dt, 1)}
     log(f"train step unet_simple B={B}: {1e3 * dt:.1f} ms")
+    # the same step with the training convs' operands rounded to 16 bits while they are staged (opt-in, DYF_TRAIN_OPERANDS; fp32
+    # tensors and master weights, fp32 accumulation; gradients within ~5e-2 of the fp32 step's norm, tests/test_gpu_training.py)
+    os.environ["DYF_TRAIN_OPERANDS"] = "bf16"
+    try:
+        dt16, loss16 = timed(step_ns, 2)
+    finally:
+        os.environ.pop("DYF_TRAIN_OPERANDS", None)
+    out["unet_simple_ns_16bit_operands"] = {"workload": out["unet_simple_ns"]["workload"].replace(", fp32", ", fp32 tensors, conv operands "
+                                                                                                    "rounded to bf16 in the kernels (opt-in)"),
+                                            "batch": B, "ms_per_step": round(1e3 * dt16, 1), "loss": round(loss16, 4),
+                                            "achieved": round(fl / dt16 / 1e12, 1), "unit": "TFLOP/s", "samples_per_s": round(B / dt16, 1),
+                                            "speedup_vs_fp32": round(dt / dt16, 2)}
+    log(f"train step unet_simple B={B}, 16-bit conv operands: {1e3 * dt16:.1f} ms")
     m._engine.close()
     del m
     # ---- unet.Unet at the OISST shapes, B = 8

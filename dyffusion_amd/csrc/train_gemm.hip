@@ -16,6 +16,9 @@
 // MFMAs of stage s.
 #include "train_internal.h"
 
+#include <cstdlib>
+#include <cstring>
+
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 namespace {
@@ -199,6 +202,182 @@ __global__ __launch_bounds__(256) void t_gemm_mfma(dyf::TConv g, const float* __
 #endif
 }
 
+// ---- 16-bit operands (round 4, opt-in: DYF_TRAIN_OPERANDS=bf16 | fp16).  The same three gathers with the operands rounded to the
+// engine's 16-bit format WHILE they are staged into LDS (activations, gradients and weights stay fp32 in HBM: "fp32 master weights"),
+// fp32 accumulation on v_mfma_f32_32x32x16: 16x the matrix rate of the fp32 instruction, so the kernel is bound by its operand
+// loads (24 KB of fp32 per 32-deep K stage and workgroup) instead of by the matrix cores.  K stage 32 = two k16 sub-steps; LDS tiles
+// [row][32 k] 16-bit, rows 80 bytes apart; a lane's fragment is one ds_read_b128.  What changes numerically is the products' input
+// precision (8 / 11 mantissa bits): gradients agree with the fp32 path to ~1e-2 of their norm (tests/test_gpu_training.py), the
+// usual mixed-precision trade; the default stays fp32 (1e-6 parity with autograd over the oracle).
+constexpr int GK16 = 32, LDR16 = 40;  // K stage, LDS row pitch in 16-bit elements
+
+template <int MODE>
+__global__ __launch_bounds__(256) void t_gemm_mfma16(dyf::TConv g, const float* __restrict__ Ap, const float* __restrict__ Bp,
+                                                     const float* __restrict__ bias, float* __restrict__ Cp, int split_len) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __shared__ __attribute__((aligned(16))) el16_t As[2][GM * LDR16];
+    __shared__ __attribute__((aligned(16))) el16_t Bs[2][GN * LDR16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tm = blockIdx.x, tn = blockIdx.y;
+    const int taps = g.k * g.k;
+    const long long opix = (long long)g.n * g.ho * g.wo, ipix = (long long)g.n * g.h * g.w;
+    const long long M = MODE == TG_FWD ? opix : MODE == TG_DGRAD ? ipix : g.cout;
+    const int CK = MODE == TG_FWD ? g.cin : g.cout;
+    int tap = 0;
+    long long kbeg = 0, kend = 0;
+    int nstage, st0 = 0;
+    if (MODE == TG_WGRAD) {
+        tap = blockIdx.z % taps;
+        kbeg = (long long)(blockIdx.z / taps) * split_len;
+        kend = kbeg + split_len < opix ? kbeg + split_len : opix;
+        nstage = (int)((kend - kbeg + GK16 - 1) / GK16);
+    } else {
+        const int total = taps * CK / GK16;
+        st0 = split_len > 0 ? (int)blockIdx.z * split_len : 0;
+        nstage = split_len > 0 ? min(split_len, total - st0) : total;
+    }
+    // A, forward / dgrad: 4 slots (row = s >> 3, k quad = s & 7); wgrad: 4 slots (k = s >> 5, m quad = s & 31)
+    int a_b[4], a_y[4], a_x[4];
+    bool a_ok[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int s = tid + 256 * i;
+        a_b[i] = a_y[i] = a_x[i] = 0;
+        a_ok[i] = false;
+        if (MODE != TG_WGRAD) {
+            const long long m = (long long)tm * GM + (s >> 3);
+            a_ok[i] = m < M;
+            const int pw = MODE == TG_FWD ? g.wo : g.w, ph = MODE == TG_FWD ? g.ho : g.h;
+            const long long mm = a_ok[i] ? m : 0;
+            a_x[i] = (int)(mm % pw);
+            a_y[i] = (int)((mm / pw) % ph);
+            a_b[i] = (int)(mm / ((long long)pw * ph));
+        }
+    }
+    float4 ra[4], rb[2];
+    auto load = [&](int stage) {
+        if (MODE != TG_WGRAD) {
+            const int k0 = stage * GK16;
+            const int tp = k0 / CK, c0 = k0 - tp * CK;
+            const int ky = tp / g.k, kx = tp - ky * g.k;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int kq = (tid + 256 * i) & 7;
+                ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (MODE == TG_FWD) {
+                    const int iy = a_y[i] * g.s - g.p + ky, ix = a_x[i] * g.s - g.p + kx;
+                    if (a_ok[i] && (unsigned)iy < (unsigned)g.h && (unsigned)ix < (unsigned)g.w)
+                        ra[i] = *(const float4*)(Ap + (((size_t)a_b[i] * g.h + iy) * g.w + ix) * g.cin + c0 + kq * 4);
+                } else {
+                    const int ty = a_y[i] + g.p - ky, tx = a_x[i] + g.p - kx;
+                    const int oy = ty / g.s, ox = tx / g.s;
+                    if (a_ok[i] && ty >= 0 && tx >= 0 && oy * g.s == ty && ox * g.s == tx && oy < g.ho && ox < g.wo)
+                        ra[i] = *(const float4*)(Ap + (((size_t)a_b[i] * g.ho + oy) * g.wo + ox) * g.cout + c0 + kq * 4);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int s = tid + 256 * i, bk = s >> 4, bnq = s & 15;
+                if (MODE == TG_FWD)
+                    rb[i] = *(const float4*)(Bp + ((size_t)tp * g.cin + c0 + bk) * g.cout + tn * GN + bnq * 4);
+                else
+                    rb[i] = *(const float4*)(Bp + ((size_t)(c0 + bk) * taps + tp) * g.cin + tn * GN + bnq * 4);
+            }
+        } else {
+            const long long p0 = kbeg + (long long)stage * GK16;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int s = tid + 256 * i;
+                const long long pix = p0 + (s >> 5);
+                const int m = tm * GM + (s & 31) * 4;
+                ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (pix < kend && m < g.cout) ra[i] = *(const float4*)(Ap + (size_t)pix * g.cout + m);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int s = tid + 256 * i, bk = s >> 4, bnq = s & 15;
+                const long long pix = p0 + bk;
+                rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (pix < kend) {
+                    const int ox = (int)(pix % g.wo), oy = (int)((pix / g.wo) % g.ho), b = (int)(pix / ((long long)g.wo * g.ho));
+                    const int ky = tap / g.k, kx = tap - ky * g.k;
+                    const int iy = oy * g.s - g.p + ky, ix = ox * g.s - g.p + kx;
+                    if ((unsigned)iy < (unsigned)g.h && (unsigned)ix < (unsigned)g.w)
+                        rb[i] = *(const float4*)(Bp + (((size_t)b * g.h + iy) * g.w + ix) * g.cin + tn * GN + bnq * 4);
+                }
+            }
+        }
+    };
+    auto store = [&](int buf) {
+        if (MODE != TG_WGRAD) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {  // 4 consecutive k of one row: one 8-byte store
+                const int s = tid + 256 * i;
+                *(uint2*)&As[buf][(s >> 3) * LDR16 + 4 * (s & 7)] = make_uint2(pack_el16x2(ra[i].x, ra[i].y), pack_el16x2(ra[i].z, ra[i].w));
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {  // 4 consecutive rows (cout) of one k (pixel)
+                const int s = tid + 256 * i, k = s >> 5;
+                el16_t* d = &As[buf][((s & 31) * 4) * LDR16 + k];
+                d[0] = f32_to_el16(ra[i].x); d[LDR16] = f32_to_el16(ra[i].y); d[2 * LDR16] = f32_to_el16(ra[i].z); d[3 * LDR16] = f32_to_el16(ra[i].w);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {  // 4 consecutive columns n of one k
+            const int s = tid + 256 * i, bk = s >> 4, bnq = s & 15;
+            el16_t* d = &Bs[buf][(bnq * 4) * LDR16 + bk];
+            d[0] = f32_to_el16(rb[i].x); d[LDR16] = f32_to_el16(rb[i].y); d[2 * LDR16] = f32_to_el16(rb[i].z); d[3 * LDR16] = f32_to_el16(rb[i].w);
+        }
+    };
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.0f;
+    if (nstage > 0) {
+        load(st0);
+        store(0);
+    }
+    __syncthreads();
+    for (int st = 0; st < nstage; ++st) {
+        const int buf = st & 1;
+        if (st + 1 < nstage) load(st0 + st + 1);
+        const el16_t* ar0 = &As[buf][(wm * 64 + l31) * LDR16 + hi * 8];
+        const el16_t* ar1 = ar0 + 32 * LDR16;
+        const el16_t* br = &Bs[buf][(wn * 32 + l31) * LDR16 + hi * 8];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const el16x8_t a0 = *(const el16x8_t*)(ar0 + ks * 16), a1 = *(const el16x8_t*)(ar1 + ks * 16);
+            const el16x8_t b = *(const el16x8_t*)(br + ks * 16);
+            acc[0] = DYF_MFMA_32x32x16(a0, b, acc[0], 0, 0, 0);
+            acc[1] = DYF_MFMA_32x32x16(a1, b, acc[1], 0, 0, 0);
+        }
+        if (st + 1 < nstage) store(buf ^ 1);
+        __syncthreads();
+    }
+    const int n = tn * GN + wn * 32 + l31;
+    const float bv = (MODE != TG_WGRAD && bias) ? bias[n] : 0.0f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const long long m = (long long)tm * GM + wm * 64 + i * 32 + 8 * (r >> 2) + 4 * hi + (r & 3);
+            if (m >= M) continue;
+            if (MODE == TG_WGRAD) {
+                atomicAdd(Cp + ((size_t)m * taps + tap) * g.cin + n, acc[i][r]);
+            } else {
+                const int NC = MODE == TG_FWD ? g.cout : g.cin;
+                if (split_len > 0) Cp[((size_t)blockIdx.z * M + m) * NC + n] = acc[i][r];
+                else Cp[(size_t)m * NC + n] = acc[i][r] + bv;
+            }
+        }
+#endif
+}
+
 // y[i] = bias[i % N] + sum over the splits, in split order
 __global__ void t_splitk_finish(const float* ws, int splits, long long MN, int N, const float* bias, float* y) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -211,6 +390,13 @@ __global__ void t_splitk_finish(const float* ws, int splits, long long MN, int N
 }  // namespace
 
 namespace dyf {
+
+// DYF_TRAIN_OPERANDS=bf16 (or fp16, or 16): the training convs round their operands to the engine's 16-bit format while staging
+// them (t_gemm_mfma16); unset / fp32: fp32 operands (t_gemm_mfma).  Read per call: tests flip it in-process.
+static bool train_operands16() {
+    const char* v = getenv("DYF_TRAIN_OPERANDS");
+    return v && (!strcmp(v, "bf16") || !strcmp(v, "fp16") || !strcmp(v, "16"));
+}
 
 // split-K plan of a forward / dgrad launch: (splits, stages per split); splits == 1 -> no split
 static void plan_splitk(long long tiles, int stages, int& splits, int& len) {
@@ -229,10 +415,14 @@ bool tgemm_conv_fwd(const TConv& g, const float* x, const float* wt, const float
                     hipStream_t st) {
     if (g.cin % GK != 0 || g.cout % GN != 0) return false;
     const long long M = (long long)g.n * g.ho * g.wo, mt = (M + GM - 1) / GM;
+    const bool h16 = train_operands16() && g.cin % GK16 == 0;
     int splits, len;
-    plan_splitk(mt * (g.cout / GN), g.k * g.k * g.cin / GK, splits, len);
+    plan_splitk(mt * (g.cout / GN), g.k * g.k * g.cin / (h16 ? GK16 : GK), splits, len);
     if (splits > 1 && (ws == nullptr || (size_t)splits * M * g.cout > ws_floats)) { splits = 1; len = 0; }
-    hipLaunchKernelGGL(t_gemm_mfma<TG_FWD>, dim3((unsigned)mt, g.cout / GN, splits), dim3(256), 0, st, g, x, wt, bias, splits > 1 ? ws : y, len);
+    if (h16)
+        hipLaunchKernelGGL(t_gemm_mfma16<TG_FWD>, dim3((unsigned)mt, g.cout / GN, splits), dim3(256), 0, st, g, x, wt, bias, splits > 1 ? ws : y, len);
+    else
+        hipLaunchKernelGGL(t_gemm_mfma<TG_FWD>, dim3((unsigned)mt, g.cout / GN, splits), dim3(256), 0, st, g, x, wt, bias, splits > 1 ? ws : y, len);
     if (splits > 1)
         hipLaunchKernelGGL(t_splitk_finish, dim3((unsigned)((M * g.cout + 255) / 256)), dim3(256), 0, st, ws, splits, M * g.cout, g.cout, bias, y);
     return true;
@@ -242,10 +432,14 @@ bool tgemm_conv_dgrad(const TConv& g, const float* dz, const float* w, const flo
                       hipStream_t st) {
     if (g.cout % GK != 0 || g.cin % GN != 0) return false;
     const long long M = (long long)g.n * g.h * g.w, mt = (M + GM - 1) / GM;
+    const bool h16 = train_operands16() && g.cout % GK16 == 0;
     int splits, len;
-    plan_splitk(mt * (g.cin / GN), g.k * g.k * g.cout / GK, splits, len);
+    plan_splitk(mt * (g.cin / GN), g.k * g.k * g.cout / (h16 ? GK16 : GK), splits, len);
     if (splits > 1 && (ws == nullptr || (size_t)splits * M * g.cin > ws_floats)) { splits = 1; len = 0; }
-    hipLaunchKernelGGL(t_gemm_mfma<TG_DGRAD>, dim3((unsigned)mt, g.cin / GN, splits), dim3(256), 0, st, g, dz, w, bias, splits > 1 ? ws : dx, len);
+    if (h16)
+        hipLaunchKernelGGL(t_gemm_mfma16<TG_DGRAD>, dim3((unsigned)mt, g.cin / GN, splits), dim3(256), 0, st, g, dz, w, bias, splits > 1 ? ws : dx, len);
+    else
+        hipLaunchKernelGGL(t_gemm_mfma<TG_DGRAD>, dim3((unsigned)mt, g.cin / GN, splits), dim3(256), 0, st, g, dz, w, bias, splits > 1 ? ws : dx, len);
     if (splits > 1)
         hipLaunchKernelGGL(t_splitk_finish, dim3((unsigned)((M * g.cin + 255) / 256)), dim3(256), 0, st, ws, splits, M * g.cin, g.cin, bias, dx);
     return true;
@@ -258,10 +452,15 @@ bool tgemm_conv_wgrad(const TConv& g, const float* dz, const float* x, float* dw
     const int taps = g.k * g.k, mt = (g.cout + GM - 1) / GM, nt = g.cin / GN;
     // enough workgroups to fill the chip, at least 256 pixels per split
     long long splits = std::max<long long>(1, std::min<long long>((pix + 255) / 256, (2048 + (long long)mt * nt * taps - 1) / ((long long)mt * nt * taps)));
-    int len = (int)(((pix + splits - 1) / splits + GK - 1) / GK * GK);
+    const bool h16 = train_operands16();
+    const int gk = h16 ? GK16 : GK;
+    int len = (int)(((pix + splits - 1) / splits + gk - 1) / gk * gk);
     splits = (pix + len - 1) / len;
     if ((long long)taps * splits > 65535) return false;
-    hipLaunchKernelGGL(t_gemm_mfma<TG_WGRAD>, dim3(mt, nt, (unsigned)(taps * splits)), dim3(256), 0, st, g, dz, x, nullptr, dw, len);
+    if (h16)
+        hipLaunchKernelGGL(t_gemm_mfma16<TG_WGRAD>, dim3(mt, nt, (unsigned)(taps * splits)), dim3(256), 0, st, g, dz, x, nullptr, dw, len);
+    else
+        hipLaunchKernelGGL(t_gemm_mfma<TG_WGRAD>, dim3(mt, nt, (unsigned)(taps * splits)), dim3(256), 0, st, g, dz, x, nullptr, dw, len);
     return true;
 }
 
