@@ -174,8 +174,18 @@ def sample_sharded(model: _Sampler, initial_condition: Tensor, static_condition:
         stack, slot_keys = model.sample_stack(x, c)
     stack = stack.contiguous()  # (h, rpr, C, H, W): the engine's forecast stack, already contiguous
     full = torch.empty((world, *stack.shape), dtype=stack.dtype, device=stack.device)
-    if dist.get_backend(group) == "gloo":  # CPU tests: gloo has no all_gather_into_tensor
-        dist.all_gather([full[k] for k in range(world)], stack, group=group)
+    if dist.get_backend(group) == "gloo":  # CPU tests / plumbing rehearsals: gloo has no all_gather_into_tensor
+        if stack.is_cuda:
+            # staged through the host HERE, not by gloo: after one gloo collective on device tensors (its own streams + host
+            # callbacks) the next replay of a row-grouped rollout (three graphs on three streams) took 107 s instead of 0.65 s on an
+            # MI355X shared by two ranks (gpurun_out/shard_oisst.log, round 4); ungrouped rollouts were unaffected
+            host = stack.cpu()
+            parts = [torch.empty_like(host) for _ in range(world)]
+            dist.all_gather(parts, host, group=group)
+            for k in range(world):
+                full[k].copy_(parts[k])
+        else:
+            dist.all_gather([full[k] for k in range(world)], stack, group=group)
     else:
         dist.all_gather_into_tensor(full, stack, group=group)  # ONE collective
     out = _unpack_stack(full, nb, world)
