@@ -154,3 +154,61 @@ def test_gather_unpack_matches_the_row_split():
         for r in range(world):
             lo, hi = shard_rows(total, world, r)
             assert torch.equal(out[:, lo:hi], full[r, :, : hi - lo])
+
+
+def _grouped_worker(rank, world, port, q):
+    """OISST-shaped ResNet-UNet pair, 240 rows sharded over two ranks on ONE GPU: 120 rows per rank = three row groups (three graphs on
+    three streams per rank); MC dropout on."""
+    import time
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from dyffusion_amd.distributed import sample_sharded
+    from tests.test_gpu_row_groups import sharded_group_model
+    torch.cuda.set_device(0)
+    m, x0 = sharded_group_model(120)
+    x0 = x0.cuda()
+    times, first = [], None
+    for call in range(3):  # first call captures the graphs, the later ones replay them behind an exchange
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        out = sample_sharded(m, x0, None)
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+        if call == 0:  # (later calls continue the dropout / noise streams: other draws)
+            first = {k: v[[0, 119, 120, 239]].cpu() for k, v in out.items()}
+    if rank == 0:
+        q.put((m._engine.row_groups, times, first))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_with_row_groups_replay_at_speed_and_match_one_process():
+    """Regression (round 4): after ONE gloo collective on device tensors the next replay of a row-grouped rollout took 107 s instead of
+    0.65 s on a GPU shared by two ranks; `sample_sharded` now stages a gloo exchange through host tensors.  Rows of both ranks must
+    be those of the single-process rollout of the whole batch up to 16-bit rounding (global-row dropout and noise streams: a row
+    that drew another row's would differ by O(1); the kernel forms follow the rows per launch, so not bit for bit) and a replay must
+    not crawl."""
+    from tests.test_gpu_row_groups import sharded_group_model
+    m, x0 = sharded_group_model(240)
+    want = {k: v[[0, 119, 120, 239]].cpu() for k, v in m.sample(x0.cuda()).items()}
+    m._engine.close()
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_grouped_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    groups, times, got = q.get(timeout=600)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert groups == 3
+    assert max(times[1:]) < 10.0, times  # ~0.5 s when healthy
+    from tests.helpers import rel_rms
+    worst = max(rel_rms(got[k][r], want[k][r]) for k in want for r in range(4))
+    print(f"two ranks x 120 rows on three groups each vs one process: worst row rel-RMS {worst:.3e}; call times {times}")
+    assert worst <= 1e-2

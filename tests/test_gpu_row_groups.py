@@ -26,6 +26,18 @@ def _oisst_pair(**drop):
     return cfg, PF, PI, mirror
 
 
+def sharded_group_model(max_batch, total=240):
+    """(model, x0): the OISST-shaped pair with every dropout site on, `total` input rows, an engine sized for `max_batch` rows
+    (>= 120: three row groups).  Shared with tests/test_gpu_distributed.py (two ranks of 120 rows on one GPU)."""
+    cfg, PF, PI, mirror = _oisst_pair(block_dropout=0.3, block_dropout1=0.2, attn_dropout=0.1)
+    F_, I_ = mirror(PF, cfg, 1, 1, 1), mirror(PI, cfg, 2, 0, 1)
+    hp = dict(OISST_HP, forward_conditioning="data+noise", enable_interpolator_dropout=True, additional_interpolation_steps=3)
+    m = D.DYffusion(F_, D.InterpolatorHandle(I_, 7), max_batch=max_batch, **hp)
+    m.seed(99)
+    x0 = torch.randn(total, 1, 60, 60, generator=torch.Generator().manual_seed(5))
+    return m, x0
+
+
 def test_default_groups_follow_architecture_and_size():
     cfg, PF, PI, mirror = _oisst_pair()
     F_, I_ = mirror(PF, cfg, 1, 1, 1), mirror(PI, cfg, 2, 0, 1)
