@@ -31,6 +31,7 @@ constexpr int BM = 256;
 constexpr int A_BYTES = BM * 128;      // one K step of the pixel operand: 256 rows x 64 channels bf16
 constexpr int OROW = 144;              // output staging: [16 pixels][64 channels] 16-bit + 16 B pad per pixel and wave
 constexpr int LDS_TOTAL = 2 * A_BYTES + 4 * 16 * OROW; // 64 KB + 9 KB staging: two workgroups per CU
+constexpr int LDS_TOTAL_SH3 = 2 * (BM + 3) * 128 + 4 * 16 * OROW;  // SH3 form: + 3 rows per stage (75 520 B; + 4 KB fused GroupNorm)
 constexpr int RA = BM / 32;            // rows gathered per lane per K step
 constexpr int TH = BM / 16;            // 2-D tile: 16 rows of 16 pixels
 }  // namespace
@@ -45,10 +46,21 @@ constexpr int TH = BM / 16;            // 2-D tile: 16 rows of 16 pixels
 // two samples (the launcher requires planes of >= 128 pixels): it publishes the octet sums of each, sweeps the granules of each
 // (slot = slab index inside the sample, in row order) and keeps both (A, C) tables in its OWN 1 KB of LDS -- no workgroup barrier;
 // every lane then picks the table of its row's sample.
-template <int WN, bool GNF = false>
+// SH3 (3x3 / stride 1 / pad 1 on row-major 256-pixel tiles): the three taps of one window ROW share ONE gather.  Tile row r is output
+// pixel m0 + r; its centre-column operand of window row dy is input pixel (oy - 1 + dy, ox), and the dx = 0 / 2 operands are the
+// centre-column operands of pixels m0 + r -+ 1 -- the neighbouring LDS rows -- unless the pixel sits on the left / right edge of its
+// image row, where the tap lies in the zero padding (the lane then reads a row of zeros).  A K step gathered 32 KB for 32 MFMAs per
+// wave and the gather's latency (~2 us under load, one step in flight per workgroup) set the pace: 0.18-0.22 of the MFMA peak on
+// the 30^2 / 15^2 levels of the ResNet-UNet.  Now one gather (256 + 2 rows) feeds 96 MFMAs per wave, one barrier per window row.
+// Stage layout: rows 0..255 as before (16-byte slots swizzled by (row >> 1) & 7), row 256 = pixel m0 - 1, row 257 = pixel m0 + 256
+// (both unswizzled), row 258 = zeros.
+template <int WN, bool GNF = false, bool SH3 = false>
 __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(ConvArgs a, int M, int tiles_m, int tiles_n) {
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int STAGE_BYTES = SH3 ? (BM + 3) * 128 : A_BYTES;
+    constexpr int EPI_OFF = 2 * STAGE_BYTES;             // output staging of the epilogue
+    constexpr int LDS_END = EPI_OFF + 4 * 16 * OROW;     // (GNF: the waves' coefficient tables follow)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -122,9 +134,75 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(ConvArgs a, int M, 
         a_pix[j] = pix;
     }
 
+    // SH3: the two extension rows (waves 0 / 1: pixel m0 - 1 / m0 + 256) and the per-lane fragment addresses of (dx, mt)
+    int e_pix = 0;
+    unsigned e_mask = 0;
+    unsigned fa[3][MT];
+    if constexpr (SH3) {
+        if (wave < 2) {
+            const long long m = (long long)tm * BM + (wave == 0 ? -1 : BM);
+            if (m >= 0 && m < M) {
+                const int n_img = (int)(m / plane), rem = (int)(m - (long long)n_img * plane), oy = rem / a.wo, ox = rem - oy * a.wo;
+                e_pix = (n_img * a.h + oy - 1) * a.w + ox - 1;
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+                    if ((unsigned)(oy - 1 + ky) < (unsigned)a.h) e_mask |= 1u << (ky * 3 + 1);
+            }
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int r = wm * (32 * MT) + mt * 32 + l31;
+            const int m = min(tm * BM + r, M - 1);
+            const int ox = (m % plane) % a.wo;
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int rr = r + dx - 1;
+                const bool zero = (dx == 0 && ox == 0) || (dx == 2 && ox == a.wo - 1);
+                unsigned rowoff, key = 0;
+                if (zero) rowoff = (BM + 2) * 128;
+                else if (rr < 0) rowoff = BM * 128;
+                else if (rr >= BM) rowoff = (BM + 1) * 128;
+                else { rowoff = (unsigned)rr * 128u; key = (unsigned)(rr >> 1) & 7u; }
+                fa[dx][mt] = rowoff + ((((unsigned)hi) ^ key) << 4);
+            }
+        }
+        if (tid < 16) *(uint4*)(smem + (tid >> 3) * STAGE_BYTES + (BM + 2) * 128 + (tid & 7) * 16) = make_uint4(0, 0, 0, 0);
+        __syncthreads();
+    }
+
     int is_tap = 0, is_chunk = 0;
     auto issue_a = [&](int stage) {  // LDS-DMA gather of K step (is_tap, is_chunk); taps fastest (L2 reuse of the window)
-        char* As = smem + stage * A_BYTES;
+        char* As = smem + stage * STAGE_BYTES;
+        if constexpr (SH3) {  // is_tap = 3 dy: ONE gather per window row -- the centre column (tap 3 dy + 1) of every tile row
+            const int dy = is_tap / 3;
+            const unsigned tap_bit = 1u << (is_tap + 1);
+            const int cb = is_chunk << 6;
+            const bool second = cb >= a.c0;
+            const int csrc = second ? a.c1 : pitch0;
+            const unsigned tbase = (unsigned)((dy * a.w + 1) * csrc * 2) + (unsigned)((second ? cb - a.c0 : cb) * 2);
+            const unsigned pitch_b = (unsigned)(csrc * 2);
+#pragma unroll
+            for (int j = 0; j < RA; ++j) {
+                const unsigned vo = (a_mask[j] & tap_bit) ? (unsigned)(a_pix[j] * (int)pitch_b) + tbase + gchunk * 16 : 0xFFFFFFFFu;
+                if (second)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a1, LDS_PTR(As + (j * 4 + wave) * 1024), 16, vo, 0, 0, 0);
+                else
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a0, LDS_PTR(As + (j * 4 + wave) * 1024), 16, vo, 0, 0, 0);
+            }
+            if (wave < 2 && lane < 8) {
+                const unsigned vo = (e_mask & tap_bit) ? (unsigned)(e_pix * (int)pitch_b) + tbase + (unsigned)lane * 16u : 0xFFFFFFFFu;
+                if (second)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a1, LDS_PTR(As + (BM + wave) * 128), 16, vo, 0, 0, 0);
+                else
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a0, LDS_PTR(As + (BM + wave) * 128), 16, vo, 0, 0, 0);
+            }
+            is_tap += 3;
+            if (is_tap == 9) {
+                is_tap = 0;
+                ++is_chunk;
+            }
+            return;
+        }
         const int dy = is_tap / a.kw, dx = is_tap - dy * a.kw;
         const unsigned tap_bit = 1u << is_tap;
         const int cb = is_chunk << 6;
@@ -175,8 +253,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(ConvArgs a, int M, 
     __builtin_amdgcn_sched_barrier(0);
 #define RDA1(SET, KS, MT)                                                                                    \
     {                                                                                                        \
-        const unsigned pm = (a_x ^ (unsigned)((KS) << 5)) + As;                                              \
-        DSR(aq[SET][MT], pm, (MT) * 4096)                                                                    \
+        if constexpr (SH3) {                                                                                 \
+            const unsigned pm = (fa[dxi][MT] ^ (unsigned)((KS) << 5)) + As;                                  \
+            DSR(aq[SET][MT], pm, 0)                                                                          \
+        } else {                                                                                             \
+            const unsigned pm = (a_x ^ (unsigned)((KS) << 5)) + As;                                          \
+            DSR(aq[SET][MT], pm, (MT) * 4096)                                                                \
+        }                                                                                                    \
     }
 #define MF(MT, NT, ASET, BSET)                                                                               \
     acc[MT][NT] = DYF_MFMA_32x32x16(__builtin_bit_cast(el16x8_t, bq[BSET][NT]), aq[ASET][MT], \
@@ -208,20 +291,43 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(ConvArgs a, int M, 
     ISSUE_B(0, soff_cur, 0)
     ISSUE_B(1, soff_cur, 1)
     ISSUE_B(2, soff_cur, 2)
-    for (int k = 0; k < nk; ++k) {
-        const unsigned soff_next = soff_cur < soff_last ? soff_cur + STEP_BYTES : soff_cur;  // tail: harmless re-fetch
-        if (k == 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // first gather (older than the 6 weight loads)
-        __builtin_amdgcn_s_barrier();  // gather of step k visible; every wave is done with the other stage
-        __builtin_amdgcn_sched_barrier(0);
-        if (k + 1 < nk) issue_a((k + 1) & 1);
-        const unsigned As = lds_base + (unsigned)((k & 1) * A_BYTES) + a_row;
-        RDA1(0, 0, 0) RDA1(0, 0, 1)
-        if constexpr (MT == 4) { RDA1(0, 0, 2) RDA1(0, 0, 3) }
-        SLOT(3, soff_cur, 3, true, 1, 1, 0, 0)
-        SLOT(0, soff_next, 0, true, 0, 2, 1, 1)
-        SLOT(1, soff_next, 1, true, 1, 3, 0, 2)
-        SLOT(2, soff_next, 2, false, 0, 0, 1, 3)
-        soff_cur = soff_next;
+    if constexpr (SH3) {
+        const int ngroups = 3 * cpt;  // (chunk, window row): three K steps (dx = 0, 1, 2) per gather
+        for (int g = 0; g < ngroups; ++g) {
+            if (g == 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // first gather (older than the 6 weight loads)
+            __builtin_amdgcn_s_barrier();  // gather of group g visible; every wave is done with the other stage
+            __builtin_amdgcn_sched_barrier(0);
+            if (g + 1 < ngroups) issue_a((g + 1) & 1);
+            const unsigned As = lds_base + (unsigned)((g & 1) * STAGE_BYTES);
+#pragma unroll
+            for (int dxi = 0; dxi < 3; ++dxi) {
+                const unsigned soff_next = soff_cur < soff_last ? soff_cur + STEP_BYTES : soff_cur;  // tail: harmless re-fetch
+                RDA1(0, 0, 0) RDA1(0, 0, 1)
+                if constexpr (MT == 4) { RDA1(0, 0, 2) RDA1(0, 0, 3) }
+                SLOT(3, soff_cur, 3, true, 1, 1, 0, 0)
+                SLOT(0, soff_next, 0, true, 0, 2, 1, 1)
+                SLOT(1, soff_next, 1, true, 1, 3, 0, 2)
+                SLOT(2, soff_next, 2, false, 0, 0, 1, 3)
+                soff_cur = soff_next;
+            }
+        }
+    } else {
+        constexpr int dxi = 0;  // (RDA1's SH3 branch is discarded)
+        for (int k = 0; k < nk; ++k) {
+            const unsigned soff_next = soff_cur < soff_last ? soff_cur + STEP_BYTES : soff_cur;  // tail: harmless re-fetch
+            if (k == 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // first gather (older than the 6 weight loads)
+            __builtin_amdgcn_s_barrier();  // gather of step k visible; every wave is done with the other stage
+            __builtin_amdgcn_sched_barrier(0);
+            if (k + 1 < nk) issue_a((k + 1) & 1);
+            const unsigned As = lds_base + (unsigned)((k & 1) * A_BYTES) + a_row;
+            RDA1(0, 0, 0) RDA1(0, 0, 1)
+            if constexpr (MT == 4) { RDA1(0, 0, 2) RDA1(0, 0, 3) }
+            SLOT(3, soff_cur, 3, true, 1, 1, 0, 0)
+            SLOT(0, soff_next, 0, true, 0, 2, 1, 1)
+            SLOT(1, soff_next, 1, true, 1, 3, 0, 2)
+            SLOT(2, soff_next, 2, false, 0, 0, 1, 3)
+            soff_cur = soff_next;
+        }
     }
 #undef SLOT
 #undef PIN
@@ -240,7 +346,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(ConvArgs a, int M, 
     // epilogue used to expose 16 store round trips.
     // FAST: 16-bit output only, no residual (every hot launch): those pointer tests are wave-uniform branches, and joins too.
     // ---- GNF phases A and B (gn_fused.h): statistics of y = acc + bias per (sample, octet), exchanged through granules
-    float* const gcf = (float*)(smem + LDS_TOTAL) + wave * 256;  // this wave's (A, C) tables: [2 samples][A[64] | C[64]]
+    float* const gcf = (float*)(smem + LDS_END) + wave * 256;  // this wave's (A, C) tables: [2 samples][A[64] | C[64]]
     int g_bnd = 0x7fffffff;  // first output row (index into M) of the slab's SECOND sample
     if constexpr (GNF) {
         const GnFuse& G = a.gnf;
@@ -381,7 +487,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(ConvArgs a, int M, 
         // LDS staging tile, half at a time, and leave as stores of 8 whole lines (stored from the registers a store instruction
         // writes a 32-byte piece of 32 lines -- worth 20 % of the store-bound conv_enc0_stem_kernel, 1-5 % of the halo kernels)
         constexpr bool STAGED = FAST && FULL;
-        unsigned char* ost = (unsigned char*)smem + 2 * A_BYTES + wave * (16 * OROW);
+        unsigned char* ost = (unsigned char*)smem + EPI_OFF + wave * (16 * OROW);
         const int rpx = lane >> 3, rch = lane & 7;  // read-back role: (pixel 8 k + rpx of the half, 16-byte chunk)
         uint4 ostage[4];
 #pragma unroll
@@ -519,6 +625,9 @@ hipError_t conv_igemm2_init() {
     hipError_t e = hipFuncSetAttribute((const void*)conv_igemm2_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)(conv_igemm2_kernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL + 4096);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)conv_igemm2_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)(conv_igemm2_kernel<2, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL_SH3);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)(conv_igemm2_kernel<2, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL_SH3 + 4096);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)(conv_igemm2_kernel<1, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL_SH3);
     return e;
 }
 
@@ -536,21 +645,34 @@ hipError_t launch_conv_igemm2(const ConvArgs& a, hipStream_t stream) {
         const long long tb = sel * (a.cout / 128), ts = sel * (a.cout / 64);
         small = 0.56 * (double)((ts + 511) / 512) < 0.92 * (double)((tb + 511) / 512);
     }
+    // SH3 (one gather per window row): 3x3 / stride 1 / pad 1 on row-major tiles (the kernel tiles 2-D when wo % 16 == 0 && ho % 16 == 0)
+    static const bool sh3_on = !(getenv("DYF_IGEMM2_SH3") && atoi(getenv("DYF_IGEMM2_SH3")) == 0);
+    const bool sh3 = sh3_on && a.kh == 3 && a.kw == 3 && a.stride == 1 && a.pad == 1 && a.ho == a.h && a.wo == a.w && a.wo >= 2 &&
+                     !(a.wo % 16 == 0 && a.ho % TH == 0);
     if (a.gnf.gran != nullptr) {  // GroupNorm fused (launch_conv_gn_fused checked the shape): + 4 KB of LDS for the waves' (A, C) tables
-        dyf_form_note("conv_igemm2_kernel<2>+gn_fused", a.n);
+        dyf_form_note(sh3 ? "conv_igemm2_kernel<2>+gn_fused+sh3" : "conv_igemm2_kernel<2>+gn_fused", a.n);
         const int tiles_n = a.cout / 128;
         ConvArgs b = a;
         if (getenv("DYF_GN_FUSE_NOWAIT")) b.gnf.slots = -1;  // timing experiment (WRONG results): no granule sweep
-        hipLaunchKernelGGL((conv_igemm2_kernel<2, true>), dim3(tiles_m * tiles_n), dim3(256), LDS_TOTAL + 4096, stream, b, (int)M, tiles_m, tiles_n);
+        if (sh3)
+            hipLaunchKernelGGL((conv_igemm2_kernel<2, true, true>), dim3(tiles_m * tiles_n), dim3(256), LDS_TOTAL_SH3 + 4096, stream, b, (int)M, tiles_m, tiles_n);
+        else
+            hipLaunchKernelGGL((conv_igemm2_kernel<2, true>), dim3(tiles_m * tiles_n), dim3(256), LDS_TOTAL + 4096, stream, b, (int)M, tiles_m, tiles_n);
         return hipGetLastError();
     }
-    dyf_form_note(small ? "conv_igemm2_kernel<1>" : "conv_igemm2_kernel<2>", a.n);
+    dyf_form_note(small ? (sh3 ? "conv_igemm2_kernel<1>+sh3" : "conv_igemm2_kernel<1>") : (sh3 ? "conv_igemm2_kernel<2>+sh3" : "conv_igemm2_kernel<2>"), a.n);
     if (!small) {
         const int tiles_n = a.cout / 128;
-        hipLaunchKernelGGL(conv_igemm2_kernel<2>, dim3(tiles_m * tiles_n), dim3(256), LDS_TOTAL, stream, a, (int)M, tiles_m, tiles_n);
+        if (sh3)
+            hipLaunchKernelGGL((conv_igemm2_kernel<2, false, true>), dim3(tiles_m * tiles_n), dim3(256), LDS_TOTAL_SH3, stream, a, (int)M, tiles_m, tiles_n);
+        else
+            hipLaunchKernelGGL(conv_igemm2_kernel<2>, dim3(tiles_m * tiles_n), dim3(256), LDS_TOTAL, stream, a, (int)M, tiles_m, tiles_n);
     } else {
         const int tiles_n = a.cout / 64;
-        hipLaunchKernelGGL(conv_igemm2_kernel<1>, dim3(tiles_m * tiles_n), dim3(256), LDS_TOTAL, stream, a, (int)M, tiles_m, tiles_n);
+        if (sh3)
+            hipLaunchKernelGGL((conv_igemm2_kernel<1, false, true>), dim3(tiles_m * tiles_n), dim3(256), LDS_TOTAL_SH3, stream, a, (int)M, tiles_m, tiles_n);
+        else
+            hipLaunchKernelGGL(conv_igemm2_kernel<1>, dim3(tiles_m * tiles_n), dim3(256), LDS_TOTAL, stream, a, (int)M, tiles_m, tiles_n);
     }
     return hipGetLastError();
 }
