@@ -102,10 +102,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(ConvArgs a, int M, 
     // ---- per-lane gather descriptors (as conv.hip): DMA row (j*4 + wave)*8 + sub, LDS slot swizzled by (row >> 1) & 7
     const int sub = lane >> 3;
     const int gchunk = (lane & 7) ^ ((((wave & 1) << 2) | (sub >> 1)) & 7);
-    int a_pix[RA];        // pixel index of tap (0,0): may be slightly negative (offsets are formed modulo 2^32)
-    unsigned a_mask[RA];  // tap validity bits
+    int a_pix[SH3 ? 1 : RA];        // pixel index of tap (0,0): may be slightly negative (offsets are formed modulo 2^32)
+    unsigned a_mask[SH3 ? 1 : RA];  // tap validity bits
 #pragma unroll
-    for (int j = 0; j < RA; ++j) {
+    for (int j = 0; j < (SH3 ? 0 : RA); ++j) {
         const int row = (j * 4 + wave) * 8 + sub;
         unsigned mask = 0;
         int pix = 0;
@@ -134,20 +134,24 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(ConvArgs a, int M, 
         a_pix[j] = pix;
     }
 
-    // SH3: the two extension rows (waves 0 / 1: pixel m0 - 1 / m0 + 256) and the per-lane fragment addresses of (dx, mt)
-    int e_pix = 0;
-    unsigned e_mask = 0;
-    unsigned fa[3][MT];
+    // SH3 (h == ho, w == wo: the input pixel of output pixel m at window row dy, centre column, is m + (dy - 1) w).  Registers are
+    // short in this kernel (254 of 256 before SH3): DMA row j of this lane is output pixel m_lane + 32 j, three bits per row say
+    // whether it exists (m < M) and whether it lies on the top / bottom image row (window row 0 / 2 in the zero padding).
+    const int m_lane = tm * BM + wave * 8 + sub;
+    unsigned vbits = 0, e_bits = 0;
+    int e_m = 0;
+    unsigned fa[2][MT];  // fragment addresses (inside a stage) of dx = 0 / 2; dx = 1 is the row itself (a_row + immediates)
     if constexpr (SH3) {
-        if (wave < 2) {
-            const long long m = (long long)tm * BM + (wave == 0 ? -1 : BM);
-            if (m >= 0 && m < M) {
-                const int n_img = (int)(m / plane), rem = (int)(m - (long long)n_img * plane), oy = rem / a.wo, ox = rem - oy * a.wo;
-                e_pix = (n_img * a.h + oy - 1) * a.w + ox - 1;
+        auto rowbits = [&](long long m) -> unsigned {
+            if (m < 0 || m >= M) return 0u;
+            const int oy = (int)(m % plane) / a.wo;
+            return 1u | (oy == 0 ? 2u : 0u) | (oy == a.h - 1 ? 4u : 0u);
+        };
 #pragma unroll
-                for (int ky = 0; ky < 3; ++ky)
-                    if ((unsigned)(oy - 1 + ky) < (unsigned)a.h) e_mask |= 1u << (ky * 3 + 1);
-            }
+        for (int j = 0; j < RA; ++j) vbits |= rowbits(m_lane + 32 * j) << (3 * j);
+        if (wave < 2) {  // extension rows: pixel m0 - 1 (wave 0) / m0 + 256 (wave 1)
+            e_m = tm * BM + (wave == 0 ? -1 : BM);
+            e_bits = rowbits(e_m);
         }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
@@ -155,15 +159,15 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(ConvArgs a, int M, 
             const int m = min(tm * BM + r, M - 1);
             const int ox = (m % plane) % a.wo;
 #pragma unroll
-            for (int dx = 0; dx < 3; ++dx) {
-                const int rr = r + dx - 1;
-                const bool zero = (dx == 0 && ox == 0) || (dx == 2 && ox == a.wo - 1);
+            for (int d = 0; d < 2; ++d) {
+                const int rr = r + 2 * d - 1;
+                const bool zero = d == 0 ? ox == 0 : ox == a.wo - 1;
                 unsigned rowoff, key = 0;
                 if (zero) rowoff = (BM + 2) * 128;
                 else if (rr < 0) rowoff = BM * 128;
                 else if (rr >= BM) rowoff = (BM + 1) * 128;
                 else { rowoff = (unsigned)rr * 128u; key = (unsigned)(rr >> 1) & 7u; }
-                fa[dx][mt] = rowoff + ((((unsigned)hi) ^ key) << 4);
+                fa[d][mt] = rowoff + ((((unsigned)hi) ^ key) << 4);
             }
         }
         if (tid < 16) *(uint4*)(smem + (tid >> 3) * STAGE_BYTES + (BM + 2) * 128 + (tid & 7) * 16) = make_uint4(0, 0, 0, 0);
@@ -173,24 +177,25 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(ConvArgs a, int M, 
     int is_tap = 0, is_chunk = 0;
     auto issue_a = [&](int stage) {  // LDS-DMA gather of K step (is_tap, is_chunk); taps fastest (L2 reuse of the window)
         char* As = smem + stage * STAGE_BYTES;
-        if constexpr (SH3) {  // is_tap = 3 dy: ONE gather per window row -- the centre column (tap 3 dy + 1) of every tile row
+        if constexpr (SH3) {  // is_tap = 3 dy: ONE gather per window row -- the centre column of every tile row
             const int dy = is_tap / 3;
-            const unsigned tap_bit = 1u << (is_tap + 1);
+            const unsigned bad = dy == 0 ? 2u : dy == 2 ? 4u : 0u;  // window row 0 / 2 of a top / bottom image row: zero padding
             const int cb = is_chunk << 6;
             const bool second = cb >= a.c0;
             const int csrc = second ? a.c1 : pitch0;
-            const unsigned tbase = (unsigned)((dy * a.w + 1) * csrc * 2) + (unsigned)((second ? cb - a.c0 : cb) * 2);
-            const unsigned pitch_b = (unsigned)(csrc * 2);
+            const unsigned cbytes = (unsigned)((second ? cb - a.c0 : cb) * 2);
+            const int pitch_b = csrc * 2, shift = (dy - 1) * a.w;
 #pragma unroll
             for (int j = 0; j < RA; ++j) {
-                const unsigned vo = (a_mask[j] & tap_bit) ? (unsigned)(a_pix[j] * (int)pitch_b) + tbase + gchunk * 16 : 0xFFFFFFFFu;
+                const unsigned b = (vbits >> (3 * j)) & 7u;
+                const unsigned vo = ((b & 1u) && !(b & bad)) ? (unsigned)((m_lane + 32 * j + shift) * pitch_b) + cbytes + gchunk * 16 : 0xFFFFFFFFu;
                 if (second)
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a1, LDS_PTR(As + (j * 4 + wave) * 1024), 16, vo, 0, 0, 0);
                 else
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a0, LDS_PTR(As + (j * 4 + wave) * 1024), 16, vo, 0, 0, 0);
             }
             if (wave < 2 && lane < 8) {
-                const unsigned vo = (e_mask & tap_bit) ? (unsigned)(e_pix * (int)pitch_b) + tbase + (unsigned)lane * 16u : 0xFFFFFFFFu;
+                const unsigned vo = ((e_bits & 1u) && !(e_bits & bad)) ? (unsigned)((e_m + shift) * pitch_b) + cbytes + (unsigned)lane * 16u : 0xFFFFFFFFu;
                 if (second)
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a1, LDS_PTR(As + (BM + wave) * 128), 16, vo, 0, 0, 0);
                 else
@@ -253,8 +258,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(ConvArgs a, int M, 
     __builtin_amdgcn_sched_barrier(0);
 #define RDA1(SET, KS, MT)                                                                                    \
     {                                                                                                        \
-        if constexpr (SH3) {                                                                                 \
-            const unsigned pm = (fa[dxi][MT] ^ (unsigned)((KS) << 5)) + As;                                  \
+        if constexpr (SH3 && dxi != 1) {                                                                     \
+            const unsigned pm = (fa[dxi >> 1][MT] ^ (unsigned)((KS) << 5)) + (As - a_row);                   \
             DSR(aq[SET][MT], pm, 0)                                                                          \
         } else {                                                                                             \
             const unsigned pm = (a_x ^ (unsigned)((KS) << 5)) + As;                                          \
@@ -298,18 +303,21 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(ConvArgs a, int M, 
             __builtin_amdgcn_s_barrier();  // gather of group g visible; every wave is done with the other stage
             __builtin_amdgcn_sched_barrier(0);
             if (g + 1 < ngroups) issue_a((g + 1) & 1);
-            const unsigned As = lds_base + (unsigned)((g & 1) * STAGE_BYTES);
-#pragma unroll
-            for (int dxi = 0; dxi < 3; ++dxi) {
-                const unsigned soff_next = soff_cur < soff_last ? soff_cur + STEP_BYTES : soff_cur;  // tail: harmless re-fetch
-                RDA1(0, 0, 0) RDA1(0, 0, 1)
-                if constexpr (MT == 4) { RDA1(0, 0, 2) RDA1(0, 0, 3) }
-                SLOT(3, soff_cur, 3, true, 1, 1, 0, 0)
-                SLOT(0, soff_next, 0, true, 0, 2, 1, 1)
-                SLOT(1, soff_next, 1, true, 1, 3, 0, 2)
-                SLOT(2, soff_next, 2, false, 0, 0, 1, 3)
-                soff_cur = soff_next;
+            const unsigned As = lds_base + (unsigned)((g & 1) * STAGE_BYTES) + a_row;
+#define KSTEP3(DX)                                                                                           \
+            {                                                                                                \
+                constexpr int dxi = DX;                                                                      \
+                const unsigned soff_next = soff_cur < soff_last ? soff_cur + STEP_BYTES : soff_cur;          \
+                RDA1(0, 0, 0) RDA1(0, 0, 1)                                                                  \
+                if constexpr (MT == 4) { RDA1(0, 0, 2) RDA1(0, 0, 3) }                                       \
+                SLOT(3, soff_cur, 3, true, 1, 1, 0, 0)                                                       \
+                SLOT(0, soff_next, 0, true, 0, 2, 1, 1)                                                      \
+                SLOT(1, soff_next, 1, true, 1, 3, 0, 2)                                                      \
+                SLOT(2, soff_next, 2, false, 0, 0, 1, 3)                                                     \
+                soff_cur = soff_next;                                                                        \
             }
+            KSTEP3(0) KSTEP3(1) KSTEP3(2)
+#undef KSTEP3
         }
     } else {
         constexpr int dxi = 0;  // (RDA1's SH3 branch is discarded)
@@ -646,7 +654,7 @@ hipError_t launch_conv_igemm2(const ConvArgs& a, hipStream_t stream) {
         small = 0.56 * (double)((ts + 511) / 512) < 0.92 * (double)((tb + 511) / 512);
     }
     // SH3 (one gather per window row): 3x3 / stride 1 / pad 1 on row-major tiles (the kernel tiles 2-D when wo % 16 == 0 && ho % 16 == 0)
-    static const bool sh3_on = !(getenv("DYF_IGEMM2_SH3") && atoi(getenv("DYF_IGEMM2_SH3")) == 0);
+    const bool sh3_on = !(getenv("DYF_IGEMM2_SH3") && atoi(getenv("DYF_IGEMM2_SH3")) == 0);  // (read per launch: tests compare the two forms)
     const bool sh3 = sh3_on && a.kh == 3 && a.kw == 3 && a.stride == 1 && a.pad == 1 && a.ho == a.h && a.wo == a.w && a.wo >= 2 &&
                      !(a.wo % 16 == 0 && a.ho % TH == 0);
     if (a.gnf.gran != nullptr) {  // GroupNorm fused (launch_conv_gn_fused checked the shape): + 4 KB of LDS for the waves' (A, C) tables

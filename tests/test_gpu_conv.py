@@ -82,6 +82,12 @@ IGEMM2_CASES = [
     (1, 60, 60, 64, 64, 3, 1, 1),       # the OISST level-0 plane: raster tiling, ragged last tile
     (3, 15, 15, 128, 192, 3, 1, 1),
     (1, 32, 32, 64, 320, 1, 1, 0),
+    # 3x3 / stride 1 / pad 1 on raster tiles = the SH3 form (one gather per window row, dx = 0 / 2 from the neighbouring LDS rows):
+    # several tiles with sample boundaries inside, 2 and 4 chunks, tile rows that start / end mid image row, a 2-pixel-wide plane
+    (7, 30, 30, 128, 128, 3, 1, 1),
+    (9, 15, 15, 256, 256, 3, 1, 1),
+    (5, 23, 2, 64, 128, 3, 1, 1),
+    (2, 16, 19, 128, 64, 3, 1, 1),
 ]
 
 
@@ -108,6 +114,12 @@ def test_second_igemm_form_matches_torch(engine, case, monkeypatch):
         assert rel_rms(got, want) <= 4e-3
         if act == 2:
             assert rel_rms(got, first) <= 2.5e-3  # the two MFMA forms differ by summation order only
+            if k == 3 and stride == 1 and pad == 1 and not (w % 16 == 0 and h % 16 == 0):
+                # the SH3 form ran: it must reproduce the one-gather-per-tap form BIT FOR BIT (same operands, same summation order)
+                monkeypatch.setenv("DYF_IGEMM2_SH3", "0")
+                per_tap = engine.op_conv2d(x.cuda(), wt, stride, pad, scale.cuda(), shift.cuda(), act=act, path=1).float().cpu()
+                monkeypatch.delenv("DYF_IGEMM2_SH3")
+                assert torch.equal(got, per_tap), float((got - per_tap).abs().max())
 
 
 HALO3_CASES = [(2, 16, 16, 64, 256, 3, 1, 1), (1, 32, 48, 128, 256, 3, 1, 1), (3, 8, 16, 192, 512, 3, 1, 1),
