@@ -323,7 +323,7 @@ def bench_synth512(dev, nb=4, reps=1):
     res = {"workload": SYNTH512_WORKLOAD + ", 1 GPU", "dtype": "fp16", "rows": nb,
            "net_forwards_per_rollout": nf + ni, "fields_per_s": round(nb * 32 / dt, 1), "ms_per_rollout": round(1e3 * dt, 2),
            "gflop_per_field": round(fl / 32 / 1e9, 2), "whole_rollout_tflops": round(nb * fl / dt / 1e12, 1),
-           "roofline": _resnet_roofline(eng, 1, nb, "flash_attention2_kernel (16 384 tokens, 4 heads x 32; dropout on the "
+           "roofline": _resnet_roofline(eng, 1, nb, "flash_attention4_kernel (16 384 tokens, 4 heads x 32; dropout on the "
                                                     "probabilities in the interpolator's launches)", PEAK_BF16_TFLOPS),
            "roofline_conv": _resnet_roofline(eng, 0, nb, "level-0 3x3 weight-standardised convs 64->64 @512x512", PEAK_BF16_TFLOPS)}
     log(f"512^2 NB={nb} (fp16): {res['ms_per_rollout']} ms per rollout -> {res['fields_per_s']} fields/s")

@@ -115,6 +115,43 @@ def test_attention_core_16384_tokens(dtype):
     assert err <= (1.5e-3 if dtype == "fp16" else 8e-3)
 
 
+def _attention_reference(qkv):
+    n = qkv.shape[1]
+    q, k, v = (qkv.float()[0, :, i * 128:(i + 1) * 128].reshape(n, 4, 32).permute(1, 0, 2) for i in range(3))
+    want = torch.stack([torch.softmax(q[h] @ k[h].T * (32 ** -0.5), dim=-1) @ v[h] for h in range(4)])
+    return want.permute(1, 0, 2).reshape(1, n, 128)
+
+
+@pytest.mark.parametrize("dtype", ["fp16", "bf16"])
+def test_attention_core_sequence_lengths_and_score_ranges(dtype):
+    """The pipelined flash kernel (flash_attention4_kernel) against plain fp32 PyTorch on the same 16-bit operands:
+      * token counts 1 ... 1 100 (no whole 64-key tile; whole tiles only; whole tiles + a partial last tile of <= 32 and > 32 keys;
+        four- and eight-wave workgroups: >= 512 tokens);
+      * score ranges that take each branch of its lazy maximum: |scores| small (m stays exactly 0: no bias products), scores with
+        a spread of +-90 in the log2 domain (the sum check fires, m moves, the scores in flight are shifted), every score near
+        -70 (m != 0 from the first sub-tile on), every score near +70."""
+    cfg = D.net_config(in_channels=3, cond_channels=0, out_channels=3, dim=64, upsample_dims=[64, 64])
+    eng = D.HipEngine(cfg, cfg, 16, 16, max_batch=1, use_graph=False, dtype=dtype)
+    tol = 2e-3 if dtype == "fp16" else 1e-2
+    worst = 0.0
+    for n in (1, 31, 64, 100, 128, 200, 512, 577, 1100):
+        for case in ("small", "spread", "low", "high"):
+            g = torch.Generator().manual_seed(1000 * n + len(case))
+            x = torch.randn(1, n, 384, generator=g)
+            if case == "spread":
+                x[:, :, :256] *= 4.0
+            elif case in ("low", "high"):  # q near +3, k near -3 / +3 in every channel: q.k * 32^-1/2 * log2(e) near -+73
+                x[:, :, :128] = 3.0 + 0.1 * x[:, :, :128]
+                x[:, :, 128:256] = (-3.0 if case == "low" else 3.0) + 0.1 * x[:, :, 128:256]
+            qkv = x.to(DEV).to(eng.torch_dtype)
+            got = eng.op_attention(qkv).float()
+            assert bool(torch.isfinite(got).all()), (n, case)
+            err = rel_rms(got.cpu(), _attention_reference(qkv).cpu())
+            worst = max(worst, err)
+            assert err <= tol, (n, case, err)
+    print(f"attention core, 9 token counts x 4 score ranges ({dtype}): worst rel-rms {worst:.3e}")
+
+
 def test_config5_h32_rollout_properties():
     """h=32 rollout at 512^2 x 4 channels (fp16, dropout on in the interpolator): every field finite, rows independent
     (2-row batch == two 1-row batches with row offsets; engines created with batch_invariant=True: kernel forms chosen for max_batch), hipGraph replay == eager launches, bit for bit."""
