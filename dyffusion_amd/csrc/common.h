@@ -119,6 +119,18 @@ struct RngKey {
 // keep word of element pair `pair_index` of a row: Weyl sequence (one add per consecutive pair after strength reduction)
 // through two xorshift-multiply rounds built on 24-bit multiplies (the conv epilogues spend most of their VALU time here;
 // the murmur3 finaliser costs two quarter-rate multiplies per pair).
+// (split for kernels that walk consecutive pairs: the Weyl value of pair i + d is that of pair i plus the constant
+// d * RNG_WEYL, so a loop carries it with one add instead of a quarter-rate 32-bit multiply per pair)
+constexpr uint32_t RNG_WEYL = 0x9E3779B1u;
+__device__ __host__ __forceinline__ uint32_t rng_weyl(uint32_t pair_index, RngKey key) { return pair_index * RNG_WEYL + key.k0; }
+__device__ __host__ __forceinline__ uint32_t rng_pair_mix(uint32_t x, RngKey key) {
+    x ^= x >> 15;
+    x = mul_u24(x, 0x735A2Du) + key.k1;
+    x ^= x >> 13;
+    x = mul_u24(x, 0x97E5B5u);
+    x ^= x >> 16;
+    return x;
+}
 __device__ __host__ __forceinline__ uint32_t rng_pair_word(uint32_t pair_index, RngKey key) {
     uint32_t x = pair_index * 0x9E3779B1u + key.k0;
     x ^= x >> 15;

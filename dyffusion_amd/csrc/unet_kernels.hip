@@ -2496,7 +2496,7 @@ template <bool DROP, bool BIASED, bool TAIL>
 __device__ __forceinline__ void fa4_step(const AttnArgs& a, fa_f32x16& sc_cur, fa_f32x16& sc_next, const el16_t* kc0, const el16_t* kc1,
                                          const el16_t* kn0, const el16_t* kn1, const el16_t* vc, const el16x8_t (&qf)[2], fa_f32x16& o, float& m,
                                          fa_f32x2& l2, el16x8_t& bm, const el16x8_t aone, bool& first, bool& biased, int jb, int q, int N, int hi,
-                                         RngKey dkey) {
+                                         RngKey dkey) {  // q: DROP kernels pass the lane's Weyl value wq instead of the query index
     const fa_f32x16 zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
     const el16x8_t vf0 = fa4_vfrag(vc), vf1 = fa4_vfrag(vc + 16 * 16);
     if (TAIL) {  // partial last tile: the scores of THIS sub-tile are computed here, keys beyond the sequence masked
@@ -2576,10 +2576,12 @@ __device__ __forceinline__ void fa4_step(const AttnArgs& a, fa_f32x16& sc_cur, f
     l2 += ts;  // the normaliser is accumulated BEFORE dropout (attention.py:69-70)
     if (DROP) {
         const uint32_t th = a.drop.thresh16;
-        const uint32_t e0 = (uint32_t)q * (uint32_t)N + (uint32_t)(jb + 4 * hi);  // even: N even, jb and 4*hi multiples of 4
+        // element q * N + jb + 4 hi (even: N even, jb and 4 hi multiples of 4) -> pair index / 2; wq = the Weyl value of the
+        // lane's pair (q * N + 4 hi) / 2, the sub-tile adds (jb / 2) * RNG_WEYL (scalar) and register pair pr a constant
+        const uint32_t w0 = (uint32_t)q + (uint32_t)(jb >> 1) * RNG_WEYL;
 #pragma unroll
-        for (int pr = 0; pr < 8; ++pr) {  // registers 2*pr, 2*pr + 1: keys e0 + 8*(pr >> 1) + 2*(pr & 1) + {0, 1}
-            const uint32_t w = rng_pair_word((e0 + 8u * (uint32_t)(pr >> 1) + 2u * (uint32_t)(pr & 1)) >> 1, dkey);
+        for (int pr = 0; pr < 8; ++pr) {  // registers 2*pr, 2*pr + 1: keys jb + 4 hi + 8*(pr >> 1) + 2*(pr & 1) + {0, 1}
+            const uint32_t w = rng_pair_mix(w0 + (4u * (uint32_t)(pr >> 1) + (uint32_t)(pr & 1)) * RNG_WEYL, dkey);
             p[2 * pr] = (w & 0xffffu) < th ? p[2 * pr] : 0.0f;
             p[2 * pr + 1] = (w >> 16) < th ? p[2 * pr + 1] : 0.0f;
         }
@@ -2651,6 +2653,8 @@ __global__ __launch_bounds__(64 * NW, FA4_MINW) void flash_attention4_kernel(Att
     for (int r = 0; r < 16; ++r) o[r] = scA[r] = scB[r] = 0.0f;
     bool first = true, biased = false;
     const RngKey dkey = DROP ? attn_drop_key(a.drop, n, (uint32_t)h) : RngKey{0u, 0u};
+    // DROP: what the steps receive as "q" is the Weyl value of the lane's first keep-word pair, (q0 * N + 4 hi) / 2
+    const int qarg = DROP ? (int)rng_weyl(((uint32_t)q0 * (uint32_t)N + 4u * (uint32_t)hi) >> 1, dkey) : q0;
 
     // staging role: thread -> (key, 16-B chunk of 8 channels); NW = 4: every thread carries its K and its V piece, NW = 8: the
     // threads of waves 0-3 carry K, those of waves 4-7 V.  Rows beyond the sequence are CLAMPED to the last row (finite values;
@@ -2706,9 +2710,9 @@ __global__ __launch_bounds__(64 * NW, FA4_MINW) void flash_attention4_kernel(Att
         const el16_t* B0 = KV + c0;                                                                                                       \
         const el16_t* B1 = KV + c1;                                                                                                       \
         fa4_step<DROP, B, false>(a, scA, scB, B0 + kf0, B0 + kf1, B0 + 1024 + kf0, B0 + 1024 + kf1, B0 + vf0, qf, o, m, l2, bm, aone,    \
-                                 first, biased, j0, q0, N, hi, dkey);                                                                     \
+                                 first, biased, j0, qarg, N, hi, dkey);                                                                   \
         fa4_step<DROP, B, false>(a, scB, scA, B0 + 1024 + kf0, B0 + 1024 + kf1, B1 + kf0, B1 + kf1, B0 + vf0 + 32 * 16, qf, o, m, l2, bm, \
-                                 aone, first, biased, j0 + 32, q0, N, hi, dkey);                                                          \
+                                 aone, first, biased, j0 + 32, qarg, N, hi, dkey);                                                        \
         const int tmp = c0;                                                                                                               \
         c0 = c1;                                                                                                                          \
         c1 = c2b;                                                                                                                         \
