@@ -658,7 +658,8 @@ hipError_t launch_conv_igemm2(const ConvArgs& a, hipStream_t stream) {
     const bool sh3 = sh3_on && a.kh == 3 && a.kw == 3 && a.stride == 1 && a.pad == 1 && a.ho == a.h && a.wo == a.w && a.wo >= 2 &&
                      !(a.wo % 16 == 0 && a.ho % TH == 0);
     if (a.gnf.gran != nullptr) {  // GroupNorm fused (launch_conv_gn_fused checked the shape): + 4 KB of LDS for the waves' (A, C) tables
-        dyf_form_note(sh3 ? "conv_igemm2_kernel<2>+gn_fused+sh3" : "conv_igemm2_kernel<2>+gn_fused", a.n);
+        dyf_form_note("conv_igemm2_kernel<2>+gn_fused", a.n);
+        if (sh3) dyf_form_note("conv_igemm2_kernel+sh3", a.n);  // (a note of its own: the form log's kernel names stay those of the tile shape)
         const int tiles_n = a.cout / 128;
         ConvArgs b = a;
         if (getenv("DYF_GN_FUSE_NOWAIT")) b.gnf.slots = -1;  // timing experiment (WRONG results): no granule sweep
@@ -668,7 +669,8 @@ hipError_t launch_conv_igemm2(const ConvArgs& a, hipStream_t stream) {
             hipLaunchKernelGGL((conv_igemm2_kernel<2, true>), dim3(tiles_m * tiles_n), dim3(256), LDS_TOTAL + 4096, stream, b, (int)M, tiles_m, tiles_n);
         return hipGetLastError();
     }
-    dyf_form_note(small ? (sh3 ? "conv_igemm2_kernel<1>+sh3" : "conv_igemm2_kernel<1>") : (sh3 ? "conv_igemm2_kernel<2>+sh3" : "conv_igemm2_kernel<2>"), a.n);
+    dyf_form_note(small ? "conv_igemm2_kernel<1>" : "conv_igemm2_kernel<2>", a.n);
+    if (sh3) dyf_form_note("conv_igemm2_kernel+sh3", a.n);
     if (!small) {
         const int tiles_n = a.cout / 128;
         if (sh3)
