@@ -421,6 +421,18 @@ def bench_train_steps(dev):
                     "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(fl / dt / 1e12 / PEAK_FP32_MFMA_TFLOPS, 3),
                     "samples_per_s": round(B / dt, 1)}
         log(f"train step unet.Unet B={B}: {1e3 * dt:.1f} ms")
+        if B == 64:  # the same step with the conv operands rounded to 16 bits while staged (opt-in; same launchers as the NS step)
+            os.environ["DYF_TRAIN_OPERANDS"] = "bf16"
+            try:
+                dt16, loss16 = timed(step_rn, 3)
+            finally:
+                os.environ.pop("DYF_TRAIN_OPERANDS", None)
+            out[key + "_16bit_operands"] = {"workload": out[key]["workload"].replace(", fp32", ", fp32 tensors, conv operands rounded to "
+                                                                                     "bf16 in the kernels (opt-in)"),
+                                            "batch": B, "ms_per_step": round(1e3 * dt16, 1), "loss": round(loss16, 4),
+                                            "loss_fp32_operands": round(loss, 4), "achieved": round(fl / dt16 / 1e12, 1),
+                                            "unit": "TFLOP/s", "samples_per_s": round(B / dt16, 1), "speedup_vs_fp32": round(dt / dt16, 2)}
+            log(f"train step unet.Unet B={B}, 16-bit conv operands: {1e3 * dt16:.1f} ms (loss {loss16:.4f} vs {loss:.4f})")
         m2._engine.close()
         del m2
     return out

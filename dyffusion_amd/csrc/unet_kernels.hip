@@ -2531,10 +2531,17 @@ __device__ __forceinline__ void fa4_step(const AttnArgs& a, fa_f32x16& sc_cur, f
         sc_next = DYF_MFMA_32x32x16(k1, qf[1], sc_next, 0, 0, 0);
 #endif
     }
+#if FA4_SCALAR_SUM  // experiment: four scalar chains instead of packed adds
+    float s0 = p[0] + p[4], s1 = p[1] + p[5], s2 = p[2] + p[6], s3 = p[3] + p[7];
+    s0 += p[8]; s1 += p[9]; s2 += p[10]; s3 += p[11];
+    s0 += p[12]; s1 += p[13]; s2 += p[14]; s3 += p[15];
+    fa_f32x2 ts = fa_f32x2{s0 + s2, s1 + s3};
+#else
     fa_f32x2 ts = fa_f32x2{p[0], p[1]};
 #if !defined(FA4_X_MFMAONLY)
 #pragma unroll
     for (int r = 2; r < 16; r += 2) ts += fa_f32x2{p[r], p[r + 1]};
+#endif
 #endif
     const float tsum = ts.x + ts.y;
     // wave-uniform slow path; rare after the first sub-tiles.  (An un-biased instantiation entered with m != 0 -- the step right
@@ -2660,22 +2667,23 @@ __global__ __launch_bounds__(64 * NW, FA4_MINW) void flash_attention4_kernel(Att
     // threads of waves 0-3 carry K, those of waves 4-7 V.  Rows beyond the sequence are CLAMPED to the last row (finite values;
     // their scores are masked in the tail step and their tiles never read in the main loop).
     const int st_id = tid & 255, skey = st_id >> 2, sch = st_id & 3;
-    const bool vrole = NW == 8 && tid >= 256;
+    const bool vrole = NW >= 8 && (tid & 511) >= 256;
     const int kdst = skey * 32 + ((sch ^ ((skey >> 2) & 3)) << 3);
     const int vdst = 64 * 32 + (sch >> 1) * FA4_VH + skey * 16 + (sch & 1) * 8;
     const int sdst = vrole ? vdst : kdst;
     const el16_t* gk = base + hd + h * 32 + sch * 8 + (vrole ? hd : 0);
     uint4 kv_n = make_uint4(0, 0, 0, 0), vv_n = make_uint4(0, 0, 0, 0);
+    const bool stager = NW <= 8 || tid < 512;  // NW = 16: waves 0-7 stage
     auto fetch = [&](int j0) {  // K / V of a later 64-key tile travel through registers while the current one is consumed
         const uint32_t row = (uint32_t)min(j0 + skey, N - 1);
-        kv_n = *(const uint4*)(gk + row * (uint32_t)C3);
+        if (stager) kv_n = *(const uint4*)(gk + row * (uint32_t)C3);
         if (NW == 4) vv_n = *(const uint4*)(gk + hd + row * (uint32_t)C3);
     };
     auto stage = [&](int buf) {
         if (NW == 4) {
             *(uint4*)(KV + buf + kdst) = kv_n;
             *(uint4*)(KV + buf + vdst) = vv_n;
-        } else {
+        } else if (stager) {
             *(uint4*)(KV + buf + sdst) = kv_n;
         }
     };
@@ -2765,12 +2773,14 @@ hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
         // the fourth form: one 32-query block per wave, DYF_FLASH_NW = 8 (default) / 4 waves per workgroup; a sequence shorter than
         // 512 tokens stays on four waves (more workgroups)
         static const int nw_env = getenv("DYF_FLASH_NW") ? atoi(getenv("DYF_FLASH_NW")) : 8;
-        const int nw = nw_env == 8 && a.hw >= 512 ? 8 : 4;
+        const int nw = nw_env == 16 && a.hw >= 2048 ? 16 : nw_env >= 8 && a.hw >= 512 ? 8 : 4;
         const bool v4 = flash >= 4 && (!drop || (a.drop.mode == 1 && (a.hw & 1) == 0 && a.hw % (32 * nw) == 0));
         if (v4) {
-            dyf_form_note(nw == 8 ? "flash_attention4_kernel<NW=8>" : "flash_attention4_kernel<NW=4>", a.n);
+            dyf_form_note(nw == 16 ? "flash_attention4_kernel<NW=16>" : nw == 8 ? "flash_attention4_kernel<NW=8>" : "flash_attention4_kernel<NW=4>", a.n);
             const int qb4 = (a.hw + 32 * nw - 1) / (32 * nw);
-            if (nw == 8 && drop) hipLaunchKernelGGL((flash_attention4_kernel<true, 8>), dim3(a.n * a.heads * qb4), dim3(512), 0, s, a);
+            if (nw == 16 && drop) hipLaunchKernelGGL((flash_attention4_kernel<true, 16>), dim3(a.n * a.heads * qb4), dim3(1024), 0, s, a);
+            else if (nw == 16) hipLaunchKernelGGL((flash_attention4_kernel<false, 16>), dim3(a.n * a.heads * qb4), dim3(1024), 0, s, a);
+            else if (nw == 8 && drop) hipLaunchKernelGGL((flash_attention4_kernel<true, 8>), dim3(a.n * a.heads * qb4), dim3(512), 0, s, a);
             else if (nw == 8) hipLaunchKernelGGL((flash_attention4_kernel<false, 8>), dim3(a.n * a.heads * qb4), dim3(512), 0, s, a);
             else if (drop) hipLaunchKernelGGL((flash_attention4_kernel<true, 4>), dim3(a.n * a.heads * qb4), dim3(256), 0, s, a);
             else hipLaunchKernelGGL((flash_attention4_kernel<false, 4>), dim3(a.n * a.heads * qb4), dim3(256), 0, s, a);
