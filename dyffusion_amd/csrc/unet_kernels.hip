@@ -2015,7 +2015,8 @@ __device__ __forceinline__ void fa2_subtile(const AttnArgs& a, const el16_t* kf0
                 bm[b][0] = (short)(hi == 0 ? ((__builtin_bit_cast(uint32_t, -mn)) >> 16) : 0u);
             }
 #endif
-            const float alpha = __builtin_amdgcn_exp2f(-delta);             // (first: O and l are still zero)
+            // (first: O and l are still zero -- and a first maximum below -128 would make exp2(-delta) infinite: 0 * inf)
+            const float alpha = first ? 1.0f : __builtin_amdgcn_exp2f(-delta);
             m[b] += delta;
             l2[b] *= alpha;
 #pragma unroll
