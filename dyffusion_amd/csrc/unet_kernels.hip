@@ -2493,6 +2493,31 @@ __device__ __forceinline__ el16x8_t fa4_vfrag(const el16_t* v) {  // keys {0..3}
     uint2 w[2] = {__builtin_bit_cast(uint2, lo), __builtin_bit_cast(uint2, hi)};
     return *(el16x8_t*)w;
 }
+#ifndef FA4_MFMA_SUM
+#define FA4_MFMA_SUM 1
+#endif
+// sum of a lane's sixteen packed 16-bit values on the matrix pipe (see fa4_step)
+__device__ __forceinline__ float fa4_rowsum(const uint32_t (&pk)[8]) {
+    typedef float fa_f32x4 __attribute__((ext_vector_type(4)));
+    fa_f32x4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+#if DYF_F16
+    typedef _Float16 fa_h4 __attribute__((ext_vector_type(4)));
+    const fa_h4 ones = {(_Float16)1.0f, (_Float16)1.0f, (_Float16)1.0f, (_Float16)1.0f};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const uint2 w = make_uint2(pk[2 * t], pk[2 * t + 1]);
+        acc = __builtin_amdgcn_mfma_f32_4x4x4f16(ones, __builtin_bit_cast(fa_h4, w), acc, 0, 0, 0);
+    }
+#else
+    const fa_bf16x4 ones = {0x3F80, 0x3F80, 0x3F80, 0x3F80};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const uint2 w = make_uint2(pk[2 * t], pk[2 * t + 1]);
+        acc = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(ones, __builtin_bit_cast(fa_bf16x4, w), acc, 0, 0, 0);
+    }
+#endif
+    return acc[0];
+}
 template <bool DROP, bool BIASED, bool TAIL>
 __device__ __forceinline__ void fa4_step(const AttnArgs& a, fa_f32x16& sc_cur, fa_f32x16& sc_next, const el16_t* kc0, const el16_t* kc1,
                                          const el16_t* kn0, const el16_t* kn1, const el16_t* vc, const el16x8_t (&qf)[2], fa_f32x16& o, float& m,
@@ -2532,7 +2557,23 @@ __device__ __forceinline__ void fa4_step(const AttnArgs& a, fa_f32x16& sc_cur, f
         sc_next = DYF_MFMA_32x32x16(k1, qf[1], sc_next, 0, 0, 0);
 #endif
     }
-#if FA4_SCALAR_SUM  // experiment: four scalar chains instead of packed adds
+#if FA4_MFMA_SUM
+    // no dropout: the sub-tile's sum comes from the MATRIX pipe -- four 4x4x4 products of the packed probabilities with a tile of
+    // ones give every lane the sum of its own sixteen values (block b = lane / 4, column j = lane % 4: D[b][i][j] = sum_k B[b][k][j]
+    // for every row i), eight packed vector adds fewer per sub-tile; the sum is that of the ROUNDED probabilities, which is what
+    // the P V products use
+    uint32_t pk[8];
+    fa_f32x2 ts;
+    if (!DROP) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) pk[t] = pack_el16x2(p[2 * t], p[2 * t + 1]);
+        ts = fa_f32x2{fa4_rowsum(pk), 0.0f};
+    } else {
+        ts = fa_f32x2{p[0], p[1]};
+#pragma unroll
+        for (int r = 2; r < 16; r += 2) ts += fa_f32x2{p[r], p[r + 1]};
+    }
+#elif FA4_SCALAR_SUM  // experiment: four scalar chains instead of packed adds
     float s0 = p[0] + p[4], s1 = p[1] + p[5], s2 = p[2] + p[6], s3 = p[3] + p[7];
     s0 += p[8]; s1 += p[9]; s2 += p[10]; s3 += p[11];
     s0 += p[12]; s1 += p[13]; s2 += p[14]; s3 += p[15];
@@ -2576,9 +2617,18 @@ __device__ __forceinline__ void fa4_step(const AttnArgs& a, fa_f32x16& sc_cur, f
             p[r] = __builtin_amdgcn_exp2f(raw[r] - mn);
             if (!TAIL) sc_next[r] -= BIASED ? delta : mn;  // computed with the old -m / without a bias product
         }
-        ts = fa_f32x2{p[0], p[1]};
+#if FA4_MFMA_SUM
+        if (!DROP) {
 #pragma unroll
-        for (int r = 2; r < 16; r += 2) ts += fa_f32x2{p[r], p[r + 1]};
+            for (int t = 0; t < 8; ++t) pk[t] = pack_el16x2(p[2 * t], p[2 * t + 1]);
+            ts = fa_f32x2{fa4_rowsum(pk), 0.0f};
+        } else
+#endif
+        {
+            ts = fa_f32x2{p[0], p[1]};
+#pragma unroll
+            for (int r = 2; r < 16; r += 2) ts += fa_f32x2{p[r], p[r + 1]};
+        }
         first = false;
     }
     l2 += ts;  // the normaliser is accumulated BEFORE dropout (attention.py:69-70)
@@ -2594,12 +2644,19 @@ __device__ __forceinline__ void fa4_step(const AttnArgs& a, fa_f32x16& sc_cur, f
             p[2 * pr + 1] = (w >> 16) < th ? p[2 * pr + 1] : 0.0f;
         }
     }
+#if FA4_MFMA_SUM
+    if (DROP) {
+#pragma unroll
+        for (int t = 0; t < 8; ++t) pk[t] = pack_el16x2(p[2 * t], p[2 * t + 1]);
+    }
+#else
     uint32_t pk[8];
 #pragma unroll
 #if defined(FA4_X_MFMAONLY)
     for (int t = 0; t < 8; ++t) pk[t] = __builtin_bit_cast(uint32_t, p[2 * t]);
 #else
     for (int t = 0; t < 8; ++t) pk[t] = pack_el16x2(p[2 * t], p[2 * t + 1]);
+#endif
 #endif
 #if defined(FA4_X_NOPV)
     o[0] += __builtin_bit_cast(float, pk[0] ^ pk[1] ^ pk[2] ^ pk[3]) + (float)vf0[0];
