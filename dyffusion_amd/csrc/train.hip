@@ -226,6 +226,38 @@ __global__ void t_conv_fwd(TConv g, const float* x, const float* wt, const float
     y[i] = acc;
 }
 
+// the same sums in the same order, four output channels per thread (cout % 4 == 0): 16-byte weight loads and stores.  The
+// small-channel convs of unet_simple (the 1x1 stem 5 -> 64 and the readout's input gradient 3 -> 64, 4x4 / stride 2) are
+// latency-bound in the one-channel form: 1.4 ms per launch at 32 rows x 256^2.
+__global__ __launch_bounds__(256) void t_conv_fwd4(TConv g, const float* x, const float* wt, const float* bias, float* y) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int c4 = g.cout >> 2;
+    if (i >= (long long)g.n * g.ho * g.wo * c4) return;
+    const int co = (int)(i % c4) * 4;
+    const long long pix = i / c4;
+    const int ox = (int)(pix % g.wo), oy = (int)((pix / g.wo) % g.ho), b = (int)(pix / ((long long)g.wo * g.ho));
+    float4 acc = bias ? *(const float4*)(bias + co) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    for (int ky = 0; ky < g.k; ++ky) {
+        const int iy = oy * g.s - g.p + ky;
+        if ((unsigned)iy >= (unsigned)g.h) continue;
+        for (int kx = 0; kx < g.k; ++kx) {
+            const int ix = ox * g.s - g.p + kx;
+            if ((unsigned)ix >= (unsigned)g.w) continue;
+            const float* xp = x + (((size_t)b * g.h + iy) * g.w + ix) * g.cin;
+            const float* wp = wt + (size_t)(ky * g.k + kx) * g.cin * g.cout + co;
+            for (int ci = 0; ci < g.cin; ++ci) {
+                const float xv = xp[ci];
+                const float4 w4 = *(const float4*)(wp + (size_t)ci * g.cout);
+                acc.x = fmaf(xv, w4.x, acc.x);
+                acc.y = fmaf(xv, w4.y, acc.y);
+                acc.z = fmaf(xv, w4.z, acc.z);
+                acc.w = fmaf(xv, w4.w, acc.w);
+            }
+        }
+    }
+    *(float4*)(y + (size_t)pix * g.cout + co) = acc;
+}
+
 // dx[n,iy,ix,ci] = sum over (ky,kx) with (iy+p-ky) % s == 0 and co of dz[n,(iy+p-ky)/s,(ix+p-kx)/s,co] * w[co][tap][ci]
 // (+ bias[ci] when used as the FORWARD of a transposed convolution)
 __global__ void t_conv_dgrad(TConv g, const float* dz, const float* w, const float* bias, float* dx) {
@@ -273,11 +305,14 @@ __global__ __launch_bounds__(256) void t_conv_dgrad_smalln(TConv g, const float*
     const long long pp = live ? pix : total - 1;
     const int ix = (int)(pp % g.w), iy = (int)((pp / g.w) % g.h), b = (int)(pp / ((long long)g.w * g.h));
     float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+    // stride a power of two (every shipped layer): shifts -- two divisions by a run-time stride per tap were most of this kernel's
+    // instructions (16 taps x ~70 of them against four taps of useful work: 3.5 ms per readout launch at 32 rows x 512^2)
+    const int sh = (g.s & (g.s - 1)) == 0 ? __builtin_ctz((unsigned)g.s) : -1;
     for (int ky = 0; ky < g.k; ++ky) {
-        const int ty = iy + g.p - ky, oy = ty / g.s;
+        const int ty = iy + g.p - ky, oy = sh >= 0 ? ty >> sh : ty / g.s;
         if (ty < 0 || oy * g.s != ty || oy >= g.ho) continue;
         for (int kx = 0; kx < g.k; ++kx) {
-            const int tx = ix + g.p - kx, ox = tx / g.s;
+            const int tx = ix + g.p - kx, ox = sh >= 0 ? tx >> sh : tx / g.s;
             if (tx < 0 || ox * g.s != tx || ox >= g.wo) continue;
             const float* zp = dz + (((size_t)b * g.ho + oy) * g.wo + ox) * g.cout;
             const float4* wt = sn_w + (size_t)(ky * g.k + kx) * g.cout;
@@ -345,6 +380,105 @@ __global__ __launch_bounds__(256) void t_conv_wgrad(TConv g, const float* dz, co
     }
     if (co < g.cout && ci < g.cin) atomicAdd(dw + ((size_t)co * taps + tap) * g.cin + ci, acc);
     if (db && tap == 0 && cit == 0 && tci == 0 && co < g.cout) atomicAdd(db + co, accb);
+}
+
+// The same sums for STRIDE 2 with one thread per result pixel: wave w of a workgroup owns the pixels of parity class
+// (py, px) = (w >> 1, w & 1) of one row pair -- 64 of them, every other column -- so the taps that reach them, ky = (iy + p) mod 2
+// (+ 2, ...) and the same in x, are the same for the whole wave: no per-lane tap test, the weights of a (tap, channel quad) are one
+// broadcast LDS read, a lane walks the 64 channels of its four source pixels with 16-byte loads and keeps its cin sums in
+// registers (the 16-lanes-per-pixel form above re-reads every source pixel through shuffles and reductions: 3.3 ms per readout
+// launch at 32 rows x 512^2, cache-traffic bound).  h and w even.
+__global__ __launch_bounds__(256) void t_conv_dgrad_smalln_s2(TConv g, const float* dz, const float* w, const float* bias, float* dx) {
+    extern __shared__ float4 sn_w[];  // [taps][cout]
+    const int taps = g.k * g.k;
+    for (int i = threadIdx.x; i < taps * g.cout; i += 256) {
+        const int tap = i / g.cout, co = i - tap * g.cout;
+        const float* wp = w + ((size_t)co * taps + tap) * g.cin;
+        sn_w[i] = make_float4(wp[0], g.cin > 1 ? wp[1] : 0.0f, g.cin > 2 ? wp[2] : 0.0f, g.cin > 3 ? wp[3] : 0.0f);
+    }
+    __syncthreads();
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int py = wave >> 1, px = wave & 1;
+    const int wc = (g.w / 2 + 63) / 64, hh = g.h / 2;
+    int bid = blockIdx.x;
+    const int cx = bid % wc;
+    bid /= wc;
+    const int ry = bid % hh, b = bid / hh;
+    const int iy = 2 * ry + py, ix = 2 * (cx * 64 + lane) + px;
+    const bool live = ix < g.w;
+    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+    for (int ky = (iy + g.p) & 1; ky < g.k; ky += 2) {
+        const int ty = iy + g.p - ky, oy = ty >> 1;
+        if (ty < 0 || oy >= g.ho) continue;  // wave-uniform
+        for (int kx = (px + g.p) & 1; kx < g.k; kx += 2) {
+            const int tx = ix + g.p - kx, ox = tx >> 1;
+            if (!(live && tx >= 0 && ox < g.wo)) continue;  // lanes at the left / right border only
+            const float* zp = dz + (((size_t)b * g.ho + oy) * g.wo + ox) * g.cout;
+            const float4* wt = sn_w + (size_t)(ky * g.k + kx) * g.cout;
+            for (int c0 = 0; c0 < g.cout; c0 += 4) {
+                const float4 z = *(const float4*)(zp + c0);
+                const float4 w0 = wt[c0], w1 = wt[c0 + 1], w2 = wt[c0 + 2], w3 = wt[c0 + 3];
+                a0 = fmaf(z.x, w0.x, fmaf(z.y, w1.x, fmaf(z.z, w2.x, fmaf(z.w, w3.x, a0))));
+                a1 = fmaf(z.x, w0.y, fmaf(z.y, w1.y, fmaf(z.z, w2.y, fmaf(z.w, w3.y, a1))));
+                a2 = fmaf(z.x, w0.z, fmaf(z.y, w1.z, fmaf(z.z, w2.z, fmaf(z.w, w3.z, a2))));
+                a3 = fmaf(z.x, w0.w, fmaf(z.y, w1.w, fmaf(z.z, w2.w, fmaf(z.w, w3.w, a3))));
+            }
+        }
+    }
+    if (!live) return;
+    float* o = dx + (((size_t)b * g.h + iy) * g.w + ix) * g.cin;
+    o[0] = a0 + (bias ? bias[0] : 0.0f);
+    if (g.cin > 1) o[1] = a1 + (bias ? bias[1] : 0.0f);
+    if (g.cin > 2) o[2] = a2 + (bias ? bias[2] : 0.0f);
+    if (g.cin > 3) o[3] = a3 + (bias ? bias[3] : 0.0f);
+}
+
+// Weight gradient of a conv with a handful of INPUT channels (the 1x1 stem, cin = 5; the readout's transposed conv, cin = 3,
+// 16 taps), cout a multiple of 64: the tiled kernel above spends two barriers per 16 pixels on a 16 x 16 tile of which 3 - 5
+// columns exist (3.3 ms per launch at 32 rows).  Here a wave owns 64 output channels (lane = co) and walks its share of the
+// workgroup's pixels: dz[m][co] is one coalesced load, the shifted x pixel of a tap is the same for the whole wave (scalar
+// loads), and every lane keeps all taps x cin partial sums in registers (NACC = taps * cin <= 64).  The four waves of a workgroup
+// take every fourth pixel; their sums meet in LDS and leave with one atomic per (co, tap, ci) and workgroup.
+template <int K, int CIN>
+__global__ __launch_bounds__(256) void t_conv_wgrad_smallc(TConv g, const float* dz, const float* x, float* dw, float* db, int pix_per_block) {
+    constexpr int NACC = K * K * CIN;
+    __shared__ float red[3][NACC + 1][64];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int cob = blockIdx.y * 64;
+    const long long M = (long long)g.n * g.ho * g.wo;
+    const long long m0 = (long long)blockIdx.x * pix_per_block, m1 = m0 + pix_per_block < M ? m0 + pix_per_block : M;
+    float acc[NACC], accb = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) acc[i] = 0.0f;
+    for (long long m = m0 + wave; m < m1; m += 4) {
+        const float z = dz[(size_t)m * g.cout + cob + lane];
+        accb += z;
+        const int ox = (int)(m % g.wo), oy = (int)((m / g.wo) % g.ho), b = (int)(m / ((long long)g.wo * g.ho));
+#pragma unroll
+        for (int ky = 0; ky < K; ++ky) {
+            const int iy = oy * g.s - g.p + ky;
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx) {
+                const int ix = ox * g.s - g.p + kx;
+                const bool in = (unsigned)iy < (unsigned)g.h && (unsigned)ix < (unsigned)g.w;  // wave-uniform
+                const float* xp = x + (((size_t)b * g.h + (in ? iy : 0)) * g.w + (in ? ix : 0)) * CIN;
+#pragma unroll
+                for (int ci = 0; ci < CIN; ++ci) acc[(ky * K + kx) * CIN + ci] = fmaf(z, in ? xp[ci] : 0.0f, acc[(ky * K + kx) * CIN + ci]);
+            }
+        }
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int i = 0; i < NACC; ++i) red[wave - 1][i][lane] = acc[i];
+        red[wave - 1][NACC][lane] = accb;
+    }
+    __syncthreads();
+    if (wave > 0) return;
+    const int co = cob + lane;
+#pragma unroll
+    for (int i = 0; i < NACC; ++i)
+        atomicAdd(dw + (size_t)co * NACC + i, acc[i] + red[0][i][lane] + red[1][i][lane] + red[2][i][lane]);  // dw[co][tap][ci]
+    if (db) atomicAdd(db + co, accb + red[0][NACC][lane] + red[1][NACC][lane] + red[2][NACC][lane]);
 }
 
 // ------------------------------------------------------------------------------------------------ normalisation + FiLM + act + dropout
@@ -768,12 +902,24 @@ dyf_status conv_fwd(dyf_engine* e, const TConv& g, const float* x, const float* 
         TK(hipGetLastError());
         return DYF_OK;
     }
-    hipLaunchKernelGGL(t_conv_fwd, dim3(nblk((long long)g.n * g.ho * g.wo * g.cout)), dim3(256), 0, st, g, x, wt, b, y);
+    static const bool small = !(getenv("DYF_TRAIN_SMALLC") && atoi(getenv("DYF_TRAIN_SMALLC")) == 0);  // =0: the round-3 VALU forms (A/B)
+    if (small && g.cout % 4 == 0)
+        hipLaunchKernelGGL(t_conv_fwd4, dim3(nblk((long long)g.n * g.ho * g.wo * (g.cout / 4))), dim3(256), 0, st, g, x, wt, b, y);
+    else
+        hipLaunchKernelGGL(t_conv_fwd, dim3(nblk((long long)g.n * g.ho * g.wo * g.cout)), dim3(256), 0, st, g, x, wt, b, y);
     TK(hipGetLastError());
     return DYF_OK;
 }
 dyf_status conv_dgrad(dyf_engine* e, const TConv& g, const float* dz, const float* w, const float* bias, float* dx, hipStream_t st) {
     if (train_mfma() && tgemm_conv_dgrad(g, dz, w, bias, dx, splitk_ws(e), TRAIN_SPLITK_FLOATS, st)) {
+        TK(hipGetLastError());
+        return DYF_OK;
+    }
+    static const bool small = !(getenv("DYF_TRAIN_SMALLC") && atoi(getenv("DYF_TRAIN_SMALLC")) == 0);
+    if (small && g.s == 2 && g.cin <= 4 && g.cout % 4 == 0 && g.h % 2 == 0 && g.w % 2 == 0 && (size_t)g.k * g.k * g.cout * 16 <= 65536) {
+        const int wc = (g.w / 2 + 63) / 64;
+        hipLaunchKernelGGL(t_conv_dgrad_smalln_s2, dim3((unsigned)((long long)g.n * (g.h / 2) * wc)), dim3(256), (size_t)g.k * g.k * g.cout * 16, st,
+                           g, dz, w, bias, dx);
         TK(hipGetLastError());
         return DYF_OK;
     }
@@ -800,6 +946,22 @@ dyf_status conv_wgrad(dyf_engine* e, const TConv& g, const float* dz, const floa
         }
         TK(hipGetLastError());
         return DYF_OK;
+    }
+    static const bool small = !(getenv("DYF_TRAIN_SMALLC") && atoi(getenv("DYF_TRAIN_SMALLC")) == 0);
+    if (small && g.cout % 64 == 0 && M >= 4096) {
+        const int cob = g.cout / 64;
+        const long long blocks = std::max<long long>(1, std::min<long long>(M / 512, 1024 / cob));  // >= 512 pixels per workgroup
+        const int ppb = (int)((M + blocks - 1) / blocks);
+        const dim3 grid((unsigned)((M + ppb - 1) / ppb), (unsigned)cob);
+#define SMALLC(KK, CC) if (g.k == KK && g.cin == CC) { hipLaunchKernelGGL((t_conv_wgrad_smallc<KK, CC>), grid, dim3(256), 0, st, g, dz, x, dw, db, ppb); launched = true; }
+        bool launched = false;
+        SMALLC(1, 1) SMALLC(1, 2) SMALLC(1, 3) SMALLC(1, 4) SMALLC(1, 5) SMALLC(1, 6) SMALLC(1, 7) SMALLC(1, 8)
+        SMALLC(4, 1) SMALLC(4, 2) SMALLC(4, 3) SMALLC(4, 4)
+#undef SMALLC
+        if (launched) {
+            TK(hipGetLastError());
+            return DYF_OK;
+        }
     }
     const int tiles = g.k * g.k * ((g.cout + 15) / 16) * ((g.cin + 15) / 16);
     long long slices = std::max<long long>(1, std::min<long long>((M + 255) / 256, (4096 + tiles - 1) / tiles));

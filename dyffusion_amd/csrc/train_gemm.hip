@@ -78,6 +78,17 @@ __global__ __launch_bounds__(256) void t_gemm_mfma(dyf::TConv g, const float* __
         }
     }
     const int b_k = tid >> 4, b_nq = tid & 15;  // B: k row, n quad
+    // dgrad: stride a power of two (every shipped layer) -> shifts instead of two divisions by a run-time stride per slot and stage
+    const int sh = (g.s & (g.s - 1)) == 0 ? __builtin_ctz((unsigned)g.s) : -1;
+    // wgrad: (ox, oy, b) of this thread's B pixel, carried from stage to stage (the stages of a launch are loaded in order) instead
+    // of three 64-bit divisions per stage
+    int w_ox = 0, w_oy = 0, w_b = 0;
+    if (MODE == TG_WGRAD) {
+        const unsigned pix0 = (unsigned)(kbeg + b_k);
+        w_ox = (int)(pix0 % (unsigned)g.wo);
+        w_oy = (int)((pix0 / (unsigned)g.wo) % (unsigned)g.ho);
+        w_b = (int)(pix0 / ((unsigned)g.wo * (unsigned)g.ho));
+    }
 
     float4 ra[2], rb;
     auto load = [&](int stage) {
@@ -95,7 +106,7 @@ __global__ __launch_bounds__(256) void t_gemm_mfma(dyf::TConv g, const float* __
                         ra[i] = *(const float4*)(Ap + (((size_t)a_b[i] * g.h + iy) * g.w + ix) * g.cin + c0 + kq * 4);
                 } else {
                     const int ty = a_y[i] + g.p - ky, tx = a_x[i] + g.p - kx;
-                    const int oy = ty / g.s, ox = tx / g.s;
+                    const int oy = sh >= 0 ? ty >> sh : ty / g.s, ox = sh >= 0 ? tx >> sh : tx / g.s;
                     if (a_ok[i] && ty >= 0 && tx >= 0 && oy * g.s == ty && ox * g.s == tx && oy < g.ho && ox < g.wo)
                         ra[i] = *(const float4*)(Ap + (((size_t)a_b[i] * g.ho + oy) * g.wo + ox) * g.cout + c0 + kq * 4);
                 }
@@ -117,11 +128,16 @@ __global__ __launch_bounds__(256) void t_gemm_mfma(dyf::TConv g, const float* __
             const long long pix = p0 + b_k;
             rb = make_float4(0.f, 0.f, 0.f, 0.f);
             if (pix < kend) {
-                const int ox = (int)(pix % g.wo), oy = (int)((pix / g.wo) % g.ho), b = (int)(pix / ((long long)g.wo * g.ho));
+                const int ox = w_ox, oy = w_oy, b = w_b;
                 const int ky = tap / g.k, kx = tap - ky * g.k;
                 const int iy = oy * g.s - g.p + ky, ix = ox * g.s - g.p + kx;
                 if ((unsigned)iy < (unsigned)g.h && (unsigned)ix < (unsigned)g.w)
                     rb = *(const float4*)(Bp + (((size_t)b * g.h + iy) * g.w + ix) * g.cin + tn * GN + b_nq * 4);
+            }
+            w_ox += GK;  // the next stage's pixel
+            while (w_ox >= g.wo) {
+                w_ox -= g.wo;
+                if (++w_oy >= g.ho) { w_oy = 0; ++w_b; }
             }
         }
     };
@@ -256,6 +272,17 @@ __global__ __launch_bounds__(256) void t_gemm_mfma16(dyf::TConv g, const float* 
             a_b[i] = (int)(mm / ((long long)pw * ph));
         }
     }
+    const int sh = (g.s & (g.s - 1)) == 0 ? __builtin_ctz((unsigned)g.s) : -1;  // (as in t_gemm_mfma)
+    int w_ox[2] = {0, 0}, w_oy[2] = {0, 0}, w_b[2] = {0, 0};
+    if (MODE == TG_WGRAD) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const unsigned pix0 = (unsigned)(kbeg + ((tid + 256 * i) >> 4));
+            w_ox[i] = (int)(pix0 % (unsigned)g.wo);
+            w_oy[i] = (int)((pix0 / (unsigned)g.wo) % (unsigned)g.ho);
+            w_b[i] = (int)(pix0 / ((unsigned)g.wo * (unsigned)g.ho));
+        }
+    }
     float4 ra[4], rb[2];
     auto load = [&](int stage) {
         if (MODE != TG_WGRAD) {
@@ -272,7 +299,7 @@ __global__ __launch_bounds__(256) void t_gemm_mfma16(dyf::TConv g, const float* 
                         ra[i] = *(const float4*)(Ap + (((size_t)a_b[i] * g.h + iy) * g.w + ix) * g.cin + c0 + kq * 4);
                 } else {
                     const int ty = a_y[i] + g.p - ky, tx = a_x[i] + g.p - kx;
-                    const int oy = ty / g.s, ox = tx / g.s;
+                    const int oy = sh >= 0 ? ty >> sh : ty / g.s, ox = sh >= 0 ? tx >> sh : tx / g.s;
                     if (a_ok[i] && ty >= 0 && tx >= 0 && oy * g.s == ty && ox * g.s == tx && oy < g.ho && ox < g.wo)
                         ra[i] = *(const float4*)(Ap + (((size_t)a_b[i] * g.ho + oy) * g.wo + ox) * g.cout + c0 + kq * 4);
                 }
@@ -301,11 +328,16 @@ __global__ __launch_bounds__(256) void t_gemm_mfma16(dyf::TConv g, const float* 
                 const long long pix = p0 + bk;
                 rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (pix < kend) {
-                    const int ox = (int)(pix % g.wo), oy = (int)((pix / g.wo) % g.ho), b = (int)(pix / ((long long)g.wo * g.ho));
+                    const int ox = w_ox[i], oy = w_oy[i], b = w_b[i];
                     const int ky = tap / g.k, kx = tap - ky * g.k;
                     const int iy = oy * g.s - g.p + ky, ix = ox * g.s - g.p + kx;
                     if ((unsigned)iy < (unsigned)g.h && (unsigned)ix < (unsigned)g.w)
                         rb[i] = *(const float4*)(Bp + (((size_t)b * g.h + iy) * g.w + ix) * g.cin + tn * GN + bnq * 4);
+                }
+                w_ox[i] += GK16;  // the next stage's pixel
+                while (w_ox[i] >= g.wo) {
+                    w_ox[i] -= g.wo;
+                    if (++w_oy[i] >= g.ho) { w_oy[i] = 0; ++w_b[i]; }
                 }
             }
         }
