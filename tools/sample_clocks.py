@@ -77,3 +77,15 @@ m.sample(x0, static_condition=st)
 sample_while("NS rollout, 80 rows (hipGraph replay)", lambda: m.sample(x0, static_condition=st), 6.0)
 z0, zs = torch.zeros_like(x0), torch.zeros_like(st)
 sample_while("NS rollout, 80 rows, all-zero inputs", lambda: m.sample(z0, static_condition=zs), 6.0)
+m._engine.close()
+del m
+mo, _, _, _ = bench.oisst_model(300)
+xo = torch.randn(300, 1, 60, 60, generator=g).cuda()
+mo.sample(xo)
+sample_while("OISST rollout, 300 rows, 3 row groups (hipGraph replay)", lambda: mo.sample(xo), 6.0)
+mo._engine.close()
+del mo
+ms = bench.synth512_model(4)
+xs = torch.randn(4, 4, 512, 512, generator=g).cuda()
+ms.sample(xs)
+sample_while("512^2 rollout, 4 rows, fp16 (hipGraph replay)", lambda: ms.sample(xs), 6.0)
