@@ -814,11 +814,13 @@ hipError_t launch_conv_gn_fused(const ConvArgs& a_in, int path, hipStream_t stre
         if (!b.wpk_frag) b.wpk_frag = conv_lookup_frag(b.wpk);
         const long long tiles2 = ((nsel * a.ho * a.wo + 255) / 256) * (a.cout / 128);
         // un-fused, the 256 x 128 tiles pay off from 384 tiles on (below that conv_igemm_kernel<128, 128> is ahead); fused, the form
-        // also saves the three GroupNorm launches behind it: taken from 256 tiles on (the 128 -> 128 convs of the 15 x 15 level at
-        // 300 rows: 264 tiles) -- DYF_GN_FUSE_MIN_TILES overrides, DYF_IGEMM2_MIN_TILES (tests) wins
+        // also saves the three GroupNorm launches behind it (statistics, finalise, apply: 15 us of launches at small batches): taken
+        // from 32 tiles on.  Measured at the end of round 4, OISST shapes, fields/s with the threshold at 256 (the first choice) /
+        // 64 / 16: 300 rows 4 154 / 4 165 / 4 181, 150 rows 3 568 / 3 626 / 3 631, 75 rows 2 360 / 2 494 / 2 479, 38 rows 1 548 /
+        // 1 619 / 1 654, 16 rows 811 / 811 / 791 (32: 818) -- DYF_GN_FUSE_MIN_TILES overrides, DYF_IGEMM2_MIN_TILES (tests) wins
         const char* mt = getenv("DYF_IGEMM2_MIN_TILES");
         const char* mf = getenv("DYF_GN_FUSE_MIN_TILES");
-        const long long min_tiles = mt ? atoll(mt) : mf ? atoll(mf) : 256;
+        const long long min_tiles = mt ? atoll(mt) : mf ? atoll(mf) : 32;
         const int slots = conv_igemm2_gn_slots(a.ho, a.wo);
         if (tiles2 >= min_tiles && slots > 0 && slots <= GN_FUSE_MAX_SLOTS && slots <= G.max_slots && conv_igemm2_supported(b)) {
             b.gnf.slots = slots;
