@@ -280,7 +280,7 @@ def bench_oisst(dev, nb=300, reps=3):
 
 def oisst_batch_curve(dev, first, nbs=(38, 75, 150)):
     """fields/s of the OISST workload at the row counts one GPU gets when 300 rows are sharded 8 / 4 / 2 ways: an engine of its own
-    per point (the default row groups follow max_batch: 3 from 120 rows, 2 from 64, none below)."""
+    per point (the default row groups follow max_batch: 3 from 72 rows on, none below)."""
     curve = dict(first)
     for nb in nbs:
         m, _, _, _ = oisst_model(nb)

@@ -29,9 +29,11 @@ int default_row_groups(const dyf_engine* e) {
     if (plane > 128 * 128) return 1;
     const long long pix = plane * e->cfg.max_batch;
     // OISST shapes (60 x 60), fields/s with 1 / 2 / 3 / 4 groups: 300 rows 3 198 / 3 568 / 3 722 / 2 966; 150 rows 2 758 / 3 005 /
-    // 3 126 / 2 209; 80 rows 2 182 / 2 231 / 2 055 / 1 347; 512 rows 3 620 / 3 805 / 3 835 / 3 541
-    if (pix >= 120ll * 60 * 60) return 3;
-    if (pix >= 64ll * 60 * 60) return 2;
+    // 3 126 / 2 209; 80 rows 2 182 / 2 231 / 2 055 / 1 347; 512 rows 3 620 / 3 805 / 3 835 / 3 541 (round 3).  Re-measured at the end
+    // of round 4 (GroupNorm fused at every level, 1 / 2 / 3 groups): 64 rows 2 328 / 2 158 / 2 197; 75 rows 2 307 / 2 387 / 2 439;
+    // 100 rows 2 737 / 2 810 / 2 898; 120 rows 3 101 / 3 085 / 3 181 -> three groups from 72 rows on, none below (two groups are
+    // what an engine that owns a communicator is capped to, dyf_comm_init)
+    if (pix >= 72ll * 60 * 60) return 3;
     return 1;
 }
 

@@ -41,7 +41,7 @@ def sharded_group_model(max_batch, total=240):
 def test_default_groups_follow_architecture_and_size():
     cfg, PF, PI, mirror = _oisst_pair()
     F_, I_ = mirror(PF, cfg, 1, 1, 1), mirror(PI, cfg, 2, 0, 1)
-    for nb, want in [(300, 3), (150, 3), (80, 2), (40, 1)]:
+    for nb, want in [(300, 3), (150, 3), (80, 3), (64, 1), (40, 1)]:  # three groups from 72 rows on (engine.hip default_row_groups)
         m = D.DYffusion(F_, D.InterpolatorHandle(I_, 7), max_batch=nb, forward_conditioning="data+noise", **OISST_HP)
         m._ensure_engine((60, 60), nb)
         assert m._engine.row_groups == want, (nb, m._engine.row_groups)
