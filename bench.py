@@ -454,7 +454,9 @@ def cpu_baseline(F, I):
     reference through tests/golden) runs the SAME workload, MC dropout on (RNG is a third of the reference's CPU time and is
     not skipped), at NB = 1 and NB = 4.  Bounded sample (~30 s): full rollouts, repeated while time allows.
     Threads: ATen's small-tensor ops and bernoulli_ stop scaling far below the core count of a 2-socket host, so one
-    interpolator forward is timed at 32 / 64 (/ all, up to 96) threads and the fastest setting is used -- and reported."""
+    interpolator forward is timed at 16 / 32 / 64 / 128 threads (those that the host has; all of them on hosts of <= 96 threads; the
+    256-thread setting of the GPU boxes was measured once at 17 s per forward against 0.13 s on 32 and is not re-timed on every run)
+    and the fastest setting is used -- the sweep is reported in the line (`thread_sweep_s`)."""
     from oracle import nets, sampler
 
     ncpu = os.cpu_count() or 1
@@ -475,7 +477,8 @@ def cpu_baseline(F, I):
         best = None
         forced = os.environ.get("DYF_CPU_THREADS")
         # (all 256 hardware threads of the 2-socket host: 17 s for the forward that takes 0.13 s on 32 -- not tried beyond 96)
-        for nt in ([int(forced)] if forced else sorted({min(32, ncpu), min(64, ncpu)} | ({ncpu} if ncpu <= 96 else set()))):
+        sweep = {}
+        for nt in ([int(forced)] if forced else sorted({min(t, ncpu) for t in (16, 32, 64, 128)} | ({ncpu} if ncpu <= 96 else set()))):
             torch.set_num_threads(nt)
             xi = torch.cat([x4[:1], x4[:1]], 1)
             i_fn(xi, torch.ones(1), c4[:1])  # warm-up (thread pool, mkldnn primitives)
@@ -483,6 +486,7 @@ def cpu_baseline(F, I):
             i_fn(xi, torch.ones(1), c4[:1])
             dt = time.perf_counter() - t0
             log(f"cpu baseline: one interpolator forward on {nt} threads {dt:.3f} s")
+            sweep[nt] = round(dt, 4)
             if best is None or dt < best[1]:
                 best = (nt, dt)
         torch.set_num_threads(best[0])
@@ -497,10 +501,10 @@ def cpu_baseline(F, I):
             log(f"cpu baseline NB={nb}: {reps} rollout(s) in {dt:.1f} s = {res[nb][2]:.3f} fields/s")
     top = max(res, key=lambda k: res[k][2])
     return {"value": round(res[top][2], 4), "unit": "fields/s", "cores": best[0], "kind": "port",
-            "host_cores": ncpu, "cpu_model": cpu_model(),
+            "host_cores": ncpu, "cpu_model": cpu_model(), "thread_sweep_s": {str(k): v for k, v in sweep.items()},
             "fields_per_s_nb1": round(res[1][2], 4), "fields_per_s_nb4": round(res[4][2], 4),
             "sample": f"full h={HORIZON} rollouts (60 network forwards each), fp32, MC dropout on: NB=1 x{res[1][0]} in {res[1][1]:.1f} s, "
-                      f"NB=4 x{res[4][0]} in {res[4][1]:.1f} s; {best[0]} of {ncpu} host threads (fastest of 32/64 on one forward)"}
+                      f"NB=4 x{res[4][0]} in {res[4][1]:.1f} s; {best[0]} of {ncpu} host threads (fastest of {'/'.join(str(k) for k in sweep)} on one forward)"}
 
 
 def main():
@@ -648,9 +652,12 @@ def main():
         eng.close()
         del model
         torch.cuda.empty_cache()
+        # (DYF_BENCH_OISST_ROWS / DYF_BENCH_SYNTH_ROWS shrink the two ensembles for the 2-ranks-on-one-GPU rehearsal of this branch,
+        # tests/test_gpu_bench_multirank.py; the driver's SCALE runs use the defaults)
+        oisst_rows, synth_rows = int(os.environ.get("DYF_BENCH_OISST_ROWS", "300")), int(os.environ.get("DYF_BENCH_SYNTH_ROWS", "8"))
         for key, make, shape, rows, horizon, wl in (
-                ("config2_oisst", lambda r: oisst_model(r)[0], (1, 60, 60), 300, 7, OISST_WORKLOAD),
-                ("config4_synth512", synth512_model, (4, 512, 512), 8, 32, SYNTH512_WORKLOAD)):
+                ("config2_oisst", lambda r: oisst_model(r)[0], (1, 60, 60), oisst_rows, 7, OISST_WORKLOAD),
+                ("config4_synth512", synth512_model, (4, 512, 512), synth_rows, 32, SYNTH512_WORKLOAD)):
             try:
                 rpr = rows_per_rank(rows, world)
                 mdl = make(rpr)

@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("DYF_LIB") or os.path.join(_HERE, "lib", "libdyffusion
 LIB_PATH_F16 = os.environ.get("DYF_LIB_F16") or os.path.join(_HERE, "lib", "libdyffusion_hip_f16.so")
 DTYPES = {"bf16": 0, "bfloat16": 0, "fp16": 1, "float16": 1, "half": 1}
 
-DYF_ABI_VERSION = 6
+DYF_ABI_VERSION = 7
 DYF_OK, DYF_ERR_INVALID_ARGUMENT, DYF_ERR_UNSUPPORTED, DYF_ERR_HIP, DYF_ERR_STATE = range(5)
 NET_FORECASTER, NET_INTERPOLATOR = 0, 1
 ARCH_UNET_SIMPLE, ARCH_UNET_RESNET = 0, 1
@@ -113,6 +113,9 @@ SYMBOLS = [
     ("dyf_train_conv_check", C.c_int, [_P] + [C.c_int32] * 9 + [C.c_uint32, C.POINTER(C.c_float)]),
     ("dyf_apply_boundary_conditions", C.c_int, [_P, C.POINTER(BcArgs), _P, _P]),
     ("dyf_debug_read_block_output", C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, _P, _P]),
+    ("dyf_poll_errors", C.c_int, [_P, C.c_int32]),
+    ("dyf_gn_fuse_state", C.c_int, [_P, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    ("dyf_debug_gn_fuse", C.c_int, [_P, C.c_uint32, C.c_int32]),
     ("dyf_debug_form_log", None, [C.c_int32]),
     ("dyf_debug_form_log_read", C.c_int32, [C.c_char_p, C.c_int32]),
 ]

@@ -13,6 +13,18 @@
 #endif
 typedef uint16_t el16_t;
 
+// Timing-experiment switches that produce WRONG RESULTS (one part of a kernel's work removed to see what it costs; their findings
+// are recorded in DESIGN.md) exist only in experiment builds: tools/build_variant.sh compiles ONE translation unit with
+// -DDYF_EXPERIMENT_BUILD plus the switch into tools/variants/libvar_<name>.so.  A product build (__graft_entry__.build) that sees
+// any of them stops here, and the run-time ones (DYF_GN_FUSE_NOWAIT, DYF_EXP_DEC5_1316) are not compiled in.
+#if !defined(DYF_EXPERIMENT_BUILD) &&                                                                                               \
+    (defined(HALO_EXP_NO_DMA_WAIT) || defined(HALO_EXP_NO_STORE) || defined(HALO_EXP_W_ALIAS) || defined(HALO_EXP_W_SHARE) ||        \
+     defined(HALO_EXP_NO_HALO) || defined(HALO_EXP_NO_EPI) || defined(HALO_EXP_LDS_SKIP) || defined(FA_EXP_NO_EXP) ||                \
+     defined(FA_EXP_NOSYNC) || defined(FA_EXP_NO_VT) || defined(FA4_X_NOEXP) || defined(FA4_X_MFMAONLY) || defined(FA4_X_NOQK) ||    \
+     defined(FA4_X_NOPV) || defined(FA4_X_NOSTAGE))
+#error "a wrong-results timing switch (HALO_EXP_* / FA_EXP_* / FA4_X_*) is defined in a product build: use tools/build_variant.sh"
+#endif
+
 // Kernel-form log (test seam, include/dyffusion_hip_testing.h dyf_debug_form_log*): every launcher that chooses between kernel
 // forms notes the form it took and the batch rows of the launch; off unless a test enables it (one predictable branch).
 extern bool g_dyf_form_log_on;

@@ -89,6 +89,7 @@ hipError_t launch_conv_stats(const ConvArgs& a, int path, hipStream_t stream, in
 // not served by a fused form: the caller runs the conv and the GroupNorm kernels)
 hipError_t launch_conv_gn_fused(const ConvArgs& a, int path, hipStream_t stream, bool* fused);
 int conv_gn_fused_max_slots(int h, int w);
+bool conv_igemm2_tile2d(int ho, int wo);  // conv_igemm2_kernel tiles this output plane 2-D (TH x 16 pixel tiles inside one sample)
 int conv_igemm2_gn_slots(int ho, int wo);  // slots per sample of the fused conv_igemm2_kernel<2> on an ho x wo output plane (0: not served)  // upper bound of GnFuse::slots on an h x w plane (sizing of GnFuse::gran), 0 = never fused
 int conv_halo5_gn_slots(int h, int w);  // slots per sample of conv_up_halo_kernel<5> on an h x w plane (sizing of gn_part)
 void pack_up2x_weights(const float* w, int cout, int cin, el16_t* out);
@@ -110,6 +111,9 @@ bool plan_up_sparse_columns_mixed(const std::vector<uint8_t>& needed, int w, int
 bool conv_halo_rows_up_supported(const ConvArgs& a);   // in addition to conv_up_halo_supported
 bool conv_halo_rows3_supported(const ConvArgs& a);     // in addition to conv_halo3_supported (h % 8 / w % 16 not needed)
 hipError_t conv_halo_rows_init();
+// sum of ConvArgs::splitk raw fp32 partials [split][m][cout] (in split order) + the conv epilogue, 4 channels per thread (conv.hip);
+// needs cout % 4 == 0
+hipError_t launch_conv_splitk_finish4(const ConvArgs& a, long long M, hipStream_t stream);
 hipError_t launch_conv_halo_rows_up(const ConvArgs& a, hipStream_t stream);  // main kernel only (after up_border_kernel)
 hipError_t launch_conv_halo_rows3(const ConvArgs& a, hipStream_t stream);
 hipError_t conv_up_halo_init();

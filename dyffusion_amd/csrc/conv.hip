@@ -578,6 +578,41 @@ __global__ void conv_splitk_finish_kernel(ConvArgs a, long long M) {
     if (a.out_f32) a.out_f32[i] = v;
 }
 
+// The same finish with 4 consecutive channels per thread (cout % 4 == 0): 16-byte loads of the partials, one keep word per pair,
+// 8-byte stores -- the finish of the rows kernels' split-K launches (conv_halo_rows.hip), whose outputs are whole decoder planes.
+__global__ __launch_bounds__(256) void conv_splitk_finish4_kernel(ConvArgs a, long long M) {
+    const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = M * a.cout;
+    const long long i = q * 4;
+    if (i >= total) return;
+    const int co = (int)(i % a.cout);
+    const long long m = i / a.cout;
+    const int plane = a.ho * a.wo;
+    const int n = (int)(m / plane);
+    float4 s4 = *(const float4*)(a.splitk_ws + (size_t)i);
+    for (int s = 1; s < a.splitk; ++s) {
+        const float4 t4 = *(const float4*)(a.splitk_ws + (size_t)s * (size_t)total + (size_t)i);
+        s4.x += t4.x; s4.y += t4.y; s4.z += t4.z; s4.w += t4.w;
+    }
+    const size_t ci = (size_t)(a.coef_div > 1 ? n / a.coef_div : n) * a.coef_stride + co;
+    const float4 ca = *(const float4*)(a.coef_a + ci), cc = *(const float4*)(a.coef_c + ci);
+    float v[4] = {fmaf(s4.x, ca.x, cc.x), fmaf(s4.y, ca.y, cc.y), fmaf(s4.z, ca.z, cc.z), fmaf(s4.w, ca.w, cc.w)};
+    act_drop<4>(v, (uint32_t)i, (uint32_t)n * (uint32_t)(plane * a.cout), a.act, a.drop, drop_row_key(a.drop, n));
+    if (a.residual) {
+        const uint2 rr = *(const uint2*)(a.residual + (size_t)i);
+        v[0] += el16_lo(rr.x); v[1] += el16_hi(rr.x); v[2] += el16_lo(rr.y); v[3] += el16_hi(rr.y);
+    }
+    if (a.out_f32) *(float4*)(a.out_f32 + (size_t)i) = make_float4(v[0], v[1], v[2], v[3]);
+    if (a.out_el16) *(uint2*)(a.out_el16 + (size_t)i) = make_uint2(pack_el16x2(v[0], v[1]), pack_el16x2(v[2], v[3]));
+}
+
+hipError_t launch_conv_splitk_finish4(const ConvArgs& a, long long M, hipStream_t stream) {
+    if ((a.cout & 3) != 0 || a.splitk_ws == nullptr || a.splitk < 1) return hipErrorInvalidValue;
+    const long long quads = M * a.cout / 4;
+    hipLaunchKernelGGL(conv_splitk_finish4_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, stream, a, M);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------------ launchers
 bool conv_mfma_supported(const ConvArgs& a) {
     if (a.act == ACT_GELU) return false;  // the MFMA epilogues are instantiated for none / ReLU / LeakyReLU / SiLU
@@ -725,7 +760,8 @@ hipError_t launch_conv_stats(const ConvArgs& a_in, int path, hipStream_t stream,
             if (!(h3 && atoi(h3) == 0)) {
                 ConvArgs b = a;
                 b.wpk_up_frag = conv_lookup_halo3_frag(b.wpk);
-                const char* mt3 = getenv("DYF_HALO3_MIN_TILES");
+                const char* mt3 = getenv("DYF_HALO_S2_MIN_TILES");  // (its own switch since round 5; DYF_HALO3_MIN_TILES still applies when unset)
+                if (!mt3) mt3 = getenv("DYF_HALO3_MIN_TILES");
                 // cout % 256 == 0: 8 x 16 tiles x 256 channels; else 16 x 16 tiles x 128 channels
                 const long long tiles3 = a.cout % 256 == 0 ? (nsel * a.ho * a.wo / 128) * (a.cout / 256)
                                                            : (nsel * a.ho * a.wo / 256) * (a.cout / 128);
@@ -822,6 +858,11 @@ hipError_t launch_conv_gn_fused(const ConvArgs& a_in, int path, hipStream_t stre
         const char* mf = getenv("DYF_GN_FUSE_MIN_TILES");
         const long long min_tiles = mt ? atoll(mt) : mf ? atoll(mf) : 32;
         const int slots = conv_igemm2_gn_slots(a.ho, a.wo);
+        // flattened-M tiles cut a sample into 128-row slabs at (n * plane) % 128: unless plane % 128 == 0 (or the tiles are 2-D) the
+        // fp32 partial sums of a sample are grouped by its POSITION in the launch, and (mean, 1/std) differ in the last bits between
+        // batch offsets / ranks -- not acceptable to a batch_invariant engine, which then takes the three-kernel path
+        const bool position_free = conv_igemm2_tile2d(a.ho, a.wo) || (a.ho * a.wo) % 128 == 0;
+        if (G.invariant && !position_free) return hipSuccess;
         if (tiles2 >= min_tiles && slots > 0 && slots <= GN_FUSE_MAX_SLOTS && slots <= G.max_slots && conv_igemm2_supported(b)) {
             b.gnf.slots = slots;
             *fused = true;

@@ -18,6 +18,7 @@
 #include "conv.h"
 
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 #include <type_traits>
 #include <vector>
@@ -76,8 +77,12 @@ constexpr unsigned rows_woff(int g) { return (unsigned)(((g % 3) * 3 + g / 12) *
 
 }  // namespace
 
-template <int SP, int SH>
-__device__ __forceinline__ void conv_halo_rows_body(const ConvArgs& a, int tiles_x, int tiles_per_img, int tiles_m, int tiles_n, int bid) {
+// KS: split-K instance (conv_halo_rows_splitk_kernel, dense forms): the workgroup contracts the chunks [ks_idx * cpt / ksplit,
+// (ks_idx + 1) * cpt / ksplit) only and leaves its raw fp32 accumulators in ConvArgs::splitk_ws[ks_idx][pixel][channel]; the border
+// ring goes into split 0; conv_splitk_finish4_kernel adds the splits in index order and runs the epilogue.
+template <int SP, int SH, bool KS = false>
+__device__ __forceinline__ void conv_halo_rows_body(const ConvArgs& a, int tiles_x, int tiles_per_img, int tiles_m, int tiles_n, int bid,
+                                                    int ks_idx = 0, int ksplit = 1) {
 #if defined(__HIP_DEVICE_COMPILE__)
     using H = RowsCfg<SP, SH>;
     constexpr int HALO_W = H::W, HALO_REAL = H::REAL, HALO_BYTES = H::BYTES;
@@ -115,6 +120,7 @@ __device__ __forceinline__ void conv_halo_rows_body(const ConvArgs& a, int tiles
 
     const int cin = a.c0 + a.c1;
     const int cpt = cin >> 6;
+    const int cbeg = KS ? ks_idx * cpt / ksplit : 0, cend = KS ? (ks_idx + 1) * cpt / ksplit : cpt;  // this workgroup's chunks
     const int gh = a.h, gw = a.w;
     const size_t npix = (size_t)a.n * a.h * a.w;
     const auto rsrc_a0 = __builtin_amdgcn_make_buffer_rsrc((void*)a.src0, 0, (int)(unsigned)(npix * a.c0 * 2), 0x00020000);
@@ -170,7 +176,7 @@ __device__ __forceinline__ void conv_halo_rows_body(const ConvArgs& a, int tiles
         for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[nt][t][r] = 0.0f;
-    if (!H::PLAIN) {
+    if (!H::PLAIN && (!KS || ks_idx == 0)) {
         // border pixels of the OUTPUT start from the correction sums of up_border_kernel (ring index: top row, bottom row,
         // left column, right column); lane (l31, hi) holds channels nt*32 + 8*g + 4*hi + {0..3} of its pixel
         const bool edge_col = col == 0 || col == gw - 1;
@@ -261,7 +267,7 @@ __device__ __forceinline__ void conv_halo_rows_body(const ConvArgs& a, int tiles
         MS(3 * (S) + 2, (S) & 1, ((S) + 1) & 1, 4, 5, LOAD, false)                                           \
     }
 
-    issue_halo(0);
+    issue_halo(cbeg);
     // timing experiments (wrong results): -DHALO_EXP_W_SHARE makes the four waves stream the SAME fragments (do simultaneous
     // requests meet in L1?), -DHALO_EXP_W_ALIAS serves the stream from 16 KB
 #ifdef HALO_EXP_W_SHARE
@@ -269,7 +275,7 @@ __device__ __forceinline__ void conv_halo_rows_body(const ConvArgs& a, int tiles
 #else
     const unsigned soff_w = (unsigned)(wpy * (R_STEP_BYTES / 2) + wpx * 2048);
 #endif
-    unsigned soff_c = (unsigned)((tn * cpt) * 16) * (unsigned)R_STEP_BYTES + soff_w, soff_n = soff_c;
+    unsigned soff_c = (unsigned)((tn * cpt + cbeg) * 16) * (unsigned)R_STEP_BYTES + soff_w, soff_n = soff_c;
     // (pinned in program order: the compiler's own vmcnt at the loop head is merged over the entry and the back edge)
     PIN
     ISSUE_B(0, soff_c + rows_woff(0)) PIN
@@ -277,14 +283,14 @@ __device__ __forceinline__ void conv_halo_rows_body(const ConvArgs& a, int tiles
     ISSUE_B(2, soff_c + rows_woff(2)) PIN
     ISSUE_B(3, soff_c + rows_woff(3)) PIN
     ISSUE_B(4, soff_c + rows_woff(4)) PIN
-    for (int chunk = 0; chunk < cpt; ++chunk) {
+    for (int chunk = cbeg; chunk < cend; ++chunk) {
         if (H::NBUF == 2) {
             // halo of this chunk landed (everything older than the 10 weight loads in flight), every wave is done with the
             // other buffer -> prefetch the next chunk's halo into it
             asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
-            if (chunk + 1 < cpt) issue_halo(chunk + 1);
+            if (chunk + 1 < cend) issue_halo(chunk + 1);
         } else {
 #ifdef HALO_EXP_NO_DMA_WAIT  // timing experiment (wrong results): the single-buffered halo is not waited for
             asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
@@ -296,14 +302,14 @@ __device__ __forceinline__ void conv_halo_rows_body(const ConvArgs& a, int tiles
         }
         const unsigned Hs = lds_base + (H::NBUF == 2 ? (chunk & 1) * HALO_BYTES : 0);
         asm volatile("" : "+v"(cl));  // keep the LDS addresses from being hoisted out of the chunk loop
-        soff_n = chunk + 1 < cpt ? soff_c + 16u * (unsigned)R_STEP_BYTES : soff_c;  // tail: harmless re-fetch
+        soff_n = chunk + 1 < cend ? soff_c + 16u * (unsigned)R_STEP_BYTES : soff_c;  // tail: harmless re-fetch
         PADDR(0)
         RD(0, 0) RD(0, 1) RD(0, 2) RD(0, 3) RD(0, 4) RD(0, 5)
         SS(0, true) SS(1, true) SS(2, true) SS(3, true)
         SS(4, true) SS(5, true) SS(6, true) SS(7, true)
         SS(8, true) SS(9, true) SS(10, true) SS(11, false)
         soff_c = soff_n;
-        if (H::NBUF == 1 && chunk + 1 < cpt) {  // single buffer: every wave is done reading -> request the next chunk's halo
+        if (H::NBUF == 1 && chunk + 1 < cend) {  // single buffer: every wave is done reading -> request the next chunk's halo
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
             issue_halo(chunk + 1);
@@ -335,6 +341,20 @@ __device__ __forceinline__ void conv_halo_rows_body(const ConvArgs& a, int tiles
                                           (uint32_t)(tn * 64)
                                     : o0;
     const uint32_t st_stride = SP == 1 ? (uint32_t)(2 * a.up_wo_store * a.cout) : t_stride;
+    if constexpr (KS) {
+        static_assert(SP != 1, "split-K serves the dense forms");
+        // raw fp32 partial sums, [split][output element] in the layout of the (dense NHWC) output tensor
+        float* ws = a.splitk_ws + (size_t)ks_idx * ((size_t)a.n * a.ho * a.wo * a.cout);
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *(float4*)(ws + (size_t)(o0 + t * t_stride + nt * 32 + 8 * g + 4 * hi)) =
+                        make_float4(acc[nt][t][4 * g], acc[nt][t][4 * g + 1], acc[nt][t][4 * g + 2], acc[nt][t][4 * g + 3]);
+        return;
+    }
     auto epilogue = [&](auto act_c, auto mode_c) {
         constexpr int ACT = decltype(act_c)::value, MODE = decltype(mode_c)::value;
         const float ps = drop_prescale<ACT, MODE>(a.drop);  // dropout scale folded into the affine
@@ -586,6 +606,50 @@ __global__ __launch_bounds__(256, 2) void conv_halo_rows_kernel(ConvArgs a, int 
     conv_halo_rows_body<SP, SH>(a, tiles_x, tiles_per_img, tiles_m, tiles_n, (int)blockIdx.x);
 }
 
+// Split-K instance for FEW ROWS (round 5).  A tile of these kernels is 24 us (dec4, 4 chunks) to 85 us (dec2, 16 chunks) of one
+// workgroup's serial instruction stream, whatever the batch: at one or two rows a launch is 16 - 128 workgroups on 256 CUs and takes
+// exactly that long (profiles/r04i_bench_nb1: dec3 + dec4 21 % of the rollout), at 10 - 20 rows dec2 / dec3 are 80 - 320 workgroups
+// -- one tile time for a quarter of the chip, or two for a chip and a quarter.  Here blockIdx.y deals a tile's 64-channel chunks to
+// `splitk` workgroups (raw fp32 partials in ConvArgs::splitk_ws, the split-K scratch conv_igemm_kernel uses) and
+// conv_splitk_finish4_kernel adds them in split order and runs the epilogue: the K chain of a workgroup and the idle part of the
+// chip shrink by the factor.  The summation order of an output element depends on the factor only, which the launcher derives from
+// the tile count of ConvArgs::n_sel rows when the engine pins the forms.
+template <int SP>
+__global__ __launch_bounds__(256, 2) void conv_halo_rows_splitk_kernel(ConvArgs a, int tiles_x, int tiles_per_img, int tiles_m, int tiles_n) {
+    conv_halo_rows_body<SP, 0, true>(a, tiles_x, tiles_per_img, tiles_m, tiles_n, (int)blockIdx.x, (int)blockIdx.y, a.splitk);
+}
+
+// Split factor of a dense rows launch, 1 = no split.  What the split buys is the K chain of a tile (one workgroup keeps one CU's matrix
+// pipe busy for ~5.3 us per 64-channel chunk: dec2 85 us, dec3 42 us, dec4 / dec5 21 us per tile) divided by the factor -- as long as
+// the workgroups still fit the chip side by side; what it costs is writing the fp32 partials and reading them back (2 s + 1 passes
+// over the output at ~4 TB/s, the partial stores are 16-byte pieces) and one more launch.  Measured on the NS decoder (round 5,
+// tools/bench_small_rows.py): dec3 at one row 42 -> 21 us with 8 splits, dec4 at two rows 22 -> 42 us with 4 (its 128 x 128 output is
+// 17 MB per partial set) -- so the factor comes from this cost model, not from a fill target: a power of two that divides the chunk
+// count, at most 8, that minimises the modelled time.  m_cout = output elements of the launch.  DYF_HALO_SPLITK=0 disables,
+// DYF_HALO_SPLITK_FORCE=s forces a factor (tests); both read per launch.
+static int rows_splitk_factor(const ConvArgs& a, long long tiles_sel, long long tiles, int cpt, long long m_cout) {
+    if (a.splitk_ws == nullptr || a.out_f32 != nullptr || a.out_el16 == nullptr || (a.cout & 3) != 0) return 1;
+    const char* on = getenv("DYF_HALO_SPLITK");
+    if (on && atoi(on) == 0) return 1;
+    int best = 1;
+    if (const char* f = getenv("DYF_HALO_SPLITK_FORCE")) {
+        best = atoi(f);
+        if (best < 1 || best > 8 || (best & (best - 1)) != 0 || cpt % best != 0) best = 1;
+    } else {
+        // the model is evaluated for the rows the form is pinned to (n_sel) so that a batch_invariant engine keeps one factor
+        const double bytes = (double)m_cout * ((double)tiles_sel / (double)std::max<long long>(tiles, 1)) * 4.0;
+        double best_us = 1e30;
+        for (int s = 1; s <= 8 && cpt % s == 0; s *= 2) {
+            const double rounds = std::ceil((double)tiles_sel * s / 256.0);
+            double us = rounds * (5.3 * cpt / s + 4.0);
+            if (s > 1) us += 3.0 + (2.0 * s + 1.0) * bytes / 4.0e6;
+            if (us < best_us * (s > 1 ? 0.9 : 1.0)) { best_us = us; best = s; }  // a split must win by 10 %
+        }
+    }
+    while (best > 1 && (long long)best * m_cout > a.splitk_cap) best >>= 1;
+    return best;
+}
+
 // EXPERIMENT (DYF_ROWS_PERSISTENT=512; off by default: measured SLOWER, dec4 541 -> 555 us, dec3 283 -> 287 us -- the hardware already
 // starts a new one-tile workgroup the moment one retires, so nothing is gained, and the tile boundary adds a barrier).
 // Persistent form: 512 resident workgroups walk the tiles (stride = grid, a multiple of 8: a workgroup stays on its XCD).  A wave
@@ -665,6 +729,12 @@ hipError_t conv_halo_rows_init() {
         e = hipFuncSetAttribute((const void*)conv_halo_rows_persistent_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 RowsCfg<0>::LDS_TOTAL);
     if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)conv_halo_rows_splitk_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                RowsCfg<0>::LDS_TOTAL);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)conv_halo_rows_splitk_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                RowsCfg<2>::LDS_TOTAL);
+    if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)conv_halo_rows_mixed_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 std::max((int)RowsCfg<1, 1>::LDS_TOTAL, (int)RowsCfg<1, 2>::LDS_TOTAL));
     return e;
@@ -708,9 +778,24 @@ hipError_t launch_conv_halo_rows_up(const ConvArgs& a, hipStream_t stream) {
     }
     const int tiles_x = sparse ? a.up_ntiles : a.w / R_TW, tiles_per_img = tiles_x * (a.h / R_TH);
     int tiles_m = a.n * tiles_per_img;
+#ifdef DYF_EXPERIMENT_BUILD
     // timing experiment (WRONG results): 13 of 16 sparse tiles -- what packing the 52-column lists without padded slots would save
     static const bool exp1316 = getenv("DYF_EXP_DEC5_1316") && atoi(getenv("DYF_EXP_DEC5_1316")) != 0;
     if (sparse && exp1316) tiles_m = tiles_m * 13 / 16;
+#endif
+    if (!sparse) {
+        const long long sel = (long long)(a.n_sel > 0 ? a.n_sel : a.n) * tiles_per_img * tiles_n;
+        const long long m_cout = (long long)a.n * a.ho * a.wo * a.cout;
+        const int sk = rows_splitk_factor(a, sel, (long long)tiles_m * tiles_n, (a.c0 + a.c1) >> 6, m_cout);
+        if (sk > 1) {
+            ConvArgs b = a;
+            b.splitk = sk;
+            dyf_form_note("conv_halo_rows_kernel<0>+splitk", a.n);
+            hipLaunchKernelGGL(conv_halo_rows_splitk_kernel<0>, dim3(tiles_m * tiles_n, sk), dim3(256), RowsCfg<0>::LDS_TOTAL, stream, b, tiles_x,
+                               tiles_per_img, tiles_m, tiles_n);
+            return launch_conv_splitk_finish4(b, (long long)a.n * a.ho * a.wo, stream);
+        }
+    }
     dyf_form_note(sparse ? "conv_halo_rows_kernel<1>" : "conv_halo_rows_kernel<0>", a.n);
     static const int persist = getenv("DYF_ROWS_PERSISTENT") ? atoi(getenv("DYF_ROWS_PERSISTENT")) : 0;
     if (sparse)
@@ -728,6 +813,18 @@ hipError_t launch_conv_halo_rows_up(const ConvArgs& a, hipStream_t stream) {
 hipError_t launch_conv_halo_rows3(const ConvArgs& a, hipStream_t stream) {
     const int tiles_x = a.w / R_TW, tiles_per_img = tiles_x * (a.h / R_TH);
     const int tiles_m = a.n * tiles_per_img, tiles_n = a.cout / 256;
+    {
+        const long long sel = (long long)(a.n_sel > 0 ? a.n_sel : a.n) * tiles_per_img * tiles_n;
+        const int sk = rows_splitk_factor(a, sel, (long long)tiles_m * tiles_n, (a.c0 + a.c1) >> 6, (long long)a.n * a.ho * a.wo * a.cout);
+        if (sk > 1) {
+            ConvArgs b = a;
+            b.splitk = sk;
+            dyf_form_note("conv_halo_rows_kernel<2>+splitk", a.n);
+            hipLaunchKernelGGL(conv_halo_rows_splitk_kernel<2>, dim3(tiles_m * tiles_n, sk), dim3(256), RowsCfg<2>::LDS_TOTAL, stream, b, tiles_x,
+                               tiles_per_img, tiles_m, tiles_n);
+            return launch_conv_splitk_finish4(b, (long long)a.n * a.ho * a.wo, stream);
+        }
+    }
     dyf_form_note("conv_halo_rows_kernel<2>", a.n);
     hipLaunchKernelGGL(conv_halo_rows_kernel<2>, dim3(tiles_m * tiles_n), dim3(256), RowsCfg<2>::LDS_TOTAL, stream, a, tiles_x,
                        tiles_per_img, tiles_m, tiles_n);

@@ -429,8 +429,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(ConvArgs a, int M, 
         if (cross) publish(nA + 1, slotB, true);
         const double inv_count = 1.0 / ((double)plane * cpg);
         auto coefs = [&](int n_img, int nslots, float* dst) {
-            const float2 mr = gn_fuse_sweep<16>(G.gran + ((size_t)n_img * G.max_slots * oct + (ch0 >> 3)) * 2, oct * 2, nslots, tag, cpg,
-                                                inv_count, G.err, lane);
+            const float2 mr = gn_fuse_sweep<16>(G.gran + ((size_t)n_img * G.max_slots * oct + (ch0 >> 3)) * 2, oct * 2, nslots, tag ^ G.test_tag_xor, cpg,
+                                                inv_count, G.err, lane, G.timeout_ticks);
             const float2 ac = gn_fuse_coef(G, ch0 + lane, a.coef_div > 1 ? n_img / a.coef_div : n_img, mr);
             dst[lane] = ac.x;
             dst[64 + lane] = ac.y;
@@ -591,9 +591,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(ConvArgs a, int M, 
 #endif
 }
 
+bool conv_igemm2_tile2d(int ho, int wo) { return wo % 16 == 0 && ho % TH == 0; }
+
 int conv_igemm2_gn_slots(int ho, int wo) {
     const int plane = ho * wo;
-    if (wo % 16 == 0 && ho % TH == 0) return (wo / 16) * (ho / TH) * 2;  // 2-D tiles: two 128-row slabs per tile, all inside the sample
+    if (conv_igemm2_tile2d(ho, wo)) return (wo / 16) * (ho / TH) * 2;  // 2-D tiles: two 128-row slabs per tile, all inside the sample
     if (plane < 128) return 0;  // a slab would touch more than two samples
     return (plane + 127) / 128 + 1;
 }
@@ -662,7 +664,9 @@ hipError_t launch_conv_igemm2(const ConvArgs& a, hipStream_t stream) {
         if (sh3) dyf_form_note("conv_igemm2_kernel+sh3", a.n);  // (a note of its own: the form log's kernel names stay those of the tile shape)
         const int tiles_n = a.cout / 128;
         ConvArgs b = a;
+#ifdef DYF_EXPERIMENT_BUILD
         if (getenv("DYF_GN_FUSE_NOWAIT")) b.gnf.slots = -1;  // timing experiment (WRONG results): no granule sweep
+#endif
         if (sh3)
             hipLaunchKernelGGL((conv_igemm2_kernel<2, true, true>), dim3(tiles_m * tiles_n), dim3(256), LDS_TOTAL_SH3 + 4096, stream, b, (int)M, tiles_m, tiles_n);
         else

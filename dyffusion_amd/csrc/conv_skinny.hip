@@ -22,7 +22,6 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
 namespace {
-constexpr int SK_WAVES = 16;  // waves per workgroup = K split factor
 constexpr int SK_DEPTH = 8;   // k16 sub-steps of operand loads in flight per wave (K <= 2048: a wave's whole share)
 }
 
@@ -30,13 +29,19 @@ constexpr int SK_DEPTH = 8;   // k16 sub-steps of operand loads in flight per wa
 // every forward (~2 us per dependent round trip) and the first form of this kernel -- four waves per tile walking K / 4 each with
 // 8 loads in flight -- needed four round trips (10-18 us per launch, no better than split-K + finish).  Sixteen waves per tile
 // each own K / 16 = at most 8 sub-steps at K = 2048 and issue ALL their loads at once: one round trip.
-__global__ __launch_bounds__(1024) void conv_skinny_kernel(ConvArgs a, int M, int tiles_m) {
+// NW = 16 waves per tile (above), or 8 once the sixteen-wave workgroups would not fit the chip side by side (two per CU by wave slots:
+// 512): enc4 / the low-res dec1 conv at 20 rows are 640 tiles -- 1.25 rounds of 7-8 us each, 23 us per launch in
+// profiles/r05c_bench_nb10 -- while eight-wave workgroups (32 KB of LDS, four per CU) all run at once, each wave with twice the
+// sub-steps (two batches of loads at K = 2048).
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void conv_skinny_kernel_t(ConvArgs a, int M, int tiles_m) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    __shared__ __attribute__((aligned(16))) float red[SK_WAVES][4][64][4];  // [wave][register group][lane][4 registers]: 64 KB
+    constexpr int SK_WAVES = NW;
+    __shared__ __attribute__((aligned(16))) float red[SK_WAVES][4][64][4];  // [wave][register group][lane][4 registers]: 64 KB at 16 waves
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
     const int tm = blockIdx.x % tiles_m, cb32 = blockIdx.x / tiles_m;  // pixel tile, 32-channel block
-    const int taps = a.kh * a.kw, cpt = a.c0 >> 6, nk = taps * cpt;
+    const int taps = a.kh * a.kw, cpt0 = a.c0 >> 6, cpt = (a.c0 + a.c1) >> 6, nk = taps * cpt;  // chunks of src0, then of src1 (channel concat)
     const int plane = a.ho * a.wo;
     // this lane's output pixel (its operand row) and input window origin
     const int p = tm * 32 + l31;
@@ -46,6 +51,7 @@ __global__ __launch_bounds__(1024) void conv_skinny_kernel(ConvArgs a, int M, in
     const int iy0 = oy * a.stride - a.pad, ix0 = ox * a.stride - a.pad;  // input pixel of tap (0, 0): may lie in the zero padding
     const size_t npix = (size_t)a.n * a.h * a.w;
     const auto rsrc_x = __builtin_amdgcn_make_buffer_rsrc((void*)a.src0, 0, (int)(unsigned)(npix * a.c0 * 2), 0x00020000);
+    const auto rsrc_x1 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.c1 ? a.src1 : a.src0), 0, (int)(unsigned)(npix * (a.c1 ? a.c1 : a.c0) * 2), 0x00020000);
     const auto rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.wpk_frag, 0, (int)(unsigned)((size_t)a.cout * nk * 128), 0x00020000);
     // weight fragments (pack_conv_frag, 128-channel column blocks): [tn][K step = chunk * taps + tap][wn][ks][half][lane] x 16 B
     const int tn = cb32 >> 2, wn = (cb32 >> 1) & 1, half = cb32 & 1;
@@ -65,9 +71,11 @@ __global__ __launch_bounds__(1024) void conv_skinny_kernel(ConvArgs a, int M, in
         // a tap in the zero padding: an out-of-range offset, which the buffer bounds check answers with zeros
         const int iy = iy0 + dy, ix = ix0 + dx;
         const bool in = (unsigned)iy < (unsigned)a.h && (unsigned)ix < (unsigned)a.w;
-        const unsigned xo = in ? (unsigned)((n_img * a.h + iy) * a.w + ix) * (unsigned)(a.c0 * 2) + x_lane + (unsigned)(chunk * 128 + ks * 32)
+        const bool first = chunk < cpt0;  // wave-uniform (a wave's sub-steps are contiguous, but may straddle the two sources)
+        const int cs = first ? a.c0 : a.c1, cl = first ? chunk : chunk - cpt0;
+        const unsigned xo = in ? (unsigned)((n_img * a.h + iy) * a.w + ix) * (unsigned)(cs * 2) + x_lane + (unsigned)(cl * 128 + ks * 32)
                                : 0xFFFFFFFFu;
-        xf = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, xo, 0, 0);
+        xf = first ? __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, xo, 0, 0) : __builtin_amdgcn_raw_buffer_load_b128(rsrc_x1, xo, 0, 0);
     };
     f32x16 acc;
 #pragma unroll
@@ -120,22 +128,30 @@ __global__ __launch_bounds__(1024) void conv_skinny_kernel(ConvArgs a, int M, in
 // shapes the kernel takes: stride == kernel (1 or 2), pad 0, one source, 128-channel column blocks (the fragment layout of
 // pack_conv_frag), fragment copy registered
 bool conv_skinny_supported(const ConvArgs& a) {
-    if (a.up2x || a.wpk_frag == nullptr || a.c1 != 0 || a.pix_pitch0 != 0) return false;
+    if (a.up2x || a.wpk_frag == nullptr || a.pix_pitch0 != 0 || (a.c1 != 0 && a.src1 == nullptr)) return false;
     if (a.kh < 1 || a.kw < 1 || a.kh * a.kw > 16 || a.stride < 1 || a.pad < 0) return false;
     // 16 .. 128 k16 sub-steps: at least one per wave, at most SK_DEPTH (one memory round trip).  Deeper K (enc3: 256, dec2: 576
     // sub-steps) was measured SLOWER here than split-K over workgroups (NS at 4 / 7 rows: 3 250 / 4 560 against 3 910 / 5 130 fields/s)
     static const int max_steps = getenv("DYF_SKINNY_MAX_KSTEPS") ? atoi(getenv("DYF_SKINNY_MAX_KSTEPS")) : 32;
-    const int nk = a.kh * a.kw * (a.c0 >> 6);
-    if (a.c0 % 64 != 0 || a.cout % 128 != 0 || nk < 4 || nk > max_steps) return false;
+    const int nk = a.kh * a.kw * ((a.c0 + a.c1) >> 6);
+    if (a.c0 % 64 != 0 || a.c1 % 64 != 0 || a.cout % 128 != 0 || nk < 4 || nk > max_steps) return false;
     if (a.ho != (a.h + 2 * a.pad - a.kh) / a.stride + 1 || a.wo != (a.w + 2 * a.pad - a.kw) / a.stride + 1) return false;
     const size_t npix = (size_t)a.n * a.h * a.w;
-    return npix * a.c0 * 2 < 0x7F000000ull && (size_t)a.cout * a.kh * a.kw * a.c0 * 2 < 0x7F000000ull &&
+    return npix * a.c0 * 2 < 0x7F000000ull && npix * (size_t)a.c1 * 2 < 0x7F000000ull && (size_t)a.cout * a.kh * a.kw * (a.c0 + a.c1) * 2 < 0x7F000000ull &&
            (size_t)a.n * a.ho * a.wo * a.cout < 0xFFFFFFF0ull;
 }
 
 hipError_t launch_conv_skinny(const ConvArgs& a, hipStream_t stream) {
     const int M = a.n * a.ho * a.wo, tiles_m = (M + 31) / 32;
     dyf_form_note("conv_skinny_kernel", a.n);
-    hipLaunchKernelGGL(conv_skinny_kernel, dim3(tiles_m * (a.cout / 32)), dim3(1024), 0, stream, a, M, tiles_m);
+    const long long wgs = (long long)tiles_m * (a.cout / 32);
+    // the form follows the tile count of ConvArgs::n_sel rows when the engine pins the forms (the K order of an output differs)
+    const long long sel = a.n_sel > 0 ? ((long long)a.n_sel * a.ho * a.wo + 31) / 32 * (a.cout / 32) : wgs;
+    static const long long w8_from = getenv("DYF_SKINNY_W8_FROM") ? atoll(getenv("DYF_SKINNY_W8_FROM")) : 513;
+    if (sel >= w8_from) {
+        dyf_form_note("conv_skinny_kernel<8>", a.n);
+        hipLaunchKernelGGL(conv_skinny_kernel_t<8>, dim3((unsigned)wgs), dim3(512), 0, stream, a, M, tiles_m);
+    } else
+        hipLaunchKernelGGL(conv_skinny_kernel_t<16>, dim3((unsigned)wgs), dim3(1024), 0, stream, a, M, tiles_m);
     return hipGetLastError();
 }

@@ -580,7 +580,8 @@ __global__ __launch_bounds__(256, 2) void conv_up_halo_kernel(ConvArgs a, int ti
         if (wave == 0) {
             const int cpg = a.cout / G.groups;
             const float2 mr = gn_fuse_sweep<16>(G.gran + ((size_t)n_img * G.max_slots * (a.cout >> 3) + tn * 8) * 2, (a.cout >> 3) * 2,
-                                                G.slots, tag, cpg, 1.0 / ((double)a.ho * a.wo * cpg), G.err, lane);
+                                                G.slots, tag ^ G.test_tag_xor, cpg, 1.0 / ((double)a.ho * a.wo * cpg), G.err, lane,
+                                                G.timeout_ticks);
             const float2 ac = gn_fuse_coef(G, ch_blk + lane, a.coef_div > 1 ? n_img / a.coef_div : n_img, mr);
             cfA[lane] = ac.x;
             cfC[lane] = ac.y;
@@ -1057,7 +1058,9 @@ hipError_t launch_conv_halo5(const ConvArgs& a, hipStream_t stream) {
     static const bool plain_epi = !(getenv("DYF_HALO5_PLAIN_EPI") && atoi(getenv("DYF_HALO5_PLAIN_EPI")) == 0);
     if (a.gnf.gran != nullptr) {  // GroupNorm fused: + 1 KB of LDS for the per-channel (A, C) table
         ConvArgs b = a;
+#ifdef DYF_EXPERIMENT_BUILD
         if (getenv("DYF_GN_FUSE_NOWAIT")) b.gnf.slots = 0;  // timing experiment (WRONG results): no granule sweep
+#endif
         hipLaunchKernelGGL((conv_up_halo_kernel<5, 2>), dim3(tiles_m * tiles_n), dim3(256), H5::LDS_TOTAL + 1024, stream, b, tiles_x,
                            tiles_per_img, tiles_m, tiles_n, 0);
     }
@@ -1119,6 +1122,8 @@ hipError_t launch_conv_halo3(const ConvArgs& a, hipStream_t stream) {
 
 constexpr int UB_LDS = 4 * 2 * 8192;  // up_border_kernel: per wave two stages of [2 samples][32 pixels][64 channels] bf16
 __global__ void up_border_kernel(ConvArgs a, int tr, int tc);
+template <int NW>
+__global__ __launch_bounds__(NW * 64, NW / 4) void up_border_split_kernel(ConvArgs a, int tr, int tc);  // (the bounds must sit on the FIRST declaration: the template is instantiated from here)
 
 hipError_t conv_up_halo_init() {
     hipError_t e = hipFuncSetAttribute((const void*)conv_up_halo_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1145,6 +1150,8 @@ hipError_t conv_up_halo_init() {
         e = hipFuncSetAttribute((const void*)(conv_up_halo_kernel<5, 2>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 HaloCfg<5>::LDS_TOTAL + 1024);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)up_border_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, UB_LDS);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)up_border_split_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 16384);
     return e;
 }
 
@@ -1324,11 +1331,193 @@ __global__ __launch_bounds__(256) void up_border_kernel(ConvArgs a, int tr, int 
 #endif
 }
 
+
+// Few-rows form of up_border_kernel (round 5).  The kernel above gives a wave its whole K chain -- 3 taps x cin / 64 iterations of
+// one memory round trip each (12 at dec4 / dec5, 24 at dec3; the corner workgroups 8 / 16), whatever the batch: 16 - 27 us per launch,
+// three launches per forward, 15.9 % of a 1-row rollout and still 7.9 % at 10 rows (profiles/r04h/i_bench_nb*), all of it in front of
+// the main kernel, which starts its border accumulators from these sums.  At a few rows the chip is empty, so here
+//   * a segment workgroup owns a (32-pixel tile, ONE sample, 64 channels) unit, a corner workgroup 32 samples of one corner, and
+//     deals the unit's (tap, chunk) iterations -- taps innermost -- to its NW = 8 waves: iteration it = wave, wave + NW, ...;
+//   * a wave stages an iteration's 32 x 128-byte pixel rows in a 4 KB slot of its own 16 KB of LDS: a ring of FOUR slots, so the
+//     operands of up to four iterations (every iteration of a segment wave: ceil(24 / 8) = 3 at dec3, 2 at dec4 / dec5) are in
+//     flight together -- one memory round trip instead of one per iteration; the corner workgroups (7 taps: 4 - 7 iterations per
+//     wave) take two;
+//   * the partial accumulators are parked in the same LDS and added in WAVE ORDER (waves 0 / 1 finish one 32-channel half each): a
+//     sum does not depend on timing.
+// First version of this kernel (two samples per workgroup, two-slot pipeline): 12 us per launch against 16 - 27; the __launch_bounds__
+// must sit on the first declaration (the template is instantiated from conv_up_halo_init, above the definition) -- without them the
+// compiler assumed 1 024 threads, capped the kernel at 128 VGPRs and spilled 46 of them: slower than the kernel it replaces.
+struct UbSlot {
+    uint4 wa[4], wb[4];
+};
+template <int NW>
+__global__ __launch_bounds__(NW * 64, NW / 4) void up_border_split_kernel(ConvArgs a, int tr, int tc) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    extern __shared__ __attribute__((aligned(16))) char ub_smem[];
+    const int lane = threadIdx.x & 63, l31 = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int cb_blk = blockIdx.z;
+    const int nseg = 4 * tr + 4 * tc;
+    const bool cornerwg = (int)blockIdx.x >= nseg;
+    if (cornerwg && (blockIdx.y & 31) != 0) return;  // a corner workgroup covers 32 samples
+    const int nbase = blockIdx.y;
+    int py, px, i0 = 0, j0 = 0, tt = 0;
+    bool rowseg = true;
+    if (cornerwg) {
+        const int c = blockIdx.x - nseg;
+        py = c >> 1; px = c & 1;
+        i0 = py ? a.h - 1 : 0;
+        j0 = px ? a.w - 1 : 0;
+    } else {
+        int t = blockIdx.x, seg;
+        if (t < 4 * tr) { seg = t / tr; tt = t - seg * tr; }
+        else { t -= 4 * tr; seg = 4 + t / tc; tt = t - (seg - 4) * tc; }
+        rowseg = seg < 4;
+        if (rowseg) { py = seg >> 1; px = seg & 1; i0 = py ? a.h - 1 : 0; }
+        else { px = (seg - 4) >> 1; py = seg & 1; j0 = px ? a.w - 1 : 0; }
+    }
+    auto tile_pixel = [&](int p, int& ii, int& jj) -> bool {  // as in up_border_kernel
+        if (cornerwg) { ii = i0; jj = j0; return true; }
+        if (rowseg) {
+            ii = i0; jj = tt * 32 + p;
+            const bool ok = jj < a.w;
+            jj = min(jj, a.w - 1);
+            return ok && !(px ? jj == a.w - 1 : jj == 0);
+        }
+        const int idx = tt * 32 + p;
+        jj = j0; ii = min(py ? idx : idx + 1, a.h - 1);
+        return idx < a.h - 1;
+    };
+    const int cin = a.c0 + a.c1, kchunks = cin >> 6;
+    auto sample_of = [&](int p) { return min(cornerwg ? nbase + p : nbase, a.n - 1); };
+    const int ntaps = cornerwg ? 7 : 3;
+    const int niter = ntaps * kchunks;
+    f32x16 acc[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[nt][q] = 0.0f;
+    const size_t npix = (size_t)a.n * a.h * a.w;
+    const auto rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)a.src0, 0, (int)(unsigned)(npix * a.c0 * 2), 0x00020000);
+    const auto rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.c1 ? a.src1 : a.src0), 0,
+                                                       (int)(unsigned)(npix * (a.c1 ? a.c1 : a.c0) * 2), 0x00020000);
+    char* xs = ub_smem + wave * 16384;
+    const int dsub = lane >> 3, dslot = lane & 7;
+    // per-lane source pixel of the four DMA instructions of an iteration at (dy, dx) = (0, 0): they only shift with the tap
+    int sii[4], sjj[4], ssm[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        const int p = d * 8 + dsub;
+        (void)tile_pixel(p, sii[d], sjj[d]);
+        ssm[d] = sample_of(p);
+    }
+    auto load = [&](UbSlot& st, int slot, int it) {
+        const int kc = it / ntaps, u = it - kc * ntaps;  // taps innermost (their pixel rows overlap: L1 / L2 reuse)
+        int tap, dy = 0, dx = 0;
+        if ((cornerwg || rowseg) && u < 3) { tap = 9 + u; dx = u - 1; }
+        else if (cornerwg && u < 6) { tap = 12 + (u - 3); dy = u - 4; }
+        else if (cornerwg) { tap = 15; }
+        else { tap = 12 + u; dy = u - 1; }
+        const bool first = kc * 64 < a.c0;
+        const int cs = first ? a.c0 : a.c1;
+        const unsigned coff = (unsigned)((first ? kc * 64 : kc * 64 - a.c0) * 2);
+        char* dst = xs + slot * 4096;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const int p = d * 8 + dsub;
+            const int sy = min(max(sii[d] + dy, 0), a.h - 1), sx = min(max(sjj[d] + dx, 0), a.w - 1);
+            const unsigned off = (unsigned)(((ssm[d] * a.h + sy) * a.w + sx) * cs * 2) + coff + (unsigned)((dslot ^ ((p >> 1) & 7)) << 4);
+            if (first) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, LDS_PTR(dst + d * 1024), 16, off, 0, 0, 0);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, LDS_PTR(dst + d * 1024), 16, off, 0, 0, 0);
+        }
+        const char* wf = (const char*)a.wpk_up_frag + ((size_t)(cb_blk * kchunks + kc) * 16 + tap) * STEP_BYTES + py * (STEP_BYTES / 2) +
+                         px * 2048 + lane * 16;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            st.wa[q] = *(const uint4*)(wf + q * 4096);
+            st.wb[q] = *(const uint4*)(wf + q * 4096 + 1024);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // `behind` = iterations requested AFTER this one (12 vector-memory operations each) that may still be in flight
+    auto compute = [&](const UbSlot& st, int slot, int behind) {
+        if (behind >= 3) asm volatile("s_waitcnt vmcnt(36)" ::: "memory");
+        else if (behind == 2) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+        else if (behind == 1) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        const char* src = xs + slot * 4096 + l31 * 128;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int piece = ((q * 2 + hi) ^ ((l31 >> 1) & 7)) << 4;
+            const uint4 xv = *(const uint4*)(src + piece);
+            acc[0] = DYF_MFMA_32x32x16(__builtin_bit_cast(el16x8_t, st.wa[q]), __builtin_bit_cast(el16x8_t, xv), acc[0], 0, 0, 0);
+            acc[1] = DYF_MFMA_32x32x16(__builtin_bit_cast(el16x8_t, st.wb[q]), __builtin_bit_cast(el16x8_t, xv), acc[1], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // this wave's iterations: wave, wave + NW, ... (wave-uniform count), in batches of up to four requests
+    const int mine = wave < niter ? (niter - wave + NW - 1) / NW : 0;
+    for (int j0b = 0; j0b < mine; j0b += 4) {
+        const int nb4 = min(4, mine - j0b);  // wave-uniform
+        UbSlot s0, s1, s2, s3;
+        load(s0, 0, wave + (j0b + 0) * NW);
+        if (nb4 > 1) load(s1, 1, wave + (j0b + 1) * NW);
+        if (nb4 > 2) load(s2, 2, wave + (j0b + 2) * NW);
+        if (nb4 > 3) load(s3, 3, wave + (j0b + 3) * NW);
+        compute(s0, 0, nb4 - 1);
+        if (nb4 > 1) compute(s1, 1, nb4 - 2);
+        if (nb4 > 2) compute(s2, 2, nb4 - 3);
+        if (nb4 > 3) compute(s3, 3, 0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the slots are re-filled by the next batch
+    }
+    // ---- sum over the waves in wave order: every wave parks its 32 accumulator registers in its OWN 16 KB (8 KB used)
+    float* red = (float*)(ub_smem + wave * 16384);  // [nt * 16 + q][64 lanes]
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) red[(nt * 16 + q) * 64 + lane] = acc[nt][q];
+    __syncthreads();
+    if (wave >= 2) return;
+    const int nt = wave;
+    float sum[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) sum[q] = ((const float*)ub_smem)[(nt * 16 + q) * 64 + lane];
+    for (int w = 1; w < NW; ++w) {
+        const float* rw = (const float*)(ub_smem + w * 16384);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) sum[q] += rw[(nt * 16 + q) * 64 + lane];
+    }
+    int ii, jj;
+    const bool valid = tile_pixel(l31, ii, jj);
+    const int Y = 2 * ii + py, X = 2 * jj + px;
+    const int ring = Y == 0 ? X : Y == a.ho - 1 ? a.wo + X : X == 0 ? 2 * a.wo + Y - 1 : 2 * a.wo + (a.ho - 2) + Y - 1;
+    const int ring_len = 2 * a.wo + 2 * (a.ho - 2);
+    const int smp = cornerwg ? nbase + l31 : nbase;
+    if (smp >= a.n || !valid) return;
+    float* op = a.up_border + ((size_t)smp * ring_len + ring) * a.cout + cb_blk * 64 + 4 * hi + nt * 32;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) *(float4*)(op + 8 * g) = make_float4(sum[4 * g], sum[4 * g + 1], sum[4 * g + 2], sum[4 * g + 3]);
+#endif
+}
+constexpr int UB_SPLIT_NW = 8;
+
 hipError_t launch_conv_up_halo(const ConvArgs& a, hipStream_t stream) {
     if (a.up_border == nullptr || a.wpk_up_frag == nullptr) return hipErrorInvalidValue;
     {
         const int tr = (a.w + 31) / 32, tc = (a.h - 1 + 31) / 32;
-        hipLaunchKernelGGL(up_border_kernel, dim3(4 * tr + 4 * tc + 4, (a.n + 7) / 8, a.cout / 64), dim3(256), UB_LDS, stream, a, tr, tc);
+        // few rows: the K-split form (one sample per workgroup instead of eight: 8 x as many, 8 waves each -- past ~40 rows the form
+        // above, whose workgroups already fill the chip, does the same sums with less LDS traffic).  DYF_UP_BORDER_SPLIT_ROWS
+        // moves the switch (0 = never); the form is chosen for ConvArgs::n_sel rows when the engine pins the forms (batch_invariant)
+        const char* sre = getenv("DYF_UP_BORDER_SPLIT_ROWS");  // read per launch (parity tests)
+        const int split_rows = sre ? atoi(sre) : 40;
+        if ((a.n_sel > 0 ? a.n_sel : a.n) <= split_rows) {
+            dyf_form_note("up_border_split_kernel", a.n);
+            hipLaunchKernelGGL(up_border_split_kernel<UB_SPLIT_NW>, dim3(4 * tr + 4 * tc + 4, a.n, a.cout / 64), dim3(UB_SPLIT_NW * 64),
+                               UB_SPLIT_NW * 16384, stream, a, tr, tc);
+        } else
+            hipLaunchKernelGGL(up_border_kernel, dim3(4 * tr + 4 * tc + 4, (a.n + 7) / 8, a.cout / 64), dim3(256), UB_LDS, stream, a, tr, tc);
     }
     const bool sparse = a.up_cols != nullptr;
     // rows form (conv_halo_rows.hip: one-row pixel tiles, half the LDS fragment reads) where the plane tiles by 4 x 32;

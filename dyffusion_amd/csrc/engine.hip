@@ -169,7 +169,12 @@ dyf_status net_forward(dyf_engine* e, int which, const Source* srcs, int nsrc, i
     if (n.sc) return sc_forward(e, which, srcs, nsrc, nb, o, out_dev, st);
     Workspace& ws = e->ws;
     const int H = e->cfg.height, W = e->cfg.width;
-    if (o.dropout_mode == 1 && (n.cfg.dropout > 0.0f || n.cfg.input_dropout > 0.0f))
+    // a forward that draws masks starts by filling the row-key table and advancing the forward counter: a one-block kernel of its
+    // own, or -- fused stem, no dropout inside the stem -- block 0 of the stem launch (kernels.hip stem_rng_begin)
+    const bool draws = o.dropout_mode == 1 && (n.cfg.dropout > 0.0f || n.cfg.input_dropout > 0.0f);
+    static const bool fold_rng = !(getenv("DYF_FOLD_RNG_BEGIN") && atoi(getenv("DYF_FOLD_RNG_BEGIN")) == 0);
+    const bool rng_in_stem = draws && fold_rng && n.stem_fused && e->cfg.enable_mfma && e->fuse_stem && n.cfg.input_dropout == 0.0f;
+    if (draws && !rng_in_stem)
         HIP_TRY(e, launch_rng_begin_forward(e->rng_state, e->row_keys, nb, o.src_rows > 0 ? o.src_rows : nb, st));
     // ---- stem: outer resample + 1x1 conv
     StemArgs sa{};
@@ -188,6 +193,9 @@ dyf_status net_forward(dyf_engine* e, int which, const Source* srcs, int nsrc, i
     // a Dropout between init_conv and the first encoder conv (input_dropout > 0) breaks their composition: separate stem kernel
     const bool fused_stem = n.stem_fused && e->cfg.enable_mfma && e->fuse_stem && n.cfg.input_dropout == 0.0f;
     sa.drop = make_input_drop(e, n, o);
+    if (rng_in_stem) {
+        sa.rng_state = e->rng_state; sa.rng_row_keys = e->row_keys; sa.rng_rows = nb; sa.rng_rows_per_fwd = o.src_rows > 0 ? o.src_rows : nb;
+    }
     if (fused_stem) {
         sa.out = ws.stem16;
         HIP_TRY(e, launch_stem16(sa, st));
@@ -256,9 +264,31 @@ dyf_status net_forward(dyf_engine* e, int which, const Source* srcs, int nsrc, i
             HIP_TRY(e, hipEventCreate(&pe0));
             HIP_TRY(e, hipEventCreate(&pe1));
         }
+        // 1 x 1 decoder blocks (dec0, dec1): the pointwise conv commutes with the per-channel bilinear upsample, so it runs on the
+        // LOW-res cat[x, skip] (a quarter of the pixels, nothing materialised) into fp32 and one pass upsamples + applies the block's
+        // epilogue (kernels.h Up2xEpiArgs); DYF_DEC_COMMUTE=0 keeps upsample -> conv
+        static const bool commute = !(getenv("DYF_DEC_COMMUTE") && atoi(getenv("DYF_DEC_COMMUTE")) == 0);
+        const bool commuted = commute && b.k == 1 && b.stride == 1 && b.pad == 0 && e->cfg.enable_mfma && (b.cout & 3) == 0 &&
+                              (size_t)nb * lh * lw * b.cout * sizeof(float) <= (size_t)nb * b.in_h * b.in_w * b.cin * sizeof(el16_t);
         if (use_fused_up(e, b, f)) {
             if (prof) HIP_TRY(e, hipEventRecord(pe0, st));
             HIP_TRY(e, launch_conv(f, 1, st));
+            if (prof) HIP_TRY(e, hipEventRecord(pe1, st));
+        } else if (commuted) {
+            ConvArgs lo = a;
+            lo.src0 = x; lo.c0 = b.cin - skip_c; lo.src1 = skip; lo.c1 = skip_c;
+            lo.h = lh; lo.w = lw; lo.ho = lh; lo.wo = lw;
+            lo.coef_a = ws.ones_f; lo.coef_c = ws.zeros_f; lo.coef_stride = 0; lo.coef_div = 0;
+            lo.act = ACT_NONE; lo.drop = DropSpec{};
+            lo.out_el16 = nullptr; lo.out_f32 = (float*)ws.up;  // (the materialised-upsample scratch is free in this form)
+            if (prof) HIP_TRY(e, hipEventRecord(pe0, st));
+            dyf_status s = run_conv(e, lo, st);
+            if (s != DYF_OK) return s;
+            Up2xEpiArgs u{};
+            u.lo = (const float*)ws.up; u.n = nb; u.h = lh; u.w = lw; u.c = b.cout;
+            u.coef_a = a.coef_a; u.coef_c = a.coef_c; u.coef_stride = a.coef_stride; u.coef_div = a.coef_div;
+            u.act = a.act; u.drop = a.drop; u.out = a.out_el16;
+            HIP_TRY(e, launch_up2x_epilogue(u, st));
             if (prof) HIP_TRY(e, hipEventRecord(pe1, st));
         } else {  // materialise the upsampled tensor, then a plain conv
             Up2xArgs u{};
@@ -467,6 +497,16 @@ dyf_status dyf_engine_create(const dyf_engine_config* cfg, dyf_engine** out_engi
     ALLOC(ws.up_border, ub_el);
     ALLOC(ws.coef_pair, 4 * tc);
     ALLOC(ws.splitk, DYF_SPLITK_FLOATS);
+    {
+        size_t cmax = 64;
+        for (int w = 0; w < 2; ++w)
+            for (int i = 0; i < 12; ++i) cmax = std::max<size_t>(cmax, (size_t)e->net[w].blk[i].cout);
+        ALLOC(ws.zeros_f, cmax);
+        ALLOC(ws.ones_f, cmax);
+        std::vector<float> ones(cmax, 1.0f);
+        if (hipMemcpy(ws.ones_f, ones.data(), cmax * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
+            return bail(DYF_ERR_HIP, "hipMemcpy(ones)");
+    }
     ALLOC(e->s_pair, 2 * (size_t)cfg->max_batch * DYF_MAX_OUT_CH * cfg->height * cfg->width);
     ALLOC(e->s_time, 64);
     ALLOC(e->rng_state, DYF_RNG_STATE_WORDS);
@@ -866,9 +906,21 @@ dyf_status dyf_net_flops_executed(const dyf_engine* e, int32_t which, double* fl
 }
 
 // A fused GroupNorm conv (gn_fused.h) whose granule sweep timed out raised the engine's host-visible error word and NaN-poisoned
-// its output.  Checked at the head of every forward / sampling entry point (a plain host read, no synchronisation): the engine
-// then drops its captured graphs, keeps to the three-kernel GroupNorm path from now on and fails THIS call, naming the earlier one.
-static dyf_status gn_fuse_check(dyf_engine* e) {
+// its output.  The word is looked at (a plain host read, no synchronisation) at the head of every forward / sampling entry point
+// and by dyf_poll_errors, which the caller runs once the call's work has completed: the engine then drops its captured graphs and
+// keeps to the three-kernel GroupNorm path from now on, and the call that looks fails, naming what happened.
+static bool gn_fuse_live(const dyf_engine* e) {
+    auto live = [](const dyf_engine* x) {
+        if (x->gn_err_host == nullptr || x->gn_fuse_disabled) return false;
+        return (x->net[0].rn != nullptr) || (x->net[1].rn != nullptr);
+    };
+    if (live(e)) return true;
+    for (const dyf_engine* c : e->groups)
+        if (live(c)) return true;
+    return false;
+}
+
+static dyf_status gn_fuse_check(dyf_engine* e, bool earlier_call = true) {
     bool hit = false, slow = false;
     auto one = [&](dyf_engine* x) {
         if (x->gn_err_host && ((volatile uint32_t*)x->gn_err_host)[0] != 0u) hit = true;
@@ -884,6 +936,7 @@ static dyf_status gn_fuse_check(dyf_engine* e) {
     auto disable = [](dyf_engine* x) {
         if (x->gn_err_host) ((volatile uint32_t*)x->gn_err_host)[0] = ((volatile uint32_t*)x->gn_err_host)[1] = 0u;
         x->gn_fuse_disabled = true;
+        ++x->gn_fuse_downgrades;
         for (auto& kv : x->graphs) {
             if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
             if (kv.second.graph) (void)hipGraphDestroy(kv.second.graph);
@@ -892,12 +945,61 @@ static dyf_status gn_fuse_check(dyf_engine* e) {
     };
     disable(e);
     for (dyf_engine* c : e->groups) disable(c);
+    if (getenv("DYF_VERBOSE") && atoi(getenv("DYF_VERBOSE")) != 0)
+        fprintf(stderr, "[dyffusion_hip] engine %p leaves the fused GroupNorm path (%s): captured graphs dropped, three-kernel GroupNorm from now on\n",
+                (void*)e, hit ? "a granule sweep timed out" : "a granule sweep needed > 1 ms: the GPU is shared");
     // slow only: every sweep did match (results are correct) but took > 1 ms -- the sample's workgroups were not co-scheduled (a
     // GPU shared with another process): later calls take the three-kernel path, nothing to report
     if (!hit) return DYF_OK;
     return fail(e, DYF_ERR_STATE,
-                "a fused GroupNorm convolution of an EARLIER call timed out waiting for its sample's statistics (that call's output was "
-                "NaN-poisoned); the engine now runs the un-fused GroupNorm kernels -- repeat the call");
+                earlier_call
+                    ? "a fused GroupNorm convolution of an EARLIER call timed out waiting for its sample's statistics (that call's output was "
+                      "NaN-poisoned); the engine now runs the un-fused GroupNorm kernels -- repeat the call"
+                    : "a fused GroupNorm convolution timed out waiting for its sample's statistics: the output of the call(s) submitted since "
+                      "the last successful dyf_poll_errors is NaN-poisoned; the engine now runs the un-fused GroupNorm kernels -- repeat the call");
+}
+
+// Asynchronous failures of work ALREADY SUBMITTED (every entry point here only enqueues): a caller that wants the failing call
+// itself to fail -- the Python wrappers do -- polls after it.  synchronize != 0 waits for the device first; an engine that has no
+// live fused-GroupNorm form returns at once without waiting (nothing here can fail asynchronously).
+dyf_status dyf_poll_errors(dyf_engine* e, int32_t synchronize) {
+    if (!e) return DYF_ERR_INVALID_ARGUMENT;
+    if (!gn_fuse_live(e)) return DYF_OK;
+    if (synchronize) {
+        HIP_TRY(e, hipSetDevice(e->cfg.device));
+        HIP_TRY(e, hipDeviceSynchronize());
+    }
+    return gn_fuse_check(e, false);
+}
+
+// state of the fused GroupNorm path: bit 0 = live (a ResNet-UNet engine that still uses it), *downgrades = times it was left
+dyf_status dyf_gn_fuse_state(const dyf_engine* e, int32_t* live, int32_t* downgrades) {
+    if (!e) return DYF_ERR_INVALID_ARGUMENT;
+    if (live) *live = gn_fuse_live(e) ? 1 : 0;
+    int d = e->gn_fuse_downgrades;
+    for (const dyf_engine* c : e->groups) d = std::max(d, c->gn_fuse_downgrades);
+    if (downgrades) *downgrades = d;
+    return DYF_OK;
+}
+
+// test hook (include/dyffusion_hip_testing.h): bound of the granule sweeps in 100 MHz ticks (0 = default 2 s) and, force_timeout != 0,
+// make every sweep wait for a tag nobody publishes.  Both travel as kernel arguments: captured graphs are dropped.
+dyf_status dyf_debug_gn_fuse(dyf_engine* e, uint32_t timeout_ticks, int32_t force_timeout) {
+    if (!e) return DYF_ERR_INVALID_ARGUMENT;
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    HIP_TRY(e, hipDeviceSynchronize());
+    auto set = [&](dyf_engine* x) {
+        x->gn_timeout_ticks = timeout_ticks;
+        x->gn_test_tag_xor = force_timeout ? 0x5A000000u : 0u;
+        for (auto& kv : x->graphs) {
+            if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
+            if (kv.second.graph) (void)hipGraphDestroy(kv.second.graph);
+        }
+        x->graphs.clear();
+    };
+    set(e);
+    for (dyf_engine* c : e->groups) set(c);
+    return DYF_OK;
 }
 
 dyf_status dyf_net_forward(dyf_engine* e, int32_t which, const float* inputs_dev, const float* time_dev,
@@ -1040,6 +1142,24 @@ dyf_status dyf_set_plan(dyf_engine* e, const dyf_plan* p) {
                                      row * sizeof(float), hipMemcpyDeviceToDevice));
         }
     }
+    {   // ... and the row pairs (i_next, i_cur) of every cold-sampling step's paired interpolator call, staged ONCE here: run_plan used
+        // to copy the two rows next to each other with two memcpy nodes per step (~12 us of a 250 us one-row step)
+        Net& I = e->net[DYF_NET_INTERPOLATOR];
+        const size_t row = (size_t)2 * I.total_c;
+        e->pair_coef = nullptr;
+        if (!ph.steps.empty() && I.tables && !I.rn && !I.sc) {
+            dyf_status s = dev_alloc(e, &e->pair_coef, ph.steps.size() * 2 * row);
+            if (s != DYF_OK) return s;
+            for (size_t k = 0; k < ph.steps.size(); ++k) {
+                const dyf_plan_step& stp = ph.steps[k];
+                if (!(stp.i_next >= 0.0f && stp.i_cur >= 0.0f)) continue;
+                HIP_TRY(e, hipMemcpy(e->pair_coef + (2 * k) * row, I.tables + (size_t)I.table_of_time.at(stp.i_next) * row, row * sizeof(float),
+                                     hipMemcpyDeviceToDevice));
+                HIP_TRY(e, hipMemcpy(e->pair_coef + (2 * k + 1) * row, I.tables + (size_t)I.table_of_time.at(stp.i_cur) * row, row * sizeof(float),
+                                     hipMemcpyDeviceToDevice));
+            }
+        }
+    }
     HIP_TRY(e, hipDeviceSynchronize());
     ph.set = true;
     e->last_groups = 0;
@@ -1113,15 +1233,20 @@ dyf_status run_plan(dyf_engine* e, int nb, const uint8_t* const* masks, const fl
     // the batch.  The FiLM coefficient rows of the two times are staged next to each other; out: [2][nb][C][H][W].
     // Not with injected masks (their layout is one tensor per forward and site) and only for arch unet_simple.
     const bool can_pair = !inject && !I.rn && !I.sc && e->pair_interp;
-    auto interp2 = [&](float ta, float tb, const float* x_last, float* out2) -> dyf_status {
+    auto interp2 = [&](int step, float ta, float tb, const float* x_last, float* out2) -> dyf_status {
         const size_t row = (size_t)2 * I.total_c;
-        HIP_TRY(e, hipMemcpyAsync(e->ws.coef_pair, I.tables + (size_t)I.table_of_time.at(ta) * row, row * sizeof(float),
-                                  hipMemcpyDeviceToDevice, st));
-        HIP_TRY(e, hipMemcpyAsync(e->ws.coef_pair + row, I.tables + (size_t)I.table_of_time.at(tb) * row, row * sizeof(float),
-                                  hipMemcpyDeviceToDevice, st));
+        const float* pair = e->ws.coef_pair;
+        if (e->pair_coef) {  // staged at dyf_set_plan
+            pair = e->pair_coef + (size_t)(2 * step) * row;
+        } else {
+            HIP_TRY(e, hipMemcpyAsync(e->ws.coef_pair, I.tables + (size_t)I.table_of_time.at(ta) * row, row * sizeof(float),
+                                      hipMemcpyDeviceToDevice, st));
+            HIP_TRY(e, hipMemcpyAsync(e->ws.coef_pair + row, I.tables + (size_t)I.table_of_time.at(tb) * row, row * sizeof(float),
+                                      hipMemcpyDeviceToDevice, st));
+        }
         Source srcs[3] = {{e->s_init, e->wC}, {x_last, e->C}, {e->s_static, e->Cs}};
         const int ns = e->Cs > 0 ? 3 : 2;
-        FwdOpts o{e->ws.coef_pair, e->ws.coef_pair + I.total_c, (int)row, i_mode, nullptr};
+        FwdOpts o{pair, pair + I.total_c, (int)row, i_mode, nullptr};
         o.src_rows = nb;
         o.coef_div = nb;
         return net_forward(e, DYF_NET_INTERPOLATOR, srcs, ns, 2 * nb, o, out2, st);
@@ -1169,16 +1294,16 @@ dyf_status run_plan(dyf_engine* e, int nb, const uint8_t* const* masks, const fl
         const bool cold_pair = can_pair && ph.hdr.sampling_cold && !(s.is_last && !ph.hdr.cold_for_last_step) &&
                                s.i_next >= 0.0f && s.i_cur >= 0.0f;
         if (cold_pair) {  // both interpolations of this step in one forward: s_pair = [I(.., s_next) ; I(.., s)]
-            dyf_status r = interp2(s.i_next, s.i_cur, e->s_x0hat, e->s_pair);
+            dyf_status r = interp2(step_idx, s.i_next, s.i_cur, e->s_x0hat, e->s_pair);
             if (r != DYF_OK) return r;
             LOG_COPY(1, e->s_pair);
             LOG_COPY(2, e->s_pair + field);
             if (logging) e->log_has_cur[step_idx] = 1;
-            HIP_TRY(e, launch_cold_update(e->s_xs, e->s_pair + field, e->s_pair, (long long)field, st));
+            // (the new x_s goes to its forecast-stack slot in the same pass when the step emits a prediction)
+            HIP_TRY(e, launch_cold_update(e->s_xs, e->s_pair + field, e->s_pair, (long long)field, st,
+                                          s.out_slot >= 0 ? e->s_stack + (size_t)s.out_slot * field : nullptr));
             if (&s == &ph.steps.back())  // sample_loop's third return value for a truncated schedule (dyffusion.py:424-425)
                 HIP_TRY(e, hipMemcpyAsync(e->s_next, e->s_pair, fbytes, hipMemcpyDeviceToDevice, st));
-            if (s.out_slot >= 0)
-                HIP_TRY(e, hipMemcpyAsync(e->s_stack + (size_t)s.out_slot * field, e->s_xs, fbytes, hipMemcpyDeviceToDevice, st));
             ++step_idx;
             continue;
         }
@@ -1770,6 +1895,7 @@ dyf_status dyf_op_conv2d(dyf_engine* e, const uint16_t* x_dev, const float* w_ho
         conv_register_halo3_frag(wdev, h3dev);
     }
     a.act = act; a.out_el16 = y_dev; a.zero_page = e->ws.zero_page;
+    a.splitk_ws = e->ws.splitk; a.splitk_cap = e->ws.splitk ? DYF_SPLITK_FLOATS : 0;  // the split-K forms, as in the engine's own launches
     if (scale_dev && shift_dev) {
         a.coef_a = scale_dev; a.coef_c = shift_dev; a.coef_stride = cout;
     } else {
@@ -1821,6 +1947,7 @@ dyf_status dyf_op_upconv2d(dyf_engine* e, const uint16_t* x_dev, const float* w_
     a.kh = 3; a.kw = 3; a.stride = 1; a.pad = 1; a.cout = cout; a.wpk = wdev; a.wpk_up = wdev; a.up2x = 1;
     a.wpk_up_frag = frag ? wdev + pu.size() : nullptr;
     a.act = act; a.out_el16 = y_dev;
+    a.splitk_ws = e->ws.splitk; a.splitk_cap = e->ws.splitk ? DYF_SPLITK_FLOATS : 0;
     float* border = nullptr;
     HIP_TRY(e, hipMalloc((void**)&border, conv_up_border_floats(n, h, w, cout) * sizeof(float)));
     a.up_border = border;

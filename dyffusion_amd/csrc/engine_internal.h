@@ -89,6 +89,8 @@ struct Workspace {
     float* up_border = nullptr;  // border-correction scratch of the fused-upsample halo convs (ConvArgs::up_border)
     float* coef_pair = nullptr;  // [2][2][total_c]: FiLM coefficient rows of a paired interpolator call
     float* splitk = nullptr;     // split-K partials of the small-batch convs (ConvArgs::splitk_ws), DYF_SPLITK_FLOATS floats
+    float* ones_f = nullptr;     // [max cout] 1.0f / 0.0f: identity epilogue of the commuted 1 x 1 decoder convs (raw fp32 output)
+    float* zeros_f = nullptr;
 };
 
 struct PlanHost {
@@ -138,6 +140,7 @@ struct dyf_engine {
     std::vector<int> prof_rows;
     float* s_pair = nullptr;        // [2][max_batch][C][H][W]: outputs of a paired interpolator call
     float* refine_coef = nullptr;   // [n_refine][2][total_c]: FiLM rows of the refinement pass in refine order (plan allocation)
+    float* pair_coef = nullptr;     // [n_steps][2 rows][2][total_c]: FiLM rows (i_next, i_cur) of every step's paired interpolator call (plan allocation)
     bool pair_interp = true;        // DYF_PAIR_INTERP=0: one forward per interpolator call (A/B testing)
     // engine-owned exchange (dyf_comm_init / dyf_sample_gather): RCCL communicator (ncclComm_t) and the all-gather receive buffer
     void* comm = nullptr;
@@ -170,6 +173,9 @@ struct dyf_engine {
     uint32_t* gn_err_host = nullptr;
     uint32_t* gn_err_dev = nullptr;
     bool gn_fuse_disabled = false;
+    uint32_t gn_timeout_ticks = 0;   // dyf_debug_gn_fuse: sweep bound in 100 MHz ticks (0 = the 2 s default)
+    uint32_t gn_test_tag_xor = 0;    // dyf_debug_gn_fuse: nonzero = every sweep waits for a tag nobody publishes (forced time-out)
+    int gn_fuse_downgrades = 0;      // times this engine left the fused path (time-out or slow sweep): dyf_gn_fuse_state
 };
 
 namespace dyf {

@@ -38,6 +38,11 @@ struct GnFuse {
     const float* film_a;       // (1 + scale) rows [row][film_stride] or null (second Block of a ResnetBlock: no FiLM)
     const float* film_c;
     int film_stride;
+    int invariant;             // batch_invariant engines: only forms whose (mean, 1/std) bits do not depend on the sample's position in
+                               // the launch (halo5, 2-D tiles, plane % 128 == 0: a sample's 128-row slabs start at its first pixel)
+    uint32_t timeout_ticks;    // bound of a granule sweep in s_memrealtime ticks (100 MHz); 0 = GN_FUSE_TIMEOUT_TICKS (2 s)
+    uint32_t test_tag_xor;     // test hook (dyf_debug_gn_fuse): the sweeps wait for tag ^ this -- a tag nobody publishes when nonzero, i.e.
+                               // every sweep of the launch runs into its time-out, as if a workgroup of the sample never arrived
     uint32_t* err;             // host-visible (pinned, mapped) words: [0] nonzero after a sweep timed out (output NaN-poisoned),
                                // [1] nonzero after a sweep took > 1 024 passes (correct, but the workgroups are not co-scheduled)
 };
@@ -69,7 +74,8 @@ __device__ __forceinline__ double gn_shfl_xor_f64(double v, int d) {
 #endif
 template <int MAXJ>
 __device__ __forceinline__ float2 gn_fuse_sweep(const unsigned long long* base, int slot_stride, int nslots, uint32_t tag, int cpg,
-                                               double inv_count, uint32_t* err, int lane) {
+                                               double inv_count, uint32_t* err, int lane, uint32_t timeout_ticks = 0) {
+    const unsigned long long limit = timeout_ticks ? (unsigned long long)timeout_ticks : GN_FUSE_TIMEOUT_TICKS;
     const int v = lane & 15, sg = lane >> 4;
     const gn_gu64* p = (const gn_gu64*)base + v;
     double part = 0.0;
@@ -98,7 +104,7 @@ __device__ __forceinline__ float2 gn_fuse_sweep(const unsigned long long* base, 
                 if (lane == 0 && err) __hip_atomic_store(err + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
             const bool gave_up = err && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u;
-            if (gave_up || now - t_start > GN_FUSE_TIMEOUT_TICKS) {
+            if (gave_up || now - t_start > limit) {
                 failed = true;
                 break;
             }

@@ -53,6 +53,11 @@ struct StemArgs {
     int dim;
     el16_t* out;            // [n][uh][uw][dim]
     DropSpec drop;          // dropout_input on the 1x1 conv's output (stem_kernel only; mode 0 = off)
+    // start of a forward that draws masks, folded into the fused-stem kernels (their block 0 does the work of
+    // rng_begin_forward_kernel: nothing in the stem reads the row keys, the first consumer is the next launch): null = not folded
+    uint32_t* rng_state;
+    uint32_t* rng_row_keys;
+    int rng_rows, rng_rows_per_fwd;
 };
 hipError_t launch_stem(const StemArgs& a, hipStream_t s);
 // Fused-stem form: only the outer resample, written as a zero-bordered [n][uh+2][uw+2][16] bf16 tensor whose channel
@@ -69,6 +74,22 @@ struct Up2xArgs {
     el16_t* out;            // [n][2h][2w][c0+c1]
 };
 hipError_t launch_up2x(const Up2xArgs& a, hipStream_t s);
+
+// Decoder blocks with a 1 x 1 conv (dec0, dec1 of unet_simple: Upsample(x2, bilinear) -> Conv2d(k = 1) -> BatchNorm -> FiLM -> ReLU ->
+// Dropout, unet_simple.py:40-52,72-80): a pointwise conv commutes with the per-channel bilinear upsample (its taps sum to 1), so the
+// conv runs on the LOW-res cat[x, skip] -- a quarter of the pixels, no materialised upsample -- into an fp32 tensor, and this pass
+// upsamples it and applies the block's epilogue: out[n][2h][2w][c] = drop(act(lerp(lo) * A + C)).
+struct Up2xEpiArgs {
+    const float* lo;        // [n][h][w][c] fp32: the conv WITHOUT bias (the bias lives in C)
+    int n, h, w, c;
+    const float* coef_a;    // as ConvArgs: row = sample / coef_div, stride coef_stride
+    const float* coef_c;
+    int coef_stride, coef_div;
+    int act;
+    DropSpec drop;
+    el16_t* out;            // [n][2h][2w][c]
+};
+hipError_t launch_up2x_epilogue(const Up2xEpiArgs& a, hipStream_t s);
 
 // K5: GroupNorm(G) + FiLM + LeakyReLU + Dropout on an fp32 NHWC tensor -> NHWC bf16 (unet_simple.py:56 + :72-80)
 struct GroupNormArgs {
@@ -111,7 +132,7 @@ hipError_t launch_readout(const ReadoutArgs& a, hipStream_t s);
 hipError_t launch_readout_tables(const ReadoutArgs& a, hipStream_t s);
 
 // K10: sampler elementwise (dyffusion.py:381-391, :219-227)
-hipError_t launch_cold_update(float* x_s, const float* x_cur, const float* x_next, long long count, hipStream_t s);
+hipError_t launch_cold_update(float* x_s, const float* x_cur, const float* x_next, long long count, hipStream_t s, float* copy = nullptr);
 // out = tau*cond + (1-tau)*noise ; noise from `noise` if non-null else Box-Muller on the counter RNG
 hipError_t launch_noisy_condition(float* out, const float* cond, const float* noise, float tau, long long count,
                                   int row_elems, uint32_t* rng_state, hipStream_t s);

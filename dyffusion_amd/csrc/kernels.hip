@@ -178,9 +178,24 @@ hipError_t launch_stem(const StemArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
+// rng_begin_forward_kernel's work done by block 0 of a stem launch (StemArgs::rng_state != null): one launch (and one kernel
+// boundary) less per forward that draws masks -- 6-7 us of a 250 us one-row forward.  Same arithmetic, same table.
+__device__ __forceinline__ void stem_rng_begin(const StemArgs& a) {
+    if (a.rng_state == nullptr || blockIdx.x != 0) return;
+    const uint32_t lo = a.rng_state[0], hi = a.rng_state[1], fwd0 = a.rng_state[2], row0 = a.rng_state[3];
+    for (int r = threadIdx.x; r < a.rng_rows; r += blockDim.x) {
+        const RngKey k = rng_row_key(lo, hi, fwd0 + (uint32_t)(r / a.rng_rows_per_fwd), row0 + (uint32_t)(r % a.rng_rows_per_fwd));
+        a.rng_row_keys[2 * r] = k.k0;
+        a.rng_row_keys[2 * r + 1] = k.k1;
+    }
+    __syncthreads();  // (every thread of block 0 has read fwd0)
+    if (threadIdx.x == 0) a.rng_state[2] = fwd0 + (uint32_t)((a.rng_rows + a.rng_rows_per_fwd - 1) / a.rng_rows_per_fwd);
+}
+
 // init_conv is linear and nothing non-linear sits between it and the first encoder conv (dropout_input has p = 0),
 // so conv4x4(init_conv(x)) is ONE 4x4 conv on the resampled raw channels.  This kernel only resamples.
 __global__ __launch_bounds__(256) void stem16_kernel(StemArgs a) {
+    stem_rng_begin(a);
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     const int ph = a.uh + 2, pw = a.uw + 2;
     const long long total = (long long)a.n * ph * pw;
@@ -237,6 +252,7 @@ constexpr int ST_ROWS = 8;
 template <int CP>  // channels padded to a multiple of 4 (LDS row of a source pixel)
 __global__ __launch_bounds__(512) void stem16_rows_kernel(StemArgs a, int nblk) {
     extern __shared__ __attribute__((aligned(16))) float st_rows[];  // [ST_ROWS + 2][w][CP]
+    stem_rng_begin(a);
     const int ph = a.uh + 2, pw = a.uw + 2;
     const int n = blockIdx.x / nblk, rb = blockIdx.x - n * nblk;
     const int py0 = rb * ST_ROWS, py1 = min(py0 + ST_ROWS, ph);           // padded rows of this block
@@ -563,6 +579,62 @@ hipError_t launch_up2x(const Up2xArgs& a, hipStream_t s) {
     return hipGetLastError();
 }
 
+// Upsample + epilogue of the commuted 1 x 1 decoder blocks (Up2xEpiArgs, kernels.h).  A thread owns one LOW-res pixel and 4 channels:
+// 9 float4 loads (its 3 x 3 neighbourhood, stencils of bilinear_coord as in up2x_quad_kernel) make the 2 x 2 outputs.
+__global__ __launch_bounds__(256) void up2x_epilogue_kernel(Up2xEpiArgs a, long long total) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int groups = a.c >> 2;
+    const int g = (int)(idx % groups);
+    const int pix = (int)(idx / groups);
+    const int plane = a.h * a.w;
+    const int n = pix / plane, rem = pix - n * plane;
+    const int i = rem / a.w, j = rem - i * a.w;
+    int ya[2], yb[2], xa[2], xb[2];
+    float ly[2], lx[2];
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+        bilinear_coord(2 * i + d, 0.5f, a.h, ya[d], yb[d], ly[d]);
+        bilinear_coord(2 * j + d, 0.5f, a.w, xa[d], xb[d], lx[d]);
+    }
+    const int ys[3] = {ya[0], i, yb[1]}, xs[3] = {xa[0], j, xb[1]};
+    float4 t[3][3];
+    const float* base = a.lo + (size_t)n * plane * a.c + g * 4;
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int q = 0; q < 3; ++q) t[r][q] = *(const float4*)(base + ((size_t)ys[r] * a.w + xs[q]) * a.c);
+    const size_t ci = (size_t)(a.coef_div > 1 ? n / a.coef_div : n) * a.coef_stride + g * 4;
+    const float4 ca = *(const float4*)(a.coef_a + ci), cc = *(const float4*)(a.coef_c + ci);
+    const RngKey key = drop_row_key(a.drop, n);
+    const int ow = 2 * a.w, oh = 2 * a.h;
+    const uint32_t row0 = (uint32_t)n * (uint32_t)(oh * ow * a.c);
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+        for (int dx = 0; dx < 2; ++dx) {
+            const float4 q00 = t[dy][dx], q01 = t[dy][dx + 1], q10 = t[dy + 1][dx], q11 = t[dy + 1][dx + 1];
+            const float fx = lx[dx], fy = ly[dy];
+            auto lerp = [&](float a00, float a01, float a10, float a11) {
+                const float top = a00 * (1.0f - fx) + a01 * fx, bot = a10 * (1.0f - fx) + a11 * fx;
+                return top * (1.0f - fy) + bot * fy;
+            };
+            float v[4] = {fmaf(lerp(q00.x, q01.x, q10.x, q11.x), ca.x, cc.x), fmaf(lerp(q00.y, q01.y, q10.y, q11.y), ca.y, cc.y),
+                          fmaf(lerp(q00.z, q01.z, q10.z, q11.z), ca.z, cc.z), fmaf(lerp(q00.w, q01.w, q10.w, q11.w), ca.w, cc.w)};
+            const uint32_t e0 = (uint32_t)(((n * oh + 2 * i + dy) * ow + 2 * j + dx)) * (uint32_t)a.c + (uint32_t)(g * 4);
+            act_drop<4>(v, e0, row0, a.act, a.drop, key);
+            *(uint2*)(a.out + (size_t)e0) = make_uint2(pack_el16x2(v[0], v[1]), pack_el16x2(v[2], v[3]));
+        }
+}
+
+hipError_t launch_up2x_epilogue(const Up2xEpiArgs& a, hipStream_t s) {
+    if ((a.c & 3) != 0 || a.h < 1 || a.w < 1 || (size_t)a.n * 4 * a.h * a.w * a.c >= 0xFFFFFFF0ull) return hipErrorInvalidValue;
+    const long long total = (long long)a.n * a.h * a.w * (a.c >> 2);
+    dyf_form_note("up2x_epilogue_kernel", a.n);
+    hipLaunchKernelGGL(up2x_epilogue_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a, total);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------------ K5 GroupNorm
 // nn.GroupNorm(8, C) of the last encoder block (unet_simple.py:56) + FiLM + LeakyReLU + Dropout (:72-80).
 __global__ __launch_bounds__(256) void groupnorm_kernel(GroupNormArgs a) {
@@ -594,7 +666,81 @@ __global__ __launch_bounds__(256) void groupnorm_kernel(GroupNormArgs a) {
     }
 }
 
+// Small planes (the GroupNorm block of unet_simple sits at the bottleneck: 4 x 4 pixels x 64 channels per group): ONE WAVE per
+// (sample, group) keeps its <= 32 elements per lane in registers -- one pass over memory instead of three, wave reductions instead of
+// two block reductions -- mean first, then the variance of the centred values (as groupnorm_kernel and ATen do).
+template <int PER>  // float4 pieces per lane
+__global__ __launch_bounds__(256) void groupnorm_wave_kernel(GroupNormArgs a) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int ng = blockIdx.x * 4 + wv;
+    if (ng >= a.n * a.groups) return;
+    const int n = ng / a.groups, g = ng - n * a.groups;
+    const int cpg = a.c / a.groups, q4 = cpg >> 2;   // float4 pieces per pixel of the group
+    const int pieces = a.hw * q4;
+    const float* x = a.x + (size_t)n * a.hw * a.c + g * cpg;
+    float4 v[PER];
+    float s = 0.0f;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int pc = lane + 64 * k;
+        v[k] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (pc < pieces) {
+            v[k] = *(const float4*)(x + (size_t)(pc / q4) * a.c + (pc % q4) * 4);
+            s += (v[k].x + v[k].y) + (v[k].z + v[k].w);
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) s += __shfl_xor(s, d, 64);
+    const float count = (float)(a.hw * cpg);
+    const float mean = s / count;
+    float var = 0.0f;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        if (lane + 64 * k < pieces) {
+            const float dx = v[k].x - mean, dy = v[k].y - mean, dz = v[k].z - mean, dw = v[k].w - mean;
+            var = fmaf(dx, dx, var); var = fmaf(dy, dy, var); var = fmaf(dz, dz, var); var = fmaf(dw, dw, var);
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) var += __shfl_xor(var, d, 64);
+    const float rstd = rsqrtf(var / count + 1e-5f);
+    const RngKey key = drop_row_key(a.drop, n);
+    const uint32_t row0 = (uint32_t)((size_t)n * a.hw * a.c);
+    const size_t frow = (size_t)(a.film_div > 1 ? n / a.film_div : n) * a.film_stride;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int pc = lane + 64 * k;
+        if (pc >= pieces) continue;
+        const int p = pc / q4, ch = g * cpg + (pc % q4) * 4;
+        const float4 ga = *(const float4*)(a.gamma + ch), be = *(const float4*)(a.beta + ch);
+        const float4 fa = *(const float4*)(a.film_a + frow + ch), fc = *(const float4*)(a.film_c + frow + ch);
+        float y[4] = {(v[k].x - mean) * rstd * ga.x + be.x, (v[k].y - mean) * rstd * ga.y + be.y, (v[k].z - mean) * rstd * ga.z + be.z,
+                      (v[k].w - mean) * rstd * ga.w + be.w};
+        y[0] = fmaf(y[0], fa.x, fc.x); y[1] = fmaf(y[1], fa.y, fc.y); y[2] = fmaf(y[2], fa.z, fc.z); y[3] = fmaf(y[3], fa.w, fc.w);
+        const uint32_t e0 = row0 + (uint32_t)(p * a.c + ch);
+        act_drop<4>(y, e0, row0, a.act, a.drop, key);
+        *(uint2*)(a.out + (size_t)e0) = make_uint2(pack_el16x2(y[0], y[1]), pack_el16x2(y[2], y[3]));
+    }
+}
+
 hipError_t launch_groupnorm(const GroupNormArgs& a, hipStream_t s) {
+    const int cpg = a.groups > 0 ? a.c / a.groups : 0;
+    const char* we = getenv("DYF_GN_WAVE");  // read per launch (parity test)
+    if (!(we && atoi(we) == 0) && cpg > 0 && cpg * a.groups == a.c && (cpg & 3) == 0 && a.act != ACT_GELU &&
+        (size_t)a.n * a.hw * a.c < 0xFFFFFFF0ull) {
+        const int pieces = a.hw * (cpg >> 2);
+        const unsigned blocks = (unsigned)((a.n * a.groups + 3) / 4);
+        if (pieces <= 256) {
+            dyf_form_note("groupnorm_wave_kernel", a.n);
+            hipLaunchKernelGGL(groupnorm_wave_kernel<4>, dim3(blocks), dim3(256), 0, s, a);
+            return hipGetLastError();
+        }
+        if (pieces <= 512) {
+            dyf_form_note("groupnorm_wave_kernel", a.n);
+            hipLaunchKernelGGL(groupnorm_wave_kernel<8>, dim3(blocks), dim3(256), 0, s, a);
+            return hipGetLastError();
+        }
+    }
     hipLaunchKernelGGL(groupnorm_kernel, dim3(a.n * a.groups), dim3(256), 0, s, a);
     return hipGetLastError();
 }
@@ -1170,14 +1316,19 @@ hipError_t launch_readout(const ReadoutArgs& a, hipStream_t s) {
 
 // ------------------------------------------------------------------------------------------------ K10 sampler
 // dyffusion.py:388  x_s = x_s - I(s) + I(s_next), kept in fp32 (SURVEY hard-part (f))
-__global__ void cold_update_kernel(float* x_s, const float* x_cur, const float* x_next, long long count) {
+// copy: second destination of the new x_s (the forecast-stack slot of a step that emits a prediction; saves the copy node), or null
+__global__ void cold_update_kernel(float* x_s, const float* x_cur, const float* x_next, long long count, float* copy) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < count) x_s[i] = x_s[i] - x_cur[i] + x_next[i];
+    if (i < count) {
+        const float v = x_s[i] - x_cur[i] + x_next[i];
+        x_s[i] = v;
+        if (copy) copy[i] = v;
+    }
 }
 
-hipError_t launch_cold_update(float* x_s, const float* x_cur, const float* x_next, long long count, hipStream_t s) {
+hipError_t launch_cold_update(float* x_s, const float* x_cur, const float* x_next, long long count, hipStream_t s, float* copy) {
     hipLaunchKernelGGL(cold_update_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s, x_s, x_cur, x_next,
-                       count);
+                       count, copy);
     return hipGetLastError();
 }
 

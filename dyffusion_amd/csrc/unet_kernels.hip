@@ -2215,7 +2215,8 @@ __global__ __launch_bounds__(256, QB == 2 ? FA2_MINW2 : FA2_MINW) void flash_att
     }
 }
 
-// ---- third form (round 4): the second form's data flow with the vector-ALU work of the common path cut to what the softmax needs
+// ---- third form (round 4; its kernel, flash_attention3_kernel, was retired in round 5 -- the arithmetic described here lives on in
+// the fourth form below, which is why the description stays): the second form's data flow with the vector-ALU work of the common path cut to what the softmax needs
 // -- 16 exponentials, 8 packs and the normaliser sums per 16 scores of a lane.  Counters and the instruction stream of the second
 // form (profiles/r03_flash_attention_pmc.txt; 95 vector instructions per 32 x 32 sub-tile at 86 % vector-issue occupancy) say
 // where the rest went:
@@ -2229,238 +2230,6 @@ __global__ __launch_bounds__(256, QB == 2 ? FA2_MINW2 : FA2_MINW) void flash_att
 //   * 32 v_mov per 64-key tile copied the O accumulators between the register assignments of the three sub-tile variants that
 //     shared one loop -> the main loop holds ONLY the whole-tile variant; a partial last tile runs after it through the general
 //     sub-tile of the second form, and launches whose dropout layout the paired keep words cannot serve stay on the second form.
-template <bool DROP, int QB>
-__device__ __forceinline__ void fa3_subtile(const AttnArgs& a, const el16_t* kf0, const el16_t* kf1, const el16_t* vf0, const el16x8_t (&qf)[QB][2],
-                                            fa_f32x16 (&o)[QB], float (&m)[QB], fa_f32x2 (&l2)[QB], el16x8_t (&bm)[QB], const el16x8_t aone,
-                                            bool& first, int jb, int st, int q0, int N, int hi, RngKey dkey) {
-    const fa_f32x16 zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-    const el16x8_t k0 = *(const el16x8_t*)(kf0 + st * 1024), k1 = *(const el16x8_t*)(kf1 + st * 1024);
-    float p[QB][16];
-    fa_f32x2 ts[QB];
-#pragma unroll
-    for (int b = 0; b < QB; ++b) {
-#if defined(FA3_EXP_NOBIAS)   // timing experiments (wrong results)
-        fa_f32x16 sc = DYF_MFMA_32x32x16(k0, qf[b][0], zero, 0, 0, 0);
-        sc = DYF_MFMA_32x32x16(k1, qf[b][1], sc, 0, 0, 0);
-#elif defined(FA3_EXP_NOQK)
-        fa_f32x16 sc = DYF_MFMA_32x32x16(aone, bm[b], zero, 0, 0, 0);
-#else
-        fa_f32x16 sc = DYF_MFMA_32x32x16(aone, bm[b], zero, 0, 0, 0);  // -m[q] in every (key, q) entry
-        sc = DYF_MFMA_32x32x16(k0, qf[b][0], sc, 0, 0, 0);
-        sc = DYF_MFMA_32x32x16(k1, qf[b][1], sc, 0, 0, 0);
-#endif
-        // lane (q, hi) holds (score - m) of keys jb + (r&3) + 8(r>>2) + 4hi of query q, in the log2 domain
-#pragma unroll
-#ifdef FA3_EXP_NOEXP
-        for (int r = 0; r < 16; ++r) p[b][r] = sc[r] + 1.0f;
-#else
-        for (int r = 0; r < 16; ++r) p[b][r] = __builtin_amdgcn_exp2f(sc[r]);
-#endif
-#if FA3_SCALAR_SUM
-        float s0 = p[b][0], s1 = p[b][1];
-#pragma unroll
-        for (int r = 2; r < 16; r += 2) {
-            s0 += p[b][r];
-            s1 += p[b][r + 1];
-        }
-        ts[b] = fa_f32x2{s0, s1};
-#else
-        ts[b] = fa_f32x2{p[b][0], p[b][1]};
-#pragma unroll
-        for (int r = 2; r < 16; r += 2) ts[b] += fa_f32x2{p[b][r], p[b][r + 1]};
-#endif
-    }
-    float tsum = ts[0].x + ts[0].y;
-    if (QB == 2) tsum = fmaxf(tsum, ts[QB - 1].x + ts[QB - 1].y);
-    if (first || __builtin_amdgcn_ballot_w64(!(tsum <= 4096.0f)) != 0ull) {  // wave-uniform; rare after the first sub-tiles
-#pragma unroll
-        for (int b = 0; b < QB; ++b) {
-            fa_f32x16 sc = DYF_MFMA_32x32x16(k0, qf[b][0], zero, 0, 0, 0);  // raw scores
-            sc = DYF_MFMA_32x32x16(k1, qf[b][1], sc, 0, 0, 0);
-            float t = fmaxf(fmaxf(sc[0], sc[1]), sc[2]);
-#pragma unroll
-            for (int r = 3; r < 15; r += 2) t = fmaxf(fmaxf(t, sc[r]), sc[r + 1]);
-            t = fmaxf(t, sc[15]);
-            t = fmaxf(t, __shfl_xor(t, 32, 64));  // both lanes of a query agree on the new maximum
-            if (!first) t = fmaxf(t, m[b]);
-            // m travels as a 16-bit matrix operand: clamp into the type's finite range, round to nearest even
-            const float mn = el16_to_f32(f32_to_el16(fminf(fmaxf(t, -60000.0f), 60000.0f)));
-            const float alpha = first ? 1.0f : __builtin_amdgcn_exp2f(m[b] - mn);  // (first: O and l are still zero)
-            m[b] = mn;
-            bm[b][0] = __builtin_bit_cast(el16_native_t, (el16_t)(hi == 0 ? f32_to_el16(-mn) : (el16_t)0));
-            l2[b] *= alpha;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                o[b][r] *= alpha;
-                p[b][r] = __builtin_amdgcn_exp2f(sc[r] - mn);
-            }
-            ts[b] = fa_f32x2{p[b][0], p[b][1]};
-#pragma unroll
-            for (int r = 2; r < 16; r += 2) ts[b] += fa_f32x2{p[b][r], p[b][r + 1]};
-        }
-        first = false;
-    }
-    uint32_t pk[QB][8];
-#pragma unroll
-    for (int b = 0; b < QB; ++b) {
-        l2[b] += ts[b];  // the normaliser is accumulated BEFORE dropout (attention.py:69-70)
-        if (DROP) {
-            const int q = q0 + 32 * b;
-            const uint32_t th = a.drop.thresh16;
-            const uint32_t e0 = (uint32_t)q * (uint32_t)N + (uint32_t)(jb + 4 * hi);  // even: N even, jb and 4*hi multiples of 4
-#pragma unroll
-            for (int pr = 0; pr < 8; ++pr) {  // registers 2*pr, 2*pr + 1: keys e0 + 8*(pr >> 1) + 2*(pr & 1) + {0, 1}
-                const uint32_t w = rng_pair_word((e0 + 8u * (uint32_t)(pr >> 1) + 2u * (uint32_t)(pr & 1)) >> 1, dkey);
-                p[b][2 * pr] = (w & 0xffffu) < th ? p[b][2 * pr] : 0.0f;
-                p[b][2 * pr + 1] = (w >> 16) < th ? p[b][2 * pr + 1] : 0.0f;
-            }
-        }
-#pragma unroll
-        for (int t = 0; t < 8; ++t) pk[b][t] = pack_el16x2(p[b][2 * t], p[b][2 * t + 1]);
-    }
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) {
-        const el16_t* vr = vf0 + st * 32 + s2 * 16;  // V^T fragment: lane (d = l31, hi): keys st*32 + 16*s2 + 4*hi + {0..3} and + 8
-        uint2 v0 = *(const uint2*)vr, v1 = *(const uint2*)(vr + 8);
-        uint32_t vw[4] = {v0.x, v0.y, v1.x, v1.y};
-        const el16x8_t vf = *(el16x8_t*)vw;
-#pragma unroll
-        for (int b = 0; b < QB; ++b) {
-            uint32_t pw[4] = {pk[b][4 * s2], pk[b][4 * s2 + 1], pk[b][4 * s2 + 2], pk[b][4 * s2 + 3]};
-#ifdef FA3_EXP_NOPV
-            o[b][s2] += __builtin_bit_cast(float, pw[0] ^ pw[1] ^ pw[2] ^ pw[3]) + (float)vf[0];
-#else
-            o[b] = DYF_MFMA_32x32x16(vf, *(el16x8_t*)pw, o[b], 0, 0, 0);
-#endif
-        }
-    }
-}
-
-#ifndef FA3_MINW
-#define FA3_MINW 4
-#endif
-#ifndef FA3_MINW2
-#define FA3_MINW2 3
-#endif
-// Launch contract: DROP kernels need a.drop.mode == 1, an even token count and whole query blocks (launch_attention checks).
-template <bool DROP, int QB>
-__global__ __launch_bounds__(256, QB == 2 ? FA3_MINW2 : FA3_MINW) void flash_attention3_kernel(AttnArgs a) {
-    __shared__ __attribute__((aligned(16))) el16_t Ks[64 * 32];   // [key][32 ch], 16-B chunk ^= (key >> 2) & 3
-    __shared__ __attribute__((aligned(16))) el16_t Vt[32 * 68];   // [ch][64 keys + 4 pad]
-    constexpr int QW = 32 * QB, QG = 4 * QW;   // queries per wave / per workgroup
-    const int qblocks = (a.hw + QG - 1) / QG;
-    // XCD-aware block map as in the second form: (sample, head) bh is pinned to XCD bh % 8 when their number divides by 8
-    int bh = blockIdx.x / qblocks, qb = blockIdx.x % qblocks;
-    if ((a.n * a.heads) % 8 == 0) {
-        const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
-        bh = (k / qblocks) * 8 + xcd;
-        qb = k % qblocks;
-    }
-    const int n = bh / a.heads, h = bh % a.heads;
-    const int C3 = 3 * a.heads * 32, hd = a.heads * 32, N = a.hw;
-    const el16_t* base = a.qkv + (size_t)n * N * C3;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, hi = lane >> 5;
-    const int q0 = qb * QG + wave * QW + l31;   // query of block 0; block b: + 32 b
-    const float c2 = 0.17677669529663687f * 1.4426950408889634f;  // 32^-1/2 * log2(e): scores live in the log2 domain
-    el16x8_t qf[QB][2];  // Q fragments (B operand of S^T), pre-multiplied by c2: lane (q, hi) holds channels ks*16 + hi*8 .. +8
-    fa_f32x16 o[QB];
-    float m[QB];
-    fa_f32x2 l2[QB];
-    el16x8_t bm[QB];     // B operand of the bias product: k-slot 0 (lanes hi == 0, element 0) = -m of the lane's query
-    el16x8_t aone;       // its A operand: k-slot 0 = 1 for every key
-    const el16_t* kf0 = Ks + l31 * 32 + (((0 + hi) ^ ((l31 >> 2) & 3)) << 3);
-    const el16_t* kf1 = Ks + l31 * 32 + (((2 + hi) ^ ((l31 >> 2) & 3)) << 3);
-    const el16_t* vf0 = Vt + l31 * 68 + 4 * hi;
-#pragma unroll
-    for (int t = 0; t < 8; ++t) aone[t] = __builtin_bit_cast(el16_native_t, (el16_t)0);
-    aone[0] = __builtin_bit_cast(el16_native_t, (el16_t)(hi == 0 ? f32_to_el16(1.0f) : (el16_t)0));
-#pragma unroll
-    for (int b = 0; b < QB; ++b) {
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (q0 + 32 * b < N) v = *(const uint4*)(base + (size_t)(q0 + 32 * b) * C3 + h * 32 + ks * 16 + hi * 8);
-            uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-            for (int t = 0; t < 4; ++t) w[t] = pack_el16x2(el16_lo(w[t]) * c2, el16_hi(w[t]) * c2);
-            qf[b][ks] = *(el16x8_t*)w;
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o[b][r] = 0.0f;
-        m[b] = 0.0f;
-        l2[b] = fa_f32x2{0.0f, 0.0f};
-#pragma unroll
-        for (int t = 0; t < 8; ++t) bm[b][t] = __builtin_bit_cast(el16_native_t, (el16_t)0);
-    }
-    bool first = true;
-    const RngKey dkey = DROP ? attn_drop_key(a.drop, n, (uint32_t)h) : RngKey{0u, 0u};
-
-    const int skey = tid >> 2, sch = tid & 3;   // staging role: thread -> (key, 16-B chunk of 8 channels)
-    uint4 kv_n = make_uint4(0, 0, 0, 0), vv_n = make_uint4(0, 0, 0, 0);
-    auto fetch = [&](int j0) {  // K / V of the NEXT 64-key tile travel through registers while the current one is consumed
-        const int j = j0 + skey;
-        kv_n = make_uint4(0, 0, 0, 0);
-        vv_n = kv_n;
-        if (j < N) {
-            kv_n = *(const uint4*)(base + (size_t)j * C3 + hd + h * 32 + sch * 8);
-            vv_n = *(const uint4*)(base + (size_t)j * C3 + 2 * hd + h * 32 + sch * 8);
-        }
-    };
-    auto stage = [&]() {
-        *(uint4*)(Ks + skey * 32 + ((sch ^ ((skey >> 2) & 3)) << 3)) = kv_n;
-        const el16_t* ve = (const el16_t*)&vv_n;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) Vt[(sch * 8 + i) * 68 + skey] = ve[i];
-    };
-    fetch(0);
-    int j0 = 0;
-    for (; j0 + 64 <= N; j0 += 64) {  // whole tiles only
-#ifdef FA3_EXP_NOSTAGE
-        if (j0 == 0) {
-            __syncthreads();
-            stage();
-            __syncthreads();
-        }
-#else
-        __syncthreads();  // every wave is done reading the previous tile
-        stage();
-        if (j0 + 64 < N) fetch(j0 + 64);
-        __syncthreads();
-#endif
-#pragma nounroll
-        for (int st = 0; st < 2; ++st)
-            fa3_subtile<DROP, QB>(a, kf0, kf1, vf0, qf, o, m, l2, bm, aone, first, j0 + 32 * st, st, q0, N, hi, dkey);
-    }
-    if (!DROP && j0 < N) {  // partial last tile: the general sub-tile of the second form (accumulators start at -m)
-        __syncthreads();
-        stage();
-        __syncthreads();
-        fa_f32x16 negm[QB];
-        fa_bf16x4 bm2[QB];
-        const fa_bf16x4 aone2 = {0, 0, 0, 0};
-#pragma unroll
-        for (int b = 0; b < QB; ++b) bm2[b] = fa_bf16x4{0, 0, 0, 0};
-        fa2_subtile<0, false, QB, false>(a, kf0, kf1, vf0, qf, o, negm, m, l2, first, j0, 0, q0, N, hi, dkey, (uint32_t)bh, aone2, bm2);
-        if (j0 + 32 < N) fa2_subtile<0, false, QB, false>(a, kf0, kf1, vf0, qf, o, negm, m, l2, first, j0 + 32, 1, q0, N, hi, dkey, (uint32_t)bh, aone2, bm2);
-    }
-#pragma unroll
-    for (int b = 0; b < QB; ++b) {
-        const float ll = l2[b].x + l2[b].y;
-        const float l = ll + __shfl_xor(ll, 32, 64);
-        const int q = q0 + 32 * b;
-        if (q >= N) continue;
-        // O^T[d][q]: lane (q, hi) holds d = (r&3) + 8(r>>2) + 4hi  -> four 8-byte stores of 4 consecutive channels
-        const float inv = (DROP ? a.drop.scale : 1.0f) / l;
-        el16_t* op = a.out + ((size_t)n * N + q) * hd + h * 32;  // "b h (x y) d -> b (h d) x y"
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            uint2 w;
-            w.x = pack_el16x2(o[b][g * 4 + 0] * inv, o[b][g * 4 + 1] * inv);
-            w.y = pack_el16x2(o[b][g * 4 + 2] * inv, o[b][g * 4 + 3] * inv);
-            *(uint2*)(op + 8 * g + 4 * hi) = w;
-        }
-    }
-}
 
 // ---- fourth form (round 4): the third form's arithmetic as a SOFTWARE PIPELINE over 32-key sub-tiles.  Timing experiments on the
 // third form (tools/variants, wrong results: no bias product -4 %, no S^T products -17 %, no exponentials -12 %, no P V products
@@ -2813,8 +2582,8 @@ __global__ __launch_bounds__(64 * NW, FA4_MINW) void flash_attention4_kernel(Att
 }
 
 hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
-    // DYF_FLASH_ATTN: unset / 4 = flash_attention4_kernel (the pipelined form), 3 = flash_attention3_kernel (both fall back to
-    // flash_attention2_kernel for the dropout layouts they do not take), 2 = flash_attention2_kernel, 1 = the first flash form,
+    // DYF_FLASH_ATTN: unset / 4 (/ 3: that kernel was retired in round 5) = flash_attention4_kernel (the pipelined form; falls back to
+    // flash_attention2_kernel for the dropout layouts it does not take), 2 = flash_attention2_kernel, 1 = the first flash form,
     // 0 = the plain per-query kernel
     static const int flash = getenv("DYF_FLASH_ATTN") ? atoi(getenv("DYF_FLASH_ATTN")) : 4;
     if (flash != 0 && a.hw <= 65535) {
@@ -2826,13 +2595,11 @@ hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
         const bool drop = a.drop.mode != 0;
         const bool qb2 = flash != 1 && a.hw >= 512 && (drop ? qb_drop == 2 && flash >= 3 : qb_env == 2);
         const int qblocks2 = (a.hw + 255) / 256;
-        // the third form's dropout kernels: engine streams (paired keep words), an even token count, whole query blocks
-        const bool v3 = flash >= 3 && (!drop || (a.drop.mode == 1 && (a.hw & 1) == 0 && a.hw % (qb2 ? 256 : 128) == 0));
         // the fourth form: one 32-query block per wave, DYF_FLASH_NW = 8 (default) / 4 waves per workgroup; a sequence shorter than
         // 512 tokens stays on four waves (more workgroups)
         static const int nw_env = getenv("DYF_FLASH_NW") ? atoi(getenv("DYF_FLASH_NW")) : 8;
         const int nw = nw_env == 16 && a.hw >= 2048 ? 16 : nw_env >= 8 && a.hw >= 512 ? 8 : 4;
-        const bool v4 = flash >= 4 && (!drop || (a.drop.mode == 1 && (a.hw & 1) == 0 && a.hw % (32 * nw) == 0));
+        const bool v4 = flash >= 3 && (!drop || (a.drop.mode == 1 && (a.hw & 1) == 0 && a.hw % (32 * nw) == 0));
         if (v4) {
             dyf_form_note(nw == 16 ? "flash_attention4_kernel<NW=16>" : nw == 8 ? "flash_attention4_kernel<NW=8>" : "flash_attention4_kernel<NW=4>", a.n);
             const int qb4 = (a.hw + 32 * nw - 1) / (32 * nw);
@@ -2842,14 +2609,6 @@ hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
             else if (nw == 8) hipLaunchKernelGGL((flash_attention4_kernel<false, 8>), dim3(a.n * a.heads * qb4), dim3(512), 0, s, a);
             else if (drop) hipLaunchKernelGGL((flash_attention4_kernel<true, 4>), dim3(a.n * a.heads * qb4), dim3(256), 0, s, a);
             else hipLaunchKernelGGL((flash_attention4_kernel<false, 4>), dim3(a.n * a.heads * qb4), dim3(256), 0, s, a);
-            return hipGetLastError();
-        }
-        if (v3) {
-            dyf_form_note(qb2 ? "flash_attention3_kernel<QB=2>" : "flash_attention3_kernel<QB=1>", a.n);
-            if (qb2 && drop) hipLaunchKernelGGL((flash_attention3_kernel<true, 2>), dim3(a.n * a.heads * qblocks2), dim3(256), 0, s, a);
-            else if (qb2) hipLaunchKernelGGL((flash_attention3_kernel<false, 2>), dim3(a.n * a.heads * qblocks2), dim3(256), 0, s, a);
-            else if (drop) hipLaunchKernelGGL((flash_attention3_kernel<true, 1>), dim3(a.n * a.heads * qblocks), dim3(256), 0, s, a);
-            else hipLaunchKernelGGL((flash_attention3_kernel<false, 1>), dim3(a.n * a.heads * qblocks), dim3(256), 0, s, a);
             return hipGetLastError();
         }
         const bool qb2v2 = qb2 && !drop;

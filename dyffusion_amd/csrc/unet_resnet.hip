@@ -519,6 +519,8 @@ dyf_status rn_forward(dyf_engine* e, int which, const Source* srcs, int nsrc, in
         a.gnf.max_slots = r->gn_max_slots; a.gnf.groups = c.groups; a.gnf.bias = bias; a.gnf.gamma = gamma; a.gnf.beta = beta;
         if (with_film) { a.gnf.film_a = o.coef_a + film_off; a.gnf.film_c = o.coef_c + film_off; a.gnf.film_stride = o.coef_stride; }
         a.gnf.err = e->gn_err_dev;
+        a.gnf.invariant = e->cfg.batch_invariant ? 1 : 0;
+        a.gnf.timeout_ticks = e->gn_timeout_ticks; a.gnf.test_tag_xor = e->gn_test_tag_xor;
         const int path = (e->cfg.enable_mfma && conv_mfma_supported(a)) ? 1 : 0;
         ProfScope prof(e, e->prof_layer == DYF_PROF_RESNET_BASE + DYF_PROF_RN_CONV3_L0 && hh == e->cfg.height && ww == e->cfg.width &&
                               c0 + c1 == cout, nb, st);

@@ -268,23 +268,29 @@ class DYffusion(nn.Module):
         if hp.sampling_type not in ("cold", "naive"):
             raise ValueError(f"unknown sampling type {hp.sampling_type}")
         steps, refine, n_slots = self._build_plan()
-        eng.set_plan(steps, sampling_cold=hp.sampling_type == "cold",
-                     cold_for_last_step=hp.use_cold_sampling_for_last_step,
-                     forward_conditioning=hp.forward_conditioning, refine=refine, n_out_slots=n_slots,
-                     interpolator_dropout=bool(self.enable_interpolator_dropout or self.training),
-                     forecaster_dropout=bool(self.enable_forecaster_dropout))
         # bf16 storage and the ResNet-UNet: ~1e-2 per forward, 4.6e-2 - 5.2e-2 per field over the T = 32 OISST plan (93 chained
         # forwards; tests/test_gpu_unet_resnet.py) -- twice the 2.5e-2 this engine holds its 16-bit rollouts to.  Such a plan is
         # REFUSED in bf16 rather than served at a tolerance nobody asked for: fp16 (the backbone's default) carries 6e-3 over the
         # same rollout at the same speed.  DYF_ALLOW_BF16_LONG_ROLLOUT=1 / allow_bf16_long_rollout overrides (timing experiments).
-        nf, ni = eng.forward_counts()
-        if eng.dtype == "bf16" and eng.cfg.net[L.NET_FORECASTER].arch == L.ARCH_UNET_RESNET and nf + ni > BF16_RESNET_MAX_FORWARDS \
+        # Either network of the pair counts (the interpolator runs most of the chained forwards), and the check comes BEFORE
+        # dyf_set_plan: a refused plan leaves the engine's current plan, its FiLM tables and its captured graphs untouched.
+        cold = hp.sampling_type == "cold"
+        nf = len(steps)  # the count dyf_plan_forward_counts reports for this plan
+        ni = len(refine) + sum(1 for st in steps if st["i_next"] is not None) + \
+            sum(1 for st in steps if cold and st["i_cur"] is not None and not (st["is_last"] and not hp.use_cold_sampling_for_last_step))
+        resnet = any(eng.cfg.net[k].arch == L.ARCH_UNET_RESNET for k in (L.NET_FORECASTER, L.NET_INTERPOLATOR))
+        if eng.dtype == "bf16" and resnet and nf + ni > BF16_RESNET_MAX_FORWARDS \
                 and not (self.allow_bf16_long_rollout or os.environ.get("DYF_ALLOW_BF16_LONG_ROLLOUT") == "1"):
-            eng.plan_valid = False
             raise NotImplementedError(
                 f"a rollout of {nf + ni} network forwards of unet.Unet in bf16 storage drifts ~5e-2 from the fp32 reference "
                 f"(limit here: {BF16_RESNET_MAX_FORWARDS} forwards, <= 2.5e-2); use dtype='fp16' (the default for this backbone, "
                 f"6e-3 over the same rollout) or pass allow_bf16_long_rollout=True to accept the drift")
+        eng.set_plan(steps, sampling_cold=cold,
+                     cold_for_last_step=hp.use_cold_sampling_for_last_step,
+                     forward_conditioning=hp.forward_conditioning, refine=refine, n_out_slots=n_slots,
+                     interpolator_dropout=bool(self.enable_interpolator_dropout or self.training),
+                     forecaster_dropout=bool(self.enable_forecaster_dropout))
+        assert (nf, ni) == tuple(eng.forward_counts()), ((nf, ni), eng.forward_counts())
         self._plan_key = key
         self._plan_steps = steps
         self._emitted_slots = sorted({st["out_slot"] for st in steps if st["out_slot"] is not None})

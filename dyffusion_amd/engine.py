@@ -107,6 +107,22 @@ class HipEngine:
         if st != L.DYF_OK:
             _raise(st, self._lib.dyf_last_error(self._h).decode())
 
+    def poll_errors(self, synchronize: bool = True):
+        """dyf_poll_errors: asynchronous failures of the work just submitted (a fused GroupNorm convolution whose wait for its
+        sample's statistics timed out; csrc/gn_fused.h) fail THIS call instead of the next one.  Engines without a live fused form
+        (unet_simple, SimpleConvNet, after a downgrade) return at once; ResNet-UNet engines wait for the device first."""
+        self._check(self._lib.dyf_poll_errors(self._h, int(synchronize)))
+
+    def gn_fuse_state(self):
+        """(live, downgrades): the fused GroupNorm form is in use / how often this engine left it (dyf_gn_fuse_state)."""
+        live, down = C.c_int32(0), C.c_int32(0)
+        self._check(self._lib.dyf_gn_fuse_state(self._h, C.byref(live), C.byref(down)))
+        return bool(live.value), down.value
+
+    def debug_gn_fuse(self, timeout_ticks: int = 0, force_timeout: bool = False):
+        """Test hook (dyf_debug_gn_fuse): sweep bound in 100 MHz ticks, forced time-out of every granule sweep."""
+        self._check(self._lib.dyf_debug_gn_fuse(self._h, int(timeout_ticks), int(force_timeout)))
+
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
             self._lib.dyf_engine_destroy(self._h)
@@ -186,6 +202,7 @@ class HipEngine:
         self._check(self._lib.dyf_net_forward(
             self._h, net, inputs.data_ptr(), None if time is None else time.data_ptr(),
             None if condition is None else condition.data_ptr(), out.data_ptr(), nb, dropout_mode, mptr, self._stream()))
+        self.poll_errors()
         return out
 
     # ------------------------------------------------------------------ sampler seam
@@ -244,6 +261,7 @@ class HipEngine:
         self._check(self._lib.dyf_sample(self._h, initial.data_ptr(), None if static is None else static.data_ptr(),
                                          out.data_ptr(), nb, mptr, None if noise is None else noise.data_ptr(),
                                          self._stream()))
+        self.poll_errors()
         return out
 
     # ------------------------------------------------------------------ engine-owned exchange (ensemble sharding over GPUs)
@@ -293,6 +311,7 @@ class HipEngine:
         out = torch.empty((self.n_out_slots, int(total_rows), c_out, self.height, self.width), dtype=torch.float32, device=initial.device)
         self._check(self._lib.dyf_sample_gather(self._h, initial.data_ptr(), None if static is None else static.data_ptr(),
                                                 out.data_ptr(), nb, int(total_rows), self._stream()))
+        self.poll_errors()
         return out
 
     def sampler_state(self, what: int, nb: int) -> torch.Tensor:

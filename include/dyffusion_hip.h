@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define DYF_ABI_VERSION 6
+#define DYF_ABI_VERSION 7
 
 typedef struct dyf_engine dyf_engine;
 
@@ -157,6 +157,18 @@ dyf_status dyf_set_plan(dyf_engine* engine, const dyf_plan* plan);
  * (n_steps, NB, window*C, H, W) standard-normal draws for forward_conditioning="data+noise" parity. */
 dyf_status dyf_sample(dyf_engine* engine, const float* initial_dev, const float* static_dev, float* out_dev,
                       int32_t nb, const uint8_t* const* masks_dev, const float* noise_dev, void* stream);
+/* Asynchronous failures (ABI 7).  Every entry point only ENQUEUES work on the caller's stream; the one thing that can go wrong
+ * after that is a fused GroupNorm convolution of the ResNet-UNet (csrc/gn_fused.h: workgroups of one sample meet inside the launch)
+ * whose wait for its sample's statistics times out -- its output is then NaN-poisoned and a host-visible word is raised.
+ * dyf_poll_errors reports that: DYF_OK, or DYF_ERR_STATE naming it (the engine has then already dropped its captured graphs and
+ * runs the un-fused GroupNorm kernels from now on: repeat the call).  synchronize != 0 waits for the device to finish first, so a
+ * caller that polls right after dyf_sample / dyf_sample_gather / dyf_net_forward gets the failure from the SAME call (the Python
+ * wrappers do).  Engines without a live fused form (unet_simple, SimpleConvNet, DYF_GN_FUSED=0, after a downgrade) return
+ * DYF_OK at once without waiting.  Un-polled failures are still reported at the head of the next entry point.
+ * dyf_gn_fuse_state: *live = the fused form is in use, *downgrades = how often the engine left it (time-out, or sweeps slower than
+ * 1 ms on a GPU shared with another process -- the latter is not an error; DYF_VERBOSE=1 logs either to stderr). */
+dyf_status dyf_poll_errors(dyf_engine* engine, int32_t synchronize);
+dyf_status dyf_gn_fuse_state(const dyf_engine* engine, int32_t* live, int32_t* downgrades);
 /* log_every_t of sample_loop (dyffusion.py:339-344, 398-406): with logging enabled a dyf_sample call also keeps, per sampling step,
  * x0_hat (what = 0, the reference's `intermediate_{s}_x0hat`), x_interpolated_s_next (1: `xipol_{s}_dmodel`, and `t{k}_preds2` on
  * the steps that emit a forecast) and, for cold sampling, x_interpolated_s (2: `xipol_{s}_dmodel2`; as in the reference the last

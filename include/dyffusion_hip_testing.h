@@ -82,6 +82,11 @@ dyf_status dyf_train_conv_check(dyf_engine* engine, int32_t kind, int32_t n, int
 dyf_status dyf_debug_read_block_output(dyf_engine* engine, int32_t net, int32_t layer, int32_t nb, float* out_dev,
                                        void* stream);
 
+/* Fused GroupNorm (csrc/gn_fused.h) failure drill: timeout_ticks = bound of a granule sweep in 100 MHz ticks (0 = the default, 2 s);
+ * force_timeout != 0 makes every sweep wait for a tag nobody publishes, i.e. behave as if a workgroup of its sample never arrived.
+ * Drops the captured graphs (both values travel as kernel arguments) after waiting for the device. */
+dyf_status dyf_debug_gn_fuse(dyf_engine* engine, uint32_t timeout_ticks, int32_t force_timeout);
+
 /* Kernel-form log: which kernel FORM every launcher took (conv_halo_rows_kernel<0/1/2>, conv_up_halo_kernel<3/4/5>,
  * conv_igemm2_kernel<1/2>, conv_igemm_kernel<..>(+splitk), conv_enc0_stem_kernel, stem16_rows_kernel, up2x_quad_kernel,
  * readout_dma_kernel, ...) and for how many batch rows.  Forms are chosen per launch from tile counts (csrc/conv.hip

@@ -5,7 +5,8 @@ oracle calls are the test modules' own functions -- this script only runs them w
 
 Run in the build container:  python tests/golden/make_oracle_cache.py        (about 4 minutes of CPU time)
 These are oracle outputs, not reference outputs: the oracle is pinned to the reference by the CPU suite (tests/test_oracle_*.py),
-and tests/test_oracle_cache.py recomputes an entry there."""
+and tests/test_oracle_cache.py recomputes a row of every entry there.  The script refuses to write while the CPU
+oracle suite (tests/test_oracle_*.py, tests/test_rng_host.py) is red."""
 import os
 import sys
 import time
@@ -14,6 +15,17 @@ ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", ".."))
 sys.path.insert(0, ROOT)
 os.environ["DYF_WRITE_ORACLE_CACHE"] = "1"
 os.environ["DYF_ORACLE_CACHE"] = "0"  # recompute everything
+
+import subprocess  # noqa: E402
+
+if os.environ.get("DYF_CACHE_SKIP_SUITE") != "1":
+    # an oracle that no longer reproduces the reference's golden vectors must not be frozen into fixtures: the CPU oracle suite
+    # (oracle vs tests/golden/*.npz|json, generated from the imported reference) has to be green first
+    suite = ["tests/test_oracle_schedule.py", "tests/test_oracle_nets.py", "tests/test_oracle_sampler.py", "tests/test_oracle_losses.py",
+             "tests/test_oracle_metrics.py", "tests/test_oracle_boundary.py", "tests/test_rng_host.py"]
+    rc = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "not gpu"] + suite, cwd=ROOT).returncode
+    if rc != 0:
+        raise SystemExit("the CPU oracle suite is red: refusing to write tests/golden/oracle_cache (fix the oracle first)")
 
 import torch  # noqa: E402
 

@@ -55,32 +55,74 @@ def oracle_rollout(PF, PI, mcfg, hp, x0, c, drop=None, noise_fn=None):
 
 _ORACLE_CACHE = {}
 _CACHE_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_cache")
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def oracle_code_hash():
+    """sha-256 over the sources an oracle result is a function of: oracle/*.py (the restatement) and tests/rng_host.py (the host
+    rebuild of the engine's dropout masks the `ns80_dropout_*` entry is computed with).  Line endings normalised; the file names
+    are part of the digest."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(_ROOT, "oracle", "*.py"))) + [os.path.join(_ROOT, "tests", "rng_host.py")]
+    for f in files:
+        h.update(os.path.relpath(f, _ROOT).replace(os.sep, "/").encode() + b"\0")
+        with open(f, "rb") as fh:
+            h.update(fh.read().replace(b"\r\n", b"\n") + b"\0")
+    return h.hexdigest()
+
+
+def config_hash(config):
+    import hashlib
+    return hashlib.sha256(json.dumps(config, sort_keys=True, default=str).encode()).hexdigest()
+
+
+def _flatten(depends_on):
+    for t in depends_on:
+        if isinstance(t, dict):  # a parameter dict: every tensor, in key order
+            for k in sorted(t):
+                yield t[k]
+        else:
+            yield t
 
 
 def _fingerprint(tensors):
     """Identity of what an oracle result was computed FROM (inputs, weights): float64 sums of |x| and of x * index -- cheap, and any
-    change of a seed, a shape or an initialiser changes it."""
+    change of a seed, a shape or an initialiser changes it.  Entries of `tensors` may be parameter dicts (every tensor counts)."""
     acc = []
-    for t in tensors:
+    for t in _flatten(tensors):
         t = t.detach().double().reshape(-1)
         acc += [float(t.abs().sum()), float((t * torch.arange(1, t.numel() + 1, dtype=torch.float64).remainder(97.0)).sum()), float(t.numel())]
     return acc
 
 
-def cached(key, fn, depends_on=None):
+def cache_entry_valid(z, fp, config):
+    """A disk entry is used only while ALL of these still hold: the fingerprint of the inputs and weights, the hash of the
+    hyper-parameters / configuration the oracle ran with, and the hash of the oracle's own sources."""
+    if "__code__" not in z.files or "__config__" not in z.files:
+        return False
+    if str(z["__code__"]) != oracle_code_hash() or str(z["__config__"]) != config_hash(config):
+        return False
+    return z["__fingerprint__"].shape == (len(fp),) and np.allclose(z["__fingerprint__"], np.array(fp), rtol=1e-12, atol=0.0)
+
+
+def cached(key, fn, depends_on=None, config=None):
     """Memo for CPU-oracle results.  In the process: shared by the parametrisations of one test (bf16 / fp16 builds compare with the
     SAME fp32 oracle output).  On disk (tests/golden/oracle_cache/<key>.npz, written by tests/golden/make_oracle_cache.py in the build
     container): the full-size oracle runs are what the GPU suite spends its time on -- minutes of fp32 CPU rollouts per test -- so
-    their OUTPUTS are kept as small fixtures next to a fingerprint of the inputs and weights they were computed from (`depends_on`:
-    the tensors; a cache whose fingerprint differs is ignored and the oracle runs).  The oracle itself stays pinned to the
-    reference by the CPU suite; tests/test_oracle_cache.py recomputes a cached entry there."""
+    their OUTPUTS are kept as small fixtures next to (a) a fingerprint of the inputs and weights they were computed from
+    (`depends_on`: tensors and whole parameter dicts), (b) a hash of `config` (hyper-parameters, model configuration, row lists) and
+    (c) a hash of the oracle's sources (oracle/*.py, tests/rng_host.py).  An entry for which any of the three differs is ignored and
+    the oracle runs.  The oracle itself stays pinned to the reference by the CPU suite; tests/test_oracle_cache.py recomputes rows of
+    EVERY cached entry there."""
     if key in _ORACLE_CACHE:
         return _ORACLE_CACHE[key]
     path = os.path.join(_CACHE_DIR, key + ".npz")
     fp = None if depends_on is None else _fingerprint(depends_on)
     if fp is not None and os.path.exists(path) and os.environ.get("DYF_ORACLE_CACHE", "1") != "0":
         with np.load(path, allow_pickle=False) as z:
-            if z["__fingerprint__"].shape == (len(fp),) and np.allclose(z["__fingerprint__"], np.array(fp), rtol=1e-12, atol=0.0):
+            if cache_entry_valid(z, fp, config):
                 kind = str(z["__kind__"])
                 if kind == "tensor":
                     val = torch.from_numpy(z["value"].copy())
@@ -92,9 +134,9 @@ def cached(key, fn, depends_on=None):
     _ORACLE_CACHE[key] = val
     if fp is not None and os.environ.get("DYF_WRITE_ORACLE_CACHE") == "1":
         os.makedirs(_CACHE_DIR, exist_ok=True)
+        meta = dict(__fingerprint__=np.array(fp), __code__=oracle_code_hash(), __config__=config_hash(config))
         if torch.is_tensor(val):
-            np.savez_compressed(path, __fingerprint__=np.array(fp), __kind__="tensor", value=val.detach().cpu().numpy())
+            np.savez_compressed(path, __kind__="tensor", value=val.detach().cpu().numpy(), **meta)
         elif isinstance(val, dict) and all(torch.is_tensor(v) for v in val.values()):
-            np.savez_compressed(path, __fingerprint__=np.array(fp), __kind__="dict",
-                                **{"v::" + k: v.detach().cpu().numpy() for k, v in val.items()})
+            np.savez_compressed(path, __kind__="dict", **meta, **{"v::" + k: v.detach().cpu().numpy() for k, v in val.items()})
     return val

@@ -69,7 +69,7 @@ def oracle_nb80_rows(mk, PF, PI, x0, c, rows):
     def run():
         out = oracle_rollout(PF, PI, mk, HP, x0[rows], c[rows])
         return {k: out[k] for k in ("t1_preds", "t8_preds", "t16_preds")}
-    return cached("ns80_rows_" + "_".join(map(str, rows)), run, depends_on=[x0[rows], c[rows], PF["init_conv.weight"], PI["readout.0.weight"]])
+    return cached("ns80_rows_" + "_".join(map(str, rows)), run, depends_on=[x0[rows], c[rows], PF, PI], config=dict(model=mk, hp=HP, rows=list(rows)))
 
 
 def oracle_nb80_row_with_engine_masks(mk, PF, PI, x0, c, hp, seed, r):
@@ -88,7 +88,7 @@ def oracle_nb80_row_with_engine_masks(mk, PF, PI, x0, c, hp, seed, r):
             out = sampler.sample_loop(lambda x, t, cond: nets.unet_simple_forward(PF, mk, x, t, cond), i_fn, x0[r:r + 1], c[r:r + 1], hp)
         return {k: out[k] for k in ("t1_preds", "t8_preds", "t16_preds")}
     return cached(f"ns80_dropout_seed{seed}_row{r}", run,
-                  depends_on=[x0[r:r + 1], c[r:r + 1], PF["init_conv.weight"], PI["readout.0.weight"], torch.tensor([float(seed % 100003), float(r)])])
+                  depends_on=[x0[r:r + 1], c[r:r + 1], PF, PI], config=dict(model=mk, hp=hp, seed=int(seed), row=int(r)))
 
 
 def test_nb80_graph_paired_rollout_rows_match_the_oracle():
@@ -213,7 +213,7 @@ def oracle_oisst_fwd_eval(cfg, PI, x, t, rows):
     def run():
         with torch.no_grad():
             return nets.resnet_unet_forward(PI, cfg, x[rows], t[rows], None)
-    return cached("oisst300_fwd_eval", run, depends_on=[x[rows], t[rows], PI["init_conv.weight"], PI["final_conv.weight"]])
+    return cached("oisst300_fwd_eval", run, depends_on=[x[rows], t[rows], PI], config=dict(model=cfg, rows=list(rows)))
 
 
 OISST_ROLLOUT_HP = dict(timesteps=7, schedule="before_t1_only", additional_interpolation_steps=25, interpolate_before_t1=True,
@@ -237,7 +237,7 @@ def oracle_oisst_rollout_rows(cfg, PF, PI, x0, noise, rows):
             return sampler.sample_loop(lambda x, t, cnd: nets.resnet_unet_forward(PF, cfg, x, t, cnd),
                                        lambda x, t, cnd: nets.resnet_unet_forward(PI, cfg, x, t, cnd), x0[rows], None, OISST_ROLLOUT_HP,
                                        noise_fn=lambda tensor: noise[next(it)][rows])
-    return cached("oisst300_rollout_rows", run, depends_on=[x0[rows], noise[:, rows], PF["init_conv.weight"], PI["final_conv.weight"]])
+    return cached("oisst300_rollout_rows", run, depends_on=[x0[rows], noise[:, rows], PF, PI], config=dict(model=cfg, hp=OISST_ROLLOUT_HP, rows=list(rows)))
 
 
 @pytest.mark.parametrize("dtype", ["fp16", "bf16"])

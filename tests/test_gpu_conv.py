@@ -200,3 +200,79 @@ def test_fused_upsample_conv_matches_torch(engine, case):
     for sl in [(slice(None), 0), (slice(None), -1), (slice(None), slice(None), 0), (slice(None), slice(None), -1)]:
         assert rel_rms(y[sl], want[sl]) <= 8e-3, (sl, rel_rms(y[sl], want[sl]))
     assert max_abs(y, want) <= 3 * 2 ** -8 * float(want.abs().max()) + 2e-3
+
+
+def _form_log(engine_obj, fn):
+    engine_obj.form_log(True)
+    out = fn()
+    forms = engine_obj.form_log_read()
+    engine_obj.form_log(False)
+    return out, forms
+
+
+# (n, h, w, cin, cout) of fused x2-upsample convs at FEW ROWS: the decoder shapes of unet_simple at one / two rows (dec3: 32 x 32
+# low-res, 8 chunks; dec4: 64 x 64, 4 chunks) and shapes where the split is 2 / the ring has ragged tiles / three samples share the
+# border kernel's sample pairs unevenly
+SPLIT_UPCASES = [(1, 32, 32, 512, 128, 8), (2, 64, 64, 256, 128, 4), (3, 32, 64, 256, 64, 2), (5, 48, 32, 128, 64, 2), (1, 32, 32, 128, 128, 2),
+                 (1, 32, 32, 512, 128, 0)]  # last entry: factor 0 = whatever the launcher's cost model picks (8 for dec3 at one row)
+
+
+@pytest.mark.parametrize("case", SPLIT_UPCASES, ids=lambda c: "x".join(map(str, c)))
+def test_rows_splitk_upsample_conv_matches_torch_and_the_unsplit_kernel(engine, case, monkeypatch):
+    """Round 5: conv_halo_rows_splitk_kernel<0> (a tile's 64-channel chunks dealt to 2 / 4 / 8 workgroups, raw fp32 partials,
+    conv_splitk_finish4_kernel) and up_border_split_kernel (the border ring's K chain dealt to the 8 waves of a workgroup) -- what a
+    decoder launch of a few rows takes -- against ATen and against the one-workgroup-per-tile kernels they replace."""
+    n, h, w, cin, cout, factor = case
+    g = torch.Generator().manual_seed(sum(case[:5]) + 5)
+    x = torch.randn(n, h, w, cin, generator=g).to(torch.bfloat16)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    scale = 1.0 + 0.3 * torch.randn(n, cout, generator=g)
+    shift = 0.2 * torch.randn(n, cout, generator=g)
+    monkeypatch.setenv("DYF_HALO_SPLITK", "0")
+    monkeypatch.setenv("DYF_UP_BORDER_SPLIT_ROWS", "0")
+    old, forms0 = _form_log(engine, lambda: engine.op_upconv2d(x.cuda(), wt, scale.cuda(), shift.cuda(), act=1).float().cpu())
+    assert "conv_halo_rows_kernel<0>" in forms0 and not any("split" in k for k in forms0), sorted(forms0)
+    monkeypatch.delenv("DYF_HALO_SPLITK")
+    monkeypatch.delenv("DYF_UP_BORDER_SPLIT_ROWS")
+    if factor:
+        monkeypatch.setenv("DYF_HALO_SPLITK_FORCE", str(factor))
+    y, forms = _form_log(engine, lambda: engine.op_upconv2d(x.cuda(), wt, scale.cuda(), shift.cuda(), act=1).float().cpu())
+    assert "conv_halo_rows_kernel<0>+splitk" in forms and "up_border_split_kernel" in forms, sorted(forms)
+    up = F.interpolate(x.float().permute(0, 3, 1, 2), scale_factor=2, mode="bilinear")
+    want = F.relu(F.conv2d(up, wt, None, 1, 1) * scale[:, :, None, None] + shift[:, :, None, None]).permute(0, 2, 3, 1)
+    assert rel_rms(y, want) <= 6e-3, rel_rms(y, want)
+    for sl in [(slice(None), 0), (slice(None), -1), (slice(None), slice(None), 0), (slice(None), slice(None), -1)]:
+        assert rel_rms(y[sl], want[sl]) <= 8e-3, (sl, rel_rms(y[sl], want[sl]))
+        assert rel_rms(y[sl], old[sl]) <= 2.5e-3, (sl, rel_rms(y[sl], old[sl]))  # the ring: summation order only
+    assert max_abs(y, want) <= 3 * 2 ** -8 * float(want.abs().max()) + 2e-3
+    assert rel_rms(y, old) <= 2.5e-3
+    # ... and the split kernels reproduce themselves bit for bit (fixed summation order: splits / waves are added by index)
+    y2 = engine.op_upconv2d(x.cuda(), wt, scale.cuda(), shift.cuda(), act=1).float().cpu()
+    assert torch.equal(y, y2)
+
+
+@pytest.mark.parametrize("case", [(2, 32, 32, 1024, 256, 8), (1, 8, 64, 256, 512, 4), (3, 16, 32, 128, 256, 2)], ids=lambda c: "x".join(map(str, c)))
+def test_rows_splitk_plain_conv_matches_torch_and_the_unsplit_kernel(engine, case, monkeypatch):
+    """conv_halo_rows_splitk_kernel<2>: the plain 3x3 / 256-channel-block form (dec2 of unet_simple: 16 chunks, 8 tiles per row) at few
+    rows, forced onto the rows kernel as the engine's tile thresholds would at >= 10 rows."""
+    n, h, w, cin, cout, factor = case
+    g = torch.Generator().manual_seed(sum(case[:5]) + 9)
+    x = torch.randn(n, h, w, cin, generator=g).to(torch.bfloat16)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    scale = 1.0 + 0.3 * torch.randn(n, cout, generator=g)
+    shift = 0.2 * torch.randn(n, cout, generator=g)
+    monkeypatch.setenv("DYF_HALO3_MIN_TILES", "1")
+    monkeypatch.setenv("DYF_HALO_SPLITK", "0")
+    old, forms0 = _form_log(engine, lambda: engine.op_conv2d(x.cuda(), wt, 1, 1, scale.cuda(), shift.cuda(), act=2, path=1).float().cpu())
+    assert "conv_halo_rows_kernel<2>" in forms0, sorted(forms0)
+    monkeypatch.delenv("DYF_HALO_SPLITK")
+    monkeypatch.setenv("DYF_HALO_SPLITK_FORCE", str(factor))
+    y, forms = _form_log(engine, lambda: engine.op_conv2d(x.cuda(), wt, 1, 1, scale.cuda(), shift.cuda(), act=2, path=1).float().cpu())
+    assert "conv_halo_rows_kernel<2>+splitk" in forms, sorted(forms)
+    want = reference(x, wt, 1, 1, scale, shift, 2)
+    tol = 1.5 * 2 ** -8 * float(want.abs().max()) + 1e-3
+    assert max_abs(y, want) <= tol
+    assert rel_rms(y, want) <= 4e-3
+    for sl in [(slice(None), 0), (slice(None), -1), (slice(None), slice(None), 0), (slice(None), slice(None), -1)]:
+        assert rel_rms(y[sl], want[sl]) <= 5e-3, sl
+    assert rel_rms(y, old) <= 2.5e-3

@@ -67,7 +67,7 @@ def oracle_grouped_rows(cfg, PF, PI, hp, x0, rows):
         with torch.no_grad():
             return sampler.sample_loop(lambda x, t, cnd: nets.resnet_unet_forward(PF, cfg, x, t, cnd),
                                        lambda x, t, cnd: nets.resnet_unet_forward(PI, cfg, x, t, cnd), x0[rows], None, hp)
-    return cached("oisst300_grouped_rows", run, depends_on=[x0[rows], PF["init_conv.weight"], PI["final_conv.weight"]])
+    return cached("oisst300_grouped_rows", run, depends_on=[x0[rows], PF, PI], config=dict(model=cfg, hp=hp, rows=list(rows)))
 
 
 @pytest.mark.parametrize("dtype", ["fp16"])  # (a 93-forward ResNet-UNet plan is refused in bf16: test_gpu_unet_resnet.py)

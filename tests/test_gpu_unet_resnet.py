@@ -379,3 +379,117 @@ def test_fused_groupnorm_convs_match_the_unfused_chain_and_are_reproducible():
     e0 = max(rel_rms(outs["0"][0][r], want[r]) for r in range(nb))
     print(f"vs the fp32 oracle: fused {e1:.3e}, un-fused {e0:.3e}")
     assert e1 <= 4e-3
+
+
+def _invariant_engine(net, hw, max_batch, dtype="fp16"):
+    from dyffusion_amd import _lib as L
+    from dyffusion_amd.engine import HipEngine, upload_weights
+    cfg = net.engine_net_config()
+    eng = HipEngine(cfg, cfg, hw[0], hw[1], max_batch=max_batch, use_graph=False, dtype=dtype, batch_invariant=True, row_groups=1)
+    upload_weights(net, eng, L.NET_FORECASTER)
+    return eng
+
+
+@pytest.mark.parametrize("force_igemm2", [False, True], ids=["default-conv-forms", "second-igemm-form"])
+def test_batch_invariant_resnet_rows_do_not_depend_on_their_position_on_ragged_planes(force_igemm2, monkeypatch):
+    """conv_igemm2_kernel<2, true> on flattened-M tiles reduces the GroupNorm statistics per 128-row slab of the
+    n * plane axis; with plane % 128 != 0 (OISST levels 60 x 60, 30 x 30, 15 x 15) a sample's slab partition -- and so the last bits
+    of (mean, 1/std) -- depended on its position in the launch.  A batch_invariant engine now keeps to position-free forms (halo5,
+    2-D tiles, plane % 128 == 0; otherwise the three-kernel path): rows [2, 5) of a 6-row launch, run alone at positions 0..2 with
+    their global row offset, must reproduce bit for bit, eval and with the engine's MC dropout."""
+    if force_igemm2:
+        monkeypatch.setenv("DYF_IGEMM2_MIN_TILES", "1")  # the large-batch forms (what 300 rows select) on this small launch
+    cfg = dict(dim=64, dim_mults=[1, 2, 4], with_time_emb=True, block_dropout=0.3, block_dropout1=0.1, attn_dropout=0.0,
+               resnet_block_groups=8, input_dropout=0.0, upsample_dims=None)
+    P = seeded_unet(64, (1, 2, 4), 2, 1, seed=5)
+    net = mirror(P, cfg, 2, 0, 1, "fp16")
+    eng = _invariant_engine(net, (60, 60), 6)
+    g = torch.Generator().manual_seed(16)
+    x, t = torch.randn(6, 2, 60, 60, generator=g).to(DEV), (torch.arange(6) % 7 + 1).float().to(DEV)
+    eng.form_log(True)
+    full = eng.net_forward(0, x, t, None).clone()
+    forms = eng.form_log_read()
+    eng.form_log(False)
+    print(sorted(forms))
+    if force_igemm2:  # the 15 x 15 and 30 x 30 levels would take the fused flattened-M form; the invariant engine must not
+        assert "conv_igemm2_kernel<2>+gn_fused" not in forms, sorted(forms)
+    part = eng.net_forward(0, x[2:5].contiguous(), t[2:5].contiguous(), None)
+    assert torch.equal(full[2:5], part), float((full[2:5] - part).abs().max())
+    eng.seed(3)
+    eng.set_row_offset(0)
+    full_d = eng.net_forward(0, x, t, None, dropout_mode=1).clone()
+    eng.seed(3)
+    eng.set_row_offset(2)
+    part_d = eng.net_forward(0, x[2:5].contiguous(), t[2:5].contiguous(), None, dropout_mode=1)
+    assert torch.equal(full_d[2:5], part_d), float((full_d[2:5] - part_d).abs().max())
+    assert not torch.equal(full_d, full)
+    eng.close()
+
+
+def test_fused_groupnorm_timeout_fails_the_same_call_and_the_engine_recovers_unfused():
+    """the time-out path of the fused GroupNorm (csrc/gn_fused.h).  With the drill switched on
+    (dyf_debug_gn_fuse: every granule sweep waits for a tag nobody publishes, bound 20 ms instead of 2 s) the launch must still
+    TERMINATE, its output must be NaN-poisoned, and the failure must surface in the SAME call (the wrapper polls dyf_poll_errors after
+    the work completed) -- not in the next one.  The engine then runs the three-kernel GroupNorm path: the repeated call is correct
+    (equal to an engine that never fused, bit for bit) and the fused form stays off."""
+    from dyffusion_amd.engine import EngineError
+    cfg = dict(dim=64, dim_mults=[1, 2, 4], with_time_emb=True, block_dropout=0.0, block_dropout1=0.0, attn_dropout=0.0,
+               resnet_block_groups=8, input_dropout=0.0, upsample_dims=None)
+    P = seeded_unet(64, (1, 2, 4), 2, 1, seed=5)
+    g = torch.Generator().manual_seed(26)
+    nb = 8
+    x, t = torch.randn(nb, 2, 60, 60, generator=g).to(DEV), (torch.arange(nb) % 7 + 1).float().to(DEV)
+    net = mirror(P, cfg, 2, 0, 1, "fp16")
+    net._own_engine(nb, (60, 60))
+    eng = net._engine
+    assert eng.gn_fuse_state() == (True, 0)
+    eng.form_log(True)
+    good = net(x, time=t).clone()
+    forms = eng.form_log_read()
+    assert any(k.endswith("+gn_fused") for k in forms), sorted(forms)
+    eng.debug_gn_fuse(timeout_ticks=2_000_000, force_timeout=True)  # 20 ms
+    import time as _time
+    t0 = _time.perf_counter()
+    with pytest.raises(EngineError, match="timed out"):
+        net(x, time=t)
+    dt = _time.perf_counter() - t0
+    print(f"forced time-out: the call failed after {dt:.2f} s")
+    assert dt < 30.0
+    live, downgrades = eng.gn_fuse_state()
+    assert (live, downgrades) == (False, 1)
+    eng.debug_gn_fuse(0, False)
+    eng.form_log(True)
+    again = net(x, time=t).clone()  # no exception: the failure was consumed by the call that caused it
+    forms = eng.form_log_read()
+    eng.form_log(False)
+    assert not any(k.endswith("+gn_fused") for k in forms), sorted(forms)
+    assert bool(torch.isfinite(again).all())
+    assert rel_rms(again.cpu(), good.cpu()) <= 4e-3
+    eng.close()
+    # the poisoned output itself: a second engine, polling switched off for one call
+    net3 = mirror(P, cfg, 2, 0, 1, "fp16")
+    net3._own_engine(nb, (60, 60))
+    e3 = net3._engine
+    e3.debug_gn_fuse(timeout_ticks=2_000_000, force_timeout=True)
+    e3.poll_errors = lambda *a, **k: None  # (instance attribute shadows the method)
+    bad = net3(x, time=t)
+    torch.cuda.synchronize()
+    assert bool(torch.isnan(bad).all()), "a timed-out sweep must poison what it could not normalise"
+    del e3.poll_errors
+    with pytest.raises(EngineError, match="timed out"):
+        e3.poll_errors()
+    e3.poll_errors()  # reported once
+    e3.close()
+    prev = os.environ.get("DYF_GN_FUSED")
+    os.environ["DYF_GN_FUSED"] = "0"
+    try:
+        net2 = mirror(P, cfg, 2, 0, 1, "fp16")
+        never = net2(x, time=t)
+        assert net2._engine.gn_fuse_state()[0] is False
+        assert torch.equal(never, again)
+        net2._engine.close()
+    finally:
+        if prev is None:
+            os.environ.pop("DYF_GN_FUSED", None)
+        else:
+            os.environ["DYF_GN_FUSED"] = prev
