@@ -385,8 +385,9 @@ def bench_train_steps(dev):
     out["unet_simple_ns_16bit_operands"] = {"workload": out["unet_simple_ns"]["workload"].replace(", fp32", ", fp32 tensors, conv operands "
                                                                                                     "rounded to bf16 in the kernels (opt-in)"),
                                             "batch": B, "ms_per_step": round(1e3 * dt16, 1), "loss": round(loss16, 4),
-                                            "achieved": round(fl / dt16 / 1e12, 1), "unit": "TFLOP/s", "samples_per_s": round(B / dt16, 1),
-                                            "speedup_vs_fp32": round(dt / dt16, 2)}
+                                            "achieved": round(fl / dt16 / 1e12, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                                            "frac": round(fl / dt16 / 1e12 / PEAK_BF16_TFLOPS, 4),  # against the 16-bit MFMA peak: the operands are 16-bit
+                                            "samples_per_s": round(B / dt16, 1), "speedup_vs_fp32": round(dt / dt16, 2)}
     log(f"train step unet_simple B={B}, 16-bit conv operands: {1e3 * dt16:.1f} ms")
     m._engine.close()
     del m
@@ -431,7 +432,8 @@ def bench_train_steps(dev):
                                                                                      "bf16 in the kernels (opt-in)"),
                                             "batch": B, "ms_per_step": round(1e3 * dt16, 1), "loss": round(loss16, 4),
                                             "loss_fp32_operands": round(loss, 4), "achieved": round(fl / dt16 / 1e12, 1),
-                                            "unit": "TFLOP/s", "samples_per_s": round(B / dt16, 1), "speedup_vs_fp32": round(dt / dt16, 2)}
+                                            "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(fl / dt16 / 1e12 / PEAK_BF16_TFLOPS, 4),
+                                            "samples_per_s": round(B / dt16, 1), "speedup_vs_fp32": round(dt / dt16, 2)}
             log(f"train step unet.Unet B={B}, 16-bit conv operands: {1e3 * dt16:.1f} ms (loss {loss16:.4f} vs {loss:.4f})")
         m2._engine.close()
         del m2

@@ -90,6 +90,7 @@ hipError_t launch_conv_stats(const ConvArgs& a, int path, hipStream_t stream, in
 hipError_t launch_conv_gn_fused(const ConvArgs& a, int path, hipStream_t stream, bool* fused);
 int conv_gn_fused_max_slots(int h, int w);
 bool conv_igemm2_tile2d(int ho, int wo);  // conv_igemm2_kernel tiles this output plane 2-D (TH x 16 pixel tiles inside one sample)
+int conv_igemm2_gn_slots_bm128(int ho, int wo);  // ... of its 128-pixel tile form (64-row statistics slabs)
 int conv_igemm2_gn_slots(int ho, int wo);  // slots per sample of the fused conv_igemm2_kernel<2> on an ho x wo output plane (0: not served)  // upper bound of GnFuse::slots on an h x w plane (sizing of GnFuse::gran), 0 = never fused
 int conv_halo5_gn_slots(int h, int w);  // slots per sample of conv_up_halo_kernel<5> on an h x w plane (sizing of gn_part)
 void pack_up2x_weights(const float* w, int cout, int cin, el16_t* out);

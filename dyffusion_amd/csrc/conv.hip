@@ -814,6 +814,8 @@ int conv_gn_fused_max_slots(int h, int w) {
     if (s5 <= GN_FUSE_MAX_SLOTS) best = s5;
     const int si = conv_igemm2_gn_slots(h, w);
     if (si > 0 && si <= GN_FUSE_MAX_SLOTS) best = std::max(best, si);
+    const int s128 = conv_igemm2_gn_slots_bm128(h, w);
+    if (s128 > 0 && s128 <= GN_FUSE_MAX_SLOTS) best = std::max(best, s128);
     return best;
 }
 
@@ -863,8 +865,23 @@ hipError_t launch_conv_gn_fused(const ConvArgs& a_in, int path, hipStream_t stre
         // batch offsets / ranks -- not acceptable to a batch_invariant engine, which then takes the three-kernel path
         const bool position_free = conv_igemm2_tile2d(a.ho, a.wo) || (a.ho * a.wo) % 128 == 0;
         if (G.invariant && !position_free) return hipSuccess;
+        // few tiles: the 128-pixel tile form (half the K chain per wave, twice the workgroups) while the 256-pixel tiles would leave
+        // CUs idle -- DYF_IGEMM2_BM128_BELOW tiles (0 = never); not for batch_invariant engines whose planes are not slab-aligned
+        // (the same position argument as above, with 64-row slabs)
+        const char* b128 = getenv("DYF_IGEMM2_BM128_BELOW");  // read per launch (parity test)
+        const long long bm128_below = b128 ? atoll(b128) : 224;
+        const int slots128 = conv_igemm2_gn_slots_bm128(a.ho, a.wo);
+        const bool free128 = (a.wo % 16 == 0 && a.ho % 8 == 0) || (a.ho * a.wo) % 64 == 0;
+        if (tiles2 >= min_tiles && tiles2 < bm128_below && slots128 > 0 && slots128 <= GN_FUSE_MAX_SLOTS && slots128 <= G.max_slots &&
+            (!G.invariant || free128) && conv_igemm2_supported(b)) {
+            b.gnf.slots = slots128;
+            b.gnf.bm = 128;
+            *fused = true;
+            return launch_conv_igemm2(b, stream);
+        }
         if (tiles2 >= min_tiles && slots > 0 && slots <= GN_FUSE_MAX_SLOTS && slots <= G.max_slots && conv_igemm2_supported(b)) {
             b.gnf.slots = slots;
+            b.gnf.bm = 256;
             *fused = true;
             return launch_conv_igemm2(b, stream);
         }

@@ -54,17 +54,24 @@ constexpr int TH = BM / 16;            // 2-D tile: 16 rows of 16 pixels
 // the 30^2 / 15^2 levels of the ResNet-UNet.  Now one gather (256 + 2 rows) feeds 96 MFMAs per wave, one barrier per window row.
 // Stage layout: rows 0..255 as before (16-byte slots swizzled by (row >> 1) & 7), row 256 = pixel m0 - 1, row 257 = pixel m0 + 256
 // (both unswizzled), row 258 = zeros.
-template <int WN, bool GNF = false, bool SH3 = false>
+// BMT = 128 (round 5; WN = 2 only): 128 pixels x 128 channels per workgroup, waves 2 x 2 of 64 pixels x 64 channels (2 x 2 tiles) --
+// half the K chain per wave and twice the workgroups.  A 256 x 128 tile with K = 9 x 256 keeps one CU's matrix pipe busy for ~25 us
+// whatever the batch; the 15 x 15 level of the ResNet-UNet at 38 rows is 68 such tiles on 256 CUs, 43 us per launch, fourteen
+// launches per forward (profiles/r05f_oisst_nb38): the launcher takes this form while the large tiles leave CUs idle.
+template <int WN, bool GNF = false, bool SH3 = false, int BMT = 256>
 __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(ConvArgs a, int M, int tiles_m, int tiles_n) {
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    static_assert(BMT == 256 || (BMT == 128 && WN == 2), "the 128-pixel tile exists for 128-channel column blocks");
+    constexpr int BM = BMT, A_BYTES = BM * 128, RA = BM / 32, TH = BM / 16;  // (shadow the 256-pixel constants of the namespace)
     constexpr int STAGE_BYTES = SH3 ? (BM + 3) * 128 : A_BYTES;
     constexpr int EPI_OFF = 2 * STAGE_BYTES;             // output staging of the epilogue
     constexpr int LDS_END = EPI_OFF + 4 * 16 * OROW;     // (GNF: the waves' coefficient tables follow)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    constexpr int BN = 64 * WN, MT = WN == 2 ? 4 : 2;  // channels per workgroup, 32-pixel sub-tiles per wave
+    constexpr int BN = 64 * WN, MT = (WN == 2 ? 4 : 2) * BM / 256;  // channels per workgroup, 32-pixel sub-tiles per wave
+    constexpr int SLAB = 32 * MT;                                     // output rows of a wave (its GroupNorm statistics slab)
     constexpr int STEP_BYTES = BN * 128;              // weights of one K step of one column block: BN channels x 64 k bf16
     static_assert(!GNF || WN == 2, "the fused GroupNorm epilogue exists for WN = 2");
     const int wm = WN == 2 ? wave >> 1 : wave, wn = WN == 2 ? wave & 1 : 0;
@@ -359,7 +366,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(ConvArgs a, int M, 
     if constexpr (GNF) {
         const GnFuse& G = a.gnf;
         const uint32_t tag = (*G.epoch << 8) | G.conv_tag;
-        const int slab0 = tm * BM + wm * 128;  // first row of this wave's slab
+        const int slab0 = tm * BM + wm * SLAB;  // first row of this wave's slab
         const int ch0 = tn * BN + wn * 64;     // first channel of this wave's block
         const int oct = a.cout >> 3, cpg = a.cout / G.groups;
         int nA, slotA, nslotsA, nslotsB = 0, slotB = 0;
@@ -371,14 +378,14 @@ __global__ __launch_bounds__(256, 2) void conv_igemm2_kernel(ConvArgs a, int M, 
         } else {
             nA = slab0 / plane;
             g_bnd = (nA + 1) * plane;
-            cross = slab0 + 128 > g_bnd && g_bnd < M;
-            const int fA = (nA * plane) >> 7;
-            slotA = (slab0 >> 7) - fA;
-            nslotsA = ((g_bnd - 1) >> 7) - fA + 1;
+            cross = slab0 + SLAB > g_bnd && g_bnd < M;
+            const int fA = (nA * plane) / SLAB;
+            slotA = slab0 / SLAB - fA;
+            nslotsA = (g_bnd - 1) / SLAB - fA + 1;
             if (cross) {
-                const int fB = g_bnd >> 7;
-                slotB = (slab0 >> 7) - fB;  // = 0: the slab that crosses into a sample is that sample's first
-                nslotsB = ((g_bnd + plane - 1) >> 7) - fB + 1;
+                const int fB = g_bnd / SLAB;
+                slotB = slab0 / SLAB - fB;  // = 0: the slab that crosses into a sample is that sample's first
+                nslotsB = (g_bnd + plane - 1) / SLAB - fB + 1;
             }
         }
         auto publish = [&](int n_img, int slot, bool second) {
@@ -600,6 +607,14 @@ int conv_igemm2_gn_slots(int ho, int wo) {
     return (plane + 127) / 128 + 1;
 }
 
+// ... of the 128-pixel tile form (64-row slabs; its 2-D tiles are 8 rows x 16 pixels)
+int conv_igemm2_gn_slots_bm128(int ho, int wo) {
+    const int plane = ho * wo;
+    if (wo % 16 == 0 && ho % 8 == 0) return (wo / 16) * (ho / 8) * 2;
+    if (plane < 64) return 0;
+    return (plane + 63) / 64 + 1;
+}
+
 // wpk [cout][taps][cin] bf16 -> MFMA fragment order [column block tn (128 ch)][K step = chunk*taps + tap][wn][ks][half]
 // [lane][8 k]: lane (l31, hi) of fragment (wn, ks, half) holds channel tn*128 + wn*64 + half*32 + l31,
 // k = chunk*64 + ks*16 + hi*8 + {0..7} of tap `tap`
@@ -638,6 +653,8 @@ hipError_t conv_igemm2_init() {
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)(conv_igemm2_kernel<2, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL_SH3);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)(conv_igemm2_kernel<2, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL_SH3 + 4096);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)(conv_igemm2_kernel<1, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL_SH3);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)(conv_igemm2_kernel<2, true, false, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL + 4096);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)(conv_igemm2_kernel<2, true, true, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL_SH3 + 4096);
     return e;
 }
 
@@ -659,6 +676,20 @@ hipError_t launch_conv_igemm2(const ConvArgs& a, hipStream_t stream) {
     const bool sh3_on = !(getenv("DYF_IGEMM2_SH3") && atoi(getenv("DYF_IGEMM2_SH3")) == 0);  // (read per launch: tests compare the two forms)
     const bool sh3 = sh3_on && a.kh == 3 && a.kw == 3 && a.stride == 1 && a.pad == 1 && a.ho == a.h && a.wo == a.w && a.wo >= 2 &&
                      !(a.wo % 16 == 0 && a.ho % TH == 0);
+    if (a.gnf.gran != nullptr && a.gnf.bm == 128) {  // the 128-pixel tile form (launch_conv_gn_fused chose it and counted its slots)
+        dyf_form_note("conv_igemm2_kernel<2>+gn_fused", a.n);
+        dyf_form_note("conv_igemm2_kernel<2,bm128>+gn_fused", a.n);
+        if (sh3) dyf_form_note("conv_igemm2_kernel+sh3", a.n);
+        const int tiles_n = a.cout / 128, tiles_m128 = (int)((M + 127) / 128);
+        const bool sh3_128 = sh3_on && a.kh == 3 && a.kw == 3 && a.stride == 1 && a.pad == 1 && a.ho == a.h && a.wo == a.w && a.wo >= 2 &&
+                             !(a.wo % 16 == 0 && a.ho % 8 == 0);
+        // (LDS: the 256-pixel sizes are requested -- an upper bound; two workgroups per CU either way)
+        if (sh3_128)
+            hipLaunchKernelGGL((conv_igemm2_kernel<2, true, true, 128>), dim3(tiles_m128 * tiles_n), dim3(256), 2 * (128 + 3) * 128 + 4 * 16 * OROW + 4096, stream, a, (int)M, tiles_m128, tiles_n);
+        else
+            hipLaunchKernelGGL((conv_igemm2_kernel<2, true, false, 128>), dim3(tiles_m128 * tiles_n), dim3(256), 2 * 128 * 128 + 4 * 16 * OROW + 4096, stream, a, (int)M, tiles_m128, tiles_n);
+        return hipGetLastError();
+    }
     if (a.gnf.gran != nullptr) {  // GroupNorm fused (launch_conv_gn_fused checked the shape): + 4 KB of LDS for the waves' (A, C) tables
         dyf_form_note("conv_igemm2_kernel<2>+gn_fused", a.n);
         if (sh3) dyf_form_note("conv_igemm2_kernel+sh3", a.n);  // (a note of its own: the form log's kernel names stay those of the tile shape)

@@ -31,6 +31,7 @@ struct GnFuse {
     uint32_t conv_tag;         // index of this conv inside the forward (8 bits)
     int max_slots;             // slot stride of `gran` (>= the launch's slots per sample)
     int slots;                 // slots per sample of this launch (set by the launcher)
+    int bm;                    // conv_igemm2_kernel: pixel rows of the workgroup tile the slots were counted for (0 / 256: the default, 128)
     int groups;
     const float* bias;         // conv bias [cout]
     const float* gamma;        // GroupNorm affine [cout]

@@ -493,3 +493,49 @@ def test_fused_groupnorm_timeout_fails_the_same_call_and_the_engine_recovers_unf
             os.environ.pop("DYF_GN_FUSED", None)
         else:
             os.environ["DYF_GN_FUSED"] = prev
+
+
+def test_small_tile_fused_igemm_form_matches_the_large_tile_form_and_the_oracle(monkeypatch):
+    """Round 5: conv_igemm2_kernel<2, true, *, 128> -- the fused-GroupNorm implicit GEMM on 128-pixel tiles (64-row statistics slabs)
+    that the launcher takes while the 256-pixel tiles would leave CUs idle: the 15 x 15 level of the OISST shapes at 38 rows (68
+    large tiles).  Against the 256-pixel form (DYF_IGEMM2_BM128_BELOW=0, read per launch), eval and with the engine's MC dropout
+    (same masks: the streams are keyed by element), against the fp32 oracle on a few rows, and bit-reproducible run to run."""
+    cfg = dict(dim=64, dim_mults=[1, 2, 4], with_time_emb=True, block_dropout=0.3, block_dropout1=0.1, attn_dropout=0.0,
+               resnet_block_groups=8, input_dropout=0.0, upsample_dims=None)
+    P = seeded_unet(64, (1, 2, 4), 2, 1, seed=5)
+    g = torch.Generator().manual_seed(36)
+    nb = 38
+    x, t = torch.randn(nb, 2, 60, 60, generator=g), (torch.arange(nb) % 7 + 1).float()
+    net = mirror(P, cfg, 2, 0, 1, "fp16")
+    net._own_engine(nb, (60, 60))
+    eng = net._engine
+    outs = {}
+    for below in ("0", None):
+        if below is None:
+            monkeypatch.delenv("DYF_IGEMM2_BM128_BELOW", raising=False)
+        else:
+            monkeypatch.setenv("DYF_IGEMM2_BM128_BELOW", below)
+        eng.form_log(True)
+        y_eval = net(x.to(DEV), time=t.to(DEV)).cpu()
+        forms = eng.form_log_read()
+        eng.form_log(False)
+        small = "conv_igemm2_kernel<2,bm128>+gn_fused" in forms
+        assert small == (below is None), sorted(forms)
+        assert "conv_igemm2_kernel<2>+gn_fused" in forms
+        eng.seed(11)
+        y_d = eng.net_forward(0, x.to(DEV), t.to(DEV), None, dropout_mode=1).cpu()
+        eng.seed(11)
+        assert torch.equal(y_d, eng.net_forward(0, x.to(DEV), t.to(DEV), None, dropout_mode=1).cpu())
+        assert torch.equal(y_eval, net(x.to(DEV), time=t.to(DEV)).cpu())
+        outs[below] = (y_eval, y_d)
+    for i, nm in enumerate(("eval", "engine dropout")):
+        e = max(rel_rms(outs[None][i][r], outs["0"][i][r]) for r in range(nb))
+        print(f"128- vs 256-pixel tiles, {nm}: worst row rel-RMS {e:.3e}")
+        assert e <= 4e-3
+    rows = [0, 17, 37]
+    with torch.no_grad():
+        want = nets.resnet_unet_forward(P, cfg, x[rows], t[rows], None)
+    err = max(rel_rms(outs[None][0][r], want[i]) for i, r in enumerate(rows))
+    print(f"128-pixel tiles vs the fp32 oracle: {err:.3e}")
+    assert err <= TOL["fp16"]
+    eng.close()
