@@ -176,11 +176,29 @@ __device__ __host__ __forceinline__ uint32_t keep_threshold16(float p) {
     return keep >= 65536.0f ? 65536u : (uint32_t)keep;
 }
 
+// QUAD form (round 5: the softmax probabilities of Attention, attention.py:70 -- N^2 elements per head, where the keep-word hash was
+// 2.7x the rest of the softmax's vector work): one 32-bit word per FOUR consecutive elements, 8 bits each against an 8-bit
+// threshold.  The keep probability is then k / 256 with k = floor((1 - p) * 256) (>= 1) -- within 2^-8 of 1 - p -- and the survivors are
+// scaled by 256 / k instead of 1 / (1 - p): E[mask * scale] = 1 EXACTLY, as for nn.Dropout; what differs from the reference is the
+// drop rate itself by < 0.4 % absolute (p = 0.1: 0.1016), invisible next to the Monte-Carlo spread of the ensemble it generates.
+// Every other dropout site keeps the 16-bit pair form below (threshold resolution 2^-16).
+__device__ __host__ __forceinline__ uint32_t keep_threshold8(float p) {
+    const float keep = (1.0f - p) * 256.0f;
+    const uint32_t k = keep >= 256.0f ? 256u : (uint32_t)keep;
+    return k < 1u ? 1u : k;
+}
+__device__ __host__ __forceinline__ uint32_t rng_quad_word(uint32_t quad_index, RngKey key) { return rng_pair_word(quad_index, key); }
+
 // element e of the row's NHWC tensor: keep iff its 16-bit slice of pair word e>>1 is below the threshold
 __device__ __host__ __forceinline__ bool rng_keep(uint32_t e, RngKey key, uint32_t thresh16) {
     uint32_t w = rng_pair_word(e >> 1, key);
     uint32_t v = (e & 1u) ? (w >> 16) : (w & 0xffffu);
     return v < thresh16;
+}
+
+__device__ __host__ __forceinline__ bool rng_keep8(uint32_t e, RngKey key, uint32_t thresh8) {
+    const uint32_t w = rng_quad_word(e >> 2, key);
+    return ((w >> (8u * (e & 3u))) & 0xffu) < thresh8;
 }
 
 // Dropout site id (rng_layer_salt argument) of unet_simple's dropout_input; the 12 UNetBlocks are sites 0..11
@@ -194,6 +212,8 @@ struct DropSpec {
     RngKey salt;              // rng_layer_salt(layer slot) (mode 1)
     const uint32_t* row_keys; // device [launch rows][2]: rng_row_key of every row of this launch (mode 1)
     const uint8_t* mask;      // device NHWC uint8 keep mask of the whole launch (mode 2)
+    uint32_t thresh8;         // quad form (attention probabilities, mode 1): keep threshold k of 256 and the matching scale 256 / k
+    float scale8;
 };
 
 // stream key of launch row `n` (batch row inside this launch)

@@ -37,11 +37,17 @@ constexpr int R_STEP_BYTES = 32768;  // weights of one (tap, chunk) step: 256 co
 // (12-pixel halo).  Shapes 1 and 2 let a 52-entry list be tiled as 3 x 16 + 4 with every lane used (13 instead of 16 MFMA tile
 // units per 32 rows); they keep the column-only swizzle key -- lanes of different row sets that read the same column collide in
 // LDS (2- / 4-way), which the LDS pipe (17 % busy in these kernels) absorbs -- and store straight from the registers.
-template <int SP, int SH = 0>
+// TR (dense forms only, round 5): tile rows per wave -- 4 (the form everything above describes), 2 or 1.  A tile is one CU's matrix
+// pipe for ~5.3 us per 64-channel chunk whatever the batch; at a few rows the launches are 80 - 320 such tiles on 256 CUs (one tile
+// time for a third of the chip, or two for a chip and a quarter).  Tiles of 2 / 1 rows are 2 / 4 x as many workgroups of half / a
+// quarter of the K-loop work each (same halo machinery: TR + 2 halo rows, TR + 2 row fragments per super-slot feeding 3 TR x 2
+// MFMAs per (dx, ks)); the weight stream per MFMA grows by the same factor, which is why the large-batch form stays at 4.
+template <int SP, int SH = 0, int TR = 4>
 struct RowsCfg {
     static constexpr int COLS = SP == 1 ? (SH == 1 ? 16 : SH == 2 ? 4 : 32) : 32;  // list entries (columns) per tile row set
     static constexpr int RSETS = 32 / COLS;                                          // row sets of 4 rows each
-    static constexpr int ROWS = R_TH * RSETS;                                        // tile rows of a workgroup
+    static constexpr int ROWS = TR * RSETS;                                          // tile rows of a workgroup
+    static_assert(TR == 4 || (SP != 1 && (TR == 2 || TR == 1)), "short tiles exist for the dense forms");
     static constexpr int W = SP == 1 ? (SH == 1 ? 48 : SH == 2 ? 12 : 72) : 34;  // halo width in pixels
     static constexpr int REAL = (ROWS + 2) * W;       // 204 / 432 / 480 / 408
     static constexpr int PIX = (REAL + 7) / 8 * 8;    // padded to whole DMA instructions (8 pixels each)
@@ -80,11 +86,11 @@ constexpr unsigned rows_woff(int g) { return (unsigned)(((g % 3) * 3 + g / 12) *
 // KS: split-K instance (conv_halo_rows_splitk_kernel, dense forms): the workgroup contracts the chunks [ks_idx * cpt / ksplit,
 // (ks_idx + 1) * cpt / ksplit) only and leaves its raw fp32 accumulators in ConvArgs::splitk_ws[ks_idx][pixel][channel]; the border
 // ring goes into split 0; conv_splitk_finish4_kernel adds the splits in index order and runs the epilogue.
-template <int SP, int SH, bool KS = false>
+template <int SP, int SH, bool KS = false, int TR = 4>
 __device__ __forceinline__ void conv_halo_rows_body(const ConvArgs& a, int tiles_x, int tiles_per_img, int tiles_m, int tiles_n, int bid,
                                                     int ks_idx = 0, int ksplit = 1) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    using H = RowsCfg<SP, SH>;
+    using H = RowsCfg<SP, SH, TR>;
     constexpr int HALO_W = H::W, HALO_REAL = H::REAL, HALO_BYTES = H::BYTES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
@@ -173,7 +179,7 @@ __device__ __forceinline__ void conv_halo_rows_body(const ConvArgs& a, int tiles
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+        for (int t = 0; t < TR; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[nt][t][r] = 0.0f;
     if (!H::PLAIN && (!KS || ks_idx == 0)) {
@@ -184,8 +190,8 @@ __device__ __forceinline__ void conv_halo_rows_body(const ConvArgs& a, int tiles
             const int ring_len = 2 * a.wo + 2 * (a.ho - 2);
             const int X = 2 * col + wpx;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int Y = 2 * (ty0 + R_TH * rs + t) + wpy;
+            for (int t = 0; t < TR; ++t) {
+                const int Y = 2 * (ty0 + TR * rs + t) + wpy;
                 int ring = -1;
                 if (Y == 0) ring = X;
                 else if (Y == a.ho - 1) ring = a.wo + X;
@@ -207,7 +213,7 @@ __device__ __forceinline__ void conv_halo_rows_body(const ConvArgs& a, int tiles
     }
 
     int cl = col - cbase;  // halo column of this lane's pixel at dx = 0 (>= 1); halo row of tile row t at dy = 0 is 4 rs + t + 1
-    const unsigned rs_off = (unsigned)(rs * R_TH * H::ROW_BYTES);  // the lane's row set inside the halo (0 unless a sparse shape)
+    const unsigned rs_off = (unsigned)(rs * TR * H::ROW_BYTES);  // the lane's row set inside the halo (0 unless a sparse shape)
     const unsigned lds_base = (unsigned)(uintptr_t)LDS_PTR(smem);
     const unsigned w_voff = (unsigned)lane * 16u;
 
@@ -239,9 +245,11 @@ __device__ __forceinline__ void conv_halo_rows_body(const ConvArgs& a, int tiles
         }                                                                                                    \
         pa = (ax ^ (unsigned)(((SN) & 3) << 5)) + ab;                                                        \
     }
-#define RD(SET, R) DSRO(pq[SET][R], pa, (R) * H::ROW_BYTES)
+#define RD(SET, R) if constexpr ((R) < TR + 2) { DSRO(pq[SET][R], pa, (R) * H::ROW_BYTES) }
 #define MF(NT, T, ASET, BSET, DY)                                                                            \
-    acc[NT][T] = DYF_MFMA_32x32x16(__builtin_bit_cast(el16x8_t, bq[BSET][NT]), pq[ASET][(T) + (DY)], acc[NT][T], 0, 0, 0);
+    if constexpr ((T) < TR) {                                                                                \
+        acc[NT][T] = DYF_MFMA_32x32x16(__builtin_bit_cast(el16x8_t, bq[BSET][NT]), pq[ASET][(T) + (DY)], acc[NT][T], 0, 0, 0); \
+    }
     // mini-slot G of the chunk (dy = G % 3): 8 MFMAs on ring set G % 6; requests the fragments of mini-slot G + 5
 #define WSRC(G) ((G) < 36 ? soff_c + rows_woff((G) % 36) : soff_n + rows_woff((G) % 36))
 #define MS(G, ASET, LSET, R0, R1, LOAD, WAITL)                                                               \
@@ -332,7 +340,7 @@ __device__ __forceinline__ void conv_halo_rows_body(const ConvArgs& a, int tiles
     const uint32_t row0 = (uint32_t)n_img * (uint32_t)(a.ho * a.wo * a.cout);
     const int ch_blk = H::PLAIN ? tn * 256 + wave * 64 : tn * 64;
     const uint32_t ci_base = (uint32_t)((a.coef_div > 1 ? n_img / a.coef_div : n_img) * a.coef_stride + ch_blk + 4 * hi);
-    const int ry0 = ty0 + R_TH * rs;  // first of the lane's four tile rows
+    const int ry0 = ty0 + TR * rs;  // first of the lane's tile rows
     const uint32_t m0 = H::PLAIN ? (uint32_t)((n_img * a.ho + ty0) * a.wo + col)
                                 : (uint32_t)((n_img * a.ho + 2 * ry0 + wpy) * a.wo + 2 * col + wpx);
     const uint32_t o0 = m0 * (uint32_t)a.cout + (uint32_t)ch_blk;
@@ -346,7 +354,7 @@ __device__ __forceinline__ void conv_halo_rows_body(const ConvArgs& a, int tiles
         // raw fp32 partial sums, [split][output element] in the layout of the (dense NHWC) output tensor
         float* ws = a.splitk_ws + (size_t)ks_idx * ((size_t)a.n * a.ho * a.wo * a.cout);
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+        for (int t = 0; t < TR; ++t)
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
@@ -381,7 +389,7 @@ __device__ __forceinline__ void conv_halo_rows_body(const ConvArgs& a, int tiles
             const uint32_t row_base = store0 - (uint32_t)l31 * pstride;             // pixel 0 of this wave's tile row 0
             const int rpx = lane >> 3, rch = lane & 7;                              // read-back role: (pixel 8 k + rpx, 16-byte chunk)
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
+            for (int t = 0; t < TR; ++t) {
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
@@ -441,7 +449,7 @@ __device__ __forceinline__ void conv_halo_rows_body(const ConvArgs& a, int tiles
             const uint32_t row_base = (uint32_t)((n_img * a.ho + 2 * ty0 + wpy) * a.up_wo_store) * (uint32_t)a.cout + (uint32_t)(tn * 64);
             const int rpx = lane >> 3, rch = lane & 7;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
+            for (int t = 0; t < TR; ++t) {
                 uint4 o[2][2];
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt)
@@ -505,7 +513,7 @@ __device__ __forceinline__ void conv_halo_rows_body(const ConvArgs& a, int tiles
                 }
             const int rpx = lane >> 3, rch = lane & 7;  // read-back role: (slot 8 k + rpx, 16-byte chunk)
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
+            for (int t = 0; t < TR; ++t) {
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
@@ -561,7 +569,7 @@ __device__ __forceinline__ void conv_halo_rows_body(const ConvArgs& a, int tiles
                 cc[g2][4] = cc1.x * ps; cc[g2][5] = cc1.y * ps; cc[g2][6] = cc1.z * ps; cc[g2][7] = cc1.w * ps;
             }
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
+            for (int t = 0; t < TR; ++t) {
 #pragma unroll
                 for (int g2 = 0; g2 < 2; ++g2) {
                     const int cg0 = nt * 32 + 16 * g2;
@@ -614,6 +622,32 @@ __global__ __launch_bounds__(256, 2) void conv_halo_rows_kernel(ConvArgs a, int 
 // conv_splitk_finish4_kernel adds them in split order and runs the epilogue: the K chain of a workgroup and the idle part of the
 // chip shrink by the factor.  The summation order of an output element depends on the factor only, which the launcher derives from
 // the tile count of ConvArgs::n_sel rows when the engine pins the forms.
+// short tiles (RowsCfg TR = 2 / 1): dense upsample form (SP = 0) and plain 3x3 form (SP = 2)
+template <int SP, int TR>
+__global__ __launch_bounds__(256, 2) void conv_halo_rows_tr_kernel(ConvArgs a, int tiles_x, int tiles_per_img, int tiles_m, int tiles_n) {
+    conv_halo_rows_body<SP, 0, false, TR>(a, tiles_x, tiles_per_img, tiles_m, tiles_n, (int)blockIdx.x);
+}
+
+// Tile rows per wave of a dense launch of `tiles4` four-row tiles (counted for ConvArgs::n_sel rows when the engine pins the forms).
+// A CU works through its workgroups at the rate of its matrix pipe whether one or two are resident, so what short tiles buy is
+// GRANULARITY: launches that leave CUs idle (<= 128 tiles: halves / quarters spread over twice / four times the CUs) or end in a
+// ragged round (256 < tiles <= 384: 2.5 half-tiles per CU instead of 2 whole ones on a quarter of the chip).  DYF_ROWS_TR = 4 / 2 /
+// 1 forces a shape (read per launch); measured in DESIGN.md 5 (round 5).
+static int rows_tile_rows(long long tiles4, int h) {
+    if (const char* f = getenv("DYF_ROWS_TR")) {
+        const int t = atoi(f);
+        if ((t == 1 || t == 2 || t == 4) && h % t == 0) return t;
+    }
+    // measured (NS decoder, us per launch with 4- / 2- / 1-row tiles; dec3 = 16 tiles per row, dec4 = 64, dec2 = 8): dec3 at 4 rows
+    // 43.3 / 36.8 / 36.8, at 7 rows 51.2 / 39.7 / 55.7, at 10 rows 52.8 / 60.3 / 76.9, at 20 rows 101.7 / 93.8 / 128.5; dec4 at 1 row
+    // 30.5 / 22.0 / 21.8, at 2 rows 31.4 / 24.7 / 32.5, at 4 rows 36.6 / 40.1 / 54.4; dec2 at 10 rows 53.3 (split-K) / 48.5 / 82.9, at 14
+    // rows 61.8 / 54.1 / 86.8, at 40 rows 166.6 / 157.9 / 230.8 -- one-row tiles never win; at <= 32 tiles the four-row tiles with
+    // split-K (rows_splitk_factor) are as good or better (dec3 at one row 31.4 against 34.8)
+    if (tiles4 > 32 && tiles4 <= 128) return 2;
+    if (tiles4 > 256 && tiles4 <= 384) return 2;
+    return 4;
+}
+
 template <int SP>
 __global__ __launch_bounds__(256, 2) void conv_halo_rows_splitk_kernel(ConvArgs a, int tiles_x, int tiles_per_img, int tiles_m, int tiles_n) {
     conv_halo_rows_body<SP, 0, true>(a, tiles_x, tiles_per_img, tiles_m, tiles_n, (int)blockIdx.x, (int)blockIdx.y, a.splitk);
@@ -729,6 +763,14 @@ hipError_t conv_halo_rows_init() {
         e = hipFuncSetAttribute((const void*)conv_halo_rows_persistent_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 RowsCfg<0>::LDS_TOTAL);
     if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)(conv_halo_rows_tr_kernel<0, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (RowsCfg<0, 0, 2>::LDS_TOTAL));
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)(conv_halo_rows_tr_kernel<0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (RowsCfg<0, 0, 1>::LDS_TOTAL));
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)(conv_halo_rows_tr_kernel<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (RowsCfg<2, 0, 2>::LDS_TOTAL));
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)(conv_halo_rows_tr_kernel<2, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (RowsCfg<2, 0, 1>::LDS_TOTAL));
+    if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)conv_halo_rows_splitk_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 RowsCfg<0>::LDS_TOTAL);
     if (e == hipSuccess)
@@ -784,7 +826,18 @@ hipError_t launch_conv_halo_rows_up(const ConvArgs& a, hipStream_t stream) {
     if (sparse && exp1316) tiles_m = tiles_m * 13 / 16;
 #endif
     if (!sparse) {
-        const long long sel = (long long)(a.n_sel > 0 ? a.n_sel : a.n) * tiles_per_img * tiles_n;
+        const long long sel4 = (long long)(a.n_sel > 0 ? a.n_sel : a.n) * tiles_per_img * tiles_n;
+        const int tr = rows_tile_rows(sel4, a.h);
+        if (tr != 4) {
+            const int tpi = tiles_x * (a.h / tr), tm = a.n * tpi;
+            dyf_form_note(tr == 2 ? "conv_halo_rows_kernel<0>+tr2" : "conv_halo_rows_kernel<0>+tr1", a.n);
+            if (tr == 2)
+                hipLaunchKernelGGL((conv_halo_rows_tr_kernel<0, 2>), dim3(tm * tiles_n), dim3(256), (RowsCfg<0, 0, 2>::LDS_TOTAL), stream, a, tiles_x, tpi, tm, tiles_n);
+            else
+                hipLaunchKernelGGL((conv_halo_rows_tr_kernel<0, 1>), dim3(tm * tiles_n), dim3(256), (RowsCfg<0, 0, 1>::LDS_TOTAL), stream, a, tiles_x, tpi, tm, tiles_n);
+            return hipGetLastError();
+        }
+        const long long sel = sel4;
         const long long m_cout = (long long)a.n * a.ho * a.wo * a.cout;
         const int sk = rows_splitk_factor(a, sel, (long long)tiles_m * tiles_n, (a.c0 + a.c1) >> 6, m_cout);
         if (sk > 1) {
@@ -815,6 +868,16 @@ hipError_t launch_conv_halo_rows3(const ConvArgs& a, hipStream_t stream) {
     const int tiles_m = a.n * tiles_per_img, tiles_n = a.cout / 256;
     {
         const long long sel = (long long)(a.n_sel > 0 ? a.n_sel : a.n) * tiles_per_img * tiles_n;
+        const int tr = rows_tile_rows(sel, a.h);
+        if (tr != 4) {
+            const int tpi = tiles_x * (a.h / tr), tm = a.n * tpi;
+            dyf_form_note(tr == 2 ? "conv_halo_rows_kernel<2>+tr2" : "conv_halo_rows_kernel<2>+tr1", a.n);
+            if (tr == 2)
+                hipLaunchKernelGGL((conv_halo_rows_tr_kernel<2, 2>), dim3(tm * tiles_n), dim3(256), (RowsCfg<2, 0, 2>::LDS_TOTAL), stream, a, tiles_x, tpi, tm, tiles_n);
+            else
+                hipLaunchKernelGGL((conv_halo_rows_tr_kernel<2, 1>), dim3(tm * tiles_n), dim3(256), (RowsCfg<2, 0, 1>::LDS_TOTAL), stream, a, tiles_x, tpi, tm, tiles_n);
+            return hipGetLastError();
+        }
         const int sk = rows_splitk_factor(a, sel, (long long)tiles_m * tiles_n, (a.c0 + a.c1) >> 6, (long long)a.n * a.ho * a.wo * a.cout);
         if (sk > 1) {
             ConvArgs b = a;

@@ -2041,6 +2041,8 @@ dyf_status dyf_op_attention_dropout(dyf_engine* e, const uint16_t* qkv_dev, int3
         a.drop.mode = 1;
         a.drop.scale = 1.0f / (1.0f - p);
         a.drop.thresh16 = keep_threshold16(p);
+        a.drop.thresh8 = keep_threshold8(p);
+        a.drop.scale8 = 256.0f / (float)a.drop.thresh8;
         a.drop.salt = rng_layer_salt(0u);
         a.drop.row_keys = e->row_keys;
     }

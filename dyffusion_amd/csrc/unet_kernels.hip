@@ -1698,9 +1698,11 @@ __device__ __forceinline__ RngKey attn_drop_key(const DropSpec& d, int n, uint32
 __device__ __forceinline__ float attn_drop(float p, const DropSpec& d, RngKey key, uint32_t bh, uint32_t i, uint32_t j,
                                            uint32_t n) {
     if (d.mode == 0) return p;
-    const bool keep = d.mode == 1 ? rng_keep(i * n + j, key, d.thresh16) : (d.mask[((size_t)bh * n + i) * n + j] != 0);
-    return keep ? p * d.scale : 0.0f;
+    if (d.mode == 1) return rng_keep8(i * n + j, key, d.thresh8) ? p * d.scale8 : 0.0f;  // quad form (common.h)
+    return d.mask[((size_t)bh * n + i) * n + j] != 0 ? p * d.scale : 0.0f;
 }
+// scale of the survivors: engine streams use the quad form's 256 / k, injected masks the reference's 1 / (1 - p)
+__device__ __forceinline__ float attn_drop_scale(const DropSpec& d) { return d.mode == 1 ? d.scale8 : d.scale; }
 
 // One thread per query, keys/values of the head streamed through LDS in tiles of 64, online softmax in fp32.
 __global__ __launch_bounds__(64) void attention_kernel(AttnArgs a) {
@@ -1852,14 +1854,16 @@ __global__ __launch_bounds__(256) void flash_attention_kernel(AttnArgs a) {
             }
         }
         if (VARIANT == 2) {
-            const uint32_t th = a.drop.thresh16;
-            const float dsc = a.drop.scale;
-            const uint32_t e0 = (uint32_t)q * (uint32_t)N + (uint32_t)(jb + 4 * hi);  // even: N even, jb and 4*hi multiples of 4
+            const uint32_t th = a.drop.thresh8;
+            const float dsc = a.drop.scale8;
+            const uint32_t e0 = (uint32_t)q * (uint32_t)N + (uint32_t)(jb + 4 * hi);  // a multiple of 4: N % 4 == 0, jb and 4*hi are
 #pragma unroll
-            for (int pr = 0; pr < 8; ++pr) {  // registers 2*pr, 2*pr + 1: keys e0 + 8*(pr >> 1) + 2*(pr & 1) + {0, 1}
-                const uint32_t w = rng_pair_word((e0 + 8u * (uint32_t)(pr >> 1) + 2u * (uint32_t)(pr & 1)) >> 1, dkey);
-                p[2 * pr] = (w & 0xffffu) < th ? p[2 * pr] * dsc : 0.0f;
-                p[2 * pr + 1] = (w >> 16) < th ? p[2 * pr + 1] * dsc : 0.0f;
+            for (int g = 0; g < 4; ++g) {  // registers 4g .. 4g + 3: keys e0 + 8g + {0..3} = ONE quad word (common.h rng_keep8)
+                const uint32_t w = rng_quad_word((e0 + 8u * (uint32_t)g) >> 2, dkey);
+                p[4 * g] = (w & 0xffu) < th ? p[4 * g] * dsc : 0.0f;
+                p[4 * g + 1] = ((w >> 8) & 0xffu) < th ? p[4 * g + 1] * dsc : 0.0f;
+                p[4 * g + 2] = ((w >> 16) & 0xffu) < th ? p[4 * g + 2] * dsc : 0.0f;
+                p[4 * g + 3] = (w >> 24) < th ? p[4 * g + 3] * dsc : 0.0f;
             }
         }
         psum += __shfl_xor(psum, 32, 64);
@@ -1895,7 +1899,7 @@ __global__ __launch_bounds__(256) void flash_attention_kernel(AttnArgs a) {
         if (whole && a.drop.mode == 0) {
             subtile(j0, 0, std::integral_constant<int, 1>{});
             subtile(j0 + 32, 1, std::integral_constant<int, 1>{});
-        } else if (whole && a.drop.mode == 1 && (N & 1) == 0 && (qb + 1) * 128 <= N) {
+        } else if (whole && a.drop.mode == 1 && (N & 3) == 0 && (qb + 1) * 128 <= N) {
             subtile(j0, 0, std::integral_constant<int, 2>{});
             subtile(j0 + 32, 1, std::integral_constant<int, 2>{});
         } else {
@@ -2047,20 +2051,22 @@ __device__ __forceinline__ void fa2_subtile(const AttnArgs& a, const el16_t* kf0
         for (int r = 0; r < 16; r += 2) l2[b] += fa_f32x2{p[r], p[r + 1]};
         const int q = q0 + 32 * b;
         if (VARIANT == 2) {
-            const uint32_t th = a.drop.thresh16;
-            const uint32_t e0 = (uint32_t)q * (uint32_t)N + (uint32_t)(jb + 4 * hi);  // even: N even, jb and 4*hi multiples of 4
+            const uint32_t th = a.drop.thresh8;
+            const uint32_t e0 = (uint32_t)q * (uint32_t)N + (uint32_t)(jb + 4 * hi);  // a multiple of 4: N % 4 == 0, jb and 4*hi are
 #pragma unroll
-            for (int pr = 0; pr < 8; ++pr) {  // registers 2*pr, 2*pr + 1: keys e0 + 8*(pr >> 1) + 2*(pr & 1) + {0, 1}
-                const uint32_t w = rng_pair_word((e0 + 8u * (uint32_t)(pr >> 1) + 2u * (uint32_t)(pr & 1)) >> 1, dkey);
-                p[2 * pr] = (w & 0xffffu) < th ? p[2 * pr] : 0.0f;
-                p[2 * pr + 1] = (w >> 16) < th ? p[2 * pr + 1] : 0.0f;
+            for (int g = 0; g < 4; ++g) {  // registers 4g .. 4g + 3: keys e0 + 8g + {0..3} = ONE quad word
+                const uint32_t w = rng_quad_word((e0 + 8u * (uint32_t)g) >> 2, dkey);
+                p[4 * g] = (w & 0xffu) < th ? p[4 * g] : 0.0f;
+                p[4 * g + 1] = ((w >> 8) & 0xffu) < th ? p[4 * g + 1] : 0.0f;
+                p[4 * g + 2] = ((w >> 16) & 0xffu) < th ? p[4 * g + 2] : 0.0f;
+                p[4 * g + 3] = (w >> 24) < th ? p[4 * g + 3] : 0.0f;
             }
         } else if (VARIANT == 0 && DROP) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int j = jb + (r & 3) + 8 * (r >> 2) + 4 * hi;
                 const bool keep = j < N && q < N &&
-                                  (a.drop.mode == 1 ? rng_keep((uint32_t)q * (uint32_t)N + (uint32_t)j, dkey, a.drop.thresh16)
+                                  (a.drop.mode == 1 ? rng_keep8((uint32_t)q * (uint32_t)N + (uint32_t)j, dkey, a.drop.thresh8)
                                                     : (a.drop.mask[((size_t)bh * N + q) * N + j] != 0));
                 p[r] = keep ? p[r] : 0.0f;
             }
@@ -2187,7 +2193,7 @@ __global__ __launch_bounds__(256, QB == 2 ? FA2_MINW2 : FA2_MINW) void flash_att
 #pragma nounroll
             for (int st = 0; st < 2; ++st)
                 fa2_subtile<1, false, QB, NEGM>(a, kf0, kf1, vf0, qf, o, negm, m, l2, first, j0 + 32 * st, st, q0, N, hi, dkey, (uint32_t)bh, aone, bm);
-        } else if (DROP && whole && a.drop.mode == 1 && (N & 1) == 0 && (qb + 1) * QG <= N) {
+        } else if (DROP && whole && a.drop.mode == 1 && (N & 3) == 0 && (qb + 1) * QG <= N) {
 #pragma nounroll
             for (int st = 0; st < 2; ++st)
                 fa2_subtile<2, DROP, QB, NEGM>(a, kf0, kf1, vf0, qf, o, negm, m, l2, first, j0 + 32 * st, st, q0, N, hi, dkey, (uint32_t)bh, aone, bm);
@@ -2203,7 +2209,7 @@ __global__ __launch_bounds__(256, QB == 2 ? FA2_MINW2 : FA2_MINW) void flash_att
         const int q = q0 + 32 * b;
         if (q >= N) continue;
         // O^T[d][q]: lane (q, hi) holds d = (r&3) + 8(r>>2) + 4hi  -> four 8-byte stores of 4 consecutive channels
-        const float inv = (DROP ? a.drop.scale : 1.0f) / l;
+        const float inv = (DROP ? attn_drop_scale(a.drop) : 1.0f) / l;
         el16_t* op = a.out + ((size_t)n * N + q) * hd + h * 32;  // "b h (x y) d -> b (h d) x y"
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -2402,15 +2408,18 @@ __device__ __forceinline__ void fa4_step(const AttnArgs& a, fa_f32x16& sc_cur, f
     }
     l2 += ts;  // the normaliser is accumulated BEFORE dropout (attention.py:69-70)
     if (DROP) {
-        const uint32_t th = a.drop.thresh16;
-        // element q * N + jb + 4 hi (even: N even, jb and 4 hi multiples of 4) -> pair index / 2; wq = the Weyl value of the
-        // lane's pair (q * N + 4 hi) / 2, the sub-tile adds (jb / 2) * RNG_WEYL (scalar) and register pair pr a constant
-        const uint32_t w0 = (uint32_t)q + (uint32_t)(jb >> 1) * RNG_WEYL;
+        const uint32_t th = a.drop.thresh8;
+        // QUAD form (common.h rng_keep8): element q * N + jb + 4 hi is a multiple of 4 (N % 4 == 0) -> quad index / 4; what arrives as
+        // `q` is the Weyl value of the lane's quad (q * N + 4 hi) / 4, the sub-tile adds (jb / 4) * RNG_WEYL (scalar) and register group g
+        // (keys jb + 4 hi + 8 g + {0..3}) the constant 2 g * RNG_WEYL: FOUR hashes per 16 probabilities (eight in the pair form)
+        const uint32_t w0 = (uint32_t)q + (uint32_t)(jb >> 2) * RNG_WEYL;
 #pragma unroll
-        for (int pr = 0; pr < 8; ++pr) {  // registers 2*pr, 2*pr + 1: keys jb + 4 hi + 8*(pr >> 1) + 2*(pr & 1) + {0, 1}
-            const uint32_t w = rng_pair_mix(w0 + (4u * (uint32_t)(pr >> 1) + (uint32_t)(pr & 1)) * RNG_WEYL, dkey);
-            p[2 * pr] = (w & 0xffffu) < th ? p[2 * pr] : 0.0f;
-            p[2 * pr + 1] = (w >> 16) < th ? p[2 * pr + 1] : 0.0f;
+        for (int g = 0; g < 4; ++g) {
+            const uint32_t w = rng_pair_mix(w0 + (2u * (uint32_t)g) * RNG_WEYL, dkey);
+            p[4 * g] = (w & 0xffu) < th ? p[4 * g] : 0.0f;
+            p[4 * g + 1] = ((w >> 8) & 0xffu) < th ? p[4 * g + 1] : 0.0f;
+            p[4 * g + 2] = ((w >> 16) & 0xffu) < th ? p[4 * g + 2] : 0.0f;
+            p[4 * g + 3] = (w >> 24) < th ? p[4 * g + 3] : 0.0f;
         }
     }
 #if FA4_MFMA_SUM
@@ -2488,7 +2497,7 @@ __global__ __launch_bounds__(64 * NW, FA4_MINW) void flash_attention4_kernel(Att
     bool first = true, biased = false;
     const RngKey dkey = DROP ? attn_drop_key(a.drop, n, (uint32_t)h) : RngKey{0u, 0u};
     // DROP: what the steps receive as "q" is the Weyl value of the lane's first keep-word pair, (q0 * N + 4 hi) / 2
-    const int qarg = DROP ? (int)rng_weyl(((uint32_t)q0 * (uint32_t)N + 4u * (uint32_t)hi) >> 1, dkey) : q0;
+    const int qarg = DROP ? (int)rng_weyl(((uint32_t)q0 * (uint32_t)N + 4u * (uint32_t)hi) >> 2, dkey) : q0;
 
     // staging role: thread -> (key, 16-B chunk of 8 channels); NW = 4: every thread carries its K and its V piece, NW = 8: the
     // threads of waves 0-3 carry K, those of waves 4-7 V.  Rows beyond the sequence are CLAMPED to the last row (finite values;
@@ -2570,7 +2579,7 @@ __global__ __launch_bounds__(64 * NW, FA4_MINW) void flash_attention4_kernel(Att
     const float l = ll + __shfl_xor(ll, 32, 64);
     if (q0 >= N) return;
     // O^T[d][q]: lane (q, hi) holds d = (r&3) + 8(r>>2) + 4hi  -> four 8-byte stores of 4 consecutive channels
-    const float inv = (DROP ? a.drop.scale : 1.0f) / l;
+    const float inv = (DROP ? attn_drop_scale(a.drop) : 1.0f) / l;
     el16_t* op = a.out + ((size_t)n * N + q0) * hd + h * 32;  // "b h (x y) d -> b (h d) x y"
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -2599,7 +2608,7 @@ hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
         // 512 tokens stays on four waves (more workgroups)
         static const int nw_env = getenv("DYF_FLASH_NW") ? atoi(getenv("DYF_FLASH_NW")) : 8;
         const int nw = nw_env == 16 && a.hw >= 2048 ? 16 : nw_env >= 8 && a.hw >= 512 ? 8 : 4;
-        const bool v4 = flash >= 3 && (!drop || (a.drop.mode == 1 && (a.hw & 1) == 0 && a.hw % (32 * nw) == 0));
+        const bool v4 = flash >= 3 && (!drop || (a.drop.mode == 1 && (a.hw & 3) == 0 && a.hw % (32 * nw) == 0));
         if (v4) {
             dyf_form_note(nw == 16 ? "flash_attention4_kernel<NW=16>" : nw == 8 ? "flash_attention4_kernel<NW=8>" : "flash_attention4_kernel<NW=4>", a.n);
             const int qb4 = (a.hw + 32 * nw - 1) / (32 * nw);

@@ -87,6 +87,8 @@ struct DropCtx {  // walks the dropout sites in execution order (same order as t
         d.mode = o->dropout_mode;
         d.scale = 1.0f / (1.0f - p);
         d.thresh16 = keep_threshold16(p);
+        d.thresh8 = keep_threshold8(p);
+        d.scale8 = 256.0f / (float)d.thresh8;
         d.salt = rng_layer_salt((uint32_t)site++);
         d.row_keys = e->row_keys;
         if (d.mode == 2) {

@@ -228,6 +228,7 @@ def test_rows_splitk_upsample_conv_matches_torch_and_the_unsplit_kernel(engine, 
     wt = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
     scale = 1.0 + 0.3 * torch.randn(n, cout, generator=g)
     shift = 0.2 * torch.randn(n, cout, generator=g)
+    monkeypatch.setenv("DYF_ROWS_TR", "4")  # (short tiles are another round-5 form: tested below)
     monkeypatch.setenv("DYF_HALO_SPLITK", "0")
     monkeypatch.setenv("DYF_UP_BORDER_SPLIT_ROWS", "0")
     old, forms0 = _form_log(engine, lambda: engine.op_upconv2d(x.cuda(), wt, scale.cuda(), shift.cuda(), act=1).float().cpu())
@@ -262,6 +263,7 @@ def test_rows_splitk_plain_conv_matches_torch_and_the_unsplit_kernel(engine, cas
     scale = 1.0 + 0.3 * torch.randn(n, cout, generator=g)
     shift = 0.2 * torch.randn(n, cout, generator=g)
     monkeypatch.setenv("DYF_HALO3_MIN_TILES", "1")
+    monkeypatch.setenv("DYF_ROWS_TR", "4")
     monkeypatch.setenv("DYF_HALO_SPLITK", "0")
     old, forms0 = _form_log(engine, lambda: engine.op_conv2d(x.cuda(), wt, 1, 1, scale.cuda(), shift.cuda(), act=2, path=1).float().cpu())
     assert "conv_halo_rows_kernel<2>" in forms0, sorted(forms0)
@@ -276,3 +278,50 @@ def test_rows_splitk_plain_conv_matches_torch_and_the_unsplit_kernel(engine, cas
     for sl in [(slice(None), 0), (slice(None), -1), (slice(None), slice(None), 0), (slice(None), slice(None), -1)]:
         assert rel_rms(y[sl], want[sl]) <= 5e-3, sl
     assert rel_rms(y, old) <= 2.5e-3
+
+
+@pytest.mark.parametrize("tr", [2, 1])
+@pytest.mark.parametrize("case", [(2, 32, 32, 256, 128), (1, 64, 64, 128, 64), (3, 40, 64, 192, 128)], ids=lambda c: "x".join(map(str, c)))
+def test_short_tile_rows_forms_reproduce_the_four_row_tiles_bitwise_upsample(engine, case, tr, monkeypatch):
+    """Round 5: conv_halo_rows_tr_kernel<0, 2 / 1> -- the fused x2-upsample conv on tiles of 2 / 1 rows per wave (2 / 4 x the
+    workgroups for under-filled launches).  Same operands, same K order per output element as the four-row tiles: bit-identical."""
+    n, h, w, cin, cout = case
+    g = torch.Generator().manual_seed(sum(case) + 21)
+    x = torch.randn(n, h, w, cin, generator=g).to(torch.bfloat16)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    scale = 1.0 + 0.3 * torch.randn(n, cout, generator=g)
+    shift = 0.2 * torch.randn(n, cout, generator=g)
+    monkeypatch.setenv("DYF_HALO_SPLITK", "0")
+    monkeypatch.setenv("DYF_ROWS_TR", "4")
+    ref, forms0 = _form_log(engine, lambda: engine.op_upconv2d(x.cuda(), wt, scale.cuda(), shift.cuda(), act=1).float().cpu())
+    assert "conv_halo_rows_kernel<0>" in forms0 and not any("+tr" in k for k in forms0), sorted(forms0)
+    monkeypatch.setenv("DYF_ROWS_TR", str(tr))
+    y, forms = _form_log(engine, lambda: engine.op_upconv2d(x.cuda(), wt, scale.cuda(), shift.cuda(), act=1).float().cpu())
+    assert f"conv_halo_rows_kernel<0>+tr{tr}" in forms, sorted(forms)
+    assert torch.equal(y, ref), float((y - ref).abs().max())
+    up = F.interpolate(x.float().permute(0, 3, 1, 2), scale_factor=2, mode="bilinear")
+    want = F.relu(F.conv2d(up, wt, None, 1, 1) * scale[:, :, None, None] + shift[:, :, None, None]).permute(0, 2, 3, 1)
+    assert rel_rms(y, want) <= 6e-3
+
+
+@pytest.mark.parametrize("tr", [2, 1])
+@pytest.mark.parametrize("case", [(2, 32, 32, 256, 256), (1, 8, 64, 128, 512)], ids=lambda c: "x".join(map(str, c)))
+def test_short_tile_rows_forms_reproduce_the_four_row_tiles_bitwise_plain(engine, case, tr, monkeypatch):
+    """conv_halo_rows_tr_kernel<2, 2 / 1>: the plain 3x3 / 256-channel-block form on short tiles."""
+    n, h, w, cin, cout = case
+    g = torch.Generator().manual_seed(sum(case) + 23)
+    x = torch.randn(n, h, w, cin, generator=g).to(torch.bfloat16)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    scale = 1.0 + 0.3 * torch.randn(n, cout, generator=g)
+    shift = 0.2 * torch.randn(n, cout, generator=g)
+    monkeypatch.setenv("DYF_HALO3_MIN_TILES", "1")
+    monkeypatch.setenv("DYF_HALO_SPLITK", "0")
+    monkeypatch.setenv("DYF_ROWS_TR", "4")
+    ref, forms0 = _form_log(engine, lambda: engine.op_conv2d(x.cuda(), wt, 1, 1, scale.cuda(), shift.cuda(), act=2, path=1).float().cpu())
+    assert "conv_halo_rows_kernel<2>" in forms0 and not any("+tr" in k for k in forms0), sorted(forms0)
+    monkeypatch.setenv("DYF_ROWS_TR", str(tr))
+    y, forms = _form_log(engine, lambda: engine.op_conv2d(x.cuda(), wt, 1, 1, scale.cuda(), shift.cuda(), act=2, path=1).float().cpu())
+    assert f"conv_halo_rows_kernel<2>+tr{tr}" in forms, sorted(forms)
+    assert torch.equal(y, ref), float((y - ref).abs().max())
+    want = reference(x, wt, 1, 1, scale, shift, 2)
+    assert rel_rms(y, want) <= 4e-3

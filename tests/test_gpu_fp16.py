@@ -176,3 +176,35 @@ def test_config5_h32_rollout_properties():
         assert torch.equal(full[k], eager[k]), k
         assert torch.equal(full[k][:1], r0[k]) and torch.equal(full[k][1:], r1[k]), k
     assert not torch.equal(full["t32_preds"][0], full["t32_preds"][1])
+
+
+@pytest.mark.parametrize("p", [0.1, 0.3, 0.6])
+def test_attention_probability_dropout_quad_form_keep_rate_and_unbiasedness(p):
+    """Round 5: the engine's dropout on the softmax probabilities draws ONE 32-bit word per four consecutive keys and compares 8 bits
+    each with k = floor((1 - p) * 256) (csrc/common.h rng_keep8): the keep rate is k / 256 -- within 2^-8 of 1 - p -- and survivors are
+    scaled by 256 / k, so E[dropout(P)] = P exactly as for nn.Dropout.  With V = one-hot rows the output IS the (dropped, scaled)
+    probability mass per key block: checked here through uniform attention (q = 0: P = 1 / N) and a V whose channel c marks the
+    keys j % 32 == c -- out[i, c] = scale * (kept keys of class c) / N."""
+    import dyffusion_amd as D
+    cfg = D.resnet_net_config(in_channels=2, cond_channels=0, out_channels=1, dim=64, dim_mults=(1, 2))
+    eng = D.HipEngine(cfg, cfg, 16, 16, max_batch=2, use_graph=False, dtype="fp16")
+    n, N = 2, 1024
+    qkv = torch.zeros(n, N, 3 * 128, dtype=torch.float16)
+    cls = torch.arange(N) % 32
+    for h in range(4):
+        qkv[:, torch.arange(N), 2 * 128 + h * 32 + cls] = 1.0  # V: one-hot class of the key
+    eng.seed(7)
+    out = eng.op_attention(qkv.to(DEV), p_drop=p).float().cpu()  # (n, N, 128): per query the kept mass per class, scaled
+    k = max(1, int((1.0 - p) * 256.0))
+    keep_rate, scale = k / 256.0, 256.0 / k
+    per_query = out.reshape(n, N, 4, 32).sum(-1)  # scale * kept / N per (row, query, head)
+    mean = float(per_query.mean())
+    # n * N * 4 queries x N keys each: the mean kept fraction has a standard error of sqrt(r (1 - r) / 8.4e6) ~ 1.6e-4
+    kept_frac = mean / scale
+    print(f"p={p}: kept fraction {kept_frac:.5f} (k/256 = {keep_rate:.5f}, 1-p = {1 - p:.5f}); E[scaled mass] = {mean:.5f}")
+    assert abs(kept_frac - keep_rate) < 1.2e-3, (kept_frac, keep_rate)
+    assert abs(keep_rate - (1.0 - p)) <= 1.0 / 256.0
+    assert abs(mean - 1.0) < 2.5e-3  # unbiased: the scale is the inverse of the ACTUAL keep rate (fp16 output rounding included)
+    # rows / heads / queries draw different masks
+    assert float(per_query.std()) > 0
+    eng.close()
