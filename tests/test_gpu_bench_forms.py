@@ -116,6 +116,64 @@ def test_nb80_graph_paired_rollout_rows_match_the_oracle():
     assert worst <= TOL
 
 
+# kernel forms a FEW-ROW rollout must take on an engine sized for 80 rows (round 5, DESIGN.md 4.9: what one GPU runs when the 80-row
+# evaluation batch / a 50-member ensemble is sharded 8 ways): {rows of the call: forms that must appear}
+SMALL_FORMS = {
+    1: ["up_border_split_kernel", "up2x_epilogue_kernel", "conv_halo_rows_kernel<0>+splitk", "conv_halo_rows_kernel<0>+tr2",
+        "groupnorm_wave_kernel", "conv_skinny_kernel"],
+    7: ["up_border_split_kernel", "up2x_epilogue_kernel", "conv_halo_rows_kernel<0>+tr2", "conv_halo_rows_kernel<2>+tr2", "groupnorm_wave_kernel"],
+    10: ["up_border_split_kernel", "up2x_epilogue_kernel", "conv_halo_rows_kernel<0>+tr2", "conv_halo_rows_kernel<2>+tr2", "groupnorm_wave_kernel",
+         "conv_skinny_kernel<8>"],
+}
+
+
+@pytest.mark.parametrize("nb", [1, 7, 10])
+def test_few_row_rollouts_on_the_80_row_engine_match_the_oracle(nb):
+    """the forms of the few-rows regime pinned to the oracle.  The call's rows are rows of the 80-row benchmark batch
+    (rows are independent, so the cached oracle rollouts of rows 0 and 79 are the targets): (a) MC dropout off -- rows 0 and 79 first,
+    filler rows behind them; (b) the benchmarked mode -- rows 80 - nb .. 79 at row offset 80 - nb with the seed of the 80-row test, so
+    the LAST row draws exactly the masks of global row 79, rebuilt on the host for the oracle (tests/rng_host.py)."""
+    mk, PF, PI, x0, c = _setup()
+    m = build_dyffusion(PF, PI, mk, 3, 2, HP, max_batch=NB, use_graph=True)
+    m._ensure_engine((221, 42), NB)
+    eng = m._engine
+    order = ([0, 79] + list(range(1, nb - 1)))[:nb] if nb > 1 else [79]
+    xs, cs = x0[order].to(DEV), c[order].to(DEV)
+    eng.form_log(True)
+    first = {k: v.clone() for k, v in m.sample(xs, static_condition=cs).items()}
+    forms = eng.form_log_read()
+    eng.form_log(False)
+    print(f"{nb} rows:", {k: sorted(v) for k, v in forms.items()})
+    for f in SMALL_FORMS[nb]:
+        assert f in forms, (f, sorted(forms))
+    replay = m.sample(xs, static_condition=cs)
+    for k in first:
+        assert torch.equal(first[k], replay[k]), k
+    want = oracle_nb80_rows(mk, PF, PI, x0, c, [0, 79])
+    worst = 0.0
+    for k in ("t1_preds", "t8_preds", "t16_preds"):
+        for pos, r in enumerate(order[:2]):
+            e = rel_rms(replay[k][pos].cpu(), want[k][0 if r == 0 else 1])
+            print(f"{nb} rows, dropout off: {k} batch row {pos} (= row {r} of the 80): rel-RMS {e:.3e}")
+            worst = max(worst, e)
+    assert worst <= TOL
+    eng.close()
+    # (b) engine MC dropout
+    hp = dict(HP, enable_interpolator_dropout=True)
+    seed = 20260929
+    m2 = build_dyffusion(PF, PI, mk, 3, 2, hp, max_batch=NB, use_graph=True)
+    m2.seed(seed)
+    m2.set_row_offset(NB - nb)
+    rows = list(range(NB - nb, NB))
+    got = m2.sample(x0[rows].to(DEV), static_condition=c[rows].to(DEV))
+    want = oracle_nb80_row_with_engine_masks(mk, PF, PI, x0, c, hp, seed, 79)
+    for k in ("t1_preds", "t8_preds", "t16_preds"):
+        e = rel_rms(got[k][nb - 1].cpu(), want[k][0])
+        print(f"{nb} rows, engine MC dropout, last row = global row 79: {k} rel-RMS {e:.3e}")
+        assert e <= TOL, (k, e)
+    m2._engine.close()
+
+
 def test_nb80_graph_paired_rollout_with_mc_dropout_rows_match_the_oracle_on_the_engines_masks():
     """(b) the benchmarked mode itself: MC dropout drawn by the engine's generator inside the captured, paired rollout."""
     mk, PF, PI, x0, c = _setup()
