@@ -1122,8 +1122,8 @@ hipError_t launch_conv_halo3(const ConvArgs& a, hipStream_t stream) {
 
 constexpr int UB_LDS = 4 * 2 * 8192;  // up_border_kernel: per wave two stages of [2 samples][32 pixels][64 channels] bf16
 __global__ void up_border_kernel(ConvArgs a, int tr, int tc);
-template <int NW>
-__global__ __launch_bounds__(NW * 64, NW / 4) void up_border_split_kernel(ConvArgs a, int tr, int tc);  // (the bounds must sit on the FIRST declaration: the template is instantiated from here)
+template <int NW, bool KSPLIT>
+__global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void up_border_split_kernel(ConvArgs a, int tr, int tc);  // (the bounds must sit on the FIRST declaration: the template is instantiated from here)
 
 hipError_t conv_up_halo_init() {
     hipError_t e = hipFuncSetAttribute((const void*)conv_up_halo_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1151,7 +1151,9 @@ hipError_t conv_up_halo_init() {
                                 HaloCfg<5>::LDS_TOTAL + 1024);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)up_border_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, UB_LDS);
     if (e == hipSuccess)
-        e = hipFuncSetAttribute((const void*)up_border_split_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 16384);
+        e = hipFuncSetAttribute((const void*)(up_border_split_kernel<8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 16384);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)(up_border_split_kernel<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 16384);
     return e;
 }
 
@@ -1350,8 +1352,10 @@ __global__ __launch_bounds__(256) void up_border_kernel(ConvArgs a, int tr, int 
 struct UbSlot {
     uint4 wa[4], wb[4];
 };
-template <int NW>
-__global__ __launch_bounds__(NW * 64, NW / 4) void up_border_split_kernel(ConvArgs a, int tr, int tc) {
+// KSPLIT = false (many rows): the same 4-slot ring without the K split -- a workgroup's NW waves own NW different samples (corner
+// workgroups: NW x 32) and each walks its whole chain four iterations at a time; nothing is summed across waves.
+template <int NW, bool KSPLIT>
+__global__ __launch_bounds__(NW * 64, (NW + 3) / 4) void up_border_split_kernel(ConvArgs a, int tr, int tc) {
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) char ub_smem[];
     const int lane = threadIdx.x & 63, l31 = lane & 31, hi = lane >> 5;
@@ -1359,8 +1363,11 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void up_border_split_kernel(ConvAr
     const int cb_blk = blockIdx.z;
     const int nseg = 4 * tr + 4 * tc;
     const bool cornerwg = (int)blockIdx.x >= nseg;
-    if (cornerwg && (blockIdx.y & 31) != 0) return;  // a corner workgroup covers 32 samples
-    const int nbase = blockIdx.y;
+    // samples: K-split form -- blockIdx.y = one sample (corner workgroups every 32nd y: 32 samples); otherwise blockIdx.y = a group
+    // of NW samples, one per wave (corner workgroups every 32nd y: NW x 32 samples, 32 per wave)
+    if (cornerwg && (blockIdx.y & 31) != 0) return;
+    const int nbase = KSPLIT ? (int)blockIdx.y : (cornerwg ? (int)blockIdx.y * NW + 32 * wave : (int)blockIdx.y * NW + wave);
+    if (!KSPLIT && nbase >= a.n) return;  // wave-uniform: this wave's sample(s) do not exist
     int py, px, i0 = 0, j0 = 0, tt = 0;
     bool rowseg = true;
     if (cornerwg) {
@@ -1456,20 +1463,38 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void up_border_split_kernel(ConvAr
         }
         __builtin_amdgcn_sched_barrier(0);
     };
-    // this wave's iterations: wave, wave + NW, ... (wave-uniform count), in batches of up to four requests
-    const int mine = wave < niter ? (niter - wave + NW - 1) / NW : 0;
+    // this wave's iterations: wave, wave + NW, ... (K-split form) or all of them, in batches of up to four requests
+    constexpr int ISTR = KSPLIT ? NW : 1;
+    const int ifirst = KSPLIT ? wave : 0;
+    const int mine = ifirst < niter ? (niter - ifirst + ISTR - 1) / ISTR : 0;
     for (int j0b = 0; j0b < mine; j0b += 4) {
         const int nb4 = min(4, mine - j0b);  // wave-uniform
         UbSlot s0, s1, s2, s3;
-        load(s0, 0, wave + (j0b + 0) * NW);
-        if (nb4 > 1) load(s1, 1, wave + (j0b + 1) * NW);
-        if (nb4 > 2) load(s2, 2, wave + (j0b + 2) * NW);
-        if (nb4 > 3) load(s3, 3, wave + (j0b + 3) * NW);
+        load(s0, 0, ifirst + (j0b + 0) * ISTR);
+        if (nb4 > 1) load(s1, 1, ifirst + (j0b + 1) * ISTR);
+        if (nb4 > 2) load(s2, 2, ifirst + (j0b + 2) * ISTR);
+        if (nb4 > 3) load(s3, 3, ifirst + (j0b + 3) * ISTR);
         compute(s0, 0, nb4 - 1);
         if (nb4 > 1) compute(s1, 1, nb4 - 2);
         if (nb4 > 2) compute(s2, 2, nb4 - 3);
         if (nb4 > 3) compute(s3, 3, 0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the slots are re-filled by the next batch
+    }
+    if constexpr (!KSPLIT) {  // every wave owns its sample(s): store both channel halves straight from the accumulators
+        int ii, jj;
+        const bool valid = tile_pixel(l31, ii, jj);
+        const int Y = 2 * ii + py, X = 2 * jj + px;
+        const int ring = Y == 0 ? X : Y == a.ho - 1 ? a.wo + X : X == 0 ? 2 * a.wo + Y - 1 : 2 * a.wo + (a.ho - 2) + Y - 1;
+        const int ring_len = 2 * a.wo + 2 * (a.ho - 2);
+        const int smp = cornerwg ? nbase + l31 : nbase;
+        if (smp >= a.n || !valid) return;
+        float* op = a.up_border + ((size_t)smp * ring_len + ring) * a.cout + cb_blk * 64 + 4 * hi;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *(float4*)(op + nt * 32 + 8 * g) = make_float4(acc[nt][4 * g], acc[nt][4 * g + 1], acc[nt][4 * g + 2], acc[nt][4 * g + 3]);
+        return;
     }
     // ---- sum over the waves in wave order: every wave parks its 32 accumulator registers in its OWN 16 KB (8 KB used)
     float* red = (float*)(ub_smem + wave * 16384);  // [nt * 16 + q][64 lanes]
@@ -1512,10 +1537,20 @@ hipError_t launch_conv_up_halo(const ConvArgs& a, hipStream_t stream) {
         // moves the switch (0 = never); the form is chosen for ConvArgs::n_sel rows when the engine pins the forms (batch_invariant)
         const char* sre = getenv("DYF_UP_BORDER_SPLIT_ROWS");  // read per launch (parity tests)
         const int split_rows = sre ? atoi(sre) : 40;
+        // EXPERIMENT, off by default (DYF_UP_BORDER_RING4=1 enables; read per launch): the four-slot ring without the K split for many
+        // rows.  Measured SLOWER than the two-slot kernel where it would apply: NS at 80 rows 8 784-8 804 against 8 843-8 851 fields/s
+        // (three runs each, same box), dec3 / dec4 / dec5 at 80 rows 306.6 / 568.7 / 527.9 against 293.8 / 560.9 / 523.7 us -- with
+        // 480-1 440 workgroups the chip is full either way and the ring's 64 KB of LDS per workgroup halves the resident ones.
+        const char* r4e = getenv("DYF_UP_BORDER_RING4");
+        const bool ring4 = r4e && atoi(r4e) != 0;
         if ((a.n_sel > 0 ? a.n_sel : a.n) <= split_rows) {
             dyf_form_note("up_border_split_kernel", a.n);
-            hipLaunchKernelGGL(up_border_split_kernel<UB_SPLIT_NW>, dim3(4 * tr + 4 * tc + 4, a.n, a.cout / 64), dim3(UB_SPLIT_NW * 64),
+            hipLaunchKernelGGL((up_border_split_kernel<UB_SPLIT_NW, true>), dim3(4 * tr + 4 * tc + 4, a.n, a.cout / 64), dim3(UB_SPLIT_NW * 64),
                                UB_SPLIT_NW * 16384, stream, a, tr, tc);
+        } else if (ring4) {
+            // many rows, opt-in: four samples per workgroup, one per wave, the chain four iterations at a time
+            dyf_form_note("up_border_ring4_kernel", a.n);
+            hipLaunchKernelGGL((up_border_split_kernel<4, false>), dim3(4 * tr + 4 * tc + 4, (a.n + 3) / 4, a.cout / 64), dim3(256), 4 * 16384, stream, a, tr, tc);
         } else
             hipLaunchKernelGGL(up_border_kernel, dim3(4 * tr + 4 * tc + 4, (a.n + 7) / 8, a.cout / 64), dim3(256), UB_LDS, stream, a, tr, tc);
     }

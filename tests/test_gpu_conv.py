@@ -231,8 +231,17 @@ def test_rows_splitk_upsample_conv_matches_torch_and_the_unsplit_kernel(engine, 
     monkeypatch.setenv("DYF_ROWS_TR", "4")  # (short tiles are another round-5 form: tested below)
     monkeypatch.setenv("DYF_HALO_SPLITK", "0")
     monkeypatch.setenv("DYF_UP_BORDER_SPLIT_ROWS", "0")
+    monkeypatch.setenv("DYF_UP_BORDER_RING4", "0")
     old, forms0 = _form_log(engine, lambda: engine.op_upconv2d(x.cuda(), wt, scale.cuda(), shift.cuda(), act=1).float().cpu())
-    assert "conv_halo_rows_kernel<0>" in forms0 and not any("split" in k for k in forms0), sorted(forms0)
+    assert "conv_halo_rows_kernel<0>" in forms0 and not any("split" in k or "ring4" in k for k in forms0), sorted(forms0)
+    # the many-rows form of the border ring (four samples per workgroup, a four-slot ring per wave, no K split): same sums, other order
+    monkeypatch.setenv("DYF_UP_BORDER_RING4", "1")  # (opt-in: measured slower than the two-slot kernel at 80 rows, kept as an experiment)
+    y4, forms4 = _form_log(engine, lambda: engine.op_upconv2d(x.cuda(), wt, scale.cuda(), shift.cuda(), act=1).float().cpu())
+    assert "up_border_ring4_kernel" in forms4, sorted(forms4)
+    assert torch.equal(y4[:, 1:-1, 1:-1], old[:, 1:-1, 1:-1])  # the interior does not see the ring
+    for sl in [(slice(None), 0), (slice(None), -1), (slice(None), slice(None), 0), (slice(None), slice(None), -1)]:
+        assert rel_rms(y4[sl], old[sl]) <= 2.5e-3, (sl, rel_rms(y4[sl], old[sl]))
+    monkeypatch.delenv("DYF_UP_BORDER_RING4")
     monkeypatch.delenv("DYF_HALO_SPLITK")
     monkeypatch.delenv("DYF_UP_BORDER_SPLIT_ROWS")
     if factor:
