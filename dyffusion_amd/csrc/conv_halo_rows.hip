@@ -868,7 +868,13 @@ hipError_t launch_conv_halo_rows3(const ConvArgs& a, hipStream_t stream) {
     const int tiles_m = a.n * tiles_per_img, tiles_n = a.cout / 256;
     {
         const long long sel = (long long)(a.n_sel > 0 ? a.n_sel : a.n) * tiles_per_img * tiles_n;
-        const int tr = rows_tile_rows(sel, a.h);
+        // The plain form keeps its four-row tiles (+ split-K) by default: isolated, its two-row tiles look better (dec2 at 10 rows 48.5
+        // against 53.3 + 8 us), INSIDE the rollout they are worse (80.7 us against 53.5 + 7.9: the 16-chunk weight stream of dec2, twice as
+        // long per MFMA with half tiles, comes from the Infinity Cache there, not from a warm L2) -- whole rollouts, same box, two runs each,
+        // ms at 1 / 4 / 7 / 10 rows: short tiles for the upsample form only 8.90 / 14.69 / 20.20 / 26.37, for both forms 8.90 / 14.79 / 20.39 /
+        // 26.68, four-row tiles only 9.09 / 14.85 / 20.28 / 26.46.  DYF_ROWS_TR_PLAIN=1 (or DYF_ROWS_TR) applies the rule here too.
+        const char* tpe = getenv("DYF_ROWS_TR_PLAIN");
+        const int tr = ((tpe && atoi(tpe) != 0) || getenv("DYF_ROWS_TR")) ? rows_tile_rows(sel, a.h) : 4;
         if (tr != 4) {
             const int tpi = tiles_x * (a.h / tr), tm = a.n * tpi;
             dyf_form_note(tr == 2 ? "conv_halo_rows_kernel<2>+tr2" : "conv_halo_rows_kernel<2>+tr1", a.n);

@@ -121,8 +121,8 @@ def test_nb80_graph_paired_rollout_rows_match_the_oracle():
 SMALL_FORMS = {
     1: ["up_border_split_kernel", "up2x_epilogue_kernel", "conv_halo_rows_kernel<0>+splitk", "conv_halo_rows_kernel<0>+tr2",
         "groupnorm_wave_kernel", "conv_skinny_kernel"],
-    7: ["up_border_split_kernel", "up2x_epilogue_kernel", "conv_halo_rows_kernel<0>+tr2", "conv_halo_rows_kernel<2>+tr2", "groupnorm_wave_kernel"],
-    10: ["up_border_split_kernel", "up2x_epilogue_kernel", "conv_halo_rows_kernel<0>+tr2", "conv_halo_rows_kernel<2>+tr2", "groupnorm_wave_kernel",
+    7: ["up_border_split_kernel", "up2x_epilogue_kernel", "conv_halo_rows_kernel<0>+tr2", "conv_halo_rows_kernel<2>+splitk", "groupnorm_wave_kernel"],
+    10: ["up_border_split_kernel", "up2x_epilogue_kernel", "conv_halo_rows_kernel<0>+tr2", "conv_halo_rows_kernel<2>+splitk", "groupnorm_wave_kernel",
          "conv_skinny_kernel<8>"],
 }
 
