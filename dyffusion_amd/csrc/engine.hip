@@ -2003,10 +2003,11 @@ dyf_status dyf_op_linear_attention_fused(dyf_engine* e, const uint16_t* xn_dev, 
     hipStream_t st = (hipStream_t)stream;
     std::vector<el16_t> fq((size_t)384 * c), fo((size_t)c * 128);
     linattn_fused_pack(wqkv_host, wout_host, c, fq.data(), fo.data());
-    const size_t nblk = ((size_t)hw + 1023) / 1024;
+    const size_t nblk = ((size_t)hw + 255) / 256;  // (the smallest workgroups of the fused form: 8 groups of 32 pixels)
+    const size_t scratch_floats = (size_t)n * 4 * (nblk * 1088 + 1024);
     float *scratch = nullptr, *bo = nullptr;
     el16_t *dq = nullptr, *dout = nullptr;
-    hipError_t err = hipMalloc((void**)&scratch, (size_t)n * 4 * (nblk * 1088 + 1024) * sizeof(float));
+    hipError_t err = hipMalloc((void**)&scratch, scratch_floats * sizeof(float));
     if (err == hipSuccess) err = hipMalloc((void**)&bo, (size_t)c * sizeof(float));
     if (err == hipSuccess) err = hipMalloc((void**)&dq, fq.size() * sizeof(el16_t));
     if (err == hipSuccess) err = hipMalloc((void**)&dout, fo.size() * sizeof(el16_t));
@@ -2016,7 +2017,7 @@ dyf_status dyf_op_linear_attention_fused(dyf_engine* e, const uint16_t* xn_dev, 
     if (err == hipSuccess) {
         LinAttnFusedArgs f{};
         f.xn = xn_dev; f.xres = xres_dev; f.n = n; f.hw = hw; f.c = c; f.wqkv_frag = dq; f.wout_frag = dout; f.bout = bo;
-        f.y = y_dev; f.scratch = scratch;
+        f.y = y_dev; f.scratch = scratch; f.scratch_floats = (long long)scratch_floats;
         err = launch_linear_attention_fused(f, st);
     }
     if (err == hipSuccess) err = hipStreamSynchronize(st);

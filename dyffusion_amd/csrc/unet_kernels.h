@@ -80,7 +80,10 @@ struct LinAttnFusedArgs {
     const el16_t* wout_frag;
     const float* bout;        // [c]
     el16_t* y;                // [n][hw][c]
-    float* scratch;           // as LinAttnArgs.scratch
+    float* scratch;           // as LinAttnArgs.scratch, sized for 8-group workgroups (rn_alloc_workspace)
+    int groups_per_block;     // 32-pixel groups per workgroup: 32 (the large-batch form), 16 or 8; 0 = chosen by the launcher from the
+                              // workgroup count (batch_invariant engines pin 32: the partials are merged per workgroup)
+    long long scratch_floats; // capacity of `scratch` (0 = unknown: only 32-group workgroups are used)
 };
 bool linattn_fused_supported(int c);
 hipError_t linattn_fused_init();

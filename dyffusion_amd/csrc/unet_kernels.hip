@@ -1360,7 +1360,8 @@ __device__ __forceinline__ float lf_sum32(float x) {
     const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
     return __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
 }
-constexpr int LF_GROUPS = 32;  // 32-pixel groups per workgroup (= LA_PIX pixels: the partial layout is shared with the unfused form)
+constexpr int LF_GROUPS = 32;  // 32-pixel groups per workgroup of the large-batch form (= LA_PIX pixels); the kernels take the count as an
+                               // argument (`gpb`: 32 / 16 / 8, launch_linear_attention_fused)
 
 template <int C>
 struct LfCfg {
@@ -1373,7 +1374,7 @@ struct LfCfg {
 
 template <int C>
 __global__ __launch_bounds__(256, 2) void linattn_fused_ctx_kernel(const el16_t* __restrict__ xn, int hw, const el16_t* __restrict__ wfrag,
-                                                                float* __restrict__ part, int nblk) {
+                                                                float* __restrict__ part, int nblk, int gpb) {
     constexpr int KS = LfCfg<C>::KS;
     extern __shared__ __attribute__((aligned(16))) unsigned char lf_smem[];
     uint4* wl = (uint4*)lf_smem;                                  // [8][KS][64]
@@ -1405,8 +1406,8 @@ __global__ __launch_bounds__(256, 2) void linattn_fused_ctx_kernel(const el16_t*
         for (int s = 0; s < KS; ++s) xf[s] = src[2 * s];
         __builtin_amdgcn_sched_barrier(0);  // issue here, a group ahead (the scheduler would sink the loads to their uses)
     };
-    int g = blk * LF_GROUPS + wave;
-    const int gend = min((blk + 1) * LF_GROUPS, ngroups);
+    int g = blk * gpb + wave;
+    const int gend = min((blk + 1) * gpb, ngroups);
     uint4 xc[KS], xnx[KS];
     if (g < gend) load(g, xc);
     // W_k is pre-scaled by log2(e) (linattn_fused_pack): exp(k - max) = exp2(k2 - max2), and m[] is in log2 units
@@ -1511,7 +1512,7 @@ template <int C>
 __global__ __launch_bounds__(256, 2) void linattn_fused_out_kernel(const el16_t* __restrict__ xn, const el16_t* __restrict__ xres, int hw,
                                                                 const el16_t* __restrict__ wfrag, const el16_t* __restrict__ wofrag,
                                                                 const float* __restrict__ bias, const el16_t* __restrict__ frags,
-                                                                el16_t* __restrict__ y) {
+                                                                el16_t* __restrict__ y, int gpb) {
     constexpr int KS = LfCfg<C>::KS, OG = C / 32;
     extern __shared__ __attribute__((aligned(16))) unsigned char lf_smem[];
     uint4* wq = (uint4*)lf_smem;                                            // [4][KS][64]
@@ -1537,8 +1538,8 @@ __global__ __launch_bounds__(256, 2) void linattn_fused_out_kernel(const el16_t*
         for (int s = 0; s < KS; ++s) xf[s] = src[2 * s];
         __builtin_amdgcn_sched_barrier(0);
     };
-    int g = blk * LF_GROUPS + wave;
-    const int gend = min((blk + 1) * LF_GROUPS, ngroups);
+    int g = blk * gpb + wave;
+    const int gend = min((blk + 1) * gpb, ngroups);
     uint4 xc[KS], xnx[KS];
     if (g < gend) load(g, xc);
     for (; g < gend; g += 4) {
@@ -1668,20 +1669,39 @@ void linattn_fused_pack(const float* w_qkv, const float* w_out, int c, el16_t* q
 }
 
 hipError_t launch_linear_attention_fused(const LinAttnFusedArgs& a, hipStream_t s) {
-    const int nblk = (a.hw + LA_PIX - 1) / LA_PIX, BH = a.n * LA_HEADS;
+    // Pixels per workgroup.  A workgroup loads the block's weights into LDS (32 / 64 KB) and then walks its 32-pixel groups, four at
+    // a time: with 1 024 pixels per workgroup a 60 x 60 plane is 4 workgroups per sample and a 30 x 30 plane ONE -- at 38 rows the two
+    // passes were 152 / 38 workgroups of a 20 us serial chain each (22-28 us per launch, eight launches per forward,
+    // profiles/r05f_oisst_nb38).  Below 384 workgroups the launch halves / quarters the block (more, shorter chains; the merge
+    // kernel takes any number of partials).  DYF_LINATTN_GPB = 32 / 16 / 8 forces a size (read per launch).
+    const int ngroups = (a.hw + 31) / 32, BH = a.n * LA_HEADS;
+    int gpb = a.groups_per_block;
+    if (const char* ge = getenv("DYF_LINATTN_GPB")) gpb = atoi(ge);
+    if (gpb != 32 && gpb != 16 && gpb != 8) {
+        gpb = 32;
+        // (measured, OISST rollouts with blocks of 32 only / this rule at 512: 38 rows 1 791 / 1 824 fields/s, 75 rows 2 651 / 2 758, 150 rows
+        // 3 676 / 3 691, 300 rows on three groups 4 090 / 4 073 -- 400-workgroup launches of a group gain nothing: the rule stops at 384)
+        while (gpb > 8 && (long long)((ngroups + gpb - 1) / gpb) * a.n < 384) gpb >>= 1;
+    }
+    int nblk = (ngroups + gpb - 1) / gpb;
+    while (gpb < 32 && (a.scratch_floats <= 0 || (long long)BH * nblk * LA_PART + (long long)BH * 1024 > a.scratch_floats)) {
+        gpb <<= 1;  // the partials of the smaller blocks do not fit the scratch
+        nblk = (ngroups + gpb - 1) / gpb;
+    }
     float* part = a.scratch;
     el16_t* frags = (el16_t*)(a.scratch + (size_t)BH * nblk * LA_PART);
     const dim3 grid(nblk, a.n);
+    dyf_form_note(gpb == 32 ? "linattn_fused_kernels<gpb=32>" : gpb == 16 ? "linattn_fused_kernels<gpb=16>" : "linattn_fused_kernels<gpb=8>", a.n);
     if (a.c == 64) {
-        hipLaunchKernelGGL(linattn_fused_ctx_kernel<64>, grid, dim3(256), LfCfg<64>::CTX_LDS, s, a.xn, a.hw, a.wqkv_frag, part, nblk);
+        hipLaunchKernelGGL(linattn_fused_ctx_kernel<64>, grid, dim3(256), LfCfg<64>::CTX_LDS, s, a.xn, a.hw, a.wqkv_frag, part, nblk, gpb);
     } else {
-        hipLaunchKernelGGL(linattn_fused_ctx_kernel<128>, grid, dim3(256), LfCfg<128>::CTX_LDS, s, a.xn, a.hw, a.wqkv_frag, part, nblk);
+        hipLaunchKernelGGL(linattn_fused_ctx_kernel<128>, grid, dim3(256), LfCfg<128>::CTX_LDS, s, a.xn, a.hw, a.wqkv_frag, part, nblk, gpb);
     }
     hipLaunchKernelGGL(linattn_merge_kernel, dim3(BH, (nblk >= 32 && BH < 128) ? 4 : 1), dim3(256), 0, s, (const float*)part, nblk, 1.0f / (float)a.hw, frags, 1);
     if (a.c == 64) {
-        hipLaunchKernelGGL(linattn_fused_out_kernel<64>, grid, dim3(256), LfCfg<64>::OUT_LDS, s, a.xn, a.xres, a.hw, a.wqkv_frag, a.wout_frag, a.bout, (const el16_t*)frags, a.y);
+        hipLaunchKernelGGL(linattn_fused_out_kernel<64>, grid, dim3(256), LfCfg<64>::OUT_LDS, s, a.xn, a.xres, a.hw, a.wqkv_frag, a.wout_frag, a.bout, (const el16_t*)frags, a.y, gpb);
     } else {
-        hipLaunchKernelGGL(linattn_fused_out_kernel<128>, grid, dim3(256), LfCfg<128>::OUT_LDS, s, a.xn, a.xres, a.hw, a.wqkv_frag, a.wout_frag, a.bout, (const el16_t*)frags, a.y);
+        hipLaunchKernelGGL(linattn_fused_out_kernel<128>, grid, dim3(256), LfCfg<128>::OUT_LDS, s, a.xn, a.xres, a.hw, a.wqkv_frag, a.wout_frag, a.bout, (const el16_t*)frags, a.y, gpb);
     }
     return hipGetLastError();
 }

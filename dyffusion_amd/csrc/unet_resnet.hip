@@ -59,6 +59,7 @@ struct RNet {
     uint32_t* gn_epoch = nullptr;
     int gn_max_slots = 0;
     float* la_scratch = nullptr;   // LinearAttention partials + context
+    size_t la_scratch_floats = 0;
     size_t buf_elems = 0;          // elements of one pool buffer at max_batch
     std::vector<el16_t*> pool;
 };
@@ -293,8 +294,10 @@ dyf_status rn_alloc_workspace(dyf_engine* e) {
             }
         }
         {
-            const size_t nblk = ((size_t)e->cfg.height * e->cfg.width + 1023) / 1024;
-            dyf_status s = dev_alloc(e, &r->la_scratch, (size_t)e->cfg.max_batch * HEADS * (nblk * 1088 + 1024));  // partials + ctx fragments
+            // partials of the smallest workgroups of the fused form (8 groups = 256 pixels each) + ctx fragments
+            const size_t nblk = ((size_t)e->cfg.height * e->cfg.width + 255) / 256;
+            r->la_scratch_floats = (size_t)e->cfg.max_batch * HEADS * (nblk * 1088 + 1024);
+            dyf_status s = dev_alloc(e, &r->la_scratch, r->la_scratch_floats);
             if (s != DYF_OK) return s;
         }
         const int nbuf = 2 * r->nlev + 8;
@@ -601,6 +604,7 @@ dyf_status rn_forward(dyf_engine* e, int which, const Source* srcs, int nsrc, in
             LinAttnFusedArgs f{};
             f.xn = ln; f.xres = x; f.n = nb; f.hw = hw; f.c = a.dim; f.wqkv_frag = a.wqkv_frag; f.wout_frag = a.wout_frag;
             f.bout = a.bout; f.y = yf; f.scratch = r->la_scratch;
+            f.scratch_floats = (long long)r->la_scratch_floats; f.groups_per_block = e->cfg.batch_invariant ? 32 : 0;
             HIP_TRY(e, launch_linear_attention_fused(f, st));
             pool.put(ln);
             *out = yf;

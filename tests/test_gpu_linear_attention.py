@@ -68,3 +68,32 @@ def test_fused_linear_attention_block_matches_fp32_reference(engine, n, hw, c):
     assert torch.isfinite(got).all()
     err = (got - want).abs().max().item()
     assert err <= 2.0 ** -8 * want.abs().max().item() + 1.5e-2 * att.abs().max().item() + 1e-6, err
+
+
+@pytest.mark.parametrize("c,n,hw", [(64, 2, 3600), (128, 3, 900), (64, 1, 5000), (128, 2, 225)])
+def test_fused_linear_attention_block_sizes_agree(engine, c, n, hw, monkeypatch):
+    """Round 5: the fused block's workgroups walk 32, 16 or 8 groups of 32 pixels (DYF_LINATTN_GPB, read per launch; the launcher takes
+    the smaller blocks while a launch is under 512 workgroups -- the few-rows regime).  The blocks only change how the online softmax
+    over the pixels is cut into partials: every size within the tolerance of the fp32 reference, and within rounding of one another."""
+    g = torch.Generator().manual_seed(n * 31 + hw + c)
+    xn = torch.randn(n, hw, c, generator=g).to(torch.bfloat16)
+    xres = (2.0 * torch.randn(n, hw, c, generator=g)).to(torch.bfloat16)
+    wqkv = torch.randn(384, c, generator=g) * (1.5 / c ** 0.5)
+    wqkv[128:160] *= 3.0
+    wout = torch.randn(c, 128, generator=g) * (8.0 / 128 ** 0.5)
+    bout = torch.randn(c, generator=g)
+    want = _ref_block(xn, xres, wqkv, wout, bout)
+    att = want - xres.float() - bout
+    outs = {}
+    for gpb in ("32", "16", "8"):
+        monkeypatch.setenv("DYF_LINATTN_GPB", gpb)
+        engine.form_log(True)
+        outs[gpb] = engine.op_linear_attention_fused(xn.cuda(), xres.cuda(), wqkv, wout, bout).float().cpu()
+        forms = engine.form_log_read()
+        engine.form_log(False)
+        assert f"linattn_fused_kernels<gpb={gpb}>" in forms, sorted(forms)
+        err = (outs[gpb] - want).abs().max().item()
+        assert err <= 2.0 ** -8 * want.abs().max().item() + 1.5e-2 * att.abs().max().item() + 1e-6, (gpb, err)
+    for gpb in ("16", "8"):
+        d = (outs[gpb] - outs["32"]).abs().max().item()
+        assert d <= 2.0 ** -7 * want.abs().max().item(), (gpb, d)
