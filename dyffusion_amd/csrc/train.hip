@@ -1587,6 +1587,12 @@ __global__ void t_fill_hash(float* p, long long n, uint32_t seed) {
     const uint32_t h = fmix32((uint32_t)i * 0x9E3779B1u + seed);
     p[i] = ((float)(h >> 8) * (1.0f / 8388608.0f) - 1.0f);  // uniform in [-1, 1)
 }
+// in place: every value rounded to the engine's 16-bit format (what the 16-bit-operand convs do while staging) -- on such data the
+// fp32 reference kernels and the 16-bit matrix-core forms differ only by summation order
+__global__ void t_round16(float* p, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = el16_to_f32(f32_to_el16(p[i]));
+}
 __global__ void t_maxabs2(const float* a, const float* b, long long n, unsigned* out) {  // out[0] = max |a - b|, out[1] = max |b| (bit patterns)
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -1617,6 +1623,11 @@ dyf_status dyf_train_conv_check(dyf_engine* e, int32_t kind, int32_t n, int32_t 
     hipLaunchKernelGGL(t_fill_hash, dim3(nblk(nz)), dim3(256), 0, st, z, nz, seed + 1u);
     hipLaunchKernelGGL(t_fill_hash, dim3(nblk(nw)), dim3(256), 0, st, wgt, nw, seed + 2u);   // used in BOTH weight layouts' index spaces
     hipLaunchKernelGGL(t_fill_hash, dim3(nblk(std::max(cin, cout))), dim3(256), 0, st, bias, (long long)std::max(cin, cout), seed + 3u);
+    if (const char* ops = getenv("DYF_TRAIN_OPERANDS"); ops && (!strcmp(ops, "bf16") || !strcmp(ops, "fp16") || !strcmp(ops, "16"))) {
+        hipLaunchKernelGGL(t_round16, dim3(nblk(nx)), dim3(256), 0, st, x, nx);
+        hipLaunchKernelGGL(t_round16, dim3(nblk(nz)), dim3(256), 0, st, z, nz);
+        hipLaunchKernelGGL(t_round16, dim3(nblk(nw)), dim3(256), 0, st, wgt, nw);
+    }
     float res[3] = {0.0f, 0.0f, 0.0f};
     for (int pass = 0; pass < 2; ++pass) {  // pass 0: with the split-K workspace, pass 1: without
         float* ws = pass == 0 ? splitk_ws(e) : nullptr;

@@ -448,6 +448,7 @@ bool tgemm_conv_fwd(const TConv& g, const float* x, const float* wt, const float
     if (g.cin % GK != 0 || g.cout % GN != 0) return false;
     const long long M = (long long)g.n * g.ho * g.wo, mt = (M + GM - 1) / GM;
     const bool h16 = train_operands16() && g.cin % GK16 == 0;
+    if (h16 && thalo_conv3x3(g, 0, x, wt, bias, y, ws, ws_floats, st)) return true;
     int splits, len;
     plan_splitk(mt * (g.cout / GN), g.k * g.k * g.cin / (h16 ? GK16 : GK), splits, len);
     if (splits > 1 && (ws == nullptr || (size_t)splits * M * g.cout > ws_floats)) { splits = 1; len = 0; }
@@ -465,6 +466,7 @@ bool tgemm_conv_dgrad(const TConv& g, const float* dz, const float* w, const flo
     if (g.cout % GK != 0 || g.cin % GN != 0) return false;
     const long long M = (long long)g.n * g.h * g.w, mt = (M + GM - 1) / GM;
     const bool h16 = train_operands16() && g.cout % GK16 == 0;
+    if (h16 && thalo_conv3x3(g, 1, dz, w, bias, dx, ws, ws_floats, st)) return true;
     int splits, len;
     plan_splitk(mt * (g.cin / GN), g.k * g.k * g.cout / (h16 ? GK16 : GK), splits, len);
     if (splits > 1 && (ws == nullptr || (size_t)splits * M * g.cin > ws_floats)) { splits = 1; len = 0; }
@@ -485,6 +487,7 @@ bool tgemm_conv_wgrad(const TConv& g, const float* dz, const float* x, float* dw
     // enough workgroups to fill the chip, at least 256 pixels per split
     long long splits = std::max<long long>(1, std::min<long long>((pix + 255) / 256, (2048 + (long long)mt * nt * taps - 1) / ((long long)mt * nt * taps)));
     const bool h16 = train_operands16();
+    if (h16 && thalo_wgrad3x3(g, dz, x, dw, st)) return true;
     const int gk = h16 ? GK16 : GK;
     int len = (int)(((pix + splits - 1) / splits + gk - 1) / gk * gk);
     splits = (pix + len - 1) / len;

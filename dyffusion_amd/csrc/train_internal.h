@@ -19,4 +19,10 @@ bool tgemm_conv_dgrad(const TConv& g, const float* dz, const float* w, const flo
                       hipStream_t st);
 bool tgemm_conv_wgrad(const TConv& g, const float* dz, const float* x, float* dw, hipStream_t st);
 
+// 3 x 3 / stride 1 / pad 1 layers with 16-bit operands, tile + halo staged once (train_halo16.hip); false: shape not covered.
+// mode 0: forward (A = x, W = wt[tap][ci][co]); mode 1: data gradient (A = dz, W = w[co][tap][ci]); ws receives the 16-bit weights
+bool thalo_conv3x3(const TConv& g, int mode, const float* A, const float* W, const float* bias, float* C, float* ws, size_t ws_floats,
+                   hipStream_t st);
+bool thalo_wgrad3x3(const TConv& g, const float* dz, const float* x, float* dw, hipStream_t st);
+
 }  // namespace dyf

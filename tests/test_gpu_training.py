@@ -320,6 +320,42 @@ def test_matrix_core_training_convs_match_the_plain_kernels(case, kind):
     assert split <= 2e-5 and unsplit <= 2e-5
 
 
+HALO16_CASES = [
+    # (n, h, w, cin, cout, k, s, p): 3 x 3 / stride 1 / pad 1 layers with >= 192 tiles of 8 x 16 pixels
+    (8, 64, 64, 128, 64, 3, 1, 1),    # two K chunks, 64 output channels
+    (8, 64, 64, 64, 128, 3, 1, 1),    # 128-channel column block (forward) / two K chunks (dgrad)
+    (8, 60, 60, 64, 64, 3, 1, 1),     # OISST plane: ragged tiles in both directions
+    (8, 40, 72, 192, 128, 3, 1, 1),   # three K chunks, h a multiple of the tile, w not
+    (13, 17, 250, 64, 64, 3, 1, 1),   # rows of 250 pixels: last column tile 10 wide, h = 17: a one-row tile at the bottom
+]
+
+
+@pytest.mark.parametrize("case", HALO16_CASES, ids=lambda c: "x".join(map(str, c)))
+@pytest.mark.parametrize("kind", [0, 1, 2], ids=["forward", "dgrad", "wgrad"])
+def test_16bit_halo_training_convs_match_the_plain_kernels(case, kind, monkeypatch):
+    """csrc/train_halo16.hip (round 5: 3 x 3 / stride 1 layers of the training step with 16-bit operands -- tile + halo staged once,
+    all nine taps from LDS; the weight gradient with both operands transposed on the way into LDS and the column shift made in
+    registers) against the one-thread-per-output fp32 kernels.  The check rounds its hash-random inputs to the 16-bit format first,
+    so both sides sum the same exact products and only the summation order differs: 2e-5 of the largest reference value, as
+    for the fp32 matrix-core forms.  The tap-by-tap 16-bit implicit GEMM these replace (DYF_TRAIN_HALO16=0) must pass the same check."""
+    import dyffusion_amd as D
+    from dyffusion_amd.engine import net_config
+    monkeypatch.setenv("DYF_TRAIN_OPERANDS", "bf16")
+    cfg = net_config(in_channels=3, cond_channels=2, out_channels=3, dim=64, with_time_emb=True, upsample_dims=(64, 64), dropout=0.0)
+    eng = D.HipEngine(cfg, cfg, 23, 11, max_batch=1, use_graph=False)
+    want_form = ("t_halo3x3_16:forward", "t_halo3x3_16:dgrad", "t_wgrad3x3_16")[kind]
+    for halo in ("1", "0"):
+        monkeypatch.setenv("DYF_TRAIN_HALO16", halo)
+        eng.form_log(True)
+        split, unsplit, took = eng.train_conv_check(kind, *case, seed=17 + kind)
+        forms = eng.form_log_read()
+        eng.form_log(False)
+        assert took
+        assert (want_form in forms) == (halo == "1"), forms
+        print(f"kind {kind} {case} halo16={halo}: rel max err {split:.2e} / {unsplit:.2e}")
+        assert split <= 2e-5 and unsplit <= 2e-5
+
+
 def test_gpu_resident_parameters_train_like_cpu_resident_ones():
     """A forecaster moved to the GPU: gradients are exported device-to-device (dyf_train_export_dev) and the refreshed weights read
     in place (dyf_train_load_weights_dev).  Two SGD steps must produce the parameters of the CPU-resident run (host round
