@@ -495,6 +495,17 @@ __global__ __launch_bounds__(256) void t_nc_sums(const float* z, int hw, int C, 
             s += v;
             q += v * v;
         }
+        if (nsub > 1) {  // the pixel groups of a channel meet in LDS: one atomic per (workgroup, channel) instead of nsub
+            __shared__ double red[2][256];
+            red[0][threadIdx.x] = s;
+            red[1][threadIdx.x] = q;
+            __syncthreads();
+            if (sub != 0) continue;
+            for (int j = 1; j < nsub; ++j) {
+                s += red[0][j * C + c];
+                q += red[1][j * C + c];
+            }
+        }
         atomicAdd(S + (size_t)b * C + c, s);
         atomicAdd(Q + (size_t)b * C + c, q);
     }
@@ -608,6 +619,21 @@ __global__ __launch_bounds__(256) void t_norm_bwd_sums(TNorm a, const float* z, 
             sb += dpre;
             scx += (double)dbn * xh;
             sd += dbn;
+        }
+        if (nsub > 1) {  // (as t_nc_sums)
+            __shared__ double red[4][256];
+            red[0][threadIdx.x] = sa;
+            red[1][threadIdx.x] = sb;
+            red[2][threadIdx.x] = scx;
+            red[3][threadIdx.x] = sd;
+            __syncthreads();
+            if (sub != 0) continue;
+            for (int j = 1; j < nsub; ++j) {
+                sa += red[0][j * a.C + c];
+                sb += red[1][j * a.C + c];
+                scx += red[2][j * a.C + c];
+                sd += red[3][j * a.C + c];
+            }
         }
         atomicAdd(A + (size_t)b * a.C + c, sa);
         atomicAdd(B + (size_t)b * a.C + c, sb);

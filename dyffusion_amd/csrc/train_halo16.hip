@@ -51,23 +51,78 @@ __global__ void t_pack_w16(const float* __restrict__ src, int cin, int cout, int
 }
 
 // ---------------------------------------------------------------------------------------------- forward / data gradient
+// A workgroup walks tiles_per_wg consecutive tiles of one column block as ONE stream of (tile, 64-channel chunk, tap) steps:
+//   weights   step g's [BN][64] image is DMA'd (buffer_load ... lds, no registers) into slot g % 4 of a ring, three steps ahead;
+//             lane (row r, slot s) of a DMA instruction fetches chunk s ^ key(row), so the linear 1 KB it writes is the swizzled image
+//   halo      the NEXT chunk's (or next tile's) halo is requested into registers at the first tap of a chunk and rounded into the
+//             other halo buffer after the chunk's ninth tap
+//   one barrier per step: it publishes the step's weights (every wave waits for its own DMA pieces first) and frees the slot of
+//   the step before.  vmcnt: loads return in order, so "at most 2 stages outstanding" (the two requested after the one awaited)
+//   is always enough -- halo loads and the epilogue's stores in between only make the wait longer, never too short.
+#define LDS_PTR(p) ((__attribute__((address_space(3))) void*)(p))
+
 template <int BN>
-__global__ __launch_bounds__(256, 2) void t_halo3x3_16(int n_img_total, int h, int w, int CK, int NC, const float* __restrict__ A,
-                                                       const el16_t* __restrict__ Wb, const float* __restrict__ bias,
-                                                       float* __restrict__ C, int tiles_x, int tiles_per_img) {
+__global__ __launch_bounds__(256, BN == 64 ? 2 : 1) void t_halo3x3_16(int h, int w, int CK, int NC, const float* __restrict__ A,
+                                                                      const el16_t* __restrict__ Wb, const float* __restrict__ bias,
+                                                                      float* __restrict__ C, int tiles_x, int tiles_per_img,
+                                                                      int tiles_total, int tiles_per_wg, int nblocks) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    constexpr int NT = BN / 32;
-    constexpr int XS_BYTES = HP * 128 + 512;  // (+ pad: keeps the B images 512-byte aligned)
-    constexpr int B_BYTES = BN * 128;
-    __shared__ __attribute__((aligned(16))) char smem[XS_BYTES + 2 * B_BYTES];
-    char* Xs = smem;
-    char* Bs = smem + XS_BYTES;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int NT = BN / 32, RING = 4, BI = BN / 32;  // BI: DMA instructions per wave and step (BN rows x 128 B over 4 waves)
+    constexpr int XS_BYTES = HP * 128 + 512, B_BYTES = BN * 128;
+    constexpr int HV = (HP * 16 + 255) / 256;  // 12 halo float4 per thread (the last one: wave 0 only)
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 halo buffers + the weight ring
+    char* const Bring = smem + 2 * XS_BYTES;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
-    const int tile = blockIdx.x, n0 = blockIdx.y * BN;
-    const int img = tile / tiles_per_img, t_in = tile - img * tiles_per_img;
-    const int y0 = (t_in / tiles_x) * TH, x0 = (t_in % tiles_x) * TW;
+    const int nb = blockIdx.x % nblocks, wg = blockIdx.x / nblocks, n0 = nb * BN;
+    const int t_beg = wg * tiles_per_wg, t_end = min(t_beg + tiles_per_wg, tiles_total);
     const int nchunks = CK >> 6;
+    const auto rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)Wb, 0, (int)(unsigned)((size_t)NC * 9 * CK * 2), 0x00020000);
+
+    // weight DMA: instruction j of this wave fills rows (wave * BI + j) * 8 ... + 8 of the step's image
+    unsigned w_voff[BI];
+#pragma unroll
+    for (int j = 0; j < BI; ++j) {
+        const int n = (wave * BI + j) * 8 + (lane >> 3);
+        const int c = (lane & 7) ^ ((n >> 1) & 7);
+        w_voff[j] = (unsigned)((size_t)(n0 + n) * 9 * CK + c * 8) * 2u;
+    }
+    int is_tap = 0, is_chunk = 0, is_slot = 0;  // the step the next issue_b requests (runs past the end: harmless re-fetches)
+    auto issue_b = [&]() {
+        const unsigned soff = (unsigned)(is_tap * CK + (is_chunk << 6)) * 2u;
+#pragma unroll
+        for (int j = 0; j < BI; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, LDS_PTR(Bring + is_slot * B_BYTES + (wave * BI + j) * 1024), 16, w_voff[j], soff, 0, 0);
+        if (++is_tap == 9) { is_tap = 0; if (++is_chunk == nchunks) is_chunk = 0; }
+        if (++is_slot == RING) is_slot = 0;
+    };
+
+    float4 hv[HV];
+    auto halo_load = [&](int tile, int chunk) {
+        const int img = tile / tiles_per_img, t_in = tile - img * tiles_per_img;
+        const int y0 = (t_in / tiles_x) * TH, x0 = (t_in % tiles_x) * TW;
+#pragma unroll
+        for (int j = 0; j < HV; ++j) {
+            const int idx = tid + 256 * j;
+            const int hp = min(idx >> 4, HP - 1), q = idx & 15;
+            const int hy = (int)((unsigned)hp / (unsigned)HW), hx = hp - hy * HW;
+            const int yy = y0 - 1 + hy, xx = x0 - 1 + hx;
+            hv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if ((unsigned)yy < (unsigned)h && (unsigned)xx < (unsigned)w)
+                hv[j] = *(const float4*)(A + (((size_t)img * h + yy) * w + xx) * CK + (chunk << 6) + q * 4);
+        }
+    };
+    auto halo_store = [&](int buf) {
+        char* Xs = smem + buf * XS_BYTES;
+#pragma unroll
+        for (int j = 0; j < HV; ++j) {
+            const int idx = tid + 256 * j;
+            const int hp = idx >> 4, q = idx & 15;
+            if (idx < HP * 16)
+                *(uint2*)(Xs + hp * 128 + (((q >> 1) ^ hkey(hp)) << 4) + (q & 1) * 8) =
+                    make_uint2(pack_el16x2(hv[j].x, hv[j].y), pack_el16x2(hv[j].z, hv[j].w));
+        }
+    };
 
     f32x16 acc[NT];
 #pragma unroll
@@ -76,77 +131,64 @@ __global__ __launch_bounds__(256, 2) void t_halo3x3_16(int n_img_total, int h, i
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
 
     // this lane's pixel of the wave's 32-pixel block: tile rows 2 * wave + {0, 1}, 16 columns
-    const int prow = 2 * wave + (l31 >> 4), pcol = l31 & 15;
-    const int hp00 = prow * HW + pcol;  // halo pixel at tap (0, 0)
+    const int hp00 = (2 * wave + (l31 >> 4)) * HW + (l31 & 15);  // halo pixel at tap (0, 0)
 
-    uint4 rb[BN / 32];  // the next tap's weights on their way into LDS: BN rows x 8 chunks of 16 bytes over 256 threads
-    auto load_b = [&](int chunk, int tap) {
+    halo_load(t_beg, 0);
 #pragma unroll
-        for (int i = 0; i < BN / 32; ++i) {
-            const int idx = tid + 256 * i, n = idx >> 3, c = idx & 7;
-            rb[i] = *(const uint4*)(Wb + ((size_t)(n0 + n) * 9 + tap) * CK + (chunk << 6) + c * 8);
-        }
-    };
-    auto store_b = [&](int buf) {
+    for (int i = 0; i < RING - 1; ++i) issue_b();
+    halo_store(0);
+    int xbuf = 0, slot = 0;
+    for (int tile = t_beg; tile < t_end; ++tile) {
+        for (int chunk = 0; chunk < nchunks; ++chunk) {
+            const bool last = chunk + 1 == nchunks;
+            const bool has_next = !last || tile + 1 < t_end;
+            const char* Xs = smem + xbuf * XS_BYTES;
 #pragma unroll
-        for (int i = 0; i < BN / 32; ++i) {
-            const int idx = tid + 256 * i, n = idx >> 3, c = idx & 7;
-            *(uint4*)(Bs + buf * B_BYTES + n * 128 + ((c ^ ((n >> 1) & 7)) << 4)) = rb[i];
-        }
-    };
-
-    for (int chunk = 0; chunk < nchunks; ++chunk) {
-        __syncthreads();  // every wave is done with the previous chunk's halo and weight images
-        load_b(chunk, 0);
-        // halo of this chunk: 180 pixels x 16 float4, rounded to 16 bit; pixels outside the image are the conv's zero padding
-#pragma unroll 4
-        for (int idx = tid; idx < HP * 16; idx += 256) {
-            const int hp = idx >> 4, q = idx & 15;
-            const int hy = (int)((unsigned)hp / (unsigned)HW), hx = hp - hy * HW;
-            const int yy = y0 - 1 + hy, xx = x0 - 1 + hx;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if ((unsigned)yy < (unsigned)h && (unsigned)xx < (unsigned)w)
-                v = *(const float4*)(A + (((size_t)img * h + yy) * w + xx) * CK + (chunk << 6) + q * 4);
-            *(uint2*)(Xs + hp * 128 + (((q >> 1) ^ hkey(hp)) << 4) + (q & 1) * 8) = make_uint2(pack_el16x2(v.x, v.y), pack_el16x2(v.z, v.w));
-        }
-        store_b(0);
-        __syncthreads();
-#pragma unroll 1
-        for (int tap = 0; tap < 9; ++tap) {
-            const int buf = tap & 1;
-            if (tap + 1 < 9) load_b(chunk, tap + 1);
-            const int ky = tap / 3, kx = tap - 3 * ky;
-            const int hp = hp00 + ky * HW + kx;
-            const char* ap = Xs + hp * 128;
-            const int akey = hkey(hp);
-            const char* bp = Bs + buf * B_BYTES;
+            for (int tap = 0; tap < 9; ++tap) {
+                // (a raw s_barrier: __syncthreads() is a fence, and the compiler drains vmcnt to 0 in front of it -- the whole ring)
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((RING - 2) * BI) : "memory");
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                if (tap == 0 && has_next) halo_load(last ? tile + 1 : tile, last ? 0 : chunk + 1);
+                issue_b();
+                const int hp = hp00 + (tap / 3) * HW + (tap % 3);
+                const char* ap = Xs + hp * 128;
+                const int akey = hkey(hp);
+                const char* bp = Bring + slot * B_BYTES;
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const int c16 = ks * 2 + hi;
-                const el16x8_t a = *(const el16x8_t*)(ap + ((c16 ^ akey) << 4));
+                for (int ks = 0; ks < 4; ++ks) {
+                    const int c16 = ks * 2 + hi;
+                    const el16x8_t a = *(const el16x8_t*)(ap + ((c16 ^ akey) << 4));
 #pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    const int n = t * 32 + l31;
-                    const el16x8_t b = *(const el16x8_t*)(bp + n * 128 + ((c16 ^ ((n >> 1) & 7)) << 4));
-                    acc[t] = DYF_MFMA_32x32x16(a, b, acc[t], 0, 0, 0);
+                    for (int t = 0; t < NT; ++t) {
+                        const int n = t * 32 + l31;
+                        const el16x8_t b = *(const el16x8_t*)(bp + n * 128 + ((c16 ^ ((n >> 1) & 7)) << 4));
+                        acc[t] = DYF_MFMA_32x32x16(a, b, acc[t], 0, 0, 0);
+                    }
                 }
+                if (++slot == RING) slot = 0;
             }
-            if (tap + 1 < 9) store_b(buf ^ 1);
-            __syncthreads();
+            // the other halo buffer was last read a whole chunk (nine barriers) ago
+            if (has_next) halo_store(xbuf ^ 1);
+            xbuf ^= 1;
+        }
+        // D[i][j]: lane j = l31 holds output channel n0 + 32 t + l31, register r the pixel i = 8 (r >> 2) + 4 hi + (r & 3) of the block
+        const int img = tile / tiles_per_img, t_in = tile - img * tiles_per_img;
+        const int y0 = (t_in / tiles_x) * TH, x0 = (t_in % tiles_x) * TW;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int n = n0 + t * 32 + l31;
+            const float bv = bias ? bias[n] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = 8 * (r >> 2) + 4 * hi + (r & 3);
+                const int y = y0 + 2 * wave + (i >> 4), x = x0 + (i & 15);
+                if (y < h && x < w) C[(((size_t)img * h + y) * w + x) * NC + n] = acc[t][r] + bv;
+                acc[t][r] = 0.0f;
+            }
         }
     }
-    // D[i][j]: lane j = l31 holds output channel n0 + 32 t + l31, register r the pixel i = 8 (r >> 2) + 4 hi + (r & 3) of the block
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const int n = n0 + t * 32 + l31;
-        const float bv = bias ? bias[n] : 0.0f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int i = 8 * (r >> 2) + 4 * hi + (r & 3);
-            const int y = y0 + 2 * wave + (i >> 4), x = x0 + (i & 15);
-            if (y < h && x < w) C[(((size_t)img * h + y) * w + x) * NC + n] = acc[t][r] + bv;
-        }
-    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the look-ahead DMA of steps past the end must land before the LDS is released
 #endif
 }
 
@@ -286,17 +328,25 @@ bool thalo_conv3x3(const TConv& g, int mode, const float* A, const float* W, con
     if (ws == nullptr || welems > ws_floats * 2) return false;
     const int tiles_x = (g.w + TW - 1) / TW, tiles_per_img = tiles_x * ((g.h + TH - 1) / TH);
     const long long tiles = (long long)g.n * tiles_per_img;
-    const int bn = NC % 128 == 0 ? 128 : 64;
-    if (tiles * (NC / bn) < 192 || tiles > 0x7fffffffll) return false;  // small planes: the split-K forms of train_gemm.hip
+    // 64-channel column blocks (two workgroups per CU) also where 128 divides: NS B=32 step 110 -> 109 ms, ResNet-UNet B=64 144 -> 141 ms;
+    // the column blocks of a tile are neighbours in the grid (its halo is read from L2 by all but the first)
+    constexpr int bn = 64;
+    if (tiles * (NC / bn) < 192 || tiles > 0x7fffffffll) return false;  // small planes: the split-K forms of train_gemm.hip  // small planes: the split-K forms of train_gemm.hip
     el16_t* wb = (el16_t*)ws;
     dyf_form_note(mode ? "t_halo3x3_16:dgrad" : "t_halo3x3_16:forward", g.n);
     hipLaunchKernelGGL(t_pack_w16, dim3((unsigned)((welems + 255) / 256)), dim3(256), 0, st, W, g.cin, g.cout, mode, wb);
-    if (bn == 128)
-        hipLaunchKernelGGL(t_halo3x3_16<128>, dim3((unsigned)tiles, NC / 128), dim3(256), 0, st, g.n, g.h, g.w, CK, NC, A, wb, bias, C, tiles_x,
-                           tiles_per_img);
-    else
-        hipLaunchKernelGGL(t_halo3x3_16<64>, dim3((unsigned)tiles, NC / 64), dim3(256), 0, st, g.n, g.h, g.w, CK, NC, A, wb, bias, C, tiles_x,
-                           tiles_per_img);
+    const int nblocks = NC / bn;
+    // a workgroup streams several tiles (prefetch runs across tile boundaries); about 2 048 workgroups per launch
+    const int per = (int)std::max<long long>(1, std::min<long long>(16, tiles * nblocks / 2048));
+    const long long wgs = (tiles + per - 1) / per * nblocks;
+    constexpr int XS = HP * 128 + 512;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)t_halo3x3_16<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * XS + 4 * 64 * 128);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(t_halo3x3_16<64>, dim3((unsigned)wgs), dim3(256), 2 * XS + 4 * 64 * 128, st, g.h, g.w, CK, NC, A, wb, bias, C, tiles_x,
+                       tiles_per_img, (int)tiles, per, nblocks);
     return true;
 }
 

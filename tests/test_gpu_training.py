@@ -384,7 +384,8 @@ def test_gpu_resident_parameters_train_like_cpu_resident_ones():
     for k, a in finals[0].items():
         b = finals[1][k]
         if a.is_floating_point():
-            assert torch.allclose(a, b, rtol=1e-4, atol=2e-6), k
+            # (atol: the fp32 atomics of the weight-gradient kernels leave run-to-run noise of a few 1e-6 after two steps -- seen 1 run in 5)
+            assert torch.allclose(a, b, rtol=1e-4, atol=1e-5), k
         else:
             assert torch.equal(a, b), k
 
