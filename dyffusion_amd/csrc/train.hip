@@ -433,6 +433,66 @@ __global__ __launch_bounds__(256) void t_conv_dgrad_smalln_s2(TConv g, const flo
     if (g.cin > 3) o[3] = a3 + (bias ? bias[3] : 0.0f);
 }
 
+// The 4 x 4 / stride 2 / pad 1 case with 64 source channels (the readout's transposed conv) with the source rows in LDS: the form
+// above has every lane walk the 256-byte rows of its four source pixels alone (16 bytes of a line per load instruction, each
+// line fetched again by the three other parity classes: 2.0 ms per launch at 32 rows x 512^2, 8 ms of a 108 ms step).  Here the
+// workgroup's three source rows x 66 columns are staged once with coalesced loads (pixel pitch 68 floats: the lanes' 16-byte
+// reads fall on distinct banks) and serve all four parity classes.
+constexpr int CT_COLS = 66, CT_PITCH = 68;
+__global__ __launch_bounds__(256) void t_conv_dgrad_smalln_s2_rows(TConv g, const float* dz, const float* w, const float* bias, float* dx) {
+    extern __shared__ __attribute__((aligned(16))) float ct_smem[];
+    float4* sn_w = (float4*)ct_smem;              // [16 taps][64 co] x (cin <= 4 weights)
+    float* zs = ct_smem + 16 * 64 * 4;            // [3 rows][66 columns][68]
+    for (int i = threadIdx.x; i < 16 * 64; i += 256) {
+        const int tap = i >> 6, co = i & 63;
+        const float* wp = w + ((size_t)co * 16 + tap) * g.cin;
+        sn_w[i] = make_float4(wp[0], g.cin > 1 ? wp[1] : 0.0f, g.cin > 2 ? wp[2] : 0.0f, g.cin > 3 ? wp[3] : 0.0f);
+    }
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int py = wave >> 1, px = wave & 1;
+    const int wc = (g.w / 2 + 63) / 64, hh = g.h / 2;
+    int bid = blockIdx.x;
+    const int cx = bid % wc;
+    bid /= wc;
+    const int ry = bid % hh, b = bid / hh;
+    for (int idx = threadIdx.x; idx < 3 * CT_COLS * 16; idx += 256) {
+        const int r = idx / (CT_COLS * 16), rem = idx - r * (CT_COLS * 16), pc = rem >> 4, q = rem & 15;
+        const int oy = ry - 1 + r, ox = cx * 64 - 1 + pc;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if ((unsigned)oy < (unsigned)g.ho && (unsigned)ox < (unsigned)g.wo) v = *(const float4*)(dz + (((size_t)b * g.ho + oy) * g.wo + ox) * 64 + q * 4);
+        *(float4*)(zs + (r * CT_COLS + pc) * CT_PITCH + q * 4) = v;
+    }
+    __syncthreads();
+    const int iy = 2 * ry + py, ix = 2 * (cx * 64 + lane) + px;
+    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+#pragma unroll
+    for (int jy = 0; jy < 2; ++jy) {
+        const int ky = ((py + 1) & 1) + 2 * jy, oy = (iy + 1 - ky) >> 1;   // rows outside the image were staged as zeros
+        const int r = oy - (ry - 1);
+#pragma unroll
+        for (int jx = 0; jx < 2; ++jx) {
+            const int kx = ((px + 1) & 1) + 2 * jx, ox = (ix + 1 - kx) >> 1;
+            const float* zp = zs + (r * CT_COLS + (ox - (cx * 64 - 1))) * CT_PITCH;
+            const float4* wt = sn_w + (ky * 4 + kx) * 64;
+#pragma unroll 4
+            for (int c0 = 0; c0 < 64; c0 += 4) {
+                const float4 z = *(const float4*)(zp + c0);
+                const float4 w0 = wt[c0], w1 = wt[c0 + 1], w2 = wt[c0 + 2], w3 = wt[c0 + 3];
+                a0 = fmaf(z.x, w0.x, fmaf(z.y, w1.x, fmaf(z.z, w2.x, fmaf(z.w, w3.x, a0))));
+                a1 = fmaf(z.x, w0.y, fmaf(z.y, w1.y, fmaf(z.z, w2.y, fmaf(z.w, w3.y, a1))));
+                a2 = fmaf(z.x, w0.z, fmaf(z.y, w1.z, fmaf(z.z, w2.z, fmaf(z.w, w3.z, a2))));
+                a3 = fmaf(z.x, w0.w, fmaf(z.y, w1.w, fmaf(z.z, w2.w, fmaf(z.w, w3.w, a3))));
+            }
+        }
+    }
+    if (ix >= g.w) return;
+    float* o = dx + (((size_t)b * g.h + iy) * g.w + ix) * g.cin;
+    o[0] = a0 + (bias ? bias[0] : 0.0f);
+    if (g.cin > 1) o[1] = a1 + (bias ? bias[1] : 0.0f);
+    if (g.cin > 2) o[2] = a2 + (bias ? bias[2] : 0.0f);
+    if (g.cin > 3) o[3] = a3 + (bias ? bias[3] : 0.0f);
+}
+
 // Weight gradient of a conv with a handful of INPUT channels (the 1x1 stem, cin = 5; the readout's transposed conv, cin = 3,
 // 16 taps), cout a multiple of 64: the tiled kernel above spends two barriers per 16 pixels on a 16 x 16 tile of which 3 - 5
 // columns exist (3.3 ms per launch at 32 rows).  Here a wave owns 64 output channels (lane = co) and walks its share of the
@@ -942,6 +1002,19 @@ dyf_status conv_dgrad(dyf_engine* e, const TConv& g, const float* dz, const floa
         return DYF_OK;
     }
     static const bool small = !(getenv("DYF_TRAIN_SMALLC") && atoi(getenv("DYF_TRAIN_SMALLC")) == 0);
+    if (small && g.s == 2 && g.k == 4 && g.p == 1 && g.cin <= 4 && g.cout == 64 && g.h % 2 == 0 && g.w % 2 == 0 && g.ho == g.h / 2 && g.wo == g.w / 2 &&
+        !(getenv("DYF_TRAIN_CT_ROWS") && atoi(getenv("DYF_TRAIN_CT_ROWS")) == 0)) {
+        const int wc = (g.w / 2 + 63) / 64;
+        constexpr size_t lds = (size_t)(16 * 64 * 4 + 3 * CT_COLS * CT_PITCH) * sizeof(float);
+        static bool attr_done = false;
+        if (!attr_done) {
+            (void)hipFuncSetAttribute((const void*)t_conv_dgrad_smalln_s2_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            attr_done = true;
+        }
+        hipLaunchKernelGGL(t_conv_dgrad_smalln_s2_rows, dim3((unsigned)((long long)g.n * (g.h / 2) * wc)), dim3(256), lds, st, g, dz, w, bias, dx);
+        TK(hipGetLastError());
+        return DYF_OK;
+    }
     if (small && g.s == 2 && g.cin <= 4 && g.cout % 4 == 0 && g.h % 2 == 0 && g.w % 2 == 0 && (size_t)g.k * g.k * g.cout * 16 <= 65536) {
         const int wc = (g.w / 2 + 63) / 64;
         hipLaunchKernelGGL(t_conv_dgrad_smalln_s2, dim3((unsigned)((long long)g.n * (g.h / 2) * wc)), dim3(256), (size_t)g.k * g.k * g.cout * 16, st,
@@ -983,6 +1056,7 @@ dyf_status conv_wgrad(dyf_engine* e, const TConv& g, const float* dz, const floa
         bool launched = false;
         SMALLC(1, 1) SMALLC(1, 2) SMALLC(1, 3) SMALLC(1, 4) SMALLC(1, 5) SMALLC(1, 6) SMALLC(1, 7) SMALLC(1, 8)
         SMALLC(4, 1) SMALLC(4, 2) SMALLC(4, 3) SMALLC(4, 4)
+        SMALLC(7, 1) SMALLC(7, 2)  // the ResNet-UNet's 7 x 7 init conv on 1-2 input channels (98 sums per lane)
 #undef SMALLC
         if (launched) {
             TK(hipGetLastError());

@@ -229,7 +229,7 @@ constexpr int GK16 = 32, LDR16 = 40;  // K stage, LDS row pitch in 16-bit elemen
 
 template <int MODE>
 __global__ __launch_bounds__(256) void t_gemm_mfma16(dyf::TConv g, const float* __restrict__ Ap, const float* __restrict__ Bp,
-                                                     const float* __restrict__ bias, float* __restrict__ Cp, int split_len) {
+                                                     const float* __restrict__ bias, float* __restrict__ Cp, int split_len, int pmode) {
 #if defined(__HIP_DEVICE_COMPILE__)
     __shared__ __attribute__((aligned(16))) el16_t As[2][GM * LDR16];
     __shared__ __attribute__((aligned(16))) el16_t Bs[2][GN * LDR16];
@@ -239,7 +239,11 @@ __global__ __launch_bounds__(256) void t_gemm_mfma16(dyf::TConv g, const float* 
     const int tm = blockIdx.x, tn = blockIdx.y;
     const int taps = g.k * g.k;
     const long long opix = (long long)g.n * g.ho * g.wo, ipix = (long long)g.n * g.h * g.w;
-    const long long M = MODE == TG_FWD ? opix : MODE == TG_DGRAD ? ipix : g.cout;
+    // pmode (data gradient of a 4 x 4 / stride 2 / pad 1 conv, h and w even): blockIdx.z is the parity class (iy & 1, ix & 1) of the input
+    // pixels of this launch slice; a class is reached by 2 x 2 of the 16 taps only (ky = (iy + 1) mod 2 (+ 2), kx likewise), so its rows
+    // run a dense K = 4 cout instead of 16 cout with three quarters of the gathers predicated off
+    const int ppy = (MODE == TG_DGRAD && pmode) ? (int)(blockIdx.z >> 1) : 0, ppx = (MODE == TG_DGRAD && pmode) ? (int)(blockIdx.z & 1) : 0;
+    const long long M = MODE == TG_FWD ? opix : MODE == TG_DGRAD ? (pmode ? ipix / 4 : ipix) : g.cout;
     const int CK = MODE == TG_FWD ? g.cin : g.cout;
     int tap = 0;
     long long kbeg = 0, kend = 0;
@@ -250,7 +254,7 @@ __global__ __launch_bounds__(256) void t_gemm_mfma16(dyf::TConv g, const float* 
         kend = kbeg + split_len < opix ? kbeg + split_len : opix;
         nstage = (int)((kend - kbeg + GK16 - 1) / GK16);
     } else {
-        const int total = taps * CK / GK16;
+        const int total = (MODE == TG_DGRAD && pmode ? 4 : taps) * CK / GK16;
         st0 = split_len > 0 ? (int)blockIdx.z * split_len : 0;
         nstage = split_len > 0 ? min(split_len, total - st0) : total;
     }
@@ -265,11 +269,13 @@ __global__ __launch_bounds__(256) void t_gemm_mfma16(dyf::TConv g, const float* 
         if (MODE != TG_WGRAD) {
             const long long m = (long long)tm * GM + (s >> 3);
             a_ok[i] = m < M;
-            const int pw = MODE == TG_FWD ? g.wo : g.w, ph = MODE == TG_FWD ? g.ho : g.h;
+            const bool pm = MODE == TG_DGRAD && pmode;
+            const int pw = MODE == TG_FWD ? g.wo : (pm ? g.w / 2 : g.w), ph = MODE == TG_FWD ? g.ho : (pm ? g.h / 2 : g.h);
             const long long mm = a_ok[i] ? m : 0;
             a_x[i] = (int)(mm % pw);
             a_y[i] = (int)((mm / pw) % ph);
             a_b[i] = (int)(mm / ((long long)pw * ph));
+            if (pm) { a_x[i] = 2 * a_x[i] + ppx; a_y[i] = 2 * a_y[i] + ppy; }
         }
     }
     const int sh = (g.s & (g.s - 1)) == 0 ? __builtin_ctz((unsigned)g.s) : -1;  // (as in t_gemm_mfma)
@@ -287,8 +293,10 @@ __global__ __launch_bounds__(256) void t_gemm_mfma16(dyf::TConv g, const float* 
     auto load = [&](int stage) {
         if (MODE != TG_WGRAD) {
             const int k0 = stage * GK16;
-            const int tp = k0 / CK, c0 = k0 - tp * CK;
-            const int ky = tp / g.k, kx = tp - ky * g.k;
+            const int tq = k0 / CK, c0 = k0 - tq * CK;
+            const bool pm = MODE == TG_DGRAD && pmode;
+            const int ky = pm ? ((ppy + 1) & 1) + 2 * (tq >> 1) : tq / g.k, kx = pm ? ((ppx + 1) & 1) + 2 * (tq & 1) : tq - (tq / g.k) * g.k;
+            const int tp = ky * g.k + kx;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int kq = (tid + 256 * i) & 7;
@@ -403,7 +411,11 @@ __global__ __launch_bounds__(256) void t_gemm_mfma16(dyf::TConv g, const float* 
                 atomicAdd(Cp + ((size_t)m * taps + tap) * g.cin + n, acc[i][r]);
             } else {
                 const int NC = MODE == TG_FWD ? g.cout : g.cin;
-                if (split_len > 0) Cp[((size_t)blockIdx.z * M + m) * NC + n] = acc[i][r];
+                if (MODE == TG_DGRAD && pmode) {
+                    const int pw = g.w / 2, ph = g.h / 2;
+                    const int cx = (int)(m % pw), cy = (int)((m / pw) % ph), cb = (int)(m / ((long long)pw * ph));
+                    Cp[(((size_t)cb * g.h + 2 * cy + ppy) * g.w + 2 * cx + ppx) * NC + n] = acc[i][r] + bv;
+                } else if (split_len > 0) Cp[((size_t)blockIdx.z * M + m) * NC + n] = acc[i][r];
                 else Cp[(size_t)m * NC + n] = acc[i][r] + bv;
             }
         }
@@ -453,7 +465,7 @@ bool tgemm_conv_fwd(const TConv& g, const float* x, const float* wt, const float
     plan_splitk(mt * (g.cout / GN), g.k * g.k * g.cin / (h16 ? GK16 : GK), splits, len);
     if (splits > 1 && (ws == nullptr || (size_t)splits * M * g.cout > ws_floats)) { splits = 1; len = 0; }
     if (h16)
-        hipLaunchKernelGGL(t_gemm_mfma16<TG_FWD>, dim3((unsigned)mt, g.cout / GN, splits), dim3(256), 0, st, g, x, wt, bias, splits > 1 ? ws : y, len);
+        hipLaunchKernelGGL(t_gemm_mfma16<TG_FWD>, dim3((unsigned)mt, g.cout / GN, splits), dim3(256), 0, st, g, x, wt, bias, splits > 1 ? ws : y, len, 0);
     else
         hipLaunchKernelGGL(t_gemm_mfma<TG_FWD>, dim3((unsigned)mt, g.cout / GN, splits), dim3(256), 0, st, g, x, wt, bias, splits > 1 ? ws : y, len);
     if (splits > 1)
@@ -467,11 +479,21 @@ bool tgemm_conv_dgrad(const TConv& g, const float* dz, const float* w, const flo
     const long long M = (long long)g.n * g.h * g.w, mt = (M + GM - 1) / GM;
     const bool h16 = train_operands16() && g.cout % GK16 == 0;
     if (h16 && thalo_conv3x3(g, 1, dz, w, bias, dx, ws, ws_floats, st)) return true;
+    {   // 4 x 4 / stride 2 / pad 1: one launch slice per parity class of the input pixels (see the kernel); small planes keep split-K
+        const bool pclass = !(getenv("DYF_TRAIN_DGRAD_PARITY") && atoi(getenv("DYF_TRAIN_DGRAD_PARITY")) == 0);  // per call: tests flip it
+        const long long mq = ((long long)g.n * g.h * g.w / 4 + GM - 1) / GM;
+        if (h16 && pclass && g.k == 4 && g.s == 2 && g.p == 1 && g.h % 2 == 0 && g.w % 2 == 0 && g.ho == g.h / 2 && g.wo == g.w / 2 &&
+            mq * (g.cin / GN) >= 64 && mq <= 0x7fffffffll) {
+            dyf_form_note("t_gemm_mfma16:dgrad_parity", g.n);
+            hipLaunchKernelGGL(t_gemm_mfma16<TG_DGRAD>, dim3((unsigned)mq, g.cin / GN, 4), dim3(256), 0, st, g, dz, w, bias, dx, 0, 1);
+            return true;
+        }
+    }
     int splits, len;
     plan_splitk(mt * (g.cin / GN), g.k * g.k * g.cout / (h16 ? GK16 : GK), splits, len);
     if (splits > 1 && (ws == nullptr || (size_t)splits * M * g.cin > ws_floats)) { splits = 1; len = 0; }
     if (h16)
-        hipLaunchKernelGGL(t_gemm_mfma16<TG_DGRAD>, dim3((unsigned)mt, g.cin / GN, splits), dim3(256), 0, st, g, dz, w, bias, splits > 1 ? ws : dx, len);
+        hipLaunchKernelGGL(t_gemm_mfma16<TG_DGRAD>, dim3((unsigned)mt, g.cin / GN, splits), dim3(256), 0, st, g, dz, w, bias, splits > 1 ? ws : dx, len, 0);
     else
         hipLaunchKernelGGL(t_gemm_mfma<TG_DGRAD>, dim3((unsigned)mt, g.cin / GN, splits), dim3(256), 0, st, g, dz, w, bias, splits > 1 ? ws : dx, len);
     if (splits > 1)
@@ -493,7 +515,7 @@ bool tgemm_conv_wgrad(const TConv& g, const float* dz, const float* x, float* dw
     splits = (pix + len - 1) / len;
     if ((long long)taps * splits > 65535) return false;
     if (h16)
-        hipLaunchKernelGGL(t_gemm_mfma16<TG_WGRAD>, dim3(mt, nt, (unsigned)(taps * splits)), dim3(256), 0, st, g, dz, x, nullptr, dw, len);
+        hipLaunchKernelGGL(t_gemm_mfma16<TG_WGRAD>, dim3(mt, nt, (unsigned)(taps * splits)), dim3(256), 0, st, g, dz, x, nullptr, dw, len, 0);
     else
         hipLaunchKernelGGL(t_gemm_mfma<TG_WGRAD>, dim3(mt, nt, (unsigned)(taps * splits)), dim3(256), 0, st, g, dz, x, nullptr, dw, len);
     return true;

@@ -370,6 +370,29 @@ def test_16bit_halo_training_convs_match_the_plain_kernels(case, kind, monkeypat
         assert split <= 2e-5 and unsplit <= 2e-5
 
 
+@pytest.mark.parametrize("case", [(8, 64, 64, 64, 128, 4, 2, 1), (4, 60, 92, 128, 64, 4, 2, 1), (2, 128, 128, 128, 256, 4, 2, 1)],
+                         ids=lambda c: "x".join(map(str, c)))
+def test_16bit_stride2_data_gradient_by_parity_classes_matches_the_plain_kernel(case, monkeypatch):
+    """Data gradient of the 4 x 4 / stride 2 / pad 1 encoder convs with 16-bit operands: one launch slice per parity class of the input
+    pixels, each running its 2 x 2 reachable taps as a dense K = 4 cout (csrc/train_gemm.hip, pmode) instead of all 16 taps with three
+    quarters of the gathers predicated off.  Against the one-thread-per-output fp32 kernel on inputs rounded to 16 bit (2e-5), and the
+    16-tap form (DYF_TRAIN_DGRAD_PARITY=0) held to the same bound."""
+    import dyffusion_amd as D
+    from dyffusion_amd.engine import net_config
+    monkeypatch.setenv("DYF_TRAIN_OPERANDS", "bf16")
+    cfg = net_config(in_channels=3, cond_channels=2, out_channels=3, dim=64, with_time_emb=True, upsample_dims=(64, 64), dropout=0.0)
+    eng = D.HipEngine(cfg, cfg, 23, 11, max_batch=1, use_graph=False)
+    for parity in ("1", "0"):
+        monkeypatch.setenv("DYF_TRAIN_DGRAD_PARITY", parity)
+        eng.form_log(True)
+        split, unsplit, took = eng.train_conv_check(1, *case, seed=23)
+        forms = eng.form_log_read()
+        eng.form_log(False)
+        assert took and ("t_gemm_mfma16:dgrad_parity" in forms) == (parity == "1"), forms
+        print(f"dgrad {case} parity={parity}: rel max err {split:.2e} / {unsplit:.2e}")
+        assert split <= 2e-5 and unsplit <= 2e-5
+
+
 def test_gpu_resident_parameters_train_like_cpu_resident_ones():
     """A forecaster moved to the GPU: gradients are exported device-to-device (dyf_train_export_dev) and the refreshed weights read
     in place (dyf_train_load_weights_dev).  Two SGD steps must produce the parameters of the CPU-resident run (host round
