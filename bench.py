@@ -376,7 +376,8 @@ def bench_train_steps(dev):
                              "samples_per_s": round(B / dt, 1)}
     log(f"train step unet_simple B={B}: {1e3 * dt:.1f} ms")
     # the same step with the training convs' operands rounded to 16 bits while they are staged (opt-in, DYF_TRAIN_OPERANDS; fp32
-    # tensors and master weights, fp32 accumulation; gradients within ~5e-2 of the fp32 step's norm, tests/test_gpu_training.py)
+    # tensors and master weights, fp32 accumulation; csrc/train_halo16.hip + train_gemm.hip t_gemm_mfma16; how far the gradients
+    # move: tests/test_gpu_training.py test_training_step_with_16bit_conv_operands_tracks_the_fp32_step)
     os.environ["DYF_TRAIN_OPERANDS"] = "bf16"
     try:
         dt16, loss16 = timed(step_ns, 2)
@@ -429,7 +430,8 @@ def bench_train_steps(dev):
             finally:
                 os.environ.pop("DYF_TRAIN_OPERANDS", None)
             out[key + "_16bit_operands"] = {"workload": out[key]["workload"].replace(", fp32", ", fp32 tensors, conv operands rounded to "
-                                                                                     "bf16 in the kernels (opt-in)"),
+                                                                                     f"{m2._engine.dtype} (the engine's 16-bit format) in the "
+                                                                                     "kernels (opt-in)"),
                                             "batch": B, "ms_per_step": round(1e3 * dt16, 1), "loss": round(loss16, 4),
                                             "loss_fp32_operands": round(loss, 4), "achieved": round(fl / dt16 / 1e12, 1),
                                             "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(fl / dt16 / 1e12 / PEAK_BF16_TFLOPS, 4),

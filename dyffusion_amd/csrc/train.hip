@@ -758,9 +758,13 @@ __global__ void t_norm_bwd_apply(TNorm a, const float* z, const float* dy, const
 // y[r][o] = bias[o] + sum_k f(x[r][k]) W[o][k] (f = SiLU when pre): one wave per output column o, lanes over k (coalesced rows
 // of W), every row r of the (small) batch from the same W row
 __global__ __launch_bounds__(256) void t_linear_fwd(const float* x, const float* W, const float* bias, int rows, int K, int O, int pre, float* y) {
+    // blockIdx.y: 16-row slice of the batch (one slice walked all 64 rows of an OISST step alone, SiLU of the whole input per output
+    // column: 63 us per call; launch with grid.y = ceil(rows / 16))
     const int o = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (o >= O) return;
-    for (int r0 = 0; r0 < rows; r0 += 4) {
+    const int rbeg = blockIdx.y * 16;
+    rows = min(rows, rbeg + 16);
+    for (int r0 = rbeg; r0 < rows; r0 += 4) {
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
         for (int k = lane; k < K; k += 64) {
             const float wv = W[(size_t)o * K + k];
@@ -1224,9 +1228,9 @@ dyf_status dyf_train_forward(dyf_engine* e, int32_t which, int32_t slot, const f
     if (n.cfg.with_time_emb) {
         TA(t.e0, nb * n.dim); TA(t.l1, nb * n.tdim); TA(t.gl, nb * n.tdim); TA(t.temb, nb * n.tdim);
         hipLaunchKernelGGL(t_sinusoid, dim3(nblk(nb * n.dim)), dim3(256), 0, st, time_dev, nb, n.dim, t.e0);
-        hipLaunchKernelGGL(t_linear_fwd, dim3((unsigned)((n.tdim + 3) / 4)), dim3(256), 0, st, t.e0, w.t_w1, w.t_b1, nb, n.dim, n.tdim, 0, t.l1);
+        hipLaunchKernelGGL(t_linear_fwd, dim3((unsigned)((n.tdim + 3) / 4), (unsigned)((nb + 15) / 16)), dim3(256), 0, st, t.e0, w.t_w1, w.t_b1, nb, n.dim, n.tdim, 0, t.l1);
         hipLaunchKernelGGL(t_gelu_fwd, dim3(nblk((long long)nb * n.tdim)), dim3(256), 0, st, t.l1, (long long)nb * n.tdim, t.gl);
-        hipLaunchKernelGGL(t_linear_fwd, dim3((unsigned)((n.tdim + 3) / 4)), dim3(256), 0, st, t.gl, w.t_w2, w.t_b2, nb, n.tdim, n.tdim, 0, t.temb);
+        hipLaunchKernelGGL(t_linear_fwd, dim3((unsigned)((n.tdim + 3) / 4), (unsigned)((nb + 15) / 16)), dim3(256), 0, st, t.gl, w.t_w2, w.t_b2, nb, n.tdim, n.tdim, 0, t.temb);
     }
     // ---- stem: cat -> outer resample -> 1x1 conv
     TA(t.x_in, (size_t)nb * hw * cin);
@@ -1280,7 +1284,7 @@ dyf_status dyf_train_forward(dyf_engine* e, int32_t which, int32_t slot, const f
                            w.blk[i].rvar, t.mean[i], t.rstd[i]);
         if (n.cfg.with_time_emb) {
             TA(t.ss[i], (size_t)nb * 2 * b.cout);
-            hipLaunchKernelGGL(t_linear_fwd, dim3((unsigned)((2 * b.cout + 3) / 4)), dim3(256), 0, st, t.temb, w.blk[i].fw, w.blk[i].fb, nb, n.tdim, 2 * b.cout, 1, t.ss[i]);
+            hipLaunchKernelGGL(t_linear_fwd, dim3((unsigned)((2 * b.cout + 3) / 4), (unsigned)((nb + 15) / 16)), dim3(256), 0, st, t.temb, w.blk[i].fw, w.blk[i].fb, nb, n.tdim, 2 * b.cout, 1, t.ss[i]);
         }
         TNorm a{nb, ohw, b.cout, 8, b.gn ? 1 : 0, b.act, t.mean[i], t.rstd[i], w.blk[i].gamma, w.blk[i].beta, t.ss[i], drop_on ? 1 : 0,
                 1.0f / (1.0f - n.cfg.dropout), keep_threshold16(n.cfg.dropout), rng_layer_salt((uint32_t)i), t.row_keys};
