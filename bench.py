@@ -375,16 +375,16 @@ def bench_train_steps(dev):
                              "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(fl / dt / 1e12 / PEAK_FP32_MFMA_TFLOPS, 3),
                              "samples_per_s": round(B / dt, 1)}
     log(f"train step unet_simple B={B}: {1e3 * dt:.1f} ms")
-    # the same step with the training convs' operands rounded to 16 bits while they are staged (opt-in, DYF_TRAIN_OPERANDS; fp32
+    # the same step with the training convs' operands rounded to 16 bits while they are staged (opt-in: train_precision=16; fp32
     # tensors and master weights, fp32 accumulation; csrc/train_halo16.hip + train_gemm.hip t_gemm_mfma16; how far the gradients
     # move: tests/test_gpu_training.py test_training_step_with_16bit_conv_operands_tracks_the_fp32_step)
-    os.environ["DYF_TRAIN_OPERANDS"] = "bf16"
+    m._engine.train_set_precision("16-mixed")  # the reference's trainer.precision=16: C-ABI dyf_train_set_precision
     try:
         dt16, loss16 = timed(step_ns, 2)
     finally:
-        os.environ.pop("DYF_TRAIN_OPERANDS", None)
+        m._engine.train_set_precision(32)
     out["unet_simple_ns_16bit_operands"] = {"workload": out["unet_simple_ns"]["workload"].replace(", fp32", ", fp32 tensors, conv operands "
-                                                                                                    "rounded to bf16 in the kernels (opt-in)"),
+                                                                                                    "rounded to bf16 in the kernels (train_precision=16)"),
                                             "batch": B, "ms_per_step": round(1e3 * dt16, 1), "loss": round(loss16, 4),
                                             "achieved": round(fl / dt16 / 1e12, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                                             "frac": round(fl / dt16 / 1e12 / PEAK_BF16_TFLOPS, 4),  # against the 16-bit MFMA peak: the operands are 16-bit
@@ -424,14 +424,14 @@ def bench_train_steps(dev):
                     "samples_per_s": round(B / dt, 1)}
         log(f"train step unet.Unet B={B}: {1e3 * dt:.1f} ms")
         if B == 64:  # the same step with the conv operands rounded to 16 bits while staged (opt-in; same launchers as the NS step)
-            os.environ["DYF_TRAIN_OPERANDS"] = "bf16"
+            m2._engine.train_set_precision("16-mixed")
             try:
                 dt16, loss16 = timed(step_rn, 3)
             finally:
-                os.environ.pop("DYF_TRAIN_OPERANDS", None)
+                m2._engine.train_set_precision(32)
             out[key + "_16bit_operands"] = {"workload": out[key]["workload"].replace(", fp32", ", fp32 tensors, conv operands rounded to "
                                                                                      f"{m2._engine.dtype} (the engine's 16-bit format) in the "
-                                                                                     "kernels (opt-in)"),
+                                                                                     "kernels (train_precision=16)"),
                                             "batch": B, "ms_per_step": round(1e3 * dt16, 1), "loss": round(loss16, 4),
                                             "loss_fp32_operands": round(loss, 4), "achieved": round(fl / dt16 / 1e12, 1),
                                             "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(fl / dt16 / 1e12 / PEAK_BF16_TFLOPS, 4),

@@ -12,7 +12,7 @@ LIB_PATH = os.environ.get("DYF_LIB") or os.path.join(_HERE, "lib", "libdyffusion
 LIB_PATH_F16 = os.environ.get("DYF_LIB_F16") or os.path.join(_HERE, "lib", "libdyffusion_hip_f16.so")
 DTYPES = {"bf16": 0, "bfloat16": 0, "fp16": 1, "float16": 1, "half": 1}
 
-DYF_ABI_VERSION = 7
+DYF_ABI_VERSION = 8
 DYF_OK, DYF_ERR_INVALID_ARGUMENT, DYF_ERR_UNSUPPORTED, DYF_ERR_HIP, DYF_ERR_STATE = range(5)
 NET_FORECASTER, NET_INTERPOLATOR = 0, 1
 ARCH_UNET_SIMPLE, ARCH_UNET_RESNET = 0, 1
@@ -108,6 +108,8 @@ SYMBOLS = [
     ("dyf_train_forward", C.c_int, [_P, C.c_int32, C.c_int32, _P, _P, _P, _P, C.c_int32, C.c_int32, _P]),
     ("dyf_train_backward", C.c_int, [_P, C.c_int32, _P, _P, C.c_int32, _P]),
     ("dyf_train_zero_grads", C.c_int, [_P, C.c_int32]),
+    ("dyf_train_set_precision", C.c_int, [_P, C.c_int32]),
+    ("dyf_train_precision", C.c_int32, [_P]),
     ("dyf_train_export", C.c_int, [_P, C.c_int32, C.c_int32, C.POINTER(C.c_char_p), C.POINTER(_P)]),
     ("dyf_criterion_grad", C.c_int, [_P, _P, _P, C.c_int64, C.c_int32, C.c_float, _P, _P]),
     ("dyf_train_conv_check", C.c_int, [_P] + [C.c_int32] * 9 + [C.c_uint32, C.POINTER(C.c_float)]),

@@ -152,6 +152,7 @@ struct dyf_engine {
     // overlap: tails of under-filled launches and launch gaps of one group are covered by the others
     std::vector<dyf_engine*> groups;
     bool is_group_child = false;
+    int train_precision = 0;  // dyf_train_set_precision: 0 = DYF_TRAIN_OPERANDS decides (default fp32), 32, 16
     int form_rows_scale = 1;             // child: kernel forms are chosen for this many times the rows of a launch (the siblings' share)
     hipStream_t group_stream = nullptr;  // child: the stream its share runs on
     hipEvent_t group_done = nullptr;     // child: recorded behind its share

@@ -1187,10 +1187,18 @@ dyf_status dyf_train_zero_grads(dyf_engine* e, int32_t which) {
     return DYF_OK;
 }
 
+dyf_status dyf_train_set_precision(dyf_engine* e, int32_t bits) {
+    if (!e || (bits != 0 && bits != 16 && bits != 32)) return fail(e, DYF_ERR_INVALID_ARGUMENT, "dyf_train_set_precision: bits must be 0, 16 or 32");
+    e->train_precision = bits;
+    return DYF_OK;
+}
+int32_t dyf_train_precision(const dyf_engine* e) { return e ? e->train_precision : -1; }
+
 dyf_status dyf_train_forward(dyf_engine* e, int32_t which, int32_t slot, const float* inputs_dev, const float* time_dev,
                              const float* cond_dev, float* out_dev, int32_t nb, int32_t flags, void* stream) {
     if (!e || which < 0 || which > 1 || slot < 0 || slot > 3 || !inputs_dev || !out_dev || nb < 1)
         return fail(e, DYF_ERR_INVALID_ARGUMENT, "dyf_train_forward: bad arguments");
+    const TrainPrecisionScope precision(e->train_precision);
     if (e->net[which].rn) {
         TK(hipSetDevice(e->cfg.device));
         if (e->train) {  // the slot now belongs to this forward: drop a unet_simple tape that may sit in it
@@ -1317,6 +1325,7 @@ dyf_status dyf_train_forward(dyf_engine* e, int32_t which, int32_t slot, const f
 
 dyf_status dyf_train_backward(dyf_engine* e, int32_t slot, const float* dout_dev, float* dinputs_dev, int32_t param_grads, void* stream) {
     if (!e || slot < 0 || slot > 3 || !dout_dev) return fail(e, DYF_ERR_INVALID_ARGUMENT, "dyf_train_backward: bad arguments");
+    const TrainPrecisionScope precision(e->train_precision);
     if (e->train && e->train->rtape[slot] && e->train->tape[slot].net < 0) {  // the slot holds a ResNet-UNet forward
         TK(hipSetDevice(e->cfg.device));
         return rn_train_backward(e, slot, dout_dev, dinputs_dev, param_grads, (hipStream_t)stream);
@@ -1727,7 +1736,8 @@ dyf_status dyf_train_conv_check(dyf_engine* e, int32_t kind, int32_t n, int32_t 
     hipLaunchKernelGGL(t_fill_hash, dim3(nblk(nz)), dim3(256), 0, st, z, nz, seed + 1u);
     hipLaunchKernelGGL(t_fill_hash, dim3(nblk(nw)), dim3(256), 0, st, wgt, nw, seed + 2u);   // used in BOTH weight layouts' index spaces
     hipLaunchKernelGGL(t_fill_hash, dim3(nblk(std::max(cin, cout))), dim3(256), 0, st, bias, (long long)std::max(cin, cout), seed + 3u);
-    if (const char* ops = getenv("DYF_TRAIN_OPERANDS"); ops && (!strcmp(ops, "bf16") || !strcmp(ops, "fp16") || !strcmp(ops, "16"))) {
+    const TrainPrecisionScope precision(e->train_precision);
+    if (train_operands16()) {
         hipLaunchKernelGGL(t_round16, dim3(nblk(nx)), dim3(256), 0, st, x, nx);
         hipLaunchKernelGGL(t_round16, dim3(nblk(nz)), dim3(256), 0, st, z, nz);
         hipLaunchKernelGGL(t_round16, dim3(nblk(nw)), dim3(256), 0, st, wgt, nw);

@@ -435,9 +435,13 @@ __global__ void t_splitk_finish(const float* ws, int splits, long long MN, int N
 
 namespace dyf {
 
-// DYF_TRAIN_OPERANDS=bf16 (or fp16, or 16): the training convs round their operands to the engine's 16-bit format while staging
-// them (t_gemm_mfma16); unset / fp32: fp32 operands (t_gemm_mfma).  Read per call: tests flip it in-process.
-static bool train_operands16() {
+// 16-bit operands: the training convs round their operands to the engine's 16-bit format while staging them (t_gemm_mfma16,
+// train_halo16.hip) -- chosen per engine by dyf_train_set_precision(16) (the reference's `trainer.precision=16`), or, for engines
+// that did not say (0), by DYF_TRAIN_OPERANDS=bf16 | fp16 | 16 (read per call: tests flip it in-process).  Otherwise fp32 operands.
+thread_local int g_train_precision = 0;
+bool train_operands16() {
+    if (g_train_precision == 16) return true;
+    if (g_train_precision == 32) return false;
     const char* v = getenv("DYF_TRAIN_OPERANDS");
     return v && (!strcmp(v, "bf16") || !strcmp(v, "fp16") || !strcmp(v, "16"));
 }

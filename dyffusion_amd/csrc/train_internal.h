@@ -13,6 +13,16 @@ struct TConv {  // geometry of one nn.Conv2d on NHWC fp32 tensors: x (n, h, w, c
 
 // fp32 MFMA implicit-GEMM forms (train_gemm.hip); return false when the shape is not covered (caller falls back to the VALU kernel)
 // ws / ws_floats: workspace for the split-K partial sums of launches with few output tiles (null: never split)
+// Operand format of the training convs for the calls of THIS thread: set by the training entry points from the engine's
+// dyf_train_set_precision (0 = the DYF_TRAIN_OPERANDS environment variable decides: unset / fp32 -> fp32 operands).
+extern thread_local int g_train_precision;
+bool train_operands16();
+struct TrainPrecisionScope {
+    int prev;
+    explicit TrainPrecisionScope(int p) : prev(g_train_precision) { g_train_precision = p; }
+    ~TrainPrecisionScope() { g_train_precision = prev; }
+};
+
 bool tgemm_conv_fwd(const TConv& g, const float* x, const float* wt, const float* bias, float* y, float* ws, size_t ws_floats,
                     hipStream_t st);
 bool tgemm_conv_dgrad(const TConv& g, const float* dz, const float* w, const float* bias, float* dx, float* ws, size_t ws_floats,

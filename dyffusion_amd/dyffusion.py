@@ -34,7 +34,7 @@ class DYffusion(nn.Module):
                  enable_forecaster_dropout: bool = False, max_batch: int = 64, use_graph: bool = True,
                  enable_mfma: bool = True, loss_function: str = "mean_squared_error", dtype: Optional[str] = None,
                  batch_invariant: bool = False, row_groups: Optional[int] = None, allow_bf16_long_rollout: bool = False,
-                 **kwargs):
+                 train_precision=None, **kwargs):
         super().__init__()
         if model is None:
             raise ValueError("Arg ``model`` is missing... Please provide a backbone model for the diffusion model (e.g. a Unet)")
@@ -105,7 +105,10 @@ class DYffusion(nn.Module):
         dtype = dtype or default_dtype_for(model)
         self._engine_opts = dict(max_batch=max_batch, use_graph=use_graph, enable_mfma=enable_mfma, dtype=dtype,
                                  batch_invariant=batch_invariant,  # batch_invariant: bit-identical rows under any batching / sharding
-                                 row_groups=row_groups)  # concurrent row groups of a sampling call (None = engine default)
+                                 row_groups=row_groups,  # concurrent row groups of a sampling call (None = engine default)
+                                 # operand precision of the training step's convolutions: the reference's `trainer.precision`
+                                 # (32 default; 16 / "16-mixed" / "bf16-mixed": HipEngine.train_set_precision)
+                                 train_precision=train_precision)
         self.allow_bf16_long_rollout = bool(allow_bf16_long_rollout)
         self._engine: Optional[HipEngine] = None
         self._plan_key = None

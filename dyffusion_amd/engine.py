@@ -72,10 +72,22 @@ def _f32c(t: torch.Tensor, name: str) -> torch.Tensor:
     return t.contiguous()
 
 
+def parse_train_precision(precision) -> int:
+    """Lightning-style precision value -> bits for dyf_train_set_precision (0 = not set)."""
+    if precision is None:
+        return 0
+    key = str(precision).lower()
+    if key in ("32", "32-true", "fp32", "float32"):
+        return 32
+    if key in ("16", "16-mixed", "bf16", "bf16-mixed", "fp16", "fp16-mixed"):
+        return 16
+    raise ValueError(f"train precision {precision!r}: expected 32 / '32-true' or 16 / '16-mixed' / 'bf16-mixed'")
+
+
 class HipEngine:
     def __init__(self, forecaster: L.NetConfig, interpolator: L.NetConfig, height: int, width: int, max_batch: int,
                  device: Optional[int] = None, use_graph: bool = True, enable_mfma: bool = True, dtype: str = "bf16",
-                 batch_invariant: bool = False, row_groups: Optional[int] = None):
+                 batch_invariant: bool = False, row_groups: Optional[int] = None, train_precision=None):
         if not torch.cuda.is_available():
             raise EngineError("no GPU visible: the DYffusion HIP engine needs an MI355X (gfx950); there is no CPU fallback")
         self.dtype = dtype
@@ -93,6 +105,8 @@ class HipEngine:
         self._h = h
         if row_groups is not None:  # None: the engine's own default (dyf_engine_create, DYF_ROW_GROUPS)
             self._check(self._lib.dyf_set_row_groups(self._h, int(row_groups)))
+        if train_precision is not None:
+            self.train_set_precision(train_precision)
         self._plan_keepalive = None
         self.n_out_slots = 0
         self._tape_net = {}       # tape slot -> network of the recorded training forward
@@ -501,6 +515,16 @@ class HipEngine:
         self._check(self._lib.dyf_train_backward(self._h, slot, dout.data_ptr(), None if din is None else din.data_ptr(),
                                                  int(param_grads), self._stream()))
         return din
+
+    def train_set_precision(self, precision) -> None:
+        """Operand precision of the training convolutions (dyf_train_set_precision; the reference's Lightning `trainer.precision`):
+        32 / "32" / "32-true" = fp32 operands (default), 16 / "16-mixed" / "bf16-mixed" = operands rounded to this engine's 16-bit
+        format while staged (fp32 tensors, master weights and accumulation), None = leave it to DYF_TRAIN_OPERANDS."""
+        self._check(self._lib.dyf_train_set_precision(self._h, parse_train_precision(precision)))
+
+    @property
+    def train_precision(self) -> int:
+        return int(self._lib.dyf_train_precision(self._h))
 
     def train_zero_grads(self, net: int):
         self._check(self._lib.dyf_train_zero_grads(self._h, net))

@@ -171,7 +171,7 @@ class Unet(nn.Module):
             # row_groups=1: this engine serves net_forward / the training step, never dyf_sample -- the default row groups would
             # cost a workspace and a packed weight copy each for nothing
             self._engine = HipEngine(cfg, cfg, hw[0], hw[1], max_batch=nb, use_graph=False, dtype=default_dtype_for(self),
-                                     row_groups=1)
+                                     row_groups=1, train_precision=getattr(self, "train_precision", None))
             self._engine_slot, self._engine_key = L.NET_FORECASTER, key
             upload_weights(self, self._engine, self._engine_slot)
         return self._engine

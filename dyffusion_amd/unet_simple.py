@@ -122,7 +122,8 @@ class UNet(nn.Module):
         if self._engine is None or (self._engine_key != "attached" and
                                     (self._engine_key[0] != key[0] or self._engine_key[1] < nb)):
             cfg = self.engine_net_config()
-            self._engine = HipEngine(cfg, cfg, hw[0], hw[1], max_batch=nb, use_graph=False, dtype=default_dtype_for(self))
+            self._engine = HipEngine(cfg, cfg, hw[0], hw[1], max_batch=nb, use_graph=False, dtype=default_dtype_for(self),
+                                     train_precision=getattr(self, "train_precision", None))
             self._engine_slot = L.NET_FORECASTER
             self._engine_key = key
             upload_weights(self, self._engine, self._engine_slot)

@@ -268,6 +268,54 @@ def test_training_step_with_16bit_conv_operands_tracks_the_fp32_step(dtype, monk
     assert rel[worst] > 1e-6  # the switch did select the 16-bit kernels
 
 
+def test_train_precision_knob_selects_the_operand_format(monkeypatch):
+    """`DYffusion(train_precision=...)` / `HipEngine.train_set_precision` -> C-ABI `dyf_train_set_precision` (the reference's Lightning
+    `trainer.precision`): 16 / "16-mixed" runs the 16-bit-operand kernels without any environment variable, 32 keeps fp32 operands even
+    when DYF_TRAIN_OPERANDS asks for 16 bits, None leaves the choice to the variable; bad values are refused."""
+    from tests.gpu_common import seeded_pair
+    mk = dict(dim=64, outer_sample_mode="bilinear", upsample_dims=[128, 128], with_time_emb=True, input_dropout=0.0, dropout=0.0)
+    hp = dict(timesteps=4, schedule="before_t1_only", additional_interpolation_steps=0, additional_interpolation_steps_factor=0,
+              interpolate_before_t1=True, time_encoding="dynamics", forward_conditioning="none", lambda_reconstruction=1.0,
+              lambda_reconstruction2=0.5, loss_function="l1", enable_interpolator_dropout=True, model=mk)
+    C, Cs, B = 3, 2, 4
+    PF, PI = seeded_pair(64, C, Cs)
+    g = torch.Generator().manual_seed(3)
+    xt_last, cond = torch.randn(B, C, 23, 11, generator=g), torch.randn(B, C, 23, 11, generator=g)
+    sc, t = torch.rand(B, Cs, 23, 11, generator=g), torch.tensor([0, 2, 3, 1])
+
+    def step(precision, env):
+        if env:
+            monkeypatch.setenv("DYF_TRAIN_OPERANDS", env)
+        else:
+            monkeypatch.delenv("DYF_TRAIN_OPERANDS", raising=False)
+        m = build_dyffusion(PF, PI, mk, C, Cs, hp, max_batch=B, train_precision=precision)
+        m.seed(7)
+        m.train()
+        m._ensure_engine((23, 11), B)
+        eng = m._engine
+        eng.form_log(True)
+        out = m.p_losses(xt_last.to(DEV), cond.to(DEV), t.to(DEV), static_condition=sc.to(DEV))
+        out["loss"].backward()
+        forms = eng.form_log_read()
+        eng.form_log(False)
+        bits = eng.train_precision
+        loss = float(out["loss"].detach())
+        m.eval()
+        eng.close()
+        return bits, any(k.startswith("t_halo3x3_16") for k in forms), loss
+
+    b_knob, used_knob, l_knob = step("16-mixed", None)
+    b_env, used_env, l_env = step(None, "bf16")
+    b_32, used_32, l_32 = step(32, "bf16")
+    b_def, used_def, l_def = step(None, None)
+    assert (b_knob, b_env, b_32, b_def) == (16, 0, 32, 0)
+    assert used_knob and used_env and not used_32 and not used_def
+    assert l_knob == pytest.approx(l_env, rel=1e-6) and l_32 == pytest.approx(l_def, rel=1e-6)
+    assert l_knob != l_def
+    with pytest.raises(ValueError):
+        build_dyffusion(PF, PI, mk, C, Cs, hp, max_batch=B, train_precision="8")._ensure_engine((23, 11), B)
+
+
 def test_sampling_after_training_uses_the_updated_weights():
     """Train -> sample -> train -> sample on ONE engine (captured rollout graph, weights re-uploaded after optimizer.step()):
     every sample must equal, bit for bit, what a fresh engine built from the current state_dict samples with the same seed --
