@@ -439,10 +439,11 @@ __global__ __launch_bounds__(256) void t_conv_dgrad_smalln_s2(TConv g, const flo
 // workgroup's three source rows x 66 columns are staged once with coalesced loads (pixel pitch 68 floats: the lanes' 16-byte
 // reads fall on distinct banks) and serve all four parity classes.
 constexpr int CT_COLS = 66, CT_PITCH = 68;
-__global__ __launch_bounds__(256) void t_conv_dgrad_smalln_s2_rows(TConv g, const float* dz, const float* w, const float* bias, float* dx) {
+__global__ __launch_bounds__(256) void t_conv_dgrad_smalln_s2_rows(TConv g, const float* dz, const float* w, const float* bias, float* dx, int pairs_per_wg) {
     extern __shared__ __attribute__((aligned(16))) float ct_smem[];
     float4* sn_w = (float4*)ct_smem;              // [16 taps][64 co] x (cin <= 4 weights)
     float* zs = ct_smem + 16 * 64 * 4;            // [3 rows][66 columns][68]
+    // (the weight table costs 3 072 strided 4-byte loads: a workgroup builds it once and walks pairs_per_wg output row pairs with it)
     for (int i = threadIdx.x; i < 16 * 64; i += 256) {
         const int tap = i >> 6, co = i & 63;
         const float* wp = w + ((size_t)co * 16 + tap) * g.cin;
@@ -450,47 +451,54 @@ __global__ __launch_bounds__(256) void t_conv_dgrad_smalln_s2_rows(TConv g, cons
     }
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int py = wave >> 1, px = wave & 1;
-    const int wc = (g.w / 2 + 63) / 64, hh = g.h / 2;
+    const int wc = (g.w / 2 + 63) / 64, hh = g.h / 2, groups = (hh + pairs_per_wg - 1) / pairs_per_wg;
     int bid = blockIdx.x;
     const int cx = bid % wc;
     bid /= wc;
-    const int ry = bid % hh, b = bid / hh;
-    for (int idx = threadIdx.x; idx < 3 * CT_COLS * 16; idx += 256) {
-        const int r = idx / (CT_COLS * 16), rem = idx - r * (CT_COLS * 16), pc = rem >> 4, q = rem & 15;
-        const int oy = ry - 1 + r, ox = cx * 64 - 1 + pc;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if ((unsigned)oy < (unsigned)g.ho && (unsigned)ox < (unsigned)g.wo) v = *(const float4*)(dz + (((size_t)b * g.ho + oy) * g.wo + ox) * 64 + q * 4);
-        *(float4*)(zs + (r * CT_COLS + pc) * CT_PITCH + q * 4) = v;
-    }
-    __syncthreads();
-    const int iy = 2 * ry + py, ix = 2 * (cx * 64 + lane) + px;
-    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+    const int rg = bid % groups, b = bid / groups;
+    const int ix = 2 * (cx * 64 + lane) + px;
+    const float b0 = bias ? bias[0] : 0.0f, b1 = bias && g.cin > 1 ? bias[1] : 0.0f, b2 = bias && g.cin > 2 ? bias[2] : 0.0f,
+                b3 = bias && g.cin > 3 ? bias[3] : 0.0f;
+    for (int ry = rg * pairs_per_wg; ry < min(hh, (rg + 1) * pairs_per_wg); ++ry) {
+        __syncthreads();  // the weight table is complete / every wave is done with the previous rows
+        for (int idx = threadIdx.x; idx < 3 * CT_COLS * 16; idx += 256) {
+            const int r = idx / (CT_COLS * 16), rem = idx - r * (CT_COLS * 16), pc = rem >> 4, q = rem & 15;
+            const int oy = ry - 1 + r, ox = cx * 64 - 1 + pc;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if ((unsigned)oy < (unsigned)g.ho && (unsigned)ox < (unsigned)g.wo) v = *(const float4*)(dz + (((size_t)b * g.ho + oy) * g.wo + ox) * 64 + q * 4);
+            *(float4*)(zs + (r * CT_COLS + pc) * CT_PITCH + q * 4) = v;
+        }
+        __syncthreads();
+        const int iy = 2 * ry + py;
+        float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
 #pragma unroll
-    for (int jy = 0; jy < 2; ++jy) {
-        const int ky = ((py + 1) & 1) + 2 * jy, oy = (iy + 1 - ky) >> 1;   // rows outside the image were staged as zeros
-        const int r = oy - (ry - 1);
+        for (int jy = 0; jy < 2; ++jy) {
+            const int ky = ((py + 1) & 1) + 2 * jy, oy = (iy + 1 - ky) >> 1;   // rows outside the image were staged as zeros
+            const int r = oy - (ry - 1);
 #pragma unroll
-        for (int jx = 0; jx < 2; ++jx) {
-            const int kx = ((px + 1) & 1) + 2 * jx, ox = (ix + 1 - kx) >> 1;
-            const float* zp = zs + (r * CT_COLS + (ox - (cx * 64 - 1))) * CT_PITCH;
-            const float4* wt = sn_w + (ky * 4 + kx) * 64;
+            for (int jx = 0; jx < 2; ++jx) {
+                const int kx = ((px + 1) & 1) + 2 * jx, ox = (ix + 1 - kx) >> 1;
+                const float* zp = zs + (r * CT_COLS + (ox - (cx * 64 - 1))) * CT_PITCH;
+                const float4* wt = sn_w + (ky * 4 + kx) * 64;
 #pragma unroll 4
-            for (int c0 = 0; c0 < 64; c0 += 4) {
-                const float4 z = *(const float4*)(zp + c0);
-                const float4 w0 = wt[c0], w1 = wt[c0 + 1], w2 = wt[c0 + 2], w3 = wt[c0 + 3];
-                a0 = fmaf(z.x, w0.x, fmaf(z.y, w1.x, fmaf(z.z, w2.x, fmaf(z.w, w3.x, a0))));
-                a1 = fmaf(z.x, w0.y, fmaf(z.y, w1.y, fmaf(z.z, w2.y, fmaf(z.w, w3.y, a1))));
-                a2 = fmaf(z.x, w0.z, fmaf(z.y, w1.z, fmaf(z.z, w2.z, fmaf(z.w, w3.z, a2))));
-                a3 = fmaf(z.x, w0.w, fmaf(z.y, w1.w, fmaf(z.z, w2.w, fmaf(z.w, w3.w, a3))));
+                for (int c0 = 0; c0 < 64; c0 += 4) {
+                    const float4 z = *(const float4*)(zp + c0);
+                    const float4 w0 = wt[c0], w1 = wt[c0 + 1], w2 = wt[c0 + 2], w3 = wt[c0 + 3];
+                    a0 = fmaf(z.x, w0.x, fmaf(z.y, w1.x, fmaf(z.z, w2.x, fmaf(z.w, w3.x, a0))));
+                    a1 = fmaf(z.x, w0.y, fmaf(z.y, w1.y, fmaf(z.z, w2.y, fmaf(z.w, w3.y, a1))));
+                    a2 = fmaf(z.x, w0.z, fmaf(z.y, w1.z, fmaf(z.z, w2.z, fmaf(z.w, w3.z, a2))));
+                    a3 = fmaf(z.x, w0.w, fmaf(z.y, w1.w, fmaf(z.z, w2.w, fmaf(z.w, w3.w, a3))));
+                }
             }
         }
+        if (ix < g.w) {
+            float* o = dx + (((size_t)b * g.h + iy) * g.w + ix) * g.cin;
+            o[0] = a0 + b0;
+            if (g.cin > 1) o[1] = a1 + b1;
+            if (g.cin > 2) o[2] = a2 + b2;
+            if (g.cin > 3) o[3] = a3 + b3;
+        }
     }
-    if (ix >= g.w) return;
-    float* o = dx + (((size_t)b * g.h + iy) * g.w + ix) * g.cin;
-    o[0] = a0 + (bias ? bias[0] : 0.0f);
-    if (g.cin > 1) o[1] = a1 + (bias ? bias[1] : 0.0f);
-    if (g.cin > 2) o[2] = a2 + (bias ? bias[2] : 0.0f);
-    if (g.cin > 3) o[3] = a3 + (bias ? bias[3] : 0.0f);
 }
 
 // Weight gradient of a conv with a handful of INPUT channels (the 1x1 stem, cin = 5; the readout's transposed conv, cin = 3,
@@ -539,6 +547,77 @@ __global__ __launch_bounds__(256) void t_conv_wgrad_smallc(TConv g, const float*
     for (int i = 0; i < NACC; ++i)
         atomicAdd(dw + (size_t)co * NACC + i, acc[i] + red[0][i][lane] + red[1][i][lane] + red[2][i][lane]);  // dw[co][tap][ci]
     if (db) atomicAdd(db + co, accb + red[0][NACC][lane] + red[1][NACC][lane] + red[2][NACC][lane]);
+}
+
+// The same weight gradient on the fp32 matrix cores (v_mfma_f32_32x32x2_f32: fp32 operands, so it serves both operand modes):
+// dW[co][j] = sum_p dz[p][co] * patch[p][j], j = (tap, ci) padded to 32 NT columns, one extra column of ones collects the bias gradient.
+// A wave walks its pixel range two pixels per MFMA (lanes hi = 0 / 1): the A fragment is the pixels' 128-byte row of dz, the B fragment
+// is gathered by per-lane CONSTANT offsets (lane j's tap and channel never change) from the pixel pair's base, taps outside the image
+// predicated to zero.  (The form above keeps taps x cin sums per lane and feeds them from scalar loads, one pixel at a time: 2.5 ms per
+// launch for the readout's 4 x 4 x 3 at 32 rows, 1.0 ms for the 7 x 7 x 2 init conv -- its traffic time is ~0.1 ms.)  wo even.
+typedef __attribute__((ext_vector_type(16))) float tw_f32x16;
+template <int NT>
+__global__ __launch_bounds__(256) void t_conv_wgrad_smallc_mfma(TConv g, const float* __restrict__ dz, const float* __restrict__ x,
+                                                                float* __restrict__ dw, float* __restrict__ db, int pairs_per_wave) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l31 = lane & 31, hi = lane >> 5;
+    const int cob = blockIdx.y * 64, nacc = g.k * g.k * g.cin;
+    const long long total_pairs = (long long)g.n * g.ho * g.wo / 2;
+    const long long pair0 = ((long long)blockIdx.x * 4 + wave) * pairs_per_wave;
+    const long long pair1 = pair0 + pairs_per_wave < total_pairs ? pair0 + pairs_per_wave : total_pairs;
+    int jy[NT], jx[NT], jc[NT], jkind[NT];  // column j = 32 t + l31: tap row / column, channel; kind 0 = padding, 1 = weight, 2 = ones
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int j = t * 32 + l31, tap = j / g.cin;
+        jkind[t] = j < nacc ? 1 : j == nacc ? 2 : 0;
+        jy[t] = tap / g.k;
+        jx[t] = tap - jy[t] * g.k;
+        jc[t] = j - tap * g.cin;
+    }
+    tw_f32x16 acc[2][NT];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[c][t][r] = 0.0f;
+    if (pair0 < pair1) {
+        const long long p0 = 2 * pair0;
+        int ox0 = (int)(p0 % g.wo), oy = (int)((p0 / g.wo) % g.ho), b = (int)(p0 / ((long long)g.wo * g.ho));
+        for (long long pair = pair0; pair < pair1; ++pair) {
+            const size_t p = (size_t)(2 * pair + hi);
+            const float a0 = dz[p * g.cout + cob + l31], a1 = dz[p * g.cout + cob + 32 + l31];
+            const int iy0 = oy * g.s - g.p, ix0 = (ox0 + hi) * g.s - g.p;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int iy = iy0 + jy[t], ix = ix0 + jx[t];
+                float bv = jkind[t] == 2 ? 1.0f : 0.0f;
+                if (jkind[t] == 1 && (unsigned)iy < (unsigned)g.h && (unsigned)ix < (unsigned)g.w)
+                    bv = x[(((size_t)b * g.h + iy) * g.w + ix) * g.cin + jc[t]];
+                acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv, acc[0][t], 0, 0, 0);
+                acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv, acc[1][t], 0, 0, 0);
+            }
+            ox0 += 2;
+            if (ox0 >= g.wo) {
+                ox0 = 0;
+                if (++oy >= g.ho) { oy = 0; ++b; }
+            }
+        }
+    }
+    // D[i][j]: lane j = l31, register r -> row i = 8 (r >> 2) + 4 hi + (r & 3)
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int j = t * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = cob + c * 32 + 8 * (r >> 2) + 4 * hi + (r & 3);
+                if (j < nacc) atomicAdd(dw + (size_t)co * nacc + j, acc[c][t][r]);   // dw[co][tap][ci]
+                else if (j == nacc && db) atomicAdd(db + co, acc[c][t][r]);
+            }
+        }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------ normalisation + FiLM + act + dropout
@@ -1015,7 +1094,11 @@ dyf_status conv_dgrad(dyf_engine* e, const TConv& g, const float* dz, const floa
             (void)hipFuncSetAttribute((const void*)t_conv_dgrad_smalln_s2_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             attr_done = true;
         }
-        hipLaunchKernelGGL(t_conv_dgrad_smalln_s2_rows, dim3((unsigned)((long long)g.n * (g.h / 2) * wc)), dim3(256), lds, st, g, dz, w, bias, dx);
+        // output row pairs per workgroup: as many as still leave ~2 048 workgroups
+        const long long all_pairs = (long long)g.n * (g.h / 2) * wc;
+        const int ppw = (int)std::max<long long>(1, std::min<long long>(16, all_pairs / 2048));
+        const int groups = (g.h / 2 + ppw - 1) / ppw;
+        hipLaunchKernelGGL(t_conv_dgrad_smalln_s2_rows, dim3((unsigned)((long long)g.n * groups * wc)), dim3(256), lds, st, g, dz, w, bias, dx, ppw);
         TK(hipGetLastError());
         return DYF_OK;
     }
@@ -1051,6 +1134,18 @@ dyf_status conv_wgrad(dyf_engine* e, const TConv& g, const float* dz, const floa
         return DYF_OK;
     }
     static const bool small = !(getenv("DYF_TRAIN_SMALLC") && atoi(getenv("DYF_TRAIN_SMALLC")) == 0);
+    if (small && g.cout % 64 == 0 && M >= 4096 && g.wo % 2 == 0 && g.k * g.k * g.cin + 1 <= 128 && g.cin <= 8 &&
+        !(getenv("DYF_TRAIN_SMALLC_MFMA") && atoi(getenv("DYF_TRAIN_SMALLC_MFMA")) == 0)) {  // read per call: tests run both forms
+        const long long pairs = M / 2;
+        const int ppw = (int)std::max<long long>(64, (pairs + 2047) / 2048);  // ~2 048 waves per 64-channel block
+        const dim3 grid((unsigned)((pairs + 4ll * ppw - 1) / (4ll * ppw)), (unsigned)(g.cout / 64));
+        if (g.k * g.k * g.cin + 1 <= 64)
+            hipLaunchKernelGGL(t_conv_wgrad_smallc_mfma<2>, grid, dim3(256), 0, st, g, dz, x, dw, db, ppw);
+        else
+            hipLaunchKernelGGL(t_conv_wgrad_smallc_mfma<4>, grid, dim3(256), 0, st, g, dz, x, dw, db, ppw);
+        TK(hipGetLastError());
+        return DYF_OK;
+    }
     if (small && g.cout % 64 == 0 && M >= 4096) {
         const int cob = g.cout / 64;
         const long long blocks = std::max<long long>(1, std::min<long long>(M / 512, 1024 / cob));  // >= 512 pixels per workgroup
@@ -1716,7 +1811,7 @@ __global__ void t_maxabs2(const float* a, const float* b, long long n, unsigned*
 
 dyf_status dyf_train_conv_check(dyf_engine* e, int32_t kind, int32_t n, int32_t h, int32_t w, int32_t cin, int32_t cout, int32_t k,
                                 int32_t s, int32_t p, uint32_t seed, float* out_host) {
-    if (!e || !out_host || kind < 0 || kind > 2 || n < 1 || h < 1 || w < 1 || cin < 1 || cout < 1 || k < 1 || s < 1)
+    if (!e || !out_host || kind < 0 || kind > 3 || n < 1 || h < 1 || w < 1 || cin < 1 || cout < 1 || k < 1 || s < 1)
         return fail(e, DYF_ERR_INVALID_ARGUMENT, "dyf_train_conv_check: bad arguments");
     TK(hipSetDevice(e->cfg.device));
     if (!e->train) e->train = new TrainState();
@@ -1755,7 +1850,9 @@ dyf_status dyf_train_conv_check(dyf_engine* e, int32_t kind, int32_t n, int32_t 
             took = tgemm_conv_dgrad(g, z, wgt, bias, got, ws, TRAIN_SPLITK_FLOATS, st);
             hipLaunchKernelGGL(t_conv_dgrad, dim3(nblk(nx)), dim3(256), 0, st, g, z, wgt, bias, ref);
         } else {
-            took = tgemm_conv_wgrad(g, z, x, got, st);
+            // kind 3: whatever conv_wgrad picks for the shape (the small-channel forms sit behind it, not behind tgemm_conv_wgrad)
+            if (kind == 3) { CK(conv_wgrad(e, g, z, x, got, nullptr, st)); took = true; }
+            else took = tgemm_conv_wgrad(g, z, x, got, st);
             const long long M = (long long)n * ho * wo;
             const int tiles = k * k * ((cout + 15) / 16) * ((cin + 15) / 16);
             long long slices = std::max<long long>(1, std::min<long long>((M + 255) / 256, (4096 + tiles - 1) / tiles));
@@ -1776,7 +1873,7 @@ dyf_status dyf_train_conv_check(dyf_engine* e, int32_t kind, int32_t n, int32_t 
             if (!(ga > 0.0f)) res[pass] = 1.0f;
             if (getenv("DYF_TRAIN_CHECK_VERBOSE")) fprintf(stderr, "conv_check kind %d pass %d: max|diff| %g max|ref| %g max|got| %g\n", kind, pass, d, m, ga);
         }
-        if (kind == 2) { res[1] = res[0]; break; }
+        if (kind >= 2) { res[1] = res[0]; break; }
     }
 #undef CK
     TK(hipDeviceSynchronize());

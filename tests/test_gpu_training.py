@@ -441,6 +441,23 @@ def test_16bit_stride2_data_gradient_by_parity_classes_matches_the_plain_kernel(
         assert split <= 2e-5 and unsplit <= 2e-5
 
 
+@pytest.mark.parametrize("case", [(4, 64, 64, 5, 64, 1, 1, 0), (2, 128, 128, 3, 64, 4, 2, 1), (3, 60, 60, 2, 64, 7, 1, 3), (2, 96, 64, 1, 128, 7, 1, 3)],
+                         ids=lambda c: "x".join(map(str, c)))
+def test_small_channel_weight_gradient_on_the_matrix_cores_matches_the_plain_kernel(case, monkeypatch):
+    """Weight gradient of the convs with a handful of input channels (1 x 1 stem on 5, the readout's 4 x 4 / stride 2 on 3, the ResNet-UNet's
+    7 x 7 init conv on 1-2): `t_conv_wgrad_smallc_mfma` (fp32 MFMA, the (tap, channel) axis gathered by constant per-lane offsets, one column of
+    ones for the bias gradient's sums) and the per-lane-sums form it replaces, both against the one-thread-per-output kernel."""
+    import dyffusion_amd as D
+    from dyffusion_amd.engine import net_config
+    cfg = net_config(in_channels=3, cond_channels=2, out_channels=3, dim=64, with_time_emb=True, upsample_dims=(64, 64), dropout=0.0)
+    eng = D.HipEngine(cfg, cfg, 23, 11, max_batch=1, use_graph=False)
+    for mfma in ("1", "0"):
+        monkeypatch.setenv("DYF_TRAIN_SMALLC_MFMA", mfma)
+        err, _, took = eng.train_conv_check(3, *case, seed=31)
+        print(f"wgrad {case} mfma={mfma}: rel max err {err:.2e}")
+        assert took and err <= 2e-5
+
+
 def test_gpu_resident_parameters_train_like_cpu_resident_ones():
     """A forecaster moved to the GPU: gradients are exported device-to-device (dyf_train_export_dev) and the refreshed weights read
     in place (dyf_train_load_weights_dev).  Two SGD steps must produce the parameters of the CPU-resident run (host round
