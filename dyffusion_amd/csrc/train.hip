@@ -258,6 +258,57 @@ __global__ __launch_bounds__(256) void t_conv_fwd4(TConv g, const float* x, cons
     *(float4*)(y + (size_t)pix * g.cout + co) = acc;
 }
 
+// The same convs on the fp32 matrix cores (wo a multiple of 32: a wave's 32 pixels are one row segment): y[p][co] = bias[co] +
+// sum_j patch[p][j] W[j][co] with j = (tap, ci) walked two per v_mfma_f32_32x32x2_f32 -- lane (pixel, j parity) gathers its patch
+// value through a small LDS table j -> (ky, kx, ci) (taps outside the image predicated to zero), the W row of a step is one
+// coalesced 256-byte read; 64 output channels per wave pass, results leave as 128-byte rows.  Summation order differs from the
+// kernels above in the last bits (fp32 throughout).  550 us per launch in the four-channel form at 32 rows x 256^2.
+typedef __attribute__((ext_vector_type(16))) float tf_f32x16;
+__global__ __launch_bounds__(256) void t_conv_fwd_smallc_mfma(TConv g, const float* __restrict__ x, const float* __restrict__ wt,
+                                                              const float* __restrict__ bias, float* __restrict__ y, int tiles_per_wave) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __shared__ int tbl[128];
+    const int nacc = g.k * g.k * g.cin, ksteps = (nacc + 1) >> 1;
+    if (threadIdx.x < 128) {
+        const int j = threadIdx.x, tap = j / g.cin, ky = tap / g.k;
+        tbl[j] = j < nacc ? (ky | ((tap - ky * g.k) << 8) | ((j - tap * g.cin) << 16)) : -1;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l31 = lane & 31, hi = lane >> 5;
+    const int cob = blockIdx.y * 64;
+    const long long tiles = (long long)g.n * g.ho * g.wo / 32;
+    const long long t0 = ((long long)blockIdx.x * 4 + wave) * tiles_per_wave, t1 = t0 + tiles_per_wave < tiles ? t0 + tiles_per_wave : tiles;
+    const float bv0 = bias ? bias[cob + l31] : 0.0f, bv1 = bias ? bias[cob + 32 + l31] : 0.0f;
+    for (long long tile = t0; tile < t1; ++tile) {
+        const long long p0 = tile * 32;
+        const int ox0 = (int)(p0 % g.wo), oy = (int)((p0 / g.wo) % g.ho), b = (int)(p0 / ((long long)g.wo * g.ho));
+        const int iy0 = oy * g.s - g.p, ix0 = (ox0 + l31) * g.s - g.p;
+        tf_f32x16 acc0, acc1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.0f;
+#pragma unroll 4
+        for (int kk = 0; kk < ksteps; ++kk) {
+            const int j = 2 * kk + hi, e = tbl[j];
+            float a = 0.0f, w0 = 0.0f, w1 = 0.0f;
+            if (e >= 0) {
+                const int iy = iy0 + (e & 255), ix = ix0 + ((e >> 8) & 255);
+                if ((unsigned)iy < (unsigned)g.h && (unsigned)ix < (unsigned)g.w) a = x[(((size_t)b * g.h + iy) * g.w + ix) * g.cin + (e >> 16)];
+                w0 = wt[(size_t)j * g.cout + cob + l31];
+                w1 = wt[(size_t)j * g.cout + cob + 32 + l31];
+            }
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, w0, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, w1, acc1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {  // D[i][j]: lane j = l31 -> channel, register r -> pixel i = 8 (r >> 2) + 4 hi + (r & 3)
+            const size_t row = (size_t)(p0 + 8 * (r >> 2) + 4 * hi + (r & 3)) * g.cout + cob;
+            y[row + l31] = acc0[r] + bv0;
+            y[row + 32 + l31] = acc1[r] + bv1;
+        }
+    }
+#endif
+}
+
 // dx[n,iy,ix,ci] = sum over (ky,kx) with (iy+p-ky) % s == 0 and co of dz[n,(iy+p-ky)/s,(ix+p-kx)/s,co] * w[co][tap][ci]
 // (+ bias[ci] when used as the FORWARD of a transposed convolution)
 __global__ void t_conv_dgrad(TConv g, const float* dz, const float* w, const float* bias, float* dx) {
@@ -584,24 +635,36 @@ __global__ __launch_bounds__(256) void t_conv_wgrad_smallc_mfma(TConv g, const f
     if (pair0 < pair1) {
         const long long p0 = 2 * pair0;
         int ox0 = (int)(p0 % g.wo), oy = (int)((p0 / g.wo) % g.ho), b = (int)(p0 / ((long long)g.wo * g.ho));
-        for (long long pair = pair0; pair < pair1; ++pair) {
-            const size_t p = (size_t)(2 * pair + hi);
-            const float a0 = dz[p * g.cout + cob + l31], a1 = dz[p * g.cout + cob + 32 + l31];
-            const int iy0 = oy * g.s - g.p, ix0 = (ox0 + hi) * g.s - g.p;
+        constexpr int UN = 4;  // pixel pairs whose operands are requested before the first MFMA (a wave has one or two neighbours on its SIMD)
+        for (long long pair = pair0; pair < pair1; pair += UN) {
+            float a0[UN], a1[UN], bv[UN][NT];
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const int iy = iy0 + jy[t], ix = ix0 + jx[t];
-                float bv = jkind[t] == 2 ? 1.0f : 0.0f;
-                if (jkind[t] == 1 && (unsigned)iy < (unsigned)g.h && (unsigned)ix < (unsigned)g.w)
-                    bv = x[(((size_t)b * g.h + iy) * g.w + ix) * g.cin + jc[t]];
-                acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv, acc[0][t], 0, 0, 0);
-                acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv, acc[1][t], 0, 0, 0);
+            for (int u = 0; u < UN; ++u) {
+                const bool live = pair + u < pair1;  // wave-uniform
+                const size_t p = (size_t)(2 * (live ? pair + u : pair) + hi);
+                a0[u] = live ? dz[p * g.cout + cob + l31] : 0.0f;
+                a1[u] = live ? dz[p * g.cout + cob + 32 + l31] : 0.0f;
+                const int iy0 = oy * g.s - g.p, ix0 = (ox0 + hi) * g.s - g.p;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const int iy = iy0 + jy[t], ix = ix0 + jx[t];
+                    bv[u][t] = jkind[t] == 2 ? 1.0f : 0.0f;
+                    if (live && jkind[t] == 1 && (unsigned)iy < (unsigned)g.h && (unsigned)ix < (unsigned)g.w)
+                        bv[u][t] = x[(((size_t)b * g.h + iy) * g.w + ix) * g.cin + jc[t]];
+                }
+                ox0 += 2;
+                if (ox0 >= g.wo) {
+                    ox0 = 0;
+                    if (++oy >= g.ho) { oy = 0; ++b; }
+                }
             }
-            ox0 += 2;
-            if (ox0 >= g.wo) {
-                ox0 = 0;
-                if (++oy >= g.ho) { oy = 0; ++b; }
-            }
+#pragma unroll
+            for (int u = 0; u < UN; ++u)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u], bv[u][t], acc[0][t], 0, 0, 0);
+                    acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u], bv[u][t], acc[1][t], 0, 0, 0);
+                }
         }
     }
     // D[i][j]: lane j = l31, register r -> row i = 8 (r >> 2) + 4 hi + (r & 3)
@@ -1072,7 +1135,14 @@ dyf_status conv_fwd(dyf_engine* e, const TConv& g, const float* x, const float* 
         return DYF_OK;
     }
     static const bool small = !(getenv("DYF_TRAIN_SMALLC") && atoi(getenv("DYF_TRAIN_SMALLC")) == 0);  // =0: the round-3 VALU forms (A/B)
-    if (small && g.cout % 4 == 0)
+    const long long Mf = (long long)g.n * g.ho * g.wo;
+    if (small && g.cout % 64 == 0 && g.wo % 32 == 0 && g.cin <= 8 && g.k * g.k * g.cin <= 126 && g.k < 256 && Mf >= 4096 &&
+        !(getenv("DYF_TRAIN_SMALLC_MFMA") && atoi(getenv("DYF_TRAIN_SMALLC_MFMA")) == 0)) {
+        const long long tiles = Mf / 32;
+        const int tpw = (int)std::max<long long>(1, (tiles + 4095) / 4096);  // ~4 096 waves per 64-channel block
+        hipLaunchKernelGGL(t_conv_fwd_smallc_mfma, dim3((unsigned)((tiles + 4ll * tpw - 1) / (4ll * tpw)), (unsigned)(g.cout / 64)), dim3(256), 0, st, g, x,
+                           wt, b, y, tpw);
+    } else if (small && g.cout % 4 == 0)
         hipLaunchKernelGGL(t_conv_fwd4, dim3(nblk((long long)g.n * g.ho * g.wo * (g.cout / 4))), dim3(256), 0, st, g, x, wt, b, y);
     else
         hipLaunchKernelGGL(t_conv_fwd, dim3(nblk((long long)g.n * g.ho * g.wo * g.cout)), dim3(256), 0, st, g, x, wt, b, y);
@@ -1811,7 +1881,7 @@ __global__ void t_maxabs2(const float* a, const float* b, long long n, unsigned*
 
 dyf_status dyf_train_conv_check(dyf_engine* e, int32_t kind, int32_t n, int32_t h, int32_t w, int32_t cin, int32_t cout, int32_t k,
                                 int32_t s, int32_t p, uint32_t seed, float* out_host) {
-    if (!e || !out_host || kind < 0 || kind > 3 || n < 1 || h < 1 || w < 1 || cin < 1 || cout < 1 || k < 1 || s < 1)
+    if (!e || !out_host || kind < 0 || kind > 4 || n < 1 || h < 1 || w < 1 || cin < 1 || cout < 1 || k < 1 || s < 1)
         return fail(e, DYF_ERR_INVALID_ARGUMENT, "dyf_train_conv_check: bad arguments");
     TK(hipSetDevice(e->cfg.device));
     if (!e->train) e->train = new TrainState();
@@ -1821,7 +1891,7 @@ dyf_status dyf_train_conv_check(dyf_engine* e, int32_t kind, int32_t n, int32_t 
     std::vector<void*> tmp;
     float *x = nullptr, *z = nullptr, *wgt = nullptr, *bias = nullptr, *ref = nullptr, *got = nullptr;
     unsigned* mx = nullptr;
-    const long long nout = kind == 0 ? nz : kind == 1 ? nx : nw;
+    const long long nout = (kind == 0 || kind == 4) ? nz : kind == 1 ? nx : nw;
 #define CK(expr) do { dyf_status _s = (expr); if (_s != DYF_OK) { tfree(e, tmp); return _s; } } while (0)
     CK(talloc(e, tmp, &x, (size_t)nx, false)); CK(talloc(e, tmp, &z, (size_t)nz, false)); CK(talloc(e, tmp, &wgt, (size_t)nw, false));
     CK(talloc(e, tmp, &bias, (size_t)std::max(cin, cout), false));
@@ -1843,7 +1913,11 @@ dyf_status dyf_train_conv_check(dyf_engine* e, int32_t kind, int32_t n, int32_t 
         bool took = false;
         TK(hipMemsetAsync(got, 0, (size_t)nout * sizeof(float), st));
         TK(hipMemsetAsync(ref, 0, (size_t)nout * sizeof(float), st));
-        if (kind == 0) {
+        if (kind == 4) {  // whatever conv_fwd picks for the shape (the small-channel forms sit behind it)
+            CK(conv_fwd(e, g, x, wgt, bias, got, st));
+            took = true;
+            hipLaunchKernelGGL(t_conv_fwd, dim3(nblk(nz)), dim3(256), 0, st, g, x, wgt, bias, ref);
+        } else if (kind == 0) {
             took = tgemm_conv_fwd(g, x, wgt, bias, got, ws, TRAIN_SPLITK_FLOATS, st);
             hipLaunchKernelGGL(t_conv_fwd, dim3(nblk(nz)), dim3(256), 0, st, g, x, wgt, bias, ref);
         } else if (kind == 1) {

@@ -556,7 +556,8 @@ class HipEngine:
         return d
 
     def train_conv_check(self, kind: int, n: int, h: int, w: int, cin: int, cout: int, k: int, s: int, p: int, seed: int = 1):
-        """Test seam: one training convolution (0 forward, 1 dgrad, 2 wgrad) on the fp32 matrix cores vs the plain VALU kernel.
+        """Test seam: one training convolution (0 forward, 1 dgrad, 2 wgrad on the matrix-core launchers; 3 wgrad, 4 forward through the
+        step's dispatchers) vs the plain VALU kernel.
         Returns (relative max error with split-K workspace, without, whether the matrix-core form took the shape)."""
         out = (C.c_float * 3)()
         self._check(self._lib.dyf_train_conv_check(self._h, kind, n, h, w, cin, cout, k, s, p, C.c_uint32(seed), out))

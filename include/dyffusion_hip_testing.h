@@ -70,7 +70,9 @@ dyf_status dyf_op_attention_dropout(dyf_engine* engine, const uint16_t* qkv_dev,
                                     void* stream);
 
 /* One training convolution (csrc/train_gemm.hip: fp32 matrix-core forward / dgrad / wgrad of nn.Conv2d on NHWC fp32 tensors) on
- * hash-random data against the plain VALU kernel of csrc/train.hip.  kind 0 forward, 1 data gradient, 2 weight gradient; geometry
+ * hash-random data against the plain VALU kernel of csrc/train.hip.  kind 0 forward, 1 data gradient, 2 weight gradient (the
+ * matrix-core launchers of train_gemm.hip / train_halo16.hip), 3 weight gradient and 4 forward through the step's own dispatchers
+ * (conv_wgrad / conv_fwd: reaches the small-channel forms); with 16-bit operands selected the inputs are rounded to 16 bit first; geometry
  * as nn.Conv2d(cin, cout, k, stride s, padding p) on (n, h, w).  out_host[0] = max |mfma - valu| / max |valu| with the split-K
  * workspace, [1] = the same for the unsplit launch, [2] = 1 if the matrix-core form took the shape. */
 dyf_status dyf_train_conv_check(dyf_engine* engine, int32_t kind, int32_t n, int32_t h, int32_t w, int32_t cin, int32_t cout,

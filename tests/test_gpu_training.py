@@ -456,6 +456,11 @@ def test_small_channel_weight_gradient_on_the_matrix_cores_matches_the_plain_ker
         err, _, took = eng.train_conv_check(3, *case, seed=31)
         print(f"wgrad {case} mfma={mfma}: rel max err {err:.2e}")
         assert took and err <= 2e-5
+        # the forward of the same layer (t_conv_fwd_smallc_mfma where the output rows are multiples of 32 pixels, else the
+        # four-channels-per-thread kernel), kind 4 = whatever conv_fwd picks
+        errf, _, tookf = eng.train_conv_check(4, *case, seed=32)
+        print(f"forward {case} mfma={mfma}: rel max err {errf:.2e}")
+        assert tookf and errf <= 2e-5
 
 
 def test_gpu_resident_parameters_train_like_cpu_resident_ones():
