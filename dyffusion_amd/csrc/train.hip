@@ -143,7 +143,9 @@ __device__ __forceinline__ void up2x_adj_taps(int i, int h, int o[4], float w[4]
     o[0] = max(o[0], 0);
     o[3] = min(o[3], 2 * h - 1);
 }
-__global__ __launch_bounds__(256) void t_up2x_bwd(const float* dout, int n, int h, int w, int C4, float* din) {
+// (din / Ca4, din2 / Cb4: the gradient of a CONCATENATED low-resolution tensor leaves as its two parts -- channel quads [0, Ca4) to
+// din, the rest to din2 -- so that no split pass follows; din2 = null, Ca4 = C4: one tensor)
+__global__ __launch_bounds__(256) void t_up2x_bwd(const float* dout, int n, int h, int w, int C4, float* din, int Ca4, float* din2) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long long)n * h * w * C4) return;
     const int c4 = (int)(idx % C4);
@@ -163,9 +165,11 @@ __global__ __launch_bounds__(256) void t_up2x_bwd(const float* dout, int n, int 
             const float4 v = src[((size_t)oy[a] * (2 * w) + ox[q]) * C4];
             acc.x = fmaf(f, v.x, acc.x); acc.y = fmaf(f, v.y, acc.y); acc.z = fmaf(f, v.z, acc.z); acc.w = fmaf(f, v.w, acc.w);
         }
-    ((float4*)din)[idx] = acc;
+    if (c4 < Ca4) ((float4*)din)[p * Ca4 + c4] = acc;
+    else ((float4*)din2)[p * (C4 - Ca4) + (c4 - Ca4)] = acc;
 }
-__global__ __launch_bounds__(256) void t_up2x_fwd(const float* in, int n, int h, int w, int C4, float* out) {
+// (in / Ca4, in2: x2 upsample of the concatenation [in | in2] without materialising it; in2 = null, Ca4 = C4: one tensor)
+__global__ __launch_bounds__(256) void t_up2x_fwd(const float* in, int n, int h, int w, int C4, float* out, int Ca4, const float* in2) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long long)n * 4 * h * w * C4) return;
     const int c4 = (int)(idx % C4);
@@ -175,9 +179,10 @@ __global__ __launch_bounds__(256) void t_up2x_fwd(const float* in, int n, int h,
     float ly, lx;
     bilinear_coord(oy, 0.5f, h, y0, y1, ly);
     bilinear_coord(ox, 0.5f, w, x0, x1, lx);
-    const float4* base = (const float4*)in + (size_t)b * h * w * C4 + c4;
-    const float4 v00 = base[((size_t)y0 * w + x0) * C4], v01 = base[((size_t)y0 * w + x1) * C4];
-    const float4 v10 = base[((size_t)y1 * w + x0) * C4], v11 = base[((size_t)y1 * w + x1) * C4];
+    const int Cs = c4 < Ca4 ? Ca4 : C4 - Ca4;  // channel quads of the source this quad comes from
+    const float4* base = (c4 < Ca4 ? (const float4*)in + c4 : (const float4*)in2 + (c4 - Ca4)) + (size_t)b * h * w * Cs;
+    const float4 v00 = base[((size_t)y0 * w + x0) * Cs], v01 = base[((size_t)y0 * w + x1) * Cs];
+    const float4 v10 = base[((size_t)y1 * w + x0) * Cs], v11 = base[((size_t)y1 * w + x1) * Cs];
     float4 r;
 #define UP2X_MIX(m) { const float top = v00.m * (1.0f - lx) + v01.m * lx, bot = v10.m * (1.0f - lx) + v11.m * lx; r.m = top * (1.0f - ly) + bot * ly; }
     UP2X_MIX(x) UP2X_MIX(y) UP2X_MIX(z) UP2X_MIX(w)
@@ -1427,19 +1432,31 @@ dyf_status dyf_train_forward(dyf_engine* e, int32_t which, int32_t slot, const f
     Q = S + (size_t)nb * 1024;
     // ---- the 12 blocks
     const float* x = t.s0;
+    const float* x2 = nullptr;  // second part of a pending torch.cat([x, x2]) (channels xc | x2c): the x2 upsample reads both parts
+    int xc = 0, x2c = 0;
     int lh = n.uh, lw = n.uw;
     for (int i = 0; i < 12; ++i) {
         const UBlock& b = n.blk[i];
         if (b.cout > 1024) return fail(e, DYF_ERR_UNSUPPORTED, "training path: more than 1024 channels per block");
+        const bool up2 = b.transposed && b.cin % 4 == 0 && b.in_h == 2 * lh && b.in_w == 2 * lw;
+        if (x2 && !(up2 && xc % 4 == 0 && x2c % 4 == 0)) {  // no consumer that reads two parts: materialise the concatenation
+            float* cat = nullptr;
+            TA(cat, (size_t)nb * lh * lw * (xc + x2c));
+            hipLaunchKernelGGL(t_concat2, dim3(nblk((long long)nb * lh * lw * (xc + x2c))), dim3(256), 0, st, x, xc, x2, x2c, (long long)nb * lh * lw, cat);
+            x = cat;
+            x2 = nullptr;
+        }
         const float* cx = x;
         if (b.transposed) {  // x2 bilinear upsample in front of the conv
             float* u = nullptr;
             TA(u, (size_t)nb * b.in_h * b.in_w * b.cin);
-            if (b.cin % 4 == 0 && b.in_h == 2 * lh && b.in_w == 2 * lw)
-                hipLaunchKernelGGL(t_up2x_fwd, dim3(nblk((long long)nb * b.in_h * b.in_w * (b.cin / 4))), dim3(256), 0, st, x, nb, lh, lw, b.cin / 4, u);
+            if (up2)
+                hipLaunchKernelGGL(t_up2x_fwd, dim3(nblk((long long)nb * b.in_h * b.in_w * (b.cin / 4))), dim3(256), 0, st, x, nb, lh, lw, b.cin / 4, u,
+                                   x2 ? xc / 4 : b.cin / 4, x2);
             else
                 hipLaunchKernelGGL(t_resize_fwd, dim3(nblk((long long)nb * b.in_h * b.in_w * b.cin)), dim3(256), 0, st, x, nb, lh, lw, b.cin, b.in_h, b.in_w, 0, u);
             cx = u;
+            x2 = nullptr;
         }
         t.cin_ptr[i] = (float*)cx;
         const long long out_el = (long long)nb * b.out_h * b.out_w * b.cout;
@@ -1465,13 +1482,10 @@ dyf_status dyf_train_forward(dyf_engine* e, int32_t which, int32_t slot, const f
         TK(hipGetLastError());
         x = t.y[i];
         lh = b.out_h; lw = b.out_w;
-        if (i >= 6 && i < 11) {  // torch.cat([x, skip]) (unet_simple.py:176-177)
-            const UBlock& sk = n.blk[10 - i];
-            float* cat = nullptr;
-            TA(cat, (size_t)nb * lh * lw * (b.cout + sk.cout));
-            hipLaunchKernelGGL(t_concat2, dim3(nblk((long long)nb * lh * lw * (b.cout + sk.cout))), dim3(256), 0, st, t.y[i], b.cout, t.y[10 - i], sk.cout,
-                               (long long)nb * lh * lw, cat);
-            x = cat;
+        if (i >= 6 && i < 11) {  // torch.cat([x, skip]) (unet_simple.py:176-177): left to the next block's upsample (two sources)
+            x2 = t.y[10 - i];
+            xc = b.cout;
+            x2c = n.blk[10 - i].cout;
         }
     }
     t.xlast = (float*)x;
@@ -1523,6 +1537,7 @@ dyf_status dyf_train_backward(dyf_engine* e, int32_t slot, const float* dout_dev
     TA(dx, (size_t)nb * lh * lw * n.dim);
     TS(conv_fwd(e, gc, d_r, w.ro_wt, nullptr, dx, st));
     // ---- blocks, last to first
+    bool presplit = false;  // dy of the next (lower) block is already d y_i, its skip part already in dskip
     float* dskip[5] = {};
     for (int j = 0; j < 5; ++j) TZ(dskip[j], (size_t)nb * n.blk[j].out_h * n.blk[j].out_w * n.blk[j].cout);
     float* dsilu = nullptr;
@@ -1536,7 +1551,9 @@ dyf_status dyf_train_backward(dyf_engine* e, int32_t slot, const float* dout_dev
         const UBlock& b = n.blk[i];
         const int ohw = b.out_h * b.out_w;
         const long long out_el = (long long)nb * ohw * b.cout;
-        if (i >= 6 && i < 11) {  // dy currently holds d cat[y_i, skip]: split
+        if (i >= 6 && i < 11 && presplit) {  // the upsample adjoint of block i + 1 already wrote the two parts
+            presplit = false;
+        } else if (i >= 6 && i < 11) {  // dy currently holds d cat[y_i, skip]: split
             const UBlock& sk = n.blk[10 - i];
             float* dyi = nullptr;
             TA(dyi, out_el);
@@ -1576,8 +1593,18 @@ dyf_status dyf_train_backward(dyf_engine* e, int32_t slot, const float* dout_dev
             const int ph = b.in_h / 2, pw = b.in_w / 2;
             float* dlow = nullptr;
             if (b.cin % 4 == 0 && b.in_h == 2 * ph && b.in_w == 2 * pw) {
-                TA(dlow, (size_t)nb * ph * pw * b.cin);
-                hipLaunchKernelGGL(t_up2x_bwd, dim3(nblk((long long)nb * ph * pw * (b.cin / 4))), dim3(256), 0, st, dcx, nb, ph, pw, b.cin / 4, dlow);
+                // the upsampled tensor of blocks 7..11 is cat[y_{i-1}, skip]: its gradient leaves as the two parts (no split pass)
+                const int ca = i >= 7 ? n.blk[i - 1].cout : b.cin, cb = b.cin - ca;
+                if (i >= 7 && ca % 4 == 0 && cb % 4 == 0 && cb == n.blk[11 - i].cout) {
+                    TA(dlow, (size_t)nb * ph * pw * ca);
+                    hipLaunchKernelGGL(t_up2x_bwd, dim3(nblk((long long)nb * ph * pw * (b.cin / 4))), dim3(256), 0, st, dcx, nb, ph, pw, b.cin / 4, dlow, ca / 4,
+                                       dskip[11 - i]);
+                    presplit = true;
+                } else {
+                    TA(dlow, (size_t)nb * ph * pw * b.cin);
+                    hipLaunchKernelGGL(t_up2x_bwd, dim3(nblk((long long)nb * ph * pw * (b.cin / 4))), dim3(256), 0, st, dcx, nb, ph, pw, b.cin / 4, dlow, b.cin / 4,
+                                       (float*)nullptr);
+                }
             } else {
                 TZ(dlow, (size_t)nb * ph * pw * b.cin);
                 hipLaunchKernelGGL(t_resize_bwd, dim3(nblk((long long)nb * b.in_h * b.in_w * b.cin)), dim3(256), 0, st, dcx, nb, ph, pw, b.cin, b.in_h, b.in_w, 0, dlow);

@@ -491,8 +491,11 @@ def test_gpu_resident_parameters_train_like_cpu_resident_ones():
     for k, a in finals[0].items():
         b = finals[1][k]
         if a.is_floating_point():
-            # (atol: the fp32 atomics of the weight-gradient kernels leave run-to-run noise of a few 1e-6 after two steps -- seen 1 run in 5)
-            assert torch.allclose(a, b, rtol=1e-4, atol=1e-5), k
+            # (tolerance: the fp32 atomics of the weight-gradient kernels make the first step's gradients differ in the last bits from run
+            # to run; the second step then sees weights that differ by ~1e-8, and a (Leaky)ReLU or L1 residual that this moves across
+            # zero changes a gradient by a whole term -- parameters after two steps differ by up to ~1e-5 absolute / 5e-5 relative
+            # between two runs of the SAME path, seen in about half the runs.  A wrong export or refresh path is off by O(1).)
+            assert torch.allclose(a, b, rtol=1e-3, atol=1e-4), k
         else:
             assert torch.equal(a, b), k
 
