@@ -250,8 +250,8 @@ dyf_status dyf_train_forward(dyf_engine* engine, int32_t net, int32_t slot, cons
 dyf_status dyf_train_backward(dyf_engine* engine, int32_t slot, const float* dout_dev, float* dinputs_dev, int32_t param_grads,
                               void* stream);
 dyf_status dyf_train_zero_grads(dyf_engine* engine, int32_t net);
-/* Operand precision of the training convolutions (ABI 8) -- the reference's `trainer.precision` (Lightning; src/configs/trainer/*.yaml,
- * run.py): 32 = fp32 operands on the fp32 matrix cores (the default; gradients at the 1e-6 level of autograd over the oracle),
+/* Operand precision of the training convolutions (ABI 8) -- the reference's `trainer.precision` (Lightning; src/configs/trainer/default.yaml:14
+ * "precision: 32   # 32 or 16"): 32 = fp32 operands on the fp32 matrix cores (the default; gradients at the 1e-6 level of autograd over the oracle),
  * 16 = "16-mixed": activations, gradients, master weights and accumulation stay fp32, the conv operands are rounded to the engine's
  * 16-bit format (dyf_engine_config.dtype) while they are staged (csrc/train_halo16.hip, csrc/train_gemm.hip), 0 = not set: the
  * DYF_TRAIN_OPERANDS environment variable decides per call (unset: 32).  Applies to the dyf_train_forward / dyf_train_backward
