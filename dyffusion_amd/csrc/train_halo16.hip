@@ -74,8 +74,13 @@ __global__ __launch_bounds__(256, BN == 64 ? 2 : 1) void t_halo3x3_16(int h, int
     char* const Bring = smem + 2 * XS_BYTES;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
-    const int nb = blockIdx.x % nblocks, wg = blockIdx.x / nblocks, n0 = nb * BN;
+    // XCD-aware order (workgroup id % 8 = XCD, each with its own L2): the column blocks of one tile range follow one another on the
+    // SAME XCD, so all but the first find the fp32 halo in that L2 -- with the blocks on neighbouring ids (= 8 different L2s) the PMC
+    // counted the A operand NC / 64 times (16 x 256^2 x 64 -> 128 data gradient: 727 MB fetched for 376 MB of halo)
+    const int xq = blockIdx.x >> 3;
+    const int nb = xq % nblocks, wg = (xq / nblocks) * 8 + (int)(blockIdx.x & 7), n0 = nb * BN;
     const int t_beg = wg * tiles_per_wg, t_end = min(t_beg + tiles_per_wg, tiles_total);
+    if (t_beg >= tiles_total) return;  // (the grid is rounded up to whole groups of 8 tile ranges)
     const int nchunks = CK >> 6;
     const auto rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)Wb, 0, (int)(unsigned)((size_t)NC * 9 * CK * 2), 0x00020000);
 
@@ -338,7 +343,7 @@ bool thalo_conv3x3(const TConv& g, int mode, const float* A, const float* W, con
     const int nblocks = NC / bn;
     // a workgroup streams several tiles (prefetch runs across tile boundaries); about 2 048 workgroups per launch
     const int per = (int)std::max<long long>(1, std::min<long long>(16, tiles * nblocks / 2048));
-    const long long wgs = (tiles + per - 1) / per * nblocks;
+    const long long wgs = ((tiles + per - 1) / per + 7) / 8 * 8 * nblocks;  // whole groups of 8 tile ranges (XCD-aware order in the kernel)
     constexpr int XS = HP * 128 + 512;
     static bool attr_done = false;
     if (!attr_done) {
