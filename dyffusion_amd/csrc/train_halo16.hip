@@ -363,8 +363,10 @@ bool thalo_wgrad3x3(const TConv& g, const float* dz, const float* x, float* dw, 
     const long long tiles = (long long)g.n * tiles_per_img;
     const int pairs = (g.cout / 64) * (g.cin / 64);
     if (tiles < 64 || tiles > 0x7fffffffll || g.cin / 64 > 65535 || g.cout / 64 > 65535) return false;
-    // enough workgroups to fill the chip twice over, at least 4 tiles each
-    long long splits = std::max<long long>(1, std::min<long long>(tiles / 4, (1024 + pairs - 1) / pairs));
+    // one resident round (2 workgroups x 256 CUs): every workgroup ends with 64 x 64 x 9 fp32 atomics, so more, shorter workgroups cost
+    // more than they balance -- us per launch with 256 / 512 / 1 024 / 2 048 workgroups: 16 x 256^2 x 128 -> 64 439 / 314 / 383 / 430,
+    // 64 x 60^2 x 128 -> 128 201 / 173 / 234 / 327, 32 x 64^2 x 256 -> 256 361 / 250 / 298 / 379
+    long long splits = std::max<long long>(1, std::min<long long>(tiles / 4, (512 + pairs - 1) / pairs));
     const int per = (int)((tiles + splits - 1) / splits);
     splits = (tiles + per - 1) / per;
     dyf_form_note("t_wgrad3x3_16", g.n);
