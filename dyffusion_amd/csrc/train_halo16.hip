@@ -341,8 +341,11 @@ bool thalo_conv3x3(const TConv& g, int mode, const float* A, const float* W, con
     dyf_form_note(mode ? "t_halo3x3_16:dgrad" : "t_halo3x3_16:forward", g.n);
     hipLaunchKernelGGL(t_pack_w16, dim3((unsigned)((welems + 255) / 256)), dim3(256), 0, st, W, g.cin, g.cout, mode, wb);
     const int nblocks = NC / bn;
-    // a workgroup streams several tiles (prefetch runs across tile boundaries); about 2 048 workgroups per launch
-    const int per = (int)std::max<long long>(1, std::min<long long>(16, tiles * nblocks / 2048));
+    // a workgroup streams several tiles (prefetch runs across tile boundaries)
+    // (measured, us per launch with ~512 / 1 024 / 2 048 / 4 096 workgroups: 64 x 60^2 x 64 -> 64 49 / 52 / 55 / 56, 64 x 30^2 x 256 -> 128 data
+    // gradient 66 / 69 / 72 / 72, 16 x 256^2 x 64 -> 128 data gradient 385 / 384 / 377 / 379: one resident round for the smaller launches)
+    const long long htarget = tiles * nblocks <= 8192 ? 512 : 2048;
+    const int per = (int)std::max<long long>(1, std::min<long long>(16, tiles * nblocks / htarget));
     const long long wgs = ((tiles + per - 1) / per + 7) / 8 * 8 * nblocks;  // whole groups of 8 tile ranges (XCD-aware order in the kernel)
     constexpr int XS = HP * 128 + 512;
     static bool attr_done = false;
