@@ -168,7 +168,7 @@ def projection(curve, total, parts=8):
             "ceiling": round(total / per, 3)}
 
 
-def ns_batch_curve(model, dev, nbs=(1, 4, 7, 10, 25, 38, 50, 80)):
+def ns_batch_curve(model, dev, nbs=(1, 4, 7, 10, 15, 25, 38, 50, 80, 120, 200)):
     """fields/s of the headline NS workload at smaller row counts on the SAME engine (graph per batch size; kernel forms are chosen
     per call from tile counts: split-K / implicit-GEMM forms at small batches) -- the rows one GPU gets when an ensemble is sharded."""
     g = torch.Generator().manual_seed(101)
@@ -176,7 +176,7 @@ def ns_batch_curve(model, dev, nbs=(1, 4, 7, 10, 25, 38, 50, 80)):
     for nb in nbs:
         x0 = torch.randn(nb, C, H, W, generator=g).to(dev)
         st = torch.rand(nb, CS, H, W, generator=g).to(dev)
-        dt = _time_rollouts(model, x0, 3 if nb >= 25 else 5, st)
+        dt = _time_rollouts(model, x0, 2 if nb > 80 else 3 if nb >= 25 else 5, st)  # (> 80 rows: the engine is re-created at that size)
         curve[nb] = round(nb * HORIZON / dt, 1)
     log(f"NS batch curve (fields/s): {curve}")
     return curve
@@ -511,6 +511,30 @@ def cpu_baseline(F, I):
                       f"NB=4 x{res[4][0]} in {res[4][1]:.1f} s; {best[0]} of {ncpu} host threads (fastest of {'/'.join(str(k) for k in sweep)} on one forward)"}
 
 
+def self_launch(n):
+    """Replace this process by `python -m torch.distributed.run --nnodes=1 --nproc-per-node n --master-addr 127.0.0.1 --master-port P
+    bench.py <the same arguments>` (P: a free port picked here).  When the host shows fewer GPUs than ranks (the one-GPU rehearsal of
+    the N > 1 branch: ranks wrap onto the devices there are) RCCL cannot build the communicator ("Duplicate GPU detected"), so
+    torch.distributed is pointed at gloo unless the caller chose a backend."""
+    import socket
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this host driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    if torch.cuda.device_count() < n and "DYF_DIST_BACKEND" not in env:
+        env["DYF_DIST_BACKEND"] = "gloo"
+        log(f"{torch.cuda.device_count()} visible GPU(s) for {n} ranks: ranks share devices, torch.distributed over gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log("self-launch: " + " ".join(cmd))
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os.execve(sys.executable, cmd, env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -531,7 +555,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N>1")
+        if "WORLD_SIZE" in os.environ or args.gpus < 1:
+            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's rank count and --gpus disagree")
+        # plain `python bench.py --gpus N` (no launcher): re-execute this file under torch.distributed.run, one rank per GPU --
+        # the same command line the driver uses for N > 1; rank 0 of the child prints the ONE JSON line on the inherited stdout
+        return self_launch(args.gpus)
     ndev = torch.cuda.device_count()
     dev_index = local_rank % max(1, ndev)  # one rank per GPU under the driver; ranks wrap only in single-GPU smoke runs
     torch.cuda.set_device(dev_index)
@@ -564,13 +592,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def sharded_run(mdl, x_full, s_full, hw, horizon, steps, warmup):
+    def sharded_run(mdl, x_full, s_full, hw, horizon, steps, warmup, gather=gather):
         """K timed steps of `mdl` on the rows of x_full sharded over the ranks: every rank samples its block of global rows (same seed,
         global-row dropout streams) and, N > 1, the forecast stack is all-gathered inside EVERY step (one collective, issued by the
         engine on the rollout's stream when it owns a communicator).  Returns (seconds MAX over ranks, exchange used, ncclCommCount)."""
         rows = x_full.shape[0]
         lo, hi = shard_rows(rows, world, rank)
         exch, seen = "none", 0
+        # (growing the engine replaces it and drops its communicator: do that HERE, on every rank alike, before the communicator check)
+        mdl._ensure_engine(hw, rows_per_rank(rows, world))
         if world > 1 and gather:
             exch = "torch"
             if want_engine_comm:
@@ -602,6 +632,53 @@ def main():
             dt = float(t.item())
         assert all(bool(torch.isfinite(v).all()) for v in preds.values()), "non-finite forecast"
         return dt, exch, seen
+
+    def rank0_alone(make, x_full, s_full, steps, warmup=1):
+        """The N = 1 equivalent measured INSIDE the N > 1 job, same node, same process: rank 0 samples all rows of x_full by itself
+        (no exchange) while the other ranks wait at the fence -- on an engine of its own (`make(rows)`, sized for those rows exactly as
+        a 1-GPU job would size it; the sharded model and its communicator are not touched).  Seconds for `steps` steps (on every rank)."""
+        kw = {} if s_full is None else {"static_condition": s_full}
+        dt = 0.0
+        fence()
+        if rank == 0:
+            mdl = make(x_full.shape[0])
+            mdl.seed(2)
+            for _ in range(warmup):
+                mdl.sample(x_full, **kw)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                mdl.sample(x_full, **kw)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            mdl._engine.close()
+            del mdl
+            torch.cuda.empty_cache()
+        fence()
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def strong_entry(mdl, x_full, s_full, hw, horizon, steps, alone=None):
+        """One fixed ensemble sharded over the ranks: fields/s with the exchange, the same steps WITHOUT the exchange (its own cost =
+        the difference), and rank 0 alone on the whole ensemble -> a same-node speed-up."""
+        rows = x_full.shape[0]
+        d, ex, seen = sharded_run(mdl, x_full, s_full, hw, horizon, steps, 1)
+        ent = {"total_rows": rows, "rows_per_gpu": rows_per_rank(rows, world), "scaling": "strong",
+               "rows_by_rank": [b - a for a, b in (shard_rows(rows, world, r) for r in range(world))],
+               "fields_per_s": round(rows * horizon * steps / d, 1), "ms_per_step": round(1e3 * d / steps, 3), "exchange": ex, "nranks_seen": seen,
+               "row_groups": mdl._engine.row_groups}
+        if gather:
+            d0, _, _ = sharded_run(mdl, x_full, s_full, hw, horizon, steps, 1, gather=False)
+            ent["ms_per_step_without_exchange"] = round(1e3 * d0 / steps, 3)
+            ent["exchange_ms_per_step"] = round(1e3 * (d - d0) / steps, 3)
+        if alone is not None:
+            d1 = rank0_alone(alone, x_full, s_full, steps)
+            ent["rank0_alone_fields_per_s"] = round(rows * horizon * steps / d1, 1)
+            ent["rank0_alone_ms_per_step"] = round(1e3 * d1 / steps, 3)
+            ent["speedup_vs_rank0_alone"] = round(d1 / d, 3)
+            ent["ceiling"] = round(rows / rows_per_rank(rows, world), 3)
+        return ent
 
     # every rank holds the full (total_rows, ...) inputs (111 KB per row) and the same seed
     g = torch.Generator().manual_seed(100)
@@ -637,23 +714,38 @@ def main():
     }
     if world > 1:
         result["nranks_seen"] = nranks_seen  # ncclCommCount of the engine's communicator (0: the torch.distributed route ran)
+        result["rows_by_rank"] = [b - a for a, b in (shard_rows(total_rows, world, r) for r in range(world))]
+        result["devices_visible"] = ndev
+        if gather:  # the all-gather's own cost: the same K steps without it
+            d0, _, _ = sharded_run(model, x0, static, (H, W), HORIZON, args.steps, 1, gather=False)
+            result["ms_per_step_without_exchange"] = round(1e3 * d0 / args.steps, 3)
+            result["exchange_ms_per_step"] = round(1e3 * (dt - d0) / args.steps, 3)
+        # N = 1 equivalent inside this run: rank 0 alone on ONE rank's rows (weak scaling: the per-GPU work is what stays fixed) or on
+        # the whole fixed ensemble (strong scaling)
+        xa, sa = (x0, static) if strong else (x0[:nb], static[:nb])
+        d1 = rank0_alone(lambda r: build_model(r, use_graph=not args.no_graph)[0], xa, sa, args.steps)
+        result["rank0_alone"] = {"rows": xa.shape[0], "fields_per_s": round(xa.shape[0] * HORIZON * args.steps / d1, 1),
+                                 "ms_per_step": round(1e3 * d1 / args.steps, 3),
+                                 "speedup_of_this_line": round((fields / dt) / (xa.shape[0] * HORIZON * args.steps / d1), 3),
+                                 "ideal": world if not strong else round(total_rows / nb, 3)}
 
     extras = not args.no_extra_configs
     if world > 1 and extras:
         # ---- N > 1: the other multi-GPU workloads of BASELINE.json, each sharded over the ranks through the same exchange.
         # STRONG scaling of the headline workload: a fixed ensemble (the reference's 50 members; its 80-row evaluation batch) split over
         # the ranks -- what north_star's ">= 6x at 8 GPUs" is about; the weak line above keeps 80 rows per GPU.
+        # 200 rows = the reference's NS TEST call (eval_batch_size 4 x num_predictions 50: experiment/navier_stokes.yaml:12, mode/test.yaml:9)
         result["strong"] = {}
-        for m_rows in (50, 80):
+        for m_rows in [int(v) for v in os.environ.get("DYF_BENCH_STRONG_ROWS", "50,80,200").split(",")]:
             gs = torch.Generator().manual_seed(100)
             xs, ss = torch.randn(m_rows, C, H, W, generator=gs).to(dev), torch.rand(m_rows, CS, H, W, generator=gs).to(dev)
-            d2, ex2, seen2 = sharded_run(model, xs, ss, (H, W), HORIZON, max(3, args.steps), 1)
-            k = max(3, args.steps)
-            result["strong"][f"ensemble_{m_rows}"] = {"total_rows": m_rows, "rows_per_gpu": rows_per_rank(m_rows, world), "scaling": "strong",
-                                                      "fields_per_s": round(m_rows * HORIZON * k / d2, 1), "ms_per_step": round(1e3 * d2 / k, 3),
-                                                      "exchange": ex2, "nranks_seen": seen2}
+            try:
+                result["strong"][f"ensemble_{m_rows}"] = strong_entry(model, xs, ss, (H, W), HORIZON, max(3, args.steps),
+                                                                      alone=lambda r: build_model(r, use_graph=not args.no_graph)[0])
+            except Exception as ex:  # identical on every rank (same shapes)
+                result["strong"][f"ensemble_{m_rows}"] = {"error": f"{type(ex).__name__}: {ex}"}
             log(f"strong scaling, {m_rows} rows over {world} ranks: {result['strong'][f'ensemble_{m_rows}']}")
-        eng.close()
+        model._engine.close()
         del model
         torch.cuda.empty_cache()
         # (DYF_BENCH_OISST_ROWS / DYF_BENCH_SYNTH_ROWS shrink the two ensembles for the 2-ranks-on-one-GPU rehearsal of this branch,
@@ -668,10 +760,10 @@ def main():
                 xf = torch.randn(rows, *shape, generator=torch.Generator().manual_seed(3)).to(dev)
                 mdl._ensure_engine(shape[1:], rpr)
                 reps = 3 if key == "config2_oisst" else 1
-                d3, ex3, seen3 = sharded_run(mdl, xf, None, shape[1:], horizon, reps, 1)
-                result[key] = {"workload": wl + f", {rows} rows sharded over {world} GPUs", "total_rows": rows, "rows_per_gpu": rpr,
-                               "row_groups": mdl._engine.row_groups, "scaling": "strong", "fields_per_s": round(rows * horizon * reps / d3, 1),
-                               "ms_per_rollout": round(1e3 * d3 / reps, 2), "exchange": ex3, "nranks_seen": seen3}
+                # (rank 0 alone on the whole ensemble only for OISST; the 512^2 ensemble alone is 8 x 16 s of rollout)
+                ent = strong_entry(mdl, xf, None, shape[1:], horizon, reps, alone=make if key == "config2_oisst" else None)
+                ent.update({"workload": wl + f", {rows} rows sharded over {world} GPUs", "ms_per_rollout": ent["ms_per_step"]})
+                result[key] = ent
                 log(f"{key} on {world} ranks: {result[key]}")
                 mdl._engine.close()
                 del mdl
@@ -717,7 +809,7 @@ def main():
             # need this engine first, then close it, then OISST FIRST among the other engines.
             guarded("batch_curve", lambda: {"unit": "fields/s", "navier_stokes": ns_batch_curve(model, dev)})
             guarded("config3_ns_ar64", lambda: bench_ns_ar64(model, dev))
-            eng.close()
+            model._engine.close()  # (the 120- / 200-row points of the curve re-created the engine: `eng` is the closed 80-row one)
             del model
             torch.cuda.empty_cache()
             guarded("config2_oisst", lambda: bench_oisst(dev))
@@ -732,6 +824,9 @@ def main():
                 result["strong_scaling_projection"] = {
                     "what": "time of ONE GPU on the whole ensemble / time of the slowest of 8 GPUs on its ceil(rows / 8) share, from this "
                             "GPU's batch curve (the 1-collective all-gather of the forecast stack is not in it)",
+                    # 200 rows = the reference's NS TEST call: eval_batch_size 4 x num_predictions 50 (experiment/navier_stokes.yaml:12,
+                    # mode/test.yaml:9); 80 rows = its validation call (4 x 20); 50 = one batch item's members
+                    "navier_stokes_200": projection(curve["navier_stokes"], 200), "navier_stokes_120": projection(curve["navier_stokes"], 120),
                     "navier_stokes_80": projection(curve["navier_stokes"], 80), "navier_stokes_50": projection(curve["navier_stokes"], 50),
                     "oisst_300": projection(oi, 300)}
             guarded("config1_ns_c2", lambda: bench_ns_c2(dev, nb))

@@ -27,10 +27,14 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _run_bench(nproc, extra_args, extra_env, timeout=900):
+def _run_bench(nproc, extra_args, extra_env, timeout=900, self_launch=False):
     env = dict(os.environ, DYF_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0",
-               DYF_BENCH_OISST_ROWS="160", DYF_BENCH_SYNTH_ROWS="2", **extra_env)
-    if nproc > 1:
+               DYF_BENCH_OISST_ROWS="160", DYF_BENCH_SYNTH_ROWS="2", **{"DYF_BENCH_STRONG_ROWS": "50,80", **extra_env})
+    if self_launch:  # the driver's N = 1 command shape with --gpus N: no launcher, no WORLD_SIZE / RANK in the environment
+        for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "DYF_DIST_BACKEND", "MASTER_ADDR"):
+            env.pop(k, None)
+        cmd = [sys.executable, "bench.py", "--gpus", str(nproc)]
+    elif nproc > 1:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
                "--master-port", str(_free_port()), "bench.py", "--gpus", str(nproc)]
     else:
@@ -42,7 +46,7 @@ def _run_bench(nproc, extra_args, extra_env, timeout=900):
     return json.loads(lines[0]), r.stderr
 
 
-def _check_multirank_line(res, world, rows_per_gpu):
+def _check_multirank_line(res, world, rows_per_gpu, strong_rows=(("ensemble_50", 50), ("ensemble_80", 80))):
     assert res["n_gpus"] == world and res["scaling"] == "weak" and res["metric"].startswith("sampled fields/sec")
     assert res["config"]["rows_per_gpu"] == rows_per_gpu and res["config"]["total_rows"] == world * rows_per_gpu
     assert res["value"] > 0 and res["ms_per_step"] > 0 and res["unit"] == "fields/s" and res["dtype"] == "bf16"
@@ -50,11 +54,20 @@ def _check_multirank_line(res, world, rows_per_gpu):
     for key in ("strong", "config2_oisst", "config4_synth512"):
         assert key in res, sorted(res)
         assert "error" not in res[key], (key, res[key])
-    for name, rows in (("ensemble_50", 50), ("ensemble_80", 80)):
+    assert sum(res["rows_by_rank"]) == world * rows_per_gpu and len(res["rows_by_rank"]) == world
+    assert res["ms_per_step_without_exchange"] > 0 and "exchange_ms_per_step" in res
+    a = res["rank0_alone"]  # the N = 1 equivalent measured inside the run (weak scaling: one rank's rows)
+    assert a["rows"] == rows_per_gpu and a["fields_per_s"] > 0 and a["ideal"] == world and a["speedup_of_this_line"] > 0
+    for name, rows in strong_rows:
         s = res["strong"][name]
+        assert "error" not in s, s
         assert s["total_rows"] == rows and s["rows_per_gpu"] == -(-rows // world) and s["scaling"] == "strong"
         assert s["fields_per_s"] > 0 and s["exchange"] in ("torch", "engine")
+        assert sum(s["rows_by_rank"]) == rows and max(s["rows_by_rank"]) == s["rows_per_gpu"]
+        assert s["rank0_alone_fields_per_s"] > 0 and s["speedup_vs_rank0_alone"] > 0 and s["ceiling"] == round(rows / s["rows_per_gpu"], 3)
+        assert s["ms_per_step_without_exchange"] > 0
     o = res["config2_oisst"]
+    assert o["rank0_alone_fields_per_s"] > 0 and sum(o["rows_by_rank"]) == 160
     assert o["total_rows"] == 160 and o["rows_per_gpu"] == 80 and o["fields_per_s"] > 0 and o["scaling"] == "strong"
     assert o["row_groups"] >= 2, o  # 80 rows of 60 x 60 per rank: the grouped rollout is what the SCALE run will launch at 150
     z = res["config4_synth512"]
@@ -76,6 +89,20 @@ def test_bench_two_ranks_on_one_gpu_torch_exchange_and_consistency_with_one_rank
     print(f"2 ranks x 8 rows on one GPU: {two['value']:.0f} fields/s; 1 rank x 16 rows: {one['value']:.0f} fields/s; ratio {ratio:.2f}")
     # same GPU, same total rows: two time-sliced 8-row rollouts + a host-staged gloo exchange against one 16-row rollout
     assert 0.25 <= ratio <= 1.3, ratio
+
+
+def test_bench_self_launches_its_ranks_when_no_launcher_started_it():
+    """`python bench.py --gpus 2 --steps 2 --warmup 1` -- the driver's N = 1 command with another N, nothing in the environment:
+    bench.py re-executes itself under torch.distributed.run (it used to SystemExit), notices that one visible GPU
+    cannot carry two RCCL ranks and points torch.distributed at gloo, and rank 0 prints the one line -- here with the reference's
+    200-row NS test ensemble (4 x 50 members) in the `strong` object, each entry with its own rank-0-alone time."""
+    res, err = _run_bench(2, ["--steps", "2", "--warmup", "1", "--nb", "8"], {"DYF_BENCH_STRONG_ROWS": "50,200"}, self_launch=True, timeout=1500)
+    assert "self-launch:" in err and "torch.distributed.run" in err
+    _check_multirank_line(res, 2, 8, strong_rows=(("ensemble_50", 50), ("ensemble_200", 200)))
+    assert res["nranks_seen"] == 0 and res["devices_visible"] >= 1
+    s = res["strong"]["ensemble_200"]
+    print("200 rows over 2 ranks on one GPU:", s)
+    assert s["rows_by_rank"] == [100, 100]
 
 
 def test_bench_two_ranks_engine_exchange_requested_falls_back_on_every_rank_or_runs():
