@@ -143,6 +143,27 @@ def _resnet_roofline(eng, kind, nb, name, peak_tflops):
     return r
 
 
+HBM_KERNELS = ("stem16_rows_kernel", "up2x_quad_kernel", "up2x_epilogue_kernel", "readout_dma_kernel", "layernorm_c_vec_kernel",
+               "up2x_nearest_vec_kernel", "gn_apply_walk_kernel", "gn_apply_part_kernel")
+
+
+def hbm_kernels(eng, nb):
+    """north_star: "rocprof-reported HBM GB/s for the norm/activation kernels".  For every HBM-bound kernel the rollout launches (norm,
+    activation, resample, readout: the launchers that open a KernelProf scope, csrc/common.h): HIP events around each of its launches in
+    ONE eager rollout (dyf_time_named_kernel_in_rollout), ALGORITHMIC bytes (every operand once, 16-bit activations) / time -> GB/s and
+    the fraction of the 8 TB/s HBM3E peak.  With row groups the launches cover one group's rows (as `_resnet_roofline`).  The rocprofv3
+    kernel tables under profiles/ hold the same average durations."""
+    rows = -(-nb // eng.row_groups)
+    out = {}
+    for name in HBM_KERNELS:
+        ms, n, by = eng.time_named_kernel_in_rollout(name, rows)
+        if n > 0 and ms > 0:
+            out[name] = {"launches": n, "rows_per_launch": rows, "avg_us": round(1e3 * ms / n, 2),
+                         "algorithmic_bytes_per_launch": round(by / n), "gbps": round(by / ms / 1e6, 1),
+                         "frac_of_hbm_peak": round(by / ms / 1e6 / 8000.0, 4), "share_of_rollout_ms": round(ms, 3)}
+    return out
+
+
 def _time_rollouts(model, x0, reps, static=None):
     kw = {} if static is None else {"static_condition": static}
     model.sample(x0, **kw)  # captures the graph
@@ -272,7 +293,8 @@ def bench_oisst(dev, nb=300, reps=3):
                                                     "dropout (+ residual) of their Block fused into the epilogue (conv_up_halo_kernel<5, 2>)",
                                         PEAK_BF16_TFLOPS),
            "roofline_groupnorm": _resnet_roofline(eng, 2, nb, "separate GroupNorm(8)+FiLM+SiLU+dropout(+residual) launches, 64 ch @60x60",
-                                                  PEAK_BF16_TFLOPS)}
+                                                  PEAK_BF16_TFLOPS),
+           "hbm_kernels": hbm_kernels(eng, nb)}
     log(f"OISST NB={nb} ({dtype}): {res['ms_per_rollout']} ms per rollout -> {res['fields_per_s']} fields/s")
     eng.close()
     return res
@@ -325,7 +347,8 @@ def bench_synth512(dev, nb=4, reps=1):
            "gflop_per_field": round(fl / 32 / 1e9, 2), "whole_rollout_tflops": round(nb * fl / dt / 1e12, 1),
            "roofline": _resnet_roofline(eng, 1, nb, "flash_attention4_kernel (16 384 tokens, 4 heads x 32; dropout on the "
                                                     "probabilities in the interpolator's launches)", PEAK_BF16_TFLOPS),
-           "roofline_conv": _resnet_roofline(eng, 0, nb, "level-0 3x3 weight-standardised convs 64->64 @512x512", PEAK_BF16_TFLOPS)}
+           "roofline_conv": _resnet_roofline(eng, 0, nb, "level-0 3x3 weight-standardised convs 64->64 @512x512", PEAK_BF16_TFLOPS),
+           "hbm_kernels": hbm_kernels(eng, nb)}
     log(f"512^2 NB={nb} (fp16): {res['ms_per_rollout']} ms per rollout -> {res['fields_per_s']} fields/s")
     eng.close()
     return res
@@ -795,6 +818,10 @@ def main():
         result["roofline_dec5_sparse"] = layer_roofline(
             11, "conv_halo_rows_mixed_kernel = conv_halo_rows_kernel<1, SH> (dec5: fused x2-upsample + 3x3 conv, 256->64 ch, 128^2->256^2, "
                 "104 of 256 output columns as 3 x 16 + 4 list entries per phase)")
+        try:  # the HBM-bound kernels of the headline rollout (norm / activation / resample / readout)
+            result["hbm_kernels"] = hbm_kernels(eng, nb)
+        except Exception as ex:
+            result["hbm_kernels"] = {"error": f"{type(ex).__name__}: {ex}"}
         if extras:
             def guarded(key, fn):
                 try:

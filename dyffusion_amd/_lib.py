@@ -120,6 +120,10 @@ SYMBOLS = [
     ("dyf_debug_gn_fuse", C.c_int, [_P, C.c_uint32, C.c_int32]),
     ("dyf_debug_form_log", None, [C.c_int32]),
     ("dyf_debug_form_log_read", C.c_int32, [C.c_char_p, C.c_int32]),
+    ("dyf_time_named_kernel_in_rollout", C.c_int, [_P, C.c_char_p, C.c_int32, _P, C.POINTER(C.c_double), C.POINTER(C.c_int32),
+                                                  C.POINTER(C.c_double)]),
+    ("dyf_debug_set_form", None, [C.c_char_p, C.c_char_p]),
+    ("dyf_debug_forms", C.c_int32, [C.c_char_p, C.c_int32]),
 ]
 
 
@@ -148,5 +152,28 @@ def lib(dtype: str = "bf16") -> C.CDLL:
         l = load_library(LIB_PATH_F16 if code else LIB_PATH)
         if l.dyf_dtype() != code:
             raise ImportError(f"library for dtype {dtype} reports dyf_dtype() = {l.dyf_dtype()}")
+        for k, v in _FORMS.items():  # switches set before this build of the library was loaded
+            l.dyf_debug_set_form(k.encode(), v.encode())
         _LIBS[code] = l
     return _LIBS[code]
+
+
+_FORMS = {}
+
+
+def set_form(key=None, value=None) -> None:
+    """Test / tool seam (include/dyffusion_hip_testing.h dyf_debug_set_form): set kernel-form switch `key` to `value` in every loaded
+    build of the library (and in builds loaded later); value None removes the key, key None removes all.  The product never calls
+    this, and the library reads no such switch from the environment."""
+    if key is None:
+        _FORMS.clear()
+    elif value is None:
+        _FORMS.pop(key, None)
+    else:
+        _FORMS[key] = str(value)
+    for l in _LIBS.values():
+        l.dyf_debug_set_form(None if key is None else key.encode(), None if value is None else str(value).encode())
+
+
+def forms() -> dict:
+    return dict(_FORMS)

@@ -1,6 +1,7 @@
 // Shared device/host helpers for the gfx950 DYffusion engine.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <cstring>
 #include <stdint.h>
 
 // 16-bit storage element of activations and weights in HBM (NHWC), raw bits.  One source, two builds of the library:
@@ -32,6 +33,31 @@ void dyf_form_note_slow(const char* form, long long rows);
 static inline void dyf_form_note(const char* form, long long rows) {
     if (g_dyf_form_log_on) dyf_form_note_slow(form, rows);
 }
+
+// Kernel-form switches (the A/B + parity harness): which of several equivalent kernel forms a launcher takes, thresholds of the
+// form policy, a few wrong-results timing probes.  Their values come ONLY from dyf_debug_set_form (include/dyffusion_hip_testing.h,
+// called by tests/ and tools/): the library reads NONE of them from the environment (round 5 did: a stray DYF_* variable changed
+// kernel forms, and for the training operands the numerics, under a caller who never asked).  dyf_form(key) = the value set for
+// `key`, or nullptr -- one relaxed load when nothing is set, which is every production process.  Keys keep their historic names.
+extern int g_dyf_form_count;
+const char* dyf_form_slow(const char* key);
+static inline const char* dyf_form(const char* key) { return g_dyf_form_count ? dyf_form_slow(key) : nullptr; }
+
+// In-rollout timing of ONE named kernel (bench.py `hbm_kernels`; include/dyffusion_hip_testing.h dyf_time_named_kernel_in_rollout):
+// the launchers of the HBM-bound kernels (norm / activation / resample / readout) open a KernelProf scope around their launch with
+// the launch's ALGORITHMIC bytes (every operand once); while a name is armed, scopes of that name bracket the launch with HIP events on
+// its stream.  Off (one pointer test) everywhere else.
+extern const char* g_dyf_prof_name;
+void dyf_prof_begin(hipStream_t st, double bytes);
+void dyf_prof_end(hipStream_t st);
+struct KernelProf {
+    hipStream_t st;
+    bool on;
+    KernelProf(const char* name, hipStream_t s, double algorithmic_bytes) : st(s), on(g_dyf_prof_name && !strcmp(name, g_dyf_prof_name)) {
+        if (on) dyf_prof_begin(st, algorithmic_bytes);
+    }
+    ~KernelProf() { if (on) dyf_prof_end(st); }
+};
 
 #if DYF_F16
 typedef _Float16 el16_native_t;

@@ -25,6 +25,7 @@
 #include <type_traits>
 
 #include <cstdlib>
+#include <deque>
 #include <map>
 #include <mutex>
 #include <string>
@@ -47,6 +48,63 @@ std::string dyf_form_log_text() {
     std::string t;
     for (auto& kv : g_form_log) t += kv.first + "=" + std::to_string(kv.second) + ";";
     return t;
+}
+// ---- kernel-form switches (common.h dyf_form): key -> value, set only through dyf_debug_set_form.  Values are interned and never
+// freed (a pointer handed out by dyf_form stays valid for the life of the process).
+int g_dyf_form_count = 0;
+static std::map<std::string, const char*> g_form_values;
+static std::deque<std::string> g_form_arena;
+const char* dyf_form_slow(const char* key) {
+    std::lock_guard<std::mutex> lk(g_form_mu);
+    auto it = g_form_values.find(key);
+    return it == g_form_values.end() ? nullptr : it->second;
+}
+void dyf_form_set(const char* key, const char* value) {
+    std::lock_guard<std::mutex> lk(g_form_mu);
+    if (!key) g_form_values.clear();
+    else if (!value) g_form_values.erase(key);
+    else {
+        g_form_arena.emplace_back(value);
+        g_form_values[key] = g_form_arena.back().c_str();
+    }
+    __atomic_store_n(&g_dyf_form_count, (int)g_form_values.size(), __ATOMIC_RELEASE);
+}
+std::string dyf_form_text() {
+    std::lock_guard<std::mutex> lk(g_form_mu);
+    std::string t;
+    for (auto& kv : g_form_values) t += kv.first + "=" + kv.second + ";";
+    return t;
+}
+// ---- named-kernel timing (common.h KernelProf): (start, stop, algorithmic bytes) of every launch of the armed name
+const char* g_dyf_prof_name = nullptr;
+static std::string g_prof_name_store;
+struct ProfRec { hipEvent_t e0, e1; double bytes; };
+static std::deque<ProfRec> g_prof_recs;
+void dyf_prof_begin(hipStream_t st, double bytes) {
+    ProfRec r{nullptr, nullptr, bytes};
+    if (g_prof_recs.size() >= 16384 || hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return;
+    (void)hipEventRecord(r.e0, st);
+    g_prof_recs.push_back(r);
+}
+void dyf_prof_end(hipStream_t st) {
+    if (!g_prof_recs.empty()) (void)hipEventRecord(g_prof_recs.back().e1, st);
+}
+void dyf_prof_arm(const char* name) {  // nullptr disarms; pending records are dropped
+    for (auto& r : g_prof_recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+    g_prof_recs.clear();
+    g_prof_name_store = name ? name : "";
+    g_dyf_prof_name = name ? g_prof_name_store.c_str() : nullptr;
+}
+// after the stream has been synchronised: total ms, total bytes, launches of the armed name; disarms
+void dyf_prof_collect(double* total_ms, double* total_bytes, int* launches) {
+    double ms = 0.0, by = 0.0;
+    int n = 0;
+    for (auto& r : g_prof_recs) {
+        float t = 0.0f;
+        if (hipEventElapsedTime(&t, r.e0, r.e1) == hipSuccess) { ms += t; by += r.bytes; ++n; }
+    }
+    *total_ms = ms; *total_bytes = by; *launches = n;
+    dyf_prof_arm(nullptr);
 }
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
@@ -649,11 +707,11 @@ static hipError_t launch_igemm(ConvArgs a, hipStream_t stream) {
         // output pixels pays more for writing / re-reading the partials than it gains (enc1 at NB = 7: 224 tiles, 58 MB of
         // partials).  Tiny problems (<= 32 tiles) always get the layer's full factor, so small batches, their row splits and
         // the paired launches sum in the same order and stay bit-identical.
-        static const bool enabled = !(getenv("DYF_SPLITK") && atoi(getenv("DYF_SPLITK")) == 0);
+        const bool enabled = !(dyf_form("DYF_SPLITK") && atoi(dyf_form("DYF_SPLITK")) == 0);
         const int nk = a.kh * a.kw * ((a.c0 + a.c1) >> 6);
         const long long tiles = (((long long)(a.n_sel > 0 ? a.n_sel : a.n) * a.ho * a.wo + BM - 1) / BM) * tiles_n;
-        static const long long max_tiles = getenv("DYF_SPLITK_MAX_TILES") ? atoll(getenv("DYF_SPLITK_MAX_TILES")) : 128;
-        static const long long fill = getenv("DYF_SPLITK_FILL") ? atoll(getenv("DYF_SPLITK_FILL")) : 512;
+        const long long max_tiles = dyf_form("DYF_SPLITK_MAX_TILES") ? atoll(dyf_form("DYF_SPLITK_MAX_TILES")) : 128;
+        const long long fill = dyf_form("DYF_SPLITK_FILL") ? atoll(dyf_form("DYF_SPLITK_FILL")) : 512;
         int s = std::min(16, nk / 8);
         while (s > 1 && s * tiles > fill) s >>= 1;
         const long long need = (long long)s * M * a.cout;
@@ -700,11 +758,11 @@ hipError_t launch_conv_stats(const ConvArgs& a_in, int path, hipStream_t stream,
     a.gn_slots = 0;
     const long long nsel = a.n_sel > 0 ? a.n_sel : a.n;  // rows the kernel form is chosen for (ConvArgs::n_sel)
     if (path == 1 && conv_mfma_supported(a)) {
-        static const bool use_halo = !(getenv("DYF_UP_HALO") && atoi(getenv("DYF_UP_HALO")) == 0);
+        const bool use_halo = !(dyf_form("DYF_UP_HALO") && atoi(dyf_form("DYF_UP_HALO")) == 0);
         // halo form from 32 x 32 low-res planes on; below that (dec2: 16 x 16, 2 tiles per image) the materialised upsample +
         // plain 3x3 halo conv is still slightly ahead (7 715 vs 7 690 fields/s with DYF_HALO_MIN_PLANE=16: 640 workgroups of
         // the fused form fill 1.25 rounds of the 512 resident ones)
-        static const int halo_min = getenv("DYF_HALO_MIN_PLANE") ? atoi(getenv("DYF_HALO_MIN_PLANE")) : 32;
+        const int halo_min = dyf_form("DYF_HALO_MIN_PLANE") ? atoi(dyf_form("DYF_HALO_MIN_PLANE")) : 32;
         if (a.up2x && a.up_cols)  // sparse-column form: only the halo kernel writes the compact output tensor
             return conv_up_halo_supported(a) ? launch_conv_up_halo(a, stream) : hipErrorInvalidValue;
         if (a.up2x && use_halo && a.h >= halo_min && a.w >= halo_min && conv_up_halo_supported(a)) return launch_conv_up_halo(a, stream);
@@ -712,15 +770,15 @@ hipError_t launch_conv_stats(const ConvArgs& a_in, int path, hipStream_t stream,
         // instead of one gather per tap); DYF_HALO3=0 disables, DYF_HALO3_MIN_TILES sets the smallest launch (measured at NB = 80,
         // enc3 with 320 tiles 115 -> 94 us; round 4, with the rows forms: from 80 tiles on -- NS at 7 / 10 / 25 rows +3.4 / +5.7 /
         // +2.5 % against the 256 of rounds 1-3, nothing lost at 4 or 80 rows; 64 costs 2.4 % at 4 rows)
-        static const bool h5_all = getenv("DYF_HALO5_ALL") && atoi(getenv("DYF_HALO5_ALL")) != 0;
+        const bool h5_all = dyf_form("DYF_HALO5_ALL") && atoi(dyf_form("DYF_HALO5_ALL")) != 0;
         if (!a.up2x && a.kh == 3 && a.kw == 3 && a.cout % 256 == 0 && !h5_all && a.out_f32 == nullptr && a.residual == nullptr) {
-            const char* h3 = getenv("DYF_HALO3");
+            const char* h3 = dyf_form("DYF_HALO3");
             if (!(h3 && atoi(h3) == 0)) {
                 ConvArgs b = a;
                 b.wpk_up_frag = conv_lookup_halo3_frag(b.wpk);
-                const char* mt3 = getenv("DYF_HALO3_MIN_TILES");
+                const char* mt3 = dyf_form("DYF_HALO3_MIN_TILES");
                 const long long tiles3 = (nsel * a.h * a.w / 128) * (a.cout / 256);
-                static const bool rows = !(getenv("DYF_HALO_ROWS") && atoi(getenv("DYF_HALO_ROWS")) == 0);
+                const bool rows = !(dyf_form("DYF_HALO_ROWS") && atoi(dyf_form("DYF_HALO_ROWS")) == 0);
                 if (b.wpk_up_frag && tiles3 >= (mt3 ? atoll(mt3) : 80) && conv_halo3_supported(b))
                     return rows && conv_halo_rows3_supported(b) ? launch_conv_halo_rows3(b, stream) : launch_conv_halo3(b, stream);
             }
@@ -732,8 +790,8 @@ hipError_t launch_conv_stats(const ConvArgs& a_in, int path, hipStream_t stream,
         // shapes at 38 / 75 rows +5.8 / +3 % against the 256 of round 3).
         if (!a.up2x && a.kh == 3 && a.kw == 3 && a.stride == 1 && a.cout % 64 == 0 && (a.cout % 256 != 0 || h5_all) && a.out_f32 == nullptr &&
             a.residual == nullptr) {
-            static const bool h5 = !(getenv("DYF_HALO5") && atoi(getenv("DYF_HALO5")) == 0);
-            static const long long h5_min = getenv("DYF_HALO5_MIN_TILES") ? atoll(getenv("DYF_HALO5_MIN_TILES")) : 64;
+            const bool h5 = !(dyf_form("DYF_HALO5") && atoi(dyf_form("DYF_HALO5")) == 0);
+            const long long h5_min = dyf_form("DYF_HALO5_MIN_TILES") ? atoll(dyf_form("DYF_HALO5_MIN_TILES")) : 64;
             if (h5) {
                 ConvArgs b = a;
                 b.wpk_up_frag = conv_lookup_halo3_frag(b.wpk);
@@ -756,39 +814,39 @@ hipError_t launch_conv_stats(const ConvArgs& a_in, int path, hipStream_t stream,
         }
         if (!a.up2x && a.kh == 4 && a.kw == 4 && a.stride == 2 && a.cout % 128 == 0 && a.c1 == 0 && a.out_f32 == nullptr &&
             a.residual == nullptr && a.pix_pitch0 == 0) {  // 4x4 / s2 convs: the same kernel on the space-to-depth view
-            const char* h3 = getenv("DYF_HALO3");
+            const char* h3 = dyf_form("DYF_HALO3");
             if (!(h3 && atoi(h3) == 0)) {
                 ConvArgs b = a;
                 b.wpk_up_frag = conv_lookup_halo3_frag(b.wpk);
-                const char* mt3 = getenv("DYF_HALO_S2_MIN_TILES");  // (its own switch since round 5; DYF_HALO3_MIN_TILES still applies when unset)
-                if (!mt3) mt3 = getenv("DYF_HALO3_MIN_TILES");
+                const char* mt3 = dyf_form("DYF_HALO_S2_MIN_TILES");  // (its own switch since round 5; DYF_HALO3_MIN_TILES still applies when unset)
+                if (!mt3) mt3 = dyf_form("DYF_HALO3_MIN_TILES");
                 // cout % 256 == 0: 8 x 16 tiles x 256 channels; else 16 x 16 tiles x 128 channels
                 const long long tiles3 = a.cout % 256 == 0 ? (nsel * a.ho * a.wo / 128) * (a.cout / 256)
                                                            : (nsel * a.ho * a.wo / 256) * (a.cout / 128);
                 if (b.wpk_up_frag && tiles3 >= (mt3 ? atoll(mt3) : 80) && conv_halo_s2_supported(b)) return launch_conv_halo_s2(b, stream);
             }
         }
-        static const bool use_igemm2 = !(getenv("DYF_IGEMM2") && atoi(getenv("DYF_IGEMM2")) == 0);
+        const bool use_igemm2 = !(dyf_form("DYF_IGEMM2") && atoi(dyf_form("DYF_IGEMM2")) == 0);
         if (!a.up2x && use_igemm2 && a.cout % 64 == 0) {  // cout % 128 == 0: 256 x 128 tiles, else 256 x 64
             ConvArgs b = a;
             if (!b.wpk_frag) b.wpk_frag = conv_lookup_frag(b.wpk);
             // 256 x 128 tiles pay off once they fill the chip (2 workgroups x 256 CUs); below that the 128 x 128 form's
             // finer tiles win (measured at NB = 50: dec2/enc2 with 400 tiles +9 %/+4 %, enc3 with 200 tiles -20 %)
             const long long tiles2 = ((nsel * a.ho * a.wo + 255) / 256) * (a.cout % 128 == 0 ? a.cout / 128 : a.cout / 64);
-            const char* mt = getenv("DYF_IGEMM2_MIN_TILES");  // tests force the form on small problems
+            const char* mt = dyf_form("DYF_IGEMM2_MIN_TILES");  // tests force the form on small problems
             const long long min_tiles = mt ? atoll(mt) : 384;
             if (tiles2 >= min_tiles && conv_igemm2_supported(b)) return launch_conv_igemm2(b, stream);
         }
         // few rows: 1x1 / 2x2-s2 convs whose 128 x 128 tiles would not even fill a quarter of the chip (the split-K regime of
         // launch_igemm) run on conv_skinny_kernel -- K split over the four waves of a 32 x 32 tile, one launch (DYF_SKINNY=0 disables)
         if (!a.up2x && a.cout % 128 == 0) {
-            static const bool skinny = !(getenv("DYF_SKINNY") && atoi(getenv("DYF_SKINNY")) == 0);
+            const bool skinny = !(dyf_form("DYF_SKINNY") && atoi(dyf_form("DYF_SKINNY")) == 0);
             const long long tiles128 = ((nsel * a.ho * a.wo + 127) / 128) * (a.cout / 128);
             ConvArgs b = a;
             if (!b.wpk_frag) b.wpk_frag = conv_lookup_frag(b.wpk);
             // (64 tiles of 128 x 128: NS at 1 / 4 / 7 / 10 rows +10.6 / +4 / +2 / +1 %, nothing lost at 25 / 38; at 128 the 25- and
             // 38-row rollouts lose 2.5 %)
-            static const long long sk_max = getenv("DYF_SKINNY_MAX_TILES") ? atoll(getenv("DYF_SKINNY_MAX_TILES")) : 64;
+            const long long sk_max = dyf_form("DYF_SKINNY_MAX_TILES") ? atoll(dyf_form("DYF_SKINNY_MAX_TILES")) : 64;
             if (skinny && tiles128 <= sk_max && conv_skinny_supported(b)) return launch_conv_skinny(b, stream);
         }
         if (a.cout % 128 == 0)
@@ -832,8 +890,8 @@ hipError_t launch_conv_gn_fused(const ConvArgs& a_in, int path, hipStream_t stre
     if (cpg < 8 || cpg % 8 != 0 || 64 % cpg != 0 || cpg * G.groups != a.cout) return hipSuccess;  // a group lies inside one 64-channel block
     const long long nsel = a.n_sel > 0 ? a.n_sel : a.n;
     if (a.kh == 3 && a.kw == 3 && a.stride == 1 && a.pad == 1 && a.cout % 64 == 0 && a.cout % 256 != 0) {
-        static const bool h5 = !(getenv("DYF_HALO5") && atoi(getenv("DYF_HALO5")) == 0);
-        static const long long h5_min = getenv("DYF_HALO5_MIN_TILES") ? atoll(getenv("DYF_HALO5_MIN_TILES")) : 64;
+        const bool h5 = !(dyf_form("DYF_HALO5") && atoi(dyf_form("DYF_HALO5")) == 0);
+        const long long h5_min = dyf_form("DYF_HALO5_MIN_TILES") ? atoll(dyf_form("DYF_HALO5_MIN_TILES")) : 64;
         ConvArgs b = a;
         b.wpk_up_frag = conv_lookup_halo3_frag(b.wpk);
         const long long ty = (a.h + 15) / 16, tx = (a.w + 31) / 32;
@@ -846,7 +904,7 @@ hipError_t launch_conv_gn_fused(const ConvArgs& a_in, int path, hipStream_t stre
             return launch_conv_halo5(b, stream);
         }
     }
-    static const bool use_igemm2 = !(getenv("DYF_IGEMM2") && atoi(getenv("DYF_IGEMM2")) == 0);
+    const bool use_igemm2 = !(dyf_form("DYF_IGEMM2") && atoi(dyf_form("DYF_IGEMM2")) == 0);
     if (use_igemm2 && a.cout % 128 == 0) {
         ConvArgs b = a;
         if (!b.wpk_frag) b.wpk_frag = conv_lookup_frag(b.wpk);
@@ -856,8 +914,8 @@ hipError_t launch_conv_gn_fused(const ConvArgs& a_in, int path, hipStream_t stre
         // from 32 tiles on.  Measured at the end of round 4, OISST shapes, fields/s with the threshold at 256 (the first choice) /
         // 64 / 16: 300 rows 4 154 / 4 165 / 4 181, 150 rows 3 568 / 3 626 / 3 631, 75 rows 2 360 / 2 494 / 2 479, 38 rows 1 548 /
         // 1 619 / 1 654, 16 rows 811 / 811 / 791 (32: 818) -- DYF_GN_FUSE_MIN_TILES overrides, DYF_IGEMM2_MIN_TILES (tests) wins
-        const char* mt = getenv("DYF_IGEMM2_MIN_TILES");
-        const char* mf = getenv("DYF_GN_FUSE_MIN_TILES");
+        const char* mt = dyf_form("DYF_IGEMM2_MIN_TILES");
+        const char* mf = dyf_form("DYF_GN_FUSE_MIN_TILES");
         const long long min_tiles = mt ? atoll(mt) : mf ? atoll(mf) : 32;
         const int slots = conv_igemm2_gn_slots(a.ho, a.wo);
         // flattened-M tiles cut a sample into 128-row slabs at (n * plane) % 128: unless plane % 128 == 0 (or the tiles are 2-D) the
@@ -868,7 +926,7 @@ hipError_t launch_conv_gn_fused(const ConvArgs& a_in, int path, hipStream_t stre
         // few tiles: the 128-pixel tile form (half the K chain per wave, twice the workgroups) while the 256-pixel tiles would leave
         // CUs idle -- DYF_IGEMM2_BM128_BELOW tiles (0 = never); not for batch_invariant engines whose planes are not slab-aligned
         // (the same position argument as above, with 64-row slabs)
-        const char* b128 = getenv("DYF_IGEMM2_BM128_BELOW");  // read per launch (parity test)
+        const char* b128 = dyf_form("DYF_IGEMM2_BM128_BELOW");  // read per launch (parity test)
         const long long bm128_below = b128 ? atoll(b128) : 224;
         const int slots128 = conv_igemm2_gn_slots_bm128(a.ho, a.wo);
         const bool free128 = (a.wo % 16 == 0 && a.ho % 8 == 0) || (a.ho * a.wo) % 64 == 0;

@@ -179,7 +179,7 @@ void pack_enc0_stem_frag(const el16_t* wpk, int cout, el16_t* out) {
 
 // the fused-stem view of enc0 (engine.hip fused_enc0_args): 16-channel pixels declared as 64-channel ones, kh = 4, kw = 1
 bool conv_enc0_stem_supported(const ConvArgs& a) {
-    static const bool on = !(getenv("DYF_ENC0_STEM") && atoi(getenv("DYF_ENC0_STEM")) == 0);
+    const bool on = !(dyf_form("DYF_ENC0_STEM") && atoi(dyf_form("DYF_ENC0_STEM")) == 0);
     if (!on || a.pix_pitch0 != 16 || a.c0 != 64 || a.c1 != 0 || a.kh != 4 || a.kw != 1 || a.stride != 2 || a.pad != 0) return false;
     if (a.up2x || a.residual || a.out_f32 || !a.out_el16 || (a.cout != 64 && a.cout != 128)) return false;
     if (a.wo % 32 != 0 || (a.ho * (a.wo / 32)) % 16 != 0 || a.h != 2 * a.ho + 2 || a.w != 2 * a.wo + 2) return false;

@@ -634,7 +634,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo_rows_tr_kernel(ConvArgs a, i
 // ragged round (256 < tiles <= 384: 2.5 half-tiles per CU instead of 2 whole ones on a quarter of the chip).  DYF_ROWS_TR = 4 / 2 /
 // 1 forces a shape (read per launch); measured in DESIGN.md 5 (round 5).
 static int rows_tile_rows(long long tiles4, int h) {
-    if (const char* f = getenv("DYF_ROWS_TR")) {
+    if (const char* f = dyf_form("DYF_ROWS_TR")) {
         const int t = atoi(f);
         if ((t == 1 || t == 2 || t == 4) && h % t == 0) return t;
     }
@@ -663,10 +663,10 @@ __global__ __launch_bounds__(256, 2) void conv_halo_rows_splitk_kernel(ConvArgs 
 // DYF_HALO_SPLITK_FORCE=s forces a factor (tests); both read per launch.
 static int rows_splitk_factor(const ConvArgs& a, long long tiles_sel, long long tiles, int cpt, long long m_cout) {
     if (a.splitk_ws == nullptr || a.out_f32 != nullptr || a.out_el16 == nullptr || (a.cout & 3) != 0) return 1;
-    const char* on = getenv("DYF_HALO_SPLITK");
+    const char* on = dyf_form("DYF_HALO_SPLITK");
     if (on && atoi(on) == 0) return 1;
     int best = 1;
-    if (const char* f = getenv("DYF_HALO_SPLITK_FORCE")) {
+    if (const char* f = dyf_form("DYF_HALO_SPLITK_FORCE")) {
         best = atoi(f);
         if (best < 1 || best > 8 || (best & (best - 1)) != 0 || cpt % best != 0) best = 1;
     } else {
@@ -792,7 +792,7 @@ hipError_t launch_conv_halo_rows_up(const ConvArgs& a, hipStream_t stream) {
         constexpr int LDS_S0 = RowsCfg<1, 0>::LDS_TOTAL, LDS_S1 = RowsCfg<1, 1>::LDS_TOTAL, LDS_S2 = RowsCfg<1, 2>::LDS_TOTAL;
         const int cnt[3] = {a.up_mix[0], a.up_mix[1], a.up_mix[2]};
         const int off[3] = {0, 32 * cnt[0], 32 * cnt[0] + 16 * cnt[1]}, cb[3] = {0, cnt[0], cnt[0] + cnt[1]};
-        static const bool one_grid = !(getenv("DYF_SPARSE_MIXED_ONE_GRID") && atoi(getenv("DYF_SPARSE_MIXED_ONE_GRID")) == 0);
+        const bool one_grid = !(dyf_form("DYF_SPARSE_MIXED_ONE_GRID") && atoi(dyf_form("DYF_SPARSE_MIXED_ONE_GRID")) == 0);
         if (one_grid && cnt[1] > 0 && cnt[2] > 0) {  // the 16- and 4-entry tiles in one grid; 32-entry tiles (if any) on their own below
             RowsMixGeom g1{off[1], cb[1], cnt[1], cnt[1] * (a.h / (2 * R_TH)), a.n * cnt[1] * (a.h / (2 * R_TH))};
             RowsMixGeom g2{off[2], cb[2], cnt[2], cnt[2] * (a.h / (8 * R_TH)), a.n * cnt[2] * (a.h / (8 * R_TH))};
@@ -822,7 +822,7 @@ hipError_t launch_conv_halo_rows_up(const ConvArgs& a, hipStream_t stream) {
     int tiles_m = a.n * tiles_per_img;
 #ifdef DYF_EXPERIMENT_BUILD
     // timing experiment (WRONG results): 13 of 16 sparse tiles -- what packing the 52-column lists without padded slots would save
-    static const bool exp1316 = getenv("DYF_EXP_DEC5_1316") && atoi(getenv("DYF_EXP_DEC5_1316")) != 0;
+    const bool exp1316 = dyf_form("DYF_EXP_DEC5_1316") && atoi(dyf_form("DYF_EXP_DEC5_1316")) != 0;
     if (sparse && exp1316) tiles_m = tiles_m * 13 / 16;
 #endif
     if (!sparse) {
@@ -850,7 +850,7 @@ hipError_t launch_conv_halo_rows_up(const ConvArgs& a, hipStream_t stream) {
         }
     }
     dyf_form_note(sparse ? "conv_halo_rows_kernel<1>" : "conv_halo_rows_kernel<0>", a.n);
-    static const int persist = getenv("DYF_ROWS_PERSISTENT") ? atoi(getenv("DYF_ROWS_PERSISTENT")) : 0;
+    const int persist = dyf_form("DYF_ROWS_PERSISTENT") ? atoi(dyf_form("DYF_ROWS_PERSISTENT")) : 0;
     if (sparse)
         hipLaunchKernelGGL((conv_halo_rows_kernel<1, 0>), dim3(tiles_m * tiles_n), dim3(256), RowsCfg<1>::LDS_TOTAL, stream, a, tiles_x,
                            tiles_per_img, tiles_m, tiles_n);
@@ -873,8 +873,8 @@ hipError_t launch_conv_halo_rows3(const ConvArgs& a, hipStream_t stream) {
         // long per MFMA with half tiles, comes from the Infinity Cache there, not from a warm L2) -- whole rollouts, same box, two runs each,
         // ms at 1 / 4 / 7 / 10 rows: short tiles for the upsample form only 8.90 / 14.69 / 20.20 / 26.37, for both forms 8.90 / 14.79 / 20.39 /
         // 26.68, four-row tiles only 9.09 / 14.85 / 20.28 / 26.46.  DYF_ROWS_TR_PLAIN=1 (or DYF_ROWS_TR) applies the rule here too.
-        const char* tpe = getenv("DYF_ROWS_TR_PLAIN");
-        const int tr = ((tpe && atoi(tpe) != 0) || getenv("DYF_ROWS_TR")) ? rows_tile_rows(sel, a.h) : 4;
+        const char* tpe = dyf_form("DYF_ROWS_TR_PLAIN");
+        const int tr = ((tpe && atoi(tpe) != 0) || dyf_form("DYF_ROWS_TR")) ? rows_tile_rows(sel, a.h) : 4;
         if (tr != 4) {
             const int tpi = tiles_x * (a.h / tr), tm = a.n * tpi;
             dyf_form_note(tr == 2 ? "conv_halo_rows_kernel<2>+tr2" : "conv_halo_rows_kernel<2>+tr1", a.n);

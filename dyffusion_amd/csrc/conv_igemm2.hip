@@ -665,7 +665,7 @@ hipError_t launch_conv_igemm2(const ConvArgs& a, hipStream_t stream) {
     // workgroups -- the 15 x 15 level of the ResNet-UNet at 300 rows is 528 tiles = two rounds for 1.03 rounds of work, 1 056 small
     // tiles are three rounds of half the size -- but a small tile takes ~0.75 of a large one's time (every pixel fragment feeds half
     // as many MFMAs): OISST rollout 675 -> 698 ms.  DYF_IGEMM2_BALANCE=1 re-enables the experiment.
-    static const bool balance = getenv("DYF_IGEMM2_BALANCE") && atoi(getenv("DYF_IGEMM2_BALANCE")) != 0;
+    const bool balance = dyf_form("DYF_IGEMM2_BALANCE") && atoi(dyf_form("DYF_IGEMM2_BALANCE")) != 0;
     bool small = a.cout % 128 != 0;
     if (!small && balance) {
         const long long sel = a.n_sel > 0 ? ((long long)a.n_sel * a.ho * a.wo + BM - 1) / BM : tiles_m;
@@ -673,7 +673,7 @@ hipError_t launch_conv_igemm2(const ConvArgs& a, hipStream_t stream) {
         small = 0.56 * (double)((ts + 511) / 512) < 0.92 * (double)((tb + 511) / 512);
     }
     // SH3 (one gather per window row): 3x3 / stride 1 / pad 1 on row-major tiles (the kernel tiles 2-D when wo % 16 == 0 && ho % 16 == 0)
-    const bool sh3_on = !(getenv("DYF_IGEMM2_SH3") && atoi(getenv("DYF_IGEMM2_SH3")) == 0);  // (read per launch: tests compare the two forms)
+    const bool sh3_on = !(dyf_form("DYF_IGEMM2_SH3") && atoi(dyf_form("DYF_IGEMM2_SH3")) == 0);  // (read per launch: tests compare the two forms)
     const bool sh3 = sh3_on && a.kh == 3 && a.kw == 3 && a.stride == 1 && a.pad == 1 && a.ho == a.h && a.wo == a.w && a.wo >= 2 &&
                      !(a.wo % 16 == 0 && a.ho % TH == 0);
     if (a.gnf.gran != nullptr && a.gnf.bm == 128) {  // the 128-pixel tile form (launch_conv_gn_fused chose it and counted its slots)
@@ -696,7 +696,7 @@ hipError_t launch_conv_igemm2(const ConvArgs& a, hipStream_t stream) {
         const int tiles_n = a.cout / 128;
         ConvArgs b = a;
 #ifdef DYF_EXPERIMENT_BUILD
-        if (getenv("DYF_GN_FUSE_NOWAIT")) b.gnf.slots = -1;  // timing experiment (WRONG results): no granule sweep
+        if (dyf_form("DYF_GN_FUSE_NOWAIT")) b.gnf.slots = -1;  // timing experiment (WRONG results): no granule sweep
 #endif
         if (sh3)
             hipLaunchKernelGGL((conv_igemm2_kernel<2, true, true>), dim3(tiles_m * tiles_n), dim3(256), LDS_TOTAL_SH3 + 4096, stream, b, (int)M, tiles_m, tiles_n);

@@ -132,7 +132,7 @@ bool conv_skinny_supported(const ConvArgs& a) {
     if (a.kh < 1 || a.kw < 1 || a.kh * a.kw > 16 || a.stride < 1 || a.pad < 0) return false;
     // 16 .. 128 k16 sub-steps: at least one per wave, at most SK_DEPTH (one memory round trip).  Deeper K (enc3: 256, dec2: 576
     // sub-steps) was measured SLOWER here than split-K over workgroups (NS at 4 / 7 rows: 3 250 / 4 560 against 3 910 / 5 130 fields/s)
-    static const int max_steps = getenv("DYF_SKINNY_MAX_KSTEPS") ? atoi(getenv("DYF_SKINNY_MAX_KSTEPS")) : 32;
+    const int max_steps = dyf_form("DYF_SKINNY_MAX_KSTEPS") ? atoi(dyf_form("DYF_SKINNY_MAX_KSTEPS")) : 32;
     const int nk = a.kh * a.kw * ((a.c0 + a.c1) >> 6);
     if (a.c0 % 64 != 0 || a.c1 % 64 != 0 || a.cout % 128 != 0 || nk < 4 || nk > max_steps) return false;
     if (a.ho != (a.h + 2 * a.pad - a.kh) / a.stride + 1 || a.wo != (a.w + 2 * a.pad - a.kw) / a.stride + 1) return false;
@@ -147,7 +147,7 @@ hipError_t launch_conv_skinny(const ConvArgs& a, hipStream_t stream) {
     const long long wgs = (long long)tiles_m * (a.cout / 32);
     // the form follows the tile count of ConvArgs::n_sel rows when the engine pins the forms (the K order of an output differs)
     const long long sel = a.n_sel > 0 ? ((long long)a.n_sel * a.ho * a.wo + 31) / 32 * (a.cout / 32) : wgs;
-    static const long long w8_from = getenv("DYF_SKINNY_W8_FROM") ? atoll(getenv("DYF_SKINNY_W8_FROM")) : 513;
+    const long long w8_from = dyf_form("DYF_SKINNY_W8_FROM") ? atoll(dyf_form("DYF_SKINNY_W8_FROM")) : 513;
     if (sel >= w8_from) {
         dyf_form_note("conv_skinny_kernel<8>", a.n);
         hipLaunchKernelGGL(conv_skinny_kernel_t<8>, dim3((unsigned)wgs), dim3(512), 0, stream, a, M, tiles_m);

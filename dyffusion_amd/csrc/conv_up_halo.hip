@@ -1055,11 +1055,11 @@ hipError_t launch_conv_halo5(const ConvArgs& a, hipStream_t stream) {
     const int tiles_x = (a.w + H5::TW - 1) / H5::TW, tiles_per_img = tiles_x * ((a.h + H5::TH - 1) / H5::TH);
     const int tiles_m = a.n * tiles_per_img, tiles_n = a.cout / 64;
     dyf_form_note(a.gnf.gran ? "conv_up_halo_kernel<5>+gn_fused" : "conv_up_halo_kernel<5>", a.n);
-    static const bool plain_epi = !(getenv("DYF_HALO5_PLAIN_EPI") && atoi(getenv("DYF_HALO5_PLAIN_EPI")) == 0);
+    const bool plain_epi = !(dyf_form("DYF_HALO5_PLAIN_EPI") && atoi(dyf_form("DYF_HALO5_PLAIN_EPI")) == 0);
     if (a.gnf.gran != nullptr) {  // GroupNorm fused: + 1 KB of LDS for the per-channel (A, C) table
         ConvArgs b = a;
 #ifdef DYF_EXPERIMENT_BUILD
-        if (getenv("DYF_GN_FUSE_NOWAIT")) b.gnf.slots = 0;  // timing experiment (WRONG results): no granule sweep
+        if (dyf_form("DYF_GN_FUSE_NOWAIT")) b.gnf.slots = 0;  // timing experiment (WRONG results): no granule sweep
 #endif
         hipLaunchKernelGGL((conv_up_halo_kernel<5, 2>), dim3(tiles_m * tiles_n), dim3(256), H5::LDS_TOTAL + 1024, stream, b, tiles_x,
                            tiles_per_img, tiles_m, tiles_n, 0);
@@ -1535,13 +1535,13 @@ hipError_t launch_conv_up_halo(const ConvArgs& a, hipStream_t stream) {
         // few rows: the K-split form (one sample per workgroup instead of eight: 8 x as many, 8 waves each -- past ~40 rows the form
         // above, whose workgroups already fill the chip, does the same sums with less LDS traffic).  DYF_UP_BORDER_SPLIT_ROWS
         // moves the switch (0 = never); the form is chosen for ConvArgs::n_sel rows when the engine pins the forms (batch_invariant)
-        const char* sre = getenv("DYF_UP_BORDER_SPLIT_ROWS");  // read per launch (parity tests)
+        const char* sre = dyf_form("DYF_UP_BORDER_SPLIT_ROWS");  // read per launch (parity tests)
         const int split_rows = sre ? atoi(sre) : 40;
         // EXPERIMENT, off by default (DYF_UP_BORDER_RING4=1 enables; read per launch): the four-slot ring without the K split for many
         // rows.  Measured SLOWER than the two-slot kernel where it would apply: NS at 80 rows 8 784-8 804 against 8 843-8 851 fields/s
         // (three runs each, same box), dec3 / dec4 / dec5 at 80 rows 306.6 / 568.7 / 527.9 against 293.8 / 560.9 / 523.7 us -- with
         // 480-1 440 workgroups the chip is full either way and the ring's 64 KB of LDS per workgroup halves the resident ones.
-        const char* r4e = getenv("DYF_UP_BORDER_RING4");
+        const char* r4e = dyf_form("DYF_UP_BORDER_RING4");
         const bool ring4 = r4e && atoi(r4e) != 0;
         if ((a.n_sel > 0 ? a.n_sel : a.n) <= split_rows) {
             dyf_form_note("up_border_split_kernel", a.n);
@@ -1557,7 +1557,7 @@ hipError_t launch_conv_up_halo(const ConvArgs& a, hipStream_t stream) {
     const bool sparse = a.up_cols != nullptr;
     // rows form (conv_halo_rows.hip: one-row pixel tiles, half the LDS fragment reads) where the plane tiles by 4 x 32;
     // DYF_HALO_ROWS=0 keeps this file's kernels.  The sparse lists are planned for one form or the other (32 / 16 slots).
-    static const bool rows = !(getenv("DYF_HALO_ROWS") && atoi(getenv("DYF_HALO_ROWS")) == 0);
+    const bool rows = !(dyf_form("DYF_HALO_ROWS") && atoi(dyf_form("DYF_HALO_ROWS")) == 0);
     if (sparse ? ((a.up_mix[0] | a.up_mix[1] | a.up_mix[2]) != 0 || a.up_npad != a.up_ntiles * 16) : (rows && conv_halo_rows_up_supported(a)))
         return launch_conv_halo_rows_up(a, stream);
     const int tiles_x = sparse ? a.up_ntiles : a.w / TILE_W, tiles_per_img = tiles_x * (a.h / TILE_H);
@@ -1570,7 +1570,7 @@ hipError_t launch_conv_up_halo(const ConvArgs& a, hipStream_t stream) {
         // DYF_HALO_TN_XCD=1: one column block per XCD (measured on dec4 at NB=80: HBM-side reads 722 -> 513 MB because the
         // weights stay in L2, but the two column blocks of a tile read their halo on different XCDs; time 649 -> 663 us,
         // whole rollout unchanged -- the extra reads of the default mapping are served by the Infinity Cache).  Off by default.
-        static const int xenv = getenv("DYF_HALO_TN_XCD") ? atoi(getenv("DYF_HALO_TN_XCD")) : 0;
+        const int xenv = dyf_form("DYF_HALO_TN_XCD") ? atoi(dyf_form("DYF_HALO_TN_XCD")) : 0;
         const bool xmode = (xenv & 1) != 0 && (tiles_n == 2 || tiles_n == 4 || tiles_n == 8);
         const int groups = xmode ? 8 / tiles_n : 1, chunk = (tiles_m + groups - 1) / groups;
         const unsigned grid = xmode ? (unsigned)(8 * chunk) : (unsigned)(tiles_m * tiles_n);

@@ -5,6 +5,11 @@
 // :140-163 + :480-494 (q_sample / _interpolate), :205-239 (predict_x_last) and src/models/unet_simple.py:164-197.
 #include "engine_internal.h"
 
+void dyf_form_set(const char* key, const char* value);  // conv.hip: the kernel-form switch table (common.h dyf_form)
+std::string dyf_form_text();
+void dyf_prof_arm(const char* name);  // conv.hip: named-kernel timing (common.h KernelProf)
+void dyf_prof_collect(double* total_ms, double* total_bytes, int* launches);
+
 #include <dlfcn.h>
 #include <mutex>
 #include <rccl/rccl.h>  // types only: the functions are resolved with dlsym (rccl_api below)
@@ -172,7 +177,7 @@ dyf_status net_forward(dyf_engine* e, int which, const Source* srcs, int nsrc, i
     // a forward that draws masks starts by filling the row-key table and advancing the forward counter: a one-block kernel of its
     // own, or -- fused stem, no dropout inside the stem -- block 0 of the stem launch (kernels.hip stem_rng_begin)
     const bool draws = o.dropout_mode == 1 && (n.cfg.dropout > 0.0f || n.cfg.input_dropout > 0.0f);
-    static const bool fold_rng = !(getenv("DYF_FOLD_RNG_BEGIN") && atoi(getenv("DYF_FOLD_RNG_BEGIN")) == 0);
+    const bool fold_rng = !(dyf_form("DYF_FOLD_RNG_BEGIN") && atoi(dyf_form("DYF_FOLD_RNG_BEGIN")) == 0);
     const bool rng_in_stem = draws && fold_rng && n.stem_fused && e->cfg.enable_mfma && e->fuse_stem && n.cfg.input_dropout == 0.0f;
     if (draws && !rng_in_stem)
         HIP_TRY(e, launch_rng_begin_forward(e->rng_state, e->row_keys, nb, o.src_rows > 0 ? o.src_rows : nb, st));
@@ -267,7 +272,7 @@ dyf_status net_forward(dyf_engine* e, int which, const Source* srcs, int nsrc, i
         // 1 x 1 decoder blocks (dec0, dec1): the pointwise conv commutes with the per-channel bilinear upsample, so it runs on the
         // LOW-res cat[x, skip] (a quarter of the pixels, nothing materialised) into fp32 and one pass upsamples + applies the block's
         // epilogue (kernels.h Up2xEpiArgs); DYF_DEC_COMMUTE=0 keeps upsample -> conv
-        static const bool commute = !(getenv("DYF_DEC_COMMUTE") && atoi(getenv("DYF_DEC_COMMUTE")) == 0);
+        const bool commute = !(dyf_form("DYF_DEC_COMMUTE") && atoi(dyf_form("DYF_DEC_COMMUTE")) == 0);
         const bool commuted = commute && b.k == 1 && b.stride == 1 && b.pad == 0 && e->cfg.enable_mfma && (b.cout & 3) == 0 &&
                               (size_t)nb * lh * lw * b.cout * sizeof(float) <= (size_t)nb * b.in_h * b.in_w * b.cin * sizeof(el16_t);
         if (use_fused_up(e, b, f)) {
@@ -407,11 +412,11 @@ dyf_status dyf_engine_create(const dyf_engine_config* cfg, dyf_engine** out_engi
 
     dyf_engine* e = new dyf_engine();
     e->cfg = *cfg;
-    if (const char* fu = getenv("DYF_FUSE_UP2X")) e->fuse_up2x = atoi(fu) != 0;
-    if (const char* fm = getenv("DYF_FUSE_MIN_PLANE")) e->fuse_min_plane = atoi(fm);
-    if (const char* fs = getenv("DYF_FUSE_STEM")) e->fuse_stem = atoi(fs) != 0;
-    if (const char* pi = getenv("DYF_PAIR_INTERP")) e->pair_interp = atoi(pi) != 0;
-    if (const char* pz = getenv("DYF_POISON_DEC5")) e->poison_dec5 = atoi(pz) != 0;
+    if (const char* fu = dyf_form("DYF_FUSE_UP2X")) e->fuse_up2x = atoi(fu) != 0;
+    if (const char* fm = dyf_form("DYF_FUSE_MIN_PLANE")) e->fuse_min_plane = atoi(fm);
+    if (const char* fs = dyf_form("DYF_FUSE_STEM")) e->fuse_stem = atoi(fs) != 0;
+    if (const char* pi = dyf_form("DYF_PAIR_INTERP")) e->pair_interp = atoi(pi) != 0;
+    if (const char* pz = dyf_form("DYF_POISON_DEC5")) e->poison_dec5 = atoi(pz) != 0;
     if (conv_init() != hipSuccess || linattn_fused_init() != hipSuccess || hipStreamCreateWithFlags(&e->cap_stream, hipStreamNonBlocking) != hipSuccess) {
         delete e;
         return fail(nullptr, DYF_ERR_HIP, "engine initialisation failed (conv_init / stream create)");
@@ -518,19 +523,19 @@ dyf_status dyf_engine_create(const dyf_engine_config* cfg, dyf_engine** out_engi
         if (hipHostGetDevicePointer((void**)&e->gn_err_dev, e->gn_err_host, 0) != hipSuccess) e->gn_err_dev = nullptr;
     }
     if (!e->gn_err_dev) e->gn_fuse_disabled = true;  // no way to report a timed-out sweep: keep to the three-kernel path
-    if (const char* gf = getenv("DYF_GN_FUSED")) if (atoi(gf) == 0) e->gn_fuse_disabled = true;
+    if (const char* gf = dyf_form("DYF_GN_FUSED")) if (atoi(gf) == 0) e->gn_fuse_disabled = true;
     {
         dyf_status rs = rn_alloc_workspace(e);
         if (rs != DYF_OK) return bail(rs, e->err);
         rs = sc_alloc_workspace(e);
         if (rs != DYF_OK) return bail(rs, e->err);
     }
-    if (const char* gm = getenv("DYF_GROUP_MIN_ROWS")) e->group_min_rows = std::max(1, atoi(gm));
+    if (const char* gm = dyf_form("DYF_GROUP_MIN_ROWS")) e->group_min_rows = std::max(1, atoi(gm));
     *out_engine = e;
     if (!g_creating_group_child) {
         // default: DYF_ROW_GROUPS, else by architecture (measured on the ResNet-UNet shapes)
         int g = 1;
-        if (const char* rg = getenv("DYF_ROW_GROUPS")) g = atoi(rg);
+        if (const char* rg = dyf_form("DYF_ROW_GROUPS")) g = atoi(rg);
         else g = default_row_groups(e);
         if (g > 1) {
             dyf_status gs = dyf_set_row_groups(e, g);
@@ -574,7 +579,7 @@ dyf_status dyf_set_row_groups(dyf_engine* e, int32_t n_groups) {
         // kernel forms of a group's launches are chosen by the tile count of all n_groups concurrent launches (OISST 300 rows:
         // 3 680 -> 3 750 fields/s; the 100-row shares otherwise fall below the tile thresholds of the large-batch forms)
         c->form_rows_scale = n_groups;
-        if (const char* fs = getenv("DYF_GROUP_FORM_SCALE")) c->form_rows_scale = atoi(fs) != 0 ? n_groups : 1;
+        if (const char* fs = dyf_form("DYF_GROUP_FORM_SCALE")) c->form_rows_scale = atoi(fs) != 0 ? n_groups : 1;
         e->groups.push_back(c);
         if (hipStreamCreateWithFlags(&c->group_stream, hipStreamNonBlocking) != hipSuccess ||
             hipEventCreateWithFlags(&c->group_done, hipEventDisableTiming) != hipSuccess) {
@@ -756,7 +761,7 @@ static dyf_status load_weights_one(dyf_engine* e, int32_t which, int32_t n_tenso
             // The readout (sparse transposed conv + final resample, readout kernels in kernels.hip) reads only the columns
             // of the last decoder block that the final bilinear interpolation touches: for the NS grid (42 native columns
             // from a 512-wide transposed-conv output) 104 of 256.  Plan the column lists of the sparse halo form.
-            const bool sparse_ok = !(getenv("DYF_SPARSE_DEC5") && atoi(getenv("DYF_SPARSE_DEC5")) == 0);  // read per upload
+            const bool sparse_ok = !(dyf_form("DYF_SPARSE_DEC5") && atoi(dyf_form("DYF_SPARSE_DEC5")) == 0);  // read per upload
             if (i == 11 && b.wpk_up_frag && sparse_ok) {
                 const int iw = b.out_w, tw = 2 * iw, ow = e->cfg.width;
                 std::vector<uint8_t> needed(iw, 0);
@@ -779,12 +784,12 @@ static dyf_status load_weights_one(dyf_engine* e, int32_t which, int32_t n_tenso
                 int nt = 0, nv0 = 0, nv1 = 0;
                 // the compact tensor is read by the MFMA form of the readout only (dim 64, <= 4 output channels)
                 // list tiles of 32 slots for the rows form of the halo kernel (conv_halo_rows.hip), 16 for conv_up_halo_kernel<1>
-                static const bool rows_env = !(getenv("DYF_HALO_ROWS") && atoi(getenv("DYF_HALO_ROWS")) == 0);
+                const bool rows_env = !(dyf_form("DYF_HALO_ROWS") && atoi(dyf_form("DYF_HALO_ROWS")) == 0);
                 int slots = rows_env && (b.out_h / 2) % 4 == 0 ? conv_halo_rows_slots() : 16;
                 bool planned = false;
                 int mix[3] = {0, 0, 0};
                 // mixed list tiling (no padded MFMA lanes: 52 entries = 3 x 16 + 4) first; DYF_SPARSE_MIXED=0: uniform tiles only
-                static const bool mixed_env = !(getenv("DYF_SPARSE_MIXED") && atoi(getenv("DYF_SPARSE_MIXED")) == 0);
+                const bool mixed_env = !(dyf_form("DYF_SPARSE_MIXED") && atoi(dyf_form("DYF_SPARSE_MIXED")) == 0);
                 if (n.dim == 64 && n.cfg.out_channels <= 4 && mixed_env && slots == conv_halo_rows_slots() &&
                     plan_up_sparse_columns_mixed(needed, iw / 2, b.out_h / 2, cols, cbase, cidx, cmap, mix, nv0, nv1)) {
                     planned = true;
@@ -966,8 +971,13 @@ dyf_status dyf_poll_errors(dyf_engine* e, int32_t synchronize) {
     if (!e) return DYF_ERR_INVALID_ARGUMENT;
     if (!gn_fuse_live(e)) return DYF_OK;
     if (synchronize) {
+        // only the stream the last call was enqueued on (the row groups' streams join it before the call returns): other streams of
+        // the process -- RCCL's, the caller's own async work -- are not stalled.  A stream that is being captured cannot be waited
+        // for (and nothing has run yet): the check then reads the error words as they are.
         HIP_TRY(e, hipSetDevice(e->cfg.device));
-        HIP_TRY(e, hipDeviceSynchronize());
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(e->poll_stream, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusNone; }
+        if (cs == hipStreamCaptureStatusNone) HIP_TRY(e, hipStreamSynchronize(e->poll_stream));
     }
     return gn_fuse_check(e, false);
 }
@@ -1011,6 +1021,7 @@ dyf_status dyf_net_forward(dyf_engine* e, int32_t which, const float* inputs_dev
     if (!n.loaded) return fail(e, DYF_ERR_STATE, "dyf_load_weights has not been called for this network");
     if (nb < 1 || nb > e->cfg.max_batch) return fail(e, DYF_ERR_INVALID_ARGUMENT, "batch size outside [1, max_batch]");
     if (!inputs_dev || !out_dev) return fail(e, DYF_ERR_INVALID_ARGUMENT, "inputs/out must not be null");
+    e->poll_stream = (hipStream_t)stream;
     if ((n.cfg.cond_channels > 0) != (condition_dev != nullptr))
         return fail(e, DYF_ERR_INVALID_ARGUMENT, "condition must be given iff num_conditional_channels > 0");
     if (n.cfg.with_time_emb && !time_dev) return fail(e, DYF_ERR_INVALID_ARGUMENT, "time must be given when with_time_emb");
@@ -1346,7 +1357,7 @@ dyf_status run_plan(dyf_engine* e, int nb, const uint8_t* const* masks, const fl
     // straight into the contiguous [k][nb][C][H][W] block of the forecast stack.  k is bounded by the workspace (2 max_batch rows):
     // an engine created for 80 rows refines a 10-row call in one 150-row launch instead of eight 20-row ones (the small-batch /
     // ensemble-sharded regime); at nb = max_batch it is the pair it always was.  DYF_REFINE_BATCH caps k.
-    const int refine_cap = getenv("DYF_REFINE_BATCH") ? std::max(1, atoi(getenv("DYF_REFINE_BATCH"))) : 1 << 20;  // read per capture
+    const int refine_cap = dyf_form("DYF_REFINE_BATCH") ? std::max(1, atoi(dyf_form("DYF_REFINE_BATCH"))) : 1 << 20;  // read per capture
     const int kmax = can_pair ? std::max(1, std::min(refine_cap, 2 * e->cfg.max_batch / nb)) : 1;
     for (size_t r = 0; r < ph.refine_times.size();) {
         size_t k = 1;
@@ -1477,6 +1488,7 @@ static dyf_status sample_into_stack(dyf_engine* e, const float* initial_dev, con
 dyf_status dyf_sample(dyf_engine* e, const float* initial_dev, const float* static_dev, float* out_dev, int32_t nb,
                       const uint8_t* const* masks_dev, const float* noise_dev, void* stream) {
     if (e && !out_dev) return fail(e, DYF_ERR_INVALID_ARGUMENT, "out must not be null");
+    if (e) e->poll_stream = (hipStream_t)stream;
     dyf_status r = sample_into_stack(e, initial_dev, static_dev, nb, masks_dev, noise_dev, stream);
     if (r != DYF_OK) return r;
     const size_t field = (size_t)nb * e->C * e->cfg.height * e->cfg.width;
@@ -1583,6 +1595,7 @@ dyf_status dyf_sample_gather(dyf_engine* e, const float* initial_dev, const floa
     const int world = e->comm_world;
     if (total_rows < 1 || (long long)nb * world < total_rows || nb != (total_rows + world - 1) / world)
         return fail(e, DYF_ERR_INVALID_ARGUMENT, "every rank samples nb = ceil(total_rows / world) rows");
+    e->poll_stream = (hipStream_t)stream;
     dyf_status r = sample_into_stack(e, initial_dev, static_dev, nb, nullptr, nullptr, stream);
     if (r != DYF_OK) return r;
     hipStream_t st = (hipStream_t)stream;
@@ -1826,6 +1839,35 @@ dyf_status dyf_time_kernel_in_rollout(dyf_engine* e, int32_t kind, int32_t nb, v
                            : kind == 1 ? 2.0 * nb * tok * (384.0 + 128.0)
                                        : 2.0 * nb * H * W * d * 2.0;  // GroupNorm chain, fused ideal: read once, write once
     return time_class_in_rollout(e, DYF_PROF_RESNET_BASE + kind, nb, (hipStream_t)stream, avg_ms, launches);
+}
+
+dyf_status dyf_time_named_kernel_in_rollout(dyf_engine* e, const char* kernel, int32_t nb, void* stream, double* total_ms, int32_t* launches,
+                                            double* total_bytes) {
+    if (!e || !kernel || !total_ms || !launches || !total_bytes) return fail(e, DYF_ERR_INVALID_ARGUMENT, "null argument");
+    if (!e->plan.set || !e->s_init) return fail(e, DYF_ERR_STATE, "needs a plan and one earlier dyf_sample call (its inputs are re-used)");
+    if (nb < 1 || nb > e->cfg.max_batch) return fail(e, DYF_ERR_INVALID_ARGUMENT, "batch size outside [1, max_batch]");
+    HIP_TRY(e, hipSetDevice(e->cfg.device));
+    hipStream_t st = (hipStream_t)stream;
+    dyf_prof_arm(kernel);
+    dyf_status r = run_plan(e, nb, nullptr, nullptr, st);  // eager launch of the whole rollout on the engine itself (no graph, no row groups)
+    const hipError_t se = hipStreamSynchronize(st);
+    int n = 0;
+    dyf_prof_collect(total_ms, total_bytes, &n);
+    *launches = n;
+    if (r != DYF_OK) return r;
+    if (se != hipSuccess) return fail(e, DYF_ERR_HIP, std::string("rollout: ") + hipGetErrorString(se));
+    return DYF_OK;
+}
+
+void dyf_debug_set_form(const char* key, const char* value) { dyf_form_set(key, value); }
+int32_t dyf_debug_forms(char* buf, int32_t cap) {
+    const std::string t = dyf_form_text();
+    if (buf && cap > 0) {
+        const size_t n = std::min<size_t>(t.size(), (size_t)cap - 1);
+        memcpy(buf, t.data(), n);
+        buf[n] = 0;
+    }
+    return (int32_t)t.size();
 }
 
 void dyf_debug_form_log(int32_t enable) { dyf_form_log_enable(enable != 0); }

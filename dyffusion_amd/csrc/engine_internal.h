@@ -176,6 +176,7 @@ struct dyf_engine {
     bool gn_fuse_disabled = false;
     uint32_t gn_timeout_ticks = 0;   // dyf_debug_gn_fuse: sweep bound in 100 MHz ticks (0 = the 2 s default)
     uint32_t gn_test_tag_xor = 0;    // dyf_debug_gn_fuse: nonzero = every sweep waits for a tag nobody publishes (forced time-out)
+    hipStream_t poll_stream = nullptr;  // the stream of the last dyf_net_forward / dyf_sample / dyf_sample_gather: what dyf_poll_errors waits for
     int gn_fuse_downgrades = 0;      // times this engine left the fused path (time-out or slow sweep): dyf_gn_fuse_state
 };
 
@@ -277,7 +278,7 @@ inline dyf_status upload_conv_weights(dyf_engine* e, el16_t** out, const std::ve
         if (st != DYF_OK) return st;
         conv_register_halo3_frag(*out, frag);
     }
-    const bool h5_all = getenv("DYF_HALO5_ALL") && atoi(getenv("DYF_HALO5_ALL")) != 0;  // experiment: SP = 5 for every 3x3
+    const bool h5_all = dyf_form("DYF_HALO5_ALL") && atoi(dyf_form("DYF_HALO5_ALL")) != 0;  // experiment: SP = 5 for every 3x3
     if (taps == 9 && cout % 64 == 0 && (cout % 256 != 0 || h5_all) && cin % 64 == 0 && (size_t)cout * taps * cin == pk.size()) {
         std::vector<el16_t> pf((size_t)cout * 16 * cin);  // halo form of plain 3x3 convs with 64 / 128 output channels (SP = 5)
         pack_halo3_frag64(pk.data(), cout, cin, pf.data());

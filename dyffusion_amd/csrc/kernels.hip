@@ -413,11 +413,12 @@ __global__ __launch_bounds__(512) void stem16_rows_kernel(StemArgs a, int nblk) 
 hipError_t launch_stem16(const StemArgs& a, hipStream_t s) {
     const int cp = (a.cin + 3) / 4 * 4;  // cin <= 15 (the fused stem's bias channel is slot cin)
     const size_t lds = (size_t)(ST_ROWS + 2) * a.w * cp * sizeof(float) + (size_t)(a.uw + 2 + ST_ROWS) * 16 + 8 * 2048;  // rows + stencil tables + per-wave output tiles
-    const char* env = getenv("DYF_STEM16_ROWS");  // read per launch: the parity test flips it
+    const char* env = dyf_form("DYF_STEM16_ROWS");  // read per launch: the parity test flips it
     if (!(env && atoi(env) == 0) && lds <= 48 * 1024 && cp <= 16 && a.h <= a.uh && 2 * (a.uw + 2) >= 512) {
         const int nblk = (a.uh + 2 + ST_ROWS - 1) / ST_ROWS;
         const dim3 grid((unsigned)(a.n * nblk)), block(512);
         dyf_form_note("stem16_rows_kernel", a.n);
+        KernelProf kp("stem16_rows_kernel", s, (double)(a.src_rows ? a.src_rows : a.n) * a.h * a.w * a.cin * 4.0 + (double)a.n * (a.uh + 2) * (a.uw + 2) * 16 * 2.0);
         if (cp == 4) hipLaunchKernelGGL(stem16_rows_kernel<4>, grid, block, lds, s, a, nblk);
         else if (cp == 8) hipLaunchKernelGGL(stem16_rows_kernel<8>, grid, block, lds, s, a, nblk);
         else if (cp == 12) hipLaunchKernelGGL(stem16_rows_kernel<12>, grid, block, lds, s, a, nblk);
@@ -567,10 +568,11 @@ hipError_t launch_up2x(const Up2xArgs& a, hipStream_t s) {
     const bool vec = (a.c0 % 8 == 0) && (a.c1 % 8 == 0);
     const long long total = (long long)a.n * 4 * a.h * a.w * (vec ? c / 8 : c);
     const unsigned blocks = (unsigned)((total + 255) / 256);
-    const char* env = getenv("DYF_UP2X_QUAD");  // read per launch (parity test)
+    const char* env = dyf_form("DYF_UP2X_QUAD");  // read per launch (parity test)
     if (vec && !(env && atoi(env) == 0) && a.h >= 2 && a.w >= 2) {
         const long long quads = total / 4;
         dyf_form_note("up2x_quad_kernel", a.n);
+        KernelProf kp("up2x_quad_kernel", s, (double)a.n * a.h * a.w * c * 2.0 * 5.0);  // read once, write 4x
         hipLaunchKernelGGL(up2x_quad_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, s, a, quads);
     } else if (vec)
         hipLaunchKernelGGL(up2x_kernel<8>, dim3(blocks), dim3(256), 0, s, a, total);
@@ -631,6 +633,7 @@ hipError_t launch_up2x_epilogue(const Up2xEpiArgs& a, hipStream_t s) {
     if ((a.c & 3) != 0 || a.h < 1 || a.w < 1 || (size_t)a.n * 4 * a.h * a.w * a.c >= 0xFFFFFFF0ull) return hipErrorInvalidValue;
     const long long total = (long long)a.n * a.h * a.w * (a.c >> 2);
     dyf_form_note("up2x_epilogue_kernel", a.n);
+    KernelProf kp("up2x_epilogue_kernel", s, (double)a.n * a.h * a.w * a.c * (4.0 + 4 * 2.0));  // fp32 low-res in, 16-bit x 4 out
     hipLaunchKernelGGL(up2x_epilogue_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a, total);
     return hipGetLastError();
 }
@@ -725,7 +728,7 @@ __global__ __launch_bounds__(256) void groupnorm_wave_kernel(GroupNormArgs a) {
 
 hipError_t launch_groupnorm(const GroupNormArgs& a, hipStream_t s) {
     const int cpg = a.groups > 0 ? a.c / a.groups : 0;
-    const char* we = getenv("DYF_GN_WAVE");  // read per launch (parity test)
+    const char* we = dyf_form("DYF_GN_WAVE");  // read per launch (parity test)
     if (!(we && atoi(we) == 0) && cpg > 0 && cpg * a.groups == a.c && (cpg & 3) == 0 && a.act != ACT_GELU &&
         (size_t)a.n * a.hw * a.c < 0xFFFFFFF0ull) {
         const int pieces = a.hw * (cpg >> 2);
@@ -1266,8 +1269,8 @@ __global__ __launch_bounds__(256, 4) void readout_dma_kernel(ReadoutArgs a, int 
 
 hipError_t launch_readout(const ReadoutArgs& a, hipStream_t s) {
     const long long total = (long long)a.n * a.oh * a.ow;
-    static const bool regw = !(getenv("DYF_READOUT_REGW") && atoi(getenv("DYF_READOUT_REGW")) == 0);
-    static const bool use_mfma = !(getenv("DYF_READOUT_MFMA") && atoi(getenv("DYF_READOUT_MFMA")) == 0);
+    const bool regw = !(dyf_form("DYF_READOUT_REGW") && atoi(dyf_form("DYF_READOUT_REGW")) == 0);
+    const bool use_mfma = !(dyf_form("DYF_READOUT_MFMA") && atoi(dyf_form("DYF_READOUT_MFMA")) == 0);
     if (a.col_map && !(a.wfrag && a.cin == 64 && a.cout >= 1 && a.cout <= 4)) return hipErrorInvalidValue;
     if ((use_mfma || a.col_map) && a.wfrag && a.cin == 64 && a.cout >= 1 && a.cout <= 4 && total < (1ll << 30)) {
         const long long groups = (total + 15) / 16;
@@ -1276,9 +1279,11 @@ hipError_t launch_readout(const ReadoutArgs& a, hipStream_t s) {
         if (per < 1) per = 1;
         waves = (groups + per - 1) / per;
         // DMA-staged gather (DYF_READOUT_DMA=0: the register-shuffle form); the DMA's buffer descriptor addresses < 4 GB
-        static const bool use_dma = !(getenv("DYF_READOUT_DMA") && atoi(getenv("DYF_READOUT_DMA")) == 0);
+        const bool use_dma = !(dyf_form("DYF_READOUT_DMA") && atoi(dyf_form("DYF_READOUT_DMA")) == 0);
         const bool dma = use_dma && a.row_tab && a.col_tab && (size_t)a.n * a.ih * a.iw_store * 128 < 0x7F000000ull;
         dyf_form_note(dma ? "readout_dma_kernel" : "readout_mfma_kernel", a.n);
+        KernelProf kp(dma ? "readout_dma_kernel" : "readout_mfma_kernel", s,
+                      (double)a.n * a.ih * a.iw_store * a.cin * 2.0 + (double)a.n * a.cout * a.oh * a.ow * 4.0);
         if (dma)
             hipLaunchKernelGGL(readout_dma_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 8192 + 4 * 8192, s, a, per);
         else

@@ -1077,7 +1077,7 @@ dyf_status talloc(dyf_engine* e, std::vector<void*>& owner, T** out, size_t coun
     else {
         // test hook (DYF_TRAIN_POISON=1): blocks handed out without zero-fill start as NaN patterns, so a kernel that consumes a
         // buffer it did not fully write shows up in the gradients instead of hiding behind whatever the block held before
-        static const bool poison = getenv("DYF_TRAIN_POISON") && atoi(getenv("DYF_TRAIN_POISON")) != 0;
+        const bool poison = dyf_form("DYF_TRAIN_POISON") && atoi(dyf_form("DYF_TRAIN_POISON")) != 0;
         if (poison) TK(hipMemsetAsync(p, 0xFF, bytes, ts ? ts->stream : nullptr));
     }
     owner.push_back(p);
@@ -1130,7 +1130,7 @@ float* splitk_ws(dyf_engine* e) {
 
 // DYF_TRAIN_MFMA=0 keeps the plain VALU kernels (A/B and a second implementation for the tests)
 bool train_mfma() {
-    static const bool on = !(getenv("DYF_TRAIN_MFMA") && atoi(getenv("DYF_TRAIN_MFMA")) == 0);
+    const bool on = !(dyf_form("DYF_TRAIN_MFMA") && atoi(dyf_form("DYF_TRAIN_MFMA")) == 0);
     return on;
 }
 
@@ -1139,10 +1139,10 @@ dyf_status conv_fwd(dyf_engine* e, const TConv& g, const float* x, const float* 
         TK(hipGetLastError());
         return DYF_OK;
     }
-    static const bool small = !(getenv("DYF_TRAIN_SMALLC") && atoi(getenv("DYF_TRAIN_SMALLC")) == 0);  // =0: the round-3 VALU forms (A/B)
+    const bool small = !(dyf_form("DYF_TRAIN_SMALLC") && atoi(dyf_form("DYF_TRAIN_SMALLC")) == 0);  // =0: the round-3 VALU forms (A/B)
     const long long Mf = (long long)g.n * g.ho * g.wo;
     if (small && g.cout % 64 == 0 && g.wo % 32 == 0 && g.cin <= 8 && g.k * g.k * g.cin <= 126 && g.k < 256 && Mf >= 4096 &&
-        !(getenv("DYF_TRAIN_SMALLC_MFMA") && atoi(getenv("DYF_TRAIN_SMALLC_MFMA")) == 0)) {
+        !(dyf_form("DYF_TRAIN_SMALLC_MFMA") && atoi(dyf_form("DYF_TRAIN_SMALLC_MFMA")) == 0)) {
         const long long tiles = Mf / 32;
         const int tpw = (int)std::max<long long>(1, (tiles + 4095) / 4096);  // ~4 096 waves per 64-channel block
         hipLaunchKernelGGL(t_conv_fwd_smallc_mfma, dim3((unsigned)((tiles + 4ll * tpw - 1) / (4ll * tpw)), (unsigned)(g.cout / 64)), dim3(256), 0, st, g, x,
@@ -1159,16 +1159,13 @@ dyf_status conv_dgrad(dyf_engine* e, const TConv& g, const float* dz, const floa
         TK(hipGetLastError());
         return DYF_OK;
     }
-    static const bool small = !(getenv("DYF_TRAIN_SMALLC") && atoi(getenv("DYF_TRAIN_SMALLC")) == 0);
+    const bool small = !(dyf_form("DYF_TRAIN_SMALLC") && atoi(dyf_form("DYF_TRAIN_SMALLC")) == 0);
     if (small && g.s == 2 && g.k == 4 && g.p == 1 && g.cin <= 4 && g.cout == 64 && g.h % 2 == 0 && g.w % 2 == 0 && g.ho == g.h / 2 && g.wo == g.w / 2 &&
-        !(getenv("DYF_TRAIN_CT_ROWS") && atoi(getenv("DYF_TRAIN_CT_ROWS")) == 0)) {
+        !(dyf_form("DYF_TRAIN_CT_ROWS") && atoi(dyf_form("DYF_TRAIN_CT_ROWS")) == 0)) {
         const int wc = (g.w / 2 + 63) / 64;
         constexpr size_t lds = (size_t)(16 * 64 * 4 + 3 * CT_COLS * CT_PITCH) * sizeof(float);
-        static bool attr_done = false;
-        if (!attr_done) {
-            (void)hipFuncSetAttribute((const void*)t_conv_dgrad_smalln_s2_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            attr_done = true;
-        }
+        if (!train_raise_dynamic_lds(t_conv_dgrad_smalln_s2_rows, (int)lds))
+            return fail(e, DYF_ERR_HIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed for t_conv_dgrad_smalln_s2_rows");
         // output row pairs per workgroup: as many as still leave ~2 048 workgroups
         const long long all_pairs = (long long)g.n * (g.h / 2) * wc;
         const int ppw = (int)std::max<long long>(1, std::min<long long>(16, all_pairs / 2048));
@@ -1208,9 +1205,9 @@ dyf_status conv_wgrad(dyf_engine* e, const TConv& g, const float* dz, const floa
         TK(hipGetLastError());
         return DYF_OK;
     }
-    static const bool small = !(getenv("DYF_TRAIN_SMALLC") && atoi(getenv("DYF_TRAIN_SMALLC")) == 0);
+    const bool small = !(dyf_form("DYF_TRAIN_SMALLC") && atoi(dyf_form("DYF_TRAIN_SMALLC")) == 0);
     if (small && g.cout % 64 == 0 && M >= 4096 && g.wo % 2 == 0 && g.k * g.k * g.cin + 1 <= 128 && g.cin <= 8 &&
-        !(getenv("DYF_TRAIN_SMALLC_MFMA") && atoi(getenv("DYF_TRAIN_SMALLC_MFMA")) == 0)) {  // read per call: tests run both forms
+        !(dyf_form("DYF_TRAIN_SMALLC_MFMA") && atoi(dyf_form("DYF_TRAIN_SMALLC_MFMA")) == 0)) {  // read per call: tests run both forms
         const long long pairs = M / 2;
         const int ppw = (int)std::max<long long>(64, (pairs + 2047) / 2048);  // ~2 048 waves per 64-channel block
         const dim3 grid((unsigned)((pairs + 4ll * ppw - 1) / (4ll * ppw)), (unsigned)(g.cout / 64));
@@ -1892,11 +1889,11 @@ __global__ void t_fill_hash(float* p, long long n, uint32_t seed) {
     const uint32_t h = fmix32((uint32_t)i * 0x9E3779B1u + seed);
     p[i] = ((float)(h >> 8) * (1.0f / 8388608.0f) - 1.0f);  // uniform in [-1, 1)
 }
-// in place: every value rounded to the engine's 16-bit format (what the 16-bit-operand convs do while staging) -- on such data the
+// in place: every value rounded to bf16, the training operand format (what the 16-bit-operand convs do while staging) -- on such data the
 // fp32 reference kernels and the 16-bit matrix-core forms differ only by summation order
 __global__ void t_round16(float* p, long long n) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) p[i] = el16_to_f32(f32_to_el16(p[i]));
+    if (i < n) p[i] = t16_to_f32(f32_to_t16(p[i]));  // bf16: the training operand format of both builds (train_internal.h)
 }
 __global__ void t_maxabs2(const float* a, const float* b, long long n, unsigned* out) {  // out[0] = max |a - b|, out[1] = max |b| (bit patterns)
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1972,7 +1969,7 @@ dyf_status dyf_train_conv_check(dyf_engine* e, int32_t kind, int32_t n, int32_t 
             memcpy(&d, &hm[0], 4); memcpy(&m, &hm[1], 4); memcpy(&ga, &hm[2], 4);
             res[pass] = m > 0.0f ? d / m : 1.0f;  // an all-zero reference is a failed check, not a perfect one
             if (!(ga > 0.0f)) res[pass] = 1.0f;
-            if (getenv("DYF_TRAIN_CHECK_VERBOSE")) fprintf(stderr, "conv_check kind %d pass %d: max|diff| %g max|ref| %g max|got| %g\n", kind, pass, d, m, ga);
+            if (dyf_form("DYF_TRAIN_CHECK_VERBOSE")) fprintf(stderr, "conv_check kind %d pass %d: max|diff| %g max|ref| %g max|got| %g\n", kind, pass, d, m, ga);
         }
         if (kind >= 2) { res[1] = res[0]; break; }
     }

@@ -219,7 +219,7 @@ __global__ __launch_bounds__(256) void t_gemm_mfma(dyf::TConv g, const float* __
 }
 
 // ---- 16-bit operands (round 4, opt-in: DYF_TRAIN_OPERANDS=bf16 | fp16).  The same three gathers with the operands rounded to the
-// engine's 16-bit format WHILE they are staged into LDS (activations, gradients and weights stay fp32 in HBM: "fp32 master weights"),
+// bf16 (always: train_internal.h) WHILE they are staged into LDS (activations, gradients and weights stay fp32 in HBM: "fp32 master weights"),
 // fp32 accumulation on v_mfma_f32_32x32x16: 16x the matrix rate of the fp32 instruction, so the kernel is bound by its operand
 // loads (24 KB of fp32 per 32-deep K stage and workgroup) instead of by the matrix cores.  K stage 32 = two k16 sub-steps; LDS tiles
 // [row][32 k] 16-bit, rows 80 bytes apart; a lane's fragment is one ds_read_b128.  What changes numerically is the products' input
@@ -231,8 +231,8 @@ template <int MODE>
 __global__ __launch_bounds__(256) void t_gemm_mfma16(dyf::TConv g, const float* __restrict__ Ap, const float* __restrict__ Bp,
                                                      const float* __restrict__ bias, float* __restrict__ Cp, int split_len, int pmode) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    __shared__ __attribute__((aligned(16))) el16_t As[2][GM * LDR16];
-    __shared__ __attribute__((aligned(16))) el16_t Bs[2][GN * LDR16];
+    __shared__ __attribute__((aligned(16))) t16_t As[2][GM * LDR16];
+    __shared__ __attribute__((aligned(16))) t16_t Bs[2][GN * LDR16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
@@ -355,21 +355,21 @@ __global__ __launch_bounds__(256) void t_gemm_mfma16(dyf::TConv g, const float* 
 #pragma unroll
             for (int i = 0; i < 4; ++i) {  // 4 consecutive k of one row: one 8-byte store
                 const int s = tid + 256 * i;
-                *(uint2*)&As[buf][(s >> 3) * LDR16 + 4 * (s & 7)] = make_uint2(pack_el16x2(ra[i].x, ra[i].y), pack_el16x2(ra[i].z, ra[i].w));
+                *(uint2*)&As[buf][(s >> 3) * LDR16 + 4 * (s & 7)] = make_uint2(pack_t16x2(ra[i].x, ra[i].y), pack_t16x2(ra[i].z, ra[i].w));
             }
         } else {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {  // 4 consecutive rows (cout) of one k (pixel)
                 const int s = tid + 256 * i, k = s >> 5;
-                el16_t* d = &As[buf][((s & 31) * 4) * LDR16 + k];
-                d[0] = f32_to_el16(ra[i].x); d[LDR16] = f32_to_el16(ra[i].y); d[2 * LDR16] = f32_to_el16(ra[i].z); d[3 * LDR16] = f32_to_el16(ra[i].w);
+                t16_t* d = &As[buf][((s & 31) * 4) * LDR16 + k];
+                d[0] = f32_to_t16(ra[i].x); d[LDR16] = f32_to_t16(ra[i].y); d[2 * LDR16] = f32_to_t16(ra[i].z); d[3 * LDR16] = f32_to_t16(ra[i].w);
             }
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {  // 4 consecutive columns n of one k
             const int s = tid + 256 * i, bk = s >> 4, bnq = s & 15;
-            el16_t* d = &Bs[buf][(bnq * 4) * LDR16 + bk];
-            d[0] = f32_to_el16(rb[i].x); d[LDR16] = f32_to_el16(rb[i].y); d[2 * LDR16] = f32_to_el16(rb[i].z); d[3 * LDR16] = f32_to_el16(rb[i].w);
+            t16_t* d = &Bs[buf][(bnq * 4) * LDR16 + bk];
+            d[0] = f32_to_t16(rb[i].x); d[LDR16] = f32_to_t16(rb[i].y); d[2 * LDR16] = f32_to_t16(rb[i].z); d[3 * LDR16] = f32_to_t16(rb[i].w);
         }
     };
 
@@ -386,15 +386,15 @@ __global__ __launch_bounds__(256) void t_gemm_mfma16(dyf::TConv g, const float* 
     for (int st = 0; st < nstage; ++st) {
         const int buf = st & 1;
         if (st + 1 < nstage) load(st0 + st + 1);
-        const el16_t* ar0 = &As[buf][(wm * 64 + l31) * LDR16 + hi * 8];
-        const el16_t* ar1 = ar0 + 32 * LDR16;
-        const el16_t* br = &Bs[buf][(wn * 32 + l31) * LDR16 + hi * 8];
+        const t16_t* ar0 = &As[buf][(wm * 64 + l31) * LDR16 + hi * 8];
+        const t16_t* ar1 = ar0 + 32 * LDR16;
+        const t16_t* br = &Bs[buf][(wn * 32 + l31) * LDR16 + hi * 8];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            const el16x8_t a0 = *(const el16x8_t*)(ar0 + ks * 16), a1 = *(const el16x8_t*)(ar1 + ks * 16);
-            const el16x8_t b = *(const el16x8_t*)(br + ks * 16);
-            acc[0] = DYF_MFMA_32x32x16(a0, b, acc[0], 0, 0, 0);
-            acc[1] = DYF_MFMA_32x32x16(a1, b, acc[1], 0, 0, 0);
+            const t16x8_t a0 = *(const t16x8_t*)(ar0 + ks * 16), a1 = *(const t16x8_t*)(ar1 + ks * 16);
+            const t16x8_t b = *(const t16x8_t*)(br + ks * 16);
+            acc[0] = T16_MFMA_32x32x16(a0, b, acc[0], 0, 0, 0);
+            acc[1] = T16_MFMA_32x32x16(a1, b, acc[1], 0, 0, 0);
         }
         if (st + 1 < nstage) store(buf ^ 1);
         __syncthreads();
@@ -435,22 +435,22 @@ __global__ void t_splitk_finish(const float* ws, int splits, long long MN, int N
 
 namespace dyf {
 
-// 16-bit operands: the training convs round their operands to the engine's 16-bit format while staging them (t_gemm_mfma16,
+// 16-bit operands: the training convs round their operands to bf16 (both builds: train_internal.h) while staging them (t_gemm_mfma16,
 // train_halo16.hip) -- chosen per engine by dyf_train_set_precision(16) (the reference's `trainer.precision=16`), or, for engines
-// that did not say (0), by DYF_TRAIN_OPERANDS=bf16 | fp16 | 16 (read per call: tests flip it in-process).  Otherwise fp32 operands.
+// that did not say (0), by the tests' kernel-form switch DYF_TRAIN_OPERANDS=bf16 | 16 (dyf_debug_set_form; read per call).  Otherwise fp32.
 thread_local int g_train_precision = 0;
 bool train_operands16() {
     if (g_train_precision == 16) return true;
     if (g_train_precision == 32) return false;
-    const char* v = getenv("DYF_TRAIN_OPERANDS");
-    return v && (!strcmp(v, "bf16") || !strcmp(v, "fp16") || !strcmp(v, "16"));
+    const char* v = dyf_form("DYF_TRAIN_OPERANDS");
+    return v && (!strcmp(v, "bf16") || !strcmp(v, "16"));
 }
 
 // split-K plan of a forward / dgrad launch: (splits, stages per split); splits == 1 -> no split
 static void plan_splitk(long long tiles, int stages, int& splits, int& len) {
     splits = 1;
     len = 0;
-    static const bool enabled = !(getenv("DYF_TRAIN_SPLITK") && atoi(getenv("DYF_TRAIN_SPLITK")) == 0);
+    const bool enabled = !(dyf_form("DYF_TRAIN_SPLITK") && atoi(dyf_form("DYF_TRAIN_SPLITK")) == 0);
     if (!enabled || tiles >= 128 || stages < 16) return;
     long long want = std::min<long long>((512 + tiles - 1) / tiles, stages / 4);  // >= 4 stages per split
     if (want < 2) return;
@@ -484,7 +484,7 @@ bool tgemm_conv_dgrad(const TConv& g, const float* dz, const float* w, const flo
     const bool h16 = train_operands16() && g.cout % GK16 == 0;
     if (h16 && thalo_conv3x3(g, 1, dz, w, bias, dx, ws, ws_floats, st)) return true;
     {   // 4 x 4 / stride 2 / pad 1: one launch slice per parity class of the input pixels (see the kernel); small planes keep split-K
-        const bool pclass = !(getenv("DYF_TRAIN_DGRAD_PARITY") && atoi(getenv("DYF_TRAIN_DGRAD_PARITY")) == 0);  // per call: tests flip it
+        const bool pclass = !(dyf_form("DYF_TRAIN_DGRAD_PARITY") && atoi(dyf_form("DYF_TRAIN_DGRAD_PARITY")) == 0);  // per call: tests flip it
         const long long mq = ((long long)g.n * g.h * g.w / 4 + GM - 1) / GM;
         if (h16 && pclass && g.k == 4 && g.s == 2 && g.p == 1 && g.h % 2 == 0 && g.w % 2 == 0 && g.ho == g.h / 2 && g.wo == g.w / 2 &&
             mq * (g.cin / GN) >= 64 && mq <= 0x7fffffffll) {

@@ -1,5 +1,5 @@
 // 3 x 3 / stride 1 / pad 1 convolutions of the training step with 16-bit operands (DYF_TRAIN_OPERANDS=bf16): forward, data
-// gradient and weight gradient on fp32 NHWC tensors, the operands rounded to the engine's 16-bit format while they are staged
+// gradient and weight gradient on fp32 NHWC tensors, the operands rounded to bf16 (in both builds of the library) while they are staged
 // (the reference gets these from torch.autograd over src/models/unet_simple.py:29-56 and src/models/unet.py:58-109).
 //
 // Why a second form next to train_gemm.hip: its implicit GEMM gathers the A operand tap by tap, so a 3 x 3 conv reads every
@@ -36,7 +36,7 @@ __device__ __forceinline__ int hkey(int hp) { return ((hp >> 1) - (int)((unsigne
 // ---------------------------------------------------------------------------------------------- weights -> 16 bit, [n][tap][k]
 // mode 0 (forward):  src = wt[tap][ci][co]            -> dst[co][tap][ci]
 // mode 1 (dgrad):    src = w[co][tap][ci], mirrored   -> dst[ci][8 - tap][co]
-__global__ void t_pack_w16(const float* __restrict__ src, int cin, int cout, int mode, el16_t* __restrict__ dst) {
+__global__ void t_pack_w16(const float* __restrict__ src, int cin, int cout, int mode, t16_t* __restrict__ dst) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long total = (long long)cin * cout * 9;
     if (i >= total) return;
@@ -47,7 +47,7 @@ __global__ void t_pack_w16(const float* __restrict__ src, int cin, int cout, int
     float v;
     if (mode == 0) v = src[((size_t)tap * cin + k) * cout + n];
     else v = src[((size_t)k * 9 + (8 - tap)) * cin + n];
-    dst[i] = f32_to_el16(v);
+    dst[i] = f32_to_t16(v);
 }
 
 // ---------------------------------------------------------------------------------------------- forward / data gradient
@@ -63,7 +63,7 @@ __global__ void t_pack_w16(const float* __restrict__ src, int cin, int cout, int
 
 template <int BN>
 __global__ __launch_bounds__(256, BN == 64 ? 2 : 1) void t_halo3x3_16(int h, int w, int CK, int NC, const float* __restrict__ A,
-                                                                      const el16_t* __restrict__ Wb, const float* __restrict__ bias,
+                                                                      const t16_t* __restrict__ Wb, const float* __restrict__ bias,
                                                                       float* __restrict__ C, int tiles_x, int tiles_per_img,
                                                                       int tiles_total, int tiles_per_wg, int nblocks) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256, BN == 64 ? 2 : 1) void t_halo3x3_16(int h, int
             const int hp = idx >> 4, q = idx & 15;
             if (idx < HP * 16)
                 *(uint2*)(Xs + hp * 128 + (((q >> 1) ^ hkey(hp)) << 4) + (q & 1) * 8) =
-                    make_uint2(pack_el16x2(hv[j].x, hv[j].y), pack_el16x2(hv[j].z, hv[j].w));
+                    make_uint2(pack_t16x2(hv[j].x, hv[j].y), pack_t16x2(hv[j].z, hv[j].w));
         }
     };
 
@@ -163,12 +163,12 @@ __global__ __launch_bounds__(256, BN == 64 ? 2 : 1) void t_halo3x3_16(int h, int
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
                     const int c16 = ks * 2 + hi;
-                    const el16x8_t a = *(const el16x8_t*)(ap + ((c16 ^ akey) << 4));
+                    const t16x8_t a = *(const t16x8_t*)(ap + ((c16 ^ akey) << 4));
 #pragma unroll
                     for (int t = 0; t < NT; ++t) {
                         const int n = t * 32 + l31;
-                        const el16x8_t b = *(const el16x8_t*)(bp + n * 128 + ((c16 ^ ((n >> 1) & 7)) << 4));
-                        acc[t] = DYF_MFMA_32x32x16(a, b, acc[t], 0, 0, 0);
+                        const t16x8_t b = *(const t16x8_t*)(bp + n * 128 + ((c16 ^ ((n >> 1) & 7)) << 4));
+                        acc[t] = T16_MFMA_32x32x16(a, b, acc[t], 0, 0, 0);
                     }
                 }
                 if (++slot == RING) slot = 0;
@@ -241,7 +241,7 @@ __global__ __launch_bounds__(256, 2) void t_wgrad3x3_16(int h, int w, int cin, i
                 v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (yy < h && xx < w) v[j] = *(const float4*)(dz + (((size_t)img * h + yy) * w + xx) * cout + co0 + cq * 4);
             }
-#define PACK8(F) u32x4{pack_el16x2(v[0].F, v[1].F), pack_el16x2(v[2].F, v[3].F), pack_el16x2(v[4].F, v[5].F), pack_el16x2(v[6].F, v[7].F)}
+#define PACK8(F) u32x4{pack_t16x2(v[0].F, v[1].F), pack_t16x2(v[2].F, v[3].F), pack_t16x2(v[4].F, v[5].F), pack_t16x2(v[6].F, v[7].F)}
             const int r0 = cq * 4;
             *(u32x4*)(Dz + (r0 + 0) * DZ_PITCH + ((pg ^ ((r0 + 0) & 15)) << 4)) = PACK8(x);
             *(u32x4*)(Dz + (r0 + 1) * DZ_PITCH + ((pg ^ ((r0 + 1) & 15)) << 4)) = PACK8(y);
@@ -275,16 +275,16 @@ __global__ __launch_bounds__(256, 2) void t_wgrad3x3_16(int h, int w, int cin, i
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if ((unsigned)yy < (unsigned)h && (unsigned)xx < (unsigned)w) v = *(const float4*)(x + (((size_t)img * h + yy) * w + xx) * cin + ci0 + cq * 4);
             const int r0 = cq * 4, ch = hy * 4 + (side ? 3 : 0), eo = side ? 0 : 14;
-            *(el16_t*)(Xt + (r0 + 0) * XT_PITCH + ((ch ^ ((r0 + 0) & 15)) << 4) + eo) = f32_to_el16(v.x);
-            *(el16_t*)(Xt + (r0 + 1) * XT_PITCH + ((ch ^ ((r0 + 1) & 15)) << 4) + eo) = f32_to_el16(v.y);
-            *(el16_t*)(Xt + (r0 + 2) * XT_PITCH + ((ch ^ ((r0 + 2) & 15)) << 4) + eo) = f32_to_el16(v.z);
-            *(el16_t*)(Xt + (r0 + 3) * XT_PITCH + ((ch ^ ((r0 + 3) & 15)) << 4) + eo) = f32_to_el16(v.w);
+            *(t16_t*)(Xt + (r0 + 0) * XT_PITCH + ((ch ^ ((r0 + 0) & 15)) << 4) + eo) = f32_to_t16(v.x);
+            *(t16_t*)(Xt + (r0 + 1) * XT_PITCH + ((ch ^ ((r0 + 1) & 15)) << 4) + eo) = f32_to_t16(v.y);
+            *(t16_t*)(Xt + (r0 + 2) * XT_PITCH + ((ch ^ ((r0 + 2) & 15)) << 4) + eo) = f32_to_t16(v.z);
+            *(t16_t*)(Xt + (r0 + 3) * XT_PITCH + ((ch ^ ((r0 + 3) & 15)) << 4) + eo) = f32_to_t16(v.w);
         }
         __syncthreads();
         // 8 k-steps of 16 pixels (tile row y; lanes hi = 0 / 1 take columns 0-7 / 8-15)
 #pragma unroll 2
         for (int y = 0; y < TH; ++y) {
-            const el16x8_t a = *(const el16x8_t*)(a_base + (((y * 2 + hi) ^ a_key) << 4));
+            const t16x8_t a = *(const t16x8_t*)(a_base + (((y * 2 + hi) ^ a_key) << 4));
 #pragma unroll
             for (int ky = 0; ky < 3; ++ky) {
                 const int ch = (y + ky) * 4 + hi;  // block holding columns [8 hi - 8, 8 hi) of halo row y + ky
@@ -295,9 +295,9 @@ __global__ __launch_bounds__(256, 2) void t_wgrad3x3_16(int h, int w, int cin, i
                                s23 = __builtin_amdgcn_alignbyte(cu.w, cu.z, 2);
                 const u32x4 left = {__builtin_amdgcn_alignbyte(cu.x, pv.w, 2), s01, s12, s23};    // pixels shifted by -1 column
                 const u32x4 right = {s01, s12, s23, __builtin_amdgcn_alignbyte(nx.x, cu.w, 2)};   // pixels shifted by +1 column
-                acc[ky * 3 + 0] = DYF_MFMA_32x32x16(a, __builtin_bit_cast(el16x8_t, left), acc[ky * 3 + 0], 0, 0, 0);
-                acc[ky * 3 + 1] = DYF_MFMA_32x32x16(a, __builtin_bit_cast(el16x8_t, cu), acc[ky * 3 + 1], 0, 0, 0);
-                acc[ky * 3 + 2] = DYF_MFMA_32x32x16(a, __builtin_bit_cast(el16x8_t, right), acc[ky * 3 + 2], 0, 0, 0);
+                acc[ky * 3 + 0] = T16_MFMA_32x32x16(a, __builtin_bit_cast(t16x8_t, left), acc[ky * 3 + 0], 0, 0, 0);
+                acc[ky * 3 + 1] = T16_MFMA_32x32x16(a, __builtin_bit_cast(t16x8_t, cu), acc[ky * 3 + 1], 0, 0, 0);
+                acc[ky * 3 + 2] = T16_MFMA_32x32x16(a, __builtin_bit_cast(t16x8_t, right), acc[ky * 3 + 2], 0, 0, 0);
             }
         }
     }
@@ -315,7 +315,7 @@ __global__ __launch_bounds__(256, 2) void t_wgrad3x3_16(int h, int w, int cin, i
 }
 
 bool halo16_enabled() {
-    const char* v = getenv("DYF_TRAIN_HALO16");  // =0: the tap-by-tap implicit GEMM of train_gemm.hip for these layers too (A/B)
+    const char* v = dyf_form("DYF_TRAIN_HALO16");  // =0: the tap-by-tap implicit GEMM of train_gemm.hip for these layers too (A/B)
     return !(v && atoi(v) == 0);
 }
 
@@ -337,7 +337,7 @@ bool thalo_conv3x3(const TConv& g, int mode, const float* A, const float* W, con
     // the column blocks of a tile are neighbours in the grid (its halo is read from L2 by all but the first)
     constexpr int bn = 64;
     if (tiles * (NC / bn) < 192 || tiles > 0x7fffffffll) return false;  // small planes: the split-K forms of train_gemm.hip  // small planes: the split-K forms of train_gemm.hip
-    el16_t* wb = (el16_t*)ws;
+    t16_t* wb = (t16_t*)ws;
     dyf_form_note(mode ? "t_halo3x3_16:dgrad" : "t_halo3x3_16:forward", g.n);
     hipLaunchKernelGGL(t_pack_w16, dim3((unsigned)((welems + 255) / 256)), dim3(256), 0, st, W, g.cin, g.cout, mode, wb);
     const int nblocks = NC / bn;
@@ -348,11 +348,7 @@ bool thalo_conv3x3(const TConv& g, int mode, const float* A, const float* W, con
     const int per = (int)std::max<long long>(1, std::min<long long>(16, tiles * nblocks / htarget));
     const long long wgs = ((tiles + per - 1) / per + 7) / 8 * 8 * nblocks;  // whole groups of 8 tile ranges (XCD-aware order in the kernel)
     constexpr int XS = HP * 128 + 512;
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)t_halo3x3_16<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * XS + 4 * 64 * 128);
-        attr_done = true;
-    }
+    if (!train_raise_dynamic_lds(t_halo3x3_16<64>, 2 * XS + 4 * 64 * 128)) return false;  // per device; the tap-by-tap form takes the layer
     hipLaunchKernelGGL(t_halo3x3_16<64>, dim3((unsigned)wgs), dim3(256), 2 * XS + 4 * 64 * 128, st, g.h, g.w, CK, NC, A, wb, bias, C, tiles_x,
                        tiles_per_img, (int)tiles, per, nblocks);
     return true;

@@ -5,6 +5,49 @@
 
 #include <algorithm>
 
+// ---- the 16-bit operand format of the TRAINING convs: always bf16, in both builds of the library (the fp16 build too).
+// Training tensors, master weights, accumulators and statistics are fp32; only the MFMA operands are rounded while they are staged,
+// so the format is independent of the engine's inference storage type.  fp16 operands would need the reference's GradScaler
+// (Lightning precision=16): with mean-reduced losses dL/dout is ~1e-6..1e-7 at real batch sizes, below fp16's normal range, and the
+// rounded gradient operand keeps a few bits or flushes to zero.  bf16 has fp32's exponent: no loss scale, no skipped steps.
+typedef __bf16 t16_native_t;
+typedef t16_native_t t16x8_t __attribute__((ext_vector_type(8)));
+typedef t16_native_t t16x2_native_t __attribute__((ext_vector_type(2)));
+typedef uint16_t t16_t;
+#define T16_MFMA_32x32x16(a, b, c, x, y, z) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z)
+__device__ __host__ __forceinline__ t16_t f32_to_t16(float f) {  // round-to-nearest-even, NaN preserved
+    uint32_t u = __builtin_bit_cast(uint32_t, f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (t16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (t16_t)(u >> 16);
+}
+__device__ __host__ __forceinline__ float t16_to_f32(t16_t v) { return __builtin_bit_cast(float, ((uint32_t)v) << 16); }
+__device__ __forceinline__ uint32_t pack_t16x2(float lo, float hi) {  // one v_cvt_pk_bf16_f32
+#if defined(__HIP_DEVICE_COMPILE__)
+    const f32x2_native_t v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, t16x2_native_t));
+#else
+    return (uint32_t)f32_to_t16(lo) | ((uint32_t)f32_to_t16(hi) << 16);
+#endif
+}
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a PER-DEVICE attribute: the training launchers that need more than the 64 KB
+// default raise it once per (kernel, device) -- a process-wide flag left the second GPU of a process at the default, and its first
+// launch failed.  Returns false (and the launcher declines the shape) when the attribute cannot be set.
+#include <atomic>
+template <typename K>
+static inline bool train_raise_dynamic_lds(K kernel, int bytes) {
+    static std::atomic<unsigned char> done[64];  // per instantiation (= per kernel); 0 not tried, 1 set, 2 failed
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;
+    unsigned char st = done[dev].load(std::memory_order_acquire);
+    if (st == 0) {
+        st = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess ? 1 : 2;
+        done[dev].store(st, std::memory_order_release);
+    }
+    return st == 1;
+}
+
 namespace dyf {
 
 struct TConv {  // geometry of one nn.Conv2d on NHWC fp32 tensors: x (n, h, w, cin) -> y (n, ho, wo, cout), k x k / stride s / pad p

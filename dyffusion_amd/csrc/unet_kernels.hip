@@ -237,7 +237,7 @@ hipError_t launch_stem_conv(const StemConvArgs& a, hipStream_t s) {
     const long long total = (long long)a.n * a.h * a.w;
     if (a.wfrag && a.dim == 64 && a.ksteps >= 1 && a.ksteps == stem_frag_steps(a.k, a.cin) && a.nsrc <= 4 &&
         (long long)a.h * a.w * 4 < (1ll << 31)) {
-        static const bool use_mfma = !(getenv("DYF_STEM_MFMA") && atoi(getenv("DYF_STEM_MFMA")) == 0);
+        const bool use_mfma = !(dyf_form("DYF_STEM_MFMA") && atoi(dyf_form("DYF_STEM_MFMA")) == 0);
         if (use_mfma) {
             const int ts = (a.k * a.k + 15) / 16;
             const size_t lds = (size_t)a.ksteps * 4 * 64 * 16;
@@ -827,19 +827,21 @@ hipError_t launch_gn_act(const GnActArgs& a, hipStream_t s) {
             float2* mr = (float2*)(a.stats + (size_t)a.n * a.groups * 2 * GN_MAX_BLOCKS);
             dyf_form_note("gn_finalize_part_kernel+gn_apply", a.n);
             hipLaunchKernelGGL(gn_finalize_part_kernel, dim3(a.groups, a.n), dim3(256), 0, s, a.part, a.part_slots, a.c, a.groups, a.hw, mr);
+            KernelProf kp("gn_apply_walk_kernel", s, (double)a.n * a.hw * a.c * 2.0 * (a.residual ? 3.0 : 2.0));
             hipLaunchKernelGGL(gn_apply_walk_kernel, dim3(bx, a.n), dim3(256), 0, s, a, (const float2*)mr);
             return hipGetLastError();
         }
         dyf_form_note("gn_apply_part_kernel", a.n);
+        KernelProf kp("gn_apply_part_kernel", s, (double)a.n * a.hw * a.c * 2.0 * (a.residual ? 3.0 : 2.0));
         hipLaunchKernelGGL(gn_apply_part_kernel, dim3(bx, a.n), dim3(256), 0, s, a);
         return hipGetLastError();
     }
     if (a.stats && (a.c % 8 == 0) && (cpg % 8 == 0) && a.groups <= 64) {
         {
             const int chunks = a.c >> 3, cq = cpg >> 3;
-            static const bool fused = getenv("DYF_GN_FUSED_SAMPLE") && atoi(getenv("DYF_GN_FUSED_SAMPLE")) != 0;  // experiment, off
+            const bool fused = dyf_form("DYF_GN_FUSED_SAMPLE") && atoi(dyf_form("DYF_GN_FUSED_SAMPLE")) != 0;  // experiment, off
             const long long per = (long long)a.hw * chunks;
-            static const int reread = getenv("DYF_GN_FUSED_REREAD") ? atoi(getenv("DYF_GN_FUSED_REREAD")) : 0;  // experiment: 1 = never keep
+            const int reread = dyf_form("DYF_GN_FUSED_REREAD") ? atoi(dyf_form("DYF_GN_FUSED_REREAD")) : 0;  // experiment: 1 = never keep
             if (fused && (chunks & (chunks - 1)) == 0 && (cq & (cq - 1)) == 0 && chunks <= 256 && per <= 1024 * 32) {
                 dyf_form_note("gn_fused_sample_kernel", a.n);
                 if (per <= 512 * 8 && !reread) hipLaunchKernelGGL((gn_fused_sample_kernel<8, 512, true>), dim3(a.n), dim3(512), 0, s, a);
@@ -860,9 +862,10 @@ hipError_t launch_gn_act(const GnActArgs& a, hipStream_t s) {
         hipLaunchKernelGGL(gn_finalize_kernel, dim3((cnt + 255) / 256), dim3(256), 0, s, (const double*)a.stats, cnt, (int)bx,
                            1.0 / ((double)a.hw * cpg), mr);
         const int chunks = a.c >> 3;
-        static const bool walk = !(getenv("DYF_GN_WALK") && atoi(getenv("DYF_GN_WALK")) == 0);
+        const bool walk = !(dyf_form("DYF_GN_WALK") && atoi(dyf_form("DYF_GN_WALK")) == 0);
         if (walk && (chunks & (chunks - 1)) == 0 && chunks <= 256 && a.n <= 65535) {
             const int rows = 256 / chunks;
+            KernelProf kp("gn_apply_walk_kernel", s, (double)a.n * a.hw * a.c * 2.0 * (a.residual ? 3.0 : 2.0));
             hipLaunchKernelGGL(gn_apply_walk_kernel, dim3((unsigned)((a.hw + rows * GP - 1) / (rows * GP)), a.n), dim3(256), 0, s, a, (const float2*)mr);
         } else {
             hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a, (const float2*)mr);
@@ -950,6 +953,7 @@ hipError_t launch_layernorm_c(const LayerNormArgs& a, hipStream_t s) {
     const int chunks = a.c >> 3;
     if ((a.c & 7) == 0 && chunks >= 1 && chunks <= 64 && (chunks & (chunks - 1)) == 0) {
         const long long threads = a.pixels * chunks;
+        KernelProf kp("layernorm_c_vec_kernel", s, (double)a.pixels * a.c * 2.0 * 2.0);
         hipLaunchKernelGGL(layernorm_c_vec_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, a, chunks);
         return hipGetLastError();
     }
@@ -1638,7 +1642,7 @@ __global__ __launch_bounds__(256, 2) void linattn_fused_out_kernel(const el16_t*
 }
 
 bool linattn_fused_supported(int c) {
-    static const bool on = !(getenv("DYF_LINATTN_FUSED") && atoi(getenv("DYF_LINATTN_FUSED")) == 0);
+    const bool on = !(dyf_form("DYF_LINATTN_FUSED") && atoi(dyf_form("DYF_LINATTN_FUSED")) == 0);
     return on && (c == 64 || c == 128);
 }
 
@@ -1676,7 +1680,7 @@ hipError_t launch_linear_attention_fused(const LinAttnFusedArgs& a, hipStream_t 
     // kernel takes any number of partials).  DYF_LINATTN_GPB = 32 / 16 / 8 forces a size (read per launch).
     const int ngroups = (a.hw + 31) / 32, BH = a.n * LA_HEADS;
     int gpb = a.groups_per_block;
-    if (const char* ge = getenv("DYF_LINATTN_GPB")) gpb = atoi(ge);
+    if (const char* ge = dyf_form("DYF_LINATTN_GPB")) gpb = atoi(ge);
     if (gpb != 32 && gpb != 16 && gpb != 8) {
         gpb = 32;
         // (measured, OISST rollouts with blocks of 32 only / this rule at 512: 38 rows 1 791 / 1 824 fields/s, 75 rows 2 651 / 2 758, 150 rows
@@ -2614,19 +2618,19 @@ hipError_t launch_attention(const AttnArgs& a, hipStream_t s) {
     // DYF_FLASH_ATTN: unset / 4 (/ 3: that kernel was retired in round 5) = flash_attention4_kernel (the pipelined form; falls back to
     // flash_attention2_kernel for the dropout layouts it does not take), 2 = flash_attention2_kernel, 1 = the first flash form,
     // 0 = the plain per-query kernel
-    static const int flash = getenv("DYF_FLASH_ATTN") ? atoi(getenv("DYF_FLASH_ATTN")) : 4;
+    const int flash = dyf_form("DYF_FLASH_ATTN") ? atoi(dyf_form("DYF_FLASH_ATTN")) : 4;
     if (flash != 0 && a.hw <= 65535) {
         const int qblocks = (a.hw + 127) / 128;
         // 64 queries per wave from 512 tokens on (DYF_FLASH_QB=1 keeps 32): shorter sequences would leave CUs without a workgroup
-        static const int qb_env = getenv("DYF_FLASH_QB") ? atoi(getenv("DYF_FLASH_QB")) : 2;
+        const int qb_env = dyf_form("DYF_FLASH_QB") ? atoi(dyf_form("DYF_FLASH_QB")) : 2;
         // with dropout on the probabilities: DYF_FLASH_QB_DROP=2 selects the 64-query form (the second form spilled there)
-        static const int qb_drop = getenv("DYF_FLASH_QB_DROP") ? atoi(getenv("DYF_FLASH_QB_DROP")) : 1;
+        const int qb_drop = dyf_form("DYF_FLASH_QB_DROP") ? atoi(dyf_form("DYF_FLASH_QB_DROP")) : 1;
         const bool drop = a.drop.mode != 0;
         const bool qb2 = flash != 1 && a.hw >= 512 && (drop ? qb_drop == 2 && flash >= 3 : qb_env == 2);
         const int qblocks2 = (a.hw + 255) / 256;
         // the fourth form: one 32-query block per wave, DYF_FLASH_NW = 8 (default) / 4 waves per workgroup; a sequence shorter than
         // 512 tokens stays on four waves (more workgroups)
-        static const int nw_env = getenv("DYF_FLASH_NW") ? atoi(getenv("DYF_FLASH_NW")) : 8;
+        const int nw_env = dyf_form("DYF_FLASH_NW") ? atoi(dyf_form("DYF_FLASH_NW")) : 8;
         const int nw = nw_env == 16 && a.hw >= 2048 ? 16 : nw_env >= 8 && a.hw >= 512 ? 8 : 4;
         const bool v4 = flash >= 3 && (!drop || (a.drop.mode == 1 && (a.hw & 3) == 0 && a.hw % (32 * nw) == 0));
         if (v4) {
@@ -2784,6 +2788,7 @@ hipError_t launch_up2x_nearest(const el16_t* src, int n, int h, int w, int c, el
     const long long total = (long long)n * 4 * h * w * c;
     if (c % 8 == 0 && total / 32 < 0xFFFFFFFFll) {
         const unsigned tv = (unsigned)((long long)n * h * w * (c / 8));
+        KernelProf kp("up2x_nearest_vec_kernel", s, (double)n * h * w * c * 2.0 * 5.0);  // read once, write 4x
         hipLaunchKernelGGL(up2x_nearest_vec_kernel, dim3((tv + 255) / 256), dim3(256), 0, s, (const uint4*)src, h, w, c / 8,
                            (uint4*)out, tv);
         return hipGetLastError();

@@ -539,7 +539,7 @@ dyf_status rn_forward(dyf_engine* e, int which, const Source* srcs, int nsrc, in
                         el16_t** out) -> dyf_status {
         el16_t* t1 = pool.get();
         // GroupNorm statistics from the conv's fp32 accumulators where the kernel form produces them (conv_up_halo_kernel<5>)
-        static const bool fuse_stats = !(getenv("DYF_GN_CONV_STATS") && atoi(getenv("DYF_GN_CONV_STATS")) == 0);
+        const bool fuse_stats = !(dyf_form("DYF_GN_CONV_STATS") && atoi(dyf_form("DYF_GN_CONV_STATS")) == 0);
         const bool ask = fuse_stats && gn_part_supported(b.cout, c.groups) &&
                          (size_t)nb * conv_halo5_gn_slots(hh, ww) * (b.cout / 8) * 2 <= r->gn_part_floats;
         int slots1 = 0, slots2 = 0;

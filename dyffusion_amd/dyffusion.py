@@ -293,7 +293,12 @@ class DYffusion(nn.Module):
                      forward_conditioning=hp.forward_conditioning, refine=refine, n_out_slots=n_slots,
                      interpolator_dropout=bool(self.enable_interpolator_dropout or self.training),
                      forecaster_dropout=bool(self.enable_forecaster_dropout))
-        assert (nf, ni) == tuple(eng.forward_counts()), ((nf, ni), eng.forward_counts())
+        if (nf, ni) != tuple(eng.forward_counts()):
+            # the count above (it gates the bf16 refusal BEFORE dyf_set_plan) and the engine's own disagree: a bug in one of the two.
+            # The engine now holds a plan this object did not vet: forget it so the next call re-plans instead of re-failing.
+            self._plan_key = None
+            eng.plan_valid = False
+            raise RuntimeError(f"plan forward counts: host mirror {(nf, ni)} vs dyf_plan_forward_counts {tuple(eng.forward_counts())}")
         self._plan_key = key
         self._plan_steps = steps
         self._emitted_slots = sorted({st["out_slot"] for st in steps if st["out_slot"] is not None})

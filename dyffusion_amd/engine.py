@@ -80,6 +80,12 @@ def parse_train_precision(precision) -> int:
     if key in ("32", "32-true", "fp32", "float32"):
         return 32
     if key in ("16", "16-mixed", "bf16", "bf16-mixed", "fp16", "fp16-mixed"):
+        # every 16-bit request runs as bf16-mixed (csrc/train_internal.h): the engine has no GradScaler, and fp16 gradient operands
+        # without one lose the gradient at real batch sizes (dL/dout ~ 1 / numel).  An explicit fp16 request is told so once.
+        if key in ("fp16", "fp16-mixed"):
+            import warnings
+            warnings.warn("train precision 'fp16-mixed' runs as bf16-mixed: the engine rounds its training conv operands to bf16 "
+                          "(no loss scaling needed); fp16 operands are not offered", stacklevel=2)
         return 16
     raise ValueError(f"train precision {precision!r}: expected 32 / '32-true' or 16 / '16-mixed' / 'bf16-mixed'")
 
@@ -112,6 +118,7 @@ class HipEngine:
         self._tape_net = {}       # tape slot -> network of the recorded training forward
         self._tape_nb = {}        # tape slot -> batch rows of the recorded forward (train_backward validates dout against it)
         self.comm_rank, self.comm_world = 0, 1
+        self.synchronize_errors = True  # poll_errors() after every call waits for the call's stream (ResNet-UNet engines only)
         self.train_step_id = 0    # bumped by every p_losses / get_loss training forward: a loss of an older step cannot run backward
         self.plan_valid = False   # cleared by load_weights: the plan's FiLM tables are functions of the weights
         self.weights_version = 0
@@ -121,10 +128,15 @@ class HipEngine:
         if st != L.DYF_OK:
             _raise(st, self._lib.dyf_last_error(self._h).decode())
 
-    def poll_errors(self, synchronize: bool = True):
+    def poll_errors(self, synchronize: Optional[bool] = None):
         """dyf_poll_errors: asynchronous failures of the work just submitted (a fused GroupNorm convolution whose wait for its
         sample's statistics timed out; csrc/gn_fused.h) fail THIS call instead of the next one.  Engines without a live fused form
-        (unet_simple, SimpleConvNet, after a downgrade) return at once; ResNet-UNet engines wait for the device first."""
+        (unet_simple, SimpleConvNet, after a downgrade) return at once; ResNet-UNet engines first wait for the STREAM the call was
+        enqueued on (never for the device: other streams keep running; a stream under capture is not waited for).  A caller that
+        wants net_forward / sample / sample_gather to stay asynchronous sets `engine.synchronize_errors = False`: a failure is then
+        reported by the next entry point instead."""
+        if synchronize is None:
+            synchronize = self.synchronize_errors
         self._check(self._lib.dyf_poll_errors(self._h, int(synchronize)))
 
     def gn_fuse_state(self):
@@ -438,6 +450,13 @@ class HipEngine:
                                                          C.byref(by)))
         return ms.value, cnt.value, fl.value, by.value
 
+    def time_named_kernel_in_rollout(self, kernel: str, nb: int):
+        """(total ms, launches, total algorithmic bytes) of every launch of `kernel` in one eager rollout (dyffusion_hip_testing.h)."""
+        ms, by, n = C.c_double(0.0), C.c_double(0.0), C.c_int32(0)
+        self._check(self._lib.dyf_time_named_kernel_in_rollout(self._h, kernel.encode(), nb, self._stream(), C.byref(ms), C.byref(n),
+                                                               C.byref(by)))
+        return ms.value, n.value, by.value
+
     def op_conv2d(self, x_nhwc_bf16: torch.Tensor, weight: torch.Tensor, stride: int, pad: int,
                   scale: Optional[torch.Tensor] = None, shift: Optional[torch.Tensor] = None, act: int = 0,
                   path: int = 1) -> torch.Tensor:
@@ -518,8 +537,9 @@ class HipEngine:
 
     def train_set_precision(self, precision) -> None:
         """Operand precision of the training convolutions (dyf_train_set_precision; the reference's Lightning `trainer.precision`):
-        32 / "32" / "32-true" = fp32 operands (default), 16 / "16-mixed" / "bf16-mixed" = operands rounded to this engine's 16-bit
-        format while staged (fp32 tensors, master weights and accumulation), None = leave it to DYF_TRAIN_OPERANDS."""
+        32 / "32" / "32-true" = fp32 operands (default), 16 / "16-mixed" / "bf16-mixed" = operands rounded to bf16 while staged (fp32
+        tensors, master weights and accumulation) -- bf16 on fp16 engines too: the reference's precision=16 is fp16 + GradScaler, and
+        fp16 gradient operands without a loss scale underflow at real batch sizes (`parse_train_precision`); None = not set (fp32)."""
         self._check(self._lib.dyf_train_set_precision(self._h, parse_train_precision(precision)))
 
     @property

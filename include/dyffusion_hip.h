@@ -161,9 +161,10 @@ dyf_status dyf_sample(dyf_engine* engine, const float* initial_dev, const float*
  * after that is a fused GroupNorm convolution of the ResNet-UNet (csrc/gn_fused.h: workgroups of one sample meet inside the launch)
  * whose wait for its sample's statistics times out -- its output is then NaN-poisoned and a host-visible word is raised.
  * dyf_poll_errors reports that: DYF_OK, or DYF_ERR_STATE naming it (the engine has then already dropped its captured graphs and
- * runs the un-fused GroupNorm kernels from now on: repeat the call).  synchronize != 0 waits for the device to finish first, so a
+ * runs the un-fused GroupNorm kernels from now on: repeat the call).  synchronize != 0 first waits for the STREAM of the engine's last
+ * dyf_sample / dyf_sample_gather / dyf_net_forward call (not for the device: other streams keep running; a stream under capture is not waited for), so a
  * caller that polls right after dyf_sample / dyf_sample_gather / dyf_net_forward gets the failure from the SAME call (the Python
- * wrappers do).  Engines without a live fused form (unet_simple, SimpleConvNet, DYF_GN_FUSED=0, after a downgrade) return
+ * wrappers do).  Engines without a live fused form (unet_simple, SimpleConvNet, after a downgrade) return
  * DYF_OK at once without waiting.  Un-polled failures are still reported at the head of the next entry point.
  * dyf_gn_fuse_state: *live = the fused form is in use, *downgrades = how often the engine left it (time-out, or sweeps slower than
  * 1 ms on a GPU shared with another process -- the latter is not an error; DYF_VERBOSE=1 logs either to stderr). */
@@ -252,10 +253,13 @@ dyf_status dyf_train_backward(dyf_engine* engine, int32_t slot, const float* dou
 dyf_status dyf_train_zero_grads(dyf_engine* engine, int32_t net);
 /* Operand precision of the training convolutions (ABI 8) -- the reference's `trainer.precision` (Lightning; src/configs/trainer/default.yaml:14
  * "precision: 32   # 32 or 16"): 32 = fp32 operands on the fp32 matrix cores (the default; gradients at the 1e-6 level of autograd over the oracle),
- * 16 = "16-mixed": activations, gradients, master weights and accumulation stay fp32, the conv operands are rounded to the engine's
- * 16-bit format (dyf_engine_config.dtype) while they are staged (csrc/train_halo16.hip, csrc/train_gemm.hip), 0 = not set: the
- * DYF_TRAIN_OPERANDS environment variable decides per call (unset: 32).  Applies to the dyf_train_forward / dyf_train_backward
- * calls that follow; a recorded forward and its backward should run under the same setting. */
+ * 16 = "bf16-mixed": activations, gradients, master weights and accumulation stay fp32, the conv operands are rounded to bf16 -- in
+ * BOTH builds of the library, whatever dyf_engine_config.dtype is -- while they are staged (csrc/train_halo16.hip,
+ * csrc/train_gemm.hip).  Lightning's precision=16 is fp16 + a GradScaler; this engine answers the same request with bf16 operands,
+ * which need no loss scale (with mean-reduced losses dL/dout is ~1e-6..1e-7 at real batch sizes, below fp16's normal range).
+ * 0 = not set (fp32 operands; the tests' kernel-form switch DYF_TRAIN_OPERANDS of dyffusion_hip_testing.h can select 16-bit operands
+ * for such engines).  Applies to the dyf_train_forward / dyf_train_backward calls that follow; a recorded forward and its backward
+ * should run under the same setting. */
 dyf_status dyf_train_set_precision(dyf_engine* engine, int32_t bits);
 int32_t dyf_train_precision(const dyf_engine* engine);
 /* Copy gradients out by the reference's state_dict names (PyTorch layouts), HOST fp32 buffers; "*.running_mean/var" return the

@@ -31,6 +31,15 @@ dyf_status dyf_time_layer_in_rollout(dyf_engine* engine, int32_t layer, int32_t 
 dyf_status dyf_time_kernel_in_rollout(dyf_engine* engine, int32_t kind, int32_t nb, void* stream, double* avg_ms,
                                       int32_t* launches, double* flops, double* algorithmic_bytes);
 
+/* The HBM-bound kernels (bench.py `hbm_kernels`; north_star: "HBM GB/s for the norm/activation kernels"): over ONE eagerly launched
+ * rollout of the current plan at nb rows, HIP events on `stream` around every launch of the kernel called `kernel` --
+ * "layernorm_c_vec_kernel", "up2x_quad_kernel", "up2x_epilogue_kernel", "stem16_rows_kernel", "readout_dma_kernel",
+ * "up2x_nearest_vec_kernel", "gn_apply_walk_kernel", "gn_apply_part_kernel" (the launchers that open a KernelProf scope, csrc/common.h).
+ * total_ms = sum of the launch durations, total_bytes = sum of their ALGORITHMIC bytes (every operand once, 16-bit activations),
+ * launches = how many (0: the rollout does not launch that kernel).  GB/s = total_bytes / total_ms / 1e6. */
+dyf_status dyf_time_named_kernel_in_rollout(dyf_engine* engine, const char* kernel, int32_t nb, void* stream, double* total_ms,
+                                            int32_t* launches, double* total_bytes);
+
 /* ---- op-level seam (tests only): one Conv2d + fused epilogue on NHWC bf16 tensors ---------------------------- */
 /* x_dev (N,H,W,Cin) bf16 bits; w (Cout,Cin,kh,kw) host fp32; scale/shift (N,Cout) device fp32 or NULL;
  * y_dev (N,Ho,Wo,Cout) bf16 bits.  act: 0 none, 1 relu, 2 leaky(0.2).  path: 0 direct, 1 MFMA implicit GEMM. */
@@ -98,6 +107,17 @@ dyf_status dyf_debug_gn_fuse(dyf_engine* engine, uint32_t timeout_ticks, int32_t
  * NUL-terminated and truncated to cap bytes, and returns the untruncated length. */
 void dyf_debug_form_log(int32_t enable);
 int32_t dyf_debug_form_log_read(char* buf, int32_t cap);
+
+/* Kernel-form switches (tests/ and tools/ only).  The launchers choose between equivalent kernel forms from tile counts; the
+ * parity tests force each form on small problems, the A/B tools flip one form at a time, a few keys are wrong-results timing
+ * probes.  This call is the ONLY way to set them: libdyffusion_hip.so reads none of them from the environment (the only
+ * environment variables it reads are DYF_VERBOSE -- print the engine's form policy at creation -- and DYF_RCCL_LIB -- the librccl
+ * to dlopen).  Process-wide (per library: the bf16 and the fp16 build each hold their own table); read per launch / per engine
+ * creation / per weight upload as DESIGN.md 7.1 lists.  key = the historic switch name ("DYF_IGEMM2_MIN_TILES", ...), value = its
+ * text; value NULL removes the key, key NULL removes every key.  dyf_debug_forms writes "key=value;..." like
+ * dyf_debug_form_log_read. */
+void dyf_debug_set_form(const char* key, const char* value);
+int32_t dyf_debug_forms(char* buf, int32_t cap);
 
 #ifdef __cplusplus
 }

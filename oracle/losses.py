@@ -110,3 +110,69 @@ def interpolation_loss(interpolator: NetFn, dynamics: Tensor, t: Tensor, conditi
     targets = dynamics[torch.arange(b), window + t.long() - 1]
     pred = interpolator(inputs, t, condition)
     return criterion_fn(loss_function)(pred, targets)
+
+
+# ------------------------------------------------------------------------------------------------ mixed-precision training model
+# The engine's `train_precision=16` ("bf16-mixed"; csrc/train_gemm.hip, csrc/train_halo16.hip, csrc/train_internal.h): every tensor,
+# the master weights, the accumulators and the statistics stay fp32; a training convolution that runs on the 16-bit matrix cores
+# rounds its two OPERANDS to bf16 (round-to-nearest-even) while it stages them -- the forward (x, w), the data gradient (dz, w) and
+# the weight gradient (dz, x) each on their own.  Which of the three run on the 16-bit cores is a function of the layer's channel
+# counts (the dispatch of csrc/train_gemm.hip tgemm_conv_fwd / _dgrad / _wgrad): the 1x1 stem (cin = 5 / 8), the readout's
+# transposed conv (3 channels) and every Linear / attention contraction stay fp32.
+# This is a MODEL of that arithmetic under torch.autograd (same roundings at the same places, fp32 accumulation by ATen instead of
+# the MFMA's order): the reference has no such mode (Lightning's precision=16 is autocast fp16 + GradScaler), so there is no
+# golden vector for it -- tests/test_gpu_training.py holds the engine's 16-bit step to this model, and this model's fp32 limit
+# (rounding off) IS the reference-pinned oracle above.
+def bf16_round(x: Tensor) -> Tensor:
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+def conv_operand_rules(cin: int, cout: int):
+    """(forward, data gradient, weight gradient) run with bf16 operands?  csrc/train_gemm.hip: GN = 64, GK = 16, GK16 = 32."""
+    fwd = cin % 16 == 0 and cout % 64 == 0 and cin % 32 == 0
+    dgrad = cout % 16 == 0 and cin % 64 == 0 and cout % 32 == 0
+    wgrad = cin % 64 == 0 and cout % 4 == 0
+    return fwd, dgrad, wgrad
+
+
+class _Conv2dRoundedOperands(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, bias, stride, padding):
+        cout, cin = w.shape[0], w.shape[1]
+        f16, d16, w16 = conv_operand_rules(cin, cout)
+        ctx.save_for_backward(x, w)
+        ctx.cfg = (stride, padding, d16, w16, bias is not None)
+        xr, wr = (bf16_round(x), bf16_round(w)) if f16 else (x, w)
+        return torch.nn.functional.conv2d(xr, wr, bias, stride=stride, padding=padding)
+
+    @staticmethod
+    def backward(ctx, dz):
+        x, w = ctx.saved_tensors
+        stride, padding, d16, w16, has_bias = ctx.cfg
+        dz = dz.contiguous()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            a, b = (bf16_round(dz), bf16_round(w)) if d16 else (dz, w)
+            dx = torch.nn.grad.conv2d_input(x.shape, b, a, stride=stride, padding=padding)
+        if ctx.needs_input_grad[1]:
+            a, b = (bf16_round(dz), bf16_round(x)) if w16 else (dz, x)
+            dw = torch.nn.grad.conv2d_weight(b, w.shape, a, stride=stride, padding=padding)
+        if has_bias and ctx.needs_input_grad[2]:
+            db = dz.sum(dim=(0, 2, 3))  # the bias gradient is a plain fp32 reduction of dz in the engine too
+        return dx, dw, db, None, None
+
+
+class training_operand_rounding:
+    """`with training_operand_rounding(): ...` -- every nn.Conv2d of the restated backbones (oracle.nets.conv2d) runs as the
+    engine's bf16-mixed training convolution for the duration of the block."""
+
+    def __enter__(self):
+        from . import nets
+        self._nets = nets
+        self._prev = nets._CONV2D[0]
+        nets._CONV2D[0] = lambda x, w, bias=None, stride=1, padding=0: _Conv2dRoundedOperands.apply(x, w, bias, stride, padding)
+        return self
+
+    def __exit__(self, *exc):
+        self._nets._CONV2D[0] = self._prev
+        return False

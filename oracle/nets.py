@@ -23,6 +23,15 @@ from torch import Tensor
 
 LEAKY_SLOPE = 0.2  # unet_simple.py:10
 
+# Every nn.Conv2d of the restated backbones goes through `conv2d` below: F.conv2d, unless a test has swapped in a model of the
+# engine's arithmetic for the duration of a `with` block (oracle/losses.py `training_operand_rounding`: the bf16 operand rounding
+# of the engine's mixed-precision training convolutions under torch.autograd).
+_CONV2D = [F.conv2d]
+
+
+def conv2d(x: Tensor, w: Tensor, bias: Optional[Tensor] = None, stride=1, padding=0) -> Tensor:
+    return _CONV2D[0](x, w, bias, stride=stride, padding=padding)
+
 
 # ----------------------------------------------------------------------------- dropout sources
 class DropoutOff:
@@ -185,7 +194,7 @@ def unet_simple_forward(P: Dict[str, Tensor], cfg: dict, inputs: Tensor, time: O
     native_hw = x.shape[-2:]
     if cfg.get("upsample_dims") is not None:
         x = F.interpolate(x, size=tuple(cfg["upsample_dims"]), mode=mode)
-    x = F.conv2d(x, P["init_conv.weight"], P["init_conv.bias"])
+    x = conv2d(x, P["init_conv.weight"], P["init_conv.bias"])
     x = dropout.apply(x, cfg.get("input_dropout", 0.0))
     if taps is not None:
         taps["init"] = x
@@ -194,7 +203,7 @@ def unet_simple_forward(P: Dict[str, Tensor], cfg: dict, inputs: Tensor, time: O
     skips = []
     for li, (_, _, k, s, pad, norm, act) in enumerate(enc):
         pre = f"input_ops.{li}"
-        x = F.conv2d(x, P[f"{pre}.ops.0.weight"], P[f"{pre}.ops.0.bias"], stride=s, padding=pad)
+        x = conv2d(x, P[f"{pre}.ops.0.weight"], P[f"{pre}.ops.0.bias"], stride=s, padding=pad)
         x = _norm(P, f"{pre}.ops.1", x, norm, bn_training)
         if temb is not None:
             scale, shift = film(P, f"{pre}.time_mlp", temb)
@@ -208,7 +217,7 @@ def unet_simple_forward(P: Dict[str, Tensor], cfg: dict, inputs: Tensor, time: O
     for li, (_, _, k, s, pad, norm, act) in enumerate(dec):
         pre = f"output_ops.{li}"
         x = F.interpolate(x, scale_factor=2, mode="bilinear")
-        x = F.conv2d(x, P[f"{pre}.ops.1.weight"], P[f"{pre}.ops.1.bias"], stride=1, padding=pad)
+        x = conv2d(x, P[f"{pre}.ops.1.weight"], P[f"{pre}.ops.1.bias"], stride=1, padding=pad)
         x = _norm(P, f"{pre}.ops.2", x, norm, bn_training)
         if temb is not None:
             scale, shift = film(P, f"{pre}.time_mlp", temb)
@@ -293,7 +302,7 @@ def simple_conv_net_forward(P: Dict[str, Tensor], cfg: dict, inputs: Tensor, tim
         pre = f"convs.{li}"
         res = x
         w = P[f"{pre}.conv.weight"]
-        x = F.conv2d(x, w, P[f"{pre}.conv.bias"], padding=(k - 1) // 2)
+        x = conv2d(x, w, P[f"{pre}.conv.bias"], padding=(k - 1) // 2)
         x = F.batch_norm(x, P[f"{pre}.norm.running_mean"], P[f"{pre}.norm.running_var"], P[f"{pre}.norm.weight"],
                          P[f"{pre}.norm.bias"], training=False, eps=1e-5)
         if temb is not None:
@@ -303,7 +312,7 @@ def simple_conv_net_forward(P: Dict[str, Tensor], cfg: dict, inputs: Tensor, tim
         x = dropout.apply(x, cfg.get("dropout", 0.0))
         if cfg.get("residual", True) and w.shape[0] == w.shape[1]:
             x = x + res
-    return F.conv2d(x, P["head.weight"], P["head.bias"])
+    return conv2d(x, P["head.weight"], P["head.bias"])
 
 
 # ----------------------------------------------------------------------------- unet.Unet (OISST / synthetic backbone)
@@ -312,7 +321,7 @@ def _ws_conv3x3(P, prefix, x):
     w = P[f"{prefix}.weight"]
     mean = w.mean(dim=(1, 2, 3), keepdim=True)
     var = w.var(dim=(1, 2, 3), unbiased=False, keepdim=True)
-    return F.conv2d(x, (w - mean) * (var + 1e-5).rsqrt(), P[f"{prefix}.bias"], padding=1)
+    return conv2d(x, (w - mean) * (var + 1e-5).rsqrt(), P[f"{prefix}.bias"], padding=1)
 
 
 def _resnet_block(P, pre, x, temb, groups, p1, p2, dropout):
@@ -329,7 +338,7 @@ def _resnet_block(P, pre, x, temb, groups, p1, p2, dropout):
         h = F.group_norm(h, groups, P[f"{pre}.block2.norm.weight"], P[f"{pre}.block2.norm.bias"], eps=1e-5)
         h = dropout.apply(F.silu(h), p2)
     if f"{pre}.residual_conv.weight" in P:
-        x = F.conv2d(x, P[f"{pre}.residual_conv.weight"], P[f"{pre}.residual_conv.bias"])
+        x = conv2d(x, P[f"{pre}.residual_conv.weight"], P[f"{pre}.residual_conv.bias"])
     return h + x
 
 
@@ -346,14 +355,14 @@ def _linear_attention(P, pre, x, heads, dim_head, p_attn, dropout):
     n = hh * ww
     y = _channel_layernorm(x, P[f"{pre}.fn.norm.g"])
     y = dropout.apply(y, p_attn)
-    qkv = F.conv2d(y, P[f"{pre}.fn.fn.to_qkv.1.weight"]).reshape(b, 3, heads, dim_head, n)
+    qkv = conv2d(y, P[f"{pre}.fn.fn.to_qkv.1.weight"]).reshape(b, 3, heads, dim_head, n)
     q, k, v = qkv[:, 0], qkv[:, 1], qkv[:, 2]
     q = q.softmax(dim=-2) * dim_head ** -0.5
     k = k.softmax(dim=-1)
     v = v / n
     context = torch.einsum("bhdn,bhen->bhde", k, v)
     out = torch.einsum("bhde,bhdn->bhen", context, q).reshape(b, heads * dim_head, hh, ww)
-    return F.conv2d(out, P[f"{pre}.fn.fn.to_out.weight"], P[f"{pre}.fn.fn.to_out.bias"]) + x
+    return conv2d(out, P[f"{pre}.fn.fn.to_out.weight"], P[f"{pre}.fn.fn.to_out.bias"]) + x
 
 
 def _full_attention(P, pre, x, heads, dim_head, p_attn, dropout):
@@ -362,13 +371,13 @@ def _full_attention(P, pre, x, heads, dim_head, p_attn, dropout):
     b, c, hh, ww = x.shape
     n = hh * ww
     y = _channel_layernorm(x, P[f"{pre}.fn.norm.g"])
-    qkv = F.conv2d(y, P[f"{pre}.fn.fn.to_qkv.weight"]).reshape(b, 3, heads, dim_head, n)
+    qkv = conv2d(y, P[f"{pre}.fn.fn.to_qkv.weight"]).reshape(b, 3, heads, dim_head, n)
     q, k, v = qkv[:, 0] * dim_head ** -0.5, qkv[:, 1], qkv[:, 2]
     attn = torch.einsum("bhdi,bhdj->bhij", q, k).softmax(dim=-1)
     attn = dropout.apply(attn, p_attn)
     out = torch.einsum("bhij,bhdj->bhid", attn, v)                        # (b, h, n, d)
     out = out.permute(0, 1, 3, 2).reshape(b, heads * dim_head, hh, ww)    # "b h (x y) d -> b (h d) x y"
-    return F.conv2d(out, P[f"{pre}.fn.fn.to_out.weight"], P[f"{pre}.fn.fn.to_out.bias"]) + x
+    return conv2d(out, P[f"{pre}.fn.fn.to_out.weight"], P[f"{pre}.fn.fn.to_out.bias"]) + x
 
 
 def resnet_unet_forward(P: Dict[str, Tensor], cfg: dict, x: Tensor, time: Optional[Tensor] = None,
@@ -387,7 +396,7 @@ def resnet_unet_forward(P: Dict[str, Tensor], cfg: dict, x: Tensor, time: Option
         x = torch.cat([condition, x], dim=1)
     # (no outer resampler: the reference's Unet cannot be constructed with upsample_dims -- unet.py:155 reads an attribute that is never set)
     assert cfg.get("upsample_dims") is None
-    x = F.conv2d(x, P["init_conv.weight"], P["init_conv.bias"], padding=cfg.get("init_padding", 3))
+    x = conv2d(x, P["init_conv.weight"], P["init_conv.bias"], padding=cfg.get("init_padding", 3))
     # unet.py:276-277: two independent Dropouts on init_conv's output, the copy kept for the final residual first
     p_in = cfg.get("input_dropout", 0.0)
     r = dropout.apply(x, p_in) if p_in > 0 else x
@@ -403,9 +412,9 @@ def resnet_unet_forward(P: Dict[str, Tensor], cfg: dict, x: Tensor, time: Option
         x = _linear_attention(P, f"{pre}.2", x, heads, dh, pa, dropout)
         skips.append(x)
         if li < nlev - 1 and not keep:
-            x = F.conv2d(x, P[f"{pre}.3.weight"], P[f"{pre}.3.bias"], stride=2, padding=1)   # Downsample: k4 s2 p1
+            x = conv2d(x, P[f"{pre}.3.weight"], P[f"{pre}.3.bias"], stride=2, padding=1)   # Downsample: k4 s2 p1
         else:
-            x = F.conv2d(x, P[f"{pre}.3.weight"], P[f"{pre}.3.bias"], padding=1)
+            x = conv2d(x, P[f"{pre}.3.weight"], P[f"{pre}.3.bias"], padding=1)
     x = _resnet_block(P, "mid_block1", x, temb, groups, p1, p2, dropout)
     x = _full_attention(P, "mid_attn", x, heads, dh, pa, dropout)
     x = _resnet_block(P, "mid_block2", x, temb, groups, p1, p2, dropout)
@@ -416,8 +425,8 @@ def resnet_unet_forward(P: Dict[str, Tensor], cfg: dict, x: Tensor, time: Option
         x = _linear_attention(P, f"{pre}.2", x, heads, dh, pa, dropout)
         if li < nlev - 1 and not keep:
             x = F.interpolate(x, scale_factor=2, mode="nearest")
-            x = F.conv2d(x, P[f"{pre}.3.1.weight"], P[f"{pre}.3.1.bias"], padding=1)
+            x = conv2d(x, P[f"{pre}.3.1.weight"], P[f"{pre}.3.1.bias"], padding=1)
         else:
-            x = F.conv2d(x, P[f"{pre}.3.weight"], P[f"{pre}.3.bias"], padding=1)
+            x = conv2d(x, P[f"{pre}.3.weight"], P[f"{pre}.3.bias"], padding=1)
     x = _resnet_block(P, "final_res_block", torch.cat([x, r], dim=1), temb, groups, p1, p2, dropout)
-    return F.conv2d(x, P["final_conv.weight"], P["final_conv.bias"])
+    return conv2d(x, P["final_conv.weight"], P["final_conv.bias"])

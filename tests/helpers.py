@@ -57,3 +57,13 @@ def boundary_case(name):
     expected = preds.clone().reshape(-1)
     expected[torch.from_numpy(z["changed_idx"])] = torch.from_numpy(z["changed_val"])
     return system, preds, torch.zeros(B, C, Hh, Ww), meta, time, expected.reshape(shape)
+
+
+def apply_test_forms():
+    """Child scripts of the parity tests: the kernel-form switches of the case arrive in DYF_TEST_FORMS ("KEY=VALUE;..."), are read
+    HERE -- by test code -- and handed to the library through dyf_debug_set_form; the library itself reads nothing of the kind from
+    the environment (include/dyffusion_hip_testing.h)."""
+    from dyffusion_amd import _lib
+    for item in filter(None, os.environ.get("DYF_TEST_FORMS", "").split(";")):
+        key, _, value = item.partition("=")
+        _lib.set_form(key, value)

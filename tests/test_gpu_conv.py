@@ -92,7 +92,7 @@ IGEMM2_CASES = [
 
 
 @pytest.mark.parametrize("case", IGEMM2_CASES, ids=lambda c: "x".join(map(str, c)))
-def test_second_igemm_form_matches_torch(engine, case, monkeypatch):
+def test_second_igemm_form_matches_torch(engine, case, form_switch):
     """conv_igemm2_kernel (256 x 128 tiles, weights streamed in fragment order) is selected by tile count in production;
     DYF_IGEMM2_MIN_TILES=1 forces it on these small problems.  Checked against torch and against the 128 x 128 form."""
     n, h, w, cin, cout, k, stride, pad = case
@@ -101,9 +101,9 @@ def test_second_igemm_form_matches_torch(engine, case, monkeypatch):
     wt = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
     scale = 1.0 + 0.3 * torch.randn(n, cout, generator=g)
     shift = 0.2 * torch.randn(n, cout, generator=g)
-    monkeypatch.setenv("DYF_IGEMM2_MIN_TILES", "1000000000")
+    form_switch.setenv("DYF_IGEMM2_MIN_TILES", "1000000000")
     first = engine.op_conv2d(x.cuda(), wt, stride, pad, scale.cuda(), shift.cuda(), act=2, path=1).float().cpu()
-    monkeypatch.setenv("DYF_IGEMM2_MIN_TILES", "1")
+    form_switch.setenv("DYF_IGEMM2_MIN_TILES", "1")
     for act, use_coef in [(0, False), (2, True), (1, True)]:
         y = engine.op_conv2d(x.cuda(), wt, stride, pad, scale.cuda() if use_coef else None,
                              shift.cuda() if use_coef else None, act=act, path=1)
@@ -116,9 +116,9 @@ def test_second_igemm_form_matches_torch(engine, case, monkeypatch):
             assert rel_rms(got, first) <= 2.5e-3  # the two MFMA forms differ by summation order only
             if k == 3 and stride == 1 and pad == 1 and not (w % 16 == 0 and h % 16 == 0):
                 # the SH3 form ran: it must reproduce the one-gather-per-tap form BIT FOR BIT (same operands, same summation order)
-                monkeypatch.setenv("DYF_IGEMM2_SH3", "0")
+                form_switch.setenv("DYF_IGEMM2_SH3", "0")
                 per_tap = engine.op_conv2d(x.cuda(), wt, stride, pad, scale.cuda(), shift.cuda(), act=act, path=1).float().cpu()
-                monkeypatch.delenv("DYF_IGEMM2_SH3")
+                form_switch.delenv("DYF_IGEMM2_SH3")
                 assert torch.equal(got, per_tap), float((got - per_tap).abs().max())
 
 
@@ -133,7 +133,7 @@ HALO3_CASES = [(2, 16, 16, 64, 256, 3, 1, 1), (1, 32, 48, 128, 256, 3, 1, 1), (3
 
 
 @pytest.mark.parametrize("case", HALO3_CASES, ids=lambda c: "x".join(map(str, c)))
-def test_plain_convs_on_the_halo_kernel_match_torch(engine, case, monkeypatch):
+def test_plain_convs_on_the_halo_kernel_match_torch(engine, case, form_switch):
     """conv_up_halo_kernel<2> / <3>: plain 3x3 / s1 / p1 and 4x4 / s2 / p1 convs (cout % 256 == 0) with the window in LDS
     and zero-filled borders; production uses them from 512 tiles on, DYF_HALO3_MIN_TILES=1 forces them here.  Borders
     checked separately."""
@@ -143,10 +143,10 @@ def test_plain_convs_on_the_halo_kernel_match_torch(engine, case, monkeypatch):
     wt = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
     scale = 1.0 + 0.3 * torch.randn(n, cout, generator=g)
     shift = 0.2 * torch.randn(n, cout, generator=g)
-    monkeypatch.setenv("DYF_HALO3", "0")
+    form_switch.setenv("DYF_HALO3", "0")
     other = engine.op_conv2d(x.cuda(), wt, stride, pad, scale.cuda(), shift.cuda(), act=1, path=1).float().cpu()
-    monkeypatch.setenv("DYF_HALO3", "1")
-    monkeypatch.setenv("DYF_HALO3_MIN_TILES", "1")
+    form_switch.setenv("DYF_HALO3", "1")
+    form_switch.setenv("DYF_HALO3_MIN_TILES", "1")
     y = engine.op_conv2d(x.cuda(), wt, stride, pad, scale.cuda(), shift.cuda(), act=1, path=1).float().cpu()
     want = reference(x, wt, stride, pad, scale, shift, 1)
     tol = 1.5 * 2 ** -8 * float(want.abs().max()) + 1e-3
@@ -218,7 +218,7 @@ SPLIT_UPCASES = [(1, 32, 32, 512, 128, 8), (2, 64, 64, 256, 128, 4), (3, 32, 64,
 
 
 @pytest.mark.parametrize("case", SPLIT_UPCASES, ids=lambda c: "x".join(map(str, c)))
-def test_rows_splitk_upsample_conv_matches_torch_and_the_unsplit_kernel(engine, case, monkeypatch):
+def test_rows_splitk_upsample_conv_matches_torch_and_the_unsplit_kernel(engine, case, form_switch):
     """Round 5: conv_halo_rows_splitk_kernel<0> (a tile's 64-channel chunks dealt to 2 / 4 / 8 workgroups, raw fp32 partials,
     conv_splitk_finish4_kernel) and up_border_split_kernel (the border ring's K chain dealt to the 8 waves of a workgroup) -- what a
     decoder launch of a few rows takes -- against ATen and against the one-workgroup-per-tile kernels they replace."""
@@ -228,24 +228,24 @@ def test_rows_splitk_upsample_conv_matches_torch_and_the_unsplit_kernel(engine, 
     wt = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
     scale = 1.0 + 0.3 * torch.randn(n, cout, generator=g)
     shift = 0.2 * torch.randn(n, cout, generator=g)
-    monkeypatch.setenv("DYF_ROWS_TR", "4")  # (short tiles are another round-5 form: tested below)
-    monkeypatch.setenv("DYF_HALO_SPLITK", "0")
-    monkeypatch.setenv("DYF_UP_BORDER_SPLIT_ROWS", "0")
-    monkeypatch.setenv("DYF_UP_BORDER_RING4", "0")
+    form_switch.setenv("DYF_ROWS_TR", "4")  # (short tiles are another round-5 form: tested below)
+    form_switch.setenv("DYF_HALO_SPLITK", "0")
+    form_switch.setenv("DYF_UP_BORDER_SPLIT_ROWS", "0")
+    form_switch.setenv("DYF_UP_BORDER_RING4", "0")
     old, forms0 = _form_log(engine, lambda: engine.op_upconv2d(x.cuda(), wt, scale.cuda(), shift.cuda(), act=1).float().cpu())
     assert "conv_halo_rows_kernel<0>" in forms0 and not any("split" in k or "ring4" in k for k in forms0), sorted(forms0)
     # the many-rows form of the border ring (four samples per workgroup, a four-slot ring per wave, no K split): same sums, other order
-    monkeypatch.setenv("DYF_UP_BORDER_RING4", "1")  # (opt-in: measured slower than the two-slot kernel at 80 rows, kept as an experiment)
+    form_switch.setenv("DYF_UP_BORDER_RING4", "1")  # (opt-in: measured slower than the two-slot kernel at 80 rows, kept as an experiment)
     y4, forms4 = _form_log(engine, lambda: engine.op_upconv2d(x.cuda(), wt, scale.cuda(), shift.cuda(), act=1).float().cpu())
     assert "up_border_ring4_kernel" in forms4, sorted(forms4)
     assert torch.equal(y4[:, 1:-1, 1:-1], old[:, 1:-1, 1:-1])  # the interior does not see the ring
     for sl in [(slice(None), 0), (slice(None), -1), (slice(None), slice(None), 0), (slice(None), slice(None), -1)]:
         assert rel_rms(y4[sl], old[sl]) <= 2.5e-3, (sl, rel_rms(y4[sl], old[sl]))
-    monkeypatch.delenv("DYF_UP_BORDER_RING4")
-    monkeypatch.delenv("DYF_HALO_SPLITK")
-    monkeypatch.delenv("DYF_UP_BORDER_SPLIT_ROWS")
+    form_switch.delenv("DYF_UP_BORDER_RING4")
+    form_switch.delenv("DYF_HALO_SPLITK")
+    form_switch.delenv("DYF_UP_BORDER_SPLIT_ROWS")
     if factor:
-        monkeypatch.setenv("DYF_HALO_SPLITK_FORCE", str(factor))
+        form_switch.setenv("DYF_HALO_SPLITK_FORCE", str(factor))
     y, forms = _form_log(engine, lambda: engine.op_upconv2d(x.cuda(), wt, scale.cuda(), shift.cuda(), act=1).float().cpu())
     assert "conv_halo_rows_kernel<0>+splitk" in forms and "up_border_split_kernel" in forms, sorted(forms)
     up = F.interpolate(x.float().permute(0, 3, 1, 2), scale_factor=2, mode="bilinear")
@@ -262,7 +262,7 @@ def test_rows_splitk_upsample_conv_matches_torch_and_the_unsplit_kernel(engine, 
 
 
 @pytest.mark.parametrize("case", [(2, 32, 32, 1024, 256, 8), (1, 8, 64, 256, 512, 4), (3, 16, 32, 128, 256, 2)], ids=lambda c: "x".join(map(str, c)))
-def test_rows_splitk_plain_conv_matches_torch_and_the_unsplit_kernel(engine, case, monkeypatch):
+def test_rows_splitk_plain_conv_matches_torch_and_the_unsplit_kernel(engine, case, form_switch):
     """conv_halo_rows_splitk_kernel<2>: the plain 3x3 / 256-channel-block form (dec2 of unet_simple: 16 chunks, 8 tiles per row) at few
     rows, forced onto the rows kernel as the engine's tile thresholds would at >= 10 rows."""
     n, h, w, cin, cout, factor = case
@@ -271,13 +271,13 @@ def test_rows_splitk_plain_conv_matches_torch_and_the_unsplit_kernel(engine, cas
     wt = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
     scale = 1.0 + 0.3 * torch.randn(n, cout, generator=g)
     shift = 0.2 * torch.randn(n, cout, generator=g)
-    monkeypatch.setenv("DYF_HALO3_MIN_TILES", "1")
-    monkeypatch.setenv("DYF_ROWS_TR", "4")
-    monkeypatch.setenv("DYF_HALO_SPLITK", "0")
+    form_switch.setenv("DYF_HALO3_MIN_TILES", "1")
+    form_switch.setenv("DYF_ROWS_TR", "4")
+    form_switch.setenv("DYF_HALO_SPLITK", "0")
     old, forms0 = _form_log(engine, lambda: engine.op_conv2d(x.cuda(), wt, 1, 1, scale.cuda(), shift.cuda(), act=2, path=1).float().cpu())
     assert "conv_halo_rows_kernel<2>" in forms0, sorted(forms0)
-    monkeypatch.delenv("DYF_HALO_SPLITK")
-    monkeypatch.setenv("DYF_HALO_SPLITK_FORCE", str(factor))
+    form_switch.delenv("DYF_HALO_SPLITK")
+    form_switch.setenv("DYF_HALO_SPLITK_FORCE", str(factor))
     y, forms = _form_log(engine, lambda: engine.op_conv2d(x.cuda(), wt, 1, 1, scale.cuda(), shift.cuda(), act=2, path=1).float().cpu())
     assert "conv_halo_rows_kernel<2>+splitk" in forms, sorted(forms)
     want = reference(x, wt, 1, 1, scale, shift, 2)
@@ -291,7 +291,7 @@ def test_rows_splitk_plain_conv_matches_torch_and_the_unsplit_kernel(engine, cas
 
 @pytest.mark.parametrize("tr", [2, 1])
 @pytest.mark.parametrize("case", [(2, 32, 32, 256, 128), (1, 64, 64, 128, 64), (3, 40, 64, 192, 128)], ids=lambda c: "x".join(map(str, c)))
-def test_short_tile_rows_forms_reproduce_the_four_row_tiles_bitwise_upsample(engine, case, tr, monkeypatch):
+def test_short_tile_rows_forms_reproduce_the_four_row_tiles_bitwise_upsample(engine, case, tr, form_switch):
     """Round 5: conv_halo_rows_tr_kernel<0, 2 / 1> -- the fused x2-upsample conv on tiles of 2 / 1 rows per wave (2 / 4 x the
     workgroups for under-filled launches).  Same operands, same K order per output element as the four-row tiles: bit-identical."""
     n, h, w, cin, cout = case
@@ -300,11 +300,11 @@ def test_short_tile_rows_forms_reproduce_the_four_row_tiles_bitwise_upsample(eng
     wt = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
     scale = 1.0 + 0.3 * torch.randn(n, cout, generator=g)
     shift = 0.2 * torch.randn(n, cout, generator=g)
-    monkeypatch.setenv("DYF_HALO_SPLITK", "0")
-    monkeypatch.setenv("DYF_ROWS_TR", "4")
+    form_switch.setenv("DYF_HALO_SPLITK", "0")
+    form_switch.setenv("DYF_ROWS_TR", "4")
     ref, forms0 = _form_log(engine, lambda: engine.op_upconv2d(x.cuda(), wt, scale.cuda(), shift.cuda(), act=1).float().cpu())
     assert "conv_halo_rows_kernel<0>" in forms0 and not any("+tr" in k for k in forms0), sorted(forms0)
-    monkeypatch.setenv("DYF_ROWS_TR", str(tr))
+    form_switch.setenv("DYF_ROWS_TR", str(tr))
     y, forms = _form_log(engine, lambda: engine.op_upconv2d(x.cuda(), wt, scale.cuda(), shift.cuda(), act=1).float().cpu())
     assert f"conv_halo_rows_kernel<0>+tr{tr}" in forms, sorted(forms)
     assert torch.equal(y, ref), float((y - ref).abs().max())
@@ -315,7 +315,7 @@ def test_short_tile_rows_forms_reproduce_the_four_row_tiles_bitwise_upsample(eng
 
 @pytest.mark.parametrize("tr", [2, 1])
 @pytest.mark.parametrize("case", [(2, 32, 32, 256, 256), (1, 8, 64, 128, 512)], ids=lambda c: "x".join(map(str, c)))
-def test_short_tile_rows_forms_reproduce_the_four_row_tiles_bitwise_plain(engine, case, tr, monkeypatch):
+def test_short_tile_rows_forms_reproduce_the_four_row_tiles_bitwise_plain(engine, case, tr, form_switch):
     """conv_halo_rows_tr_kernel<2, 2 / 1>: the plain 3x3 / 256-channel-block form on short tiles."""
     n, h, w, cin, cout = case
     g = torch.Generator().manual_seed(sum(case) + 23)
@@ -323,12 +323,12 @@ def test_short_tile_rows_forms_reproduce_the_four_row_tiles_bitwise_plain(engine
     wt = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
     scale = 1.0 + 0.3 * torch.randn(n, cout, generator=g)
     shift = 0.2 * torch.randn(n, cout, generator=g)
-    monkeypatch.setenv("DYF_HALO3_MIN_TILES", "1")
-    monkeypatch.setenv("DYF_HALO_SPLITK", "0")
-    monkeypatch.setenv("DYF_ROWS_TR", "4")
+    form_switch.setenv("DYF_HALO3_MIN_TILES", "1")
+    form_switch.setenv("DYF_HALO_SPLITK", "0")
+    form_switch.setenv("DYF_ROWS_TR", "4")
     ref, forms0 = _form_log(engine, lambda: engine.op_conv2d(x.cuda(), wt, 1, 1, scale.cuda(), shift.cuda(), act=2, path=1).float().cpu())
     assert "conv_halo_rows_kernel<2>" in forms0 and not any("+tr" in k for k in forms0), sorted(forms0)
-    monkeypatch.setenv("DYF_ROWS_TR", str(tr))
+    form_switch.setenv("DYF_ROWS_TR", str(tr))
     y, forms = _form_log(engine, lambda: engine.op_conv2d(x.cuda(), wt, 1, 1, scale.cuda(), shift.cuda(), act=2, path=1).float().cpu())
     assert f"conv_halo_rows_kernel<2>+tr{tr}" in forms, sorted(forms)
     assert torch.equal(y, ref), float((y - ref).abs().max())

@@ -154,7 +154,7 @@ def test_rng_mode_rollout_equals_oracle_with_host_reproduced_masks(hp_extra, max
     assert min(rel_rms(got1[k], got2[k]) for k in got1) > 5e-2
 
 
-def test_rng_stream_is_invariant_to_pairing_graph_batching_and_row_offset(monkeypatch):
+def test_rng_stream_is_invariant_to_pairing_graph_batching_and_row_offset(form_switch):
     """(b) same seed -> same bits, however the rows are launched."""
     PF, PI = seeded_pair(64, 3, 2)
     g = torch.Generator().manual_seed(22)
@@ -178,7 +178,7 @@ def test_rng_stream_is_invariant_to_pairing_graph_batching_and_row_offset(monkey
     lo, hi = run(True, rows=slice(0, 2))[0], run(True, rows=slice(2, 4), offset=2)[0]
     for k in eager:  # two "ranks" of two rows each == the four-row batch (invariant to the number of GPUs)
         assert torch.equal(ref[0][k][:2], lo[k]) and torch.equal(ref[0][k][2:], hi[k]), k
-    monkeypatch.setenv("DYF_PAIR_INTERP", "0")  # one launch per interpolator forward instead of paired 2 nb-row launches
+    form_switch.setenv("DYF_PAIR_INTERP", "0")  # one launch per interpolator forward instead of paired 2 nb-row launches
     unpaired = run(True)[0]
     assert all(torch.equal(ref[0][k], unpaired[k]) for k in unpaired), "paired launch != two separate forwards"
 

@@ -71,7 +71,7 @@ def test_fused_linear_attention_block_matches_fp32_reference(engine, n, hw, c):
 
 
 @pytest.mark.parametrize("c,n,hw", [(64, 2, 3600), (128, 3, 900), (64, 1, 5000), (128, 2, 225)])
-def test_fused_linear_attention_block_sizes_agree(engine, c, n, hw, monkeypatch):
+def test_fused_linear_attention_block_sizes_agree(engine, c, n, hw, form_switch):
     """Round 5: the fused block's workgroups walk 32, 16 or 8 groups of 32 pixels (DYF_LINATTN_GPB, read per launch; the launcher takes
     the smaller blocks while a launch is under 512 workgroups -- the few-rows regime).  The blocks only change how the online softmax
     over the pixels is cut into partials: every size within the tolerance of the fp32 reference, and within rounding of one another."""
@@ -86,7 +86,7 @@ def test_fused_linear_attention_block_sizes_agree(engine, c, n, hw, monkeypatch)
     att = want - xres.float() - bout
     outs = {}
     for gpb in ("32", "16", "8"):
-        monkeypatch.setenv("DYF_LINATTN_GPB", gpb)
+        form_switch.setenv("DYF_LINATTN_GPB", gpb)
         engine.form_log(True)
         outs[gpb] = engine.op_linear_attention_fused(xn.cuda(), xres.cuda(), wqkv, wout, bout).float().cpu()
         forms = engine.form_log_read()

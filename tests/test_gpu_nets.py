@@ -106,11 +106,11 @@ def test_rows_are_independent():
 
 
 @pytest.mark.parametrize("force_igemm2", [False, True], ids=["default-conv-forms", "second-igemm-form"])
-def test_fullsize_ns_forwards_match_reference_fields(force_igemm2, monkeypatch):
+def test_fullsize_ns_forwards_match_reference_fields(force_igemm2, form_switch):
     """BASELINE config 2 shapes (221x42 -> 256^2, dim 64): one forecaster + one interpolator forward vs the
     reference's own outputs (fixture G6).  force_igemm2: the conv form production picks at bench batch sizes."""
     if force_igemm2:
-        monkeypatch.setenv("DYF_IGEMM2_MIN_TILES", "1")
+        form_switch.setenv("DYF_IGEMM2_MIN_TILES", "1")
     meta, fields = jload("fullsize_checksums.json"), load_npz("fullsize_ns_fields.npz")
     mk = meta["model"]
     PF = oinit.seeded_state(oinit.unet_simple_param_shapes(64, 5, 3), meta["seeds"]["forecaster"])
@@ -130,7 +130,7 @@ def test_fullsize_ns_forwards_match_reference_fields(force_igemm2, monkeypatch):
     assert eF <= TOL and eI <= TOL
 
 
-def test_sparse_last_decoder_block_writes_every_pixel_the_readout_reads(monkeypatch):
+def test_sparse_last_decoder_block_writes_every_pixel_the_readout_reads(form_switch):
     """The last decoder block computes only the output columns the readout's final bilinear resample touches (104 of 256
     for the NS grid).  With the block's output buffer poisoned (NaN) before every launch, a needed-but-skipped pixel would
     surface as NaN in the network output; the dense form (DYF_SPARSE_DEC5=0 at weight upload) must agree bit for bit on the
@@ -142,12 +142,12 @@ def test_sparse_last_decoder_block_writes_every_pixel_the_readout_reads(monkeypa
     x0 = torch.randn(3, 3, 221, 42, generator=g)
     c = torch.rand(3, 2, 221, 42, generator=g)
     t = torch.tensor([3.0, 0.0, 11.0], device=DEV)
-    monkeypatch.setenv("DYF_POISON_DEC5", "1")
+    form_switch.setenv("DYF_POISON_DEC5", "1")
     sparse = mirror_from_params(PF, mk, 3, 2, 3)
     y_sparse = sparse(x0.to(DEV), time=t, condition=c.to(DEV)).cpu()
     assert torch.isfinite(y_sparse).all(), "a pixel the readout reads was not written by the sparse-column conv"
     assert rel_rms(y_sparse[:1], nets.unet_simple_forward(PF, mk, x0[:1], t[:1].cpu(), c[:1])) <= TOL
-    monkeypatch.setenv("DYF_SPARSE_DEC5", "0")
+    form_switch.setenv("DYF_SPARSE_DEC5", "0")
     dense = mirror_from_params(PF, mk, 3, 2, 3)
     y_dense = dense(x0.to(DEV), time=t, condition=c.to(DEV)).cpu()
     assert torch.equal(y_sparse, y_dense)
@@ -212,6 +212,8 @@ _ENC0_SCRIPT = """
 import sys, torch
 sys.path.insert(0, {root!r})
 from tests.gpu_common import mirror_from_params, seeded_pair
+from tests.helpers import apply_test_forms
+apply_test_forms()
 PF, PI = seeded_pair(64, 3, 2, seeds=(31, 32))
 mk = dict(dim=64, with_time_emb=True, upsample_dims=[256, 256], dropout=0.25)
 g = torch.Generator().manual_seed(5)
@@ -231,7 +233,7 @@ torch.save(outs, {out!r})
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
-def test_persistent_enc0_kernel_matches_the_implicit_gemm_form(tmp_path, dtype):
+def test_persistent_enc0_kernel_matches_the_implicit_gemm_form(tmp_path, dtype, form_switch):
     """enc0 on the fused stem at NB = 8 (4 096 row segments: the persistent kernel of conv_enc0_stem.hip takes the layer) against
     the same forward with DYF_ENC0_STEM=0 (conv_igemm2_kernel): same K order, same epilogue and dropout stream -> the block output
     agrees to a 16-bit rounding tie, with and without engine dropout.  The form is chosen once per process: two subprocesses."""
@@ -242,7 +244,7 @@ def test_persistent_enc0_kernel_matches_the_implicit_gemm_form(tmp_path, dtype):
     outs = []
     for on in ("1", "0"):
         out = str(tmp_path / f"enc0_{on}.pt")
-        subprocess.run([_sys.executable, "-c", _ENC0_SCRIPT.format(root=root, out=out, dtype=dtype)], check=True, env=dict(os.environ, DYF_ENC0_STEM=on),
+        subprocess.run([_sys.executable, "-c", _ENC0_SCRIPT.format(root=root, out=out, dtype=dtype)], check=True, env=form_switch.env(DYF_ENC0_STEM=on),
                        timeout=900)
         outs.append(torch.load(out))
     for k in outs[0]:
@@ -255,7 +257,7 @@ def test_persistent_enc0_kernel_matches_the_implicit_gemm_form(tmp_path, dtype):
 
 
 @pytest.mark.parametrize("mode", ["bilinear", "nearest"])
-def test_row_block_stem_matches_the_per_pixel_form(mode, monkeypatch):
+def test_row_block_stem_matches_the_per_pixel_form(mode, form_switch):
     """The fused stem's resample kernel (221 x 42 -> 256 x 256, zero-bordered 16-channel tensor): the row-block form
     (stem16_rows_kernel: the block's source rows in LDS, 16-byte tap reads, two lanes per pixel) evaluates the same expressions in
     the same order as the per-pixel form (DYF_STEM16_ROWS=0); FMA contraction differs, so the first block's output agrees to a
@@ -267,7 +269,7 @@ def test_row_block_stem_matches_the_per_pixel_form(mode, monkeypatch):
     net = mirror_from_params(PI, mk, 6, 2, 3)
     outs = []
     for rows in ("1", "0"):
-        monkeypatch.setenv("DYF_STEM16_ROWS", rows)
+        form_switch.setenv("DYF_STEM16_ROWS", rows)
         y = net(x.to(DEV), time=t.to(DEV), condition=c.to(DEV)).cpu()
         outs.append((net._engine.read_block_output(net._engine_slot, 0, 3).cpu(), y))
     (e_new, y_new), (e_old, y_old) = outs
@@ -280,7 +282,7 @@ def test_row_block_stem_matches_the_per_pixel_form(mode, monkeypatch):
         assert frac <= 1e-3 and rel_rms(e_new, e_old) <= 1e-3 and rel_rms(y_new, y_old) <= 1e-2  # a flipped 16-bit value is a 4e-3 perturbation
 
 
-def test_quad_form_of_the_x2_upsample_matches_the_per_pixel_form(monkeypatch):
+def test_quad_form_of_the_x2_upsample_matches_the_per_pixel_form(form_switch):
     """The materialised x2 bilinear upsample of the small decoder planes (dec0-dec2): up2x_quad_kernel (a thread makes the 2 x 2
     outputs of one input pixel from its 3 x 3 neighbourhood) against up2x_kernel<8> (DYF_UP2X_QUAD=0): same stencils and
     expressions; FMA contraction may differ by a 16-bit rounding tie on a few elements."""
@@ -291,7 +293,7 @@ def test_quad_form_of_the_x2_upsample_matches_the_per_pixel_form(monkeypatch):
     net = mirror_from_params(PI, mk, 6, 2, 3)
     outs = []
     for quad in ("1", "0"):
-        monkeypatch.setenv("DYF_UP2X_QUAD", quad)
+        form_switch.setenv("DYF_UP2X_QUAD", quad)
         y = net(x.to(DEV), time=t.to(DEV), condition=c.to(DEV)).cpu()
         outs.append([net._engine.read_block_output(net._engine_slot, li, 2).cpu() for li in (6, 7, 8)] + [y])
     for name, a, b in zip(("dec0", "dec1", "dec2", "y"), outs[0], outs[1]):

@@ -211,22 +211,19 @@ def test_training_step_at_dim64_on_the_matrix_cores_matches_autograd_of_the_orac
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp16"])
-def test_training_step_with_16bit_conv_operands_tracks_the_fp32_step(dtype, monkeypatch):
-    """Opt-in (DYF_TRAIN_OPERANDS=bf16 | fp16 | 16): the training convolutions round their operands to the engine's 16-bit format while
-    staging them (csrc/train_halo16.hip for the 3 x 3 / stride-1 layers, csrc/train_gemm.hip t_gemm_mfma16 for the rest: fp32 tensors
-    and master weights in HBM, fp32 accumulation) -- the usual mixed-precision trade.  Against the engine's own fp32 step on the same
-    inputs, masks and weights (dim 64, 128 x 128 backbone grid, both loss terms, B = 4; the fp32 step is held to the oracle's autograd
-    by the tests above): loss within 1 %, the whole gradient's direction, and PER PARAMETER ||g16 - g32|| / ||g32||:
-      fp16 operands (11 significant bits): cosine 0.99994, per parameter worst 9.8e-2, median 8.1e-2   -> asserted 0.9995 / 1.5e-1
-      bf16 operands ( 8 significant bits): cosine 0.9929,  per parameter worst 2.4e-1, median 1.9e-1   -> asserted 0.985  / 3.5e-1
-    The per-parameter ratios are NOT rounding accumulating smoothly (the kernels reproduce the fp32 kernels to 2e-5 on inputs that
-    are exactly representable: test_16bit_halo_training_convs_match_the_plain_kernels): this objective is an L1 loss behind (Leaky)ReLUs,
-    MC-dropout and batch statistics over planes down to 2 x 2 -- a pre-activation or a residual that rounding moves across zero flips a
-    derivative from one constant to another, and every tensor feels the flips behind it (round 4's tap-by-tap kernels measured the
-    same cosine, 0.9929).  The 3e-2
-    per-parameter bound asked for in round 4's review is therefore not reachable by any 16-bit operand format on this objective;
-    what is asserted is the measured level with margin.  Parameters whose fp32 gradient is below 1e-5 of the gradient norm are left out
-    of the ratio (conv biases in front of a batch-statistics BatchNorm: true gradient exactly zero)."""
+def test_training_step_with_16bit_conv_operands_matches_the_operand_rounding_model(dtype):
+    """`train_precision=16` ("bf16-mixed"): the training convolutions round their operands to bf16 while staging them
+    (csrc/train_halo16.hip for the 3 x 3 / stride-1 layers, csrc/train_gemm.hip t_gemm_mfma16 for the rest; fp32 tensors, master
+    weights, accumulation and statistics; bf16 on the fp16 engine too: csrc/train_internal.h).  The check is against an ORACLE-SIDE
+    MODEL of that arithmetic -- `oracle.losses.training_operand_rounding`: torch.autograd over the reference-pinned restatement with
+    every conv's forward / data-gradient / weight-gradient operands rounded to bf16 where the engine's dispatch rounds them -- with
+    the engine's own dropout masks, on the dim-64 pair of the fp32 test above (128 x 128 backbone grid, both loss terms, L1).
+    Until round 5 this mode was only compared with the engine's own fp32 step (per-parameter ||dg|| / ||g|| <= 0.35: a bound that
+    would hide a wrong tap).  Rounding at the same places means the same (Leaky)ReLU / L1 / batch-statistics branches are taken, so
+    engine and model agree almost as closely as the fp32 pair does (what remains: fp32 summation order, and values that sit within
+    1e-6 of a bf16 rounding boundary).  Asserted: losses within 1e-3 relative; every parameter's gradient within 2e-2 of the global
+    gradient norm of the MODEL; and the engine is >= 10x closer to the model than the model is to the fp32 oracle (the rounding
+    effect itself, printed) -- i.e. the test would notice a rounding applied at the wrong operand."""
     from tests.gpu_common import seeded_pair
     mk = dict(dim=64, outer_sample_mode="bilinear", upsample_dims=[128, 128], with_time_emb=True, input_dropout=0.0, dropout=0.15)
     hp = dict(timesteps=4, schedule="before_t1_only", additional_interpolation_steps=0, additional_interpolation_steps_factor=0,
@@ -237,38 +234,39 @@ def test_training_step_with_16bit_conv_operands_tracks_the_fp32_step(dtype, monk
     g = torch.Generator().manual_seed(3)
     xt_last, cond = torch.randn(B, C, 23, 11, generator=g), torch.randn(B, C, 23, 11, generator=g)
     sc, t = torch.rand(B, Cs, 23, 11, generator=g), torch.tensor([0, 2, 3, 1])
-    res = {}
-    for mode in ("fp32", "16"):
-        if mode == "16":
-            monkeypatch.setenv("DYF_TRAIN_OPERANDS", dtype)
-        else:
-            monkeypatch.delenv("DYF_TRAIN_OPERANDS", raising=False)
-        m = build_dyffusion(PF, PI, mk, C, Cs, hp, max_batch=B, dtype=dtype)
-        m.seed(4242)
-        m.train()
-        out = m.p_losses(xt_last.to(DEV), cond.to(DEV), t.to(DEV), static_condition=sc.to(DEV))
-        out["loss"].backward()
-        res[mode] = (float(out["loss"]), {k: p.grad.detach().cpu().clone() for k, p in m.model.named_parameters()})
-        m.eval()
-        m._engine.close()
-    (l32, g32), (l16, g16) = res["fp32"], res["16"]
-    gn = float(torch.cat([v.reshape(-1) for v in g32.values()]).norm())
-    rel = {k: float((g16[k] - g32[k]).norm() / g32[k].norm()) for k in g32 if float(g32[k].norm()) > 1e-5 * gn}
-    worst = max(rel, key=rel.get)
-    med = sorted(rel.values())[len(rel) // 2]
-    a, b = torch.cat([v.reshape(-1) for v in g32.values()]), torch.cat([v.reshape(-1) for v in g16.values()])
-    cos = float((a @ b) / (a.norm() * b.norm()))
-    print(f"{dtype} conv operands vs fp32: loss {l16:.6f} vs {l32:.6f}; per-parameter ||dg|| / ||g||: worst {rel[worst]:.2e} ({worst}), "
-          f"median {med:.2e} over {len(rel)} of {len(g32)} tensors; cosine of the whole gradient {cos:.5f}")
-    assert l16 == pytest.approx(l32, rel=1e-2)
-    if dtype == "fp16":
-        assert rel[worst] <= 1.5e-1 and cos >= 0.9995
-    else:
-        assert rel[worst] <= 3.5e-1 and cos >= 0.985
-    assert rel[worst] > 1e-6  # the switch did select the 16-bit kernels
+    seed = 4242
+    m = build_dyffusion(PF, PI, mk, C, Cs, hp, max_batch=B, dtype=dtype, train_precision="bf16-mixed")
+    m.seed(seed)
+    m.train()
+    m._ensure_engine((23, 11), B)
+    eng = m._engine
+    eng.form_log(True)
+    out = m.p_losses(xt_last.to(DEV), cond.to(DEV), t.to(DEV), static_condition=sc.to(DEV))
+    out["loss"].backward()
+    forms = eng.form_log_read()
+    eng.form_log(False)
+    assert any(k.startswith("t_halo3x3_16") for k in forms), sorted(forms)  # the 16-bit kernels did run
+    got = {k: p.grad.detach().cpu().clone() for k, p in m.model.named_parameters()}
+    with losses.training_operand_rounding():
+        want, model, _ = _oracle_step(PF, PI, mk, hp, xt_last, cond, t, sc, seed)
+    want32, g32, _ = _oracle_step(PF, PI, mk, hp, xt_last, cond, t, sc, seed)
+    cat = lambda d: torch.cat([d[k].reshape(-1) for k in sorted(model)])
+    gn = float(cat(model).norm())
+    errs = {k: float((got[k] - model[k]).norm()) / gn for k in model}
+    worst = max(errs, key=errs.get)
+    e_model, e_round = float((cat(got) - cat(model)).norm()) / gn, float((cat(model) - cat(g32)).norm()) / gn
+    print(f"{dtype} engine, bf16-mixed step: loss {float(out['loss']):.6f} (model {float(want['loss']):.6f}, fp32 oracle {float(want32['loss']):.6f}); "
+          f"engine vs model: whole gradient {e_model:.2e}, worst tensor {errs[worst]:.2e} of the gradient norm ({worst}); "
+          f"model vs fp32 oracle (the rounding itself): {e_round:.2e}")
+    for k_got, k_want in (("loss", "loss"), ("train/loss_forward", "loss_forward"), ("train/loss_forward2", "loss_forward2")):
+        assert float(out[k_got]) == pytest.approx(float(want[k_want]), rel=1e-3), k_got
+    assert errs[worst] <= 2e-2
+    assert e_round > 1e-3 and e_model <= 0.1 * e_round
+    m.eval()
+    eng.close()
 
 
-def test_train_precision_knob_selects_the_operand_format(monkeypatch):
+def test_train_precision_knob_selects_the_operand_format(form_switch):
     """`DYffusion(train_precision=...)` / `HipEngine.train_set_precision` -> C-ABI `dyf_train_set_precision` (the reference's Lightning
     `trainer.precision`): 16 / "16-mixed" runs the 16-bit-operand kernels without any environment variable, 32 keeps fp32 operands even
     when DYF_TRAIN_OPERANDS asks for 16 bits, None leaves the choice to the variable; bad values are refused."""
@@ -285,9 +283,9 @@ def test_train_precision_knob_selects_the_operand_format(monkeypatch):
 
     def step(precision, env):
         if env:
-            monkeypatch.setenv("DYF_TRAIN_OPERANDS", env)
+            form_switch.setenv("DYF_TRAIN_OPERANDS", env)
         else:
-            monkeypatch.delenv("DYF_TRAIN_OPERANDS", raising=False)
+            form_switch.delenv("DYF_TRAIN_OPERANDS", raising=False)
         m = build_dyffusion(PF, PI, mk, C, Cs, hp, max_batch=B, train_precision=precision)
         m.seed(7)
         m.train()
@@ -394,7 +392,7 @@ HALO16_CASES = [
 
 @pytest.mark.parametrize("case", HALO16_CASES, ids=lambda c: "x".join(map(str, c)))
 @pytest.mark.parametrize("kind", [0, 1, 2], ids=["forward", "dgrad", "wgrad"])
-def test_16bit_halo_training_convs_match_the_plain_kernels(case, kind, monkeypatch):
+def test_16bit_halo_training_convs_match_the_plain_kernels(case, kind, form_switch):
     """csrc/train_halo16.hip (round 5: 3 x 3 / stride 1 layers of the training step with 16-bit operands -- tile + halo staged once,
     all nine taps from LDS; the weight gradient with both operands transposed on the way into LDS and the column shift made in
     registers) against the one-thread-per-output fp32 kernels.  The check rounds its hash-random inputs to the 16-bit format first,
@@ -402,12 +400,12 @@ def test_16bit_halo_training_convs_match_the_plain_kernels(case, kind, monkeypat
     for the fp32 matrix-core forms.  The tap-by-tap 16-bit implicit GEMM these replace (DYF_TRAIN_HALO16=0) must pass the same check."""
     import dyffusion_amd as D
     from dyffusion_amd.engine import net_config
-    monkeypatch.setenv("DYF_TRAIN_OPERANDS", "bf16")
+    form_switch.setenv("DYF_TRAIN_OPERANDS", "bf16")
     cfg = net_config(in_channels=3, cond_channels=2, out_channels=3, dim=64, with_time_emb=True, upsample_dims=(64, 64), dropout=0.0)
     eng = D.HipEngine(cfg, cfg, 23, 11, max_batch=1, use_graph=False)
     want_form = ("t_halo3x3_16:forward", "t_halo3x3_16:dgrad", "t_wgrad3x3_16")[kind]
     for halo in ("1", "0"):
-        monkeypatch.setenv("DYF_TRAIN_HALO16", halo)
+        form_switch.setenv("DYF_TRAIN_HALO16", halo)
         eng.form_log(True)
         split, unsplit, took = eng.train_conv_check(kind, *case, seed=17 + kind)
         forms = eng.form_log_read()
@@ -420,18 +418,18 @@ def test_16bit_halo_training_convs_match_the_plain_kernels(case, kind, monkeypat
 
 @pytest.mark.parametrize("case", [(8, 64, 64, 64, 128, 4, 2, 1), (4, 60, 92, 128, 64, 4, 2, 1), (2, 128, 128, 128, 256, 4, 2, 1)],
                          ids=lambda c: "x".join(map(str, c)))
-def test_16bit_stride2_data_gradient_by_parity_classes_matches_the_plain_kernel(case, monkeypatch):
+def test_16bit_stride2_data_gradient_by_parity_classes_matches_the_plain_kernel(case, form_switch):
     """Data gradient of the 4 x 4 / stride 2 / pad 1 encoder convs with 16-bit operands: one launch slice per parity class of the input
     pixels, each running its 2 x 2 reachable taps as a dense K = 4 cout (csrc/train_gemm.hip, pmode) instead of all 16 taps with three
     quarters of the gathers predicated off.  Against the one-thread-per-output fp32 kernel on inputs rounded to 16 bit (2e-5), and the
     16-tap form (DYF_TRAIN_DGRAD_PARITY=0) held to the same bound."""
     import dyffusion_amd as D
     from dyffusion_amd.engine import net_config
-    monkeypatch.setenv("DYF_TRAIN_OPERANDS", "bf16")
+    form_switch.setenv("DYF_TRAIN_OPERANDS", "bf16")
     cfg = net_config(in_channels=3, cond_channels=2, out_channels=3, dim=64, with_time_emb=True, upsample_dims=(64, 64), dropout=0.0)
     eng = D.HipEngine(cfg, cfg, 23, 11, max_batch=1, use_graph=False)
     for parity in ("1", "0"):
-        monkeypatch.setenv("DYF_TRAIN_DGRAD_PARITY", parity)
+        form_switch.setenv("DYF_TRAIN_DGRAD_PARITY", parity)
         eng.form_log(True)
         split, unsplit, took = eng.train_conv_check(1, *case, seed=23)
         forms = eng.form_log_read()
@@ -443,7 +441,7 @@ def test_16bit_stride2_data_gradient_by_parity_classes_matches_the_plain_kernel(
 
 @pytest.mark.parametrize("case", [(4, 64, 64, 5, 64, 1, 1, 0), (2, 128, 128, 3, 64, 4, 2, 1), (3, 60, 60, 2, 64, 7, 1, 3), (2, 96, 64, 1, 128, 7, 1, 3)],
                          ids=lambda c: "x".join(map(str, c)))
-def test_small_channel_weight_gradient_on_the_matrix_cores_matches_the_plain_kernel(case, monkeypatch):
+def test_small_channel_weight_gradient_on_the_matrix_cores_matches_the_plain_kernel(case, form_switch):
     """Weight gradient of the convs with a handful of input channels (1 x 1 stem on 5, the readout's 4 x 4 / stride 2 on 3, the ResNet-UNet's
     7 x 7 init conv on 1-2): `t_conv_wgrad_smallc_mfma` (fp32 MFMA, the (tap, channel) axis gathered by constant per-lane offsets, one column of
     ones for the bias gradient's sums) and the per-lane-sums form it replaces, both against the one-thread-per-output kernel."""
@@ -452,7 +450,7 @@ def test_small_channel_weight_gradient_on_the_matrix_cores_matches_the_plain_ker
     cfg = net_config(in_channels=3, cond_channels=2, out_channels=3, dim=64, with_time_emb=True, upsample_dims=(64, 64), dropout=0.0)
     eng = D.HipEngine(cfg, cfg, 23, 11, max_batch=1, use_graph=False)
     for mfma in ("1", "0"):
-        monkeypatch.setenv("DYF_TRAIN_SMALLC_MFMA", mfma)
+        form_switch.setenv("DYF_TRAIN_SMALLC_MFMA", mfma)
         err, _, took = eng.train_conv_check(3, *case, seed=31)
         print(f"wgrad {case} mfma={mfma}: rel max err {err:.2e}")
         assert took and err <= 2e-5

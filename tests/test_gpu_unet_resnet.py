@@ -100,12 +100,12 @@ def seeded_unet(dim, mults, cin, cout, seed):
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("force_igemm2", [False, True], ids=["default-conv-forms", "second-igemm-form"])
 @pytest.mark.parametrize("hw,nb,n_in,n_cond", [((60, 60), 2, 2, 0), ((32, 48), 2, 1, 1)])
-def test_dim64_oisst_shape_matches_oracle(hw, nb, n_in, n_cond, force_igemm2, dtype, monkeypatch):
+def test_dim64_oisst_shape_matches_oracle(hw, nb, n_in, n_cond, force_igemm2, dtype, form_switch):
     """OISST configuration of the reference (dim 64, mults (1,2,4), 60x60): MFMA conv path.  force_igemm2: every conv with
     cout % 128 == 0 (two-source skip convs, fp32 GroupNorm inputs, residual epilogues) through conv_igemm2_kernel, which
     production selects only for large batches."""
     if force_igemm2:
-        monkeypatch.setenv("DYF_IGEMM2_MIN_TILES", "1")
+        form_switch.setenv("DYF_IGEMM2_MIN_TILES", "1")
     cfg = dict(dim=64, dim_mults=[1, 2, 4], with_time_emb=True, block_dropout=0.3, block_dropout1=0.1, attn_dropout=0.2,
                resnet_block_groups=8, input_dropout=0.0, upsample_dims=None)
     P = seeded_unet(64, (1, 2, 4), n_in + n_cond, 1, seed=51)
@@ -246,6 +246,8 @@ _ATTN_DROP_SCRIPT = r"""
 import sys, torch
 sys.path.insert(0, {root!r})
 from tests.test_gpu_unet_resnet import mirror, seeded_unet
+from tests.helpers import apply_test_forms
+apply_test_forms()
 cfg = dict(dim=64, dim_mults=[1, 2], with_time_emb=True, block_dropout=0.0, block_dropout1=0.0, attn_dropout=0.3,
            resnet_block_groups=8, input_dropout=0.0, upsample_dims=None)
 P = seeded_unet(64, (1, 2), 2, 1, seed=71)
@@ -259,7 +261,7 @@ torch.save(y, {out!r})
 """
 
 
-def test_flash_attention_engine_dropout_draws_the_masks_of_the_plain_kernel(tmp_path):
+def test_flash_attention_engine_dropout_draws_the_masks_of_the_plain_kernel(tmp_path, form_switch):
     """Attention-probability dropout from the engine's generator: the flash kernel hashes one keep word per PAIR of keys
     (16 x 16 = 256 tokens: both query blocks are whole, the paired form runs), the plain kernel (DYF_FLASH_ATTN=0) evaluates
     `rng_keep(q * N + j)` per element.  Same seed -> the same masks, so the outputs agree to rounding (different masks at
@@ -272,7 +274,7 @@ def test_flash_attention_engine_dropout_draws_the_masks_of_the_plain_kernel(tmp_
     # the plain per-query kernel
     for flash in ("4", "3", "2", "0"):
         out = str(tmp_path / f"y{flash}.pt")
-        env = dict(os.environ, DYF_FLASH_ATTN=flash)
+        env = form_switch.env(DYF_FLASH_ATTN=flash)
         subprocess.run([_sys.executable, "-c", _ATTN_DROP_SCRIPT.format(root=root, out=out)], check=True, env=env, timeout=600)
         outs[flash] = torch.load(out)
     for flash in ("4", "3", "2"):
@@ -286,6 +288,8 @@ _HALO5_EPI_SCRIPT = r"""
 import sys, torch
 sys.path.insert(0, {root!r})
 from tests.test_gpu_unet_resnet import mirror, seeded_unet
+from tests.helpers import apply_test_forms
+apply_test_forms()
 cfg = dict(dim=64, dim_mults=[1, 2, 4], with_time_emb=True, block_dropout=0.0, block_dropout1=0.0, attn_dropout=0.0,
            resnet_block_groups=8, input_dropout=0.0, upsample_dims=None)
 P = seeded_unet(64, (1, 2, 4), 2, 1, seed=5)
@@ -303,7 +307,7 @@ torch.save(y, {out!r})
 """
 
 
-def test_halo5_plain_epilogue_instantiation_equals_the_general_one(tmp_path):
+def test_halo5_plain_epilogue_instantiation_equals_the_general_one(tmp_path, form_switch):
     """conv_up_halo_kernel<5, true> (only the no-activation / no-dropout epilogue instantiated: what every 3x3 conv of the
     ResNet-UNet launches by default) against the general instantiation (DYF_HALO5_PLAIN_EPI=0, all twelve epilogues): the same
     source path compiled twice, so the forward must agree BITWISE; the default one is pinned to the oracle by every other test of
@@ -314,14 +318,14 @@ def test_halo5_plain_epilogue_instantiation_equals_the_general_one(tmp_path):
     outs = {}
     for v in ("1", "0"):
         out = str(tmp_path / f"y{v}.pt")
-        env = dict(os.environ, DYF_HALO5_PLAIN_EPI=v, DYF_GN_FUSED="0")  # the un-fused chain: conv<5> + statistics epilogue + gn_apply_part
+        env = form_switch.env(DYF_HALO5_PLAIN_EPI=v, DYF_GN_FUSED="0")  # the un-fused chain: conv<5> + statistics epilogue + gn_apply_part
         subprocess.run([_sys.executable, "-c", _HALO5_EPI_SCRIPT.format(root=root, out=out)], check=True, env=env, timeout=600)
         outs[v] = torch.load(out)
     assert torch.isfinite(outs["1"]).all() and float(outs["1"].std()) > 0
     assert torch.equal(outs["1"], outs["0"])
 
 
-def test_fused_groupnorm_convs_match_the_unfused_chain_and_are_reproducible():
+def test_fused_groupnorm_convs_match_the_unfused_chain_and_are_reproducible(form_switch):
     """Round 4 (csrc/gn_fused.h): GroupNorm + FiLM + SiLU + dropout (+ residual) inside the producing conv, with the statistics
     exchanged between the workgroups of a sample INSIDE the launch, against the three-kernel chain (DYF_GN_FUSED=0, read per engine)
     on the OISST shapes at 40 rows -- conv_up_halo_kernel<5, 2> on the 60 x 60 and 30 x 30 levels, conv_igemm2_kernel<2, true> (rows of
@@ -335,11 +339,10 @@ def test_fused_groupnorm_convs_match_the_unfused_chain_and_are_reproducible():
     nb = 40
     x, t = torch.randn(nb, 2, 60, 60, generator=g), (torch.arange(nb) % 7 + 1).float()
     outs = {}
-    prev = os.environ.get("DYF_GN_FUSED")
     try:
         for fused in ("1", "0"):
-            os.environ["DYF_GN_FUSED"] = fused
-            os.environ["DYF_IGEMM2_MIN_TILES"] = "1"  # the large-batch implicit-GEMM form at 40 rows (as at 300 rows by default)
+            form_switch.setenv("DYF_GN_FUSED", fused)
+            form_switch.setenv("DYF_IGEMM2_MIN_TILES", "1")  # the large-batch implicit-GEMM form at 40 rows (as at 300 rows by default)
             net = mirror(P, cfg, 2, 0, 1, "fp16")
             net._own_engine(nb, (60, 60))
             eng = net._engine
@@ -364,11 +367,8 @@ def test_fused_groupnorm_convs_match_the_unfused_chain_and_are_reproducible():
             outs[fused] = (y_eval, y_d1)
             eng.close()
     finally:
-        os.environ.pop("DYF_IGEMM2_MIN_TILES", None)
-        if prev is None:
-            os.environ.pop("DYF_GN_FUSED", None)
-        else:
-            os.environ["DYF_GN_FUSED"] = prev
+        form_switch.delenv("DYF_IGEMM2_MIN_TILES")
+        form_switch.delenv("DYF_GN_FUSED")
     with torch.no_grad():
         want = nets.resnet_unet_forward(P, cfg, x, t, None)
     for i, nm in enumerate(("eval", "engine dropout")):
@@ -391,14 +391,14 @@ def _invariant_engine(net, hw, max_batch, dtype="fp16"):
 
 
 @pytest.mark.parametrize("force_igemm2", [False, True], ids=["default-conv-forms", "second-igemm-form"])
-def test_batch_invariant_resnet_rows_do_not_depend_on_their_position_on_ragged_planes(force_igemm2, monkeypatch):
+def test_batch_invariant_resnet_rows_do_not_depend_on_their_position_on_ragged_planes(force_igemm2, form_switch):
     """conv_igemm2_kernel<2, true> on flattened-M tiles reduces the GroupNorm statistics per 128-row slab of the
     n * plane axis; with plane % 128 != 0 (OISST levels 60 x 60, 30 x 30, 15 x 15) a sample's slab partition -- and so the last bits
     of (mean, 1/std) -- depended on its position in the launch.  A batch_invariant engine now keeps to position-free forms (halo5,
     2-D tiles, plane % 128 == 0; otherwise the three-kernel path): rows [2, 5) of a 6-row launch, run alone at positions 0..2 with
     their global row offset, must reproduce bit for bit, eval and with the engine's MC dropout."""
     if force_igemm2:
-        monkeypatch.setenv("DYF_IGEMM2_MIN_TILES", "1")  # the large-batch forms (what 300 rows select) on this small launch
+        form_switch.setenv("DYF_IGEMM2_MIN_TILES", "1")  # the large-batch forms (what 300 rows select) on this small launch
     cfg = dict(dim=64, dim_mults=[1, 2, 4], with_time_emb=True, block_dropout=0.3, block_dropout1=0.1, attn_dropout=0.0,
                resnet_block_groups=8, input_dropout=0.0, upsample_dims=None)
     P = seeded_unet(64, (1, 2, 4), 2, 1, seed=5)
@@ -426,7 +426,7 @@ def test_batch_invariant_resnet_rows_do_not_depend_on_their_position_on_ragged_p
     eng.close()
 
 
-def test_fused_groupnorm_timeout_fails_the_same_call_and_the_engine_recovers_unfused():
+def test_fused_groupnorm_timeout_fails_the_same_call_and_the_engine_recovers_unfused(form_switch):
     """the time-out path of the fused GroupNorm (csrc/gn_fused.h).  With the drill switched on
     (dyf_debug_gn_fuse: every granule sweep waits for a tag nobody publishes, bound 20 ms instead of 2 s) the launch must still
     TERMINATE, its output must be NaN-poisoned, and the failure must surface in the SAME call (the wrapper polls dyf_poll_errors after
@@ -480,8 +480,7 @@ def test_fused_groupnorm_timeout_fails_the_same_call_and_the_engine_recovers_unf
         e3.poll_errors()
     e3.poll_errors()  # reported once
     e3.close()
-    prev = os.environ.get("DYF_GN_FUSED")
-    os.environ["DYF_GN_FUSED"] = "0"
+    form_switch.setenv("DYF_GN_FUSED", "0")
     try:
         net2 = mirror(P, cfg, 2, 0, 1, "fp16")
         never = net2(x, time=t)
@@ -489,13 +488,10 @@ def test_fused_groupnorm_timeout_fails_the_same_call_and_the_engine_recovers_unf
         assert torch.equal(never, again)
         net2._engine.close()
     finally:
-        if prev is None:
-            os.environ.pop("DYF_GN_FUSED", None)
-        else:
-            os.environ["DYF_GN_FUSED"] = prev
+        form_switch.delenv("DYF_GN_FUSED")
 
 
-def test_small_tile_fused_igemm_form_matches_the_large_tile_form_and_the_oracle(monkeypatch):
+def test_small_tile_fused_igemm_form_matches_the_large_tile_form_and_the_oracle(form_switch):
     """Round 5: conv_igemm2_kernel<2, true, *, 128> -- the fused-GroupNorm implicit GEMM on 128-pixel tiles (64-row statistics slabs)
     that the launcher takes while the 256-pixel tiles would leave CUs idle: the 15 x 15 level of the OISST shapes at 38 rows (68
     large tiles).  Against the 256-pixel form (DYF_IGEMM2_BM128_BELOW=0, read per launch), eval and with the engine's MC dropout
@@ -512,9 +508,9 @@ def test_small_tile_fused_igemm_form_matches_the_large_tile_form_and_the_oracle(
     outs = {}
     for below in ("0", None):
         if below is None:
-            monkeypatch.delenv("DYF_IGEMM2_BM128_BELOW", raising=False)
+            form_switch.delenv("DYF_IGEMM2_BM128_BELOW", raising=False)
         else:
-            monkeypatch.setenv("DYF_IGEMM2_BM128_BELOW", below)
+            form_switch.setenv("DYF_IGEMM2_BM128_BELOW", below)
         eng.form_log(True)
         y_eval = net(x.to(DEV), time=t.to(DEV)).cpu()
         forms = eng.form_log_read()

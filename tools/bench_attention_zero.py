@@ -2,6 +2,9 @@
 import os, sys, torch
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 sys.path.insert(0, ROOT)
+from tools._forms import forward_env_forms  # noqa: E402
+
+forward_env_forms()  # DYF_* switches of this run -> dyf_debug_set_form
 import dyffusion_amd as D
 from dyffusion_amd.engine import net_config
 nb, n = 4, 16384

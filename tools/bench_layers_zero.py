@@ -3,6 +3,9 @@ per channel: no operand toggling), same instruction stream -- is the halo kernel
 import os, sys, torch
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 sys.path.insert(0, ROOT)
+from tools._forms import forward_env_forms  # noqa: E402
+
+forward_env_forms()  # DYF_* switches of this run -> dyf_debug_set_form
 import bench
 nb, iters = 80, 30
 mode = sys.argv[1]

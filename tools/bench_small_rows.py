@@ -10,6 +10,9 @@ import torch
 
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 sys.path.insert(0, ROOT)
+from tools._forms import forward_env_forms  # noqa: E402
+
+forward_env_forms()  # DYF_* switches of this run -> dyf_debug_set_form
 import bench  # noqa: E402
 
 what = sys.argv[1] if len(sys.argv) > 1 else "both"

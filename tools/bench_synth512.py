@@ -8,6 +8,9 @@ import torch
 
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 sys.path.insert(0, ROOT)
+from tools._forms import forward_env_forms  # noqa: E402
+
+forward_env_forms()  # DYF_* switches of this run -> dyf_debug_set_form
 import dyffusion_amd as D  # noqa: E402
 from bench import random_state  # noqa: E402
 

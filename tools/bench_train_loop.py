@@ -2,6 +2,9 @@
 configs[1] shapes.  usage: python tools/bench_train_loop.py [B] [cuda]   (cuda: forecaster parameters resident on the GPU)"""
 import os, sys, time, torch
 sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
+from tools._forms import forward_env_forms  # noqa: E402
+
+forward_env_forms()  # DYF_* switches of this run -> dyf_debug_set_form
 import bench
 kw = dict(bench.DIFFUSION_KW, lambda_reconstruction=1.0, lambda_reconstruction2=0.5, loss_function="l1")
 bench.DIFFUSION_KW.clear(); bench.DIFFUSION_KW.update(kw)

@@ -1,6 +1,9 @@
 """2 ranks (gloo) on ONE GPU: the OISST sharded step of bench.py, per-call times. env DYF_GN_FUSED, MODE=sharded|plain|stack"""
 import os, sys, time
 sys.path.insert(0, os.getcwd())
+from tools._forms import forward_env_forms  # noqa: E402
+
+forward_env_forms()  # DYF_* switches of this run -> dyf_debug_set_form
 import torch, torch.distributed as dist
 import bench
 from dyffusion_amd.distributed import sample_sharded, shard_rows, rows_per_rank

@@ -2,6 +2,9 @@
 usage: two_proc_oisst.py <rows> <row_groups> <calls>; env DYF_GN_FUSED"""
 import os, sys, time
 sys.path.insert(0, os.getcwd())
+from tools._forms import forward_env_forms  # noqa: E402
+
+forward_env_forms()  # DYF_* switches of this run -> dyf_debug_set_form
 import torch
 import bench
 rows, groups, calls = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
