@@ -20,7 +20,7 @@ typedef uint16_t el16_t;
 // any of them stops here, and the run-time ones (DYF_GN_FUSE_NOWAIT, DYF_EXP_DEC5_1316) are not compiled in.
 #if !defined(DYF_EXPERIMENT_BUILD) &&                                                                                               \
     (defined(HALO_EXP_NO_DMA_WAIT) || defined(HALO_EXP_NO_STORE) || defined(HALO_EXP_W_ALIAS) || defined(HALO_EXP_W_SHARE) ||        \
-     defined(HALO_EXP_NO_HALO) || defined(HALO_EXP_NO_EPI) || defined(HALO_EXP_LDS_SKIP) || defined(FA_EXP_NO_EXP) ||                \
+     defined(HALO_EXP_NO_HALO) || defined(HALO_EXP_NO_EPI) || defined(HALO_EXP_TIMELINE) || defined(HALO_EXP_LDS_SKIP) || defined(FA_EXP_NO_EXP) ||                \
      defined(FA_EXP_NOSYNC) || defined(FA_EXP_NO_VT) || defined(FA4_X_NOEXP) || defined(FA4_X_MFMAONLY) || defined(FA4_X_NOQK) ||    \
      defined(FA4_X_NOPV) || defined(FA4_X_NOSTAGE))
 #error "a wrong-results timing switch (HALO_EXP_* / FA_EXP_* / FA4_X_*) is defined in a product build: use tools/build_variant.sh"

@@ -133,6 +133,11 @@ void pack_halo_s2_frag(const el16_t* wpk, int cout, int cin, el16_t* out);
 bool conv_halo5_supported(const ConvArgs& a);
 hipError_t launch_conv_halo5(const ConvArgs& a, hipStream_t stream);
 void pack_halo3_frag64(const el16_t* wpk, int cout, int cin, el16_t* out);
+// the same convs WITH the fused GroupNorm epilogue on 16 x 16-pixel tiles, three workgroups per CU (conv_gn16.hip); fragments of
+// pack_halo3_frag64; ONE statistics slot per workgroup
+bool conv_gn16_supported(const ConvArgs& a);
+int conv_gn16_slots(int h, int w);
+hipError_t launch_conv_gn16(const ConvArgs& a, hipStream_t stream);
 void conv_register_halo3_frag(const el16_t* wpk_dev, const el16_t* frag_dev);
 const el16_t* conv_lookup_halo3_frag(const el16_t* wpk_dev);
 // enc0 on the fused stem (conv_enc0_stem.hip): persistent, weights resident in LDS, pixel fragments straight from global memory;

@@ -870,6 +870,8 @@ int conv_gn_fused_max_slots(int h, int w) {
     int best = 0;
     const int s5 = conv_halo5_gn_slots(h, w);
     if (s5 <= GN_FUSE_MAX_SLOTS) best = s5;
+    const int s16 = conv_gn16_slots(h, w);
+    if (s16 <= GN_FUSE_MAX_SLOTS) best = std::max(best, s16);
     const int si = conv_igemm2_gn_slots(h, w);
     if (si > 0 && si <= GN_FUSE_MAX_SLOTS) best = std::max(best, si);
     const int s128 = conv_igemm2_gn_slots_bm128(h, w);
@@ -894,6 +896,19 @@ hipError_t launch_conv_gn_fused(const ConvArgs& a_in, int path, hipStream_t stre
         const long long h5_min = dyf_form("DYF_HALO5_MIN_TILES") ? atoll(dyf_form("DYF_HALO5_MIN_TILES")) : 64;
         ConvArgs b = a;
         b.wpk_up_frag = conv_lookup_halo3_frag(b.wpk);
+        {   // 16 x 16 tiles, three workgroups per CU (conv_gn16.hip; DYF_GN16=0: the 16 x 32 form below)
+            const bool g16 = !(dyf_form("DYF_GN16") && atoi(dyf_form("DYF_GN16")) == 0);
+            const long long g16_min = dyf_form("DYF_GN16_MIN_TILES") ? atoll(dyf_form("DYF_GN16_MIN_TILES")) : 64;
+            const int slots16 = conv_gn16_slots(a.h, a.w);
+            const long long tiles16 = nsel * slots16 * (a.cout / 64);
+            const bool covers16 = 10ll * a.h * a.w >= 6ll * slots16 * 256;
+            if (g16 && b.wpk_up_frag && covers16 && tiles16 >= g16_min && slots16 <= GN_FUSE_MAX_SLOTS && slots16 <= G.max_slots &&
+                conv_gn16_supported(b)) {
+                b.gnf.slots = slots16;
+                *fused = true;
+                return launch_conv_gn16(b, stream);
+            }
+        }
         const long long ty = (a.h + 15) / 16, tx = (a.w + 31) / 32;
         const long long tiles5 = nsel * ty * tx * (a.cout / 64);
         const bool covers = 10ll * a.h * a.w >= 6ll * ty * 16 * tx * 32;

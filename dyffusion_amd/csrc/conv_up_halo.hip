@@ -33,6 +33,10 @@
 #include <algorithm>
 #include <type_traits>
 #include <vector>
+#ifdef HALO_EXP_TIMELINE
+#include <cstdio>
+#include <string>
+#endif
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
@@ -105,6 +109,13 @@ struct HaloCfg {
 // OISST rollout 121.3 -> 114.7 us (300 rows), 51.7 -> 48.7 us (100 rows).
 // EPI = 2 (SP = 5 only): GroupNorm fused into this conv -- in-launch statistics exchange between the workgroups of a sample, then
 // normalise + FiLM + SiLU + dropout (+ residual) in the epilogue (gn_fused.h; ConvArgs::gnf).
+#ifdef HALO_EXP_TIMELINE  // experiment builds only (tools/build_variant.sh): per-wave shader-clock stamps at the phase boundaries of the EPI = 2 form
+__device__ unsigned long long g_halo_tl[1 << 18];
+#define TL_STAMP(K)                                                                                              \
+    if (EPI == 2 && blockIdx.x < 8192 && lane == 0) g_halo_tl[(blockIdx.x * 4 + wave) * 8 + (K)] = __builtin_amdgcn_s_memtime();
+#else
+#define TL_STAMP(K)
+#endif
 template <int SP, int EPI = 0>
 __global__ __launch_bounds__(256, 2) void conv_up_halo_kernel(ConvArgs a, int tiles_x, int tiles_per_img, int tiles_m,
                                                               int tiles_n, int xmode) {
@@ -121,6 +132,7 @@ __global__ __launch_bounds__(256, 2) void conv_up_halo_kernel(ConvArgs a, int ti
     const int l31 = lane & 31, hi = lane >> 5;
     const int wpy = wave >> 1, wpx = wave & 1;  // output phase of this wave
 
+    TL_STAMP(0)
     // XCD-aware tile id; the column blocks of one tile are consecutive (they share the halo in L2)
     const int total = tiles_m * tiles_n;
     const int bid = blockIdx.x;
@@ -403,6 +415,7 @@ __global__ __launch_bounds__(256, 2) void conv_up_halo_kernel(ConvArgs a, int ti
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
+            if (chunk == 0) { TL_STAMP(1) }
         }
         const unsigned Hs = lds_base + (H::NBUF == 2 ? (chunk & 1) * HALO_BYTES : 0);
         asm volatile("" : "+v"(hp0));  // keep the per-tap LDS addresses from being hoisted out of the chunk loop
@@ -514,6 +527,7 @@ __global__ __launch_bounds__(256, 2) void conv_up_halo_kernel(ConvArgs a, int ti
                            : o0;
     const uint32_t smt_stride = SP == 1 ? (uint32_t)(4 * a.up_wo_store * a.cout) : mt_stride;
     if constexpr (EPI == 2) {
+        TL_STAMP(2)
         // ---- GroupNorm fused (gn_fused.h).  Phase A: (sum, sum of squares) of y = acc + bias per 8-channel octet over this wave's
         // 128 pixels (pixels beyond a ragged plane masked by a 0 / 1 factor), reduce-scatter butterfly, 16 granules per wave.
         const GnFuse& G = a.gnf;
@@ -573,6 +587,7 @@ __global__ __launch_bounds__(256, 2) void conv_up_halo_kernel(ConvArgs a, int ti
             }
         };
         if (has_res) load_res(0, 0, rq[0]);
+        TL_STAMP(3)
         // Phase B: wave 0 sweeps the sample's granules and parks (A, C) of the block's 64 channels in LDS (its own 512 bytes behind
         // the halo: the other waves may still be in their K loop)
         float* cfA = (float*)(smem + H::LDS_TOTAL);
@@ -585,8 +600,10 @@ __global__ __launch_bounds__(256, 2) void conv_up_halo_kernel(ConvArgs a, int ti
             const float2 ac = gn_fuse_coef(G, ch_blk + lane, a.coef_div > 1 ? n_img / a.coef_div : n_img, mr);
             cfA[lane] = ac.x;
             cfC[lane] = ac.y;
+            TL_STAMP(6)
         }
         __syncthreads();
+        TL_STAMP(4)
         // Phase C: y * A + C -> SiLU -> dropout -> (+ residual) -> 16-bit, stored as the plain epilogue stores
         auto fused = [&](auto mode_c) {
             constexpr int MODE = decltype(mode_c)::value;
@@ -636,6 +653,7 @@ __global__ __launch_bounds__(256, 2) void conv_up_halo_kernel(ConvArgs a, int ti
         };
         if (a.drop.mode == 1) fused(std::integral_constant<int, 1>{});
         else fused(std::integral_constant<int, 0>{});
+        TL_STAMP(5)
         return;
     }
     // (activation, dropout mode) are wave-uniform: the whole epilogue is instantiated per pair and dispatched once
@@ -1063,6 +1081,23 @@ hipError_t launch_conv_halo5(const ConvArgs& a, hipStream_t stream) {
 #endif
         hipLaunchKernelGGL((conv_up_halo_kernel<5, 2>), dim3(tiles_m * tiles_n), dim3(256), H5::LDS_TOTAL + 1024, stream, b, tiles_x,
                            tiles_per_img, tiles_m, tiles_n, 0);
+#ifdef HALO_EXP_TIMELINE
+        if (const char* tl = dyf_form("DYF_TIMELINE_DUMP")) {  // "path:N": the stamps of the N-th fused launch of the process (eager launches only)
+            static int count = 0;
+            const char* colon = strrchr(tl, ':');
+            if (colon && ++count == atoi(colon + 1)) {
+                (void)hipStreamSynchronize(stream);
+                std::vector<unsigned long long> h((size_t)1 << 18);
+                (void)hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_halo_tl), h.size() * 8);
+                if (FILE* f = fopen(std::string(tl, colon - tl).c_str(), "wb")) {
+                    const int hdr[4] = {tiles_m * tiles_n, a.n, a.residual != nullptr, a.drop.mode};
+                    fwrite(hdr, sizeof(int), 4, f);
+                    fwrite(h.data(), 8, (size_t)std::min(tiles_m * tiles_n, 8192) * 32, f);
+                    fclose(f);
+                }
+            }
+        }
+#endif
     }
     else if (plain_epi && a.act == ACT_NONE && a.drop.mode == 0)
         hipLaunchKernelGGL((conv_up_halo_kernel<5, 1>), dim3(tiles_m * tiles_n), dim3(256), H5::LDS_TOTAL, stream, a, tiles_x,

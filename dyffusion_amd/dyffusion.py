@@ -231,6 +231,11 @@ class DYffusion(nn.Module):
         if self._engine is None or (self._engine.height, self._engine.width) != tuple(hw) or self._engine.max_batch < nb:
             opts = dict(self._engine_opts)
             opts["max_batch"] = max(opts["max_batch"], nb)
+            if self._engine is not None:
+                # the engine being replaced is destroyed NOW, not when its last Python reference goes: its captured graphs keep a
+                # hardware queue of the process (row-grouped rollouts of another engine then share the remaining ones: OISST 3 990 ->
+                # 3 330 fields/s in a bench.py that still held the old NS engine), and the networks are attached to the new one anyway
+                self._engine.close()
             self._engine = HipEngine(self.model.engine_net_config(), self._ipol_net.engine_net_config(), hw[0], hw[1], **opts)
             self.model.attach_engine(self._engine, L.NET_FORECASTER)
             self._ipol_net.attach_engine(self._engine, L.NET_INTERPOLATOR)

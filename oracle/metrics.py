@@ -1,6 +1,9 @@
 """ORACLE (test infrastructure, not product): numpy restatement of the reference's ensemble metrics,
 `src/utilities/evaluation.py:10-136`.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline may import this.
 
+PARITY STATUS: pinned for MSE / SSR (against the imported reference's own functions), DEFINITIONAL for CRPS (the reference
+delegates CRPS to xskillscore, which exists neither in this image nor in the reference tree: no output of it can be generated).
+
 Pinning: `ensemble_mse` / `spread_skill_ratio` are checked against the reference's own functions imported from
 /root/reference (tests/test_oracle_metrics.py, tests/golden/metrics_*.npz).  `crps_ensemble` lives in third-party
 dependencies that are absent here (xskillscore 0.0.24 -> properscoring 0.1 `crps_ensemble`, requirements of the

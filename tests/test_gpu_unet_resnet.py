@@ -325,8 +325,11 @@ def test_halo5_plain_epilogue_instantiation_equals_the_general_one(tmp_path, for
     assert torch.equal(outs["1"], outs["0"])
 
 
-def test_fused_groupnorm_convs_match_the_unfused_chain_and_are_reproducible(form_switch):
-    """Round 4 (csrc/gn_fused.h): GroupNorm + FiLM + SiLU + dropout (+ residual) inside the producing conv, with the statistics
+@pytest.mark.parametrize("small_tiles", ["1", "0"], ids=["gn16-16x16-tiles", "halo5-16x32-tiles"])
+def test_fused_groupnorm_convs_match_the_unfused_chain_and_are_reproducible(small_tiles, form_switch):
+    """(round 6: `small_tiles` -- the 60 x 60 / 30 x 30 levels on conv_gn16_kernel, 16 x 16-pixel tiles and three workgroups per CU, the
+    default; DYF_GN16=0 keeps them on conv_up_halo_kernel<5, 2>, 16 x 32 tiles.)
+    Round 4 (csrc/gn_fused.h): GroupNorm + FiLM + SiLU + dropout (+ residual) inside the producing conv, with the statistics
     exchanged between the workgroups of a sample INSIDE the launch, against the three-kernel chain (DYF_GN_FUSED=0, read per engine)
     on the OISST shapes at 40 rows -- conv_up_halo_kernel<5, 2> on the 60 x 60 and 30 x 30 levels, conv_igemm2_kernel<2, true> (rows of
     the 15 x 15 planes straddle the 256-pixel tiles) -- eval and with the engine's MC dropout (same masks: the streams are keyed by
@@ -342,6 +345,7 @@ def test_fused_groupnorm_convs_match_the_unfused_chain_and_are_reproducible(form
     try:
         for fused in ("1", "0"):
             form_switch.setenv("DYF_GN_FUSED", fused)
+            form_switch.setenv("DYF_GN16", small_tiles)
             form_switch.setenv("DYF_IGEMM2_MIN_TILES", "1")  # the large-batch implicit-GEMM form at 40 rows (as at 300 rows by default)
             net = mirror(P, cfg, 2, 0, 1, "fp16")
             net._own_engine(nb, (60, 60))
@@ -352,7 +356,9 @@ def test_fused_groupnorm_convs_match_the_unfused_chain_and_are_reproducible(form
             eng.form_log(False)
             print(fused, sorted(forms))
             if fused == "1":
-                assert "conv_up_halo_kernel<5>+gn_fused" in forms and "conv_igemm2_kernel<2>+gn_fused" in forms, sorted(forms)
+                tiled = "conv_gn16_kernel+gn_fused" if small_tiles == "1" else "conv_up_halo_kernel<5>+gn_fused"
+                other = "conv_up_halo_kernel<5>+gn_fused" if small_tiles == "1" else "conv_gn16_kernel+gn_fused"
+                assert tiled in forms and other not in forms and "conv_igemm2_kernel<2>+gn_fused" in forms, sorted(forms)
                 # every GroupNorm runs inside its conv (at most the four 64 -> 64 convs of the 30 x 30 level could fall below the tile
                 # threshold of conv_up_halo_kernel<5> at 40 rows: 80 tiles against the 64 it takes since round 4)
                 assert "gn_apply_part_kernel" not in forms and sum(forms.get("gn_stats_kernel+gn_apply", {}).values()) <= 4, forms
@@ -369,6 +375,7 @@ def test_fused_groupnorm_convs_match_the_unfused_chain_and_are_reproducible(form
     finally:
         form_switch.delenv("DYF_IGEMM2_MIN_TILES")
         form_switch.delenv("DYF_GN_FUSED")
+        form_switch.delenv("DYF_GN16")
     with torch.no_grad():
         want = nets.resnet_unet_forward(P, cfg, x, t, None)
     for i, nm in enumerate(("eval", "engine dropout")):
