@@ -140,6 +140,10 @@ int conv_gn16_slots(int h, int w);
 hipError_t launch_conv_gn16(const ConvArgs& a, hipStream_t stream);
 void conv_register_halo3_frag(const el16_t* wpk_dev, const el16_t* frag_dev);
 const el16_t* conv_lookup_halo3_frag(const el16_t* wpk_dev);
+// 3 x 3 convs with cout % 256 == 0 keep the 256-channel-block fragments (pack_halo3_frag) in the halo3 registry; their 64-channel-block
+// copy (pack_halo3_frag64, what conv_gn16_kernel streams) lives here
+void conv_register_frag64(const el16_t* wpk_dev, const el16_t* frag_dev);
+const el16_t* conv_lookup_frag64(const el16_t* wpk_dev);
 // enc0 on the fused stem (conv_enc0_stem.hip): persistent, weights resident in LDS, pixel fragments straight from global memory;
 // the fragments (pack_enc0_stem_frag) are registered in the halo3 registry under the composed weights' pointer
 bool conv_enc0_stem_supported(const ConvArgs& a);

@@ -891,6 +891,24 @@ hipError_t launch_conv_gn_fused(const ConvArgs& a_in, int path, hipStream_t stre
     const int cpg = G.groups > 0 ? a.cout / G.groups : 0;
     if (cpg < 8 || cpg % 8 != 0 || 64 % cpg != 0 || cpg * G.groups != a.cout) return hipSuccess;  // a group lies inside one 64-channel block
     const long long nsel = a.n_sel > 0 ? a.n_sel : a.n;
+    if (a.kh == 3 && a.kw == 3 && a.stride == 1 && a.pad == 1 && a.cout % 256 == 0) {
+        // 256-channel level on SMALL planes (15 x 15 at OISST: one 16 x 16 tile per sample): conv_gn16_kernel with four 64-channel column
+        // blocks per sample instead of conv_igemm2_kernel<2, true>'s 256-pixel x 128-channel tiles -- half the K chain per workgroup,
+        // more than twice the workgroups (400 against 176 at 100 rows).  DYF_GN16_C256=0: off
+        const bool on = !(dyf_form("DYF_GN16") && atoi(dyf_form("DYF_GN16")) == 0) && !(dyf_form("DYF_GN16_C256") && atoi(dyf_form("DYF_GN16_C256")) == 0);
+        ConvArgs b = a;
+        b.wpk_up_frag = conv_lookup_frag64(b.wpk);
+        const int slots16 = conv_gn16_slots(a.h, a.w);
+        const long long tiles16 = nsel * slots16 * (a.cout / 64);
+        const bool covers16 = 10ll * a.h * a.w >= 6ll * slots16 * 256;
+        const long long max_plane = dyf_form("DYF_GN16_C256_MAX_PLANE") ? atoll(dyf_form("DYF_GN16_C256_MAX_PLANE")) : 1024;
+        if (on && b.wpk_up_frag && covers16 && (long long)a.h * a.w <= max_plane && tiles16 >= 64 && slots16 <= GN_FUSE_MAX_SLOTS &&
+            slots16 <= G.max_slots && conv_gn16_supported(b)) {
+            b.gnf.slots = slots16;
+            *fused = true;
+            return launch_conv_gn16(b, stream);
+        }
+    }
     if (a.kh == 3 && a.kw == 3 && a.stride == 1 && a.pad == 1 && a.cout % 64 == 0 && a.cout % 256 != 0) {
         const bool h5 = !(dyf_form("DYF_HALO5") && atoi(dyf_form("DYF_HALO5")) == 0);
         const long long h5_min = dyf_form("DYF_HALO5_MIN_TILES") ? atoll(dyf_form("DYF_HALO5_MIN_TILES")) : 64;

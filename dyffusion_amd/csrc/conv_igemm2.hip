@@ -726,6 +726,7 @@ namespace {
 std::mutex g_frag_mu;
 std::unordered_map<const void*, const el16_t*> g_frag;
 std::unordered_map<const void*, const el16_t*> g_frag3;  // halo-kernel fragments of plain 3x3 convs
+std::unordered_map<const void*, const el16_t*> g_frag64; // pack_halo3_frag64 fragments of 3x3 convs whose g_frag3 entry is the 256-channel-block order
 }  // namespace
 
 void conv_register_frag(const el16_t* wpk_dev, const el16_t* frag_dev) {
@@ -737,6 +738,18 @@ void conv_unregister_frag(const void* wpk_dev) {
     std::lock_guard<std::mutex> lk(g_frag_mu);
     g_frag.erase(wpk_dev);
     g_frag3.erase(wpk_dev);
+    g_frag64.erase(wpk_dev);
+}
+
+void conv_register_frag64(const el16_t* wpk_dev, const el16_t* frag_dev) {
+    std::lock_guard<std::mutex> lk(g_frag_mu);
+    g_frag64[(const void*)wpk_dev] = frag_dev;
+}
+
+const el16_t* conv_lookup_frag64(const el16_t* wpk_dev) {
+    std::lock_guard<std::mutex> lk(g_frag_mu);
+    auto it = g_frag64.find((const void*)wpk_dev);
+    return it == g_frag64.end() ? nullptr : it->second;
 }
 
 void conv_register_halo3_frag(const el16_t* wpk_dev, const el16_t* frag_dev) {

@@ -294,6 +294,12 @@ inline dyf_status upload_conv_weights(dyf_engine* e, el16_t** out, const std::ve
         st = dev_upload(e, &frag, pf);
         if (st != DYF_OK) return st;
         conv_register_halo3_frag(*out, frag);
+        // ... and the 64-channel-block order for conv_gn16_kernel (the fused-GroupNorm 3 x 3 convs of the ResNet-UNet's 256-channel level)
+        pack_halo3_frag64(pk.data(), cout, cin, pf.data());
+        el16_t* frag64 = nullptr;
+        st = dev_upload(e, &frag64, pf);
+        if (st != DYF_OK) return st;
+        conv_register_frag64(*out, frag64);
     }
     return DYF_OK;
 }
