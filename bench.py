@@ -290,7 +290,7 @@ def bench_oisst(dev, nb=300, reps=3):
            "net_forwards_per_rollout": nf + ni, "fields_per_s": round(nb * 7 / dt, 1), "ms_per_rollout": round(1e3 * dt, 2),
            "gflop_per_field": round(fl / 7 / 1e9, 2), "whole_rollout_tflops": round(nb * fl / dt / 1e12, 1),
            "roofline": _resnet_roofline(eng, 0, nb, "level-0 3x3 weight-standardised convs 64->64 @60x60 WITH the GroupNorm + FiLM + SiLU + "
-                                                    "dropout (+ residual) of their Block fused into the epilogue (conv_up_halo_kernel<5, 2>)",
+                                                    "dropout (+ residual) of their Block fused into the epilogue (conv_gn16_kernel: 16 x 16 tiles, 3 workgroups per CU)",
                                         PEAK_BF16_TFLOPS),
            "roofline_groupnorm": _resnet_roofline(eng, 2, nb, "separate GroupNorm(8)+FiLM+SiLU+dropout(+residual) launches, 64 ch @60x60",
                                                   PEAK_BF16_TFLOPS),
