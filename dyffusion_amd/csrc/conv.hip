@@ -900,9 +900,10 @@ hipError_t launch_conv_gn_fused(const ConvArgs& a_in, int path, hipStream_t stre
         b.wpk_up_frag = conv_lookup_frag64(b.wpk);
         const int slots16 = conv_gn16_slots(a.h, a.w);
         const long long tiles16 = nsel * slots16 * (a.cout / 64);
-        const bool covers16 = 10ll * a.h * a.w >= 6ll * slots16 * 256;
+        const bool covers16 = 10ll * a.h * a.w >= 6ll * slots16 * 256 || (dyf_form("DYF_GN16_ANY_PLANE") && atoi(dyf_form("DYF_GN16_ANY_PLANE")) != 0);
         const long long max_plane = dyf_form("DYF_GN16_C256_MAX_PLANE") ? atoll(dyf_form("DYF_GN16_C256_MAX_PLANE")) : 1024;
-        if (on && b.wpk_up_frag && covers16 && (long long)a.h * a.w <= max_plane && tiles16 >= 64 && slots16 <= GN_FUSE_MAX_SLOTS &&
+        const long long c256_min = dyf_form("DYF_GN16_MIN_TILES") ? atoll(dyf_form("DYF_GN16_MIN_TILES")) : 64;
+        if (on && b.wpk_up_frag && covers16 && (long long)a.h * a.w <= max_plane && tiles16 >= c256_min && slots16 <= GN_FUSE_MAX_SLOTS &&
             slots16 <= G.max_slots && conv_gn16_supported(b)) {
             b.gnf.slots = slots16;
             *fused = true;
@@ -919,7 +920,8 @@ hipError_t launch_conv_gn_fused(const ConvArgs& a_in, int path, hipStream_t stre
             const long long g16_min = dyf_form("DYF_GN16_MIN_TILES") ? atoll(dyf_form("DYF_GN16_MIN_TILES")) : 64;
             const int slots16 = conv_gn16_slots(a.h, a.w);
             const long long tiles16 = nsel * slots16 * (a.cout / 64);
-            const bool covers16 = 10ll * a.h * a.w >= 6ll * slots16 * 256;
+            // (planes that fill less than 60 % of their tiles are left to the other forms; DYF_GN16_ANY_PLANE=1: the tests' tiny planes)
+            const bool covers16 = 10ll * a.h * a.w >= 6ll * slots16 * 256 || (dyf_form("DYF_GN16_ANY_PLANE") && atoi(dyf_form("DYF_GN16_ANY_PLANE")) != 0);
             if (g16 && b.wpk_up_frag && covers16 && tiles16 >= g16_min && slots16 <= GN_FUSE_MAX_SLOTS && slots16 <= G.max_slots &&
                 conv_gn16_supported(b)) {
                 b.gnf.slots = slots16;

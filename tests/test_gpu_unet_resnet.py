@@ -388,6 +388,51 @@ def test_fused_groupnorm_convs_match_the_unfused_chain_and_are_reproducible(smal
     assert e1 <= 4e-3
 
 
+@pytest.mark.parametrize("hw", [(32, 48), (20, 36), (16, 16), (12, 8)], ids=lambda v: "x".join(map(str, v)))
+def test_small_tile_fused_conv_on_ragged_and_tiny_planes(hw, form_switch):
+    """conv_gn16_kernel (16 x 16 tiles, one statistics slot per workgroup) away from the OISST shapes: planes that tile evenly (32 x 48),
+    ragged in both directions (20 x 36 -> 10 x 18 -> 5 x 9), exactly one tile (16 x 16) and smaller than a tile at every level
+    (12 x 8 -> 6 x 4 -> 3 x 2: a workgroup's halo is mostly out-of-image zeros, three of its four waves own no valid row).  The tile
+    threshold is forced down (3 rows would not reach 64 tiles), the 256-channel level included.  Against the fp32 oracle, against the
+    un-fused three-kernel chain on the same engine build, eval and with the engine's MC dropout; two runs agree bitwise."""
+    cfg = dict(dim=64, dim_mults=[1, 2, 4], with_time_emb=True, block_dropout=0.3, block_dropout1=0.1, attn_dropout=0.0,
+               resnet_block_groups=8, input_dropout=0.0, upsample_dims=None)
+    P = seeded_unet(64, (1, 2, 4), 2, 1, seed=77)
+    g = torch.Generator().manual_seed(sum(hw))
+    nb = 3
+    x, t = torch.randn(nb, 2, *hw, generator=g), torch.tensor([1.0, 3.0, 6.0])
+    outs = {}
+    for fused in ("1", "0"):
+        form_switch.setenv("DYF_GN_FUSED", fused)
+        form_switch.setenv("DYF_GN16_MIN_TILES", "1")
+        form_switch.setenv("DYF_GN16_ANY_PLANE", "1")  # (production leaves planes that fill < 60 % of their tiles to the other forms)
+        net = mirror(P, cfg, 2, 0, 1, "fp16")
+        net._own_engine(nb, hw)
+        eng = net._engine
+        eng.form_log(True)
+        y = net(x.to(DEV), time=t.to(DEV)).cpu()
+        forms = eng.form_log_read()
+        eng.form_log(False)
+        if fused == "1":
+            assert "conv_gn16_kernel+gn_fused" in forms, sorted(forms)
+            assert "conv_up_halo_kernel<5>+gn_fused" not in forms, sorted(forms)
+        else:
+            assert not any(k.endswith("+gn_fused") for k in forms), sorted(forms)
+        eng.seed(5)
+        yd = eng.net_forward(0, x.to(DEV), t.to(DEV), None, dropout_mode=1).cpu()
+        eng.seed(5)
+        yd2 = eng.net_forward(0, x.to(DEV), t.to(DEV), None, dropout_mode=1).cpu()
+        assert torch.equal(yd, yd2) and torch.equal(y, net(x.to(DEV), time=t.to(DEV)).cpu())
+        assert bool(torch.isfinite(y).all()) and bool(torch.isfinite(yd).all())
+        outs[fused] = (y, yd)
+        eng.close()
+    with torch.no_grad():
+        want = nets.resnet_unet_forward(P, cfg, x, t, None)
+    e_or, e_un, e_dr = rel_rms(outs["1"][0], want), rel_rms(outs["1"][0], outs["0"][0]), rel_rms(outs["1"][1], outs["0"][1])
+    print(f"{hw}: conv_gn16 vs oracle {e_or:.3e} (un-fused {rel_rms(outs['0'][0], want):.3e}); vs the un-fused chain: eval {e_un:.3e}, dropout {e_dr:.3e}")
+    assert e_or <= TOL["fp16"] and e_un <= 4e-3 and e_dr <= 4e-3
+
+
 def _invariant_engine(net, hw, max_batch, dtype="fp16"):
     from dyffusion_amd import _lib as L
     from dyffusion_amd.engine import HipEngine, upload_weights
