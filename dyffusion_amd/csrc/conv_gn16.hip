@@ -246,30 +246,63 @@ __global__ __launch_bounds__(256, 3) void conv_gn16_kernel(ConvArgs a, int tiles
             red[wave * 16 + idx] = tot;
         }
     }
-    // residual (the ResnetBlock's shortcut, added last): two 8-byte pieces per (nt, mt, g2) step, fetched one (nt, mt) group ahead
+    // residual (the ResnetBlock's shortcut, added last): two 8-byte pieces per (nt, mt, g2) step; ALL 32 registers of it are requested
+    // here, in front of the statistics exchange -- the loads (one group ahead they cost ~3 k cycles of exposed latency per tile) land
+    // while the workgroup waits for the sample's other tiles
     const bool has_res = a.residual != nullptr;
-    uint2 rq[2][4];
-    auto load_res = [&](int nt, int mt, uint2 (&r)[4]) {
-        const bool st_ok = lane_valid && orow0 + 2 * mt < a.ho;
+    uint2 rq[4][4];
+    if (has_res) {
 #pragma unroll
-        for (int g2 = 0; g2 < 2; ++g2) {
-            const size_t e0 = (size_t)(o0 + mt * mt_stride + nt * 32 + 16 * g2 + 4 * hi);
-            r[2 * g2] = st_ok ? *(const uint2*)(a.residual + e0) : make_uint2(0, 0);
-            r[2 * g2 + 1] = st_ok ? *(const uint2*)(a.residual + e0 + 8) : make_uint2(0, 0);
+        for (int s = 0; s < 4; ++s) {
+            const int nt = s >> 1, mt = s & 1;
+            const bool st_ok = lane_valid && orow0 + 2 * mt < a.ho;
+#pragma unroll
+            for (int g2 = 0; g2 < 2; ++g2) {
+                const size_t e0 = (size_t)(o0 + mt * mt_stride + nt * 32 + 16 * g2 + 4 * hi);
+                rq[s][2 * g2] = st_ok ? *(const uint2*)(a.residual + e0) : make_uint2(0, 0);
+                rq[s][2 * g2 + 1] = st_ok ? *(const uint2*)(a.residual + e0 + 8) : make_uint2(0, 0);
+            }
         }
-    };
-    if (has_res) load_res(0, 0, rq[0]);
+    }
     TL16(3)
     __syncthreads();  // the four waves' statistics are in LDS (and every wave has left the K loop)
     // Phase B: wave 0 adds the waves' values in wave order, publishes the workgroup's slot (16 granules), sweeps the sample's slots and
     // parks (A, C) of the block's 64 channels in LDS
     float* cfA = (float*)(smem + COEF16_OFF);
     float* cfC = cfA + 64;
+    // dropout keep bits of this lane's 64 elements (engine generator: one hash per pair of consecutive channels, 16-bit thresholds --
+    // the stream of act_drop_fixed), bit ((nt * 2 + mt) * 2 + g2) * 8 + t: computed inside the wait for the sample's statistics, which
+    // they do not depend on (~3 k cycles of the epilogue of a dropout launch)
+    uint32_t keep[2] = {0u, 0u};
+    auto prehash = [&]() {
+        if (a.drop.mode != 1) return;
+        const uint32_t th = a.drop.thresh16;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int nt = s >> 1, mt = s & 1;
+#pragma unroll
+            for (int g2 = 0; g2 < 2; ++g2) {
+                const uint32_t e0 = o0 + mt * mt_stride + nt * 32 + 16 * g2 + 4 * hi;
+                uint32_t bits = 0u;
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2)  // channels e0 + {0..3} and e0 + 8 + {0..3}
+#pragma unroll
+                    for (int p = 0; p < 2; ++p) {
+                        const uint32_t w = rng_pair_word(((e0 + 8 * h2 - row0) >> 1) + p, key);
+                        bits |= ((w & 0xffffu) < th ? 1u : 0u) << (4 * h2 + 2 * p);
+                        bits |= ((w >> 16) < th ? 1u : 0u) << (4 * h2 + 2 * p + 1);
+                    }
+                keep[s >> 1] |= bits << (((s & 1) * 2 + g2) * 8);
+            }
+        }
+    };
+    if (wave != 0) prehash();
     if (wave == 0) {
         if (lane < 16) {
             const float tot = ((red[lane] + red[16 + lane]) + red[32 + lane]) + red[48 + lane];
             gn_store_granule(G.gran + (((size_t)n_img * G.max_slots + t_in) * (a.cout >> 3) + tn * 8) * 2 + lane, tag, tot);
         }
+        prehash();  // (after the publication -- the other workgroups wait for it -- and before the sweep: the granules arrive meanwhile)
         const int cpg = a.cout / G.groups;
         const float2 mr = gn_fuse_sweep<16>(G.gran + ((size_t)n_img * G.max_slots * (a.cout >> 3) + tn * 8) * 2, (a.cout >> 3) * 2, G.slots,
                                             tag ^ G.test_tag_xor, cpg, 1.0 / ((double)a.ho * a.wo * cpg), G.err, lane, G.timeout_ticks);
@@ -284,35 +317,34 @@ __global__ __launch_bounds__(256, 3) void conv_gn16_kernel(ConvArgs a, int tiles
     // l and l + 32 (v_permlane32_swap), after which every lane owns 8 consecutive channels = one 16-byte store
     auto fused = [&](auto mode_c) {
         constexpr int MODE = decltype(mode_c)::value;
+        // 32-channel half outermost, pixel tiles, then the two 16-channel groups of the half: the two 32-byte pieces of a pixel's 64-byte
+        // half block are stored back to back (they leave the L2 as one 64-byte write)
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-            float ca[2][8], cc[2][8];
-#pragma unroll
-            for (int g2 = 0; g2 < 2; ++g2) {
-                const int cg0 = nt * 32 + 16 * g2 + 4 * hi;
-                const float4 a0 = *(const float4*)(cfA + cg0), a1 = *(const float4*)(cfA + cg0 + 8);
-                const float4 c0 = *(const float4*)(cfC + cg0), c1 = *(const float4*)(cfC + cg0 + 8);
-                ca[g2][0] = a0.x; ca[g2][1] = a0.y; ca[g2][2] = a0.z; ca[g2][3] = a0.w;
-                ca[g2][4] = a1.x; ca[g2][5] = a1.y; ca[g2][6] = a1.z; ca[g2][7] = a1.w;
-                cc[g2][0] = c0.x; cc[g2][1] = c0.y; cc[g2][2] = c0.z; cc[g2][3] = c0.w;
-                cc[g2][4] = c1.x; cc[g2][5] = c1.y; cc[g2][6] = c1.z; cc[g2][7] = c1.w;
-            }
+        for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
                 const int s = nt * 2 + mt;
-                if (has_res && s + 1 < 4) load_res((s + 1) >> 1, (s + 1) & 1, rq[(s + 1) & 1]);
                 const bool st_ok = lane_valid && orow0 + 2 * mt < a.ho;
 #pragma unroll
                 for (int g2 = 0; g2 < 2; ++g2) {
+                    // (A, C) of this lane's 8 channels of the 16-channel group, from LDS per use: 16 live registers instead of 64 beside
+                    // the accumulators and the prefetched residual
+                    const int cgl = nt * 32 + 16 * g2 + 4 * hi;
+                    const float4 a0 = *(const float4*)(cfA + cgl), a1 = *(const float4*)(cfA + cgl + 8);
+                    const float4 c0 = *(const float4*)(cfC + cgl), c1 = *(const float4*)(cfC + cgl + 8);
+                    const float ca[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+                    const float cc[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
                     const int cg0 = nt * 32 + 16 * g2;
-                    const uint32_t e0 = o0 + mt * mt_stride + cg0 + 4 * hi;
                     float v[8];
 #pragma unroll
-                    for (int t = 0; t < 8; ++t) v[t] = fmaf(acc[nt][mt][8 * g2 + t], ca[g2][t], cc[g2][t]);
-                    act_drop_fixed<4, ACT_SILU, MODE, true>(v, e0, row0, a.drop, key);
-                    act_drop_fixed<4, ACT_SILU, MODE, true>(v + 4, e0 + 8, row0, a.drop, key);
+                    for (int t = 0; t < 8; ++t) v[t] = act_fixed<ACT_SILU>(fmaf(acc[nt][mt][8 * g2 + t], ca[t], cc[t]));
+                    if constexpr (MODE == 1) {
+                        const uint32_t kb = keep[nt] >> ((mt * 2 + g2) * 8);
+#pragma unroll
+                        for (int t = 0; t < 8; ++t) v[t] = ((kb >> t) & 1u) ? v[t] * a.drop.scale : 0.0f;
+                    }
                     if (has_res) {
-                        const uint2 r0 = rq[s & 1][2 * g2], r1 = rq[s & 1][2 * g2 + 1];
+                        const uint2 r0 = rq[s][2 * g2], r1 = rq[s][2 * g2 + 1];
                         const uint32_t rw[4] = {r0.x, r0.y, r1.x, r1.y};
 #pragma unroll
                         for (int t = 0; t < 8; ++t) v[t] += (t & 1) ? el16_hi(rw[t >> 1]) : el16_lo(rw[t >> 1]);
@@ -326,7 +358,6 @@ __global__ __launch_bounds__(256, 3) void conv_gn16_kernel(ConvArgs a, int tiles
                     if (st_ok) *(uint4*)(a.out_el16 + (size_t)(o0 + mt * mt_stride + cg0 + 8 * hi)) = o;
                 }
             }
-        }
     };
     if (a.drop.mode == 1) fused(std::integral_constant<int, 1>{});
     else fused(std::integral_constant<int, 0>{});

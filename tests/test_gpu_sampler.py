@@ -82,6 +82,42 @@ def test_graph_replay_equals_eager_and_is_repeatable():
     assert worst <= TOL
 
 
+def test_named_kernel_timer_counts_every_launch_of_the_hbm_bound_kernels():
+    """bench.py `hbm_kernels` (north star: "HBM GB/s for the norm/activation kernels") rests on dyf_time_named_kernel_in_rollout: HIP
+    events around every launch of ONE named kernel in an eager rollout.  On a small h = 4 rollout (4 forecaster + 8 interpolator
+    forwards: cold sampling, refine on): the readout runs once per forward -- 12 launches -- with the algorithmic bytes of 12
+    readouts; a kernel the rollout does not launch reports nothing; timing does not disturb the engine (the next sample is bitwise
+    the previous one)."""
+    hp = dict(timesteps=4, forward_conditioning="none", interpolate_before_t1=True, schedule="before_t1_only",
+              sampling_type="cold", refine_intermediate_predictions=True, enable_interpolator_dropout=False,
+              num_input_channels=3)
+    mk = dict(dim=64, upsample_dims=[64, 64], outer_sample_mode="bilinear", with_time_emb=True, dropout=0.15)
+    PF, PI = seeded_pair(64, 3, 2)
+    g = torch.Generator().manual_seed(2)
+    nb = 3
+    x0, c = torch.randn(nb, 3, 23, 11, generator=g).to(DEV), torch.rand(nb, 2, 23, 11, generator=g).to(DEV)
+    m = build_dyffusion(PF, PI, mk, 3, 2, hp, max_batch=nb, use_graph=True)
+    before = m.sample(x0, static_condition=c)
+    eng = m._engine
+    nf, ni = eng.forward_counts()
+    assert (nf, ni) == (4, 8)
+    seen = {}
+    for name in ("readout_dma_kernel", "readout_mfma_kernel", "readout_regw_kernel", "stem16_rows_kernel", "stem16_kernel", "layernorm_c_vec_kernel"):
+        ms, n, by = eng.time_named_kernel_in_rollout(name, nb)
+        seen[name] = (ms, n, by)
+    print({k: (round(v[0], 4), v[1], int(v[2])) for k, v in seen.items()})
+    ms, n, by = seen["readout_dma_kernel"]
+    # the three interpolator refine forwards of h = 4 run as ONE batched forward over 3 nb rows, the two interpolations of a cold step as one
+    # paired forward: fewer launches than forwards, the same rows in total
+    assert 1 <= n <= nf + ni and ms > 0
+    # algorithmic bytes of one row: the (sparse-column) 64-channel decoder plane in, the native field out -- at most the dense plane
+    per_row = by / ((nf + ni) * nb)
+    assert 3 * 23 * 11 * 4.0 < per_row <= 64 * 64 * 64 * 2.0 + 3 * 23 * 11 * 4.0, per_row
+    assert seen["layernorm_c_vec_kernel"][1] == 0 and seen["layernorm_c_vec_kernel"][2] == 0  # a ResNet-UNet kernel: not launched here
+    after = m.sample(x0, static_condition=c)
+    assert all(torch.equal(before[k], after[k]) for k in before)
+
+
 def test_fullsize_ns_rollout_matches_reference_fields():
     """BASELINE config 2 (NS 221x42, h=16, cold, refine, dim 64 @256^2), NB=1, dropout off: t1/t8/t16 fields of the
     imported reference (fixture G6)."""

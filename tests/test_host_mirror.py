@@ -100,6 +100,40 @@ def test_library_exports_every_declared_symbol():
     assert lib.dyf_abi_version() == _lib.DYF_ABI_VERSION
 
 
+def test_kernel_form_switches_come_from_the_testing_call_only_never_from_the_environment(monkeypatch):
+    """libdyffusion_hip.so read 79 DYF_* variables from the environment (kernel forms and, for the training
+    operands, numerics, under a caller who never asked).  Now: (1) the only getenv()s left in csrc/ are DYF_VERBOSE and DYF_RCCL_LIB;
+    (2) the switch table is written through dyf_debug_set_form alone -- both builds, set / overwrite / remove / clear, and a variable
+    in the process environment does not appear in it."""
+    csrc = os.path.join(ROOT, "dyffusion_amd", "csrc")
+    seen = set()
+    for fn in os.listdir(csrc):
+        seen |= set(re.findall(r'getenv\("([A-Z0-9_]+)"\)', open(os.path.join(csrc, fn)).read()))
+    assert seen == {"DYF_VERBOSE", "DYF_RCCL_LIB"}, seen
+    monkeypatch.setenv("DYF_IGEMM2_MIN_TILES", "1")
+
+    def table(lib):
+        buf = ctypes.create_string_buffer(4096)
+        n = lib.dyf_debug_forms(buf, 4096)
+        assert n == len(buf.value)
+        return dict(kv.split("=", 1) for kv in buf.value.decode().split(";") if kv)
+
+    try:
+        for dtype in ("bf16", "fp16"):
+            lib = _lib.lib(dtype)
+            assert table(lib) == {}  # nothing from the environment
+        _lib.set_form("DYF_GN16", "0")
+        _lib.set_form("DYF_ROWS_TR", "2")
+        _lib.set_form("DYF_GN16", "1")
+        for dtype in ("bf16", "fp16"):
+            assert table(_lib.lib(dtype)) == {"DYF_GN16": "1", "DYF_ROWS_TR": "2"}
+        _lib.set_form("DYF_ROWS_TR", None)
+        assert table(_lib.lib("bf16")) == {"DYF_GN16": "1"} and _lib.forms() == {"DYF_GN16": "1"}
+    finally:
+        _lib.set_form(None)
+    assert table(_lib.lib("bf16")) == {} and table(_lib.lib("fp16")) == {}
+
+
 @pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
 def test_product_path_fails_loudly_without_gpu():
     m = _pair(4, interpolate_before_t1=True)
