@@ -518,10 +518,10 @@ def cpu_baseline(F, I):
                 best = (nt, dt)
         torch.set_num_threads(best[0])
         # 1 warm-up rollout (untimed: thread pool, oneDNN primitive cache, allocator), then >= 3 timed NB = 1 rollouts, each
-        # timed on its own so that the spread is in the line; NB = 4 (reported beside it, never the headline unless faster): 1 + 2
+        # timed on its own so that the spread is in the line; NB = 4 (reported beside it, never the headline unless faster): 1 rollout
         res, per = {}, {}
         sampler.sample_loop(f_fn, i_fn, x4[:1], c4[:1], cfg)
-        for nb, budget, min_reps, max_reps in ((1, 16.0, 3, 4), (4, 10.0, 2, 2)):
+        for nb, budget, min_reps, max_reps in ((1, 16.0, 3, 4), (4, 10.0, 1, 1)):  # (one NB = 4 rollout is 30 s on the GPU boxes' hosts)
             times, t_all = [], time.perf_counter()
             while len(times) < min_reps or (time.perf_counter() - t_all < budget and len(times) < max_reps):
                 t0 = time.perf_counter()
