@@ -81,22 +81,29 @@ static std::string g_prof_name_store;
 struct ProfRec { hipEvent_t e0, e1; double bytes; };
 static std::deque<ProfRec> g_prof_recs;
 void dyf_prof_begin(hipStream_t st, double bytes) {
+    std::lock_guard<std::mutex> lk(g_form_mu);  // (records of concurrent host threads interleave but stay whole; ONE armed name per process)
     ProfRec r{nullptr, nullptr, bytes};
     if (g_prof_recs.size() >= 16384 || hipEventCreate(&r.e0) != hipSuccess || hipEventCreate(&r.e1) != hipSuccess) return;
     (void)hipEventRecord(r.e0, st);
     g_prof_recs.push_back(r);
 }
 void dyf_prof_end(hipStream_t st) {
+    std::lock_guard<std::mutex> lk(g_form_mu);
     if (!g_prof_recs.empty()) (void)hipEventRecord(g_prof_recs.back().e1, st);
 }
-void dyf_prof_arm(const char* name) {  // nullptr disarms; pending records are dropped
+static void prof_arm_locked(const char* name) {
     for (auto& r : g_prof_recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
     g_prof_recs.clear();
     g_prof_name_store = name ? name : "";
     g_dyf_prof_name = name ? g_prof_name_store.c_str() : nullptr;
 }
+void dyf_prof_arm(const char* name) {  // nullptr disarms; pending records are dropped
+    std::lock_guard<std::mutex> lk(g_form_mu);
+    prof_arm_locked(name);
+}
 // after the stream has been synchronised: total ms, total bytes, launches of the armed name; disarms
 void dyf_prof_collect(double* total_ms, double* total_bytes, int* launches) {
+    std::lock_guard<std::mutex> lk(g_form_mu);
     double ms = 0.0, by = 0.0;
     int n = 0;
     for (auto& r : g_prof_recs) {
@@ -104,7 +111,7 @@ void dyf_prof_collect(double* total_ms, double* total_bytes, int* launches) {
         if (hipEventElapsedTime(&t, r.e0, r.e1) == hipSuccess) { ms += t; by += r.bytes; ++n; }
     }
     *total_ms = ms; *total_bytes = by; *launches = n;
-    dyf_prof_arm(nullptr);
+    prof_arm_locked(nullptr);
 }
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
