@@ -49,6 +49,11 @@ struct ConvArgs {
     int coef_div;        // samples per coefficient row (0/1: one row per sample; paired interpolator calls use nb)
     int act;
     DropSpec drop;
+    // nearest x2 upsample in front of a plain 3x3 conv (unet.py Upsample = nn.Upsample(scale_factor=2, mode="nearest") + Conv2d), fused:
+    // up_nearest != 0 -> src0 is the LOW-resolution tensor (n, h / 2, w / 2, c0) and (h, w) stay the conv's (upsampled) input size; the
+    // halo gather of conv_up_halo_kernel<5> reads pixel (y >> 1, x >> 1).  Only that form understands it: set it only when
+    // conv_plain3x3_takes_halo5() says the launch goes there (the caller materialises the upsample otherwise)
+    int up_nearest;
     const el16_t* residual;  // NHWC bf16 tensor added after activation/dropout (Residual(...) wrappers), or null
     el16_t* out_el16;    // NHWC bf16 output (or null)
     float* out_f32;      // NHWC fp32 output (GroupNorm input) (or null)
@@ -131,6 +136,9 @@ hipError_t launch_conv_halo_s2(const ConvArgs& a, hipStream_t stream);
 void pack_halo_s2_frag(const el16_t* wpk, int cout, int cin, el16_t* out);
 // plain 3x3 / s1 / p1 conv with cout % 64 == 0 on ANY plane size (SP = 5: four pixel sub-tiles per workgroup, ragged edges)
 bool conv_halo5_supported(const ConvArgs& a);
+// launch_conv(a, 1, ...) of this plain 3x3 conv (no statistics, no fused GroupNorm) will run on conv_up_halo_kernel<5> -- the one form
+// that can take ConvArgs::up_nearest
+bool conv_plain3x3_takes_halo5(const ConvArgs& a);
 hipError_t launch_conv_halo5(const ConvArgs& a, hipStream_t stream);
 void pack_halo3_frag64(const el16_t* wpk, int cout, int cin, el16_t* out);
 // the same convs WITH the fused GroupNorm epilogue on 16 x 16-pixel tiles, three workgroups per CU (conv_gn16.hip); fragments of

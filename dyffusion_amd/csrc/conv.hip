@@ -750,6 +750,29 @@ hipError_t conv_init() {
     return e;
 }
 
+// plain 3x3 / s1 convs with 64 or 128 (a multiple of 64 that is not one of 256) output channels on planes of any size: SP = 5 of the
+// halo kernel, when the 16 x 32 tiles cover the plane reasonably (>= 60 %) and the launch has enough of them
+static bool halo5_policy(const ConvArgs& a) {
+    const bool h5_all = dyf_form("DYF_HALO5_ALL") && atoi(dyf_form("DYF_HALO5_ALL")) != 0;
+    if (!(!a.up2x && a.kh == 3 && a.kw == 3 && a.stride == 1 && a.cout % 64 == 0 && (a.cout % 256 != 0 || h5_all) && a.out_f32 == nullptr &&
+          a.residual == nullptr))
+        return false;
+    if (dyf_form("DYF_HALO5") && atoi(dyf_form("DYF_HALO5")) == 0) return false;
+    const long long h5_min = dyf_form("DYF_HALO5_MIN_TILES") ? atoll(dyf_form("DYF_HALO5_MIN_TILES")) : 64;
+    const long long nsel = a.n_sel > 0 ? a.n_sel : a.n;
+    ConvArgs b = a;
+    b.wpk_up_frag = conv_lookup_halo3_frag(b.wpk);
+    const long long ty = (a.h + 15) / 16, tx = (a.w + 31) / 32;
+    const long long tiles5 = nsel * ty * tx * (a.cout / 64);
+    const bool covers = 10ll * a.h * a.w >= 6ll * ty * 16 * tx * 32;
+    return b.wpk_up_frag && covers && tiles5 >= h5_min && conv_halo5_supported(b);
+}
+
+bool conv_plain3x3_takes_halo5(const ConvArgs& a) {
+    // (the forms launch_conv_stats tries BEFORE SP = 5 need up2x or cout % 256 == 0: a conv that passes halo5_policy reaches it)
+    return conv_mfma_supported(a) && a.gn_part == nullptr && a.gnf.gran == nullptr && halo5_policy(a);
+}
+
 hipError_t launch_conv(const ConvArgs& a, int path, hipStream_t stream) {
     if (a.gn_part == nullptr) return launch_conv_stats(a, path, stream, nullptr);
     ConvArgs b = a;  // statistics are only produced through launch_conv_stats (the caller must learn whether they were)
@@ -764,6 +787,8 @@ hipError_t launch_conv_stats(const ConvArgs& a_in, int path, hipStream_t stream,
     a.gn_part = nullptr;  // only the form below that produces statistics sees the buffer
     a.gn_slots = 0;
     const long long nsel = a.n_sel > 0 ? a.n_sel : a.n;  // rows the kernel form is chosen for (ConvArgs::n_sel)
+    // a fused nearest upsample exists in ONE form: refuse rather than read a low-resolution tensor as the full-size one
+    if (a.up_nearest && !(path == 1 && conv_mfma_supported(a) && halo5_policy(a) && a.h % 2 == 0 && a.w % 2 == 0 && a.c1 == 0)) return hipErrorInvalidValue;
     if (path == 1 && conv_mfma_supported(a)) {
         const bool use_halo = !(dyf_form("DYF_UP_HALO") && atoi(dyf_form("DYF_UP_HALO")) == 0);
         // halo form from 32 x 32 low-res planes on; below that (dec2: 16 x 16, 2 tiles per image) the materialised upsample +
@@ -795,17 +820,11 @@ hipError_t launch_conv_stats(const ConvArgs& a_in, int path, hipStream_t stream,
         // 15 x 15).  DYF_HALO5=0 disables, DYF_HALO5_MIN_TILES sets the smallest launch (64 tiles since round 4: with the GroupNorm
         // fused into this form a small launch also saves the three GroupNorm kernels behind the implicit-GEMM fallback -- OISST
         // shapes at 38 / 75 rows +5.8 / +3 % against the 256 of round 3).
-        if (!a.up2x && a.kh == 3 && a.kw == 3 && a.stride == 1 && a.cout % 64 == 0 && (a.cout % 256 != 0 || h5_all) && a.out_f32 == nullptr &&
-            a.residual == nullptr) {
-            const bool h5 = !(dyf_form("DYF_HALO5") && atoi(dyf_form("DYF_HALO5")) == 0);
-            const long long h5_min = dyf_form("DYF_HALO5_MIN_TILES") ? atoll(dyf_form("DYF_HALO5_MIN_TILES")) : 64;
-            if (h5) {
+        if (halo5_policy(a)) {
+            {
                 ConvArgs b = a;
                 b.wpk_up_frag = conv_lookup_halo3_frag(b.wpk);
-                const long long ty = (a.h + 15) / 16, tx = (a.w + 31) / 32;
-                const long long tiles5 = nsel * ty * tx * (a.cout / 64);
-                const bool covers = 10ll * a.h * a.w >= 6ll * ty * 16 * tx * 32;
-                if (b.wpk_up_frag && covers && tiles5 >= h5_min && conv_halo5_supported(b)) {
+                {
                     if (gn_part && a.act == ACT_NONE && a.drop.mode == 0) {  // statistics of the raw conv output
                         b.gn_part = gn_part;
                         b.gn_slots = conv_halo5_gn_slots(a.h, a.w);

@@ -179,7 +179,8 @@ __global__ __launch_bounds__(256, 2) void conv_up_halo_kernel(ConvArgs a, int ti
     const int ntaps = H::S2 ? 4 : 9;
 
     const size_t npix = (size_t)a.n * a.h * a.w;
-    const auto rsrc_a0 = __builtin_amdgcn_make_buffer_rsrc((void*)a.src0, 0, (int)(unsigned)(npix * a.c0 * 2), 0x00020000);
+    // (SP = 5 with ConvArgs::up_nearest: src0 holds the (h / 2) x (w / 2) planes the gather reads at (y >> 1, x >> 1))
+    const auto rsrc_a0 = __builtin_amdgcn_make_buffer_rsrc((void*)a.src0, 0, (int)(unsigned)((SP == 5 && a.up_nearest ? npix / 4 : npix) * a.c0 * 2), 0x00020000);
     const auto rsrc_a1 = __builtin_amdgcn_make_buffer_rsrc((void*)(a.c1 ? a.src1 : a.src0), 0,
                                                            (int)(unsigned)(npix * (a.c1 ? a.c1 : a.c0) * 2), 0x00020000);
     const auto rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.wpk_up_frag, 0,
@@ -208,6 +209,8 @@ __global__ __launch_bounds__(256, 2) void conv_up_halo_kernel(ConvArgs a, int ti
         // SP = 3: halo pixel (y, x) of parity plane (0, 0) is input pixel (2y, 2x); the plane offset is added per chunk
         unsigned off = (H::S2 ? (unsigned)((n_img * a.h + 2 * y) * a.w + 2 * x) : (unsigned)((n_img * a.h + y) * a.w + x)) *
                            (unsigned)(a.c0 * 2) + gch * 16;  // c0 == c1 (checked on host)
+        if (SP == 5 && a.up_nearest)  // nn.Upsample(scale_factor=2, mode="nearest") folded into the gather: input pixel (y, x) = low-res (y >> 1, x >> 1)
+            off = (unsigned)((n_img * (a.h >> 1) + (y >> 1)) * (a.w >> 1) + (x >> 1)) * (unsigned)(a.c0 * 2) + gch * 16;
         if (H::PLAIN && (yy != y || xx != x)) off = 0xFFFFFFFFu;  // plain convs: zero padding = out-of-range DMA offset
         return off;
     };
@@ -1073,6 +1076,7 @@ hipError_t launch_conv_halo5(const ConvArgs& a, hipStream_t stream) {
     const int tiles_x = (a.w + H5::TW - 1) / H5::TW, tiles_per_img = tiles_x * ((a.h + H5::TH - 1) / H5::TH);
     const int tiles_m = a.n * tiles_per_img, tiles_n = a.cout / 64;
     dyf_form_note(a.gnf.gran ? "conv_up_halo_kernel<5>+gn_fused" : "conv_up_halo_kernel<5>", a.n);
+    if (a.up_nearest) dyf_form_note("conv_up_halo_kernel<5>+nearest_up", a.n);
     const bool plain_epi = !(dyf_form("DYF_HALO5_PLAIN_EPI") && atoi(dyf_form("DYF_HALO5_PLAIN_EPI")) == 0);
     if (a.gnf.gran != nullptr) {  // GroupNorm fused: + 1 KB of LDS for the per-channel (A, C) table
         ConvArgs b = a;

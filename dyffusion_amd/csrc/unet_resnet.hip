@@ -103,9 +103,10 @@ struct DropCtx {  // walks the dropout sites in execution order (same order as t
 dyf_status rconv(dyf_engine* e, const el16_t* s0, int c0, const el16_t* s1, int c1, int n, int h, int w, int k, int stride,
                  int pad, int cout, const el16_t* wpk, const float* coef_a, const float* coef_c, int coef_stride, int act,
                  const DropSpec& drop, const el16_t* residual, el16_t* out, hipStream_t st, float* gn_part = nullptr,
-                 int* gn_slots = nullptr) {
+                 int* gn_slots = nullptr, int up_nearest = 0) {
     ConvArgs a{};
     a.src0 = s0; a.c0 = c0; a.src1 = s1; a.c1 = c1; a.n = n; a.h = h; a.w = w;
+    a.up_nearest = up_nearest;  // s0 is the (h / 2) x (w / 2) tensor (only after rconv_nearest_fusable said yes)
     a.ho = (h + 2 * pad - k) / stride + 1; a.wo = (w + 2 * pad - k) / stride + 1;
     a.kh = k; a.kw = k; a.stride = stride; a.pad = pad; a.cout = cout; a.wpk = wpk;
     a.coef_a = coef_a; a.coef_c = coef_c; a.coef_stride = coef_stride; a.act = act; a.drop = drop;
@@ -124,6 +125,19 @@ dyf_status rconv(dyf_engine* e, const el16_t* s0, int c0, const el16_t* s1, int 
         HIP_TRY(e, launch_conv(a, path, st));
     }
     return DYF_OK;
+}
+
+// the plain 3x3 conv behind a nearest x2 upsample (output plane h x w) will run on the one form that folds the upsample into its gather
+bool rconv_nearest_fusable(dyf_engine* e, int c0, int n, int h, int w, int cout, const el16_t* wpk) {
+    if (dyf_form("DYF_FUSE_NEAREST") && atoi(dyf_form("DYF_FUSE_NEAREST")) == 0) return false;  // A/B + parity test
+    if (!e->cfg.enable_mfma || (h & 1) || (w & 1)) return false;
+    ConvArgs a{};
+    a.src0 = (const el16_t*)wpk;  // (any non-null pointer: the predicates look at shapes)
+    a.c0 = c0; a.n = n; a.h = h; a.w = w; a.ho = h; a.wo = w; a.kh = 3; a.kw = 3; a.stride = 1; a.pad = 1; a.cout = cout; a.wpk = wpk;
+    a.out_el16 = (el16_t*)wpk;
+    a.n_sel = e->cfg.batch_invariant ? 2 * e->cfg.max_batch : 0;
+    if (e->form_rows_scale > 1 && !e->cfg.batch_invariant) a.n_sel = n * e->form_rows_scale;
+    return conv_plain3x3_takes_halo5(a);
 }
 
 std::vector<el16_t> pack_conv(const float* w, int cout, int cin, int k) {
@@ -697,10 +711,18 @@ dyf_status rn_forward(dyf_engine* e, int which, const Source* srcs, int nsrc, in
         const SampW& s = r->ups[u];
         el16_t* xu = pool.get();
         if (s.nearest_up) {
-            el16_t* up = pool.get();
-            HIP_TRY(e, launch_up2x_nearest(y3, nb, hh, ww, dout, up, st));
-            TRY(rconv(e, up, dout, nullptr, 0, nb, 2 * hh, 2 * ww, 3, 1, 1, s.cout, s.w, r->ones, s.b, 0, ACT_NONE, DropSpec{}, nullptr, xu, st));
-            pool.put(up);
+            // Upsample = nearest x2 + 3x3 conv (unet.py): when the conv runs on conv_up_halo_kernel<5> its halo gather reads the low-res
+            // tensor at (y >> 1, x >> 1) -- no materialised upsample (a quarter of the halo traffic, one launch less); otherwise through
+            // up2x_nearest_vec_kernel as before
+            if (rconv_nearest_fusable(e, dout, nb, 2 * hh, 2 * ww, s.cout, s.w)) {
+                TRY(rconv(e, y3, dout, nullptr, 0, nb, 2 * hh, 2 * ww, 3, 1, 1, s.cout, s.w, r->ones, s.b, 0, ACT_NONE, DropSpec{}, nullptr, xu, st,
+                          nullptr, nullptr, 1));
+            } else {
+                el16_t* up = pool.get();
+                HIP_TRY(e, launch_up2x_nearest(y3, nb, hh, ww, dout, up, st));
+                TRY(rconv(e, up, dout, nullptr, 0, nb, 2 * hh, 2 * ww, 3, 1, 1, s.cout, s.w, r->ones, s.b, 0, ACT_NONE, DropSpec{}, nullptr, xu, st));
+                pool.put(up);
+            }
         } else {
             TRY(rconv(e, y3, dout, nullptr, 0, nb, hh, ww, 3, 1, 1, s.cout, s.w, r->ones, s.b, 0, ACT_NONE, DropSpec{}, nullptr, xu, st));
         }

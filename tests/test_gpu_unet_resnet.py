@@ -433,6 +433,40 @@ def test_small_tile_fused_conv_on_ragged_and_tiny_planes(hw, form_switch):
     assert e_or <= TOL["fp16"] and e_un <= 4e-3 and e_dr <= 4e-3
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_nearest_upsample_folded_into_the_conv_gather_changes_no_bit(dtype, form_switch):
+    """Round 6: `Upsample` of unet.py = nn.Upsample(scale_factor=2, mode="nearest") + 3x3 conv.  When that conv runs on
+    conv_up_halo_kernel<5> its halo DMA reads the LOW-resolution tensor at (y >> 1, x >> 1) (ConvArgs::up_nearest): no materialised
+    upsample, one launch less.  Same values through the same arithmetic: against DYF_FUSE_NEAREST=0 (up2x_nearest_vec_kernel + conv) the
+    forward must agree BITWISE, eval and with the engine's MC dropout, on the OISST shapes (even planes 30 -> 60 and 15 -> 30 are not:
+    15 x 15 -> 30 x 30 has an odd source, the upsampled plane is even) and on a plane that is ragged against the 16 x 32 tiles (28 x 60:
+    7 x 15 -> 14 x 30 -> 28 x 60)."""
+    cfg = dict(dim=64, dim_mults=[1, 2, 4], with_time_emb=True, block_dropout=0.3, block_dropout1=0.1, attn_dropout=0.0,
+               resnet_block_groups=8, input_dropout=0.0, upsample_dims=None)
+    P = seeded_unet(64, (1, 2, 4), 2, 1, seed=5)
+    for hw, nb in (((60, 60), 40), ((28, 60), 24)):
+        g = torch.Generator().manual_seed(6)
+        x, t = torch.randn(nb, 2, *hw, generator=g), (torch.arange(nb) % 7 + 1).float()
+        outs = {}
+        for fuse in ("1", "0"):
+            form_switch.setenv("DYF_FUSE_NEAREST", fuse)
+            form_switch.setenv("DYF_HALO5_MIN_TILES", "1")
+            net = mirror(P, cfg, 2, 0, 1, dtype)
+            net._own_engine(nb, hw)
+            eng = net._engine
+            eng.form_log(True)
+            y = net(x.to(DEV), time=t.to(DEV)).cpu()
+            forms = eng.form_log_read()
+            eng.form_log(False)
+            assert ("conv_up_halo_kernel<5>+nearest_up" in forms) == (fuse == "1"), sorted(forms)
+            eng.seed(3)
+            yd = eng.net_forward(0, x.to(DEV), t.to(DEV), None, dropout_mode=1).cpu()
+            outs[fuse] = (y, yd)
+            eng.close()
+        assert torch.equal(outs["1"][0], outs["0"][0]) and torch.equal(outs["1"][1], outs["0"][1]), hw
+        assert bool(torch.isfinite(outs["1"][0]).all()) and float(outs["1"][0].std()) > 0
+
+
 def _invariant_engine(net, hw, max_batch, dtype="fp16"):
     from dyffusion_amd import _lib as L
     from dyffusion_amd.engine import HipEngine, upload_weights
