@@ -99,19 +99,22 @@ __global__ __launch_bounds__(256, 3) void conv_gn16_kernel(ConvArgs a, int tiles
             const int yy = ty0 - 1 + hy, xx = tx0 - 1 + hx;
             const int gch = (lane & 7) ^ HKEY16(hp);
             const bool inside = yy >= 0 && yy < a.h && xx >= 0 && xx < a.w;
-            h_reg[j] = inside ? (unsigned)((n_img * a.h + yy) * a.w + xx) * (unsigned)(a.c0 * 2) + (unsigned)(gch * 16) : 0xFFFFFFFFu;
+            // (pixel index | swizzled chunk << 28: the byte offset is formed per chunk -- the two sources of a concatenated input have
+            // different pixel strides, c0 and c1 channels)
+            h_reg[j] = inside ? (unsigned)((n_img * a.h + yy) * a.w + xx) | ((unsigned)gch << 28) : 0xFFFFFFFFu;
         }
     }
     auto issue_halo = [&](int chunk) {
         const int cb = chunk << 6;
-        const bool second = cb >= a.c0;  // c1 == c0 (checked on host)
+        const bool second = cb >= a.c0;  // torch.cat([src0, src1], dim=channels): chunks [0, c0 / 64) from src0, the rest from src1
         const unsigned coff = (unsigned)((second ? cb - a.c0 : cb) * 2);
+        const unsigned pstride = (unsigned)((second ? a.c1 : a.c0) * 2);
 #pragma unroll
         for (int j = 0; j < PER_WAVE16; ++j) {
             const int i = j * 4 + wave;
             if (i < INSTR16) {
                 unsigned vo = h_reg[j];
-                if (vo != 0xFFFFFFFFu) vo += coff;
+                if (vo != 0xFFFFFFFFu) vo = (vo & 0x0FFFFFFFu) * pstride + (vo >> 28) * 16u + coff;
                 if (second)
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a1, LDS_PTR(smem + i * 1024), 16, vo, 0, 0, 0);
                 else
@@ -366,11 +369,16 @@ __global__ __launch_bounds__(256, 3) void conv_gn16_kernel(ConvArgs a, int tiles
 #endif
 }
 
-// the shapes conv_up_halo_kernel<5> takes (plain 3 x 3 / stride 1 / pad 1, channels in whole 64-blocks, fragments of
-// pack_halo3_frag64 in ConvArgs::wpk_up_frag), with the fused GroupNorm requested
+// plain 3 x 3 / stride 1 / pad 1, channels in whole 64-blocks, fragments of pack_halo3_frag64 in ConvArgs::wpk_up_frag, the fused
+// GroupNorm requested
 bool conv_gn16_supported(const ConvArgs& a) {
-    if (!conv_halo5_supported(a) || a.gnf.gran == nullptr) return false;
-    return (a.c1 == 0 || a.c1 == a.c0) && a.h >= 1 && a.w >= 1;
+    if (a.gnf.gran == nullptr || a.up2x || a.up_nearest || a.wpk_up_frag == nullptr || a.out_el16 == nullptr || a.out_f32 != nullptr) return false;
+    if (a.kh != 3 || a.kw != 3 || a.stride != 1 || a.pad != 1 || a.pix_pitch0 != 0 || a.ho != a.h || a.wo != a.w || a.h < 1 || a.w < 1) return false;
+    // two sources of ANY 64-multiples (the up path's cat([x, skip]): 256 + 128, 128 + 64, 64 + 64); conv_up_halo_kernel<5> needs c1 == c0
+    if (!(a.c0 > 0 && a.c0 % 64 == 0 && a.c1 % 64 == 0 && a.cout % 64 == 0)) return false;
+    const size_t npix = (size_t)a.n * a.h * a.w;
+    return npix < (1u << 28) && npix * (size_t)std::max(a.c0, a.c1) * 2 < 0x7F000000ull && (size_t)a.cout * 16 * (a.c0 + a.c1) * 2 < 0x7F000000ull &&
+           (size_t)a.n * a.ho * a.wo * a.cout < 0xFFFFFFF0ull;
 }
 
 int conv_gn16_slots(int h, int w) { return ((w + T16 - 1) / T16) * ((h + T16 - 1) / T16); }

@@ -237,7 +237,7 @@ def test_nb160_forward_block_outputs_match_the_oracle_taps():
 # (round 4, csrc/gn_fused.h: in-launch statistics exchange between the workgroups of a sample, no GroupNorm kernel at all) -- none
 # of which a 2-row parity test launches.  With INJECTED dropout masks the engine keeps to the un-fused chain (statistics from the
 # conv epilogue + gn_apply_part_kernel, gn_stats + gn_apply on the 15 x 15 level).  Reference: src/models/unet.py:58-109, 266-315.
-OISST_FORMS = ["conv_gn16_kernel+gn_fused", "conv_igemm2_kernel<2>+gn_fused"]  # (round 6: the 16 x 16-tile form took the 60^2 / 30^2 levels from conv_up_halo_kernel<5, 2>)
+OISST_FORMS = ["conv_gn16_kernel+gn_fused"]  # (round 6: the 16 x 16-tile form took every fused conv -- 60^2 / 30^2 / 15^2, single and two-source -- from conv_up_halo_kernel<5, 2> / conv_igemm2_kernel<2, true>)
 OISST_FORMS_UNFUSED = ["conv_up_halo_kernel<5>", "conv_igemm2_kernel<2>", "gn_apply_part_kernel", "gn_stats_kernel+gn_apply"]
 GN_KERNELS = ["gn_apply_part_kernel", "gn_stats_kernel+gn_apply", "gn_finalize_part_kernel+gn_apply"]
 OISST_TOL = {"fp16": (4e-3, 1e-2), "bf16": (2e-2, None)}  # (per forward, per field over the T=32 rollout: fp16 only)

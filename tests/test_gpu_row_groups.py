@@ -86,7 +86,7 @@ def test_oisst_nb300_grouped_rollout_rows_match_the_oracle(dtype):
     forms = eng.form_log_read()
     eng.form_log(False)
     # the launches are those of 100-row shares, GroupNorm fused into the convs (csrc/gn_fused.h)
-    for f in ("conv_gn16_kernel+gn_fused", "conv_igemm2_kernel<2>+gn_fused"):
+    for f in ("conv_gn16_kernel+gn_fused",):
         assert f in forms and 100 in forms[f], (f, forms.get(f))
     assert all(nb not in v for v in forms.values()), forms
     want = oracle_grouped_rows(cfg, PF, PI, hp, x0, rows)
