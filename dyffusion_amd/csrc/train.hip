@@ -792,6 +792,55 @@ __global__ void t_dropout_map(const float* x, float* y, int n, long long per, fl
     y[i] = rng_keep((uint32_t)(i - (long long)b * per), rk, thresh16) ? x[i] * scale : 0.0f;
 }
 
+// Element-wise passes over an NHWC tape: four channels per lane when the channel count and the pointers allow (grid.y = sample, so no
+// 64-bit division; the tensor, gamma / beta, the FiLM pair and the BatchNorm statistics as 16-byte loads issued together), one element
+// per lane otherwise.  The arithmetic per element is the same expression either way.
+struct TNormQuad {
+    float mu[4], rs[4], ga[4], be[4], sc[4], sh[4];
+    float s1[4], s2[4];  // backward only
+};
+__device__ __forceinline__ void t_f4(const float* p, float* o) {
+    const float4 v = *(const float4*)p;
+    o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+}
+__device__ __forceinline__ void t_norm_quad(const TNorm& a, int b, int c, const float* S1, const float* S2, TNormQuad& q) {
+    t_f4(a.gamma + c, q.ga);
+    t_f4(a.beta + c, q.be);
+    if (a.ss) {
+        t_f4(a.ss + (size_t)b * 2 * a.C + c, q.sc);
+        t_f4(a.ss + (size_t)b * 2 * a.C + a.C + c, q.sh);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) q.sc[k] = q.sh[k] = 0.0f;
+    }
+    if (!a.gn) {
+        t_f4(a.mean + c, q.mu);
+        t_f4(a.rstd + c, q.rs);
+        if (S1) {
+            t_f4(S1 + c, q.s1);
+            t_f4(S2 + c, q.s2);
+        }
+    } else {
+        const int cpg = a.C / a.groups;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int idx = b * a.groups + ((cpg & 3) == 0 ? c / cpg : (c + k) / cpg);
+            q.mu[k] = a.mean[idx];
+            q.rs[k] = a.rstd[idx];
+            if (S1) {
+                q.s1[k] = S1[idx];
+                q.s2[k] = S2[idx];
+            }
+        }
+    }
+}
+__device__ __forceinline__ RngKey t_row_stream(const TNorm& a, int b) {
+    return a.drop ? rng_stream_key(RngKey{a.row_keys[2 * b], a.row_keys[2 * b + 1]}, a.salt) : RngKey{0u, 0u};
+}
+__device__ __forceinline__ float t_keep_rk(const TNorm& a, const RngKey& rk, uint32_t e_in_row) {
+    if (!a.drop) return 1.0f;
+    return rng_keep(e_in_row, rk, a.thresh16) ? a.drop_scale : 0.0f;
+}
 __global__ void t_norm_fwd(TNorm a, const float* z, float* y) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long per = (long long)a.hw * a.C;
@@ -801,6 +850,37 @@ __global__ void t_norm_fwd(TNorm a, const float* z, float* y) {
     float v = (z[i] - a.mean[idx]) * a.rstd[idx] * a.gamma[c] + a.beta[c];
     if (a.ss) v = v * (1.0f + a.ss[(size_t)b * 2 * a.C + c]) + a.ss[(size_t)b * 2 * a.C + a.C + c];
     y[i] = t_act(v, a.act) * t_keep(a, b, (uint32_t)(i - (long long)b * per));
+}
+__global__ __launch_bounds__(256) void t_norm_fwd4(TNorm a, const float* z, float* y) {
+    const uint32_t per = (uint32_t)a.hw * (uint32_t)a.C;
+    const uint32_t e = (blockIdx.x * 256u + threadIdx.x) * 4u;
+    if (e >= per) return;
+    const int b = blockIdx.y, c = (int)(e % (uint32_t)a.C);
+    const size_t i = (size_t)b * per + e;
+    float zv[4], r[4];
+    t_f4(z + i, zv);
+    TNormQuad q;
+    t_norm_quad(a, b, c, nullptr, nullptr, q);
+    const RngKey rk = t_row_stream(a, b);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float v = (zv[k] - q.mu[k]) * q.rs[k] * q.ga[k] + q.be[k];
+        if (a.ss) v = v * (1.0f + q.sc[k]) + q.sh[k];
+        r[k] = t_act(v, a.act) * t_keep_rk(a, rk, e + k);
+    }
+    *(float4*)(y + i) = make_float4(r[0], r[1], r[2], r[3]);
+}
+inline bool t_vec4_ok(int C, const void* p0, const void* p1 = nullptr, const void* p2 = nullptr) {
+    return (C & 3) == 0 && (((uintptr_t)p0 | (uintptr_t)p1 | (uintptr_t)p2) & 15) == 0;
+}
+inline bool t_norm_vec4_ok(const TNorm& a) {
+    return (a.C & 3) == 0 && (long long)a.hw * a.C < (1ll << 32) && a.n <= 65535 &&
+           (((uintptr_t)a.mean | (uintptr_t)a.rstd | (uintptr_t)a.gamma | (uintptr_t)a.beta | (uintptr_t)a.ss) & 15) == 0;
+}
+inline void launch_t_norm_fwd(const TNorm& a, const float* z, float* y, hipStream_t st) {
+    const long long per = (long long)a.hw * a.C;
+    if (t_norm_vec4_ok(a) && t_vec4_ok(a.C, z, y)) hipLaunchKernelGGL(t_norm_fwd4, dim3(nblk(per / 4), a.n), dim3(256), 0, st, a, z, y);
+    else hipLaunchKernelGGL(t_norm_fwd, dim3(nblk(per * a.n)), dim3(256), 0, st, a, z, y);
 }
 
 // backward reductions, per (sample, channel) over the plane:
@@ -899,6 +979,35 @@ __global__ void t_norm_bwd_apply(TNorm a, const float* z, const float* dy, const
     const float dbn = dy[i] * t_keep(a, b, (uint32_t)(i - (long long)b * per)) * t_dact(u, a.act) * (1.0f + sc);
     dz[i] = a.rstd[idx] * (a.gamma[c] * dbn - (S1[idx] + xh * S2[idx]) * inv_count);
 }
+__global__ __launch_bounds__(256) void t_norm_bwd_apply4(TNorm a, const float* z, const float* dy, const float* S1, const float* S2, float inv_count,
+                                                         float* dz) {
+    const uint32_t per = (uint32_t)a.hw * (uint32_t)a.C;
+    const uint32_t e = (blockIdx.x * 256u + threadIdx.x) * 4u;
+    if (e >= per) return;
+    const int b = blockIdx.y, c = (int)(e % (uint32_t)a.C);
+    const size_t i = (size_t)b * per + e;
+    float zv[4], dv[4], r[4];
+    t_f4(z + i, zv);
+    t_f4(dy + i, dv);
+    TNormQuad q;
+    t_norm_quad(a, b, c, S1, S2, q);
+    const RngKey rk = t_row_stream(a, b);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float xh = (zv[k] - q.mu[k]) * q.rs[k], v = xh * q.ga[k] + q.be[k];
+        const float u = v * (1.0f + q.sc[k]) + q.sh[k];
+        const float dbn = dv[k] * t_keep_rk(a, rk, e + k) * t_dact(u, a.act) * (1.0f + q.sc[k]);
+        r[k] = q.rs[k] * (q.ga[k] * dbn - (q.s1[k] + xh * q.s2[k]) * inv_count);
+    }
+    *(float4*)(dz + i) = make_float4(r[0], r[1], r[2], r[3]);
+}
+inline void launch_t_norm_bwd_apply(const TNorm& a, const float* z, const float* dy, const float* S1, const float* S2, float inv_count, float* dz,
+                                    hipStream_t st) {
+    const long long per = (long long)a.hw * a.C;
+    if (t_norm_vec4_ok(a) && t_vec4_ok(a.C, z, dy, dz) && t_vec4_ok(0, S1, S2))
+        hipLaunchKernelGGL(t_norm_bwd_apply4, dim3(nblk(per / 4), a.n), dim3(256), 0, st, a, z, dy, S1, S2, inv_count, dz);
+    else hipLaunchKernelGGL(t_norm_bwd_apply, dim3(nblk(per * a.n)), dim3(256), 0, st, a, z, dy, S1, S2, inv_count, dz);
+}
 
 // ------------------------------------------------------------------------------------------------ small dense layers (time MLP, FiLM heads)
 // y[r][o] = b[o] + sum_k f(x[r][k]) * W[o][k];  f = identity (pre = 0) or SiLU (pre = 1)
@@ -990,13 +1099,22 @@ __global__ void t_gelu_bwd(const float* x, long long n, float* d) {  // d *= gel
 }
 
 // ------------------------------------------------------------------------------------------------ element-wise helpers
-__global__ void t_concat2(const float* a, int ca, const float* b, int cb, long long pixels, float* out) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+// (V = 4: channel quads; ca, cb multiples of 4)
+template <int V>
+__global__ __launch_bounds__(256) void t_concat2(const float* a, int ca, const float* b, int cb, long long pixels, float* out) {
+    const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * V;
     const int C = ca + cb;
     if (i >= pixels * C) return;
     const int c = (int)(i % C);
     const long long p = i / C;
-    out[i] = c < ca ? a[p * ca + c] : b[p * cb + (c - ca)];
+    const float* src = c < ca ? a + p * ca + c : b + p * cb + (c - ca);
+    if (V == 4) *(float4*)(out + i) = *(const float4*)src;
+    else out[i] = *src;
+}
+inline void launch_t_concat2(const float* a, int ca, const float* b, int cb, long long pixels, float* out, hipStream_t st) {
+    const long long total = pixels * (ca + cb);
+    if (t_vec4_ok(ca | cb, a, b, out)) hipLaunchKernelGGL(t_concat2<4>, dim3(nblk(total / 4)), dim3(256), 0, st, a, ca, b, cb, pixels, out);
+    else hipLaunchKernelGGL(t_concat2<1>, dim3(nblk(total)), dim3(256), 0, st, a, ca, b, cb, pixels, out);
 }
 // split the gradient of cat[a, b]: da = d[..., :ca] (assign), db += d[..., ca:]
 __global__ void t_split2(const float* d, int ca, int cb, long long pixels, float* da, float* db) {
@@ -1008,9 +1126,22 @@ __global__ void t_split2(const float* d, int ca, int cb, long long pixels, float
     if (c < ca) da[p * ca + c] = d[i];
     else db[p * cb + (c - ca)] += d[i];
 }
-__global__ void t_add(float* a, const float* b, long long n) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) a[i] += b[i];
+template <int V>
+__global__ __launch_bounds__(256) void t_add(float* a, const float* b, long long n) {
+    const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * V;
+    if (V == 4 && i + 3 < n) {
+        float4 x = *(float4*)(a + i);
+        const float4 y = *(const float4*)(b + i);
+        x.x += y.x; x.y += y.y; x.z += y.z; x.w += y.w;
+        *(float4*)(a + i) = x;
+        return;
+    }
+    for (int k = 0; k < V; ++k)
+        if (i + k < n) a[i + k] += b[i + k];
+}
+inline void launch_t_add(float* a, const float* b, long long n, hipStream_t st) {
+    if (t_vec4_ok(0, a, b)) hipLaunchKernelGGL(t_add<4>, dim3(nblk((n + 3) / 4)), dim3(256), 0, st, a, b, n);
+    else hipLaunchKernelGGL(t_add<1>, dim3(nblk(n)), dim3(256), 0, st, a, b, n);
 }
 // db[c] += sum_p d[p][c] for any (small) channel count: coalesced sweep of a slice of the tensor, per-block sums in LDS
 __global__ __launch_bounds__(256) void t_bias_grad(const float* d, long long pixels, int C, long long elems_per_block, float* db) {
@@ -1439,7 +1570,7 @@ dyf_status dyf_train_forward(dyf_engine* e, int32_t which, int32_t slot, const f
         if (x2 && !(up2 && xc % 4 == 0 && x2c % 4 == 0)) {  // no consumer that reads two parts: materialise the concatenation
             float* cat = nullptr;
             TA(cat, (size_t)nb * lh * lw * (xc + x2c));
-            hipLaunchKernelGGL(t_concat2, dim3(nblk((long long)nb * lh * lw * (xc + x2c))), dim3(256), 0, st, x, xc, x2, x2c, (long long)nb * lh * lw, cat);
+            launch_t_concat2(x, xc, x2, x2c, (long long)nb * lh * lw, cat, st);
             x = cat;
             x2 = nullptr;
         }
@@ -1475,7 +1606,7 @@ dyf_status dyf_train_forward(dyf_engine* e, int32_t which, int32_t slot, const f
         }
         TNorm a{nb, ohw, b.cout, 8, b.gn ? 1 : 0, b.act, t.mean[i], t.rstd[i], w.blk[i].gamma, w.blk[i].beta, t.ss[i], drop_on ? 1 : 0,
                 1.0f / (1.0f - n.cfg.dropout), keep_threshold16(n.cfg.dropout), rng_layer_salt((uint32_t)i), t.row_keys};
-        hipLaunchKernelGGL(t_norm_fwd, dim3(nblk(out_el)), dim3(256), 0, st, a, t.z[i], t.y[i]);
+        launch_t_norm_fwd(a, t.z[i], t.y[i], st);
         TK(hipGetLastError());
         x = t.y[i];
         lh = b.out_h; lw = b.out_w;
@@ -1558,7 +1689,7 @@ dyf_status dyf_train_backward(dyf_engine* e, int32_t slot, const float* dout_dev
                                dskip[10 - i]);
             dy = dyi;
         } else if (i < 5) {  // encoder outputs also feed the decoder through the skips
-            hipLaunchKernelGGL(t_add, dim3(nblk(out_el)), dim3(256), 0, st, dy, dskip[i], out_el);
+            launch_t_add(dy, dskip[i], out_el, st);
         }
         TNorm a{nb, ohw, b.cout, 8, b.gn ? 1 : 0, b.act, t.mean[i], t.rstd[i], w.blk[i].gamma, w.blk[i].beta, t.ss[i], drop_on ? 1 : 0,
                 1.0f / (1.0f - n.cfg.dropout), keep_threshold16(n.cfg.dropout), rng_layer_salt((uint32_t)i), t.row_keys};
@@ -1573,7 +1704,7 @@ dyf_status dyf_train_backward(dyf_engine* e, int32_t slot, const float* dout_dev
         float* dz = nullptr;
         TA(dz, out_el);
         const float inv_count = b.gn ? 1.0f / ((float)ohw * (b.cout / 8)) : 1.0f / ((float)nb * ohw);
-        hipLaunchKernelGGL(t_norm_bwd_apply, dim3(nblk(out_el)), dim3(256), 0, st, a, t.z[i], dy, S1, S2, inv_count, dz);
+        launch_t_norm_bwd_apply(a, t.z[i], dy, S1, S2, inv_count, dz, st);
         if (n.cfg.with_time_emb) {  // FiLM head: ss = W silu(temb) + b
             if (param_grads)
                 hipLaunchKernelGGL(t_linear_bwd_w, dim3(nblk(2 * b.cout * n.tdim)), dim3(256), 0, st, t.temb, dss, nb, n.tdim, 2 * b.cout, 1, w.blk[i].g_fw,
