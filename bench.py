@@ -375,13 +375,18 @@ def bench_train_steps(dev):
     t = torch.randint(0, HORIZON, (B,), generator=g).to(dev)
 
     def timed(step, reps):
+        """One untimed step, then `reps` steps timed one by one (a step ends in a host read of the loss, so it is synchronous anyway):
+        the MEDIAN -- a step is thousands of eager launches, and one host hiccup in a mean of two or three moved the line by 30 %."""
         step()
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
+        each = []
         for _ in range(reps):
+            t0 = time.perf_counter()
             loss = step()
-        torch.cuda.synchronize()
-        return (time.perf_counter() - t0) / reps, loss
+            torch.cuda.synchronize()
+            each.append(time.perf_counter() - t0)
+        timed.each = [round(1e3 * v, 1) for v in each]
+        return sorted(each)[len(each) // 2], loss
 
     def step_ns():
         o = m.p_losses(xt_last, cond, t, static_condition=static)
@@ -390,20 +395,20 @@ def bench_train_steps(dev):
             p_.grad = None
         return float(o["loss"])
 
-    dt, loss = timed(step_ns, 2)
+    dt, loss = timed(step_ns, 3)
     fwd = m._engine.net_flops(0)  # both nets: ~48.2 GF per row
     fl = B * fwd * (4 + 2 * 2 * 2 + 1)
     out["unet_simple_ns"] = {"workload": f"p_losses + backward, NS 221x42 shapes (unet_simple dim 64 @256^2), B={B}, both loss terms, fp32",
                              "batch": B, "ms_per_step": round(1e3 * dt, 1), "loss": round(loss, 4), "achieved": round(fl / dt / 1e12, 1),
                              "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(fl / dt / 1e12 / PEAK_FP32_MFMA_TFLOPS, 3),
-                             "samples_per_s": round(B / dt, 1)}
+                             "samples_per_s": round(B / dt, 1), "each_ms": timed.each}
     log(f"train step unet_simple B={B}: {1e3 * dt:.1f} ms")
     # the same step with the training convs' operands rounded to 16 bits while they are staged (opt-in: train_precision=16; fp32
     # tensors and master weights, fp32 accumulation; csrc/train_halo16.hip + train_gemm.hip t_gemm_mfma16; how far the gradients
     # move: tests/test_gpu_training.py test_training_step_with_16bit_conv_operands_tracks_the_fp32_step)
     m._engine.train_set_precision("16-mixed")  # the reference's trainer.precision=16: C-ABI dyf_train_set_precision
     try:
-        dt16, loss16 = timed(step_ns, 2)
+        dt16, loss16 = timed(step_ns, 5)
     finally:
         m._engine.train_set_precision(32)
     out["unet_simple_ns_16bit_operands"] = {"workload": out["unet_simple_ns"]["workload"].replace(", fp32", ", fp32 tensors, conv operands "
@@ -411,7 +416,7 @@ def bench_train_steps(dev):
                                             "batch": B, "ms_per_step": round(1e3 * dt16, 1), "loss": round(loss16, 4),
                                             "achieved": round(fl / dt16 / 1e12, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                                             "frac": round(fl / dt16 / 1e12 / PEAK_BF16_TFLOPS, 4),  # against the 16-bit MFMA peak: the operands are 16-bit
-                                            "samples_per_s": round(B / dt16, 1), "speedup_vs_fp32": round(dt / dt16, 2)}
+                                            "samples_per_s": round(B / dt16, 1), "speedup_vs_fp32": round(dt / dt16, 2), "each_ms": timed.each}
     log(f"train step unet_simple B={B}, 16-bit conv operands: {1e3 * dt16:.1f} ms")
     m._engine.close()
     del m
@@ -444,21 +449,20 @@ def bench_train_steps(dev):
         out[key] = {"workload": f"p_losses + backward, OISST 60x60 shapes (unet.Unet dim 64 mults (1,2,4)), B={B}, both loss terms, fp32",
                     "batch": B, "ms_per_step": round(1e3 * dt, 1), "loss": round(loss, 4), "achieved": round(fl / dt / 1e12, 1),
                     "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(fl / dt / 1e12 / PEAK_FP32_MFMA_TFLOPS, 3),
-                    "samples_per_s": round(B / dt, 1)}
+                    "samples_per_s": round(B / dt, 1), "each_ms": timed.each}
         log(f"train step unet.Unet B={B}: {1e3 * dt:.1f} ms")
         if B == 64:  # the same step with the conv operands rounded to 16 bits while staged (opt-in; same launchers as the NS step)
             m2._engine.train_set_precision("16-mixed")
             try:
-                dt16, loss16 = timed(step_rn, 3)
+                dt16, loss16 = timed(step_rn, 5)
             finally:
                 m2._engine.train_set_precision(32)
             out[key + "_16bit_operands"] = {"workload": out[key]["workload"].replace(", fp32", ", fp32 tensors, conv operands rounded to "
-                                                                                     f"{m2._engine.dtype} (the engine's 16-bit format) in the "
-                                                                                     "kernels (train_precision=16)"),
+                                                                                     "bf16 in the kernels (train_precision=16)"),
                                             "batch": B, "ms_per_step": round(1e3 * dt16, 1), "loss": round(loss16, 4),
                                             "loss_fp32_operands": round(loss, 4), "achieved": round(fl / dt16 / 1e12, 1),
                                             "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(fl / dt16 / 1e12 / PEAK_BF16_TFLOPS, 4),
-                                            "samples_per_s": round(B / dt16, 1), "speedup_vs_fp32": round(dt / dt16, 2)}
+                                            "samples_per_s": round(B / dt16, 1), "speedup_vs_fp32": round(dt / dt16, 2), "each_ms": timed.each}
             log(f"train step unet.Unet B={B}, 16-bit conv operands: {1e3 * dt16:.1f} ms (loss {loss16:.4f} vs {loss:.4f})")
         m2._engine.close()
         del m2
