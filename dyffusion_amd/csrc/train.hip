@@ -2022,6 +2022,10 @@ __global__ void t_fill_hash(float* p, long long n, uint32_t seed) {
 }
 // in place: every value rounded to bf16, the training operand format (what the 16-bit-operand convs do while staging) -- on such data the
 // fp32 reference kernels and the 16-bit matrix-core forms differ only by summation order
+__global__ void t_scale_exp2(float* p, long long n, int k) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = ldexpf(p[i], k);
+}
 __global__ void t_round16(float* p, long long n) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = t16_to_f32(f32_to_t16(p[i]));  // bf16: the training operand format of both builds (train_internal.h)
@@ -2056,6 +2060,11 @@ dyf_status dyf_train_conv_check(dyf_engine* e, int32_t kind, int32_t n, int32_t 
     hipLaunchKernelGGL(t_fill_hash, dim3(nblk(nz)), dim3(256), 0, st, z, nz, seed + 1u);
     hipLaunchKernelGGL(t_fill_hash, dim3(nblk(nw)), dim3(256), 0, st, wgt, nw, seed + 2u);   // used in BOTH weight layouts' index spaces
     hipLaunchKernelGGL(t_fill_hash, dim3(nblk(std::max(cin, cout))), dim3(256), 0, st, bias, (long long)std::max(cin, cout), seed + 3u);
+    // test seam DYF_TRAIN_CHECK_DZ_EXP2 = k: the output gradient is scaled by 2^-k first -- the magnitudes a mean-reduced loss gives at
+    // real batch sizes (1e-6 .. 1e-7) -- to show that the 16-bit gradient operand keeps its accuracy there (bf16 in both builds: an
+    // fp16 operand would be subnormal or zero; a power of two commutes with the rounding, so the check's tolerance is unchanged)
+    if (const char* k2 = dyf_form("DYF_TRAIN_CHECK_DZ_EXP2"))
+        hipLaunchKernelGGL(t_scale_exp2, dim3(nblk(nz)), dim3(256), 0, st, z, nz, -atoi(k2));
     const TrainPrecisionScope precision(e->train_precision);
     if (train_operands16()) {
         hipLaunchKernelGGL(t_round16, dim3(nblk(nx)), dim3(256), 0, st, x, nx);

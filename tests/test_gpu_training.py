@@ -429,6 +429,36 @@ def test_16bit_halo_training_convs_match_the_plain_kernels(case, kind, form_swit
         assert split <= 2e-5 and unsplit <= 2e-5
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "fp16"])
+@pytest.mark.parametrize("kind", [1, 2], ids=["dgrad", "wgrad"])
+def test_16bit_gradient_operands_keep_their_accuracy_at_bench_scale_magnitudes(kind, dtype, form_switch):
+    """a mean-reduced loss at real batch sizes hands the backward output gradients of 1e-6 .. 1e-7 (B = 64 on 60 x 60:
+    4e-6; NS B = 32 on 256^2: 1e-7) -- fp16's subnormal range (smallest normal 6.1e-5, smallest subnormal 6e-8), where an fp16
+    gradient operand without a loss scale keeps a few bits or none.  The 16-bit training mode therefore rounds its operands to bf16 in
+    BOTH builds of the library (train_internal.h).  Held here on the engine of either storage type: the data- and weight-gradient
+    kernels with the output gradient scaled by 2^-24 (6e-8) must match the fp32 one-thread-per-output kernels exactly as well as at
+    O(1) magnitudes (2e-5 of the largest reference value: a power of two commutes with the bf16 rounding); with an fp16 operand the
+    result would be zero or off by tens of percent."""
+    import dyffusion_amd as D
+    from dyffusion_amd.engine import net_config
+    form_switch.setenv("DYF_TRAIN_OPERANDS", "bf16")
+    cfg = net_config(in_channels=3, cond_channels=2, out_channels=3, dim=64, with_time_emb=True, upsample_dims=(64, 64), dropout=0.0)
+    eng = D.HipEngine(cfg, cfg, 23, 11, max_batch=1, use_graph=False, dtype=dtype)
+    errs = {}
+    for exp2 in (None, "24"):
+        if exp2 is None:
+            form_switch.delenv("DYF_TRAIN_CHECK_DZ_EXP2")
+        else:
+            form_switch.setenv("DYF_TRAIN_CHECK_DZ_EXP2", exp2)
+        for case in ((8, 60, 60, 64, 64, 3, 1, 1), (8, 64, 64, 128, 128, 4, 2, 1)):
+            split, unsplit, took = eng.train_conv_check(kind, *case, seed=29 + kind)
+            assert took
+            errs[(exp2, case)] = max(split, unsplit)
+            print(f"{dtype} engine, kind {kind} {case}, dz x 2^-{exp2 or 0}: rel max err {split:.2e} / {unsplit:.2e}")
+            assert split <= 2e-5 and unsplit <= 2e-5
+    eng.close()
+
+
 @pytest.mark.parametrize("case", [(8, 64, 64, 64, 128, 4, 2, 1), (4, 60, 92, 128, 64, 4, 2, 1), (2, 128, 128, 128, 256, 4, 2, 1)],
                          ids=lambda c: "x".join(map(str, c)))
 def test_16bit_stride2_data_gradient_by_parity_classes_matches_the_plain_kernel(case, form_switch):
