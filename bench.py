@@ -570,6 +570,16 @@ def self_launch(n):
     os.execve(sys.executable, cmd, env)
 
 
+def claim_stdout():
+    """File descriptor 1 belongs to the ONE JSON line.  Whatever else writes to stdout in this process -- gloo's "[Gloo] Rank 1 is
+    connected to ..." notes, RCCL's version banner at communicator creation, a stray print of a library -- is sent to stderr from here
+    on (at the descriptor level, so C and C++ code is covered); the returned file object is the original stdout."""
+    sys.stdout.flush()
+    keep = os.dup(1)
+    os.dup2(2, 1)
+    return os.fdopen(keep, "w")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -595,6 +605,7 @@ def main():
         # plain `python bench.py --gpus N` (no launcher): re-execute this file under torch.distributed.run, one rank per GPU --
         # the same command line the driver uses for N > 1; rank 0 of the child prints the ONE JSON line on the inherited stdout
         return self_launch(args.gpus)
+    json_out = claim_stdout()
     ndev = torch.cuda.device_count()
     dev_index = local_rank % max(1, ndev)  # one rank per GPU under the driver; ranks wrap only in single-GPU smoke runs
     torch.cuda.set_device(dev_index)
@@ -874,7 +885,8 @@ def main():
         if not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(F, I)
     if rank == 0:
-        print(json.dumps(result), flush=True)
+        json_out.write(json.dumps(result) + "\n")
+        json_out.flush()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

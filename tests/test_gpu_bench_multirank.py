@@ -43,6 +43,8 @@ def _run_bench(nproc, extra_args, extra_env, timeout=900, self_launch=False):
     assert r.returncode == 0, f"rc {r.returncode}\n--- stdout\n{r.stdout[-3000:]}\n--- stderr\n{r.stderr[-6000:]}"
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
     assert len(lines) == 1, f"exactly one JSON line from rank 0, got {len(lines)}:\n{r.stdout[-2000:]}"
+    # ... and NOTHING else on stdout (bench.claim_stdout: gloo's connection notes and RCCL's banner go to stderr)
+    assert [ln for ln in r.stdout.splitlines() if ln.strip()] == lines, r.stdout[:2000]
     return json.loads(lines[0]), r.stderr
 
 
