@@ -1,6 +1,8 @@
 // conv_gn16_kernel: 3 x 3 / stride 1 / pad 1 convolution WITH the GroupNorm + FiLM + SiLU + Dropout (+ residual) of its Block fused
 // into the epilogue (ResnetBlock of src/models/unet.py:58-109; gn_fused.h) on SMALL tiles -- 16 x 16 pixels x 64 output channels per
-// workgroup, THREE workgroups per CU.  Round 6; serves the 64- / 128-channel levels of the ResNet-UNet (60 x 60, 30 x 30 at OISST).
+// workgroup, THREE workgroups per CU.  Round 6; serves every fused-GroupNorm conv of the ResNet-UNet at the OISST shapes: the 64- / 128-
+// channel levels (60 x 60, 30 x 30), the 256-channel 15 x 15 level (four 64-channel blocks) and the up path's two-source inputs
+// cat([x, skip]) of unequal channel counts (conv.hip launch_conv_gn_fused holds the policy).
 //
 // Why a second form beside conv_up_halo_kernel<5, 2> (16 x 32 tiles, 128 accumulator registers per wave, 80 KB of LDS, two workgroups
 // per CU): a phase timeline of that kernel (tools/timeline_oisst.py, profiles/r06_halo5_timeline.txt) shows a tile's life as a SERIAL
