@@ -187,7 +187,8 @@ __global__ __launch_bounds__(256) void t_up2x_fwd(const float* in, int n, int h,
 #define UP2X_MIX(m) { const float top = v00.m * (1.0f - lx) + v01.m * lx, bot = v10.m * (1.0f - lx) + v11.m * lx; r.m = top * (1.0f - ly) + bot * ly; }
     UP2X_MIX(x) UP2X_MIX(y) UP2X_MIX(z) UP2X_MIX(w)
 #undef UP2X_MIX
-    ((float4*)out)[idx] = r;
+    typedef float nt_f32x4 __attribute__((ext_vector_type(4)));
+    __builtin_nontemporal_store((nt_f32x4){r.x, r.y, r.z, r.w}, (nt_f32x4*)out + idx);  // a 2 GB stream nobody re-reads from L2
 }
 __global__ void t_resize_bwd(const float* dout, int n, int ih, int iw, int C, int oh, int ow, int nearest, float* din) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
